@@ -1,0 +1,440 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lw.hpp header).
+//
+// C entry points over the CPU restatement so tests/ (ctypes), __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can drive it with the same flat arrays the product's C-ABI (include/carmel_hip.h) takes.
+// Arc arrays are in the reference's arc-id order: state-major, each state's arcs in list order
+// (derivations.h:86-101, fst.h:1331-1334).
+#include "train.hpp"
+#include <pthread.h>
+#include <functional>
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace oracle;
+
+namespace {
+struct BigStack {
+  std::function<void()> f;
+  std::string err;
+};
+void* tramp(void* p) {
+  BigStack* b = (BigStack*)p;
+  try {
+    b->f();
+  } catch (std::exception& e) {
+    b->err = e.what();
+  } catch (...) {
+    b->err = "unknown exception";
+  }
+  return 0;
+}
+thread_local std::string g_err;
+// the lattice builder recurses like the reference (derivations.h:640-704): run on a deep stack
+int run_big_stack(std::function<void()> f) {
+  BigStack b;
+  b.f = f;
+  pthread_attr_t attr;
+  pthread_attr_init(&attr);
+  pthread_attr_setstacksize(&attr, (size_t)1 << 30);
+  pthread_t th;
+  if (pthread_create(&th, &attr, tramp, &b)) {
+    g_err = "pthread_create failed";
+    return -1;
+  }
+  pthread_join(th, 0);
+  if (!b.err.empty()) {
+    g_err = b.err;
+    return -1;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+const char* orc_last_error() { return g_err.c_str(); }
+
+struct orc_wfst {
+  Wfst w;
+};
+struct orc_corpus {
+  Corpus c;
+};
+
+orc_wfst* orc_wfst_from_arrays(uint32_t n_states, uint32_t final_state, uint64_t n_arcs, const uint32_t* src,
+                               const uint32_t* dst, const uint32_t* in, const uint32_t* out, const double* logw,
+                               const uint32_t* group) {
+  orc_wfst* h = new orc_wfst();
+  h->w.states.assign(n_states, {});
+  h->w.final_state = final_state;
+  uint32_t max_in = 1, max_out = 1;
+  for (uint64_t k = 0; k < n_arcs; ++k) {
+    h->w.states[src[k]].push_back(Arc(in[k], out[k], dst[k], LW::from_ln(logw[k]), group ? group[k] : NO_GROUP));
+    if (in[k] > max_in) max_in = in[k];
+    if (out[k] > max_out) max_out = out[k];
+  }
+  for (uint32_t i = 2; i <= max_in; ++i) h->w.in_alph.index_of("i" + std::to_string(i));
+  for (uint32_t i = 2; i <= max_out; ++i) h->w.out_alph.index_of("o" + std::to_string(i));
+  return h;
+}
+orc_wfst* orc_wfst_parse(const char* text, int always_named) {
+  orc_wfst* h = new orc_wfst();
+  if (!h->w.read_legible(text, always_named != 0)) {
+    g_err = "bad WFST text";
+    delete h;
+    return 0;
+  }
+  return h;
+}
+void orc_wfst_free(orc_wfst* h) { delete h; }
+void orc_wfst_dims(orc_wfst* h, uint32_t* n_states, uint64_t* n_arcs, uint32_t* final_state) {
+  *n_states = h->w.num_states();
+  *n_arcs = h->w.num_arcs();
+  *final_state = h->w.final_state;
+}
+void orc_wfst_export(orc_wfst* h, uint32_t* src, uint32_t* dst, uint32_t* in, uint32_t* out, double* logw,
+                     uint32_t* group) {
+  uint64_t k = 0;
+  for (uint32_t s = 0; s < h->w.num_states(); ++s)
+    for (auto& a : h->w.states[s]) {
+      src[k] = s;
+      dst[k] = a.dest;
+      in[k] = a.in;
+      out[k] = a.out;
+      logw[k] = a.weight.w;
+      group[k] = a.group;
+      ++k;
+    }
+}
+void orc_wfst_set_logw(orc_wfst* h, const double* logw) {
+  uint64_t k = 0;
+  for (auto& st : h->w.states)
+    for (auto& a : st) a.weight.w = logw[k++];
+}
+void orc_wfst_reduce(orc_wfst* h) { h->w.reduce(); }
+void orc_wfst_normalize(orc_wfst* h, int group, double add_count_real) {
+  NormalizeMethod m;
+  m.group = group;
+  m.add_count = LW::from_real(add_count_real);
+  h->w.normalize(m);
+}
+// text of the transducer in carmel's output syntax (wfstio.cc:594-625); caller frees with orc_free_str
+char* orc_wfst_write(orc_wfst* h, int full, int onearc, int wmode) {
+  std::string s = h->w.write_legible(full != 0, onearc != 0, wmode);
+  char* r = (char*)std::malloc(s.size() + 1);
+  std::memcpy(r, s.c_str(), s.size() + 1);
+  return r;
+}
+void orc_free_str(char* s) { std::free(s); }
+uint32_t orc_wfst_alphabet_size(orc_wfst* h, int output) { return output ? h->w.out_alph.size() : h->w.in_alph.size(); }
+
+orc_corpus* orc_corpus_from_arrays(uint64_t n_pairs, const uint64_t* in_off, const uint32_t* in_sym,
+                                   const uint64_t* out_off, const uint32_t* out_sym, const double* weight) {
+  orc_corpus* h = new orc_corpus();
+  for (uint64_t p = 0; p < n_pairs; ++p) {
+    std::vector<unsigned> i(in_sym + in_off[p], in_sym + in_off[p + 1]);
+    std::vector<unsigned> o(out_sym + out_off[p], out_sym + out_off[p + 1]);
+    h->c.add(i, o, weight ? weight[p] : 1.0);
+  }
+  return h;
+}
+orc_corpus* orc_corpus_parse(orc_wfst* w, const char* text) {
+  orc_corpus* h = new orc_corpus();
+  read_training_corpus(w->w, text, h->c);
+  return h;
+}
+void orc_corpus_free(orc_corpus* h) { delete h; }
+void orc_corpus_dims(orc_corpus* h, uint64_t* n_pairs, uint64_t* n_in, uint64_t* n_out) {
+  *n_pairs = h->c.examples.size();
+  uint64_t a = 0, b = 0;
+  for (auto& p : h->c.examples) {
+    a += p.in.size();
+    b += p.out.size();
+  }
+  *n_in = a;
+  *n_out = b;
+}
+void orc_corpus_export(orc_corpus* h, uint64_t* in_off, uint32_t* in_sym, uint64_t* out_off, uint32_t* out_sym,
+                       double* weight) {
+  uint64_t a = 0, b = 0, k = 0;
+  for (auto& p : h->c.examples) {
+    in_off[k] = a;
+    out_off[k] = b;
+    for (unsigned s : p.in) in_sym[a++] = s;
+    for (unsigned s : p.out) out_sym[b++] = s;
+    weight[k] = p.weight;
+    ++k;
+  }
+  in_off[k] = a;
+  out_off[k] = b;
+}
+
+// One E-step over the whole corpus at the transducer's current weights (train.cc:763-773 / derivations.h:432-449).
+//   counts_ln[n_arcs]      ln of the expected count per WFST arc (-inf = none)
+//   pair_logprob[n_pairs]  ln p(pair); -inf where the pair has no derivation
+//   has_deriv[n_pairs]
+//   stats[4]               lattice states/arcs explored, states/arcs kept (derivations.h:191-247)
+//   sums[2]                sum ln p, sum weight*ln p over pairs with a derivation
+// n_threads <= 1: serial, corpus order, exactly the reference's accumulation order.  n_threads > 1: OpenMP over
+// pairs with per-thread log-domain count tables merged at the end (same values up to log-add rounding).
+int orc_estimate(orc_wfst* wh, orc_corpus* ch, int prune, double* counts_ln, double* pair_logprob, uint8_t* has_deriv,
+                 double* stats, double* sums, int n_threads) {
+  return run_big_stack([&]() {
+    Wfst& x = wh->w;
+    ArcTable arcs;
+    arcs.build(x, false, LW());
+    IoIndex io;
+    io.build(x);
+    size_t np = ch->c.examples.size();
+    DerivStats st;
+    double s0 = 0, s1 = 0;
+    if (n_threads <= 1) {
+      for (auto& a : arcs.t) a.counts = LW();
+      for (size_t p = 0; p < np; ++p) {
+        Derivations d;
+        bool ok = d.compute(x, io, arcs, ch->c.examples[p], prune != 0, &st);
+        if (has_deriv) has_deriv[p] = ok;
+        double lp = -std::numeric_limits<double>::infinity();
+        if (ok) {
+          LW prob = d.collect_counts(arcs);
+          lp = prob.w;
+          s0 += lp;
+          s1 += lp * d.weight;
+        }
+        if (pair_logprob) pair_logprob[p] = lp;
+      }
+      if (counts_ln)
+        for (size_t k = 0; k < arcs.t.size(); ++k) counts_ln[k] = arcs.t[k].counts.w;
+    } else {
+#ifdef _OPENMP
+      omp_set_num_threads(n_threads);
+#endif
+      std::vector<std::vector<LW> > tc;
+      std::vector<DerivStats> tst;
+#pragma omp parallel
+      {
+#pragma omp single
+        {
+          int nt = 1;
+#ifdef _OPENMP
+          nt = omp_get_num_threads();
+#endif
+          tc.assign(nt, std::vector<LW>(arcs.t.size()));
+          tst.assign(nt, DerivStats());
+        }
+        int me = 0;
+#ifdef _OPENMP
+        me = omp_get_thread_num();
+#endif
+        ArcTable mine = arcs;  // private count column
+        for (auto& a : mine.t) a.counts = LW();
+        double ls0 = 0, ls1 = 0;
+#pragma omp for schedule(dynamic, 64)
+        for (long p = 0; p < (long)np; ++p) {
+          Derivations d;
+          bool ok = d.compute(x, io, mine, ch->c.examples[p], prune != 0, &tst[me]);
+          if (has_deriv) has_deriv[p] = ok;
+          double lp = -std::numeric_limits<double>::infinity();
+          if (ok) {
+            LW prob = d.collect_counts(mine);
+            lp = prob.w;
+            ls0 += lp;
+            ls1 += lp * d.weight;
+          }
+          if (pair_logprob) pair_logprob[p] = lp;
+        }
+        for (size_t k = 0; k < mine.t.size(); ++k) tc[me][k] = mine.t[k].counts;
+#pragma omp critical
+        {
+          s0 += ls0;
+          s1 += ls1;
+        }
+      }
+      for (auto& t : tst) {
+        st.N += t.N;
+        st.pre_states += t.pre_states;
+        st.pre_arcs += t.pre_arcs;
+        st.post_states += t.post_states;
+        st.post_arcs += t.post_arcs;
+      }
+      if (counts_ln)
+        for (size_t k = 0; k < arcs.t.size(); ++k) {
+          LW c;
+          for (auto& t : tc) c += t[k];
+          counts_ln[k] = c.w;
+        }
+    }
+    if (stats) {
+      stats[0] = st.pre_states;
+      stats[1] = st.pre_arcs;
+      stats[2] = st.post_states;
+      stats[3] = st.post_arcs;
+    }
+    if (sums) {
+      sums[0] = s0;
+      sums[1] = s1;
+    }
+  });
+}
+
+// Lattice of one pair in the reference's own numbering: states in DFS pre-order after stable pruning, each
+// state's out-arcs in list order (derivations.h:640-704, 572-629).  Call with null arrays to get the sizes.
+int orc_lattice(orc_wfst* wh, orc_corpus* ch, uint64_t pair, int prune, uint32_t* n_states, uint64_t* n_arcs,
+                uint32_t* fin, uint32_t* a_src, uint32_t* a_dst, uint32_t* a_arcid, uint32_t* order, uint32_t* n_back) {
+  return run_big_stack([&]() {
+    Wfst& x = wh->w;
+    ArcTable arcs;
+    arcs.build(x, false, LW());
+    IoIndex io;
+    io.build(x);
+    Derivations d;
+    bool ok = d.compute(x, io, arcs, ch->c.examples[pair], prune != 0, 0);
+    if (!ok) {
+      *n_states = 0;
+      *n_arcs = 0;
+      return;
+    }
+    *n_states = (uint32_t)d.n_states();
+    *n_arcs = d.n_arcs();
+    *fin = d.fin;
+    d.make_order();
+    if (n_back) *n_back = d.n_back_edges;
+    if (order)
+      for (size_t i = 0; i < d.reverse_order.size(); ++i) order[i] = d.reverse_order[i];
+    if (a_src) {
+      uint64_t k = 0;
+      for (unsigned s = 0; s < d.g.size(); ++s)
+        for (size_t j = d.g[s].size(); j-- > 0;) {
+          a_src[k] = d.g[s][j].src;
+          a_dst[k] = d.g[s][j].dest;
+          a_arcid[k] = d.g[s][j].arcid;
+          ++k;
+        }
+    }
+  });
+}
+
+// Full EM run for a single transducer (trivial cascade): WFST::train (train.cc:503-678).
+// trace rows: [iter, log2 P, log2 ppx/symbol, log2 ppx/example, new_best, ln rel-ppx-ratio, last_change, n_example]
+int orc_train(orc_wfst* wh, orc_corpus* ch, int norm_group, double add_count, int weight_is_prior_count,
+              double smooth_floor, double converge_arc_delta, double converge_ppx_ratio, int max_iter, int cache,
+              int prune, double* trace, int max_trace, int* n_trace, double* best_ppx_ln) {
+  return run_big_stack([&]() {
+    Cascade cascade(false);
+    std::vector<NormalizeMethod> nms(1);
+    nms[0].group = norm_group;
+    nms[0].add_count = LW::from_real(add_count);
+    TrainOpts opts;
+    opts.max_iter = (unsigned)max_iter;
+    opts.cache_derivations = cache != 0;
+    opts.prune = prune != 0;
+    std::vector<IterRecord> tr;
+    LW best = train(wh->w, cascade, ch->c, nms, weight_is_prior_count != 0, LW::from_real(smooth_floor),
+                    LW::from_real(converge_arc_delta), LW::from_real(converge_ppx_ratio), opts, 0, &tr);
+    if (best_ppx_ln) *best_ppx_ln = best.w;
+    int n = 0;
+    for (auto& r : tr) {
+      if (n >= max_trace) break;
+      double* row = trace + 8 * n;
+      row[0] = r.iter;
+      row[1] = r.log2_prob;
+      row[2] = r.ppx_symbol_log2;
+      row[3] = r.ppx_example_log2;
+      row[4] = r.new_best;
+      row[5] = r.rel_ppx_ratio_ln;
+      row[6] = r.last_change;
+      row[7] = r.n_example;
+      ++n;
+    }
+    if (n_trace) *n_trace = n;
+  });
+}
+
+// Cascade EM over text inputs (compose.cc + cascade.h + train.cc), as `carmel --train-cascade corpus a b ...`.
+// normby: one char per transducer (J/C/N).  Trained member texts are returned '\0'-joined in *out_texts
+// (caller frees with orc_free_str); trace as in orc_train.
+int orc_train_cascade_text(int n_wfst, const char** wfst_texts, const char* corpus_text, const char* normby,
+                           const double* priors, int max_iter, double converge_arc_delta, double converge_ppx_ratio,
+                           int cache, int full, int onearc, char** out_texts, uint64_t* out_len, double* trace,
+                           int max_trace, int* n_trace, uint32_t* composed_dims) {
+  return run_big_stack([&]() {
+    std::vector<Wfst> chain(n_wfst);
+    for (int i = 0; i < n_wfst; ++i) {
+      if (!chain[i].read_legible(wfst_texts[i], true)) throw std::runtime_error("bad WFST text");
+      if (n_wfst > 1) chain[i].named_states = false;
+    }
+    Cascade cascade(true);
+    Wfst* result = &chain[0];
+    result->reduce();
+    if (n_wfst < 2) cascade.set_trivial();
+    cascade.add(result);
+    std::vector<Wfst*> owned;
+    bool any = false;
+    for (int i = 1; i < n_wfst; ++i) {
+      cascade.add(&chain[i]);
+      if (i == 1)
+        cascade.prepare_compose();
+      else
+        cascade.prepare_compose(false);
+      Wfst* next = new Wfst();
+      compose(*next, cascade, *result, chain[i]);
+      owned.push_back(next);
+      result = next;
+      if (!result->valid) throw std::runtime_error("empty composition");
+      if (composed_dims) {
+        composed_dims[0] = result->num_states();
+        composed_dims[1] = (uint32_t)result->num_arcs();
+      }
+      result->reduce();
+      cascade.done_composing(result);
+      any = true;
+    }
+    if (!any) cascade.set_composed(result);
+    std::vector<NormalizeMethod> nms(n_wfst);
+    for (int i = 0; i < n_wfst; ++i) {
+      char c = normby && (int)std::strlen(normby) > i ? normby[i] : 'C';
+      nms[i].group = (c == 'J' || c == 'j') ? NORM_JOINT : (c == 'N' || c == 'n') ? NORM_NONE : NORM_CONDITIONAL;
+      if (priors) nms[i].add_count = LW::from_real(priors[i]);
+    }
+    Corpus corpus;
+    read_training_corpus(*result, corpus_text, corpus);
+    TrainOpts opts;
+    opts.max_iter = (unsigned)max_iter;
+    opts.cache_derivations = cache != 0;
+    std::vector<IterRecord> tr;
+    train(*result, cascade, corpus, nms, false, LW(), LW::from_real(converge_arc_delta),
+          LW::from_real(converge_ppx_ratio), opts, 0, &tr);
+    int n = 0;
+    for (auto& r : tr) {
+      if (n >= max_trace) break;
+      double* row = trace + 8 * n;
+      row[0] = r.iter;
+      row[1] = r.log2_prob;
+      row[2] = r.ppx_symbol_log2;
+      row[3] = r.ppx_example_log2;
+      row[4] = r.new_best;
+      row[5] = r.rel_ppx_ratio_ln;
+      row[6] = r.last_change;
+      row[7] = r.n_example;
+      ++n;
+    }
+    if (n_trace) *n_trace = n;
+    if (out_texts) {
+      std::string all;
+      for (int i = 0; i < n_wfst; ++i) {
+        all += chain[i].write_legible(full != 0, onearc != 0);
+        all.push_back('\0');
+      }
+      *out_texts = (char*)std::malloc(all.size());
+      std::memcpy(*out_texts, all.data(), all.size());
+      *out_len = all.size();
+    }
+    for (Wfst* w : owned) delete w;
+  });
+}
+
+}  // extern "C"
