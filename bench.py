@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""bench.py — EM arc-weight training throughput on MI355X (one rank per GPU, RCCL all-reduce of arc counts).
+
+One "step" = one EM iteration of the hot path: forward_backward::estimate (forward sweep, backward sweep,
+expected-count accumulation over every derivation lattice of this rank's corpus shard) + the all-reduce of the
+per-arc count vector across ranks (N > 1) + forward_backward::maximize (normalisation of all arc weights).
+Inputs (transducer, lattices) are resident in HBM before the timed region.
+
+Workload (config.workload): by default BASELINE.json configs[3] shape — synthetic 1M-state / 10M-arc transducer,
+1M training pairs PER GPU (weak scaling: the corpus grows with N, the model — and therefore the 80 MB count
+all-reduce — does not).  `--config c2` selects configs[1] (100k states / 2M arcs / 50k pairs).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes(lattice_arcs, lattice_states):
+    """48 B per lattice arc (8 B arc record re-read in each of the three passes, one 8 B
+    gather of logw[arc], one 16 B read-modify-write of counts[arc]) + 16 B per lattice state (alpha and beta
+    written once).  The M-step's 16 B per WFST arc belongs to the M-step kernels, not to the sweep kernel."""
+    return 48.0 * lattice_arcs + 16.0 * lattice_states
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c4", choices=["c2", "c4", "toy"])
+    ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=20000)
+    ap.add_argument("--host-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
+        args.gpus = world
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the EM hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from carmel_amd import synth
+    from carmel_amd.trainer import HipForwardBackward
+
+    n_states, deg, npairs, seed = synth.CONFIGS[args.config]
+    if args.pairs:
+        npairs = args.pairs
+    t0 = time.time()
+    w = synth.random_wfst(n_states, deg, seed=seed)  # same model on every rank
+    c = synth.random_walk_corpus(w, npairs, seed=seed + 7919 * rank, out_degree=deg)  # this rank's shard
+    t_gen = time.time() - t0
+    fb = HipForwardBackward(w, c, device=local_rank, host_threads=args.host_threads)
+    ls = fb.lattice_stats
+    counts = torch.zeros(w.n_arcs + 4, dtype=torch.float64, device="cuda")
+    fb.use_external_counts(counts.data_ptr())
+
+    def step():
+        fb.estimate_async()
+        if world > 1:
+            fb.synchronize()  # the sweep runs on the trainer's stream; RCCL on torch's
+            dist.all_reduce(counts)
+            torch.cuda.synchronize()
+        return fb.maximize(1.0)
+
+    def fence():
+        fb.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(fb.last_kernel_ms())
+    fence()
+    dt = time.perf_counter() - t0
+    lp, wlp, n_swept = fb.read_scalars()
+    t = torch.tensor([dt, float(ls.kept_arcs), float(ls.kept_states)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0])
+        total_arcs, total_states = float(tsum[1]), float(tsum[2])
+    else:
+        total_arcs, total_states = float(ls.kept_arcs), float(ls.kept_states)
+    iters_per_s = args.steps / dt
+    value = iters_per_s * total_arcs
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        alg = algorithmic_bytes(float(ls.kept_arcs), float(ls.kept_states))
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "arc-updates/sec (EM iterations/sec x derivation-lattice arcs swept per iteration)",
+            "value": value, "unit": "arc-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %d-state / %d-arc WFST, %d training pairs per GPU (random walks of "
+                                   "5-40 arcs), conditional normalisation, cached lattices" %
+                                   (args.config, w.n_states, w.n_arcs, c.n_pairs),
+                       "pairs_per_gpu": c.n_pairs, "wfst_arcs": int(w.n_arcs), "wfst_states": int(w.n_states),
+                       "lattice_arcs_per_gpu": int(ls.kept_arcs), "lattice_states_per_gpu": int(ls.kept_states),
+                       "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, all-reduce of %d f64 "
+                       "counts per iteration" % (world, w.n_arcs + 4)},
+            "iters_per_s": iters_per_s,
+            "wfst_arcs_x_iters_per_s": iters_per_s * w.n_arcs,
+            "ln_corpus_prob_last": lp,
+            "lattice_build_s": ls.build_seconds, "synth_gen_s": t_gen,
+            "roofline": {"bound": "hbm", "kernel": "sweep_bundle_kernel<64,true>", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import binding as ob  # CPU restatement of the reference: the checker, timed as the baseline
+            ns = min(args.cpu_sample_pairs, c.n_pairs)
+            cs = c.shard(0, max(1, c.n_pairs // ns)) if ns < c.n_pairs else c
+            ow, oc = ob.OracleWfst.from_arrays(w), ob.OracleCorpus.from_arrays(cs)
+            r = ob.bench_em(ow, oc, iters=2, threads=1)
+            out["cpu_baseline"] = {
+                "value": r["lattice_arcs"] / r["sec_per_iter"], "unit": "arc-updates/s", "cores": 1, "kind": "port",
+                "sample": "first %d pairs of rank 0's shard (%d lattice arcs), same transducer; 2 EM iterations of "
+                          "the scalar oracle (estimate over cached lattices + maximize), lattice build excluded" %
+                          (cs.n_pairs, int(r["lattice_arcs"])),
+                "sec_per_iter": r["sec_per_iter"]}
+        print(json.dumps(out))
+    fence()
+    fb.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""ctypes binding of libcarmel_hip.so (include/carmel_hip.h).  The library is the product; this module is glue.
+
+There is deliberately no fallback: if the shared library is missing or a symbol is absent the import fails, and
+every compute entry point needs a GPU (carmel_hip_create refuses to run without one).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcarmel_hip.so")
+
+# every symbol include/carmel_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
+SYMBOLS = [
+    "carmel_hip_last_error", "carmel_hip_device_count", "carmel_hip_create", "carmel_hip_destroy",
+    "carmel_hip_set_corpus", "carmel_hip_build_lattices", "carmel_hip_set_norm", "carmel_hip_set_prior",
+    "carmel_hip_set_cascade", "carmel_hip_normalize", "carmel_hip_set_weights", "carmel_hip_get_weights",
+    "carmel_hip_get_arc_weights", "carmel_hip_estimate", "carmel_hip_estimate_async",
+    "carmel_hip_estimate_finish", "carmel_hip_counts_dev", "carmel_hip_counts_len", "carmel_hip_stream",
+    "carmel_hip_use_external_counts", "carmel_hip_synchronize", "carmel_hip_last_sweep_ms", "carmel_hip_read_scalars",
+    "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_save_counts",
+    "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
+    "carmel_hip_host_export", "carmel_hip_host_free",
+]
+
+
+class LatticeStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_pairs", "n_pairs_kept", "explored_states", "explored_arcs", "kept_states", "kept_arcs",
+        "n_cyclic_pairs", "n_bundles", "max_levels", "device_bytes")] + [("build_seconds", C.c_double)]
+
+
+class EstimateResult(C.Structure):
+    _fields_ = [("sum_logprob", C.c_double), ("sum_weighted_logprob", C.c_double), ("n_pairs", C.c_uint64),
+                ("kernel_ms", C.c_double)]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "carmel_amd: %s not found — build it with `make -C carmel_amd/csrc` (or __graft_entry__.build()); "
+            "there is no CPU fallback for the EM hot path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise ImportError("carmel_amd: %s lacks symbol %s" % (LIB_PATH, s))
+    lib.carmel_hip_last_error.restype = C.c_char_p
+    lib.carmel_hip_counts_dev.restype = C.c_void_p
+    lib.carmel_hip_stream.restype = C.c_void_p
+    lib.carmel_hip_counts_len.restype = C.c_uint64
+    for s in SYMBOLS:
+        f = getattr(lib, s)
+        if f.restype is C.c_int or f.restype is None:
+            pass
+    vp = C.c_void_p
+    lib.carmel_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
+    lib.carmel_hip_destroy.argtypes = [vp]
+    lib.carmel_hip_set_corpus.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
+    lib.carmel_hip_build_lattices.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(LatticeStats)]
+    lib.carmel_hip_set_norm.argtypes = [vp, C.c_int, C.c_double]
+    lib.carmel_hip_set_prior.argtypes = [vp, C.c_double, C.c_int]
+    lib.carmel_hip_set_cascade.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint64, vp, vp]
+    lib.carmel_hip_normalize.argtypes = [vp]
+    lib.carmel_hip_set_weights.argtypes = [vp, vp]
+    lib.carmel_hip_get_weights.argtypes = [vp, vp]
+    lib.carmel_hip_get_arc_weights.argtypes = [vp, vp]
+    lib.carmel_hip_estimate.argtypes = [vp, C.POINTER(EstimateResult), vp]
+    lib.carmel_hip_estimate_async.argtypes = [vp]
+    lib.carmel_hip_estimate_finish.argtypes = [vp, C.POINTER(EstimateResult), vp]
+    lib.carmel_hip_counts_dev.argtypes = [vp]
+    lib.carmel_hip_counts_len.argtypes = [vp]
+    lib.carmel_hip_stream.argtypes = [vp]
+    lib.carmel_hip_use_external_counts.argtypes = [vp, vp]
+    lib.carmel_hip_synchronize.argtypes = [vp]
+    lib.carmel_hip_last_sweep_ms.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.carmel_hip_read_scalars.argtypes = [vp, C.POINTER(EstimateResult)]
+    lib.carmel_hip_get_counts.argtypes = [vp, vp]
+    lib.carmel_hip_set_counts.argtypes = [vp, vp]
+    lib.carmel_hip_maximize.argtypes = [vp, C.c_double, C.POINTER(C.c_double)]
+    lib.carmel_hip_save_counts.argtypes = [vp]
+    lib.carmel_hip_save_best.argtypes = [vp]
+    lib.carmel_hip_load_best.argtypes = [vp]
+    lib.carmel_hip_host_build.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp,
+                                          C.c_uint64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+    lib.carmel_hip_host_dims.argtypes = [vp, vp]
+    lib.carmel_hip_host_dims.restype = None
+    lib.carmel_hip_host_export.argtypes = [vp] + [vp] * 12
+    lib.carmel_hip_host_export.restype = None
+    lib.carmel_hip_host_free.argtypes = [vp]
+    lib.carmel_hip_host_free.restype = None
+    return lib
+
+
+lib = _load()
+
+
+class CarmelHipError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        RuntimeError.__init__(self, "%s failed (%d): %s" % (where, code, lib.carmel_hip_last_error().decode()))
+
+
+def check(rc, where):
+    if rc != 0:
+        raise CarmelHipError(rc, where)
+
+
+def ptr(a):
+    """data pointer of a contiguous numpy array (or None)"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

@@ -1,0 +1,616 @@
+// engine.cpp — implementation of the C-ABI in include/carmel_hip.h on top of kernels.hip / lattice.cpp.
+// One trainer = one GPU, one HIP stream; all per-iteration state stays in HBM.
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/carmel_hip.h"
+#include "kernels.hpp"
+
+using namespace carmel_hip;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(x)                                                                                             \
+  do {                                                                                                        \
+    hipError_t e_ = (x);                                                                                      \
+    if (e_ != hipSuccess)                                                                                     \
+      return fail(CARMEL_HIP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                        \
+  } while (0)
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  hipError_t alloc(size_t count) {
+    release();
+    n = count;
+    if (!count) return hipSuccess;
+    return hipMalloc((void**)&p, count * sizeof(T));
+  }
+  hipError_t upload(const std::vector<T>& v, hipStream_t s) {
+    hipError_t e = alloc(v.size());
+    if (e != hipSuccess || v.empty()) return e;
+    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+  }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+struct carmel_hip_trainer {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  HostWfst w;
+  HostCorpus corpus;
+  bool have_corpus = false, have_lattices = false, cascade = false;
+  LatticeSet lat;  // host copy of descriptors (classes); bulk arrays are freed after upload
+  // device: model
+  DevBuf<double> arc_logw;      // composed-arc weights (single transducer: THE parameters)
+  DevBuf<double> counts;        // n_arcs + 4
+  DevBuf<uint32_t> arc_group;   // groupId (single) / chain id (cascade)
+  // device: parameters (cascade only; single transducer aliases the arc arrays)
+  DevBuf<double> param_logw_c, param_counts_c;
+  DevBuf<uint32_t> param_group_c;
+  DevBuf<uint64_t> chain_off, chain_param;
+  uint64_t n_params = 0, n_chains = 0;
+  // M-step state over parameters
+  DevBuf<double> old_logw, em_logw, best_logw, prior;
+  DevBuf<uint32_t> norm_of;
+  DevBuf<double> add_count, gsum, gres;
+  DevBuf<unsigned long long> maxchg;
+  uint64_t n_norm_groups = 0;
+  bool have_norm = false, have_prior = false;
+  int norm_group_by = CARMEL_HIP_NORM_CONDITIONAL;
+  double norm_add_count = 0, smooth_floor = 0;
+  // device: lattices
+  DevBuf<BundleDesc> bundles;
+  DevBuf<uint2_t> in_arcs, out_arcs;
+  DevBuf<uint32_t> in_off, out_off, level_off, pair_start, pair_final, pair_id;
+  DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
+  uint64_t device_bytes = 0;
+
+  double* ext_counts = nullptr;  // caller-owned n_arcs + 4 doubles (carmel_hip_use_external_counts)
+  double* counts_ptr() { return ext_counts ? ext_counts : counts.p; }
+  double* params() { return cascade ? param_logw_c.p : arc_logw.p; }
+  double* pcounts() { return cascade ? param_counts_c.p : counts_ptr(); }
+  uint32_t* pgroup() { return cascade ? param_group_c.p : arc_group.p; }
+  uint64_t np() const { return cascade ? n_params : w.n_arcs; }
+};
+
+extern "C" {
+
+const char* carmel_hip_last_error(void) { return g_err.c_str(); }
+
+int carmel_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, uint32_t final_state, uint64_t n_arcs,
+                      const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
+                      const double* logw, const uint32_t* group) {
+  if (!out || !src || !dst || !in_sym || !out_sym || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (final_state >= n_states) return fail(CARMEL_HIP_ERR_ARG, "final state out of range");
+  if (n_arcs >= 0xfffffff0ull) return fail(CARMEL_HIP_ERR_ARG, "arc ids are 32-bit (derivations.h GraphArc data)");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(CARMEL_HIP_ERR_HIP, "no HIP device: the EM hot path has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(CARMEL_HIP_ERR_ARG, "bad device index");
+  HIPCHK(hipSetDevice(device));
+  carmel_hip_trainer* t = new carmel_hip_trainer();
+  t->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&t->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete t;
+    return fail(CARMEL_HIP_ERR_HIP, hipGetErrorString(e));
+  }
+  (void)hipEventCreate(&t->ev0);
+  (void)hipEventCreate(&t->ev1);
+  HostWfst& w = t->w;
+  w.n_states = n_states;
+  w.final_state = final_state;
+  w.n_arcs = n_arcs;
+  w.src.assign(src, src + n_arcs);
+  w.dst.assign(dst, dst + n_arcs);
+  w.in.assign(in_sym, in_sym + n_arcs);
+  w.out.assign(out_sym, out_sym + n_arcs);
+  if (group)
+    w.group.assign(group, group + n_arcs);
+  else
+    w.group.assign(n_arcs, CARMEL_HIP_NO_GROUP);
+  for (uint64_t k = 0; k < n_arcs; ++k) {
+    if (src[k] >= n_states || dst[k] >= n_states) {
+      delete t;
+      return fail(CARMEL_HIP_ERR_ARG, "arc endpoint out of range");
+    }
+    if (k && src[k] < src[k - 1]) {
+      delete t;
+      return fail(CARMEL_HIP_ERR_ARG, "arcs must be in arc-id order (state-major)");
+    }
+  }
+  w.build_index();
+  std::vector<double> lw(logw, logw + n_arcs);
+  e = t->arc_logw.upload(lw, t->stream);
+  if (e == hipSuccess) e = t->arc_group.upload(w.group, t->stream);
+  if (e == hipSuccess) e = t->counts.alloc(n_arcs + 4);
+  if (e == hipSuccess) e = t->old_logw.alloc(n_arcs);
+  if (e == hipSuccess) e = t->em_logw.alloc(n_arcs);
+  if (e == hipSuccess) e = t->best_logw.alloc(n_arcs);
+  if (e == hipSuccess) e = t->maxchg.alloc(1);
+  if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+  if (e != hipSuccess) {
+    delete t;
+    return fail(CARMEL_HIP_ERR_HIP, hipGetErrorString(e));
+  }
+  *out = t;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_destroy(carmel_hip_trainer* t) {
+  if (!t) return CARMEL_HIP_OK;
+  (void)hipSetDevice(t->device);
+  if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->ev0) (void)hipEventDestroy(t->ev0);
+  if (t->ev1) (void)hipEventDestroy(t->ev1);
+  hipStream_t s = t->stream;
+  delete t;
+  if (s) (void)hipStreamDestroy(s);
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_set_corpus(carmel_hip_trainer* t, uint64_t n_pairs, const uint64_t* in_off, const uint32_t* in_sym,
+                          const uint64_t* out_off, const uint32_t* out_sym, const double* pair_weight) {
+  if (!t || !in_off || !out_off) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HostCorpus& c = t->corpus;
+  c.n_pairs = n_pairs;
+  c.in_off.assign(in_off, in_off + n_pairs + 1);
+  c.out_off.assign(out_off, out_off + n_pairs + 1);
+  c.in_sym.assign(in_sym, in_sym + in_off[n_pairs]);
+  c.out_sym.assign(out_sym, out_sym + out_off[n_pairs]);
+  if (pair_weight)
+    c.weight.assign(pair_weight, pair_weight + n_pairs);
+  else
+    c.weight.assign(n_pairs, 1.0);
+  t->have_corpus = true;
+  t->have_lattices = false;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads, uint8_t* has_derivation,
+                              carmel_hip_lattice_stats* stats) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
+  HIPCHK(hipSetDevice(t->device));
+  auto t0 = std::chrono::steady_clock::now();
+  BuildOptions opt;
+  opt.prune = prune != 0;
+  opt.threads = host_threads;
+  std::string err;
+  LatticeSet& L = t->lat;
+  if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
+  if (has_derivation) std::memcpy(has_derivation, L.has_deriv.data(), L.has_deriv.size());
+  hipStream_t s = t->stream;
+  HIPCHK(t->bundles.upload(L.bundles, s));
+  HIPCHK(t->in_arcs.upload(L.in_arcs, s));
+  HIPCHK(t->out_arcs.upload(L.out_arcs, s));
+  HIPCHK(t->in_off.upload(L.in_off, s));
+  HIPCHK(t->out_off.upload(L.out_off, s));
+  HIPCHK(t->level_off.upload(L.level_off, s));
+  HIPCHK(t->pair_start.upload(L.pair_start, s));
+  HIPCHK(t->pair_final.upload(L.pair_final, s));
+  HIPCHK(t->pair_id.upload(L.pair_id, s));
+  HIPCHK(t->pair_logw.upload(L.pair_logw, s));
+  HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
+  HIPCHK(t->alpha_g.alloc(L.in_off.size()));
+  bool need_beta = false;
+  for (auto& lc : L.classes)
+    if (lc.serial || lc.max_states == 0) need_beta = true;
+  if (need_beta)
+    HIPCHK(t->beta_g.alloc(L.in_off.size()));
+  else
+    t->beta_g.release();
+  HIPCHK(launch_fill(t->pair_logprob.p, -std::numeric_limits<double>::infinity(), t->corpus.n_pairs, s));
+  HIPCHK(hipStreamSynchronize(s));
+  t->device_bytes = t->bundles.bytes() + t->in_arcs.bytes() + t->out_arcs.bytes() + t->in_off.bytes() +
+                    t->out_off.bytes() + t->level_off.bytes() + t->pair_start.bytes() + t->pair_final.bytes() +
+                    t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
+                    t->beta_g.bytes();
+  // free the bulk host arrays; keep descriptors + classes
+  std::vector<uint2_t>().swap(L.in_arcs);
+  std::vector<uint2_t>().swap(L.out_arcs);
+  std::vector<uint32_t>().swap(L.in_off);
+  std::vector<uint32_t>().swap(L.out_off);
+  std::vector<uint32_t>().swap(L.level_off);
+  t->have_lattices = true;
+  if (stats) {
+    stats->n_pairs = t->corpus.n_pairs;
+    stats->n_pairs_kept = L.n_kept;
+    stats->explored_states = L.explored_states;
+    stats->explored_arcs = L.explored_arcs;
+    stats->kept_states = L.total_states;
+    stats->kept_arcs = L.total_arcs;
+    stats->n_cyclic_pairs = L.n_cyclic;
+    stats->n_bundles = L.bundles.size();
+    stats->max_levels = L.max_levels;
+    stats->device_bytes = t->device_bytes;
+    stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return CARMEL_HIP_OK;
+}
+
+// norm groups over a parameter table given (member, src state, input symbol, method)
+static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* member, const uint32_t* src,
+                             const uint32_t* in, const std::vector<int>& method, const std::vector<double>& addc) {
+  std::vector<uint32_t> norm_of(n);
+  std::vector<double> add;
+  std::unordered_map<uint64_t, uint32_t> ids;
+  ids.reserve(n);
+  // key: member | state | (input symbol or ~0 for JOINT).  States and symbols are 32-bit, members few: two maps
+  // deep would be simpler but slower; mix into 64 bits + verify by construction (member < 2^8, state < 2^32,
+  // symbol < 2^24 are checked).
+  for (uint64_t k = 0; k < n; ++k) {
+    uint32_t m = member ? member[k] : 0;
+    int g = method[m];
+    if (g == CARMEL_HIP_NORM_NONE) {
+      norm_of[k] = 0xffffffffu;
+      continue;
+    }
+    uint64_t sym = (g == CARMEL_HIP_NORM_JOINT) ? 0xffffffull : (uint64_t)in[k];
+    if (m >= 256 || sym > 0xffffffull) return fail(CARMEL_HIP_ERR_UNSUPPORTED, "norm-group key out of range");
+    uint64_t key = ((uint64_t)m << 56) | (sym << 32) | src[k];
+    auto it = ids.find(key);
+    if (it == ids.end()) {
+      uint32_t id = (uint32_t)add.size();
+      ids.emplace(key, id);
+      add.push_back(addc[m]);
+      norm_of[k] = id;
+    } else
+      norm_of[k] = it->second;
+  }
+  t->n_norm_groups = add.size();
+  HIPCHK(t->norm_of.upload(norm_of, t->stream));
+  HIPCHK(t->add_count.upload(add, t->stream));
+  HIPCHK(t->gsum.alloc(add.size()));
+  HIPCHK(t->gres.alloc(add.size()));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  t->have_norm = true;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_set_norm(carmel_hip_trainer* t, int norm_group_by, double add_count) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (t->cascade) return fail(CARMEL_HIP_ERR_STATE, "cascade: per-member methods come from set_cascade");
+  HIPCHK(hipSetDevice(t->device));
+  for (uint64_t k = 0; k < t->w.n_arcs; ++k)
+    if (t->w.group[k] != CARMEL_HIP_NO_GROUP && t->w.group[k] != CARMEL_HIP_LOCKED_GROUP)
+      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "tied arc groups (!N) are not supported by the GPU M-step yet");
+  t->norm_group_by = norm_group_by;
+  t->norm_add_count = add_count;
+  std::vector<int> m(1, norm_group_by);
+  std::vector<double> a(1, add_count);
+  return build_norm_groups(t, t->w.n_arcs, nullptr, t->w.src.data(), t->w.in.data(), m, a);
+}
+
+int carmel_hip_set_prior(carmel_hip_trainer* t, double smooth_floor, int weight_is_prior_count) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  t->smooth_floor = smooth_floor;
+  uint64_t n = t->w.n_arcs;  // the prior belongs to the (composed) arc table (derivations.h:96-101)
+  std::vector<double> pr(n, smooth_floor > 0 ? smooth_floor : 0.0);
+  if (weight_is_prior_count) {
+    std::vector<double> lw(n);
+    HIPCHK(hipMemcpyAsync(lw.data(), t->arc_logw.p, n * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    for (uint64_t k = 0; k < n; ++k) pr[k] += std::exp(lw[k]);
+  }
+  HIPCHK(t->prior.upload(pr, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  t->have_prior = true;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const double* param_logw,
+                           const uint32_t* param_group, const uint32_t* param_member, const uint32_t* param_src,
+                           const uint32_t* param_in, uint32_t n_members, const int* member_norm,
+                           const double* member_add_count, uint64_t n_chains, const uint64_t* chain_off,
+                           const uint64_t* chain_param) {
+  if (!t || !param_logw || !param_group || !param_member || !param_src || !param_in || !member_norm || !chain_off)
+    return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  for (uint64_t k = 0; k < t->w.n_arcs; ++k)
+    if (t->w.group[k] >= n_chains) return fail(CARMEL_HIP_ERR_ARG, "composed arc refers to a chain id out of range");
+  for (uint64_t p = 0; p < n_params; ++p)
+    if (param_group[p] != CARMEL_HIP_NO_GROUP && param_group[p] != CARMEL_HIP_LOCKED_GROUP)
+      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "tied arc groups (!N) are not supported by the GPU M-step yet");
+  for (uint64_t j = 0; j < chain_off[n_chains]; ++j)
+    if (chain_param[j] >= n_params) return fail(CARMEL_HIP_ERR_ARG, "chain refers to a parameter out of range");
+  t->cascade = true;
+  t->n_params = n_params;
+  t->n_chains = n_chains;
+  hipStream_t s = t->stream;
+  HIPCHK(t->param_logw_c.upload(std::vector<double>(param_logw, param_logw + n_params), s));
+  HIPCHK(t->param_group_c.upload(std::vector<uint32_t>(param_group, param_group + n_params), s));
+  HIPCHK(t->param_counts_c.alloc(n_params));
+  HIPCHK(t->chain_off.upload(std::vector<uint64_t>(chain_off, chain_off + n_chains + 1), s));
+  HIPCHK(t->chain_param.upload(std::vector<uint64_t>(chain_param, chain_param + chain_off[n_chains]), s));
+  HIPCHK(t->old_logw.alloc(std::max<uint64_t>(n_params, t->w.n_arcs)));
+  HIPCHK(t->em_logw.alloc(t->w.n_arcs));    // for a cascade: composed-arc counts of the previous iteration
+  HIPCHK(t->best_logw.alloc(t->w.n_arcs));  // ... and the best of those (train.cc:123-130, 449-455)
+  std::vector<int> m(member_norm, member_norm + n_members);
+  std::vector<double> a(n_members, 0.0);
+  if (member_add_count) a.assign(member_add_count, member_add_count + n_members);
+  for (uint64_t p = 0; p < n_params; ++p)
+    if (param_member[p] >= n_members) return fail(CARMEL_HIP_ERR_ARG, "param_member out of range");
+  int rc = build_norm_groups(t, n_params, param_member, param_src, param_in, m, a);
+  if (rc) return rc;
+  // composed weights from the chains (cascade.update)
+  HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
+                             t->w.n_arcs, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+
+static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
+  hipStream_t s = t->stream;
+  HIPCHK(hipMemsetAsync(t->gsum.p, 0, t->gsum.bytes(), s));
+  HIPCHK(hipMemsetAsync(t->gres.p, 0, t->gres.bytes(), s));
+  HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
+  MstepArgs M;
+  M.logw = t->params();
+  M.old_logw = t->old_logw.p;
+  M.counts = t->pcounts();
+  M.prior = (!t->cascade && t->have_prior) ? t->prior.p : nullptr;
+  M.group = t->pgroup();
+  M.norm_of = t->norm_of.p;
+  M.add_count = t->add_count.p;
+  M.gsum = t->gsum.p;
+  M.greserved = t->gres.p;
+  M.max_change_bits = t->maxchg.p;
+  M.n = t->np();
+  M.save_old = save_old;
+  HIPCHK(launch_mstep(M, use_counts, s));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_normalize(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
+  HIPCHK(hipSetDevice(t->device));
+  int rc = run_mstep(t, 0, 1);
+  if (rc) return rc;
+  if (t->cascade)
+    HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
+                               t->w.n_arcs, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_set_weights(carmel_hip_trainer* t, const double* logw) {
+  if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(t->params(), logw, t->np() * sizeof(double), hipMemcpyHostToDevice, t->stream));
+  if (t->cascade)
+    HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
+                               t->w.n_arcs, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_get_weights(carmel_hip_trainer* t, double* logw) {
+  if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(logw, t->params(), t->np() * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_get_arc_weights(carmel_hip_trainer* t, double* logw) {
+  if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(logw, t->arc_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_estimate_async(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  if (t->cascade)  // cascade.update(): composed weights from the chains
+    HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
+                               t->w.n_arcs, s));
+  HIPCHK(hipMemsetAsync(t->counts_ptr(), 0, (t->w.n_arcs + 4) * sizeof(double), s));
+  SweepArgs A;
+  A.bundles = t->bundles.p;
+  A.in_arcs = (const uint2*)t->in_arcs.p;
+  A.out_arcs = (const uint2*)t->out_arcs.p;
+  A.in_off = t->in_off.p;
+  A.out_off = t->out_off.p;
+  A.level_off = t->level_off.p;
+  A.pair_start = t->pair_start.p;
+  A.pair_final = t->pair_final.p;
+  A.pair_id = t->pair_id.p;
+  A.pair_logw = t->pair_logw.p;
+  A.logw = t->arc_logw.p;
+  A.counts = t->counts_ptr();
+  A.pair_logprob = t->pair_logprob.p;
+  A.alpha_g = t->alpha_g.p;
+  A.beta_g = t->beta_g.p;
+  A.n_arcs = t->w.n_arcs;
+  A.first_bundle = 0;
+  HIPCHK(hipEventRecord(t->ev0, s));
+  for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
+  HIPCHK(hipEventRecord(t->ev1, s));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* res) {
+  if (!t || !res) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  double sc[4];
+  HIPCHK(hipMemcpyAsync(sc, t->counts_ptr() + t->w.n_arcs, sizeof sc, hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  res->sum_logprob = sc[0];
+  res->sum_weighted_logprob = sc[1];
+  res->n_pairs = (uint64_t)(sc[2] + 0.5);
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_estimate_finish(carmel_hip_trainer* t, carmel_hip_estimate_result* res, double* per_pair_logprob) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  carmel_hip_estimate_result r;
+  std::memset(&r, 0, sizeof r);
+  int rc = carmel_hip_read_scalars(t, &r);
+  if (rc) return rc;
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, t->ev0, t->ev1));
+  r.kernel_ms = ms;
+  if (per_pair_logprob) {
+    HIPCHK(hipMemcpyAsync(per_pair_logprob, t->pair_logprob.p, t->corpus.n_pairs * sizeof(double),
+                          hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+  }
+  if (res) *res = r;
+  if (t->lat.n_kept == 0)
+    return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation - aborting training.");
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_estimate(carmel_hip_trainer* t, carmel_hip_estimate_result* res, double* per_pair_logprob) {
+  int rc = carmel_hip_estimate_async(t);
+  if (rc) return rc;
+  return carmel_hip_estimate_finish(t, res, per_pair_logprob);
+}
+
+void* carmel_hip_counts_dev(carmel_hip_trainer* t) { return t ? (void*)t->counts_ptr() : nullptr; }
+int carmel_hip_use_external_counts(carmel_hip_trainer* t, void* dev_ptr) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  t->ext_counts = (double*)dev_ptr;
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_last_sweep_ms(carmel_hip_trainer* t, double* ms) {
+  if (!t || !ms) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipEventSynchronize(t->ev1));
+  float f = 0;
+  HIPCHK(hipEventElapsedTime(&f, t->ev0, t->ev1));
+  *ms = f;
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_synchronize(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+uint64_t carmel_hip_counts_len(carmel_hip_trainer* t) { return t ? t->w.n_arcs + 4 : 0; }
+void* carmel_hip_stream(carmel_hip_trainer* t) { return t ? (void*)t->stream : nullptr; }
+
+int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts) {
+  if (!t || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(counts, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts) {
+  if (!t || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(t->counts_ptr(), counts, t->w.n_arcs * sizeof(double), hipMemcpyHostToDevice, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  if (t->cascade) {
+    // distribute_counts (cascade.h:318-325): parameter counts = sum over composed arcs using it of
+    // (composed count + composed prior)
+    HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
+    HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
+                                t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+  }
+  int rc = run_mstep(t, 1, 1);
+  if (rc) return rc;
+  double result = 10.0;  // train.cc:922
+  if (!t->cascade) {
+    if (delta_scale > 1.0) {
+      HIPCHK(launch_overrelax(t->arc_logw.p, t->old_logw.p, t->em_logw.p, t->arc_group.p, delta_scale, t->w.n_arcs, s));
+      rc = run_mstep(t, 0, 0);  // x.normalize(methods[0]) on the overrelaxed weights, scratch kept
+      if (rc) return rc;
+      HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
+      HIPCHK(launch_max_change(t->arc_logw.p, t->old_logw.p, t->arc_group.p, t->maxchg.p, t->w.n_arcs, s));
+    } else {
+      HIPCHK(hipMemcpyAsync(t->em_logw.p, t->arc_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    unsigned long long bits = 0;
+    HIPCHK(hipMemcpyAsync(&bits, t->maxchg.p, sizeof bits, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    double d;
+    std::memcpy(&d, &bits, sizeof d);
+    result = d;
+  } else {
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  if (max_change) *max_change = result;
+  return CARMEL_HIP_OK;
+}
+
+// single transducer: best_weight <- weight (train.cc:184-186).  cascade: best <- em_weight, i.e. the composed
+// COUNTS saved before this estimate (train.cc:123-130)
+int carmel_hip_save_counts(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  // for_arcs::save_counts: em_weight <- weight() of the composed arc, which after the previous maximize's
+  // prep_new_weights holds (count + prior) — here: the counts buffer of the previous estimate
+  HIPCHK(hipMemcpyAsync(t->em_logw.p, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_save_best(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  const double* from = t->cascade ? t->em_logw.p : t->arc_logw.p;
+  HIPCHK(hipMemcpyAsync(t->best_logw.p, from, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_load_best(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  if (!t->cascade) {
+    HIPCHK(hipMemcpyAsync(t->arc_logw.p, t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CARMEL_HIP_OK;
+  }
+  // load_best + use_counts_final (train.cc:673-674, cascade.h:358-364): best composed counts -> parameters
+  HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
+  // the saved value already includes the composed prior (prep_new_weights ran before it was saved)
+  HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
+                              t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+  int rc = run_mstep(t, 1, 1);
+  if (rc) return rc;
+  HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
+                             t->w.n_arcs, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+
+}  // extern "C"

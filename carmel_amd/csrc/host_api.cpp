@@ -1,0 +1,99 @@
+// host_api.cpp — host-only inspection entry points (no GPU needed): build the lattices exactly as
+// carmel_hip_build_lattices does and hand the batched-CSR image back, so the layout can be checked against the
+// oracle on machines without a device.  Nothing here computes forward/backward values.
+#include <cstring>
+#include <string>
+#include "../../include/carmel_hip.h"
+#include "lattice.hpp"
+
+using namespace carmel_hip;
+
+struct carmel_hip_host_lattices {
+  HostWfst w;
+  HostCorpus c;
+  LatticeSet L;
+  std::string err;
+};
+
+extern "C" {
+
+int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uint32_t final_state, uint64_t n_arcs,
+                          const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
+                          uint64_t n_pairs, const uint64_t* in_off, const uint32_t* cin, const uint64_t* out_off,
+                          const uint32_t* cout, const double* pair_weight, int prune, int threads,
+                          uint32_t small_pairs, uint32_t small_states) {
+  if (!out) return CARMEL_HIP_ERR_ARG;
+  carmel_hip_host_lattices* h = new carmel_hip_host_lattices();
+  h->w.n_states = n_states;
+  h->w.final_state = final_state;
+  h->w.n_arcs = n_arcs;
+  h->w.src.assign(src, src + n_arcs);
+  h->w.dst.assign(dst, dst + n_arcs);
+  h->w.in.assign(in_sym, in_sym + n_arcs);
+  h->w.out.assign(out_sym, out_sym + n_arcs);
+  h->w.build_index();
+  h->c.n_pairs = n_pairs;
+  h->c.in_off.assign(in_off, in_off + n_pairs + 1);
+  h->c.out_off.assign(out_off, out_off + n_pairs + 1);
+  h->c.in_sym.assign(cin, cin + in_off[n_pairs]);
+  h->c.out_sym.assign(cout, cout + out_off[n_pairs]);
+  if (pair_weight)
+    h->c.weight.assign(pair_weight, pair_weight + n_pairs);
+  else
+    h->c.weight.assign(n_pairs, 1.0);
+  BuildOptions opt;
+  opt.prune = prune != 0;
+  opt.threads = threads;
+  if (small_pairs) opt.small_pairs = small_pairs;
+  if (small_states) opt.small_states = small_states;
+  if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
+    delete h;
+    return CARMEL_HIP_ERR_ARG;
+  }
+  *out = h;
+  return CARMEL_HIP_OK;
+}
+
+// dims[0..9] = n_bundles, n_off (states + bundles), n_arcs, n_level_off, n_pair_slots, n_classes, n_kept,
+//              n_cyclic, explored_states, explored_arcs
+void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims) {
+  dims[0] = h->L.bundles.size();
+  dims[1] = h->L.in_off.size();
+  dims[2] = h->L.in_arcs.size();
+  dims[3] = h->L.level_off.size();
+  dims[4] = h->L.pair_id.size();
+  dims[5] = h->L.classes.size();
+  dims[6] = h->L.n_kept;
+  dims[7] = h->L.n_cyclic;
+  dims[8] = h->L.explored_states;
+  dims[9] = h->L.explored_arcs;
+}
+
+void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,
+                            uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
+                            uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,
+                            uint8_t* has_deriv) {
+  const LatticeSet& L = h->L;
+  std::memcpy(bundles64, L.bundles.data(), L.bundles.size() * sizeof(BundleDesc));
+  std::memcpy(in_arcs, L.in_arcs.data(), L.in_arcs.size() * sizeof(uint2_t));
+  std::memcpy(out_arcs, L.out_arcs.data(), L.out_arcs.size() * sizeof(uint2_t));
+  std::memcpy(in_off, L.in_off.data(), L.in_off.size() * 4);
+  std::memcpy(out_off, L.out_off.data(), L.out_off.size() * 4);
+  std::memcpy(level_off, L.level_off.data(), L.level_off.size() * 4);
+  std::memcpy(pair_start, L.pair_start.data(), L.pair_start.size() * 4);
+  std::memcpy(pair_final, L.pair_final.data(), L.pair_final.size() * 4);
+  std::memcpy(pair_id, L.pair_id.data(), L.pair_id.size() * 4);
+  std::memcpy(pair_logw, L.pair_logw.data(), L.pair_logw.size() * 8);
+  for (size_t k = 0; k < L.classes.size(); ++k) {
+    classes5[5 * k + 0] = L.classes[k].first;
+    classes5[5 * k + 1] = L.classes[k].count;
+    classes5[5 * k + 2] = L.classes[k].block;
+    classes5[5 * k + 3] = L.classes[k].max_states;
+    classes5[5 * k + 4] = L.classes[k].serial ? 1u : 0u;
+  }
+  if (has_deriv) std::memcpy(has_deriv, L.has_deriv.data(), L.has_deriv.size());
+}
+
+void carmel_hip_host_free(carmel_hip_host_lattices* h) { delete h; }
+
+}  // extern "C"

@@ -1,0 +1,362 @@
+// kernels.hip — CDNA4 (gfx950) kernels for carmel's EM hot path.  64-wide wavefronts throughout.
+//
+// Data layout (built by lattice.cpp): lattices are packed into BUNDLES, one workgroup per bundle.  A bundle's
+// states are numbered level-major (level = longest path from a start state), so
+//   forward  alpha[s] = logsumexp over in-arcs  (alpha[src] + logw[arc])   needs only earlier levels,
+//   backward beta[s]  = logsumexp over out-arcs (logw[arc] + beta[dst])    needs only later levels,
+// and both are gathers: no atomics on alpha/beta, which live in LDS for the whole sweep.  The only atomics are
+// the f64 adds of expected counts into the per-arc table (global_atomic_add_f64).
+//
+// What is computed is derivations::compute_fb + collect_counts
+// (/root/reference/carmel/src/derivations.h:400-449, graph.h:391-402) with the log-semiring of
+// graehl/shared/weight.h:737-801.  The reference adds terms one at a time with log1p(exp(-|d|)) and drops
+// addends more than 36 nats smaller; here each state's sum is one streaming logsumexp (running max + scaled
+// sum), which differs from that only in the last bits (e^-36 ~ 2e-16).
+#include "kernels.hpp"
+
+namespace carmel_hip {
+
+#define NEG_INF (-__builtin_huge_val())
+
+// streaming logsumexp accumulator: value = m + log(acc)
+struct Lse {
+  double m, acc;
+  __device__ __forceinline__ void init() {
+    m = NEG_INF;
+    acc = 0.0;
+  }
+  __device__ __forceinline__ void add(double x) {
+    if (x == NEG_INF) return;
+    if (x <= m) {
+      acc += exp(x - m);
+    } else {
+      acc = acc * exp(m - x) + 1.0;  // m == -inf: exp(-inf) = 0
+      m = x;
+    }
+  }
+  __device__ __forceinline__ double value() const { return acc > 0.0 ? m + log(acc) : NEG_INF; }
+};
+
+// the reference's own pairwise add (weight.h:765-801) — used by the serial (cyclic-lattice) sweep so that the
+// order-dependent result there is the reference's
+__device__ __forceinline__ double lw_add(double a, double b) {
+  if (a == NEG_INF) return b;
+  if (b == NEG_INF) return a;
+  double d = a - b;
+  if (d > 36.0) return a;
+  if (d < -36.0) return b;
+  if (d < 0) return b + log1p(exp(d));
+  return a + log1p(exp(-d));
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  // hardware global_atomic_add_f64 (no CAS loop)
+  unsafeAtomicAdd(p, v);
+}
+
+
+// One workgroup sweeps one bundle: forward (alpha in LDS, also streamed to alpha_g), then backward fused with
+// count accumulation (beta in LDS, alpha re-read coalesced from alpha_g).
+// USE_LDS=false: alpha/beta live in global scratch (lattices above the LDS cap).
+template <int BLOCK, bool USE_LDS>
+__global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BundleDesc d = A.bundles[A.first_bundle + blockIdx.x];
+  const int tid = threadIdx.x;
+  const uint32_t ns = d.n_states;
+  const uint2* __restrict__ ia = A.in_arcs + d.in_base;
+  const uint2* __restrict__ oa = A.out_arcs + d.out_base;
+  const uint32_t* __restrict__ ioff = A.in_off + d.off_base;
+  const uint32_t* __restrict__ ooff = A.out_off + d.off_base;
+  const uint32_t* __restrict__ lvl = A.level_off + d.level_base;
+  const double* __restrict__ logw = A.logw;
+  double* ag = A.alpha_g + d.off_base;
+  double* val = USE_LDS ? lds : (A.beta_g + d.off_base);  // alpha during forward, beta during backward
+  // ---- forward ----
+  for (uint32_t s = tid; s < ns; s += BLOCK) val[s] = NEG_INF;
+  __syncthreads();
+  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) val[A.pair_start[d.pair_base + p]] = 0.0;
+  __syncthreads();
+  for (uint32_t l = 1; l < d.n_levels; ++l) {
+    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
+    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
+      const uint32_t a0 = ioff[s], a1 = ioff[s + 1];
+      Lse acc;
+      acc.init();
+      for (uint32_t a = a0; a < a1; ++a) {
+        const uint2 r = ia[a];
+        acc.add(val[r.x] + logw[r.y]);
+      }
+      val[s] = acc.value();
+    }
+    __syncthreads();
+  }
+  for (uint32_t s = tid; s < ns; s += BLOCK) ag[s] = val[s];
+  // per pair: ln p(pair) = alpha[final]; corpus scalars
+  double s_lp = 0.0, s_wlp = 0.0;
+  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
+    const double lp = val[A.pair_final[d.pair_base + p]];
+    A.pair_logprob[A.pair_id[d.pair_base + p]] = lp;
+    s_lp += lp;
+    s_wlp += lp * exp(A.pair_logw[d.pair_base + p]);
+  }
+  __syncthreads();
+  // ---- backward + counts ----
+  // beta[final] = ln(weight) - ln p(pair): folds "* weight / prob" of derivations.h:445 into the sweep
+  for (uint32_t s = tid; s < ns; s += BLOCK) val[s] = NEG_INF;
+  __syncthreads();
+  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
+    const uint32_t f = A.pair_final[d.pair_base + p];
+    const double lp = ag[f];
+    val[f] = (lp == NEG_INF) ? NEG_INF : A.pair_logw[d.pair_base + p] - lp;
+  }
+  __syncthreads();
+  for (uint32_t l = d.n_levels; l-- > 0;) {
+    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
+    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
+      const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+      if (a0 == a1) continue;  // goal states keep their initial value
+      const double al = ag[s];
+      Lse acc;
+      acc.init();
+      for (uint32_t a = a0; a < a1; ++a) {
+        const uint2 r = oa[a];
+        const double t = logw[r.y] + val[r.x];
+        acc.add(t);
+        const double c = exp(al + t);
+        if (c > 0.0) atomic_add_f64(A.counts + r.y, c);
+      }
+      val[s] = acc.value();
+    }
+    __syncthreads();
+  }
+  // corpus scalars: wave reduce then one atomic per wave
+  for (int o = 32; o > 0; o >>= 1) {
+    s_lp += __shfl_down(s_lp, o, 64);
+    s_wlp += __shfl_down(s_wlp, o, 64);
+  }
+  if ((tid & 63) == 0 && (s_lp != 0.0 || s_wlp != 0.0)) {
+    atomic_add_f64(A.counts + A.n_arcs + 0, s_lp);
+    atomic_add_f64(A.counts + A.n_arcs + 1, s_wlp);
+  }
+  if (tid == 0) atomic_add_f64(A.counts + A.n_arcs + 2, (double)d.n_pairs);
+}
+
+// Cyclic lattices (derivations.h:726-728 "Forward/backward will miss some paths"): one lane per lattice walks
+// the states in the reference's own order with the reference's pairwise adds, so the paths it drops and the
+// values it ends with are the reference's.  States are stored in forward order; out lists and reversed-graph
+// lists are in the reference's list order (lattice.cpp).
+__global__ void sweep_serial_kernel(SweepArgs A, uint32_t n_bundles) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_bundles) return;
+  const BundleDesc d = A.bundles[A.first_bundle + b];
+  const uint2* ia = A.in_arcs + d.in_base;
+  const uint2* oa = A.out_arcs + d.out_base;
+  const uint32_t* ioff = A.in_off + d.off_base;
+  const uint32_t* ooff = A.out_off + d.off_base;
+  double* f = A.alpha_g + d.off_base;
+  double* bb = A.beta_g + d.off_base;
+  const uint32_t ns = d.n_states;
+  const uint32_t st = A.pair_start[d.pair_base], fin = A.pair_final[d.pair_base];
+  for (uint32_t s = 0; s < ns; ++s) {
+    f[s] = NEG_INF;
+    bb[s] = NEG_INF;
+  }
+  f[st] = 0.0;
+  for (uint32_t s = 0; s < ns; ++s) {  // graph.h:391-402, order = reversed DFS post-order
+    for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) {
+      const uint2 r = oa[a];
+      f[r.x] = lw_add(f[r.x], f[s] + A.logw[r.y]);
+    }
+  }
+  const double prob = f[fin];
+  A.pair_logprob[A.pair_id[d.pair_base]] = prob;
+  const double lwt = A.pair_logw[d.pair_base];
+  bb[fin] = 0.0;
+  for (uint32_t s = ns; s-- > 0;) {
+    for (uint32_t a = ioff[s]; a < ioff[s + 1]; ++a) {
+      const uint2 r = ia[a];
+      bb[r.x] = lw_add(bb[r.x], bb[s] + A.logw[r.y]);
+    }
+  }
+  if (prob != NEG_INF) {
+    for (uint32_t s = 0; s < ns; ++s)
+      for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) {
+        const uint2 r = oa[a];
+        const double c = exp(A.logw[r.y] + f[s] + bb[r.x] + lwt - prob);
+        if (c > 0.0) atomic_add_f64(A.counts + r.y, c);
+      }
+  }
+  atomic_add_f64(A.counts + A.n_arcs + 0, prob);
+  atomic_add_f64(A.counts + A.n_arcs + 1, prob * exp(lwt));
+  atomic_add_f64(A.counts + A.n_arcs + 2, 1.0);
+}
+
+// ---------------- M-step (fst.cc:86-244 for normal + locked arcs; train.cc:134-182) ----------------
+
+// pass 0: new unnormalised value per parameter (prep_new_weights + "w += addc" of normalize pass 1), group sums
+__global__ void mstep_accumulate_kernel(MstepArgs M, int use_counts) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = M.group[k];
+    const bool locked = (g == 0u);
+    const double old = M.logw[k];
+    if (M.save_old) M.old_logw[k] = old;
+    const uint32_t ng = M.norm_of[k];
+    if (ng == 0xffffffffu) continue;  // member normalised by NONE keeps its weights (cascade.h:339-350)
+    double v;  // linear
+    if (locked || !use_counts)
+      v = exp(old);
+    else
+      v = M.counts[k] + (M.prior ? M.prior[k] : 0.0);
+    v += M.add_count[ng];
+    if (v > 0.0) atomic_add_f64(locked ? (M.greserved + ng) : (M.gsum + ng), v);
+    // stash the unnormalised value (ln) for pass 1
+    M.logw[k] = v > 0.0 ? log(v) : NEG_INF;
+  }
+}
+
+// pass 1: w = (1 - reserved) * v / sum  for normal arcs (fst.cc:213-230); locked arcs keep v; max |new-old|
+__global__ void mstep_normalize_kernel(MstepArgs M) {
+  double mx = 0.0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t g = M.group[k];
+    const uint32_t ng = M.norm_of[k];
+    if (g == 0u || ng == 0xffffffffu) continue;  // locked: value already stored; NONE: untouched
+    const double lv = M.logw[k];
+    double nw;
+    const double sum = M.gsum[ng];
+    const double remain = 1.0 - M.greserved[ng];
+    if (remain > 0.0 && sum > 0.0 && lv != NEG_INF)
+      nw = lv + log(remain) - log(sum);
+    else
+      nw = NEG_INF;
+    M.logw[k] = nw;
+    const double ch = fabs(exp(nw) - exp(M.old_logw[k]));
+    mx = fmax(mx, ch);
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(M.max_change_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// overrelax (train.cc:157-171): w = old * (em/old)^rate for unlocked arcs with old > 0
+__global__ void overrelax_kernel(double* logw, const double* old_logw, double* em_logw, const uint32_t* group,
+                                 double rate, uint64_t n) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+    const double em = logw[k];
+    em_logw[k] = em;
+    if (group[k] != 0u && old_logw[k] != NEG_INF) logw[k] = old_logw[k] + (em - old_logw[k]) * rate;
+  }
+}
+
+__global__ void max_change_kernel(const double* logw, const double* old_logw, const uint32_t* group,
+                                  unsigned long long* max_change_bits, uint64_t n) {
+  double mx = 0.0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+    if (group[k] != 0u) mx = fmax(mx, fabs(exp(logw[k]) - exp(old_logw[k])));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(max_change_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+// ---------------- cascade gather / scatter (cascade.h:426-433, 286-325) ----------------
+// composed arc weight = sum of ln weights of its chain's parameters
+__global__ void chain_update_kernel(double* arc_logw, const uint32_t* arc_chain, const uint64_t* chain_off,
+                                    const uint64_t* chain_param, const double* param_logw, uint64_t n_arcs) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_arcs; k += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = arc_chain[k];
+    double w = 0.0;
+    bool zero = false;
+    for (uint64_t j = chain_off[c]; j < chain_off[c + 1]; ++j) {
+      const double pw = param_logw[chain_param[j]];
+      if (pw == NEG_INF) zero = true;
+      w += pw;
+    }
+    arc_logw[k] = zero ? NEG_INF : w;
+  }
+}
+// parameter counts += (composed count + composed prior) for every unlocked parameter of the arc's chain
+__global__ void chain_scatter_kernel(double* param_counts, const double* arc_counts, double arc_prior,
+                                     const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
+                                     const uint32_t* param_group, uint64_t n_arcs) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_arcs; k += (uint64_t)gridDim.x * blockDim.x) {
+    const double c = arc_counts[k] + arc_prior;
+    if (!(c > 0.0)) continue;
+    const uint32_t ch = arc_chain[k];
+    for (uint64_t j = chain_off[ch]; j < chain_off[ch + 1]; ++j) {
+      const uint64_t p = chain_param[j];
+      if (param_group[p] != 0u) atomic_add_f64(param_counts + p, c);
+    }
+  }
+}
+
+__global__ void fill_f64_kernel(double* p, double v, uint64_t n) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) p[k] = v;
+}
+
+// ---------------- launch helpers (called from engine.cpp, compiled in this TU) ----------------
+static inline int grid_for(uint64_t n, int block) {
+  uint64_t g = (n + block - 1) / block;
+  if (g > 256ull * 16) g = 256ull * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, hipStream_t stream) {
+  SweepArgs A = A0;
+  A.first_bundle = lc.first;
+  if (lc.serial) {
+    int block = 64;
+    int grid = (int)((lc.count + block - 1) / block);
+    hipLaunchKernelGGL(sweep_serial_kernel, dim3(grid), dim3(block), 0, stream, A, lc.count);
+    return hipGetLastError();
+  }
+  size_t lds = (size_t)lc.max_states * sizeof(double);
+  if (lc.max_states == 0) {
+    hipLaunchKernelGGL((sweep_bundle_kernel<1024, false>), dim3(lc.count), dim3(1024), 0, stream, A);
+  } else if (lc.block == 64) {
+    hipLaunchKernelGGL((sweep_bundle_kernel<64, true>), dim3(lc.count), dim3(64), lds, stream, A);
+  } else if (lc.block == 256) {
+    hipLaunchKernelGGL((sweep_bundle_kernel<256, true>), dim3(lc.count), dim3(256), lds, stream, A);
+  } else {
+    hipFuncSetAttribute((const void*)sweep_bundle_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                        (int)lds);
+    hipLaunchKernelGGL((sweep_bundle_kernel<1024, true>), dim3(lc.count), dim3(1024), lds, stream, A);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(fill_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, v, n);
+  return hipGetLastError();
+}
+hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
+  if (!M.n) return hipSuccess;
+  hipLaunchKernelGGL(mstep_accumulate_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
+  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M);
+  return hipGetLastError();
+}
+hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,
+                            uint64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(overrelax_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, logw, old_logw, em_logw, group, rate, n);
+  return hipGetLastError();
+}
+hipError_t launch_max_change(const double* logw, const double* old_logw, const uint32_t* group,
+                             unsigned long long* bits, uint64_t n, hipStream_t s) {
+  hipLaunchKernelGGL(max_change_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, logw, old_logw, group, bits, n);
+  return hipGetLastError();
+}
+hipError_t launch_chain_update(double* arc_logw, const uint32_t* arc_chain, const uint64_t* chain_off,
+                               const uint64_t* chain_param, const double* param_logw, uint64_t n_arcs, hipStream_t s) {
+  hipLaunchKernelGGL(chain_update_kernel, dim3(grid_for(n_arcs, 256)), dim3(256), 0, s, arc_logw, arc_chain, chain_off,
+                     chain_param, param_logw, n_arcs);
+  return hipGetLastError();
+}
+hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior,
+                                const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
+                                const uint32_t* param_group, uint64_t n_arcs, hipStream_t s) {
+  hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n_arcs, 256)), dim3(256), 0, s, param_counts, arc_counts,
+                     arc_prior, arc_chain, chain_off, chain_param, param_group, n_arcs);
+  return hipGetLastError();
+}
+
+}  // namespace carmel_hip

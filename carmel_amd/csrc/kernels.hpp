@@ -1,0 +1,57 @@
+// kernels.hpp — argument blocks and launch entry points shared by kernels.hip (device code) and engine.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lattice.hpp"
+
+namespace carmel_hip {
+
+struct SweepArgs {
+  const BundleDesc* bundles;
+  const uint2* in_arcs;
+  const uint2* out_arcs;
+  const uint32_t* in_off;
+  const uint32_t* out_off;
+  const uint32_t* level_off;
+  const uint32_t* pair_start;
+  const uint32_t* pair_final;
+  const uint32_t* pair_id;
+  const double* pair_logw;
+  const double* logw;       // per WFST arc
+  double* counts;           // per WFST arc, linear; [n_arcs .. n_arcs+3] = scalars
+  double* pair_logprob;     // per corpus pair
+  double* alpha_g;          // per lattice state (global scratch, indexed by off_base + s)
+  double* beta_g;           // only for bundles too large for LDS / serial sweeps
+  uint64_t n_arcs;
+  uint32_t first_bundle;
+};
+
+struct MstepArgs {
+  double* logw;             // parameters (ln), updated in place
+  double* old_logw;         // scratch (arc_counts::scratch)
+  const double* counts;     // linear expected counts per parameter
+  const double* prior;      // linear prior count per parameter (may be null => 0)
+  const uint32_t* group;    // FSTArc::groupId per parameter (0 = locked)
+  const uint32_t* norm_of;  // norm-group id per parameter; 0xffffffff = member normalised by NONE
+  const double* add_count;  // per norm group (--priors of the member it belongs to)
+  double* gsum;             // per norm group: sum over normal arcs
+  double* greserved;        // per norm group: sum over locked arcs
+  unsigned long long* max_change_bits;
+  uint64_t n;
+  int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
+};
+
+hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
+hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
+hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);
+hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,
+                            uint64_t n, hipStream_t s);
+hipError_t launch_max_change(const double* logw, const double* old_logw, const uint32_t* group,
+                             unsigned long long* bits, uint64_t n, hipStream_t s);
+hipError_t launch_chain_update(double* arc_logw, const uint32_t* arc_chain, const uint64_t* chain_off,
+                               const uint64_t* chain_param, const double* param_logw, uint64_t n_arcs, hipStream_t s);
+hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior,
+                                const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
+                                const uint32_t* param_group, uint64_t n_arcs, hipStream_t s);
+
+}  // namespace carmel_hip

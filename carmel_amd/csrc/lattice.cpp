@@ -1,0 +1,709 @@
+// lattice.cpp — see lattice.hpp.  Host C++ only (no HIP): builds lattices and the batched-CSR image.
+#include "lattice.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <thread>
+#include <atomic>
+
+namespace carmel_hip {
+
+void HostWfst::build_index() {
+  idx_off.assign((size_t)n_states + 1, 0);
+  for (uint64_t k = 0; k < n_arcs; ++k) idx_off[src[k] + 1]++;
+  for (uint32_t s = 0; s < n_states; ++s) idx_off[s + 1] += idx_off[s];
+  idx_key.resize(n_arcs);
+  idx_arc.resize(n_arcs);
+  std::vector<uint64_t> cur(idx_off.begin(), idx_off.end() - 1);
+  for (uint64_t k = 0; k < n_arcs; ++k) {
+    uint64_t p = cur[src[k]]++;
+    idx_key[p] = ((uint64_t)in[k] << 32) | out[k];
+    idx_arc[p] = (uint32_t)k;
+  }
+  // sort each state's slice by key, ties by arc id (stable) == wfst_io_index's per-(in,out) push_back order
+  // (derivations.h:150-154)
+  std::vector<uint32_t> perm;
+  std::vector<uint64_t> tk;
+  std::vector<uint32_t> ta;
+  for (uint32_t s = 0; s < n_states; ++s) {
+    uint64_t a = idx_off[s], b = idx_off[s + 1];
+    size_t n = (size_t)(b - a);
+    if (n < 2) continue;
+    bool sorted = true;
+    for (size_t i = 1; i < n; ++i)
+      if (idx_key[a + i] < idx_key[a + i - 1]) {
+        sorted = false;
+        break;
+      }
+    if (sorted) continue;
+    perm.resize(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return idx_key[a + x] < idx_key[a + y]; });
+    tk.resize(n);
+    ta.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      tk[i] = idx_key[a + perm[i]];
+      ta[i] = idx_arc[a + perm[i]];
+    }
+    std::copy(tk.begin(), tk.end(), idx_key.begin() + a);
+    std::copy(ta.begin(), ta.end(), idx_arc.begin() + a);
+  }
+}
+
+namespace {
+
+// open-addressing map (i, s, o) -> lattice state id, reused across pairs by one thread
+struct StateMap {
+  struct Slot {
+    uint32_t i, s, o, id;
+  };
+  std::vector<Slot> slots;
+  std::vector<uint32_t> stamp;
+  uint32_t gen = 0;
+  size_t mask = 0, used = 0;
+  void reset(size_t want) {
+    size_t cap = 64;
+    while (cap < want * 2) cap <<= 1;
+    if (cap > slots.size()) {
+      slots.assign(cap, Slot());
+      stamp.assign(cap, 0);
+      gen = 0;
+    }
+    mask = slots.size() - 1;
+    used = 0;
+    if (++gen == 0) {
+      std::fill(stamp.begin(), stamp.end(), 0);
+      gen = 1;
+    }
+  }
+  static inline uint64_t hash(uint32_t i, uint32_t s, uint32_t o) {
+    uint64_t h = ((uint64_t)i << 40) ^ ((uint64_t)o << 20) ^ s;
+    h *= 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29;
+    h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 32;
+    return h;
+  }
+  void grow() {
+    std::vector<Slot> old;
+    std::vector<uint32_t> ost;
+    old.swap(slots);
+    ost.swap(stamp);
+    uint32_t og = gen;
+    slots.assign(old.size() * 2, Slot());
+    stamp.assign(old.size() * 2, 0);
+    mask = slots.size() - 1;
+    gen = 1;
+    used = 0;
+    for (size_t k = 0; k < old.size(); ++k)
+      if (ost[k] == og) {
+        bool ins;
+        find_or_insert(old[k].i, old[k].s, old[k].o, old[k].id, ins);
+      }
+  }
+  // returns id; inserted=true when (i,s,o) was new and got new_id
+  uint32_t find_or_insert(uint32_t i, uint32_t s, uint32_t o, uint32_t new_id, bool& inserted) {
+    if ((used + 1) * 2 > slots.size()) grow();
+    size_t p = (size_t)hash(i, s, o) & mask;
+    for (;;) {
+      if (stamp[p] != gen) {
+        stamp[p] = gen;
+        slots[p] = Slot{i, s, o, new_id};
+        ++used;
+        inserted = true;
+        return new_id;
+      }
+      const Slot& sl = slots[p];
+      if (sl.i == i && sl.s == s && sl.o == o) {
+        inserted = false;
+        return sl.id;
+      }
+      p = (p + 1) & mask;
+    }
+  }
+  bool find(uint32_t i, uint32_t s, uint32_t o, uint32_t& id) const {
+    size_t p = (size_t)hash(i, s, o) & mask;
+    for (;;) {
+      if (stamp[p] != gen) return false;
+      const Slot& sl = slots[p];
+      if (sl.i == i && sl.s == s && sl.o == o) {
+        id = sl.id;
+        return true;
+      }
+      p = (p + 1) & mask;
+    }
+  }
+};
+
+struct Frame {
+  uint32_t sid, i, s, o;
+  int phase;          // -1 not started, 0..3 label classes, 4 done
+  uint64_t pos, end;  // current slice of the arc index
+  uint32_t ni, no;    // child positions for the current phase
+  bool dead, pending;
+  uint32_t pend_dst, pend_arc;
+};
+
+struct Scratch {
+  StateMap map;
+  std::vector<Frame> stack;
+  std::vector<uint8_t> removed;
+  std::vector<PairLattice::E> edges;
+  std::vector<uint32_t> a, b, c, d;
+};
+
+inline void key_range(const HostWfst& w, uint32_t s, uint64_t key, uint64_t& lo, uint64_t& hi) {
+  uint64_t a = w.idx_off[s], b = w.idx_off[s + 1];
+  const uint64_t* k = w.idx_key.data();
+  if (b - a <= 8) {
+    while (a < b && k[a] < key) ++a;
+    uint64_t e = a;
+    while (e < b && k[e] == key) ++e;
+    lo = a;
+    hi = e;
+    return;
+  }
+  const uint64_t* p = std::lower_bound(k + a, k + b, key);
+  lo = (uint64_t)(p - k);
+  uint64_t e = lo;
+  while (e < b && k[e] == key) ++e;
+  hi = e;
+}
+
+}  // namespace
+
+// Exploration in the reference's order (derivations.h:640-704): depth first; from a node the four label classes
+// (e,e), (e,out[o]), (in[i],e), (in[i],out[o]) in that order; within a class the WFST arcs in arc-id order; an arc
+// is kept iff its destination is not (yet) known to be dead.  State ids come out in DFS pre-order like the
+// reference's, which is what lets a cyclic lattice be swept in the reference's order later.
+static void explore(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out, uint32_t n_out,
+                    Scratch& sc, uint32_t& n_states, bool& found_goal, uint32_t& goal_id, uint64_t& explored_arcs) {
+  const uint32_t EPS = 0;
+  sc.map.reset(256);
+  sc.stack.clear();
+  sc.removed.clear();
+  sc.edges.clear();
+  explored_arcs = 0;
+  n_states = 0;
+  const uint32_t gi = n_in, gs = w.final_state, go = n_out;
+  auto new_state = [&](uint32_t i, uint32_t s, uint32_t o) -> uint32_t {
+    bool ins;
+    uint32_t id = sc.map.find_or_insert(i, s, o, n_states, ins);
+    if (ins) {
+      ++n_states;
+      sc.removed.push_back(0);
+      Frame f;
+      f.sid = id;
+      f.i = i;
+      f.s = s;
+      f.o = o;
+      f.phase = -1;
+      f.pos = f.end = 0;
+      f.ni = f.no = 0;
+      f.dead = !(i == gi && s == gs && o == go);
+      f.pending = false;
+      f.pend_dst = f.pend_arc = 0;
+      sc.stack.push_back(f);
+      return id | 0x80000000u;  // high bit: newly created (a frame was pushed)
+    }
+    return id;
+  };
+  new_state(0, 0, 0);
+  while (!sc.stack.empty()) {
+    size_t fi = sc.stack.size() - 1;
+    {
+      Frame& F = sc.stack[fi];
+      if (F.pending) {  // the child pushed for F.pend_arc has finished
+        if (!sc.removed[F.pend_dst]) {
+          sc.edges.push_back(PairLattice::E{F.sid, F.pend_dst, F.pend_arc});
+          F.dead = false;
+        }
+        F.pending = false;
+        ++F.pos;
+      }
+    }
+    bool pushed = false;
+    for (;;) {
+      Frame& F = sc.stack[fi];
+      if (F.pos < F.end) {
+        uint32_t arc = w.idx_arc[F.pos];
+        ++explored_arcs;
+        uint32_t r = new_state(F.ni, w.dst[arc], F.no);  // may reallocate sc.stack
+        Frame& G = sc.stack[fi];
+        if (r & 0x80000000u) {
+          G.pending = true;
+          G.pend_dst = r & 0x7fffffffu;
+          G.pend_arc = arc;
+          pushed = true;
+          break;
+        }
+        if (!sc.removed[r]) {
+          sc.edges.push_back(PairLattice::E{G.sid, r, arc});
+          G.dead = false;
+        }
+        ++G.pos;
+        continue;
+      }
+      // next label class
+      ++F.phase;
+      if (F.phase > 3) {
+        sc.removed[F.sid] = F.dead;
+        sc.stack.pop_back();
+        break;
+      }
+      bool useO = F.o < n_out, useI = F.i < n_in;
+      uint32_t si = EPS, so = EPS;
+      bool ok = true;
+      F.ni = F.i;
+      F.no = F.o;
+      switch (F.phase) {
+        case 0:
+          break;
+        case 1:
+          ok = useO;
+          if (ok) {
+            so = out[F.o];
+            F.no = F.o + 1;
+          }
+          break;
+        case 2:
+          ok = useI;
+          if (ok) {
+            si = in[F.i];
+            F.ni = F.i + 1;
+          }
+          break;
+        case 3:
+          ok = useI && useO;
+          if (ok) {
+            si = in[F.i];
+            so = out[F.o];
+            F.ni = F.i + 1;
+            F.no = F.o + 1;
+          }
+          break;
+      }
+      if (ok)
+        key_range(w, F.s, ((uint64_t)si << 32) | so, F.pos, F.end);
+      else
+        F.pos = F.end = 0;
+    }
+    (void)pushed;
+  }
+  found_goal = sc.map.find(gi, gs, go, goal_id);
+}
+
+void build_pair_lattice_impl(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out,
+                             uint32_t n_out, bool /*prune*/, PairLattice& lat, bool& has_deriv, Scratch& sc) {
+  uint32_t nst = 0, goal = 0;
+  bool found = false;
+  uint64_t explored_arcs = 0;
+  explore(w, in, n_in, out, n_out, sc, nst, found, goal, explored_arcs);
+  lat = PairLattice();
+  lat.explored_states = nst;
+  lat.explored_arcs = explored_arcs;
+  has_deriv = found;
+  if (!found) return;
+  // co-reachability over kept edges (drops the junk cycles the reference's remove[] marking lets through; they
+  // carry zero backward mass there, so nothing observable changes)
+  std::vector<uint32_t>& indeg_off = sc.a;  // CSR of reversed edges
+  indeg_off.assign((size_t)nst + 1, 0);
+  for (auto& e : sc.edges) indeg_off[e.dst + 1]++;
+  for (uint32_t s = 0; s < nst; ++s) indeg_off[s + 1] += indeg_off[s];
+  std::vector<uint32_t>& rsrc = sc.b;
+  rsrc.resize(sc.edges.size());
+  {
+    std::vector<uint32_t>& cur = sc.c;
+    cur.assign(indeg_off.begin(), indeg_off.end() - 1);
+    for (auto& e : sc.edges) rsrc[cur[e.dst]++] = e.src;
+  }
+  std::vector<uint32_t>& keep_id = sc.d;  // old -> new or ~0
+  keep_id.assign(nst, 0xffffffffu);
+  {
+    std::vector<uint32_t>& st = sc.c;
+    st.clear();
+    st.push_back(goal);
+    keep_id[goal] = 0;
+    while (!st.empty()) {
+      uint32_t v = st.back();
+      st.pop_back();
+      for (uint32_t k = indeg_off[v]; k < indeg_off[v + 1]; ++k) {
+        uint32_t u = rsrc[k];
+        if (keep_id[u] == 0xffffffffu) {
+          keep_id[u] = 0;
+          st.push_back(u);
+        }
+      }
+    }
+  }
+  uint32_t kept = 0;
+  for (uint32_t s = 0; s < nst; ++s)
+    if (keep_id[s] != 0xffffffffu && !sc.removed[s]) keep_id[s] = kept++;
+    else keep_id[s] = 0xffffffffu;
+  lat.n_states = kept;
+  lat.start = keep_id[0];
+  lat.fin = keep_id[goal];
+  lat.edges.reserve(sc.edges.size());
+  for (auto& e : sc.edges)
+    if (keep_id[e.src] != 0xffffffffu && keep_id[e.dst] != 0xffffffffu)
+      lat.edges.push_back(PairLattice::E{keep_id[e.src], keep_id[e.dst], e.arc});
+  // levels: Kahn over the kept graph, level = longest path from the start
+  std::vector<uint32_t>& indeg = sc.a;
+  indeg.assign(kept, 0);
+  for (auto& e : lat.edges) indeg[e.dst]++;
+  std::vector<uint32_t>& ooff = sc.b;
+  ooff.assign((size_t)kept + 1, 0);
+  for (auto& e : lat.edges) ooff[e.src + 1]++;
+  for (uint32_t s = 0; s < kept; ++s) ooff[s + 1] += ooff[s];
+  std::vector<uint32_t> odst(lat.edges.size());
+  {
+    std::vector<uint32_t>& cur = sc.c;
+    cur.assign(ooff.begin(), ooff.end() - 1);
+    for (auto& e : lat.edges) odst[cur[e.src]++] = e.dst;  // insertion order per state preserved
+  }
+  lat.level.assign(kept, 0);
+  std::vector<uint32_t>& q = sc.c;
+  q.clear();
+  for (uint32_t s = 0; s < kept; ++s)
+    if (indeg[s] == 0) q.push_back(s);
+  size_t done = 0;
+  uint32_t maxlev = 0;
+  while (done < q.size()) {
+    uint32_t u = q[done++];
+    uint32_t lu = lat.level[u];
+    for (uint32_t k = ooff[u]; k < ooff[u + 1]; ++k) {
+      uint32_t v = odst[k];
+      if (lat.level[v] < lu + 1) lat.level[v] = lu + 1;
+      if (--indeg[v] == 0) q.push_back(v);
+    }
+    if (lu > maxlev) maxlev = lu;
+  }
+  if (done == kept) {
+    lat.n_levels = maxlev + 1;
+    return;
+  }
+  // cyclic: the reference sweeps in reversed DFS post-order from the start, walking each state's out-arc list
+  // newest-first (graph.h:91-94 push_front, :267-283 order_from) and skipping back edges.  level[] := position
+  // in that forward order, so the serial kernel can reproduce the reference's values exactly.
+  lat.cyclic = true;
+  std::vector<uint8_t> begun(kept, 0), fin(kept, 0);
+  std::vector<uint32_t> post;
+  post.reserve(kept);
+  std::vector<std::pair<uint32_t, uint32_t> > st;  // (state, next arc index counting from the end)
+  st.push_back({lat.start, 0});
+  begun[lat.start] = 1;
+  while (!st.empty()) {
+    uint32_t u = st.back().first;
+    uint32_t k = st.back().second;
+    uint32_t deg = ooff[u + 1] - ooff[u];
+    if (k < deg) {
+      st.back().second++;
+      uint32_t v = odst[ooff[u + 1] - 1 - k];  // newest first
+      if (!fin[v] && !begun[v]) {
+        begun[v] = 1;
+        st.push_back({v, 0});
+      }
+    } else {
+      fin[u] = 1;
+      post.push_back(u);
+      st.pop_back();
+    }
+  }
+  // every kept state is reachable from the start, so post covers all of them
+  for (uint32_t p = 0; p < post.size(); ++p) lat.level[post[p]] = (uint32_t)(post.size() - 1 - p);
+  lat.n_levels = kept;
+}
+
+void build_pair_lattice(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out, uint32_t n_out,
+                        bool prune, PairLattice& lat, bool& has_deriv) {
+  Scratch sc;
+  build_pair_lattice_impl(w, in, n_in, out, n_out, prune, lat, has_deriv, sc);
+}
+
+namespace {
+
+// Lay one bundle out: states level-major (within a level: pair order, then the pair's own state order), in-arcs
+// grouped by destination, out-arcs grouped by source.
+struct BundlePlan {
+  std::vector<uint32_t> pairs;  // indices into the kept-pair list
+  uint64_t n_states = 0, n_arcs = 0;
+  uint32_t n_levels = 0;
+  bool cyclic = false;
+};
+
+}  // namespace
+
+bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& opt, LatticeSet& out,
+                    std::string& err) {
+  if (w.idx_off.size() != (size_t)w.n_states + 1) {
+    err = "WFST index not built";
+    return false;
+  }
+  const uint64_t np = c.n_pairs;
+  std::vector<PairLattice> lats(np);
+  out = LatticeSet();
+  out.has_deriv.assign(np, 0);
+  int nt = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+  if (nt < 1) nt = 1;
+  if ((uint64_t)nt > np) nt = (int)std::max<uint64_t>(1, np);
+  {
+    std::atomic<uint64_t> next(0);
+    auto work = [&]() {
+      Scratch sc;
+      for (;;) {
+        uint64_t p0 = next.fetch_add(256);
+        if (p0 >= np) break;
+        uint64_t p1 = std::min(np, p0 + 256);
+        for (uint64_t p = p0; p < p1; ++p) {
+          bool hd = false;
+          build_pair_lattice_impl(w, c.in_sym.data() + c.in_off[p], (uint32_t)(c.in_off[p + 1] - c.in_off[p]),
+                                  c.out_sym.data() + c.out_off[p], (uint32_t)(c.out_off[p + 1] - c.out_off[p]),
+                                  opt.prune, lats[p], hd, sc);
+          out.has_deriv[p] = hd;
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  std::vector<uint32_t> kept;
+  for (uint64_t p = 0; p < np; ++p) {
+    out.explored_states += lats[p].explored_states;
+    out.explored_arcs += lats[p].explored_arcs;
+    if (out.has_deriv[p]) kept.push_back((uint32_t)p);
+  }
+  out.n_kept = kept.size();
+  // ---- pack into bundles ----
+  // small lattices: sort by (levels, states) so that a bundle's members have similar depth (level-synchronous
+  // sweeps idle the lanes of members that ran out of levels)
+  std::vector<uint32_t> small, big, cyc;
+  for (uint32_t p : kept) {
+    const PairLattice& L = lats[p];
+    if (L.cyclic)
+      cyc.push_back(p);
+    else if (L.n_states * 4 <= opt.small_states)
+      small.push_back(p);
+    else
+      big.push_back(p);
+  }
+  std::stable_sort(small.begin(), small.end(), [&](uint32_t a, uint32_t b) {
+    if (lats[a].n_levels != lats[b].n_levels) return lats[a].n_levels > lats[b].n_levels;
+    return lats[a].n_states > lats[b].n_states;
+  });
+  std::stable_sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return lats[a].n_states < lats[b].n_states; });
+  std::vector<BundlePlan> plans;
+  {
+    BundlePlan cur;
+    for (uint32_t p : small) {
+      const PairLattice& L = lats[p];
+      if (!cur.pairs.empty() && (cur.pairs.size() >= opt.small_pairs || cur.n_states + L.n_states > opt.small_states)) {
+        plans.push_back(cur);
+        cur = BundlePlan();
+      }
+      cur.pairs.push_back(p);
+      cur.n_states += L.n_states;
+      cur.n_arcs += L.edges.size();
+      cur.n_levels = std::max(cur.n_levels, L.n_levels);
+    }
+    if (!cur.pairs.empty()) plans.push_back(cur);
+  }
+  size_t n_small = plans.size();
+  for (uint32_t p : big) {
+    BundlePlan b;
+    b.pairs.push_back(p);
+    b.n_states = lats[p].n_states;
+    b.n_arcs = lats[p].edges.size();
+    b.n_levels = lats[p].n_levels;
+    plans.push_back(b);
+  }
+  size_t n_acyclic = plans.size();
+  for (uint32_t p : cyc) {
+    BundlePlan b;
+    b.pairs.push_back(p);
+    b.n_states = lats[p].n_states;
+    b.n_arcs = lats[p].edges.size();
+    b.n_levels = lats[p].n_levels;
+    b.cyclic = true;
+    plans.push_back(b);
+  }
+  out.n_cyclic = cyc.size();
+  // launch classes
+  auto add_class = [&](size_t first, size_t count, uint32_t block, uint32_t max_states, bool serial) {
+    if (!count) return;
+    LatticeSet::LaunchClass lc;
+    lc.first = (uint32_t)first;
+    lc.count = (uint32_t)count;
+    lc.block = block;
+    lc.max_states = max_states;
+    lc.serial = serial;
+    out.classes.push_back(lc);
+  };
+  if (n_small) {
+    uint64_t mx = 0;
+    for (size_t b = 0; b < n_small; ++b) mx = std::max(mx, plans[b].n_states);
+    add_class(0, n_small, 64, (uint32_t)mx, false);
+  }
+  {
+    // big lattices ascending by states: classes at 8K-state (64 KiB) and lds_states_max boundaries, then global
+    size_t i = n_small;
+    const uint32_t caps[2] = {8192, opt.lds_states_max};
+    for (int k = 0; k < 2 && i < n_acyclic; ++k) {
+      size_t j = i;
+      uint64_t mx = 0;
+      while (j < n_acyclic && plans[j].n_states <= caps[k]) {
+        mx = std::max(mx, plans[j].n_states);
+        ++j;
+      }
+      add_class(i, j - i, k == 0 ? 256 : 1024, (uint32_t)mx, false);
+      i = j;
+    }
+    if (i < n_acyclic) add_class(i, n_acyclic - i, 1024, 0, false);
+  }
+  add_class(n_acyclic, plans.size() - n_acyclic, 64, 0, true);
+  // offsets
+  size_t nb = plans.size();
+  out.bundles.resize(nb);
+  uint64_t arc_base = 0, off_base = 0, lev_base = 0, pair_base = 0;
+  for (size_t b = 0; b < nb; ++b) {
+    BundleDesc& d = out.bundles[b];
+    std::memset(&d, 0, sizeof d);
+    d.in_base = d.out_base = arc_base;
+    d.off_base = off_base;
+    d.n_states = (uint32_t)plans[b].n_states;
+    d.n_levels = plans[b].n_levels;
+    d.level_base = (uint32_t)lev_base;
+    d.pair_base = (uint32_t)pair_base;
+    d.n_pairs = (uint32_t)plans[b].pairs.size();
+    d.flags = plans[b].cyclic ? 1u : 0u;
+    d.n_arcs = plans[b].n_arcs;
+    arc_base += plans[b].n_arcs;
+    off_base += plans[b].n_states + 1;
+    lev_base += (uint64_t)plans[b].n_levels + 1;
+    pair_base += plans[b].pairs.size();
+    out.max_levels = std::max<uint64_t>(out.max_levels, plans[b].n_levels);
+    if (lev_base > 0xffffffffull || pair_base > 0xffffffffull) {
+      err = "lattice set too large for 32-bit level/pair tables";
+      return false;
+    }
+  }
+  out.total_arcs = arc_base;
+  out.total_states = off_base - nb;
+  out.in_arcs.resize(arc_base);
+  out.out_arcs.resize(arc_base);
+  out.in_off.resize(off_base);
+  out.out_off.resize(off_base);
+  out.level_off.resize(lev_base);
+  out.pair_start.resize(pair_base);
+  out.pair_final.resize(pair_base);
+  out.pair_id.resize(pair_base);
+  out.pair_logw.resize(pair_base);
+  {
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+      std::vector<uint32_t> lvl_cnt, newid, cur;
+      std::vector<std::vector<uint32_t> > maps;
+      for (;;) {
+        size_t b = next.fetch_add(8);
+        if (b >= nb) break;
+        size_t be = std::min(nb, b + 8);
+        for (; b < be; ++b) {
+          const BundlePlan& P = plans[b];
+          const BundleDesc& d = out.bundles[b];
+          uint32_t nl = d.n_levels;
+          // count states per level across members
+          lvl_cnt.assign((size_t)nl + 1, 0);
+          for (uint32_t p : P.pairs) {
+            const PairLattice& L = lats[p];
+            for (uint32_t s = 0; s < L.n_states; ++s) lvl_cnt[L.level[s] + 1]++;
+          }
+          for (uint32_t l = 0; l < nl; ++l) lvl_cnt[l + 1] += lvl_cnt[l];
+          uint32_t* lo = out.level_off.data() + d.level_base;
+          for (uint32_t l = 0; l <= nl; ++l) lo[l] = lvl_cnt[l];
+          cur.assign(lvl_cnt.begin(), lvl_cnt.end() - 1);
+          maps.resize(P.pairs.size());
+          for (size_t m = 0; m < P.pairs.size(); ++m) {
+            const PairLattice& L = lats[P.pairs[m]];
+            maps[m].resize(L.n_states);
+            for (uint32_t s = 0; s < L.n_states; ++s) maps[m][s] = cur[L.level[s]]++;
+            out.pair_start[d.pair_base + m] = maps[m][L.start];
+            out.pair_final[d.pair_base + m] = maps[m][L.fin];
+            out.pair_id[d.pair_base + m] = P.pairs[m];
+            double wt = c.weight.empty() ? 1.0 : c.weight[P.pairs[m]];
+            out.pair_logw[d.pair_base + m] = wt > 0 ? std::log(wt) : -std::numeric_limits<double>::infinity();
+          }
+          uint32_t* ioff = out.in_off.data() + d.off_base;
+          uint32_t* ooff = out.out_off.data() + d.off_base;
+          std::fill(ioff, ioff + d.n_states + 1, 0u);
+          std::fill(ooff, ooff + d.n_states + 1, 0u);
+          for (size_t m = 0; m < P.pairs.size(); ++m) {
+            const PairLattice& L = lats[P.pairs[m]];
+            for (auto& e : L.edges) {
+              ioff[maps[m][e.dst] + 1]++;
+              ooff[maps[m][e.src] + 1]++;
+            }
+          }
+          for (uint32_t s = 0; s < d.n_states; ++s) {
+            ioff[s + 1] += ioff[s];
+            ooff[s + 1] += ooff[s];
+          }
+          uint2_t* ia = out.in_arcs.data() + d.in_base;
+          uint2_t* oa = out.out_arcs.data() + d.out_base;
+          std::vector<uint32_t>& ci = newid;
+          ci.assign(ioff, ioff + d.n_states);
+          std::vector<uint32_t> co(ooff, ooff + d.n_states);
+          if (!P.cyclic) {
+            for (size_t m = 0; m < P.pairs.size(); ++m) {
+              const PairLattice& L = lats[P.pairs[m]];
+              for (auto& e : L.edges) {
+                uint32_t s = maps[m][e.src], t = maps[m][e.dst];
+                ia[ci[t]++] = uint2_t{s, e.arc};
+                oa[co[s]++] = uint2_t{t, e.arc};
+              }
+            }
+          } else {
+            // reference list orders (one member): out-list of a state = newest insertion first; the reversed
+            // graph's list of v = reverse of (old state id ascending, list order) — derivations.h:546-550,
+            // graph.cc:41-57.  Old state ids are the PairLattice ids (DFS pre-order, stably compacted).
+            const PairLattice& L = lats[P.pairs[0]];
+            const auto& mp = maps[0];
+            std::vector<uint32_t> eo((size_t)L.n_states + 1, 0);
+            for (auto& e : L.edges) eo[e.src + 1]++;
+            for (uint32_t s = 0; s < L.n_states; ++s) eo[s + 1] += eo[s];
+            std::vector<uint32_t> byl(L.edges.size());
+            {
+              std::vector<uint32_t> cc(eo.begin(), eo.end() - 1);
+              for (uint32_t k = 0; k < L.edges.size(); ++k) byl[cc[L.edges[k].src]++] = k;
+            }
+            // list order per old state: reverse insertion
+            std::vector<uint32_t> listorder;
+            listorder.reserve(L.edges.size());
+            for (uint32_t s = 0; s < L.n_states; ++s)
+              for (uint32_t k = eo[s + 1]; k-- > eo[s];) listorder.push_back(byl[k]);
+            for (uint32_t k : listorder) {
+              const auto& e = L.edges[k];
+              oa[co[mp[e.src]]++] = uint2_t{mp[e.dst], e.arc};
+            }
+            // reversed lists: walking listorder pushes to the FRONT of r[dst]; final list = reverse of that walk
+            for (size_t q = listorder.size(); q-- > 0;) {
+              const auto& e = L.edges[listorder[q]];
+              ia[ci[mp[e.dst]]++] = uint2_t{mp[e.src], e.arc};
+            }
+          }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    int nt2 = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, nb / 8));
+    for (int t = 1; t < nt2; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  return true;
+}
+
+}  // namespace carmel_hip

@@ -1,0 +1,105 @@
+// lattice.hpp — host-side construction of per-pair derivation lattices and their batched-CSR layout for HBM.
+//
+// What it computes is what the reference's derivations::compute + prune compute
+// (/root/reference/carmel/src/derivations.h:479-513, 640-704, 572-629): the product graph of
+// (input position, WFST state, output position) restricted to states that lie on a start->goal path, each
+// lattice arc carrying the id of the WFST arc it uses.  How it computes it is different by design: no
+// recursion, no per-node malloc — an explicit-stack forward exploration over a flat (state,in,out)-sorted arc
+// index, a reverse sweep for co-reachability, a Kahn pass that assigns every state its longest-path LEVEL,
+// and then packing of many lattices into workgroup-sized BUNDLES whose states are stored level-major so the
+// GPU sweeps are level-synchronous gathers with no atomics on the forward/backward values.
+#pragma once
+#include <cstdint>
+#include <vector>
+#include <string>
+
+namespace carmel_hip {
+
+struct HostWfst {
+  uint32_t n_states = 0, final_state = 0;
+  uint64_t n_arcs = 0;
+  std::vector<uint32_t> src, dst, in, out, group;
+  // (src, in, out)-sorted index: idx_off[s]..idx_off[s+1] are positions into idx_key/idx_arc
+  std::vector<uint64_t> idx_off;
+  std::vector<uint64_t> idx_key;  // (in << 32) | out, ascending within a state
+  std::vector<uint32_t> idx_arc;  // arc id; ties keep arc-id order
+  void build_index();
+};
+
+struct HostCorpus {
+  uint64_t n_pairs = 0;
+  std::vector<uint64_t> in_off, out_off;
+  std::vector<uint32_t> in_sym, out_sym;
+  std::vector<double> weight;
+};
+
+// One pair's pruned lattice, states numbered arbitrarily, with levels.
+struct PairLattice {
+  uint32_t n_states = 0, n_levels = 0;
+  uint32_t start = 0, fin = 0;
+  bool cyclic = false;
+  std::vector<uint32_t> level;  // per state (acyclic) — for cyclic lattices: position in the reference's sweep order
+  struct E {
+    uint32_t src, dst, arc;
+  };
+  std::vector<E> edges;
+  uint64_t explored_states = 0, explored_arcs = 0;
+};
+
+// A bundle = lattices swept together by one workgroup.  All indices below are bundle-local.
+struct BundleDesc {      // mirrored on the device (keep POD, 64 bytes)
+  uint64_t in_base;      // into in_arcs[]   ({src_state, arc_id} sorted by dst state, level-major)
+  uint64_t out_base;     // into out_arcs[]  ({dst_state, arc_id} sorted by src state)
+  uint64_t off_base;     // into in_off[] / out_off[] (n_states + 1 entries per bundle) and into alpha scratch
+  uint32_t n_states;
+  uint32_t n_levels;
+  uint32_t level_base;   // into level_off[] (n_levels + 1 entries per bundle)
+  uint32_t pair_base;    // into pair_start[] / pair_final[] / pair_id[] / pair_logw[]
+  uint32_t n_pairs;
+  uint32_t flags;        // bit0: cyclic -> serial in-order sweep (reference order)
+  uint64_t n_arcs;
+  uint64_t pad;
+};
+static_assert(sizeof(BundleDesc) == 64, "BundleDesc layout");
+
+struct uint2_t {
+  uint32_t x, y;
+};
+
+struct LatticeSet {
+  std::vector<BundleDesc> bundles;
+  std::vector<uint2_t> in_arcs, out_arcs;
+  std::vector<uint32_t> in_off, out_off;  // bundle-relative arc offsets
+  std::vector<uint32_t> level_off;
+  std::vector<uint32_t> pair_start, pair_final, pair_id;
+  std::vector<double> pair_logw;  // ln(pair weight)
+  // launch classes: bundle index ranges sorted by LDS need
+  struct LaunchClass {
+    uint32_t first, count;   // bundles[first .. first+count)
+    uint32_t block;          // threads per workgroup
+    uint32_t max_states;     // LDS doubles needed (0 => values live in global scratch)
+    bool serial;             // cyclic bundles
+  };
+  std::vector<LaunchClass> classes;
+  uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
+  uint64_t explored_states = 0, explored_arcs = 0;
+  std::vector<uint8_t> has_deriv;
+  uint64_t n_kept = 0;
+};
+
+struct BuildOptions {
+  bool prune = true;
+  int threads = 0;
+  uint32_t small_pairs = 64;       // lattices per small bundle (one wavefront wide)
+  uint32_t small_states = 2048;    // state cap of a small bundle (16 KiB of f64 in LDS)
+  uint32_t lds_states_max = 16384; // one array of f64 in LDS: 128 KiB
+};
+
+// Builds every pair's lattice (parallel over pairs) and packs them.  Returns false + err on failure.
+bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& opt, LatticeSet& out, std::string& err);
+
+// single pair (exposed for tests)
+void build_pair_lattice(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out, uint32_t n_out,
+                        bool prune, PairLattice& lat, bool& has_deriv);
+
+}  // namespace carmel_hip

@@ -1,0 +1,81 @@
+"""Synthetic transducers and corpora for the benchmark configurations (fixed seeds).
+
+The generator is this build's own code.  Like the reference's WFST::generate (carmel/src/fst.cc:24-79) every pair
+is read off an actual start->final path, so every pair has at least one derivation.
+"""
+import numpy as np
+
+from .model import Corpus, Wfst
+
+FIRST_SYM = 2  # 0 = *e*, 1 = *w* (carmel/src/fst.h:58-59,409)
+
+
+def random_wfst(n_states, out_degree, n_sym=64, p_eps=0.1, seed=1):
+    """n_states states, every non-final state has `out_degree` arcs: arc 0 goes to the single final state
+    (n_states-1, no out-arcs), the rest to uniform non-final states.  Labels: *e* with probability p_eps per
+    side, else uniform over n_sym-1 symbols.  Weights Dirichlet(1) per (state, input) group, i.e. a proper
+    conditional model."""
+    rng = np.random.default_rng(seed)
+    F = n_states - 1
+    ns = n_states - 1  # states with arcs
+    src = np.repeat(np.arange(ns, dtype=np.uint32), out_degree)
+    dst = rng.integers(0, F, size=(ns, out_degree), dtype=np.uint32)
+    dst[:, 0] = F
+    dst = dst.reshape(-1)
+
+    def labels():
+        lab = rng.integers(FIRST_SYM, FIRST_SYM + n_sym - 1, size=ns * out_degree, dtype=np.uint32)
+        lab[rng.random(ns * out_degree) < p_eps] = 0
+        return lab
+
+    isym, osym = labels(), labels()
+    g = rng.exponential(size=ns * out_degree)
+    key = src.astype(np.uint64) * np.uint64(1 << 20) + isym.astype(np.uint64)
+    _, inv = np.unique(key, return_inverse=True)
+    sums = np.bincount(inv, weights=g)
+    logw = np.log(g / sums[inv])
+    return Wfst(n_states, F, src, dst, isym, osym, logw)
+
+
+def random_walk_corpus(w, n_pairs, min_arcs=5, max_arcs=40, seed=1, out_degree=None):
+    """pairs read off uniform random walks start->final of min_arcs..max_arcs arcs (last arc = arc 0 of the
+    current state, which enters the final state)"""
+    rng = np.random.default_rng(seed + 1000003)
+    if out_degree is None:
+        out_degree = int(np.searchsorted(w.src, 1))  # arcs of state 0
+    L = rng.integers(min_arcs, max_arcs + 1, size=n_pairs)
+    cur = np.zeros(n_pairs, dtype=np.int64)
+    maxL = int(L.max())
+    ins = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    outs = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    for step in range(maxL):
+        active = step < L
+        last = step == L - 1
+        pick = rng.integers(1, out_degree, size=n_pairs)
+        pick[last] = 0
+        arc = cur * out_degree + pick
+        arc[~active] = 0
+        ins[:, step] = np.where(active, w.isym[arc], 0)
+        outs[:, step] = np.where(active, w.osym[arc], 0)
+        cur = np.where(active, w.dst[arc].astype(np.int64), cur)
+    mi, mo = ins != 0, outs != 0
+    in_off = np.concatenate([[0], np.cumsum(mi.sum(1))]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(mo.sum(1))]).astype(np.uint64)
+    return Corpus(in_off, ins[mi], out_off, outs[mo])
+
+
+CONFIGS = {
+    # name: (n_states, out_degree, n_pairs, seed)
+    "toy": (200, 6, 300, 7),
+    "c2": (100000, 20, 50000, 1),    # BASELINE.json configs[1]: 100k states / 2M arcs, 50k pairs
+    "c4": (1000000, 10, 1000000, 3),  # configs[3]: 1M states / 10M arcs, 1M pairs
+}
+
+
+def make_config(name, n_pairs=None):
+    n_states, deg, npairs, seed = CONFIGS[name]
+    if n_pairs is not None:
+        npairs = n_pairs
+    w = random_wfst(n_states, deg, seed=seed)
+    c = random_walk_corpus(w, npairs, seed=seed, out_degree=deg)
+    return w, c

@@ -1,0 +1,213 @@
+"""Python mirror of the reference's training interface for this path, over the C-ABI.
+
+  HipForwardBackward  ~ forward_backward (carmel/src/train.cc:224-460): estimate() / maximize()
+  train()             ~ WFST::train      (carmel/src/train.cc:503-678): iteration control + convergence
+
+It exists so the parity tests read like the reference's own usage and so bench.py / torch.distributed can drive
+one trainer per GPU; the arithmetic all happens in libcarmel_hip.so on the GPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _capi
+from ._capi import EstimateResult, LatticeStats, check, lib, ptr
+from .model import NORM_CONDITIONAL
+
+
+class TrainOpts(object):
+    """WFST::train_opts (carmel/src/fst.h:1080-1095) + the -e / -X defaults of carmel.cc:896-897"""
+
+    def __init__(self, max_iter=500, converge_arc_delta=1e-4, converge_ppx_ratio=.999,
+                 learning_rate_growth_factor=1.0):
+        self.max_iter = max_iter
+        self.converge_arc_delta = converge_arc_delta
+        self.converge_ppx_ratio = converge_ppx_ratio
+        self.learning_rate_growth_factor = learning_rate_growth_factor
+
+
+class HipForwardBackward(object):
+    def __init__(self, wfst, corpus, norm_group=NORM_CONDITIONAL, add_count=0.0, smooth_floor=0.0,
+                 weight_is_prior_count=False, device=0, prune=True, host_threads=0, cascade=None,
+                 normalize_first=True):
+        self.wfst, self.corpus = wfst, corpus
+        h = C.c_void_p()
+        check(lib.carmel_hip_create(C.byref(h), device, wfst.n_states, wfst.final, wfst.n_arcs, ptr(wfst.src),
+                                    ptr(wfst.dst), ptr(wfst.isym), ptr(wfst.osym), ptr(wfst.logw), ptr(wfst.group)),
+              "carmel_hip_create")
+        self.h = h
+        self.cascade = cascade
+        if cascade is not None:
+            c = cascade
+            check(lib.carmel_hip_set_cascade(
+                h, len(c["param_logw"]), ptr(c["param_logw"]), ptr(c["param_group"]), ptr(c["param_member"]),
+                ptr(c["param_src"]), ptr(c["param_in"]), len(c["member_norm"]), ptr(c["member_norm"]),
+                ptr(c["member_add_count"]), len(c["chain_off"]) - 1, ptr(c["chain_off"]), ptr(c["chain_param"])),
+                "carmel_hip_set_cascade")
+            self.n_params = len(c["param_logw"])
+        else:
+            check(lib.carmel_hip_set_norm(h, norm_group, add_count), "carmel_hip_set_norm")
+            self.n_params = wfst.n_arcs
+        if normalize_first:  # WFST::train: cascade.normalize(methods) before anything else (train.cc:509)
+            check(lib.carmel_hip_normalize(h), "carmel_hip_normalize")
+        if cascade is None or smooth_floor:
+            check(lib.carmel_hip_set_prior(h, smooth_floor, 1 if weight_is_prior_count else 0), "carmel_hip_set_prior")
+        check(lib.carmel_hip_set_corpus(h, corpus.n_pairs, ptr(corpus.in_off), ptr(corpus.in_sym),
+                                        ptr(corpus.out_off), ptr(corpus.out_sym), ptr(corpus.weight)),
+              "carmel_hip_set_corpus")
+        self.has_deriv = np.zeros(corpus.n_pairs, dtype=np.uint8)
+        self.lattice_stats = LatticeStats()
+        check(lib.carmel_hip_build_lattices(h, 1 if prune else 0, host_threads, ptr(self.has_deriv),
+                                            C.byref(self.lattice_stats)), "carmel_hip_build_lattices")
+        self.stats = corpus.stats(self.has_deriv.astype(bool))  # cached_derivs.h:87-98 recount
+        self.last = None
+
+    def close(self):
+        if self.h:
+            lib.carmel_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- E-step --------------------------------------------------------------------------------------
+    def estimate(self, per_pair=False):
+        """returns (ln unweighted corpus prob, ln weighted corpus prob); counts stay on the GPU"""
+        res = EstimateResult()
+        pp = np.empty(self.corpus.n_pairs) if per_pair else None
+        check(lib.carmel_hip_estimate(self.h, C.byref(res), ptr(pp)), "carmel_hip_estimate")
+        self.last = res
+        self.pair_logprob = pp
+        return res.sum_logprob, res.sum_weighted_logprob
+
+    def estimate_async(self):
+        check(lib.carmel_hip_estimate_async(self.h), "carmel_hip_estimate_async")
+
+    def synchronize(self):
+        check(lib.carmel_hip_synchronize(self.h), "carmel_hip_synchronize")
+
+    def last_kernel_ms(self):
+        ms = C.c_double(0)
+        check(lib.carmel_hip_last_sweep_ms(self.h, C.byref(ms)), "carmel_hip_last_sweep_ms")
+        return ms.value
+
+    def read_scalars(self):
+        res = EstimateResult()
+        check(lib.carmel_hip_read_scalars(self.h, C.byref(res)), "carmel_hip_read_scalars")
+        return res.sum_logprob, res.sum_weighted_logprob, res.n_pairs
+
+    def use_external_counts(self, dev_ptr):
+        check(lib.carmel_hip_use_external_counts(self.h, C.c_void_p(dev_ptr)), "carmel_hip_use_external_counts")
+
+    def counts(self):
+        out = np.empty(self.wfst.n_arcs)
+        check(lib.carmel_hip_get_counts(self.h, ptr(out)), "carmel_hip_get_counts")
+        return out
+
+    # -- M-step --------------------------------------------------------------------------------------
+    def maximize(self, delta_scale=1.0):
+        mc = C.c_double(0)
+        check(lib.carmel_hip_maximize(self.h, delta_scale, C.byref(mc)), "carmel_hip_maximize")
+        return mc.value
+
+    def weights(self):
+        out = np.empty(self.n_params)
+        check(lib.carmel_hip_get_weights(self.h, ptr(out)), "carmel_hip_get_weights")
+        return out
+
+    def arc_weights(self):
+        out = np.empty(self.wfst.n_arcs)
+        check(lib.carmel_hip_get_arc_weights(self.h, ptr(out)), "carmel_hip_get_arc_weights")
+        return out
+
+    def set_weights(self, logw):
+        logw = np.ascontiguousarray(logw, dtype=np.float64)
+        assert len(logw) == self.n_params
+        check(lib.carmel_hip_set_weights(self.h, ptr(logw)), "carmel_hip_set_weights")
+
+    def save_counts(self):
+        check(lib.carmel_hip_save_counts(self.h), "carmel_hip_save_counts")
+
+    def save_best(self):
+        check(lib.carmel_hip_save_best(self.h), "carmel_hip_save_best")
+
+    def load_best(self):
+        check(lib.carmel_hip_load_best(self.h), "carmel_hip_load_best")
+
+
+def _rel_ppx_ratio_ln(new_ppx_ln, old_ppx_ln):
+    # logweight::relative_perplexity_ratio (graehl/shared/weight.h:247-249): (new/old).root(|ln new|)
+    if new_ppx_ln == 0:
+        return float("nan")
+    return (new_ppx_ln - old_ppx_ln) / abs(new_ppx_ln)
+
+
+def train(fb, opts=None, log=None):
+    """WFST::train's loop (carmel/src/train.cc:552-667) for one start (no random restarts).
+
+    Returns (best per-example perplexity ln, trace); trace rows are dicts with the fields of one reference log
+    line (train.cc:587-613).  On return the trainer holds the weights that produced the best estimate
+    (train.cc:592-600, 673-674)."""
+    opts = opts or TrainOpts()
+    using_cascade = fb.cascade is not None
+    st = fb.stats
+    W = st["total_weight"]
+    n_sym = max(st["n_input"], st["n_output"])
+    best = float("inf")
+    have_good = False
+    last_change = 10.0
+    last_ppx = float("inf")
+    learning_rate = 1.0
+    growth = 1.0 if using_cascade else opts.learning_rate_growth_factor
+    trace = []
+    it = 0
+    last_was_reset = False
+    while True:
+        first_time = it == 0
+        it += 1
+        cascade_counts = using_cascade and not first_time
+        if cascade_counts:
+            fb.save_counts()
+        if opts.max_iter is not None and it > opts.max_iter and have_good:
+            break
+        lp, wlp = fb.estimate()
+        new_ppx = -wlp / W  # ln of p.ppxper(totalEmpiricalWeight)  (weight.h:311)
+        rec = dict(iter=it, log2_prob=lp / math.log(2), log2_ppx_symbol=(-lp / n_sym) / math.log(2) if n_sym else 0.0,
+                   log2_ppx_example=(-lp / st["n_pairs"]) / math.log(2), n_symbol=n_sym, n_example=st["n_pairs"],
+                   new_best=False, rel_ppx_ratio_ln=float("nan"), last_change=last_change)
+        if new_ppx < best and (not using_cascade or cascade_counts):
+            rec["new_best"] = True
+            best = new_ppx
+            have_good = True
+            fb.save_best()
+        if first_time:
+            ratio_ln = -float("inf")
+        else:
+            ratio_ln = _rel_ppx_ratio_ln(new_ppx, last_ppx)
+            rec["rel_ppx_ratio_ln"] = ratio_ln
+        trace.append(rec)
+        if log:
+            log(rec)
+        if not last_was_reset:
+            if ratio_ln >= math.log(opts.converge_ppx_ratio):
+                if learning_rate > 1:
+                    learning_rate = 1.0
+                    last_was_reset = True
+                    # keep_em_weight is handled inside the library's overrelax bookkeeping: not mirrored here
+                    raise NotImplementedError("over-relaxed EM restart path (carmel -o) is not mirrored in Python")
+                if have_good:
+                    break
+            elif learning_rate < 20:
+                learning_rate *= growth
+        else:
+            last_was_reset = False
+        last_change = fb.maximize(learning_rate)
+        if last_change <= opts.converge_arc_delta and have_good:
+            break
+        last_ppx = new_ppx
+    fb.load_best()
+    return best, trace

@@ -1,0 +1,175 @@
+/* carmel_hip.h — C-ABI of the MI355X-native EM / Gibbs hot path for carmel.
+ *
+ * The reference (graehl/carmel) has no FFI: its seams for this path are C++ member functions
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces; INTEGRATION.md shows
+ * the few lines a carmel maintainer adds in train.cc / gibbs.cc to call them.
+ *
+ * Conventions: plain pointers and sizes only; every array is caller-owned host memory unless the name says
+ * `_dev`; all functions return 0 on success or a negative code, with text in carmel_hip_last_error() (no
+ * exceptions cross this boundary — the reference throws std::runtime_error, carmel.cc:1558-1561); one handle
+ * per GPU; a handle is not thread-safe (like the reference, cascade.h:16).
+ *
+ * Arc numbering is the reference's: arc id = position in `for s in states: for a in states[s].arcs`
+ * (derivations.h:86-101, fst.h:1331-1334); all per-arc arrays are in that order.  Weights are natural logs
+ * (logweight<double>, weight.h:132-135; zero = -inf).  Expected counts cross the boundary in the LINEAR
+ * domain (f64): the reference accumulates them with log-add (derivations.h:445), here they are plain sums so
+ * that corpus shards can be combined with one all-reduce.
+ */
+#ifndef CARMEL_HIP_H
+#define CARMEL_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CARMEL_HIP_OK 0
+#define CARMEL_HIP_ERR_ARG -1
+#define CARMEL_HIP_ERR_HIP -2      /* a HIP runtime call failed / no device */
+#define CARMEL_HIP_ERR_STATE -3    /* call order violated (e.g. estimate before build_lattices) */
+#define CARMEL_HIP_ERR_NO_DERIV -4 /* no training example had a derivation (train.cc:241-252) */
+#define CARMEL_HIP_ERR_UNSUPPORTED -5
+
+#define CARMEL_HIP_NO_GROUP 0xFFFFFFFFu /* FSTArc::no_group  (arc.h:49) */
+#define CARMEL_HIP_LOCKED_GROUP 0u      /* FSTArc::locked_group (arc.h:50) */
+
+/* WFST::norm_group_by (fst.h) */
+#define CARMEL_HIP_NORM_CONDITIONAL 0
+#define CARMEL_HIP_NORM_JOINT 1
+#define CARMEL_HIP_NORM_NONE 2
+
+typedef struct carmel_hip_trainer carmel_hip_trainer;
+
+const char* carmel_hip_last_error(void);
+int carmel_hip_device_count(void);
+
+/* Replaces: arcs_table<arc_counts>(WFST&, per_arc_prior, global_prior)  derivations.h:79-101, train.h:28-40,
+ * i.e. the forward_backward constructor's view of the (composed) transducer, train.cc:367-411.
+ * `group` may be NULL (all arcs normal).  For a real cascade `group[k]` is the chain id of composed arc k
+ * (cascade.h:18-21) and carmel_hip_set_cascade must follow. */
+int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, uint32_t final_state, uint64_t n_arcs,
+                      const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
+                      const double* logw, const uint32_t* group);
+int carmel_hip_destroy(carmel_hip_trainer* t);
+
+/* Replaces: training_corpus + IOSymSeq (train.h:80-189) as filled by WFST::read_training_corpus
+ * (train.cc:985-1025).  Pair p's input symbols are in_sym[in_off[p] .. in_off[p+1]).  pair_weight NULL = 1. */
+int carmel_hip_set_corpus(carmel_hip_trainer* t, uint64_t n_pairs, const uint64_t* in_off, const uint32_t* in_sym,
+                          const uint64_t* out_off, const uint32_t* out_sym, const double* pair_weight);
+
+typedef struct carmel_hip_lattice_stats {
+  uint64_t n_pairs;          /* pairs given */
+  uint64_t n_pairs_kept;     /* pairs with >= 1 derivation (cached_derivs.h:87-98) */
+  uint64_t explored_states;  /* derivations::statistics pre  (derivations.h:191-247) */
+  uint64_t explored_arcs;
+  uint64_t kept_states;      /* ... post: states/arcs on some start->goal path */
+  uint64_t kept_arcs;
+  uint64_t n_cyclic_pairs;   /* lattices with a cycle (derivations.h:726-728 warns); swept in the reference's order */
+  uint64_t n_bundles;        /* workgroup-sized batches of lattices laid out in HBM */
+  uint64_t max_levels;
+  uint64_t device_bytes;     /* HBM held by lattices */
+  double build_seconds;
+} carmel_hip_lattice_stats;
+
+/* Replaces: cached_derivs::cache_derivations (cached_derivs.h:104-138) -> derivations::init_and_compute
+ * (derivations.h:471-513, 640-704) + prune (:572-629): builds every pair's derivation lattice once, drops
+ * pairs without a derivation, and lays the lattices out in HBM as batched CSR.  has_derivation[n_pairs] and
+ * stats may be NULL.  host_threads <= 0: all cores. */
+int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads, uint8_t* has_derivation,
+                              carmel_hip_lattice_stats* stats);
+
+/* Replaces: WFST::NormalizeMethod for a single (non-cascade) transducer — carmel -n/-j/-u and --priors
+ * (carmel.cc:488-499); used by carmel_hip_maximize / carmel_hip_normalize. */
+int carmel_hip_set_norm(carmel_hip_trainer* t, int norm_group_by, double add_count);
+
+/* Replaces: per-arc prior of arcs_table (derivations.h:99-100): prior = smooth_floor (+ current arc weight when
+ * weight_is_prior_count, carmel -U), captured at call time like the arcs_table constructor does. */
+int carmel_hip_set_prior(carmel_hip_trainer* t, double smooth_floor, int weight_is_prior_count);
+
+/* Replaces: cascade_parameters chains (cascade.h:233, 489-599) for --train-cascade.  Parameters are the arcs
+ * of the original transducers, concatenated member by member in visit order.  chain c lists
+ * chain_param[chain_off[c] .. chain_off[c+1]).  param_member[p] = index of the member transducer;
+ * member_norm[m] / member_add_count[m] = its NormalizeMethod; param_src / param_in give (state, input symbol)
+ * for norm-group formation; param_group as FSTArc::groupId (0 = locked). */
+int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const double* param_logw,
+                           const uint32_t* param_group, const uint32_t* param_member, const uint32_t* param_src,
+                           const uint32_t* param_in, uint32_t n_members, const int* member_norm,
+                           const double* member_add_count, uint64_t n_chains, const uint64_t* chain_off,
+                           const uint64_t* chain_param);
+
+/* Replaces: WFST::normalize(method) (fst.cc:86-244) applied to the current weights (cascade: every member,
+ * cascade.h:402-405, then cascade.update()).  WFST::train calls it once before iteration 1 (train.cc:509). */
+int carmel_hip_normalize(carmel_hip_trainer* t);
+
+/* Set / get the current arc weights (ln).  For a cascade these are the PARAMETER weights (n_params). */
+int carmel_hip_set_weights(carmel_hip_trainer* t, const double* logw);
+int carmel_hip_get_weights(carmel_hip_trainer* t, double* logw);
+/* composed-arc weights after cascade.update() (n_arcs); same as get_weights for a single transducer */
+int carmel_hip_get_arc_weights(carmel_hip_trainer* t, double* logw);
+
+typedef struct carmel_hip_estimate_result {
+  double sum_logprob;          /* ln of unweighted_corpus_prob  (train.cc:330) */
+  double sum_weighted_logprob; /* ln of weighted_corpus_prob    (train.cc:331) */
+  uint64_t n_pairs;            /* pairs swept (those with a derivation) */
+  double kernel_ms;            /* HIP-event time of the sweep kernels of this call, on the trainer's stream */
+} carmel_hip_estimate_result;
+
+/* Replaces: forward_backward::estimate (train.cc:763-773) = cascade.update (cascade.h:466-479) + clear counts +
+ * for every pair derivations::collect_counts (derivations.h:400-449: forward sweep, backward sweep, count
+ * accumulation).  Runs on the GPU over this trainer's corpus shard; counts stay on the device
+ * (carmel_hip_counts_dev) until carmel_hip_get_counts / carmel_hip_maximize.
+ * per_pair_logprob (n_pairs given to set_corpus; -inf for dropped pairs) may be NULL.
+ * carmel_hip_estimate_async only enqueues (for overlap with an all-reduce on another stream); _finish syncs and
+ * fills the result. */
+int carmel_hip_estimate(carmel_hip_trainer* t, carmel_hip_estimate_result* res, double* per_pair_logprob);
+int carmel_hip_estimate_async(carmel_hip_trainer* t);
+int carmel_hip_estimate_finish(carmel_hip_trainer* t, carmel_hip_estimate_result* res, double* per_pair_logprob);
+
+/* Device buffer of n_arcs + 4 doubles: linear expected counts per (composed) arc followed by
+ * {sum_logprob, sum_weighted_logprob, n_pairs, 0}.  This is the ONE buffer a data-parallel caller sums across
+ * ranks between estimate and maximize (RCCL allReduce(sum) over xGMI); see bench.py / INTEGRATION.md. */
+void* carmel_hip_counts_dev(carmel_hip_trainer* t);
+uint64_t carmel_hip_counts_len(carmel_hip_trainer* t);
+void* carmel_hip_stream(carmel_hip_trainer* t); /* hipStream_t the trainer enqueues on */
+/* Let the caller own that buffer (e.g. a torch tensor handed to torch.distributed): dev_ptr must hold
+ * n_arcs + 4 doubles on this trainer's device and outlive the trainer; NULL switches back. */
+int carmel_hip_use_external_counts(carmel_hip_trainer* t, void* dev_ptr);
+int carmel_hip_synchronize(carmel_hip_trainer* t); /* wait for everything enqueued on the trainer's stream */
+/* HIP-event time (ms) of the sweep kernels of the most recent estimate, measured on the trainer's stream */
+int carmel_hip_last_sweep_ms(carmel_hip_trainer* t, double* ms);
+/* after an external all-reduce of counts_dev: re-read the three scalars into res */
+int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* res);
+int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts /* n_arcs, linear */);
+int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts /* n_arcs, linear */);
+
+/* Replaces: forward_backward::maximize (train.cc:893-923): prep_new_weights (:134-153), cascade.use_counts
+ * (distribute_counts cascade.h:318-325 + normalize fst.cc:86-244), overrelax (:157-171, delta_scale > 1 only for
+ * a single transducer) and max_change (:173-182).  *max_change gets max |new - old| in the real domain
+ * (10 for a real cascade, train.cc:922). */
+int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change);
+
+/* Replaces: for_arcs::save_best / save_best_counts / use_best_weight (train.cc:123-198, 449-457) and
+ * cascade.use_counts_final (cascade.h:358-364): device-side snapshots so WFST::train's "keep the weights that
+ * produced the best estimate" needs no host copies. */
+int carmel_hip_save_counts(carmel_hip_trainer* t); /* for_arcs::save_counts: em_weight <- weight (cascade) */
+int carmel_hip_save_best(carmel_hip_trainer* t);
+int carmel_hip_load_best(carmel_hip_trainer* t);
+
+/* ---- host-only inspection (no GPU needed): the lattice image carmel_hip_build_lattices uploads ----
+ * Used by the CPU test-suite to check lattice construction and layout against the oracle. */
+typedef struct carmel_hip_host_lattices carmel_hip_host_lattices;
+int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uint32_t final_state, uint64_t n_arcs,
+                          const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
+                          uint64_t n_pairs, const uint64_t* in_off, const uint32_t* cin, const uint64_t* out_off,
+                          const uint32_t* cout, const double* pair_weight, int prune, int threads,
+                          uint32_t small_pairs, uint32_t small_states);
+void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims10);
+void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,
+                            uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
+                            uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,
+                            uint8_t* has_deriv);
+void carmel_hip_host_free(carmel_hip_host_lattices* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,217 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes binding of oracle/liboracle.so (the CPU restatement of the
+reference's algorithm).  Imported only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so", "oracle_carmel"])
+
+
+build()
+lib = C.CDLL(LIB_PATH)
+vp = C.c_void_p
+lib.orc_last_error.restype = C.c_char_p
+lib.orc_wfst_from_arrays.restype = vp
+lib.orc_wfst_from_arrays.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
+lib.orc_wfst_parse.restype = vp
+lib.orc_wfst_parse.argtypes = [C.c_char_p, C.c_int]
+lib.orc_wfst_free.argtypes = [vp]
+lib.orc_wfst_dims.argtypes = [vp, vp, vp, vp]
+lib.orc_wfst_export.argtypes = [vp] + [vp] * 6
+lib.orc_wfst_set_logw.argtypes = [vp, vp]
+lib.orc_wfst_reduce.argtypes = [vp]
+lib.orc_wfst_normalize.argtypes = [vp, C.c_int, C.c_double]
+lib.orc_wfst_write.restype = vp
+lib.orc_wfst_write.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+lib.orc_free_str.argtypes = [vp]
+lib.orc_wfst_alphabet_size.restype = C.c_uint32
+lib.orc_wfst_alphabet_size.argtypes = [vp, C.c_int]
+lib.orc_corpus_from_arrays.restype = vp
+lib.orc_corpus_from_arrays.argtypes = [C.c_uint64, vp, vp, vp, vp, vp]
+lib.orc_corpus_parse.restype = vp
+lib.orc_corpus_parse.argtypes = [vp, C.c_char_p]
+lib.orc_corpus_free.argtypes = [vp]
+lib.orc_corpus_dims.argtypes = [vp, vp, vp, vp]
+lib.orc_corpus_export.argtypes = [vp] + [vp] * 5
+lib.orc_estimate.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int]
+lib.orc_lattice.argtypes = [vp, vp, C.c_uint64, C.c_int] + [vp] * 8
+lib.orc_train.argtypes = [vp, vp, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                          C.c_int, vp, C.c_int, vp, vp]
+lib.orc_train_cascade_text.argtypes = [C.c_int, vp, C.c_char_p, C.c_char_p, vp, C.c_int, C.c_double, C.c_double,
+                                       C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]
+
+
+lib.orc_bench_em.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+
+
+def bench_em(w, c, norm_group=0, iters=3, threads=1):
+    """CPU baseline: cached lattices, `iters` x (estimate + maximize).  Returns dict(sec_per_iter, lattice_arcs,
+    build_sec, ln_prob)"""
+    out = np.zeros(4)
+    _chk(lib.orc_bench_em(w.h, c.h, norm_group, iters, threads, _p(out)))
+    return dict(sec_per_iter=out[0], lattice_arcs=out[1], build_sec=out[2], ln_prob=out[3])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def _chk(rc):
+    if rc != 0:
+        raise RuntimeError("oracle: " + lib.orc_last_error().decode())
+
+
+TRACE_FIELDS = ("iter", "log2_prob", "log2_ppx_symbol", "log2_ppx_example", "new_best", "rel_ppx_ratio_ln",
+                "last_change", "n_example")
+
+
+class OracleWfst(object):
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_arrays(cls, w):
+        """w: carmel_amd.model.Wfst (or anything with the same array attributes)"""
+        return cls(lib.orc_wfst_from_arrays(w.n_states, w.final, w.n_arcs, _p(w.src), _p(w.dst), _p(w.isym),
+                                            _p(w.osym), _p(w.logw), _p(w.group)))
+
+    @classmethod
+    def parse(cls, text, always_named=True):
+        h = lib.orc_wfst_parse(text.encode(), 1 if always_named else 0)
+        if not h:
+            raise ValueError("oracle: bad WFST text")
+        return cls(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_wfst_free(self.h)
+            self.h = None
+
+    def dims(self):
+        a, b, c = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        lib.orc_wfst_dims(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
+
+    def arrays(self):
+        ns, na, fin = self.dims()
+        src, dst, i, o, g = (np.zeros(na, np.uint32) for _ in range(5))
+        lw = np.zeros(na)
+        lib.orc_wfst_export(self.h, _p(src), _p(dst), _p(i), _p(o), _p(lw), _p(g))
+        return dict(n_states=ns, final=fin, src=src, dst=dst, isym=i, osym=o, logw=lw, group=g)
+
+    def set_logw(self, lw):
+        lw = np.ascontiguousarray(lw, dtype=np.float64)
+        lib.orc_wfst_set_logw(self.h, _p(lw))
+
+    def reduce(self):
+        lib.orc_wfst_reduce(self.h)
+
+    def normalize(self, group=0, add_count=0.0):
+        lib.orc_wfst_normalize(self.h, group, add_count)
+
+    def write(self, full=False, onearc=False, wmode=0):
+        s = lib.orc_wfst_write(self.h, int(full), int(onearc), wmode)
+        txt = C.string_at(s).decode()
+        lib.orc_free_str(s)
+        return txt
+
+    def alphabet_size(self, output=False):
+        return lib.orc_wfst_alphabet_size(self.h, int(output))
+
+
+class OracleCorpus(object):
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def from_arrays(cls, c):
+        return cls(lib.orc_corpus_from_arrays(c.n_pairs, _p(c.in_off), _p(c.in_sym), _p(c.out_off), _p(c.out_sym),
+                                              _p(c.weight)))
+
+    @classmethod
+    def parse(cls, wfst, text):
+        return cls(lib.orc_corpus_parse(wfst.h, text.encode()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_corpus_free(self.h)
+            self.h = None
+
+    def arrays(self):
+        n, a, b = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        lib.orc_corpus_dims(self.h, C.byref(n), C.byref(a), C.byref(b))
+        io, oo = np.zeros(n.value + 1, np.uint64), np.zeros(n.value + 1, np.uint64)
+        isym, osym = np.zeros(a.value, np.uint32), np.zeros(b.value, np.uint32)
+        wt = np.zeros(n.value)
+        lib.orc_corpus_export(self.h, _p(io), _p(isym), _p(oo), _p(osym), _p(wt))
+        return dict(in_off=io, in_sym=isym, out_off=oo, out_sym=osym, weight=wt)
+
+
+def estimate(w, c, prune=True, n_threads=1):
+    """one E-step; returns dict(counts_ln, pair_logprob, has_deriv, stats, sum_logprob, sum_weighted_logprob)"""
+    ns, na, _ = w.dims()
+    npairs = len(c.arrays()["weight"])
+    counts = np.zeros(na)
+    pl = np.zeros(npairs)
+    hd = np.zeros(npairs, np.uint8)
+    stats = np.zeros(4)
+    sums = np.zeros(2)
+    _chk(lib.orc_estimate(w.h, c.h, int(prune), _p(counts), _p(pl), _p(hd), _p(stats), _p(sums), n_threads))
+    return dict(counts_ln=counts, pair_logprob=pl, has_deriv=hd.astype(bool), stats=stats, sum_logprob=sums[0],
+                sum_weighted_logprob=sums[1])
+
+
+def lattice(w, c, pair, prune=True):
+    ns, na, fin, nb = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+    _chk(lib.orc_lattice(w.h, c.h, pair, int(prune), C.byref(ns), C.byref(na), C.byref(fin), None, None, None, None,
+                         C.byref(nb)))
+    if ns.value == 0:
+        return None
+    s, d, a = (np.zeros(na.value, np.uint32) for _ in range(3))
+    order = np.zeros(ns.value, np.uint32)
+    _chk(lib.orc_lattice(w.h, c.h, pair, int(prune), C.byref(ns), C.byref(na), C.byref(fin), _p(s), _p(d), _p(a),
+                         _p(order), C.byref(nb)))
+    return dict(n_states=ns.value, fin=fin.value, src=s, dst=d, arcid=a, reverse_order=order, n_back_edges=nb.value)
+
+
+def train(w, c, norm_group=0, add_count=0.0, weight_is_prior_count=False, smooth_floor=0.0, converge_arc_delta=1e-4,
+          converge_ppx_ratio=.999, max_iter=500, cache=False, prune=True, max_trace=1000):
+    tr = np.zeros((max_trace, 8))
+    n = C.c_int(0)
+    best = C.c_double(0)
+    _chk(lib.orc_train(w.h, c.h, norm_group, add_count, int(weight_is_prior_count), smooth_floor, converge_arc_delta,
+                       converge_ppx_ratio, max_iter, int(cache), int(prune), _p(tr), max_trace, C.byref(n),
+                       C.byref(best)))
+    rows = [dict(zip(TRACE_FIELDS, tr[i])) for i in range(n.value)]
+    return best.value, rows
+
+
+def train_cascade_text(wfst_texts, corpus_text, normby=None, priors=None, max_iter=500, converge_arc_delta=1e-4,
+                       converge_ppx_ratio=.999, cache=False, full=True, onearc=True, max_trace=1000):
+    n = len(wfst_texts)
+    arr = (C.c_char_p * n)(*[t.encode() for t in wfst_texts])
+    tr = np.zeros((max_trace, 8))
+    nt = C.c_int(0)
+    out = vp()
+    olen = C.c_uint64(0)
+    dims = np.zeros(2, np.uint32)
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    _chk(lib.orc_train_cascade_text(n, arr, corpus_text.encode(), (normby or "").encode() or None, _p(pri), max_iter,
+                                    converge_arc_delta, converge_ppx_ratio, int(cache), int(full), int(onearc),
+                                    C.byref(out), C.byref(olen), _p(tr), max_trace, C.byref(nt), _p(dims)))
+    raw = C.string_at(out, olen.value)
+    lib.orc_free_str(out)
+    texts = [t.decode() for t in raw.split(b"\0")[:n]]
+    rows = [dict(zip(TRACE_FIELDS, tr[i])) for i in range(nt.value)]
+    return rows, texts, (int(dims[0]), int(dims[1]))
+
+
+CLI = os.path.join(_HERE, "oracle_carmel")

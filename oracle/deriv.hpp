@@ -372,7 +372,9 @@ struct Derivations {
   }
 
   // derivations.h:432-449.  posteriors (optional): per lattice arc, in (state, list-order) sequence
-  LW collect_counts(ArcTable& t, std::vector<LW>* f_out = 0, std::vector<LW>* b_out = 0) {
+  // counts_override: accumulate into this table instead of ArcRec::counts (per-thread tables of the OpenMP
+  // baseline in oracle_capi.cpp; same arithmetic)
+  LW collect_counts(ArcTable& t, std::vector<LW>* f_out = 0, std::vector<LW>* b_out = 0, LW* counts_override = 0) {
     std::vector<LW> f, b;
     auto wf = [&](const GArc& a) { return t.t[a.arcid].arc->weight; };
     LW prob = compute_fb(f, b, wf);
@@ -382,7 +384,8 @@ struct Derivations {
         const GArc& a = arcs[k];
         ArcRec& ac = t.t[a.arcid];
         LW arc_contrib = ac.arc->weight * f[a.src] * b[a.dest];
-        ac.counts += arc_contrib * LW::from_real(weight) / prob;
+        LW& cnt = counts_override ? counts_override[a.arcid] : ac.counts;
+        cnt += arc_contrib * LW::from_real(weight) / prob;
       }
     }
     if (f_out) f_out->swap(f);

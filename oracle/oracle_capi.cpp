@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <sstream>
+#include <chrono>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -351,6 +352,78 @@ int orc_train(orc_wfst* wh, orc_corpus* ch, int norm_group, double add_count, in
       ++n;
     }
     if (n_trace) *n_trace = n;
+  });
+}
+
+// CPU baseline for bench.py: lattices are built once (like carmel -:), then `iters` EM iterations
+// (estimate over the cached lattices + maximize) are timed.  threads <= 1: the scalar restatement, corpus order.
+// threads > 1: OpenMP over cached lattices with per-thread log-domain count tables.
+// out[0] = seconds per iteration, out[1] = lattice arcs swept per iteration, out[2] = lattice build seconds,
+// out[3] = ln corpus prob of the last estimate
+int orc_bench_em(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int threads, double* out) {
+  return run_big_stack([&]() {
+    Wfst& x = wh->w;
+    Cascade cascade(false);
+    std::vector<NormalizeMethod> nms(1);
+    nms[0].group = norm_group;
+    cascade.set_composed(&x);
+    cascade.normalize(nms);
+    TrainOpts opts;
+    opts.cache_derivations = true;
+    auto t0 = std::chrono::steady_clock::now();
+    ForwardBackward fb(x, cascade, false, LW(), opts, ch->c);
+    auto t1 = std::chrono::steady_clock::now();
+    double arcs = 0;
+    for (auto& d : fb.derivs) arcs += (double)d.n_arcs();
+    LW corpus_p;
+    auto run_iter = [&]() {
+      if (threads <= 1) {
+        fb.estimate(corpus_p);
+      } else {
+#ifdef _OPENMP
+        omp_set_num_threads(threads);
+#endif
+        for (auto& a : fb.arcs.t) a.counts = LW();
+        size_t na = fb.arcs.t.size();
+        double sum = 0;
+        std::vector<std::vector<LW> > tc;
+#pragma omp parallel
+        {
+#pragma omp single
+          {
+            int nt = 1;
+#ifdef _OPENMP
+            nt = omp_get_num_threads();
+#endif
+            tc.assign(nt, std::vector<LW>(na));
+          }
+          int me = 0;
+#ifdef _OPENMP
+          me = omp_get_thread_num();
+#endif
+          double ls = 0;
+#pragma omp for schedule(dynamic, 64)
+          for (long p = 0; p < (long)fb.derivs.size(); ++p) ls += fb.derivs[p].collect_counts(fb.arcs, 0, 0, tc[me].data()).w;
+#pragma omp critical
+          sum += ls;
+#pragma omp for schedule(static)
+          for (long k = 0; k < (long)na; ++k) {
+            LW c;
+            for (auto& t : tc) c += t[k];
+            fb.arcs.t[k].counts = c;
+          }
+        }
+        corpus_p = LW::from_ln(sum);
+      }
+      fb.maximize(nms, 1.0);
+    };
+    auto t2 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) run_iter();
+    auto t3 = std::chrono::steady_clock::now();
+    out[0] = std::chrono::duration<double>(t3 - t2).count() / (iters > 0 ? iters : 1);
+    out[1] = arcs;
+    out[2] = std::chrono::duration<double>(t1 - t0).count();
+    out[3] = corpus_p.w;
   });
 }
 

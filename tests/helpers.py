@@ -1,0 +1,117 @@
+"""Test helpers: the host-side lattice image as numpy arrays, and a plain numpy sweep over that image (used on
+machines without a GPU to check the LAYOUT the kernels consume against the oracle's E-step)."""
+import ctypes as C
+
+import numpy as np
+
+from carmel_amd._capi import lib, ptr
+
+BUNDLE_DTYPE = np.dtype([("in_base", "<u8"), ("out_base", "<u8"), ("off_base", "<u8"), ("n_states", "<u4"),
+                         ("n_levels", "<u4"), ("level_base", "<u4"), ("pair_base", "<u4"), ("n_pairs", "<u4"),
+                         ("flags", "<u4"), ("n_arcs", "<u8"), ("pad", "<u8")])
+assert BUNDLE_DTYPE.itemsize == 64
+
+
+def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0):
+    h = C.c_void_p()
+    rc = lib.carmel_hip_host_build(C.byref(h), w.n_states, w.final, w.n_arcs, ptr(w.src), ptr(w.dst), ptr(w.isym),
+                                   ptr(w.osym), c.n_pairs, ptr(c.in_off), ptr(c.in_sym), ptr(c.out_off),
+                                   ptr(c.out_sym), ptr(c.weight), int(prune), threads, small_pairs, small_states)
+    assert rc == 0
+    dims = np.zeros(10, np.uint64)
+    lib.carmel_hip_host_dims(h, ptr(dims))
+    nb, noff, na, nlev, npair, ncls = (int(x) for x in dims[:6])
+    out = dict(bundles=np.zeros(nb, BUNDLE_DTYPE), in_arcs=np.zeros((na, 2), np.uint32),
+               out_arcs=np.zeros((na, 2), np.uint32), in_off=np.zeros(noff, np.uint32),
+               out_off=np.zeros(noff, np.uint32), level_off=np.zeros(nlev, np.uint32),
+               pair_start=np.zeros(npair, np.uint32), pair_final=np.zeros(npair, np.uint32),
+               pair_id=np.zeros(npair, np.uint32), pair_logw=np.zeros(npair), classes=np.zeros((ncls, 5), np.uint32),
+               has_deriv=np.zeros(c.n_pairs, np.uint8))
+    lib.carmel_hip_host_export(h, ptr(out["bundles"]), ptr(out["in_arcs"]), ptr(out["out_arcs"]), ptr(out["in_off"]),
+                               ptr(out["out_off"]), ptr(out["level_off"]), ptr(out["pair_start"]),
+                               ptr(out["pair_final"]), ptr(out["pair_id"]), ptr(out["pair_logw"]),
+                               ptr(out["classes"]), ptr(out["has_deriv"]))
+    lib.carmel_hip_host_free(h)
+    out.update(n_kept=int(dims[6]), n_cyclic=int(dims[7]), explored_states=int(dims[8]), explored_arcs=int(dims[9]))
+    return out
+
+
+def _lse(xs):
+    xs = np.asarray(xs, dtype=np.float64)
+    if len(xs) == 0:
+        return -np.inf
+    m = xs.max()
+    if m == -np.inf:
+        return -np.inf
+    return m + np.log(np.exp(xs - m).sum())
+
+
+def _lwadd(a, b):
+    if a == -np.inf:
+        return b
+    if b == -np.inf:
+        return a
+    d = a - b
+    if d > 36:
+        return a
+    if d < -36:
+        return b
+    return (b + np.log1p(np.exp(d))) if d < 0 else (a + np.log1p(np.exp(-d)))
+
+
+def numpy_sweep(img, logw, n_pairs_total):
+    """forward / backward / counts over the bundle image exactly as kernels.hip walks it.
+    Returns (counts linear per WFST arc, per-pair ln prob)."""
+    counts = np.zeros(len(logw))
+    plp = np.full(n_pairs_total, -np.inf)
+    for b in img["bundles"]:
+        ns = int(b["n_states"])
+        ob, ib, ab = int(b["off_base"]), int(b["in_base"]), int(b["out_base"])
+        ioff = img["in_off"][ob:ob + ns + 1]
+        ooff = img["out_off"][ob:ob + ns + 1]
+        ia = img["in_arcs"][ib:ib + int(b["n_arcs"])]
+        oa = img["out_arcs"][ab:ab + int(b["n_arcs"])]
+        lv = img["level_off"][int(b["level_base"]):int(b["level_base"]) + int(b["n_levels"]) + 1]
+        pb, npb = int(b["pair_base"]), int(b["n_pairs"])
+        alpha = np.full(ns, -np.inf)
+        beta = np.full(ns, -np.inf)
+        if b["flags"] & 1:  # cyclic: the reference's in-order scatter sweeps
+            st, fin = int(img["pair_start"][pb]), int(img["pair_final"][pb])
+            alpha[st] = 0.0
+            for s in range(ns):
+                for a in range(ioff[0] * 0 + ooff[s], ooff[s + 1]):
+                    d, arc = oa[a]
+                    alpha[d] = _lwadd(alpha[d], alpha[s] + logw[arc])
+            prob = alpha[fin]
+            plp[img["pair_id"][pb]] = prob
+            beta[fin] = 0.0
+            for s in range(ns - 1, -1, -1):
+                for a in range(ioff[s], ioff[s + 1]):
+                    u, arc = ia[a]
+                    beta[u] = _lwadd(beta[u], beta[s] + logw[arc])
+            for s in range(ns):
+                for a in range(ooff[s], ooff[s + 1]):
+                    d, arc = oa[a]
+                    counts[arc] += np.exp(logw[arc] + alpha[s] + beta[d] + img["pair_logw"][pb] - prob)
+            continue
+        for p in range(npb):
+            alpha[img["pair_start"][pb + p]] = 0.0
+        for l in range(1, int(b["n_levels"])):
+            for s in range(lv[l], lv[l + 1]):
+                r = ia[ioff[s]:ioff[s + 1]]
+                assert np.all(r[:, 0] < lv[l]), "in-arc source must lie in an earlier level"
+                alpha[s] = _lse(alpha[r[:, 0]] + logw[r[:, 1]])
+        for p in range(npb):
+            f = img["pair_final"][pb + p]
+            plp[img["pair_id"][pb + p]] = alpha[f]
+            beta[f] = img["pair_logw"][pb + p] - alpha[f]
+        for l in range(int(b["n_levels"]) - 1, -1, -1):
+            for s in range(lv[l], lv[l + 1]):
+                r = oa[ooff[s]:ooff[s + 1]]
+                if len(r) == 0:
+                    continue
+                assert np.all(r[:, 0] >= lv[l + 1]), "out-arc destination must lie in a later level"
+                t = logw[r[:, 1]] + beta[r[:, 0]]
+                beta[s] = _lse(t)
+                np.add.at(counts, r[:, 1], np.exp(alpha[s] + t))
+    return counts, plp

@@ -1,0 +1,216 @@
+"""GPU parity tests proper (-m gpu): the HIP path through the C-ABI against the CPU oracle.
+
+Tolerances: posteriors / expected counts / per-pair probabilities within 1e-7 relative (north_star asks 1e-5; the
+only differences are summation order and one streaming logsumexp per state instead of pairwise log-adds);
+arc indexing exact (the count vector is compared arc id by arc id)."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+
+def sig6(x):
+    """the reference prints these with 6 significant digits (default ostream precision)"""
+    return float("%.6g" % x)
+
+from carmel_amd import synth
+from carmel_amd.model import NORM_CONDITIONAL, NORM_JOINT, NORM_NONE, Corpus, Wfst
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-7
+
+
+def _fb(*a, **k):
+    from carmel_amd.trainer import HipForwardBackward
+    return HipForwardBackward(*a, **k)
+
+
+def ambiguous(seed, n_states=40, deg=8, n_sym=4, n_pairs=200, p_eps=0.15, lo=3, hi=12):
+    w = synth.random_wfst(n_states, deg, n_sym=n_sym, p_eps=p_eps, seed=seed)
+    c = synth.random_walk_corpus(w, n_pairs, min_arcs=lo, max_arcs=hi, seed=seed, out_degree=deg)
+    return w, c
+
+
+def oracle_estep(oracle, w, c, group=NORM_CONDITIONAL, normalize=True):
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    if normalize:
+        ow.normalize(group, 0.0)
+    return ow, oc, oracle.estimate(ow, oc)
+
+
+@pytest.mark.parametrize("seed,kw", [
+    (1, {}), (2, dict(n_sym=3, deg=10, n_states=30)), (3, dict(n_sym=64, deg=20, n_states=500, lo=5, hi=40)),
+    (4, dict(n_sym=2, deg=6, n_states=12, hi=20, n_pairs=80)),
+])
+def test_estep_counts_and_probs(oracle, seed, kw):
+    w, c = ambiguous(seed, **kw)
+    rng = np.random.default_rng(seed)
+    c.weight[:] = rng.uniform(0.5, 3.0, c.n_pairs)  # per-example weights (train.cc:330-331)
+    fb = _fb(w, c)
+    lp, wlp = fb.estimate(per_pair=True)
+    _, _, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert np.array_equal(ok, fb.has_deriv.astype(bool))
+    np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-10, atol=1e-10)
+    assert np.all(np.isneginf(fb.pair_logprob[~ok]))
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
+    assert lp == pytest.approx(r["sum_logprob"], rel=1e-12)
+    assert wlp == pytest.approx(r["sum_weighted_logprob"], rel=1e-12)
+    fb.close()
+
+
+def test_big_single_lattice_classes(oracle):
+    # long pairs over a tiny alphabet: lattices of thousands of states -> the 256- and 1024-thread classes
+    w = synth.random_wfst(6, 5, n_sym=3, p_eps=0.2, seed=21)
+    c = synth.random_walk_corpus(w, 6, min_arcs=60, max_arcs=90, seed=21, out_degree=5)
+    fb = _fb(w, c)
+    fb.estimate(per_pair=True)
+    _, _, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert fb.lattice_stats.kept_states > 2000
+    np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-10)
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
+    fb.close()
+
+
+def test_cyclic_lattice_matches_reference_order(oracle):
+    src, dst = [0, 1, 1, 2, 2], [1, 2, 3, 1, 3]
+    isym = osym = [2, 0, 3, 0, 3]
+    w = Wfst(4, 3, src, dst, isym, osym, np.log([1.0, 0.3, 0.7, 0.4, 0.6]))
+    c = Corpus.from_lists([([2, 3], [2, 3]), ([2, 3], [2, 3])], [1.0, 2.5])
+    fb = _fb(w, c, norm_group=NORM_NONE, normalize_first=False)
+    fb.estimate(per_pair=True)
+    assert fb.lattice_stats.n_cyclic_pairs == 2
+    _, _, r = oracle_estep(oracle, w, c, normalize=False)
+    np.testing.assert_allclose(fb.pair_logprob, r["pair_logprob"], rtol=1e-12)
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=1e-10, atol=1e-300)
+    fb.close()
+
+
+def test_empty_ragged_and_no_derivation(oracle):
+    w = Wfst(3, 2, [0, 1], [1, 2], [2, 3], [2, 3], np.log([1.0, 1.0]))
+    c = Corpus.from_lists([([2, 3], [2, 3]), ([2, 2], [2, 3]), ([], []), ([2, 3], [2, 3])])
+    fb = _fb(w, c)
+    lp, _ = fb.estimate(per_pair=True)
+    assert fb.has_deriv.tolist() == [1, 0, 0, 1]
+    assert fb.stats["n_pairs"] == 2
+    np.testing.assert_allclose(fb.counts(), [2.0, 2.0])
+    assert lp == pytest.approx(0.0, abs=1e-12)
+    fb.close()
+    # every pair without a derivation: the reference aborts training (train.cc:241-252)
+    from carmel_amd import CarmelHipError
+    c2 = Corpus.from_lists([([3], [3])])
+    fb2 = _fb(w, c2)
+    with pytest.raises(CarmelHipError) as e:
+        fb2.estimate()
+    assert e.value.code == -4
+    fb2.close()
+
+
+@pytest.mark.parametrize("group", [NORM_CONDITIONAL, NORM_JOINT])
+@pytest.mark.parametrize("add_count", [0.0, 0.25])
+def test_mstep_normalize(oracle, group, add_count):
+    w, c = ambiguous(7)
+    grp = w.group.copy()
+    grp[::7] = 0  # lock every 7th arc: locked arcs keep their weight and reserve mass (fst.cc:196-230)
+    w.logw[::7] = np.log(0.05)
+    w = Wfst(w.n_states, w.final, w.src, w.dst, w.isym, w.osym, w.logw, grp)
+    fb = _fb(w, c, norm_group=group, add_count=add_count)
+    ow = oracle.OracleWfst.from_arrays(w)
+    ow.normalize(group, add_count)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-12, atol=1e-300)
+    fb.close()
+
+
+@pytest.mark.parametrize("group", [NORM_CONDITIONAL, NORM_JOINT])
+def test_full_training_trace(oracle, group):
+    from carmel_amd.trainer import TrainOpts, train
+    w, c = ambiguous(5, n_pairs=150)
+    w.logw[:] = 0.0  # flat start
+    fb = _fb(w, c, norm_group=group)
+    best, trace = train(fb, TrainOpts(max_iter=12))
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    obest, otrace = oracle.train(ow, oc, norm_group=group, max_iter=12)
+    assert len(trace) == len(otrace)
+    for a, b in zip(trace, otrace):
+        assert a["iter"] == int(b["iter"])
+        assert a["log2_prob"] == pytest.approx(b["log2_prob"], rel=1e-9)
+        assert a["log2_ppx_example"] == pytest.approx(b["log2_ppx_example"], rel=1e-9)
+        assert a["new_best"] == bool(b["new_best"])
+        if a["iter"] > 1:
+            assert a["rel_ppx_ratio_ln"] == pytest.approx(b["rel_ppx_ratio_ln"], rel=1e-6, abs=1e-12)
+            assert a["last_change"] == pytest.approx(b["last_change"], rel=1e-6, abs=1e-12)
+    assert best == pytest.approx(obest, rel=1e-9)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-6, atol=1e-12)
+    fb.close()
+
+
+def test_golden_epron_jpron(oracle, golden_dir):
+    """carmel -t epron-jpron.data epron-jpron.fst — the reference's recorded run (commands.trace:7-77)"""
+    from carmel_amd.trainer import TrainOpts, train
+    gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["epron-jpron"]
+    ow = oracle.OracleWfst.parse(open(os.path.join(golden_dir, "epron-jpron.fst")).read())
+    ow.reduce()
+    oc = oracle.OracleCorpus.parse(ow, open(os.path.join(golden_dir, "epron-jpron.data")).read())
+    a = ow.arrays()
+    w = Wfst(a["n_states"], a["final"], a["src"], a["dst"], a["isym"], a["osym"], a["logw"], a["group"])
+    ca = oc.arrays()
+    c = Corpus(ca["in_off"], ca["in_sym"], ca["out_off"], ca["out_sym"], ca["weight"])
+    fb = _fb(w, c)
+    best, trace = train(fb, TrainOpts())
+    assert len(trace) == len(gold["iters"]) == 5
+    for t, g in zip(trace, gold["iters"]):
+        assert sig6(t["log2_prob"]) == g["log2_prob"]
+        assert sig6(t["log2_ppx_example"]) == g["log2_ppx_example"]
+        assert t["new_best"] == g["new_best"]
+    # max{d(weight)} printed at iteration i is the change made by M-step i-1
+    for t, g in zip(trace[2:], gold["iters"][2:]):
+        assert t["last_change"] == pytest.approx(g["max_dweight"], rel=1e-9)
+    # final weights: the 15-digit transducer the reference printed
+    ow.set_logw(fb.weights())
+    got = ow.write(full=False, onearc=False)
+    import re
+    num = re.compile(r"(?<![\w\"])(\d+\.\d+(?:e[-+]\d+)?|\d+e[-+]\d+)(?![\w\"])")
+    gl, el = got.strip().split("\n"), gold["final_wfst"].strip().split("\n")
+    assert len(gl) == len(el)
+    for x, y in zip(gl, el):
+        assert num.sub("#", x) == num.sub("#", y)
+        for u, v in zip(num.findall(x), num.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-9)
+    fb.close()
+
+
+def test_full_size_properties_c2():
+    """BASELINE.json configs[1] at full size: properties that do not need the oracle"""
+    w, c = synth.make_config("c2")
+    fb = _fb(w, c)
+    lp, _ = fb.estimate(per_pair=True)
+    counts = fb.counts()
+    assert fb.has_deriv.all()
+    # every derivation enters the (out-arc-free) final state exactly once
+    assert counts[w.dst == w.final].sum() == pytest.approx(c.n_pairs, rel=1e-9)
+    # sum over pairs of ln p == the scalar the kernel accumulated
+    assert fb.pair_logprob.sum() == pytest.approx(lp, rel=1e-9)
+    # flow conservation: expected count into a non-final, non-start state == expected count out of it
+    inflow = np.bincount(w.dst, weights=counts, minlength=w.n_states)
+    outflow = np.bincount(w.src, weights=counts, minlength=w.n_states)
+    mid = np.ones(w.n_states, bool)
+    mid[[0, w.final]] = False
+    np.testing.assert_allclose(inflow[mid], outflow[mid], rtol=1e-9, atol=1e-9)
+    # EM monotonicity: likelihood does not decrease across iterations
+    prev = lp
+    for _ in range(3):
+        fb.maximize(1.0)
+        cur, _ = fb.estimate()
+        assert cur >= prev - 1e-6 * abs(prev)
+        prev = cur
+    # idempotence of normalisation: after an M-step every (state, input) group sums to 1
+    wts = np.exp(fb.weights())
+    key = w.src.astype(np.int64) * (1 << 20) + w.isym
+    _, inv = np.unique(key, return_inverse=True)
+    sums = np.bincount(inv, weights=wts)
+    touched = np.bincount(inv, weights=(wts > 0)) > 0
+    np.testing.assert_allclose(sums[touched], 1.0, rtol=1e-9)
+    fb.close()

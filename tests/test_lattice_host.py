@@ -1,0 +1,103 @@
+"""CPU: the product's host-side lattice builder and HBM layout against the oracle (no GPU compute)."""
+import numpy as np
+import pytest
+
+from carmel_amd import synth
+from carmel_amd.model import Corpus, Wfst
+from helpers import host_lattices, numpy_sweep
+
+
+def ambiguous(seed, n_states=40, deg=8, n_sym=4, n_pairs=60, p_eps=0.15):
+    w = synth.random_wfst(n_states, deg, n_sym=n_sym, p_eps=p_eps, seed=seed)
+    c = synth.random_walk_corpus(w, n_pairs, min_arcs=3, max_arcs=12, seed=seed, out_degree=deg)
+    return w, c
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_lattice_matches_oracle_structure(oracle, seed):
+    w, c = ambiguous(seed)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    img = host_lattices(w, c, small_pairs=8, small_states=512)
+    r = oracle.estimate(ow, oc)
+    assert np.array_equal(img["has_deriv"].astype(bool), r["has_deriv"])
+    # exploration statistics are the reference's (derivations.h:191-247): same DFS, same counts
+    assert img["explored_states"] == int(r["stats"][0])
+    assert img["explored_arcs"] == int(r["stats"][1])
+    # per pair: identical multiset of (WFST arc id) uses and identical state counts, cycles excepted (the product
+    # additionally drops states that cannot reach the goal, which the reference keeps with zero backward mass)
+    by_pair = {}
+    for b in img["bundles"]:
+        if b["n_pairs"] != 1:
+            continue
+        pid = int(img["pair_id"][b["pair_base"]])
+        arcs = img["out_arcs"][int(b["out_base"]):int(b["out_base"]) + int(b["n_arcs"]), 1]
+        by_pair[pid] = (int(b["n_states"]), np.sort(arcs))
+    for pid, (ns, arcs) in list(by_pair.items())[:20]:
+        L = oracle.lattice(ow, oc, pid)
+        if L["n_back_edges"] == 0:
+            assert ns == L["n_states"]
+            assert np.array_equal(arcs, np.sort(L["arcid"]))
+
+
+@pytest.mark.parametrize("seed,small_pairs", [(1, 8), (2, 64), (5, 3)])
+def test_layout_sweep_matches_oracle_estep(oracle, seed, small_pairs):
+    w, c = ambiguous(seed)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    img = host_lattices(w, c, small_pairs=small_pairs, small_states=1024)
+    r = oracle.estimate(ow, oc)
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    ok = r["has_deriv"]
+    np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+    ref = np.exp(r["counts_ln"])
+    np.testing.assert_allclose(counts, ref, rtol=1e-8, atol=1e-12)
+    # size-independent property: the final state has no out-arcs, so every derivation enters it exactly once:
+    # expected counts of the arcs INTO it sum to the corpus weight
+    assert abs(counts[w.dst == w.final].sum() - c.weight[ok].sum()) < 1e-9 * c.n_pairs
+
+
+def test_levels_are_topological(oracle):
+    w, c = ambiguous(9, n_states=30, deg=10, n_sym=3, n_pairs=40)
+    img = host_lattices(w, c, small_pairs=16, small_states=2048)
+    for b in img["bundles"]:
+        if b["flags"] & 1:
+            continue
+        ns, ob = int(b["n_states"]), int(b["off_base"])
+        lv = img["level_off"][int(b["level_base"]):int(b["level_base"]) + int(b["n_levels"]) + 1]
+        assert lv[0] == 0 and lv[-1] == ns and np.all(np.diff(lv.astype(np.int64)) > 0)
+        level_of = np.searchsorted(lv, np.arange(ns), side="right") - 1
+        ioff = img["in_off"][ob:ob + ns + 1]
+        ia = img["in_arcs"][int(b["in_base"]):int(b["in_base"]) + int(b["n_arcs"])]
+        for s in range(ns):
+            src = ia[ioff[s]:ioff[s + 1], 0]
+            if len(src):
+                assert level_of[src].max() + 1 == level_of[s]  # longest-path level
+
+
+def test_empty_and_no_derivation_pairs(oracle):
+    # 3-state toy: (0 -a:x-> 1 -b:y-> 2), final 2; pairs: good, wrong symbol, empty/empty
+    w = Wfst(3, 2, [0, 1], [1, 2], [2, 3], [2, 3], np.log([1.0, 1.0]))
+    c = Corpus.from_lists([([2, 3], [2, 3]), ([2, 2], [2, 3]), ([], [])])
+    img = host_lattices(w, c)
+    assert img["has_deriv"].tolist() == [1, 0, 0]
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    assert oracle.estimate(ow, oc)["has_deriv"].tolist() == [True, False, False]
+
+
+def test_cyclic_lattice_reference_order(oracle):
+    # *e*:*e* 2-cycle between states 1 and 2 on the way to the goal: the reference drops the back-edge paths
+    # (derivations.h:726-728); the product must drop the same ones
+    src = [0, 1, 1, 2, 2]
+    dst = [1, 2, 3, 1, 3]
+    isym = [2, 0, 3, 0, 3]
+    osym = [2, 0, 3, 0, 3]
+    w = Wfst(4, 3, src, dst, isym, osym, np.log([1.0, 0.3, 0.7, 0.4, 0.6]))
+    c = Corpus.from_lists([([2, 3], [2, 3])])
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    L = oracle.lattice(ow, oc, 0)
+    assert L["n_back_edges"] > 0
+    img = host_lattices(w, c)
+    assert img["n_cyclic"] == 1
+    r = oracle.estimate(ow, oc)
+    counts, plp = numpy_sweep(img, w.logw, 1)
+    np.testing.assert_allclose(plp[0], r["pair_logprob"][0], rtol=1e-12)
+    np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-10, atol=1e-300)
