@@ -21,7 +21,7 @@ SYMBOLS = [
     "carmel_hip_use_external_counts", "carmel_hip_synchronize", "carmel_hip_last_sweep_ms", "carmel_hip_read_scalars",
     "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_save_counts",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
-    "carmel_hip_host_export", "carmel_hip_host_free",
+    "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_free",
 ]
 
 
@@ -82,11 +82,14 @@ def _load():
     lib.carmel_hip_save_best.argtypes = [vp]
     lib.carmel_hip_load_best.argtypes = [vp]
     lib.carmel_hip_host_build.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp,
-                                          C.c_uint64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
+                                          C.c_uint64, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                          C.c_int]
     lib.carmel_hip_host_dims.argtypes = [vp, vp]
     lib.carmel_hip_host_dims.restype = None
     lib.carmel_hip_host_export.argtypes = [vp] + [vp] * 12
     lib.carmel_hip_host_export.restype = None
+    lib.carmel_hip_host_export_lanes.argtypes = [vp] * 8
+    lib.carmel_hip_host_export_lanes.restype = None
     lib.carmel_hip_host_free.argtypes = [vp]
     lib.carmel_hip_host_free.restype = None
     return lib

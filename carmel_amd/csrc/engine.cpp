@@ -80,6 +80,10 @@ struct carmel_hip_trainer {
   DevBuf<uint2_t> in_arcs, out_arcs;
   DevBuf<uint32_t> in_off, out_off, level_off, pair_start, pair_final, pair_id;
   DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
+  DevBuf<LaneGroup> lane_groups;
+  DevBuf<uint2_t> lane_fwd, lane_bwd;
+  DevBuf<uint32_t> lane_pair, lane_nstates;
+  DevBuf<double> lane_logw;
   uint64_t device_bytes = 0;
 
   double* ext_counts = nullptr;  // caller-owned n_arcs + 4 doubles (carmel_hip_use_external_counts)
@@ -199,6 +203,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   BuildOptions opt;
   opt.prune = prune != 0;
   opt.threads = host_threads;
+  if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
   std::string err;
   LatticeSet& L = t->lat;
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
@@ -214,6 +219,12 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->pair_final.upload(L.pair_final, s));
   HIPCHK(t->pair_id.upload(L.pair_id, s));
   HIPCHK(t->pair_logw.upload(L.pair_logw, s));
+  HIPCHK(t->lane_groups.upload(L.lane_groups, s));
+  HIPCHK(t->lane_fwd.upload(L.lane_fwd, s));
+  HIPCHK(t->lane_bwd.upload(L.lane_bwd, s));
+  HIPCHK(t->lane_pair.upload(L.lane_pair, s));
+  HIPCHK(t->lane_nstates.upload(L.lane_nstates, s));
+  HIPCHK(t->lane_logw.upload(L.lane_logw, s));
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
   HIPCHK(t->alpha_g.alloc(L.in_off.size()));
   bool need_beta = false;
@@ -228,7 +239,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   t->device_bytes = t->bundles.bytes() + t->in_arcs.bytes() + t->out_arcs.bytes() + t->in_off.bytes() +
                     t->out_off.bytes() + t->level_off.bytes() + t->pair_start.bytes() + t->pair_final.bytes() +
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
-                    t->beta_g.bytes();
+                    t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
+                    t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes();
+  std::vector<uint2_t>().swap(L.lane_fwd);
+  std::vector<uint2_t>().swap(L.lane_bwd);
   // free the bulk host arrays; keep descriptors + classes
   std::vector<uint2_t>().swap(L.in_arcs);
   std::vector<uint2_t>().swap(L.out_arcs);
@@ -244,7 +258,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     stats->kept_states = L.total_states;
     stats->kept_arcs = L.total_arcs;
     stats->n_cyclic_pairs = L.n_cyclic;
-    stats->n_bundles = L.bundles.size();
+    stats->n_bundles = L.bundles.size() + L.lane_groups.size();
     stats->max_levels = L.max_levels;
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -451,7 +465,20 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   A.beta_g = t->beta_g.p;
   A.n_arcs = t->w.n_arcs;
   A.first_bundle = 0;
+  LaneArgs LA;
+  LA.groups = t->lane_groups.p;
+  LA.fwd = (const uint2*)t->lane_fwd.p;
+  LA.bwd = (const uint2*)t->lane_bwd.p;
+  LA.lane_pair = t->lane_pair.p;
+  LA.lane_nstates = t->lane_nstates.p;
+  LA.lane_logw = t->lane_logw.p;
+  LA.logw = t->arc_logw.p;
+  LA.counts = t->counts_ptr();
+  LA.pair_logprob = t->pair_logprob.p;
+  LA.n_arcs = t->w.n_arcs;
+  LA.first_group = 0;
   HIPCHK(hipEventRecord(t->ev0, s));
+  for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
   HIPCHK(hipEventRecord(t->ev1, s));
   return CARMEL_HIP_OK;

@@ -21,7 +21,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
                           const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
                           uint64_t n_pairs, const uint64_t* in_off, const uint32_t* cin, const uint64_t* out_off,
                           const uint32_t* cout, const double* pair_weight, int prune, int threads,
-                          uint32_t small_pairs, uint32_t small_states) {
+                          uint32_t small_pairs, uint32_t small_states, int lane_states) {
   if (!out) return CARMEL_HIP_ERR_ARG;
   carmel_hip_host_lattices* h = new carmel_hip_host_lattices();
   h->w.n_states = n_states;
@@ -46,6 +46,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   opt.threads = threads;
   if (small_pairs) opt.small_pairs = small_pairs;
   if (small_states) opt.small_states = small_states;
+  if (lane_states >= 0) opt.lane_states = (uint32_t)lane_states;
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
     delete h;
     return CARMEL_HIP_ERR_ARG;
@@ -54,8 +55,9 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   return CARMEL_HIP_OK;
 }
 
-// dims[0..9] = n_bundles, n_off (states + bundles), n_arcs, n_level_off, n_pair_slots, n_classes, n_kept,
-//              n_cyclic, explored_states, explored_arcs
+// dims[0..15] = n_bundles, n_off (states + bundles), n_arcs, n_level_off, n_pair_slots, n_classes, n_kept,
+//              n_cyclic, explored_states, explored_arcs, n_lane_groups, n_lane_records, n_lane_slots,
+//              n_lane_classes, total_states, total_arcs
 void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims) {
   dims[0] = h->L.bundles.size();
   dims[1] = h->L.in_off.size();
@@ -67,6 +69,29 @@ void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims) {
   dims[7] = h->L.n_cyclic;
   dims[8] = h->L.explored_states;
   dims[9] = h->L.explored_arcs;
+  dims[10] = h->L.lane_groups.size();
+  dims[11] = h->L.lane_fwd.size();
+  dims[12] = h->L.lane_pair.size();
+  dims[13] = h->L.lane_classes.size();
+  dims[14] = h->L.total_states;
+  dims[15] = h->L.total_arcs;
+}
+
+// lane groups (see LaneGroup in lattice.hpp): groups as raw 32-byte records, streams as (x, y) u32 pairs
+void carmel_hip_host_export_lanes(carmel_hip_host_lattices* h, void* groups32, uint32_t* fwd, uint32_t* bwd,
+                                  uint32_t* lane_pair, uint32_t* lane_nstates, double* lane_logw, uint32_t* classes3) {
+  const LatticeSet& L = h->L;
+  std::memcpy(groups32, L.lane_groups.data(), L.lane_groups.size() * sizeof(LaneGroup));
+  std::memcpy(fwd, L.lane_fwd.data(), L.lane_fwd.size() * sizeof(uint2_t));
+  std::memcpy(bwd, L.lane_bwd.data(), L.lane_bwd.size() * sizeof(uint2_t));
+  std::memcpy(lane_pair, L.lane_pair.data(), L.lane_pair.size() * 4);
+  std::memcpy(lane_nstates, L.lane_nstates.data(), L.lane_nstates.size() * 4);
+  std::memcpy(lane_logw, L.lane_logw.data(), L.lane_logw.size() * 8);
+  for (size_t k = 0; k < L.lane_classes.size(); ++k) {
+    classes3[3 * k + 0] = L.lane_classes[k].first;
+    classes3[3 * k + 1] = L.lane_classes[k].count;
+    classes3[3 * k + 2] = L.lane_classes[k].max_states;
+  }
 }
 
 void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,

@@ -18,7 +18,8 @@ namespace carmel_hip {
 
 #define NEG_INF (-__builtin_huge_val())
 
-// streaming logsumexp accumulator: value = m + log(acc)
+// streaming logsumexp accumulator: value = m + log(acc).  A state with a single arc (the common case in sparse
+// lattices) costs no exp and no log: acc stays exactly 1.
 struct Lse {
   double m, acc;
   __device__ __forceinline__ void init() {
@@ -30,11 +31,11 @@ struct Lse {
     if (x <= m) {
       acc += exp(x - m);
     } else {
-      acc = acc * exp(m - x) + 1.0;  // m == -inf: exp(-inf) = 0
+      acc = (m == NEG_INF) ? 1.0 : acc * exp(m - x) + 1.0;
       m = x;
     }
   }
-  __device__ __forceinline__ double value() const { return acc > 0.0 ? m + log(acc) : NEG_INF; }
+  __device__ __forceinline__ double value() const { return acc == 1.0 ? m : (acc > 0.0 ? m + log(acc) : NEG_INF); }
 };
 
 // the reference's own pairwise add (weight.h:765-801) — used by the serial (cyclic-lattice) sweep so that the
@@ -140,6 +141,142 @@ __global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
     atomic_add_f64(A.counts + A.n_arcs + 1, s_wlp);
   }
   if (tid == 0) atomic_add_f64(A.counts + A.n_arcs + 2, (double)d.n_pairs);
+}
+
+// ---------------- lane sweep: one small lattice per lane, 64 per wavefront ----------------
+// Streams are interleaved (record k of lane l at base + k*64 + l): every wave-wide load is one 512-byte row.
+// The lane's forward values live in its own LDS column col[s*64] (conflict-free for any per-lane s); the backward
+// pass overwrites alpha[s] with beta[s] in place — when state s is processed in reverse topological order its
+// alpha is read once, and every destination it needs already holds beta.  No barriers, no offsets, no levels.
+// Loads run two chunks ahead of the arithmetic (records), one chunk ahead (weight gathers): all of them are
+// value-independent, only the LDS column carries the recurrence.
+template <int U>
+__global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const LaneGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t S = active ? A.lane_nstates[g.pair_base + lane] : 0u;
+  const double* __restrict__ logw = A.logw;
+  double* col = lds + lane;
+  const uint32_t maxlen = g.maxlen;
+  // ---------- forward ----------
+  {
+    const uint2* __restrict__ f = A.fwd + g.stream_base + lane;
+    if (active) col[0] = 0.0;
+    uint2 r0[U], r1[U];
+    double w0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r0[u] = ((uint32_t)u < maxlen) ? f[(size_t)u * 64] : make_uint2(0u, 0u);
+      r1[u] = ((uint32_t)(U + u) < maxlen) ? f[(size_t)(U + u) * 64] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) w0[u] = (r0[u].x & LANE_VALID) ? logw[r0[u].y] : 0.0;
+    Lse acc;
+    acc.init();
+    uint32_t d = 1;
+    for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
+      uint2 r2[U];
+      double w1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = k0 + 2 * U + u;
+        r2[u] = (k < maxlen) ? f[(size_t)k * 64] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) w1[u] = (r1[u].x & LANE_VALID) ? logw[r1[u].y] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t x = r0[u].x;
+        if (x & LANE_VALID) {
+          acc.add(col[(x & 0xffffu) * 64] + w0[u]);
+          if (x & LANE_LAST) {
+            col[d * 64] = acc.value();
+            ++d;
+            acc.init();
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        r0[u] = r1[u];
+        r1[u] = r2[u];
+        w0[u] = w1[u];
+      }
+    }
+  }
+  // ---------- ln p(pair), corpus scalars, beta at the goal ----------
+  double s_lp = 0.0, s_wlp = 0.0;
+  if (active) {
+    const double lp = col[(S - 1) * 64];
+    const double lwt = A.lane_logw[g.pair_base + lane];
+    A.pair_logprob[A.lane_pair[g.pair_base + lane]] = lp;
+    s_lp = lp;
+    s_wlp = lp * exp(lwt);
+    col[(S - 1) * 64] = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
+  }
+  // ---------- backward + counts ----------
+  {
+    const uint2* __restrict__ b = A.bwd + g.stream_base + lane;
+    uint2 r0[U], r1[U];
+    double w0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      r0[u] = ((uint32_t)u < maxlen) ? b[(size_t)u * 64] : make_uint2(0u, 0u);
+      r1[u] = ((uint32_t)(U + u) < maxlen) ? b[(size_t)(U + u) * 64] : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) w0[u] = (r0[u].x & LANE_VALID) ? logw[r0[u].y] : 0.0;
+    Lse acc;
+    acc.init();
+    uint32_t s = S >= 2 ? S - 2 : 0u;
+    double al = (S >= 2) ? col[s * 64] : NEG_INF;
+    for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
+      uint2 r2[U];
+      double w1[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = k0 + 2 * U + u;
+        r2[u] = (k < maxlen) ? b[(size_t)k * 64] : make_uint2(0u, 0u);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) w1[u] = (r1[u].x & LANE_VALID) ? logw[r1[u].y] : 0.0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t x = r0[u].x;
+        if (x & LANE_VALID) {
+          const double t = w0[u] + col[(x & 0xffffu) * 64];
+          acc.add(t);
+          const double c = exp(al + t);
+          if (c > 0.0) atomic_add_f64(A.counts + r0[u].y, c);
+          if (x & LANE_LAST) {
+            col[s * 64] = acc.value();  // beta[s] replaces alpha[s]
+            acc.init();
+            if (s > 0) {
+              --s;
+              al = col[s * 64];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        r0[u] = r1[u];
+        r1[u] = r2[u];
+        w0[u] = w1[u];
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s_lp += __shfl_down(s_lp, o, 64);
+    s_wlp += __shfl_down(s_wlp, o, 64);
+  }
+  if (lane == 0) {
+    atomic_add_f64(A.counts + A.n_arcs + 0, s_lp);
+    atomic_add_f64(A.counts + A.n_arcs + 1, s_wlp);
+    atomic_add_f64(A.counts + A.n_arcs + 2, (double)g.n_lanes);
+  }
 }
 
 // Cyclic lattices (derivations.h:726-728 "Forward/backward will miss some paths"): one lane per lattice walks
@@ -300,6 +437,16 @@ static inline int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
+hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc, hipStream_t stream) {
+  LaneArgs A = A0;
+  A.first_group = lc.first;
+  size_t lds = (size_t)lc.max_states * 64 * sizeof(double);
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sweep_lane_kernel<4>), dim3(lc.count), dim3(64), lds, stream, A);
+  return hipGetLastError();
+}
+
 hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, hipStream_t stream) {
   SweepArgs A = A0;
   A.first_bundle = lc.first;
@@ -317,7 +464,7 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
   } else if (lc.block == 256) {
     hipLaunchKernelGGL((sweep_bundle_kernel<256, true>), dim3(lc.count), dim3(256), lds, stream, A);
   } else {
-    hipFuncSetAttribute((const void*)sweep_bundle_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)sweep_bundle_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                         (int)lds);
     hipLaunchKernelGGL((sweep_bundle_kernel<1024, true>), dim3(lc.count), dim3(1024), lds, stream, A);
   }

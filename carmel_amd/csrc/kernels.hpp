@@ -41,6 +41,20 @@ struct MstepArgs {
   int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
 };
 
+struct LaneArgs {
+  const LaneGroup* groups;
+  const uint2* fwd;
+  const uint2* bwd;
+  const uint32_t* lane_pair;
+  const uint32_t* lane_nstates;
+  const double* lane_logw;
+  const double* logw;
+  double* counts;
+  double* pair_logprob;
+  uint64_t n_arcs;
+  uint32_t first_group;
+};
+hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);

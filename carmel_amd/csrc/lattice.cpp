@@ -481,11 +481,13 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   // ---- pack into bundles ----
   // small lattices: sort by (levels, states) so that a bundle's members have similar depth (level-synchronous
   // sweeps idle the lanes of members that ran out of levels)
-  std::vector<uint32_t> small, big, cyc;
+  std::vector<uint32_t> small, big, cyc, lane;
   for (uint32_t p : kept) {
     const PairLattice& L = lats[p];
     if (L.cyclic)
       cyc.push_back(p);
+    else if (opt.lane_states && L.n_states <= opt.lane_states)
+      lane.push_back(p);
     else if (L.n_states * 4 <= opt.small_states)
       small.push_back(p);
     else
@@ -496,6 +498,126 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     return lats[a].n_states > lats[b].n_states;
   });
   std::stable_sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return lats[a].n_states < lats[b].n_states; });
+  // ---- lane groups: one lattice per lane, 64 per wavefront ----
+  if (!lane.empty()) {
+    std::stable_sort(lane.begin(), lane.end(), [&](uint32_t a, uint32_t b) {
+      if (lats[a].edges.size() != lats[b].edges.size()) return lats[a].edges.size() > lats[b].edges.size();
+      return lats[a].n_states > lats[b].n_states;
+    });
+    size_t ng = (lane.size() + 63) / 64;
+    out.lane_groups.resize(ng);
+    out.lane_pair.assign(ng * 64, 0xffffffffu);
+    out.lane_nstates.assign(ng * 64, 0);
+    out.lane_logw.assign(ng * 64, 0.0);
+    uint64_t base = 0;
+    for (size_t g = 0; g < ng; ++g) {
+      LaneGroup& G = out.lane_groups[g];
+      std::memset(&G, 0, sizeof G);
+      size_t l0 = g * 64, l1 = std::min(lane.size(), l0 + 64);
+      G.stream_base = base;
+      G.n_lanes = (uint32_t)(l1 - l0);
+      G.pair_base = (uint32_t)l0;
+      uint32_t ml = 0, ms = 0;
+      for (size_t l = l0; l < l1; ++l) {
+        ml = std::max<uint32_t>(ml, (uint32_t)lats[lane[l]].edges.size());
+        ms = std::max(ms, lats[lane[l]].n_states);
+      }
+      G.maxlen = ml;
+      G.max_states = ms;
+      base += (uint64_t)ml * 64;
+    }
+    out.lane_fwd.assign(base, uint2_t{0, 0});
+    out.lane_bwd.assign(base, uint2_t{0, 0});
+    // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
+    {
+      size_t i = 0;
+      while (i < ng) {
+        uint32_t mx = out.lane_groups[i].max_states;
+        size_t j = i + 1;
+        while (j < ng) {
+          uint32_t m = out.lane_groups[j].max_states;
+          if (m > mx) mx = m;
+          if (j - i >= 256 && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;  // LDS waste <= 1.5x, few launches
+          ++j;
+        }
+        out.lane_classes.push_back(LatticeSet::LaneClass{(uint32_t)i, (uint32_t)(j - i), mx});
+        i = j;
+      }
+    }
+    std::atomic<size_t> nextg(0);
+    auto lwork = [&]() {
+      std::vector<uint32_t> order, newid, ioff, ooff, cur;
+      std::vector<uint32_t> ie, oe;
+      for (;;) {
+        size_t g = nextg.fetch_add(4);
+        if (g >= ng) break;
+        size_t ge = std::min(ng, g + 4);
+        for (; g < ge; ++g) {
+          const LaneGroup& G = out.lane_groups[g];
+          for (uint32_t l = 0; l < G.n_lanes; ++l) {
+            uint32_t p = lane[G.pair_base + l];
+            const PairLattice& L = lats[p];
+            const uint32_t S = L.n_states;
+            out.lane_pair[G.pair_base + l] = p;
+            out.lane_nstates[G.pair_base + l] = S;
+            double wt = c.weight.empty() ? 1.0 : c.weight[p];
+            out.lane_logw[G.pair_base + l] = wt > 0 ? std::log(wt) : -std::numeric_limits<double>::infinity();
+            // topological numbering: by (level, id); the start is alone on level 0, the goal alone on the last
+            order.resize(S);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return L.level[a] < L.level[b]; });
+            newid.resize(S);
+            for (uint32_t k = 0; k < S; ++k) newid[order[k]] = k;
+            const size_t E = L.edges.size();
+            ioff.assign((size_t)S + 1, 0);
+            ooff.assign((size_t)S + 1, 0);
+            for (auto& e : L.edges) {
+              ioff[newid[e.dst] + 1]++;
+              ooff[newid[e.src] + 1]++;
+            }
+            for (uint32_t k = 0; k < S; ++k) {
+              ioff[k + 1] += ioff[k];
+              ooff[k + 1] += ooff[k];
+            }
+            ie.resize(E);
+            oe.resize(E);
+            cur.assign(ioff.begin(), ioff.end() - 1);
+            for (uint32_t k = 0; k < E; ++k) ie[cur[newid[L.edges[k].dst]]++] = k;
+            cur.assign(ooff.begin(), ooff.end() - 1);
+            for (uint32_t k = 0; k < E; ++k) oe[cur[newid[L.edges[k].src]]++] = k;
+            uint2_t* f = out.lane_fwd.data() + G.stream_base + l;
+            uint2_t* b = out.lane_bwd.data() + G.stream_base + l;
+            size_t pos = 0;
+            for (uint32_t d = 1; d < S; ++d)
+              for (uint32_t k = ioff[d]; k < ioff[d + 1]; ++k) {
+                const auto& e = L.edges[ie[k]];
+                uint32_t x = newid[e.src] | LANE_VALID | (k + 1 == ioff[d + 1] ? LANE_LAST : 0u);
+                f[(pos++) * 64] = uint2_t{x, e.arc};
+              }
+            pos = 0;
+            for (uint32_t sidx = S; sidx-- > 0;) {
+              if (sidx == S - 1) continue;  // the goal has no out-arcs
+              for (uint32_t k = ooff[sidx]; k < ooff[sidx + 1]; ++k) {
+                const auto& e = L.edges[oe[k]];
+                uint32_t x = newid[e.dst] | LANE_VALID | (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
+                b[(pos++) * 64] = uint2_t{x, e.arc};
+              }
+            }
+          }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    int nt3 = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, ng / 4));
+    for (int t = 1; t < nt3; ++t) th.emplace_back(lwork);
+    lwork();
+    for (auto& t : th) t.join();
+    for (uint32_t p : lane) {
+      out.lane_states += lats[p].n_states;
+      out.lane_arcs += lats[p].edges.size();
+      out.max_levels = std::max<uint64_t>(out.max_levels, lats[p].n_levels);
+    }
+  }
   std::vector<BundlePlan> plans;
   {
     BundlePlan cur;
@@ -591,8 +713,8 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       return false;
     }
   }
-  out.total_arcs = arc_base;
-  out.total_states = off_base - nb;
+  out.total_arcs = arc_base + out.lane_arcs;
+  out.total_states = off_base - nb + out.lane_states;
   out.in_arcs.resize(arc_base);
   out.out_arcs.resize(arc_base);
   out.in_off.resize(off_base);

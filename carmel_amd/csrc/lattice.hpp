@@ -66,6 +66,23 @@ struct uint2_t {
   uint32_t x, y;
 };
 
+// Lane groups: 64 small acyclic lattices swept by ONE wavefront, one lattice per lane.  Each lattice is flattened
+// into two record streams (forward: in-arcs grouped by destination in topological order; backward: out-arcs
+// grouped by source in reverse topological order) and the 64 streams are interleaved record by record, so every
+// wave-wide load is one coalesced 512-byte row and the topology needs no offsets, no levels and no barriers.
+// record.x = local state index (bits 0..15) | LANE_VALID | LANE_LAST (last arc of its state); record.y = WFST arc id
+static const uint32_t LANE_LAST = 0x80000000u;
+static const uint32_t LANE_VALID = 0x40000000u;
+struct LaneGroup {        // mirrored on the device, 32 bytes
+  uint64_t stream_base;   // into lane_fwd[] / lane_bwd[] (maxlen * 64 records each)
+  uint32_t maxlen;        // records per lane (shorter lattices are padded with invalid records)
+  uint32_t n_lanes;       // lattices in this group (<= 64)
+  uint32_t pair_base;     // into lane_pair[] / lane_nstates[] / lane_logw[]
+  uint32_t max_states;
+  uint64_t pad;
+};
+static_assert(sizeof(LaneGroup) == 32, "LaneGroup layout");
+
 struct LatticeSet {
   std::vector<BundleDesc> bundles;
   std::vector<uint2_t> in_arcs, out_arcs;
@@ -81,6 +98,16 @@ struct LatticeSet {
     bool serial;             // cyclic bundles
   };
   std::vector<LaunchClass> classes;
+  // lane groups (see LaneGroup)
+  std::vector<LaneGroup> lane_groups;
+  std::vector<uint2_t> lane_fwd, lane_bwd;
+  std::vector<uint32_t> lane_pair, lane_nstates;
+  std::vector<double> lane_logw;
+  struct LaneClass {
+    uint32_t first, count, max_states;
+  };
+  std::vector<LaneClass> lane_classes;
+  uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
   uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
   uint64_t explored_states = 0, explored_arcs = 0;
   std::vector<uint8_t> has_deriv;
@@ -93,6 +120,7 @@ struct BuildOptions {
   uint32_t small_pairs = 64;       // lattices per small bundle (one wavefront wide)
   uint32_t small_states = 2048;    // state cap of a small bundle (16 KiB of f64 in LDS)
   uint32_t lds_states_max = 16384; // one array of f64 in LDS: 128 KiB
+  uint32_t lane_states = 96;       // lattices up to this many states go one-per-lane (0 disables lane groups)
 };
 
 // Builds every pair's lattice (parallel over pairs) and packs them.  Returns false + err on failure.

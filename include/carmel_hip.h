@@ -161,8 +161,10 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
                           const uint32_t* src, const uint32_t* dst, const uint32_t* in_sym, const uint32_t* out_sym,
                           uint64_t n_pairs, const uint64_t* in_off, const uint32_t* cin, const uint64_t* out_off,
                           const uint32_t* cout, const double* pair_weight, int prune, int threads,
-                          uint32_t small_pairs, uint32_t small_states);
-void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims10);
+                          uint32_t small_pairs, uint32_t small_states, int lane_states);
+void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims16);
+void carmel_hip_host_export_lanes(carmel_hip_host_lattices* h, void* groups32, uint32_t* fwd, uint32_t* bwd,
+                                  uint32_t* lane_pair, uint32_t* lane_nstates, double* lane_logw, uint32_t* classes3);
 void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,
                             uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
                             uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,

@@ -12,13 +12,20 @@ BUNDLE_DTYPE = np.dtype([("in_base", "<u8"), ("out_base", "<u8"), ("off_base", "
 assert BUNDLE_DTYPE.itemsize == 64
 
 
-def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0):
+LANE_DTYPE = np.dtype([("stream_base", "<u8"), ("maxlen", "<u4"), ("n_lanes", "<u4"), ("pair_base", "<u4"),
+                       ("max_states", "<u4"), ("pad", "<u8")])
+assert LANE_DTYPE.itemsize == 32
+LANE_LAST, LANE_VALID = 0x80000000, 0x40000000
+
+
+def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, lane_states=-1):
     h = C.c_void_p()
     rc = lib.carmel_hip_host_build(C.byref(h), w.n_states, w.final, w.n_arcs, ptr(w.src), ptr(w.dst), ptr(w.isym),
                                    ptr(w.osym), c.n_pairs, ptr(c.in_off), ptr(c.in_sym), ptr(c.out_off),
-                                   ptr(c.out_sym), ptr(c.weight), int(prune), threads, small_pairs, small_states)
+                                   ptr(c.out_sym), ptr(c.weight), int(prune), threads, small_pairs, small_states,
+                                   lane_states)
     assert rc == 0
-    dims = np.zeros(10, np.uint64)
+    dims = np.zeros(16, np.uint64)
     lib.carmel_hip_host_dims(h, ptr(dims))
     nb, noff, na, nlev, npair, ncls = (int(x) for x in dims[:6])
     out = dict(bundles=np.zeros(nb, BUNDLE_DTYPE), in_arcs=np.zeros((na, 2), np.uint32),
@@ -31,6 +38,14 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0):
                                ptr(out["out_off"]), ptr(out["level_off"]), ptr(out["pair_start"]),
                                ptr(out["pair_final"]), ptr(out["pair_id"]), ptr(out["pair_logw"]),
                                ptr(out["classes"]), ptr(out["has_deriv"]))
+    ng, nrec, nslot, nlc = (int(x) for x in dims[10:14])
+    out.update(lane_groups=np.zeros(ng, LANE_DTYPE), lane_fwd=np.zeros((nrec, 2), np.uint32),
+               lane_bwd=np.zeros((nrec, 2), np.uint32), lane_pair=np.zeros(nslot, np.uint32),
+               lane_nstates=np.zeros(nslot, np.uint32), lane_logw=np.zeros(nslot),
+               lane_classes=np.zeros((nlc, 3), np.uint32), total_states=int(dims[14]), total_arcs=int(dims[15]))
+    lib.carmel_hip_host_export_lanes(h, ptr(out["lane_groups"]), ptr(out["lane_fwd"]), ptr(out["lane_bwd"]),
+                                     ptr(out["lane_pair"]), ptr(out["lane_nstates"]), ptr(out["lane_logw"]),
+                                     ptr(out["lane_classes"]))
     lib.carmel_hip_host_free(h)
     out.update(n_kept=int(dims[6]), n_cyclic=int(dims[7]), explored_states=int(dims[8]), explored_arcs=int(dims[9]))
     return out
@@ -59,11 +74,50 @@ def _lwadd(a, b):
     return (b + np.log1p(np.exp(d))) if d < 0 else (a + np.log1p(np.exp(-d)))
 
 
+def alpha_s(col, s):
+    return col[s]
+
+
 def numpy_sweep(img, logw, n_pairs_total):
     """forward / backward / counts over the bundle image exactly as kernels.hip walks it.
     Returns (counts linear per WFST arc, per-pair ln prob)."""
     counts = np.zeros(len(logw))
     plp = np.full(n_pairs_total, -np.inf)
+    # lane groups: the per-lane record streams exactly as sweep_lane_kernel consumes them
+    for g in img.get("lane_groups", []):
+        base, ml = int(g["stream_base"]), int(g["maxlen"])
+        for l in range(int(g["n_lanes"])):
+            slot = int(g["pair_base"]) + l
+            S = int(img["lane_nstates"][slot])
+            col = np.full(S, -np.inf)
+            col[0] = 0.0
+            d, terms = 1, []
+            for k in range(ml):
+                x, arc = img["lane_fwd"][base + k * 64 + l]
+                if not x & LANE_VALID:
+                    continue
+                assert (x & 0xffff) < d
+                terms.append(col[x & 0xffff] + logw[arc])
+                if x & LANE_LAST:
+                    col[d] = _lse(terms)
+                    d, terms = d + 1, []
+            assert d == S and not terms
+            lp = col[S - 1]
+            plp[img["lane_pair"][slot]] = lp
+            col[S - 1] = img["lane_logw"][slot] - lp
+            s, terms = S - 2, []
+            for k in range(ml):
+                x, arc = img["lane_bwd"][base + k * 64 + l]
+                if not x & LANE_VALID:
+                    continue
+                assert (x & 0xffff) > s
+                t = logw[arc] + col[x & 0xffff]
+                counts[arc] += np.exp(alpha_s(col, s) + t)
+                terms.append(t)
+                if x & LANE_LAST:
+                    col[s] = _lse(terms)
+                    s, terms = s - 1, []
+            assert s == -1 and not terms
     for b in img["bundles"]:
         ns = int(b["n_states"])
         ob, ib, ab = int(b["off_base"]), int(b["in_base"]), int(b["out_base"])

@@ -17,7 +17,7 @@ def ambiguous(seed, n_states=40, deg=8, n_sym=4, n_pairs=60, p_eps=0.15):
 def test_lattice_matches_oracle_structure(oracle, seed):
     w, c = ambiguous(seed)
     ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
-    img = host_lattices(w, c, small_pairs=8, small_states=512)
+    img = host_lattices(w, c, small_pairs=8, small_states=512, lane_states=0)
     r = oracle.estimate(ow, oc)
     assert np.array_equal(img["has_deriv"].astype(bool), r["has_deriv"])
     # exploration statistics are the reference's (derivations.h:191-247): same DFS, same counts
@@ -39,11 +39,15 @@ def test_lattice_matches_oracle_structure(oracle, seed):
             assert np.array_equal(arcs, np.sort(L["arcid"]))
 
 
-@pytest.mark.parametrize("seed,small_pairs", [(1, 8), (2, 64), (5, 3)])
-def test_layout_sweep_matches_oracle_estep(oracle, seed, small_pairs):
-    w, c = ambiguous(seed)
+@pytest.mark.parametrize("seed,small_pairs,lane_states", [(1, 8, 0), (2, 64, 0), (5, 3, 0), (1, 8, 96), (2, 8, 20),
+                                                          (6, 8, 12)])
+def test_layout_sweep_matches_oracle_estep(oracle, seed, small_pairs, lane_states):
+    w, c = ambiguous(seed, n_pairs=150)
     ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
-    img = host_lattices(w, c, small_pairs=small_pairs, small_states=1024)
+    img = host_lattices(w, c, small_pairs=small_pairs, small_states=1024, lane_states=lane_states)
+    if lane_states:
+        assert len(img["lane_groups"]) > 0
+        assert int(img["lane_nstates"].max()) <= lane_states
     r = oracle.estimate(ow, oc)
     counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
     ok = r["has_deriv"]
@@ -57,7 +61,7 @@ def test_layout_sweep_matches_oracle_estep(oracle, seed, small_pairs):
 
 def test_levels_are_topological(oracle):
     w, c = ambiguous(9, n_states=30, deg=10, n_sym=3, n_pairs=40)
-    img = host_lattices(w, c, small_pairs=16, small_states=2048)
+    img = host_lattices(w, c, small_pairs=16, small_states=2048, lane_states=0)
     for b in img["bundles"]:
         if b["flags"] & 1:
             continue
