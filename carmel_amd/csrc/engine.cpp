@@ -4,6 +4,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <limits>
 #include <string>
 #include <unordered_map>
@@ -83,7 +84,10 @@ struct carmel_hip_trainer {
   DevBuf<LaneGroup> lane_groups;
   DevBuf<uint2_t> lane_fwd, lane_bwd;
   DevBuf<uint32_t> lane_pair, lane_nstates;
-  DevBuf<double> lane_logw;
+  DevBuf<double> lane_logw, post;
+  DevBuf<uint32_t> slot_arc;
+  DevBuf<uint64_t> slot_pos;
+  uint64_t lane_records = 0;
   uint64_t device_bytes = 0;
 
   double* ext_counts = nullptr;  // caller-owned n_arcs + 4 doubles (carmel_hip_use_external_counts)
@@ -225,22 +229,28 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->lane_pair.upload(L.lane_pair, s));
   HIPCHK(t->lane_nstates.upload(L.lane_nstates, s));
   HIPCHK(t->lane_logw.upload(L.lane_logw, s));
+  t->lane_records = L.lane_bwd.size();
+  HIPCHK(t->post.alloc(L.n_post));
+  HIPCHK(t->slot_arc.upload(L.slot_arc, s));
+  HIPCHK(t->slot_pos.upload(L.slot_pos, s));
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
-  HIPCHK(t->alpha_g.alloc(L.in_off.size()));
-  bool need_beta = false;
-  for (auto& lc : L.classes)
-    if (lc.serial || lc.max_states == 0) need_beta = true;
-  if (need_beta)
-    HIPCHK(t->beta_g.alloc(L.in_off.size()));
-  else
-    t->beta_g.release();
+  bool need_val = false, need_val2 = false;
+  for (auto& lc : L.classes) {
+    if (lc.serial || lc.max_states == 0) need_val = true;
+    if (lc.serial) need_val2 = true;
+  }
+  HIPCHK(t->alpha_g.alloc(need_val ? L.in_off.size() : 0));
+  HIPCHK(t->beta_g.alloc(need_val2 ? L.in_off.size() : 0));
   HIPCHK(launch_fill(t->pair_logprob.p, -std::numeric_limits<double>::infinity(), t->corpus.n_pairs, s));
   HIPCHK(hipStreamSynchronize(s));
   t->device_bytes = t->bundles.bytes() + t->in_arcs.bytes() + t->out_arcs.bytes() + t->in_off.bytes() +
                     t->out_off.bytes() + t->level_off.bytes() + t->pair_start.bytes() + t->pair_final.bytes() +
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
-                    t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes();
+                    t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() +
+                    t->slot_arc.bytes() + t->slot_pos.bytes();
+  std::vector<uint32_t>().swap(L.slot_arc);
+  std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
   std::vector<uint2_t>().swap(L.lane_bwd);
   // free the bulk host arrays; keep descriptors + classes
@@ -459,11 +469,11 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   A.pair_id = t->pair_id.p;
   A.pair_logw = t->pair_logw.p;
   A.logw = t->arc_logw.p;
-  A.counts = t->counts_ptr();
+  A.post = t->post.p + t->lane_records;
+  A.scalars = t->counts_ptr() + t->w.n_arcs;
   A.pair_logprob = t->pair_logprob.p;
-  A.alpha_g = t->alpha_g.p;
-  A.beta_g = t->beta_g.p;
-  A.n_arcs = t->w.n_arcs;
+  A.val_g = t->alpha_g.p;
+  A.val2_g = t->beta_g.p;
   A.first_bundle = 0;
   LaneArgs LA;
   LA.groups = t->lane_groups.p;
@@ -473,13 +483,20 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   LA.lane_nstates = t->lane_nstates.p;
   LA.lane_logw = t->lane_logw.p;
   LA.logw = t->arc_logw.p;
-  LA.counts = t->counts_ptr();
+  LA.post = t->post.p;
+  LA.scalars = t->counts_ptr() + t->w.n_arcs;
   LA.pair_logprob = t->pair_logprob.p;
-  LA.n_arcs = t->w.n_arcs;
   LA.first_group = 0;
   HIPCHK(hipEventRecord(t->ev0, s));
   for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
+  ReduceArgs R;
+  R.slot_arc = t->slot_arc.p;
+  R.slot_pos = t->slot_pos.p;
+  R.post = t->post.p;
+  R.counts = t->counts_ptr();
+  R.n = t->slot_arc.n;
+  HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipEventRecord(t->ev1, s));
   return CARMEL_HIP_OK;
 }

@@ -13,6 +13,7 @@
 // addends more than 36 nats smaller; here each state's sum is one streaming logsumexp (running max + scaled
 // sum), which differs from that only in the last bits (e^-36 ~ 2e-16).
 #include "kernels.hpp"
+#include <cstdlib>
 
 namespace carmel_hip {
 
@@ -56,100 +57,14 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 }
 
 
-// One workgroup sweeps one bundle: forward (alpha in LDS, also streamed to alpha_g), then backward fused with
-// count accumulation (beta in LDS, alpha re-read coalesced from alpha_g).
-// USE_LDS=false: alpha/beta live in global scratch (lattices above the LDS cap).
-template <int BLOCK, bool USE_LDS>
-__global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const BundleDesc d = A.bundles[A.first_bundle + blockIdx.x];
-  const int tid = threadIdx.x;
-  const uint32_t ns = d.n_states;
-  const uint2* __restrict__ ia = A.in_arcs + d.in_base;
-  const uint2* __restrict__ oa = A.out_arcs + d.out_base;
-  const uint32_t* __restrict__ ioff = A.in_off + d.off_base;
-  const uint32_t* __restrict__ ooff = A.out_off + d.off_base;
-  const uint32_t* __restrict__ lvl = A.level_off + d.level_base;
-  const double* __restrict__ logw = A.logw;
-  double* ag = A.alpha_g + d.off_base;
-  double* val = USE_LDS ? lds : (A.beta_g + d.off_base);  // alpha during forward, beta during backward
-  // ---- forward ----
-  for (uint32_t s = tid; s < ns; s += BLOCK) val[s] = NEG_INF;
-  __syncthreads();
-  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) val[A.pair_start[d.pair_base + p]] = 0.0;
-  __syncthreads();
-  for (uint32_t l = 1; l < d.n_levels; ++l) {
-    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
-    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
-      const uint32_t a0 = ioff[s], a1 = ioff[s + 1];
-      Lse acc;
-      acc.init();
-      for (uint32_t a = a0; a < a1; ++a) {
-        const uint2 r = ia[a];
-        acc.add(val[r.x] + logw[r.y]);
-      }
-      val[s] = acc.value();
-    }
-    __syncthreads();
-  }
-  for (uint32_t s = tid; s < ns; s += BLOCK) ag[s] = val[s];
-  // per pair: ln p(pair) = alpha[final]; corpus scalars
-  double s_lp = 0.0, s_wlp = 0.0;
-  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
-    const double lp = val[A.pair_final[d.pair_base + p]];
-    A.pair_logprob[A.pair_id[d.pair_base + p]] = lp;
-    s_lp += lp;
-    s_wlp += lp * exp(A.pair_logw[d.pair_base + p]);
-  }
-  __syncthreads();
-  // ---- backward + counts ----
-  // beta[final] = ln(weight) - ln p(pair): folds "* weight / prob" of derivations.h:445 into the sweep
-  for (uint32_t s = tid; s < ns; s += BLOCK) val[s] = NEG_INF;
-  __syncthreads();
-  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
-    const uint32_t f = A.pair_final[d.pair_base + p];
-    const double lp = ag[f];
-    val[f] = (lp == NEG_INF) ? NEG_INF : A.pair_logw[d.pair_base + p] - lp;
-  }
-  __syncthreads();
-  for (uint32_t l = d.n_levels; l-- > 0;) {
-    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
-    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
-      const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
-      if (a0 == a1) continue;  // goal states keep their initial value
-      const double al = ag[s];
-      Lse acc;
-      acc.init();
-      for (uint32_t a = a0; a < a1; ++a) {
-        const uint2 r = oa[a];
-        const double t = logw[r.y] + val[r.x];
-        acc.add(t);
-        const double c = exp(al + t);
-        if (c > 0.0) atomic_add_f64(A.counts + r.y, c);
-      }
-      val[s] = acc.value();
-    }
-    __syncthreads();
-  }
-  // corpus scalars: wave reduce then one atomic per wave
-  for (int o = 32; o > 0; o >>= 1) {
-    s_lp += __shfl_down(s_lp, o, 64);
-    s_wlp += __shfl_down(s_wlp, o, 64);
-  }
-  if ((tid & 63) == 0 && (s_lp != 0.0 || s_wlp != 0.0)) {
-    atomic_add_f64(A.counts + A.n_arcs + 0, s_lp);
-    atomic_add_f64(A.counts + A.n_arcs + 1, s_wlp);
-  }
-  if (tid == 0) atomic_add_f64(A.counts + A.n_arcs + 2, (double)d.n_pairs);
-}
-
 // ---------------- lane sweep: one small lattice per lane, 64 per wavefront ----------------
 // Streams are interleaved (record k of lane l at base + k*64 + l): every wave-wide load is one 512-byte row.
 // The lane's forward values live in its own LDS column col[s*64] (conflict-free for any per-lane s); the backward
 // pass overwrites alpha[s] with beta[s] in place — when state s is processed in reverse topological order its
 // alpha is read once, and every destination it needs already holds beta.  No barriers, no offsets, no levels.
 // Loads run two chunks ahead of the arithmetic (records), one chunk ahead (weight gathers): all of them are
-// value-independent, only the LDS column carries the recurrence.
+// value-independent, only the LDS column carries the recurrence.  Posteriors go to post[] at the record's own
+// position (coalesced 512-byte rows).
 template <int U>
 __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -216,9 +131,10 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     s_wlp = lp * exp(lwt);
     col[(S - 1) * 64] = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
   }
-  // ---------- backward + counts ----------
+  // ---------- backward + posteriors ----------
   {
     const uint2* __restrict__ b = A.bwd + g.stream_base + lane;
+    double* __restrict__ post = A.post + g.stream_base + lane;
     uint2 r0[U], r1[U];
     double w0[U];
 #pragma unroll
@@ -248,8 +164,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
         if (x & LANE_VALID) {
           const double t = w0[u] + col[(x & 0xffffu) * 64];
           acc.add(t);
-          const double c = exp(al + t);
-          if (c > 0.0) atomic_add_f64(A.counts + r0[u].y, c);
+          post[(size_t)(k0 + u) * 64] = exp(al + t);
           if (x & LANE_LAST) {
             col[s * 64] = acc.value();  // beta[s] replaces alpha[s]
             acc.init();
@@ -273,10 +188,90 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     s_wlp += __shfl_down(s_wlp, o, 64);
   }
   if (lane == 0) {
-    atomic_add_f64(A.counts + A.n_arcs + 0, s_lp);
-    atomic_add_f64(A.counts + A.n_arcs + 1, s_wlp);
-    atomic_add_f64(A.counts + A.n_arcs + 2, (double)g.n_lanes);
+    atomic_add_f64(A.scalars + 0, s_lp);
+    atomic_add_f64(A.scalars + 1, s_wlp);
+    atomic_add_f64(A.scalars + 2, (double)g.n_lanes);
   }
+}
+
+// ---------------- bundle sweep: one workgroup per bundle of lattices, level-synchronous ----------------
+// forward (alpha in LDS), then backward in place: a state's alpha is read once when its level is processed and
+// replaced by its beta; destinations lie in later levels and already hold beta.  Posteriors go to post[] at the
+// out-arc's position.  USE_LDS=false: the values live in global scratch (lattices above the LDS cap).
+template <int BLOCK, bool USE_LDS>
+__global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const BundleDesc d = A.bundles[A.first_bundle + blockIdx.x];
+  const int tid = threadIdx.x;
+  const uint32_t ns = d.n_states;
+  const uint2* __restrict__ ia = A.in_arcs + d.in_base;
+  const uint2* __restrict__ oa = A.out_arcs + d.out_base;
+  const uint32_t* __restrict__ ioff = A.in_off + d.off_base;
+  const uint32_t* __restrict__ ooff = A.out_off + d.off_base;
+  const uint32_t* __restrict__ lvl = A.level_off + d.level_base;
+  const double* __restrict__ logw = A.logw;
+  double* post = A.post + d.out_base;
+  double* val = USE_LDS ? lds : (A.val_g + d.off_base);
+  // ---- forward ----
+  for (uint32_t s = tid; s < ns; s += BLOCK) val[s] = NEG_INF;
+  __syncthreads();
+  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) val[A.pair_start[d.pair_base + p]] = 0.0;
+  __syncthreads();
+  for (uint32_t l = 1; l < d.n_levels; ++l) {
+    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
+    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
+      const uint32_t a0 = ioff[s], a1 = ioff[s + 1];
+      Lse acc;
+      acc.init();
+      for (uint32_t a = a0; a < a1; ++a) {
+        const uint2 r = ia[a];
+        acc.add(val[r.x] + logw[r.y]);
+      }
+      val[s] = acc.value();
+    }
+    __syncthreads();
+  }
+  // per pair: ln p(pair) = alpha[goal]; beta[goal] = ln(weight) - ln p(pair) folds "* weight / prob"
+  // (derivations.h:445) into the sweep.  Goals have no out-arcs, so nothing else reads their alpha.
+  double s_lp = 0.0, s_wlp = 0.0;
+  for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
+    const uint32_t f = A.pair_final[d.pair_base + p];
+    const double lp = val[f];
+    const double lwt = A.pair_logw[d.pair_base + p];
+    A.pair_logprob[A.pair_id[d.pair_base + p]] = lp;
+    s_lp += lp;
+    s_wlp += lp * exp(lwt);
+    val[f] = (lp == NEG_INF) ? NEG_INF : lwt - lp;
+  }
+  __syncthreads();
+  // ---- backward + posteriors ----
+  for (uint32_t l = d.n_levels; l-- > 0;) {
+    const uint32_t s0 = lvl[l], s1 = lvl[l + 1];
+    for (uint32_t s = s0 + tid; s < s1; s += BLOCK) {
+      const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+      if (a0 == a1) continue;  // goal states keep beta[goal]
+      const double al = val[s];
+      Lse acc;
+      acc.init();
+      for (uint32_t a = a0; a < a1; ++a) {
+        const uint2 r = oa[a];
+        const double t = logw[r.y] + val[r.x];
+        acc.add(t);
+        post[a] = exp(al + t);
+      }
+      val[s] = acc.value();
+    }
+    __syncthreads();
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    s_lp += __shfl_down(s_lp, o, 64);
+    s_wlp += __shfl_down(s_wlp, o, 64);
+  }
+  if ((tid & 63) == 0 && (s_lp != 0.0 || s_wlp != 0.0)) {
+    atomic_add_f64(A.scalars + 0, s_lp);
+    atomic_add_f64(A.scalars + 1, s_wlp);
+  }
+  if (tid == 0) atomic_add_f64(A.scalars + 2, (double)d.n_pairs);
 }
 
 // Cyclic lattices (derivations.h:726-728 "Forward/backward will miss some paths"): one lane per lattice walks
@@ -291,8 +286,9 @@ __global__ void sweep_serial_kernel(SweepArgs A, uint32_t n_bundles) {
   const uint2* oa = A.out_arcs + d.out_base;
   const uint32_t* ioff = A.in_off + d.off_base;
   const uint32_t* ooff = A.out_off + d.off_base;
-  double* f = A.alpha_g + d.off_base;
-  double* bb = A.beta_g + d.off_base;
+  double* f = A.val_g + d.off_base;
+  double* bb = A.val2_g + d.off_base;
+  double* post = A.post + d.out_base;
   const uint32_t ns = d.n_states;
   const uint32_t st = A.pair_start[d.pair_base], fin = A.pair_final[d.pair_base];
   for (uint32_t s = 0; s < ns; ++s) {
@@ -316,17 +312,48 @@ __global__ void sweep_serial_kernel(SweepArgs A, uint32_t n_bundles) {
       bb[r.x] = lw_add(bb[r.x], bb[s] + A.logw[r.y]);
     }
   }
-  if (prob != NEG_INF) {
-    for (uint32_t s = 0; s < ns; ++s)
-      for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) {
-        const uint2 r = oa[a];
-        const double c = exp(A.logw[r.y] + f[s] + bb[r.x] + lwt - prob);
-        if (c > 0.0) atomic_add_f64(A.counts + r.y, c);
-      }
+  for (uint32_t s = 0; s < ns; ++s)
+    for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) {
+      const uint2 r = oa[a];
+      post[a] = (prob != NEG_INF) ? exp(A.logw[r.y] + f[s] + bb[r.x] + lwt - prob) : 0.0;
+    }
+  atomic_add_f64(A.scalars + 0, prob);
+  atomic_add_f64(A.scalars + 1, prob * exp(lwt));
+  atomic_add_f64(A.scalars + 2, 1.0);
+}
+
+// ---------------- expected counts: segmented reduction of posteriors by WFST arc ----------------
+// Entry k (sorted by arc id on the host) says: the posterior at post[slot_pos[k]] belongs to arc slot_arc[k].
+// Each wave takes 64 consecutive entries, does a segmented scan over equal arc ids with shuffles and lets the
+// last lane of every segment write: a segment strictly inside the wave is complete (plain store); one touching the
+// wave's first or last lane may continue in a neighbour wave (atomic add — neighbours hit neighbouring addresses,
+// so these are few and cache-friendly).  counts must be zero on entry.
+__global__ __launch_bounds__(256) void count_reduce_kernel(ReduceArgs R) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t n_chunks = (R.n + 63) / 64;
+  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+  for (uint64_t ch = wave0; ch < n_chunks; ch += n_waves) {
+    const uint64_t k = ch * 64 + lane;
+    const bool valid = k < R.n;
+    const uint32_t a = valid ? R.slot_arc[k] : 0xffffffffu;
+    double v = valid ? R.post[R.slot_pos[k]] : 0.0;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double v2 = __shfl_up(v, off, 64);
+      const uint32_t a2 = __shfl_up(a, off, 64);
+      if (lane >= off && a2 == a) v += v2;
+    }
+    const uint32_t a_next = __shfl_down(a, 1, 64);
+    const uint32_t a_first = __shfl(a, 0, 64);
+    const bool tail = valid && (lane == 63 || a_next != a);
+    if (tail) {
+      if (a == a_first || lane == 63)
+        atomic_add_f64(R.counts + a, v);
+      else
+        R.counts[a] = v;
+    }
   }
-  atomic_add_f64(A.counts + A.n_arcs + 0, prob);
-  atomic_add_f64(A.counts + A.n_arcs + 1, prob * exp(lwt));
-  atomic_add_f64(A.counts + A.n_arcs + 2, 1.0);
 }
 
 // ---------------- M-step (fst.cc:86-244 for normal + locked arcs; train.cc:134-182) ----------------
@@ -465,9 +492,18 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
     hipLaunchKernelGGL((sweep_bundle_kernel<256, true>), dim3(lc.count), dim3(256), lds, stream, A);
   } else {
     (void)hipFuncSetAttribute((const void*)sweep_bundle_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                        (int)lds);
+                              (int)lds);
     hipLaunchKernelGGL((sweep_bundle_kernel<1024, true>), dim3(lc.count), dim3(1024), lds, stream, A);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream) {
+  if (!R.n) return hipSuccess;
+  uint64_t chunks = (R.n + 63) / 64;
+  uint64_t blocks = (chunks + 3) / 4;
+  if (blocks > 256ull * 32) blocks = 256ull * 32;
+  hipLaunchKernelGGL(count_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, R);
   return hipGetLastError();
 }
 

@@ -6,6 +6,25 @@
 
 namespace carmel_hip {
 
+// Expected counts are produced in two phases so that no sweep kernel issues random atomics (f64 atomic adds to a
+// table much larger than L2 run at ~5 G/s on MI355X — 10x slower than everything else in the E-step):
+//   1. the sweeps write one posterior per lattice arc into `post` at the arc's SLOT (coalesced stores);
+//   2. count_reduce sums, for every WFST arc, the posteriors of the slots that use it (slots pre-sorted by arc id
+//      on the host — the topology never changes between iterations).
+struct LaneArgs {
+  const LaneGroup* groups;
+  const uint2* fwd;
+  const uint2* bwd;
+  const uint32_t* lane_pair;
+  const uint32_t* lane_nstates;
+  const double* lane_logw;
+  const double* logw;
+  double* post;          // slot = record position in the backward stream
+  double* scalars;       // {sum ln p, sum weight*ln p, n pairs, -}
+  double* pair_logprob;
+  uint32_t first_group;
+};
+
 struct SweepArgs {
   const BundleDesc* bundles;
   const uint2* in_arcs;
@@ -17,13 +36,21 @@ struct SweepArgs {
   const uint32_t* pair_final;
   const uint32_t* pair_id;
   const double* pair_logw;
-  const double* logw;       // per WFST arc
-  double* counts;           // per WFST arc, linear; [n_arcs .. n_arcs+3] = scalars
-  double* pair_logprob;     // per corpus pair
-  double* alpha_g;          // per lattice state (global scratch, indexed by off_base + s)
-  double* beta_g;           // only for bundles too large for LDS / serial sweeps
-  uint64_t n_arcs;
+  const double* logw;     // per WFST arc
+  double* post;           // slot = post_base + out_base + position in out_arcs
+  double* scalars;
+  double* pair_logprob;   // per corpus pair
+  double* val_g;          // global scratch for alpha/beta of bundles too large for LDS and of serial sweeps
+  double* val2_g;
   uint32_t first_bundle;
+};
+
+struct ReduceArgs {
+  const uint32_t* slot_arc;   // WFST arc id of sorted entry k (ascending)
+  const uint64_t* slot_pos;   // position in post[] of sorted entry k
+  const double* post;
+  double* counts;             // per WFST arc, linear (zeroed before the launch)
+  uint64_t n;
 };
 
 struct MstepArgs {
@@ -41,21 +68,9 @@ struct MstepArgs {
   int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
 };
 
-struct LaneArgs {
-  const LaneGroup* groups;
-  const uint2* fwd;
-  const uint2* bwd;
-  const uint32_t* lane_pair;
-  const uint32_t* lane_nstates;
-  const double* lane_logw;
-  const double* logw;
-  double* counts;
-  double* pair_logprob;
-  uint64_t n_arcs;
-  uint32_t first_group;
-};
 hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
+hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream);
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,

@@ -825,6 +825,30 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     work();
     for (auto& t : th) t.join();
   }
+  // ---- posterior slots sorted by WFST arc id (counting sort) ----
+  {
+    const uint64_t nlane = out.lane_bwd.size();
+    out.n_post = nlane + out.out_arcs.size();
+    std::vector<uint64_t> cnt(w.n_arcs + 1, 0);
+    for (uint64_t k = 0; k < nlane; ++k)
+      if (out.lane_bwd[k].x & LANE_VALID) cnt[out.lane_bwd[k].y + 1]++;
+    for (const auto& r : out.out_arcs) cnt[r.y + 1]++;
+    for (uint64_t a = 0; a < w.n_arcs; ++a) cnt[a + 1] += cnt[a];
+    const uint64_t total = cnt[w.n_arcs];
+    out.slot_arc.resize(total);
+    out.slot_pos.resize(total);
+    for (uint64_t k = 0; k < nlane; ++k)
+      if (out.lane_bwd[k].x & LANE_VALID) {
+        uint64_t p = cnt[out.lane_bwd[k].y]++;
+        out.slot_arc[p] = out.lane_bwd[k].y;
+        out.slot_pos[p] = k;
+      }
+    for (uint64_t k = 0; k < out.out_arcs.size(); ++k) {
+      uint64_t p = cnt[out.out_arcs[k].y]++;
+      out.slot_arc[p] = out.out_arcs[k].y;
+      out.slot_pos[p] = nlane + k;
+    }
+  }
   return true;
 }
 
