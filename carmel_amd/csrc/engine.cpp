@@ -70,6 +70,7 @@ struct carmel_hip_trainer {
   // M-step state over parameters
   DevBuf<double> old_logw, em_logw, best_logw, prior;
   DevBuf<uint32_t> norm_of;
+  DevBuf<uint64_t> group_off, norm_perm, big_groups;
   DevBuf<double> add_count, gsum, gres;
   DevBuf<unsigned long long> maxchg;
   uint64_t n_norm_groups = 0;
@@ -84,7 +85,7 @@ struct carmel_hip_trainer {
   DevBuf<LaneGroup> lane_groups;
   DevBuf<uint2_t> lane_fwd, lane_bwd;
   DevBuf<uint32_t> lane_pair, lane_nstates;
-  DevBuf<double> lane_logw, post;
+  DevBuf<double> lane_logw, post, wcache;
   DevBuf<uint32_t> slot_arc;
   DevBuf<uint64_t> slot_pos;
   uint64_t lane_records = 0;
@@ -231,6 +232,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->lane_logw.upload(L.lane_logw, s));
   t->lane_records = L.lane_bwd.size();
   HIPCHK(t->post.alloc(L.n_post));
+  HIPCHK(t->wcache.alloc(L.lane_bwd.size()));
   HIPCHK(t->slot_arc.upload(L.slot_arc, s));
   HIPCHK(t->slot_pos.upload(L.slot_pos, s));
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
@@ -247,7 +249,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->out_off.bytes() + t->level_off.bytes() + t->pair_start.bytes() + t->pair_final.bytes() +
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
-                    t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() +
+                    t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
                     t->slot_arc.bytes() + t->slot_pos.bytes();
   std::vector<uint32_t>().swap(L.slot_arc);
   std::vector<uint64_t>().swap(L.slot_pos);
@@ -306,6 +308,22 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       norm_of[k] = it->second;
   }
   t->n_norm_groups = add.size();
+  {
+    // members of every group, contiguous (counting sort by group id); big groups listed separately
+    std::vector<uint64_t> off(add.size() + 1, 0), perm, big;
+    for (uint64_t k = 0; k < n; ++k)
+      if (norm_of[k] != 0xffffffffu) off[norm_of[k] + 1]++;
+    for (size_t g = 0; g < add.size(); ++g) off[g + 1] += off[g];
+    perm.resize(off[add.size()]);
+    std::vector<uint64_t> cur(off.begin(), off.end() - 1);
+    for (uint64_t k = 0; k < n; ++k)
+      if (norm_of[k] != 0xffffffffu) perm[cur[norm_of[k]]++] = k;
+    for (size_t g = 0; g < add.size(); ++g)
+      if (off[g + 1] - off[g] > MSTEP_BIG_GROUP) big.push_back(g);
+    HIPCHK(t->group_off.upload(off, t->stream));
+    HIPCHK(t->norm_perm.upload(perm, t->stream));
+    HIPCHK(t->big_groups.upload(big, t->stream));
+  }
   HIPCHK(t->norm_of.upload(norm_of, t->stream));
   HIPCHK(t->add_count.upload(add, t->stream));
   HIPCHK(t->gsum.alloc(add.size()));
@@ -390,8 +408,6 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
 
 static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   hipStream_t s = t->stream;
-  HIPCHK(hipMemsetAsync(t->gsum.p, 0, t->gsum.bytes(), s));
-  HIPCHK(hipMemsetAsync(t->gres.p, 0, t->gres.bytes(), s));
   HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
   MstepArgs M;
   M.logw = t->params();
@@ -401,6 +417,11 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.group = t->pgroup();
   M.norm_of = t->norm_of.p;
   M.add_count = t->add_count.p;
+  M.group_off = t->group_off.p;
+  M.norm_perm = t->norm_perm.p;
+  M.big_groups = t->big_groups.p;
+  M.n_groups = t->n_norm_groups;
+  M.n_big = t->big_groups.n;
   M.gsum = t->gsum.p;
   M.greserved = t->gres.p;
   M.max_change_bits = t->maxchg.p;
@@ -484,6 +505,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   LA.lane_logw = t->lane_logw.p;
   LA.logw = t->arc_logw.p;
   LA.post = t->post.p;
+  LA.wcache = t->wcache.p;
   LA.scalars = t->counts_ptr() + t->w.n_arcs;
   LA.pair_logprob = t->pair_logprob.p;
   LA.first_group = 0;

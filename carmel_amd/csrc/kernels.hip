@@ -75,39 +75,47 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   const double* __restrict__ logw = A.logw;
   double* col = lds + lane;
   const uint32_t maxlen = g.maxlen;
+  // Software pipeline, all value-independent: records run 3 chunks ahead of the arithmetic, weight gathers 2.
+  // ra = chunk being consumed, rb/rc = next two, rd = being loaded; wa/wb/wc likewise.
+#define LANE_LOAD_RECS(dst, base, k0_)                                                    \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                         \
+    const uint32_t k_ = (k0_) + u;                                                        \
+    dst[u] = (k_ < maxlen) ? (base)[(size_t)k_ * 64] : make_uint2(0u, 0u);                \
+  }
+#define LANE_LOAD_WS(dst, recs)                                                           \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) dst[u] = (recs[u].x & LANE_VALID) ? logw[recs[u].y] : 0.0;
   // ---------- forward ----------
   {
     const uint2* __restrict__ f = A.fwd + g.stream_base + lane;
+    double* wc_out = A.wcache + g.stream_base + lane;
     if (active) col[0] = 0.0;
-    uint2 r0[U], r1[U];
-    double w0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      r0[u] = ((uint32_t)u < maxlen) ? f[(size_t)u * 64] : make_uint2(0u, 0u);
-      r1[u] = ((uint32_t)(U + u) < maxlen) ? f[(size_t)(U + u) * 64] : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) w0[u] = (r0[u].x & LANE_VALID) ? logw[r0[u].y] : 0.0;
+    uint2 ra[U], rb[U], rc[U];
+    double wa[U], wb[U];
+    LANE_LOAD_RECS(ra, f, 0u)
+    LANE_LOAD_RECS(rb, f, (uint32_t)U)
+    LANE_LOAD_RECS(rc, f, (uint32_t)(2 * U))
+    LANE_LOAD_WS(wa, ra)
+    LANE_LOAD_WS(wb, rb)
     Lse acc;
     acc.init();
     uint32_t d = 1;
+    double prev = 0.0;  // alpha[d-1] kept in a register: a chain step never waits for the LDS round trip
     for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
-      uint2 r2[U];
-      double w1[U];
+      uint2 rd[U];
+      double wc[U];
+      LANE_LOAD_RECS(rd, f, k0 + 3 * U)
+      LANE_LOAD_WS(wc, rc)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t k = k0 + 2 * U + u;
-        r2[u] = (k < maxlen) ? f[(size_t)k * 64] : make_uint2(0u, 0u);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) w1[u] = (r1[u].x & LANE_VALID) ? logw[r1[u].y] : 0.0;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t x = r0[u].x;
+        const uint32_t x = ra[u].x;
         if (x & LANE_VALID) {
-          acc.add(col[(x & 0xffffu) * 64] + w0[u]);
+          const uint32_t src = x & LANE_STATE_MASK;
+          const double a_src = (src + 1 == d) ? prev : col[src * 64];
+          wc_out[(size_t)(k0 + u) * 64] = wa[u];
+          acc.add(a_src + wa[u]);
           if (x & LANE_LAST) {
-            col[d * 64] = acc.value();
+            prev = acc.value();
+            col[d * 64] = prev;
             ++d;
             acc.init();
           }
@@ -115,58 +123,64 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        r0[u] = r1[u];
-        r1[u] = r2[u];
-        w0[u] = w1[u];
+        ra[u] = rb[u];
+        rb[u] = rc[u];
+        rc[u] = rd[u];
+        wa[u] = wb[u];
+        wb[u] = wc[u];
       }
     }
   }
   // ---------- ln p(pair), corpus scalars, beta at the goal ----------
   double s_lp = 0.0, s_wlp = 0.0;
+  double next = NEG_INF;  // beta[s+1] in a register
   if (active) {
     const double lp = col[(S - 1) * 64];
     const double lwt = A.lane_logw[g.pair_base + lane];
     A.pair_logprob[A.lane_pair[g.pair_base + lane]] = lp;
     s_lp = lp;
     s_wlp = lp * exp(lwt);
-    col[(S - 1) * 64] = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
+    next = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
+    col[(S - 1) * 64] = next;
   }
   // ---------- backward + posteriors ----------
   {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache stores before its re-reads
     const uint2* __restrict__ b = A.bwd + g.stream_base + lane;
     double* __restrict__ post = A.post + g.stream_base + lane;
-    uint2 r0[U], r1[U];
-    double w0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      r0[u] = ((uint32_t)u < maxlen) ? b[(size_t)u * 64] : make_uint2(0u, 0u);
-      r1[u] = ((uint32_t)(U + u) < maxlen) ? b[(size_t)(U + u) * 64] : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) w0[u] = (r0[u].x & LANE_VALID) ? logw[r0[u].y] : 0.0;
+    const double* wc_in = A.wcache + g.stream_base + lane;
+#undef LANE_LOAD_WS
+#define LANE_LOAD_WS(dst, recs)                                                           \
+  _Pragma("unroll") for (int u = 0; u < U; ++u) dst[u] =                                  \
+      (recs[u].x & LANE_VALID) ? wc_in[(size_t)((recs[u].x >> LANE_FPOS_SHIFT) & LANE_FPOS_MAX) * 64] : 0.0;
+    uint2 ra[U], rb[U], rc[U];
+    double wa[U], wb[U];
+    LANE_LOAD_RECS(ra, b, 0u)
+    LANE_LOAD_RECS(rb, b, (uint32_t)U)
+    LANE_LOAD_RECS(rc, b, (uint32_t)(2 * U))
+    LANE_LOAD_WS(wa, ra)
+    LANE_LOAD_WS(wb, rb)
     Lse acc;
     acc.init();
     uint32_t s = S >= 2 ? S - 2 : 0u;
     double al = (S >= 2) ? col[s * 64] : NEG_INF;
     for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
-      uint2 r2[U];
-      double w1[U];
+      uint2 rd[U];
+      double wc[U];
+      LANE_LOAD_RECS(rd, b, k0 + 3 * U)
+      LANE_LOAD_WS(wc, rc)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const uint32_t k = k0 + 2 * U + u;
-        r2[u] = (k < maxlen) ? b[(size_t)k * 64] : make_uint2(0u, 0u);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) w1[u] = (r1[u].x & LANE_VALID) ? logw[r1[u].y] : 0.0;
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t x = r0[u].x;
+        const uint32_t x = ra[u].x;
         if (x & LANE_VALID) {
-          const double t = w0[u] + col[(x & 0xffffu) * 64];
+          const uint32_t dst = x & LANE_STATE_MASK;
+          const double b_dst = (dst == s + 1) ? next : col[dst * 64];
+          const double t = wa[u] + b_dst;
           acc.add(t);
           post[(size_t)(k0 + u) * 64] = exp(al + t);
           if (x & LANE_LAST) {
-            col[s * 64] = acc.value();  // beta[s] replaces alpha[s]
+            next = acc.value();
+            col[s * 64] = next;  // beta[s] replaces alpha[s]
             acc.init();
             if (s > 0) {
               --s;
@@ -177,12 +191,16 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        r0[u] = r1[u];
-        r1[u] = r2[u];
-        w0[u] = w1[u];
+        ra[u] = rb[u];
+        rb[u] = rc[u];
+        rc[u] = rd[u];
+        wa[u] = wb[u];
+        wb[u] = wc[u];
       }
     }
   }
+#undef LANE_LOAD_RECS
+#undef LANE_LOAD_WS
   for (int o = 32; o > 0; o >>= 1) {
     s_lp += __shfl_down(s_lp, o, 64);
     s_wlp += __shfl_down(s_wlp, o, 64);
@@ -358,45 +376,87 @@ __global__ __launch_bounds__(256) void count_reduce_kernel(ReduceArgs R) {
 
 // ---------------- M-step (fst.cc:86-244 for normal + locked arcs; train.cc:134-182) ----------------
 
-// pass 0: new unnormalised value per parameter (prep_new_weights + "w += addc" of normalize pass 1), group sums
-__global__ void mstep_accumulate_kernel(MstepArgs M, int use_counts) {
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t g = M.group[k];
-    const bool locked = (g == 0u);
-    const double old = M.logw[k];
-    if (M.save_old) M.old_logw[k] = old;
-    const uint32_t ng = M.norm_of[k];
-    if (ng == 0xffffffffu) continue;  // member normalised by NONE keeps its weights (cascade.h:339-350)
-    double v;  // linear
-    if (locked || !use_counts)
-      v = exp(old);
+// unnormalised linear value of parameter k: prep_new_weights (train.cc:134-153) + "w += addc" of normalize pass 1
+// (fst.cc:125).  Locked arcs keep their weight (plus addc, as the reference does).
+__device__ __forceinline__ double mstep_value(const MstepArgs& M, uint64_t k, int use_counts, uint32_t ng) {
+  const bool locked = (M.group[k] == 0u);
+  double v;
+  if (locked || !use_counts)
+    v = exp(M.logw[k]);
+  else
+    v = M.counts[k] + (M.prior ? M.prior[k] : 0.0);
+  return v + M.add_count[ng];
+}
+
+// pass 0: per norm group, the sum over normal arcs and over locked arcs (fst.cc:117-131).  Members of a group are
+// listed in norm_perm[group_off[g] .. group_off[g+1]); one thread per small group, no atomics.
+__global__ void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < M.n_groups;
+       g += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
+    if (j1 - j0 > MSTEP_BIG_GROUP) continue;  // handled by mstep_big_group_sum_kernel
+    double sn = 0.0, sl = 0.0;
+    for (uint64_t j = j0; j < j1; ++j) {
+      const uint64_t k = M.norm_perm[j];
+      const double v = mstep_value(M, k, use_counts, (uint32_t)g);
+      if (M.group[k] == 0u)
+        sl += v;
+      else
+        sn += v;
+    }
+    M.gsum[g] = sn;
+    M.greserved[g] = sl;
+  }
+}
+// big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
+__global__ __launch_bounds__(256) void mstep_big_group_sum_kernel(MstepArgs M, int use_counts) {
+  __shared__ double sh[2][4];
+  const uint64_t g = M.big_groups[blockIdx.x];
+  const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
+  double sn = 0.0, sl = 0.0;
+  for (uint64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+    const uint64_t k = M.norm_perm[j];
+    const double v = mstep_value(M, k, use_counts, (uint32_t)g);
+    if (M.group[k] == 0u)
+      sl += v;
     else
-      v = M.counts[k] + (M.prior ? M.prior[k] : 0.0);
-    v += M.add_count[ng];
-    if (v > 0.0) atomic_add_f64(locked ? (M.greserved + ng) : (M.gsum + ng), v);
-    // stash the unnormalised value (ln) for pass 1
-    M.logw[k] = v > 0.0 ? log(v) : NEG_INF;
+      sn += v;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    sn += __shfl_down(sn, o, 64);
+    sl += __shfl_down(sl, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = sn;
+    sh[1][threadIdx.x >> 6] = sl;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    M.gsum[g] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    M.greserved[g] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
   }
 }
 
-// pass 1: w = (1 - reserved) * v / sum  for normal arcs (fst.cc:213-230); locked arcs keep v; max |new-old|
-__global__ void mstep_normalize_kernel(MstepArgs M) {
+// pass 1: w = (1 - reserved) * v / sum for normal arcs (fst.cc:213-230); locked arcs keep v; max |new - old|
+__global__ void mstep_normalize_kernel(MstepArgs M, int use_counts) {
   double mx = 0.0;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t g = M.group[k];
     const uint32_t ng = M.norm_of[k];
-    if (g == 0u || ng == 0xffffffffu) continue;  // locked: value already stored; NONE: untouched
-    const double lv = M.logw[k];
+    const double old = M.logw[k];
+    if (M.save_old) M.old_logw[k] = old;
+    if (ng == 0xffffffffu) continue;  // member normalised by NONE keeps its weights (cascade.h:339-350)
+    const double v = mstep_value(M, k, use_counts, ng);
     double nw;
-    const double sum = M.gsum[ng];
-    const double remain = 1.0 - M.greserved[ng];
-    if (remain > 0.0 && sum > 0.0 && lv != NEG_INF)
-      nw = lv + log(remain) - log(sum);
-    else
-      nw = NEG_INF;
+    if (M.group[k] == 0u) {
+      nw = v > 0.0 ? log(v) : NEG_INF;
+    } else {
+      const double sum = M.gsum[ng];
+      const double remain = 1.0 - M.greserved[ng];
+      nw = (remain > 0.0 && sum > 0.0 && v > 0.0) ? log(remain * v / sum) : NEG_INF;
+      const double ch = fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k]));
+      mx = fmax(mx, ch);
+    }
     M.logw[k] = nw;
-    const double ch = fabs(exp(nw) - exp(M.old_logw[k]));
-    mx = fmax(mx, ch);
   }
   for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
   if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(M.max_change_bits, (unsigned long long)__double_as_longlong(mx));
@@ -468,6 +528,17 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   LaneArgs A = A0;
   A.first_group = lc.first;
   size_t lds = (size_t)lc.max_states * 64 * sizeof(double);
+  static const int U = getenv("CARMEL_HIP_LANE_U") ? atoi(getenv("CARMEL_HIP_LANE_U")) : 4;  // tuning knob
+  if (U == 8) {
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((sweep_lane_kernel<8>), dim3(lc.count), dim3(64), lds, stream, A);
+    return hipGetLastError();
+  }
+  if (U == 2) {
+    hipLaunchKernelGGL((sweep_lane_kernel<2>), dim3(lc.count), dim3(64), lds, stream, A);
+    return hipGetLastError();
+  }
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((sweep_lane_kernel<4>), dim3(lc.count), dim3(64), lds, stream, A);
@@ -514,8 +585,9 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
-  hipLaunchKernelGGL(mstep_accumulate_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
-  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M);
+  if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+  if (M.n_big) hipLaunchKernelGGL(mstep_big_group_sum_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
+  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
   return hipGetLastError();
 }
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,

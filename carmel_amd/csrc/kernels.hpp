@@ -20,6 +20,7 @@ struct LaneArgs {
   const double* lane_logw;
   const double* logw;
   double* post;          // slot = record position in the backward stream
+  double* wcache;        // weight of the arc at forward-stream position k (written forward, re-read backward)
   double* scalars;       // {sum ln p, sum weight*ln p, n pairs, -}
   double* pair_logprob;
   uint32_t first_group;
@@ -53,6 +54,7 @@ struct ReduceArgs {
   uint64_t n;
 };
 
+#define MSTEP_BIG_GROUP 512
 struct MstepArgs {
   double* logw;             // parameters (ln), updated in place
   double* old_logw;         // scratch (arc_counts::scratch)
@@ -61,6 +63,10 @@ struct MstepArgs {
   const uint32_t* group;    // FSTArc::groupId per parameter (0 = locked)
   const uint32_t* norm_of;  // norm-group id per parameter; 0xffffffff = member normalised by NONE
   const double* add_count;  // per norm group (--priors of the member it belongs to)
+  const uint64_t* group_off;   // norm group g's members: norm_perm[group_off[g] .. group_off[g+1])
+  const uint64_t* norm_perm;   // parameter ids sorted by norm group
+  const uint64_t* big_groups;  // groups with more than MSTEP_BIG_GROUP members (one workgroup each)
+  uint64_t n_groups, n_big;
   double* gsum;             // per norm group: sum over normal arcs
   double* greserved;        // per norm group: sum over locked arcs
   unsigned long long* max_change_bits;

@@ -486,7 +486,8 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     const PairLattice& L = lats[p];
     if (L.cyclic)
       cyc.push_back(p);
-    else if (opt.lane_states && L.n_states <= opt.lane_states)
+    else if (opt.lane_states && L.n_states <= opt.lane_states && L.n_states <= LANE_STATE_MASK &&
+             L.edges.size() <= LANE_FPOS_MAX)
       lane.push_back(p);
     else if (L.n_states * 4 <= opt.small_states)
       small.push_back(p);
@@ -547,7 +548,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     std::atomic<size_t> nextg(0);
     auto lwork = [&]() {
       std::vector<uint32_t> order, newid, ioff, ooff, cur;
-      std::vector<uint32_t> ie, oe;
+      std::vector<uint32_t> ie, oe, fpos;
       for (;;) {
         size_t g = nextg.fetch_add(4);
         if (g >= ng) break;
@@ -594,12 +595,19 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
                 uint32_t x = newid[e.src] | LANE_VALID | (k + 1 == ioff[d + 1] ? LANE_LAST : 0u);
                 f[(pos++) * 64] = uint2_t{x, e.arc};
               }
+            // forward position of every edge (the backward record points at it: the forward pass leaves the arc's
+            // weight there, so the backward pass re-reads it L2-hot instead of gathering it again)
+            fpos.resize(E);
+            pos = 0;
+            for (uint32_t d = 1; d < S; ++d)
+              for (uint32_t k = ioff[d]; k < ioff[d + 1]; ++k) fpos[ie[k]] = (uint32_t)pos++;
             pos = 0;
             for (uint32_t sidx = S; sidx-- > 0;) {
               if (sidx == S - 1) continue;  // the goal has no out-arcs
               for (uint32_t k = ooff[sidx]; k < ooff[sidx + 1]; ++k) {
                 const auto& e = L.edges[oe[k]];
-                uint32_t x = newid[e.dst] | LANE_VALID | (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
+                uint32_t x = newid[e.dst] | (fpos[oe[k]] << LANE_FPOS_SHIFT) | LANE_VALID |
+                             (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
                 b[(pos++) * 64] = uint2_t{x, e.arc};
               }
             }

@@ -91,13 +91,14 @@ def numpy_sweep(img, logw, n_pairs_total):
             S = int(img["lane_nstates"][slot])
             col = np.full(S, -np.inf)
             col[0] = 0.0
-            d, terms = 1, []
+            d, terms, fwd_arc_at = 1, [], []
             for k in range(ml):
                 x, arc = img["lane_fwd"][base + k * 64 + l]
                 if not x & LANE_VALID:
                     continue
-                assert (x & 0xffff) < d
-                terms.append(col[x & 0xffff] + logw[arc])
+                assert (x & 0x3ff) < d
+                terms.append(col[x & 0x3ff] + logw[arc])
+                fwd_arc_at.append(arc)
                 if x & LANE_LAST:
                     col[d] = _lse(terms)
                     d, terms = d + 1, []
@@ -110,8 +111,9 @@ def numpy_sweep(img, logw, n_pairs_total):
                 x, arc = img["lane_bwd"][base + k * 64 + l]
                 if not x & LANE_VALID:
                     continue
-                assert (x & 0xffff) > s
-                t = logw[arc] + col[x & 0xffff]
+                assert (x & 0x3ff) > s
+                assert fwd_arc_at[(x >> 10) & 0xfffff] == arc  # the backward record points at its own forward record
+                t = logw[arc] + col[x & 0x3ff]
                 counts[arc] += np.exp(alpha_s(col, s) + t)
                 terms.append(t)
                 if x & LANE_LAST:
