@@ -136,7 +136,9 @@ def main():
             "wfst_arcs_x_iters_per_s": iters_per_s * w.n_arcs,
             "ln_corpus_prob_last": lp,
             "lattice_build_s": ls.build_seconds, "synth_gen_s": t_gen,
-            "roofline": {"bound": "hbm", "kernel": "sweep_bundle_kernel<64,true>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "E-step = sweep_lane_kernel (one launch per LDS class) + "
+                         "count_reduce_kernel, timed together with HIP events on the trainer's stream",
+                         "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }

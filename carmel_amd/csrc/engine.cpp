@@ -71,10 +71,11 @@ struct carmel_hip_trainer {
   DevBuf<double> old_logw, em_logw, best_logw, prior;
   DevBuf<uint32_t> norm_of;
   DevBuf<uint64_t> group_off, norm_perm, big_groups;
-  DevBuf<double> add_count, gsum, gres;
+  DevBuf<double> add_count, gscale;
+  bool any_add_count = false;
   DevBuf<unsigned long long> maxchg;
   uint64_t n_norm_groups = 0;
-  bool have_norm = false, have_prior = false;
+  bool have_norm = false, have_prior = false, prior_nonzero = false;
   int norm_group_by = CARMEL_HIP_NORM_CONDITIONAL;
   double norm_add_count = 0, smooth_floor = 0;
   // device: lattices
@@ -86,8 +87,7 @@ struct carmel_hip_trainer {
   DevBuf<uint2_t> lane_fwd, lane_bwd;
   DevBuf<uint32_t> lane_pair, lane_nstates;
   DevBuf<double> lane_logw, post, wcache;
-  DevBuf<uint32_t> slot_arc;
-  DevBuf<uint64_t> slot_pos;
+  DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;
   uint64_t lane_records = 0;
   uint64_t device_bytes = 0;
 
@@ -233,8 +233,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   t->lane_records = L.lane_bwd.size();
   HIPCHK(t->post.alloc(L.n_post));
   HIPCHK(t->wcache.alloc(L.lane_bwd.size()));
-  HIPCHK(t->slot_arc.upload(L.slot_arc, s));
+  HIPCHK(t->arc_off.upload(L.arc_off, s));
   HIPCHK(t->slot_pos.upload(L.slot_pos, s));
+  HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
   bool need_val = false, need_val2 = false;
   for (auto& lc : L.classes) {
@@ -250,8 +251,8 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
-                    t->slot_arc.bytes() + t->slot_pos.bytes();
-  std::vector<uint32_t>().swap(L.slot_arc);
+                    t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes();
+  std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
   std::vector<uint2_t>().swap(L.lane_bwd);
@@ -326,8 +327,10 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
   }
   HIPCHK(t->norm_of.upload(norm_of, t->stream));
   HIPCHK(t->add_count.upload(add, t->stream));
-  HIPCHK(t->gsum.alloc(add.size()));
-  HIPCHK(t->gres.alloc(add.size()));
+  HIPCHK(t->gscale.alloc(add.size()));
+  t->any_add_count = false;
+  for (double a : add)
+    if (a != 0.0) t->any_add_count = true;
   HIPCHK(hipStreamSynchronize(t->stream));
   t->have_norm = true;
   return CARMEL_HIP_OK;
@@ -359,6 +362,12 @@ int carmel_hip_set_prior(carmel_hip_trainer* t, double smooth_floor, int weight_
     HIPCHK(hipStreamSynchronize(t->stream));
     for (uint64_t k = 0; k < n; ++k) pr[k] += std::exp(lw[k]);
   }
+  t->prior_nonzero = false;
+  for (double x : pr)
+    if (x != 0.0) {
+      t->prior_nonzero = true;
+      break;
+    }
   HIPCHK(t->prior.upload(pr, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   t->have_prior = true;
@@ -413,17 +422,16 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.logw = t->params();
   M.old_logw = t->old_logw.p;
   M.counts = t->pcounts();
-  M.prior = (!t->cascade && t->have_prior) ? t->prior.p : nullptr;
+  M.prior = (!t->cascade && t->have_prior && t->prior_nonzero) ? t->prior.p : nullptr;
   M.group = t->pgroup();
   M.norm_of = t->norm_of.p;
-  M.add_count = t->add_count.p;
+  M.add_count = t->any_add_count ? t->add_count.p : nullptr;
   M.group_off = t->group_off.p;
   M.norm_perm = t->norm_perm.p;
   M.big_groups = t->big_groups.p;
   M.n_groups = t->n_norm_groups;
   M.n_big = t->big_groups.n;
-  M.gsum = t->gsum.p;
-  M.greserved = t->gres.p;
+  M.gscale = t->gscale.p;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();
   M.save_old = save_old;
@@ -477,7 +485,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   if (t->cascade)  // cascade.update(): composed weights from the chains
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
-  HIPCHK(hipMemsetAsync(t->counts_ptr(), 0, (t->w.n_arcs + 4) * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(t->counts_ptr() + t->w.n_arcs, 0, 4 * sizeof(double), s));  // scalars; counts are all written
   SweepArgs A;
   A.bundles = t->bundles.p;
   A.in_arcs = (const uint2*)t->in_arcs.p;
@@ -513,11 +521,13 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
   ReduceArgs R;
-  R.slot_arc = t->slot_arc.p;
+  R.arc_off = t->arc_off.p;
   R.slot_pos = t->slot_pos.p;
+  R.hot_chunks = t->hot_chunks.p;
   R.post = t->post.p;
   R.counts = t->counts_ptr();
-  R.n = t->slot_arc.n;
+  R.n_arcs = t->w.n_arcs;
+  R.n_hot_chunks = t->hot_chunks.n / 3;
   HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipEventRecord(t->ev1, s));
   return CARMEL_HIP_OK;

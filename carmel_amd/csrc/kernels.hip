@@ -340,38 +340,35 @@ __global__ void sweep_serial_kernel(SweepArgs A, uint32_t n_bundles) {
   atomic_add_f64(A.scalars + 2, 1.0);
 }
 
-// ---------------- expected counts: segmented reduction of posteriors by WFST arc ----------------
-// Entry k (sorted by arc id on the host) says: the posterior at post[slot_pos[k]] belongs to arc slot_arc[k].
-// Each wave takes 64 consecutive entries, does a segmented scan over equal arc ids with shuffles and lets the
-// last lane of every segment write: a segment strictly inside the wave is complete (plain store); one touching the
-// wave's first or last lane may continue in a neighbour wave (atomic add — neighbours hit neighbouring addresses,
-// so these are few and cache-friendly).  counts must be zero on entry.
+// ---------------- expected counts: per-arc sum of posteriors ----------------
+// The posterior slots that use WFST arc a are slot_pos[arc_off[a] .. arc_off[a+1]) (sorted on the host once — the
+// topology never changes between iterations).  One thread per arc: reads of arc_off / slot_pos and the store of
+// counts[a] are coalesced and dense (every arc is written, so no memset), the only random traffic is one 8-byte
+// gather per slot.  Arcs with more than COUNT_HOT slots (a hub arc of a small transducer can have millions) are
+// left to count_reduce_hot_kernel: one workgroup per arc.
+#define COUNT_HOT 64
 __global__ __launch_bounds__(256) void count_reduce_kernel(ReduceArgs R) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t n_chunks = (R.n + 63) / 64;
-  const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-  for (uint64_t ch = wave0; ch < n_chunks; ch += n_waves) {
-    const uint64_t k = ch * 64 + lane;
-    const bool valid = k < R.n;
-    const uint32_t a = valid ? R.slot_arc[k] : 0xffffffffu;
-    double v = valid ? R.post[R.slot_pos[k]] : 0.0;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const double v2 = __shfl_up(v, off, 64);
-      const uint32_t a2 = __shfl_up(a, off, 64);
-      if (lane >= off && a2 == a) v += v2;
-    }
-    const uint32_t a_next = __shfl_down(a, 1, 64);
-    const uint32_t a_first = __shfl(a, 0, 64);
-    const bool tail = valid && (lane == 63 || a_next != a);
-    if (tail) {
-      if (a == a_first || lane == 63)
-        atomic_add_f64(R.counts + a, v);
-      else
-        R.counts[a] = v;
-    }
+  for (uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; a < R.n_arcs;
+       a += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j0 = R.arc_off[a], j1 = R.arc_off[a + 1];
+    double c = 0.0;
+    if (j1 - j0 <= COUNT_HOT)
+      for (uint64_t j = j0; j < j1; ++j) c += R.post[R.slot_pos[j]];
+    R.counts[a] = c;  // hot arcs: zero here, count_reduce_hot_kernel adds its chunk sums
   }
+}
+// hot arcs are cut into chunks of HOT_CHUNK slots (hot_chunks[3c] = arc, [3c+1] = first slot, [3c+2] = end): one
+// workgroup per chunk, one atomic per chunk
+__global__ __launch_bounds__(256) void count_reduce_hot_kernel(ReduceArgs R) {
+  __shared__ double sh[4];
+  const uint64_t a = R.hot_chunks[3 * (uint64_t)blockIdx.x];
+  const uint64_t j0 = R.hot_chunks[3 * (uint64_t)blockIdx.x + 1], j1 = R.hot_chunks[3 * (uint64_t)blockIdx.x + 2];
+  double c = 0.0;
+  for (uint64_t j = j0 + threadIdx.x; j < j1; j += 256) c += R.post[R.slot_pos[j]];
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomic_add_f64(R.counts + a, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
 // ---------------- M-step (fst.cc:86-244 for normal + locked arcs; train.cc:134-182) ----------------
@@ -385,7 +382,7 @@ __device__ __forceinline__ double mstep_value(const MstepArgs& M, uint64_t k, in
     v = exp(M.logw[k]);
   else
     v = M.counts[k] + (M.prior ? M.prior[k] : 0.0);
-  return v + M.add_count[ng];
+  return M.add_count ? v + M.add_count[ng] : v;
 }
 
 // pass 0: per norm group, the sum over normal arcs and over locked arcs (fst.cc:117-131).  Members of a group are
@@ -404,8 +401,9 @@ __global__ void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
       else
         sn += v;
     }
-    M.gsum[g] = sn;
-    M.greserved[g] = sl;
+    const double remain = 1.0 - sl;
+    // ln(remain) - ln(sum), kept as a difference of logs so that a lone arc (v == sum) comes out as exactly 1
+    M.gscale[g] = (remain > 0.0 && sn > 0.0) ? (sl == 0.0 ? -log(sn) : log(remain) - log(sn)) : NEG_INF;  // fst.cc:213-230
   }
 }
 // big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
@@ -432,8 +430,10 @@ __global__ __launch_bounds__(256) void mstep_big_group_sum_kernel(MstepArgs M, i
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    M.gsum[g] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    M.greserved[g] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double tn = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+    const double tl = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+    const double remain = 1.0 - tl;
+    M.gscale[g] = (remain > 0.0 && tn > 0.0) ? (tl == 0.0 ? -log(tn) : log(remain) - log(tn)) : NEG_INF;
   }
 }
 
@@ -450,9 +450,8 @@ __global__ void mstep_normalize_kernel(MstepArgs M, int use_counts) {
     if (M.group[k] == 0u) {
       nw = v > 0.0 ? log(v) : NEG_INF;
     } else {
-      const double sum = M.gsum[ng];
-      const double remain = 1.0 - M.greserved[ng];
-      nw = (remain > 0.0 && sum > 0.0 && v > 0.0) ? log(remain * v / sum) : NEG_INF;
+      const double sc = M.gscale[ng];
+      nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
       const double ch = fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k]));
       mx = fmax(mx, ch);
     }
@@ -570,11 +569,10 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
 }
 
 hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream) {
-  if (!R.n) return hipSuccess;
-  uint64_t chunks = (R.n + 63) / 64;
-  uint64_t blocks = (chunks + 3) / 4;
-  if (blocks > 256ull * 32) blocks = 256ull * 32;
-  hipLaunchKernelGGL(count_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, R);
+  if (!R.n_arcs) return hipSuccess;
+  hipLaunchKernelGGL(count_reduce_kernel, dim3(grid_for(R.n_arcs, 256)), dim3(256), 0, stream, R);
+  if (R.n_hot_chunks)
+    hipLaunchKernelGGL(count_reduce_hot_kernel, dim3((unsigned)R.n_hot_chunks), dim3(256), 0, stream, R);
   return hipGetLastError();
 }
 

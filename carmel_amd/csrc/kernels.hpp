@@ -47,11 +47,12 @@ struct SweepArgs {
 };
 
 struct ReduceArgs {
-  const uint32_t* slot_arc;   // WFST arc id of sorted entry k (ascending)
-  const uint64_t* slot_pos;   // position in post[] of sorted entry k
+  const uint64_t* arc_off;    // arc a's slots: slot_pos[arc_off[a] .. arc_off[a+1])
+  const uint64_t* slot_pos;   // position in post[] of each slot, grouped by arc
+  const uint64_t* hot_chunks; // (arc, first slot, end slot) triples covering arcs with more than COUNT_HOT slots
   const double* post;
-  double* counts;             // per WFST arc, linear (zeroed before the launch)
-  uint64_t n;
+  double* counts;             // per WFST arc, linear; every entry is written
+  uint64_t n_arcs, n_hot_chunks;
 };
 
 #define MSTEP_BIG_GROUP 512
@@ -62,13 +63,12 @@ struct MstepArgs {
   const double* prior;      // linear prior count per parameter (may be null => 0)
   const uint32_t* group;    // FSTArc::groupId per parameter (0 = locked)
   const uint32_t* norm_of;  // norm-group id per parameter; 0xffffffff = member normalised by NONE
-  const double* add_count;  // per norm group (--priors of the member it belongs to)
+  const double* add_count;  // per norm group (--priors of the member it belongs to); null when all zero
   const uint64_t* group_off;   // norm group g's members: norm_perm[group_off[g] .. group_off[g+1])
   const uint64_t* norm_perm;   // parameter ids sorted by norm group
   const uint64_t* big_groups;  // groups with more than MSTEP_BIG_GROUP members (one workgroup each)
   uint64_t n_groups, n_big;
-  double* gsum;             // per norm group: sum over normal arcs
-  double* greserved;        // per norm group: sum over locked arcs
+  double* gscale;           // per norm group: ln((1 - sum of locked arcs) / sum of normal arcs), -inf if nothing left
   unsigned long long* max_change_bits;
   uint64_t n;
   int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)

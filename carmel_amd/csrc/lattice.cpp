@@ -843,19 +843,18 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     for (const auto& r : out.out_arcs) cnt[r.y + 1]++;
     for (uint64_t a = 0; a < w.n_arcs; ++a) cnt[a + 1] += cnt[a];
     const uint64_t total = cnt[w.n_arcs];
-    out.slot_arc.resize(total);
+    out.arc_off = cnt;  // offsets before the fill pass advances the cursors
     out.slot_pos.resize(total);
     for (uint64_t k = 0; k < nlane; ++k)
-      if (out.lane_bwd[k].x & LANE_VALID) {
-        uint64_t p = cnt[out.lane_bwd[k].y]++;
-        out.slot_arc[p] = out.lane_bwd[k].y;
-        out.slot_pos[p] = k;
-      }
-    for (uint64_t k = 0; k < out.out_arcs.size(); ++k) {
-      uint64_t p = cnt[out.out_arcs[k].y]++;
-      out.slot_arc[p] = out.out_arcs[k].y;
-      out.slot_pos[p] = nlane + k;
-    }
+      if (out.lane_bwd[k].x & LANE_VALID) out.slot_pos[cnt[out.lane_bwd[k].y]++] = k;
+    for (uint64_t k = 0; k < out.out_arcs.size(); ++k) out.slot_pos[cnt[out.out_arcs[k].y]++] = nlane + k;
+    for (uint64_t a = 0; a < w.n_arcs; ++a)
+      if (out.arc_off[a + 1] - out.arc_off[a] > 64)
+        for (uint64_t j = out.arc_off[a]; j < out.arc_off[a + 1]; j += 4096) {
+          out.hot_chunks.push_back(a);
+          out.hot_chunks.push_back(j);
+          out.hot_chunks.push_back(std::min(out.arc_off[a + 1], j + 4096));
+        }
   }
   return true;
 }

@@ -115,8 +115,9 @@ struct LatticeSet {
   // posterior slots: one per lattice arc.  Lane records use their position in lane_bwd[]; bundle out-arcs use
   // lane_bwd.size() + position in out_arcs[].  slot_arc / slot_pos list every slot sorted by WFST arc id, which is
   // what lets the expected counts be a segmented sum instead of random atomics.
-  std::vector<uint32_t> slot_arc;
-  std::vector<uint64_t> slot_pos;
+  std::vector<uint64_t> arc_off;   // n_arcs + 1
+  std::vector<uint64_t> slot_pos;  // grouped by arc id
+  std::vector<uint64_t> hot_chunks;  // (arc, first, end) triples: arcs with more than 64 slots, cut into 4096-slot chunks
   uint64_t n_post = 0;  // size of the posterior array (lane records incl. padding + bundle arcs)
   uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
   uint64_t explored_states = 0, explored_arcs = 0;
