@@ -214,4 +214,65 @@ def train_cascade_text(wfst_texts, corpus_text, normby=None, priors=None, max_it
     return rows, texts, (int(dims[0]), int(dims[1]))
 
 
+lib.orc_cascade_compose_text.restype = vp
+lib.orc_cascade_compose_text.argtypes = [C.c_int, vp]
+lib.orc_cascade_free.argtypes = [vp]
+lib.orc_cascade_composed.restype = vp
+lib.orc_cascade_composed.argtypes = [vp]
+lib.orc_cascade_dims.argtypes = [vp, vp]
+lib.orc_cascade_export.argtypes = [vp] * 8
+lib.orc_cascade_corpus.restype = vp
+lib.orc_cascade_corpus.argtypes = [vp, C.c_char_p]
+lib.orc_cascade_write_member.restype = vp
+lib.orc_cascade_write_member.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+
+
+class OracleCascade(object):
+    """composition + chain bookkeeping of `carmel --train-cascade a b ...` as flat arrays"""
+
+    def __init__(self, wfst_texts):
+        n = len(wfst_texts)
+        arr = (C.c_char_p * n)(*[t.encode() for t in wfst_texts])
+        self.h = lib.orc_cascade_compose_text(n, arr)
+        if not self.h:
+            raise RuntimeError("oracle: " + lib.orc_last_error().decode())
+        dims = np.zeros(4, np.uint64)
+        lib.orc_cascade_dims(self.h, _p(dims))
+        self.n_members, self.n_params, self.n_chains, ne = (int(x) for x in dims)
+        self.param_logw = np.zeros(self.n_params)
+        self.param_group, self.param_member, self.param_src, self.param_in = (
+            np.zeros(self.n_params, np.uint32) for _ in range(4))
+        self.chain_off = np.zeros(self.n_chains + 1, np.uint64)
+        self.chain_param = np.zeros(max(ne, 1), np.uint64)
+        lib.orc_cascade_export(self.h, _p(self.param_logw), _p(self.param_group), _p(self.param_member),
+                               _p(self.param_src), _p(self.param_in), _p(self.chain_off), _p(self.chain_param))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_cascade_free(self.h)
+            self.h = None
+
+    def composed(self):
+        return OracleWfst(lib.orc_cascade_composed(self.h))
+
+    def corpus(self, text):
+        return OracleCorpus(lib.orc_cascade_corpus(self.h, text.encode()))
+
+    def write_member(self, m, param_logw, full=True, onearc=True):
+        pl = np.ascontiguousarray(param_logw, dtype=np.float64)
+        s = lib.orc_cascade_write_member(self.h, m, _p(pl), int(full), int(onearc))
+        txt = C.string_at(s).decode()
+        lib.orc_free_str(s)
+        return txt
+
+    def as_dict(self, member_norm, member_add_count=None):
+        n = self.n_members
+        return dict(param_logw=self.param_logw, param_group=self.param_group, param_member=self.param_member,
+                    param_src=self.param_src, param_in=self.param_in,
+                    member_norm=np.ascontiguousarray(member_norm, dtype=np.int32),
+                    member_add_count=np.ascontiguousarray(member_add_count if member_add_count is not None
+                                                          else np.zeros(n), dtype=np.float64),
+                    chain_off=self.chain_off, chain_param=self.chain_param)
+
+
 CLI = os.path.join(_HERE, "oracle_carmel")

@@ -510,4 +510,110 @@ int orc_train_cascade_text(int n_wfst, const char** wfst_texts, const char* corp
   });
 }
 
+// ---- cascade as flat arrays (for driving the product's carmel_hip_set_cascade from the tests) ----
+struct orc_cascade {
+  std::vector<Wfst> chain;
+  Cascade cascade{true};
+  Wfst* result = 0;
+  std::vector<Wfst*> owned;
+  ~orc_cascade() {
+    for (Wfst* w : owned) delete w;
+  }
+};
+// composes the transducers left to right exactly as `carmel --train-cascade` does (carmel.cc:1303-1355)
+orc_cascade* orc_cascade_compose_text(int n_wfst, const char** wfst_texts) {
+  orc_cascade* h = new orc_cascade();
+  int rc = run_big_stack([&]() {
+    h->chain.resize(n_wfst);
+    for (int i = 0; i < n_wfst; ++i) {
+      if (!h->chain[i].read_legible(wfst_texts[i], true)) throw std::runtime_error("bad WFST text");
+      if (n_wfst > 1) h->chain[i].named_states = false;
+    }
+    h->result = &h->chain[0];
+    h->result->reduce();
+    if (n_wfst < 2) h->cascade.set_trivial();
+    h->cascade.add(h->result);
+    bool any = false;
+    for (int i = 1; i < n_wfst; ++i) {
+      h->cascade.add(&h->chain[i]);
+      if (i == 1)
+        h->cascade.prepare_compose();
+      else
+        h->cascade.prepare_compose(false);
+      Wfst* next = new Wfst();
+      compose(*next, h->cascade, *h->result, h->chain[i]);
+      h->owned.push_back(next);
+      h->result = next;
+      if (!h->result->valid) throw std::runtime_error("empty composition");
+      h->result->reduce();
+      h->cascade.done_composing(h->result);
+      any = true;
+    }
+    if (!any) h->cascade.set_composed(h->result);
+  });
+  if (rc) {
+    delete h;
+    return 0;
+  }
+  return h;
+}
+void orc_cascade_free(orc_cascade* h) { delete h; }
+// the composed transducer as an orc_wfst (a copy; arc group = chain id)
+orc_wfst* orc_cascade_composed(orc_cascade* h) {
+  orc_wfst* w = new orc_wfst();
+  w->w = *h->result;
+  return w;
+}
+// dims: n_members, n_params, n_chains, n_chain_entries
+void orc_cascade_dims(orc_cascade* h, uint64_t* dims) {
+  dims[0] = h->chain.size();
+  uint64_t np = 0;
+  for (auto& w : h->chain) np += w.num_arcs();
+  dims[1] = np;
+  dims[2] = h->cascade.chains.size();
+  uint64_t ne = 0;
+  for (auto& c : h->cascade.chains) ne += c.size();
+  dims[3] = ne;
+}
+// parameters = member arcs concatenated in visit order; chains reference them by index
+void orc_cascade_export(orc_cascade* h, double* param_logw, uint32_t* param_group, uint32_t* param_member,
+                        uint32_t* param_src, uint32_t* param_in, uint64_t* chain_off, uint64_t* chain_param) {
+  std::unordered_map<const Arc*, uint64_t> id;
+  uint64_t k = 0;
+  for (size_t m = 0; m < h->chain.size(); ++m)
+    for (uint32_t s = 0; s < h->chain[m].num_states(); ++s)
+      for (auto& a : h->chain[m].states[s]) {
+        id[&a] = k;
+        param_logw[k] = a.weight.w;
+        param_group[k] = a.group;
+        param_member[k] = (uint32_t)m;
+        param_src[k] = s;
+        param_in[k] = a.in;
+        ++k;
+      }
+  uint64_t e = 0;
+  for (size_t c = 0; c < h->cascade.chains.size(); ++c) {
+    chain_off[c] = e;
+    for (Arc* p : h->cascade.chains[c]) chain_param[e++] = id.at(p);
+  }
+  chain_off[h->cascade.chains.size()] = e;
+}
+// corpus parsed against the composed transducer's alphabets
+orc_corpus* orc_cascade_corpus(orc_cascade* h, const char* text) {
+  orc_corpus* c = new orc_corpus();
+  read_training_corpus(*h->result, text, c->c);
+  return c;
+}
+// write member m with the given parameter weights (n_params values, concatenated order)
+char* orc_cascade_write_member(orc_cascade* h, int m, const double* param_logw, int full, int onearc) {
+  uint64_t k = 0;
+  for (int i = 0; i < m; ++i) k += h->chain[i].num_arcs();
+  for (auto& st : h->chain[m].states)
+    for (auto& a : st) a.weight.w = param_logw[k++];
+  std::string s = h->chain[m].write_legible(full != 0, onearc != 0);
+  char* r = (char*)std::malloc(s.size() + 1);
+  std::memcpy(r, s.c_str(), s.size() + 1);
+  return r;
+}
+
 }  // extern "C"

@@ -214,3 +214,65 @@ def test_full_size_properties_c2():
     touched = np.bincount(inv, weights=(wts > 0)) > 0
     np.testing.assert_allclose(sums[touched], 1.0, rtol=1e-9)
     fb.close()
+
+
+def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
+    texts = [open(os.path.join(golden_dir, n)).read() for n in names]
+    oc = oracle.OracleCascade(texts)
+    comp = oc.composed()
+    a = comp.arrays()
+    w = Wfst(a["n_states"], a["final"], a["src"], a["dst"], a["isym"], a["osym"], a["logw"], a["group"])
+    ca = oc.corpus(open(os.path.join(golden_dir, corpus_name)).read()).arrays()
+    c = Corpus(ca["in_off"], ca["in_sym"], ca["out_off"], ca["out_sym"], ca["weight"])
+    return oc, w, c
+
+
+def test_golden_cipher_cascade(oracle, golden_dir):
+    """carmel --train-cascade -HJ cipher.data cipher.wfsa cipher.fst (commands.trace:6903-6952): composed-arc
+    weights are gathered from the chains, counts scattered back, each member normalised by its own method"""
+    import re
+    from carmel_amd.trainer import TrainOpts, train
+    gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["cipher"]
+    oc, w, c = _cascade_from_golden(oracle, golden_dir, ["cipher.wfsa", "cipher.fst"], "cipher.data")
+    assert (w.n_states, w.n_arcs) == (gold["composed"]["states"], gold["composed"]["arcs"])
+    fb = _fb(w, c, cascade=oc.as_dict([NORM_CONDITIONAL, NORM_CONDITIONAL]))
+    best, trace = train(fb, TrainOpts())
+    assert len(trace) == len(gold["iters"]) == 22
+    for t, g in zip(trace, gold["iters"]):
+        assert sig6(t["log2_prob"]) == g["log2_prob"]
+        assert sig6(t["log2_ppx_example"]) == g["log2_ppx_example"]
+        assert t["new_best"] == g["new_best"]
+    for t, g in zip(trace[1:], gold["iters"][1:]):
+        assert t["rel_ppx_ratio_ln"] == pytest.approx(math.log(float(g["rel_ppx_ratio"])), rel=1e-7)
+
+    def weights(txt):
+        d = {}
+        for s, t, i, o, x in re.findall(r'\((\S+) \((\S+) (\S+) (\S+) ([^()! ]+)!?\)\)', txt):
+            d[(s, t, i, o)] = math.exp(float(x[2:])) if x.startswith("e^") else float(x)
+        return d
+    pw = fb.weights()
+    for m, name in enumerate(["cipher.wfsa.trained", "cipher.fst.trained"]):
+        got = weights(oc.write_member(m, pw))
+        exp = weights(open(os.path.join(golden_dir, name)).read())
+        assert set(got) == set(exp) and len(exp) > 500
+        for k in exp:
+            assert got[k] == pytest.approx(exp[k], rel=1e-7, abs=1e-300)
+    fb.close()
+
+
+def test_golden_tagging_cascade(oracle, golden_dir):
+    """carmel --train-cascade -HJ tagging.data tagging.fsa tagging.fst (commands.trace:5866-5890): 46 states /
+    400994 composed arcs, 1005 pairs, 9 iterations"""
+    from carmel_amd.trainer import TrainOpts, train
+    gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["tagging"]
+    oc, w, c = _cascade_from_golden(oracle, golden_dir, ["tagging.fsa", "tagging.fst"], "tagging.data")
+    assert (w.n_states, w.n_arcs) == (gold["composed"]["states"], gold["composed"]["arcs"])
+    fb = _fb(w, c, cascade=oc.as_dict([NORM_CONDITIONAL, NORM_CONDITIONAL]))
+    best, trace = train(fb, TrainOpts())
+    assert len(trace) == len(gold["iters"]) == 9
+    for t, g in zip(trace, gold["iters"]):
+        assert sig6(t["log2_prob"]) == g["log2_prob"]
+        assert sig6(t["log2_ppx_example"]) == g["log2_ppx_example"]
+        assert t["new_best"] == g["new_best"]
+        assert t["n_example"] == g["n_example"]
+    fb.close()
