@@ -1,0 +1,384 @@
+// carmel_main.cpp — `carmel`-compatible command line for the training path, running on the GPU through the C-ABI
+// (include/carmel_hip.h).  Accepts the training subset of carmel's switches (carmel.cc:929-1066):
+//
+//   carmel [-t] [--train-cascade] [-M n] [-e d] [-X r] [-f w] [-U] [-u | -j] [-? | -:] [-q] [-d] [-K] [-m] [-T n]
+//          [-F out] [-H] [-J] [-Z] [-D] [--normby=JCN..] [--priors=a,b,..] [--gpu=n] corpus transducer [transducer ...]
+//
+// With one transducer the trained transducer goes to stdout (or -F file); with --train-cascade every member is
+// written to <file>.trained (cascade.h:23-32).  EM log lines on stderr have the reference's wording
+// (train.cc:587-613, 639-657, 669-671).  Exit codes follow carmel.cc (-2 bad transducer, -9 unreadable file,
+// -11 on an error caught at top level).
+//
+// The iteration control below restates WFST::train (train.cc:503-678); every E-step and M-step runs on the GPU.
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <sstream>
+#include "../../../include/carmel_hip.h"
+#include "compose.hpp"
+#include "wfst.hpp"
+
+using namespace carmel_host;
+
+static std::string slurp(const char* fn) {
+  std::ifstream f(fn, std::ios::binary);
+  if (!f) throw std::runtime_error(std::string("File ") + fn + " could not be opened for input.");
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+static void hip_check(int rc, const char* what) {
+  if (rc != CARMEL_HIP_OK) throw std::runtime_error(std::string(what) + ": " + carmel_hip_last_error());
+}
+static std::string base2(double ln_value) {  // weight.h:529-532,603 as_base(2) at the stream's default precision
+  char buf[64];
+  std::snprintf(buf, sizeof buf, "2^%.6g", ln_value / std::log(2.0));
+  return buf;
+}
+
+struct Options {
+  bool flags[256] = {false};
+  bool train_cascade = false;
+  long max_iter = 500;  // train_opts default (fst.h:1080-1095); -1 == "-M" without a number
+  double converge = 1e-4, converge_ppx_ratio = .999, smooth_floor = 0;
+  int norm = CARMEL_HIP_NORM_CONDITIONAL;
+  std::string normby, priors, out_file;
+  int index_threshold = 32, gpu = 0;
+  std::vector<const char*> files;
+};
+
+static Options parse_args(int argc, char** argv) {
+  Options o;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    if (a.rfind("--", 0) == 0) {
+      std::string k = a.substr(2), v;
+      size_t e = k.find('=');
+      if (e != std::string::npos) {
+        v = k.substr(e + 1);
+        k = k.substr(0, e);
+      }
+      if (k == "train-cascade")
+        o.train_cascade = true;
+      else if (k == "normby")
+        o.normby = v;
+      else if (k == "priors")
+        o.priors = v;
+      else if (k == "gpu")
+        o.gpu = std::atoi(v.c_str());
+      else
+        std::cerr << "option " << k << " = " << v << " (ignored by the GPU training front end)\n";
+      continue;
+    }
+    if (a.size() > 1 && a[0] == '-') {
+      for (size_t j = 1; j < a.size(); ++j) {
+        unsigned char c = (unsigned char)a[j];
+        o.flags[c] = true;
+        if (c == 'j') o.norm = CARMEL_HIP_NORM_JOINT;
+        if (c == 'u') o.norm = CARMEL_HIP_NORM_NONE;
+        if (c == 'M') o.max_iter = -1;
+      }
+      // a switch that takes a value consumes the next argument (carmel.cc:929-1000)
+      auto value = [&]() -> const char* {
+        if (i + 1 >= argc) throw std::runtime_error("missing value after " + a);
+        return argv[++i];
+      };
+      for (size_t j = 1; j < a.size(); ++j) switch (a[j]) {
+          case 'M':  // "-M n"; a bare -M means "report the corpus perplexity only" (train.cc:516-517)
+            if (i + 1 < argc && (std::isdigit((unsigned char)argv[i + 1][0]) || argv[i + 1][0] == '-') &&
+                std::strspn(argv[i + 1], "-0123456789") == std::strlen(argv[i + 1]))
+              o.max_iter = std::atol(value());
+            break;
+          case 'e': o.converge = std::atof(value()); break;
+          case 'X': o.converge_ppx_ratio = std::atof(value()); break;
+          case 'f': o.smooth_floor = std::atof(value()); break;
+          case 'T': o.index_threshold = std::atoi(value()); break;
+          case 'F': o.out_file = value(); break;
+          default: break;
+        }
+      continue;
+    }
+    o.files.push_back(argv[i]);
+  }
+  if (o.train_cascade) o.flags[(unsigned)'t'] = true;
+  return o;
+}
+
+struct CorpusStats {  // training_corpus counters over the pairs that have a derivation (train.h:151-168)
+  double n_pairs = 0, total_weight = 0, n_input = 0, n_output = 0;
+};
+
+static int run(int argc, char** argv) {
+  Options o = parse_args(argc, argv);
+  const bool training = o.flags[(unsigned)'t'];
+  if (o.files.empty() || (training && o.files.size() < 2)) {
+    std::cerr << "usage: carmel -t [--train-cascade] [-M n] [-e d] [-X r] [-f w] [-U] [-u|-j] [-HJZD] [-F out] "
+                 "corpus transducer [transducer ...]\n"
+                 "       carmel [-HJZD] transducer [transducer ...]     (compose and print; host only)\n";
+    return -12;
+  }
+  const bool quiet = o.flags[(unsigned)'q'];
+  if (!training) o.files.insert(o.files.begin(), (const char*)0);  // no corpus argument
+  const size_t nw = o.files.size() - 1;
+  std::string corpus_text = training ? slurp(o.files[0]) : std::string();
+  std::vector<Transducer> member(nw);
+  for (size_t i = 0; i < nw; ++i) {
+    try {
+      member[i].parse(slurp(o.files[i + 1]), !o.flags[(unsigned)'K']);  // carmel.cc:1197
+    } catch (std::exception& e) {
+      std::cerr << e.what() << "\nBad format of transducer file: " << o.files[i + 1] << "\n";
+      return -2;
+    }
+    if (!o.flags[(unsigned)'m'] && nw > 1) member[i].drop_state_names();
+  }
+  // ---- composition chain, left to right (carmel.cc:1287-1355) ----
+  if (!o.flags[(unsigned)'d']) member[0].prune_useless();
+  ParamTable params;
+  ChainTable chains;
+  std::unique_ptr<Transducer> composed;
+  Transducer* result = &member[0];
+  const bool cascade = o.train_cascade && nw > 1;
+  if (nw > 1) {
+    for (size_t i = 0; i < nw; ++i) params.add_member(member[i]);
+    Composer comp(params, chains, (unsigned)o.index_threshold);
+    Operand A, B;
+    for (size_t i = 1; i < nw; ++i) {
+      A.bind(result, i > 1, params.member_base[0]);
+      B.bind(&member[i], false, params.member_base[i]);
+      std::unique_ptr<Transducer> next(new Transducer());
+      if (!comp.run(A, B, *next)) {
+        std::cerr << ")\nEmpty or invalid result of composition with transducer \"" << o.files[i + 1] << "\".\n";
+        return -3;
+      }
+      size_t st = next->states.size(), ar = next->num_arcs();
+      if (!o.flags[(unsigned)'d']) next->prune_useless();
+      if (!quiet) {
+        std::cerr << "\n\t(" << st << " states / " << ar << " arcs";
+        if (next->states.size() != st || next->num_arcs() != ar)
+          std::cerr << " reduce-> " << next->states.size() << "/" << next->num_arcs();
+        std::cerr << ")";
+      }
+      composed = std::move(next);
+      result = composed.get();
+    }
+    if (!quiet) std::cerr << std::endl;
+  }
+  if (!training) {  // plain `carmel a b ...`: print the (reduced) composition — no GPU involved
+    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
+    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
+    if (o.flags[(unsigned)'c'])
+      std::cout << "Number of states in result: " << result->states.size() << "\nNumber of arcs in result: "
+                << result->num_arcs() << "\n";
+    else
+      std::cout << result->to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
+    return 0;
+  }
+  if (nw > 1 && !cascade)
+    throw std::runtime_error("training the composition of several transducers without --train-cascade is outside "
+                             "this front end");
+  // ---- normalisation methods per member (carmel.cc:488-499) ----
+  std::vector<int> norms(nw, o.norm);
+  std::vector<double> addc(nw, 0.0);
+  for (size_t i = 0; i < o.normby.size() && i < nw; ++i) {
+    char ch = o.normby[i];
+    norms[i] = (ch == 'J' || ch == 'j') ? CARMEL_HIP_NORM_JOINT
+               : (ch == 'N' || ch == 'n') ? CARMEL_HIP_NORM_NONE
+                                          : CARMEL_HIP_NORM_CONDITIONAL;
+  }
+  {
+    std::stringstream ss(o.priors);
+    std::string tok;
+    size_t i = 0;
+    while (std::getline(ss, tok, ',') && i < nw) addc[i++] = std::atof(tok.c_str());
+  }
+  // ---- corpus ----
+  HostPairs pairs;
+  std::string warn;
+  parse_corpus(*result, corpus_text, pairs, &warn);
+  std::cerr << warn;
+  if (pairs.size() == 0) {  // corpus.set_null() (carmel.cc:1421)
+    pairs.weight.push_back(1.0);
+    pairs.in_off.push_back(0);
+    pairs.out_off.push_back(0);
+  }
+  // ---- GPU trainer ----
+  std::vector<uint32_t> src, dst, in, out, group;
+  std::vector<double> logw;
+  result->flatten(src, dst, in, out, logw, group);
+  carmel_hip_trainer* t = 0;
+  hip_check(carmel_hip_create(&t, o.gpu, (uint32_t)result->states.size(), result->final_state, logw.size(), src.data(),
+                              dst.data(), in.data(), out.data(), logw.data(), group.data()),
+            "carmel_hip_create");
+  struct Guard {
+    carmel_hip_trainer* t;
+    ~Guard() { carmel_hip_destroy(t); }
+  } guard{t};
+  if (cascade) {
+    std::vector<uint64_t> coff(1, 0), cpar;
+    for (auto& c : chains.chains) {
+      cpar.insert(cpar.end(), c.begin(), c.end());
+      coff.push_back(cpar.size());
+    }
+    if (cpar.empty()) cpar.push_back(0);
+    hip_check(carmel_hip_set_cascade(t, params.logw.size(), params.logw.data(), params.group.data(),
+                                     params.member.data(), params.src.data(), params.in.data(), (uint32_t)nw,
+                                     norms.data(), addc.data(), chains.chains.size(), coff.data(), cpar.data()),
+              "carmel_hip_set_cascade");
+  } else
+    hip_check(carmel_hip_set_norm(t, norms[0], addc[0]), "carmel_hip_set_norm");
+  hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509
+  if (!cascade || o.smooth_floor > 0)
+    hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
+  hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
+                                  pairs.out_sym.data(), pairs.weight.data()),
+            "carmel_hip_set_corpus");
+  std::vector<uint8_t> has(pairs.size(), 0);
+  carmel_hip_lattice_stats ls;
+  hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+  CorpusStats cs;
+  for (size_t p = 0; p < pairs.size(); ++p) {
+    if (!has[p]) {
+      std::cerr << "No derivations in transducer for input/output #" << (p + 1) << "\n";  // cached_derivs.h:54-58
+      continue;
+    }
+    cs.n_pairs += 1;
+    cs.total_weight += pairs.weight[p];
+    cs.n_input += (double)(pairs.in_off[p + 1] - pairs.in_off[p]);
+    cs.n_output += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
+  }
+  if (ls.n_cyclic_pairs)
+    std::cerr << "Warning: at least one cycle in derivations for " << ls.n_cyclic_pairs
+              << " example(s).  Forward/backward will miss some paths.\n";  // derivations.h:726-728
+  if (cs.n_pairs == 0) throw std::runtime_error("No training example had a derivation - aborting training.");
+  std::ostream& log = std::cerr;
+  auto print_ppx = [&](double ln_p) {  // weight.h:314-329 print_ppx_symbol
+    double n_sym = std::max(cs.n_output, cs.n_input);
+    log << "probability=" << base2(ln_p);
+    if (n_sym) log << " per-symbol-perplexity(N=" << n_sym << ")=" << base2(-ln_p / n_sym);
+    if (cs.n_pairs) log << " per-example-perplexity(N=" << cs.n_pairs << ")=" << base2(-ln_p / cs.n_pairs);
+  };
+  // ---- WFST::train (train.cc:503-678) ----
+  carmel_hip_estimate_result er;
+  if (o.max_iter == -1) {  // "-M" alone: just the corpus perplexity (train.cc:516-517)
+    hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+    log << "Corpus ";
+    print_ppx(er.sum_logprob);
+    log << "\n";
+  } else if (o.max_iter == 0 || o.max_iter == 1) {  // train.cc:520-538 (no random restarts here)
+    hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+    log << "Corpus ";
+    print_ppx(er.sum_logprob);
+    log << "\n";
+    if (o.max_iter == 1) {
+      double mc;
+      hip_check(carmel_hip_maximize(t, 1.0, &mc), "carmel_hip_maximize");
+    } else
+      log << "0 iterations specified for training; weights are left unchanged (fractional-count output is not "
+             "offered by the GPU front end).\n";
+  } else {
+    double best = std::numeric_limits<double>::infinity(), last_ppx = best, last_change = 10.0;
+    bool have_good = false;
+    long iter = 0;
+    for (;;) {
+      const bool first_time = iter == 0;
+      ++iter;
+      const bool cascade_counts = cascade && !first_time;
+      if (cascade_counts) hip_check(carmel_hip_save_counts(t), "carmel_hip_save_counts");
+      if (iter > o.max_iter && have_good) {
+        log << "Maximum number of iterations (" << o.max_iter
+            << ") reached before convergence criteria was met - greatest arc weight change was "
+            << format_weight(std::log(last_change), W_SOMETIMES_LOG) << "\n";
+        break;
+      }
+      hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+      const double new_ppx = -er.sum_weighted_logprob / cs.total_weight;  // ln p.ppxper(totalEmpiricalWeight)
+      log << "i=" << iter << " (rate=1): ";
+      print_ppx(er.sum_logprob);
+      if (new_ppx < best && (!cascade || cascade_counts)) {
+        log << " (new best)";
+        best = new_ppx;
+        have_good = true;
+        hip_check(carmel_hip_save_best(t), "carmel_hip_save_best");
+      }
+      double ratio_ln = kNegInf;
+      if (first_time) {
+        log << std::endl << "Initial best start point ppx=" << base2(new_ppx) << "\n";
+      } else {
+        ratio_ln = (new_ppx - last_ppx) / std::fabs(new_ppx);  // weight.h:247-249
+        log << " (relative-perplexity-ratio=" << format_weight(ratio_ln, W_SOMETIMES_LOG) << ")";
+        if (last_change < 1) log << ", max {d(weight)}=" << format_weight(std::log(last_change), W_SOMETIMES_LOG);
+        log << std::endl;
+      }
+      if (ratio_ln >= std::log(o.converge_ppx_ratio)) {
+        log << "Converged - per-example perplexity ratio exceeds "
+            << format_weight(std::log(o.converge_ppx_ratio), W_SOMETIMES_LOG) << " after " << iter << " iterations.\n";
+        if (!have_good)
+          log << "Because of the --train-cascade implementation, we need another iteration even though we've "
+                 "converged.\n";
+        else
+          break;
+      }
+      hip_check(carmel_hip_maximize(t, 1.0, &last_change), "carmel_hip_maximize");
+      if (last_change <= o.converge && have_good) {
+        log << "Converged - maximum weight change less than " << format_weight(std::log(o.converge), W_SOMETIMES_LOG)
+            << " after " << iter << " iterations.\n";
+        break;
+      }
+      last_ppx = new_ppx;
+    }
+    log << "Setting weights to model with lowest per-example-perplexity ( = "
+           "prod[modelprob(example)]^(-1/num_examples) = 2^(-log_2(p_model(corpus))/N) = "
+        << base2(best) << std::endl;
+    hip_check(carmel_hip_load_best(t), "carmel_hip_load_best");
+  }
+  // ---- output (carmel.cc:1435-1437, 1485-1496; cascade.h:23-32) ----
+  int wstyle = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
+  if (o.flags[(unsigned)'D']) wstyle = W_NEVER_LOG;
+  const bool full = o.flags[(unsigned)'J'], per_arc = o.flags[(unsigned)'H'];
+  if (cascade) {
+    std::vector<double> pw(params.logw.size());
+    hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
+    const char* dir = std::getenv("CARMEL_TRAINED_DIR");  // tests: write beside nothing read-only
+    for (size_t i = 0; i < nw; ++i) {
+      member[i].set_weights(pw.data() + params.member_base[i]);
+      std::string fn = std::string(o.files[i + 1]) + ".trained";
+      if (dir) {
+        std::string b = o.files[i + 1];
+        size_t sl = b.rfind('/');
+        fn = std::string(dir) + "/" + (sl == std::string::npos ? b : b.substr(sl + 1)) + ".trained";
+      }
+      log << "Writing trained " << o.files[i + 1] << " to " << fn << std::endl;
+      std::ofstream of(fn.c_str());
+      of << member[i].to_text(full, per_arc, wstyle);
+    }
+  } else {
+    std::vector<double> w(logw.size());
+    hip_check(carmel_hip_get_weights(t, w.data()), "carmel_hip_get_weights");
+    result->set_weights(w.data());
+    std::string txt = result->to_text(full, per_arc, wstyle);
+    if (!o.out_file.empty()) {
+      std::ofstream of(o.out_file.c_str());
+      if (!of) {
+        std::cerr << "Could not create file " << o.out_file << ".\n";
+        return -8;
+      }
+      of << txt;
+    } else
+      std::cout << txt;
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  try {
+    return run(argc, argv);
+  } catch (std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
+    return -11;
+  }
+}
