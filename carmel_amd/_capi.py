@@ -22,6 +22,8 @@ SYMBOLS = [
     "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_save_counts",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_free",
+    "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
+    "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform",
 ]
 
 
@@ -34,6 +36,12 @@ class LatticeStats(C.Structure):
 class EstimateResult(C.Structure):
     _fields_ = [("sum_logprob", C.c_double), ("sum_weighted_logprob", C.c_double), ("n_pairs", C.c_uint64),
                 ("kernel_ms", C.c_double)]
+
+
+class GibbsOpts(C.Structure):
+    _fields_ = [("iter", C.c_uint32), ("burnin", C.c_uint32), ("seed", C.c_uint64), ("mode", C.c_int),
+                ("uniform_p0", C.c_int), ("dirichlet_p0", C.c_int), ("final_counts", C.c_int),
+                ("exclude_prior", C.c_int), ("min_prior", C.c_double)]
 
 
 def _load():
@@ -92,6 +100,16 @@ def _load():
     lib.carmel_hip_host_export_lanes.restype = None
     lib.carmel_hip_host_free.argtypes = [vp]
     lib.carmel_hip_host_free.restype = None
+    lib.carmel_hip_gibbs_create.argtypes = [C.POINTER(vp), vp, C.POINTER(GibbsOpts)]
+    lib.carmel_hip_gibbs_destroy.argtypes = [vp]
+    lib.carmel_hip_gibbs_n_blocks.argtypes = [vp]
+    lib.carmel_hip_gibbs_n_blocks.restype = C.c_uint32
+    lib.carmel_hip_gibbs_max_sample.argtypes = [vp]
+    lib.carmel_hip_gibbs_max_sample.restype = C.c_uint32
+    lib.carmel_hip_gibbs_run.argtypes = [vp, vp, vp]
+    lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
+    lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    lib.carmel_hip_gibbs_uniform.restype = C.c_double
     return lib
 
 

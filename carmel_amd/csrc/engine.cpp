@@ -9,95 +9,15 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
-#include "../../include/carmel_hip.h"
-#include "kernels.hpp"
-
-using namespace carmel_hip;
+#include "engine.hpp"
 
 static thread_local std::string g_err;
-static int fail(int code, const std::string& msg) {
+namespace carmel_hip {
+int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
-#define HIPCHK(x)                                                                                             \
-  do {                                                                                                        \
-    hipError_t e_ = (x);                                                                                      \
-    if (e_ != hipSuccess)                                                                                     \
-      return fail(CARMEL_HIP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                        \
-  } while (0)
-
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  ~DevBuf() { release(); }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    n = 0;
-  }
-  hipError_t alloc(size_t count) {
-    release();
-    n = count;
-    if (!count) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
-  }
-  hipError_t upload(const std::vector<T>& v, hipStream_t s) {
-    hipError_t e = alloc(v.size());
-    if (e != hipSuccess || v.empty()) return e;
-    return hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
-  }
-  size_t bytes() const { return n * sizeof(T); }
-};
-
-struct carmel_hip_trainer {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  HostWfst w;
-  HostCorpus corpus;
-  bool have_corpus = false, have_lattices = false, cascade = false;
-  LatticeSet lat;  // host copy of descriptors (classes); bulk arrays are freed after upload
-  // device: model
-  DevBuf<double> arc_logw;      // composed-arc weights (single transducer: THE parameters)
-  DevBuf<double> counts;        // n_arcs + 4
-  DevBuf<uint32_t> arc_group;   // groupId (single) / chain id (cascade)
-  // device: parameters (cascade only; single transducer aliases the arc arrays)
-  DevBuf<double> param_logw_c, param_counts_c;
-  DevBuf<uint32_t> param_group_c;
-  DevBuf<uint64_t> chain_off, chain_param;
-  uint64_t n_params = 0, n_chains = 0;
-  // M-step state over parameters
-  DevBuf<double> old_logw, em_logw, best_logw, prior;
-  DevBuf<uint32_t> norm_of;
-  DevBuf<uint64_t> group_off, norm_perm, big_groups;
-  DevBuf<double> add_count, gscale;
-  bool any_add_count = false;
-  DevBuf<unsigned long long> maxchg;
-  uint64_t n_norm_groups = 0;
-  bool have_norm = false, have_prior = false, prior_nonzero = false;
-  int norm_group_by = CARMEL_HIP_NORM_CONDITIONAL;
-  double norm_add_count = 0, smooth_floor = 0;
-  // device: lattices
-  DevBuf<BundleDesc> bundles;
-  DevBuf<uint2_t> in_arcs, out_arcs;
-  DevBuf<uint32_t> in_off, out_off, level_off, pair_start, pair_final, pair_id;
-  DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
-  DevBuf<LaneGroup> lane_groups;
-  DevBuf<uint2_t> lane_fwd, lane_bwd;
-  DevBuf<uint32_t> lane_pair, lane_nstates;
-  DevBuf<double> lane_logw, post, wcache;
-  DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;
-  uint64_t lane_records = 0;
-  uint64_t device_bytes = 0;
-
-  double* ext_counts = nullptr;  // caller-owned n_arcs + 4 doubles (carmel_hip_use_external_counts)
-  double* counts_ptr() { return ext_counts ? ext_counts : counts.p; }
-  double* params() { return cascade ? param_logw_c.p : arc_logw.p; }
-  double* pcounts() { return cascade ? param_counts_c.p : counts_ptr(); }
-  uint32_t* pgroup() { return cascade ? param_group_c.p : arc_group.p; }
-  uint64_t np() const { return cascade ? n_params : w.n_arcs; }
-};
+}  // namespace carmel_hip
 
 extern "C" {
 
@@ -309,6 +229,8 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       norm_of[k] = it->second;
   }
   t->n_norm_groups = add.size();
+  t->h_norm_of = norm_of;
+  t->h_group_add = add;
   {
     // members of every group, contiguous (counting sort by group id); big groups listed separately
     std::vector<uint64_t> off(add.size() + 1, 0), perm, big;
@@ -390,6 +312,9 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
   for (uint64_t j = 0; j < chain_off[n_chains]; ++j)
     if (chain_param[j] >= n_params) return fail(CARMEL_HIP_ERR_ARG, "chain refers to a parameter out of range");
   t->cascade = true;
+  t->h_param_group.assign(param_group, param_group + n_params);
+  t->h_chain_off.assign(chain_off, chain_off + n_chains + 1);
+  t->h_chain_param.assign(chain_param, chain_param + chain_off[n_chains]);
   t->n_params = n_params;
   t->n_chains = n_chains;
   hipStream_t s = t->stream;

@@ -1,0 +1,549 @@
+// gibbs.hip — blocked Gibbs sampling of derivations (`carmel --crp`) on the GPU.
+//
+// Replaces carmel_gibbs + gibbs_base (/root/reference/carmel/src/gibbs.cc:15-41, 114-186, 306-371;
+// graehl/shared/gibbs.hpp:106-227, 589-638, 769-877) and derivations::random_path (derivations.h:318-375).
+//
+// One block = one training pair = one cached derivation lattice.  Per block and sweep: take the block's previous
+// sample out of the CRP counts, give every lattice arc the proposal weight prod_{p in chain} count[p]/normsum[p],
+// sweep backward (beta), walk start->goal choosing an out-arc with probability proportional to (w * beta[dest])^power,
+// record the chosen arcs' parameters, put them back into the counts.
+//
+// Two schedules:
+//   mode 0 (exact):    blocks are resampled strictly one after another inside ONE workgroup — the reference's
+//                      Markov chain; given the same uniforms it reproduces the reference's samples.
+//   mode 1 (parallel): every workgroup resamples its blocks against the counts of the previous sweep with its OWN
+//                      previous sample taken out (counterfactual counts, looked up through a small LDS table) and
+//                      the counts are rebuilt after the sweep.  This is a different (approximate, "stale count")
+//                      chain — SURVEY.md section 8e — and is never the default.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include "engine.hpp"
+#include "rng.hpp"
+
+namespace carmel_hip {
+
+#define G_NEG_INF (-__builtin_huge_val())
+#define G_NONORM 0xffffffffu
+
+struct GibbsArgs {
+  const BundleDesc* bundles;
+  const uint32_t* block_bundle;  // block -> bundle index
+  const uint2* out_arcs;
+  const uint32_t* out_off;
+  const uint32_t* level_off;
+  const uint32_t* pair_start;
+  const uint32_t* pair_final;
+  const double* pair_logw;
+  // composed arc -> chain of parameter ids
+  const uint64_t* chain_off;   // per composed arc (already resolved through the chain id)
+  const uint32_t* chain_param;
+  // parameters
+  const uint32_t* p_norm;      // G_NONORM = fixed probability (locked arc / NONE member): prob = p_prior
+  const double* p_prior;
+  double* p_x;                 // current count          (delta_sum::x)
+  double* p_s;                 // time-integrated count  (delta_sum::s)
+  double* p_tmax;              //                        (delta_sum::tmax)
+  double* normsum;
+  double* ccount;              // cache model (gibbs.hpp:678-742)
+  double* csum;
+  const double* snap_x;        // mode 1: counts / normsums frozen at the start of the sweep
+  const double* snap_norm;
+  // samples
+  const uint64_t* sample_off;  // capacity offsets per block
+  uint32_t* sample_len;
+  uint32_t* sample_ids;
+  uint32_t* new_len;           // mode 1: next sweep's samples are written beside the current ones
+  uint32_t* new_ids;
+  // scratch
+  double* gw;                  // per lattice arc (bundle out_base + a): ln proposal weight
+  double* beta;                // per lattice state (bundle off_base + s)
+  double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob
+  uint64_t seed;
+  uint32_t n_blocks, iter;
+  double time, power;
+};
+
+__device__ __forceinline__ double g_lwadd(double a, double b) {  // weight.h:765-801
+  if (a == G_NEG_INF) return b;
+  if (b == G_NEG_INF) return a;
+  double d = a - b;
+  if (d > 36.0) return a;
+  if (d < -36.0) return b;
+  if (d < 0) return b + log1p(exp(d));
+  return a + log1p(exp(-d));
+}
+
+// gibbs_param::addc (gibbs.hpp:210-217) + delta_sum::add_delta (delta_sum.hpp:74-84)
+__device__ __forceinline__ void g_addc(const GibbsArgs& G, uint32_t p, double d) {
+  const uint32_t n = G.p_norm[p];
+  if (n == G_NONORM) return;
+  G.normsum[n] += d;
+  const double moret = G.time - G.p_tmax[p];
+  if (moret > 0) {
+    G.p_tmax[p] = G.time;
+    G.p_s[p] += moret * G.p_x[p];
+  } else if (moret < 0)
+    G.p_s[p] += d * (-moret);
+  G.p_x[p] += d;
+}
+
+// proposal probability of parameter p (gibbs.hpp:153-157).  own_x / own_n: counts to take out first (mode 1).
+template <bool SNAP>
+__device__ __forceinline__ double g_prob(const GibbsArgs& G, uint32_t p, const uint32_t* own_ids, uint32_t own_len,
+                                         double own_wt) {
+  const uint32_t n = G.p_norm[p];
+  if (n == G_NONORM) return G.p_prior[p];
+  if (!SNAP) return G.p_x[p] / G.normsum[n];
+  double x = G.snap_x[p], ns = G.snap_norm[n];
+  for (uint32_t k = 0; k < own_len; ++k) {  // counterfactual: this block's previous sample does not count
+    const uint32_t q = own_ids[k];
+    if (q == p) x -= own_wt;
+    if (G.p_norm[q] == n) ns -= own_wt;
+  }
+  return x / ns;
+}
+
+// Resample one block.  Called by every thread of the workgroup; serial parts run on thread 0.
+// own_ids (LDS, mode 1 only): the block's previous sample.
+template <bool SNAP>
+__device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_ids, uint32_t own_cap, double* red) {
+  const int tid = threadIdx.x, NT = blockDim.x;
+  const BundleDesc d = G.bundles[G.block_bundle[b]];
+  const uint2* __restrict__ oa = G.out_arcs + d.out_base;
+  const uint32_t* __restrict__ ooff = G.out_off + d.off_base;
+  const uint32_t* __restrict__ lvl = G.level_off + d.level_base;
+  double* gw = G.gw + d.out_base;
+  double* beta = G.beta + d.off_base;
+  const double wt = exp(G.pair_logw[d.pair_base]);
+  const uint64_t so = G.sample_off[b];
+  uint32_t* ids = G.sample_ids + so;
+  uint32_t own_len = 0;
+  if (SNAP) {
+    own_len = G.sample_len[b];
+    if (own_len > own_cap) own_len = own_cap;  // capacity is sized from the longest path; cannot trigger
+    for (uint32_t k = tid; k < own_len; k += NT) own_ids[k] = ids[k];
+    __syncthreads();
+  } else {
+    // 1. take the previous sample out of the counts (gibbs.hpp:851-852)
+    if (tid == 0) {
+      const uint32_t n = G.sample_len[b];
+      for (uint32_t k = 0; k < n; ++k) g_addc(G, ids[k], -wt);
+    }
+    __syncthreads();
+  }
+  // 2. proposal weight of every lattice arc (gibbs.cc:348-359)
+  for (uint32_t a = tid; a < (uint32_t)d.n_arcs; a += NT) {
+    const uint32_t arc = oa[a].y;
+    double w = 0.0;
+    for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j)
+      w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
+    gw[a] = w;
+  }
+  for (uint32_t s = tid; s < d.n_states; s += NT) beta[s] = G_NEG_INF;
+  __syncthreads();
+  if (tid == 0) beta[G.pair_final[d.pair_base]] = 0.0;
+  __syncthreads();
+  // 3. backward sweep, level-synchronous
+  for (uint32_t l = d.n_levels; l-- > 0;) {
+    for (uint32_t s = lvl[l] + tid; s < lvl[l + 1]; s += NT) {
+      const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+      if (a0 == a1) continue;
+      double acc = G_NEG_INF;
+      for (uint32_t a = a1; a-- > a0;) acc = g_lwadd(acc, gw[a] + beta[oa[a].x]);  // list order = newest first
+      beta[s] = acc;
+    }
+    __syncthreads();
+  }
+  // 4. walk start -> goal (derivations.h:361-374; random.ipp:111-127), 5. probabilities, 6. put the new sample in
+  if (tid == 0) {
+    uint32_t* out_ids = SNAP ? (G.new_ids + so) : ids;
+    uint32_t n = 0, step = 0;
+    uint32_t s = G.pair_start[d.pair_base];
+    const uint32_t fin = G.pair_final[d.pair_base];
+    while (s != fin) {
+      const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+      double sum = G_NEG_INF;
+      for (uint32_t a = a1; a-- > a0;) sum = g_lwadd(sum, (gw[a] + beta[oa[a].x]) * G.power);
+      if (sum == G_NEG_INF) sum = 0.0;
+      double tot = 0.0;
+      for (uint32_t a = a1; a-- > a0;) tot += exp((gw[a] + beta[oa[a].x]) * G.power - sum);
+      double choice = tot * gibbs_uniform(G.seed, G.iter, b, step++);
+      uint32_t pick = a0;
+      for (uint32_t a = a1; a-- > a0;) {
+        choice -= exp((gw[a] + beta[oa[a].x]) * G.power - sum);
+        pick = a;
+        if (choice < 0) break;
+      }
+      const uint32_t arc = oa[pick].y;
+      for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) out_ids[n++] = G.chain_param[j];
+      s = oa[pick].x;
+    }
+    double cheap = 0.0, cache = 0.0;
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t p = out_ids[k];
+      cheap += log(g_prob<SNAP>(G, p, own_ids, own_len, wt));
+      if (!SNAP) {  // cache model: counts restart from the priors every sweep and grow by one per use
+        const uint32_t nn = G.p_norm[p];
+        double q = G.p_prior[p];
+        if (nn != G_NONORM) {
+          q = G.ccount[p] / G.csum[nn];
+          G.ccount[p] += 1.0;
+          G.csum[nn] += 1.0;
+        }
+        cache += log(q);
+      }
+    }
+    if (SNAP) {
+      G.new_len[b] = n;
+      red[0] += cheap;
+    } else {
+      G.sample_len[b] = n;
+      for (uint32_t k = 0; k < n; ++k) g_addc(G, out_ids[k], wt);
+      red[0] += cheap;
+      red[1] += cache;
+    }
+  }
+  __syncthreads();
+}
+
+// mode 0: the whole sweep in one workgroup, blocks strictly in order
+__global__ __launch_bounds__(256) void gibbs_sweep_exact_kernel(GibbsArgs G) {
+  __shared__ double red[2];
+  if (threadIdx.x == 0) red[0] = red[1] = 0.0;
+  __syncthreads();
+  for (uint32_t b = 0; b < G.n_blocks; ++b) g_resample_block<false>(G, b, nullptr, 0, red);
+  if (threadIdx.x == 0) {
+    G.iter_out[0] = red[1];
+    G.iter_out[1] = red[0];
+  }
+}
+
+// mode 1: blocks spread over the grid, counterfactual counts from the snapshot
+__global__ __launch_bounds__(64) void gibbs_sweep_parallel_kernel(GibbsArgs G, uint32_t own_cap) {
+  extern __shared__ uint32_t own_ids[];
+  __shared__ double red[2];
+  if (threadIdx.x == 0) red[0] = red[1] = 0.0;
+  __syncthreads();
+  for (uint32_t b = blockIdx.x; b < G.n_blocks; b += gridDim.x) g_resample_block<true>(G, b, own_ids, own_cap, red);
+  if (threadIdx.x == 0) unsafeAtomicAdd(G.iter_out + 1, red[0]);
+}
+// mode 1, after the sweep: counts := prior + weighted uses in the new samples (atomics; sample ids are scattered)
+__global__ void gibbs_recount_kernel(GibbsArgs G, double* new_x, double* new_norm) {
+  for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < G.n_blocks; b += gridDim.x * blockDim.x) {
+    const BundleDesc d = G.bundles[G.block_bundle[b]];
+    const double wt = exp(G.pair_logw[d.pair_base]);
+    const uint32_t* ids = G.new_ids + G.sample_off[b];
+    const uint32_t n = G.new_len[b];
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t p = ids[k], nn = G.p_norm[p];
+      if (nn == G_NONORM) continue;
+      unsafeAtomicAdd(new_x + p, wt);
+      unsafeAtomicAdd(new_norm + nn, wt);
+    }
+  }
+}
+// mode 1: fold the sweep's count change into the time-weighted sums (delta_sum::add_delta with d = new - old)
+__global__ void gibbs_commit_kernel(GibbsArgs G, const double* new_x, uint64_t n_params) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_params; p += (uint64_t)gridDim.x * blockDim.x) {
+    if (G.p_norm[p] == G_NONORM) continue;
+    const double d = new_x[p] - G.p_x[p];
+    const double moret = G.time - G.p_tmax[p];
+    if (moret > 0) {
+      G.p_tmax[p] = G.time;
+      G.p_s[p] += moret * G.p_x[p];
+    } else if (moret < 0)
+      G.p_s[p] += d * (-moret);
+    G.p_x[p] += d;
+  }
+}
+
+}  // namespace carmel_hip
+
+using namespace carmel_hip;
+
+struct carmel_hip_gibbs {
+  carmel_hip_trainer* t = nullptr;
+  carmel_hip_gibbs_opts opt;
+  LatticeSet lat;
+  uint64_t n_params = 0, n_norm = 0;
+  uint32_t n_blocks = 0, max_sample = 0;
+  std::vector<uint32_t> h_norm;
+  std::vector<double> h_prior;
+  DevBuf<BundleDesc> bundles;
+  DevBuf<uint2_t> out_arcs;
+  DevBuf<uint32_t> out_off, level_off, pair_start, pair_final, block_bundle, chain_param, p_norm, sample_len, sample_ids,
+      new_len, new_ids;
+  DevBuf<uint64_t> chain_off, sample_off;
+  DevBuf<double> pair_logw, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, ccount, csum, snap_x, snap_norm, gw, beta,
+      iter_out;
+  std::vector<uint64_t> h_sample_off;
+  bool ran = false;
+};
+
+extern "C" {
+
+double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, uint32_t step) {
+  return gibbs_uniform(seed, iter, block, step);
+}
+
+int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* o) {
+  if (!out || !t || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
+  if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
+  HIPCHK(hipSetDevice(t->device));
+  std::unique_ptr<carmel_hip_gibbs> g(new carmel_hip_gibbs());
+  g->t = t;
+  g->opt = *o;
+  hipStream_t s = t->stream;
+  // ---- parameters: norm group and prior pseudo-count (gibbs.cc:114-186; gibbs.hpp:589-592) ----
+  const uint64_t np = t->np();
+  g->n_params = np;
+  std::vector<double> lw(np);
+  HIPCHK(hipMemcpyAsync(lw.data(), t->params(), np * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const std::vector<uint32_t>& pg = t->cascade ? t->h_param_group : t->w.group;
+  const uint64_t ng = t->h_group_add.size();
+  g->n_norm = ng;
+  std::vector<double> gsum(ng, 0.0), gcnt(ng, 0.0);
+  for (uint64_t p = 0; p < np; ++p) {
+    uint32_t n = t->h_norm_of[p];
+    if (n == 0xffffffffu || pg[p] == CARMEL_HIP_LOCKED_GROUP) continue;
+    gsum[n] += std::exp(lw[p]);
+    gcnt[n] += 1.0;
+  }
+  g->h_norm.assign(np, 0xffffffffu);
+  g->h_prior.assign(np, 0.0);
+  for (uint64_t p = 0; p < np; ++p) {
+    uint32_t n = t->h_norm_of[p];
+    if (n == 0xffffffffu || pg[p] == CARMEL_HIP_LOCKED_GROUP) {  // fixed probability = the arc's weight
+      g->h_prior[p] = std::exp(lw[p]);
+      continue;
+    }
+    double alpha = t->h_group_add[n];
+    if (!(alpha > 0)) alpha = o->min_prior > 0 ? o->min_prior : 1e-2;  // gibbs.cc:390-397
+    double sum = o->dirichlet_p0 ? 1.0 : gsum[n];
+    g->h_norm[p] = n;
+    g->h_prior[p] = o->uniform_p0 ? alpha : alpha * (std::exp(lw[p]) / sum) * gcnt[n];
+  }
+  // ---- composed arc -> parameter ids ----
+  std::vector<uint64_t> coff(t->w.n_arcs + 1, 0);
+  std::vector<uint32_t> cpar;
+  uint32_t max_chain = 1;
+  for (uint64_t a = 0; a < t->w.n_arcs; ++a) {
+    if (t->cascade) {
+      uint32_t c = t->w.group[a];
+      for (uint64_t j = t->h_chain_off[c]; j < t->h_chain_off[c + 1]; ++j) cpar.push_back((uint32_t)t->h_chain_param[j]);
+      max_chain = std::max<uint32_t>(max_chain, (uint32_t)(t->h_chain_off[c + 1] - t->h_chain_off[c]));
+    } else
+      cpar.push_back((uint32_t)a);
+    coff[a + 1] = cpar.size();
+  }
+  // ---- one lattice per block, in corpus order ----
+  BuildOptions bo;
+  bo.lane_states = 0;
+  bo.small_pairs = 1;
+  bo.threads = 0;
+  std::string err;
+  if (!build_lattices(t->w, t->corpus, bo, g->lat, err)) return fail(CARMEL_HIP_ERR_ARG, err);
+  LatticeSet& L = g->lat;
+  if (L.n_cyclic)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "cyclic derivation lattices are not supported by the Gibbs sampler");
+  std::vector<uint32_t> bundle_of_pair(t->corpus.n_pairs, 0xffffffffu);
+  for (size_t b = 0; b < L.bundles.size(); ++b) bundle_of_pair[L.pair_id[L.bundles[b].pair_base]] = (uint32_t)b;
+  std::vector<uint32_t> bb;
+  for (uint64_t p = 0; p < t->corpus.n_pairs; ++p)
+    if (bundle_of_pair[p] != 0xffffffffu) bb.push_back(bundle_of_pair[p]);
+  g->n_blocks = (uint32_t)bb.size();
+  if (!g->n_blocks) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation - aborting training.");
+  g->h_sample_off.assign(bb.size() + 1, 0);
+  for (size_t b = 0; b < bb.size(); ++b) {
+    uint32_t cap = L.bundles[bb[b]].n_levels * max_chain;  // a path has at most n_levels - 1 arcs
+    g->max_sample = std::max(g->max_sample, cap);
+    g->h_sample_off[b + 1] = g->h_sample_off[b] + cap;
+  }
+  HIPCHK(g->bundles.upload(L.bundles, s));
+  HIPCHK(g->out_arcs.upload(L.out_arcs, s));
+  HIPCHK(g->out_off.upload(L.out_off, s));
+  HIPCHK(g->level_off.upload(L.level_off, s));
+  HIPCHK(g->pair_start.upload(L.pair_start, s));
+  HIPCHK(g->pair_final.upload(L.pair_final, s));
+  HIPCHK(g->pair_logw.upload(L.pair_logw, s));
+  HIPCHK(g->block_bundle.upload(bb, s));
+  HIPCHK(g->chain_off.upload(coff, s));
+  HIPCHK(g->chain_param.upload(cpar, s));
+  HIPCHK(g->p_norm.upload(g->h_norm, s));
+  HIPCHK(g->p_prior.upload(g->h_prior, s));
+  HIPCHK(g->p_x.alloc(np));
+  HIPCHK(g->p_s.alloc(np));
+  HIPCHK(g->p_tmax.alloc(np));
+  HIPCHK(g->normsum.alloc(ng));
+  HIPCHK(g->ccount.alloc(np));
+  HIPCHK(g->csum.alloc(ng));
+  std::vector<double> pn(ng, 0.0);
+  for (uint64_t p = 0; p < np; ++p)
+    if (g->h_norm[p] != 0xffffffffu) pn[g->h_norm[p]] += g->h_prior[p];
+  HIPCHK(g->prior_norm.upload(pn, s));
+  HIPCHK(g->sample_off.upload(g->h_sample_off, s));
+  HIPCHK(g->sample_len.alloc(bb.size()));
+  HIPCHK(g->sample_ids.alloc(g->h_sample_off.back()));
+  if (o->mode == 1) {
+    HIPCHK(g->new_len.alloc(bb.size()));
+    HIPCHK(g->new_ids.alloc(g->h_sample_off.back()));
+    HIPCHK(g->snap_x.alloc(np));
+    HIPCHK(g->snap_norm.alloc(ng));
+  }
+  HIPCHK(g->gw.alloc(L.out_arcs.size()));
+  HIPCHK(g->beta.alloc(L.out_off.size()));
+  HIPCHK(g->iter_out.alloc(2));
+  HIPCHK(hipStreamSynchronize(s));
+  *out = g.release();
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g) {
+  if (g) {
+    (void)hipSetDevice(g->t->device);
+    (void)hipStreamSynchronize(g->t->stream);
+    delete g;
+  }
+  return CARMEL_HIP_OK;
+}
+
+uint32_t carmel_hip_gibbs_n_blocks(carmel_hip_gibbs* g) { return g ? g->n_blocks : 0; }
+
+// gibbs_base::run (gibbs.hpp:803-828): restore_p0, the initial sample (iteration 0), then iter = 1..Ni with
+// time = max(0, iter - burnin); finally finalize_cumulative_counts (gibbs.hpp:626-638).
+int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  carmel_hip_trainer* t = g->t;
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  const uint64_t np = g->n_params, ng = g->n_norm;
+  // restore_p0: counts = priors, normsums = their sums, no sample
+  HIPCHK(hipMemcpyAsync(g->p_x.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(g->p_s.p, 0, np * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(g->p_tmax.p, 0, np * sizeof(double), s));
+  HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(g->sample_len.p, 0, g->sample_len.bytes(), s));
+  GibbsArgs G;
+  std::memset(&G, 0, sizeof G);
+  G.bundles = g->bundles.p;
+  G.block_bundle = g->block_bundle.p;
+  G.out_arcs = (const uint2*)g->out_arcs.p;
+  G.out_off = g->out_off.p;
+  G.level_off = g->level_off.p;
+  G.pair_start = g->pair_start.p;
+  G.pair_final = g->pair_final.p;
+  G.pair_logw = g->pair_logw.p;
+  G.chain_off = g->chain_off.p;
+  G.chain_param = g->chain_param.p;
+  G.p_norm = g->p_norm.p;
+  G.p_prior = g->p_prior.p;
+  G.p_x = g->p_x.p;
+  G.p_s = g->p_s.p;
+  G.p_tmax = g->p_tmax.p;
+  G.normsum = g->normsum.p;
+  G.ccount = g->ccount.p;
+  G.csum = g->csum.p;
+  G.snap_x = g->snap_x.p;
+  G.snap_norm = g->snap_norm.p;
+  G.sample_off = g->sample_off.p;
+  G.sample_len = g->sample_len.p;
+  G.sample_ids = g->sample_ids.p;
+  G.new_len = g->new_len.p;
+  G.new_ids = g->new_ids.p;
+  G.gw = g->gw.p;
+  G.beta = g->beta.p;
+  G.iter_out = g->iter_out.p;
+  G.seed = g->opt.seed;
+  G.n_blocks = g->n_blocks;
+  G.power = 1.0;  // constant temperature 1 (gibbs_opts.hpp:246); annealing is not offered
+  const uint32_t Ni = g->opt.iter, burnin = std::min(g->opt.burnin, g->opt.iter);
+  for (uint32_t iter = 0; iter <= Ni; ++iter) {
+    G.iter = iter;
+    G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
+    HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 2 * sizeof(double), s));
+    if (g->opt.mode == 0) {
+      HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(gibbs_sweep_exact_kernel, dim3(1), dim3(256), 0, s, G);
+    } else {
+      HIPCHK(hipMemcpyAsync(g->snap_x.p, g->p_x.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(g->snap_norm.p, g->normsum.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      uint32_t grid = std::min<uint32_t>(g->n_blocks, 256u * 16u);
+      size_t lds = (size_t)g->max_sample * sizeof(uint32_t);
+      hipLaunchKernelGGL(gibbs_sweep_parallel_kernel, dim3(grid), dim3(64), lds, s, G, g->max_sample);
+      // counts of the new samples: start from the priors, add every use
+      HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(gibbs_recount_kernel, dim3(std::min<uint32_t>((g->n_blocks + 255) / 256, 4096u)), dim3(256), 0, s,
+                         G, g->ccount.p, g->normsum.p);
+      hipLaunchKernelGGL(gibbs_commit_kernel, dim3((unsigned)std::min<uint64_t>((np + 255) / 256, 4096)), dim3(256), 0, s, G,
+                         g->ccount.p, np);
+      std::swap(g->sample_ids.p, g->new_ids.p);
+      std::swap(g->sample_len.p, g->new_len.p);
+      G.sample_ids = g->sample_ids.p;
+      G.sample_len = g->sample_len.p;
+      G.new_ids = g->new_ids.p;
+      G.new_len = g->new_len.p;
+    }
+    HIPCHK(hipGetLastError());
+    double io[2];
+    HIPCHK(hipMemcpyAsync(io, g->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (iter_logprob) iter_logprob[iter] = g->opt.mode == 0 ? io[0] : io[1];
+    if (iter_cheap_logprob) iter_cheap_logprob[iter] = io[1];
+  }
+  // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
+  std::vector<double> x(np), sacc(np), tm(np);
+  HIPCHK(hipMemcpyAsync(x.data(), g->p_x.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(sacc.data(), g->p_s.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(tm.data(), g->p_tmax.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (!(g->opt.final_counts && !g->opt.exclude_prior)) {
+    const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
+    for (uint64_t p = 0; p < np; ++p) {
+      if (g->h_norm[p] == 0xffffffffu) continue;
+      if (g->opt.exclude_prior) {
+        sacc[p] += -g->h_prior[p] * tm[p];
+        x[p] += -g->h_prior[p];
+      }
+      if (!g->opt.final_counts) {
+        sacc[p] += x[p] * (tmax1 - tm[p]);  // delta_sum::extend
+        x[p] = sacc[p];
+      }
+    }
+  }
+  std::vector<double> ns(ng, 0.0);
+  for (uint64_t p = 0; p < np; ++p)
+    if (g->h_norm[p] != 0xffffffffu) ns[g->h_norm[p]] += x[p];
+  // probs_to_cascade (gibbs.cc:66-76): weight = final_prob (gibbs.hpp:141-150), written into the trainer's parameters
+  std::vector<double> lw(np);
+  for (uint64_t p = 0; p < np; ++p) {
+    double pr = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : (x[p] > 0 ? x[p] / ns[g->h_norm[p]] : 0.0);
+    lw[p] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
+  }
+  g->ran = true;
+  return carmel_hip_set_weights(t, lw.data());
+}
+
+int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n) {
+  if (!g || !n || block >= g->n_blocks) return fail(CARMEL_HIP_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(g->t->device));
+  hipStream_t s = g->t->stream;
+  uint32_t len = 0;
+  HIPCHK(hipMemcpyAsync(&len, g->sample_len.p + block, sizeof len, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (ids && len)
+    HIPCHK(hipMemcpyAsync(ids, g->sample_ids.p + g->h_sample_off[block], len * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  *n = len;
+  return CARMEL_HIP_OK;
+}
+
+uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g) { return g ? g->max_sample : 0; }
+
+}  // extern "C"

@@ -211,3 +211,48 @@ def train(fb, opts=None, log=None):
         last_ppx = new_ppx
     fb.load_best()
     return best, trace
+
+
+class HipGibbs(object):
+    """carmel_gibbs (carmel/src/gibbs.cc:15-41) over a HipForwardBackward trainer: `carmel --crp`.
+
+    mode 0 resamples the blocks strictly in order (the reference's chain); mode 1 is the parallel stale-count
+    sweep.  After run() the trainer's parameters are the time-averaged probabilities (probs_to_cascade)."""
+
+    def __init__(self, fb, iters, burnin=0, seed=1, mode=0, uniform_p0=False, dirichlet_p0=False, final_counts=False,
+                 exclude_prior=False, min_prior=0.01):
+        from ._capi import GibbsOpts
+        self.fb = fb
+        self.opts = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), int(dirichlet_p0), int(final_counts),
+                              int(exclude_prior), min_prior)
+        h = C.c_void_p()
+        check(lib.carmel_hip_gibbs_create(C.byref(h), fb.h, C.byref(self.opts)), "carmel_hip_gibbs_create")
+        self.h = h
+        self.n_blocks = lib.carmel_hip_gibbs_n_blocks(h)
+
+    def run(self):
+        n = self.opts.iter + 1
+        self.iter_logprob, self.iter_cheap_logprob = np.zeros(n), np.zeros(n)
+        check(lib.carmel_hip_gibbs_run(self.h, ptr(self.iter_logprob), ptr(self.iter_cheap_logprob)),
+              "carmel_hip_gibbs_run")
+        return self.iter_logprob
+
+    def sample(self, block):
+        buf = np.zeros(max(1, lib.carmel_hip_gibbs_max_sample(self.h)), np.uint32)
+        n = C.c_uint32(0)
+        check(lib.carmel_hip_gibbs_get_sample(self.h, block, ptr(buf), C.byref(n)), "carmel_hip_gibbs_get_sample")
+        return buf[:n.value].tolist()
+
+    def uniform(self, it, block, step):
+        return lib.carmel_hip_gibbs_uniform(self.opts.seed, it, block, step)
+
+    def close(self):
+        if self.h:
+            lib.carmel_hip_gibbs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

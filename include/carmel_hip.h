@@ -154,6 +154,36 @@ int carmel_hip_save_counts(carmel_hip_trainer* t); /* for_arcs::save_counts: em_
 int carmel_hip_save_best(carmel_hip_trainer* t);
 int carmel_hip_load_best(carmel_hip_trainer* t);
 
+/* ---- blocked Gibbs sampling of derivations: `carmel --crp` ----
+ * Replaces: WFST::train_gibbs / carmel_gibbs (gibbs.cc:15-41, 386-430) + gibbs_base::run_starts
+ * (gibbs.hpp:803-914) + derivations::random_path (derivations.h:345-375).  The sampler is created from a trainer
+ * that already has its transducer, normalisation (the per-member --priors are the Dirichlet alphas) and corpus;
+ * parameters, norm groups and prior pseudo-counts alpha*p0*|group| are derived as add_gibbs_params does
+ * (gibbs.cc:114-186). */
+typedef struct carmel_hip_gibbs carmel_hip_gibbs;
+typedef struct carmel_hip_gibbs_opts {
+  uint32_t iter;      /* resampling sweeps after the initial sample (-M / --crp=N) */
+  uint32_t burnin;    /* --burnin: sweeps before time-averaging starts */
+  uint64_t seed;      /* of the counter-based generator carmel_hip_gibbs_uniform */
+  int mode;           /* 0 = exact: blocks strictly in order (the reference's chain); 1 = parallel stale-count sweep */
+  int uniform_p0, dirichlet_p0, final_counts, exclude_prior; /* --uniform-p0 --dirichlet-p0 --final-counts
+                                                                 --crp-exclude-prior (gibbs_opts.hpp:31-268) */
+  double min_prior;   /* replaces non-positive --priors (gibbs.cc:390-397); 0 => 0.01 */
+} carmel_hip_gibbs_opts;
+int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
+int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);
+uint32_t carmel_hip_gibbs_n_blocks(carmel_hip_gibbs* g);
+uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g);
+/* Runs iter+1 sweeps; iter_logprob[i] = ln of the "cache-model prob" log line of sweep i (gibbs.hpp:712-742; mode
+ * 1: the proposal prob), iter_cheap_logprob[i] = ln of the proposal ("--sample-prob") probability; either may be
+ * NULL.  On return the trainer's parameters hold the time-averaged probabilities (probs_to_cascade,
+ * gibbs.cc:66-76): read them with carmel_hip_get_weights. */
+int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob);
+/* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
+int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
+/* the uniform the sampler uses at (sweep, block, step of the walk): lets a checker replay the same choices */
+double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, uint32_t step);
+
 /* ---- host-only inspection (no GPU needed): the lattice image carmel_hip_build_lattices uploads ----
  * Used by the CPU test-suite to check lattice construction and layout against the oracle. */
 typedef struct carmel_hip_host_lattices carmel_hip_host_lattices;

@@ -275,4 +275,29 @@ class OracleCascade(object):
                     chain_off=self.chain_off, chain_param=self.chain_param)
 
 
+UNIFORM_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_uint32, C.c_uint32)
+lib.orc_gibbs_run.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
+                              UNIFORM_FN, vp, vp, vp, vp, vp, C.c_uint64, vp]
+
+
+def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
+              dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22):
+    """carmel --crp on an OracleCascade; `uniform(iter, block, step)` supplies every random01() draw.
+    Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
+    n = cascade.n_params
+    ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)
+    plw = np.zeros(n)
+    samp = np.zeros(max_samples, np.uint32)
+    nb = C.c_uint32(0)
+    n_pairs = len(corpus.arrays()["weight"])
+    off = np.zeros(n_pairs + 2, np.uint64)
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    cb = UNIFORM_FN(uniform)
+    _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
+                           int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
+                           _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))
+    samples = [samp[int(off[b]):int(off[b + 1])].tolist() for b in range(nb.value)]
+    return dict(iter_logprob=ilp, iter_cheap_logprob=icl, param_logw=plw, samples=samples)
+
+
 CLI = os.path.join(_HERE, "oracle_carmel")

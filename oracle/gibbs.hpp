@@ -1,0 +1,295 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lw.hpp header).
+//
+// gibbs.hpp: restatement of carmel's blocked Gibbs sampler over cached derivation lattices (`carmel --crp`).
+// Follows /root/reference:
+//   carmel/src/gibbs.cc:114-186   add_gibbs_params: one parameter per member arc; per norm group the prior
+//                                 pseudo-count is alpha * p0 * |group| (alpha = --priors, p0 = arc weight / group sum;
+//                                 just alpha with --uniform-p0); locked arcs and NONE members are fixed-probability
+//   carmel/src/gibbs.cc:306-371   resample_block -> derivations::random_path; proposal weight of a lattice arc =
+//                                 product of count/normsum over its chain; choose_arc records the chain's param ids
+//   carmel/src/derivations.h:318-375  random_path: backward sweep, lazy per-state normalisation, choose_p walk
+//   graehl/shared/random.ipp:111-127  choose_p (sum, choice = sum * random01(), subtract until negative)
+//   graehl/shared/gibbs.hpp:106-227   gibbs_param (count, norm, time-weighted running sum)
+//   graehl/shared/gibbs.hpp:803-877   run / iteration: per block remove old sample, resample, prob, add new
+//   graehl/shared/gibbs.hpp:626-638   finalize_cumulative_counts; :153-157 proposal_prob; :141-150 final_prob
+//   graehl/shared/delta_sum.hpp:49-106
+//
+// PARITY UNPINNED for the random stream: the reference draws from boost::lagged_fibonacci607 + uniform_01
+// (random.hpp:139-157) and no reference test records a sampled sequence, so the uniforms are INJECTED here
+// (callback u(iter, block, step)); everything downstream of the uniforms is restated exactly.
+#pragma once
+#include "cascade.hpp"
+#include "deriv.hpp"
+#include <functional>
+
+namespace oracle {
+
+struct DeltaSum {  // delta_sum.hpp:49-106
+  double x, tmax, s;
+  DeltaSum() : x(0), tmax(0), s(0) {}
+  void clear(double x0) {
+    x = x0;
+    s = tmax = 0;
+  }
+  void add_delta(double d, double t) {
+    double moret = t - tmax;
+    if (moret > 0) {
+      tmax = t;
+      s += moret * x;
+    } else if (moret < 0)
+      s += d * (-moret);
+    x += d;
+  }
+  void extend(double t) {
+    double moret = t - tmax;
+    if (moret < 0) throw std::runtime_error("delta_sum asked for forgotten sum at 0<t<tmax");
+    tmax = t;
+    s += x * moret;
+  }
+};
+
+struct GibbsParam {
+  static const unsigned NONORM = (unsigned)-1;
+  double prior;
+  unsigned norm;
+  DeltaSum sum;
+  bool has_norm() const { return norm != NONORM; }
+};
+
+struct GibbsOpts {
+  unsigned iter = 0;    // -M / --crp=N : number of resampling sweeps after the initial sample
+  unsigned burnin = 0;  // --burnin
+  bool uniformp0 = false, dirichlet_p0 = false, final_counts = false, exclude_prior = false;
+};
+
+struct GibbsTrace {
+  std::vector<double> iter_logprob;               // ln cache-model prob of the whole sample (the default log line,
+                                                  // gibbs_opts.hpp cache_prob = true; gibbs.hpp:712-742)
+  std::vector<double> iter_cheap_logprob;         // ln of the product over blocks of the proposal prob (--sample-prob)
+  std::vector<std::vector<unsigned> > last_sample;  // per block: param ids of the final sample
+};
+
+struct CarmelGibbs {
+  Wfst& composed;
+  Cascade& cascade;
+  Corpus& corpus;
+  std::vector<NormalizeMethod> methods;
+  GibbsOpts gopt;
+  std::vector<GibbsParam> gps;
+  std::vector<double> normsum;
+  unsigned nnorm = 0;
+  std::vector<std::vector<unsigned> > chain_params;  // composed arc id -> param ids in chain order
+  std::vector<Derivations> derivs;                    // cached lattices of the pairs that have a derivation
+  std::vector<std::vector<unsigned> > sample;
+  std::unordered_map<const Arc*, unsigned> param_of;  // member arc -> param id (the reference overwrites groupId)
+  ArcTable arcs;
+  double time = 0;
+
+  CarmelGibbs(Wfst& composed, Cascade& cascade, Corpus& corpus, const std::vector<NormalizeMethod>& m, const GibbsOpts& g)
+      : composed(composed), cascade(cascade), corpus(corpus), methods(m), gopt(g) {
+    // WFST::train_gibbs (gibbs.cc:386-397): non-positive --priors become min_prior 0.01
+    for (auto& x : methods)
+      if (!(x.add_count > LW())) x.add_count = LW::from_real(1e-2);
+    cascade.set_composed(&composed);
+    arcs.build(composed, false, LW());
+    IoIndex io;
+    io.build(composed);
+    for (auto& p : corpus.examples) {
+      derivs.emplace_back();
+      if (!derivs.back().compute(composed, io, arcs, p, true, 0)) derivs.pop_back();
+    }
+    unsigned norm = 0;
+    for (size_t i = 0; i < cascade.cascade.size(); ++i) norm = add_gibbs_params(norm, *cascade.cascade[i], methods[i]);
+    // chains of the composed arcs as param ids (trivial cascade: each arc is its own chain, cascade.h:233-239)
+    for (auto& r : arcs.t) {
+      std::vector<unsigned> ch;
+      if (cascade.trivial)
+        ch.push_back(param_of.at(r.arc));
+      else
+        for (Arc* p : cascade.chains[r.arc->group]) ch.push_back(param_of.at(p));
+      chain_params.push_back(ch);
+    }
+    sample.assign(derivs.size(), {});
+  }
+
+  unsigned define_param(unsigned norm, double prior) {
+    if (norm != GibbsParam::NONORM && norm + 1 > nnorm) nnorm = norm + 1;
+    GibbsParam g;
+    g.prior = prior;
+    g.norm = norm;
+    gps.push_back(g);
+    return (unsigned)gps.size() - 1;
+  }
+  // gibbs.cc:114-186
+  unsigned add_gibbs_params(unsigned id, Wfst& w, const NormalizeMethod& nm) {
+    if (nm.group == NORM_NONE) {
+      for (auto& st : w.states)
+        for (auto& a : st) param_of[&a] = define_param(GibbsParam::NONORM, a.weight.getReal());
+      return id;
+    }
+    double alpha = nm.add_count.getReal();
+    bool cond = nm.group == NORM_CONDITIONAL;
+    w.for_each_norm_group(nm.group, [&](unsigned, std::vector<Arc*>& g) {
+      LW sum;
+      std::vector<Arc*> unlocked;
+      for (Arc* a : g) {
+        if (a->locked())
+          param_of[a] = define_param(GibbsParam::NONORM, a->weight.getReal());
+        else {
+          unlocked.push_back(a);
+          sum += a->weight;
+        }
+      }
+      double N = (double)unlocked.size();
+      if (gopt.dirichlet_p0) sum = LW::one();
+      if (cond) std::reverse(unlocked.begin(), unlocked.end());
+      for (Arc* a : unlocked) {
+        double p0 = (a->weight / sum).getReal();
+        param_of[a] = define_param(id, gopt.uniformp0 ? alpha : alpha * p0 * N);
+      }
+      ++id;
+    });
+    return id;
+  }
+
+  double proposal_prob(unsigned p) const {  // gibbs.hpp:153-157
+    const GibbsParam& g = gps[p];
+    return g.has_norm() ? g.sum.x / normsum[g.norm] : g.prior;
+  }
+  double final_prob(unsigned p) const {  // gibbs.hpp:141-150
+    const GibbsParam& g = gps[p];
+    if (!g.has_norm()) return g.prior;
+    return g.sum.x > 0 ? g.sum.x / normsum[g.norm] : 0;
+  }
+  void addc(const std::vector<unsigned>& b, double d) {  // gibbs.hpp:769-792, 210-217
+    for (unsigned p : b) {
+      GibbsParam& g = gps[p];
+      if (g.has_norm()) {
+        normsum[g.norm] += d;
+        g.sum.add_delta(d, time);
+      }
+    }
+  }
+  LW arc_weight(const GArc& a) const {  // gibbs.cc:348-359
+    LW prob = LW::one();
+    for (unsigned p : chain_params[a.arcid]) mul_eq(prob, LW::from_real(proposal_prob(p)));
+    return prob;
+  }
+
+  // derivations.h:345-375 random_path; u(step) supplies random01()
+  void random_path(Derivations& d, std::vector<unsigned>& out, const std::function<double(unsigned)>& u, double power) {
+    size_t nst = d.g.size();
+    d.make_order();
+    std::vector<std::vector<GArc> > r;
+    d.make_reverse(r);
+    std::vector<LW> b(nst);
+    b[d.fin] = LW::one();
+    for (size_t t = 0; t < d.reverse_order.size(); ++t) {  // propagate_paths_in_order_wt over the reversed graph
+      unsigned src = d.reverse_order[t];
+      const auto& arcs_ = r[src];
+      for (size_t k = arcs_.size(); k-- > 0;) b[arcs_[k].dest] += b[src] * arc_weight(arcs_[k]);
+    }
+    unsigned s = 0, step = 0;
+    std::vector<char> normed(nst, 0);
+    std::vector<std::vector<double> > probs(nst);
+    while (s != d.fin) {
+      auto& out_arcs = d.g[s];
+      if (!normed[s]) {  // pfor::global_normalize derivations.h:318-337
+        normed[s] = 1;
+        LW sum;
+        std::vector<LW> nw;
+        for (size_t k = out_arcs.size(); k-- > 0;) {
+          LW v = (arc_weight(out_arcs[k]) * b[out_arcs[k].dest]).pow(power);
+          sum += v;
+          nw.push_back(v);
+        }
+        if (sum.isZero()) sum = LW::one();
+        for (auto& v : nw) probs[s].push_back((v / sum).getReal());  // list order
+      }
+      const auto& p = probs[s];
+      double tot = 0;
+      for (double x : p) tot += x;
+      double choice = tot * u(step++);
+      size_t pick = 0;
+      for (size_t i = 0;;) {  // choose_p random.ipp:111-127
+        choice -= p[i];
+        size_t rr = i;
+        ++i;
+        if (choice < 0 || i == p.size()) {
+          pick = rr;
+          break;
+        }
+      }
+      const GArc& a = out_arcs[out_arcs.size() - 1 - pick];  // list order = reverse insertion
+      for (unsigned pid : chain_params[a.arcid]) out.push_back(pid);
+      s = a.dest;
+    }
+  }
+
+  // gibbs.hpp:803-877 (one start, no restarts / prior inference / expectation mode)
+  void run(const std::function<double(unsigned, unsigned, unsigned)>& u, GibbsTrace* tr = 0) {
+    normsum.assign(nnorm, 0.0);
+    for (auto& g : gps)
+      if (g.has_norm()) {
+        normsum[g.norm] += g.prior;
+        g.sum.clear(g.prior);
+      }
+    for (auto& s : sample) s.clear();
+    const unsigned Ni = gopt.iter;
+    for (unsigned iter = 0; iter <= Ni; ++iter) {
+      time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)gopt.burnin);
+      LW p = LW::one(), pc = LW::one();
+      // cache model (gibbs.hpp:678-742): counts restart from the priors every iteration and grow by one per use
+      std::vector<double> ccount(gps.size(), 0.0), csum(nnorm, 0.0);
+      for (size_t i = 0; i < gps.size(); ++i)
+        if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
+      for (unsigned b = 0; b < derivs.size(); ++b) {
+        double wt = derivs[b].weight;
+        addc(sample[b], -wt);
+        sample[b].clear();
+        random_path(derivs[b], sample[b], [&](unsigned step) { return u(iter, b, step); }, 1.0);
+        LW bp = LW::one();
+        for (unsigned pid : sample[b]) mul_eq(bp, LW::from_real(proposal_prob(pid)));
+        mul_eq(p, bp);
+        LW bc = LW::one();
+        for (unsigned pid : sample[b]) {
+          const GibbsParam& g = gps[pid];
+          double q = g.has_norm() ? (ccount[pid]++ / csum[g.norm]++) : g.prior;
+          mul_eq(bc, LW::from_real(q));
+        }
+        mul_eq(pc, bc);
+        addc(sample[b], wt);
+      }
+      if (tr) {
+        tr->iter_logprob.push_back(pc.w);
+        tr->iter_cheap_logprob.push_back(p.w);
+      }
+    }
+    if (tr) tr->last_sample = sample;
+    // finalize_cumulative_counts gibbs.hpp:626-638
+    if (!(gopt.final_counts && !gopt.exclude_prior)) {
+      double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;
+      if (gopt.exclude_prior)
+        for (auto& g : gps)
+          if (g.has_norm()) {
+            g.sum.s += -g.prior * g.sum.tmax;  // addbase(-prior)
+            g.sum.x += -g.prior;
+          }
+      if (!gopt.final_counts)
+        for (auto& g : gps)
+          if (g.has_norm()) {
+            g.sum.extend(tmax1);
+            g.sum.x = g.sum.s;
+          }
+      normsum.assign(nnorm, 0.0);
+      for (auto& g : gps)
+        if (g.has_norm()) normsum[g.norm] += g.sum.x;
+    }
+    // probs_to_cascade gibbs.cc:66-76
+    for (Wfst* w : cascade.cascade)
+      for (auto& st : w->states)
+        for (auto& a : st) a.weight = LW::from_real(final_prob(param_of.at(&a)));
+  }
+};
+
+}  // namespace oracle

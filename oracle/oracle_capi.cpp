@@ -5,6 +5,7 @@
 // Arc arrays are in the reference's arc-id order: state-major, each state's arcs in list order
 // (derivations.h:86-101, fst.h:1331-1334).
 #include "train.hpp"
+#include "gibbs.hpp"
 #include <pthread.h>
 #include <functional>
 #include <cstdint>
@@ -614,6 +615,62 @@ char* orc_cascade_write_member(orc_cascade* h, int m, const double* param_logw, 
   char* r = (char*)std::malloc(s.size() + 1);
   std::memcpy(r, s.c_str(), s.size() + 1);
   return r;
+}
+
+// ---- blocked Gibbs over a composed cascade (carmel --crp), uniforms injected through a callback ----
+// out_param_logw[n_params]: ln final_prob per member arc, concatenated member order (probs_to_cascade)
+// out_samples / out_sample_off[n_blocks+1]: final sample of every block as MEMBER-ARC indices (concatenated order)
+typedef double (*orc_uniform_fn)(uint32_t iter, uint32_t block, uint32_t step);
+int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const double* priors, uint32_t iter,
+                  uint32_t burnin, int uniform_p0, int dirichlet_p0, int final_counts, int exclude_prior,
+                  orc_uniform_fn u, double* iter_logprob, double* iter_cheap_logprob, double* out_param_logw,
+                  uint32_t* out_samples, uint64_t* out_sample_off, uint64_t max_samples, uint32_t* n_blocks) {
+  return run_big_stack([&]() {
+    size_t n = h->chain.size();
+    std::vector<NormalizeMethod> nms(n);
+    for (size_t i = 0; i < n; ++i) {
+      char ch = normby && std::strlen(normby) > i ? normby[i] : 'C';
+      nms[i].group = (ch == 'J' || ch == 'j') ? NORM_JOINT : (ch == 'N' || ch == 'n') ? NORM_NONE : NORM_CONDITIONAL;
+      if (priors) nms[i].add_count = LW::from_real(priors[i]);
+    }
+    GibbsOpts go;
+    go.iter = iter;
+    go.burnin = burnin < iter ? burnin : iter;
+    go.uniformp0 = uniform_p0 != 0;
+    go.dirichlet_p0 = dirichlet_p0 != 0;
+    go.final_counts = final_counts != 0;
+    go.exclude_prior = exclude_prior != 0;
+    if (go.final_counts) go.burnin = go.iter;  // gibbs_opts.hpp validate()
+    CarmelGibbs g(*h->result, h->cascade, c->c, nms, go);
+    GibbsTrace tr;
+    g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
+    for (uint32_t i = 0; i <= iter; ++i) {
+      if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
+      if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];
+    }
+    // oracle param id -> member-arc index
+    std::vector<uint32_t> arc_index(g.gps.size(), 0);
+    uint32_t k = 0;
+    for (auto& w : h->chain)
+      for (auto& st : w.states)
+        for (auto& a : st) {
+          arc_index[g.param_of.at(&a)] = k;
+          if (out_param_logw) out_param_logw[k] = a.weight.w;
+          ++k;
+        }
+    if (n_blocks) *n_blocks = (uint32_t)tr.last_sample.size();
+    if (out_sample_off) {
+      uint64_t o = 0;
+      for (size_t b = 0; b < tr.last_sample.size(); ++b) {
+        out_sample_off[b] = o;
+        for (unsigned pid : tr.last_sample[b]) {
+          if (o >= max_samples) throw std::runtime_error("sample buffer too small");
+          out_samples[o++] = arc_index[pid];
+        }
+      }
+      out_sample_off[tr.last_sample.size()] = o;
+    }
+  });
 }
 
 }  // extern "C"
