@@ -266,6 +266,7 @@ using namespace carmel_hip;
 
 struct carmel_hip_gibbs {
   carmel_hip_trainer* t = nullptr;
+  int device = 0;
   carmel_hip_gibbs_opts opt;
   LatticeSet lat;
   uint64_t n_params = 0, n_norm = 0;
@@ -296,6 +297,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   HIPCHK(hipSetDevice(t->device));
   std::unique_ptr<carmel_hip_gibbs> g(new carmel_hip_gibbs());
   g->t = t;
+  g->device = t->device;
   g->opt = *o;
   hipStream_t s = t->stream;
   // ---- parameters: norm group and prior pseudo-count (gibbs.cc:114-186; gibbs.hpp:589-592) ----
@@ -405,8 +407,8 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
 
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g) {
   if (g) {
-    (void)hipSetDevice(g->t->device);
-    (void)hipStreamSynchronize(g->t->stream);
+    (void)hipSetDevice(g->device);
+    (void)hipDeviceSynchronize();  // the trainer (and its stream) may already be gone
     delete g;
   }
   return CARMEL_HIP_OK;
