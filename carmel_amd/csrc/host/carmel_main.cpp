@@ -49,6 +49,11 @@ struct Options {
   int norm = CARMEL_HIP_NORM_CONDITIONAL;
   std::string normby, priors, out_file;
   int index_threshold = 32, gpu = 0;
+  // --crp (carmel.cc:255-304)
+  bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
+       exclude_prior = false;
+  long crp_iters = -1, burnin = 0;
+  unsigned long long seed = 1;
   std::vector<const char*> files;
 };
 
@@ -71,6 +76,21 @@ static Options parse_args(int argc, char** argv) {
         o.priors = v;
       else if (k == "gpu")
         o.gpu = std::atoi(v.c_str());
+      else if (k == "crp") {
+        o.crp = true;
+        if (!v.empty() && std::atol(v.c_str()) > 1) o.crp_iters = std::atol(v.c_str());
+      } else if (k == "burnin")
+        o.burnin = std::atol(v.c_str());
+      else if (k == "uniform-p0")
+        o.uniform_p0 = true;
+      else if (k == "dirichlet-p0")
+        o.dirichlet_p0 = true;
+      else if (k == "final-counts")
+        o.final_counts = true;
+      else if (k == "crp-exclude-prior")
+        o.exclude_prior = true;
+      else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
+        o.crp_parallel = true;
       else
         std::cerr << "option " << k << " = " << v << " (ignored by the GPU training front end)\n";
       continue;
@@ -99,11 +119,16 @@ static Options parse_args(int argc, char** argv) {
           case 'f': o.smooth_floor = std::atof(value()); break;
           case 'T': o.index_threshold = std::atoi(value()); break;
           case 'F': o.out_file = value(); break;
+          case 'R': o.seed = std::strtoull(value(), 0, 10); break;
           default: break;
         }
       continue;
     }
     o.files.push_back(argv[i]);
+  }
+  if (o.crp) {  // force_cascade_derivs (carmel.cc:230-233)
+    o.train_cascade = true;
+    if (o.crp_iters > 1) o.max_iter = o.crp_iters;
   }
   if (o.train_cascade) o.flags[(unsigned)'t'] = true;
   return o;
@@ -231,12 +256,60 @@ static int run(int argc, char** argv) {
               "carmel_hip_set_cascade");
   } else
     hip_check(carmel_hip_set_norm(t, norms[0], addc[0]), "carmel_hip_set_norm");
-  hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509
-  if (!cascade || o.smooth_floor > 0)
+  if (!o.crp) hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509 (not for --crp, gibbs.cc:403)
+  if (!o.crp && (!cascade || o.smooth_floor > 0))
     hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
   hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
                                   pairs.out_sym.data(), pairs.weight.data()),
             "carmel_hip_set_corpus");
+  if (o.crp) {  // WFST::train_gibbs (gibbs.cc:386-430)
+    carmel_hip_gibbs_opts go;
+    std::memset(&go, 0, sizeof go);
+    go.iter = (uint32_t)(o.max_iter > 0 ? o.max_iter : 0);
+    go.burnin = (uint32_t)o.burnin;
+    go.seed = o.seed;
+    go.mode = o.crp_parallel ? 1 : 0;
+    go.uniform_p0 = o.uniform_p0;
+    go.dirichlet_p0 = o.dirichlet_p0;
+    go.final_counts = o.final_counts;
+    go.exclude_prior = o.exclude_prior;
+    go.min_prior = 1e-2;
+    for (size_t i = 0; i < nw; ++i)
+      if (addc[i] <= 0)
+        std::cerr << "Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01\n";
+    carmel_hip_gibbs* gs = 0;
+    hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
+    std::vector<double> lp(go.iter + 1);
+    int rc = carmel_hip_gibbs_run(gs, lp.data(), 0);
+    uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
+    carmel_hip_gibbs_destroy(gs);
+    hip_check(rc, "carmel_hip_gibbs_run");
+    double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
+    for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
+    for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
+      std::cerr << "Gibbs i=" << i << " " << (go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(lp[i]);
+      if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-lp[i] / n_sym);
+      std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-lp[i] / nblocks) << "\n";
+    }
+    std::vector<double> pw(cascade ? params.logw.size() : logw.size());
+    hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
+    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
+    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
+    const char* dir = std::getenv("CARMEL_TRAINED_DIR");
+    for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437
+      member[i].set_weights(pw.data() + (cascade ? params.member_base[i] : 0));
+      std::string fn = std::string(o.files[i + 1]) + ".trained";
+      if (dir) {
+        std::string b = o.files[i + 1];
+        size_t sl = b.rfind('/');
+        fn = std::string(dir) + "/" + (sl == std::string::npos ? b : b.substr(sl + 1)) + ".trained";
+      }
+      std::cerr << "Writing trained " << o.files[i + 1] << " to " << fn << std::endl;
+      std::ofstream of(fn.c_str());
+      of << member[i].to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
+    }
+    return 0;
+  }
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
   hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");

@@ -90,3 +90,32 @@ def test_flags_joint_and_max_iter(golden_dir, oracle):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-7)
+
+
+def test_crp_command(golden_dir, tmp_path, oracle):
+    """carmel --crp -M 30 --burnin=10 --priors=0.5,0.1 cipher.data cipher.wfsa cipher.fst: the front end drives the
+    exact sampler; its *.trained files carry the time-averaged probabilities the oracle computes from the same uniforms"""
+    import ctypes as C
+    import numpy as np
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    rc, out, err = run(["--crp", "-M", "30", "--burnin=10", "--priors=0.5,0.1", "-R", "5", "-HJ", g("cipher.data"),
+                        g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc == 0, err
+    lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
+    assert len(lines) == 31 and "cache-model prob=2^" in lines[0] and "per-block-ppx(N=10)" in lines[0]
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()),
+                           lambda i, b, s: lib.carmel_hip_gibbs_uniform(5, i, b, s), normby="CC", priors=[0.5, 0.1],
+                           iters=30, burnin=10)
+    logged = [float(re.search(r"prob=2\^(\S+)", l).group(1)) for l in lines]
+    for a, b in zip(logged, ref["iter_logprob"] / math.log(2)):
+        assert a == float("%.6g" % b)
+    exp_txt = oc.write_member(1, ref["param_logw"])
+    got_txt = open(os.path.join(str(tmp_path), "cipher.fst.trained")).read()
+    gl, el = got_txt.strip().split("\n"), exp_txt.strip().split("\n")
+    assert len(gl) == len(el)
+    for x, y in zip(gl, el):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-9)
