@@ -24,6 +24,10 @@ SYMBOLS = [
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform",
+    "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
+    "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
+    "carmel_hip_forests_set_weights", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
+    "carmel_hip_forests_max_sample",
 ]
 
 
@@ -110,6 +114,18 @@ def _load():
     lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.carmel_hip_gibbs_uniform.restype = C.c_double
+    lib.carmel_hip_forests_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint64, vp, vp, vp, vp, C.c_uint32, vp,
+                                              C.c_uint64, vp, vp]
+    lib.carmel_hip_forests_destroy.argtypes = [vp]
+    lib.carmel_hip_forests_estimate.argtypes = [vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_uint64), vp]
+    lib.carmel_hip_forests_get_counts.argtypes = [vp, C.c_double, vp]
+    lib.carmel_hip_forests_maximize.argtypes = [vp, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_double)]
+    lib.carmel_hip_forests_get_weights.argtypes = [vp, vp]
+    lib.carmel_hip_forests_set_weights.argtypes = [vp, vp]
+    lib.carmel_hip_forests_gibbs.argtypes = [vp, C.POINTER(GibbsOpts), C.c_double, vp, vp]
+    lib.carmel_hip_forests_get_sample.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
+    lib.carmel_hip_forests_max_sample.argtypes = [vp]
+    lib.carmel_hip_forests_max_sample.restype = C.c_uint32
     return lib
 
 

@@ -1,0 +1,899 @@
+// forest.hip — forest-em's packed AND/OR derivation forests on the GPU: inside, normalised outside, expected rule
+// counts, the EM M-step over normalisation groups, and the Gibbs sampler (inside with proposal probabilities +
+// top-down choice).
+//
+// Replaces /root/reference/forest-em/forest.hpp (inside_rec :636-697, compute_norm_outside :439-491,
+// visit_inside_norm_outside :417-438, choose_random :725-758, compute_inside(W) :768-816) and
+// forest-em.hpp (estimate :561-578, maximize :626-655, Gibbs glue :694-766); graehl/shared/normalize.hpp:123-164.
+//
+// Layout: one forest per LANE, 64 forests per wavefront (forests are small: config 5 has ~50 nodes each).  A forest
+// is flattened on the host into two record streams over its non-reference nodes renumbered in POST-ORDER (children
+// and shared sub-forests before the nodes that use them; a back-reference simply resolves to the shared node):
+//   inside stream : per node a header {AND?, rule id} followed by one record per child {child index}
+//   outside stream: the same per node, nodes in reverse post-order
+// and the 64 streams of a group are interleaved record by record so every wave-wide load is one 512-byte row.
+// inside[] (and outside[]) live in the lane's own LDS column(s).  Expected counts reuse the two-phase scheme of the
+// lattice path: one posterior per AND node into post[], then count_reduce_kernel with rules in the role of arcs.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <numeric>
+#include "engine.hpp"
+#include "rng.hpp"
+
+namespace carmel_hip {
+
+#define F_NEG_INF (-__builtin_huge_val())
+static const uint32_t F_HEADER = 0x80000000u, F_VALID = 0x40000000u, F_LAST = 0x20000000u, F_AND = 0x10000000u;
+static const uint32_t F_IDX = 0x0fffffffu;
+#define F_NONORM 0xffffffffu
+
+struct FGroup {  // 32 bytes, one wavefront of forests
+  uint64_t stream_base;
+  uint32_t maxlen, n_lanes, lane_base, max_nodes;
+  uint64_t pad;
+};
+
+struct ForestArgs {
+  const FGroup* groups;
+  const uint2* ins_stream;
+  const uint2* out_stream;
+  const uint32_t* lane_forest;   // forest id per lane slot
+  const uint32_t* lane_nodes;    // non-reference nodes per lane slot
+  const double* rule_logw;
+  double* post;                  // one slot per outside-stream record (only AND headers are used)
+  double* forest_logprob;        // per forest: ln inside[root]
+  double* scalars;               // {sum ln p over non-zero forests, n non-zero, n zero}
+  // Gibbs
+  const uint32_t* p_norm;        // per rule: norm group or F_NONORM
+  const double* p_prior;
+  const double* snap_x;          // counts / normsums the proposal is computed from
+  const double* snap_norm;
+  const uint32_t* hdr_pos;       // per (node, lane): position of the node's header in the inside stream
+  const uint64_t* sample_off;    // per forest
+  uint32_t* sample_len;
+  uint32_t* sample_rules;
+  const uint32_t* old_len;       // previous sample (counterfactual removal); may alias sample_* of the other buffer
+  const uint32_t* old_rules;
+  double* iter_out;
+  uint64_t seed;
+  uint32_t iter, first_group, serial_forest;  // serial_forest: exact mode processes exactly this forest (lane slot)
+  int counterfactual;
+};
+
+__device__ __forceinline__ double f_lwadd(double a, double b) {
+  if (a == F_NEG_INF) return b;
+  if (b == F_NEG_INF) return a;
+  double d = a - b;
+  if (d > 36.0) return a;
+  if (d < -36.0) return b;
+  if (d < 0) return b + log1p(exp(d));
+  return a + log1p(exp(-d));
+}
+
+// inside over the lane's stream with the rule weights
+__device__ __forceinline__ void f_inside(const ForestArgs& A, const FGroup& g, int lane, double* col) {
+  const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+  uint32_t d = 0;
+  bool is_and = false;
+  double acc = 0.0, m = F_NEG_INF, sum = 0.0;
+  for (uint32_t k = 0; k < g.maxlen; ++k) {
+    const uint2 r = st[(size_t)k * 64];
+    if (!(r.x & F_VALID)) continue;
+    if (r.x & F_HEADER) {
+      is_and = (r.x & F_AND) != 0;
+      if (is_and)
+        acc = A.rule_logw[r.y];
+      else {
+        m = F_NEG_INF;
+        sum = 0.0;
+      }
+    } else {
+      const double v = col[(size_t)(r.x & F_IDX) * 64];
+      if (is_and)
+        acc += v;
+      else if (v != F_NEG_INF) {  // streaming logsumexp over the OR's children
+        if (v <= m)
+          sum += exp(v - m);
+        else {
+          sum = (m == F_NEG_INF) ? 1.0 : sum * exp(m - v) + 1.0;
+          m = v;
+        }
+      }
+    }
+    if (r.x & F_LAST) {
+      col[(size_t)d * 64] = is_and ? acc : (sum == 1.0 ? m : (sum > 0.0 ? m + log(sum) : F_NEG_INF));
+      ++d;
+    }
+  }
+}
+
+// EM E-step: inside, normalised outside, posteriors of AND nodes.  LDS: two columns per lane (inside, outside).
+__global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
+  double* ins = lds + lane;
+  double* out = lds + (size_t)g.max_nodes * 64 + lane;
+  f_inside(A, g, lane, ins);
+  double lp = F_NEG_INF;
+  if (active) {
+    lp = ins[(size_t)(n - 1) * 64];
+    A.forest_logprob[A.lane_forest[g.lane_base + lane]] = lp;
+    for (uint32_t s = 0; s < n; ++s) out[(size_t)s * 64] = F_NEG_INF;
+    if (lp != F_NEG_INF) out[(size_t)(n - 1) * 64] = -lp;  // norm_outside[root] = 1 / inside[root]
+  }
+  const uint2* __restrict__ st = A.out_stream + g.stream_base + lane;
+  double* __restrict__ post = A.post + g.stream_base + lane;
+  bool is_and = false;
+  double op = F_NEG_INF, ip = F_NEG_INF;
+  for (uint32_t k = 0; k < g.maxlen; ++k) {
+    const uint2 r = st[(size_t)k * 64];
+    if (!(r.x & F_VALID)) continue;
+    if (r.x & F_HEADER) {
+      const uint32_t p = r.x & F_IDX;
+      is_and = (r.x & F_AND) != 0;
+      op = out[(size_t)p * 64];
+      ip = ins[(size_t)p * 64];
+      if (is_and) post[(size_t)k * 64] = (lp != F_NEG_INF && op != F_NEG_INF) ? exp(ip + op) : 0.0;
+    } else if (lp != F_NEG_INF && op != F_NEG_INF) {
+      const uint32_t c = r.x & F_IDX;
+      double contrib = op;
+      if (is_and) {
+        if (ip == F_NEG_INF) continue;  // 0/0 guard of forest.hpp:470
+        contrib = op + ip - ins[(size_t)c * 64];
+      }
+      out[(size_t)c * 64] = f_lwadd(out[(size_t)c * 64], contrib);
+    }
+  }
+  double s_lp = (active && lp != F_NEG_INF) ? lp : 0.0, s_n = (active && lp != F_NEG_INF) ? 1.0 : 0.0,
+         s_z = (active && lp == F_NEG_INF) ? 1.0 : 0.0;
+  for (int o = 32; o > 0; o >>= 1) {
+    s_lp += __shfl_down(s_lp, o, 64);
+    s_n += __shfl_down(s_n, o, 64);
+    s_z += __shfl_down(s_z, o, 64);
+  }
+  if (lane == 0) {
+    unsafeAtomicAdd(A.scalars + 0, s_lp);
+    unsafeAtomicAdd(A.scalars + 1, s_n);
+    unsafeAtomicAdd(A.scalars + 2, s_z);
+  }
+}
+
+// Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
+// snap_norm.  LDS per lane: inside column + a u32 work stack + the lane's previous sample.
+__global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  bool active = (uint32_t)lane < g.n_lanes;
+  if (A.serial_forest != 0xffffffffu) active = active && (g.lane_base + lane == A.serial_forest);
+  const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
+  double* ins = lds + lane;
+  uint32_t* stack = (uint32_t*)(lds + (size_t)g.max_nodes * 64) + lane;                          // [max_sample + 1][64]
+  uint32_t* own = (uint32_t*)(lds + (size_t)g.max_nodes * 64) + (size_t)(max_sample + 1) * 64 + lane;  // [max_sample][64]
+  const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
+  uint32_t own_len = 0;
+  if (active && A.counterfactual) {
+    own_len = A.old_len[forest];
+    const uint32_t* o = A.old_rules + A.sample_off[forest];
+    for (uint32_t k = 0; k < own_len; ++k) own[(size_t)k * 64] = o[k];
+  }
+  // inside with proposal probabilities (forest.hpp:768-816)
+  {
+    const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+    uint32_t d = 0;
+    bool is_and = false;
+    double acc = 0.0, sum = F_NEG_INF;
+    for (uint32_t k = 0; k < g.maxlen; ++k) {
+      const uint2 r = st[(size_t)k * 64];
+      if (!active || !(r.x & F_VALID)) continue;
+      if (r.x & F_HEADER) {
+        is_and = (r.x & F_AND) != 0;
+        if (is_and) {
+          const uint32_t rule = r.y, nn = A.p_norm[rule];
+          double pr;
+          if (nn == F_NONORM)
+            pr = A.p_prior[rule];
+          else {
+            double x = A.snap_x[rule], ns = A.snap_norm[nn];
+            for (uint32_t q = 0; q < own_len; ++q) {
+              const uint32_t rr = own[(size_t)q * 64];
+              if (rr == rule) x -= 1.0;
+              if (A.p_norm[rr] == nn) ns -= 1.0;
+            }
+            pr = x / ns;
+          }
+          acc = log(pr);
+        } else
+          sum = F_NEG_INF;
+      } else {
+        const double v = ins[(size_t)(r.x & F_IDX) * 64];
+        if (is_and)
+          acc += v;
+        else
+          sum = f_lwadd(sum, v);  // the reference's pairwise OR fold (forest.hpp:790-797)
+      }
+      if (r.x & F_LAST) {
+        ins[(size_t)d * 64] = is_and ? acc : sum;
+        ++d;
+      }
+    }
+  }
+  // top-down choice (forest.hpp:725-758) with an explicit stack; children are pushed in reverse so they pop in order
+  double cheap = 0.0;
+  if (active) {
+    const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+    const uint32_t* __restrict__ hp = A.hdr_pos + g.stream_base + lane;  // indexed [node * 64]
+    uint32_t* outr = A.sample_rules + A.sample_off[forest];
+    uint32_t sp = 0, ns = 0, step = 0;
+    stack[0] = n - 1;
+    sp = 1;
+    while (sp) {
+      const uint32_t node = stack[(size_t)(--sp) * 64];
+      const uint32_t h = hp[(size_t)node * 64];
+      const uint2 hr = st[(size_t)h * 64];
+      // children occupy records h+1 .. until the one flagged LAST (none if the header itself is LAST)
+      uint32_t nch = 0;
+      if (!(hr.x & F_LAST))
+        for (uint32_t k = h + 1;; ++k) {
+          ++nch;
+          if (st[(size_t)k * 64].x & F_LAST) break;
+        }
+      if (hr.x & F_AND) {
+        if (ns < max_sample) outr[ns] = hr.y;
+        ++ns;
+        for (uint32_t k = nch; k-- > 0;) stack[(size_t)(sp++) * 64] = st[(size_t)(h + 1 + k) * 64].x & F_IDX;
+      } else {
+        double norm = F_NEG_INF;
+        for (uint32_t k = 0; k < nch; ++k) norm = f_lwadd(norm, ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64]);
+        double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+        uint32_t pick = 0;
+        for (uint32_t k = 0;; ++k) {
+          pick = k;
+          choice -= exp(ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] - norm);
+          if (choice < 0 || k + 1 == nch) break;
+        }
+        stack[(size_t)(sp++) * 64] = st[(size_t)(h + 1 + pick) * 64].x & F_IDX;
+      }
+    }
+    A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+    for (uint32_t k = 0; k < ns && k < max_sample; ++k) {
+      const uint32_t rule = outr[k], nn = A.p_norm[rule];
+      double pr;
+      if (nn == F_NONORM)
+        pr = A.p_prior[rule];
+      else {
+        double x = A.snap_x[rule], nsum = A.snap_norm[nn];
+        for (uint32_t q = 0; q < own_len; ++q) {
+          const uint32_t rr = own[(size_t)q * 64];
+          if (rr == rule) x -= 1.0;
+          if (A.p_norm[rr] == nn) nsum -= 1.0;
+        }
+        pr = x / nsum;
+      }
+      cheap += log(pr);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) cheap += __shfl_down(cheap, o, 64);
+  if (lane == 0) unsafeAtomicAdd(A.iter_out + 1, cheap);
+}
+
+// counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors)
+__global__ void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len, const uint32_t* rules,
+                                      const uint32_t* p_norm, double* x, double* normsum, uint32_t n_forests) {
+  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_forests; f += gridDim.x * blockDim.x) {
+    const uint32_t* r = rules + sample_off[f];
+    for (uint32_t k = 0; k < sample_len[f]; ++k) {
+      const uint32_t nn = p_norm[r[k]];
+      if (nn == F_NONORM) continue;
+      unsafeAtomicAdd(x + r[k], 1.0);
+      unsafeAtomicAdd(normsum + nn, 1.0);
+    }
+  }
+}
+__global__ void forest_commit_kernel(const double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
+                                     double time, uint64_t n) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
+    if (p_norm[p] == F_NONORM) continue;
+    const double d = new_x[p] - p_x[p];
+    const double moret = time - p_tmax[p];
+    if (moret > 0) {
+      p_tmax[p] = time;
+      p_s[p] += moret * p_x[p];
+    } else if (moret < 0)
+      p_s[p] += d * (-moret);
+    p_x[p] += d;
+  }
+}
+
+// M-step (normalize.hpp:123-164): per group w = (count) / (sum + add_k); zero-count group -> uniform or zero
+__global__ void forest_mstep_kernel(double* rule_logw, const double* counts, double prior, const uint64_t* group_off,
+                                    const uint32_t* group_rule, uint64_t n_groups, double add_k, int zero_zero,
+                                    unsigned long long* max_bits) {
+  double mx = 0.0;
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t j0 = group_off[g], j1 = group_off[g + 1];
+    double sum = 0.0;
+    for (uint64_t j = j0; j < j1; ++j) sum += counts[group_rule[j]] + prior;
+    for (uint64_t j = j0; j < j1; ++j) {
+      const uint32_t r = group_rule[j];
+      double nw;
+      if (sum > 0.0) {
+        const double c = counts[r] + prior;
+        nw = c > 0.0 ? log(c / (sum + add_k)) : F_NEG_INF;
+      } else
+        nw = zero_zero ? F_NEG_INF : -log((double)(j1 - j0));
+      mx = fmax(mx, fabs(exp(nw) - exp(rule_logw[r])));
+      rule_logw[r] = nw;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(mx));
+}
+
+}  // namespace carmel_hip
+
+using namespace carmel_hip;
+
+struct carmel_hip_forests {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint64_t n_forests = 0, n_groups = 0;
+  uint32_t n_rules = 0, max_nodes = 0, max_sample = 0;
+  std::vector<FGroup> h_groups;
+  struct Cls {
+    uint32_t first, count, max_nodes;
+  };
+  std::vector<Cls> classes;
+  std::vector<uint32_t> h_norm, lane_of_forest;
+  std::vector<uint64_t> h_group_off;
+  std::vector<uint32_t> h_group_rule;
+  std::vector<uint64_t> h_sample_off;
+  DevBuf<FGroup> groups;
+  DevBuf<uint2_t> ins_stream, out_stream;
+  DevBuf<uint32_t> lane_forest, lane_nodes, hdr_pos, group_rule, p_norm, sample_len[2], sample_rules[2];
+  DevBuf<uint64_t> group_off, arc_off, slot_pos, hot_chunks, sample_off;
+  DevBuf<double> rule_logw, counts, post, forest_logprob, scalars, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, new_x,
+      iter_out;
+  DevBuf<unsigned long long> maxbits;
+};
+
+extern "C" {
+
+int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_forests, const uint64_t* node_off,
+                              const uint32_t* label, const int32_t* ref, const uint32_t* next, uint32_t n_rules,
+                              const double* rule_logw, uint64_t n_groups, const uint64_t* group_off,
+                              const uint32_t* group_rule) {
+  if (!out || !node_off || !label || !ref || !next || !rule_logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) return fail(CARMEL_HIP_ERR_HIP, "no HIP device: forest-em has no CPU fallback here");
+  if (device < 0 || device >= ndev) return fail(CARMEL_HIP_ERR_ARG, "bad device index");
+  HIPCHK(hipSetDevice(device));
+  std::unique_ptr<carmel_hip_forests> F(new carmel_hip_forests());
+  F->device = device;
+  F->n_forests = n_forests;
+  F->n_rules = n_rules;
+  F->n_groups = n_groups;
+  HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+  hipStream_t s = F->stream;
+  // ---- per forest: post-order over non-reference nodes, streams ----
+  struct Flat {
+    std::vector<uint2_t> ins, outs;
+    std::vector<uint32_t> hdr;  // per post-order node: header position in ins
+    uint32_t n = 0;
+    uint64_t max_deriv = 0;     // rules in the largest derivation (shared sub-forests count once per use)
+  };
+  std::vector<Flat> flat(n_forests);
+  for (uint64_t f = 0; f < n_forests; ++f) {
+    const uint64_t b = node_off[f], e = node_off[f + 1];
+    const uint32_t N = (uint32_t)(e - b);
+    if (!N) return fail(CARMEL_HIP_ERR_ARG, "empty forest");
+    std::vector<uint32_t> pi(N, 0xffffffffu), order;
+    // post-order = nodes sorted by (end of subtree ascending, start descending); references are skipped
+    std::vector<uint32_t> idx;
+    for (uint32_t i = 0; i < N; ++i) {
+      if (next[b + i] <= i || next[b + i] > N) return fail(CARMEL_HIP_ERR_ARG, "bad forest node extent");
+      if (ref[b + i] >= 0) {
+        if ((uint32_t)ref[b + i] >= i) return fail(CARMEL_HIP_ERR_ARG, "forest back-reference must point backwards");
+        continue;
+      }
+      if (label[b + i] >= n_rules && label[b + i] != 0) return fail(CARMEL_HIP_ERR_ARG, "rule id out of range");
+      idx.push_back(i);
+    }
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) {
+      if (next[b + x] != next[b + y]) return next[b + x] < next[b + y];
+      return x > y;
+    });
+    for (uint32_t k = 0; k < idx.size(); ++k) pi[idx[k]] = k;
+    Flat& fl = flat[f];
+    fl.n = (uint32_t)idx.size();
+    if (fl.n > F_IDX) return fail(CARMEL_HIP_ERR_UNSUPPORTED, "forest too large");
+    auto resolve = [&](uint32_t c) {
+      while (ref[b + c] >= 0) c = (uint32_t)ref[b + c];
+      return pi[c];
+    };
+    std::vector<std::vector<uint32_t> > kids(fl.n);
+    for (uint32_t k = 0; k < fl.n; ++k) {
+      uint32_t i = idx[k];
+      for (uint32_t c = i + 1; c < next[b + i]; c = next[b + c]) kids[k].push_back(resolve(c));
+    }
+    fl.hdr.resize(fl.n);
+    for (uint32_t k = 0; k < fl.n; ++k) {
+      uint32_t i = idx[k];
+      bool is_and = label[b + i] != 0;
+      fl.hdr[k] = (uint32_t)fl.ins.size();
+      uint32_t hx = F_HEADER | F_VALID | (is_and ? F_AND : 0u) | (kids[k].empty() ? F_LAST : 0u) | k;
+      fl.ins.push_back(uint2_t{hx, label[b + i]});
+      for (size_t c = 0; c < kids[k].size(); ++c)
+        fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], 0u});
+    }
+    for (uint32_t k = fl.n; k-- > 0;) {
+      uint32_t i = idx[k];
+      bool is_and = label[b + i] != 0;
+      fl.outs.push_back(uint2_t{F_HEADER | F_VALID | (is_and ? F_AND : 0u) | k, label[b + i]});
+      for (uint32_t c : kids[k]) fl.outs.push_back(uint2_t{F_VALID | c, 0u});
+    }
+    if (!(label[b + 0] == 0 || ref[b + 0] < 0)) return fail(CARMEL_HIP_ERR_ARG, "forest root cannot be a reference");
+    std::vector<uint64_t> dsz(fl.n, 0);
+    for (uint32_t k = 0; k < fl.n; ++k) {
+      uint64_t v = 0;
+      if (label[b + idx[k]] != 0) {
+        v = 1;
+        for (uint32_t c : kids[k]) v += dsz[c];
+      } else
+        for (uint32_t c : kids[k]) v = std::max(v, dsz[c]);
+      dsz[k] = std::min<uint64_t>(v, 1u << 20);
+    }
+    fl.max_deriv = std::max<uint64_t>(1, dsz[fl.n - 1]);
+  }
+  // ---- groups of 64, sorted by stream length ----
+  std::vector<uint32_t> ord(n_forests);
+  std::iota(ord.begin(), ord.end(), 0u);
+  std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b2) { return flat[a].ins.size() > flat[b2].ins.size(); });
+  const size_t ng = (n_forests + 63) / 64;
+  F->h_groups.resize(ng);
+  std::vector<uint32_t> lane_forest(ng * 64, 0xffffffffu), lane_nodes(ng * 64, 0);
+  F->lane_of_forest.assign(n_forests, 0);
+  uint64_t base = 0;
+  for (size_t gidx = 0; gidx < ng; ++gidx) {
+    FGroup& G = F->h_groups[gidx];
+    std::memset(&G, 0, sizeof G);
+    size_t l0 = gidx * 64, l1 = std::min<size_t>(n_forests, l0 + 64);
+    G.stream_base = base;
+    G.n_lanes = (uint32_t)(l1 - l0);
+    G.lane_base = (uint32_t)l0;
+    for (size_t l = l0; l < l1; ++l) {
+      const Flat& fl = flat[ord[l]];
+      G.maxlen = std::max<uint32_t>(G.maxlen, (uint32_t)fl.ins.size());
+      G.max_nodes = std::max(G.max_nodes, fl.n);
+      lane_forest[l] = ord[l];
+      lane_nodes[l] = fl.n;
+      F->lane_of_forest[ord[l]] = (uint32_t)l;
+    }
+    F->max_nodes = std::max(F->max_nodes, G.max_nodes);
+    base += (uint64_t)G.maxlen * 64;
+  }
+  std::vector<uint2_t> si(base, uint2_t{0, 0}), so(base, uint2_t{0, 0});
+  std::vector<uint32_t> hp(base, 0);
+  for (size_t gidx = 0; gidx < ng; ++gidx) {
+    const FGroup& G = F->h_groups[gidx];
+    for (uint32_t l = 0; l < G.n_lanes; ++l) {
+      const Flat& fl = flat[ord[G.lane_base + l]];
+      for (size_t k = 0; k < fl.ins.size(); ++k) si[G.stream_base + k * 64 + l] = fl.ins[k];
+      for (size_t k = 0; k < fl.outs.size(); ++k) so[G.stream_base + k * 64 + l] = fl.outs[k];
+      for (uint32_t k = 0; k < fl.n; ++k) hp[G.stream_base + (size_t)k * 64 + l] = fl.hdr[k];
+    }
+  }
+  {  // launch classes by LDS need
+    size_t i = 0;
+    while (i < ng) {
+      uint32_t mx = F->h_groups[i].max_nodes;
+      size_t j = i + 1;
+      while (j < ng) {
+        uint32_t m = F->h_groups[j].max_nodes;
+        if (m > mx) mx = m;
+        if (j - i >= 256 && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
+        ++j;
+      }
+      F->classes.push_back(carmel_hip_forests::Cls{(uint32_t)i, (uint32_t)(j - i), mx});
+      i = j;
+    }
+  }
+  // ---- posterior slots grouped by rule (AND headers of the outside stream) ----
+  std::vector<uint64_t> cnt((size_t)n_rules + 1, 0);
+  for (uint64_t k = 0; k < base; ++k)
+    if ((so[k].x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND)) cnt[so[k].y + 1]++;
+  for (uint32_t r = 0; r < n_rules; ++r) cnt[r + 1] += cnt[r];
+  std::vector<uint64_t> arc_off = cnt, slot_pos(cnt[n_rules]), hot;
+  for (uint64_t k = 0; k < base; ++k)
+    if ((so[k].x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND)) slot_pos[cnt[so[k].y]++] = k;
+  for (uint32_t r = 0; r < n_rules; ++r)
+    if (arc_off[r + 1] - arc_off[r] > 64)
+      for (uint64_t j = arc_off[r]; j < arc_off[r + 1]; j += 4096) {
+        hot.push_back(r);
+        hot.push_back(j);
+        hot.push_back(std::min(arc_off[r + 1], j + 4096));
+      }
+  // ---- normalisation groups ----
+  F->h_norm.assign(n_rules, F_NONORM);
+  F->h_group_off.assign(group_off, group_off + n_groups + 1);
+  F->h_group_rule.assign(group_rule, group_rule + group_off[n_groups]);
+  for (uint64_t gi = 0; gi < n_groups; ++gi)
+    for (uint64_t j = group_off[gi]; j < group_off[gi + 1]; ++j) {
+      if (group_rule[j] >= n_rules) return fail(CARMEL_HIP_ERR_ARG, "normalization group rule id out of range");
+      if (F->h_norm[group_rule[j]] != F_NONORM)
+        return fail(CARMEL_HIP_ERR_ARG, "a rule occurs in more than one normalization group");
+      F->h_norm[group_rule[j]] = (uint32_t)gi;
+    }
+  // samples: capacity = size of the largest derivation of the forest
+  F->h_sample_off.assign(n_forests + 1, 0);
+  for (uint64_t f = 0; f < n_forests; ++f) {
+    F->h_sample_off[f + 1] = F->h_sample_off[f] + flat[f].max_deriv;
+    F->max_sample = std::max<uint32_t>(F->max_sample, (uint32_t)flat[f].max_deriv);
+  }
+  HIPCHK(F->groups.upload(F->h_groups, s));
+  HIPCHK(F->ins_stream.upload(si, s));
+  HIPCHK(F->out_stream.upload(so, s));
+  HIPCHK(F->hdr_pos.upload(hp, s));
+  HIPCHK(F->lane_forest.upload(lane_forest, s));
+  HIPCHK(F->lane_nodes.upload(lane_nodes, s));
+  HIPCHK(F->rule_logw.upload(std::vector<double>(rule_logw, rule_logw + n_rules), s));
+  HIPCHK(F->counts.alloc(n_rules));
+  HIPCHK(F->post.alloc(base));
+  HIPCHK(F->forest_logprob.alloc(n_forests));
+  HIPCHK(F->scalars.alloc(4));
+  HIPCHK(F->arc_off.upload(arc_off, s));
+  HIPCHK(F->slot_pos.upload(slot_pos, s));
+  HIPCHK(F->hot_chunks.upload(hot, s));
+  HIPCHK(F->group_off.upload(F->h_group_off, s));
+  HIPCHK(F->group_rule.upload(F->h_group_rule, s));
+  HIPCHK(F->p_norm.upload(F->h_norm, s));
+  HIPCHK(F->sample_off.upload(F->h_sample_off, s));
+  HIPCHK(F->maxbits.alloc(1));
+  HIPCHK(F->iter_out.alloc(2));
+  HIPCHK(hipStreamSynchronize(s));
+  *out = F.release();
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_forests_destroy(carmel_hip_forests* F) {
+  if (F) {
+    (void)hipSetDevice(F->device);
+    (void)hipDeviceSynchronize();
+    hipStream_t s = F->stream;
+    delete F;
+    if (s) (void)hipStreamDestroy(s);
+  }
+  return CARMEL_HIP_OK;
+}
+
+static void fill_args(carmel_hip_forests* F, ForestArgs& A) {
+  std::memset(&A, 0, sizeof A);
+  A.groups = F->groups.p;
+  A.ins_stream = (const uint2*)F->ins_stream.p;
+  A.out_stream = (const uint2*)F->out_stream.p;
+  A.lane_forest = F->lane_forest.p;
+  A.lane_nodes = F->lane_nodes.p;
+  A.rule_logw = F->rule_logw.p;
+  A.post = F->post.p;
+  A.forest_logprob = F->forest_logprob.p;
+  A.scalars = F->scalars.p;
+  A.p_norm = F->p_norm.p;
+  A.hdr_pos = F->hdr_pos.p;
+  A.sample_off = F->sample_off.p;
+  A.iter_out = F->iter_out.p;
+  A.serial_forest = 0xffffffffu;
+}
+
+// FForests::estimate (forest-em.hpp:561-578): counts = prior_count * n_forests + expected rule counts;
+// returns the average log probability over the forests with non-zero probability
+int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, double* avg_logprob, uint64_t* n_zero,
+                                double* per_forest_logprob) {
+  if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(F->device));
+  hipStream_t s = F->stream;
+  ForestArgs A;
+  fill_args(F, A);
+  HIPCHK(hipMemsetAsync(F->scalars.p, 0, 4 * sizeof(double), s));
+  for (auto& c : F->classes) {
+    A.first_group = c.first;
+    size_t lds = (size_t)c.max_nodes * 64 * sizeof(double) * 2;
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)forest_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(forest_estimate_kernel, dim3(c.count), dim3(64), lds, s, A);
+  }
+  HIPCHK(hipGetLastError());
+  ReduceArgs R;
+  R.arc_off = F->arc_off.p;
+  R.slot_pos = F->slot_pos.p;
+  R.hot_chunks = F->hot_chunks.p;
+  R.post = F->post.p;
+  R.counts = F->counts.p;
+  R.n_arcs = F->n_rules;
+  R.n_hot_chunks = F->hot_chunks.n / 3;
+  HIPCHK(launch_count_reduce(R, s));
+  double sc[4];
+  HIPCHK(hipMemcpyAsync(sc, F->scalars.p, sizeof sc, hipMemcpyDeviceToHost, s));
+  if (per_forest_logprob)
+    HIPCHK(hipMemcpyAsync(per_forest_logprob, F->forest_logprob.p, F->n_forests * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  (void)prior_count;  // folded in at maximize / get_counts (it is a constant added to every count)
+  if (avg_logprob) *avg_logprob = sc[1] > 0 ? sc[0] / sc[1] : -std::numeric_limits<double>::infinity();
+  if (n_zero) *n_zero = (uint64_t)(sc[2] + 0.5);
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_forests_get_counts(carmel_hip_forests* F, double prior_count, double* counts) {
+  if (!F || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(F->device));
+  HIPCHK(hipMemcpyAsync(counts, F->counts.p, F->n_rules * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  const double wp = prior_count * (double)F->n_forests;
+  for (uint32_t r = 0; r < F->n_rules; ++r) counts[r] += wp;
+  return CARMEL_HIP_OK;
+}
+
+// FForests::maximize (forest-em.hpp:626-655) -> NormalizeGroups (normalize.hpp:123-164)
+int carmel_hip_forests_maximize(carmel_hip_forests* F, double prior_count, double add_k, int zero_zerocounts,
+                                double* max_delta) {
+  if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
+  HIPCHK(hipSetDevice(F->device));
+  hipStream_t s = F->stream;
+  HIPCHK(hipMemsetAsync(F->maxbits.p, 0, sizeof(unsigned long long), s));
+  if (F->n_groups) {
+    unsigned grid = (unsigned)std::min<uint64_t>((F->n_groups + 255) / 256, 4096);
+    hipLaunchKernelGGL(forest_mstep_kernel, dim3(grid), dim3(256), 0, s, F->rule_logw.p, F->counts.p,
+                       prior_count * (double)F->n_forests, F->group_off.p, F->group_rule.p, F->n_groups, add_k,
+                       zero_zerocounts, F->maxbits.p);
+    HIPCHK(hipGetLastError());
+  }
+  unsigned long long bits = 0;
+  HIPCHK(hipMemcpyAsync(&bits, F->maxbits.p, sizeof bits, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  double d;
+  std::memcpy(&d, &bits, sizeof d);
+  if (max_delta) *max_delta = d;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_forests_get_weights(carmel_hip_forests* F, double* rule_logw) {
+  if (!F || !rule_logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(F->device));
+  HIPCHK(hipMemcpyAsync(rule_logw, F->rule_logw.p, F->n_rules * sizeof(double), hipMemcpyDeviceToHost, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_forests_set_weights(carmel_hip_forests* F, const double* rule_logw) {
+  if (!F || !rule_logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(F->device));
+  HIPCHK(hipMemcpyAsync(F->rule_logw.p, rule_logw, F->n_rules * sizeof(double), hipMemcpyHostToDevice, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  return CARMEL_HIP_OK;
+}
+
+// FForests::run_gibbs (forest-em.hpp:714-734): to_gibbs (normalise, prior = alpha * p * |group|), gibbs_base::run,
+// from_gibbs (rule weights = time-averaged probabilities).  opts->mode 0: forests strictly in order (the
+// reference's chain); 1: all forests of a sweep in parallel against the previous sweep's counts with each forest's
+// own previous sample taken out.
+int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts* o, double alpha, double* iter_logprob,
+                             double* iter_cheap_logprob) {
+  if (!F || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(F->device));
+  hipStream_t s = F->stream;
+  const uint32_t nr = F->n_rules;
+  const uint64_t ng = F->n_groups, nf = F->n_forests;
+  // define_gibbs(true): normalise the current weights (counts := weights), then priors
+  std::vector<double> lw(nr);
+  HIPCHK(hipMemcpyAsync(lw.data(), F->rule_logw.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  std::vector<double> prior(nr), pn(ng, 0.0);
+  for (uint64_t gi = 0; gi < ng; ++gi) {
+    double sum = 0;
+    const uint64_t j0 = F->h_group_off[gi], j1 = F->h_group_off[gi + 1];
+    for (uint64_t j = j0; j < j1; ++j) sum += std::exp(lw[F->h_group_rule[j]]);
+    for (uint64_t j = j0; j < j1; ++j) {
+      uint32_t r = F->h_group_rule[j];
+      double p = sum > 0 ? std::exp(lw[r]) / sum : 1.0 / (double)(j1 - j0);
+      lw[r] = p > 0 ? std::log(p) : -std::numeric_limits<double>::infinity();
+      prior[r] = o->uniform_p0 ? alpha : alpha * p * (double)(j1 - j0);
+      pn[gi] += prior[r];
+    }
+  }
+  for (uint32_t r = 0; r < nr; ++r)
+    if (F->h_norm[r] == F_NONORM) prior[r] = std::exp(lw[r]);
+  HIPCHK(F->p_prior.upload(prior, s));
+  HIPCHK(F->prior_norm.upload(pn, s));
+  HIPCHK(F->p_x.upload(prior, s));
+  HIPCHK(F->normsum.upload(pn, s));
+  HIPCHK(F->p_s.alloc(nr));
+  HIPCHK(F->p_tmax.alloc(nr));
+  HIPCHK(F->new_x.alloc(nr));
+  HIPCHK(hipMemsetAsync(F->p_s.p, 0, nr * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(F->p_tmax.p, 0, nr * sizeof(double), s));
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(F->sample_len[k].alloc(nf));
+    HIPCHK(F->sample_rules[k].alloc(F->h_sample_off.back()));
+    HIPCHK(hipMemsetAsync(F->sample_len[k].p, 0, nf * sizeof(uint32_t), s));
+  }
+  ForestArgs A;
+  fill_args(F, A);
+  A.p_prior = F->p_prior.p;
+  A.seed = o->seed;
+  A.counterfactual = 1;
+  const uint32_t Ni = o->iter, burnin = std::min(o->burnin, o->iter);
+  // host mirror of counts for the exact schedule (one forest at a time: the counts move between forests)
+  std::vector<double> hx, hs, ht, hn;
+  std::vector<std::vector<uint32_t> > hsample;
+  std::vector<double> ccount, csum;
+  if (o->mode == 0) {
+    hx = prior;
+    hs.assign(nr, 0.0);
+    ht.assign(nr, 0.0);
+    hn = pn;
+    hsample.assign(nf, {});
+  }
+  int cur = 0;
+  for (uint32_t iter = 0; iter <= Ni; ++iter) {
+    const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
+    A.iter = iter;
+    HIPCHK(hipMemsetAsync(F->iter_out.p, 0, 2 * sizeof(double), s));
+    double cache_lp = 0.0, cheap_lp = 0.0;
+    if (o->mode == 1) {
+      // all forests against the counts of the previous sweep, own previous sample taken out in-kernel
+      A.snap_x = F->p_x.p;
+      A.snap_norm = F->normsum.p;
+      A.old_len = F->sample_len[cur].p;
+      A.old_rules = F->sample_rules[cur].p;
+      A.sample_len = F->sample_len[cur ^ 1].p;
+      A.sample_rules = F->sample_rules[cur ^ 1].p;
+      for (auto& c : F->classes) {
+        A.first_group = c.first;
+        size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)(F->max_sample + 1) * 64 * 4 + (size_t)F->max_sample * 64 * 4;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample);
+      }
+      HIPCHK(hipGetLastError());
+      cur ^= 1;
+      HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 4096)), dim3(256), 0, s,
+                         F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
+                         F->normsum.p, (uint32_t)nf);
+      hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
+                         F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr);
+      HIPCHK(hipGetLastError());
+      double io[2];
+      HIPCHK(hipMemcpyAsync(io, F->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      cheap_lp = cache_lp = io[1];
+    } else {
+      // exact: forest after forest; each launch resamples ONE forest on the GPU against the current counts
+      ccount = prior;
+      csum = pn;
+      A.counterfactual = 0;
+      A.snap_x = F->p_x.p;
+      A.snap_norm = F->normsum.p;
+      A.sample_len = F->sample_len[0].p;
+      A.sample_rules = F->sample_rules[0].p;
+      A.old_len = F->sample_len[0].p;
+      A.old_rules = F->sample_rules[0].p;
+      auto addc = [&](const std::vector<uint32_t>& b, double d) {  // gibbs.hpp:769-792 + delta_sum.hpp:74-84
+        for (uint32_t r : b) {
+          uint32_t n = F->h_norm[r];
+          if (n == F_NONORM) continue;
+          hn[n] += d;
+          double moret = time - ht[r];
+          if (moret > 0) {
+            ht[r] = time;
+            hs[r] += moret * hx[r];
+          } else if (moret < 0)
+            hs[r] += d * (-moret);
+          hx[r] += d;
+        }
+      };
+      std::vector<uint32_t> buf(F->max_sample);
+      for (uint64_t f = 0; f < nf; ++f) {
+        addc(hsample[f], -1.0);
+        // push the (few) changed counts: upload only what the removal touched
+        for (uint32_t r : hsample[f]) {
+          uint32_t n = F->h_norm[r];
+          if (n == F_NONORM) continue;
+          HIPCHK(hipMemcpyAsync(F->p_x.p + r, &hx[r], sizeof(double), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(F->normsum.p + n, &hn[n], sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        const uint32_t slot = F->lane_of_forest[f];
+        A.serial_forest = slot;
+        const uint32_t gidx = slot / 64;
+        A.first_group = gidx;
+        const FGroup& G = F->h_groups[gidx];
+        size_t lds = (size_t)G.max_nodes * 64 * 8 + (size_t)(F->max_sample + 1) * 64 * 4 + (size_t)F->max_sample * 64 * 4;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample);
+        uint32_t len = 0;
+        HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + f, sizeof len, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (len) HIPCHK(hipMemcpyAsync(buf.data(), F->sample_rules[0].p + F->h_sample_off[f], len * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        hsample[f].assign(buf.begin(), buf.begin() + len);
+        for (uint32_t r : hsample[f]) {  // cheap prob before re-adding; cache model (gibbs.hpp:712-742)
+          uint32_t n = F->h_norm[r];
+          cheap_lp += std::log(n == F_NONORM ? prior[r] : hx[r] / hn[n]);
+          double q = prior[r];
+          if (n != F_NONORM) {
+            q = ccount[r] / csum[n];
+            ccount[r] += 1.0;
+            csum[n] += 1.0;
+          }
+          cache_lp += std::log(q);
+        }
+        addc(hsample[f], 1.0);
+        for (uint32_t r : hsample[f]) {
+          uint32_t n = F->h_norm[r];
+          if (n == F_NONORM) continue;
+          HIPCHK(hipMemcpyAsync(F->p_x.p + r, &hx[r], sizeof(double), hipMemcpyHostToDevice, s));
+          HIPCHK(hipMemcpyAsync(F->normsum.p + n, &hn[n], sizeof(double), hipMemcpyHostToDevice, s));
+        }
+        HIPCHK(hipStreamSynchronize(s));
+      }
+    }
+    if (iter_logprob) iter_logprob[iter] = cache_lp;
+    if (iter_cheap_logprob) iter_cheap_logprob[iter] = cheap_lp;
+  }
+  // finalize_cumulative_counts + from_gibbs
+  std::vector<double> x(nr), sacc(nr), tm(nr);
+  if (o->mode == 0) {
+    x = hx;
+    sacc = hs;
+    tm = ht;
+  } else {
+    HIPCHK(hipMemcpyAsync(x.data(), F->p_x.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(sacc.data(), F->p_s.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(tm.data(), F->p_tmax.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (cur != 0) {  // keep the final samples in buffer 0 for carmel_hip_forests_get_sample
+      std::swap(F->sample_len[0].p, F->sample_len[1].p);
+      std::swap(F->sample_rules[0].p, F->sample_rules[1].p);
+    }
+  }
+  if (!(o->final_counts && !o->exclude_prior)) {
+    const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
+    if (!o->final_counts)
+      for (uint32_t r = 0; r < nr; ++r)
+        if (F->h_norm[r] != F_NONORM) {
+          sacc[r] += x[r] * (tmax1 - tm[r]);
+          x[r] = sacc[r];
+        }
+  }
+  std::vector<double> ns(ng, 0.0);
+  for (uint32_t r = 0; r < nr; ++r)
+    if (F->h_norm[r] != F_NONORM) ns[F->h_norm[r]] += x[r];
+  for (uint32_t r = 0; r < nr; ++r) {
+    double pr = F->h_norm[r] == F_NONORM ? prior[r] : (x[r] > 0 ? x[r] / ns[F->h_norm[r]] : 0.0);
+    lw[r] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
+  }
+  return carmel_hip_forests_set_weights(F, lw.data());
+}
+
+int carmel_hip_forests_get_sample(carmel_hip_forests* F, uint64_t forest, uint32_t* rules, uint32_t* n) {
+  if (!F || !n || forest >= F->n_forests) return fail(CARMEL_HIP_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(F->device));
+  uint32_t len = 0;
+  HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + forest, sizeof len, hipMemcpyDeviceToHost, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  if (rules && len)
+    HIPCHK(hipMemcpyAsync(rules, F->sample_rules[0].p + F->h_sample_off[forest], len * 4, hipMemcpyDeviceToHost, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  *n = len;
+  return CARMEL_HIP_OK;
+}
+uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* F) { return F ? F->max_sample : 0; }
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+"""Python mirror of forest-em's FForests (forest-em/forest-em.hpp) over the C-ABI: EM_executor concept
+(estimate / maximize, graehl/shared/em.hpp:74-89) and run_gibbs."""
+import ctypes as C
+
+import numpy as np
+
+from ._capi import GibbsOpts, check, lib, ptr
+
+
+class HipForests(object):
+    def __init__(self, node_off, label, ref, nxt, n_rules, rule_logw, group_off, group_rule, device=0):
+        self.node_off = np.ascontiguousarray(node_off, dtype=np.uint64)
+        self.label = np.ascontiguousarray(label, dtype=np.uint32)
+        self.ref = np.ascontiguousarray(ref, dtype=np.int32)
+        self.next = np.ascontiguousarray(nxt, dtype=np.uint32)
+        self.group_off = np.ascontiguousarray(group_off, dtype=np.uint64)
+        self.group_rule = np.ascontiguousarray(group_rule, dtype=np.uint32)
+        self.n_rules = int(n_rules)
+        self.n_forests = len(self.node_off) - 1
+        lw = np.ascontiguousarray(rule_logw, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.carmel_hip_forests_create(C.byref(h), device, self.n_forests, ptr(self.node_off), ptr(self.label),
+                                            ptr(self.ref), ptr(self.next), self.n_rules, ptr(lw),
+                                            len(self.group_off) - 1, ptr(self.group_off), ptr(self.group_rule)),
+              "carmel_hip_forests_create")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.carmel_hip_forests_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def estimate(self, prior_count=0.0, per_forest=False):
+        avg, nz = C.c_double(0), C.c_uint64(0)
+        pf = np.zeros(self.n_forests) if per_forest else None
+        check(lib.carmel_hip_forests_estimate(self.h, prior_count, C.byref(avg), C.byref(nz), ptr(pf)),
+              "carmel_hip_forests_estimate")
+        self.per_forest_logprob, self.n_zero = pf, nz.value
+        return avg.value
+
+    def counts(self, prior_count=0.0):
+        c = np.zeros(self.n_rules)
+        check(lib.carmel_hip_forests_get_counts(self.h, prior_count, ptr(c)), "carmel_hip_forests_get_counts")
+        return c
+
+    def maximize(self, prior_count=0.0, add_k=0.0, zero_zerocounts=False):
+        d = C.c_double(0)
+        check(lib.carmel_hip_forests_maximize(self.h, prior_count, add_k, int(zero_zerocounts), C.byref(d)),
+              "carmel_hip_forests_maximize")
+        return d.value
+
+    def weights(self):
+        w = np.zeros(self.n_rules)
+        check(lib.carmel_hip_forests_get_weights(self.h, ptr(w)), "carmel_hip_forests_get_weights")
+        return w
+
+    def set_weights(self, lw):
+        lw = np.ascontiguousarray(lw, dtype=np.float64)
+        check(lib.carmel_hip_forests_set_weights(self.h, ptr(lw)), "carmel_hip_forests_set_weights")
+
+    def gibbs(self, iters, burnin=0, alpha=0.1, seed=1, mode=0, uniform_p0=False, final_counts=False):
+        o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01)
+        self.iter_logprob, self.iter_cheap_logprob = np.zeros(iters + 1), np.zeros(iters + 1)
+        check(lib.carmel_hip_forests_gibbs(self.h, C.byref(o), alpha, ptr(self.iter_logprob),
+                                           ptr(self.iter_cheap_logprob)), "carmel_hip_forests_gibbs")
+        return self.iter_logprob
+
+    def sample(self, forest):
+        buf = np.zeros(max(1, lib.carmel_hip_forests_max_sample(self.h)), np.uint32)
+        n = C.c_uint32(0)
+        check(lib.carmel_hip_forests_get_sample(self.h, forest, ptr(buf), C.byref(n)), "carmel_hip_forests_get_sample")
+        return buf[:n.value].tolist()

@@ -184,6 +184,36 @@ int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* i
 /* the uniform the sampler uses at (sweep, block, step of the walk): lets a checker replay the same choices */
 double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, uint32_t step);
 
+/* ---- forest-em: packed AND/OR derivation forests (forest-em/forest.hpp, forest-em.hpp) ----
+ * Forests arrive as the reference's own node arrays: forest f owns nodes [node_off[f], node_off[f+1]) in preorder;
+ * label = rule id (0 = OR), ref >= 0 marks a back-reference to an earlier node of the same forest (#k), next = one
+ * past the node's subtree (ForestNode::next as an index relative to the forest).  Rule ids are 1-based; n_rules =
+ * max id + 1.  Normalisation groups (`-n ((1 2 3) (5 8))`) as CSR over rule ids. */
+typedef struct carmel_hip_forests carmel_hip_forests;
+int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_forests, const uint64_t* node_off,
+                              const uint32_t* label, const int32_t* ref, const uint32_t* next, uint32_t n_rules,
+                              const double* rule_logw, uint64_t n_groups, const uint64_t* group_off,
+                              const uint32_t* group_rule);
+int carmel_hip_forests_destroy(carmel_hip_forests* f);
+/* Replaces FForests::estimate (forest-em.hpp:561-578): inside (forest.hpp:636-697), normalised outside (:439-491)
+ * and count[rule] += inside*norm_outside over AND nodes (:417-438) for every forest.  avg_logprob = mean ln
+ * inside[root] over forests with non-zero probability; n_zero = the others. */
+int carmel_hip_forests_estimate(carmel_hip_forests* f, double prior_count, double* avg_logprob, uint64_t* n_zero,
+                                double* per_forest_logprob);
+int carmel_hip_forests_get_counts(carmel_hip_forests* f, double prior_count, double* counts /* n_rules, linear */);
+/* Replaces FForests::maximize (forest-em.hpp:626-655) -> NormalizeGroups::operator() (normalize.hpp:123-164) */
+int carmel_hip_forests_maximize(carmel_hip_forests* f, double prior_count, double add_k, int zero_zerocounts,
+                                double* max_delta);
+int carmel_hip_forests_get_weights(carmel_hip_forests* f, double* rule_logw);
+int carmel_hip_forests_set_weights(carmel_hip_forests* f, const double* rule_logw);
+/* Replaces FForests::run_gibbs (forest-em.hpp:714-766) + gibbs_base::run (gibbs.hpp:803-877) + choose_random
+ * (forest.hpp:725-758).  alpha = --alpha (gibbs_opts.hpp:229).  Rule weights become the time-averaged
+ * probabilities (from_gibbs). */
+int carmel_hip_forests_gibbs(carmel_hip_forests* f, const carmel_hip_gibbs_opts* opts, double alpha,
+                             double* iter_logprob, double* iter_cheap_logprob);
+int carmel_hip_forests_get_sample(carmel_hip_forests* f, uint64_t forest, uint32_t* rules, uint32_t* n);
+uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* f);
+
 /* ---- host-only inspection (no GPU needed): the lattice image carmel_hip_build_lattices uploads ----
  * Used by the CPU test-suite to check lattice construction and layout against the oracle. */
 typedef struct carmel_hip_host_lattices carmel_hip_host_lattices;

@@ -300,4 +300,71 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     return dict(iter_logprob=ilp, iter_cheap_logprob=icl, param_logw=plw, samples=samples)
 
 
+lib.orc_forests_parse.restype = vp
+lib.orc_forests_parse.argtypes = [C.c_char_p, C.c_char_p]
+lib.orc_forests_free.argtypes = [vp]
+lib.orc_forests_dims.argtypes = [vp, vp]
+lib.orc_forests_export.argtypes = [vp] * 7
+lib.orc_forests_set_weights.argtypes = [vp, vp]
+lib.orc_forests_get_weights.argtypes = [vp, vp]
+lib.orc_forests_estimate.restype = C.c_double
+lib.orc_forests_estimate.argtypes = [vp, C.c_double, vp, vp]
+lib.orc_forests_maximize.restype = C.c_double
+lib.orc_forests_maximize.argtypes = [vp, C.c_double, C.c_int]
+lib.orc_forests_gibbs.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double, UNIFORM_FN, vp, vp, vp, vp,
+                                  C.c_uint64]
+
+
+class OracleForests(object):
+    """forest-em inputs (-f forests, -n normgroups) parsed and restated by the oracle"""
+
+    def __init__(self, forests_text, normgroups_text):
+        self.h = lib.orc_forests_parse(forests_text.encode(), normgroups_text.encode())
+        if not self.h:
+            raise ValueError("oracle: " + lib.orc_last_error().decode())
+        d = np.zeros(5, np.uint64)
+        lib.orc_forests_dims(self.h, _p(d))
+        self.n_forests, self.n_nodes, self.n_rules, self.n_groups, ne = (int(x) for x in d)
+        self.node_off = np.zeros(self.n_forests + 1, np.uint64)
+        self.label, self.next = np.zeros(self.n_nodes, np.uint32), np.zeros(self.n_nodes, np.uint32)
+        self.ref = np.zeros(self.n_nodes, np.int32)
+        self.group_off = np.zeros(self.n_groups + 1, np.uint64)
+        self.group_rule = np.zeros(max(ne, 1), np.uint32)
+        lib.orc_forests_export(self.h, _p(self.node_off), _p(self.label), _p(self.ref), _p(self.next),
+                               _p(self.group_off), _p(self.group_rule))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.orc_forests_free(self.h)
+            self.h = None
+
+    def set_weights(self, lw):
+        lw = np.ascontiguousarray(lw, dtype=np.float64)
+        assert len(lw) == self.n_rules
+        lib.orc_forests_set_weights(self.h, _p(lw))
+
+    def weights(self):
+        lw = np.zeros(self.n_rules)
+        lib.orc_forests_get_weights(self.h, _p(lw))
+        return lw
+
+    def estimate(self, prior_count=0.0):
+        c, pf = np.zeros(self.n_rules), np.zeros(self.n_forests)
+        avg = lib.orc_forests_estimate(self.h, prior_count, _p(c), _p(pf))
+        return avg, c, pf
+
+    def maximize(self, add_k=0.0, zero_zerocounts=False):
+        return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
+
+    def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22):
+        ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)
+        samp = np.zeros(max_samples, np.uint32)
+        off = np.zeros(self.n_forests + 1, np.uint64)
+        cb = UNIFORM_FN(uniform)
+        _chk(lib.orc_forests_gibbs(self.h, iters, burnin, int(uniform_p0), int(final_counts), alpha, cb, _p(ilp), _p(icl),
+                                   _p(samp), _p(off), max_samples))
+        samples = [samp[int(off[b]):int(off[b + 1])].tolist() for b in range(self.n_forests)]
+        return dict(iter_logprob=ilp, iter_cheap_logprob=icl, samples=samples)
+
+
 CLI = os.path.join(_HERE, "oracle_carmel")

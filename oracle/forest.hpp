@@ -1,0 +1,428 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see lw.hpp header).
+//
+// forest.hpp: restatement of forest-em's packed AND/OR derivation forests: text reader, inside, normalised
+// outside, expected rule counts, EM over normalisation groups, and the Gibbs sampler glue.
+// Follows /root/reference/forest-em and graehl/shared:
+//   forest.hpp:60-76      ForestNode: preorder array, `next` = one past the subtree, label = rule id (0 = OR) or a
+//                         pointer to a shared sub-forest defined earlier (#k(...) defines, #k refers)
+//   forest.hpp:925-1034   text reader
+//   forest.hpp:636-697    inside_rec (AND = rule weight x children, OR = sum of children, back-reference copies;
+//                         records (parent, child) ancestry pairs in visit order)
+//   forest.hpp:439-491    compute_norm_outside (walks the ancestry list backwards)
+//   forest.hpp:417-438    visit_inside_norm_outside: count[rule] += inside * norm_outside for every AND node
+//   forest.hpp:725-758    choose_random (OR: choice = random01(), subtract inside^power / norm; AND: record the
+//                         rule, recurse into every child; a back-reference recurses with power 1 — kept)
+//   forest.hpp:768-816    compute_inside(W): inside with proposal probabilities
+//   forest-em.hpp:446-458, 511-578, 626-655   EM: counts start at prior_count * n_forests, avg log prob, maximize
+//   forest-em.hpp:694-766 Gibbs glue: parameters = rules, prior = alpha * p * |group| (normalised p), fixed if no group
+//   normalize.hpp:123-164, 245-260  w = count / (sum + add_k); zero group -> uniform (default) or zero
+//   em.hpp:107-216        overrelaxed_em loop (relative change of the average log prob < epsilon)
+// The reference computes in `float` unless --double-precision (forest-em-params.cpp:13-18); this restatement is
+// the double-precision instantiation.  Its count "overflow" side table (forest.hpp:360-407) only matters for
+// float and is not restated.  PARITY UNPINNED: the reference ships forest inputs but no expected outputs
+// (SURVEY.md section 8c), so this oracle is pinned only by hand-derived cases in tests/test_forest_oracle.py.
+#pragma once
+#include "gibbs.hpp"
+#include "lw.hpp"
+#include <cctype>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace oracle {
+
+struct FNode {
+  unsigned label;  // 0 = OR, > 0 = rule id (AND); meaningless for a back-reference
+  int ref;         // >= 0: index of the shared node this refers to
+  unsigned next;   // one past the last node of the subtree
+};
+
+struct Forest {
+  std::vector<FNode> nodes;
+  unsigned max_rule = 0;
+
+  // forest.hpp:925-1034
+  static bool parse(const std::string& s, size_t& p, Forest& f) {
+    f.nodes.clear();
+    std::vector<unsigned> open;
+    std::vector<int> backrefs;
+    bool follows_paren = false;
+    auto skipws = [&]() {
+      while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
+    };
+    skipws();
+    if (p >= s.size()) return false;
+    for (;;) {
+      skipws();
+      if (p >= s.size()) throw std::runtime_error("forest: unexpected end of input");
+      char c = s[p++];
+      if (c == '#') {
+        if (follows_paren) throw std::runtime_error("Unexpected '#' following paren in Forest");
+        size_t e = p;
+        while (e < s.size() && std::isdigit((unsigned char)s[e])) ++e;
+        unsigned id = (unsigned)std::stoul(s.substr(p, e - p));
+        p = e;
+        char d = p < s.size() ? s[p] : '\0';
+        if (d == '(') {
+          ++p;
+          if (backrefs.size() <= id) backrefs.resize(id + 1, -1);
+          backrefs[id] = (int)f.nodes.size();
+          follows_paren = true;
+          open.push_back((unsigned)f.nodes.size());
+        } else {
+          if (id >= backrefs.size() || backrefs[id] < 0) throw std::runtime_error("forest: undefined back-reference");
+          FNode n;
+          n.label = 0;
+          n.ref = backrefs[id];
+          n.next = (unsigned)f.nodes.size() + 1;
+          f.nodes.push_back(n);
+          if (open.empty()) break;
+        }
+      } else if (c == '(') {
+        follows_paren = true;
+        open.push_back((unsigned)f.nodes.size());
+      } else if (c >= '1' && c <= '9') {
+        size_t e = p;
+        while (e < s.size() && std::isdigit((unsigned char)s[e])) ++e;
+        unsigned rule = (unsigned)std::stoul(s.substr(p - 1, e - p + 1));
+        p = e;
+        if (rule > f.max_rule) f.max_rule = rule;
+        FNode n;
+        n.label = rule;
+        n.ref = -1;
+        n.next = (unsigned)f.nodes.size() + 1;
+        f.nodes.push_back(n);
+        if (!follows_paren) {
+          if (open.empty()) break;
+        } else
+          follows_paren = false;
+      } else if (c == 'O') {
+        if (p >= s.size() || s[p] != 'R') throw std::runtime_error("forest: expected OR");
+        ++p;
+        if (!follows_paren) throw std::runtime_error("OR not following paren in Forest");
+        follows_paren = false;
+        FNode n;
+        n.label = 0;
+        n.ref = -1;
+        n.next = (unsigned)f.nodes.size() + 1;
+        f.nodes.push_back(n);
+      } else if (c == ')') {
+        if (open.empty()) throw std::runtime_error("forest: unbalanced ')'");
+        if (open.back() != f.nodes.size()) f.nodes[open.back()].next = (unsigned)f.nodes.size();
+        open.pop_back();
+        if (open.empty()) break;
+      } else
+        throw std::runtime_error(std::string("Forest: unexpected char ") + c);
+    }
+    return true;
+  }
+
+  struct Anc {
+    int parent, child;
+  };
+
+  // inside with weight functor w(rule) -> LW; fills `anc` like inside_rec does
+  void inside_rec(unsigned b, const std::function<LW(unsigned)>& w, std::vector<LW>& ins, std::vector<Anc>* anc) const {
+    const FNode& n = nodes[b];
+    unsigned e = n.next;
+    if (n.ref >= 0) {
+      ins[b] = ins[n.ref];
+      return;
+    }
+    if (n.label == 0) {
+      unsigned c = b + 1;
+      unsigned nx = nodes[c].next;
+      inside_rec(c, w, ins, anc);
+      ins[b] = ins[c];
+      for (c = nx; c < e; c = nx) {
+        nx = nodes[c].next;
+        inside_rec(c, w, ins, anc);
+        ins[b] += ins[c];
+      }
+    } else {
+      ins[b] = w(n.label);
+      unsigned nx;
+      for (unsigned c = b + 1; c < e; c = nx) {
+        nx = nodes[c].next;
+        inside_rec(c, w, ins, anc);
+        mul_eq(ins[b], ins[c]);
+      }
+    }
+    if (anc)
+      for (unsigned c = b + 1; c < e; c = nodes[c].next) anc->push_back(Anc{(int)b, nodes[c].ref >= 0 ? nodes[c].ref : (int)c});
+  }
+
+  // forest.hpp:439-491
+  bool norm_outside(const std::vector<LW>& ins, const std::vector<Anc>& anc, std::vector<LW>& out) const {
+    out.assign(nodes.size(), LW());
+    if (!(ins[0] > LW())) return false;
+    out[0] = LW::from_ln(-ins[0].w);
+    for (size_t i = anc.size(); i-- > 0;) {
+      int p = anc[i].parent, c = anc[i].child;
+      if (nodes[p].label == 0)
+        out[c] += out[p];
+      else if (!ins[p].isZero())
+        out[c] += out[p] * ins[p] / ins[c];
+    }
+    return true;
+  }
+
+  // forest.hpp:725-758; u() = random01(); record(rule)
+  void choose_random(unsigned b, const std::vector<LW>& ins, const std::function<double()>& u,
+                     const std::function<void(unsigned)>& record, double power) const {
+    const FNode& n = nodes[b];
+    unsigned e = n.next;
+    if (n.ref >= 0) {
+      choose_random((unsigned)n.ref, ins, u, record, 1.0);  // the reference drops `power` here
+      return;
+    }
+    if (n.label == 0) {
+      LW norm;
+      for (unsigned i = b + 1; i != e; i = nodes[i].next) norm += ins[i].pow(power);
+      unsigned i = b + 1;
+      double choice = u();
+      for (;;) {
+        choice -= (ins[i].pow(power) / norm).getReal();
+        if (choice < 0) break;
+        unsigned nx = nodes[i].next;
+        if (nx == e) break;
+        i = nx;
+      }
+      choose_random(i, ins, u, record, power);
+    } else {
+      record(n.label);
+      for (unsigned c = b + 1; c < e; c = nodes[c].next) choose_random(c, ins, u, record, power);
+    }
+  }
+};
+
+typedef std::vector<std::vector<unsigned> > NormGroups;  // ((1 2 3) (5 8))
+
+inline NormGroups parse_normgroups(const std::string& s) {
+  NormGroups g;
+  size_t p = 0;
+  int depth = 0;
+  while (p < s.size()) {
+    char c = s[p];
+    if (c == '(') {
+      ++depth;
+      if (depth == 2) g.emplace_back();
+      ++p;
+    } else if (c == ')') {
+      --depth;
+      ++p;
+    } else if (std::isdigit((unsigned char)c)) {
+      size_t e = p;
+      while (e < s.size() && std::isdigit((unsigned char)s[e])) ++e;
+      if (depth == 2) g.back().push_back((unsigned)std::stoul(s.substr(p, e - p)));
+      p = e;
+    } else
+      ++p;
+  }
+  return g;
+}
+
+inline std::vector<Forest> parse_forests(const std::string& s) {
+  std::vector<Forest> fs;
+  size_t p = 0;
+  for (;;) {
+    Forest f;
+    if (!Forest::parse(s, p, f)) break;
+    fs.push_back(f);
+  }
+  return fs;
+}
+
+// rule weights are indexed by rule id (1-based); index 0 unused
+struct ForestEm {
+  std::vector<Forest> forests;
+  NormGroups groups;
+  std::vector<LW> w;       // rule_weights
+  std::vector<LW> counts;
+  double prior_count = 0;  // --prior-counts
+  double add_k = 0;        // --add-k-smoothing
+  bool zero_zerocounts = false;
+
+  void init(unsigned rulespace, const std::vector<double>* init_ln = 0) {
+    w.assign(rulespace, LW::one());
+    if (init_ln)
+      for (size_t i = 0; i < init_ln->size() && i < w.size(); ++i) w[i] = LW::from_ln((*init_ln)[i]);
+    counts.assign(rulespace, LW());
+  }
+  // normalize.hpp:123-164 (source = counts or weights, dest = weights); returns max |delta|
+  LW normalize_groups(std::vector<LW>& src) {
+    LW maxdiff;
+    for (auto& g : groups) {
+      LW sum;
+      for (unsigned r : g) sum += src[r];
+      if (sum > LW()) {
+        sum += LW::from_real(add_k);
+        for (unsigned r : g) {
+          LW prev = w[r];
+          w[r] = src[r] / sum;
+          LW d = absdiff(w[r], prev);
+          if (maxdiff < d) maxdiff = d;
+        }
+      } else {
+        LW setto = zero_zerocounts ? LW() : LW::from_real(1.0 / (double)g.size());
+        for (unsigned r : g) {
+          LW d = absdiff(w[r], setto);
+          if (maxdiff < d) maxdiff = d;
+          w[r] = setto;
+        }
+      }
+    }
+    return maxdiff;
+  }
+  // forest-em.hpp:561-578: returns the average log prob over forests with non-zero probability
+  double estimate(std::vector<double>* per_forest = 0) {
+    LW wp = LW::from_real(prior_count * (double)forests.size());
+    for (auto& c : counts) c = wp;
+    double total = 0;
+    size_t nz = 0;
+    for (auto& f : forests) {
+      std::vector<LW> ins(f.nodes.size()), out;
+      std::vector<Forest::Anc> anc;
+      f.inside_rec(0, [&](unsigned r) { return w[r]; }, ins, &anc);
+      if (f.norm_outside(ins, anc, out))
+        for (size_t i = 0; i < f.nodes.size(); ++i)
+          if (f.nodes[i].ref < 0 && f.nodes[i].label != 0) counts[f.nodes[i].label] += ins[i] * out[i];
+      if (per_forest) per_forest->push_back(ins[0].w);
+      if (ins[0].isZero())
+        ++nz;
+      else
+        total += ins[0].w;
+    }
+    return total / (double)(forests.size() - nz);
+  }
+  LW maximize() { return normalize_groups(counts); }
+
+  // em.hpp:107-216 (one start, learning rate 1).  Returns best average log prob; trace = per-iteration values.
+  double run_em(unsigned max_iter, double rel_eps, double converge_param_delta, std::vector<double>* trace = 0) {
+    double best = -HUGE_VAL, last = -HUGE_VAL;
+    std::vector<LW> best_w = w;
+    bool first = true;
+    for (unsigned it = 1; it <= max_iter; ++it) {
+      double alp = estimate();
+      if (trace) trace->push_back(alp);
+      if (alp > best || first) {
+        best = alp;
+        best_w = w;
+      }
+      double rel = HUGE_VAL;
+      if (!first) {
+        double la = std::fabs(last);
+        if (la < 1e-5) la = 1e-5;  // LOGPROB_EPSILON
+        rel = (alp - last) / la;
+      }
+      first = false;
+      if (rel < rel_eps) break;
+      LW d = maximize();
+      if (d.getReal() <= converge_param_delta) break;
+      last = alp;
+    }
+    w = best_w;
+    return best;
+  }
+};
+
+// forest-em's Gibbs (forest-em.hpp:694-766) on top of the gibbs_base restatement in gibbs.hpp
+struct ForestGibbs {
+  ForestEm& fe;
+  GibbsOpts gopt;
+  double alpha;
+  std::vector<GibbsParam> gps;  // indexed by rule id
+  std::vector<double> normsum;
+  std::vector<std::vector<unsigned> > sample;
+  double time = 0;
+
+  ForestGibbs(ForestEm& fe, const GibbsOpts& g, double alpha) : fe(fe), gopt(g), alpha(alpha) {
+    fe.normalize_groups(fe.w);  // define_gibbs(true): normalize() first
+    gps.assign(fe.w.size(), GibbsParam());
+    for (size_t r = 0; r < gps.size(); ++r) {  // rules outside every group keep their weight (fixed probability)
+      gps[r].norm = GibbsParam::NONORM;
+      gps[r].prior = fe.w[r].getReal();
+    }
+    for (size_t gi = 0; gi < fe.groups.size(); ++gi)
+      for (unsigned r : fe.groups[gi]) {
+        gps[r].norm = (unsigned)gi;
+        double p = fe.w[r].getReal(), N = (double)fe.groups[gi].size();
+        gps[r].prior = gopt.uniformp0 ? alpha : alpha * p * N;  // gibbs.hpp:589-592
+      }
+    sample.assign(fe.forests.size(), {});
+  }
+  double proposal_prob(unsigned r) const {
+    const GibbsParam& g = gps[r];
+    return g.has_norm() ? g.sum.x / normsum[g.norm] : g.prior;
+  }
+  void addc(const std::vector<unsigned>& b, double d) {
+    for (unsigned r : b) {
+      GibbsParam& g = gps[r];
+      if (g.has_norm()) {
+        normsum[g.norm] += d;
+        g.sum.add_delta(d, time);
+      }
+    }
+  }
+  void run(const std::function<double(unsigned, unsigned, unsigned)>& u, GibbsTrace* tr = 0) {
+    normsum.assign(fe.groups.size(), 0.0);
+    for (auto& g : gps)
+      if (g.has_norm()) {
+        normsum[g.norm] += g.prior;
+        g.sum.clear(g.prior);
+      }
+    for (auto& s : sample) s.clear();
+    const unsigned Ni = gopt.iter;
+    for (unsigned iter = 0; iter <= Ni; ++iter) {
+      time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)gopt.burnin);
+      LW p = LW::one(), pc = LW::one();
+      std::vector<double> ccount(gps.size(), 0.0), csum(fe.groups.size(), 0.0);
+      for (size_t i = 0; i < gps.size(); ++i)
+        if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
+      for (unsigned b = 0; b < fe.forests.size(); ++b) {
+        const Forest& f = fe.forests[b];
+        addc(sample[b], -1.0);  // block_weight = 1 (gibbs.hpp:829-832)
+        sample[b].clear();
+        std::vector<LW> ins(f.nodes.size());
+        f.inside_rec(0, [&](unsigned r) { return LW::from_real(proposal_prob(r)); }, ins, 0);
+        unsigned step = 0;
+        f.choose_random(0, ins, [&]() { return u(iter, b, step++); }, [&](unsigned r) { sample[b].push_back(r); }, 1.0);
+        LW bp = LW::one(), bc = LW::one();
+        for (unsigned r : sample[b]) mul_eq(bp, LW::from_real(proposal_prob(r)));
+        for (unsigned r : sample[b]) {
+          const GibbsParam& g = gps[r];
+          double q = g.has_norm() ? (ccount[r]++ / csum[g.norm]++) : g.prior;
+          mul_eq(bc, LW::from_real(q));
+        }
+        mul_eq(p, bp);
+        mul_eq(pc, bc);
+        addc(sample[b], 1.0);
+      }
+      if (tr) {
+        tr->iter_logprob.push_back(pc.w);
+        tr->iter_cheap_logprob.push_back(p.w);
+      }
+    }
+    if (tr) tr->last_sample = sample;
+    if (!(gopt.final_counts && !gopt.exclude_prior)) {
+      double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;
+      if (!gopt.final_counts)
+        for (auto& g : gps)
+          if (g.has_norm()) {
+            g.sum.extend(tmax1);
+            g.sum.x = g.sum.s;
+          }
+      normsum.assign(fe.groups.size(), 0.0);
+      for (auto& g : gps)
+        if (g.has_norm()) normsum[g.norm] += g.sum.x;
+    }
+    for (size_t r = 0; r < gps.size(); ++r) {  // from_gibbs forest-em.hpp:736-742
+      const GibbsParam& g = gps[r];
+      double pr = g.has_norm() ? (g.sum.x > 0 ? g.sum.x / normsum[g.norm] : 0.0) : g.prior;
+      fe.w[r] = LW::from_real(pr);
+    }
+  }
+};
+
+}  // namespace oracle

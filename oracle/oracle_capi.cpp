@@ -6,6 +6,7 @@
 // (derivations.h:86-101, fst.h:1331-1334).
 #include "train.hpp"
 #include "gibbs.hpp"
+#include "forest.hpp"
 #include <pthread.h>
 #include <functional>
 #include <cstdint>
@@ -666,6 +667,112 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
         for (unsigned pid : tr.last_sample[b]) {
           if (o >= max_samples) throw std::runtime_error("sample buffer too small");
           out_samples[o++] = arc_index[pid];
+        }
+      }
+      out_sample_off[tr.last_sample.size()] = o;
+    }
+  });
+}
+
+// ---- forest-em ----
+struct orc_forests {
+  ForestEm fe;
+};
+orc_forests* orc_forests_parse(const char* forests_text, const char* normgroups_text) {
+  orc_forests* h = new orc_forests();
+  try {
+    h->fe.forests = parse_forests(forests_text);
+    h->fe.groups = parse_normgroups(normgroups_text);
+    unsigned mx = 0;
+    for (auto& f : h->fe.forests) mx = std::max(mx, f.max_rule);
+    for (auto& g : h->fe.groups)
+      for (unsigned r : g) mx = std::max(mx, r);
+    h->fe.init(mx + 1);
+  } catch (std::exception& e) {
+    g_err = e.what();
+    delete h;
+    return 0;
+  }
+  return h;
+}
+void orc_forests_free(orc_forests* h) { delete h; }
+// dims: n_forests, total_nodes, rulespace, n_groups, n_group_entries
+void orc_forests_dims(orc_forests* h, uint64_t* dims) {
+  dims[0] = h->fe.forests.size();
+  uint64_t n = 0;
+  for (auto& f : h->fe.forests) n += f.nodes.size();
+  dims[1] = n;
+  dims[2] = h->fe.w.size();
+  dims[3] = h->fe.groups.size();
+  uint64_t e = 0;
+  for (auto& g : h->fe.groups) e += g.size();
+  dims[4] = e;
+}
+void orc_forests_export(orc_forests* h, uint64_t* node_off, uint32_t* label, int32_t* ref, uint32_t* next,
+                        uint64_t* group_off, uint32_t* group_rule) {
+  uint64_t k = 0, fi = 0;
+  for (auto& f : h->fe.forests) {
+    node_off[fi++] = k;
+    for (auto& n : f.nodes) {
+      label[k] = n.label;
+      ref[k] = n.ref;
+      next[k] = n.next;
+      ++k;
+    }
+  }
+  node_off[fi] = k;
+  uint64_t e = 0, gi = 0;
+  for (auto& g : h->fe.groups) {
+    group_off[gi++] = e;
+    for (unsigned r : g) group_rule[e++] = r;
+  }
+  group_off[gi] = e;
+}
+void orc_forests_set_weights(orc_forests* h, const double* lw) {
+  for (size_t i = 0; i < h->fe.w.size(); ++i) h->fe.w[i] = LW::from_ln(lw[i]);
+}
+void orc_forests_get_weights(orc_forests* h, double* lw) {
+  for (size_t i = 0; i < h->fe.w.size(); ++i) lw[i] = h->fe.w[i].w;
+}
+double orc_forests_estimate(orc_forests* h, double prior_count, double* counts_ln, double* per_forest) {
+  h->fe.prior_count = prior_count;
+  std::vector<double> pf;
+  double a = h->fe.estimate(&pf);
+  if (counts_ln)
+    for (size_t i = 0; i < h->fe.counts.size(); ++i) counts_ln[i] = h->fe.counts[i].w;
+  if (per_forest)
+    for (size_t i = 0; i < pf.size(); ++i) per_forest[i] = pf[i];
+  return a;
+}
+double orc_forests_maximize(orc_forests* h, double add_k, int zero_zero) {
+  h->fe.add_k = add_k;
+  h->fe.zero_zerocounts = zero_zero != 0;
+  return h->fe.maximize().getReal();
+}
+int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int uniform_p0, int final_counts, double alpha,
+                      orc_uniform_fn u, double* iter_logprob, double* iter_cheap_logprob, uint32_t* out_samples,
+                      uint64_t* out_sample_off, uint64_t max_samples) {
+  return run_big_stack([&]() {
+    GibbsOpts go;
+    go.iter = iter;
+    go.burnin = burnin < iter ? burnin : iter;
+    go.uniformp0 = uniform_p0 != 0;
+    go.final_counts = final_counts != 0;
+    if (go.final_counts) go.burnin = go.iter;
+    ForestGibbs g(h->fe, go, alpha);
+    GibbsTrace tr;
+    g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
+    for (uint32_t i = 0; i <= iter; ++i) {
+      if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
+      if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];
+    }
+    if (out_sample_off) {
+      uint64_t o = 0;
+      for (size_t b = 0; b < tr.last_sample.size(); ++b) {
+        out_sample_off[b] = o;
+        for (unsigned r : tr.last_sample[b]) {
+          if (o >= max_samples) throw std::runtime_error("sample buffer too small");
+          out_samples[o++] = r;
         }
       }
       out_sample_off[tr.last_sample.size()] = o;

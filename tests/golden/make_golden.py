@@ -30,6 +30,7 @@ FIXTURES = [
     ("sample/chain.2", "chain.2"),
     ("sample/chain.corpus", "chain.corpus"),
 ]
+FOREST_FIXTURES = [("sample/forests", "fem.forests"), ("sample/norm", "fem.norm"), ("sample/forest", "fem.forest")]
 
 ITER = re.compile(
     r"i=(\d+) \(rate=([^)]*)\): probability=2\^(\S+) per-output-symbol-perplexity\(N=(\d+)\)=2\^(\S+) "
@@ -55,6 +56,8 @@ def parse_iters(lines):
 def main():
     for src, dst in FIXTURES:
         shutil.copyfile(os.path.join(REF, src), os.path.join(HERE, dst))
+    for src, dst in FOREST_FIXTURES:
+        shutil.copyfile(os.path.join(REF, "..", "forest-em", src), os.path.join(HERE, dst))
     tr = open(os.path.join(TUT, "commands.trace"), errors="replace").read().split("\n")
     # line ranges (1-based) cited in SURVEY.md section 8c
     gold = {

@@ -1,0 +1,120 @@
+"""GPU: forest-em kernels (inside / outside / counts / M-step / Gibbs) through the C-ABI against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_forests(n_forests, n_rules, seed, depth=3):
+    """random AND/OR forests in the reference's text syntax, with shared sub-forests"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_forests):
+        nid = [0]
+        defined = []
+
+        def gen(d, top=False):
+            r = rng.random()
+            if not top and defined and r < 0.15:
+                return "#%d" % rng.choice(defined)
+            if d == 0 or (not top and r < 0.3):
+                return str(rng.integers(1, n_rules))
+            if r < 0.6 or top:
+                kids = " ".join(gen(d - 1) for _ in range(rng.integers(2, 4)))
+                body = "(OR %s)" % kids
+            else:
+                kids = " ".join(gen(d - 1) for _ in range(rng.integers(1, 3)))
+                body = "(%d %s)" % (rng.integers(1, n_rules), kids)
+            if not top and rng.random() < 0.3:
+                nid[0] += 1
+                defined.append(nid[0])
+                return "#%d%s" % (nid[0], body)
+            return body
+        out.append(gen(depth, top=True))
+    groups, rules = [], list(range(1, n_rules))
+    rng.shuffle(rules)
+    i = 0
+    while i < len(rules) - 2:  # the last two rules stay outside every group
+        k = int(rng.integers(2, 6))
+        groups.append(rules[i:i + k])
+        i += k
+    norm = "(" + " ".join("(" + " ".join(str(r) for r in g) + ")" for g in groups if g) + ")"
+    return "\n".join(out) + "\n", norm
+
+
+def make(oracle, ftext, ntext, seed=0):
+    from carmel_amd.forests import HipForests
+    of = oracle.OracleForests(ftext, ntext)
+    rng = np.random.default_rng(seed)
+    lw = np.log(rng.uniform(0.05, 1.0, of.n_rules))
+    of.set_weights(lw)
+    hf = HipForests(of.node_off, of.label, of.ref, of.next, of.n_rules, lw, of.group_off, of.group_rule)
+    return of, hf
+
+
+@pytest.mark.parametrize("n_forests,seed", [(5, 1), (200, 2), (1000, 3)])
+def test_forest_em_matches_oracle(oracle, n_forests, seed):
+    ftext, ntext = synth_forests(n_forests, 40, seed)
+    of, hf = make(oracle, ftext, ntext, seed)
+    for it in range(4):
+        avg = hf.estimate(prior_count=0.01, per_forest=True)
+        oavg, ocounts_ln, opf = of.estimate(prior_count=0.01)
+        assert avg == pytest.approx(oavg, rel=1e-10)
+        np.testing.assert_allclose(hf.per_forest_logprob, opf, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(hf.counts(prior_count=0.01)[1:], np.exp(ocounts_ln)[1:], rtol=1e-8, atol=1e-12)
+        d = hf.maximize(prior_count=0.01)
+        od = of.maximize()
+        assert d == pytest.approx(od, rel=1e-8, abs=1e-12)
+        gw, ow = hf.weights(), of.weights()
+        fin = np.isfinite(ow)
+        assert np.array_equal(fin, np.isfinite(gw))
+        np.testing.assert_allclose(gw[fin], ow[fin], rtol=1e-8, atol=1e-12)
+    hf.close()
+
+
+def test_reference_sample_file(oracle, golden_dir):
+    of, hf = make(oracle, open(os.path.join(golden_dir, "fem.forests")).read(),
+                  open(os.path.join(golden_dir, "fem.norm")).read())
+    avg = hf.estimate(per_forest=True)
+    oavg, ocounts_ln, opf = of.estimate()
+    np.testing.assert_allclose(hf.per_forest_logprob, opf, rtol=1e-12)
+    np.testing.assert_allclose(hf.counts()[1:], np.exp(ocounts_ln)[1:], rtol=1e-10, atol=1e-300)
+    hf.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(burnin=4), dict(uniform_p0=True), dict(final_counts=True)])
+def test_forest_gibbs_exact_chain(oracle, kw):
+    """forests strictly in order with injected uniforms: same samples, same probabilities as the oracle's
+    restatement of FForests::run_gibbs / choose_random"""
+    from carmel_amd._capi import lib
+    ftext, ntext = synth_forests(30, 25, 11)
+    of, hf = make(oracle, ftext, ntext, 11)
+    iters = 10
+    hf.gibbs(iters, alpha=0.3, seed=9, mode=0, **kw)
+    ref = of.gibbs(lambda i, b, s: lib.carmel_hip_gibbs_uniform(9, i, b, s), iters, alpha=0.3, **kw)
+    for b in range(hf.n_forests):
+        assert hf.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(hf.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(hf.weights()), np.exp(of.weights()), rtol=1e-9, atol=1e-15)
+    hf.close()
+
+
+def test_forest_gibbs_parallel_mode(oracle):
+    """stale-count parallel sweep: valid derivations, reproducible, and the same probability region as the exact chain"""
+    ftext, ntext = synth_forests(400, 40, 5)
+    res = {}
+    for mode in (0, 1):
+        of, hf = make(oracle, ftext, ntext, 5)
+        hf.gibbs(30, burnin=10, alpha=0.3, seed=2, mode=mode)
+        res[mode] = (hf.iter_cheap_logprob.copy(), [hf.sample(b) for b in range(10)], hf.weights().copy())
+        hf.close()
+    of, hf = make(oracle, ftext, ntext, 5)
+    hf.gibbs(30, burnin=10, alpha=0.3, seed=2, mode=1)
+    assert [hf.sample(b) for b in range(10)] == res[1][1]
+    hf.close()
+    assert all(len(s) > 0 for s in res[1][1])
+    t0, t1 = res[0][0][-10:].mean(), res[1][0][-10:].mean()
+    assert abs(t1 - t0) < 0.05 * abs(t0)

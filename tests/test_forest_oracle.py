@@ -1,0 +1,126 @@
+"""CPU: the forest-em oracle (oracle/forest.hpp) pinned by brute force.  The reference ships forest inputs but no
+expected outputs, so inside probabilities and expected rule counts are checked against an
+independent exhaustive enumeration of every derivation, on the reference's own unit-test forest strings
+(forest-em/forest.hpp:1041-1043) and on forest-em/sample/forests."""
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+REF_TEST_FORESTS = ["1", "#1(1 #1 (2 #1 (1 1)))", "(1 4)", "(OR (1 4) (1 3))", "(OR (1 4 4) (2 3 4) (2 4 3) (1 5))",
+                    "(OR (1 #1(4) #1) (2 #2(3) #1) (2 #1 #2) (1 5))"]
+
+
+def parse_tree(s):
+    """independent little parser: returns nested ('OR'|rule, [children]) with back-references expanded"""
+    toks = re.findall(r"#\d+\(|#\d+|\(|\)|OR|\d+", s)
+    pos = [0]
+    defs = {}
+
+    def node():
+        t = toks[pos[0]]
+        pos[0] += 1
+        m = re.match(r"#(\d+)(\()?$", t)
+        if m and not m.group(2):
+            return defs[int(m.group(1))]
+        if m or t == "(":
+            label = toks[pos[0]]
+            pos[0] += 1
+            kids = []
+            n = [label if label == "OR" else int(label), kids]
+            if m:
+                defs[int(m.group(1))] = n
+            while toks[pos[0]] != ")":
+                kids.append(node())
+            pos[0] += 1
+            return n
+        return [int(t), []]
+    return node()
+
+
+def derivations(n):
+    """all derivations as lists of rule ids"""
+    label, kids = n
+    if label == "OR":
+        out = []
+        for k in kids:
+            out.extend(derivations(k))
+        return out
+    out = [[label]]
+    for k in kids:
+        out = [a + b for a in out for b in derivations(k)]
+    return out
+
+
+def brute(forest_text, w):
+    ds = derivations(parse_tree(forest_text))
+    ps = [math.prod(w[r] for r in d) for d in ds]
+    z = sum(ps)
+    counts = np.zeros(len(w))
+    for d, p in zip(ds, ps):
+        for r in d:
+            counts[r] += p / z
+    return z, counts
+
+
+@pytest.mark.parametrize("text", REF_TEST_FORESTS[2:] + ["(OR #1(OR 1 1) #1 (2 3) (3 3))"])
+def test_inside_and_counts_match_exhaustive_enumeration(oracle, text):
+    rng = np.random.default_rng(len(text))
+    f = oracle.OracleForests(text, "()")
+    w = rng.uniform(0.1, 0.9, f.n_rules)
+    f.set_weights(np.log(w))
+    avg, counts_ln, pf = f.estimate()
+    z, counts = brute(text, w)
+    assert pf[0] == pytest.approx(math.log(z), rel=1e-12)
+    np.testing.assert_allclose(np.exp(counts_ln)[1:], counts[1:], rtol=1e-12, atol=1e-300)
+
+
+def test_sample_forests_file(oracle, golden_dir):
+    text = open(os.path.join(golden_dir, "fem.forests")).read()
+    norm = open(os.path.join(golden_dir, "fem.norm")).read()
+    f = oracle.OracleForests(text, norm)
+    assert (f.n_forests, f.n_groups) == (5, 2)
+    rng = np.random.default_rng(0)
+    w = rng.uniform(0.1, 0.9, f.n_rules)
+    f.set_weights(np.log(w))
+    avg, counts_ln, pf = f.estimate()
+    # the five forests of the file, one per top-level s-expression
+    depth, start, forests = 0, None, []
+    for i, ch in enumerate(text):
+        if ch == "(":
+            if depth == 0 and start is None:
+                start = i
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+            if depth == 0:
+                forests.append(text[start:i + 1])
+                start = None
+    tot = np.zeros(f.n_rules)
+    for k, ft in enumerate(forests):
+        z, c = brute(ft, w)
+        assert pf[k] == pytest.approx(math.log(z), rel=1e-12)
+        tot += c
+    np.testing.assert_allclose(np.exp(counts_ln)[1:], tot[1:], rtol=1e-12, atol=1e-300)
+    # M-step: groups ((1 2 7) (3 4 5 6)); rules outside every group keep their weights (forest-em.README)
+    before = f.weights().copy()
+    f.maximize()
+    after = np.exp(f.weights())
+    assert after[[1, 2, 7]].sum() == pytest.approx(1.0, rel=1e-12)
+    assert after[[3, 4, 5, 6]].sum() == pytest.approx(1.0, rel=1e-12)
+    np.testing.assert_allclose(after[[3, 4, 5, 6]], tot[[3, 4, 5, 6]] / tot[[3, 4, 5, 6]].sum(), rtol=1e-12)
+    np.testing.assert_array_equal(f.weights()[8:], before[8:])
+
+
+def test_em_increases_likelihood(oracle, golden_dir):
+    f = oracle.OracleForests(open(os.path.join(golden_dir, "fem.forests")).read(),
+                             open(os.path.join(golden_dir, "fem.norm")).read())
+    f.maximize()  # start from normalised weights
+    prev = -1e300
+    for _ in range(6):
+        avg, _, _ = f.estimate()
+        assert avg >= prev - 1e-12
+        prev = avg
+        f.maximize()
