@@ -79,3 +79,68 @@ def make_config(name, n_pairs=None):
     w = random_wfst(n_states, deg, seed=seed)
     c = random_walk_corpus(w, npairs, seed=seed, out_degree=deg)
     return w, c
+
+
+def random_forests(n_forests, n_rules=500000, mean_nodes=46, p_backref=0.6, group_mean=8, seed=4):
+    """packed AND/OR forests as preorder node arrays (label, ref, next), OR fan-out
+    2-4, ~20 % of the children of AND nodes are back-references to earlier shared sub-forests, rule ids Zipf over
+    n_rules parameters, normalisation groups of mean size group_mean.  Returns (node_off, label, ref, next,
+    n_rules + 1, group_off, group_rule)."""
+    rng = np.random.default_rng(seed)
+    zipf_p = 1.0 / np.arange(1, n_rules + 1)
+    zipf_p /= zipf_p.sum()
+    labels, refs, nexts, node_off = [], [], [], [0]
+    rule_pool = rng.choice(n_rules, size=n_forests * mean_nodes * 4 + 4096, p=zipf_p) + 1
+    rp = 0
+    u = rng.random(n_forests * mean_nodes * 16 + 16384)
+    up = 0
+    for _ in range(n_forests):
+        lab, ref, nxt = [], [], []
+        shared = []
+        budget = [int(mean_nodes * (0.5 + u[up % len(u)]))]
+        up += 1
+
+        def node(depth, kind):
+            nonlocal rp, up
+            i = len(lab)
+            lab.append(0)
+            ref.append(-1)
+            nxt.append(0)
+            budget[0] -= 1
+            if kind == 0:  # OR: 2-4 AND children
+                for _k in range(2 + int(u[up % len(u)] * 3)):
+                    node(depth + 1, 1)
+                up += 1
+            else:
+                lab[i] = int(rule_pool[rp % len(rule_pool)])
+                rp += 1
+                nk = 0 if (budget[0] <= 0 or depth > 8) else int(u[up % len(u)] * 3.2)
+                up += 1
+                for _k in range(nk):
+                    r = u[up % len(u)]
+                    up += 1
+                    if shared and r < p_backref:
+                        j = len(lab)
+                        lab.append(0)
+                        ref.append(shared[int(u[up % len(u)] * len(shared))])
+                        up += 1
+                        nxt.append(j + 1)
+                    else:
+                        c = len(lab)
+                        node(depth + 1, 0 if r > 0.6 else 1)
+                        if r > 0.7:
+                            shared.append(c)
+            nxt[i] = len(lab)
+        node(0, 0)
+        labels.extend(lab)
+        refs.extend(ref)
+        nexts.extend(nxt)
+        node_off.append(len(labels))
+    perm = rng.permutation(n_rules) + 1
+    sizes = rng.poisson(group_mean - 1, size=n_rules // group_mean + 8) + 1
+    goff = np.concatenate([[0], np.cumsum(sizes)])
+    goff = goff[goff <= n_rules]
+    if goff[-1] != n_rules:
+        goff = np.append(goff, n_rules)
+    return (np.asarray(node_off, np.uint64), np.asarray(labels, np.uint32), np.asarray(refs, np.int32),
+            np.asarray(nexts, np.uint32), n_rules + 1, goff.astype(np.uint64), perm.astype(np.uint32))
