@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
 }
 
 // Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
-// snap_norm.  LDS per lane: inside column + a u32 work stack + the lane's previous sample.
+// snap_norm.  LDS per lane: the inside column.
 __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FGroup g = A.groups[A.first_group + blockIdx.x];
@@ -174,15 +174,13 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   if (A.serial_forest != 0xffffffffu) active = active && (g.lane_base + lane == A.serial_forest);
   const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
   double* ins = lds + lane;
-  uint32_t* stack = (uint32_t*)(lds + (size_t)g.max_nodes * 64) + lane;                          // [max_sample + 1][64]
-  uint32_t* own = (uint32_t*)(lds + (size_t)g.max_nodes * 64) + (size_t)(max_sample + 1) * 64 + lane;  // [max_sample][64]
   const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
+  // the lane's previous sample (counterfactual removal) is read straight from global memory; the traversal stack
+  // lives at the tail of the forest's own sample buffer (recorded rules grow from the front, pending nodes from the
+  // back: every pending node still owes at least one rule, so the two never meet)
   uint32_t own_len = 0;
-  if (active && A.counterfactual) {
-    own_len = A.old_len[forest];
-    const uint32_t* o = A.old_rules + A.sample_off[forest];
-    for (uint32_t k = 0; k < own_len; ++k) own[(size_t)k * 64] = o[k];
-  }
+  const uint32_t* own = A.old_rules + (active ? A.sample_off[forest] : 0);
+  if (active && A.counterfactual) own_len = A.old_len[forest];
   // inside with proposal probabilities (forest.hpp:768-816)
   {
     const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
           else {
             double x = A.snap_x[rule], ns = A.snap_norm[nn];
             for (uint32_t q = 0; q < own_len; ++q) {
-              const uint32_t rr = own[(size_t)q * 64];
+              const uint32_t rr = own[q];
               if (rr == rule) x -= 1.0;
               if (A.p_norm[rr] == nn) ns -= 1.0;
             }
@@ -230,11 +228,13 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
     const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
     const uint32_t* __restrict__ hp = A.hdr_pos + g.stream_base + lane;  // indexed [node * 64]
     uint32_t* outr = A.sample_rules + A.sample_off[forest];
+    const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
+    uint32_t* stack = outr + cap;  // stack[-1 - i]
     uint32_t sp = 0, ns = 0, step = 0;
-    stack[0] = n - 1;
+    stack[-1] = n - 1;
     sp = 1;
     while (sp) {
-      const uint32_t node = stack[(size_t)(--sp) * 64];
+      const uint32_t node = stack[-(int)(sp--)];
       const uint32_t h = hp[(size_t)node * 64];
       const uint2 hr = st[(size_t)h * 64];
       // children occupy records h+1 .. until the one flagged LAST (none if the header itself is LAST)
@@ -247,7 +247,10 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
       if (hr.x & F_AND) {
         if (ns < max_sample) outr[ns] = hr.y;
         ++ns;
-        for (uint32_t k = nch; k-- > 0;) stack[(size_t)(sp++) * 64] = st[(size_t)(h + 1 + k) * 64].x & F_IDX;
+        for (uint32_t k = nch; k-- > 0;) {
+          ++sp;
+          stack[-(int)sp] = st[(size_t)(h + 1 + k) * 64].x & F_IDX;
+        }
       } else {
         double norm = F_NEG_INF;
         for (uint32_t k = 0; k < nch; ++k) norm = f_lwadd(norm, ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64]);
@@ -258,7 +261,8 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
           choice -= exp(ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] - norm);
           if (choice < 0 || k + 1 == nch) break;
         }
-        stack[(size_t)(sp++) * 64] = st[(size_t)(h + 1 + pick) * 64].x & F_IDX;
+        ++sp;
+        stack[-(int)sp] = st[(size_t)(h + 1 + pick) * 64].x & F_IDX;
       }
     }
     A.sample_len[forest] = ns < max_sample ? ns : max_sample;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
       else {
         double x = A.snap_x[rule], nsum = A.snap_norm[nn];
         for (uint32_t q = 0; q < own_len; ++q) {
-          const uint32_t rr = own[(size_t)q * 64];
+          const uint32_t rr = own[q];
           if (rr == rule) x -= 1.0;
           if (A.p_norm[rr] == nn) nsum -= 1.0;
         }
@@ -451,6 +455,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       dsz[k] = std::min<uint64_t>(v, 1u << 20);
     }
     fl.max_deriv = std::max<uint64_t>(1, dsz[fl.n - 1]);
+    if (fl.max_deriv >= (1u << 20)) return fail(CARMEL_HIP_ERR_ARG, "forest derivation larger than 2^20 rules");
   }
   // ---- groups of 64, sorted by stream length ----
   std::vector<uint32_t> ord(n_forests);
@@ -534,7 +539,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
   // samples: capacity = size of the largest derivation of the forest
   F->h_sample_off.assign(n_forests + 1, 0);
   for (uint64_t f = 0; f < n_forests; ++f) {
-    F->h_sample_off[f + 1] = F->h_sample_off[f] + flat[f].max_deriv;
+    F->h_sample_off[f + 1] = F->h_sample_off[f] + flat[f].max_deriv + 2;
     F->max_sample = std::max<uint32_t>(F->max_sample, (uint32_t)flat[f].max_deriv);
   }
   HIPCHK(F->groups.upload(F->h_groups, s));
@@ -754,7 +759,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       A.sample_rules = F->sample_rules[cur ^ 1].p;
       for (auto& c : F->classes) {
         A.first_group = c.first;
-        size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)(F->max_sample + 1) * 64 * 4 + (size_t)F->max_sample * 64 * 4;
+        size_t lds = (size_t)c.max_nodes * 64 * 8;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample);
@@ -813,7 +818,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         const uint32_t gidx = slot / 64;
         A.first_group = gidx;
         const FGroup& G = F->h_groups[gidx];
-        size_t lds = (size_t)G.max_nodes * 64 * 8 + (size_t)(F->max_sample + 1) * 64 * 4 + (size_t)F->max_sample * 64 * 4;
+        size_t lds = (size_t)G.max_nodes * 64 * 8;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample);
