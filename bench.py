@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=20000)
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--walk-arcs", default="5,40", help="min,max arcs of the random walks (SURVEY 8d: 5,40; other values are experiments)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +71,8 @@ def main():
         npairs = args.pairs
     t0 = time.time()
     w = synth.random_wfst(n_states, deg, seed=seed)  # same model on every rank
-    c = synth.random_walk_corpus(w, npairs, seed=seed + 7919 * rank, out_degree=deg)  # this rank's shard
+    lo, hi = (int(v) for v in args.walk_arcs.split(","))
+    c = synth.random_walk_corpus(w, npairs, min_arcs=lo, max_arcs=hi, seed=seed + 7919 * rank, out_degree=deg)  # this rank's shard
     t_gen = time.time() - t0
     fb = HipForwardBackward(w, c, device=local_rank, host_threads=args.host_threads)
     ls = fb.lattice_stats
@@ -126,8 +128,8 @@ def main():
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: synthetic %d-state / %d-arc WFST, %d training pairs per GPU (random walks of "
-                                   "5-40 arcs), conditional normalisation, cached lattices" %
-                                   (args.config, w.n_states, w.n_arcs, c.n_pairs),
+                                   "%s arcs), conditional normalisation, cached lattices" %
+                                   (args.config, w.n_states, w.n_arcs, c.n_pairs, args.walk_arcs.replace(",", "-")),
                        "pairs_per_gpu": c.n_pairs, "wfst_arcs": int(w.n_arcs), "wfst_states": int(w.n_states),
                        "lattice_arcs_per_gpu": int(ls.kept_arcs), "lattice_states_per_gpu": int(ls.kept_states),
                        "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, all-reduce of %d f64 "

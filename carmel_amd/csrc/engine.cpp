@@ -146,7 +146,13 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->pair_logw.upload(L.pair_logw, s));
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
   HIPCHK(t->lane_fwd.upload(L.lane_fwd, s));
-  HIPCHK(t->lane_bwd.upload(L.lane_bwd, s));
+  {
+    // the kernel needs only the destination/flags word of a backward record; the arc id (slot construction) stays here
+    std::vector<uint32_t> bx(L.lane_bwd.size());
+    for (size_t k = 0; k < bx.size(); ++k) bx[k] = L.lane_bwd[k].x;
+    HIPCHK(t->lane_bwd.upload(bx, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   HIPCHK(t->lane_pair.upload(L.lane_pair, s));
   HIPCHK(t->lane_nstates.upload(L.lane_nstates, s));
   HIPCHK(t->lane_logw.upload(L.lane_logw, s));
@@ -432,7 +438,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   LaneArgs LA;
   LA.groups = t->lane_groups.p;
   LA.fwd = (const uint2*)t->lane_fwd.p;
-  LA.bwd = (const uint2*)t->lane_bwd.p;
+  LA.bwd = t->lane_bwd.p;
   LA.lane_pair = t->lane_pair.p;
   LA.lane_nstates = t->lane_nstates.p;
   LA.lane_logw = t->lane_logw.p;
@@ -442,6 +448,16 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   LA.scalars = t->counts_ptr() + t->w.n_arcs;
   LA.pair_logprob = t->pair_logprob.p;
   LA.first_group = 0;
+  LA.trace = nullptr;
+  static const char* trace_path = getenv("CARMEL_HIP_LANE_TRACE");  // experiment: per-wave cycle stamps of the last E-step
+  static DevBuf<unsigned long long> trace_buf;
+  if (trace_path) {
+    if (trace_buf.n != t->lane_groups.n * 16) {
+      HIPCHK(trace_buf.alloc(t->lane_groups.n * 16));
+      HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
+    }
+    LA.trace = trace_buf.p;
+  }
   HIPCHK(hipEventRecord(t->ev0, s));
   for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
@@ -455,6 +471,15 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   R.n_hot_chunks = t->hot_chunks.n / 3;
   HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipEventRecord(t->ev1, s));
+  if (trace_path && trace_buf.n) {
+    std::vector<unsigned long long> h(trace_buf.n);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpy(h.data(), trace_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "wb")) {
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
+  }
   return CARMEL_HIP_OK;
 }
 

@@ -77,7 +77,8 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> in_off, out_off, level_off, pair_start, pair_final, pair_id;
   DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
   DevBuf<LaneGroup> lane_groups;
-  DevBuf<uint2_t> lane_fwd, lane_bwd;
+  DevBuf<uint2_t> lane_fwd;
+  DevBuf<uint32_t> lane_bwd;  // destination | flags words only
   DevBuf<uint32_t> lane_pair, lane_nstates;
   DevBuf<double> lane_logw, post, wcache;
   DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;

@@ -58,15 +58,23 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 
 
 // ---------------- lane sweep: one small lattice per lane, 64 per wavefront ----------------
-// Streams are interleaved (record k of lane l at base + k*64 + l): every wave-wide load is one 512-byte row.
+// Streams are interleaved (record k of lane l at base + k*64 + l): every wave-wide load is one coalesced row.
 // The lane's forward values live in its own LDS column col[s*64] (conflict-free for any per-lane s); the backward
 // pass overwrites alpha[s] with beta[s] in place — when state s is processed in reverse topological order its
 // alpha is read once, and every destination it needs already holds beta.  No barriers, no offsets, no levels.
-// Loads run two chunks ahead of the arithmetic (records), one chunk ahead (weight gathers): all of them are
-// value-independent, only the LDS column carries the recurrence.  Posteriors go to post[] at the record's own
-// position (coalesced 512-byte rows).
-template <int U>
+//
+// The wave is latency-bound, not bandwidth-bound, unless its loads run far ahead of their first use, so both passes
+// are software pipelines over chunks of U records with all loads value-independent (only the LDS column carries the
+// recurrence):
+//   forward : records are loaded R chunks ahead; the weight gather logw[arc] for a chunk is issued W chunks ahead
+//             of its use, from records that landed R-W iterations earlier.  Each weight is also stored at the arc's
+//             position in the BACKWARD stream (wcache), so
+//   backward: records (4-byte: destination + flags) and weights are two plain sequential streams, both R ahead.
+// Posteriors go to post[] at the backward record's own position (coalesced rows).
+template <int R, int W, typename LSE = Lse>
 __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
+  constexpr int U = (int)LANE_CHUNK;  // a group's row count is a multiple of U (host padding): chunks are never partial
+  static_assert(W >= 1 && W < R, "gather lead must be shorter than the record lead");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const LaneGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
@@ -75,62 +83,71 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   const double* __restrict__ logw = A.logw;
   double* col = lds + lane;
   const uint32_t maxlen = g.maxlen;
-  // Software pipeline, all value-independent: records run 3 chunks ahead of the arithmetic, weight gathers 2.
-  // ra = chunk being consumed, rb/rc = next two, rd = being loaded; wa/wb/wc likewise.
-#define LANE_LOAD_RECS(dst, base, k0_)                                                    \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) {                                         \
-    const uint32_t k_ = (k0_) + u;                                                        \
-    dst[u] = (k_ < maxlen) ? (base)[(size_t)k_ * 64] : make_uint2(0u, 0u);                \
-  }
-#define LANE_LOAD_WS(dst, recs)                                                           \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) dst[u] = (recs[u].x & LANE_VALID) ? logw[recs[u].y] : 0.0;
+  const uint32_t lastk = maxlen - 1;  // prefetches past the end re-read the last row: every load is unconditional
+  double* wcache = A.wcache + g.stream_base + lane;
+  unsigned long long t_start = 0, t_mid = 0;
+  if (A.trace) t_start = __builtin_readcyclecounter();
+  // Register rings indexed only by compile-time constants (the chunk loop is unrolled R times): a slot is refilled
+  // right after it is consumed and never moved, so no load has to land before its first real use.  All global
+  // loads and stores in the loops are unconditional (padding records are harmless: arc 0, backward row 0 of a lane
+  // that has padding is itself padding), which keeps the s_waitcnt bookkeeping exact.
   // ---------- forward ----------
   {
     const uint2* __restrict__ f = A.fwd + g.stream_base + lane;
-    double* wc_out = A.wcache + g.stream_base + lane;
     if (active) col[0] = 0.0;
-    uint2 ra[U], rb[U], rc[U];
-    double wa[U], wb[U];
-    LANE_LOAD_RECS(ra, f, 0u)
-    LANE_LOAD_RECS(rb, f, (uint32_t)U)
-    LANE_LOAD_RECS(rc, f, (uint32_t)(2 * U))
-    LANE_LOAD_WS(wa, ra)
-    LANE_LOAD_WS(wb, rb)
-    Lse acc;
+    uint2 rq[R][U];   // slot j: records of chunk c with c % R == j
+    double wq[R][U];  // slot j: their weights
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = (uint32_t)(j * U + u);
+        rq[j][u] = f[(size_t)(k < maxlen ? k : lastk) * 64];
+      }
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) wq[j][u] = logw[rq[j][u].y];
+    LSE acc;
     acc.init();
     uint32_t d = 1;
     double prev = 0.0;  // alpha[d-1] kept in a register: a chain step never waits for the LDS round trip
-    for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
-      uint2 rd[U];
-      double wc[U];
-      LANE_LOAD_RECS(rd, f, k0 + 3 * U)
-      LANE_LOAD_WS(wc, rc)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t x = ra[u].x;
-        if (x & LANE_VALID) {
-          const uint32_t src = x & LANE_STATE_MASK;
-          const double a_src = (src + 1 == d) ? prev : col[src * 64];
-          wc_out[(size_t)(k0 + u) * 64] = wa[u];
-          acc.add(a_src + wa[u]);
-          if (x & LANE_LAST) {
-            prev = acc.value();
-            col[d * 64] = prev;
-            ++d;
-            acc.init();
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ra[u] = rb[u];
-        rb[u] = rc[u];
-        rc[u] = rd[u];
-        wa[u] = wb[u];
-        wb[u] = wc[u];
-      }
-    }
+    // one step = consume chunk kb/U from ring slot j (compile-time), issue the gather W chunks ahead, refill the slot
+#define LANE_FWD_STEP(j, kb)                                                                          \
+  {                                                                                                   \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) wq[((j) + W) % R][u] = logw[rq[((j) + W) % R][u].y]; \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
+      const uint32_t x = rq[j][u].x;                                                                  \
+      const uint32_t src = x & LANE_STATE_MASK;                                                       \
+      const double w = wq[j][u];                                                                      \
+      wcache[(size_t)((x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] = w;                                \
+      const double a_src = (src + 1 == d) ? prev : col[src * 64];                                     \
+      acc.add((x & LANE_VALID) ? a_src + w : NEG_INF);                                                \
+      if (x & LANE_LAST) {                                                                            \
+        prev = acc.value();                                                                           \
+        col[d * 64] = prev;                                                                           \
+        ++d;                                                                                          \
+        acc.init();                                                                                   \
+      }                                                                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
+      const uint32_t k = (kb) + (uint32_t)(R * U + u);                                                \
+      rq[j][u] = f[(size_t)(k < maxlen ? k : lastk) * 64];                                            \
+    }                                                                                                 \
   }
+    // steady state: whole rounds of R chunks, no control flow between the steps (exact s_waitcnt counts) ...
+    uint32_t k0 = 0;
+    for (; k0 + R * U <= maxlen; k0 += R * U) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) LANE_FWD_STEP(j, k0 + (uint32_t)(j * U))
+    }
+    // ... then the last partial round (ring slots continue from 0)
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j)
+      if (k0 + (uint32_t)(j * U) < maxlen) LANE_FWD_STEP(j, k0 + (uint32_t)(j * U))
+#undef LANE_FWD_STEP
+  }
+  if (A.trace) t_mid = __builtin_readcyclecounter();
   // ---------- ln p(pair), corpus scalars, beta at the goal ----------
   double s_lp = 0.0, s_wlp = 0.0;
   double next = NEG_INF;  // beta[s+1] in a register
@@ -146,61 +163,64 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   // ---------- backward + posteriors ----------
   {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache stores before its re-reads
-    const uint2* __restrict__ b = A.bwd + g.stream_base + lane;
+    const uint32_t* __restrict__ b = A.bwd + g.stream_base + lane;
     double* __restrict__ post = A.post + g.stream_base + lane;
-    const double* wc_in = A.wcache + g.stream_base + lane;
-#undef LANE_LOAD_WS
-#define LANE_LOAD_WS(dst, recs)                                                           \
-  _Pragma("unroll") for (int u = 0; u < U; ++u) dst[u] =                                  \
-      (recs[u].x & LANE_VALID) ? wc_in[(size_t)((recs[u].x >> LANE_FPOS_SHIFT) & LANE_FPOS_MAX) * 64] : 0.0;
-    uint2 ra[U], rb[U], rc[U];
-    double wa[U], wb[U];
-    LANE_LOAD_RECS(ra, b, 0u)
-    LANE_LOAD_RECS(rb, b, (uint32_t)U)
-    LANE_LOAD_RECS(rc, b, (uint32_t)(2 * U))
-    LANE_LOAD_WS(wa, ra)
-    LANE_LOAD_WS(wb, rb)
-    Lse acc;
+    uint32_t xq[R][U];
+    double wq[R][U];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t k = (uint32_t)(j * U + u);
+        const size_t kk = (size_t)(k < maxlen ? k : lastk) * 64;
+        xq[j][u] = b[kk];
+        wq[j][u] = wcache[kk];
+      }
+    LSE acc;
     acc.init();
     uint32_t s = S >= 2 ? S - 2 : 0u;
     double al = (S >= 2) ? col[s * 64] : NEG_INF;
-    for (uint32_t k0 = 0; k0 < maxlen; k0 += U) {
-      uint2 rd[U];
-      double wc[U];
-      LANE_LOAD_RECS(rd, b, k0 + 3 * U)
-      LANE_LOAD_WS(wc, rc)
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t x = ra[u].x;
-        if (x & LANE_VALID) {
-          const uint32_t dst = x & LANE_STATE_MASK;
-          const double b_dst = (dst == s + 1) ? next : col[dst * 64];
-          const double t = wa[u] + b_dst;
-          acc.add(t);
-          post[(size_t)(k0 + u) * 64] = exp(al + t);
-          if (x & LANE_LAST) {
-            next = acc.value();
-            col[s * 64] = next;  // beta[s] replaces alpha[s]
-            acc.init();
-            if (s > 0) {
-              --s;
-              al = col[s * 64];
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ra[u] = rb[u];
-        rb[u] = rc[u];
-        rc[u] = rd[u];
-        wa[u] = wb[u];
-        wb[u] = wc[u];
-      }
-    }
+    // phase 1 of a step is the recurrence (cheap, serial): beta chain + the exponent of every posterior; phase 2 is
+    // branch-free: the U exponentials are independent and overlap in the pipeline.  Padding rows get exp(-inf) = 0
+    // (never read: count_reduce only visits valid slots).
+#define LANE_BWD_STEP(j, kb)                                                                          \
+  {                                                                                                   \
+    double arg[U];                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
+      const uint32_t x = xq[j][u];                                                                    \
+      const uint32_t dst = x & LANE_STATE_MASK;                                                       \
+      const double b_dst = (dst == s + 1) ? next : col[dst * 64];                                     \
+      const double t = (x & LANE_VALID) ? wq[j][u] + b_dst : NEG_INF;                                 \
+      acc.add(t);                                                                                     \
+      arg[u] = al + t;                                                                                \
+      if (x & LANE_LAST) {                                                                            \
+        next = acc.value();                                                                           \
+        col[s * 64] = next; /* beta[s] replaces alpha[s] */                                           \
+        acc.init();                                                                                   \
+        if (s > 0) {                                                                                  \
+          --s;                                                                                        \
+          al = col[s * 64];                                                                           \
+        }                                                                                             \
+      }                                                                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) post[(size_t)((kb) + u) * 64] = exp(arg[u]);        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
+      const uint32_t k = (kb) + (uint32_t)(R * U + u);                                                \
+      const size_t kk = (size_t)(k < maxlen ? k : lastk) * 64;                                        \
+      xq[j][u] = b[kk];                                                                               \
+      wq[j][u] = wcache[kk];                                                                          \
+    }                                                                                                 \
   }
-#undef LANE_LOAD_RECS
-#undef LANE_LOAD_WS
+    uint32_t k0 = 0;
+    for (; k0 + R * U <= maxlen; k0 += R * U) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
+    }
+#pragma unroll
+    for (int j = 0; j < R - 1; ++j)
+      if (k0 + (uint32_t)(j * U) < maxlen) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
+#undef LANE_BWD_STEP
+  }
   for (int o = 32; o > 0; o >>= 1) {
     s_lp += __shfl_down(s_lp, o, 64);
     s_wlp += __shfl_down(s_wlp, o, 64);
@@ -209,6 +229,13 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     atomic_add_f64(A.scalars + 0, s_lp);
     atomic_add_f64(A.scalars + 1, s_wlp);
     atomic_add_f64(A.scalars + 2, (double)g.n_lanes);
+    if (A.trace) {
+      unsigned long long* o = A.trace + (size_t)(A.first_group + blockIdx.x) * 16;
+      o[0] = t_start;
+      o[1] = t_mid;
+      o[2] = __builtin_readcyclecounter();
+      o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) | maxlen;  // HW_ID
+    }
   }
 }
 
@@ -523,25 +550,27 @@ static inline int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
+template <int R, int W, typename LSE = Lse>
+static hipError_t launch_lane_variant(const LaneArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sweep_lane_kernel<R, W, LSE>), dim3(grid), dim3(64), lds, stream, A);
+  return hipGetLastError();
+}
+
 hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc, hipStream_t stream) {
   LaneArgs A = A0;
   A.first_group = lc.first;
   size_t lds = (size_t)lc.max_states * 64 * sizeof(double);
-  static const int U = getenv("CARMEL_HIP_LANE_U") ? atoi(getenv("CARMEL_HIP_LANE_U")) : 4;  // tuning knob
-  if (U == 8) {
-    if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((sweep_lane_kernel<8>), dim3(lc.count), dim3(64), lds, stream, A);
-    return hipGetLastError();
+  static const int lds_scale = getenv("CARMEL_HIP_LANE_LDS_SCALE") ? atoi(getenv("CARMEL_HIP_LANE_LDS_SCALE")) : 1;
+  lds *= lds_scale;  // occupancy experiment
+  static const int V = getenv("CARMEL_HIP_LANE_VARIANT") ? atoi(getenv("CARMEL_HIP_LANE_VARIANT")) : 0;  // tuning knob
+  switch (V) {
+    case 1: return launch_lane_variant<2, 1>(A, lc.count, lds, stream);
+    case 2: return launch_lane_variant<6, 3>(A, lc.count, lds, stream);
+    case 3: return launch_lane_variant<8, 4>(A, lc.count, lds, stream);
+    default: return launch_lane_variant<4, 2>(A, lc.count, lds, stream);
   }
-  if (U == 2) {
-    hipLaunchKernelGGL((sweep_lane_kernel<2>), dim3(lc.count), dim3(64), lds, stream, A);
-    return hipGetLastError();
-  }
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((sweep_lane_kernel<4>), dim3(lc.count), dim3(64), lds, stream, A);
-  return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, hipStream_t stream) {

@@ -14,16 +14,17 @@ namespace carmel_hip {
 struct LaneArgs {
   const LaneGroup* groups;
   const uint2* fwd;
-  const uint2* bwd;
+  const uint32_t* bwd;   // backward records: destination | flags only (the arc id stays on the host)
   const uint32_t* lane_pair;
   const uint32_t* lane_nstates;
   const double* lane_logw;
   const double* logw;
   double* post;          // slot = record position in the backward stream
-  double* wcache;        // weight of the arc at forward-stream position k (written forward, re-read backward)
+  double* wcache;        // weight of the arc at BACKWARD-stream position k (written forward, streamed backward)
   double* scalars;       // {sum ln p, sum weight*ln p, n pairs, -}
   double* pair_logprob;
   uint32_t first_group;
+  unsigned long long* trace;  // experiment: per-block {t_start, t_mid, t_end, hw id} (CARMEL_HIP_LANE_TRACE)
 };
 
 struct SweepArgs {

@@ -487,7 +487,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     if (L.cyclic)
       cyc.push_back(p);
     else if (opt.lane_states && L.n_states <= opt.lane_states && L.n_states <= LANE_STATE_MASK &&
-             L.edges.size() <= LANE_FPOS_MAX)
+             L.edges.size() <= LANE_POS_MAX)
       lane.push_back(p);
     else if (L.n_states * 4 <= opt.small_states)
       small.push_back(p);
@@ -523,7 +523,8 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
         ml = std::max<uint32_t>(ml, (uint32_t)lats[lane[l]].edges.size());
         ms = std::max(ms, lats[lane[l]].n_states);
       }
-      G.maxlen = ml;
+      G.maxlen = (std::max<uint32_t>(ml, 1) + LANE_CHUNK - 1) / LANE_CHUNK * LANE_CHUNK;
+      ml = G.maxlen;
       G.max_states = ms;
       base += (uint64_t)ml * 64;
     }
@@ -538,7 +539,10 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
         while (j < ng) {
           uint32_t m = out.lane_groups[j].max_states;
           if (m > mx) mx = m;
-          if (j - i >= 256 && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;  // LDS waste <= 1.5x, few launches
+          // a class costs a launch (ramp-up + tail); it only pays when the LDS saved buys occupancy that matters:
+          // below ~20 KB per wave (8 waves per CU) the sweep is already bound by the random-gather rate
+          static const uint32_t min_split = getenv("CARMEL_HIP_LANE_SPLIT_STATES") ? (uint32_t)atoi(getenv("CARMEL_HIP_LANE_SPLIT_STATES")) : 48u;
+          if (j - i >= 256 && mx > min_split && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
           ++j;
         }
         out.lane_classes.push_back(LatticeSet::LaneClass{(uint32_t)i, (uint32_t)(j - i), mx});
@@ -588,29 +592,31 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
             for (uint32_t k = 0; k < E; ++k) oe[cur[newid[L.edges[k].src]]++] = k;
             uint2_t* f = out.lane_fwd.data() + G.stream_base + l;
             uint2_t* b = out.lane_bwd.data() + G.stream_base + l;
-            size_t pos = 0;
-            for (uint32_t d = 1; d < S; ++d)
-              for (uint32_t k = ioff[d]; k < ioff[d + 1]; ++k) {
-                const auto& e = L.edges[ie[k]];
-                uint32_t x = newid[e.src] | LANE_VALID | (k + 1 == ioff[d + 1] ? LANE_LAST : 0u);
-                f[(pos++) * 64] = uint2_t{x, e.arc};
-              }
-            // forward position of every edge (the backward record points at it: the forward pass leaves the arc's
-            // weight there, so the backward pass re-reads it L2-hot instead of gathering it again)
-            fpos.resize(E);
-            pos = 0;
-            for (uint32_t d = 1; d < S; ++d)
-              for (uint32_t k = ioff[d]; k < ioff[d + 1]; ++k) fpos[ie[k]] = (uint32_t)pos++;
-            pos = 0;
+            // backward stream first: out-arcs by source in reverse topological order.  The position of an edge there
+            // is also its posterior slot and the place where the forward pass leaves its weight (wcache), so the
+            // forward record carries it.
+            // The backward stream is RIGHT-aligned in the group's rows (it starts at row maxlen - E): for a chain the
+            // arc at forward row k then sits at backward row maxlen-1-k in every lane, so the forward pass's weight
+            // stores (wcache) are coalesced rows too; for general lattices they are near-coalesced.
+            fpos.resize(E);  // edge -> row in the backward stream
+            size_t pos = (size_t)G.maxlen - E;
             for (uint32_t sidx = S; sidx-- > 0;) {
               if (sidx == S - 1) continue;  // the goal has no out-arcs
               for (uint32_t k = ooff[sidx]; k < ooff[sidx + 1]; ++k) {
                 const auto& e = L.edges[oe[k]];
-                uint32_t x = newid[e.dst] | (fpos[oe[k]] << LANE_FPOS_SHIFT) | LANE_VALID |
-                             (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
+                uint32_t x = newid[e.dst] | LANE_VALID | (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
+                fpos[oe[k]] = (uint32_t)pos;
                 b[(pos++) * 64] = uint2_t{x, e.arc};
               }
             }
+            pos = 0;
+            for (uint32_t d = 1; d < S; ++d)
+              for (uint32_t k = ioff[d]; k < ioff[d + 1]; ++k) {
+                const auto& e = L.edges[ie[k]];
+                uint32_t x = newid[e.src] | (fpos[ie[k]] << LANE_POS_SHIFT) | LANE_VALID |
+                             (k + 1 == ioff[d + 1] ? LANE_LAST : 0u);
+                f[(pos++) * 64] = uint2_t{x, e.arc};
+              }
           }
         }
       }

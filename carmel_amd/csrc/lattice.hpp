@@ -70,13 +70,14 @@ struct uint2_t {
 // into two record streams (forward: in-arcs grouped by destination in topological order; backward: out-arcs
 // grouped by source in reverse topological order) and the 64 streams are interleaved record by record, so every
 // wave-wide load is one coalesced 512-byte row and the topology needs no offsets, no levels and no barriers.
-// record.x = local state index (bits 0..9) | [backward records: forward position of the same arc, bits 10..29]
+// record.x = local state index (bits 0..9) | [forward records: backward position of the same arc, bits 10..29]
 //            | LANE_VALID | LANE_LAST (last arc of its state); record.y = WFST arc id
+static const uint32_t LANE_CHUNK = 4;  // a group's row count (maxlen) is a multiple of this: the kernel consumes whole chunks
 static const uint32_t LANE_LAST = 0x80000000u;
 static const uint32_t LANE_VALID = 0x40000000u;
 static const uint32_t LANE_STATE_MASK = 0x3ffu;
-static const uint32_t LANE_FPOS_SHIFT = 10;
-static const uint32_t LANE_FPOS_MAX = (1u << 20) - 1;
+static const uint32_t LANE_POS_SHIFT = 10;
+static const uint32_t LANE_POS_MAX = (1u << 20) - 1;
 struct LaneGroup {        // mirrored on the device, 32 bytes
   uint64_t stream_base;   // into lane_fwd[] / lane_bwd[] (maxlen * 64 records each)
   uint32_t maxlen;        // records per lane (shorter lattices are padded with invalid records)

@@ -91,14 +91,16 @@ def numpy_sweep(img, logw, n_pairs_total):
             S = int(img["lane_nstates"][slot])
             col = np.full(S, -np.inf)
             col[0] = 0.0
-            d, terms, fwd_arc_at = 1, [], []
+            d, terms, wcache = 1, [], {}
             for k in range(ml):
                 x, arc = img["lane_fwd"][base + k * 64 + l]
                 if not x & LANE_VALID:
                     continue
                 assert (x & 0x3ff) < d
                 terms.append(col[x & 0x3ff] + logw[arc])
-                fwd_arc_at.append(arc)
+                bpos = (x >> 10) & 0xfffff  # the forward record points at the arc's backward position (wcache slot)
+                assert bpos not in wcache
+                wcache[bpos] = (arc, logw[arc])
                 if x & LANE_LAST:
                     col[d] = _lse(terms)
                     d, terms = d + 1, []
@@ -112,8 +114,8 @@ def numpy_sweep(img, logw, n_pairs_total):
                 if not x & LANE_VALID:
                     continue
                 assert (x & 0x3ff) > s
-                assert fwd_arc_at[(x >> 10) & 0xfffff] == arc  # the backward record points at its own forward record
-                t = logw[arc] + col[x & 0x3ff]
+                assert wcache[k][0] == arc  # the forward pass left this arc's weight at exactly this position
+                t = wcache[k][1] + col[x & 0x3ff]
                 counts[arc] += np.exp(alpha_s(col, s) + t)
                 terms.append(t)
                 if x & LANE_LAST:

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Summarise the two --pmc passes of tools/pmc_traffic.sh into per-kernel average FETCH_SIZE / WRITE_SIZE per launch.
+rocprofv3 reports both in KiB-sized units of 1 KB (counter description: "kilobytes"); the raw values are kept and
+the bytes derived from them are labelled with the correction applied (MI355X_MICROARCH.md §HBM: FETCH_SIZE tallies
+128-byte requests at 64 B for wide coalesced reads -> x2; narrower accesses and WRITE_SIZE are uncalibrated)."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def load(d, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            acc[k][0] += 1
+            acc[k][1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    out, cfg = sys.argv[1], sys.argv[2]
+    fe, wr = load(out + "/fetch", "FETCH_SIZE"), load(out + "/write", "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fe) | set(wr)):
+        nf, f = fe.get(k, [0, 0.0])
+        nw, w = wr.get(k, [0, 0.0])
+        kernels[k] = {"launches": nf or nw, "fetch_kb_per_launch": f / nf if nf else None,
+                      "write_kb_per_launch": w / nw if nw else None}
+    print(json.dumps({"config": cfg, "unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE, raw, per launch)",
+                      "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
