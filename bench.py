@@ -31,6 +31,30 @@ def algorithmic_bytes(lattice_arcs, lattice_states):
     return 48.0 * lattice_arcs + 16.0 * lattice_states
 
 
+ESTEP_KERNELS = ("sweep_lane_kernel", "sweep_bundle_kernel", "sweep_serial_kernel", "count_reduce_kernel",
+                 "count_reduce_hot_kernel")
+
+
+def pmc_traffic(config, walk_arcs, n_pairs):
+    """HBM-side bytes per E-step from the committed rocprofv3 PMC passes of THIS command (tools/pmc_traffic.sh: FETCH_SIZE
+    and WRITE_SIZE in separate runs, summarised per kernel by tools/pmc_summary.py into profiles/).  Correction per
+    MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies each 128-byte request at 64 B, so it is doubled (calibrated here on
+    known byte counts, profiles/r1_pmc_calibration.txt: streaming reads of 4/8/16 B per lane all report exactly half;
+    WRITE_SIZE is exact).  None when no profile of this workload is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_%s.json" % config)
+    if not os.path.exists(path) or walk_arcs != "5,40":
+        return None
+    d = json.load(open(path))
+    if d.get("pairs_per_gpu") != n_pairs:
+        return None
+    tot = 0.0
+    for name, k in d["kernels"].items():
+        if any(e in name for e in ESTEP_KERNELS) and k["fetch_kb_per_launch"] is not None:
+            per_step = k["launches"] / d["estep_count"]
+            tot += per_step * (2.0 * k["fetch_kb_per_launch"] + (k["write_kb_per_launch"] or 0.0)) * 1024.0
+    return tot
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,7 +165,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "E-step = sweep_lane_kernel (one launch per LDS class) + "
                          "count_reduce_kernel, timed together with HIP events on the trainer's stream",
                          "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(args.config, args.walk_arcs, c.n_pairs),
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }
         if not args.no_cpu_baseline:
