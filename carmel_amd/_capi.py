@@ -21,7 +21,7 @@ SYMBOLS = [
     "carmel_hip_use_external_counts", "carmel_hip_synchronize", "carmel_hip_last_sweep_ms", "carmel_hip_read_scalars",
     "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_save_counts",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
-    "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_free",
+    "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
@@ -101,6 +101,8 @@ def _load():
     lib.carmel_hip_host_export.argtypes = [vp] + [vp] * 12
     lib.carmel_hip_host_export.restype = None
     lib.carmel_hip_host_export_lanes.argtypes = [vp] * 8
+    lib.carmel_hip_host_transpose.argtypes = [vp] * 12
+    lib.carmel_hip_host_transpose.restype = None
     lib.carmel_hip_host_export_lanes.restype = None
     lib.carmel_hip_host_free.argtypes = [vp]
     lib.carmel_hip_host_free.restype = None

@@ -162,6 +162,27 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->arc_off.upload(L.arc_off, s));
   HIPCHK(t->slot_pos.upload(L.slot_pos, s));
   HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
+  {
+    static const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    t->use_transpose = want && !L.t_buckets.empty();
+    if (t->use_transpose) {
+      HIPCHK(t->t_buckets.upload(L.t_buckets, s));
+      HIPCHK(t->t_tile_base.upload(L.t_tile_base, s));
+      HIPCHK(t->t_b_arc.upload(L.t_b_arc, s));
+      HIPCHK(t->t_b_rank.upload(L.t_b_rank, s));
+      HIPCHK(t->t_b_src.upload(L.t_b_src, s));
+      HIPCHK(t->t_t_pos.upload(L.t_t_pos, s));
+      HIPCHK(t->t_t_src.upload(L.t_t_src, s));
+      HIPCHK(t->t_split_arcs.upload(L.t_split_arcs, s));
+      HIPCHK(t->t_x.alloc(L.slot_pos.size()));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    std::vector<uint16_t>().swap(L.t_b_arc);
+    std::vector<uint16_t>().swap(L.t_b_rank);
+    std::vector<uint16_t>().swap(L.t_t_pos);
+    std::vector<uint32_t>().swap(L.t_b_src);
+    std::vector<uint32_t>().swap(L.t_t_src);
+  }
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
   bool need_val = false, need_val2 = false;
   for (auto& lc : L.classes) {
@@ -177,7 +198,8 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
-                    t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes();
+                    t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
+                    t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes();
   std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
@@ -458,7 +480,27 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
     }
     LA.trace = trace_buf.p;
   }
+  TransArgs T;
+  T.buckets = t->t_buckets.p;
+  T.tile_base = t->t_tile_base.p;
+  T.b_arc = t->t_b_arc.p;
+  T.b_rank = t->t_b_rank.p;
+  T.b_src = t->t_b_src.p;
+  T.t_pos = t->t_t_pos.p;
+  T.t_src = t->t_t_src.p;
+  T.arc_off = t->arc_off.p;
+  T.x = t->t_x.p;
+  T.logw = t->arc_logw.p;
+  T.wcache = t->wcache.p;
+  T.post = t->post.p;
+  T.counts = t->counts_ptr();
+  T.n_wcache = t->wcache.n;
+  T.n_post = t->post.n;
+  T.n_buckets = (uint32_t)t->t_buckets.n;
+  T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
+  LA.pre_weights = t->use_transpose ? 1u : 0u;
   HIPCHK(hipEventRecord(t->ev0, s));
+  if (t->use_transpose) HIPCHK(launch_transpose_weights(T, s));
   for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
   ReduceArgs R;
@@ -469,7 +511,10 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   R.counts = t->counts_ptr();
   R.n_arcs = t->w.n_arcs;
   R.n_hot_chunks = t->hot_chunks.n / 3;
-  HIPCHK(launch_count_reduce(R, s));
+  if (t->use_transpose)
+    HIPCHK(launch_transpose_counts(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
+  else
+    HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipEventRecord(t->ev1, s));
   if (trace_path && trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);

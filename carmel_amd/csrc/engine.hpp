@@ -78,6 +78,13 @@ struct carmel_hip_trainer {
   DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
   DevBuf<LaneGroup> lane_groups;
   DevBuf<uint2_t> lane_fwd;
+  // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path
+  DevBuf<TransBucket> t_buckets;
+  DevBuf<uint64_t> t_tile_base;
+  DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos;
+  DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
+  DevBuf<double> t_x;
+  bool use_transpose = false;
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only
   DevBuf<uint32_t> lane_pair, lane_nstates;
   DevBuf<double> lane_logw, post, wcache;

@@ -94,6 +94,32 @@ void carmel_hip_host_export_lanes(carmel_hip_host_lattices* h, void* groups32, u
   }
 }
 
+// blocked transposition tables (see TransBucket in lattice.hpp).  dims6 = n_items, n_buckets, n_tiles, n_split_arcs,
+// n_post, n_arcs; a null pointer skips that array.  buckets24 = raw 24-byte TransBucket records.
+void carmel_hip_host_transpose(carmel_hip_host_lattices* h, uint64_t* dims6, void* buckets24, uint64_t* tile_base,
+                               uint16_t* b_arc, uint16_t* b_rank, uint32_t* b_src, uint16_t* t_pos, uint32_t* t_src,
+                               uint32_t* split_arcs, uint64_t* arc_off, uint64_t* slot_pos) {
+  const LatticeSet& L = h->L;
+  if (dims6) {
+    dims6[0] = L.slot_pos.size();
+    dims6[1] = L.t_buckets.size();
+    dims6[2] = L.t_tile_base.empty() ? 0 : L.t_tile_base.size() - 1;
+    dims6[3] = L.t_split_arcs.size();
+    dims6[4] = L.n_post;
+    dims6[5] = L.arc_off.empty() ? 0 : L.arc_off.size() - 1;
+  }
+  if (buckets24) std::memcpy(buckets24, L.t_buckets.data(), L.t_buckets.size() * sizeof(TransBucket));
+  if (tile_base) std::memcpy(tile_base, L.t_tile_base.data(), L.t_tile_base.size() * 8);
+  if (b_arc) std::memcpy(b_arc, L.t_b_arc.data(), L.t_b_arc.size() * 2);
+  if (b_rank) std::memcpy(b_rank, L.t_b_rank.data(), L.t_b_rank.size() * 2);
+  if (b_src) std::memcpy(b_src, L.t_b_src.data(), L.t_b_src.size() * 4);
+  if (t_pos) std::memcpy(t_pos, L.t_t_pos.data(), L.t_t_pos.size() * 2);
+  if (t_src) std::memcpy(t_src, L.t_t_src.data(), L.t_t_src.size() * 4);
+  if (split_arcs) std::memcpy(split_arcs, L.t_split_arcs.data(), L.t_split_arcs.size() * 4);
+  if (arc_off) std::memcpy(arc_off, L.arc_off.data(), L.arc_off.size() * 8);
+  if (slot_pos) std::memcpy(slot_pos, L.slot_pos.data(), L.slot_pos.size() * 8);
+}
+
 void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,
                             uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
                             uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,

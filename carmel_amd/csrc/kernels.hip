@@ -71,7 +71,10 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 //             position in the BACKWARD stream (wcache), so
 //   backward: records (4-byte: destination + flags) and weights are two plain sequential streams, both R ahead.
 // Posteriors go to post[] at the backward record's own position (coalesced rows).
-template <int R, int W, typename LSE = Lse>
+// PRE: the weights were already laid out in lattice order (wcache, by the blocked transposition): the forward pass
+// reads them there (rows, near-coalesced) instead of gathering logw[arc] and stores nothing.
+#define LANE_W(r) (PRE ? wcache[(size_t)(((r).x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] : logw[(r).y])
+template <int R, int W, bool PRE, typename LSE = Lse>
 __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   constexpr int U = (int)LANE_CHUNK;  // a group's row count is a multiple of U (host padding): chunks are never partial
   static_assert(W >= 1 && W < R, "gather lead must be shorter than the record lead");
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
 #pragma unroll
     for (int j = 0; j < W; ++j)
 #pragma unroll
-      for (int u = 0; u < U; ++u) wq[j][u] = logw[rq[j][u].y];
+      for (int u = 0; u < U; ++u) wq[j][u] = LANE_W(rq[j][u]);
     LSE acc;
     acc.init();
     uint32_t d = 1;
@@ -115,12 +118,12 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     // one step = consume chunk kb/U from ring slot j (compile-time), issue the gather W chunks ahead, refill the slot
 #define LANE_FWD_STEP(j, kb)                                                                          \
   {                                                                                                   \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) wq[((j) + W) % R][u] = logw[rq[((j) + W) % R][u].y]; \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) wq[((j) + W) % R][u] = LANE_W(rq[((j) + W) % R][u]); \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
       const uint32_t x = rq[j][u].x;                                                                  \
       const uint32_t src = x & LANE_STATE_MASK;                                                       \
       const double w = wq[j][u];                                                                      \
-      wcache[(size_t)((x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] = w;                                \
+      if (!PRE) wcache[(size_t)((x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] = w;                      \
       const double a_src = (src + 1 == d) ? prev : col[src * 64];                                     \
       acc.add((x & LANE_VALID) ? a_src + w : NEG_INF);                                                \
       if (x & LANE_LAST) {                                                                            \
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   }
   // ---------- backward + posteriors ----------
   {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache stores before its re-reads
+    if (!PRE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache stores before its re-reads
     const uint32_t* __restrict__ b = A.bwd + g.stream_base + lane;
     double* __restrict__ post = A.post + g.stream_base + lane;
     uint32_t xq[R][U];
@@ -220,6 +223,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     for (int j = 0; j < R - 1; ++j)
       if (k0 + (uint32_t)(j * U) < maxlen) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
 #undef LANE_BWD_STEP
+#undef LANE_W
   }
   for (int o = 32; o > 0; o >>= 1) {
     s_lp += __shfl_down(s_lp, o, 64);
@@ -542,6 +546,74 @@ __global__ void fill_f64_kernel(double* p, double v, uint64_t n) {
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) p[k] = v;
 }
 
+// ---------------- blocked transposition (TransBucket, lattice.hpp) ----------------
+// weights, pass 1: one workgroup per arc bucket.  The bucket's weights go to LDS (coalesced read), its items leave in
+// position-sorted order (coalesced write), picking their weight out of LDS.
+__global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const TransBucket B = T.buckets[blockIdx.x];
+  for (uint32_t k = threadIdx.x; k < B.n_arcs; k += 1024) lds[k] = T.logw[B.arc_lo + k];
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) T.x[B.item_base + j] = lds[T.b_arc[B.item_base + j]];
+}
+// weights, pass 2: one workgroup per tile of positions.  The tile's items arrive as runs (one per bucket), are placed
+// in LDS at their position and the tile is written to wcache in one coalesced sweep.
+__global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
+  if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
+  const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
+  for (uint32_t k = threadIdx.x; k < np; k += 1024) lds[k] = 0.0;
+  __syncthreads();
+  const uint64_t i0 = T.tile_base[blockIdx.x], i1 = T.tile_base[blockIdx.x + 1];
+  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) lds[T.t_pos[i]] = T.x[T.t_src[i]];
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < np; k += 1024) T.wcache[p0 + k] = lds[k];
+}
+// counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in bucket-major runs.
+__global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
+  const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
+  for (uint32_t k = threadIdx.x; k < np; k += 1024) lds[k] = T.post[p0 + k];
+  __syncthreads();
+  const uint64_t i0 = T.tile_base[blockIdx.x], i1 = T.tile_base[blockIdx.x + 1];
+  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) T.x[i] = lds[T.t_pos[i]];
+}
+// counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
+// then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
+// that is a piece of a split arc reduces the piece and adds it atomically.
+__global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  __shared__ double part[16];
+  const TransBucket B = T.buckets[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) lds[T.b_rank[B.item_base + j]] = T.x[T.b_src[B.item_base + j]];
+  __syncthreads();
+  if (B.flags & TRANS_SPLIT) {
+    double v = 0.0;
+    for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) v += lds[j];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int k = 0; k < 16; ++k) tot += part[k];
+      atomic_add_f64(T.counts + B.arc_lo, tot);
+    }
+    return;
+  }
+  for (uint32_t a = threadIdx.x; a < B.n_arcs; a += 1024) {
+    const uint32_t r0 = (uint32_t)(T.arc_off[B.arc_lo + a] - B.item_base), r1 = (uint32_t)(T.arc_off[B.arc_lo + a + 1] - B.item_base);
+    double v = 0.0;
+    for (uint32_t r = r0; r < r1; ++r) v += lds[r];
+    T.counts[B.arc_lo + a] = v;
+  }
+}
+__global__ void zero_list_kernel(double* p, const uint32_t* idx, uint32_t n) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) p[idx[k]] = 0.0;
+}
+
 // ---------------- launch helpers (called from engine.cpp, compiled in this TU) ----------------
 static inline int grid_for(uint64_t n, int block) {
   uint64_t g = (n + block - 1) / block;
@@ -550,11 +622,11 @@ static inline int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
-template <int R, int W, typename LSE = Lse>
+template <int R, int W, bool PRE>
 static hipError_t launch_lane_variant(const LaneArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, LSE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((sweep_lane_kernel<R, W, LSE>), dim3(grid), dim3(64), lds, stream, A);
+    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sweep_lane_kernel<R, W, PRE>), dim3(grid), dim3(64), lds, stream, A);
   return hipGetLastError();
 }
 
@@ -565,11 +637,17 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   static const int lds_scale = getenv("CARMEL_HIP_LANE_LDS_SCALE") ? atoi(getenv("CARMEL_HIP_LANE_LDS_SCALE")) : 1;
   lds *= lds_scale;  // occupancy experiment
   static const int V = getenv("CARMEL_HIP_LANE_VARIANT") ? atoi(getenv("CARMEL_HIP_LANE_VARIANT")) : 0;  // tuning knob
+  if (A.pre_weights) {
+    switch (V) {
+      case 1: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
+      case 2: return launch_lane_variant<6, 3, true>(A, lc.count, lds, stream);
+      default: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);
+    }
+  }
   switch (V) {
-    case 1: return launch_lane_variant<2, 1>(A, lc.count, lds, stream);
-    case 2: return launch_lane_variant<6, 3>(A, lc.count, lds, stream);
-    case 3: return launch_lane_variant<8, 4>(A, lc.count, lds, stream);
-    default: return launch_lane_variant<4, 2>(A, lc.count, lds, stream);
+    case 1: return launch_lane_variant<2, 1, false>(A, lc.count, lds, stream);
+    case 2: return launch_lane_variant<6, 3, false>(A, lc.count, lds, stream);
+    default: return launch_lane_variant<4, 2, false>(A, lc.count, lds, stream);
   }
 }
 
@@ -594,6 +672,33 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
                               (int)lds);
     hipLaunchKernelGGL((sweep_bundle_kernel<1024, true>), dim3(lc.count), dim3(1024), lds, stream, A);
   }
+  return hipGetLastError();
+}
+
+static void trans_lds_attr() {
+  static bool done = false;
+  if (done) return;
+  const int lds = (int)(TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) * 8;
+  (void)hipFuncSetAttribute((const void*)trans_w_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_c_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  done = true;
+}
+hipError_t launch_transpose_weights(const TransArgs& T, hipStream_t stream) {
+  trans_lds_attr();
+  if (!T.n_buckets) return hipSuccess;
+  hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  const unsigned wt = (unsigned)((T.n_wcache + TRANS_TILE - 1) / TRANS_TILE);
+  if (wt) hipLaunchKernelGGL(trans_w_tile_kernel, dim3(wt), dim3(1024), TRANS_TILE * 8, stream, T);
+  return hipGetLastError();
+}
+hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
+  trans_lds_attr();
+  if (!T.n_buckets) return hipSuccess;
+  if (n_split) hipLaunchKernelGGL(zero_list_kernel, dim3((n_split + 255) / 256), dim3(256), 0, stream, T.counts, split_arcs, n_split);
+  hipLaunchKernelGGL(trans_c_tile_kernel, dim3(T.n_tiles), dim3(1024), TRANS_TILE * 8, stream, T);
+  hipLaunchKernelGGL(trans_c_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 

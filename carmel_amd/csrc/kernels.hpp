@@ -24,6 +24,7 @@ struct LaneArgs {
   double* scalars;       // {sum ln p, sum weight*ln p, n pairs, -}
   double* pair_logprob;
   uint32_t first_group;
+  uint32_t pre_weights;  // wcache already holds every arc's weight at its backward position (blocked transposition)
   unsigned long long* trace;  // experiment: per-block {t_start, t_mid, t_end, hw id} (CARMEL_HIP_LANE_TRACE)
 };
 
@@ -56,6 +57,25 @@ struct ReduceArgs {
   uint64_t n_arcs, n_hot_chunks;
 };
 
+// blocked transposition (see TransBucket, lattice.hpp)
+struct TransArgs {
+  const TransBucket* buckets;
+  const uint64_t* tile_base;
+  const uint16_t* b_arc;
+  const uint16_t* b_rank;
+  const uint32_t* b_src;
+  const uint16_t* t_pos;
+  const uint32_t* t_src;
+  const uint64_t* arc_off;
+  double* x;              // intermediate, one f64 per item
+  const double* logw;     // per arc
+  double* wcache;         // per lane position (n_wcache entries)
+  const double* post;     // per position (n_post entries)
+  double* counts;         // per arc
+  uint64_t n_wcache, n_post;
+  uint32_t n_buckets, n_tiles;
+};
+
 #define MSTEP_BIG_GROUP 512
 struct MstepArgs {
   double* logw;             // parameters (ln), updated in place
@@ -77,6 +97,8 @@ struct MstepArgs {
 
 hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
+hipError_t launch_transpose_weights(const TransArgs& T, hipStream_t stream);
+hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream);
 hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream);
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);

@@ -10,6 +10,8 @@
 #include <atomic>
 
 namespace carmel_hip {
+void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt);
+
 
 void HostWfst::build_index() {
   idx_off.assign((size_t)n_states + 1, 0);
@@ -862,7 +864,97 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
           out.hot_chunks.push_back(std::min(out.arc_off[a + 1], j + 4096));
         }
   }
+  build_transpose(out, w.n_arcs, nt);
   return true;
+}
+
+// see TransBucket (lattice.hpp)
+void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
+  const uint64_t N = out.slot_pos.size();
+  out.t_buckets.clear();
+  out.t_split_arcs.clear();
+  if (N >= (1ull << 32) || N == 0) return;  // 32-bit item indices; the engine then keeps the gather path
+  {
+    uint64_t a = 0;
+    while (a < n_arcs) {
+      uint64_t c = out.arc_off[a + 1] - out.arc_off[a];
+      if (c > TRANS_BUCKET) {
+        out.t_split_arcs.push_back((uint32_t)a);
+        for (uint64_t g = out.arc_off[a]; g < out.arc_off[a + 1]; g += TRANS_BUCKET)
+          out.t_buckets.push_back(TransBucket{g, (uint32_t)std::min<uint64_t>(TRANS_BUCKET, out.arc_off[a + 1] - g),
+                                              (uint32_t)a, 1u, TRANS_SPLIT});
+        ++a;
+        continue;
+      }
+      uint64_t e = a, items = 0;
+      while (e < n_arcs && e - a < TRANS_BUCKET) {
+        uint64_t ce = out.arc_off[e + 1] - out.arc_off[e];
+        if (ce > TRANS_BUCKET || items + ce > TRANS_BUCKET) break;
+        items += ce;
+        ++e;
+      }
+      out.t_buckets.push_back(TransBucket{out.arc_off[a], (uint32_t)items, (uint32_t)a, (uint32_t)(e - a), 0u});
+      a = e;
+    }
+  }
+  out.t_b_arc.assign(N, 0);
+  out.t_b_rank.assign(N, 0);
+  out.t_b_src.assign(N, 0);
+  out.t_t_pos.assign(N, 0);
+  out.t_t_src.assign(N, 0);
+  const uint64_t n_tiles = (out.n_post + TRANS_TILE - 1) / TRANS_TILE;
+  out.t_tile_base.assign(n_tiles + 1, 0);
+  std::vector<uint64_t> pos_of(N);  // position of the item at bucket-major index J
+  {
+    std::atomic<size_t> next(0);
+    auto work = [&]() {
+      std::vector<std::pair<uint64_t, uint32_t>> items;  // (position, rank in arc-sorted order)
+      for (;;) {
+        size_t b = next.fetch_add(16);
+        if (b >= out.t_buckets.size()) break;
+        size_t be = std::min(out.t_buckets.size(), b + 16);
+        for (; b < be; ++b) {
+          const TransBucket& B = out.t_buckets[b];
+          items.resize(B.n_items);
+          for (uint32_t r = 0; r < B.n_items; ++r) items[r] = {out.slot_pos[B.item_base + r], r};
+          std::sort(items.begin(), items.end());
+          uint64_t a = B.arc_lo;
+          // arc of rank r: walk arc_off (ranks are arc-sorted); build rank -> local arc first
+          std::vector<uint16_t> arc_of_rank(B.n_items);
+          if (B.flags & TRANS_SPLIT) {
+            std::fill(arc_of_rank.begin(), arc_of_rank.end(), (uint16_t)0);
+          } else {
+            for (uint32_t r = 0; r < B.n_items; ++r) {
+              while (out.arc_off[a + 1] <= B.item_base + r) ++a;
+              arc_of_rank[r] = (uint16_t)(a - B.arc_lo);
+            }
+          }
+          for (uint32_t j = 0; j < B.n_items; ++j) {
+            const uint64_t J = B.item_base + j;
+            out.t_b_arc[J] = arc_of_rank[items[j].second];
+            out.t_b_rank[J] = (uint16_t)items[j].second;
+            pos_of[J] = items[j].first;
+          }
+        }
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  // tile-major order: stable counting sort of the bucket-major sequence by tile
+  for (uint64_t J = 0; J < N; ++J) out.t_tile_base[pos_of[J] / TRANS_TILE + 1]++;
+  for (uint64_t t = 0; t < n_tiles; ++t) out.t_tile_base[t + 1] += out.t_tile_base[t];
+  {
+    std::vector<uint64_t> cur(out.t_tile_base.begin(), out.t_tile_base.end() - 1);
+    for (uint64_t J = 0; J < N; ++J) {
+      const uint64_t t = pos_of[J] / TRANS_TILE, I = cur[t]++;
+      out.t_t_src[I] = (uint32_t)J;
+      out.t_t_pos[I] = (uint16_t)(pos_of[J] - t * TRANS_TILE);
+      out.t_b_src[J] = (uint32_t)I;
+    }
+  }
 }
 
 }  // namespace carmel_hip

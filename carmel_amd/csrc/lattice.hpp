@@ -78,6 +78,20 @@ static const uint32_t LANE_VALID = 0x40000000u;
 static const uint32_t LANE_STATE_MASK = 0x3ffu;
 static const uint32_t LANE_POS_SHIFT = 10;
 static const uint32_t LANE_POS_MAX = (1u << 20) - 1;
+// Blocked transposition.  Both directions of the E-step's data exchange -- weights from arc order to lattice order,
+// posteriors from lattice order back to arc order -- are the same static sparse permutation of ~one item per lattice
+// arc.  Done as random 8-byte accesses each item moves a whole 128-byte line; done in two LDS-blocked passes it is
+// sequential traffic:
+//   buckets = contiguous arc ranges with <= TRANS_BUCKET items and arcs (a bucket's weights / its items fit in LDS),
+//   tiles   = TRANS_TILE consecutive slot positions (a tile of wcache / post fits in LDS),
+//   the intermediate array X holds the items bucket-major, each bucket's items sorted by position, so the items of
+//   (bucket b, tile t) are one contiguous run in both orders.
+// An arc with more items than a bucket holds is cut into single-arc buckets flagged TRANS_SPLIT.
+static const uint32_t TRANS_TILE = 16384, TRANS_BUCKET = 16384, TRANS_SPLIT = 1u;
+struct TransBucket {      // mirrored on the device, 24 bytes
+  uint64_t item_base;     // first item: bucket-major index J == index into slot_pos[] (arc-sorted order)
+  uint32_t n_items, arc_lo, n_arcs, flags;
+};
 struct LaneGroup {        // mirrored on the device, 32 bytes
   uint64_t stream_base;   // into lane_fwd[] / lane_bwd[] (maxlen * 64 records each)
   uint32_t maxlen;        // records per lane (shorter lattices are padded with invalid records)
@@ -120,6 +134,15 @@ struct LatticeSet {
   std::vector<uint64_t> slot_pos;  // grouped by arc id
   std::vector<uint64_t> hot_chunks;  // (arc, first, end) triples: arcs with more than 64 slots, cut into 4096-slot chunks
   uint64_t n_post = 0;  // size of the posterior array (lane records incl. padding + bundle arcs)
+  // Blocked transposition between WFST-arc order and slot (position) order -- see TransBucket below.
+  std::vector<TransBucket> t_buckets;
+  std::vector<uint64_t> t_tile_base;   // n_tiles + 1: first tile-major item index of every tile
+  std::vector<uint16_t> t_b_arc;       // [J] arc - bucket.arc_lo
+  std::vector<uint16_t> t_b_rank;      // [J] rank of the item in arc-sorted order within its bucket
+  std::vector<uint32_t> t_b_src;       // [J] tile-major index I of the same item
+  std::vector<uint16_t> t_t_pos;       // [I] position - tile * TRANS_TILE
+  std::vector<uint32_t> t_t_src;       // [I] bucket-major index J of the same item
+  std::vector<uint32_t> t_split_arcs;  // arcs cut over several buckets (their counts are accumulated atomically)
   uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
   uint64_t explored_states = 0, explored_arcs = 0;
   std::vector<uint8_t> has_deriv;

@@ -229,6 +229,11 @@ void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32
                             uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
                             uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,
                             uint8_t* has_deriv);
+/* the blocked arc-order <-> lattice-order transposition tables the E-step uses instead of random gathers; dims6 =
+ * n_items, n_buckets, n_tiles, n_split_arcs, n_post, n_arcs; null pointers are skipped */
+void carmel_hip_host_transpose(carmel_hip_host_lattices* h, uint64_t* dims6, void* buckets24, uint64_t* tile_base,
+                               uint16_t* b_arc, uint16_t* b_rank, uint32_t* b_src, uint16_t* t_pos, uint32_t* t_src,
+                               uint32_t* split_arcs, uint64_t* arc_off, uint64_t* slot_pos);
 void carmel_hip_host_free(carmel_hip_host_lattices* h);
 
 #ifdef __cplusplus

@@ -12,6 +12,9 @@ BUNDLE_DTYPE = np.dtype([("in_base", "<u8"), ("out_base", "<u8"), ("off_base", "
 assert BUNDLE_DTYPE.itemsize == 64
 
 
+TRANS_TILE = 16384
+TRANS_BUCKET_DTYPE = np.dtype([("item_base", "<u8"), ("n_items", "<u4"), ("arc_lo", "<u4"), ("n_arcs", "<u4"),
+                               ("flags", "<u4")])
 LANE_DTYPE = np.dtype([("stream_base", "<u8"), ("maxlen", "<u4"), ("n_lanes", "<u4"), ("pair_base", "<u4"),
                        ("max_states", "<u4"), ("pad", "<u8")])
 assert LANE_DTYPE.itemsize == 32
@@ -46,6 +49,20 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, la
     lib.carmel_hip_host_export_lanes(h, ptr(out["lane_groups"]), ptr(out["lane_fwd"]), ptr(out["lane_bwd"]),
                                      ptr(out["lane_pair"]), ptr(out["lane_nstates"]), ptr(out["lane_logw"]),
                                      ptr(out["lane_classes"]))
+    td = np.zeros(6, np.uint64)
+    null = C.c_void_p(None)
+    lib.carmel_hip_host_transpose(h, ptr(td), *([null] * 10))
+    ni, nbk, nt, nsp, npost, narc = (int(x) for x in td)
+    tr = dict(n_items=ni, n_post=npost, n_arcs=narc, buckets=np.zeros(nbk, TRANS_BUCKET_DTYPE),
+              tile_base=np.zeros(nt + 1 if nbk else 0, np.uint64), b_arc=np.zeros(ni if nbk else 0, np.uint16),
+              b_rank=np.zeros(ni if nbk else 0, np.uint16), b_src=np.zeros(ni if nbk else 0, np.uint32),
+              t_pos=np.zeros(ni if nbk else 0, np.uint16), t_src=np.zeros(ni if nbk else 0, np.uint32),
+              split_arcs=np.zeros(nsp, np.uint32), arc_off=np.zeros(narc + 1, np.uint64),
+              slot_pos=np.zeros(ni, np.uint64))
+    lib.carmel_hip_host_transpose(h, null, ptr(tr["buckets"]), ptr(tr["tile_base"]), ptr(tr["b_arc"]),
+                                  ptr(tr["b_rank"]), ptr(tr["b_src"]), ptr(tr["t_pos"]), ptr(tr["t_src"]),
+                                  ptr(tr["split_arcs"]), ptr(tr["arc_off"]), ptr(tr["slot_pos"]))
+    out["transpose"] = tr
     lib.carmel_hip_host_free(h)
     out.update(n_kept=int(dims[6]), n_cyclic=int(dims[7]), explored_states=int(dims[8]), explored_arcs=int(dims[9]))
     return out
@@ -173,3 +190,44 @@ def numpy_sweep(img, logw, n_pairs_total):
                 beta[s] = _lse(t)
                 np.add.at(counts, r[:, 1], np.exp(alpha[s] + t))
     return counts, plp
+
+
+def transpose_weights(tr, logw, n_wcache):
+    """numpy model of trans_w_bucket_kernel + trans_w_tile_kernel: arc-order weights -> wcache (position order)"""
+    x = np.zeros(tr["n_items"])
+    for b in tr["buckets"]:
+        lo, n = int(b["item_base"]), int(b["n_items"])
+        lds = logw[int(b["arc_lo"]):int(b["arc_lo"]) + int(b["n_arcs"])]
+        x[lo:lo + n] = lds[tr["b_arc"][lo:lo + n]]
+    wc = np.zeros(n_wcache)
+    for t in range(len(tr["tile_base"]) - 1):
+        p0 = t * TRANS_TILE
+        if p0 >= n_wcache:
+            break
+        lds = np.zeros(TRANS_TILE)
+        i0, i1 = int(tr["tile_base"][t]), int(tr["tile_base"][t + 1])
+        lds[tr["t_pos"][i0:i1]] = x[tr["t_src"][i0:i1]]
+        n = min(TRANS_TILE, n_wcache - p0)
+        wc[p0:p0 + n] = lds[:n]
+    return wc
+
+
+def transpose_counts(tr, post):
+    """numpy model of trans_c_tile_kernel + trans_c_bucket_kernel: posteriors (position order) -> per-arc sums"""
+    x = np.zeros(tr["n_items"])
+    for t in range(len(tr["tile_base"]) - 1):
+        p0 = t * TRANS_TILE
+        lds = post[p0:p0 + TRANS_TILE]
+        i0, i1 = int(tr["tile_base"][t]), int(tr["tile_base"][t + 1])
+        x[i0:i1] = lds[tr["t_pos"][i0:i1]]
+    counts = np.zeros(tr["n_arcs"])
+    for b in tr["buckets"]:
+        lo, n = int(b["item_base"]), int(b["n_items"])
+        lds = np.zeros(n)
+        lds[tr["b_rank"][lo:lo + n]] = x[tr["b_src"][lo:lo + n]]
+        if b["flags"] & 1:
+            counts[int(b["arc_lo"])] += lds.sum()
+        else:
+            for a in range(int(b["arc_lo"]), int(b["arc_lo"]) + int(b["n_arcs"])):
+                counts[a] = lds[int(tr["arc_off"][a]) - lo:int(tr["arc_off"][a + 1]) - lo].sum()
+    return counts

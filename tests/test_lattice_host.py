@@ -4,6 +4,7 @@ import pytest
 
 from carmel_amd import synth
 from carmel_amd.model import Corpus, Wfst
+import helpers as H
 from helpers import host_lattices, numpy_sweep
 
 
@@ -105,3 +106,37 @@ def test_cyclic_lattice_reference_order(oracle):
     counts, plp = numpy_sweep(img, w.logw, 1)
     np.testing.assert_allclose(plp[0], r["pair_logprob"][0], rtol=1e-12)
     np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-10, atol=1e-300)
+
+
+def test_blocked_transposition_tables():
+    """the two-pass LDS-blocked transposition moves exactly what the random gather / segmented sum would"""
+    from carmel_amd import synth
+    w = synth.random_wfst(3000, 6, seed=5)
+    c = synth.random_walk_corpus(w, 90000, min_arcs=3, max_arcs=8, seed=5, out_degree=6)
+    img = H.host_lattices(w, c, threads=4)
+    tr = img["transpose"]
+    assert len(tr["split_arcs"]) >= 1
+    assert tr["n_items"] == img["total_arcs"] and len(tr["buckets"]) > 0
+    n_post = tr["n_post"]
+    # arc of every valid position, from the arc-sorted slot list
+    arc_at = np.full(n_post, -1, np.int64)
+    for a in range(tr["n_arcs"]):
+        arc_at[tr["slot_pos"][int(tr["arc_off"][a]):int(tr["arc_off"][a + 1])]] = a
+    valid = arc_at >= 0
+    assert valid.sum() == tr["n_items"]
+    # buckets tile the arc-sorted order; a hub arc (here: those out of the start state, > 16384 uses) is split
+    assert int(tr["buckets"]["n_items"].sum()) == tr["n_items"]
+    assert (tr["buckets"]["n_items"] <= 16384).all() and (tr["buckets"]["n_arcs"] <= 16384).all()
+    assert len(tr["split_arcs"]) == int(((tr["arc_off"][1:] - tr["arc_off"][:-1]) > 16384).sum())
+    rng = np.random.default_rng(0)
+    logw = rng.normal(size=tr["n_arcs"])
+    wc = H.transpose_weights(tr, logw, n_post)
+    assert np.array_equal(wc[valid], logw[arc_at[valid]])
+    post = rng.random(n_post)
+    got = H.transpose_counts(tr, post)
+    want = np.bincount(arc_at[valid], weights=post[valid], minlength=tr["n_arcs"])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+    # the items of (bucket, tile) are one run in both orders: t_src is increasing inside a tile
+    for t in range(len(tr["tile_base"]) - 1):
+        seg = tr["t_src"][int(tr["tile_base"][t]):int(tr["tile_base"][t + 1])].astype(np.int64)
+        assert (np.diff(seg) > 0).all()

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) void fwd_k(const uint2* __restrict__ recs, cons
 #pragma unroll
   for (int j = 0; j < W; ++j)
 #pragma unroll
-    for (int u = 0; u < U; ++u) wq[j][u] = (FEAT & 4) ? logw[rq[j][u].y] : sw[(size_t)(j * U + u) * 64];
+    for (int u = 0; u < U; ++u) wq[j][u] = (FEAT & 16) ? wc[(size_t)((rq[j][u].x >> 10) & 0xfffff) * 64] : (FEAT & 4) ? logw[rq[j][u].y] : sw[(size_t)(j * U + u) * 64];
   Lse acc; acc.init();
   uint32_t d = 1;
   double prev = 0.0, sum = 0.0;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void fwd_k(const uint2* __restrict__ recs, cons
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t kk = kb + W * U + u;
-        wq[(j + W) % R][u] = (FEAT & 4) ? logw[rq[(j + W) % R][u].y] : sw[(size_t)(kk < rows ? kk : lastk) * 64];
+        wq[(j + W) % R][u] = (FEAT & 16) ? wc[(size_t)((rq[(j + W) % R][u].x >> 10) & 0xfffff) * 64] : (FEAT & 4) ? logw[rq[(j + W) % R][u].y] : sw[(size_t)(kk < rows ? kk : lastk) * 64];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -81,6 +81,59 @@ __global__ __launch_bounds__(64) void fwd_k(const uint2* __restrict__ recs, cons
     }
   }
   out[(size_t)blockIdx.x * 64 + lane] = prev + sum;
+}
+
+// backward pass: x words (4 B) + weights (8 B) streamed, beta chain, posterior exp + store
+template <int FEAT, int R>
+__global__ __launch_bounds__(64) void bwd_k(const uint32_t* __restrict__ xs, const double* __restrict__ wcache,
+                                             double* __restrict__ post, double* __restrict__ out, uint32_t rows) {
+  extern __shared__ double lds[];
+  constexpr int U = 4;
+  const int lane = threadIdx.x;
+  const uint32_t* b = xs + (size_t)blockIdx.x * rows * 64 + lane;
+  const double* wc = wcache + (size_t)blockIdx.x * rows * 64 + lane;
+  double* po = post + (size_t)blockIdx.x * rows * 64 + lane;
+  double* col = lds + lane;
+  const uint32_t lastk = rows - 1;
+  uint32_t xq[R][U];
+  double wq[R][U];
+#pragma unroll
+  for (int j = 0; j < R; ++j)
+#pragma unroll
+    for (int u = 0; u < U; ++u) { uint32_t k = j * U + u; size_t kk = (size_t)(k < rows ? k : lastk) * 64; xq[j][u] = b[kk]; wq[j][u] = wc[kk]; }
+  Lse acc; acc.init();
+  uint32_t s = rows - 1;
+  double next = 0.0, al = -1.0;
+  for (uint32_t k0 = 0; k0 + R * U <= rows; k0 += R * U) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint32_t kb = k0 + j * U;
+      double arg[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t x = xq[j][u];
+        const uint32_t dst = x & SMASK;
+        const double b_dst = (dst == s + 1 || !(FEAT & 2)) ? next : col[dst * 64];
+        const double t = (x & VALID) ? wq[j][u] + b_dst : NEG_INF;
+        acc.add(t);
+        arg[u] = al + t;
+        if (x & LAST) {
+          next = acc.value();
+          if (FEAT & 2) col[s * 64] = next;
+          acc.init();
+          if (s > 0) { --s; if (FEAT & 2) al = col[s * 64]; }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double pu = (FEAT & 1) ? exp(arg[u]) : arg[u];
+        if (FEAT & 8) po[(size_t)(kb + u) * 64] = pu; else next += pu * 1e-300;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { uint32_t k = kb + R * U + u; size_t kk = (size_t)(k < rows ? k : lastk) * 64; xq[j][u] = b[kk]; wq[j][u] = wc[kk]; }
+    }
+  }
+  out[(size_t)blockIdx.x * 64 + lane] = next;
 }
 
 int main() {
@@ -116,6 +169,21 @@ int main() {
   RUN(15, 4, "+ wcache store (coalesced, reversed row)       R=4")
   RUN(4, 4, "records + gather, plain sum                    R=4")
   RUN(4, 8, "records + gather, plain sum                    R=8")
+  RUN(19, 4, "records + weights from wcache at record pos (reversed) R=4")
+  {
+    std::vector<uint32_t> hx(N);
+    for (uint32_t b = 0; b < NB; ++b) for (uint32_t k = 0; k < rows; ++k) for (uint32_t l = 0; l < 64; ++l)
+      hx[((size_t)b * rows + k) * 64 + l] = (rows - 1 - k + 1 > rows - 1 ? rows - 1 : rows - k) | VALID | LAST;
+    uint32_t* xs; double* post;
+    CK(hipMalloc(&xs, N * 4)); CK(hipMalloc(&post, N * 8));
+    CK(hipMemcpy(xs, hx.data(), N * 4, hipMemcpyHostToDevice));
+#define RUNB(FEAT, R, label) time(label, [&] { hipLaunchKernelGGL((bwd_k<FEAT, R>), dim3(NB), dim3(64), lds, 0, xs, seqw, post, out, rows); });
+    RUNB(0, 4, "bwd: x + weights streamed, chain only (no LDS/exp/store)  R=4")
+    RUNB(2, 4, "bwd: + LDS column                                         R=4")
+    RUNB(3, 4, "bwd: + exp                                                R=4")
+    RUNB(11, 4, "bwd: + posterior store                                    R=4")
+    RUNB(8, 4, "bwd: store without exp/LDS                                R=4")
+  }
   RUN(15, 2, "everything                                     R=2")
   RUN(15, 8, "everything                                     R=8")
   return 0;
