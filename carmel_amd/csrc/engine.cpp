@@ -184,6 +184,14 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     std::vector<uint32_t>().swap(L.t_t_src);
   }
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
+  {
+    std::vector<double> pw(t->corpus.n_pairs);
+    for (uint64_t p = 0; p < t->corpus.n_pairs; ++p)
+      pw[p] = L.has_deriv[p] ? (t->corpus.weight.empty() ? 1.0 : t->corpus.weight[p]) : -1.0;
+    HIPCHK(t->pair_w.upload(pw, s));
+    HIPCHK(t->scalar_partial.alloc(3 * 256));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   bool need_val = false, need_val2 = false;
   for (auto& lc : L.classes) {
     if (lc.serial || lc.max_states == 0) need_val = true;
@@ -511,6 +519,8 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   R.counts = t->counts_ptr();
   R.n_arcs = t->w.n_arcs;
   R.n_hot_chunks = t->hot_chunks.n / 3;
+  HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
+                        t->counts_ptr() + t->w.n_arcs, s));
   if (t->use_transpose)
     HIPCHK(launch_transpose_counts(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
   else

@@ -152,14 +152,11 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   }
   if (A.trace) t_mid = __builtin_readcyclecounter();
   // ---------- ln p(pair), corpus scalars, beta at the goal ----------
-  double s_lp = 0.0, s_wlp = 0.0;
   double next = NEG_INF;  // beta[s+1] in a register
   if (active) {
     const double lp = col[(S - 1) * 64];
     const double lwt = A.lane_logw[g.pair_base + lane];
-    A.pair_logprob[A.lane_pair[g.pair_base + lane]] = lp;
-    s_lp = lp;
-    s_wlp = lp * exp(lwt);
+    A.pair_logprob[A.lane_pair[g.pair_base + lane]] = lp;  // the corpus scalars are reduced from these afterwards
     next = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
     col[(S - 1) * 64] = next;
   }
@@ -225,14 +222,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
 #undef LANE_BWD_STEP
 #undef LANE_W
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    s_lp += __shfl_down(s_lp, o, 64);
-    s_wlp += __shfl_down(s_wlp, o, 64);
-  }
   if (lane == 0) {
-    atomic_add_f64(A.scalars + 0, s_lp);
-    atomic_add_f64(A.scalars + 1, s_wlp);
-    atomic_add_f64(A.scalars + 2, (double)g.n_lanes);
     if (A.trace) {
       unsigned long long* o = A.trace + (size_t)(A.first_group + blockIdx.x) * 16;
       o[0] = t_start;
@@ -282,14 +272,11 @@ __global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
   }
   // per pair: ln p(pair) = alpha[goal]; beta[goal] = ln(weight) - ln p(pair) folds "* weight / prob"
   // (derivations.h:445) into the sweep.  Goals have no out-arcs, so nothing else reads their alpha.
-  double s_lp = 0.0, s_wlp = 0.0;
   for (uint32_t p = tid; p < d.n_pairs; p += BLOCK) {
     const uint32_t f = A.pair_final[d.pair_base + p];
     const double lp = val[f];
     const double lwt = A.pair_logw[d.pair_base + p];
-    A.pair_logprob[A.pair_id[d.pair_base + p]] = lp;
-    s_lp += lp;
-    s_wlp += lp * exp(lwt);
+    A.pair_logprob[A.pair_id[d.pair_base + p]] = lp;  // the corpus scalars are reduced from these afterwards
     val[f] = (lp == NEG_INF) ? NEG_INF : lwt - lp;
   }
   __syncthreads();
@@ -312,15 +299,6 @@ __global__ __launch_bounds__(BLOCK) void sweep_bundle_kernel(SweepArgs A) {
     }
     __syncthreads();
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    s_lp += __shfl_down(s_lp, o, 64);
-    s_wlp += __shfl_down(s_wlp, o, 64);
-  }
-  if ((tid & 63) == 0 && (s_lp != 0.0 || s_wlp != 0.0)) {
-    atomic_add_f64(A.scalars + 0, s_lp);
-    atomic_add_f64(A.scalars + 1, s_wlp);
-  }
-  if (tid == 0) atomic_add_f64(A.scalars + 2, (double)d.n_pairs);
 }
 
 // Cyclic lattices (derivations.h:726-728 "Forward/backward will miss some paths"): one lane per lattice walks
@@ -366,9 +344,45 @@ __global__ void sweep_serial_kernel(SweepArgs A, uint32_t n_bundles) {
       const uint2 r = oa[a];
       post[a] = (prob != NEG_INF) ? exp(A.logw[r.y] + f[s] + bb[r.x] + lwt - prob) : 0.0;
     }
-  atomic_add_f64(A.scalars + 0, prob);
-  atomic_add_f64(A.scalars + 1, prob * exp(lwt));
-  atomic_add_f64(A.scalars + 2, 1.0);
+}
+
+// ---------------- corpus scalars (train.cc:326-332): sum ln p, sum weight * ln p, pairs ----------------
+// Reduced from pair_logprob[] in a fixed order (bit-reproducible).  Every wave adding into three shared doubles would
+// serialise ~3 atomics per wave on one address: at config-4 scale that alone held the sweep kernel at 0.4 ms.
+// pair_w[p] = the pair's weight, negative for pairs without a derivation (dropped from the corpus).
+#define SCALAR_BLOCKS 256
+__global__ __launch_bounds__(256) void scalars_partial_kernel(const double* __restrict__ pair_logprob,
+                                                              const double* __restrict__ pair_w, uint64_t n_pairs,
+                                                              double* __restrict__ partial) {
+  __shared__ double sh[3][4];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < n_pairs; p += (uint64_t)SCALAR_BLOCKS * 256) {
+    const double w = pair_w[p];
+    if (w < 0.0) continue;
+    const double lp = pair_logprob[p];
+    a += lp;
+    b += lp * w;
+    c += 1.0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_down(a, o, 64);
+    b += __shfl_down(b, o, 64);
+    c += __shfl_down(c, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+    sh[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+}
+__global__ void scalars_final_kernel(const double* __restrict__ partial, double* __restrict__ scalars) {
+  if (threadIdx.x < 3) {
+    double v = 0.0;
+    for (int k = 0; k < SCALAR_BLOCKS; ++k) v += partial[k * 3 + threadIdx.x];
+    scalars[threadIdx.x] = v;
+  }
 }
 
 // ---------------- expected counts: per-arc sum of posteriors ----------------
@@ -710,6 +724,12 @@ hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream) {
   return hipGetLastError();
 }
 
+hipError_t launch_scalars(const double* pair_logprob, const double* pair_w, uint64_t n_pairs, double* partial,
+                          double* scalars, hipStream_t s) {
+  hipLaunchKernelGGL(scalars_partial_kernel, dim3(SCALAR_BLOCKS), dim3(256), 0, s, pair_logprob, pair_w, n_pairs, partial);
+  hipLaunchKernelGGL(scalars_final_kernel, dim3(1), dim3(64), 0, s, partial, scalars);
+  return hipGetLastError();
+}
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
   if (!n) return hipSuccess;
   hipLaunchKernelGGL(fill_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, v, n);

@@ -99,6 +99,9 @@ hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc,
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
 hipError_t launch_transpose_weights(const TransArgs& T, hipStream_t stream);
 hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream);
+// partial: 3 * 256 doubles of scratch
+hipError_t launch_scalars(const double* pair_logprob, const double* pair_w, uint64_t n_pairs, double* partial,
+                          double* scalars, hipStream_t s);
 hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream);
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);

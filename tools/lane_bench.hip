@@ -136,6 +136,92 @@ __global__ __launch_bounds__(64) void bwd_k(const uint32_t* __restrict__ xs, con
   out[(size_t)blockIdx.x * 64 + lane] = next;
 }
 
+// forward (weights from wcache at the record's position) and backward in ONE kernel, as the product kernel does
+template <int R>
+__global__ __launch_bounds__(64) void fused_k(const uint2* __restrict__ recs, const uint32_t* __restrict__ xs,
+                                               const double* __restrict__ wcache, double* __restrict__ post,
+                                               double* __restrict__ out, uint32_t rows) {
+  extern __shared__ double lds[];
+  constexpr int U = 4, W = R / 2;
+  const int lane = threadIdx.x;
+  const uint2* f = recs + (size_t)blockIdx.x * rows * 64 + lane;
+  const uint32_t* b = xs + (size_t)blockIdx.x * rows * 64 + lane;
+  const double* wc = wcache + (size_t)blockIdx.x * rows * 64 + lane;
+  double* po = post + (size_t)blockIdx.x * rows * 64 + lane;
+  double* col = lds + lane;
+  const uint32_t lastk = rows - 1;
+  col[0] = 0.0;
+  double prev = 0.0;
+  {
+    uint2 rq[R][U];
+    double wq[R][U];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) { uint32_t k = j * U + u; rq[j][u] = f[(size_t)(k < rows ? k : lastk) * 64]; }
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) wq[j][u] = wc[(size_t)((rq[j][u].x >> 10) & 0xfffff) * 64];
+    Lse acc; acc.init();
+    uint32_t d = 1;
+    for (uint32_t k0 = 0; k0 + R * U <= rows; k0 += R * U) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint32_t kb = k0 + j * U;
+#pragma unroll
+        for (int u = 0; u < U; ++u) wq[(j + W) % R][u] = wc[(size_t)((rq[(j + W) % R][u].x >> 10) & 0xfffff) * 64];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t x = rq[j][u].x;
+          const double w = wq[j][u];
+          const uint32_t src = x & SMASK;
+          const double a_src = (src + 1 == d) ? prev : col[src * 64];
+          acc.add((x & VALID) ? a_src + w : NEG_INF);
+          if (x & LAST) { prev = acc.value(); col[d * 64] = prev; ++d; acc.init(); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { uint32_t k = kb + R * U + u; rq[j][u] = f[(size_t)(k < rows ? k : lastk) * 64]; }
+      }
+    }
+  }
+  double next = -prev;
+  col[rows * 64] = next;
+  {
+    uint32_t xq[R][U];
+    double wq[R][U];
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+#pragma unroll
+      for (int u = 0; u < U; ++u) { uint32_t k = j * U + u; size_t kk = (size_t)(k < rows ? k : lastk) * 64; xq[j][u] = b[kk]; wq[j][u] = wc[kk]; }
+    Lse acc; acc.init();
+    uint32_t s = rows - 1;
+    double al = col[s * 64];
+    for (uint32_t k0 = 0; k0 + R * U <= rows; k0 += R * U) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const uint32_t kb = k0 + j * U;
+        double arg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t x = xq[j][u];
+          const uint32_t dst = x & SMASK;
+          const double b_dst = (dst == s + 1) ? next : col[dst * 64];
+          const double t = (x & VALID) ? wq[j][u] + b_dst : NEG_INF;
+          acc.add(t);
+          arg[u] = al + t;
+          if (x & LAST) { next = acc.value(); col[s * 64] = next; acc.init(); if (s > 0) { --s; al = col[s * 64]; } }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) po[(size_t)(kb + u) * 64] = exp(arg[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { uint32_t k = kb + R * U + u; size_t kk = (size_t)(k < rows ? k : lastk) * 64; xq[j][u] = b[kk]; wq[j][u] = wc[kk]; }
+      }
+    }
+  }
+  out[(size_t)blockIdx.x * 64 + lane] = next;
+}
+
 int main() {
   const uint32_t rows = 32, NB = 15625;  // 1M lattices of 32 arcs
   const size_t N = (size_t)NB * rows * 64, T = 10000000;
@@ -183,6 +269,8 @@ int main() {
     RUNB(3, 4, "bwd: + exp                                                R=4")
     RUNB(11, 4, "bwd: + posterior store                                    R=4")
     RUNB(8, 4, "bwd: store without exp/LDS                                R=4")
+    time("fused forward(wcache) + backward, one kernel              R=4", [&] { hipLaunchKernelGGL((fused_k<4>), dim3(NB), dim3(64), lds + 512, 0, recs, xs, seqw, post, out, rows); });
+    time("fused forward(wcache) + backward, one kernel              R=2", [&] { hipLaunchKernelGGL((fused_k<2>), dim3(NB), dim3(64), lds + 512, 0, recs, xs, seqw, post, out, rows); });
   }
   RUN(15, 2, "everything                                     R=2")
   RUN(15, 8, "everything                                     R=8")
