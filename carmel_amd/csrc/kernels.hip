@@ -566,9 +566,28 @@ __global__ void fill_f64_kernel(double* p, double v, uint64_t n) {
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const TransBucket B = T.buckets[blockIdx.x];
-  for (uint32_t k = threadIdx.x; k < B.n_arcs; k += 1024) lds[k] = T.logw[B.arc_lo + k];
+  // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
+  // 16384 items): one dependent round trip per phase instead of one per iteration
+  double w[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t a = threadIdx.x + k * 1024;
+    w[k] = a < B.n_arcs ? T.logw[B.arc_lo + a] : 0.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = w[k];
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) T.x[B.item_base + j] = lds[T.b_arc[B.item_base + j]];
+  uint16_t ia[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t j = threadIdx.x + k * 1024;
+    ia[k] = j < B.n_items ? T.b_arc[B.item_base + j] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t j = threadIdx.x + k * 1024;
+    if (j < B.n_items) T.x[B.item_base + j] = lds[ia[k]];
+  }
 }
 // weights, pass 2: one workgroup per tile of positions.  The tile's items arrive as runs (one per bucket), are placed
 // in LDS at their position and the tile is written to wcache in one coalesced sweep.
@@ -577,22 +596,55 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
-  for (uint32_t k = threadIdx.x; k < np; k += 1024) lds[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = 0.0;
   __syncthreads();
-  const uint64_t i0 = T.tile_base[blockIdx.x], i1 = T.tile_base[blockIdx.x + 1];
-  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) lds[T.t_pos[i]] = T.x[T.t_src[i]];
+  const uint64_t i0 = T.tile_base[blockIdx.x];
+  const uint32_t ni = (uint32_t)(T.tile_base[blockIdx.x + 1] - i0);
+  uint32_t src[16];
+  uint16_t pos[16];
+  double v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t i = threadIdx.x + k * 1024;
+    src[k] = i < ni ? T.t_src[i0 + i] : 0u;
+    pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) v[k] = T.x[src[k]];
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (threadIdx.x + k * 1024 < ni) lds[pos[k]] = v[k];
   __syncthreads();
-  for (uint32_t k = threadIdx.x; k < np; k += 1024) T.wcache[p0 + k] = lds[k];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t q = threadIdx.x + k * 1024;
+    if (q < np) T.wcache[p0 + q] = lds[q];
+  }
 }
 // counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in bucket-major runs.
 __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
-  for (uint32_t k = threadIdx.x; k < np; k += 1024) lds[k] = T.post[p0 + k];
+  const uint64_t i0 = T.tile_base[blockIdx.x];
+  const uint32_t ni = (uint32_t)(T.tile_base[blockIdx.x + 1] - i0);
+  double v[16];
+  uint16_t pos[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t q = threadIdx.x + k * 1024;
+    v[k] = q < np ? T.post[p0 + q] : 0.0;
+    pos[k] = q < ni ? T.t_pos[i0 + q] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = v[k];
   __syncthreads();
-  const uint64_t i0 = T.tile_base[blockIdx.x], i1 = T.tile_base[blockIdx.x + 1];
-  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) T.x[i] = lds[T.t_pos[i]];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t i = threadIdx.x + k * 1024;
+    if (i < ni) T.x[i0 + i] = lds[pos[k]];
+  }
 }
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
 // then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
@@ -600,10 +652,27 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   __shared__ double part[16];
+  __shared__ uint32_t big[512];
+  __shared__ uint32_t n_big;
   const TransBucket B = T.buckets[blockIdx.x];
-  for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) lds[T.b_rank[B.item_base + j]] = T.x[T.b_src[B.item_base + j]];
+  {
+    uint32_t src[16];
+    uint16_t rk[16];
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint32_t j = threadIdx.x + k * 1024;
+      src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
+      rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = T.x[src[k]];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+      if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
+  }
   __syncthreads();
-  if (B.flags & TRANS_SPLIT) {
+  if (B.flags & TRANS_SINGLE) {
     double v = 0.0;
     for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) v += lds[j];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -612,15 +681,39 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     if (threadIdx.x == 0) {
       double tot = 0.0;
       for (int k = 0; k < 16; ++k) tot += part[k];
-      atomic_add_f64(T.counts + B.arc_lo, tot);
+      if (B.flags & TRANS_SPLIT)
+        atomic_add_f64(T.counts + B.arc_lo, tot);
+      else
+        T.counts[B.arc_lo] = tot;
     }
     return;
   }
+  // one thread per arc; arcs with more than 32 items are left to whole waves afterwards (fixed summation order
+  // either way)
+  if (threadIdx.x == 0) n_big = 0;
+  __syncthreads();
   for (uint32_t a = threadIdx.x; a < B.n_arcs; a += 1024) {
     const uint32_t r0 = (uint32_t)(T.arc_off[B.arc_lo + a] - B.item_base), r1 = (uint32_t)(T.arc_off[B.arc_lo + a + 1] - B.item_base);
+    if (r1 - r0 > 32) {
+      const uint32_t q = atomicAdd(&n_big, 1u);
+      if (q < 512) {
+        big[q] = a;
+        continue;
+      }
+    }
     double v = 0.0;
     for (uint32_t r = r0; r < r1; ++r) v += lds[r];
     T.counts[B.arc_lo + a] = v;
+  }
+  __syncthreads();
+  const uint32_t nb = n_big < 512 ? n_big : 512;
+  for (uint32_t q = threadIdx.x >> 6; q < nb; q += 16) {
+    const uint32_t a = big[q];
+    const uint32_t r0 = (uint32_t)(T.arc_off[B.arc_lo + a] - B.item_base), r1 = (uint32_t)(T.arc_off[B.arc_lo + a + 1] - B.item_base);
+    double v = 0.0;
+    for (uint32_t r = r0 + (threadIdx.x & 63); r < r1; r += 64) v += lds[r];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) T.counts[B.arc_lo + a] = v;
   }
 }
 __global__ void zero_list_kernel(double* p, const uint32_t* idx, uint32_t n) {

@@ -878,18 +878,21 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
     uint64_t a = 0;
     while (a < n_arcs) {
       uint64_t c = out.arc_off[a + 1] - out.arc_off[a];
-      if (c > TRANS_BUCKET) {
-        out.t_split_arcs.push_back((uint32_t)a);
+      if (c > TRANS_HEAVY) {
+        // a hub arc gets buckets of its own (one if it fits, else pieces whose sums are added atomically): its sum
+        // is a workgroup-wide reduction instead of one thread's serial loop
+        const bool split = c > TRANS_BUCKET;
+        if (split) out.t_split_arcs.push_back((uint32_t)a);
         for (uint64_t g = out.arc_off[a]; g < out.arc_off[a + 1]; g += TRANS_BUCKET)
           out.t_buckets.push_back(TransBucket{g, (uint32_t)std::min<uint64_t>(TRANS_BUCKET, out.arc_off[a + 1] - g),
-                                              (uint32_t)a, 1u, TRANS_SPLIT});
+                                              (uint32_t)a, 1u, TRANS_SINGLE | (split ? TRANS_SPLIT : 0u)});
         ++a;
         continue;
       }
       uint64_t e = a, items = 0;
       while (e < n_arcs && e - a < TRANS_BUCKET) {
         uint64_t ce = out.arc_off[e + 1] - out.arc_off[e];
-        if (ce > TRANS_BUCKET || items + ce > TRANS_BUCKET) break;
+        if (ce > TRANS_HEAVY || items + ce > TRANS_BUCKET) break;
         items += ce;
         ++e;
       }
@@ -921,7 +924,7 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
           uint64_t a = B.arc_lo;
           // arc of rank r: walk arc_off (ranks are arc-sorted); build rank -> local arc first
           std::vector<uint16_t> arc_of_rank(B.n_items);
-          if (B.flags & TRANS_SPLIT) {
+          if (B.flags & TRANS_SINGLE) {
             std::fill(arc_of_rank.begin(), arc_of_rank.end(), (uint16_t)0);
           } else {
             for (uint32_t r = 0; r < B.n_items; ++r) {

@@ -225,7 +225,7 @@ def transpose_counts(tr, post):
         lo, n = int(b["item_base"]), int(b["n_items"])
         lds = np.zeros(n)
         lds[tr["b_rank"][lo:lo + n]] = x[tr["b_src"][lo:lo + n]]
-        if b["flags"] & 1:
+        if b["flags"] & 2:  # TRANS_SINGLE: a hub arc's own bucket(s); & 1 = one of several pieces
             counts[int(b["arc_lo"])] += lds.sum()
         else:
             for a in range(int(b["arc_lo"]), int(b["arc_lo"]) + int(b["n_arcs"])):

@@ -127,7 +127,9 @@ def test_blocked_transposition_tables():
     # buckets tile the arc-sorted order; a hub arc (here: those out of the start state, > 16384 uses) is split
     assert int(tr["buckets"]["n_items"].sum()) == tr["n_items"]
     assert (tr["buckets"]["n_items"] <= 16384).all() and (tr["buckets"]["n_arcs"] <= 16384).all()
-    assert len(tr["split_arcs"]) == int(((tr["arc_off"][1:] - tr["arc_off"][:-1]) > 16384).sum())
+    uses = tr["arc_off"][1:] - tr["arc_off"][:-1]
+    assert len(tr["split_arcs"]) == int((uses > 16384).sum())
+    assert int(((tr["buckets"]["flags"] & 2) != 0).sum()) >= int((uses > 2048).sum())
     rng = np.random.default_rng(0)
     logw = rng.normal(size=tr["n_arcs"])
     wc = H.transpose_weights(tr, logw, n_post)
