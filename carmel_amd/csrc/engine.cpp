@@ -266,6 +266,9 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
   }
   t->n_norm_groups = add.size();
   t->h_norm_of = norm_of;
+  t->all_grouped = true;
+  for (uint64_t k = 0; k < n; ++k)
+    if (norm_of[k] == 0xffffffffu) t->all_grouped = false;
   t->h_group_add = add;
   {
     // members of every group, contiguous (counting sort by group id); big groups listed separately
@@ -392,7 +395,9 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.big_groups = t->big_groups.p;
   M.n_groups = t->n_norm_groups;
   M.n_big = t->big_groups.n;
-  M.gscale = t->gscale.p;
+  if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
+  M.max_partial = t->max_partial.p;
+  M.all_grouped = t->all_grouped ? 1 : 0;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();
   M.save_old = save_old;

@@ -84,6 +84,8 @@ struct carmel_hip_trainer {
   DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos;
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
   DevBuf<double> t_x;
+  DevBuf<unsigned long long> max_partial;  // M-step scratch
+  bool all_grouped = true;                 // every parameter is in a norm group
   DevBuf<double> pair_w;          // pair weight by pair id, < 0 for pairs dropped at build_lattices
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction
   bool use_transpose = false;

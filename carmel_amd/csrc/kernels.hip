@@ -430,13 +430,45 @@ __device__ __forceinline__ double mstep_value(const MstepArgs& M, uint64_t k, in
   return M.add_count ? v + M.add_count[ng] : v;
 }
 
-// pass 0: per norm group, the sum over normal arcs and over locked arcs (fst.cc:117-131).  Members of a group are
-// listed in norm_perm[group_off[g] .. group_off[g+1]); one thread per small group, no atomics.
-__global__ void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
-  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < M.n_groups;
-       g += (uint64_t)gridDim.x * blockDim.x) {
+// ln((1 - sum of locked) / sum of normal), kept as a difference of logs so that a lone arc (v == sum) comes out as
+// exactly 1 (fst.cc:213-230); -inf when nothing is left to distribute
+__device__ __forceinline__ double mstep_scale(double sn, double sl) {
+  const double remain = 1.0 - sl;
+  return (remain > 0.0 && sn > 0.0) ? (sl == 0.0 ? -log(sn) : log(remain) - log(sn)) : NEG_INF;
+}
+// new weight of member k (locked arcs keep v) and its |change| in the real domain (weight.h:837-856)
+__device__ __forceinline__ double mstep_update(const MstepArgs& M, uint64_t k, int use_counts, uint32_t g, double sc,
+                                               double& mx) {
+  const double old = M.logw[k];
+  if (M.save_old) M.old_logw[k] = old;
+  const double v = mstep_value(M, k, use_counts, g);
+  double nw;
+  if (M.group[k] == 0u) {
+    nw = v > 0.0 ? log(v) : NEG_INF;
+  } else {
+    nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
+    mx = fmax(mx, fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k])));
+  }
+  return nw;
+}
+__device__ __forceinline__ void mstep_block_max(double mx, unsigned long long* out) {
+  __shared__ double shm[4];
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (unsigned long long)__double_as_longlong(fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3])));
+}
+// The M-step of WFST::normalize (fst.cc:86-244) in one pass: one thread per norm group sums its members (listed in
+// norm_perm[group_off[g] .. group_off[g+1]), contiguous for the per-state groups of JOINT / CONDITIONAL) and then
+// writes their new weights -- no per-group scale array, no second read of the counts, no atomics.  The largest
+// |change| leaves as one partial per workgroup (every wave pushing an atomicMax onto one address is the same
+// serialisation that the corpus scalars had).
+#define MSTEP_GRID 2048
+__global__ __launch_bounds__(256) void mstep_fused_kernel(MstepArgs M, int use_counts) {
+  double mx = 0.0;
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < M.n_groups; g += (uint64_t)MSTEP_GRID * 256) {
     const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
-    if (j1 - j0 > MSTEP_BIG_GROUP) continue;  // handled by mstep_big_group_sum_kernel
+    if (j1 - j0 > MSTEP_BIG_GROUP) continue;  // mstep_big_group_kernel
     double sn = 0.0, sl = 0.0;
     for (uint64_t j = j0; j < j1; ++j) {
       const uint64_t k = M.norm_perm[j];
@@ -446,14 +478,18 @@ __global__ void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
       else
         sn += v;
     }
-    const double remain = 1.0 - sl;
-    // ln(remain) - ln(sum), kept as a difference of logs so that a lone arc (v == sum) comes out as exactly 1
-    M.gscale[g] = (remain > 0.0 && sn > 0.0) ? (sl == 0.0 ? -log(sn) : log(remain) - log(sn)) : NEG_INF;  // fst.cc:213-230
+    const double sc = mstep_scale(sn, sl);
+    for (uint64_t j = j0; j < j1; ++j) {
+      const uint64_t k = M.norm_perm[j];
+      M.logw[k] = mstep_update(M, k, use_counts, (uint32_t)g, sc, mx);
+    }
   }
+  mstep_block_max(mx, M.max_partial + blockIdx.x);
 }
 // big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
-__global__ __launch_bounds__(256) void mstep_big_group_sum_kernel(MstepArgs M, int use_counts) {
+__global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int use_counts) {
   __shared__ double sh[2][4];
+  __shared__ double sc_sh;
   const uint64_t g = M.big_groups[blockIdx.x];
   const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
   double sn = 0.0, sl = 0.0;
@@ -474,36 +510,31 @@ __global__ __launch_bounds__(256) void mstep_big_group_sum_kernel(MstepArgs M, i
     sh[1][threadIdx.x >> 6] = sl;
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const double tn = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
-    const double tl = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
-    const double remain = 1.0 - tl;
-    M.gscale[g] = (remain > 0.0 && tn > 0.0) ? (tl == 0.0 ? -log(tn) : log(remain) - log(tn)) : NEG_INF;
-  }
-}
-
-// pass 1: w = (1 - reserved) * v / sum for normal arcs (fst.cc:213-230); locked arcs keep v; max |new - old|
-__global__ void mstep_normalize_kernel(MstepArgs M, int use_counts) {
+  if (threadIdx.x == 0) sc_sh = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  __syncthreads();
+  const double sc = sc_sh;
   double mx = 0.0;
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint32_t ng = M.norm_of[k];
-    const double old = M.logw[k];
-    if (M.save_old) M.old_logw[k] = old;
-    if (ng == 0xffffffffu) continue;  // member normalised by NONE keeps its weights (cascade.h:339-350)
-    const double v = mstep_value(M, k, use_counts, ng);
-    double nw;
-    if (M.group[k] == 0u) {
-      nw = v > 0.0 ? log(v) : NEG_INF;
-    } else {
-      const double sc = M.gscale[ng];
-      nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
-      const double ch = fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k]));
-      mx = fmax(mx, ch);
-    }
-    M.logw[k] = nw;
+  for (uint64_t j = j0 + threadIdx.x; j < j1; j += 256) {
+    const uint64_t k = M.norm_perm[j];
+    M.logw[k] = mstep_update(M, k, use_counts, (uint32_t)g, sc, mx);
   }
-  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
-  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomicMax(M.max_change_bits, (unsigned long long)__double_as_longlong(mx));
+  mstep_block_max(mx, M.max_partial + MSTEP_GRID + blockIdx.x);
+}
+__global__ __launch_bounds__(256) void mstep_max_final_kernel(const unsigned long long* partial, uint64_t n,
+                                                              unsigned long long* bits) {
+  __shared__ unsigned long long shm[4];
+  unsigned long long m = 0;  // non-negative doubles order like their bit patterns
+  for (uint64_t k = threadIdx.x; k < n; k += 256) m = partial[k] > m ? partial[k] : m;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_down(m, o, 64);
+    m = other > m ? other : m;
+  }
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) m = shm[k] > m ? shm[k] : m;
+    atomicMax(bits, m);
+  }
 }
 
 // overrelax (train.cc:157-171): w = old * (em/old)^rate for unlocked arcs with old > 0
@@ -830,9 +861,16 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
-  if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
-  if (M.n_big) hipLaunchKernelGGL(mstep_big_group_sum_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
-  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
+  // parameters outside every norm group (a cascade member normalised by NONE) keep their weight; only their
+  // "previous weight" copy has to be refreshed
+  if (M.save_old && !M.all_grouped) {
+    hipError_t e = hipMemcpyAsync(M.old_logw, M.logw, M.n * sizeof(double), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(mstep_fused_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
+  if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
+  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID + M.n_big,
+                     M.max_change_bits);
   return hipGetLastError();
 }
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,
