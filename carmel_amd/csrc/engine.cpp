@@ -397,6 +397,7 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.n_big = t->big_groups.n;
   if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
   M.max_partial = t->max_partial.p;
+  M.gscale = t->gscale.p;
   M.all_grouped = t->all_grouped ? 1 : 0;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();

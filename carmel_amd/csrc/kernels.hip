@@ -464,9 +464,10 @@ __device__ __forceinline__ void mstep_block_max(double mx, unsigned long long* o
 // |change| leaves as one partial per workgroup (every wave pushing an atomicMax onto one address is the same
 // serialisation that the corpus scalars had).
 #define MSTEP_GRID 2048
-__global__ __launch_bounds__(256) void mstep_fused_kernel(MstepArgs M, int use_counts) {
-  double mx = 0.0;
-  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < M.n_groups; g += (uint64_t)MSTEP_GRID * 256) {
+// pass 0, one thread per norm group: gscale[g] from the sums over its normal and locked members (listed in
+// norm_perm[group_off[g] .. group_off[g+1]), contiguous for the per-state groups of JOINT / CONDITIONAL); no atomics
+__global__ __launch_bounds__(256) void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < M.n_groups; g += (uint64_t)gridDim.x * 256) {
     const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
     if (j1 - j0 > MSTEP_BIG_GROUP) continue;  // mstep_big_group_kernel
     double sn = 0.0, sl = 0.0;
@@ -478,18 +479,26 @@ __global__ __launch_bounds__(256) void mstep_fused_kernel(MstepArgs M, int use_c
       else
         sn += v;
     }
-    const double sc = mstep_scale(sn, sl);
-    for (uint64_t j = j0; j < j1; ++j) {
-      const uint64_t k = M.norm_perm[j];
-      M.logw[k] = mstep_update(M, k, use_counts, (uint32_t)g, sc, mx);
+    M.gscale[g] = mstep_scale(sn, sl);
+  }
+}
+// pass 1, one thread per parameter (coalesced): the new weight; the largest |change| leaves as one partial per
+// workgroup (every wave pushing an atomicMax onto one address is the same serialisation the corpus scalars had)
+__global__ __launch_bounds__(256) void mstep_normalize_kernel(MstepArgs M, int use_counts) {
+  double mx = 0.0;
+  for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < M.n; k += (uint64_t)MSTEP_GRID * 256) {
+    const uint32_t ng = M.norm_of[k];
+    if (ng == 0xffffffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
+      if (M.save_old) M.old_logw[k] = M.logw[k];
+      continue;
     }
+    M.logw[k] = mstep_update(M, k, use_counts, ng, M.gscale[ng], mx);
   }
   mstep_block_max(mx, M.max_partial + blockIdx.x);
 }
-// big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
+// pass 0 for big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
 __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int use_counts) {
   __shared__ double sh[2][4];
-  __shared__ double sc_sh;
   const uint64_t g = M.big_groups[blockIdx.x];
   const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
   double sn = 0.0, sl = 0.0;
@@ -510,15 +519,7 @@ __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int u
     sh[1][threadIdx.x >> 6] = sl;
   }
   __syncthreads();
-  if (threadIdx.x == 0) sc_sh = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
-  __syncthreads();
-  const double sc = sc_sh;
-  double mx = 0.0;
-  for (uint64_t j = j0 + threadIdx.x; j < j1; j += 256) {
-    const uint64_t k = M.norm_perm[j];
-    M.logw[k] = mstep_update(M, k, use_counts, (uint32_t)g, sc, mx);
-  }
-  mstep_block_max(mx, M.max_partial + MSTEP_GRID + blockIdx.x);
+  if (threadIdx.x == 0) M.gscale[g] = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
 }
 __global__ __launch_bounds__(256) void mstep_max_final_kernel(const unsigned long long* partial, uint64_t n,
                                                               unsigned long long* bits) {
@@ -861,15 +862,10 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
-  // parameters outside every norm group (a cascade member normalised by NONE) keep their weight; only their
-  // "previous weight" copy has to be refreshed
-  if (M.save_old && !M.all_grouped) {
-    hipError_t e = hipMemcpyAsync(M.old_logw, M.logw, M.n * sizeof(double), hipMemcpyDeviceToDevice, s);
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(mstep_fused_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
+  if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
   if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
-  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID + M.n_big,
+  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
+  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID,
                      M.max_change_bits);
   return hipGetLastError();
 }

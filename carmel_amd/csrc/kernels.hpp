@@ -90,6 +90,7 @@ struct MstepArgs {
   const uint64_t* norm_perm;   // parameter ids sorted by norm group
   const uint64_t* big_groups;  // groups with more than MSTEP_BIG_GROUP members (one workgroup each)
   uint64_t n_groups, n_big;
+  double* gscale;           // per norm group: ln((1 - sum of locked arcs) / sum of normal arcs), -inf if nothing left
   unsigned long long* max_partial;  // MSTEP_PARTIALS + n_big entries of scratch
   unsigned long long* max_change_bits;
   int all_grouped;          // every parameter belongs to a norm group
