@@ -49,6 +49,9 @@ int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, u
   }
   (void)hipEventCreate(&t->ev0);
   (void)hipEventCreate(&t->ev1);
+  (void)hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming);
   HostWfst& w = t->w;
   w.n_states = n_states;
   w.final_state = final_state;
@@ -95,9 +98,13 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   if (t->ev0) (void)hipEventDestroy(t->ev0);
   if (t->ev1) (void)hipEventDestroy(t->ev1);
-  hipStream_t s = t->stream;
+  if (t->side) (void)hipStreamSynchronize(t->side);
+  if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+  if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  hipStream_t s = t->stream, s2 = t->side;
   delete t;
   if (s) (void)hipStreamDestroy(s);
+  if (s2) (void)hipStreamDestroy(s2);
   return CARMEL_HIP_OK;
 }
 
@@ -145,7 +152,20 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->pair_id.upload(L.pair_id, s));
   HIPCHK(t->pair_logw.upload(L.pair_logw, s));
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
-  HIPCHK(t->lane_fwd.upload(L.lane_fwd, s));
+  {
+    // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
+    static const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    if (want_t && !L.t_buckets.empty()) {
+      std::vector<uint32_t> fx(L.lane_fwd.size());
+      for (size_t k = 0; k < fx.size(); ++k) fx[k] = L.lane_fwd[k].x;
+      HIPCHK(t->lane_fwdx.upload(fx, s));
+      HIPCHK(hipStreamSynchronize(s));
+      t->lane_fwd.release();
+    } else {
+      HIPCHK(t->lane_fwd.upload(L.lane_fwd, s));
+      t->lane_fwdx.release();
+    }
+  }
   {
     // the kernel needs only the destination/flags word of a backward record; the arc id (slot construction) stays here
     std::vector<uint32_t> bx(L.lane_bwd.size());
@@ -173,11 +193,13 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       HIPCHK(t->t_b_src.upload(L.t_b_src, s));
       HIPCHK(t->t_t_pos.upload(L.t_t_pos, s));
       HIPCHK(t->t_t_src.upload(L.t_t_src, s));
+      HIPCHK(t->t_a_off.upload(L.t_a_off, s));
       HIPCHK(t->t_split_arcs.upload(L.t_split_arcs, s));
       HIPCHK(t->t_x.alloc(L.slot_pos.size()));
       HIPCHK(hipStreamSynchronize(s));
     }
     std::vector<uint16_t>().swap(L.t_b_arc);
+    std::vector<uint16_t>().swap(L.t_a_off);
     std::vector<uint16_t>().swap(L.t_b_rank);
     std::vector<uint16_t>().swap(L.t_t_pos);
     std::vector<uint32_t>().swap(L.t_b_src);
@@ -204,7 +226,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   t->device_bytes = t->bundles.bytes() + t->in_arcs.bytes() + t->out_arcs.bytes() + t->in_off.bytes() +
                     t->out_off.bytes() + t->level_off.bytes() + t->pair_start.bytes() + t->pair_final.bytes() +
                     t->pair_id.bytes() + t->pair_logw.bytes() + t->pair_logprob.bytes() + t->alpha_g.bytes() +
-                    t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_bwd.bytes() +
+                    t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_fwdx.bytes() + t->lane_bwd.bytes() +
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
                     t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
                     t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes();
@@ -474,6 +496,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   LaneArgs LA;
   LA.groups = t->lane_groups.p;
   LA.fwd = (const uint2*)t->lane_fwd.p;
+  LA.fwdx = t->lane_fwdx.p;
   LA.bwd = t->lane_bwd.p;
   LA.lane_pair = t->lane_pair.p;
   LA.lane_nstates = t->lane_nstates.p;
@@ -502,7 +525,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   T.b_src = t->t_b_src.p;
   T.t_pos = t->t_t_pos.p;
   T.t_src = t->t_t_src.p;
-  T.arc_off = t->arc_off.p;
+  T.a_off = t->t_a_off.p;
   T.x = t->t_x.p;
   T.logw = t->arc_logw.p;
   T.wcache = t->wcache.p;
@@ -525,12 +548,17 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   R.counts = t->counts_ptr();
   R.n_arcs = t->w.n_arcs;
   R.n_hot_chunks = t->hot_chunks.n / 3;
+  // the corpus scalars only need pair_logprob[]: they run beside the count reduction
+  HIPCHK(hipEventRecord(t->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(t->side, t->ev_fork, 0));
   HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
-                        t->counts_ptr() + t->w.n_arcs, s));
+                        t->counts_ptr() + t->w.n_arcs, t->side));
+  HIPCHK(hipEventRecord(t->ev_join, t->side));
   if (t->use_transpose)
     HIPCHK(launch_transpose_counts(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
   else
     HIPCHK(launch_count_reduce(R, s));
+  HIPCHK(hipStreamWaitEvent(s, t->ev_join, 0));
   HIPCHK(hipEventRecord(t->ev1, s));
   if (trace_path && trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);

@@ -47,6 +47,8 @@ struct carmel_hip_trainer {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t side = nullptr;          // small independent kernels of the E-step run beside the main chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   HostWfst w;
   HostCorpus corpus;
   bool have_corpus = false, have_lattices = false, cascade = false;
@@ -81,7 +83,7 @@ struct carmel_hip_trainer {
   // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path
   DevBuf<TransBucket> t_buckets;
   DevBuf<uint64_t> t_tile_base;
-  DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos;
+  DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos, t_a_off;
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
   DevBuf<double> t_x;
   DevBuf<unsigned long long> max_partial;  // M-step scratch
@@ -90,6 +92,7 @@ struct carmel_hip_trainer {
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction
   bool use_transpose = false;
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only
+  DevBuf<uint32_t> lane_fwdx; // source | backward position | flags words only (transposition path)
   DevBuf<uint32_t> lane_pair, lane_nstates;
   DevBuf<double> lane_logw, post, wcache;
   DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;

@@ -96,7 +96,9 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   // that has padding is itself padding), which keeps the s_waitcnt bookkeeping exact.
   // ---------- forward ----------
   {
-    const uint2* __restrict__ f = A.fwd + g.stream_base + lane;
+    const uint2* __restrict__ f = A.fwd + g.stream_base + lane;            // gather path: {flags, arc id}
+    const uint32_t* __restrict__ fx = A.fwdx + g.stream_base + lane;       // PRE: the flags word alone
+#define LANE_FREC(k) (PRE ? make_uint2(fx[(size_t)(k) * 64], 0u) : f[(size_t)(k) * 64])
     if (active) col[0] = 0.0;
     uint2 rq[R][U];   // slot j: records of chunk c with c % R == j
     double wq[R][U];  // slot j: their weights
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t k = (uint32_t)(j * U + u);
-        rq[j][u] = f[(size_t)(k < maxlen ? k : lastk) * 64];
+        rq[j][u] = LANE_FREC(k < maxlen ? k : lastk);
       }
 #pragma unroll
     for (int j = 0; j < W; ++j)
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     }                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
       const uint32_t k = (kb) + (uint32_t)(R * U + u);                                                \
-      rq[j][u] = f[(size_t)(k < maxlen ? k : lastk) * 64];                                            \
+      rq[j][u] = LANE_FREC(k < maxlen ? k : lastk);                                                   \
     }                                                                                                 \
   }
     // steady state: whole rounds of R chunks, no control flow between the steps (exact s_waitcnt counts) ...
@@ -149,6 +151,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     for (int j = 0; j < R - 1; ++j)
       if (k0 + (uint32_t)(j * U) < maxlen) LANE_FWD_STEP(j, k0 + (uint32_t)(j * U))
 #undef LANE_FWD_STEP
+#undef LANE_FREC
   }
   if (A.trace) t_mid = __builtin_readcyclecounter();
   // ---------- ln p(pair), corpus scalars, beta at the goal ----------
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
   for (uint32_t a = threadIdx.x; a < B.n_arcs; a += 1024) {
-    const uint32_t r0 = (uint32_t)(T.arc_off[B.arc_lo + a] - B.item_base), r1 = (uint32_t)(T.arc_off[B.arc_lo + a + 1] - B.item_base);
+    const uint32_t r0 = T.a_off[B.arc_lo + a], r1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
     if (r1 - r0 > 32) {
       const uint32_t q = atomicAdd(&n_big, 1u);
       if (q < 512) {
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   const uint32_t nb = n_big < 512 ? n_big : 512;
   for (uint32_t q = threadIdx.x >> 6; q < nb; q += 16) {
     const uint32_t a = big[q];
-    const uint32_t r0 = (uint32_t)(T.arc_off[B.arc_lo + a] - B.item_base), r1 = (uint32_t)(T.arc_off[B.arc_lo + a + 1] - B.item_base);
+    const uint32_t r0 = T.a_off[B.arc_lo + a], r1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
     double v = 0.0;
     for (uint32_t r = r0 + (threadIdx.x & 63); r < r1; r += 64) v += lds[r];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);

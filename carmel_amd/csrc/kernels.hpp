@@ -13,7 +13,8 @@ namespace carmel_hip {
 //      on the host — the topology never changes between iterations).
 struct LaneArgs {
   const LaneGroup* groups;
-  const uint2* fwd;
+  const uint2* fwd;      // forward records {flags, arc id} (gather path)
+  const uint32_t* fwdx;  // forward records, flags word only (pre-distributed weights)
   const uint32_t* bwd;   // backward records: destination | flags only (the arc id stays on the host)
   const uint32_t* lane_pair;
   const uint32_t* lane_nstates;
@@ -66,7 +67,7 @@ struct TransArgs {
   const uint32_t* b_src;
   const uint16_t* t_pos;
   const uint32_t* t_src;
-  const uint64_t* arc_off;
+  const uint16_t* a_off;  // per arc: first item inside its bucket
   double* x;              // intermediate, one f64 per item
   const double* logw;     // per arc
   double* wcache;         // per lane position (n_wcache entries)

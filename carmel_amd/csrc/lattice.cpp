@@ -900,6 +900,10 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
       a = e;
     }
   }
+  out.t_a_off.assign(n_arcs, 0);
+  for (const TransBucket& B : out.t_buckets)
+    if (!(B.flags & TRANS_SINGLE))
+      for (uint32_t a = 0; a < B.n_arcs; ++a) out.t_a_off[B.arc_lo + a] = (uint16_t)(out.arc_off[B.arc_lo + a] - B.item_base);
   out.t_b_arc.assign(N, 0);
   out.t_b_rank.assign(N, 0);
   out.t_b_src.assign(N, 0);

@@ -143,6 +143,7 @@ struct LatticeSet {
   std::vector<uint32_t> t_b_src;       // [J] tile-major index I of the same item
   std::vector<uint16_t> t_t_pos;       // [I] position - tile * TRANS_TILE
   std::vector<uint32_t> t_t_src;       // [I] bucket-major index J of the same item
+  std::vector<uint16_t> t_a_off;       // [arc] offset of the arc's first item inside its bucket (arc-sorted order)
   std::vector<uint32_t> t_split_arcs;  // arcs cut over several buckets (their counts are accumulated atomically)
   uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
   uint64_t explored_states = 0, explored_arcs = 0;
