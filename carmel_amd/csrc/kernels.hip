@@ -780,10 +780,10 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   lds *= lds_scale;  // occupancy experiment
   static const int V = getenv("CARMEL_HIP_LANE_VARIANT") ? atoi(getenv("CARMEL_HIP_LANE_VARIANT")) : 0;  // tuning knob
   if (A.pre_weights) {
-    switch (V) {
-      case 1: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
-      case 2: return launch_lane_variant<6, 3, true>(A, lc.count, lds, stream);
-      default: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);
+    switch (V) {  // streaming only: two chunks ahead is enough, and the smaller ring leaves more registers / less code
+      case 1: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);
+      case 2: return launch_lane_variant<3, 1, true>(A, lc.count, lds, stream);
+      default: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
     }
   }
   switch (V) {
