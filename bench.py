@@ -31,8 +31,9 @@ def algorithmic_bytes(lattice_arcs, lattice_states):
     return 48.0 * lattice_arcs + 16.0 * lattice_states
 
 
-ESTEP_KERNELS = ("sweep_lane_kernel", "sweep_bundle_kernel", "sweep_serial_kernel", "count_reduce_kernel",
-                 "count_reduce_hot_kernel")
+ESTEP_KERNELS = ("trans_w_bucket_kernel", "trans_w_tile_kernel", "sweep_lane_kernel", "sweep_bundle_kernel",
+                 "sweep_serial_kernel", "trans_c_tile_kernel", "trans_c_bucket_kernel", "zero_list_kernel",
+                 "scalars_partial_kernel", "scalars_final_kernel", "count_reduce_kernel", "count_reduce_hot_kernel")
 
 
 def pmc_traffic(config, walk_arcs, n_pairs):
@@ -162,8 +163,9 @@ def main():
             "wfst_arcs_x_iters_per_s": iters_per_s * w.n_arcs,
             "ln_corpus_prob_last": lp,
             "lattice_build_s": ls.build_seconds, "synth_gen_s": t_gen,
-            "roofline": {"bound": "hbm", "kernel": "E-step = sweep_lane_kernel (one launch per LDS class) + "
-                         "count_reduce_kernel, timed together with HIP events on the trainer's stream",
+            "roofline": {"bound": "hbm", "kernel": "E-step = trans_w_bucket + trans_w_tile (weights to lattice order) + "
+                         "sweep_lane_kernel + trans_c_tile + trans_c_bucket (posteriors to per-arc counts), timed "
+                         "together with HIP events on the trainer's stream",
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, args.walk_arcs, c.n_pairs),
