@@ -257,6 +257,29 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   return CARMEL_HIP_OK;
 }
 
+// tied parameters: dense index per (cascade member, tie id) -- WFST::normalize keeps its tie tables per transducer
+static int build_ties(carmel_hip_trainer* t, uint64_t n, const uint32_t* member, const uint32_t* group) {
+  std::vector<uint32_t> tie_of(n, 0xffffffffu);
+  std::unordered_map<uint64_t, uint32_t> ids;
+  for (uint64_t k = 0; k < n; ++k) {
+    if (group[k] == CARMEL_HIP_NO_GROUP || group[k] == CARMEL_HIP_LOCKED_GROUP) continue;
+    const uint64_t key = ((uint64_t)(member ? member[k] : 0) << 32) | group[k];
+    auto it = ids.find(key);
+    if (it == ids.end()) it = ids.emplace(key, (uint32_t)ids.size()).first;
+    tie_of[k] = it->second;
+  }
+  t->n_ties = ids.size();
+  if (t->n_ties) {
+    HIPCHK(t->tie_of.upload(tie_of, t->stream));
+    HIPCHK(t->tie_tab.alloc(4 * t->n_ties));
+    HIPCHK(hipStreamSynchronize(t->stream));
+  } else {
+    t->tie_of.release();
+    t->tie_tab.release();
+  }
+  return CARMEL_HIP_OK;
+}
+
 // norm groups over a parameter table given (member, src state, input symbol, method)
 static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* member, const uint32_t* src,
                              const uint32_t* in, const std::vector<int>& method, const std::vector<double>& addc) {
@@ -323,9 +346,10 @@ int carmel_hip_set_norm(carmel_hip_trainer* t, int norm_group_by, double add_cou
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (t->cascade) return fail(CARMEL_HIP_ERR_STATE, "cascade: per-member methods come from set_cascade");
   HIPCHK(hipSetDevice(t->device));
-  for (uint64_t k = 0; k < t->w.n_arcs; ++k)
-    if (t->w.group[k] != CARMEL_HIP_NO_GROUP && t->w.group[k] != CARMEL_HIP_LOCKED_GROUP)
-      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "tied arc groups (!N) are not supported by the GPU M-step yet");
+  {
+    int rc = build_ties(t, t->w.n_arcs, nullptr, t->w.group.data());
+    if (rc) return rc;
+  }
   t->norm_group_by = norm_group_by;
   t->norm_add_count = add_count;
   std::vector<int> m(1, norm_group_by);
@@ -367,9 +391,6 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
   HIPCHK(hipSetDevice(t->device));
   for (uint64_t k = 0; k < t->w.n_arcs; ++k)
     if (t->w.group[k] >= n_chains) return fail(CARMEL_HIP_ERR_ARG, "composed arc refers to a chain id out of range");
-  for (uint64_t p = 0; p < n_params; ++p)
-    if (param_group[p] != CARMEL_HIP_NO_GROUP && param_group[p] != CARMEL_HIP_LOCKED_GROUP)
-      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "tied arc groups (!N) are not supported by the GPU M-step yet");
   for (uint64_t j = 0; j < chain_off[n_chains]; ++j)
     if (chain_param[j] >= n_params) return fail(CARMEL_HIP_ERR_ARG, "chain refers to a parameter out of range");
   t->cascade = true;
@@ -393,6 +414,8 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
   for (uint64_t p = 0; p < n_params; ++p)
     if (param_member[p] >= n_members) return fail(CARMEL_HIP_ERR_ARG, "param_member out of range");
   int rc = build_norm_groups(t, n_params, param_member, param_src, param_in, m, a);
+  if (rc) return rc;
+  rc = build_ties(t, n_params, param_member, param_group);
   if (rc) return rc;
   // composed weights from the chains (cascade.update)
   HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
@@ -420,6 +443,9 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
   M.max_partial = t->max_partial.p;
   M.gscale = t->gscale.p;
+  M.tie_of = t->n_ties ? t->tie_of.p : nullptr;
+  M.tie_tab = t->tie_tab.p;
+  M.n_ties = t->n_ties;
   M.all_grouped = t->all_grouped ? 1 : 0;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();

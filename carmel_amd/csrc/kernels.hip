@@ -448,6 +448,10 @@ __device__ __forceinline__ double mstep_update(const MstepArgs& M, uint64_t k, i
   double nw;
   if (M.group[k] == 0u) {
     nw = v > 0.0 ? log(v) : NEG_INF;
+  } else if (M.tie_of && M.tie_of[k] != 0xffffffffu) {
+    const double tw = M.tie_tab[3 * M.n_ties + M.tie_of[k]];
+    nw = tw > 0.0 ? log(tw) : NEG_INF;
+    mx = fmax(mx, fabs(tw - exp(M.save_old ? old : M.old_logw[k])));
   } else {
     nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
     mx = fmax(mx, fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k])));
@@ -467,6 +471,46 @@ __device__ __forceinline__ void mstep_block_max(double mx, unsigned long long* o
 // |change| leaves as one partial per workgroup (every wave pushing an atomicMax onto one address is the same
 // serialisation that the corpus scalars had).
 #define MSTEP_GRID 2048
+// Tied arcs (!N), fst.cc:107-152: per norm group the sum over its unlocked members (normal and tied) and over its
+// locked ones; every tied member adds its value to its tie's arc total, the group's unlocked sum to the tie's state
+// total, and the group's locked sum to the tie's maximum.  Ties are rare: atomics.
+__global__ __launch_bounds__(256) void mstep_tie_accum_kernel(MstepArgs M, int use_counts) {
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < M.n_groups; g += (uint64_t)gridDim.x * 256) {
+    const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
+    double su = 0.0, sl = 0.0;
+    bool any = false;
+    for (uint64_t j = j0; j < j1; ++j) {
+      const uint64_t k = M.norm_perm[j];
+      const double v = mstep_value(M, k, use_counts, (uint32_t)g);
+      if (M.group[k] == 0u)
+        sl += v;
+      else
+        su += v;
+      any |= M.tie_of[k] != 0xffffffffu;
+    }
+    if (!any) continue;
+    for (uint64_t j = j0; j < j1; ++j) {
+      const uint64_t k = M.norm_perm[j];
+      const uint32_t tie = M.tie_of[k];
+      if (tie == 0xffffffffu) continue;
+      atomic_add_f64(M.tie_tab + tie, mstep_value(M, k, use_counts, (uint32_t)g));
+      atomic_add_f64(M.tie_tab + M.n_ties + tie, su);
+      atomicMax((unsigned long long*)(M.tie_tab + 2 * M.n_ties + tie), (unsigned long long)__double_as_longlong(sl));
+    }
+  }
+}
+// the tie's weight (fst.cc:169-195): total / (state total / (1 - max locked)), 0 when nothing can be given
+__global__ void mstep_tie_weight_kernel(MstepArgs M) {
+  const uint64_t tie = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tie >= M.n_ties) return;
+  const double total = M.tie_tab[tie], gmax = M.tie_tab[2 * M.n_ties + tie];
+  double norm = M.tie_tab[M.n_ties + tie], w = 0.0;
+  if (!(gmax > 1.0)) {
+    if (gmax != 0.0) norm /= (1.0 - gmax);
+    if (total != 0.0) w = total / norm;
+  }
+  M.tie_tab[3 * M.n_ties + tie] = w;
+}
 // pass 0, one thread per norm group: gscale[g] from the sums over its normal and locked members (listed in
 // norm_perm[group_off[g] .. group_off[g+1]), contiguous for the per-state groups of JOINT / CONDITIONAL); no atomics
 __global__ __launch_bounds__(256) void mstep_group_sum_kernel(MstepArgs M, int use_counts) {
@@ -479,6 +523,8 @@ __global__ __launch_bounds__(256) void mstep_group_sum_kernel(MstepArgs M, int u
       const double v = mstep_value(M, k, use_counts, (uint32_t)g);
       if (M.group[k] == 0u)
         sl += v;
+      else if (M.tie_of && M.tie_of[k] != 0xffffffffu)
+        sl += M.tie_tab[3 * M.n_ties + M.tie_of[k]];  // a tied arc's share is reserved like a locked one (fst.cc:169-195)
       else
         sn += v;
     }
@@ -510,6 +556,8 @@ __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int u
     const double v = mstep_value(M, k, use_counts, (uint32_t)g);
     if (M.group[k] == 0u)
       sl += v;
+    else if (M.tie_of && M.tie_of[k] != 0xffffffffu)
+      sl += M.tie_tab[3 * M.n_ties + M.tie_of[k]];
     else
       sn += v;
   }
@@ -865,6 +913,12 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
+  if (M.n_ties && M.tie_of) {
+    hipError_t e = hipMemsetAsync(M.tie_tab, 0, 4 * M.n_ties * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+    hipLaunchKernelGGL(mstep_tie_weight_kernel, dim3((unsigned)((M.n_ties + 255) / 256)), dim3(256), 0, s, M);
+  }
   if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
   if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
   hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);

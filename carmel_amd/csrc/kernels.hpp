@@ -95,6 +95,9 @@ struct MstepArgs {
   unsigned long long* max_partial;  // MSTEP_PARTIALS + n_big entries of scratch
   unsigned long long* max_change_bits;
   int all_grouped;          // every parameter belongs to a norm group
+  const uint32_t* tie_of;   // dense tie index per parameter, 0xffffffff = not tied; null when the model has no ties
+  double* tie_tab;          // [4][n_ties]: arc total, state total, max locked sum, weight (linear)
+  uint64_t n_ties;
   uint64_t n;
   int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
 };

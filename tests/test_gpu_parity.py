@@ -124,6 +124,48 @@ def test_mstep_normalize(oracle, group, add_count):
     fb.close()
 
 
+def _with_ties(w, seed=0):
+    """lock some arcs and tie others into a few !N groups spread over many states (fst.cc:107-152, 169-195)"""
+    rng = np.random.default_rng(seed)
+    grp = w.group.copy()
+    grp[::7] = 0
+    w.logw[::7] = np.log(0.05)
+    free = np.flatnonzero(grp != 0)
+    tied = rng.choice(free, size=len(free) // 4, replace=False)
+    grp[tied] = rng.integers(1, 6, size=len(tied)).astype(np.uint32)  # tie ids 1..5
+    return Wfst(w.n_states, w.final, w.src, w.dst, w.isym, w.osym, w.logw, grp)
+
+
+@pytest.mark.parametrize("group", [NORM_CONDITIONAL, NORM_JOINT])
+@pytest.mark.parametrize("add_count", [0.0, 0.2])
+def test_mstep_normalize_tied_groups(oracle, group, add_count):
+    w, c = ambiguous(9)
+    w = _with_ties(w)
+    fb = _fb(w, c, norm_group=group, add_count=add_count)
+    ow = oracle.OracleWfst.from_arrays(w)
+    ow.normalize(group, add_count)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-11, atol=1e-300)
+    fb.close()
+
+
+def test_training_with_tied_groups(oracle):
+    from carmel_amd.trainer import TrainOpts, train
+    w, c = ambiguous(11, n_pairs=120)
+    w.logw[:] = 0.0
+    w = _with_ties(w, seed=3)
+    fb = _fb(w, c, norm_group=NORM_CONDITIONAL)
+    best, trace = train(fb, TrainOpts(max_iter=8))
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    obest, otrace = oracle.train(ow, oc, norm_group=NORM_CONDITIONAL, max_iter=8)
+    assert len(trace) == len(otrace)
+    for a, b in zip(trace, otrace):
+        assert a["log2_prob"] == pytest.approx(b["log2_prob"], rel=1e-9)
+        if a["iter"] > 1:
+            assert a["last_change"] == pytest.approx(b["last_change"], rel=1e-6, abs=1e-12)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-6, atol=1e-12)
+    fb.close()
+
+
 @pytest.mark.parametrize("group", [NORM_CONDITIONAL, NORM_JOINT])
 def test_full_training_trace(oracle, group):
     from carmel_amd.trainer import TrainOpts, train
