@@ -445,6 +445,8 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.gscale = t->gscale.p;
   M.tie_of = t->n_ties ? t->tie_of.p : nullptr;
   M.tie_tab = t->tie_tab.p;
+  if (t->n_ties && t->glocked.n != t->n_norm_groups) HIPCHK(t->glocked.alloc(t->n_norm_groups));
+  M.glocked = t->glocked.p;
   M.n_ties = t->n_ties;
   M.all_grouped = t->all_grouped ? 1 : 0;
   M.max_change_bits = t->maxchg.p;

@@ -67,6 +67,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> norm_of;
   // tied arcs (!N, fst.cc:107-152): dense tie index per parameter (0xffffffff = not tied) and the per-tie tables
   DevBuf<uint32_t> tie_of;
+  DevBuf<double> glocked;  // per norm group scratch
   DevBuf<double> tie_tab;  // 4 * n_ties: arc total, state total, max locked sum, resulting weight (linear)
   uint64_t n_ties = 0;
   DevBuf<uint64_t> group_off, norm_perm, big_groups;

@@ -13,6 +13,7 @@
 // addends more than 36 nats smaller; here each state's sum is one streaming logsumexp (running max + scaled
 // sum), which differs from that only in the last bits (e^-36 ~ 2e-16).
 #include "kernels.hpp"
+#include <cstdio>
 #include <cstdlib>
 
 namespace carmel_hip {
@@ -471,14 +472,12 @@ __device__ __forceinline__ void mstep_block_max(double mx, unsigned long long* o
 // |change| leaves as one partial per workgroup (every wave pushing an atomicMax onto one address is the same
 // serialisation that the corpus scalars had).
 #define MSTEP_GRID 2048
-// Tied arcs (!N), fst.cc:107-152: per norm group the sum over its unlocked members (normal and tied) and over its
-// locked ones; every tied member adds its value to its tie's arc total, the group's unlocked sum to the tie's state
-// total, and the group's locked sum to the tie's maximum.  Ties are rare: atomics.
-__global__ __launch_bounds__(256) void mstep_tie_accum_kernel(MstepArgs M, int use_counts) {
+// Tied arcs (!N), fst.cc:107-152.
+// pass A, one thread per norm group: the sum over its unlocked members (normal and tied) and over its locked ones
+__global__ __launch_bounds__(256) void mstep_tie_sums_kernel(MstepArgs M, int use_counts) {
   for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < M.n_groups; g += (uint64_t)gridDim.x * 256) {
     const uint64_t j0 = M.group_off[g], j1 = M.group_off[g + 1];
     double su = 0.0, sl = 0.0;
-    bool any = false;
     for (uint64_t j = j0; j < j1; ++j) {
       const uint64_t k = M.norm_perm[j];
       const double v = mstep_value(M, k, use_counts, (uint32_t)g);
@@ -486,17 +485,21 @@ __global__ __launch_bounds__(256) void mstep_tie_accum_kernel(MstepArgs M, int u
         sl += v;
       else
         su += v;
-      any |= M.tie_of[k] != 0xffffffffu;
     }
-    if (!any) continue;
-    for (uint64_t j = j0; j < j1; ++j) {
-      const uint64_t k = M.norm_perm[j];
-      const uint32_t tie = M.tie_of[k];
-      if (tie == 0xffffffffu) continue;
-      atomic_add_f64(M.tie_tab + tie, mstep_value(M, k, use_counts, (uint32_t)g));
-      atomic_add_f64(M.tie_tab + M.n_ties + tie, su);
-      atomicMax((unsigned long long*)(M.tie_tab + 2 * M.n_ties + tie), (unsigned long long)__double_as_longlong(sl));
-    }
+    M.gscale[g] = su;  // scratch until mstep_group_sum_kernel writes the real scale
+    M.glocked[g] = sl;
+  }
+}
+// pass B, one thread per parameter: a tied one adds its value to its tie's arc total, its group's unlocked sum to the
+// tie's state total, and its group's locked sum to the tie's maximum.  Ties are rare: atomics.
+__global__ __launch_bounds__(256) void mstep_tie_accum_kernel(MstepArgs M, int use_counts) {
+  for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < M.n; k += (uint64_t)gridDim.x * 256) {
+    const uint32_t tie = M.tie_of[k];
+    const uint32_t g = M.norm_of[k];
+    if (tie == 0xffffffffu || g == 0xffffffffu) continue;
+    atomic_add_f64(M.tie_tab + tie, mstep_value(M, k, use_counts, g));
+    atomic_add_f64(M.tie_tab + M.n_ties + tie, M.gscale[g]);
+    atomicMax((unsigned long long*)(M.tie_tab + 2 * M.n_ties + tie), (unsigned long long)__double_as_longlong(M.glocked[g]));
   }
 }
 // the tie's weight (fst.cc:169-195): total / (state total / (1 - max locked)), 0 when nothing can be given
@@ -913,17 +916,27 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
+  static const bool dbg = getenv("CARMEL_HIP_DEBUG") != nullptr;
+#define MSTEP_DBG(what) if (dbg) { hipError_t de = hipStreamSynchronize(s); fprintf(stderr, "[carmel_hip] mstep %s: %s\n", what, hipGetErrorString(de)); }
+  if (dbg) fprintf(stderr, "[carmel_hip] mstep n=%llu groups=%llu ties=%llu logw=%p counts=%p group=%p norm_of=%p off=%p perm=%p tie_of=%p tie_tab=%p add=%p prior=%p\n", (unsigned long long)M.n, (unsigned long long)M.n_groups, (unsigned long long)M.n_ties, (void*)M.logw, (void*)M.counts, (void*)M.group, (void*)M.norm_of, (void*)M.group_off, (void*)M.norm_perm, (void*)M.tie_of, (void*)M.tie_tab, (void*)M.add_count, (void*)M.prior);
   if (M.n_ties && M.tie_of) {
     hipError_t e = hipMemsetAsync(M.tie_tab, 0, 4 * M.n_ties * sizeof(double), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+    MSTEP_DBG("memset ties")
+    hipLaunchKernelGGL(mstep_tie_sums_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+    hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
+    MSTEP_DBG("tie_accum")
     hipLaunchKernelGGL(mstep_tie_weight_kernel, dim3((unsigned)((M.n_ties + 255) / 256)), dim3(256), 0, s, M);
+    MSTEP_DBG("tie_weight")
   }
   if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
   if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
+  MSTEP_DBG("group sums")
   hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
   hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID,
                      M.max_change_bits);
+  MSTEP_DBG("normalize + max")
+#undef MSTEP_DBG
   return hipGetLastError();
 }
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,
