@@ -700,8 +700,9 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
       if (rc) return rc;
       HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
       HIPCHK(launch_max_change(t->arc_logw.p, t->old_logw.p, t->arc_group.p, t->maxchg.p, t->w.n_arcs, s));
+      t->em_valid = true;
     } else {
-      HIPCHK(hipMemcpyAsync(t->em_logw.p, t->arc_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
+      t->em_valid = false;  // the EM update IS the weight vector: nothing to keep apart (train.cc:157-171 only acts for rate > 1)
     }
     unsigned long long bits = 0;
     HIPCHK(hipMemcpyAsync(&bits, t->maxchg.p, sizeof bits, hipMemcpyDeviceToHost, s));
@@ -713,6 +714,16 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
     HIPCHK(hipStreamSynchronize(s));
   }
   if (max_change) *max_change = result;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_keep_em_weights(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (t->cascade) return fail(CARMEL_HIP_ERR_STATE, "over-relaxed EM is off for cascades (train.cc:545-549)");
+  if (!t->em_valid) return CARMEL_HIP_OK;  // last step was a plain EM update already
+  HIPCHK(hipSetDevice(t->device));
+  HIPCHK(hipMemcpyAsync(t->arc_logw.p, t->em_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
 }
 

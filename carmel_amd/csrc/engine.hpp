@@ -96,6 +96,7 @@ struct carmel_hip_trainer {
   DevBuf<double> pair_w;          // pair weight by pair id, < 0 for pairs dropped at build_lattices
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction
   bool use_transpose = false;
+  bool em_valid = false;  // em_logw holds the plain EM update of the last (over-relaxed) maximize
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only
   DevBuf<uint32_t> lane_fwdx; // source | backward position | flags words only (transposition path)
   DevBuf<uint32_t> lane_pair, lane_nstates;

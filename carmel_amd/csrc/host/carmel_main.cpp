@@ -44,6 +44,7 @@ static std::string base2(double ln_value) {  // weight.h:529-532,603 as_base(2) 
 struct Options {
   bool flags[256] = {false};
   bool train_cascade = false;
+  double rate_growth = 1.0;  // -o (train_opts::learning_rate_growth_factor, fst.h:1083)
   long max_iter = 500;  // train_opts default (fst.h:1080-1095); -1 == "-M" without a number
   double converge = 1e-4, converge_ppx_ratio = .999, smooth_floor = 0;
   int norm = CARMEL_HIP_NORM_CONDITIONAL;
@@ -120,6 +121,9 @@ static Options parse_args(int argc, char** argv) {
           case 'T': o.index_threshold = std::atoi(value()); break;
           case 'F': o.out_file = value(); break;
           case 'R': o.seed = std::strtoull(value(), 0, 10); break;
+          case 'o':  // learning rate growth factor of over-relaxed EM (carmel.cc:940-943)
+            o.rate_growth = std::max(1.0, std::atof(value()));
+            break;
           default: break;
         }
       continue;
@@ -355,8 +359,14 @@ static int run(int argc, char** argv) {
              "offered by the GPU front end).\n";
   } else {
     double best = std::numeric_limits<double>::infinity(), last_ppx = best, last_change = 10.0;
-    bool have_good = false;
+    bool have_good = false, last_was_reset = false;
     long iter = 0;
+    double learning_rate = 1.0;
+    double growth = o.rate_growth;
+    if (cascade && growth != 1.0) {  // train.cc:545-549
+      log << "Overrelaxed EM not supported for --train-cascade (compose with -a and train, instead?).  Disabling (growth factor=1)." << std::endl;
+      growth = 1.0;
+    }
     for (;;) {
       const bool first_time = iter == 0;
       ++iter;
@@ -370,7 +380,7 @@ static int run(int argc, char** argv) {
       }
       hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
       const double new_ppx = -er.sum_weighted_logprob / cs.total_weight;  // ln p.ppxper(totalEmpiricalWeight)
-      log << "i=" << iter << " (rate=1): ";
+      log << "i=" << iter << " (rate=" << learning_rate << "): ";
       print_ppx(er.sum_logprob);
       if (new_ppx < best && (!cascade || cascade_counts)) {
         log << " (new best)";
@@ -387,16 +397,28 @@ static int run(int argc, char** argv) {
         if (last_change < 1) log << ", max {d(weight)}=" << format_weight(std::log(last_change), W_SOMETIMES_LOG);
         log << std::endl;
       }
-      if (ratio_ln >= std::log(o.converge_ppx_ratio)) {
-        log << "Converged - per-example perplexity ratio exceeds "
-            << format_weight(std::log(o.converge_ppx_ratio), W_SOMETIMES_LOG) << " after " << iter << " iterations.\n";
-        if (!have_good)
-          log << "Because of the --train-cascade implementation, we need another iteration even though we've "
-                 "converged.\n";
-        else
-          break;
-      }
-      hip_check(carmel_hip_maximize(t, 1.0, &last_change), "carmel_hip_maximize");
+      if (!last_was_reset) {
+        if (ratio_ln >= std::log(o.converge_ppx_ratio)) {
+          if (learning_rate > 1) {  // train.cc:639-643
+            log << "Failed to improve (relaxation rate too high); starting again at learning rate 1" << std::endl;
+            learning_rate = 1;
+            hip_check(carmel_hip_keep_em_weights(t), "carmel_hip_keep_em_weights");
+            last_was_reset = true;
+            continue;
+          }
+          log << "Converged - per-example perplexity ratio exceeds "
+              << format_weight(std::log(o.converge_ppx_ratio), W_SOMETIMES_LOG) << " after " << iter << " iterations.\n";
+          if (!have_good)
+            log << "Because of the --train-cascade implementation, we need another iteration even though we've "
+                   "converged.\n";
+          else
+            break;
+        } else if (learning_rate < 20) {  // MAX_LEARNING_RATE_EXP (train.cc:647)
+          learning_rate *= growth;
+        }
+      } else
+        last_was_reset = false;
+      hip_check(carmel_hip_maximize(t, learning_rate, &last_change), "carmel_hip_maximize");
       if (last_change <= o.converge && have_good) {
         log << "Converged - maximum weight change less than " << format_weight(std::log(o.converge), W_SOMETIMES_LOG)
             << " after " << iter << " iterations.\n";

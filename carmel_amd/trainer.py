@@ -114,6 +114,9 @@ class HipForwardBackward(object):
         check(lib.carmel_hip_maximize(self.h, delta_scale, C.byref(mc)), "carmel_hip_maximize")
         return mc.value
 
+    def keep_em_weights(self):
+        check(lib.carmel_hip_keep_em_weights(self.h), "carmel_hip_keep_em_weights")
+
     def weights(self):
         out = np.empty(self.n_params)
         check(lib.carmel_hip_get_weights(self.h, ptr(out)), "carmel_hip_get_weights")
@@ -178,7 +181,7 @@ def train(fb, opts=None, log=None):
         new_ppx = -wlp / W  # ln of p.ppxper(totalEmpiricalWeight)  (weight.h:311)
         rec = dict(iter=it, log2_prob=lp / math.log(2), log2_ppx_symbol=(-lp / n_sym) / math.log(2) if n_sym else 0.0,
                    log2_ppx_example=(-lp / st["n_pairs"]) / math.log(2), n_symbol=n_sym, n_example=st["n_pairs"],
-                   new_best=False, rel_ppx_ratio_ln=float("nan"), last_change=last_change)
+                   new_best=False, rel_ppx_ratio_ln=float("nan"), last_change=last_change, rate=learning_rate)
         if new_ppx < best and (not using_cascade or cascade_counts):
             rec["new_best"] = True
             best = new_ppx
@@ -195,10 +198,11 @@ def train(fb, opts=None, log=None):
         if not last_was_reset:
             if ratio_ln >= math.log(opts.converge_ppx_ratio):
                 if learning_rate > 1:
+                    # "Failed to improve (relaxation rate too high); starting again at learning rate 1" (train.cc:639-643)
                     learning_rate = 1.0
+                    fb.keep_em_weights()
                     last_was_reset = True
-                    # keep_em_weight is handled inside the library's overrelax bookkeeping: not mirrored here
-                    raise NotImplementedError("over-relaxed EM restart path (carmel -o) is not mirrored in Python")
+                    continue
                 if have_good:
                     break
             elif learning_rate < 20:

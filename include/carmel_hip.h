@@ -147,6 +147,10 @@ int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts /* n_arcs,
  * (10 for a real cascade, train.cc:922). */
 int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change);
 
+/* Replaces for_arcs::keep_em_weight (train.cc:188-190, used at :639-643): after an over-relaxed step (delta_scale > 1)
+ * failed to improve, the weights go back to the plain EM update of that step.  Valid after a carmel_hip_maximize call
+ * with delta_scale > 1 on a single transducer. */
+int carmel_hip_keep_em_weights(carmel_hip_trainer* t);
 /* Replaces: for_arcs::save_best / save_best_counts / use_best_weight (train.cc:123-198, 449-457) and
  * cascade.use_counts_final (cascade.h:358-364): device-side snapshots so WFST::train's "keep the weights that
  * produced the best estimate" needs no host copies. */

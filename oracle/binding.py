@@ -183,13 +183,15 @@ def lattice(w, c, pair, prune=True):
 
 
 def train(w, c, norm_group=0, add_count=0.0, weight_is_prior_count=False, smooth_floor=0.0, converge_arc_delta=1e-4,
-          converge_ppx_ratio=.999, max_iter=500, cache=False, prune=True, max_trace=1000):
+          converge_ppx_ratio=.999, max_iter=500, cache=False, prune=True, max_trace=1000, rate_growth=1.0):
     tr = np.zeros((max_trace, 8))
     n = C.c_int(0)
     best = C.c_double(0)
+    lib.orc_set_rate_growth(C.c_double(rate_growth))
     _chk(lib.orc_train(w.h, c.h, norm_group, add_count, int(weight_is_prior_count), smooth_floor, converge_arc_delta,
                        converge_ppx_ratio, max_iter, int(cache), int(prune), _p(tr), max_trace, C.byref(n),
                        C.byref(best)))
+    lib.orc_set_rate_growth(C.c_double(1.0))
     rows = [dict(zip(TRACE_FIELDS, tr[i])) for i in range(n.value)]
     return best.value, rows
 

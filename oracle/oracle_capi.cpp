@@ -323,6 +323,8 @@ int orc_lattice(orc_wfst* wh, orc_corpus* ch, uint64_t pair, int prune, uint32_t
 
 // Full EM run for a single transducer (trivial cascade): WFST::train (train.cc:503-678).
 // trace rows: [iter, log2 P, log2 ppx/symbol, log2 ppx/example, new_best, ln rel-ppx-ratio, last_change, n_example]
+static double g_rate_growth = 1.0;  // carmel -o (train_opts::learning_rate_growth_factor), set before orc_train
+void orc_set_rate_growth(double g) { g_rate_growth = g < 1 ? 1 : g; }
 int orc_train(orc_wfst* wh, orc_corpus* ch, int norm_group, double add_count, int weight_is_prior_count,
               double smooth_floor, double converge_arc_delta, double converge_ppx_ratio, int max_iter, int cache,
               int prune, double* trace, int max_trace, int* n_trace, double* best_ppx_ln) {
@@ -335,6 +337,7 @@ int orc_train(orc_wfst* wh, orc_corpus* ch, int norm_group, double add_count, in
     opts.max_iter = (unsigned)max_iter;
     opts.cache_derivations = cache != 0;
     opts.prune = prune != 0;
+    opts.learning_rate_growth_factor = g_rate_growth;
     std::vector<IterRecord> tr;
     LW best = train(wh->w, cascade, ch->c, nms, weight_is_prior_count != 0, LW::from_real(smooth_floor),
                     LW::from_real(converge_arc_delta), LW::from_real(converge_ppx_ratio), opts, 0, &tr);

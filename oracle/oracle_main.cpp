@@ -67,6 +67,8 @@ static int real_main(int argc, char** argv) {
         smoothFloor = LW::from_real(std::atof(next()));
       else if (last == 'T')
         idx_threshold = std::atoi(next());
+      else if (last == 'o')  // carmel.cc:940-943
+        topt.learning_rate_growth_factor = std::max(1.0, std::atof(next()));
     } else
       files.push_back(argv[i]);
   }

@@ -119,3 +119,53 @@ def test_crp_command(golden_dir, tmp_path, oracle):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-9)
+
+
+def test_tied_and_locked_arcs_through_the_cli(tmp_path):
+    """`!N` tie groups and `!` locks in the transducer file (carmel/doc/FORMATS; fst.cc:107-152): the command line's
+    trained transducer equals the oracle's on the same files"""
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    fst = tmp_path / "tied.fst"
+    fst.write_text("""F
+(S (A a x 0.5) (A a y 0.5) (B b x 0.3!1) (B b y 0.7))
+(A (F c x 0.4!1) (F c y 0.6) (F d z 0.25!) (F d x 0.75))
+(B (F c x 0.5) (F c y 0.5) (F d z 1))
+""")
+    data = tmp_path / "tied.data"
+    data.write_text("a c\nx x\na c\ny y\nb c\nx y\nb d\ny z\na d\nx x\na d\ny z\nb c\nx x\n")
+    rc, out, err = run(["-t", "-M", "6", str(data), str(fst)])
+    assert rc == 0, err
+    p = subprocess.run([oracle_cli, "-t", "-M", "6", str(data), str(fst)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True)
+    assert p.returncode == 0, p.stderr
+    assert len(ITER.findall(err)) == len(ITER.findall(p.stderr)) >= 2
+    gl, el = out.strip().split("\n"), p.stdout.strip().split("\n")
+    assert len(gl) == len(el)
+    for x, y in zip(gl, el):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-9)
+    assert "!1" in out and "!" in out
+
+
+def test_overrelaxed_em_switch(golden_dir):
+    """carmel -t -o 1.5: the log lines (rate=...) and the trained transducer equal the oracle's"""
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    args = ["-t", "-o", "1.5", "-M", "12", os.path.join(golden_dir, "epron-jpron.data"), os.path.join(golden_dir, "epron-jpron.fst")]
+    rc, out, err = run(args)
+    assert rc == 0, err
+    p = subprocess.run([oracle_cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert p.returncode == 0, p.stderr
+    mine = [l for l in err.split("\n") if l.startswith("i=")]
+    ref = [l for l in p.stderr.split("\n") if l.startswith("i=")]
+    assert len(mine) == len(ref) >= 3 and "(rate=1.5)" in mine[1] and "(rate=2.25)" in mine[2]
+    for x, y in zip(mine, ref):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-4)
+    for x, y in zip(out.strip().split("\n"), p.stdout.strip().split("\n")):
+        assert NUM.sub("#", x) == NUM.sub("#", y)

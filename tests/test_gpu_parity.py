@@ -191,6 +191,27 @@ def test_full_training_trace(oracle, group):
     fb.close()
 
 
+@pytest.mark.parametrize("growth", [1.3, 2.5])
+def test_overrelaxed_em(oracle, growth):
+    """carmel -o: w <- old * (em/old)^rate, renormalised (train.cc:157-171), rate grows by the factor while EM improves
+    and falls back to 1 with the plain EM weights when it does not (train.cc:629-648)"""
+    from carmel_amd.trainer import TrainOpts, train
+    w, c = ambiguous(21, n_pairs=150)
+    w.logw[:] = 0.0
+    fb = _fb(w, c, norm_group=NORM_CONDITIONAL)
+    best, trace = train(fb, TrainOpts(max_iter=25, learning_rate_growth_factor=growth))
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    obest, otrace = oracle.train(ow, oc, norm_group=NORM_CONDITIONAL, max_iter=25, rate_growth=growth)
+    assert len(trace) == len(otrace)
+    assert max(r["rate"] for r in trace) > 1.0
+    for a, b in zip(trace, otrace):
+        assert a["log2_prob"] == pytest.approx(b["log2_prob"], rel=1e-8)
+        assert a["new_best"] == bool(b["new_best"])
+    assert best == pytest.approx(obest, rel=1e-8)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-5, atol=1e-10)
+    fb.close()
+
+
 def test_golden_epron_jpron(oracle, golden_dir):
     """carmel -t epron-jpron.data epron-jpron.fst — the reference's recorded run (commands.trace:7-77)"""
     from carmel_amd.trainer import TrainOpts, train
