@@ -1,0 +1,246 @@
+// forest-em front end: the reference's forest-em command line (forest-em/forest-em-params.hpp:70-170) over the
+// carmel_hip_forests_* C-ABI.  Reads the forests / normalisation groups / initial parameter files the reference reads,
+// runs EM (graehl/shared/em.hpp:107-216 for one start at learning rate 1; forest-em.hpp:561-655) or the Gibbs sampler
+// (--crp, forest-em.hpp:694-766) on the GPU, and writes the parameter / count vectors the reference writes
+// (forest-em.hpp:190-201).  Host code only parses, logs and decides when to stop.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/carmel_hip.h"
+#include "forest_text.hpp"
+
+using namespace carmel_host;
+
+namespace {
+
+struct Opts {
+  std::string forests_file, normgroups_file = "-0", initparam_file = "-0", outparam_file = "-", outcounts_file = "-0";
+  long max_iter = 10000;            // --max-iter (forest-em-params.hpp:195)
+  double converge_ratio = 1.0 / 65536;   // --converge, relative change of the average log prob (:197)
+  double converge_delta = 1.0 / 65536;   // --deltaparam-epsilon (:198)
+  double prior_counts = 0, add_k = 0;
+  bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
+  long crp = 0, burnin = 0;
+  double alpha = 0.1;
+  bool final_counts = false, uniform_p0 = false, parallel = false;
+  unsigned long long seed = 0;
+  int gpu = 0;
+};
+
+void usage() {
+  std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
+               "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
+               "                 [-z] [-N] [-H] [--crp=N --alpha=A --burnin=B --final-counts --uniform-p0 --crp-parallel]\n"
+               "                 [--random-seed=S] [--gpu=D]\n"
+               "file arguments: '-' = stdin/stdout, '-0' = none\n";
+}
+
+std::string slurp(const std::string& fn) {
+  std::ostringstream ss;
+  if (fn == "-") {
+    ss << std::cin.rdbuf();
+  } else {
+    std::ifstream in(fn.c_str());
+    if (!in) throw std::runtime_error("can't open " + fn);
+    ss << in.rdbuf();
+  }
+  return ss.str();
+}
+void spit(const std::string& fn, const std::string& text) {
+  if (fn == "-") {
+    std::cout << text;
+  } else {
+    std::ofstream of(fn.c_str());
+    if (!of) throw std::runtime_error("can't create " + fn);
+    of << text;
+  }
+}
+void check(int rc, const char* what) {
+  if (rc != CARMEL_HIP_OK) throw std::runtime_error(std::string(what) + ": " + carmel_hip_last_error());
+}
+
+Opts parse_args(int argc, char** argv) {
+  Opts o;
+  for (int i = 1; i < argc; ++i) {
+    std::string a = argv[i];
+    auto value = [&](const std::string& inline_val) -> std::string {
+      if (!inline_val.empty()) return inline_val;
+      if (i + 1 >= argc) throw std::runtime_error("missing value after " + a);
+      return argv[++i];
+    };
+    std::string key, val;
+    if (a.compare(0, 2, "--") == 0) {
+      size_t e = a.find('=');
+      key = a.substr(2, e == std::string::npos ? std::string::npos : e - 2);
+      if (e != std::string::npos) val = a.substr(e + 1);
+    } else if (a.size() >= 2 && a[0] == '-') {
+      key = std::string(1, a[1]);
+      val = a.substr(2);
+    } else {
+      throw std::runtime_error("unexpected argument " + a);
+    }
+    if (key == "h" || key == "help") {
+      usage();
+      std::exit(0);
+    } else if (key == "f" || key == "forests-file") o.forests_file = value(val);
+    else if (key == "n" || key == "normgroups-file") o.normgroups_file = value(val);
+    else if (key == "I" || key == "initparam-file") o.initparam_file = value(val);
+    else if (key == "o" || key == "outparam-file") o.outparam_file = value(val);
+    else if (key == "O" || key == "outcounts-file") o.outcounts_file = value(val);
+    else if (key == "i" || key == "max-iter") o.max_iter = std::atol(value(val).c_str());
+    else if (key == "e" || key == "converge") o.converge_ratio = std::atof(value(val).c_str());
+    else if (key == "d" || key == "deltaparam-epsilon") o.converge_delta = std::atof(value(val).c_str());
+    else if (key == "p" || key == "prior-counts-per") o.prior_counts = std::atof(value(val).c_str());
+    else if (key == "k" || key == "add-k-smoothing") o.add_k = std::atof(value(val).c_str());
+    else if (key == "z" || key == "zero-zerocounts") o.zero_zerocounts = true;
+    else if (key == "N" || key == "normalize-initial") o.normalize_initial = true;
+    else if (key == "H" || key == "human-probs") o.human_probs = true;
+    else if (key == "U" || key == "use-double-precision") {}  // always double here
+    else if (key == "crp") o.crp = std::atol(value(val).c_str());
+    else if (key == "alpha") o.alpha = std::atof(value(val).c_str());
+    else if (key == "burnin") o.burnin = std::atol(value(val).c_str());
+    else if (key == "final-counts") o.final_counts = true;
+    else if (key == "uniform-p0") o.uniform_p0 = true;
+    else if (key == "crp-parallel") o.parallel = true;
+    else if (key == "random-seed") o.seed = std::strtoull(value(val).c_str(), 0, 10);
+    else if (key == "gpu") o.gpu = std::atoi(value(val).c_str());
+    else throw std::runtime_error("unknown option " + a);
+  }
+  if (o.forests_file.empty()) throw std::runtime_error("no forests file (-f)");
+  return o;
+}
+
+// NormalizeGroups on the weights themselves (normalize.hpp:123-164 with source = destination): --normalize-initial
+void normalize_weights(std::vector<double>& logw, const std::vector<uint64_t>& off, const std::vector<uint32_t>& rule,
+                       bool zero_zerocounts) {
+  for (size_t g = 0; g + 1 < off.size(); ++g) {
+    double sum = 0;
+    for (uint64_t j = off[g]; j < off[g + 1]; ++j) sum += std::exp(logw[rule[j]]);
+    for (uint64_t j = off[g]; j < off[g + 1]; ++j) {
+      if (sum > 0)
+        logw[rule[j]] = logw[rule[j]] - std::log(sum);
+      else
+        logw[rule[j]] = zero_zerocounts ? -std::numeric_limits<double>::infinity() : -std::log((double)(off[g + 1] - off[g]));
+    }
+  }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    Opts o = parse_args(argc, argv);
+    std::ostream& log = std::cerr;
+    ForestSet fs;
+    {
+      const std::string text = slurp(o.forests_file);
+      ForestReader(text, fs).read_all();
+    }
+    if (fs.n_forests() == 0) throw std::runtime_error("no forests in " + o.forests_file);
+    std::vector<uint64_t> group_off(1, 0);
+    std::vector<uint32_t> group_rule;
+    uint32_t max_rule = fs.max_rule;
+    if (o.normgroups_file != "-0") read_normgroups(slurp(o.normgroups_file), group_off, group_rule, max_rule);
+    std::vector<double> init;
+    if (o.initparam_file != "-0") {
+      init = read_params(slurp(o.initparam_file));
+      if (init.size() > max_rule) max_rule = (uint32_t)init.size();
+    }
+    const uint32_t n_rules = max_rule + 1;  // ids are 1-based; slot 0 is unused
+    std::vector<double> logw(n_rules, 0.0);  // unset parameters start at 1 (forest-em.hpp: rule_weights default)
+    for (size_t r = 0; r < init.size(); ++r) logw[r + 1] = init[r];
+    if (o.normalize_initial) normalize_weights(logw, group_off, group_rule, o.zero_zerocounts);
+    log << fs.n_forests() << " forests, " << fs.label.size() << " nodes, " << max_rule << " parameters in "
+        << group_off.size() - 1 << " normalization groups.\n";
+    carmel_hip_forests* F = nullptr;
+    check(carmel_hip_forests_create(&F, o.gpu, fs.n_forests(), fs.node_off.data(), fs.label.data(), fs.ref.data(),
+                                    fs.next.data(), n_rules, logw.data(), group_off.size() - 1, group_off.data(),
+                                    group_rule.data()),
+          "carmel_hip_forests_create");
+    const int style = o.human_probs ? W_NEVER_LOG : W_SOMETIMES_LOG;
+    if (o.crp > 0) {
+      carmel_hip_gibbs_opts go;
+      std::memset(&go, 0, sizeof go);
+      go.iter = (uint32_t)o.crp;
+      go.burnin = (uint32_t)o.burnin;
+      go.seed = o.seed;
+      go.mode = o.parallel ? 1 : 0;
+      go.uniform_p0 = o.uniform_p0;
+      go.final_counts = o.final_counts;
+      std::vector<double> lp((size_t)o.crp + 1);
+      check(carmel_hip_forests_gibbs(F, &go, o.alpha, lp.data(), nullptr), "carmel_hip_forests_gibbs");
+      for (size_t i = 0; i < lp.size(); ++i)
+        log << "i=" << i << " sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
+    } else {
+      // overrelaxed_em (em.hpp:107-216), one start, learning rate 1
+      double best = -std::numeric_limits<double>::infinity(), last = best;
+      std::vector<double> best_w = logw;
+      bool first = true;
+      for (long it = 1; it <= o.max_iter; ++it) {
+        double alp = 0;
+        uint64_t n_zero = 0;
+        check(carmel_hip_forests_estimate(F, o.prior_counts, &alp, &n_zero, nullptr), "carmel_hip_forests_estimate");
+        log << "i=" << it << " average log-prob=" << alp << " (2^" << alp / std::log(2.0) << " per forest";
+        if (n_zero) log << ", " << n_zero << " forests with zero probability ignored";
+        log << ")";
+        if (alp > best || first) {
+          best = alp;
+          check(carmel_hip_forests_get_weights(F, best_w.data()), "carmel_hip_forests_get_weights");
+          log << " (new best)";
+        }
+        double rel = std::numeric_limits<double>::infinity();
+        if (!first) {
+          double la = std::fabs(last);
+          if (la < 1e-5) la = 1e-5;  // LOGPROB_EPSILON (em.hpp)
+          rel = (alp - last) / la;
+          log << " relative change=" << rel;
+        }
+        log << "\n";
+        first = false;
+        if (rel < o.converge_ratio) {
+          log << "Converged - relative change in average log-prob less than " << o.converge_ratio << " after " << it
+              << " iterations.\n";
+          break;
+        }
+        double delta = 0;
+        check(carmel_hip_forests_maximize(F, o.prior_counts, o.add_k, o.zero_zerocounts ? 1 : 0, &delta),
+              "carmel_hip_forests_maximize");
+        if (delta <= o.converge_delta) {
+          log << "Converged - maximum parameter change " << delta << " after " << it << " iterations.\n";
+          break;
+        }
+        last = alp;
+      }
+      check(carmel_hip_forests_set_weights(F, best_w.data()), "carmel_hip_forests_set_weights");
+      log << "Best average log-prob=" << best << "\n";
+    }
+    check(carmel_hip_forests_get_weights(F, logw.data()), "carmel_hip_forests_get_weights");
+    if (o.outcounts_file != "-0") {
+      std::vector<double> counts(n_rules);
+      check(carmel_hip_forests_estimate(F, o.prior_counts, nullptr, nullptr, nullptr), "carmel_hip_forests_estimate");
+      check(carmel_hip_forests_get_counts(F, o.prior_counts, counts.data()), "carmel_hip_forests_get_counts");
+      std::vector<double> lc(n_rules);
+      for (uint32_t r = 0; r < n_rules; ++r) lc[r] = counts[r] > 0 ? std::log(counts[r]) : -std::numeric_limits<double>::infinity();
+      log << "Writing trained counts to " << o.outcounts_file << "\n";
+      spit(o.outcounts_file, write_params(lc.data() + 1, n_rules - 1, style));
+    }
+    if (o.outparam_file != "-0") {
+      log << "Writing trained parameters to " << o.outparam_file << "\n";
+      spit(o.outparam_file, write_params(logw.data() + 1, n_rules - 1, style));
+    }
+    carmel_hip_forests_destroy(F);
+    return 0;
+  } catch (std::exception& e) {
+    std::cerr << "ERROR: " << e.what() << "\n";
+    return 11;
+  }
+}

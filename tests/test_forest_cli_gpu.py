@@ -1,0 +1,106 @@
+"""GPU: the forest-em command line (carmel_amd/bin/forest-em) on the reference's sample inputs and on synthetic forests,
+against the oracle's EM over the same files; plus the host-side text reader on CPU (test_forest_text_cpu below is not
+GPU-marked)."""
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+CLI = os.path.join(ROOT, "carmel_amd", "bin", "forest-em")
+
+
+def run(args):
+    p = subprocess.run([CLI] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    return p.returncode, p.stdout, p.stderr
+
+
+def parse_vec(txt):
+    toks = txt.strip().strip("()").split()
+    out = []
+    for t in toks:
+        out.append(math.exp(float(t[2:])) if t.startswith("e^") else float(t))
+    return np.array(out)
+
+
+def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 / 65536, init=None):
+    """em.hpp:107-216 for one start at rate 1, driven from Python over the oracle's estimate / maximize"""
+    of = oracle.OracleForests(ftxt, ntxt)
+    if init is not None:
+        of.set_weights(init)
+    best, last, best_w, first, trace = -np.inf, -np.inf, of.weights(), True, []
+    for _ in range(max_iter):
+        alp = of.estimate()[0]
+        trace.append(alp)
+        if alp > best or first:
+            best, best_w = alp, of.weights()
+        rel = np.inf if first else (alp - last) / max(abs(last), 1e-5)
+        first = False
+        if rel < rel_eps:
+            break
+        if of.maximize() <= delta_eps:
+            break
+        last = alp
+    return best, best_w, trace
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_on_reference_sample(oracle, golden_dir, tmp_path):
+    """forest-em -f sample/forests -n sample/norm (forest-em/Makefile:62-67): parameters equal the oracle's EM"""
+    f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
+    out = tmp_path / "params"
+    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "30"])
+    assert rc == 0, err
+    assert "5 forests, 60 nodes" in err
+    best, bw, trace = oracle_em(oracle, open(f).read(), open(n).read(), 30)
+    got = parse_vec(out.read_text())
+    assert len(got) == len(bw) - 1
+    np.testing.assert_allclose(got, np.exp(bw[1:]), rtol=1e-9, atol=1e-300)
+    its = re.findall(r"^i=(\d+) average log-prob=(\S+)", err, re.M)
+    assert len(its) == len(trace)
+    for (i, v), t in zip(its, trace):
+        assert float(v) == pytest.approx(t, rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_options(oracle, tmp_path):
+    """initial parameters (-I), add-k smoothing, prior counts, counts output (-O), human probs (-H)"""
+    from test_forest_gpu import synth_forests
+    ftxt, ntxt = synth_forests(40, 30, seed=5)
+    (tmp_path / "f").write_text(ftxt)
+    (tmp_path / "n").write_text(ntxt)
+    rng = np.random.default_rng(2)
+    init = rng.uniform(0.1, 1.0, 29)
+    (tmp_path / "i").write_text("(" + " ".join("%.17g" % v for v in init) + ")\n")
+    rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-I", str(tmp_path / "i"), "-o",
+                       str(tmp_path / "o"), "-O", str(tmp_path / "c"), "-i", "1", "-H"])
+    assert rc == 0, err
+    of = oracle.OracleForests(ftxt, ntxt)
+    lw = np.zeros(of.n_rules)
+    lw[1:1 + len(init)] = np.log(init)
+    of.set_weights(lw)
+    avg, counts, _ = of.estimate()
+    got_c = parse_vec((tmp_path / "c").read_text())
+    np.testing.assert_allclose(got_c, counts[1:1 + len(got_c)], rtol=1e-9, atol=1e-300)
+    # one iteration: the first estimate is the best one, its (initial) weights come back
+    np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text())[:len(init)], init, rtol=1e-12)
+    assert "e^" not in (tmp_path / "o").read_text()
+
+
+def test_forest_text_cpu(golden_dir):
+    """the command line parses its inputs and fails loudly without a GPU (no CPU fallback)"""
+    if not os.path.exists(CLI):
+        pytest.skip("forest-em not built")
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("has a GPU")
+    rc, so, err = run(["-f", os.path.join(golden_dir, "fem.forests"), "-n", os.path.join(golden_dir, "fem.norm")])
+    assert rc != 0
+    assert "5 forests, 60 nodes, 16 parameters in 2 normalization groups." in err
+    assert "ERROR: carmel_hip_forests_create" in err
+    bad = run(["-f", os.path.join(golden_dir, "fem.norm")])
+    assert bad[0] != 0 and "forest 1, character" in bad[2]
