@@ -85,7 +85,7 @@ def test_forest_em_cli_options(oracle, tmp_path):
     of.set_weights(lw)
     avg, counts, _ = of.estimate()
     got_c = parse_vec((tmp_path / "c").read_text())
-    np.testing.assert_allclose(got_c, counts[1:1 + len(got_c)], rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(got_c, np.exp(counts[1:1 + len(got_c)]), rtol=1e-9, atol=1e-300)  # the oracle hands back ln counts
     # one iteration: the first estimate is the best one, its (initial) weights come back
     np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text())[:len(init)], init, rtol=1e-12)
     assert "e^" not in (tmp_path / "o").read_text()
