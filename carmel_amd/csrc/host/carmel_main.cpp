@@ -358,6 +358,7 @@ static int run(int argc, char** argv) {
       log << "0 iterations specified for training; weights are left unchanged (fractional-count output is not "
              "offered by the GPU front end).\n";
   } else {
+    const bool timing = std::getenv("CARMEL_TIMING") != nullptr;  // per-iteration wall clock on stderr
     double best = std::numeric_limits<double>::infinity(), last_ppx = best, last_change = 10.0;
     bool have_good = false, last_was_reset = false;
     long iter = 0;
@@ -378,7 +379,14 @@ static int run(int argc, char** argv) {
             << format_weight(std::log(last_change), W_SOMETIMES_LOG) << "\n";
         break;
       }
+      const auto t_e0 = std::chrono::steady_clock::now();
       hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+      if (timing) {
+        double sweep_ms = 0;
+        carmel_hip_last_sweep_ms(t, &sweep_ms);
+        log << "timing: i=" << iter << " estimate " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_e0).count()
+            << " ms (kernels " << sweep_ms << " ms)" << std::endl;
+      }
       const double new_ppx = -er.sum_weighted_logprob / cs.total_weight;  // ln p.ppxper(totalEmpiricalWeight)
       log << "i=" << iter << " (rate=" << learning_rate << "): ";
       print_ppx(er.sum_logprob);

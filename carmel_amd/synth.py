@@ -144,3 +144,47 @@ def random_forests(n_forests, n_rules=500000, mean_nodes=46, p_backref=0.6, grou
         goff = np.append(goff, n_rules)
     return (np.asarray(node_off, np.uint64), np.asarray(labels, np.uint32), np.asarray(refs, np.int32),
             np.asarray(nexts, np.uint32), n_rules + 1, goff.astype(np.uint64), perm.astype(np.uint32))
+
+
+CIPHER_PLAIN = ["_"] + [chr(ord("A") + i) for i in range(26)]
+
+
+def cipher_files(n_lines, min_len=30, max_len=80, seed=2):
+    """SURVEY.md section 8d config 3, in the reference's own file formats (carmel/sample/decipher, tutorial cipher.*):
+    a character bigram language model as a locked acceptor over *e*:"C" arcs (START + 27 states, the word separator
+    "_" can stop: `_ -> END`), a 1-state 27x27 substitution channel "C":"c" with uniform weights, and a corpus of
+    n_lines pairs (blank input line, min_len..max_len quoted cipher symbols).  Plain text is drawn from the bigram
+    model itself and enciphered with a random permutation.  Returns (lm_text, channel_text, corpus_text)."""
+    rng = np.random.default_rng(seed)
+    n = len(CIPHER_PLAIN)
+    big = rng.dirichlet(np.full(n, 0.3), size=n)       # P(next | prev), peaked like letter bigrams
+    start = rng.dirichlet(np.full(n, 0.5))
+    p_end = 0.1                                         # P(END | "_")
+    lm = ["END"]
+    for c in range(n):
+        lm.append('(START (%s *e* "%s" %.15g!))' % (CIPHER_PLAIN[c], CIPHER_PLAIN[c], start[c]))
+    for a in range(n):
+        scale = (1.0 - p_end) if a == 0 else 1.0
+        for c in range(n):
+            lm.append('(%s (%s *e* "%s" %.15g!))' % (CIPHER_PLAIN[a], CIPHER_PLAIN[c], CIPHER_PLAIN[c], big[a, c] * scale))
+    lm.append("(_ (END *e* *e* %.15g!))" % p_end)
+    cipher_syms = [s.lower() if s != "_" else "_" for s in CIPHER_PLAIN]
+    ch = ["0"]
+    for a in range(n):
+        for c in range(n):
+            ch.append('(0 (0 "%s" "%s"))' % (CIPHER_PLAIN[a], cipher_syms[c]))
+    perm = rng.permutation(n - 1) + 1                  # "_" maps to itself, letters are permuted
+    key = np.concatenate([[0], perm])
+    lens = rng.integers(min_len, max_len + 1, size=n_lines)
+    lines = []
+    cdf = np.cumsum(big, axis=1)
+    for L in lens:
+        u = rng.random(int(L))
+        cur, out = 0, [0]                               # lines start and end with the separator
+        for k in range(int(L) - 2):
+            cur = int(np.searchsorted(cdf[cur], u[k]))
+            cur = min(cur, n - 1)
+            out.append(cur)
+        out.append(0)
+        lines.append("\n" + " ".join('"%s"' % cipher_syms[key[c]] for c in out))
+    return "\n".join(lm) + "\n", "\n".join(ch) + "\n", "\n".join(lines) + "\n"
