@@ -11,6 +11,7 @@
 //
 // The iteration control below restates WFST::train (train.cc:503-678); every E-step and M-step runs on the GPU.
 #include <algorithm>
+#include <chrono>
 #include <cctype>
 #include <cstring>
 #include <cstdio>
