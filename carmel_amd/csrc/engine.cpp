@@ -10,6 +10,10 @@
 #include <unordered_map>
 #include <vector>
 #include "engine.hpp"
+#include "unrolled_args.hpp"
+
+int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats);
+int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s);
 
 static thread_local std::string g_err;
 namespace carmel_hip {
@@ -131,6 +135,12 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
   HIPCHK(hipSetDevice(t->device));
+  {
+    // one-tape models never store their lattices (unrolled.hpp)
+    int rc = unrolled_try_build(t, host_threads, has_derivation, stats);
+    if (rc) return rc;
+    if (t->unrolled) return CARMEL_HIP_OK;
+  }
   auto t0 = std::chrono::steady_clock::now();
   BuildOptions opt;
   opt.prune = prune != 0;
@@ -503,6 +513,15 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
   HIPCHK(hipMemsetAsync(t->counts_ptr() + t->w.n_arcs, 0, 4 * sizeof(double), s));  // scalars; counts are all written
+  if (t->unrolled) {
+    HIPCHK(hipEventRecord(t->ev0, s));
+    int rc = unrolled_estimate(t, s);
+    if (rc) return rc;
+    HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
+                          t->counts_ptr() + t->w.n_arcs, s));
+    HIPCHK(hipEventRecord(t->ev1, s));
+    return CARMEL_HIP_OK;
+  }
   SweepArgs A;
   A.bundles = t->bundles.p;
   A.in_arcs = (const uint2*)t->in_arcs.p;
@@ -665,6 +684,8 @@ void* carmel_hip_stream(carmel_hip_trainer* t) { return t ? (void*)t->stream : n
 
 int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts) {
   if (!t || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (t->unrolled && t->cascade)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "the unrolled sweep of a cascade accumulates per parameter: no composed-arc counts (CARMEL_HIP_UNROLLED=0 keeps explicit lattices)");
   HIPCHK(hipSetDevice(t->device));
   HIPCHK(hipMemcpyAsync(counts, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
@@ -686,9 +707,15 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
   if (t->cascade) {
     // distribute_counts (cascade.h:318-325): parameter counts = sum over composed arcs using it of
     // (composed count + composed prior)
-    HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
-    HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
-                                t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+    if (t->unrolled) {  // the sweep accumulated per parameter already
+      HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->counts_ptr(), t->u_param_uses.p,
+                                          t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
+                                          (uint32_t)t->n_params, s));
+    } else {
+      HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
+      HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
+                                  t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+    }
   }
   int rc = run_mstep(t, 1, 1);
   if (rc) return rc;
@@ -734,12 +761,19 @@ int carmel_hip_save_counts(carmel_hip_trainer* t) {
   HIPCHK(hipSetDevice(t->device));
   // for_arcs::save_counts: em_weight <- weight() of the composed arc, which after the previous maximize's
   // prep_new_weights holds (count + prior) — here: the counts buffer of the previous estimate
-  HIPCHK(hipMemcpyAsync(t->em_logw.p, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+  if (t->unrolled && t->cascade)  // parameter space: the sweep never had composed-arc counts
+    HIPCHK(hipMemcpyAsync(t->u_em_param.p, t->counts_ptr(), t->n_params * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+  else
+    HIPCHK(hipMemcpyAsync(t->em_logw.p, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
   return CARMEL_HIP_OK;
 }
 int carmel_hip_save_best(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->unrolled && t->cascade) {
+    HIPCHK(hipMemcpyAsync(t->u_best_param.p, t->u_em_param.p, t->n_params * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+    return CARMEL_HIP_OK;
+  }
   const double* from = t->cascade ? t->em_logw.p : t->arc_logw.p;
   HIPCHK(hipMemcpyAsync(t->best_logw.p, from, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
   return CARMEL_HIP_OK;
@@ -754,11 +788,17 @@ int carmel_hip_load_best(carmel_hip_trainer* t) {
     return CARMEL_HIP_OK;
   }
   // load_best + use_counts_final (train.cc:673-674, cascade.h:358-364): best composed counts -> parameters
-  HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
-  // the saved value already includes the composed prior (prep_new_weights ran before it was saved)
-  HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
-                              t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+  if (t->unrolled) {
+    HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->u_best_param.p, t->u_param_uses.p,
+                                        t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
+                                        (uint32_t)t->n_params, s));
+  } else {
+    HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
+    // the saved value already includes the composed prior (prep_new_weights ran before it was saved)
+    HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
+                                t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+  }
   int rc = run_mstep(t, 1, 1);
   if (rc) return rc;
   HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,

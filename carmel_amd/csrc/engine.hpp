@@ -5,6 +5,7 @@
 #include <vector>
 #include "../../include/carmel_hip.h"
 #include "kernels.hpp"
+#include "unrolled.hpp"
 
 namespace carmel_hip {
 int fail(int code, const std::string& msg);  // records carmel_hip_last_error() text, returns code
@@ -95,6 +96,17 @@ struct carmel_hip_trainer {
   bool all_grouped = true;                 // every parameter is in a norm group
   DevBuf<double> pair_w;          // pair weight by pair id, < 0 for pairs dropped at build_lattices
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction
+  // one-tape models: lattices are never stored, the sweep walks positions (unrolled.hpp)
+  bool unrolled = false;
+  UnrolledModel um;  // host tables (bulk arrays are freed after upload)
+  DevBuf<uint32_t> u_f_off, u_b_off, u_f_arc, u_b_arc, u_e_arc, u_pair_id;
+  DevBuf<uint8_t> u_f_src, u_b_dst, u_e_src, u_e_dst;
+  DevBuf<uint16_t> u_f_slot, u_e_slot, u_seq_sym;
+  DevBuf<uint64_t> u_seq_off;
+  DevBuf<double> u_Wf, u_Wb, u_We, u_pair_weight, u_partial;
+  DevBuf<double> u_param_uses;          // cascade: composed arcs whose chain holds the parameter (for the -f prior)
+  DevBuf<double> u_em_param, u_best_param;  // cascade: parameter-space images of em_weight / best_weight
+  uint32_t u_n_slots = 0, u_n_wg = 0;
   bool use_transpose = false;
   bool em_valid = false;  // em_logw holds the plain EM update of the last (over-relaxed) maximize
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only

@@ -1,0 +1,156 @@
+// engine_unrolled.cpp: the trainer's side of the unrolled sweep (unrolled.hpp): eligibility, upload, E-step.
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+
+#include "engine.hpp"
+#include "unrolled_args.hpp"
+
+// Tries to set the trainer up for the unrolled sweep.  Returns CARMEL_HIP_OK with t->unrolled set when the model and
+// the corpus are eligible, CARMEL_HIP_OK with t->unrolled clear when they are not (the caller then builds explicit
+// lattices), an error code on a HIP failure.
+int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats) {
+  t->unrolled = false;
+  if (const char* e = getenv("CARMEL_HIP_UNROLLED"))
+    if (atoi(e) == 0) return CARMEL_HIP_OK;
+  auto t0 = std::chrono::steady_clock::now();
+  UnrolledModel& M = t->um;
+  if (!build_unrolled(t->w, t->corpus, host_threads, M)) return CARMEL_HIP_OK;
+  // accumulator slots: the arc itself, or the unlocked parameters of its chain
+  const uint64_t n_arcs = t->w.n_arcs;
+  std::vector<uint16_t> arc_slot((size_t)n_arcs * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
+  uint32_t n_slots = 0;
+  std::vector<double> uses;
+  if (!t->cascade) {
+    if (n_arcs > UNROLLED_MAX_SLOTS) return CARMEL_HIP_OK;
+    n_slots = (uint32_t)n_arcs;
+    for (uint64_t a = 0; a < n_arcs; ++a) arc_slot[a * UNROLLED_MAX_CHAIN] = (uint16_t)a;
+  } else {
+    if (t->n_params > UNROLLED_MAX_SLOTS || t->n_params > n_arcs) return CARMEL_HIP_OK;
+    n_slots = (uint32_t)t->n_params;
+    uses.assign(n_slots, 0.0);
+    for (uint64_t a = 0; a < n_arcs; ++a) {
+      const uint32_t ch = t->w.group[a];
+      uint32_t k = 0;
+      for (uint64_t j = t->h_chain_off[ch]; j < t->h_chain_off[ch + 1]; ++j) {
+        const uint64_t p = t->h_chain_param[j];
+        if (t->h_param_group[p] == CARMEL_HIP_LOCKED_GROUP) continue;
+        if (k == UNROLLED_MAX_CHAIN) return CARMEL_HIP_OK;  // longer chains: explicit lattices
+        arc_slot[a * UNROLLED_MAX_CHAIN + k++] = (uint16_t)p;
+        uses[p] += 1.0;
+      }
+    }
+  }
+  // LDS: accumulators + per wave (max_len + 1) rows of S values, the scales, one row of beta
+  {
+    const size_t per_wave = (size_t)(M.max_len + 1) * M.S + (M.max_len + 2) + M.S;
+    if ((n_slots + 4 * per_wave) * sizeof(double) > 150 * 1024) return CARMEL_HIP_OK;
+  }
+  if (M.pair_id.empty()) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation");
+  hipStream_t s = t->stream;
+  std::vector<uint16_t> f_slot(M.f_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT),
+      e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
+  for (size_t k = 0; k < M.f_arc.size(); ++k)
+    if (M.f_arc[k] != 0xffffffffu)
+      for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) f_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.f_arc[k] * UNROLLED_MAX_CHAIN + j];
+  for (size_t k = 0; k < M.e_arc.size(); ++k)
+    for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) e_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.e_arc[k] * UNROLLED_MAX_CHAIN + j];
+  HIPCHK(t->u_f_off.upload(M.f_off, s));
+  HIPCHK(t->u_b_off.upload(M.b_off, s));
+  HIPCHK(t->u_f_arc.upload(M.f_arc, s));
+  HIPCHK(t->u_b_arc.upload(M.b_arc, s));
+  HIPCHK(t->u_e_arc.upload(M.e_arc, s));
+  HIPCHK(t->u_f_src.upload(M.f_src, s));
+  HIPCHK(t->u_b_dst.upload(M.b_dst, s));
+  HIPCHK(t->u_e_src.upload(M.e_src, s));
+  HIPCHK(t->u_e_dst.upload(M.e_dst, s));
+  HIPCHK(t->u_f_slot.upload(f_slot, s));
+  HIPCHK(t->u_e_slot.upload(e_slot, s));
+  HIPCHK(t->u_seq_off.upload(M.seq_off, s));
+  HIPCHK(t->u_seq_sym.upload(M.seq_sym, s));
+  HIPCHK(t->u_pair_id.upload(M.pair_id, s));
+  HIPCHK(t->u_pair_weight.upload(M.pair_weight, s));
+  HIPCHK(t->u_Wf.alloc(M.f_arc.size()));
+  HIPCHK(t->u_Wb.alloc(M.b_arc.size()));
+  HIPCHK(t->u_We.alloc(M.e_arc.size()));
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + 3) / 4);
+  t->u_n_slots = n_slots;
+  HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
+  if (t->cascade) {
+    HIPCHK(t->u_param_uses.upload(uses, s));
+    HIPCHK(t->u_em_param.alloc(n_slots));
+    HIPCHK(t->u_best_param.alloc(n_slots));
+  }
+  HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
+  {
+    std::vector<double> pw(t->corpus.n_pairs);
+    for (uint64_t p = 0; p < t->corpus.n_pairs; ++p)
+      pw[p] = M.has_deriv[p] ? (t->corpus.weight.empty() ? 1.0 : t->corpus.weight[p]) : -1.0;
+    HIPCHK(t->pair_w.upload(pw, s));
+    HIPCHK(t->scalar_partial.alloc(3 * 256));
+  }
+  HIPCHK(launch_fill(t->pair_logprob.p, -std::numeric_limits<double>::infinity(), t->corpus.n_pairs, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (has_derivation) std::memcpy(has_derivation, M.has_deriv.data(), M.has_deriv.size());
+  t->device_bytes = t->u_seq_sym.bytes() + t->u_seq_off.bytes() + t->u_pair_id.bytes() + t->u_pair_weight.bytes() +
+                    t->u_partial.bytes() + t->u_Wf.bytes() + t->u_Wb.bytes() + t->u_f_arc.bytes() + t->u_b_arc.bytes() +
+                    t->u_f_slot.bytes() + t->pair_logprob.bytes() + t->pair_w.bytes();
+  if (stats) {
+    std::memset(stats, 0, sizeof *stats);
+    stats->n_pairs = t->corpus.n_pairs;
+    stats->n_pairs_kept = M.pair_id.size();
+    stats->explored_arcs = M.explored_arcs;
+    stats->kept_states = M.lattice_states;
+    stats->kept_arcs = M.lattice_arcs;
+    stats->n_bundles = 0;  // nothing is laid out: the lattices are implicit
+    stats->max_levels = M.max_len + 1;
+    stats->device_bytes = t->device_bytes;
+    stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+  // the bulk host arrays are on the device now
+  std::vector<uint16_t>().swap(M.seq_sym);
+  std::vector<uint64_t>().swap(M.seq_off);
+  std::vector<double>().swap(M.pair_weight);
+  t->unrolled = true;
+  t->have_lattices = true;
+  return CARMEL_HIP_OK;
+}
+
+// the E-step proper (weights are current in t->arc_logw): counts into counts_ptr()[0 .. n_slots), ln p per pair
+int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
+  const UnrolledModel& M = t->um;
+  HIPCHK(launch_unrolled_weights(t->u_f_arc.p, t->arc_logw.p, t->u_Wf.p, (uint32_t)t->u_f_arc.n, s));
+  HIPCHK(launch_unrolled_weights(t->u_b_arc.p, t->arc_logw.p, t->u_Wb.p, (uint32_t)t->u_b_arc.n, s));
+  HIPCHK(launch_unrolled_weights(t->u_e_arc.p, t->arc_logw.p, t->u_We.p, (uint32_t)t->u_e_arc.n, s));
+  UnrolledArgs A;
+  A.S = M.S;
+  A.V = M.V;
+  A.start = M.start;
+  A.fin = M.fin;
+  A.n_eps = (uint32_t)t->u_e_arc.n;
+  A.n_slots = t->u_n_slots;
+  A.max_len = M.max_len;
+  A.n_pairs = M.pair_id.size();
+  A.f_off = t->u_f_off.p;
+  A.f_src = t->u_f_src.p;
+  A.Wf = t->u_Wf.p;
+  A.f_slot = t->u_f_slot.p;
+  A.b_off = t->u_b_off.p;
+  A.b_dst = t->u_b_dst.p;
+  A.Wb = t->u_Wb.p;
+  A.e_src = t->u_e_src.p;
+  A.e_dst = t->u_e_dst.p;
+  A.We = t->u_We.p;
+  A.e_slot = t->u_e_slot.p;
+  A.seq_off = t->u_seq_off.p;
+  A.seq_sym = t->u_seq_sym.p;
+  A.pair_id = t->u_pair_id.p;
+  A.pair_weight = t->u_pair_weight.p;
+  A.pair_logprob = t->pair_logprob.p;
+  A.partial = t->u_partial.p;
+  HIPCHK(launch_unrolled_sweep(A, t->u_n_wg, t->counts_ptr(), s));
+  return CARMEL_HIP_OK;
+}

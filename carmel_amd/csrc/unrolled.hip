@@ -1,0 +1,233 @@
+// unrolled.hip: forward-backward over lattices that are never stored (unrolled.hpp): one wavefront per training
+// pair, one lane per transducer state, positions walked in a loop.  gfx950 only.
+//
+// Arithmetic: the lattice of one pair is a chain of sparse matrix-vector products, so the sweep runs in the linear
+// domain with one rescaling per position (the classic scaled forward-backward): alpha_hat[o] sums to 1, the scale
+// c[o] goes into ln p.  A posterior is alpha_hat[o][src] * W * beta_hat[o+1][dst] / (c[o+1] * alpha_hat[L][final]);
+// nothing underflows however long the string is, and no exp/log is spent per lattice arc (two per position).  The
+// result equals the log-domain sweeps' to rounding (tests: 1e-9 on ln p, 1e-7 on counts).
+//
+// Counts: every arc adds its posterior to up to UNROLLED_MAX_CHAIN accumulator slots (the arc itself, or the unlocked
+// parameters of its cascade chain) held in LDS per workgroup (ds_add_f64), written out as one partial vector per
+// workgroup and summed in a fixed order by unrolled_reduce_kernel.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "unrolled_args.hpp"
+
+namespace carmel_hip {
+
+#define U_WAVES 4
+#define U_NEG_INF (-__builtin_huge_val())
+
+__device__ __forceinline__ double wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// linear weights in table order: Wf / Wb / We follow f_arc / b_arc / e_arc
+__global__ void unrolled_weights_kernel(const uint32_t* __restrict__ arcs, const double* __restrict__ logw,
+                                        double* __restrict__ out, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t a = arcs[k];
+  out[k] = a == 0xffffffffu ? 0.0 : exp(logw[a]);
+}
+
+__global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const uint32_t S = A.S;
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* acc = lds;                                   // n_slots accumulators, shared by the workgroup
+  const uint32_t per_wave = (A.max_len + 1) * S + (A.max_len + 2) + S;
+  double* alpha = lds + A.n_slots + (size_t)wave * per_wave;  // alpha_hat[o][s]
+  double* cs = alpha + (size_t)(A.max_len + 1) * S;           // c[o]
+  double* brow = cs + (A.max_len + 2);                        // beta_hat of the current position, for the gathers
+  for (uint32_t k = threadIdx.x; k < A.n_slots; k += 64 * U_WAVES) acc[k] = 0.0;
+  __syncthreads();
+  const bool on = lane < S;
+  const uint32_t total_waves = gridDim.x * U_WAVES;
+  for (uint64_t q = (uint64_t)blockIdx.x * U_WAVES + wave; q < A.n_pairs; q += total_waves) {
+    const uint64_t s0 = A.seq_off[q];
+    const uint32_t L = (uint32_t)(A.seq_off[q + 1] - s0);
+    const uint16_t* xs = A.seq_sym + s0;
+    // ---------- forward ----------
+    double a = (lane == A.start) ? 1.0 : 0.0;
+    for (uint32_t e = 0; e < A.n_eps; ++e) {  // *e*:*e* arcs in topological order of their sources
+      const double v = __shfl(a, A.e_src[e], 64) * A.We[e];
+      if (lane == A.e_dst[e]) a += v;
+    }
+    double lnz = 0.0;
+    bool dead = false;
+    {
+      const double c0 = wave_sum(on ? a : 0.0);
+      a /= c0;
+      lnz = log(c0);
+      if (on) alpha[lane] = a;
+      if (lane == 0) cs[0] = c0;
+    }
+    for (uint32_t o = 0; o < L; ++o) {
+      const uint32_t x = xs[o];
+      const uint32_t off = A.f_off[x], deg = (A.f_off[x + 1] - off) / S;
+      const double* arow = alpha + (size_t)o * S;
+      double v = 0.0;
+      if (on)
+        for (uint32_t it = 0; it < deg; ++it) {
+          const uint32_t k = off + it * S + lane;
+          v += arow[A.f_src[k]] * A.Wf[k];
+        }
+      for (uint32_t e = 0; e < A.n_eps; ++e) {
+        const double u = __shfl(v, A.e_src[e], 64) * A.We[e];
+        if (lane == A.e_dst[e]) v += u;
+      }
+      const double c = wave_sum(on ? v : 0.0);
+      if (!(c > 0.0)) {
+        dead = true;
+        break;
+      }
+      v /= c;
+      lnz += log(c);
+      if (on) alpha[(size_t)(o + 1) * S + lane] = v;
+      if (lane == 0) cs[o + 1] = c;
+    }
+    const double pfin = dead ? 0.0 : alpha[(size_t)L * S + A.fin];
+    const double lp = (dead || !(pfin > 0.0)) ? U_NEG_INF : lnz + log(pfin);
+    if (lane == 0) A.pair_logprob[A.pair_id[q]] = lp;
+    if (lp == U_NEG_INF) continue;
+    // ---------- backward + posteriors ----------
+    const double g = A.pair_weight[q] / pfin;  // "* weight / prob" (derivations.h:445)
+    double b = (lane == A.fin) ? 1.0 : 0.0;
+    // *e*:*e* arcs of the last position, in reverse order; their posteriors need beta of the destination complete
+    for (uint32_t e = A.n_eps; e-- > 0;) {
+      const uint32_t es = A.e_src[e], ed = A.e_dst[e];
+      const double u = __shfl(b, ed, 64) * A.We[e];
+      if (lane == es) b += u;
+      if (lane == 0) {
+        const double p = alpha[(size_t)L * S + es] * u * g;
+        for (int j = 0; j < UNROLLED_MAX_CHAIN; ++j) {
+          const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
+          if (sl != UNROLLED_NO_SLOT && p > 0.0) atomicAdd(acc + sl, p);
+        }
+      }
+    }
+    for (uint32_t o = L; o-- > 0;) {
+      const uint32_t x = xs[o];
+      const double* arow = alpha + (size_t)o * S;
+      const double gc = g / cs[o + 1];
+      // posteriors of the symbol arcs of position o: lane = destination; a run of arcs sharing their slots is added
+      // once (a cascade whose language model is locked leaves one channel parameter per lane and position)
+      {
+        const uint32_t off = A.f_off[x], deg = (A.f_off[x + 1] - off) / S;
+        if (on) {
+          const double bd = b * gc;
+          double run = 0.0;
+          uint32_t r0 = UNROLLED_NO_SLOT, r1 = UNROLLED_NO_SLOT, r2 = UNROLLED_NO_SLOT;
+          for (uint32_t it = 0; it < deg; ++it) {
+            const uint32_t k = off + it * S + lane;
+            const double p = arow[A.f_src[k]] * A.Wf[k] * bd;
+            const uint32_t t0 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN], t1 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN + 1],
+                           t2 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN + 2];
+            if (t0 != r0 || t1 != r1 || t2 != r2) {
+              if (run > 0.0) {
+                if (r0 != UNROLLED_NO_SLOT) atomicAdd(acc + r0, run);
+                if (r1 != UNROLLED_NO_SLOT) atomicAdd(acc + r1, run);
+                if (r2 != UNROLLED_NO_SLOT) atomicAdd(acc + r2, run);
+              }
+              run = 0.0;
+              r0 = t0;
+              r1 = t1;
+              r2 = t2;
+            }
+            run += p;
+          }
+          if (run > 0.0) {
+            if (r0 != UNROLLED_NO_SLOT) atomicAdd(acc + r0, run);
+            if (r1 != UNROLLED_NO_SLOT) atomicAdd(acc + r1, run);
+            if (r2 != UNROLLED_NO_SLOT) atomicAdd(acc + r2, run);
+          }
+        }
+      }
+      // beta_hat[o] from beta_hat[o+1]: lane = source
+      if (on) brow[lane] = b;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      {
+        const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
+        double v = 0.0;
+        if (on)
+          for (uint32_t it = 0; it < deg; ++it) {
+            const uint32_t k = off + it * S + lane;
+            v += brow[A.b_dst[k]] * A.Wb[k];
+          }
+        b = v / cs[o + 1];
+      }
+      for (uint32_t e = A.n_eps; e-- > 0;) {
+        const uint32_t es = A.e_src[e], ed = A.e_dst[e];
+        const double u = __shfl(b, ed, 64) * A.We[e];
+        if (lane == es) b += u;
+        if (lane == 0) {
+          const double p = arow[es] * u * g;
+          for (int j = 0; j < UNROLLED_MAX_CHAIN; ++j) {
+            const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
+            if (sl != UNROLLED_NO_SLOT && p > 0.0) atomicAdd(acc + sl, p);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  double* out = A.partial + (size_t)blockIdx.x * A.n_slots;
+  for (uint32_t k = threadIdx.x; k < A.n_slots; k += 64 * U_WAVES) out[k] = acc[k];
+}
+
+// counts[slot] = sum over workgroups, in a fixed order
+__global__ void unrolled_reduce_kernel(const double* __restrict__ partial, uint32_t n_wg, uint32_t n_slots,
+                                       double* __restrict__ counts) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_slots) return;
+  double v = 0.0;
+  for (uint32_t g = 0; g < n_wg; ++g) v += partial[(size_t)g * n_slots + k];
+  counts[k] = v;
+}
+
+// cascade: parameter counts = accumulated posteriors + the -f prior once per composed arc that uses the parameter
+// (what chain_scatter_kernel produces from composed-arc counts); locked parameters get none
+__global__ void unrolled_param_counts_kernel(double* __restrict__ out, const double* __restrict__ counts,
+                                             const double* __restrict__ uses, double floor_count,
+                                             const uint32_t* __restrict__ group, uint32_t n) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  out[p] = group[p] != 0u ? counts[p] + floor_count * uses[p] : 0.0;
+}
+hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
+                                        const uint32_t* group, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(unrolled_param_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, counts, uses, floor_count, group, n);
+  return hipGetLastError();
+}
+
+size_t unrolled_lds_bytes(const UnrolledArgs& A) {
+  const size_t per_wave = (size_t)(A.max_len + 1) * A.S + (A.max_len + 2) + A.S;
+  return (A.n_slots + U_WAVES * per_wave) * sizeof(double);
+}
+
+hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(unrolled_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, arcs, logw, out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s) {
+  const size_t lds = unrolled_lds_bytes(A);
+  static size_t attr_set = 0;
+  if (lds > 64 * 1024 && lds > attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)unrolled_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = lds;
+  }
+  hipLaunchKernelGGL(unrolled_sweep_kernel, dim3(n_wg), dim3(64 * U_WAVES), lds, s, A);
+  hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((A.n_slots + 255) / 256), dim3(256), 0, s, A.partial, n_wg, A.n_slots, counts);
+  return hipGetLastError();
+}
+
+}  // namespace carmel_hip

@@ -10,4 +10,5 @@ from carmel_amd import synth
 lm, ch, co = synth.cipher_files($N)
 open("$D/lm.wfsa", "w").write(lm); open("$D/ch.fst", "w").write(ch); open("$D/corpus", "w").write(co)
 PY
-/usr/bin/time -v env CARMEL_TIMING=1 CARMEL_TRAINED_DIR=$D ./carmel_amd/bin/carmel --train-cascade --normby=NC -HJ -M $ITERS $D/corpus $D/lm.wfsa $D/ch.fst 2>&1 | grep -E "^i=|timing|states /|Elapsed|Maximum resident|derivations|ERROR" | cut -c1-160
+export CARMEL_TIMING=1 CARMEL_TRAINED_DIR=$D
+time ./carmel_amd/bin/carmel --train-cascade --normby=NC -HJ -M $ITERS $D/corpus $D/lm.wfsa $D/ch.fst 2>&1 | grep -E "^i=|timing|states /|derivations|ERROR|rror" | cut -c1-170
