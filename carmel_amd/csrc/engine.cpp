@@ -647,7 +647,7 @@ int carmel_hip_estimate_finish(carmel_hip_trainer* t, carmel_hip_estimate_result
     HIPCHK(hipStreamSynchronize(t->stream));
   }
   if (res) *res = r;
-  if (t->lat.n_kept == 0)
+  if ((t->unrolled ? t->um.pair_id.size() : t->lat.n_kept) == 0)
     return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation - aborting training.");
   return CARMEL_HIP_OK;
 }
