@@ -45,15 +45,15 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   // LDS: accumulators + per wave (max_len + 1) rows of S values, the scales, one row of beta
   {
     const size_t per_wave = (size_t)(M.max_len + 1) * M.S + (M.max_len + 2) + M.S;
-    if ((n_slots + 4 * per_wave) * sizeof(double) > 150 * 1024) return CARMEL_HIP_OK;
+    if ((n_slots + 6 * per_wave) * sizeof(double) > 158 * 1024) return CARMEL_HIP_OK;  // 6 waves per workgroup (unrolled.hip)
   }
   if (M.pair_id.empty()) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation");
   hipStream_t s = t->stream;
-  std::vector<uint16_t> f_slot(M.f_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT),
+  std::vector<uint16_t> f_slot(M.b_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT),
       e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
-  for (size_t k = 0; k < M.f_arc.size(); ++k)
-    if (M.f_arc[k] != 0xffffffffu)
-      for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) f_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.f_arc[k] * UNROLLED_MAX_CHAIN + j];
+  for (size_t k = 0; k < M.b_arc.size(); ++k)  // slots ride with the backward (by source) table: that loop makes the posteriors
+    if (M.b_arc[k] != 0xffffffffu)
+      for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) f_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.b_arc[k] * UNROLLED_MAX_CHAIN + j];
   for (size_t k = 0; k < M.e_arc.size(); ++k)
     for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) e_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.e_arc[k] * UNROLLED_MAX_CHAIN + j];
   HIPCHK(t->u_f_off.upload(M.f_off, s));
@@ -76,7 +76,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_We.alloc(M.e_arc.size()));
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
-  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + 3) / 4);
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + 5) / 6);
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {
@@ -137,10 +137,10 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.f_off = t->u_f_off.p;
   A.f_src = t->u_f_src.p;
   A.Wf = t->u_Wf.p;
-  A.f_slot = t->u_f_slot.p;
   A.b_off = t->u_b_off.p;
   A.b_dst = t->u_b_dst.p;
   A.Wb = t->u_Wb.p;
+  A.b_slot = t->u_f_slot.p;
   A.e_src = t->u_e_src.p;
   A.e_dst = t->u_e_dst.p;
   A.We = t->u_We.p;

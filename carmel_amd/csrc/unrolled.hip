@@ -19,7 +19,8 @@
 
 namespace carmel_hip {
 
-#define U_WAVES 4
+#define U_WAVES 6
+#define U_BATCH 9
 #define U_NEG_INF (-__builtin_huge_val())
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -74,9 +75,18 @@ __global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledAr
       const double* arow = alpha + (size_t)o * S;
       double v = 0.0;
       if (on)
-        for (uint32_t it = 0; it < deg; ++it) {
-          const uint32_t k = off + it * S + lane;
-          v += arow[A.f_src[k]] * A.Wf[k];
+        for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {  // loads of a batch issue together (L2 latency once)
+          double wv[U_BATCH];
+          uint32_t sv[U_BATCH];
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) {
+            const bool ok = it0 + j < deg;
+            const uint32_t k = off + (ok ? it0 + j : it0) * S + lane;
+            wv[j] = ok ? A.Wf[k] : 0.0;
+            sv[j] = A.f_src[k];
+          }
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) v += arow[sv[j]] * wv[j];
         }
       for (uint32_t e = 0; e < A.n_eps; ++e) {
         const double u = __shfl(v, A.e_src[e], 64) * A.We[e];
@@ -116,49 +126,39 @@ __global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledAr
       const uint32_t x = xs[o];
       const double* arow = alpha + (size_t)o * S;
       const double gc = g / cs[o + 1];
-      // posteriors of the symbol arcs of position o: lane = destination; a run of arcs sharing their slots is added
-      // once (a cascade whose language model is locked leaves one channel parameter per lane and position)
-      {
-        const uint32_t off = A.f_off[x], deg = (A.f_off[x + 1] - off) / S;
-        if (on) {
-          const double bd = b * gc;
-          double run = 0.0;
-          uint32_t r0 = UNROLLED_NO_SLOT, r1 = UNROLLED_NO_SLOT, r2 = UNROLLED_NO_SLOT;
-          for (uint32_t it = 0; it < deg; ++it) {
-            const uint32_t k = off + it * S + lane;
-            const double p = arow[A.f_src[k]] * A.Wf[k] * bd;
-            const uint32_t t0 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN], t1 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN + 1],
-                           t2 = A.f_slot[(size_t)k * UNROLLED_MAX_CHAIN + 2];
-            if (t0 != r0 || t1 != r1 || t2 != r2) {
-              if (run > 0.0) {
-                if (r0 != UNROLLED_NO_SLOT) atomicAdd(acc + r0, run);
-                if (r1 != UNROLLED_NO_SLOT) atomicAdd(acc + r1, run);
-                if (r2 != UNROLLED_NO_SLOT) atomicAdd(acc + r2, run);
-              }
-              run = 0.0;
-              r0 = t0;
-              r1 = t1;
-              r2 = t2;
-            }
-            run += p;
-          }
-          if (run > 0.0) {
-            if (r0 != UNROLLED_NO_SLOT) atomicAdd(acc + r0, run);
-            if (r1 != UNROLLED_NO_SLOT) atomicAdd(acc + r1, run);
-            if (r2 != UNROLLED_NO_SLOT) atomicAdd(acc + r2, run);
-          }
-        }
-      }
-      // beta_hat[o] from beta_hat[o+1]: lane = source
+      // one loop over the out-arcs of every source (lane = source) gives both beta_hat[o] and the posteriors: the
+      // term W * beta_hat[o+1][dst] is the arc's share of beta, times alpha_hat[o][src] it is the arc's posterior
       if (on) brow[lane] = b;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       {
         const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
+        const double ag = on ? arow[lane] * gc : 0.0;
         double v = 0.0;
         if (on)
-          for (uint32_t it = 0; it < deg; ++it) {
-            const uint32_t k = off + it * S + lane;
-            v += brow[A.b_dst[k]] * A.Wb[k];
+          for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
+            double wv[U_BATCH];
+            uint32_t dv[U_BATCH];
+            uint16_t sl[U_BATCH][UNROLLED_MAX_CHAIN];
+#pragma unroll
+            for (int j = 0; j < U_BATCH; ++j) {
+              const bool ok = it0 + j < deg;
+              const uint32_t k = off + (ok ? it0 + j : it0) * S + lane;
+              wv[j] = ok ? A.Wb[k] : 0.0;
+              dv[j] = A.b_dst[k];
+#pragma unroll
+              for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c) sl[j][c] = A.b_slot[(size_t)k * UNROLLED_MAX_CHAIN + c];
+            }
+#pragma unroll
+            for (int j = 0; j < U_BATCH; ++j) {
+              const double term = brow[dv[j]] * wv[j];
+              v += term;
+              const double p = ag * term;
+              if (p > 0.0) {
+#pragma unroll
+                for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c)
+                  if (sl[j][c] != UNROLLED_NO_SLOT) atomicAdd(acc + sl[j][c], p);
+              }
+            }
           }
         b = v / cs[o + 1];
       }

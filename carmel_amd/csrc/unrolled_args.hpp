@@ -13,10 +13,10 @@ struct UnrolledArgs {
   const uint32_t* f_off;           // V + 1
   const uint8_t* f_src;
   const double* Wf;                // linear weights in f_arc order (0 for padding)
-  const uint16_t* f_slot;          // UNROLLED_MAX_CHAIN per entry
   const uint32_t* b_off;
   const uint8_t* b_dst;
   const double* Wb;
+  const uint16_t* b_slot;          // UNROLLED_MAX_CHAIN accumulator slots per entry
   const uint8_t* e_src;
   const uint8_t* e_dst;
   const double* We;
