@@ -43,10 +43,8 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
     }
   }
   // LDS: accumulators + per wave (max_len + 1) rows of S values, the scales, one row of beta
-  {
-    const size_t per_wave = (size_t)(M.max_len + 1) * M.S + (M.max_len + 2) + M.S;
-    if ((n_slots + 6 * per_wave) * sizeof(double) > 158 * 1024) return CARMEL_HIP_OK;  // 6 waves per workgroup (unrolled.hip)
-  }
+  const uint32_t n_waves = unrolled_waves(n_slots, M.max_len, M.S);
+  if (!n_waves) return CARMEL_HIP_OK;  // a pair too long for LDS: explicit lattices
   if (M.pair_id.empty()) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation");
   hipStream_t s = t->stream;
   std::vector<uint16_t> f_slot(M.b_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT),
@@ -76,7 +74,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_We.alloc(M.e_arc.size()));
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
-  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + 5) / 6);
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + n_waves - 1) / n_waves);
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {

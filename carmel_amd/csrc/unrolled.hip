@@ -19,7 +19,7 @@
 
 namespace carmel_hip {
 
-#define U_WAVES 6
+#define U_MAX_WAVES 6
 #define U_BATCH 9
 #define U_NEG_INF (-__builtin_huge_val())
 
@@ -37,7 +37,7 @@ __global__ void unrolled_weights_kernel(const uint32_t* __restrict__ arcs, const
   out[k] = a == 0xffffffffu ? 0.0 : exp(logw[a]);
 }
 
-__global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
+__global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t S = A.S;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,11 +46,12 @@ __global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledAr
   double* alpha = lds + A.n_slots + (size_t)wave * per_wave;  // alpha_hat[o][s]
   double* cs = alpha + (size_t)(A.max_len + 1) * S;           // c[o]
   double* brow = cs + (A.max_len + 2);                        // beta_hat of the current position, for the gathers
-  for (uint32_t k = threadIdx.x; k < A.n_slots; k += 64 * U_WAVES) acc[k] = 0.0;
+  for (uint32_t k = threadIdx.x; k < A.n_slots; k += blockDim.x) acc[k] = 0.0;
   __syncthreads();
   const bool on = lane < S;
-  const uint32_t total_waves = gridDim.x * U_WAVES;
-  for (uint64_t q = (uint64_t)blockIdx.x * U_WAVES + wave; q < A.n_pairs; q += total_waves) {
+  const uint32_t n_waves = blockDim.x >> 6;
+  const uint32_t total_waves = gridDim.x * n_waves;
+  for (uint64_t q = (uint64_t)blockIdx.x * n_waves + wave; q < A.n_pairs; q += total_waves) {
     const uint64_t s0 = A.seq_off[q];
     const uint32_t L = (uint32_t)(A.seq_off[q + 1] - s0);
     const uint16_t* xs = A.seq_sym + s0;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(64 * U_WAVES) void unrolled_sweep_kernel(UnrolledAr
   }
   __syncthreads();
   double* out = A.partial + (size_t)blockIdx.x * A.n_slots;
-  for (uint32_t k = threadIdx.x; k < A.n_slots; k += 64 * U_WAVES) out[k] = acc[k];
+  for (uint32_t k = threadIdx.x; k < A.n_slots; k += blockDim.x) out[k] = acc[k];
 }
 
 // counts[slot] = sum over workgroups, in a fixed order
@@ -206,9 +207,16 @@ hipError_t launch_unrolled_param_counts(double* out, const double* counts, const
   return hipGetLastError();
 }
 
-size_t unrolled_lds_bytes(const UnrolledArgs& A) {
+size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves) {
   const size_t per_wave = (size_t)(A.max_len + 1) * A.S + (A.max_len + 2) + A.S;
-  return (A.n_slots + U_WAVES * per_wave) * sizeof(double);
+  return (A.n_slots + n_waves * per_wave) * sizeof(double);
+}
+// waves per workgroup: as many as fit beside the accumulators (0: even one does not fit)
+uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S) {
+  const size_t per_wave = (size_t)(max_len + 1) * S + (max_len + 2) + S;
+  for (uint32_t w = U_MAX_WAVES; w >= 1; --w)
+    if ((n_slots + w * per_wave) * sizeof(double) <= 158 * 1024) return w;
+  return 0;
 }
 
 hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t n, hipStream_t s) {
@@ -218,14 +226,16 @@ hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, dou
 }
 
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s) {
-  const size_t lds = unrolled_lds_bytes(A);
+  const uint32_t n_waves = unrolled_waves(A.n_slots, A.max_len, A.S);
+  if (!n_waves) return hipErrorInvalidValue;
+  const size_t lds = unrolled_lds_bytes(A, n_waves);
   static size_t attr_set = 0;
   if (lds > 64 * 1024 && lds > attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)unrolled_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_set = lds;
   }
-  hipLaunchKernelGGL(unrolled_sweep_kernel, dim3(n_wg), dim3(64 * U_WAVES), lds, s, A);
+  hipLaunchKernelGGL(unrolled_sweep_kernel, dim3(n_wg), dim3(64 * n_waves), lds, s, A);
   hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((A.n_slots + 255) / 256), dim3(256), 0, s, A.partial, n_wg, A.n_slots, counts);
   return hipGetLastError();
 }

@@ -29,7 +29,8 @@ struct UnrolledArgs {
   double* partial;                 // n_workgroups * n_slots
 };
 
-size_t unrolled_lds_bytes(const UnrolledArgs& A);
+size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves);
+uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S);
 hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t n, hipStream_t s);
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
                                         const uint32_t* group, uint32_t n, hipStream_t s);
