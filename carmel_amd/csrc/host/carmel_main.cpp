@@ -318,6 +318,10 @@ static int run(int argc, char** argv) {
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
   hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+  if (std::getenv("CARMEL_TIMING"))
+    std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
+              << " layout=" << (ls.n_bundles ? "explicit" : "unrolled") << " device_bytes=" << ls.device_bytes
+              << " build_seconds=" << ls.build_seconds << std::endl;
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
     if (!has[p]) {
@@ -427,7 +431,10 @@ static int run(int argc, char** argv) {
         }
       } else
         last_was_reset = false;
+      const auto t_m0 = std::chrono::steady_clock::now();
       hip_check(carmel_hip_maximize(t, learning_rate, &last_change), "carmel_hip_maximize");
+      if (timing)
+        log << "timing: i=" << iter << " maximize " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_m0).count() << " ms" << std::endl;
       if (last_change <= o.converge && have_good) {
         log << "Converged - maximum weight change less than " << format_weight(std::log(o.converge), W_SOMETIMES_LOG)
             << " after " << iter << " iterations.\n";
