@@ -133,45 +133,34 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       {
         const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
-        const uint32_t ln = on ? lane : 0u;  // idle lanes shadow lane 0 with zero weight: the wave stays converged
         const double ag = on ? arow[lane] * gc : 0.0;
         double v = 0.0;
-        for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
-          double wv[U_BATCH];
-          uint32_t dv[U_BATCH];
-          uint32_t sl[U_BATCH][UNROLLED_MAX_CHAIN];
+        if (on)
+          for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
+            double wv[U_BATCH];
+            uint32_t dv[U_BATCH];
+            uint16_t sl[U_BATCH][UNROLLED_MAX_CHAIN];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) {
-            const bool ok = on && it0 + j < deg;
-            const uint32_t k = off + (it0 + j < deg ? it0 + j : it0) * S + ln;
-            wv[j] = ok ? A.Wb[k] : 0.0;
-            dv[j] = A.b_dst[k];
+            for (int j = 0; j < U_BATCH; ++j) {
+              const bool ok = it0 + j < deg;
+              const uint32_t k = off + (ok ? it0 + j : it0) * S + lane;
+              wv[j] = ok ? A.Wb[k] : 0.0;
+              dv[j] = A.b_dst[k];
 #pragma unroll
-            for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c)
-              sl[j][c] = ok ? (uint32_t)A.b_slot[(size_t)k * UNROLLED_MAX_CHAIN + c] : UNROLLED_NO_SLOT;
-          }
+              for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c) sl[j][c] = A.b_slot[(size_t)k * UNROLLED_MAX_CHAIN + c];
+            }
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) {
-            const double term = brow[dv[j]] * wv[j];
-            v += term;
-            const double p = ag * term;
+            for (int j = 0; j < U_BATCH; ++j) {
+              const double term = brow[dv[j]] * wv[j];
+              v += term;
+              const double p = ag * term;
+              if (p > 0.0) {
 #pragma unroll
-            for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c) {
-              // the k-th out-arcs of all sources often share a parameter (a channel entry): one add for the wave then,
-              // instead of up to 64 colliding ones
-              const uint32_t mine = sl[j][c];
-              const unsigned long long have = __ballot(mine != UNROLLED_NO_SLOT);
-              if (!have) continue;
-              const uint32_t first = __shfl(mine, __ffsll((long long)have) - 1, 64);
-              if (__ballot(mine == first) == have) {
-                const double tot = wave_sum(mine == first ? p : 0.0);
-                if (lane == 0 && tot > 0.0) atomicAdd(acc + first, tot);
-              } else if (mine != UNROLLED_NO_SLOT && p > 0.0) {
-                atomicAdd(acc + mine, p);
+                for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c)
+                  if (sl[j][c] != UNROLLED_NO_SLOT) atomicAdd(acc + sl[j][c], p);
               }
             }
           }
-        }
         b = v / cs[o + 1];
       }
       for (uint32_t e = A.n_eps; e-- > 0;) {
