@@ -5,7 +5,7 @@
 #include <vector>
 #include "../../include/carmel_hip.h"
 #include "kernels.hpp"
-#include "unrolled.hpp"
+#include "unrolled_args.hpp"
 
 namespace carmel_hip {
 int fail(int code, const std::string& msg);  // records carmel_hip_last_error() text, returns code
@@ -100,10 +100,11 @@ struct carmel_hip_trainer {
   bool unrolled = false;
   UnrolledModel um;  // host tables (bulk arrays are freed after upload)
   DevBuf<uint32_t> u_f_off, u_b_off, u_f_arc, u_b_arc, u_e_arc, u_pair_id;
-  DevBuf<uint8_t> u_f_src, u_b_dst, u_e_src, u_e_dst;
-  DevBuf<uint16_t> u_f_slot, u_e_slot, u_seq_sym;
+  DevBuf<uint8_t> u_e_src, u_e_dst;
+  DevBuf<URec> u_f_rec, u_b_rec;  // packed tables (unrolled_args.hpp)
+  DevBuf<uint16_t> u_e_slot, u_seq_sym;
   DevBuf<uint64_t> u_seq_off;
-  DevBuf<double> u_Wf, u_Wb, u_We, u_pair_weight, u_partial;
+  DevBuf<double> u_We, u_pair_weight, u_partial;
   DevBuf<double> u_param_uses;          // cascade: composed arcs whose chain holds the parameter (for the -f prior)
   DevBuf<double> u_em_param, u_best_param;  // cascade: parameter-space images of em_weight / best_weight
   uint32_t u_n_slots = 0, u_n_wg = 0;

@@ -47,11 +47,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   if (!n_waves) return CARMEL_HIP_OK;  // a pair too long for LDS: explicit lattices
   if (M.pair_id.empty()) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation");
   hipStream_t s = t->stream;
-  std::vector<uint16_t> f_slot(M.b_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT),
-      e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
-  for (size_t k = 0; k < M.b_arc.size(); ++k)  // slots ride with the backward (by source) table: that loop makes the posteriors
-    if (M.b_arc[k] != 0xffffffffu)
-      for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) f_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.b_arc[k] * UNROLLED_MAX_CHAIN + j];
+  std::vector<uint16_t> e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
   for (size_t k = 0; k < M.e_arc.size(); ++k)
     for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) e_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.e_arc[k] * UNROLLED_MAX_CHAIN + j];
   HIPCHK(t->u_f_off.upload(M.f_off, s));
@@ -59,18 +55,30 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_f_arc.upload(M.f_arc, s));
   HIPCHK(t->u_b_arc.upload(M.b_arc, s));
   HIPCHK(t->u_e_arc.upload(M.e_arc, s));
-  HIPCHK(t->u_f_src.upload(M.f_src, s));
-  HIPCHK(t->u_b_dst.upload(M.b_dst, s));
+  {
+    // packed tables: weight (refreshed every E-step), other end, slots -- one 16-byte load per entry
+    std::vector<URec> fr(M.f_arc.size()), br(M.b_arc.size());
+    for (size_t k = 0; k < fr.size(); ++k) fr[k] = URec{0.0, (uint32_t)M.f_src[k] | (UNROLLED_NO_SLOT << 16), UNROLLED_NO_SLOT | (UNROLLED_NO_SLOT << 16)};
+    for (size_t k = 0; k < br.size(); ++k) {
+      uint32_t s0 = UNROLLED_NO_SLOT, s1 = UNROLLED_NO_SLOT, s2 = UNROLLED_NO_SLOT;
+      if (M.b_arc[k] != 0xffffffffu) {
+        s0 = arc_slot[(size_t)M.b_arc[k] * UNROLLED_MAX_CHAIN];
+        s1 = arc_slot[(size_t)M.b_arc[k] * UNROLLED_MAX_CHAIN + 1];
+        s2 = arc_slot[(size_t)M.b_arc[k] * UNROLLED_MAX_CHAIN + 2];
+      }
+      br[k] = URec{0.0, (uint32_t)M.b_dst[k] | (s2 << 16), s0 | (s1 << 16)};
+    }
+    HIPCHK(t->u_f_rec.upload(fr, s));
+    HIPCHK(t->u_b_rec.upload(br, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   HIPCHK(t->u_e_src.upload(M.e_src, s));
   HIPCHK(t->u_e_dst.upload(M.e_dst, s));
-  HIPCHK(t->u_f_slot.upload(f_slot, s));
   HIPCHK(t->u_e_slot.upload(e_slot, s));
   HIPCHK(t->u_seq_off.upload(M.seq_off, s));
   HIPCHK(t->u_seq_sym.upload(M.seq_sym, s));
   HIPCHK(t->u_pair_id.upload(M.pair_id, s));
   HIPCHK(t->u_pair_weight.upload(M.pair_weight, s));
-  HIPCHK(t->u_Wf.alloc(M.f_arc.size()));
-  HIPCHK(t->u_Wb.alloc(M.b_arc.size()));
   HIPCHK(t->u_We.alloc(M.e_arc.size()));
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
@@ -94,8 +102,8 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(hipStreamSynchronize(s));
   if (has_derivation) std::memcpy(has_derivation, M.has_deriv.data(), M.has_deriv.size());
   t->device_bytes = t->u_seq_sym.bytes() + t->u_seq_off.bytes() + t->u_pair_id.bytes() + t->u_pair_weight.bytes() +
-                    t->u_partial.bytes() + t->u_Wf.bytes() + t->u_Wb.bytes() + t->u_f_arc.bytes() + t->u_b_arc.bytes() +
-                    t->u_f_slot.bytes() + t->pair_logprob.bytes() + t->pair_w.bytes();
+                    t->u_partial.bytes() + t->u_f_rec.bytes() + t->u_b_rec.bytes() + t->u_f_arc.bytes() + t->u_b_arc.bytes() +
+                    t->pair_logprob.bytes() + t->pair_w.bytes();
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
     stats->n_pairs = t->corpus.n_pairs;
@@ -120,9 +128,9 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
 // the E-step proper (weights are current in t->arc_logw): counts into counts_ptr()[0 .. n_slots), ln p per pair
 int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   const UnrolledModel& M = t->um;
-  HIPCHK(launch_unrolled_weights(t->u_f_arc.p, t->arc_logw.p, t->u_Wf.p, (uint32_t)t->u_f_arc.n, s));
-  HIPCHK(launch_unrolled_weights(t->u_b_arc.p, t->arc_logw.p, t->u_Wb.p, (uint32_t)t->u_b_arc.n, s));
-  HIPCHK(launch_unrolled_weights(t->u_e_arc.p, t->arc_logw.p, t->u_We.p, (uint32_t)t->u_e_arc.n, s));
+  HIPCHK(launch_unrolled_weights(t->u_f_arc.p, t->arc_logw.p, (double*)t->u_f_rec.p, 2, (uint32_t)t->u_f_arc.n, s));
+  HIPCHK(launch_unrolled_weights(t->u_b_arc.p, t->arc_logw.p, (double*)t->u_b_rec.p, 2, (uint32_t)t->u_b_arc.n, s));
+  HIPCHK(launch_unrolled_weights(t->u_e_arc.p, t->arc_logw.p, t->u_We.p, 1, (uint32_t)t->u_e_arc.n, s));
   UnrolledArgs A;
   A.S = M.S;
   A.V = M.V;
@@ -133,12 +141,9 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.max_len = M.max_len;
   A.n_pairs = M.pair_id.size();
   A.f_off = t->u_f_off.p;
-  A.f_src = t->u_f_src.p;
-  A.Wf = t->u_Wf.p;
+  A.f_rec = t->u_f_rec.p;
   A.b_off = t->u_b_off.p;
-  A.b_dst = t->u_b_dst.p;
-  A.Wb = t->u_Wb.p;
-  A.b_slot = t->u_f_slot.p;
+  A.b_rec = t->u_b_rec.p;
   A.e_src = t->u_e_src.p;
   A.e_dst = t->u_e_dst.p;
   A.We = t->u_We.p;

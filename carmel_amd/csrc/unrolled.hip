@@ -30,11 +30,11 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // linear weights in table order: Wf / Wb / We follow f_arc / b_arc / e_arc
 __global__ void unrolled_weights_kernel(const uint32_t* __restrict__ arcs, const double* __restrict__ logw,
-                                        double* __restrict__ out, uint32_t n) {
+                                        double* __restrict__ out, uint32_t stride, uint32_t n) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const uint32_t a = arcs[k];
-  out[k] = a == 0xffffffffu ? 0.0 : exp(logw[a]);
+  out[(size_t)k * stride] = a == 0xffffffffu ? 0.0 : exp(logw[a]);  // stride 2: the weight field of a URec
 }
 
 __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
@@ -77,17 +77,11 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
       double v = 0.0;
       if (on)
         for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {  // loads of a batch issue together (L2 latency once)
-          double wv[U_BATCH];
-          uint32_t sv[U_BATCH];
+          URec r[U_BATCH];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) {
-            const bool ok = it0 + j < deg;
-            const uint32_t k = off + (ok ? it0 + j : it0) * S + lane;
-            wv[j] = ok ? A.Wf[k] : 0.0;
-            sv[j] = A.f_src[k];
-          }
+          for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[off + (it0 + j < deg ? it0 + j : it0) * S + lane];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) v += arow[sv[j]] * wv[j];
+          for (int j = 0; j < U_BATCH; ++j) v += (it0 + j < deg) ? arow[r[j].other_slot2 & 0xffu] * r[j].w : 0.0;
         }
       for (uint32_t e = 0; e < A.n_eps; ++e) {
         const double u = __shfl(v, A.e_src[e], 64) * A.We[e];
@@ -137,27 +131,19 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
         double v = 0.0;
         if (on)
           for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
-            double wv[U_BATCH];
-            uint32_t dv[U_BATCH];
-            uint16_t sl[U_BATCH][UNROLLED_MAX_CHAIN];
+            URec r[U_BATCH];
+#pragma unroll
+            for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[off + (it0 + j < deg ? it0 + j : it0) * S + lane];
 #pragma unroll
             for (int j = 0; j < U_BATCH; ++j) {
-              const bool ok = it0 + j < deg;
-              const uint32_t k = off + (ok ? it0 + j : it0) * S + lane;
-              wv[j] = ok ? A.Wb[k] : 0.0;
-              dv[j] = A.b_dst[k];
-#pragma unroll
-              for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c) sl[j][c] = A.b_slot[(size_t)k * UNROLLED_MAX_CHAIN + c];
-            }
-#pragma unroll
-            for (int j = 0; j < U_BATCH; ++j) {
-              const double term = brow[dv[j]] * wv[j];
+              const double term = (it0 + j < deg) ? brow[r[j].other_slot2 & 0xffu] * r[j].w : 0.0;
               v += term;
               const double p = ag * term;
               if (p > 0.0) {
-#pragma unroll
-                for (int c = 0; c < (int)UNROLLED_MAX_CHAIN; ++c)
-                  if (sl[j][c] != UNROLLED_NO_SLOT) atomicAdd(acc + sl[j][c], p);
+                const uint32_t s0 = r[j].slot01 & 0xffffu, s1 = r[j].slot01 >> 16, s2 = r[j].other_slot2 >> 16;
+                if (s0 != UNROLLED_NO_SLOT) atomicAdd(acc + s0, p);
+                if (s1 != UNROLLED_NO_SLOT) atomicAdd(acc + s1, p);
+                if (s2 != UNROLLED_NO_SLOT) atomicAdd(acc + s2, p);
               }
             }
           }
@@ -219,9 +205,10 @@ uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S) {
   return 0;
 }
 
-hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t n, hipStream_t s) {
+hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t stride_doubles, uint32_t n,
+                                   hipStream_t s) {
   if (!n) return hipSuccess;
-  hipLaunchKernelGGL(unrolled_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, arcs, logw, out, n);
+  hipLaunchKernelGGL(unrolled_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, arcs, logw, out, stride_doubles, n);
   return hipGetLastError();
 }
 

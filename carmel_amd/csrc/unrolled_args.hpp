@@ -7,16 +7,20 @@
 
 namespace carmel_hip {
 
+// one table entry, one 16-byte load: the arc's linear weight, the state at its other end, its accumulator slots
+struct __attribute__((aligned(16))) URec {
+  double w;
+  uint32_t other_slot2;  // bits 0-7: source (forward table) / destination (backward table); bits 16-31: slot 2
+  uint32_t slot01;       // bits 0-15: slot 0, bits 16-31: slot 1
+};
+
 struct UnrolledArgs {
   uint32_t S, V, start, fin, n_eps, n_slots, max_len;
   uint64_t n_pairs;                // pairs with a derivation
   const uint32_t* f_off;           // V + 1
-  const uint8_t* f_src;
-  const double* Wf;                // linear weights in f_arc order (0 for padding)
+  const URec* f_rec;               // forward table (by destination); padding entries have weight 0
   const uint32_t* b_off;
-  const uint8_t* b_dst;
-  const double* Wb;
-  const uint16_t* b_slot;          // UNROLLED_MAX_CHAIN accumulator slots per entry
+  const URec* b_rec;               // backward table (by source), with the accumulator slots
   const uint8_t* e_src;
   const uint8_t* e_dst;
   const double* We;
@@ -31,7 +35,8 @@ struct UnrolledArgs {
 
 size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves);
 uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S);
-hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t n, hipStream_t s);
+hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t stride_doubles, uint32_t n,
+                                   hipStream_t s);
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
                                         const uint32_t* group, uint32_t n, hipStream_t s);
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s);
