@@ -104,7 +104,7 @@ struct carmel_hip_trainer {
   DevBuf<URec> u_f_rec, u_b_rec;  // packed tables (unrolled_args.hpp)
   DevBuf<uint16_t> u_e_slot, u_seq_sym;
   DevBuf<uint64_t> u_seq_off;
-  DevBuf<double> u_We, u_pair_weight, u_partial;
+  DevBuf<double> u_We, u_pair_weight, u_partial, u_scratch;
   DevBuf<double> u_param_uses;          // cascade: composed arcs whose chain holds the parameter (for the -f prior)
   DevBuf<double> u_em_param, u_best_param;  // cascade: parameter-space images of em_weight / best_weight
   uint32_t u_n_slots = 0, u_n_wg = 0;

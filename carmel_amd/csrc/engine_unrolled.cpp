@@ -82,7 +82,9 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_We.alloc(M.e_arc.size()));
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
-  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu, (M.pair_id.size() + n_waves - 1) / n_waves);
+  // LDS holds only accumulators and scales: several workgroups share a CU, their waves hide the table latency
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, (M.pair_id.size() + n_waves - 1) / n_waves);
+  HIPCHK(t->u_scratch.alloc(unrolled_scratch_doubles(t->u_n_wg, n_waves, M.max_len)));
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {
@@ -102,7 +104,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(hipStreamSynchronize(s));
   if (has_derivation) std::memcpy(has_derivation, M.has_deriv.data(), M.has_deriv.size());
   t->device_bytes = t->u_seq_sym.bytes() + t->u_seq_off.bytes() + t->u_pair_id.bytes() + t->u_pair_weight.bytes() +
-                    t->u_partial.bytes() + t->u_f_rec.bytes() + t->u_b_rec.bytes() + t->u_f_arc.bytes() + t->u_b_arc.bytes() +
+                    t->u_partial.bytes() + t->u_scratch.bytes() + t->u_f_rec.bytes() + t->u_b_rec.bytes() + t->u_f_arc.bytes() + t->u_b_arc.bytes() +
                     t->pair_logprob.bytes() + t->pair_w.bytes();
   if (stats) {
     std::memset(stats, 0, sizeof *stats);
@@ -154,6 +156,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.pair_weight = t->u_pair_weight.p;
   A.pair_logprob = t->pair_logprob.p;
   A.partial = t->u_partial.p;
+  A.alpha_scratch = t->u_scratch.p;
   HIPCHK(launch_unrolled_sweep(A, t->u_n_wg, t->counts_ptr(), s));
   return CARMEL_HIP_OK;
 }

@@ -19,7 +19,7 @@
 
 namespace carmel_hip {
 
-#define U_MAX_WAVES 6
+#define U_MAX_WAVES 8
 #define U_BATCH 9
 #define U_NEG_INF (-__builtin_huge_val())
 
@@ -41,15 +41,17 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t S = A.S;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double* acc = lds;                                   // n_slots accumulators, shared by the workgroup
-  const uint32_t per_wave = (A.max_len + 1) * S + (A.max_len + 2) + S;
-  double* alpha = lds + A.n_slots + (size_t)wave * per_wave;  // alpha_hat[o][s]
-  double* cs = alpha + (size_t)(A.max_len + 1) * S;           // c[o]
-  double* brow = cs + (A.max_len + 2);                        // beta_hat of the current position, for the gathers
+  const uint32_t n_waves = blockDim.x >> 6;
+  double* acc = lds;                                             // n_slots accumulators, shared by the workgroup
+  double* cs = lds + A.n_slots + (size_t)wave * (A.max_len + 2);  // this wave's scales c[o]
+  // alpha_hat and beta_hat live in registers (lane = state); a value of another state comes by cross-lane read
+  // (ds_bpermute), so LDS holds only the accumulators and many waves fit a CU -- they are what hides the L2 latency
+  // of the table reads.  alpha_hat[o][lane] is parked in a scratch row (one coalesced store / load per position).
+  double* rows = A.alpha_scratch + ((size_t)blockIdx.x * n_waves + wave) * (size_t)(A.max_len + 1) * 64 + lane;
   for (uint32_t k = threadIdx.x; k < A.n_slots; k += blockDim.x) acc[k] = 0.0;
   __syncthreads();
   const bool on = lane < S;
-  const uint32_t n_waves = blockDim.x >> 6;
+  const uint32_t ln = on ? lane : 0u;  // idle lanes shadow lane 0 and are masked out: the wave stays converged
   const uint32_t total_waves = gridDim.x * n_waves;
   for (uint64_t q = (uint64_t)blockIdx.x * n_waves + wave; q < A.n_pairs; q += total_waves) {
     const uint64_t s0 = A.seq_off[q];
@@ -64,103 +66,102 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
     double lnz = 0.0;
     bool dead = false;
     {
-      const double c0 = wave_sum(on ? a : 0.0);
+      const double c0 = wave_sum(a);
       a /= c0;
       lnz = log(c0);
-      if (on) alpha[lane] = a;
+      rows[0] = a;
       if (lane == 0) cs[0] = c0;
     }
     for (uint32_t o = 0; o < L; ++o) {
       const uint32_t x = xs[o];
       const uint32_t off = A.f_off[x], deg = (A.f_off[x + 1] - off) / S;
-      const double* arow = alpha + (size_t)o * S;
       double v = 0.0;
-      if (on)
-        for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {  // loads of a batch issue together (L2 latency once)
-          URec r[U_BATCH];
+      for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {  // loads of a batch issue together
+        URec r[U_BATCH];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[off + (it0 + j < deg ? it0 + j : it0) * S + lane];
+        for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[off + (it0 + j < deg ? it0 + j : it0) * S + ln];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) v += (it0 + j < deg) ? arow[r[j].other_slot2 & 0xffu] * r[j].w : 0.0;
+        for (int j = 0; j < U_BATCH; ++j) {
+          const double as = __shfl(a, (int)(r[j].other_slot2 & 0xffu), 64);
+          v += (it0 + j < deg) ? as * r[j].w : 0.0;
         }
+      }
+      if (!on) v = 0.0;
       for (uint32_t e = 0; e < A.n_eps; ++e) {
         const double u = __shfl(v, A.e_src[e], 64) * A.We[e];
         if (lane == A.e_dst[e]) v += u;
       }
-      const double c = wave_sum(on ? v : 0.0);
+      const double c = wave_sum(v);
       if (!(c > 0.0)) {
         dead = true;
         break;
       }
-      v /= c;
+      a = v / c;
       lnz += log(c);
-      if (on) alpha[(size_t)(o + 1) * S + lane] = v;
+      rows[(size_t)(o + 1) * 64] = a;
       if (lane == 0) cs[o + 1] = c;
     }
-    const double pfin = dead ? 0.0 : alpha[(size_t)L * S + A.fin];
+    const double pfin = dead ? 0.0 : __shfl(a, (int)A.fin, 64);
     const double lp = (dead || !(pfin > 0.0)) ? U_NEG_INF : lnz + log(pfin);
     if (lane == 0) A.pair_logprob[A.pair_id[q]] = lp;
     if (lp == U_NEG_INF) continue;
     // ---------- backward + posteriors ----------
     const double g = A.pair_weight[q] / pfin;  // "* weight / prob" (derivations.h:445)
     double b = (lane == A.fin) ? 1.0 : 0.0;
-    // *e*:*e* arcs of the last position, in reverse order; their posteriors need beta of the destination complete
+    // *e*:*e* arcs of the last position, in reverse order (a = alpha_hat[L] is still in the registers)
     for (uint32_t e = A.n_eps; e-- > 0;) {
       const uint32_t es = A.e_src[e], ed = A.e_dst[e];
       const double u = __shfl(b, ed, 64) * A.We[e];
+      const double p = __shfl(a, es, 64) * u * g;
       if (lane == es) b += u;
-      if (lane == 0) {
-        const double p = alpha[(size_t)L * S + es] * u * g;
-        for (int j = 0; j < UNROLLED_MAX_CHAIN; ++j) {
+      if (lane == 0 && p > 0.0)
+        for (int j = 0; j < (int)UNROLLED_MAX_CHAIN; ++j) {
           const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
-          if (sl != UNROLLED_NO_SLOT && p > 0.0) atomicAdd(acc + sl, p);
+          if (sl != UNROLLED_NO_SLOT) atomicAdd(acc + sl, p);
         }
-      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's scratch rows before it reads them back
+    double a_o = L ? rows[(size_t)(L - 1) * 64] : 0.0;
     for (uint32_t o = L; o-- > 0;) {
       const uint32_t x = xs[o];
-      const double* arow = alpha + (size_t)o * S;
-      const double gc = g / cs[o + 1];
+      const double a_next = o ? rows[(size_t)(o - 1) * 64] : 0.0;  // prefetch the next row
+      const double co = cs[o + 1];
+      const double ag = on ? a_o * (g / co) : 0.0;
       // one loop over the out-arcs of every source (lane = source) gives both beta_hat[o] and the posteriors: the
       // term W * beta_hat[o+1][dst] is the arc's share of beta, times alpha_hat[o][src] it is the arc's posterior
-      if (on) brow[lane] = b;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      {
-        const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
-        const double ag = on ? arow[lane] * gc : 0.0;
-        double v = 0.0;
-        if (on)
-          for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
-            URec r[U_BATCH];
+      const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
+      double v = 0.0;
+      for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
+        URec r[U_BATCH];
 #pragma unroll
-            for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[off + (it0 + j < deg ? it0 + j : it0) * S + lane];
+        for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[off + (it0 + j < deg ? it0 + j : it0) * S + ln];
 #pragma unroll
-            for (int j = 0; j < U_BATCH; ++j) {
-              const double term = (it0 + j < deg) ? brow[r[j].other_slot2 & 0xffu] * r[j].w : 0.0;
-              v += term;
-              const double p = ag * term;
-              if (p > 0.0) {
-                const uint32_t s0 = r[j].slot01 & 0xffffu, s1 = r[j].slot01 >> 16, s2 = r[j].other_slot2 >> 16;
-                if (s0 != UNROLLED_NO_SLOT) atomicAdd(acc + s0, p);
-                if (s1 != UNROLLED_NO_SLOT) atomicAdd(acc + s1, p);
-                if (s2 != UNROLLED_NO_SLOT) atomicAdd(acc + s2, p);
-              }
-            }
+        for (int j = 0; j < U_BATCH; ++j) {
+          const double bd = __shfl(b, (int)(r[j].other_slot2 & 0xffu), 64);
+          const double term = (it0 + j < deg) ? bd * r[j].w : 0.0;
+          v += term;
+          const double p = ag * term;
+          if (p > 0.0) {
+            const uint32_t t0 = r[j].slot01 & 0xffffu, t1 = r[j].slot01 >> 16, t2 = r[j].other_slot2 >> 16;
+            if (t0 != UNROLLED_NO_SLOT) atomicAdd(acc + t0, p);
+            if (t1 != UNROLLED_NO_SLOT) atomicAdd(acc + t1, p);
+            if (t2 != UNROLLED_NO_SLOT) atomicAdd(acc + t2, p);
           }
-        b = v / cs[o + 1];
+        }
       }
+      b = on ? v / co : 0.0;
       for (uint32_t e = A.n_eps; e-- > 0;) {
         const uint32_t es = A.e_src[e], ed = A.e_dst[e];
         const double u = __shfl(b, ed, 64) * A.We[e];
+        const double p = __shfl(a_o, es, 64) * u * g;
         if (lane == es) b += u;
-        if (lane == 0) {
-          const double p = arow[es] * u * g;
-          for (int j = 0; j < UNROLLED_MAX_CHAIN; ++j) {
+        if (lane == 0 && p > 0.0)
+          for (int j = 0; j < (int)UNROLLED_MAX_CHAIN; ++j) {
             const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
-            if (sl != UNROLLED_NO_SLOT && p > 0.0) atomicAdd(acc + sl, p);
+            if (sl != UNROLLED_NO_SLOT) atomicAdd(acc + sl, p);
           }
-        }
       }
+      a_o = a_next;
     }
   }
   __syncthreads();
@@ -194,15 +195,18 @@ hipError_t launch_unrolled_param_counts(double* out, const double* counts, const
 }
 
 size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves) {
-  const size_t per_wave = (size_t)(A.max_len + 1) * A.S + (A.max_len + 2) + A.S;
-  return (A.n_slots + n_waves * per_wave) * sizeof(double);
+  return (A.n_slots + (size_t)n_waves * (A.max_len + 2)) * sizeof(double);
 }
-// waves per workgroup: as many as fit beside the accumulators (0: even one does not fit)
+// waves per workgroup (0: the accumulators alone do not fit)
 uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S) {
-  const size_t per_wave = (size_t)(max_len + 1) * S + (max_len + 2) + S;
+  (void)S;
   for (uint32_t w = U_MAX_WAVES; w >= 1; --w)
-    if ((n_slots + w * per_wave) * sizeof(double) <= 158 * 1024) return w;
+    if ((n_slots + (size_t)w * (max_len + 2)) * sizeof(double) <= 64 * 1024) return w;
   return 0;
+}
+// doubles of scratch for the alpha rows of n_wg workgroups
+size_t unrolled_scratch_doubles(uint32_t n_wg, uint32_t n_waves, uint32_t max_len) {
+  return (size_t)n_wg * n_waves * (max_len + 1) * 64;
 }
 
 hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t stride_doubles, uint32_t n,
@@ -216,12 +220,6 @@ hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* c
   const uint32_t n_waves = unrolled_waves(A.n_slots, A.max_len, A.S);
   if (!n_waves) return hipErrorInvalidValue;
   const size_t lds = unrolled_lds_bytes(A, n_waves);
-  static size_t attr_set = 0;
-  if (lds > 64 * 1024 && lds > attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)unrolled_sweep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    attr_set = lds;
-  }
   hipLaunchKernelGGL(unrolled_sweep_kernel, dim3(n_wg), dim3(64 * n_waves), lds, s, A);
   hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((A.n_slots + 255) / 256), dim3(256), 0, s, A.partial, n_wg, A.n_slots, counts);
   return hipGetLastError();

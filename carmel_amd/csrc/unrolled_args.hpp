@@ -31,10 +31,12 @@ struct UnrolledArgs {
   const double* pair_weight;
   double* pair_logprob;
   double* partial;                 // n_workgroups * n_slots
+  double* alpha_scratch;           // unrolled_scratch_doubles(): per wave (max_len + 1) rows of 64
 };
 
 size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves);
 uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S);
+size_t unrolled_scratch_doubles(uint32_t n_wg, uint32_t n_waves, uint32_t max_len);
 hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t stride_doubles, uint32_t n,
                                    hipStream_t s);
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
