@@ -157,6 +157,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.pair_logprob = t->pair_logprob.p;
   A.partial = t->u_partial.p;
   A.alpha_scratch = t->u_scratch.p;
+  A.debug_no_acc = getenv("CARMEL_HIP_UNROLLED_NOACC") ? 1u : 0u;
   HIPCHK(launch_unrolled_sweep(A, t->u_n_wg, t->counts_ptr(), s));
   return CARMEL_HIP_OK;
 }

@@ -385,6 +385,11 @@ static int run(int argc, char** argv) {
         break;
       }
       const auto t_e0 = std::chrono::steady_clock::now();
+      if (iter > 2 * o.max_iter + 2 && !have_good) {
+        // the reference keeps iterating until some iteration was accepted as best (train.cc:577); with a corpus
+        // probability of zero or NaN that never happens: stop instead of spinning
+        throw std::runtime_error("no iteration produced a usable corpus probability; giving up after " + std::to_string(iter - 1) + " iterations");
+      }
       hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
       if (timing) {
         double sweep_ms = 0;

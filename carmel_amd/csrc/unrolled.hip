@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
           const double term = (it0 + j < deg) ? bd * r[j].w : 0.0;
           v += term;
           const double p = ag * term;
-          if (p > 0.0) {
+          if (p > 0.0 && !A.debug_no_acc) {
             const uint32_t t0 = r[j].slot01 & 0xffffu, t1 = r[j].slot01 >> 16, t2 = r[j].other_slot2 >> 16;
             if (t0 != UNROLLED_NO_SLOT) atomicAdd(acc + t0, p);
             if (t1 != UNROLLED_NO_SLOT) atomicAdd(acc + t1, p);
