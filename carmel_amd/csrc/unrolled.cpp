@@ -101,8 +101,12 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
       M.f_src[k] = (uint8_t)w.src[a];
     }
     std::fill(cnt.begin(), cnt.end(), 0u);
+    const uint32_t bd = (M.b_off[x + 1] - M.b_off[x]) / S;
     for (uint32_t a : by_sym[x]) {
-      const uint32_t k = M.b_off[x] + (cnt[w.src[a]]++) * S + w.src[a];
+      // row of the arc in its source's column: rotated by the source, so that the lanes of one row tend to point at
+      // different destinations / parameters (their posterior adds then do not collide in LDS)
+      const uint32_t row = (cnt[w.src[a]]++ + w.src[a]) % bd;
+      const uint32_t k = M.b_off[x] + row * S + w.src[a];
       M.b_arc[k] = a;
       M.b_dst[k] = (uint8_t)w.dst[a];
     }
