@@ -324,6 +324,20 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
   t->all_grouped = true;
   for (uint64_t k = 0; k < n; ++k)
     if (norm_of[k] == 0xffffffffu) t->all_grouped = false;
+  {
+    // how far apart do the members of one group lie?  (state-major arc tables: less than an out-degree)
+    std::vector<uint64_t> first(add.size(), ~0ull);
+    uint64_t span = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+      const uint32_t g = norm_of[k];
+      if (g == 0xffffffffu) continue;
+      if (first[g] == ~0ull) first[g] = k;
+      span = std::max(span, k - first[g]);
+    }
+    static const bool want_window = !(getenv("CARMEL_HIP_MSTEP_WINDOW") && atoi(getenv("CARMEL_HIP_MSTEP_WINDOW")) == 0);
+    t->norm_span = (want_window && span >= 1 && span <= 64) ? (uint32_t)span : 0u;
+    if (want_window && span == 0 && !add.empty()) t->norm_span = 1;  // all groups are singletons
+  }
   t->h_group_add = add;
   {
     // members of every group, contiguous (counting sort by group id); big groups listed separately
@@ -459,6 +473,7 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.glocked = t->glocked.p;
   M.n_ties = t->n_ties;
   M.all_grouped = t->all_grouped ? 1 : 0;
+  M.window_span = t->norm_span;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();
   M.save_old = save_old;

@@ -93,6 +93,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
   DevBuf<double> t_x;
   DevBuf<unsigned long long> max_partial;  // M-step scratch
+  uint32_t norm_span = 0;                  // max over norm groups of (last member - first member); 0 = unknown / too wide
   bool all_grouped = true;                 // every parameter is in a norm group
   DevBuf<double> pair_w;          // pair weight by pair id, < 0 for pairs dropped at build_lattices
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction

@@ -548,6 +548,63 @@ __global__ __launch_bounds__(256) void mstep_normalize_kernel(MstepArgs M, int u
   }
   mstep_block_max(mx, M.max_partial + blockIdx.x);
 }
+// The whole M-step in one pass when every norm group lives inside a window of `span` consecutive parameters (the
+// per-state groups of JOINT / CONDITIONAL normalisation over a state-major arc table: span < out-degree): a workgroup
+// stages 256 + 2 * span values and group ids in LDS, each thread adds up the members of its own group in ascending
+// parameter order -- the same order, hence the same bits, as the group-major pass above -- and writes its new weight.
+// One coalesced read of the counts, one write of the weights; no group table, no scale array.
+#define MSTEP_WINDOW_MAX 64
+__global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_counts, uint32_t span) {
+  __shared__ double v_sh[256 + 2 * MSTEP_WINDOW_MAX];
+  __shared__ uint32_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // group id; bit 31 set = locked member
+  const int64_t base = (int64_t)blockIdx.x * 256 - (int64_t)span;
+  const uint32_t n_tile = 256 + 2 * span;
+  for (uint32_t i = threadIdx.x; i < n_tile; i += 256) {
+    const int64_t k = base + i;
+    double v = 0.0;
+    uint32_t g = 0xffffffffu;
+    if (k >= 0 && (uint64_t)k < M.n) {
+      g = M.norm_of[k];
+      if (g != 0xffffffffu) {
+        v = mstep_value(M, (uint64_t)k, use_counts, g);
+        if (M.group[k] == 0u) g |= 0x80000000u;
+      }
+    }
+    v_sh[i] = v;
+    g_sh[i] = g;
+  }
+  __syncthreads();
+  double mx = 0.0;
+  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < M.n) {
+    const uint32_t me = threadIdx.x + span;
+    const uint32_t gid = g_sh[me];
+    if (gid == 0xffffffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
+      if (M.save_old) M.old_logw[k] = M.logw[k];
+    } else {
+      const uint32_t want = gid & 0x7fffffffu;
+      double sn = 0.0, sl = 0.0;
+      for (uint32_t j = me - span; j <= me + span; ++j) {
+        const uint32_t gj = g_sh[j];
+        if (gj == 0xffffffffu || (gj & 0x7fffffffu) != want) continue;
+        if (gj & 0x80000000u)
+          sl += v_sh[j];
+        else
+          sn += v_sh[j];
+      }
+      M.logw[k] = mstep_update(M, k, use_counts, want, mstep_scale(sn, sl), mx);
+    }
+  }
+  // more workgroups than partial slots: fold by atomicMax (2048 addresses, a few adds each: no serialisation)
+  __shared__ double shm[4];
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) shm[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double m = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
+    if (m > 0.0) atomicMax(M.max_partial + (blockIdx.x % MSTEP_GRID), (unsigned long long)__double_as_longlong(m));
+  }
+}
 // pass 0 for big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
 __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int use_counts) {
   __shared__ double sh[2][4];
@@ -919,20 +976,27 @@ hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   static const bool dbg = getenv("CARMEL_HIP_DEBUG") != nullptr;
 #define MSTEP_DBG(what) if (dbg) { hipError_t de = hipStreamSynchronize(s); fprintf(stderr, "[carmel_hip] mstep %s: %s\n", what, hipGetErrorString(de)); }
   if (dbg) fprintf(stderr, "[carmel_hip] mstep n=%llu groups=%llu ties=%llu logw=%p counts=%p group=%p norm_of=%p off=%p perm=%p tie_of=%p tie_tab=%p add=%p prior=%p\n", (unsigned long long)M.n, (unsigned long long)M.n_groups, (unsigned long long)M.n_ties, (void*)M.logw, (void*)M.counts, (void*)M.group, (void*)M.norm_of, (void*)M.group_off, (void*)M.norm_perm, (void*)M.tie_of, (void*)M.tie_tab, (void*)M.add_count, (void*)M.prior);
-  if (M.n_ties && M.tie_of) {
-    hipError_t e = hipMemsetAsync(M.tie_tab, 0, 4 * M.n_ties * sizeof(double), s);
+  if (M.window_span && !(M.n_ties && M.tie_of)) {
+    hipError_t e = hipMemsetAsync(M.max_partial, 0, MSTEP_GRID * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    MSTEP_DBG("memset ties")
-    hipLaunchKernelGGL(mstep_tie_sums_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
-    hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
-    MSTEP_DBG("tie_accum")
-    hipLaunchKernelGGL(mstep_tie_weight_kernel, dim3((unsigned)((M.n_ties + 255) / 256)), dim3(256), 0, s, M);
-    MSTEP_DBG("tie_weight")
+    hipLaunchKernelGGL(mstep_window_kernel, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
+    MSTEP_DBG("window")
+  } else {
+    if (M.n_ties && M.tie_of) {
+      hipError_t e = hipMemsetAsync(M.tie_tab, 0, 4 * M.n_ties * sizeof(double), s);
+      if (e != hipSuccess) return e;
+      MSTEP_DBG("memset ties")
+      hipLaunchKernelGGL(mstep_tie_sums_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+      hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
+      MSTEP_DBG("tie_accum")
+      hipLaunchKernelGGL(mstep_tie_weight_kernel, dim3((unsigned)((M.n_ties + 255) / 256)), dim3(256), 0, s, M);
+      MSTEP_DBG("tie_weight")
+    }
+    if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
+    if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
+    MSTEP_DBG("group sums")
+    hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
   }
-  if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
-  if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
-  MSTEP_DBG("group sums")
-  hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
   hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID,
                      M.max_change_bits);
   MSTEP_DBG("normalize + max")

@@ -95,6 +95,7 @@ struct MstepArgs {
   unsigned long long* max_partial;  // MSTEP_PARTIALS + n_big entries of scratch
   unsigned long long* max_change_bits;
   int all_grouped;          // every parameter belongs to a norm group
+  uint32_t window_span;     // > 0: every group's members lie within this many consecutive parameters (<= 64)
   double* glocked;          // per norm group scratch (ties only): sum of its locked members
   const uint32_t* tie_of;   // dense tie index per parameter, 0xffffffff = not tied; null when the model has no ties
   double* tie_tab;          // [4][n_ties]: arc total, state total, max locked sum, weight (linear)
