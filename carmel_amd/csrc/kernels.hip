@@ -592,7 +592,22 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
         else
           sn += v_sh[j];
       }
-      M.logw[k] = mstep_update(M, k, use_counts, want, mstep_scale(sn, sl), mx);
+      // new weight straight from the sums: one division, one log (and one exp for the old weight) per parameter --
+      // this kernel is bound by f64 transcendentals, not by its 40 bytes per parameter
+      const double old = M.logw[k];
+      if (M.save_old) M.old_logw[k] = old;
+      const double v = v_sh[me];
+      double nw;
+      if (gid & 0x80000000u) {
+        nw = v > 0.0 ? log(v) : NEG_INF;
+      } else {
+        const double remain = 1.0 - sl;
+        const bool ok = remain > 0.0 && sn > 0.0 && v > 0.0;
+        const double lin = ok ? (sl == 0.0 ? v / sn : v * remain / sn) : 0.0;  // a lone arc: v / v == 1 exactly
+        nw = ok ? log(lin) : NEG_INF;
+        mx = fmax(mx, fabs(lin - exp(M.save_old ? old : M.old_logw[k])));
+      }
+      M.logw[k] = nw;
     }
   }
   // more workgroups than partial slots: fold by atomicMax (2048 addresses, a few adds each: no serialisation)
