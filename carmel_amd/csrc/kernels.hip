@@ -559,20 +559,39 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   __shared__ uint32_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // group id; bit 31 set = locked member
   const int64_t base = (int64_t)blockIdx.x * 256 - (int64_t)span;
   const uint32_t n_tile = 256 + 2 * span;
-  for (uint32_t i = threadIdx.x; i < n_tile; i += 256) {
-    const int64_t k = base + i;
+  // every global load of the workgroup is issued up front (tile element, halo element, own old weight): one round
+  // trip per workgroup instead of one per dependent step
+  const uint64_t kown = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const double old_own = kown < M.n ? M.logw[kown] : 0.0;
+  int64_t kk[2] = {base + threadIdx.x, base + 256 + threadIdx.x};
+  bool in[2];
+  uint32_t gg[2], grp[2];
+  double cv[2], pv[2], lw[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    in[h] = kk[h] >= 0 && (uint64_t)kk[h] < M.n && (h == 0 || threadIdx.x < 2 * span);
+    const uint64_t k = in[h] ? (uint64_t)kk[h] : 0;
+    gg[h] = M.norm_of[k];
+    grp[h] = M.group[k];
+    lw[h] = M.logw[k];
+    cv[h] = use_counts ? M.counts[k] : 0.0;
+    pv[h] = (use_counts && M.prior) ? M.prior[k] : 0.0;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if (h == 1 && threadIdx.x >= 2 * span) break;
     double v = 0.0;
     uint32_t g = 0xffffffffu;
-    if (k >= 0 && (uint64_t)k < M.n) {
-      g = M.norm_of[k];
-      if (g != 0xffffffffu) {
-        v = mstep_value(M, (uint64_t)k, use_counts, g);
-        if (M.group[k] == 0u) g |= 0x80000000u;
-      }
+    if (in[h] && gg[h] != 0xffffffffu) {
+      g = gg[h];
+      v = (grp[h] == 0u || !use_counts) ? exp(lw[h]) : cv[h] + pv[h];  // mstep_value
+      if (M.add_count) v += M.add_count[g];
+      if (grp[h] == 0u) g |= 0x80000000u;
     }
-    v_sh[i] = v;
-    g_sh[i] = g;
+    v_sh[threadIdx.x + h * 256] = v;
+    g_sh[threadIdx.x + h * 256] = g;
   }
+  (void)n_tile;
   __syncthreads();
   double mx = 0.0;
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -580,7 +599,7 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
     const uint32_t me = threadIdx.x + span;
     const uint32_t gid = g_sh[me];
     if (gid == 0xffffffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
-      if (M.save_old) M.old_logw[k] = M.logw[k];
+      if (M.save_old) M.old_logw[k] = old_own;
     } else {
       const uint32_t want = gid & 0x7fffffffu;
       double sn = 0.0, sl = 0.0;
@@ -594,7 +613,7 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
       }
       // new weight straight from the sums: one division, one log (and one exp for the old weight) per parameter --
       // this kernel is bound by f64 transcendentals, not by its 40 bytes per parameter
-      const double old = M.logw[k];
+      const double old = old_own;
       if (M.save_old) M.old_logw[k] = old;
       const double v = v_sh[me];
       double nw;
