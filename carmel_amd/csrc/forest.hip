@@ -166,7 +166,8 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
 
 // Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
 // snap_norm.  LDS per lane: the inside column.
-__global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample) {
+__global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
+                                                           uint32_t own_cap) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
@@ -181,6 +182,15 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   uint32_t own_len = 0;
   const uint32_t* own = A.old_rules + (active ? A.sample_off[forest] : 0);
   if (active && A.counterfactual) own_len = A.old_len[forest];
+  // ... its first own_cap rules, with their norm groups, are staged in the lane's LDS column: every proposal
+  // probability scans them (counterfactual CRP counts), and two dependent global gathers per scanned rule made this
+  // kernel 15x slower than the estimate kernel on the same forests
+  uint2* own_sh = (uint2*)(lds + (size_t)ins_rows * 64) + lane;
+  const uint32_t own_lds = own_len < own_cap ? own_len : own_cap;
+  for (uint32_t q = 0; q < own_lds; ++q) {
+    const uint32_t rr = own[q];
+    own_sh[(size_t)q * 64] = make_uint2(rr, A.p_norm[rr]);
+  }
   // inside with proposal probabilities (forest.hpp:768-816)
   {
     const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
@@ -199,7 +209,12 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
             pr = A.p_prior[rule];
           else {
             double x = A.snap_x[rule], ns = A.snap_norm[nn];
-            for (uint32_t q = 0; q < own_len; ++q) {
+            for (uint32_t q = 0; q < own_lds; ++q) {
+              const uint2 o2 = own_sh[(size_t)q * 64];
+              if (o2.x == rule) x -= 1.0;
+              if (o2.y == nn) ns -= 1.0;
+            }
+            for (uint32_t q = own_lds; q < own_len; ++q) {  // a sample longer than the staged part (rare)
               const uint32_t rr = own[q];
               if (rr == rule) x -= 1.0;
               if (A.p_norm[rr] == nn) ns -= 1.0;
@@ -759,10 +774,12 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       A.sample_rules = F->sample_rules[cur ^ 1].p;
       for (auto& c : F->classes) {
         A.first_group = c.first;
-        size_t lds = (size_t)c.max_nodes * 64 * 8;
+        // LDS: the inside column + up to own_cap {rule, norm group} pairs of the previous sample per lane
+        const uint32_t own_cap = (uint32_t)std::min<size_t>(std::min<size_t>(F->max_sample, 128), (150 * 1024 - (size_t)c.max_nodes * 512) / 512);
+        size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)own_cap * 64 * 8;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample, c.max_nodes, own_cap);
       }
       HIPCHK(hipGetLastError());
       cur ^= 1;
@@ -821,7 +838,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         size_t lds = (size_t)G.max_nodes * 64 * 8;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample, G.max_nodes, 0u);
         uint32_t len = 0;
         HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + f, sizeof len, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
