@@ -29,6 +29,7 @@ namespace carmel_hip {
 static const uint32_t F_HEADER = 0x80000000u, F_VALID = 0x40000000u, F_LAST = 0x20000000u, F_AND = 0x10000000u;
 static const uint32_t F_IDX = 0x0fffffffu;
 #define F_NONORM 0xffffffffu
+#define FOREST_GHASH 2048u
 
 struct FGroup {  // 32 bytes, one wavefront of forests
   uint64_t stream_base;
@@ -58,6 +59,8 @@ struct ForestArgs {
   const uint32_t* old_len;       // previous sample (counterfactual removal); may alias sample_* of the other buffer
   const uint32_t* old_rules;
   double* iter_out;
+  uint32_t* ghash;               // FOREST_GHASH slots per forest: own-sample table of lanes that overflow LDS (may be null)
+  unsigned long long* trace;     // experiment (CARMEL_HIP_FOREST_TRACE): per block {start, after table, after inside, after walk, end}
   uint64_t seed;
   uint32_t iter, first_group, serial_forest;  // serial_forest: exact mode processes exactly this forest (lane slot)
   int counterfactual;
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
 // Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
 // snap_norm.  LDS per lane: the inside column.
 __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
-                                                           uint32_t own_cap) {
+                                                           uint32_t own_cap, uint32_t stack_lds) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
@@ -179,18 +182,74 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   // the lane's previous sample (counterfactual removal) is read straight from global memory; the traversal stack
   // lives at the tail of the forest's own sample buffer (recorded rules grow from the front, pending nodes from the
   // back: every pending node still owes at least one rule, so the two never meet)
+  unsigned long long tr0 = A.trace ? __builtin_readcyclecounter() : 0, tr1 = 0, tr2 = 0, tr3 = 0;
   uint32_t own_len = 0;
   const uint32_t* own = A.old_rules + (active ? A.sample_off[forest] : 0);
   if (active && A.counterfactual) own_len = A.old_len[forest];
-  // ... its first own_cap rules, with their norm groups, are staged in the lane's LDS column: every proposal
-  // probability scans them (counterfactual CRP counts), and two dependent global gathers per scanned rule made this
-  // kernel 15x slower than the estimate kernel on the same forests
-  uint2* own_sh = (uint2*)(lds + (size_t)ins_rows * 64) + lane;
-  const uint32_t own_lds = own_len < own_cap ? own_len : own_cap;
-  for (uint32_t q = 0; q < own_lds; ++q) {
-    const uint32_t rr = own[q];
-    own_sh[(size_t)q * 64] = make_uint2(rr, A.p_norm[rr]);
+  // ... counted into a small open-addressing table in the lane's LDS column ({rule or norm-group id, uses}): every
+  // proposal probability needs "how often does my previous sample use this rule / this group" (counterfactual CRP
+  // counts), and scanning the sample for each AND node (two dependent global gathers per scanned rule) made this
+  // kernel 15x slower than the estimate kernel on the same forests.  own_cap = table slots (a power of two, 0 = scan).
+  // a lane whose sample is too long for its LDS column uses a table in global memory instead (FOREST_GHASH slots
+  // per forest): the rare long derivation must not fall back to scanning -- one such lane held its wave 30x longer.
+  // The two tables are handled by separate code (LDS / global address spaces), never through one generic pointer.
+  uint32_t* ht_l = (uint32_t*)(lds + (size_t)ins_rows * 64) + lane;  // stride 64
+  uint32_t* ht_g = A.ghash ? A.ghash + (size_t)forest * FOREST_GHASH : nullptr;  // stride 1
+  const bool hashed_l = own_cap != 0 && own_len * 20 <= own_cap * 9;  // <= 2 keys per rule, load factor <= 0.9
+  const bool hashed_g = !hashed_l && active && ht_g != nullptr && own_len * 20 <= FOREST_GHASH * 9;
+  const bool hashed = hashed_l || hashed_g;
+#define FH_SLOT(key, mask) ((((key) * 2654435761u) >> 7) & (mask))
+#define FH_ADD(tab, stride, mask, key_)                              \
+  {                                                                  \
+    const uint32_t key = (key_);                                     \
+    for (uint32_t h = FH_SLOT(key, mask);; h = (h + 1) & (mask)) {   \
+      const uint32_t cur = (tab)[(size_t)h * (stride)];              \
+      if (cur == 0xffffffffu) {                                      \
+        (tab)[(size_t)h * (stride)] = (key << 8) | 1u;               \
+        break;                                                       \
+      }                                                              \
+      if ((cur >> 8) == key) {                                       \
+        (tab)[(size_t)h * (stride)] = cur + 1u;                      \
+        break;                                                       \
+      }                                                              \
+    }                                                                \
   }
+  if (hashed_l) {
+    const uint32_t mask = own_cap - 1;
+    for (uint32_t i = 0; i < own_cap; ++i) ht_l[(size_t)i * 64] = 0xffffffffu;
+    for (uint32_t q = 0; q < own_len; ++q) {
+      const uint32_t rr = own[q], nr = A.p_norm[rr];
+      FH_ADD(ht_l, 64, mask, rr)
+      if (nr != F_NONORM) FH_ADD(ht_l, 64, mask, nr | 0x800000u)
+    }
+  } else if (hashed_g) {
+    const uint32_t mask = FOREST_GHASH - 1;
+    for (uint32_t i = 0; i < FOREST_GHASH; ++i) ht_g[i] = 0xffffffffu;
+    for (uint32_t q = 0; q < own_len; ++q) {
+      const uint32_t rr = own[q], nr = A.p_norm[rr];
+      FH_ADD(ht_g, 1, mask, rr)
+      if (nr != F_NONORM) FH_ADD(ht_g, 1, mask, nr | 0x800000u)
+    }
+  }
+#undef FH_ADD
+  auto own_uses = [&](uint32_t key) -> double {  // uses of a rule (key = id) or of a norm group (key = id | 1 << 23)
+    if (hashed_l) {
+      const uint32_t mask = own_cap - 1;
+      for (uint32_t h = FH_SLOT(key, mask);; h = (h + 1) & mask) {
+        const uint32_t cur = ht_l[(size_t)h * 64];
+        if (cur == 0xffffffffu) return 0.0;
+        if ((cur >> 8) == key) return (double)(cur & 0xffu);
+      }
+    } else {
+      const uint32_t mask = FOREST_GHASH - 1;
+      for (uint32_t h = FH_SLOT(key, mask);; h = (h + 1) & mask) {
+        const uint32_t cur = ht_g[h];
+        if (cur == 0xffffffffu) return 0.0;
+        if ((cur >> 8) == key) return (double)(cur & 0xffu);
+      }
+    }
+  };
+  if (A.trace) tr1 = __builtin_readcyclecounter();
   // inside with proposal probabilities (forest.hpp:768-816)
   {
     const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
@@ -209,15 +268,15 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
             pr = A.p_prior[rule];
           else {
             double x = A.snap_x[rule], ns = A.snap_norm[nn];
-            for (uint32_t q = 0; q < own_lds; ++q) {
-              const uint2 o2 = own_sh[(size_t)q * 64];
-              if (o2.x == rule) x -= 1.0;
-              if (o2.y == nn) ns -= 1.0;
-            }
-            for (uint32_t q = own_lds; q < own_len; ++q) {  // a sample longer than the staged part (rare)
-              const uint32_t rr = own[q];
-              if (rr == rule) x -= 1.0;
-              if (A.p_norm[rr] == nn) ns -= 1.0;
+            if (hashed) {
+              x -= own_uses(rule);
+              ns -= own_uses(nn | 0x800000u);
+            } else {
+              for (uint32_t q = 0; q < own_len; ++q) {
+                const uint32_t rr = own[q];
+                if (rr == rule) x -= 1.0;
+                if (A.p_norm[rr] == nn) ns -= 1.0;
+              }
             }
             pr = x / ns;
           }
@@ -237,6 +296,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
       }
     }
   }
+  if (A.trace) tr2 = __builtin_readcyclecounter();
   // top-down choice (forest.hpp:725-758) with an explicit stack; children are pushed in reverse so they pop in order
   double cheap = 0.0;
   if (active) {
@@ -244,28 +304,36 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
     const uint32_t* __restrict__ hp = A.hdr_pos + g.stream_base + lane;  // indexed [node * 64]
     uint32_t* outr = A.sample_rules + A.sample_off[forest];
     const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
-    uint32_t* stack = outr + cap;  // stack[-1 - i]
+    uint32_t* stack = outr + cap;  // deep part of the stack: stack[-1 - i]
+    uint32_t* stk_sh = (uint32_t*)(lds + (size_t)ins_rows * 64) + (size_t)own_cap * 64 + lane;  // first stack_lds entries
+#define FSTACK_PUSH(v)                                       \
+  {                                                          \
+    if (sp < stack_lds)                                      \
+      stk_sh[(size_t)sp * 64] = (v);                         \
+    else                                                     \
+      stack[-(int)(sp - stack_lds) - 1] = (v);               \
+    ++sp;                                                    \
+  }
     uint32_t sp = 0, ns = 0, step = 0;
-    stack[-1] = n - 1;
-    sp = 1;
+    FSTACK_PUSH(n - 1)
     while (sp) {
-      const uint32_t node = stack[-(int)(sp--)];
+      --sp;
+      const uint32_t node = sp < stack_lds ? stk_sh[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
       const uint32_t h = hp[(size_t)node * 64];
       const uint2 hr = st[(size_t)h * 64];
-      // children occupy records h+1 .. until the one flagged LAST (none if the header itself is LAST)
-      uint32_t nch = 0;
-      if (!(hr.x & F_LAST))
+      // children occupy records h+1 .. h+nch; the count rides in the header (no dependent scan of the records)
+      uint32_t nch = (hr.x >> 20) & 0xffu;
+      if (nch == 255u) {
+        nch = 0;
         for (uint32_t k = h + 1;; ++k) {
           ++nch;
           if (st[(size_t)k * 64].x & F_LAST) break;
         }
+      }
       if (hr.x & F_AND) {
         if (ns < max_sample) outr[ns] = hr.y;
         ++ns;
-        for (uint32_t k = nch; k-- > 0;) {
-          ++sp;
-          stack[-(int)sp] = st[(size_t)(h + 1 + k) * 64].x & F_IDX;
-        }
+        for (uint32_t k = nch; k-- > 0;) FSTACK_PUSH(st[(size_t)(h + 1 + k) * 64].x & F_IDX)
       } else {
         double norm = F_NEG_INF;
         for (uint32_t k = 0; k < nch; ++k) norm = f_lwadd(norm, ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64]);
@@ -276,10 +344,11 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
           choice -= exp(ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] - norm);
           if (choice < 0 || k + 1 == nch) break;
         }
-        ++sp;
-        stack[-(int)sp] = st[(size_t)(h + 1 + pick) * 64].x & F_IDX;
+        FSTACK_PUSH(st[(size_t)(h + 1 + pick) * 64].x & F_IDX)
       }
     }
+#undef FSTACK_PUSH
+    if (A.trace) tr3 = __builtin_readcyclecounter();
     A.sample_len[forest] = ns < max_sample ? ns : max_sample;
     for (uint32_t k = 0; k < ns && k < max_sample; ++k) {
       const uint32_t rule = outr[k], nn = A.p_norm[rule];
@@ -288,10 +357,15 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
         pr = A.p_prior[rule];
       else {
         double x = A.snap_x[rule], nsum = A.snap_norm[nn];
-        for (uint32_t q = 0; q < own_len; ++q) {
-          const uint32_t rr = own[q];
-          if (rr == rule) x -= 1.0;
-          if (A.p_norm[rr] == nn) nsum -= 1.0;
+        if (hashed) {
+          x -= own_uses(rule);
+          nsum -= own_uses(nn | 0x800000u);
+        } else {
+          for (uint32_t q = 0; q < own_len; ++q) {
+            const uint32_t rr = own[q];
+            if (rr == rule) x -= 1.0;
+            if (A.p_norm[rr] == nn) nsum -= 1.0;
+          }
         }
         pr = x / nsum;
       }
@@ -300,6 +374,17 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   }
   for (int o = 32; o > 0; o >>= 1) cheap += __shfl_down(cheap, o, 64);
   if (lane == 0) unsafeAtomicAdd(A.iter_out + 1, cheap);
+  if (A.trace) {
+    unsigned long long t3 = tr3;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_down(t3, o, 64);
+      t3 = other > t3 ? other : t3;
+    }
+    if (lane == 0) {
+      unsigned long long* o = A.trace + (size_t)(A.first_group + blockIdx.x) * 8;
+      o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = t3; o[4] = __builtin_readcyclecounter(); o[5] = g.maxlen; o[6] = g.n_lanes;
+    }
+  }
 }
 
 // counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors)
@@ -447,7 +532,9 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       uint32_t i = idx[k];
       bool is_and = label[b + i] != 0;
       fl.hdr[k] = (uint32_t)fl.ins.size();
-      uint32_t hx = F_HEADER | F_VALID | (is_and ? F_AND : 0u) | (kids[k].empty() ? F_LAST : 0u) | k;
+      // header word: flags | child count in bits 20..27 (255 = "255 or more: count the records") | node order k
+      uint32_t hx = F_HEADER | F_VALID | (is_and ? F_AND : 0u) | (kids[k].empty() ? F_LAST : 0u) |
+                    ((uint32_t)std::min<size_t>(kids[k].size(), 255) << 20) | (k & 0xfffffu);
       fl.ins.push_back(uint2_t{hx, label[b + i]});
       for (size_t c = 0; c < kids[k].size(); ++c)
         fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], 0u});
@@ -608,6 +695,8 @@ static void fill_args(carmel_hip_forests* F, ForestArgs& A) {
   A.hdr_pos = F->hdr_pos.p;
   A.sample_off = F->sample_off.p;
   A.iter_out = F->iter_out.p;
+  A.trace = nullptr;
+  A.ghash = nullptr;
   A.serial_forest = 0xffffffffu;
 }
 
@@ -746,6 +835,18 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   A.p_prior = F->p_prior.p;
   A.seed = o->seed;
   A.counterfactual = 1;
+  DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
+  if (o->mode == 1 && (uint64_t)F->max_sample * 20 > 256 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
+    HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
+    A.ghash = ghash.p;
+  }
+  DevBuf<unsigned long long> trace_buf;  // experiment: per-wave phase stamps of the last parallel sweep
+  const char* trace_path = getenv("CARMEL_HIP_FOREST_TRACE");
+  if (trace_path && o->mode == 1) {
+    HIPCHK(trace_buf.alloc(F->h_groups.size() * 8));
+    HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
+    A.trace = trace_buf.p;
+  }
   const uint32_t Ni = o->iter, burnin = std::min(o->burnin, o->iter);
   // host mirror of counts for the exact schedule (one forest at a time: the counts move between forests)
   std::vector<double> hx, hs, ht, hn;
@@ -775,11 +876,16 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       for (auto& c : F->classes) {
         A.first_group = c.first;
         // LDS: the inside column + up to own_cap {rule, norm group} pairs of the previous sample per lane
-        const uint32_t own_cap = (uint32_t)std::min<size_t>(std::min<size_t>(F->max_sample, 128), (150 * 1024 - (size_t)c.max_nodes * 512) / 512);
-        size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)own_cap * 64 * 8;
+        const uint32_t stack_lds = 32;  // 8 KB: the shallow part of the traversal stack
+        uint32_t own_cap = 256;         // hash slots per lane (64 KB per wave), fewer when the inside column is large
+        while (own_cap && (size_t)c.max_nodes * 512 + (size_t)own_cap * 256 + stack_lds * 256 > 156 * 1024) own_cap >>= 1;
+        if (own_cap < 32) own_cap = 0;
+        static const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
+        if (nohash) own_cap = 0;
+        size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)own_cap * 64 * 4 + (size_t)stack_lds * 64 * 4;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample, c.max_nodes, own_cap);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample, c.max_nodes, own_cap, stack_lds);
       }
       HIPCHK(hipGetLastError());
       cur ^= 1;
@@ -838,7 +944,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         size_t lds = (size_t)G.max_nodes * 64 * 8;
         if (lds > 64 * 1024)
           (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample, G.max_nodes, 0u);
+        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample, G.max_nodes, 0u, 0u);
         uint32_t len = 0;
         HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + f, sizeof len, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -900,6 +1006,14 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   for (uint32_t r = 0; r < nr; ++r) {
     double pr = F->h_norm[r] == F_NONORM ? prior[r] : (x[r] > 0 ? x[r] / ns[F->h_norm[r]] : 0.0);
     lw[r] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
+  }
+  if (trace_buf.n) {
+    std::vector<unsigned long long> h(trace_buf.n);
+    HIPCHK(hipMemcpy(h.data(), trace_buf.p, trace_buf.bytes(), hipMemcpyDeviceToHost));
+    if (FILE* f = fopen(trace_path, "wb")) {
+      fwrite(h.data(), 8, h.size(), f);
+      fclose(f);
+    }
   }
   return carmel_hip_forests_set_weights(F, lw.data());
 }

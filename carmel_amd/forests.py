@@ -71,6 +71,10 @@ class HipForests(object):
                                            ptr(self.iter_cheap_logprob)), "carmel_hip_forests_gibbs")
         return self.iter_logprob
 
+    def max_sample(self):
+        """rules in the largest derivation of any forest"""
+        return int(lib.carmel_hip_forests_max_sample(self.h))
+
     def sample(self, forest):
         buf = np.zeros(max(1, lib.carmel_hip_forests_max_sample(self.h)), np.uint32)
         n = C.c_uint32(0)

@@ -118,3 +118,28 @@ def test_forest_gibbs_parallel_mode(oracle):
     assert all(len(s) > 0 for s in res[1][1])
     t0, t1 = res[0][0][-10:].mean(), res[1][0][-10:].mean()
     assert abs(t1 - t0) < 0.05 * abs(t0)
+
+
+def test_parallel_gibbs_sample_tables_equal_the_scan():
+    """parallel mode: the counterfactual "uses of this rule / group in my previous sample" come from a per-lane hash
+    table (LDS, global memory for long samples); the chain must be the one obtained by scanning the sample"""
+    from carmel_amd import synth
+    from carmel_amd.forests import HipForests
+    node_off, label, ref, nxt, n_rules, goff, grule = synth.random_forests(6000, n_rules=30000, mean_nodes=60, seed=9)
+    lw = np.zeros(n_rules)
+
+    def run():
+        hf = HipForests(node_off, label, ref, nxt, n_rules, lw, goff, grule)
+        hf.gibbs(4, alpha=0.1, seed=4, mode=1)
+        return hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(0, 6000, 7)], hf.max_sample()
+
+    os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
+    a, sa, ms = run()
+    os.environ["CARMEL_HIP_FOREST_NOHASH"] = "1"
+    try:
+        b, sb, _ = run()
+    finally:
+        os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
+    assert ms > 116  # some derivation is too long for the LDS table: the global table is exercised too
+    assert sa == sb
+    np.testing.assert_allclose(a, b, rtol=1e-12)
