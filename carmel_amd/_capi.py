@@ -19,7 +19,7 @@ SYMBOLS = [
     "carmel_hip_get_arc_weights", "carmel_hip_estimate", "carmel_hip_estimate_async",
     "carmel_hip_estimate_finish", "carmel_hip_counts_dev", "carmel_hip_counts_len", "carmel_hip_stream",
     "carmel_hip_use_external_counts", "carmel_hip_synchronize", "carmel_hip_last_sweep_ms", "carmel_hip_read_scalars",
-    "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_keep_em_weights", "carmel_hip_save_counts",
+    "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_keep_em_weights", "carmel_hip_random_restart", "carmel_hip_save_counts",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",

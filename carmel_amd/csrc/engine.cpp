@@ -10,6 +10,7 @@
 #include <unordered_map>
 #include <vector>
 #include "engine.hpp"
+#include "rng.hpp"
 #include "unrolled_args.hpp"
 
 int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats);
@@ -757,6 +758,25 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
   }
   if (max_change) *max_change = result;
   return CARMEL_HIP_OK;
+}
+
+int carmel_hip_random_restart(carmel_hip_trainer* t, uint64_t seed, uint32_t restart) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
+  HIPCHK(hipSetDevice(t->device));
+  const uint64_t n = t->np();
+  std::vector<double> lw(n);
+  HIPCHK(hipMemcpyAsync(lw.data(), t->params(), n * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  const std::vector<uint32_t>& grp = t->cascade ? t->h_param_group : t->w.group;
+  for (uint64_t p = 0; p < n; ++p) {
+    if (grp[p] == CARMEL_HIP_LOCKED_GROUP) continue;        // randomSet leaves locked arcs alone (fst.h:976)
+    if (t->h_norm_of[p] == 0xffffffffu) continue;           // members normalised by NONE are not randomised (cascade.h:398-401)
+    lw[p] = std::log(1.0 - gibbs_uniform(seed, restart, (uint32_t)p, 0));
+  }
+  int rc = carmel_hip_set_weights(t, lw.data());
+  if (rc) return rc;
+  return carmel_hip_normalize(t);
 }
 
 int carmel_hip_keep_em_weights(carmel_hip_trainer* t) {

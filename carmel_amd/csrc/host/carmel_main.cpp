@@ -45,6 +45,7 @@ static std::string base2(double ln_value) {  // weight.h:529-532,603 as_base(2) 
 struct Options {
   bool flags[256] = {false};
   bool train_cascade = false;
+  long restarts = 0;         // -! (train_opts::ran_restarts)
   double rate_growth = 1.0;  // -o (train_opts::learning_rate_growth_factor, fst.h:1083)
   long max_iter = 500;  // train_opts default (fst.h:1080-1095); -1 == "-M" without a number
   double converge = 1e-4, converge_ppx_ratio = .999, smooth_floor = 0;
@@ -122,6 +123,9 @@ static Options parse_args(int argc, char** argv) {
           case 'T': o.index_threshold = std::atoi(value()); break;
           case 'F': o.out_file = value(); break;
           case 'R': o.seed = std::strtoull(value(), 0, 10); break;
+          case '!':  // random restarts (carmel.cc:944-946)
+            o.restarts = std::atol(value());
+            break;
           case 'o':  // learning rate growth factor of over-relaxed EM (carmel.cc:940-943)
             o.rate_growth = std::max(1.0, std::atof(value()));
             break;
@@ -364,15 +368,19 @@ static int run(int argc, char** argv) {
              "offered by the GPU front end).\n";
   } else {
     const bool timing = std::getenv("CARMEL_TIMING") != nullptr;  // per-iteration wall clock on stderr
-    double best = std::numeric_limits<double>::infinity(), last_ppx = best, last_change = 10.0;
-    bool have_good = false, last_was_reset = false;
-    long iter = 0;
-    double learning_rate = 1.0;
+    double best = std::numeric_limits<double>::infinity(), best_start = best;
+    bool have_good = false;
     double growth = o.rate_growth;
     if (cascade && growth != 1.0) {  // train.cc:545-549
       log << "Overrelaxed EM not supported for --train-cascade (compose with -a and train, instead?).  Disabling (growth factor=1)." << std::endl;
       growth = 1.0;
     }
+    long restarts_left = o.restarts;
+    for (unsigned restart_no = 0;; ++restart_no) {  // train.cc:552-667
+    double last_ppx = std::numeric_limits<double>::infinity(), last_change = 10.0;
+    bool last_was_reset = false;
+    long iter = 0;
+    double learning_rate = 1.0;
     for (;;) {
       const bool first_time = iter == 0;
       ++iter;
@@ -408,7 +416,15 @@ static int run(int argc, char** argv) {
       }
       double ratio_ln = kNegInf;
       if (first_time) {
-        log << std::endl << "Initial best start point ppx=" << base2(new_ppx) << "\n";
+        log << std::endl;
+        if (restart_no == 0) {
+          best_start = new_ppx;
+          log << "Initial best start point ppx=" << base2(new_ppx) << "\n";
+        } else {  // random_restart_acceptor with its default infinite tolerance (fst.h:1021, 1030-1040)
+          log << "For restart " << restart_no << ", accepting worse random start of " << base2(new_ppx) << " compared to "
+              << base2(best_start) << " with relative ppx ratio="
+              << format_weight((new_ppx - best_start) / std::fabs(new_ppx), W_SOMETIMES_LOG) << " compared to target of inf\n";
+        }
       } else {
         ratio_ln = (new_ppx - last_ppx) / std::fabs(new_ppx);  // weight.h:247-249
         log << " (relative-perplexity-ratio=" << format_weight(ratio_ln, W_SOMETIMES_LOG) << ")";
@@ -446,6 +462,13 @@ static int run(int argc, char** argv) {
         break;
       }
       last_ppx = new_ppx;
+    }
+    if (restarts_left > 0) {  // train.cc:660-663
+      --restarts_left;
+      hip_check(carmel_hip_random_restart(t, o.seed, restart_no + 1), "carmel_hip_random_restart");
+      log << "\nRandom restart - " << restarts_left << " remaining.\n";
+    } else
+      break;
     }
     log << "Setting weights to model with lowest per-example-perplexity ( = "
            "prod[modelprob(example)]^(-1/num_examples) = 2^(-log_2(p_model(corpus))/N) = "

@@ -147,6 +147,11 @@ int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts /* n_arcs,
  * (10 for a real cascade, train.cc:922). */
 int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change);
 
+/* Replaces cascade_parameters::random_restart (cascade.h:398-411: WFST::randomSet on every member not normalised by
+ * NONE, then normalize): every unlocked parameter p gets the weight 1 - u(seed, restart, p) in (0, 1] from the
+ * library's counter-based generator (carmel_hip_gibbs_uniform(seed, restart, p, 0)), then the model is normalised.
+ * The reference draws from Boost's lagged_fibonacci607: restart sequences are not comparable with it (unpinned). */
+int carmel_hip_random_restart(carmel_hip_trainer* t, uint64_t seed, uint32_t restart);
 /* Replaces for_arcs::keep_em_weight (train.cc:188-190, used at :639-643): after an over-relaxed step (delta_scale > 1)
  * failed to improve, the weights go back to the plain EM update of that step.  Valid after a carmel_hip_maximize call
  * with delta_scale > 1 on a single transducer. */

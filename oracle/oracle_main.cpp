@@ -67,6 +67,10 @@ static int real_main(int argc, char** argv) {
         smoothFloor = LW::from_real(std::atof(next()));
       else if (last == 'T')
         idx_threshold = std::atoi(next());
+      else if (last == '!')  // carmel.cc:944-946
+        topt.ran_restarts = (unsigned)std::atoi(next());
+      else if (last == 'R')
+        topt.restart_seed = std::strtoull(next(), 0, 10);
       else if (last == 'o')  // carmel.cc:940-943
         topt.learning_rate_growth_factor = std::max(1.0, std::atof(next()));
     } else

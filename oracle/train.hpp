@@ -22,9 +22,10 @@ struct TrainOpts {
   unsigned max_iter;  // (unsigned)-1 == "-M" without number? no: carmel sets -1 when -M given w/o value
   double learning_rate_growth_factor;
   unsigned ran_restarts;
+  unsigned long long restart_seed;  // of the counter-based generator below (the reference's Boost stream is unpinned)
   bool cache_derivations;  // -? / -: (both are "cache" here; the reverse graph is always rebuilt)
   bool prune;
-  TrainOpts() : max_iter(500), learning_rate_growth_factor(1), ran_restarts(0), cache_derivations(false), prune(true) {}
+  TrainOpts() : max_iter(500), learning_rate_growth_factor(1), ran_restarts(0), restart_seed(0), cache_derivations(false), prune(true) {}
 };
 
 struct IterRecord {  // what one log line of train.cc:587-613 carries
@@ -162,6 +163,33 @@ struct ForwardBackward {
   }
 };
 
+// The restart generator: the library's counter-based uniform u(seed, restart, parameter, 0) restated (splitmix64
+// finaliser over the counters; the reference's Boost lagged_fibonacci607 stream is not pinned by any of its tests, so
+// restart sequences are comparable with this build's GPU path only).  Parameters are numbered member by member in
+// arc visit order; locked arcs and members normalised by NONE keep their weights (fst.h:976, cascade.h:398-401).
+inline unsigned long long restart_mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline double restart_uniform(unsigned long long seed, unsigned restart, unsigned param) {
+  unsigned long long h = restart_mix64(seed ^ 0xD1B54A32D192ED03ull);
+  h = restart_mix64(h ^ ((unsigned long long)restart << 32 | param));
+  h = restart_mix64(h ^ 0ull);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+inline void restart_randomize(Cascade& cascade, const std::vector<NormalizeMethod>& methods, unsigned long long seed,
+                              unsigned restart) {
+  unsigned p = 0;
+  for (size_t i = 0; i < cascade.cascade.size(); ++i)
+    for (auto& st : cascade.cascade[i]->states)
+      for (auto& a : st) {
+        if (!a.locked() && methods[i].group != NORM_NONE) a.weight = LW::from_real(1.0 - restart_uniform(seed, restart, p));
+        ++p;
+      }
+}
+
 // train.cc:503-678.  Returns best per-example perplexity.  `log` receives the reference's log lines; `trace`
 // (optional) receives one IterRecord per iteration.
 inline LW train(Wfst& x, Cascade& cascade, Corpus& corpus, const std::vector<NormalizeMethod>& methods,
@@ -205,6 +233,7 @@ inline LW train(Wfst& x, Cascade& cascade, Corpus& corpus, const std::vector<Nor
   bool using_cascade = !cascade.trivial;
   if (using_cascade && learning_rate_growth_factor != 1) learning_rate_growth_factor = 1;
   bool have_good_weights = false;
+  LW best_start = LW::inf();
   const double MAX_LEARNING_RATE_EXP = 20;  // fst.h MAX_LEARNING_RATE_EXP
   for (unsigned restart_no = 0;; ++restart_no) {
     unsigned train_iter = 0;
@@ -250,7 +279,14 @@ inline LW train(Wfst& x, Cascade& cascade, Corpus& corpus, const std::vector<Nor
       if (first_time) {
         log << std::endl;
         // random_restart_acceptor::accept (fst.h:1017-1040): restart 0 is always accepted
-        if (restart_no == 0) log << "Initial best start point ppx=" << lw_base2(newPerplexity) << "\n";
+        if (restart_no == 0) {
+          best_start = newPerplexity;
+          log << "Initial best start point ppx=" << lw_base2(newPerplexity) << "\n";
+        } else {  // default acceptor: infinite tolerance, every start is accepted (fst.h:1021, 1030-1040)
+          log << "For restart " << restart_no << ", accepting worse random start of " << lw_base2(newPerplexity)
+              << " compared to " << lw_base2(best_start) << " with relative ppx ratio="
+              << lw_str(relative_perplexity_ratio(newPerplexity, best_start)) << " compared to target of inf\n";
+        }
         pp_ratio_scaled = LW();
       } else {
         pp_ratio_scaled = relative_perplexity_ratio(newPerplexity, lastPerplexity);
@@ -289,8 +325,11 @@ inline LW train(Wfst& x, Cascade& cascade, Corpus& corpus, const std::vector<Nor
       }
       lastPerplexity = newPerplexity;
     }
-    if (ran_restarts > 0) {
-      throw std::runtime_error("oracle: random restarts need the reference's Boost RNG stream (parity unpinned)");
+    if (ran_restarts > 0) {  // train.cc:660-663; cascade.h:398-411 random_restart = randomSet + normalize
+      --ran_restarts;
+      restart_randomize(cascade, methods, opts.restart_seed, restart_no + 1);
+      cascade.normalize(methods);
+      log << "\nRandom restart - " << ran_restarts << " remaining.\n";
     } else
       break;
   }

@@ -169,3 +169,27 @@ def test_overrelaxed_em_switch(golden_dir):
             assert float(u) == pytest.approx(float(v), rel=1e-4)
     for x, y in zip(out.strip().split("\n"), p.stdout.strip().split("\n")):
         assert NUM.sub("#", x) == NUM.sub("#", y)
+
+
+def test_random_restarts(golden_dir):
+    """carmel -t -! 2 -R seed: two random restarts (train.cc:660-663, cascade.h:398-411).  The reference's Boost stream
+    is unpinned; the command line and the oracle share this build's counter-based generator, so their runs coincide"""
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    args = ["-t", "-!", "2", "-R", "7", "-M", "8", os.path.join(golden_dir, "epron-jpron.data"), os.path.join(golden_dir, "epron-jpron.fst")]
+    rc, out, err = run(args)
+    assert rc == 0, err
+    p = subprocess.run([oracle_cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert p.returncode == 0, p.stderr
+    keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "For restart", "Random restart", "Converged"))]
+    mine, ref = keep(err), keep(p.stderr)
+    assert len(mine) == len(ref) and sum(l.startswith("Random restart") for l in mine) == 2
+    for x, y in zip(mine, ref):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-4)
+    for x, y in zip(out.strip().split("\n"), p.stdout.strip().split("\n")):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6)
