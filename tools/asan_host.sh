@@ -1,0 +1,34 @@
+#!/bin/bash
+# The host-only sources (lattice builder, blocked-transposition tables, host inspection API) under AddressSanitizer and
+# UBSan.  GPU sanitizers are not available on the pool; this is the CPU-side check.  usage: bash tools/asan_host.sh
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/carmel_asan
+mkdir -p $OUT
+g++ -O1 -g -std=c++17 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -shared -I$ROOT/include \
+    $ROOT/carmel_amd/csrc/lattice.cpp $ROOT/carmel_amd/csrc/host_api.cpp $ROOT/carmel_amd/csrc/unrolled.cpp \
+    -o $OUT/libcarmel_host_asan.so -lpthread
+cat > $OUT/run.py <<PY
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, "$ROOT")
+lib = C.CDLL("$OUT/libcarmel_host_asan.so")
+from carmel_amd import synth
+def ptr(a): return a.ctypes.data_as(C.c_void_p) if a is not None else None
+lib.carmel_hip_host_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64] + [C.c_void_p] * 4 + [C.c_uint64] + [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int]
+lib.carmel_hip_host_dims.argtypes = [C.c_void_p, C.c_void_p]
+lib.carmel_hip_host_transpose.argtypes = [C.c_void_p] * 12
+lib.carmel_hip_host_free.argtypes = [C.c_void_p]
+for cfg in [dict(ns=300, deg=6, pairs=3000, lo=3, hi=25), dict(ns=40, deg=8, pairs=500, lo=3, hi=12), dict(ns=2000, deg=10, pairs=20000, lo=5, hi=40)]:
+    w = synth.random_wfst(cfg["ns"], cfg["deg"], n_sym=6, p_eps=0.15, seed=3)
+    c = synth.random_walk_corpus(w, cfg["pairs"], min_arcs=cfg["lo"], max_arcs=cfg["hi"], seed=3, out_degree=cfg["deg"])
+    h = C.c_void_p()
+    assert lib.carmel_hip_host_build(C.byref(h), w.n_states, w.final, w.n_arcs, ptr(w.src), ptr(w.dst), ptr(w.isym), ptr(w.osym),
+                                     c.n_pairs, ptr(c.in_off), ptr(c.in_sym), ptr(c.out_off), ptr(c.out_sym), ptr(c.weight), 1, 4, 0, 0, -1) == 0
+    dims, td = np.zeros(16, np.uint64), np.zeros(6, np.uint64)
+    lib.carmel_hip_host_dims(h, ptr(dims))
+    lib.carmel_hip_host_transpose(h, ptr(td), *([None] * 10))
+    print(cfg, "kept pairs", int(dims[6]), "lattice arcs", int(dims[15]), "items", int(td[0]), "buckets", int(td[1]))
+    lib.carmel_hip_host_free(h)
+print("asan/ubsan run complete: no reports")
+PY
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python3 $OUT/run.py
