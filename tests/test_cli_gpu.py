@@ -193,3 +193,32 @@ def test_random_restarts(golden_dir):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-6)
+
+
+def test_cascade_unrolled_equals_explicit(golden_dir, tmp_path):
+    """the cipher cascade is a one-tape transducer: by default its lattices are never stored (unrolled sweep, counts per
+    parameter); CARMEL_HIP_UNROLLED=0 builds explicit lattices (composed-arc counts + chain scatter).  Same run."""
+    g = lambda n: os.path.join(golden_dir, n)
+    args = ["--train-cascade", "-HJ", "-M", "12", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    outs = {}
+    for mode in ("unrolled", "explicit"):
+        d = tmp_path / mode
+        d.mkdir()
+        env = {"CARMEL_TRAINED_DIR": str(d), "CARMEL_TIMING": "1"}
+        if mode == "explicit":
+            env["CARMEL_HIP_UNROLLED"] = "0"
+        rc, out, err = run(args, env=env)
+        assert rc == 0, err
+        assert ("layout=" + mode) in err
+        outs[mode] = ([l for l in err.split("\n") if l.startswith("i=")], (d / "cipher.fst.trained").read_text())
+    assert len(outs["unrolled"][0]) == len(outs["explicit"][0]) == 12
+    for x, y in zip(outs["unrolled"][0], outs["explicit"][0]):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):  # 6-digit fields equal, 15-digit ratios to 1e-9
+            assert float(u) == pytest.approx(float(v), rel=1e-9)
+    a, b = outs["unrolled"][1].split("\n"), outs["explicit"][1].split("\n")
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-8)
