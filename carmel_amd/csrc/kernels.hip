@@ -738,6 +738,13 @@ __global__ void fill_f64_kernel(double* p, double v, uint64_t n) {
 }
 
 // ---------------- blocked transposition (TransBucket, lattice.hpp) ----------------
+// Workgroup b runs on XCD b % 8 (each XCD has its own L2).  Neighbouring tiles / buckets read neighbouring runs of X --
+// the 128-byte lines at the run boundaries are shared -- so neighbours are given to the same XCD, back to back:
+// work item = (b % 8) * ceil(n / 8) + b / 8.
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
+  const uint32_t per = (n + 7) / 8;
+  return (b & 7u) * per + (b >> 3);
+}
 // weights, pass 1: one workgroup per arc bucket.  The bucket's weights go to LDS (coalesced read), its items leave in
 // position-sorted order (coalesced write), picking their weight out of LDS.
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
@@ -770,14 +777,16 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
 // in LDS at their position and the tile is written to wcache in one coalesced sweep.
 __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
+  const uint32_t tile = xcd_chunked(blockIdx.x, T.n_wtiles);  // the grid is rounded up to a multiple of 8
+  if (tile >= T.n_wtiles) return;
+  const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
 #pragma unroll
   for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = 0.0;
   __syncthreads();
-  const uint64_t i0 = T.tile_base[blockIdx.x];
-  const uint32_t ni = (uint32_t)(T.tile_base[blockIdx.x + 1] - i0);
+  const uint64_t i0 = T.tile_base[tile];
+  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
   uint32_t src[16];
   uint16_t pos[16];
   double v[16];
@@ -831,7 +840,9 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   __shared__ double part[16];
   __shared__ uint32_t big[512];
   __shared__ uint32_t n_big;
-  const TransBucket B = T.buckets[blockIdx.x];
+  const uint32_t bucket = xcd_chunked(blockIdx.x, T.n_buckets);  // the grid is rounded up to a multiple of 8
+  if (bucket >= T.n_buckets) return;
+  const TransBucket B = T.buckets[bucket];
   {
     uint32_t src[16];
     uint16_t rk[16];
@@ -969,12 +980,14 @@ static void trans_lds_attr() {
   (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   done = true;
 }
-hipError_t launch_transpose_weights(const TransArgs& T, hipStream_t stream) {
+hipError_t launch_transpose_weights(const TransArgs& T0, hipStream_t stream) {
   trans_lds_attr();
-  if (!T.n_buckets) return hipSuccess;
+  if (!T0.n_buckets) return hipSuccess;
+  TransArgs T = T0;
+  T.n_wtiles = (uint32_t)((T.n_wcache + TRANS_TILE - 1) / TRANS_TILE);
   hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
   const unsigned wt = (unsigned)((T.n_wcache + TRANS_TILE - 1) / TRANS_TILE);
-  if (wt) hipLaunchKernelGGL(trans_w_tile_kernel, dim3(wt), dim3(1024), TRANS_TILE * 8, stream, T);
+  if (wt) hipLaunchKernelGGL(trans_w_tile_kernel, dim3((wt + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
@@ -982,7 +995,7 @@ hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arc
   if (!T.n_buckets) return hipSuccess;
   if (n_split) hipLaunchKernelGGL(zero_list_kernel, dim3((n_split + 255) / 256), dim3(256), 0, stream, T.counts, split_arcs, n_split);
   hipLaunchKernelGGL(trans_c_tile_kernel, dim3(T.n_tiles), dim3(1024), TRANS_TILE * 8, stream, T);
-  hipLaunchKernelGGL(trans_c_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  hipLaunchKernelGGL(trans_c_bucket_kernel, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 

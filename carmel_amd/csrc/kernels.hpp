@@ -75,6 +75,7 @@ struct TransArgs {
   double* counts;         // per arc
   uint64_t n_wcache, n_post;
   uint32_t n_buckets, n_tiles;
+  uint32_t n_wtiles;      // tiles that cover wcache (set by launch_transpose_weights)
 };
 
 #define MSTEP_BIG_GROUP 512
