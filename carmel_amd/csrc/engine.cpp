@@ -165,7 +165,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
   {
     // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
-    static const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
     if (want_t && !L.t_buckets.empty()) {
       std::vector<uint32_t> fx(L.lane_fwd.size());
       for (size_t k = 0; k < fx.size(); ++k) fx[k] = L.lane_fwd[k].x;
@@ -194,7 +194,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->slot_pos.upload(L.slot_pos, s));
   HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
   {
-    static const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
     t->use_transpose = want && !L.t_buckets.empty();
     if (t->use_transpose) {
       HIPCHK(t->t_buckets.upload(L.t_buckets, s));
@@ -335,7 +335,7 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       if (first[g] == ~0ull) first[g] = k;
       span = std::max(span, k - first[g]);
     }
-    static const bool want_window = !(getenv("CARMEL_HIP_MSTEP_WINDOW") && atoi(getenv("CARMEL_HIP_MSTEP_WINDOW")) == 0);
+    const bool want_window = !(getenv("CARMEL_HIP_MSTEP_WINDOW") && atoi(getenv("CARMEL_HIP_MSTEP_WINDOW")) == 0);
     t->norm_span = (want_window && span >= 1 && span <= 64) ? (uint32_t)span : 0u;
     if (want_window && span == 0 && !add.empty()) t->norm_span = 1;  // all groups are singletons
   }

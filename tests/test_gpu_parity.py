@@ -281,6 +281,53 @@ def test_full_size_properties_c2():
     fb.close()
 
 
+def test_full_size_properties_c4():
+    """BASELINE.json configs[3] at full size (10^6 states / 10^7 arcs / 10^6 pairs): size-independent properties, and
+    the two formulations of the E-step (blocked transposition vs gathers + per-arc slot sums) against each other"""
+    w, c = synth.make_config("c4")
+    fb = _fb(w, c)
+    assert fb.has_deriv.all()
+    lp, _ = fb.estimate(per_pair=True)
+    counts = fb.counts()
+    assert counts[w.dst == w.final].sum() == pytest.approx(c.n_pairs, rel=1e-9)
+    assert fb.pair_logprob.sum() == pytest.approx(lp, rel=1e-9)
+    inflow = np.bincount(w.dst, weights=counts, minlength=w.n_states)
+    outflow = np.bincount(w.src, weights=counts, minlength=w.n_states)
+    mid = np.ones(w.n_states, bool)
+    mid[[0, w.final]] = False
+    np.testing.assert_allclose(inflow[mid], outflow[mid], rtol=1e-9, atol=1e-9)
+    # bit-reproducibility: a second E-step on the same weights gives the same counts (fixed summation order; only
+    # the <= 1 atomic per piece of a split hub arc may differ in the last bits)
+    plp = fb.pair_logprob.copy()
+    lp2, _ = fb.estimate()
+    c2 = fb.counts()
+    assert lp2 == lp
+    assert (c2 != counts).sum() <= 16 and np.allclose(c2, counts, rtol=1e-13, atol=0)
+    os.environ["CARMEL_HIP_TRANSPOSE"] = "0"
+    try:
+        fg = _fb(w, c)
+    finally:
+        os.environ.pop("CARMEL_HIP_TRANSPOSE", None)
+    lpg, _ = fg.estimate(per_pair=True)
+    assert lpg == pytest.approx(lp, rel=1e-12)
+    np.testing.assert_allclose(fg.counts(), counts, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(fg.pair_logprob, plp, rtol=1e-12)
+    fg.close()
+    prev = lp
+    for _ in range(2):
+        fb.maximize(1.0)
+        cur, _ = fb.estimate()
+        assert cur >= prev - 1e-6 * abs(prev)
+        prev = cur
+    wts = np.exp(fb.weights())
+    key = w.src.astype(np.int64) * (1 << 20) + w.isym
+    _, inv = np.unique(key, return_inverse=True)
+    sums = np.bincount(inv, weights=wts)
+    touched = np.bincount(inv, weights=(wts > 0)) > 0
+    np.testing.assert_allclose(sums[touched], 1.0, rtol=1e-9)
+    fb.close()
+
+
 def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
     texts = [open(os.path.join(golden_dir, n)).read() for n in names]
     oc = oracle.OracleCascade(texts)
