@@ -103,6 +103,8 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   if (t->ev0) (void)hipEventDestroy(t->ev0);
   if (t->ev1) (void)hipEventDestroy(t->ev1);
+  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
+  t->graph_exec = nullptr;
   if (t->side) (void)hipStreamSynchronize(t->side);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -252,6 +254,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   std::vector<uint32_t>().swap(L.out_off);
   std::vector<uint32_t>().swap(L.level_off);
   t->have_lattices = true;
+  ++t->lattice_epoch;
   if (stats) {
     stats->n_pairs = t->corpus.n_pairs;
     stats->n_pairs_kept = L.n_kept;
@@ -520,22 +523,20 @@ int carmel_hip_get_arc_weights(carmel_hip_trainer* t, double* logw) {
   return CARMEL_HIP_OK;
 }
 
-int carmel_hip_estimate_async(carmel_hip_trainer* t) {
-  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
-  if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
-  HIPCHK(hipSetDevice(t->device));
+// Enqueues one E-step on the trainer's stream(s).  timed: bracket it with ev0 / ev1 (not inside a graph capture).
+static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   hipStream_t s = t->stream;
   if (t->cascade)  // cascade.update(): composed weights from the chains
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
   HIPCHK(hipMemsetAsync(t->counts_ptr() + t->w.n_arcs, 0, 4 * sizeof(double), s));  // scalars; counts are all written
   if (t->unrolled) {
-    HIPCHK(hipEventRecord(t->ev0, s));
+    if (timed) HIPCHK(hipEventRecord(t->ev0, s));
     int rc = unrolled_estimate(t, s);
     if (rc) return rc;
     HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
                           t->counts_ptr() + t->w.n_arcs, s));
-    HIPCHK(hipEventRecord(t->ev1, s));
+    if (timed) HIPCHK(hipEventRecord(t->ev1, s));
     return CARMEL_HIP_OK;
   }
   SweepArgs A;
@@ -599,7 +600,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   T.n_buckets = (uint32_t)t->t_buckets.n;
   T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
   LA.pre_weights = t->use_transpose ? 1u : 0u;
-  HIPCHK(hipEventRecord(t->ev0, s));
+  if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   if (t->use_transpose) HIPCHK(launch_transpose_weights(T, s));
   for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
@@ -622,8 +623,8 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   else
     HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipStreamWaitEvent(s, t->ev_join, 0));
-  HIPCHK(hipEventRecord(t->ev1, s));
-  if (trace_path && trace_buf.n) {
+  if (timed) HIPCHK(hipEventRecord(t->ev1, s));
+  if (timed && trace_path && trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);
     HIPCHK(hipStreamSynchronize(s));
     HIPCHK(hipMemcpy(h.data(), trace_buf.p, h.size() * 8, hipMemcpyDeviceToHost));
@@ -632,6 +633,52 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
       fclose(f);
     }
   }
+  return CARMEL_HIP_OK;
+}
+
+// The E-step is a fixed chain of a dozen small launches with unchanging arguments (the weights change in place): after
+// the first, eager, call it is captured once into a hipGraph and replayed -- one submission per E-step.  On small
+// corpora (config 2) the launches, not the kernels, are what an iteration costs.  CARMEL_HIP_GRAPH=0 keeps eager mode.
+static void estimate_graph_drop(carmel_hip_trainer* t) {
+  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
+  t->graph_exec = nullptr;
+}
+int carmel_hip_estimate_async(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  const bool want = !(getenv("CARMEL_HIP_GRAPH") && atoi(getenv("CARMEL_HIP_GRAPH")) == 0) && !getenv("CARMEL_HIP_LANE_TRACE");
+  const void* key = (const void*)t->counts_ptr();
+  if (!want || t->graph_failed) return estimate_enqueue(t, true);
+  if (t->graph_exec && (t->graph_key != key || t->graph_epoch != t->lattice_epoch)) estimate_graph_drop(t);
+  if (!t->graph_exec) {
+    if (t->estimates_done == 0 || t->graph_epoch_first != t->lattice_epoch) {  // first call on these lattices: eager (one-time
+      t->graph_epoch_first = t->lattice_epoch;                                  // function attributes are set outside a capture)
+      t->estimates_done = 1;
+      return estimate_enqueue(t, true);
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      t->graph_failed = true;
+      return estimate_enqueue(t, true);
+    }
+    const int rc = estimate_enqueue(t, false);
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != CARMEL_HIP_OK || e != hipSuccess || !graph || hipGraphInstantiate(&t->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipGetLastError();
+      t->graph_exec = nullptr;
+      t->graph_failed = true;
+      return estimate_enqueue(t, true);
+    }
+    (void)hipGraphDestroy(graph);
+    t->graph_key = key;
+    t->graph_epoch = t->lattice_epoch;
+  }
+  HIPCHK(hipEventRecord(t->ev0, s));
+  HIPCHK(hipGraphLaunch(t->graph_exec, s));
+  HIPCHK(hipEventRecord(t->ev1, s));
   return CARMEL_HIP_OK;
 }
 

@@ -109,6 +109,12 @@ struct carmel_hip_trainer {
   DevBuf<double> u_param_uses;          // cascade: composed arcs whose chain holds the parameter (for the -f prior)
   DevBuf<double> u_em_param, u_best_param;  // cascade: parameter-space images of em_weight / best_weight
   uint32_t u_n_slots = 0, u_n_wg = 0;
+  // the E-step as a replayed hipGraph (engine.cpp: carmel_hip_estimate_async)
+  hipGraphExec_t graph_exec = nullptr;
+  const void* graph_key = nullptr;
+  uint64_t lattice_epoch = 0, graph_epoch = 0, graph_epoch_first = ~0ull;
+  int estimates_done = 0;
+  bool graph_failed = false;
   bool use_transpose = false;
   bool em_valid = false;  // em_logw holds the plain EM update of the last (over-relaxed) maximize
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only

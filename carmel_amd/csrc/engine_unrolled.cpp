@@ -124,6 +124,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   std::vector<double>().swap(M.pair_weight);
   t->unrolled = true;
   t->have_lattices = true;
+  ++t->lattice_epoch;
   return CARMEL_HIP_OK;
 }
 
