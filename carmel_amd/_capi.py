@@ -26,7 +26,7 @@ SYMBOLS = [
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
-    "carmel_hip_forests_set_weights", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
+    "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
     "carmel_hip_forests_max_sample",
 ]
 

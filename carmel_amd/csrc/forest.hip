@@ -455,6 +455,7 @@ struct carmel_hip_forests {
   };
   std::vector<Cls> classes;
   std::vector<uint32_t> h_norm, lane_of_forest;
+  std::vector<double> h_alphas;  // --alpha=FILE: per-rule prior strength, negative = locked (empty: the scalar alpha)
   std::vector<uint64_t> h_group_off;
   std::vector<uint32_t> h_group_rule;
   std::vector<uint64_t> h_sample_off;
@@ -801,6 +802,19 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   std::vector<double> lw(nr);
   HIPCHK(hipMemcpyAsync(lw.data(), F->rule_logw.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  // per-parameter alphas (forest-em.hpp:689-709): a locked parameter (alpha < 0) is defined without a norm group, i.e.
+  // with the fixed probability it has after normalisation; the host and device norm tables are switched for this run
+  struct NormGuard {
+    carmel_hip_forests* F;
+    std::vector<uint32_t> saved;
+    bool changed = false;
+    ~NormGuard() {
+      if (!changed) return;
+      F->h_norm = saved;
+      (void)hipMemcpy(F->p_norm.p, F->h_norm.data(), F->h_norm.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    }
+  } guard{F, {}};
+  auto alpha_of = [&](uint32_t r) { return r < F->h_alphas.size() ? F->h_alphas[r] : alpha; };
   std::vector<double> prior(nr), pn(ng, 0.0);
   for (uint64_t gi = 0; gi < ng; ++gi) {
     double sum = 0;
@@ -810,10 +824,20 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       uint32_t r = F->h_group_rule[j];
       double p = sum > 0 ? std::exp(lw[r]) / sum : 1.0 / (double)(j1 - j0);
       lw[r] = p > 0 ? std::log(p) : -std::numeric_limits<double>::infinity();
-      prior[r] = o->uniform_p0 ? alpha : alpha * p * (double)(j1 - j0);
+      const double a = alpha_of(r);
+      if (a < 0) {
+        if (!guard.changed) {
+          guard.saved = F->h_norm;
+          guard.changed = true;
+        }
+        F->h_norm[r] = F_NONORM;
+        continue;
+      }
+      prior[r] = o->uniform_p0 ? a : a * p * (double)(j1 - j0);
       pn[gi] += prior[r];
     }
   }
+  if (guard.changed) HIPCHK(hipMemcpyAsync(F->p_norm.p, F->h_norm.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   for (uint32_t r = 0; r < nr; ++r)
     if (F->h_norm[r] == F_NONORM) prior[r] = std::exp(lw[r]);
   HIPCHK(F->p_prior.upload(prior, s));
@@ -1016,6 +1040,15 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     }
   }
   return carmel_hip_forests_set_weights(F, lw.data());
+}
+
+int carmel_hip_forests_set_alphas(carmel_hip_forests* F, const double* alpha_per_rule, uint32_t n) {
+  if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
+  if (alpha_per_rule && n)
+    F->h_alphas.assign(alpha_per_rule, alpha_per_rule + n);
+  else
+    F->h_alphas.clear();
+  return CARMEL_HIP_OK;
 }
 
 int carmel_hip_forests_get_sample(carmel_hip_forests* F, uint64_t forest, uint32_t* rules, uint32_t* n) {

@@ -3,6 +3,7 @@
 // runs EM (graehl/shared/em.hpp:107-216 for one start at learning rate 1; forest-em.hpp:561-655) or the Gibbs sampler
 // (--crp, forest-em.hpp:694-766) on the GPU, and writes the parameter / count vectors the reference writes
 // (forest-em.hpp:190-201).  Host code only parses, logs and decides when to stop.
+#include <cctype>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -30,7 +31,8 @@ struct Opts {
   double prior_counts = 0, add_k = 0;
   bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
   long crp = 0, burnin = 0;
-  double alpha = 0.1;
+  double alpha = 0.1;             // --const-alpha (gibbs_opts.hpp:93)
+  std::string alpha_file = "-0";  // --alpha: per-parameter alphas parallel to the weights, negative = locked (:98-99)
   bool final_counts = false, uniform_p0 = false, parallel = false;
   unsigned long long seed = 0;
   int gpu = 0;
@@ -39,7 +41,7 @@ struct Opts {
 void usage() {
   std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
-               "                 [-z] [-N] [-H] [--crp=N --alpha=A --burnin=B --final-counts --uniform-p0 --crp-parallel]\n"
+               "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --final-counts --uniform-p0 --crp-parallel]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -106,7 +108,8 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "H" || key == "human-probs") o.human_probs = true;
     else if (key == "U" || key == "use-double-precision") {}  // always double here
     else if (key == "crp") o.crp = std::atol(value(val).c_str());
-    else if (key == "alpha") o.alpha = std::atof(value(val).c_str());
+    else if (key == "const-alpha") o.alpha = std::atof(value(val).c_str());
+    else if (key == "alpha") o.alpha_file = value(val);
     else if (key == "burnin") o.burnin = std::atol(value(val).c_str());
     else if (key == "final-counts") o.final_counts = true;
     else if (key == "uniform-p0") o.uniform_p0 = true;
@@ -176,6 +179,20 @@ int main(int argc, char** argv) {
       go.mode = o.parallel ? 1 : 0;
       go.uniform_p0 = o.uniform_p0;
       go.final_counts = o.final_counts;
+      if (o.alpha_file != "-0") {
+        // "(a1 a2 ...)" indexed by rule id like forest-em.hpp:689-692 (alphas[i] for parameter i; entry 0 is the unused rule 0)
+        const std::string txt = slurp(o.alpha_file);
+        std::vector<double> al;
+        for (size_t p = 0; p < txt.size();) {
+          if (std::isdigit((unsigned char)txt[p]) || txt[p] == '-' || txt[p] == '.' || txt[p] == '+') {
+            char* e = nullptr;
+            al.push_back(std::strtod(txt.c_str() + p, &e));
+            p = (size_t)(e - txt.c_str());
+          } else
+            ++p;
+        }
+        check(carmel_hip_forests_set_alphas(F, al.data(), (uint32_t)al.size()), "carmel_hip_forests_set_alphas");
+      }
       std::vector<double> lp((size_t)o.crp + 1);
       check(carmel_hip_forests_gibbs(F, &go, o.alpha, lp.data(), nullptr), "carmel_hip_forests_gibbs");
       for (size_t i = 0; i < lp.size(); ++i)

@@ -220,6 +220,10 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* f, const double* rule_log
  * probabilities (from_gibbs). */
 int carmel_hip_forests_gibbs(carmel_hip_forests* f, const carmel_hip_gibbs_opts* opts, double alpha,
                              double* iter_logprob, double* iter_cheap_logprob);
+/* --alpha=FILE of forest-em (gibbs_opts.hpp:98-99; forest-em.hpp:681-709): a prior strength per parameter, indexed by
+ * rule id like the weights (entry 0 unused); a negative entry locks the parameter (it keeps its probability and leaves
+ * its normalisation group's counts); rules beyond n use the scalar alpha.  NULL / n = 0 clears. */
+int carmel_hip_forests_set_alphas(carmel_hip_forests* f, const double* alpha_per_rule, uint32_t n);
 int carmel_hip_forests_get_sample(carmel_hip_forests* f, uint64_t forest, uint32_t* rules, uint32_t* n);
 uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* f);
 

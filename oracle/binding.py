@@ -358,7 +358,10 @@ class OracleForests(object):
     def maximize(self, add_k=0.0, zero_zerocounts=False):
         return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
 
-    def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22):
+    def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22,
+              alphas=None):
+        al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
+        lib.orc_forests_set_alphas(_p(al), 0 if al is None else len(al))
         ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)
         samp = np.zeros(max_samples, np.uint32)
         off = np.zeros(self.n_forests + 1, np.uint64)

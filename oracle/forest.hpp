@@ -337,7 +337,9 @@ struct ForestGibbs {
   std::vector<std::vector<unsigned> > sample;
   double time = 0;
 
-  ForestGibbs(ForestEm& fe, const GibbsOpts& g, double alpha) : fe(fe), gopt(g), alpha(alpha) {
+  // alphas: --alpha=FILE, indexed by rule id; negative = locked (forest-em.hpp:681-709); rules beyond it use `alpha`
+  ForestGibbs(ForestEm& fe, const GibbsOpts& g, double alpha, const std::vector<double>& alphas = std::vector<double>())
+      : fe(fe), gopt(g), alpha(alpha) {
     fe.normalize_groups(fe.w);  // define_gibbs(true): normalize() first
     gps.assign(fe.w.size(), GibbsParam());
     for (size_t r = 0; r < gps.size(); ++r) {  // rules outside every group keep their weight (fixed probability)
@@ -346,9 +348,11 @@ struct ForestGibbs {
     }
     for (size_t gi = 0; gi < fe.groups.size(); ++gi)
       for (unsigned r : fe.groups[gi]) {
+        const double a = r < alphas.size() ? alphas[r] : alpha;
+        if (a < 0) continue;  // locked: stays a fixed-probability parameter (forest-em.hpp:704-706)
         gps[r].norm = (unsigned)gi;
         double p = fe.w[r].getReal(), N = (double)fe.groups[gi].size();
-        gps[r].prior = gopt.uniformp0 ? alpha : alpha * p * N;  // gibbs.hpp:589-592
+        gps[r].prior = gopt.uniformp0 ? a : a * p * N;  // gibbs.hpp:589-592
       }
     sample.assign(fe.forests.size(), {});
   }

@@ -752,6 +752,8 @@ double orc_forests_maximize(orc_forests* h, double add_k, int zero_zero) {
   h->fe.zero_zerocounts = zero_zero != 0;
   return h->fe.maximize().getReal();
 }
+static std::vector<double> g_forest_alphas;  // --alpha=FILE for the next orc_forests_gibbs (empty: scalar alpha)
+void orc_forests_set_alphas(const double* a, uint32_t n) { g_forest_alphas.assign(a, a + (a ? n : 0)); }
 int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int uniform_p0, int final_counts, double alpha,
                       orc_uniform_fn u, double* iter_logprob, double* iter_cheap_logprob, uint32_t* out_samples,
                       uint64_t* out_sample_off, uint64_t max_samples) {
@@ -762,7 +764,7 @@ int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int unifor
     go.uniformp0 = uniform_p0 != 0;
     go.final_counts = final_counts != 0;
     if (go.final_counts) go.burnin = go.iter;
-    ForestGibbs g(h->fe, go, alpha);
+    ForestGibbs g(h->fe, go, alpha, g_forest_alphas);
     GibbsTrace tr;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     for (uint32_t i = 0; i <= iter; ++i) {
