@@ -62,6 +62,7 @@ struct ForestArgs {
   uint32_t* ghash;               // FOREST_GHASH slots per forest: own-sample table of lanes that overflow LDS (may be null)
   unsigned long long* trace;     // experiment (CARMEL_HIP_FOREST_TRACE): per block {start, after table, after inside, after walk, end}
   uint64_t seed;
+  double power;                  // 1 / temperature of this sweep (annealing)
   uint32_t iter, first_group, serial_forest;  // serial_forest: exact mode processes exactly this forest (lane slot)
   int counterfactual;
 };
@@ -318,7 +319,10 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
     FSTACK_PUSH(n - 1)
     while (sp) {
       --sp;
-      const uint32_t node = sp < stack_lds ? stk_sh[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
+      // bit 31 of a stack entry: the node was reached through a back-reference, below which the reference chooses at
+      // temperature 1 (forest.hpp:731-732 drops `power`)
+      const uint32_t entry = sp < stack_lds ? stk_sh[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
+      const uint32_t node = entry & F_IDX, cold = entry & 0x80000000u;
       const uint32_t h = hp[(size_t)node * 64];
       const uint2 hr = st[(size_t)h * 64];
       // children occupy records h+1 .. h+nch; the count rides in the header (no dependent scan of the records)
@@ -333,18 +337,23 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
       if (hr.x & F_AND) {
         if (ns < max_sample) outr[ns] = hr.y;
         ++ns;
-        for (uint32_t k = nch; k-- > 0;) FSTACK_PUSH(st[(size_t)(h + 1 + k) * 64].x & F_IDX)
+        for (uint32_t k = nch; k-- > 0;) {
+          const uint2 cr = st[(size_t)(h + 1 + k) * 64];
+          FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y << 31))
+        }
       } else {
+        const double power = cold ? 1.0 : A.power;
         double norm = F_NEG_INF;
-        for (uint32_t k = 0; k < nch; ++k) norm = f_lwadd(norm, ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64]);
+        for (uint32_t k = 0; k < nch; ++k) norm = f_lwadd(norm, ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] * power);
         double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
         uint32_t pick = 0;
         for (uint32_t k = 0;; ++k) {
           pick = k;
-          choice -= exp(ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] - norm);
+          choice -= exp(ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64] * power - norm);
           if (choice < 0 || k + 1 == nch) break;
         }
-        FSTACK_PUSH(st[(size_t)(h + 1 + pick) * 64].x & F_IDX)
+        const uint2 cr = st[(size_t)(h + 1 + pick) * 64];
+        FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y << 31))
       }
     }
 #undef FSTACK_PUSH
@@ -523,10 +532,13 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       while (ref[b + c] >= 0) c = (uint32_t)ref[b + c];
       return pi[c];
     };
-    std::vector<std::vector<uint32_t> > kids(fl.n);
+    std::vector<std::vector<uint32_t> > kids(fl.n), kid_ref(fl.n);  // kid_ref: 1 = reached through a back-reference
     for (uint32_t k = 0; k < fl.n; ++k) {
       uint32_t i = idx[k];
-      for (uint32_t c = i + 1; c < next[b + i]; c = next[b + c]) kids[k].push_back(resolve(c));
+      for (uint32_t c = i + 1; c < next[b + i]; c = next[b + c]) {
+        kids[k].push_back(resolve(c));
+        kid_ref[k].push_back(ref[b + c] >= 0 ? 1u : 0u);
+      }
     }
     fl.hdr.resize(fl.n);
     for (uint32_t k = 0; k < fl.n; ++k) {
@@ -538,7 +550,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
                     ((uint32_t)std::min<size_t>(kids[k].size(), 255) << 20) | (k & 0xfffffu);
       fl.ins.push_back(uint2_t{hx, label[b + i]});
       for (size_t c = 0; c < kids[k].size(); ++c)
-        fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], 0u});
+        fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], kid_ref[k][c]});
     }
     for (uint32_t k = fl.n; k-- > 0;) {
       uint32_t i = idx[k];
@@ -887,6 +899,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     A.iter = iter;
+    A.power = gibbs_anneal_power(o->high_temp, o->low_temp, Ni, iter);
     HIPCHK(hipMemsetAsync(F->iter_out.p, 0, 2 * sizeof(double), s));
     double cache_lp = 0.0, cheap_lp = 0.0;
     if (o->mode == 1) {

@@ -290,6 +290,9 @@ double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, ui
   return gibbs_uniform(seed, iter, block, step);
 }
 
+double carmel_hip_gibbs_power(double high_temp, double low_temp, uint32_t iter, uint32_t sweep) {
+  return gibbs_anneal_power(high_temp, low_temp, iter, sweep);
+}
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* o) {
   if (!out || !t || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
@@ -462,10 +465,10 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.iter_out = g->iter_out.p;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
-  G.power = 1.0;  // constant temperature 1 (gibbs_opts.hpp:246); annealing is not offered
   const uint32_t Ni = g->opt.iter, burnin = std::min(g->opt.burnin, g->opt.iter);
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     G.iter = iter;
+    G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 2 * sizeof(double), s));
     if (g->opt.mode == 0) {

@@ -56,6 +56,7 @@ struct Options {
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
   long crp_iters = -1, burnin = 0;
+  double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (carmel.cc:289-290)
   unsigned long long seed = 1;
   std::vector<const char*> files;
 };
@@ -84,6 +85,10 @@ static Options parse_args(int argc, char** argv) {
         if (!v.empty() && std::atol(v.c_str()) > 1) o.crp_iters = std::atol(v.c_str());
       } else if (k == "burnin")
         o.burnin = std::atol(v.c_str());
+      else if (k == "high-temp")
+        o.high_temp = std::atof(v.c_str());
+      else if (k == "low-temp")
+        o.low_temp = std::atof(v.c_str());
       else if (k == "uniform-p0")
         o.uniform_p0 = true;
       else if (k == "dirichlet-p0")
@@ -283,6 +288,8 @@ static int run(int argc, char** argv) {
     go.final_counts = o.final_counts;
     go.exclude_prior = o.exclude_prior;
     go.min_prior = 1e-2;
+    go.high_temp = o.high_temp;
+    go.low_temp = o.low_temp;
     for (size_t i = 0; i < nw; ++i)
       if (addc[i] <= 0)
         std::cerr << "Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01\n";

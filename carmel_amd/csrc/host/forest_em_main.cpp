@@ -31,6 +31,7 @@ struct Opts {
   double prior_counts = 0, add_k = 0;
   bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
   long crp = 0, burnin = 0;
+  double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
   double alpha = 0.1;             // --const-alpha (gibbs_opts.hpp:93)
   std::string alpha_file = "-0";  // --alpha: per-parameter alphas parallel to the weights, negative = locked (:98-99)
   bool final_counts = false, uniform_p0 = false, parallel = false;
@@ -41,7 +42,7 @@ struct Opts {
 void usage() {
   std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
-               "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --final-counts --uniform-p0 --crp-parallel]\n"
+               "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -111,6 +112,8 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "const-alpha") o.alpha = std::atof(value(val).c_str());
     else if (key == "alpha") o.alpha_file = value(val);
     else if (key == "burnin") o.burnin = std::atol(value(val).c_str());
+    else if (key == "high-temp") o.high_temp = std::atof(value(val).c_str());
+    else if (key == "low-temp") o.low_temp = std::atof(value(val).c_str());
     else if (key == "final-counts") o.final_counts = true;
     else if (key == "uniform-p0") o.uniform_p0 = true;
     else if (key == "crp-parallel") o.parallel = true;
@@ -179,6 +182,8 @@ int main(int argc, char** argv) {
       go.mode = o.parallel ? 1 : 0;
       go.uniform_p0 = o.uniform_p0;
       go.final_counts = o.final_counts;
+      go.high_temp = o.high_temp;
+      go.low_temp = o.low_temp;
       if (o.alpha_file != "-0") {
         // "(a1 a2 ...)" indexed by rule id like forest-em.hpp:689-692 (alphas[i] for parameter i; entry 0 is the unused rule 0)
         const std::string txt = slurp(o.alpha_file);

@@ -22,3 +22,20 @@ CARMEL_HD inline double gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t blo
   h = gibbs_mix64(h ^ (uint64_t)step);
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
+
+// Annealing (gibbs_opts.hpp:206-211, gibbs.hpp:838-839): sweep t of n chooses with probabilities raised to 1/T(t),
+// T = graehl::clamped_time_series(high, low, n, curvature = linear = -1e8) (time_series.hpp:90-141): an exponential
+// between the two temperatures measured from an origin 1e8 * low below zero, i.e. a straight line to ~1e-8.
+inline double gibbs_anneal_power(double high, double low, uint32_t n_sweeps, uint32_t sweep) {
+  if (high == 0) high = 1;  // unset fields of a zeroed options struct
+  if (low == 0) low = 1;
+  double temp;
+  if (n_sweeps == 0 || high == low)
+    temp = high;
+  else {
+    const double x_origin = low * -100000000.0, x0 = high - x_origin, k = (low - x_origin) / x0;
+    const double t = (double)sweep, t_max = (double)n_sweeps;
+    temp = t <= 0 ? x0 + x_origin : t >= t_max ? x0 * k + x_origin : x0 * __builtin_pow(k, t / t_max) + x_origin;
+  }
+  return temp > 0 ? 1. / temp : 1.;
+}

@@ -64,11 +64,13 @@ class HipForests(object):
         lw = np.ascontiguousarray(lw, dtype=np.float64)
         check(lib.carmel_hip_forests_set_weights(self.h, ptr(lw)), "carmel_hip_forests_set_weights")
 
-    def gibbs(self, iters, burnin=0, alpha=0.1, seed=1, mode=0, uniform_p0=False, final_counts=False, alphas=None):
-        """alphas: forest-em --alpha=FILE, one prior strength per rule id (negative = locked); None: the scalar alpha"""
+    def gibbs(self, iters, burnin=0, alpha=0.1, seed=1, mode=0, uniform_p0=False, final_counts=False, alphas=None,
+              high_temp=1.0, low_temp=1.0):
+        """high_temp/low_temp: annealing, choices at probabilities^(1/temperature) (--high-temp/--low-temp).
+        alphas: forest-em --alpha=FILE, one prior strength per rule id (negative = locked); None: the scalar alpha"""
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         check(lib.carmel_hip_forests_set_alphas(self.h, ptr(al), 0 if al is None else len(al)), "carmel_hip_forests_set_alphas")
-        o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01)
+        o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01, high_temp, low_temp)
         self.iter_logprob, self.iter_cheap_logprob = np.zeros(iters + 1), np.zeros(iters + 1)
         check(lib.carmel_hip_forests_gibbs(self.h, C.byref(o), alpha, ptr(self.iter_logprob),
                                            ptr(self.iter_cheap_logprob)), "carmel_hip_forests_gibbs")

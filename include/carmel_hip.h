@@ -178,6 +178,9 @@ typedef struct carmel_hip_gibbs_opts {
   int uniform_p0, dirichlet_p0, final_counts, exclude_prior; /* --uniform-p0 --dirichlet-p0 --final-counts
                                                                  --crp-exclude-prior (gibbs_opts.hpp:31-268) */
   double min_prior;   /* replaces non-positive --priors (gibbs.cc:390-397); 0 => 0.01 */
+  double high_temp, low_temp; /* --high-temp / --low-temp (gibbs_opts.hpp:50-53, 206-211): choices are made with
+                                 probabilities raised to 1/temperature, the temperature running from high_temp at
+                                 sweep 0 to low_temp at sweep `iter`; 0 => 1 (no annealing) */
 } carmel_hip_gibbs_opts;
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);
@@ -192,6 +195,9 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
 /* the uniform the sampler uses at (sweep, block, step of the walk): lets a checker replay the same choices */
 double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, uint32_t step);
+/* the exponent 1/temperature sweep `sweep` of `iter` applies to every choice (gibbs.hpp:838-839 over
+ * gibbs_opts::temperature(), gibbs_opts.hpp:206-211) */
+double carmel_hip_gibbs_power(double high_temp, double low_temp, uint32_t iter, uint32_t sweep);
 
 /* ---- forest-em: packed AND/OR derivation forests (forest-em/forest.hpp, forest-em.hpp) ----
  * Forests arrive as the reference's own node arrays: forest f owns nodes [node_off[f], node_off[f+1]) in preorder;

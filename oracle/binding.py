@@ -282,8 +282,18 @@ lib.orc_gibbs_run.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.c_uint32, C.
                               UNIFORM_FN, vp, vp, vp, vp, vp, C.c_uint64, vp]
 
 
+lib.orc_gibbs_power.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_uint32]
+lib.orc_gibbs_power.restype = C.c_double
+
+
+def gibbs_power(high_temp, low_temp, iters, sweep):
+    """1 / temperature of one sweep (gibbs.hpp:838-839)"""
+    return lib.orc_gibbs_power(high_temp, low_temp, iters, sweep)
+
+
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
-              dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22):
+              dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
+              low_temp=1.0):
     """carmel --crp on an OracleCascade; `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
     n = cascade.n_params
@@ -295,6 +305,7 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     off = np.zeros(n_pairs + 2, np.uint64)
     pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
     cb = UNIFORM_FN(uniform)
+    lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
     _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
                            int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
                            _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))
@@ -359,7 +370,8 @@ class OracleForests(object):
         return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
 
     def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22,
-              alphas=None):
+              alphas=None, high_temp=1.0, low_temp=1.0):
+        lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         lib.orc_forests_set_alphas(_p(al), 0 if al is None else len(al))
         ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)

@@ -391,7 +391,7 @@ struct ForestGibbs {
         std::vector<LW> ins(f.nodes.size());
         f.inside_rec(0, [&](unsigned r) { return LW::from_real(proposal_prob(r)); }, ins, 0);
         unsigned step = 0;
-        f.choose_random(0, ins, [&]() { return u(iter, b, step++); }, [&](unsigned r) { sample[b].push_back(r); }, 1.0);
+        f.choose_random(0, ins, [&]() { return u(iter, b, step++); }, [&](unsigned r) { sample[b].push_back(r); }, gopt.power(iter));
         LW bp = LW::one(), bc = LW::one();
         for (unsigned r : sample[b]) mul_eq(bp, LW::from_real(proposal_prob(r)));
         for (unsigned r : sample[b]) {

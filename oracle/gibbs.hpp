@@ -60,6 +60,20 @@ struct GibbsOpts {
   unsigned iter = 0;    // -M / --crp=N : number of resampling sweeps after the initial sample
   unsigned burnin = 0;  // --burnin
   bool uniformp0 = false, dirichlet_p0 = false, final_counts = false, exclude_prior = false;
+  double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
+  // gibbs_opts.hpp:206-211 + time_series.hpp:90-141: the temperature runs from high_temp at sweep 0 to low_temp at
+  // sweep `iter` along clamped_time_series(.., curvature = linear = -1e8); gibbs.hpp:838-839: power = 1/temperature
+  double power(unsigned sweep) const {
+    double temp;
+    if (iter == 0 || high_temp == low_temp)
+      temp = high_temp;
+    else {
+      const double x_origin = low_temp * -100000000.0, x0 = high_temp - x_origin, k = (low_temp - x_origin) / x0;
+      const double t = (double)sweep, t_max = (double)iter;
+      temp = t <= 0 ? x0 + x_origin : t >= t_max ? x0 * k + x_origin : x0 * std::pow(k, t / t_max) + x_origin;
+    }
+    return temp > 0 ? 1. / temp : 1.;
+  }
 };
 
 struct GibbsTrace {
@@ -247,7 +261,7 @@ struct CarmelGibbs {
         double wt = derivs[b].weight;
         addc(sample[b], -wt);
         sample[b].clear();
-        random_path(derivs[b], sample[b], [&](unsigned step) { return u(iter, b, step); }, 1.0);
+        random_path(derivs[b], sample[b], [&](unsigned step) { return u(iter, b, step); }, gopt.power(iter));
         LW bp = LW::one();
         for (unsigned pid : sample[b]) mul_eq(bp, LW::from_real(proposal_prob(pid)));
         mul_eq(p, bp);

@@ -325,6 +325,18 @@ int orc_lattice(orc_wfst* wh, orc_corpus* ch, uint64_t pair, int prune, uint32_t
 // trace rows: [iter, log2 P, log2 ppx/symbol, log2 ppx/example, new_best, ln rel-ppx-ratio, last_change, n_example]
 static double g_rate_growth = 1.0;  // carmel -o (train_opts::learning_rate_growth_factor), set before orc_train
 void orc_set_rate_growth(double g) { g_rate_growth = g < 1 ? 1 : g; }
+static double g_high_temp = 1.0, g_low_temp = 1.0;  // --high-temp / --low-temp, set before orc_gibbs / orc_forests_gibbs
+double orc_gibbs_power(double high, double low, uint32_t iter, uint32_t sweep) {
+  GibbsOpts go;
+  go.iter = iter;
+  go.high_temp = high;
+  go.low_temp = low;
+  return go.power(sweep);
+}
+void orc_set_gibbs_temps(double high, double low) {
+  g_high_temp = high;
+  g_low_temp = low;
+}
 int orc_train(orc_wfst* wh, orc_corpus* ch, int norm_group, double add_count, int weight_is_prior_count,
               double smooth_floor, double converge_arc_delta, double converge_ppx_ratio, int max_iter, int cache,
               int prune, double* trace, int max_trace, int* n_trace, double* best_ppx_ln) {
@@ -641,6 +653,8 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.iter = iter;
     go.burnin = burnin < iter ? burnin : iter;
     go.uniformp0 = uniform_p0 != 0;
+    go.high_temp = g_high_temp;
+    go.low_temp = g_low_temp;
     go.dirichlet_p0 = dirichlet_p0 != 0;
     go.final_counts = final_counts != 0;
     go.exclude_prior = exclude_prior != 0;
@@ -762,6 +776,8 @@ int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int unifor
     go.iter = iter;
     go.burnin = burnin < iter ? burnin : iter;
     go.uniformp0 = uniform_p0 != 0;
+    go.high_temp = g_high_temp;
+    go.low_temp = g_low_temp;
     go.final_counts = final_counts != 0;
     if (go.final_counts) go.burnin = go.iter;
     ForestGibbs g(h->fe, go, alpha, g_forest_alphas);

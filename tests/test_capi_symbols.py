@@ -44,3 +44,17 @@ def test_product_does_not_touch_oracle():
                 txt = open(os.path.join(d, f)).read()
                 for needle in ("import oracle", "from oracle", "oracle/", "liboracle", "orc_", "oracle."):
                     assert needle not in txt, (os.path.join(d, f), needle)
+
+
+def test_annealing_schedule(oracle):
+    """--high-temp/--low-temp: the exponent 1/temperature per sweep (host arithmetic, no GPU).  The reference's
+    "linear" schedule is clamped_time_series with curvature -1e8 (time_series.hpp:65, 90-141): within ~1e-8 of
+    the straight line from high_temp at sweep 0 to low_temp at the last sweep, clamped outside."""
+    from carmel_amd._capi import lib
+    for hi, lo, n in [(2.0, 0.5, 10), (3.0, 0.4, 7), (1.0, 1.0, 5), (0.5, 4.0, 100), (2.0, 1.0, 0)]:
+        for t in range(0, n + 3):
+            got = lib.carmel_hip_gibbs_power(hi, lo, n, t)
+            assert got == oracle.gibbs_power(hi, lo, n, t)
+            line = hi if n == 0 else hi + (lo - hi) * min(t, n) / n
+            assert abs(1.0 / got - line) < 1e-6 * line
+    assert lib.carmel_hip_gibbs_power(0.0, 0.0, 10, 3) == 1.0  # a zeroed options struct means no annealing

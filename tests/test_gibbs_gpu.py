@@ -29,7 +29,8 @@ def _setup(oracle, texts, corpus_text, norms, priors):
 
 
 @pytest.mark.parametrize("iters,burnin,kw", [(12, 0, {}), (15, 5, {}), (8, 2, dict(uniform_p0=True)),
-                                             (8, 0, dict(final_counts=True)), (8, 3, dict(exclude_prior=True))])
+                                             (8, 0, dict(final_counts=True)), (8, 3, dict(exclude_prior=True)),
+                                             (10, 2, dict(high_temp=3.0, low_temp=0.4))])
 def test_gibbs_exact_mode_reproduces_the_reference_chain(oracle, golden_dir, iters, burnin, kw):
     from carmel_amd.trainer import HipGibbs
     g = lambda n: open(os.path.join(golden_dir, n)).read()
