@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcarmel_hip.so")
+LIB_PATH = os.environ.get("CARMEL_HIP_LIB") or os.path.join(_HERE, "libcarmel_hip.so")  # override: A/B builds
 
 # every symbol include/carmel_hip.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [

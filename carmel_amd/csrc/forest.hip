@@ -198,6 +198,8 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   uint32_t* ht_g = A.ghash ? A.ghash + (size_t)forest * FOREST_GHASH : nullptr;  // stride 1
   const bool hashed_l = own_cap != 0 && own_len * 20 <= own_cap * 9;  // <= 2 keys per rule, load factor <= 0.9
   const bool hashed_g = !hashed_l && active && ht_g != nullptr && own_len * 20 <= FOREST_GHASH * 9;
+  uint32_t gcap = 64;  // slots of the global table this lane uses: the smallest power of two with load factor <= 0.9
+  while (gcap * 9 < own_len * 20) gcap <<= 1;
   const bool hashed = hashed_l || hashed_g;
 #define FH_SLOT(key, mask) ((((key) * 2654435761u) >> 7) & (mask))
 #define FH_ADD(tab, stride, mask, key_)                              \
@@ -224,8 +226,8 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
       if (nr != F_NONORM) FH_ADD(ht_l, 64, mask, nr | 0x800000u)
     }
   } else if (hashed_g) {
-    const uint32_t mask = FOREST_GHASH - 1;
-    for (uint32_t i = 0; i < FOREST_GHASH; ++i) ht_g[i] = 0xffffffffu;
+    const uint32_t mask = gcap - 1;
+    for (uint32_t i = 0; i < gcap; ++i) ht_g[i] = 0xffffffffu;
     for (uint32_t q = 0; q < own_len; ++q) {
       const uint32_t rr = own[q], nr = A.p_norm[rr];
       FH_ADD(ht_g, 1, mask, rr)
@@ -242,7 +244,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
         if ((cur >> 8) == key) return (double)(cur & 0xffu);
       }
     } else {
-      const uint32_t mask = FOREST_GHASH - 1;
+      const uint32_t mask = gcap - 1;
       for (uint32_t h = FH_SLOT(key, mask);; h = (h + 1) & mask) {
         const uint32_t cur = ht_g[h];
         if (cur == 0xffffffffu) return 0.0;
@@ -396,17 +398,47 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   }
 }
 
-// counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors)
-__global__ void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len, const uint32_t* rules,
-                                      const uint32_t* p_norm, double* x, double* normsum, uint32_t n_forests) {
-  for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_forests; f += gridDim.x * blockDim.x) {
+// counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors).
+// A popular rule is used by a large share of the forests (the rule ids of real grammars, and of config 5, are Zipf
+// distributed) and adds to one address serialise (~9 ns each: 10^5 uses of one rule = 1 ms), so a workgroup first
+// counts in two small LDS tables (slot = id mod size, claimed by the first id that arrives; an id that finds its
+// slot taken by another goes straight to global memory) and adds each claimed slot to global memory once.
+// 16 lanes per forest; a workgroup covers 64 forests.
+#define FRC_SLOTS 2048u
+__global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
+                                                              const uint32_t* rules, const uint32_t* p_norm, double* x,
+                                                              double* normsum, uint32_t n_forests) {
+  __shared__ uint32_t key[2][FRC_SLOTS];
+  __shared__ uint32_t cnt[2][FRC_SLOTS];
+  for (uint32_t i = threadIdx.x; i < 2 * FRC_SLOTS; i += 1024) {
+    (&key[0][0])[i] = 0xffffffffu;
+    (&cnt[0][0])[i] = 0u;
+  }
+  __syncthreads();
+  auto add = [&](int t, uint32_t id, double* g) {
+    const uint32_t slot = (id * 2654435761u >> 9) & (FRC_SLOTS - 1);
+    const uint32_t old = atomicCAS(&key[t][slot], 0xffffffffu, id);
+    if (old == 0xffffffffu || old == id)
+      atomicAdd(&cnt[t][slot], 1u);
+    else
+      unsafeAtomicAdd(g + id, 1.0);
+  };
+  for (uint32_t f0 = blockIdx.x * 64; f0 < n_forests; f0 += gridDim.x * 64) {
+    const uint32_t f = f0 + (threadIdx.x >> 4);
+    if (f >= n_forests) continue;
     const uint32_t* r = rules + sample_off[f];
-    for (uint32_t k = 0; k < sample_len[f]; ++k) {
-      const uint32_t nn = p_norm[r[k]];
+    const uint32_t len = sample_len[f];
+    for (uint32_t k = threadIdx.x & 15u; k < len; k += 16) {
+      const uint32_t rule = r[k], nn = p_norm[rule];
       if (nn == F_NONORM) continue;
-      unsafeAtomicAdd(x + r[k], 1.0);
-      unsafeAtomicAdd(normsum + nn, 1.0);
+      add(0, rule, x);
+      add(1, nn, normsum);
     }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < FRC_SLOTS; i += 1024) {
+    if (cnt[0][i]) unsafeAtomicAdd(x + key[0][i], (double)cnt[0][i]);
+    if (cnt[1][i]) unsafeAtomicAdd(normsum + key[1][i], (double)cnt[1][i]);
   }
 }
 __global__ void forest_commit_kernel(const double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
@@ -872,7 +904,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   A.seed = o->seed;
   A.counterfactual = 1;
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
-  if (o->mode == 1 && (uint64_t)F->max_sample * 20 > 256 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
+  const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
+  const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
+  if (o->mode == 1 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
     A.ghash = ghash.p;
   }
@@ -913,8 +947,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       for (auto& c : F->classes) {
         A.first_group = c.first;
         // LDS: the inside column + up to own_cap {rule, norm group} pairs of the previous sample per lane
-        const uint32_t stack_lds = 32;  // 8 KB: the shallow part of the traversal stack
-        uint32_t own_cap = 256;         // hash slots per lane (64 KB per wave), fewer when the inside column is large
+        uint32_t own_cap = own_cap_max;  // hash slots per lane, fewer when the inside column is large
         while (own_cap && (size_t)c.max_nodes * 512 + (size_t)own_cap * 256 + stack_lds * 256 > 156 * 1024) own_cap >>= 1;
         if (own_cap < 32) own_cap = 0;
         static const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
@@ -928,7 +961,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       cur ^= 1;
       HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 4096)), dim3(256), 0, s,
+      hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), 0, s,
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
                          F->normsum.p, (uint32_t)nf);
       hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,

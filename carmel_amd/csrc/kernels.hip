@@ -752,23 +752,23 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   const TransBucket B = T.buckets[blockIdx.x];
   // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
   // 16384 items): one dependent round trip per phase instead of one per iteration
-  double w[16];
+  double w[TRANS_K];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     w[k] = a < B.n_arcs ? T.logw[B.arc_lo + a] : 0.0;
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = w[k];
+  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = w[k];
   __syncthreads();
-  uint16_t ia[16];
+  uint16_t ia[TRANS_K];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     ia[k] = j < B.n_items ? T.b_arc[B.item_base + j] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     if (j < B.n_items) T.x[B.item_base + j] = lds[ia[k]];
   }
@@ -783,27 +783,27 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = 0.0;
+  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = 0.0;
   __syncthreads();
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
-  uint32_t src[16];
-  uint16_t pos[16];
-  double v[16];
+  uint32_t src[TRANS_K];
+  uint16_t pos[TRANS_K];
+  double v[TRANS_K];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
     src[k] = i < ni ? T.t_src[i0 + i] : 0u;
     pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = T.x[src[k]];
+  for (int k = 0; k < TRANS_K; ++k) v[k] = T.x[src[k]];
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
+  for (int k = 0; k < TRANS_K; ++k)
     if (threadIdx.x + k * 1024 < ni) lds[pos[k]] = v[k];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t q = threadIdx.x + k * 1024;
     if (q < np) T.wcache[p0 + q] = lds[q];
   }
@@ -815,19 +815,19 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
   const uint64_t i0 = T.tile_base[blockIdx.x];
   const uint32_t ni = (uint32_t)(T.tile_base[blockIdx.x + 1] - i0);
-  double v[16];
-  uint16_t pos[16];
+  double v[TRANS_K];
+  uint16_t pos[TRANS_K];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t q = threadIdx.x + k * 1024;
     v[k] = q < np ? T.post[p0 + q] : 0.0;
     pos[k] = q < ni ? T.t_pos[i0 + q] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) lds[threadIdx.x + k * 1024] = v[k];
+  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = v[k];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
+  for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
     if (i < ni) T.x[i0 + i] = lds[pos[k]];
   }
@@ -844,19 +844,19 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   if (bucket >= T.n_buckets) return;
   const TransBucket B = T.buckets[bucket];
   {
-    uint32_t src[16];
-    uint16_t rk[16];
-    double v[16];
+    uint32_t src[TRANS_K];
+    uint16_t rk[TRANS_K];
+    double v[TRANS_K];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < TRANS_K; ++k) {
       const uint32_t j = threadIdx.x + k * 1024;
       src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = T.x[src[k]];
+    for (int k = 0; k < TRANS_K; ++k) v[k] = T.x[src[k]];
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
+    for (int k = 0; k < TRANS_K; ++k)
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
   }
   __syncthreads();
