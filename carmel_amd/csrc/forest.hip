@@ -20,6 +20,7 @@
 #include <limits>
 #include <memory>
 #include <numeric>
+#include <unordered_map>
 #include "engine.hpp"
 #include "rng.hpp"
 
@@ -34,7 +35,7 @@ static const uint32_t F_IDX = 0x0fffffffu;
 struct FGroup {  // 32 bytes, one wavefront of forests
   uint64_t stream_base;
   uint32_t maxlen, n_lanes, lane_base, max_nodes;
-  uint64_t pad;
+  uint64_t node_base;  // of the group's rows in node-indexed arrays: 64 * (sum of max_nodes over the groups before it)
 };
 
 struct ForestArgs {
@@ -59,6 +60,15 @@ struct ForestArgs {
   const uint32_t* old_len;       // previous sample (counterfactual removal); may alias sample_* of the other buffer
   const uint32_t* old_rules;
   double* iter_out;
+  // parallel sweep, second formulation (forest_proposal / forest_sample / forest_recount kernels)
+  const uint32_t* rec_cls;       // per inside-stream record (AND headers): class of its rule | class of its norm group << 16,
+                                 // both dense within the forest
+  double* rec_logp;              // per inside-stream record (AND headers): ln proposal probability of the rule
+  const uint32_t* cnt_old;       // per (group, class row, lane): uses of the class in the forest's previous sample; rows
+                                 // [0, max_nodes) = rule classes, [max_nodes, 2 max_nodes) = norm-group classes
+  uint32_t* cnt_new;
+  uint32_t* sample_hdr;          // per sample entry: stream position of the AND header it came from
+  const uint32_t* lane_of_forest;
   uint32_t* ghash;               // FOREST_GHASH slots per forest: own-sample table of lanes that overflow LDS (may be null)
   unsigned long long* trace;     // experiment (CARMEL_HIP_FOREST_TRACE): per block {start, after table, after inside, after walk, end}
   uint64_t seed;
@@ -341,7 +351,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
         ++ns;
         for (uint32_t k = nch; k-- > 0;) {
           const uint2 cr = st[(size_t)(h + 1 + k) * 64];
-          FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y << 31))
+          FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y & 0x80000000u))
         }
       } else {
         const double power = cold ? 1.0 : A.power;
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
           if (choice < 0 || k + 1 == nch) break;
         }
         const uint2 cr = st[(size_t)(h + 1 + pick) * 64];
-        FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y << 31))
+        FSTACK_PUSH((cr.x & F_IDX) | cold | (cr.y & 0x80000000u))
       }
     }
 #undef FSTACK_PUSH
@@ -398,18 +408,187 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   }
 }
 
+// ---------------- parallel sweep, second formulation ----------------
+// The sweep above spends its time in chains of dependent gathers made by one lane per forest (count tables, rule ->
+// group -> counts per AND node, one node per round trip in the walk): at 1563 waves of 64 forests the chip idles.
+// Here everything that does not depend on the recursion runs with one thread per record or per sample entry:
+//   forest_proposal_kernel  one thread per inside-stream record: ln proposal probability of every AND header
+//                           ((count - own uses) / (group sum - own uses), gibbs.hpp:589-592 with the block's own
+//                           sample taken out).  "Own uses" are kept per CLASS of equal rules / equal norm groups within
+//                           the forest (rec_cls, static), so the lookup is an index, not a search.
+//   forest_sample_kernel    one lane per forest: inside pass as a pure stream (record + its ln p, prefetched in
+//                           chunks), top-down walk with one round trip per visited node (a child record carries the
+//                           position of the child's header; header and first children are fetched together).
+//   forest_recount_kernel   one thread per sample entry: counts, class counts of the new sample, proposal probability
+//                           of the sample.
+__global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
+  const FGroup g = A.groups[blockIdx.y];
+  const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  if (k >= g.maxlen || lane >= g.n_lanes) return;
+  const size_t pos = g.stream_base + (size_t)k * 64 + lane;
+  const uint2 r = A.ins_stream[pos];
+  if ((r.x & (F_VALID | F_HEADER | F_AND)) != (F_VALID | F_HEADER | F_AND)) return;
+  const uint32_t rule = r.y, nn = A.p_norm[rule];
+  double pr;
+  if (nn == F_NONORM)
+    pr = A.p_prior[rule];
+  else {
+    const uint32_t c = A.rec_cls[pos];
+    const uint32_t* cnt = A.cnt_old + 2 * g.node_base + lane;
+    const double x = A.snap_x[rule] - (double)cnt[(size_t)(c & 0xffffu) * 64];
+    const double ns = A.snap_norm[nn] - (double)cnt[(size_t)(g.max_nodes + (c >> 16)) * 64];
+    pr = x / ns;
+  }
+  A.rec_logp[pos] = log(pr);
+}
+
+#define FS_CHUNK 4
+__global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
+                                                            uint32_t stack_lds) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
+  const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
+  double* ins = lds + lane;
+  const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+  const double* __restrict__ lp = A.rec_logp + g.stream_base + lane;
+  const uint32_t last = g.maxlen - 1;
+  unsigned long long tr0 = A.trace ? __builtin_readcyclecounter() : 0, tr2 = 0, tr3 = 0;
+  // inside with the proposal probabilities (forest.hpp:768-816)
+  {
+    uint32_t d = 0;
+    bool is_and = false;
+    double acc = 0.0, sum = F_NEG_INF;
+    for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FS_CHUNK) {
+      uint2 r[FS_CHUNK];
+      double p[FS_CHUNK];
+#pragma unroll
+      for (int j = 0; j < FS_CHUNK; ++j) {
+        const uint32_t k = min(k0 + j, last);
+        r[j] = st[(size_t)k * 64];
+        p[j] = lp[(size_t)k * 64];
+      }
+#pragma unroll
+      for (int j = 0; j < FS_CHUNK; ++j) {
+        if (k0 + j > last || !active || !(r[j].x & F_VALID)) continue;
+        if (r[j].x & F_HEADER) {
+          is_and = (r[j].x & F_AND) != 0;
+          acc = p[j];
+          sum = F_NEG_INF;
+        } else {
+          const double v = ins[(size_t)(r[j].x & F_IDX) * 64];
+          if (is_and)
+            acc += v;
+          else
+            sum = f_lwadd(sum, v);  // the reference's pairwise OR fold (forest.hpp:790-797)
+        }
+        if (r[j].x & F_LAST) {
+          ins[(size_t)d * 64] = is_and ? acc : sum;
+          ++d;
+        }
+      }
+    }
+  }
+  if (A.trace) tr2 = __builtin_readcyclecounter();
+  // top-down choice (forest.hpp:725-758); stack entries: header position | bit 31 = below a back-reference
+  if (active) {
+    uint32_t* outr = A.sample_rules + A.sample_off[forest];
+    uint32_t* outh = A.sample_hdr + A.sample_off[forest];
+    const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
+    uint32_t* stack = outr + cap;  // deep part of the stack: stack[-1 - i]
+    uint32_t* stk_sh = (uint32_t*)(lds + (size_t)ins_rows * 64) + lane;
+#define FSTACK_PUSH(v)                                       \
+  {                                                          \
+    if (sp < stack_lds)                                      \
+      stk_sh[(size_t)sp * 64] = (v);                         \
+    else                                                     \
+      stack[-(int)(sp - stack_lds) - 1] = (v);               \
+    ++sp;                                                    \
+  }
+    uint32_t sp = 0, ns = 0, step = 0;
+    FSTACK_PUSH(A.hdr_pos[g.stream_base + (size_t)(n - 1) * 64 + lane])
+    while (sp) {
+      --sp;
+      const uint32_t entry = sp < stack_lds ? stk_sh[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
+      const uint32_t h = entry & 0x7fffffffu, cold = entry & 0x80000000u;
+      const uint2 hr = st[(size_t)h * 64];
+      uint2 c[4];  // the first children ride along with the header: one round trip per node
+#pragma unroll
+      for (int j = 0; j < 4; ++j) c[j] = st[(size_t)min(h + 1 + j, last) * 64];
+      uint32_t nch = (hr.x >> 20) & 0xffu;
+      if (nch == 255u) {
+        nch = 0;
+        for (uint32_t k = h + 1;; ++k) {
+          ++nch;
+          if (st[(size_t)k * 64].x & F_LAST) break;
+        }
+      }
+      if (hr.x & F_AND) {
+        if (ns < max_sample) {
+          outr[ns] = hr.y;
+          outh[ns] = h;
+        }
+        ++ns;
+        for (uint32_t k = nch; k-- > 0;) {
+          const uint2 cr = k < 4 ? (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + k) * 64];
+          FSTACK_PUSH(cr.y | cold)
+        }
+      } else {
+        const double power = cold ? 1.0 : A.power;
+        // at temperature 1 the normaliser is the node's own inside value: the same fold over the same children
+        double norm = ins[(size_t)(hr.x & 0xfffffu) * 64];
+        if (power != 1.0) {
+          norm = F_NEG_INF;
+          for (uint32_t k = 0; k < nch; ++k) {
+            const uint2 cr = k < 4 ? (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + k) * 64];
+            norm = f_lwadd(norm, ins[(size_t)(cr.x & F_IDX) * 64] * power);
+          }
+        }
+        double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+        uint32_t pick = 0;
+        for (uint32_t k = 0;; ++k) {
+          pick = k;
+          const uint2 cr = k < 4 ? (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + k) * 64];
+          choice -= exp(ins[(size_t)(cr.x & F_IDX) * 64] * power - norm);
+          if (choice < 0 || k + 1 == nch) break;
+        }
+        const uint2 cr = pick < 4 ? (pick == 0 ? c[0] : pick == 1 ? c[1] : pick == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + pick) * 64];
+        FSTACK_PUSH(cr.y | cold)
+      }
+    }
+#undef FSTACK_PUSH
+    A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+  }
+  if (A.trace) {
+    tr3 = __builtin_readcyclecounter();
+    unsigned long long t3 = tr3;
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_down(t3, o, 64);
+      t3 = other > t3 ? other : t3;
+    }
+    if (lane == 0) {
+      unsigned long long* o = A.trace + (size_t)(A.first_group + blockIdx.x) * 8;
+      o[0] = tr0; o[1] = tr0; o[2] = tr2; o[3] = t3; o[4] = __builtin_readcyclecounter(); o[5] = g.maxlen; o[6] = g.n_lanes;
+    }
+  }
+}
+
 // counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors).
 // A popular rule is used by a large share of the forests (the rule ids of real grammars, and of config 5, are Zipf
 // distributed) and adds to one address serialise (~9 ns each: 10^5 uses of one rule = 1 ms), so a workgroup first
 // counts in two small LDS tables (slot = id mod size, claimed by the first id that arrives; an id that finds its
 // slot taken by another goes straight to global memory) and adds each claimed slot to global memory once.
-// 16 lanes per forest; a workgroup covers 64 forests.
+// 16 lanes per forest; a workgroup covers 64 forests.  With A (second formulation of the parallel sweep) it also
+// adds up the sample's ln proposal probability and counts the uses per class for the next sweep.
 #define FRC_SLOTS 2048u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
                                                               const uint32_t* rules, const uint32_t* p_norm, double* x,
-                                                              double* normsum, uint32_t n_forests) {
+                                                              double* normsum, uint32_t n_forests, ForestArgs A, int sweep2) {
   __shared__ uint32_t key[2][FRC_SLOTS];
   __shared__ uint32_t cnt[2][FRC_SLOTS];
+  __shared__ double cheap_sh[16];
   for (uint32_t i = threadIdx.x; i < 2 * FRC_SLOTS; i += 1024) {
     (&key[0][0])[i] = 0xffffffffu;
     (&cnt[0][0])[i] = 0u;
@@ -423,22 +602,51 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     else
       unsafeAtomicAdd(g + id, 1.0);
   };
+  double cheap = 0.0;
   for (uint32_t f0 = blockIdx.x * 64; f0 < n_forests; f0 += gridDim.x * 64) {
     const uint32_t f = f0 + (threadIdx.x >> 4);
     if (f >= n_forests) continue;
-    const uint32_t* r = rules + sample_off[f];
+    const uint64_t so = sample_off[f];
+    const uint32_t* r = rules + so;
     const uint32_t len = sample_len[f];
+    uint32_t lane = 0;
+    FGroup g;
+    if (sweep2) {
+      const uint32_t slot = A.lane_of_forest[f];
+      g = A.groups[slot >> 6];
+      lane = slot & 63u;
+    }
     for (uint32_t k = threadIdx.x & 15u; k < len; k += 16) {
       const uint32_t rule = r[k], nn = p_norm[rule];
+      size_t pos = 0;
+      if (sweep2) {
+        pos = g.stream_base + (size_t)A.sample_hdr[so + k] * 64 + lane;
+        cheap += A.rec_logp[pos];
+      }
       if (nn == F_NONORM) continue;
       add(0, rule, x);
       add(1, nn, normsum);
+      if (sweep2) {
+        const uint32_t c = A.rec_cls[pos];
+        uint32_t* cn = A.cnt_new + 2 * g.node_base + lane;
+        atomicAdd(cn + (size_t)(c & 0xffffu) * 64, 1u);
+        atomicAdd(cn + (size_t)(g.max_nodes + (c >> 16)) * 64, 1u);
+      }
     }
+  }
+  if (sweep2) {
+    for (int o = 32; o > 0; o >>= 1) cheap += __shfl_down(cheap, o, 64);
+    if ((threadIdx.x & 63) == 0) cheap_sh[threadIdx.x >> 6] = cheap;
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < FRC_SLOTS; i += 1024) {
     if (cnt[0][i]) unsafeAtomicAdd(x + key[0][i], (double)cnt[0][i]);
     if (cnt[1][i]) unsafeAtomicAdd(normsum + key[1][i], (double)cnt[1][i]);
+  }
+  if (sweep2 && threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 16; ++i) t += cheap_sh[i];
+    unsafeAtomicAdd(A.iter_out + 1, t);
   }
 }
 __global__ void forest_commit_kernel(const double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
@@ -490,6 +698,11 @@ struct carmel_hip_forests {
   hipStream_t stream = nullptr;
   uint64_t n_forests = 0, n_groups = 0;
   uint32_t n_rules = 0, max_nodes = 0, max_sample = 0;
+  uint64_t node_total = 0, stream_total = 0;
+  static const int N_SIDE = 4;
+  hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};  // launch classes of one sweep run side by side
+  hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+  bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
   std::vector<FGroup> h_groups;
   struct Cls {
     uint32_t first, count, max_nodes;
@@ -503,6 +716,8 @@ struct carmel_hip_forests {
   DevBuf<FGroup> groups;
   DevBuf<uint2_t> ins_stream, out_stream;
   DevBuf<uint32_t> lane_forest, lane_nodes, hdr_pos, group_rule, p_norm, sample_len[2], sample_rules[2];
+  DevBuf<uint32_t> rec_cls, own_cnt[2], sample_hdr, lane_of_forest_d;
+  DevBuf<double> rec_logp;
   DevBuf<uint64_t> group_off, arc_off, slot_pos, hot_chunks, sample_off;
   DevBuf<double> rule_logw, counts, post, forest_logprob, scalars, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, new_x,
       iter_out;
@@ -582,8 +797,11 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
                     ((uint32_t)std::min<size_t>(kids[k].size(), 255) << 20) | (k & 0xfffffu);
       fl.ins.push_back(uint2_t{hx, label[b + i]});
       for (size_t c = 0; c < kids[k].size(); ++c)
-        fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], kid_ref[k][c]});
+        fl.ins.push_back(uint2_t{F_VALID | (c + 1 == kids[k].size() ? F_LAST : 0u) | kids[k][c], kid_ref[k][c] << 31});
     }
+    // second word of a child record: stream position of the child's header | bit 31 = reached through a back-reference
+    for (uint32_t k = 0; k < fl.n; ++k)
+      for (size_t c = 0; c < kids[k].size(); ++c) fl.ins[fl.hdr[k] + 1 + c].y |= fl.hdr[kids[k][c]];
     for (uint32_t k = fl.n; k-- > 0;) {
       uint32_t i = idx[k];
       bool is_and = label[b + i] != 0;
@@ -612,7 +830,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
   F->h_groups.resize(ng);
   std::vector<uint32_t> lane_forest(ng * 64, 0xffffffffu), lane_nodes(ng * 64, 0);
   F->lane_of_forest.assign(n_forests, 0);
-  uint64_t base = 0;
+  uint64_t base = 0, node_total = 0;
   for (size_t gidx = 0; gidx < ng; ++gidx) {
     FGroup& G = F->h_groups[gidx];
     std::memset(&G, 0, sizeof G);
@@ -629,8 +847,12 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       F->lane_of_forest[ord[l]] = (uint32_t)l;
     }
     F->max_nodes = std::max(F->max_nodes, G.max_nodes);
+    G.node_base = node_total;
+    node_total += (uint64_t)G.max_nodes * 64;
     base += (uint64_t)G.maxlen * 64;
   }
+  F->node_total = node_total;
+  F->stream_total = base;
   std::vector<uint2_t> si(base, uint2_t{0, 0}), so(base, uint2_t{0, 0});
   std::vector<uint32_t> hp(base, 0);
   for (size_t gidx = 0; gidx < ng; ++gidx) {
@@ -683,6 +905,31 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         return fail(CARMEL_HIP_ERR_ARG, "a rule occurs in more than one normalization group");
       F->h_norm[group_rule[j]] = (uint32_t)gi;
     }
+  // classes of equal rules / equal norm groups within a forest, per AND header record (the parallel sweep's
+  // counterfactual counts are kept per class: forest_proposal_kernel)
+  {
+    std::vector<uint32_t> rc(base, 0);
+    F->sweep2_ok = F->max_nodes <= 0xffffu;
+    std::unordered_map<uint32_t, uint32_t> rid, gid;
+    for (size_t gidx = 0; gidx < ng && F->sweep2_ok; ++gidx) {
+      const FGroup& G = F->h_groups[gidx];
+      for (uint32_t l = 0; l < G.n_lanes; ++l) {
+        const Flat& fl = flat[ord[G.lane_base + l]];
+        rid.clear();
+        gid.clear();
+        for (uint32_t k = 0; k < fl.n; ++k) {
+          const uint2_t hr = fl.ins[fl.hdr[k]];
+          if (!(hr.x & F_AND)) continue;
+          const uint32_t a = rid.emplace(hr.y, (uint32_t)rid.size()).first->second;
+          const uint32_t nn = F->h_norm[hr.y];
+          const uint32_t b2 = nn == F_NONORM ? 0u : gid.emplace(nn, (uint32_t)gid.size()).first->second;
+          rc[G.stream_base + (size_t)fl.hdr[k] * 64 + l] = a | (b2 << 16);
+        }
+      }
+    }
+    if (F->sweep2_ok) HIPCHK(F->rec_cls.upload(rc, s));
+    HIPCHK(F->lane_of_forest_d.upload(F->lane_of_forest, s));
+  }
   // samples: capacity = size of the largest derivation of the forest
   F->h_sample_off.assign(n_forests + 1, 0);
   for (uint64_t f = 0; f < n_forests; ++f) {
@@ -719,6 +966,11 @@ int carmel_hip_forests_destroy(carmel_hip_forests* F) {
     (void)hipSetDevice(F->device);
     (void)hipDeviceSynchronize();
     hipStream_t s = F->stream;
+    for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
+      if (F->side[k]) (void)hipStreamDestroy(F->side[k]);
+      if (F->ev_side[k]) (void)hipEventDestroy(F->ev_side[k]);
+    }
+    if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
     delete F;
     if (s) (void)hipStreamDestroy(s);
   }
@@ -903,10 +1155,31 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   A.p_prior = F->p_prior.p;
   A.seed = o->seed;
   A.counterfactual = 1;
+  // parallel mode, second formulation (CARMEL_HIP_FOREST_SWEEP=1 selects the first, kept as the A/B reference)
+  const bool sweep2 = o->mode == 1 && F->sweep2_ok && !(getenv("CARMEL_HIP_FOREST_SWEEP") && atoi(getenv("CARMEL_HIP_FOREST_SWEEP")) == 1);
+  if (sweep2) {
+    for (int k = 0; k < 2; ++k) {
+      HIPCHK(F->own_cnt[k].alloc(2 * F->node_total));
+      HIPCHK(hipMemsetAsync(F->own_cnt[k].p, 0, F->own_cnt[k].bytes(), s));
+    }
+    HIPCHK(F->rec_logp.alloc(F->stream_total));
+    HIPCHK(F->sample_hdr.alloc(F->h_sample_off.back()));
+    A.rec_cls = F->rec_cls.p;
+    A.rec_logp = F->rec_logp.p;
+    A.sample_hdr = F->sample_hdr.p;
+    A.lane_of_forest = F->lane_of_forest_d.p;
+    if (!F->ev_fork) {
+      HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
+      for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
+        HIPCHK(hipStreamCreateWithFlags(&F->side[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming));
+      }
+    }
+  }
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
   const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
-  if (o->mode == 1 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
+  if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
     A.ghash = ghash.p;
   }
@@ -944,13 +1217,41 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       A.old_rules = F->sample_rules[cur].p;
       A.sample_len = F->sample_len[cur ^ 1].p;
       A.sample_rules = F->sample_rules[cur ^ 1].p;
+      if (sweep2) {
+        A.cnt_old = F->own_cnt[cur].p;
+        A.cnt_new = F->own_cnt[cur ^ 1].p;
+        HIPCHK(hipMemsetAsync(F->own_cnt[cur ^ 1].p, 0, F->own_cnt[cur ^ 1].bytes(), s));
+        uint32_t maxlen = 0;
+        for (auto& G : F->h_groups) maxlen = std::max(maxlen, G.maxlen);
+        hipLaunchKernelGGL(forest_proposal_kernel, dim3((maxlen + 3) / 4, (unsigned)F->h_groups.size()), dim3(256), 0, s, A);
+        // the launch classes (by LDS need) side by side: each ends with a few slow waves, the chip is never full
+        const int n_side = (int)std::min<size_t>(carmel_hip_forests::N_SIDE, F->classes.size() - 1);
+        if (n_side) HIPCHK(hipEventRecord(F->ev_fork, s));
+        for (size_t ci = 0; ci < F->classes.size(); ++ci) {
+          const auto& c = F->classes[ci];
+          A.first_group = c.first;
+          const size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)stack_lds * 64 * 4;
+          if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)forest_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipStream_t cs = s;
+          if (ci > 0 && n_side) {
+            cs = F->side[(ci - 1) % n_side];
+            if (ci - 1 < (size_t)n_side) HIPCHK(hipStreamWaitEvent(cs, F->ev_fork, 0));
+          }
+          hipLaunchKernelGGL(forest_sample_kernel, dim3(c.count), dim3(64), lds, cs, A, F->max_sample, c.max_nodes, stack_lds);
+        }
+        for (int k = 0; k < n_side; ++k) {
+          HIPCHK(hipEventRecord(F->ev_side[k], F->side[k]));
+          HIPCHK(hipStreamWaitEvent(s, F->ev_side[k], 0));
+        }
+      } else
       for (auto& c : F->classes) {
         A.first_group = c.first;
         // LDS: the inside column + up to own_cap {rule, norm group} pairs of the previous sample per lane
         uint32_t own_cap = own_cap_max;  // hash slots per lane, fewer when the inside column is large
         while (own_cap && (size_t)c.max_nodes * 512 + (size_t)own_cap * 256 + stack_lds * 256 > 156 * 1024) own_cap >>= 1;
         if (own_cap < 32) own_cap = 0;
-        static const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
+        const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
         if (nohash) own_cap = 0;
         size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)own_cap * 64 * 4 + (size_t)stack_lds * 64 * 4;
         if (lds > 64 * 1024)
@@ -963,7 +1264,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
       hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), 0, s,
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
-                         F->normsum.p, (uint32_t)nf);
+                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0);
       hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
                          F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr);
       HIPCHK(hipGetLastError());

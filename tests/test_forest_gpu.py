@@ -135,15 +135,22 @@ def test_parallel_gibbs_sample_tables_equal_the_scan():
         return hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(0, 6000, 7)], hf.max_sample()
 
     os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
-    a, sa, ms = run()
-    os.environ["CARMEL_HIP_FOREST_NOHASH"] = "1"
+    os.environ["CARMEL_HIP_FOREST_SWEEP"] = "1"  # the first formulation of the parallel sweep (tables per lane)
     try:
+        a, sa, ms = run()
+        os.environ["CARMEL_HIP_FOREST_NOHASH"] = "1"
         b, sb, _ = run()
     finally:
         os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
+        os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
     assert ms > 116  # some derivation is too long for the LDS table: the global table is exercised too
     assert sa == sb
     np.testing.assert_allclose(a, b, rtol=1e-12)
+    # the default (second) formulation -- proposal probabilities per record from per-class use counts, streamed inside
+    # pass, one round trip per node in the walk -- is the same chain again
+    c, sc, _ = run()
+    assert sc == sa
+    np.testing.assert_allclose(c, a, rtol=1e-12)
 
 
 def test_forest_gibbs_per_parameter_alphas(oracle):
