@@ -977,6 +977,40 @@ int carmel_hip_forests_destroy(carmel_hip_forests* F) {
   return CARMEL_HIP_OK;
 }
 
+// side streams: the launch classes of one pass run side by side (each ends with a few slow waves; no class fills the
+// chip).  with_side(F, s, i) = the stream for class i after forking from s; join_side(F, s) folds them back.
+static hipError_t ensure_side(carmel_hip_forests* F) {
+  if (F->ev_fork) return hipSuccess;
+  hipError_t e = hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming);
+  for (int k = 0; k < carmel_hip_forests::N_SIDE && e == hipSuccess; ++k) {
+    e = hipStreamCreateWithFlags(&F->side[k], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming);
+  }
+  return e;
+}
+static int n_side_for(const carmel_hip_forests* F) {
+  return F->classes.size() < 2 ? 0 : (int)std::min<size_t>(carmel_hip_forests::N_SIDE, F->classes.size() - 1);
+}
+static hipError_t fork_side(carmel_hip_forests* F, hipStream_t s) {
+  if (!n_side_for(F)) return hipSuccess;
+  hipError_t e = ensure_side(F);
+  if (e == hipSuccess) e = hipEventRecord(F->ev_fork, s);
+  for (int k = 0; k < n_side_for(F) && e == hipSuccess; ++k) e = hipStreamWaitEvent(F->side[k], F->ev_fork, 0);
+  return e;
+}
+static hipStream_t class_stream(carmel_hip_forests* F, hipStream_t s, size_t ci) {
+  const int n = n_side_for(F);
+  return (ci == 0 || !n) ? s : F->side[(ci - 1) % n];
+}
+static hipError_t join_side(carmel_hip_forests* F, hipStream_t s) {
+  hipError_t e = hipSuccess;
+  for (int k = 0; k < n_side_for(F) && e == hipSuccess; ++k) {
+    e = hipEventRecord(F->ev_side[k], F->side[k]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, F->ev_side[k], 0);
+  }
+  return e;
+}
+
 static void fill_args(carmel_hip_forests* F, ForestArgs& A) {
   std::memset(&A, 0, sizeof A);
   A.groups = F->groups.p;
@@ -1007,13 +1041,16 @@ int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, doubl
   ForestArgs A;
   fill_args(F, A);
   HIPCHK(hipMemsetAsync(F->scalars.p, 0, 4 * sizeof(double), s));
-  for (auto& c : F->classes) {
+  HIPCHK(fork_side(F, s));
+  for (size_t ci = 0; ci < F->classes.size(); ++ci) {
+    const auto& c = F->classes[ci];
     A.first_group = c.first;
     size_t lds = (size_t)c.max_nodes * 64 * sizeof(double) * 2;
     if (lds > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)forest_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(forest_estimate_kernel, dim3(c.count), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(forest_estimate_kernel, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A);
   }
+  HIPCHK(join_side(F, s));
   HIPCHK(hipGetLastError());
   ReduceArgs R;
   R.arc_off = F->arc_off.p;
@@ -1168,13 +1205,6 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     A.rec_logp = F->rec_logp.p;
     A.sample_hdr = F->sample_hdr.p;
     A.lane_of_forest = F->lane_of_forest_d.p;
-    if (!F->ev_fork) {
-      HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
-      for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&F->side[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming));
-      }
-    }
   }
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
   const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
@@ -1224,26 +1254,17 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         uint32_t maxlen = 0;
         for (auto& G : F->h_groups) maxlen = std::max(maxlen, G.maxlen);
         hipLaunchKernelGGL(forest_proposal_kernel, dim3((maxlen + 3) / 4, (unsigned)F->h_groups.size()), dim3(256), 0, s, A);
-        // the launch classes (by LDS need) side by side: each ends with a few slow waves, the chip is never full
-        const int n_side = (int)std::min<size_t>(carmel_hip_forests::N_SIDE, F->classes.size() - 1);
-        if (n_side) HIPCHK(hipEventRecord(F->ev_fork, s));
+        HIPCHK(fork_side(F, s));
         for (size_t ci = 0; ci < F->classes.size(); ++ci) {
           const auto& c = F->classes[ci];
           A.first_group = c.first;
           const size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)stack_lds * 64 * 4;
           if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)forest_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          hipStream_t cs = s;
-          if (ci > 0 && n_side) {
-            cs = F->side[(ci - 1) % n_side];
-            if (ci - 1 < (size_t)n_side) HIPCHK(hipStreamWaitEvent(cs, F->ev_fork, 0));
-          }
-          hipLaunchKernelGGL(forest_sample_kernel, dim3(c.count), dim3(64), lds, cs, A, F->max_sample, c.max_nodes, stack_lds);
+          hipLaunchKernelGGL(forest_sample_kernel, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A, F->max_sample,
+                             c.max_nodes, stack_lds);
         }
-        for (int k = 0; k < n_side; ++k) {
-          HIPCHK(hipEventRecord(F->ev_side[k], F->side[k]));
-          HIPCHK(hipStreamWaitEvent(s, F->ev_side[k], 0));
-        }
+        HIPCHK(join_side(F, s));
       } else
       for (auto& c : F->classes) {
         A.first_group = c.first;
