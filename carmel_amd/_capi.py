@@ -46,7 +46,7 @@ class GibbsOpts(C.Structure):
     _fields_ = [("iter", C.c_uint32), ("burnin", C.c_uint32), ("seed", C.c_uint64), ("mode", C.c_int),
                 ("uniform_p0", C.c_int), ("dirichlet_p0", C.c_int), ("final_counts", C.c_int),
                 ("exclude_prior", C.c_int), ("min_prior", C.c_double), ("high_temp", C.c_double),
-                ("low_temp", C.c_double)]
+                ("low_temp", C.c_double), ("expectation", C.c_int)]
 
 
 def _load():

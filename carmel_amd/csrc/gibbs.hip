@@ -60,6 +60,9 @@ struct GibbsArgs {
   // scratch
   double* gw;                  // per lattice arc (bundle out_base + a): ln proposal weight
   double* beta;                // per lattice state (bundle off_base + s)
+  double* alpha;               // --expectation: forward weights, like beta
+  double* ewt;                 // --expectation: per lattice arc, its posterior in the block's current "sample"
+  int expectation;
   double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob
   uint64_t seed;
   uint32_t n_blocks, iter;
@@ -130,7 +133,17 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     // 1. take the previous sample out of the counts (gibbs.hpp:851-852)
     if (tid == 0) {
       const uint32_t n = G.sample_len[b];
-      for (uint32_t k = 0; k < n; ++k) g_addc(G, ids[k], -wt);
+      if (G.expectation) {
+        if (n) {
+          const double* ewt = G.ewt + d.out_base;
+          for (uint32_t s = 0; s < d.n_states; ++s)
+            for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) {
+              const uint32_t arc = oa[a].y;
+              for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * -wt);
+            }
+        }
+      } else
+        for (uint32_t k = 0; k < n; ++k) g_addc(G, ids[k], -wt);
     }
     __syncthreads();
   }
@@ -156,6 +169,39 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       beta[s] = acc;
     }
     __syncthreads();
+  }
+  if (!SNAP && G.expectation) {
+    // --expectation (derivations.h:381-398, gibbs.cc:367-371, gibbs.hpp:783-792): forward sweep, posterior of every
+    // lattice arc, fractional counts in for the chain of every arc (the previous ones went out in step 1)
+    double* alpha = G.alpha + d.off_base;
+    double* ewt = G.ewt + d.out_base;
+    for (uint32_t s = tid; s < d.n_states; s += NT) alpha[s] = G_NEG_INF;
+    __syncthreads();
+    if (tid == 0) {
+      alpha[G.pair_start[d.pair_base]] = 0.0;
+      for (uint32_t s = 0; s < d.n_states; ++s) {  // states are numbered by level: sources before destinations
+        const double as = alpha[s];
+        if (as == G_NEG_INF) continue;
+        for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) alpha[oa[a].x] = g_lwadd(alpha[oa[a].x], as + gw[a]);
+      }
+    }
+    __syncthreads();
+    const double prob = alpha[G.pair_final[d.pair_base]];
+    for (uint32_t s = tid; s < d.n_states; s += NT)
+      for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) ewt[a] = exp(gw[a] + alpha[s] + beta[oa[a].x] - prob);
+    __syncthreads();
+    if (tid == 0) {
+      for (uint32_t s = 0; s < d.n_states; ++s)
+        for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) {
+          const uint32_t arc = oa[a].y;
+          for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * wt);
+        }
+      G.sample_len[b] = 1;  // "has counts in"
+      red[0] += prob;
+      red[1] += prob;
+    }
+    __syncthreads();
+    return;
   }
   // 4. walk start -> goal (derivations.h:361-374; random.ipp:111-127), 5. probabilities, 6. put the new sample in
   if (tid == 0) {
@@ -278,6 +324,7 @@ struct carmel_hip_gibbs {
   DevBuf<uint32_t> out_off, level_off, pair_start, pair_final, block_bundle, chain_param, p_norm, sample_len, sample_ids,
       new_len, new_ids;
   DevBuf<uint64_t> chain_off, sample_off;
+  DevBuf<double> alpha, ewt;
   DevBuf<double> pair_logw, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, ccount, csum, snap_x, snap_norm, gw, beta,
       iter_out;
   std::vector<uint64_t> h_sample_off;
@@ -297,6 +344,10 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   if (!out || !t || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
+  if (o->expectation && o->mode != 0)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED,
+                "--expectation is the sequential online EM of the reference (mode 0); its parallel counterpart is plain EM "
+                "with --priors (carmel_hip_estimate / carmel_hip_maximize)");
   HIPCHK(hipSetDevice(t->device));
   std::unique_ptr<carmel_hip_gibbs> g(new carmel_hip_gibbs());
   g->t = t;
@@ -402,6 +453,10 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   }
   HIPCHK(g->gw.alloc(L.out_arcs.size()));
   HIPCHK(g->beta.alloc(L.out_off.size()));
+  if (o->expectation) {
+    HIPCHK(g->alpha.alloc(L.out_off.size()));
+    HIPCHK(g->ewt.alloc(L.out_arcs.size()));
+  }
   HIPCHK(g->iter_out.alloc(2));
   HIPCHK(hipStreamSynchronize(s));
   *out = g.release();
@@ -462,6 +517,9 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.new_ids = g->new_ids.p;
   G.gw = g->gw.p;
   G.beta = g->beta.p;
+  G.alpha = g->alpha.p;
+  G.ewt = g->ewt.p;
+  G.expectation = g->opt.expectation;
   G.iter_out = g->iter_out.p;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
@@ -537,6 +595,7 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
 
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n) {
   if (!g || !n || block >= g->n_blocks) return fail(CARMEL_HIP_ERR_ARG, "bad argument");
+  if (g->opt.expectation) return fail(CARMEL_HIP_ERR_UNSUPPORTED, "there is no single sample with --expectation (gibbs.cc:259-260)");
   HIPCHK(hipSetDevice(g->t->device));
   hipStream_t s = g->t->stream;
   uint32_t len = 0;

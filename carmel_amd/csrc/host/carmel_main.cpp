@@ -53,6 +53,7 @@ struct Options {
   std::string normby, priors, out_file;
   int index_threshold = 32, gpu = 0;
   // --crp (carmel.cc:255-304)
+  bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
   long crp_iters = -1, burnin = 0;
@@ -95,6 +96,8 @@ static Options parse_args(int argc, char** argv) {
         o.dirichlet_p0 = true;
       else if (k == "final-counts")
         o.final_counts = true;
+      else if (k == "expectation")
+        o.expectation = true;
       else if (k == "crp-exclude-prior")
         o.exclude_prior = true;
       else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
@@ -283,6 +286,7 @@ static int run(int argc, char** argv) {
     go.burnin = (uint32_t)o.burnin;
     go.seed = o.seed;
     go.mode = o.crp_parallel ? 1 : 0;
+    go.expectation = o.expectation;
     go.uniform_p0 = o.uniform_p0;
     go.dirichlet_p0 = o.dirichlet_p0;
     go.final_counts = o.final_counts;
@@ -303,7 +307,7 @@ static int run(int argc, char** argv) {
     double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
     for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
     for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
-      std::cerr << "Gibbs i=" << i << " " << (go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(lp[i]);
+      std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(lp[i]);
       if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-lp[i] / n_sym);
       std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-lp[i] / nblocks) << "\n";
     }

@@ -181,6 +181,9 @@ typedef struct carmel_hip_gibbs_opts {
   double high_temp, low_temp; /* --high-temp / --low-temp (gibbs_opts.hpp:50-53, 206-211): choices are made with
                                  probabilities raised to 1/temperature, the temperature running from high_temp at
                                  sweep 0 to low_temp at sweep `iter`; 0 => 1 (no annealing) */
+  int expectation;    /* --expectation (gibbs_opts.hpp:125,166; derivations.h:381-398): instead of one sampled
+                         derivation a block contributes the posterior of every lattice arc ("online EM"); mode 0
+                         only; iter_logprob is then the ln probability of all derivations */
 } carmel_hip_gibbs_opts;
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);

@@ -60,6 +60,8 @@ struct GibbsOpts {
   unsigned iter = 0;    // -M / --crp=N : number of resampling sweeps after the initial sample
   unsigned burnin = 0;  // --burnin
   bool uniformp0 = false, dirichlet_p0 = false, final_counts = false, exclude_prior = false;
+  bool expectation = false;  // --expectation (gibbs_opts.hpp:125,166): fractional counts from a full forward/backward
+                             // over the block instead of one sampled derivation ("online EM")
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
   // gibbs_opts.hpp:206-211 + time_series.hpp:90-141: the temperature runs from high_temp at sweep 0 to low_temp at
   // sweep `iter` along clamped_time_series(.., curvature = linear = -1e8); gibbs.hpp:838-839: power = 1/temperature
@@ -95,6 +97,7 @@ struct CarmelGibbs {
   std::vector<std::vector<unsigned> > chain_params;  // composed arc id -> param ids in chain order
   std::vector<Derivations> derivs;                    // cached lattices of the pairs that have a derivation
   std::vector<std::vector<unsigned> > sample;
+  std::vector<std::vector<double> > sample_wt;  // --expectation: block_delta::wt
   std::unordered_map<const Arc*, unsigned> param_of;  // member arc -> param id (the reference overwrites groupId)
   ArcTable arcs;
   double time = 0;
@@ -184,6 +187,37 @@ struct CarmelGibbs {
       }
     }
   }
+  // gibbs.hpp:783-792 with block_delta::wt (--expectation): every id carries its own fractional weight
+  void addc_weighted(const std::vector<unsigned>& b, const std::vector<double>& w, double scale) {
+    for (size_t i = 0; i < b.size(); ++i) {
+      GibbsParam& g = gps[b[i]];
+      if (g.has_norm()) {
+        normsum[g.norm] += w[i] * scale;
+        g.sum.add_delta(w[i] * scale, time);
+      }
+    }
+  }
+  // derivations.h:381-398 collect_counts_gibbs + carmel_gibbs::choose_arc(a, wt) gibbs.cc:367-371: forward/backward
+  // with the proposal weights, then (param id, posterior of the lattice arc) for every chain element of every
+  // lattice arc, states in order, each state's list order
+  LW collect_counts_gibbs(Derivations& d, std::vector<unsigned>& ids, std::vector<double>& wts) {
+    std::vector<LW> f, b;
+    auto wf = [&](const GArc& a) { return arc_weight(a); };
+    LW prob = d.compute_fb(f, b, wf);
+    for (unsigned s = 0; s < d.g.size(); ++s) {
+      const auto& arcs_ = d.g[s];
+      for (size_t k = arcs_.size(); k-- > 0;) {
+        const GArc& a = arcs_[k];
+        LW contrib = arc_weight(a) * f[a.src] * b[a.dest];
+        double wt = (contrib / prob).getReal();
+        for (unsigned pid : chain_params[a.arcid]) {
+          ids.push_back(pid);
+          wts.push_back(wt);
+        }
+      }
+    }
+    return prob;
+  }
   LW arc_weight(const GArc& a) const {  // gibbs.cc:348-359
     LW prob = LW::one();
     for (unsigned p : chain_params[a.arcid]) mul_eq(prob, LW::from_real(proposal_prob(p)));
@@ -249,6 +283,7 @@ struct CarmelGibbs {
         g.sum.clear(g.prior);
       }
     for (auto& s : sample) s.clear();
+    sample_wt.assign(sample.size(), {});
     const unsigned Ni = gopt.iter;
     for (unsigned iter = 0; iter <= Ni; ++iter) {
       time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)gopt.burnin);
@@ -259,6 +294,16 @@ struct CarmelGibbs {
         if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
       for (unsigned b = 0; b < derivs.size(); ++b) {
         double wt = derivs[b].weight;
+        if (gopt.expectation) {  // gibbs.hpp:849-871 with gopt.expectation, gibbs.cc:311-314
+          addc_weighted(sample[b], sample_wt[b], -wt);
+          sample[b].clear();
+          sample_wt[b].clear();
+          LW bprob = collect_counts_gibbs(derivs[b], sample[b], sample_wt[b]);
+          mul_eq(p, bprob);  // "sum-all-derivations" prob (gibbs.hpp:927-941)
+          mul_eq(pc, bprob);
+          addc_weighted(sample[b], sample_wt[b], wt);
+          continue;
+        }
         addc(sample[b], -wt);
         sample[b].clear();
         random_path(derivs[b], sample[b], [&](unsigned step) { return u(iter, b, step); }, gopt.power(iter));
@@ -279,7 +324,8 @@ struct CarmelGibbs {
         tr->iter_cheap_logprob.push_back(p.w);
       }
     }
-    if (tr) tr->last_sample = sample;
+    if (tr && !gopt.expectation) tr->last_sample = sample;  // (gibbs.cc:259-260: no single sample with --expectation)
+    else if (tr) tr->last_sample.assign(sample.size(), {});
     // finalize_cumulative_counts gibbs.hpp:626-638
     if (!(gopt.final_counts && !gopt.exclude_prior)) {
       double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;

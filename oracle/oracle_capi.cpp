@@ -333,6 +333,8 @@ double orc_gibbs_power(double high, double low, uint32_t iter, uint32_t sweep) {
   go.low_temp = low;
   return go.power(sweep);
 }
+static int g_expectation = 0;  // --expectation, set before orc_gibbs_run
+void orc_set_gibbs_expectation(int on) { g_expectation = on; }
 void orc_set_gibbs_temps(double high, double low) {
   g_high_temp = high;
   g_low_temp = low;
@@ -655,6 +657,7 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.uniformp0 = uniform_p0 != 0;
     go.high_temp = g_high_temp;
     go.low_temp = g_low_temp;
+    go.expectation = g_expectation != 0;
     go.dirichlet_p0 = dirichlet_p0 != 0;
     go.final_counts = final_counts != 0;
     go.exclude_prior = exclude_prior != 0;

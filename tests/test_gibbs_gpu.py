@@ -59,6 +59,30 @@ def test_gibbs_exact_mode_reproduces_the_reference_chain(oracle, golden_dir, ite
     fb.close()
 
 
+@pytest.mark.parametrize("iters,burnin", [(6, 0), (8, 3)])
+def test_expectation_mode_is_the_reference_online_em(oracle, golden_dir, iters, burnin):
+    """--expectation (derivations.h:381-398 collect_counts_gibbs, gibbs.hpp:783-792): every block puts the posterior
+    of each of its lattice arcs into the counts instead of one sampled derivation, blocks strictly in order"""
+    from carmel_amd.trainer import HipGibbs
+    from carmel_amd._capi import CarmelHipError
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=7, mode=0, expectation=True)
+    got_lp = gs.run()
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.5, 0.1], iters=iters, burnin=burnin,
+                           expectation=True)
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    assert np.all(np.diff(got_lp[:4]) > 0)  # online EM climbs from the prior
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-8, atol=1e-14)
+    with pytest.raises(CarmelHipError):
+        gs.sample(0)  # gibbs.cc:259-260: no single sample
+    gs.close()
+    with pytest.raises(CarmelHipError):
+        HipGibbs(fb, 3, mode=1, expectation=True)  # sequential by definition
+    fb.close()
+
+
 def test_gibbs_single_transducer_joint(oracle, golden_dir):
     from carmel_amd.trainer import HipGibbs
     g = lambda n: open(os.path.join(golden_dir, n)).read()
