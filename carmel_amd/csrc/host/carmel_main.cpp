@@ -46,6 +46,9 @@ struct Options {
   bool flags[256] = {false};
   bool train_cascade = false;
   long restarts = 0;         // -! (train_opts::ran_restarts)
+  // random_restart_acceptor (fst.h:999-1044; carmel.cc:1426-1430, 1741-1749); 0 = unset
+  double restart_tolerance = 0, final_restart_tolerance = 0;
+  long final_restart = 0;
   double rate_growth = 1.0;  // -o (train_opts::learning_rate_growth_factor, fst.h:1083)
   long max_iter = 500;  // train_opts default (fst.h:1080-1095); -1 == "-M" without a number
   double converge = 1e-4, converge_ppx_ratio = .999, smooth_floor = 0;
@@ -94,6 +97,12 @@ static Options parse_args(int argc, char** argv) {
         o.uniform_p0 = true;
       else if (k == "dirichlet-p0")
         o.dirichlet_p0 = true;
+      else if (k == "restart-tolerance")
+        o.restart_tolerance = std::atof(v.c_str());
+      else if (k == "final-restart-tolerance")
+        o.final_restart_tolerance = std::atof(v.c_str());
+      else if (k == "final-restart")
+        o.final_restart = std::atol(v.c_str());
       else if (k == "final-counts")
         o.final_counts = true;
       else if (k == "expectation")
@@ -431,10 +440,22 @@ static int run(int argc, char** argv) {
         if (restart_no == 0) {
           best_start = new_ppx;
           log << "Initial best start point ppx=" << base2(new_ppx) << "\n";
-        } else {  // random_restart_acceptor with its default infinite tolerance (fst.h:1021, 1030-1040)
-          log << "For restart " << restart_no << ", accepting worse random start of " << base2(new_ppx) << " compared to "
-              << base2(best_start) << " with relative ppx ratio="
-              << format_weight((new_ppx - best_start) / std::fabs(new_ppx), W_SOMETIMES_LOG) << " compared to target of inf\n";
+        } else {  // random_restart_acceptor::accept (fst.h:1017-1040)
+          const double inf = std::numeric_limits<double>::infinity();
+          const double tol = o.restart_tolerance > 0 ? std::log(o.restart_tolerance) : inf;  // ln domain
+          const double fin = o.final_restart_tolerance > 0 ? std::log(o.final_restart_tolerance) : tol;
+          const double N = o.final_restart ? (double)o.final_restart : (double)o.restarts;
+          const double lr = restart_no >= N ? fin : tol == inf ? tol : tol + (fin - tol) * ((restart_no - 1) / (N - 1));
+          const double ppr = (new_ppx - best_start) / std::fabs(new_ppx);  // weight.h:247-249
+          const bool ok = lr > ppr;
+          log << "For restart " << restart_no << ", " << (ok ? "accepting" : "rejecting") << " worse random start of "
+              << base2(new_ppx) << " compared to " << base2(best_start) << " with relative ppx ratio="
+              << format_weight(ppr, W_SOMETIMES_LOG) << " compared to target of "
+              << (lr == inf ? std::string("inf") : format_weight(lr, W_SOMETIMES_LOG)) << "\n";
+          if (!ok) {
+            log << "Random start was insufficiently promising; trying another." << std::endl;
+            break;  // to the next random restart
+          }
         }
       } else {
         ratio_ln = (new_ppx - last_ppx) / std::fabs(new_ppx);  // weight.h:247-249

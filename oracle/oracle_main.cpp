@@ -46,6 +46,12 @@ static int real_main(int argc, char** argv) {
         normby = v;
       else if (k == "priors")
         priors = v;
+      else if (k == "restart-tolerance")  // carmel.cc:1426-1430
+        topt.restart_tolerance = std::atof(v.c_str());
+      else if (k == "final-restart-tolerance")
+        topt.final_restart_tolerance = std::atof(v.c_str());
+      else if (k == "final-restart")
+        topt.final_restart = (unsigned)std::atoi(v.c_str());
       else
         std::cerr << "oracle_carmel: ignoring option --" << k << "\n";
     } else if (a.size() > 1 && a[0] == '-') {

@@ -22,6 +22,10 @@ struct TrainOpts {
   unsigned max_iter;  // (unsigned)-1 == "-M" without number? no: carmel sets -1 when -M given w/o value
   double learning_rate_growth_factor;
   unsigned ran_restarts;
+  // random_restart_acceptor (fst.h:999-1044; carmel.cc:1426-1430): 0 = unset (tolerance infinite, final = tolerance,
+  // final_restart = ran_restarts)
+  double restart_tolerance = 0, final_restart_tolerance = 0;
+  unsigned final_restart = 0;
   unsigned long long restart_seed;  // of the counter-based generator below (the reference's Boost stream is unpinned)
   bool cache_derivations;  // -? / -: (both are "cache" here; the reverse graph is always rebuilt)
   bool prune;
@@ -278,14 +282,26 @@ inline LW train(Wfst& x, Cascade& cascade, Corpus& corpus, const std::vector<Nor
       LW pp_ratio_scaled;
       if (first_time) {
         log << std::endl;
-        // random_restart_acceptor::accept (fst.h:1017-1040): restart 0 is always accepted
+        // random_restart_acceptor::accept (fst.h:1017-1040): restart 0 is always accepted and sets the yardstick
         if (restart_no == 0) {
           best_start = newPerplexity;
           log << "Initial best start point ppx=" << lw_base2(newPerplexity) << "\n";
-        } else {  // default acceptor: infinite tolerance, every start is accepted (fst.h:1021, 1030-1040)
-          log << "For restart " << restart_no << ", accepting worse random start of " << lw_base2(newPerplexity)
-              << " compared to " << lw_base2(best_start) << " with relative ppx ratio="
-              << lw_str(relative_perplexity_ratio(newPerplexity, best_start)) << " compared to target of inf\n";
+        } else {
+          // likelihood_ratio (fst.h:1017-1021): tolerance moves to final_tolerance over restarts 1..N
+          LW tol = opts.restart_tolerance > 0 ? LW::from_real(opts.restart_tolerance) : LW::inf();
+          LW fin = opts.final_restart_tolerance > 0 ? LW::from_real(opts.final_restart_tolerance) : tol;
+          const double N = opts.final_restart ? opts.final_restart : opts.ran_restarts;
+          LW lr = restart_no >= N ? fin : tol.isInfinity() ? tol : tol * (fin / tol).pow((restart_no - 1) / (N - 1));
+          LW ppr = relative_perplexity_ratio(newPerplexity, best_start);
+          const bool ok = lr > ppr;
+          log << "For restart " << restart_no << ", " << (ok ? "accepting" : "rejecting") << " worse random start of "
+              << lw_base2(newPerplexity) << " compared to " << lw_base2(best_start) << " with relative ppx ratio="
+              << lw_str(ppr) << " compared to target of " << (lr.isInfinity() ? std::string("inf") : lw_str(lr)) << "\n";
+          if (!ok) {
+            log << "Random start was insufficiently promising; trying another." << std::endl;
+            if (trace) trace->push_back(rec);
+            break;  // to the next random restart
+          }
         }
         pp_ratio_scaled = LW();
       } else {
