@@ -50,8 +50,13 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   std::vector<uint16_t> e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
   for (size_t k = 0; k < M.e_arc.size(); ++k)
     for (uint32_t j = 0; j < UNROLLED_MAX_CHAIN; ++j) e_slot[k * UNROLLED_MAX_CHAIN + j] = arc_slot[(size_t)M.e_arc[k] * UNROLLED_MAX_CHAIN + j];
-  HIPCHK(t->u_f_off.upload(M.f_off, s));
-  HIPCHK(t->u_b_off.upload(M.b_off, s));
+  {  // table offsets in rows of S entries (the kernel's per-lane arithmetic stays free of divisions)
+    std::vector<uint32_t> fr(M.f_off.size()), br(M.b_off.size());
+    for (size_t k = 0; k < fr.size(); ++k) fr[k] = M.f_off[k] / M.S;
+    for (size_t k = 0; k < br.size(); ++k) br[k] = M.b_off[k] / M.S;
+    HIPCHK(t->u_f_off.upload(fr, s));
+    HIPCHK(t->u_b_off.upload(br, s));
+  }
   HIPCHK(t->u_f_arc.upload(M.f_arc, s));
   HIPCHK(t->u_b_arc.upload(M.b_arc, s));
   HIPCHK(t->u_e_arc.upload(M.e_arc, s));
@@ -83,7 +88,8 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
   // LDS holds only accumulators and scales: several workgroups share a CU, their waves hide the table latency
-  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, (M.pair_id.size() + n_waves - 1) / n_waves);
+  const uint32_t per_wave = M.S <= 16 ? 4u : M.S <= 32 ? 2u : 1u;  // pairs side by side in one wavefront
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, (M.pair_id.size() + n_waves * per_wave - 1) / (n_waves * per_wave));
   HIPCHK(t->u_scratch.alloc(unrolled_scratch_doubles(t->u_n_wg, n_waves, M.max_len)));
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));

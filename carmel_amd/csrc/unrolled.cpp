@@ -237,9 +237,15 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
   }
   M.max_len = maxlen.load();
   M.seq_off.assign(1, 0);
+  // pairs in order of decreasing length: the pairs that share a wavefront are neighbours in this list
+  std::vector<uint32_t> by_len;
   for (uint64_t p = 0; p < n; ++p) {
     M.explored_arcs += st_expl[p];
-    if (!M.has_deriv[p]) continue;
+    if (M.has_deriv[p]) by_len.push_back((uint32_t)p);
+  }
+  std::stable_sort(by_len.begin(), by_len.end(),
+                   [&](uint32_t x, uint32_t y) { return t_off[x + 1] - t_off[x] > t_off[y + 1] - t_off[y]; });
+  for (uint32_t p : by_len) {
     M.lattice_states += st_states[p];
     M.lattice_arcs += st_arcs[p];
     M.pair_id.push_back((uint32_t)p);

@@ -37,107 +37,141 @@ __global__ void unrolled_weights_kernel(const uint32_t* __restrict__ arcs, const
   out[(size_t)k * stride] = a == 0xffffffffu ? 0.0 : exp(logw[a]);  // stride 2: the weight field of a URec
 }
 
+// WD = lanes per training pair (16, 32 or 64: the smallest that holds the S states): a wavefront sweeps 64 / WD pairs
+// side by side, each in its own group of WD lanes, so that a 28-state transducer keeps 56 of the 64 lanes busy in
+// every table read, cross-lane read and LDS add instead of 28.  The pairs of a wavefront are neighbours in a list
+// sorted by length; the forward passes start together, the backward passes start together (each pair walks its own
+// positions L-1 .. 0), and whatever differs between the pairs (symbol, table offset, scale) is a per-lane value.
+template <int WD>
+__device__ __forceinline__ double sub_sum(double v) {
+#pragma unroll
+  for (int o = WD / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int WD>
+__device__ __forceinline__ uint32_t across_max(uint32_t v) {  // max over the pairs of the wavefront
+#pragma unroll
+  for (int o = 32; o >= WD; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+  return v;
+}
+
+template <int WD>
 __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
+  constexpr uint32_t P = 64 / WD;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t S = A.S;
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t n_waves = blockDim.x >> 6;
-  double* acc = lds;                                             // n_slots accumulators, shared by the workgroup
-  double* cs = lds + A.n_slots + (size_t)wave * (A.max_len + 2);  // this wave's scales c[o]
+  const uint32_t sub = lane / WD, sl = lane % WD, base = sub * WD;
+  double* acc = lds;                                                        // n_slots accumulators, shared by the workgroup
+  double* cs = lds + A.n_slots + ((size_t)wave * P + sub) * (A.max_len + 2);  // this pair's scales c[o]
   // alpha_hat and beta_hat live in registers (lane = state); a value of another state comes by cross-lane read
   // (ds_bpermute), so LDS holds only the accumulators and many waves fit a CU -- they are what hides the L2 latency
   // of the table reads.  alpha_hat[o][lane] is parked in a scratch row (one coalesced store / load per position).
   double* rows = A.alpha_scratch + ((size_t)blockIdx.x * n_waves + wave) * (size_t)(A.max_len + 1) * 64 + lane;
   for (uint32_t k = threadIdx.x; k < A.n_slots; k += blockDim.x) acc[k] = 0.0;
   __syncthreads();
-  const bool on = lane < S;
-  const uint32_t ln = on ? lane : 0u;  // idle lanes shadow lane 0 and are masked out: the wave stays converged
-  const uint32_t total_waves = gridDim.x * n_waves;
-  for (uint64_t q = (uint64_t)blockIdx.x * n_waves + wave; q < A.n_pairs; q += total_waves) {
-    const uint64_t s0 = A.seq_off[q];
-    const uint32_t L = (uint32_t)(A.seq_off[q + 1] - s0);
+  const bool on = sl < S;
+  const uint32_t ln = on ? sl : 0u;  // idle lanes shadow state 0 and are masked out: the wave stays converged
+  const uint64_t stride = (uint64_t)gridDim.x * n_waves * P;
+  for (uint64_t q0 = ((uint64_t)blockIdx.x * n_waves + wave) * P; q0 < A.n_pairs; q0 += stride) {
+    const uint64_t q = q0 + sub;
+    const bool valid = q < A.n_pairs;
+    const uint64_t s0 = valid ? A.seq_off[q] : 0;
+    const uint32_t L = valid ? (uint32_t)(A.seq_off[q + 1] - s0) : 0u;
+    const uint32_t Lmax = across_max<WD>(L);
     const uint16_t* xs = A.seq_sym + s0;
     // ---------- forward ----------
-    double a = (lane == A.start) ? 1.0 : 0.0;
+    double a = (valid && sl == A.start) ? 1.0 : 0.0;
     for (uint32_t e = 0; e < A.n_eps; ++e) {  // *e*:*e* arcs in topological order of their sources
-      const double v = __shfl(a, A.e_src[e], 64) * A.We[e];
-      if (lane == A.e_dst[e]) a += v;
+      const double v = __shfl(a, (int)(base + A.e_src[e]), 64) * A.We[e];
+      if (sl == A.e_dst[e]) a += v;
     }
     double lnz = 0.0;
-    bool dead = false;
+    bool dead = !valid;
     {
-      const double c0 = wave_sum(a);
-      a /= c0;
-      lnz = log(c0);
-      rows[0] = a;
-      if (lane == 0) cs[0] = c0;
+      const double c0 = sub_sum<WD>(a);
+      if (valid) {
+        a /= c0;
+        lnz = log(c0);
+        rows[0] = a;
+        if (sl == 0) cs[0] = c0;
+      }
     }
-    for (uint32_t o = 0; o < L; ++o) {
-      const uint32_t x = xs[o];
-      const uint32_t off = A.f_off[x], deg = (A.f_off[x + 1] - off) / S;
+    for (uint32_t o = 0; o < Lmax; ++o) {
+      const bool act = !dead && o < L;
+      const uint32_t x = act ? xs[o] : 0u;
+      const uint32_t row0 = A.f_off[x], deg = A.f_off[x + 1] - row0;  // in rows of S entries
+      const uint32_t degmax = across_max<WD>(deg);
       double v = 0.0;
-      for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {  // loads of a batch issue together
+      for (uint32_t it0 = 0; it0 < degmax; it0 += U_BATCH) {  // loads of a batch issue together
         URec r[U_BATCH];
 #pragma unroll
-        for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[off + (it0 + j < deg ? it0 + j : it0) * S + ln];
+        for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[(size_t)(row0 + min(it0 + j, deg - 1)) * S + ln];
 #pragma unroll
         for (int j = 0; j < U_BATCH; ++j) {
-          const double as = __shfl(a, (int)(r[j].other_slot2 & 0xffu), 64);
+          const double as = __shfl(a, (int)(base + (r[j].other_slot2 & 0xffu)), 64);
           v += (it0 + j < deg) ? as * r[j].w : 0.0;
         }
       }
       if (!on) v = 0.0;
       for (uint32_t e = 0; e < A.n_eps; ++e) {
-        const double u = __shfl(v, A.e_src[e], 64) * A.We[e];
-        if (lane == A.e_dst[e]) v += u;
+        const double u = __shfl(v, (int)(base + A.e_src[e]), 64) * A.We[e];
+        if (sl == A.e_dst[e]) v += u;
       }
-      const double c = wave_sum(v);
-      if (!(c > 0.0)) {
-        dead = true;
-        break;
+      const double c = sub_sum<WD>(v);
+      if (act) {
+        if (!(c > 0.0))
+          dead = true;
+        else {
+          a = v / c;
+          lnz += log(c);
+          rows[(size_t)(o + 1) * 64] = a;
+          if (sl == 0) cs[o + 1] = c;
+        }
       }
-      a = v / c;
-      lnz += log(c);
-      rows[(size_t)(o + 1) * 64] = a;
-      if (lane == 0) cs[o + 1] = c;
     }
-    const double pfin = dead ? 0.0 : __shfl(a, (int)A.fin, 64);
+    const double pfin = __shfl(a, (int)(base + A.fin), 64);
     const double lp = (dead || !(pfin > 0.0)) ? U_NEG_INF : lnz + log(pfin);
-    if (lane == 0) A.pair_logprob[A.pair_id[q]] = lp;
-    if (lp == U_NEG_INF) continue;
+    if (valid && sl == 0) A.pair_logprob[A.pair_id[q]] = lp;
+    const bool live = valid && lp != U_NEG_INF;
+    if (!__ballot(live)) continue;
     // ---------- backward + posteriors ----------
-    const double g = A.pair_weight[q] / pfin;  // "* weight / prob" (derivations.h:445)
-    double b = (lane == A.fin) ? 1.0 : 0.0;
+    const double g = live ? A.pair_weight[q] / pfin : 0.0;  // "* weight / prob" (derivations.h:445)
+    double b = (live && sl == A.fin) ? 1.0 : 0.0;
     // *e*:*e* arcs of the last position, in reverse order (a = alpha_hat[L] is still in the registers)
     for (uint32_t e = A.n_eps; e-- > 0;) {
       const uint32_t es = A.e_src[e], ed = A.e_dst[e];
-      const double u = __shfl(b, ed, 64) * A.We[e];
-      const double p = __shfl(a, es, 64) * u * g;
-      if (lane == es) b += u;
-      if (lane == 0 && p > 0.0)
+      const double u = __shfl(b, (int)(base + ed), 64) * A.We[e];
+      const double p = __shfl(a, (int)(base + es), 64) * u * g;
+      if (sl == es) b += u;
+      if (live && sl == 0 && p > 0.0)
         for (int j = 0; j < (int)UNROLLED_MAX_CHAIN; ++j) {
-          const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
-          if (sl != UNROLLED_NO_SLOT) atomicAdd(acc + sl, p);
+          const uint32_t t = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
+          if (t != UNROLLED_NO_SLOT) atomicAdd(acc + t, p);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's scratch rows before it reads them back
-    double a_o = L ? rows[(size_t)(L - 1) * 64] : 0.0;
-    for (uint32_t o = L; o-- > 0;) {
-      const uint32_t x = xs[o];
-      const double a_next = o ? rows[(size_t)(o - 1) * 64] : 0.0;  // prefetch the next row
-      const double co = cs[o + 1];
-      const double ag = on ? a_o * (g / co) : 0.0;
+    double a_o = (live && L) ? rows[(size_t)(L - 1) * 64] : 0.0;
+    for (uint32_t oo = 0; oo < Lmax; ++oo) {
+      const bool act = live && oo < L;
+      const uint32_t o = act ? L - 1 - oo : 0u;
+      const uint32_t x = act ? xs[o] : 0u;
+      const double a_next = (act && o) ? rows[(size_t)(o - 1) * 64] : 0.0;  // prefetch the next row
+      const double co = act ? cs[o + 1] : 1.0;
+      const double ag = (on && act) ? a_o * (g / co) : 0.0;
       // one loop over the out-arcs of every source (lane = source) gives both beta_hat[o] and the posteriors: the
       // term W * beta_hat[o+1][dst] is the arc's share of beta, times alpha_hat[o][src] it is the arc's posterior
-      const uint32_t off = A.b_off[x], deg = (A.b_off[x + 1] - off) / S;
+      const uint32_t row0 = A.b_off[x], deg = A.b_off[x + 1] - row0;
+      const uint32_t degmax = across_max<WD>(deg);
       double v = 0.0;
-      for (uint32_t it0 = 0; it0 < deg; it0 += U_BATCH) {
+      for (uint32_t it0 = 0; it0 < degmax; it0 += U_BATCH) {
         URec r[U_BATCH];
 #pragma unroll
-        for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[off + (it0 + j < deg ? it0 + j : it0) * S + ln];
+        for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[(size_t)(row0 + min(it0 + j, deg - 1)) * S + ln];
 #pragma unroll
         for (int j = 0; j < U_BATCH; ++j) {
-          const double bd = __shfl(b, (int)(r[j].other_slot2 & 0xffu), 64);
+          const double bd = __shfl(b, (int)(base + (r[j].other_slot2 & 0xffu)), 64);
           const double term = (it0 + j < deg) ? bd * r[j].w : 0.0;
           v += term;
           const double p = ag * term;
@@ -149,19 +183,19 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
           }
         }
       }
-      b = on ? v / co : 0.0;
+      if (act) b = on ? v / co : 0.0;
       for (uint32_t e = A.n_eps; e-- > 0;) {
         const uint32_t es = A.e_src[e], ed = A.e_dst[e];
-        const double u = __shfl(b, ed, 64) * A.We[e];
-        const double p = __shfl(a_o, es, 64) * u * g;
-        if (lane == es) b += u;
-        if (lane == 0 && p > 0.0)
+        const double u = __shfl(b, (int)(base + ed), 64) * A.We[e];
+        const double p = __shfl(a_o, (int)(base + es), 64) * u * g;
+        if (act && sl == es) b += u;
+        if (act && sl == 0 && p > 0.0)
           for (int j = 0; j < (int)UNROLLED_MAX_CHAIN; ++j) {
-            const uint32_t sl = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
-            if (sl != UNROLLED_NO_SLOT) atomicAdd(acc + sl, p);
+            const uint32_t t = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
+            if (t != UNROLLED_NO_SLOT) atomicAdd(acc + t, p);
           }
       }
-      a_o = a_next;
+      if (act) a_o = a_next;
     }
   }
   __syncthreads();
@@ -194,14 +228,16 @@ hipError_t launch_unrolled_param_counts(double* out, const double* counts, const
   return hipGetLastError();
 }
 
+// lanes per pair / pairs per wavefront
+static inline uint32_t unrolled_wd(uint32_t S) { return S <= 16 ? 16u : S <= 32 ? 32u : 64u; }
 size_t unrolled_lds_bytes(const UnrolledArgs& A, uint32_t n_waves) {
-  return (A.n_slots + (size_t)n_waves * (A.max_len + 2)) * sizeof(double);
+  return (A.n_slots + (size_t)n_waves * (64 / unrolled_wd(A.S)) * (A.max_len + 2)) * sizeof(double);
 }
 // waves per workgroup (0: the accumulators alone do not fit)
 uint32_t unrolled_waves(uint32_t n_slots, uint32_t max_len, uint32_t S) {
-  (void)S;
+  const uint32_t P = 64 / unrolled_wd(S);
   for (uint32_t w = U_MAX_WAVES; w >= 1; --w)
-    if ((n_slots + (size_t)w * (max_len + 2)) * sizeof(double) <= 64 * 1024) return w;
+    if ((n_slots + (size_t)w * P * (max_len + 2)) * sizeof(double) <= 64 * 1024) return w;
   return 0;
 }
 // doubles of scratch for the alpha rows of n_wg workgroups
@@ -220,7 +256,11 @@ hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* c
   const uint32_t n_waves = unrolled_waves(A.n_slots, A.max_len, A.S);
   if (!n_waves) return hipErrorInvalidValue;
   const size_t lds = unrolled_lds_bytes(A, n_waves);
-  hipLaunchKernelGGL(unrolled_sweep_kernel, dim3(n_wg), dim3(64 * n_waves), lds, s, A);
+  switch (unrolled_wd(A.S)) {
+    case 16: hipLaunchKernelGGL(unrolled_sweep_kernel<16>, dim3(n_wg), dim3(64 * n_waves), lds, s, A); break;
+    case 32: hipLaunchKernelGGL(unrolled_sweep_kernel<32>, dim3(n_wg), dim3(64 * n_waves), lds, s, A); break;
+    default: hipLaunchKernelGGL(unrolled_sweep_kernel<64>, dim3(n_wg), dim3(64 * n_waves), lds, s, A); break;
+  }
   hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((A.n_slots + 255) / 256), dim3(256), 0, s, A.partial, n_wg, A.n_slots, counts);
   return hipGetLastError();
 }

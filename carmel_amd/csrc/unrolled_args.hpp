@@ -17,7 +17,7 @@ struct __attribute__((aligned(16))) URec {
 struct UnrolledArgs {
   uint32_t S, V, start, fin, n_eps, n_slots, max_len;
   uint64_t n_pairs;                // pairs with a derivation
-  const uint32_t* f_off;           // V + 1
+  const uint32_t* f_off;           // V + 1, in rows of S entries
   const URec* f_rec;               // forward table (by destination); padding entries have weight 0
   const uint32_t* b_off;
   const URec* b_rec;               // backward table (by source), with the accumulator slots
