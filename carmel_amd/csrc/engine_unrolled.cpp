@@ -1,4 +1,5 @@
 // engine_unrolled.cpp: the trainer's side of the unrolled sweep (unrolled.hpp): eligibility, upload, E-step.
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -164,7 +165,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.pair_logprob = t->pair_logprob.p;
   A.partial = t->u_partial.p;
   A.alpha_scratch = t->u_scratch.p;
-  A.debug_no_acc = getenv("CARMEL_HIP_UNROLLED_NOACC") ? 1u : 0u;
+  A.debug_no_acc = getenv("CARMEL_HIP_UNROLLED_NOACC") ? (uint32_t)std::max(1, atoi(getenv("CARMEL_HIP_UNROLLED_NOACC"))) : 0u;  // 1: no adds, 2: forward only
   HIPCHK(launch_unrolled_sweep(A, t->u_n_wg, t->counts_ptr(), s));
   return CARMEL_HIP_OK;
 }

@@ -136,6 +136,7 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
     if (valid && sl == 0) A.pair_logprob[A.pair_id[q]] = lp;
     const bool live = valid && lp != U_NEG_INF;
     if (!__ballot(live)) continue;
+    if (A.debug_no_acc & 2u) continue;  // timing experiment: forward only
     // ---------- backward + posteriors ----------
     const double g = live ? A.pair_weight[q] / pfin : 0.0;  // "* weight / prob" (derivations.h:445)
     double b = (live && sl == A.fin) ? 1.0 : 0.0;
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
           const double term = (it0 + j < deg) ? bd * r[j].w : 0.0;
           v += term;
           const double p = ag * term;
-          if (p > 0.0 && !A.debug_no_acc) {
+          if (p > 0.0 && !(A.debug_no_acc & 1u)) {
             const uint32_t t0 = r[j].slot01 & 0xffffu, t1 = r[j].slot01 >> 16, t2 = r[j].other_slot2 >> 16;
             if (t0 != UNROLLED_NO_SLOT) atomicAdd(acc + t0, p);
             if (t1 != UNROLLED_NO_SLOT) atomicAdd(acc + t1, p);
