@@ -90,7 +90,8 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
   // LDS holds only accumulators and scales: several workgroups share a CU, their waves hide the table latency
   const uint32_t per_wave = M.S <= 16 ? 4u : M.S <= 32 ? 2u : 1u;  // pairs side by side in one wavefront
-  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, (M.pair_id.size() + n_waves * per_wave - 1) / (n_waves * per_wave));
+  const int wg_per_cu = getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU") ? std::max(1, atoi(getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU"))) : 2;
+  t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * wg_per_cu, (M.pair_id.size() + n_waves * per_wave - 1) / (n_waves * per_wave));
   HIPCHK(t->u_scratch.alloc(unrolled_scratch_doubles(t->u_n_wg, n_waves, M.max_len)));
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
@@ -149,6 +150,8 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.n_eps = (uint32_t)t->u_e_arc.n;
   A.n_slots = t->u_n_slots;
   A.max_len = M.max_len;
+  A.f_deg_u = M.f_deg_u;
+  A.b_deg_u = M.b_deg_u;
   A.n_pairs = M.pair_id.size();
   A.f_off = t->u_f_off.p;
   A.f_rec = t->u_f_rec.p;

@@ -2,6 +2,7 @@
 #include "unrolled.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <atomic>
 #include <thread>
 #include <unordered_map>
@@ -79,15 +80,30 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
     if (lab[a]) by_sym[dense[lab[a]]].push_back((uint32_t)a);
   M.f_off.assign(V + 1, 0);
   M.b_off.assign(V + 1, 0);
-  std::vector<uint32_t> cnt(S);
+  std::vector<uint32_t> cnt(S), fdeg(V, 0), bdeg(V, 0);
+  uint64_t fsum = 0, bsum = 0;
+  uint32_t fmax = 0, bmax = 0;
   for (uint32_t x = 0; x < V; ++x) {
-    uint32_t fd = 0, bd = 0;
     std::fill(cnt.begin(), cnt.end(), 0u);
-    for (uint32_t a : by_sym[x]) fd = std::max(fd, ++cnt[w.dst[a]]);
+    for (uint32_t a : by_sym[x]) fdeg[x] = std::max(fdeg[x], ++cnt[w.dst[a]]);
     std::fill(cnt.begin(), cnt.end(), 0u);
-    for (uint32_t a : by_sym[x]) bd = std::max(bd, ++cnt[w.src[a]]);
-    M.f_off[x + 1] = M.f_off[x] + fd * S;
-    M.b_off[x + 1] = M.b_off[x] + bd * S;
+    for (uint32_t a : by_sym[x]) bdeg[x] = std::max(bdeg[x], ++cnt[w.src[a]]);
+    fsum += fdeg[x];
+    bsum += bdeg[x];
+    fmax = std::max(fmax, fdeg[x]);
+    bmax = std::max(bmax, bdeg[x]);
+  }
+  // slabs of one size when that costs at most 30 % more rows: the sweep's loop bounds and addresses are then the same
+  // for every symbol (scalar arithmetic; no per-lane clamping or masking of the rows)
+  if ((uint64_t)fmax * V * 10 <= fsum * 13 && (uint64_t)bmax * V * 10 <= bsum * 13 && !getenv("CARMEL_HIP_UNROLLED_RAGGED")) {
+    M.f_deg_u = fmax;
+    M.b_deg_u = bmax;
+    std::fill(fdeg.begin(), fdeg.end(), fmax);
+    std::fill(bdeg.begin(), bdeg.end(), bmax);
+  }
+  for (uint32_t x = 0; x < V; ++x) {
+    M.f_off[x + 1] = M.f_off[x] + fdeg[x] * S;
+    M.b_off[x + 1] = M.b_off[x] + bdeg[x] * S;
   }
   M.f_arc.assign(M.f_off[V], 0xffffffffu);
   M.f_src.assign(M.f_off[V], 0);

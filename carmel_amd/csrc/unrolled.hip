@@ -20,7 +20,12 @@
 namespace carmel_hip {
 
 #define U_MAX_WAVES 8
+#ifndef U_BATCH
 #define U_BATCH 9
+#endif
+#ifndef U_WAVES_PER_EU
+#define U_WAVES_PER_EU 4
+#endif
 #define U_NEG_INF (-__builtin_huge_val())
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -56,7 +61,8 @@ __device__ __forceinline__ uint32_t across_max(uint32_t v) {  // max over the pa
 }
 
 template <int WD>
-__global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(UnrolledArgs A) {
+__global__ __launch_bounds__(64 * U_MAX_WAVES) __attribute__((amdgpu_waves_per_eu(U_WAVES_PER_EU)))
+void unrolled_sweep_kernel(UnrolledArgs A) {
   constexpr uint32_t P = 64 / WD;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t S = A.S;
@@ -101,9 +107,25 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
     for (uint32_t o = 0; o < Lmax; ++o) {
       const bool act = !dead && o < L;
       const uint32_t x = act ? xs[o] : 0u;
+      double v = 0.0;
+      if (A.f_deg_u) {  // slabs of one size: scalar loop bounds, one address per position, no masks (padding rows weigh 0)
+        const uint32_t deg = A.f_deg_u;
+        const URec* __restrict__ p = A.f_rec + (size_t)x * deg * S + ln;
+        uint32_t it0 = 0;
+        for (; it0 + U_BATCH <= deg; it0 += U_BATCH) {
+          URec r[U_BATCH];
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) r[j] = p[(size_t)(it0 + j) * S];
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) v += __shfl(a, (int)(base + (r[j].other_slot2 & 0xffu)), 64) * r[j].w;
+        }
+        for (; it0 < deg; ++it0) {
+          const URec r = p[(size_t)it0 * S];
+          v += __shfl(a, (int)(base + (r.other_slot2 & 0xffu)), 64) * r.w;
+        }
+      } else {
       const uint32_t row0 = A.f_off[x], deg = A.f_off[x + 1] - row0;  // in rows of S entries
       const uint32_t degmax = across_max<WD>(deg);
-      double v = 0.0;
       for (uint32_t it0 = 0; it0 < degmax; it0 += U_BATCH) {  // loads of a batch issue together
         URec r[U_BATCH];
 #pragma unroll
@@ -113,6 +135,7 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
           const double as = __shfl(a, (int)(base + (r[j].other_slot2 & 0xffu)), 64);
           v += (it0 + j < deg) ? as * r[j].w : 0.0;
         }
+      }
       }
       if (!on) v = 0.0;
       for (uint32_t e = 0; e < A.n_eps; ++e) {
@@ -163,9 +186,38 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
       const double ag = (on && act) ? a_o * (g / co) : 0.0;
       // one loop over the out-arcs of every source (lane = source) gives both beta_hat[o] and the posteriors: the
       // term W * beta_hat[o+1][dst] is the arc's share of beta, times alpha_hat[o][src] it is the arc's posterior
+      double v = 0.0;
+      if (A.b_deg_u) {
+        const uint32_t deg = A.b_deg_u;
+        const URec* __restrict__ p = A.b_rec + (size_t)x * deg * S + ln;
+#define U_BWD_TERM(R)                                                                                       \
+  {                                                                                                         \
+    const double term = __shfl(b, (int)(base + ((R).other_slot2 & 0xffu)), 64) * (R).w;                     \
+    v += term;                                                                                              \
+    const double pp = ag * term;                                                                            \
+    if (pp > 0.0 && !(A.debug_no_acc & 1u)) {                                                               \
+      const uint32_t t0 = (R).slot01 & 0xffffu, t1 = (R).slot01 >> 16, t2 = (R).other_slot2 >> 16;          \
+      if (t0 != UNROLLED_NO_SLOT) atomicAdd(acc + t0, pp);                                                  \
+      if (t1 != UNROLLED_NO_SLOT) atomicAdd(acc + t1, pp);                                                  \
+      if (t2 != UNROLLED_NO_SLOT) atomicAdd(acc + t2, pp);                                                  \
+    }                                                                                                       \
+  }
+        uint32_t it0 = 0;
+        for (; it0 + U_BATCH <= deg; it0 += U_BATCH) {
+          URec r[U_BATCH];
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) r[j] = p[(size_t)(it0 + j) * S];
+#pragma unroll
+          for (int j = 0; j < U_BATCH; ++j) U_BWD_TERM(r[j])
+        }
+        for (; it0 < deg; ++it0) {
+          const URec r = p[(size_t)it0 * S];
+          U_BWD_TERM(r)
+        }
+#undef U_BWD_TERM
+      } else {
       const uint32_t row0 = A.b_off[x], deg = A.b_off[x + 1] - row0;
       const uint32_t degmax = across_max<WD>(deg);
-      double v = 0.0;
       for (uint32_t it0 = 0; it0 < degmax; it0 += U_BATCH) {
         URec r[U_BATCH];
 #pragma unroll
@@ -183,6 +235,7 @@ __global__ __launch_bounds__(64 * U_MAX_WAVES) void unrolled_sweep_kernel(Unroll
             if (t2 != UNROLLED_NO_SLOT) atomicAdd(acc + t2, p);
           }
         }
+      }
       }
       if (act) b = on ? v / co : 0.0;
       for (uint32_t e = A.n_eps; e-- > 0;) {

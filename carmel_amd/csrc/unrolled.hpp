@@ -32,6 +32,7 @@ struct UnrolledModel {
   std::vector<uint32_t> f_off;   // V + 1: entry offset of symbol x's slab (f_deg[x] * S entries)
   std::vector<uint32_t> f_arc;   // arc id or 0xffffffff (padding)
   std::vector<uint8_t> f_src;
+  uint32_t f_deg_u = 0, b_deg_u = 0;  // rows per slab when every symbol's slab has the same size (0: ragged)
   std::vector<uint32_t> b_off, b_arc;
   std::vector<uint8_t> b_dst;
   std::vector<uint32_t> e_arc;   // *e*:*e* arcs in topological order of their sources

@@ -16,6 +16,7 @@ struct __attribute__((aligned(16))) URec {
 
 struct UnrolledArgs {
   uint32_t S, V, start, fin, n_eps, n_slots, max_len;
+  uint32_t f_deg_u, b_deg_u;       // rows per slab when all slabs have one size (0: ragged slabs, see f_off / b_off)
   uint64_t n_pairs;                // pairs with a derivation
   const uint32_t* f_off;           // V + 1, in rows of S entries
   const URec* f_rec;               // forward table (by destination); padding entries have weight 0
