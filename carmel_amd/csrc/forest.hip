@@ -69,6 +69,8 @@ struct ForestArgs {
   uint32_t* cnt_new;
   uint32_t* sample_hdr;          // per sample entry: stream position of the AND header it came from
   const uint32_t* lane_of_forest;
+  double* gcol;                  // forests too large for LDS: the inside (/ outside) columns of a group in global memory,
+  uint64_t gcol_stride;          //   gcol + workgroup * gcol_stride (doubles)
   uint32_t* ghash;               // FOREST_GHASH slots per forest: own-sample table of lanes that overflow LDS (may be null)
   unsigned long long* trace;     // experiment (CARMEL_HIP_FOREST_TRACE): per block {start, after table, after inside, after walk, end}
   uint64_t seed;
@@ -125,14 +127,18 @@ __device__ __forceinline__ void f_inside(const ForestArgs& A, const FGroup& g, i
 }
 
 // EM E-step: inside, normalised outside, posteriors of AND nodes.  LDS: two columns per lane (inside, outside).
+// GCOL: the columns live in global memory (A.gcol) -- forests with more nodes than LDS holds, e.g. the derivation
+// lattices carmel --fem-forest exports (tens of thousands of nodes each); still one lane per forest.
+template <bool GCOL>
 __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
   const bool active = (uint32_t)lane < g.n_lanes;
   const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
-  double* ins = lds + lane;
-  double* out = lds + (size_t)g.max_nodes * 64 + lane;
+  double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds;
+  double* ins = colbase + lane;
+  double* out = colbase + (size_t)g.max_nodes * 64 + lane;
   f_inside(A, g, lane, ins);
   double lp = F_NEG_INF;
   if (active) {
@@ -180,15 +186,18 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
 
 // Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
 // snap_norm.  LDS per lane: the inside column.
+template <bool GCOL>
 __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
                                                            uint32_t own_cap, uint32_t stack_lds) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds_all;
+  double* aux = GCOL ? lds_all : lds_all + (size_t)ins_rows * 64;  // tables and stack follow the column when it is in LDS
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
   bool active = (uint32_t)lane < g.n_lanes;
   if (A.serial_forest != 0xffffffffu) active = active && (g.lane_base + lane == A.serial_forest);
   const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
-  double* ins = lds + lane;
+  double* ins = colbase + lane;
   const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
   // the lane's previous sample (counterfactual removal) is read straight from global memory; the traversal stack
   // lives at the tail of the forest's own sample buffer (recorded rules grow from the front, pending nodes from the
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
   // a lane whose sample is too long for its LDS column uses a table in global memory instead (FOREST_GHASH slots
   // per forest): the rare long derivation must not fall back to scanning -- one such lane held its wave 30x longer.
   // The two tables are handled by separate code (LDS / global address spaces), never through one generic pointer.
-  uint32_t* ht_l = (uint32_t*)(lds + (size_t)ins_rows * 64) + lane;  // stride 64
+  uint32_t* ht_l = (uint32_t*)aux + lane;  // stride 64
   uint32_t* ht_g = A.ghash ? A.ghash + (size_t)forest * FOREST_GHASH : nullptr;  // stride 1
   const bool hashed_l = own_cap != 0 && own_len * 20 <= own_cap * 9;  // <= 2 keys per rule, load factor <= 0.9
   const bool hashed_g = !hashed_l && active && ht_g != nullptr && own_len * 20 <= FOREST_GHASH * 9;
@@ -318,7 +327,7 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
     uint32_t* outr = A.sample_rules + A.sample_off[forest];
     const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
     uint32_t* stack = outr + cap;  // deep part of the stack: stack[-1 - i]
-    uint32_t* stk_sh = (uint32_t*)(lds + (size_t)ins_rows * 64) + (size_t)own_cap * 64 + lane;  // first stack_lds entries
+    uint32_t* stk_sh = (uint32_t*)aux + (size_t)own_cap * 64 + lane;  // first stack_lds entries
 #define FSTACK_PUSH(v)                                       \
   {                                                          \
     if (sp < stack_lds)                                      \
@@ -443,15 +452,18 @@ __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
 }
 
 #define FS_CHUNK 4
+template <bool GCOL>
 __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
                                                             uint32_t stack_lds) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds;
+  double* aux = GCOL ? lds : lds + (size_t)ins_rows * 64;  // the stack follows the column when it is in LDS
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
   const bool active = (uint32_t)lane < g.n_lanes;
   const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
   const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
-  double* ins = lds + lane;
+  double* ins = colbase + lane;
   const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
   const double* __restrict__ lp = A.rec_logp + g.stream_base + lane;
   const uint32_t last = g.maxlen - 1;
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
     uint32_t* outh = A.sample_hdr + A.sample_off[forest];
     const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
     uint32_t* stack = outr + cap;  // deep part of the stack: stack[-1 - i]
-    uint32_t* stk_sh = (uint32_t*)(lds + (size_t)ins_rows * 64) + lane;
+    uint32_t* stk_sh = (uint32_t*)aux + lane;
 #define FSTACK_PUSH(v)                                       \
   {                                                          \
     if (sp < stack_lds)                                      \
@@ -693,6 +705,8 @@ __global__ void forest_mstep_kernel(double* rule_logw, const double* counts, dou
 
 using namespace carmel_hip;
 
+static const size_t F_LDS_LIMIT = 150 * 1024;  // dynamic LDS a forest kernel may ask for
+
 struct carmel_hip_forests {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -717,6 +731,8 @@ struct carmel_hip_forests {
   DevBuf<uint2_t> ins_stream, out_stream;
   DevBuf<uint32_t> lane_forest, lane_nodes, hdr_pos, group_rule, p_norm, sample_len[2], sample_rules[2];
   DevBuf<uint32_t> rec_cls, own_cnt[2], sample_hdr, lane_of_forest_d;
+  DevBuf<double> gcol;               // columns of the launch classes whose forests do not fit LDS
+  std::vector<uint64_t> gcol_off;    // per class: offset into gcol (doubles), room for two columns per group
   DevBuf<double> rec_logp;
   DevBuf<uint64_t> group_off, arc_off, slot_pos, hot_chunks, sample_off;
   DevBuf<double> rule_logw, counts, post, forest_logprob, scalars, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, new_x,
@@ -878,6 +894,14 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       F->classes.push_back(carmel_hip_forests::Cls{(uint32_t)i, (uint32_t)(j - i), mx});
       i = j;
     }
+  }
+  {  // classes too large for LDS keep their columns in global memory
+    uint64_t tot = 0;
+    for (auto& c : F->classes) {
+      F->gcol_off.push_back(tot);
+      if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) tot += (uint64_t)c.count * 2 * c.max_nodes * 64;
+    }
+    if (tot) HIPCHK(F->gcol.alloc(tot));
   }
   // ---- posterior slots grouped by rule (AND headers of the outside stream) ----
   std::vector<uint64_t> cnt((size_t)n_rules + 1, 0);
@@ -1046,9 +1070,15 @@ int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, doubl
     const auto& c = F->classes[ci];
     A.first_group = c.first;
     size_t lds = (size_t)c.max_nodes * 64 * sizeof(double) * 2;
+    if (lds > F_LDS_LIMIT) {
+      A.gcol = F->gcol.p + F->gcol_off[ci];
+      A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
+      hipLaunchKernelGGL(forest_estimate_kernel<true>, dim3(c.count), dim3(64), 0, class_stream(F, s, ci), A);
+      continue;
+    }
     if (lds > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)forest_estimate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(forest_estimate_kernel, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A);
+      (void)hipFuncSetAttribute((const void*)forest_estimate_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(forest_estimate_kernel<false>, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A);
   }
   HIPCHK(join_side(F, s));
   HIPCHK(hipGetLastError());
@@ -1206,6 +1236,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     A.sample_hdr = F->sample_hdr.p;
     A.lane_of_forest = F->lane_of_forest_d.p;
   }
+  DevBuf<double> gcol_exact;  // exact mode: the inside column of one forest too large for LDS
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
   const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
@@ -1259,9 +1290,16 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           const auto& c = F->classes[ci];
           A.first_group = c.first;
           const size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)stack_lds * 64 * 4;
+          if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
+            A.gcol = F->gcol.p + F->gcol_off[ci];
+            A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
+            hipLaunchKernelGGL(forest_sample_kernel<true>, dim3(c.count), dim3(64), (size_t)stack_lds * 64 * 4,
+                               class_stream(F, s, ci), A, F->max_sample, c.max_nodes, stack_lds);
+            continue;
+          }
           if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)forest_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          hipLaunchKernelGGL(forest_sample_kernel, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A, F->max_sample,
+            (void)hipFuncSetAttribute((const void*)forest_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(forest_sample_kernel<false>, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A, F->max_sample,
                              c.max_nodes, stack_lds);
         }
         HIPCHK(join_side(F, s));
@@ -1274,10 +1312,20 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         if (own_cap < 32) own_cap = 0;
         const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
         if (nohash) own_cap = 0;
+        if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
+          own_cap = nohash ? 0 : own_cap_max;
+          A.gcol = F->gcol.p + F->gcol_off[&c - &F->classes[0]];
+          A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
+          const size_t l2 = (size_t)own_cap * 64 * 4 + (size_t)stack_lds * 64 * 4;
+          if (l2 > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+          hipLaunchKernelGGL(forest_gibbs_kernel<true>, dim3(c.count), dim3(64), l2, s, A, F->max_sample, c.max_nodes, own_cap, stack_lds);
+          continue;
+        }
         size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)own_cap * 64 * 4 + (size_t)stack_lds * 64 * 4;
         if (lds > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(c.count), dim3(64), lds, s, A, F->max_sample, c.max_nodes, own_cap, stack_lds);
+          (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(forest_gibbs_kernel<false>, dim3(c.count), dim3(64), lds, s, A, F->max_sample, c.max_nodes, own_cap, stack_lds);
       }
       HIPCHK(hipGetLastError());
       cur ^= 1;
@@ -1334,9 +1382,16 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         A.first_group = gidx;
         const FGroup& G = F->h_groups[gidx];
         size_t lds = (size_t)G.max_nodes * 64 * 8;
-        if (lds > 64 * 1024)
-          (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(forest_gibbs_kernel, dim3(1), dim3(64), lds, s, A, F->max_sample, G.max_nodes, 0u, 0u);
+        if (lds > F_LDS_LIMIT) {
+          if (!gcol_exact.n) HIPCHK(gcol_exact.alloc((size_t)F->max_nodes * 64));
+          A.gcol = gcol_exact.p;
+          A.gcol_stride = 0;
+          hipLaunchKernelGGL(forest_gibbs_kernel<true>, dim3(1), dim3(64), 0, s, A, F->max_sample, G.max_nodes, 0u, 0u);
+        } else {
+          if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)forest_gibbs_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          hipLaunchKernelGGL(forest_gibbs_kernel<false>, dim3(1), dim3(64), lds, s, A, F->max_sample, G.max_nodes, 0u, 0u);
+        }
         uint32_t len = 0;
         HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + f, sizeof len, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -22,6 +22,7 @@
 #include <sstream>
 #include "../../../include/carmel_hip.h"
 #include "compose.hpp"
+#include "fem_export.hpp"
 #include "wfst.hpp"
 
 using namespace carmel_host;
@@ -57,6 +58,7 @@ struct Options {
   int index_threshold = 32, gpu = 0;
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
+  std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
   long crp_iters = -1, burnin = 0;
@@ -97,6 +99,16 @@ static Options parse_args(int argc, char** argv) {
         o.uniform_p0 = true;
       else if (k == "dirichlet-p0")
         o.dirichlet_p0 = true;
+      else if (k == "fem-forest") {
+        o.fem_forest = v;
+        o.train_cascade = true;  // force_cascade_derivs (carmel.cc:230-233, 764-767)
+        o.flags[(unsigned)'t'] = true;
+      } else if (k == "fem-norm")
+        o.fem_norm = v;
+      else if (k == "fem-param")
+        o.fem_param = v;
+      else if (k == "fem-alpha")
+        o.fem_alpha = v;
       else if (k == "restart-tolerance")
         o.restart_tolerance = std::atof(v.c_str());
       else if (k == "final-restart-tolerance")
@@ -288,6 +300,21 @@ static int run(int argc, char** argv) {
   hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
                                   pairs.out_sym.data(), pairs.weight.data()),
             "carmel_hip_set_corpus");
+  if (!o.fem_forest.empty()) {  // cached_derivs.h:44-50, 60-100: written on the first pass over the derivations
+    carmel_host::FemExport fe;
+    fe.n_states = (uint32_t)result->states.size();
+    fe.final_state = result->final_state;
+    fe.src = &src;
+    fe.dst = &dst;
+    fe.in = &in;
+    fe.out = &out;
+    fe.group = &group;
+    fe.chains = cascade ? &chains.chains : nullptr;
+    std::ofstream of(o.fem_forest.c_str());
+    if (!of) throw std::runtime_error("could not create --fem-forest=" + o.fem_forest);
+    fe.write_forests(of, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(), pairs.out_sym.data(),
+                     pairs.weight.data());
+  }
   if (o.crp) {  // WFST::train_gibbs (gibbs.cc:386-430)
     carmel_hip_gibbs_opts go;
     std::memset(&go, 0, sizeof go);
@@ -506,6 +533,62 @@ static int run(int argc, char** argv) {
            "prod[modelprob(example)]^(-1/num_examples) = 2^(-log_2(p_model(corpus))/N) = "
         << base2(best) << std::endl;
     hip_check(carmel_hip_load_best(t), "carmel_hip_load_best");
+  }
+  // ---- forest-em side files (carmel.cc:818-831 fem_out; cascade.h:60-116, 167-178) ----
+  if (!o.fem_norm.empty() || !o.fem_alpha.empty() || !o.fem_param.empty()) {
+    std::vector<double> all_w(cascade ? params.logw.size() : logw.size());
+    hip_check(carmel_hip_get_weights(t, all_w.data()), "carmel_hip_get_weights");
+    std::vector<const Transducer*> mem;
+    if (cascade)
+      for (size_t i = 0; i < nw; ++i) mem.push_back(&member[i]);
+    else
+      mem.push_back(result);
+    if (!o.fem_param.empty()) {
+      log << "Writing cascade weights to --fem-param=" << o.fem_param << std::endl;
+      std::ofstream of(o.fem_param.c_str());
+      for (double w : all_w) of << format_weight(w, W_SOMETIMES_LOG) << "\n";
+    }
+    if (!o.fem_norm.empty()) {
+      log << "Writing forest-em normgroups to --fem-norm=" << o.fem_norm << std::endl;
+      std::ofstream of(o.fem_norm.c_str());
+      of << "(";
+      uint64_t id0 = 1;
+      for (size_t i = 0; i < mem.size(); ++i) {
+        of << "\n";
+        const Transducer& m = *mem[i];
+        for (uint32_t s = 0; s < m.states.size(); ++s) {
+          const auto& arcs = m.states[s];
+          if (norms[i] == CARMEL_HIP_NORM_JOINT && !arcs.empty()) {
+            of << '(';
+            for (size_t k = 0; k < arcs.size(); ++k) of << ' ' << id0 + k;
+            of << " )\n";
+          } else if (norms[i] == CARMEL_HIP_NORM_CONDITIONAL) {
+            std::vector<char> done(arcs.size(), 0);
+            for (size_t k = 0; k < arcs.size(); ++k) {
+              if (done[k]) continue;
+              of << '(';
+              for (size_t j = k; j < arcs.size(); ++j)
+                if (arcs[j].in == arcs[k].in) {
+                  done[j] = 1;
+                  of << ' ' << id0 + j;
+                }
+              of << " )\n";
+            }
+          }
+          id0 += arcs.size();
+        }
+      }
+      of << ")\n";
+    }
+    if (!o.fem_alpha.empty()) {
+      log << "Writing forest-em alpha to --fem-alpha=" << o.fem_alpha << std::endl;
+      std::ofstream of(o.fem_alpha.c_str());
+      for (size_t i = 0; i < mem.size(); ++i) {
+        const double prior = norms[i] == CARMEL_HIP_NORM_NONE ? -1.0 : addc[i];
+        for (auto& st : mem[i]->states)
+          for (auto& a : st) of << (a.group == kLocked ? -1.0 : prior) << '\n';
+      }
+    }
   }
   // ---- output (carmel.cc:1435-1437, 1485-1496; cascade.h:23-32) ----
   int wstyle = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;

@@ -160,19 +160,25 @@ inline void read_normgroups(const std::string& s, std::vector<uint64_t>& group_o
   if (depth != 0) throw std::runtime_error("normalisation groups: unbalanced parentheses");
 }
 
-// parameter vector "(1 .5 e^-3 0)": the first weight belongs to rule 1 (forest-em.hpp:228-250)
+// parameter vector "(1 .5 e^-3 0)", or -- what carmel --fem-param writes -- the bare weights up to the end of the
+// file; an optional comma may follow a weight (graehl/shared/io.hpp:557-603 range_read).  The first weight belongs
+// to rule 1 (forest-em.hpp:228-250).
 inline std::vector<double> read_params(const std::string& s) {
   std::vector<double> logw;
   size_t p = 0;
   while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
-  if (p >= s.size() || s[p] != '(') throw std::runtime_error("expected a vector of weights, e.g. (1 .5 0)");
-  ++p;
+  if (p >= s.size()) throw std::runtime_error("expected a vector of weights, e.g. (1 .5 0)");
+  const bool parens = s[p] == '(';
+  if (parens) ++p;
   for (;;) {
-    while (p < s.size() && std::isspace((unsigned char)s[p])) ++p;
-    if (p >= s.size()) throw std::runtime_error("vector of weights: ')' expected");
-    if (s[p] == ')') break;
+    while (p < s.size() && (std::isspace((unsigned char)s[p]) || s[p] == ',')) ++p;
+    if (p >= s.size()) {
+      if (parens) throw std::runtime_error("vector of weights: ')' expected");
+      break;
+    }
+    if (parens && s[p] == ')') break;
     size_t e = p;
-    while (e < s.size() && !std::isspace((unsigned char)s[e]) && s[e] != ')') ++e;
+    while (e < s.size() && !std::isspace((unsigned char)s[e]) && s[e] != ')' && s[e] != ',') ++e;
     double lw;
     if (!parse_weight_token(s.substr(p, e - p), lw)) throw std::runtime_error("bad weight '" + s.substr(p, e - p) + "'");
     logw.push_back(lw);

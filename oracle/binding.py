@@ -291,6 +291,22 @@ def gibbs_power(high_temp, low_temp, iters, sweep):
     return lib.orc_gibbs_power(high_temp, low_temp, iters, sweep)
 
 
+lib.orc_fem_export.argtypes = [vp, vp, C.c_char_p, vp, C.c_int, C.c_char_p, C.c_ulong]
+lib.orc_fem_export.restype = C.c_long
+
+
+def fem_export(cascade, corpus, which, normby=None, priors=None):
+    """carmel --fem-forest (which=0) / --fem-norm (1) / --fem-param (2) / --fem-alpha (3) as text"""
+    pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
+    nb = (normby or "").encode() or None
+    n = lib.orc_fem_export(cascade.h, corpus.h, nb, _p(pri), which, None, 0)
+    if n < 0:
+        raise RuntimeError("orc_fem_export failed")
+    buf = C.create_string_buffer(n + 1)
+    lib.orc_fem_export(cascade.h, corpus.h, nb, _p(pri), which, buf, n + 1)
+    return buf.value.decode()
+
+
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
               low_temp=1.0, expectation=False):

@@ -5,6 +5,7 @@
 // Arc arrays are in the reference's arc-id order: state-major, each state's arcs in list order
 // (derivations.h:86-101, fst.h:1331-1334).
 #include "train.hpp"
+#include "fem.hpp"
 #include "gibbs.hpp"
 #include "forest.hpp"
 #include <pthread.h>
@@ -692,6 +693,32 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
       out_sample_off[tr.last_sample.size()] = o;
     }
   });
+}
+
+// carmel --fem-forest / --fem-norm / --fem-param / --fem-alpha (oracle/fem.hpp).  which: 0 forests, 1 norm groups,
+// 2 params, 3 alphas.  Returns the text length (the text is truncated to cap - 1 bytes), -1 on error.
+long orc_fem_export(orc_cascade* h, orc_corpus* c, const char* normby, const double* priors, int which, char* buf,
+                    unsigned long cap) {
+  long len = -1;
+  int rc = run_big_stack([&]() {
+    size_t n = h->chain.size();
+    std::vector<NormalizeMethod> nms(n);
+    for (size_t i = 0; i < n; ++i) {
+      char ch = normby && std::strlen(normby) > i ? normby[i] : 'C';
+      nms[i].group = (ch == 'J' || ch == 'j') ? NORM_JOINT : (ch == 'N' || ch == 'n') ? NORM_NONE : NORM_CONDITIONAL;
+      if (priors) nms[i].add_count = LW::from_real(priors[i]);
+    }
+    h->cascade.set_composed(h->result);
+    FemExport fe(h->cascade, *h->result);
+    std::string txt = which == 0 ? fe.forests(c->c) : which == 1 ? fe.norms(nms) : which == 2 ? fe.params() : fe.alphas(nms);
+    len = (long)txt.size();
+    if (buf && cap) {
+      size_t k = std::min<size_t>(txt.size(), cap - 1);
+      std::memcpy(buf, txt.data(), k);
+      buf[k] = 0;
+    }
+  });
+  return rc == 0 ? len : -1;
 }
 
 // ---- forest-em ----

@@ -6,6 +6,7 @@ import os
 import re
 import subprocess
 
+import numpy as np
 import pytest
 
 from conftest import ROOT
@@ -229,3 +230,44 @@ def test_cascade_unrolled_equals_explicit(golden_dir, tmp_path):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-8)
+
+
+def test_fem_export_bridges_to_forest_em(golden_dir, tmp_path, oracle):
+    """carmel --fem-forest/--fem-norm/--fem-param/--fem-alpha (cascade.h:60-178; sample/decipher/to-fem.sh): the
+    derivation lattices of the cipher cascade as forest-em forests.  The forests and alphas equal the oracle's
+    restatement of fem_deriv / fem_alpha character for character, the norm groups as sets; forest-em then reads the
+    files and its first E-step sees the corpus probability carmel's own E-step reports."""
+    g = lambda n: os.path.join(golden_dir, n)
+    F, N, P, A = (str(tmp_path / n) for n in ("forest", "norm", "param", "alpha"))
+    args = ["--train-cascade", "-HJ", "-M", "-1", "--normby=NC", "--priors=1e5,1e-2", "--fem-forest=" + F, "--fem-norm=" + N,
+            "--fem-param=" + P, "--fem-alpha=" + A, g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    rc, out, err = run(args, env=dict(os.environ, CARMEL_TRAINED_DIR=str(tmp_path)))
+    assert rc == 0, err
+    rd = lambda n: open(g(n)).read()
+    oc = oracle.OracleCascade([rd("cipher.wfsa"), rd("cipher.fst")])
+    oc.composed()
+    corp = oc.corpus(rd("cipher.data"))
+    assert open(F).read() == oracle.fem_export(oc, corp, 0, "NC", [1e5, 1e-2])
+    assert open(A).read() == oracle.fem_export(oc, corp, 3, "NC", [1e5, 1e-2])
+    groups = lambda txt: sorted(tuple(sorted(int(x) for x in grp.split())) for grp in re.findall(r"\(([\d ]+)\)", txt))
+    assert groups(open(N).read()) == groups(oracle.fem_export(oc, corp, 1, "NC", [1e5, 1e-2]))
+    w = [float(t[2:]) if t.startswith("e^") else (math.log(float(t)) if float(t) > 0 else -math.inf) for t in open(P).read().split()]
+    n_par = len(oracle.fem_export(oc, corp, 2).split())
+    assert len(w) == n_par
+    for grp in groups(open(N).read()):  # the channel is normalised per (state, input)
+        assert sum(math.exp(w[i - 1]) for i in grp) == pytest.approx(1.0, abs=1e-12)
+    # carmel's corpus probability ...
+    m = re.search(r"probability=2\^(-[\d.e+]+)", err)
+    assert m, err
+    log2p = float(m.group(1))
+    # ... is what forest-em's first E-step computes from the exported files
+    fem = os.path.join(ROOT, "carmel_amd", "bin", "forest-em")
+    p = subprocess.run([fem, "-f", F, "-n", N, "-I", P, "-i", "1", "-o", str(tmp_path / "out")], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True)
+    assert p.returncode == 0, p.stderr
+    of = oracle.OracleForests(open(F).read(), open(N).read())
+    lw = np.full(of.n_rules, 0.0)
+    lw[1:1 + len(w)] = w
+    of.set_weights(lw)
+    avg, _ = of.estimate()[:2]
+    assert avg * of.n_forests / math.log(2) == pytest.approx(log2p, rel=1e-5)

@@ -174,3 +174,58 @@ def test_forest_gibbs_per_parameter_alphas(oracle):
     hf2.set_weights(hf.weights()) if hasattr(hf2, "set_weights") else None
     hf.close()
     hf2.close()
+
+
+def ladder_forests(n_forests, n_rules, depth, seed):
+    """deep forests shaped like derivation lattices (what carmel --fem-forest exports): at every level an OR of two
+    or three rules that all continue into the SAME shared next level (#k defined in the first alternative)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_forests):
+        d = int(depth * rng.uniform(0.7, 1.0))
+
+        def level(k):
+            if k == d:
+                return "(%d)" % rng.integers(1, n_rules)
+            alts = [int(rng.integers(1, n_rules)) for _ in range(int(rng.integers(2, 4)))]
+            first = "(%d #%d%s)" % (alts[0], k + 1, level(k + 1))
+            rest = " ".join("(%d #%d)" % (a, k + 1) for a in alts[1:])
+            return "(OR %s %s)" % (first, rest)
+
+        out.append(level(0))
+    return "\n".join(out) + "\n"
+
+
+def test_forests_larger_than_lds(oracle):
+    """forests with more nodes than LDS holds keep their inside / outside columns in global memory: EM counts, the
+    exact Gibbs chain and the parallel sweep's invariants on ladder-shaped forests of ~700 nodes"""
+    import sys
+    from carmel_amd._capi import lib
+    sys.setrecursionlimit(10000)
+    ftext = ladder_forests(70, 40, 180, 5)
+    _, ntext = synth_forests(1, 40, 5)
+    of, hf = make(oracle, ftext, ntext, 5)
+    assert np.diff(of.node_off).max() > 600
+    avg_o, c_o, pf_o = of.estimate()
+    avg = hf.estimate()
+    assert avg == pytest.approx(avg_o, rel=1e-12)
+    np.testing.assert_allclose(hf.counts()[1:], np.exp(c_o)[1:], rtol=1e-8, atol=1e-12)
+    hf.gibbs(3, alpha=0.3, seed=9, mode=0)
+    ref = of.gibbs(lambda i, b, s: lib.carmel_hip_gibbs_uniform(9, i, b, s), 3, alpha=0.3)
+    for b in range(0, hf.n_forests, 7):
+        assert hf.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
+    hf.close()
+    res = []
+    for sweep in ("1", None):  # both formulations of the parallel sweep: the same chain
+        if sweep:
+            os.environ["CARMEL_HIP_FOREST_SWEEP"] = sweep
+        try:
+            of2, hf2 = make(oracle, ftext, ntext, 5)
+            hf2.gibbs(4, alpha=0.3, seed=2, mode=1)
+            res.append((hf2.iter_cheap_logprob.copy(), [hf2.sample(b) for b in range(0, hf2.n_forests, 5)]))
+            hf2.close()
+        finally:
+            os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
+    assert res[0][1] == res[1][1]
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
