@@ -64,6 +64,7 @@ struct ForestArgs {
   const uint32_t* rec_cls;       // per inside-stream record (AND headers): class of its rule | class of its norm group << 16,
                                  // both dense within the forest
   double* rec_logp;              // per inside-stream record (AND headers): ln proposal probability of the rule
+  double* rec_p;                 //                                          the probability itself
   const uint32_t* cnt_old;       // per (group, class row, lane): uses of the class in the forest's previous sample; rows
                                  // [0, max_nodes) = rule classes, [max_nodes, 2 max_nodes) = norm-group classes
   uint32_t* cnt_new;
@@ -449,23 +450,30 @@ __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
     pr = x / ns;
   }
   A.rec_logp[pos] = log(pr);
+  A.rec_p[pos] = pr;
 }
 
 #define FS_CHUNK 4
-template <bool GCOL>
+// EXT (temperature 1): inside values as mantissa x 2^exponent (frexp / ldexp are single instructions) instead of
+// logarithms -- a product is a multiply and an integer add, the OR fold an aligned add, a choice probability a
+// multiply by the reciprocal of the node's own inside value: a few instructions where the log domain spends an exp
+// and a log1p per child.  Differences to the log-domain fold are rounding (1e-16 relative).
+template <bool GCOL, bool EXT>
 __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
                                                             uint32_t stack_lds) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds;
-  double* aux = GCOL ? lds : lds + (size_t)ins_rows * 64;  // the stack follows the column when it is in LDS
+  // the stack follows the column(s) when they are in LDS (EXT: mantissas, then the exponents at half the size)
+  double* aux = GCOL ? lds : lds + (size_t)ins_rows * 64 + (EXT ? (size_t)ins_rows * 32 : 0);
   const FGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
   const bool active = (uint32_t)lane < g.n_lanes;
   const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
   const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
-  double* ins = colbase + lane;
+  double* ins = colbase + lane;                                           // ln inside, or its mantissa (EXT)
+  int* ine = (int*)(colbase + (size_t)ins_rows * 64) + lane;              // EXT: its exponent
   const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
-  const double* __restrict__ lp = A.rec_logp + g.stream_base + lane;
+  const double* __restrict__ lp = (EXT ? A.rec_p : A.rec_logp) + g.stream_base + lane;
   const uint32_t last = g.maxlen - 1;
   unsigned long long tr0 = A.trace ? __builtin_readcyclecounter() : 0, tr2 = 0, tr3 = 0;
   // inside with the proposal probabilities (forest.hpp:768-816)
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
     uint32_t d = 0;
     bool is_and = false;
     double acc = 0.0, sum = F_NEG_INF;
+    int acc_e = 0, sum_e = 0;  // EXT: acc / sum are mantissas
     for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FS_CHUNK) {
       uint2 r[FS_CHUNK];
       double p[FS_CHUNK];
@@ -485,6 +494,43 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 #pragma unroll
       for (int j = 0; j < FS_CHUNK; ++j) {
         if (k0 + j > last || !active || !(r[j].x & F_VALID)) continue;
+        if (EXT) {
+          if (r[j].x & F_HEADER) {
+            is_and = (r[j].x & F_AND) != 0;
+            acc = frexp(p[j], &acc_e);
+            sum = 0.0;
+            sum_e = 0;
+          } else {
+            const double vm = ins[(size_t)(r[j].x & F_IDX) * 64];
+            const int ve = ine[(size_t)(r[j].x & F_IDX) * 64];
+            if (is_and) {
+              int t;
+              acc = frexp(acc * vm, &t);
+              acc_e += ve + t;
+            } else if (vm != 0.0) {
+              if (sum == 0.0) {
+                sum = vm;
+                sum_e = ve;
+              } else {
+                const int dd = ve - sum_e;
+                int t;
+                if (dd <= 0)
+                  sum = frexp(sum + ldexp(vm, dd), &t);
+                else {
+                  sum = frexp(ldexp(sum, -dd) + vm, &t);
+                  sum_e = ve;
+                }
+                sum_e += t;
+              }
+            }
+          }
+          if (r[j].x & F_LAST) {
+            ins[(size_t)d * 64] = is_and ? acc : sum;
+            ine[(size_t)d * 64] = is_and ? acc_e : sum_e;
+            ++d;
+          }
+          continue;
+        }
         if (r[j].x & F_HEADER) {
           is_and = (r[j].x & F_AND) != 0;
           acc = p[j];
@@ -548,6 +594,20 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
           FSTACK_PUSH(cr.y | cold)
         }
       } else {
+        uint32_t pick = 0;
+        if (EXT) {  // temperature 1 throughout (the host picks this instantiation only then)
+          const uint32_t me = hr.x & 0xfffffu;
+          const double inv = 1.0 / ins[(size_t)me * 64];
+          const int ne = ine[(size_t)me * 64];
+          double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+          for (uint32_t k = 0;; ++k) {
+            pick = k;
+            const uint2 cr = k < 4 ? (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + k) * 64];
+            const uint32_t ci = cr.x & F_IDX;
+            choice -= ldexp(ins[(size_t)ci * 64] * inv, ine[(size_t)ci * 64] - ne);
+            if (choice < 0 || k + 1 == nch) break;
+          }
+        } else {
         const double power = cold ? 1.0 : A.power;
         // at temperature 1 the normaliser is the node's own inside value: the same fold over the same children
         double norm = ins[(size_t)(hr.x & 0xfffffu) * 64];
@@ -559,12 +619,12 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
           }
         }
         double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
-        uint32_t pick = 0;
         for (uint32_t k = 0;; ++k) {
           pick = k;
           const uint2 cr = k < 4 ? (k == 0 ? c[0] : k == 1 ? c[1] : k == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + k) * 64];
           choice -= exp(ins[(size_t)(cr.x & F_IDX) * 64] * power - norm);
           if (choice < 0 || k + 1 == nch) break;
+        }
         }
         const uint2 cr = pick < 4 ? (pick == 0 ? c[0] : pick == 1 ? c[1] : pick == 2 ? c[2] : c[3]) : st[(size_t)(h + 1 + pick) * 64];
         FSTACK_PUSH(cr.y | cold)
@@ -733,7 +793,7 @@ struct carmel_hip_forests {
   DevBuf<uint32_t> rec_cls, own_cnt[2], sample_hdr, lane_of_forest_d;
   DevBuf<double> gcol;               // columns of the launch classes whose forests do not fit LDS
   std::vector<uint64_t> gcol_off;    // per class: offset into gcol (doubles), room for two columns per group
-  DevBuf<double> rec_logp;
+  DevBuf<double> rec_logp, rec_p;
   DevBuf<uint64_t> group_off, arc_off, slot_pos, hot_chunks, sample_off;
   DevBuf<double> rule_logw, counts, post, forest_logprob, scalars, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, new_x,
       iter_out;
@@ -1230,9 +1290,13 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       HIPCHK(hipMemsetAsync(F->own_cnt[k].p, 0, F->own_cnt[k].bytes(), s));
     }
     HIPCHK(F->rec_logp.alloc(F->stream_total));
+    HIPCHK(F->rec_p.alloc(F->stream_total));
+    HIPCHK(hipMemsetAsync(F->rec_p.p, 0, F->rec_p.bytes(), s));  // the sample kernel reads every slot of its chunks
+    HIPCHK(hipMemsetAsync(F->rec_logp.p, 0, F->rec_logp.bytes(), s));
     HIPCHK(F->sample_hdr.alloc(F->h_sample_off.back()));
     A.rec_cls = F->rec_cls.p;
     A.rec_logp = F->rec_logp.p;
+    A.rec_p = F->rec_p.p;
     A.sample_hdr = F->sample_hdr.p;
     A.lane_of_forest = F->lane_of_forest_d.p;
   }
@@ -1289,18 +1353,26 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         for (size_t ci = 0; ci < F->classes.size(); ++ci) {
           const auto& c = F->classes[ci];
           A.first_group = c.first;
-          const size_t lds = (size_t)c.max_nodes * 64 * 8 + (size_t)stack_lds * 64 * 4;
+          // temperature 1: mantissa / exponent arithmetic (12 bytes per node); annealing: the log domain
+          const bool ext = A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN");
+          const size_t lds = (size_t)c.max_nodes * 64 * (ext ? 12 : 8) + (size_t)stack_lds * 64 * 4;
+          auto launch = [&](auto kernel, size_t bytes) {
+            if (bytes > 64 * 1024)
+              (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            hipLaunchKernelGGL(kernel, dim3(c.count), dim3(64), bytes, class_stream(F, s, ci), A, F->max_sample, c.max_nodes,
+                               stack_lds);
+          };
           if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
             A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
-            hipLaunchKernelGGL(forest_sample_kernel<true>, dim3(c.count), dim3(64), (size_t)stack_lds * 64 * 4,
-                               class_stream(F, s, ci), A, F->max_sample, c.max_nodes, stack_lds);
-            continue;
-          }
-          if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)forest_sample_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-          hipLaunchKernelGGL(forest_sample_kernel<false>, dim3(c.count), dim3(64), lds, class_stream(F, s, ci), A, F->max_sample,
-                             c.max_nodes, stack_lds);
+            if (ext)
+              launch(forest_sample_kernel<true, true>, (size_t)stack_lds * 64 * 4);
+            else
+              launch(forest_sample_kernel<true, false>, (size_t)stack_lds * 64 * 4);
+          } else if (ext)
+            launch(forest_sample_kernel<false, true>, lds);
+          else
+            launch(forest_sample_kernel<false, false>, lds);
         }
         HIPCHK(join_side(F, s));
       } else
