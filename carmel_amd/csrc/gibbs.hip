@@ -63,6 +63,8 @@ struct GibbsArgs {
   double* alpha;               // --expectation: forward weights, like beta
   double* ewt;                 // --expectation: per lattice arc, its posterior in the block's current "sample"
   int expectation;
+  int par_books;               // exact mode: count bookkeeping of a block by the whole workgroup (g_addc_all / g_block_probs)
+  uint32_t books_cap;          // ids of one sample the workgroup's LDS scratch holds
   double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob
   uint64_t seed;
   uint32_t n_blocks, iter;
@@ -109,6 +111,79 @@ __device__ __forceinline__ double g_prob(const GibbsArgs& G, uint32_t p, const u
   return x / ns;
 }
 
+// gibbs.hpp:769-792 for a whole sample at once, by every thread of the workgroup.  One thread doing it id by id
+// spends three dependent memory round trips per id -- that was three quarters of the exact sweep's time.  The result is
+// the one the sequential loop gives: the first touch of a parameter at this time folds (time - tmax) * x into the
+// running sum (one thread per parameter wins an atomicMax on the time stamp, while x is still untouched); the adds of
+// +-wt commute (equal addends).  Times never decrease within a run, so the moret < 0 branch cannot occur.
+__device__ __forceinline__ void g_addc_all(const GibbsArgs& G, const uint32_t* ids, uint32_t n, double d) {
+  const unsigned long long tb = (unsigned long long)__double_as_longlong(G.time);  // time >= 0: bit order = value order
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t p = ids[k];
+    if (G.p_norm[p] == G_NONORM) continue;
+    const unsigned long long old = atomicMax((unsigned long long*)(G.p_tmax + p), tb);
+    if (old < tb) G.p_s[p] += (G.time - __longlong_as_double((long long)old)) * G.p_x[p];
+  }
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t p = ids[k], nn = G.p_norm[p];
+    if (nn == G_NONORM) continue;
+    unsafeAtomicAdd(G.p_x + p, d);
+    unsafeAtomicAdd(G.normsum + nn, d);
+  }
+  __syncthreads();
+}
+// proposal ("cheap") and cache-model probability of a new sample (gibbs.hpp:712-742), by the whole workgroup: the
+// k-th id sees the cache counts of its parameter and of its norm group raised by the earlier ids of the same sample
+// (their number comes from a scan of the ids staged in LDS).  scratch: 2 * n uint32.  Sums in a fixed tree order.
+__device__ __forceinline__ void g_block_probs(const GibbsArgs& G, const uint32_t* ids, uint32_t n, uint32_t* scratch, double* red) {
+  uint32_t* sid = scratch;
+  uint32_t* snn = scratch + n;
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    sid[k] = ids[k];
+    snn[k] = G.p_norm[ids[k]];
+  }
+  __syncthreads();
+  double cheap = 0.0, cache = 0.0;
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t p = sid[k], nn = snn[k];
+    if (nn == G_NONORM) {
+      const double q = G.p_prior[p];
+      cheap += log(q);
+      cache += log(q);
+      continue;
+    }
+    uint32_t m = 0, M = 0;
+    for (uint32_t j = 0; j < k; ++j) {
+      m += sid[j] == p;
+      M += snn[j] == nn;
+    }
+    cheap += log(G.p_x[p] / G.normsum[nn]);
+    cache += log((G.ccount[p] + (double)m) / (G.csum[nn] + (double)M));
+  }
+  __syncthreads();  // every cache count has been read
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    if (snn[k] == G_NONORM) continue;
+    unsafeAtomicAdd(G.ccount + sid[k], 1.0);
+    unsafeAtomicAdd(G.csum + snn[k], 1.0);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    cheap += __shfl_down(cheap, o, 64);
+    cache += __shfl_down(cache, o, 64);
+  }
+  __shared__ double part[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    part[0][threadIdx.x >> 6] = cheap;
+    part[1][threadIdx.x >> 6] = cache;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    red[0] += (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+    red[1] += (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+  }
+  __syncthreads();
+}
+
 // Resample one block.  Called by every thread of the workgroup; serial parts run on thread 0.
 // own_ids (LDS, mode 1 only): the block's previous sample.
 template <bool SNAP>
@@ -131,7 +206,9 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     __syncthreads();
   } else {
     // 1. take the previous sample out of the counts (gibbs.hpp:851-852)
-    if (tid == 0) {
+    if (G.par_books && !G.expectation) {
+      g_addc_all(G, ids, G.sample_len[b], -wt);
+    } else if (tid == 0) {
       const uint32_t n = G.sample_len[b];
       if (G.expectation) {
         if (n) {
@@ -227,6 +304,9 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) out_ids[n++] = G.chain_param[j];
       s = oa[pick].x;
     }
+    if (!SNAP && G.par_books && n <= G.books_cap) {  // probabilities and counts by the whole workgroup, below
+      G.sample_len[b] = n;
+    } else {
     double cheap = 0.0, cache = 0.0;
     for (uint32_t k = 0; k < n; ++k) {
       const uint32_t p = out_ids[k];
@@ -246,21 +326,34 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       G.new_len[b] = n;
       red[0] += cheap;
     } else {
-      G.sample_len[b] = n;
+      G.sample_len[b] = G.par_books ? (n | 0x80000000u) : n;  // flag for the other threads: already booked
       for (uint32_t k = 0; k < n; ++k) g_addc(G, out_ids[k], wt);
       red[0] += cheap;
       red[1] += cache;
     }
+    }
   }
   __syncthreads();
+  if (!SNAP && G.par_books) {
+    const uint32_t n = G.sample_len[b];
+    __syncthreads();
+    if (n & 0x80000000u) {
+      if (tid == 0) G.sample_len[b] = n & 0x7fffffffu;
+    } else {
+      g_block_probs(G, ids, n, own_ids, red);
+      g_addc_all(G, ids, n, wt);
+    }
+    __syncthreads();
+  }
 }
 
 // mode 0: the whole sweep in one workgroup, blocks strictly in order
 __global__ __launch_bounds__(256) void gibbs_sweep_exact_kernel(GibbsArgs G) {
+  extern __shared__ uint32_t books[];  // 2 * G.books_cap ids: scratch of g_block_probs
   __shared__ double red[2];
   if (threadIdx.x == 0) red[0] = red[1] = 0.0;
   __syncthreads();
-  for (uint32_t b = 0; b < G.n_blocks; ++b) g_resample_block<false>(G, b, nullptr, 0, red);
+  for (uint32_t b = 0; b < G.n_blocks; ++b) g_resample_block<false>(G, b, books, 0, red);
   if (threadIdx.x == 0) {
     G.iter_out[0] = red[1];
     G.iter_out[1] = red[0];
@@ -520,6 +613,8 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.alpha = g->alpha.p;
   G.ewt = g->ewt.p;
   G.expectation = g->opt.expectation;
+  G.par_books = getenv("CARMEL_HIP_GIBBS_SERIAL_BOOKS") ? 0 : 1;  // A/B: one thread books a block's counts id by id
+  G.books_cap = std::min<uint32_t>(g->max_sample, 7168u);          // 56 KB of LDS at most
   G.iter_out = g->iter_out.p;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
@@ -532,7 +627,7 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
     if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(gibbs_sweep_exact_kernel, dim3(1), dim3(256), 0, s, G);
+      hipLaunchKernelGGL(gibbs_sweep_exact_kernel, dim3(1), dim3(256), (size_t)G.books_cap * 8, s, G);
     } else {
       HIPCHK(hipMemcpyAsync(g->snap_x.p, g->p_x.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->snap_norm.p, g->normsum.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
