@@ -65,6 +65,7 @@ struct GibbsArgs {
   int expectation;
   int par_books;               // exact mode: count bookkeeping of a block by the whole workgroup (g_addc_all / g_block_probs)
   uint32_t books_cap;          // ids of one sample the workgroup's LDS scratch holds
+  uint32_t stage_arcs, stage_states;  // exact mode: a block's lattice at most this large is staged in LDS (0: never)
   double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob
   uint64_t seed;
   uint32_t n_blocks, iter;
@@ -190,11 +191,29 @@ template <bool SNAP>
 __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_ids, uint32_t own_cap, double* red) {
   const int tid = threadIdx.x, NT = blockDim.x;
   const BundleDesc d = G.bundles[G.block_bundle[b]];
-  const uint2* __restrict__ oa = G.out_arcs + d.out_base;
-  const uint32_t* __restrict__ ooff = G.out_off + d.off_base;
-  const uint32_t* __restrict__ lvl = G.level_off + d.level_base;
+  const uint2* oa = G.out_arcs + d.out_base;
+  const uint32_t* ooff = G.out_off + d.off_base;
+  const uint32_t* lvl = G.level_off + d.level_base;
   double* gw = G.gw + d.out_base;
   double* beta = G.beta + d.off_base;
+  if (!SNAP && G.stage_arcs && d.n_arcs <= G.stage_arcs && d.n_states <= G.stage_states) {
+    // exact mode: the backward sweep (a barrier per level) and the walk (one thread) are chains of dependent reads of
+    // this block's lattice -- from LDS they cost a tenth of what they cost from L2
+    double* sgw = (double*)(own_ids + 2 * (size_t)G.books_cap);
+    double* sbeta = sgw + G.stage_arcs;
+    uint2* soa = (uint2*)(sbeta + G.stage_states);
+    uint32_t* soff = (uint32_t*)(soa + G.stage_arcs);
+    uint32_t* slvl = soff + G.stage_states + 1;
+    for (uint32_t a = tid; a < (uint32_t)d.n_arcs; a += NT) soa[a] = oa[a];
+    for (uint32_t k = tid; k <= d.n_states; k += NT) soff[k] = ooff[k];
+    for (uint32_t k = tid; k <= d.n_levels; k += NT) slvl[k] = lvl[k];
+    __syncthreads();
+    oa = soa;
+    ooff = soff;
+    lvl = slvl;
+    gw = sgw;
+    beta = sbeta;
+  }
   const double wt = exp(G.pair_logw[d.pair_base]);
   const uint64_t so = G.sample_off[b];
   uint32_t* ids = G.sample_ids + so;
@@ -288,15 +307,27 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     const uint32_t fin = G.pair_final[d.pair_base];
     while (s != fin) {
       const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
-      double sum = G_NEG_INF;
-      for (uint32_t a = a1; a-- > a0;) sum = g_lwadd(sum, (gw[a] + beta[oa[a].x]) * G.power);
+      // at temperature 1 the state's normaliser is its own beta: the backward sweep folded the same terms in the
+      // same order
+      double sum = beta[s];
+      if (G.power != 1.0) {
+        sum = G_NEG_INF;
+        for (uint32_t a = a1; a-- > a0;) sum = g_lwadd(sum, (gw[a] + beta[oa[a].x]) * G.power);
+      }
       if (sum == G_NEG_INF) sum = 0.0;
+      // each arc's probability once (kept in LDS for the usual small out-degree), used for the total and the choice
+      __shared__ double pe[32];
+      const bool keep = a1 - a0 <= 32;
       double tot = 0.0;
-      for (uint32_t a = a1; a-- > a0;) tot += exp((gw[a] + beta[oa[a].x]) * G.power - sum);
+      for (uint32_t a = a1; a-- > a0;) {
+        const double e = exp((gw[a] + beta[oa[a].x]) * G.power - sum);
+        if (keep) pe[a - a0] = e;
+        tot += e;
+      }
       double choice = tot * gibbs_uniform(G.seed, G.iter, b, step++);
       uint32_t pick = a0;
       for (uint32_t a = a1; a-- > a0;) {
-        choice -= exp((gw[a] + beta[oa[a].x]) * G.power - sum);
+        choice -= keep ? pe[a - a0] : exp((gw[a] + beta[oa[a].x]) * G.power - sum);
         pick = a;
         if (choice < 0) break;
       }
@@ -615,6 +646,8 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.expectation = g->opt.expectation;
   G.par_books = getenv("CARMEL_HIP_GIBBS_SERIAL_BOOKS") ? 0 : 1;  // A/B: one thread books a block's counts id by id
   G.books_cap = std::min<uint32_t>(g->max_sample, 7168u);          // 56 KB of LDS at most
+  G.stage_arcs = getenv("CARMEL_HIP_GIBBS_NO_STAGE") ? 0u : 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
+  G.stage_states = 1024u;                                           // 1024 states sweep and walk out of LDS
   G.iter_out = g->iter_out.p;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
@@ -627,7 +660,13 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
     if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(gibbs_sweep_exact_kernel, dim3(1), dim3(256), (size_t)G.books_cap * 8, s, G);
+      {
+        const size_t lds = (size_t)G.books_cap * 8 + (size_t)G.stage_arcs * 16 + (size_t)G.stage_states * 8 +
+                           (size_t)(2 * G.stage_states + 2) * 4;
+        if (lds > 64 * 1024)
+          (void)hipFuncSetAttribute((const void*)gibbs_sweep_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gibbs_sweep_exact_kernel, dim3(1), dim3(256), lds, s, G);
+      }
     } else {
       HIPCHK(hipMemcpyAsync(g->snap_x.p, g->p_x.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->snap_norm.p, g->normsum.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
