@@ -22,6 +22,15 @@ namespace carmel_hip {
 
 // streaming logsumexp accumulator: value = m + log(acc).  A state with a single arc (the common case in sparse
 // lattices) costs no exp and no log: acc stays exactly 1.
+// timing experiment only (tools/lane_bench_real.hip -DCARMEL_FAKE_MATH): what the sweep costs without its f64
+// transcendentals
+#ifdef CARMEL_FAKE_MATH
+#define K_EXP(x) ((x) * 0.5 + 1.0)
+#define K_LOG(x) ((x) - 1.0)
+#else
+#define K_EXP(x) exp(x)
+#define K_LOG(x) log(x)
+#endif
 struct Lse {
   double m, acc;
   __device__ __forceinline__ void init() {
@@ -31,13 +40,13 @@ struct Lse {
   __device__ __forceinline__ void add(double x) {
     if (x == NEG_INF) return;
     if (x <= m) {
-      acc += exp(x - m);
+      acc += K_EXP(x - m);
     } else {
-      acc = (m == NEG_INF) ? 1.0 : acc * exp(m - x) + 1.0;
+      acc = (m == NEG_INF) ? 1.0 : acc * K_EXP(m - x) + 1.0;
       m = x;
     }
   }
-  __device__ __forceinline__ double value() const { return acc == 1.0 ? m : (acc > 0.0 ? m + log(acc) : NEG_INF); }
+  __device__ __forceinline__ double value() const { return acc == 1.0 ? m : (acc > 0.0 ? m + K_LOG(acc) : NEG_INF); }
 };
 
 // the reference's own pairwise add (weight.h:765-801) — used by the serial (cyclic-lattice) sweep so that the
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) post[(size_t)((kb) + u) * 64] = exp(arg[u]);        \
+    _Pragma("unroll") for (int u = 0; u < U; ++u) post[(size_t)((kb) + u) * 64] = K_EXP(arg[u]);        \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
       const uint32_t k = (kb) + (uint32_t)(R * U + u);                                                \
       const size_t kk = (size_t)(k < maxlen ? k : lastk) * 64;                                        \
