@@ -124,3 +124,34 @@ def test_em_increases_likelihood(oracle, golden_dir):
         assert avg >= prev - 1e-12
         prev = avg
         f.maximize()
+
+
+def test_fem_export_forests_carry_the_lattice_probabilities(oracle, golden_dir):
+    """carmel --fem-forest (cascade.h:117-165 as restated in oracle/fem.hpp): each pair's derivation lattice written
+    as a forest.  Two independent restatements must agree: the inside probability of forest p under the cascade's
+    own arc weights (forest reader + inside_rec) is the pair's forward probability in the composed transducer
+    (derivations + compute_fb), and every arc id of a norm group belongs to one member's (state, input) group."""
+    rd = lambda n: open(os.path.join(golden_dir, n)).read()
+    for names, normby in ((("cipher.wfsa", "cipher.fst"), "NC"), (("chain.1", "chain.2"), "CC")):
+        corpus_name = "cipher.data" if names[0].startswith("cipher") else "chain.corpus"
+        oc = oracle.OracleCascade([rd(n) for n in names])
+        w = oc.composed()
+        corp = oc.corpus(rd(corpus_name))
+        ftxt = oracle.fem_export(oc, corp, 0, normby)
+        ntxt = oracle.fem_export(oc, corp, 1, normby)
+        ptxt = oracle.fem_export(oc, corp, 2, normby)
+        params = [float(t[2:]) if t.startswith("e^") else (math.log(float(t)) if float(t) > 0 else -math.inf)
+                  for t in ptxt.split()]
+        assert len(params) == oc.n_params
+        np.testing.assert_allclose(params, oc.param_logw, rtol=1e-12, atol=1e-12)
+        est = oracle.estimate(w, corp)
+        kept = est["pair_logprob"][est["has_deriv"]]
+        of = oracle.OracleForests(ftxt, ntxt)
+        assert of.n_forests == len(kept)
+        lw = np.zeros(max(of.n_rules, len(params) + 1))[:of.n_rules]
+        lw[1:min(of.n_rules, len(params) + 1)] = params[:of.n_rules - 1]
+        of.set_weights(lw)
+        _, _, per_forest = of.estimate()
+        np.testing.assert_allclose(per_forest, kept, rtol=1e-10, atol=1e-10)
+        ids = [int(x) for x in re.findall(r"\d+", ntxt)]
+        assert len(ids) == len(set(ids)) and max(ids) <= oc.n_params
