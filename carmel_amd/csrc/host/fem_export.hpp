@@ -38,7 +38,7 @@ struct FemExport {
       for (uint64_t p : (*chains)[(*group)[arc]]) ids.push_back(p + 1);
   }
 
-  struct Backref {
+  struct Shared {
     uint32_t uses = 0, id = 0;
   };
 
@@ -64,7 +64,7 @@ struct FemExport {
                            pstart.data(), pfinal.data(), pid.data(), plogw.data(), classes.data(), has.data());
     std::vector<uint32_t> bundle_of(n_pairs, 0xffffffffu);
     for (size_t b = 0; b < bundles.size(); ++b) bundle_of[pid[bundles[b].pair_base]] = (uint32_t)b;
-    std::vector<Backref> br;
+    std::vector<Shared> br;
     std::vector<uint64_t> ids;
     for (uint64_t p = 0; p < n_pairs; ++p) {
       if (bundle_of[p] == 0xffffffffu) continue;
@@ -73,20 +73,20 @@ struct FemExport {
       const uint32_t* oa = out_arcs.data() + 2 * B.out_base;  // {dst state, arc id}
       const uint32_t* off = ooff.data() + B.off_base;
       const uint32_t start = pstart[B.pair_base], fin = pfinal[B.pair_base];
-      br.assign(B.n_states, Backref());
-      uint32_t nextid = 1;
-      use(oa, off, br, nextid, start);
+      br.assign(B.n_states, Shared());
+      uint32_t next_label = 1;
+      use(oa, off, br, next_label, start);
       rec(o, oa, off, br, ids, start, fin);
       o << "\n";
     }
   }
 
   // graph.h:178-194.  The reference's lists are newest first: a state's out-arcs are walked from the back.
-  void use(const uint32_t* oa, const uint32_t* off, std::vector<Backref>& br, uint32_t& nextid, uint32_t s) const {
+  void use(const uint32_t* oa, const uint32_t* off, std::vector<Shared>& br, uint32_t& next_label, uint32_t s) const {
     std::vector<std::pair<uint32_t, uint32_t> > stack;  // explicit stack: lattices can be thousands of states deep
-    Backref& b0 = br[s];
+    Shared& b0 = br[s];
     if (b0.uses++ > 0) {
-      b0.id = nextid++;
+      b0.id = next_label++;
       return;
     }
     stack.emplace_back(s, off[s + 1]);
@@ -98,19 +98,19 @@ struct FemExport {
       }
       const uint32_t a = --top.second;
       const uint32_t d = oa[2 * a];
-      Backref& b = br[d];
+      Shared& b = br[d];
       if (b.uses++ > 0)
-        b.id = nextid++;
+        b.id = next_label++;
       else
         stack.emplace_back(d, off[d + 1]);
     }
   }
   // cascade.h:131-165
-  void rec(std::ostream& o, const uint32_t* oa, const uint32_t* off, std::vector<Backref>& br, std::vector<uint64_t>& ids,
+  void rec(std::ostream& o, const uint32_t* oa, const uint32_t* off, std::vector<Shared>& br, std::vector<uint64_t>& ids,
            uint32_t s, uint32_t fin) const {
-    Backref& b = br[s];
-    const bool backdef = b.uses > 1;
-    if (backdef) {
+    Shared& b = br[s];
+    const bool defining = b.uses > 1;
+    if (defining) {
       o << "#" << b.id;
       b.uses = 0;  // defined
     } else if (b.uses == 0) {
@@ -118,28 +118,28 @@ struct FemExport {
       return;
     }
     const uint32_t a0 = off[s], a1 = off[s + 1];
-    const bool ornode = a1 - a0 >= 2;
-    if (ornode) o << "(OR";
+    const bool alternatives = a1 - a0 >= 2;
+    if (alternatives) o << "(OR";
     for (uint32_t a = a1; a-- > a0;) {
-      if (ornode) o << " ";
+      if (alternatives) o << " ";
       chain_ids(oa[2 * a + 1], ids);
       const uint32_t n = oa[2 * a];
-      const bool mid = n != fin;
-      const bool nonleaf1 = backdef || (!ids.empty() && (ids.size() > 1 || mid));
-      if (nonleaf1) o << "(";
+      const bool inner = n != fin;
+      const bool wrap = defining || (!ids.empty() && (ids.size() > 1 || inner));
+      if (wrap) o << "(";
       bool first = true;
       for (uint64_t id : ids) {
         if (!first) o << ' ';
         first = false;
         o << id;
       }
-      if (mid) {
+      if (inner) {
         if (!first) o << ' ';
         rec(o, oa, off, br, ids, n, fin);
       }
-      if (nonleaf1) o << ")";
+      if (wrap) o << ")";
     }
-    if (ornode) o << ")";
+    if (alternatives) o << ")";
   }
 };
 

@@ -71,22 +71,22 @@ struct FemExport {
     return r;
   }
 
-  struct Backref {
+  struct Shared {
     unsigned uses = 0, id = 0;
   };
-  void use(const Derivations& d, std::vector<Backref>& ids, unsigned& nextid, unsigned s) const {
-    Backref& b = ids[s];
+  void use(const Derivations& d, std::vector<Shared>& ids, unsigned& next_label, unsigned s) const {
+    Shared& b = ids[s];
     if (b.uses++ > 0) {
-      b.id = nextid++;
+      b.id = next_label++;
       return;
     }
     const auto& arcs = d.g[s];
-    for (size_t k = arcs.size(); k-- > 0;) use(d, ids, nextid, arcs[k].dest);  // list order
+    for (size_t k = arcs.size(); k-- > 0;) use(d, ids, next_label, arcs[k].dest);  // list order
   }
-  void deriv_rec(std::ostream& o, const Derivations& d, const ArcTable& arcs, std::vector<Backref>& br, unsigned s) const {
-    Backref& b = br[s];
-    const bool backdef = b.uses > 1;
-    if (backdef) {
+  void deriv_rec(std::ostream& o, const Derivations& d, const ArcTable& arcs, std::vector<Shared>& br, unsigned s) const {
+    Shared& b = br[s];
+    const bool defining = b.uses > 1;
+    if (defining) {
       o << "#" << b.id;
       b.uses = 0;  // BACKREF_DEFINED
     } else if (b.uses == 0) {
@@ -94,29 +94,29 @@ struct FemExport {
       return;
     }
     const auto& st = d.g[s];
-    const bool ornode = st.size() >= 2;
-    if (ornode) o << "(OR";
+    const bool alternatives = st.size() >= 2;
+    if (alternatives) o << "(OR";
     for (size_t k = st.size(); k-- > 0;) {
-      if (ornode) o << " ";
+      if (alternatives) o << " ";
       const GArc& a = st[k];
       std::vector<unsigned> p = chain_ids(arcs.t[a.arcid].arc);
       const unsigned n = a.dest;
-      const bool mid = n != d.fin;
-      const bool nonleaf1 = backdef || (!p.empty() && (p.size() > 1 || mid));
-      if (nonleaf1) o << "(";
+      const bool inner = n != d.fin;
+      const bool wrap = defining || (!p.empty() && (p.size() > 1 || inner));
+      if (wrap) o << "(";
       bool first = true;
       for (unsigned id : p) {
         if (!first) o << ' ';
         first = false;
         o << id;
       }
-      if (mid) {
+      if (inner) {
         if (!first) o << ' ';
         deriv_rec(o, d, arcs, br, n);
       }
-      if (nonleaf1) o << ")";
+      if (wrap) o << ")";
     }
-    if (ornode) o << ")";
+    if (alternatives) o << ")";
   }
   // one line per training pair that has a derivation (cached_derivs.h:60-100)
   std::string forests(Corpus& corpus) {
@@ -128,9 +128,9 @@ struct FemExport {
     for (auto& p : corpus.examples) {
       Derivations d;
       if (!d.compute(composed, io, arcs, p, true, 0)) continue;
-      std::vector<Backref> br(d.g.size());
-      unsigned nextid = 1;
-      use(d, br, nextid, 0);
+      std::vector<Shared> br(d.g.size());
+      unsigned next_label = 1;
+      use(d, br, next_label, 0);
       deriv_rec(o, d, arcs, br, 0);
       o << "\n";
     }
