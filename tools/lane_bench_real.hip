@@ -1,3 +1,5 @@
+// NOTE: written against the lane kernel of profile v9; LaneArgs has grown since (4-byte forward records, wcache) and this
+// driver no longer sets every field -- kept for the record of the experiment, rebuild the argument block before use.
 // Microbenchmark (tools/, not part of the product): the PRODUCT lane-sweep kernel on the synthetic chain lattices
 // of lane_bench.hip (1M lattices x 32 arcs), to separate "kernel code" from "data / allocation environment".
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -Icarmel_amd/csrc tools/lane_bench_real.hip -o tools/lane_bench_real
