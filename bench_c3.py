@@ -18,6 +18,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def c3_traffic(lines):
+    """HBM-side bytes per launch of unrolled_sweep_kernel from the committed PMC passes (tools/c3_profile.sh at the
+    full 200 000 lines): 2 * FETCH_SIZE + WRITE_SIZE as in bench.py"""
+    path = os.path.join(ROOT, "profiles", "r1_c3_pmc_traffic.json")
+    if lines != 200000 or not os.path.exists(path):
+        return None
+    for name, k in json.load(open(path))["kernels"].items():
+        if "unrolled_sweep_kernel" in name and k["fetch_kb_per_launch"] is not None:
+            return (2.0 * k["fetch_kb_per_launch"] + (k["write_kb_per_launch"] or 0.0)) * 1024.0
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lines", type=int, default=200000)
@@ -66,8 +78,11 @@ def main():
         # the unrolled sweep is arithmetic on L2-resident tables, not an HBM stream: what explicit lattices would move
         # (48 B per lattice arc) is reported as the equivalent rate
         "roofline": {"bound": "hbm", "kernel": "unrolled_sweep_kernel", "achieved": 48.0 * arcs / (k_ms * 1e-3) / 1e9,
-                     "peak": 8000.0, "unit": "GB/s", "frac": 48.0 * arcs / (k_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
-                     "note": "algorithmic-equivalent bytes: the lattices are never stored, the kernel reads 2 bytes per position"},
+                     "peak": 8000.0, "unit": "GB/s", "frac": 48.0 * arcs / (k_ms * 1e-3) / 1e9 / 8000.0,
+                     "traffic": c3_traffic(args.lines),
+                     "note": "algorithmic-equivalent bytes of SURVEY's model (48 B per lattice arc): the lattices are never "
+                             "stored, so the fraction exceeds 1; the bytes the kernel really moves (traffic: parked "
+                             "alpha rows) are two orders of magnitude fewer and it is bound by L2 latency, not HBM"},
     }
     if not args.no_cpu_baseline:
         n = args.cpu_lines
