@@ -23,7 +23,7 @@ SYMBOLS = [
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
-    "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power",
+    "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
@@ -46,7 +46,8 @@ class GibbsOpts(C.Structure):
     _fields_ = [("iter", C.c_uint32), ("burnin", C.c_uint32), ("seed", C.c_uint64), ("mode", C.c_int),
                 ("uniform_p0", C.c_int), ("dirichlet_p0", C.c_int), ("final_counts", C.c_int),
                 ("exclude_prior", C.c_int), ("min_prior", C.c_double), ("high_temp", C.c_double),
-                ("low_temp", C.c_double), ("expectation", C.c_int)]
+                ("low_temp", C.c_double), ("expectation", C.c_int), ("restarts", C.c_uint32), ("argmax_final", C.c_int),
+                ("argmax_sum", C.c_int)]
 
 
 def _load():
@@ -113,6 +114,8 @@ def _load():
     lib.carmel_hip_gibbs_n_blocks.restype = C.c_uint32
     lib.carmel_hip_gibbs_max_sample.argtypes = [vp]
     lib.carmel_hip_gibbs_max_sample.restype = C.c_uint32
+    lib.carmel_hip_gibbs_best_run.argtypes = [vp]
+    lib.carmel_hip_gibbs_best_run.restype = C.c_uint32
     lib.carmel_hip_gibbs_run.argtypes = [vp, vp, vp]
     lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]

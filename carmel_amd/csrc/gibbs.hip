@@ -453,6 +453,7 @@ struct carmel_hip_gibbs {
       iter_out;
   std::vector<uint64_t> h_sample_off;
   bool ran = false;
+  uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
 };
 
 extern "C" {
@@ -606,12 +607,6 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
   const uint64_t np = g->n_params, ng = g->n_norm;
-  // restore_p0: counts = priors, normsums = their sums, no sample
-  HIPCHK(hipMemcpyAsync(g->p_x.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(g->p_s.p, 0, np * sizeof(double), s));
-  HIPCHK(hipMemsetAsync(g->p_tmax.p, 0, np * sizeof(double), s));
-  HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-  HIPCHK(hipMemsetAsync(g->sample_len.p, 0, g->sample_len.bytes(), s));
   GibbsArgs G;
   std::memset(&G, 0, sizeof G);
   G.bundles = g->bundles.p;
@@ -652,8 +647,25 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
   const uint32_t Ni = g->opt.iter, burnin = std::min(g->opt.burnin, g->opt.iter);
+  const uint32_t n_runs = g->opt.restarts + 1;
+  std::vector<double> lw(np), best_lw;
+  double best_all = 0, best_final = 0, best_sum = 0;
+  DevBuf<uint32_t> best_ids, best_len;  // sample of the best run so far (--crp-restarts)
+  for (uint32_t run = 0; run < n_runs; ++run) {
+  // restore_p0: counts = priors, normsums = their sums, no sample
+  HIPCHK(hipMemcpyAsync(g->p_x.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(g->p_s.p, 0, np * sizeof(double), s));
+  HIPCHK(hipMemsetAsync(g->p_tmax.p, 0, np * sizeof(double), s));
+  HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(g->sample_len.p, 0, g->sample_len.bytes(), s));
+  G.sample_ids = g->sample_ids.p;
+  G.sample_len = g->sample_len.p;
+  G.new_ids = g->new_ids.p;
+  G.new_len = g->new_len.p;
+  // gibbs_stats (gibbs_opts.hpp:270-296): over the sweeps from burn-in on
+  double st_all = 0.0, st_final = 0.0, st_sum = -std::numeric_limits<double>::infinity();
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
-    G.iter = iter;
+    G.iter = run * (Ni + 1) + iter;  // of the uniforms: every run draws its own
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 2 * sizeof(double), s));
@@ -691,8 +703,15 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
     double io[2];
     HIPCHK(hipMemcpyAsync(io, g->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    if (iter_logprob) iter_logprob[iter] = g->opt.mode == 0 ? io[0] : io[1];
-    if (iter_cheap_logprob) iter_cheap_logprob[iter] = io[1];
+    const double plog = g->opt.mode == 0 ? io[0] : io[1];
+    if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
+    if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[1];
+    if (iter >= g->opt.burnin) {  // gibbs.hpp:942-943
+      st_all += plog;
+      st_final = plog;
+      const double hi = std::max(st_sum, plog), lo = std::min(st_sum, plog);
+      st_sum = hi + (lo == -std::numeric_limits<double>::infinity() ? 0.0 : std::log1p(std::exp(lo - hi)));
+    }
   }
   // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
   std::vector<double> x(np), sacc(np), tm(np);
@@ -718,11 +737,33 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   for (uint64_t p = 0; p < np; ++p)
     if (g->h_norm[p] != 0xffffffffu) ns[g->h_norm[p]] += x[p];
   // probs_to_cascade (gibbs.cc:66-76): weight = final_prob (gibbs.hpp:141-150), written into the trainer's parameters
-  std::vector<double> lw(np);
   for (uint64_t p = 0; p < np; ++p) {
     double pr = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : (x[p] > 0 ? x[p] / ns[g->h_norm[p]] : 0.0);
     lw[p] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
   }
+  // gibbs_base::run_starts (gibbs.hpp:880-914): keep the run that is better by gibbs_stats::better (gibbs_opts.hpp:313-316)
+  const bool better = run == 0 || (g->opt.argmax_final ? st_final > best_final : g->opt.argmax_sum ? st_sum > best_sum : st_all > best_all);
+  if (better) {
+    g->best_run = run;
+    best_all = st_all;
+    best_final = st_final;
+    best_sum = st_sum;
+    best_lw = lw;
+    if (n_runs > 1 && !g->opt.expectation) {
+      HIPCHK(best_ids.alloc(g->sample_ids.n));
+      HIPCHK(best_len.alloc(g->sample_len.n));
+      HIPCHK(hipMemcpyAsync(best_ids.p, g->sample_ids.p, g->sample_ids.bytes(), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(best_len.p, g->sample_len.p, g->sample_len.bytes(), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+  }
+  }  // runs
+  if (n_runs > 1 && best_ids.p) {
+    HIPCHK(hipMemcpyAsync(g->sample_ids.p, best_ids.p, g->sample_ids.bytes(), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(g->sample_len.p, best_len.p, g->sample_len.bytes(), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  lw = best_lw;
   g->ran = true;
   return carmel_hip_set_weights(t, lw.data());
 }
@@ -743,5 +784,6 @@ int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* i
 }
 
 uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g) { return g ? g->max_sample : 0; }
+uint32_t carmel_hip_gibbs_best_run(carmel_hip_gibbs* g) { return g ? g->best_run : 0; }
 
 }  // extern "C"

@@ -58,6 +58,8 @@ struct Options {
   int index_threshold = 32, gpu = 0;
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
+  long crp_restarts = 0;     // --crp-restarts (carmel.cc:271-273)
+  bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
@@ -119,6 +121,12 @@ static Options parse_args(int argc, char** argv) {
         o.final_counts = true;
       else if (k == "expectation")
         o.expectation = true;
+      else if (k == "crp-restarts")
+        o.crp_restarts = std::atol(v.c_str());
+      else if (k == "crp-argmax-final")
+        o.crp_argmax_final = true;
+      else if (k == "crp-argmax-sum")
+        o.crp_argmax_sum = true;
       else if (k == "crp-exclude-prior")
         o.exclude_prior = true;
       else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
@@ -323,6 +331,9 @@ static int run(int argc, char** argv) {
     go.seed = o.seed;
     go.mode = o.crp_parallel ? 1 : 0;
     go.expectation = o.expectation;
+    go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
+    go.argmax_final = o.crp_argmax_final;
+    go.argmax_sum = o.crp_argmax_sum;
     go.uniform_p0 = o.uniform_p0;
     go.dirichlet_p0 = o.dirichlet_p0;
     go.final_counts = o.final_counts;
@@ -335,18 +346,25 @@ static int run(int argc, char** argv) {
         std::cerr << "Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01\n";
     carmel_hip_gibbs* gs = 0;
     hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
-    std::vector<double> lp(go.iter + 1);
+    const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
+    std::vector<double> lp((size_t)per_run * n_runs);
     int rc = carmel_hip_gibbs_run(gs, lp.data(), 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
+    const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
     double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
     for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
-    for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
-      std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(lp[i]);
-      if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-lp[i] / n_sym);
-      std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-lp[i] / nblocks) << "\n";
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      if (go.restarts) std::cerr << "(random restart " << r << " of " << go.restarts << "): \n";  // gibbs.hpp:897
+      for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
+        const double v = lp[(size_t)r * per_run + i];
+        std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(v);
+        if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-v / n_sym);
+        std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-v / nblocks) << "\n";
+      }
     }
+    if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());
     hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
     int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;

@@ -70,7 +70,7 @@ class HipForests(object):
         alphas: forest-em --alpha=FILE, one prior strength per rule id (negative = locked); None: the scalar alpha"""
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         check(lib.carmel_hip_forests_set_alphas(self.h, ptr(al), 0 if al is None else len(al)), "carmel_hip_forests_set_alphas")
-        o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01, high_temp, low_temp, 0)
+        o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01, high_temp, low_temp, 0, 0, 0, 0)
         self.iter_logprob, self.iter_cheap_logprob = np.zeros(iters + 1), np.zeros(iters + 1)
         check(lib.carmel_hip_forests_gibbs(self.h, C.byref(o), alpha, ptr(self.iter_logprob),
                                            ptr(self.iter_cheap_logprob)), "carmel_hip_forests_gibbs")

@@ -224,22 +224,29 @@ class HipGibbs(object):
     sweep.  After run() the trainer's parameters are the time-averaged probabilities (probs_to_cascade)."""
 
     def __init__(self, fb, iters, burnin=0, seed=1, mode=0, uniform_p0=False, dirichlet_p0=False, final_counts=False,
-                 exclude_prior=False, min_prior=0.01, high_temp=1.0, low_temp=1.0, expectation=False):
+                 exclude_prior=False, min_prior=0.01, high_temp=1.0, low_temp=1.0, expectation=False, restarts=0,
+                 argmax_final=False, argmax_sum=False):
         from ._capi import GibbsOpts
         self.fb = fb
         self.opts = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), int(dirichlet_p0), int(final_counts),
-                              int(exclude_prior), min_prior, high_temp, low_temp, int(expectation))
+                              int(exclude_prior), min_prior, high_temp, low_temp, int(expectation), restarts,
+                              int(argmax_final), int(argmax_sum))
         h = C.c_void_p()
         check(lib.carmel_hip_gibbs_create(C.byref(h), fb.h, C.byref(self.opts)), "carmel_hip_gibbs_create")
         self.h = h
         self.n_blocks = lib.carmel_hip_gibbs_n_blocks(h)
 
     def run(self):
-        n = self.opts.iter + 1
+        """with restarts > 0 the traces of all runs follow each other: run r is [r * (iter + 1), (r + 1) * (iter + 1))"""
+        n = (self.opts.iter + 1) * (self.opts.restarts + 1)
         self.iter_logprob, self.iter_cheap_logprob = np.zeros(n), np.zeros(n)
         check(lib.carmel_hip_gibbs_run(self.h, ptr(self.iter_logprob), ptr(self.iter_cheap_logprob)),
               "carmel_hip_gibbs_run")
         return self.iter_logprob
+
+    @property
+    def best_run(self):
+        return lib.carmel_hip_gibbs_best_run(self.h)
 
     def sample(self, block):
         buf = np.zeros(max(1, lib.carmel_hip_gibbs_max_sample(self.h)), np.uint32)

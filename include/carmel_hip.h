@@ -184,6 +184,12 @@ typedef struct carmel_hip_gibbs_opts {
   int expectation;    /* --expectation (gibbs_opts.hpp:125,166; derivations.h:381-398): instead of one sampled
                          derivation a block contributes the posterior of every lattice arc ("online EM"); mode 0
                          only; iter_logprob is then the ln probability of all derivations */
+  uint32_t restarts;  /* --crp-restarts=N: N further runs from the priors, each with its own draws (the uniforms of run
+                         r, sweep i are those of sweep r * (iter + 1) + i); the run that is best by gibbs_stats::better
+                         (gibbs_opts.hpp:270-316: product of the sweep probabilities from burn-in on) gives the final
+                         weights and sample (gibbs_base::run_starts, gibbs.hpp:880-914).  carmel_hip_gibbs_run then
+                         writes (restarts + 1) * (iter + 1) values into iter_logprob / iter_cheap_logprob */
+  int argmax_final, argmax_sum; /* --crp-argmax-final / --crp-argmax-sum: compare runs by their last sweep / by the sum */
 } carmel_hip_gibbs_opts;
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);
@@ -196,6 +202,8 @@ uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g);
 int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
+/* --crp-restarts: which run (0-based) was kept */
+uint32_t carmel_hip_gibbs_best_run(carmel_hip_gibbs* g);
 /* the uniform the sampler uses at (sweep, block, step of the walk): lets a checker replay the same choices */
 double carmel_hip_gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t block, uint32_t step);
 /* the exponent 1/temperature sweep `sweep` of `iter` applies to every choice (gibbs.hpp:838-839 over

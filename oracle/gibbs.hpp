@@ -60,6 +60,8 @@ struct GibbsOpts {
   unsigned iter = 0;    // -M / --crp=N : number of resampling sweeps after the initial sample
   unsigned burnin = 0;  // --burnin
   bool uniformp0 = false, dirichlet_p0 = false, final_counts = false, exclude_prior = false;
+  unsigned restarts = 0;                           // --crp-restarts (gibbs.hpp:880-914)
+  bool argmax_final = false, argmax_sum = false;   // --crp-argmax-final / --crp-argmax-sum (gibbs_opts.hpp:313-316)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125,166): fractional counts from a full forward/backward
                              // over the block instead of one sampled derivation ("online EM")
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
@@ -274,8 +276,49 @@ struct CarmelGibbs {
     }
   }
 
-  // gibbs.hpp:803-877 (one start, no restarts / prior inference / expectation mode)
+  // gibbs_stats (gibbs_opts.hpp:270-316)
+  struct Stats {
+    LW sumprob, allprob = LW::one(), finalprob = LW::one();
+    double N = 0;
+    void record(LW p) {
+      N += 1;
+      sumprob += p;
+      mul_eq(allprob, p);
+      finalprob = p;
+    }
+    bool better(const Stats& o, const GibbsOpts& g) const {
+      return g.argmax_final ? finalprob > o.finalprob : (g.argmax_sum ? sumprob > o.sumprob : allprob > o.allprob);
+    }
+  };
+  unsigned best_run = 0;
+  // gibbs_base::run_starts (gibbs.hpp:880-914): restarts + 1 runs from the priors; the best by Stats::better gives the
+  // final probabilities and sample.  The uniforms of run r, sweep i are those of sweep r * (iter + 1) + i.
   void run(const std::function<double(unsigned, unsigned, unsigned)>& u, GibbsTrace* tr = 0) {
+    Stats best;
+    std::vector<double> best_prob;
+    std::vector<std::vector<unsigned> > best_sample;
+    for (unsigned r = 0; r <= gopt.restarts; ++r) {
+      Stats st = run_one(u, tr, r);
+      if (r == 0 || st.better(best, gopt)) {
+        best_run = r;
+        best = st;
+        finalize_cumulative_counts();
+        best_prob.resize(gps.size());
+        for (size_t i = 0; i < gps.size(); ++i) best_prob[i] = final_prob((unsigned)i);
+        best_sample = sample;
+      }
+    }
+    sample = best_sample;
+    if (tr && !gopt.expectation) tr->last_sample = sample;  // (gibbs.cc:259-260: no single sample with --expectation)
+    else if (tr) tr->last_sample.assign(sample.size(), {});
+    // probs_to_cascade gibbs.cc:66-76
+    for (Wfst* w : cascade.cascade)
+      for (auto& st : w->states)
+        for (auto& a : st) a.weight = LW::from_real(best_prob[param_of.at(&a)]);
+  }
+  // gibbs.hpp:803-877 (one run; no prior inference)
+  Stats run_one(const std::function<double(unsigned, unsigned, unsigned)>& u, GibbsTrace* tr, unsigned run_index) {
+    Stats stats;
     normsum.assign(nnorm, 0.0);
     for (auto& g : gps)
       if (g.has_norm()) {
@@ -306,7 +349,7 @@ struct CarmelGibbs {
         }
         addc(sample[b], -wt);
         sample[b].clear();
-        random_path(derivs[b], sample[b], [&](unsigned step) { return u(iter, b, step); }, gopt.power(iter));
+        random_path(derivs[b], sample[b], [&](unsigned step) { return u(run_index * (Ni + 1) + iter, b, step); }, gopt.power(iter));
         LW bp = LW::one();
         for (unsigned pid : sample[b]) mul_eq(bp, LW::from_real(proposal_prob(pid)));
         mul_eq(p, bp);
@@ -323,10 +366,13 @@ struct CarmelGibbs {
         tr->iter_logprob.push_back(pc.w);
         tr->iter_cheap_logprob.push_back(p.w);
       }
+      if (iter >= gopt.burnin) stats.record(pc);  // gibbs.hpp:942-943 (the logged probability)
     }
-    if (tr && !gopt.expectation) tr->last_sample = sample;  // (gibbs.cc:259-260: no single sample with --expectation)
-    else if (tr) tr->last_sample.assign(sample.size(), {});
-    // finalize_cumulative_counts gibbs.hpp:626-638
+    return stats;
+  }
+  // finalize_cumulative_counts gibbs.hpp:626-638
+  void finalize_cumulative_counts() {
+    const unsigned Ni = gopt.iter;
     if (!(gopt.final_counts && !gopt.exclude_prior)) {
       double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;
       if (gopt.exclude_prior)
@@ -345,10 +391,6 @@ struct CarmelGibbs {
       for (auto& g : gps)
         if (g.has_norm()) normsum[g.norm] += g.sum.x;
     }
-    // probs_to_cascade gibbs.cc:66-76
-    for (Wfst* w : cascade.cascade)
-      for (auto& st : w->states)
-        for (auto& a : st) a.weight = LW::from_real(final_prob(param_of.at(&a)));
   }
 };
 

@@ -336,6 +336,14 @@ double orc_gibbs_power(double high, double low, uint32_t iter, uint32_t sweep) {
 }
 static int g_expectation = 0;  // --expectation, set before orc_gibbs_run
 void orc_set_gibbs_expectation(int on) { g_expectation = on; }
+static unsigned g_crp_restarts = 0;  // --crp-restarts / --crp-argmax-final / --crp-argmax-sum, set before orc_gibbs_run
+static int g_argmax_final = 0, g_argmax_sum = 0, g_best_run = 0;
+void orc_set_gibbs_restarts(unsigned n, int argmax_final, int argmax_sum) {
+  g_crp_restarts = n;
+  g_argmax_final = argmax_final;
+  g_argmax_sum = argmax_sum;
+}
+int orc_gibbs_best_run() { return g_best_run; }
 void orc_set_gibbs_temps(double high, double low) {
   g_high_temp = high;
   g_low_temp = low;
@@ -659,6 +667,9 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.high_temp = g_high_temp;
     go.low_temp = g_low_temp;
     go.expectation = g_expectation != 0;
+    go.restarts = g_crp_restarts;
+    go.argmax_final = g_argmax_final != 0;
+    go.argmax_sum = g_argmax_sum != 0;
     go.dirichlet_p0 = dirichlet_p0 != 0;
     go.final_counts = final_counts != 0;
     go.exclude_prior = exclude_prior != 0;
@@ -666,7 +677,8 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     CarmelGibbs g(*h->result, h->cascade, c->c, nms, go);
     GibbsTrace tr;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
-    for (uint32_t i = 0; i <= iter; ++i) {
+    g_best_run = (int)g.best_run;
+    for (uint32_t i = 0; i < (iter + 1) * (go.restarts + 1); ++i) {
       if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
       if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];
     }

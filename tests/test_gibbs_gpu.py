@@ -83,6 +83,33 @@ def test_expectation_mode_is_the_reference_online_em(oracle, golden_dir, iters, 
     fb.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(argmax_final=True), dict(argmax_sum=True)])
+def test_crp_restarts_keep_the_best_run(oracle, golden_dir, kw):
+    """--crp-restarts=N (gibbs_base::run_starts, gibbs.hpp:880-914): N + 1 runs from the priors, each with its own
+    draws; the run that is best by gibbs_stats::better (gibbs_opts.hpp:270-316) gives the final weights and sample"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    iters, burnin, restarts = 6, 2, 3
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=11, mode=0, restarts=restarts, **kw)
+    got_lp = gs.run()
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.5, 0.1], iters=iters, burnin=burnin,
+                           restarts=restarts, **kw)
+    assert len(got_lp) == (iters + 1) * (restarts + 1)
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    assert gs.best_run == ref["best_run"]
+    runs = got_lp.reshape(restarts + 1, iters + 1)[:, burnin:]
+    want = np.argmax(runs[:, -1]) if kw.get("argmax_final") else np.argmax(np.logaddexp.reduce(runs, axis=1)) if kw.get("argmax_sum") \
+        else np.argmax(runs.sum(axis=1))
+    assert gs.best_run == want  # ties aside, the first best run wins
+    for b in range(gs.n_blocks):
+        assert gs.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
+
+
 def test_gibbs_single_transducer_joint(oracle, golden_dir):
     from carmel_amd.trainer import HipGibbs
     g = lambda n: open(os.path.join(golden_dir, n)).read()
