@@ -66,9 +66,15 @@ def both_paths(w, c, **kw):
     return a, b
 
 
+@pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(tape="in")), (3, dict(eps_arcs=False, n_states=30, deg=14, n_sym=9)),
-                                     (4, dict(n_states=64, deg=6, hi=60))])
-def test_unrolled_estep_equals_explicit_and_oracle(oracle, seed, kw):
+                                     (4, dict(n_states=64, deg=6, hi=60)), (5, dict(n_states=9, deg=5, n_pairs=1001, hi=45)),
+                                     (6, dict(n_states=33, deg=20, n_sym=3, n_pairs=77))])
+def test_unrolled_estep_equals_explicit_and_oracle(oracle, seed, kw, ragged, monkeypatch):
+    """state counts on both sides of the 16 / 32 / 64-lane group sizes (4, 2 or 1 pairs per wavefront), pair counts
+    that do not fill the last wavefront; `ragged` forces per-symbol table slabs where slabs of one size would be used"""
+    if ragged:
+        monkeypatch.setenv("CARMEL_HIP_UNROLLED_RAGGED", "1")
     w, c = one_tape(seed, **kw)
     u, e = both_paths(w, c)
     assert u.lattice_stats.n_bundles == 0 and e.lattice_stats.n_bundles > 0  # the first really ran unrolled
