@@ -61,6 +61,32 @@ def test_estep_counts_and_probs(oracle, seed, kw):
     fb.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_estep_random_shapes(oracle, seed):
+    """randomised shapes: tiny to mid-sized transducers, few to many epsilons (cyclic lattices included), one pair to
+    hundreds, and hub arcs used thousands of times (single-arc and split buckets of the transposition)"""
+    rng = np.random.default_rng(100 + seed)
+    if seed == 0:  # an arc with more uses than one bucket holds (pieces meet in one atomic add each)
+        kw = dict(n_states=2, deg=2, n_sym=2, p_eps=0.0, n_pairs=1500, lo=40, hi=60)
+    elif seed == 1:  # hub arcs: a 3-state machine, every pair crosses the same few arcs dozens of times
+        kw = dict(n_states=3, deg=2, n_sym=2, p_eps=0.0, n_pairs=int(rng.integers(900, 1500)), lo=20, hi=40)
+    else:
+        kw = dict(n_states=int(rng.integers(3, 200)), deg=int(rng.integers(2, 12)), n_sym=int(rng.integers(2, 8)),
+                  p_eps=float(rng.uniform(0, 0.4)), n_pairs=int(rng.integers(1, 400)), lo=int(rng.integers(1, 4)),
+                  hi=int(rng.integers(4, 30)))
+    w, c = ambiguous(200 + seed, **kw)
+    c.weight[:] = rng.uniform(0.25, 2.0, c.n_pairs)
+    fb = _fb(w, c)
+    lp, wlp = fb.estimate(per_pair=True)
+    _, _, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert np.array_equal(ok, fb.has_deriv.astype(bool)), kw
+    np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9, err_msg=str(kw))
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-13, err_msg=str(kw))
+    assert wlp == pytest.approx(r["sum_weighted_logprob"], rel=1e-11)
+    fb.close()
+
+
 def test_big_single_lattice_classes(oracle):
     # long pairs over a tiny alphabet: lattices of thousands of states -> the 256- and 1024-thread classes
     w = synth.random_wfst(6, 5, n_sym=3, p_eps=0.2, seed=21)
