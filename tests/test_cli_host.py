@@ -61,3 +61,41 @@ def test_training_without_gpu_fails_loudly(golden_dir):
         pytest.skip("GPU present")
     rc, out, err = run("-t", os.path.join(golden_dir, "epron-jpron.data"), os.path.join(golden_dir, "epron-jpron.fst"))
     assert rc != 0 and "ERROR" in err and out == ""
+
+
+def random_fst_text(rng, n_states, n_arcs, in_syms, out_syms, p_eps):
+    """a small transducer in carmel's text format: named states, some *e* labels, some locked arcs"""
+    names = ["q%d" % i for i in range(n_states)]
+    lines = [names[-1]]
+    arcs = [(0, int(rng.integers(1, n_states)))] + [(int(rng.integers(0, n_states)), int(rng.integers(0, n_states)))
+                                                     for _ in range(n_arcs - 1)]
+    arcs += [(s, n_states - 1) for s in range(n_states - 1) if rng.random() < 0.5]  # ways into the final state
+    for s, d in arcs:
+        i = "*e*" if rng.random() < p_eps else str(rng.choice(in_syms))
+        o = "*e*" if rng.random() < p_eps else str(rng.choice(out_syms))
+        w = "%.4f" % rng.uniform(0.05, 1.0)
+        lock = "!" if rng.random() < 0.15 else ""
+        lines.append("(%s (%s %s %s %s%s))" % (names[s], names[d], i, o, w, lock))
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_composition_of_random_transducers(oracle, tmp_path, seed):
+    """compose.cc's three-state epsilon filter, LIFO state discovery, arc prepending and reduction on random inputs:
+    the front end's composition must be the oracle's, arc for arc, in the same order (bit-exact arc indexing)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
+    a = random_fst_text(rng, int(rng.integers(2, 7)), int(rng.integers(2, 14)), ["a", "b", "c"], mid, float(rng.uniform(0, 0.5)))
+    b = random_fst_text(rng, int(rng.integers(2, 7)), int(rng.integers(2, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.5)))
+    pa, pb = str(tmp_path / "a.fst"), str(tmp_path / "b.fst")
+    open(pa, "w").write(a)
+    open(pb, "w").write(b)
+    rc, out, err = run("-HJ", "-q", pa, pb)
+    try:
+        oc = oracle.OracleCascade([a, b])
+    except RuntimeError:
+        assert rc != 0  # empty composition: both say so
+        return
+    assert rc == 0, err
+    assert out == oc.composed().write(full=True, onearc=True), (a, b)
