@@ -271,3 +271,53 @@ def test_fem_export_bridges_to_forest_em(golden_dir, tmp_path, oracle):
     of.set_weights(lw)
     avg, _ = of.estimate()[:2]
     assert avg * of.n_forests / math.log(2) == pytest.approx(log2p, rel=1e-5)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_cascades_train_like_the_oracle(tmp_path, seed):
+    """--train-cascade on random two-member cascades (locked arcs, epsilons on every tape, pairs without derivations):
+    composition, chains, counts back to the members, per-member normalisation, best-weights bookkeeping -- the log
+    lines and the *.trained files must be the oracle command line's"""
+    from test_cli_host import random_fst_text
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    rng = np.random.default_rng(1000 + seed)
+    mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
+    a = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), ["a", "b"], mid, float(rng.uniform(0, 0.3)))
+    b = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.3)))
+    lines = []
+    ins = ["", "a", "b", "a a", "a b", "b a", "b b", "a b a"]
+    outs = ["", "u", "v", "u u", "u v", "v u", "v v", "v u v"]
+    for i in ins:  # every short pair: some have derivations, most do not
+        for o in outs:
+            if rng.random() < 0.7:
+                lines += [i, o]
+    pa, pb, pc = (str(tmp_path / n) for n in ("a.fst", "b.fst", "corpus"))
+    open(pa, "w").write(a)
+    open(pb, "w").write(b)
+    open(pc, "w").write("\n".join(lines) + "\n")
+    normby = str(rng.choice(["CC", "JC", "CJ", "NC"]))
+    args = ["--train-cascade", "-HJ", "-M", "6", "--normby=" + normby, pc, pa, pb]
+    d1, d2 = tmp_path / "mine", tmp_path / "ref"
+    d1.mkdir()
+    d2.mkdir()
+    rc, out, err = run(args, env=dict(os.environ, CARMEL_TRAINED_DIR=str(d1)))
+    p = subprocess.run([oracle_cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                       env=dict(os.environ, ORACLE_TRAINED_DIR=str(d2)))
+    if p.returncode != 0:
+        assert rc != 0, (err, p.stderr)  # empty composition / no derivations: both refuse
+        return
+    assert rc == 0, err
+    keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "Converged", "Maximum"))]
+    mine, ref = keep(err), keep(p.stderr)
+    assert len(mine) == len(ref) and mine, (err, p.stderr)
+    for x, y in zip(mine, ref):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-4, abs=1e-9)
+    for name in ("a.fst.trained", "b.fst.trained"):
+        x, y = open(str(d1 / name)).read(), open(str(d2 / name)).read()
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-12)
