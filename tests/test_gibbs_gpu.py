@@ -152,3 +152,45 @@ def test_gibbs_parallel_mode_is_a_valid_sampler(oracle, golden_dir):
     tail0, tail1 = res[0][0][-10:].mean(), res[1][0][-10:].mean()
     assert all(len(s) > 0 for s in res[1][1])
     assert abs(tail1 - tail0) < 0.05 * abs(tail0)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_gibbs_exact_chain_on_random_cascades(oracle, seed):
+    """the exact sweep on random two-member cascades (locked arcs, epsilons, pairs without derivations, mixed
+    normalisations): same samples, probabilities and time-averaged weights as the oracle's chain"""
+    from carmel_amd.trainer import HipGibbs
+    from test_cli_host import random_fst_text
+    rng = np.random.default_rng(2000 + seed)
+    mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
+    a = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), ["a", "b"], mid, float(rng.uniform(0, 0.3)))
+    b = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.3)))
+    ins = ["", "a", "b", "a a", "a b", "b a", "b b", "a b a"]
+    outs = ["", "u", "v", "u u", "u v", "v u", "v v", "v u v"]
+    lines = []
+    for i in ins:
+        for o in outs:
+            if rng.random() < 0.7:
+                lines += [i, o]
+    corpus_text = "\n".join(lines) + "\n"
+    normby = str(rng.choice(["CC", "JC", "CJ"]))
+    norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
+    priors = [float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))]
+    try:
+        oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
+    except RuntimeError:
+        pytest.skip("empty composition")
+    iters, burnin = 7, 2
+    try:
+        gs = HipGibbs(fb, iters, burnin=burnin, seed=3 + seed, mode=0)
+    except Exception as e:
+        assert "derivation" in str(e)
+        pytest.skip("no pair has a derivation")
+    got_lp = gs.run()
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin)
+    assert gs.n_blocks == len(ref["samples"])
+    for blk in range(gs.n_blocks):
+        assert gs.sample(blk) == ref["samples"][blk]
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
