@@ -63,6 +63,7 @@ struct GibbsArgs {
   double* alpha;               // --expectation: forward weights, like beta
   double* ewt;                 // --expectation: per lattice arc, its posterior in the block's current "sample"
   int expectation;
+  const double* init_logw;     // --init-em: per composed arc, the weight the first sweep of the first run samples from
   int par_books;               // exact mode: count bookkeeping of a block by the whole workgroup (g_addc_all / g_block_probs)
   uint32_t books_cap;          // ids of one sample the workgroup's LDS scratch holds
   uint32_t stage_arcs, stage_states;  // exact mode: a block's lattice at most this large is staged in LDS (0: never)
@@ -247,8 +248,11 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   for (uint32_t a = tid; a < (uint32_t)d.n_arcs; a += NT) {
     const uint32_t arc = oa[a].y;
     double w = 0.0;
-    for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j)
-      w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
+    if (G.init_logw)  // gibbs.cc:316-318 p_init
+      w = G.init_logw[arc];
+    else
+      for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j)
+        w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
     gw[a] = w;
   }
   for (uint32_t s = tid; s < d.n_states; s += NT) beta[s] = G_NEG_INF;
@@ -448,7 +452,7 @@ struct carmel_hip_gibbs {
   DevBuf<uint32_t> out_off, level_off, pair_start, pair_final, block_bundle, chain_param, p_norm, sample_len, sample_ids,
       new_len, new_ids;
   DevBuf<uint64_t> chain_off, sample_off;
-  DevBuf<double> alpha, ewt;
+  DevBuf<double> alpha, ewt, init_logw;
   DevBuf<double> pair_logw, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, ccount, csum, snap_x, snap_norm, gw, beta,
       iter_out;
   std::vector<uint64_t> h_sample_off;
@@ -666,6 +670,7 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   double st_all = 0.0, st_final = 0.0, st_sum = -std::numeric_limits<double>::infinity();
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     G.iter = run * (Ni + 1) + iter;  // of the uniforms: every run draws its own
+    G.init_logw = (run == 0 && iter == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 2 * sizeof(double), s));
@@ -785,5 +790,17 @@ int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* i
 
 uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g) { return g ? g->max_sample : 0; }
 uint32_t carmel_hip_gibbs_best_run(carmel_hip_gibbs* g) { return g ? g->best_run : 0; }
+int carmel_hip_gibbs_set_init_weights(carmel_hip_gibbs* g, const double* arc_logw) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  HIPCHK(hipSetDevice(g->t->device));
+  if (!arc_logw) {
+    g->init_logw.release();
+    return CARMEL_HIP_OK;
+  }
+  if (g->opt.expectation) return fail(CARMEL_HIP_ERR_UNSUPPORTED, "--init-em has no effect with --expectation (gibbs.cc:311-314)");
+  HIPCHK(g->init_logw.upload(std::vector<double>(arc_logw, arc_logw + g->t->w.n_arcs), g->t->stream));
+  HIPCHK(hipStreamSynchronize(g->t->stream));
+  return CARMEL_HIP_OK;
+}
 
 }  // extern "C"

@@ -59,6 +59,8 @@ struct Options {
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
   long crp_restarts = 0;     // --crp-restarts (carmel.cc:271-273)
+  long init_em = 0;          // --init-em=N, --em-p0 (carmel.cc:276-277; gibbs.cc:400-423)
+  bool em_p0 = false;
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
@@ -121,6 +123,10 @@ static Options parse_args(int argc, char** argv) {
         o.final_counts = true;
       else if (k == "expectation")
         o.expectation = true;
+      else if (k == "init-em")
+        o.init_em = std::atol(v.c_str());
+      else if (k == "em-p0")
+        o.em_p0 = true;
       else if (k == "crp-restarts")
         o.crp_restarts = std::atol(v.c_str());
       else if (k == "crp-argmax-final")
@@ -289,19 +295,24 @@ static int run(int argc, char** argv) {
     carmel_hip_trainer* t;
     ~Guard() { carmel_hip_destroy(t); }
   } guard{t};
+  std::vector<uint64_t> coff(1, 0), cpar;
   if (cascade) {
-    std::vector<uint64_t> coff(1, 0), cpar;
     for (auto& c : chains.chains) {
       cpar.insert(cpar.end(), c.begin(), c.end());
       coff.push_back(cpar.size());
     }
     if (cpar.empty()) cpar.push_back(0);
-    hip_check(carmel_hip_set_cascade(t, params.logw.size(), params.logw.data(), params.group.data(),
-                                     params.member.data(), params.src.data(), params.in.data(), (uint32_t)nw,
-                                     norms.data(), addc.data(), chains.chains.size(), coff.data(), cpar.data()),
-              "carmel_hip_set_cascade");
-  } else
-    hip_check(carmel_hip_set_norm(t, norms[0], addc[0]), "carmel_hip_set_norm");
+  }
+  auto set_methods = [&](const std::vector<double>& add) {  // the members' normalisation methods with these --priors
+    if (cascade)
+      hip_check(carmel_hip_set_cascade(t, params.logw.size(), params.logw.data(), params.group.data(),
+                                       params.member.data(), params.src.data(), params.in.data(), (uint32_t)nw,
+                                       norms.data(), add.data(), chains.chains.size(), coff.data(), cpar.data()),
+                "carmel_hip_set_cascade");
+    else
+      hip_check(carmel_hip_set_norm(t, norms[0], add[0]), "carmel_hip_set_norm");
+  };
+  set_methods(addc);
   if (!o.crp) hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509 (not for --crp, gibbs.cc:403)
   if (!o.crp && (!cascade || o.smooth_floor > 0))
     hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
@@ -323,67 +334,10 @@ static int run(int argc, char** argv) {
     fe.write_forests(of, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(), pairs.out_sym.data(),
                      pairs.weight.data());
   }
-  if (o.crp) {  // WFST::train_gibbs (gibbs.cc:386-430)
-    carmel_hip_gibbs_opts go;
-    std::memset(&go, 0, sizeof go);
-    go.iter = (uint32_t)(o.max_iter > 0 ? o.max_iter : 0);
-    go.burnin = (uint32_t)o.burnin;
-    go.seed = o.seed;
-    go.mode = o.crp_parallel ? 1 : 0;
-    go.expectation = o.expectation;
-    go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
-    go.argmax_final = o.crp_argmax_final;
-    go.argmax_sum = o.crp_argmax_sum;
-    go.uniform_p0 = o.uniform_p0;
-    go.dirichlet_p0 = o.dirichlet_p0;
-    go.final_counts = o.final_counts;
-    go.exclude_prior = o.exclude_prior;
-    go.min_prior = 1e-2;
-    go.high_temp = o.high_temp;
-    go.low_temp = o.low_temp;
-    for (size_t i = 0; i < nw; ++i)
-      if (addc[i] <= 0)
-        std::cerr << "Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01\n";
-    carmel_hip_gibbs* gs = 0;
-    hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
-    const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
-    std::vector<double> lp((size_t)per_run * n_runs);
-    int rc = carmel_hip_gibbs_run(gs, lp.data(), 0);
-    uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
-    const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
-    carmel_hip_gibbs_destroy(gs);
-    hip_check(rc, "carmel_hip_gibbs_run");
-    double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
-    for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
-    for (uint32_t r = 0; r < n_runs; ++r) {
-      if (go.restarts) std::cerr << "(random restart " << r << " of " << go.restarts << "): \n";  // gibbs.hpp:897
-      for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
-        const double v = lp[(size_t)r * per_run + i];
-        std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(v);
-        if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-v / n_sym);
-        std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-v / nblocks) << "\n";
-      }
-    }
-    if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
-    std::vector<double> pw(cascade ? params.logw.size() : logw.size());
-    hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
-    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
-    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
-    const char* dir = std::getenv("CARMEL_TRAINED_DIR");
-    for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437
-      member[i].set_weights(pw.data() + (cascade ? params.member_base[i] : 0));
-      std::string fn = std::string(o.files[i + 1]) + ".trained";
-      if (dir) {
-        std::string b = o.files[i + 1];
-        size_t sl = b.rfind('/');
-        fn = std::string(dir) + "/" + (sl == std::string::npos ? b : b.substr(sl + 1)) + ".trained";
-      }
-      std::cerr << "Writing trained " << o.files[i + 1] << " to " << fn << std::endl;
-      std::ofstream of(fn.c_str());
-      of << member[i].to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
-    }
-    return 0;
-  }
+  // ---- WFST::train (train.cc:503-678) over the trainer `t` with the iteration controls of `o`; also the --init-em pass
+  // of the sampler (gibbs.cc:411-416) ----
+  std::ostream& log = std::cerr;
+  auto train_em = [&](const Options& o) {
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
   hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
@@ -406,7 +360,6 @@ static int run(int argc, char** argv) {
     std::cerr << "Warning: at least one cycle in derivations for " << ls.n_cyclic_pairs
               << " example(s).  Forward/backward will miss some paths.\n";  // derivations.h:726-728
   if (cs.n_pairs == 0) throw std::runtime_error("No training example had a derivation - aborting training.");
-  std::ostream& log = std::cerr;
   auto print_ppx = [&](double ln_p) {  // weight.h:314-329 print_ppx_symbol
     double n_sym = std::max(cs.n_output, cs.n_input);
     log << "probability=" << base2(ln_p);
@@ -552,6 +505,95 @@ static int run(int argc, char** argv) {
         << base2(best) << std::endl;
     hip_check(carmel_hip_load_best(t), "carmel_hip_load_best");
   }
+  };
+  if (o.crp) {  // WFST::train_gibbs (gibbs.cc:386-430)
+    carmel_hip_gibbs_opts go;
+    std::memset(&go, 0, sizeof go);
+    go.iter = (uint32_t)(o.max_iter > 0 ? o.max_iter : 0);
+    go.burnin = (uint32_t)o.burnin;
+    go.seed = o.seed;
+    go.mode = o.crp_parallel ? 1 : 0;
+    go.expectation = o.expectation;
+    go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
+    go.argmax_final = o.crp_argmax_final;
+    go.argmax_sum = o.crp_argmax_sum;
+    go.uniform_p0 = o.uniform_p0;
+    go.dirichlet_p0 = o.dirichlet_p0;
+    go.final_counts = o.final_counts;
+    go.exclude_prior = o.exclude_prior;
+    go.min_prior = 1e-2;
+    go.high_temp = o.high_temp;
+    go.low_temp = o.low_temp;
+    for (size_t i = 0; i < nw; ++i)
+      if (addc[i] <= 0)
+        std::cerr << "Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01\n";
+    std::vector<double> init_arc_logw;
+    if (o.init_em > 0) {
+      // gibbs.cc:400-423: EM without priors gives the weights the first sample is drawn from; the base distribution
+      // stays the given one unless --em-p0
+      std::vector<double> p0(cascade ? params.logw.size() : logw.size());
+      hip_check(carmel_hip_get_weights(t, p0.data()), "carmel_hip_get_weights");
+      std::vector<double> zero(nw, 0.0);
+      set_methods(zero);
+      hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");
+      hip_check(carmel_hip_set_prior(t, 0.0, 0), "carmel_hip_set_prior");
+      Options em = o;
+      em.max_iter = o.init_em;
+      em.converge = 0;
+      em.converge_ppx_ratio = 1;
+      em.restarts = 0;
+      em.rate_growth = 1;
+      train_em(em);
+      init_arc_logw.resize(logw.size());
+      hip_check(carmel_hip_get_arc_weights(t, init_arc_logw.data()), "carmel_hip_get_arc_weights");
+      std::vector<double> em_w(p0.size());
+      hip_check(carmel_hip_get_weights(t, em_w.data()), "carmel_hip_get_weights");
+      set_methods(addc);
+      hip_check(carmel_hip_set_weights(t, o.em_p0 ? em_w.data() : p0.data()), "carmel_hip_set_weights");
+    }
+    carmel_hip_gibbs* gs = 0;
+    hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
+    if (!init_arc_logw.empty())
+      hip_check(carmel_hip_gibbs_set_init_weights(gs, init_arc_logw.data()), "carmel_hip_gibbs_set_init_weights");
+    const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
+    std::vector<double> lp((size_t)per_run * n_runs);
+    int rc = carmel_hip_gibbs_run(gs, lp.data(), 0);
+    uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
+    const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
+    carmel_hip_gibbs_destroy(gs);
+    hip_check(rc, "carmel_hip_gibbs_run");
+    double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
+    for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
+    for (uint32_t r = 0; r < n_runs; ++r) {
+      if (go.restarts) std::cerr << "(random restart " << r << " of " << go.restarts << "): \n";  // gibbs.hpp:897
+      for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
+        const double v = lp[(size_t)r * per_run + i];
+        std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(v);
+        if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-v / n_sym);
+        std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-v / nblocks) << "\n";
+      }
+    }
+    if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
+    std::vector<double> pw(cascade ? params.logw.size() : logw.size());
+    hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
+    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
+    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
+    const char* dir = std::getenv("CARMEL_TRAINED_DIR");
+    for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437
+      member[i].set_weights(pw.data() + (cascade ? params.member_base[i] : 0));
+      std::string fn = std::string(o.files[i + 1]) + ".trained";
+      if (dir) {
+        std::string b = o.files[i + 1];
+        size_t sl = b.rfind('/');
+        fn = std::string(dir) + "/" + (sl == std::string::npos ? b : b.substr(sl + 1)) + ".trained";
+      }
+      std::cerr << "Writing trained " << o.files[i + 1] << " to " << fn << std::endl;
+      std::ofstream of(fn.c_str());
+      of << member[i].to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
+    }
+    return 0;
+  }
+  train_em(o);
   // ---- forest-em side files (carmel.cc:818-831 fem_out; cascade.h:60-116, 167-178) ----
   if (!o.fem_norm.empty() || !o.fem_alpha.empty() || !o.fem_param.empty()) {
     std::vector<double> all_w(cascade ? params.logw.size() : logw.size());

@@ -202,6 +202,10 @@ uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g);
 int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
+/* --init-em (gibbs.cc:386-430, 306-383 p_init): ln weights of the composed arcs (carmel_hip_get_arc_weights after an EM
+ * run) from which the FIRST sweep of the first run draws its sample, in place of the proposal from the prior counts;
+ * NULL clears them */
+int carmel_hip_gibbs_set_init_weights(carmel_hip_gibbs* g, const double* arc_logw);
 /* --crp-restarts: which run (0-based) was kept */
 uint32_t carmel_hip_gibbs_best_run(carmel_hip_gibbs* g);
 /* the uniform the sampler uses at (sweep, block, step of the walk): lets a checker replay the same choices */

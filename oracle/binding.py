@@ -309,7 +309,8 @@ def fem_export(cascade, corpus, which, normby=None, priors=None):
 
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
-              low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False):
+              low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False, init_em=0,
+              em_p0=False):
     """carmel --crp on an OracleCascade; `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
     n = cascade.n_params
@@ -324,6 +325,7 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
     lib.orc_set_gibbs_expectation(int(expectation))
     lib.orc_set_gibbs_restarts(int(restarts), int(argmax_final), int(argmax_sum))
+    lib.orc_set_gibbs_init_em(int(init_em), int(em_p0))
     _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
                            int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
                            _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))

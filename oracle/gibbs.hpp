@@ -220,7 +220,12 @@ struct CarmelGibbs {
     }
     return prob;
   }
+  // --init-em (gibbs.cc:306-383 p_init, 386-430): ln weight per composed arc (arcs-table order) the first sweep of
+  // the first run samples from; use_init is set for that sweep only
+  std::vector<double> init_logw;
+  bool use_init = false;
   LW arc_weight(const GArc& a) const {  // gibbs.cc:348-359
+    if (use_init) return LW::from_ln(init_logw[a.arcid]);
     LW prob = LW::one();
     for (unsigned p : chain_params[a.arcid]) mul_eq(prob, LW::from_real(proposal_prob(p)));
     return prob;
@@ -330,6 +335,7 @@ struct CarmelGibbs {
     const unsigned Ni = gopt.iter;
     for (unsigned iter = 0; iter <= Ni; ++iter) {
       time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)gopt.burnin);
+      use_init = run_index == 0 && iter == 0 && !init_logw.empty();
       LW p = LW::one(), pc = LW::one();
       // cache model (gibbs.hpp:678-742): counts restart from the priors every iteration and grow by one per use
       std::vector<double> ccount(gps.size(), 0.0), csum(nnorm, 0.0);

@@ -344,6 +344,12 @@ void orc_set_gibbs_restarts(unsigned n, int argmax_final, int argmax_sum) {
   g_argmax_sum = argmax_sum;
 }
 int orc_gibbs_best_run() { return g_best_run; }
+static unsigned g_init_em = 0;  // --init-em=N / --em-p0 (gibbs.cc:386-430), set before orc_gibbs_run
+static int g_em_p0 = 0;
+void orc_set_gibbs_init_em(unsigned n, int em_p0) {
+  g_init_em = n;
+  g_em_p0 = em_p0;
+}
 void orc_set_gibbs_temps(double high, double low) {
   g_high_temp = high;
   g_low_temp = low;
@@ -674,7 +680,34 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.final_counts = final_counts != 0;
     go.exclude_prior = exclude_prior != 0;
     if (go.final_counts) go.burnin = go.iter;  // gibbs_opts.hpp validate()
+    std::vector<double> init_logw;
+    if (g_init_em > 0) {  // WFST::train_gibbs (gibbs.cc:400-423): EM without priors for the first sample's weights
+      std::vector<std::vector<LW> > saved;
+      for (auto& w : h->chain) {
+        saved.emplace_back();
+        for (auto& st : w.states)
+          for (auto& a : st) saved.back().push_back(a.weight);
+      }
+      std::vector<NormalizeMethod> m2 = nms;
+      for (auto& m : m2) m.add_count = LW();
+      TrainOpts t2;
+      t2.max_iter = g_init_em;
+      h->cascade.set_composed(h->result);
+      train(*h->result, h->cascade, c->c, m2, false, LW(), LW(), LW::one(), t2);
+      for (auto& st : h->result->states)
+        for (auto& a : st) init_logw.push_back(a.weight.w);
+      if (!g_em_p0) {
+        size_t i = 0;
+        for (auto& w : h->chain) {
+          size_t k = 0;
+          for (auto& st : w.states)
+            for (auto& a : st) a.weight = saved[i][k++];
+          ++i;
+        }
+      }
+    }
     CarmelGibbs g(*h->result, h->cascade, c->c, nms, go);
+    g.init_logw = init_logw;
     GibbsTrace tr;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     g_best_run = (int)g.best_run;

@@ -122,6 +122,34 @@ def test_crp_command(golden_dir, tmp_path, oracle):
             assert float(u) == pytest.approx(float(v), rel=1e-9)
 
 
+@pytest.mark.parametrize("em_p0", [False, True])
+def test_crp_init_em(golden_dir, tmp_path, oracle, em_p0):
+    """--init-em=N [--em-p0] (gibbs.cc:400-423, 306-383): N EM iterations without priors give the composed weights the
+    first sweep samples from; the base distribution stays the given one unless --em-p0"""
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    args = ["--crp", "-M", "12", "--burnin=4", "--init-em=3", "--priors=0.5,0.1", "-R", "9", "-HJ"] + (["--em-p0"] if em_p0 else [])
+    rc, out, err = run(args + [g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc == 0, err
+    lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
+    assert len(lines) == 13 and sum(l.startswith("i=") for l in err.split("\n")) == 3  # 3 EM iterations, 13 sweeps
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()),
+                           lambda i, b, s: lib.carmel_hip_gibbs_uniform(9, i, b, s), normby="CC", priors=[0.5, 0.1],
+                           iters=12, burnin=4, init_em=3, em_p0=em_p0)
+    logged = [float(re.search(r"prob=2\^(\S+)", l).group(1)) for l in lines]
+    for a, b in zip(logged, ref["iter_logprob"] / math.log(2)):
+        assert a == pytest.approx(b, rel=2e-6)
+    exp_txt = oc.write_member(1, ref["param_logw"])
+    got_txt = open(os.path.join(str(tmp_path), "cipher.fst.trained")).read()
+    gl, el = got_txt.strip().split("\n"), exp_txt.strip().split("\n")
+    assert len(gl) == len(el)
+    for x, y in zip(gl, el):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-7)
+
+
 def test_tied_and_locked_arcs_through_the_cli(tmp_path):
     """`!N` tie groups and `!` locks in the transducer file (carmel/doc/FORMATS; fst.cc:107-152): the command line's
     trained transducer equals the oracle's on the same files"""
