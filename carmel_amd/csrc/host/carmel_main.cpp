@@ -63,6 +63,7 @@ struct Options {
   bool em_p0 = false;
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
+  std::string load_fem_param;                              // --load-fem-param (carmel.cc:790-799; cascade.h:180-202)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
   long crp_iters = -1, burnin = 0;
@@ -113,6 +114,8 @@ static Options parse_args(int argc, char** argv) {
         o.fem_param = v;
       else if (k == "fem-alpha")
         o.fem_alpha = v;
+      else if (k == "load-fem-param")
+        o.load_fem_param = v;
       else if (k == "restart-tolerance")
         o.restart_tolerance = std::atof(v.c_str());
       else if (k == "final-restart-tolerance")
@@ -212,6 +215,24 @@ static int run(int argc, char** argv) {
       return -2;
     }
     if (!o.flags[(unsigned)'m'] && nw > 1) member[i].drop_state_names();
+  }
+  if (!o.load_fem_param.empty()) {  // fem_in (carmel.cc:790-799): the members' weights, one after the other, from a file
+    std::cerr << "Reading cascade weights from --load-fem-param=" << o.load_fem_param << std::endl;
+    std::ifstream in(o.load_fem_param.c_str());
+    if (!in) throw std::runtime_error("Missing --load-fem-param file.\n");
+    for (size_t i = 0; i < nw; ++i) {
+      std::vector<double> w;
+      for (auto& st : member[i].states)
+        for (size_t k = 0; k < st.size(); ++k) {
+          std::string tok;
+          double lw;
+          if (!(in >> tok) || !parse_weight_token(tok, lw))
+            throw std::runtime_error("--load-fem-param file doesn't have enough params; make sure it was --fem-param saved for "
+                                     "the same cascade");
+          w.push_back(lw);
+        }
+      member[i].set_weights(w.data());
+    }
   }
   // ---- composition chain, left to right (carmel.cc:1287-1355) ----
   if (!o.flags[(unsigned)'d']) member[0].prune_useless();

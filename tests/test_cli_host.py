@@ -99,3 +99,21 @@ def test_composition_of_random_transducers(oracle, tmp_path, seed):
         return
     assert rc == 0, err
     assert out == oc.composed().write(full=True, onearc=True), (a, b)
+
+
+def test_load_fem_param(golden_dir, tmp_path, oracle):
+    """--load-fem-param=FILE (carmel.cc:790-799; cascade.h:180-202): the members' weights, in arc order, from a file
+    such as --fem-param writes; too few weights is an error"""
+    import re
+    path = os.path.join(golden_dir, "train.a.w")
+    n = len(oracle.OracleWfst.parse(open(path).read()).arrays()["logw"])
+    ws = [0.5 / (k + 1) for k in range(n)]
+    pf = str(tmp_path / "params")
+    open(pf, "w").write("".join("%r\n" % w for w in ws))
+    rc, out, err = run("-HJ", "-d", "--load-fem-param=" + pf, path)
+    assert rc == 0, err
+    got = [float(x) for x in re.findall(r" ([0-9.e+-]+)!?\)\)", out)]
+    assert got == pytest.approx(ws, rel=1e-12)
+    open(pf, "w").write("0.5\n")
+    rc, out, err = run("-HJ", "--load-fem-param=" + pf, path)
+    assert rc != 0 and "doesn't have enough params" in err
