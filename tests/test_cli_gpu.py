@@ -349,3 +349,63 @@ def test_random_cascades_train_like_the_oracle(tmp_path, seed):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_one_tape_cascades(tmp_path, seed):
+    """decipherment-shaped cascades (an acceptor that writes `mid` symbols from nothing, a channel that rewrites them):
+    the composed transducer reads nothing, so the unrolled sweep runs (4, 2 or 1 pairs per wavefront by state count);
+    it must train like explicit lattices (CARMEL_HIP_UNROLLED=0) and like the oracle command line"""
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    rng = np.random.default_rng(3000 + seed)
+    n_states = int(rng.choice([3, 9, 17, 30, 40]))
+    mid = ["x", "y", "z", "w"][:int(rng.integers(2, 5))]
+    outs = ["u", "v", "t"][:int(rng.integers(2, 4))]
+    lm = ["q%d" % (n_states - 1)]
+    for s in range(n_states):  # a chain to the final state plus random arcs (some locked)
+        if s + 1 < n_states:
+            lm.append('(q%d (q%d *e* %s %.4f))' % (s, s + 1, rng.choice(mid), rng.uniform(0.05, 1)))
+        for _ in range(int(rng.integers(1, 4))):
+            d = int(rng.integers(0, n_states))
+            lm.append('(q%d (q%d *e* %s %.4f%s))' % (s, d, rng.choice(mid), rng.uniform(0.05, 1), "!" if rng.random() < 0.2 else ""))
+    ch = ["c"] + ['(c (c %s %s %.4f))' % (m, o, rng.uniform(0.05, 1)) for m in mid for o in outs if rng.random() < 0.8]
+    lines = []
+    for _ in range(int(rng.integers(5, 60))):
+        lines += ["", " ".join(rng.choice(outs, int(rng.integers(1, 25))))]
+    pa, pb, pc = (str(tmp_path / n) for n in ("lm.wfsa", "ch.fst", "corpus"))
+    open(pa, "w").write("\n".join(lm) + "\n")
+    open(pb, "w").write("\n".join(ch) + "\n")
+    open(pc, "w").write("\n".join(lines) + "\n")
+    args = ["--train-cascade", "-HJ", "-M", "5", "--normby=" + str(rng.choice(["NC", "CC", "JC"])), pc, pa, pb]
+    res = {}
+    for mode in ("unrolled", "explicit"):
+        d = tmp_path / mode
+        d.mkdir()
+        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_TIMING="1")
+        if mode == "explicit":
+            env["CARMEL_HIP_UNROLLED"] = "0"
+        res[mode] = run(args, env=env) + (d,)
+    p = subprocess.run([oracle_cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                       env=dict(os.environ, ORACLE_TRAINED_DIR=str(tmp_path)))
+    if p.returncode != 0:
+        assert res["unrolled"][0] != 0 and res["explicit"][0] != 0
+        return
+    assert res["unrolled"][0] == 0, res["unrolled"][2]
+    assert "layout=explicit" in res["explicit"][2]
+    if n_states >= 9:
+        assert "layout=unrolled" in res["unrolled"][2]
+    keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "Converged", "Maximum"))]
+    ref = keep(p.stderr)
+    for mode in ("unrolled", "explicit"):
+        mine = keep(res[mode][2])
+        assert len(mine) == len(ref) and mine
+        for x, y in zip(mine, ref):
+            assert NUM.sub("#", x) == NUM.sub("#", y)
+            for u, v in zip(NUM.findall(x), NUM.findall(y)):
+                assert float(u) == pytest.approx(float(v), rel=1e-4, abs=1e-9)
+        x, y = open(str(res[mode][3] / "ch.fst.trained")).read(), open(str(tmp_path / "ch.fst.trained")).read()
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-12)
