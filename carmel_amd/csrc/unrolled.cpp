@@ -165,7 +165,7 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
   const std::vector<uint32_t>& t_sym = M.tape ? c.out_sym : c.in_sym;
   const std::vector<uint64_t>& o_off = M.tape ? c.in_off : c.out_off;
   std::vector<uint64_t> st_states(n, 0), st_arcs(n, 0), st_expl(n, 0);
-  int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+  int nt = threads > 0 ? threads : std::min(32, (int)std::thread::hardware_concurrency());  // see lattice.cpp
   if (nt < 1) nt = 1;
   std::atomic<uint64_t> next(0);
   std::atomic<uint32_t> maxlen(0);
