@@ -13,8 +13,11 @@
 // lattices), an error code on a HIP failure.
 int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats) {
   t->unrolled = false;
-  if (const char* e = getenv("CARMEL_HIP_UNROLLED"))
+  bool forced = false;  // CARMEL_HIP_UNROLLED: 0 = never, 1 = whenever eligible, unset = when it pays (density test below)
+  if (const char* e = getenv("CARMEL_HIP_UNROLLED")) {
     if (atoi(e) == 0) return CARMEL_HIP_OK;
+    forced = true;
+  }
   auto t0 = std::chrono::steady_clock::now();
   UnrolledModel& M = t->um;
   if (!build_unrolled(t->w, t->corpus, host_threads, M)) return CARMEL_HIP_OK;
@@ -44,9 +47,23 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
     }
   }
   // LDS: accumulators + per wave (max_len + 1) rows of S values, the scales, one row of beta
-  const uint32_t n_waves = unrolled_waves(n_slots, M.max_len, M.S);
+  const bool wide = M.S > UNROLLED_MAX_STATES;  // a workgroup per pair, a thread per state (unrolled_wide_kernel)
+  uint32_t n_waves = wide ? 1u : unrolled_waves(n_slots, M.max_len, M.S);
+  if (wide && ((size_t)n_slots + 2 * (size_t)M.S + 16 + M.max_len + 2) * sizeof(double) > 150 * 1024) n_waves = 0;
   if (!n_waves) return CARMEL_HIP_OK;  // a pair too long for LDS: explicit lattices
   if (M.pair_id.empty()) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation");
+  if (!forced) {
+    // The sweep visits every table entry of every position, reachable or not.  That pays when most (position, state)
+    // nodes are live (decipherment: every state at every position); on sparse lattices explicit storage does orders
+    // of magnitude less work -- kept unless the explicit lattices would not fit comfortably.
+    double dense = 0.0;  // table entries the sweep would visit
+    for (size_t k = 0; k < M.seq_sym.size(); ++k) dense += (double)(M.f_off[M.seq_sym[k] + 1] - M.f_off[M.seq_sym[k]]);
+    const double density = dense > 0 ? (double)M.lattice_arcs / dense : 1.0;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const bool explicit_fits = (double)M.lattice_arcs * 64.0 < 0.25 * (double)free_b && M.lattice_arcs < (1ull << 31);
+    if (density < 0.05 && explicit_fits) return CARMEL_HIP_OK;
+  }
   hipStream_t s = t->stream;
   std::vector<uint16_t> e_slot(M.e_arc.size() * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
   for (size_t k = 0; k < M.e_arc.size(); ++k)
@@ -92,7 +109,11 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   const uint32_t per_wave = M.S <= 16 ? 4u : M.S <= 32 ? 2u : 1u;  // pairs side by side in one wavefront
   const int wg_per_cu = getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU") ? std::max(1, atoi(getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU"))) : 2;
   t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * wg_per_cu, (M.pair_id.size() + n_waves * per_wave - 1) / (n_waves * per_wave));
-  HIPCHK(t->u_scratch.alloc(unrolled_scratch_doubles(t->u_n_wg, n_waves, M.max_len)));
+  if (wide) {
+    t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, M.pair_id.size());
+    HIPCHK(t->u_scratch.alloc(unrolled_wide_scratch_doubles(t->u_n_wg, M.S, M.max_len)));
+  } else
+    HIPCHK(t->u_scratch.alloc(unrolled_scratch_doubles(t->u_n_wg, n_waves, M.max_len)));
   t->u_n_slots = n_slots;
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {

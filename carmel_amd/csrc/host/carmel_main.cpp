@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <limits>
 #include <memory>
 #include <sstream>
 #include "../../../include/carmel_hip.h"
@@ -187,6 +188,13 @@ static Options parse_args(int argc, char** argv) {
   }
   if (o.train_cascade) o.flags[(unsigned)'t'] = true;
   return o;
+}
+
+// Weight::ppxper (weight.h:311, 435-440): the n-th root of 1/p -- except that the root of a ZERO weight is ZERO
+// (WEIGHT_CORRECT_ZERO), so a corpus of probability 0 reports perplexity 2^-inf and counts as "best"; kept, because
+// the reference's iteration control then behaves the same way
+static inline double ppxper(double ln_p, double n) {
+  return ln_p == -std::numeric_limits<double>::infinity() ? ln_p : -ln_p / n;
 }
 
 struct CorpusStats {  // training_corpus counters over the pairs that have a derivation (train.h:151-168)
@@ -384,8 +392,8 @@ static int run(int argc, char** argv) {
   auto print_ppx = [&](double ln_p) {  // weight.h:314-329 print_ppx_symbol
     double n_sym = std::max(cs.n_output, cs.n_input);
     log << "probability=" << base2(ln_p);
-    if (n_sym) log << " per-symbol-perplexity(N=" << n_sym << ")=" << base2(-ln_p / n_sym);
-    if (cs.n_pairs) log << " per-example-perplexity(N=" << cs.n_pairs << ")=" << base2(-ln_p / cs.n_pairs);
+    if (n_sym) log << " per-symbol-perplexity(N=" << n_sym << ")=" << base2(ppxper(ln_p, n_sym));
+    if (cs.n_pairs) log << " per-example-perplexity(N=" << cs.n_pairs << ")=" << base2(ppxper(ln_p, cs.n_pairs));
   };
   // ---- WFST::train (train.cc:503-678) ----
   carmel_hip_estimate_result er;
@@ -444,7 +452,7 @@ static int run(int argc, char** argv) {
         log << "timing: i=" << iter << " estimate " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_e0).count()
             << " ms (kernels " << sweep_ms << " ms)" << std::endl;
       }
-      const double new_ppx = -er.sum_weighted_logprob / cs.total_weight;  // ln p.ppxper(totalEmpiricalWeight)
+      const double new_ppx = ppxper(er.sum_weighted_logprob, cs.total_weight);  // ln p.ppxper(totalEmpiricalWeight)
       log << "i=" << iter << " (rate=" << learning_rate << "): ";
       print_ppx(er.sum_logprob);
       if (new_ppx < best && (!cascade || cascade_counts)) {

@@ -9,9 +9,6 @@
 
 namespace carmel_hip {
 
-namespace {
-inline uint64_t bit(uint32_t s) { return 1ull << s; }
-}  // namespace
 
 bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, UnrolledModel& M) {
   M = UnrolledModel();
@@ -20,7 +17,7 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
     return false;
   };
   const uint32_t S = w.n_states;
-  if (S == 0 || S > UNROLLED_MAX_STATES) return no("more than 64 states");
+  if (S == 0 || S > UNROLLED_WIDE_MAX_STATES) return no("more than 1024 states");
   // which tape carries the symbols?
   bool in_used = false, out_used = false;
   for (uint64_t a = 0; a < w.n_arcs; ++a) {
@@ -71,8 +68,8 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
   std::stable_sort(eps.begin(), eps.end(), [&](uint32_t a, uint32_t b) { return depth[w.src[a]] < depth[w.src[b]]; });
   for (uint32_t a : eps) {
     M.e_arc.push_back(a);
-    M.e_src.push_back((uint8_t)w.src[a]);
-    M.e_dst.push_back((uint8_t)w.dst[a]);
+    M.e_src.push_back((uint16_t)w.src[a]);
+    M.e_dst.push_back((uint16_t)w.dst[a]);
   }
   // ELL slabs
   std::vector<std::vector<uint32_t>> by_sym(V);
@@ -114,7 +111,7 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
     for (uint32_t a : by_sym[x]) {
       const uint32_t k = M.f_off[x] + (cnt[w.dst[a]]++) * S + w.dst[a];
       M.f_arc[k] = a;
-      M.f_src[k] = (uint8_t)w.src[a];
+      M.f_src[k] = (uint16_t)w.src[a];
     }
     std::fill(cnt.begin(), cnt.end(), 0u);
     const uint32_t bd = (M.b_off[x + 1] - M.b_off[x]) / S;
@@ -124,38 +121,52 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
       const uint32_t row = (cnt[w.src[a]]++ + w.src[a]) % bd;
       const uint32_t k = M.b_off[x] + row * S + w.src[a];
       M.b_arc[k] = a;
-      M.b_dst[k] = (uint8_t)w.dst[a];
+      M.b_dst[k] = (uint16_t)w.dst[a];
     }
   }
-  // reachability tables as state masks: T[x][src] = destinations, TR[x][dst] = sources; multiplicities for the stats
-  std::vector<uint64_t> T((size_t)V * S, 0), TR((size_t)V * S, 0), E(S, 0), ER(S, 0);
+  // reachability tables as state sets (W 64-bit words per set): T[x][src] = destinations, TR[x][dst] = sources;
+  // multiplicities for the stats
+  const uint32_t W = (S + 63) / 64;
+  if ((uint64_t)V * S * W * 16 > (1ull << 30)) return no("reachability tables too large");
+  auto setbit = [&](uint64_t* m, uint32_t s) { m[s >> 6] |= 1ull << (s & 63); };
+  auto getbit = [&](const uint64_t* m, uint32_t s) { return (m[s >> 6] >> (s & 63)) & 1ull; };
+  std::vector<uint64_t> T((size_t)V * S * W, 0), TR((size_t)V * S * W, 0), E((size_t)S * W, 0), ER((size_t)S * W, 0);
   bool multi = false;
   for (uint32_t x = 0; x < V; ++x)
     for (uint32_t a : by_sym[x]) {
-      if (T[(size_t)x * S + w.src[a]] & bit(w.dst[a])) multi = true;
-      T[(size_t)x * S + w.src[a]] |= bit(w.dst[a]);
-      TR[(size_t)x * S + w.dst[a]] |= bit(w.src[a]);
+      uint64_t* row = &T[((size_t)x * S + w.src[a]) * W];
+      if (getbit(row, w.dst[a])) multi = true;
+      setbit(row, w.dst[a]);
+      setbit(&TR[((size_t)x * S + w.dst[a]) * W], w.src[a]);
     }
   std::vector<uint16_t> mult;  // [x][src][dst] when some (x, src, dst) has several arcs
   if (multi) {
+    if ((uint64_t)V * S * S * 2 > (1ull << 30)) return no("parallel arcs on too large a model");
     mult.assign((size_t)V * S * S, 0);
     for (uint32_t x = 0; x < V; ++x)
       for (uint32_t a : by_sym[x]) mult[((size_t)x * S + w.src[a]) * S + w.dst[a]]++;
   }
   for (uint32_t a : eps) {
-    E[w.src[a]] |= bit(w.dst[a]);
-    ER[w.dst[a]] |= bit(w.src[a]);
+    setbit(&E[(size_t)w.src[a] * W], w.dst[a]);
+    setbit(&ER[(size_t)w.dst[a] * W], w.src[a]);
   }
-  auto closure = [&](uint64_t m, const std::vector<uint64_t>& adj) {
+  // m |= everything reachable from m along adj (rows of W words per state)
+  auto closure = [&](uint64_t* m, const std::vector<uint64_t>& adj, std::vector<uint64_t>& tmp) {
+    if (eps.empty()) return;
     for (;;) {
-      uint64_t add = 0;
-      for (uint64_t r = m; r;) {
-        const int s = __builtin_ctzll(r);
-        r &= r - 1;
-        add |= adj[s];
+      tmp.assign(W, 0);
+      for (uint32_t wd = 0; wd < W; ++wd)
+        for (uint64_t r = m[wd]; r;) {
+          const uint32_t s = wd * 64 + (uint32_t)__builtin_ctzll(r);
+          r &= r - 1;
+          for (uint32_t k = 0; k < W; ++k) tmp[k] |= adj[(size_t)s * W + k];
+        }
+      bool grew = false;
+      for (uint32_t k = 0; k < W; ++k) {
+        if (tmp[k] & ~m[k]) grew = true;
+        m[k] |= tmp[k];
       }
-      if ((m | add) == m) return m;
-      m |= add;
+      if (!grew) return;
     }
   };
   // ---- corpus ----
@@ -170,7 +181,7 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
   std::atomic<uint64_t> next(0);
   std::atomic<uint32_t> maxlen(0);
   auto work = [&]() {
-    std::vector<uint64_t> F, B;
+    std::vector<uint64_t> F, B, tmp, live(W), dm(W);
     std::vector<uint16_t> xs;
     for (;;) {
       uint64_t p0 = next.fetch_add(256);
@@ -189,53 +200,67 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
           xs[o] = (uint16_t)it->second;
         }
         if (!known) continue;
-        F.assign(L + 1, 0);
-        B.assign(L + 1, 0);
-        F[0] = closure(bit(M.start), E);
+        F.assign((L + 1) * W, 0);
+        B.assign((L + 1) * W, 0);
+        setbit(&F[0], M.start);
+        closure(&F[0], E, tmp);
         uint64_t expl = 0;
         for (uint64_t o = 0; o < L; ++o) {
-          uint64_t m = 0;
-          for (uint64_t r = F[o]; r;) {
-            const int s = __builtin_ctzll(r);
-            r &= r - 1;
-            m |= T[(size_t)xs[o] * S + s];
-            expl += (uint64_t)__builtin_popcountll(T[(size_t)xs[o] * S + s]);
-          }
-          F[o + 1] = closure(m, E);
+          uint64_t* nx = &F[(o + 1) * W];
+          for (uint32_t wd = 0; wd < W; ++wd)
+            for (uint64_t r = F[o * W + wd]; r;) {
+              const uint32_t s = wd * 64 + (uint32_t)__builtin_ctzll(r);
+              r &= r - 1;
+              const uint64_t* row = &T[((size_t)xs[o] * S + s) * W];
+              for (uint32_t k = 0; k < W; ++k) {
+                nx[k] |= row[k];
+                expl += (uint64_t)__builtin_popcountll(row[k]);
+              }
+            }
+          closure(nx, E, tmp);
         }
         st_expl[p] = expl;
-        if (!(F[L] & bit(M.fin))) continue;
+        if (!getbit(&F[L * W], M.fin)) continue;
         M.has_deriv[p] = 1;
-        B[L] = closure(bit(M.fin), ER);
+        setbit(&B[L * W], M.fin);
+        closure(&B[L * W], ER, tmp);
         for (uint64_t o = L; o-- > 0;) {
-          uint64_t m = 0;
-          for (uint64_t r = B[o + 1]; r;) {
-            const int d = __builtin_ctzll(r);
-            r &= r - 1;
-            m |= TR[(size_t)xs[o] * S + d];
-          }
-          B[o] = closure(m, ER);
+          uint64_t* pv = &B[o * W];
+          for (uint32_t wd = 0; wd < W; ++wd)
+            for (uint64_t r = B[(o + 1) * W + wd]; r;) {
+              const uint32_t d = wd * 64 + (uint32_t)__builtin_ctzll(r);
+              r &= r - 1;
+              const uint64_t* row = &TR[((size_t)xs[o] * S + d) * W];
+              for (uint32_t k = 0; k < W; ++k) pv[k] |= row[k];
+            }
+          closure(pv, ER, tmp);
         }
         uint64_t ns = 0, na = 0;
         for (uint64_t o = 0; o <= L; ++o) {
-          const uint64_t live = F[o] & B[o];
-          ns += (uint64_t)__builtin_popcountll(live);
-          for (uint64_t r = live; r;) {
-            const int s = __builtin_ctzll(r);
-            r &= r - 1;
-            na += (uint64_t)__builtin_popcountll(E[s] & live);  // *e*:*e* arcs inside the position (single arcs assumed)
-            if (o < L) {
-              const uint64_t dm = T[(size_t)xs[o] * S + s] & F[o + 1] & B[o + 1];
-              if (!multi)
-                na += (uint64_t)__builtin_popcountll(dm);
-              else
-                for (uint64_t q = dm; q;) {
-                  const int d = __builtin_ctzll(q);
-                  q &= q - 1;
-                  na += mult[((size_t)xs[o] * S + s) * S + d];
-                }
-            }
+          for (uint32_t k = 0; k < W; ++k) {
+            live[k] = F[o * W + k] & B[o * W + k];
+            ns += (uint64_t)__builtin_popcountll(live[k]);
           }
+          for (uint32_t wd = 0; wd < W; ++wd)
+            for (uint64_t r = live[wd]; r;) {
+              const uint32_t s = wd * 64 + (uint32_t)__builtin_ctzll(r);
+              r &= r - 1;
+              for (uint32_t k = 0; k < W; ++k)  // *e*:*e* arcs inside the position (single arcs assumed)
+                na += (uint64_t)__builtin_popcountll(E[(size_t)s * W + k] & live[k]);
+              if (o < L) {
+                const uint64_t* row = &T[((size_t)xs[o] * S + s) * W];
+                for (uint32_t k = 0; k < W; ++k) dm[k] = row[k] & F[(o + 1) * W + k] & B[(o + 1) * W + k];
+                if (!multi)
+                  for (uint32_t k = 0; k < W; ++k) na += (uint64_t)__builtin_popcountll(dm[k]);
+                else
+                  for (uint32_t k = 0; k < W; ++k)
+                    for (uint64_t q = dm[k]; q;) {
+                      const uint32_t d = k * 64 + (uint32_t)__builtin_ctzll(q);
+                      q &= q - 1;
+                      na += mult[((size_t)xs[o] * S + s) * S + d];
+                    }
+              }
+            }
         }
         st_states[p] = ns;
         st_arcs[p] = na;

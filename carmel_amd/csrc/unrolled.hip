@@ -117,11 +117,11 @@ void unrolled_sweep_kernel(UnrolledArgs A) {
 #pragma unroll
           for (int j = 0; j < U_BATCH; ++j) r[j] = p[(size_t)(it0 + j) * S];
 #pragma unroll
-          for (int j = 0; j < U_BATCH; ++j) v += __shfl(a, (int)(base + (r[j].other_slot2 & 0xffu)), 64) * r[j].w;
+          for (int j = 0; j < U_BATCH; ++j) v += __shfl(a, (int)(base + (r[j].other_slot2 & 0x3ffu)), 64) * r[j].w;
         }
         for (; it0 < deg; ++it0) {
           const URec r = p[(size_t)it0 * S];
-          v += __shfl(a, (int)(base + (r.other_slot2 & 0xffu)), 64) * r.w;
+          v += __shfl(a, (int)(base + (r.other_slot2 & 0x3ffu)), 64) * r.w;
         }
       } else {
       const uint32_t row0 = A.f_off[x], deg = A.f_off[x + 1] - row0;  // in rows of S entries
@@ -132,7 +132,7 @@ void unrolled_sweep_kernel(UnrolledArgs A) {
         for (int j = 0; j < U_BATCH; ++j) r[j] = A.f_rec[(size_t)(row0 + min(it0 + j, deg - 1)) * S + ln];
 #pragma unroll
         for (int j = 0; j < U_BATCH; ++j) {
-          const double as = __shfl(a, (int)(base + (r[j].other_slot2 & 0xffu)), 64);
+          const double as = __shfl(a, (int)(base + (r[j].other_slot2 & 0x3ffu)), 64);
           v += (it0 + j < deg) ? as * r[j].w : 0.0;
         }
       }
@@ -192,7 +192,7 @@ void unrolled_sweep_kernel(UnrolledArgs A) {
         const URec* __restrict__ p = A.b_rec + (size_t)x * deg * S + ln;
 #define U_BWD_TERM(R)                                                                                       \
   {                                                                                                         \
-    const double term = __shfl(b, (int)(base + ((R).other_slot2 & 0xffu)), 64) * (R).w;                     \
+    const double term = __shfl(b, (int)(base + ((R).other_slot2 & 0x3ffu)), 64) * (R).w;                     \
     v += term;                                                                                              \
     const double pp = ag * term;                                                                            \
     if (pp > 0.0 && !(A.debug_no_acc & 1u)) {                                                               \
@@ -224,7 +224,7 @@ void unrolled_sweep_kernel(UnrolledArgs A) {
         for (int j = 0; j < U_BATCH; ++j) r[j] = A.b_rec[(size_t)(row0 + min(it0 + j, deg - 1)) * S + ln];
 #pragma unroll
         for (int j = 0; j < U_BATCH; ++j) {
-          const double bd = __shfl(b, (int)(base + (r[j].other_slot2 & 0xffu)), 64);
+          const double bd = __shfl(b, (int)(base + (r[j].other_slot2 & 0x3ffu)), 64);
           const double term = (it0 + j < deg) ? bd * r[j].w : 0.0;
           v += term;
           const double p = ag * term;
@@ -255,6 +255,179 @@ void unrolled_sweep_kernel(UnrolledArgs A) {
   __syncthreads();
   double* out = A.partial + (size_t)blockIdx.x * A.n_slots;
   for (uint32_t k = threadIdx.x; k < A.n_slots; k += blockDim.x) out[k] = acc[k];
+}
+
+// ---------------- more than 64 states: a workgroup per pair, a thread per state ----------------
+// The same scaled forward-backward with alpha_hat / beta_hat in LDS (double-buffered: a position's values are read by
+// every thread while the next position's are written), the position's scale from a workgroup-wide sum, the parked
+// alpha_hat rows S wide.  Two barriers per position (four when the transducer has *e*:*e* arcs).  Used for one-tape
+// transducers of 65 .. 1024 states (e.g. a trigram character model under a substitution channel: 729 states).
+__device__ __forceinline__ double wide_sum(double v, double* part, uint32_t n_waves) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (uint32_t k = 0; k < n_waves; ++k) t += part[k];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void unrolled_wide_kernel(UnrolledArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const uint32_t S = A.S, tid = threadIdx.x, n_waves = blockDim.x >> 6;
+  const bool on = tid < S;
+  const uint32_t ln = on ? tid : 0u;
+  double* acc = lds;                       // n_slots accumulators
+  double* va = acc + A.n_slots;            // two buffers of S values (alpha_hat, then beta_hat)
+  double* vb = va + S;
+  double* part = vb + S;                   // 16 partial sums
+  double* cs = part + 16;                  // scales c[o] of the current pair
+  const size_t Sp = (size_t)blockDim.x;    // row pitch of the parked alpha_hat rows
+  double* rows = A.alpha_scratch + (size_t)blockIdx.x * (size_t)(A.max_len + 1) * Sp + tid;
+  for (uint32_t k = tid; k < A.n_slots; k += blockDim.x) acc[k] = 0.0;
+  __syncthreads();
+  auto eps_forward = [&](double* buf, double v) -> double {  // *e*:*e* arcs in topological order of their sources
+    if (!A.n_eps) return v;
+    if (on) buf[tid] = v;
+    __syncthreads();
+    if (tid == 0)
+      for (uint32_t e = 0; e < A.n_eps; ++e) buf[A.e_dst[e]] += buf[A.e_src[e]] * A.We[e];
+    __syncthreads();
+    const double r = on ? buf[tid] : 0.0;
+    __syncthreads();
+    return r;
+  };
+  for (uint64_t q = blockIdx.x; q < A.n_pairs; q += gridDim.x) {
+    const uint64_t s0 = A.seq_off[q];
+    const uint32_t L = (uint32_t)(A.seq_off[q + 1] - s0);
+    const uint16_t* xs = A.seq_sym + s0;
+    double* cur = va;
+    double* nxt = vb;
+    // ---------- forward ----------
+    double a = eps_forward(nxt, tid == A.start ? 1.0 : 0.0);
+    double lnz = 0.0;
+    bool dead = false;
+    {
+      const double c0 = wide_sum(a, part, n_waves);
+      a /= c0;
+      lnz = log(c0);
+      rows[0] = a;
+      if (on) cur[tid] = a;
+      if (tid == 0) cs[0] = c0;
+    }
+    __syncthreads();
+    for (uint32_t o = 0; o < L; ++o) {
+      const uint32_t x = xs[o];
+      const uint32_t row0 = A.f_off[x], deg = A.f_off[x + 1] - row0;
+      const URec* __restrict__ p = A.f_rec + (size_t)row0 * S + ln;
+      double v = 0.0;
+      for (uint32_t it0 = 0; it0 < deg; it0 += 4) {
+        URec r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = p[(size_t)min(it0 + j, deg - 1) * S];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v += (it0 + j < deg) ? cur[r[j].other_slot2 & 0x3ffu] * r[j].w : 0.0;
+      }
+      if (!on) v = 0.0;
+      v = eps_forward(nxt, v);
+      const double c = wide_sum(v, part, n_waves);
+      if (!(c > 0.0)) {
+        dead = true;
+        break;
+      }
+      a = v / c;
+      lnz += log(c);
+      rows[(size_t)(o + 1) * Sp] = a;
+      if (on) nxt[tid] = a;
+      if (tid == 0) cs[o + 1] = c;
+      __syncthreads();
+      double* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    const double pfin = dead ? 0.0 : cur[A.fin];
+    const double lp = (dead || !(pfin > 0.0)) ? U_NEG_INF : lnz + log(pfin);
+    if (tid == 0) A.pair_logprob[A.pair_id[q]] = lp;
+    __syncthreads();
+    if (lp == U_NEG_INF) continue;
+    // ---------- backward + posteriors ----------
+    const double g = A.pair_weight[q] / pfin;
+    // beta_hat in the two buffers; alpha_hat[L] is still in the register a
+    double* bc = cur;  // (alpha's last buffer is free: pfin has been read by everyone behind the barrier above)
+    double* bn = nxt;
+    double b = (tid == A.fin) ? 1.0 : 0.0;
+    auto eps_backward = [&](double* bbuf, double bval, double a_here) -> double {
+      // *e*:*e* arcs inside a position, in reverse order; their posteriors go to the accumulators
+      if (!A.n_eps) return bval;
+      if (on) bbuf[tid] = bval;
+      if (on) bn[tid] = a_here;  // alpha_hat of this position, for thread 0
+      __syncthreads();
+      if (tid == 0)
+        for (uint32_t e = A.n_eps; e-- > 0;) {
+          const uint32_t es = A.e_src[e], ed = A.e_dst[e];
+          const double u = bbuf[ed] * A.We[e];
+          const double pp = bn[es] * u * g;
+          bbuf[es] += u;
+          if (pp > 0.0)
+            for (int j = 0; j < (int)UNROLLED_MAX_CHAIN; ++j) {
+              const uint32_t t = A.e_slot[e * UNROLLED_MAX_CHAIN + j];
+              if (t != UNROLLED_NO_SLOT) acc[t] += pp;
+            }
+        }
+      __syncthreads();
+      const double r = on ? bbuf[tid] : 0.0;
+      __syncthreads();
+      return r;
+    };
+    b = eps_backward(bc, b, a);
+    if (on) bc[tid] = b;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    double a_o = L ? rows[(size_t)(L - 1) * Sp] : 0.0;
+    for (uint32_t o = L; o-- > 0;) {
+      const uint32_t x = xs[o];
+      const double a_next = o ? rows[(size_t)(o - 1) * Sp] : 0.0;
+      const double co = cs[o + 1];
+      const double ag = on ? a_o * (g / co) : 0.0;
+      const uint32_t row0 = A.b_off[x], deg = A.b_off[x + 1] - row0;
+      const URec* __restrict__ p = A.b_rec + (size_t)row0 * S + ln;
+      double v = 0.0;
+      for (uint32_t it0 = 0; it0 < deg; it0 += 4) {
+        URec r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = p[(size_t)min(it0 + j, deg - 1) * S];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const double term = (it0 + j < deg) ? bc[r[j].other_slot2 & 0x3ffu] * r[j].w : 0.0;
+          v += term;
+          const double pp = ag * term;
+          if (pp > 0.0) {
+            const uint32_t t0 = r[j].slot01 & 0xffffu, t1 = r[j].slot01 >> 16, t2 = r[j].other_slot2 >> 16;
+            if (t0 != UNROLLED_NO_SLOT) atomicAdd(acc + t0, pp);
+            if (t1 != UNROLLED_NO_SLOT) atomicAdd(acc + t1, pp);
+            if (t2 != UNROLLED_NO_SLOT) atomicAdd(acc + t2, pp);
+          }
+        }
+      }
+      b = on ? v / co : 0.0;
+      __syncthreads();  // everyone has read bc
+      b = eps_backward(bc, b, a_o);
+      if (on) bc[tid] = b;
+      __syncthreads();
+      a_o = a_next;
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  double* out = A.partial + (size_t)blockIdx.x * A.n_slots;
+  for (uint32_t k = tid; k < A.n_slots; k += blockDim.x) out[k] = acc[k];
+}
+
+size_t unrolled_wide_lds_bytes(const UnrolledArgs& A) {
+  return ((size_t)A.n_slots + 2 * (size_t)A.S + 16 + A.max_len + 2) * sizeof(double);
+}
+size_t unrolled_wide_scratch_doubles(uint32_t n_wg, uint32_t S, uint32_t max_len) {
+  return (size_t)n_wg * (max_len + 1) * (((size_t)S + 63) / 64 * 64);
 }
 
 // counts[slot] = sum over workgroups, in a fixed order
@@ -307,6 +480,14 @@ hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, dou
 }
 
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s) {
+  if (A.S > UNROLLED_MAX_STATES) {
+    const size_t lds = unrolled_wide_lds_bytes(A);
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)unrolled_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(unrolled_wide_kernel, dim3(n_wg), dim3((A.S + 63) / 64 * 64), lds, s, A);
+    hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((A.n_slots + 255) / 256), dim3(256), 0, s, A.partial, n_wg, A.n_slots, counts);
+    return hipGetLastError();
+  }
   const uint32_t n_waves = unrolled_waves(A.n_slots, A.max_len, A.S);
   if (!n_waves) return hipErrorInvalidValue;
   const size_t lds = unrolled_lds_bytes(A, n_waves);

@@ -19,7 +19,8 @@
 
 namespace carmel_hip {
 
-static const uint32_t UNROLLED_MAX_STATES = 64;     // one lane per state
+static const uint32_t UNROLLED_MAX_STATES = 64;     // one lane per state (unrolled_sweep_kernel)
+static const uint32_t UNROLLED_WIDE_MAX_STATES = 1024;  // one thread per state, a workgroup per pair (unrolled_wide_kernel)
 static const uint32_t UNROLLED_MAX_SLOTS = 6144;    // count accumulators in LDS (48 KB of f64)
 static const uint32_t UNROLLED_MAX_CHAIN = 3;       // accumulator slots per arc
 static const uint32_t UNROLLED_NO_SLOT = 0xffffu;
@@ -31,12 +32,12 @@ struct UnrolledModel {
   uint32_t S = 0, V = 0, start = 0, fin = 0;
   std::vector<uint32_t> f_off;   // V + 1: entry offset of symbol x's slab (f_deg[x] * S entries)
   std::vector<uint32_t> f_arc;   // arc id or 0xffffffff (padding)
-  std::vector<uint8_t> f_src;
+  std::vector<uint16_t> f_src;
   uint32_t f_deg_u = 0, b_deg_u = 0;  // rows per slab when every symbol's slab has the same size (0: ragged)
   std::vector<uint32_t> b_off, b_arc;
-  std::vector<uint8_t> b_dst;
+  std::vector<uint16_t> b_dst;
   std::vector<uint32_t> e_arc;   // *e*:*e* arcs in topological order of their sources
-  std::vector<uint8_t> e_src, e_dst;
+  std::vector<uint16_t> e_src, e_dst;
   // corpus: pairs with a derivation, their symbol strings (dense symbol ids)
   std::vector<uint32_t> pair_id;
   std::vector<uint64_t> seq_off;

@@ -10,7 +10,7 @@ namespace carmel_hip {
 // one table entry, one 16-byte load: the arc's linear weight, the state at its other end, its accumulator slots
 struct __attribute__((aligned(16))) URec {
   double w;
-  uint32_t other_slot2;  // bits 0-7: source (forward table) / destination (backward table); bits 16-31: slot 2
+  uint32_t other_slot2;  // bits 0-9: source (forward table) / destination (backward table); bits 16-31: slot 2
   uint32_t slot01;       // bits 0-15: slot 0, bits 16-31: slot 1
 };
 
@@ -22,8 +22,8 @@ struct UnrolledArgs {
   const URec* f_rec;               // forward table (by destination); padding entries have weight 0
   const uint32_t* b_off;
   const URec* b_rec;               // backward table (by source), with the accumulator slots
-  const uint8_t* e_src;
-  const uint8_t* e_dst;
+  const uint16_t* e_src;
+  const uint16_t* e_dst;
   const double* We;
   const uint16_t* e_slot;
   const uint64_t* seq_off;
@@ -44,5 +44,8 @@ hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, dou
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
                                         const uint32_t* group, uint32_t n, hipStream_t s);
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s);
+// more than 64 states: a workgroup per pair, a thread per state
+size_t unrolled_wide_lds_bytes(const UnrolledArgs& A);
+size_t unrolled_wide_scratch_doubles(uint32_t n_wg, uint32_t S, uint32_t max_len);
 
 }  // namespace carmel_hip

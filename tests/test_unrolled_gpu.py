@@ -56,7 +56,7 @@ def one_tape(seed, n_states=12, deg=9, n_sym=5, n_pairs=300, lo=2, hi=30, eps_ar
 
 
 def both_paths(w, c, **kw):
-    os.environ.pop("CARMEL_HIP_UNROLLED", None)
+    os.environ["CARMEL_HIP_UNROLLED"] = "1"  # whenever eligible (by default sparse lattices stay explicit)
     a = HipForwardBackward(w, c, **kw)
     os.environ["CARMEL_HIP_UNROLLED"] = "0"
     try:
@@ -69,7 +69,9 @@ def both_paths(w, c, **kw):
 @pytest.mark.parametrize("ragged", [False, True])
 @pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(tape="in")), (3, dict(eps_arcs=False, n_states=30, deg=14, n_sym=9)),
                                      (4, dict(n_states=64, deg=6, hi=60)), (5, dict(n_states=9, deg=5, n_pairs=1001, hi=45)),
-                                     (6, dict(n_states=33, deg=20, n_sym=3, n_pairs=77))])
+                                     (6, dict(n_states=33, deg=20, n_sym=3, n_pairs=77)),
+                                     (7, dict(n_states=100, deg=5, hi=40)), (8, dict(n_states=300, deg=4, n_pairs=120)),
+                                     (9, dict(n_states=65, deg=8, eps_arcs=False, n_pairs=90))])
 def test_unrolled_estep_equals_explicit_and_oracle(oracle, seed, kw, ragged, monkeypatch):
     """state counts on both sides of the 16 / 32 / 64-lane group sizes (4, 2 or 1 pairs per wavefront), pair counts
     that do not fill the last wavefront; `ragged` forces per-symbol table slabs where slabs of one size would be used"""
