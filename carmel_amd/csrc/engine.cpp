@@ -774,7 +774,7 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
     if (t->unrolled) {  // the sweep accumulated per parameter already
       HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->counts_ptr(), t->u_param_uses.p,
                                           t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
-                                          (uint32_t)t->n_params, s));
+                                          t->u_slot_of.p, (uint32_t)t->n_params, s));
     } else {
       HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
       HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
@@ -845,7 +845,7 @@ int carmel_hip_save_counts(carmel_hip_trainer* t) {
   // for_arcs::save_counts: em_weight <- weight() of the composed arc, which after the previous maximize's
   // prep_new_weights holds (count + prior) — here: the counts buffer of the previous estimate
   if (t->unrolled && t->cascade)  // parameter space: the sweep never had composed-arc counts
-    HIPCHK(hipMemcpyAsync(t->u_em_param.p, t->counts_ptr(), t->n_params * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->u_em_param.p, t->counts_ptr(), t->u_n_slots * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
   else
     HIPCHK(hipMemcpyAsync(t->em_logw.p, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
   return CARMEL_HIP_OK;
@@ -854,7 +854,7 @@ int carmel_hip_save_best(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
   if (t->unrolled && t->cascade) {
-    HIPCHK(hipMemcpyAsync(t->u_best_param.p, t->u_em_param.p, t->n_params * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
+    HIPCHK(hipMemcpyAsync(t->u_best_param.p, t->u_em_param.p, t->u_n_slots * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
     return CARMEL_HIP_OK;
   }
   const double* from = t->cascade ? t->em_logw.p : t->arc_logw.p;
@@ -874,7 +874,7 @@ int carmel_hip_load_best(carmel_hip_trainer* t) {
   if (t->unrolled) {
     HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->u_best_param.p, t->u_param_uses.p,
                                         t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
-                                        (uint32_t)t->n_params, s));
+                                        t->u_slot_of.p, (uint32_t)t->n_params, s));
   } else {
     HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));

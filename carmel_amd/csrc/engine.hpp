@@ -102,6 +102,7 @@ struct carmel_hip_trainer {
   UnrolledModel um;  // host tables (bulk arrays are freed after upload)
   DevBuf<uint32_t> u_f_off, u_b_off, u_f_arc, u_b_arc, u_e_arc, u_pair_id;
   DevBuf<uint16_t> u_e_src, u_e_dst;
+  DevBuf<uint32_t> u_slot_of;  // cascade: parameter -> accumulator slot of the unrolled sweep (0xffffffff: locked)
   DevBuf<URec> u_f_rec, u_b_rec;  // packed tables (unrolled_args.hpp)
   DevBuf<uint16_t> u_e_slot, u_seq_sym;
   DevBuf<uint64_t> u_seq_off;

@@ -26,22 +26,27 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   std::vector<uint16_t> arc_slot((size_t)n_arcs * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
   uint32_t n_slots = 0;
   std::vector<double> uses;
+  std::vector<uint32_t> slot_of;  // cascade: parameter -> accumulator slot (0xffffffff: locked)
   if (!t->cascade) {
     if (n_arcs > UNROLLED_MAX_SLOTS) return CARMEL_HIP_OK;
     n_slots = (uint32_t)n_arcs;
     for (uint64_t a = 0; a < n_arcs; ++a) arc_slot[a * UNROLLED_MAX_CHAIN] = (uint16_t)a;
   } else {
-    if (t->n_params > UNROLLED_MAX_SLOTS || t->n_params > n_arcs) return CARMEL_HIP_OK;
-    n_slots = (uint32_t)t->n_params;
-    uses.assign(n_slots, 0.0);
+    // one accumulator per UNLOCKED parameter (a locked language model of 20 000 arcs under a 729-parameter channel
+    // needs 729 slots)
+    slot_of.assign(t->n_params, 0xffffffffu);
+    for (uint64_t p = 0; p < t->n_params; ++p)
+      if (t->h_param_group[p] != CARMEL_HIP_LOCKED_GROUP) slot_of[p] = n_slots++;
+    if (n_slots > UNROLLED_MAX_SLOTS || n_slots > n_arcs) return CARMEL_HIP_OK;
+    uses.assign(t->n_params, 0.0);
     for (uint64_t a = 0; a < n_arcs; ++a) {
       const uint32_t ch = t->w.group[a];
       uint32_t k = 0;
       for (uint64_t j = t->h_chain_off[ch]; j < t->h_chain_off[ch + 1]; ++j) {
         const uint64_t p = t->h_chain_param[j];
-        if (t->h_param_group[p] == CARMEL_HIP_LOCKED_GROUP) continue;
+        if (slot_of[p] == 0xffffffffu) continue;
         if (k == UNROLLED_MAX_CHAIN) return CARMEL_HIP_OK;  // longer chains: explicit lattices
-        arc_slot[a * UNROLLED_MAX_CHAIN + k++] = (uint16_t)p;
+        arc_slot[a * UNROLLED_MAX_CHAIN + k++] = (uint16_t)slot_of[p];
         uses[p] += 1.0;
       }
     }
@@ -118,6 +123,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {
     HIPCHK(t->u_param_uses.upload(uses, s));
+    HIPCHK(t->u_slot_of.upload(slot_of, s));
     HIPCHK(t->u_em_param.alloc(n_slots));
     HIPCHK(t->u_best_param.alloc(n_slots));
   }

@@ -444,14 +444,17 @@ __global__ void unrolled_reduce_kernel(const double* __restrict__ partial, uint3
 // (what chain_scatter_kernel produces from composed-arc counts); locked parameters get none
 __global__ void unrolled_param_counts_kernel(double* __restrict__ out, const double* __restrict__ counts,
                                              const double* __restrict__ uses, double floor_count,
-                                             const uint32_t* __restrict__ group, uint32_t n) {
+                                             const uint32_t* __restrict__ group, const uint32_t* __restrict__ slot_of,
+                                             uint32_t n) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  out[p] = group[p] != 0u ? counts[p] + floor_count * uses[p] : 0.0;
+  const uint32_t sl = slot_of[p];
+  out[p] = (group[p] != 0u && sl != 0xffffffffu) ? counts[sl] + floor_count * uses[p] : 0.0;
 }
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
-                                        const uint32_t* group, uint32_t n, hipStream_t s) {
-  hipLaunchKernelGGL(unrolled_param_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, counts, uses, floor_count, group, n);
+                                        const uint32_t* group, const uint32_t* slot_of, uint32_t n, hipStream_t s) {
+  hipLaunchKernelGGL(unrolled_param_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, counts, uses, floor_count, group,
+                     slot_of, n);
   return hipGetLastError();
 }
 
