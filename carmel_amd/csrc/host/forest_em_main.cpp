@@ -26,6 +26,7 @@ namespace {
 struct Opts {
   std::string forests_file, normgroups_file = "-0", initparam_file = "-0", outparam_file = "-", outcounts_file = "-0";
   long max_iter = 10000;            // --max-iter (forest-em-params.hpp:195)
+  long restarts = 0;                // -r / --random-restarts (forest-em-params.hpp:103, em.hpp:199-206)
   double converge_ratio = 1.0 / 65536;   // --converge, relative change of the average log prob (:197)
   double converge_delta = 1.0 / 65536;   // --deltaparam-epsilon (:198)
   double prior_counts = 0, add_k = 0;
@@ -100,6 +101,7 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "o" || key == "outparam-file") o.outparam_file = value(val);
     else if (key == "O" || key == "outcounts-file") o.outcounts_file = value(val);
     else if (key == "i" || key == "max-iter") o.max_iter = std::atol(value(val).c_str());
+    else if (key == "r" || key == "random-restarts") o.restarts = std::atol(value(val).c_str());
     else if (key == "e" || key == "converge") o.converge_ratio = std::atof(value(val).c_str());
     else if (key == "d" || key == "deltaparam-epsilon") o.converge_delta = std::atof(value(val).c_str());
     else if (key == "p" || key == "prior-counts-per") o.prior_counts = std::atof(value(val).c_str());
@@ -203,9 +205,13 @@ int main(int argc, char** argv) {
       for (size_t i = 0; i < lp.size(); ++i)
         log << "i=" << i << " sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
     } else {
-      // overrelaxed_em (em.hpp:107-216), one start, learning rate 1
-      double best = -std::numeric_limits<double>::infinity(), last = best;
+      // overrelaxed_em (em.hpp:107-216), learning rate 1, with its random restarts
+      double best = -std::numeric_limits<double>::infinity();
       std::vector<double> best_w = logw;
+      bool very_first = true;
+      long restarts_left = o.restarts;
+      for (uint32_t restart = 0;; ++restart) {
+      double last = -std::numeric_limits<double>::infinity();
       bool first = true;
       for (long it = 1; it <= o.max_iter; ++it) {
         double alp = 0;
@@ -214,11 +220,12 @@ int main(int argc, char** argv) {
         log << "i=" << it << " average log-prob=" << alp << " (2^" << alp / std::log(2.0) << " per forest";
         if (n_zero) log << ", " << n_zero << " forests with zero probability ignored";
         log << ")";
-        if (alp > best || first) {
+        if (alp > best || very_first) {
           best = alp;
           check(carmel_hip_forests_get_weights(F, best_w.data()), "carmel_hip_forests_get_weights");
           log << " (new best)";
         }
+        very_first = false;
         double rel = std::numeric_limits<double>::infinity();
         if (!first) {
           double la = std::fabs(last);
@@ -241,6 +248,17 @@ int main(int argc, char** argv) {
           break;
         }
         last = alp;
+      }
+      if (restarts_left <= 0) break;
+      --restarts_left;
+      log << "\nRandom restart - " << restarts_left << " remaining.\n";
+      // FForests::randomize (forest-em.hpp:393-399) -> NormalizeGroups::init_random (normalize.hpp:235-238): every rule of
+      // a norm group gets a random positive fraction (not normalised: the next M-step does that).  The draws come from
+      // this build's counter-based generator u(seed, restart, rule, 0) -- the reference's Boost stream is unpinned.
+      std::vector<double> rw(n_rules);
+      check(carmel_hip_forests_get_weights(F, rw.data()), "carmel_hip_forests_get_weights");
+      for (uint32_t r : group_rule) rw[r] = std::log(1.0 - carmel_hip_gibbs_uniform(o.seed, restart + 1, r, 0));
+      check(carmel_hip_forests_set_weights(F, rw.data()), "carmel_hip_forests_set_weights");
       }
       check(carmel_hip_forests_set_weights(F, best_w.data()), "carmel_hip_forests_set_weights");
       log << "Best average log-prob=" << best << "\n";

@@ -27,24 +27,34 @@ def parse_vec(txt):
     return np.array(out)
 
 
-def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 / 65536, init=None):
-    """em.hpp:107-216 for one start at rate 1, driven from Python over the oracle's estimate / maximize"""
+def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 / 65536, init=None, restarts=0, seed=1):
+    """em.hpp:107-216 at rate 1, driven from Python over the oracle's estimate / maximize; random restarts
+    (FForests::randomize -> NormalizeGroups::init_random) draw from the library's counter-based generator"""
     of = oracle.OracleForests(ftxt, ntxt)
     if init is not None:
         of.set_weights(init)
-    best, last, best_w, first, trace = -np.inf, -np.inf, of.weights(), True, []
-    for _ in range(max_iter):
-        alp = of.estimate()[0]
-        trace.append(alp)
-        if alp > best or first:
-            best, best_w = alp, of.weights()
-        rel = np.inf if first else (alp - last) / max(abs(last), 1e-5)
-        first = False
-        if rel < rel_eps:
-            break
-        if of.maximize() <= delta_eps:
-            break
-        last = alp
+    best, best_w, very_first, trace = -np.inf, of.weights(), True, []
+    for restart in range(restarts + 1):
+        last, first = -np.inf, True
+        for _ in range(max_iter):
+            alp = of.estimate()[0]
+            trace.append(alp)
+            if alp > best or very_first:
+                best, best_w = alp, of.weights()
+            very_first = False
+            rel = np.inf if first else (alp - last) / max(abs(last), 1e-5)
+            first = False
+            if rel < rel_eps:
+                break
+            if of.maximize() <= delta_eps:
+                break
+            last = alp
+        if restart < restarts:
+            from carmel_amd._capi import lib
+            w = of.weights()
+            for r in np.asarray(of.group_rule):
+                w[r] = math.log(1.0 - lib.carmel_hip_gibbs_uniform(seed, restart + 1, int(r), 0))
+            of.set_weights(w)
     return best, best_w, trace
 
 
@@ -64,6 +74,22 @@ def test_forest_em_cli_on_reference_sample(oracle, golden_dir, tmp_path):
     assert len(its) == len(trace)
     for (i, v), t in zip(its, trace):
         assert float(v) == pytest.approx(t, rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_random_restarts(oracle, golden_dir, tmp_path):
+    """forest-em -r 2 (em.hpp:199-206): two more starts from random parameters, the best start's parameters win"""
+    f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
+    out = tmp_path / "params"
+    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "12", "-r", "2", "--random-seed=5"])
+    assert rc == 0, err
+    assert err.count("Random restart") == 2
+    best, bw, trace = oracle_em(oracle, open(f).read(), open(n).read(), 12, restarts=2, seed=5)
+    its = re.findall(r"^i=(\d+) average log-prob=(\S+)", err, re.M)
+    assert len(its) == len(trace)
+    for (i, v), t in zip(its, trace):
+        assert float(v) == pytest.approx(t, rel=1e-5)
+    np.testing.assert_allclose(parse_vec(out.read_text()), np.exp(bw[1:]), rtol=1e-9, atol=1e-300)
 
 
 @pytest.mark.gpu
