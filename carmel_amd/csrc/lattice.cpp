@@ -1,6 +1,7 @@
 // lattice.cpp — see lattice.hpp.  Host C++ only (no HIP): builds lattices and the batched-CSR image.
 #include "lattice.hpp"
 #include <algorithm>
+#include <functional>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -857,17 +858,41 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   {
     const uint64_t nlane = out.lane_bwd.size();
     out.n_post = nlane + out.out_arcs.size();
+    // counting sort by arc id, stable in slot order.  Threads own contiguous arc ranges: each scans every record (a
+    // sequential read) and handles the records of its own arcs, so counters and output stay private and local.
     std::vector<uint64_t> cnt(w.n_arcs + 1, 0);
-    for (uint64_t k = 0; k < nlane; ++k)
-      if (out.lane_bwd[k].x & LANE_VALID) cnt[out.lane_bwd[k].y + 1]++;
-    for (const auto& r : out.out_arcs) cnt[r.y + 1]++;
+    const int ns = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (nlane + out.out_arcs.size()) / (1u << 16)));
+    auto arc_lo = [&](int t) { return (uint64_t)((__uint128_t)w.n_arcs * (uint64_t)t / (uint64_t)ns); };
+    auto in_threads = [&](const std::function<void(int)>& f) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < ns; ++t) th.emplace_back(f, t);
+      f(0);
+      for (auto& x : th) x.join();
+    };
+    in_threads([&](int t) {
+      const uint64_t lo = arc_lo(t), hi = arc_lo(t + 1);
+      for (uint64_t k = 0; k < nlane; ++k) {
+        const uint2_t r = out.lane_bwd[k];
+        if ((r.x & LANE_VALID) && r.y >= lo && r.y < hi) cnt[r.y + 1]++;
+      }
+      for (const auto& r : out.out_arcs)
+        if (r.y >= lo && r.y < hi) cnt[r.y + 1]++;
+    });
     for (uint64_t a = 0; a < w.n_arcs; ++a) cnt[a + 1] += cnt[a];
     const uint64_t total = cnt[w.n_arcs];
     out.arc_off = cnt;  // offsets before the fill pass advances the cursors
     out.slot_pos.resize(total);
-    for (uint64_t k = 0; k < nlane; ++k)
-      if (out.lane_bwd[k].x & LANE_VALID) out.slot_pos[cnt[out.lane_bwd[k].y]++] = k;
-    for (uint64_t k = 0; k < out.out_arcs.size(); ++k) out.slot_pos[cnt[out.out_arcs[k].y]++] = nlane + k;
+    in_threads([&](int t) {
+      const uint64_t lo = arc_lo(t), hi = arc_lo(t + 1);
+      for (uint64_t k = 0; k < nlane; ++k) {
+        const uint2_t r = out.lane_bwd[k];
+        if ((r.x & LANE_VALID) && r.y >= lo && r.y < hi) out.slot_pos[cnt[r.y]++] = k;
+      }
+      for (uint64_t k = 0; k < out.out_arcs.size(); ++k) {
+        const uint32_t a = out.out_arcs[k].y;
+        if (a >= lo && a < hi) out.slot_pos[cnt[a]++] = nlane + k;
+      }
+    });
     for (uint64_t a = 0; a < w.n_arcs; ++a)
       if (out.arc_off[a + 1] - out.arc_off[a] > 64)
         for (uint64_t j = out.arc_off[a]; j < out.arc_off[a + 1]; j += 4096) {
