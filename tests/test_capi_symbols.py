@@ -58,3 +58,19 @@ def test_annealing_schedule(oracle):
             line = hi if n == 0 else hi + (lo - hi) * min(t, n) / n
             assert abs(1.0 / got - line) < 1e-6 * line
     assert lib.carmel_hip_gibbs_power(0.0, 0.0, 10, 3) == 1.0  # a zeroed options struct means no annealing
+
+
+def test_committed_profiles_agree():
+    """profiles/: the E-step time bench.py measured with HIP events equals the sum of the E-step kernels' average
+    durations in the rocprofv3 --kernel-trace --stats summary of the same command (within 5 %)"""
+    import csv
+    import json
+    bench = json.load(open(os.path.join(ROOT, "profiles", "r1_v16_c4_bench.json")))
+    names = ("trans_w_bucket_kernel", "trans_w_tile_kernel", "sweep_lane_kernel", "trans_c_tile_kernel", "trans_c_bucket_kernel")
+    total = 0.0
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r1_v16_c4_kernel_stats.csv"))):
+        if any(n in r["Name"] for n in names):
+            total += float(r["AverageNs"]) * 1e-6
+    assert abs(total - bench["roofline"]["kernel_ms"]) < 0.05 * total
+    assert bench["roofline"]["frac"] == bench["roofline"]["achieved"] / bench["roofline"]["peak"]
+    assert bench["roofline"]["traffic"] > bench["roofline"]["algorithmic_bytes_per_launch"]
