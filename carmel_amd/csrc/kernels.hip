@@ -944,8 +944,11 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   if (A.pre_weights) {
     switch (V) {  // streaming only: two chunks ahead is enough, and the smaller ring leaves more registers / less code
       case 1: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);
-      case 2: return launch_lane_variant<3, 1, true>(A, lc.count, lds, stream);
-      default: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
+      case 2: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
+      case 3: return launch_lane_variant<4, 1, true>(A, lc.count, lds, stream);
+      case 4: return launch_lane_variant<5, 1, true>(A, lc.count, lds, stream);
+      case 5: return launch_lane_variant<3, 2, true>(A, lc.count, lds, stream);
+      default: return launch_lane_variant<3, 1, true>(A, lc.count, lds, stream);
     }
   }
   switch (V) {
