@@ -20,10 +20,11 @@ SYMBOLS = [
     "carmel_hip_estimate_finish", "carmel_hip_counts_dev", "carmel_hip_counts_len", "carmel_hip_stream",
     "carmel_hip_use_external_counts", "carmel_hip_synchronize", "carmel_hip_last_sweep_ms", "carmel_hip_read_scalars",
     "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_keep_em_weights", "carmel_hip_random_restart", "carmel_hip_save_counts",
+    "carmel_hip_fractional_counts", "carmel_hip_set_digamma",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
-    "carmel_hip_gibbs_run", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
+    "carmel_hip_gibbs_run", "carmel_hip_gibbs_run_ex", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
@@ -34,7 +35,8 @@ SYMBOLS = [
 class LatticeStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_pairs", "n_pairs_kept", "explored_states", "explored_arcs", "kept_states", "kept_arcs",
-        "n_cyclic_pairs", "n_bundles", "max_levels", "device_bytes")] + [("build_seconds", C.c_double)]
+        "n_cyclic_pairs", "n_bundles", "max_levels", "device_bytes")] + [("build_seconds", C.c_double)] + [
+            (n, C.c_uint64) for n in ("last_pair_explored_states", "last_pair_kept_states", "last_pair_kept_arcs")]
 
 
 class EstimateResult(C.Structure):
@@ -63,11 +65,14 @@ def _load():
     lib.carmel_hip_counts_dev.restype = C.c_void_p
     lib.carmel_hip_stream.restype = C.c_void_p
     lib.carmel_hip_counts_len.restype = C.c_uint64
-    for s in SYMBOLS:
-        f = getattr(lib, s)
-        if f.restype is C.c_int or f.restype is None:
-            pass
     vp = C.c_void_p
+    lib.carmel_hip_last_error.argtypes = []
+    lib.carmel_hip_device_count.argtypes = []
+    lib.carmel_hip_random_restart.argtypes = [vp, C.c_uint64, C.c_uint32]
+    lib.carmel_hip_keep_em_weights.argtypes = [vp]
+    lib.carmel_hip_fractional_counts.argtypes = [vp]
+    lib.carmel_hip_set_digamma.argtypes = [vp, C.c_uint32, vp, vp]
+    lib.carmel_hip_forests_set_alphas.argtypes = [vp, vp, C.c_uint32]
     lib.carmel_hip_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, C.c_uint32, C.c_uint64, vp, vp, vp, vp, vp, vp]
     lib.carmel_hip_destroy.argtypes = [vp]
     lib.carmel_hip_set_corpus.argtypes = [vp, C.c_uint64, vp, vp, vp, vp, vp]
@@ -118,6 +123,7 @@ def _load():
     lib.carmel_hip_gibbs_best_run.argtypes = [vp]
     lib.carmel_hip_gibbs_best_run.restype = C.c_uint32
     lib.carmel_hip_gibbs_run.argtypes = [vp, vp, vp]
+    lib.carmel_hip_gibbs_run_ex.argtypes = [vp, vp, vp, vp]
     lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.carmel_hip_gibbs_uniform.restype = C.c_double
@@ -135,6 +141,9 @@ def _load():
     lib.carmel_hip_forests_get_sample.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_forests_max_sample.argtypes = [vp]
     lib.carmel_hip_forests_max_sample.restype = C.c_uint32
+    for s in SYMBOLS:  # a prototype for every entry point: without one ctypes passes Python ints as C int (64-bit seeds
+        if getattr(lib, s).argtypes is None:  # and bare handles would be truncated)
+            raise ImportError("carmel_amd: no ctypes prototype for %s" % s)
     return lib
 
 

@@ -267,6 +267,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     stats->max_levels = L.max_levels;
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    stats->last_pair_explored_states = L.last_pre_states;
+    stats->last_pair_kept_states = L.last_post_states;
+    stats->last_pair_kept_arcs = L.last_post_arcs;
   }
   return CARMEL_HIP_OK;
 }
@@ -275,11 +278,17 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
 static int build_ties(carmel_hip_trainer* t, uint64_t n, const uint32_t* member, const uint32_t* group) {
   std::vector<uint32_t> tie_of(n, 0xffffffffu);
   std::unordered_map<uint64_t, uint32_t> ids;
+  t->any_locked = false;
+  t->h_tie_member.clear();
   for (uint64_t k = 0; k < n; ++k) {
+    if (group[k] == CARMEL_HIP_LOCKED_GROUP) t->any_locked = true;
     if (group[k] == CARMEL_HIP_NO_GROUP || group[k] == CARMEL_HIP_LOCKED_GROUP) continue;
     const uint64_t key = ((uint64_t)(member ? member[k] : 0) << 32) | group[k];
     auto it = ids.find(key);
-    if (it == ids.end()) it = ids.emplace(key, (uint32_t)ids.size()).first;
+    if (it == ids.end()) {
+      it = ids.emplace(key, (uint32_t)ids.size()).first;
+      t->h_tie_member.push_back(member ? member[k] : 0);
+    }
     tie_of[k] = it->second;
   }
   t->n_ties = ids.size();
@@ -301,6 +310,10 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
   std::vector<double> add;
   std::unordered_map<uint64_t, uint32_t> ids;
   ids.reserve(n);
+  t->h_group_member.clear();
+  t->any_digamma = false;
+  t->dig_alpha.release();
+  t->tie_alpha.release();
   // key: member | state | (input symbol or ~0 for JOINT).  States and symbols are 32-bit, members few: two maps
   // deep would be simpler but slower; mix into 64 bits + verify by construction (member < 2^8, state < 2^32,
   // symbol < 2^24 are checked).
@@ -319,6 +332,7 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       uint32_t id = (uint32_t)add.size();
       ids.emplace(key, id);
       add.push_back(addc[m]);
+      t->h_group_member.push_back(m);
       norm_of[k] = id;
     } else
       norm_of[k] = it->second;
@@ -391,11 +405,18 @@ int carmel_hip_set_prior(carmel_hip_trainer* t, double smooth_floor, int weight_
   t->smooth_floor = smooth_floor;
   uint64_t n = t->w.n_arcs;  // the prior belongs to the (composed) arc table (derivations.h:96-101)
   std::vector<double> pr(n, smooth_floor > 0 ? smooth_floor : 0.0);
+  t->h_arc_prior_w.clear();
+  t->arc_prior_w.release();
   if (weight_is_prior_count) {
     std::vector<double> lw(n);
     HIPCHK(hipMemcpyAsync(lw.data(), t->arc_logw.p, n * sizeof(double), hipMemcpyDeviceToHost, t->stream));
     HIPCHK(hipStreamSynchronize(t->stream));
     for (uint64_t k = 0; k < n; ++k) pr[k] += std::exp(lw[k]);
+    if (t->cascade) {  // a cascade's M-step adds the scalar -f per composed arc; -U adds the arc's own initial weight
+      t->h_arc_prior_w.resize(n);
+      for (uint64_t k = 0; k < n; ++k) t->h_arc_prior_w[k] = std::exp(lw[k]);
+      HIPCHK(t->arc_prior_w.upload(t->h_arc_prior_w, t->stream));
+    }
   }
   t->prior_nonzero = false;
   for (double x : pr)
@@ -457,6 +478,13 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
   MstepArgs M;
   M.logw = t->params();
+  M.lw_src = M.logw;
+  if (t->norm_span && !t->any_digamma && !t->n_ties && (!use_counts || t->any_locked)) {
+    // the one-pass kernel reads the weights of its halo, which its neighbours are rewriting: give it a snapshot
+    if (t->mstep_snap.n != t->np()) HIPCHK(t->mstep_snap.alloc(t->np()));
+    HIPCHK(hipMemcpyAsync(t->mstep_snap.p, M.logw, t->np() * sizeof(double), hipMemcpyDeviceToDevice, s));
+    M.lw_src = t->mstep_snap.p;
+  }
   M.old_logw = t->old_logw.p;
   M.counts = t->pcounts();
   M.prior = (!t->cascade && t->have_prior && t->prior_nonzero) ? t->prior.p : nullptr;
@@ -477,7 +505,9 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.glocked = t->glocked.p;
   M.n_ties = t->n_ties;
   M.all_grouped = t->all_grouped ? 1 : 0;
-  M.window_span = t->norm_span;
+  M.window_span = t->any_digamma ? 0u : t->norm_span;  // the one-pass kernel knows the linear scale only
+  M.dig_alpha = t->any_digamma ? t->dig_alpha.p : nullptr;
+  M.tie_alpha = (t->any_digamma && t->n_ties) ? t->tie_alpha.p : nullptr;
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();
   M.save_old = save_old;
@@ -763,6 +793,7 @@ int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts) {
   return CARMEL_HIP_OK;
 }
 
+static int cascade_param_counts(carmel_hip_trainer* t, hipStream_t s);
 int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
@@ -771,15 +802,8 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
   if (t->cascade) {
     // distribute_counts (cascade.h:318-325): parameter counts = sum over composed arcs using it of
     // (composed count + composed prior)
-    if (t->unrolled) {  // the sweep accumulated per parameter already
-      HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->counts_ptr(), t->u_param_uses.p,
-                                          t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
-                                          t->u_slot_of.p, (uint32_t)t->n_params, s));
-    } else {
-      HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
-      HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
-                                  t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
-    }
+    int rcc = cascade_param_counts(t, s);
+    if (rcc) return rcc;
   }
   int rc = run_mstep(t, 1, 1);
   if (rc) return rc;
@@ -805,6 +829,67 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
     HIPCHK(hipStreamSynchronize(s));
   }
   if (max_change) *max_change = result;
+  return CARMEL_HIP_OK;
+}
+
+// distribute_counts on the current counts (shared by maximize and fractional_counts)
+static int cascade_param_counts(carmel_hip_trainer* t, hipStream_t s) {
+  if (t->unrolled) {  // the sweep accumulated per parameter already
+    HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->counts_ptr(), t->u_param_uses.p,
+                                        t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->u_param_wprior.p, t->param_group_c.p,
+                                        t->u_slot_of.p, (uint32_t)t->n_params, s));
+  } else {
+    HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
+    HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
+                                t->arc_prior_w.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p,
+                                t->w.n_arcs, s));
+  }
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_fractional_counts(carmel_hip_trainer* t) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  hipStream_t s = t->stream;
+  if (t->cascade) {
+    int rc = cascade_param_counts(t, s);
+    if (rc) return rc;
+    HIPCHK(launch_counts_to_logw(t->param_logw_c.p, t->param_counts_c.p, nullptr, t->param_group_c.p, t->n_params, s));
+  } else {
+    HIPCHK(launch_counts_to_logw(t->arc_logw.p, t->counts_ptr(), (t->have_prior && t->prior_nonzero) ? t->prior.p : nullptr,
+                                 t->arc_group.p, t->w.n_arcs, s));
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_set_digamma(carmel_hip_trainer* t, uint32_t n_members, const double* alpha, const uint8_t* enabled) {
+  if (!t || !alpha || !enabled) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
+  HIPCHK(hipSetDevice(t->device));
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  std::vector<double> ga(t->h_group_member.size(), nan), ta(t->h_tie_member.size(), nan);
+  bool any = false;
+  for (size_t g = 0; g < ga.size(); ++g) {
+    const uint32_t m = t->h_group_member[g];
+    if (m < n_members && enabled[m]) {
+      ga[g] = alpha[m];
+      any = true;
+    }
+  }
+  for (size_t k = 0; k < ta.size(); ++k) {
+    const uint32_t m = t->h_tie_member[k];
+    if (m < n_members && enabled[m]) ta[k] = alpha[m];
+  }
+  t->any_digamma = any;
+  if (any) {
+    HIPCHK(t->dig_alpha.upload(ga, t->stream));
+    HIPCHK(t->tie_alpha.upload(ta, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+  } else {
+    t->dig_alpha.release();
+    t->tie_alpha.release();
+  }
   return CARMEL_HIP_OK;
 }
 
@@ -873,14 +958,15 @@ int carmel_hip_load_best(carmel_hip_trainer* t) {
   // load_best + use_counts_final (train.cc:673-674, cascade.h:358-364): best composed counts -> parameters
   if (t->unrolled) {
     HIPCHK(launch_unrolled_param_counts(t->param_counts_c.p, t->u_best_param.p, t->u_param_uses.p,
-                                        t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->param_group_c.p,
+                                        t->smooth_floor > 0 ? t->smooth_floor : 0.0, t->u_param_wprior.p, t->param_group_c.p,
                                         t->u_slot_of.p, (uint32_t)t->n_params, s));
   } else {
     HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemsetAsync(t->param_counts_c.p, 0, t->param_counts_c.bytes(), s));
-    // the saved value already includes the composed prior (prep_new_weights ran before it was saved)
+    // the saved value is the composed COUNT of the best iteration; the composed prior is added here, as maximize does
     HIPCHK(launch_chain_scatter(t->param_counts_c.p, t->counts_ptr(), t->smooth_floor > 0 ? t->smooth_floor : 0.0,
-                                t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p, t->w.n_arcs, s));
+                                t->arc_prior_w.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p,
+                                t->w.n_arcs, s));
   }
   int rc = run_mstep(t, 1, 1);
   if (rc) return rc;

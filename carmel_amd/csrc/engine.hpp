@@ -65,6 +65,8 @@ struct carmel_hip_trainer {
   uint64_t n_params = 0, n_chains = 0;
   // M-step state over parameters
   DevBuf<double> old_logw, em_logw, best_logw, prior;
+  DevBuf<double> mstep_snap;  // immutable copy of the weights for the one-pass M-step (see MstepArgs::lw_src)
+  bool any_locked = false;    // some parameter is locked (group 0): its weight enters its group's sum
   DevBuf<uint32_t> norm_of;
   // tied arcs (!N, fst.cc:107-152): dense tie index per parameter (0xffffffff = not tied) and the per-tie tables
   DevBuf<uint32_t> tie_of;
@@ -73,6 +75,12 @@ struct carmel_hip_trainer {
   uint64_t n_ties = 0;
   DevBuf<uint64_t> group_off, norm_perm, big_groups;
   DevBuf<double> add_count, gscale;
+  DevBuf<double> dig_alpha, tie_alpha;  // --digamma: per norm group / per tie (NaN = linear); empty when unused
+  bool any_digamma = false;
+  std::vector<uint32_t> h_group_member, h_tie_member;  // member transducer of every norm group / tie
+  DevBuf<double> arc_prior_w;           // cascade + carmel -U: initial weight of every composed arc (added to -f)
+  std::vector<double> h_arc_prior_w;
+  DevBuf<double> u_param_wprior;        // ... summed per parameter for the unrolled sweep
   bool any_add_count = false;
   DevBuf<unsigned long long> maxchg;
   uint64_t n_norm_groups = 0;

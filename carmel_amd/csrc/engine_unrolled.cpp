@@ -25,7 +25,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   const uint64_t n_arcs = t->w.n_arcs;
   std::vector<uint16_t> arc_slot((size_t)n_arcs * UNROLLED_MAX_CHAIN, (uint16_t)UNROLLED_NO_SLOT);
   uint32_t n_slots = 0;
-  std::vector<double> uses;
+  std::vector<double> uses, wprior;
   std::vector<uint32_t> slot_of;  // cascade: parameter -> accumulator slot (0xffffffff: locked)
   if (!t->cascade) {
     if (n_arcs > UNROLLED_MAX_SLOTS) return CARMEL_HIP_OK;
@@ -39,6 +39,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
       if (t->h_param_group[p] != CARMEL_HIP_LOCKED_GROUP) slot_of[p] = n_slots++;
     if (n_slots > UNROLLED_MAX_SLOTS || n_slots > n_arcs) return CARMEL_HIP_OK;
     uses.assign(t->n_params, 0.0);
+    if (!t->h_arc_prior_w.empty()) wprior.assign(t->n_params, 0.0);  // carmel -U
     for (uint64_t a = 0; a < n_arcs; ++a) {
       const uint32_t ch = t->w.group[a];
       uint32_t k = 0;
@@ -48,6 +49,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
         if (k == UNROLLED_MAX_CHAIN) return CARMEL_HIP_OK;  // longer chains: explicit lattices
         arc_slot[a * UNROLLED_MAX_CHAIN + k++] = (uint16_t)slot_of[p];
         uses[p] += 1.0;
+        if (!wprior.empty()) wprior[p] += t->h_arc_prior_w[a];
       }
     }
   }
@@ -123,6 +125,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   HIPCHK(t->u_partial.alloc((size_t)t->u_n_wg * n_slots));
   if (t->cascade) {
     HIPCHK(t->u_param_uses.upload(uses, s));
+    HIPCHK(t->u_param_wprior.upload(wprior, s));
     HIPCHK(t->u_slot_of.upload(slot_of, s));
     HIPCHK(t->u_em_param.alloc(n_slots));
     HIPCHK(t->u_best_param.alloc(n_slots));
@@ -149,6 +152,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
     stats->kept_states = M.lattice_states;
     stats->kept_arcs = M.lattice_arcs;
     stats->n_bundles = 0;  // nothing is laid out: the lattices are implicit
+    stats->last_pair_explored_states = stats->last_pair_kept_states = stats->last_pair_kept_arcs = 0;  // not tracked per pair
     stats->max_levels = M.max_len + 1;
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

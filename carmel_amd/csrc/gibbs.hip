@@ -67,7 +67,9 @@ struct GibbsArgs {
   int par_books;               // exact mode: count bookkeeping of a block by the whole workgroup (g_addc_all / g_block_probs)
   uint32_t books_cap;          // ids of one sample the workgroup's LDS scratch holds
   uint32_t stage_arcs, stage_states;  // exact mode: a block's lattice at most this large is staged in LDS (0: never)
-  double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob
+  double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob, [2] see want_after
+  int want_after;              // exact mode: also the proposal prob of every block evaluated AFTER its new sample was
+                               // added back (the "overestimate" of the comment at gibbs.hpp:866)
   uint64_t seed;
   uint32_t n_blocks, iter;
   double time, power;
@@ -183,6 +185,21 @@ __device__ __forceinline__ void g_block_probs(const GibbsArgs& G, const uint32_t
     red[0] += (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
     red[1] += (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
   }
+  __syncthreads();
+}
+
+// the proposal probability of a block's sample with the sample itself counted (whole workgroup; red[2])
+__device__ __forceinline__ void g_block_after(const GibbsArgs& G, const uint32_t* ids, uint32_t n, double* red) {
+  double v = 0.0;
+  for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+    const uint32_t p = ids[k], nn = G.p_norm[p];
+    v += log(nn == G_NONORM ? G.p_prior[p] : G.p_x[p] / G.normsum[nn]);
+  }
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) red[2] += (part[0] + part[1]) + (part[2] + part[3]);
   __syncthreads();
 }
 
@@ -380,26 +397,32 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     }
     __syncthreads();
   }
+  if (!SNAP && G.want_after && !G.expectation) {
+    __threadfence_block();
+    __syncthreads();
+    g_block_after(G, ids, G.sample_len[b] & 0x7fffffffu, red);
+  }
 }
 
 // mode 0: the whole sweep in one workgroup, blocks strictly in order
 __global__ __launch_bounds__(256) void gibbs_sweep_exact_kernel(GibbsArgs G) {
   extern __shared__ uint32_t books[];  // 2 * G.books_cap ids: scratch of g_block_probs
-  __shared__ double red[2];
-  if (threadIdx.x == 0) red[0] = red[1] = 0.0;
+  __shared__ double red[3];
+  if (threadIdx.x == 0) red[0] = red[1] = red[2] = 0.0;
   __syncthreads();
   for (uint32_t b = 0; b < G.n_blocks; ++b) g_resample_block<false>(G, b, books, 0, red);
   if (threadIdx.x == 0) {
     G.iter_out[0] = red[1];
     G.iter_out[1] = red[0];
+    G.iter_out[2] = red[2];
   }
 }
 
 // mode 1: blocks spread over the grid, counterfactual counts from the snapshot
 __global__ __launch_bounds__(64) void gibbs_sweep_parallel_kernel(GibbsArgs G, uint32_t own_cap) {
   extern __shared__ uint32_t own_ids[];
-  __shared__ double red[2];
-  if (threadIdx.x == 0) red[0] = red[1] = 0.0;
+  __shared__ double red[3];
+  if (threadIdx.x == 0) red[0] = red[1] = red[2] = 0.0;
   __syncthreads();
   for (uint32_t b = blockIdx.x; b < G.n_blocks; b += gridDim.x) g_resample_block<true>(G, b, own_ids, own_cap, red);
   if (threadIdx.x == 0) unsafeAtomicAdd(G.iter_out + 1, red[0]);
@@ -586,7 +609,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
     HIPCHK(g->alpha.alloc(L.out_off.size()));
     HIPCHK(g->ewt.alloc(L.out_arcs.size()));
   }
-  HIPCHK(g->iter_out.alloc(2));
+  HIPCHK(g->iter_out.alloc(4));
   HIPCHK(hipStreamSynchronize(s));
   *out = g.release();
   return CARMEL_HIP_OK;
@@ -606,7 +629,12 @@ uint32_t carmel_hip_gibbs_n_blocks(carmel_hip_gibbs* g) { return g ? g->n_blocks
 // gibbs_base::run (gibbs.hpp:803-828): restore_p0, the initial sample (iteration 0), then iter = 1..Ni with
 // time = max(0, iter - burnin); finally finalize_cumulative_counts (gibbs.hpp:626-638).
 int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob) {
+  return carmel_hip_gibbs_run_ex(g, iter_logprob, iter_cheap_logprob, nullptr);
+}
+int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob, double* iter_after_logprob) {
   if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  if (iter_after_logprob && (g->opt.mode != 0 || g->opt.expectation))
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "the after-add-back sample probability exists in the exact sampling mode only");
   carmel_hip_trainer* t = g->t;
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
@@ -648,6 +676,7 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
   G.stage_arcs = getenv("CARMEL_HIP_GIBBS_NO_STAGE") ? 0u : 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
   G.stage_states = 1024u;                                           // 1024 states sweep and walk out of LDS
   G.iter_out = g->iter_out.p;
+  G.want_after = iter_after_logprob ? 1 : 0;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
   const uint32_t Ni = g->opt.iter, burnin = std::min(g->opt.burnin, g->opt.iter);
@@ -673,7 +702,7 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
     G.init_logw = (run == 0 && iter == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
-    HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 2 * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 4 * sizeof(double), s));
     if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -705,12 +734,13 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
       G.new_len = g->new_len.p;
     }
     HIPCHK(hipGetLastError());
-    double io[2];
+    double io[3];
     HIPCHK(hipMemcpyAsync(io, g->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const double plog = g->opt.mode == 0 ? io[0] : io[1];
     if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
     if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[1];
+    if (iter_after_logprob) iter_after_logprob[(size_t)run * (Ni + 1) + iter] = io[2];
     if (iter >= g->opt.burnin) {  // gibbs.hpp:942-943
       st_all += plog;
       st_final = plog;

@@ -1,8 +1,14 @@
 // carmel_main.cpp — `carmel`-compatible command line for the training path, running on the GPU through the C-ABI
 // (include/carmel_hip.h).  Accepts the training subset of carmel's switches (carmel.cc:929-1066):
 //
-//   carmel [-t] [--train-cascade] [-M n] [-e d] [-X r] [-f w] [-U] [-u | -j] [-? | -:] [-q] [-d] [-K] [-m] [-T n]
-//          [-F out] [-H] [-J] [-Z] [-D] [--normby=JCN..] [--priors=a,b,..] [--gpu=n] corpus transducer [transducer ...]
+//   carmel [-t] [--train-cascade] [-M n] [-e d] [-X r] [-f w] [-U] [-u | -j] [-? | -:] [-q] [-d] [-K] [-m] [-T n] [-a]
+//          [-F out] [-H] [-J] [-Z] [-D] [-B] [-2] [-+ alpha] [--normby=JCN..] [--priors=a,b,..] [--digamma=a,,b] [--gpu=n]
+//          corpus transducer [transducer ...]
+//   carmel -S pairs transducer [transducer ...]      sum-of-paths probability of every pair (carmel.cc:1393-1410)
+//
+// A switch or option this front end does not implement is REFUSED (exit -12, like carmel's "No inputs supplied",
+// carmel.cc:1137) rather than accepted and ignored: a drop-in that silently computes something else is worse than one
+// that says no.
 //
 // With one transducer the trained transducer goes to stdout (or -F file); with --train-cascade every member is
 // written to <file>.trained (cascade.h:23-32).  EM log lines on stderr have the reference's wording
@@ -44,6 +50,10 @@ static std::string base2(double ln_value) {  // weight.h:529-532,603 as_base(2) 
   return buf;
 }
 
+struct UsageError : std::runtime_error {
+  explicit UsageError(const std::string& m) : std::runtime_error(m) {}
+};
+
 struct Options {
   bool flags[256] = {false};
   bool train_cascade = false;
@@ -55,13 +65,18 @@ struct Options {
   long max_iter = 500;  // train_opts default (fst.h:1080-1095); -1 == "-M" without a number
   double converge = 1e-4, converge_ppx_ratio = .999, smooth_floor = 0;
   int norm = CARMEL_HIP_NORM_CONDITIONAL;
-  std::string normby, priors, out_file;
+  std::string normby, priors, out_file, digamma;
+  bool have_digamma = false;       // --digamma=... (carmel.cc:495)
+  bool plus_alpha_set = false;     // -+ a (carmel.cc:1009-1013): mean-field scale of the single transducer's method
+  double plus_alpha = 0;
   int index_threshold = 32, gpu = 0;
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
   long crp_restarts = 0;     // --crp-restarts (carmel.cc:271-273)
   long init_em = 0;          // --init-em=N, --em-p0 (carmel.cc:276-277; gibbs.cc:400-423)
   bool em_p0 = false;
+  bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
+  bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   std::string load_fem_param;                              // --load-fem-param (carmel.cc:790-799; cascade.h:180-202)
@@ -131,6 +146,10 @@ static Options parse_args(int argc, char** argv) {
         o.init_em = std::atol(v.c_str());
       else if (k == "em-p0")
         o.em_p0 = true;
+      else if (k == "init-from-p0")
+        o.init_from_p0 = true;
+      else if (k == "sample-prob-after")  // not a carmel option (its old builds logged this as "sample prob")
+        o.sample_prob_after = true;
       else if (k == "crp-restarts")
         o.crp_restarts = std::atol(v.c_str());
       else if (k == "crp-argmax-final")
@@ -141,8 +160,13 @@ static Options parse_args(int argc, char** argv) {
         o.exclude_prior = true;
       else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
         o.crp_parallel = true;
-      else
-        std::cerr << "option " << k << " = " << v << " (ignored by the GPU training front end)\n";
+      else if (k == "digamma") {
+        o.digamma = v;
+        o.have_digamma = true;
+      } else if (k == "help") {
+        o.flags[(unsigned)'h'] = true;
+      } else
+        throw UsageError("option --" + k + " is not implemented by the GPU training front end");
       continue;
     }
     if (a.size() > 1 && a[0] == '-') {
@@ -176,7 +200,16 @@ static Options parse_args(int argc, char** argv) {
           case 'o':  // learning rate growth factor of over-relaxed EM (carmel.cc:940-943)
             o.rate_growth = std::max(1.0, std::atof(value()));
             break;
-          default: break;
+          case '+':  // pseudo-Dirichlet-process normalisation exp(digamma(alpha + w)) (carmel.cc:1009-1013)
+            o.plus_alpha = std::atof(value());
+            o.plus_alpha_set = true;
+            break;
+          default:
+            // switches without a value that this front end implements; everything else carmel knows (k-best, generation,
+            // projection, pruning, OpenFst, ...) is outside the training path
+            if (!std::strchr("tUujnlqdKmHJZDB2?:caSh", a[j]))
+              throw UsageError(std::string("switch -") + a[j] + " is not implemented by the GPU training front end");
+            break;
         }
       continue;
     }
@@ -204,16 +237,32 @@ struct CorpusStats {  // training_corpus counters over the pairs that have a der
 static int run(int argc, char** argv) {
   Options o = parse_args(argc, argv);
   const bool training = o.flags[(unsigned)'t'];
-  if (o.files.empty() || (training && o.files.size() < 2)) {
+  const bool scoring = !training && o.flags[(unsigned)'S'];  // carmel.cc:1134: -t overrides -S
+  const bool with_pairs = training || scoring;
+  if (o.flags[(unsigned)'h']) {
+    std::cout << "carmel (MI355X training front end): -t / --train-cascade / --crp / -S over carmel's transducer and corpus "
+                 "files; switches: -t -M -e -X -f -U -u -j -n -o -! -a -S -q -d -K -m -T -F -R -H -J -Z -D -B -2 -+ -? -: -c; "
+                 "see INTEGRATION.md\n";
+    return 0;
+  }
+  if (o.files.empty() || (with_pairs && o.files.size() < 2)) {
     std::cerr << "usage: carmel -t [--train-cascade] [-M n] [-e d] [-X r] [-f w] [-U] [-u|-j] [-HJZD] [-F out] "
                  "corpus transducer [transducer ...]\n"
                  "       carmel [-HJZD] transducer [transducer ...]     (compose and print; host only)\n";
     return -12;
   }
   const bool quiet = o.flags[(unsigned)'q'];
-  if (!training) o.files.insert(o.files.begin(), (const char*)0);  // no corpus argument
+  if (!with_pairs) o.files.insert(o.files.begin(), (const char*)0);  // no corpus argument
   const size_t nw = o.files.size() - 1;
-  std::string corpus_text = training ? slurp(o.files[0]) : std::string();
+  std::string corpus_text = with_pairs ? slurp(o.files[0]) : std::string();
+  // weight output (carmel.cc:76-101): -Z always / -D never in log form; a weight in log form is e^x, `x ln` (-2) or
+  // `x log` base 10 (-B)
+  int wstyle = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
+  if (o.flags[(unsigned)'D']) wstyle = W_NEVER_LOG;
+  if (o.flags[(unsigned)'B'])
+    wstyle |= W_BASE_LOG10;
+  else if (o.flags[(unsigned)'2'])
+    wstyle |= W_BASE_LN;
   std::vector<Transducer> member(nw);
   for (size_t i = 0; i < nw; ++i) {
     try {
@@ -251,13 +300,13 @@ static int run(int argc, char** argv) {
   const bool cascade = o.train_cascade && nw > 1;
   if (nw > 1) {
     for (size_t i = 0; i < nw; ++i) params.add_member(member[i]);
-    Composer comp(params, chains, (unsigned)o.index_threshold);
+    Composer comp(params, chains, (unsigned)o.index_threshold, /*trivial=*/!o.train_cascade);
     Operand A, B;
     for (size_t i = 1; i < nw; ++i) {
       A.bind(result, i > 1, params.member_base[0]);
       B.bind(&member[i], false, params.member_base[i]);
       std::unique_ptr<Transducer> next(new Transducer());
-      if (!comp.run(A, B, *next)) {
+      if (!(o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next) : comp.run(A, B, *next))) {  // carmel.cc:1318
         std::cerr << ")\nEmpty or invalid result of composition with transducer \"" << o.files[i + 1] << "\".\n";
         return -3;
       }
@@ -274,9 +323,8 @@ static int run(int argc, char** argv) {
     }
     if (!quiet) std::cerr << std::endl;
   }
-  if (!training) {  // plain `carmel a b ...`: print the (reduced) composition — no GPU involved
-    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
-    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
+  if (!with_pairs) {  // plain `carmel a b ...`: print the (reduced) composition — no GPU involved
+    const int ws = wstyle;
     if (o.flags[(unsigned)'c'])
       std::cout << "Number of states in result: " << result->states.size() << "\nNumber of arcs in result: "
                 << result->num_arcs() << "\n";
@@ -284,9 +332,6 @@ static int run(int argc, char** argv) {
       std::cout << result->to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
     return 0;
   }
-  if (nw > 1 && !cascade)
-    throw std::runtime_error("training the composition of several transducers without --train-cascade is outside "
-                             "this front end");
   // ---- normalisation methods per member (carmel.cc:488-499) ----
   std::vector<int> norms(nw, o.norm);
   std::vector<double> addc(nw, 0.0);
@@ -302,10 +347,35 @@ static int run(int argc, char** argv) {
     size_t i = 0;
     while (std::getline(ss, tok, ',') && i < nw) addc[i++] = std::atof(tok.c_str());
   }
+  // --digamma=0,,0.5: one component per member, empty = the usual linear normalisation (carmel.cc:495); -+ a sets it for
+  // the single method (carmel.cc:1009-1013)
+  std::vector<double> dig_alpha(nw, 0.0);
+  std::vector<uint8_t> dig_on(nw, 0);
+  if (o.plus_alpha_set)
+    for (size_t i = 0; i < nw; ++i) {
+      dig_alpha[i] = o.plus_alpha;
+      dig_on[i] = 1;
+    }
+  if (o.have_digamma) {
+    size_t i = 0, p0 = 0;
+    const std::string& d = o.digamma;
+    while (i < nw) {  // split on ',' keeping empty fields
+      size_t c = d.find(',', p0);
+      std::string tok = d.substr(p0, c == std::string::npos ? std::string::npos : c - p0);
+      if (!tok.empty()) {
+        dig_alpha[i] = std::atof(tok.c_str());
+        dig_on[i] = 1;
+      }
+      ++i;
+      if (c == std::string::npos) break;
+      p0 = c + 1;
+    }
+  }
+  const bool any_digamma = std::find(dig_on.begin(), dig_on.end(), (uint8_t)1) != dig_on.end();
   // ---- corpus ----
   HostPairs pairs;
   std::string warn;
-  parse_corpus(*result, corpus_text, pairs, &warn);
+  parse_corpus(*result, corpus_text, pairs, &warn, /*weight_lines=*/!scoring);
   std::cerr << warn;
   if (pairs.size() == 0) {  // corpus.set_null() (carmel.cc:1421)
     pairs.weight.push_back(1.0);
@@ -340,10 +410,36 @@ static int run(int argc, char** argv) {
                 "carmel_hip_set_cascade");
     else
       hip_check(carmel_hip_set_norm(t, norms[0], add[0]), "carmel_hip_set_norm");
+    if (any_digamma)
+      hip_check(carmel_hip_set_digamma(t, (uint32_t)(cascade ? nw : 1), dig_alpha.data(), dig_on.data()), "carmel_hip_set_digamma");
   };
+  if (scoring) {
+    // carmel -S (carmel.cc:1393-1410): for every pair the sum over all its derivations with the weights as they stand
+    // (WFST::sumOfAllPaths, train.cc:925-945 = derivations::init_and_compute + prob): one forward sweep per pair on the GPU
+    hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
+                                    pairs.out_sym.data(), pairs.weight.data()),
+              "carmel_hip_set_corpus");
+    std::vector<uint8_t> has(pairs.size(), 0);
+    carmel_hip_lattice_stats ls;
+    hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+    std::vector<double> lp(pairs.size(), kNegInf);
+    if (ls.n_pairs_kept) {
+      carmel_hip_estimate_result er;
+      hip_check(carmel_hip_estimate(t, &er, lp.data()), "carmel_hip_estimate");
+    }
+    double prod = 0;
+    for (size_t p = 0; p < pairs.size(); ++p) {
+      std::cout << format_weight(has[p] ? lp[p] : kNegInf, wstyle) << std::endl;
+      prod += has[p] ? lp[p] : kNegInf;
+    }
+    std::cerr << "-S corpus product of probs=" << format_weight(prod, wstyle) << ", probability=" << base2(prod);
+    if (pairs.size()) std::cerr << " per-line-perplexity(N=" << pairs.size() << ")=" << base2(ppxper(prod, (double)pairs.size()));
+    std::cerr << std::endl;
+    return 0;
+  }
   set_methods(addc);
   if (!o.crp) hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509 (not for --crp, gibbs.cc:403)
-  if (!o.crp && (!cascade || o.smooth_floor > 0))
+  if (!o.crp && (!cascade || o.smooth_floor > 0 || o.flags[(unsigned)'U']))  // arcs_table priors (derivations.h:96-101)
     hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
   hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
                                   pairs.out_sym.data(), pairs.weight.data()),
@@ -374,6 +470,17 @@ static int run(int argc, char** argv) {
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (ls.n_bundles ? "explicit" : "unrolled") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
+  if (o.crp || o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) {
+    // `log << derivations::global_stats` of cache_derivations (cached_derivs.h:137; derivations.h:197-247).  What the
+    // reference prints as "Pre pruning: (S states, A arcs)" is A summed over all pairs but S of the LAST pair, and
+    // "Post pruning" is the last pair that has a derivation (see carmel_hip_lattice_stats).  Its two "Avg # of paths"
+    // lines are not produced.
+    const double s0 = (double)ls.last_pair_explored_states, a0 = (double)ls.explored_arcs, s1 = (double)ls.last_pair_kept_states,
+                 a1 = (double)ls.last_pair_kept_arcs;
+    std::cerr << "\nTotal for " << pairs.size() << " cached derivations:\nPre pruning: (" << s0 << " states, " << a0
+              << " arcs)\nPost pruning: (" << s1 << " states, " << a1 << " arcs)\nPortion kept: (" << (s0 ? s1 / s0 : 0.0)
+              << " states, " << (a0 ? a1 / a0 : 1.0) << " arcs)\n";
+  }
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
     if (!has[p]) {
@@ -402,17 +509,20 @@ static int run(int argc, char** argv) {
     log << "Corpus ";
     print_ppx(er.sum_logprob);
     log << "\n";
-  } else if (o.max_iter == 0 || o.max_iter == 1) {  // train.cc:520-538 (no random restarts here)
+  } else if (o.max_iter == 0 || (o.max_iter == 1 && o.restarts == 0)) {  // train.cc:520-538
+    if (o.max_iter == 0)
+      log << "0 iterations specified for training; output weights will be unnormalized fractional counts (except locked "
+             "arcs).\n";
     hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
     log << "Corpus ";
     print_ppx(er.sum_logprob);
-    log << "\n";
-    if (o.max_iter == 1) {
+    if (o.max_iter == 0)  // prep_new_weights(1.0) + cascade.distribute_counts()
+      hip_check(carmel_hip_fractional_counts(t), "carmel_hip_fractional_counts");
+    else {
       double mc;
       hip_check(carmel_hip_maximize(t, 1.0, &mc), "carmel_hip_maximize");
-    } else
-      log << "0 iterations specified for training; weights are left unchanged (fractional-count output is not "
-             "offered by the GPU front end).\n";
+    }
+    log << "\n";
   } else {
     const bool timing = std::getenv("CARMEL_TIMING") != nullptr;  // per-iteration wall clock on stderr
     double best = std::numeric_limits<double>::infinity(), best_start = best;
@@ -580,13 +690,29 @@ static int run(int argc, char** argv) {
       set_methods(addc);
       hip_check(carmel_hip_set_weights(t, o.em_p0 ? em_w.data() : p0.data()), "carmel_hip_set_weights");
     }
+    if (o.init_from_p0 && o.init_em <= 0) {
+      // gibbs.cc:405-421: the first sample comes from the composed transducer's own weights instead of the cache.  For a
+      // real cascade those are the products made at composition time (cascade.normalize normalises the members, nothing
+      // updates the composed arcs); a single transducer is its own cascade: its weights normalised without priors.
+      init_arc_logw = logw;
+      if (!cascade) {
+        std::vector<double> p0(logw.size());
+        hip_check(carmel_hip_get_weights(t, p0.data()), "carmel_hip_get_weights");
+        std::vector<double> zero(nw, 0.0);
+        set_methods(zero);
+        hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");
+        hip_check(carmel_hip_get_arc_weights(t, init_arc_logw.data()), "carmel_hip_get_arc_weights");
+        set_methods(addc);
+        hip_check(carmel_hip_set_weights(t, p0.data()), "carmel_hip_set_weights");
+      }
+    }
     carmel_hip_gibbs* gs = 0;
     hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
     if (!init_arc_logw.empty())
       hip_check(carmel_hip_gibbs_set_init_weights(gs, init_arc_logw.data()), "carmel_hip_gibbs_set_init_weights");
     const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
-    std::vector<double> lp((size_t)per_run * n_runs);
-    int rc = carmel_hip_gibbs_run(gs, lp.data(), 0);
+    std::vector<double> lp((size_t)per_run * n_runs), lp_after(o.sample_prob_after ? lp.size() : 0);
+    int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
     const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
     carmel_hip_gibbs_destroy(gs);
@@ -596,8 +722,10 @@ static int run(int argc, char** argv) {
     for (uint32_t r = 0; r < n_runs; ++r) {
       if (go.restarts) std::cerr << "(random restart " << r << " of " << go.restarts << "): \n";  // gibbs.hpp:897
       for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
-        const double v = lp[(size_t)r * per_run + i];
-        std::cerr << "Gibbs i=" << i << " " << (go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model") << " prob=" << base2(v);
+        const double v = o.sample_prob_after ? lp_after[(size_t)r * per_run + i] : lp[(size_t)r * per_run + i];
+        std::cerr << "Gibbs i=" << i << " "
+                  << (o.sample_prob_after ? "sample(after add-back)" : go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model")
+                  << " prob=" << base2(v);
         if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-v / n_sym);
         std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-v / nblocks) << "\n";
       }
@@ -605,8 +733,7 @@ static int run(int argc, char** argv) {
     if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());
     hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
-    int ws = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
-    if (o.flags[(unsigned)'D']) ws = W_NEVER_LOG;
+    const int ws = wstyle;
     const char* dir = std::getenv("CARMEL_TRAINED_DIR");
     for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437
       member[i].set_weights(pw.data() + (cascade ? params.member_base[i] : 0));
@@ -680,8 +807,6 @@ static int run(int argc, char** argv) {
     }
   }
   // ---- output (carmel.cc:1435-1437, 1485-1496; cascade.h:23-32) ----
-  int wstyle = o.flags[(unsigned)'Z'] ? W_ALWAYS_LOG : W_SOMETIMES_LOG;
-  if (o.flags[(unsigned)'D']) wstyle = W_NEVER_LOG;
   const bool full = o.flags[(unsigned)'J'], per_arc = o.flags[(unsigned)'H'];
   if (cascade) {
     std::vector<double> pw(params.logw.size());
@@ -720,6 +845,9 @@ static int run(int argc, char** argv) {
 int main(int argc, char** argv) {
   try {
     return run(argc, argv);
+  } catch (UsageError& e) {
+    std::cerr << "carmel: " << e.what() << "\n";
+    return -12;
   } catch (std::exception& e) {
     std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
     return -11;

@@ -5,8 +5,17 @@
 // Semantics follow /root/reference/carmel/src/compose.cc:163-531 (filter states :315-324; composite states numbered
 // in discovery order from a LIFO work list :193,326-328; arcs prepended to their state :128-141; the larger of the
 // two operand states is indexed when it has more than -T arcs :334-338; several finals joined by locked *e*:*e*
-// arcs :503-530) and cascade.h:489-599 (which original arcs a composed arc stands for).  The `-a` 2-state filter is
-// not offered.
+// arcs :503-530) and cascade.h:489-599 (which original arcs a composed arc stands for).
+//
+// run_a() is carmel -a (compose.cc:219-313): the 2-state filter that keeps the arcs of the two operands apart -- an arc
+// a:x of A leads to a "mediate" state (A's destination, B's state, x) from which B's x:c arcs leave -- so every composed
+// arc stands for ONE operand arc (chains of length 0 or 1 per composition).  The reference walks A's per-state
+// output-symbol hash table in bucket order there; here the symbols are taken in ascending id order, so composite states
+// may be NUMBERED differently from the reference's (paths, weights and chains are the same; no reference fixture pins the
+// numbering of a -a composition).
+//
+// trivial = no --train-cascade (cascade.h:566-592 with `trivial`): composed arcs carry no chains -- an arc built from a
+// pair has no group, an arc copied from one operand arc keeps that arc's own group.
 #pragma once
 #include <algorithm>
 #include <map>
@@ -68,8 +77,84 @@ struct Operand {
 
 class Composer {
  public:
-  Composer(const ParamTable& params, ChainTable& chains, unsigned index_threshold = 32)
-      : P(params), C(chains), T(index_threshold) {}
+  Composer(const ParamTable& params, ChainTable& chains, unsigned index_threshold = 32, bool trivial = false)
+      : P(params), C(chains), T(index_threshold), trivial_(trivial) {}
+
+  // carmel -a: see the header comment.  Same conventions as run().
+  bool run_a(const Operand& A, const Operand& B, Transducer& out) {
+    const Transducer& a = *A.t;
+    const Transducer& b = *B.t;
+    out = Transducer();
+    out.in_syms = a.in_syms;
+    out.out_syms = b.out_syms;
+    out.named = false;
+    std::vector<uint32_t> a2b(a.out_syms.names.size(), kNoGroup);
+    for (uint32_t i = 0; i < a2b.size(); ++i) b.in_syms.find(a.out_syms.names[i], a2b[i]);
+    std::unordered_map<uint64_t, uint32_t> ids;       // (qa, qb, filter) -> state
+    std::map<std::vector<uint32_t>, uint32_t> mids;   // (A's destination, B's state, hidden symbol) -> mediate state
+    std::vector<Job> work;
+    std::vector<std::vector<HArc> >& S = out.states;
+    auto key = [&](uint32_t qa, uint32_t qb, int f) { return ((uint64_t)qa * b.states.size() + qb) * 3 + (uint64_t)f; };
+    S.emplace_back();
+    ids.emplace(key(0, 0, 0), 0u);
+    work.push_back(Job{0, 0, 0, 0});
+    auto emit = [&](uint32_t from, uint32_t in, uint32_t o, uint32_t qa, uint32_t qb, int f, double lw, uint32_t chain) {
+      auto ins = ids.emplace(key(qa, qb, f), (uint32_t)S.size());
+      if (ins.second) {
+        work.push_back(Job{ins.first->second, qa, qb, f});
+        S.emplace_back();
+      }
+      HArc x;
+      x.in = in;
+      x.out = o;
+      x.dest = ins.first->second;
+      x.logw = lw;
+      x.group = chain;
+      S[from].push_back(x);
+    };
+    while (!work.empty()) {
+      const Job j = work.back();
+      work.pop_back();
+      const auto& la = a.states[j.qa];
+      const auto& lb = b.states[j.qb];
+      // A's arcs by output symbol, B's by input symbol; within a symbol newest-first, like the push_front lists of
+      // State::indexBy (state.h:158-199)
+      std::map<uint32_t, std::vector<size_t> > by_out, by_in;
+      for (size_t k = la.size(); k-- > 0;) by_out[la[k].out].push_back(k);
+      for (size_t k = lb.size(); k-- > 0;) by_in[lb[k].in].push_back(k);
+      for (auto& kv : by_out) {
+        const uint32_t sym = kv.first;
+        if (sym == 0) {
+          if (j.f == 0)  // a:*e* of A alone, B stays (filter 0 -> 0)
+            for (size_t ka : kv.second) emit(j.id, la[ka].in, 0, la[ka].dest, j.qb, 0, la[ka].logw, lone_chain(A, j.qa, ka));
+          continue;
+        }
+        if (a2b[sym] == kNoGroup) continue;
+        auto mb = by_in.find(a2b[sym]);
+        if (mb == by_in.end()) continue;
+        for (size_t ka : kv.second) {
+          const std::vector<uint32_t> mk{la[ka].dest, j.qb, sym};
+          auto ins = mids.emplace(mk, (uint32_t)S.size());
+          const uint32_t M = ins.first->second;
+          if (ins.second) {  // new mediate state: B's matching arcs leave it, input *e*
+            S.emplace_back();
+            for (size_t kb : mb->second) emit(M, 0, lb[kb].out, la[ka].dest, lb[kb].dest, 0, lb[kb].logw, lone_chain(B, j.qb, kb));
+          }
+          HArc x;  // A's arc into the mediate state, output *e*
+          x.in = la[ka].in;
+          x.out = 0;
+          x.dest = M;
+          x.logw = la[ka].logw;
+          x.group = lone_chain(A, j.qa, ka);
+          S[j.id].push_back(x);
+        }
+      }
+      auto eb = by_in.find(0u);
+      if (eb != by_in.end())  // *e*:c of B alone, A stays (-> filter 1)
+        for (size_t kb : eb->second) emit(j.id, 0, lb[kb].out, j.qa, lb[kb].dest, 1, lb[kb].logw, lone_chain(B, j.qb, kb));
+    }
+    return finish(out, ids, key(a.final_state, b.final_state, 0));
+  }
 
   // returns false when the composition is empty (no final reachable)
   bool run(const Operand& A, const Operand& B, Transducer& out) {
@@ -180,10 +265,16 @@ class Composer {
             if (lb[kb].in == 0) b_alone(kb);
       }
     }
-    // finals (compose.cc:503-530)
+    return finish(out, ids, key(a.final_state, b.final_state, 0));
+  }
+
+ private:
+  // finals (compose.cc:503-530): key0 = key of (a.final, b.final, filter 0); filters are consecutive keys
+  bool finish(Transducer& out, const std::unordered_map<uint64_t, uint32_t>& ids, uint64_t key0) {
+    std::vector<std::vector<HArc> >& S = out.states;
     int found[3] = {-1, -1, -1}, n = 0;
     for (int f = 0; f < 3; ++f) {
-      auto it = ids.find(key(a.final_state, b.final_state, f));
+      auto it = ids.find(key0 + (uint64_t)f);
       if (it != ids.end()) {
         found[f] = (int)it->second;
         out.final_state = it->second;
@@ -198,7 +289,7 @@ class Composer {
         if (found[f] >= 0) {
           HArc x;
           x.dest = out.final_state;
-          x.group = 0;  // nil chain == locked at weight 1
+          x.group = 0;  // nil chain == locked at weight 1 (locked_1_groupid is 0 with or without chains)
           S[found[f]].push_back(x);
         }
     }
@@ -206,7 +297,6 @@ class Composer {
     return true;
   }
 
- private:
   struct Job {
     uint32_t id, qa, qb;
     int f;
@@ -218,12 +308,14 @@ class Composer {
   const ParamTable& P;
   ChainTable& C;
   unsigned T;
+  bool trivial_;
 
   void prepend(std::vector<uint64_t>& chain, uint64_t p) const {
     if (!P.locked_one(p)) chain.insert(chain.begin(), p);  // cascade.h:507-510
   }
   // chain of a composed arc made from arc ka of A's state qa and arc kb of B's state qb (cascade.h:536-551)
   uint32_t pair_chain(const Operand& A, uint32_t qa, size_t ka, const Operand& B, uint32_t qb, size_t kb) {
+    if (trivial_) return kNoGroup;  // cascade.h:581-583
     std::vector<uint64_t> c;
     const uint32_t ga = A.t->states[qa][ka].group, gb = B.t->states[qb][kb].group;
     if (A.is_chain) {
@@ -245,7 +337,7 @@ class Composer {
   }
   // chain of a composed arc that copies one operand arc (cascade.h:566-579)
   uint32_t lone_chain(const Operand& X, uint32_t q, size_t k) {
-    if (X.is_chain) return X.t->states[q][k].group;
+    if (trivial_ || X.is_chain) return X.t->states[q][k].group;  // cascade.h:566-569
     uint64_t p = X.param_of(q, k);
     auto it = C.lone.find(p);
     if (it != C.lone.end()) return it->second;

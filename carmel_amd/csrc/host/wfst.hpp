@@ -85,13 +85,20 @@ inline bool parse_weight_token(const std::string& tok, double& logw) {
   return true;
 }
 
-enum WeightStyle { W_SOMETIMES_LOG = 0, W_ALWAYS_LOG = 1, W_NEVER_LOG = 2 };
+// W_BASE_*: how a weight in log form is spelt -- e^x (default), `x ln` with carmel -2, `x log` (base 10) with -B
+// (weight.h:468-489; carmel.cc:76-101 / WFST::output_format)
+enum WeightStyle { W_SOMETIMES_LOG = 0, W_ALWAYS_LOG = 1, W_NEVER_LOG = 2, W_STYLE_MASK = 3, W_BASE_LN = 16, W_BASE_LOG10 = 32 };
 inline std::string format_weight(double logw, int style) {  // weight.h:468-489, 15 significant digits
   char buf[64];
   if (!(logw > kNegInf)) return "0";
   bool fits = logw < 82.0 && logw > -82.0;
-  if ((style == W_SOMETIMES_LOG && fits) || style == W_NEVER_LOG)
+  const int st = style & W_STYLE_MASK;
+  if ((st == W_SOMETIMES_LOG && fits) || st == W_NEVER_LOG)
     std::snprintf(buf, sizeof buf, "%.15g", std::exp(logw));
+  else if (style & W_BASE_LN)
+    std::snprintf(buf, sizeof buf, "%.15gln", logw);
+  else if (style & W_BASE_LOG10)
+    std::snprintf(buf, sizeof buf, "%.15glog", logw * (1. / 2.30258509299404568402));  // getLog10 = oo_ln10 * ln (weight.h:122-126, 265)
   else
     std::snprintf(buf, sizeof buf, "e^%.15g", logw);
   return buf;
@@ -458,7 +465,8 @@ struct HostPairs {
   size_t size() const { return weight.size(); }
 };
 
-inline void parse_corpus(Transducer& x, const std::string& text, HostPairs& c, std::string* warnings = 0) {
+inline void parse_corpus(Transducer& x, const std::string& text, HostPairs& c, std::string* warnings = 0,
+                         bool weight_lines = true) {  // carmel -S: plain alternating lines, no weights (carmel.cc:1393-1410)
   size_t p = 0;
   auto next_line = [&](std::string& line) {
     if (p >= text.size()) return false;
@@ -472,7 +480,7 @@ inline void parse_corpus(Transducer& x, const std::string& text, HostPairs& c, s
   while (next_line(line)) {
     double wt = 1.0;
     char f = line.empty() ? '\0' : line[0];
-    if (std::isdigit((unsigned char)f) || f == '-' || f == '.' || f == 'e') {  // a weight line
+    if (weight_lines && (std::isdigit((unsigned char)f) || f == '-' || f == '.' || f == 'e')) {  // a weight line
       char* e = 0;
       wt = std::strtod(line.c_str(), &e);
       if (e == line.c_str()) {

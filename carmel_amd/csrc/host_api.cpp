@@ -57,7 +57,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
 
 // dims[0..15] = n_bundles, n_off (states + bundles), n_arcs, n_level_off, n_pair_slots, n_classes, n_kept,
 //              n_cyclic, explored_states, explored_arcs, n_lane_groups, n_lane_records, n_lane_slots,
-//              n_lane_classes, total_states, total_arcs
+//              n_lane_classes, total_states, total_arcs, last pair: explored states, kept states, kept arcs
 void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims) {
   dims[0] = h->L.bundles.size();
   dims[1] = h->L.in_off.size();
@@ -75,6 +75,9 @@ void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims) {
   dims[13] = h->L.lane_classes.size();
   dims[14] = h->L.total_states;
   dims[15] = h->L.total_arcs;
+  dims[16] = h->L.last_pre_states;
+  dims[17] = h->L.last_post_states;
+  dims[18] = h->L.last_post_arcs;
 }
 
 // lane groups (see LaneGroup in lattice.hpp): groups as raw 32-byte records, streams as (x, y) u32 pairs

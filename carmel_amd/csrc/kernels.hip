@@ -431,6 +431,29 @@ __global__ __launch_bounds__(256) void count_reduce_hot_kernel(ReduceArgs R) {
 
 // ---------------- M-step (fst.cc:86-244 for normal + locked arcs; train.cc:134-182) ----------------
 
+// digamma(x), x > 0: the recurrence psi(x) = psi(x + 1) - 1/x up to x >= 10, then the asymptotic series
+// ln x - 1/(2x) - sum_k B_2k / (2k x^2k) (Abramowitz & Stegun 6.3.18; the reference calls boost::math::digamma at 8
+// digits, digamma.hpp:24-30 -- a third-party dependency absent from the tree, restated from the published series)
+__device__ __forceinline__ double digamma_pos(double x) {
+  double r = 0.0;
+  while (x < 10.0) {
+    r -= 1.0 / x;
+    x += 1.0;
+  }
+  const double z = 1.0 / (x * x);
+  // B_2k / 2k: 1/12, -1/120, 1/252, -1/240, 1/132, -691/32760, 1/12
+  const double ser = z * (1.0 / 12 - z * (1.0 / 120 - z * (1.0 / 252 - z * (1.0 / 240 - z * (1.0 / 132 - z * (691.0 / 32760 - z / 12))))));
+  return r + log(x) - 0.5 / x - ser;
+}
+// ln of mean_field_scale::operator() (mean_field_scale.hpp:40-52): linear (alpha is NaN) -> ln x; else
+// exp(digamma(x + alpha)), continued linearly to 0 below x + alpha = .0002
+__device__ __forceinline__ double ln_scale(double x, double alpha) {
+  if (alpha != alpha) return x > 0.0 ? log(x) : NEG_INF;
+  const double xa = x + alpha, floor_x = .0002;
+  if (xa < floor_x) return xa > 0.0 ? digamma_pos(floor_x) + log(xa / floor_x) : NEG_INF;
+  return digamma_pos(xa);
+}
+
 // unnormalised linear value of parameter k: prep_new_weights (train.cc:134-153) + "w += addc" of normalize pass 1
 // (fst.cc:125).  Locked arcs keep their weight (plus addc, as the reference does).
 __device__ __forceinline__ double mstep_value(const MstepArgs& M, uint64_t k, int use_counts, uint32_t ng) {
@@ -445,8 +468,9 @@ __device__ __forceinline__ double mstep_value(const MstepArgs& M, uint64_t k, in
 
 // ln((1 - sum of locked) / sum of normal), kept as a difference of logs so that a lone arc (v == sum) comes out as
 // exactly 1 (fst.cc:213-230); -inf when nothing is left to distribute
-__device__ __forceinline__ double mstep_scale(double sn, double sl) {
+__device__ __forceinline__ double mstep_scale(double sn, double sl, double alpha = __builtin_nan("")) {
   const double remain = 1.0 - sl;
+  if (alpha == alpha) return (remain > 0.0 && sn > 0.0) ? log(remain) - ln_scale(sn, alpha) : NEG_INF;  // fst.cc:217-221
   return (remain > 0.0 && sn > 0.0) ? (sl == 0.0 ? -log(sn) : log(remain) - log(sn)) : NEG_INF;
 }
 // new weight of member k (locked arcs keep v) and its |change| in the real domain (weight.h:837-856)
@@ -463,7 +487,10 @@ __device__ __forceinline__ double mstep_update(const MstepArgs& M, uint64_t k, i
     nw = tw > 0.0 ? log(tw) : NEG_INF;
     mx = fmax(mx, fabs(tw - exp(M.save_old ? old : M.old_logw[k])));
   } else {
-    nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
+    if (M.dig_alpha && M.dig_alpha[g] == M.dig_alpha[g])
+      nw = sc != NEG_INF ? ln_scale(v, M.dig_alpha[g]) + sc : NEG_INF;
+    else
+      nw = (sc != NEG_INF && v > 0.0) ? log(v) + sc : NEG_INF;
     mx = fmax(mx, fabs(exp(nw) - exp(M.save_old ? old : M.old_logw[k])));
   }
   return nw;
@@ -519,7 +546,10 @@ __global__ void mstep_tie_weight_kernel(MstepArgs M) {
   double norm = M.tie_tab[M.n_ties + tie], w = 0.0;
   if (!(gmax > 1.0)) {
     if (gmax != 0.0) norm /= (1.0 - gmax);
-    if (total != 0.0) w = total / norm;
+    if (total != 0.0) {
+      const double a = M.tie_alpha ? M.tie_alpha[tie] : __builtin_nan("");
+      w = (a == a) ? exp(ln_scale(total, a) - ln_scale(norm, a)) : total / norm;  // scale(groupTotal) / scale(groupNorm)
+    }
   }
   M.tie_tab[3 * M.n_ties + tie] = w;
 }
@@ -540,7 +570,7 @@ __global__ __launch_bounds__(256) void mstep_group_sum_kernel(MstepArgs M, int u
       else
         sn += v;
     }
-    M.gscale[g] = mstep_scale(sn, sl);
+    M.gscale[g] = mstep_scale(sn, sl, M.dig_alpha ? M.dig_alpha[g] : __builtin_nan(""));
   }
 }
 // pass 1, one thread per parameter (coalesced): the new weight; the largest |change| leaves as one partial per
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
     const uint64_t k = in[h] ? (uint64_t)kk[h] : 0;
     gg[h] = M.norm_of[k];
     grp[h] = M.group[k];
-    lw[h] = M.logw[k];
+    lw[h] = M.lw_src[k];
     cv[h] = use_counts ? M.counts[k] : 0.0;
     pv[h] = (use_counts && M.prior) ? M.prior[k] : 0.0;
   }
@@ -673,7 +703,9 @@ __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int u
     sh[1][threadIdx.x >> 6] = sl;
   }
   __syncthreads();
-  if (threadIdx.x == 0) M.gscale[g] = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3]);
+  if (threadIdx.x == 0)
+    M.gscale[g] = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3],
+                              M.dig_alpha ? M.dig_alpha[g] : __builtin_nan(""));
 }
 __global__ __launch_bounds__(256) void mstep_max_final_kernel(const unsigned long long* partial, uint64_t n,
                                                               unsigned long long* bits) {
@@ -729,10 +761,10 @@ __global__ void chain_update_kernel(double* arc_logw, const uint32_t* arc_chain,
 }
 // parameter counts += (composed count + composed prior) for every unlocked parameter of the arc's chain
 __global__ void chain_scatter_kernel(double* param_counts, const double* arc_counts, double arc_prior,
-                                     const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
-                                     const uint32_t* param_group, uint64_t n_arcs) {
+                                     const double* arc_prior_w, const uint32_t* arc_chain, const uint64_t* chain_off,
+                                     const uint64_t* chain_param, const uint32_t* param_group, uint64_t n_arcs) {
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_arcs; k += (uint64_t)gridDim.x * blockDim.x) {
-    const double c = arc_counts[k] + arc_prior;
+    const double c = arc_counts[k] + (arc_prior_w ? arc_prior + arc_prior_w[k] : arc_prior);
     if (!(c > 0.0)) continue;
     const uint32_t ch = arc_chain[k];
     for (uint64_t j = chain_off[ch]; j < chain_off[ch + 1]; ++j) {
@@ -1078,11 +1110,25 @@ hipError_t launch_chain_update(double* arc_logw, const uint32_t* arc_chain, cons
                      chain_param, param_logw, n_arcs);
   return hipGetLastError();
 }
-hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior,
+hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior, const double* arc_prior_w,
                                 const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
                                 const uint32_t* param_group, uint64_t n_arcs, hipStream_t s) {
   hipLaunchKernelGGL(chain_scatter_kernel, dim3(grid_for(n_arcs, 256)), dim3(256), 0, s, param_counts, arc_counts,
-                     arc_prior, arc_chain, chain_off, chain_param, param_group, n_arcs);
+                     arc_prior, arc_prior_w, arc_chain, chain_off, chain_param, param_group, n_arcs);
+  return hipGetLastError();
+}
+__global__ void counts_to_logw_kernel(double* logw, const double* counts, const double* prior, const uint32_t* group,
+                                      uint64_t n) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+    if (group[k] != 0u) {
+      const double v = counts[k] + (prior ? prior[k] : 0.0);
+      logw[k] = v > 0.0 ? log(v) : NEG_INF;
+    }
+}
+hipError_t launch_counts_to_logw(double* logw, const double* counts, const double* prior, const uint32_t* group, uint64_t n,
+                                 hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(counts_to_logw_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, logw, counts, prior, group, n);
   return hipGetLastError();
 }
 

@@ -82,6 +82,10 @@ struct TransArgs {
 #define MSTEP_PARTIALS 2048
 struct MstepArgs {
   double* logw;             // parameters (ln), updated in place
+  const double* lw_src;     // mstep_window_kernel: where the ln weights of the tile AND its halo are read -- `logw` itself
+                            // only when no thread needs a neighbour's weight (counts in use, no locked member);
+                            // otherwise a snapshot taken before the launch, because neighbouring workgroups overwrite
+                            // logw in place with no ordering between them
   double* old_logw;         // scratch (arc_counts::scratch)
   const double* counts;     // linear expected counts per parameter
   const double* prior;      // linear prior count per parameter (may be null => 0)
@@ -103,6 +107,11 @@ struct MstepArgs {
   uint64_t n_ties;
   uint64_t n;
   int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
+  // --digamma (mean_field_scale.hpp:40-52): per norm group / per tie the alpha of exp(digamma(x + alpha)) that replaces
+  // x in the numerator and the denominator of the normalisation; NaN = the usual linear scale.  Null when no member
+  // asked for it (the one-pass window kernel only handles the linear scale).
+  const double* dig_alpha;
+  const double* tie_alpha;
 };
 
 hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
@@ -121,8 +130,12 @@ hipError_t launch_max_change(const double* logw, const double* old_logw, const u
                              unsigned long long* bits, uint64_t n, hipStream_t s);
 hipError_t launch_chain_update(double* arc_logw, const uint32_t* arc_chain, const uint64_t* chain_off,
                                const uint64_t* chain_param, const double* param_logw, uint64_t n_arcs, hipStream_t s);
-hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior,
+// arc_prior_w: optional per-arc addition to the prior (carmel -U on a cascade: the composed arc's initial weight)
+hipError_t launch_chain_scatter(double* param_counts, const double* arc_counts, double arc_prior, const double* arc_prior_w,
                                 const uint32_t* arc_chain, const uint64_t* chain_off, const uint64_t* chain_param,
                                 const uint32_t* param_group, uint64_t n_arcs, hipStream_t s);
+// the max_iter == 0 branch of WFST::train (train.cc:527-529): logw[k] = ln(counts[k] (+ prior[k])) for unlocked k
+hipError_t launch_counts_to_logw(double* logw, const double* counts, const double* prior, const uint32_t* group, uint64_t n,
+                                 hipStream_t s);
 
 }  // namespace carmel_hip

@@ -488,7 +488,12 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   for (uint64_t p = 0; p < np; ++p) {
     out.explored_states += lats[p].explored_states;
     out.explored_arcs += lats[p].explored_arcs;
-    if (out.has_deriv[p]) kept.push_back((uint32_t)p);
+    out.last_pre_states = lats[p].explored_states;
+    if (out.has_deriv[p]) {
+      kept.push_back((uint32_t)p);
+      out.last_post_states = lats[p].n_states;
+      out.last_post_arcs = lats[p].edges.size();
+    }
   }
   out.n_kept = kept.size();
   phase("derivations (per pair)");

@@ -150,6 +150,9 @@ struct LatticeSet {
   std::vector<uint32_t> t_split_arcs;  // arcs cut over several buckets (their counts are accumulated atomically)
   uint64_t total_states = 0, total_arcs = 0, max_levels = 0, n_cyclic = 0;
   uint64_t explored_states = 0, explored_arcs = 0;
+  // derivations::statistics as the reference keeps it (derivations.h:197-210, 617-618): pre.states is ASSIGNED per pair
+  // (the last pair's), post.states / post.arcs are the last pair's that has a derivation
+  uint64_t last_pre_states = 0, last_post_states = 0, last_post_arcs = 0;
   std::vector<uint8_t> has_deriv;
   uint64_t n_kept = 0;
 };

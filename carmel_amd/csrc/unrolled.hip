@@ -444,17 +444,19 @@ __global__ void unrolled_reduce_kernel(const double* __restrict__ partial, uint3
 // (what chain_scatter_kernel produces from composed-arc counts); locked parameters get none
 __global__ void unrolled_param_counts_kernel(double* __restrict__ out, const double* __restrict__ counts,
                                              const double* __restrict__ uses, double floor_count,
-                                             const uint32_t* __restrict__ group, const uint32_t* __restrict__ slot_of,
-                                             uint32_t n) {
+                                             const double* __restrict__ wprior, const uint32_t* __restrict__ group,
+                                             const uint32_t* __restrict__ slot_of, uint32_t n) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const uint32_t sl = slot_of[p];
-  out[p] = (group[p] != 0u && sl != 0xffffffffu) ? counts[sl] + floor_count * uses[p] : 0.0;
+  out[p] = (group[p] != 0u && sl != 0xffffffffu) ? counts[sl] + floor_count * uses[p] + (wprior ? wprior[p] : 0.0) : 0.0;
 }
+// wprior: carmel -U on a cascade -- per parameter, the initial weights of the composed arcs that use it (may be null)
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
-                                        const uint32_t* group, const uint32_t* slot_of, uint32_t n, hipStream_t s) {
-  hipLaunchKernelGGL(unrolled_param_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, counts, uses, floor_count, group,
-                     slot_of, n);
+                                        const double* wprior, const uint32_t* group, const uint32_t* slot_of, uint32_t n,
+                                        hipStream_t s) {
+  hipLaunchKernelGGL(unrolled_param_counts_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, counts, uses, floor_count, wprior,
+                     group, slot_of, n);
   return hipGetLastError();
 }
 

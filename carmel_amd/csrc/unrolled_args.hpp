@@ -42,7 +42,8 @@ size_t unrolled_scratch_doubles(uint32_t n_wg, uint32_t n_waves, uint32_t max_le
 hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, double* out, uint32_t stride_doubles, uint32_t n,
                                    hipStream_t s);
 hipError_t launch_unrolled_param_counts(double* out, const double* counts, const double* uses, double floor_count,
-                                        const uint32_t* group, const uint32_t* slot_of, uint32_t n, hipStream_t s);
+                                        const double* wprior, const uint32_t* group, const uint32_t* slot_of, uint32_t n,
+                                        hipStream_t s);
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s);
 // more than 64 states: a workgroup per pair, a thread per state
 size_t unrolled_wide_lds_bytes(const UnrolledArgs& A);

@@ -236,13 +236,20 @@ class HipGibbs(object):
         self.h = h
         self.n_blocks = lib.carmel_hip_gibbs_n_blocks(h)
 
-    def run(self):
-        """with restarts > 0 the traces of all runs follow each other: run r is [r * (iter + 1), (r + 1) * (iter + 1))"""
+    def run(self, after=False):
+        """with restarts > 0 the traces of all runs follow each other: run r is [r * (iter + 1), (r + 1) * (iter + 1)).
+        after=True (exact mode) also fills iter_after_logprob (carmel_hip_gibbs_run_ex)"""
         n = (self.opts.iter + 1) * (self.opts.restarts + 1)
         self.iter_logprob, self.iter_cheap_logprob = np.zeros(n), np.zeros(n)
-        check(lib.carmel_hip_gibbs_run(self.h, ptr(self.iter_logprob), ptr(self.iter_cheap_logprob)),
-              "carmel_hip_gibbs_run")
+        self.iter_after_logprob = np.zeros(n) if after else None
+        check(lib.carmel_hip_gibbs_run_ex(self.h, ptr(self.iter_logprob), ptr(self.iter_cheap_logprob),
+                                          ptr(self.iter_after_logprob)), "carmel_hip_gibbs_run_ex")
         return self.iter_logprob
+
+    def set_init_weights(self, arc_logw):
+        """--init-em / --init-from-p0: ln weight per composed arc the first sweep of the first run samples from"""
+        a = None if arc_logw is None else np.ascontiguousarray(arc_logw, dtype=np.float64)
+        check(lib.carmel_hip_gibbs_set_init_weights(self.h, ptr(a)), "carmel_hip_gibbs_set_init_weights")
 
     @property
     def best_run(self):

@@ -68,6 +68,11 @@ typedef struct carmel_hip_lattice_stats {
   uint64_t max_levels;
   uint64_t device_bytes;     /* HBM held by lattices */
   double build_seconds;
+  /* derivations::statistics exactly as the reference keeps it (derivations.h:197-210, 617-618, 687), for its
+   * "Pre pruning / Post pruning" log lines: pre.arcs accumulates over all pairs (= explored_arcs above), but pre.states,
+   * post.states and post.arcs are ASSIGNED per pair -- what is logged is the last pair's (post: the last pair that has a
+   * derivation).  commands.trace:6984-6986 pins them on the tagging cascade: (100 states, 182891 arcs) -> (75, 164). */
+  uint64_t last_pair_explored_states, last_pair_kept_states, last_pair_kept_arcs;
 } carmel_hip_lattice_stats;
 
 /* Replaces: cached_derivs::cache_derivations (cached_derivs.h:104-138) -> derivations::init_and_compute
@@ -147,6 +152,18 @@ int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts /* n_arcs,
  * (10 for a real cascade, train.cc:922). */
 int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change);
 
+/* Replaces: the `max_iter == 0` branch of WFST::train (train.cc:520-531: for_arcs::prep_new_weights(1.0) followed by
+ * cascade.distribute_counts(), no normalisation) -- after an estimate, every unlocked parameter's weight becomes its
+ * unnormalised fractional count (+ prior); locked parameters keep their weights.  `carmel -t -M 0`. */
+int carmel_hip_fractional_counts(carmel_hip_trainer* t);
+
+/* Replaces: WFST::NormalizeMethod::scale = mean_field_scale (graehl/shared/mean_field_scale.hpp:40-52; carmel --digamma=a,,b
+ * per cascade member, carmel.cc:495, and `-+ a` for a single transducer, carmel.cc:1009-1013): for member m with
+ * enabled[m] != 0 the normalisation of carmel_hip_normalize / carmel_hip_maximize uses exp(digamma(x + alpha[m])) in place
+ * of x for the numerator and for the group sum (fst.cc:189, 217-221).  Call after carmel_hip_set_norm / _set_cascade
+ * (which reset it); a single transducer is member 0. */
+int carmel_hip_set_digamma(carmel_hip_trainer* t, uint32_t n_members, const double* alpha, const uint8_t* enabled);
+
 /* Replaces cascade_parameters::random_restart (cascade.h:398-411: WFST::randomSet on every member not normalised by
  * NONE, then normalize): every unlocked parameter p gets the weight 1 - u(seed, restart, p) in (0, 1] from the
  * library's counter-based generator (carmel_hip_gibbs_uniform(seed, restart, p, 0)), then the model is normalised.
@@ -200,6 +217,12 @@ uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g);
  * NULL.  On return the trainer's parameters hold the time-averaged probabilities (probs_to_cascade,
  * gibbs.cc:66-76): read them with carmel_hip_get_weights. */
 int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob);
+/* ... and a third series (exact mode only; may be NULL): ln of the product over blocks of the proposal probability of the
+ * block's new sample evaluated AFTER that sample was added back to the counts -- the "overestimate" the comment at
+ * gibbs.hpp:866 describes.  It is what the older carmel binary that recorded carmel-tutorial/commands.trace logged as
+ * "sample prob" (its 6001 values for `--crp -M 6000` on the tagging cascade, trace lines 6989-12990, are this repo's only
+ * reference-held datum for the sampler); today's carmel logs the cache-model probability instead. */
+int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob, double* iter_after_logprob);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
 /* --init-em (gibbs.cc:386-430, 306-383 p_init): ln weights of the composed arcs (carmel_hip_get_arc_weights after an EM
@@ -256,7 +279,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
                           uint64_t n_pairs, const uint64_t* in_off, const uint32_t* cin, const uint64_t* out_off,
                           const uint32_t* cout, const double* pair_weight, int prune, int threads,
                           uint32_t small_pairs, uint32_t small_states, int lane_states);
-void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims16);
+void carmel_hip_host_dims(carmel_hip_host_lattices* h, uint64_t* dims19);
 void carmel_hip_host_export_lanes(carmel_hip_host_lattices* h, void* groups32, uint32_t* fwd, uint32_t* bwd,
                                   uint32_t* lane_pair, uint32_t* lane_nstates, double* lane_logw, uint32_t* classes3);
 void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,

@@ -218,6 +218,8 @@ def train_cascade_text(wfst_texts, corpus_text, normby=None, priors=None, max_it
 
 lib.orc_cascade_compose_text.restype = vp
 lib.orc_cascade_compose_text.argtypes = [C.c_int, vp]
+lib.orc_cascade_compose_text_ex.restype = vp
+lib.orc_cascade_compose_text_ex.argtypes = [C.c_int, vp, C.c_int, C.c_int]
 lib.orc_cascade_free.argtypes = [vp]
 lib.orc_cascade_composed.restype = vp
 lib.orc_cascade_composed.argtypes = [vp]
@@ -232,10 +234,11 @@ lib.orc_cascade_write_member.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
 class OracleCascade(object):
     """composition + chain bookkeeping of `carmel --train-cascade a b ...` as flat arrays"""
 
-    def __init__(self, wfst_texts):
+    def __init__(self, wfst_texts, remember=True, dash_a=False):
+        """remember=False: plain `carmel a b` (no chains); dash_a: carmel -a (2-state filter, compose.cc:219-313)"""
         n = len(wfst_texts)
         arr = (C.c_char_p * n)(*[t.encode() for t in wfst_texts])
-        self.h = lib.orc_cascade_compose_text(n, arr)
+        self.h = lib.orc_cascade_compose_text_ex(n, arr, int(remember), int(dash_a))
         if not self.h:
             raise RuntimeError("oracle: " + lib.orc_last_error().decode())
         dims = np.zeros(4, np.uint64)
@@ -310,7 +313,7 @@ def fem_export(cascade, corpus, which, normby=None, priors=None):
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
               low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False, init_em=0,
-              em_p0=False):
+              em_p0=False, init_from_p0=False):
     """carmel --crp on an OracleCascade; `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
     n = cascade.n_params
@@ -326,11 +329,16 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     lib.orc_set_gibbs_expectation(int(expectation))
     lib.orc_set_gibbs_restarts(int(restarts), int(argmax_final), int(argmax_sum))
     lib.orc_set_gibbs_init_em(int(init_em), int(em_p0))
+    lib.orc_set_gibbs_init_from_p0(int(init_from_p0))
     _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
                            int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
                            _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))
     samples = [samp[int(off[b]):int(off[b + 1])].tolist() for b in range(nb.value)]
-    return dict(iter_logprob=ilp, iter_cheap_logprob=icl, param_logw=plw, samples=samples, best_run=lib.orc_gibbs_best_run())
+    after = np.zeros(len(ilp))
+    lib.orc_gibbs_last_after(_p(after), len(after))
+    lib.orc_set_gibbs_init_from_p0(0)
+    return dict(iter_logprob=ilp, iter_cheap_logprob=icl, iter_after_logprob=after, param_logw=plw, samples=samples,
+                best_run=lib.orc_gibbs_best_run())
 
 
 lib.orc_forests_parse.restype = vp

@@ -5,7 +5,8 @@
 // Follows /root/reference/carmel/src/:
 //   compose.cc:163-531  WFST::set_compose (3-state filter :315-498; LIFO queue :193,326-328; arc prepend via
 //                       COMPOSEARC_GROUP :128-141; multiple finals :503-530).  The `-a` 2-state filter
-//                       (:219-313) walks a HashTable in bucket order and is NOT restated (unpinned).
+//                       (:219-313) is compose_a below; the reference walks a HashTable in bucket order there
+//                       (state NUMBERING unpinned -- ascending symbol order here), paths and chains are exact.
 //   compose.h:10-45     TrioKey (qa,qb,filter)
 //   state.h:158-199     indexBy: per-key lists built with push_front => matches come in REVERSED arc order
 //   cascade.h:489-599   record / record1 / record2 / record_eps / cons / cons_chain (chain ids = groupId)
@@ -15,6 +16,7 @@
 #pragma once
 #include "wfst.hpp"
 #include <map>
+#include <tuple>
 
 namespace oracle {
 
@@ -400,6 +402,100 @@ inline void compose(Wfst& out, Cascade& cascade, Wfst& a, Wfst& b, unsigned inde
       if (pFinal[i] >= 0) S[pFinal[i]].push_back(Arc(EMPTY, EMPTY, out.final_state, LW::one(), cascade.locked_1_groupid()));
   }
   for (auto& st : S) std::reverse(st.begin(), st.end());  // push_front lists
+}
+
+// compose.cc:219-313, carmel -a ("preserveGroups"): 2-state filter
+//   0->0 : a:c from a:b (in l) and b:c (in r), incl. b=*e*;  1->0 : the same with b != *e*;  0->1, 1->1 : *e*:c from r.
+// An arc a:b of l goes to a "mediate" state (l's destination, r's state, b) as a:*e*; r's b:c arcs leave it as *e*:c.
+// Every composed arc is recorded with record1 / record2: it stands for exactly one operand arc.
+inline void compose_a(Wfst& out, Cascade& cascade, Wfst& a, Wfst& b) {
+  out = Wfst();
+  out.in_alph = a.in_alph;
+  out.out_alph = b.out_alph;
+  out.named_states = false;
+  if (!(a.valid && b.valid)) {
+    out.valid = false;
+    return;
+  }
+  std::vector<unsigned> map(a.out_alph.size());
+  for (unsigned i = 0; i < a.out_alph.size(); ++i) {
+    const unsigned* ip = b.in_alph.find(a.out_alph.names[i]);
+    map[i] = ip ? *ip : ~0u;
+  }
+  typedef std::tuple<unsigned, unsigned, int> Trio;      // qa, qb, filter
+  typedef std::tuple<unsigned, unsigned, unsigned> Half;  // l_dest, r_source, hidden letter
+  std::map<Trio, unsigned> stateMap;
+  std::map<Half, unsigned> arcStateMap;
+  std::vector<std::pair<unsigned, Trio> > queue;
+  std::vector<std::vector<Arc> >& S = out.states;
+  S.clear();
+  S.emplace_back();
+  stateMap[Trio(0, 0, 0)] = 0;
+  queue.push_back({0u, Trio(0, 0, 0)});
+  auto composearc = [&](unsigned from, unsigned in, unsigned o, Trio dest, LW weight, unsigned g) {
+    auto ins = stateMap.emplace(dest, (unsigned)S.size());
+    if (ins.second) {
+      queue.push_back({ins.first->second, dest});
+      S.emplace_back();
+    }
+    S[from].push_back(Arc(in, o, ins.first->second, weight, g));
+  };
+  while (!queue.empty()) {
+    const unsigned source = queue.back().first;
+    const Trio tri = queue.back().second;
+    queue.pop_back();
+    const unsigned sqa = std::get<0>(tri), sqb = std::get<1>(tri);
+    const int filter = std::get<2>(tri);
+    auto& qa = a.states[sqa];
+    auto& qb = b.states[sqb];
+    std::map<unsigned, std::vector<Arc*> > aindex, bindex;  // ascending symbol; lists newest first (push_front)
+    for (size_t k = qa.size(); k-- > 0;) aindex[qa[k].out].push_back(&qa[k]);
+    for (size_t k = qb.size(); k-- > 0;) bindex[qb[k].in].push_back(&qb[k]);
+    for (auto& ll : aindex) {
+      if (ll.first == EPS) {
+        if (filter == 0)
+          for (Arc* la : ll.second) composearc(source, la->in, EPS, Trio(la->dest, sqb, 0), la->weight, cascade.record1(la));
+        continue;
+      }
+      if (map[ll.first] == ~0u) continue;
+      auto matches = bindex.find(map[ll.first]);
+      if (matches == bindex.end()) continue;
+      for (Arc* la : ll.second) {
+        auto ins = arcStateMap.emplace(Half(la->dest, sqb, ll.first), (unsigned)S.size());
+        const unsigned mediate = ins.first->second;
+        if (ins.second) {
+          S.emplace_back();
+          for (Arc* ra : matches->second)
+            composearc(mediate, EPS, ra->out, Trio(la->dest, ra->dest, 0), ra->weight, cascade.record2(ra));
+        }
+        S[source].push_back(Arc(la->in, EPS, mediate, la->weight, cascade.record1(la)));
+      }
+    }
+    auto eb = bindex.find(EPS);
+    if (eb != bindex.end())
+      for (Arc* ra : eb->second) composearc(source, EPS, ra->out, Trio(sqa, ra->dest, 1), ra->weight, cascade.record2(ra));
+  }
+  unsigned nFinal = 0;
+  int pFinal[3] = {-1, -1, -1};
+  for (int i = 0; i < 3; ++i) {
+    auto it = stateMap.find(Trio(a.final_state, b.final_state, i));
+    if (it != stateMap.end()) {
+      pFinal[i] = (int)it->second;
+      ++nFinal;
+      out.final_state = it->second;
+    }
+  }
+  if (nFinal == 0) {
+    out.valid = false;
+    return;
+  }
+  if (nFinal > 1) {
+    out.final_state = (unsigned)S.size();
+    S.emplace_back();
+    for (int i = 0; i < 3; ++i)
+      if (pFinal[i] >= 0) S[pFinal[i]].push_back(Arc(EPS, EPS, out.final_state, LW::one(), cascade.locked_1_groupid()));
+  }
+  for (auto& st : S) std::reverse(st.begin(), st.end());
 }
 
 }  // namespace oracle

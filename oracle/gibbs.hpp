@@ -84,6 +84,9 @@ struct GibbsTrace {
   std::vector<double> iter_logprob;               // ln cache-model prob of the whole sample (the default log line,
                                                   // gibbs_opts.hpp cache_prob = true; gibbs.hpp:712-742)
   std::vector<double> iter_cheap_logprob;         // ln of the product over blocks of the proposal prob (--sample-prob)
+  std::vector<double> iter_after_logprob;         // ... with every block's prob taken AFTER its sample was added back: the
+                                                  // "overestimate" of the comment at gibbs.hpp:866 -- what the older binary
+                                                  // behind carmel-tutorial/commands.trace logged as its sample prob
   std::vector<std::vector<unsigned> > last_sample;  // per block: param ids of the final sample
 };
 
@@ -336,7 +339,7 @@ struct CarmelGibbs {
     for (unsigned iter = 0; iter <= Ni; ++iter) {
       time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)gopt.burnin);
       use_init = run_index == 0 && iter == 0 && !init_logw.empty();
-      LW p = LW::one(), pc = LW::one();
+      LW p = LW::one(), pc = LW::one(), pself = LW::one();
       // cache model (gibbs.hpp:678-742): counts restart from the priors every iteration and grow by one per use
       std::vector<double> ccount(gps.size(), 0.0), csum(nnorm, 0.0);
       for (size_t i = 0; i < gps.size(); ++i)
@@ -367,10 +370,13 @@ struct CarmelGibbs {
         }
         mul_eq(pc, bc);
         addc(sample[b], wt);
+        for (unsigned pid : sample[b]) mul_eq(pself, LW::from_real(proposal_prob(pid)));
       }
+
       if (tr) {
         tr->iter_logprob.push_back(pc.w);
         tr->iter_cheap_logprob.push_back(p.w);
+        tr->iter_after_logprob.push_back(pself.w);
       }
       if (iter >= gopt.burnin) stats.record(pc);  // gibbs.hpp:942-943 (the logged probability)
     }

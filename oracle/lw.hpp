@@ -146,15 +146,22 @@ inline bool lw_set_string(LW& out, const char* s) {  // weight.h:492-495 setStri
 
 // weight.h:468-489 print with precision 15; SOMETIMES_LOG: real if |ln|<82 else e^x (carmel default,
 // wfstio.cc:47-50); always_log => e^x; never_log => real
-enum LwPrintMode { LW_SOMETIMES_LOG = 0, LW_ALWAYS_LOG = 1, LW_NEVER_LOG = 2 };
+// log base of the log form (weight.h:476-486): e^x, `x ln` (carmel -2), `x log` base 10 (carmel -B; getLog10 :265)
+enum LwPrintMode { LW_SOMETIMES_LOG = 0, LW_ALWAYS_LOG = 1, LW_NEVER_LOG = 2, LW_MODE_MASK = 3, LW_BASE_LN = 16, LW_BASE_LOG10 = 32 };
 inline std::string lw_str(LW x, int mode = LW_SOMETIMES_LOG, int precision = 15) {
   char buf[64];
   if (x.isZero()) return "0";
-  if ((mode == LW_SOMETIMES_LOG && x.fitsInReal()) || mode == LW_NEVER_LOG) {
+  const int m = mode & LW_MODE_MASK;
+  if ((m == LW_SOMETIMES_LOG && x.fitsInReal()) || m == LW_NEVER_LOG) {
     std::snprintf(buf, sizeof buf, "%.*g", precision, x.getReal());
     return buf;
   }
-  std::snprintf(buf, sizeof buf, "e^%.*g", precision, x.w);
+  if (mode & LW_BASE_LN)
+    std::snprintf(buf, sizeof buf, "%.*gln", precision, x.w);
+  else if (mode & LW_BASE_LOG10)
+    std::snprintf(buf, sizeof buf, "%.*glog", precision, (1. / 2.30258509299404568402) * x.w);
+  else
+    std::snprintf(buf, sizeof buf, "e^%.*g", precision, x.w);
   return buf;
 }
 // weight.h:529-532,603 as_base(2): "2^<log2>" at the stream's current precision (default 6)

@@ -350,6 +350,12 @@ void orc_set_gibbs_init_em(unsigned n, int em_p0) {
   g_init_em = n;
   g_em_p0 = em_p0;
 }
+static int g_init_from_p0 = 0;  // --init-from-p0 (gibbs.cc:405-421)
+void orc_set_gibbs_init_from_p0(int on) { g_init_from_p0 = on; }
+static std::vector<double> g_last_after;  // GibbsTrace::iter_after_logprob of the last orc_gibbs_run
+void orc_gibbs_last_after(double* out, uint32_t n) {
+  for (uint32_t i = 0; i < n && i < g_last_after.size(); ++i) out[i] = g_last_after[i];
+}
 void orc_set_gibbs_temps(double high, double low) {
   g_high_temp = high;
   g_low_temp = low;
@@ -548,6 +554,7 @@ int orc_train_cascade_text(int n_wfst, const char** wfst_texts, const char* corp
 struct orc_cascade {
   std::vector<Wfst> chain;
   Cascade cascade{true};
+  explicit orc_cascade(bool remember = true) : cascade(remember) {}
   Wfst* result = 0;
   std::vector<Wfst*> owned;
   ~orc_cascade() {
@@ -555,8 +562,13 @@ struct orc_cascade {
   }
 };
 // composes the transducers left to right exactly as `carmel --train-cascade` does (carmel.cc:1303-1355)
+orc_cascade* orc_cascade_compose_text_ex(int n_wfst, const char** wfst_texts, int remember, int dash_a);
 orc_cascade* orc_cascade_compose_text(int n_wfst, const char** wfst_texts) {
-  orc_cascade* h = new orc_cascade();
+  return orc_cascade_compose_text_ex(n_wfst, wfst_texts, 1, 0);
+}
+// remember = 0: plain `carmel a b` (trivial cascade: no chains, cascade.h:566-592); dash_a: carmel -a (compose.cc:219-313)
+orc_cascade* orc_cascade_compose_text_ex(int n_wfst, const char** wfst_texts, int remember, int dash_a) {
+  orc_cascade* h = new orc_cascade(remember != 0);
   int rc = run_big_stack([&]() {
     h->chain.resize(n_wfst);
     for (int i = 0; i < n_wfst; ++i) {
@@ -575,7 +587,10 @@ orc_cascade* orc_cascade_compose_text(int n_wfst, const char** wfst_texts) {
       else
         h->cascade.prepare_compose(false);
       Wfst* next = new Wfst();
-      compose(*next, h->cascade, *h->result, h->chain[i]);
+      if (dash_a)
+        compose_a(*next, h->cascade, *h->result, h->chain[i]);
+      else
+        compose(*next, h->cascade, *h->result, h->chain[i]);
       h->owned.push_back(next);
       h->result = next;
       if (!h->result->valid) throw std::runtime_error("empty composition");
@@ -706,11 +721,28 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
         }
       }
     }
+    if (g_init_from_p0 && g_init_em <= 0) {
+      // --init-from-p0 (gibbs.cc:405-421): the first sample is drawn from the composed transducer's own weights, not from
+      // the cache.  cascade.normalize(m2) normalises the MEMBERS (add_count 0) and the composed weights are saved without
+      // a cascade.update(): for a real cascade they are the products made at composition time; a single transducer is
+      // its own cascade, so there they are the normalised weights.  The members' weights are restored afterwards.
+      if (h->cascade.trivial) {
+        std::vector<NormalizeMethod> m2 = nms;
+        for (auto& m : m2) m.add_count = LW();
+        Wfst copy = *h->result;
+        copy.normalize(m2[0]);
+        for (auto& st : copy.states)
+          for (auto& a : st) init_logw.push_back(a.weight.w);
+      } else
+        for (auto& st : h->result->states)
+          for (auto& a : st) init_logw.push_back(a.weight.w);
+    }
     CarmelGibbs g(*h->result, h->cascade, c->c, nms, go);
     g.init_logw = init_logw;
     GibbsTrace tr;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     g_best_run = (int)g.best_run;
+    g_last_after = tr.iter_after_logprob;
     for (uint32_t i = 0; i < (iter + 1) * (go.restarts + 1); ++i) {
       if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
       if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];

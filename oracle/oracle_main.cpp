@@ -28,7 +28,9 @@ static int real_main(int argc, char** argv) {
   TrainOpts topt;
   LW converge = LW::from_real(1e-4), converge_pp = LW::from_real(.999), smoothFloor;
   NormalizeMethod nm;
-  std::string normby, priors;
+  std::string normby, priors, digamma;
+  bool have_digamma = false, plus_set = false;
+  double plus_alpha = 0;
   std::vector<const char*> files;
   int idx_threshold = 32;
   for (int i = 1; i < argc; ++i) {
@@ -46,7 +48,10 @@ static int real_main(int argc, char** argv) {
         normby = v;
       else if (k == "priors")
         priors = v;
-      else if (k == "restart-tolerance")  // carmel.cc:1426-1430
+      else if (k == "digamma") {
+        digamma = v;
+        have_digamma = true;
+      } else if (k == "restart-tolerance")  // carmel.cc:1426-1430
         topt.restart_tolerance = std::atof(v.c_str());
       else if (k == "final-restart-tolerance")
         topt.final_restart_tolerance = std::atof(v.c_str());
@@ -79,11 +84,16 @@ static int real_main(int argc, char** argv) {
         topt.restart_seed = std::strtoull(next(), 0, 10);
       else if (last == 'o')  // carmel.cc:940-943
         topt.learning_rate_growth_factor = std::max(1.0, std::atof(next()));
+      else if (last == '+') {  // carmel.cc:1009-1013
+        plus_alpha = std::atof(next());
+        plus_set = true;
+      }
     } else
       files.push_back(argv[i]);
   }
   if (trainc) flags['t'] = true;
-  if (!flags['t'] || files.size() < 2) {
+  const bool scoring = !flags['t'] && flags['S'];
+  if (!(flags['t'] || scoring) || files.size() < 2) {
     std::cerr << "usage: oracle_carmel -t [opts] corpus wfst [wfst...]\n";
     return 2;
   }
@@ -114,7 +124,10 @@ static int real_main(int argc, char** argv) {
     else
       cascade.prepare_compose(false);
     Wfst* next = new Wfst();
-    compose(*next, cascade, *result, chain[i], (unsigned)idx_threshold);
+    if (flags['a'])  // carmel.cc:1318
+      compose_a(*next, cascade, *result, chain[i]);
+    else
+      compose(*next, cascade, *result, chain[i], (unsigned)idx_threshold);
     owned.push_back(next);
     result = next;
     if (!result->valid) {
@@ -147,14 +160,66 @@ static int real_main(int argc, char** argv) {
     size_t i = 0;
     while (std::getline(ss, tok, ',') && i < N) nms[i++].add_count = LW::from_real(std::atof(tok.c_str()));
   }
+  if (plus_set)
+    for (auto& m : nms) {
+      m.scale.linear = false;
+      m.scale.alpha = plus_alpha;
+    }
+  if (have_digamma) {  // carmel.cc:495: one component per transducer, empty = linear
+    size_t i = 0, p0 = 0;
+    while (i < N) {
+      size_t c = digamma.find(',', p0);
+      std::string tok = digamma.substr(p0, c == std::string::npos ? std::string::npos : c - p0);
+      if (!tok.empty()) {
+        nms[i].scale.linear = false;
+        nms[i].scale.alpha = std::atof(tok.c_str());
+      }
+      ++i;
+      if (c == std::string::npos) break;
+      p0 = c + 1;
+    }
+  }
+  int wmode = flags['Z'] ? LW_ALWAYS_LOG : LW_SOMETIMES_LOG;
+  if (flags['D']) wmode = LW_NEVER_LOG;
+  if (flags['B'])
+    wmode |= LW_BASE_LOG10;
+  else if (flags['2'])
+    wmode |= LW_BASE_LN;
+  if (scoring) {  // carmel -S (carmel.cc:1393-1410): WFST::sumOfAllPaths per pair of lines, no weight lines
+    ArcTable arcs;
+    arcs.build(*result, false, LW());
+    IoIndex io;
+    io.build(*result);
+    size_t p = 0;
+    auto next_line = [&](std::string& line) {
+      if (p >= corpus_text.size()) return false;
+      size_t e = corpus_text.find('\n', p);
+      if (e == std::string::npos) e = corpus_text.size();
+      line.assign(corpus_text, p, e - p);
+      p = e + 1;
+      return true;
+    };
+    std::string l1, l2;
+    while (next_line(l1) && next_line(l2)) {
+      Corpus one;
+      std::string w2;
+      read_training_corpus(*result, "1\n" + l1 + "\n" + l2 + "\n", one, &w2);
+      Derivations d;
+      LW prob;
+      if (!one.examples.empty() && d.compute(*result, io, arcs, one.examples.front(), true, 0)) {
+        std::vector<LW> f, b;
+        prob = d.compute_fb(f, b, [&](const GArc& a) { return arcs.t[a.arcid].arc->weight; });
+      }
+      std::cout << lw_str(prob, wmode) << std::endl;
+    }
+    return 0;
+  }
   Corpus corpus;
   std::string warn;
   read_training_corpus(*result, corpus_text, corpus, &warn);
   std::cerr << warn;
   std::vector<IterRecord> trace;
   train(*result, cascade, corpus, nms, flags['U'], smoothFloor, converge, converge_pp, topt, &std::cerr, &trace);
-  int wmode = flags['Z'] ? LW_ALWAYS_LOG : LW_SOMETIMES_LOG;
-  if (flags['D']) wmode = LW_NEVER_LOG;
   if (trainc) {
     for (size_t i = 0; i < nw; ++i) {
       std::string fn = std::string(files[i + 1]) + ".trained";

@@ -9,7 +9,9 @@
 //   wfstio.cc:631-651  symbolList (corpus line -> symbol ids, new symbols get fresh ids)
 //   fst.cc:468-524     reduce() (+ state.h:280-289 remove_epsilons_to); fst.cc:528-543 removeMarkedStates
 //   fst.cc:86-244      normalize() with locked / tied groups; fst.h:1362-1446 NormGroupIter
-//   mean_field_scale.hpp:40-52 (linear scale only; digamma needs boost::math — not restated)
+//   mean_field_scale.hpp:40-52 (linear, or exp(digamma(x + alpha)); boost::math::digamma is a third-party dependency
+//                              absent from the tree: restated below from its published definition, to full f64
+//                              precision -- the reference asks boost for 8 digits, digamma.hpp:24-30)
 #pragma once
 #include "lw.hpp"
 #include <vector>
@@ -265,9 +267,32 @@ inline bool lw_read(CharStream& in, LW& w) {
 }
 
 enum NormGroupBy { NORM_CONDITIONAL = 0, NORM_JOINT = 1, NORM_NONE = 2 };  // fst.h norm_group_by
+// psi(x), x > 0 (Abramowitz & Stegun 6.3.5, 6.3.18): psi(x) = psi(x + 1) - 1/x until x >= 20, then
+// ln x - 1/(2x) - 1/(12 x^2) + 1/(120 x^4) - 1/(252 x^6) + 1/(240 x^8) - 1/(132 x^10)
+inline double digamma(double x) {
+  double r = 0;
+  while (x < 20) {
+    r -= 1 / x;
+    x += 1;
+  }
+  double z = 1 / (x * x);
+  return r + std::log(x) - 0.5 / x - z * (1. / 12 - z * (1. / 120 - z * (1. / 252 - z * (1. / 240 - z / 132))));
+}
+struct MeanFieldScale {  // mean_field_scale.hpp:24-52
+  bool linear = true;
+  double alpha = 0;
+  LW operator()(LW x) const {
+    if (linear) return x;
+    double xa = x.getReal() + alpha;
+    const double floor = .0002;
+    if (xa < floor) return LW::from_ln(digamma(floor)) * LW::from_real(xa / floor);
+    return LW::from_ln(digamma(xa));
+  }
+};
 struct NormalizeMethod {
   int group;
   LW add_count;  // --priors
+  MeanFieldScale scale;  // --digamma / -+ (carmel.cc:495, 1009-1013)
   NormalizeMethod() : group(NORM_CONDITIONAL) {}
 };
 
@@ -566,6 +591,7 @@ struct Wfst {
     int group = method.group;
     if (group == NORM_NONE) return;
     LW addc = method.add_count;
+    const MeanFieldScale& scale = method.scale;
     std::unordered_map<unsigned, LW> groupArcTotal, groupStateTotal, groupMaxLockedSum;
     // pass 1 (fst.cc:117-152)
     for_each_norm_group(group, [&](unsigned, std::vector<Arc*>& g) {
@@ -601,7 +627,7 @@ struct Wfst {
             if (!gmax.isZero()) div_eq(groupNorm, one - gmax);
             LW groupTotal = groupArcTotal[pg];
             if (!groupTotal.isZero()) {
-              a->weight = groupTotal / groupNorm;  // scale() is identity for linear mean_field_scale
+              a->weight = scale(groupTotal) / scale(groupNorm);  // fst.cc:189
               reserved += a->weight;
             } else
               a->weight = LW();
@@ -616,9 +642,9 @@ struct Wfst {
       fraction_remain = fraction_remain - reserved;
       bool something_left = !fraction_remain.isZero();
       if (something_left && (uniform_zero_normgroups || !normal_sum.isZero())) {
-        LW scaled_sum = normal_sum;
+        LW scaled_sum = scale(normal_sum);  // fst.cc:217-221
         for (Arc* a : g)
-          if (a->normal()) a->weight = fraction_remain * a->weight / scaled_sum;
+          if (a->normal()) a->weight = fraction_remain * scale(a->weight) / scaled_sum;
       } else
         for (Arc* a : g)
           if (a->normal()) a->weight = LW();

@@ -53,7 +53,33 @@ def parse_iters(lines):
     return out
 
 
+def sample_corpus(arcs, final, n_pairs, seed):
+    """config 1 (BASELINE.json configs[0]): a corpus of n_pairs output strings read off random start->final
+    paths of a small *e*-input transducer, each arc chosen in proportion to its weight (what `carmel -g` does,
+    fst.cc:24-79, with this script's own numpy stream).  arcs: {state: [(dest, out_symbol_or_None, weight)]}.
+    Format: blank input line, output line (cipher/epsilon-string-pairs)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(n_pairs):
+        s, out = 0, []
+        while s != final:
+            ws = np.array([a[2] for a in arcs[s]])
+            k = int(rng.choice(len(ws), p=ws / ws.sum()))
+            if arcs[s][k][1]:
+                out.append(arcs[s][k][1])
+            s = arcs[s][k][0]
+        lines += ["", " ".join(out)]
+    return "\n".join(lines) + "\n"
+
+
 def main():
+    # config 1 corpora, sampled from the reference's own toy transducers test/train.a.w and sample/wfst3
+    open(os.path.join(HERE, "train.a.w.corpus100"), "w").write(sample_corpus(
+        {0: [(2, None, .1), (1, "b", .6), (0, "a", .3)], 1: [(2, "a", .3), (0, "b", .7)]}, 2, 100, 1))
+    open(os.path.join(HERE, "wfst3.corpus100"), "w").write(sample_corpus(
+        {0: [(2, None, .1), (1, "b", .6), (0, "a", .3), (4, "a", .1)], 1: [(2, "a", .3), (0, "b", .7)], 4: [(2, "c", 1.)]},
+        2, 100, 2))
     for src, dst in FIXTURES:
         shutil.copyfile(os.path.join(REF, src), os.path.join(HERE, dst))
     for src, dst in FOREST_FIXTURES:
@@ -71,8 +97,25 @@ def main():
                    "trace_lines": "6903-6952", "iters": parse_iters(tr[6902:6952]),
                    "composed": {"states": 57, "arcs": 11511}},
     }
+    # carmel --crp -M 6000 tagging.data tagging.fsa tagging.fst (commands:33; trace lines 6976-12990).  The lattice
+    # statistics are deterministic; note what derivations::statistics holds (derivations.h:197-210, 617-618, 687): "pre"
+    # arcs accumulate over all pairs, while pre.states / post.states / post.arcs are ASSIGNED per pair, i.e. they are
+    # the LAST pair's.  The 6001 per-sweep "sample prob" lines depend on the reference's Boost random stream.
+    crp = []
+    for ln in tr[6988:12990]:
+        m = re.match(r"Gibbs i=(\d+) 0\.+ sample prob=2\^(\S+) per-point-ppx\(N=(\d+)\)=2\^(\S+) per-block-ppx\(N=(\d+)\)", ln)
+        if m:
+            crp.append(float(m.group(2)))
+            n_sym, n_blocks = int(m.group(3)), int(m.group(5))
+    assert len(crp) == 6001
+    m = re.search(r"Pre pruning: \((\d+) states, (\d+) arcs\)\nPost pruning: \((\d+) states, (\d+) arcs\)", "\n".join(tr[6980:6988]))
+    gold["tagging-crp"] = {"command": "carmel --crp -M 6000 tagging.data tagging.fsa tagging.fst", "trace_lines": "6976-12990",
+                           "pre_states_last_pair": int(m.group(1)), "pre_arcs_all_pairs": int(m.group(2)),
+                           "post_states_last_pair": int(m.group(3)), "post_arcs_last_pair": int(m.group(4)),
+                           "n_symbols": n_sym, "n_blocks": n_blocks, "log2_sample_prob": crp,
+                           "burned_in_avg_log2": 214371}
     for k, v in gold.items():
-        print(k, len(v["iters"]), "iterations")
+        print(k, len(v.get("iters", v.get("log2_sample_prob"))), "iterations")
     json.dump(gold, open(os.path.join(HERE, "trace_expected.json"), "w"), indent=1)
 
 

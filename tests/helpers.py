@@ -28,7 +28,7 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, la
                                    ptr(c.out_sym), ptr(c.weight), int(prune), threads, small_pairs, small_states,
                                    lane_states)
     assert rc == 0
-    dims = np.zeros(16, np.uint64)
+    dims = np.zeros(19, np.uint64)
     lib.carmel_hip_host_dims(h, ptr(dims))
     nb, noff, na, nlev, npair, ncls = (int(x) for x in dims[:6])
     out = dict(bundles=np.zeros(nb, BUNDLE_DTYPE), in_arcs=np.zeros((na, 2), np.uint32),
@@ -45,7 +45,8 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, la
     out.update(lane_groups=np.zeros(ng, LANE_DTYPE), lane_fwd=np.zeros((nrec, 2), np.uint32),
                lane_bwd=np.zeros((nrec, 2), np.uint32), lane_pair=np.zeros(nslot, np.uint32),
                lane_nstates=np.zeros(nslot, np.uint32), lane_logw=np.zeros(nslot),
-               lane_classes=np.zeros((nlc, 3), np.uint32), total_states=int(dims[14]), total_arcs=int(dims[15]))
+               lane_classes=np.zeros((nlc, 3), np.uint32), total_states=int(dims[14]), total_arcs=int(dims[15]),
+               explored_states=int(dims[8]), explored_arcs=int(dims[9]), last_pair=tuple(int(x) for x in dims[16:19]))
     lib.carmel_hip_host_export_lanes(h, ptr(out["lane_groups"]), ptr(out["lane_fwd"]), ptr(out["lane_bwd"]),
                                      ptr(out["lane_pair"]), ptr(out["lane_nstates"]), ptr(out["lane_logw"]),
                                      ptr(out["lane_classes"]))

@@ -20,6 +20,8 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_capi.SYMBOLS) == syms
+    for s in syms:  # every entry point has a ctypes prototype (a missing one marshals 64-bit arguments as C int)
+        assert getattr(_capi.lib, s).argtypes is not None, s
 
 
 def test_no_gpu_means_loud_failure():

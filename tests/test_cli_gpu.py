@@ -407,3 +407,198 @@ def test_random_one_tape_cascades(tmp_path, seed):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-12)
+
+
+ORACLE_CLI = os.path.join(ROOT, "oracle", "oracle_carmel")
+
+
+def _sub(tmp_path, name):
+    d = tmp_path / name
+    d.mkdir()
+    return d
+
+
+def _same_run(args, tmp_path, trained=(), rel=1e-7, iter_rel=1e-5, env=None):
+    """the front end and the oracle's command line on the same arguments: same EM log lines (6 printed digits), same
+    stdout / *.trained files (weights to `rel`)"""
+    assert os.path.exists(ORACLE_CLI), "oracle CLI not built (make -C oracle)"
+    d1, d2 = tmp_path / "gpu", tmp_path / "cpu"
+    d1.mkdir()
+    d2.mkdir()
+    rc, out, err = run(args, env=dict(env or {}, CARMEL_TRAINED_DIR=str(d1)))
+    assert rc == 0, err
+    e = dict(os.environ)
+    e["ORACLE_TRAINED_DIR"] = str(d2)
+    p = subprocess.run([ORACLE_CLI] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=e)
+    assert p.returncode == 0, p.stderr
+    mine = [l for l in err.split("\n") if l.startswith("i=") or l.startswith("Corpus ")]
+    ref = [l for l in p.stderr.split("\n") if l.startswith("i=") or l.startswith("Corpus ")]
+    assert len(mine) == len(ref) >= 1, (err, p.stderr)
+    for x, y in zip(mine, ref):
+        assert NUM.sub("#", x) == NUM.sub("#", y), (x, y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=iter_rel)
+
+    def same_text(a, b):
+        al, bl = a.strip().split("\n"), b.strip().split("\n")
+        assert len(al) == len(bl)
+        for x, y in zip(al, bl):
+            assert NUM.sub("#", x) == NUM.sub("#", y), (x, y)
+            for u, v in zip(NUM.findall(x), NUM.findall(y)):
+                assert float(u) == pytest.approx(float(v), rel=rel, abs=1e-300)
+    same_text(out, p.stdout)
+    for name in trained:
+        same_text(open(str(d1 / (name + ".trained"))).read(), open(str(d2 / (name + ".trained"))).read())
+    return err, out
+
+
+@pytest.mark.parametrize("model,corpus", [("train.a.w", "train.a.w.corpus100"), ("wfst3", "wfst3.corpus100"),
+                                          ("train.a.u", "train.a.w.corpus100")])
+def test_config1_toy_transducer_ten_iterations(golden_dir, tmp_path, model, corpus):
+    """BASELINE.json configs[0]: the reference's 3-state toy transducers (carmel/test/train.a.w, carmel/sample/wfst3),
+    `carmel -t -M 10` on a 100-pair corpus sampled from them (tests/golden/make_golden.py), against the oracle's run"""
+    g = lambda n: os.path.join(golden_dir, n)
+    err, out = _same_run(["-t", "-M", "10", g(corpus), g(model)], tmp_path)
+    assert len(ITER.findall(err)) >= 2
+
+
+def test_dash_a_composition_trains_the_same_model(golden_dir, tmp_path):
+    """carmel -a (compose.cc:219-313): more states, fewer arcs, the same paths -- so --train-cascade reports the same
+    corpus probabilities iteration by iteration and writes the same trained members with and without it (the property
+    carmel/test/test.compose.-a.sh checks through -S), and both equal the oracle's -a run"""
+    g = lambda n: os.path.join(golden_dir, n)
+    base = ["--train-cascade", "-HJ", "-M", "6", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    e_a, _ = _same_run(["-a"] + base, _sub(tmp_path, "a"), trained=("cipher.wfsa", "cipher.fst"))
+    d = tmp_path / "plain"
+    d.mkdir()
+    rc, out, e_p = run(base, env={"CARMEL_TRAINED_DIR": str(d)})
+    assert rc == 0, e_p
+    ia, ip = ITER.findall(e_a), ITER.findall(e_p)
+    assert len(ia) == len(ip) == 6
+    for x, y in zip(ia, ip):
+        assert float(x[1]) == pytest.approx(float(y[1]), rel=1e-5)
+    assert "(57 states / 11511 arcs)" in e_p and "(57 states / 11511 arcs)" not in e_a
+    ta = open(str(tmp_path / "a" / "gpu" / "cipher.fst.trained")).read()
+    tp = open(str(d / "cipher.fst.trained")).read()
+    for x, y in zip(ta.strip().split("\n"), tp.strip().split("\n")):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
+
+
+def test_dash_S_scores_pairs_and_agrees_with_dash_a(tmp_path, oracle):
+    """carmel -S (carmel.cc:1393-1410): one sum-of-paths probability per pair; -a and the plain composition give the same
+    scores (carmel/test/test.compose.-a.sh), and both are the oracle's"""
+    import numpy as np
+    from test_cli_host import random_fst_text
+    done = 0
+    for seed in range(60):
+        rng = np.random.default_rng(500 + seed)
+        mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
+        a = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), ["a", "b"], mid, float(rng.uniform(0, 0.3)))
+        b = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.3)))
+        try:
+            oracle.OracleCascade([a, b])
+        except RuntimeError:
+            continue
+        pa, pb, pc = str(tmp_path / ("a%d" % seed)), str(tmp_path / ("b%d" % seed)), str(tmp_path / ("c%d" % seed))
+        open(pa, "w").write(a)
+        open(pb, "w").write(b)
+        lines = []
+        for i in ["", "a", "b", "a b", "b a", "a b a"]:
+            for o in ["", "u", "v", "u v", "v u v"]:
+                lines += [i, o]
+        open(pc, "w").write("\n".join(lines) + "\n")
+        res = []
+        for extra in ([], ["-a"]):
+            rc, out, err = run(["-S", "-q"] + extra + [pc, pa, pb])
+            assert rc == 0, err
+            p = subprocess.run([ORACLE_CLI, "-S", "-q"] + extra + [pc, pa, pb], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               universal_newlines=True)
+            assert p.returncode == 0, p.stderr
+            got, ref = [float(x) for x in out.split()], [float(x) for x in p.stdout.split()]
+            assert len(got) == len(ref) == 30
+            assert got == pytest.approx(ref, rel=1e-9, abs=1e-300)
+            res.append(got)
+            assert "-S corpus product of probs=" in err
+        assert res[0] == pytest.approx(res[1], rel=1e-9, abs=1e-300)
+        if any(x > 0 for x in res[0]):
+            done += 1
+        if done >= 12:
+            break
+    assert done >= 12
+
+
+@pytest.mark.parametrize("opts", [["--digamma=0,"], ["--digamma=,0.5"], ["--digamma=0.1,0.2", "--priors=0.5,0.5"]])
+def test_digamma_cascade(golden_dir, tmp_path, opts):
+    """--digamma (mean_field_scale.hpp:40-52, fst.cc:189, 217-221; carmel.cc:495): exp(digamma(x + alpha)) in the
+    numerator and the denominator of a member's normalisation"""
+    g = lambda n: os.path.join(golden_dir, n)
+    _same_run(["--train-cascade", "-HJ", "-M", "5"] + opts + [g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")], tmp_path,
+              trained=("cipher.wfsa", "cipher.fst"), rel=1e-6)
+
+
+def test_digamma_single_transducer_plus_switch(golden_dir, tmp_path):
+    g = lambda n: os.path.join(golden_dir, n)
+    _same_run(["-t", "-M", "4", "-+", "0", g("epron-jpron.data"), g("epron-jpron.fst")], tmp_path, rel=1e-6)
+    _same_run(["-t", "-j", "-M", "4", "-+", "0.25", g("wfst3.corpus100"), g("wfst3")], _sub(tmp_path, "j"), rel=1e-6)
+
+
+def test_zero_iterations_give_fractional_counts(golden_dir, tmp_path):
+    """-M 0 (train.cc:520-531): the output weights are the unnormalised expected counts (+ -f), locked arcs untouched"""
+    g = lambda n: os.path.join(golden_dir, n)
+    err, out = _same_run(["-t", "-M", "0", "-f", "0.5", g("epron-jpron.data"), g("epron-jpron.fst")], tmp_path)
+    assert "output weights will be unnormalized fractional counts" in err
+    _same_run(["--train-cascade", "-HJ", "-M", "0", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")], _sub(tmp_path, "c"),
+              trained=("cipher.wfsa", "cipher.fst"))
+
+
+def test_prior_counts_from_weights_on_a_cascade(golden_dir, tmp_path):
+    """-U with --train-cascade (derivations.h:96-101): every composed arc's initial weight is a prior count"""
+    g = lambda n: os.path.join(golden_dir, n)
+    for k, env in enumerate(({}, {"CARMEL_HIP_UNROLLED": "0"})):  # the unrolled sweep and explicit lattices
+        _same_run(["--train-cascade", "-HJ", "-U", "-f", "0.01", "-M", "4", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")],
+                  _sub(tmp_path, str(k)), trained=("cipher.wfsa", "cipher.fst"), env=env)
+
+
+def test_single_iteration_with_restarts_runs_the_restart_loop(golden_dir, tmp_path):
+    """-M 1 -! 2: the one-iteration shortcut is taken only without random restarts (train.cc:520)"""
+    g = lambda n: os.path.join(golden_dir, n)
+    err, out = _same_run(["-t", "-M", "1", "-!", "2", "-R", "4", g("epron-jpron.data"), g("epron-jpron.fst")], tmp_path)
+    assert err.count("Random restart - ") == 2
+
+
+def test_training_a_plain_composition(golden_dir, tmp_path):
+    """carmel -t corpus a b without --train-cascade trains the composed arcs themselves (cascade trivial)"""
+    g = lambda n: os.path.join(golden_dir, n)
+    _same_run(["-t", "-M", "3", g("chain.corpus"), g("chain.1"), g("chain.2")], tmp_path)
+
+
+def test_crp_tagging_against_the_recorded_run(golden_dir, tmp_path):
+    """$CARMEL --crp -M 6000 tagging.data tagging.fsa tagging.fst (commands:33; trace lines 6976-12990), the only
+    reference-held data for the sampler: the lattice statistics exactly, the level of the per-sweep sample probability
+    within a band (see tests/test_gibbs_host.py::test_oracle_sampler_reaches_the_recorded_probability_level for what
+    the recorded binary logged and why the band is 0.2 %).  Exact mode, 1200 sweeps (the recorded chain is level from
+    sweep ~500 on; its per-1000-sweep means lie within 2^-214294 .. 2^-214366)."""
+    import numpy as np
+    gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["tagging-crp"]
+    g = lambda n: os.path.join(golden_dir, n)
+    rc, out, err = run(["--crp", "-M", "1200", "--init-from-p0", "--sample-prob-after", "-R", "1", "-HJ", g("tagging.data"),
+                        g("tagging.fsa"), g("tagging.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc == 0, err
+    assert "(46 states / 400994 arcs)" in err
+    assert err.count("Gibbs sampling requires positive --priors for base model / initial sample.  Setting to 0.01") == 2
+    assert "Pre pruning: (%d states, %d arcs)" % (gold["pre_states_last_pair"], gold["pre_arcs_all_pairs"]) in err
+    assert "Post pruning: (%d states, %d arcs)" % (gold["post_states_last_pair"], gold["post_arcs_last_pair"]) in err
+    assert "Portion kept: (0.75 states, 0.000896709 arcs)" in err  # trace line 6986
+    lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
+    assert len(lines) == 1201
+    assert "per-point-ppx(N=%d)" % gold["n_symbols"] in lines[0] and "per-block-ppx(N=%d)" % gold["n_blocks"] in lines[0]
+    got = np.array([float(re.search(r"prob=2\^(\S+)", l).group(1)) for l in lines])
+    rec = np.array(gold["log2_sample_prob"])
+    level = rec[1000:].mean()
+    assert abs(got[200:].mean() - level) < 0.002 * abs(level)
+    assert got[200:].std() < 3 * rec[1000:].std()
+    assert got[1] < got[10] < got[50] < level + 300
+    for name in ("tagging.fsa", "tagging.fst"):
+        assert os.path.getsize(os.path.join(str(tmp_path), name + ".trained")) > 1000

@@ -37,7 +37,7 @@ def test_composition_is_the_references(oracle, golden_dir, a, b, states, arcs):
     assert rc == 0, err
     assert "Number of states in result: %d" % states in out and "Number of arcs in result: %d" % arcs in out
     rc, out, err = run("-HJ", "-q", pa, pb)
-    oc = oracle.OracleCascade([open(pa).read(), open(pb).read()])
+    oc = oracle.OracleCascade([open(pa).read(), open(pb).read()], remember=False)  # plain `carmel a b`: no chains
     assert out == oc.composed().write(full=True, onearc=True)
 
 
@@ -79,10 +79,13 @@ def random_fst_text(rng, n_states, n_arcs, in_syms, out_syms, p_eps):
     return "\n".join(lines) + "\n"
 
 
+@pytest.mark.parametrize("dash_a", [False, True])
 @pytest.mark.parametrize("seed", range(40))
-def test_composition_of_random_transducers(oracle, tmp_path, seed):
-    """compose.cc's three-state epsilon filter, LIFO state discovery, arc prepending and reduction on random inputs:
-    the front end's composition must be the oracle's, arc for arc, in the same order (bit-exact arc indexing)"""
+def test_composition_of_random_transducers(oracle, tmp_path, seed, dash_a):
+    """compose.cc's three-state epsilon filter (and, with -a, its two-state filter with mediate states, :219-313), LIFO
+    state discovery, arc prepending and reduction on random inputs: the front end's composition must be the oracle's,
+    arc for arc, in the same order (bit-exact arc indexing), groups included (a plain composition keeps the group of a
+    copied epsilon arc and gives none to a paired one, cascade.h:566-592)"""
     import numpy as np
     rng = np.random.default_rng(seed)
     mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
@@ -91,9 +94,9 @@ def test_composition_of_random_transducers(oracle, tmp_path, seed):
     pa, pb = str(tmp_path / "a.fst"), str(tmp_path / "b.fst")
     open(pa, "w").write(a)
     open(pb, "w").write(b)
-    rc, out, err = run("-HJ", "-q", pa, pb)
+    rc, out, err = run("-HJ", "-q", *((["-a"] if dash_a else []) + [pa, pb]))
     try:
-        oc = oracle.OracleCascade([a, b])
+        oc = oracle.OracleCascade([a, b], remember=False, dash_a=dash_a)
     except RuntimeError:
         assert rc != 0  # empty composition: both say so
         return
@@ -117,3 +120,41 @@ def test_load_fem_param(golden_dir, tmp_path, oracle):
     open(pf, "w").write("0.5\n")
     rc, out, err = run("-HJ", "--load-fem-param=" + pf, path)
     assert rc != 0 and "doesn't have enough params" in err
+
+
+def test_unimplemented_switches_are_refused(golden_dir):
+    """a switch or option outside the training path exits -12 with a message instead of being accepted and ignored
+    (the verdict of round 1: `-a`, `-B`, `-k n` were swallowed; carmel.cc:1137 is the reference's own -12)"""
+    path = os.path.join(golden_dir, "train.a.w")
+    for args in (["-k", "3", path], ["-g", "5", path], ["--matrix-fb", "-t", path, path], ["-v", path], ["-N", "0", path],
+                 ["--project-left", path], ["-tx", path, path]):
+        rc, out, err = run(*args)
+        assert rc == 256 - 12, (args, rc, err)
+        assert "not implemented" in err and out == ""
+    rc, out, err = run("-h")
+    assert rc == 0
+
+
+@pytest.mark.parametrize("flags,suffix", [("-ZB", "log"), ("-Z2", "ln"), ("-Z", None)])
+def test_weight_output_bases(golden_dir, oracle, flags, suffix):
+    """-B / -2 (carmel.cc:76-101; weight.h:476-486): a weight in log form is written `x log` (base 10) or `x ln` instead
+    of e^x; the reader takes all three spellings back (weight.h:503-528) to the same weights"""
+    import math
+    import re
+    path = os.path.join(golden_dir, "train.a.w")
+    rc, out, err = run(flags, "-HJ", path)
+    assert rc == 0, err
+    ws = oracle.OracleWfst.parse(open(path).read())
+    ws.reduce()
+    want = ws.arrays()["logw"]
+    toks = re.findall(r" (\S+)\)\)", out)
+    assert len(toks) == len(want)
+    for tok, lw in zip(toks, want):
+        if suffix == "log":
+            assert tok.endswith("log") and float(tok[:-3]) * math.log(10) == pytest.approx(lw, abs=1e-12)
+        elif suffix == "ln":
+            assert tok.endswith("ln") and float(tok[:-2]) == pytest.approx(lw, abs=1e-12)
+        else:
+            assert tok.startswith("e^") and float(tok[2:]) == pytest.approx(lw, abs=1e-12)
+    back = oracle.OracleWfst.parse(out)  # the oracle's reader parses what the front end wrote
+    assert back.arrays()["logw"] == pytest.approx(want, abs=1e-12)

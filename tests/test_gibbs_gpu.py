@@ -59,6 +59,29 @@ def test_gibbs_exact_mode_reproduces_the_reference_chain(oracle, golden_dir, ite
     fb.close()
 
 
+def test_first_sample_from_given_weights_and_the_after_statistic(oracle, golden_dir):
+    """--init-from-p0 (gibbs.cc:405-421: the first sweep samples from the composed transducer's own weights instead of
+    the cache) and the add-back sample probability (carmel_hip_gibbs_run_ex): the exact chain and all three per-sweep
+    probabilities equal the oracle's"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    gs = HipGibbs(fb, 9, burnin=3, seed=5, mode=0)
+    gs.set_init_weights(fb.wfst.logw)  # the composed arcs' weights as composed
+    got_lp = gs.run(after=True)
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.5, 0.1], iters=9, burnin=3, init_from_p0=True)
+    for b in range(gs.n_blocks):
+        assert gs.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(gs.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(gs.iter_after_logprob, ref["iter_after_logprob"], rtol=1e-10)
+    assert np.all(gs.iter_after_logprob > gs.iter_cheap_logprob)  # counting the sample itself can only raise it
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
+
+
 @pytest.mark.parametrize("iters,burnin", [(6, 0), (8, 3)])
 def test_expectation_mode_is_the_reference_online_em(oracle, golden_dir, iters, burnin):
     """--expectation (derivations.h:381-398 collect_counts_gibbs, gibbs.hpp:783-792): every block puts the posterior
@@ -154,37 +177,45 @@ def test_gibbs_parallel_mode_is_a_valid_sampler(oracle, golden_dir):
     assert abs(tail1 - tail0) < 0.05 * abs(tail0)
 
 
+def _random_cascade_case(oracle, seed):
+    """a random two-member cascade + corpus on which the sampler has something to do: draws are rejected (on the CPU,
+    with the oracle) until the composition is non-empty and at least one pair has a derivation, so every seed runs"""
+    from test_cli_host import random_fst_text
+    for attempt in range(200):
+        rng = np.random.default_rng(2000 + seed + 1000 * attempt)
+        mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
+        a = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), ["a", "b"], mid, float(rng.uniform(0, 0.3)))
+        b = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.3)))
+        ins = ["", "a", "b", "a a", "a b", "b a", "b b", "a b a"]
+        outs = ["", "u", "v", "u u", "u v", "v u", "v v", "v u v"]
+        lines = []
+        for i in ins:
+            for o in outs:
+                if rng.random() < 0.7:
+                    lines += [i, o]
+        corpus_text = "\n".join(lines) + "\n"
+        normby = str(rng.choice(["CC", "JC", "CJ"]))
+        priors = [float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))]
+        try:
+            oc = oracle.OracleCascade([a, b])
+            if not oracle.estimate(oc.composed(), oc.corpus(corpus_text))["has_deriv"].any():
+                continue
+        except RuntimeError:  # empty composition
+            continue
+        return a, b, corpus_text, normby, priors
+    raise AssertionError("no usable random cascade for seed %d" % seed)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_gibbs_exact_chain_on_random_cascades(oracle, seed):
     """the exact sweep on random two-member cascades (locked arcs, epsilons, pairs without derivations, mixed
     normalisations): same samples, probabilities and time-averaged weights as the oracle's chain"""
     from carmel_amd.trainer import HipGibbs
-    from test_cli_host import random_fst_text
-    rng = np.random.default_rng(2000 + seed)
-    mid = ["x", "y", "z"][:int(rng.integers(2, 4))]
-    a = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), ["a", "b"], mid, float(rng.uniform(0, 0.3)))
-    b = random_fst_text(rng, int(rng.integers(2, 6)), int(rng.integers(4, 14)), mid, ["u", "v"], float(rng.uniform(0, 0.3)))
-    ins = ["", "a", "b", "a a", "a b", "b a", "b b", "a b a"]
-    outs = ["", "u", "v", "u u", "u v", "v u", "v v", "v u v"]
-    lines = []
-    for i in ins:
-        for o in outs:
-            if rng.random() < 0.7:
-                lines += [i, o]
-    corpus_text = "\n".join(lines) + "\n"
-    normby = str(rng.choice(["CC", "JC", "CJ"]))
+    a, b, corpus_text, normby, priors = _random_cascade_case(oracle, seed)
     norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
-    priors = [float(rng.uniform(0.05, 1.0)), float(rng.uniform(0.05, 1.0))]
-    try:
-        oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
-    except RuntimeError:
-        pytest.skip("empty composition")
+    oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
     iters, burnin = 7, 2
-    try:
-        gs = HipGibbs(fb, iters, burnin=burnin, seed=3 + seed, mode=0)
-    except Exception as e:
-        assert "derivation" in str(e)
-        pytest.skip("no pair has a derivation")
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=3 + seed, mode=0)
     got_lp = gs.run()
     ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin)
     assert gs.n_blocks == len(ref["samples"])

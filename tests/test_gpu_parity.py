@@ -414,3 +414,30 @@ def test_golden_tagging_cascade(oracle, golden_dir):
         assert t["new_best"] == g["new_best"]
         assert t["n_example"] == g["n_example"]
     fb.close()
+
+
+@pytest.mark.parametrize("group", [NORM_CONDITIONAL, NORM_JOINT])
+@pytest.mark.parametrize("lock,add_count", [(False, 0.0), (True, 0.0), (True, 0.3)])
+def test_mstep_normalize_large_unnormalised_model(oracle, group, lock, add_count):
+    """WFST::normalize (fst.cc:86-244) of an UNNORMALISED 1.2 M-arc model through the one-pass window kernel: with 12 arcs
+    per state every 256-parameter workgroup boundary cuts a norm group, so each workgroup reads weights that its
+    neighbours are rewriting in the same launch -- they must come from the snapshot, not from the live array."""
+    w = synth.random_wfst(100001, 12, n_sym=4, p_eps=0.1, seed=21)
+    rng = np.random.default_rng(5)
+    logw = np.log(rng.uniform(0.05, 4.0, w.n_arcs))
+    grp = w.group.copy()
+    if lock:
+        grp[::5] = 0
+        logw[::5] = np.log(0.02)
+    w = Wfst(w.n_states, w.final, w.src, w.dst, w.isym, w.osym, logw, grp)
+    c = synth.random_walk_corpus(w, 20, min_arcs=3, max_arcs=8, seed=21, out_degree=12)
+    ow = oracle.OracleWfst.from_arrays(w)
+    ow.normalize(group, add_count)
+    want = np.exp(ow.arrays()["logw"])
+    got = []
+    for _ in range(2):
+        fb = _fb(w, c, norm_group=group, add_count=add_count)  # normalises once at construction (train.cc:509)
+        got.append(fb.weights())
+        fb.close()
+    np.testing.assert_allclose(np.exp(got[0]), want, rtol=1e-12, atol=1e-300)
+    assert np.array_equal(got[0], got[1])
