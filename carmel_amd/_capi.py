@@ -23,7 +23,7 @@ SYMBOLS = [
     "carmel_hip_fractional_counts", "carmel_hip_set_digamma",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
-    "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_max_sample",
+    "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_lattice_stats", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_run_ex", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
@@ -116,6 +116,7 @@ def _load():
     lib.carmel_hip_gibbs_create.argtypes = [C.POINTER(vp), vp, C.POINTER(GibbsOpts)]
     lib.carmel_hip_gibbs_destroy.argtypes = [vp]
     lib.carmel_hip_gibbs_n_blocks.argtypes = [vp]
+    lib.carmel_hip_gibbs_lattice_stats.argtypes = [vp, C.POINTER(LatticeStats)]
     lib.carmel_hip_gibbs_n_blocks.restype = C.c_uint32
     lib.carmel_hip_gibbs_max_sample.argtypes = [vp]
     lib.carmel_hip_gibbs_max_sample.restype = C.c_uint32

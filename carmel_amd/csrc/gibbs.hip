@@ -625,6 +625,24 @@ int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g) {
 }
 
 uint32_t carmel_hip_gibbs_n_blocks(carmel_hip_gibbs* g) { return g ? g->n_blocks : 0; }
+int carmel_hip_gibbs_lattice_stats(carmel_hip_gibbs* g, carmel_hip_lattice_stats* st) {
+  if (!g || !st) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  const LatticeSet& L = g->lat;
+  std::memset(st, 0, sizeof *st);
+  st->n_pairs = g->t->corpus.n_pairs;
+  st->n_pairs_kept = L.n_kept;
+  st->explored_states = L.explored_states;
+  st->explored_arcs = L.explored_arcs;
+  st->kept_states = L.total_states;
+  st->kept_arcs = L.total_arcs;
+  st->n_cyclic_pairs = L.n_cyclic;
+  st->n_bundles = L.bundles.size();
+  st->max_levels = L.max_levels;
+  st->last_pair_explored_states = L.last_pre_states;
+  st->last_pair_kept_states = L.last_post_states;
+  st->last_pair_kept_arcs = L.last_post_arcs;
+  return CARMEL_HIP_OK;
+}
 
 // gibbs_base::run (gibbs.hpp:803-828): restore_p0, the initial sample (iteration 0), then iter = 1..Ni with
 // time = max(0, iter - burnin); finally finalize_cumulative_counts (gibbs.hpp:626-638).

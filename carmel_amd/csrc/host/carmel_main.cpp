@@ -438,9 +438,14 @@ static int run(int argc, char** argv) {
     return 0;
   }
   set_methods(addc);
+  // arcs_table priors (derivations.h:96-101) are captured when forward_backward is constructed (train.cc:513): after
+  // cascade.normalize (train.cc:509), which for a real cascade normalises the MEMBERS only -- the composed arcs still
+  // carry their composition-time products until the first cascade.update() (train.cc:576).  So -U on a cascade takes its
+  // prior counts from the weights as composed; a single transducer is its own cascade and gives its normalised weights.
+  const bool want_prior = !o.crp && (!cascade || o.smooth_floor > 0 || o.flags[(unsigned)'U']);
+  if (want_prior && cascade) hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
   if (!o.crp) hip_check(carmel_hip_normalize(t), "carmel_hip_normalize");  // train.cc:509 (not for --crp, gibbs.cc:403)
-  if (!o.crp && (!cascade || o.smooth_floor > 0 || o.flags[(unsigned)'U']))  // arcs_table priors (derivations.h:96-101)
-    hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
+  if (want_prior && !cascade) hip_check(carmel_hip_set_prior(t, o.smooth_floor, o.flags[(unsigned)'U'] ? 1 : 0), "carmel_hip_set_prior");
   hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
                                   pairs.out_sym.data(), pairs.weight.data()),
             "carmel_hip_set_corpus");
@@ -459,6 +464,17 @@ static int run(int argc, char** argv) {
     fe.write_forests(of, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(), pairs.out_sym.data(),
                      pairs.weight.data());
   }
+  // `log << derivations::global_stats` of cache_derivations (cached_derivs.h:137; derivations.h:197-247), printed whenever
+  // the derivations are cached (-? -: --crp).  What the reference prints as "Pre pruning: (S states, A arcs)" is A summed
+  // over all pairs but S of the LAST pair, and "Post pruning" is the last pair that has a derivation (see
+  // carmel_hip_lattice_stats).  Its two "Avg # of paths" lines are not produced.
+  auto log_lattice_stats = [](const carmel_hip_lattice_stats& ls, size_t n) {
+    const double s0 = (double)ls.last_pair_explored_states, a0 = (double)ls.explored_arcs, s1 = (double)ls.last_pair_kept_states,
+                 a1 = (double)ls.last_pair_kept_arcs;
+    std::cerr << "\nTotal for " << n << " cached derivations:\nPre pruning: (" << s0 << " states, " << a0
+              << " arcs)\nPost pruning: (" << s1 << " states, " << a1 << " arcs)\nPortion kept: (" << (s0 ? s1 / s0 : 0.0)
+              << " states, " << (a0 ? a1 / a0 : 1.0) << " arcs)\n";
+  };
   // ---- WFST::train (train.cc:503-678) over the trainer `t` with the iteration controls of `o`; also the --init-em pass
   // of the sampler (gibbs.cc:411-416) ----
   std::ostream& log = std::cerr;
@@ -470,17 +486,7 @@ static int run(int argc, char** argv) {
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (ls.n_bundles ? "explicit" : "unrolled") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
-  if (o.crp || o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) {
-    // `log << derivations::global_stats` of cache_derivations (cached_derivs.h:137; derivations.h:197-247).  What the
-    // reference prints as "Pre pruning: (S states, A arcs)" is A summed over all pairs but S of the LAST pair, and
-    // "Post pruning" is the last pair that has a derivation (see carmel_hip_lattice_stats).  Its two "Avg # of paths"
-    // lines are not produced.
-    const double s0 = (double)ls.last_pair_explored_states, a0 = (double)ls.explored_arcs, s1 = (double)ls.last_pair_kept_states,
-                 a1 = (double)ls.last_pair_kept_arcs;
-    std::cerr << "\nTotal for " << pairs.size() << " cached derivations:\nPre pruning: (" << s0 << " states, " << a0
-              << " arcs)\nPost pruning: (" << s1 << " states, " << a1 << " arcs)\nPortion kept: (" << (s0 ? s1 / s0 : 0.0)
-              << " states, " << (a0 ? a1 / a0 : 1.0) << " arcs)\n";
-  }
+  if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
     if (!has[p]) {
@@ -708,6 +714,10 @@ static int run(int argc, char** argv) {
     }
     carmel_hip_gibbs* gs = 0;
     hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
+    {
+      carmel_hip_lattice_stats gls;
+      if (carmel_hip_gibbs_lattice_stats(gs, &gls) == CARMEL_HIP_OK) log_lattice_stats(gls, pairs.size());
+    }
     if (!init_arc_logw.empty())
       hip_check(carmel_hip_gibbs_set_init_weights(gs, init_arc_logw.data()), "carmel_hip_gibbs_set_init_weights");
     const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;

@@ -53,7 +53,7 @@ struct FemExport {
       carmel_hip_host_lattices* h;
       ~Free() { carmel_hip_host_free(h); }
     } guard{h};
-    uint64_t dims[16];
+    uint64_t dims[19];
     carmel_hip_host_dims(h, dims);
     std::vector<FemLatticeRecord> bundles(dims[0]);
     std::vector<uint32_t> in_arcs(2 * dims[2]), out_arcs(2 * dims[2]), ioff(dims[1]), ooff(dims[1]), lvl(dims[3]), pstart(dims[4]),

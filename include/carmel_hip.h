@@ -211,6 +211,8 @@ typedef struct carmel_hip_gibbs_opts {
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);
 uint32_t carmel_hip_gibbs_n_blocks(carmel_hip_gibbs* g);
+/* derivations::global_stats of the sampler's cached lattices (cached_derivs.h:137): see carmel_hip_lattice_stats */
+int carmel_hip_gibbs_lattice_stats(carmel_hip_gibbs* g, carmel_hip_lattice_stats* stats);
 uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g);
 /* Runs iter+1 sweeps; iter_logprob[i] = ln of the "cache-model prob" log line of sweep i (gibbs.hpp:712-742; mode
  * 1: the proposal prob), iter_cheap_logprob[i] = ln of the proposal ("--sample-prob") probability; either may be

@@ -467,6 +467,166 @@ int orc_bench_em(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int th
   });
 }
 
+// CPU baseline with the fixed and the per-lattice-arc cost told apart.  One EM iteration of the reference costs
+//   clear counts (O(|WFST arcs|)) + per pair forward/backward/counts (O(lattice arcs)) + maximize (O(|WFST arcs|)),
+// so the seconds per iteration on a SAMPLE of the corpus say little about the full corpus unless the two parts are
+// separated: the E-step is timed over the first quarter of the cached lattices and over all of them, maximize on its
+// own, once single-threaded (the reference is single-threaded) and once with OpenMP over `threads` cores (atomic adds
+// into one linear-domain count table, parallel clear / prep_new_weights / per-state normalisation -- weights checked
+// against the serial normalize).  out[0] build seconds, [1] lattice arcs of the quarter, [2] of all, then per leg (serial at 3,
+// threaded at 7): E-step seconds on the quarter, on all, maximize seconds, ln corpus prob of the last full E-step.
+int orc_bench_em_fit(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int threads, double* out) {
+  return run_big_stack([&]() {
+    typedef std::chrono::steady_clock clk;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    Wfst& x = wh->w;
+    Cascade cascade(false);
+    std::vector<NormalizeMethod> nms(1);
+    nms[0].group = norm_group;
+    cascade.set_composed(&x);
+    cascade.normalize(nms);
+    TrainOpts opts;
+    opts.cache_derivations = true;
+    auto t0 = clk::now();
+    ForwardBackward fb(x, cascade, false, LW(), opts, ch->c);
+    out[0] = secs(t0, clk::now());
+    const size_t n_all = fb.derivs.size(), n_q = std::max<size_t>(1, n_all / 4);
+    double arcs_q = 0, arcs_all = 0;
+    for (size_t p = 0; p < n_all; ++p) {
+      arcs_all += (double)fb.derivs[p].n_arcs();
+      if (p < n_q) arcs_q += (double)fb.derivs[p].n_arcs();
+    }
+    out[1] = arcs_q;
+    out[2] = arcs_all;
+    const size_t na = fb.arcs.t.size();
+    if (iters < 1) iters = 1;
+    // ---- serial leg: the reference's own loop ----
+    auto estep_serial = [&](size_t n) {
+      for (auto& a : fb.arcs.t) a.counts = LW();
+      double sum = 0;
+      for (size_t p = 0; p < n; ++p) sum += fb.derivs[p].collect_counts(fb.arcs).w;
+      return sum;
+    };
+    double lp = 0;
+    auto t1 = clk::now();
+    for (int i = 0; i < iters; ++i) estep_serial(n_q);
+    auto t2 = clk::now();
+    for (int i = 0; i < iters; ++i) lp = estep_serial(n_all);
+    auto t3 = clk::now();
+    // maximize changes the weights; the E-steps above all ran on the same ones
+    for (int i = 0; i < iters; ++i) {
+      if (i) estep_serial(n_all);  // fresh counts for a repeat (not timed below)
+      auto ta = clk::now();
+      fb.maximize(nms, 1.0);
+      out[5] += secs(ta, clk::now()) / iters;
+    }
+    out[3] = secs(t1, t2) / iters;
+    out[4] = secs(t2, t3) / iters;
+    out[6] = lp;
+    if (threads <= 1) return;
+#ifdef _OPENMP
+    omp_set_num_threads(threads);
+    // per-thread copies of a 10^7-entry count table would cost O(threads x |WFST arcs|) per iteration in clearing and
+    // reducing alone; the threaded leg adds into ONE table of linear-domain doubles with atomic adds instead
+    std::vector<double> lin(na);
+    auto estep_par = [&](size_t n) {
+      double sum = 0;
+#pragma omp parallel
+      {
+#pragma omp for schedule(static)
+        for (long k = 0; k < (long)na; ++k) lin[k] = 0.0;
+
+        double ls = 0;
+        std::vector<LW> f, b;
+#pragma omp for schedule(dynamic, 64)
+        for (long p = 0; p < (long)n; ++p) {
+          Derivations& d = fb.derivs[p];
+          auto wf = [&](const GArc& a) { return fb.arcs.t[a.arcid].arc->weight; };
+          LW prob = d.compute_fb(f, b, wf);
+          ls += prob.w;
+          for (unsigned st = 0; st < d.g.size(); ++st)
+            for (const GArc& a : d.g[st]) {  // derivations.h:439-447 with the sum taken in the linear domain
+              const double v = (fb.arcs.t[a.arcid].arc->weight * f[a.src] * b[a.dest] * LW::from_real(d.weight) / prob).getReal();
+#pragma omp atomic
+              lin[a.arcid] += v;
+            }
+        }
+#pragma omp critical
+        sum += ls;
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (long k = 0; k < (long)na; ++k) fb.arcs.t[k].counts = lin[k] > 0 ? LW::from_real(lin[k]) : LW();  // (log(0) traps: slow)
+      }
+      return sum;
+    };
+    // maximize with the per-state work spread over the cores: prep_new_weights (train.cc:134-153), then every state's
+    // norm groups (no ties here: fst.cc:196-230 reduces to w = (1 - locked) * w / sum per group), then max_change
+    std::vector<size_t> first_arc(x.num_states() + 1, 0);
+    for (unsigned st = 0; st < x.num_states(); ++st) first_arc[st + 1] = first_arc[st] + x.states[st].size();
+    auto maximize_par = [&]() {
+#pragma omp parallel for schedule(static)
+      for (long st = 0; st < (long)x.num_states(); ++st) {
+        auto& arcs = x.states[st];
+        for (size_t k = 0; k < arcs.size(); ++k) {
+          ArcRec& a = fb.arcs.t[first_arc[st] + k];
+          if (!arcs[k].locked()) {
+            a.scratch = arcs[k].weight;
+            arcs[k].weight = a.counts + a.prior_counts;
+          }
+        }
+        std::vector<char> done(arcs.size(), 0);
+        for (size_t k = 0; k < arcs.size(); ++k) {
+          if (done[k]) continue;
+          LW normal, locked;
+          for (size_t j = k; j < arcs.size(); ++j)
+            if (norm_group == NORM_JOINT || arcs[j].in == arcs[k].in) (arcs[j].locked() ? locked : normal) += arcs[j].weight;
+          LW remain = LW::one() - locked;
+          for (size_t j = k; j < arcs.size(); ++j)
+            if (norm_group == NORM_JOINT || arcs[j].in == arcs[k].in) {
+              done[j] = 1;
+              if (!arcs[j].locked()) arcs[j].weight = (!remain.isZero() && !normal.isZero()) ? remain * arcs[j].weight / normal : LW();
+            }
+        }
+      }
+    };
+    bool plain = norm_group != NORM_NONE;
+    for (auto& st : x.states)
+      for (auto& a : st)
+        if (a.tied()) plain = false;
+    auto t4 = clk::now();
+    for (int i = 0; i < iters; ++i) estep_par(n_q);
+    auto t5 = clk::now();
+    for (int i = 0; i < iters; ++i) lp = estep_par(n_all);
+    auto t6 = clk::now();
+    out[7] = secs(t4, t5) / iters;
+    out[8] = secs(t5, t6) / iters;
+    for (int i = 0; i < iters; ++i) {
+      if (i) estep_par(n_all);
+      auto ta = clk::now();
+      if (plain)
+        maximize_par();
+      else
+        fb.maximize(nms, 1.0);
+      out[9] += secs(ta, clk::now()) / iters;
+    }
+    out[10] = lp;
+    if (plain) {  // the spread-out maximize must give what the reference's gives: redo the last one serially and compare
+      std::vector<double> got;
+      for (auto& st : x.states)
+        for (auto& a : st) got.push_back(a.weight.w);
+      size_t k = 0;
+      for (auto& r : fb.arcs.t) r.arc->weight = r.scratch;  // back to the weights before it
+      fb.maximize(nms, 1.0);
+      for (auto& st : x.states)
+        for (auto& a : st) {
+          const double d = std::fabs(std::exp(a.weight.w) - std::exp(got[k++]));
+          if (d > 1e-12) throw std::runtime_error("bench: parallel maximize disagrees with WFST::normalize");
+        }
+    }
+#endif
+  });
+}
+
 // Cascade EM over text inputs (compose.cc + cascade.h + train.cc), as `carmel --train-cascade corpus a b ...`.
 // normby: one char per transducer (J/C/N).  Trained member texts are returned '\0'-joined in *out_texts
 // (caller frees with orc_free_str); trace as in orc_train.

@@ -24,7 +24,7 @@ for cfg in [dict(ns=300, deg=6, pairs=3000, lo=3, hi=25), dict(ns=40, deg=8, pai
     h = C.c_void_p()
     assert lib.carmel_hip_host_build(C.byref(h), w.n_states, w.final, w.n_arcs, ptr(w.src), ptr(w.dst), ptr(w.isym), ptr(w.osym),
                                      c.n_pairs, ptr(c.in_off), ptr(c.in_sym), ptr(c.out_off), ptr(c.out_sym), ptr(c.weight), 1, 4, 0, 0, -1) == 0
-    dims, td = np.zeros(16, np.uint64), np.zeros(6, np.uint64)
+    dims, td = np.zeros(19, np.uint64), np.zeros(6, np.uint64)
     lib.carmel_hip_host_dims(h, ptr(dims))
     lib.carmel_hip_host_transpose(h, ptr(td), *([None] * 10))
     print(cfg, "kept pairs", int(dims[6]), "lattice arcs", int(dims[15]), "items", int(td[0]), "buckets", int(td[1]))
