@@ -57,6 +57,11 @@ int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, u
   (void)hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming);
+  for (int k = 0; k < carmel_hip_trainer::N_CHUNK_STREAMS; ++k) {
+    (void)hipStreamCreateWithFlags(&t->cstream[k], hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&t->cev[k], hipEventDisableTiming);
+  }
   HostWfst& w = t->w;
   w.n_states = n_states;
   w.final_state = final_state;
@@ -108,6 +113,14 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (t->side) (void)hipStreamSynchronize(t->side);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+  if (t->ev_w) (void)hipEventDestroy(t->ev_w);
+  for (int k = 0; k < carmel_hip_trainer::N_CHUNK_STREAMS; ++k) {
+    if (t->cstream[k]) {
+      (void)hipStreamSynchronize(t->cstream[k]);
+      (void)hipStreamDestroy(t->cstream[k]);
+    }
+    if (t->cev[k]) (void)hipEventDestroy(t->cev[k]);
+  }
   hipStream_t s = t->stream, s2 = t->side;
   delete t;
   if (s) (void)hipStreamDestroy(s);
@@ -149,6 +162,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.prune = prune != 0;
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
+  if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));
   std::string err;
   LatticeSet& L = t->lat;
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
@@ -209,6 +223,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       HIPCHK(t->t_a_off.upload(L.t_a_off, s));
       HIPCHK(t->t_split_arcs.upload(L.t_split_arcs, s));
       HIPCHK(t->t_x.alloc(L.slot_pos.size()));
+      HIPCHK(t->t_xc.alloc(L.slot_pos.size()));
       HIPCHK(hipStreamSynchronize(s));
     }
     std::vector<uint16_t>().swap(L.t_b_arc);
@@ -242,7 +257,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_fwdx.bytes() + t->lane_bwd.bytes() +
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
                     t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
-                    t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes();
+                    t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes() + t->t_xc.bytes();
   std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
@@ -305,7 +320,8 @@ static int build_ties(carmel_hip_trainer* t, uint64_t n, const uint32_t* member,
 
 // norm groups over a parameter table given (member, src state, input symbol, method)
 static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* member, const uint32_t* src,
-                             const uint32_t* in, const std::vector<int>& method, const std::vector<double>& addc) {
+                             const uint32_t* in, const std::vector<int>& method, const std::vector<double>& addc,
+                             const uint32_t* group) {
   std::vector<uint32_t> norm_of(n);
   std::vector<double> add;
   std::unordered_map<uint64_t, uint32_t> ids;
@@ -374,6 +390,13 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
     HIPCHK(t->big_groups.upload(big, t->stream));
   }
   HIPCHK(t->norm_of.upload(norm_of, t->stream));
+  {
+    std::vector<uint16_t> code(t->norm_span ? n : 0);
+    for (uint64_t k = 0; k < code.size(); ++k)
+      code[k] = norm_of[k] == 0xffffffffu ? (uint16_t)0xffffu
+                                          : (uint16_t)((norm_of[k] & 0x3fffu) | (group[k] == CARMEL_HIP_LOCKED_GROUP ? 0x4000u : 0u));
+    HIPCHK(t->norm_code16.upload(code, t->stream));
+  }
   HIPCHK(t->add_count.upload(add, t->stream));
   HIPCHK(t->gscale.alloc(add.size()));
   t->any_add_count = false;
@@ -396,7 +419,7 @@ int carmel_hip_set_norm(carmel_hip_trainer* t, int norm_group_by, double add_cou
   t->norm_add_count = add_count;
   std::vector<int> m(1, norm_group_by);
   std::vector<double> a(1, add_count);
-  return build_norm_groups(t, t->w.n_arcs, nullptr, t->w.src.data(), t->w.in.data(), m, a);
+  return build_norm_groups(t, t->w.n_arcs, nullptr, t->w.src.data(), t->w.in.data(), m, a, t->w.group.data());
 }
 
 int carmel_hip_set_prior(carmel_hip_trainer* t, double smooth_floor, int weight_is_prior_count) {
@@ -462,7 +485,7 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
   if (member_add_count) a.assign(member_add_count, member_add_count + n_members);
   for (uint64_t p = 0; p < n_params; ++p)
     if (param_member[p] >= n_members) return fail(CARMEL_HIP_ERR_ARG, "param_member out of range");
-  int rc = build_norm_groups(t, n_params, param_member, param_src, param_in, m, a);
+  int rc = build_norm_groups(t, n_params, param_member, param_src, param_in, m, a, param_group);
   if (rc) return rc;
   rc = build_ties(t, n_params, param_member, param_group);
   if (rc) return rc;
@@ -478,7 +501,8 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
   MstepArgs M;
   M.logw = t->params();
-  M.lw_src = M.logw;
+  M.lw_src = nullptr;  // the one-pass kernel needs no current weight besides each thread's own
+  M.code16 = t->norm_code16.p;
   if (t->norm_span && !t->any_digamma && !t->n_ties && (!use_counts || t->any_locked)) {
     // the one-pass kernel reads the weights of its halo, which its neighbours are rewriting: give it a snapshot
     if (t->mstep_snap.n != t->np()) HIPCHK(t->mstep_snap.alloc(t->np()));
@@ -519,7 +543,7 @@ int carmel_hip_normalize(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   HIPCHK(hipSetDevice(t->device));
-  int rc = run_mstep(t, 0, 1);
+  int rc = run_mstep(t, 0, 2);
   if (rc) return rc;
   if (t->cascade)
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
@@ -621,6 +645,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   T.t_src = t->t_t_src.p;
   T.a_off = t->t_a_off.p;
   T.x = t->t_x.p;
+  T.xc = t->t_xc.p;
   T.logw = t->arc_logw.p;
   T.wcache = t->wcache.p;
   T.post = t->post.p;
@@ -631,8 +656,37 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
   LA.pre_weights = t->use_transpose ? 1u : 0u;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
-  if (t->use_transpose) HIPCHK(launch_transpose_weights(T, s));
-  for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+  const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
+  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_classes[0].tile_count &&
+                            !(getenv("CARMEL_HIP_ESTEP_STREAMS") && atoi(getenv("CARMEL_HIP_ESTEP_STREAMS")) <= 1);
+  if (t->use_transpose) HIPCHK(launch_trans_w_bucket(T, s));
+  if (side_by_side) {
+    // chunk k: weights of its tiles to lattice order -> its sweep -> its posteriors out to X, on stream k mod 4.  The
+    // kernels of different chunks overlap: a workgroup of the tile passes holds a whole CU's LDS and alternates between
+    // a load phase and a store phase, the sweep is a stream of many light waves -- side by side they fill each other's
+    // idle memory cycles.
+    HIPCHK(hipEventRecord(t->ev_w, s));
+    const int NS = carmel_hip_trainer::N_CHUNK_STREAMS;
+    bool used[carmel_hip_trainer::N_CHUNK_STREAMS] = {false, false, false, false};
+    size_t k = 0;
+    for (auto& lc : t->lat.lane_classes) {
+      hipStream_t cs = t->cstream[k % NS];
+      if (!used[k % NS]) HIPCHK(hipStreamWaitEvent(cs, t->ev_w, 0));
+      used[k % NS] = true;
+      HIPCHK(launch_trans_w_tiles(T, lc.tile_first, lc.tile_count, cs));
+      HIPCHK(launch_lane_sweep(LA, lc, cs));
+      HIPCHK(launch_trans_c_tiles(T, lc.tile_first, lc.tile_count, cs));
+      ++k;
+    }
+    for (int q = 0; q < NS; ++q)
+      if (used[q]) {
+        HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
+        HIPCHK(hipStreamWaitEvent(s, t->cev[q], 0));
+      }
+  } else {
+    if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
+    for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+  }
   for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
   ReduceArgs R;
   R.arc_off = t->arc_off.p;
@@ -648,9 +702,12 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
                         t->counts_ptr() + t->w.n_arcs, t->side));
   HIPCHK(hipEventRecord(t->ev_join, t->side));
-  if (t->use_transpose)
-    HIPCHK(launch_transpose_counts(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
-  else
+  if (t->use_transpose) {
+    // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
+    const uint32_t first = side_by_side ? lane_tiles : 0u;
+    HIPCHK(launch_trans_c_tiles(T, first, T.n_tiles > first ? T.n_tiles - first : 0u, s));
+    HIPCHK(launch_trans_c_bucket(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
+  } else
     HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipStreamWaitEvent(s, t->ev_join, 0));
   if (timed) HIPCHK(hipEventRecord(t->ev1, s));
@@ -805,7 +862,8 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
     int rcc = cascade_param_counts(t, s);
     if (rcc) return rcc;
   }
-  int rc = run_mstep(t, 1, 1);
+  // the weights before the update are kept only when the over-relaxation step needs them (train.cc:157-171)
+  int rc = run_mstep(t, 1, (!t->cascade && delta_scale > 1.0) ? 1 : 2);
   if (rc) return rc;
   double result = 10.0;  // train.cc:922
   if (!t->cascade) {
@@ -968,7 +1026,7 @@ int carmel_hip_load_best(carmel_hip_trainer* t) {
                                 t->arc_prior_w.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_group_c.p,
                                 t->w.n_arcs, s));
   }
-  int rc = run_mstep(t, 1, 1);
+  int rc = run_mstep(t, 1, 2);
   if (rc) return rc;
   HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                              t->w.n_arcs, s));

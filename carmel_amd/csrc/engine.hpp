@@ -50,6 +50,11 @@ struct carmel_hip_trainer {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t side = nullptr;          // small independent kernels of the E-step run beside the main chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  // the chunks of a lane class flow through weights-in / sweep / posteriors-out side by side on these streams
+  static const int N_CHUNK_STREAMS = 4;
+  hipStream_t cstream[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t cev[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_w = nullptr;
   HostWfst w;
   HostCorpus corpus;
   bool have_corpus = false, have_lattices = false, cascade = false;
@@ -68,6 +73,7 @@ struct carmel_hip_trainer {
   DevBuf<double> mstep_snap;  // immutable copy of the weights for the one-pass M-step (see MstepArgs::lw_src)
   bool any_locked = false;    // some parameter is locked (group 0): its weight enters its group's sum
   DevBuf<uint32_t> norm_of;
+  DevBuf<uint16_t> norm_code16;  // MstepArgs::code16 (one-pass M-step)
   // tied arcs (!N, fst.cc:107-152): dense tie index per parameter (0xffffffff = not tied) and the per-tie tables
   DevBuf<uint32_t> tie_of;
   DevBuf<double> glocked;  // per norm group scratch
@@ -99,7 +105,7 @@ struct carmel_hip_trainer {
   DevBuf<uint64_t> t_tile_base;
   DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos, t_a_off;
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
-  DevBuf<double> t_x;
+  DevBuf<double> t_x, t_xc;
   DevBuf<unsigned long long> max_partial;  // M-step scratch
   uint32_t norm_span = 0;                  // max over norm groups of (last member - first member); 0 = unknown / too wide
   bool all_grouped = true;                 // every parameter is in a norm group

@@ -477,7 +477,7 @@ __device__ __forceinline__ double mstep_scale(double sn, double sl, double alpha
 __device__ __forceinline__ double mstep_update(const MstepArgs& M, uint64_t k, int use_counts, uint32_t g, double sc,
                                                double& mx) {
   const double old = M.logw[k];
-  if (M.save_old) M.old_logw[k] = old;
+  if (M.save_old == 1) M.old_logw[k] = old;
   const double v = mstep_value(M, k, use_counts, g);
   double nw;
   if (M.group[k] == 0u) {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(256) void mstep_normalize_kernel(MstepArgs M, int u
   for (uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x; k < M.n; k += (uint64_t)MSTEP_GRID * 256) {
     const uint32_t ng = M.norm_of[k];
     if (ng == 0xffffffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
-      if (M.save_old) M.old_logw[k] = M.logw[k];
+      if (M.save_old == 1) M.old_logw[k] = M.logw[k];
       continue;
     }
     M.logw[k] = mstep_update(M, k, use_counts, ng, M.gscale[ng], mx);
@@ -593,26 +593,26 @@ __global__ __launch_bounds__(256) void mstep_normalize_kernel(MstepArgs M, int u
 // parameter order -- the same order, hence the same bits, as the group-major pass above -- and writes its new weight.
 // One coalesced read of the counts, one write of the weights; no group table, no scale array.
 #define MSTEP_WINDOW_MAX 64
+template <bool NEED_LW>
 __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_counts, uint32_t span) {
   __shared__ double v_sh[256 + 2 * MSTEP_WINDOW_MAX];
-  __shared__ uint32_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // group id; bit 31 set = locked member
+  __shared__ uint16_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // MstepArgs::code16
   const int64_t base = (int64_t)blockIdx.x * 256 - (int64_t)span;
-  const uint32_t n_tile = 256 + 2 * span;
   // every global load of the workgroup is issued up front (tile element, halo element, own old weight): one round
-  // trip per workgroup instead of one per dependent step
+  // trip per workgroup instead of one per dependent step.  NEED_LW: some member's value is its current weight (no
+  // counts in use, or locked members) -- read from the snapshot lw_src, never from the array being rewritten.
   const uint64_t kown = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const double old_own = kown < M.n ? M.logw[kown] : 0.0;
   int64_t kk[2] = {base + threadIdx.x, base + 256 + threadIdx.x};
   bool in[2];
-  uint32_t gg[2], grp[2];
+  uint16_t code[2];
   double cv[2], pv[2], lw[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     in[h] = kk[h] >= 0 && (uint64_t)kk[h] < M.n && (h == 0 || threadIdx.x < 2 * span);
     const uint64_t k = in[h] ? (uint64_t)kk[h] : 0;
-    gg[h] = M.norm_of[k];
-    grp[h] = M.group[k];
-    lw[h] = M.lw_src[k];
+    code[h] = M.code16[k];
+    lw[h] = NEED_LW ? M.lw_src[k] : 0.0;
     cv[h] = use_counts ? M.counts[k] : 0.0;
     pv[h] = (use_counts && M.prior) ? M.prior[k] : 0.0;
   }
@@ -620,43 +620,41 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   for (int h = 0; h < 2; ++h) {
     if (h == 1 && threadIdx.x >= 2 * span) break;
     double v = 0.0;
-    uint32_t g = 0xffffffffu;
-    if (in[h] && gg[h] != 0xffffffffu) {
-      g = gg[h];
-      v = (grp[h] == 0u || !use_counts) ? exp(lw[h]) : cv[h] + pv[h];  // mstep_value
-      if (M.add_count) v += M.add_count[g];
-      if (grp[h] == 0u) g |= 0x80000000u;
+    uint16_t g = 0xffffu;
+    if (in[h] && code[h] != 0xffffu) {
+      g = code[h];
+      const bool locked = (g & 0x4000u) != 0;
+      v = (NEED_LW && (locked || !use_counts)) ? exp(lw[h]) : cv[h] + pv[h];  // mstep_value
+      if (M.add_count) v += M.add_count[M.norm_of[kk[h]]];
     }
     v_sh[threadIdx.x + h * 256] = v;
     g_sh[threadIdx.x + h * 256] = g;
   }
-  (void)n_tile;
   __syncthreads();
   double mx = 0.0;
   const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (k < M.n) {
     const uint32_t me = threadIdx.x + span;
-    const uint32_t gid = g_sh[me];
-    if (gid == 0xffffffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
-      if (M.save_old) M.old_logw[k] = old_own;
+    const uint16_t gid = g_sh[me];
+    if (gid == 0xffffu) {  // member normalised by NONE keeps its weights (cascade.h:339-350)
+      if (M.save_old == 1) M.old_logw[k] = old_own;
     } else {
-      const uint32_t want = gid & 0x7fffffffu;
+      const uint16_t want = gid & 0x3fffu;
       double sn = 0.0, sl = 0.0;
       for (uint32_t j = me - span; j <= me + span; ++j) {
-        const uint32_t gj = g_sh[j];
-        if (gj == 0xffffffffu || (gj & 0x7fffffffu) != want) continue;
-        if (gj & 0x80000000u)
+        const uint16_t gj = g_sh[j];
+        if (gj == 0xffffu || (gj & 0x3fffu) != want) continue;
+        if (gj & 0x4000u)
           sl += v_sh[j];
         else
           sn += v_sh[j];
       }
-      // new weight straight from the sums: one division, one log (and one exp for the old weight) per parameter --
-      // this kernel is bound by f64 transcendentals, not by its 40 bytes per parameter
+      // new weight straight from the sums: one division, one log (and one exp for the old weight) per parameter
       const double old = old_own;
-      if (M.save_old) M.old_logw[k] = old;
+      if (M.save_old == 1) M.old_logw[k] = old;
       const double v = v_sh[me];
       double nw;
-      if (gid & 0x80000000u) {
+      if (gid & 0x4000u) {
         nw = v > 0.0 ? log(v) : NEG_INF;
       } else {
         const double remain = 1.0 - sl;
@@ -818,8 +816,9 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
 // in LDS at their position and the tile is written to wcache in one coalesced sweep.
 __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const uint32_t tile = xcd_chunked(blockIdx.x, T.n_wtiles);  // the grid is rounded up to a multiple of 8
-  if (tile >= T.n_wtiles) return;
+  const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
+  if (tloc >= T.tile_count) return;
+  const uint32_t tile = T.tile_first + tloc;
   const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
@@ -852,10 +851,11 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
 // counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in bucket-major runs.
 __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const uint64_t p0 = (uint64_t)blockIdx.x * TRANS_TILE;
+  const uint32_t tile = T.tile_first + blockIdx.x;
+  const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
-  const uint64_t i0 = T.tile_base[blockIdx.x];
-  const uint32_t ni = (uint32_t)(T.tile_base[blockIdx.x + 1] - i0);
+  const uint64_t i0 = T.tile_base[tile];
+  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
   double v[TRANS_K];
   uint16_t pos[TRANS_K];
 #pragma unroll
@@ -870,7 +870,7 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
 #pragma unroll
   for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
-    if (i < ni) T.x[i0 + i] = lds[pos[k]];
+    if (i < ni) T.xc[i0 + i] = lds[pos[k]];
   }
 }
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
@@ -895,7 +895,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_K; ++k) v[k] = T.x[src[k]];
+    for (int k = 0; k < TRANS_K; ++k) v[k] = T.xc[src[k]];
 #pragma unroll
     for (int k = 0; k < TRANS_K; ++k)
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
@@ -1024,21 +1024,34 @@ static void trans_lds_attr() {
   (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   done = true;
 }
-hipError_t launch_transpose_weights(const TransArgs& T0, hipStream_t stream) {
+hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream) {
   trans_lds_attr();
-  if (!T0.n_buckets) return hipSuccess;
-  TransArgs T = T0;
-  T.n_wtiles = (uint32_t)((T.n_wcache + TRANS_TILE - 1) / TRANS_TILE);
+  if (!T.n_buckets) return hipSuccess;
   hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
-  const unsigned wt = (unsigned)((T.n_wcache + TRANS_TILE - 1) / TRANS_TILE);
-  if (wt) hipLaunchKernelGGL(trans_w_tile_kernel, dim3((wt + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
-hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
+hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32_t tile_count, hipStream_t stream) {
+  trans_lds_attr();
+  if (!T0.n_buckets || !tile_count) return hipSuccess;
+  TransArgs T = T0;
+  T.tile_first = tile_first;
+  T.tile_count = tile_count;
+  hipLaunchKernelGGL(trans_w_tile_kernel, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
+  return hipGetLastError();
+}
+hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32_t tile_count, hipStream_t stream) {
+  trans_lds_attr();
+  if (!T0.n_buckets || !tile_count) return hipSuccess;
+  TransArgs T = T0;
+  T.tile_first = tile_first;
+  T.tile_count = tile_count;
+  hipLaunchKernelGGL(trans_c_tile_kernel, dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
+  return hipGetLastError();
+}
+hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
   trans_lds_attr();
   if (!T.n_buckets) return hipSuccess;
   if (n_split) hipLaunchKernelGGL(zero_list_kernel, dim3((n_split + 255) / 256), dim3(256), 0, stream, T.counts, split_arcs, n_split);
-  hipLaunchKernelGGL(trans_c_tile_kernel, dim3(T.n_tiles), dim3(1024), TRANS_TILE * 8, stream, T);
   hipLaunchKernelGGL(trans_c_bucket_kernel, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
@@ -1070,7 +1083,10 @@ hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (M.window_span && !(M.n_ties && M.tie_of)) {
     hipError_t e = hipMemsetAsync(M.max_partial, 0, MSTEP_GRID * sizeof(unsigned long long), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(mstep_window_kernel, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
+    if (M.lw_src)
+      hipLaunchKernelGGL(mstep_window_kernel<true>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
+    else
+      hipLaunchKernelGGL(mstep_window_kernel<false>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
     MSTEP_DBG("window")
   } else {
     if (M.n_ties && M.tie_of) {

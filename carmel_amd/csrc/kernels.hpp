@@ -68,7 +68,9 @@ struct TransArgs {
   const uint16_t* t_pos;
   const uint32_t* t_src;
   const uint16_t* a_off;  // per arc: first item inside its bucket
-  double* x;              // intermediate, one f64 per item
+  double* x;              // intermediate of the weights direction, one f64 per item (bucket-major index)
+  double* xc;             // intermediate of the counts direction (tile-major index): a buffer of its own, so that one
+                          // chunk's posteriors can leave while another chunk's weights are still being read
   const double* logw;     // per arc
   double* wcache;         // per lane position (n_wcache entries)
   const double* post;     // per position (n_post entries)
@@ -76,6 +78,7 @@ struct TransArgs {
   uint64_t n_wcache, n_post;
   uint32_t n_buckets, n_tiles;
   uint32_t n_wtiles;      // tiles that cover wcache (set by launch_transpose_weights)
+  uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
 };
 
 #define MSTEP_BIG_GROUP 512
@@ -106,7 +109,12 @@ struct MstepArgs {
   double* tie_tab;          // [4][n_ties]: arc total, state total, max locked sum, weight (linear)
   uint64_t n_ties;
   uint64_t n;
-  int save_old;             // 0: keep old_logw from the previous pass (second normalise after overrelax)
+  int save_old;             // 1: old_logw <- the weights before this pass, |change| against them; 0: keep old_logw from the
+                            // previous pass and compare against it (second normalise after overrelax); 2: old_logw is not
+                            // needed afterwards (no over-relaxation): do not write it, compare against the weight read
+  const uint16_t* code16;   // mstep_window_kernel: per parameter, norm-group id mod 2^14 | 0x4000 if locked; 0xffff = no norm
+                            // group.  Ids are handed out in first-seen order, so inside a window of < 2^14 parameters equal
+                            // low bits mean equal groups: 2 bytes per parameter instead of norm_of + group (8)
   // --digamma (mean_field_scale.hpp:40-52): per norm group / per tie the alpha of exp(digamma(x + alpha)) that replaces
   // x in the numerator and the denominator of the normalisation; NaN = the usual linear scale.  Null when no member
   // asked for it (the one-pass window kernel only handles the linear scale).
@@ -116,8 +124,12 @@ struct MstepArgs {
 
 hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
-hipError_t launch_transpose_weights(const TransArgs& T, hipStream_t stream);
-hipError_t launch_transpose_counts(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream);
+// the two passes of either direction as separate launches: the bucket passes cover the whole model, the tile passes a
+// range of tiles (so that chunks of the corpus can flow through weights-in / sweep / posteriors-out side by side)
+hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream);
+hipError_t launch_trans_w_tiles(const TransArgs& T, uint32_t tile_first, uint32_t tile_count, hipStream_t stream);
+hipError_t launch_trans_c_tiles(const TransArgs& T, uint32_t tile_first, uint32_t tile_count, hipStream_t stream);
+hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream);
 // partial: 3 * 256 doubles of scratch
 hipError_t launch_scalars(const double* pair_logprob, const double* pair_w, uint64_t n_pairs, double* partial,
                           double* scalars, hipStream_t s);

@@ -529,12 +529,10 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     out.lane_pair.assign(ng * 64, 0xffffffffu);
     out.lane_nstates.assign(ng * 64, 0);
     out.lane_logw.assign(ng * 64, 0.0);
-    uint64_t base = 0;
     for (size_t g = 0; g < ng; ++g) {
       LaneGroup& G = out.lane_groups[g];
       std::memset(&G, 0, sizeof G);
       size_t l0 = g * 64, l1 = std::min(lane.size(), l0 + 64);
-      G.stream_base = base;
       G.n_lanes = (uint32_t)(l1 - l0);
       G.pair_base = (uint32_t)l0;
       uint32_t ml = 0, ms = 0;
@@ -543,13 +541,10 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
         ms = std::max(ms, lats[lane[l]].n_states);
       }
       G.maxlen = (std::max<uint32_t>(ml, 1) + LANE_CHUNK - 1) / LANE_CHUNK * LANE_CHUNK;
-      ml = G.maxlen;
       G.max_states = ms;
-      base += (uint64_t)ml * 64;
     }
-    out.lane_fwd.assign(base, uint2_t{0, 0});
-    out.lane_bwd.assign(base, uint2_t{0, 0});
     // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
+    std::vector<LatticeSet::LaneClass> classes;
     {
       size_t i = 0;
       while (i < ng) {
@@ -564,10 +559,49 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
           if (j - i >= 256 && mx > min_split && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
           ++j;
         }
-        out.lane_classes.push_back(LatticeSet::LaneClass{(uint32_t)i, (uint32_t)(j - i), mx});
+        LatticeSet::LaneClass lc;
+        lc.first = (uint32_t)i;
+        lc.count = (uint32_t)(j - i);
+        lc.max_states = mx;
+        classes.push_back(lc);
         i = j;
       }
     }
+    // chunks: every class is cut into pieces of about equal record count; a piece's stream starts on a tile boundary
+    uint64_t base = 0;
+    const uint32_t want_chunks = std::max<uint32_t>(1, opt.lane_chunks);
+    for (const auto& lc : classes) {
+      uint64_t rows = 0;
+      for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
+      // no chunk smaller than 16 tiles' worth of records: a launch has to fill the chip
+      const uint32_t nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE)));
+      uint32_t g = lc.first;
+      uint64_t done = 0;
+      for (uint32_t k = 0; k < nch; ++k) {
+        const uint64_t goal = rows * (k + 1) / nch;
+        LatticeSet::LaneClass piece = lc;
+        piece.first = g;
+        if (nch > 1 || want_chunks > 1) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
+        piece.tile_first = (uint32_t)(base / TRANS_TILE);
+        uint32_t mx = 0;
+        while (g < lc.first + lc.count && (done < goal || k + 1 == nch)) {
+          LaneGroup& G = out.lane_groups[g];
+          G.stream_base = base;
+          base += (uint64_t)G.maxlen * 64;
+          done += G.maxlen;
+          mx = std::max(mx, G.max_states);
+          ++g;
+        }
+        piece.count = g - piece.first;
+        piece.max_states = lc.max_states;  // one LDS size per class keeps the occupancy of its pieces equal
+        (void)mx;
+        piece.tile_count = (uint32_t)((base + TRANS_TILE - 1) / TRANS_TILE) - piece.tile_first;
+        if (piece.count) out.lane_classes.push_back(piece);
+      }
+    }
+    if (want_chunks > 1) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
+    out.lane_fwd.assign(base, uint2_t{0, 0});
+    out.lane_bwd.assign(base, uint2_t{0, 0});
     std::atomic<size_t> nextg(0);
     auto lwork = [&]() {
       std::vector<uint32_t> order, newid, ioff, ooff, cur;

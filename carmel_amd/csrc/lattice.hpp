@@ -126,8 +126,13 @@ struct LatticeSet {
   std::vector<uint2_t> lane_fwd, lane_bwd;
   std::vector<uint32_t> lane_pair, lane_nstates;
   std::vector<double> lane_logw;
+  // a launch of the lane sweep: groups [first, first + count) sharing one LDS size.  A class is cut into CHUNKS whose
+  // record streams start on a tile boundary of the blocked transposition (padding rows in between), so that the
+  // weights-in / sweep / posteriors-out kernels of different chunks can run side by side on separate streams:
+  // tiles [tile_first, tile_first + tile_count) cover exactly this chunk's records.
   struct LaneClass {
     uint32_t first, count, max_states;
+    uint32_t tile_first = 0, tile_count = 0;
   };
   std::vector<LaneClass> lane_classes;
   uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
@@ -164,6 +169,9 @@ struct BuildOptions {
   uint32_t small_states = 2048;    // state cap of a small bundle (16 KiB of f64 in LDS)
   uint32_t lds_states_max = 16384; // one array of f64 in LDS: 128 KiB
   uint32_t lane_states = 96;       // lattices up to this many states go one-per-lane (0 disables lane groups)
+  uint32_t lane_chunks = 1;        // chunks per lane class (see LatticeSet::LaneClass); 1 = one launch per class (default:
+                                   // measured on config 4, four chunks on four streams overlap their kernels but finish no
+                                   // sooner -- the E-step is bound by its total HBM traffic -- and cost 46 us of extra tails)
 };
 
 // Builds every pair's lattice (parallel over pairs) and packs them.  Returns false + err on failure.
