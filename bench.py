@@ -8,7 +8,10 @@ Inputs (transducer, lattices) are resident in HBM before the timed region.
 
 Workload (config.workload): by default BASELINE.json configs[3] shape — synthetic 1M-state / 10M-arc transducer,
 1M training pairs PER GPU (weak scaling: the corpus grows with N, the model — and therefore the 80 MB count
-all-reduce — does not).  `--config c2` selects configs[1] (100k states / 2M arcs / 50k pairs).
+all-reduce — does not).  `--scaling strong` keeps the corpus at 1M pairs in total and gives every rank 1/N of it.
+`--config c2` selects configs[1] (100k states / 2M arcs / 50k pairs).  For N > 1 the all-reduce is the library's own
+(carmel_hip_allreduce_counts: RCCL enqueued on the trainer's stream between the count pass and the M-step, no host
+synchronisation inside a step); torch.distributed only carries the communicator id, the barrier and the max-over-ranks.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
 """
@@ -63,6 +66,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=["c2", "c4", "toy"])
     ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (default: the config's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --pairs per GPU; strong: --pairs in total, sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: host cores, at most 64)")
@@ -98,19 +103,24 @@ def main():
     t0 = time.time()
     w = synth.random_wfst(n_states, deg, seed=seed)  # same model on every rank
     lo, hi = (int(v) for v in args.walk_arcs.split(","))
-    c = synth.random_walk_corpus(w, npairs, min_arcs=lo, max_arcs=hi, seed=seed + 7919 * rank, out_degree=deg)  # this rank's shard
+    if args.scaling == "strong" and world > 1:  # one corpus, every rank takes its contiguous block of pairs
+        c = synth.random_walk_corpus(w, npairs, min_arcs=lo, max_arcs=hi, seed=seed, out_degree=deg).shard(rank, world)
+    else:
+        c = synth.random_walk_corpus(w, npairs, min_arcs=lo, max_arcs=hi, seed=seed + 7919 * rank, out_degree=deg)  # this rank's shard
     t_gen = time.time() - t0
     fb = HipForwardBackward(w, c, device=local_rank, host_threads=args.host_threads)
     ls = fb.lattice_stats
-    counts = torch.zeros(w.n_arcs + 4, dtype=torch.float64, device="cuda")
-    fb.use_external_counts(counts.data_ptr())
+    comm = None
+    if world > 1:
+        from carmel_amd.trainer import HipComm
+        ids = [HipComm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = HipComm(local_rank, rank, world, ids[0])
 
     def step():
         fb.estimate_async()
-        if world > 1:
-            fb.synchronize()  # the sweep runs on the trainer's stream; RCCL on torch's
-            dist.all_reduce(counts)
-            torch.cuda.synchronize()
+        if comm is not None:
+            fb.allreduce_counts(comm)  # stream-ordered: count pass -> all-reduce -> M-step
         return fb.maximize(1.0)
 
     def fence():
@@ -151,15 +161,16 @@ def main():
         out = {
             "metric": "arc-updates/sec (EM iterations/sec x derivation-lattice arcs swept per iteration)",
             "value": value, "unit": "arc-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d-state / %d-arc WFST, %d training pairs per GPU (random walks of "
+            "config": {"workload": "%s: synthetic %d-state / %d-arc WFST, %d training pairs %s (random walks of "
                                    "%s arcs), conditional normalisation, cached lattices" %
-                                   (args.config, w.n_states, w.n_arcs, c.n_pairs, args.walk_arcs.replace(",", "-")),
+                                   (args.config, w.n_states, w.n_arcs, npairs, "in total, sharded" if args.scaling == "strong"
+                                    and world > 1 else "per GPU", args.walk_arcs.replace(",", "-")),
                        "pairs_per_gpu": c.n_pairs, "wfst_arcs": int(w.n_arcs), "wfst_states": int(w.n_states),
                        "lattice_arcs_per_gpu": int(ls.kept_arcs), "lattice_states_per_gpu": int(ls.kept_states),
-                       "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, all-reduce of %d f64 "
-                       "counts per iteration" % (world, w.n_arcs + 4)},
+                       "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, RCCL all-reduce of %d f64 "
+                       "counts per iteration on the trainer's stream" % (world, w.n_arcs + 4)},
             "iters_per_s": iters_per_s,
             "wfst_arcs_x_iters_per_s": iters_per_s * w.n_arcs,
             "ln_corpus_prob_last": lp,
@@ -205,6 +216,8 @@ def main():
         print(json.dumps(out))
     fence()
     fb.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

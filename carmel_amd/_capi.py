@@ -29,6 +29,8 @@ SYMBOLS = [
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
     "carmel_hip_forests_max_sample",
+    "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
+    "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
 ]
 
 
@@ -70,6 +72,13 @@ def _load():
     lib.carmel_hip_device_count.argtypes = []
     lib.carmel_hip_random_restart.argtypes = [vp, C.c_uint64, C.c_uint32]
     lib.carmel_hip_keep_em_weights.argtypes = [vp]
+    lib.carmel_hip_comm_unique_id.argtypes = [vp]
+    lib.carmel_hip_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
+    lib.carmel_hip_comm_destroy.argtypes = [vp]
+    lib.carmel_hip_comm_rank.argtypes = [vp]
+    lib.carmel_hip_comm_world.argtypes = [vp]
+    lib.carmel_hip_allreduce_counts.argtypes = [vp, vp]
+    lib.carmel_hip_comm_allreduce_host.argtypes = [vp, vp, C.c_uint32, C.c_int]
     lib.carmel_hip_fractional_counts.argtypes = [vp]
     lib.carmel_hip_set_digamma.argtypes = [vp, C.c_uint32, vp, vp]
     lib.carmel_hip_forests_set_alphas.argtypes = [vp, vp, C.c_uint32]

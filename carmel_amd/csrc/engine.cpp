@@ -387,6 +387,8 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       if (off[g + 1] - off[g] > MSTEP_BIG_GROUP) big.push_back(g);
     HIPCHK(t->group_off.upload(off, t->stream));
     HIPCHK(t->norm_perm.upload(perm, t->stream));
+    t->h_group_off = off;
+    t->h_norm_perm = perm;
     HIPCHK(t->big_groups.upload(big, t->stream));
   }
   HIPCHK(t->norm_of.upload(norm_of, t->stream));
@@ -396,6 +398,22 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       code[k] = norm_of[k] == 0xffffffffu ? (uint16_t)0xffffu
                                           : (uint16_t)((norm_of[k] & 0x3fffu) | (group[k] == CARMEL_HIP_LOCKED_GROUP ? 0x4000u : 0u));
     HIPCHK(t->norm_code16.upload(code, t->stream));
+    // members of every parameter's group as offsets -15 .. +16 (bit offset + 15), unlocked and locked apart
+    std::vector<uint32_t> mask, lmask;
+    if (t->norm_span && t->norm_span <= 15 && !(getenv("CARMEL_HIP_MSTEP_MASK") && atoi(getenv("CARMEL_HIP_MSTEP_MASK")) == 0)) {
+      mask.assign(n, 0u);
+      lmask.assign(n, 0u);
+      const std::vector<uint64_t>& off = t->h_group_off;
+      const std::vector<uint64_t>& perm = t->h_norm_perm;
+      for (size_t g = 0; g + 1 < off.size(); ++g)
+        for (uint64_t a = off[g]; a < off[g + 1]; ++a)
+          for (uint64_t b = off[g]; b < off[g + 1]; ++b) {
+            const int64_t d = (int64_t)perm[b] - (int64_t)perm[a];  // within +-15 by the span check
+            (group[perm[b]] == CARMEL_HIP_LOCKED_GROUP ? lmask : mask)[perm[a]] |= 1u << (uint32_t)(d + 15);
+          }
+    }
+    HIPCHK(t->norm_mask32.upload(mask, t->stream));
+    HIPCHK(t->norm_lockmask32.upload(lmask, t->stream));
   }
   HIPCHK(t->add_count.upload(add, t->stream));
   HIPCHK(t->gscale.alloc(add.size()));
@@ -503,6 +521,8 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.logw = t->params();
   M.lw_src = nullptr;  // the one-pass kernel needs no current weight besides each thread's own
   M.code16 = t->norm_code16.p;
+  M.mask32 = t->norm_mask32.n ? t->norm_mask32.p : nullptr;
+  M.lockmask32 = t->norm_lockmask32.n ? t->norm_lockmask32.p : nullptr;
   if (t->norm_span && !t->any_digamma && !t->n_ties && (!use_counts || t->any_locked)) {
     // the one-pass kernel reads the weights of its halo, which its neighbours are rewriting: give it a snapshot
     if (t->mstep_snap.n != t->np()) HIPCHK(t->mstep_snap.alloc(t->np()));

@@ -74,6 +74,7 @@ struct carmel_hip_trainer {
   bool any_locked = false;    // some parameter is locked (group 0): its weight enters its group's sum
   DevBuf<uint32_t> norm_of;
   DevBuf<uint16_t> norm_code16;  // MstepArgs::code16 (one-pass M-step)
+  DevBuf<uint32_t> norm_mask32, norm_lockmask32;  // MstepArgs::mask32 / lockmask32
   // tied arcs (!N, fst.cc:107-152): dense tie index per parameter (0xffffffff = not tied) and the per-tie tables
   DevBuf<uint32_t> tie_of;
   DevBuf<double> glocked;  // per norm group scratch
@@ -141,6 +142,7 @@ struct carmel_hip_trainer {
   uint64_t device_bytes = 0;
   // host copies the Gibbs sampler set-up needs (gibbs.hip)
   std::vector<uint32_t> h_norm_of, h_param_group;
+  std::vector<uint64_t> h_group_off, h_norm_perm;  // members of every norm group (host copy, for the M-step masks)
   std::vector<double> h_group_add;
   std::vector<uint64_t> h_chain_off, h_chain_param;
 

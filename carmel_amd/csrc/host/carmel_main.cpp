@@ -27,6 +27,9 @@
 #include <limits>
 #include <memory>
 #include <sstream>
+#include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include "../../../include/carmel_hip.h"
 #include "compose.hpp"
 #include "fem_export.hpp"
@@ -70,6 +73,7 @@ struct Options {
   bool plus_alpha_set = false;     // -+ a (carmel.cc:1009-1013): mean-field scale of the single transducer's method
   double plus_alpha = 0;
   int index_threshold = 32, gpu = 0;
+  int gpus = 1;  // --gpus=N: corpus-sharded EM, one process per GPU (not a carmel option: carmel is single-process)
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
   long crp_restarts = 0;     // --crp-restarts (carmel.cc:271-273)
@@ -107,6 +111,8 @@ static Options parse_args(int argc, char** argv) {
         o.priors = v;
       else if (k == "gpu")
         o.gpu = std::atoi(v.c_str());
+      else if (k == "gpus")
+        o.gpus = std::max(1, std::atoi(v.c_str()));
       else if (k == "crp") {
         o.crp = true;
         if (!v.empty() && std::atol(v.c_str()) > 1) o.crp_iters = std::atol(v.c_str());
@@ -234,6 +240,8 @@ struct CorpusStats {  // training_corpus counters over the pairs that have a der
   double n_pairs = 0, total_weight = 0, n_input = 0, n_output = 0;
 };
 
+static std::vector<pid_t> g_kids;  // --gpus: the other ranks (rank 0 only)
+
 static int run(int argc, char** argv) {
   Options o = parse_args(argc, argv);
   const bool training = o.flags[(unsigned)'t'];
@@ -251,7 +259,40 @@ static int run(int argc, char** argv) {
                  "       carmel [-HJZD] transducer [transducer ...]     (compose and print; host only)\n";
     return -12;
   }
-  const bool quiet = o.flags[(unsigned)'q'];
+  // ---- --gpus=N: N processes, one per GPU, forked before anything touches a GPU.  Every rank reads the same files and
+  // composes the same cascade; rank r keeps the r-th contiguous block of the training pairs, builds its lattices, and the
+  // expected counts are summed across ranks once per iteration (carmel_hip_allreduce_counts: RCCL over xGMI, on the
+  // trainer's stream between the count pass and the M-step).  The M-step is replicated, so every rank holds the same
+  // weights and takes the same decisions; rank 0 alone logs and writes the results. ----
+  int rank = 0, world = (training && !o.crp) ? o.gpus : 1;
+  std::vector<int> id_pipes;  // rank 0: write ends towards the other ranks
+  int id_read = -1;
+  std::vector<pid_t>& kids = g_kids;
+  if (world > 1 && (!o.fem_forest.empty() || !o.fem_norm.empty() || !o.fem_param.empty() || !o.fem_alpha.empty()))
+    throw UsageError("--gpus with the --fem-* exports is not supported (the export walks the whole corpus)");
+  if (world > 1) {
+    for (int r = 1; r < world; ++r) {
+      int fd[2];
+      if (pipe(fd) != 0) throw std::runtime_error("pipe() failed");
+      pid_t pid = fork();
+      if (pid < 0) throw std::runtime_error("fork() failed");
+      if (pid == 0) {
+        rank = r;
+        close(fd[1]);
+        id_read = fd[0];
+        for (int w : id_pipes) close(w);
+        id_pipes.clear();
+        kids.clear();
+        if (!std::freopen("/dev/null", "w", stdout) || !std::freopen("/dev/null", "w", stderr)) return -11;
+        break;
+      }
+      close(fd[0]);
+      id_pipes.push_back(fd[1]);
+      kids.push_back(pid);
+    }
+  } else if (o.gpus > 1)
+    std::cerr << "--gpus=" << o.gpus << " applies to EM training (-t / --train-cascade); running on one GPU\n";
+  const bool quiet = o.flags[(unsigned)'q'] || rank > 0;
   if (!with_pairs) o.files.insert(o.files.begin(), (const char*)0);  // no corpus argument
   const size_t nw = o.files.size() - 1;
   std::string corpus_text = with_pairs ? slurp(o.files[0]) : std::string();
@@ -387,13 +428,64 @@ static int run(int argc, char** argv) {
   std::vector<double> logw;
   result->flatten(src, dst, in, out, logw, group);
   carmel_hip_trainer* t = 0;
-  hip_check(carmel_hip_create(&t, o.gpu, (uint32_t)result->states.size(), result->final_state, logw.size(), src.data(),
+  // (CARMEL_HIP_COMM=host: every rank on the same GPU, sums staged through shared memory -- single-GPU boxes, tests)
+  const bool one_device = std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host";
+  const int my_device = o.gpu + (one_device ? 0 : rank);
+  hip_check(carmel_hip_create(&t, my_device, (uint32_t)result->states.size(), result->final_state, logw.size(), src.data(),
                               dst.data(), in.data(), out.data(), logw.data(), group.data()),
             "carmel_hip_create");
   struct Guard {
     carmel_hip_trainer* t;
     ~Guard() { carmel_hip_destroy(t); }
   } guard{t};
+  carmel_hip_comm* comm = 0;
+  if (world > 1) {
+    unsigned char id[128];
+    if (rank == 0) {
+      hip_check(carmel_hip_comm_unique_id(id), "carmel_hip_comm_unique_id");
+      for (int w : id_pipes) {
+        if (write(w, id, sizeof id) != (ssize_t)sizeof id) throw std::runtime_error("could not hand the communicator id to a rank");
+        close(w);
+      }
+    } else {
+      size_t got = 0;
+      while (got < sizeof id) {
+        ssize_t n = read(id_read, id + got, sizeof id - got);
+        if (n <= 0) throw std::runtime_error("rank 0 went away before the communicator id arrived");
+        got += (size_t)n;
+      }
+      close(id_read);
+    }
+    hip_check(carmel_hip_comm_create(&comm, my_device, rank, world, id), "carmel_hip_comm_create");
+    // this rank's block of the training pairs
+    const size_t n = pairs.size(), lo = n * (size_t)rank / (size_t)world, hi = n * (size_t)(rank + 1) / (size_t)world;
+    HostPairs mine;
+    mine.in_off.assign(1, 0);
+    mine.out_off.assign(1, 0);
+    for (size_t p = lo; p < hi; ++p) {
+      mine.in_sym.insert(mine.in_sym.end(), pairs.in_sym.begin() + pairs.in_off[p], pairs.in_sym.begin() + pairs.in_off[p + 1]);
+      mine.out_sym.insert(mine.out_sym.end(), pairs.out_sym.begin() + pairs.out_off[p], pairs.out_sym.begin() + pairs.out_off[p + 1]);
+      mine.in_off.push_back(mine.in_sym.size());
+      mine.out_off.push_back(mine.out_sym.size());
+      mine.weight.push_back(pairs.weight[p]);
+    }
+    pairs = mine;
+    if (!quiet) std::cerr << "Corpus sharded over " << world << " GPUs: rank 0 keeps " << pairs.size() << " of " << n << " pairs\n";
+  }
+  struct CommGuard {
+    carmel_hip_comm*& c;
+    ~CommGuard() { carmel_hip_comm_destroy(c); }
+  } comm_guard{comm};
+  // one E-step over the whole corpus: the count pass on this rank's shard, then (N > 1) the sum over the ranks
+  auto estimate_all = [&](carmel_hip_estimate_result* er) {
+    if (!comm) {
+      hip_check(carmel_hip_estimate(t, er, 0), "carmel_hip_estimate");
+      return;
+    }
+    hip_check(carmel_hip_estimate_async(t), "carmel_hip_estimate_async");
+    hip_check(carmel_hip_allreduce_counts(t, comm), "carmel_hip_allreduce_counts");
+    hip_check(carmel_hip_read_scalars(t, er), "carmel_hip_read_scalars");
+  };
   std::vector<uint64_t> coff(1, 0), cpar;
   if (cascade) {
     for (auto& c : chains.chains) {
@@ -501,6 +593,14 @@ static int run(int argc, char** argv) {
   if (ls.n_cyclic_pairs)
     std::cerr << "Warning: at least one cycle in derivations for " << ls.n_cyclic_pairs
               << " example(s).  Forward/backward will miss some paths.\n";  // derivations.h:726-728
+  if (comm) {  // the counters of training_corpus over ALL ranks' surviving pairs
+    double v[5] = {cs.n_pairs, cs.total_weight, cs.n_input, cs.n_output, (double)ls.n_cyclic_pairs};
+    hip_check(carmel_hip_comm_allreduce_host(comm, v, 5, 0), "carmel_hip_comm_allreduce_host");
+    cs.n_pairs = v[0];
+    cs.total_weight = v[1];
+    cs.n_input = v[2];
+    cs.n_output = v[3];
+  }
   if (cs.n_pairs == 0) throw std::runtime_error("No training example had a derivation - aborting training.");
   auto print_ppx = [&](double ln_p) {  // weight.h:314-329 print_ppx_symbol
     double n_sym = std::max(cs.n_output, cs.n_input);
@@ -511,7 +611,7 @@ static int run(int argc, char** argv) {
   // ---- WFST::train (train.cc:503-678) ----
   carmel_hip_estimate_result er;
   if (o.max_iter == -1) {  // "-M" alone: just the corpus perplexity (train.cc:516-517)
-    hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+    estimate_all(&er);
     log << "Corpus ";
     print_ppx(er.sum_logprob);
     log << "\n";
@@ -519,7 +619,7 @@ static int run(int argc, char** argv) {
     if (o.max_iter == 0)
       log << "0 iterations specified for training; output weights will be unnormalized fractional counts (except locked "
              "arcs).\n";
-    hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+    estimate_all(&er);
     log << "Corpus ";
     print_ppx(er.sum_logprob);
     if (o.max_iter == 0)  // prep_new_weights(1.0) + cascade.distribute_counts()
@@ -561,7 +661,7 @@ static int run(int argc, char** argv) {
         // probability of zero or NaN that never happens: stop instead of spinning
         throw std::runtime_error("no iteration produced a usable corpus probability; giving up after " + std::to_string(iter - 1) + " iterations");
       }
-      hip_check(carmel_hip_estimate(t, &er, 0), "carmel_hip_estimate");
+      estimate_all(&er);
       if (timing) {
         double sweep_ms = 0;
         carmel_hip_last_sweep_ms(t, &sweep_ms);
@@ -760,6 +860,7 @@ static int run(int argc, char** argv) {
     return 0;
   }
   train_em(o);
+  if (rank > 0) return 0;  // the results are identical on every rank; rank 0 writes them
   // ---- forest-em side files (carmel.cc:818-831 fem_out; cascade.h:60-116, 167-178) ----
   if (!o.fem_norm.empty() || !o.fem_alpha.empty() || !o.fem_param.empty()) {
     std::vector<double> all_w(cascade ? params.logw.size() : logw.size());
@@ -853,13 +954,21 @@ static int run(int argc, char** argv) {
 }
 
 int main(int argc, char** argv) {
+  int rc;
   try {
-    return run(argc, argv);
+    rc = run(argc, argv);
   } catch (UsageError& e) {
     std::cerr << "carmel: " << e.what() << "\n";
-    return -12;
+    rc = -12;
   } catch (std::exception& e) {
     std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
-    return -11;
+    rc = -11;
   }
+  // --gpus: rank 0 waits for the other ranks; if it failed itself they may be waiting in a collective -- end them
+  for (pid_t p : g_kids) {
+    if (rc != 0) kill(p, SIGTERM);
+    int st = 0;
+    if (waitpid(p, &st, 0) > 0 && (!WIFEXITED(st) || WEXITSTATUS(st) != 0) && rc == 0) rc = -11;
+  }
+  return rc;
 }

@@ -603,6 +603,8 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   // counts in use, or locked members) -- read from the snapshot lw_src, never from the array being rewritten.
   const uint64_t kown = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   const double old_own = kown < M.n ? M.logw[kown] : 0.0;
+  const uint32_t mask_own = (M.mask32 && kown < M.n) ? M.mask32[kown] : 0u;
+  const uint32_t lock_own = (NEED_LW && M.mask32 && kown < M.n) ? M.lockmask32[kown] : 0u;
   int64_t kk[2] = {base + threadIdx.x, base + 256 + threadIdx.x};
   bool in[2];
   uint16_t code[2];
@@ -641,14 +643,19 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
     } else {
       const uint16_t want = gid & 0x3fffu;
       double sn = 0.0, sl = 0.0;
-      for (uint32_t j = me - span; j <= me + span; ++j) {
-        const uint16_t gj = g_sh[j];
-        if (gj == 0xffffu || (gj & 0x3fffu) != want) continue;
-        if (gj & 0x4000u)
-          sl += v_sh[j];
-        else
-          sn += v_sh[j];
-      }
+      if (M.mask32) {  // the members are known: add them up in ascending order (the order of the scan below)
+        for (uint32_t m = mask_own; m; m &= m - 1) sn += v_sh[me + (uint32_t)__builtin_ctz(m) - 15u];
+        if (NEED_LW)
+          for (uint32_t m = lock_own; m; m &= m - 1) sl += v_sh[me + (uint32_t)__builtin_ctz(m) - 15u];
+      } else
+        for (uint32_t j = me - span; j <= me + span; ++j) {
+          const uint16_t gj = g_sh[j];
+          if (gj == 0xffffu || (gj & 0x3fffu) != want) continue;
+          if (gj & 0x4000u)
+            sl += v_sh[j];
+          else
+            sn += v_sh[j];
+        }
       // new weight straight from the sums: one division, one log (and one exp for the old weight) per parameter
       const double old = old_own;
       if (M.save_old == 1) M.old_logw[k] = old;
@@ -772,6 +779,9 @@ __global__ void chain_scatter_kernel(double* param_counts, const double* arc_cou
   }
 }
 
+__global__ void add_f64_kernel(double* dst, const double* src, uint64_t n) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) dst[k] += src[k];
+}
 __global__ void fill_f64_kernel(double* p, double v, uint64_t n) {
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) p[k] = v;
 }
@@ -1068,6 +1078,11 @@ hipError_t launch_scalars(const double* pair_logprob, const double* pair_w, uint
                           double* scalars, hipStream_t s) {
   hipLaunchKernelGGL(scalars_partial_kernel, dim3(SCALAR_BLOCKS), dim3(256), 0, s, pair_logprob, pair_w, n_pairs, partial);
   hipLaunchKernelGGL(scalars_final_kernel, dim3(1), dim3(64), 0, s, partial, scalars);
+  return hipGetLastError();
+}
+hipError_t launch_add(double* dst, const double* src, uint64_t n, hipStream_t s) {
+  if (!n) return hipSuccess;
+  hipLaunchKernelGGL(add_f64_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, dst, src, n);
   return hipGetLastError();
 }
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {

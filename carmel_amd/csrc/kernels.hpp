@@ -112,6 +112,12 @@ struct MstepArgs {
   int save_old;             // 1: old_logw <- the weights before this pass, |change| against them; 0: keep old_logw from the
                             // previous pass and compare against it (second normalise after overrelax); 2: old_logw is not
                             // needed afterwards (no over-relaxation): do not write it, compare against the weight read
+  const uint32_t* mask32;   // mstep_window_kernel, span <= 15: per parameter, which of the parameters at offsets -15 .. +16 are the
+                            // unlocked members of its norm group (bit offset + 15; its own bit included when it is unlocked) --
+                            // the topology is static, so the kernel adds up exactly its group's members instead of scanning
+                            // and comparing the whole window (the scan, not the 26 bytes per parameter, was what the kernel
+                            // spent its time on); lockmask32: the locked members.  Null when span > 15.
+  const uint32_t* lockmask32;
   const uint16_t* code16;   // mstep_window_kernel: per parameter, norm-group id mod 2^14 | 0x4000 if locked; 0xffff = no norm
                             // group.  Ids are handed out in first-seen order, so inside a window of < 2^14 parameters equal
                             // low bits mean equal groups: 2 bytes per parameter instead of norm_of + group (8)
@@ -135,6 +141,7 @@ hipError_t launch_scalars(const double* pair_logprob, const double* pair_w, uint
                           double* scalars, hipStream_t s);
 hipError_t launch_count_reduce(const ReduceArgs& R, hipStream_t stream);
 hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s);
+hipError_t launch_add(double* dst, const double* src, uint64_t n, hipStream_t s);  // dst += src
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s);
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,
                             uint64_t n, hipStream_t s);

@@ -27,6 +27,39 @@ class TrainOpts(object):
         self.learning_rate_growth_factor = learning_rate_growth_factor
 
 
+class HipComm(object):
+    """carmel_hip_comm: the RCCL communicator of corpus-sharded EM (one process per GPU).  Rank 0 makes the id with
+    HipComm.unique_id() and hands the 128 bytes to the other ranks by any means."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        check(lib.carmel_hip_comm_unique_id(buf), "carmel_hip_comm_unique_id")
+        return bytes(buf.raw)
+
+    def __init__(self, device, rank, world, id_bytes):
+        assert len(id_bytes) == 128
+        h = C.c_void_p()
+        check(lib.carmel_hip_comm_create(C.byref(h), device, rank, world, C.c_char_p(id_bytes)), "carmel_hip_comm_create")
+        self.h, self.rank, self.world = h, rank, world
+
+    def allreduce_host(self, values, op_max=False):
+        v = np.ascontiguousarray(values, dtype=np.float64).copy()
+        check(lib.carmel_hip_comm_allreduce_host(self.h, ptr(v), len(v), 1 if op_max else 0), "carmel_hip_comm_allreduce_host")
+        return v
+
+    def close(self):
+        if self.h:
+            lib.carmel_hip_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HipForwardBackward(object):
     def __init__(self, wfst, corpus, norm_group=NORM_CONDITIONAL, add_count=0.0, smooth_floor=0.0,
                  weight_is_prior_count=False, device=0, prune=True, host_threads=0, cascade=None,
@@ -89,6 +122,10 @@ class HipForwardBackward(object):
 
     def synchronize(self):
         check(lib.carmel_hip_synchronize(self.h), "carmel_hip_synchronize")
+
+    def allreduce_counts(self, comm):
+        """enqueue the RCCL all-reduce (sum) of counts[n_arcs + 4] on the trainer's stream (no host sync)"""
+        check(lib.carmel_hip_allreduce_counts(self.h, comm.h), "carmel_hip_allreduce_counts")
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

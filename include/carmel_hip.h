@@ -180,6 +180,25 @@ int carmel_hip_save_counts(carmel_hip_trainer* t); /* for_arcs::save_counts: em_
 int carmel_hip_save_best(carmel_hip_trainer* t);
 int carmel_hip_load_best(carmel_hip_trainer* t);
 
+/* ---- corpus-sharded EM over the GPUs of one node (RCCL over xGMI) ----
+ * No reference counterpart (carmel is single-process); SURVEY.md 8(e): every rank holds the whole model and a shard of
+ * the training pairs, and the one exchange per iteration is the sum of counts[n_arcs + 4] (expected counts + the corpus
+ * scalars of train.cc:326-332) between estimate and maximize.  One process per GPU; rank 0 makes the 128-byte id
+ * (carmel_hip_comm_unique_id) and hands it to the others by any means (the carmel front end uses a pipe, bench.py
+ * torch.distributed).  carmel_hip_allreduce_counts ENQUEUES the all-reduce on the trainer's stream, in place on
+ * carmel_hip_counts_dev: estimate_async -> allreduce_counts -> maximize needs no host synchronisation in between
+ * (carmel_hip_read_scalars afterwards gives the corpus-wide scalars).  RCCL is loaded at run time (dlopen); without it
+ * these calls return CARMEL_HIP_ERR_UNSUPPORTED.  carmel_hip_comm_allreduce_host sums (or maximises) a few host doubles
+ * across ranks -- corpus statistics, timings. */
+typedef struct carmel_hip_comm carmel_hip_comm;
+int carmel_hip_comm_unique_id(void* id128);
+int carmel_hip_comm_create(carmel_hip_comm** out, int device, int rank, int world, const void* id128);
+int carmel_hip_comm_destroy(carmel_hip_comm* c);
+int carmel_hip_comm_rank(carmel_hip_comm* c);
+int carmel_hip_comm_world(carmel_hip_comm* c);
+int carmel_hip_allreduce_counts(carmel_hip_trainer* t, carmel_hip_comm* c);
+int carmel_hip_comm_allreduce_host(carmel_hip_comm* c, double* v, uint32_t n, int op_max);
+
 /* ---- blocked Gibbs sampling of derivations: `carmel --crp` ----
  * Replaces: WFST::train_gibbs / carmel_gibbs (gibbs.cc:15-41, 386-430) + gibbs_base::run_starts
  * (gibbs.hpp:803-914) + derivations::random_path (derivations.h:345-375).  The sampler is created from a trainer

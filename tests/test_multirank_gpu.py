@@ -1,0 +1,92 @@
+"""GPU: the product's N > 1 path -- corpus shards, the trainers' device count buffer (n_arcs + 4 doubles) summed
+across ranks between estimate_async and maximize, corpus scalars re-read after the sum, replicated M-step -- gives
+the single-rank trainer's weights and corpus probabilities.  Two ranks share GPU 0 here (the pool has one GPU per
+box), so the sum travels over gloo through the host; the RCCL entry points are exercised with a world of one.  Both
+trainer layouts are covered: explicit lattices and the unrolled cascade sweep (whose buffer holds per-parameter sums)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "multirank_worker.py")
+
+
+def _run(world, mode, tmp_path, tag, extra=()):
+    port = 29600 + (os.getpid() % 1500) + (abs(hash((mode, tag))) % 300)
+    out = str(tmp_path / ("w_%s_%d.npy" % (tag, world)))
+    procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(world), str(port), out, mode] + list(extra),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True) for r in range(world)]
+    for p in procs:
+        o, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, o
+    return np.load(out)
+
+
+@pytest.mark.parametrize("mode", ["synth", "cipher", "cipher-explicit"])
+def test_two_ranks_reproduce_the_single_rank_trainer(tmp_path, mode):
+    one = _run(1, mode, tmp_path, "one")
+    two = _run(2, mode, tmp_path, "two")
+    nlog = 12
+    w1, w2 = one[:-nlog], two[:-nlog]
+    fin = np.isfinite(w1)
+    assert np.array_equal(fin, np.isfinite(w2))
+    np.testing.assert_allclose(np.exp(w2[fin]), np.exp(w1[fin]), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(two[-nlog:], one[-nlog:], rtol=1e-10)
+    assert one[-nlog + 2] > 0 and one[-nlog] < 0  # pairs swept, ln P
+
+
+def test_rccl_entry_points_with_a_world_of_one(tmp_path):
+    """carmel_hip_comm_unique_id / _create / carmel_hip_allreduce_counts (stream-ordered, no host sync) / _destroy:
+    with one rank the sum is the identity, so the run must equal the plain one"""
+    plain = _run(1, "synth", tmp_path, "plain")
+    rccl = _run(1, "synth", tmp_path, "rccl", extra=["--rccl"])
+    np.testing.assert_array_equal(plain, rccl)
+
+
+@pytest.mark.parametrize("mode", ["synth", "cipher"])
+def test_library_allreduce_two_ranks_host_transport(tmp_path, mode):
+    """the library's own exchange -- carmel_hip_allreduce_counts enqueued between estimate_async and maximize, exactly
+    what bench.py and `carmel --gpus` do -- with two ranks on the one GPU of this box: CARMEL_HIP_COMM=host stages the
+    sum through shared memory (RCCL refuses two ranks on one device) and adds on the GPU"""
+    os.environ["CARMEL_HIP_COMM"] = "host"
+    try:
+        two = _run(2, mode, tmp_path, "lib2", extra=["--rccl"])
+    finally:
+        del os.environ["CARMEL_HIP_COMM"]
+    one = _run(1, mode, tmp_path, "lib1")
+    nlog = 12
+    fin = np.isfinite(one[:-nlog])
+    np.testing.assert_allclose(np.exp(two[:-nlog][fin]), np.exp(one[:-nlog][fin]), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(two[-nlog:], one[-nlog:], rtol=1e-10)
+
+
+@pytest.mark.parametrize("args", [["-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"],
+                                  ["--train-cascade", "-HJ", "-M", "5", "cipher.data", "cipher.wfsa", "cipher.fst"],
+                                  ["-t", "-M", "4", "-!", "1", "-R", "3", "train.a.w.corpus100", "train.a.w"]])
+def test_front_end_gpus_switch(golden_dir, tmp_path, args):
+    """carmel --gpus=2: two processes forked before any GPU call, the corpus in two blocks, counts summed every
+    iteration, replicated M-step -- the log lines and the trained transducers of the one-process run"""
+    import re
+    cli = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
+    full = [os.path.join(golden_dir, a) if os.path.exists(os.path.join(golden_dir, a)) else a for a in args]
+    outs = []
+    for n in (1, 2):
+        d = tmp_path / ("n%d" % n)
+        d.mkdir()
+        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_HIP_COMM="host")
+        p = subprocess.run([cli, "--gpus=%d" % n] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                           env=env, timeout=600)
+        assert p.returncode == 0, p.stderr
+        trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
+        outs.append(([l for l in p.stderr.split("\n") if l.startswith("i=")], p.stdout + trained))
+    assert len(outs[0][0]) == len(outs[1][0]) >= 2
+    num = re.compile(r"(?<![\w\"])(\d+\.\d+(?:e[-+]\d+)?|\d+e[-+]\d+)(?![\w\"])")
+    for a, b in zip(outs[0][0] + outs[0][1].split("\n"), outs[1][0] + outs[1][1].split("\n")):
+        assert num.sub("#", a) == num.sub("#", b), (a, b)
+        for u, v in zip(num.findall(a), num.findall(b)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
