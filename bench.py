@@ -59,12 +59,199 @@ def pmc_traffic(config, walk_arcs, n_pairs):
     return tot
 
 
+F64_PEAK_TFLOPS = 78.6  # MI355X fp64 vector = matrix rate (AMD data sheet; the microarchitecture guide lists no f64 peak)
+
+
+def _replicas(value):
+    """c3 / c5 at N > 1: independent replicas, one per GPU (no data-path collective: SURVEY 8e -- the sampler does not
+    shard exactly, and config 3's model is 758 parameters); the job's value is the sum over the ranks"""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return value, 1
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group("nccl")
+    t = torch.tensor([value], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t)
+    dist.destroy_process_group()
+    return float(t[0]), world
+
+
+def other_configs(args):
+    """BASELINE.json configs[2] (cipher cascade, 200k lines) and configs[4] (forest-em, 5M-node packed forest) under the
+    same output contract.  A step is one EM iteration (c3) / one Gibbs sweep over all forests (c5)."""
+    import re
+    import subprocess
+    import tempfile
+    import numpy as np
+    from carmel_amd import synth
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.config == "amb":
+        # ambiguous lattices (config 4's are 99.99 % single-path chains, so it never exercises the log-semiring sum): the
+        # reference's own tagging cascade (carmel-tutorial/tagging.*: tag bigram model o tag->word lexicon, 46 states /
+        # 400 994 composed arcs; a sentence's lattice is positions x candidate tags), its 1005-sentence corpus repeated
+        d = tempfile.mkdtemp(prefix="amb_")
+        g = lambda n: os.path.join(ROOT, "tests", "golden", n)
+        reps = max(1, args.pairs // 1005) if args.pairs else 100
+        open(os.path.join(d, "corpus"), "w").write(open(g("tagging.data")).read() * reps)
+        iters = args.steps + args.warmup
+        cmd = [os.path.join(ROOT, "carmel_amd", "bin", "carmel"), "--gpu=%d" % local_rank, "--train-cascade", "-HJ", "-M", str(iters),
+               "-X", "1.1", "-e", "0", os.path.join(d, "corpus"), g("tagging.fsa"), g("tagging.fst")]
+        p = subprocess.run(cmd, env=dict(os.environ, CARMEL_TIMING="1", CARMEL_TRAINED_DIR=d), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, universal_newlines=True)
+        if p.returncode != 0:
+            sys.exit(p.stderr[-2000:])
+        lat = re.search(r"timing: lattices pairs_kept=(\d+) states=(\d+) arcs=(\d+) layout=(\w+) device_bytes=(\d+) build_seconds=(\S+)", p.stderr)
+        est = [float(x) for x in re.findall(r"timing: i=\d+ estimate (\S+) ms", p.stderr)][args.warmup:]
+        ker = [float(x) for x in re.findall(r"estimate \S+ ms \(kernels (\S+) ms\)", p.stderr)][args.warmup:]
+        mx = [float(x) for x in re.findall(r"timing: i=\d+ maximize (\S+) ms", p.stderr)][args.warmup:]
+        arcs, states = float(lat.group(3)), float(lat.group(2))
+        ms = (sum(est) + sum(mx)) / max(len(est), 1)
+        k_ms = sum(ker) / max(len(ker), 1)
+        alg = algorithmic_bytes(arcs, states)
+        value, world = _replicas(arcs / (ms * 1e-3))
+        out = {"metric": "arc-updates/sec (EM iterations/sec x derivation-lattice arcs swept per iteration)", "value": value,
+               "unit": "arc-updates/s", "n_gpus": world, "steps": len(est), "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "carmel-tutorial tagging.* x%d" % reps,
+               "config": {"workload": "amb: tagging cascade (tag bigram model o lexicon, 46 states / 400994 composed arcs), the "
+                                      "tutorial's 1005 sentences x %d = %d pairs, carmel --train-cascade through the front end; "
+                                      "ambiguous lattices (positions x candidate tags)" % (reps, int(lat.group(1))),
+                          "lattice_arcs_per_gpu": int(arcs), "lattice_states_per_gpu": int(states), "lattice_layout": lat.group(4),
+                          "parallelism": "replicas x%d" % world},
+               "lattice_build_s": float(lat.group(6)), "estep_ms": sum(est) / max(len(est), 1), "mstep_ms": sum(mx) / max(len(mx), 1),
+               "roofline": {"bound": "hbm", "kernel": "E-step (weights to lattice order, lane / bundle sweeps, posteriors to counts), HIP "
+                            "events on the trainer's stream", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                            "kernel_ms": k_ms}}
+        if not args.no_cpu_baseline and rank == 0:
+            # the trace of the reference itself: 25.9-26.5 s per iteration on this cascade (commands.trace:5868-5889,
+            # unknown hardware, no derivation caching); here the oracle with cached derivations on the 1005 sentences
+            oc = [os.path.join(ROOT, "oracle", "oracle_carmel"), "--train-cascade", "-HJ", "-:", "-X", "1.1", "-e", "0", "-M"]
+            tail = [g("tagging.data"), g("tagging.fsa"), g("tagging.fst")]
+            dts = []
+            for it in ("1", "3"):
+                t0 = time.time()
+                q = subprocess.run(oc + [it] + tail, env=dict(os.environ, ORACLE_TRAINED_DIR=d), stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, universal_newlines=True)
+                dts.append(time.time() - t0)
+            if q.returncode == 0 and dts[1] > dts[0]:
+                per_iter = (dts[1] - dts[0]) / 2.0
+                out["cpu_baseline"] = {"value": arcs / reps / per_iter, "unit": "arc-updates/s", "cores": 1, "kind": "port",
+                                       "sample": "the oracle's command line on the 1005 sentences (one repetition), cached "
+                                                 "derivations: (time of 3 iterations - time of 1) / 2 = %.2f s per iteration "
+                                                 "(the reference's own trace: 26 s per iteration without caching)" % per_iter}
+    elif args.config == "c3":
+        d = tempfile.mkdtemp(prefix="c3_")
+        lm, ch, co = synth.cipher_files(args.lines)
+        for name, txt in (("lm.wfsa", lm), ("ch.fst", ch), ("corpus", co)):
+            open(os.path.join(d, name), "w").write(txt)
+        iters = args.steps + args.warmup
+        cmd = [os.path.join(ROOT, "carmel_amd", "bin", "carmel"), "--gpu=%d" % local_rank, "--train-cascade", "--normby=NC", "-HJ", "-M", str(iters), "-X", "1.1",
+               "-e", "0", os.path.join(d, "corpus"), os.path.join(d, "lm.wfsa"), os.path.join(d, "ch.fst")]
+        p = subprocess.run(cmd, env=dict(os.environ, CARMEL_TIMING="1", CARMEL_TRAINED_DIR=d), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, universal_newlines=True)
+        if p.returncode != 0:
+            sys.exit(p.stderr[-2000:])
+        lat = re.search(r"timing: lattices pairs_kept=(\d+) states=(\d+) arcs=(\d+) layout=(\w+)", p.stderr)
+        est = [float(x) for x in re.findall(r"timing: i=\d+ estimate (\S+) ms", p.stderr)][args.warmup:]
+        ker = [float(x) for x in re.findall(r"estimate \S+ ms \(kernels (\S+) ms\)", p.stderr)][args.warmup:]
+        mx = [float(x) for x in re.findall(r"timing: i=\d+ maximize (\S+) ms", p.stderr)][args.warmup:]
+        arcs = float(lat.group(3))
+        ms = (sum(est) + sum(mx)) / max(len(est), 1)
+        k_ms = sum(ker) / max(len(ker), 1)
+        # the unrolled sweep never stores a lattice: per lattice arc it does one multiply-add forwards, and backwards a
+        # multiply-add, the posterior (two multiplies) and its accumulation -- 8 f64 flops -- out of L2-resident tables
+        flops = 8.0 * arcs
+        value, world = _replicas(arcs / (ms * 1e-3))
+        out = {"metric": "arc-updates/sec (EM iterations/sec x derivation-lattice arcs swept per iteration)", "value": value,
+               "unit": "arc-updates/s", "n_gpus": world, "steps": len(est), "warmup": args.warmup, "ms_per_step": ms,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "c3: cipher cascade, character bigram LM (29 states, locked) o 27x27 substitution channel, "
+                                      "%d lines of 30-80 symbols, carmel --train-cascade --normby=NC through the front end; "
+                                      "lattices unrolled over string positions, never stored" % args.lines,
+                          "lattice_arcs_per_gpu": int(arcs), "lattice_layout": lat.group(4), "parallelism": "replicas x%d" % world},
+               "roofline": {"bound": "mfma", "kernel": "unrolled_sweep_kernel (f64 vector FMAs on L2-resident tables; priced "
+                            "against the f64 rate, 8 flops per lattice arc -- it moves 2 B of HBM per string position)",
+                            "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": flops / (k_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
+        if not args.no_cpu_baseline and rank == 0:
+            n = 150
+            lm2, ch2, co2 = synth.cipher_files(n)
+            for name, txt in (("lm2.wfsa", lm2), ("ch2.fst", ch2), ("corpus2", co2)):
+                open(os.path.join(d, name), "w").write(txt)
+            oc = [os.path.join(ROOT, "oracle", "oracle_carmel"), "--train-cascade", "--normby=NC", "-HJ", "-:", "-M"]
+            tail = [os.path.join(d, "corpus2"), os.path.join(d, "lm2.wfsa"), os.path.join(d, "ch2.fst")]
+            dts = []
+            for it in ("1", "3"):  # the difference of two runs leaves the per-iteration time (composition, build cancel)
+                t0 = time.time()
+                q = subprocess.run(oc + [it, "-X", "1.1", "-e", "0"] + tail, env=dict(os.environ, ORACLE_TRAINED_DIR=d),
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+                dts.append(time.time() - t0)
+            if q.returncode == 0 and dts[1] > dts[0]:
+                per_iter = (dts[1] - dts[0]) / 2.0
+                out["cpu_baseline"] = {"value": arcs * n / args.lines / per_iter, "unit": "arc-updates/s", "cores": 1, "kind": "port",
+                                       "sample": "the oracle's command line on %d lines of the same model, cached derivations: "
+                                                 "(time of 3 iterations - time of 1) / 2 = %.2f s per iteration" % (n, per_iter)}
+    else:
+        from carmel_amd.forests import HipForests
+        node_off, label, ref, nxt, n_rules, goff, grule = synth.random_forests(args.forests)
+        rng = np.random.default_rng(4)
+        lw = np.log(rng.uniform(0.05, 1.0, n_rules))
+        hf = HipForests(node_off, label, ref, nxt, n_rules, lw, goff, grule, device=local_rank)
+        hf.maximize()
+        hf.gibbs(max(args.warmup, 1), alpha=0.1, seed=4 + rank, mode=1)
+        t0 = time.perf_counter()
+        hf.gibbs(args.steps, burnin=args.steps // 4, alpha=0.1, seed=4 + rank, mode=1)
+        dt = time.perf_counter() - t0
+        sweeps = args.steps + 1
+        n_nodes = float(len(label))
+        n_sampled = float(np.mean([len(hf.sample(f)) for f in range(0, args.forests, max(1, args.forests // 2000))])) * args.forests
+        ms = 1e3 * dt / sweeps
+        alg = 40.0 * n_nodes + 64.0 * n_sampled  # SURVEY 8(d): node record, proposal gather, inside write + read; two count RMWs per sampled rule
+        value, world = _replicas(n_nodes * sweeps / dt)
+        out = {"metric": "forest-node updates/sec (Gibbs sweeps/sec x nodes of the packed forests; carmel's arc-updates for "
+                         "forest-em)", "value": value, "unit": "node-updates/s", "n_gpus": world, "steps": sweeps,
+               "warmup": max(args.warmup, 1), "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "c5: forest-em --crp on %d synthetic packed forests (%d nodes, %d parameters, alpha 0.1), "
+                                      "parallel stale-count sweeps" % (args.forests, int(n_nodes), n_rules - 1),
+                          "sampled_rules_per_sweep": int(n_sampled), "parallelism": "replicas x%d (independent chains)" % world},
+               "sweeps_per_s": sweeps / dt,
+               "roofline": {"bound": "hbm", "kernel": "one sweep = forest_proposal + forest_sample (per launch class) + forest_recount; "
+                            "timed as wall time per sweep around carmel_hip_forests_gibbs (launch gaps included)",
+                            "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg}}
+        hf.close()
+        if not args.no_cpu_baseline and rank == 0:
+            from oracle import binding as ob
+            from carmel_amd._capi import lib
+            nf = min(args.forests, 3000)
+            txt = synth.forests_to_text(node_off, label, ref, nxt, 0, nf)
+            norm = "(" + " ".join("(" + " ".join(str(int(r)) for r in grule[int(goff[g]):int(goff[g + 1])]) + ")"
+                                  for g in range(len(goff) - 1)) + ")"
+            of = ob.OracleForests(txt, norm)
+            of.set_weights(lw[:of.n_rules] if of.n_rules <= len(lw) else np.concatenate([lw, np.zeros(of.n_rules - len(lw))]))
+            t0 = time.time()
+            of.gibbs(lambda i, b, st: lib.carmel_hip_gibbs_uniform(4, i, b, st), 9, burnin=2, alpha=0.1)
+            cdt = time.time() - t0
+            out["cpu_baseline"] = {"value": float(of.n_nodes) * 10 / cdt, "unit": "node-updates/s", "cores": 1, "kind": "port",
+                                   "sample": "the first %d forests (%d nodes), same parameters; 10 exact (sequential) sweeps of the "
+                                             "scalar oracle, uniforms through a callback" % (nf, of.n_nodes)}
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c4", "toy"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c4", "toy", "c3", "c5", "amb"])
+    ap.add_argument("--lines", type=int, default=200000, help="c3: corpus lines")
+    ap.add_argument("--forests", type=int, default=100000, help="c5: forests")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU (default: the config's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --pairs per GPU; strong: --pairs in total, sharded over the GPUs")
@@ -75,6 +262,8 @@ def main():
     ap.add_argument("--walk-arcs", default="5,40", help="min,max arcs of the random walks (SURVEY 8d: 5,40; other values are experiments)")
     args = ap.parse_args()
 
+    if args.config in ("c3", "c5", "amb"):
+        return other_configs(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -894,6 +894,17 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   const uint32_t bucket = xcd_chunked(blockIdx.x, T.n_buckets);  // the grid is rounded up to a multiple of 8
   if (bucket >= T.n_buckets) return;
   const TransBucket B = T.buckets[bucket];
+  // every global load of the workgroup is issued before the first barrier: item indices, the items, and the item
+  // ranges of this thread's arcs (the per-arc loop below then runs out of registers and LDS alone)
+  uint16_t r0[TRANS_K], r1[TRANS_K];
+  const bool single = (B.flags & TRANS_SINGLE) != 0;
+#pragma unroll
+  for (int k = 0; k < TRANS_K; ++k) {
+    const uint32_t a = threadIdx.x + k * 1024;
+    const bool ok = !single && a < B.n_arcs;
+    r0[k] = ok ? T.a_off[B.arc_lo + a] : (uint16_t)0;
+    r1[k] = (ok && a + 1 < B.n_arcs) ? T.a_off[B.arc_lo + a + 1] : (uint16_t)0;
+  }
   {
     uint32_t src[TRANS_K];
     uint16_t rk[TRANS_K];
@@ -911,7 +922,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
   }
   __syncthreads();
-  if (B.flags & TRANS_SINGLE) {
+  if (single) {
     double v = 0.0;
     for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) v += lds[j];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -931,9 +942,12 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   // either way)
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
-  for (uint32_t a = threadIdx.x; a < B.n_arcs; a += 1024) {
-    const uint32_t r0 = T.a_off[B.arc_lo + a], r1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
-    if (r1 - r0 > 32) {
+#pragma unroll
+  for (int k = 0; k < TRANS_K; ++k) {
+    const uint32_t a = threadIdx.x + k * 1024;
+    if (a >= B.n_arcs) break;
+    const uint32_t q0 = r0[k], q1 = a + 1 < B.n_arcs ? (uint32_t)r1[k] : B.n_items;
+    if (q1 - q0 > 32) {
       const uint32_t q = atomicAdd(&n_big, 1u);
       if (q < 512) {
         big[q] = a;
@@ -941,16 +955,16 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
       }
     }
     double v = 0.0;
-    for (uint32_t r = r0; r < r1; ++r) v += lds[r];
+    for (uint32_t r = q0; r < q1; ++r) v += lds[r];
     T.counts[B.arc_lo + a] = v;
   }
   __syncthreads();
   const uint32_t nb = n_big < 512 ? n_big : 512;
   for (uint32_t q = threadIdx.x >> 6; q < nb; q += 16) {
     const uint32_t a = big[q];
-    const uint32_t r0 = T.a_off[B.arc_lo + a], r1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
+    const uint32_t q0 = T.a_off[B.arc_lo + a], q1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
     double v = 0.0;
-    for (uint32_t r = r0 + (threadIdx.x & 63); r < r1; r += 64) v += lds[r];
+    for (uint32_t r = q0 + (threadIdx.x & 63); r < q1; r += 64) v += lds[r];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) T.counts[B.arc_lo + a] = v;
   }

@@ -146,6 +146,34 @@ def random_forests(n_forests, n_rules=500000, mean_nodes=46, p_backref=0.6, grou
             np.asarray(nexts, np.uint32), n_rules + 1, goff.astype(np.uint64), perm.astype(np.uint32))
 
 
+def forests_to_text(node_off, label, ref, nxt, f0, f1):
+    """forests [f0, f1) of the node arrays random_forests returns, in forest-em's text format (one forest per line:
+    `(OR a b)`, `(rule child ...)`, `#k(...)` defines and `#k` references a shared sub-forest; forest.hpp:39-46)"""
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    lines = []
+    for f in range(f0, f1):
+        b, e = int(node_off[f]), int(node_off[f + 1])
+        lab, rf, nx = label[b:e], ref[b:e], nxt[b:e]
+        ids = {}
+        for i in range(e - b):
+            if rf[i] >= 0 and int(rf[i]) not in ids:
+                ids[int(rf[i])] = len(ids) + 1
+
+        def emit(i):
+            if rf[i] >= 0:
+                return "#%d" % ids[int(rf[i])]
+            kids, j = [], i + 1
+            while j < int(nx[i]):
+                kids.append(emit(j))
+                j = int(nx[j])
+            head = "OR" if lab[i] == 0 else str(int(lab[i]))
+            body = "(%s %s)" % (head, " ".join(kids)) if kids else head
+            return ("#%d%s" % (ids[i], body)) if i in ids else body
+        lines.append(emit(0))
+    return "\n".join(lines) + "\n"
+
+
 CIPHER_PLAIN = ["_"] + [chr(ord("A") + i) for i in range(26)]
 
 
