@@ -95,7 +95,7 @@ def other_configs(args):
         # 400 994 composed arcs; a sentence's lattice is positions x candidate tags), its 1005-sentence corpus repeated
         d = tempfile.mkdtemp(prefix="amb_")
         g = lambda n: os.path.join(ROOT, "tests", "golden", n)
-        reps = max(1, args.pairs // 1005) if args.pairs else 100
+        reps = max(1, args.pairs // 1005) if args.pairs else 400  # 402 000 pairs: enough wavefronts to fill 256 CUs
         open(os.path.join(d, "corpus"), "w").write(open(g("tagging.data")).read() * reps)
         iters = args.steps + args.warmup
         cmd = [os.path.join(ROOT, "carmel_amd", "bin", "carmel"), "--gpu=%d" % local_rank, "--train-cascade", "-HJ", "-M", str(iters),

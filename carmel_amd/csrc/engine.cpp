@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <cstdlib>
 #include <limits>
@@ -58,6 +59,9 @@ int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, u
   (void)hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming);
+  (void)hipStreamCreateWithFlags(&t->bstream, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&t->ev_b0, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&t->ev_b1, hipEventDisableTiming);
   for (int k = 0; k < carmel_hip_trainer::N_CHUNK_STREAMS; ++k) {
     (void)hipStreamCreateWithFlags(&t->cstream[k], hipStreamNonBlocking);
     (void)hipEventCreateWithFlags(&t->cev[k], hipEventDisableTiming);
@@ -114,6 +118,12 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
   if (t->ev_w) (void)hipEventDestroy(t->ev_w);
+  if (t->bstream) {
+    (void)hipStreamSynchronize(t->bstream);
+    (void)hipStreamDestroy(t->bstream);
+  }
+  if (t->ev_b0) (void)hipEventDestroy(t->ev_b0);
+  if (t->ev_b1) (void)hipEventDestroy(t->ev_b1);
   for (int k = 0; k < carmel_hip_trainer::N_CHUNK_STREAMS; ++k) {
     if (t->cstream[k]) {
       (void)hipStreamSynchronize(t->cstream[k]);
@@ -268,6 +278,13 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   std::vector<uint32_t>().swap(L.in_off);
   std::vector<uint32_t>().swap(L.out_off);
   std::vector<uint32_t>().swap(L.level_off);
+  if (getenv("CARMEL_TIMING")) {
+    fprintf(stderr, "timing: layout lane_arcs=%llu lane_groups=%zu lane_pieces=%zu bundles=%zu bundle_classes=%zu total_arcs=%llu aligned=%d\n",
+            (unsigned long long)L.lane_arcs, L.lane_groups.size(), L.lane_classes.size(), L.bundles.size(), L.classes.size(),
+            (unsigned long long)L.total_arcs, (int)L.lane_tiles_aligned);
+    for (auto& lc : L.lane_classes) fprintf(stderr, "timing:   lane piece groups=%u max_states=%u tiles=%u\n", lc.count, lc.max_states, lc.tile_count);
+    for (auto& lc : L.classes) fprintf(stderr, "timing:   bundle class count=%u block=%u max_states=%u serial=%d\n", lc.count, lc.block, lc.max_states, (int)lc.serial);
+  }
   t->have_lattices = true;
   ++t->lattice_epoch;
   if (stats) {
@@ -677,9 +694,17 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.pre_weights = t->use_transpose ? 1u : 0u;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
-  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_classes[0].tile_count &&
+  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned &&
                             !(getenv("CARMEL_HIP_ESTEP_STREAMS") && atoi(getenv("CARMEL_HIP_ESTEP_STREAMS")) <= 1);
+  // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
+  const bool bundles_beside = side_by_side && !t->lat.classes.empty();
   if (t->use_transpose) HIPCHK(launch_trans_w_bucket(T, s));
+  if (bundles_beside) {  // (after the bucket pass: its workgroups need a CU's LDS nearly whole)
+    HIPCHK(hipEventRecord(t->ev_b0, s));
+    HIPCHK(hipStreamWaitEvent(t->bstream, t->ev_b0, 0));
+    for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, t->bstream));
+    HIPCHK(hipEventRecord(t->ev_b1, t->bstream));
+  }
   if (side_by_side) {
     // chunk k: weights of its tiles to lattice order -> its sweep -> its posteriors out to X, on stream k mod 4.  The
     // kernels of different chunks overlap: a workgroup of the tile passes holds a whole CU's LDS and alternates between
@@ -707,7 +732,10 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
     for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   }
-  for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
+  if (bundles_beside)
+    HIPCHK(hipStreamWaitEvent(s, t->ev_b1, 0));
+  else
+    for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, s));
   ReduceArgs R;
   R.arc_off = t->arc_off.p;
   R.slot_pos = t->slot_pos.p;

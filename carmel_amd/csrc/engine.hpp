@@ -55,6 +55,8 @@ struct carmel_hip_trainer {
   hipStream_t cstream[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t cev[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_w = nullptr;
+  hipStream_t bstream = nullptr;  // the bundle sweeps (they gather their weights themselves) run beside the lane pieces
+  hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
   HostWfst w;
   HostCorpus corpus;
   bool have_corpus = false, have_lattices = false, cascade = false;

@@ -81,7 +81,8 @@ struct TransArgs {
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
 };
 
-#define MSTEP_BIG_GROUP 512
+#define MSTEP_BIG_GROUP 48  // a group above this size is summed by a workgroup of its own (one thread walking 500 members is a
+                           // chain of 500 dependent loads: 0.22 ms on the tagging lexicon's per-tag groups)
 #define MSTEP_PARTIALS 2048
 struct MstepArgs {
   double* logw;             // parameters (ln), updated in place

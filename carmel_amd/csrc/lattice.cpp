@@ -567,39 +567,49 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
         i = j;
       }
     }
-    // chunks: every class is cut into pieces of about equal record count; a piece's stream starts on a tile boundary
+    // pieces: every class is cut into lane_chunks pieces of about equal record count.  When there is more than one
+    // piece (several classes, or chunks), each piece's stream starts on a tile boundary of the blocked transposition, so
+    // that the tile passes can be launched per piece and the pieces can run side by side
     uint64_t base = 0;
     const uint32_t want_chunks = std::max<uint32_t>(1, opt.lane_chunks);
+    std::vector<uint32_t> nchs;
+    size_t n_pieces = 0;
     for (const auto& lc : classes) {
       uint64_t rows = 0;
       for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
       // no chunk smaller than 16 tiles' worth of records: a launch has to fill the chip
-      const uint32_t nch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE)));
+      nchs.push_back((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE))));
+      n_pieces += nchs.back();
+    }
+    const bool align = n_pieces > 1;
+    out.lane_tiles_aligned = align;
+    for (size_t ci = 0; ci < classes.size(); ++ci) {
+      const auto& lc = classes[ci];
+      uint64_t rows = 0;
+      for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
+      const uint32_t nch = nchs[ci];
       uint32_t g = lc.first;
       uint64_t done = 0;
       for (uint32_t k = 0; k < nch; ++k) {
         const uint64_t goal = rows * (k + 1) / nch;
         LatticeSet::LaneClass piece = lc;
         piece.first = g;
-        if (nch > 1 || want_chunks > 1) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
+        if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
         piece.tile_first = (uint32_t)(base / TRANS_TILE);
-        uint32_t mx = 0;
         while (g < lc.first + lc.count && (done < goal || k + 1 == nch)) {
           LaneGroup& G = out.lane_groups[g];
           G.stream_base = base;
           base += (uint64_t)G.maxlen * 64;
           done += G.maxlen;
-          mx = std::max(mx, G.max_states);
           ++g;
         }
         piece.count = g - piece.first;
         piece.max_states = lc.max_states;  // one LDS size per class keeps the occupancy of its pieces equal
-        (void)mx;
         piece.tile_count = (uint32_t)((base + TRANS_TILE - 1) / TRANS_TILE) - piece.tile_first;
         if (piece.count) out.lane_classes.push_back(piece);
       }
     }
-    if (want_chunks > 1) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
+    if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
     out.lane_fwd.assign(base, uint2_t{0, 0});
     out.lane_bwd.assign(base, uint2_t{0, 0});
     std::atomic<size_t> nextg(0);

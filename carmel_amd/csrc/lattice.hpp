@@ -135,6 +135,7 @@ struct LatticeSet {
     uint32_t tile_first = 0, tile_count = 0;
   };
   std::vector<LaneClass> lane_classes;
+  bool lane_tiles_aligned = false;  // the pieces' tile ranges are disjoint (required for launching the tile passes per piece)
   uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
   // posterior slots: one per lattice arc.  Lane records use their position in lane_bwd[]; bundle out-arcs use
   // lane_bwd.size() + position in out_arcs[].  slot_arc / slot_pos list every slot sorted by WFST arc id, which is
