@@ -29,6 +29,8 @@ SYMBOLS = [
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
     "carmel_hip_forests_max_sample",
+    "carmel_hip_compose", "carmel_hip_composition_states", "carmel_hip_composition_arcs", "carmel_hip_composition_seconds",
+    "carmel_hip_composition_export", "carmel_hip_composition_free",
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
 ]
@@ -73,6 +75,16 @@ def _load():
     lib.carmel_hip_random_restart.argtypes = [vp, C.c_uint64, C.c_uint32]
     lib.carmel_hip_keep_em_weights.argtypes = [vp]
     lib.carmel_hip_comm_unique_id.argtypes = [vp]
+    lib.carmel_hip_compose.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp,
+                                       C.c_uint32, vp, C.c_uint32, C.c_uint32]
+    lib.carmel_hip_composition_states.argtypes = [vp]
+    lib.carmel_hip_composition_states.restype = C.c_uint64
+    lib.carmel_hip_composition_arcs.argtypes = [vp]
+    lib.carmel_hip_composition_arcs.restype = C.c_uint64
+    lib.carmel_hip_composition_seconds.argtypes = [vp]
+    lib.carmel_hip_composition_seconds.restype = C.c_double
+    lib.carmel_hip_composition_export.argtypes = [vp] * 11
+    lib.carmel_hip_composition_free.argtypes = [vp]
     lib.carmel_hip_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
     lib.carmel_hip_comm_destroy.argtypes = [vp]
     lib.carmel_hip_comm_rank.argtypes = [vp]

@@ -80,6 +80,7 @@ struct Options {
   long init_em = 0;          // --init-em=N, --em-p0 (carmel.cc:276-277; gibbs.cc:400-423)
   bool em_p0 = false;
   bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
+  bool gpu_compose = false;        // --gpu-compose: the product construction of the composition on the GPU (compose.hip)
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
@@ -154,6 +155,8 @@ static Options parse_args(int argc, char** argv) {
         o.em_p0 = true;
       else if (k == "init-from-p0")
         o.init_from_p0 = true;
+      else if (k == "gpu-compose")
+        o.gpu_compose = true;
       else if (k == "sample-prob-after")  // not a carmel option (its old builds logged this as "sample prob")
         o.sample_prob_after = true;
       else if (k == "crp-restarts")
@@ -347,7 +350,13 @@ static int run(int argc, char** argv) {
       A.bind(result, i > 1, params.member_base[0]);
       B.bind(&member[i], false, params.member_base[i]);
       std::unique_ptr<Transducer> next(new Transducer());
-      if (!(o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next) : comp.run(A, B, *next))) {  // carmel.cc:1318
+      double dev_s = 0;
+      const bool ok = o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next)  // carmel.cc:1318
+                      : o.gpu_compose        ? comp.run_device(A, B, *next, o.gpu + ((std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host") ? 0 : rank), &dev_s)
+                                             : comp.run(A, B, *next);
+      if (o.gpu_compose && !o.flags[(unsigned)'a'] && std::getenv("CARMEL_TIMING"))
+        std::cerr << "timing: composition on the GPU " << dev_s << " s\n";
+      if (!ok) {
         std::cerr << ")\nEmpty or invalid result of composition with transducer \"" << o.files[i + 1] << "\".\n";
         return -3;
       }

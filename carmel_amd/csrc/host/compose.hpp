@@ -19,6 +19,7 @@
 #pragma once
 #include <algorithm>
 #include <map>
+#include "../../../include/carmel_hip.h"
 #include "wfst.hpp"
 
 namespace carmel_host {
@@ -154,6 +155,93 @@ class Composer {
         for (size_t kb : eb->second) emit(j.id, 0, lb[kb].out, j.qa, lb[kb].dest, 1, lb[kb].logw, lone_chain(B, j.qb, kb));
     }
     return finish(out, ids, key(a.final_state, b.final_state, 0));
+  }
+
+  // The same composition with the product construction done on the GPU (carmel_hip_compose, csrc/compose.hip): the
+  // device expands every composite state in the reference's emission order and reports, per arc, which arc of A and / or
+  // of B it was built from; what is sequential by definition is done here, in one pass over that output -- composite
+  // states get the numbers the reference's LIFO work list would give them (compose.cc:193, 326-328) and chains are
+  // created in emission order (cascade.h:507-599).  The result is, arc for arc, that of run().
+  bool run_device(const Operand& A, const Operand& B, Transducer& out, int device, double* device_seconds = 0) {
+    const Transducer& a = *A.t;
+    const Transducer& b = *B.t;
+    out = Transducer();
+    out.in_syms = a.in_syms;
+    out.out_syms = b.out_syms;
+    out.named = false;
+    std::vector<uint32_t> a2b(a.out_syms.names.size(), kNoGroup), b2a(b.in_syms.names.size(), kNoGroup);
+    for (uint32_t i = 0; i < a2b.size(); ++i) b.in_syms.find(a.out_syms.names[i], a2b[i]);
+    for (uint32_t i = 0; i < b2a.size(); ++i) a.out_syms.find(b.in_syms.names[i], b2a[i]);
+    struct Flat {
+      std::vector<uint64_t> off;
+      std::vector<uint32_t> in, out, dst;
+      std::vector<double> lw;
+      explicit Flat(const Transducer& t) {
+        off.push_back(0);
+        for (auto& st : t.states) {
+          for (auto& x : st) {
+            in.push_back(x.in);
+            out.push_back(x.out);
+            dst.push_back(x.dest);
+            lw.push_back(x.logw);
+          }
+          off.push_back(in.size());
+        }
+        if (in.empty()) {  // keep the pointers valid
+          in.push_back(0);
+          out.push_back(0);
+          dst.push_back(0);
+          lw.push_back(0);
+        }
+      }
+    } fa(a), fb(b);
+    carmel_hip_composition* c = 0;
+    if (carmel_hip_compose(&c, device, (uint32_t)a.states.size(), fa.off.data(), fa.in.data(), fa.out.data(), fa.dst.data(),
+                           fa.lw.data(), (uint32_t)b.states.size(), fb.off.data(), fb.in.data(), fb.out.data(), fb.dst.data(),
+                           fb.lw.data(), a2b.data(), (uint32_t)a2b.size(), b2a.data(), (uint32_t)b2a.size(), T) != CARMEL_HIP_OK)
+      throw std::runtime_error(std::string("carmel_hip_compose: ") + carmel_hip_last_error());
+    const size_t ns = carmel_hip_composition_states(c), na = carmel_hip_composition_arcs(c);
+    if (device_seconds) *device_seconds = carmel_hip_composition_seconds(c);
+    std::vector<uint64_t> off(ns + 1);
+    std::vector<uint32_t> qa(ns), qb(ns), ain(na ? na : 1), aout(na ? na : 1), adst(na ? na : 1), aka(na ? na : 1), akb(na ? na : 1);
+    std::vector<uint8_t> fl(ns);
+    std::vector<double> alw(na ? na : 1);
+    const int rc = carmel_hip_composition_export(c, off.data(), qa.data(), qb.data(), fl.data(), ain.data(), aout.data(), adst.data(),
+                                                 alw.data(), aka.data(), akb.data());
+    carmel_hip_composition_free(c);
+    if (rc != CARMEL_HIP_OK) throw std::runtime_error(std::string("carmel_hip_composition_export: ") + carmel_hip_last_error());
+    std::vector<std::vector<HArc> >& S = out.states;
+    std::vector<uint32_t> id(ns, kNoGroup), work;
+    S.emplace_back();
+    id[0] = 0;
+    work.push_back(0);
+    while (!work.empty()) {
+      const uint32_t t = work.back();
+      work.pop_back();
+      const uint32_t cur = id[t];
+      for (uint64_t e = off[t]; e < off[t + 1]; ++e) {
+        const uint32_t d = adst[e];
+        if (id[d] == kNoGroup) {
+          id[d] = (uint32_t)S.size();
+          S.emplace_back();
+          work.push_back(d);
+        }
+        HArc x;
+        x.in = ain[e];
+        x.out = aout[e];
+        x.dest = id[d];
+        x.logw = alw[e];
+        x.group = aka[e] != kNoGroup && akb[e] != kNoGroup ? pair_chain(A, qa[t], aka[e], B, qb[t], akb[e])
+                  : aka[e] != kNoGroup                       ? lone_chain(A, qa[t], aka[e])
+                                                             : lone_chain(B, qb[t], akb[e]);
+        S[cur].push_back(x);
+      }
+    }
+    auto key = [&](uint32_t x, uint32_t y, int f) { return ((uint64_t)x * b.states.size() + y) * 3 + (uint64_t)f; };
+    std::unordered_map<uint64_t, uint32_t> finals;
+    for (size_t t = 0; t < ns; ++t)
+      if (qa[t] == a.final_state && qb[t] == b.final_state && id[t] != kNoGroup) finals.emplace(key(qa[t], qb[t], fl[t]), id[t]);
+    return finish(out, finals, key(a.final_state, b.final_state, 0));
   }
 
   // returns false when the composition is empty (no final reachable)

@@ -292,6 +292,31 @@ int carmel_hip_forests_set_alphas(carmel_hip_forests* f, const double* alpha_per
 int carmel_hip_forests_get_sample(carmel_hip_forests* f, uint64_t forest, uint32_t* rules, uint32_t* n);
 uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* f);
 
+/* ---- composition on the GPU ----
+ * Replaces: the product construction of WFST::set_compose with the default 3-state epsilon filter (compose.cc:163-498):
+ * composite states (qa, qb, filter), each expanded in the reference's own emission order (which of its three code paths
+ * runs depends on the operand states' sizes and carmel -T = index_threshold, compose.cc:330-498), arc weight wa * wb.
+ * Operands are CSR (a_off[q] .. a_off[q + 1] are state q's arcs in list order, state 0 the start), a2b / b2a map A's
+ * output symbol ids to B's input symbol ids and back (0xffffffff: no such symbol).  The result lists the composite
+ * states in DISCOVERY order of the device's frontier expansion (state 0 = (0, 0, 0)) with their arcs in emission order;
+ * arc_dst are those temporary state ids, arc_ka / arc_kb the position (within its state) of the A / B arc the composed
+ * arc was built from (0xffffffff: none) -- what cascade_parameters::record / record1 / record2 are given
+ * (cascade.h:507-599).  The reference's state NUMBERING (LIFO work list, compose.cc:193, 326-328) and chain ids are
+ * sequential definitions: host/compose.hpp derives them from this output in one pass (Composer::run_device). */
+typedef struct carmel_hip_composition carmel_hip_composition;
+int carmel_hip_compose(carmel_hip_composition** out, int device, uint32_t a_states, const uint64_t* a_off, const uint32_t* a_in,
+                       const uint32_t* a_out, const uint32_t* a_dst, const double* a_logw, uint32_t b_states,
+                       const uint64_t* b_off, const uint32_t* b_in, const uint32_t* b_out, const uint32_t* b_dst,
+                       const double* b_logw, const uint32_t* a2b, uint32_t n_a2b, const uint32_t* b2a, uint32_t n_b2a,
+                       uint32_t index_threshold);
+uint64_t carmel_hip_composition_states(carmel_hip_composition* c);
+uint64_t carmel_hip_composition_arcs(carmel_hip_composition* c);
+double carmel_hip_composition_seconds(carmel_hip_composition* c);
+int carmel_hip_composition_export(carmel_hip_composition* c, uint64_t* state_off, uint32_t* state_qa, uint32_t* state_qb,
+                                  uint8_t* state_filter, uint32_t* arc_in, uint32_t* arc_out, uint32_t* arc_dst,
+                                  double* arc_logw, uint32_t* arc_ka, uint32_t* arc_kb);
+int carmel_hip_composition_free(carmel_hip_composition* c);
+
 /* ---- host-only inspection (no GPU needed): the lattice image carmel_hip_build_lattices uploads ----
  * Used by the CPU test-suite to check lattice construction and layout against the oracle. */
 typedef struct carmel_hip_host_lattices carmel_hip_host_lattices;
