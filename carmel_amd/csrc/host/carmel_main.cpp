@@ -80,6 +80,7 @@ struct Options {
   long init_em = 0;          // --init-em=N, --em-p0 (carmel.cc:276-277; gibbs.cc:400-423)
   bool em_p0 = false;
   bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
+  bool cache_no_prune = false;     // --cache-no-prune
   bool gpu_compose = false;        // --gpu-compose: the product construction of the composition on the GPU (compose.hip)
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
@@ -157,6 +158,12 @@ static Options parse_args(int argc, char** argv) {
         o.init_from_p0 = true;
       else if (k == "gpu-compose")
         o.gpu_compose = true;
+      else if (k == "disk-cache-derivations" || k == "disk-cache-bufsize") {
+        // carmel.cc:243-246, fst.h:1057-1076: where the reference keeps cached derivations when they outgrow memory.  Here
+        // they are built once and live in HBM (288 GB per GPU); the option changes nothing about the results
+        std::cerr << "option " << k << " = " << v << ": derivations are cached in GPU memory, no disk cache is created\n";
+      } else if (k == "cache-no-prune")  // carmel.cc:241: keep states that cannot reach the goal in the cached lattices
+        o.cache_no_prune = true;
       else if (k == "sample-prob-after")  // not a carmel option (its old builds logged this as "sample prob")
         o.sample_prob_after = true;
       else if (k == "crp-restarts")
@@ -582,7 +589,7 @@ static int run(int argc, char** argv) {
   auto train_em = [&](const Options& o) {
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
-  hip_check(carmel_hip_build_lattices(t, 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+  hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
   if (std::getenv("CARMEL_TIMING"))
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (ls.n_bundles ? "explicit" : "unrolled") << " device_bytes=" << ls.device_bytes

@@ -86,6 +86,7 @@ class Composer {
     const Transducer& a = *A.t;
     const Transducer& b = *B.t;
     out = Transducer();
+    if (a.states.empty() || b.states.empty()) return false;  // an operand without states: !valid() (compose.cc:176-179)
     out.in_syms = a.in_syms;
     out.out_syms = b.out_syms;
     out.named = false;
@@ -166,6 +167,7 @@ class Composer {
     const Transducer& a = *A.t;
     const Transducer& b = *B.t;
     out = Transducer();
+    if (a.states.empty() || b.states.empty()) return false;
     out.in_syms = a.in_syms;
     out.out_syms = b.out_syms;
     out.named = false;
@@ -249,6 +251,7 @@ class Composer {
     const Transducer& a = *A.t;
     const Transducer& b = *B.t;
     out = Transducer();
+    if (a.states.empty() || b.states.empty()) return false;
     out.in_syms = a.in_syms;
     out.out_syms = b.out_syms;
     out.named = false;

@@ -602,3 +602,21 @@ def test_crp_tagging_against_the_recorded_run(golden_dir, tmp_path):
     assert got[1] < got[10] < got[50] < level + 300
     for name in ("tagging.fsa", "tagging.fst"):
         assert os.path.getsize(os.path.join(str(tmp_path), name + ".trained")) > 1000
+
+
+def test_cache_options_change_nothing_about_the_results(golden_dir):
+    """-? / -: / --disk-cache-derivations / --cache-no-prune (carmel.cc:235-251) only say where and how derivations are
+    cached; here they always live in GPU memory.  Unpruned lattices keep dead-end states (their backward weight is 0), so
+    the training run is the same; with -? the reference's derivation statistics are logged (cached_derivs.h:137)."""
+    g = lambda n: os.path.join(golden_dir, n)
+    base = ["-t", "-M", "4", g("epron-jpron.data"), g("epron-jpron.fst")]
+    rc, out0, err0 = run(base)
+    assert rc == 0, err0
+    for extra in (["-?"], ["-:"], ["--disk-cache-derivations=/tmp/x.XXXXXX", "--disk-cache-bufsize=1M"], ["--cache-no-prune", "-?"]):
+        rc, out, err = run(extra + base)
+        assert rc == 0, err
+        assert out == out0
+        assert [l for l in err.split("\n") if l.startswith("i=")] == [l for l in err0.split("\n") if l.startswith("i=")]
+        if "-?" in extra:
+            assert "Pre pruning: (" in err and "Post pruning: (" in err
+    assert "Pre pruning" not in err0

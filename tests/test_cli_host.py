@@ -98,7 +98,8 @@ def test_composition_of_random_transducers(oracle, tmp_path, seed, dash_a):
     try:
         oc = oracle.OracleCascade([a, b], remember=False, dash_a=dash_a)
     except RuntimeError:
-        assert rc != 0  # empty composition: both say so
+        # both say so: an unusable transducer file (-2, carmel.cc:1213) or an empty composition (-3, carmel.cc:1336-1341)
+        assert (rc == 256 - 3 and "Empty or invalid result of composition" in err) or (rc == 256 - 2 and "Bad format" in err)
         return
     assert rc == 0, err
     assert out == oc.composed().write(full=True, onearc=True), (a, b)

@@ -62,8 +62,9 @@ def test_three_members_and_training(golden_dir, tmp_path):
     the device composition: the same iterations, the same trained members"""
     g = lambda n: os.path.join(golden_dir, n)
     ident = tmp_path / "ident.fst"
-    ident.write_text("0\n" + "".join('(0 (0 "%s" "%s" 0.9))\n(0 (0 "%s" "%s" 0.1))\n' % (c, c, c, d)
-                                      for c, d in zip("abcdefghij", "bcdefghija")))
+    syms = sorted(set(re.findall(r'"([^"]+)"\)\)', open(g("cipher.fst")).read())))  # the channel's output alphabet
+    ident.write_text("0\n" + "".join('(0 (0 "%s" "%s" 0.9))\n(0 (0 "%s" "%s" 0.1))\n' % (c, c, d, c)
+                                      for c, d in zip(syms, syms[1:] + syms[:1])))  # a noisy copy: every symbol is mostly itself
     outs = []
     for extra in ([], ["--gpu-compose"]):
         d = tmp_path / ("o%d" % len(outs))
