@@ -31,6 +31,7 @@ SYMBOLS = [
     "carmel_hip_forests_max_sample",
     "carmel_hip_compose", "carmel_hip_composition_states", "carmel_hip_composition_arcs", "carmel_hip_composition_seconds",
     "carmel_hip_composition_export", "carmel_hip_composition_free",
+    "carmel_hip_debug_lattice_fingerprint",
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
 ]
@@ -75,6 +76,7 @@ def _load():
     lib.carmel_hip_random_restart.argtypes = [vp, C.c_uint64, C.c_uint32]
     lib.carmel_hip_keep_em_weights.argtypes = [vp]
     lib.carmel_hip_comm_unique_id.argtypes = [vp]
+    lib.carmel_hip_debug_lattice_fingerprint.argtypes = [vp, vp]
     lib.carmel_hip_compose.argtypes = [C.POINTER(vp), C.c_int, C.c_uint32, vp, vp, vp, vp, vp, C.c_uint32, vp, vp, vp, vp, vp, vp,
                                        C.c_uint32, vp, C.c_uint32, C.c_uint32]
     lib.carmel_hip_composition_states.argtypes = [vp]

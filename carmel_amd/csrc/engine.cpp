@@ -15,6 +15,9 @@
 #include "unrolled_args.hpp"
 
 int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats);
+int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* has_derivation, carmel_hip_lattice_stats* stats,
+                       bool& done);
+int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out);
 int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -173,8 +176,24 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
   if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));
+  {
+    // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;
+    // otherwise -- or with CARMEL_HIP_GPU_BUILD=0 -- the host builder below does the whole corpus
+    const bool want_gpu = !(getenv("CARMEL_HIP_GPU_BUILD") && atoi(getenv("CARMEL_HIP_GPU_BUILD")) == 0) &&
+                          !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    if (want_gpu) {
+      bool done = false;
+      int rc = gpu_build_lattices(t, opt, has_derivation, stats, done);
+      if (rc) return rc;
+      if (done) {
+        if (getenv("CARMEL_TIMING")) fprintf(stderr, "timing: lattices built on the GPU\n");
+        return CARMEL_HIP_OK;
+      }
+    }
+  }
   std::string err;
   LatticeSet& L = t->lat;
+  L = LatticeSet();
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
   if (has_derivation) std::memcpy(has_derivation, L.has_deriv.data(), L.has_deriv.size());
   hipStream_t s = t->stream;
@@ -997,6 +1016,13 @@ int carmel_hip_set_digamma(carmel_hip_trainer* t, uint32_t n_members, const doub
     t->tie_alpha.release();
   }
   return CARMEL_HIP_OK;
+}
+
+int carmel_hip_debug_lattice_fingerprint(carmel_hip_trainer* t, uint64_t* out16) {
+  if (!t || !out16) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
+  HIPCHK(hipSetDevice(t->device));
+  return carmel_hip_debug_lattice_fingerprint_impl(t, out16);
 }
 
 int carmel_hip_random_restart(carmel_hip_trainer* t, uint64_t seed, uint32_t restart) {

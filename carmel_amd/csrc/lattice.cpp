@@ -56,6 +56,81 @@ void HostWfst::build_index() {
   }
 }
 
+// Given out.lane_groups with maxlen / max_states / n_lanes / pair_base filled in: the launch classes (by LDS need), their
+// pieces, and every group's stream_base.  Returns the number of records of the lane streams (padding included).
+uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt) {
+  const size_t ng = out.lane_groups.size();
+  out.lane_classes.clear();
+  // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
+  std::vector<LatticeSet::LaneClass> classes;
+  {
+    size_t i = 0;
+    while (i < ng) {
+      uint32_t mx = out.lane_groups[i].max_states;
+      size_t j = i + 1;
+      while (j < ng) {
+        uint32_t m = out.lane_groups[j].max_states;
+        if (m > mx) mx = m;
+        // a class costs a launch (ramp-up + tail); it only pays when the LDS saved buys occupancy that matters:
+        // below ~20 KB per wave (8 waves per CU) the sweep is already bound by the random-gather rate
+        static const uint32_t min_split = getenv("CARMEL_HIP_LANE_SPLIT_STATES") ? (uint32_t)atoi(getenv("CARMEL_HIP_LANE_SPLIT_STATES")) : 48u;
+        if (j - i >= 256 && mx > min_split && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
+        ++j;
+      }
+      LatticeSet::LaneClass lc;
+      lc.first = (uint32_t)i;
+      lc.count = (uint32_t)(j - i);
+      lc.max_states = mx;
+      classes.push_back(lc);
+      i = j;
+    }
+  }
+  // pieces: every class is cut into lane_chunks pieces of about equal record count.  When there is more than one
+  // piece (several classes, or chunks), each piece's stream starts on a tile boundary of the blocked transposition, so
+  // that the tile passes can be launched per piece and the pieces can run side by side
+  uint64_t base = 0;
+  const uint32_t want_chunks = std::max<uint32_t>(1, opt.lane_chunks);
+  std::vector<uint32_t> nchs;
+  size_t n_pieces = 0;
+  for (const auto& lc : classes) {
+    uint64_t rows = 0;
+    for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
+    // no chunk smaller than 16 tiles' worth of records: a launch has to fill the chip
+    nchs.push_back((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE))));
+    n_pieces += nchs.back();
+  }
+  const bool align = n_pieces > 1;
+  out.lane_tiles_aligned = align;
+  for (size_t ci = 0; ci < classes.size(); ++ci) {
+    const auto& lc = classes[ci];
+    uint64_t rows = 0;
+    for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
+    const uint32_t nch = nchs[ci];
+    uint32_t g = lc.first;
+    uint64_t done = 0;
+    for (uint32_t k = 0; k < nch; ++k) {
+      const uint64_t goal = rows * (k + 1) / nch;
+      LatticeSet::LaneClass piece = lc;
+      piece.first = g;
+      if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
+      piece.tile_first = (uint32_t)(base / TRANS_TILE);
+      while (g < lc.first + lc.count && (done < goal || k + 1 == nch)) {
+        LaneGroup& G = out.lane_groups[g];
+        G.stream_base = base;
+        base += (uint64_t)G.maxlen * 64;
+        done += G.maxlen;
+        ++g;
+      }
+      piece.count = g - piece.first;
+      piece.max_states = lc.max_states;  // one LDS size per class keeps the occupancy of its pieces equal
+      piece.tile_count = (uint32_t)((base + TRANS_TILE - 1) / TRANS_TILE) - piece.tile_first;
+      if (piece.count) out.lane_classes.push_back(piece);
+    }
+  }
+  if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
+  return base;
+}
+
 namespace {
 
 // open-addressing map (i, s, o) -> lattice state id, reused across pairs by one thread
@@ -543,73 +618,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       G.maxlen = (std::max<uint32_t>(ml, 1) + LANE_CHUNK - 1) / LANE_CHUNK * LANE_CHUNK;
       G.max_states = ms;
     }
-    // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
-    std::vector<LatticeSet::LaneClass> classes;
-    {
-      size_t i = 0;
-      while (i < ng) {
-        uint32_t mx = out.lane_groups[i].max_states;
-        size_t j = i + 1;
-        while (j < ng) {
-          uint32_t m = out.lane_groups[j].max_states;
-          if (m > mx) mx = m;
-          // a class costs a launch (ramp-up + tail); it only pays when the LDS saved buys occupancy that matters:
-          // below ~20 KB per wave (8 waves per CU) the sweep is already bound by the random-gather rate
-          static const uint32_t min_split = getenv("CARMEL_HIP_LANE_SPLIT_STATES") ? (uint32_t)atoi(getenv("CARMEL_HIP_LANE_SPLIT_STATES")) : 48u;
-          if (j - i >= 256 && mx > min_split && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
-          ++j;
-        }
-        LatticeSet::LaneClass lc;
-        lc.first = (uint32_t)i;
-        lc.count = (uint32_t)(j - i);
-        lc.max_states = mx;
-        classes.push_back(lc);
-        i = j;
-      }
-    }
-    // pieces: every class is cut into lane_chunks pieces of about equal record count.  When there is more than one
-    // piece (several classes, or chunks), each piece's stream starts on a tile boundary of the blocked transposition, so
-    // that the tile passes can be launched per piece and the pieces can run side by side
-    uint64_t base = 0;
-    const uint32_t want_chunks = std::max<uint32_t>(1, opt.lane_chunks);
-    std::vector<uint32_t> nchs;
-    size_t n_pieces = 0;
-    for (const auto& lc : classes) {
-      uint64_t rows = 0;
-      for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
-      // no chunk smaller than 16 tiles' worth of records: a launch has to fill the chip
-      nchs.push_back((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE))));
-      n_pieces += nchs.back();
-    }
-    const bool align = n_pieces > 1;
-    out.lane_tiles_aligned = align;
-    for (size_t ci = 0; ci < classes.size(); ++ci) {
-      const auto& lc = classes[ci];
-      uint64_t rows = 0;
-      for (uint32_t g = lc.first; g < lc.first + lc.count; ++g) rows += out.lane_groups[g].maxlen;
-      const uint32_t nch = nchs[ci];
-      uint32_t g = lc.first;
-      uint64_t done = 0;
-      for (uint32_t k = 0; k < nch; ++k) {
-        const uint64_t goal = rows * (k + 1) / nch;
-        LatticeSet::LaneClass piece = lc;
-        piece.first = g;
-        if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
-        piece.tile_first = (uint32_t)(base / TRANS_TILE);
-        while (g < lc.first + lc.count && (done < goal || k + 1 == nch)) {
-          LaneGroup& G = out.lane_groups[g];
-          G.stream_base = base;
-          base += (uint64_t)G.maxlen * 64;
-          done += G.maxlen;
-          ++g;
-        }
-        piece.count = g - piece.first;
-        piece.max_states = lc.max_states;  // one LDS size per class keeps the occupancy of its pieces equal
-        piece.tile_count = (uint32_t)((base + TRANS_TILE - 1) / TRANS_TILE) - piece.tile_first;
-        if (piece.count) out.lane_classes.push_back(piece);
-      }
-    }
-    if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
+    const uint64_t base = assign_lane_classes(out, opt);
     out.lane_fwd.assign(base, uint2_t{0, 0});
     out.lane_bwd.assign(base, uint2_t{0, 0});
     std::atomic<size_t> nextg(0);

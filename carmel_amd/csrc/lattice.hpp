@@ -178,6 +178,9 @@ struct BuildOptions {
 // Builds every pair's lattice (parallel over pairs) and packs them.  Returns false + err on failure.
 bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& opt, LatticeSet& out, std::string& err);
 
+// launch classes, pieces and stream bases of the lane groups (shared by the host builder and the GPU builder)
+uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt);
+
 // single pair (exposed for tests)
 void build_pair_lattice(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out, uint32_t n_out,
                         bool prune, PairLattice& lat, bool& has_deriv);

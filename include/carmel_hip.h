@@ -82,6 +82,11 @@ typedef struct carmel_hip_lattice_stats {
 int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads, uint8_t* has_derivation,
                               carmel_hip_lattice_stats* stats);
 
+/* Test hook: 16 checksums of the lattice image in device memory (lane groups and record streams, transposition tables,
+ * pair weights) -- the GPU lattice builder (csrc/lattice_gpu.hip; CARMEL_HIP_GPU_BUILD=0 switches it off) must leave
+ * the very bytes the host builder leaves. */
+int carmel_hip_debug_lattice_fingerprint(carmel_hip_trainer* t, uint64_t* out16);
+
 /* Replaces: WFST::NormalizeMethod for a single (non-cascade) transducer — carmel -n/-j/-u and --priors
  * (carmel.cc:488-499); used by carmel_hip_maximize / carmel_hip_normalize. */
 int carmel_hip_set_norm(carmel_hip_trainer* t, int norm_group_by, double add_count);

@@ -1,0 +1,86 @@
+"""GPU: derivation-lattice construction on the device (csrc/lattice_gpu.hip) against the host builder: the two must
+leave the SAME image in device memory -- lane groups, record streams, posterior slots, transposition tables, checked
+through checksums of every array -- and therefore the same has_derivation flags, statistics and expected counts, bit for
+bit.  Corpora with a lattice the device builder does not take (a cycle, more than 96 states) go to the host builder."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from carmel_amd import synth
+from carmel_amd.model import Corpus, Wfst
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(w, c, gpu):
+    from carmel_amd._capi import check, lib, ptr
+    from carmel_amd.trainer import HipForwardBackward
+    os.environ["CARMEL_HIP_GPU_BUILD"] = "1" if gpu else "0"
+    try:
+        fb = HipForwardBackward(w, c)
+    finally:
+        del os.environ["CARMEL_HIP_GPU_BUILD"]
+    fp = np.zeros(16, np.uint64)
+    check(lib.carmel_hip_debug_lattice_fingerprint(fb.h, ptr(fp)), "fingerprint")
+    ls = fb.lattice_stats
+    stats = tuple(int(getattr(ls, n)) for n in ("n_pairs", "n_pairs_kept", "explored_states", "explored_arcs", "kept_states",
+                                                 "kept_arcs", "last_pair_explored_states", "last_pair_kept_states",
+                                                 "last_pair_kept_arcs"))
+    lp, wlp = fb.estimate(per_pair=True)
+    res = dict(fp=fp, stats=stats, has=fb.has_deriv.copy(), counts=fb.counts(), pair_lp=fb.pair_logprob.copy(), lp=lp,
+               seconds=ls.build_seconds)
+    fb.maximize(1.0)
+    res["w1"] = fb.weights()
+    fb.close()
+    return res
+
+
+def _same(a, b):
+    assert a["stats"] == b["stats"]
+    assert np.array_equal(a["has"], b["has"])
+    assert np.array_equal(a["fp"], b["fp"]), (a["fp"], b["fp"])
+    assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["pair_lp"], b["pair_lp"]) and a["lp"] == b["lp"]
+    assert np.array_equal(a["w1"], b["w1"])
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(n_sym=3, deg=10, n_states=30)), (3, dict(n_sym=64, deg=20, n_states=500, lo=5, hi=40)),
+                                     (4, dict(n_sym=2, deg=6, n_states=12, hi=9, n_pairs=80)), (5, dict(n_sym=6, deg=12, n_states=2000, n_pairs=3000, hi=16))])
+def test_small_corpora(seed, kw):
+    from test_gpu_parity import ambiguous
+    w, c = ambiguous(seed, **kw)
+    rng = np.random.default_rng(seed)
+    c.weight[:] = rng.uniform(0.5, 3.0, c.n_pairs)
+    # a few pairs that have no derivation, an empty pair, a one-sided pair
+    extra = Corpus.from_lists([([2, 3, 2], [3]), ([], []), ([2], []), ([3, 3, 3, 3, 3, 3, 3, 3], [2, 2])], np.array([1.0, 2.0, 0.5, 1.5]))
+    c = Corpus(np.concatenate([c.in_off, c.in_off[-1] + extra.in_off[1:]]), np.concatenate([c.in_sym, extra.in_sym]),
+               np.concatenate([c.out_off, c.out_off[-1] + extra.out_off[1:]]), np.concatenate([c.out_sym, extra.out_sym]),
+               np.concatenate([c.weight, extra.weight]))
+    _same(_build(w, c, False), _build(w, c, True))
+
+
+def test_config2_and_a_slice_of_config4():
+    for name, n in (("c2", None), ("c4", 200000)):
+        w, c = synth.make_config(name, n_pairs=n)
+        host, dev = _build(w, c, False), _build(w, c, True)
+        _same(host, dev)
+        assert dev["seconds"] < host["seconds"]
+
+
+def test_corpora_outside_its_scope_go_to_the_host_builder(oracle):
+    """a cyclic lattice, and lattices wider than the one-per-lane layout: CARMEL_HIP_GPU_BUILD=1 must give what the host
+    builder gives (it IS the host builder then)"""
+    # *e*:*e* loop -> cyclic derivation lattices (derivations.h:726-728)
+    src = np.array([0, 0, 1, 1], np.uint32)
+    dst = np.array([1, 2, 0, 2], np.uint32)
+    isym = np.array([0, 2, 0, 3], np.uint32)
+    osym = np.array([0, 2, 0, 3], np.uint32)
+    w = Wfst(3, 2, src, dst, isym, osym, np.log([0.5, 0.5, 0.4, 0.6]))
+    c = Corpus.from_lists([([2], [2]), ([3], [3])])
+    _same(_build(w, c, False), _build(w, c, True))
+    w, c = synth.random_wfst(200, 8, n_sym=4, p_eps=0.1, seed=5), None
+    c = synth.random_walk_corpus(w, 300, min_arcs=5, max_arcs=16, seed=5, out_degree=8)  # hundreds of states per lattice
+    a, b = _build(w, c, False), _build(w, c, True)
+    _same(a, b)
+    assert a["stats"][4] / a["stats"][1] > 96
