@@ -79,8 +79,8 @@ def test_corpora_outside_its_scope_go_to_the_host_builder(oracle):
     w = Wfst(3, 2, src, dst, isym, osym, np.log([0.5, 0.5, 0.4, 0.6]))
     c = Corpus.from_lists([([2], [2]), ([3], [3])])
     _same(_build(w, c, False), _build(w, c, True))
-    w, c = synth.random_wfst(200, 8, n_sym=4, p_eps=0.1, seed=5), None
-    c = synth.random_walk_corpus(w, 300, min_arcs=5, max_arcs=16, seed=5, out_degree=8)  # hundreds of states per lattice
+    w = synth.random_wfst(20000, 12, n_sym=4, p_eps=0.1, seed=5)
+    c = synth.random_walk_corpus(w, 100, min_arcs=5, max_arcs=16, seed=5, out_degree=12)  # thousands of states per lattice
     a, b = _build(w, c, False), _build(w, c, True)
     _same(a, b)
     assert a["stats"][4] / a["stats"][1] > 96
