@@ -45,11 +45,19 @@ def pmc_traffic(config, walk_arcs, n_pairs):
     MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies each 128-byte request at 64 B, so it is doubled (calibrated here on
     known byte counts, profiles/r1_pmc_calibration.txt: streaming reads of 4/8/16 B per lane all report exactly half;
     WRITE_SIZE is exact).  None when no profile of this workload is committed."""
+    import hashlib
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_%s.json" % config)
     if not os.path.exists(path) or walk_arcs != "5,40":
         return None
     d = json.load(open(path))
     if d.get("pairs_per_gpu") != n_pairs:
+        return None
+    # the counters belong to one build of the kernels: after any change to kernels.hip, or under an A/B library or a
+    # CARMEL_HIP_* switch, the committed figure says nothing about this run
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "carmel_amd", "csrc", "kernels.hip")
+    if d.get("kernels_hip_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+        return None
+    if os.environ.get("CARMEL_HIP_LIB") or any(k.startswith("CARMEL_HIP_") for k in os.environ):
         return None
     tot = 0.0
     for name, k in d["kernels"].items():
@@ -370,6 +378,9 @@ def main():
                          "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args.config, args.walk_arcs, c.n_pairs),
+                         "traffic_source": "profiles/pmc_traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                           "command (tools/pmc_traffic.sh), committed; null when kernels.hip changed since, the "
+                                           "workload differs or a CARMEL_HIP_* switch is set -- not measured by this run" % args.config,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }
         if not args.no_cpu_baseline:

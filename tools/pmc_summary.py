@@ -38,6 +38,11 @@ def main():
         meta.update({"pairs_per_gpu": pairs, "estep_count": max(sweeps),
                      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config %s "
                                 "--steps 3 --warmup 1 --no-cpu-baseline  [tools/pmc_traffic.sh]" % cfg})
+    # which build of the kernels these counters belong to: bench.py reports them only for the same sources
+    import hashlib
+    import os
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carmel_amd", "csrc", "kernels.hip")
+    meta["kernels_hip_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
     meta["kernels"] = kernels
     print(json.dumps(meta, indent=1))
 
