@@ -18,6 +18,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
 int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* has_derivation, carmel_hip_lattice_stats* stats,
                        bool& done);
 int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out);
+int build_run_tables(carmel_hip_trainer* t);
 int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -187,7 +188,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       if (rc) return rc;
       if (done) {
         if (getenv("CARMEL_TIMING")) fprintf(stderr, "timing: lattices built on the GPU\n");
-        return CARMEL_HIP_OK;
+        return build_run_tables(t);
       }
     }
   }
@@ -306,6 +307,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   }
   t->have_lattices = true;
   ++t->lattice_epoch;
+  {
+    int rc = build_run_tables(t);
+    if (rc) return rc;
+  }
   if (stats) {
     stats->n_pairs = t->corpus.n_pairs;
     stats->n_pairs_kept = L.n_kept;
@@ -700,6 +705,13 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   T.t_pos = t->t_t_pos.p;
   T.t_src = t->t_t_src.p;
   T.a_off = t->t_a_off.p;
+  T.tr_off = t->tr_off.p;
+  T.tr_rel = t->tr_rel.p;
+  T.tr_src = t->tr_src.p;
+  T.br_off = t->br_off.p;
+  T.br_rel = t->br_rel.p;
+  T.br_src = t->br_src.p;
+  T.use_runs = t->use_runs ? 1u : 0u;
   T.x = t->t_x.p;
   T.xc = t->t_xc.p;
   T.logw = t->arc_logw.p;

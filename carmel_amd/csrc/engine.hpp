@@ -109,6 +109,9 @@ struct carmel_hip_trainer {
   DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos, t_a_off;
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
   DevBuf<double> t_x, t_xc;
+  DevBuf<uint32_t> tr_off, tr_src, br_off, br_src;  // run-length form of t_t_src / t_b_src (TransArgs)
+  DevBuf<uint16_t> tr_rel, br_rel;
+  bool use_runs = false;
   DevBuf<unsigned long long> max_partial;  // M-step scratch
   uint32_t norm_span = 0;                  // max over norm groups of (last member - first member); 0 = unknown / too wide
   bool all_grouped = true;                 // every parameter is in a norm group

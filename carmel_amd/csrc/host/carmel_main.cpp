@@ -162,6 +162,13 @@ static Options parse_args(int argc, char** argv) {
         // carmel.cc:243-246, fst.h:1057-1076: where the reference keeps cached derivations when they outgrow memory.  Here
         // they are built once and live in HBM (288 GB per GPU); the option changes nothing about the results
         std::cerr << "option " << k << " = " << v << ": derivations are cached in GPU memory, no disk cache is created\n";
+      } else if (k == "matrix-fb") {
+        // carmel.cc:238, train.cc:254-266, 698-860: the legacy dense forward/backward over an (input position x output
+        // position x state) matrix.  It sums over the same derivations as the sparse lattices (train.cc:726-744 visits the
+        // same label classes; e_forward_topo orders the *e*:*e* arcs), so for transducers without *e*:*e* cycles the
+        // counts are the same numbers; this build always sweeps lattices
+        std::cerr << "option matrix-fb: the dense matrix is not used; derivation lattices give the same sums"
+                     " (transducers with *e*:*e* cycles: both drop some cyclic paths, not necessarily the same ones)\n";
       } else if (k == "cache-no-prune")  // carmel.cc:241: keep states that cannot reach the goal in the cached lattices
         o.cache_no_prune = true;
       else if (k == "sample-prob-after")  // not a carmel option (its old builds logged this as "sample prob")

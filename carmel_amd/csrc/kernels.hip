@@ -794,6 +794,15 @@ __device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
   const uint32_t per = (n + 7) / 8;
   return (b & 7u) * per + (b >> 3);
 }
+// source index of item i of a tile / bucket from its run table staged in LDS (nr runs: rel ascending, rel[0] == 0)
+__device__ __forceinline__ uint32_t run_source(const uint16_t* rel, const uint32_t* src, uint32_t nr, uint32_t i) {
+  uint32_t lo = 0, hi = nr - 1;
+  while (lo < hi) {
+    const uint32_t m = (lo + hi + 1) >> 1;
+    if (rel[m] <= i) lo = m; else hi = m - 1;
+  }
+  return src[lo] + (i - rel[lo]);
+}
 // weights, pass 1: one workgroup per arc bucket.  The bucket's weights go to LDS (coalesced read), its items leave in
 // position-sorted order (coalesced write), picking their weight out of LDS.
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
@@ -824,8 +833,11 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
 }
 // weights, pass 2: one workgroup per tile of positions.  The tile's items arrive as runs (one per bucket), are placed
 // in LDS at their position and the tile is written to wcache in one coalesced sweep.
+template <bool RL>
 __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  uint16_t* r_rel = (uint16_t*)(lds + TRANS_TILE);
+  uint32_t* r_src = (uint32_t*)(r_rel + TRANS_RUN_CAP);
   const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
   if (tloc >= T.tile_count) return;
   const uint32_t tile = T.tile_first + tloc;
@@ -834,6 +846,15 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
 #pragma unroll
   for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = 0.0;
+  uint32_t nr = 0;
+  if (RL) {
+    const uint32_t r0 = T.tr_off[tile];
+    nr = T.tr_off[tile + 1] - r0;
+    for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
+      r_rel[r] = T.tr_rel[r0 + r];
+      r_src[r] = T.tr_src[r0 + r];
+    }
+  }
   __syncthreads();
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
@@ -843,7 +864,10 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
 #pragma unroll
   for (int k = 0; k < TRANS_K; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
-    src[k] = i < ni ? T.t_src[i0 + i] : 0u;
+    if (RL)
+      src[k] = i < ni ? run_source(r_rel, r_src, nr, i) : 0u;
+    else
+      src[k] = i < ni ? T.t_src[i0 + i] : 0u;
     pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
   }
 #pragma unroll
@@ -886,8 +910,11 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
 // then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
 // that is a piece of a split arc reduces the piece and adds it atomically.
+template <bool RL>
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  uint16_t* r_rel = (uint16_t*)(lds + TRANS_BUCKET);
+  uint32_t* r_src = (uint32_t*)(r_rel + TRANS_RUN_CAP);
   __shared__ double part[16];
   __shared__ uint32_t big[512];
   __shared__ uint32_t n_big;
@@ -909,10 +936,23 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     uint32_t src[TRANS_K];
     uint16_t rk[TRANS_K];
     double v[TRANS_K];
+    uint32_t nr = 0;
+    if (RL) {
+      const uint32_t r0 = T.br_off[bucket];
+      nr = T.br_off[bucket + 1] - r0;
+      for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
+        r_rel[r] = T.br_rel[r0 + r];
+        r_src[r] = T.br_src[r0 + r];
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int k = 0; k < TRANS_K; ++k) {
       const uint32_t j = threadIdx.x + k * 1024;
-      src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
+      if (RL)
+        src[k] = j < B.n_items ? run_source(r_rel, r_src, nr, j) : 0u;
+      else
+        src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
@@ -1042,10 +1082,13 @@ static void trans_lds_attr() {
   static bool done = false;
   if (done) return;
   const int lds = (int)(TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) * 8;
+  const int lds_rl = lds + TRANS_RUN_CAP * 6;
   (void)hipFuncSetAttribute((const void*)trans_w_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
   (void)hipFuncSetAttribute((const void*)trans_c_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
   done = true;
 }
 hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream) {
@@ -1060,7 +1103,10 @@ hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   TransArgs T = T0;
   T.tile_first = tile_first;
   T.tile_count = tile_count;
-  hipLaunchKernelGGL(trans_w_tile_kernel, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
+  if (T.use_runs)
+    hipLaunchKernelGGL(trans_w_tile_kernel<true>, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
+  else
+    hipLaunchKernelGGL(trans_w_tile_kernel<false>, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32_t tile_count, hipStream_t stream) {
@@ -1076,7 +1122,10 @@ hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs,
   trans_lds_attr();
   if (!T.n_buckets) return hipSuccess;
   if (n_split) hipLaunchKernelGGL(zero_list_kernel, dim3((n_split + 255) / 256), dim3(256), 0, stream, T.counts, split_arcs, n_split);
-  hipLaunchKernelGGL(trans_c_bucket_kernel, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  if (T.use_runs)
+    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+  else
+    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 

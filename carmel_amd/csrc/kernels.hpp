@@ -78,9 +78,19 @@ struct TransArgs {
   uint64_t n_wcache, n_post;
   uint32_t n_buckets, n_tiles;
   uint32_t n_wtiles;      // tiles that cover wcache (set by launch_transpose_weights)
+  // run-length form of t_src / b_src: inside one (bucket, tile) cell both indices advance together, so a run of items
+  // is {first item relative to its tile / bucket, source index of that item}: ~0.5 B per item instead of 4
+  const uint32_t* tr_off;   // per tile: its runs are [tr_off[t], tr_off[t + 1])
+  const uint16_t* tr_rel;
+  const uint32_t* tr_src;
+  const uint32_t* br_off;   // per bucket
+  const uint16_t* br_rel;
+  const uint32_t* br_src;
+  uint32_t use_runs;        // every tile and bucket has at most TRANS_RUN_CAP runs (they are staged in LDS)
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
 };
 
+#define TRANS_RUN_CAP 2560
 #define MSTEP_BIG_GROUP 48  // a group above this size is summed by a workgroup of its own (one thread walking 500 members is a
                            // chain of 500 dependent loads: 0.22 ms on the tagging lexicon's per-tag groups)
 #define MSTEP_PARTIALS 2048

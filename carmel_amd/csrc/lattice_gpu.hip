@@ -659,6 +659,100 @@ static int bits_for(uint64_t v) {
 
 }  // namespace
 
+// ---- run-length form of the transposition's source indices (TransArgs::tr_* / br_*) ----
+namespace {
+__global__ void run_flags_kernel(const uint32_t* src, uint64_t n, uint32_t* flags) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flags[i] = (i == 0 || src[i] != src[i - 1] + 1u) ? 1u : 0u;
+}
+__global__ void run_starts_kernel(const uint64_t* starts, uint64_t n_seg, uint64_t n, uint32_t* flags) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < n_seg && starts[s] < n) flags[starts[s]] = 1u;
+}
+__global__ void run_emit_kernel(const uint32_t* src, const uint32_t* flags, const uint32_t* rid, const uint64_t* starts, uint64_t n_seg,
+                                uint64_t n, uint16_t* run_rel, uint32_t* run_src) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !flags[i]) return;
+  uint64_t lo = 0, hi = n_seg - 1;  // last segment with starts[seg] <= i (empty segments share a start: the last one wins)
+  while (lo < hi) {
+    const uint64_t m = (lo + hi + 1) >> 1;
+    if (starts[m] <= i) lo = m; else hi = m - 1;
+  }
+  run_rel[rid[i]] = (uint16_t)(i - starts[lo]);
+  run_src[rid[i]] = src[i];
+}
+__global__ void run_off_kernel(const uint32_t* rid, const uint64_t* starts, uint64_t n_seg, uint64_t n, uint32_t total, uint32_t* seg_off,
+                               uint32_t* max_runs) {
+  const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s > n_seg) return;
+  const uint32_t mine = (s == n_seg || starts[s] >= n) ? total : rid[starts[s]];
+  seg_off[s] = mine;
+  if (s < n_seg) {
+    const uint32_t next = (s + 1 == n_seg || starts[s + 1] >= n) ? total : rid[starts[s + 1]];
+    atomicMax(max_runs, next - mine);
+  }
+}
+__global__ void bucket_starts_kernel(const TransBucket* b, uint32_t nb, uint64_t n, uint64_t* starts) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nb) starts[k] = b[k].item_base;
+  if (k == nb) starts[k] = n;
+}
+int run_table(hipStream_t s, DevBuf<char>& tmp, const uint32_t* src, uint64_t n, const uint64_t* starts, uint64_t n_seg, DevBuf<uint32_t>& off,
+              DevBuf<uint16_t>& rel, DevBuf<uint32_t>& rsrc, uint32_t& max_runs) {
+  DevBuf<uint32_t> flags, rid, d_max;
+  HIPCHK(flags.alloc(n + 1));
+  HIPCHK(rid.alloc(n + 1));
+  HIPCHK(d_max.alloc(1));
+  HIPCHK(hipMemsetAsync(d_max.p, 0, 4, s));
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(run_flags_kernel, dim3(g), dim3(256), 0, s, src, n, flags.p);
+  hipLaunchKernelGGL(run_starts_kernel, dim3((unsigned)((n_seg + 255) / 256)), dim3(256), 0, s, starts, n_seg, n, flags.p);
+  size_t bytes = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags.p, rid.p, (int)n, s));
+  if (tmp.n < bytes) HIPCHK(tmp.alloc(bytes));
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, flags.p, rid.p, (int)n, s));
+  uint32_t last_rid = 0, last_flag = 0;
+  HIPCHK(hipMemcpyAsync(&last_rid, rid.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(&last_flag, flags.p + (n - 1), 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const uint32_t total = last_rid + last_flag;
+  HIPCHK(off.alloc(n_seg + 1));
+  HIPCHK(rel.alloc(total));
+  HIPCHK(rsrc.alloc(total));
+  hipLaunchKernelGGL(run_emit_kernel, dim3(g), dim3(256), 0, s, src, flags.p, rid.p, starts, n_seg, n, rel.p, rsrc.p);
+  hipLaunchKernelGGL(run_off_kernel, dim3((unsigned)((n_seg + 256) / 256)), dim3(256), 0, s, rid.p, starts, n_seg, n, total, off.p, d_max.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(&max_runs, d_max.p, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+}  // namespace
+
+// after either builder: derive the run tables from t_t_src / t_b_src (which stay, for the A/B switch and the checksums)
+int build_run_tables(carmel_hip_trainer* t) {
+  t->use_runs = false;
+  if (!t->use_transpose || !t->t_buckets.n || !t->t_t_src.n) return CARMEL_HIP_OK;
+  if (getenv("CARMEL_HIP_TRANS_RUNS") && atoi(getenv("CARMEL_HIP_TRANS_RUNS")) == 0) return CARMEL_HIP_OK;
+  hipStream_t s = t->stream;
+  const uint64_t n = t->t_t_src.n;
+  const uint64_t n_tiles = t->t_tile_base.n - 1;
+  const uint32_t nb = (uint32_t)t->t_buckets.n;
+  DevBuf<char> tmp;
+  DevBuf<uint64_t> bstarts;
+  HIPCHK(bstarts.alloc((size_t)nb + 1));
+  hipLaunchKernelGGL(bucket_starts_kernel, dim3((nb + 256) / 256), dim3(256), 0, s, t->t_buckets.p, nb, n, bstarts.p);
+  uint32_t max_t = 0, max_b = 0;
+  int rc = run_table(s, tmp, t->t_t_src.p, n, t->t_tile_base.p, n_tiles, t->tr_off, t->tr_rel, t->tr_src, max_t);
+  if (rc) return rc;
+  rc = run_table(s, tmp, t->t_b_src.p, n, bstarts.p, nb, t->br_off, t->br_rel, t->br_src, max_b);
+  if (rc) return rc;
+  t->use_runs = max_t <= TRANS_RUN_CAP && max_b <= TRANS_RUN_CAP && max_t > 0 && max_b > 0;
+  if (getenv("CARMEL_TIMING"))
+    fprintf(stderr, "timing: transposition runs: %zu per %llu items, at most %u per tile / %u per bucket -> %s\n", t->tr_src.n,
+            (unsigned long long)n, max_t, max_b, t->use_runs ? "run-length indices" : "per-item indices");
+  return CARMEL_HIP_OK;
+}
+
 // checksums of the lattice image in device memory: lets a test assert that the GPU builder and the host builder leave
 // the very same bytes behind.  out[16].
 int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out) {
