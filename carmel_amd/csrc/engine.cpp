@@ -368,6 +368,8 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
   std::unordered_map<uint64_t, uint32_t> ids;
   ids.reserve(n);
   t->h_group_member.clear();
+  t->h_group_src.clear();
+  t->h_group_joint.clear();
   t->any_digamma = false;
   t->dig_alpha.release();
   t->tie_alpha.release();
@@ -390,6 +392,8 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       ids.emplace(key, id);
       add.push_back(addc[m]);
       t->h_group_member.push_back(m);
+      t->h_group_src.push_back(src[k]);
+      t->h_group_joint.push_back(g == CARMEL_HIP_NORM_JOINT ? 1 : 0);
       norm_of[k] = id;
     } else
       norm_of[k] = it->second;

@@ -87,6 +87,8 @@ struct carmel_hip_trainer {
   DevBuf<double> dig_alpha, tie_alpha;  // --digamma: per norm group / per tie (NaN = linear); empty when unused
   bool any_digamma = false;
   std::vector<uint32_t> h_group_member, h_tie_member;  // member transducer of every norm group / tie
+  std::vector<uint32_t> h_group_src;    // source state (in its member) of every norm group
+  std::vector<uint8_t> h_group_joint;   // 1 if the group's member normalises JOINT (one group per state)
   DevBuf<double> arc_prior_w;           // cascade + carmel -U: initial weight of every composed arc (added to -f)
   std::vector<double> h_arc_prior_w;
   DevBuf<double> u_param_wprior;        // ... summed per parameter for the unrolled sweep

@@ -457,11 +457,109 @@ __global__ void gibbs_commit_kernel(GibbsArgs G, const double* new_x, uint64_t n
   }
 }
 
+// ---- prior-scale inference (gibbs.hpp:404-553) ----
+// gibbs_param::scale_prior (gibbs.hpp:161-176) for every parameter, one thread per norm group walking its members in
+// ascending order (the reference's order within a group; groups do not interact): prior *= f, the count and its
+// time-weighted sum move with it (delta_sum::addbase), the group's normsum too; psum = the new prior mass of the group
+__global__ void gibbs_scale_priors_kernel(GibbsArgs G, const uint64_t* group_off, const uint64_t* norm_perm, uint64_t n_groups,
+                                          const uint32_t* meta, const double* scales, int invert, double* p_prior,
+                                          double* prior_norm) {
+  const uint64_t n = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_groups) return;
+  const uint32_t i = meta[n];
+  double ns = G.normsum[n], ps = 0.0;
+  for (uint64_t j = group_off[n]; j < group_off[n + 1]; ++j) {
+    const uint64_t p = norm_perm[j];
+    if (G.p_norm[p] == G_NONORM) continue;  // a locked member of the group: a fixed probability, no prior
+    double pr = p_prior[p];
+    if (i > 0) {
+      double f = scales[i];
+      if (invert) f = 1. / f;
+      const double sc = f * pr, d = sc - pr;
+      G.p_s[p] += d * G.p_tmax[p];
+      G.p_x[p] += d;
+      ns += d;
+      pr = sc;
+      p_prior[p] = pr;
+    }
+    ps += pr;
+  }
+  G.normsum[n] = ns;
+  prior_norm[n] = ps;
+}
+// gibbs_base::cache_prob(recompute) (gibbs.hpp:712-742): the cache-model probability of the WHOLE current sample, block
+// after block, from cache counts that start at the priors (ccount / csum were reset by the caller); iter_out[3]
+__global__ __launch_bounds__(256) void gibbs_cache_prob_kernel(GibbsArgs G) {
+  extern __shared__ uint32_t books[];
+  __shared__ double red[3];
+  if (threadIdx.x == 0) red[0] = red[1] = red[2] = 0.0;
+  __syncthreads();
+  for (uint32_t b = 0; b < G.n_blocks; ++b) {
+    const uint32_t* ids = G.sample_ids + G.sample_off[b];
+    const uint32_t n = G.sample_len[b];
+    if (n <= G.books_cap) {
+      g_block_probs(G, ids, n, books, red);
+    } else {
+      if (threadIdx.x == 0) {
+        double cache = 0.0;
+        for (uint32_t k = 0; k < n; ++k) {
+          const uint32_t p = ids[k], nn = G.p_norm[p];
+          double q = G.p_prior[p];
+          if (nn != G_NONORM) {
+            q = G.ccount[p] / G.csum[nn];
+            G.ccount[p] += 1.0;
+            G.csum[nn] += 1.0;
+          }
+          cache += log(q);
+        }
+        red[1] += cache;
+      }
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) G.iter_out[3] = red[1];
+}
+
 }  // namespace carmel_hip
 
 using namespace carmel_hip;
 
+// the standard normal's cdf and quantile (the reference uses boost::math::normal_distribution, gibbs.hpp:474-516 -- a
+// third-party dependency absent from the tree; restated from the published algorithm: Wichura, AS 241 (PPND16), 1988)
+static double pi_norm_cdf(double z) { return 0.5 * std::erfc(-z / std::sqrt(2.0)); }
+static double pi_norm_quantile(double p) {
+  const double q = p - 0.5;
+  if (std::fabs(q) <= 0.425) {
+    const double r = 0.180625 - q * q;
+    return q * (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r + 4.5921953931549871457e4) * r + 1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r + 1.3314166789178437745e2) * r + 3.3871328727963666080e0) /
+           (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r + 2.1213794301586595867e4) * r + 5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r + 4.2313330701600911252e1) * r + 1.0);
+  }
+  double r = q < 0 ? p : 1.0 - p;
+  r = std::sqrt(-std::log(r));
+  double v;
+  if (r <= 5.0) {
+    r -= 1.6;
+    v = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r + 1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r + 4.63033784615654529590e0) * r + 1.42343711074968357734e0) /
+        (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r + 1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r + 2.05319162663775882187e0) * r + 1.0);
+  } else {
+    r -= 5.0;
+    v = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r + 2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r + 5.46378491116411436990e0) * r + 6.65790464350110377720e0) /
+        (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r + 7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r + 5.99832206555887937690e-1) * r + 1.0);
+  }
+  return q < 0 ? -v : v;
+}
+
 struct carmel_hip_gibbs {
+  // --prior-inference-* (gibbs_opts.hpp:82-89, 148-153)
+  double pi_stddev = 0;
+  bool pi_restart_fresh = false;
+  uint32_t pi_start = 0, pi_end = 0, n_scale = 0;
+  std::vector<uint32_t> h_meta;       // metanorm: scale group of every norm group, 0 = never scaled (gibbs.hpp:404-470)
+  DevBuf<uint32_t> d_meta;
+  DevBuf<double> d_scales;
+  std::vector<double> cumulative;     // product of the accepted scales per scale group
+  std::vector<double> h_prior0;       // the priors before any inference (--prior-inference-restart-fresh)
+  std::vector<double> pi_trace;       // per sweep: {proposed, accepted, ln p1, ln p2, a2, p_accept}
   carmel_hip_trainer* t = nullptr;
   int device = 0;
   carmel_hip_gibbs_opts opt;
@@ -615,6 +713,95 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   return CARMEL_HIP_OK;
 }
 
+int carmel_hip_gibbs_set_prior_inference(carmel_hip_gibbs* g, double stddev, int global, int local, int restart_fresh,
+                                         uint32_t start, uint32_t end, const int* member_priorgroup,
+                                         const uint32_t* member_n_states, uint32_t n_members) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  if (stddev > 0 && (g->opt.mode != 0 || g->opt.expectation))
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "prior inference works with the cache-model probability of the exact blocked sampler only (gibbs.hpp:528-529)");
+  carmel_hip_trainer* t = g->t;
+  HIPCHK(hipSetDevice(t->device));
+  g->pi_stddev = stddev;
+  g->pi_restart_fresh = restart_fresh != 0;
+  g->pi_start = start;
+  g->pi_end = end;
+  const size_t ng = g->n_norm;
+  // The reference's norm ids (gibbs.cc:114-186 over NormGroupIter, fst.h:1362-1445): members in order; a JOINT member
+  // has one group PER STATE, arcs or not; a CONDITIONAL member one per (state, input) that has arcs.  Groups without
+  // parameters own no counts, but each still draws a scale that enters the acceptance ratio, so they are counted here.
+  std::vector<uint32_t> refid(ng, 0u), ref_member;  // product group -> reference norm id; reference id -> member
+  {
+    uint32_t members = 0;
+    for (size_t n = 0; n < ng; ++n) members = std::max(members, t->h_group_member[n] + 1);
+    members = std::max(members, n_members);
+    std::vector<uint32_t> states(members, 0u);
+    for (size_t n = 0; n < ng; ++n)
+      if (t->h_group_joint[n]) states[t->h_group_member[n]] = std::max(states[t->h_group_member[n]], t->h_group_src[n] + 1);
+    if (member_n_states)
+      for (uint32_t m = 0; m < n_members; ++m) states[m] = std::max(states[m], member_n_states[m]);
+    size_t n = 0;
+    for (uint32_t m = 0; m < members; ++m) {
+      const uint32_t base = (uint32_t)ref_member.size();
+      bool joint = false;
+      size_t e = n;
+      for (; e < ng && t->h_group_member[e] == m; ++e) joint = joint || t->h_group_joint[e] != 0;
+      if (joint) {
+        for (size_t k = n; k < e; ++k) refid[k] = base + t->h_group_src[k];
+        ref_member.insert(ref_member.end(), states[m], m);
+      } else {
+        for (size_t k = n; k < e; ++k) refid[k] = base + (uint32_t)(k - n);
+        ref_member.insert(ref_member.end(), e - n, m);
+      }
+      n = e;
+    }
+  }
+  const size_t nref = ref_member.size();
+  // metanorm as add_gibbs_params builds it: --prior-groupby 0 = fixed, 1 = one scale per transducer (the default),
+  // 2 = one per norm group
+  std::vector<uint32_t> meta(nref, 0u);
+  uint32_t nexti = 1;
+  for (size_t r = 0; r < nref;) {
+    const uint32_t m = ref_member[r];
+    const int pg = (member_priorgroup && m < n_members) ? member_priorgroup[m] : 1;
+    for (; r < nref && ref_member[r] == m; ++r) {
+      meta[r] = pg == 0 ? 0u : nexti;
+      if (pg == 2) ++nexti;
+    }
+    if (pg == 1) ++nexti;
+  }
+  // finish_params cuts the table back to nnorm (gibbs.hpp:572-579), and nnorm only counts up to the last norm group that
+  // owns a parameter (define_param, gibbs.hpp:582-588)
+  size_t nnorm = 0;
+  for (uint32_t n : g->h_norm)
+    if (n != 0xffffffffu) nnorm = std::max(nnorm, (size_t)refid[n] + 1);
+  if (global) {  // gibbs.hpp:575-578
+    nexti = 2;
+    std::fill(meta.begin(), meta.end(), 1u);
+  }
+  if (local) {
+    nexti = (uint32_t)nnorm + 1;
+    for (size_t r = 0; r < nref; ++r) meta[r] = r < nnorm ? (uint32_t)r + 1 : 0u;
+  }
+  g->h_meta.assign(ng, 0u);
+  for (size_t n = 0; n < ng; ++n) g->h_meta[n] = meta[refid[n]];
+  g->n_scale = nexti - 1;
+  g->cumulative.assign(g->n_scale, 1.0);
+  g->h_prior0 = g->h_prior;
+  HIPCHK(g->d_meta.upload(g->h_meta, t->stream));
+  HIPCHK(g->d_scales.alloc(nexti));
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_gibbs_prior_trace(carmel_hip_gibbs* g, double* out6, uint32_t n_sweeps, double* cumulative, uint32_t n_cumulative) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  if (out6)
+    for (size_t k = 0; k < (size_t)n_sweeps * 6; ++k) out6[k] = k < g->pi_trace.size() ? g->pi_trace[k] : 0.0;
+  if (cumulative)
+    for (uint32_t k = 0; k < n_cumulative; ++k) cumulative[k] = k < g->cumulative.size() ? g->cumulative[k] : 1.0;
+  return CARMEL_HIP_OK;
+}
+uint32_t carmel_hip_gibbs_n_prior_scales(carmel_hip_gibbs* g) { return g ? g->n_scale : 0; }
+
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g) {
   if (g) {
     (void)hipSetDevice(g->device);
@@ -702,7 +889,17 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   std::vector<double> lw(np), best_lw;
   double best_all = 0, best_final = 0, best_sum = 0;
   DevBuf<uint32_t> best_ids, best_len;  // sample of the best run so far (--crp-restarts)
+  g->pi_trace.assign((size_t)n_runs * (Ni + 1) * 6, 0.0);
   for (uint32_t run = 0; run < n_runs; ++run) {
+  if (g->pi_stddev > 0 && run > 0 && g->pi_restart_fresh) {  // gibbs.hpp:889-898: the priors start over
+    HIPCHK(hipMemcpyAsync(g->p_prior.p, g->h_prior0.data(), np * sizeof(double), hipMemcpyHostToDevice, s));
+    std::vector<double> pn(ng, 0.0);
+    for (uint64_t p = 0; p < np; ++p)
+      if (g->h_norm[p] != 0xffffffffu) pn[g->h_norm[p]] += g->h_prior0[p];
+    HIPCHK(hipMemcpyAsync(g->prior_norm.p, pn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    g->cumulative.assign(g->n_scale, 1.0);
+  }
   // restore_p0: counts = priors, normsums = their sums, no sample
   HIPCHK(hipMemcpyAsync(g->p_x.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(g->p_s.p, 0, np * sizeof(double), s));
@@ -756,6 +953,58 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     HIPCHK(hipMemcpyAsync(io, g->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const double plog = g->opt.mode == 0 ? io[0] : io[1];
+    {
+      // propose_new_priors (gibbs.hpp:525-553), on the sweeps that infer (gibbs.hpp:559-563)
+      const uint32_t pstart = g->pi_start ? g->pi_start : g->opt.burnin;
+      if (g->pi_stddev > 0 && g->n_scale && iter > 0 && pstart <= iter && (!g->pi_end || iter < g->pi_end)) {
+        const double sdev = g->pi_stddev;
+        const double q0 = pi_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;  // scale ratios are > 0 (gibbs.hpp:488-499)
+        std::vector<double> sc(g->n_scale + 1, 1.0);
+        double ln_a2 = 0.0;
+        for (uint32_t k = 1; k <= g->n_scale; ++k) {
+          const double u = gibbs_uniform(g->opt.seed, G.iter, 0xfffffffeu, k);
+          sc[k] = 1.0 + sdev * pi_norm_quantile(q0 + u * qrem);
+          const double d_old = 1.0 / sc[k] - 1.0, d_new = sc[k] - 1.0;  // q(old | new) / q(new | old), both N(1, sdev)
+          ln_a2 += (d_new * d_new - d_old * d_old) / (2.0 * sdev * sdev);
+        }
+        HIPCHK(hipMemcpyAsync(g->d_scales.p, sc.data(), sc.size() * sizeof(double), hipMemcpyHostToDevice, s));
+        const size_t lds_c = (size_t)G.books_cap * 8;
+        auto cache_prob_all = [&](double& out) -> int {
+          HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+          hipLaunchKernelGGL(gibbs_cache_prob_kernel, dim3(1), dim3(256), lds_c, s, G);
+          HIPCHK(hipGetLastError());
+          HIPCHK(hipMemcpyAsync(&out, g->iter_out.p + 3, sizeof(double), hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          return CARMEL_HIP_OK;
+        };
+        auto scale = [&](int invert) -> int {
+          hipLaunchKernelGGL(gibbs_scale_priors_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, s, G, t->group_off.p,
+                             t->norm_perm.p, (uint64_t)ng, g->d_meta.p, g->d_scales.p, invert, g->p_prior.p, g->prior_norm.p);
+          HIPCHK(hipGetLastError());
+          return CARMEL_HIP_OK;
+        };
+        double p1 = 0, p2 = 0;
+        int rc = cache_prob_all(p1);
+        if (!rc) rc = scale(0);
+        if (!rc) rc = cache_prob_all(p2);
+        if (rc) return rc;
+        const double a = std::exp((p2 - p1) + ln_a2);
+        const bool accept = gibbs_uniform(g->opt.seed, G.iter, 0xffffffffu, 0) < a;
+        if (!accept) {
+          rc = scale(1);
+          if (rc) return rc;
+        } else
+          for (uint32_t k = 1; k <= g->n_scale; ++k) g->cumulative[k - 1] *= sc[k];
+        double* tr = g->pi_trace.data() + ((size_t)run * (Ni + 1) + iter) * 6;
+        tr[0] = 1;
+        tr[1] = accept ? 1 : 0;
+        tr[2] = p1;
+        tr[3] = p2;
+        tr[4] = std::exp(ln_a2);
+        tr[5] = a;
+      }
+    }
     if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
     if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[1];
     if (iter_after_logprob) iter_after_logprob[(size_t)run * (Ni + 1) + iter] = io[2];
@@ -767,6 +1016,10 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     }
   }
   // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
+  if (g->pi_stddev > 0) {  // the priors have moved
+    HIPCHK(hipMemcpyAsync(g->h_prior.data(), g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
   std::vector<double> x(np), sacc(np), tm(np);
   HIPCHK(hipMemcpyAsync(x.data(), g->p_x.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(sacc.data(), g->p_s.p, np * sizeof(double), hipMemcpyDeviceToHost, s));

@@ -82,6 +82,10 @@ struct Options {
   bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
   bool cache_no_prune = false;     // --cache-no-prune
   bool gpu_compose = false;        // --gpu-compose: the product construction of the composition on the GPU (compose.hip)
+  // prior-scale inference (carmel.cc:291-294, 497; gibbs.hpp:525-563)
+  double pi_stddev = 0;
+  bool pi_global = false, pi_restart_fresh = false, pi_show = false;
+  std::string prior_groupby;
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
@@ -183,6 +187,20 @@ static Options parse_args(int argc, char** argv) {
         o.exclude_prior = true;
       else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
         o.crp_parallel = true;
+      else if (k == "prior-inference-stddev")
+        o.pi_stddev = std::atof(v.c_str());
+      else if (k == "prior-inference-global")
+        o.pi_global = true;
+      else if (k == "prior-inference-restart-fresh")
+        o.pi_restart_fresh = true;
+      else if (k == "prior-inference-show")
+        o.pi_show = true;
+      else if (k == "prior-groupby")
+        o.prior_groupby = v;
+      else if (k == "prior-inference-start" || k == "prior-inference-end" || k == "prior-inference-local")
+        // gibbs_opts.hpp:85-89 documents them and forest-em reads them; carmel.cc:291-294 never does, so carmel runs as
+        // if they were not given.  Same here (the library has them: carmel_hip_gibbs_set_prior_inference).
+        std::cerr << "--" << k << " is not read by carmel (carmel.cc:291-294); ignored\n";
       else if (k == "digamma") {
         o.digamma = v;
         o.have_digamma = true;
@@ -398,7 +416,15 @@ static int run(int argc, char** argv) {
   }
   // ---- normalisation methods per member (carmel.cc:488-499) ----
   std::vector<int> norms(nw, o.norm);
-  std::vector<double> addc(nw, 0.0);
+  std::vector<double> addc(nw, o.pi_stddev != 0 ? 1.0 : 0.0);  // carmel.cc:491-492: inferred priors start from 1
+  std::vector<int> priorgroup(nw, 1);
+  for (size_t i = 0; i < o.prior_groupby.size() && i < nw; ++i) {  // fst.h:586-598
+    const char ch = o.prior_groupby[i];
+    if (ch < '0' || ch > '2')
+      throw std::runtime_error("prior-groupby characters must be 0 (no scaling), 1 (same scaling for whole xdcr), or 2 "
+                               "(separate scaling for each normgroup)");
+    priorgroup[i] = ch - '0';
+  }
   for (size_t i = 0; i < o.normby.size() && i < nw; ++i) {
     char ch = o.normby[i];
     norms[i] = (ch == 'J' || ch == 'j') ? CARMEL_HIP_NORM_JOINT
@@ -844,10 +870,21 @@ static int run(int argc, char** argv) {
     if (!init_arc_logw.empty())
       hip_check(carmel_hip_gibbs_set_init_weights(gs, init_arc_logw.data()), "carmel_hip_gibbs_set_init_weights");
     const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
+    std::vector<uint32_t> member_states(nw, (uint32_t)result->states.size());
+    if (cascade)
+      for (size_t i = 0; i < nw; ++i) member_states[i] = (uint32_t)member[i].states.size();
+    if (o.pi_stddev > 0)
+      hip_check(carmel_hip_gibbs_set_prior_inference(gs, o.pi_stddev, o.pi_global, 0, o.pi_restart_fresh, 0, 0, priorgroup.data(),
+                                                     member_states.data(), (uint32_t)nw),
+                "carmel_hip_gibbs_set_prior_inference");
     std::vector<double> lp((size_t)per_run * n_runs), lp_after(o.sample_prob_after ? lp.size() : 0);
     int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
     const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
+    std::vector<double> ptrace((size_t)per_run * n_runs * 6, 0.0), pcum(carmel_hip_gibbs_n_prior_scales(gs), 1.0);
+    if (o.pi_stddev > 0 && rc == CARMEL_HIP_OK)
+      hip_check(carmel_hip_gibbs_prior_trace(gs, ptrace.data(), per_run * n_runs, pcum.data(), (uint32_t)pcum.size()),
+                "carmel_hip_gibbs_prior_trace");
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
     double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
@@ -856,12 +893,21 @@ static int run(int argc, char** argv) {
       if (go.restarts) std::cerr << "(random restart " << r << " of " << go.restarts << "): \n";  // gibbs.hpp:897
       for (uint32_t i = 0; i <= go.iter; ++i) {  // gibbs.hpp:927-955, gibbs_opts.hpp:298-312
         const double v = o.sample_prob_after ? lp_after[(size_t)r * per_run + i] : lp[(size_t)r * per_run + i];
-        std::cerr << "Gibbs i=" << i << " "
-                  << (o.sample_prob_after ? "sample(after add-back)" : go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model")
+        std::cerr << "Gibbs i=" << i << " ";
+        const double* pt = ptrace.data() + ((size_t)r * per_run + i) * 6;
+        if (pt[0] != 0)  // propose_new_priors' line (gibbs.hpp:539-547); the scales shown are the final ones
+          std::cerr << (pt[1] != 0 ? "accepted" : "rejected") << " new priors with p1=" << base2(pt[2]) << " p2=" << base2(pt[3])
+                    << " a1=p2/p1=" << std::exp(pt[3] - pt[2]) << " a2=q(1|2)/q(2|1)=" << pt[4] << " p_accept=" << pt[5] << ". ";
+        std::cerr << (o.sample_prob_after ? "sample(after add-back)" : go.expectation ? "sum-all-derivations" : go.mode ? "cheap(proposal)" : "cache-model")
                   << " prob=" << base2(v);
         if (n_sym) std::cerr << " per-point-ppx(N=" << n_sym << ")=" << base2(-v / n_sym);
         std::cerr << " per-block-ppx(N=" << nblocks << ")=" << base2(-v / nblocks) << "\n";
       }
+    }
+    if (o.pi_show) {  // gibbs.hpp:826-827
+      std::cerr << "Final prior-scale=[";
+      for (size_t k = 0; k < pcum.size(); ++k) std::cerr << (k ? " " : "") << pcum[k];
+      std::cerr << "]\n";
     }
     if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());

@@ -288,6 +288,25 @@ class HipGibbs(object):
         a = None if arc_logw is None else np.ascontiguousarray(arc_logw, dtype=np.float64)
         check(lib.carmel_hip_gibbs_set_init_weights(self.h, ptr(a)), "carmel_hip_gibbs_set_init_weights")
 
+    def set_prior_inference(self, stddev, global_=False, local=False, restart_fresh=False, start=0, end=0, groupby=None,
+                            n_states=None):
+        """--prior-inference-stddev / -global / -local / -restart-fresh / -start / -end, --prior-groupby (one 0/1/2 per
+        member transducer): prior-scale inference after every inferring sweep (gibbs.hpp:525-563).  n_states: the members'
+        state counts (a JOINT member has a norm group, and so a scale, per state -- with arcs or not)"""
+        ns = None if n_states is None else np.ascontiguousarray(n_states, dtype=np.uint32)
+        n = len(ns) if ns is not None else (len(groupby) if groupby is not None else 0)
+        gb = None if groupby is None else np.ascontiguousarray(list(groupby) + [1] * (n - len(groupby)), dtype=np.int32)
+        check(lib.carmel_hip_gibbs_set_prior_inference(self.h, float(stddev), int(global_), int(local), int(restart_fresh),
+                                                       int(start), int(end), ptr(gb), ptr(ns), n),
+              "carmel_hip_gibbs_set_prior_inference")
+
+    def prior_trace(self):
+        """(per sweep {proposed, accepted, ln p1, ln p2, a2, p_accept}, cumulative scale per scale group)"""
+        n = (self.opts.iter + 1) * (self.opts.restarts + 1)
+        tr, cum = np.zeros((n, 6)), np.zeros(max(1, lib.carmel_hip_gibbs_n_prior_scales(self.h)))
+        check(lib.carmel_hip_gibbs_prior_trace(self.h, ptr(tr), n, ptr(cum), len(cum)), "carmel_hip_gibbs_prior_trace")
+        return tr, cum[:lib.carmel_hip_gibbs_n_prior_scales(self.h)]
+
     @property
     def best_run(self):
         return lib.carmel_hip_gibbs_best_run(self.h)

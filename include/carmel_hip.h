@@ -249,6 +249,24 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
  * "sample prob" (its 6001 values for `--crp -M 6000` on the tagging cascade, trace lines 6989-12990, are this repo's only
  * reference-held datum for the sampler); today's carmel logs the cache-model probability instead. */
 int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob, double* iter_after_logprob);
+/* Replaces: prior-scale inference, gibbs_base::propose_new_priors (gibbs.hpp:404-553; carmel --prior-inference-stddev=s
+ * [--prior-inference-global | -local] [--prior-inference-restart-fresh] [--prior-inference-start= --prior-inference-end=]
+ * [--prior-groupby=012..]): after every inferring sweep (gibbs.hpp:559-563) each scale group's prior pseudo-counts are
+ * proposed to be multiplied by a factor drawn from N(1, stddev) truncated to > 0, and the proposal is accepted with
+ * probability p2 / p1 * q(old|new) / q(new|old), p1 / p2 = the cache-model probability of the whole current sample under
+ * the old / new priors.  member_priorgroup[m]: 0 = never scaled, 1 = one scale for the whole member transducer (default),
+ * 2 = one per norm group.  member_n_states[m] (may be null: the highest source state + 1): a JOINT member has one
+ * norm group per state in the reference, arcs or not (fst.h:1362-1445), and every group draws a scale that enters the
+ * acceptance ratio, so the count of states decides how many scales there are.  Exact mode only.  Call between create and run.  The uniforms are
+ * carmel_hip_gibbs_uniform(seed, sweep, 0xfffffffe, k) for scale group k (1-based) and (seed, sweep, 0xffffffff, 0) for
+ * the acceptance.  carmel_hip_gibbs_prior_trace: per sweep {proposed, accepted, ln p1, ln p2, a2, p_accept} and the
+ * cumulative scale per scale group (--prior-inference-show). */
+int carmel_hip_gibbs_set_prior_inference(carmel_hip_gibbs* g, double stddev, int global, int local, int restart_fresh,
+                                         uint32_t start, uint32_t end, const int* member_priorgroup,
+                                         const uint32_t* member_n_states, uint32_t n_members);
+int carmel_hip_gibbs_prior_trace(carmel_hip_gibbs* g, double* out6, uint32_t n_sweeps, double* cumulative, uint32_t n_cumulative);
+uint32_t carmel_hip_gibbs_n_prior_scales(carmel_hip_gibbs* g);
+
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
 /* --init-em (gibbs.cc:386-430, 306-383 p_init): ln weights of the composed arcs (carmel_hip_get_arc_weights after an EM

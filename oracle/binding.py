@@ -243,6 +243,7 @@ lib.orc_cascade_composed.restype = vp
 lib.orc_cascade_composed.argtypes = [vp]
 lib.orc_cascade_dims.argtypes = [vp, vp]
 lib.orc_cascade_export.argtypes = [vp] * 8
+lib.orc_cascade_member_states.argtypes = [vp, vp]
 lib.orc_cascade_corpus.restype = vp
 lib.orc_cascade_corpus.argtypes = [vp, C.c_char_p]
 lib.orc_cascade_write_member.restype = vp
@@ -288,6 +289,13 @@ class OracleCascade(object):
         lib.orc_free_str(s)
         return txt
 
+    @property
+    def member_states(self):
+        """state count of every member transducer (a JOINT member has one norm group per state)"""
+        out = np.zeros(self.n_members, np.uint32)
+        lib.orc_cascade_member_states(self.h, _p(out))
+        return out
+
     def as_dict(self, member_norm, member_add_count=None):
         n = self.n_members
         return dict(param_logw=self.param_logw, param_group=self.param_group, param_member=self.param_member,
@@ -328,11 +336,17 @@ def fem_export(cascade, corpus, which, normby=None, priors=None):
     return buf.value.decode()
 
 
+lib.orc_set_gibbs_prior_inference.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, vp, C.c_uint32]
+lib.orc_gibbs_last_prior_trace.argtypes = [vp, C.c_uint32, vp, C.c_uint32]
+lib.orc_gibbs_last_prior_trace.restype = C.c_uint32
+
+
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
               low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False, init_em=0,
-              em_p0=False, init_from_p0=False):
-    """carmel --crp on an OracleCascade; `uniform(iter, block, step)` supplies every random01() draw.
+              em_p0=False, init_from_p0=False, prior_inference=None):
+    """carmel --crp on an OracleCascade; prior_inference = dict(stddev, global_, local, restart_fresh, start, end, groupby)
+    turns on prior-scale inference (gibbs.hpp:525-553). `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
     n = cascade.n_params
     ilp, icl = np.zeros((iters + 1) * (restarts + 1)), np.zeros((iters + 1) * (restarts + 1))
@@ -348,6 +362,11 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     lib.orc_set_gibbs_restarts(int(restarts), int(argmax_final), int(argmax_sum))
     lib.orc_set_gibbs_init_em(int(init_em), int(em_p0))
     lib.orc_set_gibbs_init_from_p0(int(init_from_p0))
+    pi = dict(prior_inference or {})
+    gb = np.ascontiguousarray(pi.get("groupby", []), dtype=np.int32)
+    lib.orc_set_gibbs_prior_inference(C.c_double(pi.get("stddev", 0.0)), int(pi.get("global_", False)), int(pi.get("local", False)),
+                                      int(pi.get("restart_fresh", False)), int(pi.get("start", 0)), int(pi.get("end", 0)),
+                                      _p(gb) if len(gb) else None, len(gb))
     _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
                            int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
                            _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))
@@ -355,8 +374,12 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     after = np.zeros(len(ilp))
     lib.orc_gibbs_last_after(_p(after), len(after))
     lib.orc_set_gibbs_init_from_p0(0)
+    ptrace, cum = np.zeros((len(ilp), 6)), np.zeros(4096)
+    lib.orc_gibbs_last_prior_trace.restype = C.c_uint32
+    ncum = lib.orc_gibbs_last_prior_trace(_p(ptrace), len(ilp), _p(cum), len(cum))
+    lib.orc_set_gibbs_prior_inference(C.c_double(0.0), 0, 0, 0, 0, 0, None, 0)
     return dict(iter_logprob=ilp, iter_cheap_logprob=icl, iter_after_logprob=after, param_logw=plw, samples=samples,
-                best_run=lib.orc_gibbs_best_run())
+                best_run=lib.orc_gibbs_best_run(), prior_trace=ptrace, prior_cumulative=cum[:ncum])
 
 
 lib.orc_forests_parse.restype = vp

@@ -64,6 +64,11 @@ struct GibbsOpts {
   bool argmax_final = false, argmax_sum = false;   // --crp-argmax-final / --crp-argmax-sum (gibbs_opts.hpp:313-316)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125,166): fractional counts from a full forward/backward
                              // over the block instead of one sampled derivation ("online EM")
+  // prior-scale inference (gibbs_opts.hpp:82-89, 148-153; fst.h:553-600 --prior-groupby per member: 0 fixed, 1 single, 2 local)
+  double prior_inference_stddev = 0;
+  bool prior_inference_global = false, prior_inference_local = false, prior_inference_restart_fresh = false;
+  unsigned prior_inference_start = 0, prior_inference_end = 0;
+  std::vector<int> priorgroup;
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
   // gibbs_opts.hpp:206-211 + time_series.hpp:90-141: the temperature runs from high_temp at sweep 0 to low_temp at
   // sweep `iter` along clamped_time_series(.., curvature = linear = -1e8); gibbs.hpp:838-839: power = 1/temperature
@@ -88,7 +93,33 @@ struct GibbsTrace {
                                                   // "overestimate" of the comment at gibbs.hpp:866 -- what the older binary
                                                   // behind carmel-tutorial/commands.trace logged as its sample prob
   std::vector<std::vector<unsigned> > last_sample;  // per block: param ids of the final sample
+  std::vector<double> prior_trace;                // per sweep: {proposed, accepted, ln p1, ln p2, a2, p_accept}
+  std::vector<double> cumulative;                 // metanorm::cumulative after the last run
 };
+
+// boost::math::normal_distribution's cdf / quantile (gibbs.hpp:474-516; boost is absent from the tree): the cdf from erfc,
+// the quantile by bisection on it polished with Newton steps -- deliberately not the rational approximation the product uses
+inline double normal_cdf(double x, double mean, double sdev) { return 0.5 * std::erfc(-(x - mean) / (sdev * std::sqrt(2.0))); }
+inline double normal_pdf(double x, double mean, double sdev) {
+  const double z = (x - mean) / sdev;
+  return std::exp(-0.5 * z * z) / (sdev * std::sqrt(2.0 * 3.14159265358979323846));
+}
+inline double normal_quantile(double p, double mean, double sdev) {
+  double lo = -40, hi = 40;
+  for (int i = 0; i < 200; ++i) {
+    double mid = 0.5 * (lo + hi);
+    if (normal_cdf(mid, 0, 1) < p) lo = mid; else hi = mid;
+  }
+  double z = 0.5 * (lo + hi);
+  for (int i = 0; i < 3; ++i) {
+    double pdf = normal_pdf(z, 0, 1);
+    if (!(pdf > 1e-300)) break;
+    double step = (normal_cdf(z, 0, 1) - p) / pdf;
+    if (!(std::fabs(step) < 1e-3)) break;
+    z -= step;
+  }
+  return mean + sdev * z;
+}
 
 struct CarmelGibbs {
   Wfst& composed;
@@ -121,7 +152,19 @@ struct CarmelGibbs {
       if (!derivs.back().compute(composed, io, arcs, p, true, 0)) derivs.pop_back();
     }
     unsigned norm = 0;
-    for (size_t i = 0; i < cascade.cascade.size(); ++i) norm = add_gibbs_params(norm, *cascade.cascade[i], methods[i]);
+    for (size_t i = 0; i < cascade.cascade.size(); ++i)
+      norm = add_gibbs_params(norm, *cascade.cascade[i], methods[i], i < gopt.priorgroup.size() ? gopt.priorgroup[i] : 1);
+    // finish_params (gibbs.hpp:572-579)
+    metanorm.resize(nnorm, 0u);
+    if (gopt.prior_inference_global) {
+      nexti = 2;
+      std::fill(metanorm.begin(), metanorm.end(), 1u);
+    }
+    if (gopt.prior_inference_local) {
+      nexti = nnorm + 1;
+      for (unsigned i = 0; i < nnorm; ++i) metanorm[i] = i + 1;
+    }
+    cumulative.assign(nexti - 1, 1.0);
     // chains of the composed arcs as param ids (trivial cascade: each arc is its own chain, cascade.h:233-239)
     for (auto& r : arcs.t) {
       std::vector<unsigned> ch;
@@ -142,8 +185,12 @@ struct CarmelGibbs {
     gps.push_back(g);
     return (unsigned)gps.size() - 1;
   }
+  // metanorm (gibbs.hpp:404-470): scale group of every norm group; 0 = never scaled
+  std::vector<unsigned> metanorm;
+  unsigned nexti = 1;
+  std::vector<double> cumulative;
   // gibbs.cc:114-186
-  unsigned add_gibbs_params(unsigned id, Wfst& w, const NormalizeMethod& nm) {
+  unsigned add_gibbs_params(unsigned id, Wfst& w, const NormalizeMethod& nm, int pgroup) {
     if (nm.group == NORM_NONE) {
       for (auto& st : w.states)
         for (auto& a : st) param_of[&a] = define_param(GibbsParam::NONORM, a.weight.getReal());
@@ -169,9 +216,77 @@ struct CarmelGibbs {
         double p0 = (a->weight / sum).getReal();
         param_of[a] = define_param(id, gopt.uniformp0 ? alpha : alpha * p0 * N);
       }
+      if (metanorm.size() <= id) metanorm.resize(id + 1, 0u);
+      metanorm[id] = pgroup == 0 ? 0u : nexti;  // gibbs.cc:132-137
+      if (pgroup == 2) ++nexti;
       ++id;
     });
+    if (pgroup == 1) ++nexti;  // gibbs.cc:184
     return id;
+  }
+  // metanorm::scale_priors + gibbs_param::scale_prior (gibbs.hpp:161-176, 430-443)
+  void scale_priors(const std::vector<double>& sc, bool invert) {
+    for (unsigned i = 1; i < nexti; ++i) {
+      if (invert) cumulative[i - 1] /= sc[i]; else cumulative[i - 1] *= sc[i];
+    }
+    for (auto& g : gps)
+      if (g.has_norm()) {
+        unsigned i = metanorm[g.norm];
+        if (i > 0) {
+          double f = sc[i];
+          if (invert) f = 1. / f;
+          double s2 = f * g.prior, d = s2 - g.prior;
+          g.sum.s += d * g.sum.tmax;  // delta_sum::addbase
+          g.sum.x += d;
+          normsum[g.norm] += d;
+          g.prior = s2;
+        }
+      }
+  }
+  // cache_prob(recompute) (gibbs.hpp:712-722): the whole current sample under cache counts that restart at the priors
+  LW cache_prob_all() {
+    std::vector<double> ccount(gps.size(), 0.0), csum(nnorm, 0.0);
+    for (size_t i = 0; i < gps.size(); ++i)
+      if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
+    LW w = LW::one();
+    for (auto& blk : sample)
+      for (unsigned pid : blk) {
+        const GibbsParam& g = gps[pid];
+        double q = g.has_norm() ? (ccount[pid]++ / csum[g.norm]++) : g.prior;
+        mul_eq(w, LW::from_real(q));
+      }
+    return w;
+  }
+  bool inferring(unsigned iter) const {  // gibbs.hpp:559-563
+    unsigned start = gopt.prior_inference_start ? gopt.prior_inference_start : gopt.burnin;
+    return gopt.prior_inference_stddev > 0 && start <= iter && (!gopt.prior_inference_end || iter < gopt.prior_inference_end);
+  }
+  // propose_new_priors (gibbs.hpp:525-553); u(0xfffffffe, k) draws scale group k, u(0xffffffff, 0) the acceptance
+  void propose_new_priors(const std::function<double(unsigned, unsigned)>& u, double* tr6) {
+    const double sdev = gopt.prior_inference_stddev;
+    const double q0 = normal_cdf(0, 1, sdev), qrem = 1 - q0;
+    std::vector<double> sc(nexti, 1.0);
+    LW q2_1 = LW::one(), q1_2 = LW::one();
+    for (unsigned i = 1; i < nexti; ++i) {
+      sc[i] = normal_quantile(q0 + u(0xfffffffeu, i) * qrem, 1, sdev);
+      mul_eq(q2_1, LW::from_real(normal_pdf(sc[i], 1, sdev)));
+      mul_eq(q1_2, LW::from_real(normal_pdf(1 / sc[i], 1, sdev)));
+    }
+    LW a2 = q1_2 / q2_1;
+    LW p1 = cache_prob_all();
+    scale_priors(sc, false);
+    LW p2 = cache_prob_all();
+    LW a = (p2 / p1) * a2;
+    bool accept = u(0xffffffffu, 0) < a.getReal();
+    if (!accept) scale_priors(sc, true);
+    if (tr6) {
+      tr6[0] = 1;
+      tr6[1] = accept;
+      tr6[2] = p1.w;
+      tr6[3] = p2.w;
+      tr6[4] = a2.getReal();
+      tr6[5] = a.getReal();
+    }
   }
 
   double proposal_prob(unsigned p) const {  // gibbs.hpp:153-157
@@ -305,7 +420,15 @@ struct CarmelGibbs {
     Stats best;
     std::vector<double> best_prob;
     std::vector<std::vector<unsigned> > best_sample;
+    std::vector<double> priors0;
+    const bool restart_priors = gopt.restarts > 0 && gopt.prior_inference_restart_fresh;  // gibbs.hpp:889-898
+    if (restart_priors)
+      for (auto& g : gps) priors0.push_back(g.prior);
     for (unsigned r = 0; r <= gopt.restarts; ++r) {
+      if (r > 0 && restart_priors) {
+        for (size_t i = 0; i < gps.size(); ++i) gps[i].prior = priors0[i];
+        cumulative.assign(nexti - 1, 1.0);
+      }
       Stats st = run_one(u, tr, r);
       if (r == 0 || st.better(best, gopt)) {
         best_run = r;
@@ -317,6 +440,7 @@ struct CarmelGibbs {
       }
     }
     sample = best_sample;
+    if (tr) tr->cumulative = cumulative;
     if (tr && !gopt.expectation) tr->last_sample = sample;  // (gibbs.cc:259-260: no single sample with --expectation)
     else if (tr) tr->last_sample.assign(sample.size(), {});
     // probs_to_cascade gibbs.cc:66-76
@@ -373,7 +497,14 @@ struct CarmelGibbs {
         for (unsigned pid : sample[b]) mul_eq(pself, LW::from_real(proposal_prob(pid)));
       }
 
+      double tr6[6] = {0, 0, 0, 0, 0, 0};
+      if (iter > 0 && inferring(iter)) {  // gibbs.hpp:874-875
+        if (gopt.expectation) throw std::runtime_error("prior inference not yet supported for expectation");
+        const unsigned sweep = run_index * (Ni + 1) + iter;
+        propose_new_priors([&](unsigned b, unsigned k) { return u(sweep, b, k); }, tr6);
+      }
       if (tr) {
+        tr->prior_trace.insert(tr->prior_trace.end(), tr6, tr6 + 6);
         tr->iter_logprob.push_back(pc.w);
         tr->iter_cheap_logprob.push_back(p.w);
         tr->iter_after_logprob.push_back(pself.w);

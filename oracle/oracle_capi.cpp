@@ -352,6 +352,27 @@ void orc_set_gibbs_init_em(unsigned n, int em_p0) {
 }
 static int g_init_from_p0 = 0;  // --init-from-p0 (gibbs.cc:405-421)
 void orc_set_gibbs_init_from_p0(int on) { g_init_from_p0 = on; }
+// --prior-inference-* / --prior-groupby, set before orc_gibbs_run; the trace of the last run
+static double g_pi_stddev = 0;
+static int g_pi_global = 0, g_pi_local = 0, g_pi_fresh = 0;
+static unsigned g_pi_start = 0, g_pi_end = 0;
+static std::vector<int> g_pi_groupby;
+static std::vector<double> g_last_prior_trace, g_last_cumulative;
+void orc_set_gibbs_prior_inference(double stddev, int global, int local, int restart_fresh, uint32_t start, uint32_t end,
+                                   const int* groupby, uint32_t n) {
+  g_pi_stddev = stddev;
+  g_pi_global = global;
+  g_pi_local = local;
+  g_pi_fresh = restart_fresh;
+  g_pi_start = start;
+  g_pi_end = end;
+  g_pi_groupby.assign(groupby, groupby + (groupby ? n : 0));
+}
+uint32_t orc_gibbs_last_prior_trace(double* out6, uint32_t n_sweeps, double* cumulative, uint32_t n_cum) {
+  for (size_t k = 0; k < (size_t)n_sweeps * 6; ++k) out6[k] = k < g_last_prior_trace.size() ? g_last_prior_trace[k] : 0.0;
+  for (uint32_t k = 0; k < n_cum; ++k) cumulative[k] = k < g_last_cumulative.size() ? g_last_cumulative[k] : 1.0;
+  return (uint32_t)g_last_cumulative.size();
+}
 static std::vector<double> g_last_after;  // GibbsTrace::iter_after_logprob of the last orc_gibbs_run
 void orc_gibbs_last_after(double* out, uint32_t n) {
   for (uint32_t i = 0; i < n && i < g_last_after.size(); ++i) out[i] = g_last_after[i];
@@ -784,6 +805,9 @@ void orc_cascade_dims(orc_cascade* h, uint64_t* dims) {
   for (auto& c : h->cascade.chains) ne += c.size();
   dims[3] = ne;
 }
+void orc_cascade_member_states(orc_cascade* h, uint32_t* n_states) {
+  for (size_t m = 0; m < h->chain.size(); ++m) n_states[m] = h->chain[m].num_states();
+}
 // parameters = member arcs concatenated in visit order; chains reference them by index
 void orc_cascade_export(orc_cascade* h, double* param_logw, uint32_t* param_group, uint32_t* param_member,
                         uint32_t* param_src, uint32_t* param_in, uint64_t* chain_off, uint64_t* chain_param) {
@@ -855,6 +879,13 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.final_counts = final_counts != 0;
     go.exclude_prior = exclude_prior != 0;
     if (go.final_counts) go.burnin = go.iter;  // gibbs_opts.hpp validate()
+    go.prior_inference_stddev = g_pi_stddev;
+    go.prior_inference_global = g_pi_global != 0;
+    go.prior_inference_local = g_pi_local != 0;
+    go.prior_inference_restart_fresh = g_pi_fresh != 0;
+    go.prior_inference_start = g_pi_start;
+    go.prior_inference_end = g_pi_end;
+    go.priorgroup = g_pi_groupby;
     std::vector<double> init_logw;
     if (g_init_em > 0) {  // WFST::train_gibbs (gibbs.cc:400-423): EM without priors for the first sample's weights
       std::vector<std::vector<LW> > saved;
@@ -903,6 +934,8 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     g_best_run = (int)g.best_run;
     g_last_after = tr.iter_after_logprob;
+    g_last_prior_trace = tr.prior_trace;
+    g_last_cumulative = tr.cumulative;
     for (uint32_t i = 0; i < (iter + 1) * (go.restarts + 1); ++i) {
       if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
       if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];

@@ -621,3 +621,47 @@ def test_cache_options_change_nothing_about_the_results(golden_dir):
         if "-?" in extra:
             assert "Pre pruning: (" in err and "Post pruning: (" in err
     assert "Pre pruning" not in err0
+
+
+def test_crp_prior_inference_command(golden_dir, tmp_path, oracle):
+    """carmel --crp --prior-inference-stddev=0.05 --prior-groupby=12 --prior-inference-show (carmel.cc:291-294, 491-497;
+    gibbs.hpp:525-563): priors default to 1, every sweep from burn-in on proposes new prior scales, the log says what was
+    decided, and the trained transducer is the oracle's on the same uniforms"""
+    import numpy as np
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    rc, out, err = run(["--crp", "-M", "14", "--burnin=4", "--prior-inference-stddev=0.05", "--prior-groupby=11",
+                        "--prior-inference-show", "--prior-inference-start=2", "-R", "21", "-HJ", g("cipher.data"),
+                        g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc == 0, err
+    assert "--prior-inference-start is not read by carmel" in err
+    lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
+    assert len(lines) == 15
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()),
+                           lambda i, b, s: lib.carmel_hip_gibbs_uniform(21, i, b, s), normby="CC", priors=[1.0, 1.0],
+                           iters=14, burnin=4, prior_inference=dict(stddev=0.05, groupby=[1, 1]))
+    tr = ref["prior_trace"]
+    for i, l in enumerate(lines):
+        said = "accepted" if " accepted new priors with p1=" in l else "rejected" if " rejected new priors with p1=" in l else None
+        want = None if tr[i, 0] == 0 else ("accepted" if tr[i, 1] else "rejected")
+        assert said == want, l
+        if want:
+            assert float(re.search(r"p_accept=(\S+)\. ", l).group(1)) == pytest.approx(tr[i, 5], rel=1e-5)
+    assert tr[:4, 0].sum() == 0 and tr[4:, 0].all()
+    final = re.search(r"Final prior-scale=\[(.*)\]", err).group(1).split()
+    np.testing.assert_allclose([float(x) for x in final], ref["prior_cumulative"], rtol=1e-5)
+    logged = [float(re.search(r"prob=2\^(\S+)", l).group(1)) for l in lines]
+    for a, b in zip(logged, ref["iter_logprob"] / math.log(2)):
+        assert a == pytest.approx(b, rel=2e-6)
+    exp_txt = oc.write_member(1, ref["param_logw"])
+    got_txt = open(os.path.join(str(tmp_path), "cipher.fst.trained")).read()
+    gl, el = got_txt.strip().split("\n"), exp_txt.strip().split("\n")
+    assert len(gl) == len(el)
+    for x, y in zip(gl, el):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-7)
+    rc, out, err = run(["--crp", "-M", "3", "--prior-inference-stddev=0.1", "--prior-groupby=13", g("cipher.data"),
+                        g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc != 0 and "prior-groupby characters must be 0" in err

@@ -127,7 +127,7 @@ def test_unimplemented_switches_are_refused(golden_dir):
     """a switch or option outside the training path exits -12 with a message instead of being accepted and ignored
     (the verdict of round 1: `-a`, `-B`, `-k n` were swallowed; carmel.cc:1137 is the reference's own -12)"""
     path = os.path.join(golden_dir, "train.a.w")
-    for args in (["-k", "3", path], ["-g", "5", path], ["--prior-inference-stddev=0.5", "-t", path, path], ["-v", path], ["-N", "0", path],
+    for args in (["-k", "3", path], ["-g", "5", path], ["-v", path], ["-N", "0", path],
                  ["--project-left", path], ["-tx", path, path]):
         rc, out, err = run(*args)
         assert rc == 256 - 12, (args, rc, err)

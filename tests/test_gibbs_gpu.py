@@ -225,3 +225,58 @@ def test_gibbs_exact_chain_on_random_cascades(oracle, seed):
     np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
     gs.close()
     fb.close()
+
+
+_PI_CASES = [dict(stddev=0.1), dict(stddev=0.3, global_=True), dict(stddev=0.2, local=True),
+             dict(stddev=0.25, groupby=[2, 1]), dict(stddev=0.25, groupby=[0, 2]), dict(stddev=0.5, start=1, end=5),
+             dict(stddev=0.2, restart_fresh=True, restarts=2), dict(stddev=0.2, restarts=1)]
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_gibbs_prior_scale_inference_follows_the_oracle(oracle, seed):
+    """--prior-inference-stddev / -global / -local / -restart-fresh / -start / -end and --prior-groupby
+    (gibbs.hpp:404-563): after every inferring sweep the priors of each scale group are proposed to move by a truncated
+    N(1, stddev) factor and the move is accepted by the Metropolis-Hastings ratio of the whole sample's cache-model
+    probability.  Same proposals, same accept/reject decisions, same probabilities, same samples and final weights as
+    the oracle's restatement on the same uniforms."""
+    from carmel_amd.trainer import HipGibbs
+    a, b, corpus_text, normby, priors = _random_cascade_case(oracle, seed)
+    norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
+    oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
+    case = dict(_PI_CASES[seed % len(_PI_CASES)])
+    restarts = case.pop("restarts", 0)
+    iters, burnin = 9, 2
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=11 + seed, mode=0, restarts=restarts)
+    gs.set_prior_inference(n_states=oc.member_states, **case)
+    got_lp = gs.run()
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin,
+                           restarts=restarts, prior_inference=case)
+    tr, cum = gs.prior_trace()
+    rt = ref["prior_trace"]
+    assert tr[:, 0].sum() > 0                                   # proposals were made ...
+    np.testing.assert_array_equal(tr[:, :2], rt[:, :2])         # ... on the same sweeps, with the same decisions
+    np.testing.assert_allclose(tr[:, 2:4], rt[:, 2:4], rtol=1e-10)
+    np.testing.assert_allclose(tr[:, 4:], rt[:, 4:], rtol=1e-7)
+    np.testing.assert_allclose(cum, ref["prior_cumulative"], rtol=1e-12)
+    for blk in range(gs.n_blocks):
+        assert gs.sample(blk) == ref["samples"][blk]
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    assert gs.best_run == ref["best_run"]
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
+
+
+def test_gibbs_prior_inference_is_refused_outside_the_exact_sampler(oracle):
+    """gibbs.hpp:528-529: prior inference needs the cache-model probability of single samples"""
+    from carmel_amd.trainer import HipGibbs
+    from carmel_amd._capi import CarmelHipError
+    a, b, corpus_text, normby, priors = _random_cascade_case(oracle, 0)
+    norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
+    oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
+    for kw in (dict(mode=1), dict(expectation=True)):
+        gs = HipGibbs(fb, 3, seed=1, **kw)
+        with pytest.raises(CarmelHipError):
+            gs.set_prior_inference(0.1)
+        gs.close()
+    fb.close()

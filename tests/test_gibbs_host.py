@@ -70,3 +70,34 @@ def test_oracle_sampler_reaches_the_recorded_probability_level(oracle, golden_di
     assert abs(after[100:].mean() - level) < 0.002 * abs(level)
     assert after[1] < after[10] < after[100:].mean() + 300  # climbs from the random first sample, as the recorded one does
     assert ref["iter_logprob"][100:].mean() / math.log(2) < level - 20000  # the cache-model probability is another quantity
+
+
+def test_oracle_prior_scale_inference_invariants(oracle):
+    """the restatement of propose_new_priors (gibbs.hpp:525-553) on the tutorial's tagging cascade: p1 -- the cache-model
+    probability of the whole sample recomputed under the current priors -- is the probability the sweep itself logged;
+    rejected proposals leave the cumulative scales alone; the quantile used for the truncated N(1, sdev) inverts the cdf"""
+    import os
+    import numpy as np
+    g = lambda n: os.path.join(os.path.dirname(__file__), "golden", n)
+    texts = [open(g(n)).read() for n in ("cipher.wfsa", "cipher.fst")]
+    oc = oracle.OracleCascade(texts)
+    corp = oc.corpus(open(g("cipher.data")).read())
+    rng = np.random.default_rng(5)
+    table = {}
+
+    def u(it, blk, step):
+        return table.setdefault((it, blk, step), float(rng.random()))
+    iters = 12
+    ref = oracle.gibbs_run(oc, corp, u, normby="JC", priors=[0.5, 0.2], iters=iters, burnin=3,
+                           prior_inference=dict(stddev=0.05, groupby=[1, 1]))
+    tr = ref["prior_trace"]
+    assert tr[:3, 0].sum() == 0 and (tr[3:, 0] == 1).all()   # the sweeps from burn-in on infer
+    prop = tr[:, 0] == 1
+    assert prop.sum() == iters - 2
+    np.testing.assert_allclose(tr[prop, 2], ref["iter_logprob"][prop], rtol=1e-12)
+    acc = tr[prop, 1] == 1
+    assert 0 < acc.sum() < prop.sum()   # some accepted, some rejected (seeded)
+    # accepted proposals are exactly those whose uniform fell below p_accept
+    for it in np.nonzero(prop)[0]:
+        assert (table[(int(it), 0xffffffff, 0)] < tr[it, 5]) == bool(tr[it, 1])
+    assert len(ref["prior_cumulative"]) == 2 and (ref["prior_cumulative"] > 0).all()
