@@ -42,7 +42,8 @@ class LatticeStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_pairs", "n_pairs_kept", "explored_states", "explored_arcs", "kept_states", "kept_arcs",
         "n_cyclic_pairs", "n_bundles", "max_levels", "device_bytes")] + [("build_seconds", C.c_double)] + [
-            (n, C.c_uint64) for n in ("last_pair_explored_states", "last_pair_kept_states", "last_pair_kept_arcs")]
+            (n, C.c_uint64) for n in ("last_pair_explored_states", "last_pair_kept_states", "last_pair_kept_arcs",
+                                      "n_windowed_pairs")]
 
 
 class EstimateResult(C.Structure):

@@ -177,6 +177,8 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
   if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));
+  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
+  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   {
     // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;
     // otherwise -- or with CARMEL_HIP_GPU_BUILD=0 -- the host builder below does the whole corpus
@@ -236,6 +238,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   t->lane_records = L.lane_bwd.size();
   HIPCHK(t->post.alloc(L.n_post));
   HIPCHK(t->wcache.alloc(L.lane_bwd.size()));
+  if (L.lane_spill_rows)
+    HIPCHK(t->lane_spill.alloc(L.lane_spill_rows * 64));
+  else
+    t->lane_spill.release();
   HIPCHK(t->arc_off.upload(L.arc_off, s));
   HIPCHK(t->slot_pos.upload(L.slot_pos, s));
   HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
@@ -302,7 +308,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     fprintf(stderr, "timing: layout lane_arcs=%llu lane_groups=%zu lane_pieces=%zu bundles=%zu bundle_classes=%zu total_arcs=%llu aligned=%d\n",
             (unsigned long long)L.lane_arcs, L.lane_groups.size(), L.lane_classes.size(), L.bundles.size(), L.classes.size(),
             (unsigned long long)L.total_arcs, (int)L.lane_tiles_aligned);
-    for (auto& lc : L.lane_classes) fprintf(stderr, "timing:   lane piece groups=%u max_states=%u tiles=%u\n", lc.count, lc.max_states, lc.tile_count);
+    for (auto& lc : L.lane_classes) fprintf(stderr, "timing:   lane piece groups=%u %s=%u tiles=%u\n", lc.count, lc.windowed ? "window" : "max_states", lc.max_states, lc.tile_count);
     for (auto& lc : L.classes) fprintf(stderr, "timing:   bundle class count=%u block=%u max_states=%u serial=%d\n", lc.count, lc.block, lc.max_states, (int)lc.serial);
   }
   t->have_lattices = true;
@@ -326,6 +332,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     stats->last_pair_explored_states = L.last_pre_states;
     stats->last_pair_kept_states = L.last_post_states;
     stats->last_pair_kept_arcs = L.last_post_arcs;
+    stats->n_windowed_pairs = 0;
+    for (auto& g : L.lane_groups)
+      if (g.window) stats->n_windowed_pairs += g.n_lanes;
   }
   return CARMEL_HIP_OK;
 }
@@ -689,6 +698,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.wcache = t->wcache.p;
   LA.scalars = t->counts_ptr() + t->w.n_arcs;
   LA.pair_logprob = t->pair_logprob.p;
+  LA.spill = t->lane_spill.p;
   LA.first_group = 0;
   LA.trace = nullptr;
   static const char* trace_path = getenv("CARMEL_HIP_LANE_TRACE");  // experiment: per-wave cycle stamps of the last E-step

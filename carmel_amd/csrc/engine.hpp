@@ -143,7 +143,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only
   DevBuf<uint32_t> lane_fwdx; // source | backward position | flags words only (transposition path)
   DevBuf<uint32_t> lane_pair, lane_nstates;
-  DevBuf<double> lane_logw, post, wcache;
+  DevBuf<double> lane_logw, post, wcache, lane_spill;
   DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;
   uint64_t lane_records = 0;
   uint64_t device_bytes = 0;

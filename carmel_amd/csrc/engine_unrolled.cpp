@@ -153,6 +153,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
     stats->kept_arcs = M.lattice_arcs;
     stats->n_bundles = 0;  // nothing is laid out: the lattices are implicit
     stats->last_pair_explored_states = stats->last_pair_kept_states = stats->last_pair_kept_arcs = 0;  // not tracked per pair
+    stats->n_windowed_pairs = 0;
     stats->max_levels = M.max_len + 1;
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

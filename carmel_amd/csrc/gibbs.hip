@@ -828,6 +828,7 @@ int carmel_hip_gibbs_lattice_stats(carmel_hip_gibbs* g, carmel_hip_lattice_stats
   st->last_pair_explored_states = L.last_pre_states;
   st->last_pair_kept_states = L.last_post_states;
   st->last_pair_kept_arcs = L.last_post_arcs;
+  st->n_windowed_pairs = 0;
   return CARMEL_HIP_OK;
 }
 

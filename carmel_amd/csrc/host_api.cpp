@@ -1,6 +1,8 @@
 // host_api.cpp — host-only inspection entry points (no GPU needed): build the lattices exactly as
 // carmel_hip_build_lattices does and hand the batched-CSR image back, so the layout can be checked against the
 // oracle on machines without a device.  Nothing here computes forward/backward values.
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include "../../include/carmel_hip.h"
@@ -47,6 +49,8 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   if (small_pairs) opt.small_pairs = small_pairs;
   if (small_states) opt.small_states = small_states;
   if (lane_states >= 0) opt.lane_states = (uint32_t)lane_states;
+  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
+  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
     delete h;
     return CARMEL_HIP_ERR_ARG;

@@ -84,7 +84,10 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 // PRE: the weights were already laid out in lattice order (wcache, by the blocked transposition): the forward pass
 // reads them there (rows, near-coalesced) instead of gathering logw[arc] and stores nothing.
 #define LANE_W(r) (PRE ? wcache[(size_t)(((r).x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] : logw[(r).y])
-template <int R, int W, bool PRE, typename LSE = Lse>
+// WIN: windowed groups (LaneGroup::window): state s lives at LDS row s mod window; the forward values are also parked in
+// the group's global column (spill) and the backward pass gathers alpha[source] per record from there, two pipeline stages
+// like the forward pass's weight gather (the backward record carries its arc's source state), instead of reading it from LDS.
+template <int R, int W, bool PRE, typename LSE = Lse, bool WIN = false>
 __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   constexpr int U = (int)LANE_CHUNK;  // a group's row count is a multiple of U (host padding): chunks are never partial
   static_assert(W >= 1 && W < R, "gather lead must be shorter than the record lead");
@@ -95,6 +98,8 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   const uint32_t S = active ? A.lane_nstates[g.pair_base + lane] : 0u;
   const double* __restrict__ logw = A.logw;
   double* col = lds + lane;
+  const uint32_t wm = WIN ? g.window - 1u : 0xffffffffu;
+  double* spill = WIN ? A.spill + (size_t)g.spill_row * 64 + lane : nullptr;
   const uint32_t maxlen = g.maxlen;
   const uint32_t lastk = maxlen - 1;  // prefetches past the end re-read the last row: every load is unconditional
   double* wcache = A.wcache + g.stream_base + lane;
@@ -110,6 +115,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     const uint32_t* __restrict__ fx = A.fwdx + g.stream_base + lane;       // PRE: the flags word alone
 #define LANE_FREC(k) (PRE ? make_uint2(fx[(size_t)(k) * 64], 0u) : f[(size_t)(k) * 64])
     if (active) col[0] = 0.0;
+    if (WIN && active) spill[0] = 0.0;
     uint2 rq[R][U];   // slot j: records of chunk c with c % R == j
     double wq[R][U];  // slot j: their weights
 #pragma unroll
@@ -136,11 +142,12 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
       const uint32_t src = x & LANE_STATE_MASK;                                                       \
       const double w = wq[j][u];                                                                      \
       if (!PRE) wcache[(size_t)((x >> LANE_POS_SHIFT) & LANE_POS_MAX) * 64] = w;                      \
-      const double a_src = (src + 1 == d) ? prev : col[src * 64];                                     \
+      const double a_src = (src + 1 == d) ? prev : col[(src & wm) * 64];                              \
       acc.add((x & LANE_VALID) ? a_src + w : NEG_INF);                                                \
       if (x & LANE_LAST) {                                                                            \
         prev = acc.value();                                                                           \
-        col[d * 64] = prev;                                                                           \
+        col[(d & wm) * 64] = prev;                                                                    \
+        if (WIN) spill[(size_t)d * 64] = prev;                                                        \
         ++d;                                                                                          \
         acc.init();                                                                                   \
       }                                                                                               \
@@ -167,19 +174,21 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   // ---------- ln p(pair), corpus scalars, beta at the goal ----------
   double next = NEG_INF;  // beta[s+1] in a register
   if (active) {
-    const double lp = col[(S - 1) * 64];
+    const double lp = col[((S - 1) & wm) * 64];
     const double lwt = A.lane_logw[g.pair_base + lane];
     A.pair_logprob[A.lane_pair[g.pair_base + lane]] = lp;  // the corpus scalars are reduced from these afterwards
     next = (lp == NEG_INF) ? NEG_INF : lwt - lp;  // folds "* weight / prob" (derivations.h:445)
-    col[(S - 1) * 64] = next;
+    col[((S - 1) & wm) * 64] = next;
   }
   // ---------- backward + posteriors ----------
   {
-    if (!PRE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache stores before its re-reads
+    if (!PRE || WIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache / spill stores before its re-reads
     const uint32_t* __restrict__ b = A.bwd + g.stream_base + lane;
     double* __restrict__ post = A.post + g.stream_base + lane;
     uint32_t xq[R][U];
     double wq[R][U];
+    double aq[WIN ? R : 1][U];  // WIN: alpha[source] of the records in xq
+#define LANE_ASRC(x) spill[(size_t)(((x) >> LANE_POS_SHIFT) & LANE_STATE_MASK) * 64]
 #pragma unroll
     for (int j = 0; j < R; ++j)
 #pragma unroll
@@ -189,30 +198,40 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
         xq[j][u] = b[kk];
         wq[j][u] = wcache[kk];
       }
+    if (WIN) {
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+#pragma unroll
+        for (int u = 0; u < U; ++u) aq[WIN ? j : 0][u] = LANE_ASRC(xq[j][u]);
+    }
     LSE acc;
     acc.init();
     uint32_t s = S >= 2 ? S - 2 : 0u;
-    double al = (S >= 2) ? col[s * 64] : NEG_INF;
+    double al = (!WIN && S >= 2) ? col[s * 64] : NEG_INF;
     // phase 1 of a step is the recurrence (cheap, serial): beta chain + the exponent of every posterior; phase 2 is
     // branch-free: the U exponentials are independent and overlap in the pipeline.  Padding rows get exp(-inf) = 0
     // (never read: count_reduce only visits valid slots).
 #define LANE_BWD_STEP(j, kb)                                                                          \
   {                                                                                                   \
     double arg[U];                                                                                    \
+    if (WIN) {                                                                                        \
+      _Pragma("unroll") for (int u = 0; u < U; ++u)                                                   \
+        aq[WIN ? ((j) + W) % R : 0][u] = LANE_ASRC(xq[((j) + W) % R][u]);                             \
+    }                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
       const uint32_t x = xq[j][u];                                                                    \
       const uint32_t dst = x & LANE_STATE_MASK;                                                       \
-      const double b_dst = (dst == s + 1) ? next : col[dst * 64];                                     \
+      const double b_dst = (dst == s + 1) ? next : col[(dst & wm) * 64];                              \
       const double t = (x & LANE_VALID) ? wq[j][u] + b_dst : NEG_INF;                                 \
       acc.add(t);                                                                                     \
-      arg[u] = al + t;                                                                                \
+      arg[u] = (WIN ? aq[WIN ? (j) : 0][u] : al) + t;                                                 \
       if (x & LANE_LAST) {                                                                            \
         next = acc.value();                                                                           \
-        col[s * 64] = next; /* beta[s] replaces alpha[s] */                                           \
+        col[(s & wm) * 64] = next; /* beta[s] replaces alpha[s] */                                    \
         acc.init();                                                                                   \
         if (s > 0) {                                                                                  \
           --s;                                                                                        \
-          al = col[s * 64];                                                                           \
+          if (!WIN) al = col[s * 64];                                                                 \
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
@@ -233,6 +252,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
     for (int j = 0; j < R - 1; ++j)
       if (k0 + (uint32_t)(j * U) < maxlen) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
 #undef LANE_BWD_STEP
+#undef LANE_ASRC
 #undef LANE_W
   }
   if (lane == 0) {
@@ -1022,11 +1042,11 @@ static inline int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
-template <int R, int W, bool PRE>
+template <int R, int W, bool PRE, bool WIN = false>
 static hipError_t launch_lane_variant(const LaneArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((sweep_lane_kernel<R, W, PRE>), dim3(grid), dim3(64), lds, stream, A);
+    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, PRE, Lse, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sweep_lane_kernel<R, W, PRE, Lse, WIN>), dim3(grid), dim3(64), lds, stream, A);
   return hipGetLastError();
 }
 
@@ -1037,6 +1057,18 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   static const int lds_scale = getenv("CARMEL_HIP_LANE_LDS_SCALE") ? atoi(getenv("CARMEL_HIP_LANE_LDS_SCALE")) : 1;
   lds *= lds_scale;  // occupancy experiment
   static const int V = getenv("CARMEL_HIP_LANE_VARIANT") ? atoi(getenv("CARMEL_HIP_LANE_VARIANT")) : 0;  // tuning knob
+  if (lc.windowed) {
+    if (!A.spill) return hipErrorInvalidValue;
+    if (A.pre_weights) {
+      switch (V) {  // tagging cascade x400: <4,2> 495 us, <4,1> 511, <3,1> 534, <3,2> 643
+        case 6: return launch_lane_variant<3, 1, true, true>(A, lc.count, lds, stream);
+        case 3: return launch_lane_variant<4, 1, true, true>(A, lc.count, lds, stream);
+        case 5: return launch_lane_variant<3, 2, true, true>(A, lc.count, lds, stream);
+        default: return launch_lane_variant<4, 2, true, true>(A, lc.count, lds, stream);
+      }
+    }
+    return launch_lane_variant<4, 2, false, true>(A, lc.count, lds, stream);
+  }
   if (A.pre_weights) {
     switch (V) {  // streaming only: two chunks ahead is enough, and the smaller ring leaves more registers / less code
       case 1: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);

@@ -24,6 +24,7 @@ struct LaneArgs {
   double* wcache;        // weight of the arc at BACKWARD-stream position k (written forward, streamed backward)
   double* scalars;       // {sum ln p, sum weight*ln p, n pairs, -}
   double* pair_logprob;
+  double* spill;         // windowed groups: forward values, one column of 64-lane rows per group (LaneGroup::spill_row)
   uint32_t first_group;
   uint32_t pre_weights;  // wcache already holds every arc's weight at its backward position (blocked transposition)
   unsigned long long* trace;  // experiment: per-block {t_start, t_mid, t_end, hw id} (CARMEL_HIP_LANE_TRACE)

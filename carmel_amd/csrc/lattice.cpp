@@ -70,6 +70,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt) {
       size_t j = i + 1;
       while (j < ng) {
         uint32_t m = out.lane_groups[j].max_states;
+        if ((out.lane_groups[j].window != 0) != (out.lane_groups[i].window != 0)) break;  // two kernels
         if (m > mx) mx = m;
         // a class costs a launch (ramp-up + tail); it only pays when the LDS saved buys occupancy that matters:
         // below ~20 KB per wave (8 waves per CU) the sweep is already bound by the random-gather rate
@@ -81,6 +82,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt) {
       lc.first = (uint32_t)i;
       lc.count = (uint32_t)(j - i);
       lc.max_states = mx;
+      lc.windowed = out.lane_groups[i].window != 0;
       classes.push_back(lc);
       i = j;
     }
@@ -231,6 +233,7 @@ struct Scratch {
   std::vector<uint8_t> removed;
   std::vector<PairLattice::E> edges;
   std::vector<uint32_t> a, b, c, d;
+  std::vector<uint32_t> span_cnt, span_id;
 };
 
 inline void key_range(const HostWfst& w, uint32_t s, uint64_t key, uint64_t& lo, uint64_t& hi) {
@@ -551,6 +554,20 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
                                   c.out_sym.data() + c.out_off[p], (uint32_t)(c.out_off[p + 1] - c.out_off[p]),
                                   opt.prune, lats[p], hd, sc);
           out.has_deriv[p] = hd;
+          PairLattice& L = lats[p];
+          if (hd && !L.cyclic && opt.lane_window && L.n_states > opt.lane_window_min && L.n_states <= LANE_STATE_MASK) {
+            // the lane layout numbers the states by (level, id): how far apart are the ends of an arc there?
+            std::vector<uint32_t>& cnt = sc.span_cnt;
+            std::vector<uint32_t>& nid = sc.span_id;
+            cnt.assign((size_t)L.n_levels + 2, 0);
+            for (uint32_t st = 0; st < L.n_states; ++st) cnt[L.level[st] + 1]++;
+            for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
+            nid.resize(L.n_states);
+            for (uint32_t st = 0; st < L.n_states; ++st) nid[st] = cnt[L.level[st]]++;
+            uint32_t sp = 1;
+            for (auto& e : L.edges) sp = std::max(sp, nid[e.dst] - nid[e.src]);
+            L.span = sp;
+          }
         }
       }
     };
@@ -575,11 +592,29 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   // ---- pack into bundles ----
   // small lattices: sort by (levels, states) so that a bundle's members have similar depth (level-synchronous
   // sweeps idle the lanes of members that ran out of levels)
-  std::vector<uint32_t> small, big, cyc, lane;
+  std::vector<uint32_t> small, big, cyc, lane, lane_win;
+  // ring of LDS rows a windowed lattice needs: the power of two above its span
+  // Windows cost a launch class, a second kernel and 16 B of traffic per state: they are used when lattices above
+  // lane_window_min states carry a tenth of the corpus' arcs (the tagging cascade: nearly all; config 4: none -- and the
+  // GPU builder, which lays out plain groups only, applies the same rule to decide whether the corpus is its case)
+  uint64_t arcs_all = 0, arcs_big = 0;
+  for (uint32_t p : kept) {
+    arcs_all += lats[p].edges.size();
+    if (lats[p].n_states > opt.lane_window_min) arcs_big += lats[p].edges.size();
+  }
+  const bool use_window = opt.lane_window && arcs_big * 10 >= arcs_all;
+  auto window_of = [&](const PairLattice& L) -> uint32_t {
+    if (!use_window || !L.span) return 0u;
+    uint32_t w = 8;
+    while (w < L.span + 1) w <<= 1;
+    return (w <= opt.lane_window && w < L.n_states) ? w : 0u;
+  };
   for (uint32_t p : kept) {
     const PairLattice& L = lats[p];
     if (L.cyclic)
       cyc.push_back(p);
+    else if (opt.lane_states && window_of(L) && L.edges.size() <= LANE_POS_MAX)
+      lane_win.push_back(p);
     else if (opt.lane_states && L.n_states <= opt.lane_states && L.n_states <= LANE_STATE_MASK &&
              L.edges.size() <= LANE_POS_MAX)
       lane.push_back(p);
@@ -594,30 +629,57 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   });
   std::stable_sort(big.begin(), big.end(), [&](uint32_t a, uint32_t b) { return lats[a].n_states < lats[b].n_states; });
   // ---- lane groups: one lattice per lane, 64 per wavefront ----
-  if (!lane.empty()) {
+  if (!lane.empty() || !lane_win.empty()) {
     std::stable_sort(lane.begin(), lane.end(), [&](uint32_t a, uint32_t b) {
       if (lats[a].edges.size() != lats[b].edges.size()) return lats[a].edges.size() > lats[b].edges.size();
       return lats[a].n_states > lats[b].n_states;
     });
-    size_t ng = (lane.size() + 63) / 64;
+    // windowed lattices: by window first (a group's ring is its widest member's), then by length
+    std::stable_sort(lane_win.begin(), lane_win.end(), [&](uint32_t a, uint32_t b) {
+      const uint32_t wa = window_of(lats[a]), wb = window_of(lats[b]);
+      if (wa != wb) return wa > wb;
+      if (lats[a].edges.size() != lats[b].edges.size()) return lats[a].edges.size() > lats[b].edges.size();
+      return lats[a].n_states > lats[b].n_states;
+    });
+    // plain groups, then windowed groups (a group never mixes the two): `lane` becomes one slot per lane, 64 per group
+    const size_t ng_plain = (lane.size() + 63) / 64, ng = ng_plain + (lane_win.size() + 63) / 64;
+    {
+      std::vector<uint32_t> slots(ng * 64, 0xffffffffu);
+      std::copy(lane.begin(), lane.end(), slots.begin());
+      std::copy(lane_win.begin(), lane_win.end(), slots.begin() + ng_plain * 64);
+      lane.swap(slots);
+    }
     out.lane_groups.resize(ng);
     out.lane_pair.assign(ng * 64, 0xffffffffu);
     out.lane_nstates.assign(ng * 64, 0);
     out.lane_logw.assign(ng * 64, 0.0);
+    uint64_t spill_rows = 0;
     for (size_t g = 0; g < ng; ++g) {
       LaneGroup& G = out.lane_groups[g];
       std::memset(&G, 0, sizeof G);
-      size_t l0 = g * 64, l1 = std::min(lane.size(), l0 + 64);
+      size_t l0 = g * 64, l1 = l0;
+      while (l1 < l0 + 64 && lane[l1] != 0xffffffffu) ++l1;
       G.n_lanes = (uint32_t)(l1 - l0);
       G.pair_base = (uint32_t)l0;
-      uint32_t ml = 0, ms = 0;
+      uint32_t ml = 0, ms = 0, win = 0;
       for (size_t l = l0; l < l1; ++l) {
         ml = std::max<uint32_t>(ml, (uint32_t)lats[lane[l]].edges.size());
         ms = std::max(ms, lats[lane[l]].n_states);
+        if (g >= ng_plain) win = std::max(win, window_of(lats[lane[l]]));
       }
       G.maxlen = (std::max<uint32_t>(ml, 1) + LANE_CHUNK - 1) / LANE_CHUNK * LANE_CHUNK;
-      G.max_states = ms;
+      G.max_states = win ? win : ms;
+      G.window = win;
+      if (win) {
+        if (spill_rows + ms > 0xffffffffull) {
+          err = "too many windowed lattice states for one trainer";
+          return false;
+        }
+        G.spill_row = (uint32_t)spill_rows;
+        spill_rows += ms;
+      }
     }
+    out.lane_spill_rows = spill_rows;
     const uint64_t base = assign_lane_classes(out, opt);
     out.lane_fwd.assign(base, uint2_t{0, 0});
     out.lane_bwd.assign(base, uint2_t{0, 0});
@@ -676,7 +738,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
               if (sidx == S - 1) continue;  // the goal has no out-arcs
               for (uint32_t k = ooff[sidx]; k < ooff[sidx + 1]; ++k) {
                 const auto& e = L.edges[oe[k]];
-                uint32_t x = newid[e.dst] | LANE_VALID | (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
+                uint32_t x = newid[e.dst] | (sidx << LANE_POS_SHIFT) | LANE_VALID | (k + 1 == ooff[sidx + 1] ? LANE_LAST : 0u);
                 fpos[oe[k]] = (uint32_t)pos;
                 b[(pos++) * 64] = uint2_t{x, e.arc};
               }
@@ -699,6 +761,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     lwork();
     for (auto& t : th) t.join();
     for (uint32_t p : lane) {
+      if (p == 0xffffffffu) continue;
       out.lane_states += lats[p].n_states;
       out.lane_arcs += lats[p].edges.size();
       out.max_levels = std::max<uint64_t>(out.max_levels, lats[p].n_levels);

@@ -44,6 +44,7 @@ struct PairLattice {
   };
   std::vector<E> edges;
   uint64_t explored_states = 0, explored_arcs = 0;
+  uint32_t span = 0;  // max over the arcs of (dst - src) in the (level, id) numbering of the lane layout; 0 = not computed
 };
 
 // A bundle = lattices swept together by one workgroup.  All indices below are bundle-local.
@@ -71,7 +72,12 @@ struct uint2_t {
 // grouped by source in reverse topological order) and the 64 streams are interleaved record by record, so every
 // wave-wide load is one coalesced 512-byte row and the topology needs no offsets, no levels and no barriers.
 // record.x = local state index (bits 0..9) | [forward records: backward position of the same arc, bits 10..29]
-//            | LANE_VALID | LANE_LAST (last arc of its state); record.y = WFST arc id
+//            | [backward records: the arc's SOURCE state, bits 10..19] | LANE_VALID | LANE_LAST (last arc of its state);
+//            record.y = WFST arc id
+// Windowed groups (LaneGroup::window = W, a power of two): every arc of every lattice in the group spans fewer than W states
+// of the topological numbering, so the sweep keeps only a ring of W values per lane in LDS (state s at row s mod W) and
+// parks the forward values in a global column (lane_spill) for the backward pass.  LDS per wave: 512 B * W instead of
+// 512 B * states -- what decides how many waves a CU holds for lattices of a hundred states.
 static const uint32_t LANE_CHUNK = 4;  // a group's row count (maxlen) is a multiple of this: the kernel consumes whole chunks
 static const uint32_t LANE_LAST = 0x80000000u;
 static const uint32_t LANE_VALID = 0x40000000u;
@@ -101,8 +107,9 @@ struct LaneGroup {        // mirrored on the device, 32 bytes
   uint32_t maxlen;        // records per lane (shorter lattices are padded with invalid records)
   uint32_t n_lanes;       // lattices in this group (<= 64)
   uint32_t pair_base;     // into lane_pair[] / lane_nstates[] / lane_logw[]
-  uint32_t max_states;
-  uint64_t pad;
+  uint32_t max_states;    // LDS rows the group needs: its largest lattice, or the window
+  uint32_t window;        // 0: the whole column lives in LDS; W: ring of W rows + lane_spill
+  uint32_t spill_row;     // windowed: first row (of 64 doubles) of the group's columns in lane_spill
 };
 static_assert(sizeof(LaneGroup) == 32, "LaneGroup layout");
 
@@ -133,7 +140,9 @@ struct LatticeSet {
   struct LaneClass {
     uint32_t first, count, max_states;
     uint32_t tile_first = 0, tile_count = 0;
+    bool windowed = false;
   };
+  uint64_t lane_spill_rows = 0;  // rows of 64 doubles for the forward values of the windowed groups
   std::vector<LaneClass> lane_classes;
   bool lane_tiles_aligned = false;  // the pieces' tile ranges are disjoint (required for launching the tile passes per piece)
   uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
@@ -170,6 +179,10 @@ struct BuildOptions {
   uint32_t small_states = 2048;    // state cap of a small bundle (16 KiB of f64 in LDS)
   uint32_t lds_states_max = 16384; // one array of f64 in LDS: 128 KiB
   uint32_t lane_states = 96;       // lattices up to this many states go one-per-lane (0 disables lane groups)
+  uint32_t lane_window = 64;       // lattices whose arcs span fewer states than this go one-per-lane with a ring of that
+                                   // many LDS rows whatever their size (up to 1023 states); 0 disables windowed groups
+  uint32_t lane_window_min = 40;   // ... but only lattices above this many states: below ~20 KB of LDS per wave the
+                                   // occupancy is not what bounds the sweep (and the GPU builder covers those)
   uint32_t lane_chunks = 1;        // chunks per lane class (see LatticeSet::LaneClass); 1 = one launch per class (default:
                                    // measured on config 4, four chunks on four streams overlap their kernels but finish no
                                    // sooner -- the E-step is bound by its total HBM traffic -- and cost 46 us of extra tails)

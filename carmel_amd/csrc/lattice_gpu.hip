@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
       for (uint32_t k = ooff2[sidx]; k < ooff2[sidx + 1]; ++k) {
         const uint32_t e = oe[k];
         fpos[e] = (uint16_t)pos;
-        rb[pos] = (uint32_t)newid[e_dst[e]] | LANE_VALID | (k + 1 == ooff2[sidx + 1] ? LANE_LAST : 0u);
+        rb[pos] = (uint32_t)newid[e_dst[e]] | (sidx << LANE_POS_SHIFT) | LANE_VALID | (k + 1 == ooff2[sidx + 1] ? LANE_LAST : 0u);
         ra[pos] = e_arc[e];
         ++pos;
       }
@@ -409,10 +409,11 @@ __global__ void pair_key_kernel(const uint16_t* E, const uint16_t* S, const uint
                                : ~0ull;
 }
 
-// statistics: {pairs kept, fallback pairs, explored states, explored arcs, kept states, kept arcs}
+// statistics: {pairs kept, fallback pairs, explored states, explored arcs, kept states, kept arcs, kept arcs of the lattices
+// above win_min states}
 __global__ void pair_stats_kernel(const uint16_t* E, const uint16_t* S, const uint8_t* flags, const uint32_t* xs, const uint32_t* xa,
-                                  uint64_t n, unsigned long long* out) {
-  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+                                  uint64_t n, uint32_t win_min, unsigned long long* out) {
+  unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
     v[0] += (flags[p] & PF_HAS) ? 1 : 0;
     v[1] += (flags[p] & PF_FALLBACK) ? 1 : 0;
@@ -420,8 +421,9 @@ __global__ void pair_stats_kernel(const uint16_t* E, const uint16_t* S, const ui
     v[3] += xa[p];
     v[4] += S[p];
     v[5] += E[p];
+    v[6] += S[p] > win_min ? E[p] : 0;
   }
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 7; ++k) {
     for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
     if ((threadIdx.x & 63) == 0 && v[k]) atomicAdd(out + k, v[k]);
   }
@@ -869,12 +871,15 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   DevBuf<unsigned long long> d_stats;
   HIPCHK(d_stats.alloc(8));
   HIPCHK(hipMemsetAsync(d_stats.p, 0, 64, s));
-  hipLaunchKernelGGL(pair_stats_kernel, dim3(1024), dim3(256), 0, s, pp_E.p, pp_S.p, pp_flags.p, pp_xs.p, pp_xa.p, np, d_stats.p);
+  hipLaunchKernelGGL(pair_stats_kernel, dim3(1024), dim3(256), 0, s, pp_E.p, pp_S.p, pp_flags.p, pp_xs.p, pp_xa.p, np, opt.lane_window_min, d_stats.p);
   unsigned long long hs[8];
   HIPCHK(hipMemcpyAsync(hs, d_stats.p, 64, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   lap("explore + prune + records");
   if (hs[1]) return CARMEL_HIP_OK;  // some pair is not a case for this builder: the host builder does the whole corpus
+  // a corpus with a tenth of its arcs in lattices above lane_window_min states gets windowed lane groups (lattice.cpp,
+  // the same rule): those are laid out on the host
+  if (opt.lane_window && hs[6] * 10 >= hs[5]) return CARMEL_HIP_OK;
   const uint64_t n_kept = hs[0], n_items = hs[5];
   if (!n_kept || n_items >= (1ull << 32)) return CARMEL_HIP_OK;
   // ---- lane groups ----
@@ -1084,6 +1089,9 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     stats->last_pair_explored_states = L.last_pre_states;
     stats->last_pair_kept_states = L.last_post_states;
     stats->last_pair_kept_arcs = L.last_post_arcs;
+    stats->n_windowed_pairs = 0;
+    for (auto& g : L.lane_groups)
+      if (g.window) stats->n_windowed_pairs += g.n_lanes;
   }
   lap("finish");
   done = true;

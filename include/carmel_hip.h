@@ -73,6 +73,7 @@ typedef struct carmel_hip_lattice_stats {
    * post.states and post.arcs are ASSIGNED per pair -- what is logged is the last pair's (post: the last pair that has a
    * derivation).  commands.trace:6984-6986 pins them on the tagging cascade: (100 states, 182891 arcs) -> (75, 164). */
   uint64_t last_pair_explored_states, last_pair_kept_states, last_pair_kept_arcs;
+  uint64_t n_windowed_pairs; /* lattices swept one per lane through a ring of LDS rows (lattice.hpp, LaneGroup::window) */
 } carmel_hip_lattice_stats;
 
 /* Replaces: cached_derivs::cache_derivations (cached_derivs.h:104-138) -> derivations::init_and_compute

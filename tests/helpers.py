@@ -16,7 +16,7 @@ TRANS_TILE = 16384
 TRANS_BUCKET_DTYPE = np.dtype([("item_base", "<u8"), ("n_items", "<u4"), ("arc_lo", "<u4"), ("n_arcs", "<u4"),
                                ("flags", "<u4")])
 LANE_DTYPE = np.dtype([("stream_base", "<u8"), ("maxlen", "<u4"), ("n_lanes", "<u4"), ("pair_base", "<u4"),
-                       ("max_states", "<u4"), ("pad", "<u8")])
+                       ("max_states", "<u4"), ("window", "<u4"), ("spill_row", "<u4")])
 assert LANE_DTYPE.itemsize == 32
 LANE_LAST, LANE_VALID = 0x80000000, 0x40000000
 
@@ -104,40 +104,50 @@ def numpy_sweep(img, logw, n_pairs_total):
     # lane groups: the per-lane record streams exactly as sweep_lane_kernel consumes them
     for g in img.get("lane_groups", []):
         base, ml = int(g["stream_base"]), int(g["maxlen"])
+        # windowed groups (LaneGroup::window): state s lives in ring row s mod window -- stale rows are POISONED here, so
+        # an arc that reaches outside the ring shows up as a NaN -- and the forward values are parked in `spill`
+        win = int(g["window"])
         for l in range(int(g["n_lanes"])):
             slot = int(g["pair_base"]) + l
             S = int(img["lane_nstates"][slot])
-            col = np.full(S, -np.inf)
-            col[0] = 0.0
+            rows = win if win else S
+            if win:
+                assert win & (win - 1) == 0 and int(g["max_states"]) == win
+            wm = rows - 1 if win else 0xffffffff
+            col = np.full(rows, np.nan)
+            spill = np.full(S, np.nan)
+            col[0] = spill[0] = 0.0
             d, terms, wcache = 1, [], {}
             for k in range(ml):
                 x, arc = img["lane_fwd"][base + k * 64 + l]
                 if not x & LANE_VALID:
                     continue
-                assert (x & 0x3ff) < d
-                terms.append(col[x & 0x3ff] + logw[arc])
+                src = int(x & 0x3ff)
+                assert src < d and (not win or d - src < win)
+                terms.append(col[src & wm] + logw[arc])
                 bpos = (x >> 10) & 0xfffff  # the forward record points at the arc's backward position (wcache slot)
                 assert bpos not in wcache
                 wcache[bpos] = (arc, logw[arc])
                 if x & LANE_LAST:
-                    col[d] = _lse(terms)
+                    col[d & wm] = spill[d] = _lse(terms)
                     d, terms = d + 1, []
             assert d == S and not terms
-            lp = col[S - 1]
+            lp = col[(S - 1) & wm]
             plp[img["lane_pair"][slot]] = lp
-            col[S - 1] = img["lane_logw"][slot] - lp
+            col[(S - 1) & wm] = img["lane_logw"][slot] - lp
             s, terms = S - 2, []
             for k in range(ml):
                 x, arc = img["lane_bwd"][base + k * 64 + l]
                 if not x & LANE_VALID:
                     continue
-                assert (x & 0x3ff) > s
+                dst = int(x & 0x3ff)
+                assert dst > s and ((x >> 10) & 0x3ff) == s  # the backward record carries its source state
                 assert wcache[k][0] == arc  # the forward pass left this arc's weight at exactly this position
-                t = wcache[k][1] + col[x & 0x3ff]
-                counts[arc] += np.exp(alpha_s(col, s) + t)
+                t = wcache[k][1] + col[dst & wm]
+                counts[arc] += np.exp(spill[(x >> 10) & 0x3ff] + t)
                 terms.append(t)
                 if x & LANE_LAST:
-                    col[s] = _lse(terms)
+                    col[s & wm] = _lse(terms)
                     s, terms = s - 1, []
             assert s == -1 and not terms
     for b in img["bundles"]:

@@ -441,3 +441,57 @@ def test_mstep_normalize_large_unnormalised_model(oracle, group, lock, add_count
         fb.close()
     np.testing.assert_allclose(np.exp(got[0]), want, rtol=1e-12, atol=1e-300)
     assert np.array_equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("seed,window", [(0, 64), (1, 64), (2, 32), (3, 16), (4, 64), (5, 8)])
+def test_windowed_lane_groups(oracle, monkeypatch, seed, window):
+    """lattices whose arcs span few states of the topological numbering are swept one per lane through a RING of LDS rows
+    (lattice.hpp, LaneGroup::window): the forward values are parked in a global column and gathered back per record.  The
+    window is forced onto small lattices here (it normally starts above 40 states); results are the oracle's."""
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "4")
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", str(window))
+    rng = np.random.default_rng(300 + seed)
+    if seed % 2 == 0:  # narrow, long lattices: few states per level
+        kw = dict(n_states=int(rng.integers(4, 40)), deg=int(rng.integers(2, 5)), n_sym=int(rng.integers(3, 9)), p_eps=0.05,
+                  n_pairs=int(rng.integers(100, 500)), lo=10, hi=int(rng.integers(20, 70)))
+    else:
+        kw = dict(n_states=int(rng.integers(3, 100)), deg=int(rng.integers(2, 10)), n_sym=int(rng.integers(2, 6)),
+                  p_eps=float(rng.uniform(0, 0.3)), n_pairs=int(rng.integers(50, 400)), lo=int(rng.integers(2, 6)),
+                  hi=int(rng.integers(8, 40)))
+    w, c = ambiguous(400 + seed, **kw)
+    c.weight[:] = rng.uniform(0.25, 2.0, c.n_pairs)
+    fb = _fb(w, c)
+    assert fb.lattice_stats.n_windowed_pairs > 0, kw
+    lp, wlp = fb.estimate(per_pair=True)
+    _, _, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert np.array_equal(ok, fb.has_deriv.astype(bool)), kw
+    np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9, err_msg=str(kw))
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-13, err_msg=str(kw))
+    assert wlp == pytest.approx(r["sum_weighted_logprob"], rel=1e-11)
+    # the same corpus without windows: the same numbers
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", "0")
+    fb2 = _fb(w, c)
+    assert fb2.lattice_stats.n_windowed_pairs == 0
+    fb2.estimate(per_pair=True)
+    np.testing.assert_allclose(fb.counts(), fb2.counts(), rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(fb.pair_logprob[ok], fb2.pair_logprob[ok], rtol=1e-13)
+    fb.close()
+    fb2.close()
+
+
+def test_windowed_tagging_cascade(oracle, golden_dir, monkeypatch):
+    """the tutorial's tagging cascade (sentence lattices of positions x candidate tags: up to hundreds of states, arcs
+    between neighbouring positions only) with every lattice above 8 states windowed: the recorded trace still holds"""
+    from carmel_amd.trainer import TrainOpts, train
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "8")
+    gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["tagging"]
+    oc, w, c = _cascade_from_golden(oracle, golden_dir, ["tagging.fsa", "tagging.fst"], "tagging.data")
+    fb = _fb(w, c, cascade=oc.as_dict([NORM_CONDITIONAL, NORM_CONDITIONAL]))
+    assert fb.lattice_stats.n_windowed_pairs > 500
+    best, trace = train(fb, TrainOpts())
+    assert len(trace) == len(gold["iters"]) == 9
+    for t, g in zip(trace, gold["iters"]):
+        assert sig6(t["log2_prob"]) == g["log2_prob"]
+        assert sig6(t["log2_ppx_example"]) == g["log2_ppx_example"]
+    fb.close()

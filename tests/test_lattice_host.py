@@ -48,7 +48,9 @@ def test_layout_sweep_matches_oracle_estep(oracle, seed, small_pairs, lane_state
     img = host_lattices(w, c, small_pairs=small_pairs, small_states=1024, lane_states=lane_states)
     if lane_states:
         assert len(img["lane_groups"]) > 0
-        assert int(img["lane_nstates"].max()) <= lane_states
+        plain = np.concatenate([img["lane_nstates"][int(g["pair_base"]):int(g["pair_base"]) + 64] for g in img["lane_groups"]
+                                if not g["window"]] or [np.zeros(1, np.uint32)])
+        assert int(plain.max()) <= lane_states  # windowed groups take larger lattices (LaneGroup::window)
     r = oracle.estimate(ow, oc)
     counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
     ok = r["has_deriv"]
@@ -142,3 +144,24 @@ def test_blocked_transposition_tables():
     for t in range(len(tr["tile_base"]) - 1):
         seg = tr["t_src"][int(tr["tile_base"][t]):int(tr["tile_base"][t + 1])].astype(np.int64)
         assert (np.diff(seg) > 0).all()
+
+
+@pytest.mark.parametrize("seed,window,wmin", [(1, 64, 4), (2, 32, 4), (3, 16, 6), (4, 8, 4), (5, 64, 40)])
+def test_windowed_lane_layout(oracle, monkeypatch, seed, window, wmin):
+    """windowed lane groups (LaneGroup::window): lattices whose arcs span fewer than `window` states of the topological
+    numbering keep only a ring of that many rows; the host restatement of the sweep poisons stale ring rows, so an arc that
+    reached outside the ring would surface as a NaN.  Counts and probabilities are the oracle's."""
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", str(window))
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", str(wmin))
+    w = synth.random_wfst(12 + 5 * seed, 3 + seed % 3, n_sym=3 + seed, p_eps=0.1, seed=70 + seed)
+    c = synth.random_walk_corpus(w, 150, min_arcs=4, max_arcs=30 + 10 * seed, seed=70 + seed, out_degree=3 + seed % 3)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    img = host_lattices(w, c, small_pairs=8, small_states=1024, lane_states=96)
+    wins = [int(g["window"]) for g in img["lane_groups"] if g["window"]]
+    assert wins and max(wins) <= window
+    r = oracle.estimate(ow, oc)
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    ok = r["has_deriv"]
+    assert not np.isnan(counts).any()
+    np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
