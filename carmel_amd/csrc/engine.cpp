@@ -468,6 +468,22 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
     }
     HIPCHK(t->norm_mask32.upload(mask, t->stream));
     HIPCHK(t->norm_lockmask32.upload(lmask, t->stream));
+    // spans of 16 .. 31 (config 2: 20 arcs per state, groups up to 19 apart): the same with 64-bit masks, bit offset + 31
+    std::vector<unsigned long long> mask64, lmask64;
+    if (t->norm_span > 15 && t->norm_span <= 31 && !(getenv("CARMEL_HIP_MSTEP_MASK") && atoi(getenv("CARMEL_HIP_MSTEP_MASK")) == 0)) {
+      mask64.assign(n, 0ull);
+      lmask64.assign(n, 0ull);
+      const std::vector<uint64_t>& off = t->h_group_off;
+      const std::vector<uint64_t>& perm = t->h_norm_perm;
+      for (size_t g = 0; g + 1 < off.size(); ++g)
+        for (uint64_t a = off[g]; a < off[g + 1]; ++a)
+          for (uint64_t b = off[g]; b < off[g + 1]; ++b) {
+            const int64_t d = (int64_t)perm[b] - (int64_t)perm[a];
+            (group[perm[b]] == CARMEL_HIP_LOCKED_GROUP ? lmask64 : mask64)[perm[a]] |= 1ull << (uint32_t)(d + 31);
+          }
+    }
+    HIPCHK(t->norm_mask64.upload(mask64, t->stream));
+    HIPCHK(t->norm_lockmask64.upload(lmask64, t->stream));
   }
   HIPCHK(t->add_count.upload(add, t->stream));
   HIPCHK(t->gscale.alloc(add.size()));
@@ -570,13 +586,14 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
 
 static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   hipStream_t s = t->stream;
-  HIPCHK(hipMemsetAsync(t->maxchg.p, 0, sizeof(unsigned long long), s));
   MstepArgs M;
   M.logw = t->params();
   M.lw_src = nullptr;  // the one-pass kernel needs no current weight besides each thread's own
   M.code16 = t->norm_code16.p;
   M.mask32 = t->norm_mask32.n ? t->norm_mask32.p : nullptr;
   M.lockmask32 = t->norm_lockmask32.n ? t->norm_lockmask32.p : nullptr;
+  M.mask64 = t->norm_mask64.n ? t->norm_mask64.p : nullptr;
+  M.lockmask64 = t->norm_lockmask64.n ? t->norm_lockmask64.p : nullptr;
   if (t->norm_span && !t->any_digamma && !t->n_ties && (!use_counts || t->any_locked)) {
     // the one-pass kernel reads the weights of its halo, which its neighbours are rewriting: give it a snapshot
     if (t->mstep_snap.n != t->np()) HIPCHK(t->mstep_snap.alloc(t->np()));
@@ -594,7 +611,10 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.big_groups = t->big_groups.p;
   M.n_groups = t->n_norm_groups;
   M.n_big = t->big_groups.n;
-  if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
+  if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) {
+    HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
+    HIPCHK(hipMemsetAsync(t->max_partial.p, 0, t->max_partial.bytes(), s));  // once: mstep_max_final_kernel clears what it reads
+  }
   M.max_partial = t->max_partial.p;
   M.gscale = t->gscale.p;
   M.tie_of = t->n_ties ? t->tie_of.p : nullptr;
@@ -657,7 +677,6 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   if (t->cascade)  // cascade.update(): composed weights from the chains
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
-  HIPCHK(hipMemsetAsync(t->counts_ptr() + t->w.n_arcs, 0, 4 * sizeof(double), s));  // scalars; counts are all written
   if (t->unrolled) {
     if (timed) HIPCHK(hipEventRecord(t->ev0, s));
     int rc = unrolled_estimate(t, s);

@@ -77,6 +77,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> norm_of;
   DevBuf<uint16_t> norm_code16;  // MstepArgs::code16 (one-pass M-step)
   DevBuf<uint32_t> norm_mask32, norm_lockmask32;  // MstepArgs::mask32 / lockmask32
+  DevBuf<unsigned long long> norm_mask64, norm_lockmask64;  // ... for spans of 16 .. 31
   // tied arcs (!N, fst.cc:107-152): dense tie index per parameter (0xffffffff = not tied) and the per-tie tables
   DevBuf<uint32_t> tie_of;
   DevBuf<double> glocked;  // per norm group scratch

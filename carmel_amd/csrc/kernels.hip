@@ -410,12 +410,15 @@ __global__ __launch_bounds__(256) void scalars_partial_kernel(const double* __re
   __syncthreads();
   if (threadIdx.x < 3) partial[blockIdx.x * 3 + threadIdx.x] = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
 }
+// (all four scalar slots are written: nothing has to clear them before an E-step)
 __global__ void scalars_final_kernel(const double* __restrict__ partial, double* __restrict__ scalars) {
   if (threadIdx.x < 3) {
-    double v = 0.0;
-    for (int k = 0; k < SCALAR_BLOCKS; ++k) v += partial[k * 3 + threadIdx.x];
-    scalars[threadIdx.x] = v;
-  }
+    double v[4] = {0.0, 0.0, 0.0, 0.0};  // four independent chains of loads, added in a fixed order
+    for (int k = 0; k < SCALAR_BLOCKS; k += 4)
+      for (int j = 0; j < 4; ++j) v[j] += partial[(k + j) * 3 + threadIdx.x];
+    scalars[threadIdx.x] = (v[0] + v[1]) + (v[2] + v[3]);
+  } else if (threadIdx.x == 3)
+    scalars[3] = 0.0;
 }
 
 // ---------------- expected counts: per-arc sum of posteriors ----------------
@@ -625,6 +628,8 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   const double old_own = kown < M.n ? M.logw[kown] : 0.0;
   const uint32_t mask_own = (M.mask32 && kown < M.n) ? M.mask32[kown] : 0u;
   const uint32_t lock_own = (NEED_LW && M.mask32 && kown < M.n) ? M.lockmask32[kown] : 0u;
+  const unsigned long long mask_own64 = (M.mask64 && kown < M.n) ? M.mask64[kown] : 0ull;
+  const unsigned long long lock_own64 = (NEED_LW && M.mask64 && kown < M.n) ? M.lockmask64[kown] : 0ull;
   int64_t kk[2] = {base + threadIdx.x, base + 256 + threadIdx.x};
   bool in[2];
   uint16_t code[2];
@@ -667,6 +672,10 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
         for (uint32_t m = mask_own; m; m &= m - 1) sn += v_sh[me + (uint32_t)__builtin_ctz(m) - 15u];
         if (NEED_LW)
           for (uint32_t m = lock_own; m; m &= m - 1) sl += v_sh[me + (uint32_t)__builtin_ctz(m) - 15u];
+      } else if (M.mask64) {
+        for (unsigned long long m = mask_own64; m; m &= m - 1) sn += v_sh[me + (uint32_t)__builtin_ctzll(m) - 31u];
+        if (NEED_LW)
+          for (unsigned long long m = lock_own64; m; m &= m - 1) sl += v_sh[me + (uint32_t)__builtin_ctzll(m) - 31u];
       } else
         for (uint32_t j = me - span; j <= me + span; ++j) {
           const uint16_t gj = g_sh[j];
@@ -732,11 +741,15 @@ __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int u
     M.gscale[g] = mstep_scale(sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3], sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3],
                               M.dig_alpha ? M.dig_alpha[g] : __builtin_nan(""));
 }
-__global__ __launch_bounds__(256) void mstep_max_final_kernel(const unsigned long long* partial, uint64_t n,
+// (the partials are cleared for the next pass here and the result is stored, not folded: no memset per M-step)
+__global__ __launch_bounds__(256) void mstep_max_final_kernel(unsigned long long* partial, uint64_t n,
                                                               unsigned long long* bits) {
   __shared__ unsigned long long shm[4];
   unsigned long long m = 0;  // non-negative doubles order like their bit patterns
-  for (uint64_t k = threadIdx.x; k < n; k += 256) m = partial[k] > m ? partial[k] : m;
+  for (uint64_t k = threadIdx.x; k < n; k += 256) {
+    m = partial[k] > m ? partial[k] : m;
+    partial[k] = 0ull;
+  }
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned long long other = __shfl_down(m, o, 64);
     m = other > m ? other : m;
@@ -745,7 +758,7 @@ __global__ __launch_bounds__(256) void mstep_max_final_kernel(const unsigned lon
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int k = 1; k < 4; ++k) m = shm[k] > m ? shm[k] : m;
-    atomicMax(bits, m);
+    *bits = m;
   }
 }
 
@@ -1191,8 +1204,6 @@ hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
 #define MSTEP_DBG(what) if (dbg) { hipError_t de = hipStreamSynchronize(s); fprintf(stderr, "[carmel_hip] mstep %s: %s\n", what, hipGetErrorString(de)); }
   if (dbg) fprintf(stderr, "[carmel_hip] mstep n=%llu groups=%llu ties=%llu logw=%p counts=%p group=%p norm_of=%p off=%p perm=%p tie_of=%p tie_tab=%p add=%p prior=%p\n", (unsigned long long)M.n, (unsigned long long)M.n_groups, (unsigned long long)M.n_ties, (void*)M.logw, (void*)M.counts, (void*)M.group, (void*)M.norm_of, (void*)M.group_off, (void*)M.norm_perm, (void*)M.tie_of, (void*)M.tie_tab, (void*)M.add_count, (void*)M.prior);
   if (M.window_span && !(M.n_ties && M.tie_of)) {
-    hipError_t e = hipMemsetAsync(M.max_partial, 0, MSTEP_GRID * sizeof(unsigned long long), s);
-    if (e != hipSuccess) return e;
     if (M.lw_src)
       hipLaunchKernelGGL(mstep_window_kernel<true>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
     else

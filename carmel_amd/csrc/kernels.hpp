@@ -130,6 +130,8 @@ struct MstepArgs {
                             // and comparing the whole window (the scan, not the 26 bytes per parameter, was what the kernel
                             // spent its time on); lockmask32: the locked members.  Null when span > 15.
   const uint32_t* lockmask32;
+  const unsigned long long* mask64;  // the same for spans of 16 .. 31: offsets -31 .. +32, bit offset + 31
+  const unsigned long long* lockmask64;
   const uint16_t* code16;   // mstep_window_kernel: per parameter, norm-group id mod 2^14 | 0x4000 if locked; 0xffff = no norm
                             // group.  Ids are handed out in first-seen order, so inside a window of < 2^14 parameters equal
                             // low bits mean equal groups: 2 bytes per parameter instead of norm_of + group (8)
