@@ -768,6 +768,11 @@ using namespace carmel_hip;
 static const size_t F_LDS_LIMIT = 150 * 1024;  // dynamic LDS a forest kernel may ask for
 
 struct carmel_hip_forests {
+  // --prior-inference-* (gibbs_opts.hpp:82-89): carmel_hip_forests_set_prior_inference / _prior_trace
+  double pi_stddev = 0;
+  bool pi_global = false, pi_local = false;
+  uint32_t pi_start = 0, pi_end = 0;
+  std::vector<double> pi_trace, pi_cumulative;
   int device = 0;
   hipStream_t stream = nullptr;
   uint64_t n_forests = 0, n_groups = 0;
@@ -1210,6 +1215,27 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* F, const double* rule_log
   return CARMEL_HIP_OK;
 }
 
+int carmel_hip_forests_set_prior_inference(carmel_hip_forests* F, double stddev, int global, int local, uint32_t start,
+                                           uint32_t end) {
+  if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
+  F->pi_stddev = stddev;
+  F->pi_global = global != 0;
+  F->pi_local = local != 0;
+  F->pi_start = start;
+  F->pi_end = end;
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_forests_prior_trace(carmel_hip_forests* F, double* out6, uint32_t n_sweeps, double* cumulative, uint32_t n_cumulative,
+                                   uint32_t* n_scales) {
+  if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
+  if (out6)
+    for (size_t k = 0; k < (size_t)n_sweeps * 6; ++k) out6[k] = k < F->pi_trace.size() ? F->pi_trace[k] : 0.0;
+  if (cumulative)
+    for (uint32_t k = 0; k < n_cumulative; ++k) cumulative[k] = k < F->pi_cumulative.size() ? F->pi_cumulative[k] : 1.0;
+  if (n_scales) *n_scales = (uint32_t)F->pi_cumulative.size();
+  return CARMEL_HIP_OK;
+}
+
 // FForests::run_gibbs (forest-em.hpp:714-734): to_gibbs (normalise, prior = alpha * p * |group|), gibbs_base::run,
 // from_gibbs (rule weights = time-averaged probabilities).  opts->mode 0: forests strictly in order (the
 // reference's chain); 1: all forests of a sweep in parallel against the previous sweep's counts with each forest's
@@ -1217,6 +1243,8 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* F, const double* rule_log
 int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts* o, double alpha, double* iter_logprob,
                              double* iter_cheap_logprob) {
   if (!F || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (F->pi_stddev > 0 && o->mode != 0)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "prior inference works with the cache-model probability of the exact blocked sampler only (gibbs.hpp:528-529)");
   HIPCHK(hipSetDevice(F->device));
   hipStream_t s = F->stream;
   const uint32_t nr = F->n_rules;
@@ -1259,6 +1287,31 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       prior[r] = o->uniform_p0 ? a : a * p * (double)(j1 - j0);
       pn[gi] += prior[r];
     }
+  }
+  // prior-scale groups as forest-em builds them (forest-em.hpp:723-734 to_gibbs; normalize.hpp:194-210; gibbs.hpp:572-579):
+  // the norm ids given to define_param_id start at ONE while to_gibbs registers scale groups for ids 0 .. G-1, so norm group
+  // g is scaled by scale index g + 2, the first factor is drawn for nobody, and finish_params' resize(nnorm) leaves the LAST
+  // norm group with the never-scaled index 0; every drawn factor enters q(old|new)/q(new|old) all the same.
+  std::vector<uint32_t> meta;  // by reference norm id (= group index + 1)
+  uint32_t nexti = 1;
+  F->pi_trace.assign((size_t)(o->iter + 1) * 6, 0.0);
+  F->pi_cumulative.clear();
+  if (F->pi_stddev > 0) {
+    uint32_t nnorm = 0;
+    for (uint32_t r = 0; r < nr; ++r)
+      if (F->h_norm[r] != F_NONORM) nnorm = std::max(nnorm, F->h_norm[r] + 2);
+    meta.assign(nnorm, 0u);
+    for (uint32_t i = 0; i < nnorm && i < ng; ++i) meta[i] = i + 1;
+    nexti = (uint32_t)ng + 1;
+    if (F->pi_global) {
+      nexti = 2;
+      std::fill(meta.begin(), meta.end(), 1u);
+    }
+    if (F->pi_local) {
+      nexti = nnorm + 1;
+      for (uint32_t i = 0; i < nnorm; ++i) meta[i] = i + 1;
+    }
+    F->pi_cumulative.assign(nexti - 1, 1.0);
   }
   if (guard.changed) HIPCHK(hipMemcpyAsync(F->p_norm.p, F->h_norm.data(), nr * sizeof(uint32_t), hipMemcpyHostToDevice, s));
   for (uint32_t r = 0; r < nr; ++r)
@@ -1489,6 +1542,75 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           HIPCHK(hipMemcpyAsync(F->normsum.p + n, &hn[n], sizeof(double), hipMemcpyHostToDevice, s));
         }
         HIPCHK(hipStreamSynchronize(s));
+      }
+      // propose_new_priors (gibbs.hpp:525-553) on the sweeps that infer (gibbs.hpp:559-563).  The exact schedule keeps its
+      // counts on the host between forests (above); the proposal moves them there and the device copies follow.
+      const uint32_t pstart = F->pi_start ? F->pi_start : burnin;
+      if (F->pi_stddev > 0 && nexti > 1 && iter > 0 && pstart <= iter && (!F->pi_end || iter < F->pi_end)) {
+        const double sdev = F->pi_stddev;
+        const double q0 = gibbs_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;
+        std::vector<double> sc(nexti, 1.0);
+        double ln_a2 = 0.0;
+        for (uint32_t k = 1; k < nexti; ++k) {
+          sc[k] = 1.0 + sdev * gibbs_norm_quantile(q0 + gibbs_uniform(o->seed, iter, 0xfffffffeu, k) * qrem);
+          const double d_old = 1.0 / sc[k] - 1.0, d_new = sc[k] - 1.0;
+          ln_a2 += (d_new * d_new - d_old * d_old) / (2.0 * sdev * sdev);
+        }
+        auto cache_prob_all = [&]() {
+          std::vector<double> cc = prior, cs = pn;
+          double lp = 0.0;
+          for (uint64_t f = 0; f < nf; ++f)
+            for (uint32_t r : hsample[f]) {
+              const uint32_t n = F->h_norm[r];
+              double q = prior[r];
+              if (n != F_NONORM) {
+                q = cc[r] / cs[n];
+                cc[r] += 1.0;
+                cs[n] += 1.0;
+              }
+              lp += std::log(q);
+            }
+          return lp;
+        };
+        auto scale = [&](bool invert) {
+          std::fill(pn.begin(), pn.end(), 0.0);
+          for (uint32_t r = 0; r < nr; ++r) {
+            const uint32_t n = F->h_norm[r];
+            if (n == F_NONORM) continue;
+            const uint32_t i = meta[n + 1];
+            if (i > 0) {
+              double fct = sc[i];
+              if (invert) fct = 1.0 / fct;
+              const double s2 = fct * prior[r], d = s2 - prior[r];
+              hs[r] += d * ht[r];
+              hx[r] += d;
+              hn[n] += d;
+              prior[r] = s2;
+            }
+            pn[n] += prior[r];
+          }
+        };
+        const double p1 = cache_prob_all();
+        scale(false);
+        const double p2 = cache_prob_all();
+        const double a = std::exp((p2 - p1) + ln_a2);
+        const bool accept = gibbs_uniform(o->seed, iter, 0xffffffffu, 0) < a;
+        if (!accept)
+          scale(true);
+        else
+          for (uint32_t k = 1; k < nexti; ++k) F->pi_cumulative[k - 1] *= sc[k];
+        HIPCHK(hipMemcpyAsync(F->p_prior.p, prior.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(F->prior_norm.p, pn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(F->p_x.p, hx.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(F->normsum.p, hn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+        double* tr = F->pi_trace.data() + (size_t)iter * 6;
+        tr[0] = 1;
+        tr[1] = accept ? 1 : 0;
+        tr[2] = p1;
+        tr[3] = p2;
+        tr[4] = std::exp(ln_a2);
+        tr[5] = a;
       }
     }
     if (iter_logprob) iter_logprob[iter] = cache_lp;

@@ -526,8 +526,8 @@ using namespace carmel_hip;
 
 // the standard normal's cdf and quantile (the reference uses boost::math::normal_distribution, gibbs.hpp:474-516 -- a
 // third-party dependency absent from the tree; restated from the published algorithm: Wichura, AS 241 (PPND16), 1988)
-static double pi_norm_cdf(double z) { return 0.5 * std::erfc(-z / std::sqrt(2.0)); }
-static double pi_norm_quantile(double p) {
+double gibbs_norm_cdf(double z) { return 0.5 * std::erfc(-z / std::sqrt(2.0)); }
+double gibbs_norm_quantile(double p) {
   const double q = p - 0.5;
   if (std::fabs(q) <= 0.425) {
     const double r = 0.180625 - q * q;
@@ -959,12 +959,12 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       const uint32_t pstart = g->pi_start ? g->pi_start : g->opt.burnin;
       if (g->pi_stddev > 0 && g->n_scale && iter > 0 && pstart <= iter && (!g->pi_end || iter < g->pi_end)) {
         const double sdev = g->pi_stddev;
-        const double q0 = pi_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;  // scale ratios are > 0 (gibbs.hpp:488-499)
+        const double q0 = gibbs_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;  // scale ratios are > 0 (gibbs.hpp:488-499)
         std::vector<double> sc(g->n_scale + 1, 1.0);
         double ln_a2 = 0.0;
         for (uint32_t k = 1; k <= g->n_scale; ++k) {
           const double u = gibbs_uniform(g->opt.seed, G.iter, 0xfffffffeu, k);
-          sc[k] = 1.0 + sdev * pi_norm_quantile(q0 + u * qrem);
+          sc[k] = 1.0 + sdev * gibbs_norm_quantile(q0 + u * qrem);
           const double d_old = 1.0 / sc[k] - 1.0, d_new = sc[k] - 1.0;  // q(old | new) / q(new | old), both N(1, sdev)
           ln_a2 += (d_new * d_new - d_old * d_old) / (2.0 * sdev * sdev);
         }

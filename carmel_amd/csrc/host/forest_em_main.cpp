@@ -33,6 +33,10 @@ struct Opts {
   bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
   long crp = 0, burnin = 0;
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
+  // --prior-inference-* (gibbs_opts.hpp:82-89; forest-em reads all of them through gibbs_opts' own option table)
+  double pi_stddev = 0;
+  bool pi_global = false, pi_local = false, pi_show = false;
+  long pi_start = 0, pi_end = 0;
   double alpha = 0.1;             // --const-alpha (gibbs_opts.hpp:93)
   std::string alpha_file = "-0";  // --alpha: per-parameter alphas parallel to the weights, negative = locked (:98-99)
   bool final_counts = false, uniform_p0 = false, parallel = false;
@@ -43,7 +47,8 @@ struct Opts {
 void usage() {
   std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
-               "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel]\n"
+               "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel\n"
+               "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show]]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -119,6 +124,13 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "final-counts") o.final_counts = true;
     else if (key == "uniform-p0") o.uniform_p0 = true;
     else if (key == "crp-parallel") o.parallel = true;
+    else if (key == "prior-inference-stddev") o.pi_stddev = std::atof(value(val).c_str());
+    else if (key == "prior-inference-global") o.pi_global = true;
+    else if (key == "prior-inference-local") o.pi_local = true;
+    else if (key == "prior-inference-show") o.pi_show = true;
+    else if (key == "prior-inference-start") o.pi_start = std::atol(value(val).c_str());
+    else if (key == "prior-inference-end") o.pi_end = std::atol(value(val).c_str());
+    else if (key == "prior-inference-restart-fresh") {}  // acts on --crp-restarts only, which this front end does not run
     else if (key == "random-seed") o.seed = std::strtoull(value(val).c_str(), 0, 10);
     else if (key == "gpu") o.gpu = std::atoi(value(val).c_str());
     else throw std::runtime_error("unknown option " + a);
@@ -201,9 +213,28 @@ int main(int argc, char** argv) {
         check(carmel_hip_forests_set_alphas(F, al.data(), (uint32_t)al.size()), "carmel_hip_forests_set_alphas");
       }
       std::vector<double> lp((size_t)o.crp + 1);
+      check(carmel_hip_forests_set_prior_inference(F, o.pi_stddev, o.pi_global, o.pi_local, (uint32_t)std::max(0L, o.pi_start),
+                                                   (uint32_t)std::max(0L, o.pi_end)),
+            "carmel_hip_forests_set_prior_inference");
       check(carmel_hip_forests_gibbs(F, &go, o.alpha, lp.data(), nullptr), "carmel_hip_forests_gibbs");
-      for (size_t i = 0; i < lp.size(); ++i)
-        log << "i=" << i << " sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
+      std::vector<double> ptrace(lp.size() * 6, 0.0), pcum(group_off.size() + 1, 1.0);
+      uint32_t n_scales = 0;
+      check(carmel_hip_forests_prior_trace(F, ptrace.data(), (uint32_t)lp.size(), pcum.data(), (uint32_t)pcum.size(), &n_scales),
+            "carmel_hip_forests_prior_trace");
+      for (size_t i = 0; i < lp.size(); ++i) {
+        log << "i=" << i << " ";
+        const double* pt = ptrace.data() + i * 6;
+        if (pt[0] != 0)  // propose_new_priors' line (gibbs.hpp:539-547)
+          log << (pt[1] != 0 ? "accepted" : "rejected") << " new priors with p1=2^" << pt[2] / std::log(2.0) << " p2=2^"
+              << pt[3] / std::log(2.0) << " a1=p2/p1=" << std::exp(pt[3] - pt[2]) << " a2=q(1|2)/q(2|1)=" << pt[4]
+              << " p_accept=" << pt[5] << ". ";
+        log << "sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
+      }
+      if (o.pi_show) {  // gibbs.hpp:826-827
+        log << "Final prior-scale=[";
+        for (uint32_t k = 0; k < n_scales && k < pcum.size(); ++k) log << (k ? " " : "") << pcum[k];
+        log << "]\n";
+      }
     } else {
       // overrelaxed_em (em.hpp:107-216), learning rate 1, with its random restarts
       double best = -std::numeric_limits<double>::infinity();

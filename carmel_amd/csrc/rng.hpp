@@ -26,6 +26,9 @@ CARMEL_HD inline double gibbs_uniform(uint64_t seed, uint32_t iter, uint32_t blo
 // Annealing (gibbs_opts.hpp:206-211, gibbs.hpp:838-839): sweep t of n chooses with probabilities raised to 1/T(t),
 // T = graehl::clamped_time_series(high, low, n, curvature = linear = -1e8) (time_series.hpp:90-141): an exponential
 // between the two temperatures measured from an origin 1e8 * low below zero, i.e. a straight line to ~1e-8.
+// the standard normal's cdf and quantile for the prior-scale proposals (gibbs.hip; Wichura's AS 241)
+double gibbs_norm_cdf(double z);
+double gibbs_norm_quantile(double p);
 inline double gibbs_anneal_power(double high, double low, uint32_t n_sweeps, uint32_t sweep) {
   if (high == 0) high = 1;  // unset fields of a zeroed options struct
   if (low == 0) low = 1;

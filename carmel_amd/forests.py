@@ -65,15 +65,26 @@ class HipForests(object):
         check(lib.carmel_hip_forests_set_weights(self.h, ptr(lw)), "carmel_hip_forests_set_weights")
 
     def gibbs(self, iters, burnin=0, alpha=0.1, seed=1, mode=0, uniform_p0=False, final_counts=False, alphas=None,
-              high_temp=1.0, low_temp=1.0):
+              high_temp=1.0, low_temp=1.0, prior_inference=None):
         """high_temp/low_temp: annealing, choices at probabilities^(1/temperature) (--high-temp/--low-temp).
+        prior_inference: dict(stddev, global_, local, start, end) -- --prior-inference-* (gibbs.hpp:525-563), exact mode;
+        afterwards self.prior_trace (per sweep {proposed, accepted, ln p1, ln p2, a2, p_accept}) and self.prior_cumulative.
         alphas: forest-em --alpha=FILE, one prior strength per rule id (negative = locked); None: the scalar alpha"""
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         check(lib.carmel_hip_forests_set_alphas(self.h, ptr(al), 0 if al is None else len(al)), "carmel_hip_forests_set_alphas")
         o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), 0, 0.01, high_temp, low_temp, 0, 0, 0, 0)
         self.iter_logprob, self.iter_cheap_logprob = np.zeros(iters + 1), np.zeros(iters + 1)
+        pi = dict(prior_inference or {})
+        check(lib.carmel_hip_forests_set_prior_inference(self.h, float(pi.get("stddev", 0.0)), int(pi.get("global_", False)),
+                                                         int(pi.get("local", False)), int(pi.get("start", 0)),
+                                                         int(pi.get("end", 0))), "carmel_hip_forests_set_prior_inference")
         check(lib.carmel_hip_forests_gibbs(self.h, C.byref(o), alpha, ptr(self.iter_logprob),
                                            ptr(self.iter_cheap_logprob)), "carmel_hip_forests_gibbs")
+        ns = C.c_uint32(0)
+        self.prior_trace, cum = np.zeros((iters + 1, 6)), np.zeros(1 << 16)
+        check(lib.carmel_hip_forests_prior_trace(self.h, ptr(self.prior_trace), iters + 1, ptr(cum), len(cum), C.byref(ns)),
+              "carmel_hip_forests_prior_trace")
+        self.prior_cumulative = cum[:ns.value]
         return self.iter_logprob
 
     def max_sample(self):

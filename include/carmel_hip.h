@@ -309,6 +309,16 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* f, const double* rule_log
  * probabilities (from_gibbs). */
 int carmel_hip_forests_gibbs(carmel_hip_forests* f, const carmel_hip_gibbs_opts* opts, double alpha,
                              double* iter_logprob, double* iter_cheap_logprob);
+/* Replaces: prior-scale inference in forest-em's sampler (forest-em.hpp:723-734 to_gibbs + gibbs.hpp:404-563; forest-em
+ * --prior-inference-stddev / -global / -local / -start / -end): as carmel_hip_gibbs_set_prior_inference, with forest-em's
+ * scale groups -- one per norm group, shifted by one as the reference registers them (the last norm group is never scaled,
+ * the first factor scales nobody; --prior-inference-local scales every group).  Exact mode (mode 0) only.  Call before
+ * carmel_hip_forests_gibbs; _prior_trace afterwards: per sweep {proposed, accepted, ln p1, ln p2, a2, p_accept}. */
+int carmel_hip_forests_set_prior_inference(carmel_hip_forests* F, double stddev, int global, int local, uint32_t start,
+                                           uint32_t end);
+int carmel_hip_forests_prior_trace(carmel_hip_forests* F, double* out6, uint32_t n_sweeps, double* cumulative,
+                                   uint32_t n_cumulative, uint32_t* n_scales);
+
 /* --alpha=FILE of forest-em (gibbs_opts.hpp:98-99; forest-em.hpp:681-709): a prior strength per parameter, indexed by
  * rule id like the weights (entry 0 unused); a negative entry locks the parameter (it keeps its probability and leaves
  * its normalisation group's counts); rules beyond n use the scalar alpha.  NULL / n = 0 clears. */

@@ -439,8 +439,11 @@ class OracleForests(object):
         return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
 
     def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22,
-              alphas=None, high_temp=1.0, low_temp=1.0):
+              alphas=None, high_temp=1.0, low_temp=1.0, prior_inference=None):
         lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
+        pi = dict(prior_inference or {})
+        lib.orc_set_gibbs_prior_inference(C.c_double(pi.get("stddev", 0.0)), int(pi.get("global_", False)),
+                                          int(pi.get("local", False)), 0, int(pi.get("start", 0)), int(pi.get("end", 0)), None, 0)
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         lib.orc_forests_set_alphas(_p(al), 0 if al is None else len(al))
         ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)
@@ -450,7 +453,11 @@ class OracleForests(object):
         _chk(lib.orc_forests_gibbs(self.h, iters, burnin, int(uniform_p0), int(final_counts), alpha, cb, _p(ilp), _p(icl),
                                    _p(samp), _p(off), max_samples))
         samples = [samp[int(off[b]):int(off[b + 1])].tolist() for b in range(self.n_forests)]
-        return dict(iter_logprob=ilp, iter_cheap_logprob=icl, samples=samples)
+        ptrace, cum = np.zeros((iters + 1, 6)), np.zeros(1 << 16)
+        ncum = lib.orc_gibbs_last_prior_trace(_p(ptrace), iters + 1, _p(cum), len(cum))
+        lib.orc_set_gibbs_prior_inference(C.c_double(0.0), 0, 0, 0, 0, 0, None, 0)
+        return dict(iter_logprob=ilp, iter_cheap_logprob=icl, samples=samples, prior_trace=ptrace,
+                    prior_cumulative=cum[:ncum])
 
 
 CLI = os.path.join(_HERE, "oracle_carmel")

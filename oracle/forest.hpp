@@ -355,6 +355,83 @@ struct ForestGibbs {
         gps[r].prior = gopt.uniformp0 ? a : a * p * N;  // gibbs.hpp:589-592
       }
     sample.assign(fe.forests.size(), {});
+    // prior-scale groups as forest-em builds them (forest-em.hpp:723-734 to_gibbs; normalize.hpp:194-210): the norm ids
+    // handed to define_param_id start at ONE (visit_norm_param's normi), while to_gibbs registers scale groups for ids
+    // 0 .. G-1: norm group g (id g + 1) is scaled with group g + 1's factor -- scale index g + 2 --, the first factor is
+    // drawn for nobody, and finish_params' resize(nnorm) (gibbs.hpp:572-579) gives the LAST norm group the never-scaled
+    // index 0.  Every drawn factor enters q(old|new)/q(new|old) all the same.  Restated as it is.
+    const unsigned G = (unsigned)fe.groups.size();
+    unsigned nnorm = 0;
+    for (auto& g : gps)
+      if (g.has_norm()) nnorm = std::max(nnorm, g.norm + 2);  // reference id = norm + 1
+    metanorm.assign(nnorm, 0u);
+    for (unsigned i = 0; i < nnorm && i < G; ++i) metanorm[i] = i + 1;
+    nexti = G + 1;
+    if (gopt.prior_inference_global) {
+      nexti = 2;
+      std::fill(metanorm.begin(), metanorm.end(), 1u);
+    }
+    if (gopt.prior_inference_local) {
+      nexti = nnorm + 1;
+      for (unsigned i = 0; i < nnorm; ++i) metanorm[i] = i + 1;
+    }
+    cumulative.assign(nexti - 1, 1.0);
+  }
+  std::vector<unsigned> metanorm;  // by reference norm id (= our group index + 1)
+  unsigned nexti = 1;
+  std::vector<double> cumulative;
+  void scale_priors(const std::vector<double>& sc, bool invert) {  // gibbs.hpp:161-176, 430-443
+    for (unsigned i = 1; i < nexti; ++i) {
+      if (invert) cumulative[i - 1] /= sc[i]; else cumulative[i - 1] *= sc[i];
+    }
+    for (auto& g : gps)
+      if (g.has_norm()) {
+        const unsigned i = metanorm[g.norm + 1];
+        if (i > 0) {
+          double f = sc[i];
+          if (invert) f = 1. / f;
+          const double s2 = f * g.prior, d = s2 - g.prior;
+          g.sum.s += d * g.sum.tmax;
+          g.sum.x += d;
+          normsum[g.norm] += d;
+          g.prior = s2;
+        }
+      }
+  }
+  LW cache_prob_all() const {  // gibbs.hpp:712-722
+    std::vector<double> ccount(gps.size(), 0.0), csum(fe.groups.size(), 0.0);
+    for (size_t i = 0; i < gps.size(); ++i)
+      if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
+    LW w = LW::one();
+    for (auto& blk : sample)
+      for (unsigned r : blk) {
+        const GibbsParam& g = gps[r];
+        const double q = g.has_norm() ? (ccount[r]++ / csum[g.norm]++) : g.prior;
+        mul_eq(w, LW::from_real(q));
+      }
+    return w;
+  }
+  void propose_new_priors(const std::function<double(unsigned, unsigned)>& u, double* tr6) {  // gibbs.hpp:525-553
+    const double sdev = gopt.prior_inference_stddev;
+    const double q0 = normal_cdf(0, 1, sdev), qrem = 1 - q0;
+    std::vector<double> sc(nexti, 1.0);
+    LW q2_1 = LW::one(), q1_2 = LW::one();
+    for (unsigned i = 1; i < nexti; ++i) {
+      sc[i] = normal_quantile(q0 + u(0xfffffffeu, i) * qrem, 1, sdev);
+      mul_eq(q2_1, LW::from_real(normal_pdf(sc[i], 1, sdev)));
+      mul_eq(q1_2, LW::from_real(normal_pdf(1 / sc[i], 1, sdev)));
+    }
+    const LW a2 = q1_2 / q2_1, p1 = cache_prob_all();
+    scale_priors(sc, false);
+    const LW p2 = cache_prob_all(), a = (p2 / p1) * a2;
+    const bool accept = u(0xffffffffu, 0) < a.getReal();
+    if (!accept) scale_priors(sc, true);
+    tr6[0] = 1;
+    tr6[1] = accept;
+    tr6[2] = p1.w;
+    tr6[3] = p2.w;
+    tr6[4] = a2.getReal();
+    tr6[5] = a.getReal();
   }
   double proposal_prob(unsigned r) const {
     const GibbsParam& g = gps[r];
@@ -403,11 +480,19 @@ struct ForestGibbs {
         mul_eq(pc, bc);
         addc(sample[b], 1.0);
       }
+      double tr6[6] = {0, 0, 0, 0, 0, 0};
+      {
+        const unsigned start = gopt.prior_inference_start ? gopt.prior_inference_start : gopt.burnin;  // gibbs.hpp:559-563
+        if (iter > 0 && gopt.prior_inference_stddev > 0 && start <= iter && (!gopt.prior_inference_end || iter < gopt.prior_inference_end))
+          propose_new_priors([&](unsigned b, unsigned k) { return u(iter, b, k); }, tr6);
+      }
       if (tr) {
+        tr->prior_trace.insert(tr->prior_trace.end(), tr6, tr6 + 6);
         tr->iter_logprob.push_back(pc.w);
         tr->iter_cheap_logprob.push_back(p.w);
       }
     }
+    if (tr) tr->cumulative = cumulative;
     if (tr) tr->last_sample = sample;
     if (!(gopt.final_counts && !gopt.exclude_prior)) {
       double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;

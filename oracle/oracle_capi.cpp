@@ -1080,9 +1080,16 @@ int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int unifor
     go.low_temp = g_low_temp;
     go.final_counts = final_counts != 0;
     if (go.final_counts) go.burnin = go.iter;
+    go.prior_inference_stddev = g_pi_stddev;
+    go.prior_inference_global = g_pi_global != 0;
+    go.prior_inference_local = g_pi_local != 0;
+    go.prior_inference_start = g_pi_start;
+    go.prior_inference_end = g_pi_end;
     ForestGibbs g(h->fe, go, alpha, g_forest_alphas);
     GibbsTrace tr;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
+    g_last_prior_trace = tr.prior_trace;
+    g_last_cumulative = tr.cumulative;
     for (uint32_t i = 0; i <= iter; ++i) {
       if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
       if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];

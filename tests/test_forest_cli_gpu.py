@@ -117,6 +117,34 @@ def test_forest_em_cli_options(oracle, tmp_path):
     assert "e^" not in (tmp_path / "o").read_text()
 
 
+@pytest.mark.gpu
+def test_forest_em_cli_prior_inference(oracle, tmp_path):
+    """forest-em --crp=N --prior-inference-stddev=S --prior-inference-local --prior-inference-show: the log says what each
+    inferring sweep decided, as the oracle decides on the same uniforms; the written parameters are the oracle's"""
+    from carmel_amd._capi import lib
+    from test_forest_gpu import synth_forests
+    ftxt, ntxt = synth_forests(40, 30, seed=5)
+    (tmp_path / "f").write_text(ftxt)
+    (tmp_path / "n").write_text(ntxt)
+    rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / "o"), "--crp=10", "--burnin=3",
+                       "--const-alpha=0.3", "--prior-inference-stddev=0.1", "--prior-inference-local", "--prior-inference-show",
+                       "--random-seed=23"])
+    assert rc == 0, err
+    of = oracle.OracleForests(ftxt, ntxt)
+    ref = of.gibbs(lambda i, b, st: lib.carmel_hip_gibbs_uniform(23, i, b, st), 10, burnin=3, alpha=0.3,
+                   prior_inference=dict(stddev=0.1, local=True))
+    lines = [l for l in (so + err).split("\n") if re.match(r"i=\d+ ", l)]
+    assert len(lines) == 11
+    tr = ref["prior_trace"]
+    for i, l in enumerate(lines):
+        said = "accepted" if " accepted new priors with p1=" in l else "rejected" if " rejected new priors with p1=" in l else None
+        assert said == (None if tr[i, 0] == 0 else ("accepted" if tr[i, 1] else "rejected")), l
+    final = re.search(r"Final prior-scale=\[(.*)\]", so + err).group(1).split()
+    np.testing.assert_allclose([float(x) for x in final], ref["prior_cumulative"], rtol=1e-5)
+    got = parse_vec((tmp_path / "o").read_text())
+    np.testing.assert_allclose(got, np.exp(of.weights()[1:1 + len(got)]), rtol=1e-9, atol=1e-300)
+
+
 def test_forest_text_cpu(golden_dir):
     """the command line parses its inputs and fails loudly without a GPU (no CPU fallback)"""
     if not os.path.exists(CLI):

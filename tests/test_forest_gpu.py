@@ -229,3 +229,37 @@ def test_forests_larger_than_lds(oracle):
             os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
     assert res[0][1] == res[1][1]
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
+
+
+@pytest.mark.parametrize("case", [dict(stddev=0.1), dict(stddev=0.3, global_=True), dict(stddev=0.2, local=True),
+                                  dict(stddev=0.25, start=2, end=7), dict(stddev=0.15, alphas=True)])
+def test_forest_gibbs_prior_scale_inference(oracle, case):
+    """forest-em --prior-inference-stddev / -global / -local / -start / -end (forest-em.hpp:723-734 + gibbs.hpp:404-563): the
+    exact chain with a prior-scale proposal after every inferring sweep -- same proposals, decisions, probabilities, samples
+    and final weights as the oracle's restatement (including forest-em's off-by-one scale groups: the last norm group is
+    never scaled unless -local)."""
+    from carmel_amd._capi import lib
+    case = dict(case)
+    ftext, ntext = synth_forests(40, 25, 13)
+    of, hf = make(oracle, ftext, ntext, 13)
+    kw = {}
+    if case.pop("alphas", False):  # some rules locked (alpha < 0), others with their own strength
+        rng = np.random.default_rng(3)
+        kw["alphas"] = np.where(rng.random(hf.n_rules) < 0.15, -1.0, rng.uniform(0.05, 0.6, hf.n_rules))
+    iters, burnin = 12, 3
+    hf.gibbs(iters, burnin=burnin, alpha=0.3, seed=17, mode=0, prior_inference=case, **kw)
+    ref = of.gibbs(lambda i, b, s: lib.carmel_hip_gibbs_uniform(17, i, b, s), iters, burnin=burnin, alpha=0.3,
+                   prior_inference=case, **kw)
+    tr, rt = hf.prior_trace, ref["prior_trace"]
+    assert tr[:, 0].sum() > 0
+    np.testing.assert_array_equal(tr[:, :2], rt[:, :2])
+    np.testing.assert_allclose(tr[:, 2:4], rt[:, 2:4], rtol=1e-10)
+    np.testing.assert_allclose(tr[:, 4:], rt[:, 4:], rtol=1e-7)
+    np.testing.assert_allclose(hf.prior_cumulative, ref["prior_cumulative"], rtol=1e-12)
+    for b in range(hf.n_forests):
+        assert hf.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(hf.weights()), np.exp(of.weights()), rtol=1e-9, atol=1e-15)
+    with pytest.raises(Exception):
+        hf.gibbs(3, alpha=0.3, seed=1, mode=1, prior_inference=dict(stddev=0.1))
+    hf.close()
