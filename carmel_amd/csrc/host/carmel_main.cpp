@@ -86,6 +86,9 @@ struct Options {
   double pi_stddev = 0;
   bool pi_global = false, pi_restart_fresh = false, pi_show = false;
   std::string prior_groupby;
+  long number_from = 0;            // --number-from=N (carmel.cc:768, 802-806)
+  std::string write_loaded;        // --write-loaded=suffix (carmel.cc:758, 807)
+  bool have_write_loaded = false;
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
@@ -197,6 +200,12 @@ static Options parse_args(int argc, char** argv) {
         o.pi_show = true;
       else if (k == "prior-groupby")
         o.prior_groupby = v;
+      else if (k == "number-from")
+        o.number_from = std::atol(v.c_str());
+      else if (k == "write-loaded") {
+        o.write_loaded = v;
+        o.have_write_loaded = true;
+      }
       else if (k == "prior-inference-start" || k == "prior-inference-end" || k == "prior-inference-local")
         // gibbs_opts.hpp:85-89 documents them and forest-em reads them; carmel.cc:291-294 never does, so carmel runs as
         // if they were not given.  Same here (the library has them: carmel_hip_gibbs_set_prior_inference).
@@ -367,53 +376,6 @@ static int run(int argc, char** argv) {
       member[i].set_weights(w.data());
     }
   }
-  // ---- composition chain, left to right (carmel.cc:1287-1355) ----
-  if (!o.flags[(unsigned)'d']) member[0].prune_useless();
-  ParamTable params;
-  ChainTable chains;
-  std::unique_ptr<Transducer> composed;
-  Transducer* result = &member[0];
-  const bool cascade = o.train_cascade && nw > 1;
-  if (nw > 1) {
-    for (size_t i = 0; i < nw; ++i) params.add_member(member[i]);
-    Composer comp(params, chains, (unsigned)o.index_threshold, /*trivial=*/!o.train_cascade);
-    Operand A, B;
-    for (size_t i = 1; i < nw; ++i) {
-      A.bind(result, i > 1, params.member_base[0]);
-      B.bind(&member[i], false, params.member_base[i]);
-      std::unique_ptr<Transducer> next(new Transducer());
-      double dev_s = 0;
-      const bool ok = o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next)  // carmel.cc:1318
-                      : o.gpu_compose        ? comp.run_device(A, B, *next, o.gpu + ((std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host") ? 0 : rank), &dev_s)
-                                             : comp.run(A, B, *next);
-      if (o.gpu_compose && !o.flags[(unsigned)'a'] && std::getenv("CARMEL_TIMING"))
-        std::cerr << "timing: composition on the GPU " << dev_s << " s\n";
-      if (!ok) {
-        std::cerr << ")\nEmpty or invalid result of composition with transducer \"" << o.files[i + 1] << "\".\n";
-        return -3;
-      }
-      size_t st = next->states.size(), ar = next->num_arcs();
-      if (!o.flags[(unsigned)'d']) next->prune_useless();
-      if (!quiet) {
-        std::cerr << "\n\t(" << st << " states / " << ar << " arcs";
-        if (next->states.size() != st || next->num_arcs() != ar)
-          std::cerr << " reduce-> " << next->states.size() << "/" << next->num_arcs();
-        std::cerr << ")";
-      }
-      composed = std::move(next);
-      result = composed.get();
-    }
-    if (!quiet) std::cerr << std::endl;
-  }
-  if (!with_pairs) {  // plain `carmel a b ...`: print the (reduced) composition — no GPU involved
-    const int ws = wstyle;
-    if (o.flags[(unsigned)'c'])
-      std::cout << "Number of states in result: " << result->states.size() << "\nNumber of arcs in result: "
-                << result->num_arcs() << "\n";
-    else
-      std::cout << result->to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
-    return 0;
-  }
   // ---- normalisation methods per member (carmel.cc:488-499) ----
   std::vector<int> norms(nw, o.norm);
   std::vector<double> addc(nw, o.pi_stddev != 0 ? 1.0 : 0.0);  // carmel.cc:491-492: inferred priors start from 1
@@ -462,6 +424,77 @@ static int run(int argc, char** argv) {
     }
   }
   const bool any_digamma = std::find(dig_on.begin(), dig_on.end(), (uint8_t)1) != dig_on.end();
+  // fem_in (carmel.cc:785-808): with --normby the INPUT transducers are normalised before anything is composed
+  if (!o.normby.empty()) {
+    std::cerr << "Normalizing input transducers by --normby=" << o.normby << std::endl;
+    for (size_t i = 0; i < nw; ++i) member[i].normalize(norms[i], addc[i], dig_on[i] != 0, dig_alpha[i]);
+  }
+  if (o.number_from > 0) {
+    std::cerr << "Assigning unique group ids to each arc in input cascade starting at " << o.number_from << ".\n";
+    uint32_t label = (uint32_t)o.number_from;
+    for (size_t i = 0; i < nw; ++i) label = member[i].number_arcs_from(label);
+  }
+  if (o.have_write_loaded) {  // cascade.h:23-32
+    for (size_t i = 0; i < nw; ++i) {
+      std::string fn = o.write_loaded.empty() ? std::string(o.files[i + 1]) : std::string(o.files[i + 1]) + "." + o.write_loaded;
+      if (const char* dir = std::getenv("CARMEL_TRAINED_DIR")) {
+        std::string bname = o.files[i + 1];
+        size_t sl = bname.rfind('/');
+        if (sl != std::string::npos) bname = bname.substr(sl + 1);
+        fn = std::string(dir) + "/" + bname + (o.write_loaded.empty() ? "" : "." + o.write_loaded);
+      }
+      std::cerr << "Writing " << o.write_loaded << ' ' << o.files[i + 1] << " to " << fn << std::endl;
+      std::ofstream of(fn.c_str());
+      of << member[i].to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], wstyle);
+    }
+  }
+  // ---- composition chain, left to right (carmel.cc:1287-1355) ----
+  if (!o.flags[(unsigned)'d']) member[0].prune_useless();
+  ParamTable params;
+  ChainTable chains;
+  std::unique_ptr<Transducer> composed;
+  Transducer* result = &member[0];
+  const bool cascade = o.train_cascade && nw > 1;
+  if (nw > 1) {
+    for (size_t i = 0; i < nw; ++i) params.add_member(member[i]);
+    Composer comp(params, chains, (unsigned)o.index_threshold, /*trivial=*/!o.train_cascade);
+    Operand A, B;
+    for (size_t i = 1; i < nw; ++i) {
+      A.bind(result, i > 1, params.member_base[0]);
+      B.bind(&member[i], false, params.member_base[i]);
+      std::unique_ptr<Transducer> next(new Transducer());
+      double dev_s = 0;
+      const bool ok = o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next)  // carmel.cc:1318
+                      : o.gpu_compose        ? comp.run_device(A, B, *next, o.gpu + ((std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host") ? 0 : rank), &dev_s)
+                                             : comp.run(A, B, *next);
+      if (o.gpu_compose && !o.flags[(unsigned)'a'] && std::getenv("CARMEL_TIMING"))
+        std::cerr << "timing: composition on the GPU " << dev_s << " s\n";
+      if (!ok) {
+        std::cerr << ")\nEmpty or invalid result of composition with transducer \"" << o.files[i + 1] << "\".\n";
+        return -3;
+      }
+      size_t st = next->states.size(), ar = next->num_arcs();
+      if (!o.flags[(unsigned)'d']) next->prune_useless();
+      if (!quiet) {
+        std::cerr << "\n\t(" << st << " states / " << ar << " arcs";
+        if (next->states.size() != st || next->num_arcs() != ar)
+          std::cerr << " reduce-> " << next->states.size() << "/" << next->num_arcs();
+        std::cerr << ")";
+      }
+      composed = std::move(next);
+      result = composed.get();
+    }
+    if (!quiet) std::cerr << std::endl;
+  }
+  if (!with_pairs) {  // plain `carmel a b ...`: print the (reduced) composition — no GPU involved
+    const int ws = wstyle;
+    if (o.flags[(unsigned)'c'])
+      std::cout << "Number of states in result: " << result->states.size() << "\nNumber of arcs in result: "
+                << result->num_arcs() << "\n";
+    else
+      std::cout << result->to_text(o.flags[(unsigned)'J'], o.flags[(unsigned)'H'], ws);
+    return 0;
+  }
   // ---- corpus ----
   HostPairs pairs;
   std::string warn;

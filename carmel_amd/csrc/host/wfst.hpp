@@ -297,6 +297,118 @@ class Transducer {
     for (auto& st : states)
       for (auto& a : st) a.logw = logw[k++];
   }
+  // WFST::normalize (fst.cc:86-244) on the input transducers themselves: what carmel does to every input BEFORE composing
+  // when --normby is given (fem_normby, carmel.cc:778-783, 800).  by: 0 = per (state, input), 1 = per state, 2 = none.
+  // add_count is added to every weight first -- locked arcs keep it --, locked arcs reserve their weight, tied groups get
+  // (sum of their arcs) / (sum of their states' unlocked mass, made room for the largest locked sum), the rest shares what
+  // is left in proportion.  scale: the mean-field scale exp(digamma(x + alpha)) (mean_field_scale.hpp:40-52) or linear.
+  // (The training-time M-step runs on the GPU, kernels.hip; this host pass only prepares inputs, like the parser.)
+  static double ln_add(double a, double b) {
+    if (a == kNegInf) return b;
+    if (b == kNegInf) return a;
+    return a > b ? a + std::log1p(std::exp(b - a)) : b + std::log1p(std::exp(a - b));
+  }
+  static double digamma_pos(double x) {  // recurrence up to 6, then the asymptotic series
+    double r = 0;
+    while (x < 6) {
+      r -= 1 / x;
+      x += 1;
+    }
+    const double f = 1 / (x * x);
+    return r + std::log(x) - 0.5 / x - f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132)))));
+  }
+  void normalize(int by, double add_count, bool dig, double dig_alpha) {
+    if (by == 2) return;
+    auto scale = [&](double lw) -> double {  // ln of the scaled weight
+      if (!dig) return lw;
+      const double xa = std::exp(lw) + dig_alpha, floor = .0002;
+      if (xa < floor) return digamma_pos(floor) + std::log(xa / floor);
+      return digamma_pos(xa);
+    };
+    const double ln_add_count = add_count > 0 ? std::log(add_count) : kNegInf;
+    // norm groups: lists of (state, arc index)
+    std::vector<std::vector<std::pair<uint32_t, uint32_t> > > groups;
+    for (uint32_t st = 0; st < states.size(); ++st) {
+      if (by == 1) {
+        groups.emplace_back();
+        for (uint32_t k = 0; k < states[st].size(); ++k) groups.back().push_back({st, k});
+      } else {
+        std::unordered_map<uint32_t, size_t> at;
+        for (uint32_t k = 0; k < states[st].size(); ++k) {
+          auto it = at.find(states[st][k].in);
+          if (it == at.end()) {
+            at.emplace(states[st][k].in, groups.size());
+            groups.emplace_back();
+            groups.back().push_back({st, k});
+          } else
+            groups[it->second].push_back({st, k});
+        }
+      }
+    }
+    std::unordered_map<uint32_t, double> tie_arc, tie_state, tie_maxlocked;  // ln; missing = 0
+    auto get = [](std::unordered_map<uint32_t, double>& m, uint32_t k) -> double& {
+      auto it = m.find(k);
+      if (it == m.end()) it = m.emplace(k, kNegInf).first;
+      return it->second;
+    };
+    for (auto& g : groups) {
+      double sum = kNegInf, locked = kNegInf;
+      for (auto& sk : g) {
+        HArc& a = states[sk.first][sk.second];
+        a.logw = ln_add(a.logw, ln_add_count);
+        if (a.group == kLocked) locked = ln_add(locked, a.logw); else sum = ln_add(sum, a.logw);
+      }
+      for (auto& sk : g) {
+        const HArc& a = states[sk.first][sk.second];
+        if (a.group != kLocked && a.group != kNoGroup) {
+          double& t = get(tie_arc, a.group);
+          t = ln_add(t, a.logw);
+          double& u = get(tie_state, a.group);
+          u = ln_add(u, sum);
+          double& m = get(tie_maxlocked, a.group);
+          if (locked > m) m = locked;
+        }
+      }
+    }
+    for (auto& g : groups) {
+      double normal = kNegInf, reserved = kNegInf;
+      for (auto& sk : g) {
+        HArc& a = states[sk.first][sk.second];
+        if (a.group != kLocked && a.group != kNoGroup) {
+          double gnorm = get(tie_state, a.group);
+          const double gmax = get(tie_maxlocked, a.group);
+          if (gmax > 0.0) {  // locked arcs of some state sum to more than 1
+            a.logw = kNegInf;
+          } else {
+            if (gmax != kNegInf) gnorm -= std::log1p(-std::exp(gmax));
+            const double gtot = get(tie_arc, a.group);
+            if (gtot != kNegInf) {
+              a.logw = scale(gtot) - scale(gnorm);
+              reserved = ln_add(reserved, a.logw);
+            } else
+              a.logw = kNegInf;
+          }
+        } else if (a.group == kLocked)
+          reserved = ln_add(reserved, a.logw);
+        else
+          normal = ln_add(normal, a.logw);
+      }
+      // 1 - reserved (weight.h's operator-=: a result below zero is zero)
+      const double remain = reserved == kNegInf ? 0.0 : (reserved >= 0.0 ? kNegInf : std::log1p(-std::exp(reserved)));
+      const bool left = remain != kNegInf && normal != kNegInf;
+      const double scaled_sum = left ? scale(normal) : 0.0;
+      for (auto& sk : g) {
+        HArc& a = states[sk.first][sk.second];
+        if (a.group == kNoGroup) a.logw = left ? remain + scale(a.logw) - scaled_sum : kNegInf;
+      }
+    }
+  }
+  // cascade_parameters::number_from (cascade.h:52-64) / WFST::numberArcsFrom (fst.cc:290-298): consecutive tie-group ids
+  uint32_t number_arcs_from(uint32_t label) {
+    for (auto& st : states)
+      for (auto& a : st) a.group = label++;
+    return label;
+  }
 
  private:
   std::unordered_map<std::string, uint32_t> name_ids_;

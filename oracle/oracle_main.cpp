@@ -109,6 +109,43 @@ static int real_main(int argc, char** argv) {
     }
     if (!flags['m'] && nw > 1) chain[i].named_states = false;  // unNameStates carmel.cc:1200
   }
+  // carmel_main::norms() carmel.cc:488-499
+  size_t N = trainc ? nw : 1;
+  std::vector<NormalizeMethod> nms(N, nm);
+  for (size_t i = 0; i < normby.size() && i < N; ++i) {
+    char c = normby[i];
+    nms[i].group = (c == 'J' || c == 'j') ? NORM_JOINT : (c == 'N' || c == 'n') ? NORM_NONE : NORM_CONDITIONAL;
+  }
+  {
+    std::stringstream ss(priors);
+    std::string tok;
+    size_t i = 0;
+    while (std::getline(ss, tok, ',') && i < N) nms[i++].add_count = LW::from_real(std::atof(tok.c_str()));
+  }
+  if (plus_set)
+    for (auto& m : nms) {
+      m.scale.linear = false;
+      m.scale.alpha = plus_alpha;
+    }
+  if (have_digamma) {  // carmel.cc:495: one component per transducer, empty = linear
+    size_t i = 0, p0 = 0;
+    while (i < N) {
+      size_t c = digamma.find(',', p0);
+      std::string tok = digamma.substr(p0, c == std::string::npos ? std::string::npos : c - p0);
+      if (!tok.empty()) {
+        nms[i].scale.linear = false;
+        nms[i].scale.alpha = std::atof(tok.c_str());
+      }
+      ++i;
+      if (c == std::string::npos) break;
+      p0 = c + 1;
+    }
+  }
+  // fem_in -> fem_normby (carmel.cc:778-783, 800): with --normby the inputs are normalised before composition
+  if (!normby.empty()) {
+    std::cerr << "Normalizing input transducers by --normby=" << normby << std::endl;
+    for (size_t i = 0; i < nw; ++i) chain[i].normalize(nms[i < N ? i : 0]);
+  }
   bool remember = trainc;
   Cascade cascade(remember);
   Wfst* result = &chain[0];
@@ -147,38 +184,6 @@ static int real_main(int argc, char** argv) {
   }
   if (!anycomposed) cascade.set_composed(result);
   if (!flags['q']) std::cerr << std::endl;
-  // carmel_main::norms() carmel.cc:488-499
-  size_t N = trainc ? nw : 1;
-  std::vector<NormalizeMethod> nms(N, nm);
-  for (size_t i = 0; i < normby.size() && i < N; ++i) {
-    char c = normby[i];
-    nms[i].group = (c == 'J' || c == 'j') ? NORM_JOINT : (c == 'N' || c == 'n') ? NORM_NONE : NORM_CONDITIONAL;
-  }
-  {
-    std::stringstream ss(priors);
-    std::string tok;
-    size_t i = 0;
-    while (std::getline(ss, tok, ',') && i < N) nms[i++].add_count = LW::from_real(std::atof(tok.c_str()));
-  }
-  if (plus_set)
-    for (auto& m : nms) {
-      m.scale.linear = false;
-      m.scale.alpha = plus_alpha;
-    }
-  if (have_digamma) {  // carmel.cc:495: one component per transducer, empty = linear
-    size_t i = 0, p0 = 0;
-    while (i < N) {
-      size_t c = digamma.find(',', p0);
-      std::string tok = digamma.substr(p0, c == std::string::npos ? std::string::npos : c - p0);
-      if (!tok.empty()) {
-        nms[i].scale.linear = false;
-        nms[i].scale.alpha = std::atof(tok.c_str());
-      }
-      ++i;
-      if (c == std::string::npos) break;
-      p0 = c + 1;
-    }
-  }
   int wmode = flags['Z'] ? LW_ALWAYS_LOG : LW_SOMETIMES_LOG;
   if (flags['D']) wmode = LW_NEVER_LOG;
   if (flags['B'])

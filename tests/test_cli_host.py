@@ -159,3 +159,57 @@ def test_weight_output_bases(golden_dir, oracle, flags, suffix):
             assert tok.startswith("e^") and float(tok[2:]) == pytest.approx(lw, abs=1e-12)
     back = oracle.OracleWfst.parse(out)  # the oracle's reader parses what the front end wrote
     assert back.arrays()["logw"] == pytest.approx(want, abs=1e-12)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_normby_normalises_the_inputs_before_composing(oracle, tmp_path, seed):
+    """fem_in -> fem_normby (carmel.cc:778-808): with --normby every INPUT transducer is normalised -- priors added, locked
+    arcs reserving their weight, tied groups sharing one -- before anything is composed; --write-loaded=suffix writes them,
+    --number-from=N first gives every arc its own tie group.  The host-side normalisation (the same fst.cc:86-244 the GPU
+    M-step implements) against the oracle's, on random transducers with locked and tied arcs."""
+    import re
+    import numpy as np
+    rng = np.random.default_rng(500 + seed)
+    a = random_fst_text(rng, int(rng.integers(2, 7)), int(rng.integers(3, 16)), ["a", "b", "c"], ["x", "y"], float(rng.uniform(0, 0.3)))
+    b = random_fst_text(rng, int(rng.integers(2, 7)), int(rng.integers(3, 16)), ["x", "y"], ["u", "v"], float(rng.uniform(0, 0.3)))
+    # tie some unlocked arcs of b into groups 7 and 8
+    lines = b.split("\n")
+    for k in range(1, len(lines)):
+        if lines[k].endswith("))") and not lines[k].endswith("!))") and rng.random() < 0.3:
+            lines[k] = lines[k][:-2] + "!%d))" % int(rng.integers(7, 9))
+    b = "\n".join(lines)
+    pa, pb = str(tmp_path / "a.fst"), str(tmp_path / "b.fst")
+    open(pa, "w").write(a)
+    open(pb, "w").write(b)
+    normby = "".join(rng.choice(["J", "C", "N"], 2))
+    priors = [float(rng.choice([0.0, 0.25, 1.5])), float(rng.choice([0.0, 0.1]))]
+    env = dict(os.environ, CARMEL_TRAINED_DIR=str(tmp_path))
+    p = subprocess.run([CLI, "-HJm", "-q", "--normby=" + normby, "--priors=%r,%r" % tuple(priors), "--write-loaded=loaded", pa, pb],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env)
+    if p.returncode == 256 - 2:  # a random file whose final state has no arc: both readers refuse it
+        with pytest.raises((RuntimeError, ValueError)):
+            oracle.OracleWfst.parse(a), oracle.OracleWfst.parse(b)
+        return
+    assert p.returncode in (0, 256 - 3), p.stderr   # (the composition itself may be empty)
+    assert "Normalizing input transducers by --normby=" + normby in p.stderr
+    num = re.compile(r"(?<![A-Za-z_*])-?\d+\.?\d*(?:e[+-]?\d+)?(?![A-Za-z_])")
+    for path, text, ch, pr in ((pa, a, normby[0], priors[0]), (pb, b, normby[1], priors[1])):
+        ow = oracle.OracleWfst.parse(text)
+        if ch != "N":
+            ow.normalize(1 if ch == "J" else 0, pr)
+        want = ow.write(full=True, onearc=True)
+        got = open(os.path.join(str(tmp_path), os.path.basename(path) + ".loaded")).read()
+        gl, wl = got.strip().split("\n"), want.strip().split("\n")
+        assert len(gl) == len(wl)
+        for x, y in zip(gl, wl):
+            assert num.sub("#", x) == num.sub("#", y), (x, y)
+            for u, v in zip(num.findall(x), num.findall(y)):
+                assert float(u) == pytest.approx(float(v), rel=1e-9, abs=1e-300)
+    # --number-from: consecutive group ids over the inputs, in file order
+    p = subprocess.run([CLI, "-HJm", "-q", "--number-from=5", "--write-loaded=num", pa, pb], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, universal_newlines=True, env=env)
+    assert "Assigning unique group ids to each arc in input cascade starting at 5" in p.stderr
+    ids = []
+    for path in (pa, pb):
+        ids += [int(x) for x in re.findall(r"!(\d+)\)\)", open(os.path.join(str(tmp_path), os.path.basename(path) + ".num")).read())]
+    assert ids == list(range(5, 5 + len(ids))) and len(ids) > 0
