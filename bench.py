@@ -171,8 +171,19 @@ def other_configs(args):
         ms = (sum(est) + sum(mx)) / max(len(est), 1)
         k_ms = sum(ker) / max(len(ker), 1)
         # the unrolled sweep never stores a lattice: per lattice arc it does one multiply-add forwards, and backwards a
-        # multiply-add, the posterior (two multiplies) and its accumulation -- 8 f64 flops -- out of L2-resident tables
-        flops = 8.0 * arcs
+        # multiply-add, the posterior (two multiplies) and its accumulation -- 8 f64 flops -- out of L2-resident tables.
+        # In its dense form (dense.hpp: weight(s -> s', c) = A[s][s'] * B[c][s']) a position of a string is two S x S
+        # vector-matrix products (forward, backward): 4 S^2 flops, S the real state count (the padding is not priced).
+        dn = re.search(r"timing: dense sweep S=(\d+) padded=(\d+) .* positions=(\d+)", p.stderr)
+        if dn:
+            flops = 4.0 * float(dn.group(1)) ** 2 * float(dn.group(3))
+            kname = ("dense_mfma_kernel (v_mfma_f64_16x16x4_f64: per string position two %sx%s vector-matrix products, priced at "
+                     "4 S^2 flops per position against the f64 vector peak; tools/f64_rate.hip measures 49.7 TFLOP/s for the f64 "
+                     "matrix instruction and 65.8 for v_fma_f64 on this part)" % (dn.group(1), dn.group(1)))
+        else:
+            flops = 8.0 * arcs
+            kname = ("unrolled_sweep_kernel (f64 vector FMAs on L2-resident tables; priced against the f64 rate, 8 flops per "
+                     "lattice arc -- it moves 2 B of HBM per string position)")
         value, world = _replicas(arcs / (ms * 1e-3))
         out = {"metric": "arc-updates/sec (EM iterations/sec x derivation-lattice arcs swept per iteration)", "value": value,
                "unit": "arc-updates/s", "n_gpus": world, "steps": len(est), "warmup": args.warmup, "ms_per_step": ms,
@@ -181,8 +192,7 @@ def other_configs(args):
                                       "%d lines of 30-80 symbols, carmel --train-cascade --normby=NC through the front end; "
                                       "lattices unrolled over string positions, never stored" % args.lines,
                           "lattice_arcs_per_gpu": int(arcs), "lattice_layout": lat.group(4), "parallelism": "replicas x%d" % world},
-               "roofline": {"bound": "mfma", "kernel": "unrolled_sweep_kernel (f64 vector FMAs on L2-resident tables; priced "
-                            "against the f64 rate, 8 flops per lattice arc -- it moves 2 B of HBM per string position)",
+               "roofline": {"bound": "mfma", "kernel": kname,
                             "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": flops / (k_ms * 1e-3) / 1e12 / F64_PEAK_TFLOPS, "traffic": None, "kernel_ms": k_ms}}
         if not args.no_cpu_baseline and rank == 0:

@@ -882,6 +882,11 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   return CARMEL_HIP_OK;
 }
 
+int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
+  if (!t || !t->have_lattices) return -1;
+  return t->unrolled ? (t->dense ? 2 : 1) : 0;
+}
+
 int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* res) {
   if (!t || !res) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));

@@ -133,6 +133,14 @@ struct carmel_hip_trainer {
   DevBuf<double> u_param_uses;          // cascade: composed arcs whose chain holds the parameter (for the -f prior)
   DevBuf<double> u_em_param, u_best_param;  // cascade: parameter-space images of em_weight / best_weight
   uint32_t u_n_slots = 0, u_n_wg = 0;
+  // rank-1 dense form of the unrolled sweep (dense.hpp): weight(s -> s', c) = A[s][s'] * B[c][s']
+  bool dense = false;
+  uint32_t d_SP = 0, d_groups = 0;
+  DevBuf<double> d_A, d_AT, d_B, d_vbuf, d_zbuf, d_weight, d_partial;
+  DevBuf<uint32_t> d_a_off, d_a_par, d_b_off, d_b_par, d_len, d_pair;
+  DevBuf<uint8_t> d_a_has, d_b_has;
+  DevBuf<uint16_t> d_Bslot, d_sym;
+  DevBuf<uint64_t> d_sym_off, d_vbuf_off;
   // the E-step as a replayed hipGraph (engine.cpp: carmel_hip_estimate_async)
   hipGraphExec_t graph_exec = nullptr;
   const void* graph_key = nullptr;

@@ -1,12 +1,149 @@
 // engine_unrolled.cpp: the trainer's side of the unrolled sweep (unrolled.hpp): eligibility, upload, E-step.
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 
+#include "dense.hpp"
 #include "engine.hpp"
 #include "unrolled_args.hpp"
+#include <numeric>
+
+// The rank-1 dense form (dense.hpp).  Eligible: a cascade, at most DENSE_MAX_STATES states, no *e*:*e* arcs, and for every
+// arc (s -> s', symbol c) the parameters of its chain that collect NO counts are the same for all c (they make A[s][s']),
+// the ones that do are the same for all s (at most one: B[c][s'] and its accumulator), and an arc exists exactly when both
+// its A and its B entry do.  Returns false (with t->dense clear) when the model is not of that shape.
+static int dense_try_build(carmel_hip_trainer* t, const UnrolledModel& M, const std::vector<uint32_t>& slot_of, uint32_t n_slots,
+                           bool& built) {
+  built = false;
+  t->dense = false;
+  if (const char* e = getenv("CARMEL_HIP_DENSE"))
+    if (atoi(e) == 0) return CARMEL_HIP_OK;
+  const uint32_t S = M.S, V = M.V, SP = dense_padded_states(S);
+  if (!t->cascade || !SP || S > DENSE_MAX_STATES || M.e_arc.size() > 16 || V == 0 || V > 4096) return CARMEL_HIP_OK;
+  for (uint32_t a : M.e_arc) {  // *e*:*e* arcs are swept but collect nothing here: all their parameters must be count-free
+    const uint32_t ch = t->w.group[a];
+    for (uint64_t j = t->h_chain_off[ch]; j < t->h_chain_off[ch + 1]; ++j)
+      if (slot_of[t->h_chain_param[j]] != 0xffffffffu) return CARMEL_HIP_OK;
+  }
+  if ((size_t)V * SP * 10 + (size_t)n_slots * 8 > 60 * 1024) return CARMEL_HIP_OK;  // B, its slots and the accumulators live in LDS
+  std::vector<std::vector<uint32_t> > la((size_t)SP * SP), ub((size_t)V * SP);
+  std::vector<uint8_t> a_has((size_t)SP * SP, 0), b_has((size_t)V * SP, 0);
+  std::vector<uint8_t> seen((size_t)S * S * V, 0);
+  std::vector<uint32_t> L, U;
+  uint64_t n_seen = 0;
+  for (uint32_t x = 0; x < V; ++x)
+    for (uint32_t e = M.f_off[x]; e < M.f_off[x + 1]; ++e) {
+      const uint32_t a = M.f_arc[e];
+      if (a == 0xffffffffu) continue;
+      const uint32_t dst = (e - M.f_off[x]) % S, src = M.f_src[e];
+      uint8_t& sn = seen[((size_t)src * S + dst) * V + x];
+      if (sn) return CARMEL_HIP_OK;  // two arcs between the same states with the same symbol
+      sn = 1;
+      ++n_seen;
+      L.clear();
+      U.clear();
+      const uint32_t ch = t->w.group[a];
+      for (uint64_t j = t->h_chain_off[ch]; j < t->h_chain_off[ch + 1]; ++j) {
+        const uint32_t p = (uint32_t)t->h_chain_param[j];
+        (slot_of[p] == 0xffffffffu ? L : U).push_back(p);
+      }
+      std::sort(L.begin(), L.end());
+      std::sort(U.begin(), U.end());
+      if (U.size() > 1) return CARMEL_HIP_OK;
+      const size_t ka = (size_t)src * SP + dst, kb = (size_t)x * SP + dst;
+      if (!a_has[ka]) {
+        a_has[ka] = 1;
+        la[ka] = L;
+      } else if (la[ka] != L)
+        return CARMEL_HIP_OK;
+      if (!b_has[kb]) {
+        b_has[kb] = 1;
+        ub[kb] = U;
+      } else if (ub[kb] != U)
+        return CARMEL_HIP_OK;
+    }
+  {  // rank-1 support: every (A entry, B entry) pair that meets in a destination state is an arc
+    uint64_t want = 0;
+    for (uint32_t d = 0; d < S; ++d) {
+      uint64_t na = 0, nb = 0;
+      for (uint32_t s0 = 0; s0 < S; ++s0) na += a_has[(size_t)s0 * SP + d];
+      for (uint32_t x = 0; x < V; ++x) nb += b_has[(size_t)x * SP + d];
+      want += na * nb;
+    }
+    if (want != n_seen || !n_seen) return CARMEL_HIP_OK;
+  }
+  // strings: sorted by length, 64 per wavefront
+  const size_t np = M.pair_id.size();
+  std::vector<uint32_t> order(np);
+  std::iota(order.begin(), order.end(), 0u);
+  auto len_of = [&](uint32_t k) { return (uint32_t)(M.seq_off[k + 1] - M.seq_off[k]); };
+  for (uint32_t k = 0; k < np; ++k)
+    if (len_of(k) == 0) return CARMEL_HIP_OK;  // (an empty string has no position to sweep)
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return len_of(a) > len_of(b); });
+  const uint32_t ng = (uint32_t)((np + 63) / 64);
+  std::vector<uint64_t> sym_off(ng + 1, 0), vbuf_off(ng + 1, 0);
+  for (uint32_t g = 0; g < ng; ++g) {
+    const uint64_t tmax = len_of(order[(size_t)g * 64]);
+    sym_off[g + 1] = sym_off[g] + tmax * 64;
+    vbuf_off[g + 1] = vbuf_off[g] + tmax * SP * 64;
+  }
+  if (vbuf_off[ng] * 8 > (16ull << 30)) return CARMEL_HIP_OK;
+  std::vector<uint16_t> sym(sym_off[ng], 0);
+  std::vector<uint32_t> len((size_t)ng * 64, 0), pair((size_t)ng * 64, 0);
+  std::vector<double> weight((size_t)ng * 64, 0.0);
+  for (size_t k = 0; k < np; ++k) {
+    const uint32_t q = order[k], g = (uint32_t)(k / 64), l = (uint32_t)(k % 64), T = len_of(q);
+    len[k] = T;
+    pair[k] = M.pair_id[q];
+    weight[k] = M.pair_weight[q];
+    for (uint32_t tt = 0; tt < T; ++tt) sym[sym_off[g] + (size_t)tt * 64 + l] = M.seq_sym[M.seq_off[q] + tt];
+  }
+  std::vector<uint32_t> a_off(la.size() + 1, 0), a_par, b_off(ub.size() + 1, 0), b_par;
+  for (size_t k = 0; k < la.size(); ++k) {
+    a_par.insert(a_par.end(), la[k].begin(), la[k].end());
+    a_off[k + 1] = (uint32_t)a_par.size();
+  }
+  std::vector<uint16_t> bslot(ub.size(), (uint16_t)0xffffu);
+  for (size_t k = 0; k < ub.size(); ++k) {
+    b_par.insert(b_par.end(), ub[k].begin(), ub[k].end());
+    b_off[k + 1] = (uint32_t)b_par.size();
+    if (ub[k].size() == 1) bslot[k] = (uint16_t)slot_of[ub[k][0]];
+  }
+  if (a_par.empty()) a_par.push_back(0);
+  if (b_par.empty()) b_par.push_back(0);
+  hipStream_t s = t->stream;
+  HIPCHK(t->d_a_off.upload(a_off, s));
+  HIPCHK(t->d_a_par.upload(a_par, s));
+  HIPCHK(t->d_b_off.upload(b_off, s));
+  HIPCHK(t->d_b_par.upload(b_par, s));
+  HIPCHK(t->d_a_has.upload(a_has, s));
+  HIPCHK(t->d_b_has.upload(b_has, s));
+  HIPCHK(t->d_Bslot.upload(bslot, s));
+  HIPCHK(t->d_sym.upload(sym, s));
+  HIPCHK(t->d_sym_off.upload(sym_off, s));
+  HIPCHK(t->d_vbuf_off.upload(vbuf_off, s));
+  HIPCHK(t->d_len.upload(len, s));
+  HIPCHK(t->d_pair.upload(pair, s));
+  HIPCHK(t->d_weight.upload(weight, s));
+  HIPCHK(t->d_A.alloc((size_t)SP * SP));
+  HIPCHK(t->d_AT.alloc((size_t)SP * SP));
+  HIPCHK(t->d_B.alloc((size_t)V * SP));
+  HIPCHK(t->d_vbuf.alloc(vbuf_off[ng]));
+  HIPCHK(t->d_zbuf.alloc(sym_off[ng]));
+  HIPCHK(t->d_partial.alloc((size_t)ng * n_slots));
+  HIPCHK(hipStreamSynchronize(s));
+  t->d_SP = SP;
+  t->d_groups = ng;
+  t->dense = true;
+  if (getenv("CARMEL_TIMING"))
+    fprintf(stderr, "timing: dense sweep S=%u padded=%u symbols=%u eps=%zu slots=%u strings=%zu positions=%llu groups=%u parked_bytes=%llu\n", S, SP,
+            V, M.e_arc.size(), n_slots, np, (unsigned long long)M.seq_sym.size(), ng, (unsigned long long)(vbuf_off[ng] * 8));
+  built = true;
+  return CARMEL_HIP_OK;
+}
 
 // Tries to set the trainer up for the unrolled sweep.  Returns CARMEL_HIP_OK with t->unrolled set when the model and
 // the corpus are eligible, CARMEL_HIP_OK with t->unrolled clear when they are not (the caller then builds explicit
@@ -158,6 +295,14 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
+  if (t->cascade) {
+    bool dense_built = false;
+    int rc = dense_try_build(t, M, slot_of, n_slots, dense_built);
+    if (rc) return rc;
+    if (dense_built) t->device_bytes += t->d_vbuf.bytes() + t->d_zbuf.bytes() + t->d_sym.bytes() + t->d_partial.bytes();
+    if (stats) stats->device_bytes = t->device_bytes;
+  } else
+    t->dense = false;
   // the bulk host arrays are on the device now
   std::vector<uint16_t>().swap(M.seq_sym);
   std::vector<uint64_t>().swap(M.seq_off);
@@ -171,6 +316,40 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
 // the E-step proper (weights are current in t->arc_logw): counts into counts_ptr()[0 .. n_slots), ln p per pair
 int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   const UnrolledModel& M = t->um;
+  if (t->dense) {
+    HIPCHK(launch_dense_tables(t->d_A.p, t->d_AT.p, t->d_B.p, t->d_SP, M.V, t->d_a_off.p, t->d_a_par.p, t->d_b_off.p, t->d_b_par.p,
+                               t->d_a_has.p, t->d_b_has.p, t->param_logw_c.p, s));
+    DenseArgs D;
+    D.S = M.S;
+    D.SP = t->d_SP;
+    D.V = M.V;
+    D.start = M.start;
+    D.fin = M.fin;
+    D.n_slots = t->u_n_slots;
+    D.n_eps = (uint32_t)t->u_e_arc.n;
+    D.debug = getenv("CARMEL_HIP_DENSE_DEBUG") ? (uint32_t)atoi(getenv("CARMEL_HIP_DENSE_DEBUG")) : 0u;
+    D.e_src = t->u_e_src.p;
+    D.e_dst = t->u_e_dst.p;
+    D.We = t->u_We.p;
+    HIPCHK(launch_unrolled_weights(t->u_e_arc.p, t->arc_logw.p, t->u_We.p, 1, (uint32_t)t->u_e_arc.n, s));
+    D.A = t->d_A.p;
+    D.AT = t->d_AT.p;
+    D.B = t->d_B.p;
+    D.Bslot = t->d_Bslot.p;
+    D.sym = t->d_sym.p;
+    D.sym_off = t->d_sym_off.p;
+    D.len = t->d_len.p;
+    D.pair = t->d_pair.p;
+    D.weight = t->d_weight.p;
+    D.pair_logprob = t->pair_logprob.p;
+    D.vbuf = t->d_vbuf.p;
+    D.vbuf_off = t->d_vbuf_off.p;
+    D.zbuf = t->d_zbuf.p;
+    D.partial = t->d_partial.p;
+    HIPCHK(launch_dense_sweep(D, t->d_groups, s));
+    HIPCHK(launch_unrolled_reduce(t->d_partial.p, t->d_groups, t->u_n_slots, t->counts_ptr(), s));
+    return CARMEL_HIP_OK;
+  }
   HIPCHK(launch_unrolled_weights(t->u_f_arc.p, t->arc_logw.p, (double*)t->u_f_rec.p, 2, (uint32_t)t->u_f_arc.n, s));
   HIPCHK(launch_unrolled_weights(t->u_b_arc.p, t->arc_logw.p, (double*)t->u_b_rec.p, 2, (uint32_t)t->u_b_arc.n, s));
   HIPCHK(launch_unrolled_weights(t->u_e_arc.p, t->arc_logw.p, t->u_We.p, 1, (uint32_t)t->u_e_arc.n, s));

@@ -658,7 +658,7 @@ static int run(int argc, char** argv) {
   hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
   if (std::getenv("CARMEL_TIMING"))
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
-              << " layout=" << (ls.n_bundles ? "explicit" : "unrolled") << " device_bytes=" << ls.device_bytes
+              << " layout=" << (carmel_hip_lattice_layout(t) == 2 ? "unrolled_dense" : carmel_hip_lattice_layout(t) == 1 ? "unrolled" : "explicit") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;

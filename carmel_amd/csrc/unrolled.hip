@@ -484,6 +484,45 @@ hipError_t launch_unrolled_weights(const uint32_t* arcs, const double* logw, dou
   return hipGetLastError();
 }
 
+// many rows (the dense sweep leaves one per group of 64 strings): two levels, both in a fixed order (deterministic).
+// Level 1: the rows are cut into gridDim.y contiguous chunks; a workgroup sums the rows of its chunk for 64 slots (four
+// wavefronts take every fourth row) and leaves the sum in the chunk's own first row.  Level 2: the same kernel over those
+// first rows (stride = rows per chunk), into counts.
+__global__ __launch_bounds__(256) void unrolled_reduce_rows_kernel(double* __restrict__ partial, uint32_t n_rows, uint32_t chunk,
+                                                                   uint32_t stride, uint32_t n_slots, double* __restrict__ out) {
+  __shared__ double sh[4][64];
+  const uint32_t k = blockIdx.x * 64 + (threadIdx.x & 63), share = threadIdx.x >> 6;
+  const uint32_t r0 = blockIdx.y * chunk, r1 = min(n_rows, r0 + chunk);  // in units of `stride` rows
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (k < n_slots) {
+    uint32_t w = r0 + share;
+    for (; w + 12 < r1; w += 16)
+      for (int j = 0; j < 4; ++j) v[j] += partial[(size_t)(w + 4 * j) * stride * n_slots + k];
+    for (; w < r1; w += 4) v[0] += partial[(size_t)w * stride * n_slots + k];
+  }
+  sh[share][threadIdx.x & 63] = (v[0] + v[1]) + (v[2] + v[3]);
+  __syncthreads();
+  if (share == 0 && k < n_slots) {
+    const double sum = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (out)
+      out[k] = sum;
+    else
+      partial[(size_t)r0 * stride * n_slots + k] = sum;
+  }
+}
+// (partial is used as scratch when it has many rows)
+hipError_t launch_unrolled_reduce(double* partial, uint32_t n_wg, uint32_t n_slots, double* counts, hipStream_t s) {
+  if (n_wg >= 256) {
+    const uint32_t chunk = 64, n_chunks = (n_wg + chunk - 1) / chunk;
+    hipLaunchKernelGGL(unrolled_reduce_rows_kernel, dim3((n_slots + 63) / 64, n_chunks), dim3(256), 0, s, partial, n_wg, chunk, 1u,
+                       n_slots, (double*)nullptr);
+    hipLaunchKernelGGL(unrolled_reduce_rows_kernel, dim3((n_slots + 63) / 64, 1), dim3(256), 0, s, partial, n_chunks, n_chunks, chunk,
+                       n_slots, counts);
+  } else
+    hipLaunchKernelGGL(unrolled_reduce_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, s, partial, n_wg, n_slots, counts);
+  return hipGetLastError();
+}
+
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s) {
   if (A.S > UNROLLED_MAX_STATES) {
     const size_t lds = unrolled_wide_lds_bytes(A);

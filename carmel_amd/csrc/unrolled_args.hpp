@@ -45,6 +45,8 @@ hipError_t launch_unrolled_param_counts(double* out, const double* counts, const
                                         const double* wprior, const uint32_t* group, const uint32_t* slot_of, uint32_t n,
                                         hipStream_t s);
 hipError_t launch_unrolled_sweep(const UnrolledArgs& A, uint32_t n_wg, double* counts, hipStream_t s);
+// counts[k] = sum over the n_wg rows of partial[row][k]
+hipError_t launch_unrolled_reduce(double* partial, uint32_t n_wg, uint32_t n_slots, double* counts, hipStream_t s);
 // more than 64 states: a workgroup per pair, a thread per state
 size_t unrolled_wide_lds_bytes(const UnrolledArgs& A);
 size_t unrolled_wide_scratch_doubles(uint32_t n_wg, uint32_t S, uint32_t max_len);

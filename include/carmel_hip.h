@@ -87,6 +87,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
  * pair weights) -- the GPU lattice builder (csrc/lattice_gpu.hip; CARMEL_HIP_GPU_BUILD=0 switches it off) must leave
  * the very bytes the host builder leaves. */
 int carmel_hip_debug_lattice_fingerprint(carmel_hip_trainer* t, uint64_t* out16);
+/* how the derivation lattices are held: 0 = explicit (lane groups / bundles in HBM), 1 = unrolled over string positions
+ * (one-tape models, never stored), 2 = unrolled in the rank-1 dense form (LM o channel cascades, dense.hpp); -1: none built */
+int carmel_hip_lattice_layout(carmel_hip_trainer* t);
 
 /* Replaces: WFST::NormalizeMethod for a single (non-cascade) transducer — carmel -n/-j/-u and --priors
  * (carmel.cc:488-499); used by carmel_hip_maximize / carmel_hip_normalize. */

@@ -665,3 +665,48 @@ def test_crp_prior_inference_command(golden_dir, tmp_path, oracle):
     rc, out, err = run(["--crp", "-M", "3", "--prior-inference-stddev=0.1", "--prior-groupby=13", g("cipher.data"),
                         g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
     assert rc != 0 and "prior-groupby characters must be 0" in err
+
+
+@pytest.mark.parametrize("n_lines,normby", [(40, "NC"), (200, "NC"), (70, "NJ")])
+def test_dense_rank1_sweep_on_the_cipher_cascade(tmp_path, n_lines, normby):
+    """config 3's shape (locked character bigram LM o 27x27 substitution channel): the composed arcs factor as
+    A[s][s'] * B[c][s'], so the unrolled sweep runs in its dense form (dense.hpp: one string per lane, alpha in registers,
+    A through the scalar unit).  Same perplexities and the same trained channel as the table-walking unrolled sweep
+    (CARMEL_HIP_DENSE=0), explicit lattices (CARMEL_HIP_UNROLLED=0) and the oracle's command line."""
+    from carmel_amd import synth
+    if not os.path.exists(ORACLE_CLI):
+        pytest.skip("oracle CLI not built")
+    lm, ch, co = synth.cipher_files(n_lines, min_len=5, max_len=40, seed=7)
+    pa, pb, pc = (str(tmp_path / n) for n in ("lm.wfsa", "ch.fst", "corpus"))
+    open(pa, "w").write(lm)
+    open(pb, "w").write(ch)
+    open(pc, "w").write(co)
+    args = ["--train-cascade", "-HJ", "-M", "6", "--normby=" + normby, pc, pa, pb]
+    res = {}
+    for mode, env in (("dense", {}), ("tables", {"CARMEL_HIP_DENSE": "0"}), ("explicit", {"CARMEL_HIP_UNROLLED": "0"})):
+        d = tmp_path / mode
+        d.mkdir()
+        res[mode] = run(args, env=dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_TIMING="1", **env)) + (d,)
+        assert res[mode][0] == 0, res[mode][2]
+    assert "layout=unrolled_dense" in res["dense"][2]
+    assert "layout=unrolled " in res["tables"][2] and "layout=explicit" in res["explicit"][2]
+    p = subprocess.run([ORACLE_CLI] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                       env=dict(os.environ, ORACLE_TRAINED_DIR=str(tmp_path)))
+    assert p.returncode == 0, p.stderr
+    keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "Converged", "Maximum"))]
+    ref = keep(p.stderr)
+    for mode in ("dense", "tables", "explicit"):
+        mine = keep(res[mode][2])
+        assert len(mine) == len(ref) and mine
+        for x, y in zip(mine, ref):
+            assert NUM.sub("#", x) == NUM.sub("#", y)
+            for u, v in zip(NUM.findall(x), NUM.findall(y)):
+                assert float(u) == pytest.approx(float(v), rel=1e-5, abs=1e-9)
+        x, y = open(str(res[mode][3] / "ch.fst.trained")).read(), open(str(tmp_path / "ch.fst.trained")).read()
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-12)
+    # dense against the table walk: the same sums in another order
+    x, y = open(str(res["dense"][3] / "ch.fst.trained")).read(), open(str(res["tables"][3] / "ch.fst.trained")).read()
+    for u, v in zip(NUM.findall(x), NUM.findall(y)):
+        assert float(u) == pytest.approx(float(v), rel=1e-9, abs=1e-14)
