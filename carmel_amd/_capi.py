@@ -25,7 +25,7 @@ SYMBOLS = [
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_transpose", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_lattice_stats", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_run_ex", "carmel_hip_gibbs_set_prior_inference", "carmel_hip_gibbs_prior_trace",
-    "carmel_hip_gibbs_n_prior_scales", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
+    "carmel_hip_gibbs_n_prior_scales", "carmel_hip_gibbs_set_run_share", "carmel_hip_gibbs_best_stats", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
@@ -153,6 +153,8 @@ def _load():
     lib.carmel_hip_gibbs_set_prior_inference.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_uint32, vp, vp, C.c_uint32]
     lib.carmel_hip_gibbs_prior_trace.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.carmel_hip_gibbs_n_prior_scales.argtypes = [vp]
+    lib.carmel_hip_gibbs_set_run_share.argtypes = [vp, C.c_uint32, C.c_uint32]
+    lib.carmel_hip_gibbs_best_stats.argtypes = [vp, vp, vp]
     lib.carmel_hip_lattice_layout.argtypes = [vp]
     lib.carmel_hip_forests_set_prior_inference.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
     lib.carmel_hip_forests_prior_trace.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp]

@@ -579,6 +579,10 @@ struct carmel_hip_gibbs {
   std::vector<uint64_t> h_sample_off;
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
+  // runs as replicas (carmel_hip_gibbs_set_run_share): this sampler takes the runs r with r % run_stride == run_first
+  uint32_t run_first = 0, run_stride = 1;
+  bool ran_any = false;
+  double best_stats[3] = {0, 0, 0};  // gibbs_stats of the kept run: allprob, finalprob, sumprob (ln)
 };
 
 extern "C" {
@@ -891,7 +895,11 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   double best_all = 0, best_final = 0, best_sum = 0;
   DevBuf<uint32_t> best_ids, best_len;  // sample of the best run so far (--crp-restarts)
   g->pi_trace.assign((size_t)n_runs * (Ni + 1) * 6, 0.0);
+  if (g->run_stride > 1 && g->pi_stddev > 0 && !g->pi_restart_fresh)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "runs as replicas need independent runs: the inferred priors drift from run to run unless --prior-inference-restart-fresh");
+  g->ran_any = false;
   for (uint32_t run = 0; run < n_runs; ++run) {
+  if (run % g->run_stride != g->run_first) continue;  // another replica's run
   if (g->pi_stddev > 0 && run > 0 && g->pi_restart_fresh) {  // gibbs.hpp:889-898: the priors start over
     HIPCHK(hipMemcpyAsync(g->p_prior.p, g->h_prior0.data(), np * sizeof(double), hipMemcpyHostToDevice, s));
     std::vector<double> pn(ng, 0.0);
@@ -1049,12 +1057,15 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     lw[p] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
   }
   // gibbs_base::run_starts (gibbs.hpp:880-914): keep the run that is better by gibbs_stats::better (gibbs_opts.hpp:313-316)
-  const bool better = run == 0 || (g->opt.argmax_final ? st_final > best_final : g->opt.argmax_sum ? st_sum > best_sum : st_all > best_all);
+  const bool better = !g->ran_any || (g->opt.argmax_final ? st_final > best_final : g->opt.argmax_sum ? st_sum > best_sum : st_all > best_all);
   if (better) {
     g->best_run = run;
     best_all = st_all;
     best_final = st_final;
     best_sum = st_sum;
+    g->best_stats[0] = st_all;
+    g->best_stats[1] = st_final;
+    g->best_stats[2] = st_sum;
     best_lw = lw;
     if (n_runs > 1 && !g->opt.expectation) {
       HIPCHK(best_ids.alloc(g->sample_ids.n));
@@ -1064,7 +1075,12 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       HIPCHK(hipStreamSynchronize(s));
     }
   }
+  g->ran_any = true;
   }  // runs
+  if (!g->ran_any) {  // more replicas than runs: nothing to keep, the trainer's weights stay
+    g->ran = true;
+    return CARMEL_HIP_OK;
+  }
   if (n_runs > 1 && best_ids.p) {
     HIPCHK(hipMemcpyAsync(g->sample_ids.p, best_ids.p, g->sample_ids.bytes(), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(g->sample_len.p, best_len.p, g->sample_len.bytes(), hipMemcpyDeviceToDevice, s));
@@ -1092,6 +1108,18 @@ int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* i
 
 uint32_t carmel_hip_gibbs_max_sample(carmel_hip_gibbs* g) { return g ? g->max_sample : 0; }
 uint32_t carmel_hip_gibbs_best_run(carmel_hip_gibbs* g) { return g ? g->best_run : 0; }
+int carmel_hip_gibbs_set_run_share(carmel_hip_gibbs* g, uint32_t first, uint32_t stride) {
+  if (!g || stride == 0 || first >= stride) return fail(CARMEL_HIP_ERR_ARG, "bad run share");
+  g->run_first = first;
+  g->run_stride = stride;
+  return CARMEL_HIP_OK;
+}
+int carmel_hip_gibbs_best_stats(carmel_hip_gibbs* g, double* out3, int* ran_any) {
+  if (!g || !out3) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  for (int k = 0; k < 3; ++k) out3[k] = g->best_stats[k];
+  if (ran_any) *ran_any = g->ran_any ? 1 : 0;
+  return CARMEL_HIP_OK;
+}
 int carmel_hip_gibbs_set_init_weights(carmel_hip_gibbs* g, const double* arc_logw) {
   if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
   HIPCHK(hipSetDevice(g->t->device));

@@ -308,7 +308,9 @@ static int run(int argc, char** argv) {
   // expected counts are summed across ranks once per iteration (carmel_hip_allreduce_counts: RCCL over xGMI, on the
   // trainer's stream between the count pass and the M-step).  The M-step is replicated, so every rank holds the same
   // weights and takes the same decisions; rank 0 alone logs and writes the results. ----
-  int rank = 0, world = (training && !o.crp) ? o.gpus : 1;
+  // (--crp: the runs of --crp-restarts are independent chains; with --gpus=N rank r takes the runs r, r + N, ... on the whole
+  // corpus and the ranks agree on the run to keep -- gibbs_base::run_starts with its runs side by side)
+  int rank = 0, world = training ? ((o.crp && o.crp_restarts <= 0) ? 1 : o.gpus) : 1;
   std::vector<int> id_pipes;  // rank 0: write ends towards the other ranks
   int id_read = -1;
   std::vector<pid_t>& kids = g_kids;
@@ -335,7 +337,7 @@ static int run(int argc, char** argv) {
       kids.push_back(pid);
     }
   } else if (o.gpus > 1)
-    std::cerr << "--gpus=" << o.gpus << " applies to EM training (-t / --train-cascade); running on one GPU\n";
+    std::cerr << "--gpus=" << o.gpus << " applies to EM training (-t / --train-cascade) and to the runs of --crp --crp-restarts=R; running on one GPU\n";
   const bool quiet = o.flags[(unsigned)'q'] || rank > 0;
   if (!with_pairs) o.files.insert(o.files.begin(), (const char*)0);  // no corpus argument
   const size_t nw = o.files.size() - 1;
@@ -539,6 +541,8 @@ static int run(int argc, char** argv) {
       close(id_read);
     }
     hip_check(carmel_hip_comm_create(&comm, my_device, rank, world, id), "carmel_hip_comm_create");
+  }
+  if (world > 1 && !o.crp) {
     // this rank's block of the training pairs
     const size_t n = pairs.size(), lo = n * (size_t)rank / (size_t)world, hi = n * (size_t)(rank + 1) / (size_t)world;
     HostPairs mine;
@@ -675,7 +679,7 @@ static int run(int argc, char** argv) {
   if (ls.n_cyclic_pairs)
     std::cerr << "Warning: at least one cycle in derivations for " << ls.n_cyclic_pairs
               << " example(s).  Forward/backward will miss some paths.\n";  // derivations.h:726-728
-  if (comm) {  // the counters of training_corpus over ALL ranks' surviving pairs
+  if (comm && !o.crp) {  // the counters of training_corpus over ALL ranks' surviving pairs (--crp: every rank has the whole corpus)
     double v[5] = {cs.n_pairs, cs.total_weight, cs.n_input, cs.n_output, (double)ls.n_cyclic_pairs};
     hip_check(carmel_hip_comm_allreduce_host(comm, v, 5, 0), "carmel_hip_comm_allreduce_host");
     cs.n_pairs = v[0];
@@ -911,15 +915,53 @@ static int run(int argc, char** argv) {
                                                      member_states.data(), (uint32_t)nw),
                 "carmel_hip_gibbs_set_prior_inference");
     std::vector<double> lp((size_t)per_run * n_runs), lp_after(o.sample_prob_after ? lp.size() : 0);
+    if (world > 1) hip_check(carmel_hip_gibbs_set_run_share(gs, (uint32_t)rank, (uint32_t)world), "carmel_hip_gibbs_set_run_share");
     int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
-    const uint32_t best_run = carmel_hip_gibbs_best_run(gs);
+    uint32_t best_run = carmel_hip_gibbs_best_run(gs);
+    double my_stats[3] = {0, 0, 0};
+    int my_ran = 0;
+    if (rc == CARMEL_HIP_OK) hip_check(carmel_hip_gibbs_best_stats(gs, my_stats, &my_ran), "carmel_hip_gibbs_best_stats");
     std::vector<double> ptrace((size_t)per_run * n_runs * 6, 0.0), pcum(carmel_hip_gibbs_n_prior_scales(gs), 1.0);
     if (o.pi_stddev > 0 && rc == CARMEL_HIP_OK)
       hip_check(carmel_hip_gibbs_prior_trace(gs, ptrace.data(), per_run * n_runs, pcum.data(), (uint32_t)pcum.size()),
                 "carmel_hip_gibbs_prior_trace");
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
+    if (world > 1) {
+      // every rank's traces (zeros for the runs it did not take) add up to the whole log; the kept run is the best of the
+      // ranks' bests by gibbs_stats::better, the earlier run on a tie -- what the sequential loop would have kept
+      hip_check(carmel_hip_comm_allreduce_host(comm, lp.data(), (uint32_t)lp.size(), 0), "carmel_hip_comm_allreduce_host");
+      if (!lp_after.empty())
+        hip_check(carmel_hip_comm_allreduce_host(comm, lp_after.data(), (uint32_t)lp_after.size(), 0), "carmel_hip_comm_allreduce_host");
+      if (o.pi_stddev > 0)
+        hip_check(carmel_hip_comm_allreduce_host(comm, ptrace.data(), (uint32_t)ptrace.size(), 0), "carmel_hip_comm_allreduce_host");
+      std::vector<double> all((size_t)world * 5, 0.0);
+      all[(size_t)rank * 5] = my_ran;
+      all[(size_t)rank * 5 + 1] = my_stats[0];
+      all[(size_t)rank * 5 + 2] = my_stats[1];
+      all[(size_t)rank * 5 + 3] = my_stats[2];
+      all[(size_t)rank * 5 + 4] = best_run;
+      hip_check(carmel_hip_comm_allreduce_host(comm, all.data(), (uint32_t)all.size(), 0), "carmel_hip_comm_allreduce_host");
+      int winner = -1;
+      for (int r = 0; r < world; ++r) {
+        if (all[(size_t)r * 5] == 0) continue;
+        if (winner < 0) {
+          winner = r;
+          continue;
+        }
+        const int k = go.argmax_final ? 2 : go.argmax_sum ? 3 : 1;
+        const double mine = all[(size_t)r * 5 + k], best = all[(size_t)winner * 5 + k];
+        if (mine > best || (mine == best && all[(size_t)r * 5 + 4] < all[(size_t)winner * 5 + 4])) winner = r;
+      }
+      best_run = (uint32_t)all[(size_t)winner * 5 + 4];
+      std::vector<double> wts(cascade ? params.logw.size() : logw.size(), 0.0);
+      if (rank == winner) hip_check(carmel_hip_get_weights(t, wts.data()), "carmel_hip_get_weights");
+      // (ln weights: -inf from the winner plus 0 from the others stays -inf)
+      hip_check(carmel_hip_comm_allreduce_host(comm, wts.data(), (uint32_t)wts.size(), 0), "carmel_hip_comm_allreduce_host");
+      hip_check(carmel_hip_set_weights(t, wts.data()), "carmel_hip_set_weights");
+      if (rank > 0) return 0;
+    }
     double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())
     for (size_t p = 0; p < pairs.size(); ++p) n_sym += (double)(pairs.out_off[p + 1] - pairs.out_off[p]);
     for (uint32_t r = 0; r < n_runs; ++r) {

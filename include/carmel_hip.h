@@ -253,6 +253,14 @@ int carmel_hip_gibbs_run(carmel_hip_gibbs* g, double* iter_logprob, double* iter
  * "sample prob" (its 6001 values for `--crp -M 6000` on the tagging cascade, trace lines 6989-12990, are this repo's only
  * reference-held datum for the sampler); today's carmel logs the cache-model probability instead. */
 int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* iter_cheap_logprob, double* iter_after_logprob);
+/* The runs of --crp-restarts as replicas (gibbs.hpp:880-914: every run starts from the priors, the uniforms of run r are
+ * those of sweeps r * (iter + 1) ...: the runs are independent): a sampler with run share (first, stride) executes the runs
+ * r with r % stride == first and keeps the best of them; carmel_hip_gibbs_best_run / _best_stats ({ln allprob, ln finalprob,
+ * ln sumprob} of the kept run, gibbs_opts.hpp:270-316) let the caller pick the overall winner -- the better by
+ * gibbs_stats::better, the earlier run on a tie, which is what the sequential loop keeps (carmel --crp --gpus=N). */
+int carmel_hip_gibbs_set_run_share(carmel_hip_gibbs* g, uint32_t first, uint32_t stride);
+int carmel_hip_gibbs_best_stats(carmel_hip_gibbs* g, double* out3, int* ran_any);
+
 /* Replaces: prior-scale inference, gibbs_base::propose_new_priors (gibbs.hpp:404-553; carmel --prior-inference-stddev=s
  * [--prior-inference-global | -local] [--prior-inference-restart-fresh] [--prior-inference-start= --prior-inference-end=]
  * [--prior-groupby=012..]): after every inferring sweep (gibbs.hpp:559-563) each scale group's prior pseudo-counts are

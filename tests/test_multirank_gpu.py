@@ -90,3 +90,28 @@ def test_front_end_gpus_switch(golden_dir, tmp_path, args):
         assert num.sub("#", a) == num.sub("#", b), (a, b)
         for u, v in zip(num.findall(a), num.findall(b)):
             assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
+
+
+@pytest.mark.parametrize("extra", [["--crp-restarts=3"], ["--crp-restarts=4", "--crp-argmax-final"], ["--crp-restarts=1"]])
+def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_path, extra):
+    """carmel --crp --crp-restarts=R --gpus=N (gibbs.hpp:880-914): the runs are independent chains (each from the priors, its
+    own uniforms), so rank r takes the runs r, r + N, ... on the whole corpus and the ranks keep the best by
+    gibbs_stats::better, the earlier on a tie.  Three ranks (two when there are two runs; all on this box's one GPU, sums
+    through shared memory) must log every run's sweeps, keep the same run and write the same transducers as one process."""
+    import re
+    cli = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
+    args = ["--crp", "-M", "12", "--burnin=4", "--priors=0.5,0.1", "-R", "5", "-HJ"] + extra + [
+        os.path.join(golden_dir, n) for n in ("cipher.data", "cipher.wfsa", "cipher.fst")]
+    outs = []
+    for n in (1, 3):
+        d = tmp_path / ("n%d" % n)
+        d.mkdir()
+        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_HIP_COMM="host")
+        p = subprocess.run([cli, "--gpus=%d" % n] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+                           env=env, timeout=600)
+        assert p.returncode == 0, p.stderr
+        trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
+        keep = [l for l in p.stderr.split("\n") if l.startswith(("Gibbs i=", "(random restart", "Kept run"))]
+        outs.append((keep, trained))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 13   # the same log, line for line: every run, the same kept run
+    assert outs[0][1] == outs[1][1]                              # the same trained transducers, byte for byte
