@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Runs the randomised GPU parity tests on seeds beyond the ones the test suite fixes (a fuzzing campaign, through gpurun):
+    python tools/fuzz_gpu.py [first_seed] [n_seeds]
+Every failure is printed with its test and seed; exit status 1 if any."""
+import os
+import sys
+import tempfile
+import traceback
+import pathlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import pytest  # noqa: E402
+from oracle import binding as oracle  # noqa: E402  (the checker)
+import test_cli_gpu as C  # noqa: E402
+import test_gibbs_gpu as G  # noqa: E402
+import test_gpu_parity as P  # noqa: E402
+import test_compose_gpu as K  # noqa: E402
+import test_forest_gpu as F  # noqa: E402
+
+
+class MP(object):
+    """a stand-in for pytest's monkeypatch: setenv only"""
+    def __init__(self):
+        self.saved = {}
+
+    def setenv(self, k, v):
+        self.saved.setdefault(k, os.environ.get(k))
+        os.environ[k] = v
+
+    def undo(self):
+        for k, v in self.saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    cases = [
+        ("cli random cascades", lambda d, s: C.test_random_cascades_train_like_the_oracle(d, s)),
+        ("cli one-tape cascades", lambda d, s: C.test_random_one_tape_cascades(d, s)),
+        ("gibbs exact chain", lambda d, s: G.test_gibbs_exact_chain_on_random_cascades(oracle, s)),
+        ("gibbs prior inference", lambda d, s: G.test_gibbs_prior_scale_inference_follows_the_oracle(oracle, s)),
+        ("estep random shapes", lambda d, s: P.test_estep_random_shapes(oracle, 2 + s % 100000)),
+        ("windowed lane groups", lambda d, s, mp=None: P.test_windowed_lane_groups(oracle, mp, s, [8, 16, 32, 64][s % 4])),
+        ("compose on the device", lambda d, s: K.test_random_transducers(oracle, d, s, ["32", "2"][s % 2])),
+        ("forest em", lambda d, s: F.test_forest_em_matches_oracle(oracle, 20 + (s * 37) % 400, s)),
+    ]
+    only = os.environ.get("FUZZ_ONLY")
+    if only:
+        cases = [c for c in cases if only in c[0]]
+    fails = 0
+    for name, fn in cases:
+        ok = 0
+        for seed in range(first, first + n):
+            with tempfile.TemporaryDirectory() as d:
+                mp = MP()
+                try:
+                    if "mp" in fn.__code__.co_varnames[:fn.__code__.co_argcount]:
+                        fn(pathlib.Path(d), seed, mp)
+                    else:
+                        fn(pathlib.Path(d), seed)
+                    ok += 1
+                except pytest.skip.Exception:
+                    ok += 1
+                except BaseException as e:  # noqa: BLE001
+                    fails += 1
+                    where = traceback.extract_tb(e.__traceback__)[-1]
+                    print("FAIL %s seed %d at %s:%d: %s" % (name, seed, os.path.basename(where.filename), where.lineno,
+                                                           "".join(traceback.format_exception_only(type(e), e)).strip()[:600]))
+                finally:
+                    mp.undo()
+        print("%-28s %d / %d ok" % (name, ok, n), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
