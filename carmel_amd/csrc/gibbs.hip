@@ -33,6 +33,8 @@ struct GibbsArgs {
   const uint32_t* block_bundle;  // block -> bundle index
   const uint2* out_arcs;
   const uint32_t* out_off;
+  const uint2* in_arcs;          // cyclic lattices only: the reversed graph's lists in the reference's order (lattice.cpp)
+  const uint32_t* in_off;
   const uint32_t* level_off;
   const uint32_t* pair_start;
   const uint32_t* pair_final;
@@ -214,7 +216,11 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   const uint32_t* lvl = G.level_off + d.level_base;
   double* gw = G.gw + d.out_base;
   double* beta = G.beta + d.off_base;
-  if (!SNAP && G.stage_arcs && d.n_arcs <= G.stage_arcs && d.n_states <= G.stage_states) {
+  // A lattice with a cycle (derivations.h:726-728) is stored in the reference's own sweep order -- states in its forward
+  // order, out lists newest first, reversed lists as it walks them (lattice.cpp) -- and is swept by one thread in that
+  // order, so that what random_path sees (back edges' partial sums included) is what the reference sees.
+  const bool cyc = (d.flags & 1u) != 0;
+  if (!SNAP && !cyc && G.stage_arcs && d.n_arcs <= G.stage_arcs && d.n_states <= G.stage_states) {
     // exact mode: the backward sweep (a barrier per level) and the walk (one thread) are chains of dependent reads of
     // this block's lattice -- from LDS they cost a tenth of what they cost from L2
     double* sgw = (double*)(own_ids + 2 * (size_t)G.books_cap);
@@ -251,7 +257,8 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
         if (n) {
           const double* ewt = G.ewt + d.out_base;
           for (uint32_t s = 0; s < d.n_states; ++s)
-            for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) {
+            for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
+              const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;  // list order
               const uint32_t arc = oa[a].y;
               for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * -wt);
             }
@@ -276,7 +283,28 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   __syncthreads();
   if (tid == 0) beta[G.pair_final[d.pair_base]] = 0.0;
   __syncthreads();
-  // 3. backward sweep, level-synchronous
+  // 3. backward sweep: level-synchronous; a cyclic lattice in the reference's order (graph.h:391-402 over the reversed graph)
+  if (cyc) {
+    if (tid == 0) {
+      const uint2* ia = G.in_arcs + d.in_base;
+      const uint32_t* ioff = G.in_off + d.off_base;
+      for (uint32_t s = d.n_states; s-- > 0;) {
+        const double bs = beta[s];
+        if (bs == G_NEG_INF) continue;
+        for (uint32_t a = ioff[s]; a < ioff[s + 1]; ++a) {
+          const uint2 r = ia[a];  // {source state, composed arc}
+          double w = 0.0;
+          if (G.init_logw)
+            w = G.init_logw[r.y];
+          else
+            for (uint64_t j = G.chain_off[r.y]; j < G.chain_off[r.y + 1]; ++j)
+              w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
+          beta[r.x] = g_lwadd(beta[r.x], bs + w);
+        }
+      }
+    }
+    __syncthreads();
+  } else
   for (uint32_t l = d.n_levels; l-- > 0;) {
     for (uint32_t s = lvl[l] + tid; s < lvl[l + 1]; s += NT) {
       const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
@@ -299,7 +327,10 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       for (uint32_t s = 0; s < d.n_states; ++s) {  // states are numbered by level: sources before destinations
         const double as = alpha[s];
         if (as == G_NEG_INF) continue;
-        for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) alpha[oa[a].x] = g_lwadd(alpha[oa[a].x], as + gw[a]);
+        for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
+          const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;
+          alpha[oa[a].x] = g_lwadd(alpha[oa[a].x], as + gw[a]);
+        }
       }
     }
     __syncthreads();
@@ -309,7 +340,8 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     __syncthreads();
     if (tid == 0) {
       for (uint32_t s = 0; s < d.n_states; ++s)
-        for (uint32_t a = ooff[s + 1]; a-- > ooff[s];) {
+        for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
+          const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;
           const uint32_t arc = oa[a].y;
           for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * wt);
         }
@@ -330,28 +362,33 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
       // at temperature 1 the state's normaliser is its own beta: the backward sweep folded the same terms in the
       // same order
+      const uint32_t deg = a1 - a0;
+#define G_LIST(i) (cyc ? a0 + (i) : a1 - 1 - (i)) /* the i-th arc of the state's list (newest first) */
       double sum = beta[s];
-      if (G.power != 1.0) {
+      if (G.power != 1.0 || cyc) {  // (a cyclic lattice's beta is the reference's scatter, not this sum)
         sum = G_NEG_INF;
-        for (uint32_t a = a1; a-- > a0;) sum = g_lwadd(sum, (gw[a] + beta[oa[a].x]) * G.power);
+        for (uint32_t i = 0; i < deg; ++i) sum = g_lwadd(sum, (gw[G_LIST(i)] + beta[oa[G_LIST(i)].x]) * G.power);
       }
       if (sum == G_NEG_INF) sum = 0.0;
       // each arc's probability once (kept in LDS for the usual small out-degree), used for the total and the choice
       __shared__ double pe[32];
       const bool keep = a1 - a0 <= 32;
       double tot = 0.0;
-      for (uint32_t a = a1; a-- > a0;) {
+      for (uint32_t i = 0; i < deg; ++i) {
+        const uint32_t a = G_LIST(i);
         const double e = exp((gw[a] + beta[oa[a].x]) * G.power - sum);
         if (keep) pe[a - a0] = e;
         tot += e;
       }
       double choice = tot * gibbs_uniform(G.seed, G.iter, b, step++);
       uint32_t pick = a0;
-      for (uint32_t a = a1; a-- > a0;) {
+      for (uint32_t i = 0; i < deg; ++i) {
+        const uint32_t a = G_LIST(i);
         choice -= keep ? pe[a - a0] : exp((gw[a] + beta[oa[a].x]) * G.power - sum);
         pick = a;
         if (choice < 0) break;
       }
+#undef G_LIST
       const uint32_t arc = oa[pick].y;
       for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) out_ids[n++] = G.chain_param[j];
       s = oa[pick].x;
@@ -569,7 +606,8 @@ struct carmel_hip_gibbs {
   std::vector<uint32_t> h_norm;
   std::vector<double> h_prior;
   DevBuf<BundleDesc> bundles;
-  DevBuf<uint2_t> out_arcs;
+  DevBuf<uint2_t> out_arcs, in_arcs;
+  DevBuf<uint32_t> in_off;
   DevBuf<uint32_t> out_off, level_off, pair_start, pair_final, block_bundle, chain_param, p_norm, sample_len, sample_ids,
       new_len, new_ids;
   DevBuf<uint64_t> chain_off, sample_off;
@@ -659,8 +697,6 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   std::string err;
   if (!build_lattices(t->w, t->corpus, bo, g->lat, err)) return fail(CARMEL_HIP_ERR_ARG, err);
   LatticeSet& L = g->lat;
-  if (L.n_cyclic)
-    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "cyclic derivation lattices are not supported by the Gibbs sampler");
   std::vector<uint32_t> bundle_of_pair(t->corpus.n_pairs, 0xffffffffu);
   for (size_t b = 0; b < L.bundles.size(); ++b) bundle_of_pair[L.pair_id[L.bundles[b].pair_base]] = (uint32_t)b;
   std::vector<uint32_t> bb;
@@ -677,6 +713,10 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   HIPCHK(g->bundles.upload(L.bundles, s));
   HIPCHK(g->out_arcs.upload(L.out_arcs, s));
   HIPCHK(g->out_off.upload(L.out_off, s));
+  if (L.n_cyclic) {
+    HIPCHK(g->in_arcs.upload(L.in_arcs, s));
+    HIPCHK(g->in_off.upload(L.in_off, s));
+  }
   HIPCHK(g->level_off.upload(L.level_off, s));
   HIPCHK(g->pair_start.upload(L.pair_start, s));
   HIPCHK(g->pair_final.upload(L.pair_final, s));
@@ -855,6 +895,8 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.block_bundle = g->block_bundle.p;
   G.out_arcs = (const uint2*)g->out_arcs.p;
   G.out_off = g->out_off.p;
+  G.in_arcs = (const uint2*)g->in_arcs.p;
+  G.in_off = g->in_off.p;
   G.level_off = g->level_off.p;
   G.pair_start = g->pair_start.p;
   G.pair_final = g->pair_final.p;

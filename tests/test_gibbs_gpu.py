@@ -280,3 +280,27 @@ def test_gibbs_prior_inference_is_refused_outside_the_exact_sampler(oracle):
             gs.set_prior_inference(0.1)
         gs.close()
     fb.close()
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(expectation=True), dict(high_temp=2.0, low_temp=0.5)])
+def test_gibbs_on_lattices_with_cycles(oracle, kw):
+    """a pair whose derivation lattice has a cycle (*e* loops; derivations.h:726-728 warns and goes on): the sampler sweeps
+    such a block in the reference's own order -- its forward order of the states, its list order of the arcs, back edges'
+    partial sums included -- so the chain is still the oracle's (found by tools/fuzz_gpu.py: seed 1027 of the random
+    cascades; the sampler used to refuse these)"""
+    from carmel_amd.trainer import HipGibbs
+    a, b, corpus_text, normby, priors = _random_cascade_case(oracle, 1027)
+    norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
+    oc, ocorp, fb = _setup(oracle, [a, b], corpus_text, norms, priors)
+    assert fb.lattice_stats.n_cyclic_pairs > 0
+    iters, burnin = 7, 2
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=5, mode=0, **kw)
+    got_lp = gs.run()
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin, **kw)
+    if not kw.get("expectation"):
+        for blk in range(gs.n_blocks):
+            assert gs.sample(blk) == ref["samples"][blk]
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
