@@ -296,10 +296,18 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the EM hot path has no CPU fallback")
+    # CARMEL_HIP_COMM=host (tests on a one-GPU box): every rank on GPU 0, sums staged through shared memory, gloo for control
+    one_device = os.environ.get("CARMEL_HIP_COMM") == "host"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctl = "cpu" if one_device else "cuda"  # where the few control values of the collectives below live
 
     from carmel_amd import synth
     from carmel_amd.trainer import HipForwardBackward
@@ -317,17 +325,47 @@ def main():
     t_gen = time.time() - t0
     fb = HipForwardBackward(w, c, device=local_rank, host_threads=args.host_threads)
     ls = fb.lattice_stats
-    comm = None
+    comm, ext_counts, exchange = None, None, "none"
     if world > 1:
+        # the library's own exchange (RCCL on the trainer's stream).  Should the communicator not come up on every rank,
+        # all ranks fall back together to torch.distributed on the trainer's device count buffer (round 1's path: two host
+        # synchronisations per step) -- the line then says so in config.parallelism
         from carmel_amd.trainer import HipComm
-        ids = [HipComm.unique_id() if rank == 0 else None]
+        ok = 0 if os.environ.get("BENCH_FORCE_TORCH_EXCHANGE") else 1  # (test hook for the fallback below)
+        try:
+            ids = [HipComm.unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            ids, ok = [None], 0
+            sys.stderr.write("bench.py: library communicator unavailable (%s)\n" % e)
         dist.broadcast_object_list(ids, src=0)
-        comm = HipComm(local_rank, rank, world, ids[0])
+        if ids[0] is None:
+            ok = 0
+        if ok:
+            try:
+                comm = HipComm(local_rank, rank, world, ids[0])
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                sys.stderr.write("bench.py: rank %d could not join the library communicator (%s)\n" % (rank, e))
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if comm is not None:
+                comm.close()
+            comm = None
+            ext_counts = torch.zeros(int(w.n_arcs) + 4, dtype=torch.float64, device="cuda")
+            fb.use_external_counts(ext_counts.data_ptr())
+            exchange = "torch.distributed all-reduce of %d f64 counts per iteration (library communicator unavailable), two host synchronisations per step" % (w.n_arcs + 4)
+        else:
+            exchange = "RCCL all-reduce of %d f64 counts per iteration on the trainer's stream" % (w.n_arcs + 4)
 
     def step():
         fb.estimate_async()
         if comm is not None:
             fb.allreduce_counts(comm)  # stream-ordered: count pass -> all-reduce -> M-step
+        elif ext_counts is not None:
+            fb.synchronize()
+            dist.all_reduce(ext_counts)
+            torch.cuda.synchronize()
         return fb.maximize(1.0)
 
     def fence():
@@ -348,7 +386,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     lp, wlp, n_swept = fb.read_scalars()
-    t = torch.tensor([dt, float(ls.kept_arcs), float(ls.kept_states)], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, float(ls.kept_arcs), float(ls.kept_states)], dtype=torch.float64, device=ctl)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -376,8 +414,7 @@ def main():
                                     and world > 1 else "per GPU", args.walk_arcs.replace(",", "-")),
                        "pairs_per_gpu": c.n_pairs, "wfst_arcs": int(w.n_arcs), "wfst_states": int(w.n_states),
                        "lattice_arcs_per_gpu": int(ls.kept_arcs), "lattice_states_per_gpu": int(ls.kept_states),
-                       "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, RCCL all-reduce of %d f64 "
-                       "counts per iteration on the trainer's stream" % (world, w.n_arcs + 4)},
+                       "bundles_per_gpu": int(ls.n_bundles), "parallelism": "corpus-sharded x%d, %s" % (world, exchange)},
             "iters_per_s": iters_per_s,
             "wfst_arcs_x_iters_per_s": iters_per_s * w.n_arcs,
             "ln_corpus_prob_last": lp,
