@@ -115,3 +115,28 @@ def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_pat
         outs.append((keep, trained))
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 13   # the same log, line for line: every run, the same kept run
     assert outs[0][1] == outs[1][1]                              # the same trained transducers, byte for byte
+
+
+def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
+    """bench.py's own N > 1 branch (corpus shards, the library's all-reduce between the count pass and the M-step, timing
+    over ranks, one JSON line from rank 0), launched the way the driver launches it.  Two ranks share this box's GPU
+    (CARMEL_HIP_COMM=host).  With --scaling strong both runs train on the same 6000 pairs: after the same number of steps
+    the corpus probability must be the one-rank run's."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    common = ["--config", "c2", "--pairs", "6000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
+    env = dict(os.environ, CARMEL_HIP_COMM="host")
+    one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         universal_newlines=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    port = 29800 + os.getpid() % 150
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--scaling", "strong"] + common,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.split("\n") if l.startswith("{")][-1])
+    j2 = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][-1])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    assert j2["config"]["pairs_per_gpu"] == 3000 and "corpus-sharded x2" in j2["config"]["parallelism"]
+    assert j2["value"] > 0 and j2["roofline"]["frac"] > 0
+    assert j2["ln_corpus_prob_last"] == pytest.approx(j1["ln_corpus_prob_last"], rel=1e-9)
