@@ -18,7 +18,10 @@ lib.carmel_hip_host_build.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_ui
 lib.carmel_hip_host_dims.argtypes = [C.c_void_p, C.c_void_p]
 lib.carmel_hip_host_transpose.argtypes = [C.c_void_p] * 12
 lib.carmel_hip_host_free.argtypes = [C.c_void_p]
-for cfg in [dict(ns=300, deg=6, pairs=3000, lo=3, hi=25), dict(ns=40, deg=8, pairs=500, lo=3, hi=12), dict(ns=2000, deg=10, pairs=20000, lo=5, hi=40)]:
+import os
+for cfg in [dict(ns=300, deg=6, pairs=3000, lo=3, hi=25), dict(ns=40, deg=8, pairs=500, lo=3, hi=12), dict(ns=2000, deg=10, pairs=20000, lo=5, hi=40),
+            dict(ns=12, deg=3, pairs=2000, lo=10, hi=60, win=4), dict(ns=30, deg=4, pairs=1500, lo=20, hi=90, win=4)]:
+    os.environ["CARMEL_HIP_LANE_WINDOW_MIN"] = str(cfg.get("win", 40))  # the last two: windowed lane groups
     w = synth.random_wfst(cfg["ns"], cfg["deg"], n_sym=6, p_eps=0.15, seed=3)
     c = synth.random_walk_corpus(w, cfg["pairs"], min_arcs=cfg["lo"], max_arcs=cfg["hi"], seed=3, out_degree=cfg["deg"])
     h = C.c_void_p()
@@ -32,3 +35,18 @@ for cfg in [dict(ns=300, deg=6, pairs=3000, lo=3, hi=25), dict(ns=40, deg=8, pai
 print("asan/ubsan run complete: no reports")
 PY
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) ASAN_OPTIONS=detect_leaks=0 python3 $OUT/run.py
+# the front end's host-only paths (reader, writer, composition with and without -a, --normby / --number-from /
+# --write-loaded) under the same sanitizers, linked against the (uninstrumented) library; nothing here touches a GPU
+B=$OUT/carmel_asan_bin
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include $ROOT/carmel_amd/csrc/host/carmel_main.cpp \
+    -o $B -L$ROOT/carmel_amd -lcarmel_hip -Wl,-rpath,$ROOT/carmel_amd -lpthread
+G=$ROOT/tests/golden
+export ASAN_OPTIONS=detect_leaks=0 CARMEL_TRAINED_DIR=$OUT
+: > $OUT/front.err
+$B -HJ -q $G/cipher.wfsa $G/cipher.fst > /dev/null 2>> $OUT/front.err
+$B -HJm -q --normby=JC --priors=0.5,0.1 --write-loaded=x --number-from=3 $G/cipher.wfsa $G/cipher.fst > /dev/null 2>> $OUT/front.err
+$B -a -HJ -q $G/chain.1 $G/chain.2 > /dev/null 2>> $OUT/front.err || true
+$B -c $G/tagging.fsa $G/tagging.fst > /dev/null 2>> $OUT/front.err
+for f in epron-jpron.fst train.a.w wfst3 tagging.fst; do $B -HJ $G/$f > /dev/null 2>> $OUT/front.err; done
+if grep -q "ERROR: AddressSanitizer\|runtime error" $OUT/front.err; then grep "ERROR\|runtime error" $OUT/front.err | head; exit 1; fi
+echo "front end under asan/ubsan: no reports"
