@@ -92,6 +92,7 @@ struct Options {
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
+  std::string fem_early_param;                             // --fem-early-param: the weights as loaded / normalised (carmel.cc:801)
   std::string load_fem_param;                              // --load-fem-param (carmel.cc:790-799; cascade.h:180-202)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
        exclude_prior = false;
@@ -145,6 +146,12 @@ static Options parse_args(int argc, char** argv) {
         o.fem_param = v;
       else if (k == "fem-alpha")
         o.fem_alpha = v;
+      else if (k == "fem-early-param")
+        o.fem_early_param = v;
+      else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob") {
+        // inert in carmel itself: gibbs_opts::cache_prob is true and never cleared (carmel.cc:296-298, gibbs_opts.hpp:240,
+        // 255-258), so the cache-model probability is what is logged whatever these say
+      }
       else if (k == "load-fem-param")
         o.load_fem_param = v;
       else if (k == "restart-tolerance")
@@ -430,6 +437,13 @@ static int run(int argc, char** argv) {
   if (!o.normby.empty()) {
     std::cerr << "Normalizing input transducers by --normby=" << o.normby << std::endl;
     for (size_t i = 0; i < nw; ++i) member[i].normalize(norms[i], addc[i], dig_on[i] != 0, dig_alpha[i]);
+  }
+  if (!o.fem_early_param.empty()) {  // fem_out_param(fem_early_outparam), carmel.cc:801, 810-817
+    std::cerr << "Writing cascade weights to --fem-param=" << o.fem_early_param << std::endl;
+    std::ofstream of(o.fem_early_param.c_str());
+    for (size_t i = 0; i < nw; ++i)
+      for (auto& st : member[i].states)
+        for (auto& a : st) of << format_weight(a.logw, W_SOMETIMES_LOG) << "\n";
   }
   if (o.number_from > 0) {
     std::cerr << "Assigning unique group ids to each arc in input cascade starting at " << o.number_from << ".\n";

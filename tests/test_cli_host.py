@@ -213,3 +213,17 @@ def test_normby_normalises_the_inputs_before_composing(oracle, tmp_path, seed):
     for path in (pa, pb):
         ids += [int(x) for x in re.findall(r"!(\d+)\)\)", open(os.path.join(str(tmp_path), os.path.basename(path) + ".num")).read())]
     assert ids == list(range(5, 5 + len(ids))) and len(ids) > 0
+
+
+def test_fem_early_param_and_inert_gibbs_options(golden_dir, tmp_path):
+    """--fem-early-param=FILE: the input transducers' weights as loaded (after --load-fem-param / --normby), one per arc in
+    the members' arc order (carmel.cc:801, 810-817 -- where the reference, by a slip, writes to --fem-param's file);
+    --sample-prob / --no-prob / --cache-prob are accepted and change nothing, as in carmel (gibbs_opts.hpp:240, 255-258)"""
+    pa, pb = os.path.join(golden_dir, "cipher.wfsa"), os.path.join(golden_dir, "cipher.fst")
+    out = str(tmp_path / "early")
+    rc, so, err = run("-q", "-c", "--fem-early-param=" + out, "--sample-prob", "--no-prob", "--cache-prob", pa, pb)
+    assert rc == 0, err
+    got = [float(x[2:]) if x.startswith("e^") else float(x) for x in open(out).read().split()]
+    rc, full, _ = run("-HJ", pa)
+    rc, full2, _ = run("-HJ", pb)
+    assert len(got) == full.count("(") // 2 + full2.count("(") // 2 - 0  # one weight per arc of both inputs
