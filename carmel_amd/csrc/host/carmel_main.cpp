@@ -92,6 +92,8 @@ struct Options {
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
+  long print_from = 0, print_to = 0;  // --print-from=m --print-to=n (gibbs_opts.hpp; gibbs.cc:258-296): the final sample's
+                                      // path through input transducers m .. n-1, one line each, on stdout
   std::string fem_early_param;                             // --fem-early-param: the weights as loaded / normalised (carmel.cc:801)
   std::string load_fem_param;                              // --load-fem-param (carmel.cc:790-799; cascade.h:180-202)
   bool crp = false, crp_parallel = false, uniform_p0 = false, dirichlet_p0 = false, final_counts = false,
@@ -148,6 +150,10 @@ static Options parse_args(int argc, char** argv) {
         o.fem_alpha = v;
       else if (k == "fem-early-param")
         o.fem_early_param = v;
+      else if (k == "print-from")
+        o.print_from = std::atol(v.c_str());
+      else if (k == "print-to")
+        o.print_to = std::atol(v.c_str());
       else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob") {
         // inert in carmel itself: gibbs_opts::cache_prob is true and never cleared (carmel.cc:296-298, gibbs_opts.hpp:240,
         // 255-258), so the cache-model probability is what is logged whatever these say
@@ -264,7 +270,8 @@ static Options parse_args(int argc, char** argv) {
           default:
             // switches without a value that this front end implements; everything else carmel knows (k-best, generation,
             // projection, pruning, OpenFst, ...) is outside the training path
-            if (!std::strchr("tUujnlqdKmHJZDB2?:caSh", a[j]))
+            // (O I Q W E @: WFST::path_print, fst.h:60-160 -- how --print-to writes the sampled paths)
+            if (!std::strchr("tUujnlqdKmHJZDB2?:caShOIQWE@", a[j]))
               throw UsageError(std::string("switch -") + a[j] + " is not implemented by the GPU training front end");
             break;
         }
@@ -940,6 +947,20 @@ static int run(int argc, char** argv) {
     if (o.pi_stddev > 0 && rc == CARMEL_HIP_OK)
       hip_check(carmel_hip_gibbs_prior_trace(gs, ptrace.data(), per_run * n_runs, pcum.data(), (uint32_t)pcum.size()),
                 "carmel_hip_gibbs_prior_trace");
+    // --print-to: the kept run's sample, block by block (parameter ids along the path, chain order)
+    std::vector<std::vector<uint32_t> > final_sample;
+    const bool printing = o.print_to > o.print_from;
+    if (printing && rc == CARMEL_HIP_OK) {
+      if (go.expectation) throw std::runtime_error("can't print sample when using expectation because there is no single sample.\n");
+      if (world > 1) throw UsageError("--print-to with --gpus is not implemented by the GPU training front end (the kept sample lives on one rank)");
+      std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_gibbs_max_sample(gs)));
+      final_sample.resize(nblocks);
+      for (uint32_t b = 0; b < nblocks; ++b) {
+        uint32_t n = 0;
+        hip_check(carmel_hip_gibbs_get_sample(gs, b, buf.data(), &n), "carmel_hip_gibbs_get_sample");
+        final_sample[b].assign(buf.begin(), buf.begin() + n);
+      }
+    }
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
     if (world > 1) {
@@ -1002,6 +1023,97 @@ static int run(int argc, char** argv) {
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());
     hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
     const int ws = wstyle;
+    if (printing) {
+      // gibbs_base::print_all -> carmel_gibbs::print_sample (gibbs.hpp:1066-1078; gibbs.cc:258-296): per block, for every
+      // input transducer in [from, to) the arcs of the sampled path that belong to it, through WFST::path_print; an arc's
+      // weight is its probability as trained (proposal_prob after the counts were finalised)
+      const size_t n_members = cascade ? nw : 1;
+      long a = o.print_from, b = o.print_to;
+      if (!(b > a && a < (long)n_members)) {
+        std::cerr << "--print-from,-to gibbs [" << a << "," << b << ") is out of range for " << n_members << " input transducers.\n";
+      } else {
+        if (b > (long)n_members) b = (long)n_members;
+        std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << ((double)go.iter - (double)std::min(go.burnin, go.iter))
+                  << "):\n";
+        // parameter id -> (member, source state, arc)
+        std::vector<const Transducer*> mem;
+        std::vector<size_t> base;
+        if (cascade)
+          for (size_t i = 0; i < nw; ++i) {
+            mem.push_back(&member[i]);
+            base.push_back(params.member_base[i]);
+          }
+        else {
+          mem.push_back(result);
+          base.push_back(0);
+        }
+        std::vector<uint32_t> p_src;
+        std::vector<const HArc*> p_arc;
+        std::vector<uint32_t> p_mem;
+        for (size_t i = 0; i < mem.size(); ++i)
+          for (uint32_t st = 0; st < mem[i]->states.size(); ++st)
+            for (auto& arc : mem[i]->states[st]) {
+              p_src.push_back(st);
+              p_arc.push_back(&arc);
+              p_mem.push_back((uint32_t)i);
+            }
+        const bool fO = o.flags[(unsigned)'O'], fI = o.flags[(unsigned)'I'], fQ = o.flags[(unsigned)'Q'], fAT = o.flags[(unsigned)'@'],
+                   fW = o.flags[(unsigned)'W'], fE = o.flags[(unsigned)'E'];
+        auto unquote = [](const std::string& x) {
+          return (x.size() >= 2 && x[0] == '"' && x[x.size() - 1] == '"') ? x.substr(1, x.size() - 2) : x;
+        };
+        for (auto& blk : final_sample)
+          for (long i = a; i < b; ++i) {
+            const Transducer& W = *mem[(size_t)i];
+            bool first = true;
+            double lw_path = 0.0;
+            std::vector<uint32_t> outs;
+            auto sp = [&]() {
+              if (!first) std::cout << ' ';
+              first = false;
+            };
+            for (uint32_t pid : blk) {
+              if (pid >= p_mem.size() || p_mem[pid] != (uint32_t)i) continue;
+              const HArc& arc = *p_arc[pid];
+              lw_path += pw[pid];
+              if (fAT) {
+                if (arc.out != 0) outs.push_back(arc.out);
+                if (arc.in != 0) {
+                  sp();
+                  std::cout << W.in_syms.names[arc.in];
+                }
+              } else if (fO || fI) {
+                const uint32_t id = fO ? arc.out : arc.in;
+                if (!(fE && id == 0)) {
+                  sp();
+                  const std::string& nm = fO ? W.out_syms.names[id] : W.in_syms.names[id];
+                  std::cout << (fQ ? unquote(nm) : nm);
+                }
+              } else {
+                sp();
+                std::cout << '(' << W.state_name(p_src[pid]) << " -> " << W.state_name(arc.dest) << ' ' << W.in_syms.names[arc.in] << " : "
+                          << W.out_syms.names[arc.out] << " / " << format_weight(pw[pid], ws) << ")";
+              }
+            }
+            if (fAT) {
+              std::cout << std::endl;
+              bool f2 = true;
+              for (uint32_t id : outs) {
+                if (!f2) std::cout << ' ';
+                f2 = false;
+                std::cout << W.out_syms.names[id];
+              }
+              std::cout << std::endl;
+            } else {
+              if (!fW) {
+                sp();
+                std::cout << format_weight(lw_path, ws);
+              }
+              std::cout << std::endl;
+            }
+          }
+      }
+    }
     const char* dir = std::getenv("CARMEL_TRAINED_DIR");
     for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437
       member[i].set_weights(pw.data() + (cascade ? params.member_base[i] : 0));

@@ -710,3 +710,53 @@ def test_dense_rank1_sweep_on_the_cipher_cascade(tmp_path, n_lines, normby):
     x, y = open(str(res["dense"][3] / "ch.fst.trained")).read(), open(str(res["tables"][3] / "ch.fst.trained")).read()
     for u, v in zip(NUM.findall(x), NUM.findall(y)):
         assert float(u) == pytest.approx(float(v), rel=1e-9, abs=1e-14)
+
+
+def test_crp_prints_the_final_sample(golden_dir, tmp_path, oracle):
+    """--print-from=m --print-to=n (gibbs.cc:258-296, gibbs.hpp:1066-1078; WFST::path_print fst.h:60-160): after the run, for
+    every block the sampled path through input transducers m .. n-1, one line each, on stdout -- how a --crp user reads the
+    sample (the decipherment, the tag sequence).  On the cipher cascade: the channel's outputs along the path are the
+    cipher text itself, its inputs are the language model's outputs, the printed path weights are the products of the
+    trained probabilities the oracle computes for the same sample."""
+    import numpy as np
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    base = ["--crp", "-M", "10", "--burnin=3", "--priors=0.5,0.1", "-R", "7", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    env = {"CARMEL_TRAINED_DIR": str(tmp_path)}
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()), lambda i, b, s: lib.carmel_hip_gibbs_uniform(7, i, b, s),
+                           normby="CC", priors=[0.5, 0.1], iters=10, burnin=3)
+    member = np.asarray(oc.param_member)
+    cipher = [l.split() for l in open(g("cipher.data")).read().split("\n")[1::2] if l.strip()]
+    # (1) default format: arcs as (src -> dst in : out / w), then the path's weight
+    rc, out, err = run(["--print-from=0", "--print-to=2"] + base, env=env)
+    assert rc == 0, err
+    assert out.startswith("\n# final best gibbs run (start #0 t=7):\n")
+    lines = out.split("\n")[2:]
+    lines = [l for l in lines if l != ""]
+    assert len(lines) == 2 * len(ref["samples"]) == 20
+    tok = re.compile(r"\((\S+) -> (\S+) (\S+) : (\S+) / (\S+)\)")
+    for b, ids in enumerate(ref["samples"]):
+        ids = np.asarray(ids)
+        for m in (0, 1):
+            line = lines[2 * b + m]
+            arcs = tok.findall(line)
+            mine = ids[member[ids] == m]
+            assert len(arcs) == len(mine)
+            want = float(np.exp(ref["param_logw"][mine].sum()))
+            assert float(line.split()[-1].replace("e^", "") if not line.split()[-1].startswith("e^") else
+                         math.exp(float(line.split()[-1][2:]))) == pytest.approx(want, rel=1e-6)
+            for (s0, d0, i0, o0, w0), pid in zip(arcs, mine):
+                assert (math.exp(float(w0[2:])) if w0.startswith("e^") else float(w0)) == pytest.approx(
+                    float(np.exp(ref["param_logw"][pid])), rel=1e-6)
+    # (2) -O -Q -W -E on the channel: its outputs along the path are the cipher text; -I gives the plain text the LM wrote
+    rc, out_o, err = run(["--print-from=1", "--print-to=2", "-OQWE"] + base, env=env)
+    assert rc == 0, err
+    got = [l.split() for l in out_o.split("\n")[2:] if l != ""]
+    assert got == [[c.strip('"') for c in line] for line in cipher]
+    rc, out_i, err = run(["--print-from=1", "--print-to=2", "-IQWE"] + base, env=env)
+    rc2, out_lm, err2 = run(["--print-from=0", "--print-to=1", "-OQWE"] + base, env=env)
+    assert rc == 0 and rc2 == 0
+    plain_ch = [l.split() for l in out_i.split("\n")[2:] if l != ""]
+    plain_lm = [l.split() for l in out_lm.split("\n")[2:] if l != ""]
+    assert plain_ch == plain_lm and all(len(a) == len(b) for a, b in zip(plain_ch, cipher))
