@@ -37,6 +37,7 @@ struct Opts {
   double pi_stddev = 0;
   bool pi_global = false, pi_local = false, pi_show = false;
   long pi_start = 0, pi_end = 0;
+  std::string outsample_file;  // --outsample-file (gibbs_opts.hpp:100-101; forest-em.hpp:768-787): the final sample, rule ids per forest
   double alpha = 0.1;             // --const-alpha (gibbs_opts.hpp:93)
   std::string alpha_file = "-0";  // --alpha: per-parameter alphas parallel to the weights, negative = locked (:98-99)
   bool final_counts = false, uniform_p0 = false, parallel = false;
@@ -48,7 +49,7 @@ void usage() {
   std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
                "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel\n"
-               "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show]]\n"
+               "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -124,6 +125,7 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "final-counts") o.final_counts = true;
     else if (key == "uniform-p0") o.uniform_p0 = true;
     else if (key == "crp-parallel") o.parallel = true;
+    else if (key == "outsample-file") o.outsample_file = value(val);
     else if (key == "prior-inference-stddev") o.pi_stddev = std::atof(value(val).c_str());
     else if (key == "prior-inference-global") o.pi_global = true;
     else if (key == "prior-inference-local") o.pi_local = true;
@@ -229,6 +231,16 @@ int main(int argc, char** argv) {
               << pt[3] / std::log(2.0) << " a1=p2/p1=" << std::exp(pt[3] - pt[2]) << " a2=q(1|2)/q(2|1)=" << pt[4]
               << " p_accept=" << pt[5] << ". ";
         log << "sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
+      }
+      if (!o.outsample_file.empty()) {  // print_sample (forest-em.hpp:768-787): one line per forest, its rules in the order sampled
+        std::ofstream of(o.outsample_file.c_str());
+        std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_forests_max_sample(F)));
+        for (uint64_t f = 0; f < fs.n_forests(); ++f) {
+          uint32_t n = 0;
+          check(carmel_hip_forests_get_sample(F, f, buf.data(), &n), "carmel_hip_forests_get_sample");
+          for (uint32_t k = 0; k < n; ++k) of << (k ? " " : "") << buf[k];
+          of << "\n";
+        }
       }
       if (o.pi_show) {  // gibbs.hpp:826-827
         log << "Final prior-scale=[";

@@ -128,7 +128,7 @@ def test_forest_em_cli_prior_inference(oracle, tmp_path):
     (tmp_path / "n").write_text(ntxt)
     rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / "o"), "--crp=10", "--burnin=3",
                        "--const-alpha=0.3", "--prior-inference-stddev=0.1", "--prior-inference-local", "--prior-inference-show",
-                       "--random-seed=23"])
+                       "--random-seed=23", "--outsample-file=" + str(tmp_path / "samples")])
     assert rc == 0, err
     of = oracle.OracleForests(ftxt, ntxt)
     ref = of.gibbs(lambda i, b, st: lib.carmel_hip_gibbs_uniform(23, i, b, st), 10, burnin=3, alpha=0.3,
@@ -143,6 +143,9 @@ def test_forest_em_cli_prior_inference(oracle, tmp_path):
     np.testing.assert_allclose([float(x) for x in final], ref["prior_cumulative"], rtol=1e-5)
     got = parse_vec((tmp_path / "o").read_text())
     np.testing.assert_allclose(got, np.exp(of.weights()[1:1 + len(got)]), rtol=1e-9, atol=1e-300)
+    # --outsample-file (forest-em.hpp:768-787): the final sample, one forest per line, rule ids in the order sampled
+    samples = [[int(x) for x in l.split()] for l in (tmp_path / "samples").read_text().split("\n")[:-1]]
+    assert samples == ref["samples"]
 
 
 def test_forest_text_cpu(golden_dir):
