@@ -1634,6 +1634,12 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   }
   if (!(o->final_counts && !o->exclude_prior)) {
     const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
+    if (o->exclude_prior)  // --crp-exclude-prior (gibbs.hpp:629-631): addbase(-prior) before the counts are extended
+      for (uint32_t r = 0; r < nr; ++r)
+        if (F->h_norm[r] != F_NONORM) {
+          sacc[r] += -prior[r] * tm[r];
+          x[r] += -prior[r];
+        }
     if (!o->final_counts)
       for (uint32_t r = 0; r < nr; ++r)
         if (F->h_norm[r] != F_NONORM) {

@@ -37,6 +37,7 @@ struct Opts {
   double pi_stddev = 0;
   bool pi_global = false, pi_local = false, pi_show = false;
   long pi_start = 0, pi_end = 0;
+  bool exclude_prior = false;  // --crp-exclude-prior (gibbs_opts.hpp; gibbs.hpp:629-631)
   std::string outsample_file;  // --outsample-file (gibbs_opts.hpp:100-101; forest-em.hpp:768-787): the final sample, rule ids per forest
   double alpha = 0.1;             // --const-alpha (gibbs_opts.hpp:93)
   std::string alpha_file = "-0";  // --alpha: per-parameter alphas parallel to the weights, negative = locked (:98-99)
@@ -126,6 +127,7 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "uniform-p0") o.uniform_p0 = true;
     else if (key == "crp-parallel") o.parallel = true;
     else if (key == "outsample-file") o.outsample_file = value(val);
+    else if (key == "crp-exclude-prior") o.exclude_prior = true;
     else if (key == "prior-inference-stddev") o.pi_stddev = std::atof(value(val).c_str());
     else if (key == "prior-inference-global") o.pi_global = true;
     else if (key == "prior-inference-local") o.pi_local = true;
@@ -198,6 +200,7 @@ int main(int argc, char** argv) {
       go.mode = o.parallel ? 1 : 0;
       go.uniform_p0 = o.uniform_p0;
       go.final_counts = o.final_counts;
+      go.exclude_prior = o.exclude_prior;
       go.high_temp = o.high_temp;
       go.low_temp = o.low_temp;
       if (o.alpha_file != "-0") {

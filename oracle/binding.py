@@ -439,8 +439,9 @@ class OracleForests(object):
         return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
 
     def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22,
-              alphas=None, high_temp=1.0, low_temp=1.0, prior_inference=None):
+              alphas=None, high_temp=1.0, low_temp=1.0, prior_inference=None, exclude_prior=False):
         lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
+        lib.orc_forests_set_exclude_prior(int(exclude_prior))
         pi = dict(prior_inference or {})
         lib.orc_set_gibbs_prior_inference(C.c_double(pi.get("stddev", 0.0)), int(pi.get("global_", False)),
                                           int(pi.get("local", False)), 0, int(pi.get("start", 0)), int(pi.get("end", 0)), None, 0)

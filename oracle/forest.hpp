@@ -496,6 +496,12 @@ struct ForestGibbs {
     if (tr) tr->last_sample = sample;
     if (!(gopt.final_counts && !gopt.exclude_prior)) {
       double tmax1 = ((double)Ni - (double)gopt.burnin) + 1;
+      if (gopt.exclude_prior)  // gibbs.hpp:629-631
+        for (auto& g : gps)
+          if (g.has_norm()) {
+            g.sum.s += -g.prior * g.sum.tmax;
+            g.sum.x += -g.prior;
+          }
       if (!gopt.final_counts)
         for (auto& g : gps)
           if (g.has_norm()) {

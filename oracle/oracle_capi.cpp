@@ -1066,6 +1066,8 @@ double orc_forests_maximize(orc_forests* h, double add_k, int zero_zero) {
   h->fe.zero_zerocounts = zero_zero != 0;
   return h->fe.maximize().getReal();
 }
+static int g_forest_exclude_prior = 0;  // --crp-exclude-prior for the next orc_forests_gibbs
+void orc_forests_set_exclude_prior(int on) { g_forest_exclude_prior = on; }
 static std::vector<double> g_forest_alphas;  // --alpha=FILE for the next orc_forests_gibbs (empty: scalar alpha)
 void orc_forests_set_alphas(const double* a, uint32_t n) { g_forest_alphas.assign(a, a + (a ? n : 0)); }
 int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int uniform_p0, int final_counts, double alpha,
@@ -1079,6 +1081,7 @@ int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int unifor
     go.high_temp = g_high_temp;
     go.low_temp = g_low_temp;
     go.final_counts = final_counts != 0;
+    go.exclude_prior = g_forest_exclude_prior != 0;
     if (go.final_counts) go.burnin = go.iter;
     go.prior_inference_stddev = g_pi_stddev;
     go.prior_inference_global = g_pi_global != 0;

@@ -84,7 +84,7 @@ def test_reference_sample_file(oracle, golden_dir):
     hf.close()
 
 
-@pytest.mark.parametrize("kw", [dict(), dict(burnin=4), dict(uniform_p0=True), dict(final_counts=True),
+@pytest.mark.parametrize("kw", [dict(), dict(burnin=4), dict(uniform_p0=True), dict(final_counts=True), dict(exclude_prior=True, burnin=3),
                                 dict(high_temp=2.5, low_temp=0.5)])
 def test_forest_gibbs_exact_chain(oracle, kw):
     """forests strictly in order with injected uniforms: same samples, same probabilities as the oracle's
