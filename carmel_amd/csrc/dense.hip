@@ -232,7 +232,10 @@ typedef double dense_d4 __attribute__((ext_vector_type(4)));
 // A workgroup is a group of 64 strings; each of its four wavefronts takes 16 of them (one tile of strings): the registers
 // of a wavefront are the two constant operands and ONE tile's values, so several workgroups share a CU and their
 // wavefronts hide each other's load and LDS latencies.
-template <int NB16>  // SP = 16 * NB16
+// PHASE 0: both passes in one launch; 1: the forward pass alone (leaves alpha_T[goal] per string in D.afbuf); 2: the backward
+// pass alone.  Split, each launch keeps ONE of the two constant operands in registers and none of the other pass's state:
+// three to four wavefronts per SIMD instead of two.
+template <int NB16, int PHASE>  // SP = 16 * NB16
 __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
   constexpr int SP = 16 * NB16, KS = 4 * NB16;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -241,10 +244,11 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
   double* Bl = acc + nsl;
   uint16_t* Sl = (uint16_t*)(Bl + D.V * SP);
   const int lane = threadIdx.x & 63, nb = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
-  for (uint32_t k = threadIdx.x; k < D.n_slots; k += 256) acc[k] = 0.0;
+  if (PHASE != 1)
+    for (uint32_t k = threadIdx.x; k < D.n_slots; k += 256) acc[k] = 0.0;
   for (uint32_t k = threadIdx.x; k < D.V * SP; k += 256) {
     Bl[k] = D.B[k];
-    Sl[k] = D.Bslot[k];
+    if (PHASE != 1) Sl[k] = D.Bslot[k];
   }
   __syncthreads();
   const uint32_t g = blockIdx.x;
@@ -257,13 +261,13 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
   double* __restrict__ zb = D.zbuf + D.sym_off[g] + nb * 16 + c16;
   double* __restrict__ vb = D.vbuf + D.vbuf_off[g] + (size_t)nb * KS * 64 + lane;  // row (t * 4 + nb) * KS + ks
   // the constant operands: forward A^T, backward A
-  double aop[NB16][KS], aop2[NB16][KS];
+  double aop[PHASE != 2 ? NB16 : 1][KS], aop2[PHASE != 1 ? NB16 : 1][KS];
 #pragma unroll
   for (int ib = 0; ib < NB16; ++ib)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      aop[ib][ks] = D.A[(size_t)(ks * 4 + q) * SP + ib * 16 + c16];
-      aop2[ib][ks] = D.A[(size_t)(ib * 16 + c16) * SP + ks * 4 + q];
+      if (PHASE != 2) aop[PHASE != 2 ? ib : 0][ks] = D.A[(size_t)(ks * 4 + q) * SP + ib * 16 + c16];
+      if (PHASE != 1) aop2[PHASE != 1 ? ib : 0][ks] = D.A[(size_t)(ib * 16 + c16) * SP + ks * 4 + q];
     }
   // a sum over the four lanes that share a string
   auto sum4 = [](double x) {
@@ -294,12 +298,15 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
       for (int ks = 0; ks < KS; ++ks) b[ks] += ((uint32_t)ks == (src >> 2) && (uint32_t)q == (src & 3u)) ? add : 0.0;
     }
   };
+  double af = 0.0;
+  uint32_t c_next = 0u;
+  if (PHASE != 2) {
   // ---------- forward ----------
   double al[KS], lp = 0.0;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) al[ks] = ((uint32_t)(ks * 4 + q) == D.start) ? 1.0 : 0.0;
   eps_forward(al);
-  uint32_t c_next = Tmax ? (0 < T ? sym[0] : 0u) : 0u;  // the symbol of a position is fetched one position ahead
+  c_next = Tmax ? (0 < T ? sym[0] : 0u) : 0u;  // the symbol of a position is fetched one position ahead
   for (uint32_t t = 0; t < Tmax; ++t) {
     const bool active = t < T;
     const uint32_t c = c_next;
@@ -315,8 +322,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
     for (int ks = 0; ks < KS; ks += 2)
 #pragma unroll
       for (int ib = 0; ib < NB16; ++ib) {
-        d[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ib][ks], al[ks], d[ib], 0, 0, 0);
-        d1[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ib][ks + 1], al[ks + 1], d1[ib], 0, 0, 0);
+        d[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[PHASE != 2 ? ib : 0][ks], al[ks], d[ib], 0, 0, 0);
+        d1[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[PHASE != 2 ? ib : 0][ks + 1], al[ks + 1], d1[ib], 0, 0, 0);
       }
 #pragma unroll
     for (int ib = 0; ib < NB16; ++ib) d[ib] += d1[ib];
@@ -342,8 +349,12 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
       zb[(size_t)t * 64] = z;
     }
   }
-  const double af = state_value(al, D.fin);
+  af = state_value(al, D.fin);
   if (T && q == 0) D.pair_logprob[D.pair[g * 64 + nb * 16 + c16]] = lp + log(af);
+  if (PHASE == 1 && q == 0) D.afbuf[g * 64 + nb * 16 + c16] = af;
+  } else
+    af = D.afbuf[g * 64 + nb * 16 + c16];
+  if (PHASE == 1) return;
   if (D.debug & 4u) Tmax = 0;
   // ---------- backward + posteriors ----------
   double be[KS];
@@ -397,8 +408,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
     for (int ks = 0; ks < KS; ks += 2)
 #pragma unroll
       for (int ib = 0; ib < NB16; ++ib) {
-        d[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop2[ib][ks], w[ks], d[ib], 0, 0, 0);
-        d1[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop2[ib][ks + 1], w[ks + 1], d1[ib], 0, 0, 0);
+        d[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop2[PHASE != 1 ? ib : 0][ks], w[ks], d[ib], 0, 0, 0);
+        d1[ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop2[PHASE != 1 ? ib : 0][ks + 1], w[ks + 1], d1[ib], 0, 0, 0);
       }
 #pragma unroll
     for (int ib = 0; ib < NB16; ++ib) d[ib] += d1[ib];
@@ -417,10 +428,20 @@ hipError_t launch_dense_sweep(const DenseArgs& D, uint32_t n_groups, hipStream_t
   static const bool no_mfma = getenv("CARMEL_HIP_DENSE_MFMA") && atoi(getenv("CARMEL_HIP_DENSE_MFMA")) == 0;  // A/B: vector variants
   if (!no_mfma && (D.SP == 16 || D.SP == 32)) {
     const size_t l2 = (((size_t)D.n_slots + 1) & ~(size_t)1) * 8 + (size_t)D.V * D.SP * 8 + (((size_t)D.V * D.SP + 3) / 4) * 8 + 16;
-    if (D.SP == 16)
-      hipLaunchKernelGGL(dense_mfma_kernel<1>, dim3(n_groups), dim3(256), l2, s, D);
-    else
-      hipLaunchKernelGGL(dense_mfma_kernel<2>, dim3(n_groups), dim3(256), l2, s, D);
+    static const bool split = !(getenv("CARMEL_HIP_DENSE_SPLIT") && atoi(getenv("CARMEL_HIP_DENSE_SPLIT")) == 0);  // 0: one launch for both passes
+    if (D.SP == 16) {
+      if (split && D.afbuf) {
+        hipLaunchKernelGGL((dense_mfma_kernel<1, 1>), dim3(n_groups), dim3(256), l2, s, D);
+        hipLaunchKernelGGL((dense_mfma_kernel<1, 2>), dim3(n_groups), dim3(256), l2, s, D);
+      } else
+        hipLaunchKernelGGL((dense_mfma_kernel<1, 0>), dim3(n_groups), dim3(256), l2, s, D);
+    } else {
+      if (split && D.afbuf) {
+        hipLaunchKernelGGL((dense_mfma_kernel<2, 1>), dim3(n_groups), dim3(256), l2, s, D);
+        hipLaunchKernelGGL((dense_mfma_kernel<2, 2>), dim3(n_groups), dim3(256), l2, s, D);
+      } else
+        hipLaunchKernelGGL((dense_mfma_kernel<2, 0>), dim3(n_groups), dim3(256), l2, s, D);
+    }
     return hipGetLastError();
   }
   static const bool smem = !(getenv("CARMEL_HIP_DENSE_SMEM") && atoi(getenv("CARMEL_HIP_DENSE_SMEM")) == 0);  // 0: the LDS-broadcast variant (measured slower)

@@ -34,6 +34,7 @@ struct DenseArgs {
   double* vbuf;             // per group: (t * SP + j) * 64 + lane, from vbuf_off[g]
   const uint64_t* vbuf_off;
   double* zbuf;             // same indexing as sym
+  double* afbuf;            // [n_groups * 64] alpha_T[goal] per string, between the two launches of the split sweep (may be null)
   double* partial;          // [n_groups][n_slots]
 };
 

@@ -136,7 +136,7 @@ struct carmel_hip_trainer {
   // rank-1 dense form of the unrolled sweep (dense.hpp): weight(s -> s', c) = A[s][s'] * B[c][s']
   bool dense = false;
   uint32_t d_SP = 0, d_groups = 0;
-  DevBuf<double> d_A, d_AT, d_B, d_vbuf, d_zbuf, d_weight, d_partial;
+  DevBuf<double> d_A, d_AT, d_B, d_vbuf, d_zbuf, d_afbuf, d_weight, d_partial;
   DevBuf<uint32_t> d_a_off, d_a_par, d_b_off, d_b_par, d_len, d_pair;
   DevBuf<uint8_t> d_a_has, d_b_has;
   DevBuf<uint16_t> d_Bslot, d_sym;

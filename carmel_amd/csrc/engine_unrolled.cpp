@@ -133,6 +133,7 @@ static int dense_try_build(carmel_hip_trainer* t, const UnrolledModel& M, const 
   HIPCHK(t->d_B.alloc((size_t)V * SP));
   HIPCHK(t->d_vbuf.alloc(vbuf_off[ng]));
   HIPCHK(t->d_zbuf.alloc(sym_off[ng]));
+  HIPCHK(t->d_afbuf.alloc((size_t)ng * 64));
   HIPCHK(t->d_partial.alloc((size_t)ng * n_slots));
   HIPCHK(hipStreamSynchronize(s));
   t->d_SP = SP;
@@ -345,6 +346,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
     D.vbuf = t->d_vbuf.p;
     D.vbuf_off = t->d_vbuf_off.p;
     D.zbuf = t->d_zbuf.p;
+    D.afbuf = t->d_afbuf.p;
     D.partial = t->d_partial.p;
     HIPCHK(launch_dense_sweep(D, t->d_groups, s));
     HIPCHK(launch_unrolled_reduce(t->d_partial.p, t->d_groups, t->u_n_slots, t->counts_ptr(), s));
