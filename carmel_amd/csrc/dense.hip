@@ -302,7 +302,9 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
   uint32_t c_next = 0u;
   if (PHASE != 2) {
   // ---------- forward ----------
-  double al[KS], lp = 0.0;
+  // ln p = sum over positions of ln z: the product of the z is kept as mantissa x 2^exponent, one log at the end
+  double al[KS], lp_m = 1.0;
+  int lp_e = 0;
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) al[ks] = ((uint32_t)(ks * 4 + q) == D.start) ? 1.0 : 0.0;
   eps_forward(al);
@@ -345,12 +347,15 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
       eps_forward(v);
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) al[ks] = v[ks];
-      lp += log(z);
-      zb[(size_t)t * 64] = z;
+      int e1, e2;
+      const double m1 = frexp(z, &e1);
+      lp_m = frexp(lp_m * m1, &e2);
+      lp_e += e1 + e2;
+      zb[(size_t)t * 64] = zi;  // the backward pass wants the reciprocal
     }
   }
   af = state_value(al, D.fin);
-  if (T && q == 0) D.pair_logprob[D.pair[g * 64 + nb * 16 + c16]] = lp + log(af);
+  if (T && q == 0) D.pair_logprob[D.pair[g * 64 + nb * 16 + c16]] = log(lp_m) + (double)lp_e * 0.693147180559945309417 + log(af);
   if (PHASE == 1 && q == 0) D.afbuf[g * 64 + nb * 16 + c16] = af;
   } else
     af = D.afbuf[g * 64 + nb * 16 + c16];
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) be[ks] = 0.0;
   // the parked forward values, the symbol and the scale of a position are fetched one position ahead
-  double vq[KS], z_next = 1.0;
+  double vq[KS], z_next = 0.0;  // (zbuf holds 1 / z)
   c_next = 0u;
   if (Tmax) {
     const uint32_t t = Tmax - 1;
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
       for (int ks = 0; ks < KS; ++ks) be[ks] = ((uint32_t)(ks * 4 + q) == D.fin) ? 1.0 / af : 0.0;
     }
     const uint32_t c = c_next;
-    const double zi = active ? 1.0 / z_next : 0.0;
+    const double zi = active ? z_next : 0.0;
     double vt[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) vt[ks] = vq[ks];
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) vq[ks] = (D.debug & 2u) ? 1.0 : vb[((size_t)(t - 1) * 4 * KS + ks) * 64];
       c_next = (t - 1 < T) ? sym[(size_t)(t - 1) * 64] : 0u;
-      z_next = (t - 1 < T) ? zb[(size_t)(t - 1) * 64] : 1.0;
+      z_next = (t - 1 < T) ? zb[(size_t)(t - 1) * 64] : 0.0;
     }
     if (active) eps_backward(be);
     double w[KS];
