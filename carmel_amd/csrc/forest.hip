@@ -657,7 +657,8 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 #define FRC_SLOTS 2048u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
                                                               const uint32_t* rules, const uint32_t* p_norm, double* x,
-                                                              double* normsum, uint32_t n_forests, ForestArgs A, int sweep2) {
+                                                              double* normsum, uint32_t n_forests, ForestArgs A, int sweep2,
+                                                              const uint32_t* slot_forest, uint32_t slot0, uint32_t slot1) {
   __shared__ uint32_t key[2][FRC_SLOTS];
   __shared__ uint32_t cnt[2][FRC_SLOTS];
   __shared__ double cheap_sh[16];
@@ -675,16 +676,21 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
       unsafeAtomicAdd(g + id, 1.0);
   };
   double cheap = 0.0;
-  for (uint32_t f0 = blockIdx.x * 64; f0 < n_forests; f0 += gridDim.x * 64) {
-    const uint32_t f = f0 + (threadIdx.x >> 4);
-    if (f >= n_forests) continue;
+  // slot_forest: the forests of the lane slots [slot0, slot1) -- one launch class, recounted as soon as its sample kernel is
+  // done, beside the other classes still sampling; otherwise all forests in corpus order
+  const uint32_t i_begin = slot_forest ? slot0 : 0u, i_end = slot_forest ? slot1 : n_forests;
+  for (uint32_t f0 = i_begin + blockIdx.x * 64; f0 < i_end; f0 += gridDim.x * 64) {
+    const uint32_t i = f0 + (threadIdx.x >> 4);
+    if (i >= i_end) continue;
+    const uint32_t f = slot_forest ? slot_forest[i] : i;
+    if (f == 0xffffffffu) continue;  // an empty lane slot
     const uint64_t so = sample_off[f];
     const uint32_t* r = rules + so;
     const uint32_t len = sample_len[f];
     uint32_t lane = 0;
     FGroup g;
     if (sweep2) {
-      const uint32_t slot = A.lane_of_forest[f];
+      const uint32_t slot = slot_forest ? i : A.lane_of_forest[f];
       g = A.groups[slot >> 6];
       lane = slot & 63u;
     }
@@ -800,6 +806,7 @@ struct carmel_hip_forests {
   std::vector<uint64_t> gcol_off;    // per class: offset into gcol (doubles), room for two columns per group
   DevBuf<double> rec_logp, rec_p;
   DevBuf<uint64_t> group_off, arc_off, slot_pos, hot_chunks, sample_off;
+  DevBuf<double> normsum2;  // the norm sums being recounted while a sweep still reads the current ones (carmel_hip_forests_gibbs)
   DevBuf<double> rule_logw, counts, post, forest_logprob, scalars, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, new_x,
       iter_out;
   DevBuf<unsigned long long> maxbits;
@@ -1336,8 +1343,12 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   A.seed = o->seed;
   A.counterfactual = 1;
   // parallel mode, second formulation (CARMEL_HIP_FOREST_SWEEP=1 selects the first, kept as the A/B reference)
+  bool split_recount = false;  // set below
   const bool sweep2 = o->mode == 1 && F->sweep2_ok && !(getenv("CARMEL_HIP_FOREST_SWEEP") && atoi(getenv("CARMEL_HIP_FOREST_SWEEP")) == 1);
   if (sweep2) {
+    // the classes' recounts beside the classes still sampling (CARMEL_HIP_FOREST_RECOUNT_SPLIT=0: one recount after all)
+    split_recount = !(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT") && atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT")) == 0);
+    if (split_recount) HIPCHK(F->normsum2.alloc(ng));
     for (int k = 0; k < 2; ++k) {
       HIPCHK(F->own_cnt[k].alloc(2 * F->node_total));
       HIPCHK(hipMemsetAsync(F->own_cnt[k].p, 0, F->own_cnt[k].bytes(), s));
@@ -1381,6 +1392,14 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     hsample.assign(nf, {});
   }
   int cur = 0;
+  struct EvGuard {
+    hipEvent_t e = nullptr;
+    ~EvGuard() {
+      if (e) (void)hipEventDestroy(e);
+    }
+  } evg;
+  HIPCHK(hipEventCreateWithFlags(&evg.e, hipEventDisableTiming));
+  hipEvent_t ev_io = evg.e;
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     A.iter = iter;
@@ -1402,6 +1421,11 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         uint32_t maxlen = 0;
         for (auto& G : F->h_groups) maxlen = std::max(maxlen, G.maxlen);
         hipLaunchKernelGGL(forest_proposal_kernel, dim3((maxlen + 3) / 4, (unsigned)F->h_groups.size()), dim3(256), 0, s, A);
+        if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
+                                           // sweep reads the current one).  Later sweeps: prepared at the end of the previous one
+          HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(F->normsum2.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
         HIPCHK(fork_side(F, s));
         for (size_t ci = 0; ci < F->classes.size(); ++ci) {
           const auto& c = F->classes[ci];
@@ -1426,6 +1450,11 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             launch(forest_sample_kernel<false, true>, lds);
           else
             launch(forest_sample_kernel<false, false>, lds);
+          if (split_recount)  // this class's new samples into the counts, on its own stream, while the other classes still sample
+            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / 4, 1u), 2048u)), dim3(1024), 0,
+                               class_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
+                               F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
+                               (c.first + c.count) * 64u);
         }
         HIPCHK(join_side(F, s));
       } else
@@ -1454,17 +1483,28 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       }
       HIPCHK(hipGetLastError());
       cur ^= 1;
+      if (split_recount)
+        std::swap(F->normsum.p, F->normsum2.p);  // the sums the classes just recounted become the current ones
+      else {
       HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
       hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), 0, s,
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
-                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0);
+                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u);
+      }
       hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
                          F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr);
       HIPCHK(hipGetLastError());
       double io[2];
       HIPCHK(hipMemcpyAsync(io, F->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
+      if (split_recount && iter < Ni) {
+        // the next sweep's count buffers are reset behind the read-back: the host goes on as soon as `io` has landed
+        HIPCHK(hipEventRecord(ev_io, s));
+        HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(F->normsum2.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipEventSynchronize(ev_io));
+      } else
+        HIPCHK(hipStreamSynchronize(s));
       cheap_lp = cache_lp = io[1];
     } else {
       // exact: forest after forest; each launch resamples ONE forest on the GPU against the current counts
