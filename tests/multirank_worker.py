@@ -4,7 +4,7 @@ that buffer, carmel_hip_read_scalars, carmel_hip_maximize.  Both ranks may share
 through the host over gloo (RCCL refuses two ranks on one device); `--rccl` uses carmel_hip_allreduce_counts instead
 (one GPU per rank, or world 1).
 
-usage: multirank_worker.py RANK WORLD PORT OUT.npy MODE(synth|cipher|cipher-explicit) [--rccl]"""
+usage: multirank_worker.py RANK WORLD PORT OUT.npy MODE(synth|cipher|cipher-explicit|dense) [--rccl]"""
 import os
 import sys
 
@@ -25,6 +25,18 @@ def build(mode, rank, world):
         return w, HipForwardBackward(w, c.shard(rank, world), device=0)
     from oracle import binding as ob
     g = lambda n: open(os.path.join(ROOT, "tests", "golden", n)).read()
+    if mode == "dense":  # config 3's shape: the unrolled sweep in its rank-1 dense form (dense.hpp), counts per channel parameter
+        from carmel_amd.model import NORM_CONDITIONAL, NORM_NONE
+        lm, ch, co = synth.cipher_files(90, min_len=5, max_len=30, seed=5)
+        oc = ob.OracleCascade([lm, ch])
+        a = oc.composed().arrays()
+        w = Wfst(a["n_states"], a["final"], a["src"], a["dst"], a["isym"], a["osym"], a["logw"], a["group"])
+        ca = oc.corpus(co).arrays()
+        c = Corpus(ca["in_off"], ca["in_sym"], ca["out_off"], ca["out_sym"], ca["weight"])
+        fb = HipForwardBackward(w, c.shard(rank, world), cascade=oc.as_dict([NORM_NONE, NORM_CONDITIONAL], [0.0, 0.0]), device=0)
+        from carmel_amd._capi import lib
+        assert lib.carmel_hip_lattice_layout(fb.h) == 2, "expected the dense layout"
+        return w, fb
     oc = ob.OracleCascade([g("cipher.wfsa"), g("cipher.fst")])
     a = oc.composed().arrays()
     w = Wfst(a["n_states"], a["final"], a["src"], a["dst"], a["isym"], a["osym"], a["logw"], a["group"])

@@ -27,7 +27,7 @@ def _run(world, mode, tmp_path, tag, extra=()):
     return np.load(out)
 
 
-@pytest.mark.parametrize("mode", ["synth", "cipher", "cipher-explicit"])
+@pytest.mark.parametrize("mode", ["synth", "cipher", "cipher-explicit", "dense"])
 def test_two_ranks_reproduce_the_single_rank_trainer(tmp_path, mode):
     one = _run(1, mode, tmp_path, "one")
     two = _run(2, mode, tmp_path, "two")
