@@ -184,7 +184,23 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     // otherwise -- or with CARMEL_HIP_GPU_BUILD=0 -- the host builder below does the whole corpus
     const bool want_gpu = !(getenv("CARMEL_HIP_GPU_BUILD") && atoi(getenv("CARMEL_HIP_GPU_BUILD")) == 0) &&
                           !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
-    if (want_gpu) {
+    // a probe: a few pairs spread over the corpus built on the host first (milliseconds).  If one of them is already not
+    // a case for the GPU builder -- a cycle, more states than a lane takes, more arcs than its record buffers (256) -- the
+    // corpus goes to the host builder without the device attempt (0.1 s on the tagging cascade x400 before it gives up)
+    bool probe_ok = true;
+    if (want_gpu && t->corpus.n_pairs > 4096) {
+      const uint64_t np = t->corpus.n_pairs, n_probe = 64;
+      for (uint64_t k = 0; k < n_probe && probe_ok; ++k) {
+        const uint64_t p = k * (np / n_probe);
+        PairLattice pl;
+        bool hd = false;
+        build_pair_lattice(t->w, t->corpus.in_sym.data() + t->corpus.in_off[p], (uint32_t)(t->corpus.in_off[p + 1] - t->corpus.in_off[p]),
+                           t->corpus.out_sym.data() + t->corpus.out_off[p], (uint32_t)(t->corpus.out_off[p + 1] - t->corpus.out_off[p]),
+                           opt.prune, pl, hd);
+        if (pl.explored_states > 256 || (hd && (pl.cyclic || pl.n_states > opt.lane_states || pl.edges.size() > 256))) probe_ok = false;
+      }
+    }
+    if (want_gpu && probe_ok) {
       bool done = false;
       int rc = gpu_build_lattices(t, opt, has_derivation, stats, done);
       if (rc) return rc;
