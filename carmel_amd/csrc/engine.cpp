@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <limits>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "engine.hpp"
@@ -28,6 +29,19 @@ int fail(int code, const std::string& msg) {
   return code;
 }
 }  // namespace carmel_hip
+
+// [0, n) cut over a few host threads (the record arrays of a large corpus are tens of millions of words)
+template <class F>
+static void host_parallel_for(size_t n, F f) {
+  const size_t nt = n < (1u << 20) ? 1 : std::min<size_t>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+  if (nt <= 1) {
+    f(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (size_t k = 0; k < nt; ++k) th.emplace_back([&, k]() { f(n * k / nt, n * (k + 1) / nt); });
+  for (auto& x : th) x.join();
+}
 
 extern "C" {
 
@@ -232,7 +246,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
     if (want_t && !L.t_buckets.empty()) {
       std::vector<uint32_t> fx(L.lane_fwd.size());
-      for (size_t k = 0; k < fx.size(); ++k) fx[k] = L.lane_fwd[k].x;
+      host_parallel_for(fx.size(), [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) fx[k] = L.lane_fwd[k].x;
+      });
       HIPCHK(t->lane_fwdx.upload(fx, s));
       HIPCHK(hipStreamSynchronize(s));
       t->lane_fwd.release();
@@ -244,7 +260,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   {
     // the kernel needs only the destination/flags word of a backward record; the arc id (slot construction) stays here
     std::vector<uint32_t> bx(L.lane_bwd.size());
-    for (size_t k = 0; k < bx.size(); ++k) bx[k] = L.lane_bwd[k].x;
+    host_parallel_for(bx.size(), [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; ++k) bx[k] = L.lane_bwd[k].x;
+    });
     HIPCHK(t->lane_bwd.upload(bx, s));
     HIPCHK(hipStreamSynchronize(s));
   }
