@@ -265,7 +265,7 @@ def other_configs(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None, help="default 20; c5: 1000 sweeps, the length BASELINE.json's config names")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=["c2", "c4", "toy", "c3", "c5", "amb"])
     ap.add_argument("--lines", type=int, default=200000, help="c3: corpus lines")
@@ -279,6 +279,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--walk-arcs", default="5,40", help="min,max arcs of the random walks (SURVEY 8d: 5,40; other values are experiments)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 1000 if args.config == "c5" else 20
 
     if args.config in ("c3", "c5", "amb"):
         return other_configs(args)

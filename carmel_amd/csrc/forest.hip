@@ -16,6 +16,7 @@
 // lattice path: one posterior per AND node into post[], then count_reduce_kernel with rules in the role of arcs.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <memory>
@@ -458,9 +459,17 @@ __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
 // logarithms -- a product is a multiply and an integer add, the OR fold an aligned add, a choice probability a
 // multiply by the reciprocal of the node's own inside value: a few instructions where the log domain spends an exp
 // and a log1p per child.  Differences to the log-domain fold are rounding (1e-16 relative).
-template <bool GCOL, bool EXT>
+//
+// LW (walk tables in LDS): the top-down walk is a chain of dependent reads -- a node's record names its children -- and
+// from the global stream each visited node costs a memory round trip (~2 500 cycles; the walk was 2/3 of a wave's time).
+// The inside pass sees every record anyway, so it leaves the walk's view of the forest in LDS as 16-bit words: per node
+// the slot of its first child (| 0x8000 = AND) and the stream position of its header, per child entry the child's node
+// (| 0x8000 = reached through a back-reference).  The walk then reads LDS only (same order, same uniforms, same
+// arithmetic: the same sample) and leaves the header positions of the chosen rules; forest_recount_kernel, which reads
+// the records at those positions anyway, writes the rule ids into the sample.
+template <bool GCOL, bool EXT, bool LW>
 __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
-                                                            uint32_t stack_lds) {
+                                                            uint32_t stack_lds, uint32_t kid_rows) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds;
   // the stack follows the column(s) when they are in LDS (EXT: mantissas, then the exponents at half the size)
@@ -472,6 +481,13 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
   const uint32_t forest = active ? A.lane_forest[g.lane_base + lane] : 0u;
   double* ins = colbase + lane;                                           // ln inside, or its mantissa (EXT)
   int* ine = (int*)(colbase + (size_t)ins_rows * 64) + lane;              // EXT: its exponent
+  // LW: 16-bit rows after the columns: first-child slot per node (+ one closing row), header position per node, child
+  // entries, the walk's stack
+  unsigned short* wt = (unsigned short*)aux + lane;
+  unsigned short* ht = wt + (size_t)(ins_rows + 1) * 64;
+  unsigned short* ct = ht + (size_t)ins_rows * 64;
+  unsigned short* stk16 = ct + (size_t)kid_rows * 64;
+  uint32_t slot = 0;
   const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
   const double* __restrict__ lp = (EXT ? A.rec_p : A.rec_logp) + g.stream_base + lane;
   const uint32_t last = g.maxlen - 1;
@@ -482,18 +498,41 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
     bool is_and = false;
     double acc = 0.0, sum = F_NEG_INF;
     int acc_e = 0, sum_e = 0;  // EXT: acc / sum are mantissas
+    // three chunks of records in flight: the loads of chunk k + 2 are issued before chunk k is folded (a wave is alone
+    // on its SIMD most of the time -- LDS bounds the occupancy --, so nobody else hides the stream's latency)
+    uint2 r[FS_CHUNK], r1[FS_CHUNK], r2[FS_CHUNK];
+    double p[FS_CHUNK], p1[FS_CHUNK], p2[FS_CHUNK];
+#define FS_LOAD(R, P, base)                                  \
+  _Pragma("unroll") for (int j = 0; j < FS_CHUNK; ++j) {     \
+    const uint32_t k = min((base) + j, last);                \
+    R[j] = st[(size_t)k * 64];                               \
+    P[j] = lp[(size_t)k * 64];                               \
+  }
+    FS_LOAD(r, p, 0u)
+    FS_LOAD(r1, p1, (uint32_t)FS_CHUNK)
     for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FS_CHUNK) {
-      uint2 r[FS_CHUNK];
-      double p[FS_CHUNK];
+      if (k0) {
 #pragma unroll
-      for (int j = 0; j < FS_CHUNK; ++j) {
-        const uint32_t k = min(k0 + j, last);
-        r[j] = st[(size_t)k * 64];
-        p[j] = lp[(size_t)k * 64];
+        for (int j = 0; j < FS_CHUNK; ++j) {
+          r[j] = r1[j];
+          p[j] = p1[j];
+          r1[j] = r2[j];
+          p1[j] = p2[j];
+        }
       }
+      FS_LOAD(r2, p2, k0 + 2u * FS_CHUNK)
 #pragma unroll
       for (int j = 0; j < FS_CHUNK; ++j) {
         if (k0 + j > last || !active || !(r[j].x & F_VALID)) continue;
+        if (LW) {
+          if (r[j].x & F_HEADER) {
+            wt[(size_t)d * 64] = (unsigned short)(slot | ((r[j].x & F_AND) ? 0x8000u : 0u));
+            ht[(size_t)d * 64] = (unsigned short)(k0 + j);
+          } else {
+            ct[(size_t)slot * 64] = (unsigned short)((r[j].x & 0x7fffu) | ((r[j].y >> 31) << 15));
+            ++slot;
+          }
+        }
         if (EXT) {
           if (r[j].x & F_HEADER) {
             is_and = (r[j].x & F_AND) != 0;
@@ -550,8 +589,94 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
     }
   }
   if (A.trace) tr2 = __builtin_readcyclecounter();
+  if (LW && active) {
+    // the same walk over the LDS tables; stack entries: node | 0x8000 = below a back-reference
+    wt[(size_t)n * 64] = (unsigned short)slot;
+    uint32_t* outh = A.sample_hdr + A.sample_off[forest];
+    const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
+    uint32_t* stack = A.sample_rules + A.sample_off[forest] + cap;  // deep part of the stack: stack[-1 - i]
+#define FSTACK_PUSH(v)                                       \
+  {                                                          \
+    if (sp < stack_lds)                                      \
+      stk16[(size_t)sp * 64] = (unsigned short)(v);          \
+    else                                                     \
+      stack[-(int)(sp - stack_lds) - 1] = (v);               \
+    ++sp;                                                    \
+  }
+    // `entry` = the node to visit next, kept in a register when it is the child just chosen or an AND node's first
+    // child (what the stack would hand back at once); F_NONE = take it from the stack
+    const uint32_t F_NONE = 0xffffffffu;
+    uint32_t sp = 0, ns = 0, step = 0, entry = n - 1;
+    for (;;) {
+      if (entry == F_NONE) {
+        if (!sp) break;
+        --sp;
+        entry = sp < stack_lds ? (uint32_t)stk16[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
+      }
+      const uint32_t me = entry & 0x7fffu, cold = entry & 0x8000u;
+      const uint32_t w0 = wt[(size_t)me * 64], w1 = wt[(size_t)(me + 1) * 64];
+      const uint32_t first = w0 & 0x7fffu, nch = (w1 & 0x7fffu) - first;
+      if (w0 & 0x8000u) {
+        if (ns < max_sample) outh[ns] = ht[(size_t)me * 64];
+        ++ns;
+        for (uint32_t k = nch; k-- > 1;) FSTACK_PUSH((uint32_t)ct[(size_t)(first + k) * 64] | cold)
+        entry = nch ? ((uint32_t)ct[(size_t)first * 64] | cold) : F_NONE;
+      } else {
+        uint32_t pick = 0;
+        if (EXT) {
+          // the first four children's values at once (rows past the node's children are read and ignored: every row
+          // below kid_rows exists), then the reference's serial subtraction on registers
+          uint32_t ci4[4];
+          double vm4[4];
+          int ve4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ci4[q] = ct[(size_t)min(first + q, kid_rows - 1) * 64] & 0x7fffu;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            vm4[q] = ins[(size_t)min(ci4[q], ins_rows - 1) * 64];
+            ve4[q] = ine[(size_t)min(ci4[q], ins_rows - 1) * 64];
+          }
+          const double inv = 1.0 / ins[(size_t)me * 64];
+          const int ne = ine[(size_t)me * 64];
+          double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+          for (uint32_t k = 0;; ++k) {
+            pick = k;
+            double vm;
+            int ve;
+            if (k < 4) {
+              vm = k == 0 ? vm4[0] : k == 1 ? vm4[1] : k == 2 ? vm4[2] : vm4[3];
+              ve = k == 0 ? ve4[0] : k == 1 ? ve4[1] : k == 2 ? ve4[2] : ve4[3];
+            } else {
+              const uint32_t ci = ct[(size_t)(first + k) * 64] & 0x7fffu;
+              vm = ins[(size_t)ci * 64];
+              ve = ine[(size_t)ci * 64];
+            }
+            choice -= ldexp(vm * inv, ve - ne);
+            if (choice < 0 || k + 1 == nch) break;
+          }
+        } else {
+          const double power = cold ? 1.0 : A.power;
+          double norm = ins[(size_t)me * 64];
+          if (power != 1.0) {
+            norm = F_NEG_INF;
+            for (uint32_t k = 0; k < nch; ++k)
+              norm = f_lwadd(norm, ins[(size_t)(ct[(size_t)(first + k) * 64] & 0x7fffu) * 64] * power);
+          }
+          double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+          for (uint32_t k = 0;; ++k) {
+            pick = k;
+            choice -= exp(ins[(size_t)(ct[(size_t)(first + k) * 64] & 0x7fffu) * 64] * power - norm);
+            if (choice < 0 || k + 1 == nch) break;
+          }
+        }
+        entry = (uint32_t)ct[(size_t)(first + pick) * 64] | cold;
+      }
+    }
+#undef FSTACK_PUSH
+    A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+  }
   // top-down choice (forest.hpp:725-758); stack entries: header position | bit 31 = below a back-reference
-  if (active) {
+  if (!LW && active) {
     uint32_t* outr = A.sample_rules + A.sample_off[forest];
     uint32_t* outh = A.sample_hdr + A.sample_off[forest];
     const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
@@ -656,7 +781,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 // adds up the sample's ln proposal probability and counts the uses per class for the next sweep.
 #define FRC_SLOTS 2048u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
-                                                              const uint32_t* rules, const uint32_t* p_norm, double* x,
+                                                              uint32_t* rules, const uint32_t* p_norm, double* x,
                                                               double* normsum, uint32_t n_forests, ForestArgs A, int sweep2,
                                                               const uint32_t* slot_forest, uint32_t slot0, uint32_t slot1) {
   __shared__ uint32_t key[2][FRC_SLOTS];
@@ -694,22 +819,48 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
       g = A.groups[slot >> 6];
       lane = slot & 63u;
     }
+    if (sweep2) {
+      // the sample as header positions (forest_sample_kernel<.., LW> leaves no rule ids): the rule is in the record.  Four
+      // entries per lane at a time -- position -> record -> norm group is a chain of three round trips, and a large
+      // sample would walk it ten times in a row
+      uint32_t* cn = A.cnt_new + 2 * g.node_base + lane;
+      for (uint32_t k0 = threadIdx.x & 15u; k0 < len; k0 += 64) {
+        size_t pos[4];
+        uint32_t rule[4], nn[4], c[4];
+        double lpv[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          ok[q] = k0 + 16u * q < len;
+          pos[q] = g.stream_base + (size_t)(ok[q] ? A.sample_hdr[so + k0 + 16u * q] : 0u) * 64 + lane;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          rule[q] = A.ins_stream[pos[q]].y;
+          lpv[q] = A.rec_logp[pos[q]];
+          c[q] = A.rec_cls[pos[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nn[q] = ok[q] ? p_norm[rule[q]] : F_NONORM;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (!ok[q]) continue;
+          rules[so + k0 + 16u * q] = rule[q];
+          cheap += lpv[q];
+          if (nn[q] == F_NONORM) continue;
+          add(0, rule[q], x);
+          add(1, nn[q], normsum);
+          atomicAdd(cn + (size_t)(c[q] & 0xffffu) * 64, 1u);
+          atomicAdd(cn + (size_t)(g.max_nodes + (c[q] >> 16)) * 64, 1u);
+        }
+      }
+      continue;
+    }
     for (uint32_t k = threadIdx.x & 15u; k < len; k += 16) {
       const uint32_t rule = r[k], nn = p_norm[rule];
-      size_t pos = 0;
-      if (sweep2) {
-        pos = g.stream_base + (size_t)A.sample_hdr[so + k] * 64 + lane;
-        cheap += A.rec_logp[pos];
-      }
       if (nn == F_NONORM) continue;
       add(0, rule, x);
       add(1, nn, normsum);
-      if (sweep2) {
-        const uint32_t c = A.rec_cls[pos];
-        uint32_t* cn = A.cnt_new + 2 * g.node_base + lane;
-        atomicAdd(cn + (size_t)(c & 0xffffu) * 64, 1u);
-        atomicAdd(cn + (size_t)(g.max_nodes + (c >> 16)) * 64, 1u);
-      }
     }
   }
   if (sweep2) {
@@ -785,12 +936,13 @@ struct carmel_hip_forests {
   uint32_t n_rules = 0, max_nodes = 0, max_sample = 0;
   uint64_t node_total = 0, stream_total = 0;
   static const int N_SIDE = 4;
-  hipStream_t side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};  // launch classes of one sweep run side by side
-  hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t side[N_SIDE] = {};  // launch classes of one sweep run side by side
+  hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {};
   bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
   std::vector<FGroup> h_groups;
   struct Cls {
     uint32_t first, count, max_nodes;
+    uint32_t max_kids = 0, maxlen = 0;  // child entries / records of the class's largest lane (LDS walk tables)
   };
   std::vector<Cls> classes;
   std::vector<uint32_t> h_norm, lane_of_forest;
@@ -952,7 +1104,14 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       for (uint32_t k = 0; k < fl.n; ++k) hp[G.stream_base + (size_t)k * 64 + l] = fl.hdr[k];
     }
   }
-  {  // launch classes by LDS need
+  {  // launch classes by LDS need: a class ends where the groups have shrunk to 2/3 of its largest (CARMEL_HIP_FOREST_CLASSES=
+     // "num,den,min groups").  Finer classes (4,5,64: eleven for config 5) pad less LDS but were slower, 0.96 against
+     // 0.79 ms per sweep: only four or five kernels run side by side, the rest queue behind them
+    unsigned cls_num = 2, cls_den = 3, cls_min = 256;
+    if (const char* e = getenv("CARMEL_HIP_FOREST_CLASSES")) {
+      unsigned a = 0, b = 0, c = 0;
+      if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a && b && a < b && c) cls_num = a, cls_den = b, cls_min = c;
+    }
     size_t i = 0;
     while (i < ng) {
       uint32_t mx = F->h_groups[i].max_nodes;
@@ -960,10 +1119,19 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       while (j < ng) {
         uint32_t m = F->h_groups[j].max_nodes;
         if (m > mx) mx = m;
-        if (j - i >= 256 && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
+        if (j - i >= cls_min && (uint64_t)m * cls_den <= (uint64_t)mx * cls_num) break;
         ++j;
       }
-      F->classes.push_back(carmel_hip_forests::Cls{(uint32_t)i, (uint32_t)(j - i), mx});
+      carmel_hip_forests::Cls c{(uint32_t)i, (uint32_t)(j - i), mx};
+      for (size_t q = i; q < j; ++q) {
+        const FGroup& G = F->h_groups[q];
+        c.maxlen = std::max(c.maxlen, G.maxlen);
+        for (uint32_t l = 0; l < G.n_lanes; ++l) {
+          const Flat& fl = flat[ord[G.lane_base + l]];
+          c.max_kids = std::max<uint32_t>(c.max_kids, (uint32_t)(fl.ins.size() - fl.n));
+        }
+      }
+      F->classes.push_back(c);
       i = j;
     }
   }
@@ -1367,6 +1535,11 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   DevBuf<double> gcol_exact;  // exact mode: the inside column of one forest too large for LDS
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
   const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
+  // the walk of forest_sample_kernel over tables in LDS (CARMEL_HIP_FOREST_LDSWALK=0: over the global stream, the A/B reference)
+  // groups per workgroup of a class's recount (fewer groups per workgroup = more workgroups, each adding its share of
+  // the popular rules to the same addresses: 1 and 2 measured slower than 4, 122 and 84 against 77 us for the last class)
+  const uint32_t recount_div = getenv("CARMEL_HIP_FOREST_RECOUNT_DIV") ? std::max(1, atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_DIV"))) : 4;
+  const bool lds_walk = !(getenv("CARMEL_HIP_FOREST_LDSWALK") && atoi(getenv("CARMEL_HIP_FOREST_LDSWALK")) == 0);
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
   if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
@@ -1392,20 +1565,23 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     hsample.assign(nf, {});
   }
   int cur = 0;
-  struct EvGuard {
-    hipEvent_t e = nullptr;
-    ~EvGuard() {
-      if (e) (void)hipEventDestroy(e);
-    }
-  } evg;
-  HIPCHK(hipEventCreateWithFlags(&evg.e, hipEventDisableTiming));
-  hipEvent_t ev_io = evg.e;
+  DevBuf<double> iter_all;  // parallel mode: {-, ln proposal probability of the sweep's samples} per sweep
+  std::vector<double> iter_host;
+  uint32_t io_done = 0;
+  if (o->mode == 1) {
+    HIPCHK(iter_all.alloc(2 * ((size_t)Ni + 1)));
+    HIPCHK(hipMemsetAsync(iter_all.p, 0, iter_all.bytes(), s));
+    iter_host.assign(2 * ((size_t)Ni + 1), 0.0);
+  }
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     A.iter = iter;
     A.power = gibbs_anneal_power(o->high_temp, o->low_temp, Ni, iter);
-    HIPCHK(hipMemsetAsync(F->iter_out.p, 0, 2 * sizeof(double), s));
     double cache_lp = 0.0, cheap_lp = 0.0;
+    if (o->mode == 1)  // a slot per sweep, read back in batches: the host runs ahead of the device, no round trip per sweep
+      A.iter_out = iter_all.p + 2 * (size_t)iter;
+    else
+      HIPCHK(hipMemsetAsync(F->iter_out.p, 0, 2 * sizeof(double), s));
     if (o->mode == 1) {
       // all forests against the counts of the previous sweep, own previous sample taken out in-kernel
       A.snap_x = F->p_x.p;
@@ -1433,25 +1609,36 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           // temperature 1: mantissa / exponent arithmetic (12 bytes per node); annealing: the log domain
           const bool ext = A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN");
           const size_t lds = (size_t)c.max_nodes * 64 * (ext ? 12 : 8) + (size_t)stack_lds * 64 * 4;
+          // with the walk's tables in LDS: 16-bit rows (2 per node + 1, the child entries, the stack)
+          const uint32_t kid_rows = std::max(c.max_kids, 1u);
+          const size_t lds_lw = (size_t)c.max_nodes * 64 * (ext ? 12 : 8) +
+                                ((size_t)2 * c.max_nodes + 1 + kid_rows + stack_lds) * 64 * 2;
+          const bool lw = lds_walk && c.max_nodes < 0x8000u && c.max_kids < 0x8000u && c.maxlen <= 0x10000u &&
+                          (size_t)c.max_nodes * 64 * 8 * 2 <= F_LDS_LIMIT && lds_lw <= F_LDS_LIMIT;
           auto launch = [&](auto kernel, size_t bytes) {
             if (bytes > 64 * 1024)
               (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
             hipLaunchKernelGGL(kernel, dim3(c.count), dim3(64), bytes, class_stream(F, s, ci), A, F->max_sample, c.max_nodes,
-                               stack_lds);
+                               stack_lds, kid_rows);
           };
           if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
             A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
             if (ext)
-              launch(forest_sample_kernel<true, true>, (size_t)stack_lds * 64 * 4);
+              launch(forest_sample_kernel<true, true, false>, (size_t)stack_lds * 64 * 4);
             else
-              launch(forest_sample_kernel<true, false>, (size_t)stack_lds * 64 * 4);
+              launch(forest_sample_kernel<true, false, false>, (size_t)stack_lds * 64 * 4);
+          } else if (lw) {
+            if (ext)
+              launch(forest_sample_kernel<false, true, true>, lds_lw);
+            else
+              launch(forest_sample_kernel<false, false, true>, lds_lw);
           } else if (ext)
-            launch(forest_sample_kernel<false, true>, lds);
+            launch(forest_sample_kernel<false, true, false>, lds);
           else
-            launch(forest_sample_kernel<false, false>, lds);
+            launch(forest_sample_kernel<false, false, false>, lds);
           if (split_recount)  // this class's new samples into the counts, on its own stream, while the other classes still sample
-            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / 4, 1u), 2048u)), dim3(1024), 0,
+            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), 0,
                                class_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
                                (c.first + c.count) * 64u);
@@ -1495,17 +1682,21 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
                          F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr);
       HIPCHK(hipGetLastError());
-      double io[2];
-      HIPCHK(hipMemcpyAsync(io, F->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
-      if (split_recount && iter < Ni) {
-        // the next sweep's count buffers are reset behind the read-back: the host goes on as soon as `io` has landed
-        HIPCHK(hipEventRecord(ev_io, s));
+      if (split_recount && iter < Ni) {  // the next sweep's count buffers start from the priors
         HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpyAsync(F->normsum2.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipEventSynchronize(ev_io));
-      } else
+      }
+      if (iter == Ni || (iter & 63u) == 63u) {  // the sweeps' probabilities, 64 sweeps at a time
+        HIPCHK(hipMemcpyAsync(iter_host.data() + 2 * (size_t)io_done, iter_all.p + 2 * (size_t)io_done,
+                              2 * (size_t)(iter + 1 - io_done) * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-      cheap_lp = cache_lp = io[1];
+        for (uint32_t q = io_done; q <= iter; ++q) {
+          if (iter_logprob) iter_logprob[q] = iter_host[2 * (size_t)q + 1];
+          if (iter_cheap_logprob) iter_cheap_logprob[q] = iter_host[2 * (size_t)q + 1];
+        }
+        io_done = iter + 1;
+      }
+      continue;
     } else {
       // exact: forest after forest; each launch resamples ONE forest on the GPU against the current counts
       ccount = prior;

@@ -11,6 +11,10 @@ rows = [r for r in csv.DictReader(open(sys.argv[1])) if 'forest' in r['Kernel_Na
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 t0 = None
 # the last sweep: from the last proposal kernel on
+props = [int(r['Start_Timestamp']) for r in rows if 'proposal' in r['Kernel_Name']]
+if len(props) > 2:
+    d = sorted(b - a for a, b in zip(props, props[1:]))
+    print("sweep period (proposal start to proposal start): median %.1f us, min %.1f us over %d sweeps" % (d[len(d) // 2] / 1e3, d[0] / 1e3, len(d)))
 idx = max(i for i, r in enumerate(rows) if 'proposal' in r['Kernel_Name'])
 base = int(rows[idx]['Start_Timestamp'])
 for r in rows[idx:]:
