@@ -487,7 +487,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
   unsigned short* ht = wt + (size_t)(ins_rows + 1) * 64;
   unsigned short* ct = ht + (size_t)ins_rows * 64;
   unsigned short* stk16 = ct + (size_t)kid_rows * 64;
-  uint32_t slot = 0;
+  uint32_t slot = 0, hpos = 0;
   const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
   const double* __restrict__ lp = (EXT ? A.rec_p : A.rec_logp) + g.stream_base + lane;
   const uint32_t last = g.maxlen - 1;
@@ -523,6 +523,43 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
       FS_LOAD(r2, p2, k0 + 2u * FS_CHUNK)
 #pragma unroll
       for (int j = 0; j < FS_CHUNK; ++j) {
+        if constexpr (EXT && LW) {
+          // the same fold without branches: a wave's lanes sit at headers, AND children and OR children alike, every
+          // branch was taken by somebody and the jumps around them cost as much as the arithmetic.  All candidates
+          // are computed (the same operations on the same operands as below), selects keep the one that applies; the
+          // node's running value and header position are stored at every record, the last store stays.
+          const uint32_t rx = r[j].x, ry = r[j].y;
+          if (k0 + j <= last && active && (rx & F_VALID)) {
+            const bool hdr = (rx & F_HEADER) != 0, child = !hdr;
+            const uint32_t row = min(rx & F_IDX, ins_rows - 1);  // (a header's low bits are not a row: read and ignored)
+            const double vm = ins[(size_t)row * 64];
+            const int ve = ine[(size_t)row * 64];
+            hpos = hdr ? k0 + j : hpos;
+            unsigned short* tp = hdr ? wt + (size_t)d * 64 : ct + (size_t)slot * 64;
+            *tp = (unsigned short)(hdr ? (slot | ((rx & F_AND) ? 0x8000u : 0u)) : ((rx & 0x7fffu) | ((ry >> 31) << 15)));
+            ht[(size_t)d * 64] = (unsigned short)hpos;
+            slot += child ? 1u : 0u;
+            int he, pe, se;
+            const double hm = frexp(p[j], &he);
+            const double pm = frexp(acc * vm, &pe);
+            const int dd = ve - sum_e;
+            const bool le = dd <= 0;
+            const double lo = le ? vm : sum, hi = le ? sum : vm;
+            const double sm = frexp(hi + ldexp(lo, le ? dd : -dd), &se);
+            const bool fold_and = child && is_and, fold_or = child && !is_and && vm != 0.0, sum0 = sum == 0.0;
+            acc_e = hdr ? he : fold_and ? acc_e + ve + pe : acc_e;
+            acc = hdr ? hm : fold_and ? pm : acc;
+            const int nsum_e = sum0 ? ve : (le ? sum_e : ve) + se;
+            const double nsum = sum0 ? vm : sm;
+            sum_e = hdr ? 0 : fold_or ? nsum_e : sum_e;
+            sum = hdr ? 0.0 : fold_or ? nsum : sum;
+            is_and = hdr ? (rx & F_AND) != 0 : is_and;
+            ins[(size_t)d * 64] = is_and ? acc : sum;
+            ine[(size_t)d * 64] = is_and ? acc_e : sum_e;
+            d += (rx & F_LAST) ? 1u : 0u;
+          }
+          continue;
+        }
         if (k0 + j > last || !active || !(r[j].x & F_VALID)) continue;
         if (LW) {
           if (r[j].x & F_HEADER) {
@@ -607,52 +644,46 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
     // child (what the stack would hand back at once); F_NONE = take it from the stack
     const uint32_t F_NONE = 0xffffffffu;
     uint32_t sp = 0, ns = 0, step = 0, entry = n - 1;
+    // One turn of the loop = an OR node's choice AND the chosen AND node's expansion: the lanes of a wave sit at OR and at
+    // AND nodes alike, so both halves are executed every turn anyway -- visiting the pair in one turn halves the turns.
     for (;;) {
       if (entry == F_NONE) {
         if (!sp) break;
         --sp;
         entry = sp < stack_lds ? (uint32_t)stk16[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
       }
-      const uint32_t me = entry & 0x7fffu, cold = entry & 0x8000u;
-      const uint32_t w0 = wt[(size_t)me * 64], w1 = wt[(size_t)(me + 1) * 64];
-      const uint32_t first = w0 & 0x7fffu, nch = (w1 & 0x7fffu) - first;
-      if (w0 & 0x8000u) {
-        if (ns < max_sample) outh[ns] = ht[(size_t)me * 64];
-        ++ns;
-        for (uint32_t k = nch; k-- > 1;) FSTACK_PUSH((uint32_t)ct[(size_t)(first + k) * 64] | cold)
-        entry = nch ? ((uint32_t)ct[(size_t)first * 64] | cold) : F_NONE;
-      } else {
+      uint32_t me = entry & 0x7fffu, cold = entry & 0x8000u;
+      uint32_t w0 = wt[(size_t)me * 64], w1 = wt[(size_t)(me + 1) * 64];
+      uint32_t first = w0 & 0x7fffu, nch = (w1 & 0x7fffu) - first;
+      if (!(w0 & 0x8000u)) {
         uint32_t pick = 0;
         if (EXT) {
-          // the first four children's values at once (rows past the node's children are read and ignored: every row
-          // below kid_rows exists), then the reference's serial subtraction on registers
+          // the first four children's shares at once (rows past the node's children are read and ignored: every row
+          // below kid_rows exists), then the reference's serial subtraction without branches: the same differences in
+          // the same order, the first one below zero (or the last child) is the choice
           uint32_t ci4[4];
-          double vm4[4];
-          int ve4[4];
+          double t4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) ci4[q] = ct[(size_t)min(first + q, kid_rows - 1) * 64] & 0x7fffu;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            vm4[q] = ins[(size_t)min(ci4[q], ins_rows - 1) * 64];
-            ve4[q] = ine[(size_t)min(ci4[q], ins_rows - 1) * 64];
-          }
           const double inv = 1.0 / ins[(size_t)me * 64];
           const int ne = ine[(size_t)me * 64];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t row = min(ci4[q], ins_rows - 1);
+            t4[q] = ldexp(ins[(size_t)row * 64] * inv, ine[(size_t)row * 64] - ne);
+          }
           double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
-          for (uint32_t k = 0;; ++k) {
-            pick = k;
-            double vm;
-            int ve;
-            if (k < 4) {
-              vm = k == 0 ? vm4[0] : k == 1 ? vm4[1] : k == 2 ? vm4[2] : vm4[3];
-              ve = k == 0 ? ve4[0] : k == 1 ? ve4[1] : k == 2 ? ve4[2] : ve4[3];
-            } else {
+          const double c0 = choice - t4[0], c1 = c0 - t4[1], c2 = c1 - t4[2], c3 = c2 - t4[3];
+          const bool s0 = c0 < 0 || nch == 1, s1 = c1 < 0 || nch == 2, s2 = c2 < 0 || nch == 3, s3 = c3 < 0 || nch == 4;
+          pick = s0 ? 0u : s1 ? 1u : s2 ? 2u : 3u;
+          if (!(s0 || s1 || s2 || s3)) {
+            choice = c3;
+            for (uint32_t k = 4;; ++k) {
+              pick = k;
               const uint32_t ci = ct[(size_t)(first + k) * 64] & 0x7fffu;
-              vm = ins[(size_t)ci * 64];
-              ve = ine[(size_t)ci * 64];
+              choice -= ldexp(ins[(size_t)ci * 64] * inv, ine[(size_t)ci * 64] - ne);
+              if (choice < 0 || k + 1 == nch) break;
             }
-            choice -= ldexp(vm * inv, ve - ne);
-            if (choice < 0 || k + 1 == nch) break;
           }
         } else {
           const double power = cold ? 1.0 : A.power;
@@ -670,6 +701,18 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
           }
         }
         entry = (uint32_t)ct[(size_t)(first + pick) * 64] | cold;
+        me = entry & 0x7fffu;
+        cold = entry & 0x8000u;
+        w0 = wt[(size_t)me * 64];
+        w1 = wt[(size_t)(me + 1) * 64];
+        first = w0 & 0x7fffu;
+        nch = (w1 & 0x7fffu) - first;
+      }
+      if (w0 & 0x8000u) {
+        if (ns < max_sample) outh[ns] = ht[(size_t)me * 64];
+        ++ns;
+        for (uint32_t k = nch; k-- > 1;) FSTACK_PUSH((uint32_t)ct[(size_t)(first + k) * 64] | cold)
+        entry = nch ? ((uint32_t)ct[(size_t)first * 64] | cold) : F_NONE;
       }
     }
 #undef FSTACK_PUSH
@@ -780,6 +823,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 // 16 lanes per forest; a workgroup covers 64 forests.  With A (second formulation of the parallel sweep) it also
 // adds up the sample's ln proposal probability and counts the uses per class for the next sweep.
 #define FRC_SLOTS 2048u
+#define FRC_FORESTS 256u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
                                                               uint32_t* rules, const uint32_t* p_norm, double* x,
                                                               double* normsum, uint32_t n_forests, ForestArgs A, int sweep2,
@@ -804,36 +848,57 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
   // slot_forest: the forests of the lane slots [slot0, slot1) -- one launch class, recounted as soon as its sample kernel is
   // done, beside the other classes still sampling; otherwise all forests in corpus order
   const uint32_t i_begin = slot_forest ? slot0 : 0u, i_end = slot_forest ? slot1 : n_forests;
-  for (uint32_t f0 = i_begin + blockIdx.x * 64; f0 < i_end; f0 += gridDim.x * 64) {
-    const uint32_t i = f0 + (threadIdx.x >> 4);
-    if (i >= i_end) continue;
-    const uint32_t f = slot_forest ? slot_forest[i] : i;
-    if (f == 0xffffffffu) continue;  // an empty lane slot
-    const uint64_t so = sample_off[f];
-    const uint32_t* r = rules + so;
-    const uint32_t len = sample_len[f];
-    uint32_t lane = 0;
-    FGroup g;
-    if (sweep2) {
-      const uint32_t slot = slot_forest ? i : A.lane_of_forest[f];
-      g = A.groups[slot >> 6];
-      lane = slot & 63u;
-    }
-    if (sweep2) {
-      // the sample as header positions (forest_sample_kernel<.., LW> leaves no rule ids): the rule is in the record.  Four
-      // entries per lane at a time -- position -> record -> norm group is a chain of three round trips, and a large
-      // sample would walk it ten times in a row
-      uint32_t* cn = A.cnt_new + 2 * g.node_base + lane;
-      for (uint32_t k0 = threadIdx.x & 15u; k0 < len; k0 += 64) {
-        size_t pos[4];
-        uint32_t rule[4], nn[4], c[4];
+  if (sweep2) {
+    // The entries of FRC_FORESTS forests at a time, dealt out evenly: a prefix sum of the sample lengths in LDS, entry e
+    // belongs to the forest whose range holds it (binary search).  (Sixteen lanes per forest, forest after forest, left
+    // a workgroup waiting for its largest sample four times in a row: 75-110 us for the classes of large forests.)
+    __shared__ uint32_t pre[FRC_FORESTS + 1];
+    __shared__ uint32_t fid[FRC_FORESTS];
+    for (uint32_t f0 = i_begin + blockIdx.x * FRC_FORESTS; f0 < i_end; f0 += gridDim.x * FRC_FORESTS) {
+      __syncthreads();
+      if (threadIdx.x < FRC_FORESTS) {
+        const uint32_t i = f0 + threadIdx.x;
+        const uint32_t f = i < i_end ? (slot_forest ? slot_forest[i] : i) : 0xffffffffu;
+        fid[threadIdx.x] = f;
+        pre[threadIdx.x + 1] = f == 0xffffffffu ? 0u : sample_len[f];
+      }
+      if (threadIdx.x == 0) pre[0] = 0;
+      __syncthreads();
+      for (uint32_t o = 1; o < FRC_FORESTS; o <<= 1) {  // inclusive scan of pre[1 ..]
+        uint32_t v = 0;
+        if (threadIdx.x < FRC_FORESTS && threadIdx.x >= o) v = pre[threadIdx.x + 1 - o];
+        __syncthreads();
+        if (threadIdx.x < FRC_FORESTS) pre[threadIdx.x + 1] += v;
+        __syncthreads();
+      }
+      const uint32_t total = pre[FRC_FORESTS];
+      for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 1024) {  // four entries per thread in flight
+        size_t pos[4], so[4], nb[4];
+        uint32_t rule[4], nn[4], c[4], mxn[4];
         double lpv[4];
         bool ok[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          ok[q] = k0 + 16u * q < len;
-          pos[q] = g.stream_base + (size_t)(ok[q] ? A.sample_hdr[so + k0 + 16u * q] : 0u) * 64 + lane;
+          const uint32_t e = e0 + 1024u * q;
+          ok[q] = e < total;
+          uint32_t lo = 0, hi = FRC_FORESTS;  // the last forest slot whose range starts at or before e
+          while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (pre[mid] <= (ok[q] ? e : 0u))
+              lo = mid;
+            else
+              hi = mid;
+          }
+          const uint32_t f = ok[q] ? fid[lo] : 0u;  // (a range that holds an entry belongs to a real forest)
+          const uint32_t slot = ok[q] ? (slot_forest ? f0 + lo : A.lane_of_forest[f]) : 0u;
+          const FGroup g = A.groups[slot >> 6];
+          so[q] = sample_off[f] + (ok[q] ? e - pre[lo] : 0u);
+          mxn[q] = g.max_nodes;
+          nb[q] = 2 * g.node_base + (slot & 63u);
+          pos[q] = g.stream_base + (slot & 63u);
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pos[q] += (size_t)(ok[q] ? A.sample_hdr[so[q]] : 0u) * 64;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           rule[q] = A.ins_stream[pos[q]].y;
@@ -845,17 +910,26 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (!ok[q]) continue;
-          rules[so + k0 + 16u * q] = rule[q];
+          rules[so[q]] = rule[q];
           cheap += lpv[q];
           if (nn[q] == F_NONORM) continue;
           add(0, rule[q], x);
           add(1, nn[q], normsum);
+          uint32_t* cn = A.cnt_new + nb[q];
           atomicAdd(cn + (size_t)(c[q] & 0xffffu) * 64, 1u);
-          atomicAdd(cn + (size_t)(g.max_nodes + (c[q] >> 16)) * 64, 1u);
+          atomicAdd(cn + (size_t)(mxn[q] + (c[q] >> 16)) * 64, 1u);
         }
       }
-      continue;
     }
+  } else
+  for (uint32_t f0 = i_begin + blockIdx.x * 64; f0 < i_end; f0 += gridDim.x * 64) {
+    const uint32_t i = f0 + (threadIdx.x >> 4);
+    if (i >= i_end) continue;
+    const uint32_t f = slot_forest ? slot_forest[i] : i;
+    if (f == 0xffffffffu) continue;  // an empty lane slot
+    const uint64_t so = sample_off[f];
+    const uint32_t* r = rules + so;
+    const uint32_t len = sample_len[f];
     for (uint32_t k = threadIdx.x & 15u; k < len; k += 16) {
       const uint32_t rule = r[k], nn = p_norm[rule];
       if (nn == F_NONORM) continue;
@@ -878,11 +952,19 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     unsafeAtomicAdd(A.iter_out + 1, t);
   }
 }
-__global__ void forest_commit_kernel(const double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
-                                     double time, uint64_t n) {
+// reset_x / reset_norm (may be null): the count buffers of the NEXT sweep start from the priors -- set here, by the thread
+// that has just read the slot, instead of two copies behind the kernel
+__global__ void forest_commit_kernel(double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
+                                     double time, uint64_t n, const double* reset_x, double* next_norm,
+                                     const double* reset_norm, uint64_t n_norm) {
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_norm && next_norm;
+       p += (uint64_t)gridDim.x * blockDim.x)
+    next_norm[p] = reset_norm[p];
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
     if (p_norm[p] == F_NONORM) continue;
-    const double d = new_x[p] - p_x[p];
+    const double nx = new_x[p];
+    if (reset_x) new_x[p] = reset_x[p];
+    const double d = nx - p_x[p];
     const double moret = time - p_tmax[p];
     if (moret > 0) {
       p_tmax[p] = time;
@@ -1593,7 +1675,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       if (sweep2) {
         A.cnt_old = F->own_cnt[cur].p;
         A.cnt_new = F->own_cnt[cur ^ 1].p;
-        HIPCHK(hipMemsetAsync(F->own_cnt[cur ^ 1].p, 0, F->own_cnt[cur ^ 1].bytes(), s));
+        // (the class counts of this sweep's samples go to own_cnt[cur ^ 1]: cleared at allocation and, from then on,
+        // during the previous sweep -- below, behind the proposal kernel that was its last reader)
         uint32_t maxlen = 0;
         for (auto& G : F->h_groups) maxlen = std::max(maxlen, G.maxlen);
         hipLaunchKernelGGL(forest_proposal_kernel, dim3((maxlen + 3) / 4, (unsigned)F->h_groups.size()), dim3(256), 0, s, A);
@@ -1643,6 +1726,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
                                (c.first + c.count) * 64u);
         }
+        // the buffer the proposal kernel has just read is the next sweep's cnt_new: cleared here, on the main stream behind
+        // its class, while the longer classes still sample
+        if (iter < Ni) HIPCHK(hipMemsetAsync(F->own_cnt[cur].p, 0, F->own_cnt[cur].bytes(), s));
         HIPCHK(join_side(F, s));
       } else
       for (auto& c : F->classes) {
@@ -1679,13 +1765,13 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
                          F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u);
       }
-      hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
-                         F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr);
-      HIPCHK(hipGetLastError());
-      if (split_recount && iter < Ni) {  // the next sweep's count buffers start from the priors
-        HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(F->normsum2.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      {  // (split recount: the next sweep's count buffers start from the priors, reset by the commit itself)
+        const bool reset = split_recount && iter < Ni;
+        hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
+                           F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr, reset ? (const double*)F->p_prior.p : nullptr,
+                           reset ? F->normsum2.p : nullptr, (const double*)F->prior_norm.p, (uint64_t)ng);
       }
+      HIPCHK(hipGetLastError());
       if (iter == Ni || (iter & 63u) == 63u) {  // the sweeps' probabilities, 64 sweeps at a time
         HIPCHK(hipMemcpyAsync(iter_host.data() + 2 * (size_t)io_done, iter_all.p + 2 * (size_t)io_done,
                               2 * (size_t)(iter + 1 - io_done) * sizeof(double), hipMemcpyDeviceToHost, s));
