@@ -29,7 +29,7 @@ SYMBOLS = [
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_get_sample",
-    "carmel_hip_forests_max_sample",
+    "carmel_hip_forests_max_sample", "carmel_hip_forests_viterbi", "carmel_hip_forests_get_viterbi",
     "carmel_hip_compose", "carmel_hip_composition_states", "carmel_hip_composition_arcs", "carmel_hip_composition_seconds",
     "carmel_hip_composition_export", "carmel_hip_composition_free",
     "carmel_hip_debug_lattice_fingerprint", "carmel_hip_lattice_layout",
@@ -176,6 +176,8 @@ def _load():
     lib.carmel_hip_forests_get_sample.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_forests_max_sample.argtypes = [vp]
     lib.carmel_hip_forests_max_sample.restype = C.c_uint32
+    lib.carmel_hip_forests_viterbi.argtypes = [vp, vp]
+    lib.carmel_hip_forests_get_viterbi.argtypes = [vp, C.c_uint64, vp, vp, C.POINTER(C.c_uint32)]
     for s in SYMBOLS:  # a prototype for every entry point: without one ctypes passes Python ints as C int (64-bit seeds
         if getattr(lib, s).argtypes is None:  # and bare handles would be truncated)
             raise ImportError("carmel_amd: no ctypes prototype for %s" % s)

@@ -815,6 +815,103 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
   }
 }
 
+// Viterbi (forest.hpp:507-632): max-product inside -- an AND node is its rule's weight times its children, an OR node
+// keeps its FIRST best child (a later child must be strictly better, forest.hpp:547) -- and the best derivation walked
+// from the root, recorded in pre-order as {rule, number of children} per AND node (what write_viterbi_rec prints).  One
+// lane per forest over the same record streams as the E-step; GCOL: the column in global memory (forests beyond LDS).
+template <bool GCOL>
+__global__ __launch_bounds__(64) void forest_viterbi_kernel(ForestArgs A, uint32_t max_sample, uint32_t ins_rows,
+                                                             uint32_t stack_lds, double* best_logprob) {
+  extern __shared__ __attribute__((aligned(16))) double lds_all[];
+  double* colbase = GCOL ? A.gcol + (size_t)blockIdx.x * A.gcol_stride : lds_all;
+  double* aux = GCOL ? lds_all : lds_all + (size_t)ins_rows * 64;
+  const FGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  if ((uint32_t)lane >= g.n_lanes) return;
+  const uint32_t n = A.lane_nodes[g.lane_base + lane];
+  const uint32_t forest = A.lane_forest[g.lane_base + lane];
+  double* ins = colbase + lane;
+  const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+  {
+    uint32_t d = 0;
+    bool is_and = false, first = true;
+    double acc = 0.0, best = F_NEG_INF;
+    for (uint32_t k = 0; k < g.maxlen; ++k) {
+      const uint2 r = st[(size_t)k * 64];
+      if (!(r.x & F_VALID)) continue;
+      if (r.x & F_HEADER) {
+        is_and = (r.x & F_AND) != 0;
+        acc = is_and ? A.rule_logw[r.y] : 0.0;
+        best = F_NEG_INF;
+        first = true;
+      } else {
+        const double v = ins[(size_t)(r.x & F_IDX) * 64];
+        if (is_and)
+          acc += v;
+        else if (first || best < v)
+          best = v;
+        first = false;
+      }
+      if (r.x & F_LAST) {
+        ins[(size_t)d * 64] = is_and ? acc : best;
+        ++d;
+      }
+    }
+  }
+  best_logprob[forest] = ins[(size_t)(n - 1) * 64];
+  const uint32_t* __restrict__ hp = A.hdr_pos + g.stream_base + lane;
+  uint32_t* outr = A.sample_rules + A.sample_off[forest];
+  uint32_t* outa = A.sample_hdr + A.sample_off[forest];
+  const uint32_t cap = (uint32_t)(A.sample_off[forest + 1] - A.sample_off[forest]);
+  uint32_t* stack = outr + cap;  // deep part of the stack: stack[-1 - i]
+  uint32_t* stk_sh = (uint32_t*)aux + lane;
+#define FSTACK_PUSH(v)                                       \
+  {                                                          \
+    if (sp < stack_lds)                                      \
+      stk_sh[(size_t)sp * 64] = (v);                         \
+    else                                                     \
+      stack[-(int)(sp - stack_lds) - 1] = (v);               \
+    ++sp;                                                    \
+  }
+  uint32_t sp = 0, ns = 0;
+  FSTACK_PUSH(n - 1)
+  while (sp) {
+    --sp;
+    const uint32_t node = sp < stack_lds ? stk_sh[(size_t)sp * 64] : stack[-(int)(sp - stack_lds) - 1];
+    const uint32_t h = hp[(size_t)node * 64];
+    const uint2 hr = st[(size_t)h * 64];
+    uint32_t nch = (hr.x >> 20) & 0xffu;
+    if (nch == 255u) {
+      nch = 0;
+      for (uint32_t k = h + 1;; ++k) {
+        ++nch;
+        if (st[(size_t)k * 64].x & F_LAST) break;
+      }
+    }
+    if (hr.x & F_AND) {
+      if (ns < max_sample) {
+        outr[ns] = hr.y;
+        outa[ns] = nch;
+      }
+      ++ns;
+      for (uint32_t k = nch; k-- > 0;) FSTACK_PUSH(st[(size_t)(h + 1 + k) * 64].x & F_IDX)
+    } else {
+      uint32_t pick = 0;
+      double best = ins[(size_t)(st[(size_t)(h + 1) * 64].x & F_IDX) * 64];
+      for (uint32_t k = 1; k < nch; ++k) {
+        const double v = ins[(size_t)(st[(size_t)(h + 1 + k) * 64].x & F_IDX) * 64];
+        if (best < v) {
+          best = v;
+          pick = k;
+        }
+      }
+      FSTACK_PUSH(st[(size_t)(h + 1 + pick) * 64].x & F_IDX)
+    }
+  }
+#undef FSTACK_PUSH
+  A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+}
+
 // counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors).
 // A popular rule is used by a large share of the forests (the rule ids of real grammars, and of config 5, are Zipf
 // distributed) and adds to one address serialise (~9 ns each: 10^5 uses of one rule = 1 ms), so a workgroup first
@@ -2004,5 +2101,64 @@ int carmel_hip_forests_get_sample(carmel_hip_forests* F, uint64_t forest, uint32
   return CARMEL_HIP_OK;
 }
 uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* F) { return F ? F->max_sample : 0; }
+
+// Replaces FForest::compute_viterbi + write_viterbi's walk (forest.hpp:507-632) for every forest, with the current weights.
+int carmel_hip_forests_viterbi(carmel_hip_forests* F, double* best_logprob) {
+  if (!F || !best_logprob) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(F->device));
+  hipStream_t s = F->stream;
+  const uint64_t nf = F->n_forests;
+  if (!F->sample_len[0].n) HIPCHK(F->sample_len[0].alloc(nf));
+  if (!F->sample_rules[0].n) HIPCHK(F->sample_rules[0].alloc(F->h_sample_off.back()));
+  if (!F->sample_hdr.n) HIPCHK(F->sample_hdr.alloc(F->h_sample_off.back()));
+  DevBuf<double> best;
+  HIPCHK(best.alloc(nf));
+  ForestArgs A;
+  fill_args(F, A);
+  A.sample_len = F->sample_len[0].p;
+  A.sample_rules = F->sample_rules[0].p;
+  A.sample_hdr = F->sample_hdr.p;
+  const uint32_t stack_lds = 32u;
+  HIPCHK(fork_side(F, s));
+  for (size_t ci = 0; ci < F->classes.size(); ++ci) {
+    const auto& c = F->classes[ci];
+    A.first_group = c.first;
+    const size_t col = (size_t)c.max_nodes * 64 * sizeof(double), stk = (size_t)stack_lds * 64 * 4;
+    if (col * 2 > F_LDS_LIMIT) {  // (the class has room for two columns per group in gcol: the E-step's)
+      A.gcol = F->gcol.p + F->gcol_off[ci];
+      A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
+      hipLaunchKernelGGL(forest_viterbi_kernel<true>, dim3(c.count), dim3(64), stk, class_stream(F, s, ci), A, F->max_sample,
+                         c.max_nodes, stack_lds, best.p);
+      continue;
+    }
+    if (col + stk > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)forest_viterbi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)(col + stk));
+    hipLaunchKernelGGL(forest_viterbi_kernel<false>, dim3(c.count), dim3(64), col + stk, class_stream(F, s, ci), A,
+                       F->max_sample, c.max_nodes, stack_lds, best.p);
+  }
+  HIPCHK(join_side(F, s));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(best_logprob, best.p, nf * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_forests_get_viterbi(carmel_hip_forests* F, uint64_t forest, uint32_t* rules, uint32_t* arity, uint32_t* n) {
+  if (!F || !n || forest >= F->n_forests || !F->sample_hdr.n || !F->sample_len[0].n)
+    return fail(CARMEL_HIP_ERR_ARG, "bad argument (carmel_hip_forests_viterbi first)");
+  HIPCHK(hipSetDevice(F->device));
+  uint32_t len = 0;
+  HIPCHK(hipMemcpyAsync(&len, F->sample_len[0].p + forest, sizeof len, hipMemcpyDeviceToHost, F->stream));
+  HIPCHK(hipStreamSynchronize(F->stream));
+  if (rules && arity && len) {
+    HIPCHK(hipMemcpyAsync(rules, F->sample_rules[0].p + F->h_sample_off[forest], len * 4, hipMemcpyDeviceToHost, F->stream));
+    HIPCHK(hipMemcpyAsync(arity, F->sample_hdr.p + F->h_sample_off[forest], len * 4, hipMemcpyDeviceToHost, F->stream));
+  }
+  HIPCHK(hipStreamSynchronize(F->stream));
+  *n = len;
+  return CARMEL_HIP_OK;
+}
+
 
 }  // extern "C"

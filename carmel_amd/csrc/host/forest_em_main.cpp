@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <limits>
 #include <sstream>
@@ -31,6 +32,12 @@ struct Opts {
   double converge_delta = 1.0 / 65536;   // --deltaparam-epsilon (:198)
   double prior_counts = 0, add_k = 0;
   bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
+  bool initial_1 = false;    // -u / --initial-1-params: all parameters start at 1 (forest-em.hpp:307-308) instead of uniform per group
+  bool random_set = false;   // --random-set: a random first parameter set (forest-em.hpp:313-316)
+  // the outputs of the reference's "final iteration" (forest-em-params.cpp:125-132; forest-em.hpp:497-554)
+  std::string out_inside_file = "-0";  // -S / --out-per-forest-inside-sum
+  std::string out_pfc_file = "-0";     // -E / --out-per-forest-counts-file
+  std::string outviterbi_file = "-0";  // -v / --outviterbi-file
   long crp = 0, burnin = 0;
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
   // --prior-inference-* (gibbs_opts.hpp:82-89; forest-em reads all of them through gibbs_opts' own option table)
@@ -116,6 +123,11 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "z" || key == "zero-zerocounts") o.zero_zerocounts = true;
     else if (key == "N" || key == "normalize-initial") o.normalize_initial = true;
     else if (key == "H" || key == "human-probs") o.human_probs = true;
+    else if (key == "u" || key == "initial-1-params") o.initial_1 = true;
+    else if (key == "random-set") o.random_set = true;
+    else if (key == "S" || key == "out-per-forest-inside-sum") o.out_inside_file = value(val);
+    else if (key == "E" || key == "out-per-forest-counts-file") o.out_pfc_file = value(val);
+    else if (key == "v" || key == "outviterbi-file") o.outviterbi_file = value(val);
     else if (key == "U" || key == "use-double-precision") {}  // always double here
     else if (key == "crp") o.crp = std::atol(value(val).c_str());
     else if (key == "const-alpha") o.alpha = std::atof(value(val).c_str());
@@ -170,6 +182,8 @@ int main(int argc, char** argv) {
       ForestReader(text, fs).read_all();
     }
     if (fs.n_forests() == 0) throw std::runtime_error("no forests in " + o.forests_file);
+    if (o.normgroups_file == "-0" && (o.max_iter || o.normalize_initial))  // forest-em-params.cpp:59-60
+      throw std::runtime_error("Missing normgroups-file.\n");
     std::vector<uint64_t> group_off(1, 0);
     std::vector<uint32_t> group_rule;
     uint32_t max_rule = fs.max_rule;
@@ -180,9 +194,43 @@ int main(int argc, char** argv) {
       if (init.size() > max_rule) max_rule = (uint32_t)init.size();
     }
     const uint32_t n_rules = max_rule + 1;  // ids are 1-based; slot 0 is unused
-    std::vector<double> logw(n_rules, 0.0);  // unset parameters start at 1 (forest-em.hpp: rule_weights default)
-    for (size_t r = 0; r < init.size(); ++r) logw[r + 1] = init[r];
-    if (o.normalize_initial) normalize_weights(logw, group_off, group_rule, o.zero_zerocounts);
+    // FForests::init_rule_weights (forest-em.hpp:297-318): an initial parameter file must cover every rule of the forests
+    // and the groups; without one every norm group starts uniform (NormalizeGroups::init_uniform, normalize.hpp:212-234:
+    // each member 1, then divided by the group's sum) and a rule in no group keeps the default weight ZERO
+    // (dynamic_array::reinit_nodestroy with T(), weight.h:339) -- or, with -u, every parameter starts at 1
+    const double neg_inf = -std::numeric_limits<double>::infinity();
+    std::vector<double> logw(n_rules, 0.0);
+    if (o.initparam_file != "-0") {
+      uint32_t need = fs.max_rule;
+      for (uint32_t r : group_rule) need = std::max(need, r);
+      if (init.size() < need) throw std::runtime_error("Initial params file wasn't large enough for forests/norms.");
+      if (init.size() > need)
+        log << "Warning: more initial rule weights were provided (" << init.size() + 1
+            << ") than used in norms or forests: " << need + 1 << "\n";
+      for (size_t r = 0; r < init.size(); ++r) logw[r + 1] = init[r];
+      if (o.normalize_initial) normalize_weights(logw, group_off, group_rule, o.zero_zerocounts);
+    } else if (!o.initial_1) {
+      std::fill(logw.begin(), logw.end(), neg_inf);
+      for (size_t g = 0; g + 1 < group_off.size(); ++g)
+        for (uint64_t j = group_off[g]; j < group_off[g + 1]; ++j)
+          logw[group_rule[j]] = -std::log((double)(group_off[g + 1] - group_off[g]));
+    }
+    // FForests::randomize (forest-em.hpp:393-399) -> NormalizeGroups::init_random (normalize.hpp:235-238, visit :212-228):
+    // every rule of a norm group gets a random positive fraction, then the group is divided by its sum.  The draws come
+    // from this build's counter-based generator u(seed, restart, rule, 0) -- the reference's Boost stream is unpinned.
+    auto randomize = [&](std::vector<double>& w, uint32_t restart) {
+      for (size_t g = 0; g + 1 < group_off.size(); ++g) {
+        double sum = 0;
+        for (uint64_t j = group_off[g]; j < group_off[g + 1]; ++j) {
+          const double v = 1.0 - carmel_hip_gibbs_uniform(o.seed, restart, group_rule[j], 0);
+          w[group_rule[j]] = std::log(v);
+          sum += v;
+        }
+        if (sum > 0)
+          for (uint64_t j = group_off[g]; j < group_off[g + 1]; ++j) w[group_rule[j]] -= std::log(sum);
+      }
+    };
+    if (o.random_set && o.initparam_file == "-0") randomize(logw, 0);
     log << fs.n_forests() << " forests, " << fs.label.size() << " nodes, " << max_rule << " parameters in "
         << group_off.size() - 1 << " normalization groups.\n";
     carmel_hip_forests* F = nullptr;
@@ -298,12 +346,9 @@ int main(int argc, char** argv) {
       if (restarts_left <= 0) break;
       --restarts_left;
       log << "\nRandom restart - " << restarts_left << " remaining.\n";
-      // FForests::randomize (forest-em.hpp:393-399) -> NormalizeGroups::init_random (normalize.hpp:235-238): every rule of
-      // a norm group gets a random positive fraction (not normalised: the next M-step does that).  The draws come from
-      // this build's counter-based generator u(seed, restart, rule, 0) -- the reference's Boost stream is unpinned.
       std::vector<double> rw(n_rules);
       check(carmel_hip_forests_get_weights(F, rw.data()), "carmel_hip_forests_get_weights");
-      for (uint32_t r : group_rule) rw[r] = std::log(1.0 - carmel_hip_gibbs_uniform(o.seed, restart + 1, r, 0));
+      randomize(rw, restart + 1);
       check(carmel_hip_forests_set_weights(F, rw.data()), "carmel_hip_forests_set_weights");
       }
       check(carmel_hip_forests_set_weights(F, best_w.data()), "carmel_hip_forests_set_weights");
@@ -322,6 +367,65 @@ int main(int argc, char** argv) {
     if (o.outparam_file != "-0") {
       log << "Writing trained parameters to " << o.outparam_file << "\n";
       spit(o.outparam_file, write_params(logw.data() + 1, n_rules - 1, style));
+    }
+    // the reference's "final iteration" (forest-em-params.cpp:125-132; FForests::operator() forest-em.hpp:511-554): one more
+    // pass over the forests with the final parameters, printing per forest the Viterbi derivation (-v), the per-forest
+    // counts (-E) and the inside sum (-S)
+    if (o.outviterbi_file != "-0" || o.out_pfc_file != "-0" || o.out_inside_file != "-0") {
+      if (o.outviterbi_file != "-0") log << "Running final viterbi forests decoding.\n";
+      if (o.out_pfc_file != "-0") log << "Running final per-forest counts collection.\n";
+      if (o.out_inside_file != "-0") log << "Running final per-forest inside score printing.\n";
+      log << "Repeating final iteration ...";
+      const uint64_t nf = fs.n_forests();
+      std::vector<double> sum(nf);
+      check(carmel_hip_forests_estimate(F, o.prior_counts, nullptr, nullptr, sum.data()), "carmel_hip_forests_estimate");
+      if (o.outviterbi_file != "-0") {
+        std::vector<double> best(nf);
+        check(carmel_hip_forests_viterbi(F, best.data()), "carmel_hip_forests_viterbi");
+        const uint32_t cap = std::max<uint32_t>(1, carmel_hip_forests_max_sample(F));
+        std::vector<uint32_t> rules(cap), arity(cap);
+        std::string out;
+        for (uint64_t f = 0; f < nf; ++f) {
+          uint32_t n = 0;
+          check(carmel_hip_forests_get_viterbi(F, f, rules.data(), arity.data(), &n), "carmel_hip_forests_get_viterbi");
+          // write_viterbi (forest.hpp:581-585): best/sum=percent% then the tree (write_viterbi_rec :590-632)
+          char pct[64];
+          std::snprintf(pct, sizeof pct, "%g", 100 * std::exp(best[f] - sum[f]));
+          out += format_weight(best[f], style) + "/" + format_weight(sum[f], style) + "=" + pct + "% ";
+          uint32_t k = 0;
+          std::function<void()> tree = [&]() {
+            if (k >= n) return;
+            const uint32_t r = rules[k], a = arity[k];
+            ++k;
+            if (!a) {
+              out += std::to_string(r);
+              return;
+            }
+            out += "(" + std::to_string(r);
+            for (uint32_t c = 0; c < a; ++c) {
+              out += " ";
+              tree();
+            }
+            out += ")";
+          };
+          tree();
+          out += "\n";
+        }
+        spit(o.outviterbi_file, out);
+      }
+      if (o.out_pfc_file != "-0") {
+        // FForests::operator()(rule, inside, norm_outside) (forest-em.hpp:383-389) adds a forest's counts to the global table
+        // and leaves per_forest_counts -- its accumulate is commented out -- empty: the reference prints "()" per forest
+        std::string out;
+        for (uint64_t f = 0; f < nf; ++f) out += "()\n";
+        spit(o.out_pfc_file, out);
+      }
+      if (o.out_inside_file != "-0") {
+        std::string out;
+        for (uint64_t f = 0; f < nf; ++f) out += format_weight(sum[f], style) + "\n";
+        spit(o.out_inside_file, out);
+      }
+      log << "\n";
     }
     carmel_hip_forests_destroy(F);
     return 0;

@@ -92,6 +92,21 @@ class HipForests(object):
         """rules in the largest derivation of any forest"""
         return int(lib.carmel_hip_forests_max_sample(self.h))
 
+    def viterbi(self):
+        """forest.hpp:507-632: ln of the best derivation of every forest under the current weights; `best_derivation(f)` then
+        gives forest f's derivation in pre-order as (rule, number of children) pairs"""
+        best = np.zeros(self.n_forests, np.float64)
+        check(lib.carmel_hip_forests_viterbi(self.h, ptr(best)), "carmel_hip_forests_viterbi")
+        return best
+
+    def best_derivation(self, forest):
+        cap = max(1, lib.carmel_hip_forests_max_sample(self.h))
+        rules, arity = np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+        n = C.c_uint32(0)
+        check(lib.carmel_hip_forests_get_viterbi(self.h, forest, ptr(rules), ptr(arity), C.byref(n)),
+              "carmel_hip_forests_get_viterbi")
+        return list(zip(rules[:n.value].tolist(), arity[:n.value].tolist()))
+
     def sample(self, forest):
         buf = np.zeros(max(1, lib.carmel_hip_forests_max_sample(self.h)), np.uint32)
         n = C.c_uint32(0)

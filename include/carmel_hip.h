@@ -336,6 +336,14 @@ int carmel_hip_forests_prior_trace(carmel_hip_forests* F, double* out6, uint32_t
 int carmel_hip_forests_set_alphas(carmel_hip_forests* f, const double* alpha_per_rule, uint32_t n);
 int carmel_hip_forests_get_sample(carmel_hip_forests* f, uint64_t forest, uint32_t* rules, uint32_t* n);
 uint32_t carmel_hip_forests_max_sample(carmel_hip_forests* f);
+/* Replaces FForest::compute_viterbi + write_viterbi (forest.hpp:507-632; forest-em -v / --outviterbi-file, FForests::
+ * operator() forest-em.hpp:546-550): with the current weights, the max-product inside of every forest -- an OR node keeps
+ * its first best child, a later child must be strictly better (forest.hpp:547) -- in best_logprob[n_forests] (natural log),
+ * and the best derivation of each forest walked from its root.  carmel_hip_forests_get_viterbi then returns a forest's
+ * derivation in pre-order as {rule id, number of children} per AND node -- what write_viterbi_rec prints as
+ * "(rule child child)" / "rule" (at most carmel_hip_forests_max_sample entries). */
+int carmel_hip_forests_viterbi(carmel_hip_forests* f, double* best_logprob);
+int carmel_hip_forests_get_viterbi(carmel_hip_forests* f, uint64_t forest, uint32_t* rules, uint32_t* arity, uint32_t* n);
 
 /* ---- composition on the GPU ----
  * Replaces: the product construction of WFST::set_compose with the default 3-state epsilon filter (compose.cc:163-498):

@@ -393,6 +393,10 @@ lib.orc_forests_estimate.restype = C.c_double
 lib.orc_forests_estimate.argtypes = [vp, C.c_double, vp, vp]
 lib.orc_forests_maximize.restype = C.c_double
 lib.orc_forests_maximize.argtypes = [vp, C.c_double, C.c_int]
+lib.orc_forests_init_rule_weights.argtypes = [vp, C.c_int]
+lib.orc_forests_randomize.argtypes = [vp, vp]
+lib.orc_forests_viterbi_line.restype = C.c_int
+lib.orc_forests_viterbi_line.argtypes = [vp, C.c_uint64, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
 lib.orc_forests_gibbs.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_double, UNIFORM_FN, vp, vp, vp, vp,
                                   C.c_uint64]
 
@@ -437,6 +441,23 @@ class OracleForests(object):
 
     def maximize(self, add_k=0.0, zero_zerocounts=False):
         return lib.orc_forests_maximize(self.h, add_k, int(zero_zerocounts))
+
+    def init_rule_weights(self, ones=False):
+        """forest-em.hpp:297-318 without -I: uniform per norm group (rules of no group: weight 0), or all 1 (-u)"""
+        lib.orc_forests_init_rule_weights(self.h, int(ones))
+
+    def randomize(self, fraction):
+        """forest-em.hpp:393-399: fraction[rule] per member, each group divided by its sum"""
+        fr = np.ascontiguousarray(fraction, np.float64)
+        lib.orc_forests_randomize(self.h, _p(fr))
+
+    def viterbi_line(self, forest, mode=0):
+        """the -v / --outviterbi-file line of one forest, and ln of its best derivation"""
+        buf = C.create_string_buffer(1 << 16)
+        best = C.c_double(0)
+        n = lib.orc_forests_viterbi_line(self.h, forest, mode, buf, len(buf), C.byref(best))
+        assert n >= 0
+        return buf.value.decode(), best.value
 
     def gibbs(self, uniform, iters, burnin=0, alpha=0.1, uniform_p0=False, final_counts=False, max_samples=1 << 22,
               alphas=None, high_temp=1.0, low_temp=1.0, prior_inference=None, exclude_prior=False):

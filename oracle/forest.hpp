@@ -27,6 +27,7 @@
 #include <cctype>
 #include <functional>
 #include <stdexcept>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -168,6 +169,59 @@ struct Forest {
     return true;
   }
 
+  // forest.hpp:514-574 viterbi_rec: inside with max for OR -- the first child starts as the best, a later one replaces
+  // it only if strictly better (:547) -- and viterbi[or node] = its best child
+  void viterbi_rec(unsigned b, const std::function<LW(unsigned)>& w, std::vector<LW>& ins, std::vector<unsigned>& vit) const {
+    const FNode& n = nodes[b];
+    unsigned e = n.next;
+    if (n.ref >= 0) {
+      ins[b] = ins[n.ref];
+      return;
+    }
+    if (n.label == 0) {
+      unsigned c = b + 1;
+      unsigned nx = nodes[c].next;
+      viterbi_rec(c, w, ins, vit);
+      ins[b] = ins[c];
+      vit[b] = c;
+      for (c = nx; c < e; c = nx) {
+        nx = nodes[c].next;
+        viterbi_rec(c, w, ins, vit);
+        if (ins[b] < ins[c]) {
+          ins[b] = ins[c];
+          vit[b] = c;
+        }
+      }
+    } else {
+      ins[b] = w(n.label);
+      unsigned nx;
+      for (unsigned c = b + 1; c < e; c = nx) {
+        nx = nodes[c].next;
+        viterbi_rec(c, w, ins, vit);
+        mul_eq(ins[b], ins[c]);
+      }
+    }
+  }
+  // forest.hpp:590-632 write_viterbi_rec: a leaf rule prints as "rule", a rule with children as "(rule child child)"
+  void write_viterbi_rec(unsigned b, const std::vector<unsigned>& vit, std::string& o) const {
+    const FNode& n = nodes[b];
+    if (n.ref >= 0) {
+      write_viterbi_rec((unsigned)n.ref, vit, o);
+    } else if (n.label == 0) {
+      write_viterbi_rec(vit[b], vit, o);
+    } else if (b + 1 == n.next) {
+      o += std::to_string(n.label);
+    } else {
+      o += '(';
+      o += std::to_string(n.label);
+      for (unsigned c = b + 1; c < n.next; c = nodes[c].next) {
+        o += ' ';
+        write_viterbi_rec(c, vit, o);
+      }
+      o += ')';
+    }
+  }
+
   // forest.hpp:725-758; u() = random01(); record(rule)
   void choose_random(unsigned b, const std::vector<LW>& ins, const std::function<double()>& u,
                      const std::function<void(unsigned)>& record, double power) const {
@@ -249,6 +303,49 @@ struct ForestEm {
     if (init_ln)
       for (size_t i = 0; i < init_ln->size() && i < w.size(); ++i) w[i] = LW::from_ln((*init_ln)[i]);
     counts.assign(rulespace, LW());
+  }
+  // FForests::init_rule_weights without an initial parameter file (forest-em.hpp:297-318): every parameter 1 (-u), or every
+  // norm group uniform -- NormalizeGroups::init_uniform = init(w, set_one()) (normalize.hpp:212-234): each member set to 1
+  // and divided by the group's sum -- with the rules of no group left at the default weight, ZERO (weight.h:339)
+  void init_rule_weights(bool ones) {
+    w.assign(w.size(), ones ? LW::one() : LW());
+    if (!ones)
+      for (auto& g : groups) {
+        LW sum;
+        for (unsigned r : g) {
+          w[r] = LW::one();
+          sum += w[r];
+        }
+        if (sum > LW())
+          for (unsigned r : g) w[r] = w[r] / sum;
+      }
+  }
+  // FForests::randomize -> NormalizeGroups::init_random (forest-em.hpp:393-399, normalize.hpp:235-238): a random positive
+  // fraction per member (fraction(rule) supplied by the caller), then the group divided by its sum
+  void randomize(const std::function<double(unsigned)>& fraction) {
+    for (auto& g : groups) {
+      LW sum;
+      for (unsigned r : g) {
+        w[r] = LW::from_real(fraction(r));
+        sum += w[r];
+      }
+      if (sum > LW())
+        for (unsigned r : g) w[r] = w[r] / sum;
+    }
+  }
+  // forest-em.hpp:546-550 + forest.hpp:581-585: "best/sum=PERCENT% tree" for one forest (weights print like parameters)
+  std::string viterbi_line(const Forest& f, int mode, double* best_ln = 0) const {
+    std::vector<LW> ins(f.nodes.size());
+    f.inside_rec(0, [&](unsigned r) { return w[r]; }, ins, 0);
+    const LW sum = ins[0];
+    std::vector<unsigned> vit(f.nodes.size(), 0);
+    f.viterbi_rec(0, [&](unsigned r) { return w[r]; }, ins, vit);
+    if (best_ln) *best_ln = ins[0].w;
+    char pct[64];
+    std::snprintf(pct, sizeof pct, "%g", 100 * (ins[0] / sum).getReal());
+    std::string o = lw_str(ins[0], mode) + "/" + lw_str(sum, mode) + "=" + pct + "% ";
+    f.write_viterbi_rec(0, vit, o);
+    return o;
   }
   // normalize.hpp:123-164 (source = counts or weights, dest = weights); returns max |delta|
   LW normalize_groups(std::vector<LW>& src) {

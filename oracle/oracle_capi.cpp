@@ -1061,6 +1061,18 @@ double orc_forests_estimate(orc_forests* h, double prior_count, double* counts_l
     for (size_t i = 0; i < pf.size(); ++i) per_forest[i] = pf[i];
   return a;
 }
+void orc_forests_init_rule_weights(orc_forests* h, int ones) { h->fe.init_rule_weights(ones != 0); }
+// fraction[rule]: the random positive fraction drawn for each rule (the caller's generator)
+void orc_forests_randomize(orc_forests* h, const double* fraction) {
+  h->fe.randomize([&](unsigned r) { return fraction[r]; });
+}
+// the -v line of forest `forest` into buf (mode: LwPrintMode); returns its length, best_ln = ln of the best derivation
+int orc_forests_viterbi_line(orc_forests* h, uint64_t forest, int mode, char* buf, int cap, double* best_ln) {
+  const std::string s = h->fe.viterbi_line(h->fe.forests[forest], mode, best_ln);
+  if ((int)s.size() + 1 > cap) return -(int)s.size();
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return (int)s.size();
+}
 double orc_forests_maximize(orc_forests* h, double add_k, int zero_zero) {
   h->fe.add_k = add_k;
   h->fe.zero_zerocounts = zero_zero != 0;

@@ -27,12 +27,18 @@ def parse_vec(txt):
     return np.array(out)
 
 
-def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 / 65536, init=None, restarts=0, seed=1):
+def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 / 65536, init=None, restarts=0, seed=1,
+              ones=False, random_set=False, keep=None):
     """em.hpp:107-216 at rate 1, driven from Python over the oracle's estimate / maximize; random restarts
     (FForests::randomize -> NormalizeGroups::init_random) draw from the library's counter-based generator"""
     of = oracle.OracleForests(ftxt, ntxt)
     if init is not None:
         of.set_weights(init)
+    else:
+        of.init_rule_weights(ones=ones)  # forest-em.hpp:297-318: uniform per norm group unless -u
+    if random_set:
+        from carmel_amd._capi import lib
+        of.randomize([1.0 - lib.carmel_hip_gibbs_uniform(seed, 0, r, 0) for r in range(of.n_rules)])
     best, best_w, very_first, trace = -np.inf, of.weights(), True, []
     for restart in range(restarts + 1):
         last, first = -np.inf, True
@@ -51,10 +57,10 @@ def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 /
             last = alp
         if restart < restarts:
             from carmel_amd._capi import lib
-            w = of.weights()
-            for r in np.asarray(of.group_rule):
-                w[r] = math.log(1.0 - lib.carmel_hip_gibbs_uniform(seed, restart + 1, int(r), 0))
-            of.set_weights(w)
+            of.randomize([1.0 - lib.carmel_hip_gibbs_uniform(seed, restart + 1, r, 0) for r in range(of.n_rules)])
+    if keep is not None:
+        of.set_weights(best_w)
+        keep.append(of)
     return best, best_w, trace
 
 
@@ -100,7 +106,7 @@ def test_forest_em_cli_options(oracle, tmp_path):
     (tmp_path / "f").write_text(ftxt)
     (tmp_path / "n").write_text(ntxt)
     rng = np.random.default_rng(2)
-    init = rng.uniform(0.1, 1.0, 29)
+    init = rng.uniform(0.1, 1.0, oracle.OracleForests(ftxt, ntxt).n_rules - 1)  # (a shorter file is an error: below)
     (tmp_path / "i").write_text("(" + " ".join("%.17g" % v for v in init) + ")\n")
     rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-I", str(tmp_path / "i"), "-o",
                        str(tmp_path / "o"), "-O", str(tmp_path / "c"), "-i", "1", "-H"])
@@ -115,6 +121,53 @@ def test_forest_em_cli_options(oracle, tmp_path):
     # one iteration: the first estimate is the best one, its (initial) weights come back
     np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text())[:len(init)], init, rtol=1e-12)
     assert "e^" not in (tmp_path / "o").read_text()
+    # FForests::init_rule_weights (forest-em.hpp:299-301): an initial parameter file that does not cover every rule
+    (tmp_path / "short").write_text("(" + " ".join("%.17g" % v for v in init[:5]) + ")\n")
+    rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-I", str(tmp_path / "short"), "-i", "1"])
+    assert rc != 0 and "Initial params file wasn't large enough" in err
+    rc, so, err = run(["-f", str(tmp_path / "f"), "-i", "1"])  # forest-em-params.cpp:59-60
+    assert rc != 0 and "Missing normgroups-file" in err
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_initial_parameters_and_final_outputs(oracle, golden_dir, tmp_path):
+    """Without -I every norm group starts uniform and a rule of no group at weight 0 (forest-em.hpp:297-318), with -u every
+    parameter at 1, with --random-set at random fractions normalised per group; and the reference's final iteration
+    (forest-em-params.cpp:125-132): -v the Viterbi derivation of every forest as `best/sum=percent% tree` (forest.hpp:507-632),
+    -S the inside sums, -E the per-forest counts -- which the reference prints as `()` (forest-em.hpp:383-389)."""
+    from test_forest_gpu import synth_forests
+    cases = [(open(os.path.join(golden_dir, "fem.forests")).read(), open(os.path.join(golden_dir, "fem.norm")).read())]
+    cases += [synth_forests(40, 30, seed=s) for s in (5, 6)]
+    for ci, (ftxt, ntxt) in enumerate(cases):
+        (tmp_path / "f").write_text(ftxt)
+        (tmp_path / "n").write_text(ntxt)
+        for flags, kw in (([], {}), (["-u"], dict(ones=True)), (["--random-set", "--random-seed=9"], dict(random_set=True, seed=9))):
+            rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / "o"), "-i", "6",
+                               "-v", str(tmp_path / "v"), "-S", str(tmp_path / "s"), "-E", str(tmp_path / "e")] + flags)
+            assert rc == 0, err
+            keep = []
+            best, bw, trace = oracle_em(oracle, ftxt, ntxt, 6, keep=keep, **kw)
+            its = re.findall(r"^i=(\d+) average log-prob=(\S+)", err, re.M)
+            assert len(its) == len(trace), (ci, flags)
+            for (i, v), t in zip(its, trace):
+                assert float(v) == pytest.approx(t, rel=1e-5), (ci, flags)
+            of = keep[0]
+            vit = (tmp_path / "v").read_text().split("\n")[:-1]
+            ins = (tmp_path / "s").read_text().split("\n")[:-1]
+            assert (tmp_path / "e").read_text() == "()\n" * of.n_forests
+            assert len(vit) == len(ins) == of.n_forests
+            _, _, pf = of.estimate()
+            for f in range(of.n_forests):
+                line, best_ln = of.viterbi_line(f)
+                got_head, got_tree = vit[f].split("% ", 1)
+                ref_head, ref_tree = line.split("% ", 1)
+                assert got_tree == ref_tree, (ci, flags, f)
+                gb, rest = got_head.split("/")
+                gs, gp = rest.split("=")
+                assert parse_vec("(" + gb + ")")[0] == pytest.approx(math.exp(best_ln), rel=1e-9)
+                assert parse_vec("(" + gs + ")")[0] == pytest.approx(math.exp(pf[f]), rel=1e-9)
+                assert float(gp) == pytest.approx(100 * math.exp(best_ln - pf[f]), rel=1e-4)
+                assert parse_vec("(" + ins[f] + ")")[0] == pytest.approx(math.exp(pf[f]), rel=1e-9)
 
 
 @pytest.mark.gpu
@@ -131,6 +184,7 @@ def test_forest_em_cli_prior_inference(oracle, tmp_path):
                        "--random-seed=23", "--outsample-file=" + str(tmp_path / "samples")])
     assert rc == 0, err
     of = oracle.OracleForests(ftxt, ntxt)
+    of.init_rule_weights()
     ref = of.gibbs(lambda i, b, st: lib.carmel_hip_gibbs_uniform(23, i, b, st), 10, burnin=3, alpha=0.3,
                    prior_inference=dict(stddev=0.1, local=True))
     lines = [l for l in (so + err).split("\n") if re.match(r"i=\d+ ", l)]
