@@ -351,13 +351,19 @@ int main(int argc, char** argv) {
       randomize(rw, restart + 1);
       check(carmel_hip_forests_set_weights(F, rw.data()), "carmel_hip_forests_set_weights");
       }
-      check(carmel_hip_forests_set_weights(F, best_w.data()), "carmel_hip_forests_set_weights");
+      // FForests::save_best / restore_best act only when random restarts were asked for (save_best_enable = restarts,
+      // forest-em.hpp:363, 660-671): otherwise the parameters stay as the last M-step left them
+      if (o.restarts > 0) check(carmel_hip_forests_set_weights(F, best_w.data()), "carmel_hip_forests_set_weights");
       log << "Best average log-prob=" << best << "\n";
     }
     check(carmel_hip_forests_get_weights(F, logw.data()), "carmel_hip_forests_get_weights");
     if (o.outcounts_file != "-0") {
       std::vector<double> counts(n_rules);
-      check(carmel_hip_forests_estimate(F, o.prior_counts, nullptr, nullptr, nullptr), "carmel_hip_forests_estimate");
+      // FForests::write_counts prints the count table as the LAST estimate of the EM loop left it (forest-em-params.cpp:121-122)
+      // -- the counts under the parameters of that estimate, one M-step behind the final ones when the loop ended after a
+      // maximize; only a run without any estimate (the sampler, -i 0) collects them now
+      if (o.crp > 0 || o.max_iter <= 0)
+        check(carmel_hip_forests_estimate(F, o.prior_counts, nullptr, nullptr, nullptr), "carmel_hip_forests_estimate");
       check(carmel_hip_forests_get_counts(F, o.prior_counts, counts.data()), "carmel_hip_forests_get_counts");
       std::vector<double> lc(n_rules);
       for (uint32_t r = 0; r < n_rules; ++r) lc[r] = counts[r] > 0 ? std::log(counts[r]) : -std::numeric_limits<double>::infinity();

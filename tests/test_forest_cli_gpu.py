@@ -58,8 +58,13 @@ def oracle_em(oracle, ftxt, ntxt, max_iter, rel_eps=1.0 / 65536, delta_eps=1.0 /
         if restart < restarts:
             from carmel_amd._capi import lib
             of.randomize([1.0 - lib.carmel_hip_gibbs_uniform(seed, restart + 1, r, 0) for r in range(of.n_rules)])
-    if keep is not None:
+    # FForests::restore_best (forest-em.hpp:660-671) acts only when restarts were asked for (save_best_enable, :363):
+    # otherwise the parameters stay as the last M-step left them
+    if restarts > 0:
         of.set_weights(best_w)
+    else:
+        best_w = of.weights()
+    if keep is not None:
         keep.append(of)
     return best, best_w, trace
 
@@ -118,8 +123,9 @@ def test_forest_em_cli_options(oracle, tmp_path):
     avg, counts, _ = of.estimate()
     got_c = parse_vec((tmp_path / "c").read_text())
     np.testing.assert_allclose(got_c, np.exp(counts[1:1 + len(got_c)]), rtol=1e-9, atol=1e-300)  # the oracle hands back ln counts
-    # one iteration: the first estimate is the best one, its (initial) weights come back
-    np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text())[:len(init)], init, rtol=1e-12)
+    # one iteration = one estimate and one M-step (em.hpp:126-196; no restarts: nothing restores the first parameters)
+    of.maximize()
+    np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text())[:len(init)], np.exp(of.weights()[1:1 + len(init)]), rtol=1e-9)
     assert "e^" not in (tmp_path / "o").read_text()
     # FForests::init_rule_weights (forest-em.hpp:299-301): an initial parameter file that does not cover every rule
     (tmp_path / "short").write_text("(" + " ".join("%.17g" % v for v in init[:5]) + ")\n")
