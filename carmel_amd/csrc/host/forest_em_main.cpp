@@ -208,7 +208,8 @@ int main(int argc, char** argv) {
         log << "Warning: more initial rule weights were provided (" << init.size() + 1
             << ") than used in norms or forests: " << need + 1 << "\n";
       for (size_t r = 0; r < init.size(); ++r) logw[r + 1] = init[r];
-      if (o.normalize_initial) normalize_weights(logw, group_off, group_rule, o.zero_zerocounts);
+      // forests.normalize() (forest-em-params.cpp:96-97 -> normalize.hpp:242-245): the default UNIFORM_ZEROCOUNTS, whatever -z says
+      if (o.normalize_initial) normalize_weights(logw, group_off, group_rule, false);
     } else if (!o.initial_1) {
       std::fill(logw.begin(), logw.end(), neg_inf);
       for (size_t g = 0; g + 1 < group_off.size(); ++g)
