@@ -91,41 +91,71 @@ __device__ __forceinline__ double f_lwadd(double a, double b) {
   return a + log1p(exp(-d));
 }
 
-// inside over the lane's stream with the rule weights
+// inside over the lane's stream with the rule weights.  The records run three chunks of four ahead of the fold and an
+// AND header's weight -- a gather that depends on its record -- one chunk ahead: a wave is alone on its SIMD most of the
+// time (two columns of LDS per forest bound the occupancy), nobody else hides the two round trips.
+#define FE_CHUNK 4
 __device__ __forceinline__ void f_inside(const ForestArgs& A, const FGroup& g, int lane, double* col) {
   const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+  const double* __restrict__ lw = A.rule_logw;
+  const uint32_t last = g.maxlen - 1;
   uint32_t d = 0;
   bool is_and = false;
   double acc = 0.0, m = F_NEG_INF, sum = 0.0;
-  for (uint32_t k = 0; k < g.maxlen; ++k) {
-    const uint2 r = st[(size_t)k * 64];
-    if (!(r.x & F_VALID)) continue;
-    if (r.x & F_HEADER) {
-      is_and = (r.x & F_AND) != 0;
-      if (is_and)
-        acc = A.rule_logw[r.y];
-      else {
-        m = F_NEG_INF;
-        sum = 0.0;
+  uint2 r[FE_CHUNK], r1[FE_CHUNK], r2[FE_CHUNK];
+  double w[FE_CHUNK], w1[FE_CHUNK];
+#define FE_LOAD(R, base) \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j) R[j] = st[(size_t)min((base) + j, last) * 64];
+  // (only an AND header's second word is a rule id: every other record reads entry 0 and ignores it)
+#define FE_GATHER(W, R)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j)                                                           \
+      W[j] = lw[(R[j].x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND) ? R[j].y : 0u];
+  FE_LOAD(r, 0u)
+  FE_LOAD(r1, (uint32_t)FE_CHUNK)
+  FE_GATHER(w, r)
+  for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FE_CHUNK) {
+    if (k0) {
+#pragma unroll
+      for (int j = 0; j < FE_CHUNK; ++j) {
+        r[j] = r1[j];
+        r1[j] = r2[j];
+        w[j] = w1[j];
       }
-    } else {
-      const double v = col[(size_t)(r.x & F_IDX) * 64];
-      if (is_and)
-        acc += v;
-      else if (v != F_NEG_INF) {  // streaming logsumexp over the OR's children
-        if (v <= m)
-          sum += exp(v - m);
+    }
+    FE_LOAD(r2, k0 + 2u * FE_CHUNK)
+    FE_GATHER(w1, r1)
+#pragma unroll
+    for (int j = 0; j < FE_CHUNK; ++j) {
+      if (k0 + j > last || !(r[j].x & F_VALID)) continue;
+      if (r[j].x & F_HEADER) {
+        is_and = (r[j].x & F_AND) != 0;
+        if (is_and)
+          acc = w[j];
         else {
-          sum = (m == F_NEG_INF) ? 1.0 : sum * exp(m - v) + 1.0;
-          m = v;
+          m = F_NEG_INF;
+          sum = 0.0;
+        }
+      } else {
+        const double v = col[(size_t)(r[j].x & F_IDX) * 64];
+        if (is_and)
+          acc += v;
+        else if (v != F_NEG_INF) {  // streaming logsumexp over the OR's children
+          if (v <= m)
+            sum += exp(v - m);
+          else {
+            sum = (m == F_NEG_INF) ? 1.0 : sum * exp(m - v) + 1.0;
+            m = v;
+          }
         }
       }
-    }
-    if (r.x & F_LAST) {
-      col[(size_t)d * 64] = is_and ? acc : (sum == 1.0 ? m : (sum > 0.0 ? m + log(sum) : F_NEG_INF));
-      ++d;
+      if (r[j].x & F_LAST) {
+        col[(size_t)d * 64] = is_and ? acc : (sum == 1.0 ? m : (sum > 0.0 ? m + log(sum) : F_NEG_INF));
+        ++d;
+      }
     }
   }
+#undef FE_LOAD
+#undef FE_GATHER
 }
 
 // EM E-step: inside, normalised outside, posteriors of AND nodes.  LDS: two columns per lane (inside, outside).
@@ -153,9 +183,26 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
   double* __restrict__ post = A.post + g.stream_base + lane;
   bool is_and = false;
   double op = F_NEG_INF, ip = F_NEG_INF;
-  for (uint32_t k = 0; k < g.maxlen; ++k) {
-    const uint2 r = st[(size_t)k * 64];
-    if (!(r.x & F_VALID)) continue;
+  const uint32_t last = g.maxlen - 1;
+  uint2 rr[FE_CHUNK], rr1[FE_CHUNK], rr2[FE_CHUNK];  // three chunks of records in flight, as in the inside pass
+#define FE_LOAD(R, base) \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j) R[j] = st[(size_t)min((base) + j, last) * 64];
+  FE_LOAD(rr, 0u)
+  FE_LOAD(rr1, (uint32_t)FE_CHUNK)
+  for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FE_CHUNK) {
+    if (k0) {
+#pragma unroll
+      for (int j = 0; j < FE_CHUNK; ++j) {
+        rr[j] = rr1[j];
+        rr1[j] = rr2[j];
+      }
+    }
+    FE_LOAD(rr2, k0 + 2u * FE_CHUNK)
+#pragma unroll
+   for (int j = 0; j < FE_CHUNK; ++j) {
+    const uint32_t k = k0 + j;
+    const uint2 r = rr[j];
+    if (k > last || !(r.x & F_VALID)) continue;
     if (r.x & F_HEADER) {
       const uint32_t p = r.x & F_IDX;
       is_and = (r.x & F_AND) != 0;
@@ -171,7 +218,9 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
       }
       out[(size_t)c * 64] = f_lwadd(out[(size_t)c * 64], contrib);
     }
+   }
   }
+#undef FE_LOAD
   double s_lp = (active && lp != F_NEG_INF) ? lp : 0.0, s_n = (active && lp != F_NEG_INF) ? 1.0 : 0.0,
          s_z = (active && lp == F_NEG_INF) ? 1.0 : 0.0;
   for (int o = 32; o > 0; o >>= 1) {
