@@ -263,3 +263,82 @@ def test_forest_gibbs_prior_scale_inference(oracle, case):
     with pytest.raises(Exception):
         hf.gibbs(3, alpha=0.3, seed=1, mode=1, prior_inference=dict(stddev=0.1))
     hf.close()
+
+
+def shaped_forests(n_forests, n_rules, seed, or_max, and_max, depth, spine=0):
+    """forests with wide OR / AND nodes (more than the four children the sampler's walk takes at once) and, with `spine`,
+    a left spine of that many AND nodes whose later children wait on the walk's stack (deeper than its 32 LDS entries)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n_forests):
+        defined, nid = [], [0]
+
+        def gen(d, top=False):
+            r = rng.random()
+            if not top and defined and r < 0.1:
+                return "#%d" % rng.choice(defined)
+            if d == 0 or (not top and r < 0.25):
+                return str(rng.integers(1, n_rules))
+            if r < 0.6 or top:
+                body = "(OR %s)" % " ".join(gen(d - 1) for _ in range(rng.integers(2, or_max + 1)))
+            else:
+                body = "(%d %s)" % (rng.integers(1, n_rules), " ".join(gen(d - 1) for _ in range(rng.integers(1, and_max + 1))))
+            if not top and rng.random() < 0.2:
+                nid[0] += 1
+                defined.append(nid[0])
+                return "#%d%s" % (nid[0], body)
+            return body
+
+        t = gen(depth, top=True)
+        for _ in range(spine):
+            t = "(%d %s %d %d)" % (rng.integers(1, n_rules), t, rng.integers(1, n_rules), rng.integers(1, n_rules))
+        out.append(t)
+    rules = list(range(1, n_rules))
+    rng.shuffle(rules)
+    groups, i = [], 0
+    while i < len(rules):
+        k = int(rng.integers(2, 7))
+        groups.append(rules[i:i + k])
+        i += k
+    return "\n".join(out) + "\n", "(" + " ".join("(" + " ".join(str(r) for r in g) + ")" for g in groups) + ")"
+
+
+@pytest.mark.parametrize("shape", [dict(or_max=9, and_max=2, depth=3), dict(or_max=3, and_max=7, depth=3),
+                                   dict(or_max=6, and_max=5, depth=2, spine=24), dict(or_max=2, and_max=2, depth=4, spine=45),
+                                   dict(or_max=12, and_max=3, depth=2, temps=(2.5, 0.5)), dict(or_max=4, and_max=4, depth=3, temps=(3.0, 1.0))])
+def test_parallel_sweep_formulations_on_wide_and_deep_forests(oracle, shape):
+    """The parallel sweep's three implementations -- tables per lane (CARMEL_HIP_FOREST_SWEEP=1), streamed proposals with the
+    walk over the global stream (CARMEL_HIP_FOREST_LDSWALK=0) and the default, walk tables in LDS -- are one chain: same samples,
+    same probabilities, on OR / AND nodes wider than the walk's four-at-once, stacks deeper than its LDS part, annealed or not"""
+    from carmel_amd.forests import HipForests
+    shape = dict(shape)
+    temps = shape.pop("temps", None)
+    seed = shape.pop("seed", 17)
+    ftext, ntext = shaped_forests(300, 60, seed, **shape)
+    of = oracle.OracleForests(ftext, ntext)  # (the oracle's reader: text -> arrays)
+    lw = np.log(np.random.default_rng(3).uniform(0.05, 1.0, of.n_rules))
+    kw = dict(high_temp=temps[0], low_temp=temps[1]) if temps else {}
+
+    def run(env):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hf = HipForests(of.node_off, of.label, of.ref, of.next, of.n_rules, lw, of.group_off, of.group_rule)
+            hf.gibbs(6, burnin=2, alpha=0.2, seed=21, mode=1, **kw)
+            res = (hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(hf.n_forests)], hf.weights().copy())
+            hf.close()
+            return res
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    a = run({"CARMEL_HIP_FOREST_SWEEP": "1"})
+    for env in ({}, {"CARMEL_HIP_FOREST_LDSWALK": "0"}, {"CARMEL_HIP_FOREST_LOGDOMAIN": "1"}):
+        b = run(env)
+        assert b[1] == a[1], env
+        np.testing.assert_allclose(b[0], a[0], rtol=1e-11)
+        np.testing.assert_allclose(np.exp(b[2]), np.exp(a[2]), rtol=1e-10, atol=1e-300)
+    assert max(len(s) for s in a[1]) > (40 if shape.get("spine", 0) > 30 else 1)

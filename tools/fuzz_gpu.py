@@ -49,6 +49,9 @@ def main():
         ("windowed lane groups", lambda d, s, mp=None: P.test_windowed_lane_groups(oracle, mp, s, [8, 16, 32, 64][s % 4])),
         ("compose on the device", lambda d, s: K.test_random_transducers(oracle, d, s, ["32", "2"][s % 2])),
         ("forest em", lambda d, s: F.test_forest_em_matches_oracle(oracle, 20 + (s * 37) % 400, s)),
+        ("forest sweep formulations", lambda d, s: F.test_parallel_sweep_formulations_on_wide_and_deep_forests(
+            oracle, dict(or_max=2 + s % 11, and_max=1 + (s // 11) % 7, depth=2 + s % 3, spine=(s % 5 == 0) * (20 + s % 30), seed=s,
+                         **({"temps": (2.5, 0.5)} if s % 4 == 1 else {})))),
     ]
     only = os.environ.get("FUZZ_ONLY")
     if only:
