@@ -350,6 +350,16 @@ def main():
                 sys.stderr.write("bench.py: rank %d could not join the library communicator (%s)\n" % (rank, e))
         flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:  # every rank joined: one exchange end to end before anything is timed
+            try:
+                fb.estimate_async()
+                fb.allreduce_counts(comm)
+                fb.synchronize()
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                sys.stderr.write("bench.py: rank %d: the library's all-reduce failed (%s)\n" % (rank, e))
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
             if comm is not None:
                 comm.close()
