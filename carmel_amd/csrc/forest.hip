@@ -235,6 +235,197 @@ __global__ __launch_bounds__(64) void forest_estimate_kernel(ForestArgs A) {
   }
 }
 
+// The same E-step with inside / outside values as mantissa x 2^exponent pairs (as forest_sample_kernel<.., EXT>): a product is
+// a multiply and an integer add, the OR fold / the outside accumulation an aligned add, an AND child's share a divide --
+// where the log domain spends an exp and a log1p per child.  12 bytes per value instead of 8 (columns: inside mantissas,
+// outside mantissas, then the two exponent columns); differences to the log-domain kernel are rounding (1e-16 relative).
+struct FExt {
+  double m;  // 0 (the value zero) or in [0.5, 1)
+  int e;
+};
+__device__ __forceinline__ FExt fx_norm(double v, int e) {
+  int t;
+  FExt r;
+  r.m = frexp(v, &t);
+  r.e = v == 0.0 ? 0 : e + t;
+  return r;
+}
+__device__ __forceinline__ FExt fx_add(FExt a, FExt b) {  // a + b, either may be zero
+  if (a.m == 0.0) return b;
+  if (b.m == 0.0) return a;
+  const int dd = b.e - a.e;
+  return dd <= 0 ? fx_norm(a.m + ldexp(b.m, dd), a.e) : fx_norm(ldexp(a.m, -dd) + b.m, b.e);
+}
+// a rule's weight from its natural log without leaving the range of a double: 2^(w log2 e) = 2^k x 2^f
+__device__ __forceinline__ FExt fx_from_ln(double lnw) {
+  FExt r;
+  if (lnw == F_NEG_INF) {
+    r.m = 0.0;
+    r.e = 0;
+    return r;
+  }
+  const double l2 = lnw * 1.4426950408889634074, k = floor(l2);
+  return fx_norm(exp2(l2 - k), (int)k);
+}
+__global__ __launch_bounds__(64) void forest_estimate_ext_kernel(ForestArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const FGroup g = A.groups[A.first_group + blockIdx.x];
+  const int lane = threadIdx.x;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t n = active ? A.lane_nodes[g.lane_base + lane] : 0u;
+  const uint32_t rows = g.max_nodes;
+  double* im = lds + lane;
+  double* om = lds + (size_t)rows * 64 + lane;
+  int* ie = (int*)(lds + (size_t)2 * rows * 64) + lane;
+  int* oe = ie + (size_t)rows * 64;
+  const uint32_t last = g.maxlen - 1;
+  {  // inside (f_inside's pipeline: records three chunks ahead, AND headers' weights one chunk ahead)
+    const uint2* __restrict__ st = A.ins_stream + g.stream_base + lane;
+    const double* __restrict__ lw = A.rule_logw;
+    uint32_t d = 0;
+    bool is_and = false;
+    FExt acc = {0.0, 0}, sum = {0.0, 0};
+    uint2 r[FE_CHUNK], r1[FE_CHUNK], r2[FE_CHUNK];
+    double w[FE_CHUNK], w1[FE_CHUNK];
+#define FE_LOAD(R, base) \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j) R[j] = st[(size_t)min((base) + j, last) * 64];
+#define FE_GATHER(W, R)                                                                                          \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j)                                                           \
+      W[j] = lw[(R[j].x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND) ? R[j].y : 0u];
+    FE_LOAD(r, 0u)
+    FE_LOAD(r1, (uint32_t)FE_CHUNK)
+    FE_GATHER(w, r)
+    for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FE_CHUNK) {
+      if (k0) {
+#pragma unroll
+        for (int j = 0; j < FE_CHUNK; ++j) {
+          r[j] = r1[j];
+          r1[j] = r2[j];
+          w[j] = w1[j];
+        }
+      }
+      FE_LOAD(r2, k0 + 2u * FE_CHUNK)
+      FE_GATHER(w1, r1)
+#pragma unroll
+      for (int j = 0; j < FE_CHUNK; ++j) {
+        // without branches, as the sampler's fold: every candidate is computed, selects keep the one that applies, the
+        // node's running value is stored at every record (the last store stays)
+        const uint32_t rx = r[j].x;
+        if (k0 + j <= last && (rx & F_VALID)) {
+          const bool hdr = (rx & F_HEADER) != 0, child = !hdr;
+          const size_t c = (size_t)min(rx & F_IDX, rows - 1) * 64;  // (a header's low bits are not a row: read and ignored)
+          const double vm = im[c];
+          const int ve = ie[c];
+          const FExt h = fx_from_ln(w[j]);
+          int pe, se;
+          const double pm = frexp(acc.m * vm, &pe);
+          const int dd = ve - sum.e;
+          const bool le = dd <= 0;
+          const double lo = le ? vm : sum.m, hi = le ? sum.m : vm;
+          const double sm = frexp(hi + ldexp(lo, le ? dd : -dd), &se);
+          const bool fold_and = child && is_and, fold_or = child && !is_and && vm != 0.0, sum0 = sum.m == 0.0;
+          is_and = hdr ? (rx & F_AND) != 0 : is_and;
+          const bool take_h = hdr && is_and;
+          acc.e = take_h ? h.e : fold_and ? (acc.m * vm == 0.0 ? 0 : acc.e + ve + pe) : acc.e;
+          acc.m = take_h ? h.m : fold_and ? pm : acc.m;
+          const int nsum_e = sum0 ? ve : (le ? sum.e : ve) + se;
+          const double nsum = sum0 ? vm : sm;
+          sum.e = hdr ? 0 : fold_or ? nsum_e : sum.e;
+          sum.m = hdr ? 0.0 : fold_or ? nsum : sum.m;
+          im[(size_t)d * 64] = is_and ? acc.m : sum.m;
+          ie[(size_t)d * 64] = is_and ? acc.e : sum.e;
+          d += (rx & F_LAST) ? 1u : 0u;
+        }
+      }
+    }
+#undef FE_LOAD
+#undef FE_GATHER
+  }
+  double lp = F_NEG_INF;
+  if (active) {
+    const double rm = im[(size_t)(n - 1) * 64];
+    const int re = ie[(size_t)(n - 1) * 64];
+    if (rm != 0.0) lp = log(rm) + (double)re * 0.69314718055994530942;
+    A.forest_logprob[A.lane_forest[g.lane_base + lane]] = lp;
+    for (uint32_t q = 0; q < n; ++q) {
+      om[(size_t)q * 64] = 0.0;
+      oe[(size_t)q * 64] = 0;
+    }
+    if (rm != 0.0) {  // norm_outside[root] = 1 / inside[root]
+      const FExt o = fx_norm(1.0 / rm, -re);
+      om[(size_t)(n - 1) * 64] = o.m;
+      oe[(size_t)(n - 1) * 64] = o.e;
+    }
+  }
+  const uint2* __restrict__ st = A.out_stream + g.stream_base + lane;
+  double* __restrict__ post = A.post + g.stream_base + lane;
+  bool is_and = false;
+  FExt op = {0.0, 0}, ip = {0.0, 0};
+  uint2 rr[FE_CHUNK], rr1[FE_CHUNK], rr2[FE_CHUNK];
+#define FE_LOAD(R, base) \
+  _Pragma("unroll") for (int j = 0; j < FE_CHUNK; ++j) R[j] = st[(size_t)min((base) + j, last) * 64];
+  FE_LOAD(rr, 0u)
+  FE_LOAD(rr1, (uint32_t)FE_CHUNK)
+  for (uint32_t k0 = 0; k0 < g.maxlen; k0 += FE_CHUNK) {
+    if (k0) {
+#pragma unroll
+      for (int j = 0; j < FE_CHUNK; ++j) {
+        rr[j] = rr1[j];
+        rr1[j] = rr2[j];
+      }
+    }
+    FE_LOAD(rr2, k0 + 2u * FE_CHUNK)
+#pragma unroll
+    for (int j = 0; j < FE_CHUNK; ++j) {
+      const uint32_t k = k0 + j;
+      const uint2 r = rr[j];
+      if (k > last || !(r.x & F_VALID)) continue;
+      // one straight line for headers and children alike (the lanes of a wave are at both): the row's four values are
+      // read, a header keeps them as its node's, a child adds its share to them and stores them back
+      const bool hdr = (r.x & F_HEADER) != 0;
+      const size_t c = (size_t)min(r.x & F_IDX, rows - 1) * 64;
+      const double cm_o = om[c], cm_i = im[c];
+      const int ce_o = oe[c], ce_i = ie[c];
+      if (hdr) {
+        is_and = (r.x & F_AND) != 0;
+        op.m = cm_o;
+        op.e = ce_o;
+        ip.m = cm_i;
+        ip.e = ce_i;
+        if (is_and) post[(size_t)k * 64] = (lp != F_NEG_INF && op.m != 0.0) ? ldexp(ip.m * op.m, ip.e + op.e) : 0.0;
+      }
+      // a child's share: the parent's outside value (OR), or outside x inside of the parent / inside of the child (AND;
+      // 0/0 guard of forest.hpp:470: an AND parent of inside zero passes nothing on)
+      const bool share = !hdr && lp != F_NEG_INF && op.m != 0.0 && !(is_and && ip.m == 0.0);
+      int qe, se;
+      const double qm = frexp(is_and ? op.m * ip.m / cm_i : op.m, &qe);
+      const int q_e = (is_and ? op.e + ip.e - ce_i : op.e) + qe;
+      const int dd = q_e - ce_o;
+      const bool le = dd <= 0;
+      const double lo = le ? qm : cm_o, hi = le ? cm_o : qm;
+      const double sm = frexp(hi + ldexp(lo, le ? dd : -dd), &se);
+      const bool cur0 = cm_o == 0.0;
+      if (share) {
+        om[c] = cur0 ? qm : sm;
+        oe[c] = cur0 ? q_e : (le ? ce_o : q_e) + se;
+      }
+    }
+  }
+#undef FE_LOAD
+  double s_lp = (active && lp != F_NEG_INF) ? lp : 0.0, s_n = (active && lp != F_NEG_INF) ? 1.0 : 0.0,
+         s_z = (active && lp == F_NEG_INF) ? 1.0 : 0.0;
+  for (int o = 32; o > 0; o >>= 1) {
+    s_lp += __shfl_down(s_lp, o, 64);
+    s_n += __shfl_down(s_n, o, 64);
+    s_z += __shfl_down(s_z, o, 64);
+  }
+  if (lane == 0) {
+    unsafeAtomicAdd(A.scalars + 0, s_lp);
+    unsafeAtomicAdd(A.scalars + 1, s_n);
+    unsafeAtomicAdd(A.scalars + 2, s_z);
+  }
+}
+
 // Gibbs: resample every forest of the group (or, exact mode, the single forest A.serial_forest) against snap_x /
 // snap_norm.  LDS per lane: the inside column.
 template <bool GCOL>
@@ -1534,6 +1725,8 @@ int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, doubl
   fill_args(F, A);
   HIPCHK(hipMemsetAsync(F->scalars.p, 0, 4 * sizeof(double), s));
   HIPCHK(fork_side(F, s));
+  // mantissa / exponent arithmetic where the columns fit LDS at 12 bytes per value (CARMEL_HIP_FOREST_EM_EXT=0: the log domain)
+  static const bool em_ext = !(getenv("CARMEL_HIP_FOREST_EM_EXT") && atoi(getenv("CARMEL_HIP_FOREST_EM_EXT")) == 0);
   for (size_t ci = 0; ci < F->classes.size(); ++ci) {
     const auto& c = F->classes[ci];
     A.first_group = c.first;
@@ -1542,6 +1735,13 @@ int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, doubl
       A.gcol = F->gcol.p + F->gcol_off[ci];
       A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
       hipLaunchKernelGGL(forest_estimate_kernel<true>, dim3(c.count), dim3(64), 0, class_stream(F, s, ci), A);
+      continue;
+    }
+    const size_t lds_ext = (size_t)c.max_nodes * 64 * 24;
+    if (em_ext && lds_ext <= F_LDS_LIMIT) {
+      if (lds_ext > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)forest_estimate_ext_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ext);
+      hipLaunchKernelGGL(forest_estimate_ext_kernel, dim3(c.count), dim3(64), lds_ext, class_stream(F, s, ci), A);
       continue;
     }
     if (lds > 64 * 1024)
