@@ -905,14 +905,16 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
           double t4[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) ci4[q] = ct[(size_t)min(first + q, kid_rows - 1) * 64] & 0x7fffu;
-          const double inv = 1.0 / ins[(size_t)me * 64];
+          // (the shares are taken against u x the node's own value instead of dividing each by it: choice, children and
+          // the node's value all in units of 2^ne -- the reference's comparison times a positive constant)
+          const double zm = ins[(size_t)me * 64];
           const int ne = ine[(size_t)me * 64];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const uint32_t row = min(ci4[q], ins_rows - 1);
-            t4[q] = ldexp(ins[(size_t)row * 64] * inv, ine[(size_t)row * 64] - ne);
+            t4[q] = ldexp(ins[(size_t)row * 64], ine[(size_t)row * 64] - ne);
           }
-          double choice = gibbs_uniform(A.seed, A.iter, forest, step++);
+          double choice = gibbs_uniform(A.seed, A.iter, forest, step++) * zm;
           const double c0 = choice - t4[0], c1 = c0 - t4[1], c2 = c1 - t4[2], c3 = c2 - t4[3];
           const bool s0 = c0 < 0 || nch == 1, s1 = c1 < 0 || nch == 2, s2 = c2 < 0 || nch == 3, s3 = c3 < 0 || nch == 4;
           pick = s0 ? 0u : s1 ? 1u : s2 ? 2u : 3u;
@@ -921,7 +923,7 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
             for (uint32_t k = 4;; ++k) {
               pick = k;
               const uint32_t ci = ct[(size_t)(first + k) * 64] & 0x7fffu;
-              choice -= ldexp(ins[(size_t)ci * 64] * inv, ine[(size_t)ci * 64] - ne);
+              choice -= ldexp(ins[(size_t)ci * 64], ine[(size_t)ci * 64] - ne);
               if (choice < 0 || k + 1 == nch) break;
             }
           }
