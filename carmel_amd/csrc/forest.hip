@@ -39,7 +39,18 @@ struct FGroup {  // 32 bytes, one wavefront of forests
   uint64_t node_base;  // of the group's rows in node-indexed arrays: 64 * (sum of max_nodes over the groups before it)
 };
 
+struct FAnd {  // one per AND header record of the inside streams, in stream order (forest_proposal_kernel)
+  uint64_t pos;    // position in the stream arrays
+  uint32_t group;  // lane group
+  uint32_t cls;    // rec_cls of the record
+  uint32_t rule;
+  uint32_t pad;
+};
+
 struct ForestArgs {
+  const FAnd* and_list;          // the AND header records (n_and of them)
+  uint64_t n_and;
+  int p_only;                    // this sweep needs the proposal probabilities only, not their logarithms (temperature 1)
   const FGroup* groups;
   const uint2* ins_stream;
   const uint2* out_stream;
@@ -673,25 +684,26 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
 //   forest_recount_kernel   one thread per sample entry: counts, class counts of the new sample, proposal probability
 //                           of the sample.
 __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
-  const FGroup g = A.groups[blockIdx.y];
-  const uint32_t k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
-  if (k >= g.maxlen || lane >= g.n_lanes) return;
-  const size_t pos = g.stream_base + (size_t)k * 64 + lane;
-  const uint2 r = A.ins_stream[pos];
-  if ((r.x & (F_VALID | F_HEADER | F_AND)) != (F_VALID | F_HEADER | F_AND)) return;
-  const uint32_t rule = r.y, nn = A.p_norm[rule];
+  // one thread per AND header, from the static list of them ({position, group, classes, rule}: the records themselves are
+  // not read, and the 55 % of the stream that is not an AND header is not visited)
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.n_and) return;
+  const FAnd e = A.and_list[i];
+  const FGroup g = A.groups[e.group];
+  const uint32_t lane = (uint32_t)(e.pos - g.stream_base) & 63u;
+  const uint32_t rule = e.rule, nn = A.p_norm[rule];
   double pr;
   if (nn == F_NONORM)
     pr = A.p_prior[rule];
   else {
-    const uint32_t c = A.rec_cls[pos];
+    const uint32_t c = e.cls;
     const uint32_t* cnt = A.cnt_old + 2 * g.node_base + lane;
     const double x = A.snap_x[rule] - (double)cnt[(size_t)(c & 0xffffu) * 64];
     const double ns = A.snap_norm[nn] - (double)cnt[(size_t)(g.max_nodes + (c >> 16)) * 64];
     pr = x / ns;
   }
-  A.rec_logp[pos] = log(pr);
-  A.rec_p[pos] = pr;
+  A.rec_p[e.pos] = pr;
+  if (!A.p_only) A.rec_logp[e.pos] = log(pr);
 }
 
 #define FS_CHUNK 4
@@ -1241,7 +1253,7 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           rule[q] = A.ins_stream[pos[q]].y;
-          lpv[q] = A.rec_logp[pos[q]];
+          lpv[q] = A.p_only ? A.rec_p[pos[q]] : A.rec_logp[pos[q]];
           c[q] = A.rec_cls[pos[q]];
         }
 #pragma unroll
@@ -1250,7 +1262,7 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
         for (int q = 0; q < 4; ++q) {
           if (!ok[q]) continue;
           rules[so[q]] = rule[q];
-          cheap += lpv[q];
+          cheap += A.p_only ? log(lpv[q]) : lpv[q];
           if (nn[q] == F_NONORM) continue;
           add(0, rule[q], x);
           add(1, nn[q], normsum);
@@ -1375,6 +1387,8 @@ struct carmel_hip_forests {
   DevBuf<uint2_t> ins_stream, out_stream;
   DevBuf<uint32_t> lane_forest, lane_nodes, hdr_pos, group_rule, p_norm, sample_len[2], sample_rules[2];
   DevBuf<uint32_t> rec_cls, own_cnt[2], sample_hdr, lane_of_forest_d;
+  DevBuf<FAnd> and_list;
+  uint64_t n_and = 0;
   DevBuf<double> gcol;               // columns of the launch classes whose forests do not fit LDS
   std::vector<uint64_t> gcol_off;    // per class: offset into gcol (doubles), room for two columns per group
   DevBuf<double> rec_logp, rec_p;
@@ -1612,7 +1626,20 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         }
       }
     }
-    if (F->sweep2_ok) HIPCHK(F->rec_cls.upload(rc, s));
+    if (F->sweep2_ok) {
+      HIPCHK(F->rec_cls.upload(rc, s));
+      std::vector<FAnd> al;
+      for (size_t gidx = 0; gidx < ng; ++gidx) {
+        const FGroup& G = F->h_groups[gidx];
+        for (uint64_t q = 0; q < (uint64_t)G.maxlen * 64; ++q) {
+          const uint2_t r = si[G.stream_base + q];
+          if ((r.x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND))
+            al.push_back(FAnd{G.stream_base + q, (uint32_t)gidx, rc[G.stream_base + q], r.y, 0u});
+        }
+      }
+      F->n_and = al.size();
+      HIPCHK(F->and_list.upload(al, s));
+    }
     HIPCHK(F->lane_of_forest_d.upload(F->lane_of_forest, s));
   }
   // samples: capacity = size of the largest derivation of the forest
@@ -2025,9 +2052,10 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         A.cnt_new = F->own_cnt[cur ^ 1].p;
         // (the class counts of this sweep's samples go to own_cnt[cur ^ 1]: cleared at allocation and, from then on,
         // during the previous sweep -- below, behind the proposal kernel that was its last reader)
-        uint32_t maxlen = 0;
-        for (auto& G : F->h_groups) maxlen = std::max(maxlen, G.maxlen);
-        hipLaunchKernelGGL(forest_proposal_kernel, dim3((maxlen + 3) / 4, (unsigned)F->h_groups.size()), dim3(256), 0, s, A);
+        A.and_list = F->and_list.p;
+        A.n_and = F->n_and;
+        A.p_only = (A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN")) ? 1 : 0;
+        if (F->n_and) hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
         if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
                                            // sweep reads the current one).  Later sweeps: prepared at the end of the previous one
           HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
