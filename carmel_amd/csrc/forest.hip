@@ -1173,25 +1173,35 @@ __global__ __launch_bounds__(64) void forest_viterbi_kernel(ForestArgs A, uint32
 // slot taken by another goes straight to global memory) and adds each claimed slot to global memory once.
 // 16 lanes per forest; a workgroup covers 64 forests.  With A (second formulation of the parallel sweep) it also
 // adds up the sample's ln proposal probability and counts the uses per class for the next sweep.
-#define FRC_SLOTS 2048u
 #define FRC_FORESTS 256u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
                                                               uint32_t* rules, const uint32_t* p_norm, double* x,
                                                               double* normsum, uint32_t n_forests, ForestArgs A, int sweep2,
-                                                              const uint32_t* slot_forest, uint32_t slot0, uint32_t slot1) {
-  __shared__ uint32_t key[2][FRC_SLOTS];
-  __shared__ uint32_t cnt[2][FRC_SLOTS];
+                                                              const uint32_t* slot_forest, uint32_t slot0, uint32_t slot1,
+                                                              uint32_t n_slots0, uint32_t n_slots1) {
+  // the two tables in dynamic LDS: n_slots0 {key, count} pairs for rules, n_slots1 for norm groups (powers of two)
+  extern __shared__ uint32_t frc_lds[];
+  uint32_t* const key0 = frc_lds;
+  uint32_t* const cnt0 = key0 + n_slots0;
+  uint32_t* const key1 = cnt0 + n_slots0;
+  uint32_t* const cnt1 = key1 + n_slots1;
   __shared__ double cheap_sh[16];
-  for (uint32_t i = threadIdx.x; i < 2 * FRC_SLOTS; i += 1024) {
-    (&key[0][0])[i] = 0xffffffffu;
-    (&cnt[0][0])[i] = 0u;
+  for (uint32_t i = threadIdx.x; i < n_slots0; i += 1024) {
+    key0[i] = 0xffffffffu;
+    cnt0[i] = 0u;
+  }
+  for (uint32_t i = threadIdx.x; i < n_slots1; i += 1024) {
+    key1[i] = 0xffffffffu;
+    cnt1[i] = 0u;
   }
   __syncthreads();
   auto add = [&](int t, uint32_t id, double* g) {
-    const uint32_t slot = (id * 2654435761u >> 9) & (FRC_SLOTS - 1);
-    const uint32_t old = atomicCAS(&key[t][slot], 0xffffffffu, id);
+    uint32_t* const key = t ? key1 : key0;
+    uint32_t* const cnt = t ? cnt1 : cnt0;
+    const uint32_t slot = (id * 2654435761u >> 9) & ((t ? n_slots1 : n_slots0) - 1);
+    const uint32_t old = atomicCAS(&key[slot], 0xffffffffu, id);
     if (old == 0xffffffffu || old == id)
-      atomicAdd(&cnt[t][slot], 1u);
+      atomicAdd(&cnt[slot], 1u);
     else
       unsafeAtomicAdd(g + id, 1.0);
   };
@@ -1293,10 +1303,10 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     if ((threadIdx.x & 63) == 0) cheap_sh[threadIdx.x >> 6] = cheap;
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < FRC_SLOTS; i += 1024) {
-    if (cnt[0][i]) unsafeAtomicAdd(x + key[0][i], (double)cnt[0][i]);
-    if (cnt[1][i]) unsafeAtomicAdd(normsum + key[1][i], (double)cnt[1][i]);
-  }
+  for (uint32_t i = threadIdx.x; i < n_slots0; i += 1024)
+    if (cnt0[i]) unsafeAtomicAdd(x + key0[i], (double)cnt0[i]);
+  for (uint32_t i = threadIdx.x; i < n_slots1; i += 1024)
+    if (cnt1[i]) unsafeAtomicAdd(normsum + key1[i], (double)cnt1[i]);
   if (sweep2 && threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < 16; ++i) t += cheap_sh[i];
@@ -1996,6 +2006,15 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   // groups per workgroup of a class's recount (fewer groups per workgroup = more workgroups, each adding its share of
   // the popular rules to the same addresses: 1 and 2 measured slower than 4, 122 and 84 against 77 us for the last class)
   const uint32_t recount_div = getenv("CARMEL_HIP_FOREST_RECOUNT_DIV") ? std::max(1, atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_DIV"))) : 4;
+  // the recount's LDS tables: rules / norm groups (CARMEL_HIP_FOREST_RECOUNT_SLOTS="s0,s1", powers of two)
+  uint32_t frc_slots0 = 8192, frc_slots1 = 4096;
+  if (const char* e = getenv("CARMEL_HIP_FOREST_RECOUNT_SLOTS")) {
+    unsigned a = 0, b = 0;
+    if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 64 && b >= 64 && !(a & (a - 1)) && !(b & (b - 1)) && (size_t)(a + b) * 8 <= 150 * 1024)
+      frc_slots0 = a, frc_slots1 = b;
+  }
+  const size_t frc_bytes = (size_t)(frc_slots0 + frc_slots1) * 8;
+  (void)hipFuncSetAttribute((const void*)forest_recount_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)frc_bytes);
   const bool lds_walk = !(getenv("CARMEL_HIP_FOREST_LDSWALK") && atoi(getenv("CARMEL_HIP_FOREST_LDSWALK")) == 0);
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
   if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
@@ -2097,10 +2116,10 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           else
             launch(forest_sample_kernel<false, false, false>, lds);
           if (split_recount)  // this class's new samples into the counts, on its own stream, while the other classes still sample
-            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), 0,
+            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), frc_bytes,
                                class_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
-                               (c.first + c.count) * 64u);
+                               (c.first + c.count) * 64u, frc_slots0, frc_slots1);
         }
         // the buffer the proposal kernel has just read is the next sweep's cnt_new: cleared here, on the main stream behind
         // its class, while the longer classes still sample
@@ -2137,9 +2156,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       else {
       HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), 0, s,
+      hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), frc_bytes, s,
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
-                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u);
+                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u, frc_slots0, frc_slots1);
       }
       {  // (split recount: the next sweep's count buffers start from the priors, reset by the commit itself)
         const bool reset = split_recount && iter < Ni;
