@@ -44,7 +44,7 @@ struct FAnd {  // one per AND header record of the inside streams, in stream ord
   uint32_t group;  // lane group
   uint32_t cls;    // rec_cls of the record
   uint32_t rule;
-  uint32_t pad;
+  uint32_t forest;
 };
 
 struct ForestArgs {
@@ -77,7 +77,9 @@ struct ForestArgs {
                                  // both dense within the forest
   double* rec_logp;              // per inside-stream record (AND headers): ln proposal probability of the rule
   double* rec_p;                 //                                          the probability itself
-  const uint32_t* cnt_old;       // per (group, class row, lane): uses of the class in the forest's previous sample; rows
+  uint32_t* sample_cls;          // per sample entry: the rec_cls word of its record (0xffffffff: a rule outside every norm
+                                 // group), written by the recount, scanned by the next sweep's proposal kernel
+  const uint32_t* cnt_old;       // (unused since the class scan) per (group, class row, lane): uses of the class in the forest's previous sample; rows
                                  // [0, max_nodes) = rule classes, [max_nodes, 2 max_nodes) = norm-group classes
   uint32_t* cnt_new;
   uint32_t* sample_hdr;          // per sample entry: stream position of the AND header it came from
@@ -689,17 +691,29 @@ __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= A.n_and) return;
   const FAnd e = A.and_list[i];
-  const FGroup g = A.groups[e.group];
-  const uint32_t lane = (uint32_t)(e.pos - g.stream_base) & 63u;
   const uint32_t rule = e.rule, nn = A.p_norm[rule];
   double pr;
   if (nn == F_NONORM)
     pr = A.p_prior[rule];
   else {
-    const uint32_t c = e.cls;
-    const uint32_t* cnt = A.cnt_old + 2 * g.node_base + lane;
-    const double x = A.snap_x[rule] - (double)cnt[(size_t)(c & 0xffffu) * 64];
-    const double ns = A.snap_norm[nn] - (double)cnt[(size_t)(g.max_nodes + (c >> 16)) * 64];
+    // how often the forest's previous sample uses this rule / this norm group: a scan of the sample's class words.  The
+    // list is ordered by forest, so the threads of a wave scan the same few samples together (the reads are broadcasts)
+    const uint32_t c = e.cls, cr = c & 0xffffu, cn = c >> 16;
+    const uint32_t* __restrict__ sc = A.sample_cls + A.sample_off[e.forest];
+    const uint32_t len = A.old_len[e.forest];
+    uint32_t own_r = 0, own_n = 0, j = 0;
+    for (; j + 4 <= len; j += 4) {  // four words in flight
+      const uint32_t w0 = sc[j], w1 = sc[j + 1], w2 = sc[j + 2], w3 = sc[j + 3];
+      own_r += ((w0 & 0xffffu) == cr) + ((w1 & 0xffffu) == cr) + ((w2 & 0xffffu) == cr) + ((w3 & 0xffffu) == cr);
+      own_n += ((w0 >> 16) == cn) + ((w1 >> 16) == cn) + ((w2 >> 16) == cn) + ((w3 >> 16) == cn);
+    }
+    for (; j < len; ++j) {
+      const uint32_t w = sc[j];
+      own_r += (w & 0xffffu) == cr ? 1u : 0u;
+      own_n += (w >> 16) == cn ? 1u : 0u;
+    }
+    const double x = A.snap_x[rule] - (double)own_r;
+    const double ns = A.snap_norm[nn] - (double)own_n;
     pr = x / ns;
   }
   A.rec_p[e.pos] = pr;
@@ -1234,8 +1248,8 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
       }
       const uint32_t total = pre[FRC_FORESTS];
       for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 1024) {  // four entries per thread in flight
-        size_t pos[4], so[4], nb[4];
-        uint32_t rule[4], nn[4], c[4], mxn[4];
+        size_t pos[4], so[4];
+        uint32_t rule[4], nn[4], c[4];
         double lpv[4];
         bool ok[4];
 #pragma unroll
@@ -1254,8 +1268,6 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
           const uint32_t slot = ok[q] ? (slot_forest ? f0 + lo : A.lane_of_forest[f]) : 0u;
           const FGroup g = A.groups[slot >> 6];
           so[q] = sample_off[f] + (ok[q] ? e - pre[lo] : 0u);
-          mxn[q] = g.max_nodes;
-          nb[q] = 2 * g.node_base + (slot & 63u);
           pos[q] = g.stream_base + (slot & 63u);
         }
 #pragma unroll
@@ -1272,13 +1284,11 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
         for (int q = 0; q < 4; ++q) {
           if (!ok[q]) continue;
           rules[so[q]] = rule[q];
+          A.sample_cls[so[q]] = nn[q] == F_NONORM ? 0xffffffffu : c[q];
           cheap += A.p_only ? log(lpv[q]) : lpv[q];
           if (nn[q] == F_NONORM) continue;
           add(0, rule[q], x);
           add(1, nn[q], normsum);
-          uint32_t* cn = A.cnt_new + nb[q];
-          atomicAdd(cn + (size_t)(c[q] & 0xffffu) * 64, 1u);
-          atomicAdd(cn + (size_t)(mxn[q] + (c[q] >> 16)) * 64, 1u);
         }
       }
     }
@@ -1396,7 +1406,7 @@ struct carmel_hip_forests {
   DevBuf<FGroup> groups;
   DevBuf<uint2_t> ins_stream, out_stream;
   DevBuf<uint32_t> lane_forest, lane_nodes, hdr_pos, group_rule, p_norm, sample_len[2], sample_rules[2];
-  DevBuf<uint32_t> rec_cls, own_cnt[2], sample_hdr, lane_of_forest_d;
+  DevBuf<uint32_t> rec_cls, sample_cls, sample_hdr, lane_of_forest_d;
   DevBuf<FAnd> and_list;
   uint64_t n_and = 0;
   DevBuf<double> gcol;               // columns of the launch classes whose forests do not fit LDS
@@ -1638,14 +1648,16 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     }
     if (F->sweep2_ok) {
       HIPCHK(F->rec_cls.upload(rc, s));
-      std::vector<FAnd> al;
+      std::vector<FAnd> al;  // forest after forest: the threads of a wave scan the same forest's previous sample
       for (size_t gidx = 0; gidx < ng; ++gidx) {
         const FGroup& G = F->h_groups[gidx];
-        for (uint64_t q = 0; q < (uint64_t)G.maxlen * 64; ++q) {
-          const uint2_t r = si[G.stream_base + q];
-          if ((r.x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND))
-            al.push_back(FAnd{G.stream_base + q, (uint32_t)gidx, rc[G.stream_base + q], r.y, 0u});
-        }
+        for (uint32_t l = 0; l < G.n_lanes; ++l)
+          for (uint32_t k = 0; k < G.maxlen; ++k) {
+            const uint64_t q = G.stream_base + (uint64_t)k * 64 + l;
+            const uint2_t r = si[q];
+            if ((r.x & (F_VALID | F_HEADER | F_AND)) == (F_VALID | F_HEADER | F_AND))
+              al.push_back(FAnd{q, (uint32_t)gidx, rc[q], r.y, lane_forest[G.lane_base + l]});
+          }
       }
       F->n_and = al.size();
       HIPCHK(F->and_list.upload(al, s));
@@ -1984,10 +1996,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     // the classes' recounts beside the classes still sampling (CARMEL_HIP_FOREST_RECOUNT_SPLIT=0: one recount after all)
     split_recount = !(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT") && atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT")) == 0);
     if (split_recount) HIPCHK(F->normsum2.alloc(ng));
-    for (int k = 0; k < 2; ++k) {
-      HIPCHK(F->own_cnt[k].alloc(2 * F->node_total));
-      HIPCHK(hipMemsetAsync(F->own_cnt[k].p, 0, F->own_cnt[k].bytes(), s));
-    }
+    HIPCHK(F->sample_cls.alloc(F->h_sample_off.back()));
     HIPCHK(F->rec_logp.alloc(F->stream_total));
     HIPCHK(F->rec_p.alloc(F->stream_total));
     HIPCHK(hipMemsetAsync(F->rec_p.p, 0, F->rec_p.bytes(), s));  // the sample kernel reads every slot of its chunks
@@ -2067,10 +2076,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       A.sample_len = F->sample_len[cur ^ 1].p;
       A.sample_rules = F->sample_rules[cur ^ 1].p;
       if (sweep2) {
-        A.cnt_old = F->own_cnt[cur].p;
-        A.cnt_new = F->own_cnt[cur ^ 1].p;
-        // (the class counts of this sweep's samples go to own_cnt[cur ^ 1]: cleared at allocation and, from then on,
-        // during the previous sweep -- below, behind the proposal kernel that was its last reader)
+        A.sample_cls = F->sample_cls.p;
+        // (the previous sample's class words, written by its recount: what the proposal kernel scans for the forest's own uses)
         A.and_list = F->and_list.p;
         A.n_and = F->n_and;
         A.p_only = (A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN")) ? 1 : 0;
@@ -2121,9 +2128,6 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
                                (c.first + c.count) * 64u, frc_slots0, frc_slots1);
         }
-        // the buffer the proposal kernel has just read is the next sweep's cnt_new: cleared here, on the main stream behind
-        // its class, while the longer classes still sample
-        if (iter < Ni) HIPCHK(hipMemsetAsync(F->own_cnt[cur].p, 0, F->own_cnt[cur].bytes(), s));
         HIPCHK(join_side(F, s));
       } else
       for (auto& c : F->classes) {
