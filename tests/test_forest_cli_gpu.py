@@ -221,3 +221,32 @@ def test_forest_text_cpu(golden_dir):
     assert "ERROR: carmel_hip_forests_create" in err
     bad = run(["-f", os.path.join(golden_dir, "fem.norm")])
     assert bad[0] != 0 and "forest 1, character" in bad[2]
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_parallel_sampler(oracle, tmp_path):
+    """forest-em --crp=N --crp-parallel: the throughput mode through the front end -- valid derivations for every forest
+    (--outsample-file), a reproducible run, normalised parameters, and the sample's probability in the region the exact
+    chain reaches on the same files"""
+    from test_forest_gpu import synth_forests
+    ftxt, ntxt = synth_forests(300, 40, seed=8)
+    (tmp_path / "f").write_text(ftxt)
+    (tmp_path / "n").write_text(ntxt)
+    of = oracle.OracleForests(ftxt, ntxt)
+    outs = {}
+    for tag, flags in (("par", ["--crp-parallel"]), ("par2", ["--crp-parallel"]), ("exact", [])):
+        rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / ("o" + tag)), "--crp=40",
+                           "--burnin=10", "--const-alpha=0.3", "--random-seed=5", "--outsample-file=" + str(tmp_path / ("s" + tag))] + flags)
+        assert rc == 0, err
+        lp = [float(x) for x in re.findall(r"sample log-prob=(\S+)", so + err)]
+        assert len(lp) == 41
+        outs[tag] = (parse_vec((tmp_path / ("o" + tag)).read_text()), (tmp_path / ("s" + tag)).read_text(), lp)
+    assert outs["par"][1] == outs["par2"][1] and outs["par"][2] == outs["par2"][2]
+    samples = [[int(x) for x in l.split()] for l in outs["par"][1].split("\n")[:-1]]
+    assert len(samples) == of.n_forests and all(len(s) > 0 for s in samples)
+    w = outs["par"][0]
+    for g in range(of.n_groups):
+        mem = np.asarray(of.group_rule[int(of.group_off[g]):int(of.group_off[g + 1])])
+        assert w[mem - 1].sum() == pytest.approx(1.0, abs=1e-9)
+    a, b = np.mean(outs["par"][2][-10:]), np.mean(outs["exact"][2][-10:])
+    assert abs(a - b) < 0.05 * abs(b)
