@@ -79,9 +79,6 @@ struct ForestArgs {
   double* rec_p;                 //                                          the probability itself
   uint32_t* sample_cls;          // per sample entry: the rec_cls word of its record (0xffffffff: a rule outside every norm
                                  // group), written by the recount, scanned by the next sweep's proposal kernel
-  const uint32_t* cnt_old;       // (unused since the class scan) per (group, class row, lane): uses of the class in the forest's previous sample; rows
-                                 // [0, max_nodes) = rule classes, [max_nodes, 2 max_nodes) = norm-group classes
-  uint32_t* cnt_new;
   uint32_t* sample_hdr;          // per sample entry: stream position of the AND header it came from
   const uint32_t* lane_of_forest;
   double* gcol;                  // forests too large for LDS: the inside (/ outside) columns of a group in global memory,
@@ -676,15 +673,16 @@ __global__ __launch_bounds__(64) void forest_gibbs_kernel(ForestArgs A, uint32_t
 // The sweep above spends its time in chains of dependent gathers made by one lane per forest (count tables, rule ->
 // group -> counts per AND node, one node per round trip in the walk): at 1563 waves of 64 forests the chip idles.
 // Here everything that does not depend on the recursion runs with one thread per record or per sample entry:
-//   forest_proposal_kernel  one thread per inside-stream record: ln proposal probability of every AND header
-//                           ((count - own uses) / (group sum - own uses), gibbs.hpp:589-592 with the block's own
-//                           sample taken out).  "Own uses" are kept per CLASS of equal rules / equal norm groups within
-//                           the forest (rec_cls, static), so the lookup is an index, not a search.
-//   forest_sample_kernel    one lane per forest: inside pass as a pure stream (record + its ln p, prefetched in
-//                           chunks), top-down walk with one round trip per visited node (a child record carries the
-//                           position of the child's header; header and first children are fetched together).
-//   forest_recount_kernel   one thread per sample entry: counts, class counts of the new sample, proposal probability
-//                           of the sample.
+//   forest_proposal_kernel  one thread per AND header (a static list of them, forest after forest): proposal probability
+//                           of its rule ((count - own uses) / (group sum - own uses), gibbs.hpp:589-592 with the block's
+//                           own sample taken out).  Equal rules / equal norm groups within a forest form CLASSES
+//                           (rec_cls, static); "own uses" = how many class words of the forest's previous sample
+//                           (sample_cls, left by the recount) match -- a short scan, shared by the threads of a wave.
+//   forest_sample_kernel    one lane per forest: inside pass as a pure stream (record + its p, three chunks in flight),
+//                           top-down walk over 16-bit tables the inside pass leaves in LDS (LW; otherwise over the
+//                           global stream, one round trip per visited node).
+//   forest_recount_kernel   one thread per sample entry: rule ids and class words of the new sample, counts, proposal
+//                           probability of the sample.
 __global__ __launch_bounds__(256) void forest_proposal_kernel(ForestArgs A) {
   // one thread per AND header, from the static list of them ({position, group, classes, rule}: the records themselves are
   // not read, and the 55 % of the stream that is not an AND header is not visited)
@@ -1183,10 +1181,11 @@ __global__ __launch_bounds__(64) void forest_viterbi_kernel(ForestArgs A, uint32
 // counts of a sweep's samples: x[rule] += 1, normsum[group] += 1 per use (the caller starts from the priors).
 // A popular rule is used by a large share of the forests (the rule ids of real grammars, and of config 5, are Zipf
 // distributed) and adds to one address serialise (~9 ns each: 10^5 uses of one rule = 1 ms), so a workgroup first
-// counts in two small LDS tables (slot = id mod size, claimed by the first id that arrives; an id that finds its
+// counts in two LDS tables (slot = hash of the id, claimed by the first id that arrives; an id that finds its
 // slot taken by another goes straight to global memory) and adds each claimed slot to global memory once.
-// 16 lanes per forest; a workgroup covers 64 forests.  With A (second formulation of the parallel sweep) it also
-// adds up the sample's ln proposal probability and counts the uses per class for the next sweep.
+// First formulation: 16 lanes per forest, a workgroup covers 64 forests at a time.  Second formulation (sweep2): the
+// entries of 256 forests dealt out evenly; it also writes the sample's rule ids and class words (from the records at
+// the positions the sampler left) and adds up the sample's ln proposal probability.
 #define FRC_FORESTS 256u
 __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sample_off, const uint32_t* sample_len,
                                                               uint32_t* rules, const uint32_t* p_norm, double* x,
