@@ -155,3 +155,70 @@ def test_fem_export_forests_carry_the_lattice_probabilities(oracle, golden_dir):
         np.testing.assert_allclose(per_forest, kept, rtol=1e-10, atol=1e-10)
         ids = [int(x) for x in re.findall(r"\d+", ntxt)]
         assert len(ids) == len(set(ids)) and max(ids) <= oc.n_params
+
+
+def best_tree(n, w):
+    """independent Viterbi over the parsed tree: (probability, printed tree); an OR node keeps its FIRST best child"""
+    label, kids = n
+    if label == "OR":
+        best = None
+        for k in kids:
+            c = best_tree(k, w)
+            if best is None or c[0] > best[0]:
+                best = c
+        return best
+    p, parts = w[label], []
+    for k in kids:
+        cp, ct = best_tree(k, w)
+        p *= cp
+        parts.append(ct)
+    return p, (str(label) if not kids else "(%d %s)" % (label, " ".join(parts)))
+
+
+@pytest.mark.parametrize("text", REF_TEST_FORESTS[2:] + ["(OR #1(OR 1 1) #1 (2 3) (3 3))", "(OR (1 (OR 2 3) (OR (4 5) 6)) (2 #7(OR 3 (5 6)) #7))"])
+def test_viterbi_matches_exhaustive_enumeration(oracle, text):
+    """forest-em -v (forest.hpp:507-632): the best derivation's probability is the maximum over all derivations, the printed
+    tree is an independent recursion's (first best child on ties: the weights below make ties on purpose), and the line reads
+    best/sum=percent% tree"""
+    for tie in (False, True):
+        rng = np.random.default_rng(len(text))
+        f = oracle.OracleForests(text, "()")
+        w = np.full(f.n_rules, 0.5) if tie else rng.uniform(0.1, 0.9, f.n_rules)
+        f.set_weights(np.log(w))
+        line, best_ln = f.viterbi_line(0, mode=2)  # never-log weights
+        ds = derivations(parse_tree(text))
+        ps = [math.prod(w[r] for r in d) for d in ds]
+        assert math.exp(best_ln) == pytest.approx(max(ps), rel=1e-12)
+        p, tree = best_tree(parse_tree(text), w)
+        head, got_tree = line.split("% ", 1)
+        # (two derivations that differ in the order of their factors tie up to rounding in a random draw: the tree is then
+        # decided by the last bit; with the weights all 1/2 every product is exact and the FIRST best child must win)
+        n_best = sum(1 for q in ps if abs(q - max(ps)) <= 1e-12 * max(ps))
+        if tie or n_best == 1:
+            assert got_tree == tree
+        assert math.prod(w[int(r)] for r in re.findall(r"\d+", got_tree)) == pytest.approx(max(ps), rel=1e-12)
+        b, rest = head.split("/")
+        z, pct = rest.split("=")
+        assert float(b) == pytest.approx(p, rel=1e-12) and float(z) == pytest.approx(sum(ps), rel=1e-12)
+        assert float(pct) == pytest.approx(100 * p / sum(ps), rel=1e-5)
+
+
+def test_initial_parameters_and_random_sets(oracle, golden_dir):
+    """FForests::init_rule_weights / randomize (forest-em.hpp:297-318, 393-399; normalize.hpp:212-238): uniform per norm group
+    with the rules of no group at weight zero, all ones with -u, random fractions divided by their group's sum"""
+    ftxt = "(OR (1 4) (2 3) (5 6))\n(OR (7 1) (2 8))\n"
+    ntxt = "((1 2 5) (3 4) (6))"
+    f = oracle.OracleForests(ftxt, ntxt)
+    f.init_rule_weights()
+    w = np.exp(f.weights())
+    np.testing.assert_allclose(w[[1, 2, 5]], 1 / 3)
+    np.testing.assert_allclose(w[[3, 4]], 1 / 2)
+    assert w[6] == 1.0 and w[7] == 0.0 and w[8] == 0.0  # 7 and 8 are in no group
+    f.init_rule_weights(ones=True)
+    np.testing.assert_allclose(np.exp(f.weights()), 1.0)
+    fr = np.array([0, .2, .3, .9, .1, .5, .7, .4, .4])
+    f.randomize(fr)
+    w = np.exp(f.weights())
+    np.testing.assert_allclose(w[[1, 2, 5]], fr[[1, 2, 5]] / fr[[1, 2, 5]].sum())
+    np.testing.assert_allclose(w[[3, 4]], fr[[3, 4]] / fr[[3, 4]].sum())
+    assert w[6] == pytest.approx(1.0) and w[7] == pytest.approx(1.0) and w[8] == pytest.approx(1.0)  # untouched since -u
