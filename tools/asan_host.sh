@@ -50,3 +50,22 @@ $B -c $G/tagging.fsa $G/tagging.fst > /dev/null 2>> $OUT/front.err
 for f in epron-jpron.fst train.a.w wfst3 tagging.fst; do $B -HJ $G/$f > /dev/null 2>> $OUT/front.err; done
 if grep -q "ERROR: AddressSanitizer\|runtime error" $OUT/front.err; then grep "ERROR\|runtime error" $OUT/front.err | head; exit 1; fi
 echo "front end under asan/ubsan: no reports"
+# forest-em's host-only paths: the forest / normalisation-group / parameter readers, the initial parameters (uniform, -u,
+# --random-set, -I with -N) and the option handling up to the first device call, which fails without a GPU (exit != 0 is
+# expected here; malformed inputs must be diagnosed, not crash)
+FB=$OUT/forest_em_asan_bin
+g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I$ROOT/include $ROOT/carmel_amd/csrc/host/forest_em_main.cpp \
+    -o $FB -L$ROOT/carmel_amd -lcarmel_hip -Wl,-rpath,$ROOT/carmel_amd -lpthread
+: > $OUT/forest.err
+printf '(0.5 0.25 0.125 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5 0.5)\n' > $OUT/fem.init
+for args in "" "-u" "--random-set --random-seed=4" "-I $OUT/fem.init -N" "-I $OUT/fem.init -z -N -H" "--crp=5 --crp-parallel" \
+            "-v $OUT/v -S $OUT/s -E $OUT/e"; do
+  $FB -f $G/fem.forests -n $G/fem.norm -i 2 -o $OUT/fem.out $args > /dev/null 2>> $OUT/forest.err || true
+done
+$FB -f $G/fem.norm -n $G/fem.norm > /dev/null 2>> $OUT/forest.err || true          # not a forest
+$FB -f $G/fem.forests -n $G/fem.forests > /dev/null 2>> $OUT/forest.err || true    # not a group list
+head -c 300 $G/fem.forests > $OUT/fem.cut; $FB -f $OUT/fem.cut -n $G/fem.norm > /dev/null 2>> $OUT/forest.err || true  # truncated
+printf '(1 2)\n' > $OUT/fem.short; $FB -f $G/fem.forests -n $G/fem.norm -I $OUT/fem.short > /dev/null 2>> $OUT/forest.err || true
+$FB -f $G/fem.forests > /dev/null 2>> $OUT/forest.err || true                       # missing normgroups-file
+if grep -q "ERROR: AddressSanitizer\|runtime error" $OUT/forest.err; then grep "ERROR: Addr\|runtime error" $OUT/forest.err | head; exit 1; fi
+echo "forest-em front end under asan/ubsan: no reports"
