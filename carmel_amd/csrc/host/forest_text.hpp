@@ -187,13 +187,17 @@ inline std::vector<double> read_params(const std::string& s) {
   return logw;
 }
 
+// FForests::write_params / write_counts (forest-em.hpp:190-201): print_range(out, begin + 1, end, multiline = true,
+// parens = false) -- a space, the weight and a newline per parameter (graehl/shared/io.hpp:327-343) -- then std::endl: one
+// weight per line and an empty line at the end, the format of forest-em/sample/best_weights and of what -I reads back
 inline std::string write_params(const double* logw, size_t n, int style) {  // logw[0] belongs to rule 1
-  std::string out = "(";
+  std::string out;
   for (size_t i = 0; i < n; ++i) {
-    if (i) out += ' ';
+    out += ' ';
     out += format_weight(logw[i], style);
+    out += '\n';
   }
-  out += ")\n";
+  out += '\n';
   return out;
 }
 
