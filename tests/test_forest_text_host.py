@@ -1,0 +1,55 @@
+"""CPU: forest-em's text formats in the front end (carmel_amd/csrc/host/forest_text.hpp), through a small compiled driver."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+DRIVER = r'''
+#include <cmath>
+#include <cstdio>
+#include <iostream>
+#include <limits>
+#include "forest_text.hpp"
+using namespace carmel_host;
+int main() {
+  const double inf = std::numeric_limits<double>::infinity();
+  const double lw[5] = {std::log(0.5), -300.0, -inf, 0.0, std::log(0.125)};
+  const std::string sometimes = write_params(lw, 5, W_SOMETIMES_LOG), never = write_params(lw, 5, W_NEVER_LOG);
+  std::cout << sometimes << "--\n" << never << "--\n";
+  for (const std::string& text : {sometimes, never, std::string("(0.5 e^-300 0 1 .125)\n"), std::string("0.5, e^-300\n0\n1 .125")}) {
+    std::vector<double> back = read_params(text);
+    std::printf("%zu", back.size());
+    for (double v : back) std::printf(" %.17g", v);
+    std::printf("\n");
+  }
+  return 0;
+}
+'''
+
+
+def test_parameter_files_are_written_and_read_as_the_reference_does(tmp_path):
+    """FForests::write_params / write_counts (forest-em.hpp:190-201: print_range multiline, no parentheses, then endl --
+    graehl/shared/io.hpp:327-343): a space, the weight and a newline per parameter and an empty line at the end, the format of
+    forest-em/sample/best_weights; read_params takes that, the parenthesised vector and comma-separated weights alike"""
+    src = tmp_path / "driver.cpp"
+    src.write_text(DRIVER)
+    exe = tmp_path / "driver"
+    inc = os.path.join(ROOT, "carmel_amd", "csrc", "host")
+    r = subprocess.run(["g++", "-std=c++17", "-O0", "-I", inc, "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    if r.returncode != 0:
+        pytest.fail(r.stderr[-2000:])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, universal_newlines=True).stdout
+    sometimes, never, rest = out.split("--\n")
+    assert sometimes == " 0.5\n e^-300\n 0\n 1\n 0.125\n\n"
+    assert never.split("\n")[0] == " 0.5" and never.endswith("\n\n") and "e^" not in never
+    rows = [l.split() for l in rest.strip().split("\n")]
+    assert [r[0] for r in rows] == ["5", "5", "5", "5"]
+    import math
+    for i in (0, 2, 3):  # e^-300 survives in the log forms; the never-log file prints it as a real number
+        vals = [float(x) for x in rows[i][1:]]
+        assert vals[0] == pytest.approx(math.log(0.5)) and vals[1] == pytest.approx(-300.0) and vals[2] == -math.inf
+        assert vals[3] == 0.0 and vals[4] == pytest.approx(math.log(0.125))
+    assert float(rows[1][2]) == pytest.approx(-300.0, rel=1e-12)
