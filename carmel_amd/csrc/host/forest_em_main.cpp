@@ -25,11 +25,12 @@ using namespace carmel_host;
 namespace {
 
 struct Opts {
-  std::string forests_file, normgroups_file = "-0", initparam_file = "-0", outparam_file = "-", outcounts_file = "-0";
-  long max_iter = 10000;            // --max-iter (forest-em-params.hpp:195)
+  // (defaults: ForestEmParams::set_defaults, forest-em-params.hpp:178-224 -- no parameter file is written unless -o names one)
+  std::string forests_file, normgroups_file = "-0", initparam_file = "-0", outparam_file = "-0", outcounts_file = "-0";
+  long max_iter = 1000;             // --max-iter (forest-em-params.hpp:195)
   long restarts = 0;                // -r / --random-restarts (forest-em-params.hpp:103, em.hpp:199-206)
   double converge_ratio = 1.0 / 65536;   // --converge, relative change of the average log prob (:197)
-  double converge_delta = 1.0 / 65536;   // --deltaparam-epsilon (:198)
+  double converge_delta = 0;             // --deltaparam-epsilon (:198): by default only a maximize that changes nothing ends the run
   double prior_counts = 0, add_k = 0;
   bool zero_zerocounts = false, normalize_initial = false, human_probs = false;
   bool initial_1 = false;    // -u / --initial-1-params: all parameters start at 1 (forest-em.hpp:307-308) instead of uniform per group

@@ -74,7 +74,7 @@ def test_forest_em_cli_on_reference_sample(oracle, golden_dir, tmp_path):
     """forest-em -f sample/forests -n sample/norm (forest-em/Makefile:62-67): parameters equal the oracle's EM"""
     f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
     out = tmp_path / "params"
-    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "30"])
+    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "30", "-d", "1.52587890625e-05"])
     assert rc == 0, err
     assert "5 forests, 60 nodes" in err
     best, bw, trace = oracle_em(oracle, open(f).read(), open(n).read(), 30)
@@ -92,7 +92,7 @@ def test_forest_em_cli_random_restarts(oracle, golden_dir, tmp_path):
     """forest-em -r 2 (em.hpp:199-206): two more starts from random parameters, the best start's parameters win"""
     f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
     out = tmp_path / "params"
-    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "12", "-r", "2", "--random-seed=5"])
+    rc, so, err = run(["-f", f, "-n", n, "-o", str(out), "-i", "12", "-r", "2", "--random-seed=5", "-d", "1.52587890625e-05"])
     assert rc == 0, err
     assert err.count("Random restart") == 2
     best, bw, trace = oracle_em(oracle, open(f).read(), open(n).read(), 12, restarts=2, seed=5)
@@ -149,7 +149,7 @@ def test_forest_em_cli_initial_parameters_and_final_outputs(oracle, golden_dir, 
         (tmp_path / "n").write_text(ntxt)
         for flags, kw in (([], {}), (["-u"], dict(ones=True)), (["--random-set", "--random-seed=9"], dict(random_set=True, seed=9))):
             rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / "o"), "-i", "6",
-                               "-v", str(tmp_path / "v"), "-S", str(tmp_path / "s"), "-E", str(tmp_path / "e")] + flags)
+                               "-d", "1.52587890625e-05", "-v", str(tmp_path / "v"), "-S", str(tmp_path / "s"), "-E", str(tmp_path / "e")] + flags)
             assert rc == 0, err
             keep = []
             best, bw, trace = oracle_em(oracle, ftxt, ntxt, 6, keep=keep, **kw)
