@@ -2036,7 +2036,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
     A.trace = trace_buf.p;
   }
-  const uint32_t Ni = o->iter, burnin = std::min(o->burnin, o->iter);
+  // gibbs_opts::validate (gibbs_opts.hpp:253-266): --final-counts makes every sweep but the last burn-in; burnin <= iter
+  const uint32_t Ni = o->iter, burnin = o->final_counts ? o->iter : std::min(o->burnin, o->iter);
   // host mirror of counts for the exact schedule (one forest at a time: the counts move between forests)
   std::vector<double> hx, hs, ht, hn;
   std::vector<std::vector<uint32_t> > hsample;

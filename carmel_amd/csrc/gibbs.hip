@@ -931,7 +931,8 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.want_after = iter_after_logprob ? 1 : 0;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
-  const uint32_t Ni = g->opt.iter, burnin = std::min(g->opt.burnin, g->opt.iter);
+  // gibbs_opts::validate (gibbs_opts.hpp:253-266): --final-counts makes every sweep but the last burn-in; burnin <= iter
+  const uint32_t Ni = g->opt.iter, burnin = g->opt.final_counts ? g->opt.iter : std::min(g->opt.burnin, g->opt.iter);
   const uint32_t n_runs = g->opt.restarts + 1;
   std::vector<double> lw(np), best_lw;
   double best_all = 0, best_final = 0, best_sum = 0;
@@ -1006,7 +1007,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     const double plog = g->opt.mode == 0 ? io[0] : io[1];
     {
       // propose_new_priors (gibbs.hpp:525-553), on the sweeps that infer (gibbs.hpp:559-563)
-      const uint32_t pstart = g->pi_start ? g->pi_start : g->opt.burnin;
+      const uint32_t pstart = g->pi_start ? g->pi_start : burnin;
       if (g->pi_stddev > 0 && g->n_scale && iter > 0 && pstart <= iter && (!g->pi_end || iter < g->pi_end)) {
         const double sdev = g->pi_stddev;
         const double q0 = gibbs_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;  // scale ratios are > 0 (gibbs.hpp:488-499)
@@ -1059,7 +1060,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
     if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[1];
     if (iter_after_logprob) iter_after_logprob[(size_t)run * (Ni + 1) + iter] = io[2];
-    if (iter >= g->opt.burnin) {  // gibbs.hpp:942-943
+    if (iter >= burnin) {  // gibbs.hpp:942-943
       st_all += plog;
       st_final = plog;
       const double hi = std::max(st_sum, plog), lo = std::min(st_sum, plog);

@@ -1033,7 +1033,7 @@ static int run(int argc, char** argv) {
         std::cerr << "--print-from,-to gibbs [" << a << "," << b << ") is out of range for " << n_members << " input transducers.\n";
       } else {
         if (b > (long)n_members) b = (long)n_members;
-        std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << ((double)go.iter - (double)std::min(go.burnin, go.iter))
+        std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << ((double)go.iter - (double)(go.final_counts ? go.iter : std::min(go.burnin, go.iter)))
                   << "):\n";
         // parameter id -> (member, source state, arc)
         std::vector<const Transducer*> mem;
