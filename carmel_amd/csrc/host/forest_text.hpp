@@ -145,6 +145,8 @@ inline void read_normgroups(const std::string& s, std::vector<uint64_t>& group_o
       if (depth == 2) group_off.push_back(group_rule.size());
       --depth;
       ++p;
+      if (depth == 0) return;  // one list is read (`in >> norm_groups`, forest-em.hpp read_norm_groups): whatever follows it --
+                               // forests, in forest-em/sample/norm_and_forests -- is not the groups' business
     } else if (std::isdigit((unsigned char)c)) {
       uint64_t v = 0;
       while (p < s.size() && std::isdigit((unsigned char)s[p])) v = v * 10 + (uint64_t)(s[p++] - '0');
@@ -157,7 +159,8 @@ inline void read_normgroups(const std::string& s, std::vector<uint64_t>& group_o
       throw std::runtime_error(std::string("normalisation groups: unexpected character '") + c + "'");
     }
   }
-  if (depth != 0) throw std::runtime_error("normalisation groups: unbalanced parentheses");
+  throw std::runtime_error(depth ? "normalisation groups: unbalanced parentheses"
+                                : "Expected normalization groups list e.g. ((1 2 3) (4 5) (6))");
 }
 
 // parameter vector "(1 .5 e^-3 0)", or -- what carmel --fem-param writes -- the bare weights up to the end of the

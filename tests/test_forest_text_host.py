@@ -24,6 +24,20 @@ int main() {
     for (double v : back) std::printf(" %.17g", v);
     std::printf("\n");
   }
+  // forest-em/sample/norm_and_forests: the groups' list is followed by forests, which are not its business
+  std::vector<uint64_t> off;
+  std::vector<uint32_t> rule;
+  uint32_t mx = 0;
+  read_normgroups("((1 2 7 ) (3 4 5 6))\n(1 4)\n(OR (1 4) (1 3))\n", off, rule, mx);
+  std::printf("groups %zu rules %zu max %u\n", off.size() - 1, rule.size(), mx);
+  for (const char* bad : {"", "   ", "((1 2) (3", "(OR 1 2)"}) {
+    try {
+      read_normgroups(bad, off, rule, mx);
+      std::printf("accepted\n");
+    } catch (std::exception& e) {
+      std::printf("refused: %s\n", e.what());
+    }
+  }
   return 0;
 }
 '''
@@ -42,6 +56,10 @@ def test_parameter_files_are_written_and_read_as_the_reference_does(tmp_path):
     if r.returncode != 0:
         pytest.fail(r.stderr[-2000:])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, universal_newlines=True).stdout
+    out, groups = out.split("groups ", 1)
+    assert groups.split("\n")[0] == "2 rules 7 max 7"
+    assert groups.split("\n")[1:5] == ["refused: Expected normalization groups list e.g. ((1 2 3) (4 5) (6))"] * 2 + \
+        ["refused: normalisation groups: unbalanced parentheses", "refused: normalisation groups: unexpected character 'O'"]
     sometimes, never, rest = out.split("--\n")
     assert sometimes == " 0.5\n e^-300\n 0\n 1\n 0.125\n\n"
     assert never.split("\n")[0] == " 0.5" and never.endswith("\n\n") and "e^" not in never
