@@ -1110,17 +1110,42 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
     work();
     for (auto& t : th) t.join();
   }
-  // tile-major order: stable counting sort of the bucket-major sequence by tile
-  for (uint64_t J = 0; J < N; ++J) out.t_tile_base[pos_of[J] / TRANS_TILE + 1]++;
-  for (uint64_t t = 0; t < n_tiles; ++t) out.t_tile_base[t + 1] += out.t_tile_base[t];
+  // tile-major order: stable counting sort of the bucket-major sequence by tile.  Threads own contiguous ranges of J: a
+  // histogram per thread, cursors from the prefix over (tile, thread) -- thread 0's items of a tile first --, then every
+  // thread scatters its own range: the same order as one thread walking J = 0 .. N - 1
   {
-    std::vector<uint64_t> cur(out.t_tile_base.begin(), out.t_tile_base.end() - 1);
-    for (uint64_t J = 0; J < N; ++J) {
-      const uint64_t t = pos_of[J] / TRANS_TILE, I = cur[t]++;
-      out.t_t_src[I] = (uint32_t)J;
-      out.t_t_pos[I] = (uint16_t)(pos_of[J] - t * TRANS_TILE);
-      out.t_b_src[J] = (uint32_t)I;
+    const int ns = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)std::max(nt, 1), N / (1u << 18)));
+    auto j_lo = [&](int t) { return (uint64_t)((__uint128_t)N * (uint64_t)t / (uint64_t)ns); };
+    std::vector<std::vector<uint64_t>> hist((size_t)ns, std::vector<uint64_t>(n_tiles, 0));
+    auto in_threads = [&](const std::function<void(int)>& f) {
+      std::vector<std::thread> th;
+      for (int t = 1; t < ns; ++t) th.emplace_back(f, t);
+      f(0);
+      for (auto& x : th) x.join();
+    };
+    in_threads([&](int t) {
+      std::vector<uint64_t>& h = hist[(size_t)t];
+      for (uint64_t J = j_lo(t), e = j_lo(t + 1); J < e; ++J) h[pos_of[J] / TRANS_TILE]++;
+    });
+    uint64_t acc = 0;
+    for (uint64_t tile = 0; tile < n_tiles; ++tile) {
+      out.t_tile_base[tile] = acc;
+      for (int t = 0; t < ns; ++t) {
+        const uint64_t c = hist[(size_t)t][tile];
+        hist[(size_t)t][tile] = acc;  // becomes thread t's cursor for this tile
+        acc += c;
+      }
     }
+    out.t_tile_base[n_tiles] = acc;
+    in_threads([&](int t) {
+      std::vector<uint64_t>& cur = hist[(size_t)t];
+      for (uint64_t J = j_lo(t), e = j_lo(t + 1); J < e; ++J) {
+        const uint64_t tile = pos_of[J] / TRANS_TILE, I = cur[tile]++;
+        out.t_t_src[I] = (uint32_t)J;
+        out.t_t_pos[I] = (uint16_t)(pos_of[J] - tile * TRANS_TILE);
+        out.t_b_src[J] = (uint32_t)I;
+      }
+    });
   }
 }
 

@@ -165,3 +165,18 @@ def test_windowed_lane_layout(oracle, monkeypatch, seed, window, wmin):
     assert not np.isnan(counts).any()
     np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
+
+
+def test_layout_and_tables_do_not_depend_on_the_thread_count():
+    """the host builder's threads (derivations per pair, slots by arc, buckets, the tile-major counting sort) produce the bytes
+    one thread produces -- what the GPU builder is compared with (tests/test_lattice_gpu.py) must not depend on the host"""
+    w = synth.random_wfst(50000, 20, seed=3)
+    c = synth.random_walk_corpus(w, 26000, min_arcs=5, max_arcs=40, seed=10, out_degree=20)
+    a, b = host_lattices(w, c, threads=1), host_lattices(w, c, threads=8)
+    ta, tb = a["transpose"], b["transpose"]
+    assert ta["n_items"] > 2 * (1 << 18)  # several threads in the tile-major sort
+    for k in ("tile_base", "b_arc", "b_rank", "b_src", "t_pos", "t_src", "split_arcs", "arc_off", "slot_pos"):
+        assert np.array_equal(ta[k], tb[k]), k
+    assert ta["buckets"].tobytes() == tb["buckets"].tobytes()
+    for k in ("lane_fwd", "lane_bwd", "lane_pair", "lane_nstates", "lane_groups"):
+        assert np.array_equal(a[k], b[k]), k
