@@ -1,17 +1,31 @@
 // kernels.hip — CDNA4 (gfx950) kernels for carmel's EM hot path.  64-wide wavefronts throughout.
 //
-// Data layout (built by lattice.cpp): lattices are packed into BUNDLES, one workgroup per bundle.  A bundle's
-// states are numbered level-major (level = longest path from a start state), so
-//   forward  alpha[s] = logsumexp over in-arcs  (alpha[src] + logw[arc])   needs only earlier levels,
-//   backward beta[s]  = logsumexp over out-arcs (logw[arc] + beta[dst])    needs only later levels,
-// and both are gathers: no atomics on alpha/beta, which live in LDS for the whole sweep.  The only atomics are
-// the f64 adds of expected counts into the per-arc table (global_atomic_add_f64).
+// One E-step (forward_backward::estimate, /root/reference/carmel/src/train.cc:763-773) is five stream kernels:
+//   trans_w_bucket -> trans_w_tile   the arc weights, permuted from WFST-arc order into lattice (slot) order through
+//                                    the blocked transposition tables of lattice.hpp (TransBucket): two coalesced
+//                                    passes through LDS instead of one random gather per lattice arc;
+//   sweep_lane                       one derivation lattice per LANE (64 lattices per wavefront, record streams
+//                                    interleaved row by row so every wave-wide load is one coalesced row): forward
+//                                    over the in-arc stream with alpha in the lane's own LDS column, backward in
+//                                    place over the out-arc stream, posterior exp(alpha + w + beta - ln p) written
+//                                    to the arc's slot (derivations.h:400-449, graph.h:391-402).  Windowed groups
+//                                    keep a ring of W rows instead of the whole column (lattices up to 1023 states);
+//   sweep_wave                       one lattice per WAVEFRONT (lattices too large for a lane): the 64 lanes take the
+//                                    arcs of a level, __shfl / DPP log-sum-exp across the lanes that share a state;
+//   sweep_bundle / sweep_serial      the level-synchronous workgroup-per-bundle gather sweep (kept for lattices beyond
+//                                    the wave kernel's LDS) and the reference-order sweep of cyclic lattices;
+//   trans_c_tile -> trans_c_bucket   the posteriors back into arc order, each arc's uses summed in a fixed order.
+// No kernel on this path issues an atomic: counts are bit-reproducible run to run (the one exception: the partial
+// sums of a hub arc split over several buckets meet in one atomic add per piece).
 //
-// What is computed is derivations::compute_fb + collect_counts
-// (/root/reference/carmel/src/derivations.h:400-449, graph.h:391-402) with the log-semiring of
-// graehl/shared/weight.h:737-801.  The reference adds terms one at a time with log1p(exp(-|d|)) and drops
-// addends more than 36 nats smaller; here each state's sum is one streaming logsumexp (running max + scaled
-// sum), which differs from that only in the last bits (e^-36 ~ 2e-16).
+// Arithmetic is the log-semiring of graehl/shared/weight.h:737-801 in f64.  The reference adds terms one at a time
+// with log1p(exp(-|d|)) and drops addends more than 36 nats smaller; here each state's sum is one streaming logsumexp
+// (running max + scaled sum), which differs from that only in the last bits (e^-36 ~ 2e-16).  Counts are LINEAR f64.
+//
+// The M-step (forward_backward::maximize, train.cc:893-923 -> WFST::normalize, fst.cc:86-244) is mstep_window_kernel
+// (one pass, norm groups within a window of consecutive parameters) or the general mstep_group_sum / _big_group /
+// _normalize / _tie_* kernels; chain_update / chain_scatter are cascade_parameters::update / distribute_counts
+// (cascade.h:286-325, 466-479).
 #include "kernels.hpp"
 #include <cstdio>
 #include <cstdlib>

@@ -64,6 +64,75 @@ def random_walk_corpus(w, n_pairs, min_arcs=5, max_arcs=40, seed=1, out_degree=N
     return Corpus(in_off, ins[mi], out_off, outs[mo])
 
 
+def clustered_wfst(n_states, out_degree, members=2, n_sym=64, p_eps=0.1, seed=1, n_in_sym=4):
+    """A transducer whose derivation lattices are AMBIGUOUS at any size (random_wfst's are single paths: with uniform
+    destinations over 10^6 states two partial derivations never meet again).  The states with arcs form clusters of
+    `members` states; the cluster's `out_degree / members` moves each carry one label pair and one destination cluster,
+    and every member of the source cluster has an arc for the move to EVERY member of the destination cluster -- an HMM
+    whose hidden variable is the member: a pair read off a walk determines the cluster sequence, not the members, so its
+    lattice is positions x members with members^2 arcs between neighbouring positions (every lattice state has `members`
+    in-arcs; the tagging cascade of the tutorial has the same shape).  Move 0 enters the single final state (`members`
+    parallel arcs per state, each a parameter of its own).  Arc order is state-major, moves in order, destination member
+    innermost.  Input labels come from a SMALL alphabet (n_in_sym - 1 symbols), output labels from n_sym - 1: several moves
+    of a cluster share an input symbol, so the conditional model P(out | in) spreads its mass over them and a pair's
+    probability is below one (with distinct input labels every pair would have probability exactly 1 whatever the weights).
+    Weights Dirichlet(1) per (state, input) group like random_wfst."""
+    rng = np.random.default_rng(seed)
+    M = int(members)
+    assert out_degree % M == 0 and (n_states - 1) % M == 0
+    moves = out_degree // M
+    F = n_states - 1
+    ncl = (n_states - 1) // M
+    dcl = rng.integers(0, ncl, size=(ncl, moves), dtype=np.int64)
+
+    def labels(k):
+        lab = rng.integers(FIRST_SYM, FIRST_SYM + k - 1, size=(ncl, moves), dtype=np.uint32)
+        lab[rng.random((ncl, moves)) < p_eps] = 0
+        return lab
+
+    li, lo = labels(n_in_sym), labels(n_sym)
+    ns = ncl * M
+    src = np.repeat(np.arange(ns, dtype=np.uint32), out_degree)
+    cl = np.repeat(np.arange(ncl, dtype=np.int64), M * out_degree)              # cluster of every arc's source
+    mv = np.tile(np.repeat(np.arange(moves, dtype=np.int64), M), ns)             # move of every arc
+    dm = np.tile(np.arange(M, dtype=np.int64), ns * moves)                       # destination member
+    dst = (dcl[cl, mv] * M + dm).astype(np.uint32)
+    dst[mv == 0] = F
+    isym, osym = li[cl, mv], lo[cl, mv]
+    g = rng.exponential(size=ns * out_degree)
+    key = src.astype(np.uint64) * np.uint64(1 << 20) + isym.astype(np.uint64)
+    _, inv = np.unique(key, return_inverse=True)
+    sums = np.bincount(inv, weights=g)
+    return Wfst(n_states, F, src, dst, isym, osym, np.log(g / sums[inv]))
+
+
+def clustered_walk_corpus(w, n_pairs, out_degree, members=2, min_arcs=5, max_arcs=40, seed=1):
+    """pairs read off random walks over clustered_wfst's moves (the last move is move 0, into the final state); the walk
+    starts at state 0, i.e. member 0 of cluster 0"""
+    rng = np.random.default_rng(seed + 1000003)
+    M = int(members)
+    moves = out_degree // M
+    L = rng.integers(min_arcs, max_arcs + 1, size=n_pairs)
+    cur = np.zeros(n_pairs, dtype=np.int64)  # current state (member 0 of the current cluster)
+    maxL = int(L.max())
+    ins = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    outs = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    for step in range(maxL):
+        active = step < L
+        last = step == L - 1
+        pick = rng.integers(1, moves, size=n_pairs) if moves > 1 else np.zeros(n_pairs, dtype=np.int64)
+        pick[last] = 0
+        arc = cur * out_degree + pick * M  # the move's arc to member 0 of the destination
+        arc[~active] = 0
+        ins[:, step] = np.where(active, w.isym[arc], 0)
+        outs[:, step] = np.where(active, w.osym[arc], 0)
+        cur = np.where(active & ~last, w.dst[arc].astype(np.int64), cur)
+    mi, mo = ins != 0, outs != 0
+    in_off = np.concatenate([[0], np.cumsum(mi.sum(1))]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(mo.sum(1))]).astype(np.uint64)
+    return Corpus(in_off, ins[mi], out_off, outs[mo])
+
+
 CONFIGS = {
     # name: (n_states, out_degree, n_pairs, seed)
     "toy": (200, 6, 300, 7),
@@ -71,13 +140,35 @@ CONFIGS = {
     "c4": (1000000, 10, 1000000, 3),  # configs[3]: 1M states / 10M arcs, 1M pairs
 }
 
+# the clustered (ambiguous) workloads next to them: name -> (n_states, out_degree, members, n_pairs, seed, min_arcs, max_arcs)
+CLUSTERED = {
+    # config 4's sizes with lattices that exercise the log-semiring sum: 10^6 states / 12*10^6 arcs / 10^6 pairs, three
+    # members per cluster => a lattice is positions x 3 states, 9 arcs between neighbouring positions, 3 in-arcs per state
+    "c4a": (999999 + 1, 12, 3, 1000000, 5, 5, 40),
+    # few LONG lattices (320 .. 4800 states, 64 arcs per position): the large-lattice path, one lattice per wavefront
+    "long": (8 * 12500 + 1, 32, 8, 5000, 6, 40, 600),
+    "toya": (3 * 60 + 1, 12, 3, 300, 8, 3, 14),
+}
 
-def make_config(name, n_pairs=None):
+
+def make_config(name, n_pairs=None, rank=0, walk=None):
+    """(transducer, corpus) of a named synthetic workload; rank r > 0 draws another shard of the same size (other walks over
+    the same transducer), walk = (min_arcs, max_arcs) overrides the walk lengths (experiments)"""
+    if name in CLUSTERED:
+        n_states, deg, members, npairs, seed, lo, hi = CLUSTERED[name]
+        if n_pairs is not None:
+            npairs = n_pairs
+        if walk:
+            lo, hi = walk
+        w = clustered_wfst(n_states, deg, members=members, seed=seed)
+        c = clustered_walk_corpus(w, npairs, deg, members=members, min_arcs=lo, max_arcs=hi, seed=seed + 7919 * rank)
+        return w, c
     n_states, deg, npairs, seed = CONFIGS[name]
     if n_pairs is not None:
         npairs = n_pairs
+    lo, hi = walk or (5, 40)
     w = random_wfst(n_states, deg, seed=seed)
-    c = random_walk_corpus(w, npairs, seed=seed, out_degree=deg)
+    c = random_walk_corpus(w, npairs, min_arcs=lo, max_arcs=hi, seed=seed + 7919 * rank, out_degree=deg)
     return w, c
 
 
@@ -204,15 +295,22 @@ def cipher_files(n_lines, min_len=30, max_len=80, seed=2):
     perm = rng.permutation(n - 1) + 1                  # "_" maps to itself, letters are permuted
     key = np.concatenate([[0], perm])
     lens = rng.integers(min_len, max_len + 1, size=n_lines)
-    lines = []
     cdf = np.cumsum(big, axis=1)
-    for L in lens:
-        u = rng.random(int(L))
-        cur, out = 0, [0]                               # lines start and end with the separator
-        for k in range(int(L) - 2):
-            cur = int(np.searchsorted(cdf[cur], u[k]))
-            cur = min(cur, n - 1)
-            out.append(cur)
-        out.append(0)
-        lines.append("\n" + " ".join('"%s"' % cipher_syms[key[c]] for c in out))
+    # every line draws len uniforms (the last two go unused) and walks the bigram chain from the separator; the walks of
+    # all lines advance together, one position per step (same draws, same text as a line-by-line loop)
+    u_all = rng.random(int(lens.sum()))
+    off = np.concatenate([[0], np.cumsum(lens)])[:-1]
+    maxL = int(lens.max())
+    sym = np.zeros((n_lines, maxL), dtype=np.int64)  # plain symbol per position; position 0 and len - 1 are the separator
+    cur = np.zeros(n_lines, dtype=np.int64)
+    for k in range(maxL - 2):
+        act = np.nonzero(k < lens - 2)[0]
+        if not len(act):
+            break
+        nxt = (cdf[cur[act]] < u_all[off[act] + k][:, None]).sum(axis=1)  # = searchsorted(cdf[cur], u), side "left"
+        nxt = np.minimum(nxt, n - 1)
+        cur[act] = nxt
+        sym[act, k + 1] = nxt
+    quoted = np.array(['"%s"' % cipher_syms[key[c]] for c in range(n)], dtype=object)
+    lines = ["\n" + " ".join(quoted[sym[i, :lens[i]]]) for i in range(n_lines)]
     return "\n".join(lm) + "\n", "\n".join(ch) + "\n", "\n".join(lines) + "\n"

@@ -48,6 +48,12 @@ class HipComm(object):
         check(lib.carmel_hip_comm_allreduce_host(self.h, ptr(v), len(v), 1 if op_max else 0), "carmel_hip_comm_allreduce_host")
         return v
 
+    def describe(self, n):
+        return "RCCL all-reduce of %d f64 counts per iteration on the trainer's stream" % n
+
+    def abort(self):
+        self.close()
+
     def close(self):
         if self.h:
             lib.carmel_hip_comm_destroy(self.h)
@@ -126,6 +132,16 @@ class HipForwardBackward(object):
     def allreduce_counts(self, comm):
         """enqueue the RCCL all-reduce (sum) of counts[n_arcs + 4] on the trainer's stream (no host sync)"""
         check(lib.carmel_hip_allreduce_counts(self.h, comm.h), "carmel_hip_allreduce_counts")
+
+    def layout_description(self):
+        """how the derivation lattices of this shard are held (carmel_hip_lattice_layout + carmel_hip_lattice_stats)"""
+        ls, lay = self.lattice_stats, lib.carmel_hip_lattice_layout(self.h)
+        if lay == 1:
+            return "unrolled over string positions (never stored)"
+        if lay == 2:
+            return "unrolled, rank-1 dense form (never stored)"
+        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM" % (
+            ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9)
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

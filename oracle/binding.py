@@ -60,13 +60,16 @@ def bench_em(w, c, norm_group=0, iters=3, threads=1):
     return dict(sec_per_iter=out[0], lattice_arcs=out[1], build_sec=out[2], ln_prob=out[3])
 
 
-def bench_em_fit(w, c, norm_group=0, iters=2, threads=1):
+def bench_em_fit(w, c, norm_group=0, iters=2, threads=1, check=False):
     """CPU baseline with the fixed (O(|WFST arcs|): clear counts + maximize) and the per-lattice-arc cost of an EM
     iteration separated (orc_bench_em_fit): E-step timed on a quarter and on all of the sample's cached lattices,
     maximize on its own; serial, and -- threads > 1 -- with OpenMP.  Returns dict(build_sec, arcs_quarter, arcs_all,
     serial=dict(estep_quarter, estep_all, maximize, ln_prob, fixed_sec, sec_per_arc), threaded=... or None)"""
     out = np.zeros(11)
-    _chk(lib.orc_bench_em_fit(w.h, c.h, norm_group, iters, threads, _p(out)))
+    counts_ln = pair_lp = None
+    if check:
+        counts_ln, pair_lp = np.zeros(w.dims()[1]), np.full(len(c.arrays()["weight"]), np.nan)
+    _chk(lib.orc_bench_em_fit_check(w.h, c.h, norm_group, iters, threads, _p(out), _p(counts_ln), _p(pair_lp)))
 
     def leg(o):
         eq, ea, mx, lp = (float(v) for v in out[o:o + 4])
@@ -74,7 +77,7 @@ def bench_em_fit(w, c, norm_group=0, iters=2, threads=1):
         return dict(estep_quarter=eq, estep_all=ea, maximize=mx, ln_prob=lp, sec_per_arc=b,
                     fixed_sec=max(eq - b * out[1], 0.0) + mx)
     return dict(build_sec=float(out[0]), arcs_quarter=float(out[1]), arcs_all=float(out[2]), serial=leg(3),
-                threaded=leg(7) if threads > 1 else None)
+                threaded=leg(7) if threads > 1 else None, counts_ln=counts_ln, pair_logprob=pair_lp)
 
 
 def _p(a):
@@ -235,6 +238,7 @@ def train_cascade_text(wfst_texts, corpus_text, normby=None, priors=None, max_it
 
 lib.orc_cascade_compose_text.restype = vp
 lib.orc_bench_em_fit.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp]
+lib.orc_bench_em_fit_check.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
 lib.orc_cascade_compose_text.argtypes = [C.c_int, vp]
 lib.orc_cascade_compose_text_ex.restype = vp
 lib.orc_cascade_compose_text_ex.argtypes = [C.c_int, vp, C.c_int, C.c_int]

@@ -496,7 +496,16 @@ int orc_bench_em(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int th
 // into one linear-domain count table, parallel clear / prep_new_weights / per-state normalisation -- weights checked
 // against the serial normalize).  out[0] build seconds, [1] lattice arcs of the quarter, [2] of all, then per leg (serial at 3,
 // threaded at 7): E-step seconds on the quarter, on all, maximize seconds, ln corpus prob of the last full E-step.
+// orc_bench_em_fit_check: the same, and the answers of the serial leg's last full E-step are handed back so that the caller
+// can check the GPU against them on the very sample that was timed: counts_ln[n_arcs] (ln expected count per arc, as
+// arc_counts::counts holds it) and pair_lp[n surviving pairs, corpus order] (ln p of each pair); either may be null.
+int orc_bench_em_fit_check(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int threads, double* out, double* counts_ln,
+                           double* pair_lp);
 int orc_bench_em_fit(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int threads, double* out) {
+  return orc_bench_em_fit_check(wh, ch, norm_group, iters, threads, out, nullptr, nullptr);
+}
+int orc_bench_em_fit_check(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, int threads, double* out, double* counts_ln,
+                           double* pair_lp) {
   return run_big_stack([&]() {
     typedef std::chrono::steady_clock clk;
     auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
@@ -525,7 +534,11 @@ int orc_bench_em_fit(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, in
     auto estep_serial = [&](size_t n) {
       for (auto& a : fb.arcs.t) a.counts = LW();
       double sum = 0;
-      for (size_t p = 0; p < n; ++p) sum += fb.derivs[p].collect_counts(fb.arcs).w;
+      for (size_t p = 0; p < n; ++p) {
+        const double lpp = fb.derivs[p].collect_counts(fb.arcs).w;
+        if (pair_lp) pair_lp[p] = lpp;
+        sum += lpp;
+      }
       return sum;
     };
     double lp = 0;
@@ -534,6 +547,8 @@ int orc_bench_em_fit(orc_wfst* wh, orc_corpus* ch, int norm_group, int iters, in
     auto t2 = clk::now();
     for (int i = 0; i < iters; ++i) lp = estep_serial(n_all);
     auto t3 = clk::now();
+    if (counts_ln)
+      for (size_t k = 0; k < na; ++k) counts_ln[k] = fb.arcs.t[k].counts.w;
     // maximize changes the weights; the E-steps above all ran on the same ones
     for (int i = 0; i < iters; ++i) {
       if (i) estep_serial(n_all);  // fresh counts for a repeat (not timed below)

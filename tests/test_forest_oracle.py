@@ -222,3 +222,28 @@ def test_initial_parameters_and_random_sets(oracle, golden_dir):
     np.testing.assert_allclose(w[[1, 2, 5]], fr[[1, 2, 5]] / fr[[1, 2, 5]].sum())
     np.testing.assert_allclose(w[[3, 4]], fr[[3, 4]] / fr[[3, 4]].sum())
     assert w[6] == pytest.approx(1.0) and w[7] == pytest.approx(1.0) and w[8] == pytest.approx(1.0)  # untouched since -u
+
+
+def test_exact_chain_settles_on_the_enumerated_stationary_distribution(oracle):
+    """The sampler restatement pinned on something other than itself: on a corpus small enough to enumerate (5 forests,
+    1 600 joint assignments) the transition matrix of one sweep is built from the definition of a block's proposal
+    (tests/forest_enum.py; forest-em.hpp:750-766, gibbs.hpp:589-592, 769-792) and the time-averaged rule probabilities of the
+    oracle's chain must be its stationary expectations: 16 chains of 8 000 sweeps, per rule z = (mean - exact) / standard
+    error over chains, |z| < 4.9 (Student t, 15 degrees of freedom, overall level 1e-3 over 8 rules, two-sided).  The
+    stale-count sweep's stationary distribution (a different chain) must lie outside that band: the test discriminates."""
+    import math
+    from carmel_amd._capi import lib
+    from forest_enum import TOY_FORESTS, TOY_NORM, toy_setup
+    of = oracle.OracleForests(TOY_FORESTS, TOY_NORM)
+    lw = np.log(np.random.default_rng(3).uniform(0.2, 1.0, of.n_rules))
+    derivs, exact = toy_setup(of.node_off, of.label, of.ref, of.next, of.n_rules, of.group_off, of.group_rule, lw, 0.5)
+    chains = []
+    for seed in range(16):
+        of.set_weights(lw)
+        of.gibbs(lambda i, b, s: lib.carmel_hip_gibbs_uniform(5 + 7919 * seed, i, b, s), 8000, burnin=500, alpha=0.5)
+        chains.append(np.exp(of.weights()[1:]))
+    chains = np.asarray(chains)
+    mean, se = chains.mean(0), chains.std(0, ddof=1) / math.sqrt(len(chains))
+    z = (mean - exact[False][1:]) / se
+    assert np.all(np.abs(z) < 4.9), z
+    assert np.max(np.abs((mean - exact[True][1:]) / se)) > 6.0

@@ -180,3 +180,20 @@ def test_layout_and_tables_do_not_depend_on_the_thread_count():
     assert ta["buckets"].tobytes() == tb["buckets"].tobytes()
     for k in ("lane_fwd", "lane_bwd", "lane_pair", "lane_nstates", "lane_groups"):
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name,pairs", [("toya", None), ("c4a", 400), ("long", 6)])
+def test_clustered_workloads_layout_matches_oracle(oracle, name, pairs):
+    """the clustered (ambiguous) transducers of bench.py's c4a / long workloads: every lattice state is a real log-semiring
+    sum (members^2 arcs between neighbouring positions); host builder + layout (windowed lane groups, bundles) swept in
+    numpy against the oracle's E-step"""
+    w, c = synth.make_config(name, n_pairs=pairs)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    img = host_lattices(w, c, small_pairs=8, small_states=1024, lane_states=96)
+    assert img["total_arcs"] / img["total_states"] > (2.0 if name != "long" else 6.0)
+    r = oracle.estimate(ow, oc)
+    assert r["has_deriv"].all() and img["has_deriv"].all()
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    np.testing.assert_allclose(plp, r["pair_logprob"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
+    assert abs(counts[w.dst == w.final].sum() - c.n_pairs) < 1e-9 * c.n_pairs
