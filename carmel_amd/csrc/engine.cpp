@@ -193,6 +193,8 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
+  if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;  // A/B: 0 = no one-per-wavefront lattices (bundles as before)
+  if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
   {
     // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;
     // otherwise -- or with CARMEL_HIP_GPU_BUILD=0 -- the host builder below does the whole corpus
@@ -241,6 +243,14 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->pair_id.upload(L.pair_id, s));
   HIPCHK(t->pair_logw.upload(L.pair_logw, s));
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
+  HIPCHK(t->wave_descs.upload(L.waves, s));
+  HIPCHK(t->wave_fwd.upload(L.wave_fwd, s));
+  HIPCHK(t->wave_bwd.upload(L.wave_bwd, s));
+  HIPCHK(t->wave_level_off.upload(L.wave_level_off, s));
+  HIPCHK(t->wave_frow.upload(L.wave_frow, s));
+  HIPCHK(t->wave_brow.upload(L.wave_brow, s));
+  t->wave_slot_base = L.wave_slot_base;
+  t->wave_records = L.wave_bwd.size();
   {
     // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
     const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
@@ -269,9 +279,11 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->lane_pair.upload(L.lane_pair, s));
   HIPCHK(t->lane_nstates.upload(L.lane_nstates, s));
   HIPCHK(t->lane_logw.upload(L.lane_logw, s));
-  t->lane_records = L.lane_bwd.size();
+  t->lane_records = L.wave_slot_base + L.wave_bwd.size();  // first bundle slot: [lane records | wave records | bundle arcs]
   HIPCHK(t->post.alloc(L.n_post));
-  HIPCHK(t->wcache.alloc(L.lane_bwd.size()));
+  HIPCHK(t->wcache.alloc(t->lane_records));
+  if (!L.waves.empty() && L.t_buckets.empty())
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "lattice set too large for the blocked transposition (2^32 items) with one-per-wavefront lattices");
   if (L.lane_spill_rows)
     HIPCHK(t->lane_spill.alloc(L.lane_spill_rows * 64));
   else
@@ -327,11 +339,16 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->beta_g.bytes() + t->lane_groups.bytes() + t->lane_fwd.bytes() + t->lane_fwdx.bytes() + t->lane_bwd.bytes() +
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
                     t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
-                    t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes() + t->t_xc.bytes();
+                    t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes() + t->t_xc.bytes() +
+                    t->wave_descs.bytes() + t->wave_fwd.bytes() + t->wave_bwd.bytes() + t->wave_level_off.bytes() +
+                    t->wave_frow.bytes() + t->wave_brow.bytes();
   std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
   std::vector<uint2_t>().swap(L.lane_bwd);
+  std::vector<uint2_t>().swap(L.wave_fwd);
+  std::vector<uint32_t>().swap(L.wave_bwd);
+  std::vector<uint32_t>().swap(L.wave_bwd_arc);
   // free the bulk host arrays; keep descriptors + classes
   std::vector<uint2_t>().swap(L.in_arcs);
   std::vector<uint2_t>().swap(L.out_arcs);
@@ -343,6 +360,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
             (unsigned long long)L.lane_arcs, L.lane_groups.size(), L.lane_classes.size(), L.bundles.size(), L.classes.size(),
             (unsigned long long)L.total_arcs, (int)L.lane_tiles_aligned);
     for (auto& lc : L.lane_classes) fprintf(stderr, "timing:   lane piece groups=%u %s=%u tiles=%u\n", lc.count, lc.windowed ? "window" : "max_states", lc.max_states, lc.tile_count);
+    for (auto& wc : L.wave_classes) fprintf(stderr, "timing:   wave class count=%u max_states=%u max_width=%u\n", wc.count, wc.max_states, wc.max_width);
     for (auto& lc : L.classes) fprintf(stderr, "timing:   bundle class count=%u block=%u max_states=%u serial=%d\n", lc.count, lc.block, lc.max_states, (int)lc.serial);
   }
   t->have_lattices = true;
@@ -359,7 +377,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     stats->kept_states = L.total_states;
     stats->kept_arcs = L.total_arcs;
     stats->n_cyclic_pairs = L.n_cyclic;
-    stats->n_bundles = L.bundles.size() + L.lane_groups.size();
+    stats->n_bundles = L.bundles.size() + L.lane_groups.size() + L.waves.size();
     stats->max_levels = L.max_levels;
     stats->device_bytes = t->device_bytes;
     stats->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -763,6 +781,18 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     }
     LA.trace = trace_buf.p;
   }
+  WaveArgs WA;
+  WA.descs = t->wave_descs.p;
+  WA.fwd = (const uint2*)t->wave_fwd.p;
+  WA.bwd = t->wave_bwd.p;
+  WA.level_off = t->wave_level_off.p;
+  WA.frow = t->wave_frow.p;
+  WA.brow = t->wave_brow.p;
+  WA.wcache = t->wcache.p + t->wave_slot_base;
+  WA.post = t->post.p + t->wave_slot_base;
+  WA.pair_logprob = t->pair_logprob.p;
+  WA.first = 0;
+  WA.max_states = WA.max_width = 0;
   TransArgs T;
   T.buckets = t->t_buckets.p;
   T.tile_base = t->t_tile_base.p;
@@ -792,7 +822,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.pre_weights = t->use_transpose ? 1u : 0u;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
-  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned &&
+  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty() &&
                             !(getenv("CARMEL_HIP_ESTEP_STREAMS") && atoi(getenv("CARMEL_HIP_ESTEP_STREAMS")) <= 1);
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
@@ -828,6 +858,8 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
       }
   } else {
     if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
+    // the one-per-wavefront lattices first: their launch is the long pole, the lane waves fill in beside and after it
+    for (auto& wc : t->lat.wave_classes) HIPCHK(launch_wave_sweep(WA, wc, s));
     for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
   }
   if (bundles_beside)

@@ -104,6 +104,10 @@ struct carmel_hip_trainer {
   DevBuf<uint2_t> in_arcs, out_arcs;
   DevBuf<uint32_t> in_off, out_off, level_off, pair_start, pair_final, pair_id;
   DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
+  DevBuf<WaveDesc> wave_descs;  // one lattice per wavefront (lattice.hpp)
+  DevBuf<uint2_t> wave_fwd;
+  DevBuf<uint32_t> wave_bwd, wave_level_off, wave_frow, wave_brow;
+  uint64_t wave_slot_base = 0, wave_records = 0;
   DevBuf<LaneGroup> lane_groups;
   DevBuf<uint2_t> lane_fwd;
   // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path

@@ -693,6 +693,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   BuildOptions bo;
   bo.lane_states = 0;
   bo.small_pairs = 1;
+  bo.wave = false;  // the sampler walks bundles (one lattice each)
   bo.threads = 0;
   std::string err;
   if (!build_lattices(t->w, t->corpus, bo, g->lat, err)) return fail(CARMEL_HIP_ERR_ARG, err);

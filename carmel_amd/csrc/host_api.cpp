@@ -51,6 +51,8 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   if (lane_states >= 0) opt.lane_states = (uint32_t)lane_states;
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
+  if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;
+  if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
     delete h;
     return CARMEL_HIP_ERR_ARG;
@@ -150,6 +152,37 @@ void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32
     classes5[5 * k + 4] = L.classes[k].serial ? 1u : 0u;
   }
   if (has_deriv) std::memcpy(has_deriv, L.has_deriv.data(), L.has_deriv.size());
+}
+
+// one-per-wavefront lattices (WaveDesc, lattice.hpp).  dims6 = n_waves, forward records, backward records, level
+// entries, n_classes, wave_slot_base; null pointers are skipped.  descs64 = raw 64-byte WaveDesc records; fwd as (x, y)
+// u32 pairs; bwd_arc = the WFST arc of every backward record (0xffffffff: padding); classes4 = first, count, max_states,
+// max_width per launch class.
+void carmel_hip_host_export_waves(carmel_hip_host_lattices* h, uint64_t* dims6, void* descs64, uint32_t* fwd, uint32_t* bwd,
+                                  uint32_t* bwd_arc, uint32_t* level_off, uint32_t* frow, uint32_t* brow, uint32_t* classes4) {
+  const LatticeSet& L = h->L;
+  if (dims6) {
+    dims6[0] = L.waves.size();
+    dims6[1] = L.wave_fwd.size();
+    dims6[2] = L.wave_bwd.size();
+    dims6[3] = L.wave_level_off.size();
+    dims6[4] = L.wave_classes.size();
+    dims6[5] = L.wave_slot_base;
+  }
+  if (descs64) std::memcpy(descs64, L.waves.data(), L.waves.size() * sizeof(WaveDesc));
+  if (fwd) std::memcpy(fwd, L.wave_fwd.data(), L.wave_fwd.size() * sizeof(uint2_t));
+  if (bwd) std::memcpy(bwd, L.wave_bwd.data(), L.wave_bwd.size() * 4);
+  if (bwd_arc) std::memcpy(bwd_arc, L.wave_bwd_arc.data(), L.wave_bwd_arc.size() * 4);
+  if (level_off) std::memcpy(level_off, L.wave_level_off.data(), L.wave_level_off.size() * 4);
+  if (frow) std::memcpy(frow, L.wave_frow.data(), L.wave_frow.size() * 4);
+  if (brow) std::memcpy(brow, L.wave_brow.data(), L.wave_brow.size() * 4);
+  if (classes4)
+    for (size_t k = 0; k < L.wave_classes.size(); ++k) {
+      classes4[4 * k + 0] = L.wave_classes[k].first;
+      classes4[4 * k + 1] = L.wave_classes[k].count;
+      classes4[4 * k + 2] = L.wave_classes[k].max_states;
+      classes4[4 * k + 3] = L.wave_classes[k].max_width;
+    }
 }
 
 void carmel_hip_host_free(carmel_hip_host_lattices* h) { delete h; }

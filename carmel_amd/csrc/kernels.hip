@@ -280,6 +280,146 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   }
 }
 
+// ---------------- wave sweep: one lattice per wavefront, the lanes over the arcs of a level ----------------
+// (WaveDesc, lattice.hpp.)  All forward / backward values of the lattice live in LDS.  A level's log-sums are formed by
+// the 64 lanes together: every arc's term t = value[other end] + weight goes into its state's running maximum with an LDS
+// atomic max, then exp(t - max) into its state's sum with an LDS atomic add, and one lane per state finishes
+// value = max + log(sum) -- the streaming logsumexp of the lane kernel, term order aside.  The backward pass overwrites
+// alpha[s] with beta[s] in place once level(s) is done (every destination lies in a later level and already holds beta)
+// and writes each arc's posterior exp(alpha[src] + w + beta'[dst]) at the arc's own row position: coalesced, like its
+// weight reads.  The forward pass reads its weights at the arcs' backward positions: a gather, but inside the lattice's own
+// stretch of wcache and -- a level's in-arcs being the previous levels' out-arcs -- mostly inside a few rows of it.
+// The records and weights of the next level's first row are requested before the current level is finished (they depend
+// on nothing the sweep computes).
+__device__ __forceinline__ void lds_max_f64(double* p, double v) {
+  __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_add_f64(double* p, double v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const WaveDesc d = A.descs[A.first + blockIdx.x];
+  const uint32_t lane = threadIdx.x;
+  double* val = lds;
+  double* mx = lds + A.max_states;
+  double* sm = mx + A.max_width;
+  const uint32_t* __restrict__ lvl = A.level_off + d.level_base;
+  const uint32_t* __restrict__ frow = A.frow + d.level_base;
+  const uint32_t* __restrict__ brow = A.brow + d.level_base;
+  const uint2* __restrict__ f = A.fwd + d.fwd_base + lane;
+  const uint32_t* __restrict__ b = A.bwd + d.bwd_base + lane;
+  const double* __restrict__ wc = A.wcache + d.bwd_base;
+  double* __restrict__ post = A.post + d.bwd_base + lane;
+  const uint32_t S = d.n_states, NL = d.n_levels;
+  for (uint32_t s = lane; s < S; s += 64) val[s] = NEG_INF;
+  for (uint32_t i = lane; i < d.max_width; i += 64) {
+    mx[i] = NEG_INF;
+    sm[i] = 0.0;
+  }
+  __syncthreads();
+  if (lane == 0) val[0] = 0.0;
+  __syncthreads();
+  // ---------- forward ----------
+  {
+    uint2 rec = f[(size_t)frow[1] * 64];  // level 1 always has a row (the start has out-arcs)
+    double w = wc[rec.y];
+    uint32_t r0 = frow[1], r1 = frow[2];
+    for (uint32_t l = 1; l < NL; ++l) {
+      const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
+      // the next level's first row, requested now
+      const uint32_t nr0 = r1, nr1 = (l + 1 < NL) ? frow[l + 2] : r1;
+      const uint2 nrec = f[(size_t)(nr0 < frow[NL] ? nr0 : r0) * 64];
+      const double nw = wc[nrec.y];
+      const bool v0 = (rec.x & WAVE_VALID) != 0;
+      const uint32_t dr0 = (rec.x >> 16) & 0x3fffu;
+      const double t0 = v0 ? val[rec.x & 0xffffu] + w : NEG_INF;
+      if (t0 > NEG_INF) lds_max_f64(&mx[dr0], t0);
+      for (uint32_t r = r0 + 1; r < r1; ++r) {
+        const uint2 q = f[(size_t)r * 64];
+        const double t = (q.x & WAVE_VALID) ? val[q.x & 0xffffu] + wc[q.y] : NEG_INF;
+        if (t > NEG_INF) lds_max_f64(&mx[(q.x >> 16) & 0x3fffu], t);
+      }
+      __syncthreads();
+      if (t0 > NEG_INF) lds_add_f64(&sm[dr0], K_EXP(t0 - mx[dr0]));
+      for (uint32_t r = r0 + 1; r < r1; ++r) {
+        const uint2 q = f[(size_t)r * 64];
+        const double t = (q.x & WAVE_VALID) ? val[q.x & 0xffffu] + wc[q.y] : NEG_INF;
+        const uint32_t dr = (q.x >> 16) & 0x3fffu;
+        if (t > NEG_INF) lds_add_f64(&sm[dr], K_EXP(t - mx[dr]));
+      }
+      __syncthreads();
+      for (uint32_t i = lane; i < ns; i += 64) {
+        const double m = mx[i], a = sm[i];
+        val[s0 + i] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));
+        mx[i] = NEG_INF;
+        sm[i] = 0.0;
+      }
+      __syncthreads();
+      rec = nrec;
+      w = nw;
+      r0 = nr0;
+      r1 = nr1;
+    }
+  }
+  // ---------- ln p(pair); beta'[goal] = ln(weight) - ln p folds "* weight / prob" (derivations.h:445) ----------
+  if (lane == 0) {
+    const double lp = val[S - 1];
+    A.pair_logprob[d.pair] = lp;
+    val[S - 1] = (lp == NEG_INF) ? NEG_INF : d.logw - lp;
+  }
+  __syncthreads();
+  // ---------- backward + posteriors ----------
+  {
+    uint32_t r0 = brow[1], r1 = brow[2];
+    uint32_t x = b[(size_t)r0 * 64];
+    double w = wc[(size_t)r0 * 64 + lane];
+    for (uint32_t k = 1; k < NL; ++k) {
+      const uint32_t l = NL - 1 - k;
+      const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
+      const uint32_t nr0 = r1, nr1 = (k + 1 < NL) ? brow[k + 2] : r1;
+      const size_t np = (size_t)(nr0 < brow[NL] ? nr0 : r0) * 64;
+      const uint32_t nx = b[np];
+      const double nw = wc[np + lane];
+      const bool v0 = (x & WAVE_VALID) != 0;
+      const uint32_t sr0 = (x >> 16) & 0x3fffu;
+      const double t0 = v0 ? w + val[x & 0xffffu] : NEG_INF;
+      const double a0 = v0 ? val[s0 + sr0] : NEG_INF;
+      if (t0 > NEG_INF) lds_max_f64(&mx[sr0], t0);
+      post[(size_t)r0 * 64] = K_EXP(a0 + t0);  // exp(-inf) = 0 on padding and dead arcs
+      for (uint32_t r = r0 + 1; r < r1; ++r) {
+        const uint32_t q = b[(size_t)r * 64];
+        const bool v = (q & WAVE_VALID) != 0;
+        const uint32_t sr = (q >> 16) & 0x3fffu;
+        const double t = v ? wc[(size_t)r * 64 + lane] + val[q & 0xffffu] : NEG_INF;
+        const double a = v ? val[s0 + sr] : NEG_INF;
+        if (t > NEG_INF) lds_max_f64(&mx[sr], t);
+        post[(size_t)r * 64] = K_EXP(a + t);
+      }
+      __syncthreads();
+      if (t0 > NEG_INF) lds_add_f64(&sm[sr0], K_EXP(t0 - mx[sr0]));
+      for (uint32_t r = r0 + 1; r < r1; ++r) {
+        const uint32_t q = b[(size_t)r * 64];
+        const uint32_t sr = (q >> 16) & 0x3fffu;
+        const double t = (q & WAVE_VALID) ? wc[(size_t)r * 64 + lane] + val[q & 0xffffu] : NEG_INF;
+        if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));
+      }
+      __syncthreads();
+      for (uint32_t i = lane; i < ns; i += 64) {
+        const double m = mx[i], a = sm[i];
+        val[s0 + i] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));  // beta[s] replaces alpha[s]
+        mx[i] = NEG_INF;
+        sm[i] = 0.0;
+      }
+      __syncthreads();
+      x = nx;
+      w = nw;
+      r0 = nr0;
+      r1 = nr1;
+    }
+  }
+}
+
 // ---------------- bundle sweep: one workgroup per bundle of lattices, level-synchronous ----------------
 // forward (alpha in LDS), then backward in place: a state's alpha is read once when its level is processed and
 // replaced by its beta; destinations lie in later levels and already hold beta.  Posteriors go to post[] at the
@@ -1111,6 +1251,21 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
     case 2: return launch_lane_variant<6, 3, false>(A, lc.count, lds, stream);
     default: return launch_lane_variant<4, 2, false>(A, lc.count, lds, stream);
   }
+}
+
+hipError_t launch_wave_sweep(const WaveArgs& A0, const LatticeSet::WaveClass& wc, hipStream_t stream) {
+  WaveArgs A = A0;
+  A.first = wc.first;
+  A.max_states = wc.max_states;
+  A.max_width = wc.max_width;
+  const size_t lds = ((size_t)wc.max_states + 2 * (size_t)wc.max_width) * sizeof(double);
+  static size_t lds_set = 0;
+  if (lds > 64 * 1024 && lds > lds_set) {
+    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  hipLaunchKernelGGL(sweep_wave_kernel, dim3(wc.count), dim3(64), lds, stream, A);
+  return hipGetLastError();
 }
 
 hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, hipStream_t stream) {

@@ -50,6 +50,21 @@ struct SweepArgs {
   uint32_t first_bundle;
 };
 
+// one lattice per wavefront (WaveDesc, lattice.hpp)
+struct WaveArgs {
+  const WaveDesc* descs;
+  const uint2* fwd;
+  const uint32_t* bwd;
+  const uint32_t* level_off;
+  const uint32_t* frow;
+  const uint32_t* brow;
+  const double* wcache;   // at the first wave slot: the weight of the arc at backward position k
+  double* post;           // at the first wave slot: posteriors, same positions
+  double* pair_logprob;
+  uint32_t first;         // first descriptor of this launch
+  uint32_t max_states, max_width;  // LDS of this launch: (max_states + 2 * max_width) doubles
+};
+
 struct ReduceArgs {
   const uint64_t* arc_off;    // arc a's slots: slot_pos[arc_off[a] .. arc_off[a+1])
   const uint64_t* slot_pos;   // position in post[] of each slot, grouped by arc
@@ -144,6 +159,7 @@ struct MstepArgs {
 
 hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
+hipError_t launch_wave_sweep(const WaveArgs& A, const LatticeSet::WaveClass& wc, hipStream_t stream);
 // the two passes of either direction as separate launches: the bucket passes cover the whole model, the tile passes a
 // range of tiles (so that chunks of the corpus can flow through weights-in / sweep / posteriors-out side by side)
 hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream);

@@ -609,15 +609,38 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     while (w < L.span + 1) w <<= 1;
     return (w <= opt.lane_window && w < L.n_states) ? w : 0u;
   };
+  // one lattice per wavefront (WaveDesc): what no lane takes, when it is wide enough to feed 64 lanes; and what a windowed
+  // lane would take, when the corpus is too small to fill the chip one lattice per lane
+  std::vector<uint32_t> wave;
+  auto wave_fits = [&](const PairLattice& L, double min_width) {
+    if (!opt.wave || L.cyclic || L.n_states < 2 || L.n_states > WAVE_MAX_STATES || L.n_levels < 2) return false;
+    if ((double)L.edges.size() < min_width * (double)(L.n_levels - 1)) return false;
+    std::vector<uint32_t> cnt((size_t)L.n_levels, 0);
+    for (uint32_t st = 0; st < L.n_states; ++st)
+      if (++cnt[L.level[st]] > WAVE_MAX_WIDTH) return false;
+    return true;
+  };
+  uint64_t n_windowed = 0;
   for (uint32_t p : kept) {
     const PairLattice& L = lats[p];
+    if (!L.cyclic && opt.lane_states && L.edges.size() <= LANE_POS_MAX && L.n_states <= LANE_STATE_MASK &&
+        (window_of(L) || L.n_states <= opt.lane_states))
+      ++n_windowed;  // every lattice a lane would take, plain or windowed: is that enough one-per-lane work to fill the chip?
+  }
+  for (uint32_t p : kept) {
+    const PairLattice& L = lats[p];
+    const bool plain_lane = opt.lane_states && L.n_states <= opt.lane_states && L.n_states <= LANE_STATE_MASK && L.edges.size() <= LANE_POS_MAX;
     if (L.cyclic)
       cyc.push_back(p);
-    else if (opt.lane_states && window_of(L) && L.edges.size() <= LANE_POS_MAX)
-      lane_win.push_back(p);
-    else if (opt.lane_states && L.n_states <= opt.lane_states && L.n_states <= LANE_STATE_MASK &&
-             L.edges.size() <= LANE_POS_MAX)
+    else if (opt.lane_states && window_of(L) && L.edges.size() <= LANE_POS_MAX) {
+      if (!plain_lane && n_windowed < opt.wave_lane_threshold && wave_fits(L, opt.wave_lane_min_width))
+        wave.push_back(p);
+      else
+        lane_win.push_back(p);
+    } else if (plain_lane)
       lane.push_back(p);
+    else if (wave_fits(L, opt.wave_min_width))
+      wave.push_back(p);
     else if (L.n_states * 4 <= opt.small_states)
       small.push_back(p);
     else
@@ -767,6 +790,180 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       out.max_levels = std::max<uint64_t>(out.max_levels, lats[p].n_levels);
     }
   }
+  // ---- wave lattices: one per wavefront (WaveDesc) ----
+  if (!wave.empty()) {
+    // launch order: largest first (the long ones start early, the short ones fill the tail); classes by LDS need
+    std::stable_sort(wave.begin(), wave.end(), [&](uint32_t a, uint32_t b) {
+      if (lats[a].n_states != lats[b].n_states) return lats[a].n_states > lats[b].n_states;
+      return lats[a].edges.size() > lats[b].edges.size();
+    });
+    const size_t nw = wave.size();
+    out.waves.resize(nw);
+    std::vector<uint64_t> frows(nw + 1, 0), brows(nw + 1, 0), lbase(nw + 1, 0);
+    {
+      std::atomic<size_t> next(0);
+      auto count = [&]() {
+        std::vector<uint32_t> fi, bo, width;
+        for (;;) {
+          const size_t k = next.fetch_add(16);
+          if (k >= nw) break;
+          for (size_t q = k; q < std::min(nw, k + 16); ++q) {
+            const PairLattice& L = lats[wave[q]];
+            fi.assign(L.n_levels, 0);
+            bo.assign(L.n_levels, 0);
+            width.assign(L.n_levels, 0);
+            for (auto& e : L.edges) {
+              fi[L.level[e.dst]]++;
+              bo[L.level[e.src]]++;
+            }
+            for (uint32_t st = 0; st < L.n_states; ++st) width[L.level[st]]++;
+            uint64_t rf = 0, rb = 0;
+            uint32_t mw = 0;
+            for (uint32_t l = 0; l < L.n_levels; ++l) {
+              rf += (fi[l] + 63) / 64;
+              rb += (bo[l] + 63) / 64;
+              mw = std::max(mw, width[l]);
+            }
+            frows[q + 1] = rf;
+            brows[q + 1] = rb;
+            lbase[q + 1] = (uint64_t)L.n_levels + 1;
+            out.waves[q].max_width = mw;
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      const int ntw = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, nw / 16));
+      for (int t = 1; t < ntw; ++t) th.emplace_back(count);
+      count();
+      for (auto& t : th) t.join();
+    }
+    for (size_t q = 0; q < nw; ++q) {
+      frows[q + 1] += frows[q];
+      brows[q + 1] += brows[q];
+      lbase[q + 1] += lbase[q];
+    }
+    if (lbase[nw] > 0xffffffffull || brows[nw] * 64 > (1ull << 40)) {
+      err = "wave lattice set too large";
+      return false;
+    }
+    out.wave_fwd.assign(frows[nw] * 64, uint2_t{0, 0});
+    out.wave_bwd.assign(brows[nw] * 64, 0u);
+    out.wave_bwd_arc.assign(brows[nw] * 64, 0xffffffffu);
+    out.wave_level_off.resize(lbase[nw]);
+    out.wave_frow.resize(lbase[nw]);
+    out.wave_brow.resize(lbase[nw]);
+    {
+      std::atomic<size_t> next(0);
+      auto fill = [&]() {
+        std::vector<uint32_t> order, newid, ioff, ooff, cur, ie, oe, bpos;
+        for (;;) {
+          const size_t k = next.fetch_add(8);
+          if (k >= nw) break;
+          for (size_t q = k; q < std::min(nw, k + 8); ++q) {
+            const uint32_t p = wave[q];
+            const PairLattice& L = lats[p];
+            WaveDesc& D = out.waves[q];
+            const uint32_t mw = D.max_width;
+            std::memset(&D, 0, sizeof D);
+            D.max_width = mw;
+            D.fwd_base = frows[q] * 64;
+            D.bwd_base = brows[q] * 64;
+            D.n_states = L.n_states;
+            D.n_levels = L.n_levels;
+            D.level_base = (uint32_t)lbase[q];
+            D.pair = p;
+            const double wt = c.weight.empty() ? 1.0 : c.weight[p];
+            D.logw = wt > 0 ? std::log(wt) : -std::numeric_limits<double>::infinity();
+            D.n_arcs = L.edges.size();
+            const uint32_t S = L.n_states, NL = L.n_levels;
+            const size_t E = L.edges.size();
+            order.resize(S);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return L.level[a] < L.level[b]; });
+            newid.resize(S);
+            for (uint32_t i = 0; i < S; ++i) newid[order[i]] = i;
+            uint32_t* lo = out.wave_level_off.data() + D.level_base;
+            uint32_t* fr = out.wave_frow.data() + D.level_base;
+            uint32_t* br = out.wave_brow.data() + D.level_base;
+            std::fill(lo, lo + NL + 1, 0u);
+            for (uint32_t st = 0; st < S; ++st) lo[L.level[st] + 1]++;
+            for (uint32_t l = 0; l < NL; ++l) lo[l + 1] += lo[l];
+            ioff.assign((size_t)S + 1, 0);
+            ooff.assign((size_t)S + 1, 0);
+            for (auto& e : L.edges) {
+              ioff[newid[e.dst] + 1]++;
+              ooff[newid[e.src] + 1]++;
+            }
+            for (uint32_t i = 0; i < S; ++i) {
+              ioff[i + 1] += ioff[i];
+              ooff[i + 1] += ooff[i];
+            }
+            ie.resize(E);
+            oe.resize(E);
+            cur.assign(ioff.begin(), ioff.end() - 1);
+            for (uint32_t i = 0; i < E; ++i) ie[cur[newid[L.edges[i].dst]]++] = i;
+            cur.assign(ooff.begin(), ooff.end() - 1);
+            for (uint32_t i = 0; i < E; ++i) oe[cur[newid[L.edges[i].src]]++] = i;
+            // backward stream: step k = source level NL - 1 - k (the goal's level has no out-arcs: step 0 is empty)
+            bpos.resize(E);
+            uint32_t* B = out.wave_bwd.data() + D.bwd_base;
+            uint32_t* BA = out.wave_bwd_arc.data() + D.bwd_base;
+            uint32_t row = 0;
+            for (uint32_t kk = 0; kk < NL; ++kk) {
+              br[kk] = row;
+              const uint32_t l = NL - 1 - kk;
+              const uint32_t a0 = ooff[lo[l]], a1 = ooff[lo[l + 1]];
+              for (uint32_t a = a0; a < a1; ++a) {
+                const auto& e = L.edges[oe[a]];
+                const uint32_t pos = row * 64 + (a - a0);
+                bpos[oe[a]] = pos;
+                B[pos] = newid[e.dst] | ((newid[e.src] - lo[l]) << 16) | WAVE_VALID;
+                BA[pos] = e.arc;
+              }
+              row += (a1 - a0 + 63) / 64;
+            }
+            br[NL] = row;
+            uint2_t* F = out.wave_fwd.data() + D.fwd_base;
+            row = 0;
+            for (uint32_t l = 0; l < NL; ++l) {
+              fr[l] = row;
+              const uint32_t a0 = ioff[lo[l]], a1 = ioff[lo[l + 1]];
+              for (uint32_t a = a0; a < a1; ++a) {
+                const auto& e = L.edges[ie[a]];
+                F[(size_t)row * 64 + (a - a0)] = uint2_t{newid[e.src] | ((newid[e.dst] - lo[l]) << 16) | WAVE_VALID, bpos[ie[a]]};
+              }
+              row += (a1 - a0 + 63) / 64;
+            }
+            fr[NL] = row;
+          }
+        }
+      };
+      std::vector<std::thread> th;
+      const int ntw = (int)std::min<size_t>((size_t)nt, std::max<size_t>(1, nw / 8));
+      for (int t = 1; t < ntw; ++t) th.emplace_back(fill);
+      fill();
+      for (auto& t : th) t.join();
+    }
+    // classes by LDS need (8 B per state + 16 B per state of the widest level), largest first
+    const uint32_t caps[] = {WAVE_MAX_STATES, 8192, 4096, 2048, 1024, 512, 0};
+    size_t i = 0;
+    for (int kc = 0; caps[kc] && i < nw; ++kc) {
+      size_t j = i;
+      uint32_t ms = 0, mw = 0;
+      while (j < nw && out.waves[j].n_states > caps[kc + 1]) {
+        ms = std::max(ms, out.waves[j].n_states);
+        mw = std::max(mw, out.waves[j].max_width);
+        ++j;
+      }
+      if (j > i) out.wave_classes.push_back(LatticeSet::WaveClass{(uint32_t)i, (uint32_t)(j - i), ms, mw});
+      i = j;
+    }
+    for (uint32_t p : wave) {
+      out.wave_states += lats[p].n_states;
+      out.wave_arcs += lats[p].edges.size();
+      out.max_levels = std::max<uint64_t>(out.max_levels, lats[p].n_levels);
+    }
+  }
   std::vector<BundlePlan> plans;
   {
     BundlePlan cur;
@@ -862,8 +1059,8 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       return false;
     }
   }
-  out.total_arcs = arc_base + out.lane_arcs;
-  out.total_states = off_base - nb + out.lane_states;
+  out.total_arcs = arc_base + out.lane_arcs + out.wave_arcs;
+  out.total_states = off_base - nb + out.lane_states + out.wave_states;
   out.in_arcs.resize(arc_base);
   out.out_arcs.resize(arc_base);
   out.in_off.resize(off_base);
@@ -977,12 +1174,16 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   phase("layout (lanes, bundles)");
   // ---- posterior slots sorted by WFST arc id (counting sort) ----
   {
-    const uint64_t nlane = out.lane_bwd.size();
+    // positions: [lane records | (up to a tile boundary) wave records | bundle out-arcs]
+    const uint64_t nlane_rec = out.lane_bwd.size();
+    const uint64_t nwave = out.wave_bwd.size();
+    out.wave_slot_base = nwave ? (nlane_rec + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE : nlane_rec;
+    const uint64_t nlane = out.wave_slot_base + nwave;  // first bundle slot
     out.n_post = nlane + out.out_arcs.size();
     // counting sort by arc id, stable in slot order.  Threads own contiguous arc ranges: each scans every record (a
     // sequential read) and handles the records of its own arcs, so counters and output stay private and local.
     std::vector<uint64_t> cnt(w.n_arcs + 1, 0);
-    const int ns = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (nlane + out.out_arcs.size()) / (1u << 16)));
+    const int ns = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (nlane_rec + nwave + out.out_arcs.size()) / (1u << 16)));
     auto arc_lo = [&](int t) { return (uint64_t)((__uint128_t)w.n_arcs * (uint64_t)t / (uint64_t)ns); };
     auto in_threads = [&](const std::function<void(int)>& f) {
       std::vector<std::thread> th;
@@ -992,10 +1193,12 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     };
     in_threads([&](int t) {
       const uint64_t lo = arc_lo(t), hi = arc_lo(t + 1);
-      for (uint64_t k = 0; k < nlane; ++k) {
+      for (uint64_t k = 0; k < nlane_rec; ++k) {
         const uint2_t r = out.lane_bwd[k];
         if ((r.x & LANE_VALID) && r.y >= lo && r.y < hi) cnt[r.y + 1]++;
       }
+      for (const uint32_t a : out.wave_bwd_arc)
+        if (a != 0xffffffffu && a >= lo && a < hi) cnt[(uint64_t)a + 1]++;
       for (const auto& r : out.out_arcs)
         if (r.y >= lo && r.y < hi) cnt[r.y + 1]++;
     });
@@ -1005,9 +1208,13 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     out.slot_pos.resize(total);
     in_threads([&](int t) {
       const uint64_t lo = arc_lo(t), hi = arc_lo(t + 1);
-      for (uint64_t k = 0; k < nlane; ++k) {
+      for (uint64_t k = 0; k < nlane_rec; ++k) {
         const uint2_t r = out.lane_bwd[k];
         if ((r.x & LANE_VALID) && r.y >= lo && r.y < hi) out.slot_pos[cnt[r.y]++] = k;
+      }
+      for (uint64_t k = 0; k < nwave; ++k) {
+        const uint32_t a = out.wave_bwd_arc[k];
+        if (a != 0xffffffffu && a >= lo && a < hi) out.slot_pos[cnt[a]++] = out.wave_slot_base + k;
       }
       for (uint64_t k = 0; k < out.out_arcs.size(); ++k) {
         const uint32_t a = out.out_arcs[k].y;

@@ -113,7 +113,50 @@ struct LaneGroup {        // mirrored on the device, 32 bytes
 };
 static_assert(sizeof(LaneGroup) == 32, "LaneGroup layout");
 
+// Wave lattices: one lattice per WAVEFRONT, its 64 lanes over the ARCS of a level -- for lattices that are too large for a
+// lane (or too few to fill the chip one per lane) and wide enough to feed 64 lanes.  States are numbered level-major
+// (level = longest path from the start: the start is state 0, the goal the last state).  Two record streams, both cut
+// into ROWS of 64 records that never straddle a level (padded with invalid records), so that a row is one coalesced load
+// and all of its arcs are independent:
+//   forward : the in-arcs of the states of level 1, 2, ... (by destination); record {x, y}:
+//             x = source state (bits 0..15) | destination - first state of its level (bits 16..29) | WAVE_VALID,
+//             y = the arc's position in the backward stream (relative to the lattice) = where its weight lies in wcache;
+//   backward: the out-arcs of the states of level L-2, L-3, ... 0 (by source); record
+//             x = destination state (bits 0..15) | source - first state of its level (bits 16..29) | WAVE_VALID.
+// A backward record's position is also the arc's posterior slot and the place of its weight in wcache (the blocked
+// transposition delivers the weights there), so the backward pass streams rows and the forward pass gathers inside the
+// lattice's own stretch of wcache.  The sweep keeps all forward / backward values of the lattice in LDS (8 B per state)
+// and adds up a level's log-sums with LDS atomics (max, then sum of exp): no segment bookkeeping, any arc order.
+static const uint32_t WAVE_VALID = 0x80000000u;
+static const uint32_t WAVE_MAX_STATES = 16384, WAVE_MAX_WIDTH = 1024;
+struct WaveDesc {         // mirrored on the device, 64 bytes
+  uint64_t fwd_base;      // into wave_fwd[]
+  uint64_t bwd_base;      // into wave_bwd[]; slot of a backward record = wave_slot_base + bwd_base + its position
+  uint32_t n_states, n_levels;
+  uint32_t level_base;    // into wave_level_off[] / wave_frow[] / wave_brow[] (n_levels + 1 entries each)
+  uint32_t pair;          // corpus pair
+  uint32_t max_width;     // states of its widest level
+  uint32_t pad0;
+  double logw;            // ln(pair weight)
+  uint64_t n_arcs;
+  uint64_t pad1;
+};
+static_assert(sizeof(WaveDesc) == 64, "WaveDesc layout");
+
 struct LatticeSet {
+  std::vector<WaveDesc> waves;
+  std::vector<uint2_t> wave_fwd;
+  std::vector<uint32_t> wave_bwd;
+  std::vector<uint32_t> wave_bwd_arc;    // host only: WFST arc id of every backward record (0xffffffff: padding)
+  std::vector<uint32_t> wave_level_off;  // per lattice n_levels + 1: first state of level l
+  std::vector<uint32_t> wave_frow;       // ... first forward row (of 64 records) of destination level l
+  std::vector<uint32_t> wave_brow;       // ... first backward row of step k (source level n_levels - 1 - k)
+  struct WaveClass {
+    uint32_t first, count, max_states, max_width;
+  };
+  std::vector<WaveClass> wave_classes;   // launches, largest lattices first
+  uint64_t wave_slot_base = 0;           // position of the first wave slot in post[] / wcache[] (a tile boundary)
+  uint64_t wave_states = 0, wave_arcs = 0;
   std::vector<BundleDesc> bundles;
   std::vector<uint2_t> in_arcs, out_arcs;
   std::vector<uint32_t> in_off, out_off;  // bundle-relative arc offsets
@@ -183,6 +226,11 @@ struct BuildOptions {
                                    // many LDS rows whatever their size (up to 1023 states); 0 disables windowed groups
   uint32_t lane_window_min = 40;   // ... but only lattices above this many states: below ~20 KB of LDS per wave the
                                    // occupancy is not what bounds the sweep (and the GPU builder covers those)
+  bool wave = true;                // one-lattice-per-wavefront layout for large / few-and-wide lattices (WaveDesc)
+  double wave_min_width = 4.0;     // ... for lattices that no lane takes: at least this many arcs per level on average
+                                   // (narrower ones stay in bundles: 64 of them side by side feed a wave better)
+  double wave_lane_min_width = 16.0;    // ... for lattices a WINDOWED lane would take: this wide, and only when the corpus
+  uint64_t wave_lane_threshold = 262144;  // has fewer lane-sized lattices than this (4 waves per SIMD of one-per-lane work)
   uint32_t lane_chunks = 1;        // chunks per lane class (see LatticeSet::LaneClass); 1 = one launch per class (default:
                                    // measured on config 4, four chunks on four streams overlap their kernels but finish no
                                    // sooner -- the E-step is bound by its total HBM traffic -- and cost 46 us of extra tails)

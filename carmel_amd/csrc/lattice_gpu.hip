@@ -1013,6 +1013,14 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   // ---- the rest of the trainer's image ----
   t->use_transpose = true;
   t->lane_records = n_rec;
+  t->wave_descs.release();  // (a one-per-lane corpus has no one-per-wavefront lattices)
+  t->wave_fwd.release();
+  t->wave_bwd.release();
+  t->wave_level_off.release();
+  t->wave_frow.release();
+  t->wave_brow.release();
+  t->wave_slot_base = n_rec;
+  t->wave_records = 0;
   HIPCHK(t->post.alloc(n_post));
   HIPCHK(t->wcache.alloc(n_rec));
   t->bundles.release();

@@ -390,6 +390,10 @@ void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32
 void carmel_hip_host_transpose(carmel_hip_host_lattices* h, uint64_t* dims6, void* buckets24, uint64_t* tile_base,
                                uint16_t* b_arc, uint16_t* b_rank, uint32_t* b_src, uint16_t* t_pos, uint32_t* t_src,
                                uint32_t* split_arcs, uint64_t* arc_off, uint64_t* slot_pos);
+/* the one-lattice-per-wavefront layout (csrc/lattice.hpp, WaveDesc); dims6 = n_waves, forward records, backward records,
+ * level entries, n_classes, first wave slot; null pointers are skipped */
+void carmel_hip_host_export_waves(carmel_hip_host_lattices* h, uint64_t* dims6, void* descs64, uint32_t* fwd, uint32_t* bwd,
+                                  uint32_t* bwd_arc, uint32_t* level_off, uint32_t* frow, uint32_t* brow, uint32_t* classes4);
 void carmel_hip_host_free(carmel_hip_host_lattices* h);
 
 #ifdef __cplusplus

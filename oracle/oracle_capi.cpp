@@ -531,12 +531,13 @@ int orc_bench_em_fit_check(orc_wfst* wh, orc_corpus* ch, int norm_group, int ite
     const size_t na = fb.arcs.t.size();
     if (iters < 1) iters = 1;
     // ---- serial leg: the reference's own loop ----
+    bool record_lp = true;  // (the E-steps after the first maximize run on other weights: their ln p are not the answers)
     auto estep_serial = [&](size_t n) {
       for (auto& a : fb.arcs.t) a.counts = LW();
       double sum = 0;
       for (size_t p = 0; p < n; ++p) {
         const double lpp = fb.derivs[p].collect_counts(fb.arcs).w;
-        if (pair_lp) pair_lp[p] = lpp;
+        if (pair_lp && record_lp) pair_lp[p] = lpp;
         sum += lpp;
       }
       return sum;
@@ -549,6 +550,7 @@ int orc_bench_em_fit_check(orc_wfst* wh, orc_corpus* ch, int norm_group, int ite
     auto t3 = clk::now();
     if (counts_ln)
       for (size_t k = 0; k < na; ++k) counts_ln[k] = fb.arcs.t[k].counts.w;
+    record_lp = false;
     // maximize changes the weights; the E-steps above all ran on the same ones
     for (int i = 0; i < iters; ++i) {
       if (i) estep_serial(n_all);  // fresh counts for a repeat (not timed below)

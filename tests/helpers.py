@@ -19,6 +19,11 @@ LANE_DTYPE = np.dtype([("stream_base", "<u8"), ("maxlen", "<u4"), ("n_lanes", "<
                        ("max_states", "<u4"), ("window", "<u4"), ("spill_row", "<u4")])
 assert LANE_DTYPE.itemsize == 32
 LANE_LAST, LANE_VALID = 0x80000000, 0x40000000
+WAVE_DTYPE = np.dtype([("fwd_base", "<u8"), ("bwd_base", "<u8"), ("n_states", "<u4"), ("n_levels", "<u4"),
+                       ("level_base", "<u4"), ("pair", "<u4"), ("max_width", "<u4"), ("pad0", "<u4"), ("logw", "<f8"),
+                       ("n_arcs", "<u8"), ("pad1", "<u8")])
+assert WAVE_DTYPE.itemsize == 64
+WAVE_VALID = 0x80000000
 
 
 def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, lane_states=-1):
@@ -64,6 +69,15 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, la
                                   ptr(tr["b_rank"]), ptr(tr["b_src"]), ptr(tr["t_pos"]), ptr(tr["t_src"]),
                                   ptr(tr["split_arcs"]), ptr(tr["arc_off"]), ptr(tr["slot_pos"]))
     out["transpose"] = tr
+    wd = np.zeros(6, np.uint64)
+    lib.carmel_hip_host_export_waves(h, ptr(wd), *([null] * 8))
+    nw, nfw, nbw, nlv, nwc, wbase = (int(x) for x in wd)
+    wv = dict(descs=np.zeros(nw, WAVE_DTYPE), fwd=np.zeros((nfw, 2), np.uint32), bwd=np.zeros(nbw, np.uint32),
+              bwd_arc=np.zeros(nbw, np.uint32), level_off=np.zeros(nlv, np.uint32), frow=np.zeros(nlv, np.uint32),
+              brow=np.zeros(nlv, np.uint32), classes=np.zeros((nwc, 4), np.uint32), slot_base=wbase)
+    lib.carmel_hip_host_export_waves(h, null, ptr(wv["descs"]), ptr(wv["fwd"]), ptr(wv["bwd"]), ptr(wv["bwd_arc"]),
+                                     ptr(wv["level_off"]), ptr(wv["frow"]), ptr(wv["brow"]), ptr(wv["classes"]))
+    out["waves"] = wv
     lib.carmel_hip_host_free(h)
     out.update(n_kept=int(dims[6]), n_cyclic=int(dims[7]), explored_states=int(dims[8]), explored_arcs=int(dims[9]))
     return out
@@ -150,6 +164,61 @@ def numpy_sweep(img, logw, n_pairs_total):
                     col[s & wm] = _lse(terms)
                     s, terms = s - 1, []
             assert s == -1 and not terms
+    # one-per-wavefront lattices: rows of 64 records per level, exactly as sweep_wave_kernel consumes them (WaveDesc)
+    wv = img.get("waves")
+    for d in (wv["descs"] if wv is not None else []):
+        S, NL, lb = int(d["n_states"]), int(d["n_levels"]), int(d["level_base"])
+        lvl, frow, brow = (wv[k][lb:lb + NL + 1].astype(np.int64) for k in ("level_off", "frow", "brow"))
+        fb, bb = int(d["fwd_base"]), int(d["bwd_base"])
+        assert lvl[0] == 0 and lvl[1] == 1 and lvl[NL] == S and lvl[NL] - lvl[NL - 1] == 1  # start and goal alone on their levels
+        assert int(np.diff(lvl).max()) == int(d["max_width"])
+        val = np.full(S, np.nan)
+        val[0] = 0.0
+        n_valid = 0
+        for l in range(1, NL):
+            assert frow[l + 1] > frow[l]
+            terms = {}
+            for r in range(frow[l], frow[l + 1]):
+                for x, y in wv["fwd"][fb + r * 64:fb + r * 64 + 64]:
+                    if not x & WAVE_VALID:
+                        continue
+                    src, dr = int(x & 0xffff), int((x >> 16) & 0x3fff)
+                    assert src < lvl[l] and dr < lvl[l + 1] - lvl[l], "in-arc source must lie in an earlier level"
+                    arc = int(wv["bwd_arc"][bb + int(y)])  # the forward record points at the arc's backward position
+                    assert arc != 0xffffffff and wv["bwd"][bb + int(y)] & WAVE_VALID
+                    assert int(wv["bwd"][bb + int(y)] & 0xffff) == lvl[l] + dr  # ... whose record names the same destination
+                    terms.setdefault(dr, []).append(val[src] + logw[arc])
+                    n_valid += 1
+            assert sorted(terms) == list(range(lvl[l + 1] - lvl[l]))  # every state of the level has an in-arc
+            for dr, ts in terms.items():
+                val[lvl[l] + dr] = _lse(ts)
+        assert n_valid == int(d["n_arcs"])
+        lp = val[S - 1]
+        plp[int(d["pair"])] = lp
+        val[S - 1] = float(d["logw"]) - lp
+        n_valid = 0
+        for k in range(1, NL):
+            l = NL - 1 - k
+            assert brow[k + 1] > brow[k]
+            terms = {}
+            for r in range(brow[k], brow[k + 1]):
+                for j in range(64):
+                    pos = bb + r * 64 + j
+                    x = int(wv["bwd"][pos])
+                    if not x & WAVE_VALID:
+                        assert wv["bwd_arc"][pos] == 0xffffffff
+                        continue
+                    dst, sr = x & 0xffff, (x >> 16) & 0x3fff
+                    assert dst >= lvl[l + 1] and sr < lvl[l + 1] - lvl[l], "out-arc destination must lie in a later level"
+                    arc = int(wv["bwd_arc"][pos])
+                    t = logw[arc] + val[dst]
+                    counts[arc] += np.exp(val[lvl[l] + sr] + t)
+                    terms.setdefault(sr, []).append(t)
+                    n_valid += 1
+            assert sorted(terms) == list(range(lvl[l + 1] - lvl[l]))
+            for sr, ts in terms.items():
+                val[lvl[l] + sr] = _lse(ts)
+        assert n_valid == int(d["n_arcs"])
     for b in img["bundles"]:
         ns = int(b["n_states"])
         ob, ib, ab = int(b["off_base"]), int(b["in_base"]), int(b["out_base"])

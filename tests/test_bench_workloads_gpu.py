@@ -111,8 +111,7 @@ def test_c5_full_size_parallel_sweep_properties():
         assert len(s) > 0
         ends = _match(label[b:e], ref[b:e], nxt[b:e], 0, s, 0)
         assert len(s) in ends, "forest %d: the sample is not a derivation of the forest" % f
-    n_and = np.diff(node_off.astype(np.int64))
-    assert all(0 < len(s) <= n_and[f] for f, s in enumerate(samples))
+    assert all(len(s) > 0 for s in samples)  # (a shared sub-forest can be expanded more than once: no upper bound by nodes)
     # (b)
     uses = np.bincount(np.concatenate([np.asarray(s, np.int64) for s in samples]), minlength=n_rules).astype(np.float64)
     gid, gsize, p0, prior = group_priors(n_rules, goff, grule, lw, 0.1)  # alpha * p0 * |group| (gibbs.hpp:589-592)

@@ -197,3 +197,44 @@ def test_clustered_workloads_layout_matches_oracle(oracle, name, pairs):
     np.testing.assert_allclose(plp, r["pair_logprob"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
     assert abs(counts[w.dst == w.final].sum() - c.n_pairs) < 1e-9 * c.n_pairs
+
+
+@pytest.mark.parametrize("seed,lane_states", [(1, 0), (2, 0), (3, 12), (4, 0), (5, 20)])
+def test_wave_layout_on_ambiguous_lattices(oracle, monkeypatch, seed, lane_states):
+    """the one-lattice-per-wavefront layout (WaveDesc) forced onto small ambiguous corpora (every acyclic lattice no lane
+    takes, however narrow): rows of 64 records that never straddle a level, forward records pointing at their arc's backward
+    position; swept in numpy exactly as sweep_wave_kernel walks it, against the oracle -- and the blocked transposition
+    tables must cover the wave slots (weights in, posteriors out) exactly"""
+    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
+    c = synth.random_walk_corpus(w, 120, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    img = host_lattices(w, c, small_pairs=8, small_states=1024, lane_states=lane_states)
+    wv = img["waves"]
+    assert len(wv["descs"]) > 10 and wv["slot_base"] % H.TRANS_TILE == 0
+    cyc = sum(1 for b in img["bundles"] if b["flags"] & 1)
+    assert len(img["bundles"]) == cyc  # bundles are left with the cyclic lattices only
+    r = oracle.estimate(ow, oc)
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    ok = r["has_deriv"]
+    np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
+    # transposition: every wave slot gets its arc's weight, and the posteriors written there come back to its arc
+    tr = img["transpose"]
+    n_post = tr["n_post"]
+    arc_at = np.full(n_post, -1, np.int64)
+    for a in range(tr["n_arcs"]):
+        arc_at[tr["slot_pos"][int(tr["arc_off"][a]):int(tr["arc_off"][a + 1])]] = a
+    nb = len(wv["bwd"])
+    wslots = arc_at[wv["slot_base"]:wv["slot_base"] + nb]
+    want = np.where(wv["bwd_arc"] == 0xffffffff, -1, wv["bwd_arc"].astype(np.int64))
+    assert np.array_equal(wslots, want)
+    rng = np.random.default_rng(seed)
+    logw = rng.normal(size=tr["n_arcs"])
+    wc = H.transpose_weights(tr, logw, wv["slot_base"] + nb)
+    valid = want >= 0
+    assert np.array_equal(wc[wv["slot_base"]:][valid], logw[want[valid]])
+    post = rng.random(n_post)
+    got = H.transpose_counts(tr, post)
+    v = arc_at >= 0
+    np.testing.assert_allclose(got, np.bincount(arc_at[v], weights=post[v], minlength=tr["n_arcs"]), rtol=1e-12, atol=0)

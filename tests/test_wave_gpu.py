@@ -1,0 +1,61 @@
+"""GPU: the one-lattice-per-wavefront sweep (sweep_wave_kernel; csrc/lattice.hpp WaveDesc) through the C-ABI against the
+oracle -- forced onto small ambiguous corpora of every shape (CARMEL_HIP_WAVE_MIN_WIDTH=0: however narrow), on weighted
+pairs, on lattices with zero-weight arcs, and where it is the natural choice: few long, wide lattices."""
+import numpy as np
+import pytest
+
+from carmel_amd import synth
+from carmel_amd.model import Corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(oracle, w, c, iters=3, expect_waves=True, rtol=1e-7):
+    from carmel_amd.trainer import HipForwardBackward
+    fb = HipForwardBackward(w, c)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    ow.normalize(0, 0.0)
+    for it in range(iters):
+        lp, wlp = fb.estimate(per_pair=True)
+        r = oracle.estimate(ow, oc)
+        ok = r["has_deriv"]
+        assert np.array_equal(ok, fb.has_deriv.astype(bool))
+        np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=rtol, atol=1e-12)
+        assert lp == pytest.approx(r["sum_logprob"], rel=1e-10, abs=1e-9)
+        assert wlp == pytest.approx(r["sum_weighted_logprob"], rel=1e-10, abs=1e-9)
+        fb.maximize(1.0)
+        ow.set_logw(fb.weights())
+    fb.close()
+
+
+@pytest.mark.parametrize("seed,lane_states", [(1, "0"), (2, "0"), (3, "12"), (4, "0"), (5, "20"), (6, "0")])
+def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states):
+    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", lane_states)
+    w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
+    c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
+    rng = np.random.default_rng(seed)
+    c.weight[:] = rng.uniform(0.5, 3.0, c.n_pairs)  # pair weights: beta'[goal] = ln weight - ln p
+    if seed == 6:  # zero-weight arcs: -inf terms must neither poison a state's sum nor count
+        w.logw[rng.random(w.n_arcs) < 0.15] = -np.inf
+    _check(oracle, w, c)
+
+
+def test_wide_levels_span_several_rows(oracle, monkeypatch):
+    """levels with more than 64 arcs (several rows per level) and states with many in-arcs: a dense little transducer"""
+    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", "0")
+    w = synth.clustered_wfst(12 * 4 + 1, 48, members=12, n_sym=6, n_in_sym=3, seed=21)
+    c = synth.clustered_walk_corpus(w, 60, 48, members=12, min_arcs=3, max_arcs=25, seed=21)
+    _check(oracle, w, c, iters=2)
+
+
+def test_long_workload_slice_uses_the_wave_sweep(oracle):
+    """bench.py --config long: these lattices go one per wavefront by the builder's own rule"""
+    from carmel_amd.trainer import HipForwardBackward
+    w, c = synth.make_config("long", n_pairs=40)
+    fb = HipForwardBackward(w, c)
+    assert fb.lattice_stats.n_windowed_pairs == 0 and fb.lattice_stats.n_bundles == 40
+    fb.close()
+    _check(oracle, w, c, iters=2)
