@@ -194,6 +194,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;  // A/B: 0 = no one-per-wavefront lattices (bundles as before)
+  if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
   if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
   {
     // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;
@@ -251,6 +252,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->wave_brow.upload(L.wave_brow, s));
   t->wave_slot_base = L.wave_slot_base;
   t->wave_records = L.wave_bwd.size();
+  HIPCHK(t->wave_spill.alloc(L.wave_spill_states));
   {
     // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
     const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
@@ -341,7 +343,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
                     t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes() + t->t_xc.bytes() +
                     t->wave_descs.bytes() + t->wave_fwd.bytes() + t->wave_bwd.bytes() + t->wave_level_off.bytes() +
-                    t->wave_frow.bytes() + t->wave_brow.bytes();
+                    t->wave_frow.bytes() + t->wave_brow.bytes() + t->wave_spill.bytes();
   std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
   std::vector<uint2_t>().swap(L.lane_fwd);
@@ -360,7 +362,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
             (unsigned long long)L.lane_arcs, L.lane_groups.size(), L.lane_classes.size(), L.bundles.size(), L.classes.size(),
             (unsigned long long)L.total_arcs, (int)L.lane_tiles_aligned);
     for (auto& lc : L.lane_classes) fprintf(stderr, "timing:   lane piece groups=%u %s=%u tiles=%u\n", lc.count, lc.windowed ? "window" : "max_states", lc.max_states, lc.tile_count);
-    for (auto& wc : L.wave_classes) fprintf(stderr, "timing:   wave class count=%u max_states=%u max_width=%u\n", wc.count, wc.max_states, wc.max_width);
+    for (auto& wc : L.wave_classes) fprintf(stderr, "timing:   wave class count=%u max_states=%u max_width=%u ring=%u\n", wc.count, wc.max_states, wc.max_width, wc.ring);
     for (auto& lc : L.classes) fprintf(stderr, "timing:   bundle class count=%u block=%u max_states=%u serial=%d\n", lc.count, lc.block, lc.max_states, (int)lc.serial);
   }
   t->have_lattices = true;
@@ -791,6 +793,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   WA.wcache = t->wcache.p + t->wave_slot_base;
   WA.post = t->post.p + t->wave_slot_base;
   WA.pair_logprob = t->pair_logprob.p;
+  WA.spill = t->wave_spill.p;
   WA.first = 0;
   WA.max_states = WA.max_width = 0;
   TransArgs T;
@@ -858,9 +861,30 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
       }
   } else {
     if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
-    // the one-per-wavefront lattices first: their launch is the long pole, the lane waves fill in beside and after it
-    for (auto& wc : t->lat.wave_classes) HIPCHK(launch_wave_sweep(WA, wc, s));
-    for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+    // the one-per-wavefront lattices: every class is one launch of single-wave workgroups with its own LDS size -- side by
+    // side on the chunk streams (a class alone rarely fills the chip), the lane waves beside them on the main stream
+    if (t->lat.wave_classes.size() > 1 || (!t->lat.wave_classes.empty() && !t->lat.lane_classes.empty())) {
+      HIPCHK(hipEventRecord(t->ev_w, s));
+      const int NS = carmel_hip_trainer::N_CHUNK_STREAMS;
+      bool used[carmel_hip_trainer::N_CHUNK_STREAMS] = {false, false, false, false};
+      size_t k = 0;
+      for (auto& wc : t->lat.wave_classes) {
+        hipStream_t cs = t->cstream[k % NS];
+        if (!used[k % NS]) HIPCHK(hipStreamWaitEvent(cs, t->ev_w, 0));
+        used[k % NS] = true;
+        HIPCHK(launch_wave_sweep(WA, wc, cs));
+        ++k;
+      }
+      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+      for (int q = 0; q < NS; ++q)
+        if (used[q]) {
+          HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
+          HIPCHK(hipStreamWaitEvent(s, t->cev[q], 0));
+        }
+    } else {
+      for (auto& wc : t->lat.wave_classes) HIPCHK(launch_wave_sweep(WA, wc, s));
+      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+    }
   }
   if (bundles_beside)
     HIPCHK(hipStreamWaitEvent(s, t->ev_b1, 0));

@@ -108,6 +108,7 @@ struct carmel_hip_trainer {
   DevBuf<uint2_t> wave_fwd;
   DevBuf<uint32_t> wave_bwd, wave_level_off, wave_frow, wave_brow;
   uint64_t wave_slot_base = 0, wave_records = 0;
+  DevBuf<double> wave_spill;
   DevBuf<LaneGroup> lane_groups;
   DevBuf<uint2_t> lane_fwd;
   // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path

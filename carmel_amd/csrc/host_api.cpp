@@ -52,6 +52,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
   if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;
+  if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;
   if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
     delete h;
@@ -181,7 +182,7 @@ void carmel_hip_host_export_waves(carmel_hip_host_lattices* h, uint64_t* dims6, 
       classes4[4 * k + 0] = L.wave_classes[k].first;
       classes4[4 * k + 1] = L.wave_classes[k].count;
       classes4[4 * k + 2] = L.wave_classes[k].max_states;
-      classes4[4 * k + 3] = L.wave_classes[k].max_width;
+      classes4[4 * k + 3] = L.wave_classes[k].max_width | (L.wave_classes[k].ring << 16);
     }
 }
 

@@ -297,13 +297,20 @@ __device__ __forceinline__ void lds_max_f64(double* p, double v) {
 __device__ __forceinline__ void lds_add_f64(double* p, double v) {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+// RING (WaveDesc::ring): the values live in a ring of `ring` LDS slots (state s at s mod ring; no arc spans more states than
+// that), the forward values are parked in the lattice's stretch of A.spill and come back one level at a time (al[]) for the
+// posteriors.  Records and weights are requested TWO levels ahead of their use.
+template <bool RING>
 __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WaveDesc d = A.descs[A.first + blockIdx.x];
   const uint32_t lane = threadIdx.x;
   double* val = lds;
-  double* mx = lds + A.max_states;
+  double* mx = lds + A.max_states;  // (RING: max_states = the ring)
   double* sm = mx + A.max_width;
+  double* al = sm + A.max_width;    // RING only: alpha of the states of the level the backward pass is at
+  const uint32_t rm = RING ? d.ring - 1u : 0xffffffffu;
+  double* __restrict__ spill = RING ? A.spill + d.spill_base : nullptr;
   const uint32_t* __restrict__ lvl = A.level_off + d.level_base;
   const uint32_t* __restrict__ frow = A.frow + d.level_base;
   const uint32_t* __restrict__ brow = A.brow + d.level_base;
@@ -312,87 +319,121 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   const double* __restrict__ wc = A.wcache + d.bwd_base;
   double* __restrict__ post = A.post + d.bwd_base + lane;
   const uint32_t S = d.n_states, NL = d.n_levels;
-  for (uint32_t s = lane; s < S; s += 64) val[s] = NEG_INF;
+  if (RING) {
+    for (uint32_t s = lane; s <= rm; s += 64) val[s] = NEG_INF;
+  } else {
+    for (uint32_t s = lane; s < S; s += 64) val[s] = NEG_INF;
+  }
   for (uint32_t i = lane; i < d.max_width; i += 64) {
     mx[i] = NEG_INF;
     sm[i] = 0.0;
   }
   __syncthreads();
-  if (lane == 0) val[0] = 0.0;
+  if (lane == 0) {
+    val[0] = 0.0;
+    if (RING) spill[0] = 0.0;
+  }
   __syncthreads();
   // ---------- forward ----------
   {
-    uint2 rec = f[(size_t)frow[1] * 64];  // level 1 always has a row (the start has out-arcs)
-    double w = wc[rec.y];
-    uint32_t r0 = frow[1], r1 = frow[2];
+    const uint32_t rend = frow[NL];
+    // the first rows of this level (r0), the next (r1) and the one after (r2): records and weights in registers
+    uint32_t r0 = frow[1], r1 = frow[2], r2 = NL > 2 ? frow[3] : r1;
+    uint2 rec0 = f[(size_t)r0 * 64], rec1 = f[(size_t)(r1 < rend ? r1 : r0) * 64];
+    double w0 = wc[rec0.y], w1 = wc[rec1.y];
     for (uint32_t l = 1; l < NL; ++l) {
       const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
-      // the next level's first row, requested now
-      const uint32_t nr0 = r1, nr1 = (l + 1 < NL) ? frow[l + 2] : r1;
-      const uint2 nrec = f[(size_t)(nr0 < frow[NL] ? nr0 : r0) * 64];
-      const double nw = wc[nrec.y];
-      const bool v0 = (rec.x & WAVE_VALID) != 0;
-      const uint32_t dr0 = (rec.x >> 16) & 0x3fffu;
-      const double t0 = v0 ? val[rec.x & 0xffffu] + w : NEG_INF;
+      const uint32_t r3 = (l + 3 <= NL) ? frow[l + 3] : rend;
+      const uint2 rec2 = f[(size_t)(r2 < rend ? r2 : r0) * 64];
+      const double w2 = wc[rec2.y];
+      const bool v0 = (rec0.x & WAVE_VALID) != 0;
+      const uint32_t dr0 = (rec0.x >> 16) & 0x3fffu;
+      const double t0 = v0 ? val[(rec0.x & 0xffffu) & rm] + w0 : NEG_INF;
       if (t0 > NEG_INF) lds_max_f64(&mx[dr0], t0);
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint2 q = f[(size_t)r * 64];
-        const double t = (q.x & WAVE_VALID) ? val[q.x & 0xffffu] + wc[q.y] : NEG_INF;
+        const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;
         if (t > NEG_INF) lds_max_f64(&mx[(q.x >> 16) & 0x3fffu], t);
       }
       __syncthreads();
       if (t0 > NEG_INF) lds_add_f64(&sm[dr0], K_EXP(t0 - mx[dr0]));
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint2 q = f[(size_t)r * 64];
-        const double t = (q.x & WAVE_VALID) ? val[q.x & 0xffffu] + wc[q.y] : NEG_INF;
+        const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;
         const uint32_t dr = (q.x >> 16) & 0x3fffu;
         if (t > NEG_INF) lds_add_f64(&sm[dr], K_EXP(t - mx[dr]));
       }
       __syncthreads();
       for (uint32_t i = lane; i < ns; i += 64) {
         const double m = mx[i], a = sm[i];
-        val[s0 + i] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));
+        const double v = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));
+        val[(s0 + i) & rm] = v;
+        if (RING) spill[s0 + i] = v;
         mx[i] = NEG_INF;
         sm[i] = 0.0;
       }
       __syncthreads();
-      rec = nrec;
-      w = nw;
-      r0 = nr0;
-      r1 = nr1;
+      rec0 = rec1;
+      w0 = w1;
+      rec1 = rec2;
+      w1 = w2;
+      r0 = r1;
+      r1 = r2;
+      r2 = r3;
     }
   }
   // ---------- ln p(pair); beta'[goal] = ln(weight) - ln p folds "* weight / prob" (derivations.h:445) ----------
   if (lane == 0) {
-    const double lp = val[S - 1];
+    const double lp = val[(S - 1) & rm];
     A.pair_logprob[d.pair] = lp;
-    val[S - 1] = (lp == NEG_INF) ? NEG_INF : d.logw - lp;
+    val[(S - 1) & rm] = (lp == NEG_INF) ? NEG_INF : d.logw - lp;
   }
+  if (RING) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's spill stores before its re-reads
   __syncthreads();
   // ---------- backward + posteriors ----------
   {
-    uint32_t r0 = brow[1], r1 = brow[2];
-    uint32_t x = b[(size_t)r0 * 64];
-    double w = wc[(size_t)r0 * 64 + lane];
+    const uint32_t rend = brow[NL];
+    uint32_t r0 = brow[1], r1 = brow[2], r2 = NL > 2 ? brow[3] : r1;
+    size_t p1 = (size_t)(r1 < rend ? r1 : r0) * 64;
+    uint32_t x0 = b[(size_t)r0 * 64], x1 = b[p1];
+    double w0 = wc[(size_t)r0 * 64 + lane], w1 = wc[p1 + lane];
+    // RING: alpha of the level of this step (a0v) and of the next step (a1v), one state per lane (levels are at most a
+    // wavefront wide)
+    double a0v = NEG_INF, a1v = NEG_INF;
+    if (RING) {
+      const uint32_t la = NL - 2, sa = lvl[la], na = lvl[la + 1] - sa;
+      a0v = lane < na ? spill[sa + lane] : NEG_INF;
+      if (NL > 2) {
+        const uint32_t sb = lvl[la - 1], nb = lvl[la] - sb;
+        a1v = lane < nb ? spill[sb + lane] : NEG_INF;
+      }
+      al[lane] = a0v;
+      __syncthreads();
+    }
     for (uint32_t k = 1; k < NL; ++k) {
       const uint32_t l = NL - 1 - k;
       const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
-      const uint32_t nr0 = r1, nr1 = (k + 1 < NL) ? brow[k + 2] : r1;
-      const size_t np = (size_t)(nr0 < brow[NL] ? nr0 : r0) * 64;
-      const uint32_t nx = b[np];
-      const double nw = wc[np + lane];
-      const bool v0 = (x & WAVE_VALID) != 0;
-      const uint32_t sr0 = (x >> 16) & 0x3fffu;
-      const double t0 = v0 ? w + val[x & 0xffffu] : NEG_INF;
-      const double a0 = v0 ? val[s0 + sr0] : NEG_INF;
+      const uint32_t r3 = (k + 3 <= NL) ? brow[k + 3] : rend;
+      const size_t p2 = (size_t)(r2 < rend ? r2 : r0) * 64;
+      const uint32_t x2 = b[p2];
+      const double w2 = wc[p2 + lane];
+      double a2v = NEG_INF;
+      if (RING && l >= 2) {
+        const uint32_t sc = lvl[l - 2], nc = lvl[l - 1] - sc;
+        a2v = lane < nc ? spill[sc + lane] : NEG_INF;
+      }
+      const bool v0 = (x0 & WAVE_VALID) != 0;
+      const uint32_t sr0 = (x0 >> 16) & 0x3fffu;
+      const double t0 = v0 ? w0 + val[(x0 & 0xffffu) & rm] : NEG_INF;
+      const double al0 = v0 ? (RING ? al[sr0] : val[s0 + sr0]) : NEG_INF;
       if (t0 > NEG_INF) lds_max_f64(&mx[sr0], t0);
-      post[(size_t)r0 * 64] = K_EXP(a0 + t0);  // exp(-inf) = 0 on padding and dead arcs
+      post[(size_t)r0 * 64] = K_EXP(al0 + t0);  // exp(-inf) = 0 on padding and dead arcs
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint32_t q = b[(size_t)r * 64];
         const bool v = (q & WAVE_VALID) != 0;
         const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = v ? wc[(size_t)r * 64 + lane] + val[q & 0xffffu] : NEG_INF;
-        const double a = v ? val[s0 + sr] : NEG_INF;
+        const double t = v ? wc[(size_t)r * 64 + lane] + val[(q & 0xffffu) & rm] : NEG_INF;
+        const double a = v ? (RING ? al[sr] : val[s0 + sr]) : NEG_INF;
         if (t > NEG_INF) lds_max_f64(&mx[sr], t);
         post[(size_t)r * 64] = K_EXP(a + t);
       }
@@ -401,21 +442,26 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint32_t q = b[(size_t)r * 64];
         const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = (q & WAVE_VALID) ? wc[(size_t)r * 64 + lane] + val[q & 0xffffu] : NEG_INF;
+        const double t = (q & WAVE_VALID) ? wc[(size_t)r * 64 + lane] + val[(q & 0xffffu) & rm] : NEG_INF;
         if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));
       }
       __syncthreads();
       for (uint32_t i = lane; i < ns; i += 64) {
         const double m = mx[i], a = sm[i];
-        val[s0 + i] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));  // beta[s] replaces alpha[s]
+        val[(s0 + i) & rm] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));  // beta[s] (full form: replaces alpha[s])
         mx[i] = NEG_INF;
         sm[i] = 0.0;
       }
+      if (RING) al[lane] = a1v;  // the next step's level
       __syncthreads();
-      x = nx;
-      w = nw;
-      r0 = nr0;
-      r1 = nr1;
+      x0 = x1;
+      w0 = w1;
+      x1 = x2;
+      w1 = w2;
+      a1v = a2v;
+      r0 = r1;
+      r1 = r2;
+      r2 = r3;
     }
   }
 }
@@ -1256,15 +1302,22 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
 hipError_t launch_wave_sweep(const WaveArgs& A0, const LatticeSet::WaveClass& wc, hipStream_t stream) {
   WaveArgs A = A0;
   A.first = wc.first;
-  A.max_states = wc.max_states;
   A.max_width = wc.max_width;
+  if (wc.ring) {
+    if (!A.spill) return hipErrorInvalidValue;
+    A.max_states = wc.ring;
+    const size_t lds = ((size_t)wc.ring + 3 * (size_t)wc.max_width) * sizeof(double);
+    hipLaunchKernelGGL(sweep_wave_kernel<true>, dim3(wc.count), dim3(64), lds, stream, A);
+    return hipGetLastError();
+  }
+  A.max_states = wc.max_states;
   const size_t lds = ((size_t)wc.max_states + 2 * (size_t)wc.max_width) * sizeof(double);
   static size_t lds_set = 0;
   if (lds > 64 * 1024 && lds > lds_set) {
-    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set = lds;
   }
-  hipLaunchKernelGGL(sweep_wave_kernel, dim3(wc.count), dim3(64), lds, stream, A);
+  hipLaunchKernelGGL(sweep_wave_kernel<false>, dim3(wc.count), dim3(64), lds, stream, A);
   return hipGetLastError();
 }
 

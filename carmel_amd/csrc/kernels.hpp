@@ -61,6 +61,7 @@ struct WaveArgs {
   const double* wcache;   // at the first wave slot: the weight of the arc at backward position k
   double* post;           // at the first wave slot: posteriors, same positions
   double* pair_logprob;
+  double* spill;          // ring lattices: parked forward values (WaveDesc::spill_base)
   uint32_t first;         // first descriptor of this launch
   uint32_t max_states, max_width;  // LDS of this launch: (max_states + 2 * max_width) doubles
 };

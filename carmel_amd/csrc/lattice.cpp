@@ -803,7 +803,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     {
       std::atomic<size_t> next(0);
       auto count = [&]() {
-        std::vector<uint32_t> fi, bo, width;
+        std::vector<uint32_t> fi, bo, width, lo_, nid_;
         for (;;) {
           const size_t k = next.fetch_add(16);
           if (k >= nw) break;
@@ -828,6 +828,20 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
             brows[q + 1] = rb;
             lbase[q + 1] = (uint64_t)L.n_levels + 1;
             out.waves[q].max_width = mw;
+            // how far apart are an arc's ends in the level-major numbering?  (ring form)
+            uint32_t ring = 0;
+            if (mw <= WAVE_RING_WIDTH && opt.wave_ring) {
+              lo_.assign((size_t)L.n_levels + 1, 0);
+              for (uint32_t l = 0; l < L.n_levels; ++l) lo_[l + 1] = lo_[l] + width[l];
+              nid_.resize(L.n_states);
+              for (uint32_t st = 0; st < L.n_states; ++st) nid_[st] = lo_[L.level[st]]++;
+              uint32_t sp = 1;
+              for (auto& e : L.edges) sp = std::max(sp, nid_[e.dst] - nid_[e.src]);
+              uint32_t r = 8;
+              while (r < sp) r <<= 1;
+              if (r <= WAVE_RING_MAX && r < L.n_states) ring = r;
+            }
+            out.waves[q].ring = ring;
           }
         }
       };
@@ -837,11 +851,43 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       count();
       for (auto& t : th) t.join();
     }
+    {
+      // launch order: ring lattices first (widest ring first), then the full-LDS ones; inside, the largest first
+      std::vector<uint32_t> perm(nw);
+      std::iota(perm.begin(), perm.end(), 0u);
+      std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t ra = out.waves[a].ring, rb = out.waves[b].ring;
+        if ((ra != 0) != (rb != 0)) return ra != 0;
+        return ra > rb;
+      });
+      std::vector<uint32_t> wave2(nw);
+      std::vector<WaveDesc> d2(nw);
+      std::vector<uint64_t> f2(nw + 1, 0), b2(nw + 1, 0), l2(nw + 1, 0);
+      for (size_t q = 0; q < nw; ++q) {
+        wave2[q] = wave[perm[q]];
+        d2[q] = out.waves[perm[q]];
+        f2[q + 1] = frows[perm[q] + 1];
+        b2[q + 1] = brows[perm[q] + 1];
+        l2[q + 1] = lbase[perm[q] + 1];
+      }
+      wave.swap(wave2);
+      out.waves.swap(d2);
+      frows.swap(f2);
+      brows.swap(b2);
+      lbase.swap(l2);
+    }
+    uint64_t spill = 0;
+    std::vector<uint64_t> spill_base(nw, 0);
     for (size_t q = 0; q < nw; ++q) {
       frows[q + 1] += frows[q];
       brows[q + 1] += brows[q];
       lbase[q + 1] += lbase[q];
+      if (out.waves[q].ring) {
+        spill_base[q] = spill;
+        spill += lats[wave[q]].n_states;
+      }
     }
+    out.wave_spill_states = spill;
     if (lbase[nw] > 0xffffffffull || brows[nw] * 64 > (1ull << 40)) {
       err = "wave lattice set too large";
       return false;
@@ -863,9 +909,11 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
             const uint32_t p = wave[q];
             const PairLattice& L = lats[p];
             WaveDesc& D = out.waves[q];
-            const uint32_t mw = D.max_width;
+            const uint32_t mw = D.max_width, ring = D.ring;
             std::memset(&D, 0, sizeof D);
             D.max_width = mw;
+            D.ring = ring;
+            D.spill_base = spill_base[q];
             D.fwd_base = frows[q] * 64;
             D.bwd_base = brows[q] * 64;
             D.n_states = L.n_states;
@@ -944,9 +992,19 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       fill();
       for (auto& t : th) t.join();
     }
-    // classes by LDS need (8 B per state + 16 B per state of the widest level), largest first
-    const uint32_t caps[] = {WAVE_MAX_STATES, 8192, 4096, 2048, 1024, 512, 0};
+    // classes: one per ring size, then the full-LDS lattices by LDS need (8 B per state + 16 B per state of the widest
+    // level), largest first
     size_t i = 0;
+    while (i < nw && out.waves[i].ring) {
+      size_t j = i;
+      uint32_t ms = 0;
+      while (j < nw && out.waves[j].ring == out.waves[i].ring) ms = std::max(ms, out.waves[j++].n_states);
+      LatticeSet::WaveClass wc{(uint32_t)i, (uint32_t)(j - i), ms, WAVE_RING_WIDTH};
+      wc.ring = out.waves[i].ring;
+      out.wave_classes.push_back(wc);
+      i = j;
+    }
+    const uint32_t caps[] = {WAVE_MAX_STATES, 8192, 4096, 2048, 1024, 512, 0};
     for (int kc = 0; caps[kc] && i < nw; ++kc) {
       size_t j = i;
       uint32_t ms = 0, mw = 0;

@@ -129,6 +129,11 @@ static_assert(sizeof(LaneGroup) == 32, "LaneGroup layout");
 // and adds up a level's log-sums with LDS atomics (max, then sum of exp): no segment bookkeeping, any arc order.
 static const uint32_t WAVE_VALID = 0x80000000u;
 static const uint32_t WAVE_MAX_STATES = 16384, WAVE_MAX_WIDTH = 1024;
+// Ring form (WaveDesc::ring): when no arc spans more than R states of the level-major numbering and no level is wider than
+// a wavefront, the sweep keeps only a ring of R values in LDS -- a kilobyte instead of 8 B per state, so a CU holds its full
+// complement of waves (the sweep of one lattice is a chain of dependent LDS round trips: what hides it is other lattices)
+// -- and parks the forward values in a global column for the posteriors of the backward pass (+16 B per state).
+static const uint32_t WAVE_RING_MAX = 1024, WAVE_RING_WIDTH = 64;
 struct WaveDesc {         // mirrored on the device, 64 bytes
   uint64_t fwd_base;      // into wave_fwd[]
   uint64_t bwd_base;      // into wave_bwd[]; slot of a backward record = wave_slot_base + bwd_base + its position
@@ -136,10 +141,10 @@ struct WaveDesc {         // mirrored on the device, 64 bytes
   uint32_t level_base;    // into wave_level_off[] / wave_frow[] / wave_brow[] (n_levels + 1 entries each)
   uint32_t pair;          // corpus pair
   uint32_t max_width;     // states of its widest level
-  uint32_t pad0;
+  uint32_t ring;          // 0: every state's value lives in LDS; R (a power of two): a ring of R values, state s at s mod R
   double logw;            // ln(pair weight)
   uint64_t n_arcs;
-  uint64_t pad1;
+  uint64_t spill_base;    // ring lattices: first state in the global column of parked forward values (wave_spill)
 };
 static_assert(sizeof(WaveDesc) == 64, "WaveDesc layout");
 
@@ -153,7 +158,9 @@ struct LatticeSet {
   std::vector<uint32_t> wave_brow;       // ... first backward row of step k (source level n_levels - 1 - k)
   struct WaveClass {
     uint32_t first, count, max_states, max_width;
+    uint32_t ring = 0;  // > 0: every member sweeps through a ring of this many values (max_states is not used then)
   };
+  uint64_t wave_spill_states = 0;        // doubles of the parked forward values of the ring lattices
   std::vector<WaveClass> wave_classes;   // launches, largest lattices first
   uint64_t wave_slot_base = 0;           // position of the first wave slot in post[] / wcache[] (a tile boundary)
   uint64_t wave_states = 0, wave_arcs = 0;
@@ -226,6 +233,7 @@ struct BuildOptions {
                                    // many LDS rows whatever their size (up to 1023 states); 0 disables windowed groups
   uint32_t lane_window_min = 40;   // ... but only lattices above this many states: below ~20 KB of LDS per wave the
                                    // occupancy is not what bounds the sweep (and the GPU builder covers those)
+  bool wave_ring = true;           // ring form of the wave sweep where the lattice allows it (WaveDesc::ring)
   bool wave = true;                // one-lattice-per-wavefront layout for large / few-and-wide lattices (WaveDesc)
   double wave_min_width = 4.0;     // ... for lattices that no lane takes: at least this many arcs per level on average
                                    // (narrower ones stay in bundles: 64 of them side by side feed a wave better)

@@ -1019,6 +1019,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   t->wave_level_off.release();
   t->wave_frow.release();
   t->wave_brow.release();
+  t->wave_spill.release();
   t->wave_slot_base = n_rec;
   t->wave_records = 0;
   HIPCHK(t->post.alloc(n_post));

@@ -20,8 +20,8 @@ LANE_DTYPE = np.dtype([("stream_base", "<u8"), ("maxlen", "<u4"), ("n_lanes", "<
 assert LANE_DTYPE.itemsize == 32
 LANE_LAST, LANE_VALID = 0x80000000, 0x40000000
 WAVE_DTYPE = np.dtype([("fwd_base", "<u8"), ("bwd_base", "<u8"), ("n_states", "<u4"), ("n_levels", "<u4"),
-                       ("level_base", "<u4"), ("pair", "<u4"), ("max_width", "<u4"), ("pad0", "<u4"), ("logw", "<f8"),
-                       ("n_arcs", "<u8"), ("pad1", "<u8")])
+                       ("level_base", "<u4"), ("pair", "<u4"), ("max_width", "<u4"), ("ring", "<u4"), ("logw", "<f8"),
+                       ("n_arcs", "<u8"), ("spill_base", "<u8")])
 assert WAVE_DTYPE.itemsize == 64
 WAVE_VALID = 0x80000000
 
@@ -172,8 +172,29 @@ def numpy_sweep(img, logw, n_pairs_total):
         fb, bb = int(d["fwd_base"]), int(d["bwd_base"])
         assert lvl[0] == 0 and lvl[1] == 1 and lvl[NL] == S and lvl[NL] - lvl[NL - 1] == 1  # start and goal alone on their levels
         assert int(np.diff(lvl).max()) == int(d["max_width"])
-        val = np.full(S, np.nan)
-        val[0] = 0.0
+        # ring form (WaveDesc::ring): state s lives in slot s mod ring -- stale slots are what they are, so an arc reaching
+        # further back than the ring would read another state's value and the comparison with the oracle would fail; the
+        # forward values are parked in `spill` for the posteriors
+        ring = int(d["ring"])
+        if ring:
+            assert ring & (ring - 1) == 0 and int(d["max_width"]) <= 64 and ring < S
+
+        class Ring(object):
+            def __init__(self):
+                self.a = np.full(ring if ring else S, np.nan)
+                self.owner = np.full(ring if ring else S, -1)
+
+            def __getitem__(self, s):
+                k = s % ring if ring else s
+                assert self.owner[k] == s, "ring slot holds another state's value"
+                return self.a[k]
+
+            def __setitem__(self, s, v):
+                k = s % ring if ring else s
+                self.a[k], self.owner[k] = v, s
+        val = Ring()
+        spill = np.full(S, np.nan)
+        val[0] = spill[0] = 0.0
         n_valid = 0
         for l in range(1, NL):
             assert frow[l + 1] > frow[l]
@@ -191,7 +212,7 @@ def numpy_sweep(img, logw, n_pairs_total):
                     n_valid += 1
             assert sorted(terms) == list(range(lvl[l + 1] - lvl[l]))  # every state of the level has an in-arc
             for dr, ts in terms.items():
-                val[lvl[l] + dr] = _lse(ts)
+                val[lvl[l] + dr] = spill[lvl[l] + dr] = _lse(ts)
         assert n_valid == int(d["n_arcs"])
         lp = val[S - 1]
         plp[int(d["pair"])] = lp
@@ -212,7 +233,7 @@ def numpy_sweep(img, logw, n_pairs_total):
                     assert dst >= lvl[l + 1] and sr < lvl[l + 1] - lvl[l], "out-arc destination must lie in a later level"
                     arc = int(wv["bwd_arc"][pos])
                     t = logw[arc] + val[dst]
-                    counts[arc] += np.exp(val[lvl[l] + sr] + t)
+                    counts[arc] += np.exp(spill[lvl[l] + sr] + t)
                     terms.setdefault(sr, []).append(t)
                     n_valid += 1
             assert sorted(terms) == list(range(lvl[l + 1] - lvl[l]))

@@ -276,7 +276,7 @@ def test_clustered_workloads_match_the_oracle(oracle, name, pairs):
 def test_c4a_full_size_properties():
     """bench.py's c4a at full size (10^6 pairs, ~2*10^8 lattice arcs): flow conservation (the expected counts of the arcs into
     the final state sum to the corpus weight; per state, counts in = counts out), EM monotone over three iterations, the
-    weights normalised per (state, input symbol), two E-steps bit-identical"""
+    weights normalised per (state, input symbol), two E-steps identical to 1e-13"""
     from carmel_amd import synth
     from carmel_amd.trainer import HipForwardBackward
     w, c = synth.make_config("c4a")
@@ -289,7 +289,9 @@ def test_c4a_full_size_properties():
         cnt = fb.counts()
         if it == 0:
             fb.estimate()
-            assert np.array_equal(cnt, fb.counts())
+            # (bit-identical but for the hub arcs: an arc used more than 16 384 times is summed in pieces that meet in one
+            # atomic add each -- the clusters next to the start are used by a third of the corpus)
+            np.testing.assert_allclose(cnt, fb.counts(), rtol=1e-13, atol=0)
             assert cnt[w.dst == w.final].sum() == pytest.approx(c.n_pairs, rel=1e-9)
             inflow = np.bincount(w.dst, weights=cnt, minlength=w.n_states)
             outflow = np.bincount(w.src, weights=cnt, minlength=w.n_states)

@@ -29,9 +29,13 @@ def _check(oracle, w, c, iters=3, expect_waves=True, rtol=1e-7):
     fb.close()
 
 
+@pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("seed,lane_states", [(1, "0"), (2, "0"), (3, "12"), (4, "0"), (5, "20"), (6, "0")])
-def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states):
+def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states, ring):
+    """ring = 1: the ring form where a lattice allows it (values in a ring of LDS slots, forward values parked in HBM);
+    ring = 0: every lattice with all of its values in LDS"""
     monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
     monkeypatch.setenv("CARMEL_HIP_LANE_STATES", lane_states)
     w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
     c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
@@ -39,6 +43,13 @@ def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states
     c.weight[:] = rng.uniform(0.5, 3.0, c.n_pairs)  # pair weights: beta'[goal] = ln weight - ln p
     if seed == 6:  # zero-weight arcs: -inf terms must neither poison a state's sum nor count
         w.logw[rng.random(w.n_arcs) < 0.15] = -np.inf
+        # (pairs left without a path of non-zero weight divide by a zero probability in the reference: keep the others)
+        ow = oracle.OracleWfst.from_arrays(w)
+        ow.normalize(0, 0.0)
+        r = oracle.estimate(ow, oracle.OracleCorpus.from_arrays(c))
+        keep = np.nonzero(r["has_deriv"] & np.isfinite(r["pair_logprob"]))[0]
+        assert 50 < len(keep) < c.n_pairs
+        c = c.subset(keep)
     _check(oracle, w, c)
 
 
@@ -51,9 +62,11 @@ def test_wide_levels_span_several_rows(oracle, monkeypatch):
     _check(oracle, w, c, iters=2)
 
 
-def test_long_workload_slice_uses_the_wave_sweep(oracle):
+@pytest.mark.parametrize("ring", ["1", "0"])
+def test_long_workload_slice_uses_the_wave_sweep(oracle, monkeypatch, ring):
     """bench.py --config long: these lattices go one per wavefront by the builder's own rule"""
     from carmel_amd.trainer import HipForwardBackward
+    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
     w, c = synth.make_config("long", n_pairs=40)
     fb = HipForwardBackward(w, c)
     assert fb.lattice_stats.n_windowed_pairs == 0 and fb.lattice_stats.n_bundles == 40
