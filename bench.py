@@ -183,59 +183,74 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
     t_gen = time.time() - t0
     fb = HipForwardBackward(w, c, device=local_rank, host_threads=args.host_threads)
     ls = fb.lattice_stats
-    comm, ext_counts, exchange = None, None, "none"
-    if world > 1:
-        # the library's own exchange (RCCL on the trainer's stream).  Should the communicator not come up on every rank,
-        # all ranks fall back together to torch.distributed on the trainer's device count buffer (round 1's path: two host
-        # synchronisations per step) -- the line then says so in config.parallelism
+    comm, ext_counts, exchange, xinfo = None, None, "none", None
+    loopback = world == 1 and headline and not args.no_exchange_loopback and name in ("c4", "c2", "toy")
+    if world > 1 or loopback:
+        # the library's own exchange (csrc/exchange.cpp: RCCL -- or the transport of --comm-plugin -- on the communicator's
+        # stream beside the count pass).  Should the communicator not come up on every rank, all ranks fall back together
+        # to torch.distributed on the trainer's device count buffer (round 1's path: two host synchronisations per step)
+        # -- the line then says so in config.parallelism
         from carmel_amd.trainer import HipComm
         ok = 0 if os.environ.get("BENCH_FORCE_TORCH_EXCHANGE") else 1  # (test hook for the fallback below)
+        ids = [None]
         try:
-            ids = [HipComm.unique_id() if rank == 0 else None]
+            if rank == 0:
+                ids = ["%s_%d_%d" % (os.path.basename(args.comm_plugin), os.getpid(), int(time.time()))] if args.comm_plugin else [HipComm.unique_id()]
         except Exception as e:  # noqa: BLE001
             ids, ok = [None], 0
             sys.stderr.write("bench.py: library communicator unavailable (%s)\n" % e)
-        dist.broadcast_object_list(ids, src=0)
+        if world > 1:
+            dist.broadcast_object_list(ids, src=0)
         if ids[0] is None:
             ok = 0
         if ok:
             try:
-                comm = HipComm(local_rank, rank, world, ids[0])
+                comm = (HipComm.custom(args.comm_plugin, ids[0], local_rank, rank, world) if args.comm_plugin
+                        else HipComm(local_rank, rank, world, ids[0]))
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 sys.stderr.write("bench.py: rank %d could not join the library communicator (%s)\n" % (rank, e))
-        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:  # every rank joined: one exchange end to end before anything is timed
+        if world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag[0])
+        if ok == 1 and not loopback:  # every rank joined: plan, and one exchange end to end before anything is timed
             try:
+                xinfo = fb.exchange_plan(comm, args.exchange_chunks, args.exchange == "allreduce")
                 fb.estimate_async()
                 fb.allreduce_counts(comm)
             except Exception as e:  # noqa: BLE001
                 ok = 0
                 sys.stderr.write("bench.py: rank %d: the library's exchange failed at enqueue (%s)\n" % (rank, e))
-            # agree BEFORE anybody waits on the stream: a rank whose enqueue failed never joins the collective, and its
+            # agree BEFORE anybody waits on a stream: a rank whose enqueue failed never joins the collective, and its
             # peers would wait for it forever (round-2 advisor finding)
             flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag[0]) == 1:
+            ok = int(flag[0])
+            if ok == 1:
+                fb.maximize(1.0)
                 fb.synchronize()
             elif comm is not None:
                 comm.abort()
                 comm = None
-        if int(flag[0]) == 0:
+        if ok == 0 and not loopback:
             if comm is not None:
                 comm.close()
             comm = None
             ext_counts = torch.zeros(int(w.n_arcs) + 4, dtype=torch.float64, device="cuda")
             fb.use_external_counts(ext_counts.data_ptr())
             exchange = "torch.distributed all-reduce of %d f64 counts per iteration (library communicator unavailable), two host synchronisations per step" % (w.n_arcs + 4)
-        else:
-            exchange = comm.describe(w.n_arcs + 4)
+        elif not loopback:
+            exchange = ("%s: reduce-scatter of the counts in %d arc-range chunks beside the count pass (%.1f MB out per rank), M-step on "
+                        "1/%d of the arcs, all-gather of the weights chunk by chunk into the next count pass (%.1f MB), one small "
+                        "all-reduce (%.0f KB)" % (comm.transport, xinfo["n_chunks"], xinfo["bytes_reduce_scatter"] / 1e6, world,
+                                                  xinfo["bytes_all_gather"] / 1e6, xinfo["bytes_all_reduce"] / 1e3)) if xinfo["sharded"] else (
+                        "%s: all-reduce of %d f64 counts per iteration on the trainer's stream, replicated M-step" % (comm.transport, w.n_arcs + 4))
 
     def step():
         fb.estimate_async()
-        if comm is not None:
-            fb.allreduce_counts(comm)  # stream-ordered: count pass -> exchange -> M-step
+        if comm is not None and not loopback:
+            fb.allreduce_counts(comm)  # stream-ordered: count pass (-> reduce-scatters beside it) -> M-step (-> all-gathers)
         elif ext_counts is not None:
             fb.synchronize()
             dist.all_reduce(ext_counts)
@@ -254,15 +269,52 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
     for _ in range(warmup):
         step()
     fence()
-    kernel_ms, exch_ms = [], []
+    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
         kernel_ms.append(fb.last_kernel_ms())
-        if comm is not None and hasattr(fb, "last_exchange_ms"):
-            exch_ms.append(fb.last_exchange_ms())
     fence()
     dt = time.perf_counter() - t0
+    # the exchange on its own, and what of it the step does not hide: exchange_ms = one iteration's collectives back to
+    # back on the communicator's stream (carmel_hip_exchange_measure); exposed_exchange_ms = the step time with the exchange
+    # minus the step time of the same trainer without it (a few extra steps, outside the timed region).  At N = 1 both
+    # are measured over a loopback communicator of one rank (the collectives still run; they move nothing between GPUs).
+    xch = None
+    if comm is not None and ext_counts is None:
+        def timed(fn, n):
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            fence()
+            return 1e3 * (time.perf_counter() - t1) / n
+        n_x = max(3, min(10, steps))
+        if loopback:
+            xinfo = fb.exchange_plan(comm, args.exchange_chunks, args.exchange == "allreduce")
+
+        def with_x():
+            fb.estimate_async()
+            fb.allreduce_counts(comm)
+            fb.maximize(1.0)
+
+        def without_x():
+            fb.estimate_async()
+            fb.maximize(1.0)
+        with_x()
+        ms_with = timed(with_x, n_x)
+        x_ms = fb.exchange_measure(5)
+        fb.exchange_clear()
+        without_x()
+        ms_without = timed(without_x, n_x)
+        tt = torch.tensor([ms_with, ms_without, x_ms], dtype=torch.float64, device=ctl)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        xch = {"world": world, "loopback": bool(loopback), "sharded": xinfo["sharded"], "n_chunks": xinfo["n_chunks"],
+               "transport": comm.transport, "exchange_ms": float(tt[2]), "exposed_exchange_ms": max(0.0, float(tt[0]) - float(tt[1])),
+               "ms_per_step_with_exchange": float(tt[0]), "ms_per_step_without_exchange": float(tt[1]),
+               "bytes_reduce_scatter_per_rank": xinfo["bytes_reduce_scatter"], "bytes_all_gather_per_rank": xinfo["bytes_all_gather"],
+               "bytes_all_reduce": xinfo["bytes_all_reduce"]}
     lp, wlp, n_swept = fb.read_scalars()
     t = torch.tensor([dt, float(ls.kept_arcs), float(ls.kept_states)], dtype=torch.float64, device=ctl)
     if world > 1:
@@ -310,11 +362,8 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                                            "workload differs or a CARMEL_HIP_* switch is set -- not measured by this run" % name,
                          "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
         }
-        if exch_ms:
-            # HIP events on the trainer's stream around the exchange (reduce-scatter pieces, sharded M-step, all-gather):
-            # exchange_ms = what the exchange would cost on its own, exposed = the part not hidden behind the count pass
-            out["exchange_ms"] = float(np.mean([e[0] for e in exch_ms]))
-            out["exposed_exchange_ms"] = float(np.mean([e[1] for e in exch_ms]))
+        if xch:
+            out["exchange_ms"], out["exposed_exchange_ms"], out["exchange"] = xch["exchange_ms"], xch["exposed_exchange_ms"], xch
     fence()
     fb.close()
     if comm is not None:
@@ -525,6 +574,11 @@ def main():
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: host cores, at most 64)")
     ap.add_argument("--host-threads", type=int, default=0)
+    ap.add_argument("--comm-plugin", default=None, help="a transport library for the exchange instead of RCCL (carmel_hip_comm_create_custom), "
+                    "e.g. tests/native/libhosttransport.so: every rank then runs on GPU 0 (several ranks on a one-GPU box)")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"], help="form of the count exchange at N > 1")
+    ap.add_argument("--exchange-chunks", type=int, default=0, help="arc-range chunks of the sharded exchange (0: the library's default, 8)")
+    ap.add_argument("--no-exchange-loopback", action="store_true", help="N = 1: skip the loopback measurement of the exchange")
     ap.add_argument("--walk-arcs", default=None, help="min,max arcs of the headline's random walks (default: the config's; other values are experiments)")
     args = ap.parse_args()
     if args.steps is None:
@@ -545,8 +599,8 @@ def main():
         import torch.distributed as dist
         if not torch.cuda.is_available():
             sys.exit("bench.py needs a GPU: the EM hot path has no CPU fallback")
-        # CARMEL_HIP_COMM=host (tests on a one-GPU box): every rank on GPU 0, sums staged through shared memory, gloo for control
-        one_device = os.environ.get("CARMEL_HIP_COMM") == "host"
+        # --comm-plugin (tests on a one-GPU box): every rank on GPU 0, the sums through the plugin's transport, gloo for control
+        one_device = bool(args.comm_plugin)
         if one_device:
             local_rank = 0
         torch.cuda.set_device(local_rank)

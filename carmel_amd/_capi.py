@@ -35,6 +35,8 @@ SYMBOLS = [
     "carmel_hip_debug_lattice_fingerprint", "carmel_hip_lattice_layout",
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
+    "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_exchange_plan",
+    "carmel_hip_exchange_info", "carmel_hip_exchange_measure", "carmel_hip_exchange_clear", "carmel_hip_set_layout_policy",
 ]
 
 
@@ -91,6 +93,16 @@ def _load():
     lib.carmel_hip_composition_free.argtypes = [vp]
     lib.carmel_hip_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
     lib.carmel_hip_comm_destroy.argtypes = [vp]
+    lib.carmel_hip_comm_abort.argtypes = [vp]
+    lib.carmel_hip_comm_transport_name.argtypes = [vp]
+    lib.carmel_hip_comm_transport_name.restype = C.c_char_p
+    lib.carmel_hip_comm_create_custom.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
+    lib.carmel_hip_exchange_plan.argtypes = [vp, vp, C.c_uint32, C.c_int]
+    lib.carmel_hip_exchange_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                             C.POINTER(C.c_uint64)]
+    lib.carmel_hip_exchange_measure.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
+    lib.carmel_hip_exchange_clear.argtypes = [vp]
+    lib.carmel_hip_set_layout_policy.argtypes = [vp, C.c_int]
     lib.carmel_hip_comm_rank.argtypes = [vp]
     lib.carmel_hip_comm_world.argtypes = [vp]
     lib.carmel_hip_allreduce_counts.argtypes = [vp, vp]

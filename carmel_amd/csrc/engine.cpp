@@ -20,6 +20,13 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
                        bool& done);
 int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out);
 int build_run_tables(carmel_hip_trainer* t);
+// exchange.cpp: the sharded count exchange of corpus-sharded EM
+int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T);
+int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T);
+int exchange_counts_tail(carmel_hip_trainer* t, ExchangePlan* xp);
+int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_change, int* handled);
+int exchange_settle(carmel_hip_trainer* t, bool need_counts);
+void exchange_drop(carmel_hip_trainer* t);
 int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s);
 
 static thread_local std::string g_err;
@@ -125,6 +132,7 @@ int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, u
 }
 
 int carmel_hip_destroy(carmel_hip_trainer* t) {
+  if (t && t->xplan) exchange_drop(t);
   if (!t) return CARMEL_HIP_OK;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
@@ -179,6 +187,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) exchange_drop(t);  // the plan follows the lattices' transposition tables: plan again after a rebuild
   {
     // one-tape models never store their lattices (unrolled.hpp)
     int rc = unrolled_try_build(t, host_threads, has_derivation, stats);
@@ -638,9 +647,10 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
   return CARMEL_HIP_OK;
 }
 
-static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
+// the argument block of one M-step pass over the parameters (shared with the sharded M-step of exchange.cpp)
+int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M) {
   hipStream_t s = t->stream;
-  MstepArgs M;
+  M.block_first = 0;
   M.logw = t->params();
   M.lw_src = nullptr;  // the one-pass kernel needs no current weight besides each thread's own
   M.code16 = t->norm_code16.p;
@@ -683,7 +693,13 @@ static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
   M.max_change_bits = t->maxchg.p;
   M.n = t->np();
   M.save_old = save_old;
-  HIPCHK(launch_mstep(M, use_counts, s));
+  return CARMEL_HIP_OK;
+}
+static int run_mstep(carmel_hip_trainer* t, int use_counts, int save_old) {
+  MstepArgs M;
+  int rc = mstep_args(t, use_counts, save_old, M);
+  if (rc) return rc;
+  HIPCHK(launch_mstep(M, use_counts, t->stream));
   return CARMEL_HIP_OK;
 }
 
@@ -691,6 +707,10 @@ int carmel_hip_normalize(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   int rc = run_mstep(t, 0, 2);
   if (rc) return rc;
   if (t->cascade)
@@ -703,6 +723,10 @@ int carmel_hip_normalize(carmel_hip_trainer* t) {
 int carmel_hip_set_weights(carmel_hip_trainer* t, const double* logw) {
   if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(t->params(), logw, t->np() * sizeof(double), hipMemcpyHostToDevice, t->stream));
   if (t->cascade)
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
@@ -713,6 +737,10 @@ int carmel_hip_set_weights(carmel_hip_trainer* t, const double* logw) {
 int carmel_hip_get_weights(carmel_hip_trainer* t, double* logw) {
   if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(logw, t->params(), t->np() * sizeof(double), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
@@ -720,9 +748,45 @@ int carmel_hip_get_weights(carmel_hip_trainer* t, double* logw) {
 int carmel_hip_get_arc_weights(carmel_hip_trainer* t, double* logw) {
   if (!t || !logw) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(logw, t->arc_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
+}
+
+void trans_args(carmel_hip_trainer* t, TransArgs& T) {
+  T.buckets = t->t_buckets.p;
+  T.tile_base = t->t_tile_base.p;
+  T.b_arc = t->t_b_arc.p;
+  T.b_rank = t->t_b_rank.p;
+  T.b_src = t->t_b_src.p;
+  T.t_pos = t->t_t_pos.p;
+  T.t_src = t->t_t_src.p;
+  T.a_off = t->t_a_off.p;
+  T.tr_off = t->tr_off.p;
+  T.tr_rel = t->tr_rel.p;
+  T.tr_src = t->tr_src.p;
+  T.br_off = t->br_off.p;
+  T.br_rel = t->br_rel.p;
+  T.br_src = t->br_src.p;
+  T.use_runs = t->use_runs ? 1u : 0u;
+  T.x = t->t_x.p;
+  T.xc = t->t_xc.p;
+  T.logw = t->arc_logw.p;
+  T.wcache = t->wcache.p;
+  T.post = t->post.p;
+  T.counts = t->counts_ptr();
+  T.n_wcache = t->wcache.n;
+  T.n_post = t->post.n;
+  T.n_buckets = (uint32_t)t->t_buckets.n;
+  T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
+  T.tile_first = T.tile_count = 0;
+  T.bucket_first = 0;
+  T.bucket_count = T.n_buckets;
+  T.n_wtiles = 0;
 }
 
 // Enqueues one E-step on the trainer's stream(s).  timed: bracket it with ev0 / ev1 (not inside a graph capture).
@@ -797,39 +861,20 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   WA.first = 0;
   WA.max_states = WA.max_width = 0;
   TransArgs T;
-  T.buckets = t->t_buckets.p;
-  T.tile_base = t->t_tile_base.p;
-  T.b_arc = t->t_b_arc.p;
-  T.b_rank = t->t_b_rank.p;
-  T.b_src = t->t_b_src.p;
-  T.t_pos = t->t_t_pos.p;
-  T.t_src = t->t_t_src.p;
-  T.a_off = t->t_a_off.p;
-  T.tr_off = t->tr_off.p;
-  T.tr_rel = t->tr_rel.p;
-  T.tr_src = t->tr_src.p;
-  T.br_off = t->br_off.p;
-  T.br_rel = t->br_rel.p;
-  T.br_src = t->br_src.p;
-  T.use_runs = t->use_runs ? 1u : 0u;
-  T.x = t->t_x.p;
-  T.xc = t->t_xc.p;
-  T.logw = t->arc_logw.p;
-  T.wcache = t->wcache.p;
-  T.post = t->post.p;
-  T.counts = t->counts_ptr();
-  T.n_wcache = t->wcache.n;
-  T.n_post = t->post.n;
-  T.n_buckets = (uint32_t)t->t_buckets.n;
-  T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
+  trans_args(t, T);
   LA.pre_weights = t->use_transpose ? 1u : 0u;
+  ExchangePlan* const xp = (t->xplan && exchange_is_sharded(t->xplan) && t->use_transpose) ? t->xplan : nullptr;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
   const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty() &&
                             !(getenv("CARMEL_HIP_ESTEP_STREAMS") && atoi(getenv("CARMEL_HIP_ESTEP_STREAMS")) <= 1);
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
-  if (t->use_transpose) HIPCHK(launch_trans_w_bucket(T, s));
+  if (xp) {  // the weights arrive arc range by arc range (all-gather of the sharded M-step): exchange.cpp
+    int rc = exchange_weights_in(t, xp, T);
+    if (rc) return rc;
+  } else if (t->use_transpose)
+    HIPCHK(launch_trans_w_bucket(T, s));
   if (bundles_beside) {  // (after the bucket pass: its workgroups need a CU's LDS nearly whole)
     HIPCHK(hipEventRecord(t->ev_b0, s));
     HIPCHK(hipStreamWaitEvent(t->bstream, t->ev_b0, 0));
@@ -908,11 +953,19 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
     const uint32_t first = side_by_side ? lane_tiles : 0u;
     HIPCHK(launch_trans_c_tiles(T, first, T.n_tiles > first ? T.n_tiles - first : 0u, s));
-    HIPCHK(launch_trans_c_bucket(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
+    if (xp) {  // the counts leave arc range by arc range, each into its reduce-scatter while the next is being summed
+      int rc = exchange_counts_out(t, xp, T);
+      if (rc) return rc;
+    } else
+      HIPCHK(launch_trans_c_bucket(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
   } else
     HIPCHK(launch_count_reduce(R, s));
   HIPCHK(hipStreamWaitEvent(s, t->ev_join, 0));
   if (timed) HIPCHK(hipEventRecord(t->ev1, s));
+  if (xp) {  // (after ev1: the E-step's own time stays comparable with the one-GPU figure)
+    int rc = exchange_counts_tail(t, xp);
+    if (rc) return rc;
+  }
   if (timed && trace_path && trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);
     HIPCHK(hipStreamSynchronize(s));
@@ -940,7 +993,7 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   hipStream_t s = t->stream;
   const bool want = getenv("CARMEL_HIP_GRAPH") && atoi(getenv("CARMEL_HIP_GRAPH")) != 0 && !getenv("CARMEL_HIP_LANE_TRACE");
   const void* key = (const void*)t->counts_ptr();
-  if (!want || t->graph_failed) return estimate_enqueue(t, true);
+  if (!want || t->graph_failed || t->xplan) return estimate_enqueue(t, true);
   if (t->graph_exec && (t->graph_key != key || t->graph_epoch != t->lattice_epoch)) estimate_graph_drop(t);
   if (!t->graph_exec) {
     if (t->estimates_done == 0 || t->graph_epoch_first != t->lattice_epoch) {  // first call on these lattices: eager (one-time
@@ -972,6 +1025,11 @@ int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   return CARMEL_HIP_OK;
 }
 
+int carmel_hip_set_layout_policy(carmel_hip_trainer* t, int allow_unrolled) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  t->allow_unrolled = allow_unrolled != 0;
+  return CARMEL_HIP_OK;
+}
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;
   return t->unrolled ? (t->dense ? 2 : 1) : 0;
@@ -980,6 +1038,10 @@ int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
 int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* res) {
   if (!t || !res) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {  // a planned exchange delivers the corpus-wide scalars with the counts
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   double sc[4];
   HIPCHK(hipMemcpyAsync(sc, t->counts_ptr() + t->w.n_arcs, sizeof sc, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
@@ -1034,6 +1096,10 @@ int carmel_hip_last_sweep_ms(carmel_hip_trainer* t, double* ms) {
 int carmel_hip_synchronize(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
 }
@@ -1045,6 +1111,10 @@ int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts) {
   if (t->unrolled && t->cascade)
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "the unrolled sweep of a cascade accumulates per parameter: no composed-arc counts (CARMEL_HIP_UNROLLED=0 keeps explicit lattices)");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, true);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(counts, t->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
@@ -1052,6 +1122,10 @@ int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts) {
 int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts) {
   if (!t || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(t->counts_ptr(), counts, t->w.n_arcs * sizeof(double), hipMemcpyHostToDevice, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
@@ -1063,6 +1137,17 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
+  if (t->xplan) {
+    // corpus-sharded EM with a planned exchange: every rank normalises its own arc ranges and the weights are gathered
+    // (exchange.cpp); an over-relaxed step needs every count everywhere, so the count pieces are gathered first
+    if (delta_scale <= 1.0) {
+      int handled = 0;
+      int xrc = exchange_maximize(t, t->xplan, max_change, &handled);
+      if (xrc || handled) return xrc;
+    }
+    int xrc = exchange_settle(t, true);
+    if (xrc) return xrc;
+  }
   if (t->cascade) {
     // distribute_counts (cascade.h:318-325): parameter counts = sum over composed arcs using it of
     // (composed count + composed prior)
@@ -1115,6 +1200,10 @@ static int cascade_param_counts(carmel_hip_trainer* t, hipStream_t s) {
 int carmel_hip_fractional_counts(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, true);
+    if (xrc) return xrc;
+  }
   hipStream_t s = t->stream;
   if (t->cascade) {
     int rc = cascade_param_counts(t, s);
@@ -1169,6 +1258,10 @@ int carmel_hip_random_restart(carmel_hip_trainer* t, uint64_t seed, uint32_t res
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   const uint64_t n = t->np();
   std::vector<double> lw(n);
   HIPCHK(hipMemcpyAsync(lw.data(), t->params(), n * sizeof(double), hipMemcpyDeviceToHost, t->stream));
@@ -1189,6 +1282,10 @@ int carmel_hip_keep_em_weights(carmel_hip_trainer* t) {
   if (t->cascade) return fail(CARMEL_HIP_ERR_STATE, "over-relaxed EM is off for cascades (train.cc:545-549)");
   if (!t->em_valid) return CARMEL_HIP_OK;  // last step was a plain EM update already
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   HIPCHK(hipMemcpyAsync(t->arc_logw.p, t->em_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
@@ -1199,6 +1296,10 @@ int carmel_hip_keep_em_weights(carmel_hip_trainer* t) {
 int carmel_hip_save_counts(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   // for_arcs::save_counts: em_weight <- weight() of the composed arc, which after the previous maximize's
   // prep_new_weights holds (count + prior) — here: the counts buffer of the previous estimate
   if (t->unrolled && t->cascade)  // parameter space: the sweep never had composed-arc counts
@@ -1210,6 +1311,10 @@ int carmel_hip_save_counts(carmel_hip_trainer* t) {
 int carmel_hip_save_best(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   if (t->unrolled && t->cascade) {
     HIPCHK(hipMemcpyAsync(t->u_best_param.p, t->u_em_param.p, t->u_n_slots * sizeof(double), hipMemcpyDeviceToDevice, t->stream));
     return CARMEL_HIP_OK;
@@ -1221,6 +1326,10 @@ int carmel_hip_save_best(carmel_hip_trainer* t) {
 int carmel_hip_load_best(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) {
+    int xrc = exchange_settle(t, false);
+    if (xrc) return xrc;
+  }
   hipStream_t s = t->stream;
   if (!t->cascade) {
     HIPCHK(hipMemcpyAsync(t->arc_logw.p, t->best_logw.p, t->w.n_arcs * sizeof(double), hipMemcpyDeviceToDevice, s));

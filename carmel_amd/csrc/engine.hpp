@@ -44,7 +44,9 @@ struct DevBuf {
   size_t bytes() const { return n * sizeof(T); }
 };
 
+struct ExchangePlan;  // exchange.cpp
 struct carmel_hip_trainer {
+  ExchangePlan* xplan = nullptr;  // the count exchange of corpus-sharded EM, when a communicator was planned in
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -127,6 +129,7 @@ struct carmel_hip_trainer {
   DevBuf<double> scalar_partial;  // scratch of the corpus-scalar reduction
   // one-tape models: lattices are never stored, the sweep walks positions (unrolled.hpp)
   bool unrolled = false;
+  bool allow_unrolled = true;  // carmel_hip_set_layout_policy
   UnrolledModel um;  // host tables (bulk arrays are freed after upload)
   DevBuf<uint32_t> u_f_off, u_b_off, u_f_arc, u_b_arc, u_e_arc, u_pair_id;
   DevBuf<uint16_t> u_e_src, u_e_dst;
@@ -175,3 +178,7 @@ struct carmel_hip_trainer {
   uint64_t np() const { return cascade ? n_params : w.n_arcs; }
 };
 
+// engine.cpp pieces the exchange shares
+extern "C" int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M);
+extern "C" void trans_args(carmel_hip_trainer* t, TransArgs& T);
+bool exchange_is_sharded(const ExchangePlan* xp);  // exchange.cpp

@@ -151,6 +151,7 @@ static int dense_try_build(carmel_hip_trainer* t, const UnrolledModel& M, const 
 // lattices), an error code on a HIP failure.
 int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats) {
   t->unrolled = false;
+  if (!t->allow_unrolled) return CARMEL_HIP_OK;  // carmel_hip_set_layout_policy: explicit lattices on every rank
   bool forced = false;  // CARMEL_HIP_UNROLLED: 0 = never, 1 = whenever eligible, unset = when it pays (density test below)
   if (const char* e = getenv("CARMEL_HIP_UNROLLED")) {
     if (atoi(e) == 0) return CARMEL_HIP_OK;

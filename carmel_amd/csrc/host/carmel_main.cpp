@@ -27,8 +27,11 @@
 #include <limits>
 #include <memory>
 #include <sstream>
+#include <dlfcn.h>
 #include <signal.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 #include "../../../include/carmel_hip.h"
 #include "compose.hpp"
@@ -74,6 +77,9 @@ struct Options {
   double plus_alpha = 0;
   int index_threshold = 32, gpu = 0;
   int gpus = 1;  // --gpus=N: corpus-sharded EM, one process per GPU (not a carmel option: carmel is single-process)
+  std::string comm_plugin;  // --comm-plugin=LIB.so: a transport of the caller's own instead of RCCL (carmel_hip_comm_create_custom);
+                            // every rank then runs on the device --gpu names (the transport decides where the data travels)
+  int exchange_chunks = 0;  // --exchange-chunks=K: arc-range chunks of the sharded count exchange (0: the library's default)
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
   long crp_restarts = 0;     // --crp-restarts (carmel.cc:271-273)
@@ -125,6 +131,10 @@ static Options parse_args(int argc, char** argv) {
         o.gpu = std::atoi(v.c_str());
       else if (k == "gpus")
         o.gpus = std::max(1, std::atoi(v.c_str()));
+      else if (k == "comm-plugin")
+        o.comm_plugin = v;
+      else if (k == "exchange-chunks")
+        o.exchange_chunks = std::max(0, std::atoi(v.c_str()));
       else if (k == "crp") {
         o.crp = true;
         if (!v.empty() && std::atol(v.c_str()) > 1) o.crp_iters = std::atol(v.c_str());
@@ -299,6 +309,25 @@ struct CorpusStats {  // training_corpus counters over the pairs that have a der
 };
 
 static std::vector<pid_t> g_kids;  // --gpus: the other ranks (rank 0 only)
+static int g_rank = 0;
+static std::string g_session;  // --comm-plugin: the name the ranks' transports meet under
+static volatile sig_atomic_t g_waiting = 0;  // rank 0 is in its final waitpid loop (children may exit normally)
+// A rank that dies leaves the others waiting in a collective for ever (RCCL blocks; round-2 advisor finding): rank 0
+// watches its children and ends the whole job the moment one of them exits abnormally.
+static void on_sigchld(int) {
+  if (g_waiting) return;
+  int st = 0;
+  for (pid_t p : g_kids) {
+    const pid_t r = waitpid(p, &st, WNOHANG);
+    if (r == p && (!WIFEXITED(st) || WEXITSTATUS(st) != 0)) {
+      static const char msg[] = "ERROR: a rank of --gpus ended abnormally; ending the job\n";
+      if (write(2, msg, sizeof msg - 1) < 0) {}
+      for (pid_t q : g_kids)
+        if (q != p) kill(q, SIGTERM);
+      _exit(245);  // -11
+    }
+  }
+}
 
 static int run(int argc, char** argv) {
   Options o = parse_args(argc, argv);
@@ -331,6 +360,11 @@ static int run(int argc, char** argv) {
   if (world > 1 && (!o.fem_forest.empty() || !o.fem_norm.empty() || !o.fem_param.empty() || !o.fem_alpha.empty()))
     throw UsageError("--gpus with the --fem-* exports is not supported (the export walks the whole corpus)");
   if (world > 1) {
+    {
+      char buf[96];
+      std::snprintf(buf, sizeof buf, "carmel_%d_%ld", (int)getpid(), (long)time(nullptr));
+      g_session = buf;
+    }
     for (int r = 1; r < world; ++r) {
       int fd[2];
       if (pipe(fd) != 0) throw std::runtime_error("pipe() failed");
@@ -343,12 +377,23 @@ static int run(int argc, char** argv) {
         for (int w : id_pipes) close(w);
         id_pipes.clear();
         kids.clear();
-        if (!std::freopen("/dev/null", "w", stdout) || !std::freopen("/dev/null", "w", stderr)) return -11;
+        // a rank other than 0 says nothing unless something goes wrong (its log lines are rank 0's): stdout is dropped, stderr is
+        // kept so that the reason a rank died is not lost; and no rank outlives rank 0
+        if (!std::freopen("/dev/null", "w", stdout)) return -11;
+        prctl(PR_SET_PDEATHSIG, SIGTERM);
+        g_rank = r;
         break;
       }
       close(fd[0]);
       id_pipes.push_back(fd[1]);
       kids.push_back(pid);
+    }
+    if (rank == 0) {
+      struct sigaction sa;
+      std::memset(&sa, 0, sizeof sa);
+      sa.sa_handler = on_sigchld;
+      sa.sa_flags = SA_RESTART | SA_NOCLDSTOP;
+      sigaction(SIGCHLD, &sa, nullptr);
     }
   } else if (o.gpus > 1)
     std::cerr << "--gpus=" << o.gpus << " applies to EM training (-t / --train-cascade) and to the runs of --crp --crp-restarts=R; running on one GPU\n";
@@ -488,7 +533,7 @@ static int run(int argc, char** argv) {
       std::unique_ptr<Transducer> next(new Transducer());
       double dev_s = 0;
       const bool ok = o.flags[(unsigned)'a'] ? comp.run_a(A, B, *next)  // carmel.cc:1318
-                      : o.gpu_compose        ? comp.run_device(A, B, *next, o.gpu + ((std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host") ? 0 : rank), &dev_s)
+                      : o.gpu_compose        ? comp.run_device(A, B, *next, o.gpu + (o.comm_plugin.empty() ? rank : 0), &dev_s)
                                              : comp.run(A, B, *next);
       if (o.gpu_compose && !o.flags[(unsigned)'a'] && std::getenv("CARMEL_TIMING"))
         std::cerr << "timing: composition on the GPU " << dev_s << " s\n";
@@ -533,8 +578,8 @@ static int run(int argc, char** argv) {
   std::vector<double> logw;
   result->flatten(src, dst, in, out, logw, group);
   carmel_hip_trainer* t = 0;
-  // (CARMEL_HIP_COMM=host: every rank on the same GPU, sums staged through shared memory -- single-GPU boxes, tests)
-  const bool one_device = std::getenv("CARMEL_HIP_COMM") && std::string(std::getenv("CARMEL_HIP_COMM")) == "host";
+  // (--comm-plugin: the caller's transport carries the sums; every rank runs on the device --gpu names -- single-GPU boxes, tests)
+  const bool one_device = !o.comm_plugin.empty();
   const int my_device = o.gpu + (one_device ? 0 : rank);
   hip_check(carmel_hip_create(&t, my_device, (uint32_t)result->states.size(), result->final_state, logw.size(), src.data(),
                               dst.data(), in.data(), out.data(), logw.data(), group.data()),
@@ -544,7 +589,21 @@ static int run(int argc, char** argv) {
     ~Guard() { carmel_hip_destroy(t); }
   } guard{t};
   carmel_hip_comm* comm = 0;
-  if (world > 1) {
+  if (world > 1 && !o.comm_plugin.empty()) {
+    // the plugin exports  int carmel_hip_transport_open(const char* session, int rank, int world, int device,
+    // carmel_hip_transport* out);  the session name is the same on every rank (made before the ranks were forked)
+    void* h = dlopen(o.comm_plugin.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) throw std::runtime_error(std::string("--comm-plugin: ") + dlerror());
+    typedef int (*open_fn)(const char*, int, int, int, carmel_hip_transport*);
+    open_fn op = (open_fn)dlsym(h, "carmel_hip_transport_open");
+    if (!op) throw std::runtime_error("--comm-plugin: the library does not export carmel_hip_transport_open");
+    carmel_hip_transport tr;
+    std::memset(&tr, 0, sizeof tr);
+    if (op(g_session.c_str(), rank, world, my_device, &tr) != 0) throw std::runtime_error("--comm-plugin: carmel_hip_transport_open failed");
+    hip_check(carmel_hip_comm_create_custom(&comm, my_device, rank, world, &tr), "carmel_hip_comm_create_custom");
+    for (int w : id_pipes) close(w);
+    if (id_read >= 0) close(id_read);
+  } else if (world > 1) {
     unsigned char id[128];
     if (rank == 0) {
       hip_check(carmel_hip_comm_unique_id(id), "carmel_hip_comm_unique_id");
@@ -685,6 +744,19 @@ static int run(int argc, char** argv) {
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (carmel_hip_lattice_layout(t) == 2 ? "unrolled_dense" : carmel_hip_lattice_layout(t) == 1 ? "unrolled" : "explicit") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
+  if (comm && !o.crp) {
+    // every rank must hold its lattices in the same layout (a shard with one over-long pair would keep explicit lattices
+    // while the others unroll, and the count buffers being summed would mean different things): agree, or rebuild all
+    // with explicit lattices; then plan the exchange (sharded where the model allows it, csrc/exchange.cpp)
+    double lay[2] = {(double)carmel_hip_lattice_layout(t), -(double)carmel_hip_lattice_layout(t)};
+    hip_check(carmel_hip_comm_allreduce_host(comm, lay, 2, 1), "carmel_hip_comm_allreduce_host");
+    if (lay[0] != -lay[1]) {
+      if (!quiet) std::cerr << "The ranks' shards chose different lattice layouts; rebuilding every rank with explicit lattices\n";
+      hip_check(carmel_hip_set_layout_policy(t, 0), "carmel_hip_set_layout_policy");
+      hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+    }
+    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
+  }
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
@@ -1231,10 +1303,12 @@ int main(int argc, char** argv) {
     std::cerr << "carmel: " << e.what() << "\n";
     rc = -12;
   } catch (std::exception& e) {
+    if (g_rank) std::cerr << "[rank " << g_rank << "] ";
     std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
     rc = -11;
   }
   // --gpus: rank 0 waits for the other ranks; if it failed itself they may be waiting in a collective -- end them
+  g_waiting = 1;
   for (pid_t p : g_kids) {
     if (rc != 0) kill(p, SIGTERM);
     int st = 0;

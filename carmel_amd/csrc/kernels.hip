@@ -820,11 +820,12 @@ template <bool NEED_LW>
 __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_counts, uint32_t span) {
   __shared__ double v_sh[256 + 2 * MSTEP_WINDOW_MAX];
   __shared__ uint16_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // MstepArgs::code16
-  const int64_t base = (int64_t)blockIdx.x * 256 - (int64_t)span;
+  const uint32_t blk = M.block_first + blockIdx.x;
+  const int64_t base = (int64_t)blk * 256 - (int64_t)span;
   // every global load of the workgroup is issued up front (tile element, halo element, own old weight): one round
   // trip per workgroup instead of one per dependent step.  NEED_LW: some member's value is its current weight (no
   // counts in use, or locked members) -- read from the snapshot lw_src, never from the array being rewritten.
-  const uint64_t kown = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t kown = (uint64_t)blk * 256 + threadIdx.x;
   const double old_own = kown < M.n ? M.logw[kown] : 0.0;
   const uint32_t mask_own = (M.mask32 && kown < M.n) ? M.mask32[kown] : 0u;
   const uint32_t lock_own = (NEED_LW && M.mask32 && kown < M.n) ? M.lockmask32[kown] : 0u;
@@ -859,7 +860,7 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   }
   __syncthreads();
   double mx = 0.0;
-  const uint64_t k = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t k = (uint64_t)blk * 256 + threadIdx.x;
   if (k < M.n) {
     const uint32_t me = threadIdx.x + span;
     const uint16_t gid = g_sh[me];
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_
   __syncthreads();
   if (threadIdx.x == 0) {
     const double m = fmax(fmax(shm[0], shm[1]), fmax(shm[2], shm[3]));
-    if (m > 0.0) atomicMax(M.max_partial + (blockIdx.x % MSTEP_GRID), (unsigned long long)__double_as_longlong(m));
+    if (m > 0.0) atomicMax(M.max_partial + (blk % MSTEP_GRID), (unsigned long long)__double_as_longlong(m));
   }
 }
 // pass 0 for big groups (e.g. JOINT normalisation of a state with 10^5 arcs): one workgroup per group
@@ -1040,7 +1041,7 @@ __device__ __forceinline__ uint32_t run_source(const uint16_t* rel, const uint32
 // position-sorted order (coalesced write), picking their weight out of LDS.
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const TransBucket B = T.buckets[blockIdx.x];
+  const TransBucket B = T.buckets[T.bucket_first + blockIdx.x];
   // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
   // 16384 items): one dependent round trip per phase instead of one per iteration
   double w[TRANS_K];
@@ -1151,8 +1152,9 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   __shared__ double part[16];
   __shared__ uint32_t big[512];
   __shared__ uint32_t n_big;
-  const uint32_t bucket = xcd_chunked(blockIdx.x, T.n_buckets);  // the grid is rounded up to a multiple of 8
-  if (bucket >= T.n_buckets) return;
+  const uint32_t bloc = xcd_chunked(blockIdx.x, T.bucket_count);  // the grid is rounded up to a multiple of 8
+  if (bloc >= T.bucket_count) return;
+  const uint32_t bucket = T.bucket_first + bloc;
   const TransBucket B = T.buckets[bucket];
   // every global load of the workgroup is issued before the first barrier: item indices, the items, and the item
   // ranges of this thread's arcs (the per-arc loop below then runs out of registers and LDS alone)
@@ -1358,12 +1360,16 @@ static void trans_lds_attr() {
   (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
   done = true;
 }
-hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream) {
+hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint32_t count, hipStream_t stream) {
   trans_lds_attr();
-  if (!T.n_buckets) return hipSuccess;
-  hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(T.n_buckets), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  if (!T0.n_buckets || !count) return hipSuccess;
+  TransArgs T = T0;
+  T.bucket_first = first;
+  T.bucket_count = count;
+  hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(count), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
+hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream) { return launch_trans_w_bucket_range(T, 0, T.n_buckets, stream); }
 hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32_t tile_count, hipStream_t stream) {
   trans_lds_attr();
   if (!T0.n_buckets || !tile_count) return hipSuccess;
@@ -1385,14 +1391,42 @@ hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   hipLaunchKernelGGL(trans_c_tile_kernel, dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
-hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
+hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(zero_list_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, p, idx, n);
+  return hipGetLastError();
+}
+hipError_t launch_trans_c_bucket_range(const TransArgs& T0, uint32_t first, uint32_t count, hipStream_t stream) {
   trans_lds_attr();
-  if (!T.n_buckets) return hipSuccess;
-  if (n_split) hipLaunchKernelGGL(zero_list_kernel, dim3((n_split + 255) / 256), dim3(256), 0, stream, T.counts, split_arcs, n_split);
+  if (!T0.n_buckets || !count) return hipSuccess;
+  TransArgs T = T0;
+  T.bucket_first = first;
+  T.bucket_count = count;
   if (T.use_runs)
-    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
   else
-    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((T.n_buckets + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
+    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  return hipGetLastError();
+}
+hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
+  if (!T.n_buckets) return hipSuccess;
+  hipError_t e = launch_zero_list(T.counts, split_arcs, n_split, stream);
+  if (e != hipSuccess) return e;
+  return launch_trans_c_bucket_range(T, 0, T.n_buckets, stream);
+}
+__global__ void gather_idx_kernel(double* small, const double* src, const uint32_t* idx, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) small[k] = src[idx[k]];
+}
+__global__ void scatter_idx_kernel(double* dst, const double* small, const uint32_t* idx, uint32_t n) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n) dst[idx[k]] = small[k];
+}
+hipError_t launch_gather_idx(double* small, const double* src, const uint32_t* idx, uint32_t n, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(gather_idx_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, small, src, idx, n);
+  return hipGetLastError();
+}
+hipError_t launch_scatter_idx(double* dst, const double* small, const uint32_t* idx, uint32_t n, hipStream_t stream) {
+  if (n) hipLaunchKernelGGL(scatter_idx_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dst, small, idx, n);
   return hipGetLastError();
 }
 
@@ -1451,6 +1485,20 @@ hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
                      M.max_change_bits);
   MSTEP_DBG("normalize + max")
 #undef MSTEP_DBG
+  return hipGetLastError();
+}
+hipError_t launch_mstep_window_range(const MstepArgs& M0, int use_counts, uint32_t block_first, uint32_t n_blocks, hipStream_t s) {
+  if (!n_blocks) return hipSuccess;
+  MstepArgs M = M0;
+  M.block_first = block_first;
+  if (M.lw_src)
+    hipLaunchKernelGGL(mstep_window_kernel<true>, dim3(n_blocks), dim3(256), 0, s, M, use_counts, M.window_span);
+  else
+    hipLaunchKernelGGL(mstep_window_kernel<false>, dim3(n_blocks), dim3(256), 0, s, M, use_counts, M.window_span);
+  return hipGetLastError();
+}
+hipError_t launch_mstep_max_final(const MstepArgs& M, hipStream_t s) {
+  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID, M.max_change_bits);
   return hipGetLastError();
 }
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,

@@ -105,6 +105,7 @@ struct TransArgs {
   const uint32_t* br_src;
   uint32_t use_runs;        // every tile and bucket has at most TRANS_RUN_CAP runs (they are staged in LDS)
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
+  uint32_t bucket_first, bucket_count;  // the bucket range of this launch of a bucket pass (arc-range chunks of the exchange)
 };
 
 #define TRANS_RUN_CAP 2560
@@ -137,6 +138,8 @@ struct MstepArgs {
   double* tie_tab;          // [4][n_ties]: arc total, state total, max locked sum, weight (linear)
   uint64_t n_ties;
   uint64_t n;
+  uint32_t block_first;     // mstep_window_kernel: first 256-parameter block of this launch (the sharded M-step of the
+                            // multi-GPU exchange runs it over this rank's arc ranges only)
   int save_old;             // 1: old_logw <- the weights before this pass, |change| against them; 0: keep old_logw from the
                             // previous pass and compare against it (second normalise after overrelax); 2: old_logw is not
                             // needed afterwards (no over-relaxation): do not write it, compare against the weight read
@@ -164,6 +167,16 @@ hipError_t launch_wave_sweep(const WaveArgs& A, const LatticeSet::WaveClass& wc,
 // the two passes of either direction as separate launches: the bucket passes cover the whole model, the tile passes a
 // range of tiles (so that chunks of the corpus can flow through weights-in / sweep / posteriors-out side by side)
 hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream);
+// ... over buckets [first, first + count) only
+hipError_t launch_trans_w_bucket_range(const TransArgs& T, uint32_t first, uint32_t count, hipStream_t stream);
+hipError_t launch_trans_c_bucket_range(const TransArgs& T, uint32_t first, uint32_t count, hipStream_t stream);
+hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream);
+// small[k] = src[idx[k]] / dst[idx[k]] = small[k]   (halo values of the exchange)
+hipError_t launch_gather_idx(double* small, const double* src, const uint32_t* idx, uint32_t n, hipStream_t stream);
+hipError_t launch_scatter_idx(double* dst, const double* small, const uint32_t* idx, uint32_t n, hipStream_t stream);
+// the one-pass M-step over parameters [256 * block_first, 256 * (block_first + n_blocks)) only
+hipError_t launch_mstep_window_range(const MstepArgs& M, int use_counts, uint32_t block_first, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_mstep_max_final(const MstepArgs& M, hipStream_t s);
 hipError_t launch_trans_w_tiles(const TransArgs& T, uint32_t tile_first, uint32_t tile_count, hipStream_t stream);
 hipError_t launch_trans_c_tiles(const TransArgs& T, uint32_t tile_first, uint32_t tile_count, hipStream_t stream);
 hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream);

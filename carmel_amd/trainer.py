@@ -43,16 +43,37 @@ class HipComm(object):
         check(lib.carmel_hip_comm_create(C.byref(h), device, rank, world, C.c_char_p(id_bytes)), "carmel_hip_comm_create")
         self.h, self.rank, self.world = h, rank, world
 
+    @classmethod
+    def custom(cls, plugin_path, session, device, rank, world):
+        """a communicator over a transport of the caller's own (carmel_hip_comm_create_custom): `plugin_path` is a shared
+        library exporting carmel_hip_transport_open(session, rank, world, device, carmel_hip_transport*) -- e.g. the test
+        transport tests/native/libhosttransport.so, which lets several ranks share one GPU"""
+        plug = C.CDLL(plugin_path)
+        tr = (C.c_void_p * 6)()
+        plug.carmel_hip_transport_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        rc = plug.carmel_hip_transport_open(session.encode(), rank, world, device, C.cast(tr, C.c_void_p))
+        if rc != 0:
+            raise RuntimeError("carmel_hip_transport_open(%s) failed: %d" % (plugin_path, rc))
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        check(lib.carmel_hip_comm_create_custom(C.byref(h), device, rank, world, C.cast(tr, C.c_void_p)), "carmel_hip_comm_create_custom")
+        self.h, self.rank, self.world, self._plug = h, rank, world, plug
+        return self
+
+    @property
+    def transport(self):
+        return lib.carmel_hip_comm_transport_name(self.h).decode()
+
     def allreduce_host(self, values, op_max=False):
         v = np.ascontiguousarray(values, dtype=np.float64).copy()
         check(lib.carmel_hip_comm_allreduce_host(self.h, ptr(v), len(v), 1 if op_max else 0), "carmel_hip_comm_allreduce_host")
         return v
 
-    def describe(self, n):
-        return "RCCL all-reduce of %d f64 counts per iteration on the trainer's stream" % n
-
     def abort(self):
-        self.close()
+        """after a collective failed on some rank: drop what is enqueued instead of waiting for it"""
+        if self.h:
+            lib.carmel_hip_comm_abort(self.h)
+            self.h = None
 
     def close(self):
         if self.h:
@@ -102,6 +123,11 @@ class HipForwardBackward(object):
         self.stats = corpus.stats(self.has_deriv.astype(bool))  # cached_derivs.h:87-98 recount
         self.last = None
 
+    def rebuild_lattices(self, prune=True, host_threads=0):
+        """carmel_hip_build_lattices again (after carmel_hip_set_layout_policy)"""
+        check(lib.carmel_hip_build_lattices(self.h, 1 if prune else 0, host_threads, ptr(self.has_deriv),
+                                            C.byref(self.lattice_stats)), "carmel_hip_build_lattices")
+
     def close(self):
         if self.h:
             lib.carmel_hip_destroy(self.h)
@@ -142,6 +168,31 @@ class HipForwardBackward(object):
             return "unrolled, rank-1 dense form (never stored)"
         return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM" % (
             ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9)
+
+    def exchange_plan(self, comm, n_chunks=0, force_allreduce=False):
+        """plan the per-iteration exchange (collective); returns exchange_info()"""
+        check(lib.carmel_hip_exchange_plan(self.h, comm.h, n_chunks, int(force_allreduce)), "carmel_hip_exchange_plan")
+        return self.exchange_info()
+
+    def exchange_info(self):
+        sh, k = C.c_int(0), C.c_uint32(0)
+        rs, ag, ar = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib.carmel_hip_exchange_info(self.h, C.byref(sh), C.byref(k), C.byref(rs), C.byref(ag), C.byref(ar)),
+              "carmel_hip_exchange_info")
+        return dict(sharded=bool(sh.value), n_chunks=k.value, bytes_reduce_scatter=rs.value, bytes_all_gather=ag.value,
+                    bytes_all_reduce=ar.value)
+
+    def exchange_measure(self, reps=5):
+        """ms of one iteration's exchange on its own (all its collectives back to back; collective)"""
+        ms = C.c_double(0)
+        check(lib.carmel_hip_exchange_measure(self.h, reps, C.byref(ms)), "carmel_hip_exchange_measure")
+        return ms.value
+
+    def exchange_clear(self):
+        check(lib.carmel_hip_exchange_clear(self.h), "carmel_hip_exchange_clear")
+
+    def set_layout_policy(self, allow_unrolled):
+        check(lib.carmel_hip_set_layout_policy(self.h, int(allow_unrolled)), "carmel_hip_set_layout_policy")
 
     def last_kernel_ms(self):
         ms = C.c_double(0)

@@ -203,10 +203,50 @@ typedef struct carmel_hip_comm carmel_hip_comm;
 int carmel_hip_comm_unique_id(void* id128);
 int carmel_hip_comm_create(carmel_hip_comm** out, int device, int rank, int world, const void* id128);
 int carmel_hip_comm_destroy(carmel_hip_comm* c);
+/* after a collective failed on some rank: drop whatever is still enqueued instead of waiting for it (ncclCommAbort) */
+int carmel_hip_comm_abort(carmel_hip_comm* c);
 int carmel_hip_comm_rank(carmel_hip_comm* c);
 int carmel_hip_comm_world(carmel_hip_comm* c);
+const char* carmel_hip_comm_transport_name(carmel_hip_comm* c);
 int carmel_hip_allreduce_counts(carmel_hip_trainer* t, carmel_hip_comm* c);
 int carmel_hip_comm_allreduce_host(carmel_hip_comm* c, double* v, uint32_t n, int op_max);
+
+/* A communicator over a transport of the caller's own (MPI, sockets, a test harness) instead of RCCL: three collectives on
+ * f64 DEVICE buffers.  `stream` is a hipStream_t: the operation must be ordered after the work already enqueued on it and
+ * be complete -- or enqueued on it -- when the call returns (a transport that works through the host synchronises the
+ * stream).  allreduce: buf[0 .. n) := sum (op 0) or max (op 1) over the ranks.  reduce_scatter: buf holds world * count
+ * doubles; afterwards this rank's piece buf[rank * count ..) holds the sum over the ranks of that piece (the other pieces are
+ * unspecified).  all_gather: every rank's piece is copied to all ranks.  reduce_scatter / all_gather may be NULL (the
+ * library then uses allreduce: same sums, more traffic).  All return 0 on success.  destroy may be NULL. */
+typedef struct carmel_hip_transport {
+  void* ctx;
+  int (*allreduce)(void* ctx, double* dev_buf, uint64_t n, int op, void* stream);
+  int (*reduce_scatter)(void* ctx, double* dev_buf, uint64_t count, void* stream);
+  int (*all_gather)(void* ctx, double* dev_buf, uint64_t count, void* stream);
+  void (*destroy)(void* ctx);
+  const char* name;
+} carmel_hip_transport;
+int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, int world, const carmel_hip_transport* tr);
+
+/* The per-iteration exchange, planned once after carmel_hip_build_lattices (collective: every rank calls it; it also
+ * checks that the ranks hold their lattices in the same layout).  With a plan an iteration is still
+ *     carmel_hip_estimate_async -> carmel_hip_allreduce_counts -> carmel_hip_maximize,
+ * but for a single transducer under JOINT / CONDITIONAL normalisation it runs SHARDED: the arc table in n_chunks chunks
+ * (0: 8) of `world` pieces; the count pass hands each chunk to a reduce-scatter on the communicator's own stream while the
+ * next chunk is still being summed; carmel_hip_maximize normalises this rank's pieces only and all-gathers the weights chunk
+ * by chunk into the next count pass (csrc/exchange.cpp).  Other models (cascades, unrolled / dense
+ * layouts, tied groups, force_allreduce != 0) keep the one all-reduce of counts[n_arcs + 4] and the replicated M-step.
+ * The results are the same either way up to the order of the sums.  carmel_hip_exchange_info says which form was planned
+ * and what one iteration moves per rank; carmel_hip_exchange_measure times the exchange of one iteration on its own (all
+ * its collectives back to back, nothing to hide behind; collective); carmel_hip_exchange_clear drops the plan. */
+int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int force_allreduce);
+int carmel_hip_exchange_info(carmel_hip_trainer* t, int* sharded, uint32_t* n_chunks, uint64_t* bytes_reduce_scatter,
+                             uint64_t* bytes_all_gather, uint64_t* bytes_all_reduce);
+int carmel_hip_exchange_measure(carmel_hip_trainer* t, uint32_t reps, double* ms_per_exchange);
+int carmel_hip_exchange_clear(carmel_hip_trainer* t);
+/* allow_unrolled = 0: carmel_hip_build_lattices keeps explicit lattices even for one-tape models (what every rank must do
+ * when the ranks' shards would choose different layouts); 1 (default): the builder decides per shard */
+int carmel_hip_set_layout_policy(carmel_hip_trainer* t, int allow_unrolled);
 
 /* ---- blocked Gibbs sampling of derivations: `carmel --crp` ----
  * Replaces: WFST::train_gibbs / carmel_gibbs (gibbs.cc:15-41, 386-430) + gibbs_base::run_starts

@@ -4,7 +4,13 @@ that buffer, carmel_hip_read_scalars, carmel_hip_maximize.  Both ranks may share
 through the host over gloo (RCCL refuses two ranks on one device); `--rccl` uses carmel_hip_allreduce_counts instead
 (one GPU per rank, or world 1).
 
-usage: multirank_worker.py RANK WORLD PORT OUT.npy MODE(synth|cipher|cipher-explicit|dense) [--rccl]"""
+`--plugin=LIB.so:SESSION` (with --rccl) makes the library's communicator over that transport instead of RCCL
+(carmel_hip_comm_create_custom; tests/native/libhosttransport.so lets the ranks share one GPU); `--plan[=K]` plans the
+exchange (carmel_hip_exchange_plan: sharded where the model allows it), `--plan-allreduce` plans its all-reduce form;
+`--disagree` makes rank 1 keep explicit lattices first (the ranks' layouts differ: the plan must refuse, then every rank
+rebuilds with explicit lattices).
+
+usage: multirank_worker.py RANK WORLD PORT OUT.npy MODE(synth|synth-big|cipher|cipher-explicit|dense) [--rccl] [...]"""
 import os
 import sys
 
@@ -22,6 +28,10 @@ def build(mode, rank, world):
     if mode == "synth":
         w = synth.random_wfst(60, 8, n_sym=4, p_eps=0.15, seed=3)
         c = synth.random_walk_corpus(w, 301, min_arcs=3, max_arcs=12, seed=3, out_degree=8)  # odd size: ragged shards
+        return w, HipForwardBackward(w, c.shard(rank, world), device=0)
+    if mode == "synth-big":  # enough arcs for the sharded exchange (world * 512 at least), groups straddling piece boundaries
+        w = synth.random_wfst(3001, 7, n_sym=5, p_eps=0.15, seed=4)
+        c = synth.random_walk_corpus(w, 4001, min_arcs=3, max_arcs=14, seed=4, out_degree=7)
         return w, HipForwardBackward(w, c.shard(rank, world), device=0)
     from oracle import binding as ob
     g = lambda n: open(os.path.join(ROOT, "tests", "golden", n)).read()
@@ -59,15 +69,38 @@ def main():
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         dist.init_process_group("gloo", rank=rank, world_size=world)
     w, fb = build(mode, rank, world)
-    counts = torch.zeros(w.n_arcs + 4, dtype=torch.float64, device="cuda:0")
-    fb.use_external_counts(counts.data_ptr())
+    plugin = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--plugin=")]
+    plan = [a for a in sys.argv if a.startswith("--plan")]
+    counts = None
+    if not plan:  # (a planned exchange works on the trainer's own buffer)
+        counts = torch.zeros(w.n_arcs + 4, dtype=torch.float64, device="cuda:0")
+        fb.use_external_counts(counts.data_ptr())
     comm = None
     if rccl:
         from carmel_amd.trainer import HipComm
-        ids = [HipComm.unique_id() if rank == 0 else None]
-        if world > 1:
-            dist.broadcast_object_list(ids, src=0)
-        comm = HipComm(0, rank, world, ids[0])
+        if plugin:
+            path, session = plugin[0].rsplit(":", 1)
+            comm = HipComm.custom(path, session, 0, rank, world)
+        else:
+            ids = [HipComm.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
+            comm = HipComm(0, rank, world, ids[0])
+    info = None
+    if plan:
+        if "--disagree" in sys.argv:
+            if rank == 1:  # this rank keeps explicit lattices, the others unroll: the plan must refuse on EVERY rank
+                fb.set_layout_policy(False)
+                fb.rebuild_lattices()
+            try:
+                fb.exchange_plan(comm)
+                raise SystemExit("the plan accepted ranks with different lattice layouts")
+            except RuntimeError as e:
+                assert "different layouts" in str(e), str(e)
+            fb.set_layout_policy(False)
+            fb.rebuild_lattices()
+        k = plan[0].split("=", 1)
+        info = fb.exchange_plan(comm, int(k[1]) if len(k) > 1 and k[0] == "--plan" else 0, force_allreduce=plan[0] == "--plan-allreduce")
     logs = []
     for it in range(4):
         if fb.cascade is not None and it > 0:
@@ -84,8 +117,13 @@ def main():
         lp, wlp, n = fb.read_scalars()
         logs += [lp, wlp, float(n)]
         fb.maximize(1.0)
+    if "--check-counts" in sys.argv:  # after a sharded exchange the whole count vector must still be there for the asking
+        fb.estimate_async()
+        fb.allreduce_counts(comm)
+        cnt = fb.counts()
+        logs += [float(cnt.sum()), float((cnt * np.arange(len(cnt))).sum())]
     if rank == 0:
-        np.save(out, np.concatenate([fb.weights(), logs]))
+        np.save(out, np.concatenate([fb.weights(), logs, [1.0 if (info and info["sharded"]) else 0.0]]))
     fb.close()
     if comm is not None:
         comm.close()

@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "multirank_worker.py")
 
 
+PLUGIN = os.path.join(ROOT, "tests", "native", "libhosttransport.so")
+
+
+def _plugin(tag):
+    """--plugin argument of the worker: the test transport under a session name of this test's own"""
+    return "--plugin=%s:cht_%d_%s" % (PLUGIN, os.getpid(), tag)
+
+
 def _run(world, mode, tmp_path, tag, extra=()):
     port = 29600 + (os.getpid() % 1500) + (abs(hash((mode, tag))) % 300)
     out = str(tmp_path / ("w_%s_%d.npy" % (tag, world)))
@@ -31,12 +39,12 @@ def _run(world, mode, tmp_path, tag, extra=()):
 def test_two_ranks_reproduce_the_single_rank_trainer(tmp_path, mode):
     one = _run(1, mode, tmp_path, "one")
     two = _run(2, mode, tmp_path, "two")
-    nlog = 12
+    nlog = 13
     w1, w2 = one[:-nlog], two[:-nlog]
     fin = np.isfinite(w1)
     assert np.array_equal(fin, np.isfinite(w2))
     np.testing.assert_allclose(np.exp(w2[fin]), np.exp(w1[fin]), rtol=1e-9, atol=1e-300)
-    np.testing.assert_allclose(two[-nlog:], one[-nlog:], rtol=1e-10)
+    np.testing.assert_allclose(two[-nlog:-1], one[-nlog:-1], rtol=1e-10)
     assert one[-nlog + 2] > 0 and one[-nlog] < 0  # pairs swept, ln P
 
 
@@ -50,19 +58,72 @@ def test_rccl_entry_points_with_a_world_of_one(tmp_path):
 
 @pytest.mark.parametrize("mode", ["synth", "cipher"])
 def test_library_allreduce_two_ranks_host_transport(tmp_path, mode):
-    """the library's own exchange -- carmel_hip_allreduce_counts enqueued between estimate_async and maximize, exactly
-    what bench.py and `carmel --gpus` do -- with two ranks on the one GPU of this box: CARMEL_HIP_COMM=host stages the
-    sum through shared memory (RCCL refuses two ranks on one device) and adds on the GPU"""
-    os.environ["CARMEL_HIP_COMM"] = "host"
-    try:
-        two = _run(2, mode, tmp_path, "lib2", extra=["--rccl"])
-    finally:
-        del os.environ["CARMEL_HIP_COMM"]
+    """the library's own exchange in its plain form -- carmel_hip_allreduce_counts enqueued between estimate_async and
+    maximize -- with two ranks on the one GPU of this box: the communicator runs over the test transport
+    tests/native/libhosttransport.so (carmel_hip_comm_create_custom; RCCL refuses two ranks on one device)"""
+    two = _run(2, mode, tmp_path, "lib2", extra=["--rccl", _plugin("ar" + mode)])
     one = _run(1, mode, tmp_path, "lib1")
-    nlog = 12
+    nlog = 13
     fin = np.isfinite(one[:-nlog])
     np.testing.assert_allclose(np.exp(two[:-nlog][fin]), np.exp(one[:-nlog][fin]), rtol=1e-9, atol=1e-300)
-    np.testing.assert_allclose(two[-nlog:], one[-nlog:], rtol=1e-10)
+    np.testing.assert_allclose(two[-nlog:-1], one[-nlog:-1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_exchange_is_the_all_reduce_bit_for_bit(tmp_path, world):
+    """carmel_hip_exchange_plan on a single transducer: the arc table in chunks of `world` pieces, a reduce-scatter per chunk
+    beside the count pass, the M-step on this rank's pieces only, the weights all-gathered chunk by chunk into the next count
+    pass, norm groups that straddle piece boundaries summed from one small all-reduce.  The test transport adds the ranks'
+    values in rank order in all of its collectives, so the sharded exchange must give the all-reduce form's weights and
+    corpus probabilities BIT FOR BIT (4 iterations; 2 and 4 ranks, default and 3 chunks) -- and the one-rank trainer's to
+    rounding.  The whole count vector is still there for the asking after a sharded exchange (carmel_hip_get_counts)."""
+    plain = _run(world, "synth-big", tmp_path, "plain%d" % world, extra=["--rccl", _plugin("p%d" % world), "--plan-allreduce", "--check-counts"])
+    assert plain[-1] == 0.0
+    for k, tag in ((0, "d"), (3, "k3")):
+        sh = _run(world, "synth-big", tmp_path, "sh%d%s" % (world, tag),
+                  extra=["--rccl", _plugin("s%d%s" % (world, tag)), "--plan=%d" % k if k else "--plan", "--check-counts"])
+        assert sh[-1] == 1.0, "the exchange was not planned in its sharded form"
+        np.testing.assert_array_equal(sh[:-1], plain[:-1])
+    one = _run(1, "synth-big", tmp_path, "one_big")
+    nw = len(one) - 13
+    fin = np.isfinite(one[:nw])
+    assert np.array_equal(fin, np.isfinite(plain[:nw]))
+    np.testing.assert_allclose(np.exp(plain[:nw][fin]), np.exp(one[:nw][fin]), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(plain[nw:nw + 12], one[nw:nw + 12], rtol=1e-10)
+
+
+def test_sharded_exchange_with_one_rank_is_the_plain_trainer(tmp_path):
+    """world 1 over RCCL (the collectives run, nothing travels): the sharded M-step over block ranges and the chunked bucket
+    passes are the plain ones, so the run must equal the plain trainer bit for bit"""
+    plain = _run(1, "synth-big", tmp_path, "plain1")
+    sh = _run(1, "synth-big", tmp_path, "sh1", extra=["--rccl", "--plan"])
+    assert sh[-1] == 1.0
+    np.testing.assert_array_equal(sh[:-1], plain[:-1])
+
+
+@pytest.mark.parametrize("mode,world", [("cipher", 2), ("cipher-explicit", 2), ("dense", 2), ("cipher", 4)])
+def test_planned_exchange_on_cascades_keeps_the_all_reduce(tmp_path, mode, world):
+    """cascades -- explicit lattices, the unrolled sweep, its dense form -- take the all-reduce form of a planned exchange
+    (their parameters are few; the unrolled buffers hold per-parameter sums): two and four ranks against one"""
+    many = _run(world, mode, tmp_path, "pl%d" % world, extra=["--rccl", _plugin("c%s%d" % (mode, world)), "--plan"])
+    assert many[-1] == 0.0
+    one = _run(1, mode, tmp_path, "pl1")
+    nlog = 13
+    fin = np.isfinite(one[:-nlog])
+    np.testing.assert_allclose(np.exp(many[:-nlog][fin]), np.exp(one[:-nlog][fin]), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(many[-nlog:-1], one[-nlog:-1], rtol=1e-10)
+
+
+def test_ranks_with_different_layouts_are_refused_then_rebuilt(tmp_path):
+    """round-2 advisor finding: a shard that keeps explicit lattices beside shards that unroll would sum per-arc counts into
+    per-parameter sums.  carmel_hip_exchange_plan compares the layouts over the communicator and refuses on every rank;
+    after carmel_hip_set_layout_policy(0) + a rebuild everywhere the run is the one-rank run"""
+    two = _run(2, "cipher", tmp_path, "dis2", extra=["--rccl", _plugin("dis"), "--plan", "--disagree"])
+    one = _run(1, "cipher", tmp_path, "dis1")
+    nlog = 13
+    fin = np.isfinite(one[:-nlog])
+    np.testing.assert_allclose(np.exp(two[:-nlog][fin]), np.exp(one[:-nlog][fin]), rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(two[-nlog:-1], one[-nlog:-1], rtol=1e-10)
 
 
 @pytest.mark.parametrize("args", [["-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"],
@@ -78,8 +139,8 @@ def test_front_end_gpus_switch(golden_dir, tmp_path, args):
     for n in (1, 2):
         d = tmp_path / ("n%d" % n)
         d.mkdir()
-        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_HIP_COMM="host")
-        p = subprocess.run([cli, "--gpus=%d" % n] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d))
+        p = subprocess.run([cli, "--gpus=%d" % n, "--comm-plugin=" + PLUGIN] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
                            env=env, timeout=600)
         assert p.returncode == 0, p.stderr
         trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
@@ -106,8 +167,8 @@ def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_pat
     for n in (1, 3):
         d = tmp_path / ("n%d" % n)
         d.mkdir()
-        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d), CARMEL_HIP_COMM="host")
-        p = subprocess.run([cli, "--gpus=%d" % n] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
+        env = dict(os.environ, CARMEL_TRAINED_DIR=str(d))
+        p = subprocess.run([cli, "--gpus=%d" % n, "--comm-plugin=" + PLUGIN] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True,
                            env=env, timeout=600)
         assert p.returncode == 0, p.stderr
         trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
@@ -120,12 +181,13 @@ def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_pat
 def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     """bench.py's own N > 1 branch (corpus shards, the library's all-reduce between the count pass and the M-step, timing
     over ranks, one JSON line from rank 0), launched the way the driver launches it.  Two ranks share this box's GPU
-    (CARMEL_HIP_COMM=host).  With --scaling strong both runs train on the same 6000 pairs: after the same number of steps
+    (--comm-plugin: the test transport).  With --scaling strong both runs train on the same 6000 pairs: after the same number of steps
     the corpus probability must be the one-rank run's."""
     import json
     bench = os.path.join(ROOT, "bench.py")
-    common = ["--config", "c2", "--pairs", "6000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"]
-    env = dict(os.environ, CARMEL_HIP_COMM="host")
+    common = ["--config", "c2", "--pairs", "6000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
+              "--comm-plugin", PLUGIN]
+    env = dict(os.environ)
     one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          universal_newlines=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
@@ -140,3 +202,7 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     assert j2["config"]["pairs_per_gpu"] == 3000 and "corpus-sharded x2" in j2["config"]["parallelism"]
     assert j2["value"] > 0 and j2["roofline"]["frac"] > 0
     assert j2["ln_corpus_prob_last"] == pytest.approx(j1["ln_corpus_prob_last"], rel=1e-9)
+    # the exchange is on the line: planned sharded, its own time and the part the step does not hide
+    assert j2["exchange"]["sharded"] and j2["exchange"]["world"] == 2 and j2["exchange_ms"] > 0 and j2["exposed_exchange_ms"] >= 0
+    assert "reduce-scatter" in j2["config"]["parallelism"]
+    assert j1["exchange"]["loopback"] and j1["exchange_ms"] > 0
