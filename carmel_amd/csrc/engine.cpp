@@ -651,6 +651,7 @@ int carmel_hip_set_cascade(carmel_hip_trainer* t, uint64_t n_params, const doubl
 int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M) {
   hipStream_t s = t->stream;
   M.block_first = 0;
+  M.n_ranges = 0;
   M.logw = t->params();
   M.lw_src = nullptr;  // the one-pass kernel needs no current weight besides each thread's own
   M.code16 = t->norm_code16.p;

@@ -28,7 +28,7 @@
 #include <cstring>
 #include "comm.hpp"
 
-static const int XCH_MAX_CHUNKS = 32;
+static const int XCH_MAX_CHUNKS = MSTEP_MAX_RANGES - 1;
 
 struct ExchangePlan {
   carmel_hip_comm* comm = nullptr;
@@ -95,6 +95,9 @@ int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs
   hipStream_t s = t->stream, x = xp->comm->xstream;
   double* counts = t->counts_ptr();
   HIPCHK(launch_zero_list(counts, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
+  // the trainer's stream first, all of it (enqueueing a collective costs the host several kernel launches' worth of time:
+  // interleaved, the count pass would wait for the host), then the collectives on the communicator's stream, each behind
+  // its chunk's event
   uint32_t done = 0, hdone = 0;
   for (uint32_t k = 0; k < xp->K; ++k) {
     if (xp->cb_end[k] > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->cb_end[k] - done, s));
@@ -104,11 +107,13 @@ int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs
       HIPCHK(launch_gather_idx(xp->small.p + hdone, counts, xp->halo_idx.p + hdone, xp->halo_end[k] - hdone, s));
     hdone = std::max(hdone, xp->halo_end[k]);
     HIPCHK(hipEventRecord(xp->ev_chunk[k], s));
+  }
+  if (xp->n_buckets > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->n_buckets - done, s));
+  for (uint32_t k = 0; k < xp->K; ++k) {
     HIPCHK(hipStreamWaitEvent(x, xp->ev_chunk[k], 0));
     int rc = comm_reduce_scatter(xp->comm, counts + xp->A[k], (size_t)((xp->A[k + 1] - xp->A[k]) / xp->N), x);
     if (rc) return rc;
   }
-  if (xp->n_buckets > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->n_buckets - done, s));
   xp->counts_pending = true;
   return CARMEL_HIP_OK;
 }
@@ -178,14 +183,25 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   MstepArgs M;
   rc = mstep_args(t, 1, 2, M);
   if (rc) return rc;
+  // one launch over this rank's K pieces and the arcs after the last whole chunk (every rank has THEIR counts from the small
+  // all-reduce and normalises them itself)
+  M.n_ranges = 0;
+  uint32_t cum = 0;
+  auto add = [&](uint64_t first_block, uint64_t n_blocks) {
+    if (!n_blocks) return;
+    M.range_first[M.n_ranges] = (uint32_t)first_block;
+    M.range_cum[M.n_ranges] = cum;
+    cum += (uint32_t)n_blocks;
+    ++M.n_ranges;
+  };
   for (uint32_t k = 0; k < xp->K; ++k) {
     const uint64_t P = (xp->A[k + 1] - xp->A[k]) / xp->N, p0 = xp->A[k] + (uint64_t)xp->rank * P;
-    HIPCHK(launch_mstep_window_range(M, 1, (uint32_t)(p0 / 256), (uint32_t)(P / 256), s));
+    add(p0 / 256, P / 256);
   }
-  // the arcs after the last whole chunk: every rank has their counts (small all-reduce) and normalises them itself
   const uint64_t tail0 = xp->A[xp->K];
-  if (xp->n_arcs > tail0)
-    HIPCHK(launch_mstep_window_range(M, 1, (uint32_t)(tail0 / 256), (uint32_t)((xp->n_arcs - tail0 + 255) / 256), s));
+  if (xp->n_arcs > tail0) add(tail0 / 256, (xp->n_arcs - tail0 + 255) / 256);
+  M.range_cum[M.n_ranges] = cum;
+  HIPCHK(launch_mstep_window_range(M, 1, 0, cum, s));
   HIPCHK(launch_mstep_max_final(M, s));
   HIPCHK(hipEventRecord(xp->ev_m_done, s));
   HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
@@ -245,7 +261,7 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
   xp->sharded = can;
   if (can) {
     const uint64_t M = t->w.n_arcs, gran = (uint64_t)xp->N * 256;
-    uint32_t K = n_chunks ? n_chunks : 8u;
+    uint32_t K = n_chunks ? n_chunks : 4u;
     K = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(K, XCH_MAX_CHUNKS), std::max<uint64_t>(1, M / gran));
     xp->K = K;
     xp->A.assign(K + 1, 0);

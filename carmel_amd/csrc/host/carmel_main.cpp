@@ -310,6 +310,7 @@ struct CorpusStats {  // training_corpus counters over the pairs that have a der
 
 static std::vector<pid_t> g_kids;  // --gpus: the other ranks (rank 0 only)
 static int g_rank = 0;
+static int g_err_fd = -1;  // ranks > 0: the job's stderr, for the one message that says why the rank failed
 static std::string g_session;  // --comm-plugin: the name the ranks' transports meet under
 static volatile sig_atomic_t g_waiting = 0;  // rank 0 is in its final waitpid loop (children may exit normally)
 // A rank that dies leaves the others waiting in a collective for ever (RCCL blocks; round-2 advisor finding): rank 0
@@ -377,9 +378,10 @@ static int run(int argc, char** argv) {
         for (int w : id_pipes) close(w);
         id_pipes.clear();
         kids.clear();
-        // a rank other than 0 says nothing unless something goes wrong (its log lines are rank 0's): stdout is dropped, stderr is
-        // kept so that the reason a rank died is not lost; and no rank outlives rank 0
-        if (!std::freopen("/dev/null", "w", stdout)) return -11;
+        // a rank other than 0 says nothing unless something goes wrong (its log lines are rank 0's): its streams are dropped, but
+        // a copy of stderr is kept for the reason it died, should it die; and no rank outlives rank 0
+        g_err_fd = dup(2);
+        if (!std::freopen("/dev/null", "w", stdout) || !std::freopen("/dev/null", "w", stderr)) return -11;
         prctl(PR_SET_PDEATHSIG, SIGTERM);
         g_rank = r;
         break;
@@ -1303,8 +1305,10 @@ int main(int argc, char** argv) {
     std::cerr << "carmel: " << e.what() << "\n";
     rc = -12;
   } catch (std::exception& e) {
-    if (g_rank) std::cerr << "[rank " << g_rank << "] ";
-    std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
+    if (g_rank && g_err_fd >= 0)
+      dprintf(g_err_fd, "[rank %d] ERROR: %s\n", g_rank, e.what());
+    else
+      std::cerr << "ERROR: " << e.what() << "\n";  // carmel.cc:1558-1561
     rc = -11;
   }
   // --gpus: rank 0 waits for the other ranks; if it failed itself they may be waiting in a collective -- end them

@@ -820,7 +820,12 @@ template <bool NEED_LW>
 __global__ __launch_bounds__(256) void mstep_window_kernel(MstepArgs M, int use_counts, uint32_t span) {
   __shared__ double v_sh[256 + 2 * MSTEP_WINDOW_MAX];
   __shared__ uint16_t g_sh[256 + 2 * MSTEP_WINDOW_MAX];  // MstepArgs::code16
-  const uint32_t blk = M.block_first + blockIdx.x;
+  uint32_t blk = M.block_first + blockIdx.x;
+  if (M.n_ranges) {
+    uint32_t r = 0;
+    while (r + 1 < M.n_ranges && blockIdx.x >= M.range_cum[r + 1]) ++r;
+    blk = M.range_first[r] + (blockIdx.x - M.range_cum[r]);
+  }
   const int64_t base = (int64_t)blk * 256 - (int64_t)span;
   // every global load of the workgroup is issued up front (tile element, halo element, own old weight): one round
   // trip per workgroup instead of one per dependent step.  NEED_LW: some member's value is its current weight (no

@@ -112,6 +112,7 @@ struct TransArgs {
 #define MSTEP_BIG_GROUP 48  // a group above this size is summed by a workgroup of its own (one thread walking 500 members is a
                            // chain of 500 dependent loads: 0.22 ms on the tagging lexicon's per-tag groups)
 #define MSTEP_PARTIALS 2048
+#define MSTEP_MAX_RANGES 17
 struct MstepArgs {
   double* logw;             // parameters (ln), updated in place
   const double* lw_src;     // mstep_window_kernel: where the ln weights of the tile AND its halo are read -- `logw` itself
@@ -138,8 +139,13 @@ struct MstepArgs {
   double* tie_tab;          // [4][n_ties]: arc total, state total, max locked sum, weight (linear)
   uint64_t n_ties;
   uint64_t n;
-  uint32_t block_first;     // mstep_window_kernel: first 256-parameter block of this launch (the sharded M-step of the
-                            // multi-GPU exchange runs it over this rank's arc ranges only)
+  uint32_t block_first;     // mstep_window_kernel: first 256-parameter block of this launch
+  // ... or (n_ranges > 0) the launch covers several block ranges -- the sharded M-step of the multi-GPU exchange runs over
+  // this rank's arc ranges only: workgroup b belongs to range r with range_cum[r] <= b < range_cum[r + 1] and handles
+  // block range_first[r] + (b - range_cum[r])
+  uint32_t n_ranges;
+  uint32_t range_first[MSTEP_MAX_RANGES];
+  uint32_t range_cum[MSTEP_MAX_RANGES + 1];
   int save_old;             // 1: old_logw <- the weights before this pass, |change| against them; 0: keep old_logw from the
                             // previous pass and compare against it (second normalise after overrelax); 2: old_logw is not
                             // needed afterwards (no over-relaxation): do not write it, compare against the weight read

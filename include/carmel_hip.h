@@ -232,7 +232,7 @@ int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, i
  * checks that the ranks hold their lattices in the same layout).  With a plan an iteration is still
  *     carmel_hip_estimate_async -> carmel_hip_allreduce_counts -> carmel_hip_maximize,
  * but for a single transducer under JOINT / CONDITIONAL normalisation it runs SHARDED: the arc table in n_chunks chunks
- * (0: 8) of `world` pieces; the count pass hands each chunk to a reduce-scatter on the communicator's own stream while the
+ * (0: 4; at most 16) of `world` pieces; the count pass hands each chunk to a reduce-scatter on the communicator's own stream while the
  * next chunk is still being summed; carmel_hip_maximize normalises this rank's pieces only and all-gathers the weights chunk
  * by chunk into the next count pass (csrc/exchange.cpp).  Other models (cascades, unrolled / dense
  * layouts, tied groups, force_allreduce != 0) keep the one all-reduce of counts[n_arcs + 4] and the replicated M-step.
