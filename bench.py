@@ -276,6 +276,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
         kernel_ms.append(fb.last_kernel_ms())
     fence()
     dt = time.perf_counter() - t0
+    lp, wlp, n_swept = fb.read_scalars()
     # the exchange on its own, and what of it the step does not hide: exchange_ms = one iteration's collectives back to
     # back on the communicator's stream (carmel_hip_exchange_measure); exposed_exchange_ms = the step time with the exchange
     # minus the step time of the same trainer without it (a few extra steps, outside the timed region).  At N = 1 both
@@ -315,7 +316,6 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                "ms_per_step_with_exchange": float(tt[0]), "ms_per_step_without_exchange": float(tt[1]),
                "bytes_reduce_scatter_per_rank": xinfo["bytes_reduce_scatter"], "bytes_all_gather_per_rank": xinfo["bytes_all_gather"],
                "bytes_all_reduce": xinfo["bytes_all_reduce"]}
-    lp, wlp, n_swept = fb.read_scalars()
     t = torch.tensor([dt, float(ls.kept_arcs), float(ls.kept_states)], dtype=torch.float64, device=ctl)
     if world > 1:
         tmax = t.clone()

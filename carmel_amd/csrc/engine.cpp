@@ -1109,9 +1109,42 @@ void* carmel_hip_stream(carmel_hip_trainer* t) { return t ? (void*)t->stream : n
 
 int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts) {
   if (!t || !counts) return fail(CARMEL_HIP_ERR_ARG, "null argument");
-  if (t->unrolled && t->cascade)
-    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "the unrolled sweep of a cascade accumulates per parameter: no composed-arc counts (CARMEL_HIP_UNROLLED=0 keeps explicit lattices)");
   HIPCHK(hipSetDevice(t->device));
+  if (t->unrolled && t->cascade) {
+    // The unrolled / dense sweep of a cascade accumulates per PARAMETER; the reference always has arc_counts::counts per
+    // composed arc (train.h:28-40, derivations.h:432-449).  They depend on the composed arcs' weights and the corpus only,
+    // so they come from one on-demand pass over EXPLICIT lattices: a second trainer over the same composed transducer
+    // with its weights as they stand now, explicit layout, one E-step.  (Counts of the weights the last estimate saw: the
+    // trainer's weights change only in maximize.)
+    const double need = (double)t->um.lattice_arcs * 64.0;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(hipMemGetInfo(&free_b, &total_b));
+    if (t->um.lattice_arcs >= (1ull << 31) || need > 0.5 * (double)free_b)
+      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "composed-arc counts under the unrolled sweep need explicit lattices: " +
+                                                  std::to_string((unsigned long long)(need / 1e9)) + " GB for this corpus");
+    std::vector<double> aw(t->w.n_arcs);
+    HIPCHK(hipMemcpyAsync(aw.data(), t->arc_logw.p, aw.size() * sizeof(double), hipMemcpyDeviceToHost, t->stream));
+    HIPCHK(hipStreamSynchronize(t->stream));
+    carmel_hip_trainer* x = nullptr;
+    int rc = carmel_hip_create(&x, t->device, t->w.n_states, t->w.final_state, t->w.n_arcs, t->w.src.data(), t->w.dst.data(),
+                               t->w.in.data(), t->w.out.data(), aw.data(), nullptr);
+    if (rc) return rc;
+    struct Guard {
+      carmel_hip_trainer* x;
+      ~Guard() { carmel_hip_destroy(x); }
+    } guard{x};
+    x->allow_unrolled = false;
+    const HostCorpus& c = t->corpus;
+    rc = carmel_hip_set_corpus(x, c.n_pairs, c.in_off.data(), c.in_sym.data(), c.out_off.data(), c.out_sym.data(),
+                               c.weight.empty() ? nullptr : c.weight.data());
+    if (!rc) rc = carmel_hip_build_lattices(x, 1, 0, nullptr, nullptr);
+    carmel_hip_estimate_result er;
+    if (!rc) rc = carmel_hip_estimate(x, &er, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(counts, x->counts_ptr(), t->w.n_arcs * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIPCHK(hipStreamSynchronize(x->stream));
+    return CARMEL_HIP_OK;
+  }
   if (t->xplan) {
     int xrc = exchange_settle(t, true);
     if (xrc) return xrc;

@@ -495,3 +495,38 @@ def test_windowed_tagging_cascade(oracle, golden_dir, monkeypatch):
         assert sig6(t["log2_prob"]) == g["log2_prob"]
         assert sig6(t["log2_ppx_example"]) == g["log2_ppx_example"]
     fb.close()
+
+
+def test_linear_count_floor_against_the_log_counts(oracle):
+    """Expected counts cross the boundary as LINEAR f64 (include/carmel_hip.h; the one buffer summed across ranks); the
+    reference keeps them as logs and adds with log-add (derivations.h:439-447, weight.h:765-801).  The two agree wherever a
+    posterior is representable: this test walks a pair's two derivations further and further apart -- the second 1e-100,
+    1e-250, 1e-300 and e^-800 times as probable as the first -- and pins the floor: down to 1e-300 the GPU's count is the
+    oracle's exp(log count) to 1e-7; below the smallest normal double (e^-708.4) it is EXACTLY 0 where the reference holds
+    e^-800.  What that changes: a normalisation group whose every member's count is below the floor is a zero group here
+    (weights 0, fst.cc:217-221) where the reference would still normalise its tiny counts; nothing else -- a count that
+    small moves no weight by more than 1e-308.  ("Numerics".)"""
+    # states: 0 -a-> 1 -b-> 3 (final) and 0 -a-> 2 -b-> 3: two derivations of the pair (a b, a b); state 2's arcs are the unlikely ones
+    for ln_ratio in (-230.0, -575.0, -690.0, -800.0):
+        src = np.array([0, 0, 1, 2], np.uint32)
+        dst = np.array([1, 2, 3, 3], np.uint32)
+        sym = np.array([2, 2, 3, 3], np.uint32)
+        logw = np.array([0.0, ln_ratio, 0.0, 0.0])
+        w = Wfst(4, 3, src, dst, sym, sym, logw)
+        c = Corpus.from_lists([([2, 3], [2, 3])] * 3)
+        from carmel_amd.trainer import HipForwardBackward
+        fb = HipForwardBackward(w, c, norm_group=NORM_NONE, normalize_first=False)
+        fb.estimate(per_pair=True)
+        got = fb.counts()
+        ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+        r = oracle.estimate(ow, oc)
+        want_ln = r["counts_ln"]
+        np.testing.assert_allclose(fb.pair_logprob, r["pair_logprob"], rtol=1e-12, atol=1e-12)
+        assert want_ln[1] == pytest.approx(math.log(3.0) + ln_ratio, rel=1e-12)  # the reference keeps the log count
+        if ln_ratio > -700:
+            np.testing.assert_allclose(got, np.exp(want_ln), rtol=1e-7, atol=0)
+            assert got[1] > 0
+        else:
+            assert got[1] == 0.0 and got[3] == 0.0  # below the floor: exactly zero, never a denormal or a NaN
+            np.testing.assert_allclose(got[[0, 2]], np.exp(want_ln[[0, 2]]), rtol=1e-12)
+        fb.close()

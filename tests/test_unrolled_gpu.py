@@ -109,3 +109,27 @@ def test_unrolled_training_equals_explicit(oracle):
     np.testing.assert_allclose(np.exp(u.weights()), np.exp(e.weights()), rtol=1e-6, atol=1e-12)
     u.close()
     e.close()
+
+
+@pytest.mark.parametrize("mode,layout", [("cipher", 1), ("dense", 2)])
+def test_composed_arc_counts_under_the_unrolled_cascade_sweep(mode, layout, monkeypatch):
+    """the reference always has arc_counts::counts per COMPOSED arc (train.h:28-40, derivations.h:432-449); the unrolled /
+    dense sweep of a cascade accumulates per parameter, so carmel_hip_get_counts runs one on-demand pass over explicit
+    lattices with the composed weights as they stand: the same counts as a trainer that keeps explicit lattices"""
+    import multirank_worker as mw
+    from carmel_amd._capi import lib
+    w, u = mw.build(mode, 0, 1)
+    assert lib.carmel_hip_lattice_layout(u.h) == layout
+    monkeypatch.setenv("CARMEL_HIP_UNROLLED", "0")
+    w2, e = mw.build(mode, 0, 1)
+    assert lib.carmel_hip_lattice_layout(e.h) == 0
+    for it in range(2):
+        lu, le = u.estimate(), e.estimate()
+        assert lu[0] == pytest.approx(le[0], rel=1e-10)
+        cu, ce = u.counts(), e.counts()
+        assert cu.shape == ce.shape == (w.n_arcs,) and ce.sum() > 0
+        np.testing.assert_allclose(cu, ce, rtol=1e-8, atol=1e-12)
+        u.maximize(1.0)
+        e.maximize(1.0)
+    u.close()
+    e.close()
