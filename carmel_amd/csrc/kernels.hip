@@ -1149,16 +1149,10 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
 // then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
 // that is a piece of a split arc reduces the piece and adds it atomically.
-// The items sit in LDS in arc-sorted order and one thread adds up one arc's contiguous range: with u uses per arc the threads
-// of a wave read addresses u doubles apart -- for u = 16 (ambiguous corpora: an arc is used by many lattices) every lane of a
-// half-wave hits the same bank.  The item of rank r lives at r + r / 32: the stride between neighbouring threads stops being a
-// multiple of the bank count.
-#define TC_SKEW(r) ((r) + ((r) >> 5))
-#define TC_LDS_ITEMS (TRANS_BUCKET + TRANS_BUCKET / 32)
 template <bool RL>
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  uint16_t* r_rel = (uint16_t*)(lds + TC_LDS_ITEMS);
+  uint16_t* r_rel = (uint16_t*)(lds + TRANS_BUCKET);
   uint32_t* r_src = (uint32_t*)(r_rel + TRANS_RUN_CAP);
   __shared__ double part[16];
   __shared__ uint32_t big[512];
@@ -1205,12 +1199,12 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     for (int k = 0; k < TRANS_K; ++k) v[k] = T.xc[src[k]];
 #pragma unroll
     for (int k = 0; k < TRANS_K; ++k)
-      if (threadIdx.x + k * 1024 < B.n_items) lds[TC_SKEW((uint32_t)rk[k])] = v[k];
+      if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
   }
   __syncthreads();
   if (single) {
     double v = 0.0;
-    for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) v += lds[TC_SKEW(j)];
+    for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) v += lds[j];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -1241,7 +1235,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
       }
     }
     double v = 0.0;
-    for (uint32_t r = q0; r < q1; ++r) v += lds[TC_SKEW(r)];
+    for (uint32_t r = q0; r < q1; ++r) v += lds[r];
     T.counts[B.arc_lo + a] = v;
   }
   __syncthreads();
@@ -1250,7 +1244,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     const uint32_t a = big[q];
     const uint32_t q0 = T.a_off[B.arc_lo + a], q1 = a + 1 < B.n_arcs ? (uint32_t)T.a_off[B.arc_lo + a + 1] : B.n_items;
     double v = 0.0;
-    for (uint32_t r = q0 + (threadIdx.x & 63); r < q1; r += 64) v += lds[TC_SKEW(r)];
+    for (uint32_t r = q0 + (threadIdx.x & 63); r < q1; r += 64) v += lds[r];
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     if ((threadIdx.x & 63) == 0) T.counts[B.arc_lo + a] = v;
   }
@@ -1367,8 +1361,8 @@ static void trans_lds_attr() {
   (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
   (void)hipFuncSetAttribute((const void*)trans_c_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS_ITEMS * 8);
-  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TC_LDS_ITEMS * 8 + TRANS_RUN_CAP * 6);
+  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
   done = true;
 }
 hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint32_t count, hipStream_t stream) {
@@ -1413,9 +1407,9 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T0, uint32_t first, uint
   T.bucket_first = first;
   T.bucket_count = count;
   if (T.use_runs)
-    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((count + 7) / 8 * 8), dim3(1024), TC_LDS_ITEMS * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
   else
-    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((count + 7) / 8 * 8), dim3(1024), TC_LDS_ITEMS * 8, stream, T);
+    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {
