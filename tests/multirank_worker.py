@@ -45,7 +45,7 @@ def build(mode, rank, world):
         c = Corpus(ca["in_off"], ca["in_sym"], ca["out_off"], ca["out_sym"], ca["weight"])
         fb = HipForwardBackward(w, c.shard(rank, world), cascade=oc.as_dict([NORM_NONE, NORM_CONDITIONAL], [0.0, 0.0]), device=0)
         from carmel_amd._capi import lib
-        assert lib.carmel_hip_lattice_layout(fb.h) == 2, "expected the dense layout"
+        assert os.environ.get("CARMEL_HIP_UNROLLED") == "0" or lib.carmel_hip_lattice_layout(fb.h) == 2, "expected the dense layout"
         return w, fb
     oc = ob.OracleCascade([g("cipher.wfsa"), g("cipher.fst")])
     a = oc.composed().arrays()
