@@ -160,7 +160,7 @@ def cpu_leg(ob, w, cs, full_arcs, nthreads, device, parity=True):
         np.testing.assert_allclose(gc, oc_lin, rtol=1e-7, atol=1e-12, err_msg="bench.py: GPU expected counts differ from the oracle's on the cpu_baseline sample")
         checked = int(keep.sum())
         out["parity"] = {"checked_pairs": checked, "checked_arcs": int(len(gc)), "rtol": 1e-7,
-                         "max_rel_err_ln_p": float(np.max(np.abs(glp - olp) / np.maximum(np.abs(olp), 1e-300))) if checked else 0.0,
+                         "max_abs_err_ln_p": float(np.max(np.abs(glp - olp))) if checked else 0.0,
                          "max_abs_err_counts": float(np.max(np.abs(gc - oc_lin)))}
     return out, checked
 
@@ -495,7 +495,7 @@ def run_c3(args, steps, warmup, local_rank=0, rank=0):
     return out
 
 
-def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=2):
+def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=1):
     """BASELINE.json configs[4]: forest-em --crp sweeps over synthetic packed forests.  A step is one Gibbs sweep over all
     forests: the parallel stale-count sweep (the throughput mode) and -- `exact` -- the reference's sequential chain"""
     import numpy as np
@@ -533,7 +533,7 @@ def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=2):
         hf.set_weights(lw)
         hf.maximize()
         t0 = time.perf_counter()
-        hf.gibbs(exact_sweeps - 1, alpha=0.1, seed=4 + rank, mode=0)
+        hf.gibbs(exact_sweeps - 1, alpha=0.1, seed=4 + rank, mode=0)  # (iter + 1 sweeps: the initial sample counts)
         edt = time.perf_counter() - t0
         out["exact"] = {"sweeps": exact_sweeps, "ms_per_step": 1e3 * edt / exact_sweeps, "value": n_nodes * exact_sweeps / edt,
                         "unit": "node-updates/s", "note": "mode 0: the reference's sequential chain over all %d forests" % args.forests}
