@@ -1081,6 +1081,183 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
   }
 }
 
+// ---- several lanes per forest (parallel sweep, temperature 1) ----
+// forest_sample_kernel is one forest per lane: a forest's inside values take a column of LDS per lane (40-110 KB per wave on
+// config 5: two or three waves per CU, nobody to hide a wave's dependent LDS round trips behind) and a sweep costs what its
+// slowest lane costs.  Here a forest gets FM_G lanes (FM_FPW = 64 / FM_G forests per wavefront) and a few hundred bytes of
+// LDS: its tables (children lists, node order by HEIGHT) are copied in once, the inside pass goes height by height with the
+// lanes over the nodes of a height (a node's children are all of lower height), and the walk is breadth-first: the lanes
+// take the entries of the current frontier, an OR entry chooses one child, an AND entry records its rule and hands on all of
+// its children; slots in the next frontier and in the sample come from a prefix sum over the lanes (no atomics: the order is
+// the same in every run).  Arithmetic is forest_sample_kernel's EXT form (mantissa x 2^exponent).  ONE difference in the
+// chain: the sequential walk draws its uniforms by the ORDER OF VISITS of a depth-first walk, which a breadth-first walk
+// does not have -- the uniform of a visit is keyed by its position in the breadth-first order instead.  Every visit still has
+// a uniform of its own (a shared sub-forest expanded twice chooses twice): the same kind of chain -- the stale-count sweep of
+// forest-em.hpp:750-766 with other random numbers -- validated against the sweep's enumerated stationary distribution
+// (tests/test_bench_workloads_gpu.py) instead of draw for draw.
+#define FM_G 8
+#define FM_FPW (64 / FM_G)
+struct FMultiArgs {
+  const uint16_t* tab;      // per forest: {n, H, n_kids, -}, lvl_off[H + 1], ord[n], kid_off[n + 1], kids[n_kids] (| 0x8000: back-reference)
+  const uint32_t* hdr;      // per forest, per node: row of its header in the lane's inside stream | bit 31 = AND
+  const uint64_t* tab_off;  // per lane slot: offset into tab (u16 words) / hdr (u32 words)
+  const uint64_t* hdr_off;
+  uint32_t lane_lo, lane_hi;            // the lane slots of this launch (a launch class)
+  uint32_t max_tab, max_n, max_front;   // LDS per forest: table words, nodes, frontier entries
+};
+__device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t& total) {
+  // exclusive prefix sum over the FM_G lanes of a forest; total = the sum
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < FM_G; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, FM_G);
+    if (li >= (uint32_t)d) x += y;
+  }
+  total = __shfl(x, FM_G - 1, FM_G);
+  return x - v;
+}
+__global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
+  extern __shared__ __attribute__((aligned(16))) double fm_lds[];
+  const uint32_t sub = threadIdx.x / FM_G, li = threadIdx.x % FM_G;
+  const uint32_t slot = M.lane_lo + blockIdx.x * FM_FPW + sub;
+  const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;
+  const bool active = forest != 0xffffffffu;
+  // this forest's stretch of LDS: mantissas (f64), exponents (i32), header words (u32), table + two frontiers (u16)
+  const size_t per = (size_t)M.max_n * 16 + (((size_t)M.max_tab + 2 * (size_t)M.max_front) * 2 + 15) / 16 * 16;
+  char* mine = (char*)fm_lds + per * sub;
+  double* vm = (double*)mine;
+  int* ve = (int*)(vm + M.max_n);
+  uint32_t* hd = (uint32_t*)(ve + M.max_n);
+  unsigned short* tb = (unsigned short*)(hd + M.max_n);
+  unsigned short* fr0 = tb + M.max_tab;
+  unsigned short* fr1 = fr0 + M.max_front;
+  uint32_t n = 0, H = 0;
+  const FGroup g = A.groups[active ? slot / 64 : M.lane_lo / 64];
+  const uint32_t lane = slot % 64;
+  if (active) {
+    const unsigned short* __restrict__ src = M.tab + M.tab_off[slot];
+    n = src[0];
+    H = src[1];
+    const uint32_t words = 4u + (H + 1) + n + (n + 1) + src[2];
+    for (uint32_t k = li; k < words; k += FM_G) tb[k] = src[k];
+    const uint32_t* __restrict__ hs = M.hdr + M.hdr_off[slot];
+    for (uint32_t k = li; k < n; k += FM_G) hd[k] = hs[k];
+  }
+  __syncthreads();
+  const unsigned short* lvl = tb + 4;
+  const unsigned short* ord = lvl + H + 1;
+  const unsigned short* koff = ord + n;
+  const unsigned short* kids = koff + n + 1;
+  const double* __restrict__ recp = A.rec_p + g.stream_base + lane;
+  // ---- inside, height by height (forest.hpp:768-816 with the proposal probabilities) ----
+  uint32_t Hmax = H;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) Hmax = max(Hmax, (uint32_t)__shfl_xor((int)Hmax, o, 64));
+  for (uint32_t h = 0; h < Hmax; ++h) {
+    if (h < H)
+      for (uint32_t j = lvl[h] + li; j < lvl[h + 1]; j += FM_G) {
+        const uint32_t node = ord[j];
+        const uint32_t hw = hd[node], k0 = koff[node], k1 = koff[node + 1];
+        double m;
+        int e;
+        if (hw & 0x80000000u) {  // AND: its rule's proposal probability times its children
+          m = frexp(recp[(size_t)(hw & 0x7fffffffu) * 64], &e);
+          for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t c = kids[k] & 0x7fffu;
+            int t;
+            m = frexp(m * vm[c], &t);
+            e += ve[c] + t;
+          }
+        } else {  // OR: the sum of its children, aligned to the larger exponent
+          m = 0.0;
+          e = 0;
+          for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t c = kids[k] & 0x7fffu;
+            const double cm = vm[c];
+            const int ce = ve[c];
+            if (cm == 0.0) continue;
+            if (m == 0.0) {
+              m = cm;
+              e = ce;
+            } else {
+              const int dd = ce - e;
+              int t;
+              if (dd <= 0)
+                m = frexp(m + ldexp(cm, dd), &t);
+              else {
+                m = frexp(ldexp(m, -dd) + cm, &t);
+                e = ce;
+              }
+              e += t;
+            }
+          }
+        }
+        vm[node] = m;
+        ve[node] = e;
+      }
+    __syncthreads();
+  }
+  // ---- the walk, breadth first (forest.hpp:725-758) ----
+  uint32_t nfr = active ? 1u : 0u, ns = 0, visited = 0;
+  if (active && li == 0) fr0[0] = (unsigned short)(n - 1);
+  __syncthreads();
+  uint32_t* outh = active ? A.sample_hdr + A.sample_off[forest] : nullptr;
+  unsigned short* cur = fr0;
+  unsigned short* nxt = fr1;
+  for (;;) {
+    if (!__any(nfr != 0)) break;
+    uint32_t nn = 0;  // entries of the next frontier so far
+    for (uint32_t base = 0; __any(base < nfr); base += FM_G) {
+      const uint32_t idx = base + li;
+      const bool have = idx < nfr;
+      uint32_t push = 0, rec = 0, node = 0, k0 = 0, pick = 0;
+      bool is_and = false;
+      if (have) {
+        node = cur[idx] & 0x7fffu;
+        const uint32_t hw = hd[node];
+        k0 = koff[node];
+        const uint32_t nch = koff[node + 1] - k0;
+        is_and = (hw & 0x80000000u) != 0;
+        if (is_and) {
+          rec = 1;
+          push = nch;
+        } else if (nch) {
+          // the reference's serial subtraction: the first child whose share takes the choice below zero, or the last
+          const int ne = ve[node];
+          double choice = gibbs_uniform(A.seed, A.iter, forest, visited + idx) * vm[node];
+          for (uint32_t k = 0;; ++k) {
+            pick = k;
+            const uint32_t c = kids[k0 + k] & 0x7fffu;
+            choice -= ldexp(vm[c], ve[c] - ne);
+            if (choice < 0 || k + 1 == nch) break;
+          }
+          push = 1;
+        }
+      }
+      uint32_t tot_push, tot_rec;
+      const uint32_t at = fm_prefix(push, li, tot_push), ar = fm_prefix(rec, li, tot_rec);
+      if (have) {
+        if (is_and) {
+          if (ns + ar < max_sample) outh[ns + ar] = hd[node] & 0x7fffffffu;
+          for (uint32_t k = 0; k < push; ++k)
+            if (nn + at + k < M.max_front) nxt[nn + at + k] = kids[k0 + k];
+        } else if (push) {
+          if (nn + at < M.max_front) nxt[nn + at] = kids[k0 + pick];
+        }
+      }
+      nn += tot_push;
+      ns += tot_rec;
+    }
+    visited += nfr;
+    __syncthreads();
+    nfr = nn < M.max_front ? nn : M.max_front;
+    unsigned short* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+  if (active && li == 0) A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+}
+
 // Viterbi (forest.hpp:507-632): max-product inside -- an AND node is its rule's weight times its children, an OR node
 // keeps its FIRST best child (a later child must be strictly better, forest.hpp:547) -- and the best derivation walked
 // from the root, recorded in pre-order as {rule, number of children} per AND node (what write_viterbi_rec prints).  One
@@ -1391,10 +1568,16 @@ struct carmel_hip_forests {
   hipStream_t side[N_SIDE] = {};  // launch classes of one sweep run side by side
   hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {};
   bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
+  // several lanes per forest (forest_sample_multi_kernel): per-forest tables, per lane slot
+  bool multi_ok = false;
+  DevBuf<uint16_t> mt_tab;
+  DevBuf<uint32_t> mt_hdr;
+  DevBuf<uint64_t> mt_tab_off, mt_hdr_off;
   std::vector<FGroup> h_groups;
   struct Cls {
     uint32_t first, count, max_nodes;
     uint32_t max_kids = 0, maxlen = 0;  // child entries / records of the class's largest lane (LDS walk tables)
+    uint32_t m_tab = 0, m_n = 0, m_front = 0;  // forest_sample_multi_kernel: table words / nodes / frontier entries of its largest forest
   };
   std::vector<Cls> classes;
   std::vector<uint32_t> h_norm, lane_of_forest;
@@ -1443,6 +1626,9 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     std::vector<uint32_t> hdr;  // per post-order node: header position in ins
     uint32_t n = 0;
     uint64_t max_deriv = 0;     // rules in the largest derivation (shared sub-forests count once per use)
+    std::vector<uint16_t> mt;   // forest_sample_multi_kernel's table block (FMultiArgs::tab); empty: the forest does not fit it
+    std::vector<uint32_t> mh;   // ... header row | AND per node
+    uint32_t m_front = 0;       // ... entries of its widest breadth-first frontier (bounded by the largest derivation)
   };
   std::vector<Flat> flat(n_forests);
   for (uint64_t f = 0; f < n_forests; ++f) {
@@ -1515,6 +1701,59 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     }
     fl.max_deriv = std::max<uint64_t>(1, dsz[fl.n - 1]);
     if (fl.max_deriv >= (1u << 20)) return fail(CARMEL_HIP_ERR_ARG, "forest derivation larger than 2^20 rules");
+    {
+      // tables of the several-lanes-per-forest sampler: nodes by height (leaves 0; a node is above all of its children,
+      // reached directly or through a back-reference), children lists, header rows
+      size_t nk = 0;
+      for (uint32_t k = 0; k < fl.n; ++k) nk += kids[k].size();
+      // a bound on any frontier of a breadth-first walk: the visits -- OR entries included -- of the largest derivation
+      std::vector<uint64_t> vsz(fl.n, 0);
+      for (uint32_t k = 0; k < fl.n; ++k) {
+        uint64_t v = 0;
+        if (label[b + idx[k]] != 0)
+          for (uint32_t c : kids[k]) v += vsz[c];
+        else
+          for (uint32_t c : kids[k]) v = std::max(v, vsz[c]);
+        vsz[k] = std::min<uint64_t>(v + 1, 1u << 20);
+      }
+      const uint64_t front = vsz[fl.n - 1] + 1;
+      if (fl.n < 0x7fffu && nk < 0x7fffu && front < 4096) {
+        std::vector<uint32_t> height(fl.n, 0);
+        uint32_t Hh = 0;
+        for (uint32_t k = 0; k < fl.n; ++k) {  // post-order: children first
+          uint32_t hh = 0;
+          for (uint32_t c : kids[k]) hh = std::max(hh, height[c] + 1);
+          height[k] = hh;
+          Hh = std::max(Hh, hh + 1);
+        }
+        std::vector<uint16_t>& mt = fl.mt;
+        mt.assign(4, 0);
+        mt[0] = (uint16_t)fl.n;
+        mt[1] = (uint16_t)Hh;
+        mt[2] = (uint16_t)nk;
+        std::vector<uint32_t> cnt(Hh + 1, 0);
+        for (uint32_t k = 0; k < fl.n; ++k) cnt[height[k] + 1]++;
+        for (uint32_t h = 0; h < Hh; ++h) cnt[h + 1] += cnt[h];
+        for (uint32_t h = 0; h <= Hh; ++h) mt.push_back((uint16_t)cnt[h]);
+        std::vector<uint16_t> ordv(fl.n);
+        {
+          std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
+          for (uint32_t k = 0; k < fl.n; ++k) ordv[cur[height[k]]++] = (uint16_t)k;
+        }
+        mt.insert(mt.end(), ordv.begin(), ordv.end());
+        uint32_t off = 0;
+        for (uint32_t k = 0; k < fl.n; ++k) {
+          mt.push_back((uint16_t)off);
+          off += (uint32_t)kids[k].size();
+        }
+        mt.push_back((uint16_t)off);
+        for (uint32_t k = 0; k < fl.n; ++k)
+          for (size_t c = 0; c < kids[k].size(); ++c) mt.push_back((uint16_t)(kids[k][c] | (kid_ref[k][c] ? 0x8000u : 0u)));
+        fl.mh.resize(fl.n);
+        for (uint32_t k = 0; k < fl.n; ++k) fl.mh[k] = fl.hdr[k] | (label[b + idx[k]] != 0 ? 0x80000000u : 0u);
+        fl.m_front = (uint32_t)front;
+      }
+    }
   }
   // ---- groups of 64, sorted by stream length ----
   std::vector<uint32_t> ord(n_forests);
@@ -1583,10 +1822,36 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         for (uint32_t l = 0; l < G.n_lanes; ++l) {
           const Flat& fl = flat[ord[G.lane_base + l]];
           c.max_kids = std::max<uint32_t>(c.max_kids, (uint32_t)(fl.ins.size() - fl.n));
+          c.m_tab = std::max<uint32_t>(c.m_tab, (uint32_t)fl.mt.size());
+          c.m_n = std::max(c.m_n, fl.n);
+          c.m_front = std::max(c.m_front, fl.m_front);
         }
       }
       F->classes.push_back(c);
       i = j;
+    }
+  }
+  {  // the several-lanes-per-forest tables, in lane-slot order (a wavefront's forests are neighbours)
+    F->multi_ok = true;
+    for (uint64_t f = 0; f < n_forests; ++f)
+      if (flat[f].mt.empty()) F->multi_ok = false;
+    if (F->multi_ok) {
+      std::vector<uint64_t> toff(ng * 64, 0), hoff(ng * 64, 0);
+      std::vector<uint16_t> tab;
+      std::vector<uint32_t> hdrs;
+      for (size_t l = 0; l < ng * 64; ++l) {
+        if (lane_forest[l] == 0xffffffffu) continue;
+        const Flat& fl = flat[lane_forest[l]];
+        toff[l] = tab.size();
+        hoff[l] = hdrs.size();
+        tab.insert(tab.end(), fl.mt.begin(), fl.mt.end());
+        hdrs.insert(hdrs.end(), fl.mh.begin(), fl.mh.end());
+      }
+      HIPCHK(F->mt_tab.upload(tab, s));
+      HIPCHK(F->mt_hdr.upload(hdrs, s));
+      HIPCHK(F->mt_tab_off.upload(toff, s));
+      HIPCHK(F->mt_hdr_off.upload(hoff, s));
+      HIPCHK(hipStreamSynchronize(s));
     }
   }
   {  // classes too large for LDS keep their columns in global memory
@@ -2024,6 +2289,10 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   const size_t frc_bytes = (size_t)(frc_slots0 + frc_slots1) * 8;
   (void)hipFuncSetAttribute((const void*)forest_recount_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)frc_bytes);
   const bool lds_walk = !(getenv("CARMEL_HIP_FOREST_LDSWALK") && atoi(getenv("CARMEL_HIP_FOREST_LDSWALK")) == 0);
+  // several lanes per forest in the parallel sweep (CARMEL_HIP_FOREST_MULTI=0: one forest per lane, the A/B reference -- and the
+  // chain whose uniforms are keyed like the sequential walk's)
+  const bool multi = sweep2 && F->multi_ok && !(getenv("CARMEL_HIP_FOREST_MULTI") && atoi(getenv("CARMEL_HIP_FOREST_MULTI")) == 0);
+  const uint64_t nf_slots = F->h_groups.size() * 64;
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
   if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
@@ -2106,7 +2375,22 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             hipLaunchKernelGGL(kernel, dim3(c.count), dim3(64), bytes, class_stream(F, s, ci), A, F->max_sample, c.max_nodes,
                                stack_lds, kid_rows);
           };
-          if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
+          // several lanes per forest (temperature 1, tables within LDS): forest_sample_multi_kernel
+          const size_t fm_per = (size_t)c.m_n * 16 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
+          if (multi && ext && fm_per * FM_FPW <= 64 * 1024) {
+            FMultiArgs MA;
+            MA.tab = F->mt_tab.p;
+            MA.hdr = F->mt_hdr.p;
+            MA.tab_off = F->mt_tab_off.p;
+            MA.hdr_off = F->mt_hdr_off.p;
+            MA.lane_lo = c.first * 64u;
+            MA.lane_hi = (uint32_t)std::min<uint64_t>((uint64_t)(c.first + c.count) * 64u, nf_slots);
+            MA.max_tab = c.m_tab;
+            MA.max_n = c.m_n;
+            MA.max_front = c.m_front;
+            const uint32_t nwg = (MA.lane_hi - MA.lane_lo + FM_FPW - 1) / FM_FPW;
+            hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, class_stream(F, s, ci), A, MA, F->max_sample);
+          } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
             A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
             if (ext)

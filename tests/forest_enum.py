@@ -37,6 +37,56 @@ def match(label, ref, nxt, i, sample, pos):
 
 
 # ---- the exact stationary distribution of a sweep on an enumerable corpus -------------------------------------------------
+def match_bfs(label, ref, nxt, sample):
+    """True iff `sample` lists, in BREADTH-FIRST order, the rules of a derivation of the forest: the walk of the several-lanes
+    sampler -- a frontier of nodes; an AND entry records its rule and hands all of its children to the next frontier, an OR
+    entry hands on ONE child (its choice), back-references resolve to their shared sub-forest.  The choice of an OR entry is
+    checked as soon as it is made: a chosen AND child's rule must be the sample's entry at the position the child will be
+    recorded at (the number of AND entries before it in the next frontier)."""
+    def res(i):
+        while ref[i] >= 0:
+            i = int(ref[i])
+        return i
+
+    def kids(i):
+        return [res(c) for c in children(nxt, i)]
+
+    import sys
+    sys.setrecursionlimit(max(20000, sys.getrecursionlimit()))
+    sample = list(sample)
+
+    def level(front, pos):
+        """front: the nodes of this frontier; pos: sample position of the first AND entry of this frontier"""
+        if not front:
+            return pos == len(sample)
+        n_and = sum(1 for v in front if label[v] != 0)
+        if pos + n_and > len(sample) or any(sample[pos + k] != label[v] for k, v in enumerate(v for v in front if label[v] != 0)):
+            return False
+        nxt_pos = pos + n_and
+
+        def fill(i, nf, n_and_next):
+            if i == len(front):
+                return level(nf, nxt_pos)
+            v = front[i]
+            if label[v] != 0:
+                ks = kids(v)
+                na = n_and_next
+                for c in ks:  # the AND children are recorded next level in this order: check them now
+                    if label[c] != 0:
+                        if nxt_pos + na >= len(sample) or sample[nxt_pos + na] != label[c]:
+                            return False
+                        na += 1
+                return fill(i + 1, nf + ks, na)
+            for c in kids(v):
+                if label[c] != 0 and (nxt_pos + n_and_next >= len(sample) or sample[nxt_pos + n_and_next] != label[c]):
+                    continue
+                if fill(i + 1, nf + [c], n_and_next + (1 if label[c] != 0 else 0)):
+                    return True
+            return False
+        return fill(0, [], 0)
+    return level([res(0)], 0)
+
+
 TOY_FORESTS = """(OR (1 (OR 4 5)) (2 6) (3 (OR 4 6)))
 (OR (1 5) (2 (OR 4 5 6)))
 (OR (2 (OR (7 4) (8 5))) (3 6) (1 4))

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
-from forest_enum import TOY_FORESTS, TOY_NORM, derivations as _derivations, match as _match, group_priors, toy_setup
+from forest_enum import TOY_FORESTS, TOY_NORM, derivations as _derivations, match_bfs, group_priors, toy_setup
 
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
@@ -82,8 +82,9 @@ def test_c5_slice_forest_em_and_exact_chain_match_the_oracle(oracle):
 
 def test_c5_full_size_parallel_sweep_properties():
     """bench.py --config c5's workload at full size (100 000 forests, 4.5 M nodes, 500 000 parameters), parallel stale-count
-    sweeps: (a) every forest's sample is a derivation of that forest -- its rules, in visit order, are matched against the
-    forest's own AND/OR structure, so the number of sampled rules equals the AND nodes visited; (b) the counts behind the
+    sweeps (the several-lanes-per-forest sampler): (a) every forest's sample is a derivation of that forest -- its rules, in the
+    breadth-first order of the walk, are matched against the forest's own AND/OR structure, so the number of sampled rules
+    equals the AND nodes visited; (b) the counts behind the
     final weights are exactly the sum over the samples: with --final-counts every rule's weight must equal
     (uses in the samples + prior) / (that sum over its norm group), and every group sums to one; (c) a run is reproducible
     for a seed; (d) the per-sweep probability is finite at every sweep"""
@@ -109,8 +110,7 @@ def test_c5_full_size_parallel_sweep_properties():
         e = int(node_off[f + 1])
         s = samples[f]
         assert len(s) > 0
-        ends = _match(label[b:e], ref[b:e], nxt[b:e], 0, s, 0)
-        assert len(s) in ends, "forest %d: the sample is not a derivation of the forest" % f
+        assert match_bfs(label[b:e], ref[b:e], nxt[b:e], s), "forest %d: the sample is not a derivation of the forest" % f
     assert all(len(s) > 0 for s in samples)  # (a shared sub-forest can be expanded more than once: no upper bound by nodes)
     # (b)
     uses = np.bincount(np.concatenate([np.asarray(s, np.int64) for s in samples]), minlength=n_rules).astype(np.float64)
@@ -122,8 +122,8 @@ def test_c5_full_size_parallel_sweep_properties():
     np.testing.assert_allclose(np.bincount(gid[in_g], weights=np.exp(wts[in_g]), minlength=len(gsize)), 1.0, rtol=1e-9)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode):
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode, monkeypatch):
     """5 forests x 4-5 derivations each = 1 600 joint states: the sweep's transition matrix is built exactly
     (tests/forest_enum.py) and its stationary rule-usage expectations are compared with what the GPU chain time-averages (the
     rule weights after the run are (average use + prior) / (its norm group's), from_gibbs forest-em.hpp:736-742).  16
@@ -133,6 +133,9 @@ def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle
     sweep has its OWN stationary distribution; the last assertion checks that on this corpus the other sweep's distribution
     is outside what the test resolves, i.e. that the test discriminates between the two chains)."""
     from carmel_amd.forests import HipForests
+    if mode == 2:  # the parallel sweep's one-forest-per-lane kernel (mode 1 is the several-lanes-per-forest default)
+        monkeypatch.setenv("CARMEL_HIP_FOREST_MULTI", "0")
+        mode = 1
     of = oracle.OracleForests(TOY_FORESTS, TOY_NORM)  # (the oracle only parses the text here)
     n_rules = of.n_rules
     lw = np.log(np.random.default_rng(3).uniform(0.2, 1.0, n_rules))

@@ -217,6 +217,7 @@ def test_forests_larger_than_lds(oracle):
     np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
     hf.close()
     res = []
+    os.environ["CARMEL_HIP_FOREST_MULTI"] = "0"  # (the one-forest-per-lane formulations: uniforms keyed like the sequential walk's)
     for sweep in ("1", None):  # both formulations of the parallel sweep: the same chain
         if sweep:
             os.environ["CARMEL_HIP_FOREST_SWEEP"] = sweep
@@ -227,6 +228,7 @@ def test_forests_larger_than_lds(oracle):
             hf2.close()
         finally:
             os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
+    os.environ.pop("CARMEL_HIP_FOREST_MULTI", None)
     assert res[0][1] == res[1][1]
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
 
@@ -307,8 +309,8 @@ def shaped_forests(n_forests, n_rules, seed, or_max, and_max, depth, spine=0):
                                    dict(or_max=6, and_max=5, depth=2, spine=24), dict(or_max=2, and_max=2, depth=4, spine=45),
                                    dict(or_max=12, and_max=3, depth=2, temps=(2.5, 0.5)), dict(or_max=4, and_max=4, depth=3, temps=(3.0, 1.0))])
 def test_parallel_sweep_formulations_on_wide_and_deep_forests(oracle, shape):
-    """The parallel sweep's three implementations -- tables per lane (CARMEL_HIP_FOREST_SWEEP=1), streamed proposals with the
-    walk over the global stream (CARMEL_HIP_FOREST_LDSWALK=0) and the default, walk tables in LDS -- are one chain: same samples,
+    """The parallel sweep's three one-forest-per-lane implementations -- tables per lane (CARMEL_HIP_FOREST_SWEEP=1), streamed
+    proposals with the walk over the global stream (CARMEL_HIP_FOREST_LDSWALK=0), walk tables in LDS -- are one chain: same samples,
     same probabilities, on OR / AND nodes wider than the walk's four-at-once, stacks deeper than its LDS part, annealed or not"""
     from carmel_amd.forests import HipForests
     shape = dict(shape)
@@ -336,9 +338,67 @@ def test_parallel_sweep_formulations_on_wide_and_deep_forests(oracle, shape):
                     os.environ[k] = v
 
     a = run({"CARMEL_HIP_FOREST_SWEEP": "1"})
-    for env in ({}, {"CARMEL_HIP_FOREST_LDSWALK": "0"}, {"CARMEL_HIP_FOREST_LOGDOMAIN": "1"}):
+    for env in ({"CARMEL_HIP_FOREST_MULTI": "0"}, {"CARMEL_HIP_FOREST_MULTI": "0", "CARMEL_HIP_FOREST_LDSWALK": "0"},
+                {"CARMEL_HIP_FOREST_LOGDOMAIN": "1"}):
         b = run(env)
         assert b[1] == a[1], env
         np.testing.assert_allclose(b[0], a[0], rtol=1e-11)
         np.testing.assert_allclose(np.exp(b[2]), np.exp(a[2]), rtol=1e-10, atol=1e-300)
     assert max(len(s) for s in a[1]) > (40 if shape.get("spine", 0) > 30 else 1)
+
+
+def _weights_from_samples(hf, of, lw, alpha, samples):
+    """what --final-counts must leave: (uses in the samples + prior) / (that over the rule's norm group)"""
+    from forest_enum import group_priors
+    gid, gsize, p0, prior = group_priors(of.n_rules, of.group_off, of.group_rule, lw, alpha)
+    uses = np.bincount(np.concatenate([np.asarray(x, np.int64) for x in samples]), minlength=of.n_rules).astype(np.float64)
+    in_g = gid >= 0
+    tot = np.bincount(gid[in_g], weights=(uses + prior)[in_g], minlength=len(gsize))
+    return in_g, (uses + prior)[in_g] / tot[gid[in_g]]
+
+
+@pytest.mark.parametrize("shape", [dict(), dict(fan=9), dict(arity=7), dict(spine=45), dict(fan=6, arity=5, seed=23)])
+def test_several_lanes_per_forest_sampler(oracle, shape):
+    """forest_sample_multi_kernel (the default of the parallel sweep at temperature 1): eight lanes per forest, inside pass
+    height by height, breadth-first walk.  Its uniforms are keyed by the breadth-first order of visits, so it is not the
+    one-per-lane chain draw for draw; what must hold: every sample is a derivation of its forest (matched in breadth-first
+    order against the forest's AND/OR structure, shared sub-forests included), the counts behind the final weights are the
+    samples' (--final-counts), a run is reproducible, and the sweep probabilities sit where the one-per-lane chain's sit.
+    Shapes: wide OR nodes, wide AND nodes, deep spines, both.  (Its stationary distribution is checked against the enumerated
+    one in tests/test_bench_workloads_gpu.py.)"""
+    from carmel_amd.forests import HipForests
+    from forest_enum import match_bfs
+    shape = dict(shape)
+    seed = shape.pop("seed", 17)
+    ftext, ntext = shaped_forests(300, 60, seed, **shape)
+    of = oracle.OracleForests(ftext, ntext)
+    lw = np.log(np.random.default_rng(3).uniform(0.05, 1.0, of.n_rules))
+
+    def run(env, **kw):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            hf = HipForests(of.node_off, of.label, of.ref, of.next, of.n_rules, lw, of.group_off, of.group_rule)
+            hf.gibbs(8, burnin=2, alpha=0.2, seed=21, mode=1, **kw)
+            res = (hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(hf.n_forests)], hf.weights().copy())
+            hf.close()
+            return res
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
+    a = run({}, final_counts=True)
+    b = run({}, final_counts=True)
+    assert a[1] == b[1] and np.array_equal(a[2], b[2])
+    old = run({"CARMEL_HIP_FOREST_MULTI": "0"}, final_counts=True)
+    assert a[1] != old[1]  # (the several-lanes kernel really ran: another chain)
+    for f, smp in enumerate(a[1]):
+        lo, hi = int(of.node_off[f]), int(of.node_off[f + 1])
+        assert match_bfs(of.label[lo:hi], of.ref[lo:hi], of.next[lo:hi], smp), "forest %d: not a derivation in breadth-first order" % f
+    in_g, expect = _weights_from_samples(None, of, lw, 0.2, a[1])
+    np.testing.assert_allclose(np.exp(a[2][in_g]), expect, rtol=1e-9, atol=1e-300)
+    # the same region of probability as the one-per-lane chain after the same number of sweeps
+    assert abs(a[0][-3:].mean() - old[0][-3:].mean()) < 0.05 * abs(old[0][-3:].mean())
