@@ -1706,17 +1706,28 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       // reached directly or through a back-reference), children lists, header rows
       size_t nk = 0;
       for (uint32_t k = 0; k < fl.n; ++k) nk += kids[k].size();
-      // a bound on any frontier of a breadth-first walk: the visits -- OR entries included -- of the largest derivation
-      std::vector<uint64_t> vsz(fl.n, 0);
-      for (uint32_t k = 0; k < fl.n; ++k) {
-        uint64_t v = 0;
-        if (label[b + idx[k]] != 0)
-          for (uint32_t c : kids[k]) v += vsz[c];
-        else
-          for (uint32_t c : kids[k]) v = std::max(v, vsz[c]);
-        vsz[k] = std::min<uint64_t>(v + 1, 1u << 20);
+      // the widest frontier a breadth-first walk can reach: w[d][k] = most entries d levels below node k (an AND node hands on
+      // all of its children, an OR node the widest of them); depth by depth until nothing is left
+      uint64_t front = 1;
+      {
+        std::vector<uint64_t> w(fl.n, 1), w2(fl.n);
+        for (uint32_t depth = 0; depth < 4096; ++depth) {
+          bool any = false;
+          for (uint32_t k = 0; k < fl.n; ++k) {  // (children have smaller ids: w of the previous depth is complete)
+            uint64_t v = 0;
+            if (label[b + idx[k]] != 0)
+              for (uint32_t c : kids[k]) v += w[c];
+            else
+              for (uint32_t c : kids[k]) v = std::max(v, w[c]);
+            w2[k] = std::min<uint64_t>(v, 1u << 20);
+            any = any || v;
+          }
+          w.swap(w2);
+          front = std::max(front, w[fl.n - 1]);
+          if (!any) break;
+        }
+        front += 1;
       }
-      const uint64_t front = vsz[fl.n - 1] + 1;
       if (fl.n < 0x7fffu && nk < 0x7fffu && front < 4096) {
         std::vector<uint32_t> height(fl.n, 0);
         uint32_t Hh = 0;
