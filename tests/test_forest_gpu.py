@@ -361,7 +361,8 @@ def _weights_from_samples(hf, of, lw, alpha, samples):
     return in_g, (uses + prior)[in_g] / tot[gid[in_g]]
 
 
-@pytest.mark.parametrize("shape", [dict(), dict(fan=9), dict(arity=7), dict(spine=45), dict(fan=6, arity=5, seed=23)])
+@pytest.mark.parametrize("shape", [dict(or_max=3, and_max=3, depth=3), dict(or_max=9, and_max=2, depth=3), dict(or_max=3, and_max=7, depth=3),
+                                   dict(or_max=2, and_max=2, depth=4, spine=45), dict(or_max=6, and_max=5, depth=2, spine=24, seed=23)])
 def test_several_lanes_per_forest_sampler(oracle, shape):
     """forest_sample_multi_kernel (the default of the parallel sweep at temperature 1): eight lanes per forest, inside pass
     height by height, breadth-first walk.  Its uniforms are keyed by the breadth-first order of visits, so it is not the
