@@ -204,7 +204,6 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;  // A/B: 0 = no one-per-wavefront lattices (bundles as before)
   if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
-  if (const char* e = getenv("CARMEL_HIP_LANE_SORT")) opt.lane_sort_by_arcs = atoi(e) != 0;  // A/B: 0 = corpus order among equal shapes
   if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
   {
     // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;

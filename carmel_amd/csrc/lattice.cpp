@@ -658,19 +658,11 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       return lats[a].n_states > lats[b].n_states;
     });
     // windowed lattices: by window first (a group's ring is its widest member's), then by length
-    // ... and, among lattices of one shape, by the arcs they use (their edge lists compared arc by arc): lattices that share
-    // a prefix of their derivations end up in the same lane group, so the group's tile of the blocked transposition draws
-    // longer runs from fewer arc buckets (a corpus of walks from one start state shares its first steps: config c4a)
     std::stable_sort(lane_win.begin(), lane_win.end(), [&](uint32_t a, uint32_t b) {
       const uint32_t wa = window_of(lats[a]), wb = window_of(lats[b]);
       if (wa != wb) return wa > wb;
       if (lats[a].edges.size() != lats[b].edges.size()) return lats[a].edges.size() > lats[b].edges.size();
-      if (lats[a].n_states != lats[b].n_states) return lats[a].n_states > lats[b].n_states;
-      if (!opt.lane_sort_by_arcs) return false;
-      const auto &ea = lats[a].edges, &eb = lats[b].edges;
-      for (size_t k = 0; k < ea.size(); ++k)
-        if (ea[k].arc != eb[k].arc) return ea[k].arc < eb[k].arc;
-      return false;
+      return lats[a].n_states > lats[b].n_states;
     });
     // plain groups, then windowed groups (a group never mixes the two): `lane` becomes one slot per lane, 64 per group
     const size_t ng_plain = (lane.size() + 63) / 64, ng = ng_plain + (lane_win.size() + 63) / 64;

@@ -94,6 +94,13 @@ TOY_FORESTS = """(OR (1 (OR 4 5)) (2 6) (3 (OR 4 6)))
 (OR (7 (OR 1 2)) (8 3) (7 4 5))
 """
 TOY_NORM = "((1 2 3) (4 5 6) (7 8))"
+# a second enumerable corpus for what the first does not have: an OR node with five children, an AND node with nine (a
+# breadth-first frontier wider than the eight lanes a forest gets), a shared sub-forest expanded twice in one derivation
+TOY2_FORESTS = """(OR (1 (OR 4 5 6 7 8)) (2 #1(OR 4 5) #1))
+(OR (3 1 2 4 5 6 7 8 1 2) (3 4))
+(OR (1 (OR 4 5)) (2 (OR 6 7 8)) 3)
+"""
+TOY2_NORM = "((1 2 3) (4 5 6 7 8))"
 
 
 def derivations(label, ref, nxt, i):

@@ -15,7 +15,7 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
-from forest_enum import TOY_FORESTS, TOY_NORM, derivations as _derivations, match_bfs, group_priors, toy_setup
+from forest_enum import TOY_FORESTS, TOY_NORM, TOY2_FORESTS, TOY2_NORM, derivations as _derivations, match_bfs, group_priors, toy_setup
 
 pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
@@ -122,8 +122,9 @@ def test_c5_full_size_parallel_sweep_properties():
     np.testing.assert_allclose(np.bincount(gid[in_g], weights=np.exp(wts[in_g]), minlength=len(gsize)), 1.0, rtol=1e-9)
 
 
+@pytest.mark.parametrize("corpus", [1, 2])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode, monkeypatch):
+def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode, corpus, monkeypatch):
     """5 forests x 4-5 derivations each = 1 600 joint states: the sweep's transition matrix is built exactly
     (tests/forest_enum.py) and its stationary rule-usage expectations are compared with what the GPU chain time-averages (the
     rule weights after the run are (average use + prior) / (its norm group's), from_gibbs forest-em.hpp:736-742).  16
@@ -136,12 +137,13 @@ def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle
     if mode == 2:  # the parallel sweep's one-forest-per-lane kernel (mode 1 is the several-lanes-per-forest default)
         monkeypatch.setenv("CARMEL_HIP_FOREST_MULTI", "0")
         mode = 1
-    of = oracle.OracleForests(TOY_FORESTS, TOY_NORM)  # (the oracle only parses the text here)
+    # corpus 2: a five-way OR, a nine-child AND (a frontier wider than a forest's eight lanes), a shared sub-forest expanded twice
+    of = oracle.OracleForests(*((TOY_FORESTS, TOY_NORM) if corpus == 1 else (TOY2_FORESTS, TOY2_NORM)))  # (the oracle only parses)
     n_rules = of.n_rules
     lw = np.log(np.random.default_rng(3).uniform(0.2, 1.0, n_rules))
     alpha = 0.5
     derivs, exact = toy_setup(of.node_off, of.label, of.ref, of.next, n_rules, of.group_off, of.group_rule, lw, alpha)
-    assert [len(d) for d in derivs] == [5, 4, 4, 5, 4]
+    assert [len(d) for d in derivs] == ([5, 4, 4, 5, 4] if corpus == 1 else [9, 2, 6])
     hf = HipForests(of.node_off, of.label, of.ref, of.next, n_rules, lw, of.group_off, of.group_rule)
     chains = []
     for seed in range(16):
@@ -153,8 +155,9 @@ def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle
     mean, se = chains.mean(0), chains.std(0, ddof=1) / math.sqrt(len(chains))
     z = (mean - exact[mode == 1][1:]) / se
     assert np.all(np.abs(z) < 4.9), (z, mean, exact[mode == 1][1:])
-    z_other = (mean - exact[mode != 1][1:]) / se
-    assert np.max(np.abs(z_other)) > 6.0, z_other
+    if corpus == 1:  # (on corpus 2 the two sweeps' stationary expectations differ by 3e-7: nothing to tell apart)
+        z_other = (mean - exact[mode != 1][1:]) / se
+        assert np.max(np.abs(z_other)) > 6.0, z_other
 
 
 def test_parallel_sweep_approaches_the_exact_chain_as_the_corpus_grows():
