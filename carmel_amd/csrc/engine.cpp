@@ -223,13 +223,22 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
         build_pair_lattice(t->w, t->corpus.in_sym.data() + t->corpus.in_off[p], (uint32_t)(t->corpus.in_off[p + 1] - t->corpus.in_off[p]),
                            t->corpus.out_sym.data() + t->corpus.out_off[p], (uint32_t)(t->corpus.out_off[p + 1] - t->corpus.out_off[p]),
                            opt.prune, pl, hd);
-        if (pl.explored_states > 256 || (hd && (pl.cyclic || pl.n_states > opt.lane_states || pl.edges.size() > 256))) probe_ok = false;
+        // beyond the small capacities (256 explored states, 256 lattice arcs): the builder's large ones; beyond those, a cycle:
+        // the host
+        if (pl.explored_states > 200 || (hd && (pl.n_states > opt.lane_states || pl.edges.size() > 200))) opt.gpu_large_caps = true;
+        if (pl.explored_states > 1024 || (hd && (pl.cyclic || pl.n_states > 1023 || pl.edges.size() > 1536))) probe_ok = false;
       }
     }
     if (want_gpu && probe_ok) {
       bool done = false;
       int rc = gpu_build_lattices(t, opt, has_derivation, stats, done);
       if (rc) return rc;
+      if (!done && !opt.gpu_large_caps) {  // (small corpora are not probed: a pair beyond the small capacities may fit the large ones)
+        opt.gpu_large_caps = true;
+        rc = gpu_build_lattices(t, opt, has_derivation, stats, done);
+        if (rc) return rc;
+        if (!done) opt.gpu_large_caps = false;
+      }
       if (done) {
         if (getenv("CARMEL_TIMING")) fprintf(stderr, "timing: lattices built on the GPU\n");
         return build_run_tables(t);

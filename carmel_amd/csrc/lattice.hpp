@@ -233,6 +233,7 @@ struct BuildOptions {
                                    // many LDS rows whatever their size (up to 1023 states); 0 disables windowed groups
   uint32_t lane_window_min = 40;   // ... but only lattices above this many states: below ~20 KB of LDS per wave the
                                    // occupancy is not what bounds the sweep (and the GPU builder covers those)
+  bool gpu_large_caps = false;     // GPU builder: the larger per-pair capacities (lattices of up to 1 023 states; set by the probe)
   bool wave_ring = true;           // ring form of the wave sweep where the lattice allows it (WaveDesc::ring)
   bool wave = true;                // one-lattice-per-wavefront layout for large / few-and-wide lattices (WaveDesc)
   double wave_min_width = 4.0;     // ... for lattices that no lane takes: at least this many arcs per level on average

@@ -32,11 +32,15 @@
 
 namespace {
 
-const uint32_t GX = 256;   // explored states per pair
-const uint32_t GE = 448;   // edges kept during exploration, per pair
-const uint32_t GK = 256;   // arcs of the pruned lattice, per pair (stride of the per-pair record arrays)
-const uint32_t GH = 512;   // hash slots (2 * GX)
-const uint32_t G_THREADS = 131072;
+// per-pair capacities of the exploration (GArgs::cx ...): explored states, edges kept during exploration, arcs of the pruned
+// lattice (stride of the per-pair record arrays), hash slots (2 * cx).  Two sizes: the small one covers corpora of plain
+// one-per-lane lattices (config 4: 17 KB of scratch per thread), the large one corpora with windowed groups -- lattices of
+// up to 1 023 states (the tagging cascade, config c4a).
+struct GCaps {
+  uint32_t cx, ce, ck, ch, threads;
+};
+const GCaps G_SMALL = {256, 448, 256, 512, 131072};
+const GCaps G_LARGE = {1024, 2560, 1536, 2048, 65536};
 
 enum { PF_HAS = 1, PF_FALLBACK = 2 };
 
@@ -54,6 +58,10 @@ struct GArgs {
   const uint32_t* out_sym;
   uint64_t n_pairs;
   uint32_t lane_states;
+  uint32_t cx, ce, ck, ch;   // capacities (GCaps)
+  uint32_t span_min;         // lattices above this many states get their span (BuildOptions::lane_window_min)
+  uint16_t* pp_span;         // max over the arcs of (dst - src) in the (level, id) numbering; 0 = not computed
+  uint16_t* pp_L;            // levels
   // per-thread scratch
   uint8_t* scratch;
   uint32_t scratch_stride;
@@ -94,6 +102,7 @@ __device__ __forceinline__ void key_range(const GArgs& G, uint32_t s, uint64_t k
 __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint8_t* base = G.scratch + (size_t)tid * G.scratch_stride;
+  const uint32_t GX = G.cx, GE = G.ce, GK = G.ck, GH = G.ch;
   // carve the private slice
   uint32_t* st_i = (uint32_t*)base;             // [GX]
   uint32_t* st_s = st_i + GX;
@@ -113,10 +122,10 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
   uint16_t* wd = wc + GE + 2;
   uint16_t* we = wd + GE + 2;
   uint16_t* wf = we + GE + 2;
-  uint8_t* removed = (uint8_t*)(wf + GE + 2);   // [GX]
+  uint16_t* level = wf + GE + 2;                // [GX]
+  uint8_t* removed = (uint8_t*)(level + GX);    // [GX]
   uint8_t* f_phase = removed + GX;              // [GX]
   uint8_t* f_flags = f_phase + GX;              // bit0 dead, bit1 pending
-  uint8_t* level = f_flags + GX;                // [GX]
   for (uint64_t p = tid; p < G.n_pairs; p += (uint64_t)gridDim.x * blockDim.x) {
     const uint32_t* in = G.in_sym + G.in_off[p];
     const uint32_t* out = G.out_sym + G.out_off[p];
@@ -242,6 +251,8 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
     G.pp_xa[p] = explored_arcs;
     G.pp_E[p] = 0;
     G.pp_S[p] = 0;
+    G.pp_span[p] = 0;
+    G.pp_L[p] = 0;
     if (overflow) {
       G.pp_flags[p] = PF_FALLBACK;
       continue;
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
         ++E;
       }
     const uint32_t S = kept;
-    if (S > G.lane_states || S > 1023u || E > GK || keep[0] == 0xffffu) {  // not a one-lattice-per-lane case
+    if (S > 1023u || E > GK || E > LANE_POS_MAX || keep[0] == 0xffffu) {  // not a one-lattice-per-lane case, plain or windowed
       G.pp_flags[p] = PF_HAS | PF_FALLBACK;
       continue;
     }
@@ -334,7 +345,7 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
       const uint32_t lu = level[u];
       for (uint32_t k = ooff[u]; k < ooff[u + 1]; ++k) {
         const uint32_t v = odst[k];
-        if (level[v] < lu + 1) level[v] = (uint8_t)(lu + 1);
+        if (level[v] < lu + 1) level[v] = (uint16_t)(lu + 1);
         if (--indeg[v] == 0) q[qn++] = (uint16_t)v;
       }
     }
@@ -373,6 +384,16 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
       for (uint32_t s = 0; s < S; ++s) c[s] = ooff2[s];
       for (uint32_t e = 0; e < E; ++e) oe[c[newid[e_src[e]]]++] = (uint16_t)e;
     }
+    if (S > G.span_min) {  // how far apart are an arc's ends in this numbering?  (windowed groups, lattice.cpp)
+      uint32_t sp = 1;
+      for (uint32_t e = 0; e < E; ++e) sp = max(sp, (uint32_t)newid[e_dst[e]] - (uint32_t)newid[e_src[e]]);
+      G.pp_span[p] = (uint16_t)sp;
+    }
+    {
+      uint32_t nl = 0;
+      for (uint32_t s2 = 0; s2 < S; ++s2) nl = max(nl, (uint32_t)level[s2] + 1u);
+      G.pp_L[p] = (uint16_t)nl;
+    }
     uint32_t* rf = G.rec_fwd + p * GK;
     uint32_t* rb = G.rec_bwd + p * GK;
     uint32_t* ra = G.rec_arc + p * GK;
@@ -400,12 +421,60 @@ __global__ __launch_bounds__(256) void explore_kernel(GArgs G) {
   }
 }
 
-// sort key of a pair: lattices with more arcs first, then more states, then corpus order (the host's stable_sort);
-// pairs without a derivation last
-__global__ void pair_key_kernel(const uint16_t* E, const uint16_t* S, const uint8_t* flags, uint64_t n, unsigned long long* key) {
+// the ring a windowed lattice needs (lattice.cpp window_of): the power of two above its span, 0 = not windowed
+__device__ __forceinline__ uint32_t window_of(uint32_t span, uint32_t S, uint32_t use_window, uint32_t lane_window) {
+  if (!use_window || !span) return 0u;
+  uint32_t w = 8;
+  while (w < span + 1) w <<= 1;
+  return (w <= lane_window && w < S) ? w : 0u;
+}
+struct ClassArgs {
+  const uint16_t* E;
+  const uint16_t* S;
+  const uint16_t* span;
+  const uint16_t* L;
+  const uint8_t* flags;
+  uint64_t n;
+  uint32_t use_window, lane_window, lane_states;
+  double wave_min_width;  // (BuildOptions::wave_lane_min_width)
+};
+// what a pair is: 0 = plain lane, w = windowed lane with a ring of w rows, 0xff = neither (the host builder's business);
+// counts {plain, windowed, other, windowed AND above lane_states AND wide enough for a wavefront of its own}
+__global__ void classify_kernel(ClassArgs C, uint8_t* win, unsigned long long* out) {
+  unsigned long long v[4] = {0, 0, 0, 0};
+  for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < C.n; p += (uint64_t)gridDim.x * blockDim.x) {
+    uint8_t k = 0;
+    if (C.flags[p] & PF_HAS) {
+      const uint32_t S = C.S[p], E = C.E[p];
+      const uint32_t w = window_of(C.span[p], S, C.use_window, C.lane_window);
+      if (w) {
+        k = (uint8_t)w;
+        ++v[1];
+        if (S > C.lane_states && C.L[p] > 1 && (double)E >= C.wave_min_width * (double)(C.L[p] - 1)) ++v[3];
+      } else if (S <= C.lane_states)
+        ++v[0];
+      else {
+        k = 0xff;
+        ++v[2];
+      }
+    }
+    win[p] = k;
+  }
+  for (int q = 0; q < 4; ++q) {
+    for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+    if ((threadIdx.x & 63) == 0 && v[q]) atomicAdd(out + q, v[q]);
+  }
+}
+
+// sort key of a pair: plain lattices first -- more arcs first, then more states, then corpus order (the host's stable_sort)
+// --, then the windowed ones -- wider ring first, then the same; pairs without a derivation last
+__global__ void pair_key_kernel(const uint16_t* E, const uint16_t* S, const uint8_t* flags, const uint8_t* win, uint64_t n,
+                                unsigned long long* key) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  key[p] = (flags[p] & PF_HAS) ? (((unsigned long long)(0xffffu - E[p]) << 48) | ((unsigned long long)(0xffffu - S[p]) << 32) | p)
+  const unsigned long long w = win[p];
+  key[p] = (flags[p] & PF_HAS) ? ((w ? (1ull << 62) | ((0x7full - w) << 55) : 0ull) | ((unsigned long long)(0x7ffu - E[p]) << 44) |
+                                  ((unsigned long long)(0x3ffu - S[p]) << 34) | p)
                                : ~0ull;
 }
 
@@ -429,44 +498,63 @@ __global__ void pair_stats_kernel(const uint16_t* E, const uint16_t* S, const ui
   }
 }
 
-// one wave per lane group: its descriptor (rows, widest lattice)
+// lane slot -> index in the sorted pair list: the plain lattices fill groups [0, ng_plain), the windowed ones start a group
+// of their own (lattice.cpp: a group never mixes the two); 2^63 = an empty slot
+struct SlotMap {
+  uint64_t n_plain, n_win;
+  uint32_t ng_plain;
+  __device__ __forceinline__ unsigned long long at(uint32_t group, uint32_t lane) const {
+    if (group < ng_plain) {
+      const uint64_t j = (uint64_t)group * 64 + lane;
+      return j < n_plain ? j : ~0ull;
+    }
+    const uint64_t r = (uint64_t)(group - ng_plain) * 64 + lane;
+    return r < n_win ? n_plain + r : ~0ull;
+  }
+};
+
+// one wave per lane group: its descriptor (rows, widest lattice, widest ring)
 __global__ __launch_bounds__(64) void group_dims_kernel(const unsigned long long* sorted_key, const uint16_t* E, const uint16_t* S,
-                                                        uint64_t n_kept, uint32_t* g_maxlen, uint32_t* g_maxstates,
-                                                        uint32_t* g_items) {
-  const uint64_t j = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  uint32_t e = 0, s = 0;
-  if (j < n_kept) {
+                                                        const uint8_t* win, SlotMap M, uint32_t* g_maxlen, uint32_t* g_maxstates,
+                                                        uint32_t* g_items, uint32_t* g_window) {
+  const unsigned long long j = M.at(blockIdx.x, threadIdx.x);
+  uint32_t e = 0, s = 0, w = 0;
+  if (j != ~0ull) {
     const uint32_t p = (uint32_t)(sorted_key[j] & 0xffffffffull);
     e = E[p];
     s = S[p];
+    w = win[p];
   }
-  uint32_t me = e, ms = s, te = e;
+  uint32_t me = e, ms = s, te = e, mw = w;
   for (int o = 32; o > 0; o >>= 1) {
     me = max(me, (uint32_t)__shfl_down(me, o, 64));
     ms = max(ms, (uint32_t)__shfl_down(ms, o, 64));
+    mw = max(mw, (uint32_t)__shfl_down(mw, o, 64));
     te += (uint32_t)__shfl_down(te, o, 64);
   }
   if (threadIdx.x == 0) {
     g_maxlen[blockIdx.x] = (max(me, 1u) + LANE_CHUNK - 1) / LANE_CHUNK * LANE_CHUNK;
     g_maxstates[blockIdx.x] = ms;
     g_items[blockIdx.x] = te;
+    g_window[blockIdx.x] = mw;
   }
 }
 
 // one wave per lane group: interleave the 64 record streams, emit the (arc, slot) items
 __global__ __launch_bounds__(64) void interleave_kernel(const LaneGroup* groups, const unsigned long long* sorted_key, const uint16_t* E,
                                                         const uint16_t* S, const uint32_t* rec_fwd, const uint32_t* rec_bwd,
-                                                        const uint32_t* rec_arc, const double* pair_weight, uint64_t n_kept,
+                                                        const uint32_t* rec_arc, const double* pair_weight, SlotMap M, uint32_t GK,
                                                         const unsigned long long* g_item_off, uint32_t* lane_fwdx, uint32_t* lane_bwd,
                                                         uint32_t* lane_pair, uint32_t* lane_nstates, double* lane_logw,
                                                         unsigned long long* items) {
   const LaneGroup g = groups[blockIdx.x];
   const uint32_t lane = threadIdx.x;
-  const uint64_t j = (uint64_t)g.pair_base + lane;
+  const uint64_t j = (uint64_t)g.pair_base + lane;  // lane slot
+  const unsigned long long sj = M.at(blockIdx.x, lane);
   uint32_t e = 0, p = 0;
-  const bool active = lane < g.n_lanes && j < n_kept;
+  const bool active = lane < g.n_lanes && sj != ~0ull;
   if (active) {
-    p = (uint32_t)(sorted_key[j] & 0xffffffffull);
+    p = (uint32_t)(sorted_key[sj] & 0xffffffffull);
     e = E[p];
     lane_pair[j] = p;
     lane_nstates[j] = S[p];
@@ -798,6 +886,8 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   const HostWfst& w = t->w;
   const HostCorpus& c = t->corpus;
   const uint64_t np = c.n_pairs;
+  const GCaps caps = opt.gpu_large_caps ? G_LARGE : G_SMALL;
+  const uint32_t GX = caps.cx, GE = caps.ce, GK = caps.ck, GH = caps.ch;
   if (!np || !opt.lane_states || opt.lane_states > GX || !opt.prune) return CARMEL_HIP_OK;
   if (np >= 0xfffffff0ull || w.n_arcs >= 0xfffffff0ull) return CARMEL_HIP_OK;
   const auto t0 = std::chrono::steady_clock::now();
@@ -829,10 +919,13 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   }
   HIPCHK(d_pw.upload(c.weight, s));
   // ---- one thread per pair: explore, prune, levels, lane records ----
-  const uint32_t stride = (uint32_t)(((4 * (6 * GX + GE) + 2 * (GH + 2 * GX + 2 * GE + 6 * (GE + 2)) + 4 * GX) + 63) / 64 * 64);
-  const uint32_t n_threads = (uint32_t)std::min<uint64_t>(G_THREADS, (np + 255) / 256 * 256);
-  DevBuf<uint8_t> scratch, pp_flags;
-  DevBuf<uint16_t> pp_E, pp_S;
+  const uint32_t stride = (uint32_t)(((4 * (6 * GX + GE) + 2 * (GH + 3 * GX + 2 * GE + 6 * (GE + 2)) + 3 * GX) + 63) / 64 * 64);
+  const uint32_t n_threads = (uint32_t)std::min<uint64_t>(caps.threads, (np + 255) / 256 * 256);
+  DevBuf<uint8_t> scratch, pp_flags, pp_win;
+  DevBuf<uint16_t> pp_E, pp_S, pp_span, pp_L;
+  HIPCHK(pp_span.alloc(np));
+  HIPCHK(pp_L.alloc(np));
+  HIPCHK(pp_win.alloc(np));
   DevBuf<uint32_t> pp_xs, pp_xa, rec_fwd, rec_bwd, rec_arc;
   HIPCHK(scratch.alloc((size_t)n_threads * stride));
   HIPCHK(pp_flags.alloc(np));
@@ -855,6 +948,13 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   G.out_sym = d_out.p;
   G.n_pairs = np;
   G.lane_states = opt.lane_states;
+  G.cx = GX;
+  G.ce = GE;
+  G.ck = GK;
+  G.ch = GH;
+  G.span_min = opt.lane_window ? opt.lane_window_min : 0xffffffffu;
+  G.pp_span = pp_span.p;
+  G.pp_L = pp_L.p;
   G.scratch = scratch.p;
   G.scratch_stride = stride;
   G.pp_E = pp_E.p;
@@ -877,47 +977,85 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   HIPCHK(hipStreamSynchronize(s));
   lap("explore + prune + records");
   if (hs[1]) return CARMEL_HIP_OK;  // some pair is not a case for this builder: the host builder does the whole corpus
-  // a corpus with a tenth of its arcs in lattices above lane_window_min states gets windowed lane groups (lattice.cpp,
-  // the same rule): those are laid out on the host
-  if (opt.lane_window && hs[6] * 10 >= hs[5]) return CARMEL_HIP_OK;
   const uint64_t n_kept = hs[0], n_items = hs[5];
-  if (!n_kept || n_items >= (1ull << 32)) return CARMEL_HIP_OK;
+  if (!n_kept || n_items >= (1ull << 32) || np >= (1ull << 32)) return CARMEL_HIP_OK;
+  // a corpus with a tenth of its arcs in lattices above lane_window_min states gets windowed lane groups (lattice.cpp, the
+  // same rule); what every pair is -- plain lane, windowed lane with a ring of w rows, neither -- follows from its span
+  const uint32_t use_window = (opt.lane_window && hs[6] * 10 >= hs[5]) ? 1u : 0u;
+  unsigned long long hc[4] = {0, 0, 0, 0};
+  {
+    ClassArgs CA;
+    CA.E = pp_E.p;
+    CA.S = pp_S.p;
+    CA.span = pp_span.p;
+    CA.L = pp_L.p;
+    CA.flags = pp_flags.p;
+    CA.n = np;
+    CA.use_window = use_window;
+    CA.lane_window = opt.lane_window;
+    CA.lane_states = opt.lane_states;
+    CA.wave_min_width = opt.wave_lane_min_width;
+    HIPCHK(hipMemsetAsync(d_stats.p, 0, 64, s));
+    hipLaunchKernelGGL(classify_kernel, dim3(1024), dim3(256), 0, s, CA, pp_win.p, d_stats.p);
+    HIPCHK(hipMemcpyAsync(hc, d_stats.p, 32, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  const uint64_t n_plain = hc[0], n_win = hc[1];
+  if (hc[2]) return CARMEL_HIP_OK;  // lattices no lane takes: bundles / one-per-wavefront lattices are laid out on the host
+  // (the host builder gives wide windowed lattices a wavefront of their own when the corpus is too small to fill the chip
+  // one per lane: lattice.cpp, BuildOptions::wave_lane_threshold)
+  if (opt.wave && hc[3] && n_plain + n_win < opt.wave_lane_threshold) return CARMEL_HIP_OK;
   // ---- lane groups ----
   DevBuf<unsigned long long> key, key_sorted;
   DevBuf<char> tmp;
   HIPCHK(key.alloc(np));
   HIPCHK(key_sorted.alloc(np));
-  hipLaunchKernelGGL(pair_key_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, pp_E.p, pp_S.p, pp_flags.p, np, key.p);
+  hipLaunchKernelGGL(pair_key_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, pp_E.p, pp_S.p, pp_flags.p, pp_win.p, np, key.p);
   HIPCHK(sort_keys(tmp, key.p, key_sorted.p, np, 64, s));
-  const size_t ng = (size_t)((n_kept + 63) / 64);
-  DevBuf<uint32_t> g_maxlen, g_maxstates, g_items;
+  const size_t ng_plain = (size_t)((n_plain + 63) / 64), ng = ng_plain + (size_t)((n_win + 63) / 64);
+  SlotMap SM;
+  SM.n_plain = n_plain;
+  SM.n_win = n_win;
+  SM.ng_plain = (uint32_t)ng_plain;
+  DevBuf<uint32_t> g_maxlen, g_maxstates, g_items, g_window;
   HIPCHK(g_maxlen.alloc(ng));
   HIPCHK(g_maxstates.alloc(ng));
   HIPCHK(g_items.alloc(ng));
-  hipLaunchKernelGGL(group_dims_kernel, dim3((unsigned)ng), dim3(64), 0, s, key_sorted.p, pp_E.p, pp_S.p, n_kept, g_maxlen.p,
-                     g_maxstates.p, g_items.p);
-  std::vector<uint32_t> h_maxlen(ng), h_maxstates(ng), h_items(ng);
+  HIPCHK(g_window.alloc(ng));
+  hipLaunchKernelGGL(group_dims_kernel, dim3((unsigned)ng), dim3(64), 0, s, key_sorted.p, pp_E.p, pp_S.p, pp_win.p, SM, g_maxlen.p,
+                     g_maxstates.p, g_items.p, g_window.p);
+  std::vector<uint32_t> h_maxlen(ng), h_maxstates(ng), h_items(ng), h_window(ng);
   HIPCHK(hipMemcpyAsync(h_maxlen.data(), g_maxlen.p, ng * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(h_maxstates.data(), g_maxstates.p, ng * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(h_items.data(), g_items.p, ng * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipMemcpyAsync(h_window.data(), g_window.p, ng * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   LatticeSet& L = t->lat;
   L = LatticeSet();
   L.lane_groups.resize(ng);
   std::vector<unsigned long long> h_item_off(ng);
+  uint64_t spill_rows = 0;
   {
     unsigned long long acc = 0;
     for (size_t g = 0; g < ng; ++g) {
       LaneGroup& Gd = L.lane_groups[g];
       std::memset(&Gd, 0, sizeof Gd);
-      Gd.n_lanes = (uint32_t)std::min<uint64_t>(64, n_kept - g * 64);
+      Gd.n_lanes = (uint32_t)(g < ng_plain ? std::min<uint64_t>(64, n_plain - g * 64) : std::min<uint64_t>(64, n_win - (g - ng_plain) * 64));
       Gd.pair_base = (uint32_t)(g * 64);
       Gd.maxlen = h_maxlen[g];
-      Gd.max_states = h_maxstates[g];
+      const uint32_t win = g < ng_plain ? 0u : h_window[g];
+      Gd.max_states = win ? win : h_maxstates[g];
+      Gd.window = win;
+      if (win) {
+        if (spill_rows + h_maxstates[g] > 0xffffffffull) return CARMEL_HIP_OK;
+        Gd.spill_row = (uint32_t)spill_rows;
+        spill_rows += h_maxstates[g];
+      }
       h_item_off[g] = acc;
       acc += h_items[g];
     }
   }
+  L.lane_spill_rows = spill_rows;
   const uint64_t n_rec = assign_lane_classes(L, opt);  // launch classes, pieces, stream bases: the host builder's own rule
   if (n_rec >= (1ull << 32)) return CARMEL_HIP_OK;
   lap("pair sort + lane groups");
@@ -936,8 +1074,12 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   HIPCHK(items.alloc(n_items));
   HIPCHK(items_sorted.alloc(n_items));
   hipLaunchKernelGGL(interleave_kernel, dim3((unsigned)ng), dim3(64), 0, s, t->lane_groups.p, key_sorted.p, pp_E.p, pp_S.p, rec_fwd.p,
-                     rec_bwd.p, rec_arc.p, d_pw.p, n_kept, d_item_off.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_pair.p,
+                     rec_bwd.p, rec_arc.p, d_pw.p, SM, GK, d_item_off.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_pair.p,
                      t->lane_nstates.p, t->lane_logw.p, items.p);
+  if (spill_rows)
+    HIPCHK(t->lane_spill.alloc(spill_rows * 64));
+  else
+    t->lane_spill.release();
   HIPCHK(hipGetLastError());
   lap("record streams");
   // ---- slots by arc ----
@@ -1080,7 +1222,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   t->device_bytes = t->lane_groups.bytes() + t->lane_fwdx.bytes() + t->lane_bwd.bytes() + t->lane_pair.bytes() + t->lane_nstates.bytes() +
                     t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() + t->arc_off.bytes() + t->slot_pos.bytes() +
                     t->t_b_arc.bytes() + t->t_b_rank.bytes() + t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() +
-                    t->t_x.bytes() + t->t_xc.bytes() + t->pair_logprob.bytes();
+                    t->t_x.bytes() + t->t_xc.bytes() + t->pair_logprob.bytes() + t->lane_spill.bytes();
   t->have_lattices = true;
   ++t->lattice_epoch;
   if (stats) {
@@ -1098,6 +1240,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     stats->last_pair_explored_states = L.last_pre_states;
     stats->last_pair_kept_states = L.last_post_states;
     stats->last_pair_kept_arcs = L.last_post_arcs;
+    stats->n_windowed_pairs = n_win;
     stats->n_windowed_pairs = 0;
     for (auto& g : L.lane_groups)
       if (g.window) stats->n_windowed_pairs += g.n_lanes;

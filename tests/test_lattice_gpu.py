@@ -85,3 +85,43 @@ def test_corpora_outside_its_scope_go_to_the_host_builder(oracle):
     a, b = _build(w, c, False), _build(w, c, True)
     _same(a, b)
     assert a["stats"][4] / a["stats"][1] > 96
+
+
+def _tagging(reps):
+    from oracle import binding as ob
+    from conftest import GOLDEN
+    g = lambda n: open(os.path.join(GOLDEN, n)).read()
+    oc = ob.OracleCascade([g("tagging.fsa"), g("tagging.fst")])
+    a = oc.composed().arrays()
+    w = Wfst(a["n_states"], a["final"], a["src"], a["dst"], a["isym"], a["osym"], a["logw"], a["group"])
+    ca = oc.corpus(g("tagging.data") * reps).arrays()
+    return w, Corpus(ca["in_off"], ca["in_sym"], ca["out_off"], ca["out_sym"], ca["weight"])
+
+
+@pytest.mark.parametrize("name", ["c4a", "tagging", "forced"])
+def test_windowed_corpora_are_built_on_the_device(name, capfd, monkeypatch):
+    """round 3: corpora with WINDOWED lane groups (lattices of up to 1 023 states whose arcs span few states of the
+    topological numbering: the tagging cascade, config c4a) -- larger per-pair capacities for the exploration, the span and
+    the ring of every lattice, plain groups then windowed groups, parked-value rows -- leave the host builder's image, byte
+    for byte.  `forced`: windows forced onto small random lattices (CARMEL_HIP_LANE_WINDOW_MIN)."""
+    monkeypatch.setenv("CARMEL_TIMING", "1")
+    if name == "c4a":
+        w, c = synth.make_config("c4a", n_pairs=30000)
+    elif name == "tagging":
+        w, c = _tagging(6)
+    else:
+        monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "6")
+        w = synth.random_wfst(40, 4, n_sym=4, p_eps=0.1, seed=73)
+        c = synth.random_walk_corpus(w, 3000, min_arcs=4, max_arcs=50, seed=73, out_degree=4)
+    host = _build(w, c, False)
+    capfd.readouterr()
+    dev = _build(w, c, True)
+    err = capfd.readouterr().err
+    assert "lattices built on the GPU" in err, "the device builder gave the corpus back to the host"
+    _same(host, dev)
+    from carmel_amd.trainer import HipForwardBackward
+    fb = HipForwardBackward(w, c)
+    assert fb.lattice_stats.n_windowed_pairs > 0
+    fb.close()
+    if name == "tagging":
+        assert dev["seconds"] < host["seconds"]
