@@ -558,8 +558,7 @@ __global__ __launch_bounds__(64) void interleave_kernel(const LaneGroup* groups,
     e = E[p];
     lane_pair[j] = p;
     lane_nstates[j] = S[p];
-    const double wt = pair_weight ? pair_weight[p] : 1.0;
-    lane_logw[j] = wt > 0 ? log(wt) : -__builtin_huge_val();
+    lane_logw[j] = pair_weight ? pair_weight[p] : 0.0;  // (ln of the pair's weight, taken on the host: the host builder's bits)
   } else if (lane < 64) {
     lane_pair[j] = 0xffffffffu;
     lane_nstates[j] = 0;
@@ -917,7 +916,11 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     HIPCHK(d_in.upload(a, s));
     HIPCHK(d_out.upload(b, s));
   }
-  HIPCHK(d_pw.upload(c.weight, s));
+  {
+    std::vector<double> lw(c.weight.size());
+    for (size_t k = 0; k < lw.size(); ++k) lw[k] = c.weight[k] > 0 ? std::log(c.weight[k]) : -std::numeric_limits<double>::infinity();
+    HIPCHK(d_pw.upload(lw, s));
+  }
   // ---- one thread per pair: explore, prune, levels, lane records ----
   const uint32_t stride = (uint32_t)(((4 * (6 * GX + GE) + 2 * (GH + 3 * GX + 2 * GE + 6 * (GE + 2)) + 3 * GX) + 63) / 64 * 64);
   const uint32_t n_threads = (uint32_t)std::min<uint64_t>(caps.threads, (np + 255) / 256 * 256);
