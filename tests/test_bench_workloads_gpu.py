@@ -146,27 +146,28 @@ def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle
     assert [len(d) for d in derivs] == ([5, 4, 4, 5, 4] if corpus == 1 else [9, 2, 6])
     hf = HipForests(of.node_off, of.label, of.ref, of.next, n_rules, lw, of.group_off, of.group_rule)
     chains = []
-    for seed in range(16):
+    n_chains, n_sweeps = (12, 4000) if mode == 0 else (16, 6000)  # (the exact chain is one launch per forest: 60 us each)
+    for seed in range(n_chains):
         hf.set_weights(lw)
-        hf.gibbs(6000, burnin=500, alpha=alpha, seed=5 + 7919 * seed, mode=mode)
+        hf.gibbs(n_sweeps, burnin=500, alpha=alpha, seed=5 + 7919 * seed, mode=mode)
         chains.append(np.exp(hf.weights()[1:]))
     hf.close()
     chains = np.asarray(chains)
     mean, se = chains.mean(0), chains.std(0, ddof=1) / math.sqrt(len(chains))
     z = (mean - exact[mode == 1][1:]) / se
-    assert np.all(np.abs(z) < 4.9), (z, mean, exact[mode == 1][1:])
+    assert np.all(np.abs(z) < (4.9 if n_chains == 16 else 5.5)), (z, mean, exact[mode == 1][1:])
     if corpus == 1:  # (on corpus 2 the two sweeps' stationary expectations differ by 3e-7: nothing to tell apart)
         z_other = (mean - exact[mode != 1][1:]) / se
         assert np.max(np.abs(z_other)) > 6.0, z_other
 
 
 def test_parallel_sweep_approaches_the_exact_chain_as_the_corpus_grows():
-    """the stale-count sweep's bias is O(1 / blocks): on 400 and on 4 000 forests of the benchmarked generator (restricted to
+    """the stale-count sweep's bias is O(1 / blocks): on 300 and on 1 500 forests of the benchmarked generator (restricted to
     few rules so that every rule is used often) the time-averaged rule probabilities of the parallel chain and of the exact
-    chain agree within 3 standard errors + a bias allowance that shrinks with the corpus (0.02 -> 0.004 absolute)"""
+    chain agree within 3 standard errors + a bias allowance that shrinks with the corpus (0.02 -> 0.006 absolute)"""
     from carmel_amd import synth
     from carmel_amd.forests import HipForests
-    for nf, allow in ((300, 0.02), (3000, 0.004)):
+    for nf, allow in ((300, 0.02), (1500, 0.006)):
         node_off, label, ref, nxt, n_rules, goff, grule = synth.random_forests(nf, n_rules=60, mean_nodes=20, seed=12)
         lw = np.log(np.random.default_rng(5).uniform(0.2, 1.0, n_rules))
         res = {}
@@ -174,7 +175,7 @@ def test_parallel_sweep_approaches_the_exact_chain_as_the_corpus_grows():
             runs = []
             for seed in range(4):
                 hf = HipForests(node_off, label, ref, nxt, n_rules, lw, goff, grule)
-                hf.gibbs(200 if mode == 0 else 1500, burnin=100, alpha=0.3, seed=7 + seed, mode=mode)
+                hf.gibbs(120 if mode == 0 else 1500, burnin=100, alpha=0.3, seed=7 + seed, mode=mode)
                 runs.append(np.exp(hf.weights()[1:]))
                 hf.close()
             runs = np.asarray(runs)
