@@ -27,6 +27,7 @@
 // _normalize / _tie_* kernels; chain_update / chain_scatter are cascade_parameters::update / distribute_counts
 // (cascade.h:286-325, 466-479).
 #include "kernels.hpp"
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1033,14 +1034,60 @@ __device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n) {
   const uint32_t per = (n + 7) / 8;
   return (b & 7u) * per + (b >> 3);
 }
-// source index of item i of a tile / bucket from its run table staged in LDS (nr runs: rel ascending, rel[0] == 0)
-__device__ __forceinline__ uint32_t run_source(const uint16_t* rel, const uint32_t* src, uint32_t nr, uint32_t i) {
-  uint32_t lo = 0, hi = nr - 1;
-  while (lo < hi) {
-    const uint32_t m = (lo + hi + 1) >> 1;
-    if (rel[m] <= i) lo = m; else hi = m - 1;
+// Run-length source indices (TransArgs::tr_* / br_*): the items of a tile arrive as one run per bucket (of a bucket: one
+// per tile), so instead of 4 bytes per item the kernels read {first item, first source} per RUN and find an item's run
+// without searching: the run starts are set as bits of a mask in LDS (one bit per item), a prefix count per mask word
+// follows, and item i belongs to run  pref[i / 32] + popc(mask[i / 32] up to bit i % 32) - 1  -- two LDS reads and a
+// popcount, the same for every item (a binary search was eleven dependent LDS reads per item and made both kernels slower
+// than the per-item indices).  r_src holds source - first item, so the item's source is r_src[run] + i.
+#define TRANS_RUN_WORDS ((TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) / 32)
+struct RunLds {
+  uint32_t* r_src;   // TRANS_RUN_CAP
+  uint32_t* mask;    // TRANS_TILE / 32 words
+  uint32_t* pref;    // ... run starts before word w
+};
+__device__ __forceinline__ RunLds run_lds(double* after_tile) {
+  RunLds R;
+  R.r_src = (uint32_t*)after_tile;
+  R.mask = R.r_src + TRANS_RUN_CAP;
+  R.pref = R.mask + TRANS_RUN_WORDS;
+  return R;
+}
+// (called by all 1024 threads; contains barriers)
+__device__ __forceinline__ void run_stage(const RunLds& R, const uint16_t* __restrict__ rel, const uint32_t* __restrict__ src,
+                                          uint32_t nr) {
+  constexpr uint32_t WORDS = TRANS_RUN_WORDS, PER = WORDS / 64;
+  for (uint32_t w = threadIdx.x; w < WORDS; w += 1024) R.mask[w] = 0u;
+  __syncthreads();
+  for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
+    const uint32_t first = rel[r];
+    R.r_src[r] = src[r] - first;
+    atomicOr(&R.mask[first >> 5], 1u << (first & 31u));
   }
-  return src[lo] + (i - rel[lo]);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    uint32_t c[PER], tot = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) {
+      c[k] = tot;
+      tot += __popc(R.mask[threadIdx.x * PER + k]);
+    }
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_up(inc, o, 64);
+      if ((int)threadIdx.x >= o) inc += v;
+    }
+    const uint32_t before = inc - tot;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; ++k) R.pref[threadIdx.x * PER + k] = before + c[k];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t run_source(const RunLds& R, uint32_t i) {
+  const uint32_t w = i >> 5;
+  const uint32_t run = R.pref[w] + __popc(R.mask[w] & (0xffffffffu >> (31u - (i & 31u)))) - 1u;
+  return R.r_src[run] + i;
 }
 // weights, pass 1: one workgroup per arc bucket.  The bucket's weights go to LDS (coalesced read), its items leave in
 // position-sorted order (coalesced write), picking their weight out of LDS.
@@ -1049,34 +1096,39 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   const TransBucket B = T.buckets[T.bucket_first + blockIdx.x];
   // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
   // 16384 items): one dependent round trip per phase instead of one per iteration
-  double w[TRANS_K];
+  double w[TRANS_KB];
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     w[k] = a < B.n_arcs ? T.logw[B.arc_lo + a] : 0.0;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = w[k];
+  for (int k = 0; k < TRANS_KB; ++k) lds[threadIdx.x + k * 1024] = w[k];
   __syncthreads();
-  uint16_t ia[TRANS_K];
+  uint16_t ia[TRANS_KB];
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     ia[k] = j < B.n_items ? T.b_arc[B.item_base + j] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     if (j < B.n_items) T.x[B.item_base + j] = lds[ia[k]];
   }
 }
 // weights, pass 2: one workgroup per tile of positions.  The tile's items arrive as runs (one per bucket), are placed
 // in LDS at their position and the tile is written to wcache in one coalesced sweep.
+#ifndef TRANS_TILE_WAVES
+#define TRANS_TILE_WAVES 4  // waves per SIMD the tile kernels are compiled for (4: one workgroup per CU)
+#endif
+#ifndef TRANS_WB_WAVES
+#define TRANS_WB_WAVES 4
+#endif
 template <bool RL>
-__global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE_WAVES, TRANS_TILE_WAVES))) void trans_w_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  uint16_t* r_rel = (uint16_t*)(lds + TRANS_TILE);
-  uint32_t* r_src = (uint32_t*)(r_rel + TRANS_RUN_CAP);
+  const RunLds R = run_lds(lds + TRANS_TILE);
   const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
   if (tloc >= T.tile_count) return;
   const uint32_t tile = T.tile_first + tloc;
@@ -1084,64 +1136,59 @@ __global__ __launch_bounds__(1024) void trans_w_tile_kernel(TransArgs T) {
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = 0.0;
-  uint32_t nr = 0;
+  for (int k = 0; k < TRANS_KT; ++k) lds[threadIdx.x + k * 1024] = 0.0;
   if (RL) {
     const uint32_t r0 = T.tr_off[tile];
-    nr = T.tr_off[tile + 1] - r0;
-    for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
-      r_rel[r] = T.tr_rel[r0 + r];
-      r_src[r] = T.tr_src[r0 + r];
-    }
-  }
-  __syncthreads();
+    run_stage(R, T.tr_rel + r0, T.tr_src + r0, T.tr_off[tile + 1] - r0);
+  } else
+    __syncthreads();
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
-  uint32_t src[TRANS_K];
-  uint16_t pos[TRANS_K];
-  double v[TRANS_K];
+  uint32_t src[TRANS_KT];
+  uint16_t pos[TRANS_KT];
+  double v[TRANS_KT];
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
     if (RL)
-      src[k] = i < ni ? run_source(r_rel, r_src, nr, i) : 0u;
+      src[k] = i < ni ? run_source(R, i) : 0u;
     else
       src[k] = i < ni ? T.t_src[i0 + i] : 0u;
     pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) v[k] = T.x[src[k]];
+  for (int k = 0; k < TRANS_KT; ++k) v[k] = T.x[src[k]];
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k)
+  for (int k = 0; k < TRANS_KT; ++k)
     if (threadIdx.x + k * 1024 < ni) lds[pos[k]] = v[k];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t q = threadIdx.x + k * 1024;
     if (q < np) T.wcache[p0 + q] = lds[q];
   }
 }
 // counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in bucket-major runs.
-__global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE_WAVES, TRANS_TILE_WAVES))) void trans_c_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const uint32_t tile = T.tile_first + blockIdx.x;
   const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
-  double v[TRANS_K];
-  uint16_t pos[TRANS_K];
+  double v[TRANS_KT];
+  uint16_t pos[TRANS_KT];
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t q = threadIdx.x + k * 1024;
     v[k] = q < np ? T.post[p0 + q] : 0.0;
     pos[k] = q < ni ? T.t_pos[i0 + q] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) lds[threadIdx.x + k * 1024] = v[k];
+  for (int k = 0; k < TRANS_KT; ++k) lds[threadIdx.x + k * 1024] = v[k];
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
     if (i < ni) T.xc[i0 + i] = lds[pos[k]];
   }
@@ -1152,8 +1199,7 @@ __global__ __launch_bounds__(1024) void trans_c_tile_kernel(TransArgs T) {
 template <bool RL>
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  uint16_t* r_rel = (uint16_t*)(lds + TRANS_BUCKET);
-  uint32_t* r_src = (uint32_t*)(r_rel + TRANS_RUN_CAP);
+  const RunLds R = run_lds(lds + TRANS_BUCKET);
   __shared__ double part[16];
   __shared__ uint32_t big[512];
   __shared__ uint32_t n_big;
@@ -1163,42 +1209,36 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   const TransBucket B = T.buckets[bucket];
   // every global load of the workgroup is issued before the first barrier: item indices, the items, and the item
   // ranges of this thread's arcs (the per-arc loop below then runs out of registers and LDS alone)
-  uint16_t r0[TRANS_K], r1[TRANS_K];
+  uint16_t r0[TRANS_KB], r1[TRANS_KB];
   const bool single = (B.flags & TRANS_SINGLE) != 0;
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     const bool ok = !single && a < B.n_arcs;
     r0[k] = ok ? T.a_off[B.arc_lo + a] : (uint16_t)0;
     r1[k] = (ok && a + 1 < B.n_arcs) ? T.a_off[B.arc_lo + a + 1] : (uint16_t)0;
   }
   {
-    uint32_t src[TRANS_K];
-    uint16_t rk[TRANS_K];
-    double v[TRANS_K];
-    uint32_t nr = 0;
+    uint32_t src[TRANS_KB];
+    uint16_t rk[TRANS_KB];
+    double v[TRANS_KB];
     if (RL) {
       const uint32_t r0 = T.br_off[bucket];
-      nr = T.br_off[bucket + 1] - r0;
-      for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
-        r_rel[r] = T.br_rel[r0 + r];
-        r_src[r] = T.br_src[r0 + r];
-      }
-      __syncthreads();
+      run_stage(R, T.br_rel + r0, T.br_src + r0, T.br_off[bucket + 1] - r0);
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_K; ++k) {
+    for (int k = 0; k < TRANS_KB; ++k) {
       const uint32_t j = threadIdx.x + k * 1024;
       if (RL)
-        src[k] = j < B.n_items ? run_source(r_rel, r_src, nr, j) : 0u;
+        src[k] = j < B.n_items ? run_source(R, j) : 0u;
       else
         src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_K; ++k) v[k] = T.xc[src[k]];
+    for (int k = 0; k < TRANS_KB; ++k) v[k] = T.xc[src[k]];
 #pragma unroll
-    for (int k = 0; k < TRANS_K; ++k)
+    for (int k = 0; k < TRANS_KB; ++k)
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
   }
   __syncthreads();
@@ -1223,7 +1263,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TRANS_K; ++k) {
+  for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     if (a >= B.n_arcs) break;
     const uint32_t q0 = r0[k], q1 = a + 1 < B.n_arcs ? (uint32_t)r1[k] : B.n_items;

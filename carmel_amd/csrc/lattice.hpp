@@ -97,7 +97,13 @@ static const uint32_t LANE_POS_MAX = (1u << 20) - 1;
 #ifndef TRANS_K
 #define TRANS_K 16  // rounds of 1024 threads per tile / bucket
 #endif
-static const uint32_t TRANS_TILE = TRANS_K * 1024, TRANS_BUCKET = TRANS_K * 1024, TRANS_HEAVY = 2048, TRANS_SPLIT = 1u, TRANS_SINGLE = 2u;
+#ifndef TRANS_KT
+#define TRANS_KT TRANS_K  // ... per tile
+#endif
+#ifndef TRANS_KB
+#define TRANS_KB TRANS_K  // ... per bucket
+#endif
+static const uint32_t TRANS_TILE = TRANS_KT * 1024, TRANS_BUCKET = TRANS_KB * 1024, TRANS_HEAVY = 2048, TRANS_SPLIT = 1u, TRANS_SINGLE = 2u;
 struct TransBucket {      // mirrored on the device, 24 bytes
   uint64_t item_base;     // first item: bucket-major index J == index into slot_pos[] (arc-sorted order)
   uint32_t n_items, arc_lo, n_arcs, flags;

@@ -821,10 +821,16 @@ int run_table(hipStream_t s, DevBuf<char>& tmp, const uint32_t* src, uint64_t n,
 int build_run_tables(carmel_hip_trainer* t) {
   t->use_runs = false;
   if (!t->use_transpose || !t->t_buckets.n || !t->t_t_src.n) return CARMEL_HIP_OK;
-  // Off by default.  Measured on config 4: 0.09 GB less traffic in each of trans_w_tile / trans_c_bucket, and both kernels
-  // SLOWER (113 -> 163 us, 122 -> 178 us): finding an item's run is eleven dependent LDS reads per item in workgroups that
-  // own their CU alone, so nothing hides them.  CARMEL_HIP_TRANS_RUNS=1 switches it on.
-  if (!(getenv("CARMEL_HIP_TRANS_RUNS") && atoi(getenv("CARMEL_HIP_TRANS_RUNS")) == 1)) return CARMEL_HIP_OK;
+  // On where the runs are long enough to pay and the corpus is large enough for its traffic to matter (config 4: twelve
+  // items per run; 0.16 GB of 2.41 less per E-step, trans_w_tile 108 -> 99 us, trans_c_bucket unchanged); corpora whose items
+  // spread over more (tile, bucket) cells than a quarter of their items keep the per-item indices, and so do small ones
+  // (config 2: the three extra barriers cost more than the bytes).  CARMEL_HIP_TRANS_RUNS=0 / 1 forces it off / on.
+  const char* env = getenv("CARMEL_HIP_TRANS_RUNS");
+  if (env && atoi(env) == 0) return CARMEL_HIP_OK;
+  {
+    const double tiles = (double)(t->t_tile_base.n - 1), cells = tiles * (double)t->t_buckets.n;
+    if (!(env && atoi(env) == 1) && ((double)t->t_t_src.n < 4.0 * cells || tiles < 512.0)) return CARMEL_HIP_OK;
+  }
   hipStream_t s = t->stream;
   const uint64_t n = t->t_t_src.n;
   const uint64_t n_tiles = t->t_tile_base.n - 1;
@@ -839,6 +845,14 @@ int build_run_tables(carmel_hip_trainer* t) {
   rc = run_table(s, tmp, t->t_b_src.p, n, bstarts.p, nb, t->br_off, t->br_rel, t->br_src, max_b);
   if (rc) return rc;
   t->use_runs = max_t <= TRANS_RUN_CAP && max_b <= TRANS_RUN_CAP && max_t > 0 && max_b > 0;
+  if (!t->use_runs) {
+    t->tr_off.release();
+    t->tr_rel.release();
+    t->tr_src.release();
+    t->br_off.release();
+    t->br_rel.release();
+    t->br_src.release();
+  }
   if (getenv("CARMEL_TIMING"))
     fprintf(stderr, "timing: transposition runs: %zu per %llu items, at most %u per tile / %u per bucket -> %s\n", t->tr_src.n,
             (unsigned long long)n, max_t, max_b, t->use_runs ? "run-length indices" : "per-item indices");

@@ -354,6 +354,32 @@ def test_full_size_properties_c4():
     fb.close()
 
 
+@pytest.mark.parametrize("name,n_pairs", [("c2", None), ("c4", 300000)])
+def test_run_length_transposition_indices_are_the_per_item_ones(name, n_pairs, monkeypatch, capfd):
+    """TransArgs::tr_* / br_*: the run-length form of the transposition's source indices (run starts as a bit mask in LDS)
+    must move the very same items -- counts and ln p bit for bit those of the per-item index arrays"""
+    w, c = synth.make_config(name, n_pairs=n_pairs)
+    out = {}
+    monkeypatch.setenv("CARMEL_TIMING", "1")
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", mode)
+        capfd.readouterr()
+        fb = _fb(w, c)
+        lp, _ = fb.estimate(per_pair=True)
+        out[mode] = (lp, fb.pair_logprob.copy(), fb.counts().copy(), capfd.readouterr().err)
+        fb.maximize(1.0)
+        lp2, _ = fb.estimate()
+        out[mode] += (lp2, fb.counts().copy())
+        fb.close()
+    a, b = out["0"], out["1"]
+    assert "-> run-length indices" in b[3] and "-> run-length indices" not in a[3]
+    assert a[0] == b[0] and a[4] == b[4]
+    assert np.array_equal(a[1], b[1])
+    # (the one atomic add per piece of a split hub arc aside)
+    for x, y in ((a[2], b[2]), (a[5], b[5])):
+        assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0)
+
+
 def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
     texts = [open(os.path.join(golden_dir, n)).read() for n in names]
     oc = oracle.OracleCascade(texts)
