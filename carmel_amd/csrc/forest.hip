@@ -1122,6 +1122,8 @@ __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t&
 __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double fm_lds[];
   const uint32_t sub = threadIdx.x / FM_G, li = threadIdx.x % FM_G;
+  const unsigned long long tr0 = A.trace ? __builtin_readcyclecounter() : 0;
+  unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;
   const uint32_t slot = M.lane_lo + blockIdx.x * FM_FPW + sub;
   const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;
   const bool active = forest != 0xffffffffu;
@@ -1185,6 +1187,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     }
   }
   __syncthreads();
+  if (A.trace) tr1 = __builtin_readcyclecounter();
   const unsigned short* lvl = tb + 4;
   const unsigned short* ord = lvl + H + 1;
   const unsigned short* koff = ord + n;
@@ -1238,6 +1241,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
       }
     __syncthreads();
   }
+  if (A.trace) tr2 = __builtin_readcyclecounter();
   // ---- the walk, breadth first (forest.hpp:725-758) ----
   uint32_t nfr = active ? 1u : 0u, ns = 0, visited = 0;
   if (active && li == 0) fr0[0] = (unsigned short)(n - 1);
@@ -1298,6 +1302,19 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     nxt = t;
   }
   if (active && li == 0) A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+  if (A.trace) {
+    tr3 = __builtin_readcyclecounter();
+    uint32_t nmax = n, hmax = H, vmax = visited;
+    for (int o = 32; o > 0; o >>= 1) {
+      nmax = max(nmax, (uint32_t)__shfl_xor((int)nmax, o, 64));
+      hmax = max(hmax, (uint32_t)__shfl_xor((int)hmax, o, 64));
+      vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, o, 64));
+    }
+    if (threadIdx.x == 0) {
+      unsigned long long* o = A.trace + ((size_t)M.lane_lo / FM_FPW + blockIdx.x) * 8;
+      o[0] = tr0; o[1] = tr1; o[2] = tr2; o[3] = tr3; o[4] = tr3; o[5] = nmax; o[6] = hmax; o[7] = vmax;
+    }
+  }
 }
 
 // Viterbi (forest.hpp:507-632): max-product inside -- an AND node is its rule's weight times its children, an OR node
@@ -2367,7 +2384,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   DevBuf<unsigned long long> trace_buf;  // experiment: per-wave phase stamps of the last parallel sweep
   const char* trace_path = getenv("CARMEL_HIP_FOREST_TRACE");
   if (trace_path && o->mode == 1) {
-    HIPCHK(trace_buf.alloc(F->h_groups.size() * 8));
+    HIPCHK(trace_buf.alloc(F->h_groups.size() * 8 * 8));  // (the several-lanes sampler: eight workgroups per lane group)
     HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
     A.trace = trace_buf.p;
   }
