@@ -58,7 +58,7 @@ class GibbsOpts(C.Structure):
                 ("uniform_p0", C.c_int), ("dirichlet_p0", C.c_int), ("final_counts", C.c_int),
                 ("exclude_prior", C.c_int), ("min_prior", C.c_double), ("high_temp", C.c_double),
                 ("low_temp", C.c_double), ("expectation", C.c_int), ("restarts", C.c_uint32), ("argmax_final", C.c_int),
-                ("argmax_sum", C.c_int)]
+                ("argmax_sum", C.c_int), ("include_self", C.c_int), ("random_start", C.c_int)]
 
 
 def _load():

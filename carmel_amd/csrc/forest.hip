@@ -2243,6 +2243,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   if (!F || !o) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (F->pi_stddev > 0 && o->mode != 0)
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "prior inference works with the cache-model probability of the exact blocked sampler only (gibbs.hpp:528-529)");
+  if (o->include_self || o->random_start || o->expectation)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "--include-self / --random-start / --expectation are carmel's (carmel_hip_gibbs_create), not the forest sampler's");
   HIPCHK(hipSetDevice(F->device));
   hipStream_t s = F->stream;
   const uint32_t nr = F->n_rules;

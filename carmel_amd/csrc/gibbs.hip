@@ -65,6 +65,14 @@ struct GibbsArgs {
   double* alpha;               // --expectation: forward weights, like beta
   double* ewt;                 // --expectation: per lattice arc, its posterior in the block's current "sample"
   int expectation;
+  int include_self;            // --include-self (gibbs.hpp:851-870): the block's previous counts stay in while its proposal is
+                               // formed and leave just before the new ones go in
+  int randomize;               // --expectation, initial sweep of a --random-start run or of a restart (gibbs.hpp:816, 860-864,
+                               // 296-301): every (arc, chain element) entry's weight is scaled by its own uniform, the
+                               // block's probability counts as 0
+  uint32_t* old_ids;           // --include-self, sampling: the previous sample of the block being resampled (exact mode)
+  const uint32_t* ent_base;    // --expectation: per lattice arc (bundle out-arc order), the number of its first entry in the
+                               // reference's listing of the block's fractional counts
   const double* init_logw;     // --init-em: per composed arc, the weight the first sweep of the first run samples from
   int par_books;               // exact mode: count bookkeeping of a block by the whole workgroup (g_addc_all / g_block_probs)
   uint32_t books_cap;          // ids of one sample the workgroup's LDS scratch holds
@@ -207,6 +215,26 @@ __device__ __forceinline__ void g_block_after(const GibbsArgs& G, const uint32_t
 
 // Resample one block.  Called by every thread of the workgroup; serial parts run on thread 0.
 // own_ids (LDS, mode 1 only): the block's previous sample.
+// --expectation: the block's previous fractional counts out of the counts (gibbs.hpp:851-852 / 869-870 over block_delta::wt):
+// entry by entry in the order they went in; a block whose entries were scaled by the uniforms of the previous sweep
+// (sample_len 2: the randomised initial sweep) takes the same factors again
+__device__ void g_take_out_expected(const GibbsArgs& G, const BundleDesc& d, const uint2* oa, const uint32_t* ooff, bool cyc,
+                                    uint32_t b, double wt) {
+  const uint32_t n = G.sample_len[b];
+  if (!n) return;
+  const double* ewt = G.ewt + d.out_base;
+  const uint32_t* eb = G.ent_base + d.out_base;
+  for (uint32_t s = 0; s < d.n_states; ++s)
+    for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
+      const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;  // list order
+      const uint32_t arc = oa[a].y;
+      uint32_t k = eb[a];
+      for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j, ++k) {
+        const double f = n == 2u ? gibbs_uniform(G.seed, G.iter - 1u, b, k) : 1.0;
+        g_addc(G, G.chain_param[j], (ewt[a] * f) * -wt);
+      }
+    }
+}
 template <bool SNAP>
 __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_ids, uint32_t own_cap, double* red) {
   const int tid = threadIdx.x, NT = blockDim.x;
@@ -241,30 +269,27 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   const double wt = exp(G.pair_logw[d.pair_base]);
   const uint64_t so = G.sample_off[b];
   uint32_t* ids = G.sample_ids + so;
-  uint32_t own_len = 0;
+  uint32_t own_len = 0, old_n = 0;
   if (SNAP) {
-    own_len = G.sample_len[b];
+    own_len = G.include_self ? 0u : G.sample_len[b];  // (--include-self: no counterfactual subtraction of the own uses)
     if (own_len > own_cap) own_len = own_cap;  // capacity is sized from the longest path; cannot trigger
     for (uint32_t k = tid; k < own_len; k += NT) own_ids[k] = ids[k];
     __syncthreads();
   } else {
-    // 1. take the previous sample out of the counts (gibbs.hpp:851-852)
-    if (G.par_books && !G.expectation) {
+    // 1. take the previous sample out of the counts (gibbs.hpp:851-852) -- unless --include-self: then it is set aside
+    // (sampling: copied; --expectation: the arcs' previous posteriors stay where they are) and leaves in step 6
+    if (G.include_self) {
+      if (!G.expectation) {
+        old_n = G.sample_len[b];
+        for (uint32_t k = tid; k < old_n; k += NT) G.old_ids[k] = ids[k];
+      }
+    } else if (G.par_books && !G.expectation) {
       g_addc_all(G, ids, G.sample_len[b], -wt);
     } else if (tid == 0) {
-      const uint32_t n = G.sample_len[b];
-      if (G.expectation) {
-        if (n) {
-          const double* ewt = G.ewt + d.out_base;
-          for (uint32_t s = 0; s < d.n_states; ++s)
-            for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
-              const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;  // list order
-              const uint32_t arc = oa[a].y;
-              for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * -wt);
-            }
-        }
-      } else
-        for (uint32_t k = 0; k < n; ++k) g_addc(G, ids[k], -wt);
+      if (G.expectation)
+        g_take_out_expected(G, d, oa, ooff, cyc, b, wt);
+      else
+        for (uint32_t k = 0, n = G.sample_len[b]; k < n; ++k) g_addc(G, ids[k], -wt);
     }
     __syncthreads();
   }
@@ -335,19 +360,29 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     }
     __syncthreads();
     const double prob = alpha[G.pair_final[d.pair_base]];
+    if (G.include_self) {  // the previous posteriors leave now (gibbs.hpp:869-870), before they are overwritten
+      if (tid == 0) g_take_out_expected(G, d, oa, ooff, cyc, b, wt);
+      __syncthreads();
+    }
     for (uint32_t s = tid; s < d.n_states; s += NT)
       for (uint32_t a = ooff[s]; a < ooff[s + 1]; ++a) ewt[a] = exp(gw[a] + alpha[s] + beta[oa[a].x] - prob);
     __syncthreads();
     if (tid == 0) {
+      const uint32_t* eb = G.ent_base + d.out_base;  // entry numbers: (arc, chain element) in the order the reference lists them
       for (uint32_t s = 0; s < d.n_states; ++s)
         for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
           const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;
           const uint32_t arc = oa[a].y;
-          for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) g_addc(G, G.chain_param[j], ewt[a] * wt);
+          uint32_t k = eb[a];
+          for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j, ++k) {
+            const double f = G.randomize ? gibbs_uniform(G.seed, G.iter, b, k) : 1.0;
+            g_addc(G, G.chain_param[j], (ewt[a] * f) * wt);
+          }
         }
-      G.sample_len[b] = 1;  // "has counts in"
-      red[0] += prob;
-      red[1] += prob;
+      G.sample_len[b] = G.randomize ? 2u : 1u;  // "has counts in" (2: scaled entry by entry by this sweep's uniforms)
+      const double bp = G.randomize ? G_NEG_INF : prob;  // (gibbs.hpp:863: bd.prob = 0)
+      red[0] += bp;
+      red[1] += bp;
     }
     __syncthreads();
     return;
@@ -416,6 +451,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       red[0] += cheap;
     } else {
       G.sample_len[b] = G.par_books ? (n | 0x80000000u) : n;  // flag for the other threads: already booked
+      for (uint32_t k = 0; k < old_n; ++k) g_addc(G, G.old_ids[k], -wt);  // (--include-self: gibbs.hpp:869-870)
       for (uint32_t k = 0; k < n; ++k) g_addc(G, out_ids[k], wt);
       red[0] += cheap;
       red[1] += cache;
@@ -430,6 +466,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       if (tid == 0) G.sample_len[b] = n & 0x7fffffffu;
     } else {
       g_block_probs(G, ids, n, own_ids, red);
+      if (old_n) g_addc_all(G, G.old_ids, old_n, -wt);  // (--include-self)
       g_addc_all(G, ids, n, wt);
     }
     __syncthreads();
@@ -592,7 +629,7 @@ struct carmel_hip_gibbs {
   bool pi_restart_fresh = false;
   uint32_t pi_start = 0, pi_end = 0, n_scale = 0;
   std::vector<uint32_t> h_meta;       // metanorm: scale group of every norm group, 0 = never scaled (gibbs.hpp:404-470)
-  DevBuf<uint32_t> d_meta;
+  DevBuf<uint32_t> d_meta, old_ids, ent_base;
   DevBuf<double> d_scales;
   std::vector<double> cumulative;     // product of the accepted scales per scale group
   std::vector<double> h_prior0;       // the priors before any inference (--prior-inference-restart-fresh)
@@ -694,6 +731,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   bo.lane_states = 0;
   bo.small_pairs = 1;
   bo.wave = false;  // the sampler walks bundles (one lattice each)
+  bo.keep_state_ids = o->expectation != 0;
   bo.threads = 0;
   std::string err;
   if (!build_lattices(t->w, t->corpus, bo, g->lat, err)) return fail(CARMEL_HIP_ERR_ARG, err);
@@ -751,6 +789,29 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   if (o->expectation) {
     HIPCHK(g->alpha.alloc(L.out_off.size()));
     HIPCHK(g->ewt.alloc(L.out_arcs.size()));
+    // --random-start / restarts (gibbs.hpp:296-301): every ENTRY of a block's fractional counts -- one per lattice arc and chain
+    // element, listed as collect_counts_gibbs lists them (derivations.h:381-398: the lattice's states in their own numbering,
+    // each state's arcs in list order) -- is scaled by its own uniform: the entry number of every out-arc's first element
+    std::vector<uint32_t> eb(L.out_arcs.size(), 0u), inv;
+    for (size_t b = 0; b < bb.size(); ++b) {
+      const BundleDesc& d = L.bundles[bb[b]];
+      const uint32_t* ooff = L.out_off.data() + d.off_base;
+      const uint32_t* orig = L.state_orig.data() + d.off_base;
+      const bool cyc = (d.flags & 1u) != 0;
+      inv.assign(d.n_states, 0u);
+      for (uint32_t s = 0; s < d.n_states; ++s) inv[orig[s]] = s;
+      uint32_t k = 0;
+      for (uint32_t q = 0; q < d.n_states; ++q) {
+        const uint32_t s = inv[q];
+        for (uint32_t i = 0, deg = ooff[s + 1] - ooff[s]; i < deg; ++i) {
+          const uint32_t a = cyc ? ooff[s] + i : ooff[s + 1] - 1 - i;  // list order
+          eb[d.out_base + a] = k;
+          const uint32_t arc = L.out_arcs[d.out_base + a].y;
+          k += (uint32_t)(coff[arc + 1] - coff[arc]);
+        }
+      }
+    }
+    HIPCHK(g->ent_base.upload(eb, s));
   }
   HIPCHK(g->iter_out.alloc(4));
   HIPCHK(hipStreamSynchronize(s));
@@ -924,6 +985,14 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.alpha = g->alpha.p;
   G.ewt = g->ewt.p;
   G.expectation = g->opt.expectation;
+  G.include_self = g->opt.include_self ? 1 : 0;
+  G.randomize = 0;
+  G.old_ids = nullptr;
+  G.ent_base = g->ent_base.p;
+  if (G.include_self && !G.expectation && g->opt.mode == 0) {  // the sample a block is resampled against, set aside
+    if (!g->old_ids.n) HIPCHK(g->old_ids.alloc(std::max<uint32_t>(g->max_sample, 1u)));
+    G.old_ids = g->old_ids.p;
+  }
   G.par_books = getenv("CARMEL_HIP_GIBBS_SERIAL_BOOKS") ? 0 : 1;  // A/B: one thread books a block's counts id by id
   G.books_cap = std::min<uint32_t>(g->max_sample, 7168u);          // 56 KB of LDS at most
   G.stage_arcs = getenv("CARMEL_HIP_GIBBS_NO_STAGE") ? 0u : 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
@@ -967,6 +1036,8 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   double st_all = 0.0, st_final = 0.0, st_sum = -std::numeric_limits<double>::infinity();
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     G.iter = run * (Ni + 1) + iter;  // of the uniforms: every run draws its own
+    // gibbs.hpp:816: the initial --expectation sweep of a --random-start run, and of every restart
+    G.randomize = (g->opt.expectation && iter == 0 && (g->opt.random_start || run > 0)) ? 1 : 0;
     G.init_logw = (run == 0 && iter == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);

@@ -97,6 +97,7 @@ struct Options {
   bool have_write_loaded = false;
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
+  bool include_self = false, random_start = false;  // gibbs_opts.hpp:40-41, 127-128
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   long print_from = 0, print_to = 0;  // --print-from=m --print-to=n (gibbs_opts.hpp; gibbs.cc:258-296): the final sample's
                                       // path through input transducers m .. n-1, one line each, on stdout
@@ -209,6 +210,10 @@ static Options parse_args(int argc, char** argv) {
         o.crp_argmax_final = true;
       else if (k == "crp-argmax-sum")
         o.crp_argmax_sum = true;
+      else if (k == "include-self")
+        o.include_self = true;
+      else if (k == "random-start")
+        o.random_start = true;
       else if (k == "crp-exclude-prior")
         o.exclude_prior = true;
       else if (k == "crp-parallel")  // not a carmel option: the stale-count parallel sweep (gibbs.hip mode 1)
@@ -943,6 +948,8 @@ static int run(int argc, char** argv) {
     go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
     go.argmax_final = o.crp_argmax_final;
     go.argmax_sum = o.crp_argmax_sum;
+    go.include_self = o.include_self;
+    go.random_start = o.random_start;
     go.uniform_p0 = o.uniform_p0;
     go.dirichlet_p0 = o.dirichlet_p0;
     go.final_counts = o.final_counts;

@@ -1126,6 +1126,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   out.level_off.resize(lev_base);
   out.pair_start.resize(pair_base);
   out.pair_final.resize(pair_base);
+  if (opt.keep_state_ids) out.state_orig.assign(out.out_off.size(), 0u);
   out.pair_id.resize(pair_base);
   out.pair_logw.resize(pair_base);
   {
@@ -1156,6 +1157,8 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
             const PairLattice& L = lats[P.pairs[m]];
             maps[m].resize(L.n_states);
             for (uint32_t s = 0; s < L.n_states; ++s) maps[m][s] = cur[L.level[s]]++;
+            if (opt.keep_state_ids)
+              for (uint32_t s = 0; s < L.n_states; ++s) out.state_orig[d.off_base + maps[m][s]] = s;
             out.pair_start[d.pair_base + m] = maps[m][L.start];
             out.pair_final[d.pair_base + m] = maps[m][L.fin];
             out.pair_id[d.pair_base + m] = P.pairs[m];

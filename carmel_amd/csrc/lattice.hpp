@@ -205,6 +205,8 @@ struct LatticeSet {
   // posterior slots: one per lattice arc.  Lane records use their position in lane_bwd[]; bundle out-arcs use
   // lane_bwd.size() + position in out_arcs[].  slot_arc / slot_pos list every slot sorted by WFST arc id, which is
   // what lets the expected counts be a segmented sum instead of random atomics.
+  std::vector<uint32_t> state_orig;  // BuildOptions::keep_state_ids: per bundle state (indexed like out_off), the state's id in
+                                     // its pair's own lattice = the reference's numbering (derivations.h: creation order)
   std::vector<uint64_t> arc_off;   // n_arcs + 1
   std::vector<uint64_t> slot_pos;  // grouped by arc id
   std::vector<uint64_t> hot_chunks;  // (arc, first, end) triples: arcs with more than 64 slots, cut into 4096-slot chunks
@@ -239,6 +241,7 @@ struct BuildOptions {
                                    // many LDS rows whatever their size (up to 1023 states); 0 disables windowed groups
   uint32_t lane_window_min = 40;   // ... but only lattices above this many states: below ~20 KB of LDS per wave the
                                    // occupancy is not what bounds the sweep (and the GPU builder covers those)
+  bool keep_state_ids = false;     // also fill LatticeSet::state_orig (the sampler's --expectation entry order needs them)
   bool gpu_large_caps = false;     // GPU builder: the larger per-pair capacities (lattices of up to 1 023 states; set by the probe)
   bool wave_ring = true;           // ring form of the wave sweep where the lattice allows it (WaveDesc::ring)
   bool wave = true;                // one-lattice-per-wavefront layout for large / few-and-wide lattices (WaveDesc)

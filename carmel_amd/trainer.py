@@ -329,12 +329,12 @@ class HipGibbs(object):
 
     def __init__(self, fb, iters, burnin=0, seed=1, mode=0, uniform_p0=False, dirichlet_p0=False, final_counts=False,
                  exclude_prior=False, min_prior=0.01, high_temp=1.0, low_temp=1.0, expectation=False, restarts=0,
-                 argmax_final=False, argmax_sum=False):
+                 argmax_final=False, argmax_sum=False, include_self=False, random_start=False):
         from ._capi import GibbsOpts
         self.fb = fb
         self.opts = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), int(dirichlet_p0), int(final_counts),
                               int(exclude_prior), min_prior, high_temp, low_temp, int(expectation), restarts,
-                              int(argmax_final), int(argmax_sum))
+                              int(argmax_final), int(argmax_sum), int(include_self), int(random_start))
         h = C.c_void_p()
         check(lib.carmel_hip_gibbs_create(C.byref(h), fb.h, C.byref(self.opts)), "carmel_hip_gibbs_create")
         self.h = h

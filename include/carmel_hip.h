@@ -275,6 +275,14 @@ typedef struct carmel_hip_gibbs_opts {
                          weights and sample (gibbs_base::run_starts, gibbs.hpp:880-914).  carmel_hip_gibbs_run then
                          writes (restarts + 1) * (iter + 1) values into iter_logprob / iter_cheap_logprob */
   int argmax_final, argmax_sum; /* --crp-argmax-final / --crp-argmax-sum: compare runs by their last sweep / by the sum */
+  int include_self;   /* --include-self (gibbs_opts.hpp:40-41, 162; gibbs.hpp:851-870): a block's previous counts stay in the
+                         counts while its proposal is formed and leave just before the new ones are added (with
+                         --expectation: "incremental EM"); mode 1: no counterfactual subtraction of the block's own uses */
+  int random_start;   /* --random-start (gibbs_opts.hpp:127-128, 167; gibbs.hpp:816, 860-864, 296-301): --expectation only --
+                         the initial sweep's fractional counts are scaled entry by entry (one entry per lattice arc and chain
+                         element, in the reference's listing order) by carmel_hip_gibbs_uniform(seed, sweep, block, entry)
+                         and that sweep's probability is logged as 0.  Restart runs (run > 0) do this whatever the flag says,
+                         as the reference does */
 } carmel_hip_gibbs_opts;
 int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const carmel_hip_gibbs_opts* opts);
 int carmel_hip_gibbs_destroy(carmel_hip_gibbs* g);

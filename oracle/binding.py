@@ -348,7 +348,7 @@ lib.orc_gibbs_last_prior_trace.restype = C.c_uint32
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
               low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False, init_em=0,
-              em_p0=False, init_from_p0=False, prior_inference=None):
+              em_p0=False, init_from_p0=False, prior_inference=None, include_self=False, random_start=False):
     """carmel --crp on an OracleCascade; prior_inference = dict(stddev, global_, local, restart_fresh, start, end, groupby)
     turns on prior-scale inference (gibbs.hpp:525-553). `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
@@ -363,6 +363,7 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     cb = UNIFORM_FN(uniform)
     lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
     lib.orc_set_gibbs_expectation(int(expectation))
+    lib.orc_set_gibbs_self_start(int(include_self), int(random_start))
     lib.orc_set_gibbs_restarts(int(restarts), int(argmax_final), int(argmax_sum))
     lib.orc_set_gibbs_init_em(int(init_em), int(em_p0))
     lib.orc_set_gibbs_init_from_p0(int(init_from_p0))

@@ -64,6 +64,10 @@ struct GibbsOpts {
   bool argmax_final = false, argmax_sum = false;   // --crp-argmax-final / --crp-argmax-sum (gibbs_opts.hpp:313-316)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125,166): fractional counts from a full forward/backward
                              // over the block instead of one sampled derivation ("online EM")
+  bool include_self = false;  // --include-self (gibbs_opts.hpp:40-41, 162; gibbs.hpp:851-870): the block's own counts stay in
+                              // while its proposal is formed; they leave just before the new ones go in
+  bool random_start = false;  // --random-start (gibbs_opts.hpp:127-128, 167; gibbs.hpp:816, 860-864, 296-301): --expectation's
+                              // initial per-entry counts are scaled by random01() each (implied for restarts)
   // prior-scale inference (gibbs_opts.hpp:82-89, 148-153; fst.h:553-600 --prior-groupby per member: 0 fixed, 1 single, 2 local)
   double prior_inference_stddev = 0;
   bool prior_inference_global = false, prior_inference_local = false, prior_inference_restart_fresh = false;
@@ -470,17 +474,31 @@ struct CarmelGibbs {
         if (gps[i].has_norm()) csum[gps[i].norm] += (ccount[i] = gps[i].prior);
       for (unsigned b = 0; b < derivs.size(); ++b) {
         double wt = derivs[b].weight;
+        // gibbs.hpp:851-857: the old counts leave now, or (--include-self) are set aside and leave after the resampling
+        std::vector<unsigned> self_ids;
+        std::vector<double> self_wt;
         if (gopt.expectation) {  // gibbs.hpp:849-871 with gopt.expectation, gibbs.cc:311-314
-          addc_weighted(sample[b], sample_wt[b], -wt);
+          if (!gopt.include_self) addc_weighted(sample[b], sample_wt[b], -wt);
+          else {
+            self_ids.swap(sample[b]);
+            self_wt.swap(sample_wt[b]);
+          }
           sample[b].clear();
           sample_wt[b].clear();
           LW bprob = collect_counts_gibbs(derivs[b], sample[b], sample_wt[b]);
+          // gibbs.hpp:816, 860-864: the initial sample's weights scaled by one random01() each; its probability is logged as 0
+          if (iter == 0 && (gopt.random_start || run_index > 0)) {
+            for (size_t k = 0; k < sample_wt[b].size(); ++k) sample_wt[b][k] *= u(run_index * (Ni + 1) + iter, b, (unsigned)k);
+            bprob = LW::zero();
+          }
           mul_eq(p, bprob);  // "sum-all-derivations" prob (gibbs.hpp:927-941)
           mul_eq(pc, bprob);
+          if (gopt.include_self) addc_weighted(self_ids, self_wt, -wt);
           addc_weighted(sample[b], sample_wt[b], wt);
           continue;
         }
-        addc(sample[b], -wt);
+        if (!gopt.include_self) addc(sample[b], -wt);
+        else self_ids.swap(sample[b]);
         sample[b].clear();
         random_path(derivs[b], sample[b], [&](unsigned step) { return u(run_index * (Ni + 1) + iter, b, step); }, gopt.power(iter));
         LW bp = LW::one();
@@ -493,6 +511,7 @@ struct CarmelGibbs {
           mul_eq(bc, LW::from_real(q));
         }
         mul_eq(pc, bc);
+        if (gopt.include_self) addc(self_ids, -wt);
         addc(sample[b], wt);
         for (unsigned pid : sample[b]) mul_eq(pself, LW::from_real(proposal_prob(pid)));
       }

@@ -336,6 +336,11 @@ double orc_gibbs_power(double high, double low, uint32_t iter, uint32_t sweep) {
 }
 static int g_expectation = 0;  // --expectation, set before orc_gibbs_run
 void orc_set_gibbs_expectation(int on) { g_expectation = on; }
+static int g_include_self = 0, g_random_start = 0;  // --include-self / --random-start, set before orc_gibbs_run
+void orc_set_gibbs_self_start(int include_self, int random_start) {
+  g_include_self = include_self;
+  g_random_start = random_start;
+}
 static unsigned g_crp_restarts = 0;  // --crp-restarts / --crp-argmax-final / --crp-argmax-sum, set before orc_gibbs_run
 static int g_argmax_final = 0, g_argmax_sum = 0, g_best_run = 0;
 void orc_set_gibbs_restarts(unsigned n, int argmax_final, int argmax_sum) {
@@ -889,6 +894,8 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     go.high_temp = g_high_temp;
     go.low_temp = g_low_temp;
     go.expectation = g_expectation != 0;
+    go.include_self = g_include_self != 0;
+    go.random_start = g_random_start != 0;
     go.restarts = g_crp_restarts;
     go.argmax_final = g_argmax_final != 0;
     go.argmax_sum = g_argmax_sum != 0;

@@ -122,6 +122,38 @@ def test_crp_command(golden_dir, tmp_path, oracle):
             assert float(u) == pytest.approx(float(v), rel=1e-9)
 
 
+@pytest.mark.parametrize("flags,kw", [(["--include-self"], dict(include_self=True)),
+                                      (["--expectation", "--include-self", "--random-start"],
+                                       dict(expectation=True, include_self=True, random_start=True))])
+def test_crp_include_self_and_random_start_switches(golden_dir, tmp_path, oracle, flags, kw):
+    """carmel --crp --include-self / --expectation --random-start (carmel.cc:269-270; gibbs.hpp:816, 851-870): the switches
+    reach the sampler -- the logged probabilities and the trained weights are the oracle's with the same options"""
+    import numpy as np
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    rc, out, err = run(["--crp", "-M", "8", "--burnin=2", "--priors=0.5,0.1", "-R", "5", "-HJ"] + flags +
+                       [g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
+    assert rc == 0, err
+    lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
+    assert len(lines) == 9
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()),
+                           lambda i, b, s: lib.carmel_hip_gibbs_uniform(5, i, b, s), normby="CC", priors=[0.5, 0.1],
+                           iters=8, burnin=2, **kw)
+    logged = [re.search(r"prob=2\^(\S+)", l).group(1) for l in lines]
+    for a, b in zip(logged, ref["iter_logprob"] / math.log(2)):
+        if np.isneginf(b):  # the randomised initial sweep: probability 0
+            assert "inf" in a.lower()
+        else:
+            assert float(a) == float("%.6g" % b)
+    exp_txt = oc.write_member(1, ref["param_logw"])
+    got_txt = open(os.path.join(str(tmp_path), "cipher.fst.trained")).read()
+    for x, y in zip(got_txt.strip().split("\n"), exp_txt.strip().split("\n")):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-8)
+
+
 @pytest.mark.parametrize("em_p0", [False, True])
 def test_crp_init_em(golden_dir, tmp_path, oracle, em_p0):
     """--init-em=N [--em-p0] (gibbs.cc:400-423, 306-383): N EM iterations without priors give the composed weights the

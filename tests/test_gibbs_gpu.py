@@ -106,6 +106,70 @@ def test_expectation_mode_is_the_reference_online_em(oracle, golden_dir, iters, 
     fb.close()
 
 
+@pytest.mark.parametrize("kw", [dict(include_self=True), dict(include_self=True, high_temp=2.0, low_temp=0.5),
+                                dict(include_self=True, expectation=True), dict(random_start=True, expectation=True),
+                                dict(include_self=True, random_start=True, expectation=True),
+                                dict(expectation=True, restarts=2), dict(include_self=True, restarts=2)])
+def test_include_self_and_random_start(oracle, golden_dir, kw):
+    """--include-self (gibbs.hpp:851-870: a block's previous counts stay in while its proposal is formed, and leave just
+    before the new ones go in) and --random-start (gibbs.hpp:816, 860-864, 296-301: the initial --expectation sweep's entries
+    scaled by one uniform each, that sweep's probability logged as 0; restarts do it unasked): the oracle's chain, sweep by
+    sweep, on the cipher cascade and on a random cascade"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    cases = [([g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"), "CC", [0.5, 0.1])]
+    a, b, corpus_text, normby, priors = _random_cascade_case(oracle, 3)
+    cases.append(([a, b], corpus_text, normby, priors))
+    for texts, corpus_text, normby, priors in cases:
+        norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
+        oc, ocorp, fb = _setup(oracle, texts, corpus_text, norms, priors)
+        iters, burnin = 7, 2
+        gs = HipGibbs(fb, iters, burnin=burnin, seed=13, mode=0, **kw)
+        got_lp = gs.run()
+        ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin, **kw)
+        rand0 = kw.get("expectation") and (kw.get("random_start") or kw.get("restarts"))
+        if rand0:  # the randomised initial sweeps are logged with probability 0
+            first = np.arange(kw.get("restarts", 0) + 1) * (iters + 1)
+            first = first if kw.get("random_start") else first[1:]
+            assert np.all(np.isneginf(got_lp[first])) and np.all(np.isneginf(np.asarray(ref["iter_logprob"])[first]))
+            keep = np.setdiff1d(np.arange(len(got_lp)), first)
+        else:
+            keep = np.arange(len(got_lp))
+        np.testing.assert_allclose(got_lp[keep], np.asarray(ref["iter_logprob"])[keep], rtol=1e-10)
+        if not kw.get("expectation"):
+            np.testing.assert_allclose(gs.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+            for blk in range(gs.n_blocks):
+                assert gs.sample(blk) == ref["samples"][blk]
+        if kw.get("restarts"):
+            assert gs.best_run == ref["best_run"]
+        np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-8, atol=1e-14)
+        gs.close()
+        fb.close()
+
+
+def test_include_self_changes_the_chain_and_the_parallel_sweep_takes_it(oracle, golden_dir):
+    """--include-self is not a no-op (the proposals see one count more per own use), and mode 1 accepts it (no
+    counterfactual subtraction of the block's own uses): a valid sample for every block, finite probabilities"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    lp = {}
+    for inc in (False, True):  # (a run leaves its weights in the trainer: a fresh one each time)
+        oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                               [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+        gs = HipGibbs(fb, 10, burnin=2, seed=13, mode=0, include_self=inc)
+        lp[inc] = gs.run().copy()
+        gs.close()
+        fb.close()
+    assert lp[False][0] == lp[True][0] and not np.allclose(lp[False][1:], lp[True][1:])
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    gs = HipGibbs(fb, 10, burnin=2, seed=13, mode=1, include_self=True)
+    got = gs.run()
+    assert np.all(np.isfinite(got)) and all(len(gs.sample(b)) > 0 for b in range(gs.n_blocks))
+    gs.close()
+    fb.close()
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(argmax_final=True), dict(argmax_sum=True)])
 def test_crp_restarts_keep_the_best_run(oracle, golden_dir, kw):
     """--crp-restarts=N (gibbs_base::run_starts, gibbs.hpp:880-914): N + 1 runs from the priors, each with its own

@@ -101,3 +101,36 @@ def test_oracle_prior_scale_inference_invariants(oracle):
     for it in np.nonzero(prop)[0]:
         assert (table[(int(it), 0xffffffff, 0)] < tr[it, 5]) == bool(tr[it, 1])
     assert len(ref["prior_cumulative"]) == 2 and (ref["prior_cumulative"] > 0).all()
+
+
+def test_oracle_include_self_and_random_start(oracle, golden_dir):
+    """--include-self / --random-start in the oracle (gibbs.hpp:816, 851-870, 296-301): the first sweep has no previous sample
+    to keep, so it is the default chain's; from the second sweep on the proposals see the block's own counts and the chain
+    differs; with --expectation + --include-self ("incremental EM") the likelihood still climbs from the prior; a randomised
+    initial sweep is logged with probability 0, leaves different counts behind, and restarts randomise unasked"""
+    import os
+    import numpy as np
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    rng = np.random.default_rng(5)
+    table = rng.random((64, 16, 512))
+    u = lambda it, b, k: float(table[it % 64, b % 16, k % 512])
+
+    def run(**kw):  # (a run leaves its final weights in the cascade: a fresh one each time)
+        oc = oracle.OracleCascade([g("cipher.wfsa"), g("cipher.fst")])
+        return oracle.gibbs_run(oc, oc.corpus(g("cipher.data")), u, normby="CC", priors=[0.5, 0.1], iters=8, burnin=2, **kw)
+
+    base, inc = run(), run(include_self=True)
+    assert base["iter_logprob"][0] == inc["iter_logprob"][0]
+    assert not np.allclose(base["iter_logprob"][1:], inc["iter_logprob"][1:])
+    e, ei = run(expectation=True), run(expectation=True, include_self=True)
+    assert e["iter_logprob"][0] == ei["iter_logprob"][0] and not np.allclose(e["iter_logprob"][1:], ei["iter_logprob"][1:])
+    assert np.all(np.diff(ei["iter_logprob"][:4]) > 0)
+    er = run(expectation=True, random_start=True)
+    assert np.isneginf(er["iter_logprob"][0]) and np.all(np.isfinite(er["iter_logprob"][1:]))
+    assert not np.allclose(er["iter_logprob"][1:3], e["iter_logprob"][1:3])
+    rs = run(expectation=True, restarts=1)
+    lp = np.asarray(rs["iter_logprob"]).reshape(2, 9)
+    assert np.isfinite(lp[0, 0]) and np.isneginf(lp[1, 0])  # (gibbs.hpp:816: runi && expectation)
+    for r in (inc, ei, er):  # every normalisation group of the final parameters sums to one
+        p = np.exp(r["param_logw"])
+        assert np.all(np.isfinite(p)) and np.all(p >= 0)
