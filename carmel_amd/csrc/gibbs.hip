@@ -630,6 +630,9 @@ struct carmel_hip_gibbs {
   uint32_t pi_start = 0, pi_end = 0, n_scale = 0;
   std::vector<uint32_t> h_meta;       // metanorm: scale group of every norm group, 0 = never scaled (gibbs.hpp:404-470)
   DevBuf<uint32_t> d_meta, old_ids, ent_base;
+  uint32_t obs_every = 0;  // carmel_hip_gibbs_set_observer
+  carmel_hip_gibbs_observer_fn obs_fn = nullptr;
+  void* obs_ctx = nullptr;
   DevBuf<double> d_scales;
   std::vector<double> cumulative;     // product of the accepted scales per scale group
   std::vector<double> h_prior0;       // the priors before any inference (--prior-inference-restart-fresh)
@@ -1138,6 +1141,8 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       const double hi = std::max(st_sum, plog), lo = std::min(st_sum, plog);
       st_sum = hi + (lo == -std::numeric_limits<double>::infinity() ? 0.0 : std::log1p(std::exp(lo - hi)));
     }
+    // maybe_print_periodic (gibbs.hpp:959-968): the caller looks at the sample and the counts as they stand after this sweep
+    if (g->obs_fn && g->obs_every && iter % g->obs_every == 0) g->obs_fn(g->obs_ctx, run, iter, G.time);
   }
   // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
   if (g->pi_stddev > 0) {  // the priors have moved
@@ -1218,6 +1223,28 @@ int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* i
     HIPCHK(hipMemcpyAsync(ids, g->sample_ids.p + g->h_sample_off[block], len * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   *n = len;
+  return CARMEL_HIP_OK;
+}
+
+int carmel_hip_gibbs_set_observer(carmel_hip_gibbs* g, uint32_t every, carmel_hip_gibbs_observer_fn fn, void* ctx) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null sampler");
+  g->obs_every = fn ? every : 0u;
+  g->obs_fn = fn;
+  g->obs_ctx = ctx;
+  return CARMEL_HIP_OK;
+}
+// gibbs_base::proposal_prob (gibbs.hpp:163-170) of every parameter from the counts as they stand: count / norm sum, the prior
+// of a parameter outside the norm groups
+int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob) {
+  if (!g || !prob) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(g->t->device));
+  hipStream_t s = g->t->stream;
+  const size_t np = g->h_norm.size();
+  std::vector<double> x(np), ns(g->n_norm);
+  HIPCHK(hipMemcpyAsync(x.data(), g->p_x.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (g->n_norm) HIPCHK(hipMemcpyAsync(ns.data(), g->normsum.p, g->n_norm * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  for (size_t p = 0; p < np; ++p) prob[p] = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : x[p] / ns[g->h_norm[p]];
   return CARMEL_HIP_OK;
 }
 

@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <sstream>
@@ -98,6 +99,7 @@ struct Options {
   bool sample_prob_after = false;  // --sample-prob-after: log the add-back proposal probability (carmel_hip_gibbs_run_ex)
   bool crp_argmax_final = false, crp_argmax_sum = false;
   bool include_self = false, random_start = false;  // gibbs_opts.hpp:40-41, 127-128
+  long print_every = 0;                              // gibbs_opts.hpp:78-79
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   long print_from = 0, print_to = 0;  // --print-from=m --print-to=n (gibbs_opts.hpp; gibbs.cc:258-296): the final sample's
                                       // path through input transducers m .. n-1, one line each, on stdout
@@ -165,6 +167,8 @@ static Options parse_args(int argc, char** argv) {
         o.print_from = std::atol(v.c_str());
       else if (k == "print-to")
         o.print_to = std::atol(v.c_str());
+      else if (k == "print-every")  // gibbs_opts.hpp:78-79, gibbs.hpp:959-968
+        o.print_every = std::atol(v.c_str());
       else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob") {
         // inert in carmel itself: gibbs_opts::cache_prob is true and never cleared (carmel.cc:296-298, gibbs_opts.hpp:240,
         // 255-258), so the cache-model probability is what is logged whatever these say
@@ -1000,6 +1004,89 @@ static int run(int argc, char** argv) {
         hip_check(carmel_hip_set_weights(t, p0.data()), "carmel_hip_set_weights");
       }
     }
+    // gibbs_base::print_all -> carmel_gibbs::print_sample (gibbs.hpp:1066-1078; gibbs.cc:258-296): per block, for every input
+    // transducer in [a, b) the arcs of the sampled path that belong to it, through WFST::path_print; an arc's weight is
+    // proposal_prob of its parameter at the time of printing (plw: ln of it, per parameter)
+    const int ws = wstyle;
+    auto print_paths = [&](const std::vector<std::vector<uint32_t> >& smp, const std::vector<double>& plw, long a, long b) {
+    // parameter id -> (member, source state, arc)
+    std::vector<const Transducer*> mem;
+    std::vector<size_t> base;
+    if (cascade)
+      for (size_t i = 0; i < nw; ++i) {
+        mem.push_back(&member[i]);
+        base.push_back(params.member_base[i]);
+      }
+    else {
+      mem.push_back(result);
+      base.push_back(0);
+    }
+    std::vector<uint32_t> p_src;
+    std::vector<const HArc*> p_arc;
+    std::vector<uint32_t> p_mem;
+    for (size_t i = 0; i < mem.size(); ++i)
+      for (uint32_t st = 0; st < mem[i]->states.size(); ++st)
+        for (auto& arc : mem[i]->states[st]) {
+          p_src.push_back(st);
+          p_arc.push_back(&arc);
+          p_mem.push_back((uint32_t)i);
+        }
+    const bool fO = o.flags[(unsigned)'O'], fI = o.flags[(unsigned)'I'], fQ = o.flags[(unsigned)'Q'], fAT = o.flags[(unsigned)'@'],
+               fW = o.flags[(unsigned)'W'], fE = o.flags[(unsigned)'E'];
+    auto unquote = [](const std::string& x) {
+      return (x.size() >= 2 && x[0] == '"' && x[x.size() - 1] == '"') ? x.substr(1, x.size() - 2) : x;
+    };
+    for (auto& blk : smp)
+      for (long i = a; i < b; ++i) {
+        const Transducer& W = *mem[(size_t)i];
+        bool first = true;
+        double lw_path = 0.0;
+        std::vector<uint32_t> outs;
+        auto sp = [&]() {
+          if (!first) std::cout << ' ';
+          first = false;
+        };
+        for (uint32_t pid : blk) {
+          if (pid >= p_mem.size() || p_mem[pid] != (uint32_t)i) continue;
+          const HArc& arc = *p_arc[pid];
+          lw_path += plw[pid];
+          if (fAT) {
+            if (arc.out != 0) outs.push_back(arc.out);
+            if (arc.in != 0) {
+              sp();
+              std::cout << W.in_syms.names[arc.in];
+            }
+          } else if (fO || fI) {
+            const uint32_t id = fO ? arc.out : arc.in;
+            if (!(fE && id == 0)) {
+              sp();
+              const std::string& nm = fO ? W.out_syms.names[id] : W.in_syms.names[id];
+              std::cout << (fQ ? unquote(nm) : nm);
+            }
+          } else {
+            sp();
+            std::cout << '(' << W.state_name(p_src[pid]) << " -> " << W.state_name(arc.dest) << ' ' << W.in_syms.names[arc.in] << " : "
+                      << W.out_syms.names[arc.out] << " / " << format_weight(plw[pid], ws) << ")";
+          }
+        }
+        if (fAT) {
+          std::cout << std::endl;
+          bool f2 = true;
+          for (uint32_t id : outs) {
+            if (!f2) std::cout << ' ';
+            f2 = false;
+            std::cout << W.out_syms.names[id];
+          }
+          std::cout << std::endl;
+        } else {
+          if (!fW) {
+            sp();
+            std::cout << format_weight(lw_path, ws);
+          }
+          std::cout << std::endl;
+        }
+      }
+    };
     carmel_hip_gibbs* gs = 0;
     hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
     {
@@ -1017,6 +1104,44 @@ static int run(int argc, char** argv) {
                                                      member_states.data(), (uint32_t)nw),
                 "carmel_hip_gibbs_set_prior_inference");
     std::vector<double> lp((size_t)per_run * n_runs), lp_after(o.sample_prob_after ? lp.size() : 0);
+    // --print-every=N (gibbs_opts.hpp:78-79; gibbs.hpp:959-968 maybe_print_periodic): after sweeps 0, N, 2N, ... a comment line
+    // and, with --print-to, every block's sampled path -- the arcs carry the proposal probabilities of that moment
+    // (gibbs.cc:272-286).  The count / norm tables of --print-counts-* / --print-norms-* are not written.
+    std::function<void(uint32_t, uint32_t, double)> periodic = [&](uint32_t, uint32_t iter, double time) {
+      std::cout << "# Gibbs i=" << iter << " ";
+      if (go.high_temp != go.low_temp && (go.high_temp > 0 || go.low_temp > 0)) {  // gibbs.hpp:945-955 itername
+        const double pw_ = carmel_hip_gibbs_power(go.high_temp, go.low_temp, go.iter, iter);
+        std::cout << "temperature=" << 1.0 / pw_ << " power=" << pw_ << " ";
+      }
+      std::cout << "t=" << time << "\n";
+      if (!(o.print_to > o.print_from)) return;
+      if (go.expectation) throw std::runtime_error("can't print sample when using expectation because there is no single sample.\n");
+      const size_t n_members = cascade ? nw : 1;
+      long a = o.print_from, b = o.print_to;
+      if (!(b > a && a < (long)n_members)) return;
+      if (b > (long)n_members) b = (long)n_members;
+      const uint32_t nbk = carmel_hip_gibbs_n_blocks(gs);
+      std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_gibbs_max_sample(gs)));
+      std::vector<std::vector<uint32_t> > smp(nbk);
+      for (uint32_t bk = 0; bk < nbk; ++bk) {
+        uint32_t n = 0;
+        hip_check(carmel_hip_gibbs_get_sample(gs, bk, buf.data(), &n), "carmel_hip_gibbs_get_sample");
+        smp[bk].assign(buf.begin(), buf.begin() + n);
+      }
+      std::vector<double> pr(cascade ? params.logw.size() : logw.size());
+      hip_check(carmel_hip_gibbs_current_probs(gs, pr.data()), "carmel_hip_gibbs_current_probs");
+      for (double& x : pr) x = x > 0 ? std::log(x) : -std::numeric_limits<double>::infinity();
+      print_paths(smp, pr, a, b);
+    };
+    if (o.print_every > 0) {
+      if (world > 1) throw UsageError("--print-every with --gpus is not implemented by the GPU training front end");
+      hip_check(carmel_hip_gibbs_set_observer(gs, (uint32_t)o.print_every,
+                                              [](void* ctx, uint32_t run, uint32_t iter, double time) {
+                                                (*(std::function<void(uint32_t, uint32_t, double)>*)ctx)(run, iter, time);
+                                              },
+                                              &periodic),
+                "carmel_hip_gibbs_set_observer");
+    }
     if (world > 1) hip_check(carmel_hip_gibbs_set_run_share(gs, (uint32_t)rank, (uint32_t)world), "carmel_hip_gibbs_set_run_share");
     int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
@@ -1103,7 +1228,6 @@ static int run(int argc, char** argv) {
     if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());
     hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
-    const int ws = wstyle;
     if (printing) {
       // gibbs_base::print_all -> carmel_gibbs::print_sample (gibbs.hpp:1066-1078; gibbs.cc:258-296): per block, for every
       // input transducer in [from, to) the arcs of the sampled path that belong to it, through WFST::path_print; an arc's
@@ -1116,83 +1240,7 @@ static int run(int argc, char** argv) {
         if (b > (long)n_members) b = (long)n_members;
         std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << ((double)go.iter - (double)(go.final_counts ? go.iter : std::min(go.burnin, go.iter)))
                   << "):\n";
-        // parameter id -> (member, source state, arc)
-        std::vector<const Transducer*> mem;
-        std::vector<size_t> base;
-        if (cascade)
-          for (size_t i = 0; i < nw; ++i) {
-            mem.push_back(&member[i]);
-            base.push_back(params.member_base[i]);
-          }
-        else {
-          mem.push_back(result);
-          base.push_back(0);
-        }
-        std::vector<uint32_t> p_src;
-        std::vector<const HArc*> p_arc;
-        std::vector<uint32_t> p_mem;
-        for (size_t i = 0; i < mem.size(); ++i)
-          for (uint32_t st = 0; st < mem[i]->states.size(); ++st)
-            for (auto& arc : mem[i]->states[st]) {
-              p_src.push_back(st);
-              p_arc.push_back(&arc);
-              p_mem.push_back((uint32_t)i);
-            }
-        const bool fO = o.flags[(unsigned)'O'], fI = o.flags[(unsigned)'I'], fQ = o.flags[(unsigned)'Q'], fAT = o.flags[(unsigned)'@'],
-                   fW = o.flags[(unsigned)'W'], fE = o.flags[(unsigned)'E'];
-        auto unquote = [](const std::string& x) {
-          return (x.size() >= 2 && x[0] == '"' && x[x.size() - 1] == '"') ? x.substr(1, x.size() - 2) : x;
-        };
-        for (auto& blk : final_sample)
-          for (long i = a; i < b; ++i) {
-            const Transducer& W = *mem[(size_t)i];
-            bool first = true;
-            double lw_path = 0.0;
-            std::vector<uint32_t> outs;
-            auto sp = [&]() {
-              if (!first) std::cout << ' ';
-              first = false;
-            };
-            for (uint32_t pid : blk) {
-              if (pid >= p_mem.size() || p_mem[pid] != (uint32_t)i) continue;
-              const HArc& arc = *p_arc[pid];
-              lw_path += pw[pid];
-              if (fAT) {
-                if (arc.out != 0) outs.push_back(arc.out);
-                if (arc.in != 0) {
-                  sp();
-                  std::cout << W.in_syms.names[arc.in];
-                }
-              } else if (fO || fI) {
-                const uint32_t id = fO ? arc.out : arc.in;
-                if (!(fE && id == 0)) {
-                  sp();
-                  const std::string& nm = fO ? W.out_syms.names[id] : W.in_syms.names[id];
-                  std::cout << (fQ ? unquote(nm) : nm);
-                }
-              } else {
-                sp();
-                std::cout << '(' << W.state_name(p_src[pid]) << " -> " << W.state_name(arc.dest) << ' ' << W.in_syms.names[arc.in] << " : "
-                          << W.out_syms.names[arc.out] << " / " << format_weight(pw[pid], ws) << ")";
-              }
-            }
-            if (fAT) {
-              std::cout << std::endl;
-              bool f2 = true;
-              for (uint32_t id : outs) {
-                if (!f2) std::cout << ' ';
-                f2 = false;
-                std::cout << W.out_syms.names[id];
-              }
-              std::cout << std::endl;
-            } else {
-              if (!fW) {
-                sp();
-                std::cout << format_weight(lw_path, ws);
-              }
-              std::cout << std::endl;
-            }
-          }
+        print_paths(final_sample, pw, a, b);
       }
     }
     const char* dir = std::getenv("CARMEL_TRAINED_DIR");

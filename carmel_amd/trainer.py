@@ -384,6 +384,19 @@ class HipGibbs(object):
         check(lib.carmel_hip_gibbs_get_sample(self.h, block, ptr(buf), C.byref(n)), "carmel_hip_gibbs_get_sample")
         return buf[:n.value].tolist()
 
+    def observe(self, every, fn):
+        """fn(run, iter, time) after every sweep whose number divides by `every` (carmel --print-every); inside it
+        sample(b) and current_probs() show the chain as it stands"""
+        from ._capi import GIBBS_OBSERVER_FN
+        self._obs = GIBBS_OBSERVER_FN(lambda ctx, run, it, time: fn(run, it, time)) if fn else GIBBS_OBSERVER_FN()
+        check(lib.carmel_hip_gibbs_set_observer(self.h, every if fn else 0, self._obs, None), "carmel_hip_gibbs_set_observer")
+
+    def current_probs(self):
+        """gibbs_base::proposal_prob of every parameter from the counts as they stand"""
+        out = np.zeros(self.fb.n_params, np.float64)
+        check(lib.carmel_hip_gibbs_current_probs(self.h, out.ctypes.data_as(C.c_void_p)), "carmel_hip_gibbs_current_probs")
+        return out
+
     def uniform(self, it, block, step):
         return lib.carmel_hip_gibbs_uniform(self.opts.seed, it, block, step)
 

@@ -327,6 +327,14 @@ int carmel_hip_gibbs_set_prior_inference(carmel_hip_gibbs* g, double stddev, int
 int carmel_hip_gibbs_prior_trace(carmel_hip_gibbs* g, double* out6, uint32_t n_sweeps, double* cumulative, uint32_t n_cumulative);
 uint32_t carmel_hip_gibbs_n_prior_scales(carmel_hip_gibbs* g);
 
+/* Replaces: gibbs_base::maybe_print_periodic (gibbs.hpp:959-968; carmel --print-every=N): after every sweep i of a run with
+ * i % every == 0 the sampler calls fn(ctx, run, i, time) on the calling thread, the stream idle; inside the call
+ * carmel_hip_gibbs_get_sample gives the sample as it stands and carmel_hip_gibbs_current_probs the proposal probability
+ * (gibbs.hpp:163-170) of every parameter from the counts as they stand -- what print_path prints on the arcs
+ * (gibbs.cc:272-286).  every = 0 or fn = NULL: none. */
+typedef void (*carmel_hip_gibbs_observer_fn)(void* ctx, uint32_t run, uint32_t iter, double time);
+int carmel_hip_gibbs_set_observer(carmel_hip_gibbs* g, uint32_t every, carmel_hip_gibbs_observer_fn fn, void* ctx);
+int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
 /* --init-em (gibbs.cc:386-430, 306-383 p_init): ln weights of the composed arcs (carmel_hip_get_arc_weights after an EM

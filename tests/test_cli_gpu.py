@@ -792,3 +792,43 @@ def test_crp_prints_the_final_sample(golden_dir, tmp_path, oracle):
     plain_ch = [l.split() for l in out_i.split("\n")[2:] if l != ""]
     plain_lm = [l.split() for l in out_lm.split("\n")[2:] if l != ""]
     assert plain_ch == plain_lm and all(len(a) == len(b) for a, b in zip(plain_ch, cipher))
+
+
+@pytest.mark.gpu
+def test_crp_print_every(golden_dir, tmp_path, oracle):
+    """--print-every=N with --print-to (gibbs_opts.hpp:78-79; gibbs.hpp:959-968 maybe_print_periodic): after sweeps 0, N, 2N, ...
+    a comment line "# Gibbs i=<sweep> t=<time>" and every block's path as it stands; the final print follows as always.  The
+    periodic samples are the oracle's chain stopped at those sweeps (the chain is a function of the uniforms alone: a run of
+    k sweeps ends in the sample the longer run holds after sweep k, given the same burn-in clock)."""
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    base = ["--crp", "-M", "9", "--burnin=3", "--priors=0.5,0.1", "-R", "7", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    env = {"CARMEL_TRAINED_DIR": str(tmp_path)}
+    rc, out, err = run(["--print-every=3", "--print-from=1", "--print-to=2", "-OQWE"] + base, env=env)
+    assert rc == 0, err
+    heads = [l for l in out.split("\n") if l.startswith("# Gibbs i=")]
+    assert heads == ["# Gibbs i=0 t=0", "# Gibbs i=3 t=0", "# Gibbs i=6 t=3", "# Gibbs i=9 t=6"]
+    chunks = re.split(r"# Gibbs i=\d+ t=\d+\n", out)
+    assert len(chunks) == 5 and "# final best gibbs run (start #0 t=6):" in chunks[4]
+    per = [[l for l in c.split("\n") if l and not l.startswith("#")] for c in chunks[1:]]
+    assert all(len(p) == 10 for p in per[:3]) and len(per[3]) == 20  # (the last chunk: sweep 9's print and the final one)
+    assert per[3][:10] == per[3][10:]
+    # -O on the channel: whatever the sweep, the channel's outputs along the path are the cipher text
+    cipher = [[c.strip('"') for c in l.split()] for l in open(g("cipher.data")).read().split("\n")[1::2] if l.strip()]
+    for p in per[:3]:
+        assert [l.split() for l in p] == cipher
+    # the plain text (the LM's side) after sweep 3 = the final sample of a 3-sweep run on the same uniforms
+    rc, out_i, err = run(["--print-every=3", "--print-from=0", "--print-to=1", "-OQWE"] + base, env=env)
+    assert rc == 0, err
+    parts = re.split(r"# Gibbs i=\d+ t=\d+\n", out_i)
+    at0 = [l for l in parts[1].split("\n") if l and not l.startswith("#")]
+    at3 = [l for l in parts[2].split("\n") if l and not l.startswith("#")]
+    assert at0 != at3  # the plain text moves
+    short = [x if x != "9" else "3" for x in base]
+    rc, out_s, err = run(["--print-from=0", "--print-to=1", "-OQWE"] + short, env=env)
+    assert rc == 0, err
+    fin3 = [l for l in out_s.split("\n") if l and not l.startswith("#")]
+    assert at3 == fin3
+    # the count / norm tables stay refused
+    rc, out, err = run(["--print-every=3", "--print-counts-to=5"] + base, env=env)
+    assert rc != 0 and "print-counts-to" in err

@@ -368,3 +368,24 @@ def test_gibbs_on_lattices_with_cycles(oracle, kw):
     np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
     gs.close()
     fb.close()
+
+
+def test_observer_sees_the_chain_as_it_stands(oracle, golden_dir):
+    """carmel_hip_gibbs_set_observer / _current_probs: called after sweeps 0, 2, 4, ...; the probabilities it reads are
+    count / norm sum of that moment (a distribution per norm group), the sample the one a shorter run ends with"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    gs = HipGibbs(fb, 6, burnin=2, seed=7, mode=0)
+    seen = []
+    gs.observe(2, lambda run, it, time: seen.append((run, it, time, [gs.sample(b) for b in range(gs.n_blocks)], gs.current_probs())))
+    gs.run()
+    assert [(r, i, t) for r, i, t, _, _ in seen] == [(0, 0, 0.0), (0, 2, 0.0), (0, 4, 2.0), (0, 6, 4.0)]
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.5, 0.1], iters=4, burnin=2)
+    assert seen[2][3] == ref["samples"]
+    for _, _, _, _, p in seen:
+        assert np.all(p > 0) and np.all(p <= 1)
+    assert not np.allclose(seen[0][4], seen[3][4])
+    gs.close()
+    fb.close()
