@@ -33,3 +33,11 @@ try:
 except Exception as e: print("$CFG pmc failed", e)
 PY
 done
+# c5: kernel stats of the parallel sweep
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kf && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kf -- python3 $R/bench.py --config c5 --no-cpu-baseline --no-secondary --steps 200 > /tmp/kf.log 2>&1
+f=$(find /tmp/kf -name '*kernel_stats.csv' | head -1); cp $f $O/c5_kernel_stats.csv
+python3 - "$f" <<'PY'
+import csv,sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:8]:
+    print("   %-70s calls %6s avg %9.1f us"%(r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
+PY
