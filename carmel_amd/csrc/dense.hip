@@ -8,8 +8,8 @@
 namespace carmel_hip {
 
 uint32_t dense_padded_states(uint32_t S) {
-  // 16 and 32 run on the matrix cores (dense_mfma_kernel); CARMEL_HIP_DENSE_MFMA=0 pads to the next of the vector sizes
-  static const bool no_mfma = getenv("CARMEL_HIP_DENSE_MFMA") && atoi(getenv("CARMEL_HIP_DENSE_MFMA")) == 0;
+  // 16 and 32 run on the matrix cores (dense_mfma_kernel); no_mfma (a source switch, for A/B) pads to the next of the vector sizes
+  static const bool no_mfma = false;
   static const uint32_t vec[] = {4, 8, 12, 16, 20, 24, 28, 30, 32}, mat[] = {4, 8, 12, 16, 32};
   if (no_mfma) {
     for (uint32_t p : vec)
@@ -430,10 +430,10 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(DenseArgs D) {
 }
 
 hipError_t launch_dense_sweep(const DenseArgs& D, uint32_t n_groups, hipStream_t s) {
-  static const bool no_mfma = getenv("CARMEL_HIP_DENSE_MFMA") && atoi(getenv("CARMEL_HIP_DENSE_MFMA")) == 0;  // A/B: vector variants
+  static const bool no_mfma = false;  // A/B (source switch): the vector variants
   if (!no_mfma && (D.SP == 16 || D.SP == 32)) {
     const size_t l2 = (((size_t)D.n_slots + 1) & ~(size_t)1) * 8 + (size_t)D.V * D.SP * 8 + (((size_t)D.V * D.SP + 3) / 4) * 8 + 16;
-    static const bool split = !(getenv("CARMEL_HIP_DENSE_SPLIT") && atoi(getenv("CARMEL_HIP_DENSE_SPLIT")) == 0);  // 0: one launch for both passes
+    static const bool split = true;  // (false: one launch for both passes -- measured slower)
     if (D.SP == 16) {
       if (split && D.afbuf) {
         hipLaunchKernelGGL((dense_mfma_kernel<1, 1>), dim3(n_groups), dim3(256), l2, s, D);
@@ -449,7 +449,7 @@ hipError_t launch_dense_sweep(const DenseArgs& D, uint32_t n_groups, hipStream_t
     }
     return hipGetLastError();
   }
-  static const bool smem = !(getenv("CARMEL_HIP_DENSE_SMEM") && atoi(getenv("CARMEL_HIP_DENSE_SMEM")) == 0);  // 0: the LDS-broadcast variant (measured slower)
+  static const bool smem = true;  // (false: the LDS-broadcast variant, measured slower)
   const size_t lds = (((size_t)D.n_slots + 1) & ~(size_t)1) * 8 + (size_t)D.V * D.SP * 8 + (((size_t)D.V * D.SP + 3) / 4) * 8 +
                      (smem ? 0 : (size_t)2 * D.SP * D.SP * 8) + 16;
 #define DENSE_CASE(P)                                                                                                   \

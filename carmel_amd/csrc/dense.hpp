@@ -17,7 +17,7 @@ static const uint32_t DENSE_MAX_STATES = 32;
 
 struct DenseArgs {
   uint32_t S, SP, V, start, fin, n_slots, n_eps;
-  uint32_t debug;           // timing experiments (CARMEL_HIP_DENSE_DEBUG): 1 no posterior adds, 2 no parked values, 4 no backward pass
+  uint32_t debug;           // timing experiments (set in the source): 1 no posterior adds, 2 no parked values, 4 no backward pass
   const uint16_t* e_src;    // *e*:*e* arcs in topological order of their sources (they collect no counts here)
   const uint16_t* e_dst;
   const double* We;         // their linear weights

@@ -199,7 +199,6 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.prune = prune != 0;
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
-  if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;  // A/B: 0 = no one-per-wavefront lattices (bundles as before)
@@ -494,9 +493,8 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       if (first[g] == ~0ull) first[g] = k;
       span = std::max(span, k - first[g]);
     }
-    const bool want_window = !(getenv("CARMEL_HIP_MSTEP_WINDOW") && atoi(getenv("CARMEL_HIP_MSTEP_WINDOW")) == 0);
-    t->norm_span = (want_window && span >= 1 && span <= 64) ? (uint32_t)span : 0u;
-    if (want_window && span == 0 && !add.empty()) t->norm_span = 1;  // all groups are singletons
+    t->norm_span = (span >= 1 && span <= 64) ? (uint32_t)span : 0u;
+    if (span == 0 && !add.empty()) t->norm_span = 1;  // all groups are singletons
   }
   t->h_group_add = add;
   {
@@ -526,7 +524,7 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
     HIPCHK(t->norm_code16.upload(code, t->stream));
     // members of every parameter's group as offsets -15 .. +16 (bit offset + 15), unlocked and locked apart
     std::vector<uint32_t> mask, lmask;
-    if (t->norm_span && t->norm_span <= 15 && !(getenv("CARMEL_HIP_MSTEP_MASK") && atoi(getenv("CARMEL_HIP_MSTEP_MASK")) == 0)) {
+    if (t->norm_span && t->norm_span <= 15) {
       mask.assign(n, 0u);
       lmask.assign(n, 0u);
       const std::vector<uint64_t>& off = t->h_group_off;
@@ -542,7 +540,7 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
     HIPCHK(t->norm_lockmask32.upload(lmask, t->stream));
     // spans of 16 .. 31 (config 2: 20 arcs per state, groups up to 19 apart): the same with 64-bit masks, bit offset + 31
     std::vector<unsigned long long> mask64, lmask64;
-    if (t->norm_span > 15 && t->norm_span <= 31 && !(getenv("CARMEL_HIP_MSTEP_MASK") && atoi(getenv("CARMEL_HIP_MSTEP_MASK")) == 0)) {
+    if (t->norm_span > 15 && t->norm_span <= 31) {
       mask64.assign(n, 0ull);
       lmask64.assign(n, 0ull);
       const std::vector<uint64_t>& off = t->h_group_off;
@@ -876,8 +874,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   ExchangePlan* const xp = (t->xplan && exchange_is_sharded(t->xplan) && t->use_transpose) ? t->xplan : nullptr;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
-  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty() &&
-                            !(getenv("CARMEL_HIP_ESTEP_STREAMS") && atoi(getenv("CARMEL_HIP_ESTEP_STREAMS")) <= 1);
+  const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty();
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
   if (xp) {  // the weights arrive arc range by arc range (all-gather of the sharded M-step): exchange.cpp

@@ -253,7 +253,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, t->device);
   // LDS holds only accumulators and scales: several workgroups share a CU, their waves hide the table latency
   const uint32_t per_wave = M.S <= 16 ? 4u : M.S <= 32 ? 2u : 1u;  // pairs side by side in one wavefront
-  const int wg_per_cu = getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU") ? std::max(1, atoi(getenv("CARMEL_HIP_UNROLLED_WGS_PER_CU"))) : 2;
+  const int wg_per_cu = 2;
   t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * wg_per_cu, (M.pair_id.size() + n_waves * per_wave - 1) / (n_waves * per_wave));
   if (wide) {
     t->u_n_wg = (uint32_t)std::min<uint64_t>((uint64_t)n_cu * 2, M.pair_id.size());
@@ -329,7 +329,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
     D.fin = M.fin;
     D.n_slots = t->u_n_slots;
     D.n_eps = (uint32_t)t->u_e_arc.n;
-    D.debug = getenv("CARMEL_HIP_DENSE_DEBUG") ? (uint32_t)atoi(getenv("CARMEL_HIP_DENSE_DEBUG")) : 0u;
+    D.debug = 0u;
     D.e_src = t->u_e_src.p;
     D.e_dst = t->u_e_dst.p;
     D.We = t->u_We.p;
@@ -382,7 +382,7 @@ int unrolled_estimate(carmel_hip_trainer* t, hipStream_t s) {
   A.pair_logprob = t->pair_logprob.p;
   A.partial = t->u_partial.p;
   A.alpha_scratch = t->u_scratch.p;
-  A.debug_no_acc = getenv("CARMEL_HIP_UNROLLED_NOACC") ? (uint32_t)std::max(1, atoi(getenv("CARMEL_HIP_UNROLLED_NOACC"))) : 0u;  // 1: no adds, 2: forward only
+  A.debug_no_acc = 0u;
   HIPCHK(launch_unrolled_sweep(A, t->u_n_wg, t->counts_ptr(), s));
   return CARMEL_HIP_OK;
 }

@@ -1867,14 +1867,10 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       for (uint32_t k = 0; k < fl.n; ++k) hp[G.stream_base + (size_t)k * 64 + l] = fl.hdr[k];
     }
   }
-  {  // launch classes by LDS need: a class ends where the groups have shrunk to 2/3 of its largest (CARMEL_HIP_FOREST_CLASSES=
-     // "num,den,min groups").  Finer classes (4,5,64: eleven for config 5) pad less LDS but were slower, 0.96 against
-     // 0.79 ms per sweep: only four or five kernels run side by side, the rest queue behind them
-    unsigned cls_num = 2, cls_den = 3, cls_min = 256;
-    if (const char* e = getenv("CARMEL_HIP_FOREST_CLASSES")) {
-      unsigned a = 0, b = 0, c = 0;
-      if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a && b && a < b && c) cls_num = a, cls_den = b, cls_min = c;
-    }
+  {  // launch classes by LDS need: a class ends where the groups have shrunk to 2/3 of its largest, 256 groups at least.
+     // Finer classes (4/5, 64 groups: eleven for config 5) pad less LDS but were slower, 0.96 against 0.79 ms per sweep: only
+     // four or five kernels run side by side, the rest queue behind them
+    const unsigned cls_num = 2, cls_den = 3, cls_min = 256;
     size_t i = 0;
     while (i < ng) {
       uint32_t mx = F->h_groups[i].max_nodes;
@@ -2120,8 +2116,8 @@ int carmel_hip_forests_estimate(carmel_hip_forests* F, double prior_count, doubl
   fill_args(F, A);
   HIPCHK(hipMemsetAsync(F->scalars.p, 0, 4 * sizeof(double), s));
   HIPCHK(fork_side(F, s));
-  // mantissa / exponent arithmetic where the columns fit LDS at 12 bytes per value (CARMEL_HIP_FOREST_EM_EXT=0: the log domain)
-  static const bool em_ext = !(getenv("CARMEL_HIP_FOREST_EM_EXT") && atoi(getenv("CARMEL_HIP_FOREST_EM_EXT")) == 0);
+  // mantissa / exponent arithmetic where the columns fit LDS at 12 bytes per value (otherwise: the log domain)
+  static const bool em_ext = true;
   for (size_t ci = 0; ci < F->classes.size(); ++ci) {
     const auto& c = F->classes[ci];
     A.first_group = c.first;
@@ -2339,8 +2335,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   bool split_recount = false;  // set below
   const bool sweep2 = o->mode == 1 && F->sweep2_ok && !(getenv("CARMEL_HIP_FOREST_SWEEP") && atoi(getenv("CARMEL_HIP_FOREST_SWEEP")) == 1);
   if (sweep2) {
-    // the classes' recounts beside the classes still sampling (CARMEL_HIP_FOREST_RECOUNT_SPLIT=0: one recount after all)
-    split_recount = !(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT") && atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_SPLIT")) == 0);
+    // the classes' recounts beside the classes still sampling (false: one recount after all, the earlier form)
+    split_recount = true;
     if (split_recount) HIPCHK(F->normsum2.alloc(ng));
     HIPCHK(F->sample_cls.alloc(F->h_sample_off.back()));
     HIPCHK(F->rec_logp.alloc(F->stream_total));
@@ -2356,18 +2352,13 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   }
   DevBuf<double> gcol_exact;  // exact mode: the inside column of one forest too large for LDS
   DevBuf<uint32_t> ghash;  // parallel mode: global own-sample tables, only when some derivation can overflow the LDS table
-  const uint32_t own_cap_max = getenv("CARMEL_HIP_FOREST_OWNCAP") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_OWNCAP")) : 256u;
+  const uint32_t own_cap_max = 256u;
   // the walk of forest_sample_kernel over tables in LDS (CARMEL_HIP_FOREST_LDSWALK=0: over the global stream, the A/B reference)
   // groups per workgroup of a class's recount (fewer groups per workgroup = more workgroups, each adding its share of
   // the popular rules to the same addresses: 1 and 2 measured slower than 4, 122 and 84 against 77 us for the last class)
-  const uint32_t recount_div = getenv("CARMEL_HIP_FOREST_RECOUNT_DIV") ? std::max(1, atoi(getenv("CARMEL_HIP_FOREST_RECOUNT_DIV"))) : 4;
-  // the recount's LDS tables: rules / norm groups (CARMEL_HIP_FOREST_RECOUNT_SLOTS="s0,s1", powers of two)
-  uint32_t frc_slots0 = 8192, frc_slots1 = 4096;
-  if (const char* e = getenv("CARMEL_HIP_FOREST_RECOUNT_SLOTS")) {
-    unsigned a = 0, b = 0;
-    if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 64 && b >= 64 && !(a & (a - 1)) && !(b & (b - 1)) && (size_t)(a + b) * 8 <= 150 * 1024)
-      frc_slots0 = a, frc_slots1 = b;
-  }
+  const uint32_t recount_div = 4;
+  // the recount's LDS tables: rules / norm groups (powers of two)
+  const uint32_t frc_slots0 = 8192, frc_slots1 = 4096;
   const size_t frc_bytes = (size_t)(frc_slots0 + frc_slots1) * 8;
   (void)hipFuncSetAttribute((const void*)forest_recount_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)frc_bytes);
   const bool lds_walk = !(getenv("CARMEL_HIP_FOREST_LDSWALK") && atoi(getenv("CARMEL_HIP_FOREST_LDSWALK")) == 0);
@@ -2378,8 +2369,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   auto fm_bytes = [](const carmel_hip_forests::Cls& c) {  // LDS of one forest in forest_sample_multi_kernel
     return (size_t)c.m_n * 24 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
   };
-  const uint32_t stack_lds = getenv("CARMEL_HIP_FOREST_STACK") ? (uint32_t)atoi(getenv("CARMEL_HIP_FOREST_STACK")) : 32u;
-  if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH") && !getenv("CARMEL_HIP_FOREST_NOGHASH")) {
+  const uint32_t stack_lds = 32u;
+  if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
     A.ghash = ghash.p;
   }

@@ -996,9 +996,9 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     if (!g->old_ids.n) HIPCHK(g->old_ids.alloc(std::max<uint32_t>(g->max_sample, 1u)));
     G.old_ids = g->old_ids.p;
   }
-  G.par_books = getenv("CARMEL_HIP_GIBBS_SERIAL_BOOKS") ? 0 : 1;  // A/B: one thread books a block's counts id by id
+  G.par_books = 1;  // (0: one thread books a block's counts id by id -- the A/B reference)
   G.books_cap = std::min<uint32_t>(g->max_sample, 7168u);          // 56 KB of LDS at most
-  G.stage_arcs = getenv("CARMEL_HIP_GIBBS_NO_STAGE") ? 0u : 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
+  G.stage_arcs = 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
   G.stage_states = 1024u;                                           // 1024 states sweep and walk out of LDS
   G.iter_out = g->iter_out.p;
   G.want_after = iter_after_logprob ? 1 : 0;

@@ -74,7 +74,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt) {
         if (m > mx) mx = m;
         // a class costs a launch (ramp-up + tail); it only pays when the LDS saved buys occupancy that matters:
         // below ~20 KB per wave (8 waves per CU) the sweep is already bound by the random-gather rate
-        static const uint32_t min_split = getenv("CARMEL_HIP_LANE_SPLIT_STATES") ? (uint32_t)atoi(getenv("CARMEL_HIP_LANE_SPLIT_STATES")) : 48u;
+        const uint32_t min_split = 48u;
         if (j - i >= 256 && mx > min_split && (uint64_t)m * 3 <= (uint64_t)mx * 2) break;
         ++j;
       }

@@ -32,7 +32,7 @@ struct UnrolledArgs {
   const double* pair_weight;
   double* pair_logprob;
   double* partial;                 // n_workgroups * n_slots
-  uint32_t debug_no_acc;           // timing experiment (CARMEL_HIP_UNROLLED_NOACC): skip the posterior adds
+  uint32_t debug_no_acc;           // timing experiment (set in the source): skip the posterior adds
   double* alpha_scratch;           // unrolled_scratch_doubles(): per wave (max_len + 1) rows of 64
 };
 

@@ -22,8 +22,6 @@ run base X=1
 run v3 CARMEL_HIP_LANE_VARIANT=3
 run v5 CARMEL_HIP_LANE_VARIANT=5
 run v6 CARMEL_HIP_LANE_VARIANT=6
-run chunks2 CARMEL_HIP_LANE_CHUNKS=2
-run chunks4 CARMEL_HIP_LANE_CHUNKS=4
 run runs CARMEL_HIP_TRANS_RUNS=1
 run lane128 CARMEL_HIP_LANE_STATES=128
 grep "timing:   lane piece\|timing: layout\|lattice build" $O/c4a_base.err | head -20
