@@ -1098,7 +1098,8 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 #define FM_G 8
 #define FM_FPW (64 / FM_G)
 struct FMultiArgs {
-  const uint16_t* tab;      // per forest: {n, H, n_kids, -}, lvl_off[H + 1], ord[n], kid_off[n + 1], kids[n_kids] (| 0x8000: back-reference)
+  const uint16_t* tab;      // per forest, its nodes numbered by height: {n, H, n_kids, -}, lvl_off[H + 1], kid_off[n + 1],
+                            // kids[n_kids] (| 0x8000: back-reference)
   const uint32_t* hdr;      // per forest, per node: {row of its header in the lane's inside stream | bit 31 = AND, rule id,
                             // class word (ForestArgs::rec_cls), norm group}: four words per node
   const uint64_t* tab_off;  // per lane slot: offset into tab (u16 words) / hdr (u32 words)
@@ -1119,6 +1120,7 @@ __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t&
   total = __shfl(x, FM_G - 1, FM_G);
   return x - v;
 }
+#define FM_EBIAS 2048
 __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double fm_lds[];
   const uint32_t sub = threadIdx.x / FM_G, li = threadIdx.x % FM_G;
@@ -1127,13 +1129,12 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
   const uint32_t slot = M.lane_lo + blockIdx.x * FM_FPW + sub;
   const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;
   const bool active = forest != 0xffffffffu;
-  // this forest's stretch of LDS: mantissas (f64), proposal probabilities (f64), exponents (i32), header words (u32),
-  // table + two frontiers (u16)
-  const size_t per = (size_t)M.max_n * 24 + (((size_t)M.max_tab + 2 * (size_t)M.max_front) * 2 + 15) / 16 * 16;
+  // this forest's stretch of LDS: mantissas (f64), exponents (i32), header words (u32: row of the node's header record | the
+  // exponent of an AND node's proposal probability + FM_EBIAS, bits 16..30 | bit 31 = AND), table + two frontiers (u16)
+  const size_t per = (size_t)M.max_n * 16 + (((size_t)M.max_tab + 2 * (size_t)M.max_front) * 2 + 15) / 16 * 16;
   char* mine = (char*)fm_lds + per * sub;
   double* vm = (double*)mine;
-  double* pp = vm + M.max_n;
-  int* ve = (int*)(pp + M.max_n);
+  int* ve = (int*)(vm + M.max_n);
   uint32_t* hd = (uint32_t*)(ve + M.max_n);
   unsigned short* tb = (unsigned short*)(hd + M.max_n);
   unsigned short* fr0 = tb + M.max_tab;
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     const unsigned short* __restrict__ src = M.tab + M.tab_off[slot];
     n = src[0];
     H = src[1];
-    const uint32_t words = 4u + (H + 1) + n + (n + 1) + src[2];
+    const uint32_t words = 4u + (H + 1) + (n + 1) + src[2];
     for (uint32_t k = li; k < words; k += FM_G) tb[k] = src[k];
     if (M.own_proposal)
       for (uint32_t k = li; k < n; k += FM_G) ve[k] = 0;
@@ -1167,45 +1168,51 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
   __syncthreads();
   if (active) {
     const uint4* __restrict__ hs = (const uint4*)(M.hdr + M.hdr_off[slot]);
-    const double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
+    double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
     for (uint32_t k = li; k < n; k += FM_G) {
       const uint4 h = hs[k];  // {header row | AND, rule, class word, norm group}
-      hd[k] = h.x;
+      uint32_t hw = h.x;
       if (h.x & 0x80000000u) {
         double pr;
         if (!M.own_proposal)
           pr = recp0[(size_t)(h.x & 0x7fffffffu) * 64];
-        else if (h.w == F_NONORM)
-          pr = A.p_prior[h.y];
         else {
-          // forest_proposal_kernel: (count - own uses) / (norm sum - own uses of the group)
-          const uint32_t own_r = (uint32_t)ve[h.z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[h.z >> 16] >> 16;
-          pr = (A.snap_x[h.y] - (double)own_r) / (A.snap_norm[h.w] - (double)own_n);
+          if (h.w == F_NONORM)
+            pr = A.p_prior[h.y];
+          else {
+            // forest_proposal_kernel: (count - own uses) / (norm sum - own uses of the group)
+            const uint32_t own_r = (uint32_t)ve[h.z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[h.z >> 16] >> 16;
+            pr = (A.snap_x[h.y] - (double)own_r) / (A.snap_norm[h.w] - (double)own_n);
+          }
+          recp0[(size_t)(h.x & 0x7fffffffu) * 64] = pr;  // (the recount reads the sampled rules' probabilities)
         }
-        pp[k] = pr;
+        // the inside pass starts an AND node from its probability: mantissa where the node's value will be, exponent in the
+        // header word (the exponents' rows still hold the histogram)
+        int e;
+        vm[k] = frexp(pr, &e);
+        hw |= (uint32_t)(e + FM_EBIAS) << 16;
       }
+      hd[k] = hw;
     }
   }
   __syncthreads();
   if (A.trace) tr1 = __builtin_readcyclecounter();
   const unsigned short* lvl = tb + 4;
-  const unsigned short* ord = lvl + H + 1;
-  const unsigned short* koff = ord + n;
+  const unsigned short* koff = lvl + H + 1;
   const unsigned short* kids = koff + n + 1;
-  double* __restrict__ recp = A.rec_p + g.stream_base + lane;
   // ---- inside, height by height (forest.hpp:768-816 with the proposal probabilities) ----
   uint32_t Hmax = H;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) Hmax = max(Hmax, (uint32_t)__shfl_xor((int)Hmax, o, 64));
   for (uint32_t h = 0; h < Hmax; ++h) {
     if (h < H)
-      for (uint32_t j = lvl[h] + li; j < lvl[h + 1]; j += FM_G) {
-        const uint32_t node = ord[j];
+      for (uint32_t node = lvl[h] + li; node < lvl[h + 1]; node += FM_G) {  // (the nodes of a height: a range of ids)
         const uint32_t hw = hd[node], k0 = koff[node], k1 = koff[node + 1];
         double m;
         int e;
         if (hw & 0x80000000u) {  // AND: its rule's proposal probability times its children
-          m = frexp(pp[node], &e);
+          m = vm[node];
+          e = (int)((hw >> 16) & 0x7fffu) - FM_EBIAS;
           for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t c = kids[k] & 0x7fffu;
             int t;
@@ -1283,8 +1290,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
       const uint32_t at = fm_prefix(push, li, tot_push), ar = fm_prefix(rec, li, tot_rec);
       if (have) {
         if (is_and) {
-          if (ns + ar < max_sample) outh[ns + ar] = hd[node] & 0x7fffffffu;
-          if (M.own_proposal) recp[(size_t)(hd[node] & 0x7fffffffu) * 64] = pp[node];  // (the recount reads the sampled rules' probabilities)
+          if (ns + ar < max_sample) outh[ns + ar] = hd[node] & 0xffffu;
           for (uint32_t k = 0; k < push; ++k)
             if (nn + at + k < M.max_front) nxt[nn + at + k] = kids[k0 + k];
         } else if (push) {
@@ -1688,6 +1694,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     std::vector<uint16_t> mt;   // forest_sample_multi_kernel's table block (FMultiArgs::tab); empty: the forest does not fit it
     std::vector<uint32_t> mh;   // ... header row | AND per node
     uint32_t m_front = 0;       // ... entries of its widest breadth-first frontier (bounded by the largest derivation)
+    std::vector<uint16_t> m_ord;  // ... its nodes by height: sampler's node id -> node
   };
   std::vector<Flat> flat(n_forests);
   for (uint64_t f = 0; f < n_forests; ++f) {
@@ -1805,22 +1812,30 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         for (uint32_t k = 0; k < fl.n; ++k) cnt[height[k] + 1]++;
         for (uint32_t h = 0; h < Hh; ++h) cnt[h + 1] += cnt[h];
         for (uint32_t h = 0; h <= Hh; ++h) mt.push_back((uint16_t)cnt[h]);
-        std::vector<uint16_t> ordv(fl.n);
+        // the sampler numbers the nodes BY HEIGHT (stable: the root, alone at the top, stays last): the nodes of a height are a
+        // range of ids, a node's children have smaller ids
+        std::vector<uint16_t>& ordv = fl.m_ord;
+        ordv.assign(fl.n, 0);
+        std::vector<uint16_t> newid(fl.n);
         {
           std::vector<uint32_t> cur(cnt.begin(), cnt.end() - 1);
-          for (uint32_t k = 0; k < fl.n; ++k) ordv[cur[height[k]]++] = (uint16_t)k;
+          for (uint32_t k = 0; k < fl.n; ++k) {
+            newid[k] = (uint16_t)cur[height[k]];
+            ordv[cur[height[k]]++] = (uint16_t)k;
+          }
         }
-        mt.insert(mt.end(), ordv.begin(), ordv.end());
         uint32_t off = 0;
-        for (uint32_t k = 0; k < fl.n; ++k) {
+        for (uint32_t q = 0; q < fl.n; ++q) {
           mt.push_back((uint16_t)off);
-          off += (uint32_t)kids[k].size();
+          off += (uint32_t)kids[ordv[q]].size();
         }
         mt.push_back((uint16_t)off);
-        for (uint32_t k = 0; k < fl.n; ++k)
-          for (size_t c = 0; c < kids[k].size(); ++c) mt.push_back((uint16_t)(kids[k][c] | (kid_ref[k][c] ? 0x8000u : 0u)));
+        for (uint32_t q = 0; q < fl.n; ++q) {
+          const uint32_t k = ordv[q];
+          for (size_t c = 0; c < kids[k].size(); ++c) mt.push_back((uint16_t)(newid[kids[k][c]] | (kid_ref[k][c] ? 0x8000u : 0u)));
+        }
         fl.mh.assign((size_t)4 * fl.n, 0u);  // (class words and norm groups follow once they are known)
-        for (uint32_t k = 0; k < fl.n; ++k) fl.mh[4 * k] = fl.hdr[k] | (label[b + idx[k]] != 0 ? 0x80000000u : 0u);
+        for (uint32_t q = 0; q < fl.n; ++q) fl.mh[4 * q] = fl.hdr[ordv[q]] | (label[b + idx[ordv[q]]] != 0 ? 0x80000000u : 0u);
         fl.m_front = (uint32_t)front;
       }
     }
@@ -1988,10 +2003,11 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         tab.insert(tab.end(), fl.mt.begin(), fl.mt.end());
         hdrs.insert(hdrs.end(), fl.mh.begin(), fl.mh.end());
         const FGroup& G = F->h_groups[l / 64];
-        for (uint32_t k = 0; k < fl.n; ++k) {  // rule, class word (rec_cls) and norm group of the node's header record
+        for (uint32_t q = 0; q < fl.n; ++q) {  // rule, class word (rec_cls) and norm group of the node's header record
+          const uint32_t k = fl.m_ord[q];
           const uint2_t hr = fl.ins[fl.hdr[k]];
           if (!(hr.x & F_AND)) continue;
-          uint32_t* w = &hdrs[hoff[l] + 4 * (size_t)k];
+          uint32_t* w = &hdrs[hoff[l] + 4 * (size_t)q];
           w[1] = hr.y;
           w[2] = rc_all[G.stream_base + (size_t)fl.hdr[k] * 64 + (l % 64)];
           w[3] = F->h_norm[hr.y];
@@ -2367,7 +2383,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   const bool multi = sweep2 && F->multi_ok && !(getenv("CARMEL_HIP_FOREST_MULTI") && atoi(getenv("CARMEL_HIP_FOREST_MULTI")) == 0);
   const uint64_t nf_slots = F->h_groups.size() * 64;
   auto fm_bytes = [](const carmel_hip_forests::Cls& c) {  // LDS of one forest in forest_sample_multi_kernel
-    return (size_t)c.m_n * 24 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
+    return (size_t)c.m_n * 16 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
   };
   const uint32_t stack_lds = 32u;
   if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH")) {
