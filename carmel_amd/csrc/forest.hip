@@ -1102,8 +1102,10 @@ struct FMultiArgs {
                             // kids[n_kids] (| 0x8000: back-reference)
   const uint32_t* hdr;      // per forest, per node: {row of its header in the lane's inside stream | bit 31 = AND, rule id,
                             // class word (ForestArgs::rec_cls), norm group}: four words per node
-  const uint64_t* tab_off;  // per lane slot: offset into tab (u16 words) / hdr (u32 words)
-  const uint64_t* hdr_off;
+  const uint4* slots;       // per lane slot, two words of 16 bytes: {tab offset (u16 words, a multiple of 8: the table is copied
+                            // 16 bytes at a time), hdr offset (u32 words)} as two 64-bit numbers, {sample offset (64 bit),
+                            // forest (0xffffffff: none), nodes | table words << 15}: everything the staging needs to address
+                            // its loads, in one round trip
   uint32_t lane_lo, lane_hi;            // the lane slots of this launch (a launch class)
   uint32_t max_tab, max_n, max_front;   // LDS per forest: table words, nodes, frontier entries
   int own_proposal;                     // the kernel computes the rules' proposal probabilities itself (forest_proposal_kernel
@@ -1121,13 +1123,16 @@ __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t&
   return x - v;
 }
 #define FM_EBIAS 2048
+#define FM_TQ 4  // 16-byte pieces of the forest's table per lane in the first round of loads (x FM_G lanes x 8 words)
+#define FM_SC 4  // class words of the previous sample per lane ...
+#define FM_HR 8  // header rows per lane ...
 __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double fm_lds[];
   const uint32_t sub = threadIdx.x / FM_G, li = threadIdx.x % FM_G;
   const unsigned long long tr0 = A.trace ? __builtin_readcyclecounter() : 0;
   unsigned long long tr1 = 0, tr2 = 0, tr3 = 0;
   const uint32_t slot = M.lane_lo + blockIdx.x * FM_FPW + sub;
-  const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;
+  const uint32_t forest = slot < M.lane_hi ? A.lane_forest[slot] : 0xffffffffu;  // (rides along with the descriptor's loads)
   const bool active = forest != 0xffffffffu;
   // this forest's stretch of LDS: mantissas (f64), exponents (i32), header words (u32: row of the node's header record | the
   // exponent of an AND node's proposal probability + FM_EBIAS, bits 16..30 | bit 31 = AND), table + two frontiers (u16)
@@ -1139,61 +1144,124 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
   unsigned short* tb = (unsigned short*)(hd + M.max_n);
   unsigned short* fr0 = tb + M.max_tab;
   unsigned short* fr1 = fr0 + M.max_front;
-  uint32_t n = 0, H = 0;
+  // ---- staging: three rounds of loads.  (1) the slot's descriptor; (2) the forest's tables (16 bytes a load), the length
+  // and the first FM_SC x FM_G class words of its previous sample, the header rows of its first FM_HR x FM_G nodes; (3) the
+  // snapshot counts of those rows' rules.  Forests with more nodes / longer samples continue in loops afterwards.
   const FGroup g = A.groups[active ? slot / 64 : M.lane_lo / 64];
   const uint32_t lane = slot % 64;
+  uint4 d0 = make_uint4(0, 0, 0, 0), d1 = make_uint4(0, 0, 0, 0);
   if (active) {
-    const unsigned short* __restrict__ src = M.tab + M.tab_off[slot];
-    n = src[0];
-    H = src[1];
-    const uint32_t words = 4u + (H + 1) + (n + 1) + src[2];
-    for (uint32_t k = li; k < words; k += FM_G) tb[k] = src[k];
-    if (M.own_proposal)
+    d0 = M.slots[2 * (size_t)slot];
+    d1 = M.slots[2 * (size_t)slot + 1];
+  }
+  const uint32_t n = d1.w & 0x7fffu, words = d1.w >> 15;
+  const unsigned short* __restrict__ src = M.tab + (((uint64_t)d0.y << 32) | d0.x);
+  const uint4* __restrict__ hs = (const uint4*)(M.hdr + (((uint64_t)d0.w << 32) | d0.z));
+  const uint32_t* __restrict__ sc = A.sample_cls + (((uint64_t)d1.y << 32) | d1.x);
+  double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
+  const bool own = M.own_proposal != 0;
+  uint32_t plen = 0;
+  uint32_t scq[FM_SC];
+  uint4 hq[FM_HR];
+  double sx[FM_HR], sn[FM_HR];
+  {
+    const uint4* __restrict__ s4 = (const uint4*)src;
+    uint4* t4 = (uint4*)tb;
+    const uint32_t w4 = (words + 7) / 8;
+    uint4 tq[FM_TQ];
+#pragma unroll
+    for (int q = 0; q < FM_TQ; ++q) tq[q] = li + q * FM_G < w4 ? s4[li + q * FM_G] : make_uint4(0, 0, 0, 0);
+    if (active && own) plen = A.old_len[forest];
+#pragma unroll
+    for (int q = 0; q < FM_SC; ++q) scq[q] = (active && own) ? sc[li + q * FM_G] : 0xffffffffu;  // (read past the sample: its capacity, or the padding)
+#pragma unroll
+    for (int q = 0; q < FM_HR; ++q) hq[q] = li + q * FM_G < n ? hs[li + q * FM_G] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < FM_TQ; ++q)
+      if (li + q * FM_G < w4) t4[li + q * FM_G] = tq[q];
+    for (uint32_t k = li + FM_TQ * FM_G; k < w4; k += FM_G) t4[k] = s4[k];  // (tables beyond FM_TQ x FM_G x 8 words)
+    if (own)
       for (uint32_t k = li; k < n; k += FM_G) ve[k] = 0;
+    // round three: what the rows' probabilities need from the snapshot (or the probabilities themselves)
+#pragma unroll
+    for (int q = 0; q < FM_HR; ++q) {
+      const uint4 h = hq[q];
+      sx[q] = 0.0;
+      sn[q] = 1.0;
+      if (h.x & 0x80000000u) {
+        if (!own)
+          sx[q] = recp0[(size_t)(h.x & 0x7fffffffu) * 64];
+        else if (h.w == F_NONORM)
+          sx[q] = A.p_prior[h.y];
+        else {
+          sx[q] = A.snap_x[h.y];
+          sn[q] = A.snap_norm[h.w];
+        }
+      }
+    }
   }
   __syncthreads();
-  if (active && M.own_proposal) {
+  if (active && own) {
     // how often the forest's previous sample uses each of its rule classes (low half) and norm-group classes (high half):
     // one pass over the sample's class words (forest_proposal_kernel scans them per rule); the exponents' rows hold the
     // counts until the inside pass writes them
-    const uint32_t* __restrict__ sc = A.sample_cls + A.sample_off[forest];
-    const uint32_t plen = A.old_len[forest];
-    for (uint32_t j = li; j < plen; j += FM_G) {
+#define FM_HIST(wd)                                                                                          \
+  if ((wd) != 0xffffffffu) { /* (0xffffffff: a rule outside the normalisation groups) */                    \
+    __hip_atomic_fetch_add(&ve[(wd) & 0xffffu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);          \
+    __hip_atomic_fetch_add(&ve[(wd) >> 16], 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);        \
+  }
+#pragma unroll
+    for (int q = 0; q < FM_SC; ++q)
+      if (li + q * FM_G < plen) FM_HIST(scq[q])
+    for (uint32_t j = li + FM_SC * FM_G; j < plen; j += FM_G) {
       const uint32_t wd = sc[j];
-      if (wd == 0xffffffffu) continue;  // (a rule outside the normalisation groups)
-      __hip_atomic_fetch_add(&ve[wd & 0xffffu], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add(&ve[wd >> 16], 0x10000, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      FM_HIST(wd)
     }
+#undef FM_HIST
   }
   __syncthreads();
+  const uint32_t H = active ? tb[1] : 0u;
   if (active) {
-    const uint4* __restrict__ hs = (const uint4*)(M.hdr + M.hdr_off[slot]);
-    double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
-    for (uint32_t k = li; k < n; k += FM_G) {
-      const uint4 h = hs[k];  // {header row | AND, rule, class word, norm group}
-      uint32_t hw = h.x;
+    // an AND node's row: its proposal probability -- forest_proposal_kernel's (count - own uses) / (norm sum - own uses of the
+    // group) -- as the mantissa where the node's value will be and the exponent in the header word (the exponents' rows
+    // still hold the histogram); the recount reads the sampled rules' probabilities from rec_p
+#define FM_ROW(k, hh, px, pn)                                                                                 \
+  {                                                                                                          \
+    uint32_t hw = (hh).x;                                                                                     \
+    if (hw & 0x80000000u) {                                                                                  \
+      double pr = (px);                                                                                       \
+      if (own) {                                                                                             \
+        if ((hh).w != F_NONORM) {                                                                             \
+          const uint32_t own_r = (uint32_t)ve[(hh).z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[(hh).z >> 16] >> 16; \
+          pr = ((px) - (double)own_r) / ((pn) - (double)own_n);                                              \
+        }                                                                                                    \
+        recp0[(size_t)(hw & 0x7fffffffu) * 64] = pr;                                                         \
+      }                                                                                                      \
+      int e;                                                                                                 \
+      vm[k] = frexp(pr, &e);                                                                                 \
+      hw |= (uint32_t)(e + FM_EBIAS) << 16;                                                                  \
+    }                                                                                                        \
+    hd[k] = hw;                                                                                              \
+  }
+#pragma unroll
+    for (int q = 0; q < FM_HR; ++q)
+      if (li + q * FM_G < n) FM_ROW(li + q * FM_G, hq[q], sx[q], sn[q])
+    for (uint32_t k = li + FM_HR * FM_G; k < n; k += FM_G) {  // (forests beyond FM_HR x FM_G nodes: two more rounds)
+      const uint4 h = hs[k];
+      double x = 0.0, nrm = 1.0;
       if (h.x & 0x80000000u) {
-        double pr;
-        if (!M.own_proposal)
-          pr = recp0[(size_t)(h.x & 0x7fffffffu) * 64];
+        if (!own)
+          x = recp0[(size_t)(h.x & 0x7fffffffu) * 64];
+        else if (h.w == F_NONORM)
+          x = A.p_prior[h.y];
         else {
-          if (h.w == F_NONORM)
-            pr = A.p_prior[h.y];
-          else {
-            // forest_proposal_kernel: (count - own uses) / (norm sum - own uses of the group)
-            const uint32_t own_r = (uint32_t)ve[h.z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[h.z >> 16] >> 16;
-            pr = (A.snap_x[h.y] - (double)own_r) / (A.snap_norm[h.w] - (double)own_n);
-          }
-          recp0[(size_t)(h.x & 0x7fffffffu) * 64] = pr;  // (the recount reads the sampled rules' probabilities)
+          x = A.snap_x[h.y];
+          nrm = A.snap_norm[h.w];
         }
-        // the inside pass starts an AND node from its probability: mantissa where the node's value will be, exponent in the
-        // header word (the exponents' rows still hold the histogram)
-        int e;
-        vm[k] = frexp(pr, &e);
-        hw |= (uint32_t)(e + FM_EBIAS) << 16;
       }
-      hd[k] = hw;
+      FM_ROW(k, h, x, nrm)
     }
+#undef FM_ROW
   }
   __syncthreads();
   if (A.trace) tr1 = __builtin_readcyclecounter();
@@ -1637,7 +1705,7 @@ struct carmel_hip_forests {
   bool multi_ok = false;
   DevBuf<uint16_t> mt_tab;
   DevBuf<uint32_t> mt_hdr;
-  DevBuf<uint64_t> mt_tab_off, mt_hdr_off;
+  DevBuf<uint32_t> mt_slots;  // FMultiArgs::slots
   std::vector<FGroup> h_groups;
   struct Cls {
     uint32_t first, count, max_nodes;
@@ -1903,7 +1971,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         for (uint32_t l = 0; l < G.n_lanes; ++l) {
           const Flat& fl = flat[ord[G.lane_base + l]];
           c.max_kids = std::max<uint32_t>(c.max_kids, (uint32_t)(fl.ins.size() - fl.n));
-          c.m_tab = std::max<uint32_t>(c.m_tab, (uint32_t)fl.mt.size());
+          c.m_tab = std::max<uint32_t>(c.m_tab, (uint32_t)((fl.mt.size() + 7) / 8 * 8));  // (copied 16 bytes at a time)
           c.m_n = std::max(c.m_n, fl.n);
           c.m_front = std::max(c.m_front, fl.m_front);
         }
@@ -1993,6 +2061,12 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       if (flat[f].mt.empty()) F->multi_ok = false;
     if (F->multi_ok) {
       std::vector<uint64_t> toff(ng * 64, 0), hoff(ng * 64, 0);
+      std::vector<uint32_t> slots(ng * 64 * 8, 0u);
+      for (size_t l = 0; l < ng * 64; ++l) slots[8 * l + 6] = 0xffffffffu;
+      // (the samples' offsets: capacity = size of the largest derivation of the forest, as below)
+      std::vector<uint64_t> so_all(n_forests + 1, 0);
+      for (uint64_t f = 0; f < n_forests; ++f) so_all[f + 1] = so_all[f] + flat[f].max_deriv + 2;
+      auto F_sample_off_of = [&](uint32_t f) { return so_all[f]; };
       std::vector<uint16_t> tab;
       std::vector<uint32_t> hdrs;
       for (size_t l = 0; l < ng * 64; ++l) {
@@ -2001,6 +2075,19 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
         toff[l] = tab.size();
         hoff[l] = hdrs.size();
         tab.insert(tab.end(), fl.mt.begin(), fl.mt.end());
+        tab.resize((tab.size() + 7) / 8 * 8, 0);  // (copied 16 bytes at a time)
+        {
+          const uint64_t so = F_sample_off_of(lane_forest[l]);
+          uint32_t* d = &slots[8 * l];
+          d[0] = (uint32_t)toff[l];
+          d[1] = (uint32_t)(toff[l] >> 32);
+          d[2] = (uint32_t)hoff[l];
+          d[3] = (uint32_t)(hoff[l] >> 32);
+          d[4] = (uint32_t)so;
+          d[5] = (uint32_t)(so >> 32);
+          d[6] = lane_forest[l];
+          d[7] = fl.n | ((uint32_t)fl.mt.size() << 15);
+        }
         hdrs.insert(hdrs.end(), fl.mh.begin(), fl.mh.end());
         const FGroup& G = F->h_groups[l / 64];
         for (uint32_t q = 0; q < fl.n; ++q) {  // rule, class word (rec_cls) and norm group of the node's header record
@@ -2015,8 +2102,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       }
       HIPCHK(F->mt_tab.upload(tab, s));
       HIPCHK(F->mt_hdr.upload(hdrs, s));
-      HIPCHK(F->mt_tab_off.upload(toff, s));
-      HIPCHK(F->mt_hdr_off.upload(hoff, s));
+      HIPCHK(F->mt_slots.upload(slots, s));
       HIPCHK(hipStreamSynchronize(s));
     }
   }
@@ -2354,7 +2440,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     // the classes' recounts beside the classes still sampling (false: one recount after all, the earlier form)
     split_recount = true;
     if (split_recount) HIPCHK(F->normsum2.alloc(ng));
-    HIPCHK(F->sample_cls.alloc(F->h_sample_off.back()));
+    HIPCHK(F->sample_cls.alloc(F->h_sample_off.back() + 64));  // (+ the sampler's staging reads a fixed number of words ahead)
     HIPCHK(F->rec_logp.alloc(F->stream_total));
     HIPCHK(F->rec_p.alloc(F->stream_total));
     HIPCHK(hipMemsetAsync(F->rec_p.p, 0, F->rec_p.bytes(), s));  // the sample kernel reads every slot of its chunks
@@ -2480,8 +2566,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             FMultiArgs MA;
             MA.tab = F->mt_tab.p;
             MA.hdr = F->mt_hdr.p;
-            MA.tab_off = F->mt_tab_off.p;
-            MA.hdr_off = F->mt_hdr_off.p;
+            MA.slots = (const uint4*)F->mt_slots.p;
             MA.lane_lo = c.first * 64u;
             MA.lane_hi = (uint32_t)std::min<uint64_t>((uint64_t)(c.first + c.count) * 64u, nf_slots);
             MA.max_tab = c.m_tab;
