@@ -1126,6 +1126,7 @@ __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t&
 #define FM_TQ 4  // 16-byte pieces of the forest's table per lane in the first round of loads (x FM_G lanes x 8 words)
 #define FM_SC 4  // class words of the previous sample per lane ...
 #define FM_HR 8  // header rows per lane ...
+#define FM_KP 4  // children of a node whose values the inside pass requests before it folds them
 __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double fm_lds[];
   const uint32_t sub = threadIdx.x / FM_G, li = threadIdx.x % FM_G;
@@ -1276,40 +1277,69 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     if (h < H)
       for (uint32_t node = lvl[h] + li; node < lvl[h + 1]; node += FM_G) {  // (the nodes of a height: a range of ids)
         const uint32_t hw = hd[node], k0 = koff[node], k1 = koff[node + 1];
+        // the first FM_KP children's values are requested together, before the fold (which is a chain): one LDS round trip
+        // for the ids, one for the values, instead of two per child
+        uint32_t cq[FM_KP];
+        double mq[FM_KP];
+        int eq[FM_KP];
+#pragma unroll
+        for (int i = 0; i < FM_KP; ++i) cq[i] = k0 + i < k1 ? (uint32_t)(kids[k0 + i] & 0x7fffu) : node;
+#pragma unroll
+        for (int i = 0; i < FM_KP; ++i) {
+          mq[i] = vm[cq[i]];
+          eq[i] = ve[cq[i]];
+        }
         double m;
         int e;
         if (hw & 0x80000000u) {  // AND: its rule's proposal probability times its children
           m = vm[node];
           e = (int)((hw >> 16) & 0x7fffu) - FM_EBIAS;
-          for (uint32_t k = k0; k < k1; ++k) {
+#define FM_AND_FOLD(cm, ce)   \
+  {                           \
+    int t;                    \
+    m = frexp(m * (cm), &t);  \
+    e += (ce) + t;            \
+  }
+#pragma unroll
+          for (int i = 0; i < FM_KP; ++i)
+            if (k0 + i < k1) FM_AND_FOLD(mq[i], eq[i])
+          for (uint32_t k = k0 + FM_KP; k < k1; ++k) {
             const uint32_t c = kids[k] & 0x7fffu;
-            int t;
-            m = frexp(m * vm[c], &t);
-            e += ve[c] + t;
+            FM_AND_FOLD(vm[c], ve[c])
           }
+#undef FM_AND_FOLD
         } else {  // OR: the sum of its children, aligned to the larger exponent
           m = 0.0;
           e = 0;
-          for (uint32_t k = k0; k < k1; ++k) {
+#define FM_OR_FOLD(cm_, ce_)                      \
+  {                                               \
+    const double cm = (cm_);                      \
+    const int ce = (ce_);                         \
+    if (cm != 0.0) {                              \
+      if (m == 0.0) {                             \
+        m = cm;                                   \
+        e = ce;                                   \
+      } else {                                    \
+        const int dd = ce - e;                    \
+        int t;                                    \
+        if (dd <= 0)                              \
+          m = frexp(m + ldexp(cm, dd), &t);       \
+        else {                                    \
+          m = frexp(ldexp(m, -dd) + cm, &t);      \
+          e = ce;                                 \
+        }                                         \
+        e += t;                                   \
+      }                                           \
+    }                                             \
+  }
+#pragma unroll
+          for (int i = 0; i < FM_KP; ++i)
+            if (k0 + i < k1) FM_OR_FOLD(mq[i], eq[i])
+          for (uint32_t k = k0 + FM_KP; k < k1; ++k) {
             const uint32_t c = kids[k] & 0x7fffu;
-            const double cm = vm[c];
-            const int ce = ve[c];
-            if (cm == 0.0) continue;
-            if (m == 0.0) {
-              m = cm;
-              e = ce;
-            } else {
-              const int dd = ce - e;
-              int t;
-              if (dd <= 0)
-                m = frexp(m + ldexp(cm, dd), &t);
-              else {
-                m = frexp(ldexp(m, -dd) + cm, &t);
-                e = ce;
-              }
-              e += t;
-            }
+            FM_OR_FOLD(vm[c], ve[c])
           }
+#undef FM_OR_FOLD
         }
         vm[node] = m;
         ve[node] = e;
@@ -1343,13 +1373,32 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
           push = nch;
         } else if (nch) {
           // the reference's serial subtraction: the first child whose share takes the choice below zero, or the last
+          // (the first FM_KP children's values requested together, as in the inside pass; the same differences in the same order)
+          uint32_t cq[FM_KP];
+          double mq[FM_KP];
+          int eq[FM_KP];
+#pragma unroll
+          for (int i = 0; i < FM_KP; ++i) cq[i] = (uint32_t)i < nch ? (uint32_t)(kids[k0 + i] & 0x7fffu) : node;
+#pragma unroll
+          for (int i = 0; i < FM_KP; ++i) {
+            mq[i] = vm[cq[i]];
+            eq[i] = ve[cq[i]];
+          }
           const int ne = ve[node];
           double choice = gibbs_uniform(A.seed, A.iter, forest, visited + idx) * vm[node];
-          for (uint32_t k = 0;; ++k) {
+          bool done = false;
+#pragma unroll
+          for (int i = 0; i < FM_KP; ++i)
+            if (!done && (uint32_t)i < nch) {
+              pick = (uint32_t)i;
+              choice -= ldexp(mq[i], eq[i] - ne);
+              done = choice < 0 || (uint32_t)i + 1 == nch;
+            }
+          for (uint32_t k = FM_KP; !done; ++k) {
             pick = k;
             const uint32_t c = kids[k0 + k] & 0x7fffu;
             choice -= ldexp(vm[c], ve[c] - ne);
-            if (choice < 0 || k + 1 == nch) break;
+            done = choice < 0 || k + 1 == nch;
           }
           push = 1;
         }
