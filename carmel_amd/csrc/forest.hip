@@ -1746,7 +1746,8 @@ struct carmel_hip_forests {
   uint64_t n_forests = 0, n_groups = 0;
   uint32_t n_rules = 0, max_nodes = 0, max_sample = 0;
   uint64_t node_total = 0, stream_total = 0;
-  static const int N_SIDE = 4;
+  static const int N_SIDE = 3;  // + the caller's stream (carmel_hip_forests_create: how they come by hardware queues of their own)
+  std::vector<int> class_side;  // per launch class: -1 = the caller's stream, k = side[k] (dealt by load, largest class first)
   hipStream_t side[N_SIDE] = {};  // launch classes of one sweep run side by side
   hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {};
   bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
@@ -1801,6 +1802,20 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
   F->n_rules = n_rules;
   F->n_groups = n_groups;
   HIPCHK(hipStreamCreateWithFlags(&F->stream, hipStreamNonBlocking));
+  // (the side streams right behind it: four streams created in a row land on four different hardware queues)
+  HIPCHK(hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming));
+  // The side streams belong to the HIGH priority class -- not for the priority: the runtime keeps a pool of hardware queues per
+  // priority class (four each), and streams of the default class share theirs with every other stream of the process (torch's,
+  // a trainer's): in bench.py's full run two launch classes landed on one queue and ran one after the other, 0.41 ms per sweep
+  // against 0.33 on its own.  In a class of their own the three get a queue each: 0.33 in both places.
+  {
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
+      HIPCHK(hipStreamCreateWithPriority(&F->side[k], hipStreamNonBlocking, prio_hi));
+      HIPCHK(hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming));
+    }
+  }
   hipStream_t s = F->stream;
   // ---- per forest: post-order over non-reference nodes, streams ----
   struct Flat {
@@ -2205,13 +2220,7 @@ int carmel_hip_forests_destroy(carmel_hip_forests* F) {
 // side streams: the launch classes of one pass run side by side (each ends with a few slow waves; no class fills the
 // chip).  with_side(F, s, i) = the stream for class i after forking from s; join_side(F, s) folds them back.
 static hipError_t ensure_side(carmel_hip_forests* F) {
-  if (F->ev_fork) return hipSuccess;
-  hipError_t e = hipEventCreateWithFlags(&F->ev_fork, hipEventDisableTiming);
-  for (int k = 0; k < carmel_hip_forests::N_SIDE && e == hipSuccess; ++k) {
-    e = hipStreamCreateWithFlags(&F->side[k], hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming);
-  }
-  return e;
+  return F->ev_fork ? hipSuccess : hipErrorNotInitialized;  // (created with the forests, carmel_hip_forests_create)
 }
 static int n_side_for(const carmel_hip_forests* F) {
   return F->classes.size() < 2 ? 0 : (int)std::min<size_t>(carmel_hip_forests::N_SIDE, F->classes.size() - 1);
@@ -2225,7 +2234,23 @@ static hipError_t fork_side(carmel_hip_forests* F, hipStream_t s) {
 }
 static hipStream_t class_stream(carmel_hip_forests* F, hipStream_t s, size_t ci) {
   const int n = n_side_for(F);
-  return (ci == 0 || !n) ? s : F->side[(ci - 1) % n];
+  if (!n) return s;
+  if (F->class_side.size() != F->classes.size()) {
+    // longest class first onto the least loaded stream (load = lane groups x rows of the longest lane: the records a class reads)
+    std::vector<size_t> order(F->classes.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    auto cost = [&](size_t i) { return (double)F->classes[i].count * (double)F->classes[i].maxlen; };
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(a) > cost(b); });
+    std::vector<double> load((size_t)n + 1, 0.0);
+    F->class_side.assign(F->classes.size(), -1);
+    for (size_t i : order) {
+      const size_t k = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+      F->class_side[i] = (int)k - 1;
+      load[k] += cost(i);
+    }
+  }
+  const int k = F->class_side[ci];
+  return k < 0 ? s : F->side[k];
 }
 static hipError_t join_side(carmel_hip_forests* F, hipStream_t s) {
   hipError_t e = hipSuccess;
