@@ -92,6 +92,18 @@ def test_sharded_exchange_is_the_all_reduce_bit_for_bit(tmp_path, world):
     np.testing.assert_allclose(plain[nw:nw + 12], one[nw:nw + 12], rtol=1e-10)
 
 
+def test_sharded_exchange_over_run_length_indices(tmp_path, monkeypatch):
+    """the chunked bucket / tile passes of the sharded exchange with the transposition's run-length source indices forced on
+    (CARMEL_HIP_TRANS_RUNS=1: the default on config-4-sized shards, which no test corpus reaches): bit for bit the per-item
+    indices' weights, two ranks"""
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", mode)
+        runs[mode] = _run(2, "synth-big", tmp_path, "rl" + mode, extra=["--rccl", _plugin("rl" + mode), "--plan", "--check-counts"])
+        assert runs[mode][-1] == 1.0
+    np.testing.assert_array_equal(runs["0"], runs["1"])
+
+
 def test_sharded_exchange_with_one_rank_is_the_plain_trainer(tmp_path):
     """world 1 over RCCL (the collectives run, nothing travels): the sharded M-step over block ranges and the chunked bucket
     passes are the plain ones, so the run must equal the plain trainer bit for bit"""
