@@ -781,6 +781,14 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
   T.br_rel = t->br_rel.p;
   T.br_src = t->br_src.p;
   T.use_runs = t->use_runs ? 1u : 0u;
+  {
+    // which pass of a direction does the random access: the first one (a scattered write nobody waits for) where a
+    // (tile, bucket) cell holds a run of items -- the corpora that get run-length indices --, the second one (a gather)
+    // where cells hold an item or two and a scattered write would touch a line per item.  CARMEL_HIP_TRANS_SCATTER is the
+    // A/B switch (bit-identical results).
+    const char* e = getenv("CARMEL_HIP_TRANS_SCATTER");
+    T.scatter = e ? (uint32_t)atoi(e) : (t->use_runs ? 3u : 0u);
+  }
   T.x = t->t_x.p;
   T.xc = t->t_xc.p;
   T.logw = t->arc_logw.p;

@@ -1091,9 +1091,20 @@ __device__ __forceinline__ uint32_t run_source(const RunLds& R, uint32_t i) {
 }
 // weights, pass 1: one workgroup per arc bucket.  The bucket's weights go to LDS (coalesced read), its items leave in
 // position-sorted order (coalesced write), picking their weight out of LDS.
+// SC (TransArgs::scatter bit 0): the items leave for their TILE-major place instead (one contiguous run per tile: a
+// scattered write that nobody waits for), and pass 2 reads its tile's items as one sequential stretch -- the dependent
+// round trip "index, then gather" moves from the reading pass, which waits for it, to the writing pass, which does not.
+template <bool SC, bool RL>
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const TransBucket B = T.buckets[T.bucket_first + blockIdx.x];
+  const RunLds R = run_lds(lds + TRANS_BUCKET);
+  uint32_t bloc = blockIdx.x;
+  if (SC) {
+    bloc = xcd_chunked(blockIdx.x, T.bucket_count);  // the grid is rounded up to a multiple of 8
+    if (bloc >= T.bucket_count) return;
+  }
+  const uint32_t bucket = T.bucket_first + bloc;
+  const TransBucket B = T.buckets[bucket];
   // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
   // 16384 items): one dependent round trip per phase instead of one per iteration
   double w[TRANS_KB];
@@ -1102,19 +1113,30 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
     const uint32_t a = threadIdx.x + k * 1024;
     w[k] = a < B.n_arcs ? T.logw[B.arc_lo + a] : 0.0;
   }
-#pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) lds[threadIdx.x + k * 1024] = w[k];
-  __syncthreads();
   uint16_t ia[TRANS_KB];
+  uint32_t dst[TRANS_KB];
 #pragma unroll
   for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     ia[k] = j < B.n_items ? T.b_arc[B.item_base + j] : (uint16_t)0;
+    if (SC && !RL) dst[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
   }
+#pragma unroll
+  for (int k = 0; k < TRANS_KB; ++k) lds[threadIdx.x + k * 1024] = w[k];
+  if (SC && RL) {
+    const uint32_t r0 = T.br_off[bucket];
+    run_stage(R, T.br_rel + r0, T.br_src + r0, T.br_off[bucket + 1] - r0);
+  } else
+    __syncthreads();
 #pragma unroll
   for (int k = 0; k < TRANS_KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
-    if (j < B.n_items) T.x[B.item_base + j] = lds[ia[k]];
+    if (j < B.n_items) {
+      if (SC)
+        T.x[RL ? run_source(R, j) : dst[k]] = lds[ia[k]];
+      else
+        T.x[B.item_base + j] = lds[ia[k]];
+    }
   }
 }
 // weights, pass 2: one workgroup per tile of positions.  The tile's items arrive as runs (one per bucket), are placed
@@ -1125,7 +1147,8 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
 #ifndef TRANS_WB_WAVES
 #define TRANS_WB_WAVES 4
 #endif
-template <bool RL>
+// SQ: pass 1 scattered (see trans_w_bucket_kernel<true, ..>): the tile's items are x[tile_base .. ) in item order.
+template <bool RL, bool SQ>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE_WAVES, TRANS_TILE_WAVES))) void trans_w_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const RunLds R = run_lds(lds + TRANS_TILE);
@@ -1137,7 +1160,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) lds[threadIdx.x + k * 1024] = 0.0;
-  if (RL) {
+  if (RL && !SQ) {
     const uint32_t r0 = T.tr_off[tile];
     run_stage(R, T.tr_rel + r0, T.tr_src + r0, T.tr_off[tile + 1] - r0);
   } else
@@ -1150,14 +1173,22 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
-    if (RL)
+    if (SQ)
+      src[k] = 0u;
+    else if (RL)
       src[k] = i < ni ? run_source(R, i) : 0u;
     else
       src[k] = i < ni ? T.t_src[i0 + i] : 0u;
     pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_KT; ++k) v[k] = T.x[src[k]];
+  for (int k = 0; k < TRANS_KT; ++k) {
+    if (SQ) {
+      const uint32_t i = threadIdx.x + k * 1024;
+      v[k] = i < ni ? T.x[i0 + i] : 0.0;
+    } else
+      v[k] = T.x[src[k]];
+  }
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k)
     if (threadIdx.x + k * 1024 < ni) lds[pos[k]] = v[k];
@@ -1168,35 +1199,56 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
     if (q < np) T.wcache[p0 + q] = lds[q];
   }
 }
-// counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in bucket-major runs.
+// counts, pass 1: one workgroup per tile: posteriors to LDS (coalesced), items out in item order (tile-major).
+// SC (TransArgs::scatter bit 1): items out to their BUCKET-major place (one contiguous run per bucket), pass 2 reads a
+// bucket's items as one sequential stretch.
+template <bool SC, bool RL>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE_WAVES, TRANS_TILE_WAVES))) void trans_c_tile_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const uint32_t tile = T.tile_first + blockIdx.x;
+  const RunLds R = run_lds(lds + TRANS_TILE);
+  uint32_t tloc = blockIdx.x;
+  if (SC) {
+    tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
+    if (tloc >= T.tile_count) return;
+  }
+  const uint32_t tile = T.tile_first + tloc;
   const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
   const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
   double v[TRANS_KT];
   uint16_t pos[TRANS_KT];
+  uint32_t dst[TRANS_KT];
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t q = threadIdx.x + k * 1024;
     v[k] = q < np ? T.post[p0 + q] : 0.0;
     pos[k] = q < ni ? T.t_pos[i0 + q] : (uint16_t)0;
+    if (SC && !RL) dst[k] = q < ni ? T.t_src[i0 + q] : 0u;
   }
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) lds[threadIdx.x + k * 1024] = v[k];
-  __syncthreads();
+  if (SC && RL) {
+    const uint32_t r0 = T.tr_off[tile];
+    run_stage(R, T.tr_rel + r0, T.tr_src + r0, T.tr_off[tile + 1] - r0);
+  } else
+    __syncthreads();
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) {
     const uint32_t i = threadIdx.x + k * 1024;
-    if (i < ni) T.xc[i0 + i] = lds[pos[k]];
+    if (i < ni) {
+      if (SC)
+        T.xc[RL ? run_source(R, i) : dst[k]] = lds[pos[k]];
+      else
+        T.xc[i0 + i] = lds[pos[k]];
+    }
   }
 }
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
 // then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
 // that is a piece of a split arc reduces the piece and adds it atomically.
-template <bool RL>
+// SQ: pass 1 scattered (trans_c_tile_kernel<true, ..>): the bucket's items are xc[item_base .. ) in item order.
+template <bool RL, bool SQ>
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const RunLds R = run_lds(lds + TRANS_BUCKET);
@@ -1222,21 +1274,29 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     uint32_t src[TRANS_KB];
     uint16_t rk[TRANS_KB];
     double v[TRANS_KB];
-    if (RL) {
+    if (RL && !SQ) {
       const uint32_t r0 = T.br_off[bucket];
       run_stage(R, T.br_rel + r0, T.br_src + r0, T.br_off[bucket + 1] - r0);
     }
 #pragma unroll
     for (int k = 0; k < TRANS_KB; ++k) {
       const uint32_t j = threadIdx.x + k * 1024;
-      if (RL)
+      if (SQ)
+        src[k] = 0u;
+      else if (RL)
         src[k] = j < B.n_items ? run_source(R, j) : 0u;
       else
         src[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_KB; ++k) v[k] = T.xc[src[k]];
+    for (int k = 0; k < TRANS_KB; ++k) {
+      if (SQ) {
+        const uint32_t j = threadIdx.x + k * 1024;
+        v[k] = j < B.n_items ? T.xc[B.item_base + j] : 0.0;
+      } else
+        v[k] = T.xc[src[k]];
+    }
 #pragma unroll
     for (int k = 0; k < TRANS_KB; ++k)
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
@@ -1259,7 +1319,9 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     return;
   }
   // one thread per arc; arcs with more than 32 items are left to whole waves afterwards (fixed summation order
-  // either way)
+  // either way).  (A thread's 16 arcs advancing together, one item of each per step -- 16 independent LDS reads per
+  // step instead of a chain per arc -- was measured 50 % slower on config 4, 86 -> 132 us: the loop is not what the
+  // kernel waits for, and the 48 extra registers cost more than the chains.)
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
 #pragma unroll
@@ -1392,17 +1454,24 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
   return hipGetLastError();
 }
 
+#define TRANS_SET_LDS(K, BYTES) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
 static void trans_lds_attr() {
   static bool done = false;
   if (done) return;
   const int lds = (int)(TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) * 8;
   const int lds_rl = lds + TRANS_RUN_CAP * 6;
-  (void)hipFuncSetAttribute((const void*)trans_w_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_w_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
-  (void)hipFuncSetAttribute((const void*)trans_c_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  (void)hipFuncSetAttribute((const void*)trans_c_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_rl);
+  TRANS_SET_LDS((trans_w_bucket_kernel<false, false>), lds);
+  TRANS_SET_LDS((trans_w_bucket_kernel<true, false>), lds);
+  TRANS_SET_LDS((trans_w_bucket_kernel<true, true>), lds_rl);
+  TRANS_SET_LDS((trans_w_tile_kernel<false, false>), lds);
+  TRANS_SET_LDS((trans_w_tile_kernel<true, false>), lds_rl);
+  TRANS_SET_LDS((trans_w_tile_kernel<false, true>), lds);
+  TRANS_SET_LDS((trans_c_tile_kernel<false, false>), lds);
+  TRANS_SET_LDS((trans_c_tile_kernel<true, false>), lds);
+  TRANS_SET_LDS((trans_c_tile_kernel<true, true>), lds_rl);
+  TRANS_SET_LDS((trans_c_bucket_kernel<false, false>), lds);
+  TRANS_SET_LDS((trans_c_bucket_kernel<true, false>), lds_rl);
+  TRANS_SET_LDS((trans_c_bucket_kernel<false, true>), lds);
   done = true;
 }
 hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint32_t count, hipStream_t stream) {
@@ -1411,7 +1480,13 @@ hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint
   TransArgs T = T0;
   T.bucket_first = first;
   T.bucket_count = count;
-  hipLaunchKernelGGL(trans_w_bucket_kernel, dim3(count), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  const dim3 g8((count + 7) / 8 * 8);
+  if (!(T.scatter & 1u))
+    hipLaunchKernelGGL((trans_w_bucket_kernel<false, false>), dim3(count), dim3(1024), TRANS_BUCKET * 8, stream, T);
+  else if (T.use_runs)
+    hipLaunchKernelGGL((trans_w_bucket_kernel<true, true>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+  else
+    hipLaunchKernelGGL((trans_w_bucket_kernel<true, false>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream) { return launch_trans_w_bucket_range(T, 0, T.n_buckets, stream); }
@@ -1421,10 +1496,13 @@ hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   TransArgs T = T0;
   T.tile_first = tile_first;
   T.tile_count = tile_count;
-  if (T.use_runs)
-    hipLaunchKernelGGL(trans_w_tile_kernel<true>, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
+  const dim3 g8((tile_count + 7) / 8 * 8);
+  if (T.scatter & 1u)
+    hipLaunchKernelGGL((trans_w_tile_kernel<false, true>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
+  else if (T.use_runs)
+    hipLaunchKernelGGL((trans_w_tile_kernel<true, false>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
   else
-    hipLaunchKernelGGL(trans_w_tile_kernel<false>, dim3((tile_count + 7) / 8 * 8), dim3(1024), TRANS_TILE * 8, stream, T);
+    hipLaunchKernelGGL((trans_w_tile_kernel<false, false>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32_t tile_count, hipStream_t stream) {
@@ -1433,7 +1511,13 @@ hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   TransArgs T = T0;
   T.tile_first = tile_first;
   T.tile_count = tile_count;
-  hipLaunchKernelGGL(trans_c_tile_kernel, dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
+  const dim3 g8((tile_count + 7) / 8 * 8);
+  if (!(T.scatter & 2u))
+    hipLaunchKernelGGL((trans_c_tile_kernel<false, false>), dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
+  else if (T.use_runs)
+    hipLaunchKernelGGL((trans_c_tile_kernel<true, true>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
+  else
+    hipLaunchKernelGGL((trans_c_tile_kernel<true, false>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream) {
@@ -1446,10 +1530,13 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T0, uint32_t first, uint
   TransArgs T = T0;
   T.bucket_first = first;
   T.bucket_count = count;
-  if (T.use_runs)
-    hipLaunchKernelGGL(trans_c_bucket_kernel<true>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+  const dim3 g8((count + 7) / 8 * 8);
+  if (T.scatter & 2u)
+    hipLaunchKernelGGL((trans_c_bucket_kernel<false, true>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
+  else if (T.use_runs)
+    hipLaunchKernelGGL((trans_c_bucket_kernel<true, false>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
   else
-    hipLaunchKernelGGL(trans_c_bucket_kernel<false>, dim3((count + 7) / 8 * 8), dim3(1024), TRANS_BUCKET * 8, stream, T);
+    hipLaunchKernelGGL((trans_c_bucket_kernel<false, false>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
 }
 hipError_t launch_trans_c_bucket(const TransArgs& T, const uint32_t* split_arcs, uint32_t n_split, hipStream_t stream) {

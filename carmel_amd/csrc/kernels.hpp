@@ -104,6 +104,9 @@ struct TransArgs {
   const uint16_t* br_rel;
   const uint32_t* br_src;
   uint32_t use_runs;        // every tile and bucket has at most TRANS_RUN_CAP runs (they are staged in LDS)
+  uint32_t scatter;         // bit 0 (weights) / bit 1 (counts): the first pass of that direction writes its items where the
+                            // second pass reads them as one sequential stretch (x tile-major / xc bucket-major), instead of
+                            // writing sequentially and leaving the gather to the second pass
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
   uint32_t bucket_first, bucket_count;  // the bucket range of this launch of a bucket pass (arc-range chunks of the exchange)
 };

@@ -380,6 +380,34 @@ def test_run_length_transposition_indices_are_the_per_item_ones(name, n_pairs, m
         assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0)
 
 
+@pytest.mark.parametrize("name,n_pairs", [("c2", None), ("c4", 300000), ("c4a", 40000)])
+def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n_pairs, monkeypatch):
+    """TransArgs::scatter: either direction of the blocked transposition may do its random access in the FIRST pass (a
+    scattered write of one run per tile / bucket) and read sequentially in the second, instead of writing sequentially
+    and gathering.  Same items, same per-arc summation order: counts and ln p bit for bit, with per-item and with
+    run-length indices"""
+    w, c = synth.make_config(name, n_pairs=n_pairs)
+    out = {}
+    for runs in ("0", "1"):
+        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", runs)
+        for mode in ("0", "1", "2", "3"):
+            monkeypatch.setenv("CARMEL_HIP_TRANS_SCATTER", mode)
+            fb = _fb(w, c)
+            lp, _ = fb.estimate(per_pair=True)
+            res = (lp, fb.pair_logprob.copy(), fb.counts().copy())
+            fb.maximize(1.0)
+            lp2, _ = fb.estimate()
+            out[runs, mode] = res + (lp2, fb.counts().copy())
+            fb.close()
+    a = out["0", "0"]
+    for key, b in out.items():
+        assert a[0] == b[0] and a[3] == b[3], key
+        assert np.array_equal(a[1], b[1]), key
+        # (the one atomic add per piece of a split hub arc aside)
+        for x, y in ((a[2], b[2]), (a[4], b[4])):
+            assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0), key
+
+
 def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
     texts = [open(os.path.join(golden_dir, n)).read() for n in names]
     oc = oracle.OracleCascade(texts)
