@@ -36,7 +36,7 @@ SYMBOLS = [
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
     "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_exchange_plan",
-    "carmel_hip_exchange_info", "carmel_hip_exchange_measure", "carmel_hip_exchange_clear", "carmel_hip_set_layout_policy",
+    "carmel_hip_exchange_info", "carmel_hip_exchange_measure", "carmel_hip_exchange_clear", "carmel_hip_set_layout_policy", "carmel_hip_set_matrix_fb",
 ]
 
 
@@ -106,6 +106,7 @@ def _load():
     lib.carmel_hip_exchange_measure.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
     lib.carmel_hip_exchange_clear.argtypes = [vp]
     lib.carmel_hip_set_layout_policy.argtypes = [vp, C.c_int]
+    lib.carmel_hip_set_matrix_fb.argtypes = [vp, C.c_int]
     lib.carmel_hip_comm_rank.argtypes = [vp]
     lib.carmel_hip_comm_world.argtypes = [vp]
     lib.carmel_hip_allreduce_counts.argtypes = [vp, vp]

@@ -136,6 +136,8 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (!t) return CARMEL_HIP_OK;
   (void)hipSetDevice(t->device);
   if (t->stream) (void)hipStreamSynchronize(t->stream);
+  if (t->matrix) matrix_release(t->matrix);
+  t->matrix = nullptr;
   if (t->ev0) (void)hipEventDestroy(t->ev0);
   if (t->ev1) (void)hipEventDestroy(t->ev1);
   if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
@@ -188,6 +190,13 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
   HIPCHK(hipSetDevice(t->device));
   if (t->xplan) exchange_drop(t);  // the plan follows the lattices' transposition tables: plan again after a rebuild
+  t->build_prune = prune;
+  t->build_threads = host_threads;
+  if (t->matrix) {  // its tables follow the corpus: carmel_hip_set_matrix_fb again after a rebuild
+    HIPCHK(hipStreamSynchronize(t->stream));
+    matrix_release(t->matrix);
+    t->matrix = nullptr;
+  }
   {
     // one-tape models never store their lattices (unrolled.hpp)
     int rc = unrolled_try_build(t, host_threads, has_derivation, stats);
@@ -811,6 +820,15 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   if (t->cascade)  // cascade.update(): composed weights from the chains
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
+  if (t->matrix) {  // carmel --matrix-fb: no lattice is swept
+    if (timed) HIPCHK(hipEventRecord(t->ev0, s));
+    int rc = matrix_estimate(t, t->matrix, s);
+    if (rc) return rc;
+    HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
+                          t->counts_ptr() + t->w.n_arcs, s));
+    if (timed) HIPCHK(hipEventRecord(t->ev1, s));
+    return CARMEL_HIP_OK;
+  }
   if (t->unrolled) {
     if (timed) HIPCHK(hipEventRecord(t->ev0, s));
     int rc = unrolled_estimate(t, s);
@@ -1044,6 +1062,29 @@ int carmel_hip_set_layout_policy(carmel_hip_trainer* t, int allow_unrolled) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   t->allow_unrolled = allow_unrolled != 0;
   return CARMEL_HIP_OK;
+}
+int carmel_hip_set_matrix_fb(carmel_hip_trainer* t, int on) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  if (t->matrix) {
+    HIPCHK(hipStreamSynchronize(t->stream));
+    matrix_release(t->matrix);
+    t->matrix = nullptr;
+  }
+  if (!on) return CARMEL_HIP_OK;
+  if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_set_matrix_fb: build_lattices first (it finds the pairs without a derivation)");
+  if (t->xplan) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_set_matrix_fb: drop the exchange plan first (the matrix E-step keeps the one all-reduce)");
+  if (t->unrolled) {
+    // the unrolled / dense sweep of a one-tape cascade keeps its counts per parameter slot; the matrix walk produces them
+    // per composed arc, as explicit lattices do: rebuild with explicit lattices so that maximize / save_best / get_counts
+    // read the layout they are given
+    const bool keep = t->allow_unrolled;
+    t->allow_unrolled = false;
+    const int rc = carmel_hip_build_lattices(t, t->build_prune, t->build_threads, nullptr, nullptr);
+    t->allow_unrolled = keep;
+    if (rc) return rc;
+  }
+  return matrix_setup(t, &t->matrix);
 }
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;

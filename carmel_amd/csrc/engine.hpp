@@ -170,6 +170,8 @@ struct carmel_hip_trainer {
   std::vector<double> h_group_add;
   std::vector<uint64_t> h_chain_off, h_chain_param;
 
+  int build_prune = 1, build_threads = 0;  // the arguments of the last carmel_hip_build_lattices
+  void* matrix = nullptr;  // carmel_hip_set_matrix_fb: device tables of the dense-matrix E-step (matrix_fb.hip)
   double* ext_counts = nullptr;  // caller-owned n_arcs + 4 doubles (carmel_hip_use_external_counts)
   double* counts_ptr() { return ext_counts ? ext_counts : counts.p; }
   double* params() { return cascade ? param_logw_c.p : arc_logw.p; }
@@ -182,3 +184,8 @@ struct carmel_hip_trainer {
 extern "C" int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M);
 extern "C" void trans_args(carmel_hip_trainer* t, TransArgs& T);
 bool exchange_is_sharded(const ExchangePlan* xp);  // exchange.cpp
+namespace carmel_hip {  // matrix_fb.hip
+int matrix_setup(carmel_hip_trainer* t, void** out);
+int matrix_estimate(carmel_hip_trainer* t, void* state, hipStream_t s);
+void matrix_release(void* state);
+}

@@ -88,6 +88,7 @@ struct Options {
   bool em_p0 = false;
   bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
   bool cache_no_prune = false;     // --cache-no-prune
+  bool matrix_fb = false;          // --matrix-fb (carmel.cc:238)
   bool gpu_compose = false;        // --gpu-compose: the product construction of the composition on the GPU (compose.hip)
   // prior-scale inference (carmel.cc:291-294, 497; gibbs.hpp:525-563)
   double pi_stddev = 0;
@@ -198,12 +199,9 @@ static Options parse_args(int argc, char** argv) {
         // they are built once and live in HBM (288 GB per GPU); the option changes nothing about the results
         std::cerr << "option " << k << " = " << v << ": derivations are cached in GPU memory, no disk cache is created\n";
       } else if (k == "matrix-fb") {
-        // carmel.cc:238, train.cc:254-266, 698-860: the legacy dense forward/backward over an (input position x output
-        // position x state) matrix.  It sums over the same derivations as the sparse lattices (train.cc:726-744 visits the
-        // same label classes; e_forward_topo orders the *e*:*e* arcs), so for transducers without *e*:*e* cycles the
-        // counts are the same numbers; this build always sweeps lattices
-        std::cerr << "option matrix-fb: the dense matrix is not used; derivation lattices give the same sums"
-                     " (transducers with *e*:*e* cycles: both drop some cyclic paths, not necessarily the same ones)\n";
+        // carmel.cc:238, train.cc:254-266, 698-860: forward/backward over the dense (input position x output position x
+        // state) matrix instead of derivation lattices (carmel_hip_set_matrix_fb, csrc/matrix_fb.hip)
+        o.matrix_fb = true;
       } else if (k == "cache-no-prune")  // carmel.cc:241: keep states that cannot reach the goal in the cached lattices
         o.cache_no_prune = true;
       else if (k == "sample-prob-after")  // not a carmel option (its old builds logged this as "sample prob")
@@ -767,6 +765,14 @@ static int run(int argc, char** argv) {
       hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
     }
     hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
+  }
+  if (o.matrix_fb) {  // train.cc:381-383
+    if (comm && !o.crp)
+      std::cerr << "option matrix-fb: not combined with --gpus (the sharded count exchange follows the lattices' layout); sweeping lattices\n";
+    else {
+      std::cerr << "Using (input,state,output) full matrix, not derivation lattice.  Usually slower.\n";
+      hip_check(carmel_hip_set_matrix_fb(t, 1), "carmel_hip_set_matrix_fb");
+    }
   }
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;

@@ -191,6 +191,10 @@ class HipForwardBackward(object):
     def exchange_clear(self):
         check(lib.carmel_hip_exchange_clear(self.h), "carmel_hip_exchange_clear")
 
+    def set_matrix_fb(self, on=True):
+        """carmel --matrix-fb: the E-step over the dense (input, output, state) matrix instead of derivation lattices"""
+        check(lib.carmel_hip_set_matrix_fb(self.h, int(on)), "carmel_hip_set_matrix_fb")
+
     def set_layout_policy(self, allow_unrolled):
         check(lib.carmel_hip_set_layout_policy(self.h, int(allow_unrolled)), "carmel_hip_set_layout_policy")
 

@@ -247,6 +247,14 @@ int carmel_hip_exchange_clear(carmel_hip_trainer* t);
 /* allow_unrolled = 0: carmel_hip_build_lattices keeps explicit lattices even for one-tape models (what every rank must do
  * when the ranks' shards would choose different layouts); 1 (default): the builder decides per shard */
 int carmel_hip_set_layout_policy(carmel_hip_trainer* t, int allow_unrolled);
+/* `carmel --matrix-fb` (carmel.cc:238; forward_backward::matrix_compute / estimate_matrix / matrix_count, train.cc:698-745,
+ * 776-860, 288-296): on != 0 makes carmel_hip_estimate* run the dense (input position x output position x state)
+ * forward/backward -- one workgroup per pair, anti-diagonal by anti-diagonal, *e*:*e* arcs by levels of the epsilon graph
+ * (csrc/matrix_fb.hip) -- instead of sweeping derivation lattices; counts, ln p per pair and the corpus scalars come out
+ * as usual, so maximize / cascades / over-relaxation are unchanged.  After carmel_hip_build_lattices (which drops the pairs
+ * without a derivation).  CARMEL_HIP_ERR_UNSUPPORTED when the *e*:*e* arcs form a cycle or the longest pair's matrices do
+ * not fit in device memory; 0 switches back to the lattices. */
+int carmel_hip_set_matrix_fb(carmel_hip_trainer* t, int on);
 
 /* ---- blocked Gibbs sampling of derivations: `carmel --crp` ----
  * Replaces: WFST::train_gibbs / carmel_gibbs (gibbs.cc:15-41, 386-430) + gibbs_base::run_starts

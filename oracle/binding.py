@@ -189,6 +189,21 @@ def estimate(w, c, prune=True, n_threads=1):
                 sum_weighted_logprob=sums[1])
 
 
+lib.orc_estimate_matrix.argtypes = [vp, vp, vp, vp, vp]
+
+
+def estimate_matrix(w, c):
+    """one E-step of carmel --matrix-fb (oracle/matrix.hpp); dict(counts_ln, pair_logprob, sum_logprob,
+    sum_weighted_logprob, eps_back_edges)"""
+    ns, na, _ = w.dims()
+    npairs = len(c.arrays()["weight"])
+    counts = np.zeros(na)
+    pl = np.zeros(npairs)
+    sums = np.zeros(3)
+    _chk(lib.orc_estimate_matrix(w.h, c.h, _p(counts), _p(pl), _p(sums)))
+    return dict(counts_ln=counts, pair_logprob=pl, sum_logprob=sums[0], sum_weighted_logprob=sums[1], eps_back_edges=int(sums[2]))
+
+
 def lattice(w, c, pair, prune=True):
     ns, na, fin, nb = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
     _chk(lib.orc_lattice(w.h, c.h, pair, int(prune), C.byref(ns), C.byref(na), C.byref(fin), None, None, None, None,

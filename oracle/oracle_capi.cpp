@@ -5,6 +5,7 @@
 // Arc arrays are in the reference's arc-id order: state-major, each state's arcs in list order
 // (derivations.h:86-101, fst.h:1331-1334).
 #include "train.hpp"
+#include "matrix.hpp"
 #include "fem.hpp"
 #include "gibbs.hpp"
 #include "forest.hpp"
@@ -175,6 +176,30 @@ void orc_corpus_export(orc_corpus* h, uint64_t* in_off, uint32_t* in_sym, uint64
   }
   in_off[k] = a;
   out_off[k] = b;
+}
+
+// One E-step over the dense (input, output, state) matrix (carmel --matrix-fb; matrix.hpp).  counts_ln / pair_logprob as
+// orc_estimate; sums[3] = sum ln p, sum weight * ln p, number of back edges of the *e*:*e* graph.
+int orc_estimate_matrix(orc_wfst* wh, orc_corpus* ch, double* counts_ln, double* pair_logprob, double* sums) {
+  return run_big_stack([&]() {
+    Wfst& x = wh->w;
+    ArcTable arcs;
+    arcs.build(x, false, LW());
+    MatrixFB m(x, arcs);
+    LW un;
+    std::vector<double> pl;
+    LW ret = m.estimate(ch->c, un, &pl);
+    if (counts_ln)
+      for (size_t k = 0; k < arcs.t.size(); ++k) counts_ln[k] = arcs.t[k].counts.w;
+    if (pair_logprob)
+      for (size_t k = 0; k < pl.size(); ++k) pair_logprob[k] = pl[k];
+    if (sums) {
+      sums[0] = un.w;
+      sums[1] = ret.w;
+      sums[2] = m.n_back_edges;
+    }
+    return 0;
+  });
 }
 
 // One E-step over the whole corpus at the transducer's current weights (train.cc:763-773 / derivations.h:432-449).
