@@ -338,14 +338,17 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   // ---------- forward ----------
   {
     const uint32_t rend = frow[NL];
-    // the first rows of this level (r0), the next (r1) and the one after (r2): records and weights in registers
-    uint32_t r0 = frow[1], r1 = frow[2], r2 = NL > 2 ? frow[3] : r1;
-    uint2 rec0 = f[(size_t)r0 * 64], rec1 = f[(size_t)(r1 < rend ? r1 : r0) * 64];
+    // the first rows of this level (r0) and of the next three (r1 .. r3): records three levels ahead, their weights two --
+    // a record's weight is a gather through the record (wc[rec.y]), and issued in the same step as the record's own load it
+    // made every step wait out a full memory round trip; now the gather goes through the record requested a step earlier
+#define WAVE_FROW(k) ((k) <= NL ? frow[(k)] : rend)
+    uint32_t r0 = frow[1], r1 = WAVE_FROW(2), r2 = WAVE_FROW(3), r3 = WAVE_FROW(4);
+    uint2 rec0 = f[(size_t)r0 * 64], rec1 = f[(size_t)(r1 < rend ? r1 : r0) * 64], rec2 = f[(size_t)(r2 < rend ? r2 : r0) * 64];
     double w0 = wc[rec0.y], w1 = wc[rec1.y];
     for (uint32_t l = 1; l < NL; ++l) {
       const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
-      const uint32_t r3 = (l + 3 <= NL) ? frow[l + 3] : rend;
-      const uint2 rec2 = f[(size_t)(r2 < rend ? r2 : r0) * 64];
+      const uint32_t r4 = WAVE_FROW(l + 4);
+      const uint2 rec3 = f[(size_t)(r3 < rend ? r3 : r0) * 64];
       const double w2 = wc[rec2.y];
       const bool v0 = (rec0.x & WAVE_VALID) != 0;
       const uint32_t dr0 = (rec0.x >> 16) & 0x3fffu;
@@ -378,10 +381,13 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       w0 = w1;
       rec1 = rec2;
       w1 = w2;
+      rec2 = rec3;
       r0 = r1;
       r1 = r2;
       r2 = r3;
+      r3 = r4;
     }
+#undef WAVE_FROW
   }
   // ---------- ln p(pair); beta'[goal] = ln(weight) - ln p folds "* weight / prob" (derivations.h:445) ----------
   if (lane == 0) {
