@@ -644,8 +644,7 @@ def test_cache_options_change_nothing_about_the_results(golden_dir):
     base = ["-t", "-M", "4", g("epron-jpron.data"), g("epron-jpron.fst")]
     rc, out0, err0 = run(base)
     assert rc == 0, err0
-    for extra in (["-?"], ["-:"], ["--disk-cache-derivations=/tmp/x.XXXXXX", "--disk-cache-bufsize=1M"], ["--cache-no-prune", "-?"],
-                  ["--matrix-fb"]):
+    for extra in (["-?"], ["-:"], ["--disk-cache-derivations=/tmp/x.XXXXXX", "--disk-cache-bufsize=1M"], ["--cache-no-prune", "-?"]):  # (--matrix-fb is an E-step of its own now: tests/test_matrix_fb_gpu.py)
         rc, out, err = run(extra + base)
         assert rc == 0, err
         assert out == out0
