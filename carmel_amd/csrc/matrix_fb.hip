@@ -293,9 +293,16 @@ int matrix_setup(carmel_hip_trainer* t, void** out) {
   MUP(cout_off, c.out_off);
   MUP(cin_sym, c.in_sym);
   MUP(cout_sym, c.out_sym);
-  uint64_t max_cells = 1;
-  for (uint64_t p = 0; p < c.n_pairs; ++p)
-    max_cells = std::max(max_cells, (c.in_off[p + 1] - c.in_off[p] + 1) * (c.out_off[p + 1] - c.out_off[p] + 1));
+  uint64_t max_cells = 1, max_diag = 1;
+  for (uint64_t p = 0; p < c.n_pairs; ++p) {
+    const uint64_t ni = c.in_off[p + 1] - c.in_off[p], no = c.out_off[p + 1] - c.out_off[p];
+    max_cells = std::max(max_cells, (ni + 1) * (no + 1));
+    max_diag = std::max(max_diag, std::min(ni, no) + 1);
+  }
+  if (max_diag * w.n_states >= (1ull << 31) || max_cells >= (1ull << 31)) {
+    delete M;
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "--matrix-fb: (cells of a diagonal) x states exceeds the kernel's 32-bit thread indices; train on derivation lattices");
+  }
   M->slab_stride = 2 * max_cells * w.n_states;
   // (|in| + 1)(|out| + 1) * states doubles, twice, per resident pair: at most 1024 pairs at a time, inside a quarter of the
   // free memory

@@ -18,6 +18,8 @@ import test_gibbs_gpu as G  # noqa: E402
 import test_gpu_parity as P  # noqa: E402
 import test_compose_gpu as K  # noqa: E402
 import test_forest_gpu as F  # noqa: E402
+import test_matrix_fb_gpu as M  # noqa: E402
+import numpy as np  # noqa: E402
 
 
 class MP(object):
@@ -52,6 +54,31 @@ def main():
         ("forest sweep formulations", lambda d, s: F.test_parallel_sweep_formulations_on_wide_and_deep_forests(
             oracle, dict(or_max=2 + s % 11, and_max=1 + (s // 11) % 7, depth=2 + s % 3, spine=(s % 5 == 0) * (20 + s % 30), seed=s,
                          **({"temps": (2.5, 0.5)} if s % 4 == 1 else {})))),
+    ]
+    def scatter_case(d, s, mp=None):
+        """random ambiguous models: the four forms of the transposition (first pass scatters / second pass gathers, per
+        direction), per-item and run-length indices, must give the same counts bit for bit"""
+        w, c = P.ambiguous(s, n_states=20 + s % 200, deg=4 + s % 9, n_sym=2 + s % 7, n_pairs=200 + (s * 13) % 3000, p_eps=0.05 * (s % 5),
+                           lo=2, hi=6 + s % 30)
+        ref = None
+        for runs in ("0", "1"):
+            mp.setenv("CARMEL_HIP_TRANS_RUNS", runs)
+            for mode in ("0", "1", "2", "3"):
+                mp.setenv("CARMEL_HIP_TRANS_SCATTER", mode)
+                fb = P._fb(w, c)
+                lp, _ = fb.estimate(per_pair=True)
+                got = (lp, fb.pair_logprob.copy(), fb.counts().copy())
+                fb.close()
+                if ref is None:
+                    ref = got
+                assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), (runs, mode)
+                assert (got[2] != ref[2]).sum() <= 16 and np.allclose(got[2], ref[2], rtol=1e-13, atol=0), (runs, mode)
+
+    cases += [
+        ("matrix fb", lambda d, s: M.test_matrix_estep_against_the_oracle_and_the_lattices(
+            oracle, s, dict(n_states=5 + s % 80, deg=2 + s % 9, n_sym=2 + s % 6, n_pairs=20 + (s * 7) % 300, p_eps=0.05 * (s % 9), lo=1 + s % 3,
+                            hi=4 + s % 12))),
+        ("transposition forms", scatter_case),
     ]
     only = os.environ.get("FUZZ_ONLY")
     if only:
