@@ -72,7 +72,9 @@ def main():
                 if ref is None:
                     ref = got
                 assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), (runs, mode)
-                assert (got[2] != ref[2]).sum() <= 16 and np.allclose(got[2], ref[2], rtol=1e-13, atol=0), (runs, mode)
+                # (these models have a few hundred arcs with 10^4 .. 10^5 uses each: nearly every arc is a split hub whose pieces
+                # meet in one atomic add each, so the last bit moves from run to run -- of the SAME form too)
+                assert np.allclose(got[2], ref[2], rtol=1e-13, atol=0), (runs, mode)
 
     cases += [
         ("matrix fb", lambda d, s: M.test_matrix_estep_against_the_oracle_and_the_lattices(
