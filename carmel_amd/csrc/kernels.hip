@@ -43,7 +43,11 @@ namespace carmel_hip {
 #define K_EXP(x) ((x) * 0.5 + 1.0)
 #define K_LOG(x) ((x) - 1.0)
 #else
+#ifdef CARMEL_LIBM_EXP
 #define K_EXP(x) exp(x)
+#else
+#define K_EXP(x) exp_le0(x)
+#endif
 #ifdef CARMEL_LIBM_LOG
 #define K_LOG(x) log(x)
 #else
@@ -56,6 +60,30 @@ namespace carmel_hip {
 // [sqrt(1/2), sqrt(2)): ln m = 2 s (1 + z/3 + z^2/5 + ... + z^10/21), z = s^2 <= 0.0295 (the first dropped term is below 2^-60
 // of the sum).  A third of the instructions; within 2 ulp of the library's (tests/test_gpu_parity.py compares every sweep with the
 // oracle's libm arithmetic).  On the ambiguous workloads the log per state was what the lane sweeps' arithmetic was made of.
+// e^x for the arguments the sweeps have: differences to a running maximum and log-posteriors (x <= 0 up to rounding), -inf for
+// dead arcs and padding.  Cody-Waite reduction by ln 2, Taylor to r^13 on |r| <= ln2 / 2 (remainder below 2^-57), ldexp -- which
+// also carries arguments below -745 through the denormals to 0; no branches for overflow or NaN inputs, which cannot occur.
+__device__ __forceinline__ double exp_le0(double x) {
+  x = fmax(x, -1100.0);  // (-inf included; 2^-1587 is 0 through ldexp)
+  const double n = rint(x * 1.44269504088896340736);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
 __device__ __forceinline__ double log_ge1(double a) {
   int e;
   double m = frexp(a, &e);  // [0.5, 1)
