@@ -542,12 +542,15 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
   if ((uint64_t)nt > np) nt = (int)std::max<uint64_t>(1, np);
   {
     std::atomic<uint64_t> next(0);
+    // pairs are handed out in batches of 256 on large corpora; a corpus of a few thousand LONG pairs (`long`: 5 000 lattices of up
+    // to 4 800 states) would be twenty batches for thirty-two threads, so the batch shrinks until every thread gets about eight
+    const uint64_t batch = std::max<uint64_t>(1, std::min<uint64_t>(256, np / ((uint64_t)nt * 8)));
     auto work = [&]() {
       Scratch sc;
       for (;;) {
-        uint64_t p0 = next.fetch_add(256);
+        uint64_t p0 = next.fetch_add(batch);
         if (p0 >= np) break;
-        uint64_t p1 = std::min(np, p0 + 256);
+        uint64_t p1 = std::min(np, p0 + batch);
         for (uint64_t p = p0; p < p1; ++p) {
           bool hd = false;
           build_pair_lattice_impl(w, c.in_sym.data() + c.in_off[p], (uint32_t)(c.in_off[p + 1] - c.in_off[p]),
