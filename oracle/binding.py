@@ -326,6 +326,18 @@ class OracleCascade(object):
 
 
 UNIFORM_FN = C.CFUNCTYPE(C.c_double, C.c_uint32, C.c_uint32, C.c_uint32)
+lib.orc_set_native_uniform_seed.argtypes = [C.c_uint64]
+lib.orc_native_uniform.restype = C.c_double
+lib.orc_native_uniform.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+
+
+def _uniform_cb(uniform):
+    """`uniform` is a Python callable u(iter, block, step), or an int: the seed of the oracle's own counter-based stream
+    (orc_native_uniform, value for value the product's carmel_hip_gibbs_uniform(seed, ...)) -- no Python call per draw"""
+    if isinstance(uniform, (int, np.integer)):
+        lib.orc_set_native_uniform_seed(int(uniform))
+        return C.cast(lib.orc_native_uniform, UNIFORM_FN)
+    return UNIFORM_FN(uniform)
 lib.orc_gibbs_run.argtypes = [vp, vp, C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int,
                               UNIFORM_FN, vp, vp, vp, vp, vp, C.c_uint64, vp]
 
@@ -375,7 +387,7 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     n_pairs = len(corpus.arrays()["weight"])
     off = np.zeros(n_pairs + 2, np.uint64)
     pri = None if priors is None else np.ascontiguousarray(priors, dtype=np.float64)
-    cb = UNIFORM_FN(uniform)
+    cb = _uniform_cb(uniform)
     lib.orc_set_gibbs_temps(C.c_double(high_temp), C.c_double(low_temp))
     lib.orc_set_gibbs_expectation(int(expectation))
     lib.orc_set_gibbs_self_start(int(include_self), int(random_start))
@@ -491,7 +503,7 @@ class OracleForests(object):
         ilp, icl = np.zeros(iters + 1), np.zeros(iters + 1)
         samp = np.zeros(max_samples, np.uint32)
         off = np.zeros(self.n_forests + 1, np.uint64)
-        cb = UNIFORM_FN(uniform)
+        cb = _uniform_cb(uniform)
         _chk(lib.orc_forests_gibbs(self.h, iters, burnin, int(uniform_p0), int(final_counts), alpha, cb, _p(ilp), _p(icl),
                                    _p(samp), _p(off), max_samples))
         samples = [samp[int(off[b]):int(off[b + 1])].tolist() for b in range(self.n_forests)]

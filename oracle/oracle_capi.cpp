@@ -896,6 +896,25 @@ char* orc_cascade_write_member(orc_cascade* h, int m, const double* param_logw, 
   return r;
 }
 
+// ---- a uniform stream that needs no callback into Python: the splitmix64 finaliser (Steele, Lea & Flood 2014) over
+// (seed, sweep, block, step), 53 bits to [0,1).  The product's generator (carmel_hip_gibbs_uniform) is the same published
+// function; tests/test_gibbs_host.py checks the two agree value for value, so a chain driven by this one is the chain the
+// GPU sampler is compared with draw for draw.  The seed is set once per run (orc_set_native_uniform_seed).
+static uint64_t g_native_seed = 0;
+static inline uint64_t orc_mix64(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+void orc_set_native_uniform_seed(uint64_t seed) { g_native_seed = seed; }
+double orc_native_uniform(uint32_t iter, uint32_t block, uint32_t step) {
+  uint64_t h = orc_mix64(g_native_seed ^ 0xD1B54A32D192ED03ull);
+  h = orc_mix64(h ^ ((uint64_t)iter << 32 | block));
+  h = orc_mix64(h ^ (uint64_t)step);
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+
 // ---- blocked Gibbs over a composed cascade (carmel --crp), uniforms injected through a callback ----
 // out_param_logw[n_params]: ln final_prob per member arc, concatenated member order (probs_to_cascade)
 // out_samples / out_sample_off[n_blocks+1]: final sample of every block as MEMBER-ARC indices (concatenated order)

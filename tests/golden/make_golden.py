@@ -21,6 +21,11 @@ FIXTURES = [
     ("carmel-tutorial/tagging.data", "tagging.data"),
     ("carmel-tutorial/tagging.fsa", "tagging.fsa"),
     ("carmel-tutorial/tagging.fst", "tagging.fst"),
+    # written twice by the tutorial's command script (EM at commands:19, then `carmel --crp -M 6000` at commands:33): the
+    # committed copies are the SAMPLER's output -- every never-sampled arc out of state 0 reads 0.01 / (1005 + 44 * 0.01).
+    # The reference-held vector for the Gibbs bookkeeping: tests/crp_pin.py
+    ("carmel-tutorial/tagging.fsa.trained", "tagging.fsa.crp-trained"),
+    ("carmel-tutorial/tagging.fst.trained", "tagging.fst.crp-trained"),
     ("test/train.a", "train.a"),
     ("test/train.a.w", "train.a.w"),
     ("test/train.a.u", "train.a.u"),

@@ -636,6 +636,34 @@ def test_crp_tagging_against_the_recorded_run(golden_dir, tmp_path):
         assert os.path.getsize(os.path.join(str(tmp_path), name + ".trained")) > 1000
 
 
+def test_crp_tagging_bookkeeping_against_the_reference_output(golden_dir, tmp_path):
+    """$CARMEL --crp -M 6000 tagging.data tagging.fsa tagging.fst (commands:33) wrote tagging.{fsa,fst}.trained, the
+    reference's own output of the sampler (committed as tests/golden/tagging.*.crp-trained; tests/crp_pin.py says what in it
+    does not depend on Boost's random stream and checks the reference's file against that closed form first).  The front end
+    runs the reference's chain (exact mode) twice, with its own draws; the *.trained it writes must hold the reference's
+    values wherever they are determined (1e-12), the 45 group totals read back off the never-sampled members must sum to
+    the 25 120 arcs of a sample, and the large parameters must correlate with the reference's.  SURVEY 8a18:
+    gibbs.cc:66-76, 390-397; gibbs.hpp:589-592, 626-638; delta_sum.hpp:49-106.  The stale-count sweep (--crp-parallel) is
+    another chain with the same bookkeeping: it is held to the closed form too, over a run as long as the reference's."""
+    import crp_pin
+    g = lambda n: os.path.join(golden_dir, n)
+    rd = lambda n: open(g(n)).read()
+    runs = []
+    for tag, extra in (("a", ["-M", "90", "-R", "4"]), ("b", ["-M", "60", "-R", "3"]), ("p", ["-M", "6000", "-R", "5", "--crp-parallel"])):
+        d = tmp_path / tag
+        d.mkdir()
+        rc, out, err = run(["--crp"] + extra + [g("tagging.data"), g("tagging.fsa"), g("tagging.fst")], env={"CARMEL_TRAINED_DIR": str(d)})
+        assert rc == 0, err
+        assert err.count("Setting to 0.01") == 2
+        runs.append(tuple(open(os.path.join(str(d), n + ".trained")).read() for n in ("tagging.fsa", "tagging.fst")))
+    ref = (rd("tagging.fsa.crp-trained"), rd("tagging.fst.crp-trained"))
+    inputs = (rd("tagging.fsa"), rd("tagging.fst"), rd("tagging.data"))
+    res = crp_pin.check(ref, runs[0], runs[1], min_corr=0.8, inputs=inputs)
+    assert res["fsa_closed_form"] <= res["fsa_equal_to_reference"] <= res["fsa_closed_form"] + 80
+    res_p = crp_pin.check(ref, runs[2], runs[2], min_corr=0.85, inputs=inputs)
+    assert res_p["fsa_closed_form"] == res["fsa_closed_form"] >= 200
+
+
 def test_cache_options_change_nothing_about_the_results(golden_dir):
     """-? / -: / --disk-cache-derivations / --cache-no-prune (carmel.cc:235-251) only say where and how derivations are
     cached; here they always live in GPU memory.  Unpruned lattices keep dead-end states (their backward weight is 0), so

@@ -99,3 +99,24 @@ def test_logweight_identities(oracle):
     a = w.arrays()
     assert a["group"].tolist() == [0, 7, 0xFFFFFFFF, 0xFFFFFFFF]
     assert a["isym"][2] == 0 and a["osym"][2] == 0 and a["logw"][2] == 0.0
+
+
+def test_crp_tagging_bookkeeping_against_the_reference_output(oracle, golden_dir):
+    """carmel --crp -M 6000 tagging.data tagging.fsa tagging.fst (commands:33) wrote tagging.{fsa,fst}.trained: the only
+    reference-held OUTPUT of the sampler (tests/crp_pin.py says what in it does not depend on the random stream).  The
+    oracle's sampler -- min_prior 0.01 (gibbs.cc:390-397), prior = alpha * p0 * |group| (gibbs.hpp:589-592), time-averaged
+    counts (gibbs.hpp:626-638, delta_sum.hpp:49-106), probs_to_cascade (gibbs.cc:66-76) -- is run twice with its own
+    uniforms; where its two runs agree it must have written what the reference wrote, to 1e-11."""
+    import crp_pin
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    runs = []
+    for seed, sweeps in ((3, 60), (4, 90)):
+        oc = oracle.OracleCascade([g("tagging.fsa"), g("tagging.fst")])  # (a run leaves its result in the cascade: p0 of the next)
+        corpus = oc.corpus(g("tagging.data"))
+        r = oracle.gibbs_run(oc, corpus, seed, normby="CC", priors=[0.0, 0.0], iters=sweeps, burnin=0)
+        runs.append((oc.write_member(0, r["param_logw"]), oc.write_member(1, r["param_logw"])))
+    res = crp_pin.check((g("tagging.fsa.crp-trained"), g("tagging.fst.crp-trained")), runs[1], runs[0], min_corr=0.8,
+                        inputs=(g("tagging.fsa"), g("tagging.fst"), g("tagging.data")))
+    # beyond the closed form only what neither chain ever chose coincides (a first word that may be JJS once in 10^5 sweeps)
+    assert res["fsa_closed_form"] <= res["fsa_equal_to_reference"] <= res["fsa_closed_form"] + 80
+    print(res)
