@@ -231,7 +231,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                 fb.maximize(1.0)
                 fb.synchronize()
             elif comm is not None:
-                comm.abort()
+                comm.abort()  # (drops the plan it was given: the trainer runs unplanned from here on)
                 comm = None
         if ok == 0 and not loopback:
             if comm is not None:
@@ -577,7 +577,7 @@ def main():
     ap.add_argument("--comm-plugin", default=None, help="a transport library for the exchange instead of RCCL (carmel_hip_comm_create_custom), "
                     "e.g. tests/native/libhosttransport.so: every rank then runs on GPU 0 (several ranks on a one-GPU box)")
     ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"], help="form of the count exchange at N > 1")
-    ap.add_argument("--exchange-chunks", type=int, default=0, help="arc-range chunks of the sharded exchange (0: the library's default, 8)")
+    ap.add_argument("--exchange-chunks", type=int, default=0, help="arc-range chunks of the sharded exchange (0: the library's default, 4; at most 16)")
     ap.add_argument("--no-exchange-loopback", action="store_true", help="N = 1: skip the loopback measurement of the exchange")
     ap.add_argument("--walk-arcs", default=None, help="min,max arcs of the headline's random walks (default: the config's; other values are experiments)")
     args = ap.parse_args()

@@ -84,10 +84,10 @@ int comm_reduce_scatter(carmel_hip_comm* c, double* buf, size_t count, hipStream
 int comm_all_gather(carmel_hip_comm* c, double* buf, size_t count, hipStream_t s) {
   if (!count) return CARMEL_HIP_OK;
   if (c->custom) {
-    if (!c->tr.all_gather) {  // the others' pieces zeroed, then a sum
-      if (c->rank > 0) HIPCHK(hipMemsetAsync(buf, 0, (size_t)c->rank * count * sizeof(double), s));
+    if (!c->tr.all_gather) {  // the others' pieces set to -0.0, then a sum: x + -0.0 == x bit for bit, for -0.0 and +0.0 too
+      if (c->rank > 0) HIPCHK(launch_fill(buf, -0.0, (uint64_t)c->rank * count, s));
       if (c->rank + 1 < c->world)
-        HIPCHK(hipMemsetAsync(buf + (size_t)(c->rank + 1) * count, 0, (size_t)(c->world - 1 - c->rank) * count * sizeof(double), s));
+        HIPCHK(launch_fill(buf + (size_t)(c->rank + 1) * count, -0.0, (uint64_t)(c->world - 1 - c->rank) * count, s));
       return comm_allreduce(c, buf, count * (size_t)c->world, false, s);
     }
     const int rc = c->tr.all_gather(c->tr.ctx, buf, count, (void*)s);
@@ -159,6 +159,7 @@ int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, i
 int carmel_hip_comm_destroy(carmel_hip_comm* c) {
   if (!c) return CARMEL_HIP_OK;
   (void)hipSetDevice(c->device);
+  exchange_comm_gone(c);  // plans first: they hold events on this communicator's stream
   if (c->rccl) (void)g_rccl.comm_destroy((ncclComm_t)c->rccl);
   delete c;
   return CARMEL_HIP_OK;
@@ -176,6 +177,7 @@ int carmel_hip_comm_abort(carmel_hip_comm* c) {
       (void)g_rccl.comm_destroy((ncclComm_t)c->rccl);
   }
   c->rccl = nullptr;
+  exchange_comm_gone(c);  // after the abort: what was enqueued has been given up, the streams drain
   delete c;
   return CARMEL_HIP_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include "engine.hpp"
 
 struct carmel_hip_comm {
@@ -12,6 +13,8 @@ struct carmel_hip_comm {
   hipStream_t xstream = nullptr;  // the exchange's own stream: collectives run here beside the trainer's kernels
   DevBuf<double> scratch;         // small host-vector reductions
   std::string what;               // "RCCL" or the transport's name
+  std::vector<carmel_hip_trainer*> planned;  // trainers whose exchange plan points at this communicator: destroying or
+                                             // aborting it drops their plans first (exchange_comm_gone), so no plan outlives it
   ~carmel_hip_comm();
 };
 
@@ -21,3 +24,7 @@ int comm_allreduce(carmel_hip_comm* c, double* dev, size_t n, bool op_max, hipSt
 int comm_reduce_scatter(carmel_hip_comm* c, double* buf, size_t count, hipStream_t s);
 // ... every rank's piece is copied to all ranks
 int comm_all_gather(carmel_hip_comm* c, double* buf, size_t count, hipStream_t s);
+
+// the communicator is going away (destroy: after its stream has drained; abort: whatever was enqueued is given up): every
+// trainer planned on it goes back to having no plan -- a replicated M-step on whatever counts it holds
+void exchange_comm_gone(carmel_hip_comm* c);

@@ -1137,6 +1137,10 @@ int carmel_hip_estimate(carmel_hip_trainer* t, carmel_hip_estimate_result* res, 
 void* carmel_hip_counts_dev(carmel_hip_trainer* t) { return t ? (void*)t->counts_ptr() : nullptr; }
 int carmel_hip_use_external_counts(carmel_hip_trainer* t, void* dev_ptr) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  // a sharded plan reduce-scatters the trainer's OWN count buffer chunk by chunk: it cannot be pointed elsewhere under it
+  if (dev_ptr && t->xplan && exchange_is_sharded(t->xplan))
+    return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_use_external_counts: a sharded exchange is planned -- carmel_hip_exchange_clear (collective) "
+                                      "or destroy / abort the communicator first");
   t->ext_counts = (double*)dev_ptr;
   return CARMEL_HIP_OK;
 }

@@ -69,10 +69,19 @@ bool exchange_is_sharded(const ExchangePlan* xp) { return xp && xp->sharded; }
 void exchange_drop(carmel_hip_trainer* t) {
   if (!t->xplan) return;
   (void)hipSetDevice(t->device);
-  if (t->xplan->comm && t->xplan->comm->xstream) (void)hipStreamSynchronize(t->xplan->comm->xstream);
+  if (carmel_hip_comm* c = t->xplan->comm) {  // (null: the communicator went first -- exchange_comm_gone)
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    c->planned.erase(std::remove(c->planned.begin(), c->planned.end(), t), c->planned.end());
+  }
   if (t->stream) (void)hipStreamSynchronize(t->stream);
   plan_free(t->xplan);
   t->xplan = nullptr;
+}
+
+void exchange_comm_gone(carmel_hip_comm* c) {
+  const std::vector<carmel_hip_trainer*> ts = c->planned;  // (exchange_drop edits the list)
+  for (carmel_hip_trainer* t : ts) exchange_drop(t);
+  c->planned.clear();
 }
 
 // ---- weights in: trans_w_bucket chunk by chunk behind the all-gathers of the previous M-step ----
@@ -243,7 +252,8 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
   // unrolled sweep against per-arc counts: round-2 advisor finding) -- and must take the same form of the exchange
   const uint32_t span = t->norm_span;
   bool can = !force_allreduce && !t->cascade && !t->unrolled && t->use_transpose && span > 0 && span <= 64 && !t->any_digamma &&
-             !t->n_ties && t->have_norm && t->w.n_arcs >= (uint64_t)xp->N * 256 * 2 && !t->ext_counts;
+             !t->n_ties && t->have_norm && t->w.n_arcs >= (uint64_t)xp->N * 256 * 2 && !t->ext_counts &&
+             !t->matrix;  // (--matrix-fb's E-step leaves before the count pass the reduce-scatters hang on: plain all-reduce)
   {
     double v[4] = {(double)carmel_hip_lattice_layout(t), -(double)carmel_hip_lattice_layout(t), can ? 1.0 : 0.0, can ? 0.0 : 1.0};
     int rc = carmel_hip_comm_allreduce_host(c, v, 4, 1);
@@ -323,6 +333,7 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
     xp->bytes_small = (t->w.n_arcs + 4) * 8;
   }
   t->xplan = xp;
+  c->planned.push_back(t);
   return CARMEL_HIP_OK;
 }
 

@@ -172,6 +172,7 @@ class HipForwardBackward(object):
     def exchange_plan(self, comm, n_chunks=0, force_allreduce=False):
         """plan the per-iteration exchange (collective); returns exchange_info()"""
         check(lib.carmel_hip_exchange_plan(self.h, comm.h, n_chunks, int(force_allreduce)), "carmel_hip_exchange_plan")
+        self._comm = comm  # the plan points at the communicator: keep it from being collected before the trainer
         return self.exchange_info()
 
     def exchange_info(self):
@@ -190,6 +191,7 @@ class HipForwardBackward(object):
 
     def exchange_clear(self):
         check(lib.carmel_hip_exchange_clear(self.h), "carmel_hip_exchange_clear")
+        self._comm = None
 
     def set_matrix_fb(self, on=True):
         """carmel --matrix-fb: the E-step over the dense (input, output, state) matrix instead of derivation lattices"""

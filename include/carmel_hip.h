@@ -202,6 +202,9 @@ int carmel_hip_load_best(carmel_hip_trainer* t);
 typedef struct carmel_hip_comm carmel_hip_comm;
 int carmel_hip_comm_unique_id(void* id128);
 int carmel_hip_comm_create(carmel_hip_comm** out, int device, int rank, int world, const void* id128);
+/* Destroying (or aborting) a communicator first drops the exchange plan of every trainer planned on it
+ * (carmel_hip_exchange_plan): trainer and communicator may be destroyed in either order, and a trainer that outlives its
+ * communicator simply runs unplanned (local counts, replicated M-step). */
 int carmel_hip_comm_destroy(carmel_hip_comm* c);
 /* after a collective failed on some rank: drop whatever is still enqueued instead of waiting for it (ncclCommAbort) */
 int carmel_hip_comm_abort(carmel_hip_comm* c);
@@ -238,7 +241,13 @@ int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, i
  * layouts, tied groups, force_allreduce != 0) keep the one all-reduce of counts[n_arcs + 4] and the replicated M-step.
  * The results are the same either way up to the order of the sums.  carmel_hip_exchange_info says which form was planned
  * and what one iteration moves per rank; carmel_hip_exchange_measure times the exchange of one iteration on its own (all
- * its collectives back to back, nothing to hide behind; collective); carmel_hip_exchange_clear drops the plan. */
+ * its collectives back to back, nothing to hide behind; collective); carmel_hip_exchange_clear drops the plan.
+ * COLLECTIVE while a sharded plan holds reduced pieces (between carmel_hip_allreduce_counts and the next count pass):
+ * whatever needs the WHOLE count vector all-gathers it first -- carmel_hip_get_counts, carmel_hip_fractional_counts,
+ * carmel_hip_exchange_clear, carmel_hip_maximize with delta_scale > 1.  Every rank must make these calls together (a
+ * rank-0-only carmel_hip_get_counts would wait for its peers forever); with the all-reduce form they are local.
+ * carmel_hip_use_external_counts is refused under a sharded plan; matrix mode (carmel_hip_set_matrix_fb) plans the
+ * all-reduce form. */
 int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int force_allreduce);
 int carmel_hip_exchange_info(carmel_hip_trainer* t, int* sharded, uint32_t* n_chunks, uint64_t* bytes_reduce_scatter,
                              uint64_t* bytes_all_gather, uint64_t* bytes_all_reduce);

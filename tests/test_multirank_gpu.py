@@ -218,3 +218,39 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     assert j2["exchange"]["sharded"] and j2["exchange"]["world"] == 2 and j2["exchange_ms"] > 0 and j2["exposed_exchange_ms"] >= 0
     assert "reduce-scatter" in j2["config"]["parallelism"]
     assert j1["exchange"]["loopback"] and j1["exchange_ms"] > 0
+
+
+def test_communicator_and_trainer_may_go_in_either_order():
+    """round-3 advisor findings: a plan points at its communicator, so (i) destroying the communicator first must leave the
+    trainer usable and destroyable (the front end's guards ran in that order), (ii) the count buffer cannot be pointed
+    elsewhere under a sharded plan, (iii) aborting the communicator after planning -- bench.py's fallback when an enqueue
+    fails -- leaves a trainer that steps unplanned."""
+    import torch
+    from carmel_amd import synth
+    from carmel_amd.trainer import HipComm, HipForwardBackward
+    w = synth.random_wfst(400, 8, n_sym=6, p_eps=0.1, seed=5)
+    c = synth.random_walk_corpus(w, 300, min_arcs=3, max_arcs=12, seed=5, out_degree=8)
+    ref = HipForwardBackward(w, c, device=0)
+    ref.estimate()
+    ref.maximize(1.0)
+    want = ref.weights()
+    ref.close()
+    for how in ("close", "abort"):
+        fb = HipForwardBackward(w, c, device=0)
+        comm = HipComm(0, 0, 1, HipComm.unique_id())
+        info = fb.exchange_plan(comm, 2, False)
+        assert info["sharded"]
+        ext = torch.zeros(int(w.n_arcs) + 4, dtype=torch.float64, device="cuda")
+        with pytest.raises(Exception, match="sharded exchange is planned"):
+            fb.use_external_counts(ext.data_ptr())
+        fb.estimate_async()
+        fb.allreduce_counts(comm)
+        getattr(comm, how)()          # the communicator goes first; the plan goes with it
+        with pytest.raises(Exception, match="no exchange planned"):
+            fb.exchange_info()
+        fb.use_external_counts(ext.data_ptr())  # allowed again
+        fb.use_external_counts(0)
+        fb.estimate()
+        fb.maximize(1.0)
+        np.testing.assert_allclose(fb.weights(), want, rtol=1e-12)
+        fb.close()
