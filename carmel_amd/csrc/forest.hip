@@ -23,6 +23,7 @@
 #include <numeric>
 #include <unordered_map>
 #include "engine.hpp"
+#include "forest_exact.hpp"
 #include "rng.hpp"
 
 namespace carmel_hip {
@@ -1756,6 +1757,7 @@ struct carmel_hip_forests {
   DevBuf<uint16_t> mt_tab;
   DevBuf<uint32_t> mt_hdr;
   DevBuf<uint32_t> mt_slots;  // FMultiArgs::slots
+  DevBuf<uint32_t> x_desc, x_rec;  // forest_exact_kernel's per-forest descriptors and per-node records (forest_exact.hpp)
   std::vector<FGroup> h_groups;
   struct Cls {
     uint32_t first, count, max_nodes;
@@ -2167,6 +2169,53 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       HIPCHK(F->mt_tab.upload(tab, s));
       HIPCHK(F->mt_hdr.upload(hdrs, s));
       HIPCHK(F->mt_slots.upload(slots, s));
+      // the exact chain's records (forest_exact.hip), forest after forest in the order of the chain: per node its children,
+      // rule, norm group, height; per forest where they start, how many, how high, where its sample lives, and whether it
+      // fits the register path (FX_NODES nodes, FX_KIDS children a node, FX_STACK pending nodes, FX_NODES rules a derivation)
+      {
+        std::vector<uint32_t> xd(4 * (size_t)n_forests), xr, xm;
+        std::vector<uint32_t> need;
+        for (uint64_t f = 0; f < n_forests; ++f) {
+          const Flat& fl = flat[f];
+          const uint16_t* mt = fl.mt.data();
+          const uint32_t n = mt[0], H = mt[1];
+          const uint16_t* lvl = mt + 4;
+          const uint16_t* koff = lvl + H + 1;
+          const uint16_t* kids = koff + n + 1;
+          bool slow = n > FX_NODES || fl.max_deriv > FX_NODES;
+          const uint64_t first = xm.size();
+          need.assign(n, 0);
+          for (uint32_t h = 0; h < H; ++h)
+            for (uint32_t q = lvl[h]; q < lvl[h + 1]; ++q) {
+              const uint32_t nch = (uint32_t)koff[q + 1] - koff[q];
+              const bool is_and = (fl.mh[4 * (size_t)q] & 0x80000000u) != 0;
+              if (nch > FX_KIDS) slow = true;
+              uint32_t kid[4] = {0xffu, 0xffu, 0xffu, 0xffu}, nd = 0;
+              for (uint32_t c = 0; c < nch; ++c) {
+                const uint32_t id = kids[koff[q] + c] & 0x7fffu;
+                if (c < 4) kid[c] = id & 0xffu;  // (ids beyond a byte: a forest of the LDS path, which reads other tables)
+                nd = std::max(nd, is_and ? (nch - 1 - c) + need[id] : need[id]);
+              }
+              need[q] = std::min(nd, 1u << 20);
+              const uint2_t hrw = fl.ins[fl.hdr[fl.m_ord[q]]];
+              const uint32_t rule = is_and ? hrw.y : 0u;
+              xr.push_back(kid[0] | (std::min(nch, 255u) << 8) | (std::min(h, 0x7fffu) << 16) | (is_and ? 0x80000000u : 0u));
+              xr.push_back(kid[1] | (kid[2] << 8) | (kid[3] << 16));
+              xr.push_back(rule);
+              xr.push_back(is_and ? F->h_norm[rule] : F_NONORM);
+              xm.push_back(0);
+            }
+          if (need[n - 1] > FX_STACK) slow = true;
+          if (first > 0xffffffffull || (so_all[f] >> 48)) return fail(CARMEL_HIP_ERR_UNSUPPORTED, "forests too large for the exact sampler's tables");
+          uint32_t* d = &xd[4 * (size_t)f];
+          d[0] = (uint32_t)first;
+          d[1] = n | (H << 16);
+          d[2] = (uint32_t)so_all[f];
+          d[3] = (uint32_t)(so_all[f] >> 32) | (slow ? 0x10000u : 0u);
+        }
+        HIPCHK(F->x_desc.upload(xd, s));
+        HIPCHK(F->x_rec.upload(xr, s));
+      }
       HIPCHK(hipStreamSynchronize(s));
     }
   }
@@ -2499,7 +2548,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   HIPCHK(hipMemsetAsync(F->p_tmax.p, 0, nr * sizeof(double), s));
   for (int k = 0; k < 2; ++k) {
     HIPCHK(F->sample_len[k].alloc(nf));
-    HIPCHK(F->sample_rules[k].alloc(F->h_sample_off.back()));
+    HIPCHK(F->sample_rules[k].alloc(F->h_sample_off.back() + 128));  // (+ forest_exact_kernel's staging reads a fixed number of words ahead)
     HIPCHK(hipMemsetAsync(F->sample_len[k].p, 0, nf * sizeof(uint32_t), s));
   }
   ForestArgs A;
@@ -2557,13 +2606,60 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
     A.trace = trace_buf.p;
   }
+  // exact mode on the device (forest_exact.hip): one persistent wavefront per sweep, every count in device memory.  It needs
+  // the per-forest height tables of the several-lanes sampler and runs at temperature 1; annealed runs, prior-scale inference
+  // (whose proposals rescale the counts between sweeps on the host) and locked parameters keep the host-driven loop below.
+  FExactArgs XA;
+  std::memset(&XA, 0, sizeof XA);
+  DevBuf<double> x_ccount, x_csum;
+  DevBuf<unsigned long long> x_clk;
+  bool exact_dev = o->mode == 0 && F->multi_ok && !guard.changed && !(F->pi_stddev > 0) && (o->high_temp == 0 || o->high_temp == 1) &&
+                   (o->low_temp == 0 || o->low_temp == 1) && nf > 0 && !getenv("CARMEL_HIP_FOREST_EXACT_HOST");
+  if (exact_dev) {
+    for (auto& c : F->classes) {
+      XA.max_n = std::max(XA.max_n, c.m_n);
+      XA.max_tab = std::max(XA.max_tab, c.m_tab);
+      XA.max_stack = std::max(XA.max_stack, c.max_kids + 2);
+    }
+    XA.max_sample = F->max_sample + 1;
+    if (XA.max_stack > 0xffffu || XA.max_sample > 0xffffu ||
+        forest_exact_lds_bytes(XA.max_n, XA.max_tab, XA.max_stack, XA.max_sample) > F_LDS_LIMIT)
+      exact_dev = false;
+  }
+  if (exact_dev) {
+    HIPCHK(x_ccount.alloc(nr));
+    HIPCHK(x_csum.alloc(std::max<uint64_t>(ng, 1)));
+    HIPCHK(F->sample_cls.alloc(F->h_sample_off.back() + 128));  // here: the norm group of every sample entry
+    XA.xdesc = (const uint4*)F->x_desc.p;
+    XA.xrec = (const uint4*)F->x_rec.p;
+    XA.tab = F->mt_tab.p;
+    XA.hdr = F->mt_hdr.p;
+    XA.slots = (const uint4*)F->mt_slots.p;
+    XA.lane_of_forest = F->lane_of_forest_d.p;
+    XA.sample_len = F->sample_len[0].p;
+    XA.sample_rules = F->sample_rules[0].p;
+    XA.sample_nn = F->sample_cls.p;
+    XA.p_x = F->p_x.p;
+    XA.normsum = F->normsum.p;
+    XA.p_prior = F->p_prior.p;
+    XA.ccount = x_ccount.p;
+    XA.csum = x_csum.p;
+    XA.iter_out = F->iter_out.p;
+    XA.seed = o->seed;
+    XA.n_forests = (uint32_t)nf;
+    if (getenv("CARMEL_HIP_FOREST_EXACT_CLK")) {
+      HIPCHK(x_clk.alloc(8));
+      HIPCHK(hipMemsetAsync(x_clk.p, 0, 64, s));
+      XA.phase_clk = x_clk.p;
+    }
+  }
   // gibbs_opts::validate (gibbs_opts.hpp:253-266): --final-counts makes every sweep but the last burn-in; burnin <= iter
   const uint32_t Ni = o->iter, burnin = o->final_counts ? o->iter : std::min(o->burnin, o->iter);
   // host mirror of counts for the exact schedule (one forest at a time: the counts move between forests)
   std::vector<double> hx, hs, ht, hn;
   std::vector<std::vector<uint32_t> > hsample;
   std::vector<double> ccount, csum;
-  if (o->mode == 0) {
+  if (o->mode == 0 && !exact_dev) {
     hx = prior;
     hs.assign(nr, 0.0);
     ht.assign(nr, 0.0);
@@ -2725,6 +2821,20 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         io_done = iter + 1;
       }
       continue;
+    } else if (exact_dev) {
+      // exact, on the device: the whole sweep is one launch (forest_exact.hip)
+      HIPCHK(hipMemcpyAsync(x_ccount.p, F->p_prior.p, nr * sizeof(double), hipMemcpyDeviceToDevice, s));
+      if (ng) HIPCHK(hipMemcpyAsync(x_csum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      XA.iter = iter;
+      // delta_sum's fold for every parameter at once: at the start of a sweep every count is what the previous sweep left,
+      // which is what the reference folds at a parameter's first touch in this sweep (delta_sum.hpp:74-84)
+      HIPCHK(launch_forest_fold(F->p_s.p, F->p_tmax.p, F->p_x.p, time, nr, s));
+      HIPCHK(launch_forest_exact(XA, s));
+      double io[2] = {0, 0};
+      HIPCHK(hipMemcpyAsync(io, F->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      cache_lp = io[0];
+      cheap_lp = io[1];
     } else {
       // exact: forest after forest; each launch resamples ONE forest on the GPU against the current counts
       ccount = prior;
@@ -2877,7 +2987,13 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   }
   // finalize_cumulative_counts + from_gibbs
   std::vector<double> x(nr), sacc(nr), tm(nr);
-  if (o->mode == 0) {
+  if (x_clk.n) {
+    unsigned long long c[8];
+    HIPCHK(hipMemcpy(c, x_clk.p, sizeof c, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[carmel_hip] forest_exact cycles per forest: wait+proposal %.0f, inside %.0f, walk %.0f, entries+counts %.0f (register path: %llu forests x sweeps, LDS path: %llu)\n",
+            c[0] / (double)c[4], c[1] / (double)c[4], c[2] / (double)c[4], c[3] / (double)c[4], c[4], c[5]);
+  }
+  if (o->mode == 0 && !exact_dev) {
     x = hx;
     sacc = hs;
     tm = ht;
