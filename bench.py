@@ -19,6 +19,10 @@ At N = 1 the same process then runs the other workloads one after another and at
   long  5 000 pairs with lattices of 320-4 800 states (the one-lattice-per-wavefront path)
   c3    configs[2]: the cipher cascade, 200 000 lines, through the front end
   c5    configs[4]: forest-em --crp, parallel stale-count sweeps AND the exact (sequential) chain
+  crp   carmel --crp on the tutorial's tagging cascade: the exact chain and the stale-count parallel sweep
+
+The line printed is COMPACT (the driver keeps the last 2 000 characters): the headline in full, every secondary as
+{ms_per_step, kernel_ms, frac, traffic, cpu, parity, value}; the complete objects go to --full-out (a file).
 
 The `cpu_baseline` leg of every synthetic EM workload also CHECKS the GPU: the oracle's per-pair ln p and per-arc
 counts on the timed sample are compared with a GPU trainer's on the same pairs (rtol 1e-7); `parity_checked_pairs`
@@ -443,6 +447,76 @@ def run_amb(args, steps, warmup, local_rank=0, rank=0):
     return out
 
 
+def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, sweeps_exact=60):
+    """`carmel --crp` (gibbs.cc:306-371, derivations.h:345-375, gibbs.hpp:769-877) through the front end on the tutorial's
+    tagging cascade: `exact` = the reference's chain (blocks strictly in order, one workgroup; 1005 blocks), the headline of
+    this workload = the stale-count parallel sweep (--crp-parallel) on the corpus x reps_parallel.  A step is one sweep.
+    Bytes per sweep (the lattice model of SURVEY 8(d) restricted to what a sampling sweep touches): per
+    lattice arc its 8 B record once (proposal weight) + 16 B per chain element (count and norm sum of its parameter; 2
+    elements on this cascade) + the 8 B proposal weight written and read back by the backward sweep; per lattice state 8 B
+    (beta); per sampled parameter 64 B (count and norm sum read-modify-written twice: old sample out, new sample in)."""
+    d = tempfile.mkdtemp(prefix="crp_")
+    g = lambda n: os.path.join(ROOT, "tests", "golden", n)
+    exe = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
+    pat = re.compile(r"timing: gibbs mode=(\w+) sweeps=(\d+) blocks=(\d+) lattice_states=(\d+) lattice_arcs=(\d+) sampled_params=(\d+) seconds=(\S+)")
+
+    def leg(reps, sweeps, extra):
+        corpus = g("tagging.data")
+        if reps > 1:
+            corpus = os.path.join(d, "corpus%d" % reps)
+            open(corpus, "w").write(open(g("tagging.data")).read() * reps)
+        # two runs, n and 3n sweeps: composition, lattice construction and the first sample cancel in the difference
+        res = []
+        for k in (1, 3):
+            p = subprocess.run([exe, "--gpu=%d" % local_rank, "--crp", "-M", str(k * sweeps), "-R", "7"] + extra + [corpus, g("tagging.fsa"), g("tagging.fst")],
+                               env=dict(os.environ, CARMEL_TIMING="1", CARMEL_TRAINED_DIR=d), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                               universal_newlines=True)
+            m = pat.search(p.stderr)
+            if p.returncode != 0 or not m:
+                raise RuntimeError("front end failed: " + p.stderr[-1500:])
+            res.append(m)
+        n_sw = int(res[1].group(2)) - int(res[0].group(2))
+        sec = float(res[1].group(7)) - float(res[0].group(7))
+        m = res[1]
+        arcs, states, sampled = float(m.group(5)), float(m.group(4)), float(m.group(6))
+        ms = 1e3 * sec / n_sw
+        alg = arcs * (8.0 + 2 * 16.0 + 16.0) + states * 8.0 + sampled * 64.0
+        return {"blocks": int(m.group(3)), "lattice_arcs": int(arcs), "lattice_states": int(states), "sampled_params_per_sweep": int(sampled),
+                "sweeps": n_sw, "ms_per_step": ms, "value": arcs / (ms * 1e-3), "algorithmic_bytes_per_launch": alg,
+                "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+    par = leg(reps_parallel, sweeps_parallel, ["--crp-parallel"])
+    ex = leg(1, sweeps_exact, [])
+    out = {"metric": "lattice-arc updates/sec of Gibbs sweeps (sweeps/sec x derivation-lattice arcs)", "value": par["value"], "unit": "arc-updates/s",
+           "n_gpus": 1, "steps": par["sweeps"], "warmup": 0, "ms_per_step": par["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "carmel-tutorial tagging.* x%d" % reps_parallel,
+           "config": {"workload": "crp: carmel --crp --crp-parallel on the tagging cascade, %d blocks (the tutorial's 1005 sentences x %d), "
+                                  "through the front end; `exact`: the reference's chain on the 1005 blocks" % (par["blocks"], reps_parallel),
+                      "lattice_arcs_per_gpu": par["lattice_arcs"], "lattice_states_per_gpu": par["lattice_states"]},
+           "kernel_ms": par["ms_per_step"],
+           "roofline": {"bound": "hbm", "kernel": "one sweep = gibbs_sweep_parallel + gibbs_recount + gibbs_commit; wall time per sweep "
+                        "(difference of two runs of the front end: launch gaps included)", "achieved": par["frac"] * HBM_PEAK_GBS,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": par["frac"], "traffic": None,
+                        "algorithmic_bytes_per_launch": par["algorithmic_bytes_per_launch"]},
+           "exact": {k: ex[k] for k in ("blocks", "sweeps", "ms_per_step", "value", "frac", "lattice_arcs")}}
+    out["exact"]["unit"] = "arc-updates/s"
+    out["exact"]["note"] = "gibbs_sweep_exact_kernel: one workgroup, blocks strictly in order (latency-bound by construction)"
+    if not args.no_cpu_baseline and rank == 0:
+        from oracle import binding as ob
+        rd = lambda n: open(g(n)).read()
+        oc = ob.OracleCascade([rd("tagging.fsa"), rd("tagging.fst")])
+        corp = oc.corpus(rd("tagging.data"))
+        ob.gibbs_run(oc, corp, 7, normby="CC", priors=[0.0, 0.0], iters=1, burnin=0)
+        n = 120
+        t0 = time.time()
+        ob.gibbs_run(oc, corp, 7, normby="CC", priors=[0.0, 0.0], iters=n - 1, burnin=0)
+        cdt = time.time() - t0
+        out["cpu_baseline"] = {"value": ex["lattice_arcs"] * n / cdt, "unit": "arc-updates/s", "cores": 1, "kind": "port",
+                               "sample": "the oracle's sampler (the reference's chain) on the 1005 sentences, %d sweeps, its own counter-based "
+                                         "uniforms: %.1f ms per sweep" % (n, 1e3 * cdt / n)}
+    return out
+
+
 def run_c3(args, steps, warmup, local_rank=0, rank=0):
     """BASELINE.json configs[2]: the cipher cascade (character bigram LM o substitution channel) through the front end"""
     from carmel_amd import synth
@@ -548,12 +622,68 @@ def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=1):
         of = ob.OracleForests(txt, norm)
         of.set_weights(lw[:of.n_rules] if of.n_rules <= len(lw) else np.concatenate([lw, np.zeros(of.n_rules - len(lw))]))
         t0 = time.time()
-        of.gibbs(lambda i, b, st: lib.carmel_hip_gibbs_uniform(4, i, b, st), 9, burnin=2, alpha=0.1)
+        of.gibbs(4, 9, burnin=2, alpha=0.1)  # (the oracle's own counter-based uniforms: no Python call per draw)
         cdt = time.time() - t0
         out["cpu_baseline"] = {"value": float(of.n_nodes) * 10 / cdt, "unit": "node-updates/s", "cores": 1, "kind": "port",
                                "sample": "the first %d forests (%d nodes), same parameters; 10 exact (sequential) sweeps of the "
-                                         "scalar oracle, uniforms through a callback" % (nf, of.n_nodes)}
+                                         "scalar oracle" % (nf, of.n_nodes)}
     return out
+
+
+def compact_line(out):
+    """the line the driver records: the contract's keys of the headline (texts shortened), every secondary as a handful of
+    numbers.  The driver's record keeps the last 2 000 characters of stdout: all of this fits."""
+    def short(t, n):
+        t = str(t)
+        return t if len(t) <= n else t[:n - 1] + "~"
+
+    def rf(r):
+        return None if not r else {"bound": r.get("bound"), "achieved": _r4(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"),
+                                   "frac": _r4(r.get("frac")), "traffic": _r4(r.get("traffic"))}
+
+    def cb(c):
+        return None if not c else {"value": _r4(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
+                                   "sample": short(c.get("sample", ""), 90)}
+
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: (_r4(out[k]) if isinstance(out.get(k), float) else out.get(k)) for k in keep if k in out}
+    line["metric"] = short(line.get("metric", ""), 90)
+    cfg = out.get("config", {})
+    line["config"] = {"workload": short(cfg.get("workload", ""), 150), "parallelism": cfg.get("parallelism")}
+    line["kernel_ms"] = _r4(out.get("kernel_ms"))
+    line["roofline"] = rf(out.get("roofline"))
+    line["cpu_baseline"] = cb(out.get("cpu_baseline"))
+    if "parity_checked_pairs" in out:
+        line["parity_checked_pairs"] = out["parity_checked_pairs"]
+    if "exposed_exchange_ms" in out:
+        line["exposed_exchange_ms"] = _r4(out["exposed_exchange_ms"])
+    sec = {}
+    for name, r in (out.get("secondary") or {}).items():
+        if "error" in r:
+            sec[name] = {"error": short(r["error"], 80)}
+            continue
+        e = {"ms": _r4(r.get("ms_per_step")), "k_ms": _r4(r.get("kernel_ms")), "frac": _r4((r.get("roofline") or {}).get("frac")),
+             "traffic": _r4((r.get("roofline") or {}).get("traffic")), "cpu": _r4((r.get("cpu_baseline") or {}).get("value")),
+             "value": _r4(r.get("value"))}
+        if "parity_checked_pairs" in r:
+            e["parity"] = r["parity_checked_pairs"]
+        if "exact" in r:
+            e["exact_ms"] = _r4(r["exact"].get("ms_per_step"))
+        sec[name] = e
+    if sec:
+        line["secondary"] = sec
+    line["bench_wall_s"] = _r4(out.get("bench_wall_s"))
+    return line
+
+
+def _r4(x):
+    """four significant digits (None stays None)"""
+    if x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float("%.4g" % x)
+    except (TypeError, ValueError):
+        return x
 
 
 def main():
@@ -561,7 +691,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 20; c5: 1000 sweeps, the length BASELINE.json's config names")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c4", "c4a", "long", "toy", "toya", "c3", "c5", "amb"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c4", "c4a", "long", "toy", "toya", "c3", "c5", "amb", "crp"])
     ap.add_argument("--lines", type=int, default=200000, help="c3: corpus lines")
     ap.add_argument("--forests", type=int, default=100000, help="c5: forests")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU of the headline workload (default: the config's)")
@@ -569,7 +699,9 @@ def main():
                     help="weak: --pairs per GPU; strong: --pairs in total, sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="the headline workload only")
-    ap.add_argument("--secondary", default="c4a,amb,c2,long,c3,c5", help="which workloads follow the headline at N = 1")
+    ap.add_argument("--secondary", default="c4a,amb,c2,long,c3,c5,crp", help="which workloads follow the headline at N = 1")
+    ap.add_argument("--full-out", default=None, help="file for the complete JSON (default: gpurun_out/bench_full.json when that directory "
+                                                      "exists or can be made, else none); stdout carries the compact line")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: host cores, at most 64)")
@@ -588,7 +720,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     t_start = time.time()
-    if args.config in ("c3", "c5", "amb"):
+    if args.config == "crp":
+        out = run_crp(args, local_rank, rank)
+    elif args.config in ("c3", "c5", "amb"):
         out = {"c3": run_c3, "c5": run_c5, "amb": run_amb}[args.config](args, args.steps, args.warmup, local_rank, rank)
     else:
         if world != args.gpus:
@@ -624,7 +758,9 @@ def main():
                     elif name == "c3":
                         r = run_c3(args, args.secondary_steps, 3, local_rank, rank)
                     elif name == "c5":
-                        r = run_c5(args, 1000, 3, local_rank, rank)
+                        r = run_c5(args, 1000, 3, local_rank, rank, exact_sweeps=3)
+                    elif name == "crp":
+                        r = run_crp(args, local_rank, rank)
                     else:
                         r = run_em(name, args, None, 0, 1, local_rank, False, headline=False)
                 except Exception as e:  # noqa: BLE001  (a secondary must not take the headline down with it)
@@ -633,7 +769,20 @@ def main():
                 sec[name] = r
             out["secondary"] = sec
         out["bench_wall_s"] = time.time() - t_start
-        print(json.dumps(out))
+        full = args.full_out
+        if full is None:
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                full = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+            except OSError:
+                full = None
+        if full:
+            try:
+                with open(full, "w") as fh:
+                    fh.write(json.dumps(out) + "\n")
+            except OSError:
+                pass
+        print(json.dumps(compact_line(out)))
 
 
 if __name__ == "__main__":

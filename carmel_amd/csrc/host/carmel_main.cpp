@@ -1095,10 +1095,9 @@ static int run(int argc, char** argv) {
     };
     carmel_hip_gibbs* gs = 0;
     hip_check(carmel_hip_gibbs_create(&gs, t, &go), "carmel_hip_gibbs_create");
-    {
-      carmel_hip_lattice_stats gls;
-      if (carmel_hip_gibbs_lattice_stats(gs, &gls) == CARMEL_HIP_OK) log_lattice_stats(gls, pairs.size());
-    }
+    carmel_hip_lattice_stats gls;
+    std::memset(&gls, 0, sizeof gls);
+    if (carmel_hip_gibbs_lattice_stats(gs, &gls) == CARMEL_HIP_OK) log_lattice_stats(gls, pairs.size());
     if (!init_arc_logw.empty())
       hip_check(carmel_hip_gibbs_set_init_weights(gs, init_arc_logw.data()), "carmel_hip_gibbs_set_init_weights");
     const uint32_t n_runs = go.restarts + 1, per_run = go.iter + 1;
@@ -1149,8 +1148,22 @@ static int run(int argc, char** argv) {
                 "carmel_hip_gibbs_set_observer");
     }
     if (world > 1) hip_check(carmel_hip_gibbs_set_run_share(gs, (uint32_t)rank, (uint32_t)world), "carmel_hip_gibbs_set_run_share");
+    const auto t_g0 = std::chrono::steady_clock::now();
     int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
     uint32_t nblocks = carmel_hip_gibbs_n_blocks(gs);
+    if (std::getenv("CARMEL_TIMING") && rc == CARMEL_HIP_OK) {  // (bench.py --config crp)
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_g0).count();
+      std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_gibbs_max_sample(gs)));
+      uint64_t sampled = 0;
+      if (!go.expectation)
+        for (uint32_t b = 0; b < nblocks; ++b) {
+          uint32_t n = 0;
+          if (carmel_hip_gibbs_get_sample(gs, b, buf.data(), &n) == CARMEL_HIP_OK) sampled += n;
+        }
+      std::cerr << "timing: gibbs mode=" << (go.mode ? "parallel" : "exact") << " sweeps=" << (uint64_t)per_run * n_runs << " blocks=" << nblocks
+                << " lattice_states=" << gls.kept_states << " lattice_arcs=" << gls.kept_arcs << " sampled_params=" << sampled
+                << " seconds=" << sec << std::endl;
+    }
     uint32_t best_run = carmel_hip_gibbs_best_run(gs);
     double my_stats[3] = {0, 0, 0};
     int my_ran = 0;
