@@ -63,18 +63,19 @@ struct FxStage {  // one forest's records and previous sample, on their way
   uint32_t plen;
 };
 
-__device__ __forceinline__ void fx_request(const FExactArgs& A, const uint4 d, uint32_t lane, FxStage& S) {
+__device__ __forceinline__ void fx_request(const uint4* __restrict__ xrec, const uint32_t* s_rules, const uint32_t* s_nn, const uint4 d,
+                                           uint32_t lane, FxStage& S) {
   const uint32_t n = d.y & 0xffffu;
   const uint64_t so = ((uint64_t)(d.w & 0xffffu) << 32) | d.z;
 #pragma unroll
   for (int q = 0; q < FX_NS; ++q) {
     const bool have = lane + q * 64 < n;
-    S.rec[q] = have ? A.xrec[(size_t)d.x + lane + q * 64] : make_uint4(0xffu, 0xffffffu, 0, FX_NONORM);  // (an OR node without children)
+    S.rec[q] = have ? xrec[(size_t)d.x + lane + q * 64] : make_uint4(0xffu, 0xffffffu, 0, FX_NONORM);  // (an OR node without children)
   }
 #pragma unroll
   for (int q = 0; q < FX_NS; ++q) {  // (read past the sample: within its capacity or the buffer's padding)
-    S.sr[q] = A.sample_rules[so + lane + q * 64];
-    S.sn[q] = A.sample_nn[so + lane + q * 64];
+    S.sr[q] = s_rules[so + lane + q * 64];
+    S.sn[q] = s_nn[so + lane + q * 64];
   }
 }
 // the previous sample of the forest about to be resampled leaves the counts (gibbs.hpp:851-852)
@@ -109,21 +110,37 @@ struct FxProd {
   __device__ __forceinline__ double ln() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
-// The register path for a forest of at most NS * 64 nodes: inside pass and walk.  Returns false when the root's value is too
-// small for plain doubles (the caller takes the LDS path); otherwise ns entries: rule, norm group, probability, NS per lane.
-// A node's record (FExactArgs::xrec): x = first child | children << 8 | height << 16 | AND << 31, y = the other children
-// (a byte each, first to visit lowest), z = rule, w = norm group; node ids are bytes (< FX_NODES), 0xff = none.
+// LDS written by some lanes of a wavefront is read by others of the SAME wavefront: LDS operations of a wavefront complete in
+// order, so all it takes is to wait for them and to keep the compiler from moving memory operations across.  (A workgroup
+// barrier would also wait for the global loads in flight: the next forest's prefetch.)
+#define FX_WAVE_SYNC()                                   \
+  do {                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_wave_barrier();                     \
+  } while (0)
+
+// What a forest's walk reads, per node slot of a lane: the node's value, the running sums of its children's shares in the
+// same units (+inf where there is no further child: never passed), its children.
 template <int NS>
-__device__ __forceinline__ bool fx_register_path(const FExactArgs& A, const FxStage& S, const double (&p)[FX_NS], const double U,
-                                                 const uint32_t n, const uint32_t H, const uint32_t f, const uint32_t lane,
-                                                 double* vals, const uint32_t* lr, const uint32_t* ln, const double* lp,
-                                                 uint32_t& ns, uint32_t (&e_r)[FX_NS], uint32_t (&e_n)[FX_NS], double (&e_p)[FX_NS],
-                                                 unsigned long long& t_inside) {
-  // ---- inside (forest.hpp:768-816), in plain doubles: every value is a sum of products of probabilities <= 1, so what
-  // underflows next to a root >= 1e-150 could not have been chosen anyway.  Every node recomputes its value from its
-  // children's once per height: after pass h the nodes of height <= h are final (a node of height h has children below h), and
-  // nobody branches on where it stands.  A missing child reads a slot that holds the operation's neutral element ----
-  double val[NS], c0[NS], c1[NS], c2[NS];
+struct FxWalkTab {
+  double val[NS], t0[NS], t1[NS], t2[NS];
+  uint32_t kk[NS][FX_KIDS];
+};
+
+// ---- inside (forest.hpp:768-816) for a forest of at most NS * 64 nodes, a node per lane slot.  Every node recomputes its
+// value from its children's once per height: after pass h the nodes of height <= h are final (a node of height h has children
+// below h) and nobody branches on where it stands; pass h reads buffer (h - 1) & 1 and writes buffer h & 1.  A missing child
+// reads a slot that holds the operation's neutral element.
+//   EXT = false: plain doubles.  Every value is a sum of products of probabilities <= 1, so what underflows next to a root
+//                >= 1e-150 could not have been chosen anyway; a smaller root returns false and the caller comes back with
+//   EXT = true:  mantissa x 2^exponent per node (vals_e holds the exponents), exact at any depth.
+// A node's record (xrec): x = first child | children << 8 | height << 16 | AND << 31, y = the other children (a byte each,
+// first to visit lowest), z = rule, w = norm group; node ids are bytes (< FX_NODES), 0xff = none.
+template <int NS, bool EXT>
+__device__ __forceinline__ bool fx_inside(const FxStage& S, const double (&p)[FX_NS], const uint32_t n, const uint32_t H,
+                                          const uint32_t lane, double* vals, int* vals_e, FxWalkTab<NS>& W) {
+  double val[NS], c0[NS], c1[NS], c2[NS], tot[NS];
+  int ve[NS];
   uint32_t ka[NS][FX_KIDS];  // LDS slots of the children
   bool is_and[NS];
 #pragma unroll
@@ -133,67 +150,107 @@ __device__ __forceinline__ bool fx_register_path(const FExactArgs& A, const FxSt
     const uint32_t none = is_and[q] ? FX_NODES : FX_NODES + 1;  // 1.0 / 0.0
     const uint32_t kid[FX_KIDS] = {w0 & 0xffu, w1 & 0xffu, (w1 >> 8) & 0xffu, (w1 >> 16) & 0xffu};
 #pragma unroll
-    for (int j = 0; j < FX_KIDS; ++j) ka[q][j] = (uint32_t)j < nch ? kid[j] & (FX_NODES - 1) : none;
+    for (int j = 0; j < FX_KIDS; ++j) {
+      ka[q][j] = (uint32_t)j < nch ? kid[j] & (FX_NODES - 1) : none;
+      W.kk[q][j] = kid[j];
+    }
     val[q] = is_and[q] ? p[q] : 0.0;  // height 0: an AND leaf is its rule's probability
-    vals[lane + q * 64 < n ? lane + q * 64 : FX_NODES + 2] = val[q];
+    ve[q] = 0;
+    if (EXT) val[q] = frexp(val[q], &ve[q]);
+    const uint32_t at = lane + q * 64 < n ? lane + q * 64 : FX_NODES + 2;
+    vals[at] = val[q];
+    if (EXT) vals_e[at] = ve[q];
     c0[q] = c1[q] = c2[q] = 0.0;
+    tot[q] = val[q];
   }
-  __syncthreads();
-  for (uint32_t h = 1; h < H; ++h) {  // pass h reads buffer (h - 1) & 1 and writes buffer h & 1: one barrier a pass
+  FX_WAVE_SYNC();
+  for (uint32_t h = 1; h < H; ++h) {
     const double* rd = vals + ((h - 1) & 1u) * FX_VALS;
     double* wr = vals + (h & 1u) * FX_VALS;
+    const int* rde = vals_e + ((h - 1) & 1u) * FX_VALS;
+    int* wre = vals_e + (h & 1u) * FX_VALS;
     double a[NS][FX_KIDS];
+    int ae[NS][FX_KIDS];
 #pragma unroll
     for (int q = 0; q < NS; ++q)
 #pragma unroll
-      for (int j = 0; j < FX_KIDS; ++j) a[q][j] = rd[ka[q][j]];
+      for (int j = 0; j < FX_KIDS; ++j) {
+        a[q][j] = rd[ka[q][j]];
+        if (EXT) ae[q][j] = rde[ka[q][j]];
+      }
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
-      const double prod = (((p[q] * a[q][0]) * a[q][1]) * a[q][2]) * a[q][3];
-      c0[q] = a[q][0];  // running sums of the children's shares: what the walk compares u * value with
-      c1[q] = a[q][0] + a[q][1];
-      c2[q] = c1[q] + a[q][2];
-      val[q] = is_and[q] ? prod : c2[q] + a[q][3];
+      if (!EXT) {
+        const double prod = (((p[q] * a[q][0]) * a[q][1]) * a[q][2]) * a[q][3];
+        c0[q] = a[q][0];  // running sums of the children's shares: what the walk compares u * value with
+        c1[q] = a[q][0] + a[q][1];
+        c2[q] = c1[q] + a[q][2];
+        tot[q] = c2[q] + a[q][3];
+        val[q] = is_and[q] ? prod : tot[q];
+      } else {
+        // AND: mantissas multiply (five factors in [0.5, 1): no underflow), exponents add; OR: the children's shares in units
+        // of the largest exponent among them (a share 2^-1100 below it counts as nothing, as it would in any arithmetic)
+        int pe;
+        const double pm = frexp(p[q], &pe);
+        int t;
+        const double prod = frexp((((pm * a[q][0]) * a[q][1]) * a[q][2]) * a[q][3], &t);
+        const int prod_e = pe + ae[q][0] + ae[q][1] + ae[q][2] + ae[q][3] + t;
+        const int lo = -(1 << 28);
+        const int e0 = a[q][0] != 0.0 ? ae[q][0] : lo, e1 = a[q][1] != 0.0 ? ae[q][1] : lo, e2 = a[q][2] != 0.0 ? ae[q][2] : lo,
+                  e3 = a[q][3] != 0.0 ? ae[q][3] : lo;
+        const int emax = max(max(e0, e1), max(e2, e3));
+        const double s0 = ldexp(a[q][0], max(e0 - emax, -1100)), s1 = ldexp(a[q][1], max(e1 - emax, -1100)),
+                     s2 = ldexp(a[q][2], max(e2 - emax, -1100)), s3 = ldexp(a[q][3], max(e3 - emax, -1100));
+        c0[q] = s0;
+        c1[q] = s0 + s1;
+        c2[q] = c1[q] + s2;
+        tot[q] = c2[q] + s3;
+        int ts;
+        const double sm = frexp(tot[q], &ts);
+        val[q] = is_and[q] ? prod : sm;
+        ve[q] = is_and[q] ? prod_e : (tot[q] != 0.0 ? emax + ts : 0);
+      }
     }
 #pragma unroll
-    for (int q = 0; q < NS; ++q) wr[lane + q * 64 < n ? lane + q * 64 : FX_NODES + 2] = val[q];
-    __syncthreads();
+    for (int q = 0; q < NS; ++q) {
+      const uint32_t at = lane + q * 64 < n ? lane + q * 64 : FX_NODES + 2;
+      wr[at] = val[q];
+      if (EXT) wre[at] = ve[q];
+    }
+    FX_WAVE_SYNC();
   }
   const double root = vals[((H - 1) & 1u) * FX_VALS + n - 1];
-  if (A.phase_clk) t_inside = __builtin_readcyclecounter();
-  if (!(root >= 1e-150)) return false;
-  // ---- the walk, depth first (forest.hpp:725-758): an AND node is recorded and hands on its children (the first is visited
-  // next, the others wait), an OR node chooses one child with the uniform of its visit.  Everything that steers the walk is
-  // wavefront-uniform and lives in scalar registers: the node, the counters, and the pending nodes -- a byte each, packed into
-  // 128 bits, next to visit lowest (0xff at the bottom ends the walk).  A node's record is read from its lane (v_readlane);
-  // what ITS node would choose with this visit's uniform is worked out by every lane and the visited node's answer read back.
-  // A missing child's threshold is +inf: never passed ----
-  double t0[NS], t1[NS], t2[NS];
-  uint32_t kk[NS][FX_KIDS];
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
-    const uint32_t w0 = S.rec[q].x, w1 = S.rec[q].y, nch = (w0 >> 8) & 0xffu;
+    const uint32_t nch = (S.rec[q].x >> 8) & 0xffu;
     const double inf = __builtin_huge_val();
-    t0[q] = nch > 1 ? c0[q] : inf;
-    t1[q] = nch > 2 ? c1[q] : inf;
-    t2[q] = nch > 3 ? c2[q] : inf;
-    kk[q][0] = w0 & 0xffu;
-    kk[q][1] = w1 & 0xffu;
-    kk[q][2] = (w1 >> 8) & 0xffu;
-    kk[q][3] = (w1 >> 16) & 0xffu;
+    W.val[q] = tot[q];  // (an OR node's: the sum its shares were summed to; AND nodes make no choice)
+    W.t0[q] = nch > 1 ? c0[q] : inf;
+    W.t1[q] = nch > 2 ? c1[q] : inf;
+    W.t2[q] = nch > 3 ? c2[q] : inf;
   }
-  uint32_t samp[NS];
+  return EXT ? root != 0.0 : root >= 1e-150;
+}
+
+// ---- the walk, depth first (forest.hpp:725-758): an AND node is recorded and hands on its children (the first is visited
+// next, the others wait), an OR node chooses one child with the uniform of its visit -- the reference's order of draws.
+// Everything that steers the walk is wavefront-uniform and lives in scalar registers: the node, the counters, and the pending
+// nodes -- a byte each, packed into 128 bits, next to visit lowest (0xff at the bottom ends the walk).  A node's record is
+// read from its lane (v_readlane); what ITS node would choose with this visit's uniform is worked out by every lane and the
+// visited node's answer read back.  Returns the number of recorded nodes; samp[q]: lane i holds the (i + 64 q)-th.
+template <int NS>
+__device__ __forceinline__ uint32_t fx_walk(const FxStage& S, const FxWalkTab<NS>& W, const double U, const uint64_t seed,
+                                            const uint32_t iter, const uint32_t f, const uint32_t n, uint32_t (&samp)[NS]) {
 #pragma unroll
   for (int q = 0; q < NS; ++q) samp[q] = 0;
   unsigned long long pend_lo = 0xffull, pend_hi = 0;
-  uint32_t step = 0, node = n - 1;
-  ns = 0;
+  uint32_t step = 0, node = n - 1, ns = 0;
 #define FX_SLOT(arr) (NS == 1 ? arr[0] : (q ? arr[NS - 1] : arr[0]))
   for (;;) {
     const uint32_t q = NS == 1 ? 0u : node >> 6;
     const uint32_t w0 = fx_rl(NS == 1 ? S.rec[0].x : (q ? S.rec[NS - 1].x : S.rec[0].x), node);
     const uint32_t nch = (w0 >> 8) & 0xffu;
-    bool pop = nch == 0;
+    const bool pop = nch == 0;
     if (w0 & 0x80000000u) {
       if (NS == 1 || ns < 64)
         samp[0] = fx_wl(node, ns, samp[0]);
@@ -208,16 +265,16 @@ __device__ __forceinline__ bool fx_register_path(const FExactArgs& A, const FxSt
       }
       node = w0 & 0xffu;
     } else if (nch) {
-      const double u = step < 64 ? fx_rl(U, step) : gibbs_uniform(A.seed, A.iter, f, step);
+      const double u = step < 64 ? fx_rl(U, step) : gibbs_uniform(seed, iter, f, step);
       ++step;
       // the reference subtracts the children's shares from u * value one by one and stops below zero (random.ipp:111-127):
       // child j is chosen when u * value has passed the sums of the shares before it
-      const double uv = u * FX_SLOT(val);
-      const bool g1 = !(uv < FX_SLOT(t0)), g2 = g1 && !(uv < FX_SLOT(t1)), g3 = g2 && !(uv < FX_SLOT(t2));
-      uint32_t pk = NS == 1 ? kk[0][0] : (q ? kk[NS - 1][0] : kk[0][0]);
-      pk = g1 ? (NS == 1 ? kk[0][1] : (q ? kk[NS - 1][1] : kk[0][1])) : pk;
-      pk = g2 ? (NS == 1 ? kk[0][2] : (q ? kk[NS - 1][2] : kk[0][2])) : pk;
-      pk = g3 ? (NS == 1 ? kk[0][3] : (q ? kk[NS - 1][3] : kk[0][3])) : pk;
+      const double uv = u * FX_SLOT(W.val);
+      const bool g1 = !(uv < FX_SLOT(W.t0)), g2 = g1 && !(uv < FX_SLOT(W.t1)), g3 = g2 && !(uv < FX_SLOT(W.t2));
+      uint32_t pk = NS == 1 ? W.kk[0][0] : (q ? W.kk[NS - 1][0] : W.kk[0][0]);
+      pk = g1 ? (NS == 1 ? W.kk[0][1] : (q ? W.kk[NS - 1][1] : W.kk[0][1])) : pk;
+      pk = g2 ? (NS == 1 ? W.kk[0][2] : (q ? W.kk[NS - 1][2] : W.kk[0][2])) : pk;
+      pk = g3 ? (NS == 1 ? W.kk[0][3] : (q ? W.kk[NS - 1][3] : W.kk[0][3])) : pk;
       node = fx_rl(pk, node);
     }
     if (pop) {
@@ -228,7 +285,24 @@ __device__ __forceinline__ bool fx_register_path(const FExactArgs& A, const FxSt
     }
   }
 #undef FX_SLOT
-  // the sample's entries, NS per lane: rule, norm group, proposal probability of the recorded nodes
+  return ns;
+}
+
+// The register path for a forest of at most NS * 64 nodes: inside pass (plain doubles; with exponents when those underflow),
+// walk, and the sample's entries -- rule, norm group, proposal probability of the recorded nodes, NS per lane.  Returns false
+// only for a forest without any derivation (root value 0).
+template <int NS>
+__device__ __forceinline__ bool fx_register_path(const FxStage& S, const double (&p)[FX_NS], const double U, const uint64_t seed,
+                                                 const uint32_t iter, const uint32_t n, const uint32_t H, const uint32_t f,
+                                                 const uint32_t lane, double* vals, int* vals_e, const uint32_t* lr,
+                                                 const uint32_t* ln, const double* lp, uint32_t& ns, uint32_t (&e_r)[FX_NS],
+                                                 uint32_t (&e_n)[FX_NS], double (&e_p)[FX_NS], unsigned long long* t_inside) {
+  FxWalkTab<NS> W;
+  bool ok = fx_inside<NS, false>(S, p, n, H, lane, vals, vals_e, W);
+  if (!ok) ok = fx_inside<NS, true>(S, p, n, H, lane, vals, vals_e, W);
+  if (t_inside) *t_inside = __builtin_readcyclecounter();
+  uint32_t samp[NS];
+  ns = ok ? fx_walk<NS>(S, W, U, seed, iter, f, n, samp) : 0u;
 #pragma unroll
   for (int q = 0; q < NS; ++q) {
     const bool have = lane + q * 64 < ns;
@@ -243,12 +317,13 @@ __device__ __forceinline__ bool fx_register_path(const FExactArgs& A, const FxSt
     e_n[q] = FX_NONORM;
     e_p[q] = 1.0;
   }
-  return true;
+  return ok;
 }
 
 __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_lds[];
-  __shared__ double vals[2 * FX_VALS];  // register path: node values (plain doubles), two buffers; each ends in 1.0, 0.0 and a slot nobody reads
+  __shared__ double vals[2 * FX_VALS];  // register path: node values, two buffers; each ends in 1.0, 0.0 and a slot nobody reads
+  __shared__ int vals_e[2 * FX_VALS];   // ... their exponents, when plain doubles underflow (the neutral slots: 2^1 x 0.5, 0)
   __shared__ double lp[FX_NODES];     // ... proposal probability of a node's rule
   __shared__ uint32_t lr[FX_NODES], ln[FX_NODES];  // ... its rule and norm group
   const uint32_t lane = threadIdx.x;
@@ -268,6 +343,8 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
   if (lane < 2) {
     vals[lane * FX_VALS + FX_NODES] = 1.0;
     vals[lane * FX_VALS + FX_NODES + 1] = 0.0;
+    vals_e[lane * FX_VALS + FX_NODES] = 0;  // (1.0 = 1.0 x 2^0: the mantissa slot is shared by both arithmetics)
+    vals_e[lane * FX_VALS + FX_NODES + 1] = 0;
   }
   const uint32_t nf = A.n_forests;
   FxProd cheap{1.0, 0}, cnum{1.0, 0}, cden{1.0, 0};  // proposal probability; cache-model probability = cnum / cden
@@ -275,7 +352,7 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
   // ---- the pipeline's preamble: descriptors of forests 0 and 1, records of forest 0, whose previous sample leaves the counts ----
   uint4 d = A.xdesc[0], dn = A.xdesc[min(1u, nf - 1)];
   FxStage S;
-  fx_request(A, d, lane, S);
+  fx_request(A.xrec, A.sample_rules, A.sample_nn, d, lane, S);
   S.plen = A.sample_len[0];
   fx_take_out(A, d, lane, S, S.plen);
   double U = gibbs_uniform(A.seed, A.iter, 0u, lane);  // the walk's first 64 uniforms, one per lane (forest 0's)
@@ -315,7 +392,7 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
     }
     // the next forest's records and previous sample set out now: they have the phases below to arrive
     FxStage T;
-    fx_request(A, dn, lane, T);
+    fx_request(A.xrec, A.sample_rules, A.sample_nn, dn, lane, T);
     T.plen = A.sample_len[min(f + 1, nf - 1)];
     const uint4 dnn = A.xdesc[min(f + 2, nf - 1)];
     if (!slow) {
@@ -323,10 +400,13 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
       for (int q = 0; q < FX_NS; ++q)
         if (lane + q * 64 < n) lp[lane + q * 64] = p[q];
       if (A.phase_clk) t1 = __builtin_readcyclecounter();
-      const bool ok = n <= 64 ? fx_register_path<1>(A, S, p, U, n, H, f, lane, vals, lr, ln, lp, ns, e_r, e_n, e_p, t2)
-                              : fx_register_path<FX_NS>(A, S, p, U, n, H, f, lane, vals, lr, ln, lp, ns, e_r, e_n, e_p, t2);
+      FX_WAVE_SYNC();
+      unsigned long long* tp = A.phase_clk ? &t2 : nullptr;
+      if (n <= 64)
+        fx_register_path<1>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);
+      else
+        fx_register_path<FX_NS>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);
       if (A.phase_clk) t3 = __builtin_readcyclecounter();
-      slow = !ok;  // (the LDS path's arithmetic carries its own exponents)
     }
     if (!slow) {
       // ---- the new sample goes into the counts with the next forest's previous sample coming out; the cache-model counts

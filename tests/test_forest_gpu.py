@@ -1,5 +1,6 @@
 """GPU: forest-em kernels (inside / outside / counts / M-step / Gibbs) through the C-ABI against the oracle."""
 import os
+import math
 
 import numpy as np
 import pytest
@@ -408,3 +409,33 @@ def test_several_lanes_per_forest_sampler(oracle, shape):
     # (where the chain settles is checked on the enumerated stationary distribution, tests/test_bench_workloads_gpu.py: after eight
     # sweeps two chains with different draws are still 10 % apart on these corpora)
     assert np.all(np.isfinite(a[0])) and np.all(a[0] < 0)
+
+
+def test_exact_chain_on_deep_spines_whose_values_underflow_plain_doubles(oracle):
+    """forest_exact.hip's register path works in plain doubles and comes back with mantissa x 2^exponent arithmetic when a
+    forest's root value underflows: every forest is an OR over two spines of 55 AND nodes whose rules sit in ONE norm group of
+    3000 (every proposal probability ~ 1/3000, every derivation ~ 10^-190), each ending in an OR.  Draw for draw the oracle's
+    chain, as everywhere."""
+    rng = np.random.default_rng(31)
+    n_rules = 3000
+
+    def spine():
+        t = "(OR %d %d)" % tuple(rng.integers(1, n_rules, 2))
+        for d in range(55):
+            t = "(%d %s)" % (rng.integers(1, n_rules), t)
+        return t
+
+    ftext = "\n".join("(OR %s %s)" % (spine(), spine()) for _ in range(40)) + "\n"
+    ntext = "((" + " ".join(str(r) for r in range(1, n_rules)) + "))"
+    of, hf = make(oracle, ftext, ntext, 3)
+    assert of.n_nodes <= 40 * 128
+    iters = 5
+    hf.gibbs(iters, burnin=1, alpha=0.3, seed=9, mode=0)
+    ref = of.gibbs(9, iters, burnin=1, alpha=0.3)
+    assert min(len(s) for s in ref["samples"]) > 50 and ref["iter_cheap_logprob"][-1] < -40 * 150 * math.log(10)
+    for b in range(hf.n_forests):
+        assert hf.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(hf.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(hf.weights()), np.exp(of.weights()), rtol=1e-9, atol=1e-15)
+    hf.close()
