@@ -88,6 +88,29 @@ def pmc_traffic(config, walk_arcs, n_pairs):
     return tot
 
 
+SWEEP_KERNELS = ("forest_proposal_kernel", "forest_sample_kernel", "forest_sample_multi_kernel", "forest_recount_kernel",
+                 "forest_commit_kernel", "forest_gibbs_kernel")
+
+
+def pmc_traffic_c5(n_forests):
+    """HBM-side bytes per parallel sweep of config 5 from the committed PMC passes (tools/pmc_traffic.sh c5 -> profiles/
+    pmc_traffic_c5.json), FETCH_SIZE doubled as for the EM workloads; None unless the profile is of this forest.hip and size"""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_c5.json")
+    if not os.path.exists(path) or any(k.startswith("CARMEL_HIP_") for k in os.environ):
+        return None
+    d = json.load(open(path))
+    src = os.path.join(ROOT, "carmel_amd", "csrc", "forest.hip")
+    if d.get("forests") != n_forests or not d.get("sweep_count") or \
+            d.get("forest_hip_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+        return None
+    tot = 0.0
+    for name, k in d["kernels"].items():
+        if any(e in name for e in SWEEP_KERNELS) and k["fetch_kb_per_launch"] is not None:
+            tot += k["launches"] / d["sweep_count"] * (2.0 * k["fetch_kb_per_launch"] + (k["write_kb_per_launch"] or 0.0)) * 1024.0
+    return tot
+
+
 def _replicas(value):
     """c3 / c5 / amb as the headline at N > 1: independent replicas, one per GPU (no data-path collective: SURVEY 8e --
     the sampler does not shard exactly, and config 3's model is 758 parameters); the job's value is the sum over the ranks"""
@@ -601,7 +624,7 @@ def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=1):
            "roofline": {"bound": "hbm", "kernel": "one sweep = forest_proposal + forest_sample (per launch class) + forest_recount; "
                         "timed as wall time per sweep around carmel_hip_forests_gibbs (launch gaps included)",
                         "achieved": alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg}}
+                        "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic_c5(args.forests), "algorithmic_bytes_per_launch": alg}}
     if exact_sweeps:
         # the reference's chain (forests strictly in order): a parity device, latency-bound by construction
         hf.set_weights(lw)

@@ -41,8 +41,14 @@ def main():
     # which build of the kernels these counters belong to: bench.py reports them only for the same sources
     import hashlib
     import os
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carmel_amd", "csrc", "kernels.hip")
-    meta["kernels_hip_sha16"] = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carmel_amd", "csrc")
+    meta["kernels_hip_sha16"] = hashlib.sha256(open(os.path.join(csrc, "kernels.hip"), "rb").read()).hexdigest()[:16]
+    if cfg == "c5":  # the sampler's sweeps: one forest_commit_kernel launch per parallel sweep
+        commits = [v["launches"] for k, v in kernels.items() if "forest_commit_kernel" in k]
+        meta.update({"forests": 100000, "sweep_count": max(commits) if commits else 0,
+                     "forest_hip_sha16": hashlib.sha256(open(os.path.join(csrc, "forest.hip"), "rb").read()).hexdigest()[:16],
+                     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c5 --steps 3 "
+                                "--warmup 1 --no-cpu-baseline --no-secondary --no-exchange-loopback  [tools/pmc_traffic.sh]"})
     meta["kernels"] = kernels
     print(json.dumps(meta, indent=1))
 
