@@ -523,7 +523,7 @@ def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, s
                         "algorithmic_bytes_per_launch": par["algorithmic_bytes_per_launch"]},
            "exact": {k: ex[k] for k in ("blocks", "sweeps", "ms_per_step", "value", "frac", "lattice_arcs")}}
     out["exact"]["unit"] = "arc-updates/s"
-    out["exact"]["note"] = "gibbs_sweep_exact_kernel: one workgroup, blocks strictly in order (latency-bound by construction)"
+    out["exact"]["note"] = "gibbs_exact_wave_kernel: one wavefront, blocks strictly in order (the reference's chain; latency-bound by construction)"
     if not args.no_cpu_baseline and rank == 0:
         from oracle import binding as ob
         rd = lambda n: open(g(n)).read()

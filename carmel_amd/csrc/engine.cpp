@@ -140,8 +140,6 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   t->matrix = nullptr;
   if (t->ev0) (void)hipEventDestroy(t->ev0);
   if (t->ev1) (void)hipEventDestroy(t->ev1);
-  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
-  t->graph_exec = nullptr;
   if (t->side) (void)hipStreamSynchronize(t->side);
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
@@ -210,7 +208,6 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
-  if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;  // A/B: 0 = no one-per-wavefront lattices (bundles as before)
   if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
   if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
   {
@@ -1011,51 +1008,14 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   return CARMEL_HIP_OK;
 }
 
-// The E-step is a fixed chain of a dozen small launches with unchanging arguments (the weights change in place), so it
-// can be captured once into a hipGraph and replayed -- one submission per E-step.  Measured on MI355X / ROCm 7.2
-// (bench.py, graph vs eager): config 2 0.185 vs 0.167 ms per iteration, config 4 0.763 vs 0.743 ms -- the replay is
-// SLOWER than the eager launches here, so it is opt-in (CARMEL_HIP_GRAPH=1), not the default.
-static void estimate_graph_drop(carmel_hip_trainer* t) {
-  if (t->graph_exec) (void)hipGraphExecDestroy(t->graph_exec);
-  t->graph_exec = nullptr;
-}
+// (The E-step is a fixed chain of a dozen small launches with unchanging arguments, so it could be captured once into a
+// hipGraph and replayed.  Measured on MI355X / ROCm 7.2 in rounds 1, 3 and 4: the replay is SLOWER than the eager launches --
+// config 2 0.155 vs 0.132 ms per iteration, config 4 0.763 vs 0.743 -- so the capture path is gone.)
 int carmel_hip_estimate_async(carmel_hip_trainer* t) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
   if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
   HIPCHK(hipSetDevice(t->device));
-  hipStream_t s = t->stream;
-  const bool want = getenv("CARMEL_HIP_GRAPH") && atoi(getenv("CARMEL_HIP_GRAPH")) != 0 && !getenv("CARMEL_HIP_LANE_TRACE");
-  const void* key = (const void*)t->counts_ptr();
-  if (!want || t->graph_failed || t->xplan) return estimate_enqueue(t, true);
-  if (t->graph_exec && (t->graph_key != key || t->graph_epoch != t->lattice_epoch)) estimate_graph_drop(t);
-  if (!t->graph_exec) {
-    if (t->estimates_done == 0 || t->graph_epoch_first != t->lattice_epoch) {  // first call on these lattices: eager (one-time
-      t->graph_epoch_first = t->lattice_epoch;                                  // function attributes are set outside a capture)
-      t->estimates_done = 1;
-      return estimate_enqueue(t, true);
-    }
-    hipGraph_t graph = nullptr;
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
-      t->graph_failed = true;
-      return estimate_enqueue(t, true);
-    }
-    const int rc = estimate_enqueue(t, false);
-    const hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc != CARMEL_HIP_OK || e != hipSuccess || !graph || hipGraphInstantiate(&t->graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
-      if (graph) (void)hipGraphDestroy(graph);
-      (void)hipGetLastError();
-      t->graph_exec = nullptr;
-      t->graph_failed = true;
-      return estimate_enqueue(t, true);
-    }
-    (void)hipGraphDestroy(graph);
-    t->graph_key = key;
-    t->graph_epoch = t->lattice_epoch;
-  }
-  HIPCHK(hipEventRecord(t->ev0, s));
-  HIPCHK(hipGraphLaunch(t->graph_exec, s));
-  HIPCHK(hipEventRecord(t->ev1, s));
-  return CARMEL_HIP_OK;
+  return estimate_enqueue(t, true);
 }
 
 int carmel_hip_set_layout_policy(carmel_hip_trainer* t, int allow_unrolled) {

@@ -150,11 +150,7 @@ struct carmel_hip_trainer {
   DevBuf<uint16_t> d_Bslot, d_sym;
   DevBuf<uint64_t> d_sym_off, d_vbuf_off;
   // the E-step as a replayed hipGraph (engine.cpp: carmel_hip_estimate_async)
-  hipGraphExec_t graph_exec = nullptr;
-  const void* graph_key = nullptr;
-  uint64_t lattice_epoch = 0, graph_epoch = 0, graph_epoch_first = ~0ull;
-  int estimates_done = 0;
-  bool graph_failed = false;
+  uint64_t lattice_epoch = 0;
   bool use_transpose = false;
   bool em_valid = false;  // em_logw holds the plain EM update of the last (over-relaxed) maximize
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only

@@ -21,6 +21,8 @@
 #include <limits>
 #include <memory>
 #include "engine.hpp"
+#include "forest_exact.hpp"
+#include "gibbs_exact.hpp"
 #include "rng.hpp"
 
 namespace carmel_hip {
@@ -655,6 +657,10 @@ struct carmel_hip_gibbs {
   DevBuf<double> pair_logw, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, ccount, csum, snap_x, snap_norm, gw, beta,
       iter_out;
   std::vector<uint64_t> h_sample_off;
+  // the wavefront path of the exact chain (gibbs_exact.hip): per-block descriptors, per-lattice-arc records
+  bool wave_ok = false;
+  DevBuf<GxBlock> gx_blocks;
+  DevBuf<uint32_t> gx_rec, gx_nrm, sample_nrm;
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
   // runs as replicas (carmel_hip_gibbs_set_run_share): this sampler takes the runs r with r % run_stride == run_first
@@ -780,7 +786,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   HIPCHK(g->prior_norm.upload(pn, s));
   HIPCHK(g->sample_off.upload(g->h_sample_off, s));
   HIPCHK(g->sample_len.alloc(bb.size()));
-  HIPCHK(g->sample_ids.alloc(g->h_sample_off.back()));
+  HIPCHK(g->sample_ids.alloc(g->h_sample_off.back() + 128));  // (+ gibbs_exact.hip's staging reads a fixed number of words ahead)
   if (o->mode == 1) {
     HIPCHK(g->new_len.alloc(bb.size()));
     HIPCHK(g->new_ids.alloc(g->h_sample_off.back()));
@@ -815,6 +821,57 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       }
     }
     HIPCHK(g->ent_base.upload(eb, s));
+  }
+  // ---- the exact chain's wavefront path (gibbs_exact.hip): eligible when every block is an acyclic lattice within its LDS
+  // tables and every composed arc stands for at most two parameters ----
+  if (o->mode == 0 && !o->expectation && max_chain <= 2) {
+    bool ok = true;
+    for (size_t b = 0; b < bb.size() && ok; ++b) {
+      const BundleDesc& d = L.bundles[bb[b]];
+      ok = !(d.flags & 1u) && d.n_arcs <= GX_ARCS && d.n_states <= GX_STATES && d.n_levels <= GX_LEVELS &&
+           (uint64_t)d.n_levels * max_chain <= GX_SAMPLE && d.out_base + d.n_arcs <= 0xffffffffull && d.off_base <= 0xffffffffull;
+      if (ok) {  // (the goal has no way on: its backward value is the 1 it starts with)
+        const uint32_t fin = L.pair_final[d.pair_base];
+        ok = L.out_off[d.off_base + fin + 1] == L.out_off[d.off_base + fin];
+      }
+    }
+    if (ok) {
+      std::vector<GxBlock> gb(bb.size());
+      std::vector<uint32_t> rec(4 * L.out_arcs.size(), 0xffffffffu), nrm(2 * L.out_arcs.size(), 0xffffffffu);
+      for (size_t b = 0; b < bb.size(); ++b) {
+        const BundleDesc& d = L.bundles[bb[b]];
+        GxBlock& B = gb[b];
+        B.out_base = (uint32_t)d.out_base;
+        B.off_base = (uint32_t)d.off_base;
+        B.level_base = d.level_base;
+        B.n_arcs = (uint32_t)d.n_arcs;
+        B.n_states = d.n_states;
+        B.n_levels = d.n_levels;
+        B.start = L.pair_start[d.pair_base];
+        B.fin = L.pair_final[d.pair_base];
+        B.sample_off = g->h_sample_off[b];
+        B.wt = std::exp(L.pair_logw[d.pair_base]);
+        const uint32_t* ooff = L.out_off.data() + d.off_base;
+        for (uint32_t st = 0; st < d.n_states; ++st)
+          for (uint32_t a = ooff[st]; a < ooff[st + 1]; ++a) {
+            const uint2_t oa = L.out_arcs[d.out_base + a];
+            uint32_t* r = &rec[4 * (d.out_base + a)];
+            uint32_t* n = &nrm[2 * (d.out_base + a)];
+            r[0] = oa.x | (st << 16);
+            r[1] = oa.y;
+            const uint64_t c0 = coff[oa.y], c1 = coff[oa.y + 1];
+            for (uint64_t j = c0; j < c1; ++j) {
+              r[2 + (j - c0)] = cpar[j];
+              n[j - c0] = g->h_norm[cpar[j]];
+            }
+          }
+      }
+      HIPCHK(g->gx_blocks.upload(gb, s));
+      HIPCHK(g->gx_rec.upload(rec, s));
+      HIPCHK(g->gx_nrm.upload(nrm, s));
+      HIPCHK(g->sample_nrm.alloc(g->h_sample_off.back() + 128));
+      g->wave_ok = true;
+    }
   }
   HIPCHK(g->iter_out.alloc(4));
   HIPCHK(hipStreamSynchronize(s));
@@ -1004,6 +1061,38 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.want_after = iter_after_logprob ? 1 : 0;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
+  // the wavefront path runs the default chain: sampling at temperature 1 with the block's own sample taken out first
+  const bool wave_run = g->wave_ok && g->opt.mode == 0 && !g->opt.expectation && !g->opt.include_self &&
+                        (g->opt.high_temp == 0 || g->opt.high_temp == 1) && (g->opt.low_temp == 0 || g->opt.low_temp == 1) &&
+                        !getenv("CARMEL_HIP_GIBBS_WORKGROUP");
+  GxArgs GX;
+  std::memset(&GX, 0, sizeof GX);
+  DevBuf<unsigned long long> gx_clk;
+  if (wave_run) {
+    GX.blocks = g->gx_blocks.p;
+    GX.arc_rec = (const uint4*)g->gx_rec.p;
+    GX.arc_nrm = (const uint2*)g->gx_nrm.p;
+    GX.out_off = g->out_off.p;
+    GX.level_off = g->level_off.p;
+    GX.p_norm = g->p_norm.p;
+    GX.p_prior = g->p_prior.p;
+    GX.p_x = g->p_x.p;
+    GX.normsum = g->normsum.p;
+    GX.ccount = g->ccount.p;
+    GX.csum = g->csum.p;
+    GX.sample_len = g->sample_len.p;
+    GX.sample_ids = g->sample_ids.p;
+    GX.sample_nrm = g->sample_nrm.p;
+    GX.iter_out = g->iter_out.p;
+    GX.seed = g->opt.seed;
+    GX.n_blocks = g->n_blocks;
+    GX.want_after = iter_after_logprob ? 1 : 0;
+    if (getenv("CARMEL_HIP_GIBBS_CLK")) {
+      HIPCHK(gx_clk.alloc(8));
+      HIPCHK(hipMemsetAsync(gx_clk.p, 0, 64, s));
+      GX.phase_clk = gx_clk.p;
+    }
+  }
   // gibbs_opts::validate (gibbs_opts.hpp:253-266): --final-counts makes every sweep but the last burn-in; burnin <= iter
   const uint32_t Ni = g->opt.iter, burnin = g->opt.final_counts ? g->opt.iter : std::min(g->opt.burnin, g->opt.iter);
   const uint32_t n_runs = g->opt.restarts + 1;
@@ -1045,7 +1134,16 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 4 * sizeof(double), s));
-    if (g->opt.mode == 0) {
+    if (g->opt.mode == 0 && wave_run) {
+      // the chain on one wavefront (gibbs_exact.hip); delta_sum's fold for every parameter at once: at the start of a sweep every
+      // count is what the previous sweep left, which is what the reference folds at a parameter's first touch (delta_sum.hpp:74-84)
+      HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      HIPCHK(launch_forest_fold(g->p_s.p, g->p_tmax.p, g->p_x.p, G.time, np, s));
+      GX.iter = G.iter;
+      GX.init_logw = G.init_logw;
+      HIPCHK(launch_gibbs_exact_wave(GX, s));
+    } else if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
       {
@@ -1143,6 +1241,14 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     }
     // maybe_print_periodic (gibbs.hpp:959-968): the caller looks at the sample and the counts as they stand after this sweep
     if (g->obs_fn && g->obs_every && iter % g->obs_every == 0) g->obs_fn(g->obs_ctx, run, iter, G.time);
+  }
+  if (gx_clk.n) {
+    unsigned long long c[8];
+    HIPCHK(hipMemcpy(c, gx_clk.p, sizeof c, hipMemcpyDeviceToHost));
+    if (c[4])
+      fprintf(stderr, "[carmel_hip] gibbs_exact_wave cycles per block: wait+weights %.0f, backward %.0f, walk %.0f, counts %.0f (%llu blocks x sweeps)\n",
+              c[0] / (double)c[4], c[1] / (double)c[4], c[2] / (double)c[4], c[3] / (double)c[4], c[4]);
+    HIPCHK(hipMemset(gx_clk.p, 0, 64));
   }
   // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
   if (g->pi_stddev > 0) {  // the priors have moved

@@ -1,0 +1,48 @@
+// gibbs_exact.hpp — `carmel --crp`'s reference chain (blocks strictly in order) as one persistent wavefront per sweep
+// (gibbs_exact.hip); arguments as gibbs.hip's carmel_hip_gibbs_run_ex fills them.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace carmel_hip {
+
+// a block of the wavefront path: an acyclic lattice of at most GX_ARCS arcs / GX_STATES states / GX_LEVELS levels whose
+// composed arcs stand for at most two parameters; anything else keeps gibbs.hip's workgroup kernel (the same chain)
+#define GX_ARCS 1024
+#define GX_STATES 512
+#define GX_LEVELS 512
+#define GX_SAMPLE 1024
+
+struct GxBlock {  // 48 bytes per block, in corpus order (the order of the chain)
+  uint32_t out_base, off_base, level_base, n_arcs;  // into the per-lattice-arc / per-state / per-level arrays
+  uint32_t n_states, n_levels, start, fin;
+  uint64_t sample_off;
+  double wt;  // the pair's weight (counts move by it)
+};
+
+struct GxArgs {
+  const GxBlock* blocks;
+  const uint4* arc_rec;       // per lattice arc: {destination | source << 16, composed arc, parameter 0, parameter 1 (0xffffffff: none)}
+  const uint2* arc_nrm;       // ... their norm groups (0xffffffff: a fixed probability, the parameter's prior)
+  const uint32_t* out_off;    // per state: first out-arc (bundle-relative), n_states + 1 per block
+  const uint32_t* level_off;  // per level: first state, n_levels + 1 per block
+  const uint32_t* p_norm;
+  const double* p_prior;
+  double* p_x;                // CRP counts; their time-weighted sums are folded once per sweep (launch_forest_fold)
+  double* normsum;
+  double* ccount;             // cache model of this sweep (gibbs.hpp:712-742)
+  double* csum;
+  uint32_t* sample_len;
+  uint32_t* sample_ids;       // per block: parameter ids along the sampled path, chain order ...
+  uint32_t* sample_nrm;       // ... and their norm groups
+  const double* init_logw;    // --init-em / --init-from-p0: per composed arc, what the first sweep samples from (null: the counts)
+  double* iter_out;           // {ln cache-model prob, ln proposal prob, ln proposal prob after the add-back}
+  unsigned long long* phase_clk;
+  uint64_t seed;
+  uint32_t iter, n_blocks;
+  int want_after;
+};
+
+hipError_t launch_gibbs_exact_wave(const GxArgs& A, hipStream_t s);
+
+}  // namespace carmel_hip

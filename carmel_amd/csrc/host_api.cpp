@@ -54,7 +54,6 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   // lane_states = 0 asks for the plain inspection form -- every lattice a bundle (with small_pairs = 1: one lattice each),
   // what the front end's --fem-forest export walks -- unless a test forces the one-per-wavefront layout explicitly
   if (lane_states == 0 && !getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave = false;
-  if (const char* e = getenv("CARMEL_HIP_WAVE")) opt.wave = atoi(e) != 0;
   if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;
   if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {

@@ -1444,36 +1444,15 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   LaneArgs A = A0;
   A.first_group = lc.first;
   size_t lds = (size_t)lc.max_states * 64 * sizeof(double);
-  static const int lds_scale = getenv("CARMEL_HIP_LANE_LDS_SCALE") ? atoi(getenv("CARMEL_HIP_LANE_LDS_SCALE")) : 1;
-  lds *= lds_scale;  // occupancy experiment
-  static const int V = getenv("CARMEL_HIP_LANE_VARIANT") ? atoi(getenv("CARMEL_HIP_LANE_VARIANT")) : 0;  // tuning knob
+  // ring depths per form, measured (tagging cascade x400, windowed: <4,2> 495 us, <4,1> 511, <3,1> 534, <3,2> 643; streaming
+  // with weights in lattice order: two chunks ahead is enough, and the smaller ring leaves more registers / less code)
   if (lc.windowed) {
     if (!A.spill) return hipErrorInvalidValue;
-    if (A.pre_weights) {
-      switch (V) {  // tagging cascade x400: <4,2> 495 us, <4,1> 511, <3,1> 534, <3,2> 643
-        case 6: return launch_lane_variant<3, 1, true, true>(A, lc.count, lds, stream);
-        case 3: return launch_lane_variant<4, 1, true, true>(A, lc.count, lds, stream);
-        case 5: return launch_lane_variant<3, 2, true, true>(A, lc.count, lds, stream);
-        default: return launch_lane_variant<4, 2, true, true>(A, lc.count, lds, stream);
-      }
-    }
+    if (A.pre_weights) return launch_lane_variant<4, 2, true, true>(A, lc.count, lds, stream);
     return launch_lane_variant<4, 2, false, true>(A, lc.count, lds, stream);
   }
-  if (A.pre_weights) {
-    switch (V) {  // streaming only: two chunks ahead is enough, and the smaller ring leaves more registers / less code
-      case 1: return launch_lane_variant<4, 2, true>(A, lc.count, lds, stream);
-      case 2: return launch_lane_variant<2, 1, true>(A, lc.count, lds, stream);
-      case 3: return launch_lane_variant<4, 1, true>(A, lc.count, lds, stream);
-      case 4: return launch_lane_variant<5, 1, true>(A, lc.count, lds, stream);
-      case 5: return launch_lane_variant<3, 2, true>(A, lc.count, lds, stream);
-      default: return launch_lane_variant<3, 1, true>(A, lc.count, lds, stream);
-    }
-  }
-  switch (V) {
-    case 1: return launch_lane_variant<2, 1, false>(A, lc.count, lds, stream);
-    case 2: return launch_lane_variant<6, 3, false>(A, lc.count, lds, stream);
-    default: return launch_lane_variant<4, 2, false>(A, lc.count, lds, stream);
-  }
+  if (A.pre_weights) return launch_lane_variant<3, 1, true>(A, lc.count, lds, stream);
+  return launch_lane_variant<4, 2, false>(A, lc.count, lds, stream);
 }
 
 hipError_t launch_wave_sweep(const WaveArgs& A0, const LatticeSet::WaveClass& wc, hipStream_t stream) {
@@ -1656,35 +1635,25 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
   if (!M.n) return hipSuccess;
-  static const bool dbg = getenv("CARMEL_HIP_DEBUG") != nullptr;
-#define MSTEP_DBG(what) if (dbg) { hipError_t de = hipStreamSynchronize(s); fprintf(stderr, "[carmel_hip] mstep %s: %s\n", what, hipGetErrorString(de)); }
-  if (dbg) fprintf(stderr, "[carmel_hip] mstep n=%llu groups=%llu ties=%llu logw=%p counts=%p group=%p norm_of=%p off=%p perm=%p tie_of=%p tie_tab=%p add=%p prior=%p\n", (unsigned long long)M.n, (unsigned long long)M.n_groups, (unsigned long long)M.n_ties, (void*)M.logw, (void*)M.counts, (void*)M.group, (void*)M.norm_of, (void*)M.group_off, (void*)M.norm_perm, (void*)M.tie_of, (void*)M.tie_tab, (void*)M.add_count, (void*)M.prior);
   if (M.window_span && !(M.n_ties && M.tie_of)) {
     if (M.lw_src)
       hipLaunchKernelGGL(mstep_window_kernel<true>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
     else
       hipLaunchKernelGGL(mstep_window_kernel<false>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);
-    MSTEP_DBG("window")
   } else {
     if (M.n_ties && M.tie_of) {
       hipError_t e = hipMemsetAsync(M.tie_tab, 0, 4 * M.n_ties * sizeof(double), s);
       if (e != hipSuccess) return e;
-      MSTEP_DBG("memset ties")
       hipLaunchKernelGGL(mstep_tie_sums_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
       hipLaunchKernelGGL(mstep_tie_accum_kernel, dim3(grid_for(M.n, 256)), dim3(256), 0, s, M, use_counts);
-      MSTEP_DBG("tie_accum")
       hipLaunchKernelGGL(mstep_tie_weight_kernel, dim3((unsigned)((M.n_ties + 255) / 256)), dim3(256), 0, s, M);
-      MSTEP_DBG("tie_weight")
     }
     if (M.n_groups) hipLaunchKernelGGL(mstep_group_sum_kernel, dim3(grid_for(M.n_groups, 256)), dim3(256), 0, s, M, use_counts);
     if (M.n_big) hipLaunchKernelGGL(mstep_big_group_kernel, dim3((unsigned)M.n_big), dim3(256), 0, s, M, use_counts);
-    MSTEP_DBG("group sums")
     hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
   }
   hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID,
                      M.max_change_bits);
-  MSTEP_DBG("normalize + max")
-#undef MSTEP_DBG
   return hipGetLastError();
 }
 hipError_t launch_mstep_window_range(const MstepArgs& M0, int use_counts, uint32_t block_first, uint32_t n_blocks, hipStream_t s) {

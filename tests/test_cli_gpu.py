@@ -610,12 +610,12 @@ def test_crp_tagging_against_the_recorded_run(golden_dir, tmp_path):
     """$CARMEL --crp -M 6000 tagging.data tagging.fsa tagging.fst (commands:33; trace lines 6976-12990), the only
     reference-held data for the sampler: the lattice statistics exactly, the level of the per-sweep sample probability
     within a band (see tests/test_gibbs_host.py::test_oracle_sampler_reaches_the_recorded_probability_level for what
-    the recorded binary logged and why the band is 0.2 %).  Exact mode, 1200 sweeps (the recorded chain is level from
+    the recorded binary logged and why the band is 0.2 %).  Exact mode, 700 sweeps (the recorded chain is level from
     sweep ~500 on; its per-1000-sweep means lie within 2^-214294 .. 2^-214366)."""
     import numpy as np
     gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["tagging-crp"]
     g = lambda n: os.path.join(golden_dir, n)
-    rc, out, err = run(["--crp", "-M", "1200", "--init-from-p0", "--sample-prob-after", "-R", "1", "-HJ", g("tagging.data"),
+    rc, out, err = run(["--crp", "-M", "700", "--init-from-p0", "--sample-prob-after", "-R", "1", "-HJ", g("tagging.data"),
                         g("tagging.fsa"), g("tagging.fst")], env={"CARMEL_TRAINED_DIR": str(tmp_path)})
     assert rc == 0, err
     assert "(46 states / 400994 arcs)" in err
@@ -624,7 +624,7 @@ def test_crp_tagging_against_the_recorded_run(golden_dir, tmp_path):
     assert "Post pruning: (%d states, %d arcs)" % (gold["post_states_last_pair"], gold["post_arcs_last_pair"]) in err
     assert "Portion kept: (0.75 states, 0.000896709 arcs)" in err  # trace line 6986
     lines = [l for l in err.split("\n") if l.startswith("Gibbs i=")]
-    assert len(lines) == 1201
+    assert len(lines) == 701
     assert "per-point-ppx(N=%d)" % gold["n_symbols"] in lines[0] and "per-block-ppx(N=%d)" % gold["n_blocks"] in lines[0]
     got = np.array([float(re.search(r"prob=2\^(\S+)", l).group(1)) for l in lines])
     rec = np.array(gold["log2_sample_prob"])

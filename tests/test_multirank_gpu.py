@@ -200,16 +200,18 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     common = ["--config", "c2", "--pairs", "6000", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-secondary",
               "--comm-plugin", PLUGIN]
     env = dict(os.environ)
-    one = subprocess.run([sys.executable, bench, "--gpus", "1"] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    f1, f2 = str(tmp_path / "one.json"), str(tmp_path / "two.json")  # (stdout carries the compact line, --full-out everything)
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--full-out", f1] + common, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          universal_newlines=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     port = 29800 + os.getpid() % 150
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--scaling", "strong"] + common,
+                          "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2", "--scaling", "strong", "--full-out", f2] + common,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600)
     assert two.returncode == 0, two.stderr[-2000:]
-    j1 = json.loads([l for l in one.stdout.split("\n") if l.startswith("{")][-1])
-    j2 = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][-1])
+    c2 = json.loads([l for l in two.stdout.split("\n") if l.startswith("{")][-1])
+    assert c2["n_gpus"] == 2 and c2["scaling"] == "strong" and c2["roofline"]["frac"] > 0 and len(json.dumps(c2)) < 2000
+    j1, j2 = json.load(open(f1)), json.load(open(f2))
     assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
     assert j2["config"]["pairs_per_gpu"] == 3000 and "corpus-sharded x2" in j2["config"]["parallelism"]
     assert j2["value"] > 0 and j2["roofline"]["frac"] > 0
