@@ -517,7 +517,7 @@ def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, s
                                   "through the front end; `exact`: the reference's chain on the 1005 blocks" % (par["blocks"], reps_parallel),
                       "lattice_arcs_per_gpu": par["lattice_arcs"], "lattice_states_per_gpu": par["lattice_states"]},
            "kernel_ms": par["ms_per_step"],
-           "roofline": {"bound": "hbm", "kernel": "one sweep = gibbs_sweep_parallel + gibbs_recount + gibbs_commit; wall time per sweep "
+           "roofline": {"bound": "hbm", "kernel": "one sweep = gibbs_exact_wave_kernel<PAR> (a wavefront per block, two launch classes) + gibbs_recount_tables + gibbs_commit; wall time per sweep "
                         "(difference of two runs of the front end: launch gaps included)", "achieved": par["frac"] * HBM_PEAK_GBS,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": par["frac"], "traffic": None,
                         "algorithmic_bytes_per_launch": par["algorithmic_bytes_per_launch"]},

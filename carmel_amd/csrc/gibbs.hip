@@ -660,7 +660,13 @@ struct carmel_hip_gibbs {
   // the wavefront path of the exact chain (gibbs_exact.hip): per-block descriptors, per-lattice-arc records
   bool wave_ok = false;
   DevBuf<GxBlock> gx_blocks;
-  DevBuf<uint32_t> gx_rec, gx_nrm, sample_nrm;
+  DevBuf<uint32_t> gx_rec, gx_nrm, sample_nrm, new_nrm;
+  uint32_t cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
+  // parallel sweep: two launch classes by LDS need (the blocks up to the 90th percentile of arcs; the rest)
+  struct WaveClass {
+    DevBuf<uint32_t> list;
+    uint32_t n = 0, cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
+  } wclass[2];
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
   // runs as replicas (carmel_hip_gibbs_set_run_share): this sampler takes the runs r with r % run_stride == run_first
@@ -789,7 +795,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   HIPCHK(g->sample_ids.alloc(g->h_sample_off.back() + 128));  // (+ gibbs_exact.hip's staging reads a fixed number of words ahead)
   if (o->mode == 1) {
     HIPCHK(g->new_len.alloc(bb.size()));
-    HIPCHK(g->new_ids.alloc(g->h_sample_off.back()));
+    HIPCHK(g->new_ids.alloc(g->h_sample_off.back() + 128));
     HIPCHK(g->snap_x.alloc(np));
     HIPCHK(g->snap_norm.alloc(ng));
   }
@@ -824,7 +830,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   }
   // ---- the exact chain's wavefront path (gibbs_exact.hip): eligible when every block is an acyclic lattice within its LDS
   // tables and every composed arc stands for at most two parameters ----
-  if (o->mode == 0 && !o->expectation && max_chain <= 2) {
+  if (!o->expectation && max_chain <= 2) {
     bool ok = true;
     for (size_t b = 0; b < bb.size() && ok; ++b) {
       const BundleDesc& d = L.bundles[bb[b]];
@@ -870,7 +876,45 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       HIPCHK(g->gx_rec.upload(rec, s));
       HIPCHK(g->gx_nrm.upload(nrm, s));
       HIPCHK(g->sample_nrm.alloc(g->h_sample_off.back() + 128));
-      g->wave_ok = true;
+      if (o->mode == 1) HIPCHK(g->new_nrm.alloc(g->h_sample_off.back() + 128));
+      for (size_t b = 0; b < bb.size(); ++b) {
+        const BundleDesc& d = L.bundles[bb[b]];
+        g->cap_arcs = std::max(g->cap_arcs, (uint32_t)d.n_arcs);
+        g->cap_states = std::max(g->cap_states, d.n_states);
+        g->cap_levels = std::max(g->cap_levels, d.n_levels);
+        g->cap_sample = std::max(g->cap_sample, d.n_levels * max_chain);
+      }
+      g->cap_arcs = (g->cap_arcs + 3) / 4 * 4;
+      g->cap_states = (g->cap_states + 3) / 4 * 4;
+      g->cap_sample = (g->cap_sample + 3) / 4 * 4;
+      g->wave_ok = gibbs_exact_lds_bytes(g->cap_arcs, g->cap_states, g->cap_levels, g->cap_sample) <= 150 * 1024;
+      if (g->wave_ok && o->mode == 1) {
+        // a wavefront's LDS is sized by its launch's largest block: the few long sentences must not set the occupancy of all
+        std::vector<uint32_t> arcs(bb.size());
+        for (size_t b = 0; b < bb.size(); ++b) arcs[b] = (uint32_t)L.bundles[bb[b]].n_arcs;
+        std::vector<uint32_t> sorted = arcs;
+        std::sort(sorted.begin(), sorted.end());
+        const uint32_t cut = sorted[std::min(sorted.size() - 1, sorted.size() * 9 / 10)];
+        std::vector<uint32_t> lists[2];
+        for (size_t b = 0; b < bb.size(); ++b) {
+          const int c = arcs[b] <= cut ? 0 : 1;
+          const BundleDesc& d = L.bundles[bb[b]];
+          auto& W = g->wclass[c];
+          lists[c].push_back((uint32_t)b);
+          W.cap_arcs = std::max(W.cap_arcs, (uint32_t)d.n_arcs);
+          W.cap_states = std::max(W.cap_states, d.n_states);
+          W.cap_levels = std::max(W.cap_levels, d.n_levels);
+          W.cap_sample = std::max(W.cap_sample, d.n_levels * max_chain);
+        }
+        for (int c = 0; c < 2; ++c) {
+          auto& W = g->wclass[c];
+          W.n = (uint32_t)lists[c].size();
+          W.cap_arcs = (W.cap_arcs + 3) / 4 * 4;
+          W.cap_states = (W.cap_states + 3) / 4 * 4;
+          W.cap_sample = (W.cap_sample + 3) / 4 * 4;
+          if (W.n) HIPCHK(W.list.upload(lists[c], s));
+        }
+      }
     }
   }
   HIPCHK(g->iter_out.alloc(4));
@@ -1062,13 +1106,14 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
   // the wavefront path runs the default chain: sampling at temperature 1 with the block's own sample taken out first
-  const bool wave_run = g->wave_ok && g->opt.mode == 0 && !g->opt.expectation && !g->opt.include_self &&
-                        (g->opt.high_temp == 0 || g->opt.high_temp == 1) && (g->opt.low_temp == 0 || g->opt.low_temp == 1) &&
-                        !getenv("CARMEL_HIP_GIBBS_WORKGROUP");
+  const bool wave_any = g->wave_ok && !g->opt.expectation && (g->opt.high_temp == 0 || g->opt.high_temp == 1) &&
+                        (g->opt.low_temp == 0 || g->opt.low_temp == 1) && !getenv("CARMEL_HIP_GIBBS_WORKGROUP");
+  const bool wave_run = wave_any && g->opt.mode == 0 && !g->opt.include_self;
+  const bool wave_par = wave_any && g->opt.mode == 1;  // the stale-count sweep, a wavefront per block
   GxArgs GX;
   std::memset(&GX, 0, sizeof GX);
   DevBuf<unsigned long long> gx_clk;
-  if (wave_run) {
+  if (wave_run || wave_par) {
     GX.blocks = g->gx_blocks.p;
     GX.arc_rec = (const uint4*)g->gx_rec.p;
     GX.arc_nrm = (const uint2*)g->gx_nrm.p;
@@ -1083,6 +1128,14 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     GX.sample_len = g->sample_len.p;
     GX.sample_ids = g->sample_ids.p;
     GX.sample_nrm = g->sample_nrm.p;
+    GX.old_len = g->sample_len.p;
+    GX.old_ids = g->sample_ids.p;
+    GX.old_nrm = g->sample_nrm.p;
+    GX.counterfactual = g->opt.include_self ? 0 : 1;
+    GX.cap_arcs = g->cap_arcs;
+    GX.cap_states = g->cap_states;
+    GX.cap_levels = g->cap_levels;
+    GX.cap_sample = g->cap_sample;
     GX.iter_out = g->iter_out.p;
     GX.seed = g->opt.seed;
     GX.n_blocks = g->n_blocks;
@@ -1142,7 +1195,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       HIPCHK(launch_forest_fold(g->p_s.p, g->p_tmax.p, g->p_x.p, G.time, np, s));
       GX.iter = G.iter;
       GX.init_logw = G.init_logw;
-      HIPCHK(launch_gibbs_exact_wave(GX, s));
+      HIPCHK(launch_gibbs_exact_wave(GX, 0, s));
     } else if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1156,18 +1209,52 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     } else {
       HIPCHK(hipMemcpyAsync(g->snap_x.p, g->p_x.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->snap_norm.p, g->normsum.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      if (wave_par) {
+        // a wavefront per block (gibbs_exact.hip): proposals from the snapshot with the block's own sample taken out
+        // arithmetically, new samples beside the old ones; the recount and commit below are shared with the kernel it replaces
+        GX.iter = G.iter;
+        GX.init_logw = G.init_logw;
+        GX.p_x = g->snap_x.p;
+        GX.normsum = g->snap_norm.p;
+        GX.old_len = g->sample_len.p;
+        GX.old_ids = g->sample_ids.p;
+        GX.old_nrm = g->sample_nrm.p;
+        GX.sample_len = g->new_len.p;
+        GX.sample_ids = g->new_ids.p;
+        GX.sample_nrm = g->new_nrm.p;
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device);
+        for (int c = 0; c < 2; ++c) {  // (both launches on the trainer's stream: the second fills the chip as the first drains)
+          auto& W = g->wclass[c];
+          if (!W.n) continue;
+          GX.list = W.list.p;
+          GX.n_blocks = W.n;
+          GX.cap_arcs = W.cap_arcs;
+          GX.cap_states = W.cap_states;
+          GX.cap_levels = W.cap_levels;
+          GX.cap_sample = W.cap_sample;
+          const size_t lds_w = gibbs_exact_lds_bytes(GX.cap_arcs, GX.cap_states, GX.cap_levels, GX.cap_sample);
+          const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_w, 1)));
+          HIPCHK(launch_gibbs_exact_wave(GX, std::min<uint32_t>(W.n, (uint32_t)cus * per_cu), s));
+        }
+      } else {
       uint32_t grid = std::min<uint32_t>(g->n_blocks, 256u * 16u);
       size_t lds = (size_t)g->max_sample * sizeof(uint32_t);
       hipLaunchKernelGGL(gibbs_sweep_parallel_kernel, dim3(grid), dim3(64), lds, s, G, g->max_sample);
+      }
       // counts of the new samples: start from the priors, add every use
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      hipLaunchKernelGGL(gibbs_recount_kernel, dim3(std::min<uint32_t>((g->n_blocks + 255) / 256, 4096u)), dim3(256), 0, s,
-                         G, g->ccount.p, g->normsum.p);
+      if (wave_par)
+        HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_blocks, g->ccount.p, g->normsum.p, s));
+      else
+        hipLaunchKernelGGL(gibbs_recount_kernel, dim3(std::min<uint32_t>((g->n_blocks + 255) / 256, 4096u)), dim3(256), 0, s,
+                           G, g->ccount.p, g->normsum.p);
       hipLaunchKernelGGL(gibbs_commit_kernel, dim3((unsigned)std::min<uint64_t>((np + 255) / 256, 4096)), dim3(256), 0, s, G,
                          g->ccount.p, np);
       std::swap(g->sample_ids.p, g->new_ids.p);
       std::swap(g->sample_len.p, g->new_len.p);
+      std::swap(g->sample_nrm.p, g->new_nrm.p);
       G.sample_ids = g->sample_ids.p;
       G.sample_len = g->sample_len.p;
       G.new_ids = g->new_ids.p;

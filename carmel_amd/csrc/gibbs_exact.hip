@@ -18,6 +18,7 @@
 //   * counts: one round of device atomics per block -- the new sample in, the next block's previous sample out --, the
 //     cache-model probability from the values the cache counts' atomics return, the time-weighted sums folded once per sweep
 //     for every parameter (forest_exact.hpp: launch_forest_fold), workgroup-scope coherence (one wavefront, one L2).
+#include <algorithm>
 #include "gibbs_exact.hpp"
 #include "rng.hpp"
 
@@ -61,15 +62,36 @@ struct GxProd {  // a running product as mantissa x 2^exponent (one logarithm pe
   __device__ __forceinline__ double ln() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
+// the parallel sweep's own-sample tables: GX_OWN slots each (open addressing; a sample of at most GX_SQ * 64 entries)
+#define GX_OWN 256
+__device__ __forceinline__ void gx_own_put(uint32_t* keys, uint32_t* cnts, uint32_t key) {
+  for (uint32_t h = (key * 2654435761u) >> 8;; ++h) {
+    const uint32_t at = h & (GX_OWN - 1);
+    const uint32_t old = atomicCAS(keys + at, GX_NONE, key);
+    if (old == GX_NONE || old == key) {
+      atomicAdd(cnts + at, 1u);
+      return;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t gx_own_get(const uint32_t* keys, const uint32_t* cnts, uint32_t key) {
+  for (uint32_t h = (key * 2654435761u) >> 8;; ++h) {
+    const uint32_t at = h & (GX_OWN - 1);
+    const uint32_t k = keys[at];
+    if (k == key) return cnts[at];
+    if (k == GX_NONE) return 0u;
+  }
+}
 struct GxOld {  // a block's previous sample, on its way
   uint32_t id[GX_SQ], nr[GX_SQ], len;
 };
+// (A.old_*: the buffers the previous sweep wrote; the exact chain rewrites them in place, the parallel sweep writes the others)
 __device__ __forceinline__ void gx_request_old(const GxArgs& A, const GxBlock& B, uint32_t b, uint32_t lane, GxOld& O) {
-  O.len = A.sample_len[b];
+  O.len = A.old_len[b];
 #pragma unroll
   for (int q = 0; q < GX_SQ; ++q) {  // (read past the sample: within its capacity or the buffer's padding)
-    O.id[q] = A.sample_ids[B.sample_off + lane + q * 64];
-    O.nr[q] = A.sample_nrm[B.sample_off + lane + q * 64];
+    O.id[q] = A.old_ids[B.sample_off + lane + q * 64];
+    O.nr[q] = A.old_nrm[B.sample_off + lane + q * 64];
   }
 }
 __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, uint32_t lane, const GxOld& O) {
@@ -80,37 +102,57 @@ __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, u
       gx_add(A.normsum + O.nr[q], -B.wt);
     }
   for (uint32_t k = lane + GX_SQ * 64; k < O.len; k += 64) {
-    const uint32_t n = A.sample_nrm[B.sample_off + k];
+    const uint32_t n = A.old_nrm[B.sample_off + k];
     if (n == GX_NONE) continue;
-    gx_add(A.p_x + A.sample_ids[B.sample_off + k], -B.wt);
+    gx_add(A.p_x + A.old_ids[B.sample_off + k], -B.wt);
     gx_add(A.normsum + n, -B.wt);
   }
 }
 
+// PAR = false: the reference's chain, one wavefront, blocks in order, live counts.
+// PAR = true:  the stale-count parallel sweep (never the default): every wavefront of the grid takes blocks
+//              blockIdx, blockIdx + gridDim, ... against the counts of the PREVIOUS sweep (A.p_x / A.normsum point at the
+//              snapshot) with the block's own previous sample taken out arithmetically (counterfactual counts: every entry
+//              of it is compared with every lattice arc's parameters and norm groups); the new samples go to the other sample
+//              buffer and gibbs.hip's recount / commit kernels rebuild the counts from them.
+template <bool PAR>
 __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
-  __shared__ double gw[GX_ARCS];   // proposal weight the walk samples from
-  __shared__ double pc[GX_ARCS];   // ... from the counts (what the proposal probability of the sample is made of)
-  __shared__ double sh[GX_ARCS];   // the arc's share of its source state's total
-  __shared__ uint32_t ds[GX_ARCS], par0[GX_ARCS], par1[GX_ARCS];
-  __shared__ double bv[GX_STATES], bsum[GX_STATES];
-  __shared__ int be[GX_STATES], emx[GX_STATES];
-  __shared__ uint32_t ooff[GX_STATES + 1], lvl[GX_LEVELS + 1];
-  __shared__ uint32_t ids[GX_SAMPLE], idn[GX_SAMPLE];
+  extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
+  const uint32_t CA = A.cap_arcs, CS = A.cap_states, CL = A.cap_levels, CM = A.cap_sample;
+  double* gw = (double*)gx_lds;          // proposal weight the walk samples from
+  double* pc = gw + CA;                  // ... from the counts (what the proposal probability of the sample is made of)
+  double* sh = pc + CA;                  // the arc's share of its source state's total
+  double* bv = sh + CA;                  // backward values
+  double* bsum = bv + CS;
+  uint32_t* ds = (uint32_t*)(bsum + CS);
+  uint32_t* par0 = ds + CA;
+  uint32_t* par1 = par0 + CA;
+  int* be = (int*)(par1 + CA);
+  int* emx = be + CS;
+  uint32_t* ooff = (uint32_t*)(emx + CS);
+  uint32_t* lvl = ooff + CS + 1;
+  uint32_t* ids = lvl + CL + 1;
+  uint32_t* idn = ids + CM;
+  uint32_t* own_k = idn + CM;  // PAR: the block's previous sample as {parameter -> uses} and {norm group -> uses}
+  uint32_t* own_c = own_k + 2 * GX_OWN;
   const uint32_t lane = threadIdx.x;
   const uint32_t nb = A.n_blocks;
   GxProd cheap{1.0, 0}, cnum{1.0, 0}, cden{1.0, 0}, after{1.0, 0};
   unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
-  GxBlock B = A.blocks[0], Bn = A.blocks[min(1u, nb - 1)];
+  // PAR: this launch's blocks are A.list[0 .. nb) (a launch per LDS size class); i counts through the list
+  const uint32_t b0 = PAR ? blockIdx.x : 0u, stride = PAR ? gridDim.x : 1u;
+  if (b0 >= nb) return;
+#define GX_BLOCK_ID(i) ((PAR && A.list) ? A.list[(i)] : (i))
+  GxBlock B = A.blocks[GX_BLOCK_ID(b0)], Bn = A.blocks[GX_BLOCK_ID(min(b0 + stride, nb - 1))];
   GxOld O;
-  gx_request_old(A, B, 0, lane, O);
-  if (!A.want_after) gx_take_out(A, B, lane, O);
+  gx_request_old(A, B, GX_BLOCK_ID(b0), lane, O);
+  if (!PAR && !A.want_after) gx_take_out(A, B, lane, O);
   uint32_t n_prev = 0;
-  double wt_prev = 1.0;
-  (void)wt_prev;
-  for (uint32_t b = 0; b < nb; ++b) {
+  for (uint32_t bi = b0; bi < nb; bi += stride) {
+    const uint32_t b = GX_BLOCK_ID(bi);  // the block's number in the corpus: what its uniforms and its sample are keyed by
     unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
-    gx_order();  // the counts are as the chain has them
-    if (A.want_after) {
+    if (!PAR) gx_order();  // the counts are as the chain has them
+    if (!PAR && A.want_after) {
       // the previous block's sample scored with itself counted (the "overestimate" of gibbs.hpp:866), then this block's
       // previous sample leaves the counts
       for (uint32_t k = lane; k < n_prev; k += 64) {
@@ -123,12 +165,76 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     // ---- the lattice: arc records, proposal weights (gibbs.cc:348-359, gibbs.hpp:153-157), offsets ----
     const uint4* __restrict__ rec = A.arc_rec + B.out_base;
     const uint2* __restrict__ nrm = A.arc_nrm + B.out_base;
-    for (uint32_t a = lane; a < B.n_arcs; a += 64) {
-      const uint4 r = rec[a];
-      const uint2 n = nrm[a];
-      double w = 1.0;  // (a composed arc may stand for no parameter at all)
-      if (r.z != GX_NONE) w = n.x == GX_NONE ? A.p_prior[r.z] : gx_ld(A.p_x + r.z) / gx_ld(A.normsum + n.x);
-      if (r.w != GX_NONE) w *= n.y == GX_NONE ? A.p_prior[r.w] : gx_ld(A.p_x + r.w) / gx_ld(A.normsum + n.y);
+    const uint32_t own_n = PAR && A.counterfactual ? O.len : 0u;
+    const bool own_tab = PAR && own_n && own_n <= GX_SQ * 64;
+    if (own_tab) {
+      for (uint32_t i = lane; i < 2 * GX_OWN; i += 64) {
+        own_k[i] = GX_NONE;
+        own_c[i] = 0;
+      }
+      GX_WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < GX_SQ; ++q)
+        if (lane + q * 64 < own_n && O.nr[q] != GX_NONE) {  // (a fixed-probability parameter has no count to correct)
+          gx_own_put(own_k, own_c, O.id[q]);
+          gx_own_put(own_k + GX_OWN, own_c + GX_OWN, O.nr[q]);
+        }
+      GX_WAVE_SYNC();
+    }
+    for (uint32_t a0_ = 0; a0_ < B.n_arcs; a0_ += 64) {
+      const uint32_t a = a0_ + lane;
+      const bool have = a < B.n_arcs;
+      const uint4 r = have ? rec[a] : make_uint4(0, 0, GX_NONE, GX_NONE);
+      const uint2 n = have ? nrm[a] : make_uint2(GX_NONE, GX_NONE);
+      double x0 = 1.0, s0 = 1.0, x1 = 1.0, s1 = 1.0;
+      if (r.z != GX_NONE) {
+        if (n.x == GX_NONE)
+          x0 = A.p_prior[r.z];
+        else {
+          x0 = PAR ? A.p_x[r.z] : gx_ld(A.p_x + r.z);
+          s0 = PAR ? A.normsum[n.x] : gx_ld(A.normsum + n.x);
+        }
+      }
+      if (r.w != GX_NONE) {
+        if (n.y == GX_NONE)
+          x1 = A.p_prior[r.w];
+        else {
+          x1 = PAR ? A.p_x[r.w] : gx_ld(A.p_x + r.w);
+          s1 = PAR ? A.normsum[n.y] : gx_ld(A.normsum + n.y);
+        }
+      }
+      if (PAR && own_n) {
+        // counterfactual counts: this block's previous sample does not count -- how often it uses this arc's parameters and
+        // their norm groups comes out of two small tables the wavefront filled from the sample (below, once per block)
+        if (own_tab) {
+          const uint32_t c0 = r.z != GX_NONE ? gx_own_get(own_k, own_c, r.z) : 0u, c1 = r.w != GX_NONE ? gx_own_get(own_k, own_c, r.w) : 0u;
+          const uint32_t m0 = n.x != GX_NONE ? gx_own_get(own_k + GX_OWN, own_c + GX_OWN, n.x) : 0u,
+                         m1 = n.y != GX_NONE ? gx_own_get(own_k + GX_OWN, own_c + GX_OWN, n.y) : 0u;
+          x0 -= (double)c0 * B.wt;
+          s0 -= (double)m0 * B.wt;
+          x1 -= (double)c1 * B.wt;
+          s1 -= (double)m1 * B.wt;
+        } else {  // a sample too long for the tables: entry by entry
+          uint32_t c0 = 0, m0 = 0, c1 = 0, m1 = 0;
+          for (uint32_t k = 0; k < own_n; ++k) {
+            const uint32_t id = A.old_ids[B.sample_off + k], nr = A.old_nrm[B.sample_off + k];
+            c0 += id == r.z;
+            c1 += id == r.w;
+            m0 += nr == n.x;
+            m1 += nr == n.y;
+          }
+          if (n.x != GX_NONE) {
+            x0 -= (double)c0 * B.wt;
+            s0 -= (double)m0 * B.wt;
+          }
+          if (n.y != GX_NONE) {
+            x1 -= (double)c1 * B.wt;
+            s1 -= (double)m1 * B.wt;
+          }
+        }
+      }
+      if (!have) continue;
+      const double w = (x0 / s0) * (x1 / s1);
       pc[a] = w;
       gw[a] = A.init_logw ? exp(A.init_logw[r.y]) : w;
       ds[a] = r.x;
@@ -139,8 +245,8 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     for (uint32_t l = lane; l <= B.n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
     // the next block's previous sample sets out now
     GxOld On;
-    gx_request_old(A, Bn, min(b + 1, nb - 1), lane, On);
-    const GxBlock Bnn = A.blocks[min(b + 2, nb - 1)];
+    gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
+    const GxBlock Bnn = A.blocks[GX_BLOCK_ID(min(bi + 2 * stride, nb - 1))];
     const double U = gibbs_uniform(A.seed, A.iter, b, lane);  // the walk's first 64 uniforms, one per lane
     unsigned long long t1 = A.phase_clk ? __builtin_readcyclecounter() : 0;
     // ---- backward sweep (derivations.h:345-360): beta[s] = sum over out-arcs of weight x beta[destination].  A state's value
@@ -277,12 +383,14 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     }
     GX_WAVE_SYNC();
     unsigned long long t3 = A.phase_clk ? __builtin_readcyclecounter() : 0;
-    // ---- the new sample into the counts, the next block's previous sample out (gibbs.hpp:851-871, 712-742, 769-792) ----
+    // ---- the new sample into the counts, the next block's previous sample out (gibbs.hpp:851-871, 712-742, 769-792); the
+    // parallel sweep only writes its sample down (gibbs.hip recounts) ----
     for (uint32_t k = lane; k < n_ids; k += 64) {
       const uint32_t p = ids[k], n = A.p_norm[p];
       idn[k] = n;
       A.sample_ids[B.sample_off + k] = p;
       A.sample_nrm[B.sample_off + k] = n;
+      if (PAR) continue;
       if (n != GX_NONE) {
         gx_add(A.p_x + p, B.wt);
         gx_add(A.normsum + n, B.wt);
@@ -292,7 +400,7 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
         cnum.mul(A.p_prior[p]);
     }
     if (lane == 0) A.sample_len[b] = n_ids;
-    if (!A.want_after && b + 1 < nb) gx_take_out(A, Bn, lane, On);
+    if (!PAR && !A.want_after && bi + 1 < nb) gx_take_out(A, Bn, lane, On);
     n_prev = n_ids;
     B = Bn;
     Bn = Bnn;
@@ -306,6 +414,14 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
       clk[3] += t4 - t3;
       clk[4] += 1;
     }
+  }
+  if (PAR) {  // the sweep's proposal probability: every wavefront adds its blocks'
+    if (lane == 0) {
+      unsafeAtomicAdd(A.iter_out + 1, cheap.ln());
+      if (A.phase_clk)
+        for (int k = 0; k < 5; ++k) atomicAdd(A.phase_clk + k, clk[k]);
+    }
+    return;
   }
   gx_order();
   if (A.want_after)
@@ -328,8 +444,85 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
   }
 }
 
-hipError_t launch_gibbs_exact_wave(const GxArgs& A, hipStream_t s) {
-  hipLaunchKernelGGL(gibbs_exact_wave_kernel, dim3(1), dim3(64), 0, s, A);
+// ---- the parallel sweep's recount: counts := prior + weighted uses in the new samples (the caller has set them to the priors).
+// A thread per sample entry; a workgroup's entries meet in two open-addressing tables in LDS (parameter -> weight, norm group ->
+// weight) and reach global memory once per workgroup and key: the popular parameters of a model (a tagger's "the" / DT) are
+// used by most blocks, and 10^5 device-scope adds to one address serialise.  Keys that find no slot within eight probes are
+// added directly.  (gibbs.hip's recount walks a block's sample with one thread, id by id: 8 ms of a 13 ms sweep on the tagging
+// cascade x 100.)
+__device__ __forceinline__ void gx_tab_add(uint32_t* keys, double* vals, uint32_t mask, uint32_t key, double v, double* global) {
+  uint32_t h = (key * 2654435761u) >> 10;
+  for (int probe = 0; probe < 8; ++probe, ++h) {
+    const uint32_t at = h & mask;
+    const uint32_t old = atomicCAS(keys + at, 0xffffffffu, key);
+    if (old == 0xffffffffu || old == key) {
+      gx_lds_add(vals + at, v);
+      return;
+    }
+  }
+  unsafeAtomicAdd(global + key, v);
+}
+__global__ __launch_bounds__(1024) void gibbs_recount_tables_kernel(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids,
+                                                                    const uint32_t* nrm, uint32_t n_blocks, double* new_x,
+                                                                    double* new_norm, uint32_t p_slots, uint32_t n_slots) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rc_lds[];
+  double* pv = (double*)rc_lds;
+  double* nv = pv + p_slots;
+  uint32_t* pk = (uint32_t*)(nv + n_slots);
+  uint32_t* nk = pk + p_slots;
+  for (uint32_t i = threadIdx.x; i < p_slots; i += blockDim.x) {
+    pk[i] = 0xffffffffu;
+    pv[i] = 0.0;
+  }
+  for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x) {
+    nk[i] = 0xffffffffu;
+    nv[i] = 0.0;
+  }
+  __syncthreads();
+  // a wavefront per block at a time: its entries side by side
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
+  for (uint32_t b = blockIdx.x * nw + wv; b < n_blocks; b += gridDim.x * nw) {
+    const GxBlock B = blocks[b];
+    const uint32_t n = len[b];
+    for (uint32_t k = lane; k < n; k += 64) {
+      const uint32_t g = nrm[B.sample_off + k];
+      if (g == GX_NONE) continue;
+      gx_tab_add(pk, pv, p_slots - 1, ids[B.sample_off + k], B.wt, new_x);
+      gx_tab_add(nk, nv, n_slots - 1, g, B.wt, new_norm);
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < p_slots; i += blockDim.x)
+    if (pk[i] != 0xffffffffu) unsafeAtomicAdd(new_x + pk[i], pv[i]);
+  for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x)
+    if (nk[i] != 0xffffffffu) unsafeAtomicAdd(new_norm + nk[i], nv[i]);
+}
+hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
+                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s) {
+  const uint32_t p_slots = 8192, n_slots = 1024;
+  const size_t lds = (size_t)(p_slots + n_slots) * 12;
+  (void)hipFuncSetAttribute((const void*)gibbs_recount_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const uint32_t grid = std::min<uint32_t>(256u, (n_blocks + 15) / 16);
+  hipLaunchKernelGGL(gibbs_recount_tables_kernel, dim3(grid ? grid : 1u), dim3(1024), lds, s, blocks, len, ids, nrm, n_blocks, new_x, new_norm,
+                     p_slots, n_slots);
+  return hipGetLastError();
+}
+
+size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_levels, uint32_t cap_sample) {
+  return (size_t)cap_arcs * (3 * 8 + 3 * 4) + (size_t)cap_states * (2 * 8 + 2 * 4) + ((size_t)cap_states + 1 + cap_levels + 1) * 4 +
+         (size_t)cap_sample * 8 + (size_t)4 * GX_OWN * 4;
+}
+hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_t s) {
+  const size_t lds = gibbs_exact_lds_bytes(A.cap_arcs, A.cap_states, A.cap_levels, A.cap_sample);
+  if (n_waves) {  // the parallel sweep
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gibbs_exact_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gibbs_exact_wave_kernel<true>, dim3(n_waves), dim3(64), lds, s, A);
+  } else {
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)gibbs_exact_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(gibbs_exact_wave_kernel<false>, dim3(1), dim3(64), lds, s, A);
+  }
   return hipGetLastError();
 }
 

@@ -22,6 +22,7 @@ struct GxBlock {  // 48 bytes per block, in corpus order (the order of the chain
 
 struct GxArgs {
   const GxBlock* blocks;
+  const uint32_t* list;       // parallel sweep: the blocks of this launch (null: all, in order)
   const uint4* arc_rec;       // per lattice arc: {destination | source << 16, composed arc, parameter 0, parameter 1 (0xffffffff: none)}
   const uint2* arc_nrm;       // ... their norm groups (0xffffffff: a fixed probability, the parameter's prior)
   const uint32_t* out_off;    // per state: first out-arc (bundle-relative), n_states + 1 per block
@@ -32,17 +33,29 @@ struct GxArgs {
   double* normsum;
   double* ccount;             // cache model of this sweep (gibbs.hpp:712-742)
   double* csum;
-  uint32_t* sample_len;
+  uint32_t* sample_len;       // where this sweep's samples go
   uint32_t* sample_ids;       // per block: parameter ids along the sampled path, chain order ...
   uint32_t* sample_nrm;       // ... and their norm groups
+  const uint32_t* old_len;    // the previous sweep's samples (the exact chain: the same buffers)
+  const uint32_t* old_ids;
+  const uint32_t* old_nrm;
   const double* init_logw;    // --init-em / --init-from-p0: per composed arc, what the first sweep samples from (null: the counts)
   double* iter_out;           // {ln cache-model prob, ln proposal prob, ln proposal prob after the add-back}
   unsigned long long* phase_clk;
   uint64_t seed;
   uint32_t iter, n_blocks;
   int want_after;
+  int counterfactual;         // parallel sweep: take the block's own previous sample out of the snapshot counts
+  uint32_t cap_arcs, cap_states, cap_levels, cap_sample;  // LDS carve: the largest block's arcs / states / levels / sample
 };
 
-hipError_t launch_gibbs_exact_wave(const GxArgs& A, hipStream_t s);
+size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_levels, uint32_t cap_sample);
+// n_waves = 0: the exact chain (one wavefront); > 0: the stale-count parallel sweep on that many wavefronts
+hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_t s);
+
+// the parallel sweep's recount through per-workgroup LDS tables: new_x / new_norm (set to the priors by the caller) += the weighted
+// uses of the samples (len, ids, nrm)
+hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
+                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s);
 
 }  // namespace carmel_hip
