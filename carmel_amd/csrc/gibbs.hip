@@ -82,6 +82,7 @@ struct GibbsArgs {
   double* iter_out;            // [0] ln cache-model prob of the sweep, [1] ln proposal ("cheap") prob, [2] see want_after
   int want_after;              // exact mode: also the proposal prob of every block evaluated AFTER its new sample was
                                // added back (the "overestimate" of the comment at gibbs.hpp:866)
+  uint32_t* overflow;          // set when a walk through a cyclic lattice outgrew the block's sample buffer
   uint64_t seed;
   uint32_t n_blocks, iter;
   double time, power;
@@ -392,6 +393,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   // 4. walk start -> goal (derivations.h:361-374; random.ipp:111-127), 5. probabilities, 6. put the new sample in
   if (tid == 0) {
     uint32_t* out_ids = SNAP ? (G.new_ids + so) : ids;
+    const uint32_t cap_ids = (uint32_t)(G.sample_off[b + 1] - so);
     uint32_t n = 0, step = 0;
     uint32_t s = G.pair_start[d.pair_base];
     const uint32_t fin = G.pair_final[d.pair_base];
@@ -427,7 +429,15 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       }
 #undef G_LIST
       const uint32_t arc = oa[pick].y;
-      for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) out_ids[n++] = G.chain_param[j];
+      for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j) {
+        if (n < cap_ids) out_ids[n] = G.chain_param[j];
+        ++n;
+      }
+      if (n > cap_ids) {  // (only a lattice with a cycle can get here: the sample buffer is full, the run is void)
+        *G.overflow = 1u;
+        n = cap_ids;
+        break;
+      }
       s = oa[pick].x;
     }
     if (!SNAP && G.par_books && n <= G.books_cap) {  // probabilities and counts by the whole workgroup, below
@@ -760,7 +770,11 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
   if (!g->n_blocks) return fail(CARMEL_HIP_ERR_NO_DERIV, "No training example had a derivation - aborting training.");
   g->h_sample_off.assign(bb.size() + 1, 0);
   for (size_t b = 0; b < bb.size(); ++b) {
-    uint32_t cap = L.bundles[bb[b]].n_levels * max_chain;  // a path has at most n_levels - 1 arcs
+    // an acyclic lattice's path has at most n_levels - 1 arcs.  A lattice with a cycle (derivations.h:726-728) has no bound: the
+    // walk may take a loop any number of times (the reference grows a vector).  Room for a walk 32 times the lattice's states
+    // (at least 256 arcs); a longer one ends the run with an error instead of writing past the buffer (G.overflow)
+    const BundleDesc& bd = L.bundles[bb[b]];
+    uint32_t cap = ((bd.flags & 1u) ? std::max<uint32_t>(256u, 32u * bd.n_states) : bd.n_levels) * max_chain;
     g->max_sample = std::max(g->max_sample, cap);
     g->h_sample_off[b + 1] = g->h_sample_off[b] + cap;
   }
@@ -917,7 +931,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       }
     }
   }
-  HIPCHK(g->iter_out.alloc(4));
+  HIPCHK(g->iter_out.alloc(6));  // (+ the overflow flag of the walks, as a word of its own)
   HIPCHK(hipStreamSynchronize(s));
   *out = g.release();
   return CARMEL_HIP_OK;
@@ -1102,6 +1116,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.stage_arcs = 3072u;  // 48 KB + 16 KB: blocks of up to 3072 lattice arcs /
   G.stage_states = 1024u;                                           // 1024 states sweep and walk out of LDS
   G.iter_out = g->iter_out.p;
+  G.overflow = (uint32_t*)(g->iter_out.p + 4);
   G.want_after = iter_after_logprob ? 1 : 0;
   G.seed = g->opt.seed;
   G.n_blocks = g->n_blocks;
@@ -1186,7 +1201,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     G.init_logw = (run == 0 && iter == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
     G.power = gibbs_anneal_power(g->opt.high_temp, g->opt.low_temp, Ni, iter);
     G.time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
-    HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 4 * sizeof(double), s));
+    HIPCHK(hipMemsetAsync(g->iter_out.p, 0, 5 * sizeof(double), s));
     if (g->opt.mode == 0 && wave_run) {
       // the chain on one wavefront (gibbs_exact.hip); delta_sum's fold for every parameter at once: at the start of a sweep every
       // count is what the previous sweep left, which is what the reference folds at a parameter's first touch (delta_sum.hpp:74-84)
@@ -1261,9 +1276,16 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       G.new_len = g->new_len.p;
     }
     HIPCHK(hipGetLastError());
-    double io[3];
+    double io[5];
     HIPCHK(hipMemcpyAsync(io, g->iter_out.p, sizeof io, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    {
+      uint32_t ov;
+      std::memcpy(&ov, &io[4], sizeof ov);
+      if (ov)
+        return fail(CARMEL_HIP_ERR_UNSUPPORTED, "a sampled path through a derivation lattice with a cycle outgrew its sample buffer (32 x the lattice's "
+                                                "states): the reference's walk has no bound, this one has");
+    }
     const double plog = g->opt.mode == 0 ? io[0] : io[1];
     {
       // propose_new_priors (gibbs.hpp:525-553), on the sweeps that infer (gibbs.hpp:559-563)

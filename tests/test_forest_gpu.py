@@ -439,3 +439,24 @@ def test_exact_chain_on_deep_spines_whose_values_underflow_plain_doubles(oracle)
     np.testing.assert_allclose(hf.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
     np.testing.assert_allclose(np.exp(hf.weights()), np.exp(of.weights()), rtol=1e-9, atol=1e-15)
     hf.close()
+
+
+def test_exact_chain_on_the_device_is_the_host_driven_loop(oracle, monkeypatch):
+    """forest_exact.hip (one persistent wavefront, counts on the device) against the loop it replaces (a launch per forest,
+    counts on the host; CARMEL_HIP_FOREST_EXACT_HOST=1, still what annealed runs and prior-scale inference use): the same
+    samples, probabilities and weights"""
+    ftext, ntext = synth_forests(120, 40, 23)
+    out = {}
+    for which in ("device", "host"):
+        if which == "host":
+            monkeypatch.setenv("CARMEL_HIP_FOREST_EXACT_HOST", "1")
+        else:
+            monkeypatch.delenv("CARMEL_HIP_FOREST_EXACT_HOST", raising=False)
+        of, hf = make(oracle, ftext, ntext, 23)
+        hf.gibbs(8, burnin=2, alpha=0.3, seed=5, mode=0)
+        out[which] = ([hf.sample(b) for b in range(hf.n_forests)], hf.iter_logprob.copy(), hf.iter_cheap_logprob.copy(), hf.weights().copy())
+        hf.close()
+    assert out["device"][0] == out["host"][0]
+    np.testing.assert_allclose(out["device"][1], out["host"][1], rtol=1e-10)
+    np.testing.assert_allclose(out["device"][2], out["host"][2], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(out["device"][3]), np.exp(out["host"][3]), rtol=1e-9, atol=1e-15)

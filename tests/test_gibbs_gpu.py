@@ -270,10 +270,12 @@ def _random_cascade_case(oracle, seed):
     raise AssertionError("no usable random cascade for seed %d" % seed)
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", list(range(24)) + [4039])
 def test_gibbs_exact_chain_on_random_cascades(oracle, seed):
     """the exact sweep on random two-member cascades (locked arcs, epsilons, pairs without derivations, mixed
-    normalisations): same samples, probabilities and time-averaged weights as the oracle's chain"""
+    normalisations): same samples, probabilities and time-averaged weights as the oracle's chain.  (Seed 4039, found by
+    tools/fuzz_gpu.py in round 4: seven lattices with cycles whose sampled paths -- 20 parameters -- are longer than the
+    n_levels x chain length the sample buffers were sized by: a walk through a cycle has no such bound.)"""
     from carmel_amd.trainer import HipGibbs
     a, b, corpus_text, normby, priors = _random_cascade_case(oracle, seed)
     norms = [NORM_JOINT if ch == "J" else NORM_CONDITIONAL for ch in normby]
@@ -389,3 +391,30 @@ def test_observer_sees_the_chain_as_it_stands(oracle, golden_dir):
     assert not np.allclose(seen[0][4], seen[3][4])
     gs.close()
     fb.close()
+
+
+def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, monkeypatch):
+    """gibbs_exact.hip's single-wavefront kernel (linear domain, static arc records, DPP choice) and gibbs.hip's workgroup
+    kernel (log domain; CARMEL_HIP_GIBBS_WORKGROUP=1) are two implementations of the reference's chain: the same samples,
+    block for block, the same sweep probabilities and final weights -- exact mode, and the parallel sweep too."""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    res = {}
+    for mode in (0, 1):
+        for which in ("wave", "workgroup"):
+            if which == "workgroup":
+                monkeypatch.setenv("CARMEL_HIP_GIBBS_WORKGROUP", "1")
+            else:
+                monkeypatch.delenv("CARMEL_HIP_GIBBS_WORKGROUP", raising=False)
+            oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                                   [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+            gs = HipGibbs(fb, 12, burnin=3, seed=11, mode=mode)
+            lp = gs.run()
+            res[(mode, which)] = (np.array(lp), gs.iter_cheap_logprob.copy(), [gs.sample(b) for b in range(gs.n_blocks)], fb.weights().copy())
+            gs.close()
+            fb.close()
+        a, b = res[(mode, "wave")], res[(mode, "workgroup")]
+        assert a[2] == b[2]
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-10)
+        np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)

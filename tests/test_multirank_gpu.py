@@ -222,37 +222,57 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     assert j1["exchange"]["loopback"] and j1["exchange_ms"] > 0
 
 
+_LIFETIME = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import torch
+from carmel_amd import synth
+from carmel_amd.trainer import HipComm, HipForwardBackward
+w = synth.random_wfst(400, 8, n_sym=6, p_eps=0.1, seed=5)
+c = synth.random_walk_corpus(w, 300, min_arcs=3, max_arcs=12, seed=5, out_degree=8)
+ref = HipForwardBackward(w, c, device=0)
+ref.estimate()
+ref.maximize(1.0)
+want = ref.weights()
+ref.close()
+
+
+def raises(fn, what):
+    try:
+        fn()
+    except Exception as e:
+        assert what in str(e), str(e)
+        return
+    raise AssertionError("expected an error mentioning: " + what)
+
+
+for how in ("close", "abort"):
+    fb = HipForwardBackward(w, c, device=0)
+    comm = HipComm(0, 0, 1, HipComm.unique_id())
+    info = fb.exchange_plan(comm, 2, False)
+    assert info["sharded"]
+    ext = torch.zeros(int(w.n_arcs) + 4, dtype=torch.float64, device="cuda")
+    raises(lambda: fb.use_external_counts(ext.data_ptr()), "sharded exchange is planned")
+    fb.estimate_async()
+    fb.allreduce_counts(comm)
+    getattr(comm, how)()          # the communicator goes first; the plan goes with it
+    raises(lambda: fb.exchange_info(), "no exchange planned")
+    fb.use_external_counts(ext.data_ptr())  # allowed again
+    fb.use_external_counts(0)
+    fb.estimate()
+    fb.maximize(1.0)
+    np.testing.assert_allclose(fb.weights(), want, rtol=1e-12)
+    fb.close()
+print("lifetime ok")
+"""
+
+
 def test_communicator_and_trainer_may_go_in_either_order():
     """round-3 advisor findings: a plan points at its communicator, so (i) destroying the communicator first must leave the
     trainer usable and destroyable (the front end's guards ran in that order), (ii) the count buffer cannot be pointed
     elsewhere under a sharded plan, (iii) aborting the communicator after planning -- bench.py's fallback when an enqueue
-    fails -- leaves a trainer that steps unplanned."""
-    import torch
-    from carmel_amd import synth
-    from carmel_amd.trainer import HipComm, HipForwardBackward
-    w = synth.random_wfst(400, 8, n_sym=6, p_eps=0.1, seed=5)
-    c = synth.random_walk_corpus(w, 300, min_arcs=3, max_arcs=12, seed=5, out_degree=8)
-    ref = HipForwardBackward(w, c, device=0)
-    ref.estimate()
-    ref.maximize(1.0)
-    want = ref.weights()
-    ref.close()
-    for how in ("close", "abort"):
-        fb = HipForwardBackward(w, c, device=0)
-        comm = HipComm(0, 0, 1, HipComm.unique_id())
-        info = fb.exchange_plan(comm, 2, False)
-        assert info["sharded"]
-        ext = torch.zeros(int(w.n_arcs) + 4, dtype=torch.float64, device="cuda")
-        with pytest.raises(Exception, match="sharded exchange is planned"):
-            fb.use_external_counts(ext.data_ptr())
-        fb.estimate_async()
-        fb.allreduce_counts(comm)
-        getattr(comm, how)()          # the communicator goes first; the plan goes with it
-        with pytest.raises(Exception, match="no exchange planned"):
-            fb.exchange_info()
-        fb.use_external_counts(ext.data_ptr())  # allowed again
-        fb.use_external_counts(0)
-        fb.estimate()
-        fb.maximize(1.0)
-        np.testing.assert_allclose(fb.weights(), want, rtol=1e-12)
-        fb.close()
+    fails -- leaves a trainer that steps unplanned.  (In a process of its own, like every test that creates an RCCL
+    communicator.)"""
+    p = subprocess.run([sys.executable, "-c", _LIFETIME, ROOT], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=600)
+    assert p.returncode == 0 and "lifetime ok" in p.stdout, p.stdout[-3000:]

@@ -76,7 +76,22 @@ def main():
                 # meet in one atomic add each, so the last bit moves from run to run -- of the SAME form too)
                 assert np.allclose(got[2], ref[2], rtol=1e-13, atol=0), (runs, mode)
 
+    def forest_exact_case(d, s):
+        """forest_exact.hip against the oracle's chain on random forests: sizes, depths, priors and burn-in vary with the seed"""
+        ftext, ntext = F.synth_forests(20 + s % 200, 10 + s % 60, s)
+        of, hf = F.make(oracle, ftext, ntext, s)
+        iters, burnin, alpha = 3 + s % 5, s % 3, 0.05 + 0.1 * (s % 7)
+        hf.gibbs(iters, burnin=burnin, alpha=alpha, seed=s, mode=0)
+        ref = of.gibbs(s, iters, burnin=burnin, alpha=alpha)
+        for b in range(hf.n_forests):
+            assert hf.sample(b) == ref["samples"][b], b
+        np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
+        np.testing.assert_allclose(hf.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+        np.testing.assert_allclose(np.exp(hf.weights()), np.exp(of.weights()), rtol=1e-9, atol=1e-15)
+        hf.close()
+
     cases += [
+        ("forest exact chain", forest_exact_case),
         ("matrix fb", lambda d, s: M.test_matrix_estep_against_the_oracle_and_the_lattices(
             oracle, s, dict(n_states=5 + s % 80, deg=2 + s % 9, n_sym=2 + s % 6, n_pairs=20 + (s * 7) % 300, p_eps=0.05 * (s % 9), lo=1 + s % 3,
                             hi=4 + s % 12))),
@@ -89,6 +104,8 @@ def main():
     for name, fn in cases:
         ok = 0
         for seed in range(first, first + n):
+            if os.environ.get("FUZZ_VERBOSE"):
+                print("  %s seed %d" % (name, seed), flush=True)
             with tempfile.TemporaryDirectory() as d:
                 mp = MP()
                 try:
