@@ -671,6 +671,7 @@ struct carmel_hip_gibbs {
   bool wave_ok = false;
   DevBuf<GxBlock> gx_blocks;
   DevBuf<uint32_t> gx_rec, gx_nrm, sample_nrm, new_nrm;
+  DevBuf<uint16_t> gx_state_lev;
   uint32_t cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
   // parallel sweep: two launch classes by LDS need (the blocks up to the 90th percentile of arcs; the rest)
   struct WaveClass {
@@ -858,6 +859,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
     if (ok) {
       std::vector<GxBlock> gb(bb.size());
       std::vector<uint32_t> rec(4 * L.out_arcs.size(), 0xffffffffu), nrm(2 * L.out_arcs.size(), 0xffffffffu);
+      std::vector<uint16_t> slev(L.out_off.size(), 0);
       for (size_t b = 0; b < bb.size(); ++b) {
         const BundleDesc& d = L.bundles[bb[b]];
         GxBlock& B = gb[b];
@@ -872,9 +874,14 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         B.sample_off = g->h_sample_off[b];
         B.wt = std::exp(L.pair_logw[d.pair_base]);
         const uint32_t* ooff = L.out_off.data() + d.off_base;
+        const uint32_t* lo = L.level_off.data() + d.level_base;
+        for (uint32_t l = 0; l < d.n_levels; ++l)
+          for (uint32_t st = lo[l]; st < lo[l + 1]; ++st) slev[d.off_base + st] = (uint16_t)l;
+        bool trellis = slev[d.off_base + B.start] == 0;
         for (uint32_t st = 0; st < d.n_states; ++st)
           for (uint32_t a = ooff[st]; a < ooff[st + 1]; ++a) {
             const uint2_t oa = L.out_arcs[d.out_base + a];
+            if (slev[d.off_base + oa.x] != slev[d.off_base + st] + 1) trellis = false;
             uint32_t* r = &rec[4 * (d.out_base + a)];
             uint32_t* n = &nrm[2 * (d.out_base + a)];
             r[0] = oa.x | (st << 16);
@@ -885,7 +892,9 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
               n[j - c0] = g->h_norm[cpar[j]];
             }
           }
+        if (trellis) B.n_levels |= 0x80000000u;
       }
+      HIPCHK(g->gx_state_lev.upload(slev, s));
       HIPCHK(g->gx_blocks.upload(gb, s));
       HIPCHK(g->gx_rec.upload(rec, s));
       HIPCHK(g->gx_nrm.upload(nrm, s));
@@ -1134,6 +1143,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     GX.arc_nrm = (const uint2*)g->gx_nrm.p;
     GX.out_off = g->out_off.p;
     GX.level_off = g->level_off.p;
+    GX.state_lev = g->gx_state_lev.p;
     GX.p_norm = g->p_norm.p;
     GX.p_prior = g->p_prior.p;
     GX.p_x = g->p_x.p;

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
       par1[a] = r.w;
     }
     for (uint32_t s = lane; s <= B.n_states; s += 64) ooff[s] = A.out_off[B.off_base + s];
-    for (uint32_t l = lane; l <= B.n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
+    const uint32_t n_levels = B.n_levels & 0x7fffffffu;  // (bit 31: the lattice is a trellis)
+    for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
     // the next block's previous sample sets out now
     GxOld On;
     gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     // is read only by the levels before it, so the terms are added straight into it; the level's arc range comes from the
     // level table one level ahead of its use ----
     bool ext = false;
+    GX_WAVE_SYNC();
     for (;;) {
       for (uint32_t s = lane; s < B.n_states; s += 64) {
         bv[s] = 0.0;
@@ -267,9 +269,9 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
         be[B.fin] = ext ? 1 : 0;
       }
       GX_WAVE_SYNC();
-      uint32_t a_hi = ooff[lvl[B.n_levels]];
-      uint32_t s_next = B.n_levels ? lvl[B.n_levels - 1] : 0u;
-      for (uint32_t l = B.n_levels; l-- > 0;) {
+      uint32_t a_hi = ooff[lvl[n_levels]];
+      uint32_t s_next = n_levels ? lvl[n_levels - 1] : 0u;
+      for (uint32_t l = n_levels; l-- > 0;) {
         const uint32_t s_lo = s_next, s_hi = lvl[l + 1];
         const uint32_t a_lo = ooff[s_lo];
         s_next = l ? lvl[l - 1] : 0u;
@@ -318,7 +320,50 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     // reference's list order (newest first: the reverse of the stored order), are subtracted from u x total until it drops
     // below zero; the chosen arc's parameters are recorded in chain order ----
     uint32_t n_ids = 0, step = 0;
-    {
+    if (B.n_levels & 0x80000000u) {
+      // TRELLIS (every arc joins neighbouring levels -- a tagger's lattice, any epsilon-free pair): the walk visits one state
+      // per level, so the uniform of a state's choice is its level's, and EVERY state makes its choice at once -- a lane per
+      // state, the reference's subtraction over its list of arcs (random.ipp:111-127).  What is left of the walk is following
+      // the chosen arcs from the start: one LDS read per step.  be / emx hold the chosen arc and its destination.
+      for (uint32_t s = lane; s < B.n_states; s += 64) {
+        const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+        uint32_t pick = a0;
+        if (a1 > a0) {
+          double choice = gibbs_uniform(A.seed, A.iter, b, A.state_lev[B.off_base + s]) * tot[s];
+          for (uint32_t a = a1; a-- > a0;) {  // list order: newest first
+            choice -= sh[a];
+            pick = a;
+            if (choice < 0) break;
+          }
+        }
+        be[s] = (int)pick;
+        emx[s] = a1 > a0 ? (int)(ds[pick] & 0xffffu) : (int)B.fin;
+      }
+      GX_WAVE_SYNC();
+      uint32_t s = B.start, n_path = 0;
+      while (s != B.fin && n_path < CM) {
+        const uint32_t a = (uint32_t)be[s];
+        if (lane == 0) idn[n_path] = a;  // (the path's arcs; their parameters are gathered below, side by side)
+        ++n_path;
+        s = (uint32_t)emx[s];
+      }
+      GX_WAVE_SYNC();
+      for (uint32_t base = 0; base < n_path; base += 64) {
+        const uint32_t t = base + lane;
+        const bool have = t < n_path;
+        const uint32_t a = have ? idn[t] : 0u;
+        const uint32_t p0 = have ? par0[a] : GX_NONE, p1 = have ? par1[a] : GX_NONE;
+        if (have) cheap.mul(pc[a]);
+        // slots of the parameters in the sample: chain order within an arc, arcs in path order
+        const unsigned long long m0 = __ballot(p0 != GX_NONE), m1 = __ballot(p1 != GX_NONE);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const uint32_t at = n_ids + (uint32_t)__popcll(m0 & below) + (uint32_t)__popcll(m1 & below);
+        if (p0 != GX_NONE && at < CM) ids[at] = p0;
+        if (p1 != GX_NONE && at + (p0 != GX_NONE) < CM) ids[at + (p0 != GX_NONE)] = p1;
+        n_ids += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+      }
+      n_ids = min(n_ids, CM);
+    } else {
       uint32_t s = B.start;
       while (s != B.fin) {
         const uint32_t a0 = ooff[s], a1 = ooff[s + 1], deg = a1 - a0;
@@ -376,7 +421,7 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
           if (p1 != GX_NONE && n_ids + 1 < GX_SAMPLE) ids[n_ids + 1] = p1;
         }
         n_ids += p0 == GX_NONE ? 0u : (p1 != GX_NONE ? 2u : 1u);
-        cheap.mul(pcv);
+        if (lane == 0) cheap.mul(pcv);  // (per-lane products: the trellis path multiplies side by side)
         s = to;
       }
       n_ids = min(n_ids, (uint32_t)GX_SAMPLE);
@@ -416,8 +461,10 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
     }
   }
   if (PAR) {  // the sweep's proposal probability: every wavefront adds its blocks'
+    double cl = cheap.ln();
+    for (int o = 32; o > 0; o >>= 1) cl += __shfl_down(cl, o, 64);
     if (lane == 0) {
-      unsafeAtomicAdd(A.iter_out + 1, cheap.ln());
+      unsafeAtomicAdd(A.iter_out + 1, cl);
       if (A.phase_clk)
         for (int k = 0; k < 5; ++k) atomicAdd(A.phase_clk + k, clk[k]);
     }
@@ -429,15 +476,15 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
       const uint32_t p = ids[k], n = idn[k];
       after.mul(n == GX_NONE ? A.p_prior[p] : gx_ld(A.p_x + p) / gx_ld(A.normsum + n));
     }
-  // cheap is accumulated by every lane alike (the walk is wavefront-uniform): lane 0's is the sweep's
-  double cache_ln = cnum.ln() - cden.ln(), after_ln = after.ln();
+  double cache_ln = cnum.ln() - cden.ln(), after_ln = after.ln(), cheap_ln = cheap.ln();
   for (int o = 32; o > 0; o >>= 1) {
     cache_ln += __shfl_down(cache_ln, o, 64);
     after_ln += __shfl_down(after_ln, o, 64);
+    cheap_ln += __shfl_down(cheap_ln, o, 64);
   }
   if (lane == 0) {
     A.iter_out[0] = cache_ln;
-    A.iter_out[1] = cheap.ln();
+    A.iter_out[1] = cheap_ln;
     A.iter_out[2] = after_ln;
     if (A.phase_clk)
       for (int k = 0; k < 5; ++k) A.phase_clk[k] += clk[k];

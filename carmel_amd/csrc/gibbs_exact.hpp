@@ -15,7 +15,7 @@ namespace carmel_hip {
 
 struct GxBlock {  // 48 bytes per block, in corpus order (the order of the chain)
   uint32_t out_base, off_base, level_base, n_arcs;  // into the per-lattice-arc / per-state / per-level arrays
-  uint32_t n_states, n_levels, start, fin;
+  uint32_t n_states, n_levels, start, fin;           // n_levels bit 31: every arc joins neighbouring levels (a trellis)
   uint64_t sample_off;
   double wt;  // the pair's weight (counts move by it)
 };
@@ -27,6 +27,7 @@ struct GxArgs {
   const uint2* arc_nrm;       // ... their norm groups (0xffffffff: a fixed probability, the parameter's prior)
   const uint32_t* out_off;    // per state: first out-arc (bundle-relative), n_states + 1 per block
   const uint32_t* level_off;  // per level: first state, n_levels + 1 per block
+  const uint16_t* state_lev;  // per state: its level
   const uint32_t* p_norm;
   const double* p_prior;
   double* p_x;                // CRP counts; their time-weighted sums are folded once per sweep (launch_forest_fold)
