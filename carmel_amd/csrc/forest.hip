@@ -2607,13 +2607,13 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     A.trace = trace_buf.p;
   }
   // exact mode on the device (forest_exact.hip): one persistent wavefront per sweep, every count in device memory.  It needs
-  // the per-forest height tables of the several-lanes sampler and runs at temperature 1; annealed runs, prior-scale inference
-  // (whose proposals rescale the counts between sweeps on the host) and locked parameters keep the host-driven loop below.
+  // the per-forest height tables of the several-lanes sampler and runs at temperature 1; annealed runs and locked parameters keep
+  // the host-driven loop below (prior-scale inference: the proposals between sweeps are made on the host either way).
   FExactArgs XA;
   std::memset(&XA, 0, sizeof XA);
   DevBuf<double> x_ccount, x_csum;
   DevBuf<unsigned long long> x_clk;
-  bool exact_dev = o->mode == 0 && F->multi_ok && !guard.changed && !(F->pi_stddev > 0) && (o->high_temp == 0 || o->high_temp == 1) &&
+  bool exact_dev = o->mode == 0 && F->multi_ok && !guard.changed && (o->high_temp == 0 || o->high_temp == 1) &&
                    (o->low_temp == 0 || o->low_temp == 1) && nf > 0 && !getenv("CARMEL_HIP_FOREST_EXACT_HOST");
   if (exact_dev) {
     for (auto& c : F->classes) {
@@ -2912,75 +2912,94 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         }
         HIPCHK(hipStreamSynchronize(s));
       }
-      // propose_new_priors (gibbs.hpp:525-553) on the sweeps that infer (gibbs.hpp:559-563).  The exact schedule keeps its
-      // counts on the host between forests (above); the proposal moves them there and the device copies follow.
-      const uint32_t pstart = F->pi_start ? F->pi_start : burnin;
-      if (F->pi_stddev > 0 && nexti > 1 && iter > 0 && pstart <= iter && (!F->pi_end || iter < F->pi_end)) {
-        const double sdev = F->pi_stddev;
-        const double q0 = gibbs_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;
-        std::vector<double> sc(nexti, 1.0);
-        double ln_a2 = 0.0;
-        for (uint32_t k = 1; k < nexti; ++k) {
-          sc[k] = 1.0 + sdev * gibbs_norm_quantile(q0 + gibbs_uniform(o->seed, iter, 0xfffffffeu, k) * qrem);
-          const double d_old = 1.0 / sc[k] - 1.0, d_new = sc[k] - 1.0;
-          ln_a2 += (d_new * d_new - d_old * d_old) / (2.0 * sdev * sdev);
-        }
-        auto cache_prob_all = [&]() {
-          std::vector<double> cc = prior, cs = pn;
-          double lp = 0.0;
-          for (uint64_t f = 0; f < nf; ++f)
-            for (uint32_t r : hsample[f]) {
-              const uint32_t n = F->h_norm[r];
-              double q = prior[r];
-              if (n != F_NONORM) {
-                q = cc[r] / cs[n];
-                cc[r] += 1.0;
-                cs[n] += 1.0;
-              }
-              lp += std::log(q);
-            }
-          return lp;
-        };
-        auto scale = [&](bool invert) {
-          std::fill(pn.begin(), pn.end(), 0.0);
-          for (uint32_t r = 0; r < nr; ++r) {
-            const uint32_t n = F->h_norm[r];
-            if (n == F_NONORM) continue;
-            const uint32_t i = meta[n + 1];
-            if (i > 0) {
-              double fct = sc[i];
-              if (invert) fct = 1.0 / fct;
-              const double s2 = fct * prior[r], d = s2 - prior[r];
-              hs[r] += d * ht[r];
-              hx[r] += d;
-              hn[n] += d;
-              prior[r] = s2;
-            }
-            pn[n] += prior[r];
-          }
-        };
-        const double p1 = cache_prob_all();
-        scale(false);
-        const double p2 = cache_prob_all();
-        const double a = std::exp((p2 - p1) + ln_a2);
-        const bool accept = gibbs_uniform(o->seed, iter, 0xffffffffu, 0) < a;
-        if (!accept)
-          scale(true);
-        else
-          for (uint32_t k = 1; k < nexti; ++k) F->pi_cumulative[k - 1] *= sc[k];
-        HIPCHK(hipMemcpyAsync(F->p_prior.p, prior.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(F->prior_norm.p, pn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(F->p_x.p, hx.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipMemcpyAsync(F->normsum.p, hn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    // propose_new_priors (gibbs.hpp:525-553) on the sweeps that infer (gibbs.hpp:559-563), on the host: the proposal rescales
+    // every prior, count, norm sum and time-weighted sum and scores the whole sample twice.  The host-driven schedule keeps its
+    // counts there anyway; the device chain hands its state over for the proposal and takes it back (a few tens of MB per
+    // inferring sweep against a 0.5 s sweep).
+    const uint32_t pstart = F->pi_start ? F->pi_start : burnin;
+    if (o->mode == 0 && F->pi_stddev > 0 && nexti > 1 && iter > 0 && pstart <= iter && (!F->pi_end || iter < F->pi_end)) {
+      if (exact_dev) {
+        hx.resize(nr);
+        hs.resize(nr);
+        ht.resize(nr);
+        hn.resize(ng);
+        std::vector<uint32_t> sl(nf), sr(F->h_sample_off.back());
+        HIPCHK(hipMemcpyAsync(hx.data(), F->p_x.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(hs.data(), F->p_s.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(ht.data(), F->p_tmax.p, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (ng) HIPCHK(hipMemcpyAsync(hn.data(), F->normsum.p, ng * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sl.data(), F->sample_len[0].p, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sr.data(), F->sample_rules[0].p, sr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        double* tr = F->pi_trace.data() + (size_t)iter * 6;
-        tr[0] = 1;
-        tr[1] = accept ? 1 : 0;
-        tr[2] = p1;
-        tr[3] = p2;
-        tr[4] = std::exp(ln_a2);
-        tr[5] = a;
+        hsample.resize(nf);
+        for (uint64_t f = 0; f < nf; ++f) hsample[f].assign(sr.begin() + F->h_sample_off[f], sr.begin() + F->h_sample_off[f] + sl[f]);
       }
+      const double sdev = F->pi_stddev;
+      const double q0 = gibbs_norm_cdf((0.0 - 1.0) / sdev), qrem = 1.0 - q0;
+      std::vector<double> sc(nexti, 1.0);
+      double ln_a2 = 0.0;
+      for (uint32_t k = 1; k < nexti; ++k) {
+        sc[k] = 1.0 + sdev * gibbs_norm_quantile(q0 + gibbs_uniform(o->seed, iter, 0xfffffffeu, k) * qrem);
+        const double d_old = 1.0 / sc[k] - 1.0, d_new = sc[k] - 1.0;
+        ln_a2 += (d_new * d_new - d_old * d_old) / (2.0 * sdev * sdev);
+      }
+      auto cache_prob_all = [&]() {
+        std::vector<double> cc = prior, cs = pn;
+        double lp = 0.0;
+        for (uint64_t f = 0; f < nf; ++f)
+          for (uint32_t r : hsample[f]) {
+            const uint32_t n = F->h_norm[r];
+            double q = prior[r];
+            if (n != F_NONORM) {
+              q = cc[r] / cs[n];
+              cc[r] += 1.0;
+              cs[n] += 1.0;
+            }
+            lp += std::log(q);
+          }
+        return lp;
+      };
+      auto scale = [&](bool invert) {
+        std::fill(pn.begin(), pn.end(), 0.0);
+        for (uint32_t r = 0; r < nr; ++r) {
+          const uint32_t n = F->h_norm[r];
+          if (n == F_NONORM) continue;
+          const uint32_t i = meta[n + 1];
+          if (i > 0) {
+            double fct = sc[i];
+            if (invert) fct = 1.0 / fct;
+            const double s2 = fct * prior[r], d = s2 - prior[r];
+            hs[r] += d * ht[r];
+            hx[r] += d;
+            hn[n] += d;
+            prior[r] = s2;
+          }
+          pn[n] += prior[r];
+        }
+      };
+      const double p1 = cache_prob_all();
+      scale(false);
+      const double p2 = cache_prob_all();
+      const double a = std::exp((p2 - p1) + ln_a2);
+      const bool accept = gibbs_uniform(o->seed, iter, 0xffffffffu, 0) < a;
+      if (!accept)
+        scale(true);
+      else
+        for (uint32_t k = 1; k < nexti; ++k) F->pi_cumulative[k - 1] *= sc[k];
+      HIPCHK(hipMemcpyAsync(F->p_prior.p, prior.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(F->prior_norm.p, pn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(F->p_x.p, hx.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipMemcpyAsync(F->normsum.p, hn.data(), ng * sizeof(double), hipMemcpyHostToDevice, s));
+      if (exact_dev) HIPCHK(hipMemcpyAsync(F->p_s.p, hs.data(), nr * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+      double* tr = F->pi_trace.data() + (size_t)iter * 6;
+      tr[0] = 1;
+      tr[1] = accept ? 1 : 0;
+      tr[2] = p1;
+      tr[3] = p2;
+      tr[4] = std::exp(ln_a2);
+      tr[5] = a;
     }
     if (iter_logprob) iter_logprob[iter] = cache_lp;
     if (iter_cheap_logprob) iter_cheap_logprob[iter] = cheap_lp;
