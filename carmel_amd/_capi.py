@@ -22,7 +22,7 @@ SYMBOLS = [
     "carmel_hip_get_counts", "carmel_hip_set_counts", "carmel_hip_maximize", "carmel_hip_keep_em_weights", "carmel_hip_random_restart", "carmel_hip_save_counts",
     "carmel_hip_fractional_counts", "carmel_hip_set_digamma",
     "carmel_hip_save_best", "carmel_hip_load_best", "carmel_hip_host_build", "carmel_hip_host_dims",
-    "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_export_waves", "carmel_hip_host_transpose", "carmel_hip_host_free",
+    "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_export_waves", "carmel_hip_host_transpose", "carmel_hip_host_tile_sweep", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_lattice_stats", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_run_ex", "carmel_hip_gibbs_set_prior_inference", "carmel_hip_gibbs_prior_trace",
     "carmel_hip_gibbs_n_prior_scales", "carmel_hip_gibbs_set_run_share", "carmel_hip_gibbs_best_stats", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_set_observer", "carmel_hip_gibbs_current_probs", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
@@ -152,6 +152,8 @@ def _load():
     lib.carmel_hip_host_export_waves.argtypes = [vp] * 10
     lib.carmel_hip_host_transpose.argtypes = [vp] * 12
     lib.carmel_hip_host_transpose.restype = None
+    lib.carmel_hip_host_tile_sweep.argtypes = [vp] * 3
+    lib.carmel_hip_host_tile_sweep.restype = None
     lib.carmel_hip_host_export_lanes.restype = None
     lib.carmel_hip_host_free.argtypes = [vp]
     lib.carmel_hip_host_free.restype = None

@@ -206,6 +206,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.prune = prune != 0;
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
+  if (const char* e = getenv("CARMEL_HIP_TILE_SWEEP")) opt.tile_sweep = atoi(e) != 0;  // A/B: 0 = the five-kernel E-step's layout
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
@@ -267,6 +268,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->pair_id.upload(L.pair_id, s));
   HIPCHK(t->pair_logw.upload(L.pair_logw, s));
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
+  if (L.tile_sweep)
+    HIPCHK(t->tile_group.upload(L.tile_group, s));
+  else
+    t->tile_group.release();
   HIPCHK(t->wave_descs.upload(L.waves, s));
   HIPCHK(t->wave_fwd.upload(L.wave_fwd, s));
   HIPCHK(t->wave_bwd.upload(L.wave_bwd, s));
@@ -304,6 +309,12 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->lane_pair.upload(L.lane_pair, s));
   HIPCHK(t->lane_nstates.upload(L.lane_nstates, s));
   HIPCHK(t->lane_logw.upload(L.lane_logw, s));
+  if (L.tile_sweep && t->lane_fwdx.n) {
+    HIPCHK(t->lane_rec2.alloc(t->lane_bwd.n));
+    HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, t->lane_rec2.bytes(), s));
+    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, s));
+  } else
+    t->lane_rec2.release();
   t->lane_records = L.wave_slot_base + L.wave_bwd.size();  // first bundle slot: [lane records | wave records | bundle arcs]
   HIPCHK(t->post.alloc(L.n_post));
   HIPCHK(t->wcache.alloc(t->lane_records));
@@ -805,6 +816,7 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
   T.n_post = t->post.n;
   T.n_buckets = (uint32_t)t->t_buckets.n;
   T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
+  T.tile = t->lat.tile;
   T.tile_first = T.tile_count = 0;
   T.bucket_first = 0;
   T.bucket_count = T.n_buckets;
@@ -858,6 +870,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.fwd = (const uint2*)t->lane_fwd.p;
   LA.fwdx = t->lane_fwdx.p;
   LA.bwd = t->lane_bwd.p;
+  LA.rec2 = t->lane_rec2.p;
   LA.lane_pair = t->lane_pair.p;
   LA.lane_nstates = t->lane_nstates.p;
   LA.lane_logw = t->lane_logw.p;
@@ -896,7 +909,12 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.pre_weights = t->use_transpose ? 1u : 0u;
   ExchangePlan* const xp = (t->xplan && exchange_is_sharded(t->xplan) && t->use_transpose) ? t->xplan : nullptr;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
-  const uint32_t lane_tiles = (uint32_t)((t->wcache.n + TRANS_TILE - 1) / TRANS_TILE);
+  const uint32_t lane_tiles = (uint32_t)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
+  // a corpus of plain lane lattices laid out for it: weights in, sweeps and posteriors out of a tile in one kernel
+  // (CARMEL_HIP_TILE_SWEEP_KERNEL=0: the three kernels on the same layout, bit-identical)
+  static const bool tile_kernel_off = getenv("CARMEL_HIP_TILE_SWEEP_KERNEL") && atoi(getenv("CARMEL_HIP_TILE_SWEEP_KERNEL")) == 0;
+  const bool tile_sweep = t->use_transpose && t->lat.tile_sweep && t->tile_group.n && !tile_kernel_off &&
+                          ((T.scatter & 3u) == 0u || ((T.scatter & 3u) == 3u && T.use_runs));
   const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty();
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
@@ -934,6 +952,8 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
         HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
         HIPCHK(hipStreamWaitEvent(s, t->cev[q], 0));
       }
+  } else if (tile_sweep) {
+    HIPCHK(launch_tile_sweep(T, LA, t->tile_group.p, 0, lane_tiles, s));
   } else {
     if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
     // the one-per-wavefront lattices: every class is one launch of single-wave workgroups with its own LDS size -- side by
@@ -981,7 +1001,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   HIPCHK(hipEventRecord(t->ev_join, t->side));
   if (t->use_transpose) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
-    const uint32_t first = side_by_side ? lane_tiles : 0u;
+    const uint32_t first = (side_by_side || tile_sweep) ? lane_tiles : 0u;
     HIPCHK(launch_trans_c_tiles(T, first, T.n_tiles > first ? T.n_tiles - first : 0u, s));
     if (xp) {  // the counts leave arc range by arc range, each into its reduce-scatter while the next is being summed
       int rc = exchange_counts_out(t, xp, T);

@@ -112,6 +112,8 @@ struct carmel_hip_trainer {
   uint64_t wave_slot_base = 0, wave_records = 0;
   DevBuf<double> wave_spill;
   DevBuf<LaneGroup> lane_groups;
+  DevBuf<uint32_t> tile_group;  // LatticeSet::tile_group (tile sweep)
+  DevBuf<uint32_t> lane_rec2;   // ... and its packed records (LaneArgs::rec2)
   DevBuf<uint2_t> lane_fwd;
   // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path
   DevBuf<TransBucket> t_buckets;

@@ -132,6 +132,15 @@ void carmel_hip_host_transpose(carmel_hip_host_lattices* h, uint64_t* dims6, voi
   if (slot_pos) std::memcpy(slot_pos, L.slot_pos.data(), L.slot_pos.size() * 8);
 }
 
+void carmel_hip_host_tile_sweep(carmel_hip_host_lattices* h, uint32_t* info2, uint32_t* tile_group) {
+  const LatticeSet& L = h->L;
+  if (info2) {
+    info2[0] = L.tile;
+    info2[1] = L.tile_sweep ? (uint32_t)L.tile_group.size() : 0u;
+  }
+  if (tile_group && L.tile_sweep) std::memcpy(tile_group, L.tile_group.data(), L.tile_group.size() * 4);
+}
+
 void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32_t* in_arcs, uint32_t* out_arcs,
                             uint32_t* in_off, uint32_t* out_off, uint32_t* level_off, uint32_t* pair_start,
                             uint32_t* pair_final, uint32_t* pair_id, double* pair_logw, uint32_t* classes5,

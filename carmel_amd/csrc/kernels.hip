@@ -1121,13 +1121,14 @@ __device__ __forceinline__ RunLds run_lds(double* after_tile) {
   R.pref = R.mask + TRANS_RUN_WORDS;
   return R;
 }
-// (called by all 1024 threads; contains barriers)
+// (called by all NT threads of the workgroup; contains barriers)
+template <uint32_t NT = 1024>
 __device__ __forceinline__ void run_stage(const RunLds& R, const uint16_t* __restrict__ rel, const uint32_t* __restrict__ src,
                                           uint32_t nr) {
   constexpr uint32_t WORDS = TRANS_RUN_WORDS, PER = WORDS / 64;
-  for (uint32_t w = threadIdx.x; w < WORDS; w += 1024) R.mask[w] = 0u;
+  for (uint32_t w = threadIdx.x; w < WORDS; w += NT) R.mask[w] = 0u;
   __syncthreads();
-  for (uint32_t r = threadIdx.x; r < nr; r += 1024) {
+  for (uint32_t r = threadIdx.x; r < nr; r += NT) {
     const uint32_t first = rel[r];
     R.r_src[r] = src[r] - first;
     atomicOr(&R.mask[first >> 5], 1u << (first & 31u));
@@ -1223,9 +1224,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
   const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
   if (tloc >= T.tile_count) return;
   const uint32_t tile = T.tile_first + tloc;
-  const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
+  const uint64_t p0 = (uint64_t)tile * T.tile;
   if (p0 >= T.n_wcache) return;  // tiles of bundle positions: the bundle sweep gathers its weights itself
-  const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_wcache - p0);
+  const uint32_t np = (uint32_t)min((uint64_t)T.tile, T.n_wcache - p0);
 #pragma unroll
   for (int k = 0; k < TRANS_KT; ++k) lds[threadIdx.x + k * 1024] = 0.0;
   if (RL && !SQ) {
@@ -1280,8 +1281,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
     if (tloc >= T.tile_count) return;
   }
   const uint32_t tile = T.tile_first + tloc;
-  const uint64_t p0 = (uint64_t)tile * TRANS_TILE;
-  const uint32_t np = (uint32_t)min((uint64_t)TRANS_TILE, T.n_post - p0);
+  const uint64_t p0 = (uint64_t)tile * T.tile;
+  const uint32_t np = (uint32_t)min((uint64_t)T.tile, T.n_post - p0);
   const uint64_t i0 = T.tile_base[tile];
   const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
   double v[TRANS_KT];
@@ -1419,6 +1420,325 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
     if ((threadIdx.x & 63) == 0) T.counts[B.arc_lo + a] = v;
   }
 }
+// ---------------- tile sweep: weights in, lane sweeps, posteriors out -- one kernel per tile of small lattices ----------------
+// (LatticeSet::tile_sweep.)  Where every lattice of the corpus is a plain lane lattice of at most TILE_SWEEP_ROWS arcs, the lane
+// groups are laid out so that none straddles a tile of TILE_SWEEP_TILE positions, and the three middle kernels of the E-step
+// become one: the workgroup of a tile places the tile's weights (its stretch of X) in LDS at their lane positions -- what
+// trans_w_tile writes to wcache --, its wavefronts sweep the tile's groups out of LDS (the posterior of an arc replaces its
+// weight), and the tile's items leave for XC as trans_c_tile sends them.  Per lattice arc the E-step no longer writes and
+// re-reads wcache (16 B + the sweep's two reads of it) nor post (16 B): what is left between the two bucket passes is X in, one
+// packed record per position, XC out.  LDS of a tile: its positions' weights / posteriors (8 B), their records (4 B), and
+// the forward / backward values of its groups (LaneGroup::spill_row = a group's first row of 64); the run tables of the
+// scattering store are staged over the records once the sweeps are done.
+// A wavefront that sweeps out of LDS has nobody to hide behind (a tile has two to fifteen groups, a CU one tile): what it
+// costs is the length of its dependent chain.  So the topology is in LDS with the weights (no memory round trip inside the
+// sweep), and what is static about a row is decided when the records are packed (pack_tile_records_kernel): whether the
+// arc's other end is the state just finished (its value is in a register: no column read) and whether the arc is its state's
+// only one (the state's value is one addition: no log-sum-exp) -- a chain lattice's sweep is an add and a store per row.
+#define TILE_SWEEP_THREADS 512
+#define TS_SRC(x) ((x) & 0xffu)
+#define TS_POS(x) (((x) >> 8) & 63u)
+#define TS_FV 0x4000u
+#define TS_FL 0x8000u
+#define TS_DST(x) (((x) >> 16) & 0xffu)
+#define TS_BV 0x1000000u
+#define TS_BL 0x2000000u
+#define TS_FCHAIN 0x4000000u   // forward: the source is the state finished last (or the row is padding)
+#define TS_FEASY 0x8000000u    // forward: the only in-arc of its state (or padding)
+#define TS_BCHAIN 0x10000000u  // backward: the destination is the state finished last (or padding)
+#define TS_BEASY 0x20000000u   // backward: the only out-arc of its state (or padding)
+// one thread per lane of a group walks the lane's rows: the two records of a row in one word + the static properties above
+__global__ void pack_tile_records_kernel(const LaneGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ lane_nstates,
+                                         const uint32_t* __restrict__ fwdx, const uint32_t* __restrict__ bwd, uint32_t* __restrict__ out) {
+  const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (gi >= n_groups) return;
+  const LaneGroup g = groups[gi];
+  const uint32_t S = lane < g.n_lanes ? lane_nstates[g.pair_base + lane] : 0u;
+  uint32_t d = 1, s = S >= 2 ? S - 2 : 0u;
+  bool fresh_f = true, fresh_b = true;
+  for (uint32_t k = 0; k < g.maxlen; ++k) {
+    const size_t p = g.stream_base + (size_t)k * 64 + lane;
+    const uint32_t f = fwdx[p], b = bwd[p];
+    uint32_t x = (f & 0xffu) | (((f >> LANE_POS_SHIFT) & 63u) << 8) | ((f & LANE_VALID) ? TS_FV : 0u) | ((f & LANE_LAST) ? TS_FL : 0u) |
+                 ((b & 0xffu) << 16) | ((b & LANE_VALID) ? TS_BV : 0u) | ((b & LANE_LAST) ? TS_BL : 0u);
+    const bool f_pad = !(f & (LANE_VALID | LANE_LAST)), b_pad = !(b & (LANE_VALID | LANE_LAST));
+    if (f_pad || (f & LANE_STATE_MASK) + 1 == d) x |= TS_FCHAIN;
+    if (f_pad || ((f & LANE_VALID) && (f & LANE_LAST) && fresh_f)) x |= TS_FEASY;
+    if (b_pad || (b & LANE_STATE_MASK) == s + 1) x |= TS_BCHAIN;
+    if (b_pad || ((b & LANE_VALID) && (b & LANE_LAST) && fresh_b)) x |= TS_BEASY;
+    if (!f_pad) fresh_f = false;
+    if (f & LANE_LAST) {
+      ++d;
+      fresh_f = true;
+    }
+    if (!b_pad) fresh_b = false;
+    if (b & LANE_LAST) {
+      if (s > 0) --s;
+      fresh_b = true;
+    }
+    out[p] = x;
+  }
+}
+// one group: records, weights / posteriors in the lane's columns of LDS rows (recl, rows), values in its column `col`: the
+// arithmetic of sweep_lane_kernel, operation for operation (an "easy" row is Lse's own result for a single term)
+struct TileLane {  // a lane's lattice: states, ln(pair weight), corpus pair (requested a group ahead of its sweep)
+  uint32_t S, pair;
+  double lwt;
+};
+__device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, const LaneGroup& g, const int lane) {
+  TileLane L;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  L.S = active ? A.lane_nstates[g.pair_base + lane] : 0u;
+  L.lwt = active ? A.lane_logw[g.pair_base + lane] : 0.0;
+  L.pair = active ? A.lane_pair[g.pair_base + lane] : 0u;
+  return L;
+}
+__device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, const int lane, double* col,
+                                                 double* rows, const uint32_t* recl) {
+  constexpr int U = (int)LANE_CHUNK;
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t S = L.S, pair = L.pair;
+  const double lwt = L.lwt;
+  const uint32_t maxlen = g.maxlen;
+  // ---------- forward ----------
+  if (active) col[0] = 0.0;
+  {
+    Lse acc;
+    acc.init();
+    uint32_t d = 1;
+    double prev = 0.0;
+    uint32_t x1[U], x2[U];  // records of the next chunk and of the one after
+    double w1[U];           // weights of the next chunk
+#pragma unroll
+    for (int u = 0; u < U; ++u) x1[u] = recl[u * 64];
+#pragma unroll
+    for (int u = 0; u < U; ++u) x2[u] = recl[((U < maxlen ? U : 0) + u) * 64];
+#pragma unroll
+    for (int u = 0; u < U; ++u) w1[u] = rows[TS_POS(x1[u]) * 64];
+    for (uint32_t kb = 0; kb < maxlen; kb += U) {
+      uint32_t x[U];
+      double w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x[u] = x1[u];
+        w[u] = w1[u];
+        x1[u] = x2[u];
+      }
+      const uint32_t k2 = kb + 2 * U < maxlen ? kb + 2 * U : kb;  // (past the end: any row of the group)
+#pragma unroll
+      for (int u = 0; u < U; ++u) x2[u] = recl[(k2 + u) * 64];
+#pragma unroll
+      for (int u = 0; u < U; ++u) w1[u] = rows[TS_POS(x1[u]) * 64];
+      if (__all(((x[0] & x[1] & x[2] & x[3]) & (TS_FCHAIN | TS_FEASY)) == (TS_FCHAIN | TS_FEASY))) {
+        // every row of the chunk, in every lane: the only in-arc of its state, out of the state before it (or padding)
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (x[u] & TS_FV) {
+            prev += w[u];
+            col[d * 64] = prev;
+            ++d;
+          }
+        continue;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t xx = x[u];
+        double a_src = prev;
+        if (!__all(xx & TS_FCHAIN)) {
+          const double a = col[TS_SRC(xx) * 64];
+          a_src = (xx & TS_FCHAIN) ? prev : a;
+        }
+        if (__all(xx & TS_FEASY)) {
+          if (xx & TS_FV) {
+            prev = a_src + w[u];
+            col[d * 64] = prev;
+            ++d;
+          }
+        } else {
+          acc.add((xx & TS_FV) ? a_src + w[u] : NEG_INF);
+          if (xx & TS_FL) {
+            prev = acc.value();
+            col[d * 64] = prev;
+            ++d;
+            acc.init();
+          }
+        }
+      }
+    }
+  }
+  // ---------- ln p(pair), beta at the goal ----------
+  double next = NEG_INF;
+  if (active) {
+    const double lp = col[(S - 1) * 64];
+    A.pair_logprob[pair] = lp;
+    next = (lp == NEG_INF) ? NEG_INF : lwt - lp;
+    col[(S - 1) * 64] = next;
+  }
+  // ---------- backward + posteriors ----------
+  {
+    Lse acc;
+    acc.init();
+    uint32_t s = S >= 2 ? S - 2 : 0u;
+    uint32_t x1[U];
+    double w1[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x1[u] = recl[u * 64];
+      w1[u] = rows[u * 64];
+    }
+    for (uint32_t kb = 0; kb < maxlen; kb += U) {
+      double t[U], al[U];
+      uint32_t x[U];
+      double w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x[u] = x1[u];
+        w[u] = w1[u];
+      }
+      const uint32_t kn = kb + U < maxlen ? kb + U : kb;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        x1[u] = recl[(kn + u) * 64];
+        w1[u] = rows[(kn + u) * 64];
+      }
+      if (__all(((x[0] & x[1] & x[2] & x[3]) & (TS_BCHAIN | TS_BEASY)) == (TS_BCHAIN | TS_BEASY))) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          al[u] = col[s * 64];
+          t[u] = NEG_INF;
+          if (x[u] & TS_BV) {
+            next += w[u];
+            t[u] = next;
+            col[s * 64] = next;
+            if (s > 0) --s;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t xx = x[u];
+          al[u] = col[s * 64];  // alpha[s]: requested before this row can replace it with beta[s]; not waited for until the chunk's end
+          double b_dst = next;
+          if (!__all(xx & TS_BCHAIN)) {
+            const double b = col[TS_DST(xx) * 64];
+            b_dst = (xx & TS_BCHAIN) ? next : b;
+          }
+          t[u] = (xx & TS_BV) ? w[u] + b_dst : NEG_INF;
+          if (__all(xx & TS_BEASY)) {
+            if (xx & TS_BV) {
+              next = t[u];
+              col[s * 64] = next;
+              if (s > 0) --s;
+            }
+          } else {
+            acc.add(t[u]);
+            if (xx & TS_BL) {
+              next = acc.value();
+              col[s * 64] = next;
+              acc.init();
+              if (s > 0) --s;
+            }
+          }
+        }
+      }
+      // the rows' log posteriors; the exponentials are left to the whole workgroup (the tile's way out)
+#pragma unroll
+      for (int u = 0; u < U; ++u) rows[(kb + u) * 64] = (S >= 2 ? al[u] : NEG_INF) + t[u];
+    }
+  }
+}
+template <bool SCAT>
+__global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArgs T, LaneArgs A, const uint32_t* __restrict__ tile_group) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NT = TILE_SWEEP_THREADS, KT = (int)(TILE_SWEEP_TILE / NT), NW = NT / 64;
+  const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
+  if (tloc >= T.tile_count) return;
+  const uint32_t tile = T.tile_first + tloc;
+  const uint64_t i0 = T.tile_base[tile];
+  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
+  uint32_t* const recs = (uint32_t*)(lds + TILE_SWEEP_TILE);                // one packed record per position
+  double* const alpha = lds + TILE_SWEEP_TILE + TILE_SWEEP_TILE / 2;        // TILE_SWEEP_ALPHA_ROWS rows of values
+  const uint32_t g0 = tile_group[tile], g1 = tile_group[tile + 1];
+  const int lane = threadIdx.x & 63;
+  const uint64_t p0 = (uint64_t)tile * TILE_SWEEP_TILE;
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if (A.trace) t0 = __builtin_readcyclecounter();
+  // this wavefront's first group (its descriptor and its lanes' lattices arrive with the tile)
+  uint32_t gi = g0 + (threadIdx.x >> 6);
+  LaneGroup g = A.groups[gi < g1 ? gi : g0];
+  TileLane L = tile_lane(A, g, lane);
+  // ---- the tile's records as they are, its weights to their lane positions ----
+  {
+    uint32_t src[KT];
+    uint16_t pos[KT];
+    double v[KT];
+    uint4 rr[KT / 4];
+    const uint32_t np = (uint32_t)min((uint64_t)TILE_SWEEP_TILE, T.n_post - p0);  // (the record streams end with the last group)
+#pragma unroll
+    for (int k = 0; k < KT / 4; ++k) {
+      const uint32_t q = (threadIdx.x + k * NT) * 4;
+      rr[k] = q < np ? *(const uint4*)(A.rec2 + p0 + q) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const uint32_t i = threadIdx.x + k * NT;
+      src[k] = (!SCAT && i < ni) ? T.t_src[i0 + i] : 0u;
+      pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const uint32_t i = threadIdx.x + k * NT;
+      v[k] = SCAT ? (i < ni ? T.x[i0 + i] : 0.0) : T.x[src[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < KT / 4; ++k) *(uint4*)(recs + (threadIdx.x + k * NT) * 4) = rr[k];
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (threadIdx.x + k * NT < ni) lds[pos[k]] = v[k];
+  }
+  __syncthreads();
+  if (A.trace) t1 = __builtin_readcyclecounter();
+  // ---- the tile's groups, one per wavefront at a time ----
+  while (gi < g1) {
+    const uint32_t gn = gi + NW < g1 ? gi + NW : gi;  // the next one's, requested before this one's sweep
+    const LaneGroup g_next = A.groups[gn];
+    const TileLane L_next = tile_lane(A, g_next, lane);
+    const uint32_t off = (uint32_t)(g.stream_base - p0) + lane;
+    tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
+    g = g_next;
+    L = L_next;
+    gi += NW;
+  }
+  if (A.trace && lane == 0) A.trace[(size_t)tile * 16 + 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter() - t1;  // this wavefront's sweeps
+  __syncthreads();
+  if (A.trace) t2 = __builtin_readcyclecounter();
+  // ---- the tile's posteriors out ----
+  if (SCAT) {
+    const RunLds R = run_lds((double*)recs);
+    const uint32_t r0 = T.tr_off[tile];
+    run_stage<NT>(R, T.tr_rel + r0, T.tr_src + r0, T.tr_off[tile + 1] - r0);
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const uint32_t i = threadIdx.x + k * NT;
+      if (i < ni) T.xc[run_source(R, i)] = K_EXP(lds[T.t_pos[i0 + i]]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      const uint32_t i = threadIdx.x + k * NT;
+      if (i < ni) T.xc[i0 + i] = K_EXP(lds[T.t_pos[i0 + i]]);
+    }
+  }
+  if (A.trace && threadIdx.x == 0) {  // experiment (CARMEL_HIP_LANE_TRACE): cycles per phase
+    unsigned long long* o = A.trace + (size_t)tile * 16;
+    o[0] = t0;
+    o[1] = t1 - t0;
+    o[2] = t2 - t1;
+    o[3] = __builtin_readcyclecounter() - t2;
+    o[4] = ((unsigned long long)(g1 - g0) << 32) | ni;
+    o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) | A.groups[g0].maxlen;
+  }
+}
 __global__ void zero_list_kernel(double* p, const uint32_t* idx, uint32_t n) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < n) p[idx[k]] = 0.0;
@@ -1506,7 +1826,7 @@ static void trans_lds_attr() {
   static bool done = false;
   if (done) return;
   const int lds = (int)(TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) * 8;
-  const int lds_rl = lds + TRANS_RUN_CAP * 6;
+  const int lds_rl = lds + TRANS_RUN_LDS;
   TRANS_SET_LDS((trans_w_bucket_kernel<false, false>), lds);
   TRANS_SET_LDS((trans_w_bucket_kernel<true, false>), lds);
   TRANS_SET_LDS((trans_w_bucket_kernel<true, true>), lds_rl);
@@ -1531,7 +1851,7 @@ hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint
   if (!(T.scatter & 1u))
     hipLaunchKernelGGL((trans_w_bucket_kernel<false, false>), dim3(count), dim3(1024), TRANS_BUCKET * 8, stream, T);
   else if (T.use_runs)
-    hipLaunchKernelGGL((trans_w_bucket_kernel<true, true>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL((trans_w_bucket_kernel<true, true>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_LDS, stream, T);
   else
     hipLaunchKernelGGL((trans_w_bucket_kernel<true, false>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();
@@ -1547,7 +1867,7 @@ hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   if (T.scatter & 1u)
     hipLaunchKernelGGL((trans_w_tile_kernel<false, true>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
   else if (T.use_runs)
-    hipLaunchKernelGGL((trans_w_tile_kernel<true, false>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL((trans_w_tile_kernel<true, false>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_LDS, stream, T);
   else
     hipLaunchKernelGGL((trans_w_tile_kernel<false, false>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
   return hipGetLastError();
@@ -1562,9 +1882,39 @@ hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   if (!(T.scatter & 2u))
     hipLaunchKernelGGL((trans_c_tile_kernel<false, false>), dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
   else if (T.use_runs)
-    hipLaunchKernelGGL((trans_c_tile_kernel<true, true>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL((trans_c_tile_kernel<true, true>), g8, dim3(1024), TRANS_TILE * 8 + TRANS_RUN_LDS, stream, T);
   else
     hipLaunchKernelGGL((trans_c_tile_kernel<true, false>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
+  return hipGetLastError();
+}
+hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
+                             hipStream_t stream) {
+  if (!T0.n_buckets || !tile_count) return hipSuccess;
+  if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2) return hipErrorInvalidValue;
+  static bool attr = false;
+  const int lds = (int)TILE_SWEEP_LDS;
+  if (!attr) {
+    TRANS_SET_LDS((tile_sweep_kernel<false>), lds);
+    TRANS_SET_LDS((tile_sweep_kernel<true>), lds);
+    attr = true;
+  }
+  TransArgs T = T0;
+  T.tile_first = tile_first;
+  T.tile_count = tile_count;
+  const dim3 g8((tile_count + 7) / 8 * 8);
+  // (the scattering forms of both directions go together: TransArgs::scatter is 3 where the corpus has run-length indices)
+  if ((T.scatter & 3u) == 3u && T.use_runs)
+    hipLaunchKernelGGL((tile_sweep_kernel<true>), g8, dim3(TILE_SWEEP_THREADS), lds, stream, T, A, tile_group);
+  else if (!(T.scatter & 3u))
+    hipLaunchKernelGGL((tile_sweep_kernel<false>), g8, dim3(TILE_SWEEP_THREADS), lds, stream, T, A, tile_group);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
+                                    const uint32_t* bwd, uint32_t* out, hipStream_t stream) {
+  if (n_groups)
+    hipLaunchKernelGGL(pack_tile_records_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, groups, n_groups, lane_nstates, fwdx, bwd, out);
   return hipGetLastError();
 }
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream) {
@@ -1581,7 +1931,7 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T0, uint32_t first, uint
   if (T.scatter & 2u)
     hipLaunchKernelGGL((trans_c_bucket_kernel<false, true>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   else if (T.use_runs)
-    hipLaunchKernelGGL((trans_c_bucket_kernel<true, false>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_CAP * 6, stream, T);
+    hipLaunchKernelGGL((trans_c_bucket_kernel<true, false>), g8, dim3(1024), TRANS_BUCKET * 8 + TRANS_RUN_LDS, stream, T);
   else
     hipLaunchKernelGGL((trans_c_bucket_kernel<false, false>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   return hipGetLastError();

@@ -16,6 +16,7 @@ struct LaneArgs {
   const uint2* fwd;      // forward records {flags, arc id} (gather path)
   const uint32_t* fwdx;  // forward records, flags word only (pre-distributed weights)
   const uint32_t* bwd;   // backward records: destination | flags only (the arc id stays on the host)
+  const uint32_t* rec2;  // tile sweep: forward and backward record of a position packed into one word (launch_pack_tile_records)
   const uint32_t* lane_pair;
   const uint32_t* lane_nstates;
   const double* lane_logw;
@@ -107,11 +108,13 @@ struct TransArgs {
   uint32_t scatter;         // bit 0 (weights) / bit 1 (counts): the first pass of that direction writes its items where the
                             // second pass reads them as one sequential stretch (x tile-major / xc bucket-major), instead of
                             // writing sequentially and leaving the gather to the second pass
+  uint32_t tile;            // positions per tile (LatticeSet::tile)
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
   uint32_t bucket_first, bucket_count;  // the bucket range of this launch of a bucket pass (arc-range chunks of the exchange)
 };
 
-#define TRANS_RUN_CAP 2560
+#define TRANS_RUN_CAP 4096
+#define TRANS_RUN_LDS (TRANS_RUN_CAP * 4 + 4096)  // r_src + the run-start mask and its prefix counts (RunLds, kernels.hip)
 #define MSTEP_BIG_GROUP 48  // a group above this size is summed by a workgroup of its own (one thread walking 500 members is a
                            // chain of 500 dependent loads: 0.22 ms on the tagging lexicon's per-tag groups)
 #define MSTEP_PARTIALS 2048
@@ -179,6 +182,11 @@ hipError_t launch_trans_w_bucket(const TransArgs& T, hipStream_t stream);
 // ... over buckets [first, first + count) only
 hipError_t launch_trans_w_bucket_range(const TransArgs& T, uint32_t first, uint32_t count, hipStream_t stream);
 hipError_t launch_trans_c_bucket_range(const TransArgs& T, uint32_t first, uint32_t count, hipStream_t stream);
+// LatticeSet::tile_sweep: weights in, the lane sweeps and posteriors out of tiles [tile_first, tile_first + tile_count) in one kernel
+hipError_t launch_tile_sweep(const TransArgs& T, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
+                             hipStream_t stream);
+hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
+                                    const uint32_t* bwd, uint32_t* out, hipStream_t stream);
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream);
 // small[k] = src[idx[k]] / dst[idx[k]] = small[k]   (halo values of the exchange)
 hipError_t launch_gather_idx(double* small, const double* src, const uint32_t* idx, uint32_t n, hipStream_t stream);

@@ -58,9 +58,49 @@ void HostWfst::build_index() {
 
 // Given out.lane_groups with maxlen / max_states / n_lanes / pair_base filled in: the launch classes (by LDS need), their
 // pieces, and every group's stream_base.  Returns the number of records of the lane streams (padding included).
-uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt) {
+uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only_lanes) {
   const size_t ng = out.lane_groups.size();
   out.lane_classes.clear();
+  out.tile = TRANS_TILE;
+  out.tile_sweep = false;
+  out.tile_group.clear();
+  // tile sweep: plain groups only, each within a tile of positions and of value rows
+  bool sweepable = opt.tile_sweep && only_lanes && ng > 0 && opt.lane_chunks <= 1;
+  for (size_t g = 0; sweepable && g < ng; ++g) {
+    const LaneGroup& G = out.lane_groups[g];
+    if (G.window || G.maxlen > TILE_SWEEP_ROWS || G.max_states > TILE_SWEEP_ALPHA_ROWS) sweepable = false;
+  }
+  if (sweepable) {
+    out.tile = TILE_SWEEP_TILE;
+    out.tile_sweep = true;
+    out.lane_tiles_aligned = true;
+    uint64_t base = 0;
+    uint32_t rows = 0, vrows = 0, mx = 0;
+    for (size_t g = 0; g < ng; ++g) {
+      LaneGroup& G = out.lane_groups[g];
+      if (g == 0 || (uint64_t)(rows + G.maxlen) * 64 > TILE_SWEEP_TILE || vrows + G.max_states > TILE_SWEEP_ALPHA_ROWS) {
+        base = (base + TILE_SWEEP_TILE - 1) / TILE_SWEEP_TILE * TILE_SWEEP_TILE;
+        out.tile_group.push_back((uint32_t)g);
+        rows = vrows = 0;
+      }
+      G.stream_base = base;
+      G.spill_row = vrows;
+      base += (uint64_t)G.maxlen * 64;
+      rows += G.maxlen;
+      vrows += G.max_states;
+      mx = std::max(mx, G.max_states);
+    }
+    out.tile_group.push_back((uint32_t)ng);
+    base = (base + TILE_SWEEP_TILE - 1) / TILE_SWEEP_TILE * TILE_SWEEP_TILE;
+    LatticeSet::LaneClass lc;  // one class: the tile kernel needs none, the lane kernel (A/B) takes the largest column
+    lc.first = 0;
+    lc.count = (uint32_t)ng;
+    lc.max_states = mx;
+    lc.tile_first = 0;
+    lc.tile_count = (uint32_t)(base / TILE_SWEEP_TILE);
+    out.lane_classes.push_back(lc);
+    return base;
+  }
   // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
   std::vector<LatticeSet::LaneClass> classes;
   {
@@ -706,7 +746,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       }
     }
     out.lane_spill_rows = spill_rows;
-    const uint64_t base = assign_lane_classes(out, opt);
+    const uint64_t base = assign_lane_classes(out, opt, wave.empty() && small.empty() && big.empty() && cyc.empty());
     out.lane_fwd.assign(base, uint2_t{0, 0});
     out.lane_bwd.assign(base, uint2_t{0, 0});
     std::atomic<size_t> nextg(0);
@@ -1241,7 +1281,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     // positions: [lane records | (up to a tile boundary) wave records | bundle out-arcs]
     const uint64_t nlane_rec = out.lane_bwd.size();
     const uint64_t nwave = out.wave_bwd.size();
-    out.wave_slot_base = nwave ? (nlane_rec + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE : nlane_rec;
+    out.wave_slot_base = nwave ? (nlane_rec + out.tile - 1) / out.tile * out.tile : nlane_rec;
     const uint64_t nlane = out.wave_slot_base + nwave;  // first bundle slot
     out.n_post = nlane + out.out_arcs.size();
     // counting sort by arc id, stable in slot order.  Threads own contiguous arc ranges: each scans every record (a
@@ -1340,7 +1380,8 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
   out.t_b_src.assign(N, 0);
   out.t_t_pos.assign(N, 0);
   out.t_t_src.assign(N, 0);
-  const uint64_t n_tiles = (out.n_post + TRANS_TILE - 1) / TRANS_TILE;
+  const uint64_t tile_sz = out.tile;
+  const uint64_t n_tiles = (out.n_post + tile_sz - 1) / tile_sz;
   out.t_tile_base.assign(n_tiles + 1, 0);
   std::vector<uint64_t> pos_of(N);  // position of the item at bucket-major index J
   {
@@ -1396,7 +1437,7 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
     };
     in_threads([&](int t) {
       std::vector<uint64_t>& h = hist[(size_t)t];
-      for (uint64_t J = j_lo(t), e = j_lo(t + 1); J < e; ++J) h[pos_of[J] / TRANS_TILE]++;
+      for (uint64_t J = j_lo(t), e = j_lo(t + 1); J < e; ++J) h[pos_of[J] / tile_sz]++;
     });
     uint64_t acc = 0;
     for (uint64_t tile = 0; tile < n_tiles; ++tile) {
@@ -1411,9 +1452,9 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
     in_threads([&](int t) {
       std::vector<uint64_t>& cur = hist[(size_t)t];
       for (uint64_t J = j_lo(t), e = j_lo(t + 1); J < e; ++J) {
-        const uint64_t tile = pos_of[J] / TRANS_TILE, I = cur[tile]++;
+        const uint64_t tile = pos_of[J] / tile_sz, I = cur[tile]++;
         out.t_t_src[I] = (uint32_t)J;
-        out.t_t_pos[I] = (uint16_t)(pos_of[J] - tile * TRANS_TILE);
+        out.t_t_pos[I] = (uint16_t)(pos_of[J] - tile * tile_sz);
         out.t_b_src[J] = (uint32_t)I;
       }
     });

@@ -104,6 +104,13 @@ static const uint32_t LANE_POS_MAX = (1u << 20) - 1;
 #define TRANS_KB TRANS_K  // ... per bucket
 #endif
 static const uint32_t TRANS_TILE = TRANS_KT * 1024, TRANS_BUCKET = TRANS_KB * 1024, TRANS_HEAVY = 2048, TRANS_SPLIT = 1u, TRANS_SINGLE = 2u;
+// Tile sweep (LatticeSet::tile_sweep): a corpus made of plain lane lattices only is laid out in tiles of TILE_SWEEP_TILE positions
+// that no lane group straddles, so that one workgroup can take a tile's weights in, sweep its groups out of LDS and send the
+// posteriors out (tile_sweep_kernel) -- LDS of a tile: its positions (8 + 4 B each) + TILE_SWEEP_ALPHA_ROWS rows of 64 forward /
+// backward values for its groups (LaneGroup::spill_row = a group's first row; a tile closes when either runs out).
+// Lattices of at most TILE_SWEEP_ROWS arcs (a packed record has six bits for a row) and 256 states (eight for a state).
+static const uint32_t TILE_SWEEP_TILE = 8192, TILE_SWEEP_ALPHA_ROWS = 126, TILE_SWEEP_ROWS = 48;
+static const uint32_t TILE_SWEEP_LDS = TILE_SWEEP_TILE * 12 + TILE_SWEEP_ALPHA_ROWS * 64 * 8;  // weights + records + values
 struct TransBucket {      // mirrored on the device, 24 bytes
   uint64_t item_base;     // first item: bucket-major index J == index into slot_pos[] (arc-sorted order)
   uint32_t n_items, arc_lo, n_arcs, flags;
@@ -115,7 +122,8 @@ struct LaneGroup {        // mirrored on the device, 32 bytes
   uint32_t pair_base;     // into lane_pair[] / lane_nstates[] / lane_logw[]
   uint32_t max_states;    // LDS rows the group needs: its largest lattice, or the window
   uint32_t window;        // 0: the whole column lives in LDS; W: ring of W rows + lane_spill
-  uint32_t spill_row;     // windowed: first row (of 64 doubles) of the group's columns in lane_spill
+  uint32_t spill_row;     // windowed: first row (of 64 doubles) of the group's columns in lane_spill; tile sweep: first row
+                          // of the group's values in its tile's LDS
 };
 static_assert(sizeof(LaneGroup) == 32, "LaneGroup layout");
 
@@ -201,6 +209,9 @@ struct LatticeSet {
   uint64_t lane_spill_rows = 0;  // rows of 64 doubles for the forward values of the windowed groups
   std::vector<LaneClass> lane_classes;
   bool lane_tiles_aligned = false;  // the pieces' tile ranges are disjoint (required for launching the tile passes per piece)
+  uint32_t tile = TRANS_TILE;       // positions per tile of the blocked transposition: TRANS_TILE, or TILE_SWEEP_TILE when ...
+  bool tile_sweep = false;          // ... no lane group straddles a tile and a tile's groups fit one workgroup's LDS (see TILE_SWEEP_TILE)
+  std::vector<uint32_t> tile_group; // tile sweep: per lane tile, its first lane group (+ one entry: the number of groups)
   uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
   // posterior slots: one per lattice arc.  Lane records use their position in lane_bwd[]; bundle out-arcs use
   // lane_bwd.size() + position in out_arcs[].  slot_arc / slot_pos list every slot sorted by WFST arc id, which is
@@ -249,6 +260,7 @@ struct BuildOptions {
                                    // (narrower ones stay in bundles: 64 of them side by side feed a wave better)
   double wave_lane_min_width = 16.0;    // ... for lattices a WINDOWED lane would take: this wide, and only when the corpus
   uint64_t wave_lane_threshold = 262144;  // has fewer lane-sized lattices than this (4 waves per SIMD of one-per-lane work)
+  bool tile_sweep = true;          // lay a corpus of plain lane lattices out for the one-kernel tile sweep (LatticeSet::tile_sweep)
   uint32_t lane_chunks = 1;        // chunks per lane class (see LatticeSet::LaneClass); 1 = one launch per class (default:
                                    // measured on config 4, four chunks on four streams overlap their kernels but finish no
                                    // sooner -- the E-step is bound by its total HBM traffic -- and cost 46 us of extra tails)
@@ -258,7 +270,8 @@ struct BuildOptions {
 bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& opt, LatticeSet& out, std::string& err);
 
 // launch classes, pieces and stream bases of the lane groups (shared by the host builder and the GPU builder)
-uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt);
+// only_lanes: the corpus has no lattice outside the lane groups (what the tile sweep's layout requires)
+uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only_lanes);
 
 // single pair (exposed for tests)
 void build_pair_lattice(const HostWfst& w, const uint32_t* in, uint32_t n_in, const uint32_t* out, uint32_t n_out,

@@ -684,7 +684,7 @@ __global__ void bucket_key_kernel(const TransBucket* buckets, uint32_t n_buckets
 }
 // J = bucket-major index after that sort
 __global__ void bucket_major_kernel(const TransBucket* buckets, const unsigned long long* key_sorted, const uint32_t* val_sorted,
-                                    const unsigned long long* items_sorted, uint64_t n, uint16_t* b_arc, uint16_t* b_rank,
+                                    const unsigned long long* items_sorted, uint64_t n, uint32_t tile_sz, uint16_t* b_arc, uint16_t* b_rank,
                                     uint32_t* tile_key, uint32_t* J_val) {
   const uint64_t J = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (J >= n) return;
@@ -693,17 +693,17 @@ __global__ void bucket_major_kernel(const TransBucket* buckets, const unsigned l
   const TransBucket B = buckets[b];
   b_rank[J] = (uint16_t)(i - B.item_base);
   b_arc[J] = (B.flags & TRANS_SINGLE) ? (uint16_t)0 : (uint16_t)((uint32_t)(items_sorted[i] >> 32) - B.arc_lo);
-  tile_key[J] = (uint32_t)((key_sorted[J] & 0xffffffffull) / TRANS_TILE);
+  tile_key[J] = (uint32_t)((key_sorted[J] & 0xffffffffull) / tile_sz);
   J_val[J] = (uint32_t)J;
 }
 // I = tile-major index: stable sort of the bucket-major sequence by tile
 __global__ void tile_major_kernel(const uint32_t* tile_sorted, const uint32_t* J_sorted, const unsigned long long* key_sorted, uint64_t n,
-                                  uint64_t n_tiles, uint32_t* t_src, uint16_t* t_pos, uint32_t* b_src, uint64_t* tile_base) {
+                                  uint64_t n_tiles, uint32_t tile_sz, uint32_t* t_src, uint16_t* t_pos, uint32_t* b_src, uint64_t* tile_base) {
   const uint64_t I = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (I >= n) return;
   const uint32_t J = J_sorted[I], t = tile_sorted[I];
   t_src[I] = J;
-  t_pos[I] = (uint16_t)((key_sorted[J] & 0xffffffffull) - (uint64_t)t * TRANS_TILE);
+  t_pos[I] = (uint16_t)((key_sorted[J] & 0xffffffffull) - (uint64_t)t * tile_sz);
   b_src[J] = (uint32_t)I;
   const uint32_t prev = I ? tile_sorted[I - 1] : 0u;
   for (uint64_t x = (I ? (uint64_t)prev + 1 : 0); x <= t; ++x) tile_base[x] = I;
@@ -1073,11 +1073,15 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     }
   }
   L.lane_spill_rows = spill_rows;
-  const uint64_t n_rec = assign_lane_classes(L, opt);  // launch classes, pieces, stream bases: the host builder's own rule
+  const uint64_t n_rec = assign_lane_classes(L, opt, true);  // launch classes, pieces, stream bases: the host builder's own rule
   if (n_rec >= (1ull << 32)) return CARMEL_HIP_OK;
   lap("pair sort + lane groups");
   // ---- device image: lane streams ----
   HIPCHK(t->lane_groups.upload(L.lane_groups, s));
+  if (L.tile_sweep)
+    HIPCHK(t->tile_group.upload(L.tile_group, s));
+  else
+    t->tile_group.release();
   DevBuf<unsigned long long> d_item_off, items, items_sorted;
   HIPCHK(d_item_off.upload(h_item_off, s));
   HIPCHK(t->lane_fwdx.alloc(n_rec));
@@ -1098,6 +1102,12 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   else
     t->lane_spill.release();
   HIPCHK(hipGetLastError());
+  if (L.tile_sweep) {
+    HIPCHK(t->lane_rec2.alloc(n_rec));
+    HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, n_rec * 4, s));
+    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, s));
+  } else
+    t->lane_rec2.release();
   lap("record streams");
   // ---- slots by arc ----
   HIPCHK(sort_keys(tmp, items.p, items_sorted.p, n_items, 32 + bits_for(w.n_arcs), s));
@@ -1137,7 +1147,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   t->t_split_arcs.n = n_split;
   lap("buckets");
   const uint64_t n_post = n_rec;    // no bundle arcs on this path
-  const uint64_t n_tiles = (n_post + TRANS_TILE - 1) / TRANS_TILE;
+  const uint64_t n_tiles = (n_post + L.tile - 1) / L.tile;
   HIPCHK(t->t_a_off.alloc(w.n_arcs));
   HIPCHK(hipMemsetAsync(t->t_a_off.p, 0, w.n_arcs * 2, s));
   hipLaunchKernelGGL(a_off_kernel, dim3(n_buckets), dim3(256), 0, s, t->t_buckets.p, n_buckets, t->arc_off.p, t->t_a_off.p);
@@ -1161,10 +1171,10 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   HIPCHK(Jv.alloc(n_items));
   HIPCHK(J_sorted.alloc(n_items));
   hipLaunchKernelGGL(bucket_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, t->t_buckets.p, bkey_sorted.p,
-                     bval_sorted.p, items_sorted.p, n_items, t->t_b_arc.p, t->t_b_rank.p, tile_key.p, Jv.p);
+                     bval_sorted.p, items_sorted.p, n_items, L.tile, t->t_b_arc.p, t->t_b_rank.p, tile_key.p, Jv.p);
   HIPCHK(sort_pairs(tmp, tile_key.p, tile_sorted.p, Jv.p, J_sorted.p, n_items, bits_for(n_tiles), s));
   hipLaunchKernelGGL(tile_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, tile_sorted.p, J_sorted.p,
-                     bkey_sorted.p, n_items, n_tiles, t->t_t_src.p, t->t_t_pos.p, t->t_b_src.p, t->t_tile_base.p);
+                     bkey_sorted.p, n_items, n_tiles, L.tile, t->t_t_src.p, t->t_t_pos.p, t->t_b_src.p, t->t_tile_base.p);
   HIPCHK(hipGetLastError());
   HIPCHK(t->t_x.alloc(n_items));
   HIPCHK(t->t_xc.alloc(n_items));

@@ -463,6 +463,10 @@ void carmel_hip_host_export(carmel_hip_host_lattices* h, void* bundles64, uint32
 void carmel_hip_host_transpose(carmel_hip_host_lattices* h, uint64_t* dims6, void* buckets24, uint64_t* tile_base,
                                uint16_t* b_arc, uint16_t* b_rank, uint32_t* b_src, uint16_t* t_pos, uint32_t* t_src,
                                uint32_t* split_arcs, uint64_t* arc_off, uint64_t* slot_pos);
+/* the tile-sweep layout (csrc/lattice.hpp, LatticeSet::tile_sweep): info2 = positions per tile of the transposition, entries of
+ * tile_group (0: the corpus is not laid out for the one-kernel tile sweep); tile_group (may be null) = first lane group of every
+ * lane tile + the number of groups */
+void carmel_hip_host_tile_sweep(carmel_hip_host_lattices* h, uint32_t* info2, uint32_t* tile_group);
 /* the one-lattice-per-wavefront layout (csrc/lattice.hpp, WaveDesc); dims6 = n_waves, forward records, backward records,
  * level entries, n_classes, first wave slot; null pointers are skipped */
 void carmel_hip_host_export_waves(carmel_hip_host_lattices* h, uint64_t* dims6, void* descs64, uint32_t* fwd, uint32_t* bwd,

@@ -68,6 +68,12 @@ def host_lattices(w, c, prune=True, threads=2, small_pairs=0, small_states=0, la
     lib.carmel_hip_host_transpose(h, null, ptr(tr["buckets"]), ptr(tr["tile_base"]), ptr(tr["b_arc"]),
                                   ptr(tr["b_rank"]), ptr(tr["b_src"]), ptr(tr["t_pos"]), ptr(tr["t_src"]),
                                   ptr(tr["split_arcs"]), ptr(tr["arc_off"]), ptr(tr["slot_pos"]))
+    ti = np.zeros(2, np.uint32)
+    lib.carmel_hip_host_tile_sweep(h, ptr(ti), null)
+    tr["tile"] = int(ti[0])
+    tr["tile_group"] = np.zeros(int(ti[1]), np.uint32)
+    if ti[1]:
+        lib.carmel_hip_host_tile_sweep(h, null, ptr(tr["tile_group"]))
     out["transpose"] = tr
     wd = np.zeros(6, np.uint64)
     lib.carmel_hip_host_export_waves(h, ptr(wd), *([null] * 8))
@@ -302,13 +308,14 @@ def transpose_weights(tr, logw, n_wcache):
         x[lo:lo + n] = lds[tr["b_arc"][lo:lo + n]]
     wc = np.zeros(n_wcache)
     for t in range(len(tr["tile_base"]) - 1):
-        p0 = t * TRANS_TILE
+        T = tr["tile"]
+        p0 = t * T
         if p0 >= n_wcache:
             break
-        lds = np.zeros(TRANS_TILE)
+        lds = np.zeros(T)
         i0, i1 = int(tr["tile_base"][t]), int(tr["tile_base"][t + 1])
         lds[tr["t_pos"][i0:i1]] = x[tr["t_src"][i0:i1]]
-        n = min(TRANS_TILE, n_wcache - p0)
+        n = min(T, n_wcache - p0)
         wc[p0:p0 + n] = lds[:n]
     return wc
 
@@ -317,8 +324,8 @@ def transpose_counts(tr, post):
     """numpy model of trans_c_tile_kernel + trans_c_bucket_kernel: posteriors (position order) -> per-arc sums"""
     x = np.zeros(tr["n_items"])
     for t in range(len(tr["tile_base"]) - 1):
-        p0 = t * TRANS_TILE
-        lds = post[p0:p0 + TRANS_TILE]
+        p0 = t * tr["tile"]
+        lds = post[p0:p0 + tr["tile"]]
         i0, i1 = int(tr["tile_base"][t]), int(tr["tile_base"][t + 1])
         x[i0:i1] = lds[tr["t_pos"][i0:i1]]
     counts = np.zeros(tr["n_arcs"])
