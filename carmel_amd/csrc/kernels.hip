@@ -1435,7 +1435,6 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
 // sweep), and what is static about a row is decided when the records are packed (pack_tile_records_kernel): whether the
 // arc's other end is the state just finished (its value is in a register: no column read) and whether the arc is its state's
 // only one (the state's value is one addition: no log-sum-exp) -- a chain lattice's sweep is an add and a store per row.
-#define TILE_SWEEP_THREADS 512
 #define TS_SRC(x) ((x) & 0xffu)
 #define TS_POS(x) (((x) >> 8) & 63u)
 #define TS_FV 0x4000u
@@ -1485,19 +1484,21 @@ struct TileLane {  // a lane's lattice: states, ln(pair weight), corpus pair (re
   uint32_t S, pair;
   double lwt;
 };
-__device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, const LaneGroup& g, const int lane) {
+// (group gi's lanes are entries gi * 64 .. of the per-lane arrays -- LaneGroup::pair_base, both builders: the request does
+// not have to wait for the group's descriptor; lanes past n_lanes hold S = 0)
+__device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, uint32_t gi, const int lane) {
   TileLane L;
-  const bool active = (uint32_t)lane < g.n_lanes;
-  L.S = active ? A.lane_nstates[g.pair_base + lane] : 0u;
-  L.lwt = active ? A.lane_logw[g.pair_base + lane] : 0.0;
-  L.pair = active ? A.lane_pair[g.pair_base + lane] : 0u;
+  const size_t k = (size_t)gi * 64 + lane;
+  L.S = A.lane_nstates[k];
+  L.lwt = A.lane_logw[k];
+  L.pair = A.lane_pair[k];
   return L;
 }
 __device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, const int lane, double* col,
                                                  double* rows, const uint32_t* recl) {
   constexpr int U = (int)LANE_CHUNK;
   const bool active = (uint32_t)lane < g.n_lanes;
-  const uint32_t S = L.S, pair = L.pair;
+  const uint32_t S = active ? L.S : 0u, pair = L.pair;
   const double lwt = L.lwt;
   const uint32_t maxlen = g.maxlen;
   // ---------- forward ----------
@@ -1647,96 +1648,172 @@ __device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGr
     }
   }
 }
+// The kernel is persistent and its wavefronts are specialised.  A workgroup per CU walks its share of the tiles; half of its
+// wavefronts SWEEP (a group each at a time), the other half MOVE: while tile t is swept they request tile t + 1 (its stretch
+// of X, its position table, its records) into their registers and tile t's destinations, when the sweeps are done they send
+// tile t's posteriors out (exp of the log posterior the sweep left at the arc's position) and place tile t + 1 in LDS.  The
+// counter of a wavefront's outstanding loads is in order, so a sweeping wavefront that also held the next tile's requests
+// would wait for all of them at its first own load; a moving wavefront has nothing else to wait for.
+#define TILE_SWEEP_THREADS 512
+#define TILE_SWEEP_MOVERS 256
+typedef uint32_t ts_u32x4 __attribute__((ext_vector_type(4)));
+struct TileIn {  // a tile on its way in: what every moving thread holds of it (loaded values as they arrive: nothing computes
+                 // on them before the tile is placed, so nothing waits for them)
+  double v[TILE_SWEEP_TILE / TILE_SWEEP_MOVERS];
+  uint16_t pos[TILE_SWEEP_TILE / TILE_SWEEP_MOVERS];
+};
+template <bool SCAT>
+__device__ __forceinline__ void tile_request(const TransArgs& T, const LaneArgs& A, uint32_t tile, uint64_t i0, uint32_t ni, uint32_t m,
+                                             TileIn& in) {
+  constexpr int NM = TILE_SWEEP_MOVERS, KT = (int)(TILE_SWEEP_TILE / NM);
+  const uint32_t last = ni ? ni - 1 : 0u;  // every load is unconditional: items past the tile's re-read its last one
+  uint32_t src[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) {
+    const uint32_t i = min(m + k * NM, last);
+    if (!SCAT) src[k] = T.t_src[i0 + i];
+    in.pos[k] = T.t_pos[i0 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < KT; ++k) in.v[k] = T.x[SCAT ? i0 + min(m + k * NM, last) : (uint64_t)src[k]];
+}
+// the walk of a workgroup over its tiles: workgroup b runs on XCD b % 8 and takes the tiles of that XCD's contiguous eighth
+// (xcd_chunked), gridDim.x / 8 apart; the scalars of a tile (its items, its groups) are requested two tiles ahead
+struct TileWalk {
+  uint32_t tile, ni, g0, g1;
+  uint64_t i0;
+  bool ok;
+};
+__device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const uint32_t* __restrict__ tile_group, uint32_t vidx, bool ok) {
+  TileWalk w;
+  const uint32_t tloc = xcd_chunked(vidx, T.tile_count);
+  w.ok = ok && tloc < T.tile_count && vidx / 8 < (T.tile_count + 7) / 8;
+  w.tile = T.tile_first + (w.ok ? tloc : 0u);
+  w.i0 = T.tile_base[w.tile];
+  w.ni = (uint32_t)(T.tile_base[w.tile + 1] - w.i0);
+  w.g0 = tile_group[w.tile];
+  w.g1 = tile_group[w.tile + 1];
+  return w;
+}
 template <bool SCAT>
 __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArgs T, LaneArgs A, const uint32_t* __restrict__ tile_group) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int NT = TILE_SWEEP_THREADS, KT = (int)(TILE_SWEEP_TILE / NT), NW = NT / 64;
-  const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
-  if (tloc >= T.tile_count) return;
-  const uint32_t tile = T.tile_first + tloc;
-  const uint64_t i0 = T.tile_base[tile];
-  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
+  constexpr int NM = TILE_SWEEP_MOVERS, KT = (int)(TILE_SWEEP_TILE / NM), NW = (TILE_SWEEP_THREADS - NM) / 64;
   uint32_t* const recs = (uint32_t*)(lds + TILE_SWEEP_TILE);                // one packed record per position
   double* const alpha = lds + TILE_SWEEP_TILE + TILE_SWEEP_TILE / 2;        // TILE_SWEEP_ALPHA_ROWS rows of values
-  const uint32_t g0 = tile_group[tile], g1 = tile_group[tile + 1];
   const int lane = threadIdx.x & 63;
-  const uint64_t p0 = (uint64_t)tile * TILE_SWEEP_TILE;
-  unsigned long long t0 = 0, t1 = 0, t2 = 0;
-  if (A.trace) t0 = __builtin_readcyclecounter();
-  // this wavefront's first group (its descriptor and its lanes' lattices arrive with the tile)
-  uint32_t gi = g0 + (threadIdx.x >> 6);
-  LaneGroup g = A.groups[gi < g1 ? gi : g0];
-  TileLane L = tile_lane(A, g, lane);
-  // ---- the tile's records as they are, its weights to their lane positions ----
-  {
-    uint32_t src[KT];
-    uint16_t pos[KT];
-    double v[KT];
-    uint4 rr[KT / 4];
-    const uint32_t np = (uint32_t)min((uint64_t)TILE_SWEEP_TILE, T.n_post - p0);  // (the record streams end with the last group)
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t vidx = blockIdx.x;
+  TileWalk cur = tile_walk_at(T, tile_group, vidx, true);
+  if (!cur.ok) return;
+  TileWalk nxt = tile_walk_at(T, tile_group, vidx + gridDim.x, true);
+  // Both kinds of wavefront meet at the same three barriers per tile: (a) the tile is placed, (b) it is swept, (c) it is read out.
+  if (wv >= (uint32_t)NW) {
+    // ================= movers =================
+    const uint32_t m = threadIdx.x - (uint32_t)(TILE_SWEEP_THREADS - NM);
+    TileIn in;
+    tile_request<SCAT>(T, A, cur.tile, cur.i0, cur.ni, m, in);
+    for (;;) {
+      const TileWalk nn = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok);
+      // the tile's weights to their lane positions
+      uint32_t pos2[KT / 2];
 #pragma unroll
-    for (int k = 0; k < KT / 4; ++k) {
-      const uint32_t q = (threadIdx.x + k * NT) * 4;
-      rr[k] = q < np ? *(const uint4*)(A.rec2 + p0 + q) : make_uint4(0u, 0u, 0u, 0u);
-    }
+      for (int k = 0; k < KT; ++k) {
+        if (k & 1)
+          pos2[k / 2] |= (uint32_t)in.pos[k] << 16;
+        else
+          pos2[k / 2] = in.pos[k];
+        if (m + k * NM < cur.ni) lds[in.pos[k]] = in.v[k];
+      }
+      __syncthreads();  // (a)
+      // requests while the tile is swept: its destinations, then the next tile
+      uint32_t dst[KT];
+      if (SCAT) {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const uint32_t i = threadIdx.x + k * NT;
-      src[k] = (!SCAT && i < ni) ? T.t_src[i0 + i] : 0u;
-      pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
-    }
+        for (int k = 0; k < KT; ++k) {
+          dst[k] = T.t_src[cur.i0 + min(m + k * NM, cur.ni ? cur.ni - 1 : 0u)];
+        }
+      }
+      if (nxt.ok) tile_request<SCAT>(T, A, nxt.tile, nxt.i0, nxt.ni, m, in);
+      __syncthreads();  // (b)
+      // the tile's posteriors out: exp of the log posterior the sweep left at the arc's position
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const uint32_t i = threadIdx.x + k * NT;
-      v[k] = SCAT ? (i < ni ? T.x[i0 + i] : 0.0) : T.x[src[k]];
-    }
-#pragma unroll
-    for (int k = 0; k < KT / 4; ++k) *(uint4*)(recs + (threadIdx.x + k * NT) * 4) = rr[k];
-#pragma unroll
-    for (int k = 0; k < KT; ++k)
-      if (threadIdx.x + k * NT < ni) lds[pos[k]] = v[k];
-  }
-  __syncthreads();
-  if (A.trace) t1 = __builtin_readcyclecounter();
-  // ---- the tile's groups, one per wavefront at a time ----
-  while (gi < g1) {
-    const uint32_t gn = gi + NW < g1 ? gi + NW : gi;  // the next one's, requested before this one's sweep
-    const LaneGroup g_next = A.groups[gn];
-    const TileLane L_next = tile_lane(A, g_next, lane);
-    const uint32_t off = (uint32_t)(g.stream_base - p0) + lane;
-    tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
-    g = g_next;
-    L = L_next;
-    gi += NW;
-  }
-  if (A.trace && lane == 0) A.trace[(size_t)tile * 16 + 8 + (threadIdx.x >> 6)] = __builtin_readcyclecounter() - t1;  // this wavefront's sweeps
-  __syncthreads();
-  if (A.trace) t2 = __builtin_readcyclecounter();
-  // ---- the tile's posteriors out ----
-  if (SCAT) {
-    const RunLds R = run_lds((double*)recs);
-    const uint32_t r0 = T.tr_off[tile];
-    run_stage<NT>(R, T.tr_rel + r0, T.tr_src + r0, T.tr_off[tile + 1] - r0);
-#pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const uint32_t i = threadIdx.x + k * NT;
-      if (i < ni) T.xc[run_source(R, i)] = K_EXP(lds[T.t_pos[i0 + i]]);
+      for (int k = 0; k < KT; ++k) {
+        const uint32_t i = m + k * NM;
+        const uint32_t q = (k & 1) ? pos2[k / 2] >> 16 : pos2[k / 2] & 0xffffu;
+        if (i < cur.ni) T.xc[SCAT ? (uint64_t)dst[k] : cur.i0 + i] = K_EXP(lds[q]);
+        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exponentials side by side, not thirty-two (registers)
+      }
+      if (!nxt.ok) break;
+      __syncthreads();  // (c)
+      vidx += gridDim.x;
+      cur = nxt;
+      nxt = nn;
     }
   } else {
+    // ================= sweepers =================
+    constexpr int KR = (int)(TILE_SWEEP_TILE / 4 / (TILE_SWEEP_THREADS - NM));  // 16-byte pieces of a tile's records per sweeping thread
+    LaneGroup g;
+    TileLane L;
+    {
+      const uint32_t gk = cur.g0 + wv < cur.g1 ? cur.g0 + wv : cur.g0;
+      g = A.groups[gk];
+      L = tile_lane(A, gk, lane);
+      ts_u32x4 rr[KR];  // the first tile's records as they are (the stream covers whole tiles)
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-      const uint32_t i = threadIdx.x + k * NT;
-      if (i < ni) T.xc[i0 + i] = K_EXP(lds[T.t_pos[i0 + i]]);
+      for (int k = 0; k < KR; ++k)
+        rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)cur.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
+#pragma unroll
+      for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
     }
-  }
-  if (A.trace && threadIdx.x == 0) {  // experiment (CARMEL_HIP_LANE_TRACE): cycles per phase
-    unsigned long long* o = A.trace + (size_t)tile * 16;
-    o[0] = t0;
-    o[1] = t1 - t0;
-    o[2] = t2 - t1;
-    o[3] = __builtin_readcyclecounter() - t2;
-    o[4] = ((unsigned long long)(g1 - g0) << 32) | ni;
-    o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) | A.groups[g0].maxlen;
+    for (;;) {
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (A.trace) t0 = __builtin_readcyclecounter();
+      const TileWalk nn = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok);
+      const uint64_t p0 = (uint64_t)cur.tile * TILE_SWEEP_TILE;
+      // the first group of the next tile: its descriptor and lanes arrive while this tile is swept
+      const uint32_t gk_n = nxt.g0 + wv < nxt.g1 ? nxt.g0 + wv : nxt.g0;
+      const LaneGroup g_n = A.groups[gk_n];
+      const TileLane L_n = tile_lane(A, gk_n, lane);
+      __syncthreads();  // (a)
+      if (A.trace) t1 = __builtin_readcyclecounter();
+      for (uint32_t gi = cur.g0 + wv; gi < cur.g1; gi += NW) {
+        const uint32_t gk = gi + NW < cur.g1 ? gi + NW : gi;  // the wavefront's next group of this tile, requested before this one's sweep
+        const LaneGroup g_next = A.groups[gk];
+        const TileLane L_next = tile_lane(A, gk, lane);
+        const uint32_t off = (uint32_t)(g.stream_base - p0) + lane;
+        tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
+        g = g_next;
+        L = L_next;
+      }
+      if (A.trace && lane == 0) A.trace[(size_t)cur.tile * 16 + 8 + wv] = __builtin_readcyclecounter() - t1;  // this wavefront's sweeps
+      // the next tile's records: on their way while this tile's posteriors leave
+      ts_u32x4 rr[KR];
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)nxt.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
+      __syncthreads();  // (b)
+      if (A.trace) t2 = __builtin_readcyclecounter();
+      // (the movers read the posteriors out; nobody needs this tile's records any more)
+#pragma unroll
+      for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
+      if (A.trace && threadIdx.x == 0) {  // experiment (CARMEL_HIP_LANE_TRACE): cycles per phase, as the first sweeping wavefront sees them
+        unsigned long long* o = A.trace + (size_t)cur.tile * 16;
+        o[0] = t0;
+        o[1] = t1 - t0;
+        o[2] = t2 - t1;
+        o[4] = ((unsigned long long)(cur.g1 - cur.g0) << 32) | cur.ni;
+        o[5] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) | g.maxlen;
+      }
+      if (!nxt.ok) break;
+      __syncthreads();  // (c)
+      if (A.trace && threadIdx.x == 0) A.trace[(size_t)cur.tile * 16 + 3] = __builtin_readcyclecounter() - t2;
+      vidx += gridDim.x;
+      cur = nxt;
+      nxt = nn;
+      g = g_n;
+      L = L_n;
+    }
   }
 }
 __global__ void zero_list_kernel(double* p, const uint32_t* idx, uint32_t n) {
@@ -1901,7 +1978,15 @@ hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint3
   TransArgs T = T0;
   T.tile_first = tile_first;
   T.tile_count = tile_count;
-  const dim3 g8((tile_count + 7) / 8 * 8);
+  // persistent: a workgroup per CU (its LDS is a CU's), fewer when there are fewer tiles; a multiple of 8 (XCDs)
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+    n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  }
+  const dim3 g8(std::min<uint32_t>((uint32_t)n_cu, (tile_count + 7) / 8 * 8));
   // (the scattering forms of both directions go together: TransArgs::scatter is 3 where the corpus has run-length indices)
   if ((T.scatter & 3u) == 3u && T.use_runs)
     hipLaunchKernelGGL((tile_sweep_kernel<true>), g8, dim3(TILE_SWEEP_THREADS), lds, stream, T, A, tile_group);

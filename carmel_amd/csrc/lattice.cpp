@@ -78,7 +78,8 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
     uint32_t rows = 0, vrows = 0, mx = 0;
     for (size_t g = 0; g < ng; ++g) {
       LaneGroup& G = out.lane_groups[g];
-      if (g == 0 || (uint64_t)(rows + G.maxlen) * 64 > TILE_SWEEP_TILE || vrows + G.max_states > TILE_SWEEP_ALPHA_ROWS) {
+      if (g == 0 || (uint64_t)(rows + G.maxlen) * 64 > TILE_SWEEP_TILE || vrows + G.max_states > TILE_SWEEP_ALPHA_ROWS ||
+          g - out.tile_group.back() >= TILE_SWEEP_GROUPS) {
         base = (base + TILE_SWEEP_TILE - 1) / TILE_SWEEP_TILE * TILE_SWEEP_TILE;
         out.tile_group.push_back((uint32_t)g);
         rows = vrows = 0;

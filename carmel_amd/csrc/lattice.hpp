@@ -107,9 +107,10 @@ static const uint32_t TRANS_TILE = TRANS_KT * 1024, TRANS_BUCKET = TRANS_KB * 10
 // Tile sweep (LatticeSet::tile_sweep): a corpus made of plain lane lattices only is laid out in tiles of TILE_SWEEP_TILE positions
 // that no lane group straddles, so that one workgroup can take a tile's weights in, sweep its groups out of LDS and send the
 // posteriors out (tile_sweep_kernel) -- LDS of a tile: its positions (8 + 4 B each) + TILE_SWEEP_ALPHA_ROWS rows of 64 forward /
-// backward values for its groups (LaneGroup::spill_row = a group's first row; a tile closes when either runs out).
+// backward values for its groups (LaneGroup::spill_row = a group's first row; a tile closes when either runs out, or
+// at TILE_SWEEP_GROUPS groups).
 // Lattices of at most TILE_SWEEP_ROWS arcs (a packed record has six bits for a row) and 256 states (eight for a state).
-static const uint32_t TILE_SWEEP_TILE = 8192, TILE_SWEEP_ALPHA_ROWS = 126, TILE_SWEEP_ROWS = 48;
+static const uint32_t TILE_SWEEP_TILE = 8192, TILE_SWEEP_ALPHA_ROWS = 126, TILE_SWEEP_ROWS = 48, TILE_SWEEP_GROUPS = 16;
 static const uint32_t TILE_SWEEP_LDS = TILE_SWEEP_TILE * 12 + TILE_SWEEP_ALPHA_ROWS * 64 * 8;  // weights + records + values
 struct TransBucket {      // mirrored on the device, 24 bytes
   uint64_t item_base;     // first item: bucket-major index J == index into slot_pos[] (arc-sorted order)
