@@ -1447,17 +1447,31 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
 #define TS_BCHAIN 0x10000000u  // backward: the destination is the state finished last (or padding)
 #define TS_BEASY 0x20000000u   // backward: the only out-arc of its state (or padding)
 // one thread per lane of a group walks the lane's rows: the two records of a row in one word + the static properties above
+// chain[gi] = every lattice of the group is a single path (states 0 .. len in a row: forward row k is the arc k -> k + 1, whose
+// backward row is maxlen - 1 - k): tile_chain_sweep needs no records at all
 __global__ void pack_tile_records_kernel(const LaneGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ lane_nstates,
-                                         const uint32_t* __restrict__ fwdx, const uint32_t* __restrict__ bwd, uint32_t* __restrict__ out) {
+                                         const uint32_t* __restrict__ fwdx, const uint32_t* __restrict__ bwd, uint32_t* __restrict__ out,
+                                         uint32_t* __restrict__ chain) {
   const uint32_t gi = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (gi >= n_groups) return;
   const LaneGroup g = groups[gi];
   const uint32_t S = lane < g.n_lanes ? lane_nstates[g.pair_base + lane] : 0u;
   uint32_t d = 1, s = S >= 2 ? S - 2 : 0u;
   bool fresh_f = true, fresh_b = true;
+  const uint32_t len = S ? S - 1 : 0u;
+  bool path = true;
   for (uint32_t k = 0; k < g.maxlen; ++k) {
     const size_t p = g.stream_base + (size_t)k * 64 + lane;
     const uint32_t f = fwdx[p], b = bwd[p];
+    // (the backward stream of a lane ends with the group's last row: its padding comes first)
+    if (k < len)
+      path = path && (f & LANE_VALID) && (f & LANE_LAST) && (f & LANE_STATE_MASK) == k && ((f >> LANE_POS_SHIFT) & LANE_POS_MAX) == g.maxlen - 1 - k;
+    else
+      path = path && !(f & (LANE_VALID | LANE_LAST));
+    if (k >= g.maxlen - len)
+      path = path && (b & LANE_VALID) && (b & LANE_LAST) && (b & LANE_STATE_MASK) == g.maxlen - k;
+    else
+      path = path && !(b & (LANE_VALID | LANE_LAST));
     uint32_t x = (f & 0xffu) | (((f >> LANE_POS_SHIFT) & 63u) << 8) | ((f & LANE_VALID) ? TS_FV : 0u) | ((f & LANE_LAST) ? TS_FL : 0u) |
                  ((b & 0xffu) << 16) | ((b & LANE_VALID) ? TS_BV : 0u) | ((b & LANE_LAST) ? TS_BL : 0u);
     const bool f_pad = !(f & (LANE_VALID | LANE_LAST)), b_pad = !(b & (LANE_VALID | LANE_LAST));
@@ -1477,6 +1491,11 @@ __global__ void pack_tile_records_kernel(const LaneGroup* __restrict__ groups, u
     }
     out[p] = x;
   }
+  // ... and how many leading backward rows are padding in some lane of the group (its lattices are nearly of one length)
+  uint32_t pad = lane < g.n_lanes ? g.maxlen - len : 0u;
+  for (int o = 32; o > 0; o >>= 1) pad = max(pad, (uint32_t)__shfl_xor((int)pad, o, 64));
+  const bool all_paths = __all(path);
+  if (lane == 0) chain[gi] = (all_paths ? 1u : 0u) | (pad << 8);
 }
 // one group: records, weights / posteriors in the lane's columns of LDS rows (recl, rows), values in its column `col`: the
 // arithmetic of sweep_lane_kernel, operation for operation (an "easy" row is Lse's own result for a single term)
@@ -1494,11 +1513,13 @@ __device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, uint32_t gi, co
   L.pair = A.lane_pair[k];
   return L;
 }
-__device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, const int lane, double* col,
-                                                 double* rows, const uint32_t* recl) {
+// (returns ln p(pair): the caller stores it -- a store inside the sweep would sit in the wavefront's in-order queue of vector
+// memory operations in front of whatever the wavefront waits for next)
+__device__ __forceinline__ double tile_group_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, const int lane, double* col,
+                                                   double* rows, const uint32_t* recl) {
   constexpr int U = (int)LANE_CHUNK;
   const bool active = (uint32_t)lane < g.n_lanes;
-  const uint32_t S = active ? L.S : 0u, pair = L.pair;
+  const uint32_t S = active ? L.S : 0u;
   const double lwt = L.lwt;
   const uint32_t maxlen = g.maxlen;
   // ---------- forward ----------
@@ -1568,10 +1589,10 @@ __device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGr
     }
   }
   // ---------- ln p(pair), beta at the goal ----------
-  double next = NEG_INF;
+  double next = NEG_INF, lp_out = NEG_INF;
   if (active) {
     const double lp = col[(S - 1) * 64];
-    A.pair_logprob[pair] = lp;
+    lp_out = lp;
     next = (lp == NEG_INF) ? NEG_INF : lwt - lp;
     col[(S - 1) * 64] = next;
   }
@@ -1647,6 +1668,117 @@ __device__ __forceinline__ void tile_group_sweep(const LaneArgs& A, const LaneGr
       for (int u = 0; u < U; ++u) rows[(kb + u) * 64] = (S >= 2 ? al[u] : NEG_INF) + t[u];
     }
   }
+  return lp_out;
+}
+// a group of single paths (pack_tile_records_kernel's chain flag): the same additions in the same order, and nothing else --
+// no records, no branches, no validity tests.  The group's lattices are nearly of one length (lanes are sorted by length);
+// the few padding rows a lane has are given the weight 0, so that every lane walks all maxlen rows: past its lattice's end
+// the forward chain keeps adding 0 (and writes the unchanged value to column rows nobody reads: the layout gives a group
+// maxlen + 1 of them), before its first backward row the backward chain does.  (What the zeros can change is the sign of a
+// zero: -0.0 + 0.0 is +0.0.)
+__device__ __forceinline__ double tile_chain_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, uint32_t max_pad, const int lane,
+                                                   double* col, double* rows, unsigned long long* tr) {
+  constexpr int U = (int)LANE_CHUNK;
+  unsigned long long c0 = 0, c1 = 0, c2 = 0;
+  if (tr) c0 = __builtin_readcyclecounter();
+  const bool active = (uint32_t)lane < g.n_lanes;
+  const uint32_t S = active ? L.S : 0u;
+  const uint32_t len = S ? S - 1 : 0u;
+  const uint32_t maxlen = g.maxlen;
+  const uint32_t off = maxlen - len;  // backward rows before this one are padding
+  for (uint32_t k = 0; k < max_pad; ++k)
+    if (k < off) rows[k * 64] = 0.0;
+  col[0] = 0.0;
+  double prev = 0.0;
+  // Two chunks per round, each chunk's LDS reads requested while the other is worked on, into registers of its own: every
+  // wait inside the round is for a counted number of operations.
+  {
+    const double* wr = rows + (size_t)(maxlen - 1) * 64;  // the arc k -> k + 1 lies at backward row maxlen - 1 - k
+    double* cw = col + 64;
+    double wa[U], wb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wa[u] = wr[-u * 64];
+    for (uint32_t kb = 0; kb < maxlen; kb += 2 * U) {
+      const bool two = kb + U < maxlen;  // (maxlen is a multiple of U, not of 2 U)
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wb[u] = wr[-(U + u) * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        prev += wa[u];
+        cw[u * 64] = prev;
+      }
+      if (kb + 2 * U < maxlen) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wa[u] = wr[-(2 * U + u) * 64];
+      }
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          prev += wb[u];
+          cw[(U + u) * 64] = prev;
+        }
+      }
+      wr -= 2 * U * 64;
+      cw += 2 * U * 64;
+    }
+  }
+  if (tr) c1 = __builtin_readcyclecounter();
+  const double lp = prev;  // = col[(S - 1) * 64] (and every later row of the column)
+  double next = (!active || lp == NEG_INF) ? NEG_INF : L.lwt - lp;
+  {
+    // backward row k is the arc out of state maxlen - 1 - k; the rows before a lane's first are its padding
+    double* wr = rows;
+    double* ca = col + (size_t)(maxlen - 1) * 64;
+    double wa[U], aa[U], wb[U], ab[U];  // the weights, and the forward values of the states the chunk will overwrite
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      wa[u] = wr[u * 64];
+      aa[u] = ca[-u * 64];
+    }
+    for (uint32_t kb = 0; kb < maxlen; kb += 2 * U) {
+      const bool two = kb + U < maxlen;
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          wb[u] = wr[(U + u) * 64];
+          ab[u] = ca[-(U + u) * 64];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        next = wa[u] + next;
+        ca[-u * 64] = next;
+        wr[u * 64] = aa[u] + next;
+      }
+      if (kb + 2 * U < maxlen) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          wa[u] = wr[(2 * U + u) * 64];
+          aa[u] = ca[-(2 * U + u) * 64];
+        }
+      }
+      if (two) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          next = wb[u] + next;
+          ca[-(U + u) * 64] = next;
+          wr[(U + u) * 64] = ab[u] + next;
+        }
+      }
+      wr += 2 * U * 64;
+      ca -= 2 * U * 64;
+    }
+  }
+  if (tr) {
+    c2 = __builtin_readcyclecounter();
+    if (lane == 0) {
+      tr[0] = c1 - c0;
+      tr[1] = c2 - c1;
+    }
+  }
+  return lp;
 }
 // The kernel is persistent and its wavefronts are specialised.  A workgroup per CU walks its share of the tiles; half of its
 // wavefronts SWEEP (a group each at a time), the other half MOVE: while tile t is swept they request tile t + 1 (its stretch
@@ -1677,22 +1809,67 @@ __device__ __forceinline__ void tile_request(const TransArgs& T, const LaneArgs&
 #pragma unroll
   for (int k = 0; k < KT; ++k) in.v[k] = T.x[SCAT ? i0 + min(m + k * NM, last) : (uint64_t)src[k]];
 }
+// the sweeps leave an arc's LOG posterior at its position; the exponentials are the whole workgroup's (every position of the
+// tile, padding included: sixteen independent ones a thread)
+__device__ __forceinline__ void tile_exp_in_place(double* lds) {
+  constexpr int K = (int)(TILE_SWEEP_TILE / TILE_SWEEP_THREADS);
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] = lds[threadIdx.x + k * TILE_SWEEP_THREADS];
+#pragma unroll
+  for (int k = 0; k < K; ++k) lds[threadIdx.x + k * TILE_SWEEP_THREADS] = K_EXP(v[k]);
+}
 // the walk of a workgroup over its tiles: workgroup b runs on XCD b % 8 and takes the tiles of that XCD's contiguous eighth
-// (xcd_chunked), gridDim.x / 8 apart; the scalars of a tile (its items, its groups) are requested two tiles ahead
+// (xcd_chunked), gridDim.x / 8 apart; the scalars of a tile (its items, its groups) are requested two tiles ahead.
+// Wave-uniform values that are REQUESTED AHEAD (a tile's scalars, a group's descriptor) are loaded through an address the
+// compiler cannot prove uniform (ts_zero: a zero it cannot see through): a uniform vector load is moved to scalar registers
+// the moment it is issued, i.e. waited for on the spot; this way it stays a pending vector register until its use, where
+// ts_sc / ts_uniform make it scalar.
+__device__ __forceinline__ uint32_t ts_zero() {
+  uint32_t z = 0;
+  asm volatile("" : "+v"(z));
+  return z;
+}
+__device__ __forceinline__ uint32_t ts_sc(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t ts_sc(uint64_t v) { return ((uint64_t)ts_sc((uint32_t)(v >> 32)) << 32) | ts_sc((uint32_t)v); }
+__device__ __forceinline__ LaneGroup ts_uniform(const LaneGroup& v) {
+  LaneGroup g;
+  g.stream_base = ts_sc(v.stream_base);
+  g.maxlen = ts_sc(v.maxlen);
+  g.n_lanes = ts_sc(v.n_lanes);
+  g.pair_base = ts_sc(v.pair_base);
+  g.max_states = ts_sc(v.max_states);
+  g.window = 0;
+  g.spill_row = ts_sc(v.spill_row);
+  return g;
+}
 struct TileWalk {
-  uint32_t tile, ni, g0, g1;
-  uint64_t i0;
+  uint32_t tile, ni, g0, g1;  // (g0, g1, i0, i1: as loaded until ts_uniform)
+  uint64_t i0, i1;
   bool ok;
 };
-__device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const uint32_t* __restrict__ tile_group, uint32_t vidx, bool ok) {
+__device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const uint32_t* __restrict__ tile_group, uint32_t vidx, bool ok,
+                                                 uint32_t z) {
   TileWalk w;
   const uint32_t tloc = xcd_chunked(vidx, T.tile_count);
   w.ok = ok && tloc < T.tile_count && vidx / 8 < (T.tile_count + 7) / 8;
   w.tile = T.tile_first + (w.ok ? tloc : 0u);
-  w.i0 = T.tile_base[w.tile];
-  w.ni = (uint32_t)(T.tile_base[w.tile + 1] - w.i0);
-  w.g0 = tile_group[w.tile];
-  w.g1 = tile_group[w.tile + 1];
+  w.i0 = T.tile_base[w.tile + z];
+  w.i1 = T.tile_base[w.tile + 1 + z];
+  w.g0 = tile_group[w.tile + z];
+  w.g1 = tile_group[w.tile + 1 + z];
+  w.ni = 0;
+  return w;
+}
+__device__ __forceinline__ TileWalk ts_uniform(const TileWalk& v) {
+  TileWalk w;
+  w.tile = v.tile;
+  w.ok = v.ok;
+  w.i0 = ts_sc(v.i0);
+  w.i1 = ts_sc(v.i1);
+  w.ni = (uint32_t)(w.i1 - w.i0);
+  w.g0 = ts_sc(v.g0);
+  w.g1 = ts_sc(v.g1);
   return w;
 }
 template <bool SCAT>
@@ -1704,17 +1881,20 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
   const int lane = threadIdx.x & 63;
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t vidx = blockIdx.x;
-  TileWalk cur = tile_walk_at(T, tile_group, vidx, true);
+  const uint32_t z = ts_zero();
+  TileWalk cur = tile_walk_at(T, tile_group, vidx, true, z);
   if (!cur.ok) return;
-  TileWalk nxt = tile_walk_at(T, tile_group, vidx + gridDim.x, true);
-  // Both kinds of wavefront meet at the same three barriers per tile: (a) the tile is placed, (b) it is swept, (c) it is read out.
+  cur = ts_uniform(cur);
+  TileWalk nxt = ts_uniform(tile_walk_at(T, tile_group, vidx + gridDim.x, true, z));
+  TileWalk nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);  // (as loaded)
+  // Both kinds of wavefront meet at the same four barriers per tile: (a) the tile is placed, (b) it is swept, (b') its posteriors
+  // are exponentiated, (c) it is read out.
   if (wv >= (uint32_t)NW) {
     // ================= movers =================
     const uint32_t m = threadIdx.x - (uint32_t)(TILE_SWEEP_THREADS - NM);
     TileIn in;
     tile_request<SCAT>(T, A, cur.tile, cur.i0, cur.ni, m, in);
     for (;;) {
-      const TileWalk nn = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok);
       // the tile's weights to their lane positions
       uint32_t pos2[KT / 2];
 #pragma unroll
@@ -1736,29 +1916,33 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       }
       if (nxt.ok) tile_request<SCAT>(T, A, nxt.tile, nxt.i0, nxt.ni, m, in);
       __syncthreads();  // (b)
-      // the tile's posteriors out: exp of the log posterior the sweep left at the arc's position
+      tile_exp_in_place(lds);
+      __syncthreads();  // (b')
+      // the tile's posteriors out
 #pragma unroll
       for (int k = 0; k < KT; ++k) {
         const uint32_t i = m + k * NM;
         const uint32_t q = (k & 1) ? pos2[k / 2] >> 16 : pos2[k / 2] & 0xffffu;
-        if (i < cur.ni) T.xc[SCAT ? (uint64_t)dst[k] : cur.i0 + i] = K_EXP(lds[q]);
-        if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);  // four exponentials side by side, not thirty-two (registers)
+        if (i < cur.ni) T.xc[SCAT ? (uint64_t)dst[k] : cur.i0 + i] = lds[q];
       }
       if (!nxt.ok) break;
       __syncthreads();  // (c)
       vidx += gridDim.x;
       cur = nxt;
-      nxt = nn;
+      nxt = ts_uniform(nn_raw);
+      nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
     }
   } else {
     // ================= sweepers =================
     constexpr int KR = (int)(TILE_SWEEP_TILE / 4 / (TILE_SWEEP_THREADS - NM));  // 16-byte pieces of a tile's records per sweeping thread
     LaneGroup g;
     TileLane L;
+    uint32_t chain;
     {
       const uint32_t gk = cur.g0 + wv < cur.g1 ? cur.g0 + wv : cur.g0;
-      g = A.groups[gk];
+      g = ts_uniform(A.groups[gk + z]);
       L = tile_lane(A, gk, lane);
+      chain = ts_sc(A.chain[gk + z]);
       ts_u32x4 rr[KR];  // the first tile's records as they are (the stream covers whole tiles)
 #pragma unroll
       for (int k = 0; k < KR; ++k)
@@ -1769,22 +1953,32 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
     for (;;) {
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
       if (A.trace) t0 = __builtin_readcyclecounter();
-      const TileWalk nn = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok);
       const uint64_t p0 = (uint64_t)cur.tile * TILE_SWEEP_TILE;
       // the first group of the next tile: its descriptor and lanes arrive while this tile is swept
       const uint32_t gk_n = nxt.g0 + wv < nxt.g1 ? nxt.g0 + wv : nxt.g0;
-      const LaneGroup g_n = A.groups[gk_n];
+      const LaneGroup g_n = A.groups[gk_n + z];  // (as loaded: made uniform at its use)
       const TileLane L_n = tile_lane(A, gk_n, lane);
+      const uint32_t chain_n = A.chain[gk_n + z];
       __syncthreads();  // (a)
       if (A.trace) t1 = __builtin_readcyclecounter();
       for (uint32_t gi = cur.g0 + wv; gi < cur.g1; gi += NW) {
         const uint32_t gk = gi + NW < cur.g1 ? gi + NW : gi;  // the wavefront's next group of this tile, requested before this one's sweep
-        const LaneGroup g_next = A.groups[gk];
+        const LaneGroup g_next = A.groups[gk + z];
         const TileLane L_next = tile_lane(A, gk, lane);
+        const uint32_t chain_next = A.chain[gk + z];
         const uint32_t off = (uint32_t)(g.stream_base - p0) + lane;
-        tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
-        g = g_next;
+        if (A.trace && wv == 0 && lane == 0 && gi == cur.g0) A.trace[(size_t)cur.tile * 16 + 14] = __builtin_readcyclecounter() - t1;
+        double lp;
+        if (chain & 1u)
+          lp = tile_chain_sweep(A, g, L, chain >> 8, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, (A.trace && wv == 0) ? A.trace + (size_t)cur.tile * 16 + 12 : nullptr);
+        else
+          lp = tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
+        const bool active = (uint32_t)lane < g.n_lanes;
+        const uint32_t pair = L.pair;
+        g = ts_uniform(g_next);
+        chain = ts_sc(chain_next);
         L = L_next;
+        if (active) A.pair_logprob[pair] = lp;  // (after the waits for the next group's requests: see tile_group_sweep)
       }
       if (A.trace && lane == 0) A.trace[(size_t)cur.tile * 16 + 8 + wv] = __builtin_readcyclecounter() - t1;  // this wavefront's sweeps
       // the next tile's records: on their way while this tile's posteriors leave
@@ -1794,6 +1988,8 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
         rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)nxt.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
       __syncthreads();  // (b)
       if (A.trace) t2 = __builtin_readcyclecounter();
+      tile_exp_in_place(lds);
+      __syncthreads();  // (b')
       // (the movers read the posteriors out; nobody needs this tile's records any more)
 #pragma unroll
       for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
@@ -1810,9 +2006,11 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       if (A.trace && threadIdx.x == 0) A.trace[(size_t)cur.tile * 16 + 3] = __builtin_readcyclecounter() - t2;
       vidx += gridDim.x;
       cur = nxt;
-      nxt = nn;
-      g = g_n;
+      nxt = ts_uniform(nn_raw);
+      nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
+      g = ts_uniform(g_n);
       L = L_n;
+      chain = ts_sc(chain_n);
     }
   }
 }
@@ -1967,7 +2165,7 @@ hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32
 hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
                              hipStream_t stream) {
   if (!T0.n_buckets || !tile_count) return hipSuccess;
-  if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2) return hipErrorInvalidValue;
+  if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2 || !A.chain) return hipErrorInvalidValue;
   static bool attr = false;
   const int lds = (int)TILE_SWEEP_LDS;
   if (!attr) {
@@ -1997,9 +2195,10 @@ hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint3
   return hipGetLastError();
 }
 hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
-                                    const uint32_t* bwd, uint32_t* out, hipStream_t stream) {
+                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, hipStream_t stream) {
   if (n_groups)
-    hipLaunchKernelGGL(pack_tile_records_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, groups, n_groups, lane_nstates, fwdx, bwd, out);
+    hipLaunchKernelGGL(pack_tile_records_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, groups, n_groups, lane_nstates, fwdx, bwd, out,
+                       chain);
   return hipGetLastError();
 }
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream) {

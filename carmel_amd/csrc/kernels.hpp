@@ -17,6 +17,7 @@ struct LaneArgs {
   const uint32_t* fwdx;  // forward records, flags word only (pre-distributed weights)
   const uint32_t* bwd;   // backward records: destination | flags only (the arc id stays on the host)
   const uint32_t* rec2;  // tile sweep: forward and backward record of a position packed into one word (launch_pack_tile_records)
+  const uint32_t* chain; // ... per group: 1 = every lattice of the group is a single path
   const uint32_t* lane_pair;
   const uint32_t* lane_nstates;
   const double* lane_logw;
@@ -186,7 +187,7 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T, uint32_t first, uint3
 hipError_t launch_tile_sweep(const TransArgs& T, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
                              hipStream_t stream);
 hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
-                                    const uint32_t* bwd, uint32_t* out, hipStream_t stream);
+                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, hipStream_t stream);
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream);
 // small[k] = src[idx[k]] / dst[idx[k]] = small[k]   (halo values of the exchange)
 hipError_t launch_gather_idx(double* small, const double* src, const uint32_t* idx, uint32_t n, hipStream_t stream);

@@ -68,7 +68,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
   bool sweepable = opt.tile_sweep && only_lanes && ng > 0 && opt.lane_chunks <= 1;
   for (size_t g = 0; sweepable && g < ng; ++g) {
     const LaneGroup& G = out.lane_groups[g];
-    if (G.window || G.maxlen > TILE_SWEEP_ROWS || G.max_states > TILE_SWEEP_ALPHA_ROWS) sweepable = false;
+    if (G.window || G.maxlen > TILE_SWEEP_ROWS || std::max(G.max_states, G.maxlen + 1) > TILE_SWEEP_ALPHA_ROWS) sweepable = false;
   }
   if (sweepable) {
     out.tile = TILE_SWEEP_TILE;
@@ -78,7 +78,8 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
     uint32_t rows = 0, vrows = 0, mx = 0;
     for (size_t g = 0; g < ng; ++g) {
       LaneGroup& G = out.lane_groups[g];
-      if (g == 0 || (uint64_t)(rows + G.maxlen) * 64 > TILE_SWEEP_TILE || vrows + G.max_states > TILE_SWEEP_ALPHA_ROWS ||
+      const uint32_t need = std::max(G.max_states, G.maxlen + 1);  // (tile_chain_sweep writes a column row per stream row)
+      if (g == 0 || (uint64_t)(rows + G.maxlen) * 64 > TILE_SWEEP_TILE || vrows + need > TILE_SWEEP_ALPHA_ROWS ||
           g - out.tile_group.back() >= TILE_SWEEP_GROUPS) {
         base = (base + TILE_SWEEP_TILE - 1) / TILE_SWEEP_TILE * TILE_SWEEP_TILE;
         out.tile_group.push_back((uint32_t)g);
@@ -88,7 +89,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
       G.spill_row = vrows;
       base += (uint64_t)G.maxlen * 64;
       rows += G.maxlen;
-      vrows += G.max_states;
+      vrows += need;
       mx = std::max(mx, G.max_states);
     }
     out.tile_group.push_back((uint32_t)ng);

@@ -1104,10 +1104,21 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   HIPCHK(hipGetLastError());
   if (L.tile_sweep) {
     HIPCHK(t->lane_rec2.alloc(n_rec));
+    HIPCHK(t->lane_chain.alloc(ng));
     HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, n_rec * 4, s));
-    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, s));
-  } else
+    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p, s));
+    if (getenv("CARMEL_TIMING")) {
+      std::vector<uint32_t> ch(t->lane_chain.n);
+      HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      size_t n1 = 0;
+      for (uint32_t c : ch) n1 += c;
+      fprintf(stderr, "timing: tile sweep: %zu tiles, %zu groups, %zu of them single paths\n", L.tile_group.size() - 1, ch.size(), n1);
+    }
+  } else {
     t->lane_rec2.release();
+    t->lane_chain.release();
+  }
   lap("record streams");
   // ---- slots by arc ----
   HIPCHK(sort_keys(tmp, items.p, items_sorted.p, n_items, 32 + bits_for(w.n_arcs), s));
