@@ -924,7 +924,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
   // a corpus of plain lane lattices laid out for it: weights in, sweeps and posteriors out of a tile in one kernel
   // (CARMEL_HIP_TILE_SWEEP_KERNEL=0: the three kernels on the same layout, bit-identical)
-  static const bool tile_kernel_off = getenv("CARMEL_HIP_TILE_SWEEP_KERNEL") && atoi(getenv("CARMEL_HIP_TILE_SWEEP_KERNEL")) == 0;
+  const bool tile_kernel_off = getenv("CARMEL_HIP_TILE_SWEEP_KERNEL") && atoi(getenv("CARMEL_HIP_TILE_SWEEP_KERNEL")) == 0;
   const bool tile_sweep = t->use_transpose && t->lat.tile_sweep && t->tile_group.n && !tile_kernel_off &&
                           ((T.scatter & 3u) == 0u || ((T.scatter & 3u) == 3u && T.use_runs));
   const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty();
@@ -1077,6 +1077,10 @@ int carmel_hip_set_matrix_fb(carmel_hip_trainer* t, int on) {
     if (rc) return rc;
   }
   return matrix_setup(t, &t->matrix);
+}
+int carmel_hip_lattice_tile_sweep(carmel_hip_trainer* t) {
+  if (!t || !t->have_lattices || t->unrolled || !t->lat.tile_sweep || !t->tile_group.n) return 0;
+  return (int)(t->tile_group.n - 1);
 }
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;

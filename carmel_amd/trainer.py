@@ -166,8 +166,15 @@ class HipForwardBackward(object):
             return "unrolled over string positions (never stored)"
         if lay == 2:
             return "unrolled, rank-1 dense form (never stored)"
-        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM" % (
-            ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9)
+        tiles = lib.carmel_hip_lattice_tile_sweep(self.h)
+        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM%s" % (
+            ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9,
+            "; laid out for the tile sweep (%d tiles)" % tiles if tiles else "")
+
+    @property
+    def tile_sweep_tiles(self):
+        """> 0: the E-step is bucket pass, tile_sweep_kernel, bucket pass (carmel_hip_lattice_tile_sweep)"""
+        return lib.carmel_hip_lattice_tile_sweep(self.h)
 
     def exchange_plan(self, comm, n_chunks=0, force_allreduce=False):
         """plan the per-iteration exchange (collective); returns exchange_info()"""

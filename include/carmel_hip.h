@@ -87,6 +87,11 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
  * pair weights) -- the GPU lattice builder (csrc/lattice_gpu.hip; CARMEL_HIP_GPU_BUILD=0 switches it off) must leave
  * the very bytes the host builder leaves. */
 int carmel_hip_debug_lattice_fingerprint(carmel_hip_trainer* t, uint64_t* out16);
+/* > 0: the explicit lattices are laid out for the tile sweep (csrc/lattice.hpp, TILE_SWEEP_TILE: a corpus of small plain lane
+ * lattices; the E-step is bucket pass, tile_sweep_kernel, bucket pass) -- the number of tiles; 0 otherwise.
+ * CARMEL_HIP_TILE_SWEEP=0 at build time keeps the five-kernel layout, CARMEL_HIP_TILE_SWEEP_KERNEL=0 runs the three middle
+ * kernels on the tile-sweep layout (A/B switches: same counts). */
+int carmel_hip_lattice_tile_sweep(carmel_hip_trainer* t);
 /* how the derivation lattices are held: 0 = explicit (lane groups / bundles in HBM), 1 = unrolled over string positions
  * (one-tape models, never stored), 2 = unrolled in the rank-1 dense form (LM o channel cascades, dense.hpp); -1: none built */
 int carmel_hip_lattice_layout(carmel_hip_trainer* t);

@@ -408,6 +408,48 @@ def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n
             assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0), key
 
 
+@pytest.mark.parametrize("kind", ["paths", "ambiguous"])
+def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
+    """tile_sweep_kernel (kernels.hip): on a corpus of small plain lane lattices the weights' way into lattice order, the lane
+    sweeps and the posteriors' way out are one persistent kernel working out of LDS.  Same layout, the three kernels instead
+    (CARMEL_HIP_TILE_SWEEP_KERNEL=0): the same bits (ln p per pair, every count, the weights after an M-step; the sign of a
+    zero aside).  The five-kernel layout (CARMEL_HIP_TILE_SWEEP=0): the same ln p, counts equal up to the order of their sums.
+    And both are the oracle's."""
+    if kind == "paths":  # config 4's shape: nearly every lattice a single path (the record-free sweep of a group)
+        w, c = synth.make_config("c4", n_pairs=120000)
+    else:  # three symbols, no epsilons: lattices of up to a few dozen arcs with real sums
+        w = synth.random_wfst(60, 4, n_sym=3, p_eps=0.0, seed=5)
+        c = synth.random_walk_corpus(w, 40000, min_arcs=3, max_arcs=9, seed=5, out_degree=4)
+    out = {}
+    for mode in ("fused", "kernels", "layout"):
+        monkeypatch.delenv("CARMEL_HIP_TILE_SWEEP_KERNEL", raising=False)
+        monkeypatch.delenv("CARMEL_HIP_TILE_SWEEP", raising=False)
+        if mode == "kernels":
+            monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP_KERNEL", "0")
+        if mode == "layout":
+            monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP", "0")
+        fb = _fb(w, c)
+        assert (fb.tile_sweep_tiles > 0) == (mode != "layout")
+        lp, _ = fb.estimate(per_pair=True)
+        res = [lp, fb.pair_logprob.copy(), fb.counts().copy()]
+        fb.maximize(1.0)
+        lp2, _ = fb.estimate()
+        out[mode] = res + [lp2, fb.counts().copy()]
+        fb.close()
+    a, b, l = out["fused"], out["kernels"], out["layout"]
+    assert a[0] == b[0] and a[3] == b[3] and np.array_equal(a[1], b[1])
+    for x, y in ((a[2], b[2]), (a[4], b[4])):  # (the one atomic add per piece of a split hub arc aside)
+        assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0)
+    assert np.array_equal(a[1], l[1])
+    np.testing.assert_allclose(a[2], l[2], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a[4], l[4], rtol=1e-11, atol=0)
+    if kind == "ambiguous":
+        _, _, r = oracle_estep(oracle, w, c)
+        ok = r["has_deriv"]
+        np.testing.assert_allclose(a[1][ok], r["pair_logprob"][ok], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
+
+
 def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
     texts = [open(os.path.join(golden_dir, n)).read() for n in names]
     oc = oracle.OracleCascade(texts)

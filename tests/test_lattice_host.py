@@ -238,3 +238,55 @@ def test_wave_layout_on_ambiguous_lattices(oracle, monkeypatch, seed, lane_state
     got = H.transpose_counts(tr, post)
     v = arc_at >= 0
     np.testing.assert_allclose(got, np.bincount(arc_at[v], weights=post[v], minlength=tr["n_arcs"]), rtol=1e-12, atol=0)
+
+
+def test_tile_sweep_layout(monkeypatch):
+    """LatticeSet::tile_sweep (lattice.hpp, TILE_SWEEP_*): a corpus of small plain lane lattices is laid out in tiles of 8192
+    positions that no lane group straddles, with room in a workgroup's LDS for the values of a tile's groups; the tables of
+    the blocked transposition are built on those tiles and move exactly what they move on the five-kernel layout; the sweep
+    itself (numpy model over the lane groups) gives the same counts on either layout."""
+    from carmel_amd import synth
+    w = synth.random_wfst(3000, 6, seed=11)
+    c = synth.random_walk_corpus(w, 30000, min_arcs=3, max_arcs=40, seed=11, out_degree=6)
+    img = H.host_lattices(w, c, threads=4)
+    tr = img["transpose"]
+    T, tg, g = tr["tile"], tr["tile_group"], img["lane_groups"]
+    assert T == 8192 and len(tg) >= 2 and tg[0] == 0 and tg[-1] == len(g) and (np.diff(tg.astype(np.int64)) > 0).all()
+    assert (np.diff(tg.astype(np.int64)) <= 16).all()
+    for t in range(len(tg) - 1):
+        gs = g[int(tg[t]):int(tg[t + 1])]
+        lo, hi = gs["stream_base"].astype(np.int64), gs["stream_base"].astype(np.int64) + gs["maxlen"].astype(np.int64) * 64
+        assert lo.min() >= t * T and hi.max() <= (t + 1) * T and (lo[1:] == hi[:-1]).all()
+        need = np.maximum(gs["max_states"], gs["maxlen"] + 1).astype(np.int64)
+        assert (gs["window"] == 0).all() and (gs["maxlen"] <= 48).all() and need.sum() <= 126
+        # a group's values start where the previous group's end
+        assert (gs["spill_row"].astype(np.int64) == np.concatenate([[0], np.cumsum(need)[:-1]])).all()
+    n_post = tr["n_post"]
+    assert n_post % T == 0 and len(tr["tile_base"]) - 1 == n_post // T
+    rng = np.random.default_rng(1)
+    logw = rng.normal(size=tr["n_arcs"])
+    arc_at = np.full(n_post, -1, np.int64)
+    for a in range(tr["n_arcs"]):
+        arc_at[tr["slot_pos"][int(tr["arc_off"][a]):int(tr["arc_off"][a + 1])]] = a
+    valid = arc_at >= 0
+    wc = H.transpose_weights(tr, logw, n_post)
+    assert np.array_equal(wc[valid], logw[arc_at[valid]])
+    post = rng.random(n_post)
+    np.testing.assert_allclose(H.transpose_counts(tr, post), np.bincount(arc_at[valid], weights=post[valid], minlength=tr["n_arcs"]),
+                               rtol=1e-12, atol=0)
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP", "0")
+    img0 = H.host_lattices(w, c, threads=4)
+    assert img0["transpose"]["tile"] == 16384 and len(img0["transpose"]["tile_group"]) == 0
+    counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)
+    assert np.array_equal(plp, plp0)
+    np.testing.assert_allclose(counts, counts0, rtol=1e-12, atol=0)
+
+
+def test_tile_sweep_layout_is_for_small_plain_lattices_only():
+    """a corpus with one lattice beyond 48 arcs, a windowed group or a one-per-wavefront lattice keeps the five-kernel layout"""
+    from carmel_amd import synth
+    w = synth.random_wfst(3000, 6, seed=12)
+    c = synth.random_walk_corpus(w, 3000, min_arcs=3, max_arcs=60, seed=12, out_degree=6)
+    tr = H.host_lattices(w, c, threads=4)["transpose"]
+    assert tr["tile"] == 16384 and len(tr["tile_group"]) == 0
