@@ -11,10 +11,14 @@
 //                                    to the arc's slot (derivations.h:400-449, graph.h:391-402).  Windowed groups
 //                                    keep a ring of W rows instead of the whole column (lattices up to 1023 states);
 //   sweep_wave                       one lattice per WAVEFRONT (lattices too large for a lane): the 64 lanes take the
-//                                    arcs of a level, __shfl / DPP log-sum-exp across the lanes that share a state;
+//                                    arcs of a level, a state's log-sum-exp through LDS atomics (max, then scaled sum);
 //   sweep_bundle / sweep_serial      the level-synchronous workgroup-per-bundle gather sweep (kept for lattices beyond
 //                                    the wave kernel's LDS) and the reference-order sweep of cyclic lattices;
 //   trans_c_tile -> trans_c_bucket   the posteriors back into arc order, each arc's uses summed in a fixed order.
+// or, for a corpus made of small plain lane lattices (LatticeSet::tile_sweep, lattice.hpp), three:
+//   trans_w_bucket -> tile_sweep -> trans_c_bucket
+//                                    tile_sweep_kernel does trans_w_tile's, sweep_lane's and trans_c_tile's work on a
+//                                    tile of 8192 lattice positions out of one workgroup's LDS: no wcache, no post.
 // No kernel on this path issues an atomic: counts are bit-reproducible run to run (the one exception: the partial
 // sums of a hub arc split over several buckets meet in one atomic add per piece).
 //
@@ -1676,11 +1680,9 @@ __device__ __forceinline__ double tile_group_sweep(const LaneArgs& A, const Lane
 // the forward chain keeps adding 0 (and writes the unchanged value to column rows nobody reads: the layout gives a group
 // maxlen + 1 of them), before its first backward row the backward chain does.  (What the zeros can change is the sign of a
 // zero: -0.0 + 0.0 is +0.0.)
-__device__ __forceinline__ double tile_chain_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, uint32_t max_pad, const int lane,
-                                                   double* col, double* rows, unsigned long long* tr) {
+__device__ __forceinline__ double tile_chain_sweep(const LaneGroup& g, const TileLane& L, uint32_t max_pad, const int lane, double* col,
+                                                   double* rows) {
   constexpr int U = (int)LANE_CHUNK;
-  unsigned long long c0 = 0, c1 = 0, c2 = 0;
-  if (tr) c0 = __builtin_readcyclecounter();
   const bool active = (uint32_t)lane < g.n_lanes;
   const uint32_t S = active ? L.S : 0u;
   const uint32_t len = S ? S - 1 : 0u;
@@ -1724,7 +1726,6 @@ __device__ __forceinline__ double tile_chain_sweep(const LaneArgs& A, const Lane
       cw += 2 * U * 64;
     }
   }
-  if (tr) c1 = __builtin_readcyclecounter();
   const double lp = prev;  // = col[(S - 1) * 64] (and every later row of the column)
   double next = (!active || lp == NEG_INF) ? NEG_INF : L.lwt - lp;
   {
@@ -1771,13 +1772,6 @@ __device__ __forceinline__ double tile_chain_sweep(const LaneArgs& A, const Lane
       ca -= 2 * U * 64;
     }
   }
-  if (tr) {
-    c2 = __builtin_readcyclecounter();
-    if (lane == 0) {
-      tr[0] = c1 - c0;
-      tr[1] = c2 - c1;
-    }
-  }
   return lp;
 }
 // The kernel is persistent and its wavefronts are specialised.  A workgroup per CU walks its share of the tiles; half of its
@@ -1813,11 +1807,15 @@ __device__ __forceinline__ void tile_request(const TransArgs& T, const LaneArgs&
 // tile, padding included: sixteen independent ones a thread)
 __device__ __forceinline__ void tile_exp_in_place(double* lds) {
   constexpr int K = (int)(TILE_SWEEP_TILE / TILE_SWEEP_THREADS);
-  double v[K];
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] = lds[threadIdx.x + k * TILE_SWEEP_THREADS];
+  for (int k0 = 0; k0 < K; k0 += 4) {  // four side by side (a mover holds the next tile in its registers meanwhile)
+    double v[4];
 #pragma unroll
-  for (int k = 0; k < K; ++k) lds[threadIdx.x + k * TILE_SWEEP_THREADS] = K_EXP(v[k]);
+    for (int k = 0; k < 4; ++k) v[k] = lds[threadIdx.x + (k0 + k) * TILE_SWEEP_THREADS];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lds[threadIdx.x + (k0 + k) * TILE_SWEEP_THREADS] = K_EXP(v[k]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 }
 // the walk of a workgroup over its tiles: workgroup b runs on XCD b % 8 and takes the tiles of that XCD's contiguous eighth
 // (xcd_chunked), gridDim.x / 8 apart; the scalars of a tile (its items, its groups) are requested two tiles ahead.
@@ -1894,6 +1892,19 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
     const uint32_t m = threadIdx.x - (uint32_t)(TILE_SWEEP_THREADS - NM);
     TileIn in;
     tile_request<SCAT>(T, A, cur.tile, cur.i0, cur.ni, m, in);
+    // A mover sweeps as well while it has nothing to do but wait for its requests: group NW + (its number) of the tile, when
+    // that is a group of single paths (tile_chain_sweep asks the memory for nothing; a sweeper takes it otherwise).  Its
+    // descriptor and lanes are requested a tile ahead, behind the tile's own requests, and are there when the tile is placed.
+    const uint32_t mw = wv - (uint32_t)NW;
+    LaneGroup gm_raw;
+    TileLane lm;
+    uint32_t cm_raw;
+    {
+      const uint32_t gk = cur.g0 + NW + mw < cur.g1 ? cur.g0 + NW + mw : cur.g0;
+      gm_raw = A.groups[gk + z];
+      lm = tile_lane(A, gk, lane);
+      cm_raw = A.chain[gk + z];
+    }
     for (;;) {
       // the tile's weights to their lane positions
       uint32_t pos2[KT / 2];
@@ -1906,15 +1917,29 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
         if (m + k * NM < cur.ni) lds[in.pos[k]] = in.v[k];
       }
       __syncthreads();  // (a)
-      // requests while the tile is swept: its destinations, then the next tile
-      uint32_t dst[KT];
-      if (SCAT) {
-#pragma unroll
-        for (int k = 0; k < KT; ++k) {
-          dst[k] = T.t_src[cur.i0 + min(m + k * NM, cur.ni ? cur.ni - 1 : 0u)];
+      // requests while the tile is swept: the next tile (and, once its own sweep is done, this tile's destinations)
+      if (nxt.ok) tile_request<SCAT>(T, A, nxt.tile, nxt.i0, nxt.ni, m, in);
+      {
+        const LaneGroup gm = ts_uniform(gm_raw);  // (this tile's: there since the tile was placed)
+        const TileLane lm_cur = lm;
+        const uint32_t cm = ts_sc(cm_raw);
+        const bool mine = cur.g0 + NW + mw < cur.g1 && (cm & 1u);
+        const uint32_t gk = nxt.g0 + NW + mw < nxt.g1 ? nxt.g0 + NW + mw : nxt.g0;
+        gm_raw = A.groups[gk + z];
+        lm = tile_lane(A, gk, lane);
+        cm_raw = A.chain[gk + z];
+        if (mine) {
+          const uint32_t off = (uint32_t)(gm.stream_base - (uint64_t)cur.tile * TILE_SWEEP_TILE) + lane;
+          const double lp = tile_chain_sweep(gm, lm_cur, cm >> 8, lane, alpha + (size_t)gm.spill_row * 64 + lane, lds + off);
+          if ((uint32_t)lane < gm.n_lanes) A.pair_logprob[lm_cur.pair] = lp;
         }
       }
-      if (nxt.ok) tile_request<SCAT>(T, A, nxt.tile, nxt.i0, nxt.ni, m, in);
+      uint32_t dst[KT];
+      __builtin_amdgcn_sched_barrier(0);  // (not before the sweep: its registers)
+      if (SCAT) {
+#pragma unroll
+        for (int k = 0; k < KT; ++k) dst[k] = T.t_src[cur.i0 + min(m + k * NM, cur.ni ? cur.ni - 1 : 0u)];
+      }
       __syncthreads();  // (b)
       tile_exp_in_place(lds);
       __syncthreads();  // (b')
@@ -1967,13 +1992,15 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
         const TileLane L_next = tile_lane(A, gk, lane);
         const uint32_t chain_next = A.chain[gk + z];
         const uint32_t off = (uint32_t)(g.stream_base - p0) + lane;
-        if (A.trace && wv == 0 && lane == 0 && gi == cur.g0) A.trace[(size_t)cur.tile * 16 + 14] = __builtin_readcyclecounter() - t1;
-        double lp;
-        if (chain & 1u)
-          lp = tile_chain_sweep(A, g, L, chain >> 8, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, (A.trace && wv == 0) ? A.trace + (size_t)cur.tile * 16 + 12 : nullptr);
-        else
-          lp = tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
-        const bool active = (uint32_t)lane < g.n_lanes;
+        const bool movers = gi == cur.g0 + NW + wv && (chain & 1u);  // a group of single paths among the tile's second four: a mover's
+        double lp = 0.0;
+        if (!movers) {
+          if (chain & 1u)
+            lp = tile_chain_sweep(g, L, chain >> 8, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off);
+          else
+            lp = tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
+        }
+        const bool active = !movers && (uint32_t)lane < g.n_lanes;
         const uint32_t pair = L.pair;
         g = ts_uniform(g_next);
         chain = ts_sc(chain_next);

@@ -64,14 +64,14 @@ def test_annealing_schedule(oracle):
 
 def test_committed_profiles_agree():
     """profiles/ (round 4): the E-step time the default bench.py run measured with HIP events (profiles/r4_bench_full.json, the
-    headline) equals the sum of the E-step kernels' average durations in the rocprofv3 --kernel-trace --stats summary of the
+    headline) equals the sum of the three E-step kernels' average durations in the rocprofv3 --kernel-trace --stats summary of the
     same workload (profiles/r4_c4_kernel_stats.csv, tools/kstats.sh c4) within 5 %; the fraction is achieved / peak; the PMC
     traffic (profiles/pmc_traffic_c4.json, collected on the same kernels.hip) exceeds the algorithmic bytes; and the compact
     line the driver records carries every workload inside 2 000 characters."""
     import csv
     import json
     bench = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_full.json")))
-    names = ("trans_w_bucket_kernel", "trans_w_tile_kernel", "sweep_lane_kernel", "trans_c_tile_kernel", "trans_c_bucket_kernel")
+    names = ("trans_w_bucket_kernel", "tile_sweep_kernel", "trans_c_bucket_kernel")
     total = 0.0
     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_c4_kernel_stats.csv"))):
         if any(n in r["Name"] for n in names):

@@ -33,7 +33,7 @@ def main():
                       "write_kb_per_launch": w / nw if nw else None}
     meta = {"config": cfg, "unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE, raw, per launch)"}
     pairs = {"c4": 1000000, "c2": 50000, "c4a": 1000000, "long": 5000}.get(cfg)
-    sweeps = [v["launches"] for k, v in kernels.items() if "sweep_lane_kernel" in k or "sweep_wave_kernel" in k]
+    sweeps = [v["launches"] for k, v in kernels.items() if "sweep_lane_kernel" in k or "sweep_wave_kernel" in k or "tile_sweep_kernel" in k]
     if pairs and sweeps:  # what bench.py's roofline.traffic needs: E-steps profiled, workload size, the command
         meta.update({"pairs_per_gpu": pairs, "estep_count": max(sweeps),
                      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config %s "

@@ -13,6 +13,5 @@ for lo, hi in ((0, 8), (9, 16), (17, 24), (25, 32), (33, 40), (41, 48)):
     m = (ml >= lo) & (ml <= hi)
     if m.any():
         w = a[m][:, 8:12].astype(np.int64)
-        print("      wave 0: from the barrier to its first sweep %d; its last group: forward %d backward %d cycles" % (np.median(a[m][:, 14].astype(np.int64)), np.median(a[m][:, 12].astype(np.int64)), np.median(a[m][:, 13].astype(np.int64))))
         print("  maxlen %2d-%2d: tiles %5d groups %4.1f items %5d | load %6d sweep %6d store %6d | per-wave sweep max %6d" % (
             lo, hi, m.sum(), ng[m].mean(), ni[m].mean(), np.median(ld[m]), np.median(sw[m]), np.median(st[m]), np.median(w.max(1))))
