@@ -65,8 +65,8 @@ def test_annealing_schedule(oracle):
 def test_committed_profiles_agree():
     """profiles/ (round 4): the E-step time the default bench.py run measured with HIP events (profiles/r4_bench_full.json, the
     headline) equals the sum of the three E-step kernels' average durations in the rocprofv3 --kernel-trace --stats summary of the
-    same workload (profiles/r4_c4_kernel_stats.csv, tools/kstats.sh c4) within 5 %; the fraction is achieved / peak; the PMC
-    traffic (profiles/pmc_traffic_c4.json, collected on the same kernels.hip) exceeds the algorithmic bytes; and the compact
+    same workload (profiles/r4_c4_kernel_stats.csv, tools/kstats.sh c4) plus at most a tenth (the launch gaps); the fraction is achieved / peak; the PMC
+    traffic (profiles/pmc_traffic_c4.json, collected on the same kernels.hip) is within a fifth of the algorithmic bytes; and the compact
     line the driver records carries every workload inside 2 000 characters."""
     import csv
     import json
@@ -76,9 +76,10 @@ def test_committed_profiles_agree():
     for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r4_c4_kernel_stats.csv"))):
         if any(n in r["Name"] for n in names):
             total += float(r["AverageNs"]) * 1e-6
-    assert abs(total - bench["kernel_ms"]) < 0.05 * total
+    assert 0.0 <= bench["kernel_ms"] - total < 0.10 * total  # (what the events see beyond the kernels: three launches' gaps, ~25 us)
     assert bench["roofline"]["frac"] == bench["roofline"]["achieved"] / bench["roofline"]["peak"]
-    assert bench["roofline"]["traffic"] > bench["roofline"]["algorithmic_bytes_per_launch"]
+    # (with the tile sweep the measured traffic IS the model's figure: 1.45 GB against 1.455; it was 2.26 GB with five kernels)
+    assert 0.9 < bench["roofline"]["traffic"] / bench["roofline"]["algorithmic_bytes_per_launch"] < 1.2
     line = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_line.json")))
     assert len(json.dumps(line)) < 2000 and set(line["secondary"]) == {"c4a", "amb", "c2", "long", "c3", "c5", "crp"}
     assert line["value"] == float("%.4g" % bench["value"]) and line["secondary"]["c5"]["exact_ms"] < 1000

@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 4, the records of the final tree, second half: the default bench run (with the PMC files of the first half committed),
+# the phase stamps of the tile sweep, the whole GPU suite
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
+bash tools/bench_full.sh 2>&1 | tail -6
+bash tools/ts_trace.sh 2>&1 | head -12 > gpurun_out/ts_trace.txt; cat gpurun_out/ts_trace.txt
+bash tools/gpu_suite.sh 2>&1 | tail -8
