@@ -75,8 +75,9 @@ def pmc_traffic(config, walk_arcs, n_pairs):
         return None
     # the counters belong to one build of the kernels: after any change to kernels.hip, or under an A/B library or a
     # CARMEL_HIP_* switch, the committed figure says nothing about this run
-    src = os.path.join(ROOT, "carmel_amd", "csrc", "kernels.hip")
-    if d.get("kernels_hip_sha16") != hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]:
+    csrc = os.path.join(ROOT, "carmel_amd", "csrc")  # (the E-step's device code: kernels.hip, tile_sweep.hip, sweep_math.hpp)
+    sha = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("kernels.hip", "tile_sweep.hip", "sweep_math.hpp")))
+    if d.get("kernels_hip_sha16") != sha.hexdigest()[:16]:
         return None
     if os.environ.get("CARMEL_HIP_LIB") or any(k.startswith("CARMEL_HIP_") for k in os.environ):
         return None

@@ -410,7 +410,7 @@ def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n
 
 @pytest.mark.parametrize("kind", ["paths", "ambiguous"])
 def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
-    """tile_sweep_kernel (kernels.hip): on a corpus of small plain lane lattices the weights' way into lattice order, the lane
+    """tile_sweep_kernel (tile_sweep.hip): on a corpus of small plain lane lattices the weights' way into lattice order, the lane
     sweeps and the posteriors' way out are one persistent kernel working out of LDS.  Same layout, the three kernels instead
     (CARMEL_HIP_TILE_SWEEP_KERNEL=0): the same bits (ln p per pair, every count, the weights after an M-step; the sign of a
     zero aside).  The five-kernel layout (CARMEL_HIP_TILE_SWEEP=0): the same ln p, counts equal up to the order of their sums.

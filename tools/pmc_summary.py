@@ -42,7 +42,8 @@ def main():
     import hashlib
     import os
     csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "carmel_amd", "csrc")
-    meta["kernels_hip_sha16"] = hashlib.sha256(open(os.path.join(csrc, "kernels.hip"), "rb").read()).hexdigest()[:16]
+    meta["kernels_hip_sha16"] = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in
+                                                        ("kernels.hip", "tile_sweep.hip", "sweep_math.hpp"))).hexdigest()[:16]
     if cfg == "c5":  # the sampler's sweeps: one forest_commit_kernel launch per parallel sweep
         commits = [v["launches"] for k, v in kernels.items() if "forest_commit_kernel" in k]
         meta.update({"forests": 100000, "sweep_count": max(commits) if commits else 0,
