@@ -312,8 +312,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (L.tile_sweep && t->lane_fwdx.n) {
     HIPCHK(t->lane_rec2.alloc(t->lane_bwd.n));
     HIPCHK(t->lane_chain.alloc(t->lane_groups.n));
+    HIPCHK(t->tile_chain.alloc(t->tile_group.n - 1));
     HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, t->lane_rec2.bytes(), s));
-    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p, s));
+    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p,
+                                    t->tile_group.p, (uint32_t)(t->tile_group.n - 1), t->tile_chain.p, s));
     if (getenv("CARMEL_TIMING")) {
       std::vector<uint32_t> ch(t->lane_chain.n);
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
@@ -325,6 +327,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   } else {
     t->lane_rec2.release();
     t->lane_chain.release();
+    t->tile_chain.release();
   }
   t->lane_records = L.wave_slot_base + L.wave_bwd.size();  // first bundle slot: [lane records | wave records | bundle arcs]
   HIPCHK(t->post.alloc(L.n_post));
@@ -883,6 +886,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.bwd = t->lane_bwd.p;
   LA.rec2 = t->lane_rec2.p;
   LA.chain = t->lane_chain.p;
+  LA.tile_chain = t->tile_chain.p;
   LA.lane_pair = t->lane_pair.p;
   LA.lane_nstates = t->lane_nstates.p;
   LA.lane_logw = t->lane_logw.p;

@@ -115,6 +115,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> tile_group;  // LatticeSet::tile_group (tile sweep)
   DevBuf<uint32_t> lane_rec2;   // ... and its packed records (LaneArgs::rec2)
   DevBuf<uint32_t> lane_chain;  // ... per group: a group of single paths (LaneArgs::chain)
+  DevBuf<uint32_t> tile_chain;  // ... per tile: all of them (LaneArgs::tile_chain)
   DevBuf<uint2_t> lane_fwd;
   // blocked transposition tables (TransBucket, lattice.hpp); empty => gather / count_reduce path
   DevBuf<TransBucket> t_buckets;

@@ -17,7 +17,8 @@ struct LaneArgs {
   const uint32_t* fwdx;  // forward records, flags word only (pre-distributed weights)
   const uint32_t* bwd;   // backward records: destination | flags only (the arc id stays on the host)
   const uint32_t* rec2;  // tile sweep: forward and backward record of a position packed into one word (launch_pack_tile_records)
-  const uint32_t* chain; // ... per group: 1 = every lattice of the group is a single path
+  const uint32_t* chain; // ... per group: bit 0 = every lattice of the group is a single path; from bit 8: its lanes' most padding rows
+  const uint32_t* tile_chain;  // ... per tile: 1 = all of its groups are
   const uint32_t* lane_pair;
   const uint32_t* lane_nstates;
   const double* lane_logw;
@@ -187,7 +188,8 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T, uint32_t first, uint3
 hipError_t launch_tile_sweep(const TransArgs& T, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
                              hipStream_t stream);
 hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
-                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, hipStream_t stream);
+                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, const uint32_t* tile_group, uint32_t n_tiles,
+                                    uint32_t* tile_chain, hipStream_t stream);
 hipError_t launch_zero_list(double* p, const uint32_t* idx, uint32_t n, hipStream_t stream);
 // small[k] = src[idx[k]] / dst[idx[k]] = small[k]   (halo values of the exchange)
 hipError_t launch_gather_idx(double* small, const double* src, const uint32_t* idx, uint32_t n, hipStream_t stream);

@@ -1105,8 +1105,10 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   if (L.tile_sweep) {
     HIPCHK(t->lane_rec2.alloc(n_rec));
     HIPCHK(t->lane_chain.alloc(ng));
+    HIPCHK(t->tile_chain.alloc(t->tile_group.n - 1));
     HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, n_rec * 4, s));
-    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p, s));
+    HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p,
+                                    t->tile_group.p, (uint32_t)(t->tile_group.n - 1), t->tile_chain.p, s));
     if (getenv("CARMEL_TIMING")) {
       std::vector<uint32_t> ch(t->lane_chain.n);
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
@@ -1118,6 +1120,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   } else {
     t->lane_rec2.release();
     t->lane_chain.release();
+    t->tile_chain.release();
   }
   lap("record streams");
   // ---- slots by arc ----

@@ -86,6 +86,15 @@ __global__ void pack_tile_records_kernel(const LaneGroup* __restrict__ groups, u
   const bool all_paths = __all(path);
   if (lane == 0) chain[gi] = (all_paths ? 1u : 0u) | (pad << 8);
 }
+// tile_chain[t] = every group of tile t is a group of single paths: the tile's records are never looked at (nor fetched)
+__global__ void tile_chain_kernel(const uint32_t* __restrict__ tile_group, const uint32_t* __restrict__ chain, uint32_t n_tiles,
+                                  uint32_t* __restrict__ out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  uint32_t all = 1u;
+  for (uint32_t g = tile_group[t]; g < tile_group[t + 1]; ++g) all &= chain[g];
+  out[t] = all & 1u;
+}
 // one group: records, weights / posteriors in the lane's columns of LDS rows (recl, rows), values in its column `col`: the
 // arithmetic of sweep_lane_kernel, operation for operation (an "easy" row is Lse's own result for a single term)
 struct TileLane {  // a lane's lattice: states, ln(pair weight), corpus pair (requested a group ahead of its sweep)
@@ -428,12 +437,12 @@ __device__ __forceinline__ LaneGroup ts_uniform(const LaneGroup& v) {
   return g;
 }
 struct TileWalk {
-  uint32_t tile, ni, g0, g1;  // (g0, g1, i0, i1: as loaded until ts_uniform)
+  uint32_t tile, ni, g0, g1, chain;  // (g0, g1, chain, i0, i1: as loaded until ts_uniform)
   uint64_t i0, i1;
   bool ok;
 };
-__device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const uint32_t* __restrict__ tile_group, uint32_t vidx, bool ok,
-                                                 uint32_t z) {
+__device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const LaneArgs& A, const uint32_t* __restrict__ tile_group, uint32_t vidx,
+                                                 bool ok, uint32_t z) {
   TileWalk w;
   const uint32_t tloc = xcd_chunked(vidx, T.tile_count);
   w.ok = ok && tloc < T.tile_count && vidx / 8 < (T.tile_count + 7) / 8;
@@ -442,6 +451,7 @@ __device__ __forceinline__ TileWalk tile_walk_at(const TransArgs& T, const uint3
   w.i1 = T.tile_base[w.tile + 1 + z];
   w.g0 = tile_group[w.tile + z];
   w.g1 = tile_group[w.tile + 1 + z];
+  w.chain = A.tile_chain[w.tile + z];
   w.ni = 0;
   return w;
 }
@@ -454,6 +464,7 @@ __device__ __forceinline__ TileWalk ts_uniform(const TileWalk& v) {
   w.ni = (uint32_t)(w.i1 - w.i0);
   w.g0 = ts_sc(v.g0);
   w.g1 = ts_sc(v.g1);
+  w.chain = ts_sc(v.chain);
   return w;
 }
 template <bool SCAT>
@@ -466,11 +477,11 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t vidx = blockIdx.x;
   const uint32_t z = ts_zero();
-  TileWalk cur = tile_walk_at(T, tile_group, vidx, true, z);
+  TileWalk cur = tile_walk_at(T, A, tile_group, vidx, true, z);
   if (!cur.ok) return;
   cur = ts_uniform(cur);
-  TileWalk nxt = ts_uniform(tile_walk_at(T, tile_group, vidx + gridDim.x, true, z));
-  TileWalk nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);  // (as loaded)
+  TileWalk nxt = ts_uniform(tile_walk_at(T, A, tile_group, vidx + gridDim.x, true, z));
+  TileWalk nn_raw = tile_walk_at(T, A, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);  // (as loaded)
   // Both kinds of wavefront meet at the same four barriers per tile: (a) the tile is placed, (b) it is swept, (b') its posteriors
   // are exponentiated, (c) it is read out.
   if (wv >= (uint32_t)NW) {
@@ -541,7 +552,7 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       vidx += gridDim.x;
       cur = nxt;
       nxt = ts_uniform(nn_raw);
-      nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
+      nn_raw = tile_walk_at(T, A, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
     }
   } else {
     // ================= sweepers =================
@@ -554,12 +565,14 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       g = ts_uniform(A.groups[gk + z]);
       L = tile_lane(A, gk, lane);
       chain = ts_sc(A.chain[gk + z]);
-      ts_u32x4 rr[KR];  // the first tile's records as they are (the stream covers whole tiles)
+      if (!cur.chain) {  // the first tile's records as they are (the stream covers whole tiles); a tile of single paths needs none
+        ts_u32x4 rr[KR];
 #pragma unroll
-      for (int k = 0; k < KR; ++k)
-        rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)cur.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
+        for (int k = 0; k < KR; ++k)
+          rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)cur.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
 #pragma unroll
-      for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
+        for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
+      }
     }
     for (;;) {
       unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -594,18 +607,23 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
         if (active) A.pair_logprob[pair] = lp;  // (after the waits for the next group's requests: see tile_group_sweep)
       }
       if (A.trace && lane == 0) A.trace[(size_t)cur.tile * 16 + 8 + wv] = __builtin_readcyclecounter() - t1;  // this wavefront's sweeps
-      // the next tile's records: on their way while this tile's posteriors leave
+      // the next tile's records (unless it is all single paths): on their way while this tile's posteriors leave
+      const bool recs_n = nxt.ok && !nxt.chain;
       ts_u32x4 rr[KR];
+      if (recs_n) {
 #pragma unroll
-      for (int k = 0; k < KR; ++k)
-        rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)nxt.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
+        for (int k = 0; k < KR; ++k)
+          rr[k] = *(const ts_u32x4*)(A.rec2 + (uint64_t)nxt.tile * TILE_SWEEP_TILE + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4);
+      }
       __syncthreads();  // (b)
       if (A.trace) t2 = __builtin_readcyclecounter();
       tile_exp_in_place(lds);
       __syncthreads();  // (b')
       // (the movers read the posteriors out; nobody needs this tile's records any more)
+      if (recs_n) {
 #pragma unroll
-      for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
+        for (int k = 0; k < KR; ++k) *(ts_u32x4*)(recs + (threadIdx.x + k * (TILE_SWEEP_THREADS - NM)) * 4) = rr[k];
+      }
       if (A.trace && threadIdx.x == 0) {  // experiment (CARMEL_HIP_LANE_TRACE): cycles per phase, as the first sweeping wavefront sees them
         unsigned long long* o = A.trace + (size_t)cur.tile * 16;
         o[0] = t0;
@@ -620,7 +638,7 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       vidx += gridDim.x;
       cur = nxt;
       nxt = ts_uniform(nn_raw);
-      nn_raw = tile_walk_at(T, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
+      nn_raw = tile_walk_at(T, A, tile_group, vidx + 2 * gridDim.x, nxt.ok, z);
       g = ts_uniform(g_n);
       L = L_n;
       chain = ts_sc(chain_n);
@@ -631,7 +649,7 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
 hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint32_t* tile_group, uint32_t tile_first, uint32_t tile_count,
                              hipStream_t stream) {
   if (!T0.n_buckets || !tile_count) return hipSuccess;
-  if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2 || !A.chain) return hipErrorInvalidValue;
+  if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2 || !A.chain || !A.tile_chain) return hipErrorInvalidValue;
   static bool attr = false;
   const int lds = (int)TILE_SWEEP_LDS;
   if (!attr) {
@@ -661,10 +679,12 @@ hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint3
   return hipGetLastError();
 }
 hipError_t launch_pack_tile_records(const LaneGroup* groups, uint32_t n_groups, const uint32_t* lane_nstates, const uint32_t* fwdx,
-                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, hipStream_t stream) {
+                                    const uint32_t* bwd, uint32_t* out, uint32_t* chain, const uint32_t* tile_group, uint32_t n_tiles,
+                                    uint32_t* tile_chain, hipStream_t stream) {
   if (n_groups)
     hipLaunchKernelGGL(pack_tile_records_kernel, dim3((n_groups + 3) / 4), dim3(256), 0, stream, groups, n_groups, lane_nstates, fwdx, bwd, out,
                        chain);
+  if (n_tiles) hipLaunchKernelGGL(tile_chain_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, tile_group, chain, n_tiles, tile_chain);
   return hipGetLastError();
 }
 }  // namespace carmel_hip
