@@ -78,8 +78,9 @@ def test_committed_profiles_agree():
             total += float(r["AverageNs"]) * 1e-6
     assert 0.0 <= bench["kernel_ms"] - total < 0.10 * total  # (what the events see beyond the kernels: three launches' gaps, ~25 us)
     assert bench["roofline"]["frac"] == bench["roofline"]["achieved"] / bench["roofline"]["peak"]
-    # (with the tile sweep the measured traffic IS the model's figure: 1.45 GB against 1.455; it was 2.26 GB with five kernels)
-    assert 0.9 < bench["roofline"]["traffic"] / bench["roofline"]["algorithmic_bytes_per_launch"] < 1.2
+    # (with the tile sweep the measured traffic is BELOW the model's figure -- 1.33 GB against 1.455: the model's 48 B per arc
+    # count a weight and a posterior array in HBM that the E-step no longer has; it was 2.26 GB with five kernels)
+    assert 0.8 < bench["roofline"]["traffic"] / bench["roofline"]["algorithmic_bytes_per_launch"] < 1.2
     line = json.load(open(os.path.join(ROOT, "profiles", "r4_bench_line.json")))
     assert len(json.dumps(line)) < 2000 and set(line["secondary"]) == {"c4a", "amb", "c2", "long", "c3", "c5", "crp"}
     assert line["value"] == float("%.4g" % bench["value"]) and line["secondary"]["c5"]["exact_ms"] < 1000
