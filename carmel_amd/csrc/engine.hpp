@@ -34,7 +34,9 @@ struct DevBuf {
     release();
     n = count;
     if (!count) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T));
+    // (128 KB of slack behind every array: tile_sweep_kernel requests a tile's stretch of X / t_pos / t_src as whole rounds of
+    // loads without clamping the last tile's to its items -- what lies behind them is read and ignored, not faulted on)
+    return hipMalloc((void**)&p, count * sizeof(T) + 131072);
   }
   hipError_t upload(const std::vector<T>& v, hipStream_t s) {
     hipError_t e = alloc(v.size());

@@ -113,8 +113,8 @@ __device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, uint32_t gi, co
 }
 // (returns ln p(pair): the caller stores it -- a store inside the sweep would sit in the wavefront's in-order queue of vector
 // memory operations in front of whatever the wavefront waits for next)
-__device__ __forceinline__ double tile_group_sweep(const LaneArgs& A, const LaneGroup& g, const TileLane& L, const int lane, double* col,
-                                                   double* rows, const uint32_t* recl) {
+__device__ __forceinline__ double tile_group_sweep(const LaneGroup& g, const TileLane& L, const int lane, double* col, double* rows,
+                                                   const uint32_t* recl) {
   constexpr int U = (int)LANE_CHUNK;
   const bool active = (uint32_t)lane < g.n_lanes;
   const uint32_t S = active ? L.S : 0u;
@@ -386,17 +386,25 @@ template <bool SCAT>
 __device__ __forceinline__ void tile_request(const TransArgs& T, const LaneArgs& A, uint32_t tile, uint64_t i0, uint32_t ni, uint32_t m,
                                              TileIn& in) {
   constexpr int NM = TILE_SWEEP_MOVERS, KT = (int)(TILE_SWEEP_TILE / NM);
-  const uint32_t last = ni ? ni - 1 : 0u;  // every load is unconditional: items past the tile's re-read its last one
-  if (!ni) i0 = 0;                         // (a tile of lattices without an arc has no item: any item will do)
-  uint32_t src[KT];
+  // every load is unconditional and unclamped: a mover issues ~100 of them while its tile is swept, and at a lone wavefront's
+  // issue rate the address arithmetic of a clamp per load was what the sweepers ended up waiting for.  Items past the tile's
+  // are the next tile's (or the slack behind the arrays, DevBuf::alloc): read and ignored.
+  const uint16_t* __restrict__ tp = T.t_pos + i0 + m;
 #pragma unroll
-  for (int k = 0; k < KT; ++k) {
-    const uint32_t i = min(m + k * NM, last);
-    if (!SCAT) src[k] = T.t_src[i0 + i];
-    in.pos[k] = T.t_pos[i0 + i];
+  for (int k = 0; k < KT; ++k) in.pos[k] = tp[k * NM];
+  if (SCAT) {
+    const double* __restrict__ xp = T.x + i0 + m;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) in.v[k] = xp[k * NM];
+  } else {
+    const uint32_t last = ni ? ni - 1 : 0u;  // (a gather's index has to be a real one)
+    const uint32_t* __restrict__ sp = T.t_src + (ni ? i0 : 0);
+    uint32_t src[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) src[k] = sp[min(m + k * NM, last)];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) in.v[k] = T.x[src[k]];
   }
-#pragma unroll
-  for (int k = 0; k < KT; ++k) in.v[k] = T.x[SCAT ? i0 + min(m + k * NM, last) : (uint64_t)src[k]];
 }
 // the sweeps leave an arc's LOG posterior at its position; the exponentials are the whole workgroup's (every position of the
 // tile, padding included: sixteen independent ones a thread)
@@ -534,8 +542,9 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
       uint32_t dst[KT];
       __builtin_amdgcn_sched_barrier(0);  // (not before the sweep: its registers)
       if (SCAT) {
+        const uint32_t* __restrict__ sp = T.t_src + cur.i0 + m;  // (unclamped, as the tile's requests)
 #pragma unroll
-        for (int k = 0; k < KT; ++k) dst[k] = T.t_src[(cur.ni ? cur.i0 : 0) + min(m + k * NM, cur.ni ? cur.ni - 1 : 0u)];
+        for (int k = 0; k < KT; ++k) dst[k] = sp[k * NM];
       }
       __syncthreads();  // (b)
       tile_exp_in_place(lds);
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
           if (chain & 1u)
             lp = tile_chain_sweep(g, L, chain >> 8, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off);
           else
-            lp = tile_group_sweep(A, g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
+            lp = tile_group_sweep(g, L, lane, alpha + (size_t)g.spill_row * 64 + lane, lds + off, recs + off);
         }
         const bool active = !movers && (uint32_t)lane < g.n_lanes;
         const uint32_t pair = L.pair;
