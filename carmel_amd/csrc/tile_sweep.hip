@@ -13,17 +13,18 @@ namespace carmel_hip {
 // (LatticeSet::tile_sweep.)  Where every lattice of the corpus is a plain lane lattice of at most TILE_SWEEP_ROWS arcs, the lane
 // groups are laid out so that none straddles a tile of TILE_SWEEP_TILE positions, and the three middle kernels of the E-step
 // become one: the workgroup of a tile places the tile's weights (its stretch of X) in LDS at their lane positions -- what
-// trans_w_tile writes to wcache --, its wavefronts sweep the tile's groups out of LDS (the posterior of an arc replaces its
-// weight), and the tile's items leave for XC as trans_c_tile sends them.  Per lattice arc the E-step no longer writes and
-// re-reads wcache (16 B + the sweep's two reads of it) nor post (16 B): what is left between the two bucket passes is X in, one
-// packed record per position, XC out.  LDS of a tile: its positions' weights / posteriors (8 B), their records (4 B), and
-// the forward / backward values of its groups (LaneGroup::spill_row = a group's first row of 64); the run tables of the
-// scattering store are staged over the records once the sweeps are done.
-// A wavefront that sweeps out of LDS has nobody to hide behind (a tile has two to fifteen groups, a CU one tile): what it
-// costs is the length of its dependent chain.  So the topology is in LDS with the weights (no memory round trip inside the
-// sweep), and what is static about a row is decided when the records are packed (pack_tile_records_kernel): whether the
-// arc's other end is the state just finished (its value is in a register: no column read) and whether the arc is its state's
-// only one (the state's value is one addition: no log-sum-exp) -- a chain lattice's sweep is an add and a store per row.
+// trans_w_tile writes to wcache --, its wavefronts sweep the tile's groups out of LDS (the log posterior of an arc replaces
+// its weight; the whole workgroup exponentiates the tile in place afterwards), and the tile's items leave for XC where
+// trans_c_tile sends them.  Per lattice arc the E-step no longer writes and re-reads wcache (16 B + the sweep's two reads of
+// it) nor post (16 B): what is left between the two bucket passes is X in, the position table, the destinations, XC out --
+// and one packed record per position for the tiles that hold a lattice that is not a single path.  LDS of a tile: its
+// positions' weights / posteriors (8 B), their records (4 B), and the forward / backward values of its groups
+// (LaneGroup::spill_row = a group's first row of 64).
+// A wavefront that sweeps out of LDS has nobody to hide behind (a tile has two to sixteen groups, a CU one tile): what it
+// costs is what it issues.  So the topology is in LDS with the weights (no memory round trip inside a sweep), what is static
+// about a row is decided when the records are packed (pack_tile_records_kernel): whether the arc's other end is the state
+// just finished (its value is in a register: no column read) and whether the arc is its state's only one (the state's
+// value is one addition: no log-sum-exp); and a group of single paths is swept without records at all (tile_chain_sweep).
 #define TS_SRC(x) ((x) & 0xffu)
 #define TS_POS(x) (((x) >> 8) & 63u)
 #define TS_FV 0x4000u
@@ -35,8 +36,8 @@ namespace carmel_hip {
 #define TS_FEASY 0x8000000u    // forward: the only in-arc of its state (or padding)
 #define TS_BCHAIN 0x10000000u  // backward: the destination is the state finished last (or padding)
 #define TS_BEASY 0x20000000u   // backward: the only out-arc of its state (or padding)
-// one thread per lane of a group walks the lane's rows: the two records of a row in one word + the static properties above
-// chain[gi] = every lattice of the group is a single path (states 0 .. len in a row: forward row k is the arc k -> k + 1, whose
+// one thread per lane of a group walks the lane's rows: the two records of a row in one word + the static properties above;
+// chain[gi] bit 0 = every lattice of the group is a single path (states 0 .. len in a row: forward row k is the arc k -> k + 1, whose
 // backward row is maxlen - 1 - k): tile_chain_sweep needs no records at all
 __global__ void pack_tile_records_kernel(const LaneGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ lane_nstates,
                                          const uint32_t* __restrict__ fwdx, const uint32_t* __restrict__ bwd, uint32_t* __restrict__ out,
@@ -95,8 +96,6 @@ __global__ void tile_chain_kernel(const uint32_t* __restrict__ tile_group, const
   for (uint32_t g = tile_group[t]; g < tile_group[t + 1]; ++g) all &= chain[g];
   out[t] = all & 1u;
 }
-// one group: records, weights / posteriors in the lane's columns of LDS rows (recl, rows), values in its column `col`: the
-// arithmetic of sweep_lane_kernel, operation for operation (an "easy" row is Lse's own result for a single term)
 struct TileLane {  // a lane's lattice: states, ln(pair weight), corpus pair (requested a group ahead of its sweep)
   uint32_t S, pair;
   double lwt;
@@ -111,8 +110,10 @@ __device__ __forceinline__ TileLane tile_lane(const LaneArgs& A, uint32_t gi, co
   L.pair = A.lane_pair[k];
   return L;
 }
-// (returns ln p(pair): the caller stores it -- a store inside the sweep would sit in the wavefront's in-order queue of vector
-// memory operations in front of whatever the wavefront waits for next)
+// one group: records, weights / posteriors in the lane's columns of LDS rows (recl, rows), values in its column `col`: the
+// arithmetic of sweep_lane_kernel, operation for operation (an "easy" row is Lse's own result for a single term).
+// Returns ln p(pair): the caller stores it -- a store inside the sweep would sit in the wavefront's in-order queue of vector
+// memory operations in front of whatever the wavefront waits for next.
 __device__ __forceinline__ double tile_group_sweep(const LaneGroup& g, const TileLane& L, const int lane, double* col, double* rows,
                                                    const uint32_t* recl) {
   constexpr int U = (int)LANE_CHUNK;
@@ -369,11 +370,12 @@ __device__ __forceinline__ double tile_chain_sweep(const LaneGroup& g, const Til
   return lp;
 }
 // The kernel is persistent and its wavefronts are specialised.  A workgroup per CU walks its share of the tiles; half of its
-// wavefronts SWEEP (a group each at a time), the other half MOVE: while tile t is swept they request tile t + 1 (its stretch
-// of X, its position table, its records) into their registers and tile t's destinations, when the sweeps are done they send
-// tile t's posteriors out (exp of the log posterior the sweep left at the arc's position) and place tile t + 1 in LDS.  The
-// counter of a wavefront's outstanding loads is in order, so a sweeping wavefront that also held the next tile's requests
-// would wait for all of them at its first own load; a moving wavefront has nothing else to wait for.
+// wavefronts SWEEP (a group each at a time; they also fetch the next tile's records, when it needs any, once their sweeps
+// are done), the other half MOVE: while tile t is swept they request tile t + 1 (its stretch of X, its position table)
+// into their registers, sweep a group of single paths themselves, request tile t's destinations; when the sweeps are done
+// and the tile is exponentiated they send its posteriors out and place tile t + 1 in LDS.  The counter of a wavefront's
+// outstanding loads is in order, so a sweeping wavefront that also held the next tile's requests would wait for all of
+// them at its first own load; a moving wavefront has nothing else to wait for.
 #define TILE_SWEEP_THREADS 512
 #define TILE_SWEEP_MOVERS 256
 typedef uint32_t ts_u32x4 __attribute__((ext_vector_type(4)));
