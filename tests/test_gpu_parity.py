@@ -450,6 +450,34 @@ def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
         np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
 
 
+def test_tile_sweep_with_lattices_without_an_arc(oracle):
+    """pairs of two empty strings under a model whose start state is final: lattices of one state and no arc (ln p = 0, no
+    counts).  Enough of them fill tiles of the tile-sweep layout that hold no item at all; beside them short paths and
+    two-way ambiguities through the same state."""
+    rng = np.random.default_rng(7)
+    # one state, start = final; symbols: 0 = epsilon, inputs 1..3, outputs 1..2 (input 3 may write either output)
+    isym = np.array([1, 2, 3, 3], np.uint32)
+    osym = np.array([1, 2, 1, 2], np.uint32)
+    w = Wfst(1, 0, np.zeros(4, np.uint32), np.zeros(4, np.uint32), isym, osym, np.log([0.4, 0.3, 0.2, 0.1]))
+    pairs = [([], [])] * 2500
+    for _ in range(3000):
+        n = int(rng.integers(1, 9))
+        arcs = rng.integers(0, 4, n)
+        pairs.append((isym[arcs].tolist(), osym[arcs].tolist()))
+    order = rng.permutation(len(pairs))
+    c = Corpus.from_lists([pairs[i] for i in order], weights=rng.uniform(0.5, 2.0, len(pairs)))
+    fb = _fb(w, c)
+    assert fb.tile_sweep_tiles > 0
+    lp, _ = fb.estimate(per_pair=True)
+    _, _, r = oracle_estep(oracle, w, c)
+    assert r["has_deriv"].all() and np.array_equal(r["has_deriv"], fb.has_deriv.astype(bool))
+    empty = np.array([len(pairs[i][0]) == 0 for i in order])
+    assert (fb.pair_logprob[empty] == 0.0).all()
+    np.testing.assert_allclose(fb.pair_logprob, r["pair_logprob"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
+    fb.close()
+
+
 def _cascade_from_golden(oracle, golden_dir, names, corpus_name):
     texts = [open(os.path.join(golden_dir, n)).read() for n in names]
     oc = oracle.OracleCascade(texts)
