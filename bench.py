@@ -713,6 +713,37 @@ def _r4(x):
         return x
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without torch.distributed.run: one child process per rank with the launcher's environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), rank 0's stdout passed through; returns the exit code.
+    A rank that fails ends the others (they would wait in a collective for ever)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            c = p.poll()
+            if c is None:
+                continue
+            alive.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                for q in alive:  # exact PIDs we started
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -743,6 +774,10 @@ def main():
     if args.steps is None:
         args.steps = 1000 if args.config == "c5" else 20
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves.  Nothing in this process has touched
+        # a GPU yet (no HIP call, torch not imported), and the ranks are CHILD processes -- never an exec of this one.
+        sys.exit(_self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -753,8 +788,6 @@ def main():
         out = {"c3": run_c3, "c5": run_c5, "amb": run_amb}[args.config](args, args.steps, args.warmup, local_rank, rank)
     else:
         if world != args.gpus:
-            if world == 1 and args.gpus > 1:
-                sys.exit("bench.py --gpus %d must be launched through torch.distributed.run (one rank per GPU)" % args.gpus)
             args.gpus = world
         import torch
         import torch.distributed as dist

@@ -207,6 +207,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   opt.threads = host_threads;
   if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
   if (const char* e = getenv("CARMEL_HIP_TILE_SWEEP")) opt.tile_sweep = atoi(e) != 0;  // A/B: 0 = the five-kernel E-step's layout
+  if (const char* e = getenv("CARMEL_HIP_LANE_FUSED")) opt.lane_fused = atoi(e) != 0;  // A/B: 0 = the 16384-position tiles for lane corpora
+  if (getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0) opt.lane_fused = false;  // (the gather formulation has no tiles)
+  if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));  // experiment: pieces per lane class
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
   if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
@@ -321,7 +324,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       size_t n1 = 0;
-      for (uint32_t c : ch) n1 += c;
+      for (uint32_t c : ch) n1 += c & 1u;  // (bit 0; the padding field sits above it)
       fprintf(stderr, "timing: tile sweep: %zu tiles, %zu groups, %zu of them single paths\n", L.tile_group.size() - 1, ch.size(), n1);
     }
   } else {
@@ -330,7 +333,12 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     t->tile_chain.release();
   }
   t->lane_records = L.wave_slot_base + L.wave_bwd.size();  // first bundle slot: [lane records | wave records | bundle arcs]
-  HIPCHK(t->post.alloc(L.n_post));
+  // (the fused-lane layout's sweep hands its posteriors to the count pass itself: `post` is allocated on first use by the
+  // A/B switch's three kernels, ensure_post)
+  if (L.lane_fused)
+    t->post.release();
+  else
+    HIPCHK(t->post.alloc(L.n_post));
   HIPCHK(t->wcache.alloc(t->lane_records));
   if (!L.waves.empty() && L.t_buckets.empty())
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "lattice set too large for the blocked transposition (2^32 items) with one-per-wavefront lattices");
@@ -819,6 +827,7 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
     // A/B switch (bit-identical results).
     const char* e = getenv("CARMEL_HIP_TRANS_SCATTER");
     T.scatter = e ? (uint32_t)atoi(e) : (t->use_runs ? 3u : 0u);
+    if (t->lat.lane_fused) T.scatter &= ~2u;  // the sweep writes XC in tile-major item order; the bucket pass gathers
   }
   T.x = t->t_x.p;
   T.xc = t->t_xc.p;
@@ -831,10 +840,12 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
   T.n_buckets = (uint32_t)t->t_buckets.n;
   T.n_tiles = t->t_tile_base.n ? (uint32_t)(t->t_tile_base.n - 1) : 0u;
   T.tile = t->lat.tile;
+  T.bucket = t->lat.bucket;
   T.tile_first = T.tile_count = 0;
   T.bucket_first = 0;
   T.bucket_count = T.n_buckets;
   T.n_wtiles = 0;
+  T.slack_bytes = (uint32_t)DEVBUF_SLACK;  // x, xc, t_pos, t_src are DevBufs
 }
 
 // Enqueues one E-step on the trainer's stream(s).  timed: bracket it with ev0 / ev1 (not inside a graph capture).
@@ -897,6 +908,10 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.pair_logprob = t->pair_logprob.p;
   LA.spill = t->lane_spill.p;
   LA.first_group = 0;
+  LA.lds_rows = 0;
+  LA.xc_tile_base = nullptr;
+  LA.xc_t_pos = nullptr;
+  LA.xc = nullptr;
   LA.trace = nullptr;
   static const char* trace_path = getenv("CARMEL_HIP_LANE_TRACE");  // experiment: per-wave cycle stamps of the last E-step
   static DevBuf<unsigned long long> trace_buf;
@@ -923,6 +938,19 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   TransArgs T;
   trans_args(t, T);
   LA.pre_weights = t->use_transpose ? 1u : 0u;
+  // fused-lane layout: the lane sweep's backward pass sends a tile's posteriors to XC itself (sweep_lane_kernel<.., XC>);
+  // CARMEL_HIP_LANE_FUSED_KERNEL=0: sweep -> post -> trans_c_tile on the same layout (the same bits in XC)
+  const bool lane_fused = t->use_transpose && t->lat.lane_fused &&
+                          !(getenv("CARMEL_HIP_LANE_FUSED_KERNEL") && atoi(getenv("CARMEL_HIP_LANE_FUSED_KERNEL")) == 0);
+  if (lane_fused) {
+    LA.xc_tile_base = T.tile_base;
+    LA.xc_t_pos = T.t_pos;
+    LA.xc = T.xc;
+  } else if (t->lat.lane_fused && !t->post.n && t->lat.n_post) {
+    HIPCHK(t->post.alloc(t->lat.n_post));
+    T.post = LA.post = t->post.p;
+    T.n_post = t->post.n;
+  }
   ExchangePlan* const xp = (t->xplan && exchange_is_sharded(t->xplan) && t->use_transpose) ? t->xplan : nullptr;
   if (timed) HIPCHK(hipEventRecord(t->ev0, s));
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
@@ -931,6 +959,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   const bool tile_kernel_off = getenv("CARMEL_HIP_TILE_SWEEP_KERNEL") && atoi(getenv("CARMEL_HIP_TILE_SWEEP_KERNEL")) == 0;
   const bool tile_sweep = t->use_transpose && t->lat.tile_sweep && t->tile_group.n && !tile_kernel_off &&
                           ((T.scatter & 3u) == 0u || ((T.scatter & 3u) == 3u && T.use_runs));
+  bool tile_sweep_done = false;
   const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty();
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
@@ -959,8 +988,8 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
       if (!used[k % NS]) HIPCHK(hipStreamWaitEvent(cs, t->ev_w, 0));
       used[k % NS] = true;
       HIPCHK(launch_trans_w_tiles(T, lc.tile_first, lc.tile_count, cs));
-      HIPCHK(launch_lane_sweep(LA, lc, cs));
-      HIPCHK(launch_trans_c_tiles(T, lc.tile_first, lc.tile_count, cs));
+      HIPCHK(launch_lane_sweep(LA, lc, cs, lane_fused));
+      if (!lane_fused) HIPCHK(launch_trans_c_tiles(T, lc.tile_first, lc.tile_count, cs));
       ++k;
     }
     for (int q = 0; q < NS; ++q)
@@ -968,9 +997,12 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
         HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
         HIPCHK(hipStreamWaitEvent(s, t->cev[q], 0));
       }
-  } else if (tile_sweep) {
-    HIPCHK(launch_tile_sweep(T, LA, t->tile_group.p, 0, lane_tiles, s));
+  } else if (tile_sweep && launch_tile_sweep(T, LA, t->tile_group.p, 0, lane_tiles, s) == hipSuccess) {
+    // (a refused launch -- the device would not take the kernel's LDS attribute -- falls through to the three kernels, which
+    // work on the tile-sweep layout too: tile_sweep_done below stays false)
+    tile_sweep_done = true;
   } else {
+    if (tile_sweep) (void)hipGetLastError();
     if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
     // the one-per-wavefront lattices: every class is one launch of single-wave workgroups with its own LDS size -- side by
     // side on the chunk streams (a class alone rarely fills the chip), the lane waves beside them on the main stream
@@ -986,7 +1018,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
         HIPCHK(launch_wave_sweep(WA, wc, cs));
         ++k;
       }
-      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s, lane_fused));
       for (int q = 0; q < NS; ++q)
         if (used[q]) {
           HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
@@ -994,7 +1026,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
         }
     } else {
       for (auto& wc : t->lat.wave_classes) HIPCHK(launch_wave_sweep(WA, wc, s));
-      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s));
+      for (auto& lc : t->lat.lane_classes) HIPCHK(launch_lane_sweep(LA, lc, s, lane_fused));
     }
   }
   if (bundles_beside)
@@ -1017,7 +1049,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   HIPCHK(hipEventRecord(t->ev_join, t->side));
   if (t->use_transpose) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
-    const uint32_t first = (side_by_side || tile_sweep) ? lane_tiles : 0u;
+    const uint32_t first = (side_by_side || tile_sweep_done || lane_fused) ? lane_tiles : 0u;
     HIPCHK(launch_trans_c_tiles(T, first, T.n_tiles > first ? T.n_tiles - first : 0u, s));
     if (xp) {  // the counts leave arc range by arc range, each into its reduce-scatter while the next is being summed
       int rc = exchange_counts_out(t, xp, T);
@@ -1085,6 +1117,10 @@ int carmel_hip_set_matrix_fb(carmel_hip_trainer* t, int on) {
 int carmel_hip_lattice_tile_sweep(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices || t->unrolled || !t->lat.tile_sweep || !t->tile_group.n) return 0;
   return (int)(t->tile_group.n - 1);
+}
+int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t) {
+  if (!t || !t->have_lattices || t->unrolled || !t->use_transpose || !t->lat.lane_fused) return 0;
+  return (int)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
 }
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;

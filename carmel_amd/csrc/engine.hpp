@@ -20,6 +20,11 @@ using namespace carmel_hip;
       return fail(CARMEL_HIP_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_));                        \
   } while (0)
 
+// Every DevBuf is over-allocated by this many bytes: tile_sweep_kernel (and the fused lane sweep) request a tile's stretch of
+// X / t_pos / t_src as whole rounds of loads without clamping the last tile's to its items -- what lies behind them is read
+// and ignored, not faulted on.  trans_args() hands the figure to the launchers (TransArgs::slack_bytes), which refuse a
+// buffer set that does not promise it.
+static const size_t DEVBUF_SLACK = 131072;
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -34,9 +39,7 @@ struct DevBuf {
     release();
     n = count;
     if (!count) return hipSuccess;
-    // (128 KB of slack behind every array: tile_sweep_kernel requests a tile's stretch of X / t_pos / t_src as whole rounds of
-    // loads without clamping the last tile's to its items -- what lies behind them is read and ignored, not faulted on)
-    return hipMalloc((void**)&p, count * sizeof(T) + 131072);
+    return hipMalloc((void**)&p, count * sizeof(T) + DEVBUF_SLACK);
   }
   hipError_t upload(const std::vector<T>& v, hipStream_t s) {
     hipError_t e = alloc(v.size());

@@ -273,10 +273,15 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
   const uint64_t so = G.sample_off[b];
   uint32_t* ids = G.sample_ids + so;
   uint32_t own_len = 0, old_n = 0;
+  const uint32_t* own = own_ids;
   if (SNAP) {
     own_len = G.include_self ? 0u : G.sample_len[b];  // (--include-self: no counterfactual subtraction of the own uses)
-    if (own_len > own_cap) own_len = own_cap;  // capacity is sized from the longest path; cannot trigger
-    for (uint32_t k = tid; k < own_len; k += NT) own_ids[k] = ids[k];
+    // the LDS copy holds GIBBS_OWN_CAP ids at most (a cyclic lattice's sample may revisit states: its capacity is
+    // 32 * states * chain); a longer previous sample is read where it lies -- the sweep writes new_ids, not sample_ids
+    if (own_len > own_cap)
+      own = ids;
+    else
+      for (uint32_t k = tid; k < own_len; k += NT) own_ids[k] = ids[k];
     __syncthreads();
   } else {
     // 1. take the previous sample out of the counts (gibbs.hpp:851-852) -- unless --include-self: then it is set aside
@@ -304,7 +309,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
       w = G.init_logw[arc];
     else
       for (uint64_t j = G.chain_off[arc]; j < G.chain_off[arc + 1]; ++j)
-        w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
+        w += log(g_prob<SNAP>(G, G.chain_param[j], own, own_len, wt));
     gw[a] = w;
   }
   for (uint32_t s = tid; s < d.n_states; s += NT) beta[s] = G_NEG_INF;
@@ -326,7 +331,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
             w = G.init_logw[r.y];
           else
             for (uint64_t j = G.chain_off[r.y]; j < G.chain_off[r.y + 1]; ++j)
-              w += log(g_prob<SNAP>(G, G.chain_param[j], own_ids, own_len, wt));
+              w += log(g_prob<SNAP>(G, G.chain_param[j], own, own_len, wt));
           beta[r.x] = g_lwadd(beta[r.x], bs + w);
         }
       }
@@ -446,7 +451,7 @@ __device__ void g_resample_block(const GibbsArgs& G, uint32_t b, uint32_t* own_i
     double cheap = 0.0, cache = 0.0;
     for (uint32_t k = 0; k < n; ++k) {
       const uint32_t p = out_ids[k];
-      cheap += log(g_prob<SNAP>(G, p, own_ids, own_len, wt));
+      cheap += log(g_prob<SNAP>(G, p, own, own_len, wt));
       if (!SNAP) {  // cache model: counts restart from the priors every sweep and grow by one per use
         const uint32_t nn = G.p_norm[p];
         double q = G.p_prior[p];
@@ -505,6 +510,7 @@ __global__ __launch_bounds__(256) void gibbs_sweep_exact_kernel(GibbsArgs G) {
 }
 
 // mode 1: blocks spread over the grid, counterfactual counts from the snapshot
+#define GIBBS_OWN_CAP 8192u
 __global__ __launch_bounds__(64) void gibbs_sweep_parallel_kernel(GibbsArgs G, uint32_t own_cap) {
   extern __shared__ uint32_t own_ids[];
   __shared__ double red[3];
@@ -1264,8 +1270,12 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
         }
       } else {
       uint32_t grid = std::min<uint32_t>(g->n_blocks, 256u * 16u);
-      size_t lds = (size_t)g->max_sample * sizeof(uint32_t);
-      hipLaunchKernelGGL(gibbs_sweep_parallel_kernel, dim3(grid), dim3(64), lds, s, G, g->max_sample);
+      // the previous sample of a block in LDS up to GIBBS_OWN_CAP ids (32 KB: under the default dynamic-LDS limit); longer
+      // ones -- cyclic lattices -- are read from global memory by g_resample_block
+      uint32_t own_cap = std::min<uint32_t>(g->max_sample, GIBBS_OWN_CAP);
+      if (const char* e = getenv("CARMEL_HIP_GIBBS_OWN_CAP")) own_cap = std::min<uint32_t>(own_cap, (uint32_t)std::max(1, atoi(e)));  // test hook
+      size_t lds = (size_t)own_cap * sizeof(uint32_t);
+      hipLaunchKernelGGL(gibbs_sweep_parallel_kernel, dim3(grid), dim3(64), lds, s, G, own_cap);
       }
       // counts of the new samples: start from the priors, add every use
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));

@@ -51,6 +51,7 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   if (lane_states >= 0) opt.lane_states = (uint32_t)lane_states;
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
   if (const char* e = getenv("CARMEL_HIP_TILE_SWEEP")) opt.tile_sweep = atoi(e) != 0;
+  if (const char* e = getenv("CARMEL_HIP_LANE_FUSED")) opt.lane_fused = atoi(e) != 0;
   if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
   // lane_states = 0 asks for the plain inspection form -- every lattice a bundle (with small_pairs = 1: one lattice each),
   // what the front end's --fem-forest export walks -- unless a test forces the one-per-wavefront layout explicitly

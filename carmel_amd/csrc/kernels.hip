@@ -78,10 +78,16 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 // WIN: windowed groups (LaneGroup::window): state s lives at LDS row s mod window; the forward values are also parked in
 // the group's global column (spill) and the backward pass gathers alpha[source] per record from there, two pipeline stages
 // like the forward pass's weight gather (the backward record carries its arc's source state), instead of reading it from LDS.
-template <int R, int W, bool PRE, typename LSE = Lse, bool WIN = false>
-__global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
+// XC (fused-lane layout, LatticeSet::lane_fused: every group starts on a tile of LANE_FUSED_TILE positions = LANE_FUSED_ROWS rows):
+// the backward pass leaves the log posterior of a row in a 16 KB LDS stage instead of writing exp(..) to post[], and after
+// every LANE_FUSED_ROWS rows the wavefront sends the tile's items to XC in tile-major item order -- xc[i0 + i] =
+// exp(stage[t_pos[i0 + i]]) -- which is what trans_c_tile_kernel would read post[] for: `post` is never written, the tile pass
+// of the counts direction never runs, and the count pass finds the same bits in XC.
+template <int R, int W, bool PRE, typename LSE = Lse, bool WIN = false, bool XC = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) void sweep_lane_kernel(LaneArgs A) {
   constexpr int U = (int)LANE_CHUNK;  // a group's row count is a multiple of U (host padding): chunks are never partial
   static_assert(W >= 1 && W < R, "gather lead must be shorter than the record lead");
+  static_assert(!XC || ((int)LANE_FUSED_ROWS % (R * U) == 0), "a tile of the fused layout is whole rounds of the register ring");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const LaneGroup g = A.groups[A.first_group + blockIdx.x];
   const int lane = threadIdx.x;
@@ -175,7 +181,9 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
   {
     if (!PRE || WIN) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's wcache / spill stores before its re-reads
     const uint32_t* __restrict__ b = A.bwd + g.stream_base + lane;
-    double* __restrict__ post = A.post + g.stream_base + lane;
+    double* __restrict__ post = XC ? nullptr : A.post + g.stream_base + lane;
+    double* const stage_tile = lds + (size_t)A.lds_rows * 64;  // XC: LANE_FUSED_TILE doubles behind the value rows
+    double* const stage = stage_tile + lane;
     uint32_t xq[R][U];
     double wq[R][U];
     double aq[WIN ? R : 1][U];  // WIN: alpha[source] of the records in xq
@@ -226,7 +234,11 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
         }                                                                                             \
       }                                                                                               \
     }                                                                                                 \
-    _Pragma("unroll") for (int u = 0; u < U; ++u) post[(size_t)((kb) + u) * 64] = K_EXP(arg[u]);        \
+    if (XC) { /* (the exponentials stay here: they fill the gaps of the recurrence) */                \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) stage[((((kb) + u)) & (LANE_FUSED_ROWS - 1u)) * 64] = K_EXP(arg[u]); \
+    } else {                                                                                          \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) post[(size_t)((kb) + u) * 64] = K_EXP(arg[u]);    \
+    }                                                                                                 \
     _Pragma("unroll") for (int u = 0; u < U; ++u) {                                                   \
       const uint32_t k = (kb) + (uint32_t)(R * U + u);                                                \
       const size_t kk = (size_t)(k < maxlen ? k : lastk) * 64;                                        \
@@ -234,6 +246,43 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
       wq[j][u] = wcache[kk];                                                                          \
     }                                                                                                 \
   }
+    if (XC) {
+      // tile by tile: the tile's position table is requested before its rows are swept (older than every load the steps
+      // wait for), its items leave after them
+      const uint32_t tile0 = (uint32_t)(g.stream_base / LANE_FUSED_TILE);
+      for (uint32_t kt = 0; kt < maxlen; kt += LANE_FUSED_ROWS) {
+        const uint32_t tile = tile0 + kt / LANE_FUSED_ROWS;
+        const uint64_t i0 = A.xc_tile_base[tile];
+        const uint32_t ni = (uint32_t)(A.xc_tile_base[tile + 1] - i0);
+        const uint16_t* __restrict__ tp = A.xc_t_pos + i0 + lane;  // (unclamped: DEVBUF_SLACK lies behind the table)
+        uint32_t pos2[LANE_FUSED_ROWS / 2];  // two positions a register
+#pragma unroll
+        for (int u = 0; u < (int)LANE_FUSED_ROWS; u += 2) pos2[u / 2] = (uint32_t)tp[u * 64] | ((uint32_t)tp[(u + 1) * 64] << 16);
+        {
+          const uint32_t lim = min(kt + LANE_FUSED_ROWS, maxlen);
+          uint32_t k0 = kt;
+#pragma unroll 1
+          for (; k0 + R * U <= lim; k0 += R * U) {  // (a round of the ring at a time, as without XC)
+#pragma unroll
+            for (int j = 0; j < R; ++j) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
+          }
+#pragma unroll
+          for (int j = 0; j < R - 1; ++j)
+            if (k0 + (uint32_t)(j * U) < lim) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
+        }
+        double* __restrict__ out = A.xc + i0 + lane;
+#pragma unroll
+        for (int u0 = 0; u0 < (int)LANE_FUSED_ROWS; u0 += 4) {  // (four at a time: registers)
+          double v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = stage_tile[((u0 + u) & 1) ? pos2[(u0 + u) / 2] >> 16 : pos2[(u0 + u) / 2] & 0xffffu];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if ((uint32_t)((u0 + u) * 64 + lane) < ni) out[(u0 + u) * 64] = v[u];
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     uint32_t k0 = 0;
     for (; k0 + R * U <= maxlen; k0 += R * U) {
 #pragma unroll
@@ -242,6 +291,7 @@ __global__ __launch_bounds__(64) void sweep_lane_kernel(LaneArgs A) {
 #pragma unroll
     for (int j = 0; j < R - 1; ++j)
       if (k0 + (uint32_t)(j * U) < maxlen) LANE_BWD_STEP(j, k0 + (uint32_t)(j * U))
+    }
 #undef LANE_BWD_STEP
 #undef LANE_ASRC
 #undef LANE_W
@@ -1068,10 +1118,10 @@ __device__ __forceinline__ uint32_t run_source(const RunLds& R, uint32_t i) {
 // SC (TransArgs::scatter bit 0): the items leave for their TILE-major place instead (one contiguous run per tile: a
 // scattered write that nobody waits for), and pass 2 reads its tile's items as one sequential stretch -- the dependent
 // round trip "index, then gather" moves from the reading pass, which waits for it, to the writing pass, which does not.
-template <bool SC, bool RL>
+template <bool SC, bool RL, int KB = TRANS_KB>  // KB: rounds of 1024 threads a bucket holds at most (LatticeSet::bucket / 1024)
 __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const RunLds R = run_lds(lds + TRANS_BUCKET);
+  const RunLds R = run_lds(lds + KB * 1024);
   uint32_t bloc = blockIdx.x;
   if (SC) {
     bloc = xcd_chunked(blockIdx.x, T.bucket_count);  // the grid is rounded up to a multiple of 8
@@ -1081,29 +1131,29 @@ __global__ __launch_bounds__(1024) void trans_w_bucket_kernel(TransArgs T) {
   const TransBucket B = T.buckets[bucket];
   // every loop below is a fixed 16 x 1024 sweep with its loads issued as one batch (a bucket / tile holds at most
   // 16384 items): one dependent round trip per phase instead of one per iteration
-  double w[TRANS_KB];
+  double w[KB];
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     w[k] = a < B.n_arcs ? T.logw[B.arc_lo + a] : 0.0;
   }
-  uint16_t ia[TRANS_KB];
-  uint32_t dst[TRANS_KB];
+  uint16_t ia[KB];
+  uint32_t dst[KB];
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     ia[k] = j < B.n_items ? T.b_arc[B.item_base + j] : (uint16_t)0;
     if (SC && !RL) dst[k] = j < B.n_items ? T.b_src[B.item_base + j] : 0u;
   }
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) lds[threadIdx.x + k * 1024] = w[k];
+  for (int k = 0; k < KB; ++k) lds[threadIdx.x + k * 1024] = w[k];
   if (SC && RL) {
     const uint32_t r0 = T.br_off[bucket];
     run_stage(R, T.br_rel + r0, T.br_src + r0, T.br_off[bucket + 1] - r0);
   } else
     __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const uint32_t j = threadIdx.x + k * 1024;
     if (j < B.n_items) {
       if (SC)
@@ -1218,14 +1268,87 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(TRANS_TILE
     }
   }
 }
+// The tile passes for the fused-lane layout (LatticeSet::lane_fused: tiles of LANE_FUSED_TILE = 2048 positions, a lane group
+// starting on each): the same two kernels at an eighth of the size -- 256 threads, 8 items each, 16 KB of LDS, eight workgroups
+// to a CU, so one workgroup's load phase runs under another's store phase.  Per-item indices (a tile has ~230 runs of 9).
+#define TRANS_SMALL_THREADS 256
+#define TRANS_SMALL_K ((int)(LANE_FUSED_TILE / TRANS_SMALL_THREADS))
+template <bool SQ>
+__global__ __launch_bounds__(TRANS_SMALL_THREADS) void trans_w_tile_small_kernel(TransArgs T) {
+  __shared__ double lds[LANE_FUSED_TILE];
+  constexpr int NT = TRANS_SMALL_THREADS, K = TRANS_SMALL_K;
+  const uint32_t tloc = xcd_chunked(blockIdx.x, T.tile_count);  // the grid is rounded up to a multiple of 8
+  if (tloc >= T.tile_count) return;
+  const uint32_t tile = T.tile_first + tloc;
+  const uint64_t p0 = (uint64_t)tile * LANE_FUSED_TILE;
+  if (p0 >= T.n_wcache) return;
+  const uint32_t np = (uint32_t)min((uint64_t)LANE_FUSED_TILE, T.n_wcache - p0);
+  const uint64_t i0 = T.tile_base[tile];
+  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
+  uint32_t src[K];
+  uint16_t pos[K];
+  double v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = threadIdx.x + k * NT;
+    src[k] = (!SQ && i < ni) ? T.t_src[i0 + i] : 0u;
+    pos[k] = i < ni ? T.t_pos[i0 + i] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) lds[threadIdx.x + k * NT] = 0.0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = threadIdx.x + k * NT;
+    if (SQ)
+      v[k] = i < ni ? T.x[i0 + i] : 0.0;
+    else
+      v[k] = T.x[src[k]];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (threadIdx.x + k * NT < ni) lds[pos[k]] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t q = threadIdx.x + k * NT;
+    if (q < np) T.wcache[p0 + q] = lds[q];
+  }
+}
+// (gather form only: the fused-lane layout keeps the counts direction's random access in the bucket pass)
+__global__ __launch_bounds__(TRANS_SMALL_THREADS) void trans_c_tile_small_kernel(TransArgs T) {
+  __shared__ double lds[LANE_FUSED_TILE];
+  constexpr int NT = TRANS_SMALL_THREADS, K = TRANS_SMALL_K;
+  const uint32_t tile = T.tile_first + blockIdx.x;
+  const uint64_t p0 = (uint64_t)tile * LANE_FUSED_TILE;
+  const uint32_t np = p0 < T.n_post ? (uint32_t)min((uint64_t)LANE_FUSED_TILE, T.n_post - p0) : 0u;
+  const uint64_t i0 = T.tile_base[tile];
+  const uint32_t ni = (uint32_t)(T.tile_base[tile + 1] - i0);
+  double v[K];
+  uint16_t pos[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t q = threadIdx.x + k * NT;
+    v[k] = q < np ? T.post[p0 + q] : 0.0;
+    pos[k] = q < ni ? T.t_pos[i0 + q] : (uint16_t)0;
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) lds[threadIdx.x + k * NT] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const uint32_t i = threadIdx.x + k * NT;
+    if (i < ni) T.xc[i0 + i] = lds[pos[k]];
+  }
+}
 // counts, pass 2: one workgroup per arc bucket: its items (runs, one per tile) are placed in LDS in arc-sorted order,
 // then one thread per arc adds up its contiguous range in a fixed order -- no atomics, bit-reproducible.  A bucket
 // that is a piece of a split arc reduces the piece and adds it atomically.
 // SQ: pass 1 scattered (trans_c_tile_kernel<true, ..>): the bucket's items are xc[item_base .. ) in item order.
-template <bool RL, bool SQ>
+template <bool RL, bool SQ, int KB = TRANS_KB>
 __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const RunLds R = run_lds(lds + TRANS_BUCKET);
+  const RunLds R = run_lds(lds + KB * 1024);
   __shared__ double part[16];
   __shared__ uint32_t big[512];
   __shared__ uint32_t n_big;
@@ -1235,25 +1358,25 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   const TransBucket B = T.buckets[bucket];
   // every global load of the workgroup is issued before the first barrier: item indices, the items, and the item
   // ranges of this thread's arcs (the per-arc loop below then runs out of registers and LDS alone)
-  uint16_t r0[TRANS_KB], r1[TRANS_KB];
+  uint16_t r0[KB], r1[KB];
   const bool single = (B.flags & TRANS_SINGLE) != 0;
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     const bool ok = !single && a < B.n_arcs;
     r0[k] = ok ? T.a_off[B.arc_lo + a] : (uint16_t)0;
     r1[k] = (ok && a + 1 < B.n_arcs) ? T.a_off[B.arc_lo + a + 1] : (uint16_t)0;
   }
   {
-    uint32_t src[TRANS_KB];
-    uint16_t rk[TRANS_KB];
-    double v[TRANS_KB];
+    uint32_t src[KB];
+    uint16_t rk[KB];
+    double v[KB];
     if (RL && !SQ) {
       const uint32_t r0 = T.br_off[bucket];
       run_stage(R, T.br_rel + r0, T.br_src + r0, T.br_off[bucket + 1] - r0);
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_KB; ++k) {
+    for (int k = 0; k < KB; ++k) {
       const uint32_t j = threadIdx.x + k * 1024;
       if (SQ)
         src[k] = 0u;
@@ -1264,7 +1387,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
       rk[k] = j < B.n_items ? T.b_rank[B.item_base + j] : (uint16_t)0;
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_KB; ++k) {
+    for (int k = 0; k < KB; ++k) {
       if (SQ) {
         const uint32_t j = threadIdx.x + k * 1024;
         v[k] = j < B.n_items ? T.xc[B.item_base + j] : 0.0;
@@ -1272,7 +1395,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
         v[k] = T.xc[src[k]];
     }
 #pragma unroll
-    for (int k = 0; k < TRANS_KB; ++k)
+    for (int k = 0; k < KB; ++k)
       if (threadIdx.x + k * 1024 < B.n_items) lds[rk[k]] = v[k];
   }
   __syncthreads();
@@ -1299,7 +1422,7 @@ __global__ __launch_bounds__(1024) void trans_c_bucket_kernel(TransArgs T) {
   if (threadIdx.x == 0) n_big = 0;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < TRANS_KB; ++k) {
+  for (int k = 0; k < KB; ++k) {
     const uint32_t a = threadIdx.x + k * 1024;
     if (a >= B.n_arcs) break;
     const uint32_t q0 = r0[k], q1 = a + 1 < B.n_arcs ? (uint32_t)r1[k] : B.n_items;
@@ -1338,18 +1461,29 @@ static inline int grid_for(uint64_t n, int block) {
   return (int)g;
 }
 
-template <int R, int W, bool PRE, bool WIN = false>
+template <int R, int W, bool PRE, bool WIN = false, bool XC = false>
 static hipError_t launch_lane_variant(const LaneArgs& A, unsigned grid, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, PRE, Lse, WIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((sweep_lane_kernel<R, W, PRE, Lse, WIN>), dim3(grid), dim3(64), lds, stream, A);
+    (void)hipFuncSetAttribute((const void*)sweep_lane_kernel<R, W, PRE, Lse, WIN, XC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((sweep_lane_kernel<R, W, PRE, Lse, WIN, XC>), dim3(grid), dim3(64), lds, stream, A);
   return hipGetLastError();
 }
 
-hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc, hipStream_t stream) {
+hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc, hipStream_t stream, bool fused) {
   LaneArgs A = A0;
   A.first_group = lc.first;
+  A.lds_rows = lc.max_states;
   size_t lds = (size_t)lc.max_states * 64 * sizeof(double);
+  if (fused) {
+    // the posteriors leave through a stage of one tile behind the value rows (sweep_lane_kernel<.., XC>)
+    if (!A.pre_weights || !A.xc || !A.xc_tile_base || !A.xc_t_pos) return hipErrorInvalidValue;
+    lds += (size_t)LANE_FUSED_TILE * sizeof(double);
+    if (lc.windowed) {
+      if (!A.spill) return hipErrorInvalidValue;
+      return launch_lane_variant<4, 2, true, true, true>(A, lc.count, lds, stream);
+    }
+    return launch_lane_variant<4, 2, true, false, true>(A, lc.count, lds, stream);
+  }
   // ring depths per form, measured (tagging cascade x400, windowed: <4,2> 495 us, <4,1> 511, <3,1> 534, <3,2> 643; streaming
   // with weights in lattice order: two chunks ahead is enough, and the smaller ring leaves more registers / less code)
   if (lc.windowed) {
@@ -1409,8 +1543,12 @@ hipError_t launch_sweep(const SweepArgs& A0, const LatticeSet::LaunchClass& lc, 
 
 #define TRANS_SET_LDS(K, BYTES) (void)hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES)
 static void trans_lds_attr() {
-  static bool done = false;
-  if (done) return;
+  // per device (hipFuncSetAttribute is): a process that drives a second GPU sets the kernels up there too
+  static unsigned char done_dev[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+  unsigned char& done = done_dev[dev];
+  if (__atomic_load_n(&done, __ATOMIC_ACQUIRE)) return;
   const int lds = (int)(TRANS_TILE > TRANS_BUCKET ? TRANS_TILE : TRANS_BUCKET) * 8;
   const int lds_rl = lds + TRANS_RUN_LDS;
   TRANS_SET_LDS((trans_w_bucket_kernel<false, false>), lds);
@@ -1425,7 +1563,16 @@ static void trans_lds_attr() {
   TRANS_SET_LDS((trans_c_bucket_kernel<false, false>), lds);
   TRANS_SET_LDS((trans_c_bucket_kernel<true, false>), lds_rl);
   TRANS_SET_LDS((trans_c_bucket_kernel<false, true>), lds);
-  done = true;
+  {  // the half-size bucket kernels (their static LDS takes them past the default limit as well)
+    constexpr int KH = TRANS_KB / 2;
+    TRANS_SET_LDS((trans_w_bucket_kernel<false, false, KH>), lds);
+    TRANS_SET_LDS((trans_w_bucket_kernel<true, false, KH>), lds);
+    TRANS_SET_LDS((trans_w_bucket_kernel<true, true, KH>), lds_rl);
+    TRANS_SET_LDS((trans_c_bucket_kernel<false, false, KH>), lds);
+    TRANS_SET_LDS((trans_c_bucket_kernel<true, false, KH>), lds_rl);
+    TRANS_SET_LDS((trans_c_bucket_kernel<false, true, KH>), lds);
+  }
+  __atomic_store_n(&done, (unsigned char)1, __ATOMIC_RELEASE);
 }
 hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint32_t count, hipStream_t stream) {
   trans_lds_attr();
@@ -1434,6 +1581,17 @@ hipError_t launch_trans_w_bucket_range(const TransArgs& T0, uint32_t first, uint
   T.bucket_first = first;
   T.bucket_count = count;
   const dim3 g8((count + 7) / 8 * 8);
+  if (T.bucket == TRANS_BUCKET / 2) {  // half-size buckets (the fused-lane layout): 64 KB of LDS, two workgroups to a CU
+    constexpr int KH = TRANS_KB / 2;
+    if (!(T.scatter & 1u))
+      hipLaunchKernelGGL((trans_w_bucket_kernel<false, false, KH>), dim3(count), dim3(1024), KH * 1024 * 8, stream, T);
+    else if (T.use_runs)
+      hipLaunchKernelGGL((trans_w_bucket_kernel<true, true, KH>), g8, dim3(1024), KH * 1024 * 8 + TRANS_RUN_LDS, stream, T);
+    else
+      hipLaunchKernelGGL((trans_w_bucket_kernel<true, false, KH>), g8, dim3(1024), KH * 1024 * 8, stream, T);
+    return hipGetLastError();
+  }
+  if (T.bucket != TRANS_BUCKET) return hipErrorInvalidValue;
   if (!(T.scatter & 1u))
     hipLaunchKernelGGL((trans_w_bucket_kernel<false, false>), dim3(count), dim3(1024), TRANS_BUCKET * 8, stream, T);
   else if (T.use_runs)
@@ -1450,6 +1608,14 @@ hipError_t launch_trans_w_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   T.tile_first = tile_first;
   T.tile_count = tile_count;
   const dim3 g8((tile_count + 7) / 8 * 8);
+  if (T.tile == LANE_FUSED_TILE) {  // the fused-lane layout's small tiles
+    if (T.scatter & 1u)
+      hipLaunchKernelGGL((trans_w_tile_small_kernel<true>), g8, dim3(TRANS_SMALL_THREADS), 0, stream, T);
+    else
+      hipLaunchKernelGGL((trans_w_tile_small_kernel<false>), g8, dim3(TRANS_SMALL_THREADS), 0, stream, T);
+    return hipGetLastError();
+  }
+  if (T.tile != TRANS_TILE && T.tile != TILE_SWEEP_TILE) return hipErrorInvalidValue;
   if (T.scatter & 1u)
     hipLaunchKernelGGL((trans_w_tile_kernel<false, true>), g8, dim3(1024), TRANS_TILE * 8, stream, T);
   else if (T.use_runs)
@@ -1465,6 +1631,12 @@ hipError_t launch_trans_c_tiles(const TransArgs& T0, uint32_t tile_first, uint32
   T.tile_first = tile_first;
   T.tile_count = tile_count;
   const dim3 g8((tile_count + 7) / 8 * 8);
+  if (T.tile == LANE_FUSED_TILE) {
+    if (T.scatter & 2u) return hipErrorInvalidValue;  // (trans_args keeps the bit off under this layout)
+    hipLaunchKernelGGL(trans_c_tile_small_kernel, dim3(tile_count), dim3(TRANS_SMALL_THREADS), 0, stream, T);
+    return hipGetLastError();
+  }
+  if (T.tile != TRANS_TILE && T.tile != TILE_SWEEP_TILE) return hipErrorInvalidValue;
   if (!(T.scatter & 2u))
     hipLaunchKernelGGL((trans_c_tile_kernel<false, false>), dim3(tile_count), dim3(1024), TRANS_TILE * 8, stream, T);
   else if (T.use_runs)
@@ -1484,6 +1656,17 @@ hipError_t launch_trans_c_bucket_range(const TransArgs& T0, uint32_t first, uint
   T.bucket_first = first;
   T.bucket_count = count;
   const dim3 g8((count + 7) / 8 * 8);
+  if (T.bucket == TRANS_BUCKET / 2) {
+    constexpr int KH = TRANS_KB / 2;
+    if (T.scatter & 2u)
+      hipLaunchKernelGGL((trans_c_bucket_kernel<false, true, KH>), g8, dim3(1024), KH * 1024 * 8, stream, T);
+    else if (T.use_runs)
+      hipLaunchKernelGGL((trans_c_bucket_kernel<true, false, KH>), g8, dim3(1024), KH * 1024 * 8 + TRANS_RUN_LDS, stream, T);
+    else
+      hipLaunchKernelGGL((trans_c_bucket_kernel<false, false, KH>), g8, dim3(1024), KH * 1024 * 8, stream, T);
+    return hipGetLastError();
+  }
+  if (T.bucket != TRANS_BUCKET) return hipErrorInvalidValue;
   if (T.scatter & 2u)
     hipLaunchKernelGGL((trans_c_bucket_kernel<false, true>), g8, dim3(1024), TRANS_BUCKET * 8, stream, T);
   else if (T.use_runs)

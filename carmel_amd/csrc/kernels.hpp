@@ -31,6 +31,12 @@ struct LaneArgs {
   uint32_t first_group;
   uint32_t pre_weights;  // wcache already holds every arc's weight at its backward position (blocked transposition)
   unsigned long long* trace;  // experiment: per-block {t_start, t_mid, t_end, hw id} (CARMEL_HIP_LANE_TRACE)
+  // fused-lane layout (LatticeSet::lane_fused), sweep_lane_kernel<.., XC>: the backward pass stages the posteriors of a tile of
+  // LANE_FUSED_TILE positions in LDS and writes the tile's items out in tile-major order itself (what trans_c_tile does from `post`)
+  uint32_t lds_rows;             // value rows of this launch (LaneClass::max_states): the stage lies behind them
+  const uint64_t* xc_tile_base;  // TransArgs::tile_base
+  const uint16_t* xc_t_pos;      // TransArgs::t_pos
+  double* xc;                    // TransArgs::xc
 };
 
 struct SweepArgs {
@@ -111,8 +117,11 @@ struct TransArgs {
                             // second pass reads them as one sequential stretch (x tile-major / xc bucket-major), instead of
                             // writing sequentially and leaving the gather to the second pass
   uint32_t tile;            // positions per tile (LatticeSet::tile)
+  uint32_t bucket;          // items a bucket holds at most (LatticeSet::bucket: TRANS_BUCKET or half of it)
   uint32_t tile_first, tile_count;  // the tile range of this launch (a chunk of a lane class, or the bundle tiles)
   uint32_t bucket_first, bucket_count;  // the bucket range of this launch of a bucket pass (arc-range chunks of the exchange)
+  uint32_t slack_bytes;     // readable bytes behind x / xc / t_pos / t_src (DEVBUF_SLACK when they are DevBufs, engine.hpp): the
+                            // persistent tile kernels read whole rounds past a tile's last item
 };
 
 #define TRANS_RUN_CAP 4096
@@ -175,7 +184,8 @@ struct MstepArgs {
   const double* tie_alpha;
 };
 
-hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream);
+// fused: the XC form of the backward pass (LaneArgs::xc_* set; the groups lie on LANE_FUSED_TILE boundaries)
+hipError_t launch_lane_sweep(const LaneArgs& A, const LatticeSet::LaneClass& lc, hipStream_t stream, bool fused = false);
 hipError_t launch_sweep(const SweepArgs& A, const LatticeSet::LaunchClass& lc, hipStream_t stream);
 hipError_t launch_wave_sweep(const WaveArgs& A, const LatticeSet::WaveClass& wc, hipStream_t stream);
 // the two passes of either direction as separate launches: the bucket passes cover the whole model, the tile passes a

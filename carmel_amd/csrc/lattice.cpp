@@ -62,7 +62,9 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
   const size_t ng = out.lane_groups.size();
   out.lane_classes.clear();
   out.tile = TRANS_TILE;
+  out.bucket = TRANS_BUCKET;
   out.tile_sweep = false;
+  out.lane_fused = false;
   out.tile_group.clear();
   // tile sweep: plain groups only, each within a tile of positions and of value rows
   bool sweepable = opt.tile_sweep && only_lanes && ng > 0 && opt.lane_chunks <= 1;
@@ -102,6 +104,15 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
     lc.tile_count = (uint32_t)(base / TILE_SWEEP_TILE);
     out.lane_classes.push_back(lc);
     return base;
+  }
+  // fused lanes: small tiles, every group on a tile boundary of its own (LANE_FUSED_TILE, lattice.hpp)
+  const bool fused = opt.lane_fused && only_lanes && ng > 0;
+  const uint64_t TS = fused ? LANE_FUSED_TILE : TRANS_TILE;
+  out.bucket = TRANS_BUCKET;
+  if (fused) {
+    out.tile = LANE_FUSED_TILE;
+    out.lane_fused = true;
+    out.bucket = TRANS_BUCKET / 2;
   }
   // classes: contiguous runs of groups sharing one LDS size (512 B per state per wave)
   std::vector<LatticeSet::LaneClass> classes;
@@ -143,7 +154,7 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
     nchs.push_back((uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(want_chunks, rows * 64 / (16ull * TRANS_TILE))));
     n_pieces += nchs.back();
   }
-  const bool align = n_pieces > 1;
+  const bool align = n_pieces > 1 || fused;
   out.lane_tiles_aligned = align;
   for (size_t ci = 0; ci < classes.size(); ++ci) {
     const auto& lc = classes[ci];
@@ -156,10 +167,11 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
       const uint64_t goal = rows * (k + 1) / nch;
       LatticeSet::LaneClass piece = lc;
       piece.first = g;
-      if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;
-      piece.tile_first = (uint32_t)(base / TRANS_TILE);
+      if (align) base = (base + TS - 1) / TS * TS;
+      piece.tile_first = (uint32_t)(base / TS);
       while (g < lc.first + lc.count && (done < goal || k + 1 == nch)) {
         LaneGroup& G = out.lane_groups[g];
+        if (fused) base = (base + TS - 1) / TS * TS;
         G.stream_base = base;
         base += (uint64_t)G.maxlen * 64;
         done += G.maxlen;
@@ -167,11 +179,11 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
       }
       piece.count = g - piece.first;
       piece.max_states = lc.max_states;  // one LDS size per class keeps the occupancy of its pieces equal
-      piece.tile_count = (uint32_t)((base + TRANS_TILE - 1) / TRANS_TILE) - piece.tile_first;
+      piece.tile_count = (uint32_t)((base + TS - 1) / TS) - piece.tile_first;
       if (piece.count) out.lane_classes.push_back(piece);
     }
   }
-  if (align) base = (base + TRANS_TILE - 1) / TRANS_TILE * TRANS_TILE;  // bundle positions start on a tile too
+  if (align) base = (base + TS - 1) / TS * TS;  // bundle positions start on a tile too
   return base;
 }
 
@@ -1347,6 +1359,7 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
   out.t_buckets.clear();
   out.t_split_arcs.clear();
   if (N >= (1ull << 32) || N == 0) return;  // 32-bit item indices; the engine then keeps the gather path
+  const uint64_t BK = out.bucket;
   {
     uint64_t a = 0;
     while (a < n_arcs) {
@@ -1354,18 +1367,18 @@ void build_transpose(LatticeSet& out, uint64_t n_arcs, int nt) {
       if (c > TRANS_HEAVY) {
         // a hub arc gets buckets of its own (one if it fits, else pieces whose sums are added atomically): its sum
         // is a workgroup-wide reduction instead of one thread's serial loop
-        const bool split = c > TRANS_BUCKET;
+        const bool split = c > BK;
         if (split) out.t_split_arcs.push_back((uint32_t)a);
-        for (uint64_t g = out.arc_off[a]; g < out.arc_off[a + 1]; g += TRANS_BUCKET)
-          out.t_buckets.push_back(TransBucket{g, (uint32_t)std::min<uint64_t>(TRANS_BUCKET, out.arc_off[a + 1] - g),
+        for (uint64_t g = out.arc_off[a]; g < out.arc_off[a + 1]; g += BK)
+          out.t_buckets.push_back(TransBucket{g, (uint32_t)std::min<uint64_t>(BK, out.arc_off[a + 1] - g),
                                               (uint32_t)a, 1u, TRANS_SINGLE | (split ? TRANS_SPLIT : 0u)});
         ++a;
         continue;
       }
       uint64_t e = a, items = 0;
-      while (e < n_arcs && e - a < TRANS_BUCKET) {
+      while (e < n_arcs && e - a < BK) {
         uint64_t ce = out.arc_off[e + 1] - out.arc_off[e];
-        if (ce > TRANS_HEAVY || items + ce > TRANS_BUCKET) break;
+        if (ce > TRANS_HEAVY || items + ce > BK) break;
         items += ce;
         ++e;
       }

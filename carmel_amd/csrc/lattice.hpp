@@ -112,6 +112,15 @@ static const uint32_t TRANS_TILE = TRANS_KT * 1024, TRANS_BUCKET = TRANS_KB * 10
 // Lattices of at most TILE_SWEEP_ROWS arcs (a packed record has six bits for a row) and 256 states (eight for a state).
 static const uint32_t TILE_SWEEP_TILE = 8192, TILE_SWEEP_ALPHA_ROWS = 126, TILE_SWEEP_ROWS = 48, TILE_SWEEP_GROUPS = 16;
 static const uint32_t TILE_SWEEP_LDS = TILE_SWEEP_TILE * 12 + TILE_SWEEP_ALPHA_ROWS * 64 * 8;  // weights + records + values
+// Fused lanes (LatticeSet::lane_fused): a corpus whose lattices all go one per lane but are too long for the tile sweep (windowed
+// groups, plain lattices above TILE_SWEEP_ROWS arcs) is laid out with every lane group's streams starting on a tile of
+// LANE_FUSED_TILE positions = LANE_FUSED_ROWS rows of its 64 lanes: the wavefront that sweeps a group then owns whole tiles of
+// the blocked transposition, and its backward pass hands the posteriors of a tile to the count pass itself (out of a 16 KB LDS
+// stage, in tile-major item order: sweep_lane_kernel<.., XCOUT>) -- `post` is never written and trans_c_tile never runs.
+#ifndef LANE_FUSED_ROWS_N
+#define LANE_FUSED_ROWS_N 16
+#endif
+static const uint32_t LANE_FUSED_ROWS = LANE_FUSED_ROWS_N, LANE_FUSED_TILE = LANE_FUSED_ROWS * 64;
 struct TransBucket {      // mirrored on the device, 24 bytes
   uint64_t item_base;     // first item: bucket-major index J == index into slot_pos[] (arc-sorted order)
   uint32_t n_items, arc_lo, n_arcs, flags;
@@ -210,8 +219,12 @@ struct LatticeSet {
   uint64_t lane_spill_rows = 0;  // rows of 64 doubles for the forward values of the windowed groups
   std::vector<LaneClass> lane_classes;
   bool lane_tiles_aligned = false;  // the pieces' tile ranges are disjoint (required for launching the tile passes per piece)
-  uint32_t tile = TRANS_TILE;       // positions per tile of the blocked transposition: TRANS_TILE, or TILE_SWEEP_TILE when ...
+  uint32_t tile = TRANS_TILE;       // positions per tile of the blocked transposition: TRANS_TILE, LANE_FUSED_TILE, or TILE_SWEEP_TILE when ...
   bool tile_sweep = false;          // ... no lane group straddles a tile and a tile's groups fit one workgroup's LDS (see TILE_SWEEP_TILE)
+  bool lane_fused = false;          // tile == LANE_FUSED_TILE and every lane group starts on a tile (see LANE_FUSED_TILE)
+  uint32_t bucket = TRANS_BUCKET;   // items (and arcs) a bucket of the blocked transposition holds at most: TRANS_BUCKET, or half of
+                                    // it under the fused-lane layout (two bucket workgroups to a CU: measured on c4a, whose
+                                    // (bucket, tile) cells are single runs of ~6 items either way, trans_c_bucket 1229 -> 1000 us)
   std::vector<uint32_t> tile_group; // tile sweep: per lane tile, its first lane group (+ one entry: the number of groups)
   uint64_t lane_states = 0, lane_arcs = 0;  // real (unpadded) totals in lane groups
   // posterior slots: one per lattice arc.  Lane records use their position in lane_bwd[]; bundle out-arcs use
@@ -262,6 +275,8 @@ struct BuildOptions {
   double wave_lane_min_width = 16.0;    // ... for lattices a WINDOWED lane would take: this wide, and only when the corpus
   uint64_t wave_lane_threshold = 262144;  // has fewer lane-sized lattices than this (4 waves per SIMD of one-per-lane work)
   bool tile_sweep = true;          // lay a corpus of plain lane lattices out for the one-kernel tile sweep (LatticeSet::tile_sweep)
+  bool lane_fused = true;          // lay a corpus of lane lattices the tile sweep does not take out for the fused backward pass
+                                   // (LatticeSet::lane_fused)
   uint32_t lane_chunks = 1;        // chunks per lane class (see LatticeSet::LaneClass); 1 = one launch per class (default:
                                    // measured on config 4, four chunks on four streams overlap their kernels but finish no
                                    // sooner -- the E-step is bound by its total HBM traffic -- and cost 46 us of extra tails)

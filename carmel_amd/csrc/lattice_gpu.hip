@@ -601,11 +601,11 @@ __global__ void slots_kernel(const unsigned long long* items, uint64_t n, uint64
 
 // end (exclusive) of the transposition bucket that starts at arc a, for every arc that is not heavy (build_transpose's
 // greedy rule: at most TRANS_BUCKET items and arcs, stop before a heavy arc)
-__global__ void bucket_end_kernel(const uint64_t* arc_off, uint64_t n_arcs, uint32_t* b_end) {
+__global__ void bucket_end_kernel(const uint64_t* arc_off, uint64_t n_arcs, uint32_t* b_end, uint32_t BK /* LatticeSet::bucket */) {
   const uint64_t a = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (a >= n_arcs) return;
-  const uint64_t limit = arc_off[a] + TRANS_BUCKET;
-  uint64_t lo = a, hi = min(n_arcs, a + (uint64_t)TRANS_BUCKET);  // largest e in [a, hi] with arc_off[e] <= limit
+  const uint64_t limit = arc_off[a] + BK;
+  uint64_t lo = a, hi = min(n_arcs, a + (uint64_t)BK);  // largest e in [a, hi] with arc_off[e] <= limit
   while (lo < hi) {
     const uint64_t m = (lo + hi + 1) >> 1;
     if (arc_off[m] <= limit) lo = m; else hi = m - 1;
@@ -622,7 +622,7 @@ __global__ void heavy_list_kernel(const uint64_t* arc_off, uint64_t n_arcs, uint
 // the greedy chain itself: sequential by definition, a few thousand steps
 __global__ void bucket_chain_kernel(const uint64_t* arc_off, const uint32_t* b_end, uint64_t n_arcs, const uint32_t* heavy,
                                     uint32_t n_heavy, TransBucket* buckets, uint32_t* split_arcs, uint32_t cap,
-                                    uint32_t* n_out /* buckets, split arcs, overflow */) {
+                                    uint32_t* n_out /* buckets, split arcs, overflow */, uint32_t BK /* LatticeSet::bucket */) {
   if (blockIdx.x || threadIdx.x) return;
   uint64_t a = 0;
   uint32_t nb = 0, ns = 0, hp = 0;
@@ -630,14 +630,14 @@ __global__ void bucket_chain_kernel(const uint64_t* arc_off, const uint32_t* b_e
   while (a < n_arcs) {
     const uint64_t c = arc_off[a + 1] - arc_off[a];
     if (c > TRANS_HEAVY) {
-      const bool split = c > TRANS_BUCKET;
+      const bool split = c > BK;
       if (split) {
         if (ns < cap) split_arcs[ns] = (uint32_t)a;
         ++ns;
       }
-      for (uint64_t g = arc_off[a]; g < arc_off[a + 1]; g += TRANS_BUCKET) {
+      for (uint64_t g = arc_off[a]; g < arc_off[a + 1]; g += BK) {
         if (nb < cap)
-          buckets[nb] = TransBucket{g, (uint32_t)min((uint64_t)TRANS_BUCKET, arc_off[a + 1] - g), (uint32_t)a, 1u,
+          buckets[nb] = TransBucket{g, (uint32_t)min((uint64_t)BK, arc_off[a + 1] - g), (uint32_t)a, 1u,
                                     TRANS_SINGLE | (split ? TRANS_SPLIT : 0u)};
         else
           over = true;
@@ -1114,7 +1114,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
       size_t n1 = 0;
-      for (uint32_t c : ch) n1 += c;
+      for (uint32_t c : ch) n1 += c & 1u;  // (bit 0; the padding field sits above it)
       fprintf(stderr, "timing: tile sweep: %zu tiles, %zu groups, %zu of them single paths\n", L.tile_group.size() - 1, ch.size(), n1);
     }
   } else {
@@ -1135,8 +1135,8 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   DevBuf<uint32_t> b_end, d_nout;
   HIPCHK(b_end.alloc(w.n_arcs));
   HIPCHK(d_nout.alloc(4));
-  hipLaunchKernelGGL(bucket_end_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, b_end.p);
-  const uint32_t cap = (uint32_t)(2 * (n_items / TRANS_BUCKET) + w.n_arcs / TRANS_BUCKET + 2 * (n_items / TRANS_HEAVY) + 16);
+  hipLaunchKernelGGL(bucket_end_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, b_end.p, L.bucket);
+  const uint32_t cap = (uint32_t)(2 * (n_items / L.bucket) + w.n_arcs / L.bucket + 2 * (n_items / TRANS_HEAVY) + 16);
   HIPCHK(t->t_buckets.alloc(cap));
   HIPCHK(t->t_split_arcs.alloc(cap));
   DevBuf<uint32_t> heavy, heavy_sorted;
@@ -1151,7 +1151,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   if (n_heavy > cap) return fail(CARMEL_HIP_ERR_HIP, "gpu lattice build: heavy-arc list overflow");
   if (n_heavy) HIPCHK(sort_keys(tmp, heavy.p, heavy_sorted.p, n_heavy, 32, s));
   hipLaunchKernelGGL(bucket_chain_kernel, dim3(1), dim3(1), 0, s, t->arc_off.p, b_end.p, w.n_arcs, heavy_sorted.p, n_heavy,
-                     t->t_buckets.p, t->t_split_arcs.p, cap, d_nout.p);
+                     t->t_buckets.p, t->t_split_arcs.p, cap, d_nout.p, L.bucket);
   uint32_t h_nout[4] = {0, 0, 0, 0};
   HIPCHK(hipMemcpyAsync(h_nout, d_nout.p, 12, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1205,7 +1205,10 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   t->wave_spill.release();
   t->wave_slot_base = n_rec;
   t->wave_records = 0;
-  HIPCHK(t->post.alloc(n_post));
+  if (L.lane_fused)  // (allocated on first use by the A/B switch's three kernels: engine.cpp)
+    t->post.release();
+  else
+    HIPCHK(t->post.alloc(n_post));
   HIPCHK(t->wcache.alloc(n_rec));
   t->bundles.release();
   t->in_arcs.release();

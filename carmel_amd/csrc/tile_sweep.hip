@@ -661,24 +661,26 @@ hipError_t launch_tile_sweep(const TransArgs& T0, const LaneArgs& A, const uint3
                              hipStream_t stream) {
   if (!T0.n_buckets || !tile_count) return hipSuccess;
   if (T0.tile != TILE_SWEEP_TILE || !A.pre_weights || !A.rec2 || !A.chain || !A.tile_chain) return hipErrorInvalidValue;
-  static bool attr = false;
+  // the movers' unclamped requests read up to a tile's worth of items past the last tile's: 8 B (x), 2 B (t_pos), 4 B (t_src) each
+  if (T0.slack_bytes < TILE_SWEEP_TILE * sizeof(double)) return hipErrorInvalidValue;
+  // per device: the dynamic-LDS attribute of a kernel and the CU count are the device's, not the process's
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  static int dev_cus[64] = {0};  // 0: this device has not been set up (written once per device; racing writers store the same value)
   const int lds = (int)TILE_SWEEP_LDS;
-  if (!attr) {
-    TRANS_SET_LDS((tile_sweep_kernel<false>), lds);
-    TRANS_SET_LDS((tile_sweep_kernel<true>), lds);
-    attr = true;
+  if (!dev_cus[dev]) {
+    if (hipFuncSetAttribute((const void*)tile_sweep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipFuncSetAttribute((const void*)tile_sweep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return hipErrorInvalidValue;  // (the caller falls back to the three kernels on the same layout)
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
+    __atomic_store_n(&dev_cus[dev], prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8, __ATOMIC_RELEASE);
   }
+  const int n_cu = __atomic_load_n(&dev_cus[dev], __ATOMIC_ACQUIRE);
   TransArgs T = T0;
   T.tile_first = tile_first;
   T.tile_count = tile_count;
   // persistent: a workgroup per CU (its LDS is a CU's), fewer when there are fewer tiles; a multiple of 8 (XCDs)
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return hipErrorInvalidDevice;
-    n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
-  }
   const dim3 g8(std::min<uint32_t>((uint32_t)n_cu, (tile_count + 7) / 8 * 8));
   // (the scattering forms of both directions go together: TransArgs::scatter is 3 where the corpus has run-length indices)
   if ((T.scatter & 3u) == 3u && T.use_runs)

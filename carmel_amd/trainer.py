@@ -166,15 +166,21 @@ class HipForwardBackward(object):
             return "unrolled over string positions (never stored)"
         if lay == 2:
             return "unrolled, rank-1 dense form (never stored)"
-        tiles = lib.carmel_hip_lattice_tile_sweep(self.h)
-        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM%s" % (
+        tiles, fused = lib.carmel_hip_lattice_tile_sweep(self.h), lib.carmel_hip_lattice_fused_lanes(self.h)
+        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM%s%s" % (
             ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9,
-            "; laid out for the tile sweep (%d tiles)" % tiles if tiles else "")
+            "; laid out for the tile sweep (%d tiles)" % tiles if tiles else "",
+            "; fused lanes (%d tiles)" % fused if fused else "")
 
     @property
     def tile_sweep_tiles(self):
         """> 0: the E-step is bucket pass, tile_sweep_kernel, bucket pass (carmel_hip_lattice_tile_sweep)"""
         return lib.carmel_hip_lattice_tile_sweep(self.h)
+
+    @property
+    def fused_lane_tiles(self):
+        """> 0: the lane sweep's backward pass writes XC itself (carmel_hip_lattice_fused_lanes)"""
+        return lib.carmel_hip_lattice_fused_lanes(self.h)
 
     def exchange_plan(self, comm, n_chunks=0, force_allreduce=False):
         """plan the per-iteration exchange (collective); returns exchange_info()"""

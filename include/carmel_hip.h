@@ -92,6 +92,12 @@ int carmel_hip_debug_lattice_fingerprint(carmel_hip_trainer* t, uint64_t* out16)
  * CARMEL_HIP_TILE_SWEEP=0 at build time keeps the five-kernel layout, CARMEL_HIP_TILE_SWEEP_KERNEL=0 runs the three middle
  * kernels on the tile-sweep layout (A/B switches: same counts). */
 int carmel_hip_lattice_tile_sweep(carmel_hip_trainer* t);
+/* > 0: the explicit lattices are laid out as fused lanes (csrc/lattice.hpp, LANE_FUSED_TILE: a corpus of one-per-lane lattices
+ * the tile sweep does not take -- windowed groups, lattices above 48 arcs; every lane group starts on a tile of its own (LANE_FUSED_TILE positions)
+ * and the lane sweep's backward pass hands its posteriors to the count pass itself, derivations.h:432-449 without a stored
+ * posterior array) -- the number of lane tiles; 0 otherwise.  CARMEL_HIP_LANE_FUSED=0 at build time keeps the 16384-position
+ * tiles, CARMEL_HIP_LANE_FUSED_KERNEL=0 runs sweep -> post -> trans_c_tile on the fused layout (A/B switches: same counts). */
+int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t);
 /* how the derivation lattices are held: 0 = explicit (lane groups / bundles in HBM), 1 = unrolled over string positions
  * (one-tape models, never stored), 2 = unrolled in the rank-1 dense form (LM o channel cascades, dense.hpp); -1: none built */
 int carmel_hip_lattice_layout(carmel_hip_trainer* t);

@@ -372,6 +372,33 @@ def test_gibbs_on_lattices_with_cycles(oracle, kw):
     fb.close()
 
 
+def test_parallel_sweep_on_a_large_lattice_with_a_cycle(oracle, monkeypatch):
+    """--crp-parallel on a cyclic lattice of more than 256 states (round-4 advisor): the sample capacity of such a block is
+    32 x states x chain, which used to be the sweep kernel's dynamic LDS -- above 64 KB an opaque launch failure.  The previous
+    sample now lives in LDS up to a fixed cap and is read from global memory beyond it: both ways give the same sweep."""
+    from carmel_amd.trainer import HipGibbs
+    fst = 'F\n(S (S "a" "x" 0.5))\n(S (S "a" "y" 0.3))\n(S (T *e* *e* 0.1))\n(T (S *e* *e* 0.5))\n(T (S "a" "x" 0.5))\n(S (F *e* *e* 0.1))\n'
+    rng = np.random.default_rng(3)
+    lines = []
+    for n in (150, 170, 3):
+        lines += [" ".join(['"a"'] * n), " ".join('"%s"' % ("x" if r < 0.5 else "y") for r in rng.random(n))]
+    res = {}
+    for cap in (None, "3"):
+        if cap:
+            monkeypatch.setenv("CARMEL_HIP_GIBBS_OWN_CAP", cap)
+        oc, ocorp, fb = _setup(oracle, [fst], "\n".join(lines) + "\n", [NORM_CONDITIONAL], [0.3])
+        assert fb.lattice_stats.n_cyclic_pairs == 3 and fb.lattice_stats.kept_states > 2 * 256
+        gs = HipGibbs(fb, 6, burnin=2, seed=9, mode=1)
+        lp = gs.run().copy()
+        assert np.all(np.isfinite(lp))
+        res[cap] = (lp, [gs.sample(b) for b in range(gs.n_blocks)], fb.weights().copy())
+        gs.close()
+        fb.close()
+    np.testing.assert_array_equal(res[None][0], res["3"][0])
+    assert res[None][1] == res["3"][1] and all(len(s) >= 3 for s in res[None][1])
+    np.testing.assert_array_equal(res[None][2], res["3"][2])
+
+
 def test_observer_sees_the_chain_as_it_stands(oracle, golden_dir):
     """carmel_hip_gibbs_set_observer / _current_probs: called after sweeps 0, 2, 4, ...; the probabilities it reads are
     count / norm sum of that moment (a distribution per norm group), the sample the one a shorter run ends with"""

@@ -450,6 +450,55 @@ def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
         np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
 
 
+@pytest.mark.parametrize("kind", ["clustered", "long_plain", "ragged"])
+def test_fused_lane_sweep_is_the_kernels_it_replaces(oracle, kind, monkeypatch):
+    """sweep_lane_kernel<.., XC> (kernels.hip; LatticeSet::lane_fused): on a corpus of one-per-lane lattices the tile sweep does
+    not take, the lane sweep's backward pass stages a tile's posteriors in LDS and writes them to XC in tile-major item order
+    itself.  Same layout with CARMEL_HIP_LANE_FUSED_KERNEL=0 (sweep -> post -> trans_c_tile): the same bits -- ln p per pair,
+    every count, the weights after an M-step.  The 16384-position layout (CARMEL_HIP_LANE_FUSED=0): the same ln p, counts
+    equal up to the order of their sums.  And all are the oracle's."""
+    if kind == "clustered":  # c4a's shape: windowed groups (three in-arcs per state) next to plain ones
+        monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "20")
+        w = synth.clustered_wfst(3 * 400 + 1, 12, members=3, seed=5)
+        c = synth.clustered_walk_corpus(w, 9000, 12, members=3, min_arcs=3, max_arcs=40, seed=5)
+    elif kind == "long_plain":  # single paths and small ambiguities beyond the tile sweep's 48 arcs: plain groups of several tiles
+        w = synth.random_wfst(3000, 6, seed=12)
+        c = synth.random_walk_corpus(w, 6000, min_arcs=3, max_arcs=90, seed=12, out_degree=6)
+    else:  # few ragged lattices: partial groups, tiles with a handful of items, epsilons (kept off the one-per-wavefront layout)
+        monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "1e9")
+        w = synth.random_wfst(300, 4, n_sym=6, p_eps=0.1, seed=3)
+        c = synth.random_walk_corpus(w, 150, min_arcs=20, max_arcs=60, seed=3, out_degree=4)
+    out = {}
+    for mode in ("fused", "kernels", "layout"):
+        for k in ("CARMEL_HIP_LANE_FUSED_KERNEL", "CARMEL_HIP_LANE_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "kernels":
+            monkeypatch.setenv("CARMEL_HIP_LANE_FUSED_KERNEL", "0")
+        if mode == "layout":
+            monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+        fb = _fb(w, c)
+        assert fb.tile_sweep_tiles == 0 and (fb.fused_lane_tiles > 0) == (mode != "layout")
+        lp, _ = fb.estimate(per_pair=True)
+        res = [lp, fb.pair_logprob.copy(), fb.counts().copy()]
+        fb.maximize(1.0)
+        lp2, _ = fb.estimate()
+        out[mode] = res + [lp2, fb.counts().copy()]
+        fb.close()
+    a, b = out["fused"], out["kernels"]
+    assert a[0] == b[0] and a[3] == b[3] and np.array_equal(a[1], b[1])
+    for x, y in ((a[2], b[2]), (a[4], b[4])):  # (the one atomic add per piece of a split hub arc aside)
+        assert (x != y).sum() <= 16 and np.allclose(x, y, rtol=1e-13, atol=0)
+    _, _, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert ok.sum() > 0 and np.isfinite(a[1][ok]).all()
+    l = out["layout"]
+    assert np.array_equal(a[1], l[1])
+    np.testing.assert_allclose(a[2], l[2], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(a[4], l[4], rtol=1e-11, atol=0)
+    np.testing.assert_allclose(a[1][ok], r["pair_logprob"][ok], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-14)
+
+
 def test_tile_sweep_with_lattices_without_an_arc(oracle):
     """pairs of two empty strings under a model whose start state is final: lattices of one state and no arc (ln p = 0, no
     counts).  Enough of them fill tiles of the tile-sweep layout that hold no item at all; beside them short paths and

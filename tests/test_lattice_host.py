@@ -240,6 +240,9 @@ def test_wave_layout_on_ambiguous_lattices(oracle, monkeypatch, seed, lane_state
     np.testing.assert_allclose(got, np.bincount(arc_at[v], weights=post[v], minlength=tr["n_arcs"]), rtol=1e-12, atol=0)
 
 
+FUSED_TILE = 1024  # lattice.hpp: LANE_FUSED_TILE
+
+
 def test_tile_sweep_layout(monkeypatch):
     """LatticeSet::tile_sweep (lattice.hpp, TILE_SWEEP_*): a corpus of small plain lane lattices is laid out in tiles of 8192
     positions that no lane group straddles, with room in a workgroup's LDS for the values of a tile's groups; the tables of
@@ -276,17 +279,71 @@ def test_tile_sweep_layout(monkeypatch):
                                rtol=1e-12, atol=0)
     counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
     monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP", "0")
-    img0 = H.host_lattices(w, c, threads=4)
-    assert img0["transpose"]["tile"] == 16384 and len(img0["transpose"]["tile_group"]) == 0
-    counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)
-    assert np.array_equal(plp, plp0)
-    np.testing.assert_allclose(counts, counts0, rtol=1e-12, atol=0)
+    for fused, tile in (("1", FUSED_TILE), ("0", 16384)):  # without the tile sweep: the fused-lane layout, or (A/B) the round-1 tiles
+        monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", fused)
+        img0 = H.host_lattices(w, c, threads=4)
+        assert img0["transpose"]["tile"] == tile and len(img0["transpose"]["tile_group"]) == 0
+        counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)
+        assert np.array_equal(plp, plp0)
+        np.testing.assert_allclose(counts, counts0, rtol=1e-12, atol=0)
 
 
-def test_tile_sweep_layout_is_for_small_plain_lattices_only():
-    """a corpus with one lattice beyond 48 arcs, a windowed group or a one-per-wavefront lattice keeps the five-kernel layout"""
+def test_tile_sweep_layout_is_for_small_plain_lattices_only(monkeypatch):
+    """a corpus with one lattice beyond 48 arcs, a windowed group or a one-per-wavefront lattice is not laid out for the tile
+    sweep: a lanes-only corpus gets the fused-lane layout instead (LatticeSet::lane_fused, next test)"""
     from carmel_amd import synth
     w = synth.random_wfst(3000, 6, seed=12)
     c = synth.random_walk_corpus(w, 3000, min_arcs=3, max_arcs=60, seed=12, out_degree=6)
     tr = H.host_lattices(w, c, threads=4)["transpose"]
+    assert tr["tile"] == FUSED_TILE and len(tr["tile_group"]) == 0
+    monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+    tr = H.host_lattices(w, c, threads=4)["transpose"]
     assert tr["tile"] == 16384 and len(tr["tile_group"]) == 0
+
+
+def test_fused_lane_layout(oracle, monkeypatch):
+    """LatticeSet::lane_fused (lattice.hpp, LANE_FUSED_TILE): a corpus of lane lattices the tile sweep does not take -- windowed
+    groups, lattices above 48 arcs -- is laid out with every lane group on a tile of 1024 positions (16 rows of its 64 lanes) of
+    its own, so that the wavefront sweeping a group owns whole tiles of the transposition and sends its posteriors out itself.
+    The tables move what they move on the 16384-position layout; the numpy sweep gives the oracle's counts on both."""
+    from carmel_amd import synth
+    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "12")  # windows on small lattices too
+    w = synth.clustered_wfst(3 * 40 + 1, 12, members=3, seed=8)
+    c = synth.clustered_walk_corpus(w, 700, 12, members=3, min_arcs=3, max_arcs=30, seed=8)
+    img = H.host_lattices(w, c, threads=4)
+    tr, g = img["transpose"], img["lane_groups"]
+    T = FUSED_TILE
+    assert tr["tile"] == T and len(tr["tile_group"]) == 0 and len(img["bundles"]) == 0 and len(img["waves"]["descs"]) == 0
+    assert (g["window"] > 0).any() and (g["window"] == 0).any()
+    sb = g["stream_base"].astype(np.int64)
+    assert (sb % T == 0).all() and (np.diff(sb) >= g["maxlen"][:-1].astype(np.int64) * 64).all()
+    assert tr["n_post"] % T == 0 and len(tr["tile_base"]) - 1 == tr["n_post"] // T
+    # every item of a tile belongs to the one group that owns the tile
+    owner = np.searchsorted(sb, np.arange(len(tr["tile_base"]) - 1) * T, side="right") - 1
+    for t in (0, len(owner) // 2, len(owner) - 1):
+        i0, i1 = int(tr["tile_base"][t]), int(tr["tile_base"][t + 1])
+        p = t * T + tr["t_pos"][i0:i1].astype(np.int64)
+        assert (p >= sb[owner[t]]).all() and (p < sb[owner[t]] + int(g["maxlen"][owner[t]]) * 64).all()
+    n_post = tr["n_post"]
+    rng = np.random.default_rng(2)
+    logw = rng.normal(size=tr["n_arcs"])
+    arc_at = np.full(n_post, -1, np.int64)
+    for a in range(tr["n_arcs"]):
+        arc_at[tr["slot_pos"][int(tr["arc_off"][a]):int(tr["arc_off"][a + 1])]] = a
+    valid = arc_at >= 0
+    assert np.array_equal(H.transpose_weights(tr, logw, n_post)[valid], logw[arc_at[valid]])
+    post = rng.random(n_post)
+    np.testing.assert_allclose(H.transpose_counts(tr, post), np.bincount(arc_at[valid], weights=post[valid], minlength=tr["n_arcs"]),
+                               rtol=1e-12, atol=0)
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    r = oracle.estimate(ow, oc)
+    counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
+    ok = r["has_deriv"]
+    np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
+    monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+    img0 = H.host_lattices(w, c, threads=4)
+    assert img0["transpose"]["tile"] == 16384
+    counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)
+    assert np.array_equal(plp, plp0)
+    np.testing.assert_allclose(counts, counts0, rtol=1e-12, atol=0)

@@ -222,6 +222,25 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     assert j1["exchange"]["loopback"] and j1["exchange_ms"] > 0
 
 
+def test_bench_starts_its_own_ranks_without_a_launcher(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed.run in front (the way the driver starts `--gpus 1`): bench.py
+    spawns the two ranks itself as child processes before anything touches a GPU, and rank 0 prints the one line."""
+    import json
+    bench = os.path.join(ROOT, "bench.py")
+    f2 = str(tmp_path / "two.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--config", "c2", "--pairs", "4000", "--steps", "3", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-secondary", "--comm-plugin", PLUGIN, "--full-out", f2],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=env, timeout=600)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.split("\n") if l.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    c2 = json.loads(lines[0])
+    assert c2["n_gpus"] == 2 and c2["scaling"] == "weak" and c2["value"] > 0
+    j2 = json.load(open(f2))
+    assert j2["config"]["pairs_per_gpu"] == 4000 and j2["exchange"]["world"] == 2
+
+
 _LIFETIME = r"""
 import sys
 sys.path.insert(0, sys.argv[1])

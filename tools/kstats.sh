@@ -11,5 +11,6 @@ mkdir -p $R/gpurun_out; cp $f $R/gpurun_out/${CFG}_kernel_stats.csv
 python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    print("   %-60s calls %5s avg %9.1f us"%(r['Name'][:60], r['Calls'], float(r['AverageNs'])/1e3))
+    n = r['Name'].replace('carmel_hip::', '').replace('void ', '')
+    print("   %-100s calls %5s avg %9.1f us"%(n[:100], r['Calls'], float(r['AverageNs'])/1e3))
 PY
