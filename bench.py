@@ -514,6 +514,8 @@ def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, s
 
     par = leg(reps_parallel, sweeps_parallel, ["--crp-parallel"])
     ex = leg(1, sweeps_exact, [])
+    # the reference's chain 64 times over (--crp-restarts=63: independent runs, gibbs.hpp:880-914) as 64 concurrent wavefronts
+    ex64 = leg(1, max(10, sweeps_exact // 3), ["--crp-restarts=63"])
     out = {"metric": "lattice-arc updates/sec of Gibbs sweeps (sweeps/sec x derivation-lattice arcs)", "value": par["value"], "unit": "arc-updates/s",
            "n_gpus": 1, "steps": par["sweeps"], "warmup": 0, "ms_per_step": par["ms_per_step"], "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64", "data": "carmel-tutorial tagging.* x%d" % reps_parallel,
@@ -526,6 +528,9 @@ def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, s
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": par["frac"], "traffic": None,
                         "algorithmic_bytes_per_launch": par["algorithmic_bytes_per_launch"]},
            "exact": {k: ex[k] for k in ("blocks", "sweeps", "ms_per_step", "value", "frac", "lattice_arcs")}}
+    out["exact"]["chains64"] = {"runs": 64, "ms_per_chain_sweep": ex64["ms_per_step"], "value": ex64["value"], "unit": "arc-updates/s",
+                                "aggregate_over_one_chain": ex["ms_per_step"] / ex64["ms_per_step"],
+                                "note": "carmel --crp --crp-restarts=63: the 64 runs side by side, a wavefront each (GxArgs::n_chains); value = all chains' sweeps"}
     out["exact"]["unit"] = "arc-updates/s"
     out["exact"]["note"] = "gibbs_exact_wave_kernel: one wavefront, blocks strictly in order (the reference's chain; latency-bound by construction)"
     if not args.no_cpu_baseline and rank == 0:
@@ -696,6 +701,8 @@ def compact_line(out):
             e["parity"] = r["parity_checked_pairs"]
         if "exact" in r:
             e["exact_ms"] = _r4(r["exact"].get("ms_per_step"))
+            if "chains64" in r["exact"]:
+                e["exact_x64"] = _r4(r["exact"]["chains64"].get("aggregate_over_one_chain"))
         sec[name] = e
     if sec:
         line["secondary"] = sec

@@ -1187,6 +1187,161 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   if (g->run_stride > 1 && g->pi_stddev > 0 && !g->pi_restart_fresh)
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "runs as replicas need independent runs: the inferred priors drift from run to run unless --prior-inference-restart-fresh");
   g->ran_any = false;
+  // finalize_cumulative_counts + probs_to_cascade for one finished run: counts := time-integrated counts over the post-burn-in
+  // sweeps, weight = final_prob (gibbs.hpp:141-150, gibbs.cc:66-76)
+  auto final_weights = [&](std::vector<double>& x, std::vector<double>& sacc, const std::vector<double>& tm, std::vector<double>& out_lw) {
+    if (!(g->opt.final_counts && !g->opt.exclude_prior)) {
+      const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
+      for (uint64_t p = 0; p < np; ++p) {
+        if (g->h_norm[p] == 0xffffffffu) continue;
+        if (g->opt.exclude_prior) {
+          sacc[p] += -g->h_prior[p] * tm[p];
+          x[p] += -g->h_prior[p];
+        }
+        if (!g->opt.final_counts) {
+          sacc[p] += x[p] * (tmax1 - tm[p]);  // delta_sum::extend
+          x[p] = sacc[p];
+        }
+      }
+    }
+    std::vector<double> ns(ng, 0.0);
+    for (uint64_t p = 0; p < np; ++p)
+      if (g->h_norm[p] != 0xffffffffu) ns[g->h_norm[p]] += x[p];
+    for (uint64_t p = 0; p < np; ++p) {
+      double pr = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : (x[p] > 0 ? x[p] / ns[g->h_norm[p]] : 0.0);
+      out_lw[p] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
+    }
+  };
+  // ---- the runs of --crp-restarts SIDE BY SIDE (gibbs.hpp:880-914: each run starts from the priors and draws the uniforms of its
+  // own sweeps -- independent chains).  The exact chain is one wavefront; a 256-CU part runs as many chains as it is given at the
+  // price of one.  Chain c = this rank's c-th run: its own counts, cache model and sample (GxArgs::n_chains); the sweeps of all
+  // chains advance together, one launch per sweep; the best run is kept by the sequential loop's rule (the earlier on a tie).
+  // Not for: the workgroup kernel's cases, prior-scale inference (its proposals are sequential on the host), an observer.
+  {
+    std::vector<uint32_t> my_runs;
+    for (uint32_t run = 0; run < n_runs; ++run)
+      if (run % g->run_stride == g->run_first) my_runs.push_back(run);
+    uint32_t cap = 64;
+    if (const char* e = getenv("CARMEL_HIP_GIBBS_CHAINS")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
+    // memory of a chain: counts, their time-weighted sums and stamps, norm sums, the sweep's cache model, the sample
+    const uint64_t chain_bytes = (np * 4 + ng * 2) * 8 + (uint64_t)g->sample_ids.n * 8 + (uint64_t)g->n_blocks * 4 + 64;
+    cap = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(chain_bytes, 1)));
+    if (wave_run && my_runs.size() > 1 && cap > 1 && g->pi_stddev <= 0 && !g->obs_fn) {
+      const uint64_t cs = g->sample_ids.n;  // sample ids of a chain
+      DevBuf<double> mx, ms, mt, mn, mcc, mcs, mio;
+      DevBuf<uint32_t> mlen, mids, mnrm;
+      bool have_best = false;
+      std::vector<uint32_t> best_ids_h, best_len_h;
+      for (size_t b0 = 0; b0 < my_runs.size(); b0 += cap) {
+        const uint32_t R = (uint32_t)std::min<size_t>(cap, my_runs.size() - b0);
+        if (mx.n < (size_t)R * np) {
+          HIPCHK(mx.alloc((size_t)R * np));
+          HIPCHK(ms.alloc((size_t)R * np));
+          HIPCHK(mt.alloc((size_t)R * np));
+          HIPCHK(mn.alloc((size_t)R * ng));
+          HIPCHK(mcc.alloc((size_t)R * np));
+          HIPCHK(mcs.alloc((size_t)R * ng));
+          HIPCHK(mio.alloc((size_t)R * 8));
+          HIPCHK(mlen.alloc((size_t)R * g->n_blocks));
+          HIPCHK(mids.alloc((size_t)R * cs));
+          HIPCHK(mnrm.alloc((size_t)R * cs));
+        }
+        // restore_p0 for every chain: counts = priors, normsums = their sums, no sample
+        HIPCHK(launch_gibbs_broadcast(mx.p, g->p_prior.p, np, R, s));
+        HIPCHK(launch_gibbs_broadcast(mn.p, g->prior_norm.p, ng, R, s));
+        HIPCHK(hipMemsetAsync(ms.p, 0, (size_t)R * np * sizeof(double), s));
+        HIPCHK(hipMemsetAsync(mt.p, 0, (size_t)R * np * sizeof(double), s));
+        HIPCHK(hipMemsetAsync(mlen.p, 0, (size_t)R * g->n_blocks * sizeof(uint32_t), s));
+        GxArgs GC = GX;
+        GC.p_x = mx.p;
+        GC.normsum = mn.p;
+        GC.ccount = mcc.p;
+        GC.csum = mcs.p;
+        GC.sample_len = mlen.p;
+        GC.sample_ids = mids.p;
+        GC.sample_nrm = mnrm.p;
+        GC.old_len = mlen.p;
+        GC.old_ids = mids.p;
+        GC.old_nrm = mnrm.p;
+        GC.iter_out = mio.p;
+        GC.phase_clk = nullptr;
+        GC.n_chains = R;
+        GC.iter_stride = g->run_stride * (Ni + 1);
+        GC.ch_params = np;
+        GC.ch_norms = ng;
+        GC.ch_sample = cs;
+        std::vector<double> st_all(R, 0.0), st_final(R, 0.0), st_sum(R, -std::numeric_limits<double>::infinity());
+        std::vector<double> io((size_t)R * 8);
+        for (uint32_t iter = 0; iter <= Ni; ++iter) {
+          const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
+          HIPCHK(hipMemsetAsync(mio.p, 0, (size_t)R * 8 * sizeof(double), s));
+          HIPCHK(launch_gibbs_broadcast(mcc.p, g->p_prior.p, np, R, s));
+          HIPCHK(launch_gibbs_broadcast(mcs.p, g->prior_norm.p, ng, R, s));
+          HIPCHK(launch_forest_fold(ms.p, mt.p, mx.p, time, (uint64_t)R * np, s));
+          GC.iter = my_runs[b0] * (Ni + 1) + iter;
+          GC.init_logw = (iter == 0 && my_runs[b0] == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
+          GC.init_chain = GC.init_logw ? 0u : 0xffffffffu;
+          HIPCHK(launch_gibbs_exact_wave(GC, 0, s));
+          HIPCHK(hipMemcpyAsync(io.data(), mio.p, io.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          for (uint32_t c = 0; c < R; ++c) {
+            const uint32_t run = my_runs[b0 + c];
+            const double plog = io[(size_t)c * 8 + 0];
+            if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
+            if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[(size_t)c * 8 + 1];
+            if (iter_after_logprob) iter_after_logprob[(size_t)run * (Ni + 1) + iter] = io[(size_t)c * 8 + 2];
+            if (iter >= burnin) {  // gibbs.hpp:942-943
+              st_all[c] += plog;
+              st_final[c] = plog;
+              const double hi = std::max(st_sum[c], plog), lo = std::min(st_sum[c], plog);
+              st_sum[c] = hi + (lo == -std::numeric_limits<double>::infinity() ? 0.0 : std::log1p(std::exp(lo - hi)));
+            }
+          }
+        }
+        // every chain's final weights; the better run by gibbs_stats::better, in run order
+        std::vector<double> x(np), sacc(np), tm(np);
+        for (uint32_t c = 0; c < R; ++c) {
+          HIPCHK(hipMemcpyAsync(x.data(), mx.p + (size_t)c * np, np * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(sacc.data(), ms.p + (size_t)c * np, np * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIPCHK(hipMemcpyAsync(tm.data(), mt.p + (size_t)c * np, np * sizeof(double), hipMemcpyDeviceToHost, s));
+          HIPCHK(hipStreamSynchronize(s));
+          final_weights(x, sacc, tm, lw);
+          const bool better = !g->ran_any || (g->opt.argmax_final ? st_final[c] > best_final : g->opt.argmax_sum ? st_sum[c] > best_sum : st_all[c] > best_all);
+          if (better) {
+            g->best_run = my_runs[b0 + c];
+            best_all = st_all[c];
+            best_final = st_final[c];
+            best_sum = st_sum[c];
+            g->best_stats[0] = st_all[c];
+            g->best_stats[1] = st_final[c];
+            g->best_stats[2] = st_sum[c];
+            best_lw = lw;
+            best_ids_h.resize(cs);
+            best_len_h.resize(g->n_blocks);
+            HIPCHK(hipMemcpyAsync(best_ids_h.data(), mids.p + (size_t)c * cs, cs * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(best_len_h.data(), mlen.p + (size_t)c * g->n_blocks, g->n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            have_best = true;
+          }
+          g->ran_any = true;
+        }
+        if (b0 + R >= my_runs.size()) {  // what a later look at the sampler's state finds: the last run's counts
+          HIPCHK(hipMemcpyAsync(g->p_x.p, mx.p + (size_t)(R - 1) * np, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(g->p_s.p, ms.p + (size_t)(R - 1) * np, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(g->p_tmax.p, mt.p + (size_t)(R - 1) * np, np * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipMemcpyAsync(g->normsum.p, mn.p + (size_t)(R - 1) * ng, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+          HIPCHK(hipStreamSynchronize(s));
+        }
+      }
+      if (have_best) {  // the kept run's sample is the sampler's sample
+        HIPCHK(hipMemcpyAsync(g->sample_ids.p, best_ids_h.data(), cs * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipMemcpyAsync(g->sample_len.p, best_len_h.data(), g->n_blocks * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      g->ran = true;
+      return carmel_hip_set_weights(t, best_lw.data());
+    }
+  }
   for (uint32_t run = 0; run < n_runs; ++run) {
   if (run % g->run_stride != g->run_first) continue;  // another replica's run
   if (g->pi_stddev > 0 && run > 0 && g->pi_restart_fresh) {  // gibbs.hpp:889-898: the priors start over
@@ -1389,28 +1544,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   HIPCHK(hipMemcpyAsync(sacc.data(), g->p_s.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipMemcpyAsync(tm.data(), g->p_tmax.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
-  if (!(g->opt.final_counts && !g->opt.exclude_prior)) {
-    const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
-    for (uint64_t p = 0; p < np; ++p) {
-      if (g->h_norm[p] == 0xffffffffu) continue;
-      if (g->opt.exclude_prior) {
-        sacc[p] += -g->h_prior[p] * tm[p];
-        x[p] += -g->h_prior[p];
-      }
-      if (!g->opt.final_counts) {
-        sacc[p] += x[p] * (tmax1 - tm[p]);  // delta_sum::extend
-        x[p] = sacc[p];
-      }
-    }
-  }
-  std::vector<double> ns(ng, 0.0);
-  for (uint64_t p = 0; p < np; ++p)
-    if (g->h_norm[p] != 0xffffffffu) ns[g->h_norm[p]] += x[p];
-  // probs_to_cascade (gibbs.cc:66-76): weight = final_prob (gibbs.hpp:141-150), written into the trainer's parameters
-  for (uint64_t p = 0; p < np; ++p) {
-    double pr = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : (x[p] > 0 ? x[p] / ns[g->h_norm[p]] : 0.0);
-    lw[p] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
-  }
+  final_weights(x, sacc, tm, lw);
   // gibbs_base::run_starts (gibbs.hpp:880-914): keep the run that is better by gibbs_stats::better (gibbs_opts.hpp:313-316)
   const bool better = !g->ran_any || (g->opt.argmax_final ? st_final > best_final : g->opt.argmax_sum ? st_sum > best_sum : st_all > best_all);
   if (better) {

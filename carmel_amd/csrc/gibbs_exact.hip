@@ -118,6 +118,22 @@ __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, u
 template <bool PAR>
 __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
+  if (!PAR && A.n_chains > 1) {  // chain blockIdx.x of several: its own counts, cache model, sample, results and uniforms
+    const uint32_t c = blockIdx.x;
+    A.p_x += (size_t)c * A.ch_params;
+    A.ccount += (size_t)c * A.ch_params;
+    A.normsum += (size_t)c * A.ch_norms;
+    A.csum += (size_t)c * A.ch_norms;
+    A.sample_len += (size_t)c * A.n_blocks;
+    A.sample_ids += (size_t)c * A.ch_sample;
+    A.sample_nrm += (size_t)c * A.ch_sample;
+    A.old_len += (size_t)c * A.n_blocks;
+    A.old_ids += (size_t)c * A.ch_sample;
+    A.old_nrm += (size_t)c * A.ch_sample;
+    A.iter_out += (size_t)c * 8;
+    A.iter += c * A.iter_stride;
+    if (c != A.init_chain) A.init_logw = nullptr;
+  }
   const uint32_t CA = A.cap_arcs, CS = A.cap_states, CL = A.cap_levels, CM = A.cap_sample;
   double* gw = (double*)gx_lds;          // proposal weight the walk samples from
   double* pc = gw + CA;                  // ... from the counts (what the proposal probability of the sample is made of)
@@ -568,8 +584,19 @@ hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_
   } else {
     if (lds > 48 * 1024)
       (void)hipFuncSetAttribute((const void*)gibbs_exact_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(gibbs_exact_wave_kernel<false>, dim3(1), dim3(64), lds, s, A);
+    hipLaunchKernelGGL(gibbs_exact_wave_kernel<false>, dim3(A.n_chains > 1 ? A.n_chains : 1u), dim3(64), lds, s, A);
   }
+  return hipGetLastError();
+}
+__global__ void gibbs_broadcast_kernel(double* dst, const double* src, uint64_t n, uint32_t copies) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+    const double v = src[k];
+    for (uint32_t c = 0; c < copies; ++c) dst[(size_t)c * n + k] = v;
+  }
+}
+hipError_t launch_gibbs_broadcast(double* dst, const double* src, uint64_t n, uint32_t copies, hipStream_t s) {
+  if (!n || !copies) return hipSuccess;
+  hipLaunchKernelGGL(gibbs_broadcast_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 4096)), dim3(256), 0, s, dst, src, n, copies);
   return hipGetLastError();
 }
 

@@ -48,11 +48,20 @@ struct GxArgs {
   int want_after;
   int counterfactual;         // parallel sweep: take the block's own previous sample out of the snapshot counts
   uint32_t cap_arcs, cap_states, cap_levels, cap_sample;  // LDS carve: the largest block's arcs / states / levels / sample
+  // several exact chains side by side (the runs of --crp-restarts, gibbs.hpp:880-914: independent by construction): chain c =
+  // workgroup c of the launch, one wavefront, with its own counts, cache model, sample and results at these strides, drawing
+  // the uniforms of sweep iter + c * iter_stride.  n_chains <= 1: the one chain of the fields above.
+  uint32_t n_chains, iter_stride;
+  uint32_t init_chain;        // the chain init_logw is for (the very first sweep of run 0 only); 0xffffffff: none
+  uint64_t ch_params, ch_norms, ch_sample;  // doubles per chain of p_x / ccount, of normsum / csum; ids per chain of the sample buffers
 };
 
 size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_levels, uint32_t cap_sample);
-// n_waves = 0: the exact chain (one wavefront); > 0: the stale-count parallel sweep on that many wavefronts
+// n_waves = 0: the exact chain (one wavefront; GxArgs::n_chains of them side by side); > 0: the stale-count parallel sweep on that
+// many wavefronts
 hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_t s);
+// dst[c * n + k] = src[k] for c < copies (every chain's cache model starts a sweep at the priors)
+hipError_t launch_gibbs_broadcast(double* dst, const double* src, uint64_t n, uint32_t copies, hipStream_t s);
 
 // the parallel sweep's recount through per-workgroup LDS tables: new_x / new_norm (set to the priors by the caller) += the weighted
 // uses of the samples (len, ids, nrm)

@@ -197,6 +197,33 @@ def test_crp_restarts_keep_the_best_run(oracle, golden_dir, kw):
     fb.close()
 
 
+@pytest.mark.parametrize("cap", ["64", "3", "1"])
+def test_crp_restart_runs_side_by_side_are_the_runs_one_after_the_other(oracle, golden_dir, monkeypatch, cap):
+    """the runs of --crp-restarts as concurrent chains (GxArgs::n_chains: a wavefront each, its own counts, cache model, sample and
+    uniforms; gibbs.hpp:880-914): ten runs at once, in batches of three, and one after the other (CARMEL_HIP_GIBBS_CHAINS) log
+    the same probabilities sweep by sweep, keep the same run, the same sample and the same weights -- the oracle's"""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    monkeypatch.setenv("CARMEL_HIP_GIBBS_CHAINS", cap)
+    oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
+                           [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
+    iters, burnin, restarts = 5, 1, 9
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=23, mode=0, restarts=restarts)
+    gs.set_init_weights(fb.wfst.logw)  # (--init-from-p0: the very first sweep of run 0 only)
+    got_lp = gs.run(after=True)
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.5, 0.1], iters=iters, burnin=burnin,
+                           restarts=restarts, init_from_p0=True)
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(gs.iter_cheap_logprob, ref["iter_cheap_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(gs.iter_after_logprob, ref["iter_after_logprob"], rtol=1e-10)
+    assert gs.best_run == ref["best_run"]
+    for b in range(gs.n_blocks):
+        assert gs.sample(b) == ref["samples"][b]
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
+
+
 def test_gibbs_single_transducer_joint(oracle, golden_dir):
     from carmel_amd.trainer import HipGibbs
     g = lambda n: open(os.path.join(golden_dir, n)).read()
