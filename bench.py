@@ -162,6 +162,8 @@ def cpu_leg(ob, w, cs, full_arcs, nthreads, device, parity=True):
     def leg(d):
         sec = d["fixed_sec"] + d["sec_per_arc"] * full_arcs
         return {"value": full_arcs / sec, "sec_per_iter_full_shard": sec, "fixed_sec": d["fixed_sec"],
+                # the E-step alone -- the region `roofline` describes (maximize and the clearing of the count table left out)
+                "estep_value": 1.0 / d["sec_per_arc"] if d["sec_per_arc"] > 0 else None,
                 "sec_per_lattice_arc": d["sec_per_arc"], "estep_sec_sample": d["estep_all"],
                 "estep_sec_quarter_sample": d["estep_quarter"], "maximize_sec": d["maximize"]}
     out = dict(leg(r["serial"]), unit="arc-updates/s", cores=1, kind="port",

@@ -764,16 +764,14 @@ static int run(int argc, char** argv) {
       hip_check(carmel_hip_set_layout_policy(t, 0), "carmel_hip_set_layout_policy");
       hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
     }
-    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
   }
   if (o.matrix_fb) {  // train.cc:381-383
-    if (comm && !o.crp)
-      std::cerr << "option matrix-fb: not combined with --gpus (the sharded count exchange follows the lattices' layout); sweeping lattices\n";
-    else {
-      std::cerr << "Using (input,state,output) full matrix, not derivation lattice.  Usually slower.\n";
-      hip_check(carmel_hip_set_matrix_fb(t, 1), "carmel_hip_set_matrix_fb");
-    }
+    if (rank == 0) std::cerr << "Using (input,state,output) full matrix, not derivation lattice.  Usually slower.\n";
+    hip_check(carmel_hip_set_matrix_fb(t, 1), "carmel_hip_set_matrix_fb");
   }
+  // (after --matrix-fb: the matrix E-step leaves no arc-range-ordered count pass to hang reduce-scatters on, so its exchange is
+  // planned as the one all-reduce; csrc/exchange.cpp)
+  if (comm && !o.crp) hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
@@ -1112,7 +1110,30 @@ static int run(int argc, char** argv) {
     // --print-every=N (gibbs_opts.hpp:78-79; gibbs.hpp:959-968 maybe_print_periodic): after sweeps 0, N, 2N, ... a comment line
     // and, with --print-to, every block's sampled path -- the arcs carry the proposal probabilities of that moment
     // (gibbs.cc:272-286).  The count / norm tables of --print-counts-* / --print-norms-* are not written.
-    std::function<void(uint32_t, uint32_t, double)> periodic = [&](uint32_t, uint32_t iter, double time) {
+    // With --gpus the runs are spread over the ranks (replicas): every rank keeps what its runs print, run by run, and rank 0
+    // prints all of it in run order afterwards -- what one process running the runs one after the other prints.
+    std::vector<std::string> periodic_text(world > 1 ? (size_t)go.restarts + 1 : 0);
+    std::streambuf* const cout_buf = std::cout.rdbuf();
+    std::function<void(uint32_t, uint32_t, double)> periodic = [&](uint32_t run, uint32_t iter, double time) {
+      std::ostringstream cap;
+      struct Redirect {  // (print_paths writes to std::cout)
+        std::streambuf* old;
+        bool on;
+        Redirect(std::ostream& to, bool on_) : old(std::cout.rdbuf()), on(on_) {
+          if (on) std::cout.rdbuf(to.rdbuf());
+        }
+        ~Redirect() {
+          if (on) std::cout.rdbuf(old);
+        }
+      } redirect(cap, world > 1);
+      struct Keep {
+        std::ostringstream& c;
+        std::string* dst;
+        ~Keep() {
+          if (dst) *dst += c.str();
+        }
+      } keep{cap, (world > 1 && run < periodic_text.size()) ? &periodic_text[run] : nullptr};
+      (void)cout_buf;
       std::cout << "# Gibbs i=" << iter << " ";
       if (go.high_temp != go.low_temp && (go.high_temp > 0 || go.low_temp > 0)) {  // gibbs.hpp:945-955 itername
         const double pw_ = carmel_hip_gibbs_power(go.high_temp, go.low_temp, go.iter, iter);
@@ -1139,7 +1160,6 @@ static int run(int argc, char** argv) {
       print_paths(smp, pr, a, b);
     };
     if (o.print_every > 0) {
-      if (world > 1) throw UsageError("--print-every with --gpus is not implemented by the GPU training front end");
       hip_check(carmel_hip_gibbs_set_observer(gs, (uint32_t)o.print_every,
                                               [](void* ctx, uint32_t run, uint32_t iter, double time) {
                                                 (*(std::function<void(uint32_t, uint32_t, double)>*)ctx)(run, iter, time);
@@ -1177,7 +1197,6 @@ static int run(int argc, char** argv) {
     const bool printing = o.print_to > o.print_from;
     if (printing && rc == CARMEL_HIP_OK) {
       if (go.expectation) throw std::runtime_error("can't print sample when using expectation because there is no single sample.\n");
-      if (world > 1) throw UsageError("--print-to with --gpus is not implemented by the GPU training front end (the kept sample lives on one rank)");
       std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_gibbs_max_sample(gs)));
       final_sample.resize(nblocks);
       for (uint32_t b = 0; b < nblocks; ++b) {
@@ -1188,6 +1207,27 @@ static int run(int argc, char** argv) {
     }
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
+    if (world > 1 && o.print_every > 0) {
+      // the runs' periodic output to rank 0, in run order: lengths first, then the bytes (every rank fills its own runs' slots
+      // of one vector of doubles -- carmel_hip_comm_allreduce_host is the host-side collective there is)
+      std::vector<double> len(periodic_text.size(), 0.0);
+      for (size_t r = 0; r < len.size(); ++r) len[r] = (double)periodic_text[r].size();
+      hip_check(carmel_hip_comm_allreduce_host(comm, len.data(), (uint32_t)len.size(), 0), "carmel_hip_comm_allreduce_host");
+      size_t total = 0;
+      std::vector<size_t> at(len.size() + 1, 0);
+      for (size_t r = 0; r < len.size(); ++r) at[r + 1] = (total += (size_t)len[r]);
+      std::vector<double> bytes(total, 0.0);
+      for (size_t r = 0; r < len.size(); ++r)
+        for (size_t k = 0; k < periodic_text[r].size(); ++k) bytes[at[r] + k] = (double)(unsigned char)periodic_text[r][k];
+      for (size_t k0 = 0; k0 < total; k0 += 1u << 16)
+        hip_check(carmel_hip_comm_allreduce_host(comm, bytes.data() + k0, (uint32_t)std::min<size_t>(1u << 16, total - k0), 0),
+                  "carmel_hip_comm_allreduce_host");
+      if (rank == 0) {
+        std::string all(total, ' ');
+        for (size_t k = 0; k < total; ++k) all[k] = (char)(unsigned char)bytes[k];
+        std::cout << all;
+      }
+    }
     if (world > 1) {
       // every rank's traces (zeros for the runs it did not take) add up to the whole log; the kept run is the best of the
       // ranks' bests by gibbs_stats::better, the earlier run on a tie -- what the sequential loop would have kept
@@ -1220,6 +1260,27 @@ static int run(int argc, char** argv) {
       // (ln weights: -inf from the winner plus 0 from the others stays -inf)
       hip_check(carmel_hip_comm_allreduce_host(comm, wts.data(), (uint32_t)wts.size(), 0), "carmel_hip_comm_allreduce_host");
       hip_check(carmel_hip_set_weights(t, wts.data()), "carmel_hip_set_weights");
+      if (printing) {  // --print-to: the kept run's sample lives on the rank that ran it; it travels to rank 0 the same way
+        std::vector<double> bl(nblocks, 0.0);
+        if (rank == winner)
+          for (uint32_t b = 0; b < nblocks; ++b) bl[b] = (double)final_sample[b].size();
+        hip_check(carmel_hip_comm_allreduce_host(comm, bl.data(), (uint32_t)bl.size(), 0), "carmel_hip_comm_allreduce_host");
+        size_t total = 0;
+        for (double v : bl) total += (size_t)v;
+        std::vector<double> ids(total, 0.0);
+        if (rank == winner) {
+          size_t k = 0;
+          for (uint32_t b = 0; b < nblocks; ++b)
+            for (uint32_t id : final_sample[b]) ids[k++] = (double)id;
+        }
+        for (size_t k0 = 0; k0 < total; k0 += 1u << 16)
+          hip_check(carmel_hip_comm_allreduce_host(comm, ids.data() + k0, (uint32_t)std::min<size_t>(1u << 16, total - k0), 0),
+                    "carmel_hip_comm_allreduce_host");
+        final_sample.assign(nblocks, std::vector<uint32_t>());
+        size_t k = 0;
+        for (uint32_t b = 0; b < nblocks; ++b)
+          for (size_t j = 0; j < (size_t)bl[b]; ++j) final_sample[b].push_back((uint32_t)ids[k++]);
+      }
       if (rank > 0) return 0;
     }
     double n_sym = 0;  // gibbs_base::init(derivs.n_output(), derivs.size())

@@ -140,7 +140,9 @@ def test_ranks_with_different_layouts_are_refused_then_rebuilt(tmp_path):
 
 @pytest.mark.parametrize("args", [["-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"],
                                   ["--train-cascade", "-HJ", "-M", "5", "cipher.data", "cipher.wfsa", "cipher.fst"],
-                                  ["-t", "-M", "4", "-!", "1", "-R", "3", "train.a.w.corpus100", "train.a.w"]])
+                                  ["-t", "-M", "4", "-!", "1", "-R", "3", "train.a.w.corpus100", "train.a.w"],
+                                  # --matrix-fb with --gpus (round-4 verdict): the matrix E-step per shard, one all-reduce of the counts
+                                  ["--matrix-fb", "-t", "-M", "4", "epron-jpron.data", "epron-jpron.fst"]])
 def test_front_end_gpus_switch(golden_dir, tmp_path, args):
     """carmel --gpus=2: two processes forked before any GPU call, the corpus in two blocks, counts summed every
     iteration, replicated M-step -- the log lines and the trained transducers of the one-process run"""
@@ -165,7 +167,9 @@ def test_front_end_gpus_switch(golden_dir, tmp_path, args):
             assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
 
 
-@pytest.mark.parametrize("extra", [["--crp-restarts=3"], ["--crp-restarts=4", "--crp-argmax-final"], ["--crp-restarts=1"]])
+@pytest.mark.parametrize("extra", [["--crp-restarts=3"], ["--crp-restarts=4", "--crp-argmax-final"], ["--crp-restarts=1"],
+                                   # --print-every with --gpus (round-4 verdict): every run's periodic lines, in run order, from rank 0
+                                   ["--crp-restarts=3", "--print-every=5", "--print-from=1", "--print-to=2", "-OQWE"]])
 def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_path, extra):
     """carmel --crp --crp-restarts=R --gpus=N (gibbs.hpp:880-914): the runs are independent chains (each from the priors, its
     own uniforms), so rank r takes the runs r, r + N, ... on the whole corpus and the ranks keep the best by
@@ -185,9 +189,11 @@ def test_front_end_gpus_switch_runs_crp_restarts_as_replicas(golden_dir, tmp_pat
         assert p.returncode == 0, p.stderr
         trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
         keep = [l for l in p.stderr.split("\n") if l.startswith(("Gibbs i=", "(random restart", "Kept run"))]
-        outs.append((keep, trained))
+        outs.append((keep, trained, p.stdout))
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) > 13   # the same log, line for line: every run, the same kept run
     assert outs[0][1] == outs[1][1]                              # the same trained transducers, byte for byte
+    if any(e.startswith("--print-every") for e in extra):        # the periodic samples of every run, in run order
+        assert outs[0][2] == outs[1][2] and outs[0][2].count("# Gibbs i=") == 4 * 3
 
 
 def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
