@@ -1260,6 +1260,29 @@ int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts) {
   return CARMEL_HIP_OK;
 }
 
+int carmel_hip_accumulate_counts(carmel_hip_trainer* t, int op) {
+  if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");
+  HIPCHK(hipSetDevice(t->device));
+  if (t->xplan) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_accumulate_counts: drop the exchange plan first (its pieces follow one lattice set's buckets)");
+  if (t->unrolled && op != 0)
+    return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_accumulate_counts: explicit lattices only (carmel_hip_set_layout_policy(t, 0) before build_lattices)");
+  const uint64_t n = t->w.n_arcs + 4;
+  hipStream_t s = t->stream;
+  if (op == 0) {
+    if (t->counts_acc.n != n) HIPCHK(t->counts_acc.alloc(n));
+    HIPCHK(hipMemsetAsync(t->counts_acc.p, 0, n * sizeof(double), s));
+  } else if (op == 1 || op == 2) {
+    if (t->counts_acc.n != n) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_accumulate_counts: clear the accumulator first (op 0)");
+    if (op == 1)
+      HIPCHK(launch_add(t->counts_acc.p, t->counts_ptr(), n, s));
+    else
+      HIPCHK(hipMemcpyAsync(t->counts_ptr(), t->counts_acc.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+  } else
+    return fail(CARMEL_HIP_ERR_ARG, "carmel_hip_accumulate_counts: op is 0 (clear), 1 (add) or 2 (write back)");
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+
 static int cascade_param_counts(carmel_hip_trainer* t, hipStream_t s);
 int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_change) {
   if (!t) return fail(CARMEL_HIP_ERR_ARG, "null trainer");

@@ -166,6 +166,7 @@ struct carmel_hip_trainer {
   DevBuf<uint32_t> lane_fwdx; // source | backward position | flags words only (transposition path)
   DevBuf<uint32_t> lane_pair, lane_nstates;
   DevBuf<double> lane_logw, post, wcache, lane_spill;
+  DevBuf<double> counts_acc;  // carmel_hip_accumulate_counts: the count buffers of a corpus walked shard by shard, summed
   DevBuf<uint64_t> arc_off, slot_pos, hot_chunks;
   uint64_t lane_records = 0;
   uint64_t device_bytes = 0;

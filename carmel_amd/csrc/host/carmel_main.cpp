@@ -88,6 +88,8 @@ struct Options {
   bool em_p0 = false;
   bool init_from_p0 = false;   // --init-from-p0 (carmel.cc:298; gibbs.cc:405-421)
   bool cache_no_prune = false;     // --cache-no-prune
+  bool stream_lattices = false;    // --disk-cache-derivations (carmel.cc:243-246): do not keep every pair's lattice resident
+  uint64_t resident_bytes = 0;     // --disk-cache-bufsize=SIZE[K|M|G]: how much lattice memory may be resident at a time (0: 64 GB)
   bool matrix_fb = false;          // --matrix-fb (carmel.cc:238)
   bool gpu_compose = false;        // --gpu-compose: the product construction of the composition on the GPU (compose.hip)
   // prior-scale inference (carmel.cc:291-294, 497; gibbs.hpp:525-563)
@@ -194,10 +196,21 @@ static Options parse_args(int argc, char** argv) {
         o.init_from_p0 = true;
       else if (k == "gpu-compose")
         o.gpu_compose = true;
-      else if (k == "disk-cache-derivations" || k == "disk-cache-bufsize") {
-        // carmel.cc:243-246, fst.h:1057-1076: where the reference keeps cached derivations when they outgrow memory.  Here
-        // they are built once and live in HBM (288 GB per GPU); the option changes nothing about the results
-        std::cerr << "option " << k << " = " << v << ": derivations are cached in GPU memory, no disk cache is created\n";
+      else if (k == "disk-cache-derivations") {
+        // carmel.cc:243-246, fst.h:1057-1076: the reference spills its derivation cache to disk when it outgrows memory (and
+        // without -? rebuilds every pair's derivations in every iteration, cached_derivs.h:60-101).  Here: when the lattices of
+        // the corpus would take more than --disk-cache-bufsize of GPU memory they are NOT kept resident -- every iteration walks
+        // the corpus in shards, each shard's lattices rebuilt on the GPU (0.15 s per million pairs), swept and dropped, the
+        // shards' counts added up on the device (carmel_hip_accumulate_counts).  No file is created; same results.
+        o.stream_lattices = true;
+      } else if (k == "disk-cache-bufsize") {
+        char* end = nullptr;
+        double x = std::strtod(v.c_str(), &end);
+        if (end && (*end == 'K' || *end == 'k')) x *= 1024.0;
+        else if (end && (*end == 'M' || *end == 'm')) x *= 1024.0 * 1024.0;
+        else if (end && (*end == 'G' || *end == 'g')) x *= 1024.0 * 1024.0 * 1024.0;
+        if (!(x > 0)) throw UsageError("--disk-cache-bufsize needs a positive size (bytes; K, M, G suffixes)");
+        o.resident_bytes = (uint64_t)x;
       } else if (k == "matrix-fb") {
         // carmel.cc:238, train.cc:254-266, 698-860: forward/backward over the dense (input position x output position x
         // state) matrix instead of derivation lattices (carmel_hip_set_matrix_fb, csrc/matrix_fb.hip)
@@ -651,8 +664,37 @@ static int run(int argc, char** argv) {
     carmel_hip_comm*& c;
     ~CommGuard() { carmel_hip_comm_destroy(c); }
   } comm_guard{comm};
+  // --disk-cache-derivations with lattices beyond --disk-cache-bufsize: the corpus in shards of pairs [stream_cut[k], stream_cut[k+1]),
+  // never more than one shard's lattices resident (set by train_em; empty: everything is resident)
+  std::vector<size_t> stream_cut;
+  bool stream_prune = true;
+  auto set_corpus_range = [&](size_t lo, size_t hi) {
+    std::vector<uint64_t> io(1, 0), oo(1, 0);
+    for (size_t p = lo; p < hi; ++p) {
+      io.push_back(pairs.in_off[p + 1] - pairs.in_off[lo]);
+      oo.push_back(pairs.out_off[p + 1] - pairs.out_off[lo]);
+    }
+    hip_check(carmel_hip_set_corpus(t, hi - lo, io.data(), pairs.in_sym.data() + pairs.in_off[lo], oo.data(),
+                                    pairs.out_sym.data() + pairs.out_off[lo], pairs.weight.data() + lo),
+              "carmel_hip_set_corpus");
+  };
   // one E-step over the whole corpus: the count pass on this rank's shard, then (N > 1) the sum over the ranks
   auto estimate_all = [&](carmel_hip_estimate_result* er) {
+    if (stream_cut.size() > 2) {
+      // shard by shard: lattices rebuilt, swept, dropped; the count buffers (counts + corpus scalars) added up on the device
+      hip_check(carmel_hip_accumulate_counts(t, 0), "carmel_hip_accumulate_counts");
+      for (size_t k = 0; k + 1 < stream_cut.size(); ++k) {
+        set_corpus_range(stream_cut[k], stream_cut[k + 1]);
+        hip_check(carmel_hip_build_lattices(t, stream_prune ? 1 : 0, 0, nullptr, nullptr), "carmel_hip_build_lattices");
+        carmel_hip_estimate_result part;
+        hip_check(carmel_hip_estimate(t, &part, 0), "carmel_hip_estimate");
+        hip_check(carmel_hip_accumulate_counts(t, 1), "carmel_hip_accumulate_counts");
+      }
+      hip_check(carmel_hip_accumulate_counts(t, 2), "carmel_hip_accumulate_counts");
+      if (comm) hip_check(carmel_hip_allreduce_counts(t, comm), "carmel_hip_allreduce_counts");
+      hip_check(carmel_hip_read_scalars(t, er), "carmel_hip_read_scalars");
+      return;
+    }
     if (!comm) {
       hip_check(carmel_hip_estimate(t, er, 0), "carmel_hip_estimate");
       return;
@@ -748,12 +790,67 @@ static int run(int argc, char** argv) {
   auto train_em = [&](const Options& o) {
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
-  hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+  stream_cut.clear();
+  stream_prune = !o.cache_no_prune;
+  const bool may_stream = o.stream_lattices && !o.crp && !o.matrix_fb && pairs.size() > 1;  // (--matrix-fb keeps no lattices)
+  if (may_stream) {
+    // how much GPU memory do this corpus' lattices take?  A probe of its first pairs says (explicit lattices: the shards' count
+    // buffers must mean the same thing, carmel_hip_accumulate_counts)
+    hip_check(carmel_hip_set_layout_policy(t, 0), "carmel_hip_set_layout_policy");
+    const size_t n = pairs.size(), probe = std::min<size_t>(n, 16384);
+    set_corpus_range(0, probe);
+    carmel_hip_lattice_stats ps;
+    hip_check(carmel_hip_build_lattices(t, stream_prune ? 1 : 0, 0, nullptr, &ps), "carmel_hip_build_lattices");
+    const double per_pair = (double)ps.device_bytes / (double)probe;
+    const double cap = o.resident_bytes ? (double)o.resident_bytes : 64.0 * 1024 * 1024 * 1024;
+    if (per_pair * (double)n > cap) {
+      const size_t per_shard = std::max<size_t>(64, (size_t)(cap / std::max(per_pair, 1.0)));
+      for (size_t lo = 0; lo < n; lo += per_shard) stream_cut.push_back(lo);
+      stream_cut.push_back(n);
+      if (!quiet)
+        std::cerr << "Derivation lattices of " << n << " pairs would take about " << (uint64_t)(per_pair * (double)n) << " bytes of GPU memory; with "
+                  << (uint64_t)cap << " allowed they are rebuilt every iteration in " << stream_cut.size() - 1 << " shards of " << per_shard << " pairs\n";
+    }
+  }
+  if (stream_cut.size() > 2) {
+    // first pass: which pairs have a derivation, and the statistics of all shards
+    std::memset(&ls, 0, sizeof ls);
+    for (size_t k = 0; k + 1 < stream_cut.size(); ++k) {
+      set_corpus_range(stream_cut[k], stream_cut[k + 1]);
+      carmel_hip_lattice_stats ps;
+      hip_check(carmel_hip_build_lattices(t, stream_prune ? 1 : 0, 0, has.data() + stream_cut[k], &ps), "carmel_hip_build_lattices");
+      ls.n_pairs += ps.n_pairs;
+      ls.n_pairs_kept += ps.n_pairs_kept;
+      ls.explored_states += ps.explored_states;
+      ls.explored_arcs += ps.explored_arcs;
+      ls.kept_states += ps.kept_states;
+      ls.kept_arcs += ps.kept_arcs;
+      ls.n_cyclic_pairs += ps.n_cyclic_pairs;
+      ls.n_bundles += ps.n_bundles;
+      ls.max_levels = std::max(ls.max_levels, ps.max_levels);
+      ls.device_bytes = std::max(ls.device_bytes, ps.device_bytes);
+      ls.build_seconds += ps.build_seconds;
+      ls.last_pair_explored_states = ps.last_pair_explored_states;
+      if (ps.n_pairs_kept) {
+        ls.last_pair_kept_states = ps.last_pair_kept_states;
+        ls.last_pair_kept_arcs = ps.last_pair_kept_arcs;
+      }
+      ls.n_windowed_pairs += ps.n_windowed_pairs;
+    }
+  } else {
+    if (may_stream) {  // (the probe left its own corpus and layout policy behind)
+      hip_check(carmel_hip_set_layout_policy(t, 1), "carmel_hip_set_layout_policy");
+      hip_check(carmel_hip_set_corpus(t, pairs.size(), pairs.in_off.data(), pairs.in_sym.data(), pairs.out_off.data(),
+                                      pairs.out_sym.data(), pairs.weight.data()),
+                "carmel_hip_set_corpus");
+    }
+    hip_check(carmel_hip_build_lattices(t, o.cache_no_prune ? 0 : 1, 0, has.data(), &ls), "carmel_hip_build_lattices");
+  }
   if (std::getenv("CARMEL_TIMING"))
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (carmel_hip_lattice_layout(t) == 2 ? "unrolled_dense" : carmel_hip_lattice_layout(t) == 1 ? "unrolled" : "explicit") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
-  if (comm && !o.crp) {
+  if (comm && !o.crp && stream_cut.size() <= 2) {
     // every rank must hold its lattices in the same layout (a shard with one over-long pair would keep explicit lattices
     // while the others unroll, and the count buffers being summed would mean different things): agree, or rebuild all
     // with explicit lattices; then plan the exchange (sharded where the model allows it, csrc/exchange.cpp)
@@ -771,7 +868,9 @@ static int run(int argc, char** argv) {
   }
   // (after --matrix-fb: the matrix E-step leaves no arc-range-ordered count pass to hang reduce-scatters on, so its exchange is
   // planned as the one all-reduce; csrc/exchange.cpp)
-  if (comm && !o.crp) hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
+  // (streamed lattices: every shard has its own buckets, so the exchange stays the plain all-reduce of the summed buffer)
+  if (comm && !o.crp && stream_cut.size() <= 2)
+    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {

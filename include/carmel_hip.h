@@ -165,6 +165,14 @@ int carmel_hip_last_sweep_ms(carmel_hip_trainer* t, double* ms);
 int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* res);
 int carmel_hip_get_counts(carmel_hip_trainer* t, double* counts /* n_arcs, linear */);
 int carmel_hip_set_counts(carmel_hip_trainer* t, const double* counts /* n_arcs, linear */);
+/* Corpora whose derivation lattices are not kept resident all at once (the reference without -? rebuilds every pair's derivations
+ * in every iteration, cached_derivs.h:60-101, and spills its cache to disk when it outgrows memory, fst.h:1057-1076,
+ * --disk-cache-derivations): the caller walks the corpus in shards -- carmel_hip_set_corpus + carmel_hip_build_lattices +
+ * carmel_hip_estimate per shard -- and adds the shards' count buffers (n_arcs counts + the four corpus scalars) up on the
+ * device: op 0 clears the accumulator, op 1 adds the trainer's count buffer to it (after a shard's estimate), op 2 writes the
+ * sums back into the count buffer, where carmel_hip_read_scalars / _get_counts / _maximize find the whole corpus.  Explicit
+ * lattices only (carmel_hip_set_layout_policy(t, 0): the unrolled layouts keep per-parameter sums). */
+int carmel_hip_accumulate_counts(carmel_hip_trainer* t, int op);
 
 /* Replaces: forward_backward::maximize (train.cc:893-923): prep_new_weights (:134-153), cascade.use_counts
  * (distribute_counts cascade.h:318-325 + normalize fst.cc:86-244), overrelax (:157-171, delta_scale > 1 only for

@@ -593,6 +593,34 @@ def test_prior_counts_from_weights_on_a_cascade(golden_dir, tmp_path):
                   _sub(tmp_path, str(k)), trained=("cipher.wfsa", "cipher.fst"), env=env)
 
 
+@pytest.mark.parametrize("args", [["-t", "-M", "5", "train.a.w.corpus100", "train.a.w"],
+                                  ["--train-cascade", "-HJ", "-M", "3", "tagging.data", "tagging.fsa", "tagging.fst"]])
+def test_lattices_beyond_the_resident_budget_are_streamed(golden_dir, tmp_path, args):
+    """--disk-cache-derivations (carmel.cc:243-246; fst.h:1057-1076, cached_derivs.h:60-101): when the corpus' lattices would take
+    more GPU memory than --disk-cache-bufsize allows they are not kept resident -- every iteration rebuilds, sweeps and drops
+    them shard by shard (64 pairs a shard here: 2 and 16 shards) and adds the shards' counts up on the device
+    (carmel_hip_accumulate_counts).  The run is the resident run: the same log lines and trained transducers to rounding."""
+    import re
+    full = [os.path.join(golden_dir, a) if os.path.exists(os.path.join(golden_dir, a)) else a for a in args]
+    outs = []
+    for extra in ([], ["--disk-cache-derivations=/tmp/carmel.XXXXXX", "--disk-cache-bufsize=1K"]):
+        d = tmp_path / ("s%d" % len(extra))
+        d.mkdir()
+        rc, out, err = run(extra + full, env=dict(os.environ, CARMEL_TRAINED_DIR=str(d)))
+        assert rc == 0, err
+        if extra:
+            m = re.search(r"rebuilt every iteration in (\d+) shards of 64 pairs", err)
+            assert m and int(m.group(1)) >= 2, err
+        trained = "".join(open(str(d / f)).read() for f in sorted(os.listdir(str(d))))
+        outs.append(([l for l in err.split("\n") if l.startswith("i=")], trained))
+    assert len(outs[0][0]) == len(outs[1][0]) >= 2
+    num = re.compile(r"(?<![\w\"])(\d+\.\d+(?:e[-+]\d+)?|\d+e[-+]\d+)(?![\w\"])")
+    for a, b in zip(outs[0][0] + outs[0][1].split("\n"), outs[1][0] + outs[1][1].split("\n")):
+        assert num.sub("#", a) == num.sub("#", b), (a, b)
+        for u, v in zip(num.findall(a), num.findall(b)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
+
+
 def test_single_iteration_with_restarts_runs_the_restart_loop(golden_dir, tmp_path):
     """-M 1 -! 2: the one-iteration shortcut is taken only without random restarts (train.cc:520)"""
     g = lambda n: os.path.join(golden_dir, n)
