@@ -12,6 +12,7 @@
 #include <unordered_map>
 #include <vector>
 #include "engine.hpp"
+#include "host/refhash.hpp"
 #include "rng.hpp"
 #include "unrolled_args.hpp"
 
@@ -156,6 +157,11 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
       (void)hipStreamDestroy(t->cstream[k]);
     }
     if (t->cev[k]) (void)hipEventDestroy(t->cev[k]);
+    if (k == 0) {
+      for (hipEvent_t e : t->ev_piece)
+        if (e) (void)hipEventDestroy(e);
+      t->ev_piece.clear();
+    }
   }
   hipStream_t s = t->stream, s2 = t->side;
   delete t;
@@ -516,6 +522,30 @@ static int build_norm_groups(carmel_hip_trainer* t, uint64_t n, const uint32_t* 
       norm_of[k] = id;
     } else
       norm_of[k] = it->second;
+  }
+  {
+    // The reference numbers a CONDITIONAL member's groups state after state, and within a state in the order its walk over the
+    // state's symbol index visits the input symbols (fst.h:1362-1446; host/refhash.hpp replays the index: a table made for the
+    // state's arc count, one insert per arc in list order).  The ids above are first-seen ids -- what the M-step kernels use --;
+    // whoever has to talk about groups in the reference's numbering (the sampler's prior-scale groups) gets the rank here.
+    t->h_group_ref_rank.assign(add.size(), 0u);
+    std::vector<uint32_t> next_rank;  // per member
+    uint64_t k = 0;
+    std::vector<uint32_t> syms;
+    while (k < n) {
+      const uint32_t m = member ? member[k] : 0;
+      uint64_t e = k;
+      while (e < n && (member ? member[e] : 0) == m && src[e] == src[k]) ++e;  // the arcs of one state (the tables are state-major)
+      if (method[m] == CARMEL_HIP_NORM_CONDITIONAL) {
+        if (next_rank.size() <= m) next_rank.resize((size_t)m + 1, 0u);
+        syms.assign(in + k, in + e);
+        for (uint32_t sym : carmel_host::conditional_group_order(syms)) {
+          const uint64_t key = ((uint64_t)m << 56) | ((uint64_t)sym << 32) | src[k];
+          t->h_group_ref_rank[ids[key]] = next_rank[m]++;
+        }
+      }
+      k = e;
+    }
   }
   t->n_norm_groups = add.size();
   t->h_norm_of = norm_of;
@@ -974,7 +1004,32 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     for (auto& lc : t->lat.classes) HIPCHK(launch_sweep(A, lc, t->bstream));
     HIPCHK(hipEventRecord(t->ev_b1, t->bstream));
   }
-  if (side_by_side) {
+  if (side_by_side && t->lat.lane_fused) {
+    // Fused-lane layout: the pieces' weights go to lattice order on one stream, piece after piece, and the pieces' sweeps follow
+    // on another, each behind its own piece's weights -- while piece k is swept (a stream of records, weights and posteriors:
+    // bound by HBM bandwidth) the weights of piece k + 1 are gathered out of X (bound by the rate of scattered line requests):
+    // two kernels that want different things of the memory system, side by side.  (Measured on c4a: every piece on a stream
+    // of its own makes the pieces' tile kernels run beside EACH OTHER, then their sweeps beside each other -- nothing gained.)
+    // (the sweeps stay on the trainer's stream, the weights go ahead on the side stream: two streams that are known to sit on
+    // different hardware queues -- two of the chunk streams were seen to share one, which serialises them)
+    HIPCHK(hipEventRecord(t->ev_w, s));
+    hipStream_t ps = t->side, ss = s;
+    HIPCHK(hipStreamWaitEvent(ps, t->ev_w, 0));
+    const size_t np = t->lat.lane_classes.size();
+    while (t->ev_piece.size() < np) {
+      hipEvent_t e = nullptr;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      t->ev_piece.push_back(e);
+    }
+    for (size_t k = 0; k < np; ++k) {
+      const auto& lc = t->lat.lane_classes[k];
+      HIPCHK(launch_trans_w_tiles(T, lc.tile_first, lc.tile_count, ps));
+      HIPCHK(hipEventRecord(t->ev_piece[k], ps));
+      HIPCHK(hipStreamWaitEvent(ss, t->ev_piece[k], 0));
+      HIPCHK(launch_lane_sweep(LA, lc, ss, lane_fused));
+      if (!lane_fused) HIPCHK(launch_trans_c_tiles(T, lc.tile_first, lc.tile_count, ss));
+    }
+  } else if (side_by_side) {
     // chunk k: weights of its tiles to lattice order -> its sweep -> its posteriors out to X, on stream k mod 4.  The
     // kernels of different chunks overlap: a workgroup of the tile passes holds a whole CU's LDS and alternates between
     // a load phase and a store phase, the sweep is a stream of many light waves -- side by side they fill each other's

@@ -61,6 +61,7 @@ struct carmel_hip_trainer {
   static const int N_CHUNK_STREAMS = 4;
   hipStream_t cstream[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t cev[N_CHUNK_STREAMS] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_piece;  // fused-lane layout: "the weights of lane piece k are in lattice order" (created on demand)
   hipEvent_t ev_w = nullptr;
   hipStream_t bstream = nullptr;  // the bundle sweeps (they gather their weights themselves) run beside the lane pieces
   hipEvent_t ev_b0 = nullptr, ev_b1 = nullptr;
@@ -97,6 +98,8 @@ struct carmel_hip_trainer {
   std::vector<uint32_t> h_group_member, h_tie_member;  // member transducer of every norm group / tie
   std::vector<uint32_t> h_group_src;    // source state (in its member) of every norm group
   std::vector<uint8_t> h_group_joint;   // 1 if the group's member normalises JOINT (one group per state)
+  std::vector<uint32_t> h_group_ref_rank;  // CONDITIONAL groups: the group's place among its member's groups in the order the
+                                           // reference enumerates them (NormGroupIter over State::index: host/refhash.hpp)
   DevBuf<double> arc_prior_w;           // cascade + carmel -U: initial weight of every composed arc (added to -f)
   std::vector<double> h_arc_prior_w;
   DevBuf<double> u_param_wprior;        // ... summed per parameter for the unrolled sweep

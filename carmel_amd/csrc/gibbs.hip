@@ -988,7 +988,7 @@ int carmel_hip_gibbs_set_prior_inference(carmel_hip_gibbs* g, double stddev, int
         for (size_t k = n; k < e; ++k) refid[k] = base + t->h_group_src[k];
         ref_member.insert(ref_member.end(), states[m], m);
       } else {
-        for (size_t k = n; k < e; ++k) refid[k] = base + (uint32_t)(k - n);
+        for (size_t k = n; k < e; ++k) refid[k] = base + t->h_group_ref_rank[k];  // (the walk order of State::index: engine.cpp)
         ref_member.insert(ref_member.end(), e - n, m);
       }
       n = e;

@@ -37,6 +37,7 @@
 #include "../../../include/carmel_hip.h"
 #include "compose.hpp"
 #include "fem_export.hpp"
+#include "refhash.hpp"
 #include "wfst.hpp"
 
 using namespace carmel_host;
@@ -1461,22 +1462,22 @@ static int run(int argc, char** argv) {
       for (size_t i = 0; i < mem.size(); ++i) {
         of << "\n";
         const Transducer& m = *mem[i];
+        // cascade.h:99-115 over NormGroupIter (fst.h:1362-1446): JOINT -- a group per state, arcs or not, arcs in list order;
+        // CONDITIONAL -- per state the input symbols in the order the walk over State::index visits them (refhash.hpp), a
+        // symbol's arcs in reversed list order (state.h:158-199 pushes each onto the front of its symbol's list)
         for (uint32_t s = 0; s < m.states.size(); ++s) {
           const auto& arcs = m.states[s];
-          if (norms[i] == CARMEL_HIP_NORM_JOINT && !arcs.empty()) {
+          if (norms[i] == CARMEL_HIP_NORM_JOINT) {
             of << '(';
             for (size_t k = 0; k < arcs.size(); ++k) of << ' ' << id0 + k;
             of << " )\n";
-          } else if (norms[i] == CARMEL_HIP_NORM_CONDITIONAL) {
-            std::vector<char> done(arcs.size(), 0);
-            for (size_t k = 0; k < arcs.size(); ++k) {
-              if (done[k]) continue;
+          } else if (norms[i] == CARMEL_HIP_NORM_CONDITIONAL && !arcs.empty()) {
+            std::vector<uint32_t> syms;
+            for (auto& a : arcs) syms.push_back(a.in);
+            for (uint32_t sym : carmel_host::conditional_group_order(syms)) {
               of << '(';
-              for (size_t j = k; j < arcs.size(); ++j)
-                if (arcs[j].in == arcs[k].in) {
-                  done[j] = 1;
-                  of << ' ' << id0 + j;
-                }
+              for (size_t j = arcs.size(); j-- > 0;)
+                if (arcs[j].in == sym) of << ' ' << id0 + j;
               of << " )\n";
             }
           }

@@ -14,6 +14,7 @@
 //                              precision -- the reference asks boost for 8 digits, digamma.hpp:24-30)
 #pragma once
 #include "lw.hpp"
+#include "refhash.hpp"
 #include <vector>
 #include <string>
 #include <unordered_map>
@@ -552,11 +553,12 @@ struct Wfst {
     }
   }
 
-  // Norm groups in NormGroupIter order (fst.h:1362-1446). JOINT: one group per state, arcs in list order.
-  // CONDITIONAL: per state, one group per input symbol; the reference walks a HashTable (bucket order) whose
-  // per-key lists were built with push_front (state.h:158-199) => members are in REVERSED arc order.  Group
-  // order within a state only matters for group numbering (Gibbs param ids), not for EM arithmetic; we use
-  // first-seen order and say so.
+  // Norm groups in NormGroupIter order (fst.h:1362-1446). JOINT: one group per state (arcs or not), arcs in list order.
+  // CONDITIONAL: per state that has arcs, one group per input symbol, in the order the reference's walk over State::index
+  // visits the symbols -- a HashTable<UnsignedKey, List<HalfArc>> made for `size` entries and filled arc by arc in list order
+  // (state.h:158-199; refhash.hpp restates the table's bucket order) -- and within a group the arcs in REVERSED list order
+  // (every arc is pushed onto the front of its symbol's list).  The order matters for group NUMBERING only: the norm ids of the
+  // Gibbs sampler (gibbs.cc:114-186: which prior-scale draw moves which group) and the lines of --fem-norm (cascade.h:85-116).
   template <class F>
   void for_each_norm_group(int group, F f) {
     for (unsigned s = 0; s < num_states(); ++s) {
@@ -567,17 +569,13 @@ struct Wfst {
         f(s, g);
       } else if (group == NORM_CONDITIONAL) {
         if (arcs.empty()) continue;
-        std::vector<unsigned> order;
+        RefHashKeys index((unsigned)arcs.size());
         std::unordered_map<unsigned, std::vector<Arc*> > by_in;
         for (auto& a : arcs) {
-          auto it = by_in.find(a.in);
-          if (it == by_in.end()) {
-            order.push_back(a.in);
-            by_in[a.in].push_back(&a);
-          } else
-            it->second.push_back(&a);
+          index.insert(a.in);
+          by_in[a.in].push_back(&a);
         }
-        for (unsigned k : order) {
+        for (unsigned k : index.keys()) {
           std::vector<Arc*>& g = by_in[k];
           std::reverse(g.begin(), g.end());  // push_front lists
           f(s, g);

@@ -310,7 +310,8 @@ def test_fem_export_bridges_to_forest_em(golden_dir, tmp_path, oracle):
     assert open(F).read() == oracle.fem_export(oc, corp, 0, "NC", [1e5, 1e-2])
     assert open(A).read() == oracle.fem_export(oc, corp, 3, "NC", [1e5, 1e-2])
     groups = lambda txt: sorted(tuple(sorted(int(x) for x in grp.split())) for grp in re.findall(r"\(([\d ]+)\)", txt))
-    assert groups(open(N).read()) == groups(oracle.fem_export(oc, corp, 1, "NC", [1e5, 1e-2]))
+    # (round 5: in the reference's ORDER as well -- NormGroupIter's walk over State::index, host/refhash.hpp / oracle/refhash.hpp)
+    assert open(N).read() == oracle.fem_export(oc, corp, 1, "NC", [1e5, 1e-2])
     w = [float(t[2:]) if t.startswith("e^") else (math.log(float(t)) if float(t) > 0 else -math.inf) for t in open(P).read().split()]
     n_par = len(oracle.fem_export(oc, corp, 2).split())
     assert len(w) == n_par
@@ -331,6 +332,40 @@ def test_fem_export_bridges_to_forest_em(golden_dir, tmp_path, oracle):
     of.set_weights(lw)
     avg, _ = of.estimate()[:2]
     assert avg * of.n_forests / math.log(2) == pytest.approx(log2p, rel=1e-5)
+
+
+@pytest.mark.parametrize("seed,normby", [(0, "C"), (1, "C"), (2, "CJ"), (3, "JC"), (4, "CC")])
+def test_fem_norm_lists_the_groups_in_the_reference_order(tmp_path, oracle, seed, normby):
+    """--fem-norm (cascade.h:85-116): the normalisation groups in NormGroupIter's order (fst.h:1362-1446) -- a CONDITIONAL
+    member's groups state after state, a state's input symbols in the order the reference's walk over State::index (a hash table,
+    graehl/shared/2hash.h) visits them, a symbol's arcs newest first; a JOINT member's states one after the other, arcs or not.
+    The front end's file equals the oracle's text character for character on random transducers with up to 70 arcs a state
+    (tables of 4 to 128 buckets, with doublings); tests/test_refhash.py holds the oracle against a third restatement."""
+    from test_refhash import _fst_text
+    rng = np.random.default_rng(300 + seed)
+    texts, files = [], []
+    n_sym = int(rng.integers(3, 30))
+    # first member: random, every state on the path q0 -> q1 -> ... (its first arc); a second member is the identity on the
+    # alphabet (one state, a loop per symbol: the composition is the first member again)
+    text, per_state = _fst_text(rng, int(rng.integers(2, 6)), n_sym=n_sym, max_arcs=int(rng.choice([5, 9, 30, 70])))
+    texts.append(text)
+    if len(normby) > 1:
+        texts.append("F\n" + "".join('(F (F "s%d" "s%d" %.3f))\n' % (k, k, float(rng.uniform(0.1, 1.0))) for k in rng.permutation(n_sym)))
+    for k, tx in enumerate(texts):
+        f = tmp_path / ("m%d.fst" % k)
+        f.write_text(tx)
+        files.append(str(f))
+    path = " ".join('"%s"' % arcs[0] for arcs in per_state[:-1])
+    N = str(tmp_path / "norm")
+    corpus = tmp_path / "corpus"
+    corpus.write_text(path + "\n" + path + "\n")
+    args = (["--train-cascade"] if len(files) > 1 else ["-t"]) + ["-M", "-1", "--normby=" + normby, "--fem-norm=" + N, str(corpus)] + files
+    rc, out, err = run(args, env=dict(os.environ, CARMEL_TRAINED_DIR=str(tmp_path)))
+    assert rc == 0, err
+    oc = oracle.OracleCascade(texts)
+    oc.composed()
+    want = oracle.fem_export(oc, oc.corpus(corpus.read_text()), 1, normby, [0.0] * len(files))
+    assert open(N).read() == want and want.count("(") > 3
 
 
 @pytest.mark.parametrize("seed", range(12))
