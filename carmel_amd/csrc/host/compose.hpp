@@ -10,9 +10,9 @@
 // run_a() is carmel -a (compose.cc:219-313): the 2-state filter that keeps the arcs of the two operands apart -- an arc
 // a:x of A leads to a "mediate" state (A's destination, B's state, x) from which B's x:c arcs leave -- so every composed
 // arc stands for ONE operand arc (chains of length 0 or 1 per composition).  The reference walks A's per-state
-// output-symbol hash table in bucket order there; here the symbols are taken in ascending id order, so composite states
-// may be NUMBERED differently from the reference's (paths, weights and chains are the same; no reference fixture pins the
-// numbering of a -a composition).
+// output-symbol hash table in bucket order there (compose.cc:240-242); so does this one -- refhash.hpp replays the table --,
+// so composite and mediate states get the reference's numbers (no reference fixture holds a -a composition: the restatement
+// is checked against the oracle's and a third model of the table, tests/test_refhash.py).
 //
 // trivial = no --train-cascade (cascade.h:566-592 with `trivial`): composed arcs carry no chains -- an arc built from a
 // pair has no group, an arc copied from one operand arc keeps that arc's own group.
@@ -21,6 +21,7 @@
 #include <map>
 #include "../../../include/carmel_hip.h"
 #include "wfst.hpp"
+#include "refhash.hpp"
 
 namespace carmel_host {
 
@@ -124,8 +125,13 @@ class Composer {
       std::map<uint32_t, std::vector<size_t> > by_out, by_in;
       for (size_t k = la.size(); k-- > 0;) by_out[la[k].out].push_back(k);
       for (size_t k = lb.size(); k-- > 0;) by_in[lb[k].in].push_back(k);
-      for (auto& kv : by_out) {
-        const uint32_t sym = kv.first;
+      // ... and A's output symbols in the order the reference's walk over qa->index visits them (compose.cc:240-242; the
+      // index is State::indexBy(kOutput): a hash table made for the state's arc count, filled arc by arc in list order --
+      // refhash.hpp): the composite and mediate states are numbered as that walk creates them
+      std::vector<uint32_t> outs;
+      for (auto& arc : la) outs.push_back(arc.out);
+      for (uint32_t sym : conditional_group_order(outs)) {
+        auto& kv = *by_out.find(sym);
         if (sym == 0) {
           if (j.f == 0)  // a:*e* of A alone, B stays (filter 0 -> 0)
             for (size_t ka : kv.second) emit(j.id, la[ka].in, 0, la[ka].dest, j.qb, 0, la[ka].logw, lone_chain(A, j.qa, ka));

@@ -6,7 +6,7 @@
 //   compose.cc:163-531  WFST::set_compose (3-state filter :315-498; LIFO queue :193,326-328; arc prepend via
 //                       COMPOSEARC_GROUP :128-141; multiple finals :503-530).  The `-a` 2-state filter
 //                       (:219-313) is compose_a below; the reference walks a HashTable in bucket order there
-//                       (state NUMBERING unpinned -- ascending symbol order here), paths and chains are exact.
+//                       (refhash.hpp restates that order; no fixture of the reference holds a -a result).
 //   compose.h:10-45     TrioKey (qa,qb,filter)
 //   state.h:158-199     indexBy: per-key lists built with push_front => matches come in REVERSED arc order
 //   cascade.h:489-599   record / record1 / record2 / record_eps / cons / cons_chain (chain ids = groupId)
@@ -451,7 +451,12 @@ inline void compose_a(Wfst& out, Cascade& cascade, Wfst& a, Wfst& b) {
     std::map<unsigned, std::vector<Arc*> > aindex, bindex;  // ascending symbol; lists newest first (push_front)
     for (size_t k = qa.size(); k-- > 0;) aindex[qa[k].out].push_back(&qa[k]);
     for (size_t k = qb.size(); k-- > 0;) bindex[qb[k].in].push_back(&qb[k]);
-    for (auto& ll : aindex) {
+    // the walk over qa->index (compose.cc:240-242): A's output symbols in the bucket order of the table State::indexBy(kOutput)
+    // builds -- made for the state's arc count, one insert per arc in list order (refhash.hpp)
+    RefHashKeys walk((unsigned)qa.size());
+    for (auto& arc : qa) walk.insert(arc.out);
+    for (unsigned sym : walk.keys()) {
+      auto& ll = *aindex.find(sym);
       if (ll.first == EPS) {
         if (filter == 0)
           for (Arc* la : ll.second) composearc(source, la->in, EPS, Trio(la->dest, sqb, 0), la->weight, cascade.record1(la));
