@@ -55,7 +55,7 @@ def algorithmic_bytes(lattice_arcs, lattice_states):
     return 48.0 * lattice_arcs + 16.0 * lattice_states
 
 
-ESTEP_KERNELS = ("trans_w_bucket_kernel", "trans_w_tile_kernel", "tile_sweep_kernel", "sweep_lane_kernel", "sweep_bundle_kernel", "sweep_wave_kernel",
+ESTEP_KERNELS = ("trans_w_bucket_kernel", "trans_w_tile_kernel", "trans_w_tile_small_kernel", "trans_c_tile_small_kernel", "tile_sweep_kernel", "sweep_lane_kernel", "sweep_bundle_kernel", "sweep_wave_kernel",
                  "sweep_serial_kernel", "trans_c_tile_kernel", "trans_c_bucket_kernel", "zero_list_kernel",
                  "scalars_partial_kernel", "scalars_final_kernel", "count_reduce_kernel", "count_reduce_hot_kernel")
 
@@ -384,6 +384,10 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
             "roofline": {"bound": "hbm", "kernel": ("E-step = trans_w_bucket + tile_sweep (a tile's weights in, its lane sweeps out of "
                          "LDS, its posteriors out: one persistent kernel) + trans_c_bucket (posteriors to per-arc counts), timed "
                          "together with HIP events on the trainer's stream") if fb.tile_sweep_tiles else
+                         ("E-step = trans_w_bucket + trans_w_tile_small (weights to lattice order, 1024-position tiles) + sweep_lane<XC> "
+                          "(the backward pass stages a tile's posteriors in LDS and writes XC itself: no posterior array, no tile pass "
+                          "back) + trans_c_bucket (posteriors to per-arc counts), timed together with HIP events on the trainer's "
+                          "stream") if fb.fused_lane_tiles else
                          "E-step = trans_w_bucket + trans_w_tile (weights to lattice order) + "
                          "sweep_lane / sweep_wave kernels + trans_c_tile + trans_c_bucket (posteriors to per-arc counts), timed "
                          "together with HIP events on the trainer's stream",
