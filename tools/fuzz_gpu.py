@@ -125,7 +125,74 @@ def main():
             np.testing.assert_allclose(a[1][ok], r["pair_logprob"][ok], rtol=1e-10, atol=1e-10)
             np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=P.RTOL, atol=1e-14)
 
+    def fused_lane_case(d, s, mp=None):
+        """random corpora of one-per-lane lattices beyond the tile sweep (longer walks, clusters that make real sums, windows forced
+        onto small lattices for some seeds, epsilons, dead arcs, per-pair weights, partial groups): sweep_lane_kernel<.., XC> = sweep ->
+        post -> trans_c_tile_small on the same layout, bit for bit; = the 16384-position layout up to the order of the counts' sums;
+        = the oracle"""
+        rng = np.random.default_rng(s)
+        if s % 3 == 0:
+            members = 2 + s % 3
+            ncl = 5 + s % 60
+            w = P.synth.clustered_wfst(members * ncl + 1, members * (2 + s % 3), members=members, seed=s)
+            c = P.synth.clustered_walk_corpus(w, 40 + (s * 17) % 3000, members * (2 + s % 3), members=members, min_arcs=2 + s % 5,
+                                              max_arcs=6 + s % 40, seed=s)
+        else:
+            w = P.synth.random_wfst(20 + s % 400, 2 + s % 5, n_sym=3 + (s // 3) % 8, p_eps=0.03 * (s % 5), seed=s)
+            c = P.synth.random_walk_corpus(w, 40 + (s * 131) % 4000, min_arcs=2 + s % 9, max_arcs=20 + s % 80, seed=s, out_degree=2 + s % 5)
+        c.weight[:] = rng.uniform(0.25, 4.0, c.n_pairs)
+        if s % 4 == 0:
+            w.logw[rng.random(w.n_arcs) < 0.01] = -np.inf
+        mp.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "1e9")
+        if s % 2:
+            mp.setenv("CARMEL_HIP_LANE_WINDOW_MIN", str(8 + s % 30))
+        out = {}
+        for mode in ("fused", "kernels", "layout"):
+            for k in ("CARMEL_HIP_LANE_FUSED_KERNEL", "CARMEL_HIP_LANE_FUSED"):
+                os.environ.pop(k, None)
+            if mode == "kernels":
+                mp.setenv("CARMEL_HIP_LANE_FUSED_KERNEL", "0")
+            if mode == "layout":
+                mp.setenv("CARMEL_HIP_LANE_FUSED", "0")
+            fb = P._fb(w, c)
+            if mode == "fused" and not fb.fused_lane_tiles:
+                fb.close()
+                raise pytest.skip.Exception("not a fused-lane corpus (the tile sweep takes it, or a lattice no lane takes)")
+            lp, _ = fb.estimate(per_pair=True)
+            out[mode] = (lp, fb.pair_logprob.copy(), fb.counts().copy())
+            fb.close()
+        a, b, l = out["fused"], out["kernels"], out["layout"]
+        assert (a[0] == b[0] or (np.isnan(a[0]) and np.isnan(b[0]))) and np.array_equal(a[1], b[1])
+        assert np.allclose(a[2], b[2], rtol=1e-13, atol=0)
+        assert np.array_equal(a[1], l[1]) and np.allclose(a[2], l[2], rtol=1e-12, atol=0)
+        _, _, r = P.oracle_estep(oracle, w, c, normalize=False) if s % 4 == 0 else P.oracle_estep(oracle, w, c)
+        if s % 4 != 0:
+            ok = r["has_deriv"]
+            np.testing.assert_allclose(a[1][ok], r["pair_logprob"][ok], rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(a[2], np.exp(r["counts_ln"]), rtol=P.RTOL, atol=1e-14)
+
+    def chains_case(d, s, mp=None):
+        """--crp-restarts as concurrent chains on random cascades: the oracle's chain run by run, the same kept run"""
+        a, b, corpus_text, normby, priors = G._random_cascade_case(oracle, s)
+        norms = [G.NORM_JOINT if ch == "J" else G.NORM_CONDITIONAL for ch in normby]
+        oc, ocorp, fb = G._setup(oracle, [a, b], corpus_text, norms, priors)
+        from carmel_amd.trainer import HipGibbs
+        iters, burnin, restarts = 3 + s % 4, s % 2, 1 + s % 5
+        mp.setenv("CARMEL_HIP_GIBBS_CHAINS", str([64, 2, 3][s % 3]))
+        gs = HipGibbs(fb, iters, burnin=burnin, seed=s, mode=0, restarts=restarts)
+        got = gs.run()
+        ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby=normby, priors=priors, iters=iters, burnin=burnin, restarts=restarts)
+        np.testing.assert_allclose(got, ref["iter_logprob"], rtol=1e-10)
+        assert gs.best_run == ref["best_run"]
+        for blk in range(gs.n_blocks):
+            assert gs.sample(blk) == ref["samples"][blk]
+        np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-8, atol=1e-14)
+        gs.close()
+        fb.close()
+
     cases += [
+        ("fused lanes", fused_lane_case),
+        ("crp chains", chains_case),
         ("tile sweep", tile_sweep_case),
         ("forest exact chain", forest_exact_case),
         ("matrix fb", lambda d, s: M.test_matrix_estep_against_the_oracle_and_the_lattices(
