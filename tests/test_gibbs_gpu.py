@@ -13,6 +13,17 @@ from carmel_amd.model import NORM_CONDITIONAL, NORM_JOINT, Corpus, Wfst
 pytestmark = pytest.mark.gpu
 
 
+def same_kept_run(got_best, ref, iters, burnin, argmax_final=False, argmax_sum=False):
+    """the run kept by gibbs_base::run_starts (gibbs.hpp:880-914) is the oracle's -- or ties with it: on a corpus whose blocks have
+    one derivation each every run has the same probability, and which of them is `better` by a strict > then hangs on the last
+    bit of a sum (found by tools/fuzz_gpu.py, seeds 9102 and 9119: run 4 one ulp above runs 0-3 on the device, equal in the oracle)"""
+    if got_best == ref["best_run"]:
+        return True
+    lp = np.asarray(ref["iter_logprob"]).reshape(-1, iters + 1)[:, min(burnin, iters):]
+    stat = lp[:, -1] if argmax_final else np.logaddexp.reduce(lp, axis=1) if argmax_sum else lp.sum(axis=1)
+    return abs(stat[got_best] - stat[ref["best_run"]]) <= 1e-12 * abs(stat[ref["best_run"]])
+
+
 def _setup(oracle, texts, corpus_text, norms, priors):
     from carmel_amd.trainer import HipForwardBackward
     oc = oracle.OracleCascade(texts)
@@ -354,8 +365,9 @@ def test_gibbs_prior_scale_inference_follows_the_oracle(oracle, seed):
     for blk in range(gs.n_blocks):
         assert gs.sample(blk) == ref["samples"][blk]
     np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
-    assert gs.best_run == ref["best_run"]
-    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    assert same_kept_run(gs.best_run, ref, iters, burnin)
+    if gs.best_run == ref["best_run"]:
+        np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
     gs.close()
     fb.close()
 
