@@ -246,7 +246,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
             ok = int(flag[0])
         if ok == 1 and not loopback:  # every rank joined: plan, and one exchange end to end before anything is timed
             try:
-                xinfo = fb.exchange_plan(comm, args.exchange_chunks, args.exchange == "allreduce")
+                xinfo = fb.exchange_plan(comm, args.exchange_chunks, form={"sharded": "auto"}.get(args.exchange, args.exchange))
                 fb.estimate_async()
                 fb.allreduce_counts(comm)
             except Exception as e:  # noqa: BLE001
@@ -271,11 +271,18 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
             fb.use_external_counts(ext_counts.data_ptr())
             exchange = "torch.distributed all-reduce of %d f64 counts per iteration (library communicator unavailable), two host synchronisations per step" % (w.n_arcs + 4)
         elif not loopback:
-            exchange = ("%s: reduce-scatter of the counts in %d arc-range chunks beside the count pass (%.1f MB out per rank), M-step on "
-                        "1/%d of the arcs, all-gather of the weights chunk by chunk into the next count pass (%.1f MB), one small "
-                        "all-reduce (%.0f KB)" % (comm.transport, xinfo["n_chunks"], xinfo["bytes_reduce_scatter"] / 1e6, world,
-                                                  xinfo["bytes_all_gather"] / 1e6, xinfo["bytes_all_reduce"] / 1e3)) if xinfo["sharded"] else (
-                        "%s: all-reduce of %d f64 counts per iteration on the trainer's stream, replicated M-step" % (comm.transport, w.n_arcs + 4))
+            if xinfo["form"] == "direct":
+                exchange = ("%s: the counts straight to their owners in %d arc-range chunks beside the count pass (one group of sends / "
+                            "receives per chunk, %.1f MB out per rank, summed in rank order), M-step on 1/%d of the arcs, the weights "
+                            "straight to every peer chunk by chunk into the next count pass (%.1f MB); no small collective"
+                            % (comm.transport, xinfo["n_chunks"], xinfo["bytes_reduce_scatter"] / 1e6, world, xinfo["bytes_all_gather"] / 1e6))
+            elif xinfo["sharded"]:
+                exchange = ("%s: reduce-scatter of the counts in %d arc-range chunks beside the count pass (%.1f MB out per rank), M-step on "
+                            "1/%d of the arcs, all-gather of the weights chunk by chunk into the next count pass (%.1f MB), one small "
+                            "all-reduce (%.0f KB)" % (comm.transport, xinfo["n_chunks"], xinfo["bytes_reduce_scatter"] / 1e6, world,
+                                                      xinfo["bytes_all_gather"] / 1e6, xinfo["bytes_all_reduce"] / 1e3))
+            else:
+                exchange = "%s: all-reduce of %d f64 counts per iteration on the trainer's stream, replicated M-step" % (comm.transport, w.n_arcs + 4)
 
     def step():
         fb.estimate_async()
@@ -322,7 +329,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
             return 1e3 * (time.perf_counter() - t1) / n
         n_x = max(3, min(10, steps))
         if loopback:
-            xinfo = fb.exchange_plan(comm, args.exchange_chunks, args.exchange == "allreduce")
+            xinfo = fb.exchange_plan(comm, args.exchange_chunks, form={"sharded": "auto"}.get(args.exchange, args.exchange))
 
         def with_x():
             fb.estimate_async()
@@ -341,7 +348,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
         tt = torch.tensor([ms_with, ms_without, x_ms], dtype=torch.float64, device=ctl)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        xch = {"world": world, "loopback": bool(loopback), "sharded": xinfo["sharded"], "n_chunks": xinfo["n_chunks"],
+        xch = {"world": world, "loopback": bool(loopback), "sharded": xinfo["sharded"], "form": xinfo["form"], "n_chunks": xinfo["n_chunks"],
                "transport": comm.transport, "exchange_ms": float(tt[2]), "exposed_exchange_ms": max(0.0, float(tt[0]) - float(tt[1])),
                "ms_per_step_with_exchange": float(tt[0]), "ms_per_step_without_exchange": float(tt[1]),
                "bytes_reduce_scatter_per_rank": xinfo["bytes_reduce_scatter"], "bytes_all_gather_per_rank": xinfo["bytes_all_gather"],
@@ -779,7 +786,8 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0)
     ap.add_argument("--comm-plugin", default=None, help="a transport library for the exchange instead of RCCL (carmel_hip_comm_create_custom), "
                     "e.g. tests/native/libhosttransport.so: every rank then runs on GPU 0 (several ranks on a one-GPU box)")
-    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce"], help="form of the count exchange at N > 1")
+    ap.add_argument("--exchange", default="sharded", choices=["sharded", "allreduce", "collectives", "direct"],
+                    help="form of the count exchange at N > 1 (sharded: direct point-to-point groups where the transport has them, else the collectives)")
     ap.add_argument("--exchange-chunks", type=int, default=0, help="arc-range chunks of the sharded exchange (0: the library's default, 4; at most 16)")
     ap.add_argument("--no-exchange-loopback", action="store_true", help="N = 1: skip the loopback measurement of the exchange")
     ap.add_argument("--walk-arcs", default=None, help="min,max arcs of the headline's random walks (default: the config's; other values are experiments)")

@@ -35,7 +35,7 @@ SYMBOLS = [
     "carmel_hip_debug_lattice_fingerprint", "carmel_hip_lattice_layout", "carmel_hip_lattice_tile_sweep", "carmel_hip_lattice_fused_lanes", "carmel_hip_accumulate_counts",
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
-    "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_exchange_plan",
+    "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_comm_set_sendrecv", "carmel_hip_comm_selftest", "carmel_hip_exchange_plan",
     "carmel_hip_exchange_info", "carmel_hip_exchange_measure", "carmel_hip_exchange_clear", "carmel_hip_set_layout_policy", "carmel_hip_set_matrix_fb",
 ]
 
@@ -100,6 +100,8 @@ def _load():
     lib.carmel_hip_comm_transport_name.argtypes = [vp]
     lib.carmel_hip_comm_transport_name.restype = C.c_char_p
     lib.carmel_hip_comm_create_custom.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
+    lib.carmel_hip_comm_set_sendrecv.argtypes = [vp, vp]
+    lib.carmel_hip_comm_selftest.argtypes = [vp, C.c_uint32]
     lib.carmel_hip_exchange_plan.argtypes = [vp, vp, C.c_uint32, C.c_int]
     lib.carmel_hip_exchange_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                              C.POINTER(C.c_uint64)]

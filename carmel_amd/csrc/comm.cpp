@@ -23,6 +23,10 @@ struct Rccl {
   decltype(&ncclReduceScatter) reduce_scatter = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclGetErrorString) error_string = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   std::string err;
   bool load() {
     if (h) return true;
@@ -41,6 +45,10 @@ struct Rccl {
     reduce_scatter = (decltype(reduce_scatter))dlsym(h, "ncclReduceScatter");
     all_gather = (decltype(all_gather))dlsym(h, "ncclAllGather");
     error_string = (decltype(error_string))dlsym(h, "ncclGetErrorString");
+    send = (decltype(send))dlsym(h, "ncclSend");
+    recv = (decltype(recv))dlsym(h, "ncclRecv");
+    group_start = (decltype(group_start))dlsym(h, "ncclGroupStart");
+    group_end = (decltype(group_end))dlsym(h, "ncclGroupEnd");
     if (!get_unique_id || !comm_init_rank || !comm_destroy || !all_reduce || !reduce_scatter || !all_gather) {
       err = "RCCL lacks an expected symbol";
       h = nullptr;
@@ -97,7 +105,76 @@ int comm_all_gather(carmel_hip_comm* c, double* buf, size_t count, hipStream_t s
   return rc ? fail(CARMEL_HIP_ERR_HIP, "ncclAllGather: " + g_rccl.what(rc)) : CARMEL_HIP_OK;
 }
 
+bool comm_has_p2p(const carmel_hip_comm* c) {
+  return c->custom ? c->tr_sendrecv != nullptr : (g_rccl.send && g_rccl.recv && g_rccl.group_start && g_rccl.group_end);
+}
+
+// the exchange's direct form: every transfer of one chunk in one group (RCCL fuses a group's sends and receives into one launch)
+int comm_p2p(carmel_hip_comm* c, const carmel_hip_p2p* ops, uint32_t n_ops, hipStream_t s) {
+  if (!n_ops) return CARMEL_HIP_OK;
+  if (c->custom) {
+    if (!c->tr_sendrecv) return fail(CARMEL_HIP_ERR_UNSUPPORTED, c->what + ": no point-to-point transfers");
+    const int rc = c->tr_sendrecv(c->tr.ctx, ops, n_ops, (void*)s);
+    return rc ? fail(CARMEL_HIP_ERR_HIP, c->what + ": sendrecv failed (" + std::to_string(rc) + ")") : CARMEL_HIP_OK;
+  }
+  ncclResult_t rc = g_rccl.group_start();
+  if (rc) return fail(CARMEL_HIP_ERR_HIP, "ncclGroupStart: " + g_rccl.what(rc));
+  ncclResult_t bad = ncclSuccess;
+  for (uint32_t k = 0; k < n_ops && !bad; ++k) {
+    const carmel_hip_p2p& o = ops[k];
+    bad = o.send ? g_rccl.send(o.dev_buf, o.n, ncclDouble, o.peer, (ncclComm_t)c->rccl, s)
+                 : g_rccl.recv(o.dev_buf, o.n, ncclDouble, o.peer, (ncclComm_t)c->rccl, s);
+  }
+  rc = g_rccl.group_end();  // (always: an open group would swallow every later call)
+  if (bad) return fail(CARMEL_HIP_ERR_HIP, "ncclSend / ncclRecv: " + g_rccl.what(bad));
+  return rc ? fail(CARMEL_HIP_ERR_HIP, "ncclGroupEnd: " + g_rccl.what(rc)) : CARMEL_HIP_OK;
+}
+
 extern "C" {
+
+int carmel_hip_comm_set_sendrecv(carmel_hip_comm* c, carmel_hip_sendrecv_fn fn) {
+  if (!c) return fail(CARMEL_HIP_ERR_ARG, "null communicator");
+  if (!c->custom) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_comm_set_sendrecv: the communicator runs over RCCL");
+  if (!c->planned.empty()) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_comm_set_sendrecv: before any exchange is planned on it");
+  c->tr_sendrecv = fn;
+  return CARMEL_HIP_OK;
+}
+
+// every rank sends every rank (itself included, as RCCL allows inside a group) n doubles of a pattern naming sender and
+// receiver, and checks what arrives: the point-to-point groups of the exchange's direct form on this transport, before a
+// training run depends on them
+int carmel_hip_comm_selftest(carmel_hip_comm* c, uint32_t n) {
+  if (!c) return fail(CARMEL_HIP_ERR_ARG, "null communicator");
+  if (!comm_has_p2p(c)) return fail(CARMEL_HIP_ERR_UNSUPPORTED, c->what + ": no point-to-point transfers");
+  if (!n) n = 1024;
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank;
+  const bool self = !c->custom;  // (a custom transport's contract excludes the caller itself)
+  std::vector<double> h((size_t)2 * W * n, -1.0);
+  for (uint32_t q = 0; q < W; ++q)
+    for (uint32_t i = 0; i < n; ++i) h[(size_t)q * n + i] = (double)me * 1e6 + (double)q * 1e3 + (double)(i % 997);
+  DevBuf<double> d;
+  HIPCHK(d.alloc(h.size()));
+  HIPCHK(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c->xstream));
+  std::vector<carmel_hip_p2p> ops;
+  for (uint32_t q = 0; q < W; ++q) {
+    if (q == me && !self) continue;
+    ops.push_back({(int32_t)q, 1, d.p + (size_t)q * n, n});
+    ops.push_back({(int32_t)q, 0, d.p + (size_t)(W + q) * n, n});
+  }
+  int rc = comm_p2p(c, ops.data(), (uint32_t)ops.size(), c->xstream);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(h.data(), d.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, c->xstream));
+  HIPCHK(hipStreamSynchronize(c->xstream));
+  for (uint32_t q = 0; q < W; ++q) {
+    if (q == me && !self) continue;
+    for (uint32_t i = 0; i < n; ++i)
+      if (h[(size_t)(W + q) * n + i] != (double)q * 1e6 + (double)me * 1e3 + (double)(i % 997))
+        return fail(CARMEL_HIP_ERR_HIP, c->what + ": point-to-point self-test: rank " + std::to_string(me) + " got a wrong value from rank " +
+                                            std::to_string(q) + " at " + std::to_string(i));
+  }
+  return CARMEL_HIP_OK;
+}
 
 int carmel_hip_comm_unique_id(void* id128) {
   if (!id128) return fail(CARMEL_HIP_ERR_ARG, "null argument");

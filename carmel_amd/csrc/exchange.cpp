@@ -22,6 +22,18 @@
 //        order while the last pieces are still on the links.
 //    The largest weight change is a one-double all-reduce (max).
 //
+//  * sharded, DIRECT (the same chunks and pieces; the default where the transport has point-to-point transfers): a ring
+//    reduce-scatter over seven point-to-point xGMI links is bound by one link; here piece j goes STRAIGHT to rank j.
+//      - counts out: as soon as a chunk is summed, every rank sends each peer that peer's piece of it -- extended by
+//        `norm_span` arcs either side, so that a norm group straddling a piece boundary is whole on both sides -- in one
+//        group of sends / receives; what arrives is added up in RANK ORDER (xchg_sum_kernel) into a buffer of its own
+//        (`red`: the unreduced values stay where the later sends read them).  Both owners of a straddling group add the same
+//        numbers in the same order: no small all-reduce.  The arcs after the last whole chunk and the four corpus scalars,
+//        contiguous in the count buffer, go to everybody with the last chunk.
+//      - the M-step on this rank's pieces reads `red`;
+//      - weights in: piece by piece to every peer, one group per chunk; the local largest change rides with the first.
+//    2 K groups per iteration, nothing small in between; with one rank nothing is enqueued at all.
+//
 // Per-link arithmetic for 8 GPUs is in DESIGN.md section 5.
 #include <algorithm>
 #include <chrono>
@@ -33,6 +45,8 @@ static const int XCH_MAX_CHUNKS = MSTEP_MAX_RANGES - 1;
 struct ExchangePlan {
   carmel_hip_comm* comm = nullptr;
   bool sharded = false;
+  bool m_ready = false;
+  bool direct = false;               // the sharded exchange's direct form (point-to-point groups) instead of the collectives
   uint32_t K = 0, N = 1, rank = 0;
   uint64_t n_arcs = 0;
   std::vector<uint64_t> A;           // K + 1 chunk boundaries, multiples of N * 256; A[K] <= n_arcs
@@ -51,6 +65,21 @@ struct ExchangePlan {
   bool ag_pending = false;      // all-gathers of the weights enqueued, the main stream has not yet waited for them
   unsigned long long* h_max = nullptr;  // pinned
   uint64_t bytes_rs = 0, bytes_ag = 0, bytes_small = 0;
+  // ---- direct form ----
+  uint32_t span = 0;
+  std::vector<uint32_t> cbx_end;     // after buckets [0, cbx_end[k]) every arc below A[k + 1] + span is summed
+  uint64_t tail_lo = 0;              // [tail_lo, n_arcs + 4): the last span arcs of the chunks, the arcs after them, the scalars
+  uint64_t stride = 0, tail_n = 0;   // staging: peer slot q' (q' = q below rank ? q : q - 1) at stage[q' * stride], its tail at
+  DevBuf<double> red, stage, fin;    //   stage[(N - 1) * stride + q' * tail_n]; fin: the ranks' largest weight changes
+  std::vector<std::vector<carmel_hip_p2p>> ops_x, ops_g;  // per chunk: counts out / weights in
+  std::vector<carmel_hip_p2p> ops_cg;                     // the reduced count pieces to everybody (exchange_settle)
+  uint64_t piece(uint32_t k) const { return (A[k + 1] - A[k]) / N; }
+  uint64_t ext_lo(uint32_t k, uint32_t j) const {
+    const uint64_t b = A[k] + (uint64_t)j * piece(k);
+    return b > span ? b - span : 0;
+  }
+  uint64_t ext_hi(uint32_t k, uint32_t j) const { return std::min<uint64_t>(A[k] + (uint64_t)(j + 1) * piece(k) + span, n_arcs); }
+  const double* reduced(const carmel_hip_trainer* t) const;
 };
 
 static void plan_free(ExchangePlan* xp) {
@@ -84,16 +113,67 @@ void exchange_comm_gone(carmel_hip_comm* c) {
   c->planned.clear();
 }
 
+// ---- direct form: the sums of what the peers sent ----
+// out[i] = v_0[i] + v_1[i] + ... in rank order, v_rank = own (this rank's unreduced values), the others from their staging
+// slots: the order every rank uses, so two ranks that both need an arc (a norm group across a piece boundary) hold the same bits
+__global__ __launch_bounds__(256) void xchg_sum_kernel(double* __restrict__ out, const double* __restrict__ own,
+                                                       const double* __restrict__ stage, uint64_t n, uint64_t stride, uint32_t N,
+                                                       uint32_t rank) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    double v = 0.0;
+    for (uint32_t q = 0; q < N; ++q) {
+      const double x = q == rank ? own[i] : stage[(uint64_t)(q < rank ? q : q - 1) * stride + i];
+      v = q ? v + x : x;
+    }
+    out[i] = v;
+  }
+}
+// the largest weight change over the ranks (non-negative doubles order like their bit patterns)
+__global__ void xchg_max_kernel(unsigned long long* bits, const unsigned long long* fin, uint32_t N, uint32_t rank) {
+  unsigned long long m = *bits;
+  for (uint32_t q = 0; q < N; ++q)
+    if (q != rank && fin[q] > m) m = fin[q];
+  *bits = m;
+}
+static hipError_t launch_xchg_sum(double* out, const double* own, const double* stage, uint64_t n, uint64_t stride, uint32_t N,
+                                  uint32_t rank, hipStream_t s) {
+  if (!n) return hipSuccess;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(xchg_sum_kernel, dim3(grid), dim3(256), 0, s, out, own, stage, n, stride, N, rank);
+  return hipGetLastError();
+}
+const double* ExchangePlan::reduced(const carmel_hip_trainer* t) const {
+  return (direct && N > 1) ? red.p : const_cast<carmel_hip_trainer*>(t)->counts_ptr();
+}
+
+// chunk k's counts to their owners and the owners' sums, on the communicator's stream (which already waits for the chunk)
+static int direct_counts_chunk(carmel_hip_trainer* t, ExchangePlan* xp, uint32_t k) {
+  if (xp->N == 1) return CARMEL_HIP_OK;
+  hipStream_t x = xp->comm->xstream;
+  const double* counts = t->counts_ptr();
+  int rc = comm_p2p(xp->comm, xp->ops_x[k].data(), (uint32_t)xp->ops_x[k].size(), x);
+  if (rc) return rc;
+  const uint64_t lo = xp->ext_lo(k, xp->rank), hi = xp->ext_hi(k, xp->rank);
+  HIPCHK(launch_xchg_sum(xp->red.p + lo, counts + lo, xp->stage.p, hi - lo, xp->stride, xp->N, xp->rank, x));
+  if (k + 1 == xp->K) {  // the tail and the scalars: everybody's, summed by everybody
+    HIPCHK(launch_xchg_sum(xp->red.p + xp->tail_lo, counts + xp->tail_lo, xp->stage.p + (uint64_t)(xp->N - 1) * xp->stride, xp->tail_n,
+                           xp->tail_n, xp->N, xp->rank, x));
+    HIPCHK(hipMemcpyAsync(t->counts_ptr() + xp->n_arcs, xp->red.p + xp->n_arcs, 4 * sizeof(double), hipMemcpyDeviceToDevice, x));
+  }
+  return CARMEL_HIP_OK;
+}
+
 // ---- weights in: trans_w_bucket chunk by chunk behind the all-gathers of the previous M-step ----
 int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T) {
   hipStream_t s = t->stream;
   uint32_t done = 0;
   for (uint32_t k = 0; k < xp->K; ++k) {
-    if (xp->ag_pending) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag[k], 0));
+    // (a chunk that has already arrived needs no barrier packet in the queue: small models, one rank)
+    if (xp->ag_pending && hipEventQuery(xp->ev_ag[k]) != hipSuccess) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag[k], 0));
     if (xp->wb_end[k] > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->wb_end[k] - done, s));
     done = std::max(done, xp->wb_end[k]);
   }
-  if (xp->ag_pending) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag_done, 0));
+  if (xp->ag_pending && hipEventQuery(xp->ev_ag_done) != hipSuccess) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag_done, 0));
   xp->ag_pending = false;
   if (xp->n_buckets > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->n_buckets - done, s));
   return CARMEL_HIP_OK;
@@ -108,6 +188,21 @@ int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs
   // interleaved, the count pass would wait for the host), then the collectives on the communicator's stream, each behind
   // its chunk's event
   uint32_t done = 0, hdone = 0;
+  if (xp->direct) {
+    for (uint32_t k = 0; k < xp->K; ++k) {
+      if (xp->cbx_end[k] > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->cbx_end[k] - done, s));
+      done = std::max(done, xp->cbx_end[k]);
+      if (k + 1 < xp->K) HIPCHK(hipEventRecord(xp->ev_chunk[k], s));
+    }
+    if (xp->n_buckets > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->n_buckets - done, s));
+    for (uint32_t k = 0; k + 1 < xp->K; ++k) {  // (the last chunk carries the scalars: exchange_counts_tail)
+      HIPCHK(hipStreamWaitEvent(x, xp->ev_chunk[k], 0));
+      int rc = direct_counts_chunk(t, xp, k);
+      if (rc) return rc;
+    }
+    xp->counts_pending = true;
+    return CARMEL_HIP_OK;
+  }
   for (uint32_t k = 0; k < xp->K; ++k) {
     if (xp->cb_end[k] > done) HIPCHK(launch_trans_c_bucket_range(T, done, xp->cb_end[k] - done, s));
     done = std::max(done, xp->cb_end[k]);
@@ -131,6 +226,14 @@ int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs
 // arcs in one small all-reduce
 int exchange_counts_tail(carmel_hip_trainer* t, ExchangePlan* xp) {
   hipStream_t s = t->stream, x = xp->comm->xstream;
+  if (xp->direct) {
+    HIPCHK(hipEventRecord(xp->ev_tail, s));
+    HIPCHK(hipStreamWaitEvent(x, xp->ev_tail, 0));
+    int rc = direct_counts_chunk(t, xp, xp->K - 1);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(xp->ev_rs_done, x));
+    return CARMEL_HIP_OK;
+  }
   const uint32_t hdone = xp->K ? xp->halo_end[xp->K - 1] : 0u;
   if (xp->n_small > hdone)
     HIPCHK(launch_gather_idx(xp->small.p + hdone, t->counts_ptr(), xp->halo_idx.p + hdone, xp->n_small - hdone, s));
@@ -147,7 +250,7 @@ static int exchange_counts_arrive(carmel_hip_trainer* t, ExchangePlan* xp) {
   if (!xp->counts_pending) return CARMEL_HIP_OK;
   hipStream_t s = t->stream;
   HIPCHK(hipStreamWaitEvent(s, xp->ev_rs_done, 0));
-  HIPCHK(launch_scatter_idx(t->counts_ptr(), xp->small.p, xp->halo_idx.p, xp->n_small, s));
+  if (!xp->direct) HIPCHK(launch_scatter_idx(t->counts_ptr(), xp->small.p, xp->halo_idx.p, xp->n_small, s));
   xp->counts_pending = false;
   xp->counts_sharded = xp->N > 1;
   return CARMEL_HIP_OK;
@@ -168,6 +271,21 @@ int exchange_settle(carmel_hip_trainer* t, bool need_counts) {
   if (need_counts && xp->counts_sharded) {
     HIPCHK(hipEventRecord(xp->ev_tail, s));
     HIPCHK(hipStreamWaitEvent(x, xp->ev_tail, 0));
+    if (xp->direct) {  // the owners' sums to everybody (one value per arc everywhere), the tail's from this rank's own sum
+      rc = comm_p2p(xp->comm, xp->ops_cg.data(), (uint32_t)xp->ops_cg.size(), x);
+      if (rc) return rc;
+      for (uint32_t k = 0; k < xp->K; ++k) {
+        const uint64_t p0 = xp->A[k] + (uint64_t)xp->rank * xp->piece(k);
+        HIPCHK(hipMemcpyAsync(t->counts_ptr() + p0, xp->red.p + p0, xp->piece(k) * sizeof(double), hipMemcpyDeviceToDevice, x));
+      }
+      if (xp->n_arcs > xp->A[xp->K])
+        HIPCHK(hipMemcpyAsync(t->counts_ptr() + xp->A[xp->K], xp->red.p + xp->A[xp->K], (xp->n_arcs - xp->A[xp->K]) * sizeof(double),
+                              hipMemcpyDeviceToDevice, x));
+      HIPCHK(hipEventRecord(xp->ev_rs_done, x));
+      HIPCHK(hipStreamWaitEvent(s, xp->ev_rs_done, 0));
+      xp->counts_sharded = false;
+      return CARMEL_HIP_OK;
+    }
     for (uint32_t k = 0; k < xp->K; ++k) {
       rc = comm_all_gather(xp->comm, t->counts_ptr() + xp->A[k], (size_t)((xp->A[k + 1] - xp->A[k]) / xp->N), x);
       if (rc) return rc;
@@ -192,6 +310,7 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   MstepArgs M;
   rc = mstep_args(t, 1, 2, M);
   if (rc) return rc;
+  M.counts = xp->reduced(t);
   // one launch over this rank's K pieces and the arcs after the last whole chunk (every rank has THEIR counts from the small
   // all-reduce and normalises them itself)
   M.n_ranges = 0;
@@ -210,18 +329,45 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   const uint64_t tail0 = xp->A[xp->K];
   if (xp->n_arcs > tail0) add(tail0 / 256, (xp->n_arcs - tail0 + 255) / 256);
   M.range_cum[M.n_ranges] = cum;
-  HIPCHK(launch_mstep_window_range(M, 1, 0, cum, s));
-  HIPCHK(launch_mstep_max_final(M, s));
-  HIPCHK(hipEventRecord(xp->ev_m_done, s));
-  HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
-  rc = comm_allreduce(xp->comm, (double*)t->maxchg.p, 1, true, x);  // non-negative doubles: max of the values
-  if (rc) return rc;
-  HIPCHK(hipMemcpyAsync(xp->h_max, t->maxchg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, x));
-  HIPCHK(hipEventRecord(xp->ev_max, x));
-  for (uint32_t k = 0; k < xp->K; ++k) {
-    rc = comm_all_gather(xp->comm, t->arc_logw.p + xp->A[k], (size_t)((xp->A[k + 1] - xp->A[k]) / xp->N), x);
+  if (xp->direct) {
+    // the M-step on the communicator's stream, behind the sums it reads and ahead of the groups that carry its weights: one
+    // hop between the streams per iteration (count pass -> exchange) instead of three
+    if (M.lw_src || !xp->m_ready) {  // (mstep_args left a snapshot copy / first-time scratch on the trainer's stream)
+      HIPCHK(hipEventRecord(xp->ev_m_done, s));
+      HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
+      xp->m_ready = true;
+    }
+    HIPCHK(launch_mstep_window_range(M, 1, 0, cum, x));
+    HIPCHK(launch_mstep_max_final(M, x));
+  } else {
+    HIPCHK(launch_mstep_window_range(M, 1, 0, cum, s));
+    HIPCHK(launch_mstep_max_final(M, s));
+    HIPCHK(hipEventRecord(xp->ev_m_done, s));
+    HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
+  }
+  if (xp->direct) {
+    // the pieces straight to every peer, one group per chunk; the first carries this rank's largest change to everybody,
+    // so the host has max |dw| while the other chunks are still on the links
+    for (uint32_t k = 0; k < xp->K; ++k) {
+      rc = comm_p2p(xp->comm, xp->ops_g[k].data(), (uint32_t)xp->ops_g[k].size(), x);
+      if (rc) return rc;
+      if (k == 0) {
+        if (xp->N > 1) hipLaunchKernelGGL(xchg_max_kernel, dim3(1), dim3(1), 0, x, t->maxchg.p, (const unsigned long long*)xp->fin.p, xp->N, xp->rank);
+        HIPCHK(hipMemcpyAsync(xp->h_max, t->maxchg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, x));
+        HIPCHK(hipEventRecord(xp->ev_max, x));
+      }
+      HIPCHK(hipEventRecord(xp->ev_ag[k], x));
+    }
+  } else {
+    rc = comm_allreduce(xp->comm, (double*)t->maxchg.p, 1, true, x);  // non-negative doubles: max of the values
     if (rc) return rc;
-    HIPCHK(hipEventRecord(xp->ev_ag[k], x));
+    HIPCHK(hipMemcpyAsync(xp->h_max, t->maxchg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, x));
+    HIPCHK(hipEventRecord(xp->ev_max, x));
+    for (uint32_t k = 0; k < xp->K; ++k) {
+      rc = comm_all_gather(xp->comm, t->arc_logw.p + xp->A[k], (size_t)((xp->A[k + 1] - xp->A[k]) / xp->N), x);
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(xp->ev_ag[k], x));
+    }
   }
   HIPCHK(hipEventRecord(xp->ev_ag_done, x));
   xp->ag_pending = true;
@@ -237,7 +383,11 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
 
 extern "C" {
 
-int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int force_allreduce) {
+int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int form) {
+  if (form < 0 || form > 3) return fail(CARMEL_HIP_ERR_ARG, "carmel_hip_exchange_plan: form is 0 (choose), 1 (all-reduce), 2 (collectives) or 3 (direct)");
+  if (form == 3 && !comm_has_p2p(c))
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "carmel_hip_exchange_plan: the transport has no point-to-point transfers (carmel_hip_comm_set_sendrecv)");
+  const bool force_allreduce = form == 1;
   if (!t || !c) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (t->device != c->device) return fail(CARMEL_HIP_ERR_ARG, "trainer and communicator live on different devices");
   if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
@@ -269,9 +419,14 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
     can = v[2] == 1.0 && v[3] == 0.0;  // every rank can
   }
   xp->sharded = can;
+  xp->direct = can && form != 2 && comm_has_p2p(c);
+  xp->span = span;
   if (can) {
     const uint64_t M = t->w.n_arcs, gran = (uint64_t)xp->N * 256;
-    uint32_t K = n_chunks ? n_chunks : 4u;
+    // chunks: every extra chunk costs the two bucket passes a ramp and a tail (measured on config 4, one rank: +26 us at 2
+    // chunks, +58 at 3, +97 at 4, +170 at 8) and hides (K - 1) / K of them behind the links: 2 for the
+    // direct form, whose transfers are short; the ring collectives keep their 4
+    uint32_t K = n_chunks ? n_chunks : (xp->direct ? 2u : 4u);
     K = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(K, XCH_MAX_CHUNKS), std::max<uint64_t>(1, M / gran));
     xp->K = K;
     xp->A.assign(K + 1, 0);
@@ -289,6 +444,54 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
       uint32_t wbe = k ? xp->wb_end[k - 1] : 0u;
       while (wbe < B.size() && (uint64_t)B[wbe].arc_lo + B[wbe].n_arcs <= xp->A[k + 1]) ++wbe;  // reads nothing at or above A[k + 1]
       xp->wb_end[k] = wbe;
+    }
+    if (xp->direct) {
+      xp->cbx_end.assign(K, 0);
+      for (uint32_t k = 0; k < K; ++k) {
+        uint32_t b = k ? xp->cbx_end[k - 1] : 0u;
+        while (b < B.size() && B[b].arc_lo < xp->A[k + 1] + span) ++b;  // touches an arc a piece of chunk k is sent with
+        xp->cbx_end[k] = b;
+      }
+      xp->tail_lo = xp->A[K] > span ? xp->A[K] - span : 0;
+      xp->tail_n = M + 4 - xp->tail_lo;
+      const uint32_t N = xp->N, me = xp->rank;
+      for (uint32_t k = 0; k < K; ++k) xp->stride = std::max(xp->stride, xp->ext_hi(k, me) - xp->ext_lo(k, me));
+      if (N > 1) {
+        HIPCHK(xp->red.alloc(M + 4));
+        HIPCHK(xp->stage.alloc((uint64_t)(N - 1) * (xp->stride + xp->tail_n)));
+        HIPCHK(xp->fin.alloc(N));
+      }
+      double* counts = t->counts_ptr();
+      xp->ops_x.assign(K, {});
+      xp->ops_g.assign(K, {});
+      for (uint32_t k = 0; k < K; ++k) {
+        const uint64_t P = xp->piece(k);
+        for (uint32_t q = 0; q < N; ++q) {
+          if (q == me) continue;
+          const uint32_t slot = q < me ? q : q - 1;
+          // counts out: the peer's piece of the chunk with its halo; mine (with my halo) from the peer
+          xp->ops_x[k].push_back({(int32_t)q, 1, counts + xp->ext_lo(k, q), xp->ext_hi(k, q) - xp->ext_lo(k, q)});
+          xp->ops_x[k].push_back({(int32_t)q, 0, xp->stage.p + (uint64_t)slot * xp->stride, xp->ext_hi(k, me) - xp->ext_lo(k, me)});
+          xp->bytes_rs += (xp->ext_hi(k, q) - xp->ext_lo(k, q)) * 8;
+          if (k + 1 == K) {
+            xp->ops_x[k].push_back({(int32_t)q, 1, counts + xp->tail_lo, xp->tail_n});
+            xp->ops_x[k].push_back({(int32_t)q, 0, xp->stage.p + (uint64_t)(N - 1) * xp->stride + (uint64_t)slot * xp->tail_n, xp->tail_n});
+            xp->bytes_rs += xp->tail_n * 8;
+          }
+          // weights in: my piece to the peer, the peer's piece into place
+          xp->ops_g[k].push_back({(int32_t)q, 1, t->arc_logw.p + xp->A[k] + (uint64_t)me * P, P});
+          xp->ops_g[k].push_back({(int32_t)q, 0, t->arc_logw.p + xp->A[k] + (uint64_t)q * P, P});
+          xp->bytes_ag += P * 8;
+          if (k == 0) {
+            xp->ops_g[k].push_back({(int32_t)q, 1, (double*)t->maxchg.p, 1});
+            xp->ops_g[k].push_back({(int32_t)q, 0, xp->fin.p + q, 1});
+            xp->bytes_ag += 8;
+          }
+          // the reduced count pieces to everybody, when the whole vector is asked for
+          xp->ops_cg.push_back({(int32_t)q, 1, xp->red.p + xp->A[k] + (uint64_t)me * P, P});
+          xp->ops_cg.push_back({(int32_t)q, 0, counts + xp->A[k] + (uint64_t)q * P, P});
+        }
+      }
     }
     // the boundary arcs: within `span` of a piece boundary (both sides), chunk by chunk; then the tail and the scalars
     std::vector<uint32_t> idx;
@@ -316,19 +519,25 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
     HIPCHK(xp->halo_idx.upload(idx, t->stream));
     HIPCHK(xp->small.alloc(idx.size()));
     HIPCHK(hipStreamSynchronize(t->stream));
+    // the events that order this device's two streams release to the device only (a system-scope release writes the caches
+    // back: measured, 15 us per chunk boundary); ev_max is the one the host reads pinned memory behind
+    const unsigned dev_only = hipEventDisableTiming | hipEventReleaseToDevice;
     for (uint32_t k = 0; k < K; ++k) {
-      HIPCHK(hipEventCreateWithFlags(&xp->ev_chunk[k], hipEventDisableTiming));
-      HIPCHK(hipEventCreateWithFlags(&xp->ev_ag[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&xp->ev_chunk[k], dev_only));
+      HIPCHK(hipEventCreateWithFlags(&xp->ev_ag[k], dev_only));
     }
-    for (hipEvent_t* e : {&xp->ev_tail, &xp->ev_rs_done, &xp->ev_m_done, &xp->ev_ag_done, &xp->ev_max})
-      HIPCHK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (hipEvent_t* e : {&xp->ev_tail, &xp->ev_rs_done, &xp->ev_m_done, &xp->ev_ag_done})
+      HIPCHK(hipEventCreateWithFlags(e, dev_only));
+    HIPCHK(hipEventCreateWithFlags(&xp->ev_max, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&xp->tx0));
     HIPCHK(hipEventCreate(&xp->tx1));
     HIPCHK(hipHostMalloc((void**)&xp->h_max, sizeof(unsigned long long), hipHostMallocDefault));
-    const uint64_t per = (xp->A[K] / xp->N) * (xp->N - 1) * 8;  // what a rank sends (and receives) in one pass over its pieces
-    xp->bytes_rs = per;
-    xp->bytes_ag = per;
-    xp->bytes_small = (uint64_t)xp->n_small * 8;
+    if (!xp->direct) {
+      const uint64_t per = (xp->A[K] / xp->N) * (xp->N - 1) * 8;  // what a rank sends (and receives) in one pass over its pieces
+      xp->bytes_rs = per;
+      xp->bytes_ag = per;
+      xp->bytes_small = (uint64_t)xp->n_small * 8;
+    }
   } else {
     xp->bytes_small = (t->w.n_arcs + 4) * 8;
   }
@@ -341,7 +550,7 @@ int carmel_hip_exchange_info(carmel_hip_trainer* t, int* sharded, uint32_t* n_ch
                              uint64_t* bytes_all_gather, uint64_t* bytes_all_reduce) {
   if (!t || !t->xplan) return fail(CARMEL_HIP_ERR_STATE, "no exchange planned");
   const ExchangePlan* xp = t->xplan;
-  if (sharded) *sharded = xp->sharded ? 1 : 0;
+  if (sharded) *sharded = xp->sharded ? (xp->direct ? 2 : 1) : 0;
   if (n_chunks) *n_chunks = xp->K;
   if (bytes_reduce_scatter) *bytes_reduce_scatter = xp->bytes_rs;
   if (bytes_all_gather) *bytes_all_gather = xp->bytes_ag;
@@ -386,7 +595,10 @@ int carmel_hip_exchange_measure(carmel_hip_trainer* t, uint32_t reps, double* ms
   float total = 0;
   for (uint32_t r = 0; r <= reps; ++r) {  // (the first pass is a warm-up)
     HIPCHK(hipEventRecord(e0, x));
-    if (xp->sharded) {
+    if (xp->sharded && xp->direct) {
+      for (uint32_t k = 0; k < xp->K && !rc; ++k) rc = comm_p2p(xp->comm, xp->ops_x[k].data(), (uint32_t)xp->ops_x[k].size(), x);
+      for (uint32_t k = 0; k < xp->K && !rc; ++k) rc = comm_p2p(xp->comm, xp->ops_g[k].data(), (uint32_t)xp->ops_g[k].size(), x);
+    } else if (xp->sharded) {
       for (uint32_t k = 0; k < xp->K && !rc; ++k)
         rc = comm_reduce_scatter(xp->comm, t->counts_ptr() + xp->A[k], (size_t)((xp->A[k + 1] - xp->A[k]) / xp->N), x);
       if (!rc) rc = comm_allreduce(xp->comm, xp->small.p, xp->n_small, false, x);

@@ -81,6 +81,7 @@ struct Options {
   int gpus = 1;  // --gpus=N: corpus-sharded EM, one process per GPU (not a carmel option: carmel is single-process)
   std::string comm_plugin;  // --comm-plugin=LIB.so: a transport of the caller's own instead of RCCL (carmel_hip_comm_create_custom);
                             // every rank then runs on the device --gpu names (the transport decides where the data travels)
+  int exchange_form = 0;    // --exchange=auto|allreduce|collectives|direct (carmel_hip_exchange_plan's form)
   int exchange_chunks = 0;  // --exchange-chunks=K: arc-range chunks of the sharded count exchange (0: the library's default)
   // --crp (carmel.cc:255-304)
   bool expectation = false;  // --expectation (gibbs_opts.hpp:125)
@@ -140,7 +141,13 @@ static Options parse_args(int argc, char** argv) {
         o.gpus = std::max(1, std::atoi(v.c_str()));
       else if (k == "comm-plugin")
         o.comm_plugin = v;
-      else if (k == "exchange-chunks")
+      else if (k == "exchange") {
+        const char* names[] = {"auto", "allreduce", "collectives", "direct"};
+        o.exchange_form = -1;
+        for (int f = 0; f < 4; ++f)
+          if (v == names[f]) o.exchange_form = f;
+        if (o.exchange_form < 0) throw UsageError("--exchange is auto, allreduce, collectives or direct");
+      } else if (k == "exchange-chunks")
         o.exchange_chunks = std::max(0, std::atoi(v.c_str()));
       else if (k == "crp") {
         o.crp = true;
@@ -624,6 +631,8 @@ static int run(int argc, char** argv) {
     std::memset(&tr, 0, sizeof tr);
     if (op(g_session.c_str(), rank, world, my_device, &tr) != 0) throw std::runtime_error("--comm-plugin: carmel_hip_transport_open failed");
     hip_check(carmel_hip_comm_create_custom(&comm, my_device, rank, world, &tr), "carmel_hip_comm_create_custom");
+    if (carmel_hip_sendrecv_fn sr = (carmel_hip_sendrecv_fn)dlsym(h, "carmel_hip_transport_sendrecv"))  // optional: point-to-point groups
+      hip_check(carmel_hip_comm_set_sendrecv(comm, sr), "carmel_hip_comm_set_sendrecv");
     for (int w : id_pipes) close(w);
     if (id_read >= 0) close(id_read);
   } else if (world > 1) {
@@ -871,7 +880,7 @@ static int run(int argc, char** argv) {
   // planned as the one all-reduce; csrc/exchange.cpp)
   // (streamed lattices: every shard has its own buckets, so the exchange stays the plain all-reduce of the summed buffer)
   if (comm && !o.crp && stream_cut.size() <= 2)
-    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, 0), "carmel_hip_exchange_plan");
+    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, o.exchange_form), "carmel_hip_exchange_plan");
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {

@@ -58,6 +58,8 @@ class HipComm(object):
         h = C.c_void_p()
         check(lib.carmel_hip_comm_create_custom(C.byref(h), device, rank, world, C.cast(tr, C.c_void_p)), "carmel_hip_comm_create_custom")
         self.h, self.rank, self.world, self._plug = h, rank, world, plug
+        if hasattr(plug, "carmel_hip_transport_sendrecv"):  # point-to-point groups: the exchange's direct form
+            check(lib.carmel_hip_comm_set_sendrecv(h, C.cast(plug.carmel_hip_transport_sendrecv, C.c_void_p)), "carmel_hip_comm_set_sendrecv")
         return self
 
     @property
@@ -68,6 +70,10 @@ class HipComm(object):
         v = np.ascontiguousarray(values, dtype=np.float64).copy()
         check(lib.carmel_hip_comm_allreduce_host(self.h, ptr(v), len(v), 1 if op_max else 0), "carmel_hip_comm_allreduce_host")
         return v
+
+    def selftest(self, n=0):
+        """collective: the point-to-point groups of the exchange's direct form on this transport (carmel_hip_comm_selftest)"""
+        check(lib.carmel_hip_comm_selftest(self.h, n), "carmel_hip_comm_selftest")
 
     def abort(self):
         """after a collective failed on some rank: drop what is enqueued instead of waiting for it"""
@@ -182,9 +188,13 @@ class HipForwardBackward(object):
         """> 0: the lane sweep's backward pass writes XC itself (carmel_hip_lattice_fused_lanes)"""
         return lib.carmel_hip_lattice_fused_lanes(self.h)
 
-    def exchange_plan(self, comm, n_chunks=0, force_allreduce=False):
-        """plan the per-iteration exchange (collective); returns exchange_info()"""
-        check(lib.carmel_hip_exchange_plan(self.h, comm.h, n_chunks, int(force_allreduce)), "carmel_hip_exchange_plan")
+    EXCHANGE_FORMS = {"auto": 0, "allreduce": 1, "collectives": 2, "direct": 3}
+
+    def exchange_plan(self, comm, n_chunks=0, force_allreduce=False, form="auto"):
+        """plan the per-iteration exchange (collective); returns exchange_info().  form: "auto" (direct point-to-point groups
+        where the transport has them, else the collectives), "allreduce", "collectives", "direct" """
+        f = 1 if force_allreduce else self.EXCHANGE_FORMS[form]
+        check(lib.carmel_hip_exchange_plan(self.h, comm.h, n_chunks, f), "carmel_hip_exchange_plan")
         self._comm = comm  # the plan points at the communicator: keep it from being collected before the trainer
         return self.exchange_info()
 
@@ -193,7 +203,7 @@ class HipForwardBackward(object):
         rs, ag, ar = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
         check(lib.carmel_hip_exchange_info(self.h, C.byref(sh), C.byref(k), C.byref(rs), C.byref(ag), C.byref(ar)),
               "carmel_hip_exchange_info")
-        return dict(sharded=bool(sh.value), n_chunks=k.value, bytes_reduce_scatter=rs.value, bytes_all_gather=ag.value,
+        return dict(sharded=bool(sh.value), form=("allreduce", "collectives", "direct")[sh.value], n_chunks=k.value, bytes_reduce_scatter=rs.value, bytes_all_gather=ag.value,
                     bytes_all_reduce=ar.value)
 
     def exchange_measure(self, reps=5):

@@ -249,6 +249,22 @@ typedef struct carmel_hip_transport {
   const char* name;
 } carmel_hip_transport;
 int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, int world, const carmel_hip_transport* tr);
+/* ... and, optionally, point-to-point transfers for the exchange's DIRECT form (below): one call = one group of sends and
+ * receives on device buffers, all of them complete (or enqueued on `stream`) when it returns; between a pair of ranks the
+ * k-th send of the one meets the k-th receive of the other and their lengths agree; no operation names the caller itself.
+ * (RCCL: ncclGroupStart, ncclSend / ncclRecv, ncclGroupEnd.)  A custom transport without it keeps the collective form. */
+typedef struct carmel_hip_p2p {
+  int32_t peer;     /* the other rank */
+  int32_t send;     /* 1: dev_buf[0 .. n) goes to peer; 0: it is filled by peer */
+  double* dev_buf;
+  uint64_t n;       /* doubles */
+} carmel_hip_p2p;
+typedef int (*carmel_hip_sendrecv_fn)(void* ctx, const carmel_hip_p2p* ops, uint32_t n_ops, void* stream);
+int carmel_hip_comm_set_sendrecv(carmel_hip_comm* c, carmel_hip_sendrecv_fn fn);
+/* collective: every rank sends every rank n doubles (0: 1024) of a pattern naming sender and receiver through one such group
+ * and checks what arrives -- the transfers of the direct form on this transport, before a training run depends on them
+ * (over RCCL a rank also sends to itself, so a world of one exercises ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd). */
+int carmel_hip_comm_selftest(carmel_hip_comm* c, uint32_t n);
 
 /* The per-iteration exchange, planned once after carmel_hip_build_lattices (collective: every rank calls it; it also
  * checks that the ranks hold their lattices in the same layout).  With a plan an iteration is still
@@ -256,8 +272,15 @@ int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, i
  * but for a single transducer under JOINT / CONDITIONAL normalisation it runs SHARDED: the arc table in n_chunks chunks
  * (0: 4; at most 16) of `world` pieces; the count pass hands each chunk to a reduce-scatter on the communicator's own stream while the
  * next chunk is still being summed; carmel_hip_maximize normalises this rank's pieces only and all-gathers the weights chunk
- * by chunk into the next count pass (csrc/exchange.cpp).  Other models (cascades, unrolled / dense
- * layouts, tied groups, force_allreduce != 0) keep the one all-reduce of counts[n_arcs + 4] and the replicated M-step.
+ * by chunk into the next count pass (csrc/exchange.cpp).  The sharded exchange has two forms.  DIRECT
+ * (the default where the transport has point-to-point transfers -- RCCL has): every rank sends each peer that peer's piece
+ * of the chunk, with the few arcs either side that a straddling norm group needs, in ONE group of sends and receives per
+ * chunk, and adds up what arrives in rank order; the weights travel back the same way; the corpus scalars ride with the last
+ * chunk of counts, the largest weight change with the first chunk of weights: 2 x n_chunks groups per iteration and no
+ * small collective.  COLLECTIVES: ncclReduceScatter / ncclAllGather per chunk, one small all-reduce for the arcs at piece
+ * boundaries and the scalars, one for the largest change.  `form`: 0 = choose (direct, else collectives, else all-reduce),
+ * 1 = the one all-reduce of counts[n_arcs + 4] and the replicated M-step, 2 = collectives, 3 = direct (refused when the
+ * transport cannot).  Other models (cascades, unrolled / dense layouts, tied groups) keep the all-reduce whatever is asked.
  * The results are the same either way up to the order of the sums.  carmel_hip_exchange_info says which form was planned
  * and what one iteration moves per rank; carmel_hip_exchange_measure times the exchange of one iteration on its own (all
  * its collectives back to back, nothing to hide behind; collective); carmel_hip_exchange_clear drops the plan.
@@ -267,7 +290,7 @@ int carmel_hip_comm_create_custom(carmel_hip_comm** out, int device, int rank, i
  * rank-0-only carmel_hip_get_counts would wait for its peers forever); with the all-reduce form they are local.
  * carmel_hip_use_external_counts is refused under a sharded plan; matrix mode (carmel_hip_set_matrix_fb) plans the
  * all-reduce form. */
-int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int force_allreduce);
+int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int form);
 int carmel_hip_exchange_info(carmel_hip_trainer* t, int* sharded, uint32_t* n_chunks, uint64_t* bytes_reduce_scatter,
                              uint64_t* bytes_all_gather, uint64_t* bytes_all_reduce);
 int carmel_hip_exchange_measure(carmel_hip_trainer* t, uint32_t reps, double* ms_per_exchange);

@@ -86,6 +86,9 @@ def main():
             if world > 1:
                 dist.broadcast_object_list(ids, src=0)
             comm = HipComm(0, rank, world, ids[0])
+    if comm is not None and "--selftest" in sys.argv:
+        comm.selftest()
+        comm.selftest(100003)
     info = None
     if plan:
         if "--disagree" in sys.argv:
@@ -100,7 +103,11 @@ def main():
             fb.set_layout_policy(False)
             fb.rebuild_lattices()
         k = plan[0].split("=", 1)
-        info = fb.exchange_plan(comm, int(k[1]) if len(k) > 1 and k[0] == "--plan" else 0, force_allreduce=plan[0] == "--plan-allreduce")
+        form = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--form=")]
+        info = fb.exchange_plan(comm, int(k[1]) if len(k) > 1 and k[0] == "--plan" else 0, force_allreduce=plan[0] == "--plan-allreduce",
+                                form=form[0].replace("auto-direct", "auto") if form else "auto")
+        if form:  # ("auto-direct": the library's own choice must be the direct form)
+            assert info["form"] == form[0].replace("auto-", ""), info
     logs = []
     for it in range(4):
         if fb.cascade is not None and it > 0:

@@ -4,6 +4,7 @@
 // GPU (RCCL refuses two ranks on a device).  Not part of the product library; built into tests/native/ by tests/native/Makefile.
 //
 //   int carmel_hip_transport_open(const char* session, int rank, int world, int device, carmel_hip_transport* out);
+//   int carmel_hip_transport_sendrecv(void* ctx, const carmel_hip_p2p* ops, uint32_t n_ops, void* stream);   (carmel_hip_comm_set_sendrecv)
 //
 // `session` names the segment (the same string on every rank; rank 0 creates it).  Every wait has a deadline: a rank
 // that never arrives makes the others fail with an error instead of spinning for ever.
@@ -128,12 +129,91 @@ int ht_all_gather(void* ctx, double* buf, uint64_t count, void* stream) {
   }
   return 0;
 }
+// one group of sends and receives.  Rounds: every rank packs as much of its outgoing data as its slot holds as records
+// [destination, n, n doubles] behind a header [records, more to come]; after the barrier every rank picks the records
+// addressed to it out of the others' slots, in order, into its receives from that rank, in order.
+int ht_sendrecv_impl(Ring* R, const carmel_hip_p2p* ops, uint32_t n_ops, hipStream_t s) {
+  std::vector<uint32_t> sends;
+  std::vector<std::vector<uint32_t>> recvs(R->world);
+  for (uint32_t k = 0; k < n_ops; ++k) {
+    if (ops[k].peer < 0 || ops[k].peer >= R->world || ops[k].peer == R->rank) return -1;
+    if (ops[k].send)
+      sends.push_back(k);
+    else
+      recvs[ops[k].peer].push_back(k);
+  }
+  size_t si = 0;
+  uint64_t so = 0;  // next send op, doubles of it already out
+  std::vector<size_t> ri(R->world, 0);
+  std::vector<uint64_t> ro(R->world, 0);
+  if (R->cap < 8) return -1;
+  for (;;) {
+    double* mine = R->slot(R->rank);
+    size_t pos = 2, nrec = 0;
+    while (si < sends.size() && pos + 3 <= R->cap) {
+      const carmel_hip_p2p& o = ops[sends[si]];
+      const uint64_t take = std::min<uint64_t>(o.n - so, R->cap - pos - 2);
+      mine[pos] = (double)o.peer;
+      mine[pos + 1] = (double)take;
+      if (take) HT_HIP(hipMemcpyAsync(mine + pos + 2, o.dev_buf + so, take * sizeof(double), hipMemcpyDeviceToHost, s));
+      pos += 2 + take;
+      so += take;
+      ++nrec;
+      if (so == o.n) {
+        ++si;
+        so = 0;
+      }
+    }
+    mine[0] = (double)nrec;
+    mine[1] = si < sends.size() ? 1.0 : 0.0;
+    HT_HIP(hipStreamSynchronize(s));
+    if (!R->barrier_in()) return -3;
+    bool more = false;
+    for (int r = 0; r < R->world; ++r) {
+      const double* q = R->slot(r);
+      more = more || q[1] != 0.0;
+      if (r == R->rank) continue;
+      size_t p = 2;
+      for (size_t k = 0, n = (size_t)q[0]; k < n; ++k) {
+        const int dst = (int)q[p];
+        uint64_t len = (uint64_t)q[p + 1];
+        const double* data = q + p + 2;
+        p += 2 + len;
+        if (dst != R->rank) continue;
+        while (len || (ri[r] < recvs[r].size() && ops[recvs[r][ri[r]]].n == 0)) {  // (a record never spans two sends)
+          if (ri[r] >= recvs[r].size()) return -5;  // more arrives than this rank receives
+          const carmel_hip_p2p& o = ops[recvs[r][ri[r]]];
+          const uint64_t put = std::min<uint64_t>(len, o.n - ro[r]);
+          if (put) HT_HIP(hipMemcpyAsync(o.dev_buf + ro[r], data, put * sizeof(double), hipMemcpyHostToDevice, s));
+          if (put < len) return -5;  // lengths of a send and its receive differ
+          data += put;
+          len -= put;
+          ro[r] += put;
+          if (ro[r] == o.n) {
+            ++ri[r];
+            ro[r] = 0;
+          }
+        }
+      }
+    }
+    HT_HIP(hipStreamSynchronize(s));
+    if (!R->barrier_out()) return -3;
+    if (!more) break;
+  }
+  for (int r = 0; r < R->world; ++r)
+    if (ri[r] != recvs[r].size()) return -5;  // a receive nobody sent
+  return 0;
+}
 void ht_destroy(void* ctx) {
   Ring* R = (Ring*)ctx;
   if (R->base) munmap(R->base, R->bytes);
   delete R;
 }
 }  // namespace
+
+extern "C" int carmel_hip_transport_sendrecv(void* ctx, const carmel_hip_p2p* ops, uint32_t n_ops, void* stream) {
+  return ht_sendrecv_impl((Ring*)ctx, ops, n_ops, (hipStream_t)stream);
+}
 
 extern "C" int carmel_hip_transport_open(const char* session, int rank, int world, int device, carmel_hip_transport* out) {
   if (!session || !out || world < 1 || rank < 0 || rank >= world) return -1;

@@ -52,8 +52,13 @@ def test_rccl_entry_points_with_a_world_of_one(tmp_path):
     """carmel_hip_comm_unique_id / _create / carmel_hip_allreduce_counts (stream-ordered, no host sync) / _destroy:
     with one rank the sum is the identity, so the run must equal the plain one"""
     plain = _run(1, "synth", tmp_path, "plain")
-    rccl = _run(1, "synth", tmp_path, "rccl", extra=["--rccl"])
+    rccl = _run(1, "synth", tmp_path, "rccl", extra=["--rccl", "--selftest"])  # (+ a group of ncclSend / ncclRecv to itself)
     np.testing.assert_array_equal(plain, rccl)
+
+
+def test_point_to_point_selftest_over_the_test_transport(tmp_path):
+    """carmel_hip_comm_selftest with three ranks: every pair exchanges a pattern through one group, 1024 and 100003 doubles"""
+    _run(3, "synth", tmp_path, "st3", extra=["--rccl", _plugin("st3"), "--selftest"])
 
 
 @pytest.mark.parametrize("mode", ["synth", "cipher"])
@@ -71,25 +76,42 @@ def test_library_allreduce_two_ranks_host_transport(tmp_path, mode):
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_sharded_exchange_is_the_all_reduce_bit_for_bit(tmp_path, world):
-    """carmel_hip_exchange_plan on a single transducer: the arc table in chunks of `world` pieces, a reduce-scatter per chunk
-    beside the count pass, the M-step on this rank's pieces only, the weights all-gathered chunk by chunk into the next count
-    pass, norm groups that straddle piece boundaries summed from one small all-reduce.  The test transport adds the ranks'
-    values in rank order in all of its collectives, so the sharded exchange must give the all-reduce form's weights and
-    corpus probabilities BIT FOR BIT (4 iterations; 2 and 4 ranks, default and 3 chunks) -- and the one-rank trainer's to
-    rounding.  The whole count vector is still there for the asking after a sharded exchange (carmel_hip_get_counts)."""
+    """carmel_hip_exchange_plan on a single transducer, both sharded forms.  COLLECTIVES: the arc table in chunks of `world`
+    pieces, a reduce-scatter per chunk beside the count pass, the M-step on this rank's pieces only, the weights all-gathered
+    chunk by chunk into the next count pass, norm groups that straddle piece boundaries summed from one small all-reduce.
+    DIRECT (the default: the test transport has point-to-point groups, as RCCL has): every piece straight to its owner with
+    the arcs a straddling group needs, summed there in rank order, the scalars with the last chunk, the largest weight change
+    with the first chunk of weights.  The test transport adds the ranks' values in rank order in all of its collectives, so
+    both must give the all-reduce form's weights and corpus probabilities BIT FOR BIT (4 iterations; 2 and 4 ranks, default
+    and 3 chunks, and one chunk) -- and the one-rank trainer's to rounding.  The whole count vector is still there for the
+    asking after a sharded exchange (carmel_hip_get_counts)."""
     plain = _run(world, "synth-big", tmp_path, "plain%d" % world, extra=["--rccl", _plugin("p%d" % world), "--plan-allreduce", "--check-counts"])
     assert plain[-1] == 0.0
-    for k, tag in ((0, "d"), (3, "k3")):
-        sh = _run(world, "synth-big", tmp_path, "sh%d%s" % (world, tag),
-                  extra=["--rccl", _plugin("s%d%s" % (world, tag)), "--plan=%d" % k if k else "--plan", "--check-counts"])
-        assert sh[-1] == 1.0, "the exchange was not planned in its sharded form"
-        np.testing.assert_array_equal(sh[:-1], plain[:-1])
+    for form in ("direct", "collectives"):
+        for k, tag in ((0, "d"), (3, "k3"), (1, "k1")):
+            if k == 1 and form == "collectives":
+                continue
+            sh = _run(world, "synth-big", tmp_path, "sh%d%s%s" % (world, tag, form[0]),
+                      extra=["--rccl", _plugin("s%d%s%s" % (world, tag, form[0])), "--plan=%d" % k if k else "--plan", "--check-counts",
+                             "--form=" + form])
+            assert sh[-1] == 1.0, "the exchange was not planned in its sharded form"
+            np.testing.assert_array_equal(sh[:-1], plain[:-1], err_msg="%s, %d chunks" % (form, k))
     one = _run(1, "synth-big", tmp_path, "one_big")
     nw = len(one) - 13
     fin = np.isfinite(one[:nw])
     assert np.array_equal(fin, np.isfinite(plain[:nw]))
     np.testing.assert_allclose(np.exp(plain[:nw][fin]), np.exp(one[:nw][fin]), rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(plain[nw:nw + 12], one[nw:nw + 12], rtol=1e-10)
+
+
+def test_direct_exchange_through_a_small_transport_window(tmp_path, monkeypatch):
+    """the test transport's point-to-point groups in many rounds (a slot of 4096 doubles: every piece travels in parts, the
+    groups of three ranks take different numbers of rounds to drain) -- and the default form IS the direct one"""
+    plain = _run(3, "synth-big", tmp_path, "wplain", extra=["--rccl", _plugin("wp"), "--plan-allreduce", "--check-counts"])
+    monkeypatch.setenv("CARMEL_HOST_TRANSPORT_CAP", "4096")
+    sh = _run(3, "synth-big", tmp_path, "wdirect", extra=["--rccl", _plugin("wd"), "--plan", "--check-counts", "--form=auto-direct"])
+    assert sh[-1] == 1.0
+    np.testing.assert_array_equal(sh[:-1], plain[:-1])
 
 
 def test_sharded_exchange_over_run_length_indices(tmp_path, monkeypatch):
@@ -108,9 +130,10 @@ def test_sharded_exchange_with_one_rank_is_the_plain_trainer(tmp_path):
     """world 1 over RCCL (the collectives run, nothing travels): the sharded M-step over block ranges and the chunked bucket
     passes are the plain ones, so the run must equal the plain trainer bit for bit"""
     plain = _run(1, "synth-big", tmp_path, "plain1")
-    sh = _run(1, "synth-big", tmp_path, "sh1", extra=["--rccl", "--plan"])
-    assert sh[-1] == 1.0
-    np.testing.assert_array_equal(sh[:-1], plain[:-1])
+    for form in ("direct", "collectives"):
+        sh = _run(1, "synth-big", tmp_path, "sh1" + form, extra=["--rccl", "--plan", "--form=" + form])
+        assert sh[-1] == 1.0
+        np.testing.assert_array_equal(sh[:-1], plain[:-1], err_msg=form)
 
 
 @pytest.mark.parametrize("mode,world", [("cipher", 2), ("cipher-explicit", 2), ("dense", 2), ("cipher", 4)])
@@ -142,7 +165,10 @@ def test_ranks_with_different_layouts_are_refused_then_rebuilt(tmp_path):
                                   ["--train-cascade", "-HJ", "-M", "5", "cipher.data", "cipher.wfsa", "cipher.fst"],
                                   ["-t", "-M", "4", "-!", "1", "-R", "3", "train.a.w.corpus100", "train.a.w"],
                                   # --matrix-fb with --gpus (round-4 verdict): the matrix E-step per shard, one all-reduce of the counts
-                                  ["--matrix-fb", "-t", "-M", "4", "epron-jpron.data", "epron-jpron.fst"]])
+                                  ["--matrix-fb", "-t", "-M", "4", "epron-jpron.data", "epron-jpron.fst"],
+                                  # the forms of the exchange by name
+                                  ["--exchange=collectives", "-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"],
+                                  ["--exchange=direct", "--exchange-chunks=3", "-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"]])
 def test_front_end_gpus_switch(golden_dir, tmp_path, args):
     """carmel --gpus=2: two processes forked before any GPU call, the corpus in two blocks, counts summed every
     iteration, replicated M-step -- the log lines and the trained transducers of the one-process run"""
@@ -224,7 +250,7 @@ def test_bench_two_ranks_strong_scaling_is_the_one_rank_run(tmp_path):
     assert j2["ln_corpus_prob_last"] == pytest.approx(j1["ln_corpus_prob_last"], rel=1e-9)
     # the exchange is on the line: planned sharded, its own time and the part the step does not hide
     assert j2["exchange"]["sharded"] and j2["exchange"]["world"] == 2 and j2["exchange_ms"] > 0 and j2["exposed_exchange_ms"] >= 0
-    assert "reduce-scatter" in j2["config"]["parallelism"]
+    assert j2["exchange"]["form"] == "direct" and "straight to their owners" in j2["config"]["parallelism"]
     assert j1["exchange"]["loopback"] and j1["exchange_ms"] > 0
 
 
