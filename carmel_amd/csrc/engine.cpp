@@ -85,6 +85,8 @@ int carmel_hip_create(carmel_hip_trainer** out, int device, uint32_t n_states, u
   (void)hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_w, hipEventDisableTiming);
+  if (hipHostMalloc((void**)&t->h_box, 2 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) t->h_box = nullptr;
+  if (t->h_box) t->h_box[0] = t->h_box[1] = 0;
   (void)hipStreamCreateWithFlags(&t->bstream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&t->ev_b0, hipEventDisableTiming);
   (void)hipEventCreateWithFlags(&t->ev_b1, hipEventDisableTiming);
@@ -145,6 +147,7 @@ int carmel_hip_destroy(carmel_hip_trainer* t) {
   if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
   if (t->ev_join) (void)hipEventDestroy(t->ev_join);
   if (t->ev_w) (void)hipEventDestroy(t->ev_w);
+  if (t->h_box) (void)hipHostFree(t->h_box);
   if (t->bstream) {
     (void)hipStreamSynchronize(t->bstream);
     (void)hipStreamDestroy(t->bstream);
@@ -194,6 +197,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   if (!t->have_corpus) return fail(CARMEL_HIP_ERR_STATE, "set_corpus first");
   HIPCHK(hipSetDevice(t->device));
   if (t->xplan) exchange_drop(t);  // the plan follows the lattices' transposition tables: plan again after a rebuild
+  if (t->scalars_pending) {  // (the side stream may still be reading the arrays about to be rebuilt)
+    (void)hipStreamSynchronize(t->side);
+    t->scalars_pending = false;
+  }
   t->build_prune = prune;
   t->build_threads = host_threads;
   if (t->matrix) {  // its tables follow the corpus: carmel_hip_set_matrix_fb again after a rebuild
@@ -768,6 +775,9 @@ int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M
   M.dig_alpha = t->any_digamma ? t->dig_alpha.p : nullptr;
   M.tie_alpha = (t->any_digamma && t->n_ties) ? t->tie_alpha.p : nullptr;
   M.max_change_bits = t->maxchg.p;
+  static const bool mailbox = !(getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX")));
+  M.box = mailbox ? t->h_box : nullptr;  // (every M-step's last kernel leaves its result there; carmel_hip_maximize waits for its own)
+  M.box_seq = M.box ? ++t->box_seq : 0;
   M.n = t->np();
   M.save_old = save_old;
   return CARMEL_HIP_OK;
@@ -878,9 +888,57 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
   T.slack_bytes = (uint32_t)DEVBUF_SLACK;  // x, xc, t_pos, t_src are DevBufs
 }
 
+// the trainer's stream takes delivery of the corpus scalars (a9) the side stream computed behind the last count pass
+int scalars_join(carmel_hip_trainer* t) {
+  if (!t->scalars_pending) return CARMEL_HIP_OK;
+  if (hipEventQuery(t->ev_join) != hipSuccess) HIPCHK(hipStreamWaitEvent(t->stream, t->ev_join, 0));
+  t->scalars_pending = false;
+  return CARMEL_HIP_OK;
+}
+
+// one 8-byte value from the device to the host at the end of everything enqueued on s so far, and the host waiting for it:
+// a one-thread kernel stores the value and then a sequence number into pinned coherent memory (release, system scope) and
+// the host spins on the sequence number -- a third of the round trip of hipMemcpyAsync to pageable memory +
+// hipStreamSynchronize (measured on config 2, whose iteration is mostly such round trips)
+__global__ void publish_kernel(const unsigned long long* src, unsigned long long* box, unsigned long long seq) {
+  __hip_atomic_store(box, *src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(box + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// published: the last kernel on s has already stored the value under sequence number t->box_seq (mstep_max_final_kernel)
+static int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsigned long long* out, hipStream_t s, bool published) {
+  static const bool off = getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX"));
+  if (!t->h_box || off) {
+    HIPCHK(hipMemcpyAsync(out, dev, sizeof *out, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return CARMEL_HIP_OK;
+  }
+  const unsigned long long seq = published ? t->box_seq : ++t->box_seq;
+  if (!published) {
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, dev, t->h_box, seq);
+    HIPCHK(hipGetLastError());
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t spin = 0;; ++spin) {
+    if (__atomic_load_n(t->h_box + 1, __ATOMIC_ACQUIRE) == seq) break;
+    if ((spin & 0xfff) == 0xfff) {  // something went wrong on the stream, or the value is very late: ask the runtime
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.002) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (__atomic_load_n(t->h_box + 1, __ATOMIC_ACQUIRE) != seq) return fail(CARMEL_HIP_ERR_HIP, "the M-step's result never reached the host");
+        break;
+      }
+    }
+  }
+  *out = __atomic_load_n(t->h_box, __ATOMIC_RELAXED);
+  return CARMEL_HIP_OK;
+}
+
 // Enqueues one E-step on the trainer's stream(s).  timed: bracket it with ev0 / ev1 (not inside a graph capture).
 static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   hipStream_t s = t->stream;
+  {  // (the last E-step's scalars read pair_logprob[], which this one rewrites)
+    int rc = scalars_join(t);
+    if (rc) return rc;
+  }
   if (t->cascade)  // cascade.update(): composed weights from the chains
     HIPCHK(launch_chain_update(t->arc_logw.p, t->arc_group.p, t->chain_off.p, t->chain_param.p, t->param_logw_c.p,
                                t->w.n_arcs, s));
@@ -990,6 +1048,13 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   const bool tile_sweep = t->use_transpose && t->lat.tile_sweep && t->tile_group.n && !tile_kernel_off &&
                           ((T.scatter & 3u) == 0u || ((T.scatter & 3u) == 3u && T.use_runs));
   bool tile_sweep_done = false;
+  // the tile sweep clears, on its way in, the counts the count pass adds up with atomics (the arcs whose items lie in several
+  // buckets): one launch less between the sweep and the count pass (the exchange clears its own, chunk by chunk)
+  TransArgs TZ = T;
+  if (!xp) {
+    TZ.zero_list = t->t_split_arcs.p;
+    TZ.n_zero = (uint32_t)t->t_split_arcs.n;
+  }
   const bool side_by_side = t->use_transpose && t->lat.lane_classes.size() > 1 && t->lat.lane_tiles_aligned && t->lat.wave_classes.empty();
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
@@ -1052,7 +1117,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
         HIPCHK(hipEventRecord(t->cev[q], t->cstream[q]));
         HIPCHK(hipStreamWaitEvent(s, t->cev[q], 0));
       }
-  } else if (tile_sweep && launch_tile_sweep(T, LA, t->tile_group.p, 0, lane_tiles, s) == hipSuccess) {
+  } else if (tile_sweep && launch_tile_sweep(TZ, LA, t->tile_group.p, 0, lane_tiles, s) == hipSuccess) {
     // (a refused launch -- the device would not take the kernel's LDS attribute -- falls through to the three kernels, which
     // work on the tile-sweep layout too: tile_sweep_done below stays false)
     tile_sweep_done = true;
@@ -1096,12 +1161,6 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   R.counts = t->counts_ptr();
   R.n_arcs = t->w.n_arcs;
   R.n_hot_chunks = t->hot_chunks.n / 3;
-  // the corpus scalars only need pair_logprob[]: they run beside the count reduction
-  HIPCHK(hipEventRecord(t->ev_fork, s));
-  HIPCHK(hipStreamWaitEvent(t->side, t->ev_fork, 0));
-  HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
-                        t->counts_ptr() + t->w.n_arcs, t->side));
-  HIPCHK(hipEventRecord(t->ev_join, t->side));
   if (t->use_transpose) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
     const uint32_t first = (side_by_side || tile_sweep_done || lane_fused) ? lane_tiles : 0u;
@@ -1109,13 +1168,31 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     if (xp) {  // the counts leave arc range by arc range, each into its reduce-scatter while the next is being summed
       int rc = exchange_counts_out(t, xp, T);
       if (rc) return rc;
-    } else
+    } else if (tile_sweep_done)
+      HIPCHK(launch_trans_c_bucket_range(T, 0, T.n_buckets, s));  // (cleared by the sweep)
+    else
       HIPCHK(launch_trans_c_bucket(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
   } else
     HIPCHK(launch_count_reduce(R, s));
-  HIPCHK(hipStreamWaitEvent(s, t->ev_join, 0));
-  if (timed) HIPCHK(hipEventRecord(t->ev1, s));
-  if (xp) {  // (after ev1: the E-step's own time stays comparable with the one-GPU figure)
+  // the corpus scalars only need pair_logprob[]: they run on the side stream BEHIND the count pass -- beside the M-step, or
+  // whatever the caller enqueues next -- and the trainer's stream joins them when somebody needs them (scalars_join).  Forked
+  // between the sweep and the count pass (rounds 2-5) the event cost the E-step a bubble of 8 us, and the join another before
+  // the M-step (tools/r5_timeline.sh).
+  // (one event at the end of the count pass: the E-step's closing time stamp is also what the side stream waits for)
+  hipEvent_t fork = timed ? t->ev1 : t->ev_fork;
+  HIPCHK(hipEventRecord(fork, s));
+  HIPCHK(hipStreamWaitEvent(t->side, fork, 0));
+  HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
+                        t->counts_ptr() + t->w.n_arcs, t->side));
+  HIPCHK(hipEventRecord(t->ev_join, t->side));
+  t->scalars_pending = true;
+  // somebody reads the scalars straight off the stream: the exchange's tail, or a caller who owns the count buffer and orders
+  // work of their own behind the E-step (carmel_hip_stream)
+  if (xp || t->ext_counts) {
+    int rc = scalars_join(t);
+    if (rc) return rc;
+  }
+  if (xp) {
     int rc = exchange_counts_tail(t, xp);
     if (rc) return rc;
   }
@@ -1189,6 +1266,8 @@ int carmel_hip_read_scalars(carmel_hip_trainer* t, carmel_hip_estimate_result* r
     int xrc = exchange_settle(t, false);
     if (xrc) return xrc;
   }
+  int jrc = scalars_join(t);
+  if (jrc) return jrc;
   double sc[4];
   HIPCHK(hipMemcpyAsync(sc, t->counts_ptr() + t->w.n_arcs, sizeof sc, hipMemcpyDeviceToHost, t->stream));
   HIPCHK(hipStreamSynchronize(t->stream));
@@ -1251,6 +1330,8 @@ int carmel_hip_synchronize(carmel_hip_trainer* t) {
     int xrc = exchange_settle(t, false);
     if (xrc) return xrc;
   }
+  int jrc = scalars_join(t);
+  if (jrc) return jrc;
   HIPCHK(hipStreamSynchronize(t->stream));
   return CARMEL_HIP_OK;
 }
@@ -1323,6 +1404,10 @@ int carmel_hip_accumulate_counts(carmel_hip_trainer* t, int op) {
     return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_accumulate_counts: explicit lattices only (carmel_hip_set_layout_policy(t, 0) before build_lattices)");
   const uint64_t n = t->w.n_arcs + 4;
   hipStream_t s = t->stream;
+  {
+    int jrc = scalars_join(t);
+    if (jrc) return jrc;
+  }
   if (op == 0) {
     if (t->counts_acc.n != n) HIPCHK(t->counts_acc.alloc(n));
     HIPCHK(hipMemsetAsync(t->counts_acc.p, 0, n * sizeof(double), s));
@@ -1377,8 +1462,8 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
       t->em_valid = false;  // the EM update IS the weight vector: nothing to keep apart (train.cc:157-171 only acts for rate > 1)
     }
     unsigned long long bits = 0;
-    HIPCHK(hipMemcpyAsync(&bits, t->maxchg.p, sizeof bits, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    int frc = fetch_u64(t, t->maxchg.p, &bits, s, !(delta_scale > 1.0));  // (an over-relaxed step ends in max_change_kernel)
+    if (frc) return frc;
     double d;
     std::memcpy(&d, &bits, sizeof d);
     result = d;

@@ -105,6 +105,13 @@ struct carmel_hip_trainer {
   DevBuf<double> u_param_wprior;        // ... summed per parameter for the unrolled sweep
   bool any_add_count = false;
   DevBuf<unsigned long long> maxchg;
+  // the M-step's largest change reaches the host through a pinned, coherent mailbox a one-thread kernel writes (value, then a
+  // sequence number, released to the system): no copy command, no stream synchronisation on the way back (engine.cpp publish_*)
+  unsigned long long* h_box = nullptr;
+  unsigned long long box_seq = 0;
+  // the corpus scalars run on the side stream behind the count pass; the trainer's stream joins them only when somebody
+  // needs them (scalars_join): an iteration that goes straight on to the M-step never waits for them
+  bool scalars_pending = false;
   uint64_t n_norm_groups = 0;
   bool have_norm = false, have_prior = false, prior_nonzero = false;
   int norm_group_by = CARMEL_HIP_NORM_CONDITIONAL;
@@ -193,6 +200,7 @@ struct carmel_hip_trainer {
 extern "C" int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M);
 extern "C" void trans_args(carmel_hip_trainer* t, TransArgs& T);
 bool exchange_is_sharded(const ExchangePlan* xp);  // exchange.cpp
+extern "C" int scalars_join(carmel_hip_trainer* t);  // engine.cpp: before anything reads counts[n_arcs .. n_arcs + 4) on the trainer's stream
 namespace carmel_hip {  // matrix_fb.hip
 int matrix_setup(carmel_hip_trainer* t, void** out);
 int matrix_estimate(carmel_hip_trainer* t, void* state, hipStream_t s);

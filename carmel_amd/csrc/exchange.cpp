@@ -563,6 +563,10 @@ int carmel_hip_allreduce_counts(carmel_hip_trainer* t, carmel_hip_comm* c) {
   if (t->device != c->device) return fail(CARMEL_HIP_ERR_ARG, "trainer and communicator live on different devices");
   HIPCHK(hipSetDevice(t->device));
   if (t->xplan && t->xplan->sharded && t->xplan->comm == c) return exchange_counts_arrive(t, t->xplan);  // enqueued by the count pass
+  {
+    int jrc = scalars_join(t);  // (the scalars travel with the counts)
+    if (jrc) return jrc;
+  }
   // the unrolled cascade sweep keeps per-PARAMETER sums in the same buffer: its first u_n_slots entries are what counts
   // there (everything is a sum over pairs either way, so the reduction is the same plain sum); the scalars follow at
   // n_arcs.  Reducing the whole buffer keeps one collective per iteration.

@@ -982,7 +982,8 @@ __global__ __launch_bounds__(256) void mstep_big_group_kernel(MstepArgs M, int u
 }
 // (the partials are cleared for the next pass here and the result is stored, not folded: no memset per M-step)
 __global__ __launch_bounds__(256) void mstep_max_final_kernel(unsigned long long* partial, uint64_t n,
-                                                              unsigned long long* bits) {
+                                                              unsigned long long* bits, unsigned long long* box,
+                                                              unsigned long long box_seq) {
   __shared__ unsigned long long shm[4];
   unsigned long long m = 0;  // non-negative doubles order like their bit patterns
   for (uint64_t k = threadIdx.x; k < n; k += 256) {
@@ -998,6 +999,10 @@ __global__ __launch_bounds__(256) void mstep_max_final_kernel(unsigned long long
   if (threadIdx.x == 0) {
     for (int k = 1; k < 4; ++k) m = shm[k] > m ? shm[k] : m;
     *bits = m;
+    if (box) {  // the host's mailbox: the value, then the sequence number it waits for
+      __hip_atomic_store(box, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(box + 1, box_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -1742,7 +1747,7 @@ hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
     hipLaunchKernelGGL(mstep_normalize_kernel, dim3(MSTEP_GRID), dim3(256), 0, s, M, use_counts);
   }
   hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID,
-                     M.max_change_bits);
+                     M.max_change_bits, M.box, M.box_seq);
   return hipGetLastError();
 }
 hipError_t launch_mstep_window_range(const MstepArgs& M0, int use_counts, uint32_t block_first, uint32_t n_blocks, hipStream_t s) {
@@ -1756,7 +1761,8 @@ hipError_t launch_mstep_window_range(const MstepArgs& M0, int use_counts, uint32
   return hipGetLastError();
 }
 hipError_t launch_mstep_max_final(const MstepArgs& M, hipStream_t s) {
-  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID, M.max_change_bits);
+  hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID, M.max_change_bits, M.box,
+                     M.box_seq);
   return hipGetLastError();
 }
 hipError_t launch_overrelax(double* logw, const double* old_logw, double* em_logw, const uint32_t* group, double rate,

@@ -122,6 +122,10 @@ struct TransArgs {
   uint32_t bucket_first, bucket_count;  // the bucket range of this launch of a bucket pass (arc-range chunks of the exchange)
   uint32_t slack_bytes;     // readable bytes behind x / xc / t_pos / t_src (DEVBUF_SLACK when they are DevBufs, engine.hpp): the
                             // persistent tile kernels read whole rounds past a tile's last item
+  // tile_sweep_kernel, when asked: counts[zero_list[0 .. n_zero)] := 0 on its way in -- the arcs whose items lie in several
+  // buckets, which the count pass adds up with atomics (instead of a zero_list_kernel launch between the sweep and the count pass)
+  const uint32_t* zero_list = nullptr;
+  uint32_t n_zero = 0;
 };
 
 #define TRANS_RUN_CAP 4096
@@ -182,6 +186,10 @@ struct MstepArgs {
   // asked for it (the one-pass window kernel only handles the linear scale).
   const double* dig_alpha;
   const double* tie_alpha;
+  // mstep_max_final_kernel also stores the result and then box_seq into this pinned, coherent host mailbox (release, system
+  // scope) when box != null: the host spins on the sequence number instead of a copy command and a stream synchronisation
+  unsigned long long* box = nullptr;
+  unsigned long long box_seq = 0;
 };
 
 // fused: the XC form of the backward pass (LaneArgs::xc_* set; the groups lie on LANE_FUSED_TILE boundaries)

@@ -96,6 +96,8 @@ uint64_t assign_lane_classes(LatticeSet& out, const BuildOptions& opt, bool only
     }
     out.tile_group.push_back((uint32_t)ng);
     base = (base + TILE_SWEEP_TILE - 1) / TILE_SWEEP_TILE * TILE_SWEEP_TILE;
+    // a small corpus (config 2: 287 buckets of 8192 items for 256 CUs that take two each) fills the chip with half-size buckets
+    if (base / TRANS_BUCKET < 768) out.bucket = TRANS_BUCKET / 2;
     LatticeSet::LaneClass lc;  // one class: the tile kernel needs none, the lane kernel (A/B) takes the largest column
     lc.first = 0;
     lc.count = (uint32_t)ng;

@@ -487,6 +487,8 @@ __global__ __launch_bounds__(TILE_SWEEP_THREADS) void tile_sweep_kernel(TransArg
   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t vidx = blockIdx.x;
   const uint32_t z = ts_zero();
+  // (on the way in: the count pass's atomics start from zero -- TransArgs::zero_list)
+  for (uint32_t i = blockIdx.x * TILE_SWEEP_THREADS + threadIdx.x; i < T.n_zero; i += gridDim.x * TILE_SWEEP_THREADS) T.counts[T.zero_list[i]] = 0.0;
   TileWalk cur = tile_walk_at(T, A, tile_group, vidx, true, z);
   if (!cur.ok) return;
   cur = ts_uniform(cur);
