@@ -52,6 +52,13 @@ struct Opts {
   bool final_counts = false, uniform_p0 = false, parallel = false;
   unsigned long long seed = 0;
   int gpu = 0;
+  // checkpoints and reports on "watch iterations" (forest-em-params.hpp:138-168, forest-em.hpp:621-653): the first
+  // watch_period M-steps of a (re)start and every watch_period-th after
+  std::string checkpoint_prefix;      // -x / --checkpoint-prefix
+  bool checkpoint_parameters = false; // -c: <prefix>.params.restart.R.iteration.I and <prefix>.counts. ...
+  long watch_period = 10;             // -W
+  double report_counts = std::numeric_limits<double>::infinity();  // -X / --report-counts-exceeding (ln)
+  double report_probs = std::numeric_limits<double>::infinity();   // -Y / --report-probs-exceeding (ln)
 };
 
 void usage() {
@@ -59,6 +66,7 @@ void usage() {
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
                "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel\n"
                "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
+               "                 [-x checkpoint-prefix -c] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -148,11 +156,20 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "prior-inference-start") o.pi_start = std::atol(value(val).c_str());
     else if (key == "prior-inference-end") o.pi_end = std::atol(value(val).c_str());
     else if (key == "prior-inference-restart-fresh") {}  // acts on --crp-restarts only, which this front end does not run
+    else if (key == "x" || key == "checkpoint-prefix") o.checkpoint_prefix = value(val);
+    else if (key == "c" || key == "checkpoint-parameters") o.checkpoint_parameters = true;
+    else if (key == "W" || key == "watch-period") o.watch_period = std::atol(value(val).c_str());
+    else if (key == "X" || key == "report-counts-exceeding") {
+      if (!carmel_host::parse_weight_token(value(val), o.report_counts)) throw std::runtime_error("bad weight after " + a);
+    } else if (key == "Y" || key == "report-probs-exceeding") {
+      if (!carmel_host::parse_weight_token(value(val), o.report_probs)) throw std::runtime_error("bad weight after " + a);
+    }
     else if (key == "random-seed") o.seed = std::strtoull(value(val).c_str(), 0, 10);
     else if (key == "gpu") o.gpu = std::atoi(value(val).c_str());
     else throw std::runtime_error("unknown option " + a);
   }
   if (o.forests_file.empty()) throw std::runtime_error("no forests file (-f)");
+  if (o.checkpoint_prefix.empty()) o.checkpoint_parameters = false;  // forest-em-params.cpp:43-47
   return o;
 }
 
@@ -306,9 +323,11 @@ int main(int argc, char** argv) {
       std::vector<double> best_w = logw;
       bool very_first = true;
       long restarts_left = o.restarts;
+      const bool count_report = !(std::isinf(o.report_counts) && o.report_counts > 0 && std::isinf(o.report_probs) && o.report_probs > 0);
       for (uint32_t restart = 0;; ++restart) {
       double last = -std::numeric_limits<double>::infinity();
       bool first = true;
+      long m_steps = 0;  // FForests::iteration: M-steps since the (re)start (forest-em.hpp:376, 398, 653)
       for (long it = 1; it <= o.max_iter; ++it) {
         double alp = 0;
         uint64_t n_zero = 0;
@@ -339,6 +358,37 @@ int main(int argc, char** argv) {
         double delta = 0;
         check(carmel_hip_forests_maximize(F, o.prior_counts, o.add_k, o.zero_zerocounts ? 1 : 0, &delta),
               "carmel_hip_forests_maximize");
+        // FForests::maximize's tail (forest-em.hpp:638-653): on a watch iteration the parameters and the counts they were
+        // normalised from are dumped (dump_params :172-189) and the counts above the thresholds counted
+        if (m_steps <= o.watch_period || (o.watch_period && m_steps % o.watch_period == 0)) {
+          if (o.checkpoint_parameters || count_report) {
+            std::vector<double> cw(n_rules), cc(n_rules);
+            check(carmel_hip_forests_get_counts(F, o.prior_counts, cc.data()), "carmel_hip_forests_get_counts");
+            if (o.checkpoint_parameters) {
+              check(carmel_hip_forests_get_weights(F, cw.data()), "carmel_hip_forests_get_weights");
+              const std::string suffix = ".restart." + std::to_string(restart + 1) + ".iteration." + std::to_string(m_steps + 1);
+              const std::string wf = o.checkpoint_prefix + ".params" + suffix, cf = o.checkpoint_prefix + ".counts" + suffix;
+              std::vector<double> lc(n_rules);
+              for (uint32_t r = 0; r < n_rules; ++r) lc[r] = cc[r] > 0 ? std::log(cc[r]) : -std::numeric_limits<double>::infinity();
+              log << "\nWriting trained parameters to " << wf << "\n";
+              spit(wf, write_params(cw.data() + 1, n_rules - 1, style));
+              log << "Writing trained counts to " << cf << "\n";
+              spit(cf, write_params(lc.data() + 1, n_rules - 1, style));
+            }
+            if (count_report) {
+              // (both tallies run over the COUNTS, as forest-em.hpp:644-649 has them)
+              uint64_t n_count = 0, n_prob = 0;
+              for (uint32_t r = 1; r < n_rules; ++r) {
+                const double lc = cc[r] > 0 ? std::log(cc[r]) : -std::numeric_limits<double>::infinity();
+                if (lc >= o.report_counts) ++n_count;
+                if (lc >= o.report_probs) ++n_prob;
+              }
+              log << " (out of " << n_rules - 1 << " parameters, " << n_count << " had count > " << format_weight(o.report_counts, style)
+                  << ", and " << n_prob << " had prob > " << format_weight(o.report_probs, style) << ")";
+            }
+          }
+        }
+        ++m_steps;
         if (delta <= o.converge_delta) {
           log << "Converged - maximum parameter change " << delta << " after " << it << " iterations.\n";
           break;

@@ -104,6 +104,45 @@ def test_forest_em_cli_random_restarts(oracle, golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
+def test_forest_em_cli_checkpoints_on_watch_iterations(oracle, golden_dir, tmp_path):
+    """-x PREFIX -c -W 2 (forest-em-params.hpp:138-145; FForests::maximize's tail forest-em.hpp:638-653, dump_params :172-189):
+    after the first W + 1 M-steps of a (re)start and every W-th after, the parameters and the counts they were normalised from
+    go to PREFIX.{params,counts}.restart.R.iteration.I; -X / -Y report how many counts exceed the thresholds.  Every dump is the
+    oracle's state after that M-step; a random restart starts a new series"""
+    f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
+    pre = str(tmp_path / "ck")
+    rc, so, err = run(["-f", f, "-n", n, "-o", str(tmp_path / "o"), "-i", "7", "-r", "1", "--random-seed=5", "-e", "-1", "-d", "-1",
+                       "-x", pre, "-c", "-W", "2", "-X", "0.5", "-Y", "2"])
+    assert rc == 0, err
+    from carmel_amd._capi import lib
+    of = oracle.OracleForests(open(f).read(), open(n).read())
+    of.init_rule_weights()
+    reports = re.findall(r"\(out of (\d+) parameters, (\d+) had count > (\S+), and (\d+) had prob > (\S+)\)", err)
+    k = 0
+    for restart in (1, 2):
+        for m in range(7):
+            cnt = np.exp(of.estimate()[1])  # (the oracle's counts are logarithms)
+            of.maximize()
+            watch = m <= 2 or m % 2 == 0
+            for kind in ("params", "counts"):
+                path = "%s.%s.restart.%d.iteration.%d" % (pre, kind, restart, m + 1)
+                assert os.path.exists(path) == watch, path
+            if watch:
+                tag = ".restart.%d.iteration.%d" % (restart, m + 1)
+                np.testing.assert_allclose(parse_vec(open(pre + ".params" + tag).read()), np.exp(of.weights()[1:]), rtol=1e-9, atol=1e-300)
+                np.testing.assert_allclose(parse_vec(open(pre + ".counts" + tag).read()), cnt[1:], rtol=1e-9, atol=1e-300)
+                total, n_count, _, n_prob, _ = reports[k]
+                assert int(total) == of.n_rules - 1
+                assert int(n_count) == int((cnt[1:] >= 0.5).sum()) and int(n_prob) == int((cnt[1:] >= 2).sum())
+                k += 1
+        of.randomize([1.0 - lib.carmel_hip_gibbs_uniform(5, restart, r, 0) for r in range(of.n_rules)])
+    assert k == len(reports) and err.count("Writing trained parameters to " + pre) == k
+    # without a prefix -c writes nothing (forest-em-params.cpp:43-47)
+    rc, so, err = run(["-f", f, "-n", n, "-i", "3", "-c"])
+    assert rc == 0 and "Writing trained parameters" not in err
+
+
+@pytest.mark.gpu
 def test_forest_em_cli_options(oracle, tmp_path):
     """initial parameters (-I), add-k smoothing, prior counts, counts output (-O), human probs (-H)"""
     from test_forest_gpu import synth_forests
