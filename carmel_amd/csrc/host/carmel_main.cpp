@@ -81,6 +81,7 @@ struct Options {
   int gpus = 1;  // --gpus=N: corpus-sharded EM, one process per GPU (not a carmel option: carmel is single-process)
   std::string comm_plugin;  // --comm-plugin=LIB.so: a transport of the caller's own instead of RCCL (carmel_hip_comm_create_custom);
                             // every rank then runs on the device --gpu names (the transport decides where the data travels)
+  bool random_set = false;  // --random-set (carmel.cc:609-612, 786-789): a new weight on (0..1] for every unlocked arc before training
   int exchange_form = 0;    // --exchange=auto|allreduce|collectives|direct (carmel_hip_exchange_plan's form)
   int exchange_chunks = 0;  // --exchange-chunks=K: arc-range chunks of the sharded count exchange (0: the library's default)
   // --crp (carmel.cc:255-304)
@@ -141,6 +142,8 @@ static Options parse_args(int argc, char** argv) {
         o.gpus = std::max(1, std::atoi(v.c_str()));
       else if (k == "comm-plugin")
         o.comm_plugin = v;
+      else if (k == "random-set")
+        o.random_set = true;
       else if (k == "exchange") {
         const char* names[] = {"auto", "allreduce", "collectives", "direct"};
         o.exchange_form = -1;
@@ -309,7 +312,7 @@ static Options parse_args(int argc, char** argv) {
             // switches without a value that this front end implements; everything else carmel knows (k-best, generation,
             // projection, pruning, OpenFst, ...) is outside the training path
             // (O I Q W E @: WFST::path_print, fst.h:60-160 -- how --print-to writes the sampled paths)
-            if (!std::strchr("tUujnlqdKmHJZDB2?:caShOIQWE@", a[j]))
+            if (!std::strchr("tUujnlqdKmHJZDB2?:caShOIQWE@1", a[j]))
               throw UsageError(std::string("switch -") + a[j] + " is not implemented by the GPU training front end");
             break;
         }
@@ -515,7 +518,24 @@ static int run(int argc, char** argv) {
     }
   }
   const bool any_digamma = std::find(dig_on.begin(), dig_on.end(), (uint8_t)1) != dig_on.end();
-  // fem_in (carmel.cc:785-808): with --normby the INPUT transducers are normalised before anything is composed
+  // fem_in (carmel.cc:785-808).  --random-set (:786-789, cascade.h:398-401; -1 below is WFST::randomScale, fst.h:973-975, on the
+  // same draws): every unlocked arc of every member not normalised by NONE gets a new weight on (0..1] -- drawn from this
+  // build's counter-based generator, numbered member by member in arc order as the random restarts number them (the
+  // reference's Boost stream is not pinned by anything it holds); training starts by normalising (train.cc:509).
+  if (o.random_set || o.flags[(unsigned)'1']) {
+    std::cerr << "Using random seed -R " << o.seed << std::endl;  // show_seed, carmel.cc:65-69
+    uint32_t p = 0;
+    for (size_t i = 0; i < nw; ++i)
+      for (auto& st : member[i].states)
+        for (auto& a : st) {
+          if (a.group != kLocked && norms[i] != CARMEL_HIP_NORM_NONE) {
+            const double lu = std::log(1.0 - carmel_hip_gibbs_uniform(o.seed, 0, p, 0));
+            a.logw = o.random_set ? lu : a.logw + lu;
+          }
+          ++p;
+        }
+  }
+  // with --normby the INPUT transducers are normalised before anything is composed
   if (!o.normby.empty()) {
     std::cerr << "Normalizing input transducers by --normby=" << o.normby << std::endl;
     for (size_t i = 0; i < nw; ++i) member[i].normalize(norms[i], addc[i], dig_on[i] != 0, dig_alpha[i]);

@@ -24,7 +24,7 @@ static std::string slurp(const char* fn) {
 
 static int real_main(int argc, char** argv) {
   bool flags[256] = {0};
-  bool trainc = false;
+  bool trainc = false, random_set = false;
   TrainOpts topt;
   LW converge = LW::from_real(1e-4), converge_pp = LW::from_real(.999), smoothFloor;
   NormalizeMethod nm;
@@ -44,6 +44,8 @@ static int real_main(int argc, char** argv) {
       }
       if (k == "train-cascade")
         trainc = true;
+      else if (k == "random-set")
+        random_set = true;
       else if (k == "normby")
         normby = v;
       else if (k == "priors")
@@ -140,6 +142,21 @@ static int real_main(int argc, char** argv) {
       if (c == std::string::npos) break;
       p0 = c + 1;
     }
+  }
+  // fem_in (carmel.cc:785-789) --random-set / -1 (fst.h:973-977): a new weight on (0..1] for (-1: a factor on) every unlocked arc
+  // of the members not normalised by NONE, from the restart generator's stream 0 (train.hpp restart_uniform)
+  if (random_set || flags['1']) {
+    std::cerr << "Using random seed -R " << topt.restart_seed << std::endl;
+    unsigned p = 0;
+    for (size_t i = 0; i < nw; ++i)
+      for (auto& st : chain[i].states)
+        for (auto& a : st) {
+          if (!a.locked() && nms[i < N ? i : 0].group != NORM_NONE) {
+            const LW u = LW::from_real(1.0 - restart_uniform(topt.restart_seed, 0, p));
+            a.weight = random_set ? u : a.weight * u;
+          }
+          ++p;
+        }
   }
   // fem_in -> fem_normby (carmel.cc:778-783, 800): with --normby the inputs are normalised before composition
   if (!normby.empty()) {

@@ -656,6 +656,36 @@ def test_lattices_beyond_the_resident_budget_are_streamed(golden_dir, tmp_path, 
             assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
 
 
+@pytest.mark.parametrize("args", [["--random-set", "-t"], ["-1", "-t"], ["--random-set", "--train-cascade", "-HJ"],
+                                  ["--random-set", "--train-cascade", "-HJ", "--normby=JN"]])
+def test_random_set_and_random_scale(golden_dir, args):
+    """--random-set / -1 (carmel.cc:603-612, 786-789; fst.h:973-977; cascade.h:398-401): before training every unlocked arc of the
+    members not normalised by NONE gets a new weight on (0..1] (-1: is scaled by one).  The reference's Boost stream is
+    unpinned; the command line and the oracle share this build's counter-based generator, so their runs coincide -- and
+    differ from the run without the switch"""
+    oracle_cli = os.path.join(ROOT, "oracle", "oracle_carmel")
+    if not os.path.exists(oracle_cli):
+        pytest.skip("oracle CLI not built")
+    casc = "--train-cascade" in args
+    files = ["cipher.data", "cipher.wfsa", "cipher.fst"] if casc else ["epron-jpron.data", "epron-jpron.fst"]
+    full = args + ["-R", "11", "-M", "5"] + [os.path.join(golden_dir, f) for f in files]
+    rc, out, err = run(full)
+    assert rc == 0, err
+    assert "Using random seed -R 11" in err
+    p = subprocess.run([oracle_cli] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    assert p.returncode == 0, p.stderr
+    keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "Converged"))]
+    mine, ref = keep(err), keep(p.stderr)
+    assert len(mine) == len(ref) >= 3
+    for x, y in zip(mine, ref):
+        assert NUM.sub("#", x) == NUM.sub("#", y)
+        for u, v in zip(NUM.findall(x), NUM.findall(y)):
+            assert float(u) == pytest.approx(float(v), rel=1e-4)
+    rc0, out0, err0 = run([a for a in full if a not in ("--random-set", "-1")])
+    # (--normby=JN: the language model's arcs are locked and the channel is normalised by NONE -- nothing is drawn)
+    assert (keep(err0)[0] == mine[0]) == ("--normby=JN" in args)
+
+
 def test_single_iteration_with_restarts_runs_the_restart_loop(golden_dir, tmp_path):
     """-M 1 -! 2: the one-iteration shortcut is taken only without random restarts (train.cc:520)"""
     g = lambda n: os.path.join(golden_dir, n)
