@@ -19,6 +19,7 @@
 int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_derivation, carmel_hip_lattice_stats* stats);
 int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* has_derivation, carmel_hip_lattice_stats* stats,
                        bool& done);
+int gpu_tables_for_host_layout(carmel_hip_trainer* t, const std::vector<uint32_t>& lane_arc, const std::vector<uint32_t>& wave_arc);
 int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out);
 int build_run_tables(carmel_hip_trainer* t);
 // exchange.cpp: the sharded count exchange of corpus-sharded EM
@@ -270,7 +271,13 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   std::string err;
   LatticeSet& L = t->lat;
   L = LatticeSet();
+  // the host builder lays the lattices out (one-per-wavefront lattices, bundles: the cases the device builder leaves to it);
+  // sorting the posterior slots by arc and the transposition tables -- two thirds of its time on the `long` workload, all of it
+  // counting sorts -- are the device's (lattice_gpu.hip gpu_tables_for_host_layout; CARMEL_HIP_DEVICE_TABLES=0: the host's, A/B)
+  opt.device_tables = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0) &&
+                      !(getenv("CARMEL_HIP_DEVICE_TABLES") && atoi(getenv("CARMEL_HIP_DEVICE_TABLES")) == 0);
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
+  const bool have_tables = !L.t_buckets.empty() || L.tables_deferred;
   if (has_derivation) std::memcpy(has_derivation, L.has_deriv.data(), L.has_deriv.size());
   hipStream_t s = t->stream;
   HIPCHK(t->bundles.upload(L.bundles, s));
@@ -300,7 +307,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   {
     // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
     const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
-    if (want_t && !L.t_buckets.empty()) {
+    if (want_t && have_tables) {
       std::vector<uint32_t> fx(L.lane_fwd.size());
       host_parallel_for(fx.size(), [&](size_t k0, size_t k1) {
         for (size_t k = k0; k < k1; ++k) fx[k] = L.lane_fwd[k].x;
@@ -353,38 +360,50 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   else
     HIPCHK(t->post.alloc(L.n_post));
   HIPCHK(t->wcache.alloc(t->lane_records));
-  if (!L.waves.empty() && L.t_buckets.empty())
+  if (!L.waves.empty() && !have_tables)
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "lattice set too large for the blocked transposition (2^32 items) with one-per-wavefront lattices");
   if (L.lane_spill_rows)
     HIPCHK(t->lane_spill.alloc(L.lane_spill_rows * 64));
   else
     t->lane_spill.release();
-  HIPCHK(t->arc_off.upload(L.arc_off, s));
-  HIPCHK(t->slot_pos.upload(L.slot_pos, s));
-  HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
-  {
-    const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
-    t->use_transpose = want && !L.t_buckets.empty();
-    if (t->use_transpose) {
-      HIPCHK(t->t_buckets.upload(L.t_buckets, s));
-      HIPCHK(t->t_tile_base.upload(L.t_tile_base, s));
-      HIPCHK(t->t_b_arc.upload(L.t_b_arc, s));
-      HIPCHK(t->t_b_rank.upload(L.t_b_rank, s));
-      HIPCHK(t->t_b_src.upload(L.t_b_src, s));
-      HIPCHK(t->t_t_pos.upload(L.t_t_pos, s));
-      HIPCHK(t->t_t_src.upload(L.t_t_src, s));
-      HIPCHK(t->t_a_off.upload(L.t_a_off, s));
-      HIPCHK(t->t_split_arcs.upload(L.t_split_arcs, s));
-      HIPCHK(t->t_x.alloc(L.slot_pos.size()));
-      HIPCHK(t->t_xc.alloc(L.slot_pos.size()));
-      HIPCHK(hipStreamSynchronize(s));
+  if (L.tables_deferred) {
+    // the arc of every lane record (the kernels' copy keeps the flags word only), then the device does the rest
+    std::vector<uint32_t> la(L.lane_bwd.size());
+    host_parallel_for(la.size(), [&](size_t k0, size_t k1) {
+      for (size_t k = k0; k < k1; ++k) la[k] = (L.lane_bwd[k].x & LANE_VALID) ? L.lane_bwd[k].y : 0xffffffffu;
+    });
+    t->hot_chunks.release();  // (the gather formulation is not offered on top of device-built tables)
+    int rc = gpu_tables_for_host_layout(t, la, L.wave_bwd_arc);
+    if (rc) return rc;
+    t->use_transpose = true;
+  } else {
+    HIPCHK(t->arc_off.upload(L.arc_off, s));
+    HIPCHK(t->slot_pos.upload(L.slot_pos, s));
+    HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
+    {
+      const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+      t->use_transpose = want && !L.t_buckets.empty();
+      if (t->use_transpose) {
+        HIPCHK(t->t_buckets.upload(L.t_buckets, s));
+        HIPCHK(t->t_tile_base.upload(L.t_tile_base, s));
+        HIPCHK(t->t_b_arc.upload(L.t_b_arc, s));
+        HIPCHK(t->t_b_rank.upload(L.t_b_rank, s));
+        HIPCHK(t->t_b_src.upload(L.t_b_src, s));
+        HIPCHK(t->t_t_pos.upload(L.t_t_pos, s));
+        HIPCHK(t->t_t_src.upload(L.t_t_src, s));
+        HIPCHK(t->t_a_off.upload(L.t_a_off, s));
+        HIPCHK(t->t_split_arcs.upload(L.t_split_arcs, s));
+        HIPCHK(t->t_x.alloc(L.slot_pos.size()));
+        HIPCHK(t->t_xc.alloc(L.slot_pos.size()));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      std::vector<uint16_t>().swap(L.t_b_arc);
+      std::vector<uint16_t>().swap(L.t_a_off);
+      std::vector<uint16_t>().swap(L.t_b_rank);
+      std::vector<uint16_t>().swap(L.t_t_pos);
+      std::vector<uint32_t>().swap(L.t_b_src);
+      std::vector<uint32_t>().swap(L.t_t_src);
     }
-    std::vector<uint16_t>().swap(L.t_b_arc);
-    std::vector<uint16_t>().swap(L.t_a_off);
-    std::vector<uint16_t>().swap(L.t_b_rank);
-    std::vector<uint16_t>().swap(L.t_t_pos);
-    std::vector<uint32_t>().swap(L.t_b_src);
-    std::vector<uint32_t>().swap(L.t_t_src);
   }
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
   {
@@ -888,6 +907,31 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
   T.slack_bytes = (uint32_t)DEVBUF_SLACK;  // x, xc, t_pos, t_src are DevBufs
 }
 
+// CARMEL_HIP_POISON=2 (debugging): LDS keeps what the last workgroup on the CU left there -- zeros on an idle box, somebody's
+// data after somebody's job.  Filling every CU's LDS with 0xff bytes before an E-step / M-step makes a kernel that reads LDS it
+// never wrote fail on every run.
+__global__ __launch_bounds__(256) void lds_poison_kernel(unsigned* sink) {
+  extern __shared__ unsigned lds_words[];
+  const unsigned n = 160 * 1024 / 4 - 64;
+  for (unsigned i = threadIdx.x; i < n; i += 256) lds_words[i] = 0xffffffffu;
+  __syncthreads();
+  if (lds_words[(threadIdx.x * 977u) % n] != 0xffffffffu) *sink = 1;  // (keeps the stores)
+}
+static int lds_poison(carmel_hip_trainer* t) {
+  static const int mode = getenv("CARMEL_HIP_POISON") ? atoi(getenv("CARMEL_HIP_POISON")) : 0;
+  if (mode < 2) return CARMEL_HIP_OK;
+  static bool attr = false;
+  const int bytes = 160 * 1024 - 256;
+  if (!attr) {
+    HIPCHK(hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    attr = true;
+  }
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), bytes, t->stream, (unsigned*)t->maxchg.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+
 // the trainer's stream takes delivery of the corpus scalars (a9) the side stream computed behind the last count pass
 int scalars_join(carmel_hip_trainer* t) {
   if (!t->scalars_pending) return CARMEL_HIP_OK;
@@ -935,6 +979,10 @@ static int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsig
 // Enqueues one E-step on the trainer's stream(s).  timed: bracket it with ev0 / ev1 (not inside a graph capture).
 static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   hipStream_t s = t->stream;
+  {
+    int prc = lds_poison(t);
+    if (prc) return prc;
+  }
   {  // (the last E-step's scalars read pair_logprob[], which this one rewrites)
     int rc = scalars_join(t);
     if (rc) return rc;
@@ -1429,6 +1477,10 @@ int carmel_hip_maximize(carmel_hip_trainer* t, double delta_scale, double* max_c
   if (!t->have_norm) return fail(CARMEL_HIP_ERR_STATE, "set_norm / set_cascade first");
   HIPCHK(hipSetDevice(t->device));
   hipStream_t s = t->stream;
+  {
+    int prc = lds_poison(t);
+    if (prc) return prc;
+  }
   if (t->xplan) {
     // corpus-sharded EM with a planned exchange: every rank normalises its own arc ranges and the weights are gathered
     // (exchange.cpp); an over-relaxed step needs every count everywhere, so the count pieces are gathered first

@@ -1,6 +1,7 @@
 // engine.hpp — trainer state shared by engine.cpp (EM entry points) and gibbs.hip (sampler entry points).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include "../../include/carmel_hip.h"
@@ -39,7 +40,16 @@ struct DevBuf {
     release();
     n = count;
     if (!count) return hipSuccess;
-    return hipMalloc((void**)&p, count * sizeof(T) + DEVBUF_SLACK);
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T) + DEVBUF_SLACK);
+    // CARMEL_HIP_POISON=1 (debugging): fresh device memory is whatever the last process left there, usually zeros on an idle box;
+    // a pattern of 0xff bytes (a NaN to every double, an out-of-range index to every integer) makes a read of something never
+    // written show up on every run instead of on the one after somebody else's job
+    static const bool poison = getenv("CARMEL_HIP_POISON") && atoi(getenv("CARMEL_HIP_POISON"));
+    if (poison && e == hipSuccess) {
+      e = hipMemset(p, 0xff, count * sizeof(T) + DEVBUF_SLACK);
+      if (e == hipSuccess) e = hipDeviceSynchronize();  // (before anything on another stream writes there)
+    }
+    return e;
   }
   hipError_t upload(const std::vector<T>& v, hipStream_t s) {
     hipError_t e = alloc(v.size());

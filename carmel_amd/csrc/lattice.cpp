@@ -1300,6 +1300,11 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     out.wave_slot_base = nwave ? (nlane_rec + out.tile - 1) / out.tile * out.tile : nlane_rec;
     const uint64_t nlane = out.wave_slot_base + nwave;  // first bundle slot
     out.n_post = nlane + out.out_arcs.size();
+    if (opt.device_tables && out.n_post && out.n_post < (1ull << 32)) {  // (the engine sorts the slots and builds the tables on the device)
+      out.tables_deferred = true;
+      phase("slots by arc (left to the device)");
+      return true;
+    }
     // counting sort by arc id, stable in slot order.  Threads own contiguous arc ranges: each scans every record (a
     // sequential read) and handles the records of its own arcs, so counters and output stay private and local.
     std::vector<uint64_t> cnt(w.n_arcs + 1, 0);

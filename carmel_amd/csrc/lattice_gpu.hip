@@ -24,6 +24,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -893,6 +894,144 @@ int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* o
 
 // Returns CARMEL_HIP_OK with done = true when the lattices were built on the GPU; done = false: not a case for this
 // builder (the caller runs the host builder).
+// The tables of the blocked transposition from the (arc << 32 | slot) items of a lattice set, on the device: slots by arc
+// (arc_off, slot_pos), the buckets, the bucket-major and tile-major orders.  Shared by the device builder below and by the
+// host builder's layouts (one-per-wavefront lattices, bundles: gpu_tables_for_host_layout) -- the host's own counting sorts of
+// the same (lattice.cpp build_transpose) give the same bytes.  n_sort >= n_items keys are sorted; the ones past n_items carry
+// the arc id n_arcs (slots that hold no arc) and are ignored afterwards.
+static int gpu_tables_from_items(carmel_hip_trainer* t, DevBuf<char>& tmp, DevBuf<unsigned long long>& items, DevBuf<unsigned long long>& items_sorted,
+                                 uint64_t n_items, uint64_t n_sort, uint64_t n_post, const std::function<void(const char*)>& lap) {
+  const HostWfst& w = t->w;
+  const LatticeSet& L = t->lat;
+  hipStream_t s = t->stream;
+  // ---- slots by arc ----
+  HIPCHK(sort_keys(tmp, items.p, items_sorted.p, n_sort, 32 + bits_for(w.n_arcs + 1), s));
+  HIPCHK(t->arc_off.alloc(w.n_arcs + 1));
+  HIPCHK(t->slot_pos.alloc(n_items));
+  hipLaunchKernelGGL(slots_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, items_sorted.p, n_items, w.n_arcs,
+                     t->slot_pos.p, t->arc_off.p);
+  t->hot_chunks.release();  // (the gather formulation is not offered on top of this builder)
+  lap("slots by arc");
+  // ---- transposition tables ----
+  DevBuf<uint32_t> b_end, d_nout;
+  HIPCHK(b_end.alloc(w.n_arcs));
+  HIPCHK(d_nout.alloc(4));
+  hipLaunchKernelGGL(bucket_end_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, b_end.p, L.bucket);
+  const uint32_t cap = (uint32_t)(2 * (n_items / L.bucket) + w.n_arcs / L.bucket + 2 * (n_items / TRANS_HEAVY) + 16);
+  HIPCHK(t->t_buckets.alloc(cap));
+  HIPCHK(t->t_split_arcs.alloc(cap));
+  DevBuf<uint32_t> heavy, heavy_sorted;
+  HIPCHK(heavy.alloc(cap));
+  HIPCHK(heavy_sorted.alloc(cap));
+  HIPCHK(hipMemsetAsync(d_nout.p, 0, 16, s));
+  hipLaunchKernelGGL(heavy_list_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, heavy.p, cap,
+                     d_nout.p + 3);
+  uint32_t n_heavy = 0;
+  HIPCHK(hipMemcpyAsync(&n_heavy, d_nout.p + 3, 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (n_heavy > cap) return fail(CARMEL_HIP_ERR_HIP, "gpu lattice build: heavy-arc list overflow");
+  if (n_heavy) HIPCHK(sort_keys(tmp, heavy.p, heavy_sorted.p, n_heavy, 32, s));
+  hipLaunchKernelGGL(bucket_chain_kernel, dim3(1), dim3(1), 0, s, t->arc_off.p, b_end.p, w.n_arcs, heavy_sorted.p, n_heavy,
+                     t->t_buckets.p, t->t_split_arcs.p, cap, d_nout.p, L.bucket);
+  uint32_t h_nout[4] = {0, 0, 0, 0};
+  HIPCHK(hipMemcpyAsync(h_nout, d_nout.p, 12, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (h_nout[2]) return fail(CARMEL_HIP_ERR_HIP, "gpu lattice build: bucket table overflow");
+  const uint32_t n_buckets = h_nout[0], n_split = h_nout[1];
+  t->t_buckets.n = n_buckets;       // (capacity stays; .n is what the engine reads)
+  t->t_split_arcs.n = n_split;
+  lap("buckets");
+  const uint64_t n_tiles = (n_post + L.tile - 1) / L.tile;
+  HIPCHK(t->t_a_off.alloc(w.n_arcs));
+  HIPCHK(hipMemsetAsync(t->t_a_off.p, 0, w.n_arcs * 2, s));
+  hipLaunchKernelGGL(a_off_kernel, dim3(n_buckets), dim3(256), 0, s, t->t_buckets.p, n_buckets, t->arc_off.p, t->t_a_off.p);
+  DevBuf<unsigned long long> bkey, bkey_sorted;
+  DevBuf<uint32_t> bval, bval_sorted, tile_key, tile_sorted, Jv, J_sorted;
+  HIPCHK(bkey.alloc(n_items));
+  HIPCHK(bkey_sorted.alloc(n_items));
+  HIPCHK(bval.alloc(n_items));
+  HIPCHK(bval_sorted.alloc(n_items));
+  hipLaunchKernelGGL(bucket_key_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, t->t_buckets.p, n_buckets,
+                     t->slot_pos.p, n_items, bkey.p, bval.p);
+  HIPCHK(sort_pairs(tmp, bkey.p, bkey_sorted.p, bval.p, bval_sorted.p, n_items, 32 + bits_for(n_buckets), s));
+  HIPCHK(t->t_b_arc.alloc(n_items));
+  HIPCHK(t->t_b_rank.alloc(n_items));
+  HIPCHK(t->t_b_src.alloc(n_items));
+  HIPCHK(t->t_t_pos.alloc(n_items));
+  HIPCHK(t->t_t_src.alloc(n_items));
+  HIPCHK(t->t_tile_base.alloc(n_tiles + 1));
+  HIPCHK(tile_key.alloc(n_items));
+  HIPCHK(tile_sorted.alloc(n_items));
+  HIPCHK(Jv.alloc(n_items));
+  HIPCHK(J_sorted.alloc(n_items));
+  hipLaunchKernelGGL(bucket_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, t->t_buckets.p, bkey_sorted.p,
+                     bval_sorted.p, items_sorted.p, n_items, L.tile, t->t_b_arc.p, t->t_b_rank.p, tile_key.p, Jv.p);
+  HIPCHK(sort_pairs(tmp, tile_key.p, tile_sorted.p, Jv.p, J_sorted.p, n_items, bits_for(n_tiles), s));
+  hipLaunchKernelGGL(tile_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, tile_sorted.p, J_sorted.p,
+                     bkey_sorted.p, n_items, n_tiles, L.tile, t->t_t_src.p, t->t_t_pos.p, t->t_b_src.p, t->t_tile_base.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(t->t_x.alloc(n_items));
+  HIPCHK(t->t_xc.alloc(n_items));
+  lap("transposition tables");
+  return CARMEL_HIP_OK;
+}
+
+// ... for a layout of the HOST builder (lattice.cpp with BuildOptions::device_tables: one-per-wavefront lattices, bundles,
+// mixtures): the arc of every posterior slot -- [lane records | padding to a tile | wave records | bundle out-arcs] -- goes to
+// the device, the items are formed and sorted here.  lane_arc / wave_arc: 0xffffffff where a record holds no arc.
+__global__ void host_layout_items_kernel(const uint32_t* lane_arc, uint64_t n_lane, const uint32_t* wave_arc, uint64_t wave_base, uint64_t n_wave,
+                                         const uint2* out_arcs, uint64_t n_out, uint32_t n_arcs, unsigned long long* items,
+                                         unsigned long long* n_valid) {
+  const uint64_t n_post = wave_base + n_wave + n_out;
+  unsigned long long mine = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n_post; k += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t a = 0xffffffffu;
+    if (k < n_lane)
+      a = lane_arc[k];
+    else if (k >= wave_base && k < wave_base + n_wave)
+      a = wave_arc[k - wave_base];
+    else if (k >= wave_base + n_wave)
+      a = out_arcs[k - wave_base - n_wave].y;
+    const bool ok = a != 0xffffffffu;
+    items[k] = ((unsigned long long)(ok ? a : n_arcs) << 32) | (unsigned long long)k;
+    mine += ok;
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_valid, mine);
+}
+int gpu_tables_for_host_layout(carmel_hip_trainer* t, const std::vector<uint32_t>& lane_arc, const std::vector<uint32_t>& wave_arc) {
+  const LatticeSet& L = t->lat;
+  hipStream_t s = t->stream;
+  const bool timing = getenv("CARMEL_TIMING") != nullptr;
+  auto last = std::chrono::steady_clock::now();
+  std::function<void(const char*)> lap = [&](const char* what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "timing: gpu lattice build: %-34s %.4f s\n", what, std::chrono::duration<double>(now - last).count());
+    last = now;
+  };
+  const uint64_t n_lane = lane_arc.size(), n_wave = wave_arc.size(), n_out = L.out_arcs.size(), n_post = L.n_post;
+  if (n_post != L.wave_slot_base + n_wave + n_out || n_post >= (1ull << 32) || !n_post) return fail(CARMEL_HIP_ERR_ARG, "gpu_tables_for_host_layout: inconsistent layout");
+  DevBuf<uint32_t> d_lane, d_wave;
+  DevBuf<unsigned long long> items, items_sorted, d_n;
+  DevBuf<char> tmp;
+  HIPCHK(d_lane.upload(lane_arc, s));
+  HIPCHK(d_wave.upload(wave_arc, s));
+  HIPCHK(items.alloc(n_post));
+  HIPCHK(items_sorted.alloc(n_post));
+  HIPCHK(d_n.alloc(1));
+  HIPCHK(hipMemsetAsync(d_n.p, 0, 8, s));
+  hipLaunchKernelGGL(host_layout_items_kernel, dim3((unsigned)std::min<uint64_t>((n_post + 255) / 256, 65536)), dim3(256), 0, s, d_lane.p, n_lane,
+                     d_wave.p, L.wave_slot_base, n_wave, (const uint2*)t->out_arcs.p, n_out, (uint32_t)t->w.n_arcs, items.p, d_n.p);
+  unsigned long long n_items = 0;
+  HIPCHK(hipMemcpyAsync(&n_items, d_n.p, 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  lap("items of the host layout");
+  if (!n_items) return fail(CARMEL_HIP_ERR_ARG, "gpu_tables_for_host_layout: no arc in any lattice");
+  return gpu_tables_from_items(t, tmp, items, items_sorted, n_items, n_post, n_post, lap);
+}
+
 int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* has_derivation, carmel_hip_lattice_stats* stats,
                        bool& done) {
   done = false;
@@ -1123,76 +1262,11 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     t->tile_chain.release();
   }
   lap("record streams");
-  // ---- slots by arc ----
-  HIPCHK(sort_keys(tmp, items.p, items_sorted.p, n_items, 32 + bits_for(w.n_arcs), s));
-  HIPCHK(t->arc_off.alloc(w.n_arcs + 1));
-  HIPCHK(t->slot_pos.alloc(n_items));
-  hipLaunchKernelGGL(slots_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, items_sorted.p, n_items, w.n_arcs,
-                     t->slot_pos.p, t->arc_off.p);
-  t->hot_chunks.release();  // (the gather formulation is not offered on top of this builder)
-  lap("slots by arc");
-  // ---- transposition tables ----
-  DevBuf<uint32_t> b_end, d_nout;
-  HIPCHK(b_end.alloc(w.n_arcs));
-  HIPCHK(d_nout.alloc(4));
-  hipLaunchKernelGGL(bucket_end_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, b_end.p, L.bucket);
-  const uint32_t cap = (uint32_t)(2 * (n_items / L.bucket) + w.n_arcs / L.bucket + 2 * (n_items / TRANS_HEAVY) + 16);
-  HIPCHK(t->t_buckets.alloc(cap));
-  HIPCHK(t->t_split_arcs.alloc(cap));
-  DevBuf<uint32_t> heavy, heavy_sorted;
-  HIPCHK(heavy.alloc(cap));
-  HIPCHK(heavy_sorted.alloc(cap));
-  HIPCHK(hipMemsetAsync(d_nout.p, 0, 16, s));
-  hipLaunchKernelGGL(heavy_list_kernel, dim3((unsigned)((w.n_arcs + 255) / 256)), dim3(256), 0, s, t->arc_off.p, w.n_arcs, heavy.p, cap,
-                     d_nout.p + 3);
-  uint32_t n_heavy = 0;
-  HIPCHK(hipMemcpyAsync(&n_heavy, d_nout.p + 3, 4, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (n_heavy > cap) return fail(CARMEL_HIP_ERR_HIP, "gpu lattice build: heavy-arc list overflow");
-  if (n_heavy) HIPCHK(sort_keys(tmp, heavy.p, heavy_sorted.p, n_heavy, 32, s));
-  hipLaunchKernelGGL(bucket_chain_kernel, dim3(1), dim3(1), 0, s, t->arc_off.p, b_end.p, w.n_arcs, heavy_sorted.p, n_heavy,
-                     t->t_buckets.p, t->t_split_arcs.p, cap, d_nout.p, L.bucket);
-  uint32_t h_nout[4] = {0, 0, 0, 0};
-  HIPCHK(hipMemcpyAsync(h_nout, d_nout.p, 12, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
-  if (h_nout[2]) return fail(CARMEL_HIP_ERR_HIP, "gpu lattice build: bucket table overflow");
-  const uint32_t n_buckets = h_nout[0], n_split = h_nout[1];
-  t->t_buckets.n = n_buckets;       // (capacity stays; .n is what the engine reads)
-  t->t_split_arcs.n = n_split;
-  lap("buckets");
-  const uint64_t n_post = n_rec;    // no bundle arcs on this path
-  const uint64_t n_tiles = (n_post + L.tile - 1) / L.tile;
-  HIPCHK(t->t_a_off.alloc(w.n_arcs));
-  HIPCHK(hipMemsetAsync(t->t_a_off.p, 0, w.n_arcs * 2, s));
-  hipLaunchKernelGGL(a_off_kernel, dim3(n_buckets), dim3(256), 0, s, t->t_buckets.p, n_buckets, t->arc_off.p, t->t_a_off.p);
-  DevBuf<unsigned long long> bkey, bkey_sorted;
-  DevBuf<uint32_t> bval, bval_sorted, tile_key, tile_sorted, Jv, J_sorted;
-  HIPCHK(bkey.alloc(n_items));
-  HIPCHK(bkey_sorted.alloc(n_items));
-  HIPCHK(bval.alloc(n_items));
-  HIPCHK(bval_sorted.alloc(n_items));
-  hipLaunchKernelGGL(bucket_key_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, t->t_buckets.p, n_buckets,
-                     t->slot_pos.p, n_items, bkey.p, bval.p);
-  HIPCHK(sort_pairs(tmp, bkey.p, bkey_sorted.p, bval.p, bval_sorted.p, n_items, 32 + bits_for(n_buckets), s));
-  HIPCHK(t->t_b_arc.alloc(n_items));
-  HIPCHK(t->t_b_rank.alloc(n_items));
-  HIPCHK(t->t_b_src.alloc(n_items));
-  HIPCHK(t->t_t_pos.alloc(n_items));
-  HIPCHK(t->t_t_src.alloc(n_items));
-  HIPCHK(t->t_tile_base.alloc(n_tiles + 1));
-  HIPCHK(tile_key.alloc(n_items));
-  HIPCHK(tile_sorted.alloc(n_items));
-  HIPCHK(Jv.alloc(n_items));
-  HIPCHK(J_sorted.alloc(n_items));
-  hipLaunchKernelGGL(bucket_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, t->t_buckets.p, bkey_sorted.p,
-                     bval_sorted.p, items_sorted.p, n_items, L.tile, t->t_b_arc.p, t->t_b_rank.p, tile_key.p, Jv.p);
-  HIPCHK(sort_pairs(tmp, tile_key.p, tile_sorted.p, Jv.p, J_sorted.p, n_items, bits_for(n_tiles), s));
-  hipLaunchKernelGGL(tile_major_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, tile_sorted.p, J_sorted.p,
-                     bkey_sorted.p, n_items, n_tiles, L.tile, t->t_t_src.p, t->t_t_pos.p, t->t_b_src.p, t->t_tile_base.p);
-  HIPCHK(hipGetLastError());
-  HIPCHK(t->t_x.alloc(n_items));
-  HIPCHK(t->t_xc.alloc(n_items));
-  lap("transposition tables");
+  {
+    int rc = gpu_tables_from_items(t, tmp, items, items_sorted, n_items, n_items, /*n_post: no bundle arcs on this path*/ n_rec, lap);
+    if (rc) return rc;
+  }
+  const uint64_t n_post = n_rec;
   // ---- the rest of the trainer's image ----
   t->use_transpose = true;
   t->lane_records = n_rec;

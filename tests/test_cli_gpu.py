@@ -658,7 +658,7 @@ def test_lattices_beyond_the_resident_budget_are_streamed(golden_dir, tmp_path, 
 
 @pytest.mark.parametrize("args", [["--random-set", "-t"], ["-1", "-t"], ["--random-set", "--train-cascade", "-HJ"],
                                   ["--random-set", "--train-cascade", "-HJ", "--normby=JN"]])
-def test_random_set_and_random_scale(golden_dir, args):
+def test_random_set_and_random_scale(golden_dir, args, tmp_path):
     """--random-set / -1 (carmel.cc:603-612, 786-789; fst.h:973-977; cascade.h:398-401): before training every unlocked arc of the
     members not normalised by NONE gets a new weight on (0..1] (-1: is scaled by one).  The reference's Boost stream is
     unpinned; the command line and the oracle share this build's counter-based generator, so their runs coincide -- and
@@ -669,10 +669,11 @@ def test_random_set_and_random_scale(golden_dir, args):
     casc = "--train-cascade" in args
     files = ["cipher.data", "cipher.wfsa", "cipher.fst"] if casc else ["epron-jpron.data", "epron-jpron.fst"]
     full = args + ["-R", "11", "-M", "5"] + [os.path.join(golden_dir, f) for f in files]
-    rc, out, err = run(full)
+    env = {"CARMEL_TRAINED_DIR": str(tmp_path), "ORACLE_TRAINED_DIR": str(tmp_path)}  # (beside the inputs the *.trained files would replace the reference's own)
+    rc, out, err = run(full, env=env)
     assert rc == 0, err
     assert "Using random seed -R 11" in err
-    p = subprocess.run([oracle_cli] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    p = subprocess.run([oracle_cli] + full, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True, env=dict(os.environ, **env))
     assert p.returncode == 0, p.stderr
     keep = lambda txt: [l for l in txt.split("\n") if l.startswith(("i=", "Converged"))]
     mine, ref = keep(err), keep(p.stderr)
@@ -681,7 +682,7 @@ def test_random_set_and_random_scale(golden_dir, args):
         assert NUM.sub("#", x) == NUM.sub("#", y)
         for u, v in zip(NUM.findall(x), NUM.findall(y)):
             assert float(u) == pytest.approx(float(v), rel=1e-4)
-    rc0, out0, err0 = run([a for a in full if a not in ("--random-set", "-1")])
+    rc0, out0, err0 = run([a for a in full if a not in ("--random-set", "-1")], env=env)
     # (--normby=JN: the language model's arcs are locked and the channel is normalised by NONE -- nothing is drawn)
     assert (keep(err0)[0] == mine[0]) == ("--normby=JN" in args)
 

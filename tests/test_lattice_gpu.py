@@ -14,14 +14,20 @@ from carmel_amd.model import Corpus, Wfst
 pytestmark = pytest.mark.gpu
 
 
-def _build(w, c, gpu):
+def _build(w, c, gpu, device_tables=None):
+    """gpu: the device builder where it takes the corpus / False: the host builder, all of it (its own counting sorts for the
+    posterior slots and the transposition tables too, unless device_tables says otherwise)"""
     from carmel_amd._capi import check, lib, ptr
     from carmel_amd.trainer import HipForwardBackward
     os.environ["CARMEL_HIP_GPU_BUILD"] = "1" if gpu else "0"
+    if device_tables is None:
+        device_tables = gpu
+    os.environ["CARMEL_HIP_DEVICE_TABLES"] = "1" if device_tables else "0"
     try:
         fb = HipForwardBackward(w, c)
     finally:
         del os.environ["CARMEL_HIP_GPU_BUILD"]
+        del os.environ["CARMEL_HIP_DEVICE_TABLES"]
     fp = np.zeros(16, np.uint64)
     check(lib.carmel_hip_debug_lattice_fingerprint(fb.h, ptr(fp)), "fingerprint")
     ls = fb.lattice_stats
@@ -37,12 +43,19 @@ def _build(w, c, gpu):
     return res
 
 
-def _same(a, b):
+def _same(a, b, atomics=False):
+    """atomics: the corpus has arcs whose items fill several buckets -- their pieces are added to the count atomically, in an
+    order that changes from run to run, so counts and weights agree to rounding only (the tables still byte for byte)"""
     assert a["stats"] == b["stats"]
     assert np.array_equal(a["has"], b["has"])
     assert np.array_equal(a["fp"], b["fp"]), (a["fp"], b["fp"])
-    assert np.array_equal(a["counts"], b["counts"]) and np.array_equal(a["pair_lp"], b["pair_lp"]) and a["lp"] == b["lp"]
-    assert np.array_equal(a["w1"], b["w1"])
+    assert np.array_equal(a["pair_lp"], b["pair_lp"]) and a["lp"] == b["lp"]
+    if atomics:
+        np.testing.assert_allclose(a["counts"], b["counts"], rtol=1e-12)
+        np.testing.assert_allclose(np.exp(a["w1"]), np.exp(b["w1"]), rtol=1e-12)
+    else:
+        assert np.array_equal(a["counts"], b["counts"])
+        assert np.array_equal(a["w1"], b["w1"])
 
 
 @pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(n_sym=3, deg=10, n_states=30)), (3, dict(n_sym=64, deg=20, n_states=500, lo=5, hi=40)),
@@ -85,6 +98,35 @@ def test_corpora_outside_its_scope_go_to_the_host_builder(oracle):
     a, b = _build(w, c, False), _build(w, c, True)
     _same(a, b)
     assert a["stats"][4] / a["stats"][1] > 96
+
+
+@pytest.mark.parametrize("name", ["cyclic", "wide", "long", "tagging-small", "hub"])
+def test_host_layouts_get_their_tables_from_the_device(name, capfd, monkeypatch):
+    """the corpora the device builder leaves to the host (bundles of cyclic lattices, one-per-wavefront lattices, mixtures, a hub
+    arc with buckets of its own): the host lays them out and the DEVICE sorts the posterior slots by arc and builds the
+    transposition tables (gpu_tables_for_host_layout) -- the image the host's own counting sorts leave, byte for byte, and the
+    same counts"""
+    monkeypatch.setenv("CARMEL_TIMING", "1")
+    if name == "cyclic":
+        rng = np.random.default_rng(3)
+        w = synth.random_wfst(40, 5, n_sym=4, p_eps=0.25, seed=3)  # *e*:*e* arcs: cycles in the lattices
+        c = synth.random_walk_corpus(w, 300, min_arcs=3, max_arcs=10, seed=3, out_degree=5)
+    elif name == "wide":
+        w = synth.random_wfst(20000, 12, n_sym=4, p_eps=0.1, seed=5)
+        c = synth.random_walk_corpus(w, 100, min_arcs=5, max_arcs=16, seed=5, out_degree=12)
+    elif name == "long":
+        w, c = synth.make_config("long", n_pairs=300)
+    elif name == "tagging-small":
+        w, c = _tagging(2)
+    else:
+        w = synth.random_wfst(3, 2, n_sym=2, p_eps=0.0, seed=9)  # every pair crosses the same few arcs thousands of times over
+        c = synth.random_walk_corpus(w, 4000, min_arcs=20, max_arcs=40, seed=9, out_degree=2)
+    host = _build(w, c, False, device_tables=False)
+    capfd.readouterr()
+    hyb = _build(w, c, False, device_tables=True)
+    err = capfd.readouterr().err
+    assert "slots by arc (left to the device)" in err and "items of the host layout" in err
+    _same(host, hyb, atomics=name == "hub")
 
 
 def _tagging(reps):
