@@ -656,6 +656,16 @@ def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=1):
         edt = time.perf_counter() - t0
         out["exact"] = {"sweeps": exact_sweeps, "ms_per_step": 1e3 * edt / exact_sweeps, "value": n_nodes * exact_sweeps / edt,
                         "unit": "node-updates/s", "note": "mode 0: the reference's sequential chain over all %d forests" % args.forests}
+        # --crp-restarts=63: 64 such chains side by side (a wavefront each, one launch per sweep for all of them)
+        hf.set_weights(lw)
+        hf.maximize()
+        t0 = time.perf_counter()
+        hf.gibbs(exact_sweeps - 1, alpha=0.1, seed=4 + rank, mode=0, restarts=63)
+        edt64 = time.perf_counter() - t0
+        v64 = n_nodes * 64 * exact_sweeps / edt64
+        out["exact"]["chains64"] = {"runs": 64, "ms_per_chain_sweep": 1e3 * edt64 / (64 * exact_sweeps), "value": v64, "unit": "node-updates/s",
+                                    "aggregate_over_one_chain": v64 / out["exact"]["value"],
+                                    "note": "forest-em --crp-restarts=63: 64 independent exact chains in one launch per sweep"}
     hf.close()
     if not args.no_cpu_baseline and rank == 0:
         from oracle import binding as ob

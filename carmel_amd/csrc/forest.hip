@@ -24,6 +24,7 @@
 #include <unordered_map>
 #include "engine.hpp"
 #include "forest_exact.hpp"
+#include "gibbs_exact.hpp"  // launch_gibbs_broadcast
 #include "rng.hpp"
 
 namespace carmel_hip {
@@ -1737,6 +1738,7 @@ using namespace carmel_hip;
 static const size_t F_LDS_LIMIT = 150 * 1024;  // dynamic LDS a forest kernel may ask for
 
 struct carmel_hip_forests {
+  uint32_t best_run = 0;  // --crp-restarts: the run that was kept (carmel_hip_forests_best_run)
   // --prior-inference-* (gibbs_opts.hpp:82-89): carmel_hip_forests_set_prior_inference / _prior_trace
   double pi_stddev = 0;
   bool pi_global = false, pi_local = false;
@@ -2434,6 +2436,7 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* F, const double* rule_log
   return CARMEL_HIP_OK;
 }
 
+uint32_t carmel_hip_forests_best_run(carmel_hip_forests* F) { return F ? F->best_run : 0; }
 int carmel_hip_forests_set_prior_inference(carmel_hip_forests* F, double stddev, int global, int local, uint32_t start,
                                            uint32_t end) {
   if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
@@ -2655,6 +2658,142 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   }
   // gibbs_opts::validate (gibbs_opts.hpp:253-266): --final-counts makes every sweep but the last burn-in; burnin <= iter
   const uint32_t Ni = o->iter, burnin = o->final_counts ? o->iter : std::min(o->burnin, o->iter);
+  F->best_run = 0;
+  // finalize_cumulative_counts + from_gibbs of one finished run (gibbs.hpp:629-640, forest-em.hpp:736-741): ln weights from its
+  // counts, their time-weighted sums and stamps
+  auto final_weights = [&](std::vector<double>& x, std::vector<double>& sacc, const std::vector<double>& tm, std::vector<double>& out) {
+    if (!(o->final_counts && !o->exclude_prior)) {
+      const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
+      if (o->exclude_prior)  // --crp-exclude-prior (gibbs.hpp:629-631): addbase(-prior) before the counts are extended
+        for (uint32_t r = 0; r < nr; ++r)
+          if (F->h_norm[r] != F_NONORM) {
+            sacc[r] += -prior[r] * tm[r];
+            x[r] += -prior[r];
+          }
+      if (!o->final_counts)
+        for (uint32_t r = 0; r < nr; ++r)
+          if (F->h_norm[r] != F_NONORM) {
+            sacc[r] += x[r] * (tmax1 - tm[r]);
+            x[r] = sacc[r];
+          }
+    }
+    std::vector<double> ns(ng, 0.0);
+    for (uint32_t r = 0; r < nr; ++r)
+      if (F->h_norm[r] != F_NONORM) ns[F->h_norm[r]] += x[r];
+    for (uint32_t r = 0; r < nr; ++r) {
+      double pr = F->h_norm[r] == F_NONORM ? prior[r] : (x[r] > 0 ? x[r] / ns[F->h_norm[r]] : 0.0);
+      out[r] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
+    }
+  };
+  // ---- --crp-restarts (gibbs_base::run_starts, gibbs.hpp:880-914, which forest-em's sampler runs through like carmel's): every
+  // run starts from the priors and draws the uniforms of its own sweeps (run r, sweep i: those of sweep r * (iter + 1) + i), the
+  // run that is better by gibbs_stats::better gives the weights and the sample.  Independent chains: they run SIDE BY SIDE, chain c
+  // = workgroup c of forest_exact_kernel (one wavefront each; FExactArgs::n_chains), one launch per sweep for all of them, in
+  // batches of at most 64 chains / 8 GB of state.  The device chain only: temperature 1, no locked parameter, no prior inference.
+  if (o->restarts > 0) {
+    if (o->mode != 0 || !exact_dev || F->pi_stddev > 0)
+      return fail(CARMEL_HIP_ERR_UNSUPPORTED, "--crp-restarts runs the exact chain on the device: no --crp-parallel, annealing, locked parameters (negative --alpha entries) or prior inference");
+    const uint32_t n_runs = o->restarts + 1;
+    const uint64_t S = F->sample_rules[0].n, ngs = std::max<uint64_t>(ng, 1);
+    uint32_t cap = 64;
+    if (const char* e = getenv("CARMEL_HIP_GIBBS_CHAINS")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
+    const uint64_t chain_bytes = ((uint64_t)nr * 4 + ngs * 2) * 8 + S * 8 + nf * 4 + 64;
+    cap = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1, (8ull << 30) / chain_bytes));
+    DevBuf<double> mx, ms, mt, mn, mcc, mcs, mio;
+    DevBuf<uint32_t> mlen, mrules, mnn;
+    double best_all = 0, best_final = 0, best_sum = 0;
+    bool ran_any = false;
+    std::vector<double> best_lw(nr), clw(nr), x(nr), sacc(nr), tm(nr);
+    std::vector<uint32_t> best_rules, best_len;
+    for (uint32_t b0 = 0; b0 < n_runs; b0 += cap) {
+      const uint32_t R = std::min(cap, n_runs - b0);
+      if (mx.n < (size_t)R * nr) {
+        HIPCHK(mx.alloc((size_t)R * nr));
+        HIPCHK(ms.alloc((size_t)R * nr));
+        HIPCHK(mt.alloc((size_t)R * nr));
+        HIPCHK(mn.alloc((size_t)R * ngs));
+        HIPCHK(mcc.alloc((size_t)R * nr));
+        HIPCHK(mcs.alloc((size_t)R * ngs));
+        HIPCHK(mio.alloc((size_t)R * 2));
+        HIPCHK(mlen.alloc((size_t)R * nf));
+        HIPCHK(mrules.alloc((size_t)R * S));
+        HIPCHK(mnn.alloc((size_t)R * S));
+      }
+      // init_run for every chain: counts = priors, norm sums = their sums, no sample, time 0
+      HIPCHK(launch_gibbs_broadcast(mx.p, F->p_prior.p, nr, R, s));
+      if (ng) HIPCHK(launch_gibbs_broadcast(mn.p, F->prior_norm.p, ng, R, s));
+      HIPCHK(hipMemsetAsync(ms.p, 0, (size_t)R * nr * sizeof(double), s));
+      HIPCHK(hipMemsetAsync(mt.p, 0, (size_t)R * nr * sizeof(double), s));
+      HIPCHK(hipMemsetAsync(mlen.p, 0, (size_t)R * nf * sizeof(uint32_t), s));
+      FExactArgs XC = XA;
+      XC.sample_len = mlen.p;
+      XC.sample_rules = mrules.p;
+      XC.sample_nn = mnn.p;
+      XC.p_x = mx.p;
+      XC.normsum = mn.p;
+      XC.ccount = mcc.p;
+      XC.csum = mcs.p;
+      XC.iter_out = mio.p;
+      XC.phase_clk = nullptr;
+      XC.n_chains = R;
+      XC.iter_stride = Ni + 1;
+      XC.ch_rules = nr;
+      XC.ch_norms = ng;
+      XC.ch_sample = S;
+      XC.ch_forests = nf;
+      if (R == 1) {  // (a lone chain is the kernel's plain form: the strides do not apply, the base sweep does)
+        XC.n_chains = 0;
+      }
+      std::vector<double> st_all(R, 0.0), st_final(R, 0.0), st_sum(R, -std::numeric_limits<double>::infinity()), io((size_t)R * 2);
+      for (uint32_t iter = 0; iter <= Ni; ++iter) {
+        const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
+        HIPCHK(hipMemsetAsync(mio.p, 0, (size_t)R * 2 * sizeof(double), s));
+        HIPCHK(launch_gibbs_broadcast(mcc.p, F->p_prior.p, nr, R, s));
+        if (ng) HIPCHK(launch_gibbs_broadcast(mcs.p, F->prior_norm.p, ng, R, s));
+        HIPCHK(launch_forest_fold(ms.p, mt.p, mx.p, time, (uint64_t)R * nr, s));
+        XC.iter = b0 * (Ni + 1) + iter;
+        HIPCHK(launch_forest_exact(XC, s));
+        HIPCHK(hipMemcpyAsync(io.data(), mio.p, io.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        for (uint32_t c = 0; c < R; ++c) {
+          const uint32_t run = b0 + c;
+          const double plog = io[(size_t)c * 2];
+          if (iter_logprob) iter_logprob[(size_t)run * (Ni + 1) + iter] = plog;
+          if (iter_cheap_logprob) iter_cheap_logprob[(size_t)run * (Ni + 1) + iter] = io[(size_t)c * 2 + 1];
+          if (iter >= burnin) {  // gibbs.hpp:942-943: the statistics runs are compared by
+            st_all[c] += plog;
+            st_final[c] = plog;
+            const double hi = std::max(st_sum[c], plog), lo = std::min(st_sum[c], plog);
+            st_sum[c] = hi + (lo == -std::numeric_limits<double>::infinity() ? 0.0 : std::log1p(std::exp(lo - hi)));
+          }
+        }
+      }
+      for (uint32_t c = 0; c < R; ++c) {  // the better run by gibbs_stats::better (gibbs_opts.hpp:313-316), in run order
+        const bool better = !ran_any || (o->argmax_final ? st_final[c] > best_final : o->argmax_sum ? st_sum[c] > best_sum : st_all[c] > best_all);
+        ran_any = true;
+        if (!better) continue;
+        HIPCHK(hipMemcpyAsync(x.data(), mx.p + (size_t)c * nr, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(sacc.data(), ms.p + (size_t)c * nr, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(tm.data(), mt.p + (size_t)c * nr, nr * sizeof(double), hipMemcpyDeviceToHost, s));
+        best_rules.resize(S);
+        best_len.resize(nf);
+        HIPCHK(hipMemcpyAsync(best_rules.data(), mrules.p + (size_t)c * S, S * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(best_len.data(), mlen.p + (size_t)c * nf, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        final_weights(x, sacc, tm, clw);
+        best_lw = clw;
+        F->best_run = b0 + c;
+        best_all = st_all[c];
+        best_final = st_final[c];
+        best_sum = st_sum[c];
+      }
+    }
+    // the kept run's sample is the sampler's sample (carmel_hip_forests_get_sample, --outsample-file)
+    HIPCHK(hipMemcpyAsync(F->sample_rules[0].p, best_rules.data(), S * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(F->sample_len[0].p, best_len.data(), nf * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return carmel_hip_forests_set_weights(F, best_lw.data());
+  }
   // host mirror of counts for the exact schedule (one forest at a time: the counts move between forests)
   std::vector<double> hx, hs, ht, hn;
   std::vector<std::vector<uint32_t> > hsample;
@@ -3026,28 +3165,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       std::swap(F->sample_rules[0].p, F->sample_rules[1].p);
     }
   }
-  if (!(o->final_counts && !o->exclude_prior)) {
-    const double tmax1 = ((double)Ni - (double)burnin) + 1.0;
-    if (o->exclude_prior)  // --crp-exclude-prior (gibbs.hpp:629-631): addbase(-prior) before the counts are extended
-      for (uint32_t r = 0; r < nr; ++r)
-        if (F->h_norm[r] != F_NONORM) {
-          sacc[r] += -prior[r] * tm[r];
-          x[r] += -prior[r];
-        }
-    if (!o->final_counts)
-      for (uint32_t r = 0; r < nr; ++r)
-        if (F->h_norm[r] != F_NONORM) {
-          sacc[r] += x[r] * (tmax1 - tm[r]);
-          x[r] = sacc[r];
-        }
-  }
-  std::vector<double> ns(ng, 0.0);
-  for (uint32_t r = 0; r < nr; ++r)
-    if (F->h_norm[r] != F_NONORM) ns[F->h_norm[r]] += x[r];
-  for (uint32_t r = 0; r < nr; ++r) {
-    double pr = F->h_norm[r] == F_NONORM ? prior[r] : (x[r] > 0 ? x[r] / ns[F->h_norm[r]] : 0.0);
-    lw[r] = pr > 0 ? std::log(pr) : -std::numeric_limits<double>::infinity();
-  }
+  final_weights(x, sacc, tm, lw);
   if (trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);
     HIPCHK(hipMemcpy(h.data(), trace_buf.p, trace_buf.bytes(), hipMemcpyDeviceToHost));

@@ -322,6 +322,19 @@ __device__ __forceinline__ bool fx_register_path(const FxStage& S, const double 
 
 __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fx_lds[];
+  if (A.n_chains > 1) {  // chain c of --crp-restarts: its own state and its own uniforms (FExactArgs::n_chains)
+    const uint64_t c = blockIdx.x;
+    A.sample_len += c * A.ch_forests;
+    A.sample_rules += c * A.ch_sample;
+    A.sample_nn += c * A.ch_sample;
+    A.p_x += c * A.ch_rules;
+    A.normsum += c * A.ch_norms;
+    A.ccount += c * A.ch_rules;
+    A.csum += c * A.ch_norms;
+    A.iter_out += c * 2;
+    A.iter += (uint32_t)c * A.iter_stride;
+    A.phase_clk = nullptr;
+  }
   __shared__ double vals[2 * FX_VALS];  // register path: node values, two buffers; each ends in 1.0, 0.0 and a slot nobody reads
   __shared__ int vals_e[2 * FX_VALS];   // ... their exponents, when plain doubles underflow (the neutral slots: 2^1 x 0.5, 0)
   __shared__ double lp[FX_NODES];     // ... proposal probability of a node's rule
@@ -614,7 +627,7 @@ hipError_t launch_forest_exact(const FExactArgs& A, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute((const void*)forest_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(forest_exact_kernel, dim3(1), dim3(64), lds, s, A);
+  hipLaunchKernelGGL(forest_exact_kernel, dim3(A.n_chains > 1 ? A.n_chains : 1u), dim3(64), lds, s, A);
   return hipGetLastError();
 }
 hipError_t launch_forest_fold(double* p_s, double* p_tmax, const double* p_x, double time, uint64_t n, hipStream_t s) {

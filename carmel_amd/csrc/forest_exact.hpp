@@ -38,6 +38,10 @@ struct FExactArgs {
   uint64_t seed;
   uint32_t iter, n_forests;
   uint32_t max_n, max_tab, max_stack, max_sample;  // LDS path's carve: nodes, table words, stack entries, sample entries
+  // --crp-restarts, the runs side by side (gibbs.hpp:880-914: independent chains): workgroup c of the launch is chain c -- its
+  // counts, norm sums, cache model, sample and results at c times the strides below, its uniforms those of sweep iter + c * iter_stride
+  uint32_t n_chains, iter_stride;
+  uint64_t ch_rules, ch_norms, ch_sample, ch_forests;
 };
 
 size_t forest_exact_lds_bytes(uint32_t max_n, uint32_t max_tab, uint32_t max_stack, uint32_t max_sample);

@@ -40,6 +40,8 @@ struct Opts {
   std::string out_pfc_file = "-0";     // -E / --out-per-forest-counts-file
   std::string outviterbi_file = "-0";  // -v / --outviterbi-file
   long crp = 0, burnin = 0;
+  long crp_restarts = 0;            // --crp-restarts (gibbs_opts.hpp; gibbs_base::run_starts, gibbs.hpp:880-914)
+  bool argmax_final = false, argmax_sum = false;  // --crp-argmax-final / --crp-argmax-sum (gibbs_opts.hpp:270-316)
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
   // --prior-inference-* (gibbs_opts.hpp:82-89; forest-em reads all of them through gibbs_opts' own option table)
   double pi_stddev = 0;
@@ -65,6 +67,7 @@ void usage() {
   std::cerr << "usage: forest-em -f forests [-n normgroups] [-I initparams] [-o outparams] [-O outcounts]\n"
                "                 [-i max-iter] [-e converge] [-d deltaparam-epsilon] [-p prior-counts-per] [-k add-k]\n"
                "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel\n"
+               "                  --crp-restarts=R [--crp-argmax-final | --crp-argmax-sum]\n"
                "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
                "                 [-x checkpoint-prefix -c] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
@@ -142,6 +145,9 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "const-alpha") o.alpha = std::atof(value(val).c_str());
     else if (key == "alpha") o.alpha_file = value(val);
     else if (key == "burnin") o.burnin = std::atol(value(val).c_str());
+    else if (key == "crp-restarts") o.crp_restarts = std::atol(value(val).c_str());
+    else if (key == "crp-argmax-final") o.argmax_final = true;
+    else if (key == "crp-argmax-sum") o.argmax_sum = true;
     else if (key == "high-temp") o.high_temp = std::atof(value(val).c_str());
     else if (key == "low-temp") o.low_temp = std::atof(value(val).c_str());
     else if (key == "final-counts") o.final_counts = true;
@@ -155,7 +161,7 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "prior-inference-show") o.pi_show = true;
     else if (key == "prior-inference-start") o.pi_start = std::atol(value(val).c_str());
     else if (key == "prior-inference-end") o.pi_end = std::atol(value(val).c_str());
-    else if (key == "prior-inference-restart-fresh") {}  // acts on --crp-restarts only, which this front end does not run
+    else if (key == "prior-inference-restart-fresh") {}  // (restarts and prior inference do not go together here: the library refuses)
     else if (key == "x" || key == "checkpoint-prefix") o.checkpoint_prefix = value(val);
     else if (key == "c" || key == "checkpoint-parameters") o.checkpoint_parameters = true;
     else if (key == "W" || key == "watch-period") o.watch_period = std::atol(value(val).c_str());
@@ -270,6 +276,9 @@ int main(int argc, char** argv) {
       go.exclude_prior = o.exclude_prior;
       go.high_temp = o.high_temp;
       go.low_temp = o.low_temp;
+      go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
+      go.argmax_final = o.argmax_final;
+      go.argmax_sum = o.argmax_sum;
       if (o.alpha_file != "-0") {
         // "(a1 a2 ...)" indexed by rule id like forest-em.hpp:689-692 (alphas[i] for parameter i; entry 0 is the unused rule 0)
         const std::string txt = slurp(o.alpha_file);
@@ -284,17 +293,20 @@ int main(int argc, char** argv) {
         }
         check(carmel_hip_forests_set_alphas(F, al.data(), (uint32_t)al.size()), "carmel_hip_forests_set_alphas");
       }
-      std::vector<double> lp((size_t)o.crp + 1);
+      const size_t per_run = (size_t)o.crp + 1;
+      std::vector<double> lp(per_run * ((size_t)go.restarts + 1));
       check(carmel_hip_forests_set_prior_inference(F, o.pi_stddev, o.pi_global, o.pi_local, (uint32_t)std::max(0L, o.pi_start),
                                                    (uint32_t)std::max(0L, o.pi_end)),
             "carmel_hip_forests_set_prior_inference");
       check(carmel_hip_forests_gibbs(F, &go, o.alpha, lp.data(), nullptr), "carmel_hip_forests_gibbs");
       std::vector<double> ptrace(lp.size() * 6, 0.0), pcum(group_off.size() + 1, 1.0);
       uint32_t n_scales = 0;
-      check(carmel_hip_forests_prior_trace(F, ptrace.data(), (uint32_t)lp.size(), pcum.data(), (uint32_t)pcum.size(), &n_scales),
+      check(carmel_hip_forests_prior_trace(F, ptrace.data(), (uint32_t)per_run, pcum.data(), (uint32_t)pcum.size(), &n_scales),
             "carmel_hip_forests_prior_trace");
       for (size_t i = 0; i < lp.size(); ++i) {
-        log << "i=" << i << " ";
+        if (go.restarts && i % per_run == 0)  // gibbs.hpp:897
+          log << "(random restart " << i / per_run << " of " << go.restarts << "): \n";
+        log << "i=" << i % per_run << " ";
         const double* pt = ptrace.data() + i * 6;
         if (pt[0] != 0)  // propose_new_priors' line (gibbs.hpp:539-547)
           log << (pt[1] != 0 ? "accepted" : "rejected") << " new priors with p1=2^" << pt[2] / std::log(2.0) << " p2=2^"
@@ -302,6 +314,7 @@ int main(int argc, char** argv) {
               << " p_accept=" << pt[5] << ". ";
         log << "sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
       }
+      if (go.restarts) log << "\nKept run " << carmel_hip_forests_best_run(F) << " of " << go.restarts << " (gibbs_stats::better)\n";
       if (!o.outsample_file.empty()) {  // print_sample (forest-em.hpp:768-787): one line per forest, its rules in the order sampled
         std::ofstream of(o.outsample_file.c_str());
         std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_forests_max_sample(F)));

@@ -65,16 +65,19 @@ class HipForests(object):
         check(lib.carmel_hip_forests_set_weights(self.h, ptr(lw)), "carmel_hip_forests_set_weights")
 
     def gibbs(self, iters, burnin=0, alpha=0.1, seed=1, mode=0, uniform_p0=False, final_counts=False, alphas=None,
-              high_temp=1.0, low_temp=1.0, prior_inference=None, exclude_prior=False):
+              high_temp=1.0, low_temp=1.0, prior_inference=None, exclude_prior=False, restarts=0, argmax_final=False,
+              argmax_sum=False):
         """high_temp/low_temp: annealing, choices at probabilities^(1/temperature) (--high-temp/--low-temp).
         prior_inference: dict(stddev, global_, local, start, end) -- --prior-inference-* (gibbs.hpp:525-563), exact mode;
         afterwards self.prior_trace (per sweep {proposed, accepted, ln p1, ln p2, a2, p_accept}) and self.prior_cumulative.
         alphas: forest-em --alpha=FILE, one prior strength per rule id (negative = locked); None: the scalar alpha"""
         al = None if alphas is None else np.ascontiguousarray(alphas, dtype=np.float64)
         check(lib.carmel_hip_forests_set_alphas(self.h, ptr(al), 0 if al is None else len(al)), "carmel_hip_forests_set_alphas")
+        # restarts: --crp-restarts, the runs side by side on the device (carmel_hip_forests_gibbs): iter_logprob is then
+        # (restarts + 1) x (iters + 1), self.best_run the run that was kept
         o = GibbsOpts(iters, burnin, seed, mode, int(uniform_p0), 0, int(final_counts), int(exclude_prior), 0.01, high_temp, low_temp,
-                      0, 0, 0, 0)
-        self.iter_logprob, self.iter_cheap_logprob = np.zeros(iters + 1), np.zeros(iters + 1)
+                      0, restarts, int(argmax_final), int(argmax_sum))
+        self.iter_logprob, self.iter_cheap_logprob = np.zeros((restarts + 1) * (iters + 1)), np.zeros((restarts + 1) * (iters + 1))
         pi = dict(prior_inference or {})
         check(lib.carmel_hip_forests_set_prior_inference(self.h, float(pi.get("stddev", 0.0)), int(pi.get("global_", False)),
                                                          int(pi.get("local", False)), int(pi.get("start", 0)),
@@ -86,6 +89,10 @@ class HipForests(object):
         check(lib.carmel_hip_forests_prior_trace(self.h, ptr(self.prior_trace), iters + 1, ptr(cum), len(cum), C.byref(ns)),
               "carmel_hip_forests_prior_trace")
         self.prior_cumulative = cum[:ns.value]
+        self.best_run = int(lib.carmel_hip_forests_best_run(self.h))
+        if restarts:
+            self.iter_logprob = self.iter_logprob.reshape(restarts + 1, iters + 1)
+            self.iter_cheap_logprob = self.iter_cheap_logprob.reshape(restarts + 1, iters + 1)
         return self.iter_logprob
 
     def max_sample(self):

@@ -435,6 +435,14 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* f, const double* rule_log
  * probabilities (from_gibbs). */
 int carmel_hip_forests_gibbs(carmel_hip_forests* f, const carmel_hip_gibbs_opts* opts, double alpha,
                              double* iter_logprob, double* iter_cheap_logprob);
+/* opts->restarts > 0 (forest-em --crp-restarts; FForests::run_gibbs goes through gibbs_base::run_starts, forest-em.hpp:718,
+ * gibbs.hpp:880-914, like carmel's sampler): restarts + 1 independent runs, each from the priors with the uniforms of its own
+ * sweeps (run r, sweep i: those of sweep r * (iter + 1) + i); the run that is better by gibbs_stats::better (argmax_final /
+ * argmax_sum choose the statistic) gives the weights and the sample.  The runs go SIDE BY SIDE on the device, one wavefront
+ * each, up to 64 at a time; iter_logprob / iter_cheap_logprob then hold (restarts + 1) * (iter + 1) values, run-major.  For
+ * the exact chain on the device only: mode 0, temperature 1, no locked parameter, no prior inference
+ * (CARMEL_HIP_ERR_UNSUPPORTED otherwise).  carmel_hip_forests_best_run: which run (0-based) was kept. */
+uint32_t carmel_hip_forests_best_run(carmel_hip_forests* f);
 /* Replaces: prior-scale inference in forest-em's sampler (forest-em.hpp:723-734 to_gibbs + gibbs.hpp:404-563; forest-em
  * --prior-inference-stddev / -global / -local / -start / -end): as carmel_hip_gibbs_set_prior_inference, with forest-em's
  * scale groups -- one per norm group, shifted by one as the reference registers them (the last norm group is never scaled,

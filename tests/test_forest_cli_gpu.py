@@ -291,3 +291,33 @@ def test_forest_em_cli_parallel_sampler(oracle, tmp_path):
     # (a coarse band: on 300 forests the all-at-once sweep is a visibly different chain from the sequential one -- the bias
     # and its decay with corpus size are measured in test_bench_workloads_gpu.py)
     assert abs(a - b) < 0.12 * abs(b)
+
+
+@pytest.mark.gpu
+def test_forest_em_cli_crp_restarts(oracle, tmp_path):
+    """forest-em --crp=N --crp-restarts=R [--crp-argmax-final]: the front end's lines run by run ("(random restart r of R):"),
+    the kept run, its parameters and sample -- the oracle's chains on the shared uniforms (run r, sweep i: sweep r * (N + 1) + i)"""
+    from carmel_amd._capi import lib
+    from test_forest_gpu import synth_forests
+    ftxt, ntxt = synth_forests(60, 30, seed=4)
+    (tmp_path / "f").write_text(ftxt)
+    (tmp_path / "n").write_text(ntxt)
+    N, R = 12, 4
+    for flags, stat in (([], lambda t: t.sum()), (["--crp-argmax-final"], lambda t: t[-1])):
+        rc, so, err = run(["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "-o", str(tmp_path / "o"), "--crp=%d" % N, "--burnin=4",
+                           "--const-alpha=0.3", "--random-seed=5", "--crp-restarts=%d" % R, "--outsample-file=" + str(tmp_path / "s")] + flags)
+        assert rc == 0, err
+        assert [int(x) for x in re.findall(r"\(random restart (\d+) of %d\)" % R, err)] == list(range(R + 1))
+        lp = np.array([float(x) for x in re.findall(r"sample log-prob=(\S+)", err)]).reshape(R + 1, N + 1)
+        best = None
+        for r in range(R + 1):
+            of = oracle.OracleForests(ftxt, ntxt)
+            of.init_rule_weights()
+            ref = of.gibbs(lambda i, b, s, r=r: lib.carmel_hip_gibbs_uniform(5, r * (N + 1) + i, b, s), N, burnin=4, alpha=0.3)
+            np.testing.assert_allclose(lp[r], ref["iter_logprob"], rtol=1e-5)
+            st = stat(ref["iter_logprob"][4:])
+            if best is None or st > best[0]:
+                best = (st, r, ref["samples"], of.weights().copy())
+        assert "Kept run %d of %d" % (best[1], R) in err
+        np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text()), np.exp(best[3][1:]), rtol=1e-9, atol=1e-300)
+        assert [[int(x) for x in l.split()] for l in (tmp_path / "s").read_text().split("\n")[:-1]] == best[2]

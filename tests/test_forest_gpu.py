@@ -104,6 +104,51 @@ def test_forest_gibbs_exact_chain(oracle, kw):
     hf.close()
 
 
+@pytest.mark.parametrize("kw,chains", [(dict(), None), (dict(burnin=3), None), (dict(argmax_final=True), None),
+                                       (dict(argmax_sum=True, final_counts=True), None), (dict(), "3"), (dict(), "1")])
+def test_forest_gibbs_restarts_side_by_side(oracle, monkeypatch, kw, chains):
+    """forest-em --crp-restarts=R (FForests::run_gibbs -> gibbs_base::run_starts, forest-em.hpp:718, gibbs.hpp:880-914): R + 1
+    independent chains from the priors, run r drawing the uniforms of sweeps r * (iter + 1) + i, the run that is better by
+    gibbs_stats::better kept.  The device runs them side by side (a wavefront each; in batches of three and one after the other:
+    the same runs): every run is the oracle's run draw for draw, the kept run, its sample and weights the ones the sequential
+    loop keeps"""
+    from carmel_amd._capi import lib
+    if chains:
+        monkeypatch.setenv("CARMEL_HIP_GIBBS_CHAINS", chains)
+    ftext, ntext = synth_forests(30, 25, 11)
+    of, hf = make(oracle, ftext, ntext, 11)
+    w0 = of.weights().copy()
+    iters, R = 8, 6
+    sel = {k: kw.pop(k) for k in ("argmax_final", "argmax_sum") if k in kw}
+    lp = hf.gibbs(iters, alpha=0.3, seed=9, mode=0, restarts=R, **sel, **kw)
+    burnin = iters if kw.get("final_counts") else min(kw.get("burnin", 0), iters)
+    best = None
+    for r in range(R + 1):
+        of.set_weights(w0)
+        ref = of.gibbs(lambda i, b, s, r=r: lib.carmel_hip_gibbs_uniform(9, r * (iters + 1) + i, b, s), iters, alpha=0.3, **kw)
+        np.testing.assert_allclose(lp[r], ref["iter_logprob"], rtol=1e-10)
+        np.testing.assert_allclose(hf.iter_cheap_logprob[r], ref["iter_cheap_logprob"], rtol=1e-10)
+        tail = ref["iter_logprob"][burnin:]
+        stat = tail[-1] if sel.get("argmax_final") else np.logaddexp.reduce(tail) if sel.get("argmax_sum") else tail.sum()
+        if best is None or stat > best[0]:
+            best = (stat, r, ref["samples"], of.weights().copy())
+    assert hf.best_run == best[1]
+    for b in range(hf.n_forests):
+        assert hf.sample(b) == best[2][b]
+    np.testing.assert_allclose(np.exp(hf.weights()), np.exp(best[3]), rtol=1e-9, atol=1e-15)
+    hf.close()
+
+
+def test_forest_gibbs_restarts_need_the_device_chain(oracle):
+    """annealing, the parallel sweep and prior inference keep the single run: restarts are refused there"""
+    ftext, ntext = synth_forests(10, 12, 3)
+    of, hf = make(oracle, ftext, ntext, 3)
+    for kw in (dict(high_temp=2.0, low_temp=0.5), dict(mode=1), dict(prior_inference=dict(stddev=0.3))):
+        with pytest.raises(RuntimeError, match="crp-restarts"):
+            hf.gibbs(4, alpha=0.3, seed=2, restarts=2, **kw)
+    hf.close()
+
+
 def test_forest_gibbs_parallel_mode(oracle):
     """stale-count parallel sweep: valid derivations, reproducible, and the same probability region as the exact chain"""
     ftext, ntext = synth_forests(400, 40, 5)
