@@ -948,8 +948,16 @@ __global__ void publish_kernel(const unsigned long long* src, unsigned long long
   __hip_atomic_store(box, *src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __hip_atomic_store(box + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// enqueue only: the value at dev goes to the mailbox behind what is on s so far; fetch_u64(.., published = true) waits for it later
+int publish_u64(carmel_hip_trainer* t, const unsigned long long* dev, hipStream_t s) {
+  static const bool off = getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX"));
+  if (!t->h_box || off) return CARMEL_HIP_OK;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, dev, t->h_box, ++t->box_seq);
+  HIPCHK(hipGetLastError());
+  return CARMEL_HIP_OK;
+}
 // published: the last kernel on s has already stored the value under sequence number t->box_seq (mstep_max_final_kernel)
-static int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsigned long long* out, hipStream_t s, bool published) {
+int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsigned long long* out, hipStream_t s, bool published) {
   static const bool off = getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX"));
   if (!t->h_box || off) {
     HIPCHK(hipMemcpyAsync(out, dev, sizeof *out, hipMemcpyDeviceToHost, s));
@@ -1209,6 +1217,22 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   R.counts = t->counts_ptr();
   R.n_arcs = t->w.n_arcs;
   R.n_hot_chunks = t->hot_chunks.n / 3;
+  // the corpus scalars (a9) only need pair_logprob[]: on the side stream.  Under an exchange plan they are forked HERE, beside the
+  // count pass -- the exchange's last group carries them and must not wait for them behind it; otherwise behind the count pass
+  // (below), beside whatever comes next.
+  auto fork_scalars = [&](hipEvent_t fork) -> int {
+    HIPCHK(hipEventRecord(fork, s));
+    HIPCHK(hipStreamWaitEvent(t->side, fork, 0));
+    HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
+                          t->counts_ptr() + t->w.n_arcs, t->side));
+    HIPCHK(hipEventRecord(t->ev_join, t->side));
+    t->scalars_pending = true;
+    return CARMEL_HIP_OK;
+  };
+  if (xp) {
+    int rc = fork_scalars(t->ev_fork);
+    if (rc) return rc;
+  }
   if (t->use_transpose) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
     const uint32_t first = (side_by_side || tile_sweep_done || lane_fused) ? lane_tiles : 0u;
@@ -1222,18 +1246,16 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
       HIPCHK(launch_trans_c_bucket(T, t->t_split_arcs.p, (uint32_t)t->t_split_arcs.n, s));
   } else
     HIPCHK(launch_count_reduce(R, s));
-  // the corpus scalars only need pair_logprob[]: they run on the side stream BEHIND the count pass -- beside the M-step, or
-  // whatever the caller enqueues next -- and the trainer's stream joins them when somebody needs them (scalars_join).  Forked
-  // between the sweep and the count pass (rounds 2-5) the event cost the E-step a bubble of 8 us, and the join another before
-  // the M-step (tools/r5_timeline.sh).
-  // (one event at the end of the count pass: the E-step's closing time stamp is also what the side stream waits for)
-  hipEvent_t fork = timed ? t->ev1 : t->ev_fork;
-  HIPCHK(hipEventRecord(fork, s));
-  HIPCHK(hipStreamWaitEvent(t->side, fork, 0));
-  HIPCHK(launch_scalars(t->pair_logprob.p, t->pair_w.p, t->corpus.n_pairs, t->scalar_partial.p,
-                        t->counts_ptr() + t->w.n_arcs, t->side));
-  HIPCHK(hipEventRecord(t->ev_join, t->side));
-  t->scalars_pending = true;
+  // ... BEHIND the count pass -- beside the M-step, or whatever the caller enqueues next -- and the trainer's stream joins them when
+  // somebody needs them (scalars_join).  Forked between the sweep and the count pass (rounds 2-5) the event cost the E-step a
+  // bubble of 8 us, and the join another before the M-step (tools/r5_timeline.sh).  One event at the end of the count pass: the
+  // E-step's closing time stamp is also what the side stream waits for.
+  if (xp) {
+    if (timed) HIPCHK(hipEventRecord(t->ev1, s));
+  } else {
+    int rc = fork_scalars(timed ? t->ev1 : t->ev_fork);
+    if (rc) return rc;
+  }
   // somebody reads the scalars straight off the stream: the exchange's tail, or a caller who owns the count buffer and orders
   // work of their own behind the E-step (carmel_hip_stream)
   if (xp || t->ext_counts) {

@@ -210,6 +210,10 @@ struct carmel_hip_trainer {
 extern "C" int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M);
 extern "C" void trans_args(carmel_hip_trainer* t, TransArgs& T);
 bool exchange_is_sharded(const ExchangePlan* xp);  // exchange.cpp
+// engine.cpp: one 8-byte value to the host at the end of what is enqueued on s (the pinned mailbox; published: the last kernel on
+// s was an M-step's mstep_max_final_kernel, which has already stored it)
+extern "C" int publish_u64(carmel_hip_trainer* t, const unsigned long long* dev, hipStream_t s);
+extern "C" int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsigned long long* out, hipStream_t s, bool published);
 extern "C" int scalars_join(carmel_hip_trainer* t);  // engine.cpp: before anything reads counts[n_arcs .. n_arcs + 4) on the trainer's stream
 namespace carmel_hip {  // matrix_fb.hip
 int matrix_setup(carmel_hip_trainer* t, void** out);

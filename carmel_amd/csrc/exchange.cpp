@@ -307,6 +307,7 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   if (rc) return rc;
   if (!xp->counts_sharded && xp->N > 1) return CARMEL_HIP_OK;  // counts are whole (e.g. set by the caller): replicated M-step
   hipStream_t s = t->stream, x = xp->comm->xstream;
+  bool direct_mailbox = false;
   MstepArgs M;
   rc = mstep_args(t, 1, 2, M);
   if (rc) return rc;
@@ -353,8 +354,12 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
       if (rc) return rc;
       if (k == 0) {
         if (xp->N > 1) hipLaunchKernelGGL(xchg_max_kernel, dim3(1), dim3(1), 0, x, t->maxchg.p, (const unsigned long long*)xp->fin.p, xp->N, xp->rank);
-        HIPCHK(hipMemcpyAsync(xp->h_max, t->maxchg.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, x));
-        HIPCHK(hipEventRecord(xp->ev_max, x));
+        // to the host through the trainer's mailbox (with one rank the M-step's own last kernel has already put it there)
+        if (xp->N > 1) {
+          int prc = publish_u64(t, t->maxchg.p, x);
+          if (prc) return prc;
+        }
+        direct_mailbox = true;
       }
       HIPCHK(hipEventRecord(xp->ev_ag[k], x));
     }
@@ -373,9 +378,16 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   xp->ag_pending = true;
   xp->counts_sharded = false;  // consumed
   t->em_valid = false;
-  HIPCHK(hipEventSynchronize(xp->ev_max));
   double d;
-  std::memcpy(&d, xp->h_max, sizeof d);
+  if (direct_mailbox) {  // (the host has the value while the later chunks are still on the links)
+    unsigned long long bits = 0;
+    rc = fetch_u64(t, t->maxchg.p, &bits, x, true);
+    if (rc) return rc;
+    std::memcpy(&d, &bits, sizeof d);
+  } else {
+    HIPCHK(hipEventSynchronize(xp->ev_max));
+    std::memcpy(&d, xp->h_max, sizeof d);
+  }
   if (max_change) *max_change = d;
   *handled = 1;
   return CARMEL_HIP_OK;

@@ -191,7 +191,47 @@ def main():
         gs.close()
         fb.close()
 
+    def forest_chains_case(d, s, mp=None):
+        """forest-em --crp-restarts as concurrent chains on random forests: every run the oracle's, the same kept run"""
+        from carmel_amd._capi import lib
+        ftext, ntext = F.synth_forests(20 + s % 150, 10 + s % 50, s)
+        of, hf = F.make(oracle, ftext, ntext, s)
+        w0 = of.weights().copy()
+        iters, burnin, alpha, R = 3 + s % 4, s % 3, 0.05 + 0.1 * (s % 7), 1 + s % 5
+        mp.setenv("CARMEL_HIP_GIBBS_CHAINS", str([64, 2, 3][s % 3]))
+        lp = hf.gibbs(iters, burnin=burnin, alpha=alpha, seed=s, mode=0, restarts=R)
+        stats, runs = [], []
+        for r in range(R + 1):
+            of.set_weights(w0)
+            ref = of.gibbs(lambda i, b, k, r=r: lib.carmel_hip_gibbs_uniform(s, r * (iters + 1) + i, b, k), iters, burnin=burnin, alpha=alpha)
+            np.testing.assert_allclose(lp[r], ref["iter_logprob"], rtol=1e-10)
+            stats.append(ref["iter_logprob"][min(burnin, iters):].sum())
+            runs.append((ref["samples"], of.weights().copy()))
+        best = int(np.argmax(stats))  # (the earliest of equal maxima, as the sequential loop keeps it)
+        if hf.best_run != best:  # a tie in the last bits may keep another run
+            assert abs(stats[hf.best_run] - stats[best]) <= 1e-9 * abs(stats[best])
+        for b in range(hf.n_forests):
+            assert hf.sample(b) == runs[hf.best_run][0][b]
+        np.testing.assert_allclose(np.exp(hf.weights()), np.exp(runs[hf.best_run][1]), rtol=1e-9, atol=1e-15)
+        hf.close()
+
+    def host_layout_case(d, s, mp=None):
+        """corpora the device builder leaves to the host (wide lattices, cycles, mixtures): the device-built slot order and
+        transposition tables against the host's own counting sorts -- the same image, the same counts"""
+        import test_lattice_gpu as L
+        if s % 3 == 0:
+            w = P.synth.random_wfst(10 + s % 60, 3 + s % 4, n_sym=2 + s % 4, p_eps=0.2 + 0.02 * (s % 5), seed=s)  # *e*:*e* cycles
+            c = P.synth.random_walk_corpus(w, 50 + (s * 7) % 400, min_arcs=2, max_arcs=6 + s % 8, seed=s, out_degree=3 + s % 4)
+        else:
+            w = P.synth.random_wfst(2000 + (s * 97) % 20000, 6 + s % 8, n_sym=2 + s % 4, p_eps=0.05 * (s % 3), seed=s)
+            c = P.synth.random_walk_corpus(w, 20 + s % 120, min_arcs=4, max_arcs=10 + s % 10, seed=s, out_degree=6 + s % 8)
+        host = L._build(w, c, False, device_tables=False)
+        hyb = L._build(w, c, False, device_tables=True)
+        L._same(host, hyb, atomics=True)
+
     cases += [
+        ("forest crp chains", forest_chains_case),
+        ("host layout tables", host_layout_case),
         ("fused lanes", fused_lane_case),
         ("crp chains", chains_case),
         ("tile sweep", tile_sweep_case),
