@@ -86,6 +86,11 @@ def test_committed_profiles_agree():
     assert len(json.dumps(line)) < 2000 and set(line["secondary"]) == {"c4a", "amb", "c2", "long", "c3", "c5", "crp"}
     assert line["value"] == float("%.4g" % bench["value"]) and line["secondary"]["c5"]["exact_ms"] < 1000
     assert line["secondary"]["crp"]["exact_x64"] > 32  # 64 runs of --crp-restarts side by side against one chain
+    assert line["secondary"]["c5"]["exact_x64"] > 32   # ... and forest-em's
+    # config 2 since the launch bubbles went: above a fifth of the roofline, its traffic measured like config 4's
+    assert bench["secondary"]["c2"]["roofline"]["frac"] > 0.2 and bench["secondary"]["c2"]["roofline"]["traffic"] > 0
+    k4 = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_c4_kernel_stats.csv")))]
+    assert not any("zero_list_kernel" in n for n in k4)  # (the tile sweep clears the split arcs' counts itself)
     k4a = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_c4a_kernel_stats.csv")))]
     assert not any("trans_c_tile" in n for n in k4a) and any("sweep_lane_kernel<4, 2, true, carmel_hip::Lse, true, true>" in n for n in k4a)
     assert bench["secondary"]["c4a"]["roofline"]["frac"] > 0.30 and bench["secondary"]["amb"]["roofline"]["frac"] > 0.30

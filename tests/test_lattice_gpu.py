@@ -165,5 +165,5 @@ def test_windowed_corpora_are_built_on_the_device(name, capfd, monkeypatch):
     fb = HipForwardBackward(w, c)
     assert fb.lattice_stats.n_windowed_pairs > 0
     fb.close()
-    if name == "tagging":
-        assert dev["seconds"] < host["seconds"]
+    # (no timing claim on 6 030 pairs: both builders take ~0.03 s there and a 256-thread host wins as often as not;
+    # test_config2_and_a_slice_of_config4 compares the two on 200 000 pairs)
