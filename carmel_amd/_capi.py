@@ -25,7 +25,7 @@ SYMBOLS = [
     "carmel_hip_host_export", "carmel_hip_host_export_lanes", "carmel_hip_host_export_waves", "carmel_hip_host_transpose", "carmel_hip_host_tile_sweep", "carmel_hip_host_free",
     "carmel_hip_gibbs_create", "carmel_hip_gibbs_destroy", "carmel_hip_gibbs_n_blocks", "carmel_hip_gibbs_lattice_stats", "carmel_hip_gibbs_max_sample",
     "carmel_hip_gibbs_run", "carmel_hip_gibbs_run_ex", "carmel_hip_gibbs_set_prior_inference", "carmel_hip_gibbs_prior_trace",
-    "carmel_hip_gibbs_n_prior_scales", "carmel_hip_gibbs_set_run_share", "carmel_hip_gibbs_best_stats", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_set_observer", "carmel_hip_gibbs_current_probs", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
+    "carmel_hip_gibbs_n_prior_scales", "carmel_hip_gibbs_set_run_share", "carmel_hip_gibbs_best_stats", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_set_observer", "carmel_hip_gibbs_current_probs", "carmel_hip_gibbs_get_state", "carmel_hip_gibbs_final_counts", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
     "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_best_run", "carmel_hip_forests_get_sample",
@@ -186,6 +186,8 @@ def _load():
     lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_gibbs_set_observer.argtypes = [vp, C.c_uint32, GIBBS_OBSERVER_FN, vp]
     lib.carmel_hip_gibbs_current_probs.argtypes = [vp, vp]
+    lib.carmel_hip_gibbs_get_state.argtypes = [vp, vp, vp, vp, vp]
+    lib.carmel_hip_gibbs_final_counts.argtypes = [vp, vp]
     lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.carmel_hip_gibbs_uniform.restype = C.c_double
     lib.carmel_hip_gibbs_power.argtypes = [C.c_double, C.c_double, C.c_uint32, C.c_uint32]

@@ -686,6 +686,7 @@ struct carmel_hip_gibbs {
   } wclass[2];
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
+  std::vector<double> h_final_x;  // ... its counts as finalize_cumulative_counts left them (carmel_hip_gibbs_final_counts)
   // runs as replicas (carmel_hip_gibbs_set_run_share): this sampler takes the runs r with r % run_stride == run_first
   uint32_t run_first = 0, run_stride = 1;
   bool ran_any = false;
@@ -1316,6 +1317,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
             g->best_stats[1] = st_final[c];
             g->best_stats[2] = st_sum[c];
             best_lw = lw;
+            g->h_final_x = x;
             best_ids_h.resize(cs);
             best_len_h.resize(g->n_blocks);
             HIPCHK(hipMemcpyAsync(best_ids_h.data(), mids.p + (size_t)c * cs, cs * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -1556,6 +1558,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     g->best_stats[1] = st_final;
     g->best_stats[2] = st_sum;
     best_lw = lw;
+    g->h_final_x = x;
     if (n_runs > 1 && !g->opt.expectation) {
       HIPCHK(best_ids.alloc(g->sample_ids.n));
       HIPCHK(best_len.alloc(g->sample_len.n));
@@ -1614,6 +1617,28 @@ int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob) {
   if (g->n_norm) HIPCHK(hipMemcpyAsync(ns.data(), g->normsum.p, g->n_norm * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   for (size_t p = 0; p < np; ++p) prob[p] = g->h_norm[p] == 0xffffffffu ? g->h_prior[p] : x[p] / ns[g->h_norm[p]];
+  return CARMEL_HIP_OK;
+}
+
+// the sampler's counts as they stand (gibbs_param::sumcount, delta_sum.hpp: instantaneous count x, its time-weighted sum s, the
+// time tmax it is summed up to) and the priors -- what --print-counts-* shows; inside an observer call, or after the run
+int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior) {
+  if (!g) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(g->t->device));
+  hipStream_t s = g->t->stream;
+  const size_t np = g->h_norm.size();
+  if (x) HIPCHK(hipMemcpyAsync(x, g->p_x.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (sum) HIPCHK(hipMemcpyAsync(sum, g->p_s.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (tmax) HIPCHK(hipMemcpyAsync(tmax, g->p_tmax.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (prior) HIPCHK(hipMemcpyAsync(prior, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+// ... and the kept run's counts after finalize_cumulative_counts (gibbs.hpp:626-638): what the final table shows as count * (t + 1)
+int carmel_hip_gibbs_final_counts(carmel_hip_gibbs* g, double* x) {
+  if (!g || !x) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (g->h_final_x.size() != g->h_norm.size()) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_gibbs_final_counts: run the sampler first");
+  std::memcpy(x, g->h_final_x.data(), g->h_final_x.size() * sizeof(double));
   return CARMEL_HIP_OK;
 }
 

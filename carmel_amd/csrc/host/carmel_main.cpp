@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <functional>
 #include <limits>
@@ -106,6 +107,12 @@ struct Options {
   bool crp_argmax_final = false, crp_argmax_sum = false;
   bool include_self = false, random_start = false;  // gibbs_opts.hpp:40-41, 127-128
   long print_every = 0;                              // gibbs_opts.hpp:78-79
+  // the sampler's tables (gibbs_opts.hpp:64-77, 142-146, 197-203; gibbs.hpp:970-1078): parameter ids [from, to) of the count
+  // table, norm-group ids [from, to) of the norm sums; 4294967295 = to the end
+  unsigned long print_counts_from = 0, print_counts_to = 0, print_norms_from = 0, print_norms_to = 0;
+  double print_counts_sparse = 0;
+  bool rich_counts = false, norm_order = false;
+  long width = 7;
   std::string fem_forest, fem_norm, fem_param, fem_alpha;  // forest-em export (carmel.cc:756-769, 818-831)
   long print_from = 0, print_to = 0;  // --print-from=m --print-to=n (gibbs_opts.hpp; gibbs.cc:258-296): the final sample's
                                       // path through input transducers m .. n-1, one line each, on stdout
@@ -183,6 +190,24 @@ static Options parse_args(int argc, char** argv) {
         o.print_to = std::atol(v.c_str());
       else if (k == "print-every")  // gibbs_opts.hpp:78-79, gibbs.hpp:959-968
         o.print_every = std::atol(v.c_str());
+      else if (k == "print-counts-from")
+        o.print_counts_from = std::strtoul(v.c_str(), 0, 10);
+      else if (k == "print-counts-to")
+        o.print_counts_to = std::strtoul(v.c_str(), 0, 10);
+      else if (k == "print-norms-from")
+        o.print_norms_from = std::strtoul(v.c_str(), 0, 10);
+      else if (k == "print-norms-to")
+        o.print_norms_to = std::strtoul(v.c_str(), 0, 10);
+      else if (k == "print-counts-sparse")
+        o.print_counts_sparse = std::atof(v.c_str());
+      else if (k == "print-counts-rich")
+        o.rich_counts = true;
+      else if (k == "norm-order")
+        o.norm_order = true;
+      else if (k == "width") {
+        o.width = std::atol(v.c_str());
+        if (o.width < 4) o.width = 20;  // gibbs_opts.hpp:255
+      }
       else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob") {
         // inert in carmel itself: gibbs_opts::cache_prob is true and never cleared (carmel.cc:296-298, gibbs_opts.hpp:240,
         // 255-258), so the cache-model probability is what is logged whatever these say
@@ -1241,6 +1266,197 @@ static int run(int argc, char** argv) {
     // (gibbs.cc:272-286).  The count / norm tables of --print-counts-* / --print-norms-* are not written.
     // With --gpus the runs are spread over the ranks (replicas): every rank keeps what its runs print, run by run, and rank 0
     // prints all of it in run order afterwards -- what one process running the runs one after the other prints.
+    //
+    // --print-counts-from/-to, --print-norms-from/-to (gibbs.hpp:970-1078; carmel's order gibbs.cc:42-64): the tables are keyed by
+    // the ids define_param hands out (gibbs.cc:113-190): member by member, norm group by norm group in NormGroupIter's order (the
+    // order --fem-norm lists them in: refhash.hpp), a group's locked arcs first as they come, then its free arcs -- a CONDITIONAL
+    // group's in reversed list order --; a member normalised by NONE gets ids only.  Norm ids run on across the members, JOINT
+    // states without arcs included; the prior-scale group of a norm group as metanorm assigns it (gibbs.hpp:404-470).
+    const size_t n_par = cascade ? params.logw.size() : logw.size();
+    std::vector<uint32_t> ref_id(n_par, 0), ref_meta;
+    std::vector<int64_t> ref_norm(n_par, -1);
+    std::vector<std::vector<uint32_t> > norm_members;  // by reference norm id: the trainer's parameter ids
+    const bool want_counts = o.print_counts_to > o.print_counts_from, want_norms = o.print_norms_to > o.print_norms_from;
+    std::vector<const Transducer*> tmem;
+    if (cascade)
+      for (size_t i = 0; i < nw; ++i) tmem.push_back(&member[i]);
+    else
+      tmem.push_back(result);
+    if (want_counts || want_norms) {
+      uint32_t gid = 0, nexti = 1;
+      size_t p0 = 0;
+      for (size_t i = 0; i < tmem.size(); ++i) {
+        const Transducer& m = *tmem[i];
+        const int pg = priorgroup[i < priorgroup.size() ? i : 0];
+        if (norms[i] == CARMEL_HIP_NORM_NONE) {
+          for (auto& st : m.states)
+            for (size_t k = 0; k < st.size(); ++k) ref_id[p0++] = gid++;
+          continue;
+        }
+        for (uint32_t st = 0; st < m.states.size(); ++st) {
+          const auto& arcs = m.states[st];
+          auto group = [&](const std::vector<size_t>& g) {  // (arc indices within the state, in the iterator's order)
+            std::vector<size_t> free_arcs;
+            for (size_t j : g)
+              if (arcs[j].group == kLocked)
+                ref_id[p0 + j] = gid++;
+              else
+                free_arcs.push_back(j);
+            if (norms[i] == CARMEL_HIP_NORM_CONDITIONAL) std::reverse(free_arcs.begin(), free_arcs.end());
+            const uint32_t nid = (uint32_t)norm_members.size();
+            norm_members.emplace_back();
+            for (size_t j : free_arcs) {
+              ref_id[p0 + j] = gid++;
+              ref_norm[p0 + j] = nid;
+              norm_members.back().push_back((uint32_t)(p0 + j));
+            }
+            ref_meta.push_back(pg == 0 ? 0u : nexti);  // gibbs.cc:132-137
+            if (pg == 2) ++nexti;
+          };
+          if (norms[i] == CARMEL_HIP_NORM_JOINT) {
+            std::vector<size_t> g(arcs.size());
+            for (size_t j = 0; j < g.size(); ++j) g[j] = j;
+            group(g);
+          } else if (!arcs.empty()) {
+            std::vector<uint32_t> syms;
+            for (auto& a : arcs) syms.push_back(a.in);
+            for (uint32_t sym : carmel_host::conditional_group_order(syms)) {
+              std::vector<size_t> g;
+              for (size_t j = arcs.size(); j-- > 0;)
+                if (arcs[j].in == sym) g.push_back(j);
+              group(g);
+            }
+          }
+          p0 += arcs.size();
+        }
+        if (pg == 1) ++nexti;  // gibbs.cc:184
+      }
+      if (o.pi_global) std::fill(ref_meta.begin(), ref_meta.end(), 1u);  // finish_params: set_global (gibbs.hpp:572-579)
+    }
+    // print_width (graehl/shared/print_width.hpp:98-130): a number in at most `width` characters
+    auto print_width = [&](std::ostream& os, double d) {
+      const int width0 = (int)o.width;
+      if (width0 >= 20 || d == 0. || width0 <= 0) {
+        os << d;
+        return;
+      }
+      const std::ios::fmtflags f = os.flags();
+      const std::streamsize pr = os.precision();
+      int width = width0;
+      double pa = d;
+      if (d < 0) {
+        pa = -d;
+        --width;
+      }
+      auto sig_for_exp = [](int w, int e) {
+        const int r = w - (e < 100 ? 2 : 3) - 3;
+        return r > 0 ? r : 0;
+      };
+      const double wholes = std::log10(pa * (1 + 1e-8));
+      if (wholes <= width && d == (double)(int)d)
+        os << d;
+      else if (pa < 1) {
+        const int a = (int)-wholes, need = 2 + a;
+        if (need >= width)
+          os << std::scientific << std::setprecision(sig_for_exp(width, a) - 1) << d;
+        else
+          os << std::setprecision(width - 2 - a) << d;
+      } else {
+        const int a = (int)wholes, need = 1 + a;
+        if (need > width)
+          os << std::scientific << std::setprecision(sig_for_exp(width, a) - 1) << d;
+        else
+          os << std::fixed << std::setprecision(need + 1 < width ? width - need - 1 : 0) << d;
+      }
+      os.flags(f);
+      os.precision(pr);
+    };
+    // print_norms (gibbs.hpp:970-981): the norm sums of groups [from, to) -- a group's sum is the sum of its members' counts
+    auto print_norms = [&](uint32_t iter, double time, const std::vector<double>& x) {
+      if (!want_norms) return;
+      const unsigned long from = o.print_norms_from, to = std::min<unsigned long>(o.print_norms_to, norm_members.size());
+      if (!(to > from)) return;
+      std::cout << "\n# group\tnormalization group sums i=" << iter << " t=" << time << "\n(\n";
+      for (unsigned long n = from; n < to; ++n) {
+        double sum = 0;
+        for (uint32_t pp : norm_members[n]) sum += x[pp];
+        std::cout << ' ' << sum << "\n";
+      }
+      std::cout << ")\n";
+    };
+    // print_counts (gibbs.hpp:986-1064): x, s, tm = gibbs_param::sumcount; final: x holds the finalized counts, prob the weights
+    auto print_counts = [&](bool final, const char* name, uint32_t iter, double time, const std::vector<double>& x,
+                            const std::vector<double>& sacc, const std::vector<double>& tm, const std::vector<double>& prior,
+                            const std::vector<double>& prob) {
+      if (!want_counts) return;
+      const double ta = time + 1;
+      std::cout << "\n#id\tgroup\tcount\tprob";
+      if (!final) std::cout << "\tavg@" << ta << "\tlast@t\tprior\tgroupby";
+      if (o.rich_counts) std::cout << "\tparam name";
+      if (!final) std::cout << "\titer=" << iter;
+      std::cout << "\t" << name << '\n';
+      const unsigned long from = o.print_counts_from, to = std::min<unsigned long>(o.print_counts_to, n_par);
+      auto field = [&](double d) {
+        std::cout << '\t';
+        print_width(std::cout, d);
+      };
+      // the trainer's parameter p <-> (member, source state, arc)
+      auto row = [&](size_t pp, size_t mi, uint32_t src, const HArc& arc) {
+        const uint32_t gi = ref_id[pp];
+        if (!(gi >= from && gi < to)) return;
+        // (a parameter without a norm group -- a locked arc, a member normalised by NONE -- never counts: its sumcount stays 0)
+        const bool has = ref_norm[pp] >= 0;
+        const double xx = has ? x[pp] : 0.0, sx_ = has ? sacc[pp] : 0.0, tx = has ? tm[pp] : 0.0;
+        const double avg = final ? xx / ta : (ta > 0 ? (sx_ + xx * (ta - tx)) / ta : xx);  // delta_sum::avg(ta)
+        if (!(o.print_counts_sparse == 0 || avg >= prior[pp] + o.print_counts_sparse)) return;
+        std::cout << gi << '\t';
+        if (ref_norm[pp] >= 0)
+          std::cout << ref_norm[pp];
+        else
+          std::cout << "LOCKED";
+        field(final ? avg : xx);
+        field(prob[pp]);
+        if (!final) {
+          field(avg);
+          field(tx);
+          field(prior[pp]);
+          const uint32_t meta = ref_norm[pp] >= 0 ? ref_meta[(size_t)ref_norm[pp]] : 0u;
+          std::cout << '\t';
+          if (meta > 0)
+            std::cout << meta;
+          else
+            std::cout << "FIXED";
+        }
+        if (o.rich_counts) {  // carmel_gibbs::print_param (gibbs.cc:206-212): member index, then WFST::printArc without the weight
+          const Transducer& W = *tmem[mi];
+          std::cout << '\t' << mi << '(' << W.state_name(src) << " -> " << W.state_name(arc.dest) << ' ' << W.in_syms.names[arc.in]
+                    << " : " << W.out_syms.names[arc.out] << ')';
+        }
+        std::cout << '\n';
+      };
+      if (o.norm_order) {  // ids in order (gibbs.hpp:1050-1055)
+        std::vector<uint32_t> by_id(n_par);
+        std::vector<uint32_t> p_src(n_par), p_mem(n_par);
+        std::vector<const HArc*> p_arc(n_par);
+        size_t pp = 0;
+        for (size_t mi = 0; mi < tmem.size(); ++mi)
+          for (uint32_t st = 0; st < tmem[mi]->states.size(); ++st)
+            for (auto& arc : tmem[mi]->states[st]) {
+              by_id[ref_id[pp]] = (uint32_t)pp;
+              p_src[pp] = st;
+              p_mem[pp] = (uint32_t)mi;
+              p_arc[pp] = &arc;
+              ++pp;
+            }
+        for (unsigned long gi = from; gi < to; ++gi) row(by_id[gi], p_mem[by_id[gi]], p_src[by_id[gi]], *p_arc[by_id[gi]]);
+      } else {  // "print counts in fst file order, not normgroups order" (gibbs.cc:58-64)
+        size_t pp = 0;
+        for (size_t mi = 0; mi < tmem.size(); ++mi)
+          for (uint32_t st = 0; st < tmem[mi]->states.size(); ++st)
+            for (auto& arc : tmem[mi]->states[st]) row(pp++, mi, st, arc);
+      }
+      std::cout << "\n";
+    };
     std::vector<std::string> periodic_text(world > 1 ? (size_t)go.restarts + 1 : 0);
     std::streambuf* const cout_buf = std::cout.rdbuf();
     std::function<void(uint32_t, uint32_t, double)> periodic = [&](uint32_t run, uint32_t iter, double time) {
@@ -1263,12 +1479,45 @@ static int run(int argc, char** argv) {
         }
       } keep{cap, (world > 1 && run < periodic_text.size()) ? &periodic_text[run] : nullptr};
       (void)cout_buf;
+      // the tables' state: counts as they stand, their time-weighted sums and stamps, the priors, the proposal probabilities
+      std::vector<double> sx, ss, st_, sp, spr;
+      if (want_counts || want_norms) {
+        sx.resize(n_par);
+        ss.resize(n_par);
+        st_.resize(n_par);
+        sp.resize(n_par);
+        spr.resize(n_par);
+        hip_check(carmel_hip_gibbs_get_state(gs, sx.data(), ss.data(), st_.data(), sp.data()), "carmel_hip_gibbs_get_state");
+        hip_check(carmel_hip_gibbs_current_probs(gs, spr.data()), "carmel_hip_gibbs_current_probs");
+        for (size_t pp = 0; pp < n_par; ++pp)  // final_prob (gibbs.hpp:144-151): 0 for a count of 0
+          if (ref_norm[pp] >= 0 && !(sx[pp] > 0)) spr[pp] = 0;
+      }
+      if (iter == 0 && o.print_counts_sparse == 0) {  // gibbs_base::run's prologue (gibbs.hpp:811-814): the priors as counts
+        std::cout << "# ";
+        if (want_counts) {
+          std::vector<double> pprob(n_par);
+          for (size_t pp = 0; pp < n_par; ++pp) {
+            double ns = 0;
+            if (ref_norm[pp] >= 0)
+              for (uint32_t q : norm_members[(size_t)ref_norm[pp]]) ns += sp[q];
+            pprob[pp] = ref_norm[pp] >= 0 ? (sp[pp] > 0 ? sp[pp] / ns : 0.0) : sp[pp];
+          }
+          print_counts(true, "(prior counts)", 0, 0.0, sp, ss, st_, sp, pprob);
+        }
+      }
       std::cout << "# Gibbs i=" << iter << " ";
       if (go.high_temp != go.low_temp && (go.high_temp > 0 || go.low_temp > 0)) {  // gibbs.hpp:945-955 itername
         const double pw_ = carmel_hip_gibbs_power(go.high_temp, go.low_temp, go.iter, iter);
         std::cout << "temperature=" << 1.0 / pw_ << " power=" << pw_ << " ";
       }
       std::cout << "t=" << time << "\n";
+      struct Tables {  // print_all (gibbs.hpp:1066-1078): the sample, then the norm sums, then the counts
+        std::function<void()> f;
+        ~Tables() { f(); }
+      } tables{[&]() {
+        print_norms(iter, time, sx);
+        print_counts(false, "", iter, time, sx, ss, st_, sp, spr);
+      }};
       if (!(o.print_to > o.print_from)) return;
       if (go.expectation) throw std::runtime_error("can't print sample when using expectation because there is no single sample.\n");
       const size_t n_members = cascade ? nw : 1;
@@ -1296,6 +1545,8 @@ static int run(int argc, char** argv) {
                                               &periodic),
                 "carmel_hip_gibbs_set_observer");
     }
+    if (world > 1 && (want_counts || want_norms))
+      throw UsageError("--print-counts-* / --print-norms-* with --gpus: the tables are one process's (the runs are spread over the ranks)");
     if (world > 1) hip_check(carmel_hip_gibbs_set_run_share(gs, (uint32_t)rank, (uint32_t)world), "carmel_hip_gibbs_set_run_share");
     const auto t_g0 = std::chrono::steady_clock::now();
     int rc = carmel_hip_gibbs_run_ex(gs, lp.data(), 0, o.sample_prob_after ? lp_after.data() : 0);
@@ -1333,6 +1584,11 @@ static int run(int argc, char** argv) {
         hip_check(carmel_hip_gibbs_get_sample(gs, b, buf.data(), &n), "carmel_hip_gibbs_get_sample");
         final_sample[b].assign(buf.begin(), buf.begin() + n);
       }
+    }
+    std::vector<double> final_x;  // the kept run's counts as finalize_cumulative_counts left them: the final table's
+    if ((want_counts || want_norms) && rc == CARMEL_HIP_OK) {
+      final_x.resize(n_par);
+      hip_check(carmel_hip_gibbs_final_counts(gs, final_x.data()), "carmel_hip_gibbs_final_counts");
     }
     carmel_hip_gibbs_destroy(gs);
     hip_check(rc, "carmel_hip_gibbs_run");
@@ -1437,6 +1693,8 @@ static int run(int argc, char** argv) {
     if (go.restarts) std::cerr << "\nKept run " << best_run << " of " << go.restarts << " (gibbs_stats::better)\n";
     std::vector<double> pw(cascade ? params.logw.size() : logw.size());
     hip_check(carmel_hip_get_weights(t, pw.data()), "carmel_hip_get_weights");
+    const double final_t = (double)go.iter - (double)(go.final_counts ? go.iter : std::min(go.burnin, go.iter));
+    bool final_header = false;
     if (printing) {
       // gibbs_base::print_all -> carmel_gibbs::print_sample (gibbs.hpp:1066-1078; gibbs.cc:258-296): per block, for every
       // input transducer in [from, to) the arcs of the sampled path that belong to it, through WFST::path_print; an arc's
@@ -1447,10 +1705,17 @@ static int run(int argc, char** argv) {
         std::cerr << "--print-from,-to gibbs [" << a << "," << b << ") is out of range for " << n_members << " input transducers.\n";
       } else {
         if (b > (long)n_members) b = (long)n_members;
-        std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << ((double)go.iter - (double)(go.final_counts ? go.iter : std::min(go.burnin, go.iter)))
-                  << "):\n";
+        std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << final_t << "):\n";
+        final_header = true;
         print_paths(final_sample, pw, a, b);
       }
+    }
+    if (want_counts || want_norms) {  // ... then the norm sums and the counts of the kept run (gibbs.hpp:1075-1076)
+      if (!final_header) std::cout << "\n# final best gibbs run (start #" << best_run << " t=" << final_t << "):\n";
+      std::vector<double> fprob(n_par);
+      for (size_t pp = 0; pp < n_par; ++pp) fprob[pp] = std::exp(pw[pp]);  // final_prob: the weights (a locked arc's: its own)
+      print_norms(go.iter + 1, final_t, final_x);
+      print_counts(true, "", go.iter + 1, final_t, final_x, final_x, final_x, final_x, fprob);
     }
     const char* dir = std::getenv("CARMEL_TRAINED_DIR");
     for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437

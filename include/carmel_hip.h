@@ -394,6 +394,12 @@ uint32_t carmel_hip_gibbs_n_prior_scales(carmel_hip_gibbs* g);
 typedef void (*carmel_hip_gibbs_observer_fn)(void* ctx, uint32_t run, uint32_t iter, double time);
 int carmel_hip_gibbs_set_observer(carmel_hip_gibbs* g, uint32_t every, carmel_hip_gibbs_observer_fn fn, void* ctx);
 int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob);
+/* --print-counts-* / --print-norms-* (gibbs.hpp:970-1078): per parameter (the trainer's parameter order) the count as it stands,
+ * its time-weighted sum, the time it is summed up to (gibbs_param::sumcount: delta_sum.hpp) and the prior pseudo-count; any
+ * pointer may be NULL.  Inside an observer call or after the run.  _final_counts: the kept run's counts as
+ * finalize_cumulative_counts left them (gibbs.hpp:626-638). */
+int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior);
+int carmel_hip_gibbs_final_counts(carmel_hip_gibbs* g, double* x);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);
 /* --init-em (gibbs.cc:386-430, 306-383 p_init): ln weights of the composed arcs (carmel_hip_get_arc_weights after an EM

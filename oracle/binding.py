@@ -375,7 +375,7 @@ lib.orc_gibbs_last_prior_trace.restype = C.c_uint32
 def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burnin=0, uniform_p0=False,
               dirichlet_p0=False, final_counts=False, exclude_prior=False, max_samples=1 << 22, high_temp=1.0,
               low_temp=1.0, expectation=False, restarts=0, argmax_final=False, argmax_sum=False, init_em=0,
-              em_p0=False, init_from_p0=False, prior_inference=None, include_self=False, random_start=False):
+              em_p0=False, init_from_p0=False, prior_inference=None, include_self=False, random_start=False, state_trace=False):
     """carmel --crp on an OracleCascade; prior_inference = dict(stddev, global_, local, restart_fresh, start, end, groupby)
     turns on prior-scale inference (gibbs.hpp:525-553). `uniform(iter, block, step)` supplies every random01() draw.
     Returns dict(iter_logprob, iter_cheap_logprob, param_logw, samples=[per block list of member-arc indices])"""
@@ -399,6 +399,7 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     lib.orc_set_gibbs_prior_inference(C.c_double(pi.get("stddev", 0.0)), int(pi.get("global_", False)), int(pi.get("local", False)),
                                       int(pi.get("restart_fresh", False)), int(pi.get("start", 0)), int(pi.get("end", 0)),
                                       _p(gb) if len(gb) else None, len(gb))
+    lib.orc_set_gibbs_state_trace(int(state_trace))
     _chk(lib.orc_gibbs_run(cascade.h, corpus.h, (normby or "").encode() or None, _p(pri), iters, burnin,
                            int(uniform_p0), int(dirichlet_p0), int(final_counts), int(exclude_prior), cb, _p(ilp),
                            _p(icl), _p(plw), _p(samp), _p(off), max_samples, C.byref(nb)))
@@ -410,8 +411,19 @@ def gibbs_run(cascade, corpus, uniform, normby=None, priors=None, iters=10, burn
     lib.orc_gibbs_last_prior_trace.restype = C.c_uint32
     ncum = lib.orc_gibbs_last_prior_trace(_p(ptrace), len(ilp), _p(cum), len(cum))
     lib.orc_set_gibbs_prior_inference(C.c_double(0.0), 0, 0, 0, 0, 0, None, 0)
-    return dict(iter_logprob=ilp, iter_cheap_logprob=icl, iter_after_logprob=after, param_logw=plw, samples=samples,
-                best_run=lib.orc_gibbs_best_run(), prior_trace=ptrace, prior_cumulative=cum[:ncum])
+    out = dict(iter_logprob=ilp, iter_cheap_logprob=icl, iter_after_logprob=after, param_logw=plw, samples=samples,
+               best_run=lib.orc_gibbs_best_run(), prior_trace=ptrace, prior_cumulative=cum[:ncum])
+    if state_trace:
+        # what --print-counts-* / --print-norms-* show: after every sweep of every run, per parameter (member-arc order)
+        # {count x, time-weighted sum s, tmax, prior}; the kept run's finalized {count, prob}; per parameter {define_param id,
+        # norm id or -1, prior-scale group or 0}
+        nsw = len(ilp)
+        st, fin, ids = np.zeros(nsw * n * 4), np.zeros(n * 2), np.zeros(n * 3, np.int32)
+        lib.orc_set_gibbs_state_trace(0)
+        lib.orc_gibbs_last_state.restype = C.c_uint64
+        lib.orc_gibbs_last_state(_p(st), C.c_uint64(len(st)), _p(fin), C.c_uint64(len(fin)), _p(ids), C.c_uint64(len(ids)))
+        out.update(state=st.reshape(nsw, n, 4), final=fin.reshape(n, 2), ids=ids.reshape(n, 3))
+    return out
 
 
 lib.orc_forests_parse.restype = vp

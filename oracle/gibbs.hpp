@@ -99,6 +99,12 @@ struct GibbsTrace {
   std::vector<std::vector<unsigned> > last_sample;  // per block: param ids of the final sample
   std::vector<double> prior_trace;                // per sweep: {proposed, accepted, ln p1, ln p2, a2, p_accept}
   std::vector<double> cumulative;                 // metanorm::cumulative after the last run
+  // what --print-counts-* / --print-norms-* show (gibbs.hpp:970-1078), when want_state: after every sweep of every run, per
+  // parameter in define_param order {x, s, tmax, prior} (gibbs_param::sumcount, prior), then after the runs the kept run's
+  // counts as finalize_cumulative_counts left them and its final_prob
+  bool want_state = false;
+  std::vector<double> state;        // [(run, sweep)][param][4]
+  std::vector<double> final_x, final_prob;
 };
 
 // boost::math::normal_distribution's cdf / quantile (gibbs.hpp:474-516; boost is absent from the tree): the cdf from erfc,
@@ -440,6 +446,11 @@ struct CarmelGibbs {
         finalize_cumulative_counts();
         best_prob.resize(gps.size());
         for (size_t i = 0; i < gps.size(); ++i) best_prob[i] = final_prob((unsigned)i);
+        if (tr && tr->want_state) {
+          tr->final_x.resize(gps.size());
+          for (size_t i = 0; i < gps.size(); ++i) tr->final_x[i] = gps[i].sum.x;
+          tr->final_prob = best_prob;
+        }
         best_sample = sample;
       }
     }
@@ -522,6 +533,11 @@ struct CarmelGibbs {
         const unsigned sweep = run_index * (Ni + 1) + iter;
         propose_new_priors([&](unsigned b, unsigned k) { return u(sweep, b, k); }, tr6);
       }
+      if (tr && tr->want_state)
+        for (auto& g : gps) {
+          const double v[4] = {g.sum.x, g.sum.s, g.sum.tmax, g.prior};
+          tr->state.insert(tr->state.end(), v, v + 4);
+        }
       if (tr) {
         tr->prior_trace.insert(tr->prior_trace.end(), tr6, tr6 + 6);
         tr->iter_logprob.push_back(pc.w);

@@ -403,6 +403,17 @@ uint32_t orc_gibbs_last_prior_trace(double* out6, uint32_t n_sweeps, double* cum
   for (uint32_t k = 0; k < n_cum; ++k) cumulative[k] = k < g_last_cumulative.size() ? g_last_cumulative[k] : 1.0;
   return (uint32_t)g_last_cumulative.size();
 }
+// --print-counts-* / --print-norms-*: the sampler's per-parameter state after every sweep (GibbsTrace::state), kept when asked
+static int g_want_state = 0;
+static std::vector<double> g_last_state, g_last_final;  // state: [(run, sweep)][param in MEMBER-ARC order][4]; final: [param][2] = {x, prob}
+static std::vector<int32_t> g_last_ids;                 // per member-arc: {define_param id, norm id or -1, scale group (metanorm) or 0}
+void orc_set_gibbs_state_trace(int on) { g_want_state = on; }
+uint64_t orc_gibbs_last_state(double* state, uint64_t n_state, double* fin, uint64_t n_fin, int32_t* ids, uint64_t n_ids) {
+  for (uint64_t i = 0; i < n_state && i < g_last_state.size(); ++i) state[i] = g_last_state[i];
+  for (uint64_t i = 0; i < n_fin && i < g_last_final.size(); ++i) fin[i] = g_last_final[i];
+  for (uint64_t i = 0; i < n_ids && i < g_last_ids.size(); ++i) ids[i] = g_last_ids[i];
+  return g_last_state.size();
+}
 static std::vector<double> g_last_after;  // GibbsTrace::iter_after_logprob of the last orc_gibbs_run
 void orc_gibbs_last_after(double* out, uint32_t n) {
   for (uint32_t i = 0; i < n && i < g_last_after.size(); ++i) out[i] = g_last_after[i];
@@ -999,6 +1010,7 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
     CarmelGibbs g(*h->result, h->cascade, c->c, nms, go);
     g.init_logw = init_logw;
     GibbsTrace tr;
+    tr.want_state = g_want_state != 0;
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     g_best_run = (int)g.best_run;
     g_last_after = tr.iter_after_logprob;
@@ -1018,6 +1030,22 @@ int orc_gibbs_run(orc_cascade* h, orc_corpus* c, const char* normby, const doubl
           if (out_param_logw) out_param_logw[k] = a.weight.w;
           ++k;
         }
+    if (tr.want_state) {  // to member-arc order, with the ids the tables print
+      const size_t np = g.gps.size(), nsw = np ? tr.state.size() / (4 * np) : 0;
+      g_last_state.assign(tr.state.size(), 0.0);
+      g_last_final.assign(2 * np, 0.0);
+      g_last_ids.assign(3 * np, 0);
+      for (size_t pid = 0; pid < np; ++pid) {
+        const size_t a = arc_index[pid];
+        for (size_t q = 0; q < nsw; ++q)
+          for (int f = 0; f < 4; ++f) g_last_state[(q * np + a) * 4 + f] = tr.state[(q * np + pid) * 4 + f];
+        g_last_final[2 * a] = tr.final_x[pid];
+        g_last_final[2 * a + 1] = tr.final_prob[pid];
+        g_last_ids[3 * a] = (int32_t)pid;
+        g_last_ids[3 * a + 1] = g.gps[pid].has_norm() ? (int32_t)g.gps[pid].norm : -1;
+        g_last_ids[3 * a + 2] = g.gps[pid].has_norm() && g.gps[pid].norm < g.metanorm.size() ? (int32_t)g.metanorm[g.gps[pid].norm] : 0;
+      }
+    }
     if (n_blocks) *n_blocks = (uint32_t)tr.last_sample.size();
     if (out_sample_off) {
       uint64_t o = 0;

@@ -929,8 +929,9 @@ def test_crp_print_every(golden_dir, tmp_path, oracle):
     env = {"CARMEL_TRAINED_DIR": str(tmp_path)}
     rc, out, err = run(["--print-every=3", "--print-from=1", "--print-to=2", "-OQWE"] + base, env=env)
     assert rc == 0, err
-    heads = [l for l in out.split("\n") if l.startswith("# Gibbs i=")]
-    assert heads == ["# Gibbs i=0 t=0", "# Gibbs i=3 t=0", "# Gibbs i=6 t=3", "# Gibbs i=9 t=6"]
+    heads = [l for l in out.split("\n") if "# Gibbs i=" in l]
+    # (the first line carries the "# " of the run's prologue, gibbs.hpp:811-814: written whether or not a count table follows it)
+    assert heads == ["# # Gibbs i=0 t=0", "# Gibbs i=3 t=0", "# Gibbs i=6 t=3", "# Gibbs i=9 t=6"]
     chunks = re.split(r"# Gibbs i=\d+ t=\d+\n", out)
     assert len(chunks) == 5 and "# final best gibbs run (start #0 t=6):" in chunks[4]
     per = [[l for l in c.split("\n") if l and not l.startswith("#")] for c in chunks[1:]]
@@ -952,6 +953,136 @@ def test_crp_print_every(golden_dir, tmp_path, oracle):
     assert rc == 0, err
     fin3 = [l for l in out_s.split("\n") if l and not l.startswith("#")]
     assert at3 == fin3
-    # the count / norm tables stay refused
-    rc, out, err = run(["--print-every=3", "--print-counts-to=5"] + base, env=env)
-    assert rc != 0 and "print-counts-to" in err
+
+
+def _print_width(d, width):
+    """graehl/shared/print_width.hpp:98-130 restated: a number in at most `width` characters (C++ stream formatting = printf's)"""
+    g6 = lambda v: "%g" % v
+    if width >= 20 or d == 0 or width <= 0:
+        return g6(d)
+    p, w = abs(d), width - (1 if d < 0 else 0)
+    sig_for_exp = lambda wd, e: max(0, wd - (2 if e < 100 else 3) - 3)
+    sci = lambda prec: ("%.*e" % (prec, d)) if prec >= 0 else ("%e" % d)
+    wholes = math.log10(p * (1 + 1e-8))
+    if wholes <= w and d == float(int(d)):
+        return g6(d)
+    if p < 1:
+        a = int(-wholes)
+        if 2 + a >= w:
+            return sci(sig_for_exp(w, a) - 1)
+        return "%.*g" % (w - 2 - a, d)
+    a = int(wholes)
+    need = 1 + a
+    if need > w:
+        return sci(sig_for_exp(w, a) - 1)
+    return "%.*f" % (w - need - 1 if need + 1 < w else 0, d)
+
+
+def _tables(ref, oc, sweep, time, final, name, width=7, rich=False, norm_order=False, sparse=0.0, iters=None, norms=True, counts=True):
+    """gibbs.hpp:970-1078 restated over the ORACLE's state (oracle.gibbs_run(state_trace=True)): print_norms + print_counts after
+    sweep `sweep` of run 0 (final: the kept run's finalized counts), in carmel's order (gibbs.cc:42-64) or by id (--norm-order)"""
+    ids = ref["ids"]
+    n = len(ids)
+    out = []
+    if final:
+        x, prob = ref["final"][:, 0], ref["final"][:, 1]
+        s_, tm, prior = x, x, x
+    else:
+        st = ref["state"][sweep]
+        x, s_, tm, prior = st[:, 0], st[:, 1], st[:, 2], st[:, 3]
+    has = ids[:, 1] >= 0
+    nnorm = int(ids[:, 1].max()) + 1
+    # (norm ids of JOINT states without arcs have no parameter: their sums print as 0 -- count them from the --fem-norm listing)
+    nnorm = max(nnorm, ref.get("n_norms", 0))
+    nsum = np.zeros(nnorm)
+    np.add.at(nsum, ids[has, 1], x[has])
+    ta = time + 1
+    it = (iters + 1) if final else sweep
+    if norms:
+        out.append("\n# group\tnormalization group sums i=%d t=%s\n(\n" % (it, "%g" % time) + "".join(" %s\n" % ("%g" % v) for v in nsum) + ")\n")
+    if counts:
+        head = "\n#id\tgroup\tcount\tprob"
+        if not final:
+            head += "\tavg@%s\tlast@t\tprior\tgroupby" % ("%g" % ta)
+        if rich:
+            head += "\tparam name"
+        if not final:
+            head += "\titer=%d" % sweep
+        out.append(head + "\t" + name + "\n")
+        order = np.argsort(ids[:, 0], kind="stable") if norm_order else np.arange(n)
+        for p in order:
+            xx, ss, tt = (x[p], s_[p], tm[p]) if has[p] else (0.0, 0.0, 0.0)
+            avg = xx / ta if final else ((ss + xx * (ta - tt)) / ta if ta > 0 else xx)
+            if not (sparse == 0 or avg >= prior[p] + sparse):
+                continue
+            if final:
+                pr = prob[p]
+            elif has[p]:
+                pr = xx / nsum[ids[p, 1]] if xx > 0 else 0.0
+            else:
+                pr = prior[p]
+            f = lambda v: "\t" + _print_width(v, width)
+            row = "%d\t%s" % (ids[p, 0], ids[p, 1] if has[p] else "LOCKED") + f(avg if final else xx) + f(pr)
+            if not final:
+                row += f(avg) + f(tt) + f(prior[p]) + "\t" + (str(ids[p, 2]) if (has[p] and ids[p, 2] > 0) else "FIXED")
+            if rich:
+                row += "\t@%d" % oc.param_member[p]  # (the arc's name is checked for its shape in the test)
+            out.append(row + "\n")
+        out.append("\n")
+    return "".join(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,kw,normby", [([], {}, "CC"), (["--width=9", "--norm-order", "-j"], dict(width=9, norm_order=True), "JJ"),
+                                             (["--print-counts-sparse=0.25"], dict(sparse=0.25), "CC"),
+                                             (["--width=5", "--print-counts-rich", "-j"], dict(width=5, rich=True), "JJ")])
+def test_crp_count_and_norm_tables(golden_dir, tmp_path, oracle, extra, kw, normby):
+    """--print-counts-from/-to, --print-norms-from/-to (+ --width, --print-counts-sparse, --print-counts-rich, --norm-order;
+    gibbs_opts.hpp:64-77; gibbs.hpp:970-1078; carmel's row order and rich names gibbs.cc:42-64, 206-212): the sampler's tables --
+    the priors as counts at the start of a run, the counts / averages / priors and the norm sums after every --print-every-th
+    sweep, the kept run's averaged counts and probabilities at the end -- keyed by define_param's ids and the norm-group ids of
+    NormGroupIter's walk.  The reference holds no output of these switches: the expected text is restated here in Python
+    (print_width included) over the ORACLE's per-sweep state and must equal the front end's text over the device's, character
+    for character."""
+    from carmel_amd._capi import lib
+    g = lambda n: os.path.join(golden_dir, n)
+    N, B, E = 6, 2, 3
+    # (-j: JOINT groups, states without arcs included; not --normby, which also normalises the inputs before they are composed)
+    base = ["--crp", "-M", str(N), "--burnin=%d" % B, "--priors=0.5,0.1", "-R", "7", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    env = {"CARMEL_TRAINED_DIR": str(tmp_path)}
+    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
+    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()), lambda i, b, s: lib.carmel_hip_gibbs_uniform(7, i, b, s),
+                           normby=normby, priors=[0.5, 0.1], iters=N, burnin=B, state_trace=True)
+    ref["n_norms"] = oracle.fem_export(oc, oc.corpus(open(g("cipher.data")).read()), 1, normby=normby, priors=[0.5, 0.1]).count("(") - 1
+    rc, out, err = run(["--print-every=%d" % E, "--print-counts-to=4294967295", "--print-norms-to=4294967295"] + extra + base, env=env)
+    assert rc == 0, err
+    sparse = kw.get("sparse", 0.0)
+    want = ""
+    if sparse == 0:  # the run's prologue: the priors as counts (final form; ta = 1)
+        st0 = ref["state"][0]
+        prologue = dict(ref)
+        pr = st0[:, 3]
+        has = ref["ids"][:, 1] >= 0
+        ns = np.zeros(max(int(ref["ids"][:, 1].max()) + 1, ref["n_norms"]))
+        np.add.at(ns, ref["ids"][has, 1], pr[has])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            prob = np.where(has, np.where(pr > 0, pr / ns[np.where(has, ref["ids"][:, 1], 0)], 0.0), pr)
+        prologue["final"] = np.stack([pr, prob], axis=1)
+        want += "# " + _tables(prologue, oc, 0, 0.0, True, "(prior counts)", norms=False, iters=N, **kw)
+    for sweep in range(0, N + 1, E):
+        t = 0.0 if sweep == 0 else max(0.0, sweep - B)
+        want += "# Gibbs i=%d t=%s\n" % (sweep, "%g" % t) + _tables(ref, oc, sweep, t, False, "", iters=N, **kw)
+    want += "\n# final best gibbs run (start #0 t=%s):\n" % ("%g" % (N - B)) + _tables(ref, oc, None, float(N - B), True, "", iters=N, **kw)
+    if kw.get("rich"):  # "<member>(<source> -> <destination> <input> : <output>)" (gibbs.cc:206-212, fst.h:523-529): keep the member
+        out, n_rich = re.subn(r"(?m)^(\d+\t(?:\d+|LOCKED)\t.*\t)(\d)\(\S+ -> \S+ \S+ : \S+\)$", r"\1@\2", out)
+        assert n_rich > 100
+    got_l, want_l = out.split("\n"), want.split("\n")
+    bad = [(k, a, b) for k, (a, b) in enumerate(zip(got_l, want_l)) if a != b][:6]  # (no 20 000-line diff on a failure)
+    assert not bad and len(got_l) == len(want_l), (bad, len(got_l), len(want_l))
+    # id ranges: parameters [3, 8) and norm groups [1, 3) only
+    rc, out2, err = run(["--print-every=%d" % E, "--print-counts-from=3", "--print-counts-to=8", "--print-norms-from=1", "--print-norms-to=3"] + base,
+                        env=env)
+    assert rc == 0, err
+    rows = [l for l in out2.split("\n") if re.match(r"^\d+\t", l)]
+    assert rows and all(3 <= int(l.split("\t")[0]) < 8 for l in rows)
+    assert all(blk.count("\n ") == 2 for blk in re.findall(r"normalization group sums[^\n]*\n\((.*?)\)\n", out2, re.S))
