@@ -61,6 +61,9 @@ struct Opts {
   long watch_period = 10;             // -W
   double report_counts = std::numeric_limits<double>::infinity();  // -X / --report-counts-exceeding (ln)
   double report_probs = std::numeric_limits<double>::infinity();   // -Y / --report-probs-exceeding (ln)
+  long viterbi_per = 0;              // -V / --checkpoint-viterbi-per-examples: on watch iterations the Viterbi derivation of every
+                                     // n-th forest to <prefix>.viterbi.restart.R.iteration.I (forest-em.hpp:403-413, 546-550)
+  long per_forest_counts_per = 0;    // -Z / --checkpoint-per-forest-counts: ... <prefix>.per_forest_counts. ... (:416-425, 535-545)
 };
 
 void usage() {
@@ -69,7 +72,7 @@ void usage() {
                "                 [-z] [-N] [-H] [--crp=N --const-alpha=A --alpha=FILE --burnin=B --high-temp=T --low-temp=T --final-counts --uniform-p0 --crp-parallel\n"
                "                  --crp-restarts=R [--crp-argmax-final | --crp-argmax-sum]\n"
                "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
-               "                 [-x checkpoint-prefix -c] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
+               "                 [-x checkpoint-prefix -c -V viterbi-per -Z per-forest-counts-per] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -165,6 +168,8 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "x" || key == "checkpoint-prefix") o.checkpoint_prefix = value(val);
     else if (key == "c" || key == "checkpoint-parameters") o.checkpoint_parameters = true;
     else if (key == "W" || key == "watch-period") o.watch_period = std::atol(value(val).c_str());
+    else if (key == "V" || key == "checkpoint-viterbi-per-examples") o.viterbi_per = std::atol(value(val).c_str());
+    else if (key == "Z" || key == "checkpoint-per-forest-counts") o.per_forest_counts_per = std::atol(value(val).c_str());
     else if (key == "X" || key == "report-counts-exceeding") {
       if (!carmel_host::parse_weight_token(value(val), o.report_counts)) throw std::runtime_error("bad weight after " + a);
     } else if (key == "Y" || key == "report-probs-exceeding") {
@@ -175,7 +180,10 @@ Opts parse_args(int argc, char** argv) {
     else throw std::runtime_error("unknown option " + a);
   }
   if (o.forests_file.empty()) throw std::runtime_error("no forests file (-f)");
-  if (o.checkpoint_prefix.empty()) o.checkpoint_parameters = false;  // forest-em-params.cpp:43-47
+  if (o.checkpoint_prefix.empty()) {  // forest-em-params.cpp:43-50
+    o.checkpoint_parameters = false;
+    o.viterbi_per = o.per_forest_counts_per = 0;
+  }
   return o;
 }
 
@@ -264,6 +272,43 @@ int main(int argc, char** argv) {
                                     group_rule.data()),
           "carmel_hip_forests_create");
     const int style = o.human_probs ? W_NEVER_LOG : W_SOMETIMES_LOG;
+    // write_viterbi (forest.hpp:581-632) for every `every`-th forest (1-based count, as forest_no % period == 0): best/sum=percent% tree
+    auto viterbi_text = [&](const std::vector<double>& sum, uint64_t every) {
+      const uint64_t nf = fs.n_forests();
+      std::vector<double> best(nf);
+      check(carmel_hip_forests_viterbi(F, best.data()), "carmel_hip_forests_viterbi");
+      const uint32_t cap = std::max<uint32_t>(1, carmel_hip_forests_max_sample(F));
+      std::vector<uint32_t> rules(cap), arity(cap);
+      std::string out;
+      for (uint64_t f = 0; f < nf; ++f) {
+        if ((f + 1) % every) continue;
+        uint32_t n = 0;
+        check(carmel_hip_forests_get_viterbi(F, f, rules.data(), arity.data(), &n), "carmel_hip_forests_get_viterbi");
+        char pct[64];
+        std::snprintf(pct, sizeof pct, "%g", 100 * std::exp(best[f] - sum[f]));
+        out += format_weight(best[f], style) + "/" + format_weight(sum[f], style) + "=" + pct + "% ";
+        uint32_t k = 0;
+        std::function<void()> tree = [&]() {
+          if (k >= n) return;
+          const uint32_t r = rules[k], a = arity[k];
+          ++k;
+          if (!a) {
+            out += std::to_string(r);
+            return;
+          }
+          out += "(" + std::to_string(r);
+          for (uint32_t c = 0; c < a; ++c) {
+            out += " ";
+            tree();
+          }
+          out += ")";
+        };
+        tree();
+        out += "\n";
+      }
+      return out;
+    };
+
     if (o.crp > 0) {
       carmel_hip_gibbs_opts go;
       std::memset(&go, 0, sizeof go);
@@ -344,7 +389,22 @@ int main(int argc, char** argv) {
       for (long it = 1; it <= o.max_iter; ++it) {
         double alp = 0;
         uint64_t n_zero = 0;
-        check(carmel_hip_forests_estimate(F, o.prior_counts, &alp, &n_zero, nullptr), "carmel_hip_forests_estimate");
+        // watch_guard (forest-em.hpp:428-441): on a watch iteration the E-step also writes the Viterbi derivation of every -V-th
+        // forest and the (empty: forest-em.hpp:383-389) per-forest counts of every -Z-th, under the parameters it runs with
+        const bool watch_it = m_steps <= o.watch_period || (o.watch_period && m_steps % o.watch_period == 0);
+        const bool ck_vit = watch_it && o.viterbi_per > 0, ck_pfc = watch_it && o.per_forest_counts_per > 0;
+        std::vector<double> fsum(ck_vit ? fs.n_forests() : 0);
+        check(carmel_hip_forests_estimate(F, o.prior_counts, &alp, &n_zero, ck_vit ? fsum.data() : nullptr), "carmel_hip_forests_estimate");
+        if (ck_vit || ck_pfc) {
+          const std::string suffix = ".restart." + std::to_string(restart + 1) + ".iteration." + std::to_string(m_steps + 1);
+          if (ck_vit) spit(o.checkpoint_prefix + ".viterbi" + suffix, viterbi_text(fsum, (uint64_t)o.viterbi_per));
+          if (ck_pfc) {
+            std::string t2;
+            for (uint64_t f = 0; f < fs.n_forests(); ++f)
+              if ((f + 1) % (uint64_t)o.per_forest_counts_per == 0) t2 += "()\n";
+            spit(o.checkpoint_prefix + ".per_forest_counts" + suffix, t2);
+          }
+        }
         log << "i=" << it << " average log-prob=" << alp << " (2^" << alp / std::log(2.0) << " per forest";
         if (n_zero) log << ", " << n_zero << " forests with zero probability ignored";
         log << ")";
@@ -450,40 +510,7 @@ int main(int argc, char** argv) {
       const uint64_t nf = fs.n_forests();
       std::vector<double> sum(nf);
       check(carmel_hip_forests_estimate(F, o.prior_counts, nullptr, nullptr, sum.data()), "carmel_hip_forests_estimate");
-      if (o.outviterbi_file != "-0") {
-        std::vector<double> best(nf);
-        check(carmel_hip_forests_viterbi(F, best.data()), "carmel_hip_forests_viterbi");
-        const uint32_t cap = std::max<uint32_t>(1, carmel_hip_forests_max_sample(F));
-        std::vector<uint32_t> rules(cap), arity(cap);
-        std::string out;
-        for (uint64_t f = 0; f < nf; ++f) {
-          uint32_t n = 0;
-          check(carmel_hip_forests_get_viterbi(F, f, rules.data(), arity.data(), &n), "carmel_hip_forests_get_viterbi");
-          // write_viterbi (forest.hpp:581-585): best/sum=percent% then the tree (write_viterbi_rec :590-632)
-          char pct[64];
-          std::snprintf(pct, sizeof pct, "%g", 100 * std::exp(best[f] - sum[f]));
-          out += format_weight(best[f], style) + "/" + format_weight(sum[f], style) + "=" + pct + "% ";
-          uint32_t k = 0;
-          std::function<void()> tree = [&]() {
-            if (k >= n) return;
-            const uint32_t r = rules[k], a = arity[k];
-            ++k;
-            if (!a) {
-              out += std::to_string(r);
-              return;
-            }
-            out += "(" + std::to_string(r);
-            for (uint32_t c = 0; c < a; ++c) {
-              out += " ";
-              tree();
-            }
-            out += ")";
-          };
-          tree();
-          out += "\n";
-        }
-        spit(o.outviterbi_file, out);
-      }
+      if (o.outviterbi_file != "-0") spit(o.outviterbi_file, viterbi_text(sum, 1));
       if (o.out_pfc_file != "-0") {
         // FForests::operator()(rule, inside, norm_outside) (forest-em.hpp:383-389) adds a forest's counts to the global table
         // and leaves per_forest_counts -- its accumulate is commented out -- empty: the reference prints "()" per forest

@@ -137,6 +137,24 @@ def test_forest_em_cli_checkpoints_on_watch_iterations(oracle, golden_dir, tmp_p
                 k += 1
         of.randomize([1.0 - lib.carmel_hip_gibbs_uniform(5, restart, r, 0) for r in range(of.n_rules)])
     assert k == len(reports) and err.count("Writing trained parameters to " + pre) == k
+    # -V 2 / -Z 3: on the same iterations the Viterbi derivation of every second forest (the lines -v writes for those forests under
+    # the parameters of that E-step) and the empty per-forest counts of every third
+    rc, so, err = run(["-f", f, "-n", n, "-i", "3", "-e", "-1", "-d", "-1", "-x", pre + "v", "-V", "2", "-Z", "3", "-W", "1"])
+    assert rc == 0, err
+    of = oracle.OracleForests(open(f).read(), open(n).read())
+    of.init_rule_weights()
+    for m in range(3):
+        vit = open("%sv.viterbi.restart.1.iteration.%d" % (pre, m + 1)).read().split("\n")[:-1]
+        assert len(vit) == of.n_forests // 2
+        num = re.compile(r"^(\S+)/(\S+)=(\S+)% (.*)$")
+        for k, line in enumerate(vit):
+            a, b = num.match(line).groups(), num.match(of.viterbi_line(2 * k + 1)[0].rstrip("\n")).groups()
+            assert a[3] == b[3]  # the tree
+            for u, v in zip(a[:3], b[:3]):
+                assert parse_vec(u)[0] == pytest.approx(parse_vec(v)[0], rel=1e-9)
+        assert open("%sv.per_forest_counts.restart.1.iteration.%d" % (pre, m + 1)).read() == "()\n" * (of.n_forests // 3)
+        of.estimate()
+        of.maximize()
     # without a prefix -c writes nothing (forest-em-params.cpp:43-47)
     rc, so, err = run(["-f", f, "-n", n, "-i", "3", "-c"])
     assert rc == 0 and "Writing trained parameters" not in err
