@@ -208,7 +208,8 @@ static Options parse_args(int argc, char** argv) {
         o.width = std::atol(v.c_str());
         if (o.width < 4) o.width = 20;  // gibbs_opts.hpp:255
       }
-      else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob") {
+      else if (k == "sample-prob" || k == "no-prob" || k == "cache-prob" || k == "cheap-prob" || k == "progress-every") {
+        // (--progress-every: the dots gibbs.hpp:845-848 writes into the log while a sweep runs; a sweep is one launch here)
         // inert in carmel itself: gibbs_opts::cache_prob is true and never cleared (carmel.cc:296-298, gibbs_opts.hpp:240,
         // 255-258), so the cache-model probability is what is logged whatever these say
       }
