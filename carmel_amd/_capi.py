@@ -186,7 +186,7 @@ def _load():
     lib.carmel_hip_gibbs_get_sample.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_gibbs_set_observer.argtypes = [vp, C.c_uint32, GIBBS_OBSERVER_FN, vp]
     lib.carmel_hip_gibbs_current_probs.argtypes = [vp, vp]
-    lib.carmel_hip_gibbs_get_state.argtypes = [vp, vp, vp, vp, vp]
+    lib.carmel_hip_gibbs_get_state.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.carmel_hip_gibbs_final_counts.argtypes = [vp, vp]
     lib.carmel_hip_gibbs_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.carmel_hip_gibbs_uniform.restype = C.c_double

@@ -670,6 +670,7 @@ struct carmel_hip_gibbs {
       new_len, new_ids;
   DevBuf<uint64_t> chain_off, sample_off;
   DevBuf<double> alpha, ewt, init_logw;
+  DevBuf<double> p_touch;  // (see carmel_hip_gibbs_run: the "last@t" of the count table)
   DevBuf<double> pair_logw, p_prior, p_x, p_s, p_tmax, normsum, prior_norm, ccount, csum, snap_x, snap_norm, gw, beta,
       iter_out;
   std::vector<uint64_t> h_sample_off;
@@ -1359,6 +1360,16 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   HIPCHK(hipMemcpyAsync(g->p_x.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(g->p_s.p, 0, np * sizeof(double), s));
   HIPCHK(hipMemsetAsync(g->p_tmax.p, 0, np * sizeof(double), s));
+  // an observer may ask for the tables (--print-counts-*): the time of the last sweep that changed a count, as the reference's
+  // delta_sum keeps it, is tracked beside the sums (GxArgs::p_touch; the one-wavefront chain)
+  if (g->obs_fn && g->opt.mode == 0 && wave_run) {
+    if (g->p_touch.n != np) HIPCHK(g->p_touch.alloc(np));
+    HIPCHK(hipMemsetAsync(g->p_touch.p, 0, np * sizeof(double), s));
+    GX.p_touch = g->p_touch.p;
+  } else {
+    g->p_touch.release();
+    GX.p_touch = nullptr;
+  }
   HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
   HIPCHK(hipMemsetAsync(g->sample_len.p, 0, g->sample_len.bytes(), s));
   G.sample_ids = g->sample_ids.p;
@@ -1383,6 +1394,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       HIPCHK(launch_forest_fold(g->p_s.p, g->p_tmax.p, g->p_x.p, G.time, np, s));
       GX.iter = G.iter;
       GX.init_logw = G.init_logw;
+      GX.time = G.time;
       HIPCHK(launch_gibbs_exact_wave(GX, 0, s));
     } else if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1622,7 +1634,7 @@ int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob) {
 
 // the sampler's counts as they stand (gibbs_param::sumcount, delta_sum.hpp: instantaneous count x, its time-weighted sum s, the
 // time tmax it is summed up to) and the priors -- what --print-counts-* shows; inside an observer call, or after the run
-int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior) {
+int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior, double* last_touch) {
   if (!g) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(g->t->device));
   hipStream_t s = g->t->stream;
@@ -1631,6 +1643,8 @@ int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, doub
   if (sum) HIPCHK(hipMemcpyAsync(sum, g->p_s.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   if (tmax) HIPCHK(hipMemcpyAsync(tmax, g->p_tmax.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   if (prior) HIPCHK(hipMemcpyAsync(prior, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
+  // (where the chain does not track it -- the workgroup kernels, the parallel sweep --: the stamp of the sums, i.e. the sweep's time)
+  if (last_touch) HIPCHK(hipMemcpyAsync(last_touch, g->p_touch.n == np ? g->p_touch.p : g->p_tmax.p, np * sizeof(double), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   return CARMEL_HIP_OK;
 }

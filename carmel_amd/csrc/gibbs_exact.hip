@@ -100,12 +100,14 @@ __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, u
     if (lane + q * 64 < O.len && O.nr[q] != GX_NONE) {
       gx_add(A.p_x + O.id[q], -B.wt);
       gx_add(A.normsum + O.nr[q], -B.wt);
+      if (A.p_touch) A.p_touch[O.id[q]] = A.time;
     }
   for (uint32_t k = lane + GX_SQ * 64; k < O.len; k += 64) {
     const uint32_t n = A.old_nrm[B.sample_off + k];
     if (n == GX_NONE) continue;
     gx_add(A.p_x + A.old_ids[B.sample_off + k], -B.wt);
     gx_add(A.normsum + n, -B.wt);
+    if (A.p_touch) A.p_touch[A.old_ids[B.sample_off + k]] = A.time;
   }
 }
 
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
       if (n != GX_NONE) {
         gx_add(A.p_x + p, B.wt);
         gx_add(A.normsum + n, B.wt);
+        if (A.p_touch) A.p_touch[p] = A.time;
         cnum.mul(gx_add(A.ccount + p, 1.0));
         cden.mul(gx_add(A.csum + n, 1.0));
       } else

@@ -54,6 +54,11 @@ struct GxArgs {
   uint32_t n_chains, iter_stride;
   uint32_t init_chain;        // the chain init_logw is for (the very first sweep of run 0 only); 0xffffffff: none
   uint64_t ch_params, ch_norms, ch_sample;  // doubles per chain of p_x / ccount, of normsum / csum; ids per chain of the sample buffers
+  // --print-counts-*' "last@t" column (delta_sum::tmax as the reference keeps it: the time of the last sweep that changed the
+  // count -- the sums here are folded for every parameter at the start of a sweep, which moves their own stamp): when non-null,
+  // p_touch[p] = time wherever a count changes
+  double* p_touch;
+  double time;
 };
 
 size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_levels, uint32_t cap_sample);

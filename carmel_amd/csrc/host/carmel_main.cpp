@@ -1388,7 +1388,7 @@ static int run(int argc, char** argv) {
     // print_counts (gibbs.hpp:986-1064): x, s, tm = gibbs_param::sumcount; final: x holds the finalized counts, prob the weights
     auto print_counts = [&](bool final, const char* name, uint32_t iter, double time, const std::vector<double>& x,
                             const std::vector<double>& sacc, const std::vector<double>& tm, const std::vector<double>& prior,
-                            const std::vector<double>& prob) {
+                            const std::vector<double>& prob, const std::vector<double>& touch) {
       if (!want_counts) return;
       const double ta = time + 1;
       std::cout << "\n#id\tgroup\tcount\tprob";
@@ -1419,7 +1419,7 @@ static int run(int argc, char** argv) {
         field(prob[pp]);
         if (!final) {
           field(avg);
-          field(tx);
+          field(has ? touch[pp] : 0.0);  // delta_sum::tmax as the reference keeps it: the last sweep that changed the count
           field(prior[pp]);
           const uint32_t meta = ref_norm[pp] >= 0 ? ref_meta[(size_t)ref_norm[pp]] : 0u;
           std::cout << '\t';
@@ -1481,14 +1481,15 @@ static int run(int argc, char** argv) {
       } keep{cap, (world > 1 && run < periodic_text.size()) ? &periodic_text[run] : nullptr};
       (void)cout_buf;
       // the tables' state: counts as they stand, their time-weighted sums and stamps, the priors, the proposal probabilities
-      std::vector<double> sx, ss, st_, sp, spr;
+      std::vector<double> sx, ss, st_, sp, spr, stouch;
       if (want_counts || want_norms) {
         sx.resize(n_par);
         ss.resize(n_par);
         st_.resize(n_par);
         sp.resize(n_par);
         spr.resize(n_par);
-        hip_check(carmel_hip_gibbs_get_state(gs, sx.data(), ss.data(), st_.data(), sp.data()), "carmel_hip_gibbs_get_state");
+        stouch.resize(n_par);
+        hip_check(carmel_hip_gibbs_get_state(gs, sx.data(), ss.data(), st_.data(), sp.data(), stouch.data()), "carmel_hip_gibbs_get_state");
         hip_check(carmel_hip_gibbs_current_probs(gs, spr.data()), "carmel_hip_gibbs_current_probs");
         for (size_t pp = 0; pp < n_par; ++pp)  // final_prob (gibbs.hpp:144-151): 0 for a count of 0
           if (ref_norm[pp] >= 0 && !(sx[pp] > 0)) spr[pp] = 0;
@@ -1503,7 +1504,7 @@ static int run(int argc, char** argv) {
               for (uint32_t q : norm_members[(size_t)ref_norm[pp]]) ns += sp[q];
             pprob[pp] = ref_norm[pp] >= 0 ? (sp[pp] > 0 ? sp[pp] / ns : 0.0) : sp[pp];
           }
-          print_counts(true, "(prior counts)", 0, 0.0, sp, ss, st_, sp, pprob);
+          print_counts(true, "(prior counts)", 0, 0.0, sp, ss, st_, sp, pprob, stouch);
         }
       }
       std::cout << "# Gibbs i=" << iter << " ";
@@ -1517,7 +1518,7 @@ static int run(int argc, char** argv) {
         ~Tables() { f(); }
       } tables{[&]() {
         print_norms(iter, time, sx);
-        print_counts(false, "", iter, time, sx, ss, st_, sp, spr);
+        print_counts(false, "", iter, time, sx, ss, st_, sp, spr, stouch);
       }};
       if (!(o.print_to > o.print_from)) return;
       if (go.expectation) throw std::runtime_error("can't print sample when using expectation because there is no single sample.\n");
@@ -1716,7 +1717,7 @@ static int run(int argc, char** argv) {
       std::vector<double> fprob(n_par);
       for (size_t pp = 0; pp < n_par; ++pp) fprob[pp] = std::exp(pw[pp]);  // final_prob: the weights (a locked arc's: its own)
       print_norms(go.iter + 1, final_t, final_x);
-      print_counts(true, "", go.iter + 1, final_t, final_x, final_x, final_x, final_x, fprob);
+      print_counts(true, "", go.iter + 1, final_t, final_x, final_x, final_x, final_x, fprob, final_x);
     }
     const char* dir = std::getenv("CARMEL_TRAINED_DIR");
     for (size_t i = 0; i < nw; ++i) {  // cm.write_trained("trained") carmel.cc:1435-1437

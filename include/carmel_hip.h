@@ -398,7 +398,7 @@ int carmel_hip_gibbs_current_probs(carmel_hip_gibbs* g, double* prob);
  * its time-weighted sum, the time it is summed up to (gibbs_param::sumcount: delta_sum.hpp) and the prior pseudo-count; any
  * pointer may be NULL.  Inside an observer call or after the run.  _final_counts: the kept run's counts as
  * finalize_cumulative_counts left them (gibbs.hpp:626-638). */
-int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior);
+int carmel_hip_gibbs_get_state(carmel_hip_gibbs* g, double* x, double* sum, double* tmax, double* prior, double* last_touch);
 int carmel_hip_gibbs_final_counts(carmel_hip_gibbs* g, double* x);
 /* the current sample of one block: parameter ids in path order (sample[b].id, gibbs.hpp:285-338) */
 int carmel_hip_gibbs_get_sample(carmel_hip_gibbs* g, uint32_t block, uint32_t* ids, uint32_t* n);

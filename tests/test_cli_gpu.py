@@ -1032,28 +1032,15 @@ def _tables(ref, oc, sweep, time, final, name, width=7, rich=False, norm_order=F
     return "".join(out)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("extra,kw,normby", [([], {}, "CC"), (["--width=9", "--norm-order", "-j"], dict(width=9, norm_order=True), "JJ"),
-                                             (["--print-counts-sparse=0.25"], dict(sparse=0.25), "CC"),
-                                             (["--width=5", "--print-counts-rich", "-j"], dict(width=5, rich=True), "JJ")])
-def test_crp_count_and_norm_tables(golden_dir, tmp_path, oracle, extra, kw, normby):
-    """--print-counts-from/-to, --print-norms-from/-to (+ --width, --print-counts-sparse, --print-counts-rich, --norm-order;
-    gibbs_opts.hpp:64-77; gibbs.hpp:970-1078; carmel's row order and rich names gibbs.cc:42-64, 206-212): the sampler's tables --
-    the priors as counts at the start of a run, the counts / averages / priors and the norm sums after every --print-every-th
-    sweep, the kept run's averaged counts and probabilities at the end -- keyed by define_param's ids and the norm-group ids of
-    NormGroupIter's walk.  The reference holds no output of these switches: the expected text is restated here in Python
-    (print_width included) over the ORACLE's per-sweep state and must equal the front end's text over the device's, character
-    for character."""
+def _check_tables(oracle, tmp_path, files, corpus_text, extra, kw, normby, priors, seed, N=6, B=2, E=3):
+    """the front end's tables against the Python restatement over the oracle's state: see test_crp_count_and_norm_tables"""
     from carmel_amd._capi import lib
-    g = lambda n: os.path.join(golden_dir, n)
-    N, B, E = 6, 2, 3
-    # (-j: JOINT groups, states without arcs included; not --normby, which also normalises the inputs before they are composed)
-    base = ["--crp", "-M", str(N), "--burnin=%d" % B, "--priors=0.5,0.1", "-R", "7", g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")]
+    base = ["--crp", "-M", str(N), "--burnin=%d" % B, "--priors=%s" % ",".join("%.17g" % p for p in priors), "-R", str(seed)] + files
     env = {"CARMEL_TRAINED_DIR": str(tmp_path)}
-    oc = oracle.OracleCascade([open(g("cipher.wfsa")).read(), open(g("cipher.fst")).read()])
-    ref = oracle.gibbs_run(oc, oc.corpus(open(g("cipher.data")).read()), lambda i, b, s: lib.carmel_hip_gibbs_uniform(7, i, b, s),
-                           normby=normby, priors=[0.5, 0.1], iters=N, burnin=B, state_trace=True)
-    ref["n_norms"] = oracle.fem_export(oc, oc.corpus(open(g("cipher.data")).read()), 1, normby=normby, priors=[0.5, 0.1]).count("(") - 1
+    oc = oracle.OracleCascade([open(f).read() for f in files[1:]])
+    ref = oracle.gibbs_run(oc, oc.corpus(corpus_text), lambda i, b, s: lib.carmel_hip_gibbs_uniform(seed, i, b, s),
+                           normby=normby, priors=priors, iters=N, burnin=B, state_trace=True)
+    ref["n_norms"] = oracle.fem_export(oc, oc.corpus(corpus_text), 1, normby=normby, priors=priors).count("(") - 1
     rc, out, err = run(["--print-every=%d" % E, "--print-counts-to=4294967295", "--print-norms-to=4294967295"] + extra + base, env=env)
     assert rc == 0, err
     sparse = kw.get("sparse", 0.0)
@@ -1075,10 +1062,30 @@ def test_crp_count_and_norm_tables(golden_dir, tmp_path, oracle, extra, kw, norm
     want += "\n# final best gibbs run (start #0 t=%s):\n" % ("%g" % (N - B)) + _tables(ref, oc, None, float(N - B), True, "", iters=N, **kw)
     if kw.get("rich"):  # "<member>(<source> -> <destination> <input> : <output>)" (gibbs.cc:206-212, fst.h:523-529): keep the member
         out, n_rich = re.subn(r"(?m)^(\d+\t(?:\d+|LOCKED)\t.*\t)(\d)\(\S+ -> \S+ \S+ : \S+\)$", r"\1@\2", out)
-        assert n_rich > 100
+        assert n_rich > 10
     got_l, want_l = out.split("\n"), want.split("\n")
     bad = [(k, a, b) for k, (a, b) in enumerate(zip(got_l, want_l)) if a != b][:6]  # (no 20 000-line diff on a failure)
     assert not bad and len(got_l) == len(want_l), (bad, len(got_l), len(want_l))
+    return base, env
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra,kw,normby", [([], {}, "CC"), (["--width=9", "--norm-order", "-j"], dict(width=9, norm_order=True), "JJ"),
+                                             (["--print-counts-sparse=0.25"], dict(sparse=0.25), "CC"),
+                                             (["--width=5", "--print-counts-rich", "-j"], dict(width=5, rich=True), "JJ")])
+def test_crp_count_and_norm_tables(golden_dir, tmp_path, oracle, extra, kw, normby):
+    """--print-counts-from/-to, --print-norms-from/-to (+ --width, --print-counts-sparse, --print-counts-rich, --norm-order;
+    gibbs_opts.hpp:64-77; gibbs.hpp:970-1078; carmel's row order and rich names gibbs.cc:42-64, 206-212): the sampler's tables --
+    the priors as counts at the start of a run, the counts / averages / priors and the norm sums after every --print-every-th
+    sweep, the kept run's averaged counts and probabilities at the end -- keyed by define_param's ids and the norm-group ids of
+    NormGroupIter's walk.  The reference holds no output of these switches: the expected text is restated here in Python
+    (print_width included) over the ORACLE's per-sweep state and must equal the front end's text over the device's, character
+    for character.  (-j: JOINT groups, states without arcs included; not --normby, which also normalises the inputs before they
+    are composed.)"""
+    g = lambda n: os.path.join(golden_dir, n)
+    base, env = _check_tables(oracle, tmp_path, [g("cipher.data"), g("cipher.wfsa"), g("cipher.fst")], open(g("cipher.data")).read(), extra, kw,
+                              normby, [0.5, 0.1], 7)
+    E = 3
     # id ranges: parameters [3, 8) and norm groups [1, 3) only
     rc, out2, err = run(["--print-every=%d" % E, "--print-counts-from=3", "--print-counts-to=8", "--print-norms-from=1", "--print-norms-to=3"] + base,
                         env=env)
@@ -1086,3 +1093,21 @@ def test_crp_count_and_norm_tables(golden_dir, tmp_path, oracle, extra, kw, norm
     rows = [l for l in out2.split("\n") if re.match(r"^\d+\t", l)]
     assert rows and all(3 <= int(l.split("\t")[0]) < 8 for l in rows)
     assert all(blk.count("\n ") == 2 for blk in re.findall(r"normalization group sums[^\n]*\n\((.*?)\)\n", out2, re.S))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_crp_tables_on_random_cascades(tmp_path, oracle, seed):
+    """... on random two-member cascades (locked arcs, epsilons on every tape, states without arcs, pairs without derivations):
+    the ids follow define_param through the reference's hash-table walk whatever the symbols are"""
+    from test_gibbs_gpu import _random_cascade_case
+    a, b, corpus_text, _, priors = _random_cascade_case(oracle, 40 + seed)
+    pa, pb, pc = (str(tmp_path / n) for n in ("a.fst", "b.fst", "corpus"))
+    open(pa, "w").write(a)
+    open(pb, "w").write(b)
+    open(pc, "w").write(corpus_text)
+    joint = seed % 2 == 1
+    kw = [dict(), dict(width=9, norm_order=True), dict(rich=True, width=6)][seed % 3]
+    extra = (["-j"] if joint else []) + (["--width=%d" % kw["width"]] if "width" in kw else []) + (["--norm-order"] if kw.get("norm_order") else []) + \
+        (["--print-counts-rich"] if kw.get("rich") else [])
+    _check_tables(oracle, tmp_path, [pc, pa, pb], corpus_text, extra, kw, "JJ" if joint else "CC", priors, 11 + seed, N=4, B=1, E=2)

@@ -229,7 +229,22 @@ def main():
         hyb = L._build(w, c, False, device_tables=True)
         L._same(host, hyb, atomics=True)
 
+    def tables_case(d, s):
+        """carmel --print-counts-* / --print-norms-* on random cascades: the front end's tables (device state, define_param's ids
+        through the hash-table walk) against the Python restatement over the oracle's per-sweep state, character for character"""
+        a, b, corpus_text, _, priors = G._random_cascade_case(oracle, s)
+        pa, pb, pc = (str(d / n) for n in ("a.fst", "b.fst", "corpus"))
+        open(pa, "w").write(a)
+        open(pb, "w").write(b)
+        open(pc, "w").write(corpus_text)
+        joint = s % 2 == 1
+        kw = [dict(), dict(width=9, norm_order=True), dict(rich=True, width=6), dict(sparse=0.1 * (1 + s % 4)), dict(width=4 + s % 12)][s % 5]
+        extra = (["-j"] if joint else []) + (["--width=%d" % kw["width"]] if "width" in kw else []) + (["--norm-order"] if kw.get("norm_order") else []) + \
+            (["--print-counts-rich"] if kw.get("rich") else []) + (["--print-counts-sparse=%.17g" % kw["sparse"]] if "sparse" in kw else [])
+        C._check_tables(oracle, d, [pc, pa, pb], corpus_text, extra, kw, "JJ" if joint else "CC", priors, 1 + s, N=3 + s % 4, B=s % 3, E=1 + s % 3)
+
     cases += [
+        ("crp tables", tables_case),
         ("forest crp chains", forest_chains_case),
         ("host layout tables", host_layout_case),
         ("fused lanes", fused_lane_case),
