@@ -245,8 +245,22 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             ok = int(flag[0])
         if ok == 1 and not loopback:  # every rank joined: plan, and one exchange end to end before anything is timed
+            form = {"sharded": "auto"}.get(args.exchange, args.exchange)
+            if form == "auto" and world > 1:
+                # the direct form rests on the transport's point-to-point groups: one such group between all ranks, checked
+                # (carmel_hip_comm_selftest); a transport that fails it on any rank keeps the ring collectives
+                try:
+                    comm.selftest()
+                    p2p = 1
+                except Exception as e:  # noqa: BLE001
+                    p2p = 0
+                    sys.stderr.write("bench.py: rank %d: point-to-point self-test failed (%s)\n" % (rank, e))
+                flag = torch.tensor([p2p], dtype=torch.int32, device=ctl)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag[0]) == 0:
+                    form = "collectives"
             try:
-                xinfo = fb.exchange_plan(comm, args.exchange_chunks, form={"sharded": "auto"}.get(args.exchange, args.exchange))
+                xinfo = fb.exchange_plan(comm, args.exchange_chunks, form=form)
                 fb.estimate_async()
                 fb.allreduce_counts(comm)
             except Exception as e:  # noqa: BLE001

@@ -925,8 +925,21 @@ static int run(int argc, char** argv) {
   // (after --matrix-fb: the matrix E-step leaves no arc-range-ordered count pass to hang reduce-scatters on, so its exchange is
   // planned as the one all-reduce; csrc/exchange.cpp)
   // (streamed lattices: every shard has its own buckets, so the exchange stays the plain all-reduce of the summed buffer)
-  if (comm && !o.crp && stream_cut.size() <= 2)
-    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, o.exchange_form), "carmel_hip_exchange_plan");
+  if (comm && !o.crp && stream_cut.size() <= 2) {
+    // the direct form rests on the transport's point-to-point groups: one such group between all ranks, checked, before the plan
+    // is made (carmel_hip_comm_selftest); a transport that fails it on any rank keeps the ring collectives
+    int form = o.exchange_form;
+    if (form == 0 || form == 3) {
+      double bad[1] = {carmel_hip_comm_selftest(comm, 0) == CARMEL_HIP_OK ? 0.0 : 1.0};
+      hip_check(carmel_hip_comm_allreduce_host(comm, bad, 1, 1), "carmel_hip_comm_allreduce_host");
+      if (bad[0] != 0.0) {
+        if (form == 3) throw std::runtime_error("--exchange=direct: the transport's point-to-point self-test failed");
+        if (rank == 0) std::cerr << "carmel: the transport's point-to-point self-test failed; planning the exchange over the collectives\n";
+        form = 2;
+      }
+    }
+    hip_check(carmel_hip_exchange_plan(t, comm, (uint32_t)o.exchange_chunks, form), "carmel_hip_exchange_plan");
+  }
   if (o.flags[(unsigned)'?'] || o.flags[(unsigned)':']) log_lattice_stats(ls, pairs.size());
   CorpusStats cs;
   for (size_t p = 0; p < pairs.size(); ++p) {
