@@ -28,7 +28,7 @@ SYMBOLS = [
     "carmel_hip_gibbs_n_prior_scales", "carmel_hip_gibbs_set_run_share", "carmel_hip_gibbs_best_stats", "carmel_hip_forests_set_prior_inference", "carmel_hip_forests_prior_trace", "carmel_hip_gibbs_get_sample", "carmel_hip_gibbs_set_observer", "carmel_hip_gibbs_current_probs", "carmel_hip_gibbs_get_state", "carmel_hip_gibbs_final_counts", "carmel_hip_gibbs_uniform", "carmel_hip_gibbs_power", "carmel_hip_gibbs_best_run", "carmel_hip_gibbs_set_init_weights",
     "carmel_hip_forests_create", "carmel_hip_forests_destroy", "carmel_hip_forests_estimate",
     "carmel_hip_forests_get_counts", "carmel_hip_forests_maximize", "carmel_hip_forests_get_weights",
-    "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_best_run", "carmel_hip_forests_get_sample",
+    "carmel_hip_forests_set_weights", "carmel_hip_forests_set_alphas", "carmel_hip_forests_gibbs", "carmel_hip_forests_best_run", "carmel_hip_forests_final_counts", "carmel_hip_forests_get_sample",
     "carmel_hip_forests_max_sample", "carmel_hip_forests_viterbi", "carmel_hip_forests_get_viterbi",
     "carmel_hip_compose", "carmel_hip_composition_states", "carmel_hip_composition_arcs", "carmel_hip_composition_seconds",
     "carmel_hip_composition_export", "carmel_hip_composition_free",
@@ -203,6 +203,7 @@ def _load():
     lib.carmel_hip_forests_gibbs.argtypes = [vp, C.POINTER(GibbsOpts), C.c_double, vp, vp]
     lib.carmel_hip_forests_best_run.argtypes = [vp]
     lib.carmel_hip_forests_best_run.restype = C.c_uint32
+    lib.carmel_hip_forests_final_counts.argtypes = [vp, vp]
     lib.carmel_hip_forests_get_sample.argtypes = [vp, C.c_uint64, vp, C.POINTER(C.c_uint32)]
     lib.carmel_hip_forests_max_sample.argtypes = [vp]
     lib.carmel_hip_forests_max_sample.restype = C.c_uint32

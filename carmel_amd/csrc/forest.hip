@@ -1739,6 +1739,7 @@ static const size_t F_LDS_LIMIT = 150 * 1024;  // dynamic LDS a forest kernel ma
 
 struct carmel_hip_forests {
   uint32_t best_run = 0;  // --crp-restarts: the run that was kept (carmel_hip_forests_best_run)
+  std::vector<double> h_final_x;  // ... its counts as finalize_cumulative_counts left them (carmel_hip_forests_final_counts)
   // --prior-inference-* (gibbs_opts.hpp:82-89): carmel_hip_forests_set_prior_inference / _prior_trace
   double pi_stddev = 0;
   bool pi_global = false, pi_local = false;
@@ -2437,6 +2438,12 @@ int carmel_hip_forests_set_weights(carmel_hip_forests* F, const double* rule_log
 }
 
 uint32_t carmel_hip_forests_best_run(carmel_hip_forests* F) { return F ? F->best_run : 0; }
+int carmel_hip_forests_final_counts(carmel_hip_forests* F, double* x) {
+  if (!F || !x) return fail(CARMEL_HIP_ERR_ARG, "null argument");
+  if (F->h_final_x.size() != F->n_rules) return fail(CARMEL_HIP_ERR_STATE, "carmel_hip_forests_final_counts: run the sampler first");
+  std::memcpy(x, F->h_final_x.data(), F->h_final_x.size() * sizeof(double));
+  return CARMEL_HIP_OK;
+}
 int carmel_hip_forests_set_prior_inference(carmel_hip_forests* F, double stddev, int global, int local, uint32_t start,
                                            uint32_t end) {
   if (!F) return fail(CARMEL_HIP_ERR_ARG, "null handle");
@@ -2781,6 +2788,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         HIPCHK(hipMemcpyAsync(best_len.data(), mlen.p + (size_t)c * nf, nf * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         final_weights(x, sacc, tm, clw);
+        F->h_final_x = x;
         best_lw = clw;
         F->best_run = b0 + c;
         best_all = st_all[c];
@@ -3166,6 +3174,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     }
   }
   final_weights(x, sacc, tm, lw);
+  F->h_final_x = x;
   if (trace_buf.n) {
     std::vector<unsigned long long> h(trace_buf.n);
     HIPCHK(hipMemcpy(h.data(), trace_buf.p, trace_buf.bytes(), hipMemcpyDeviceToHost));

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <fstream>
 #include <functional>
+#include <iomanip>
 #include <iostream>
 #include <limits>
 #include <sstream>
@@ -40,6 +41,10 @@ struct Opts {
   std::string out_pfc_file = "-0";     // -E / --out-per-forest-counts-file
   std::string outviterbi_file = "-0";  // -v / --outviterbi-file
   long crp = 0, burnin = 0;
+  // the sampler's final tables (gibbs_opts.hpp:64-77; gibbs.hpp:970-1078 print_all at the end of run_gibbs, forest-em.hpp:719)
+  unsigned long print_counts_from = 0, print_counts_to = 0, print_norms_from = 0, print_norms_to = 0;
+  long width = 7;
+  std::string print_file;           // --print-file (gibbs_opts.hpp:102-103): where the tables go (default stdout)
   long crp_restarts = 0;            // --crp-restarts (gibbs_opts.hpp; gibbs_base::run_starts, gibbs.hpp:880-914)
   bool argmax_final = false, argmax_sum = false;  // --crp-argmax-final / --crp-argmax-sum (gibbs_opts.hpp:270-316)
   double high_temp = 1, low_temp = 1;  // --high-temp / --low-temp (gibbs_opts.hpp:50-53)
@@ -101,6 +106,44 @@ void check(int rc, const char* what) {
   if (rc != CARMEL_HIP_OK) throw std::runtime_error(std::string(what) + ": " + carmel_hip_last_error());
 }
 
+// print_width (graehl/shared/print_width.hpp:98-130): a number in at most `width` characters
+void print_width(std::ostream& os, double d, int width0) {
+  if (width0 >= 20 || d == 0. || width0 <= 0) {
+    os << d;
+    return;
+  }
+  const std::ios::fmtflags f = os.flags();
+  const std::streamsize pr = os.precision();
+  int width = width0;
+  double pa = d;
+  if (d < 0) {
+    pa = -d;
+    --width;
+  }
+  auto sig_for_exp = [](int w, int e) {
+    const int r = w - (e < 100 ? 2 : 3) - 3;
+    return r > 0 ? r : 0;
+  };
+  const double wholes = std::log10(pa * (1 + 1e-8));
+  if (wholes <= width && d == (double)(int)d)
+    os << d;
+  else if (pa < 1) {
+    const int a = (int)-wholes, need = 2 + a;
+    if (need >= width)
+      os << std::scientific << std::setprecision(sig_for_exp(width, a) - 1) << d;
+    else
+      os << std::setprecision(width - 2 - a) << d;
+  } else {
+    const int a = (int)wholes, need = 1 + a;
+    if (need > width)
+      os << std::scientific << std::setprecision(sig_for_exp(width, a) - 1) << d;
+    else
+      os << std::fixed << std::setprecision(need + 1 < width ? width - need - 1 : 0) << d;
+  }
+  os.flags(f);
+  os.precision(pr);
+}
+
 Opts parse_args(int argc, char** argv) {
   Opts o;
   for (int i = 1; i < argc; ++i) {
@@ -149,6 +192,15 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "alpha") o.alpha_file = value(val);
     else if (key == "burnin") o.burnin = std::atol(value(val).c_str());
     else if (key == "crp-restarts") o.crp_restarts = std::atol(value(val).c_str());
+    else if (key == "print-counts-from") o.print_counts_from = std::strtoul(value(val).c_str(), 0, 10);
+    else if (key == "print-counts-to") o.print_counts_to = std::strtoul(value(val).c_str(), 0, 10);
+    else if (key == "print-norms-from") o.print_norms_from = std::strtoul(value(val).c_str(), 0, 10);
+    else if (key == "print-norms-to") o.print_norms_to = std::strtoul(value(val).c_str(), 0, 10);
+    else if (key == "print-file") o.print_file = value(val);
+    else if (key == "width") {
+      o.width = std::atol(value(val).c_str());
+      if (o.width < 4) o.width = 20;  // gibbs_opts.hpp:255
+    }
     else if (key == "crp-argmax-final") o.argmax_final = true;
     else if (key == "crp-argmax-sum") o.argmax_sum = true;
     else if (key == "high-temp") o.high_temp = std::atof(value(val).c_str());
@@ -324,10 +376,11 @@ int main(int argc, char** argv) {
       go.restarts = (uint32_t)std::max(0L, o.crp_restarts);
       go.argmax_final = o.argmax_final;
       go.argmax_sum = o.argmax_sum;
+      std::vector<double> alphas_file;
       if (o.alpha_file != "-0") {
         // "(a1 a2 ...)" indexed by rule id like forest-em.hpp:689-692 (alphas[i] for parameter i; entry 0 is the unused rule 0)
         const std::string txt = slurp(o.alpha_file);
-        std::vector<double> al;
+        std::vector<double>& al = alphas_file;
         for (size_t p = 0; p < txt.size();) {
           if (std::isdigit((unsigned char)txt[p]) || txt[p] == '-' || txt[p] == '.' || txt[p] == '+') {
             char* e = nullptr;
@@ -360,6 +413,62 @@ int main(int argc, char** argv) {
         log << "sample log-prob=" << lp[i] << " (2^" << lp[i] / std::log(2.0) << ")\n";
       }
       if (go.restarts) log << "\nKept run " << carmel_hip_forests_best_run(F) << " of " << go.restarts << " (gibbs_stats::better)\n";
+      // gibbs_base::print_all (gibbs.hpp:1066-1078) at the end of FForests::run_gibbs (forest-em.hpp:719): the kept run's norm sums
+      // and averaged counts.  Parameters are rule ids (define_param_id, forest-em.hpp:695-709), norm ids the groups' numbers from ONE
+      // (visit_norm_param), a locked rule (negative --alpha entry) or one outside every group has none; the numbers through print_width.
+      if (o.print_counts_to > o.print_counts_from || o.print_norms_to > o.print_norms_from) {
+        std::ostringstream tab;
+        std::vector<double> fx(n_rules), fw(n_rules);
+        check(carmel_hip_forests_final_counts(F, fx.data()), "carmel_hip_forests_final_counts");
+        check(carmel_hip_forests_get_weights(F, fw.data()), "carmel_hip_forests_get_weights");
+        std::vector<int64_t> norm_of(n_rules, -1);
+        uint32_t nnorm = 0;
+        for (size_t g = 0; g + 1 < group_off.size(); ++g)
+          for (uint64_t j = group_off[g]; j < group_off[g + 1]; ++j) {
+            const uint32_t r = group_rule[j];
+            const double a = r < alphas_file.size() ? alphas_file[r] : o.alpha;
+            if (a < 0) continue;
+            norm_of[r] = (int64_t)g + 1;
+            nnorm = std::max<uint32_t>(nnorm, (uint32_t)g + 2);
+          }
+        const uint32_t burn = go.final_counts ? go.iter : std::min(go.burnin, go.iter);
+        const double t_final = (double)go.iter - (double)burn, ta = t_final + 1;
+        tab << "\n# final best gibbs run (start #" << carmel_hip_forests_best_run(F) << " t=" << t_final << "):\n";
+        if (o.print_norms_to > o.print_norms_from) {
+          const unsigned long to = std::min<unsigned long>(o.print_norms_to, nnorm);
+          if (to > o.print_norms_from) {
+            std::vector<double> ns(nnorm, 0.0);
+            for (uint32_t r = 0; r < n_rules; ++r)
+              if (norm_of[r] >= 0) ns[(size_t)norm_of[r]] += fx[r];
+            tab << "\n# group\tnormalization group sums i=" << go.iter + 1 << " t=" << t_final << "\n(\n";
+            for (unsigned long n = o.print_norms_from; n < to; ++n) tab << ' ' << ns[n] << "\n";
+            tab << ")\n";
+          }
+        }
+        if (o.print_counts_to > o.print_counts_from) {
+          tab << "\n#id\tgroup\tcount\tprob\t\n";
+          const unsigned long to = std::min<unsigned long>(o.print_counts_to, n_rules);
+          for (unsigned long r = o.print_counts_from; r < to; ++r) {
+            const bool has = norm_of[r] >= 0;
+            const double avg = (has ? fx[r] : 0.0) / ta;
+            tab << r << '\t';
+            if (has)
+              tab << norm_of[r];
+            else
+              tab << "LOCKED";
+            tab << '\t';
+            print_width(tab, avg, (int)o.width);
+            tab << '\t';
+            print_width(tab, std::exp(fw[r]), (int)o.width);
+            tab << '\n';
+          }
+          tab << "\n";
+        }
+        if (o.print_file.empty() || o.print_file == "-")
+          std::cout << tab.str();
+        else
+          spit(o.print_file, tab.str());
+      }
       if (!o.outsample_file.empty()) {  // print_sample (forest-em.hpp:768-787): one line per forest, its rules in the order sampled
         std::ofstream of(o.outsample_file.c_str());
         std::vector<uint32_t> buf(std::max<uint32_t>(1, carmel_hip_forests_max_sample(F)));

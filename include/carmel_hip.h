@@ -449,6 +449,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* f, const carmel_hip_gibbs_opts*
  * the exact chain on the device only: mode 0, temperature 1, no locked parameter, no prior inference
  * (CARMEL_HIP_ERR_UNSUPPORTED otherwise).  carmel_hip_forests_best_run: which run (0-based) was kept. */
 uint32_t carmel_hip_forests_best_run(carmel_hip_forests* f);
+/* per rule id the kept run's count as finalize_cumulative_counts left it (gibbs.hpp:626-638): forest-em --print-counts-* */
+int carmel_hip_forests_final_counts(carmel_hip_forests* f, double* x /* n_rules */);
 /* Replaces: prior-scale inference in forest-em's sampler (forest-em.hpp:723-734 to_gibbs + gibbs.hpp:404-563; forest-em
  * --prior-inference-stddev / -global / -local / -start / -end): as carmel_hip_gibbs_set_prior_inference, with forest-em's
  * scale groups -- one per norm group, shifted by one as the reference registers them (the last norm group is never scaled,

@@ -522,8 +522,12 @@ class OracleForests(object):
         ptrace, cum = np.zeros((iters + 1, 6)), np.zeros(1 << 16)
         ncum = lib.orc_gibbs_last_prior_trace(_p(ptrace), iters + 1, _p(cum), len(cum))
         lib.orc_set_gibbs_prior_inference(C.c_double(0.0), 0, 0, 0, 0, 0, None, 0)
+        fin = np.zeros(2 * self.n_rules)
+        lib.orc_forests_gibbs_last_final.restype = C.c_uint64
+        lib.orc_forests_gibbs_last_final(_p(fin), C.c_uint64(len(fin)))
+        # final: per rule {count as finalize_cumulative_counts left it, norm group or -1} (what forest-em --print-counts-* shows)
         return dict(iter_logprob=ilp, iter_cheap_logprob=icl, samples=samples, prior_trace=ptrace,
-                    prior_cumulative=cum[:ncum])
+                    prior_cumulative=cum[:ncum], final=fin.reshape(self.n_rules, 2))
 
 
 CLI = os.path.join(_HERE, "oracle_carmel")

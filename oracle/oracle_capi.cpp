@@ -1178,6 +1178,12 @@ static int g_forest_exclude_prior = 0;  // --crp-exclude-prior for the next orc_
 void orc_forests_set_exclude_prior(int on) { g_forest_exclude_prior = on; }
 static std::vector<double> g_forest_alphas;  // --alpha=FILE for the next orc_forests_gibbs (empty: scalar alpha)
 void orc_forests_set_alphas(const double* a, uint32_t n) { g_forest_alphas.assign(a, a + (a ? n : 0)); }
+// forest-em --print-counts-* / --print-norms-* (gibbs.hpp:970-1078): per rule {finalized count, norm group or -1} of the last run
+static std::vector<double> g_forest_final;
+uint64_t orc_forests_gibbs_last_final(double* out, uint64_t n) {
+  for (uint64_t i = 0; i < n && i < g_forest_final.size(); ++i) out[i] = g_forest_final[i];
+  return g_forest_final.size();
+}
 int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int uniform_p0, int final_counts, double alpha,
                       orc_uniform_fn u, double* iter_logprob, double* iter_cheap_logprob, uint32_t* out_samples,
                       uint64_t* out_sample_off, uint64_t max_samples) {
@@ -1201,6 +1207,11 @@ int orc_forests_gibbs(orc_forests* h, uint32_t iter, uint32_t burnin, int unifor
     g.run([&](unsigned it, unsigned b, unsigned st) { return u(it, b, st); }, &tr);
     g_last_prior_trace = tr.prior_trace;
     g_last_cumulative = tr.cumulative;
+    g_forest_final.assign(2 * g.gps.size(), 0.0);
+    for (size_t r = 0; r < g.gps.size(); ++r) {
+      g_forest_final[2 * r] = g.gps[r].has_norm() ? g.gps[r].sum.x : 0.0;
+      g_forest_final[2 * r + 1] = g.gps[r].has_norm() ? (double)g.gps[r].norm : -1.0;
+    }
     for (uint32_t i = 0; i <= iter; ++i) {
       if (iter_logprob) iter_logprob[i] = tr.iter_logprob[i];
       if (iter_cheap_logprob) iter_cheap_logprob[i] = tr.iter_cheap_logprob[i];

@@ -339,3 +339,52 @@ def test_forest_em_cli_crp_restarts(oracle, tmp_path):
         assert "Kept run %d of %d" % (best[1], R) in err
         np.testing.assert_allclose(parse_vec((tmp_path / "o").read_text()), np.exp(best[3][1:]), rtol=1e-9, atol=1e-300)
         assert [[int(x) for x in l.split()] for l in (tmp_path / "s").read_text().split("\n")[:-1]] == best[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kw", [dict(), dict(width=9, burnin=3), dict(width=5, final_counts=True)])
+def test_forest_em_cli_final_tables(oracle, tmp_path, kw):
+    """forest-em --crp=N --print-counts-to=.. --print-norms-to=.. [--width=W] [--print-file=F] (gibbs_base::print_all at the end of
+    FForests::run_gibbs, forest-em.hpp:719; gibbs.hpp:970-1078): the kept run's norm sums and averaged counts, parameters = rule ids,
+    norm ids = the groups' numbers from ONE, a locked rule (negative --alpha entry) LOCKED.  The reference holds no output of
+    these switches: the text is restated in Python (test_cli_gpu._print_width) over the ORACLE's finalized counts"""
+    from carmel_amd._capi import lib
+    from test_cli_gpu import _print_width
+    from test_forest_gpu import synth_forests
+    ftxt, ntxt = synth_forests(50, 30, seed=6)
+    (tmp_path / "f").write_text(ftxt)
+    (tmp_path / "n").write_text(ntxt)
+    of = oracle.OracleForests(ftxt, ntxt)
+    of.init_rule_weights()
+    N, width, burnin = 8, kw.get("width", 7), kw.get("burnin", 0)
+    alphas = np.full(of.n_rules, 0.3)
+    alphas[3::7] = -1.0  # some locked rules
+    (tmp_path / "a").write_text("(" + " ".join("%.17g" % a for a in alphas) + ")\n")
+    args = ["-f", str(tmp_path / "f"), "-n", str(tmp_path / "n"), "--crp=%d" % N, "--burnin=%d" % burnin, "--alpha=" + str(tmp_path / "a"),
+            "--random-seed=5", "--print-counts-to=4294967295", "--print-norms-to=4294967295", "--print-file=" + str(tmp_path / "t")]
+    if "width" in kw:
+        args.append("--width=%d" % width)
+    if kw.get("final_counts"):
+        args.append("--final-counts")
+    rc, so, err = run(args)
+    assert rc == 0, err
+    ref = of.gibbs(lambda i, b, s: lib.carmel_hip_gibbs_uniform(5, i, b, s), N, burnin=burnin, alpha=0.3, alphas=alphas,
+                   final_counts=bool(kw.get("final_counts")))
+    x, norm = ref["final"][:, 0], ref["final"][:, 1].astype(int)
+    prob = np.exp(of.weights())
+    b = N if kw.get("final_counts") else min(burnin, N)
+    t = float(N - b)
+    nnorm = norm.max() + 2
+    ns = np.zeros(nnorm)
+    np.add.at(ns, norm[norm >= 0] + 1, x[norm >= 0])
+    want = "\n# final best gibbs run (start #0 t=%g):\n" % t
+    want += "\n# group\tnormalization group sums i=%d t=%g\n(\n" % (N + 1, t) + "".join(" %g\n" % v for v in ns) + ")\n"
+    want += "\n#id\tgroup\tcount\tprob\t\n"
+    for r in range(of.n_rules):
+        has = norm[r] >= 0
+        want += "%d\t%s\t%s\t%s\n" % (r, norm[r] + 1 if has else "LOCKED", _print_width((x[r] if has else 0.0) / (t + 1), width), _print_width(prob[r], width))
+    want += "\n"
+    got = (tmp_path / "t").read_text()
+    bad = [(k, a, c) for k, (a, c) in enumerate(zip(got.split("\n"), want.split("\n"))) if a != c][:5]
+    assert not bad and len(got) == len(want), bad
+    assert any("LOCKED" in l for l in got.split("\n")[10:])
