@@ -20,6 +20,7 @@ from carmel_amd.model import NORM_CONDITIONAL, NORM_JOINT, NORM_NONE, Corpus, Wf
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-7
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _fb(*a, **k):
@@ -703,3 +704,60 @@ def test_linear_count_floor_against_the_log_counts(oracle):
             assert got[1] == 0.0 and got[3] == 0.0  # below the floor: exactly zero, never a denormal or a NaN
             np.testing.assert_allclose(got[[0, 2]], np.exp(want_ln[[0, 2]]), rtol=1e-12)
         fb.close()
+
+
+@pytest.mark.parametrize("shape", ["tile-sweep", "lanes", "cascade"])
+def test_the_iteration_without_a_synchronisation_in_the_middle(oracle, shape):
+    """estimate_async -> maximize with nothing in between (the corpus scalars run on the side stream behind the count pass and are
+    joined lazily; the M-step's largest change comes back through the pinned mailbox): three iterations that way end in the
+    weights, largest changes and corpus probabilities of three iterations that read the scalars after every E-step -- and of
+    the same with the mailbox off (CARMEL_HIP_MAILBOX=0 in a child process: the switch is read once)"""
+    import subprocess
+    import sys
+    code = """
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import test_gpu_parity as P
+from carmel_amd import synth
+shape, mode = sys.argv[1], sys.argv[2]
+if shape == "tile-sweep":
+    w = synth.random_wfst(300, 4, n_sym=6, p_eps=0.0, seed=3)
+    c = synth.random_walk_corpus(w, 4000, min_arcs=3, max_arcs=20, seed=3, out_degree=4)
+    fb = P._fb(w, c)
+elif shape == "lanes":
+    w, c = P.ambiguous(7, n_states=60, deg=8, n_sym=3, n_pairs=1500, lo=4, hi=30)
+    fb = P._fb(w, c)
+else:
+    from oracle import binding as ob
+    from conftest import GOLDEN
+    oc, w, c = P._cascade_from_golden(ob, GOLDEN, ["cipher.wfsa", "cipher.fst"], "cipher.data")
+    fb = P._fb(w, c, cascade=oc.as_dict([P.NORM_CONDITIONAL, P.NORM_CONDITIONAL]))
+out = []
+for it in range(3):
+    fb.estimate_async()
+    if mode == "read":
+        out += list(fb.read_scalars())
+    out.append(fb.maximize(1.0))
+fb.estimate_async()
+out += list(fb.read_scalars())
+out += list(fb.weights())
+print(json.dumps([float(v) if np.isfinite(v) else str(v) for v in out]))
+""" % (ROOT_DIR, os.path.join(ROOT_DIR, "tests"))
+    runs = {}
+    for mode, env in (("lazy", {}), ("read", {}), ("lazy-nobox", {"CARMEL_HIP_MAILBOX": "0"})):
+        p = subprocess.run([sys.executable, "-c", code, shape, mode.split("-")[0]], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           universal_newlines=True, env=dict(os.environ, **env), timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[mode] = json.loads(p.stdout.strip().split("\n")[-1])
+    def same(a, b):  # (arcs whose items fill several buckets are summed with atomics: the last bit moves from run to run)
+        assert len(a) == len(b)
+        for u, v in zip(a, b):
+            assert u == v if isinstance(u, str) or isinstance(v, str) else u == pytest.approx(v, rel=1e-11, abs=1e-300)
+    n = len(runs["lazy"])
+    same(runs["lazy"], runs["lazy-nobox"])
+    # the reading run carries three more scalars per iteration: compare what both have
+    lazy, read = runs["lazy"], runs["read"]
+    same(lazy[:3], [read[3], read[7], read[11]])   # the largest changes
+    same(lazy[3:], read[12:])                      # the last scalars and the weights
+    assert len(read) == n + 9
