@@ -394,8 +394,11 @@ static int run(int argc, char** argv) {
   const bool with_pairs = training || scoring;
   if (o.flags[(unsigned)'h']) {
     std::cout << "carmel (MI355X training front end): -t / --train-cascade / --crp / -S over carmel's transducer and corpus "
-                 "files; switches: -t -M -e -X -f -U -u -j -n -o -! -a -S -q -d -K -m -T -F -R -H -J -Z -D -B -2 -+ -? -: -c; "
-                 "see INTEGRATION.md\n";
+                 "files; switches: -t -M -e -X -f -U -u -j -n -o -! -1 -a -S -q -d -K -m -T -F -R -H -J -Z -D -B -2 -+ -? -: -c; "
+                 "options: --train-cascade --normby= --priors= --digamma= --random-set --disk-cache-derivations= --matrix-fb; "
+                 "the sampler: --crp[=N] --burnin= --crp-restarts= --print-every= --print-from= --print-to= --print-counts-from= "
+                 "--print-counts-to= --print-norms-from= --print-norms-to= --width= ... ; several GPUs: --gpus=N --exchange=; "
+                 "the full list and what each replaces: INTEGRATION.md\n";
     return 0;
   }
   if (o.files.empty() || (with_pairs && o.files.size() < 2)) {
@@ -1277,7 +1280,7 @@ static int run(int argc, char** argv) {
     std::vector<double> lp((size_t)per_run * n_runs), lp_after(o.sample_prob_after ? lp.size() : 0);
     // --print-every=N (gibbs_opts.hpp:78-79; gibbs.hpp:959-968 maybe_print_periodic): after sweeps 0, N, 2N, ... a comment line
     // and, with --print-to, every block's sampled path -- the arcs carry the proposal probabilities of that moment
-    // (gibbs.cc:272-286).  The count / norm tables of --print-counts-* / --print-norms-* are not written.
+    // (gibbs.cc:272-286); the count / norm tables of --print-counts-* / --print-norms-* follow it (below).
     // With --gpus the runs are spread over the ranks (replicas): every rank keeps what its runs print, run by run, and rank 0
     // prints all of it in run order afterwards -- what one process running the runs one after the other prints.
     //
