@@ -104,6 +104,18 @@ def test_sharded_exchange_is_the_all_reduce_bit_for_bit(tmp_path, world):
     np.testing.assert_allclose(plain[nw:nw + 12], one[nw:nw + 12], rtol=1e-10)
 
 
+def test_direct_exchange_with_eight_ranks(tmp_path):
+    """the arithmetic of an 8-GPU node on one GPU: eight ranks over the test transport, the direct form at its default two chunks
+    and at three -- seven peers per group, pieces of an eighth of a chunk with their halos -- against the all-reduce, bit for bit"""
+    plain = _run(8, "synth-big", tmp_path, "p8", extra=["--rccl", _plugin("p8"), "--plan-allreduce", "--check-counts"])
+    assert plain[-1] == 0.0
+    for k, tag in ((0, "d"), (3, "k3")):
+        sh = _run(8, "synth-big", tmp_path, "s8" + tag, extra=["--rccl", _plugin("s8" + tag), "--plan=%d" % k if k else "--plan", "--check-counts",
+                                                                "--form=direct"])
+        assert sh[-1] == 1.0, "the exchange was not planned in its sharded form"
+        np.testing.assert_array_equal(sh[:-1], plain[:-1])
+
+
 def test_direct_exchange_through_a_small_transport_window(tmp_path, monkeypatch):
     """the test transport's point-to-point groups in many rounds (a slot of 4096 doubles: every piece travels in parts, the
     groups of three ranks take different numbers of rounds to drain) -- and the default form IS the direct one"""
