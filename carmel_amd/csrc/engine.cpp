@@ -274,6 +274,14 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   // the host builder lays the lattices out (one-per-wavefront lattices, bundles: the cases the device builder leaves to it);
   // sorting the posterior slots by arc and the transposition tables -- two thirds of its time on the `long` workload, all of it
   // counting sorts -- are the device's (lattice_gpu.hip gpu_tables_for_host_layout; CARMEL_HIP_DEVICE_TABLES=0: the host's, A/B)
+  // one-per-wavefront lattices over a WFST whose weights the chip's caches hold (64 MB of them: the last-level cache is 256 MB)
+  // gather them from the table (sweep_wave_kernel<.., GW>): no pass writes them out in lattice order -- a fifth of the E-step on
+  // the `long` workload.  CARMEL_HIP_WAVE_GATHER=0/1: never / whatever the table's size (A/B; the same sums in the same order)
+  {
+    const char* e = getenv("CARMEL_HIP_WAVE_GATHER");
+    const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    opt.wave_gather = want_t && (e ? atoi(e) != 0 : t->w.n_arcs * sizeof(double) <= (64ull << 20));
+  }
   opt.device_tables = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0) &&
                       !(getenv("CARMEL_HIP_DEVICE_TABLES") && atoi(getenv("CARMEL_HIP_DEVICE_TABLES")) == 0);
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
@@ -298,6 +306,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->wave_descs.upload(L.waves, s));
   HIPCHK(t->wave_fwd.upload(L.wave_fwd, s));
   HIPCHK(t->wave_bwd.upload(L.wave_bwd, s));
+  if (L.wave_gather && !L.waves.empty())
+    HIPCHK(t->wave_bwd_arc.upload(L.wave_bwd_arc, s));
+  else
+    t->wave_bwd_arc.release();
   HIPCHK(t->wave_level_off.upload(L.wave_level_off, s));
   HIPCHK(t->wave_frow.upload(L.wave_frow, s));
   HIPCHK(t->wave_brow.upload(L.wave_brow, s));
@@ -359,7 +371,8 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     t->post.release();
   else
     HIPCHK(t->post.alloc(L.n_post));
-  HIPCHK(t->wcache.alloc(t->lane_records));
+  // (gathered weights: the wave records have no place in wcache, and the weight passes stop at the lane records)
+  HIPCHK(t->wcache.alloc(t->wave_bwd_arc.n ? L.wave_slot_base : t->lane_records));
   if (!L.waves.empty() && !have_tables)
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "lattice set too large for the blocked transposition (2^32 items) with one-per-wavefront lattices");
   if (L.lane_spill_rows)
@@ -405,6 +418,10 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       std::vector<uint32_t>().swap(L.t_t_src);
     }
   }
+  // (their sweep takes its weights from the transposition's weight pass or from the table: the gather formulation of the A/B
+  // switch CARMEL_HIP_TRANSPOSE=0 has neither)
+  if (!L.waves.empty() && !t->use_transpose)
+    return fail(CARMEL_HIP_ERR_UNSUPPORTED, "one-per-wavefront lattices need the blocked transposition (CARMEL_HIP_TRANSPOSE=0 is for lane corpora)");
   HIPCHK(t->pair_logprob.alloc(t->corpus.n_pairs));
   {
     std::vector<double> pw(t->corpus.n_pairs);
@@ -430,7 +447,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
                     t->lane_pair.bytes() + t->lane_nstates.bytes() + t->lane_logw.bytes() + t->post.bytes() + t->wcache.bytes() +
                     t->arc_off.bytes() + t->slot_pos.bytes() + t->hot_chunks.bytes() + t->t_b_arc.bytes() + t->t_b_rank.bytes() +
                     t->t_t_pos.bytes() + t->t_b_src.bytes() + t->t_t_src.bytes() + t->t_x.bytes() + t->t_xc.bytes() +
-                    t->wave_descs.bytes() + t->wave_fwd.bytes() + t->wave_bwd.bytes() + t->wave_level_off.bytes() +
+                    t->wave_descs.bytes() + t->wave_fwd.bytes() + t->wave_bwd.bytes() + t->wave_bwd_arc.bytes() + t->wave_level_off.bytes() +
                     t->wave_frow.bytes() + t->wave_brow.bytes() + t->wave_spill.bytes();
   std::vector<uint64_t>().swap(L.arc_off);
   std::vector<uint64_t>().swap(L.slot_pos);
@@ -1074,6 +1091,12 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   WA.frow = t->wave_frow.p;
   WA.brow = t->wave_brow.p;
   WA.wcache = t->wcache.p + t->wave_slot_base;
+  if (t->wave_bwd_arc.n) {
+    WA.wcache = nullptr;
+    WA.logw = t->arc_logw.p;
+    WA.bwd_arc = t->wave_bwd_arc.p;
+    WA.n_arcs = (uint32_t)t->w.n_arcs;
+  }
   WA.post = t->post.p + t->wave_slot_base;
   WA.pair_logprob = t->pair_logprob.p;
   WA.spill = t->wave_spill.p;
@@ -1117,7 +1140,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   if (xp) {  // the weights arrive arc range by arc range (all-gather of the sharded M-step): exchange.cpp
     int rc = exchange_weights_in(t, xp, T);
     if (rc) return rc;
-  } else if (t->use_transpose)
+  } else if (t->use_transpose && t->wcache.n)  // (nothing but gathering sweeps: no weight goes through X)
     HIPCHK(launch_trans_w_bucket(T, s));
   if (bundles_beside) {  // (after the bucket pass: its workgroups need a CU's LDS nearly whole)
     HIPCHK(hipEventRecord(t->ev_b0, s));

@@ -327,7 +327,10 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 // RING (WaveDesc::ring): the values live in a ring of `ring` LDS slots (state s at s mod ring; no arc spans more states than
 // that), the forward values are parked in the lattice's stretch of A.spill and come back one level at a time (al[]) for the
 // posteriors.  Records and weights are requested TWO levels ahead of their use.
-template <bool RING>
+// GW (WaveArgs::bwd_arc): the weights come straight from the WFST's table -- a forward record's y is the arc id, the backward
+// records' arc ids lie beside them (bwd_arc, requested one level before the weight they lead to) -- and no pass lays them out in
+// lattice order first: for a table the chip's caches hold, the gathers cost less than writing and re-reading 8 B per lattice arc.
+template <bool RING, bool GW>
 __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WaveDesc d = A.descs[A.first + blockIdx.x];
@@ -343,7 +346,9 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   const uint32_t* __restrict__ brow = A.brow + d.level_base;
   const uint2* __restrict__ f = A.fwd + d.fwd_base + lane;
   const uint32_t* __restrict__ b = A.bwd + d.bwd_base + lane;
-  const double* __restrict__ wc = A.wcache + d.bwd_base;
+  const double* __restrict__ wc = GW ? A.logw : A.wcache + d.bwd_base;
+  const uint32_t* __restrict__ ba = GW ? A.bwd_arc + d.bwd_base + lane : nullptr;
+  const uint32_t amax = A.n_arcs - 1u;  // (a padding record's arc id is 0xffffffff)
   double* __restrict__ post = A.post + d.bwd_base + lane;
   const uint32_t S = d.n_states, NL = d.n_levels;
   if (RING) {
@@ -429,7 +434,9 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
     uint32_t r0 = brow[1], r1 = brow[2], r2 = NL > 2 ? brow[3] : r1;
     size_t p1 = (size_t)(r1 < rend ? r1 : r0) * 64;
     uint32_t x0 = b[(size_t)r0 * 64], x1 = b[p1];
-    double w0 = wc[(size_t)r0 * 64 + lane], w1 = wc[p1 + lane];
+#define WAVE_BW(p, g) (GW ? wc[min((g), amax)] : wc[(p) + lane])
+    uint32_t g2 = GW ? ba[(size_t)(r2 < rend ? r2 : r0) * 64] : 0u;
+    double w0 = WAVE_BW((size_t)r0 * 64, ba[(size_t)r0 * 64]), w1 = WAVE_BW(p1, ba[p1]);
     // RING: alpha of the level of this step (a0v) and of the next step (a1v), one state per lane (levels are at most a
     // wavefront wide)
     double a0v = NEG_INF, a1v = NEG_INF;
@@ -449,7 +456,8 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       const uint32_t r3 = (k + 3 <= NL) ? brow[k + 3] : rend;
       const size_t p2 = (size_t)(r2 < rend ? r2 : r0) * 64;
       const uint32_t x2 = b[p2];
-      const double w2 = wc[p2 + lane];
+      const uint32_t g3 = GW ? ba[(size_t)(r3 < rend ? r3 : r0) * 64] : 0u;
+      const double w2 = WAVE_BW(p2, g2);
       double a2v = NEG_INF;
       if (RING && l >= 2) {
         const uint32_t sc = lvl[l - 2], nc = lvl[l - 1] - sc;
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
         const uint32_t q = b[(size_t)r * 64];
         const bool v = (q & WAVE_VALID) != 0;
         const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = v ? wc[(size_t)r * 64 + lane] + val[(q & 0xffffu) & rm] : NEG_INF;
+        const double t = v ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;
         const double a = v ? (RING ? al[sr] : val[s0 + sr]) : NEG_INF;
         if (t > NEG_INF) lds_max_f64(&mx[sr], t);
         post[(size_t)r * 64] = K_EXP(a + t);
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint32_t q = b[(size_t)r * 64];
         const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = (q & WAVE_VALID) ? wc[(size_t)r * 64 + lane] + val[(q & 0xffffu) & rm] : NEG_INF;
+        const double t = (q & WAVE_VALID) ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;
         if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));
       }
       __syncthreads();
@@ -492,10 +500,12 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       x1 = x2;
       w1 = w2;
       a1v = a2v;
+      g2 = g3;
       r0 = r1;
       r1 = r2;
       r2 = r3;
     }
+#undef WAVE_BW
   }
 }
 
@@ -1504,21 +1514,30 @@ hipError_t launch_wave_sweep(const WaveArgs& A0, const LatticeSet::WaveClass& wc
   WaveArgs A = A0;
   A.first = wc.first;
   A.max_width = wc.max_width;
+  const bool gw = A.bwd_arc != nullptr;
+  if (gw && (!A.logw || !A.n_arcs)) return hipErrorInvalidValue;
   if (wc.ring) {
     if (!A.spill) return hipErrorInvalidValue;
     A.max_states = wc.ring;
     const size_t lds = ((size_t)wc.ring + 3 * (size_t)wc.max_width) * sizeof(double);
-    hipLaunchKernelGGL(sweep_wave_kernel<true>, dim3(wc.count), dim3(64), lds, stream, A);
+    if (gw)
+      hipLaunchKernelGGL((sweep_wave_kernel<true, true>), dim3(wc.count), dim3(64), lds, stream, A);
+    else
+      hipLaunchKernelGGL((sweep_wave_kernel<true, false>), dim3(wc.count), dim3(64), lds, stream, A);
     return hipGetLastError();
   }
   A.max_states = wc.max_states;
   const size_t lds = ((size_t)wc.max_states + 2 * (size_t)wc.max_width) * sizeof(double);
   static size_t lds_set = 0;
   if (lds > 64 * 1024 && lds > lds_set) {
-    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set = lds;
   }
-  hipLaunchKernelGGL(sweep_wave_kernel<false>, dim3(wc.count), dim3(64), lds, stream, A);
+  if (gw)
+    hipLaunchKernelGGL((sweep_wave_kernel<false, true>), dim3(wc.count), dim3(64), lds, stream, A);
+  else
+    hipLaunchKernelGGL((sweep_wave_kernel<false, false>), dim3(wc.count), dim3(64), lds, stream, A);
   return hipGetLastError();
 }
 

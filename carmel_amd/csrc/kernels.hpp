@@ -68,6 +68,9 @@ struct WaveArgs {
   const uint32_t* frow;
   const uint32_t* brow;
   const double* wcache;   // at the first wave slot: the weight of the arc at backward position k
+  const double* logw = nullptr;       // gathered weights (bwd_arc set): the WFST's table, a forward record's y = the arc id
+  const uint32_t* bwd_arc = nullptr;  // ... and the arc id of every backward record (0xffffffff: padding)
+  uint32_t n_arcs = 0;
   double* post;           // at the first wave slot: posteriors, same positions
   double* pair_logprob;
   double* spill;          // ring lattices: parked forward values (WaveDesc::spill_base)

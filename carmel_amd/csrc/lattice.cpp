@@ -951,6 +951,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       err = "wave lattice set too large";
       return false;
     }
+    out.wave_gather = opt.wave_gather;
     out.wave_fwd.assign(frows[nw] * 64, uint2_t{0, 0});
     out.wave_bwd.assign(brows[nw] * 64, 0u);
     out.wave_bwd_arc.assign(brows[nw] * 64, 0xffffffffu);
@@ -1037,7 +1038,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
               const uint32_t a0 = ioff[lo[l]], a1 = ioff[lo[l + 1]];
               for (uint32_t a = a0; a < a1; ++a) {
                 const auto& e = L.edges[ie[a]];
-                F[(size_t)row * 64 + (a - a0)] = uint2_t{newid[e.src] | ((newid[e.dst] - lo[l]) << 16) | WAVE_VALID, bpos[ie[a]]};
+                F[(size_t)row * 64 + (a - a0)] = uint2_t{newid[e.src] | ((newid[e.dst] - lo[l]) << 16) | WAVE_VALID, opt.wave_gather ? e.arc : bpos[ie[a]]};
               }
               row += (a1 - a0 + 63) / 64;
             }

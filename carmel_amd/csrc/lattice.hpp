@@ -221,6 +221,7 @@ struct LatticeSet {
   bool lane_tiles_aligned = false;  // the pieces' tile ranges are disjoint (required for launching the tile passes per piece)
   uint32_t tile = TRANS_TILE;       // positions per tile of the blocked transposition: TRANS_TILE, LANE_FUSED_TILE, or TILE_SWEEP_TILE when ...
   bool tile_sweep = false;          // ... no lane group straddles a tile and a tile's groups fit one workgroup's LDS (see TILE_SWEEP_TILE)
+  bool wave_gather = false;         // a wave lattice's forward records carry the WFST arc id in y (BuildOptions::wave_gather)
   bool tables_deferred = false;     // the host builder stopped after the layout: slots by arc and the transposition tables are
                                     // built on the device from the records (BuildOptions::device_tables)
   bool lane_fused = false;          // tile == LANE_FUSED_TILE and every lane group starts on a tile (see LANE_FUSED_TILE)
@@ -277,6 +278,8 @@ struct BuildOptions {
   double wave_lane_min_width = 16.0;    // ... for lattices a WINDOWED lane would take: this wide, and only when the corpus
   uint64_t wave_lane_threshold = 262144;  // has fewer lane-sized lattices than this (4 waves per SIMD of one-per-lane work)
   bool tile_sweep = true;          // lay a corpus of plain lane lattices out for the one-kernel tile sweep (LatticeSet::tile_sweep)
+  bool wave_gather = false;        // one-per-wavefront lattices: forward record y = the WFST arc id, not the arc's backward position
+                                   // (the sweep gathers its weights from the table; no weight is laid out in lattice order)
   bool device_tables = false;      // stop after the layout: the engine builds arc_off / slot_pos and the transposition tables on
                                    // the device (lattice_gpu.hip gpu_tables_for_host_layout) -- the same bytes, a fraction of the time
   bool lane_fused = true;          // lay a corpus of lane lattices the tile sweep does not take out for the fused backward pass

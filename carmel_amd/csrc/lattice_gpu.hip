@@ -1273,6 +1273,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   t->wave_descs.release();  // (a one-per-lane corpus has no one-per-wavefront lattices)
   t->wave_fwd.release();
   t->wave_bwd.release();
+  t->wave_bwd_arc.release();
   t->wave_level_off.release();
   t->wave_frow.release();
   t->wave_brow.release();
