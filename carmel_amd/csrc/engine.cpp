@@ -1129,7 +1129,14 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   bool tile_sweep_done = false;
   // the tile sweep clears, on its way in, the counts the count pass adds up with atomics (the arcs whose items lie in several
   // buckets): one launch less between the sweep and the count pass (the exchange clears its own, chunk by chunk)
-  TransArgs TZ = T;
+  // the tiles' weights straight from the table (t_t_arc, build_run_tables): the tile kernels read `x[t_src[i]]`, whatever the two are
+  const bool tile_gather = t->use_transpose && t->t_t_arc.n && !xp && !T.use_runs && !(T.scatter & 1u);
+  TransArgs TW = T;
+  if (tile_gather) {
+    TW.x = const_cast<double*>(T.logw);
+    TW.t_src = t->t_t_arc.p;
+  }
+  TransArgs TZ = TW;
   if (!xp) {
     TZ.zero_list = t->t_split_arcs.p;
     TZ.n_zero = (uint32_t)t->t_split_arcs.n;
@@ -1140,7 +1147,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   if (xp) {  // the weights arrive arc range by arc range (all-gather of the sharded M-step): exchange.cpp
     int rc = exchange_weights_in(t, xp, T);
     if (rc) return rc;
-  } else if (t->use_transpose && t->wcache.n)  // (nothing but gathering sweeps: no weight goes through X)
+  } else if (t->use_transpose && t->wcache.n && !tile_gather)  // (nothing but gathering sweeps / tiles: no weight goes through X)
     HIPCHK(launch_trans_w_bucket(T, s));
   if (bundles_beside) {  // (after the bucket pass: its workgroups need a CU's LDS nearly whole)
     HIPCHK(hipEventRecord(t->ev_b0, s));
@@ -1167,7 +1174,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     }
     for (size_t k = 0; k < np; ++k) {
       const auto& lc = t->lat.lane_classes[k];
-      HIPCHK(launch_trans_w_tiles(T, lc.tile_first, lc.tile_count, ps));
+      HIPCHK(launch_trans_w_tiles(TW, lc.tile_first, lc.tile_count, ps));
       HIPCHK(hipEventRecord(t->ev_piece[k], ps));
       HIPCHK(hipStreamWaitEvent(ss, t->ev_piece[k], 0));
       HIPCHK(launch_lane_sweep(LA, lc, ss, lane_fused));
@@ -1186,7 +1193,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
       hipStream_t cs = t->cstream[k % NS];
       if (!used[k % NS]) HIPCHK(hipStreamWaitEvent(cs, t->ev_w, 0));
       used[k % NS] = true;
-      HIPCHK(launch_trans_w_tiles(T, lc.tile_first, lc.tile_count, cs));
+      HIPCHK(launch_trans_w_tiles(TW, lc.tile_first, lc.tile_count, cs));
       HIPCHK(launch_lane_sweep(LA, lc, cs, lane_fused));
       if (!lane_fused) HIPCHK(launch_trans_c_tiles(T, lc.tile_first, lc.tile_count, cs));
       ++k;
@@ -1202,7 +1209,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
     tile_sweep_done = true;
   } else {
     if (tile_sweep) (void)hipGetLastError();
-    if (t->use_transpose) HIPCHK(launch_trans_w_tiles(T, 0, lane_tiles, s));
+    if (t->use_transpose) HIPCHK(launch_trans_w_tiles(TW, 0, lane_tiles, s));
     // the one-per-wavefront lattices: every class is one launch of single-wave workgroups with its own LDS size -- side by
     // side on the chunk streams (a class alone rarely fills the chip), the lane waves beside them on the main stream
     if (t->lat.wave_classes.size() > 1 || (!t->lat.wave_classes.empty() && !t->lat.lane_classes.empty())) {

@@ -148,6 +148,7 @@ struct carmel_hip_trainer {
   DevBuf<uint64_t> t_tile_base;
   DevBuf<uint16_t> t_b_arc, t_b_rank, t_t_pos, t_a_off;
   DevBuf<uint32_t> t_b_src, t_t_src, t_split_arcs;
+  DevBuf<uint32_t> t_t_arc;  // the WFST arc of every tile-major item: the tile passes fetch weights from the table (build_run_tables)
   DevBuf<double> t_x, t_xc;
   DevBuf<uint32_t> tr_off, tr_src, br_off, br_src;  // run-length form of t_t_src / t_b_src (TransArgs)
   DevBuf<uint16_t> tr_rel, br_rel;

@@ -818,8 +818,37 @@ int run_table(hipStream_t s, DevBuf<char>& tmp, const uint32_t* src, uint64_t n,
 }
 }  // namespace
 
-// after either builder: derive the run tables from t_t_src / t_b_src (which stay, for the A/B switch and the checksums)
+// the WFST arc of every item in tile-major order: item J of bucket B (bucket-major: where X holds its weight) belongs to arc
+// B.arc_lo + b_arc[J] and lies at tile-major index b_src[J]
+__global__ __launch_bounds__(1024) void tile_arc_kernel(const TransBucket* buckets, const uint16_t* b_arc, const uint32_t* b_src, uint32_t* t_arc) {
+  const TransBucket B = buckets[blockIdx.x];
+  for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) t_arc[b_src[B.item_base + j]] = B.arc_lo + b_arc[B.item_base + j];
+}
+static int build_run_tables_impl(carmel_hip_trainer* t);
+// after either builder: the run tables, or the tiles' arc ids
 int build_run_tables(carmel_hip_trainer* t) {
+  t->t_t_arc.release();
+  int rc = build_run_tables_impl(t);
+  if (rc) return rc;
+  // A WFST whose weights the last-level cache holds (128 MB of them in its 256 MB), whose arcs lie in many lattices each (four
+  // items an arc and more) and a transposition with per-item indices: the tile pass (or the tile sweep) can fetch a tile's
+  // weights from the table itself -- through t_t_arc, the arc of every tile-major item -- instead of from X, and the bucket pass
+  // that writes X (8 B per item written, 8 B read back from HBM where the table's lines come from the cache) has nothing left to
+  // do.  Measured (tools/r5_tile_gather.sh): c4a (16 items an arc) 4.27 -> 3.96 ms an iteration, amb 1.21 -> 1.06; config 2
+  // (0.56 items an arc: a line fetched per item for 8 bytes of it) 0.083 -> 0.087, hence the rule.
+  // CARMEL_HIP_TILE_GATHER=0 / 1: never / whatever the sizes (A/B: the same values at the same places).
+  if (!t->use_transpose || t->use_runs || !t->t_buckets.n || !t->t_t_src.n || !t->t_b_src.n || !t->t_b_arc.n) return CARMEL_HIP_OK;
+  const char* env = getenv("CARMEL_HIP_TILE_GATHER");
+  if (env ? atoi(env) == 0 : (t->w.n_arcs * sizeof(double) > (128ull << 20) || t->t_t_src.n < 4 * t->w.n_arcs)) return CARMEL_HIP_OK;
+  HIPCHK(t->t_t_arc.alloc(t->t_t_src.n));
+  hipLaunchKernelGGL(tile_arc_kernel, dim3((unsigned)t->t_buckets.n), dim3(1024), 0, t->stream, t->t_buckets.p, t->t_b_arc.p, t->t_b_src.p,
+                     t->t_t_arc.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(t->stream));
+  return CARMEL_HIP_OK;
+}
+// derive the run tables from t_t_src / t_b_src (which stay, for the A/B switch and the checksums)
+static int build_run_tables_impl(carmel_hip_trainer* t) {
   t->use_runs = false;
   if (!t->use_transpose || !t->t_buckets.n || !t->t_t_src.n) return CARMEL_HIP_OK;
   // On where the runs are long enough to pay and the corpus is large enough for its traffic to matter (config 4: twelve

@@ -72,3 +72,50 @@ def test_long_workload_slice_uses_the_wave_sweep(oracle, monkeypatch, ring):
     assert fb.lattice_stats.n_windowed_pairs == 0 and fb.lattice_stats.n_bundles == 40
     fb.close()
     _check(oracle, w, c, iters=2)
+
+
+@pytest.mark.parametrize("ring", ["1", "0"])
+@pytest.mark.parametrize("seed", [2, 3, 5])
+def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, seed, ring):
+    """the sweep's two sources of weights -- the WFST's table through the records' arc ids (tables the caches hold: the default
+    here) and wcache, written in lattice order by the transposition's weight pass (CARMEL_HIP_WAVE_GATHER=0; what a larger
+    table gets) -- are the same numbers in the same places of the same sums"""
+    from carmel_amd.trainer import HipForwardBackward
+    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
+    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", "12" if seed == 3 else "0")  # (seed 3: lane lattices beside the waves)
+    if seed == 5:
+        w = synth.clustered_wfst(12 * 4 + 1, 48, members=12, n_sym=6, n_in_sym=3, seed=21)  # levels of several rows
+        c = synth.clustered_walk_corpus(w, 60, 48, members=12, min_arcs=3, max_arcs=25, seed=21)
+    else:
+        w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
+        c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
+    runs = []
+    for g in ("1", "0"):
+        monkeypatch.setenv("CARMEL_HIP_WAVE_GATHER", g)
+        fb = HipForwardBackward(w, c)
+        assert fb.lattice_stats.n_bundles > 0  # (wave lattices are counted with the bundles)
+        out = []
+        for _ in range(3):
+            lp, wlp = fb.estimate(per_pair=True)
+            out.append((lp, wlp, fb.pair_logprob.copy(), fb.counts().copy()))
+            fb.maximize(1.0)
+        out.append(fb.weights().copy())
+        fb.close()
+        runs.append(out)
+    for a, b in zip(runs[0][:-1], runs[1][:-1]):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.array_equal(a[2], b[2])
+        # (an arc whose items lie in several buckets is summed with one atomic per bucket: the last bits may differ)
+        assert (a[3] != b[3]).sum() <= 16 and np.allclose(a[3], b[3], rtol=1e-13, atol=0)
+    np.testing.assert_allclose(runs[0][-1], runs[1][-1], rtol=1e-12, atol=0)
+
+
+def test_waves_refuse_the_gather_formulation(monkeypatch):
+    """CARMEL_HIP_TRANSPOSE=0 (the A/B switch of the lane corpora) has no weight pass: wave lattices say so instead of sweeping
+    over weights nobody wrote"""
+    from carmel_amd.trainer import HipForwardBackward
+    monkeypatch.setenv("CARMEL_HIP_TRANSPOSE", "0")
+    w, c = synth.make_config("long", n_pairs=8)
+    with pytest.raises(Exception, match="blocked transposition"):
+        HipForwardBackward(w, c)
