@@ -32,7 +32,7 @@ SYMBOLS = [
     "carmel_hip_forests_max_sample", "carmel_hip_forests_viterbi", "carmel_hip_forests_get_viterbi",
     "carmel_hip_compose", "carmel_hip_composition_states", "carmel_hip_composition_arcs", "carmel_hip_composition_seconds",
     "carmel_hip_composition_export", "carmel_hip_composition_free",
-    "carmel_hip_debug_lattice_fingerprint", "carmel_hip_lattice_layout", "carmel_hip_lattice_tile_sweep", "carmel_hip_lattice_fused_lanes", "carmel_hip_accumulate_counts",
+    "carmel_hip_debug_lattice_fingerprint", "carmel_hip_lattice_layout", "carmel_hip_lattice_tile_sweep", "carmel_hip_lattice_fused_lanes", "carmel_hip_lattice_weight_source", "carmel_hip_accumulate_counts",
     "carmel_hip_comm_unique_id", "carmel_hip_comm_create", "carmel_hip_comm_destroy", "carmel_hip_comm_rank",
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
     "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_comm_set_sendrecv", "carmel_hip_comm_selftest", "carmel_hip_exchange_plan",
@@ -179,6 +179,7 @@ def _load():
     lib.carmel_hip_lattice_layout.argtypes = [vp]
     lib.carmel_hip_lattice_tile_sweep.argtypes = [vp]
     lib.carmel_hip_lattice_fused_lanes.argtypes = [vp]
+    lib.carmel_hip_lattice_weight_source.argtypes = [vp]
     lib.carmel_hip_accumulate_counts.argtypes = [vp, C.c_int]
     lib.carmel_hip_forests_set_prior_inference.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_uint32, C.c_uint32]
     lib.carmel_hip_forests_prior_trace.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp]

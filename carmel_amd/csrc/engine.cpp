@@ -1354,6 +1354,10 @@ int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices || t->unrolled || !t->use_transpose || !t->lat.lane_fused) return 0;
   return (int)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
 }
+int carmel_hip_lattice_weight_source(carmel_hip_trainer* t) {
+  if (!t || !t->have_lattices || t->unrolled || !t->use_transpose) return 0;
+  return (t->t_t_arc.n ? 1 : 0) | (t->wave_bwd_arc.n ? 2 : 0);
+}
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;
   return t->unrolled ? (t->dense ? 2 : 1) : 0;

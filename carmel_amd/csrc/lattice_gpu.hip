@@ -845,6 +845,8 @@ int build_run_tables(carmel_hip_trainer* t) {
                      t->t_t_arc.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(t->stream));
+  if (getenv("CARMEL_TIMING"))
+    fprintf(stderr, "timing: tile weights from the table: %zu items over %llu arcs\n", t->t_t_arc.n, (unsigned long long)t->w.n_arcs);
   return CARMEL_HIP_OK;
 }
 // derive the run tables from t_t_src / t_b_src (which stay, for the A/B switch and the checksums)

@@ -98,6 +98,13 @@ int carmel_hip_lattice_tile_sweep(carmel_hip_trainer* t);
  * posterior array) -- the number of lane tiles; 0 otherwise.  CARMEL_HIP_LANE_FUSED=0 at build time keeps the 16384-position
  * tiles, CARMEL_HIP_LANE_FUSED_KERNEL=0 runs sweep -> post -> trans_c_tile on the fused layout (A/B switches: same counts). */
 int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t);
+/* where the E-step's sweeps get an arc's weight from (derivations.h:395-417 reads the arc's own weight through a pointer): bit 0
+ * = the tile passes fetch a tile's weights from the WFST's table through the arc id of every item (no bucket pass, no X:
+ * WFSTs of four and more items an arc whose table is at most 128 MB; CARMEL_HIP_TILE_GATHER=0/1), bit 1 = the
+ * one-per-wavefront sweeps gather theirs from the table through the records' arc ids (tables of at most 64 MB;
+ * CARMEL_HIP_WAVE_GATHER=0/1); 0: every weight goes through the blocked transposition.  A/B switches: the same values at
+ * the same places of the same sums. */
+int carmel_hip_lattice_weight_source(carmel_hip_trainer* t);
 /* how the derivation lattices are held: 0 = explicit (lane groups / bundles in HBM), 1 = unrolled over string positions
  * (one-tape models, never stored), 2 = unrolled in the rank-1 dense form (LM o channel cascades, dense.hpp); -1: none built */
 int carmel_hip_lattice_layout(carmel_hip_trainer* t);

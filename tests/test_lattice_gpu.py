@@ -167,3 +167,32 @@ def test_windowed_corpora_are_built_on_the_device(name, capfd, monkeypatch):
     fb.close()
     # (no timing claim on 6 030 pairs: both builders take ~0.03 s there and a 256-thread host wins as often as not;
     # test_config2_and_a_slice_of_config4 compares the two on 200 000 pairs)
+
+
+@pytest.mark.parametrize("name", ["c4a", "tagging", "plain", "cyclic", "hub"])
+def test_tile_weights_from_the_table_are_the_same_bits(name, capfd, monkeypatch):
+    """the tile passes' two sources of weights -- X, written bucket by bucket by the first pass (CARMEL_HIP_TILE_GATHER=0; what a
+    WFST of few items an arc or a table beyond the cache gets), and the WFST's table through the arc of every tile-major item
+    (t_t_arc; no first pass) -- are the same values at the same positions: fused-lane layouts with and without windows, the tile
+    sweep's layout, bundles beside lanes, a hub arc with buckets of its own"""
+    monkeypatch.setenv("CARMEL_TIMING", "1")
+    monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", "0")  # (run-length indices keep X)
+    if name == "c4a":
+        w, c = synth.make_config("c4a", n_pairs=30000)
+    elif name == "tagging":
+        w, c = _tagging(6)
+    elif name == "plain":
+        w, c = synth.make_config("c2", n_pairs=20000)
+    elif name == "cyclic":
+        w = synth.random_wfst(40, 5, n_sym=4, p_eps=0.25, seed=3)
+        c = synth.random_walk_corpus(w, 300, min_arcs=3, max_arcs=10, seed=3, out_degree=5)
+    else:
+        w = synth.random_wfst(3, 2, n_sym=2, p_eps=0.0, seed=9)
+        c = synth.random_walk_corpus(w, 4000, min_arcs=20, max_arcs=40, seed=9, out_degree=2)
+    res = {}
+    for g in ("1", "0"):
+        monkeypatch.setenv("CARMEL_HIP_TILE_GATHER", g)
+        capfd.readouterr()
+        res[g] = _build(w, c, name in ("c4a", "tagging", "plain"))
+        assert ("tile weights from the table" in capfd.readouterr().err) == (g == "1")
+    _same(res["1"], res["0"], atomics=name == "hub")
