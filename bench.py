@@ -410,8 +410,10 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                           "(the backward pass stages a tile's posteriors in LDS and writes XC itself: no posterior array, no tile pass "
                           "back) + trans_c_bucket (posteriors to per-arc counts), timed together with HIP events on the trainer's "
                           "stream") if fb.fused_lane_tiles else
-                         ("E-step = sweep_wave kernels (weights gathered from the WFST's table: no weight pass) + trans_c_tile + "
-                          "trans_c_bucket (posteriors to per-arc counts), timed together with HIP events on the trainer's stream")
+                         ("E-step = sweep_wave kernels (weights gathered from the WFST's table: no weight pass%s + "
+                          "trans_c_bucket (posteriors to per-arc counts), timed together with HIP events on the trainer's stream") % (
+                              "; posteriors straight to the count pass's input: no posterior array, no tile pass)" if fb.weight_source & 4
+                              else ") + trans_c_tile")
                          if fb.weight_source & 2 and not ls.n_windowed_pairs and ls.n_bundles == ls.n_pairs_kept else
                          "E-step = trans_w_bucket + trans_w_tile (weights to lattice order) + "
                          "sweep_lane / sweep_wave kernels + trans_c_tile + trans_c_bucket (posteriors to per-arc counts), timed "

@@ -1104,6 +1104,12 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   WA.max_states = WA.max_width = 0;
   TransArgs T;
   trans_args(t, T);
+  // the wave sweeps' posteriors straight to XC (wave_xc_idx, build_run_tables): no `post`, no tile pass over the wave tiles
+  const bool wave_xc = t->use_transpose && t->wave_xc_idx.n && !T.use_runs && !(T.scatter & 2u);
+  if (wave_xc) {
+    WA.xc = T.xc;
+    WA.xc_idx = t->wave_xc_idx.p;
+  }
   LA.pre_weights = t->use_transpose ? 1u : 0u;
   // fused-lane layout: the lane sweep's backward pass sends a tile's posteriors to XC itself (sweep_lane_kernel<.., XC>);
   // CARMEL_HIP_LANE_FUSED_KERNEL=0: sweep -> post -> trans_c_tile on the same layout (the same bits in XC)
@@ -1266,7 +1272,8 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   if (t->use_transpose) {
     // posteriors of the tiles not yet sent out: all of them, or (side by side) the bundle positions after the lane records
     const uint32_t first = (side_by_side || tile_sweep_done || lane_fused) ? lane_tiles : 0u;
-    HIPCHK(launch_trans_c_tiles(T, first, T.n_tiles > first ? T.n_tiles - first : 0u, s));
+    const uint32_t end = wave_xc ? std::min(T.n_tiles, (uint32_t)(t->wave_slot_base / t->lat.tile)) : T.n_tiles;
+    HIPCHK(launch_trans_c_tiles(T, first, end > first ? end - first : 0u, s));
     if (xp) {  // the counts leave arc range by arc range, each into its reduce-scatter while the next is being summed
       int rc = exchange_counts_out(t, xp, T);
       if (rc) return rc;
@@ -1356,7 +1363,7 @@ int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t) {
 }
 int carmel_hip_lattice_weight_source(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices || t->unrolled || !t->use_transpose) return 0;
-  return (t->t_t_arc.n ? 1 : 0) | (t->wave_bwd_arc.n ? 2 : 0);
+  return (t->t_t_arc.n ? 1 : 0) | (t->wave_bwd_arc.n ? 2 : 0) | (t->wave_xc_idx.n ? 4 : 0);
 }
 int carmel_hip_lattice_layout(carmel_hip_trainer* t) {
   if (!t || !t->have_lattices) return -1;

@@ -133,6 +133,7 @@ struct carmel_hip_trainer {
   DevBuf<double> pair_logw, pair_logprob, alpha_g, beta_g;
   DevBuf<WaveDesc> wave_descs;  // one lattice per wavefront (lattice.hpp)
   DevBuf<uint2_t> wave_fwd;
+  DevBuf<uint32_t> wave_xc_idx;   // the item (place in XC) of every wave position: the sweep writes XC itself (build_run_tables)
   DevBuf<uint32_t> wave_bwd_arc;  // gathered weights (LatticeSet::wave_gather): the arc id of every backward record
   DevBuf<uint32_t> wave_bwd, wave_level_off, wave_frow, wave_brow;
   uint64_t wave_slot_base = 0, wave_records = 0;

@@ -330,7 +330,10 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 // GW (WaveArgs::bwd_arc): the weights come straight from the WFST's table -- a forward record's y is the arc id, the backward
 // records' arc ids lie beside them (bwd_arc, requested one level before the weight they lead to) -- and no pass lays them out in
 // lattice order first: for a table the chip's caches hold, the gathers cost less than writing and re-reading 8 B per lattice arc.
-template <bool RING, bool GW>
+// XD (WaveArgs::xc_idx): an arc's posterior goes straight to its item's place in XC (xc_idx: the tile-major item index of every
+// backward position, requested with the record) -- what trans_c_tile would read `post` for; a level's arcs being neighbours in
+// the WFST, a row's items mostly fill whole lines of XC.
+template <bool RING, bool GW, bool XD>
 __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WaveDesc d = A.descs[A.first + blockIdx.x];
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   const double* __restrict__ wc = GW ? A.logw : A.wcache + d.bwd_base;
   const uint32_t* __restrict__ ba = GW ? A.bwd_arc + d.bwd_base + lane : nullptr;
   const uint32_t amax = A.n_arcs - 1u;  // (a padding record's arc id is 0xffffffff)
-  double* __restrict__ post = A.post + d.bwd_base + lane;
+  double* __restrict__ post = XD ? A.xc : A.post + d.bwd_base + lane;
+  const uint32_t* __restrict__ xi = XD ? A.xc_idx + d.bwd_base + lane : nullptr;
   const uint32_t S = d.n_states, NL = d.n_levels;
   if (RING) {
     for (uint32_t s = lane; s <= rm; s += 64) val[s] = NEG_INF;
@@ -434,6 +438,14 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
     uint32_t r0 = brow[1], r1 = brow[2], r2 = NL > 2 ? brow[3] : r1;
     size_t p1 = (size_t)(r1 < rend ? r1 : r0) * 64;
     uint32_t x0 = b[(size_t)r0 * 64], x1 = b[p1];
+    uint32_t q0 = XD ? xi[(size_t)r0 * 64] : 0u, q1 = XD ? xi[p1] : 0u;
+#define WAVE_POST(r, q, v)                 \
+  {                                        \
+    if (!XD)                               \
+      post[(size_t)(r) * 64] = (v);        \
+    else if ((q) != 0xffffffffu)           \
+      post[(q)] = (v);                     \
+  }
 #define WAVE_BW(p, g) (GW ? wc[min((g), amax)] : wc[(p) + lane])
     uint32_t g2 = GW ? ba[(size_t)(r2 < rend ? r2 : r0) * 64] : 0u;
     double w0 = WAVE_BW((size_t)r0 * 64, ba[(size_t)r0 * 64]), w1 = WAVE_BW(p1, ba[p1]);
@@ -456,6 +468,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       const uint32_t r3 = (k + 3 <= NL) ? brow[k + 3] : rend;
       const size_t p2 = (size_t)(r2 < rend ? r2 : r0) * 64;
       const uint32_t x2 = b[p2];
+      const uint32_t q2 = XD ? xi[p2] : 0u;
       const uint32_t g3 = GW ? ba[(size_t)(r3 < rend ? r3 : r0) * 64] : 0u;
       const double w2 = WAVE_BW(p2, g2);
       double a2v = NEG_INF;
@@ -468,7 +481,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       const double t0 = v0 ? w0 + val[(x0 & 0xffffu) & rm] : NEG_INF;
       const double al0 = v0 ? (RING ? al[sr0] : val[s0 + sr0]) : NEG_INF;
       if (t0 > NEG_INF) lds_max_f64(&mx[sr0], t0);
-      post[(size_t)r0 * 64] = K_EXP(al0 + t0);  // exp(-inf) = 0 on padding and dead arcs
+      WAVE_POST(r0, q0, K_EXP(al0 + t0));  // exp(-inf) = 0 on padding and dead arcs
       for (uint32_t r = r0 + 1; r < r1; ++r) {
         const uint32_t q = b[(size_t)r * 64];
         const bool v = (q & WAVE_VALID) != 0;
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
         const double t = v ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;
         const double a = v ? (RING ? al[sr] : val[s0 + sr]) : NEG_INF;
         if (t > NEG_INF) lds_max_f64(&mx[sr], t);
-        post[(size_t)r * 64] = K_EXP(a + t);
+        WAVE_POST(r, xi[(size_t)r * 64], K_EXP(a + t));
       }
       __syncthreads();
       if (t0 > NEG_INF) lds_add_f64(&sm[sr0], K_EXP(t0 - mx[sr0]));
@@ -499,6 +512,8 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       w0 = w1;
       x1 = x2;
       w1 = w2;
+      q0 = q1;
+      q1 = q2;
       a1v = a2v;
       g2 = g3;
       r0 = r1;
@@ -506,6 +521,7 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       r2 = r3;
     }
 #undef WAVE_BW
+#undef WAVE_POST
   }
 }
 
@@ -1510,34 +1526,39 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
   return launch_lane_variant<4, 2, false>(A, lc.count, lds, stream);
 }
 
+template <bool RING>
+static void launch_wave_variant(const WaveArgs& A, uint32_t count, size_t lds, bool big_lds, hipStream_t stream) {
+  const bool gw = A.bwd_arc != nullptr, xd = A.xc_idx != nullptr;
+  static size_t lds_set[2][2] = {{0, 0}, {0, 0}};  // (the attribute is per kernel: set where a launch needs more than it has)
+  const bool set_lds = big_lds && lds > lds_set[gw][xd];
+  if (set_lds) lds_set[gw][xd] = lds;
+#define WAVE_LAUNCH(GW, XD)                                                                                                       \
+  {                                                                                                                               \
+    if (set_lds) (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<RING, GW, XD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((sweep_wave_kernel<RING, GW, XD>), dim3(count), dim3(64), lds, stream, A);                                 \
+  }
+  if (gw && xd) WAVE_LAUNCH(true, true)
+  else if (gw) WAVE_LAUNCH(true, false)
+  else if (xd) WAVE_LAUNCH(false, true)
+  else WAVE_LAUNCH(false, false)
+#undef WAVE_LAUNCH
+}
 hipError_t launch_wave_sweep(const WaveArgs& A0, const LatticeSet::WaveClass& wc, hipStream_t stream) {
   WaveArgs A = A0;
   A.first = wc.first;
   A.max_width = wc.max_width;
-  const bool gw = A.bwd_arc != nullptr;
-  if (gw && (!A.logw || !A.n_arcs)) return hipErrorInvalidValue;
+  if (A.bwd_arc && (!A.logw || !A.n_arcs)) return hipErrorInvalidValue;
+  if (A.xc_idx && !A.xc) return hipErrorInvalidValue;
   if (wc.ring) {
     if (!A.spill) return hipErrorInvalidValue;
     A.max_states = wc.ring;
     const size_t lds = ((size_t)wc.ring + 3 * (size_t)wc.max_width) * sizeof(double);
-    if (gw)
-      hipLaunchKernelGGL((sweep_wave_kernel<true, true>), dim3(wc.count), dim3(64), lds, stream, A);
-    else
-      hipLaunchKernelGGL((sweep_wave_kernel<true, false>), dim3(wc.count), dim3(64), lds, stream, A);
+    launch_wave_variant<true>(A, wc.count, lds, false, stream);
     return hipGetLastError();
   }
   A.max_states = wc.max_states;
   const size_t lds = ((size_t)wc.max_states + 2 * (size_t)wc.max_width) * sizeof(double);
-  static size_t lds_set = 0;
-  if (lds > 64 * 1024 && lds > lds_set) {
-    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_set = lds;
-  }
-  if (gw)
-    hipLaunchKernelGGL((sweep_wave_kernel<false, true>), dim3(wc.count), dim3(64), lds, stream, A);
-  else
-    hipLaunchKernelGGL((sweep_wave_kernel<false, false>), dim3(wc.count), dim3(64), lds, stream, A);
+  launch_wave_variant<false>(A, wc.count, lds, lds > 64 * 1024, stream);
   return hipGetLastError();
 }
 

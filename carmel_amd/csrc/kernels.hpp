@@ -71,6 +71,8 @@ struct WaveArgs {
   const double* logw = nullptr;       // gathered weights (bwd_arc set): the WFST's table, a forward record's y = the arc id
   const uint32_t* bwd_arc = nullptr;  // ... and the arc id of every backward record (0xffffffff: padding)
   uint32_t n_arcs = 0;
+  double* xc = nullptr;               // posteriors straight to the count pass (xc_idx set): XC, tile-major item order
+  const uint32_t* xc_idx = nullptr;   // ... the item of every backward position (0xffffffff: none), at the first wave slot
   double* post;           // at the first wave slot: posteriors, same positions
   double* pair_logprob;
   double* spill;          // ring lattices: parked forward values (WaveDesc::spill_base)

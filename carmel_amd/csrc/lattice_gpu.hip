@@ -824,11 +824,47 @@ __global__ __launch_bounds__(1024) void tile_arc_kernel(const TransBucket* bucke
   const TransBucket B = buckets[blockIdx.x];
   for (uint32_t j = threadIdx.x; j < B.n_items; j += 1024) t_arc[b_src[B.item_base + j]] = B.arc_lo + b_arc[B.item_base + j];
 }
+// the item (tile-major index: its place in XC) of every wave position; idx[] arrives filled with 0xffffffff
+__global__ __launch_bounds__(1024) void wave_item_kernel(const uint64_t* tile_base, const uint16_t* t_pos, uint32_t tile_first, uint32_t tile_sz,
+                                                         uint64_t n_wave, uint32_t* idx) {
+  const uint32_t tile = tile_first + blockIdx.x;
+  const uint64_t i0 = tile_base[tile], i1 = tile_base[tile + 1];
+  for (uint64_t i = i0 + threadIdx.x; i < i1; i += 1024) {
+    const uint64_t p = (uint64_t)blockIdx.x * tile_sz + t_pos[i];
+    if (p < n_wave) idx[p] = (uint32_t)i;
+  }
+}
+// rows (64 positions) with an item, and those of them whose items lie within 128 places of XC of one another (a wavefront
+// walks its share of the rows and adds its two totals once: same-address atomics serialise)
+__global__ __launch_bounds__(256) void wave_row_span_kernel(const uint32_t* idx, uint64_t n_rows, unsigned long long* out) {
+  const uint64_t w0 = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (uint64_t)gridDim.x * 4;
+  unsigned long long rows = 0, compact = 0;
+  for (uint64_t row = w0; row < n_rows; row += nw) {
+    const uint32_t q = idx[row * 64 + (threadIdx.x & 63)];
+    uint32_t lo = q, hi = q == 0xffffffffu ? 0u : q;
+    for (int o = 32; o; o >>= 1) {
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, o));
+    }
+    if (lo != 0xffffffffu) {
+      ++rows;
+      if (hi - lo < 128u) ++compact;
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && rows) {
+    atomicAdd(out, rows);
+    atomicAdd(out + 1, compact);
+  }
+}
 static int build_run_tables_impl(carmel_hip_trainer* t);
-// after either builder: the run tables, or the tiles' arc ids
+static int build_wave_items(carmel_hip_trainer* t);
+// after either builder: the run tables, or the tiles' arc ids; the wave positions' items
 int build_run_tables(carmel_hip_trainer* t) {
   t->t_t_arc.release();
+  t->wave_xc_idx.release();
   int rc = build_run_tables_impl(t);
+  if (rc) return rc;
+  rc = build_wave_items(t);
   if (rc) return rc;
   // A WFST whose weights the last-level cache holds (128 MB of them in its 256 MB), whose arcs lie in many lattices each (four
   // items an arc and more) and a transposition with per-item indices: the tile pass (or the tile sweep) can fetch a tile's
@@ -847,6 +883,38 @@ int build_run_tables(carmel_hip_trainer* t) {
   HIPCHK(hipStreamSynchronize(t->stream));
   if (getenv("CARMEL_TIMING"))
     fprintf(stderr, "timing: tile weights from the table: %zu items over %llu arcs\n", t->t_t_arc.n, (unsigned long long)t->w.n_arcs);
+  return CARMEL_HIP_OK;
+}
+// One-per-wavefront lattices and nothing behind them (no bundle positions in their tiles), per-item indices: the sweep can send
+// every posterior to its item's place in XC itself (sweep_wave_kernel<.., XD>) -- `post` is neither written nor read back and
+// trans_c_tile has no wave tile to do -- where that scattered write fills lines: where most rows' items are neighbours in XC (a
+// level's arcs are neighbours in the WFST, so they share a bucket and sit side by side in a tile's run: `long`, every row).
+// CARMEL_HIP_WAVE_XC=0 / 1: never / whatever the rows look like (A/B: the same values at the same places of XC).
+static int build_wave_items(carmel_hip_trainer* t) {
+  if (!t->use_transpose || t->use_runs || !t->wave_records || t->out_arcs.n || !t->t_tile_base.n || !t->t_t_pos.n) return CARMEL_HIP_OK;
+  const char* env = getenv("CARMEL_HIP_WAVE_XC");
+  if (env && atoi(env) == 0) return CARMEL_HIP_OK;
+  const uint32_t tile = t->lat.tile;
+  if (!tile || t->wave_slot_base % tile) return CARMEL_HIP_OK;
+  const uint32_t first = (uint32_t)(t->wave_slot_base / tile), n_tiles = (uint32_t)(t->t_tile_base.n - 1);
+  if (first >= n_tiles) return CARMEL_HIP_OK;
+  hipStream_t s = t->stream;
+  HIPCHK(t->wave_xc_idx.alloc(t->wave_records));
+  HIPCHK(hipMemsetAsync(t->wave_xc_idx.p, 0xff, t->wave_xc_idx.bytes(), s));
+  hipLaunchKernelGGL(wave_item_kernel, dim3(n_tiles - first), dim3(1024), 0, s, t->t_tile_base.p, t->t_t_pos.p, first, tile, (uint64_t)t->wave_records,
+                     t->wave_xc_idx.p);
+  DevBuf<unsigned long long> d;
+  HIPCHK(d.alloc(2));
+  HIPCHK(hipMemsetAsync(d.p, 0, 16, s));
+  const uint64_t n_rows = t->wave_records / 64;
+  hipLaunchKernelGGL(wave_row_span_kernel, dim3((unsigned)std::min<uint64_t>((n_rows + 3) / 4, 2048)), dim3(256), 0, s, t->wave_xc_idx.p, n_rows, d.p);
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  const bool on = env ? true : (h[0] && h[1] * 4 >= h[0] * 3);
+  if (getenv("CARMEL_TIMING"))
+    fprintf(stderr, "timing: wave posteriors straight to XC: %llu of %llu rows compact -> %s\n", h[1], h[0], on ? "on" : "off");
+  if (!on) t->wave_xc_idx.release();
   return CARMEL_HIP_OK;
 }
 // derive the run tables from t_t_src / t_b_src (which stay, for the A/B switch and the checksums)

@@ -174,17 +174,18 @@ class HipForwardBackward(object):
             return "unrolled, rank-1 dense form (never stored)"
         tiles, fused = lib.carmel_hip_lattice_tile_sweep(self.h), lib.carmel_hip_lattice_fused_lanes(self.h)
         src = self.weight_source
-        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM%s%s%s" % (
+        return "explicit: %d lattices, %d of them windowed; %d lane groups + bundles; %.2f GB in HBM%s%s%s%s" % (
             ls.n_pairs_kept, ls.n_windowed_pairs, ls.n_bundles, ls.device_bytes / 1e9,
             "; laid out for the tile sweep (%d tiles)" % tiles if tiles else "",
             "; fused lanes (%d tiles)" % fused if fused else "",
             "; weights from the WFST's table (%s)" % " and ".join(
-                n for b, n in ((1, "tile passes"), (2, "wave sweeps")) if src & b) if src else "")
+                n for b, n in ((1, "tile passes"), (2, "wave sweeps")) if src & b) if src & 3 else "",
+            "; wave posteriors straight to the count pass" if src & 4 else "")
 
     @property
     def weight_source(self):
         """bit 0: the tile passes fetch their weights from the WFST's table (no bucket pass), bit 1: the one-per-wavefront sweeps
-        do (carmel_hip_lattice_weight_source)"""
+        do, bit 2: those sweeps write the count pass's input themselves (carmel_hip_lattice_weight_source)"""
         return lib.carmel_hip_lattice_weight_source(self.h)
 
     @property

@@ -102,8 +102,10 @@ int carmel_hip_lattice_fused_lanes(carmel_hip_trainer* t);
  * = the tile passes fetch a tile's weights from the WFST's table through the arc id of every item (no bucket pass, no X:
  * WFSTs of four and more items an arc whose table is at most 128 MB; CARMEL_HIP_TILE_GATHER=0/1), bit 1 = the
  * one-per-wavefront sweeps gather theirs from the table through the records' arc ids (tables of at most 64 MB;
- * CARMEL_HIP_WAVE_GATHER=0/1); 0: every weight goes through the blocked transposition.  A/B switches: the same values at
- * the same places of the same sums. */
+ * CARMEL_HIP_WAVE_GATHER=0/1); neither: every weight goes through the blocked transposition.  Bit 2: on the way out, the
+ * one-per-wavefront sweeps send an arc's posterior (derivations.h:432-449) straight to its item's place in the count pass's
+ * input -- no posterior array, no tile pass over their tiles (corpora of such lattices alone whose rows' items are neighbours
+ * there; CARMEL_HIP_WAVE_XC=0/1).  A/B switches: the same values at the same places of the same sums. */
 int carmel_hip_lattice_weight_source(carmel_hip_trainer* t);
 /* how the derivation lattices are held: 0 = explicit (lane groups / bundles in HBM), 1 = unrolled over string positions
  * (one-tape models, never stored), 2 = unrolled in the rank-1 dense form (LM o channel cascades, dense.hpp); -1: none built */

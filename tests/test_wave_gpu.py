@@ -76,11 +76,14 @@ def test_long_workload_slice_uses_the_wave_sweep(oracle, monkeypatch, ring):
 
 @pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("seed", [2, 3, 5])
-def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, seed, ring):
+def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, capfd, seed, ring):
     """the sweep's two sources of weights -- the WFST's table through the records' arc ids (tables the caches hold: the default
     here) and wcache, written in lattice order by the transposition's weight pass (CARMEL_HIP_WAVE_GATHER=0; what a larger
-    table gets) -- are the same numbers in the same places of the same sums"""
+    table gets) -- and its two ways out for the posteriors -- `post` and the tile pass, or every posterior straight to its item's
+    place in XC (CARMEL_HIP_WAVE_XC=1: forced here, chosen where a row's items are neighbours in XC) -- are the same numbers in
+    the same places of the same sums"""
     from carmel_amd.trainer import HipForwardBackward
+    monkeypatch.setenv("CARMEL_TIMING", "1")
     monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
     monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
     monkeypatch.setenv("CARMEL_HIP_LANE_STATES", "12" if seed == 3 else "0")  # (seed 3: lane lattices beside the waves)
@@ -91,10 +94,14 @@ def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, seed, rin
         w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
         c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
     runs = []
-    for g in ("1", "0"):
+    for g, x in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("CARMEL_HIP_WAVE_GATHER", g)
+        monkeypatch.setenv("CARMEL_HIP_WAVE_XC", x)
+        capfd.readouterr()
         fb = HipForwardBackward(w, c)
+        assert ("wave posteriors straight to XC" in capfd.readouterr().err) == (x == "1")
         assert fb.lattice_stats.n_bundles > 0  # (wave lattices are counted with the bundles)
+        assert bool(fb.weight_source & 2) == (g == "1") and bool(fb.weight_source & 4) == (x == "1")
         out = []
         for _ in range(3):
             lp, wlp = fb.estimate(per_pair=True)
@@ -103,12 +110,13 @@ def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, seed, rin
         out.append(fb.weights().copy())
         fb.close()
         runs.append(out)
-    for a, b in zip(runs[0][:-1], runs[1][:-1]):
-        assert a[0] == b[0] and a[1] == b[1]
-        assert np.array_equal(a[2], b[2])
-        # (an arc whose items lie in several buckets is summed with one atomic per bucket: the last bits may differ)
-        assert (a[3] != b[3]).sum() <= 16 and np.allclose(a[3], b[3], rtol=1e-13, atol=0)
-    np.testing.assert_allclose(runs[0][-1], runs[1][-1], rtol=1e-12, atol=0)
+    for other in runs[1:]:
+        for a, b in zip(runs[0][:-1], other[:-1]):
+            assert a[0] == b[0] and a[1] == b[1]
+            assert np.array_equal(a[2], b[2])
+            # (an arc whose items lie in several buckets is summed with one atomic per bucket: the last bits may differ)
+            assert (a[3] != b[3]).sum() <= 16 and np.allclose(a[3], b[3], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(runs[0][-1], other[-1], rtol=1e-12, atol=0)
 
 
 def test_waves_refuse_the_gather_formulation(monkeypatch):
