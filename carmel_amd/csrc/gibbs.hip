@@ -641,6 +641,7 @@ double gibbs_norm_quantile(double p) {
   return q < 0 ? -v : v;
 }
 
+static constexpr int GX_WCLASSES = 4;  // LDS classes of the parallel sweep's blocks
 struct carmel_hip_gibbs {
   // --prior-inference-* (gibbs_opts.hpp:82-89, 148-153)
   double pi_stddev = 0;
@@ -684,7 +685,7 @@ struct carmel_hip_gibbs {
   struct WaveClass {
     DevBuf<uint32_t> list;
     uint32_t n = 0, cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
-  } wclass[2];
+  } wclass[GX_WCLASSES];
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
   std::vector<double> h_final_x;  // ... its counts as finalize_cumulative_counts left them (carmel_hip_gibbs_final_counts)
@@ -925,10 +926,15 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         for (size_t b = 0; b < bb.size(); ++b) arcs[b] = (uint32_t)L.bundles[bb[b]].n_arcs;
         std::vector<uint32_t> sorted = arcs;
         std::sort(sorted.begin(), sorted.end());
-        const uint32_t cut = sorted[std::min(sorted.size() - 1, sorted.size() * 9 / 10)];
-        std::vector<uint32_t> lists[2];
+        // (four classes at the median, the 80th and the 95th percentile: the tagging cascade's median sentence needs a third of
+        // the 90th percentile's LDS, and a wavefront that waits for its gathers wants neighbours)
+        const uint32_t cuts[GX_WCLASSES - 1] = {sorted[std::min(sorted.size() - 1, sorted.size() / 2)],
+                                                sorted[std::min(sorted.size() - 1, sorted.size() * 8 / 10)],
+                                                sorted[std::min(sorted.size() - 1, sorted.size() * 19 / 20)]};
+        std::vector<uint32_t> lists[GX_WCLASSES];
         for (size_t b = 0; b < bb.size(); ++b) {
-          const int c = arcs[b] <= cut ? 0 : 1;
+          int c = 0;
+          while (c < GX_WCLASSES - 1 && arcs[b] > cuts[c]) ++c;
           const BundleDesc& d = L.bundles[bb[b]];
           auto& W = g->wclass[c];
           lists[c].push_back((uint32_t)b);
@@ -937,7 +943,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           W.cap_levels = std::max(W.cap_levels, d.n_levels);
           W.cap_sample = std::max(W.cap_sample, d.n_levels * max_chain);
         }
-        for (int c = 0; c < 2; ++c) {
+        for (int c = 0; c < GX_WCLASSES; ++c) {
           auto& W = g->wclass[c];
           W.n = (uint32_t)lists[c].size();
           W.cap_arcs = (W.cap_arcs + 3) / 4 * 4;
@@ -1424,7 +1430,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
         GX.sample_nrm = g->new_nrm.p;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device);
-        for (int c = 0; c < 2; ++c) {  // (both launches on the trainer's stream: the second fills the chip as the first drains)
+        for (int c = GX_WCLASSES - 1; c >= 0; --c) {  // (all on the trainer's stream, the long blocks first: the next fills the chip as one drains)
           auto& W = g->wclass[c];
           if (!W.n) continue;
           GX.list = W.list.p;

@@ -117,8 +117,13 @@ __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, u
 //              snapshot) with the block's own previous sample taken out arithmetically (counterfactual counts: every entry
 //              of it is compared with every lattice arc's parameters and norm groups); the new samples go to the other sample
 //              buffer and gibbs.hip's recount / commit kernels rebuild the counts from them.
+#ifndef GX_PAR_WAVES
+#define GX_PAR_WAVES 4
+#endif
+// (PAR: four wavefronts a SIMD -- the sweep waits for gathers from the count tables and has a grid to hide them behind; the
+// chain is one wavefront, or 64, and keeps the registers it wants)
 template <bool PAR>
-__global__ __launch_bounds__(64) void gibbs_exact_wave_kernel(GxArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR_WAVES : 1, PAR ? GX_PAR_WAVES : 3))) void gibbs_exact_wave_kernel(GxArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
   if (!PAR && A.n_chains > 1) {  // chain blockIdx.x of several: its own counts, cache model, sample, results and uniforms
     const uint32_t c = blockIdx.x;

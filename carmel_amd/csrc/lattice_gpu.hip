@@ -874,6 +874,7 @@ int build_run_tables(carmel_hip_trainer* t) {
   // (0.56 items an arc: a line fetched per item for 8 bytes of it) 0.083 -> 0.087, hence the rule.
   // CARMEL_HIP_TILE_GATHER=0 / 1: never / whatever the sizes (A/B: the same values at the same places).
   if (!t->use_transpose || t->use_runs || !t->t_buckets.n || !t->t_t_src.n || !t->t_b_src.n || !t->t_b_arc.n) return CARMEL_HIP_OK;
+  if (!t->wcache.n) return CARMEL_HIP_OK;  // (no lane record: no tile pass in the weights' direction)
   const char* env = getenv("CARMEL_HIP_TILE_GATHER");
   if (env ? atoi(env) == 0 : (t->w.n_arcs * sizeof(double) > (128ull << 20) || t->t_t_src.n < 4 * t->w.n_arcs)) return CARMEL_HIP_OK;
   HIPCHK(t->t_t_arc.alloc(t->t_t_src.n));
