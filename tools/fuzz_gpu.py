@@ -243,7 +243,44 @@ def main():
             (["--print-counts-rich"] if kw.get("rich") else []) + (["--print-counts-sparse=%.17g" % kw["sparse"]] if "sparse" in kw else [])
         C._check_tables(oracle, d, [pc, pa, pb], corpus_text, extra, kw, "JJ" if joint else "CC", priors, 1 + s, N=3 + s % 4, B=s % 3, E=1 + s % 3)
 
+    def table_weights_case(d, s, mp=None):
+        """random ambiguous models, lattices one per lane and one per wavefront: the sweeps' weights through the transposition's
+        passes or straight from the WFST's table (CARMEL_HIP_TILE_GATHER, CARMEL_HIP_WAVE_GATHER), the wave sweeps' posteriors
+        through `post` or straight to the count pass's input (CARMEL_HIP_WAVE_XC) -- the same ln p bit for bit, the same counts
+        (up to the split arcs' atomics), and the oracle's"""
+        w, c = P.ambiguous(s, n_states=12 + s % 120, deg=3 + s % 7, n_sym=2 + s % 5, n_pairs=100 + (s * 13) % 1500, p_eps=0.04 * (s % 4),
+                           lo=2, hi=6 + s % 25)
+        mp.setenv("CARMEL_HIP_TRANS_RUNS", "0")
+        waves = s % 3 != 0
+        if waves:
+            mp.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+            mp.setenv("CARMEL_HIP_WAVE_RING", str(s % 2))
+            mp.setenv("CARMEL_HIP_LANE_STATES", "0" if s % 3 == 1 else str(6 + s % 20))
+        ref = None
+        combos = [("1", "1", "1"), ("0", "0", "0"), ("1", "0", "1"), ("0", "1", "0")] if waves else [("1", "1", "1"), ("0", "1", "1")]
+        for tg, wg, xc in combos:
+            mp.setenv("CARMEL_HIP_TILE_GATHER", tg)
+            mp.setenv("CARMEL_HIP_WAVE_GATHER", wg)
+            mp.setenv("CARMEL_HIP_WAVE_XC", xc)
+            fb = P._fb(w, c)
+            src = fb.weight_source
+            lp, _ = fb.estimate(per_pair=True)
+            got = (lp, fb.pair_logprob.copy(), fb.counts().copy(), fb.has_deriv.copy())
+            fb.close()
+            if ref is None:
+                ref = got
+                ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+                ow.normalize(0, 0.0)
+                r = oracle.estimate(ow, oc)
+                ok = r["has_deriv"]
+                assert np.array_equal(ok, got[3].astype(bool))
+                np.testing.assert_allclose(got[1][ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(got[2], np.exp(r["counts_ln"]), rtol=1e-7, atol=1e-12)
+            assert got[0] == ref[0] and np.array_equal(got[1], ref[1]), (tg, wg, xc, src)
+            np.testing.assert_allclose(got[2], ref[2], rtol=1e-12, atol=0, err_msg=str((tg, wg, xc, src)))
+
     cases += [
+        ("weights from the table", table_weights_case),
         ("crp tables", tables_case),
         ("forest crp chains", forest_chains_case),
         ("host layout tables", host_layout_case),
