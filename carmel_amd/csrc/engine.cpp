@@ -23,7 +23,7 @@ int gpu_tables_for_host_layout(carmel_hip_trainer* t, const std::vector<uint32_t
 int carmel_hip_debug_lattice_fingerprint_impl(carmel_hip_trainer* t, uint64_t* out);
 int build_run_tables(carmel_hip_trainer* t);
 // exchange.cpp: the sharded count exchange of corpus-sharded EM
-int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T);
+int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T, bool need_x);
 int exchange_counts_out(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T);
 int exchange_counts_tail(carmel_hip_trainer* t, ExchangePlan* xp);
 int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_change, int* handled);
@@ -1136,7 +1136,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   // the tile sweep clears, on its way in, the counts the count pass adds up with atomics (the arcs whose items lie in several
   // buckets): one launch less between the sweep and the count pass (the exchange clears its own, chunk by chunk)
   // the tiles' weights straight from the table (t_t_arc, build_run_tables): the tile kernels read `x[t_src[i]]`, whatever the two are
-  const bool tile_gather = t->use_transpose && t->t_t_arc.n && !xp && !T.use_runs && !(T.scatter & 1u);
+  const bool tile_gather = t->use_transpose && t->t_t_arc.n && !T.use_runs && !(T.scatter & 1u);
   TransArgs TW = T;
   if (tile_gather) {
     TW.x = const_cast<double*>(T.logw);
@@ -1151,7 +1151,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   // the bundle sweeps need nothing from the transposition: beside the lane work, on a stream of their own
   const bool bundles_beside = side_by_side && !t->lat.classes.empty();
   if (xp) {  // the weights arrive arc range by arc range (all-gather of the sharded M-step): exchange.cpp
-    int rc = exchange_weights_in(t, xp, T);
+    int rc = exchange_weights_in(t, xp, T, t->wcache.n && !tile_gather);
     if (rc) return rc;
   } else if (t->use_transpose && t->wcache.n && !tile_gather)  // (nothing but gathering sweeps / tiles: no weight goes through X)
     HIPCHK(launch_trans_w_bucket(T, s));

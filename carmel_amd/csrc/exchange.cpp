@@ -164,18 +164,20 @@ static int direct_counts_chunk(carmel_hip_trainer* t, ExchangePlan* xp, uint32_t
 }
 
 // ---- weights in: trans_w_bucket chunk by chunk behind the all-gathers of the previous M-step ----
-int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T) {
+// (need_x false: every sweep fetches its weights from the table itself -- the trainer's stream waits for the chunks and no bucket
+// pass runs)
+int exchange_weights_in(carmel_hip_trainer* t, ExchangePlan* xp, const TransArgs& T, bool need_x) {
   hipStream_t s = t->stream;
   uint32_t done = 0;
   for (uint32_t k = 0; k < xp->K; ++k) {
     // (a chunk that has already arrived needs no barrier packet in the queue: small models, one rank)
     if (xp->ag_pending && hipEventQuery(xp->ev_ag[k]) != hipSuccess) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag[k], 0));
-    if (xp->wb_end[k] > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->wb_end[k] - done, s));
+    if (need_x && xp->wb_end[k] > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->wb_end[k] - done, s));
     done = std::max(done, xp->wb_end[k]);
   }
   if (xp->ag_pending && hipEventQuery(xp->ev_ag_done) != hipSuccess) HIPCHK(hipStreamWaitEvent(s, xp->ev_ag_done, 0));
   xp->ag_pending = false;
-  if (xp->n_buckets > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->n_buckets - done, s));
+  if (need_x && xp->n_buckets > done) HIPCHK(launch_trans_w_bucket_range(T, done, xp->n_buckets - done, s));
   return CARMEL_HIP_OK;
 }
 
