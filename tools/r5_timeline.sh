@@ -14,11 +14,9 @@ python3 - "$f" <<'P'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
-# the last E-step: from the last trans_w_bucket on
-idx=[i for i,r in enumerate(rows) if "trans_w_bucket" in r["Kernel_Name"]]
-i0=idx[-1]
-t0=int(rows[i0]["Start_Timestamp"])
-i0 = idx[-2] if len(idx) > 1 else i0
+# the last whole iteration: from the kernel behind the last M-step but one (mstep_max_final closes an M-step)
+idx=[i for i,r in enumerate(rows) if "mstep_max_final" in r["Kernel_Name"]]
+i0 = idx[-2] + 1 if len(idx) > 1 else 0
 t0=int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i0+16]:
     n=r["Kernel_Name"].replace("carmel_hip::","").replace("void ","")[:60]
