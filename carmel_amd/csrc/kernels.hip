@@ -1529,9 +1529,12 @@ hipError_t launch_lane_sweep(const LaneArgs& A0, const LatticeSet::LaneClass& lc
 template <bool RING>
 static void launch_wave_variant(const WaveArgs& A, uint32_t count, size_t lds, bool big_lds, hipStream_t stream) {
   const bool gw = A.bwd_arc != nullptr, xd = A.xc_idx != nullptr;
-  static size_t lds_set[2][2] = {{0, 0}, {0, 0}};  // (the attribute is per kernel: set where a launch needs more than it has)
-  const bool set_lds = big_lds && lds > lds_set[gw][xd];
-  if (set_lds) lds_set[gw][xd] = lds;
+  // (the attribute is per kernel and per device: set where a launch needs more than the kernel has been given there)
+  static size_t lds_set[64][2][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const bool set_lds = big_lds && lds > lds_set[dev][gw][xd];
+  if (set_lds) lds_set[dev][gw][xd] = lds;
 #define WAVE_LAUNCH(GW, XD)                                                                                                       \
   {                                                                                                                               \
     if (set_lds) (void)hipFuncSetAttribute((const void*)sweep_wave_kernel<RING, GW, XD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
