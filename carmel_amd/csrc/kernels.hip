@@ -333,8 +333,9 @@ __device__ __forceinline__ void lds_add_f64(double* p, double v) {
 // XD (WaveArgs::xc_idx): an arc's posterior goes straight to its item's place in XC (xc_idx: the tile-major item index of every
 // backward position, requested with the record) -- what trans_c_tile would read `post` for; a level's arcs being neighbours in
 // the WFST, a row's items mostly fill whole lines of XC.
+// (five wavefronts a SIMD: 96 registers -- `long`'s 5000 lattices are resident all at once at five, not at four)
 template <bool RING, bool GW, bool XD>
-__global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void sweep_wave_kernel(WaveArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const WaveDesc d = A.descs[A.first + blockIdx.x];
   const uint32_t lane = threadIdx.x;
@@ -377,51 +378,72 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
     // a record's weight is a gather through the record (wc[rec.y]), and issued in the same step as the record's own load it
     // made every step wait out a full memory round trip; now the gather goes through the record requested a step earlier
 #define WAVE_FROW(k) ((k) <= NL ? frow[(k)] : rend)
+    // The records and weights in flight live in rings indexed by compile-time constants -- the level loop is unrolled four times
+    // and slot (l - 1) % 4 belongs to level l -- and are never moved: rotated through named registers (rec0 = rec1, w0 = w1 ...)
+    // every step had to wait for ALL its outstanding loads, the ones just issued for three levels ahead included, before it could
+    // move their destinations (s_waitcnt vmcnt(0) a level: a memory round trip per level step).  The row starts are scalars and rotate.
     uint32_t r0 = frow[1], r1 = WAVE_FROW(2), r2 = WAVE_FROW(3), r3 = WAVE_FROW(4);
-    uint2 rec0 = f[(size_t)r0 * 64], rec1 = f[(size_t)(r1 < rend ? r1 : r0) * 64], rec2 = f[(size_t)(r2 < rend ? r2 : r0) * 64];
-    double w0 = wc[rec0.y], w1 = wc[rec1.y];
-    for (uint32_t l = 1; l < NL; ++l) {
-      const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
-      const uint32_t r4 = WAVE_FROW(l + 4);
-      const uint2 rec3 = f[(size_t)(r3 < rend ? r3 : r0) * 64];
-      const double w2 = wc[rec2.y];
-      const bool v0 = (rec0.x & WAVE_VALID) != 0;
-      const uint32_t dr0 = (rec0.x >> 16) & 0x3fffu;
-      const double t0 = v0 ? val[(rec0.x & 0xffffu) & rm] + w0 : NEG_INF;
-      if (t0 > NEG_INF) lds_max_f64(&mx[dr0], t0);
-      for (uint32_t r = r0 + 1; r < r1; ++r) {
-        const uint2 q = f[(size_t)r * 64];
-        const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;
-        if (t > NEG_INF) lds_max_f64(&mx[(q.x >> 16) & 0x3fffu], t);
-      }
-      __syncthreads();
-      if (t0 > NEG_INF) lds_add_f64(&sm[dr0], K_EXP(t0 - mx[dr0]));
-      for (uint32_t r = r0 + 1; r < r1; ++r) {
-        const uint2 q = f[(size_t)r * 64];
-        const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;
-        const uint32_t dr = (q.x >> 16) & 0x3fffu;
-        if (t > NEG_INF) lds_add_f64(&sm[dr], K_EXP(t - mx[dr]));
-      }
-      __syncthreads();
-      for (uint32_t i = lane; i < ns; i += 64) {
-        const double m = mx[i], a = sm[i];
-        const double v = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));
-        val[(s0 + i) & rm] = v;
-        if (RING) spill[s0 + i] = v;
-        mx[i] = NEG_INF;
-        sm[i] = 0.0;
-      }
-      __syncthreads();
-      rec0 = rec1;
-      w0 = w1;
-      rec1 = rec2;
-      w1 = w2;
-      rec2 = rec3;
-      r0 = r1;
-      r1 = r2;
-      r2 = r3;
-      r3 = r4;
+    // records three levels ahead, weights two: a weight's gather goes through the record requested a step earlier and has two
+    // steps to arrive (measured the other way round -- the record two steps, the gather one: the sweep 1.33 -> 1.53 ms on `long`;
+    // and five ahead / three with the loops unrolled six times: 1.59, 9700 instructions against the instruction cache)
+    uint2 rc[4];
+    double wv[4];
+    rc[0] = f[(size_t)r0 * 64];
+    rc[1] = f[(size_t)(r1 < rend ? r1 : r0) * 64];
+    rc[2] = f[(size_t)(r2 < rend ? r2 : r0) * 64];
+    wv[0] = wc[rc[0].y];
+    wv[1] = wc[rc[1].y];
+    uint32_t l = 1;
+#define WAVE_FWD_STEP(SL)                                                                                     \
+  {                                                                                                           \
+    const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;                                                         \
+    const uint32_t r4 = WAVE_FROW(l + 4);                                                                     \
+    rc[((SL) + 3) % 4] = f[(size_t)(r3 < rend ? r3 : r0) * 64];                                               \
+    wv[((SL) + 2) % 4] = wc[rc[((SL) + 2) % 4].y];                                                            \
+    const uint32_t x0 = rc[(SL)].x;                                                                           \
+    const bool v0 = (x0 & WAVE_VALID) != 0;                                                                   \
+    const uint32_t dr0 = (x0 >> 16) & 0x3fffu;                                                                \
+    const double t0 = v0 ? val[(x0 & 0xffffu) & rm] + wv[(SL)] : NEG_INF;                                     \
+    if (t0 > NEG_INF) lds_max_f64(&mx[dr0], t0);                                                              \
+    for (uint32_t r = r0 + 1; r < r1; ++r) {                                                                  \
+      const uint2 q = f[(size_t)r * 64];                                                                      \
+      const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;                    \
+      if (t > NEG_INF) lds_max_f64(&mx[(q.x >> 16) & 0x3fffu], t);                                            \
+    }                                                                                                         \
+    __syncthreads();                                                                                          \
+    if (t0 > NEG_INF) lds_add_f64(&sm[dr0], K_EXP(t0 - mx[dr0]));                                             \
+    for (uint32_t r = r0 + 1; r < r1; ++r) {                                                                  \
+      const uint2 q = f[(size_t)r * 64];                                                                      \
+      const double t = (q.x & WAVE_VALID) ? val[(q.x & 0xffffu) & rm] + wc[q.y] : NEG_INF;                    \
+      const uint32_t dr = (q.x >> 16) & 0x3fffu;                                                              \
+      if (t > NEG_INF) lds_add_f64(&sm[dr], K_EXP(t - mx[dr]));                                               \
+    }                                                                                                         \
+    __syncthreads();                                                                                          \
+    for (uint32_t i = lane; i < ns; i += 64) {                                                                \
+      const double m = mx[i], a = sm[i];                                                                      \
+      const double v = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));                              \
+      val[(s0 + i) & rm] = v;                                                                                 \
+      if (RING) spill[s0 + i] = v;                                                                            \
+      mx[i] = NEG_INF;                                                                                        \
+      sm[i] = 0.0;                                                                                            \
+    }                                                                                                         \
+    __syncthreads();                                                                                          \
+    r0 = r1;                                                                                                  \
+    r1 = r2;                                                                                                  \
+    r2 = r3;                                                                                                  \
+    r3 = r4;                                                                                                  \
+    ++l;                                                                                                      \
+  }
+    while (l + 3 < NL) {
+      WAVE_FWD_STEP(0)
+      WAVE_FWD_STEP(1)
+      WAVE_FWD_STEP(2)
+      WAVE_FWD_STEP(3)
     }
+    if (l < NL) WAVE_FWD_STEP(0)
+    if (l < NL) WAVE_FWD_STEP(1)
+    if (l < NL) WAVE_FWD_STEP(2)
+#undef WAVE_FWD_STEP
 #undef WAVE_FROW
   }
   // ---------- ln p(pair); beta'[goal] = ln(weight) - ln p folds "* weight / prob" (derivations.h:445) ----------
@@ -435,10 +457,19 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
   // ---------- backward + posteriors ----------
   {
     const uint32_t rend = brow[NL];
-    uint32_t r0 = brow[1], r1 = brow[2], r2 = NL > 2 ? brow[3] : r1;
-    size_t p1 = (size_t)(r1 < rend ? r1 : r0) * 64;
-    uint32_t x0 = b[(size_t)r0 * 64], x1 = b[p1];
-    uint32_t q0 = XD ? xi[(size_t)r0 * 64] : 0u, q1 = XD ? xi[p1] : 0u;
+    // (as in the forward pass: the step loop unrolled three times, slot (k - 1) % 3 belongs to step k; the arc ids three steps ahead,
+    // the weights two)
+#define WAVE_BROW(j) ((j) <= NL ? brow[(j)] : rend)
+    uint32_t r0 = brow[1], r1 = brow[2], r2 = WAVE_BROW(3);
+    const size_t p1 = (size_t)(r1 < rend ? r1 : r0) * 64;
+    uint32_t xs[3], qs[3], gs[3];
+    double ws[3], avs[3];
+    xs[0] = b[(size_t)r0 * 64];
+    xs[1] = b[p1];
+    qs[0] = XD ? xi[(size_t)r0 * 64] : 0u;
+    qs[1] = XD ? xi[p1] : 0u;
+    qs[2] = 0u;
+    xs[2] = 0u;
 #define WAVE_POST(r, q, v)                 \
   {                                        \
     if (!XD)                               \
@@ -447,79 +478,87 @@ __global__ __launch_bounds__(64) void sweep_wave_kernel(WaveArgs A) {
       post[(q)] = (v);                     \
   }
 #define WAVE_BW(p, g) (GW ? wc[min((g), amax)] : wc[(p) + lane])
-    uint32_t g2 = GW ? ba[(size_t)(r2 < rend ? r2 : r0) * 64] : 0u;
-    double w0 = WAVE_BW((size_t)r0 * 64, ba[(size_t)r0 * 64]), w1 = WAVE_BW(p1, ba[p1]);
-    // RING: alpha of the level of this step (a0v) and of the next step (a1v), one state per lane (levels are at most a
-    // wavefront wide)
-    double a0v = NEG_INF, a1v = NEG_INF;
+    gs[0] = gs[1] = 0u;
+    gs[2] = GW ? ba[(size_t)(r2 < rend ? r2 : r0) * 64] : 0u;  // (the arcs of step 3: its weight is requested in step 1)
+    ws[0] = WAVE_BW((size_t)r0 * 64, ba[(size_t)r0 * 64]);
+    ws[1] = WAVE_BW(p1, ba[p1]);
+    ws[2] = 0.0;
+    // RING: alpha of the level of this step and of the next two, one state per lane (levels are at most a wavefront wide)
+    avs[0] = avs[1] = avs[2] = NEG_INF;
     if (RING) {
       const uint32_t la = NL - 2, sa = lvl[la], na = lvl[la + 1] - sa;
-      a0v = lane < na ? spill[sa + lane] : NEG_INF;
+      avs[0] = lane < na ? spill[sa + lane] : NEG_INF;
       if (NL > 2) {
         const uint32_t sb = lvl[la - 1], nb = lvl[la] - sb;
-        a1v = lane < nb ? spill[sb + lane] : NEG_INF;
+        avs[1] = lane < nb ? spill[sb + lane] : NEG_INF;
       }
-      al[lane] = a0v;
+      al[lane] = avs[0];
       __syncthreads();
     }
-    for (uint32_t k = 1; k < NL; ++k) {
-      const uint32_t l = NL - 1 - k;
-      const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;
-      const uint32_t r3 = (k + 3 <= NL) ? brow[k + 3] : rend;
-      const size_t p2 = (size_t)(r2 < rend ? r2 : r0) * 64;
-      const uint32_t x2 = b[p2];
-      const uint32_t q2 = XD ? xi[p2] : 0u;
-      const uint32_t g3 = GW ? ba[(size_t)(r3 < rend ? r3 : r0) * 64] : 0u;
-      const double w2 = WAVE_BW(p2, g2);
-      double a2v = NEG_INF;
-      if (RING && l >= 2) {
-        const uint32_t sc = lvl[l - 2], nc = lvl[l - 1] - sc;
-        a2v = lane < nc ? spill[sc + lane] : NEG_INF;
-      }
-      const bool v0 = (x0 & WAVE_VALID) != 0;
-      const uint32_t sr0 = (x0 >> 16) & 0x3fffu;
-      const double t0 = v0 ? w0 + val[(x0 & 0xffffu) & rm] : NEG_INF;
-      const double al0 = v0 ? (RING ? al[sr0] : val[s0 + sr0]) : NEG_INF;
-      if (t0 > NEG_INF) lds_max_f64(&mx[sr0], t0);
-      WAVE_POST(r0, q0, K_EXP(al0 + t0));  // exp(-inf) = 0 on padding and dead arcs
-      for (uint32_t r = r0 + 1; r < r1; ++r) {
-        const uint32_t q = b[(size_t)r * 64];
-        const bool v = (q & WAVE_VALID) != 0;
-        const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = v ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;
-        const double a = v ? (RING ? al[sr] : val[s0 + sr]) : NEG_INF;
-        if (t > NEG_INF) lds_max_f64(&mx[sr], t);
-        WAVE_POST(r, xi[(size_t)r * 64], K_EXP(a + t));
-      }
-      __syncthreads();
-      if (t0 > NEG_INF) lds_add_f64(&sm[sr0], K_EXP(t0 - mx[sr0]));
-      for (uint32_t r = r0 + 1; r < r1; ++r) {
-        const uint32_t q = b[(size_t)r * 64];
-        const uint32_t sr = (q >> 16) & 0x3fffu;
-        const double t = (q & WAVE_VALID) ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;
-        if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));
-      }
-      __syncthreads();
-      for (uint32_t i = lane; i < ns; i += 64) {
-        const double m = mx[i], a = sm[i];
-        val[(s0 + i) & rm] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));  // beta[s] (full form: replaces alpha[s])
-        mx[i] = NEG_INF;
-        sm[i] = 0.0;
-      }
-      if (RING) al[lane] = a1v;  // the next step's level
-      __syncthreads();
-      x0 = x1;
-      w0 = w1;
-      x1 = x2;
-      w1 = w2;
-      q0 = q1;
-      q1 = q2;
-      a1v = a2v;
-      g2 = g3;
-      r0 = r1;
-      r1 = r2;
-      r2 = r3;
+    uint32_t k = 1;
+#define WAVE_BWD_STEP(SL)                                                                                             \
+  {                                                                                                                   \
+    constexpr int S3 = (SL) % 3, N1 = ((SL) + 1) % 3, N2 = ((SL) + 2) % 3;                                            \
+    const uint32_t l = NL - 1 - k;                                                                                    \
+    const uint32_t s0 = lvl[l], ns = lvl[l + 1] - s0;                                                                 \
+    const uint32_t r3 = WAVE_BROW(k + 3);                                                                             \
+    const size_t p2 = (size_t)(r2 < rend ? r2 : r0) * 64;                                                             \
+    xs[N2] = b[p2];                                                                                                   \
+    if (XD) qs[N2] = xi[p2];                                                                                          \
+    if (GW) gs[S3] = ba[(size_t)(r3 < rend ? r3 : r0) * 64];                                                          \
+    ws[N2] = WAVE_BW(p2, gs[N2]);                                                                                     \
+    avs[N2] = NEG_INF;                                                                                                \
+    if (RING && l >= 2) {                                                                                             \
+      const uint32_t sc = lvl[l - 2], nc = lvl[l - 1] - sc;                                                           \
+      avs[N2] = lane < nc ? spill[sc + lane] : NEG_INF;                                                               \
+    }                                                                                                                 \
+    const uint32_t x0 = xs[S3];                                                                                       \
+    const bool v0 = (x0 & WAVE_VALID) != 0;                                                                           \
+    const uint32_t sr0 = (x0 >> 16) & 0x3fffu;                                                                        \
+    const double t0 = v0 ? ws[S3] + val[(x0 & 0xffffu) & rm] : NEG_INF;                                               \
+    const double al0 = v0 ? (RING ? al[sr0] : val[s0 + sr0]) : NEG_INF;                                               \
+    if (t0 > NEG_INF) lds_max_f64(&mx[sr0], t0);                                                                      \
+    WAVE_POST(r0, qs[S3], K_EXP(al0 + t0)); /* exp(-inf) = 0 on padding and dead arcs */                              \
+    for (uint32_t r = r0 + 1; r < r1; ++r) {                                                                          \
+      const uint32_t q = b[(size_t)r * 64];                                                                           \
+      const bool v = (q & WAVE_VALID) != 0;                                                                           \
+      const uint32_t sr = (q >> 16) & 0x3fffu;                                                                        \
+      const double t = v ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF;          \
+      const double a = v ? (RING ? al[sr] : val[s0 + sr]) : NEG_INF;                                                  \
+      if (t > NEG_INF) lds_max_f64(&mx[sr], t);                                                                       \
+      WAVE_POST(r, xi[(size_t)r * 64], K_EXP(a + t));                                                                 \
+    }                                                                                                                 \
+    __syncthreads();                                                                                                  \
+    if (t0 > NEG_INF) lds_add_f64(&sm[sr0], K_EXP(t0 - mx[sr0]));                                                     \
+    for (uint32_t r = r0 + 1; r < r1; ++r) {                                                                          \
+      const uint32_t q = b[(size_t)r * 64];                                                                           \
+      const uint32_t sr = (q >> 16) & 0x3fffu;                                                                        \
+      const double t = (q & WAVE_VALID) ? WAVE_BW((size_t)r * 64, ba[(size_t)r * 64]) + val[(q & 0xffffu) & rm] : NEG_INF; \
+      if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));                                                       \
+    }                                                                                                                 \
+    __syncthreads();                                                                                                  \
+    for (uint32_t i = lane; i < ns; i += 64) {                                                                        \
+      const double m = mx[i], a = sm[i];                                                                              \
+      val[(s0 + i) & rm] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a)); /* beta[s] (full form: replaces alpha[s]) */ \
+      mx[i] = NEG_INF;                                                                                                \
+      sm[i] = 0.0;                                                                                                    \
+    }                                                                                                                 \
+    if (RING) al[lane] = avs[N1]; /* the next step's level */                                                         \
+    __syncthreads();                                                                                                  \
+    r0 = r1;                                                                                                          \
+    r1 = r2;                                                                                                          \
+    r2 = r3;                                                                                                          \
+    ++k;                                                                                                              \
+  }
+    while (k + 2 < NL) {
+      WAVE_BWD_STEP(0)
+      WAVE_BWD_STEP(1)
+      WAVE_BWD_STEP(2)
     }
+    if (k < NL) WAVE_BWD_STEP(0)
+    if (k < NL) WAVE_BWD_STEP(1)
+#undef WAVE_BWD_STEP
+#undef WAVE_BROW
 #undef WAVE_BW
 #undef WAVE_POST
   }
