@@ -102,6 +102,6 @@ def test_committed_profiles_agree():
     kl = [r["Name"] for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r5_long_kernel_stats.csv")))]
     assert any("sweep_wave_kernel<true, true, true>" in n for n in kl) and any("trans_c_bucket" in n for n in kl)
     assert not any("trans_w_" in n or "trans_c_tile" in n for n in kl)
-    assert bench["secondary"]["long"]["roofline"]["frac"] > 0.30 and bench["secondary"]["long"]["roofline"]["traffic"] > 0
+    assert bench["secondary"]["long"]["roofline"]["frac"] > 0.33 and bench["secondary"]["long"]["roofline"]["traffic"] > 0
     assert "weights from the WFST's table (wave sweeps); wave posteriors straight" in bench["secondary"]["long"]["config"]["lattice_layout"]
     assert "weights from the WFST's table (tile passes)" in bench["secondary"]["c4a"]["config"]["lattice_layout"]
