@@ -69,6 +69,12 @@ struct Opts {
   long viterbi_per = 0;              // -V / --checkpoint-viterbi-per-examples: on watch iterations the Viterbi derivation of every
                                      // n-th forest to <prefix>.viterbi.restart.R.iteration.I (forest-em.hpp:403-413, 546-550)
   long per_forest_counts_per = 0;    // -Z / --checkpoint-per-forest-counts: ... <prefix>.per_forest_counts. ... (:416-425, 535-545)
+  // the watched rule (forest-em-params.hpp:134-137, 150-151; forest-em.hpp:120-131, 583-616): on watch iterations the top
+  // watch_depth rules of the normalisation group that holds it, by weight
+  long watch_rule = 0;               // -w / --watch-rule (0: none)
+  long watch_depth = 20;             // -D / --watch-depth
+  std::string rules_file = "-0";     // -R / --rules-file: a description per rule, line i for rule i (without one: the number i - 1,
+                                     // FileLines::getline of no file, filelines.hpp:80-83)
 };
 
 void usage() {
@@ -78,6 +84,7 @@ void usage() {
                "                  --crp-restarts=R [--crp-argmax-final | --crp-argmax-sum]\n"
                "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
                "                 [-x checkpoint-prefix -c -V viterbi-per -Z per-forest-counts-per] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
+               "                 [-w watch-rule -D watch-depth -R rules-file]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -220,6 +227,9 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "x" || key == "checkpoint-prefix") o.checkpoint_prefix = value(val);
     else if (key == "c" || key == "checkpoint-parameters") o.checkpoint_parameters = true;
     else if (key == "W" || key == "watch-period") o.watch_period = std::atol(value(val).c_str());
+    else if (key == "w" || key == "watch-rule") o.watch_rule = std::atol(value(val).c_str());
+    else if (key == "D" || key == "watch-depth") o.watch_depth = std::atol(value(val).c_str());
+    else if (key == "R" || key == "rules-file") o.rules_file = value(val);
     else if (key == "V" || key == "checkpoint-viterbi-per-examples") o.viterbi_per = std::atol(value(val).c_str());
     else if (key == "Z" || key == "checkpoint-per-forest-counts") o.per_forest_counts_per = std::atol(value(val).c_str());
     else if (key == "X" || key == "report-counts-exceeding") {
@@ -491,6 +501,59 @@ int main(int argc, char** argv) {
       bool very_first = true;
       long restarts_left = o.restarts;
       const bool count_report = !(std::isinf(o.report_counts) && o.report_counts > 0 && std::isinf(o.report_probs) && o.report_probs > 0);
+      // FForests::watch_report (forest-em.hpp:583-616): the watched group's members in the order the reports leave them (the
+      // reference sorts the group's own member list in place; here the device's normalisation keeps the file's order -- the sums
+      // of that one group may differ from the reference's in the last bit after the first report)
+      std::vector<uint32_t> watch_members;
+      std::vector<std::string> rule_names;
+      if (o.watch_rule > 0) {
+        for (size_t g = 0; g + 1 < group_off.size() && watch_members.empty(); ++g)  // find_group_holding (normalize.hpp:79-91)
+          for (uint64_t j = group_off[g]; j < group_off[g + 1]; ++j)
+            if (group_rule[j] == (uint32_t)o.watch_rule) {
+              watch_members.assign(group_rule.begin() + group_off[g], group_rule.begin() + group_off[g + 1]);
+              break;
+            }
+        if (watch_members.empty())
+          throw std::runtime_error("Couldn't find rule " + std::to_string(o.watch_rule) + " in any normalization groups.\n");
+        if (o.rules_file != "-0") {
+          std::istringstream in(slurp(o.rules_file));
+          for (std::string line; std::getline(in, line);) rule_names.push_back(line);
+          if (rule_names.size() < n_rules - 1) {  // load_rule_names (forest-em.hpp:320-332)
+            const std::string error = "Not enough lines in rule names file (" + std::to_string(n_rules - 1) + " expected, got " +
+                                      std::to_string(rule_names.size()) + ")";
+            log << error << std::endl;
+            throw std::runtime_error(error);
+          }
+        }
+      }
+      auto watch_report = [&]() {
+        if (watch_members.empty()) return;
+        std::vector<double> cw(n_rules);
+        check(carmel_hip_forests_get_weights(F, cw.data()), "carmel_hip_forests_get_weights");
+        auto gt = [&](uint32_t a, uint32_t b) { return cw[a] > cw[b]; };  // indirect_gt over the rule weights
+        const size_t size = watch_members.size();
+        const size_t depth = std::min<size_t>((size_t)std::max<long>(o.watch_depth, 0), size);
+        auto b = watch_members.begin(), mid = b + depth, end = watch_members.end();
+        // (`firsttime` is already false when maximize gets here, forest-em.hpp:622-626: a group whose first ranking is the
+        // file's order is reported as unchanged)
+        if (std::is_sorted(b, mid, gt)) {
+          log << " (no change in rank order of top " << depth << " rules)";
+          return;
+        }
+        if (mid != end)
+          std::partial_sort(b, mid, end, gt);
+        else
+          std::sort(b, end, gt);
+        log << "\nNew top " << depth << " rules for normalization group:";
+        for (; b != mid; ++b) {
+          // boost::format("\n%1% %|15t|%2% (id = %3%)"): the weight (15 digits, the stream's default spelling), padded to column 15
+          std::string line = "\n" + format_weight(cw[*b], W_SOMETIMES_LOG) + " ";
+          if (line.size() < 15) line.append(15 - line.size(), ' ');
+          line += (rule_names.empty() ? std::to_string(*b - 1) : rule_names[*b - 1]) + " (id = " + std::to_string(*b) + ")";
+          log << line;
+        }
+        log << std::endl;
+      };
       for (uint32_t restart = 0;; ++restart) {
       double last = -std::numeric_limits<double>::infinity();
       bool first = true;
@@ -543,6 +606,7 @@ int main(int argc, char** argv) {
         // FForests::maximize's tail (forest-em.hpp:638-653): on a watch iteration the parameters and the counts they were
         // normalised from are dumped (dump_params :172-189) and the counts above the thresholds counted
         if (m_steps <= o.watch_period || (o.watch_period && m_steps % o.watch_period == 0)) {
+          watch_report();
           if (o.checkpoint_parameters || count_report) {
             std::vector<double> cw(n_rules), cc(n_rules);
             check(carmel_hip_forests_get_counts(F, o.prior_counts, cc.data()), "carmel_hip_forests_get_counts");

@@ -160,6 +160,81 @@ def test_forest_em_cli_checkpoints_on_watch_iterations(oracle, golden_dir, tmp_p
     assert rc == 0 and "Writing trained parameters" not in err
 
 
+def _fmt_weight(lw):
+    """weight.h:468-489 at the stream's defaults: the number while it fits a double comfortably, e^x otherwise; 15 digits"""
+    if lw == -np.inf:
+        return "0"
+    return "%.15g" % math.exp(lw) if -82.0 < lw < 82.0 else "e^%.15g" % lw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("names", [False, True])
+def test_forest_em_cli_watch_rule(oracle, golden_dir, tmp_path, names):
+    """-w RULE -D DEPTH [-R names] (forest-em-params.hpp:134-137, 150-151; FForests::watch_report, forest-em.hpp:583-616): on watch
+    iterations, after the M-step, the top DEPTH rules by weight of the normalisation group that holds RULE -- or that their order
+    has not changed.  Restated here over the oracle's weights after every M-step: the same ranking (std::partial_sort's, ties
+    aside: the weights of a rank are compared), the same lines (weight at 15 digits, padded to column 15, the rule's description
+    or -- without -R -- its number less one, FileLines::getline of no file), the same 'no change' notes; a rule in no group and
+    a names file that is too short are refused as the reference refuses them"""
+    f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
+    of = oracle.OracleForests(open(f).read(), open(n).read())
+    of.init_rule_weights()
+    groups = [[int(x) for x in g.split()] for g in re.findall(r"\(([^()]*)\)", open(n).read()) if g.strip()]
+    group = max(groups, key=len)
+    rule, depth = group[-1], 3
+    args = ["-f", f, "-n", n, "-i", "6", "-e", "-1", "-d", "-1", "-W", "2", "-w", str(rule), "-D", str(depth)]
+    label = lambda r: str(r - 1)
+    if names:
+        rf = tmp_path / "rules"
+        rf.write_text("".join("rule number %d -> x\n" % (r + 1) for r in range(of.n_rules - 1)))
+        args += ["-R", str(rf)]
+        label = lambda r: "rule number %d -> x" % r
+    rc, so, err = run(args)
+    assert rc == 0, err
+    lines = err.split("\n")
+    members = list(group)
+    d = min(depth, len(members))
+    pos = 0
+    n_reports = n_same = 0
+    for m in range(6):
+        of.estimate()
+        of.maximize()
+        if not (m <= 2 or m % 2 == 0):
+            continue
+        w = of.weights()
+        # (an unchanged ranking's note ends without a newline, as the reference's does: the next iteration's line follows it)
+        it = [k for k in range(pos, len(lines)) if re.search(r"(^|\))i=%d " % (m + 1), lines[k])][0]
+        pos = it + 1
+        top = sorted(members, key=lambda r: -w[r])[:d]
+        if all(w[members[k]] >= w[members[k + 1]] for k in range(d - 1)):
+            assert lines[it + 1].startswith(" (no change in rank order of top %d rules)" % d), lines[it:it + 3]
+            n_same += 1
+            continue
+        assert lines[it + 1] == "" and lines[it + 2] == "New top %d rules for normalization group:" % d, lines[it:it + 4]
+        got = lines[it + 3:it + 3 + d]
+        for k, line in enumerate(got):
+            mt = re.match(r"^(\S+) +(.*) \(id = (\d+)\)$", line)
+            assert mt, line
+            r = int(mt.group(3))
+            assert r in members and mt.group(2) == label(r)
+            assert w[r] == pytest.approx(w[top[k]], rel=1e-9)  # (the k-th weight; equal weights may swap places)
+            assert parse_vec(mt.group(1))[0] == pytest.approx(math.exp(w[r]), rel=1e-9)
+            head = "\n" + mt.group(1) + " "
+            assert line.startswith((head + " " * max(0, 15 - len(head)))[1:] + label(r))
+        # (the report leaves the group's list in its new order: the next 'no change' is judged against it)
+        rest = [r for r in members if r not in [int(re.search(r"id = (\d+)", x).group(1)) for x in got]]
+        members = [int(re.search(r"id = (\d+)", x).group(1)) for x in got] + rest
+        n_reports += 1
+    assert n_reports >= 1 and n_reports + n_same == 4  # (M-steps 1, 2, 3 and 5: the first W + 1 and every W-th after)
+    rc, so, err = run(["-f", f, "-n", n, "-i", "2", "-w", str(of.n_rules + 7)])
+    assert rc != 0 and "Couldn't find rule %d in any normalization groups." % (of.n_rules + 7) in err
+    if names:
+        short = tmp_path / "short"
+        short.write_text("only one\n")
+        rc, so, err = run(["-f", f, "-n", n, "-i", "2", "-w", str(rule), "-R", str(short)])
+        assert rc != 0 and "Not enough lines in rule names file (%d expected, got 1)" % (of.n_rules - 1) in err
+
+
 @pytest.mark.gpu
 def test_forest_em_cli_options(oracle, tmp_path):
     """initial parameters (-I), add-k smoothing, prior counts, counts output (-O), human probs (-H)"""
