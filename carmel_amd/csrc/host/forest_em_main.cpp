@@ -73,6 +73,10 @@ struct Opts {
   // watch_depth rules of the normalisation group that holds it, by weight
   long watch_rule = 0;               // -w / --watch-rule (0: none)
   long watch_depth = 20;             // -D / --watch-depth
+  // rule files annotated by id (forest-em-params.hpp:158-165, forest-em-params.cpp:135-143; insert_byid, io.hpp:653-709): a copy of
+  // -b with " <F>=weight <C>=count" behind every id=N that stands at a word boundary, under a $$$ header line
+  std::string byid_rule_file = "-0", byid_output_file = "-0";  // -b / --byid-rule-file, -B / --byid-output-file
+  std::string byid_prob_field = "emprob", byid_count_field = "emcount";  // -F / --byid-prob-field, -C / --byid-count-field
   std::string rules_file = "-0";     // -R / --rules-file: a description per rule, line i for rule i (without one: the number i - 1,
                                      // FileLines::getline of no file, filelines.hpp:80-83)
 };
@@ -84,7 +88,7 @@ void usage() {
                "                  --crp-restarts=R [--crp-argmax-final | --crp-argmax-sum]\n"
                "                  --prior-inference-stddev=S [--prior-inference-global|-local] [--prior-inference-start=I --prior-inference-end=J] [--prior-inference-show] [--outsample-file=F]]\n"
                "                 [-x checkpoint-prefix -c -V viterbi-per -Z per-forest-counts-per] [-W watch-period] [-X report-counts-exceeding] [-Y report-probs-exceeding]\n"
-               "                 [-w watch-rule -D watch-depth -R rules-file]\n"
+               "                 [-w watch-rule -D watch-depth -R rules-file] [-b byid-rule-file -B byid-output-file -F prob-field -C count-field]\n"
                "                 [--random-seed=S] [--gpu=D]\n"
                "file arguments: '-' = stdin/stdout, '-0' = none\n";
 }
@@ -230,6 +234,10 @@ Opts parse_args(int argc, char** argv) {
     else if (key == "w" || key == "watch-rule") o.watch_rule = std::atol(value(val).c_str());
     else if (key == "D" || key == "watch-depth") o.watch_depth = std::atol(value(val).c_str());
     else if (key == "R" || key == "rules-file") o.rules_file = value(val);
+    else if (key == "b" || key == "byid-rule-file") o.byid_rule_file = value(val);
+    else if (key == "B" || key == "byid-output-file") o.byid_output_file = value(val);
+    else if (key == "F" || key == "byid-prob-field") o.byid_prob_field = value(val);
+    else if (key == "C" || key == "byid-count-field") o.byid_count_field = value(val);
     else if (key == "V" || key == "checkpoint-viterbi-per-examples") o.viterbi_per = std::atol(value(val).c_str());
     else if (key == "Z" || key == "checkpoint-per-forest-counts") o.per_forest_counts_per = std::atol(value(val).c_str());
     else if (key == "X" || key == "report-counts-exceeding") {
@@ -276,6 +284,7 @@ int main(int argc, char** argv) {
       ForestReader(text, fs).read_all();
     }
     if (fs.n_forests() == 0) throw std::runtime_error("no forests in " + o.forests_file);
+    if (o.byid_output_file != "-0" && o.byid_rule_file == "-0") throw std::runtime_error("Must provide byid-rule-file.");  // forest-em-params.cpp:55-56
     if (o.normgroups_file == "-0" && (o.max_iter || o.normalize_initial))  // forest-em-params.cpp:59-60
       throw std::runtime_error("Missing normgroups-file.\n");
     std::vector<uint64_t> group_off(1, 0);
@@ -697,6 +706,89 @@ int main(int argc, char** argv) {
         spit(o.out_inside_file, out);
       }
       log << "\n";
+    }
+    if (o.byid_output_file != "-0") {
+      // the counts are the table the EM loop's last estimate left (what -O prints); a run that never prepared EM has none
+      // (forest-em.hpp:213: counts.size() == 0 -- the sampler, -i 0)
+      std::vector<double> lc;
+      if (o.crp <= 0 && o.max_iter > 0) {
+        std::vector<double> counts(n_rules);
+        check(carmel_hip_forests_get_counts(F, o.prior_counts, counts.data()), "carmel_hip_forests_get_counts");
+        lc.resize(n_rules);
+        for (uint32_t r = 0; r < n_rules; ++r) lc[r] = counts[r] > 0 ? std::log(counts[r]) : -std::numeric_limits<double>::infinity();
+      }
+      const std::string in = slurp(o.byid_rule_file);
+      std::string out = "$$$";
+      size_t p = 0;
+      // copy_header (fileheader.hpp:65-83): an input that starts with $$$ keeps its header line and gets ours appended to it; one
+      // that does not gets a new one, and whatever it matched of "$$$" -- consumed by then -- goes behind it
+      while (p < in.size() && p < 3 && in[p] == '$') ++p;
+      std::string partial;
+      if (p == 3) {
+        while (p < in.size() && in[p] != '\n') out += in[p++];
+        if (p < in.size()) ++p;
+      } else {
+        out += " filetype=rule version=1.0";
+        partial = in.substr(0, p);
+      }
+      // ForestEmParams::print (forest-em-params.hpp:313-315); the command line as get_command_line spells it (shell_escape.hpp)
+      std::string cmd;
+      for (int a = 0; a < argc; ++a) {
+        const std::string arg = argv[a];
+        const char* special = " \t\n\\><|&;\"'`~*?{}$!()";
+        if (a) cmd += ' ';
+        if (arg.empty())
+          cmd += "\"\"";
+        else if (arg.find_first_of(special) == std::string::npos)
+          cmd += arg;
+        else {
+          cmd += '"';
+          for (char c : arg) {
+            if (c == '\\' || c == '"' || c == '$' || c == '`' || c == '!') cmd += '\\';
+            cmd += c;
+          }
+          cmd += '"';
+        }
+      }
+      out += " forest-em-version= {{ {v20}}} floating-point-precision= {{ {double}}} forest-em-cmdline= {{ {" + cmd + "}}}\n" + partial;
+      auto fields = [&](unsigned N) {  // FForests::operator()(out, ruleid), forest-em.hpp:205-211
+        if (N < n_rules && !o.byid_prob_field.empty()) out += " " + o.byid_prob_field + "=" + (N ? format_weight(logw[N], style) : std::string("0"));
+        if (N < lc.size() && !o.byid_count_field.empty()) out += " " + o.byid_count_field + "=" + (N ? format_weight(lc[N], style) : std::string("0"));
+      };
+      // insert_byid's state machine (io.hpp:653-709), quirks and all: "id=" counts at the start of the input and after exactly one
+      // blank; a blank in the `waiting for i` state, or a mismatch on a non-blank, sends it back to waiting for a blank
+      enum { WAIT_SPACE, WAIT_I, SEEN_I, SEEN_ID, SCAN } st = WAIT_I;
+      unsigned N = 0;
+      for (; p < in.size(); ++p) {
+        const char c = in[p];
+        auto was_space = [&]() {
+          if (c == ' ' || c == '\n' || c == '\t') st = WAIT_I;
+        };
+        switch (st) {
+          case WAIT_SPACE: was_space(); break;
+          case WAIT_I: st = c == 'i' ? SEEN_I : WAIT_SPACE; break;
+          case SEEN_I: st = c == 'd' ? SEEN_ID : WAIT_SPACE; break;
+          case SEEN_ID:
+            if (c == '=') {
+              N = 0;
+              st = SCAN;
+            } else
+              st = WAIT_SPACE;
+            break;
+          case SCAN:
+            if (c >= '0' && c <= '9')
+              N = N * 10 + (unsigned)(c - '0');
+            else {
+              st = WAIT_SPACE;
+              fields(N);
+              was_space();
+            }
+            break;
+        }
+        out += c;
+      }
+      if (st == SCAN) fields(N);  // (the file ends without a newline)
+      spit(o.byid_output_file, out);
     }
     carmel_hip_forests_destroy(F);
     return 0;

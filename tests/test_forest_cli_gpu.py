@@ -236,6 +236,56 @@ def test_forest_em_cli_watch_rule(oracle, golden_dir, tmp_path, names):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("header", [False, True])
+def test_forest_em_cli_rules_by_id(golden_dir, tmp_path, header):
+    """-b RULES -B OUT [-F field -C field] (forest-em-params.hpp:158-165, forest-em-params.cpp:135-143): RULES copied with
+    " emprob=<weight> emcount=<count>" behind every id=N at a word boundary -- the numbers -o and -O print for rule N -- under a
+    $$$ header line that carries the version and the command line (an existing header line is kept and extended).  insert_byid's
+    state machine (io.hpp:653-709) is restated here with its quirks: id= after two blanks, or inside a word, is not an id"""
+    f, n = os.path.join(golden_dir, "fem.forests"), os.path.join(golden_dir, "fem.norm")
+    body = "id=1 first rule\nS(x0:NP) -> x0 ### id=3 more\nxid=4 no boundary\ntwo  id=5 blanks\ntab\tid=6\nidd=2 i id=2\nlast id=7"
+    rules = tmp_path / "rules"
+    rules.write_text(("$$$ filetype=rule version=0.9 made by hand\n" if header else "") + body)
+    o1, o2, ob = (str(tmp_path / x) for x in ("o", "O", "B"))
+    args = ["-f", f, "-n", n, "-i", "4", "-o", o1, "-O", o2, "-b", str(rules), "-B", ob, "-F", "p", "-C", "c count"]
+    rc, so, err = run(args)
+    assert rc == 0, err
+    w = open(o1).read().strip().strip("()").split()
+    c = open(o2).read().strip().strip("()").split()
+    got = open(ob).read()
+    head, rest = got.split("\n", 1)
+    cmd = " ".join([CLI] + [('"%s"' % a if " " in a else a) for a in args])
+    tail = " forest-em-version= {{ {v20}}} floating-point-precision= {{ {double}}} forest-em-cmdline= {{ {" + cmd + "}}}"
+    assert head == ("$$$ filetype=rule version=0.9 made by hand" if header else "$$$ filetype=rule version=1.0") + tail
+    out, st, N = "", "wait_i", 0
+    fields = lambda k: " p=%s c count=%s" % (w[k - 1], c[k - 1]) if 0 < k <= len(w) else ""
+    for ch in body:
+        space = ch in " \n\t"
+        if st == "wait_space":
+            st = "wait_i" if space else st
+        elif st == "wait_i":
+            st = "seen_i" if ch == "i" else "wait_space"
+        elif st == "seen_i":
+            st = "seen_id" if ch == "d" else "wait_space"
+        elif st == "seen_id":
+            st, N = ("scan", 0) if ch == "=" else ("wait_space", N)
+        else:
+            if ch.isdigit():
+                N = N * 10 + int(ch)
+            else:
+                out += fields(N)
+                st = "wait_i" if space else "wait_space"
+        out += ch
+    if st == "scan":
+        out += fields(N)
+    assert rest == out
+    assert " p=" in out.split("\n")[0] and "id=3 p=" in out and "xid=4 no" in out and "two  id=5 blanks" in out and "tab\tid=6 p=" in out
+    assert out.endswith("last id=7 p=%s c count=%s" % (w[6], c[6]))
+    rc, so, err = run(["-f", f, "-n", n, "-i", "1", "-B", ob])
+    assert rc != 0 and "Must provide byid-rule-file." in err
+
+
+@pytest.mark.gpu
 def test_forest_em_cli_options(oracle, tmp_path):
     """initial parameters (-I), add-k smoothing, prior counts, counts output (-O), human probs (-H)"""
     from test_forest_gpu import synth_forests
