@@ -71,3 +71,21 @@ def test_parameter_files_are_written_and_read_as_the_reference_does(tmp_path):
         assert vals[0] == pytest.approx(math.log(0.5)) and vals[1] == pytest.approx(-300.0) and vals[2] == -math.inf
         assert vals[3] == 0.0 and vals[4] == pytest.approx(math.log(0.125))
     assert float(rows[1][2]) == pytest.approx(-300.0, rel=1e-12)
+
+
+def test_forest_em_refuses_what_the_reference_refuses_before_any_device_call(tmp_path):
+    """forest-em-params.cpp:55-60: an annotated rule file without the rule file, EM without normalisation groups -- and no device is
+    asked for before the complaint (there is none here); unknown switches are refused too"""
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    cli = os.path.join(ROOT, "carmel_amd", "bin", "forest-em")
+    if not os.path.exists(cli):
+        pytest.skip("front end not built")
+    f, n = os.path.join(GOLDEN, "fem.forests"), os.path.join(GOLDEN, "fem.norm")
+    run = lambda args: subprocess.run([cli] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+    p = run(["-f", f, "-n", n, "-i", "1", "-B", str(tmp_path / "out")])
+    assert p.returncode != 0 and "Must provide byid-rule-file." in p.stderr and not os.path.exists(tmp_path / "out")
+    p = run(["-f", f, "-i", "1"])
+    assert p.returncode != 0 and "Missing normgroups-file." in p.stderr
+    p = run(["-f", f, "-n", n, "--no-such-switch"])
+    assert p.returncode != 0 and "unknown option" in p.stderr
