@@ -33,6 +33,11 @@ def build(mode, rank, world):
         w = synth.random_wfst(3001, 7, n_sym=5, p_eps=0.15, seed=4)
         c = synth.random_walk_corpus(w, 4001, min_arcs=3, max_arcs=14, seed=4, out_degree=7)
         return w, HipForwardBackward(w, c.shard(rank, world), device=0)
+    if mode == "waves":  # one-per-wavefront lattices: weights gathered from the table, posteriors straight to the count pass's input
+        w, c = synth.make_config("long", n_pairs=36)
+        fb = HipForwardBackward(w, c.shard(rank, world), device=0)
+        assert fb.weight_source & 6 == 6, "expected gathering wave sweeps that write XC"
+        return w, fb
     from oracle import binding as ob
     g = lambda n: open(os.path.join(ROOT, "tests", "golden", n)).read()
     if mode == "dense":  # config 3's shape: the unrolled sweep in its rank-1 dense form (dense.hpp), counts per channel parameter

@@ -138,6 +138,18 @@ def test_sharded_exchange_over_run_length_indices(tmp_path, monkeypatch):
     np.testing.assert_array_equal(runs["0"], runs["1"])
 
 
+def test_sharded_exchange_on_one_per_wavefront_lattices(tmp_path):
+    """the exchange under the round's last E-step: wave sweeps that gather their weights from the table the all-gather fills
+    (no bucket pass behind the arriving chunks) and write the count pass's input themselves (no tile pass in front of the chunked
+    bucket passes) -- two ranks, both sharded forms against the all-reduce, bit for bit"""
+    plain = _run(2, "waves", tmp_path, "wv_plain", extra=["--rccl", _plugin("wvp"), "--plan-allreduce", "--check-counts"])
+    assert plain[-1] == 0.0
+    for form in ("direct", "collectives"):
+        sh = _run(2, "waves", tmp_path, "wv_" + form, extra=["--rccl", _plugin("wv" + form[0]), "--plan", "--check-counts", "--form=" + form])
+        assert sh[-1] == 1.0, "the exchange was not planned in its sharded form"
+        np.testing.assert_array_equal(sh[:-1], plain[:-1], err_msg=form)
+
+
 def test_sharded_exchange_with_one_rank_is_the_plain_trainer(tmp_path):
     """world 1 over RCCL (the collectives run, nothing travels): the sharded M-step over block ranges and the chunked bucket
     passes are the plain ones, so the run must equal the plain trainer bit for bit"""
