@@ -32,7 +32,10 @@ def build(mode, rank, world):
     if mode == "synth-big":  # enough arcs for the sharded exchange (world * 512 at least), groups straddling piece boundaries
         w = synth.random_wfst(3001, 7, n_sym=5, p_eps=0.15, seed=4)
         c = synth.random_walk_corpus(w, 4001, min_arcs=3, max_arcs=14, seed=4, out_degree=7)
-        return w, HipForwardBackward(w, c.shard(rank, world), device=0)
+        fb = HipForwardBackward(w, c.shard(rank, world), device=0)
+        if os.environ.get("CARMEL_HIP_TILE_GATHER") in ("0", "1"):  # (the test that forces the tile passes' source of weights)
+            assert (fb.weight_source & 1) == int(os.environ["CARMEL_HIP_TILE_GATHER"])
+        return w, fb
     if mode == "waves":  # one-per-wavefront lattices: weights gathered from the table, posteriors straight to the count pass's input
         w, c = synth.make_config("long", n_pairs=36)
         fb = HipForwardBackward(w, c.shard(rank, world), device=0)

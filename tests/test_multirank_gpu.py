@@ -138,6 +138,19 @@ def test_sharded_exchange_over_run_length_indices(tmp_path, monkeypatch):
     np.testing.assert_array_equal(runs["0"], runs["1"])
 
 
+def test_sharded_exchange_with_the_tiles_weights_from_the_table(tmp_path, monkeypatch):
+    """under a plan the tile passes may fetch their weights from the table the all-gather fills (CARMEL_HIP_TILE_GATHER=1: the
+    trainer's stream waits for the chunks and runs no bucket pass behind them) or from X (0: a bucket pass per arriving chunk):
+    the same weights after four iterations, bit for bit, two ranks"""
+    monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", "0")
+    runs = {}
+    for g in ("1", "0"):
+        monkeypatch.setenv("CARMEL_HIP_TILE_GATHER", g)
+        runs[g] = _run(2, "synth-big", tmp_path, "tg" + g, extra=["--rccl", _plugin("tg" + g), "--plan", "--check-counts"])
+        assert runs[g][-1] == 1.0
+    np.testing.assert_array_equal(runs["1"], runs["0"])
+
+
 def test_sharded_exchange_on_one_per_wavefront_lattices(tmp_path):
     """the exchange under the round's last E-step: wave sweeps that gather their weights from the table the all-gather fills
     (no bucket pass behind the arriving chunks) and write the count pass's input themselves (no tile pass in front of the chunked
