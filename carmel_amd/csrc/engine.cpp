@@ -264,7 +264,9 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
       }
       if (done) {
         if (getenv("CARMEL_TIMING")) fprintf(stderr, "timing: lattices built on the GPU\n");
-        return build_run_tables(t);
+        rc = build_run_tables(t);
+        if (stats) stats->device_bytes = t->device_bytes;  // (with the run tables / the tiles' arc ids)
+        return rc;
       }
     }
   }

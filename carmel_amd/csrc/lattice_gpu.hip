@@ -866,6 +866,11 @@ int build_run_tables(carmel_hip_trainer* t) {
   if (rc) return rc;
   rc = build_wave_items(t);
   if (rc) return rc;
+  struct Account {  // what this function leaves allocated counts as the lattices' device memory
+    carmel_hip_trainer* t;
+    ~Account() { t->device_bytes += t->t_t_arc.bytes() + t->wave_xc_idx.bytes() + t->tr_off.bytes() + t->tr_rel.bytes() + t->tr_src.bytes() +
+                                    t->br_off.bytes() + t->br_rel.bytes() + t->br_src.bytes(); }
+  } account{t};
   // A WFST whose weights the last-level cache holds (128 MB of them in its 256 MB), whose arcs lie in many lattices each (four
   // items an arc and more) and a transposition with per-item indices: the tile pass (or the tile sweep) can fetch a tile's
   // weights from the table itself -- through t_t_arc, the arc of every tile-major item -- instead of from X, and the bucket pass
