@@ -335,11 +335,11 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   if (xp->direct) {
     // the M-step on the communicator's stream, behind the sums it reads and ahead of the groups that carry its weights: one
     // hop between the streams per iteration (count pass -> exchange) instead of three
-    if (M.lw_src || !xp->m_ready) {  // (mstep_args left a snapshot copy / first-time scratch on the trainer's stream)
-      HIPCHK(hipEventRecord(xp->ev_m_done, s));
-      HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
-      xp->m_ready = true;
-    }
+    // mstep_args may have left work on the trainer's stream on ANY call (a snapshot copy, first-time scratch, max_partial
+    // re-allocated and cleared after a new set_norm / set_prior): the M-step waits for it every time -- one event
+    HIPCHK(hipEventRecord(xp->ev_m_done, s));
+    HIPCHK(hipStreamWaitEvent(x, xp->ev_m_done, 0));
+    xp->m_ready = true;
     HIPCHK(launch_mstep_window_range(M, 1, 0, cum, x));
     HIPCHK(launch_mstep_max_final(M, x));
   } else {
@@ -399,10 +399,10 @@ extern "C" {
 
 int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int form) {
   if (form < 0 || form > 3) return fail(CARMEL_HIP_ERR_ARG, "carmel_hip_exchange_plan: form is 0 (choose), 1 (all-reduce), 2 (collectives) or 3 (direct)");
+  if (!t || !c) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (form == 3 && !comm_has_p2p(c))
     return fail(CARMEL_HIP_ERR_UNSUPPORTED, "carmel_hip_exchange_plan: the transport has no point-to-point transfers (carmel_hip_comm_set_sendrecv)");
   const bool force_allreduce = form == 1;
-  if (!t || !c) return fail(CARMEL_HIP_ERR_ARG, "null argument");
   if (t->device != c->device) return fail(CARMEL_HIP_ERR_ARG, "trainer and communicator live on different devices");
   if (!t->have_lattices) return fail(CARMEL_HIP_ERR_STATE, "build_lattices first");
   HIPCHK(hipSetDevice(t->device));

@@ -726,7 +726,7 @@ static int run(int argc, char** argv) {
   // --disk-cache-derivations with lattices beyond --disk-cache-bufsize: the corpus in shards of pairs [stream_cut[k], stream_cut[k+1]),
   // never more than one shard's lattices resident (set by train_em; empty: everything is resident)
   std::vector<size_t> stream_cut;
-  bool stream_prune = true;
+  bool streaming = false, stream_prune = true;
   auto set_corpus_range = [&](size_t lo, size_t hi) {
     std::vector<uint64_t> io(1, 0), oo(1, 0);
     for (size_t p = lo; p < hi; ++p) {
@@ -737,16 +737,26 @@ static int run(int argc, char** argv) {
                                     pairs.out_sym.data() + pairs.out_off[lo], pairs.weight.data() + lo),
               "carmel_hip_set_corpus");
   };
+  // A corpus every pair of which has probability 1: the reference's log-domain arithmetic lands on ln P = 0 exactly (a count
+  // divided by itself, weight.h:737-830) and its convergence test becomes the quotient of two zeros (weight.h:247-249,
+  // train.cc:611,630: the run goes on to -M); sums of exponentials land within an ulp or two of it, on either side, and the
+  // same test then sees a ratio of -1e16 or 1.  A corpus probability within two ulps per pair of 1 therefore counts as 1.
+  auto snap_certain = [](carmel_hip_estimate_result* er) {
+    const double tol = 4.45e-16 * (double)std::max<uint64_t>(er->n_pairs, 1);
+    if (std::fabs(er->sum_logprob) <= tol) er->sum_logprob = 0.0;
+    if (std::fabs(er->sum_weighted_logprob) <= tol) er->sum_weighted_logprob = 0.0;
+  };
   // one E-step over the whole corpus: the count pass on this rank's shard, then (N > 1) the sum over the ranks
-  auto estimate_all = [&](carmel_hip_estimate_result* er) {
-    if (stream_cut.size() > 2) {
-      // shard by shard: lattices rebuilt, swept, dropped; the count buffers (counts + corpus scalars) added up on the device
+  auto estimate_all_raw = [&](carmel_hip_estimate_result* er) {
+    if (streaming) {
+      // shard by shard: lattices rebuilt, swept, dropped; the count buffers (counts + corpus scalars) added up on the device.
+      // A shard none of whose pairs has a derivation adds zeros: the reference gives up only when NO pair of the corpus has one
+      // (train.cc:241-252; train_em checks the summed count of kept pairs)
       hip_check(carmel_hip_accumulate_counts(t, 0), "carmel_hip_accumulate_counts");
       for (size_t k = 0; k + 1 < stream_cut.size(); ++k) {
         set_corpus_range(stream_cut[k], stream_cut[k + 1]);
         hip_check(carmel_hip_build_lattices(t, stream_prune ? 1 : 0, 0, nullptr, nullptr), "carmel_hip_build_lattices");
-        carmel_hip_estimate_result part;
-        hip_check(carmel_hip_estimate(t, &part, 0), "carmel_hip_estimate");
+        hip_check(carmel_hip_estimate_async(t), "carmel_hip_estimate_async");
         hip_check(carmel_hip_accumulate_counts(t, 1), "carmel_hip_accumulate_counts");
       }
       hip_check(carmel_hip_accumulate_counts(t, 2), "carmel_hip_accumulate_counts");
@@ -761,6 +771,10 @@ static int run(int argc, char** argv) {
     hip_check(carmel_hip_estimate_async(t), "carmel_hip_estimate_async");
     hip_check(carmel_hip_allreduce_counts(t, comm), "carmel_hip_allreduce_counts");
     hip_check(carmel_hip_read_scalars(t, er), "carmel_hip_read_scalars");
+  };
+  auto estimate_all = [&](carmel_hip_estimate_result* er) {
+    estimate_all_raw(er);
+    snap_certain(er);
   };
   std::vector<uint64_t> coff(1, 0), cpar;
   if (cascade) {
@@ -850,6 +864,7 @@ static int run(int argc, char** argv) {
   std::vector<uint8_t> has(pairs.size(), 0);
   carmel_hip_lattice_stats ls;
   stream_cut.clear();
+  streaming = false;
   stream_prune = !o.cache_no_prune;
   const bool may_stream = o.stream_lattices && !o.crp && !o.matrix_fb && pairs.size() > 1;  // (--matrix-fb keeps no lattices)
   if (may_stream) {
@@ -862,8 +877,15 @@ static int run(int argc, char** argv) {
     hip_check(carmel_hip_build_lattices(t, stream_prune ? 1 : 0, 0, nullptr, &ps), "carmel_hip_build_lattices");
     const double per_pair = (double)ps.device_bytes / (double)probe;
     const double cap = o.resident_bytes ? (double)o.resident_bytes : 64.0 * 1024 * 1024 * 1024;
-    if (per_pair * (double)n > cap) {
-      const size_t per_shard = std::max<size_t>(64, (size_t)(cap / std::max(per_pair, 1.0)));
+    // the ranks decide TOGETHER: a rank that streams keeps explicit lattices, plans no exchange and issues the plain all-reduce
+    // once per iteration, so if one shard of the corpus is over its budget every rank streams (its own lattices in as many
+    // shards as its own probe says, one if they fit) -- ranks on either side of the threshold would otherwise wait in
+    // different collectives, or add up count buffers that mean different things
+    double any_over[1] = {per_pair * (double)n > cap ? 1.0 : 0.0};
+    if (comm) hip_check(carmel_hip_comm_allreduce_host(comm, any_over, 1, 1), "carmel_hip_comm_allreduce_host");
+    streaming = any_over[0] != 0.0;
+    if (streaming) {
+      const size_t per_shard = std::max<size_t>(64, (size_t)std::min<double>(cap / std::max(per_pair, 1.0), 1e18));
       for (size_t lo = 0; lo < n; lo += per_shard) stream_cut.push_back(lo);
       stream_cut.push_back(n);
       if (!quiet)
@@ -871,7 +893,7 @@ static int run(int argc, char** argv) {
                   << (uint64_t)cap << " allowed they are rebuilt every iteration in " << stream_cut.size() - 1 << " shards of " << per_shard << " pairs\n";
     }
   }
-  if (stream_cut.size() > 2) {
+  if (streaming) {
     // first pass: which pairs have a derivation, and the statistics of all shards
     std::memset(&ls, 0, sizeof ls);
     for (size_t k = 0; k + 1 < stream_cut.size(); ++k) {
@@ -909,7 +931,7 @@ static int run(int argc, char** argv) {
     std::cerr << "timing: lattices pairs_kept=" << ls.n_pairs_kept << " states=" << ls.kept_states << " arcs=" << ls.kept_arcs
               << " layout=" << (carmel_hip_lattice_layout(t) == 2 ? "unrolled_dense" : carmel_hip_lattice_layout(t) == 1 ? "unrolled" : "explicit") << " device_bytes=" << ls.device_bytes
               << " build_seconds=" << ls.build_seconds << std::endl;
-  if (comm && !o.crp && stream_cut.size() <= 2) {
+  if (comm && !o.crp && !streaming) {
     // every rank must hold its lattices in the same layout (a shard with one over-long pair would keep explicit lattices
     // while the others unroll, and the count buffers being summed would mean different things): agree, or rebuild all
     // with explicit lattices; then plan the exchange (sharded where the model allows it, csrc/exchange.cpp)
@@ -928,7 +950,7 @@ static int run(int argc, char** argv) {
   // (after --matrix-fb: the matrix E-step leaves no arc-range-ordered count pass to hang reduce-scatters on, so its exchange is
   // planned as the one all-reduce; csrc/exchange.cpp)
   // (streamed lattices: every shard has its own buckets, so the exchange stays the plain all-reduce of the summed buffer)
-  if (comm && !o.crp && stream_cut.size() <= 2) {
+  if (comm && !o.crp && !streaming) {
     // the direct form rests on the transport's point-to-point groups: one such group between all ranks, checked, before the plan
     // is made (carmel_hip_comm_selftest); a transport that fails it on any rank keeps the ring collectives
     int form = o.exchange_form;

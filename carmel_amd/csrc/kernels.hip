@@ -1810,7 +1810,10 @@ hipError_t launch_fill(double* p, double v, uint64_t n, hipStream_t s) {
   return hipGetLastError();
 }
 hipError_t launch_mstep(const MstepArgs& M, int use_counts, hipStream_t s) {
-  if (!M.n) return hipSuccess;
+  if (!M.n) {  // a model without parameters: nothing moves, but the caller waits for THIS M-step's sequence number in the mailbox
+    hipLaunchKernelGGL(mstep_max_final_kernel, dim3(1), dim3(256), 0, s, M.max_partial, (uint64_t)MSTEP_GRID, M.max_change_bits, M.box, M.box_seq);
+    return hipGetLastError();
+  }
   if (M.window_span && !(M.n_ties && M.tie_of)) {
     if (M.lw_src)
       hipLaunchKernelGGL(mstep_window_kernel<true>, dim3((unsigned)((M.n + 255) / 256)), dim3(256), 0, s, M, use_counts, M.window_span);

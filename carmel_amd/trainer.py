@@ -321,6 +321,10 @@ def train(fb, opts=None, log=None):
         if opts.max_iter is not None and it > opts.max_iter and have_good:
             break
         lp, wlp = fb.estimate()
+        # a corpus probability within two ulps per pair of 1 counts as 1: the reference's log-domain arithmetic lands on ln P = 0
+        # exactly there and its convergence test divides zero by zero (host/carmel_main.cpp snap_certain)
+        tol = 4.45e-16 * max(st["n_pairs"], 1)
+        lp, wlp = (0.0 if abs(lp) <= tol else lp), (0.0 if abs(wlp) <= tol else wlp)
         new_ppx = -wlp / W  # ln of p.ppxper(totalEmpiricalWeight)  (weight.h:311)
         rec = dict(iter=it, log2_prob=lp / math.log(2), log2_ppx_symbol=(-lp / n_sym) / math.log(2) if n_sym else 0.0,
                    log2_ppx_example=(-lp / st["n_pairs"]) / math.log(2), n_symbol=n_sym, n_example=st["n_pairs"],

@@ -291,7 +291,7 @@ int carmel_hip_comm_selftest(carmel_hip_comm* c, uint32_t n);
  * 1 = the one all-reduce of counts[n_arcs + 4] and the replicated M-step, 2 = collectives, 3 = direct (refused when the
  * transport cannot).  Other models (cascades, unrolled / dense layouts, tied groups) keep the all-reduce whatever is asked.
  * The results are the same either way up to the order of the sums.  carmel_hip_exchange_info says which form was planned
- * and what one iteration moves per rank; carmel_hip_exchange_measure times the exchange of one iteration on its own (all
+ * (*sharded: 0 = the one all-reduce, 1 = sharded over the collectives, 2 = sharded, direct) and what one iteration moves per rank; carmel_hip_exchange_measure times the exchange of one iteration on its own (all
  * its collectives back to back, nothing to hide behind; collective); carmel_hip_exchange_clear drops the plan.
  * COLLECTIVE while a sharded plan holds reduced pieces (between carmel_hip_allreduce_counts and the next count pass):
  * whatever needs the WHOLE count vector all-gathers it first -- carmel_hip_get_counts, carmel_hip_fractional_counts,

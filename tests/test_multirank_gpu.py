@@ -198,6 +198,53 @@ def test_ranks_with_different_layouts_are_refused_then_rebuilt(tmp_path):
     np.testing.assert_allclose(two[-nlog:-1], one[-nlog:-1], rtol=1e-10)
 
 
+def test_ranks_on_either_side_of_the_resident_budget_stream_together(golden_dir, tmp_path):
+    """carmel --gpus=2 --disk-cache-derivations --disk-cache-bufsize=B where only ONE rank's shard of the corpus is over B
+    (round-5 advisor): a rank that streams keeps explicit lattices, plans no exchange and issues the plain all-reduce, so the
+    ranks must decide together -- one over the budget, every rank streams.  Rank 0 gets the short sentences of the tagging
+    corpus (under the budget), rank 1 the long ones (over it); the run is the one-process resident run."""
+    import re
+    cli = os.path.join(ROOT, "carmel_amd", "bin", "carmel")
+    blocks = open(os.path.join(golden_dir, "tagging.data")).read().split("\n\n")
+    sents = sorted((b.strip("\n") for b in blocks if b.strip()), key=len)
+    short, long_ = sents[:150], sents[-150:]
+    text = lambda ss: "".join("\n" + s_ + "\n" for s_ in ss)
+    files = {}
+    for name, ss in (("short", short), ("long", long_), ("both", short + long_)):
+        files[name] = str(tmp_path / (name + ".data"))
+        open(files[name], "w").write(text(ss))
+    model = [os.path.join(golden_dir, "tagging.fsa"), os.path.join(golden_dir, "tagging.fst")]
+
+    def run(extra, corpus, d, iters=3):
+        os.makedirs(d, exist_ok=True)
+        p = subprocess.run([cli] + extra + ["--train-cascade", "-HJ", "-M", str(iters), corpus] + model, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           universal_newlines=True, env=dict(os.environ, CARMEL_TRAINED_DIR=d), timeout=900)
+        assert p.returncode == 0, p.stderr
+        return p
+    # what each half would take (the front end's own estimate, read off its message)
+    need = {}
+    for name in ("short", "long"):
+        p = run(["--disk-cache-derivations=/tmp/carmel.XXXXXX", "--disk-cache-bufsize=1K"], files[name], str(tmp_path / ("probe_" + name)), iters=1)
+        need[name] = int(re.search(r"would take about (\d+) bytes", p.stderr).group(1))
+    assert need["long"] > 1.3 * need["short"], need
+    budget = (need["short"] + need["long"]) // 2
+    ref = run([], files["both"], str(tmp_path / "one"))
+    two = run(["--gpus=2", "--comm-plugin=" + PLUGIN, "--disk-cache-derivations=/tmp/carmel.XXXXXX", "--disk-cache-bufsize=%d" % budget], files["both"],
+              str(tmp_path / "two"))
+    # rank 0 (the short half) is under the budget and streams all the same: its lattices in one shard
+    assert re.search(r"rebuilt every iteration in 1 shards", two.stderr), two.stderr
+    outs = []
+    for p, d in ((ref, "one"), (two, "two")):
+        trained = "".join(open(str(tmp_path / d / f)).read() for f in sorted(os.listdir(str(tmp_path / d))))
+        outs.append(([l for l in p.stderr.split("\n") if l.startswith("i=")], trained))
+    assert len(outs[0][0]) == len(outs[1][0]) >= 2
+    num = re.compile(r"(?<![\w\"])(\d+\.\d+(?:e[-+]\d+)?|\d+e[-+]\d+)(?![\w\"])")
+    for a, b in zip(outs[0][0] + outs[0][1].split("\n"), outs[1][0] + outs[1][1].split("\n")):
+        assert num.sub("#", a) == num.sub("#", b), (a, b)
+        for u, v in zip(num.findall(a), num.findall(b)):
+            assert float(u) == pytest.approx(float(v), rel=1e-6, abs=1e-300)
+
+
 @pytest.mark.parametrize("args", [["-t", "-M", "6", "epron-jpron.data", "epron-jpron.fst"],
                                   ["--train-cascade", "-HJ", "-M", "5", "cipher.data", "cipher.wfsa", "cipher.fst"],
                                   ["-t", "-M", "4", "-!", "1", "-R", "3", "train.a.w.corpus100", "train.a.w"],
