@@ -1112,6 +1112,10 @@ struct FMultiArgs {
   uint32_t max_tab, max_n, max_front;   // LDS per forest: table words, nodes, frontier entries
   int own_proposal;                     // the kernel computes the rules' proposal probabilities itself (forest_proposal_kernel
                                         // folded in: each AND node scans the forest's previous sample for its own uses)
+  double* prob;                         // own_proposal: per node (in the order of hdr, four words a node) its rule's proposal
+                                        // probability, and the sample is written as NODE numbers: what the recount needs of a
+                                        // sampled rule -- id, class word, norm group, probability -- then lies in the forest's
+                                        // own few lines of hdr / prob instead of three interleaved record streams (round 6)
 };
 __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t& total) {
   // exclusive prefix sum over the FM_G lanes of a forest; total = the sum
@@ -1163,6 +1167,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
   const uint32_t* __restrict__ sc = A.sample_cls + (((uint64_t)d1.y << 32) | d1.x);
   double* __restrict__ recp0 = A.rec_p + g.stream_base + lane;
   const bool own = M.own_proposal != 0;
+  double* __restrict__ probp = M.prob + ((((uint64_t)d0.w << 32) | d0.z) >> 2);
   uint32_t plen = 0;
   uint32_t scq[FM_SC];
   uint4 hq[FM_HR];
@@ -1238,7 +1243,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
           const uint32_t own_r = (uint32_t)ve[(hh).z & 0xffffu] & 0xffffu, own_n = (uint32_t)ve[(hh).z >> 16] >> 16; \
           pr = ((px) - (double)own_r) / ((pn) - (double)own_n);                                              \
         }                                                                                                    \
-        recp0[(size_t)(hw & 0x7fffffffu) * 64] = pr;                                                         \
+        probp[k] = pr;                                                                                       \
       }                                                                                                      \
       int e;                                                                                                 \
       vm[k] = frexp(pr, &e);                                                                                 \
@@ -1409,7 +1414,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
       const uint32_t at = fm_prefix(push, li, tot_push), ar = fm_prefix(rec, li, tot_rec);
       if (have) {
         if (is_and) {
-          if (ns + ar < max_sample) outh[ns + ar] = hd[node] & 0xffffu;
+          if (ns + ar < max_sample) outh[ns + ar] = own ? node : (hd[node] & 0xffffu);
           for (uint32_t k = 0; k < push; ++k)
             if (nn + at + k < M.max_front) nxt[nn + at + k] = kids[k0 + k];
         } else if (push) {
@@ -1552,7 +1557,8 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
                                                               uint32_t* rules, const uint32_t* p_norm, double* x,
                                                               double* normsum, uint32_t n_forests, ForestArgs A, int sweep2,
                                                               const uint32_t* slot_forest, uint32_t slot0, uint32_t slot1,
-                                                              uint32_t n_slots0, uint32_t n_slots1) {
+                                                              uint32_t n_slots0, uint32_t n_slots1, const uint32_t* node_hdr,
+                                                              const double* node_prob, const uint4* node_slots) {
   // the two tables in dynamic LDS: n_slots0 {key, count} pairs for rules, n_slots1 for norm groups (powers of two)
   extern __shared__ uint32_t frc_lds[];
   uint32_t* const key0 = frc_lds;
@@ -1589,6 +1595,7 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     // a workgroup waiting for its largest sample four times in a row: 75-110 us for the classes of large forests.)
     __shared__ uint32_t pre[FRC_FORESTS + 1];
     __shared__ uint32_t fid[FRC_FORESTS];
+    __shared__ uint32_t nbase[FRC_FORESTS];  // node_hdr: the forest's first node in node_hdr / node_prob
     for (uint32_t f0 = i_begin + blockIdx.x * FRC_FORESTS; f0 < i_end; f0 += gridDim.x * FRC_FORESTS) {
       __syncthreads();
       if (threadIdx.x < FRC_FORESTS) {
@@ -1596,6 +1603,10 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
         const uint32_t f = i < i_end ? (slot_forest ? slot_forest[i] : i) : 0xffffffffu;
         fid[threadIdx.x] = f;
         pre[threadIdx.x + 1] = f == 0xffffffffu ? 0u : sample_len[f];
+        if (node_hdr && f != 0xffffffffu) {
+          const uint4 d0 = node_slots[2 * (size_t)(slot_forest ? i : A.lane_of_forest[f])];
+          nbase[threadIdx.x] = (uint32_t)(((((uint64_t)d0.w) << 32) | d0.z) >> 2);
+        }
       }
       if (threadIdx.x == 0) pre[0] = 0;
       __syncthreads();
@@ -1607,6 +1618,49 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
         __syncthreads();
       }
       const uint32_t total = pre[FRC_FORESTS];
+      if (node_hdr) {
+        // the sampler wrote NODE numbers: a sampled rule's id, class word and norm group are one 16-byte record of the forest's
+        // header table, its probability one double beside it -- the forest's own lines, fetched once for all its entries
+        for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 1024) {
+          size_t so[4];
+          uint32_t nd[4];
+          uint4 h[4];
+          double pv[4];
+          bool ok[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t e = e0 + 1024u * q;
+            ok[q] = e < total;
+            uint32_t lo = 0, hi = FRC_FORESTS;
+            while (hi - lo > 1) {
+              const uint32_t mid = (lo + hi) >> 1;
+              if (pre[mid] <= (ok[q] ? e : 0u))
+                lo = mid;
+              else
+                hi = mid;
+            }
+            so[q] = ok[q] ? sample_off[fid[lo]] + (e - pre[lo]) : 0u;
+            nd[q] = ok[q] ? nbase[lo] : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nd[q] += ok[q] ? A.sample_hdr[so[q]] : 0u;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            h[q] = ((const uint4*)node_hdr)[nd[q]];
+            pv[q] = node_prob[nd[q]];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if (!ok[q]) continue;
+            rules[so[q]] = h[q].y;
+            A.sample_cls[so[q]] = h[q].w == F_NONORM ? 0xffffffffu : h[q].z;
+            cheap += log(pv[q]);
+            if (h[q].w == F_NONORM) continue;
+            add(0, h[q].y, x);
+            add(1, h[q].w, normsum);
+          }
+        }
+      } else
       for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 1024) {  // four entries per thread in flight
         size_t pos[4], so[4];
         uint32_t rule[4], nn[4], c[4];
@@ -1760,6 +1814,7 @@ struct carmel_hip_forests {
   DevBuf<uint16_t> mt_tab;
   DevBuf<uint32_t> mt_hdr;
   DevBuf<uint32_t> mt_slots;  // FMultiArgs::slots
+  DevBuf<double> mt_prob;     // FMultiArgs::prob
   DevBuf<uint32_t> x_desc, x_rec;  // forest_exact_kernel's per-forest descriptors and per-node records (forest_exact.hpp)
   std::vector<FGroup> h_groups;
   struct Cls {
@@ -2053,7 +2108,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     uint64_t tot = 0;
     for (auto& c : F->classes) {
       F->gcol_off.push_back(tot);
-      if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) tot += (uint64_t)c.count * 2 * c.max_nodes * 64;
+      if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || getenv("CARMEL_HIP_FOREST_GCOL")) tot += (uint64_t)c.count * 2 * c.max_nodes * 64;
     }
     if (tot) HIPCHK(F->gcol.alloc(tot));
   }
@@ -2851,6 +2906,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         bool fold_proposal = multi && ext_now;
         for (auto& c : F->classes)
           if (fm_bytes(c) * FM_FPW > 64 * 1024) fold_proposal = false;
+        if (getenv("CARMEL_HIP_FOREST_GCOL")) fold_proposal = false;
         if (F->n_and && !fold_proposal)
           hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
         if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
@@ -2879,7 +2935,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           };
           // several lanes per forest (temperature 1, tables within LDS): forest_sample_multi_kernel
           const size_t fm_per = fm_bytes(c);
-          if (multi && ext && fm_per * FM_FPW <= 64 * 1024) {
+          bool class_nodes = false;  // the class's sample is written as node numbers (FMultiArgs::prob)
+          const bool force_gcol = getenv("CARMEL_HIP_FOREST_GCOL") != nullptr;  // experiment: every class one forest per lane, columns in global memory
+          if (multi && ext && fm_per * FM_FPW <= 64 * 1024 && !force_gcol) {
             FMultiArgs MA;
             MA.tab = F->mt_tab.p;
             MA.hdr = F->mt_hdr.p;
@@ -2890,9 +2948,12 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             MA.max_n = c.m_n;
             MA.max_front = c.m_front;
             MA.own_proposal = fold_proposal ? 1 : 0;
+            if (fold_proposal && !F->mt_prob.n) HIPCHK(F->mt_prob.alloc(F->mt_hdr.n / 4 + 8));
+            MA.prob = F->mt_prob.p;
+            class_nodes = fold_proposal;
             const uint32_t nwg = (MA.lane_hi - MA.lane_lo + FM_FPW - 1) / FM_FPW;
             hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, class_stream(F, s, ci), A, MA, F->max_sample);
-          } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
+          } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || force_gcol) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
             A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
             if (ext)
@@ -2912,7 +2973,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), frc_bytes,
                                class_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
-                               (c.first + c.count) * 64u, frc_slots0, frc_slots1);
+                               (c.first + c.count) * 64u, frc_slots0, frc_slots1, class_nodes ? (const uint32_t*)F->mt_hdr.p : nullptr,
+                               (const double*)F->mt_prob.p, (const uint4*)F->mt_slots.p);
         }
         HIPCHK(join_side(F, s));
       } else
@@ -2948,7 +3010,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
       HIPCHK(hipMemcpyAsync(F->normsum.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
       hipLaunchKernelGGL(forest_recount_kernel, dim3((unsigned)std::min<uint64_t>((nf + 255) / 256, 2048)), dim3(1024), frc_bytes, s,
                          F->sample_off.p, F->sample_len[cur].p, F->sample_rules[cur].p, F->p_norm.p, F->new_x.p,
-                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u, frc_slots0, frc_slots1);
+                         F->normsum.p, (uint32_t)nf, A, sweep2 ? 1 : 0, (const uint32_t*)nullptr, 0u, 0u, frc_slots0, frc_slots1,
+                         (const uint32_t*)nullptr, (const double*)nullptr, (const uint4*)nullptr);
       }
       {  // (split recount: the next sweep's count buffers start from the priors, reset by the commit itself)
         const bool reset = split_recount && iter < Ni;

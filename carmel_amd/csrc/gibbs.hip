@@ -23,6 +23,7 @@
 #include "engine.hpp"
 #include "forest_exact.hpp"
 #include "gibbs_exact.hpp"
+#include "gibbs_lane.hpp"
 #include "rng.hpp"
 
 namespace carmel_hip {
@@ -641,7 +642,7 @@ double gibbs_norm_quantile(double p) {
   return q < 0 ? -v : v;
 }
 
-static constexpr int GX_WCLASSES = 4;  // LDS classes of the parallel sweep's blocks
+static constexpr int GX_WCLASSES = 8;  // launch classes of the parallel sweep's blocks: four of the register kernel (by chunks of arcs), four by LDS need
 struct carmel_hip_gibbs {
   // --prior-inference-* (gibbs_opts.hpp:82-89, 148-153)
   double pi_stddev = 0;
@@ -680,12 +681,23 @@ struct carmel_hip_gibbs {
   DevBuf<GxBlock> gx_blocks;
   DevBuf<uint32_t> gx_rec, gx_nrm, sample_nrm, new_nrm;
   DevBuf<uint16_t> gx_state_lev;
+  DevBuf<uint32_t> gx_lev_arc;  // per level: its first arc (beside level_off)
+  int reg_nq = 0;               // the exact chain on gibbs_reg_wave_kernel<false, reg_nq> (0: some block is not eligible)
   uint32_t cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
   // parallel sweep: two launch classes by LDS need (the blocks up to the 90th percentile of arcs; the rest)
   struct WaveClass {
     DevBuf<uint32_t> list;
     uint32_t n = 0, cap_arcs = 0, cap_states = 0, cap_levels = 0, cap_sample = 0;
-  } wclass[GX_WCLASSES];
+    int nq = 0;  // > 0: gibbs_reg_wave_kernel<true, nq>
+  } wclass[GX_WCLASSES], wrest[GX_WCLASSES];  // wrest: the same classes without the blocks that go one per lane
+  // the parallel sweep with one block per lane (gibbs_lane.hip): trellis blocks within its LDS budget
+  DevBuf<GlGroup> gl_groups;
+  DevBuf<GlLane> gl_lanes;
+  DevBuf<uint32_t> gl_recA, gl_recB, gl_arc, gl_samp[2], rest_list;
+  DevBuf<double> gl_sw;
+  std::vector<GlClass> gl_classes;
+  uint32_t gl_ngroups = 0, n_rest = 0;
+  int gl_cur = 0;  // gl_samp[gl_cur]: the paths of the last sweep
   bool ran = false;
   uint32_t best_run = 0;  // --crp-restarts: the run whose counts and sample were kept
   std::vector<double> h_final_x;  // ... its counts as finalize_cumulative_counts left them (carmel_hip_gibbs_final_counts)
@@ -869,6 +881,8 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       std::vector<GxBlock> gb(bb.size());
       std::vector<uint32_t> rec(4 * L.out_arcs.size(), 0xffffffffu), nrm(2 * L.out_arcs.size(), 0xffffffffu);
       std::vector<uint16_t> slev(L.out_off.size(), 0);
+      std::vector<uint32_t> lev_arc(L.level_off.size(), 0u);
+      std::vector<int> need_nq(bb.size(), 0);  // the register kernel's chunks for this block (0: not eligible)
       for (size_t b = 0; b < bb.size(); ++b) {
         const BundleDesc& d = L.bundles[bb[b]];
         GxBlock& B = gb[b];
@@ -902,7 +916,13 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
             }
           }
         if (trellis) B.n_levels |= 0x80000000u;
+        for (uint32_t l = 0; l <= d.n_levels; ++l) lev_arc[d.level_base + l] = ooff[lo[l]];
+        if (trellis && d.n_levels <= GX_REG_LEVELS) {
+          const uint32_t m = std::max<uint32_t>((uint32_t)d.n_arcs, d.n_states);
+          need_nq[b] = m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 4 : m <= 512 ? 8 : 0;
+        }
       }
+      HIPCHK(g->gx_lev_arc.upload(lev_arc, s));
       HIPCHK(g->gx_state_lev.upload(slev, s));
       HIPCHK(g->gx_blocks.upload(gb, s));
       HIPCHK(g->gx_rec.upload(rec, s));
@@ -920,21 +940,45 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       g->cap_states = (g->cap_states + 3) / 4 * 4;
       g->cap_sample = (g->cap_sample + 3) / 4 * 4;
       g->wave_ok = gibbs_exact_lds_bytes(g->cap_arcs, g->cap_states, g->cap_levels, g->cap_sample) <= 150 * 1024;
+      // the register kernel (gibbs_exact.hip, round 6): the exact chain is one launch over all blocks in order, so every block
+      // must be eligible; the parallel sweep takes the eligible ones class by class.  CARMEL_HIP_GIBBS_REG=0: the LDS kernel (A/B)
+      const bool reg_on = !(getenv("CARMEL_HIP_GIBBS_REG") && atoi(getenv("CARMEL_HIP_GIBBS_REG")) == 0);
+      g->reg_nq = 0;
+      if (g->wave_ok && reg_on && o->mode == 0) {
+        int nq = 2;
+        for (size_t b = 0; b < bb.size() && nq; ++b) nq = need_nq[b] ? std::max(nq, need_nq[b]) : 0;
+        g->reg_nq = nq;
+        if (getenv("CARMEL_TIMING")) {
+          size_t bad = 0;
+          for (size_t b = 0; b < bb.size(); ++b) bad += need_nq[b] == 0;
+          fprintf(stderr, "timing: gibbs exact chain: register kernel nq %d (%zu of %zu blocks not eligible; caps arcs %u states %u levels %u)\n", nq, bad,
+                  bb.size(), g->cap_arcs, g->cap_states, g->cap_levels);
+        }
+      }
       if (g->wave_ok && o->mode == 1) {
         // a wavefront's LDS is sized by its launch's largest block: the few long sentences must not set the occupancy of all
         std::vector<uint32_t> arcs(bb.size());
         for (size_t b = 0; b < bb.size(); ++b) arcs[b] = (uint32_t)L.bundles[bb[b]].n_arcs;
-        std::vector<uint32_t> sorted = arcs;
+        std::vector<uint32_t> sorted;  // (of the blocks the LDS kernel takes)
+        for (size_t b = 0; b < bb.size(); ++b)
+          if (!(reg_on && need_nq[b])) sorted.push_back(arcs[b]);
+        if (sorted.empty()) sorted.push_back(0u);
         std::sort(sorted.begin(), sorted.end());
         // (four classes at the median, the 80th and the 95th percentile: the tagging cascade's median sentence needs a third of
         // the 90th percentile's LDS, and a wavefront that waits for its gathers wants neighbours)
-        const uint32_t cuts[GX_WCLASSES - 1] = {sorted[std::min(sorted.size() - 1, sorted.size() / 2)],
-                                                sorted[std::min(sorted.size() - 1, sorted.size() * 8 / 10)],
-                                                sorted[std::min(sorted.size() - 1, sorted.size() * 19 / 20)]};
+        const uint32_t cuts[3] = {sorted[std::min(sorted.size() - 1, sorted.size() / 2)],
+                                  sorted[std::min(sorted.size() - 1, sorted.size() * 8 / 10)],
+                                  sorted[std::min(sorted.size() - 1, sorted.size() * 19 / 20)]};
         std::vector<uint32_t> lists[GX_WCLASSES];
         for (size_t b = 0; b < bb.size(); ++b) {
           int c = 0;
-          while (c < GX_WCLASSES - 1 && arcs[b] > cuts[c]) ++c;
+          if (reg_on && need_nq[b]) {  // classes 0..3: the register kernel with 1, 2, 4, 8 chunks of arcs
+            c = need_nq[b] == 1 ? 0 : need_nq[b] == 2 ? 1 : need_nq[b] == 4 ? 2 : 3;
+            g->wclass[c].nq = need_nq[b];
+          } else {
+            while (c < 3 && arcs[b] > cuts[c]) ++c;
+            c += 4;
+          }
           const BundleDesc& d = L.bundles[bb[b]];
           auto& W = g->wclass[c];
           lists[c].push_back((uint32_t)b);
@@ -943,6 +987,51 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           W.cap_levels = std::max(W.cap_levels, d.n_levels);
           W.cap_sample = std::max(W.cap_sample, d.n_levels * max_chain);
         }
+        // one block per lane where the lattices allow it (gibbs_lane.hip); CARMEL_HIP_GIBBS_LANE=0: every block on the kernels above (A/B)
+        GlHost H;
+        if (!(getenv("CARMEL_HIP_GIBBS_LANE") && atoi(getenv("CARMEL_HIP_GIBBS_LANE")) == 0)) gibbs_lane_build(L, bb, gb, coff, cpar, g->h_norm, H);
+        if (!H.groups.empty()) {
+          g->gl_ngroups = (uint32_t)H.groups.size();
+          g->gl_classes = H.classes;
+          HIPCHK(g->gl_groups.upload(H.groups, s));
+          HIPCHK(g->gl_lanes.upload(H.lanes, s));
+          HIPCHK(g->gl_recA.upload(H.recA, s));
+          HIPCHK(g->gl_recB.upload(H.recB, s));
+          HIPCHK(g->gl_arc.upload(H.arc_id, s));
+          HIPCHK(g->gl_sw.alloc(2 * H.n_rec));
+          for (int k = 0; k < 2; ++k) {
+            HIPCHK(g->gl_samp[k].alloc(4 * H.n_samp));
+            HIPCHK(hipMemsetAsync(g->gl_samp[k].p, 0, g->gl_samp[k].bytes(), s));
+          }
+          std::vector<uint32_t> rest;
+          std::vector<uint32_t> rlists[GX_WCLASSES];
+          for (int c = 0; c < GX_WCLASSES; ++c) {
+            g->wrest[c].nq = g->wclass[c].nq;
+            for (uint32_t b : lists[c])
+              if (!H.taken[b]) {
+                rlists[c].push_back(b);
+                rest.push_back(b);
+                const BundleDesc& d = L.bundles[bb[b]];
+                auto& W = g->wrest[c];
+                W.cap_arcs = std::max(W.cap_arcs, ((uint32_t)d.n_arcs + 3) / 4 * 4);
+                W.cap_states = std::max(W.cap_states, (d.n_states + 3) / 4 * 4);
+                W.cap_levels = std::max(W.cap_levels, d.n_levels);
+                W.cap_sample = std::max(W.cap_sample, (d.n_levels * max_chain + 3) / 4 * 4);
+              }
+            g->wrest[c].n = (uint32_t)rlists[c].size();
+            if (g->wrest[c].n) HIPCHK(g->wrest[c].list.upload(rlists[c], s));
+          }
+          g->n_rest = (uint32_t)rest.size();
+          if (g->n_rest) HIPCHK(g->rest_list.upload(rest, s));
+          if (getenv("CARMEL_TIMING")) {
+            size_t taken = 0;
+            for (uint8_t t8 : H.taken) taken += t8;
+            fprintf(stderr, "timing: gibbs parallel sweep: %zu of %zu blocks one per lane in %u groups, %zu launch classes (LDS per wavefront:", taken, bb.size(),
+                    g->gl_ngroups, H.classes.size());
+            for (auto& c : H.classes) fprintf(stderr, " %zu", gibbs_lane_lds_bytes(c.W, c.LP, c.LN));
+            fprintf(stderr, " bytes)\n");
+          }
+        }
         for (int c = 0; c < GX_WCLASSES; ++c) {
           auto& W = g->wclass[c];
           W.n = (uint32_t)lists[c].size();
@@ -950,6 +1039,9 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           W.cap_states = (W.cap_states + 3) / 4 * 4;
           W.cap_sample = (W.cap_sample + 3) / 4 * 4;
           if (W.n) HIPCHK(W.list.upload(lists[c], s));
+          if (W.n && getenv("CARMEL_TIMING"))
+            fprintf(stderr, "timing: gibbs parallel class %d: %u blocks, nq %d, caps arcs %u states %u levels %u sample %u\n", c, W.n, W.nq, W.cap_arcs,
+                    W.cap_states, W.cap_levels, W.cap_sample);
         }
       }
     }
@@ -1158,6 +1250,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     GX.out_off = g->out_off.p;
     GX.level_off = g->level_off.p;
     GX.state_lev = g->gx_state_lev.p;
+    GX.lev_arc = g->gx_lev_arc.p;
     GX.p_norm = g->p_norm.p;
     GX.p_prior = g->p_prior.p;
     GX.p_x = g->p_x.p;
@@ -1180,8 +1273,8 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     GX.n_blocks = g->n_blocks;
     GX.want_after = iter_after_logprob ? 1 : 0;
     if (getenv("CARMEL_HIP_GIBBS_CLK")) {
-      HIPCHK(gx_clk.alloc(8));
-      HIPCHK(hipMemsetAsync(gx_clk.p, 0, 64, s));
+      HIPCHK(gx_clk.alloc(16));
+      HIPCHK(hipMemsetAsync(gx_clk.p, 0, 128, s));
       GX.phase_clk = gx_clk.p;
     }
   }
@@ -1289,7 +1382,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
           GC.iter = my_runs[b0] * (Ni + 1) + iter;
           GC.init_logw = (iter == 0 && my_runs[b0] == 0 && g->init_logw.n) ? g->init_logw.p : nullptr;
           GC.init_chain = GC.init_logw ? 0u : 0xffffffffu;
-          HIPCHK(launch_gibbs_exact_wave(GC, 0, s));
+          HIPCHK((g->reg_nq && !GC.init_logw) ? launch_gibbs_reg_wave(GC, 0, g->reg_nq, s) : launch_gibbs_exact_wave(GC, 0, s));
           HIPCHK(hipMemcpyAsync(io.data(), mio.p, io.size() * sizeof(double), hipMemcpyDeviceToHost, s));
           HIPCHK(hipStreamSynchronize(s));
           for (uint32_t c = 0; c < R; ++c) {
@@ -1384,6 +1477,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.new_len = g->new_len.p;
   // gibbs_stats (gibbs_opts.hpp:270-296): over the sweeps from burn-in on
   double st_all = 0.0, st_final = 0.0, st_sum = -std::numeric_limits<double>::infinity();
+  bool lane_run = false;
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     G.iter = run * (Ni + 1) + iter;  // of the uniforms: every run draws its own
     // gibbs.hpp:816: the initial --expectation sweep of a --random-start run, and of every restart
@@ -1401,7 +1495,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       GX.iter = G.iter;
       GX.init_logw = G.init_logw;
       GX.time = G.time;
-      HIPCHK(launch_gibbs_exact_wave(GX, 0, s));
+      HIPCHK((g->reg_nq && !GX.init_logw) ? launch_gibbs_reg_wave(GX, 0, g->reg_nq, s) : launch_gibbs_exact_wave(GX, 0, s));
     } else if (g->opt.mode == 0) {
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->csum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -1430,8 +1524,38 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
         GX.sample_nrm = g->new_nrm.p;
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, t->device);
+        // the blocks that go one per lane (not under prior-scale inference: its re-scoring reads the sampler's own sample format)
+        lane_run = g->gl_ngroups && g->pi_stddev <= 0;
+        if (lane_run) {
+          GlArgs LA;
+          std::memset(&LA, 0, sizeof LA);
+          LA.groups = g->gl_groups.p;
+          LA.lanes = g->gl_lanes.p;
+          LA.recA = (const uint4*)g->gl_recA.p;
+          LA.recB = (const uint4*)g->gl_recB.p;
+          LA.arc_id = g->gl_arc.p;
+          LA.sw = (double2*)g->gl_sw.p;
+          LA.samp_old = (const uint4*)g->gl_samp[g->gl_cur].p;
+          LA.samp_new = (uint4*)g->gl_samp[g->gl_cur ^ 1].p;
+          LA.p_x = g->snap_x.p;
+          LA.normsum = g->snap_norm.p;
+          LA.p_prior = g->p_prior.p;
+          LA.init_logw = G.init_logw;
+          LA.iter_out = g->iter_out.p;
+          LA.phase_clk = GX.phase_clk;
+          LA.seed = g->opt.seed;
+          LA.iter = G.iter;
+          LA.have_old = (iter > 0 && !g->opt.include_self) ? 1 : 0;
+          for (auto& c : g->gl_classes) {
+            LA.first_group = c.first;
+            LA.W = c.W;
+            LA.LP = c.LP;
+            LA.LN = c.LN;
+            HIPCHK(launch_gibbs_lane(LA, c.count, s));
+          }
+        }
         for (int c = GX_WCLASSES - 1; c >= 0; --c) {  // (all on the trainer's stream, the long blocks first: the next fills the chip as one drains)
-          auto& W = g->wclass[c];
+          auto& W = lane_run ? g->wrest[c] : g->wclass[c];
           if (!W.n) continue;
           GX.list = W.list.p;
           GX.n_blocks = W.n;
@@ -1439,6 +1563,15 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
           GX.cap_states = W.cap_states;
           GX.cap_levels = W.cap_levels;
           GX.cap_sample = W.cap_sample;
+          if (W.nq && !GX.init_logw) {
+            uint32_t own = 64;  // the own-sample tables: at most half full
+            while (own < 2 * GX.cap_sample) own <<= 1;
+            GX.own_slots = own;
+            const size_t lds_w = gibbs_reg_lds_bytes(GX.cap_arcs, GX.cap_states, GX.cap_sample, own);
+            const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(W.nq <= 4 ? 16 : 8, (160 * 1024) / std::max<size_t>(lds_w, 1)));
+            HIPCHK(launch_gibbs_reg_wave(GX, std::min<uint32_t>(W.n, (uint32_t)cus * per_cu), W.nq, s));
+            continue;
+          }
           const size_t lds_w = gibbs_exact_lds_bytes(GX.cap_arcs, GX.cap_states, GX.cap_levels, GX.cap_sample);
           const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / std::max<size_t>(lds_w, 1)));
           HIPCHK(launch_gibbs_exact_wave(GX, std::min<uint32_t>(W.n, (uint32_t)cus * per_cu), s));
@@ -1455,7 +1588,14 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       // counts of the new samples: start from the priors, add every use
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
-      if (wave_par)
+      if (wave_par && lane_run) {
+        if (g->n_rest)
+          HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_rest, g->ccount.p, g->normsum.p, s,
+                                             g->rest_list.p));
+        HIPCHK(launch_gibbs_lane_recount(g->gl_groups.p, g->gl_lanes.p, (const uint4*)g->gl_recA.p, (const uint4*)g->gl_samp[g->gl_cur ^ 1].p,
+                                         g->gl_ngroups, g->ccount.p, g->normsum.p, s));
+        g->gl_cur ^= 1;
+      } else if (wave_par)
         HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_blocks, g->ccount.p, g->normsum.p, s));
       else
         hipLaunchKernelGGL(gibbs_recount_kernel, dim3(std::min<uint32_t>((g->n_blocks + 255) / 256, 4096u)), dim3(256), 0, s,
@@ -1469,6 +1609,10 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       G.sample_len = g->sample_len.p;
       G.new_ids = g->new_ids.p;
       G.new_len = g->new_len.p;
+      // the lanes' paths in the sampler's own format, for whoever reads the sample next: the end of the run, an observer
+      if (lane_run && (iter == Ni || (g->obs_fn && g->obs_every && iter % g->obs_every == 0)))
+        HIPCHK(launch_gibbs_lane_materialize(g->gl_groups.p, g->gl_lanes.p, (const uint4*)g->gl_recA.p, (const uint4*)g->gl_samp[g->gl_cur].p,
+                                             g->gl_ngroups, g->sample_ids.p, g->sample_nrm.p, g->sample_len.p, s));
     }
     HIPCHK(hipGetLastError());
     double io[5];
@@ -1547,12 +1691,16 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     if (g->obs_fn && g->obs_every && iter % g->obs_every == 0) g->obs_fn(g->obs_ctx, run, iter, G.time);
   }
   if (gx_clk.n) {
-    unsigned long long c[8];
+    unsigned long long c[16];
     HIPCHK(hipMemcpy(c, gx_clk.p, sizeof c, hipMemcpyDeviceToHost));
+    if (c[4] && c[8])
+      fprintf(stderr, "[carmel_hip] gibbs_reg_wave: arrivals + own tables %.0f, weights %.0f, offsets + uniforms %.0f, requests %.0f | choices %.0f, path %.0f, "
+                      "parameters %.0f (per block, over ALL blocks of the sweep)\n", c[8] / (double)c[4], c[9] / (double)c[4], c[10] / (double)c[4],
+              c[11] / (double)c[4], c[12] / (double)c[4], c[13] / (double)c[4], c[14] / (double)c[4]);
     if (c[4])
       fprintf(stderr, "[carmel_hip] gibbs_exact_wave cycles per block: wait+weights %.0f, backward %.0f, walk %.0f, counts %.0f (%llu blocks x sweeps)\n",
               c[0] / (double)c[4], c[1] / (double)c[4], c[2] / (double)c[4], c[3] / (double)c[4], c[4]);
-    HIPCHK(hipMemset(gx_clk.p, 0, 64));
+    HIPCHK(hipMemset(gx_clk.p, 0, 128));
   }
   // finalize_cumulative_counts: counts := time-integrated counts over the post-burn-in sweeps
   if (g->pi_stddev > 0) {  // the priors have moved

@@ -515,6 +515,501 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
   }
 }
 
+// ---- the same sweep with a block's arcs in REGISTERS (round 6) ----
+// What the kernel above spends its time on (profiles/r6_v0_crp_phase_cycles.txt: 61 k cycles a block in the parallel sweep) is
+// not arithmetic and not bandwidth but round trips: every chunk of 64 arcs waits for its records, then for the counts they point
+// at (28 k cycles), and a level of the backward sweep is a chain of five dependent LDS reads (offset -> arc -> destination's value
+// -> add -> sync: 670 cycles x 26 levels).  Here, for TRELLIS blocks (every arc joins neighbouring levels: a tagger's lattice, any
+// epsilon-free pair) of at most 64 NQ arcs and states and 127 levels:
+//   * lane i owns arcs i, i + 64, ... for the whole block: ends, parameters, norm groups, proposal weight and share live in
+//     registers; a level of the sweep is ONE LDS read (the destination's value) and one LDS add per arc, the level's arc range a
+//     v_readlane away (lev_arc, built with the records: first arc of every level);
+//   * the NEXT block's records are requested before this block's sweep and its counts -- the parallel sweep's are the snapshot's,
+//     nobody changes them -- right after it: both round trips run behind the sweep and the walk (the exact chain's counts are live:
+//     it requests them at the top of the block, all chunks at once);
+//   * LDS per block: shares (8 B an arc, for the states' choices), destinations (2 B), values / exponents / offsets per state, the
+//     own-sample tables sized by the class's longest sample -- a quarter of the LDS kernel's, so a CU holds its 16 wavefronts;
+//   * a state's choice reads its shares four at a time; the path is one word per state (chosen arc | its destination); the path's
+//     parameters come back out of the registers by ds_bpermute.
+// Same values, same order of every state's subtraction, same uniforms: the sample of the kernel above (its sums differ by the
+// order of the LDS adds, as its own do from run to run).  Anything else -- lattices with arcs that skip levels, longer ones, the
+// sweeps that sample from --init-em weights -- keeps the kernel above.
+#define GXR_LQ 2  // registers of level offsets per lane: at most 64 GXR_LQ - 1 levels
+__device__ __forceinline__ void gxr_own_put(uint32_t* keys, uint32_t* cnts, uint32_t mask, uint32_t key) {
+  for (uint32_t h = (key * 2654435761u) >> 8;; ++h) {
+    const uint32_t at = h & mask;
+    const uint32_t old = atomicCAS(keys + at, GX_NONE, key);
+    if (old == GX_NONE || old == key) {
+      atomicAdd(cnts + at, 1u);
+      return;
+    }
+  }
+}
+__device__ __forceinline__ uint32_t gxr_own_get(const uint32_t* keys, const uint32_t* cnts, uint32_t mask, uint32_t key) {
+  for (uint32_t h = (key * 2654435761u) >> 8;; ++h) {
+    const uint32_t at = h & mask;
+    const uint32_t k = keys[at];
+    if (k == key) return cnts[at];
+    if (k == GX_NONE) return 0u;
+  }
+}
+__device__ __forceinline__ uint32_t gxr_bperm(uint32_t v, uint32_t from_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
+}
+template <bool PAR, int NQ>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? (NQ <= 4 ? 4 : 2) : 1, PAR ? (NQ <= 4 ? 4 : 2) : 2))) void gibbs_reg_wave_kernel(GxArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
+  if (!PAR && A.n_chains > 1) {
+    const uint32_t c = blockIdx.x;
+    A.p_x += (size_t)c * A.ch_params;
+    A.ccount += (size_t)c * A.ch_params;
+    A.normsum += (size_t)c * A.ch_norms;
+    A.csum += (size_t)c * A.ch_norms;
+    A.sample_len += (size_t)c * A.n_blocks;
+    A.sample_ids += (size_t)c * A.ch_sample;
+    A.sample_nrm += (size_t)c * A.ch_sample;
+    A.old_len += (size_t)c * A.n_blocks;
+    A.old_ids += (size_t)c * A.ch_sample;
+    A.old_nrm += (size_t)c * A.ch_sample;
+    A.iter_out += (size_t)c * 8;
+    A.iter += c * A.iter_stride;
+  }
+  const uint32_t CA = A.cap_arcs, CS = A.cap_states, CM = A.cap_sample, OWN = PAR ? A.own_slots : 0u;
+  double* sh = (double*)gx_lds;
+  double* bv = sh + CA;
+  double* bsum = bv + CS;
+  int* be = (int*)(bsum + CS);
+  int* emx = be + CS;
+  uint32_t* ooff = (uint32_t*)(emx + CS);
+  uint32_t* ids = ooff + CS + 1;
+  uint32_t* idn = ids + CM;
+  uint32_t* own_k = idn + CM;
+  uint32_t* own_c = own_k + 2 * OWN;
+  unsigned short* dst16 = (unsigned short*)(own_c + 2 * OWN);
+  const uint32_t lane = threadIdx.x;
+  const uint32_t nb = A.n_blocks;
+  GxProd cheap{1.0, 0}, cnum{1.0, 0}, cden{1.0, 0}, after{1.0, 0};
+  unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GXR_STAMP(v) const unsigned long long v = A.phase_clk ? __builtin_readcyclecounter() : 0;
+  const uint32_t b0 = PAR ? blockIdx.x : 0u, stride = PAR ? gridDim.x : 1u;
+  if (b0 >= nb) return;
+  GxBlock B = A.blocks[GX_BLOCK_ID(b0)], Bn = A.blocks[GX_BLOCK_ID(min(b0 + stride, nb - 1))];
+  GxOld O;
+  gx_request_old(A, B, GX_BLOCK_ID(b0), lane, O);
+  // the block's arcs: {parameters, ends, norm groups} per chunk, the first arc of every level; n*: the next block's, on their way
+  uint32_t nz[NQ], nw[NQ], nds[NQ], nnx[NQ], nny[NQ], nlev[GXR_LQ];
+  double x0[NQ], s0[NQ], x1[NQ], s1[NQ];
+#define GXR_REQUEST_RECORDS(BLK)                                                                       \
+  {                                                                                                    \
+    const uint4* __restrict__ rec_ = A.arc_rec + (BLK).out_base;                                       \
+    const uint2* __restrict__ nrm_ = A.arc_nrm + (BLK).out_base;                                       \
+    _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                                                   \
+      const uint32_t a_ = (uint32_t)q * 64u + lane;                                                    \
+      const bool have_ = a_ < (BLK).n_arcs;                                                            \
+      const uint4 r_ = have_ ? rec_[a_] : make_uint4(0, 0, GX_NONE, GX_NONE);                          \
+      const uint2 n_ = have_ ? nrm_[a_] : make_uint2(GX_NONE, GX_NONE);                                \
+      nds[q] = r_.x;                                                                                   \
+      nz[q] = r_.z;                                                                                    \
+      nw[q] = r_.w;                                                                                    \
+      nnx[q] = n_.x;                                                                                   \
+      nny[q] = n_.y;                                                                                   \
+    }                                                                                                  \
+    const uint32_t nl_ = (BLK).n_levels & 0x7fffffffu;                                                 \
+    _Pragma("unroll") for (int j = 0; j < GXR_LQ; ++j)                                                 \
+      nlev[j] = (uint32_t)j * 64u + lane <= nl_ ? A.lev_arc[(BLK).level_base + (uint32_t)j * 64u + lane] : (BLK).n_arcs; \
+  }
+  // the counts the records point at (the parallel sweep: the snapshot's, plain loads; the chain: live, workgroup-coherent)
+#define GXR_REQUEST_COUNTS()                                                    \
+  _Pragma("unroll") for (int q = 0; q < NQ; ++q) {                              \
+    x0[q] = 1.0;                                                                \
+    s0[q] = 1.0;                                                                \
+    x1[q] = 1.0;                                                                \
+    s1[q] = 1.0;                                                                \
+    if (nz[q] != GX_NONE) {                                                     \
+      if (nnx[q] == GX_NONE)                                                    \
+        x0[q] = A.p_prior[nz[q]];                                               \
+      else {                                                                    \
+        x0[q] = PAR ? A.p_x[nz[q]] : gx_ld(A.p_x + nz[q]);                      \
+        s0[q] = PAR ? A.normsum[nnx[q]] : gx_ld(A.normsum + nnx[q]);            \
+      }                                                                         \
+    }                                                                           \
+    if (nw[q] != GX_NONE) {                                                     \
+      if (nny[q] == GX_NONE)                                                    \
+        x1[q] = A.p_prior[nw[q]];                                               \
+      else {                                                                    \
+        x1[q] = PAR ? A.p_x[nw[q]] : gx_ld(A.p_x + nw[q]);                      \
+        s1[q] = PAR ? A.normsum[nny[q]] : gx_ld(A.normsum + nny[q]);            \
+      }                                                                         \
+    }                                                                           \
+  }
+  GXR_REQUEST_RECORDS(B)
+  if (PAR) GXR_REQUEST_COUNTS()
+  if (!PAR && !A.want_after) gx_take_out(A, B, lane, O);
+  uint32_t n_prev = 0;
+  for (uint32_t bi = b0; bi < nb; bi += stride) {
+    const uint32_t b = GX_BLOCK_ID(bi);
+    unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
+    if (!PAR) gx_order();
+    if (!PAR && A.want_after) {
+      for (uint32_t k = lane; k < n_prev; k += 64) {
+        const uint32_t p = ids[k], n = idn[k];
+        after.mul(n == GX_NONE ? A.p_prior[p] : gx_ld(A.p_x + p) / gx_ld(A.normsum + n));
+      }
+      gx_take_out(A, B, lane, O);
+      gx_order();
+    }
+    if (!PAR) GXR_REQUEST_COUNTS()  // (live counts: as the chain has them now)
+    // this block's arcs take their registers
+    uint32_t cz[NQ], cw[NQ], cds[NQ], lev[GXR_LQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      cz[q] = nz[q];
+      cw[q] = nw[q];
+      cds[q] = nds[q];
+    }
+#pragma unroll
+    for (int j = 0; j < GXR_LQ; ++j) lev[j] = nlev[j];
+    const uint32_t n_levels = B.n_levels & 0x7fffffffu;
+    // offsets of the states' arcs and the level of every state (the key of its uniform): on their way while the weights are formed
+    uint32_t oq[NQ + 1];
+    uint32_t slv[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const uint32_t s = (uint32_t)j * 64u + lane;
+      oq[j] = s <= B.n_states ? A.out_off[B.off_base + s] : 0u;
+      slv[j] = s < B.n_states ? (uint32_t)A.state_lev[B.off_base + s] : 0u;
+    }
+    oq[NQ] = (lane == 0 && (uint32_t)NQ * 64u <= B.n_states) ? A.out_off[B.off_base + (uint32_t)NQ * 64u] : 0u;
+    const uint32_t own_n = PAR && A.counterfactual ? O.len : 0u;
+    if (PAR && own_n) {
+      for (uint32_t i = lane; i < 2 * OWN; i += 64) {
+        own_k[i] = GX_NONE;
+        own_c[i] = 0;
+      }
+      GX_WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < GX_SQ; ++q)
+        if (lane + q * 64 < own_n && O.nr[q] != GX_NONE) {  // (a fixed-probability parameter has no count to correct)
+          gxr_own_put(own_k, own_c, OWN - 1, O.id[q]);
+          gxr_own_put(own_k + OWN, own_c + OWN, OWN - 1, O.nr[q]);
+        }
+      for (uint32_t k = lane + GX_SQ * 64; k < own_n; k += 64) {
+        const uint32_t nr = A.old_nrm[B.sample_off + k];
+        if (nr == GX_NONE) continue;
+        gxr_own_put(own_k, own_c, OWN - 1, A.old_ids[B.sample_off + k]);
+        gxr_own_put(own_k + OWN, own_c + OWN, OWN - 1, nr);
+      }
+      GX_WAVE_SYNC();
+    }
+    GXR_STAMP(ta)
+    // ---- proposal weights (gibbs.cc:348-359, gibbs.hpp:153-157) ----
+    double gwq[NQ], shq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const uint32_t a = (uint32_t)q * 64u + lane;
+      double a0 = x0[q], b0_ = s0[q], a1 = x1[q], b1 = s1[q];
+      if (PAR && own_n) {
+        const uint32_t c0 = (cz[q] != GX_NONE && nnx[q] != GX_NONE) ? gxr_own_get(own_k, own_c, OWN - 1, cz[q]) : 0u;
+        const uint32_t c1 = (cw[q] != GX_NONE && nny[q] != GX_NONE) ? gxr_own_get(own_k, own_c, OWN - 1, cw[q]) : 0u;
+        const uint32_t m0 = nnx[q] != GX_NONE ? gxr_own_get(own_k + OWN, own_c + OWN, OWN - 1, nnx[q]) : 0u;
+        const uint32_t m1 = nny[q] != GX_NONE ? gxr_own_get(own_k + OWN, own_c + OWN, OWN - 1, nny[q]) : 0u;
+        a0 -= (double)c0 * B.wt;
+        b0_ -= (double)m0 * B.wt;
+        a1 -= (double)c1 * B.wt;
+        b1 -= (double)m1 * B.wt;
+      }
+      gwq[q] = (a0 / b0_) * (a1 / b1);
+      shq[q] = 0.0;
+      if (a < B.n_arcs) dst16[a] = (unsigned short)(cds[q] & 0xffffu);
+    }
+    GXR_STAMP(tb)
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+      if ((uint32_t)j * 64u + lane <= B.n_states) ooff[(uint32_t)j * 64u + lane] = oq[j];
+    if (lane == 0 && (uint32_t)NQ * 64u <= B.n_states) ooff[(uint32_t)NQ * 64u] = oq[NQ];
+    // a state's uniform is its level's (one state per level on the walk's way)
+    double us[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) us[j] = gibbs_uniform(A.seed, A.iter, b, slv[j]);
+    GXR_STAMP(tc)
+    // the next block's records and previous sample set out now
+    GxOld On;
+    gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
+    const GxBlock Bnn = A.blocks[GX_BLOCK_ID(min(bi + 2 * stride, nb - 1))];
+    GXR_REQUEST_RECORDS(Bn)
+    unsigned long long t1 = A.phase_clk ? __builtin_readcyclecounter() : 0;
+    // ---- backward sweep (derivations.h:345-360), level by level from the goal's ----
+#define GXR_LEV(l) ((l) < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lev[0], (int)(l)) : (uint32_t)__builtin_amdgcn_readlane((int)lev[1], (int)((l) - 64u)))
+    bool ext = false;
+    for (;;) {
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        const uint32_t s = (uint32_t)j * 64u + lane;
+        if (s < B.n_states) {
+          bv[s] = 0.0;
+          bsum[s] = 0.0;
+          be[s] = 0;
+          emx[s] = -(1 << 28);
+        }
+      }
+      GX_WAVE_SYNC();
+      if (lane == 0) {
+        bv[B.fin] = ext ? 0.5 : 1.0;
+        bsum[B.fin] = 1.0;
+        be[B.fin] = ext ? 1 : 0;
+      }
+      GX_WAVE_SYNC();
+      uint32_t a_hi = B.n_arcs;
+      for (uint32_t l = n_levels; l-- > 0;) {
+        const uint32_t a_lo = GXR_LEV(l);
+        if (a_lo != a_hi) {
+          const uint32_t q_lo = a_lo >> 6, q_hi = (a_hi - 1) >> 6;
+          if (!ext) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if ((uint32_t)q >= q_lo && (uint32_t)q <= q_hi) {
+                const uint32_t a = (uint32_t)q * 64u + lane;
+                if (a >= a_lo && a < a_hi) {
+                  const uint32_t d = cds[q];
+                  const double term = gwq[q] * bv[d & 0xffffu];
+                  shq[q] = term;
+                  if (term != 0.0) gx_lds_add(&bv[d >> 16], term);
+                }
+              }
+            GX_WAVE_SYNC();
+          } else {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if ((uint32_t)q >= q_lo && (uint32_t)q <= q_hi) {
+                const uint32_t a = (uint32_t)q * 64u + lane;
+                if (a >= a_lo && a < a_hi) {
+                  const uint32_t d = cds[q];
+                  if (gwq[q] * bv[d & 0xffffu] != 0.0) gx_lds_max(&emx[d >> 16], be[d & 0xffffu]);
+                }
+              }
+            GX_WAVE_SYNC();
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              if ((uint32_t)q >= q_lo && (uint32_t)q <= q_hi) {
+                const uint32_t a = (uint32_t)q * 64u + lane;
+                if (a >= a_lo && a < a_hi) {
+                  const uint32_t d = cds[q];
+                  const double term = ldexp(gwq[q] * bv[d & 0xffffu], max(be[d & 0xffffu] - emx[d >> 16], -1100));
+                  shq[q] = term;
+                  if (term != 0.0) gx_lds_add(&bsum[d >> 16], term);
+                }
+              }
+            GX_WAVE_SYNC();
+            // (the states of the level: the sources of its arcs -- from the first arc's to the last one's)
+            const uint32_t s_lo = A.level_off[B.level_base + l], s_hi = A.level_off[B.level_base + l + 1];
+            for (uint32_t s = s_lo + lane; s < s_hi; s += 64)
+              if (ooff[s + 1] > ooff[s]) {
+                int t;
+                bv[s] = frexp(bsum[s], &t);
+                be[s] = bsum[s] != 0.0 ? emx[s] + t : 0;
+              }
+            GX_WAVE_SYNC();
+          }
+        }
+        a_hi = a_lo;
+      }
+      const double root = bv[B.start];
+      if (ext || (root >= 1e-250 && root <= 1e250)) break;
+      ext = true;  // plain doubles ran out: once more with exponents
+    }
+    double* const tot = ext ? bsum : bv;
+    // the parallel sweep's next counts set out: the snapshot's, whatever this block samples
+    double pcq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      pcq[q] = gwq[q];
+      const uint32_t a = (uint32_t)q * 64u + lane;
+      if (a < B.n_arcs) sh[a] = shq[q];
+    }
+    if (PAR) GXR_REQUEST_COUNTS()
+    GX_WAVE_SYNC();
+    unsigned long long t2 = A.phase_clk ? __builtin_readcyclecounter() : 0;
+    // ---- every state chooses its way on (random.ipp:111-127: the shares in list order, newest first, subtracted from
+    // u x total until it drops below zero), then the path is followed from the start: one word per step ----
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      const uint32_t s = (uint32_t)j * 64u + lane;
+      if (s < B.n_states) {
+        const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
+        uint32_t pick = a0;
+        if (a1 > a0) {
+          double choice = us[j] * tot[s];
+          bool done = false;
+          for (uint32_t top = a1; top > a0 && !done; top -= min(4u, top - a0)) {
+            // (four shares requested together; the subtractions in the reference's order)
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = top >= a0 + 1u + (uint32_t)i ? sh[top - 1u - (uint32_t)i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (!done && top >= a0 + 1u + (uint32_t)i) {
+                choice -= v[i];
+                pick = top - 1u - (uint32_t)i;
+                done = choice < 0;
+              }
+          }
+        }
+        be[s] = (int)(pick | ((a1 > a0 ? (uint32_t)dst16[pick] : B.fin) << 16));
+      }
+    }
+    GX_WAVE_SYNC();
+    GXR_STAMP(td)
+    uint32_t n_ids = 0;
+    unsigned long long te_ = 0;
+    {
+      uint32_t s = B.start, n_path = 0;
+      while (s != B.fin && n_path < CM) {
+        const uint32_t wd = (uint32_t)be[s];
+        if (lane == 0) idn[n_path] = wd & 0xffffu;
+        ++n_path;
+        s = wd >> 16;
+      }
+      GX_WAVE_SYNC();
+      te_ = A.phase_clk ? __builtin_readcyclecounter() : 0;
+      for (uint32_t base = 0; base < n_path; base += 64) {
+        const uint32_t t = base + lane;
+        const bool have = t < n_path;
+        const uint32_t a = have ? idn[t] : 0u;
+        const uint32_t from = a & 63u, qa = a >> 6;
+        uint32_t p0 = GX_NONE, p1 = GX_NONE, wlo = 0, whi = 0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {  // (every lane takes part in every exchange; each keeps its own chunk's answer)
+          const uint32_t z = gxr_bperm(cz[q], from), w = gxr_bperm(cw[q], from);
+          const uint32_t lo = gxr_bperm((uint32_t)__double2loint(pcq[q]), from), hi = gxr_bperm((uint32_t)__double2hiint(pcq[q]), from);
+          if (qa == (uint32_t)q) {
+            p0 = z;
+            p1 = w;
+            wlo = lo;
+            whi = hi;
+          }
+        }
+        if (!have) {
+          p0 = GX_NONE;
+          p1 = GX_NONE;
+        }
+        if (have) cheap.mul(__hiloint2double((int)whi, (int)wlo));
+        const unsigned long long m0 = __ballot(p0 != GX_NONE), m1 = __ballot(p1 != GX_NONE);
+        const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
+        const uint32_t at = n_ids + (uint32_t)__popcll(m0 & below) + (uint32_t)__popcll(m1 & below);
+        if (p0 != GX_NONE && at < CM) ids[at] = p0;
+        if (p1 != GX_NONE && at + (p0 != GX_NONE) < CM) ids[at + (p0 != GX_NONE)] = p1;
+        n_ids += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+      }
+      n_ids = min(n_ids, CM);
+    }
+    GX_WAVE_SYNC();
+    unsigned long long t3 = A.phase_clk ? __builtin_readcyclecounter() : 0;
+    // ---- the new sample into the counts, the next block's previous sample out (as in the kernel above) ----
+    for (uint32_t k = lane; k < n_ids; k += 64) {
+      const uint32_t p = ids[k], n = A.p_norm[p];
+      idn[k] = n;
+      A.sample_ids[B.sample_off + k] = p;
+      A.sample_nrm[B.sample_off + k] = n;
+      if (PAR) continue;
+      if (n != GX_NONE) {
+        gx_add(A.p_x + p, B.wt);
+        gx_add(A.normsum + n, B.wt);
+        if (A.p_touch) A.p_touch[p] = A.time;
+        cnum.mul(gx_add(A.ccount + p, 1.0));
+        cden.mul(gx_add(A.csum + n, 1.0));
+      } else
+        cnum.mul(A.p_prior[p]);
+    }
+    if (lane == 0) A.sample_len[b] = n_ids;
+    if (!PAR && !A.want_after && bi + 1 < nb) gx_take_out(A, Bn, lane, On);
+    n_prev = n_ids;
+    B = Bn;
+    Bn = Bnn;
+    O = On;
+    GX_WAVE_SYNC();
+    if (A.phase_clk) {
+      const unsigned long long t4 = __builtin_readcyclecounter();
+      clk[0] += t1 - t0;
+      clk[1] += t2 - t1;
+      clk[2] += t3 - t2;
+      clk[3] += t4 - t3;
+      clk[4] += 1;
+      sub[0] += ta - t0;
+      sub[1] += tb - ta;
+      sub[2] += tc - tb;
+      sub[3] += t1 - tc;
+      sub[4] += td - t2;
+      sub[5] += te_ - td;
+      sub[6] += t3 - te_;
+    }
+  }
+#undef GXR_LEV
+#undef GXR_REQUEST_RECORDS
+#undef GXR_REQUEST_COUNTS
+  if (PAR) {
+    double cl = cheap.ln();
+    for (int o = 32; o > 0; o >>= 1) cl += __shfl_down(cl, o, 64);
+    if (lane == 0) {
+      unsafeAtomicAdd(A.iter_out + 1, cl);
+      if (A.phase_clk) {
+        for (int k = 0; k < 5; ++k) atomicAdd(A.phase_clk + k, clk[k]);
+        for (int k = 0; k < 7; ++k) atomicAdd(A.phase_clk + 8 + k, sub[k]);
+      }
+    }
+    return;
+  }
+  gx_order();
+  if (A.want_after)
+    for (uint32_t k = lane; k < n_prev; k += 64) {
+      const uint32_t p = ids[k], n = idn[k];
+      after.mul(n == GX_NONE ? A.p_prior[p] : gx_ld(A.p_x + p) / gx_ld(A.normsum + n));
+    }
+  double cache_ln = cnum.ln() - cden.ln(), after_ln = after.ln(), cheap_ln = cheap.ln();
+  for (int o = 32; o > 0; o >>= 1) {
+    cache_ln += __shfl_down(cache_ln, o, 64);
+    after_ln += __shfl_down(after_ln, o, 64);
+    cheap_ln += __shfl_down(cheap_ln, o, 64);
+  }
+  if (lane == 0) {
+    A.iter_out[0] = cache_ln;
+    A.iter_out[1] = cheap_ln;
+    A.iter_out[2] = after_ln;
+    if (A.phase_clk) {
+      for (int k = 0; k < 5; ++k) A.phase_clk[k] += clk[k];
+      for (int k = 0; k < 7; ++k) A.phase_clk[8 + k] += sub[k];
+    }
+  }
+}
+size_t gibbs_reg_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_sample, uint32_t own_slots) {
+  return (size_t)cap_arcs * 8 + (size_t)cap_states * (2 * 8 + 2 * 4) + ((size_t)cap_states + 1) * 4 + (size_t)cap_sample * 8 +
+         (size_t)own_slots * 16 + ((size_t)cap_arcs * 2 + 15) / 16 * 16;
+}
+template <bool PAR, int NQ>
+static hipError_t launch_reg(const GxArgs& A, uint32_t grid, size_t lds, hipStream_t s) {
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)gibbs_reg_wave_kernel<PAR, NQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((gibbs_reg_wave_kernel<PAR, NQ>), dim3(grid), dim3(64), lds, s, A);
+  return hipGetLastError();
+}
+hipError_t launch_gibbs_reg_wave(const GxArgs& A, uint32_t n_waves, int nq, hipStream_t s) {
+  const size_t lds = gibbs_reg_lds_bytes(A.cap_arcs, A.cap_states, A.cap_sample, n_waves ? A.own_slots : 0u);
+  if (n_waves) {
+    switch (nq) {
+      case 1: return launch_reg<true, 1>(A, n_waves, lds, s);
+      case 2: return launch_reg<true, 2>(A, n_waves, lds, s);
+      case 4: return launch_reg<true, 4>(A, n_waves, lds, s);
+      case 8: return launch_reg<true, 8>(A, n_waves, lds, s);
+    }
+    return hipErrorInvalidValue;
+  }
+  const uint32_t grid = A.n_chains > 1 ? A.n_chains : 1u;
+  switch (nq) {
+    case 2: return launch_reg<false, 2>(A, grid, lds, s);
+    case 4: return launch_reg<false, 4>(A, grid, lds, s);
+    case 8: return launch_reg<false, 8>(A, grid, lds, s);
+  }
+  return hipErrorInvalidValue;
+}
+
 // ---- the parallel sweep's recount: counts := prior + weighted uses in the new samples (the caller has set them to the priors).
 // A thread per sample entry; a workgroup's entries meet in two open-addressing tables in LDS (parameter -> weight, norm group ->
 // weight) and reach global memory once per workgroup and key: the popular parameters of a model (a tagger's "the" / DT) are
@@ -535,7 +1030,8 @@ __device__ __forceinline__ void gx_tab_add(uint32_t* keys, double* vals, uint32_
 }
 __global__ __launch_bounds__(1024) void gibbs_recount_tables_kernel(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids,
                                                                     const uint32_t* nrm, uint32_t n_blocks, double* new_x,
-                                                                    double* new_norm, uint32_t p_slots, uint32_t n_slots) {
+                                                                    double* new_norm, uint32_t p_slots, uint32_t n_slots,
+                                                                    const uint32_t* list) {
   extern __shared__ __attribute__((aligned(16))) unsigned char rc_lds[];
   double* pv = (double*)rc_lds;
   double* nv = pv + p_slots;
@@ -552,7 +1048,8 @@ __global__ __launch_bounds__(1024) void gibbs_recount_tables_kernel(const GxBloc
   __syncthreads();
   // a wavefront per block at a time: its entries side by side
   const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
-  for (uint32_t b = blockIdx.x * nw + wv; b < n_blocks; b += gridDim.x * nw) {
+  for (uint32_t bi = blockIdx.x * nw + wv; bi < n_blocks; bi += gridDim.x * nw) {
+    const uint32_t b = list ? list[bi] : bi;  // (list: the blocks to count, n_blocks of them)
     const GxBlock B = blocks[b];
     const uint32_t n = len[b];
     for (uint32_t k = lane; k < n; k += 64) {
@@ -569,13 +1066,13 @@ __global__ __launch_bounds__(1024) void gibbs_recount_tables_kernel(const GxBloc
     if (nk[i] != 0xffffffffu) unsafeAtomicAdd(new_norm + nk[i], nv[i]);
 }
 hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
-                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s) {
+                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s, const uint32_t* list) {
   const uint32_t p_slots = 8192, n_slots = 1024;
   const size_t lds = (size_t)(p_slots + n_slots) * 12;
   (void)hipFuncSetAttribute((const void*)gibbs_recount_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const uint32_t grid = std::min<uint32_t>(256u, (n_blocks + 15) / 16);
   hipLaunchKernelGGL(gibbs_recount_tables_kernel, dim3(grid ? grid : 1u), dim3(1024), lds, s, blocks, len, ids, nrm, n_blocks, new_x, new_norm,
-                     p_slots, n_slots);
+                     p_slots, n_slots, list);
   return hipGetLastError();
 }
 

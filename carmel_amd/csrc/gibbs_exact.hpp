@@ -28,6 +28,7 @@ struct GxArgs {
   const uint32_t* out_off;    // per state: first out-arc (bundle-relative), n_states + 1 per block
   const uint32_t* level_off;  // per level: first state, n_levels + 1 per block
   const uint16_t* state_lev;  // per state: its level
+  const uint32_t* lev_arc;    // per level: its first arc (= out_off[level_off[l]]; n_levels + 1 per block, beside level_off)
   const uint32_t* p_norm;
   const double* p_prior;
   double* p_x;                // CRP counts; their time-weighted sums are folded once per sweep (launch_forest_fold)
@@ -48,6 +49,7 @@ struct GxArgs {
   int want_after;
   int counterfactual;         // parallel sweep: take the block's own previous sample out of the snapshot counts
   uint32_t cap_arcs, cap_states, cap_levels, cap_sample;  // LDS carve: the largest block's arcs / states / levels / sample
+  uint32_t own_slots;         // the register kernel's own-sample tables: slots each (a power of two, >= 2 x cap_sample)
   // several exact chains side by side (the runs of --crp-restarts, gibbs.hpp:880-914: independent by construction): chain c =
   // workgroup c of the launch, one wavefront, with its own counts, cache model, sample and results at these strides, drawing
   // the uniforms of sweep iter + c * iter_stride.  n_chains <= 1: the one chain of the fields above.
@@ -65,12 +67,17 @@ size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t ca
 // n_waves = 0: the exact chain (one wavefront; GxArgs::n_chains of them side by side); > 0: the stale-count parallel sweep on that
 // many wavefronts
 hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_t s);
+// the same sweep with a block's arcs in registers (gibbs_reg_wave_kernel): trellis blocks of at most 64 nq arcs and states and
+// GX_REG_LEVELS levels; nq = 1, 2, 4, 8 (the exact chain: 2, 4, 8)
+#define GX_REG_LEVELS 127
+size_t gibbs_reg_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_sample, uint32_t own_slots);
+hipError_t launch_gibbs_reg_wave(const GxArgs& A, uint32_t n_waves, int nq, hipStream_t s);
 // dst[c * n + k] = src[k] for c < copies (every chain's cache model starts a sweep at the priors)
 hipError_t launch_gibbs_broadcast(double* dst, const double* src, uint64_t n, uint32_t copies, hipStream_t s);
 
 // the parallel sweep's recount through per-workgroup LDS tables: new_x / new_norm (set to the priors by the caller) += the weighted
 // uses of the samples (len, ids, nrm)
 hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
-                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s);
+                                       uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s, const uint32_t* list = nullptr);
 
 }  // namespace carmel_hip

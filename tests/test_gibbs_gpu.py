@@ -459,6 +459,40 @@ def test_observer_sees_the_chain_as_it_stands(oracle, golden_dir):
     fb.close()
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(include_self=True), dict(init_p0=True)])
+def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle, golden_dir, monkeypatch, kw):
+    """gibbs_lane.hip (round 6): the stale-count sweep with 64 trellis lattices a wavefront, one per lane -- arcs streamed in the
+    order of the backward sweep, two levels of backward values per lane, every level's terms divided by a power of two, the
+    block's previous path taken out of the counts through tables over the block's local numbering -- against gibbs_exact.hip's
+    wavefront-per-block kernels (CARMEL_HIP_GIBBS_LANE=0; themselves held to the workgroup kernel and the reference's chain
+    below): the same uniforms and the same order of every state's subtractions, so the same paths block for block, the same
+    sweep probabilities and the same final weights, on the tutorial's tagging cascade (1005 sentences: trellis lattices of
+    3 to 600 arcs, the longest ones beyond the lanes' LDS budget and left to the wavefront kernels in the same sweep)."""
+    from carmel_amd.trainer import HipGibbs
+    g = lambda n: open(os.path.join(golden_dir, n)).read()
+    res = {}
+    init = kw.pop("init_p0", False)
+    for which in ("lane", "wave"):
+        if which == "wave":
+            monkeypatch.setenv("CARMEL_HIP_GIBBS_LANE", "0")
+        else:
+            monkeypatch.delenv("CARMEL_HIP_GIBBS_LANE", raising=False)
+        oc, ocorp, fb = _setup(oracle, [g("tagging.fsa"), g("tagging.fst")], g("tagging.data"), [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.1, 0.1])
+        gs = HipGibbs(fb, 9, burnin=3, seed=5, mode=1, **kw)
+        if init:  # the first sweep samples from the composed weights (--init-from-p0: gibbs.cc:405-421)
+            gs.set_init_weights(fb.arc_weights())
+        lp = gs.run()
+        res[which] = (np.array(lp), gs.iter_cheap_logprob.copy(), [gs.sample(b) for b in range(gs.n_blocks)], fb.weights().copy())
+        gs.close()
+        fb.close()
+    a, b = res["lane"], res["wave"]
+    assert all(len(x) > 0 for x in a[2])
+    assert a[2] == b[2]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)
+
+
 def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, monkeypatch):
     """gibbs_exact.hip's single-wavefront kernel (linear domain, static arc records, DPP choice) and gibbs.hip's workgroup
     kernel (log domain; CARMEL_HIP_GIBBS_WORKGROUP=1) are two implementations of the reference's chain: the same samples,
