@@ -199,6 +199,8 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
     """one synthetic EM workload (c2 / c4 / c4a / long / toy); returns the result object (rank 0) or None"""
     import numpy as np
     import torch
+    import carmel_amd
+    carmel_amd.options_from_env()  # (bench.py is a front end: CARMEL_HIP_<KEY> in its environment are the library's options)
     from carmel_amd import synth
     from carmel_amd.trainer import HipForwardBackward
     ctl = "cpu" if one_device else "cuda"  # where the few control values of the collectives below live
@@ -320,13 +322,15 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
     for _ in range(warmup):
         step()
     fence()
-    kernel_ms = []
+    kernel_ms, step_end = [], []
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        step()  # (ends when the host has the M-step's largest change: every step's end is a point on the host's clock)
+        step_end.append(time.perf_counter())
         kernel_ms.append(fb.last_kernel_ms())
     fence()
     dt = time.perf_counter() - t0
+    step_ms = 1e3 * np.diff(np.array([t0] + step_end))
     lp, wlp, n_swept = fb.read_scalars()
     # the exchange on its own, and what of it the step does not hide: exchange_ms = one iteration's collectives back to
     # back on the communicator's stream (carmel_hip_exchange_measure); exposed_exchange_ms = the step time with the exchange
@@ -389,7 +393,9 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                  ("%d-%d" % walk) if walk else {"c4a": "5-40", "long": "40-600", "toya": "3-14"}.get(name, "5-40"))
         out = {
             "metric": METRIC, "value": value, "unit": "arc-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
+            "ms_per_step": 1e3 * dt / steps, "ms_per_step_median": float(np.median(step_ms)),
+            "ms_per_step_p10": float(np.percentile(step_ms, 10)), "ms_per_step_p90": float(np.percentile(step_ms, 90)),
+            "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: " % name + WORKLOAD_TEXT[name] % shape,
                        "pairs_per_gpu": c.n_pairs, "wfst_arcs": int(w.n_arcs), "wfst_states": int(w.n_states),
@@ -424,7 +430,9 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
                          "traffic_source": "profiles/pmc_traffic_%s.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                            "command (tools/pmc_traffic.sh), committed; null when kernels.hip changed since, the "
                                            "workload differs or a CARMEL_HIP_* switch is set -- not measured by this run" % name,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms},
+                         "algorithmic_bytes_per_launch": alg, "kernel_ms": k_ms, "kernel_ms_median": float(np.median(kernel_ms)),
+                         # SURVEY 8(d)'s WHOLE formula -- the M-step's 16 B per WFST arc included -- over the whole step
+                         "frac_iteration": (alg + 16.0 * w.n_arcs) / (1e-3 * 1e3 * dt / steps) / 1e9 / HBM_PEAK_GBS},
         }
         if xch:
             out["exchange_ms"], out["exposed_exchange_ms"], out["exchange"] = xch["exchange_ms"], xch["exposed_exchange_ms"], xch
@@ -638,6 +646,8 @@ def run_c5(args, steps, warmup, local_rank=0, rank=0, exact_sweeps=1):
     """BASELINE.json configs[4]: forest-em --crp sweeps over synthetic packed forests.  A step is one Gibbs sweep over all
     forests: the parallel stale-count sweep (the throughput mode) and -- `exact` -- the reference's sequential chain"""
     import numpy as np
+    import carmel_amd
+    carmel_amd.options_from_env()  # (bench.py is a front end: CARMEL_HIP_<KEY> in its environment are the library's options)
     from carmel_amd import synth
     from carmel_amd.forests import HipForests
     node_off, label, ref, nxt, n_rules, goff, grule = synth.random_forests(args.forests)
@@ -713,14 +723,20 @@ def compact_line(out):
         return t if len(t) <= n else t[:n - 1] + "~"
 
     def rf(r):
-        return None if not r else {"bound": r.get("bound"), "achieved": _r4(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"),
-                                   "frac": _r4(r.get("frac")), "traffic": _r4(r.get("traffic"))}
+        if not r:
+            return None
+        o = {"bound": r.get("bound"), "achieved": _r4(r.get("achieved")), "peak": r.get("peak"), "unit": r.get("unit"),
+             "frac": _r4(r.get("frac")), "traffic": _r4(r.get("traffic"))}
+        if "frac_iteration" in r:
+            o["frac_iteration"] = _r4(r["frac_iteration"])
+        return o
 
     def cb(c):
         return None if not c else {"value": _r4(c.get("value")), "unit": c.get("unit"), "cores": c.get("cores"), "kind": c.get("kind"),
                                    "sample": short(c.get("sample", ""), 90)}
 
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median", "ms_per_step_p10", "ms_per_step_p90",
+            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     line = {k: (_r4(out[k]) if isinstance(out.get(k), float) else out.get(k)) for k in keep if k in out}
     line["metric"] = short(line.get("metric", ""), 90)
     cfg = out.get("config", {})
@@ -797,7 +813,7 @@ def _self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default 20; c5: 1000 sweeps, the length BASELINE.json's config names")
+    ap.add_argument("--steps", type=int, default=None, help="default 200 (c3: 20); c5: 1000 sweeps, the length BASELINE.json's config names")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c4", choices=["c2", "c4", "c4a", "long", "toy", "toya", "c3", "c5", "amb", "crp"])
     ap.add_argument("--lines", type=int, default=200000, help="c3: corpus lines")
@@ -810,7 +826,7 @@ def main():
     ap.add_argument("--secondary", default="c4a,amb,c2,long,c3,c5,crp", help="which workloads follow the headline at N = 1")
     ap.add_argument("--full-out", default=None, help="file for the complete JSON (default: gpurun_out/bench_full.json when that directory "
                                                       "exists or can be made, else none); stdout carries the compact line")
-    ap.add_argument("--secondary-steps", type=int, default=10)
+    ap.add_argument("--secondary-steps", type=int, default=40)
     ap.add_argument("--cpu-sample-pairs", type=int, default=200000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the all-cores CPU leg (0: host cores, at most 64)")
     ap.add_argument("--host-threads", type=int, default=0)
@@ -823,7 +839,8 @@ def main():
     ap.add_argument("--walk-arcs", default=None, help="min,max arcs of the headline's random walks (default: the config's; other values are experiments)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 1000 if args.config == "c5" else 20
+        # (the EM headline's timed region used to be 20 steps = 9 ms of a c4 run: round-5 verdict.  200 steps, median and p10 / p90 on the line)
+        args.steps = 1000 if args.config == "c5" else 20 if args.config in ("c3", "amb", "crp") else 200
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N` (no launcher): start the N ranks ourselves.  Nothing in this process has touched

@@ -37,6 +37,7 @@ SYMBOLS = [
     "carmel_hip_comm_world", "carmel_hip_allreduce_counts", "carmel_hip_comm_allreduce_host",
     "carmel_hip_comm_abort", "carmel_hip_comm_transport_name", "carmel_hip_comm_create_custom", "carmel_hip_comm_set_sendrecv", "carmel_hip_comm_selftest", "carmel_hip_exchange_plan",
     "carmel_hip_exchange_info", "carmel_hip_exchange_measure", "carmel_hip_exchange_clear", "carmel_hip_set_layout_policy", "carmel_hip_set_matrix_fb",
+    "carmel_hip_set_option", "carmel_hip_get_option", "carmel_hip_option_count", "carmel_hip_option_name",
 ]
 
 
@@ -80,6 +81,12 @@ def _load():
     vp = C.c_void_p
     lib.carmel_hip_last_error.argtypes = []
     lib.carmel_hip_device_count.argtypes = []
+    lib.carmel_hip_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    lib.carmel_hip_get_option.argtypes = [C.c_char_p]
+    lib.carmel_hip_get_option.restype = C.c_char_p
+    lib.carmel_hip_option_count.argtypes = []
+    lib.carmel_hip_option_name.argtypes = [C.c_int]
+    lib.carmel_hip_option_name.restype = C.c_char_p
     lib.carmel_hip_random_restart.argtypes = [vp, C.c_uint64, C.c_uint32]
     lib.carmel_hip_keep_em_weights.argtypes = [vp]
     lib.carmel_hip_comm_unique_id.argtypes = [vp]
@@ -228,6 +235,32 @@ class CarmelHipError(RuntimeError):
 def check(rc, where):
     if rc != 0:
         raise CarmelHipError(rc, where)
+
+
+def set_option(key, value):
+    """carmel_hip_set_option: one of the library's switches (include/carmel_hip.h); value None unsets it"""
+    rc = lib.carmel_hip_set_option(key.encode(), None if value is None else str(value).encode())
+    if rc != 0:
+        raise ValueError("libcarmel_hip has no option %r (it has: %s)" % (key, ", ".join(option_names())))
+
+
+def get_option(key):
+    v = lib.carmel_hip_get_option(key.encode())
+    return None if v is None else v.decode()
+
+
+def option_names():
+    return [lib.carmel_hip_option_name(i).decode() for i in range(lib.carmel_hip_option_count())]
+
+
+def options_from_env(environ=None):
+    """what the front ends do at start-up (csrc/host/env_options.hpp): CARMEL_HIP_<KEY>=v -> set_option("<key>", v), CARMEL_TIMING ->
+    "timing".  The library itself never reads the environment; bench.py and the tools call this, the package does not."""
+    names = set(option_names())
+    for k, v in (os.environ if environ is None else environ).items():
+        key = "timing" if k == "CARMEL_TIMING" else k[len("CARMEL_HIP_"):].lower() if k.startswith("CARMEL_HIP_") and k != "CARMEL_HIP_LIB" else None
+        if key in names:
+            set_option(key, v)
 
 
 def ptr(a):

@@ -12,6 +12,7 @@
 #include <unordered_map>
 #include <vector>
 #include "engine.hpp"
+#include "options.hpp"
 #include "host/refhash.hpp"
 #include "rng.hpp"
 #include "unrolled_args.hpp"
@@ -219,20 +220,20 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   BuildOptions opt;
   opt.prune = prune != 0;
   opt.threads = host_threads;
-  if (const char* e = getenv("CARMEL_HIP_LANE_STATES")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
-  if (const char* e = getenv("CARMEL_HIP_TILE_SWEEP")) opt.tile_sweep = atoi(e) != 0;  // A/B: 0 = the five-kernel E-step's layout
-  if (const char* e = getenv("CARMEL_HIP_LANE_FUSED")) opt.lane_fused = atoi(e) != 0;  // A/B: 0 = the 16384-position tiles for lane corpora
-  if (getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0) opt.lane_fused = false;  // (the gather formulation has no tiles)
-  if (const char* e = getenv("CARMEL_HIP_LANE_CHUNKS")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));  // experiment: pieces per lane class
-  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
-  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
-  if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
-  if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
+  if (const char* e = lib_opt("lane_states")) opt.lane_states = (uint32_t)atoi(e);  // tuning / A-B runs
+  if (const char* e = lib_opt("tile_sweep")) opt.tile_sweep = atoi(e) != 0;  // A/B: 0 = the five-kernel E-step's layout
+  if (const char* e = lib_opt("lane_fused")) opt.lane_fused = atoi(e) != 0;  // A/B: 0 = the 16384-position tiles for lane corpora
+  if (lib_opt("transpose") && atoi(lib_opt("transpose")) == 0) opt.lane_fused = false;  // (the gather formulation has no tiles)
+  if (const char* e = lib_opt("lane_chunks")) opt.lane_chunks = (uint32_t)std::max(1, atoi(e));  // experiment: pieces per lane class
+  if (const char* e = lib_opt("lane_window")) opt.lane_window = (uint32_t)std::max(0, atoi(e));          // 0: no windowed groups
+  if (const char* e = lib_opt("lane_window_min")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));  // tests: window small lattices too
+  if (const char* e = lib_opt("wave_ring")) opt.wave_ring = atoi(e) != 0;  // A/B: 0 = every value in LDS
+  if (const char* e = lib_opt("wave_min_width")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);  // tests: narrow lattices too
   {
     // lattice construction on the GPU (lattice_gpu.hip) when every lattice of the corpus is a one-per-lane case;
     // otherwise -- or with CARMEL_HIP_GPU_BUILD=0 -- the host builder below does the whole corpus
-    const bool want_gpu = !(getenv("CARMEL_HIP_GPU_BUILD") && atoi(getenv("CARMEL_HIP_GPU_BUILD")) == 0) &&
-                          !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    const bool want_gpu = !(lib_opt("gpu_build") && atoi(lib_opt("gpu_build")) == 0) &&
+                          !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0);
     // a probe: a few pairs spread over the corpus built on the host first (milliseconds).  If one of them is already not
     // a case for the GPU builder -- a cycle, more states than a lane takes, more arcs than its record buffers (256) -- the
     // corpus goes to the host builder without the device attempt (0.1 s on the tagging cascade x400 before it gives up)
@@ -263,7 +264,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
         if (!done) opt.gpu_large_caps = false;
       }
       if (done) {
-        if (getenv("CARMEL_TIMING")) fprintf(stderr, "timing: lattices built on the GPU\n");
+        if (lib_opt("timing")) fprintf(stderr, "timing: lattices built on the GPU\n");
         rc = build_run_tables(t);
         if (stats) stats->device_bytes = t->device_bytes;  // (with the run tables / the tiles' arc ids)
         return rc;
@@ -280,12 +281,12 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   // gather them from the table (sweep_wave_kernel<.., GW>): no pass writes them out in lattice order -- a fifth of the E-step on
   // the `long` workload.  CARMEL_HIP_WAVE_GATHER=0/1: never / whatever the table's size (A/B; the same sums in the same order)
   {
-    const char* e = getenv("CARMEL_HIP_WAVE_GATHER");
-    const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    const char* e = lib_opt("wave_gather");
+    const bool want_t = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0);
     opt.wave_gather = want_t && (e ? atoi(e) != 0 : t->w.n_arcs * sizeof(double) <= (64ull << 20));
   }
-  opt.device_tables = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0) &&
-                      !(getenv("CARMEL_HIP_DEVICE_TABLES") && atoi(getenv("CARMEL_HIP_DEVICE_TABLES")) == 0);
+  opt.device_tables = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0) &&
+                      !(lib_opt("device_tables") && atoi(lib_opt("device_tables")) == 0);
   if (!build_lattices(t->w, t->corpus, opt, L, err)) return fail(CARMEL_HIP_ERR_ARG, err);
   const bool have_tables = !L.t_buckets.empty() || L.tables_deferred;
   if (has_derivation) std::memcpy(has_derivation, L.has_deriv.data(), L.has_deriv.size());
@@ -320,7 +321,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   HIPCHK(t->wave_spill.alloc(L.wave_spill_states));
   {
     // the transposition path never looks at a forward record's arc id: it gets the flags words alone (half the bytes)
-    const bool want_t = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+    const bool want_t = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0);
     if (want_t && have_tables) {
       std::vector<uint32_t> fx(L.lane_fwd.size());
       host_parallel_for(fx.size(), [&](size_t k0, size_t k1) {
@@ -353,7 +354,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, t->lane_rec2.bytes(), s));
     HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p,
                                     t->tile_group.p, (uint32_t)(t->tile_group.n - 1), t->tile_chain.p, s));
-    if (getenv("CARMEL_TIMING")) {
+    if (lib_opt("timing")) {
       std::vector<uint32_t> ch(t->lane_chain.n);
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
@@ -396,7 +397,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
     HIPCHK(t->slot_pos.upload(L.slot_pos, s));
     HIPCHK(t->hot_chunks.upload(L.hot_chunks, s));
     {
-      const bool want = !(getenv("CARMEL_HIP_TRANSPOSE") && atoi(getenv("CARMEL_HIP_TRANSPOSE")) == 0);
+      const bool want = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0);
       t->use_transpose = want && !L.t_buckets.empty();
       if (t->use_transpose) {
         HIPCHK(t->t_buckets.upload(L.t_buckets, s));
@@ -464,7 +465,7 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   std::vector<uint32_t>().swap(L.in_off);
   std::vector<uint32_t>().swap(L.out_off);
   std::vector<uint32_t>().swap(L.level_off);
-  if (getenv("CARMEL_TIMING")) {
+  if (lib_opt("timing")) {
     fprintf(stderr, "timing: layout lane_arcs=%llu lane_groups=%zu lane_pieces=%zu bundles=%zu bundle_classes=%zu total_arcs=%llu aligned=%d\n",
             (unsigned long long)L.lane_arcs, L.lane_groups.size(), L.lane_classes.size(), L.bundles.size(), L.classes.size(),
             (unsigned long long)L.total_arcs, (int)L.lane_tiles_aligned);
@@ -813,7 +814,7 @@ int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M
   M.dig_alpha = t->any_digamma ? t->dig_alpha.p : nullptr;
   M.tie_alpha = (t->any_digamma && t->n_ties) ? t->tie_alpha.p : nullptr;
   M.max_change_bits = t->maxchg.p;
-  static const bool mailbox = !(getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX")));
+  const bool mailbox = !(lib_opt("mailbox") && !atoi(lib_opt("mailbox")));
   M.box = mailbox ? t->h_box : nullptr;  // (every M-step's last kernel leaves its result there; carmel_hip_maximize waits for its own)
   M.box_seq = M.box ? ++t->box_seq : 0;
   M.n = t->np();
@@ -903,7 +904,7 @@ void trans_args(carmel_hip_trainer* t, TransArgs& T) {
     // (tile, bucket) cell holds a run of items -- the corpora that get run-length indices --, the second one (a gather)
     // where cells hold an item or two and a scattered write would touch a line per item.  CARMEL_HIP_TRANS_SCATTER is the
     // A/B switch (bit-identical results).
-    const char* e = getenv("CARMEL_HIP_TRANS_SCATTER");
+    const char* e = lib_opt("trans_scatter");
     T.scatter = e ? (uint32_t)atoi(e) : (t->use_runs ? 3u : 0u);
     if (t->lat.lane_fused) T.scatter &= ~2u;  // the sweep writes XC in tile-major item order; the bucket pass gathers
   }
@@ -937,7 +938,7 @@ __global__ __launch_bounds__(256) void lds_poison_kernel(unsigned* sink) {
   if (lds_words[(threadIdx.x * 977u) % n] != 0xffffffffu) *sink = 1;  // (keeps the stores)
 }
 static int lds_poison(carmel_hip_trainer* t) {
-  static const int mode = getenv("CARMEL_HIP_POISON") ? atoi(getenv("CARMEL_HIP_POISON")) : 0;
+  const int mode = lib_opt("poison") ? atoi(lib_opt("poison")) : 0;
   if (mode < 2) return CARMEL_HIP_OK;
   static bool attr = false;
   const int bytes = 160 * 1024 - 256;
@@ -969,7 +970,7 @@ __global__ void publish_kernel(const unsigned long long* src, unsigned long long
 }
 // enqueue only: the value at dev goes to the mailbox behind what is on s so far; fetch_u64(.., published = true) waits for it later
 int publish_u64(carmel_hip_trainer* t, const unsigned long long* dev, hipStream_t s) {
-  static const bool off = getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX"));
+  const bool off = lib_opt("mailbox") && !atoi(lib_opt("mailbox"));
   if (!t->h_box || off) return CARMEL_HIP_OK;
   hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, s, dev, t->h_box, ++t->box_seq);
   HIPCHK(hipGetLastError());
@@ -977,7 +978,7 @@ int publish_u64(carmel_hip_trainer* t, const unsigned long long* dev, hipStream_
 }
 // published: the last kernel on s has already stored the value under sequence number t->box_seq (mstep_max_final_kernel)
 int fetch_u64(carmel_hip_trainer* t, const unsigned long long* dev, unsigned long long* out, hipStream_t s, bool published) {
-  static const bool off = getenv("CARMEL_HIP_MAILBOX") && !atoi(getenv("CARMEL_HIP_MAILBOX"));
+  const bool off = lib_opt("mailbox") && !atoi(lib_opt("mailbox"));
   if (!t->h_box || off) {
     HIPCHK(hipMemcpyAsync(out, dev, sizeof *out, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1076,7 +1077,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   LA.xc_t_pos = nullptr;
   LA.xc = nullptr;
   LA.trace = nullptr;
-  static const char* trace_path = getenv("CARMEL_HIP_LANE_TRACE");  // experiment: per-wave cycle stamps of the last E-step
+  const char* trace_path = lib_opt("lane_trace");  // experiment: per-wave cycle stamps of the last E-step
   static DevBuf<unsigned long long> trace_buf;
   if (trace_path) {
     if (trace_buf.n != t->lane_groups.n * 16) {
@@ -1116,7 +1117,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   // fused-lane layout: the lane sweep's backward pass sends a tile's posteriors to XC itself (sweep_lane_kernel<.., XC>);
   // CARMEL_HIP_LANE_FUSED_KERNEL=0: sweep -> post -> trans_c_tile on the same layout (the same bits in XC)
   const bool lane_fused = t->use_transpose && t->lat.lane_fused &&
-                          !(getenv("CARMEL_HIP_LANE_FUSED_KERNEL") && atoi(getenv("CARMEL_HIP_LANE_FUSED_KERNEL")) == 0);
+                          !(lib_opt("lane_fused_kernel") && atoi(lib_opt("lane_fused_kernel")) == 0);
   if (lane_fused) {
     LA.xc_tile_base = T.tile_base;
     LA.xc_t_pos = T.t_pos;
@@ -1131,7 +1132,7 @@ static int estimate_enqueue(carmel_hip_trainer* t, bool timed) {
   const uint32_t lane_tiles = (uint32_t)((t->wcache.n + t->lat.tile - 1) / t->lat.tile);
   // a corpus of plain lane lattices laid out for it: weights in, sweeps and posteriors out of a tile in one kernel
   // (CARMEL_HIP_TILE_SWEEP_KERNEL=0: the three kernels on the same layout, bit-identical)
-  const bool tile_kernel_off = getenv("CARMEL_HIP_TILE_SWEEP_KERNEL") && atoi(getenv("CARMEL_HIP_TILE_SWEEP_KERNEL")) == 0;
+  const bool tile_kernel_off = lib_opt("tile_sweep_kernel") && atoi(lib_opt("tile_sweep_kernel")) == 0;
   const bool tile_sweep = t->use_transpose && t->lat.tile_sweep && t->tile_group.n && !tile_kernel_off &&
                           ((T.scatter & 3u) == 0u || ((T.scatter & 3u) == 3u && T.use_runs));
   bool tile_sweep_done = false;

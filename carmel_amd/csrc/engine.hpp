@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include "../../include/carmel_hip.h"
+#include "options.hpp"
 #include "kernels.hpp"
 #include "unrolled_args.hpp"
 
@@ -44,7 +45,7 @@ struct DevBuf {
     // CARMEL_HIP_POISON=1 (debugging): fresh device memory is whatever the last process left there, usually zeros on an idle box;
     // a pattern of 0xff bytes (a NaN to every double, an out-of-range index to every integer) makes a read of something never
     // written show up on every run instead of on the one after somebody else's job
-    static const bool poison = getenv("CARMEL_HIP_POISON") && atoi(getenv("CARMEL_HIP_POISON"));
+    const bool poison = lib_opt("poison") && atoi(lib_opt("poison"));
     if (poison && e == hipSuccess) {
       e = hipMemset(p, 0xff, count * sizeof(T) + DEVBUF_SLACK);
       if (e == hipSuccess) e = hipDeviceSynchronize();  // (before anything on another stream writes there)

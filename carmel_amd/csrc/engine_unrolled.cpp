@@ -7,6 +7,7 @@
 #include <limits>
 
 #include "dense.hpp"
+#include "options.hpp"
 #include "engine.hpp"
 #include "unrolled_args.hpp"
 #include <numeric>
@@ -19,7 +20,7 @@ static int dense_try_build(carmel_hip_trainer* t, const UnrolledModel& M, const 
                            bool& built) {
   built = false;
   t->dense = false;
-  if (const char* e = getenv("CARMEL_HIP_DENSE"))
+  if (const char* e = lib_opt("dense"))
     if (atoi(e) == 0) return CARMEL_HIP_OK;
   const uint32_t S = M.S, V = M.V, SP = dense_padded_states(S);
   if (!t->cascade || !SP || S > DENSE_MAX_STATES || M.e_arc.size() > 16 || V == 0 || V > 4096) return CARMEL_HIP_OK;
@@ -139,7 +140,7 @@ static int dense_try_build(carmel_hip_trainer* t, const UnrolledModel& M, const 
   t->d_SP = SP;
   t->d_groups = ng;
   t->dense = true;
-  if (getenv("CARMEL_TIMING"))
+  if (lib_opt("timing"))
     fprintf(stderr, "timing: dense sweep S=%u padded=%u symbols=%u eps=%zu slots=%u strings=%zu positions=%llu groups=%u parked_bytes=%llu\n", S, SP,
             V, M.e_arc.size(), n_slots, np, (unsigned long long)M.seq_sym.size(), ng, (unsigned long long)(vbuf_off[ng] * 8));
   built = true;
@@ -153,7 +154,7 @@ int unrolled_try_build(carmel_hip_trainer* t, int host_threads, uint8_t* has_der
   t->unrolled = false;
   if (!t->allow_unrolled) return CARMEL_HIP_OK;  // carmel_hip_set_layout_policy: explicit lattices on every rank
   bool forced = false;  // CARMEL_HIP_UNROLLED: 0 = never, 1 = whenever eligible, unset = when it pays (density test below)
-  if (const char* e = getenv("CARMEL_HIP_UNROLLED")) {
+  if (const char* e = lib_opt("unrolled")) {
     if (atoi(e) == 0) return CARMEL_HIP_OK;
     forced = true;
   }

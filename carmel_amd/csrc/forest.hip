@@ -23,6 +23,7 @@
 #include <numeric>
 #include <unordered_map>
 #include "engine.hpp"
+#include "options.hpp"
 #include "forest_exact.hpp"
 #include "gibbs_exact.hpp"  // launch_gibbs_broadcast
 #include "rng.hpp"
@@ -2108,7 +2109,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     uint64_t tot = 0;
     for (auto& c : F->classes) {
       F->gcol_off.push_back(tot);
-      if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || getenv("CARMEL_HIP_FOREST_GCOL")) tot += (uint64_t)c.count * 2 * c.max_nodes * 64;
+      if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || lib_opt("forest_gcol")) tot += (uint64_t)c.count * 2 * c.max_nodes * 64;
     }
     if (tot) HIPCHK(F->gcol.alloc(tot));
   }
@@ -2623,7 +2624,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   A.counterfactual = 1;
   // parallel mode, second formulation (CARMEL_HIP_FOREST_SWEEP=1 selects the first, kept as the A/B reference)
   bool split_recount = false;  // set below
-  const bool sweep2 = o->mode == 1 && F->sweep2_ok && !(getenv("CARMEL_HIP_FOREST_SWEEP") && atoi(getenv("CARMEL_HIP_FOREST_SWEEP")) == 1);
+  const bool sweep2 = o->mode == 1 && F->sweep2_ok && !(lib_opt("forest_sweep") && atoi(lib_opt("forest_sweep")) == 1);
   if (sweep2) {
     // the classes' recounts beside the classes still sampling (false: one recount after all, the earlier form)
     split_recount = true;
@@ -2651,21 +2652,21 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   const uint32_t frc_slots0 = 8192, frc_slots1 = 4096;
   const size_t frc_bytes = (size_t)(frc_slots0 + frc_slots1) * 8;
   (void)hipFuncSetAttribute((const void*)forest_recount_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)frc_bytes);
-  const bool lds_walk = !(getenv("CARMEL_HIP_FOREST_LDSWALK") && atoi(getenv("CARMEL_HIP_FOREST_LDSWALK")) == 0);
+  const bool lds_walk = !(lib_opt("forest_ldswalk") && atoi(lib_opt("forest_ldswalk")) == 0);
   // several lanes per forest in the parallel sweep (CARMEL_HIP_FOREST_MULTI=0: one forest per lane, the A/B reference -- and the
   // chain whose uniforms are keyed like the sequential walk's)
-  const bool multi = sweep2 && F->multi_ok && !(getenv("CARMEL_HIP_FOREST_MULTI") && atoi(getenv("CARMEL_HIP_FOREST_MULTI")) == 0);
+  const bool multi = sweep2 && F->multi_ok && !(lib_opt("forest_multi") && atoi(lib_opt("forest_multi")) == 0);
   const uint64_t nf_slots = F->h_groups.size() * 64;
   auto fm_bytes = [](const carmel_hip_forests::Cls& c) {  // LDS of one forest in forest_sample_multi_kernel
     return (size_t)c.m_n * 16 + (((size_t)c.m_tab + 2 * (size_t)c.m_front) * 2 + 15) / 16 * 16;
   };
   const uint32_t stack_lds = 32u;
-  if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !getenv("CARMEL_HIP_FOREST_NOHASH")) {
+  if (o->mode == 1 && !sweep2 && (uint64_t)F->max_sample * 20 > 32 * 9 && !lib_opt("forest_nohash")) {
     HIPCHK(ghash.alloc((size_t)nf * FOREST_GHASH));
     A.ghash = ghash.p;
   }
   DevBuf<unsigned long long> trace_buf;  // experiment: per-wave phase stamps of the last parallel sweep
-  const char* trace_path = getenv("CARMEL_HIP_FOREST_TRACE");
+  const char* trace_path = lib_opt("forest_trace");
   if (trace_path && o->mode == 1) {
     HIPCHK(trace_buf.alloc(F->h_groups.size() * 8 * 8));  // (the several-lanes sampler: eight workgroups per lane group)
     HIPCHK(hipMemset(trace_buf.p, 0, trace_buf.bytes()));
@@ -2679,7 +2680,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   DevBuf<double> x_ccount, x_csum;
   DevBuf<unsigned long long> x_clk;
   bool exact_dev = o->mode == 0 && F->multi_ok && !guard.changed && (o->high_temp == 0 || o->high_temp == 1) &&
-                   (o->low_temp == 0 || o->low_temp == 1) && nf > 0 && !getenv("CARMEL_HIP_FOREST_EXACT_HOST");
+                   (o->low_temp == 0 || o->low_temp == 1) && nf > 0 && !lib_opt("forest_exact_host");
   if (exact_dev) {
     for (auto& c : F->classes) {
       XA.max_n = std::max(XA.max_n, c.m_n);
@@ -2712,7 +2713,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     XA.iter_out = F->iter_out.p;
     XA.seed = o->seed;
     XA.n_forests = (uint32_t)nf;
-    if (getenv("CARMEL_HIP_FOREST_EXACT_CLK")) {
+    if (lib_opt("forest_exact_clk")) {
       HIPCHK(x_clk.alloc(8));
       HIPCHK(hipMemsetAsync(x_clk.p, 0, 64, s));
       XA.phase_clk = x_clk.p;
@@ -2758,7 +2759,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     const uint32_t n_runs = o->restarts + 1;
     const uint64_t S = F->sample_rules[0].n, ngs = std::max<uint64_t>(ng, 1);
     uint32_t cap = 64;
-    if (const char* e = getenv("CARMEL_HIP_GIBBS_CHAINS")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
+    if (const char* e = lib_opt("gibbs_chains")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
     const uint64_t chain_bytes = ((uint64_t)nr * 4 + ngs * 2) * 8 + S * 8 + nf * 4 + 64;
     cap = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1, (8ull << 30) / chain_bytes));
     DevBuf<double> mx, ms, mt, mn, mcc, mcs, mio;
@@ -2899,14 +2900,14 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         // (the previous sample's class words, written by its recount: what the proposal kernel scans for the forest's own uses)
         A.and_list = F->and_list.p;
         A.n_and = F->n_and;
-        A.p_only = (A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN")) ? 1 : 0;
+        A.p_only = (A.power == 1.0 && !lib_opt("forest_logdomain")) ? 1 : 0;
         // every launch class on the several-lanes sampler: it computes the proposal probabilities itself (no kernel in front
         // of the classes, no rec_p round trip)
         const bool ext_now = A.p_only != 0;
         bool fold_proposal = multi && ext_now;
         for (auto& c : F->classes)
           if (fm_bytes(c) * FM_FPW > 64 * 1024) fold_proposal = false;
-        if (getenv("CARMEL_HIP_FOREST_GCOL")) fold_proposal = false;
+        if (lib_opt("forest_gcol")) fold_proposal = false;
         if (F->n_and && !fold_proposal)
           hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
         if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
@@ -2919,7 +2920,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           const auto& c = F->classes[ci];
           A.first_group = c.first;
           // temperature 1: mantissa / exponent arithmetic (12 bytes per node); annealing: the log domain
-          const bool ext = A.power == 1.0 && !getenv("CARMEL_HIP_FOREST_LOGDOMAIN");
+          const bool ext = A.power == 1.0 && !lib_opt("forest_logdomain");
           const size_t lds = (size_t)c.max_nodes * 64 * (ext ? 12 : 8) + (size_t)stack_lds * 64 * 4;
           // with the walk's tables in LDS: 16-bit rows (2 per node + 1, the child entries, the stack)
           const uint32_t kid_rows = std::max(c.max_kids, 1u);
@@ -2936,7 +2937,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           // several lanes per forest (temperature 1, tables within LDS): forest_sample_multi_kernel
           const size_t fm_per = fm_bytes(c);
           bool class_nodes = false;  // the class's sample is written as node numbers (FMultiArgs::prob)
-          const bool force_gcol = getenv("CARMEL_HIP_FOREST_GCOL") != nullptr;  // experiment: every class one forest per lane, columns in global memory
+          const bool force_gcol = lib_opt("forest_gcol") != nullptr;  // experiment: every class one forest per lane, columns in global memory
           if (multi && ext && fm_per * FM_FPW <= 64 * 1024 && !force_gcol) {
             FMultiArgs MA;
             MA.tab = F->mt_tab.p;
@@ -2984,7 +2985,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         uint32_t own_cap = own_cap_max;  // hash slots per lane, fewer when the inside column is large
         while (own_cap && (size_t)c.max_nodes * 512 + (size_t)own_cap * 256 + stack_lds * 256 > 156 * 1024) own_cap >>= 1;
         if (own_cap < 32) own_cap = 0;
-        const bool nohash = getenv("CARMEL_HIP_FOREST_NOHASH") != nullptr;  // A/B: scan the previous sample instead
+        const bool nohash = lib_opt("forest_nohash") != nullptr;  // A/B: scan the previous sample instead
         if (nohash) own_cap = 0;
         if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT) {
           own_cap = nohash ? 0 : own_cap_max;

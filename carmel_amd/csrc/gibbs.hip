@@ -21,6 +21,7 @@
 #include <limits>
 #include <memory>
 #include "engine.hpp"
+#include "options.hpp"
 #include "forest_exact.hpp"
 #include "gibbs_exact.hpp"
 #include "gibbs_lane.hpp"
@@ -942,13 +943,13 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       g->wave_ok = gibbs_exact_lds_bytes(g->cap_arcs, g->cap_states, g->cap_levels, g->cap_sample) <= 150 * 1024;
       // the register kernel (gibbs_exact.hip, round 6): the exact chain is one launch over all blocks in order, so every block
       // must be eligible; the parallel sweep takes the eligible ones class by class.  CARMEL_HIP_GIBBS_REG=0: the LDS kernel (A/B)
-      const bool reg_on = !(getenv("CARMEL_HIP_GIBBS_REG") && atoi(getenv("CARMEL_HIP_GIBBS_REG")) == 0);
+      const bool reg_on = !(lib_opt("gibbs_reg") && atoi(lib_opt("gibbs_reg")) == 0);
       g->reg_nq = 0;
       if (g->wave_ok && reg_on && o->mode == 0) {
         int nq = 2;
         for (size_t b = 0; b < bb.size() && nq; ++b) nq = need_nq[b] ? std::max(nq, need_nq[b]) : 0;
         g->reg_nq = nq;
-        if (getenv("CARMEL_TIMING")) {
+        if (lib_opt("timing")) {
           size_t bad = 0;
           for (size_t b = 0; b < bb.size(); ++b) bad += need_nq[b] == 0;
           fprintf(stderr, "timing: gibbs exact chain: register kernel nq %d (%zu of %zu blocks not eligible; caps arcs %u states %u levels %u)\n", nq, bad,
@@ -989,7 +990,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         }
         // one block per lane where the lattices allow it (gibbs_lane.hip); CARMEL_HIP_GIBBS_LANE=0: every block on the kernels above (A/B)
         GlHost H;
-        if (!(getenv("CARMEL_HIP_GIBBS_LANE") && atoi(getenv("CARMEL_HIP_GIBBS_LANE")) == 0)) gibbs_lane_build(L, bb, gb, coff, cpar, g->h_norm, H);
+        if (!(lib_opt("gibbs_lane") && atoi(lib_opt("gibbs_lane")) == 0)) gibbs_lane_build(L, bb, gb, coff, cpar, g->h_norm, H);
         if (!H.groups.empty()) {
           g->gl_ngroups = (uint32_t)H.groups.size();
           g->gl_classes = H.classes;
@@ -998,9 +999,9 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           HIPCHK(g->gl_recA.upload(H.recA, s));
           HIPCHK(g->gl_recB.upload(H.recB, s));
           HIPCHK(g->gl_arc.upload(H.arc_id, s));
-          HIPCHK(g->gl_sw.alloc(2 * H.n_rec));
+          HIPCHK(g->gl_sw.alloc(3 * H.n_rec));
           for (int k = 0; k < 2; ++k) {
-            HIPCHK(g->gl_samp[k].alloc(4 * H.n_samp));
+            HIPCHK(g->gl_samp[k].alloc(8 * H.n_samp));
             HIPCHK(hipMemsetAsync(g->gl_samp[k].p, 0, g->gl_samp[k].bytes(), s));
           }
           std::vector<uint32_t> rest;
@@ -1023,7 +1024,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           }
           g->n_rest = (uint32_t)rest.size();
           if (g->n_rest) HIPCHK(g->rest_list.upload(rest, s));
-          if (getenv("CARMEL_TIMING")) {
+          if (lib_opt("timing")) {
             size_t taken = 0;
             for (uint8_t t8 : H.taken) taken += t8;
             fprintf(stderr, "timing: gibbs parallel sweep: %zu of %zu blocks one per lane in %u groups, %zu launch classes (LDS per wavefront:", taken, bb.size(),
@@ -1039,7 +1040,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
           W.cap_states = (W.cap_states + 3) / 4 * 4;
           W.cap_sample = (W.cap_sample + 3) / 4 * 4;
           if (W.n) HIPCHK(W.list.upload(lists[c], s));
-          if (W.n && getenv("CARMEL_TIMING"))
+          if (W.n && lib_opt("timing"))
             fprintf(stderr, "timing: gibbs parallel class %d: %u blocks, nq %d, caps arcs %u states %u levels %u sample %u\n", c, W.n, W.nq, W.cap_arcs,
                     W.cap_states, W.cap_levels, W.cap_sample);
         }
@@ -1237,7 +1238,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   G.n_blocks = g->n_blocks;
   // the wavefront path runs the default chain: sampling at temperature 1 with the block's own sample taken out first
   const bool wave_any = g->wave_ok && !g->opt.expectation && (g->opt.high_temp == 0 || g->opt.high_temp == 1) &&
-                        (g->opt.low_temp == 0 || g->opt.low_temp == 1) && !getenv("CARMEL_HIP_GIBBS_WORKGROUP");
+                        (g->opt.low_temp == 0 || g->opt.low_temp == 1) && !lib_opt("gibbs_workgroup");
   const bool wave_run = wave_any && g->opt.mode == 0 && !g->opt.include_self;
   const bool wave_par = wave_any && g->opt.mode == 1;  // the stale-count sweep, a wavefront per block
   GxArgs GX;
@@ -1272,7 +1273,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     GX.seed = g->opt.seed;
     GX.n_blocks = g->n_blocks;
     GX.want_after = iter_after_logprob ? 1 : 0;
-    if (getenv("CARMEL_HIP_GIBBS_CLK")) {
+    if (lib_opt("gibbs_clk")) {
       HIPCHK(gx_clk.alloc(16));
       HIPCHK(hipMemsetAsync(gx_clk.p, 0, 128, s));
       GX.phase_clk = gx_clk.p;
@@ -1323,7 +1324,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     for (uint32_t run = 0; run < n_runs; ++run)
       if (run % g->run_stride == g->run_first) my_runs.push_back(run);
     uint32_t cap = 64;
-    if (const char* e = getenv("CARMEL_HIP_GIBBS_CHAINS")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
+    if (const char* e = lib_opt("gibbs_chains")) cap = (uint32_t)std::max(1, atoi(e));  // 1: one run after the other (A/B)
     // memory of a chain: counts, their time-weighted sums and stamps, norm sums, the sweep's cache model, the sample
     const uint64_t chain_bytes = (np * 4 + ng * 2) * 8 + (uint64_t)g->sample_ids.n * 8 + (uint64_t)g->n_blocks * 4 + 64;
     cap = (uint32_t)std::min<uint64_t>(cap, std::max<uint64_t>(1, (8ull << 30) / std::max<uint64_t>(chain_bytes, 1)));
@@ -1535,6 +1536,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
           LA.recB = (const uint4*)g->gl_recB.p;
           LA.arc_id = g->gl_arc.p;
           LA.sw = (double2*)g->gl_sw.p;
+          LA.tot = g->gl_sw.p + 2 * (g->gl_sw.n / 3);
           LA.samp_old = (const uint4*)g->gl_samp[g->gl_cur].p;
           LA.samp_new = (uint4*)g->gl_samp[g->gl_cur ^ 1].p;
           LA.p_x = g->snap_x.p;
@@ -1581,22 +1583,24 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
       // the previous sample of a block in LDS up to GIBBS_OWN_CAP ids (32 KB: under the default dynamic-LDS limit); longer
       // ones -- cyclic lattices -- are read from global memory by g_resample_block
       uint32_t own_cap = std::min<uint32_t>(g->max_sample, GIBBS_OWN_CAP);
-      if (const char* e = getenv("CARMEL_HIP_GIBBS_OWN_CAP")) own_cap = std::min<uint32_t>(own_cap, (uint32_t)std::max(1, atoi(e)));  // test hook
+      if (const char* e = lib_opt("gibbs_own_cap")) own_cap = std::min<uint32_t>(own_cap, (uint32_t)std::max(1, atoi(e)));  // test hook
       size_t lds = (size_t)own_cap * sizeof(uint32_t);
       hipLaunchKernelGGL(gibbs_sweep_parallel_kernel, dim3(grid), dim3(64), lds, s, G, own_cap);
       }
       // counts of the new samples: start from the priors, add every use
       HIPCHK(hipMemcpyAsync(g->ccount.p, g->p_prior.p, np * sizeof(double), hipMemcpyDeviceToDevice, s));
       HIPCHK(hipMemcpyAsync(g->normsum.p, g->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
+      // (the wavefront paths' recounts add the parameters' uses only; the norm sums are formed from the new counts group by group)
       if (wave_par && lane_run) {
         if (g->n_rest)
-          HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_rest, g->ccount.p, g->normsum.p, s,
+          HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_rest, g->ccount.p, nullptr, s,
                                              g->rest_list.p));
         HIPCHK(launch_gibbs_lane_recount(g->gl_groups.p, g->gl_lanes.p, (const uint4*)g->gl_recA.p, (const uint4*)g->gl_samp[g->gl_cur ^ 1].p,
-                                         g->gl_ngroups, g->ccount.p, g->normsum.p, s));
+                                         g->gl_ngroups, g->ccount.p, nullptr, s));
         g->gl_cur ^= 1;
       } else if (wave_par)
-        HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_blocks, g->ccount.p, g->normsum.p, s));
+        HIPCHK(launch_gibbs_recount_tables(g->gx_blocks.p, g->new_len.p, g->new_ids.p, g->new_nrm.p, g->n_blocks, g->ccount.p, nullptr, s));
+      if (wave_par) HIPCHK(launch_gibbs_normsum(g->ccount.p, g->p_norm.p, t->group_off.p, t->norm_perm.p, ng, g->normsum.p, s));
       else
         hipLaunchKernelGGL(gibbs_recount_kernel, dim3(std::min<uint32_t>((g->n_blocks + 255) / 256, 4096u)), dim3(256), 0, s,
                            G, g->ccount.p, g->normsum.p);

@@ -1056,14 +1056,40 @@ __global__ __launch_bounds__(1024) void gibbs_recount_tables_kernel(const GxBloc
       const uint32_t g = nrm[B.sample_off + k];
       if (g == GX_NONE) continue;
       gx_tab_add(pk, pv, p_slots - 1, ids[B.sample_off + k], B.wt, new_x);
-      gx_tab_add(nk, nv, n_slots - 1, g, B.wt, new_norm);
+      if (new_norm) gx_tab_add(nk, nv, n_slots - 1, g, B.wt, new_norm);
     }
   }
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < p_slots; i += blockDim.x)
     if (pk[i] != 0xffffffffu) unsafeAtomicAdd(new_x + pk[i], pv[i]);
-  for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i < n_slots && new_norm; i += blockDim.x)
     if (nk[i] != 0xffffffffu) unsafeAtomicAdd(new_norm + nk[i], nv[i]);
+}
+// the norm sums of the parallel sweep from the counts, group by group: sum over a group's counted members of their new counts
+// (prior + uses), a workgroup per group, in a fixed order.  A use used to add to its norm group as well as to its parameter: half
+// of the recount's adds, and the hottest ones -- a tagger has 45 norm groups for five million uses a sweep.
+__global__ __launch_bounds__(256) void gibbs_normsum_kernel(const double* x, const uint32_t* p_norm, const uint64_t* group_off, const uint64_t* norm_perm,
+                                                            uint64_t n_groups, double* normsum) {
+  __shared__ double part[4];
+  for (uint64_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
+    double v = 0.0;
+    for (uint64_t j = group_off[g] + threadIdx.x; j < group_off[g + 1]; j += 256) {
+      const uint64_t p = norm_perm[j];
+      if (p_norm[p] != GX_NONE) v += x[p];
+    }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) normsum[g] = (part[0] + part[1]) + (part[2] + part[3]);
+  }
+}
+hipError_t launch_gibbs_normsum(const double* x, const uint32_t* p_norm, const uint64_t* group_off, const uint64_t* norm_perm, uint64_t n_groups,
+                                double* normsum, hipStream_t s) {
+  if (!n_groups) return hipSuccess;
+  hipLaunchKernelGGL(gibbs_normsum_kernel, dim3((unsigned)std::min<uint64_t>(n_groups, 16384)), dim3(256), 0, s, x, p_norm, group_off, norm_perm,
+                     n_groups, normsum);
+  return hipGetLastError();
 }
 hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
                                        uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s, const uint32_t* list) {

@@ -80,4 +80,9 @@ hipError_t launch_gibbs_broadcast(double* dst, const double* src, uint64_t n, ui
 hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* len, const uint32_t* ids, const uint32_t* nrm,
                                        uint32_t n_blocks, double* new_x, double* new_norm, hipStream_t s, const uint32_t* list = nullptr);
 
+// normsum[g] = the sum of x over group g's members that carry counts (p_norm != none): the parallel sweep's norm sums from its new
+// counts (new_norm = nullptr in the recounts: they add parameter counts only)
+hipError_t launch_gibbs_normsum(const double* x, const uint32_t* p_norm, const uint64_t* group_off, const uint64_t* norm_perm, uint64_t n_groups,
+                                double* normsum, hipStream_t s);
+
 }  // namespace carmel_hip

@@ -32,6 +32,7 @@ namespace carmel_hip {
     __builtin_amdgcn_wave_barrier();                     \
   } while (0)
 #define GL_CH 2    // rows per stage of the pipeline
+#define GL_R 4     // stages in flight: records are requested GL_R - 1 stages ahead, the counts one
 #define GL_SLACK 8 // zero rows behind a group's last (the pipeline's look-ahead reads them)
 
 struct GlProd {  // a running product as mantissa x 2^exponent
@@ -45,6 +46,7 @@ struct GlProd {  // a running product as mantissa x 2^exponent
   __device__ __forceinline__ double ln() const { return log(m) + (double)e * 0.69314718055994530942; }
 };
 
+template <bool INIT>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void gibbs_lane_kernel(GlArgs A) {
   extern __shared__ __attribute__((aligned(16))) double gl_lds[];
   const uint32_t lane = threadIdx.x;
@@ -53,9 +55,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const GlLane L = A.lanes[(size_t)gi * 64 + lane];
   const bool active = L.block != GL_NONE;
   const uint32_t W = A.W, LP = A.LP;
-  double* win = gl_lds;                                        // [2][W][64]: backward values of this level and the next
+  double* win = gl_lds;                                            // [2][W][64]: backward values of this level and the next
   unsigned char* cp = (unsigned char*)(win + (size_t)2 * W * 64);  // [LP][64]: uses of a local parameter by the previous path
-  unsigned char* cn = cp + (size_t)LP * 64;                    // [LN][64]: ... of a local norm group
+  unsigned char* cn = cp + (size_t)LP * 64;                        // [LN][64]: ... of a local norm group
   unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
   {
     uint32_t* tz = (uint32_t*)cp;
@@ -64,11 +66,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   GL_SYNC();
   const uint32_t path = active ? L.path : 0u;
   if (A.have_old) {
-    const uint4* __restrict__ so = A.samp_old + g.samp_base + lane;
+    const uint4* __restrict__ so = A.samp_old + 2 * (g.samp_base + lane);
     for (uint32_t k = 0; k < g.path; k += 4) {
       uint4 e[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = so[(size_t)(k + q) * 64];  // (the buffer is padded by a few entries)
+      for (int q = 0; q < 4; ++q) e[q] = so[(size_t)(k + q) * 128];  // (two records an entry; the buffer is padded by a few entries)
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (k + q < path) {
@@ -83,46 +85,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   // the goal: the one state of the last level, value 1, in the window the first level's arcs read
   win[lane] = 1.0;
   unsigned long long t1 = A.phase_clk ? __builtin_readcyclecounter() : 0;
-  // ---- backward sweep ----
+  // ---- backward sweep.  Every load and store of the loop is unconditional (a row without an arc, or without a second parameter,
+  // reads entry 0 and drops it): no branch between the stages, so the waits the compiler places count exactly the loads in flight ----
   const uint4* __restrict__ pa = A.recA + g.rec_base + lane;
   const uint4* __restrict__ pb = A.recB + g.rec_base + lane;
   double2* __restrict__ psw = A.sw + g.rec_base + lane;
+  double* __restrict__ ptt = A.tot + g.rec_base + lane;
   const double wt = L.wt;
   double acc = 0.0, mx = 0.0;
   int e_next = 0;
-  uint32_t par = 0;  // the window the arcs READ (the next level's); they write the other
-  uint4 ra[3][GL_CH], rb[3][GL_CH];
-  double gx0[3][GL_CH], gs0[3][GL_CH], gx1[3][GL_CH], gs1[3][GL_CH];
+  uint32_t par = 0;   // the window the arcs READ (the next level's); they write the other
+  uint32_t fr_cur = 0;  // the first row of the state being summed
+  uint4 ra[GL_R][GL_CH], rb[GL_R][GL_CH];
+  double gx0[2][GL_CH], gs0[2][GL_CH], gx1[2][GL_CH], gs1[2][GL_CH], gin[2][GL_CH];
 #define GL_LOAD(c, S)                                                    \
   _Pragma("unroll") for (int q = 0; q < GL_CH; ++q) {                    \
     ra[S][q] = pa[(size_t)((c) * GL_CH + q) * 64];                       \
     rb[S][q] = pb[(size_t)((c) * GL_CH + q) * 64];                       \
   }
-#define GL_GATHER(S)                                                                                  \
+#define GL_GATHER(c, S, T)                                                                            \
   _Pragma("unroll") for (int q = 0; q < GL_CH; ++q) {                                                 \
     const uint32_t c_ = rb[S][q].x;                                                                   \
-    gx0[S][q] = 1.0;                                                                                  \
-    gs0[S][q] = 1.0;                                                                                  \
-    gx1[S][q] = 1.0;                                                                                  \
-    gs1[S][q] = 1.0;                                                                                  \
-    if (c_ & GL_HAS0) {                                                                               \
-      if (c_ & GL_FIX0)                                                                               \
-        gx0[S][q] = A.p_prior[ra[S][q].x];                                                            \
-      else {                                                                                          \
-        gx0[S][q] = A.p_x[ra[S][q].x];                                                                \
-        gs0[S][q] = A.normsum[ra[S][q].z];                                                            \
-      }                                                                                               \
-    }                                                                                                 \
-    if (c_ & GL_HAS1) {                                                                               \
-      if (c_ & GL_FIX1)                                                                               \
-        gx1[S][q] = A.p_prior[ra[S][q].y];                                                            \
-      else {                                                                                          \
-        gx1[S][q] = A.p_x[ra[S][q].y];                                                                \
-        gs1[S][q] = A.normsum[ra[S][q].w];                                                            \
-      }                                                                                               \
-    }                                                                                                 \
+    const double* s0_ = (c_ & GL_FIX0) ? A.p_prior : A.p_x;                                           \
+    const double* s1_ = (c_ & GL_FIX1) ? A.p_prior : A.p_x;                                           \
+    gx0[T][q] = s0_[(c_ & GL_HAS0) ? ra[S][q].x : 0u];                                                \
+    gs0[T][q] = A.normsum[((c_ & GL_HAS0) && !(c_ & GL_FIX0)) ? ra[S][q].z : 0u];                     \
+    gx1[T][q] = s1_[(c_ & GL_HAS1) ? ra[S][q].y : 0u];                                                \
+    gs1[T][q] = A.normsum[((c_ & GL_HAS1) && !(c_ & GL_FIX1)) ? ra[S][q].w : 0u];                     \
+    if (INIT) gin[T][q] = A.init_logw[A.arc_id[g.rec_base + (size_t)((c) * GL_CH + q) * 64 + lane]]; \
   }
-#define GL_COMPUTE(c, S)                                                                               \
+#define GL_COMPUTE(c, S, T)                                                                            \
   _Pragma("unroll") for (int q = 0; q < GL_CH; ++q) {                                                  \
     const uint4 b_ = rb[S][q];                                                                         \
     const uint32_t c_ = b_.x;                                                                          \
@@ -130,20 +122,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const uint32_t u0 = cp[(l0 == 0xffffu ? 0u : l0) * 64u + lane], u1 = cp[(l1 == 0xffffu ? 0u : l1) * 64u + lane]; \
     const uint32_t m0 = cn[(n0 == 0xffffu ? 0u : n0) * 64u + lane], m1 = cn[(n1 == 0xffffu ? 0u : n1) * 64u + lane]; \
     const double bnext = win[((size_t)par * W + GL_DST(c_)) * 64 + lane];                              \
-    const double a0 = gx0[S][q] - (double)(l0 == 0xffffu ? 0u : u0) * wt, d0 = gs0[S][q] - (double)(n0 == 0xffffu ? 0u : m0) * wt; \
-    const double a1 = gx1[S][q] - (double)(l1 == 0xffffu ? 0u : u1) * wt, d1 = gs1[S][q] - (double)(n1 == 0xffffu ? 0u : m1) * wt; \
+    const double x0_ = (c_ & GL_HAS0) ? gx0[T][q] : 1.0, s0_ = ((c_ & GL_HAS0) && !(c_ & GL_FIX0)) ? gs0[T][q] : 1.0; \
+    const double x1_ = (c_ & GL_HAS1) ? gx1[T][q] : 1.0, s1_ = ((c_ & GL_HAS1) && !(c_ & GL_FIX1)) ? gs1[T][q] : 1.0; \
+    const double a0 = x0_ - (double)(l0 == 0xffffu ? 0u : u0) * wt, d0 = s0_ - (double)(n0 == 0xffffu ? 0u : m0) * wt; \
+    const double a1 = x1_ - (double)(l1 == 0xffffu ? 0u : u1) * wt, d1 = s1_ - (double)(n1 == 0xffffu ? 0u : m1) * wt; \
     const double wgt = (a0 / d0) * (a1 / d1);                                                          \
-    double gw = wgt;                                                                                   \
-    if (A.init_logw && (c_ & GL_VALID)) gw = exp(A.init_logw[A.arc_id[g.rec_base + (size_t)((c) * GL_CH + q) * 64 + lane]]); \
-    const double term = gw * ldexp(bnext, -e_next);                                                    \
-    if (c_ & GL_VALID) {                                                                               \
-      acc += term;                                                                                     \
-      psw[(size_t)((c) * GL_CH + q) * 64] = make_double2(term, wgt);                                   \
-    }                                                                                                  \
+    const double gw = INIT ? exp(gin[T][q]) : wgt;                                                     \
+    const double term = (c_ & GL_VALID) ? gw * ldexp(bnext, -e_next) : 0.0;                            \
+    acc += term;                                                                                       \
+    psw[(size_t)((c) * GL_CH + q) * 64] = make_double2(term, wgt);                                     \
     if (c_ & GL_STATE_LAST) {                                                                          \
       win[((size_t)(par ^ 1u) * W + GL_SRC(c_)) * 64 + lane] = acc;                                    \
+      ptt[(size_t)fr_cur * 64] = acc;                                                                  \
       mx = fmax(mx, acc);                                                                              \
       acc = 0.0;                                                                                       \
+      fr_cur = (c) * GL_CH + q + 1;                                                                    \
     }                                                                                                  \
     if (c_ & GL_LEVEL_LAST) {                                                                          \
       int t_;                                                                                          \
@@ -153,59 +146,56 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
       par ^= 1u;                                                                                       \
     }                                                                                                  \
   }
-  const uint32_t nchunks = g.rows / GL_CH;  // (rows: a multiple of 3 GL_CH; GL_SLACK zero rows behind them)
+  const uint32_t nchunks = g.rows / GL_CH;  // (rows: a multiple of GL_R GL_CH; GL_SLACK zero rows behind them)
   GL_LOAD(0, 0)
   GL_LOAD(1, 1)
-  GL_GATHER(0)
-  for (uint32_t i = 0; i < nchunks; i += 3) {
-    GL_LOAD(i + 2, 2)
-    GL_GATHER(1)
-    GL_COMPUTE(i, 0)
-    GL_LOAD(i + 3, 0)
-    GL_GATHER(2)
-    GL_COMPUTE(i + 1, 1)
-    GL_LOAD(i + 4, 1)
-    GL_GATHER(0)
-    GL_COMPUTE(i + 2, 2)
+  GL_LOAD(2, 2)
+  GL_GATHER(0, 0, 0)
+  for (uint32_t i = 0; i < nchunks; i += GL_R) {
+    GL_LOAD(i + 3, 3)
+    GL_GATHER(i + 1, 1, 1)
+    GL_COMPUTE(i, 0, 0)
+    GL_LOAD(i + 4, 0)
+    GL_GATHER(i + 2, 2, 0)
+    GL_COMPUTE(i + 1, 1, 1)
+    GL_LOAD(i + 5, 1)
+    GL_GATHER(i + 3, 3, 1)
+    GL_COMPUTE(i + 2, 2, 0)
+    GL_LOAD(i + 6, 2)
+    GL_GATHER(i + 4, 0, 0)
+    GL_COMPUTE(i + 3, 3, 1)
   }
 #undef GL_LOAD
 #undef GL_GATHER
 #undef GL_COMPUTE
   unsigned long long t2 = A.phase_clk ? __builtin_readcyclecounter() : 0;
-  // ---- the walk (derivations.h:361-374; random.ipp:111-127) ----
+  // ---- the walk (derivations.h:361-374; random.ipp:111-127): a state per level.  One round of loads per step: the state's
+  // total (written by the sweep at its first row) and its first four rows -- shares, weights, records --; further rows only while
+  // some lane's choice is still above zero ----
   const double2* __restrict__ rsw = A.sw + g.rec_base + lane;
-  uint4* __restrict__ sn = A.samp_new + g.samp_base + lane;
+  const double* __restrict__ rtt = A.tot + g.rec_base + lane;
+  uint4* __restrict__ sn = A.samp_new + 2 * (g.samp_base + lane);
   GlProd cheap{1.0, 0};
   uint32_t cur = active ? L.start : 0u, pos = 0;
   for (uint32_t k = 0; k < g.path; ++k) {
     const bool on = k < path;
     const uint32_t fr = cur >> 8, deg = on ? (cur & 0xffu) : 0u;
+    const uint32_t lastr = fr + (deg ? deg - 1u : 0u);
     const double u = gibbs_uniform(A.seed, A.iter, L.block, k);
+    const double tot = rtt[(size_t)fr * 64];
     double2 s4[4];
-    uint4 b4[4];
+    uint4 b4[4], a4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const bool h = (uint32_t)j < deg;
-      s4[j] = h ? rsw[(size_t)(fr + j) * 64] : make_double2(0.0, 1.0);
-      b4[j] = h ? pb[(size_t)(fr + j) * 64] : make_uint4(0, 0, 0, 0);
-    }
-    // the state's total: its shares in list order, the additions the sweep made
-    double tot = 0.0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((uint32_t)j < deg) tot += s4[j].x;
-    for (uint32_t c = 4; __any(c < deg); c += 4) {
-      double sx[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) sx[j] = c + j < deg ? rsw[(size_t)(fr + c + j) * 64].x : 0.0;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c + j < deg) tot += sx[j];
+      const uint32_t r = min(fr + (uint32_t)j, lastr);
+      s4[j] = rsw[(size_t)r * 64];
+      b4[j] = pb[(size_t)r * 64];
+      a4[j] = pa[(size_t)r * 64];
     }
     double choice = u * tot;
-    bool done = false;
+    bool done = deg == 0;
     uint32_t pick = 0;
-    uint4 pb4 = make_uint4(0, 0, 0, 0);
+    uint4 pb4 = make_uint4(0, 0, 0, 0), pa4 = make_uint4(0, 0, 0, 0);
     double pw = 1.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -213,17 +203,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         choice -= s4[j].x;
         pick = (uint32_t)j;
         pb4 = b4[j];
+        pa4 = a4[j];
         pw = s4[j].y;
         done = choice < 0;
       }
     for (uint32_t c = 4; __any(!done && c < deg); c += 4) {
       double2 sx[4];
-      uint4 bx[4];
+      uint4 bx[4], ax[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const bool h = !done && c + j < deg;
-        sx[j] = h ? rsw[(size_t)(fr + c + j) * 64] : make_double2(0.0, 1.0);
-        bx[j] = h ? pb[(size_t)(fr + c + j) * 64] : make_uint4(0, 0, 0, 0);
+        const uint32_t r = min(fr + c + (uint32_t)j, lastr);
+        sx[j] = rsw[(size_t)r * 64];
+        bx[j] = pb[(size_t)r * 64];
+        ax[j] = pa[(size_t)r * 64];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -231,12 +223,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           choice -= sx[j].x;
           pick = c + j;
           pb4 = bx[j];
+          pa4 = ax[j];
           pw = sx[j].y;
           done = choice < 0;
         }
     }
     if (on && deg) {
-      sn[(size_t)k * 64] = make_uint4(fr + pick, pb4.y, pb4.z, pos);
+      sn[(size_t)k * 128] = make_uint4(fr + pick, pb4.y, pb4.z, pos);
+      sn[(size_t)k * 128 + 1] = pa4;  // (the chosen arc's parameters and norm groups: what the recount adds up)
       pos += GL_NPAR(pb4.x);
       cheap.mul(pw);
       cur = pb4.w;
@@ -260,8 +254,14 @@ size_t gibbs_lane_lds_bytes(uint32_t W, uint32_t LP, uint32_t LN) { return (size
 hipError_t launch_gibbs_lane(const GlArgs& A, uint32_t n_groups, hipStream_t s) {
   if (!n_groups) return hipSuccess;
   const size_t lds = gibbs_lane_lds_bytes(A.W, A.LP, A.LN);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)gibbs_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(gibbs_lane_kernel, dim3(n_groups), dim3(64), lds, s, A);
+  if (lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)gibbs_lane_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gibbs_lane_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (A.init_logw)
+    hipLaunchKernelGGL(gibbs_lane_kernel<true>, dim3(n_groups), dim3(64), lds, s, A);
+  else
+    hipLaunchKernelGGL(gibbs_lane_kernel<false>, dim3(n_groups), dim3(64), lds, s, A);
   return hipGetLastError();
 }
 
@@ -296,26 +296,28 @@ __global__ __launch_bounds__(1024) void gibbs_lane_recount_kernel(const GlGroup*
     nv[i] = 0.0;
   }
   __syncthreads();
-  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6;
-  for (uint32_t gi = blockIdx.x * nw + wv; gi < n_groups; gi += gridDim.x * nw) {
+  // four wavefronts to a group, each taking every fourth stretch of four path entries: the entries' two records are one
+  // coalesced 32-byte piece per lane
+  const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u, nw = blockDim.x >> 6, sub = wv & 3u;
+  for (uint32_t gi = blockIdx.x * (nw >> 2) + (wv >> 2); gi < n_groups; gi += gridDim.x * (nw >> 2)) {
     const GlGroup g = groups[gi];
     const GlLane L = lanes[(size_t)gi * 64 + lane];
     const uint32_t path = L.block != GL_NONE ? L.path : 0u;
-    for (uint32_t k = 0; k < g.path; k += 2) {
-      uint4 e[2], a[2];
+    const uint4* __restrict__ sp = samp + 2 * (g.samp_base + lane);
+    for (uint32_t k = 4 * sub; k < g.path; k += 16) {
+      uint4 a[4];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) e[q] = samp[g.samp_base + (size_t)(k + q) * 64 + lane];
+      for (int q = 0; q < 4; ++q) a[q] = sp[(size_t)(k + q) * 128 + 1];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) a[q] = k + q < path ? recA[g.rec_base + (size_t)e[q].x * 64 + lane] : make_uint4(GL_NONE, GL_NONE, GL_NONE, GL_NONE);
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < 4; ++q) {
+        if (k + q >= path) continue;
         if (a[q].x != GL_NONE && a[q].z != GL_NONE) {
           gl_tab_add(pk, pv, p_slots - 1, a[q].x, L.wt, new_x);
-          gl_tab_add(nk, nv, n_slots - 1, a[q].z, L.wt, new_norm);
+          if (new_norm) gl_tab_add(nk, nv, n_slots - 1, a[q].z, L.wt, new_norm);
         }
         if (a[q].y != GL_NONE && a[q].w != GL_NONE) {
           gl_tab_add(pk, pv, p_slots - 1, a[q].y, L.wt, new_x);
-          gl_tab_add(nk, nv, n_slots - 1, a[q].w, L.wt, new_norm);
+          if (new_norm) gl_tab_add(nk, nv, n_slots - 1, a[q].w, L.wt, new_norm);
         }
       }
     }
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(1024) void gibbs_lane_recount_kernel(const GlGroup*
   __syncthreads();
   for (uint32_t i = threadIdx.x; i < p_slots; i += blockDim.x)
     if (pk[i] != 0xffffffffu) unsafeAtomicAdd(new_x + pk[i], pv[i]);
-  for (uint32_t i = threadIdx.x; i < n_slots; i += blockDim.x)
+  for (uint32_t i = threadIdx.x; i < n_slots && new_norm; i += blockDim.x)
     if (nk[i] != 0xffffffffu) unsafeAtomicAdd(new_norm + nk[i], nv[i]);
 }
 hipError_t launch_gibbs_lane_recount(const GlGroup* groups, const GlLane* lanes, const uint4* recA, const uint4* samp, uint32_t n_groups,
@@ -332,7 +334,7 @@ hipError_t launch_gibbs_lane_recount(const GlGroup* groups, const GlLane* lanes,
   const uint32_t p_slots = 8192, n_slots = 1024;
   const size_t lds = (size_t)(p_slots + n_slots) * 12;
   (void)hipFuncSetAttribute((const void*)gibbs_lane_recount_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const uint32_t grid = std::min<uint32_t>(256u, (n_groups + 15) / 16);
+  const uint32_t grid = std::min<uint32_t>(256u, (n_groups + 3) / 4);
   hipLaunchKernelGGL(gibbs_lane_recount_kernel, dim3(grid ? grid : 1u), dim3(1024), lds, s, groups, lanes, recA, samp, n_groups, new_x, new_norm,
                      p_slots, n_slots);
   return hipGetLastError();
@@ -346,8 +348,8 @@ __global__ __launch_bounds__(256) void gibbs_lane_materialize_kernel(const GlGro
     if (L.block == GL_NONE) continue;
     uint32_t total = 0;
     for (uint32_t k = 0; k < L.path; ++k) {
-      const uint4 e = samp[g.samp_base + (size_t)k * 64 + lane];
-      const uint4 a = recA[g.rec_base + (size_t)e.x * 64 + lane];
+      const uint4 e = samp[2 * (g.samp_base + (size_t)k * 64 + lane)];
+      const uint4 a = samp[2 * (g.samp_base + (size_t)k * 64 + lane) + 1];
       uint32_t at = e.w;
       if (a.x != GL_NONE) {
         ids[L.sample_off + at] = a.x;
@@ -440,38 +442,32 @@ void gibbs_lane_build(const LatticeSet& L, const std::vector<uint32_t>& bb, cons
       gneed[gi].LN = std::max(gneed[gi].LN, need[b].LN);
       out.taken[b] = 1;
     }
-    G.rows = (rows + 3 * GL_CH - 1) / (3 * GL_CH) * (3 * GL_CH);
+    G.rows = (rows + GL_R * GL_CH - 1) / (GL_R * GL_CH) * (GL_R * GL_CH);
     G.path = path;
     G.rec_base = rec;
     G.samp_base = samp;
     rec += (uint64_t)(G.rows + GL_SLACK) * 64;
-    samp += (uint64_t)(path + 4) * 64;  // (+ the four entries the table fill reads ahead)
+    samp += (uint64_t)(path + 8) * 64;  // (+ the entries the table fill and the recount read ahead)
   }
   out.n_rec = rec;
   out.n_samp = samp;
   out.recA.assign(4 * rec, 0u);
   out.recB.assign(4 * rec, 0u);
   out.arc_id.assign(rec, 0u);
-  // launch classes: runs of groups whose LDS need stays within 1.5 x of the run's first (the groups are ordered by length, which
-  // the need follows)
-  for (size_t gi = 0; gi < ng;) {
+  // ONE launch: the groups in order of length, the LDS of a wavefront sized by the neediest group (at most 40 KB: four wavefronts a
+  // CU at worst).  A launch per LDS class ran the classes one after the other on the sampler's stream with a third of the chip's
+  // SIMDs busy in each (profiles/r6_v2_crp_kernel_stats.csv: five launches of 177 us, each as long as its longest wavefront); in
+  // one launch the short groups fill in as the long ones finish.
+  {
     GlClass c;
-    c.first = (uint32_t)gi;
-    c.W = gneed[gi].W;
-    c.LP = gneed[gi].LP;
-    c.LN = gneed[gi].LN;
-    const size_t lds0 = gibbs_lane_lds_bytes(c.W, c.LP, c.LN);
-    size_t gj = gi + 1;
-    for (; gj < ng; ++gj) {
-      const size_t lj = gibbs_lane_lds_bytes(gneed[gj].W, gneed[gj].LP, gneed[gj].LN);
-      if (lj * 3 < lds0 * 2 && lds0 > 8 * 1024) break;
-      c.W = std::max(c.W, gneed[gj].W);
-      c.LP = std::max(c.LP, gneed[gj].LP);
-      c.LN = std::max(c.LN, gneed[gj].LN);
+    c.first = 0;
+    c.count = (uint32_t)ng;
+    for (size_t gi = 0; gi < ng; ++gi) {
+      c.W = std::max(c.W, gneed[gi].W);
+      c.LP = std::max(c.LP, gneed[gi].LP);
+      c.LN = std::max(c.LN, gneed[gi].LN);
     }
-    c.count = (uint32_t)(gj - gi);
     out.classes.push_back(c);
-    gi = gj;
   }
   // the streams
   std::vector<uint32_t> srow, lp_of, ln_of;

@@ -69,6 +69,7 @@ struct GlArgs {
                            //  destination's first row << 8 | its out-degree}
   const uint32_t* arc_id;  // the composed arc (read on the sweeps that sample from --init-em weights only)
   double2* sw;             // scratch per row: {the arc's share of its state's total, its proposal weight}
+  double* tot;             // ... and at a state's first row: the state's total
   const uint4* samp_old;   // the previous sweep's paths: {row, recB.y, recB.z, place of its first parameter in the block's sample}
   uint4* samp_new;
   const double* p_x;       // the snapshot the sweep samples against

@@ -39,6 +39,7 @@
 #include "compose.hpp"
 #include "fem_export.hpp"
 #include "refhash.hpp"
+#include "env_options.hpp"
 #include "wfst.hpp"
 
 using namespace carmel_host;
@@ -1868,6 +1869,7 @@ static int run(int argc, char** argv) {
 
 int main(int argc, char** argv) {
   int rc;
+  carmel_host::import_env_options();  // (CARMEL_HIP_<KEY> / CARMEL_TIMING: the library takes them as options, not from the environment)
   try {
     rc = run(argc, argv);
   } catch (UsageError& e) {

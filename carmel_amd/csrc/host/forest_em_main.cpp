@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../../include/carmel_hip.h"
+#include "env_options.hpp"
 #include "forest_text.hpp"
 
 using namespace carmel_host;
@@ -275,6 +276,7 @@ void normalize_weights(std::vector<double>& logw, const std::vector<uint64_t>& o
 }  // namespace
 
 int main(int argc, char** argv) {
+  carmel_host::import_env_options();
   try {
     Opts o = parse_args(argc, argv);
     std::ostream& log = std::cerr;

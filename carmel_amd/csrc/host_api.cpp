@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include "../../include/carmel_hip.h"
+#include "options.hpp"
 #include "lattice.hpp"
 
 using namespace carmel_hip;
@@ -49,15 +50,15 @@ int carmel_hip_host_build(carmel_hip_host_lattices** out, uint32_t n_states, uin
   if (small_pairs) opt.small_pairs = small_pairs;
   if (small_states) opt.small_states = small_states;
   if (lane_states >= 0) opt.lane_states = (uint32_t)lane_states;
-  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
-  if (const char* e = getenv("CARMEL_HIP_TILE_SWEEP")) opt.tile_sweep = atoi(e) != 0;
-  if (const char* e = getenv("CARMEL_HIP_LANE_FUSED")) opt.lane_fused = atoi(e) != 0;
-  if (const char* e = getenv("CARMEL_HIP_LANE_WINDOW_MIN")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
+  if (const char* e = lib_opt("lane_window")) opt.lane_window = (uint32_t)std::max(0, atoi(e));  // as engine.cpp
+  if (const char* e = lib_opt("tile_sweep")) opt.tile_sweep = atoi(e) != 0;
+  if (const char* e = lib_opt("lane_fused")) opt.lane_fused = atoi(e) != 0;
+  if (const char* e = lib_opt("lane_window_min")) opt.lane_window_min = (uint32_t)std::max(0, atoi(e));
   // lane_states = 0 asks for the plain inspection form -- every lattice a bundle (with small_pairs = 1: one lattice each),
   // what the front end's --fem-forest export walks -- unless a test forces the one-per-wavefront layout explicitly
-  if (lane_states == 0 && !getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave = false;
-  if (const char* e = getenv("CARMEL_HIP_WAVE_RING")) opt.wave_ring = atoi(e) != 0;
-  if (const char* e = getenv("CARMEL_HIP_WAVE_MIN_WIDTH")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);
+  if (lane_states == 0 && !lib_opt("wave_min_width")) opt.wave = false;
+  if (const char* e = lib_opt("wave_ring")) opt.wave_ring = atoi(e) != 0;
+  if (const char* e = lib_opt("wave_min_width")) opt.wave_min_width = opt.wave_lane_min_width = atof(e);
   if (!build_lattices(h->w, h->c, opt, h->L, h->err)) {
     delete h;
     return CARMEL_HIP_ERR_ARG;

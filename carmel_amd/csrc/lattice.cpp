@@ -1,5 +1,6 @@
 // lattice.cpp — see lattice.hpp.  Host C++ only (no HIP): builds lattices and the batched-CSR image.
 #include "lattice.hpp"
+#include "options.hpp"
 #include <algorithm>
 #include <functional>
 #include <chrono>
@@ -580,7 +581,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     return false;
   }
   const uint64_t np = c.n_pairs;
-  const bool timing = getenv("CARMEL_TIMING") != nullptr;  // phase times on stderr
+  const bool timing = lib_opt("timing") != nullptr;  // phase times on stderr
   auto tick = std::chrono::steady_clock::now();
   auto phase = [&](const char* name) {
     if (!timing) return;

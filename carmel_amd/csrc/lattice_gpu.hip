@@ -30,6 +30,7 @@
 #include <limits>
 #include <vector>
 #include "engine.hpp"
+#include "options.hpp"
 
 namespace {
 
@@ -880,14 +881,14 @@ int build_run_tables(carmel_hip_trainer* t) {
   // CARMEL_HIP_TILE_GATHER=0 / 1: never / whatever the sizes (A/B: the same values at the same places).
   if (!t->use_transpose || t->use_runs || !t->t_buckets.n || !t->t_t_src.n || !t->t_b_src.n || !t->t_b_arc.n) return CARMEL_HIP_OK;
   if (!t->wcache.n) return CARMEL_HIP_OK;  // (no lane record: no tile pass in the weights' direction)
-  const char* env = getenv("CARMEL_HIP_TILE_GATHER");
+  const char* env = lib_opt("tile_gather");
   if (env ? atoi(env) == 0 : (t->w.n_arcs * sizeof(double) > (128ull << 20) || t->t_t_src.n < 4 * t->w.n_arcs)) return CARMEL_HIP_OK;
   HIPCHK(t->t_t_arc.alloc(t->t_t_src.n));
   hipLaunchKernelGGL(tile_arc_kernel, dim3((unsigned)t->t_buckets.n), dim3(1024), 0, t->stream, t->t_buckets.p, t->t_b_arc.p, t->t_b_src.p,
                      t->t_t_arc.p);
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(t->stream));
-  if (getenv("CARMEL_TIMING"))
+  if (lib_opt("timing"))
     fprintf(stderr, "timing: tile weights from the table: %zu items over %llu arcs\n", t->t_t_arc.n, (unsigned long long)t->w.n_arcs);
   return CARMEL_HIP_OK;
 }
@@ -898,7 +899,7 @@ int build_run_tables(carmel_hip_trainer* t) {
 // CARMEL_HIP_WAVE_XC=0 / 1: never / whatever the rows look like (A/B: the same values at the same places of XC).
 static int build_wave_items(carmel_hip_trainer* t) {
   if (!t->use_transpose || t->use_runs || !t->wave_records || t->out_arcs.n || !t->t_tile_base.n || !t->t_t_pos.n) return CARMEL_HIP_OK;
-  const char* env = getenv("CARMEL_HIP_WAVE_XC");
+  const char* env = lib_opt("wave_xc");
   if (env && atoi(env) == 0) return CARMEL_HIP_OK;
   const uint32_t tile = t->lat.tile;
   if (!tile || t->wave_slot_base % tile) return CARMEL_HIP_OK;
@@ -918,7 +919,7 @@ static int build_wave_items(carmel_hip_trainer* t) {
   HIPCHK(hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
   const bool on = env ? true : (h[0] && h[1] * 4 >= h[0] * 3);
-  if (getenv("CARMEL_TIMING"))
+  if (lib_opt("timing"))
     fprintf(stderr, "timing: wave posteriors straight to XC: %llu of %llu rows compact -> %s\n", h[1], h[0], on ? "on" : "off");
   if (!on) t->wave_xc_idx.release();
   return CARMEL_HIP_OK;
@@ -931,7 +932,7 @@ static int build_run_tables_impl(carmel_hip_trainer* t) {
   // items per run; 0.16 GB of 2.41 less per E-step, trans_w_tile 108 -> 99 us, trans_c_bucket unchanged); corpora whose items
   // spread over more (tile, bucket) cells than a quarter of their items keep the per-item indices, and so do small ones
   // (config 2: the three extra barriers cost more than the bytes).  CARMEL_HIP_TRANS_RUNS=0 / 1 forces it off / on.
-  const char* env = getenv("CARMEL_HIP_TRANS_RUNS");
+  const char* env = lib_opt("trans_runs");
   if (env && atoi(env) == 0) return CARMEL_HIP_OK;
   {
     const double tiles = (double)(t->t_tile_base.n - 1), cells = tiles * (double)t->t_buckets.n;
@@ -959,7 +960,7 @@ static int build_run_tables_impl(carmel_hip_trainer* t) {
     t->br_rel.release();
     t->br_src.release();
   }
-  if (getenv("CARMEL_TIMING"))
+  if (lib_opt("timing"))
     fprintf(stderr, "timing: transposition runs: %zu per %llu items, at most %u per tile / %u per bucket -> %s\n", t->tr_src.n,
             (unsigned long long)n, max_t, max_b, t->use_runs ? "run-length indices" : "per-item indices");
   return CARMEL_HIP_OK;
@@ -1107,7 +1108,7 @@ __global__ void host_layout_items_kernel(const uint32_t* lane_arc, uint64_t n_la
 int gpu_tables_for_host_layout(carmel_hip_trainer* t, const std::vector<uint32_t>& lane_arc, const std::vector<uint32_t>& wave_arc) {
   const LatticeSet& L = t->lat;
   hipStream_t s = t->stream;
-  const bool timing = getenv("CARMEL_TIMING") != nullptr;
+  const bool timing = lib_opt("timing") != nullptr;
   auto last = std::chrono::steady_clock::now();
   std::function<void(const char*)> lap = [&](const char* what) {
     if (!timing) return;
@@ -1148,7 +1149,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
   if (!np || !opt.lane_states || opt.lane_states > GX || !opt.prune) return CARMEL_HIP_OK;
   if (np >= 0xfffffff0ull || w.n_arcs >= 0xfffffff0ull) return CARMEL_HIP_OK;
   const auto t0 = std::chrono::steady_clock::now();
-  const bool timing = getenv("CARMEL_TIMING") != nullptr;
+  const bool timing = lib_opt("timing") != nullptr;
   auto lap = [&, last = t0](const char* what) mutable {
     if (!timing) return;
     (void)hipDeviceSynchronize();
@@ -1353,7 +1354,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     HIPCHK(hipMemsetAsync(t->lane_rec2.p, 0, n_rec * 4, s));
     HIPCHK(launch_pack_tile_records(t->lane_groups.p, (uint32_t)t->lane_groups.n, t->lane_nstates.p, t->lane_fwdx.p, t->lane_bwd.p, t->lane_rec2.p, t->lane_chain.p,
                                     t->tile_group.p, (uint32_t)(t->tile_group.n - 1), t->tile_chain.p, s));
-    if (getenv("CARMEL_TIMING")) {
+    if (lib_opt("timing")) {
       std::vector<uint32_t> ch(t->lane_chain.n);
       HIPCHK(hipMemcpyAsync(ch.data(), t->lane_chain.p, ch.size() * 4, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));

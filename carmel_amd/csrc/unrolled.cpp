@@ -1,5 +1,6 @@
 // unrolled.cpp: eligibility test and tables of the unrolled (position x state) sweep -- see unrolled.hpp.
 #include "unrolled.hpp"
+#include "options.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -92,7 +93,7 @@ bool build_unrolled(const HostWfst& w, const HostCorpus& c, int threads, Unrolle
   }
   // slabs of one size when that costs at most 30 % more rows: the sweep's loop bounds and addresses are then the same
   // for every symbol (scalar arithmetic; no per-lane clamping or masking of the rows)
-  if ((uint64_t)fmax * V * 10 <= fsum * 13 && (uint64_t)bmax * V * 10 <= bsum * 13 && !getenv("CARMEL_HIP_UNROLLED_RAGGED")) {
+  if ((uint64_t)fmax * V * 10 <= fsum * 13 && (uint64_t)bmax * V * 10 <= bsum * 13 && !lib_opt("unrolled_ragged")) {
     M.f_deg_u = fmax;
     M.b_deg_u = bmax;
     std::fill(fdeg.begin(), fdeg.end(), fmax);

@@ -40,6 +40,17 @@ extern "C" {
 typedef struct carmel_hip_trainer carmel_hip_trainer;
 
 const char* carmel_hip_last_error(void);
+/* The library's switches (round 6; csrc/options.hpp): formulation choices that leave the results the same -- each exists because a
+ * test holds the two forms together --, layout limits the tests force onto small cases, and traces.  Process-wide; `key` is one of
+ * carmel_hip_option_name(0 .. carmel_hip_option_count() - 1) (e.g. "tile_sweep", "gibbs_lane", "timing"), `value` a string as the
+ * former environment variable CARMEL_HIP_<KEY> took it, NULL to unset; an unknown key is CARMEL_HIP_ERR_ARG.  Options that shape
+ * a lattice layout are read by carmel_hip_build_lattices / carmel_hip_gibbs_create / carmel_hip_forests_create, the others by the
+ * call they steer.  The library does not read the environment: the front ends (carmel, forest-em, bench.py) translate
+ * CARMEL_HIP_<KEY>=v into carmel_hip_set_option("<key>", "v") and CARMEL_TIMING into "timing" for the tools that drive them. */
+int carmel_hip_set_option(const char* key, const char* value);
+const char* carmel_hip_get_option(const char* key);
+int carmel_hip_option_count(void);
+const char* carmel_hip_option_name(int i);
 int carmel_hip_device_count(void);
 
 /* Replaces: arcs_table<arc_counts>(WFST&, per_arc_prior, global_prior)  derivations.h:79-101, train.h:28-40,

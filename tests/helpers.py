@@ -339,3 +339,30 @@ def transpose_counts(tr, post):
             for a in range(int(b["arc_lo"]), int(b["arc_lo"]) + int(b["n_arcs"])):
                 counts[a] = lds[int(tr["arc_off"][a]) - lo:int(tr["arc_off"][a + 1]) - lo].sum()
     return counts
+
+
+def set_hip_option(key, value):
+    """one of the library's switches (carmel_hip_set_option; the former environment variable CARMEL_HIP_<KEY>); None unsets it"""
+    import carmel_amd
+    carmel_amd.set_option(key, None if value is None else str(value))
+
+
+class hip_env(object):
+    """switches named like the former environment variables ({"CARMEL_HIP_FOREST_MULTI": "0"}) as library options for the length of
+    a with-block"""
+
+    def __init__(self, env):
+        self.env = {("timing" if k == "CARMEL_TIMING" else k[len("CARMEL_HIP_"):].lower()): v for k, v in env.items()}
+
+    def __enter__(self):
+        import carmel_amd
+        self.saved = {k: carmel_amd.get_option(k) for k in self.env}
+        for k, v in self.env.items():
+            carmel_amd.set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        import carmel_amd
+        for k, v in self.saved.items():
+            carmel_amd.set_option(k, v)
+        return False

@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def build(mode, rank, world):
+    import carmel_amd
+    carmel_amd.options_from_env()  # (the parent test exported its switches: a front end translates them, the library does not read them)
     from carmel_amd import synth
     from carmel_amd.model import Corpus, Wfst
     from carmel_amd.trainer import HipForwardBackward
@@ -69,7 +71,9 @@ def main():
     rank, world, port, out, mode = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     rccl = "--rccl" in sys.argv
     if mode == "cipher-explicit":
+        import carmel_amd
         os.environ["CARMEL_HIP_UNROLLED"] = "0"
+        carmel_amd.set_option("unrolled", "0")
         mode = "cipher"
     import torch
     import torch.distributed as dist

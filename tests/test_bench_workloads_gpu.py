@@ -124,7 +124,7 @@ def test_c5_full_size_parallel_sweep_properties():
 
 @pytest.mark.parametrize("corpus", [1, 2])
 @pytest.mark.parametrize("mode", [0, 1, 2])
-def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode, corpus, monkeypatch):
+def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle, mode, corpus, hipopt):
     """5 forests x 4-5 derivations each = 1 600 joint states: the sweep's transition matrix is built exactly
     (tests/forest_enum.py) and its stationary rule-usage expectations are compared with what the GPU chain time-averages (the
     rule weights after the run are (average use + prior) / (its norm group's), from_gibbs forest-em.hpp:736-742).  16
@@ -135,7 +135,7 @@ def test_sampler_marginals_against_the_enumerated_stationary_distribution(oracle
     is outside what the test resolves, i.e. that the test discriminates between the two chains)."""
     from carmel_amd.forests import HipForests
     if mode == 2:  # the parallel sweep's one-forest-per-lane kernel (mode 1 is the several-lanes-per-forest default)
-        monkeypatch.setenv("CARMEL_HIP_FOREST_MULTI", "0")
+        hipopt.set("forest_multi", "0")
         mode = 1
     # corpus 2: a five-way OR, a nine-child AND (a frontier wider than a forest's eight lanes), a shared sub-forest expanded twice
     of = oracle.OracleForests(*((TOY_FORESTS, TOY_NORM) if corpus == 1 else (TOY2_FORESTS, TOY2_NORM)))  # (the oracle only parses)

@@ -5,6 +5,8 @@ import math
 import numpy as np
 import pytest
 
+from helpers import hip_env, set_hip_option  # noqa: E402,F401
+
 pytestmark = pytest.mark.gpu
 
 
@@ -106,7 +108,7 @@ def test_forest_gibbs_exact_chain(oracle, kw):
 
 @pytest.mark.parametrize("kw,chains", [(dict(), None), (dict(burnin=3), None), (dict(argmax_final=True), None),
                                        (dict(argmax_sum=True, final_counts=True), None), (dict(), "3"), (dict(), "1")])
-def test_forest_gibbs_restarts_side_by_side(oracle, monkeypatch, kw, chains):
+def test_forest_gibbs_restarts_side_by_side(oracle, hipopt, kw, chains):
     """forest-em --crp-restarts=R (FForests::run_gibbs -> gibbs_base::run_starts, forest-em.hpp:718, gibbs.hpp:880-914): R + 1
     independent chains from the priors, run r drawing the uniforms of sweeps r * (iter + 1) + i, the run that is better by
     gibbs_stats::better kept.  The device runs them side by side (a wavefront each; in batches of three and one after the other:
@@ -114,7 +116,7 @@ def test_forest_gibbs_restarts_side_by_side(oracle, monkeypatch, kw, chains):
     loop keeps"""
     from carmel_amd._capi import lib
     if chains:
-        monkeypatch.setenv("CARMEL_HIP_GIBBS_CHAINS", chains)
+        hipopt.set("gibbs_chains", chains)
     ftext, ntext = synth_forests(30, 25, 11)
     of, hf = make(oracle, ftext, ntext, 11)
     w0 = of.weights().copy()
@@ -180,25 +182,25 @@ def test_parallel_gibbs_sample_tables_equal_the_scan():
         hf.gibbs(4, alpha=0.1, seed=4, mode=1)
         return hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(0, 6000, 7)], hf.max_sample()
 
-    os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
-    os.environ["CARMEL_HIP_FOREST_SWEEP"] = "1"  # the first formulation of the parallel sweep (tables per lane)
+    set_hip_option("forest_nohash", None)
+    set_hip_option("forest_sweep", "1")  # the first formulation of the parallel sweep (tables per lane)
     try:
         a, sa, ms = run()
-        os.environ["CARMEL_HIP_FOREST_NOHASH"] = "1"
+        set_hip_option("forest_nohash", "1")
         b, sb, _ = run()
     finally:
-        os.environ.pop("CARMEL_HIP_FOREST_NOHASH", None)
-        os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
+        set_hip_option("forest_nohash", None)
+        set_hip_option("forest_sweep", None)
     assert ms > 116  # some derivation is too long for the LDS table: the global table is exercised too
     assert sa == sb
     np.testing.assert_allclose(a, b, rtol=1e-12)
     # the default (second) formulation -- proposal probabilities per record from per-class use counts, streamed inside
     # pass, one round trip per node in the walk -- is the same chain again
-    os.environ["CARMEL_HIP_FOREST_MULTI"] = "0"  # (one forest per lane: the several-lanes sampler keys its uniforms differently)
+    set_hip_option("forest_multi", "0")  # (one forest per lane: the several-lanes sampler keys its uniforms differently)
     try:
         c, sc, _ = run()
     finally:
-        os.environ.pop("CARMEL_HIP_FOREST_MULTI", None)
+        set_hip_option("forest_multi", None)
     assert sc == sa
     np.testing.assert_allclose(c, a, rtol=1e-12)
 
@@ -267,18 +269,18 @@ def test_forests_larger_than_lds(oracle):
     np.testing.assert_allclose(hf.iter_logprob, ref["iter_logprob"], rtol=1e-10)
     hf.close()
     res = []
-    os.environ["CARMEL_HIP_FOREST_MULTI"] = "0"  # (the one-forest-per-lane formulations: uniforms keyed like the sequential walk's)
+    set_hip_option("forest_multi", "0")  # (the one-forest-per-lane formulations: uniforms keyed like the sequential walk's)
     for sweep in ("1", None):  # both formulations of the parallel sweep: the same chain
         if sweep:
-            os.environ["CARMEL_HIP_FOREST_SWEEP"] = sweep
+            set_hip_option("forest_sweep", sweep)
         try:
             of2, hf2 = make(oracle, ftext, ntext, 5)
             hf2.gibbs(4, alpha=0.3, seed=2, mode=1)
             res.append((hf2.iter_cheap_logprob.copy(), [hf2.sample(b) for b in range(0, hf2.n_forests, 5)]))
             hf2.close()
         finally:
-            os.environ.pop("CARMEL_HIP_FOREST_SWEEP", None)
-    os.environ.pop("CARMEL_HIP_FOREST_MULTI", None)
+            set_hip_option("forest_sweep", None)
+    set_hip_option("forest_multi", None)
     assert res[0][1] == res[1][1]
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-12)
 
@@ -372,20 +374,12 @@ def test_parallel_sweep_formulations_on_wide_and_deep_forests(oracle, shape):
     kw = dict(high_temp=temps[0], low_temp=temps[1]) if temps else {}
 
     def run(env):
-        saved = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        with hip_env(env):
             hf = HipForests(of.node_off, of.label, of.ref, of.next, of.n_rules, lw, of.group_off, of.group_rule)
             hf.gibbs(6, burnin=2, alpha=0.2, seed=21, mode=1, **kw)
             res = (hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(hf.n_forests)], hf.weights().copy())
             hf.close()
             return res
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
 
     a = run({"CARMEL_HIP_FOREST_SWEEP": "1"})
     for env in ({"CARMEL_HIP_FOREST_MULTI": "0"}, {"CARMEL_HIP_FOREST_MULTI": "0", "CARMEL_HIP_FOREST_LDSWALK": "0"},
@@ -426,20 +420,12 @@ def test_several_lanes_per_forest_sampler(oracle, shape):
     lw = np.log(np.random.default_rng(3).uniform(0.05, 1.0, of.n_rules))
 
     def run(env, **kw):
-        saved = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        try:
+        with hip_env(env):
             hf = HipForests(of.node_off, of.label, of.ref, of.next, of.n_rules, lw, of.group_off, of.group_rule)
             hf.gibbs(8, burnin=2, alpha=0.2, seed=21, mode=1, **kw)
             res = (hf.iter_cheap_logprob.copy(), [hf.sample(f) for f in range(hf.n_forests)], hf.weights().copy())
             hf.close()
             return res
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
 
     a = run({}, final_counts=True)
     b = run({}, final_counts=True)
@@ -486,7 +472,7 @@ def test_exact_chain_on_deep_spines_whose_values_underflow_plain_doubles(oracle)
     hf.close()
 
 
-def test_exact_chain_on_the_device_is_the_host_driven_loop(oracle, monkeypatch):
+def test_exact_chain_on_the_device_is_the_host_driven_loop(oracle, hipopt):
     """forest_exact.hip (one persistent wavefront, counts on the device) against the loop it replaces (a launch per forest,
     counts on the host; CARMEL_HIP_FOREST_EXACT_HOST=1, still what annealed runs and prior-scale inference use): the same
     samples, probabilities and weights"""
@@ -494,9 +480,9 @@ def test_exact_chain_on_the_device_is_the_host_driven_loop(oracle, monkeypatch):
     out = {}
     for which in ("device", "host"):
         if which == "host":
-            monkeypatch.setenv("CARMEL_HIP_FOREST_EXACT_HOST", "1")
+            hipopt.set("forest_exact_host", "1")
         else:
-            monkeypatch.delenv("CARMEL_HIP_FOREST_EXACT_HOST", raising=False)
+            hipopt.unset("forest_exact_host")
         of, hf = make(oracle, ftext, ntext, 23)
         hf.gibbs(8, burnin=2, alpha=0.3, seed=5, mode=0)
         out[which] = ([hf.sample(b) for b in range(hf.n_forests)], hf.iter_logprob.copy(), hf.iter_cheap_logprob.copy(), hf.weights().copy())

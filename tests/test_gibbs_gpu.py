@@ -209,13 +209,13 @@ def test_crp_restarts_keep_the_best_run(oracle, golden_dir, kw):
 
 
 @pytest.mark.parametrize("cap", ["64", "3", "1"])
-def test_crp_restart_runs_side_by_side_are_the_runs_one_after_the_other(oracle, golden_dir, monkeypatch, cap):
+def test_crp_restart_runs_side_by_side_are_the_runs_one_after_the_other(oracle, golden_dir, hipopt, cap):
     """the runs of --crp-restarts as concurrent chains (GxArgs::n_chains: a wavefront each, its own counts, cache model, sample and
     uniforms; gibbs.hpp:880-914): ten runs at once, in batches of three, and one after the other (CARMEL_HIP_GIBBS_CHAINS) log
     the same probabilities sweep by sweep, keep the same run, the same sample and the same weights -- the oracle's"""
     from carmel_amd.trainer import HipGibbs
     g = lambda n: open(os.path.join(golden_dir, n)).read()
-    monkeypatch.setenv("CARMEL_HIP_GIBBS_CHAINS", cap)
+    hipopt.set("gibbs_chains", cap)
     oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
                            [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
     iters, burnin, restarts = 5, 1, 9
@@ -411,7 +411,7 @@ def test_gibbs_on_lattices_with_cycles(oracle, kw):
     fb.close()
 
 
-def test_parallel_sweep_on_a_large_lattice_with_a_cycle(oracle, monkeypatch):
+def test_parallel_sweep_on_a_large_lattice_with_a_cycle(oracle, hipopt):
     """--crp-parallel on a cyclic lattice of more than 256 states (round-4 advisor): the sample capacity of such a block is
     32 x states x chain, which used to be the sweep kernel's dynamic LDS -- above 64 KB an opaque launch failure.  The previous
     sample now lives in LDS up to a fixed cap and is read from global memory beyond it: both ways give the same sweep."""
@@ -424,7 +424,7 @@ def test_parallel_sweep_on_a_large_lattice_with_a_cycle(oracle, monkeypatch):
     res = {}
     for cap in (None, "3"):
         if cap:
-            monkeypatch.setenv("CARMEL_HIP_GIBBS_OWN_CAP", cap)
+            hipopt.set("gibbs_own_cap", cap)
         oc, ocorp, fb = _setup(oracle, [fst], "\n".join(lines) + "\n", [NORM_CONDITIONAL], [0.3])
         assert fb.lattice_stats.n_cyclic_pairs == 3 and fb.lattice_stats.kept_states > 2 * 256
         gs = HipGibbs(fb, 6, burnin=2, seed=9, mode=1)
@@ -460,7 +460,7 @@ def test_observer_sees_the_chain_as_it_stands(oracle, golden_dir):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(include_self=True), dict(init_p0=True)])
-def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle, golden_dir, monkeypatch, kw):
+def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle, golden_dir, hipopt, kw):
     """gibbs_lane.hip (round 6): the stale-count sweep with 64 trellis lattices a wavefront, one per lane -- arcs streamed in the
     order of the backward sweep, two levels of backward values per lane, every level's terms divided by a power of two, the
     block's previous path taken out of the counts through tables over the block's local numbering -- against gibbs_exact.hip's
@@ -474,9 +474,9 @@ def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle
     init = kw.pop("init_p0", False)
     for which in ("lane", "wave"):
         if which == "wave":
-            monkeypatch.setenv("CARMEL_HIP_GIBBS_LANE", "0")
+            hipopt.set("gibbs_lane", "0")
         else:
-            monkeypatch.delenv("CARMEL_HIP_GIBBS_LANE", raising=False)
+            hipopt.unset("gibbs_lane")
         oc, ocorp, fb = _setup(oracle, [g("tagging.fsa"), g("tagging.fst")], g("tagging.data"), [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.1, 0.1])
         gs = HipGibbs(fb, 9, burnin=3, seed=5, mode=1, **kw)
         if init:  # the first sweep samples from the composed weights (--init-from-p0: gibbs.cc:405-421)
@@ -493,7 +493,7 @@ def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle
     np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)
 
 
-def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, monkeypatch):
+def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, hipopt):
     """gibbs_exact.hip's single-wavefront kernel (linear domain, static arc records, DPP choice) and gibbs.hip's workgroup
     kernel (log domain; CARMEL_HIP_GIBBS_WORKGROUP=1) are two implementations of the reference's chain: the same samples,
     block for block, the same sweep probabilities and final weights -- exact mode, and the parallel sweep too."""
@@ -503,9 +503,9 @@ def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir,
     for mode in (0, 1):
         for which in ("wave", "workgroup"):
             if which == "workgroup":
-                monkeypatch.setenv("CARMEL_HIP_GIBBS_WORKGROUP", "1")
+                hipopt.set("gibbs_workgroup", "1")
             else:
-                monkeypatch.delenv("CARMEL_HIP_GIBBS_WORKGROUP", raising=False)
+                hipopt.unset("gibbs_workgroup")
             oc, ocorp, fb = _setup(oracle, [g("cipher.wfsa"), g("cipher.fst")], g("cipher.data"),
                                    [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.5, 0.1])
             gs = HipGibbs(fb, 12, burnin=3, seed=11, mode=mode)

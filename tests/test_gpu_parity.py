@@ -10,6 +10,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import hip_env, set_hip_option  # noqa: E402,F401
+
 
 def sig6(x):
     """the reference prints these with 6 significant digits (default ostream precision)"""
@@ -330,11 +332,11 @@ def test_full_size_properties_c4():
     c2 = fb.counts()
     assert lp2 == lp
     assert (c2 != counts).sum() <= 16 and np.allclose(c2, counts, rtol=1e-13, atol=0)
-    os.environ["CARMEL_HIP_TRANSPOSE"] = "0"
+    set_hip_option("transpose", "0")
     try:
         fg = _fb(w, c)
     finally:
-        os.environ.pop("CARMEL_HIP_TRANSPOSE", None)
+        set_hip_option("transpose", None)
     lpg, _ = fg.estimate(per_pair=True)
     assert lpg == pytest.approx(lp, rel=1e-12)
     np.testing.assert_allclose(fg.counts(), counts, rtol=1e-9, atol=1e-12)
@@ -356,14 +358,14 @@ def test_full_size_properties_c4():
 
 
 @pytest.mark.parametrize("name,n_pairs", [("c2", None), ("c4", 300000)])
-def test_run_length_transposition_indices_are_the_per_item_ones(name, n_pairs, monkeypatch, capfd):
+def test_run_length_transposition_indices_are_the_per_item_ones(name, n_pairs, hipopt, capfd):
     """TransArgs::tr_* / br_*: the run-length form of the transposition's source indices (run starts as a bit mask in LDS)
     must move the very same items -- counts and ln p bit for bit those of the per-item index arrays"""
     w, c = synth.make_config(name, n_pairs=n_pairs)
     out = {}
-    monkeypatch.setenv("CARMEL_TIMING", "1")
+    hipopt.set("timing", "1")
     for mode in ("0", "1"):
-        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", mode)
+        hipopt.set("trans_runs", mode)
         capfd.readouterr()
         fb = _fb(w, c)
         lp, _ = fb.estimate(per_pair=True)
@@ -382,7 +384,7 @@ def test_run_length_transposition_indices_are_the_per_item_ones(name, n_pairs, m
 
 
 @pytest.mark.parametrize("name,n_pairs", [("c2", None), ("c4", 300000), ("c4a", 40000)])
-def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n_pairs, monkeypatch):
+def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n_pairs, hipopt):
     """TransArgs::scatter: either direction of the blocked transposition may do its random access in the FIRST pass (a
     scattered write of one run per tile / bucket) and read sequentially in the second, instead of writing sequentially
     and gathering.  Same items, same per-arc summation order: counts and ln p bit for bit, with per-item and with
@@ -390,9 +392,9 @@ def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n
     w, c = synth.make_config(name, n_pairs=n_pairs)
     out = {}
     for runs in ("0", "1"):
-        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", runs)
+        hipopt.set("trans_runs", runs)
         for mode in ("0", "1", "2", "3"):
-            monkeypatch.setenv("CARMEL_HIP_TRANS_SCATTER", mode)
+            hipopt.set("trans_scatter", mode)
             fb = _fb(w, c)
             lp, _ = fb.estimate(per_pair=True)
             res = (lp, fb.pair_logprob.copy(), fb.counts().copy())
@@ -410,7 +412,7 @@ def test_scattering_first_pass_of_the_transposition_moves_the_same_items(name, n
 
 
 @pytest.mark.parametrize("kind", ["paths", "ambiguous"])
-def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
+def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, hipopt):
     """tile_sweep_kernel (tile_sweep.hip): on a corpus of small plain lane lattices the weights' way into lattice order, the lane
     sweeps and the posteriors' way out are one persistent kernel working out of LDS.  Same layout, the three kernels instead
     (CARMEL_HIP_TILE_SWEEP_KERNEL=0): the same bits (ln p per pair, every count, the weights after an M-step; the sign of a
@@ -423,12 +425,12 @@ def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
         c = synth.random_walk_corpus(w, 40000, min_arcs=3, max_arcs=9, seed=5, out_degree=4)
     out = {}
     for mode in ("fused", "kernels", "layout"):
-        monkeypatch.delenv("CARMEL_HIP_TILE_SWEEP_KERNEL", raising=False)
-        monkeypatch.delenv("CARMEL_HIP_TILE_SWEEP", raising=False)
+        hipopt.unset("tile_sweep_kernel")
+        hipopt.unset("tile_sweep")
         if mode == "kernels":
-            monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP_KERNEL", "0")
+            hipopt.set("tile_sweep_kernel", "0")
         if mode == "layout":
-            monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP", "0")
+            hipopt.set("tile_sweep", "0")
         fb = _fb(w, c)
         assert (fb.tile_sweep_tiles > 0) == (mode != "layout")
         lp, _ = fb.estimate(per_pair=True)
@@ -452,31 +454,31 @@ def test_tile_sweep_is_the_three_kernels_it_replaces(oracle, kind, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", ["clustered", "long_plain", "ragged"])
-def test_fused_lane_sweep_is_the_kernels_it_replaces(oracle, kind, monkeypatch):
+def test_fused_lane_sweep_is_the_kernels_it_replaces(oracle, kind, hipopt):
     """sweep_lane_kernel<.., XC> (kernels.hip; LatticeSet::lane_fused): on a corpus of one-per-lane lattices the tile sweep does
     not take, the lane sweep's backward pass stages a tile's posteriors in LDS and writes them to XC in tile-major item order
     itself.  Same layout with CARMEL_HIP_LANE_FUSED_KERNEL=0 (sweep -> post -> trans_c_tile): the same bits -- ln p per pair,
     every count, the weights after an M-step.  The 16384-position layout (CARMEL_HIP_LANE_FUSED=0): the same ln p, counts
     equal up to the order of their sums.  And all are the oracle's."""
     if kind == "clustered":  # c4a's shape: windowed groups (three in-arcs per state) next to plain ones
-        monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "20")
+        hipopt.set("lane_window_min", "20")
         w = synth.clustered_wfst(3 * 400 + 1, 12, members=3, seed=5)
         c = synth.clustered_walk_corpus(w, 9000, 12, members=3, min_arcs=3, max_arcs=40, seed=5)
     elif kind == "long_plain":  # single paths and small ambiguities beyond the tile sweep's 48 arcs: plain groups of several tiles
         w = synth.random_wfst(3000, 6, seed=12)
         c = synth.random_walk_corpus(w, 6000, min_arcs=3, max_arcs=90, seed=12, out_degree=6)
     else:  # few ragged lattices: partial groups, tiles with a handful of items, epsilons (kept off the one-per-wavefront layout)
-        monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "1e9")
+        hipopt.set("wave_min_width", "1e9")
         w = synth.random_wfst(300, 4, n_sym=6, p_eps=0.1, seed=3)
         c = synth.random_walk_corpus(w, 150, min_arcs=20, max_arcs=60, seed=3, out_degree=4)
     out = {}
     for mode in ("fused", "kernels", "layout"):
-        for k in ("CARMEL_HIP_LANE_FUSED_KERNEL", "CARMEL_HIP_LANE_FUSED"):
-            monkeypatch.delenv(k, raising=False)
+        for k in ("lane_fused_kernel", "lane_fused"):
+            hipopt.unset(k)
         if mode == "kernels":
-            monkeypatch.setenv("CARMEL_HIP_LANE_FUSED_KERNEL", "0")
+            hipopt.set("lane_fused_kernel", "0")
         if mode == "layout":
-            monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+            hipopt.set("lane_fused", "0")
         fb = _fb(w, c)
         assert fb.tile_sweep_tiles == 0 and (fb.fused_lane_tiles > 0) == (mode != "layout")
         lp, _ = fb.estimate(per_pair=True)
@@ -618,12 +620,12 @@ def test_mstep_normalize_large_unnormalised_model(oracle, group, lock, add_count
 
 
 @pytest.mark.parametrize("seed,window", [(0, 64), (1, 64), (2, 32), (3, 16), (4, 64), (5, 8)])
-def test_windowed_lane_groups(oracle, monkeypatch, seed, window):
+def test_windowed_lane_groups(oracle, hipopt, seed, window):
     """lattices whose arcs span few states of the topological numbering are swept one per lane through a RING of LDS rows
     (lattice.hpp, LaneGroup::window): the forward values are parked in a global column and gathered back per record.  The
     window is forced onto small lattices here (it normally starts above 40 states); results are the oracle's."""
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "4")
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", str(window))
+    hipopt.set("lane_window_min", "4")
+    hipopt.set("lane_window", str(window))
     rng = np.random.default_rng(300 + seed)
     if seed % 2 == 0:  # narrow, long lattices: few states per level
         kw = dict(n_states=int(rng.integers(4, 40)), deg=int(rng.integers(2, 5)), n_sym=int(rng.integers(3, 9)), p_eps=0.05,
@@ -644,7 +646,7 @@ def test_windowed_lane_groups(oracle, monkeypatch, seed, window):
     np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-13, err_msg=str(kw))
     assert wlp == pytest.approx(r["sum_weighted_logprob"], rel=1e-11)
     # the same corpus without windows: the same numbers
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", "0")
+    hipopt.set("lane_window", "0")
     fb2 = _fb(w, c)
     assert fb2.lattice_stats.n_windowed_pairs == 0
     fb2.estimate(per_pair=True)
@@ -654,11 +656,11 @@ def test_windowed_lane_groups(oracle, monkeypatch, seed, window):
     fb2.close()
 
 
-def test_windowed_tagging_cascade(oracle, golden_dir, monkeypatch):
+def test_windowed_tagging_cascade(oracle, golden_dir, hipopt):
     """the tutorial's tagging cascade (sentence lattices of positions x candidate tags: up to hundreds of states, arcs
     between neighbouring positions only) with every lattice above 8 states windowed: the recorded trace still holds"""
     from carmel_amd.trainer import TrainOpts, train
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "8")
+    hipopt.set("lane_window_min", "8")
     gold = json.load(open(os.path.join(golden_dir, "trace_expected.json")))["tagging"]
     oc, w, c = _cascade_from_golden(oracle, golden_dir, ["tagging.fsa", "tagging.fst"], "tagging.data")
     fb = _fb(w, c, cascade=oc.as_dict([NORM_CONDITIONAL, NORM_CONDITIONAL]))

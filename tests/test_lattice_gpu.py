@@ -8,6 +8,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import hip_env, set_hip_option  # noqa: E402,F401
+
 from carmel_amd import synth
 from carmel_amd.model import Corpus, Wfst
 
@@ -19,15 +21,15 @@ def _build(w, c, gpu, device_tables=None):
     posterior slots and the transposition tables too, unless device_tables says otherwise)"""
     from carmel_amd._capi import check, lib, ptr
     from carmel_amd.trainer import HipForwardBackward
-    os.environ["CARMEL_HIP_GPU_BUILD"] = "1" if gpu else "0"
+    set_hip_option("gpu_build", "1" if gpu else "0")
     if device_tables is None:
         device_tables = gpu
-    os.environ["CARMEL_HIP_DEVICE_TABLES"] = "1" if device_tables else "0"
+    set_hip_option("device_tables", "1" if device_tables else "0")
     try:
         fb = HipForwardBackward(w, c)
     finally:
-        del os.environ["CARMEL_HIP_GPU_BUILD"]
-        del os.environ["CARMEL_HIP_DEVICE_TABLES"]
+        set_hip_option("gpu_build", None)
+        set_hip_option("device_tables", None)
     fp = np.zeros(16, np.uint64)
     check(lib.carmel_hip_debug_lattice_fingerprint(fb.h, ptr(fp)), "fingerprint")
     ls = fb.lattice_stats
@@ -101,12 +103,12 @@ def test_corpora_outside_its_scope_go_to_the_host_builder(oracle):
 
 
 @pytest.mark.parametrize("name", ["cyclic", "wide", "long", "tagging-small", "hub"])
-def test_host_layouts_get_their_tables_from_the_device(name, capfd, monkeypatch):
+def test_host_layouts_get_their_tables_from_the_device(name, capfd, hipopt):
     """the corpora the device builder leaves to the host (bundles of cyclic lattices, one-per-wavefront lattices, mixtures, a hub
     arc with buckets of its own): the host lays them out and the DEVICE sorts the posterior slots by arc and builds the
     transposition tables (gpu_tables_for_host_layout) -- the image the host's own counting sorts leave, byte for byte, and the
     same counts"""
-    monkeypatch.setenv("CARMEL_TIMING", "1")
+    hipopt.set("timing", "1")
     if name == "cyclic":
         rng = np.random.default_rng(3)
         w = synth.random_wfst(40, 5, n_sym=4, p_eps=0.25, seed=3)  # *e*:*e* arcs: cycles in the lattices
@@ -141,18 +143,18 @@ def _tagging(reps):
 
 
 @pytest.mark.parametrize("name", ["c4a", "tagging", "forced"])
-def test_windowed_corpora_are_built_on_the_device(name, capfd, monkeypatch):
+def test_windowed_corpora_are_built_on_the_device(name, capfd, hipopt):
     """round 3: corpora with WINDOWED lane groups (lattices of up to 1 023 states whose arcs span few states of the
     topological numbering: the tagging cascade, config c4a) -- larger per-pair capacities for the exploration, the span and
     the ring of every lattice, plain groups then windowed groups, parked-value rows -- leave the host builder's image, byte
     for byte.  `forced`: windows forced onto small random lattices (CARMEL_HIP_LANE_WINDOW_MIN)."""
-    monkeypatch.setenv("CARMEL_TIMING", "1")
+    hipopt.set("timing", "1")
     if name == "c4a":
         w, c = synth.make_config("c4a", n_pairs=30000)
     elif name == "tagging":
         w, c = _tagging(6)
     else:
-        monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "6")
+        hipopt.set("lane_window_min", "6")
         w = synth.random_wfst(40, 4, n_sym=4, p_eps=0.1, seed=73)
         c = synth.random_walk_corpus(w, 3000, min_arcs=4, max_arcs=50, seed=73, out_degree=4)
     host = _build(w, c, False)
@@ -170,13 +172,13 @@ def test_windowed_corpora_are_built_on_the_device(name, capfd, monkeypatch):
 
 
 @pytest.mark.parametrize("name", ["c4a", "tagging", "plain", "cyclic", "hub"])
-def test_tile_weights_from_the_table_are_the_same_bits(name, capfd, monkeypatch):
+def test_tile_weights_from_the_table_are_the_same_bits(name, capfd, hipopt):
     """the tile passes' two sources of weights -- X, written bucket by bucket by the first pass (CARMEL_HIP_TILE_GATHER=0; what a
     WFST of few items an arc or a table beyond the cache gets), and the WFST's table through the arc of every tile-major item
     (t_t_arc; no first pass) -- are the same values at the same positions: fused-lane layouts with and without windows, the tile
     sweep's layout, bundles beside lanes, a hub arc with buckets of its own"""
-    monkeypatch.setenv("CARMEL_TIMING", "1")
-    monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", "0")  # (run-length indices keep X)
+    hipopt.set("timing", "1")
+    hipopt.set("trans_runs", "0")  # (run-length indices keep X)
     if name == "c4a":
         w, c = synth.make_config("c4a", n_pairs=30000)
     elif name == "tagging":
@@ -191,7 +193,7 @@ def test_tile_weights_from_the_table_are_the_same_bits(name, capfd, monkeypatch)
         c = synth.random_walk_corpus(w, 4000, min_arcs=20, max_arcs=40, seed=9, out_degree=2)
     res = {}
     for g in ("1", "0"):
-        monkeypatch.setenv("CARMEL_HIP_TILE_GATHER", g)
+        hipopt.set("tile_gather", g)
         capfd.readouterr()
         res[g] = _build(w, c, name in ("c4a", "tagging", "plain"))
         assert ("tile weights from the table" in capfd.readouterr().err) == (g == "1")

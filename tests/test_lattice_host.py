@@ -147,12 +147,12 @@ def test_blocked_transposition_tables():
 
 
 @pytest.mark.parametrize("seed,window,wmin", [(1, 64, 4), (2, 32, 4), (3, 16, 6), (4, 8, 4), (5, 64, 40)])
-def test_windowed_lane_layout(oracle, monkeypatch, seed, window, wmin):
+def test_windowed_lane_layout(oracle, hipopt, seed, window, wmin):
     """windowed lane groups (LaneGroup::window): lattices whose arcs span fewer than `window` states of the topological
     numbering keep only a ring of that many rows; the host restatement of the sweep poisons stale ring rows, so an arc that
     reached outside the ring would surface as a NaN.  Counts and probabilities are the oracle's."""
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW", str(window))
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", str(wmin))
+    hipopt.set("lane_window", str(window))
+    hipopt.set("lane_window_min", str(wmin))
     w = synth.random_wfst(12 + 5 * seed, 3 + seed % 3, n_sym=3 + seed, p_eps=0.1, seed=70 + seed)
     c = synth.random_walk_corpus(w, 150, min_arcs=4, max_arcs=30 + 10 * seed, seed=70 + seed, out_degree=3 + seed % 3)
     ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
@@ -200,12 +200,12 @@ def test_clustered_workloads_layout_matches_oracle(oracle, name, pairs):
 
 
 @pytest.mark.parametrize("seed,lane_states", [(1, 0), (2, 0), (3, 12), (4, 0), (5, 20)])
-def test_wave_layout_on_ambiguous_lattices(oracle, monkeypatch, seed, lane_states):
+def test_wave_layout_on_ambiguous_lattices(oracle, hipopt, seed, lane_states):
     """the one-lattice-per-wavefront layout (WaveDesc) forced onto small ambiguous corpora (every acyclic lattice no lane
     takes, however narrow): rows of 64 records that never straddle a level, forward records pointing at their arc's backward
     position; swept in numpy exactly as sweep_wave_kernel walks it, against the oracle -- and the blocked transposition
     tables must cover the wave slots (weights in, posteriors out) exactly"""
-    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
+    hipopt.set("wave_min_width", "0")
     w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
     c = synth.random_walk_corpus(w, 120, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
     ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
@@ -243,7 +243,7 @@ def test_wave_layout_on_ambiguous_lattices(oracle, monkeypatch, seed, lane_state
 FUSED_TILE = 1024  # lattice.hpp: LANE_FUSED_TILE
 
 
-def test_tile_sweep_layout(monkeypatch):
+def test_tile_sweep_layout(hipopt):
     """LatticeSet::tile_sweep (lattice.hpp, TILE_SWEEP_*): a corpus of small plain lane lattices is laid out in tiles of 8192
     positions that no lane group straddles, with room in a workgroup's LDS for the values of a tile's groups; the tables of
     the blocked transposition are built on those tiles and move exactly what they move on the five-kernel layout; the sweep
@@ -278,9 +278,9 @@ def test_tile_sweep_layout(monkeypatch):
     np.testing.assert_allclose(H.transpose_counts(tr, post), np.bincount(arc_at[valid], weights=post[valid], minlength=tr["n_arcs"]),
                                rtol=1e-12, atol=0)
     counts, plp = numpy_sweep(img, w.logw, c.n_pairs)
-    monkeypatch.setenv("CARMEL_HIP_TILE_SWEEP", "0")
+    hipopt.set("tile_sweep", "0")
     for fused, tile in (("1", FUSED_TILE), ("0", 16384)):  # without the tile sweep: the fused-lane layout, or (A/B) the round-1 tiles
-        monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", fused)
+        hipopt.set("lane_fused", fused)
         img0 = H.host_lattices(w, c, threads=4)
         assert img0["transpose"]["tile"] == tile and len(img0["transpose"]["tile_group"]) == 0
         counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)
@@ -288,7 +288,7 @@ def test_tile_sweep_layout(monkeypatch):
         np.testing.assert_allclose(counts, counts0, rtol=1e-12, atol=0)
 
 
-def test_tile_sweep_layout_is_for_small_plain_lattices_only(monkeypatch):
+def test_tile_sweep_layout_is_for_small_plain_lattices_only(hipopt):
     """a corpus with one lattice beyond 48 arcs, a windowed group or a one-per-wavefront lattice is not laid out for the tile
     sweep: a lanes-only corpus gets the fused-lane layout instead (LatticeSet::lane_fused, next test)"""
     from carmel_amd import synth
@@ -296,18 +296,18 @@ def test_tile_sweep_layout_is_for_small_plain_lattices_only(monkeypatch):
     c = synth.random_walk_corpus(w, 3000, min_arcs=3, max_arcs=60, seed=12, out_degree=6)
     tr = H.host_lattices(w, c, threads=4)["transpose"]
     assert tr["tile"] == FUSED_TILE and len(tr["tile_group"]) == 0
-    monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+    hipopt.set("lane_fused", "0")
     tr = H.host_lattices(w, c, threads=4)["transpose"]
     assert tr["tile"] == 16384 and len(tr["tile_group"]) == 0
 
 
-def test_fused_lane_layout(oracle, monkeypatch):
+def test_fused_lane_layout(oracle, hipopt):
     """LatticeSet::lane_fused (lattice.hpp, LANE_FUSED_TILE): a corpus of lane lattices the tile sweep does not take -- windowed
     groups, lattices above 48 arcs -- is laid out with every lane group on a tile of 1024 positions (16 rows of its 64 lanes) of
     its own, so that the wavefront sweeping a group owns whole tiles of the transposition and sends its posteriors out itself.
     The tables move what they move on the 16384-position layout; the numpy sweep gives the oracle's counts on both."""
     from carmel_amd import synth
-    monkeypatch.setenv("CARMEL_HIP_LANE_WINDOW_MIN", "12")  # windows on small lattices too
+    hipopt.set("lane_window_min", "12")  # windows on small lattices too
     w = synth.clustered_wfst(3 * 40 + 1, 12, members=3, seed=8)
     c = synth.clustered_walk_corpus(w, 700, 12, members=3, min_arcs=3, max_arcs=30, seed=8)
     img = H.host_lattices(w, c, threads=4)
@@ -341,7 +341,7 @@ def test_fused_lane_layout(oracle, monkeypatch):
     ok = r["has_deriv"]
     np.testing.assert_allclose(plp[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(counts, np.exp(r["counts_ln"]), rtol=1e-8, atol=1e-12)
-    monkeypatch.setenv("CARMEL_HIP_LANE_FUSED", "0")
+    hipopt.set("lane_fused", "0")
     img0 = H.host_lattices(w, c, threads=4)
     assert img0["transpose"]["tile"] == 16384
     counts0, plp0 = numpy_sweep(img0, w.logw, c.n_pairs)

@@ -126,26 +126,26 @@ def test_direct_exchange_through_a_small_transport_window(tmp_path, monkeypatch)
     np.testing.assert_array_equal(sh[:-1], plain[:-1])
 
 
-def test_sharded_exchange_over_run_length_indices(tmp_path, monkeypatch):
+def test_sharded_exchange_over_run_length_indices(tmp_path, hipopt):
     """the chunked bucket / tile passes of the sharded exchange with the transposition's run-length source indices forced on
     (CARMEL_HIP_TRANS_RUNS=1: the default on config-4-sized shards, which no test corpus reaches): bit for bit the per-item
     indices' weights, two ranks"""
     runs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", mode)
+        hipopt.set("trans_runs", mode)
         runs[mode] = _run(2, "synth-big", tmp_path, "rl" + mode, extra=["--rccl", _plugin("rl" + mode), "--plan", "--check-counts"])
         assert runs[mode][-1] == 1.0
     np.testing.assert_array_equal(runs["0"], runs["1"])
 
 
-def test_sharded_exchange_with_the_tiles_weights_from_the_table(tmp_path, monkeypatch):
+def test_sharded_exchange_with_the_tiles_weights_from_the_table(tmp_path, hipopt):
     """under a plan the tile passes may fetch their weights from the table the all-gather fills (CARMEL_HIP_TILE_GATHER=1: the
     trainer's stream waits for the chunks and runs no bucket pass behind them) or from X (0: a bucket pass per arriving chunk):
     the same weights after four iterations, bit for bit, two ranks"""
-    monkeypatch.setenv("CARMEL_HIP_TRANS_RUNS", "0")
+    hipopt.set("trans_runs", "0")
     runs = {}
     for g in ("1", "0"):
-        monkeypatch.setenv("CARMEL_HIP_TILE_GATHER", g)
+        hipopt.set("tile_gather", g)
         runs[g] = _run(2, "synth-big", tmp_path, "tg" + g, extra=["--rccl", _plugin("tg" + g), "--plan", "--check-counts"])
         assert runs[g][-1] == 1.0
     np.testing.assert_array_equal(runs["1"], runs["0"])

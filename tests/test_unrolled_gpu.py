@@ -5,6 +5,8 @@ import os
 import numpy as np
 import pytest
 
+from helpers import hip_env, set_hip_option  # noqa: E402,F401
+
 from carmel_amd import HipForwardBackward, Wfst, synth
 from carmel_amd.model import Corpus
 
@@ -56,13 +58,13 @@ def one_tape(seed, n_states=12, deg=9, n_sym=5, n_pairs=300, lo=2, hi=30, eps_ar
 
 
 def both_paths(w, c, **kw):
-    os.environ["CARMEL_HIP_UNROLLED"] = "1"  # whenever eligible (by default sparse lattices stay explicit)
+    set_hip_option("unrolled", "1")  # whenever eligible (by default sparse lattices stay explicit)
     a = HipForwardBackward(w, c, **kw)
-    os.environ["CARMEL_HIP_UNROLLED"] = "0"
+    set_hip_option("unrolled", "0")
     try:
         b = HipForwardBackward(w, c, **kw)
     finally:
-        os.environ.pop("CARMEL_HIP_UNROLLED", None)
+        set_hip_option("unrolled", None)
     return a, b
 
 
@@ -72,11 +74,11 @@ def both_paths(w, c, **kw):
                                      (6, dict(n_states=33, deg=20, n_sym=3, n_pairs=77)),
                                      (7, dict(n_states=100, deg=5, hi=40)), (8, dict(n_states=300, deg=4, n_pairs=120)),
                                      (9, dict(n_states=65, deg=8, eps_arcs=False, n_pairs=90))])
-def test_unrolled_estep_equals_explicit_and_oracle(oracle, seed, kw, ragged, monkeypatch):
+def test_unrolled_estep_equals_explicit_and_oracle(oracle, seed, kw, ragged, hipopt):
     """state counts on both sides of the 16 / 32 / 64-lane group sizes (4, 2 or 1 pairs per wavefront), pair counts
     that do not fill the last wavefront; `ragged` forces per-symbol table slabs where slabs of one size would be used"""
     if ragged:
-        monkeypatch.setenv("CARMEL_HIP_UNROLLED_RAGGED", "1")
+        hipopt.set("unrolled_ragged", "1")
     w, c = one_tape(seed, **kw)
     u, e = both_paths(w, c)
     assert u.lattice_stats.n_bundles == 0 and e.lattice_stats.n_bundles > 0  # the first really ran unrolled
@@ -112,7 +114,7 @@ def test_unrolled_training_equals_explicit(oracle):
 
 
 @pytest.mark.parametrize("mode,layout", [("cipher", 1), ("dense", 2)])
-def test_composed_arc_counts_under_the_unrolled_cascade_sweep(mode, layout, monkeypatch):
+def test_composed_arc_counts_under_the_unrolled_cascade_sweep(mode, layout, hipopt):
     """the reference always has arc_counts::counts per COMPOSED arc (train.h:28-40, derivations.h:432-449); the unrolled /
     dense sweep of a cascade accumulates per parameter, so carmel_hip_get_counts runs one on-demand pass over explicit
     lattices with the composed weights as they stand: the same counts as a trainer that keeps explicit lattices"""
@@ -120,7 +122,7 @@ def test_composed_arc_counts_under_the_unrolled_cascade_sweep(mode, layout, monk
     from carmel_amd._capi import lib
     w, u = mw.build(mode, 0, 1)
     assert lib.carmel_hip_lattice_layout(u.h) == layout
-    monkeypatch.setenv("CARMEL_HIP_UNROLLED", "0")
+    hipopt.set("unrolled", "0")
     w2, e = mw.build(mode, 0, 1)
     assert lib.carmel_hip_lattice_layout(e.h) == 0
     for it in range(2):

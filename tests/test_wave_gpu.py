@@ -31,12 +31,12 @@ def _check(oracle, w, c, iters=3, expect_waves=True, rtol=1e-7):
 
 @pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("seed,lane_states", [(1, "0"), (2, "0"), (3, "12"), (4, "0"), (5, "20"), (6, "0")])
-def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states, ring):
+def test_forced_wave_sweep_matches_oracle(oracle, hipopt, seed, lane_states, ring):
     """ring = 1: the ring form where a lattice allows it (values in a ring of LDS slots, forward values parked in HBM);
     ring = 0: every lattice with all of its values in LDS"""
-    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
-    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
-    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", lane_states)
+    hipopt.set("wave_min_width", "0")
+    hipopt.set("wave_ring", ring)
+    hipopt.set("lane_states", lane_states)
     w = synth.random_wfst(14 + 4 * seed, 4 + seed % 3, n_sym=3 + seed % 2, p_eps=0.12, seed=90 + seed)
     c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
     rng = np.random.default_rng(seed)
@@ -53,20 +53,20 @@ def test_forced_wave_sweep_matches_oracle(oracle, monkeypatch, seed, lane_states
     _check(oracle, w, c)
 
 
-def test_wide_levels_span_several_rows(oracle, monkeypatch):
+def test_wide_levels_span_several_rows(oracle, hipopt):
     """levels with more than 64 arcs (several rows per level) and states with many in-arcs: a dense little transducer"""
-    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
-    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", "0")
+    hipopt.set("wave_min_width", "0")
+    hipopt.set("lane_states", "0")
     w = synth.clustered_wfst(12 * 4 + 1, 48, members=12, n_sym=6, n_in_sym=3, seed=21)
     c = synth.clustered_walk_corpus(w, 60, 48, members=12, min_arcs=3, max_arcs=25, seed=21)
     _check(oracle, w, c, iters=2)
 
 
 @pytest.mark.parametrize("ring", ["1", "0"])
-def test_long_workload_slice_uses_the_wave_sweep(oracle, monkeypatch, ring):
+def test_long_workload_slice_uses_the_wave_sweep(oracle, hipopt, ring):
     """bench.py --config long: these lattices go one per wavefront by the builder's own rule"""
     from carmel_amd.trainer import HipForwardBackward
-    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
+    hipopt.set("wave_ring", ring)
     w, c = synth.make_config("long", n_pairs=40)
     fb = HipForwardBackward(w, c)
     assert fb.lattice_stats.n_windowed_pairs == 0 and fb.lattice_stats.n_bundles == 40
@@ -76,17 +76,17 @@ def test_long_workload_slice_uses_the_wave_sweep(oracle, monkeypatch, ring):
 
 @pytest.mark.parametrize("ring", ["1", "0"])
 @pytest.mark.parametrize("seed", [2, 3, 5])
-def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, capfd, seed, ring):
+def test_gathered_and_laid_out_weights_give_the_same_bits(hipopt, capfd, seed, ring):
     """the sweep's two sources of weights -- the WFST's table through the records' arc ids (tables the caches hold: the default
     here) and wcache, written in lattice order by the transposition's weight pass (CARMEL_HIP_WAVE_GATHER=0; what a larger
     table gets) -- and its two ways out for the posteriors -- `post` and the tile pass, or every posterior straight to its item's
     place in XC (CARMEL_HIP_WAVE_XC=1: forced here, chosen where a row's items are neighbours in XC) -- are the same numbers in
     the same places of the same sums"""
     from carmel_amd.trainer import HipForwardBackward
-    monkeypatch.setenv("CARMEL_TIMING", "1")
-    monkeypatch.setenv("CARMEL_HIP_WAVE_MIN_WIDTH", "0")
-    monkeypatch.setenv("CARMEL_HIP_WAVE_RING", ring)
-    monkeypatch.setenv("CARMEL_HIP_LANE_STATES", "12" if seed == 3 else "0")  # (seed 3: lane lattices beside the waves)
+    hipopt.set("timing", "1")
+    hipopt.set("wave_min_width", "0")
+    hipopt.set("wave_ring", ring)
+    hipopt.set("lane_states", "12" if seed == 3 else "0")  # (seed 3: lane lattices beside the waves)
     if seed == 5:
         w = synth.clustered_wfst(12 * 4 + 1, 48, members=12, n_sym=6, n_in_sym=3, seed=21)  # levels of several rows
         c = synth.clustered_walk_corpus(w, 60, 48, members=12, min_arcs=3, max_arcs=25, seed=21)
@@ -95,8 +95,8 @@ def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, capfd, se
         c = synth.random_walk_corpus(w, 400, min_arcs=3, max_arcs=14 + 4 * seed, seed=90 + seed, out_degree=4 + seed % 3)
     runs = []
     for g, x in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("CARMEL_HIP_WAVE_GATHER", g)
-        monkeypatch.setenv("CARMEL_HIP_WAVE_XC", x)
+        hipopt.set("wave_gather", g)
+        hipopt.set("wave_xc", x)
         capfd.readouterr()
         fb = HipForwardBackward(w, c)
         assert ("wave posteriors straight to XC" in capfd.readouterr().err) == (x == "1")
@@ -119,11 +119,11 @@ def test_gathered_and_laid_out_weights_give_the_same_bits(monkeypatch, capfd, se
         np.testing.assert_allclose(runs[0][-1], other[-1], rtol=1e-12, atol=0)
 
 
-def test_waves_refuse_the_gather_formulation(monkeypatch):
+def test_waves_refuse_the_gather_formulation(hipopt):
     """CARMEL_HIP_TRANSPOSE=0 (the A/B switch of the lane corpora) has no weight pass: wave lattices say so instead of sweeping
     over weights nobody wrote"""
     from carmel_amd.trainer import HipForwardBackward
-    monkeypatch.setenv("CARMEL_HIP_TRANSPOSE", "0")
+    hipopt.set("transpose", "0")
     w, c = synth.make_config("long", n_pairs=8)
     with pytest.raises(Exception, match="blocked transposition"):
         HipForwardBackward(w, c)

@@ -23,20 +23,51 @@ import numpy as np  # noqa: E402
 
 
 class MP(object):
-    """a stand-in for pytest's monkeypatch: setenv only"""
+    """a stand-in for the tests' `hipopt` fixture (and for pytest's monkeypatch: setenv): the library's switches are options now
+    (carmel_hip_set_option); the variable is exported too, for the child processes that translate their environment"""
     def __init__(self):
-        self.saved = {}
+        self.saved, self.opts = {}, {}
+
+    @staticmethod
+    def _key(k):
+        return "timing" if k == "CARMEL_TIMING" else k[len("CARMEL_HIP_"):].lower() if k.startswith("CARMEL_HIP_") else None
 
     def setenv(self, k, v):
+        import carmel_amd
         self.saved.setdefault(k, os.environ.get(k))
         os.environ[k] = v
+        if self._key(k) in carmel_amd.option_names():
+            self.opts.setdefault(self._key(k), carmel_amd.get_option(self._key(k)))
+            carmel_amd.set_option(self._key(k), v)
+
+    def delenv(self, k, raising=False):
+        import carmel_amd
+        self.saved.setdefault(k, os.environ.get(k))
+        os.environ.pop(k, None)
+        if self._key(k) in carmel_amd.option_names():
+            self.opts.setdefault(self._key(k), carmel_amd.get_option(self._key(k)))
+            carmel_amd.set_option(self._key(k), None)
+
+    def set(self, key, value):
+        env = "CARMEL_TIMING" if key == "timing" else "CARMEL_HIP_" + key.upper()
+        if value is None:
+            self.delenv(env)
+        else:
+            self.setenv(env, str(value))
+
+    def unset(self, key):
+        self.set(key, None)
 
     def undo(self):
+        import carmel_amd
         for k, v in self.saved.items():
             if v is None:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        for k, v in self.opts.items():
+            carmel_amd.set_option(k, v)
+        self.saved, self.opts = {}, {}
 
 
 def main():
@@ -103,7 +134,7 @@ def main():
         out = {}
         for mode in ("fused", "kernels", "layout"):
             for k in ("CARMEL_HIP_TILE_SWEEP_KERNEL", "CARMEL_HIP_TILE_SWEEP"):
-                os.environ.pop(k, None)
+                mp.delenv(k)
             if mode == "kernels":
                 mp.setenv("CARMEL_HIP_TILE_SWEEP_KERNEL", "0")
             if mode == "layout":
@@ -149,7 +180,7 @@ def main():
         out = {}
         for mode in ("fused", "kernels", "layout"):
             for k in ("CARMEL_HIP_LANE_FUSED_KERNEL", "CARMEL_HIP_LANE_FUSED"):
-                os.environ.pop(k, None)
+                mp.delenv(k)
             if mode == "kernels":
                 mp.setenv("CARMEL_HIP_LANE_FUSED_KERNEL", "0")
             if mode == "layout":

@@ -9,8 +9,11 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
+import carmel_amd
 from carmel_amd import synth
 from carmel_amd.forests import HipForests
+
+carmel_amd.options_from_env()
 
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 sweeps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

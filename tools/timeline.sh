@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5: start / end of every kernel of one E-step (do the streams overlap?  where are the gaps?)
-# usage: bash tools/r5_timeline.sh [chunks] [config]
+# start / end of every kernel of one E-step (do the streams overlap?  where are the gaps?)
+# usage: bash tools/timeline.sh [chunks] [config]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 CH=${1:-2}
 CFG=${2:-c4a}

@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 5: kernel timeline of one iteration with the exchange planned over a loopback communicator (world 1): what the
-# chunking itself costs.  usage: bash tools/r5_xchg_timeline.sh [chunks] [form]
+# kernel timeline of one iteration with the exchange planned over a loopback communicator (world 1): what the
+# chunking itself costs.  usage: bash tools/xchg_timeline.sh [chunks] [form]
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 K=${1:-4}
 FORM=${2:-sharded}
