@@ -141,6 +141,10 @@ WORKLOAD_TEXT = {
             "positions), %d training pairs %s (walks of %s moves: lattices of 320-4800 states), conditional normalisation, "
             "cached lattices",
     "toya": "small clustered %d-state / %d-arc WFST, %d training pairs %s (walks of %s moves)",
+    "mix": "ONE corpus of all three lattice classes: synthetic %d-state / %d-arc WFST of three regions (single paths like config 4's; "
+           "c4a's clusters of 3; `long`'s clusters of 8), %d training pairs %s -- 90 %% short single paths, 9 %% ambiguous windowed "
+           "lattices, 1 %% long wide ones (walks of %s moves), interleaved in corpus order; conditional normalisation, cached lattices",
+    "toymix": "small mixed-class %d-state / %d-arc WFST, %d training pairs %s (walks of %s moves)",
 }
 
 
@@ -390,7 +394,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
         achieved = alg / (k_ms * 1e-3) / 1e9
         shape = (w.n_states, w.n_arcs, c.n_pairs if not (args.scaling == "strong" and world > 1) else c.n_pairs * world,
                  "in total, sharded" if args.scaling == "strong" and world > 1 else "per GPU",
-                 ("%d-%d" % walk) if walk else {"c4a": "5-40", "long": "40-600", "toya": "3-14"}.get(name, "5-40"))
+                 ("%d-%d" % walk) if walk else {"c4a": "5-40", "long": "40-600", "toya": "3-14", "mix": "5-40 / 5-40 / 40-600", "toymix": "3-12 / 3-12 / 8-30"}.get(name, "5-40"))
         out = {
             "metric": METRIC, "value": value, "unit": "arc-updates/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": 1e3 * dt / steps, "ms_per_step_median": float(np.median(step_ms)),
@@ -442,7 +446,7 @@ def run_em(name, args, dist=None, rank=0, world=1, local_rank=0, one_device=Fals
         comm.close()
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import binding as ob  # CPU restatement of the reference: the checker, timed as the baseline
-        cap = args.cpu_sample_pairs if headline else {"c2": 50000, "c4a": 20000, "long": 40}.get(name, 20000)
+        cap = args.cpu_sample_pairs if headline else {"c2": 50000, "c4a": 20000, "long": 40, "mix": 4000}.get(name, 20000)
         ns = min(cap, c.n_pairs)
         cs = c.shard(0, max(1, c.n_pairs // ns)) if ns < c.n_pairs else c
         nthreads = args.cpu_threads or min(64, len(os.sched_getaffinity(0)))
@@ -815,7 +819,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 200 (c3: 20); c5: 1000 sweeps, the length BASELINE.json's config names")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", default="c4", choices=["c2", "c4", "c4a", "long", "toy", "toya", "c3", "c5", "amb", "crp"])
+    ap.add_argument("--config", default="c4", choices=["c2", "c4", "c4a", "long", "mix", "toy", "toya", "toymix", "c3", "c5", "amb", "crp"])
     ap.add_argument("--lines", type=int, default=200000, help="c3: corpus lines")
     ap.add_argument("--forests", type=int, default=100000, help="c5: forests")
     ap.add_argument("--pairs", type=int, default=None, help="pairs per GPU of the headline workload (default: the config's)")
@@ -823,7 +827,7 @@ def main():
                     help="weak: --pairs per GPU; strong: --pairs in total, sharded over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="the headline workload only")
-    ap.add_argument("--secondary", default="c4a,amb,c2,long,c3,c5,crp", help="which workloads follow the headline at N = 1")
+    ap.add_argument("--secondary", default="c4a,amb,c2,long,mix,c3,c5,crp", help="which workloads follow the headline at N = 1")
     ap.add_argument("--full-out", default=None, help="file for the complete JSON (default: gpurun_out/bench_full.json when that directory "
                                                       "exists or can be made, else none); stdout carries the compact line")
     ap.add_argument("--secondary-steps", type=int, default=40)

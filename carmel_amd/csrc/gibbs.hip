@@ -920,7 +920,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         for (uint32_t l = 0; l <= d.n_levels; ++l) lev_arc[d.level_base + l] = ooff[lo[l]];
         if (trellis && d.n_levels <= GX_REG_LEVELS) {
           const uint32_t m = std::max<uint32_t>((uint32_t)d.n_arcs, d.n_states);
-          need_nq[b] = m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 4 : m <= 512 ? 8 : 0;
+          need_nq[b] = m <= 64 ? 1 : m <= 128 ? 2 : m <= 256 ? 4 : m <= 512 ? 8 : m <= 1024 ? 16 : 0;  // (16: the exact chain only)
         }
       }
       HIPCHK(g->gx_lev_arc.upload(lev_arc, s));
@@ -945,7 +945,10 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
       // must be eligible; the parallel sweep takes the eligible ones class by class.  CARMEL_HIP_GIBBS_REG=0: the LDS kernel (A/B)
       const bool reg_on = !(lib_opt("gibbs_reg") && atoi(lib_opt("gibbs_reg")) == 0);
       g->reg_nq = 0;
-      if (g->wave_ok && reg_on && o->mode == 0) {
+      // (the exact chain: measured on the tagging cascade -- whose longest sentence needs 16 chunks -- the 16-chunk instance is
+      // twice as SLOW as the LDS kernel, 65 k cycles a block against 36 k: issuing a block's 16 x 2 record loads and exchanging 16 x 4
+      // registers for the path's parameters cost more than the level loop saves; so only when asked for: gibbs_reg = 1)
+      if (g->wave_ok && reg_on && o->mode == 0 && lib_opt("gibbs_reg") && atoi(lib_opt("gibbs_reg")) == 1) {
         int nq = 2;
         for (size_t b = 0; b < bb.size() && nq; ++b) nq = need_nq[b] ? std::max(nq, need_nq[b]) : 0;
         g->reg_nq = nq;
@@ -962,7 +965,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         for (size_t b = 0; b < bb.size(); ++b) arcs[b] = (uint32_t)L.bundles[bb[b]].n_arcs;
         std::vector<uint32_t> sorted;  // (of the blocks the LDS kernel takes)
         for (size_t b = 0; b < bb.size(); ++b)
-          if (!(reg_on && need_nq[b])) sorted.push_back(arcs[b]);
+          if (!(reg_on && need_nq[b] && need_nq[b] <= 8)) sorted.push_back(arcs[b]);
         if (sorted.empty()) sorted.push_back(0u);
         std::sort(sorted.begin(), sorted.end());
         // (four classes at the median, the 80th and the 95th percentile: the tagging cascade's median sentence needs a third of
@@ -973,7 +976,7 @@ int carmel_hip_gibbs_create(carmel_hip_gibbs** out, carmel_hip_trainer* t, const
         std::vector<uint32_t> lists[GX_WCLASSES];
         for (size_t b = 0; b < bb.size(); ++b) {
           int c = 0;
-          if (reg_on && need_nq[b]) {  // classes 0..3: the register kernel with 1, 2, 4, 8 chunks of arcs
+          if (reg_on && need_nq[b] && need_nq[b] <= 8) {  // classes 0..3: the register kernel with 1, 2, 4, 8 chunks of arcs
             c = need_nq[b] == 1 ? 0 : need_nq[b] == 2 ? 1 : need_nq[b] == 4 ? 2 : 3;
             g->wclass[c].nq = need_nq[b];
           } else {

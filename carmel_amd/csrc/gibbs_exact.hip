@@ -557,7 +557,7 @@ __device__ __forceinline__ uint32_t gxr_bperm(uint32_t v, uint32_t from_lane) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(from_lane << 2), (int)v);
 }
 template <bool PAR, int NQ>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? (NQ <= 4 ? 4 : 2) : 1, PAR ? (NQ <= 4 ? 4 : 2) : 2))) void gibbs_reg_wave_kernel(GxArgs A) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? (NQ <= 4 ? 4 : 2) : 1, PAR ? (NQ <= 4 ? 4 : 2) : (NQ <= 8 ? 2 : 1)))) void gibbs_reg_wave_kernel(GxArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gx_lds[];
   if (!PAR && A.n_chains > 1) {
     const uint32_t c = blockIdx.x;
@@ -1006,6 +1006,7 @@ hipError_t launch_gibbs_reg_wave(const GxArgs& A, uint32_t n_waves, int nq, hipS
     case 2: return launch_reg<false, 2>(A, grid, lds, s);
     case 4: return launch_reg<false, 4>(A, grid, lds, s);
     case 8: return launch_reg<false, 8>(A, grid, lds, s);
+    case 16: return launch_reg<false, 16>(A, grid, lds, s);
   }
   return hipErrorInvalidValue;
 }

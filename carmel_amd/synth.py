@@ -133,6 +133,118 @@ def clustered_walk_corpus(w, n_pairs, out_degree, members=2, min_arcs=5, max_arc
     return Corpus(in_off, ins[mi], out_off, outs[mo])
 
 
+MIX_REGIONS = (
+    # (clusters, members, moves incl. the one into the final state, input alphabet, walk lengths, share of the pairs)
+    (300000, 1, 10, 64, (5, 40), 0.90),    # single paths like config 4's: one lattice per lane, the tile sweep's class
+    (100000, 3, 4, 4, (5, 40), 0.09),      # c4a's ambiguous lattices: positions x 3 states, windowed lane groups
+    (12500, 8, 4, 4, (40, 600), 0.01),     # `long`'s: 64 arcs between positions, one lattice per wavefront
+)
+
+
+def mixed_wfst(regions=MIX_REGIONS, n_sym=64, p_eps=0.1, seed=9, entries=4):
+    """One transducer whose corpus mixes the lattice classes (round-5 verdict: every benchmarked corpus was one class).  The
+    start state (a cluster of its own) has `entries` moves into every REGION; a region is clustered_wfst's construction with its
+    own cluster size -- 1: single paths (config 4), 3: c4a's ambiguous lattices, 8: `long`'s wide ones -- and walks stay inside
+    their region.  States: the start, then the regions' clusters in order, then the final state; arcs state-major, moves in
+    order, destination member innermost, move 0 into the final state (one arc per member, as clustered_wfst).  Returns
+    (Wfst, layout) -- layout is what mixed_walk_corpus needs to follow moves."""
+    rng = np.random.default_rng(seed)
+    first_state = [1]
+    for ncl, M, _mv, _k, _w, _p in regions:
+        first_state.append(first_state[-1] + ncl * M)
+    F = first_state[-1]
+    n_states = F + 1
+    srcs, dsts, isyms, osyms, gs = [], [], [], [], []
+
+    def labels(shape, k):
+        lab = rng.integers(FIRST_SYM, FIRST_SYM + k - 1, size=shape, dtype=np.uint32)
+        lab[rng.random(shape) < p_eps] = 0
+        return lab
+
+    # the start state: move 0 into the final state, then `entries` moves into every region (to every member of the cluster entered)
+    start_moves = [(F, 1)]
+    for r, (ncl, M, _mv, _k, _w, _p) in enumerate(regions):
+        for c in rng.integers(0, ncl, size=entries):
+            start_moves.append((first_state[r] + int(c) * M, M))
+    s_in = labels(len(start_moves), n_sym)
+    s_out = rng.permutation(n_sym - 1)[:len(start_moves)].astype(np.uint32) + FIRST_SYM  # (distinct: the first move names the region)
+    start_first_arc = []
+    n0 = 0
+    for m, (d0, M) in enumerate(start_moves):
+        start_first_arc.append(n0)
+        srcs.append(np.zeros(M, dtype=np.uint32))
+        dsts.append((d0 + np.arange(M)).astype(np.uint32))
+        isyms.append(np.full(M, s_in[m], dtype=np.uint32))
+        osyms.append(np.full(M, s_out[m], dtype=np.uint32))
+        n0 += M
+    gs.append(rng.exponential(size=n0))
+    arc_base = [n0]
+    for r, (ncl, M, moves, k_in, _w, _p) in enumerate(regions):
+        s0 = first_state[r]
+        deg = moves * M
+        ns = ncl * M
+        dcl = rng.integers(0, ncl, size=(ncl, moves), dtype=np.int64)
+        li, lo = labels((ncl, moves), k_in), labels((ncl, moves), n_sym)
+        cl = np.repeat(np.arange(ncl, dtype=np.int64), M * deg)
+        mv = np.tile(np.repeat(np.arange(moves, dtype=np.int64), M), ns)
+        dm = np.tile(np.arange(M, dtype=np.int64), ns * moves)
+        dst = (s0 + dcl[cl, mv] * M + dm).astype(np.uint32)
+        dst[mv == 0] = F
+        srcs.append(np.repeat(np.arange(s0, s0 + ns, dtype=np.uint32), deg))
+        dsts.append(dst)
+        isyms.append(li[cl, mv])
+        osyms.append(lo[cl, mv])
+        gs.append(rng.exponential(size=ns * deg))
+        arc_base.append(arc_base[-1] + ns * deg)
+    src, dst, isym, osym, g = (np.concatenate(x) for x in (srcs, dsts, isyms, osyms, gs))
+    key = src.astype(np.uint64) * np.uint64(1 << 20) + isym.astype(np.uint64)
+    _, inv = np.unique(key, return_inverse=True)
+    sums = np.bincount(inv, weights=g)
+    w = Wfst(n_states, F, src, dst, isym, osym, np.log(g / sums[inv]))
+    layout = dict(regions=regions, first_state=first_state, arc_base=arc_base, start_moves=start_moves, start_first_arc=start_first_arc,
+                  entries=entries)
+    return w, layout
+
+
+def mixed_walk_corpus(w, layout, n_pairs, seed=9):
+    """pairs read off walks over mixed_wfst: the first move enters a region (drawn by the regions' shares of the pairs), the walk
+    stays there for its length, the last move is move 0 into the final state.  Pairs of the regions are interleaved in corpus
+    order (drawn independently), as a real corpus mixes short and long sentences."""
+    rng = np.random.default_rng(seed + 1000003)
+    regions = layout["regions"]
+    shares = np.array([r[5] for r in regions], dtype=np.float64)
+    reg = rng.choice(len(regions), size=n_pairs, p=shares / shares.sum())
+    lo = np.array([r[4][0] for r in regions])[reg]
+    hi = np.array([r[4][1] for r in regions])[reg]
+    L = rng.integers(lo, hi + 1)  # moves inside the region (incl. the last one)
+    M = np.array([r[1] for r in regions], dtype=np.int64)[reg]
+    moves = np.array([r[2] for r in regions], dtype=np.int64)[reg]
+    s0 = np.array(layout["first_state"][:-1], dtype=np.int64)[reg]
+    a0 = np.array(layout["arc_base"][:-1], dtype=np.int64)[reg]
+    ent = rng.integers(0, layout["entries"], size=n_pairs)
+    sm = 1 + reg * layout["entries"] + ent  # the start state's move
+    first_arc = np.array(layout["start_first_arc"], dtype=np.int64)[sm]
+    maxL = int(L.max()) + 1
+    ins = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    outs = np.zeros((n_pairs, maxL), dtype=np.uint32)
+    ins[:, 0], outs[:, 0] = w.isym[first_arc], w.osym[first_arc]
+    cur = w.dst[first_arc].astype(np.int64)  # member 0 of the cluster entered
+    for step in range(maxL - 1):
+        active = step < L
+        last = step == L - 1
+        pick = np.minimum(1 + (rng.random(n_pairs) * (moves - 1)).astype(np.int64), moves - 1)
+        pick[last] = 0
+        arc = a0 + (cur - s0) * (moves * M) + pick * M
+        arc[~active] = 0
+        ins[:, step + 1] = np.where(active, w.isym[arc], 0)
+        outs[:, step + 1] = np.where(active, w.osym[arc], 0)
+        cur = np.where(active & ~last, w.dst[arc].astype(np.int64), cur)
+    mi, mo = ins != 0, outs != 0
+    in_off = np.concatenate([[0], np.cumsum(mi.sum(1))]).astype(np.uint64)
+    out_off = np.concatenate([[0], np.cumsum(mo.sum(1))]).astype(np.uint64)
+    return Corpus(in_off, ins[mi], out_off, outs[mo]), reg
+
+
 CONFIGS = {
     # name: (n_states, out_degree, n_pairs, seed)
     "toy": (200, 6, 300, 7),
@@ -154,6 +266,12 @@ CLUSTERED = {
 def make_config(name, n_pairs=None, rank=0, walk=None):
     """(transducer, corpus) of a named synthetic workload; rank r > 0 draws another shard of the same size (other walks over
     the same transducer), walk = (min_arcs, max_arcs) overrides the walk lengths (experiments)"""
+    if name in ("mix", "toymix"):
+        # a corpus of all three lattice classes over one transducer (mixed_wfst): 200 000 pairs, 90 / 9 / 1 % by class
+        regions = MIX_REGIONS if name == "mix" else ((300, 1, 6, 16, (3, 12), 0.7), (90, 3, 4, 4, (3, 12), 0.2), (24, 8, 4, 4, (8, 30), 0.1))
+        w, layout = mixed_wfst(regions, seed=9)
+        c, _reg = mixed_walk_corpus(w, layout, n_pairs or (200000 if name == "mix" else 400), seed=9 + 7919 * rank)
+        return w, c
     if name in CLUSTERED:
         n_states, deg, members, npairs, seed, lo, hi = CLUSTERED[name]
         if n_pairs is not None:

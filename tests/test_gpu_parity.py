@@ -90,6 +90,38 @@ def test_estep_random_shapes(oracle, seed):
     fb.close()
 
 
+@pytest.mark.parametrize("scale", [1, 12])
+def test_mixed_class_corpus(oracle, scale):
+    """one corpus of all three lattice classes over one transducer (synth.mixed_wfst, the shape of `bench.py --config mix`:
+    single paths, clusters of 3, clusters of 8; short and long pairs interleaved in corpus order): per-pair ln p, the expected
+    counts and the next weights against the oracle.  scale 12: enough long wide lattices for the one-per-wavefront layout to
+    sit beside the lane groups in one lattice set."""
+    regions = ((300, 1, 6, 16, (3, 12), 0.7), (90, 3, 4, 4, (3, 12), 0.2), (24, 8, 4, 4, (8, 30 * (2 if scale > 1 else 1)), 0.1))
+    w, layout = synth.mixed_wfst(regions, seed=9)
+    c, reg = synth.mixed_walk_corpus(w, layout, 400 * scale, seed=9)
+    assert set(np.unique(reg)) == {0, 1, 2}
+    fb = _fb(w, c)
+    lp, wlp = fb.estimate(per_pair=True)
+    ow, oc, r = oracle_estep(oracle, w, c)
+    ok = r["has_deriv"]
+    assert ok.all() and np.array_equal(ok, fb.has_deriv.astype(bool))
+    np.testing.assert_allclose(fb.pair_logprob[ok], r["pair_logprob"][ok], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(fb.counts(), np.exp(r["counts_ln"]), rtol=RTOL, atol=1e-13)
+    assert lp == pytest.approx(r["sum_logprob"], rel=1e-11)
+    fb.close()
+    # ... and three iterations of training: the oracle's log lines and weights
+    from carmel_amd.trainer import TrainOpts, train
+    fb = _fb(w, c)
+    best, trace = train(fb, TrainOpts(max_iter=3))
+    ow, oc = oracle.OracleWfst.from_arrays(w), oracle.OracleCorpus.from_arrays(c)
+    obest, otrace = oracle.train(ow, oc, norm_group=NORM_CONDITIONAL, max_iter=3)
+    assert len(trace) == len(otrace) >= 3
+    for a, b in zip(trace, otrace):
+        assert a["log2_prob"] == pytest.approx(b["log2_prob"], rel=1e-9)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ow.arrays()["logw"]), rtol=1e-6, atol=1e-12)
+    fb.close()
+
+
 def test_big_single_lattice_classes(oracle):
     # long pairs over a tiny alphabet: lattices of thousands of states -> the 256- and 1024-thread classes
     w = synth.random_wfst(6, 5, n_sym=3, p_eps=0.2, seed=21)
