@@ -112,6 +112,29 @@ def pmc_traffic_c5(n_forests):
     return tot
 
 
+CRP_KERNELS = ("gibbs_lane_kernel", "gibbs_lane_recount_kernel", "gibbs_normsum_kernel", "gibbs_commit_kernel", "gibbs_exact_wave_kernel",
+               "gibbs_reg_wave_kernel", "gibbs_recount_tables_kernel")
+
+
+def pmc_traffic_crp(n_blocks):
+    """HBM-side bytes per parallel sweep of `--config crp` from the committed PMC passes (tools/gibbs_profile.sh -> profiles/
+    pmc_traffic_crp.json), FETCH_SIZE doubled as for the EM workloads; None unless the profile is of these sources and this corpus"""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic_crp.json")
+    if not os.path.exists(path) or any(k.startswith("CARMEL_HIP_") for k in os.environ):
+        return None
+    d = json.load(open(path))
+    csrc = os.path.join(ROOT, "carmel_amd", "csrc")
+    sha = hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in ("gibbs_lane.hip", "gibbs_exact.hip", "gibbs.hip"))).hexdigest()[:16]
+    if d.get("blocks") != n_blocks or not d.get("sweep_count") or d.get("gibbs_sha16") != sha:
+        return None
+    tot = 0.0
+    for name, k in d["kernels"].items():
+        if any(e in name for e in CRP_KERNELS) and k["fetch_kb_per_launch"] is not None:
+            tot += k["launches"] / d["sweep_count"] * (2.0 * k["fetch_kb_per_launch"] + (k["write_kb_per_launch"] or 0.0)) * 1024.0
+    return tot
+
+
 def _replicas(value):
     """c3 / c5 / amb as the headline at N > 1: independent replicas, one per GPU (no data-path collective: SURVEY 8e --
     the sampler does not shard exactly, and config 3's model is 758 parameters); the job's value is the sum over the ranks"""
@@ -568,9 +591,9 @@ def run_crp(args, local_rank=0, rank=0, reps_parallel=100, sweeps_parallel=40, s
                                   "through the front end; `exact`: the reference's chain on the 1005 blocks" % (par["blocks"], reps_parallel),
                       "lattice_arcs_per_gpu": par["lattice_arcs"], "lattice_states_per_gpu": par["lattice_states"]},
            "kernel_ms": par["ms_per_step"],
-           "roofline": {"bound": "hbm", "kernel": "one sweep = gibbs_exact_wave_kernel<PAR> (a wavefront per block, two launch classes) + gibbs_recount_tables + gibbs_commit; wall time per sweep "
+           "roofline": {"bound": "hbm", "kernel": "one sweep = gibbs_lane_kernel (64 lattices a wavefront, one per lane; round 6) + gibbs_lane_recount + gibbs_normsum + gibbs_commit; wall time per sweep "
                         "(difference of two runs of the front end: launch gaps included)", "achieved": par["frac"] * HBM_PEAK_GBS,
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": par["frac"], "traffic": None,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": par["frac"], "traffic": pmc_traffic_crp(par["blocks"]),
                         "algorithmic_bytes_per_launch": par["algorithmic_bytes_per_launch"]},
            "exact": {k: ex[k] for k in ("blocks", "sweeps", "ms_per_step", "value", "frac", "lattice_arcs")}}
     out["exact"]["chains64"] = {"runs": 64, "ms_per_chain_sweep": ex64["ms_per_step"], "value": ex64["value"], "unit": "arc-updates/s",
@@ -757,15 +780,18 @@ def compact_line(out):
         if "error" in r:
             sec[name] = {"error": short(r["error"], 80)}
             continue
-        e = {"ms": _r4(r.get("ms_per_step")), "k_ms": _r4(r.get("kernel_ms")), "frac": _r4((r.get("roofline") or {}).get("frac")),
-             "traffic": _r4((r.get("roofline") or {}).get("traffic")), "cpu": _r4((r.get("cpu_baseline") or {}).get("value")),
-             "value": _r4(r.get("value"))}
-        if "parity_checked_pairs" in r:
-            e["parity"] = r["parity_checked_pairs"]
-        if "exact" in r:
+        e = {}
+        if "exact" in r:  # the samplers: the reference's chain (the default mode) first, the stale-count sweep (non-default) after it
             e["exact_ms"] = _r4(r["exact"].get("ms_per_step"))
+            e["exact_value"] = _r4(r["exact"].get("value"))
             if "chains64" in r["exact"]:
                 e["exact_x64"] = _r4(r["exact"]["chains64"].get("aggregate_over_one_chain"))
+            e["parallel_ms"] = _r4(r.get("ms_per_step"))
+        e.update({"ms": _r4(r.get("ms_per_step")), "k_ms": _r4(r.get("kernel_ms")), "frac": _r4((r.get("roofline") or {}).get("frac")),
+                  "traffic": _r4((r.get("roofline") or {}).get("traffic")), "cpu": _r4((r.get("cpu_baseline") or {}).get("value")),
+                  "value": _r4(r.get("value"))})
+        if "parity_checked_pairs" in r:
+            e["parity"] = r["parity_checked_pairs"]
         sec[name] = e
     if sec:
         line["secondary"] = sec

@@ -277,13 +277,15 @@ int carmel_hip_build_lattices(carmel_hip_trainer* t, int prune, int host_threads
   // the host builder lays the lattices out (one-per-wavefront lattices, bundles: the cases the device builder leaves to it);
   // sorting the posterior slots by arc and the transposition tables -- two thirds of its time on the `long` workload, all of it
   // counting sorts -- are the device's (lattice_gpu.hip gpu_tables_for_host_layout; CARMEL_HIP_DEVICE_TABLES=0: the host's, A/B)
-  // one-per-wavefront lattices over a WFST whose weights the chip's caches hold (64 MB of them: the last-level cache is 256 MB)
+  // one-per-wavefront lattices over a WFST whose weights the chip's caches hold (128 MB of them: the last-level cache is 256 MB)
   // gather them from the table (sweep_wave_kernel<.., GW>): no pass writes them out in lattice order -- a fifth of the E-step on
   // the `long` workload.  CARMEL_HIP_WAVE_GATHER=0/1: never / whatever the table's size (A/B; the same sums in the same order)
   {
     const char* e = lib_opt("wave_gather");
     const bool want_t = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0);
-    opt.wave_gather = want_t && (e ? atoi(e) != 0 : t->w.n_arcs * sizeof(double) <= (64ull << 20));
+    // (128 MB since round 6, as for the tile passes: a mixed corpus' long lattices lie on a part of a larger table -- `mix`: 26 MB
+    // of 78 --, and the last-level cache is 256 MB)
+    opt.wave_gather = want_t && (e ? atoi(e) != 0 : t->w.n_arcs * sizeof(double) <= (128ull << 20));
   }
   opt.device_tables = !(lib_opt("transpose") && atoi(lib_opt("transpose")) == 0) &&
                       !(lib_opt("device_tables") && atoi(lib_opt("device_tables")) == 0);

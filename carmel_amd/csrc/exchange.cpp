@@ -39,6 +39,7 @@
 #include <chrono>
 #include <cstring>
 #include "comm.hpp"
+#include "options.hpp"
 
 static const int XCH_MAX_CHUNKS = MSTEP_MAX_RANGES - 1;
 
@@ -72,6 +73,20 @@ struct ExchangePlan {
   uint64_t stride = 0, tail_n = 0;   // staging: peer slot q' (q' = q below rank ? q : q - 1) at stage[q' * stride], its tail at
   DevBuf<double> red, stage, fin;    //   stage[(N - 1) * stride + q' * tail_n]; fin: the ranks' largest weight changes
   std::vector<std::vector<carmel_hip_p2p>> ops_x, ops_g;  // per chunk: counts out / weights in
+  // ---- direct form, TOUCHED arcs only (round 6).  A rank's lattices lie on a part of the arc table -- an eighth of config 4's
+  // corpus touches a quarter of its arcs -- and the rest of its count vector is zero in every iteration.  Which arcs a rank
+  // touches is fixed with its lattices: the ranks tell each other ONCE, at plan time, which arcs of every piece they will send
+  // (index lists), and per iteration a piece whose sender touches less than half of it travels as the VALUES of those arcs
+  // alone, packed.  The owner adds, per arc and in rank order, the values of the ranks that sent one: the sum the dense form
+  // makes, without its zeros -- the same bits (x + 0.0 = x).
+  bool sparse = false;
+  std::vector<uint64_t> s_off;       // per chunk: its first entry in s_idx / s_pack (K + 1)
+  DevBuf<uint32_t> s_idx;            // the arcs this rank sends packed, chunk after chunk, peer after peer
+  DevBuf<double> s_pack;             // their counts, gathered before the chunk's group
+  DevBuf<uint32_t> r_pos;            // per chunk and sender slot: where, in the sender's packed piece, the value of arc
+                                     // ext_lo(k, rank) + i lies (0xffffffff: the sender does not touch it); [K][N - 1][stride]
+  std::vector<uint32_t> r_dense;     // per chunk: bit s = sender slot s sends its piece whole
+  uint64_t bytes_rs_dense = 0;       // what the counts' way out would move without this
   std::vector<carmel_hip_p2p> ops_cg;                     // the reduced count pieces to everybody (exchange_settle)
   uint64_t piece(uint32_t k) const { return (A[k + 1] - A[k]) / N; }
   uint64_t ext_lo(uint32_t k, uint32_t j) const {
@@ -128,6 +143,40 @@ __global__ __launch_bounds__(256) void xchg_sum_kernel(double* __restrict__ out,
     out[i] = v;
   }
 }
+// ... the same sums where some senders sent the values of their touched arcs only: sender slot s of chunk k is dense (bit s of
+// `dense`: its piece lies in its staging slot as above) or packed (pos[s * stride + i] = where arc i's value lies in the slot, or none)
+__global__ __launch_bounds__(256) void xchg_sum_sparse_kernel(double* __restrict__ out, const double* __restrict__ own,
+                                                              const double* __restrict__ stage, const uint32_t* __restrict__ pos, uint64_t n,
+                                                              uint64_t stride, uint32_t N, uint32_t rank, uint32_t dense) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    double v = 0.0;
+    for (uint32_t q = 0; q < N; ++q) {
+      double x;
+      if (q == rank)
+        x = own[i];
+      else {
+        const uint32_t sl = q < rank ? q : q - 1;
+        if ((dense >> sl) & 1u)
+          x = stage[(uint64_t)sl * stride + i];
+        else {
+          const uint32_t p = pos[(uint64_t)sl * stride + i];
+          if (p == 0xffffffffu) continue;  // (the dense form adds this rank's zero here: v + 0.0 = v, and 0.0 if v is none yet)
+          x = stage[(uint64_t)sl * stride + p];
+        }
+      }
+      v = q ? v + x : x;
+    }
+    out[i] = v;
+  }
+}
+__global__ __launch_bounds__(256) void xchg_pack_kernel(double* __restrict__ out, const double* __restrict__ counts, const uint32_t* __restrict__ idx,
+                                                        uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) out[i] = counts[idx[i]];
+}
+// plan time: pos[(uint32_t)rel[j]] = j for the n arcs a sender listed (their places relative to the receiver's extended piece, as doubles)
+__global__ __launch_bounds__(256) void xchg_pos_kernel(uint32_t* __restrict__ pos, const double* __restrict__ rel, uint64_t n) {
+  for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (uint64_t)gridDim.x * 256) pos[(uint32_t)rel[j]] = (uint32_t)j;
+}
 // the largest weight change over the ranks (non-negative doubles order like their bit patterns)
 __global__ void xchg_max_kernel(unsigned long long* bits, const unsigned long long* fin, uint32_t N, uint32_t rank) {
   unsigned long long m = *bits;
@@ -151,10 +200,21 @@ static int direct_counts_chunk(carmel_hip_trainer* t, ExchangePlan* xp, uint32_t
   if (xp->N == 1) return CARMEL_HIP_OK;
   hipStream_t x = xp->comm->xstream;
   const double* counts = t->counts_ptr();
+  if (xp->sparse && xp->s_off[k + 1] > xp->s_off[k]) {  // the touched arcs' counts, packed peer after peer
+    const uint64_t n = xp->s_off[k + 1] - xp->s_off[k];
+    hipLaunchKernelGGL(xchg_pack_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 2048)), dim3(256), 0, x, xp->s_pack.p + xp->s_off[k], counts,
+                       xp->s_idx.p + xp->s_off[k], n);
+    HIPCHK(hipGetLastError());
+  }
   int rc = comm_p2p(xp->comm, xp->ops_x[k].data(), (uint32_t)xp->ops_x[k].size(), x);
   if (rc) return rc;
   const uint64_t lo = xp->ext_lo(k, xp->rank), hi = xp->ext_hi(k, xp->rank);
-  HIPCHK(launch_xchg_sum(xp->red.p + lo, counts + lo, xp->stage.p, hi - lo, xp->stride, xp->N, xp->rank, x));
+  if (xp->sparse) {
+    hipLaunchKernelGGL(xchg_sum_sparse_kernel, dim3((unsigned)std::min<uint64_t>((hi - lo + 255) / 256, 2048)), dim3(256), 0, x, xp->red.p + lo, counts + lo,
+                       xp->stage.p, xp->r_pos.p + (uint64_t)k * (xp->N - 1) * xp->stride, hi - lo, xp->stride, xp->N, xp->rank, xp->r_dense[k]);
+    HIPCHK(hipGetLastError());
+  } else
+    HIPCHK(launch_xchg_sum(xp->red.p + lo, counts + lo, xp->stage.p, hi - lo, xp->stride, xp->N, xp->rank, x));
   if (k + 1 == xp->K) {  // the tail and the scalars: everybody's, summed by everybody
     HIPCHK(launch_xchg_sum(xp->red.p + xp->tail_lo, counts + xp->tail_lo, xp->stage.p + (uint64_t)(xp->N - 1) * xp->stride, xp->tail_n,
                            xp->tail_n, xp->N, xp->rank, x));
@@ -395,6 +455,137 @@ int exchange_maximize(carmel_hip_trainer* t, ExchangePlan* xp, double* max_chang
   return CARMEL_HIP_OK;
 }
 
+// ---- the direct form's counts as touched arcs only (ExchangePlan::sparse); collective ----
+// uses[a] > 0: some item of this rank's lattices lies on arc a -- the count pass over posteriors of 1 (every layout ends in
+// trans_c_bucket reading XC, one entry per item)
+static int arc_uses(carmel_hip_trainer* t, std::vector<double>& uses) {
+  hipStream_t s = t->stream;
+  HIPCHK(hipStreamSynchronize(s));
+  TransArgs T;
+  trans_args(t, T);
+  DevBuf<double> tmp;
+  HIPCHK(tmp.alloc(t->w.n_arcs + 4));
+  HIPCHK(hipMemsetAsync(tmp.p, 0, tmp.bytes(), s));
+  HIPCHK(launch_fill(t->t_xc.p, 1.0, t->t_xc.n, s));
+  T.counts = tmp.p;
+  if (T.n_buckets) HIPCHK(launch_trans_c_bucket_range(T, 0, T.n_buckets, s));
+  uses.resize(t->w.n_arcs);
+  HIPCHK(hipMemcpyAsync(uses.data(), tmp.p, uses.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  return CARMEL_HIP_OK;
+}
+static int plan_sparse(carmel_hip_trainer* t, ExchangePlan* xp) {
+  const uint32_t N = xp->N, K = xp->K, me = xp->rank;
+  carmel_hip_comm* c = xp->comm;
+  hipStream_t x = c->xstream;
+  std::vector<double> uses;
+  int rc = arc_uses(t, uses);
+  if (rc) return rc;
+  // what I would send packed: per chunk and peer, the touched arcs of the peer's extended piece
+  std::vector<std::vector<std::vector<uint32_t>>> mine(K, std::vector<std::vector<uint32_t>>(N));
+  std::vector<double> cnt((size_t)N * K * N, 0.0);  // [sender][chunk][receiver]
+  for (uint32_t k = 0; k < K; ++k)
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me) continue;
+      for (uint64_t a = xp->ext_lo(k, q), hi = xp->ext_hi(k, q); a < hi; ++a)
+        if (uses[a] > 0.0) mine[k][q].push_back((uint32_t)a);
+      cnt[((size_t)me * K + k) * N + q] = (double)mine[k][q].size();
+    }
+  rc = carmel_hip_comm_allreduce_host(c, cnt.data(), (uint32_t)cnt.size(), 0);
+  if (rc) return rc;
+  auto n_of = [&](uint32_t sender, uint32_t k, uint32_t receiver) { return (uint64_t)cnt[((size_t)sender * K + k) * N + receiver]; };
+  auto dense = [&](uint32_t sender, uint32_t k, uint32_t receiver) {  // (both ends decide from the same numbers)
+    return 2 * n_of(sender, k, receiver) > xp->ext_hi(k, receiver) - xp->ext_lo(k, receiver);
+  };
+  // my packed sends, chunk after chunk
+  xp->s_off.assign(K + 1, 0);
+  std::vector<uint32_t> idx;
+  std::vector<std::vector<uint64_t>> off_kq(K, std::vector<uint64_t>(N, 0));
+  for (uint32_t k = 0; k < K; ++k) {
+    xp->s_off[k] = idx.size();
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me || dense(me, k, q)) continue;
+      off_kq[k][q] = idx.size();
+      idx.insert(idx.end(), mine[k][q].begin(), mine[k][q].end());
+    }
+  }
+  xp->s_off[K] = idx.size();
+  if (idx.empty()) idx.push_back(0u);
+  HIPCHK(xp->s_idx.upload(idx, x));
+  HIPCHK(xp->s_pack.alloc(idx.size()));
+  HIPCHK(xp->r_pos.alloc((uint64_t)K * (N - 1) * xp->stride));
+  HIPCHK(hipMemsetAsync(xp->r_pos.p, 0xff, xp->r_pos.bytes(), x));
+  xp->r_dense.assign(K, 0u);
+  // the index lists travel once, as doubles (places relative to the receiver's extended piece), through the same groups
+  for (uint32_t k = 0; k < K; ++k) {
+    std::vector<double> out_rel;
+    std::vector<uint64_t> out_at(N, 0), in_at(N, 0);
+    uint64_t in_total = 0;
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me) continue;
+      if (!dense(me, k, q)) {
+        out_at[q] = out_rel.size();
+        const uint64_t lo = xp->ext_lo(k, q);
+        for (uint32_t a : mine[k][q]) out_rel.push_back((double)(a - lo));
+      }
+      if (dense(q, k, me))
+        xp->r_dense[k] |= 1u << (q < me ? q : q - 1);
+      else {
+        in_at[q] = in_total;
+        in_total += n_of(q, k, me);
+      }
+    }
+    DevBuf<double> d_out, d_in;
+    if (out_rel.empty()) out_rel.push_back(0.0);
+    HIPCHK(d_out.upload(out_rel, x));
+    HIPCHK(d_in.alloc(std::max<uint64_t>(in_total, 1)));
+    std::vector<carmel_hip_p2p> ops;
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me) continue;
+      if (!dense(me, k, q) && n_of(me, k, q)) ops.push_back({(int32_t)q, 1, d_out.p + out_at[q], n_of(me, k, q)});
+      if (!dense(q, k, me) && n_of(q, k, me)) ops.push_back({(int32_t)q, 0, d_in.p + in_at[q], n_of(q, k, me)});
+    }
+    rc = comm_p2p(c, ops.data(), (uint32_t)ops.size(), x);
+    if (rc) return rc;
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me || dense(q, k, me) || !n_of(q, k, me)) continue;
+      const uint32_t sl = q < me ? q : q - 1;
+      const uint64_t n = n_of(q, k, me);
+      hipLaunchKernelGGL(xchg_pos_kernel, dim3((unsigned)std::min<uint64_t>((n + 255) / 256, 1024)), dim3(256), 0, x,
+                         xp->r_pos.p + ((uint64_t)k * (N - 1) + sl) * xp->stride, d_in.p + in_at[q], n);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(x));
+  }
+  // the groups of an iteration: packed pieces where the sender is sparse (ops_x was built dense, in the order send / receive [/
+  // tail send / tail receive] per peer)
+  xp->bytes_rs = 0;
+  for (uint32_t k = 0; k < K; ++k) {
+    size_t o = 0;
+    for (uint32_t q = 0; q < N; ++q) {
+      if (q == me) continue;
+      carmel_hip_p2p& snd = xp->ops_x[k][o];
+      carmel_hip_p2p& rcv = xp->ops_x[k][o + 1];
+      if (!dense(me, k, q)) {
+        snd.dev_buf = xp->s_pack.p + off_kq[k][q];
+        snd.n = n_of(me, k, q);
+      }
+      if (!dense(q, k, me)) rcv.n = n_of(q, k, me);
+      xp->bytes_rs += snd.n * 8;
+      o += 2;
+      if (k + 1 == K) {
+        xp->bytes_rs += xp->tail_n * 8;
+        o += 2;
+      }
+    }
+    // (an empty transfer is no transfer: both ends know)
+    auto& v = xp->ops_x[k];
+    v.erase(std::remove_if(v.begin(), v.end(), [](const carmel_hip_p2p& p) { return p.n == 0; }), v.end());
+  }
+  xp->sparse = true;
+  return CARMEL_HIP_OK;
+}
+
 extern "C" {
 
 int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t n_chunks, int form) {
@@ -504,6 +695,14 @@ int carmel_hip_exchange_plan(carmel_hip_trainer* t, carmel_hip_comm* c, uint32_t
           // the reduced count pieces to everybody, when the whole vector is asked for
           xp->ops_cg.push_back({(int32_t)q, 1, xp->red.p + xp->A[k] + (uint64_t)me * P, P});
           xp->ops_cg.push_back({(int32_t)q, 0, counts + xp->A[k] + (uint64_t)q * P, P});
+        }
+      }
+      xp->bytes_rs_dense = xp->bytes_rs;
+      if (N > 1 && N <= 32 && !lib_opt_off("exchange_sparse")) {
+        int src = plan_sparse(t, xp);
+        if (src) {
+          plan_free(xp);
+          return src;
         }
       }
     }

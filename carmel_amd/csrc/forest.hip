@@ -1098,7 +1098,9 @@ __global__ __launch_bounds__(64) void forest_sample_kernel(ForestArgs A, uint32_
 // a uniform of its own (a shared sub-forest expanded twice chooses twice): the same kind of chain -- the stale-count sweep of
 // forest-em.hpp:750-766 with other random numbers -- validated against the sweep's enumerated stationary distribution
 // (tests/test_bench_workloads_gpu.py) instead of draw for draw.
+#ifndef FM_G
 #define FM_G 8
+#endif
 #define FM_FPW (64 / FM_G)
 struct FMultiArgs {
   const uint16_t* tab;      // per forest, its nodes numbered by height: {n, H, n_kids, -}, lvl_off[H + 1], kid_off[n + 1],
@@ -1130,9 +1132,15 @@ __device__ __forceinline__ uint32_t fm_prefix(uint32_t v, uint32_t li, uint32_t&
   return x - v;
 }
 #define FM_EBIAS 2048
+#if FM_G == 8
 #define FM_TQ 4  // 16-byte pieces of the forest's table per lane in the first round of loads (x FM_G lanes x 8 words)
 #define FM_SC 4  // class words of the previous sample per lane ...
 #define FM_HR 8  // header rows per lane ...
+#else
+#define FM_TQ 8
+#define FM_SC 8
+#define FM_HR 12
+#endif
 #define FM_KP 4  // children of a node whose values the inside pass requests before it folds them
 __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, FMultiArgs M, uint32_t max_sample) {
   extern __shared__ __attribute__((aligned(16))) double fm_lds[];
@@ -2270,7 +2278,9 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
           d[0] = (uint32_t)first;
           d[1] = n | (H << 16);
           d[2] = (uint32_t)so_all[f];
-          d[3] = (uint32_t)(so_all[f] >> 32) | (slow ? 0x10000u : 0u);
+          // (bit 17: a derivation of more than 64 rules -- shared sub-forests count once per use, so 64 NODES can yield more --:
+          // the register path keeps a sample entry per lane and register, such a forest takes two registers whatever its size)
+          d[3] = (uint32_t)(so_all[f] >> 32) | (slow ? 0x10000u : 0u) | (fl.max_deriv > 64 ? 0x20000u : 0u);
         }
         HIPCHK(F->x_desc.upload(xd, s));
         HIPCHK(F->x_rec.upload(xr, s));

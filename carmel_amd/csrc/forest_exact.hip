@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
       if (A.phase_clk) t1 = __builtin_readcyclecounter();
       FX_WAVE_SYNC();
       unsigned long long* tp = A.phase_clk ? &t2 : nullptr;
-      if (n <= 64)
+      if (n <= 64 && !((d.w >> 17) & 1u))
         fx_register_path<1>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);
       else
         fx_register_path<FX_NS>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);

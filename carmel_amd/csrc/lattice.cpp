@@ -1062,7 +1062,16 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
       while (j < nw && out.waves[j].ring == out.waves[i].ring) ms = std::max(ms, out.waves[j++].n_states);
       LatticeSet::WaveClass wc{(uint32_t)i, (uint32_t)(j - i), ms, WAVE_RING_WIDTH};
       wc.ring = out.waves[i].ring;
-      out.wave_classes.push_back(wc);
+      // rings up to 128 values share a launch (a lattice keeps its own ring inside the launch's LDS, WaveDesc::ring: 1 KB of 2.5 at
+      // most): a launch per ring size left `mix`'s one lattice of ring 32 alone in front of its 1985 lattices of ring 16 -- on
+      // streams that shared a hardware queue, 0.3 ms of an empty chip
+      if (!out.wave_classes.empty() && out.wave_classes.back().ring && std::max(out.wave_classes.back().ring, wc.ring) <= 128) {
+        LatticeSet::WaveClass& b = out.wave_classes.back();
+        b.count += wc.count;
+        b.max_states = std::max(b.max_states, wc.max_states);
+        b.ring = std::max(b.ring, wc.ring);
+      } else
+        out.wave_classes.push_back(wc);
       i = j;
     }
     const uint32_t caps[] = {WAVE_MAX_STATES, 8192, 4096, 2048, 1024, 512, 0};

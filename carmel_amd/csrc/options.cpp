@@ -14,7 +14,7 @@ const char* const kKeys[] = {
     // E-step layouts and formulations (engine.cpp, lattice_gpu.hip, host_api.cpp)
     "lane_states", "tile_sweep", "lane_fused", "transpose", "lane_chunks", "lane_window", "lane_window_min", "wave_ring", "wave_min_width",
     "gpu_build", "wave_gather", "wave_xc", "tile_gather", "device_tables", "trans_scatter", "trans_runs", "lane_fused_kernel",
-    "tile_sweep_kernel", "mailbox", "poison", "lane_trace",
+    "tile_sweep_kernel", "mailbox", "poison", "lane_trace", "exchange_sparse",
     // one-tape cascades (engine_unrolled.cpp, unrolled.cpp)
     "dense", "unrolled", "unrolled_ragged",
     // the samplers (gibbs.hip, forest.hip)

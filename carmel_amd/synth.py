@@ -290,11 +290,11 @@ def make_config(name, n_pairs=None, rank=0, walk=None):
     return w, c
 
 
-def random_forests(n_forests, n_rules=500000, mean_nodes=54, p_backref=0.6, group_mean=8, seed=4):
+def random_forests(n_forests, n_rules=500000, mean_nodes=55, p_backref=0.6, group_mean=8, seed=4):
     """packed AND/OR forests as preorder node arrays (label, ref, next), OR fan-out
     2-4, ~20 % of the children of AND nodes are back-references to earlier shared sub-forests, rule ids Zipf over
     n_rules parameters, normalisation groups of mean size group_mean.  Returns (node_off, label, ref, next,
-    n_rules + 1, group_off, group_rule).  mean_nodes = 54 gives 50.4 nodes a forest: 100 000 forests are the 5 * 10^6 nodes
+    n_rules + 1, group_off, group_rule).  mean_nodes = 55 gives 50.6 nodes a forest: 100 000 forests are the 5 * 10^6 nodes
     BASELINE.json's configs[4] names (46, until round 5, gave 4.5 * 10^6)."""
     rng = np.random.default_rng(seed)
     zipf_p = 1.0 / np.arange(1, n_rules + 1)

@@ -141,6 +141,9 @@ def main():
         logs += [float(cnt.sum()), float((cnt * np.arange(len(cnt))).sum())]
     if rank == 0:
         np.save(out, np.concatenate([fb.weights(), logs, [1.0 if (info and info["sharded"]) else 0.0]]))
+        if info:  # what one iteration's exchange moves (carmel_hip_exchange_info), beside the results
+            import json
+            json.dump(info, open(out + ".info.json", "w"))
     fb.close()
     if comm is not None:
         comm.close()

@@ -50,6 +50,13 @@ def main():
                      "forest_hip_sha16": hashlib.sha256(open(os.path.join(csrc, "forest.hip"), "rb").read()).hexdigest()[:16],
                      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config c5 --steps 3 "
                                 "--warmup 1 --no-cpu-baseline --no-secondary --no-exchange-loopback  [tools/pmc_traffic.sh]"})
+    if cfg == "crp":  # the lattice sampler's parallel sweeps (tools/gibbs_profile.sh): one gibbs_commit_kernel launch per sweep
+        commits = [v["launches"] for k, v in kernels.items() if "gibbs_commit_kernel" in k]
+        meta.update({"blocks": 100500, "sweep_count": max(commits) if commits else 0,
+                     "gibbs_sha16": hashlib.sha256(b"".join(open(os.path.join(csrc, f), "rb").read() for f in
+                                                             ("gibbs_lane.hip", "gibbs_exact.hip", "gibbs.hip"))).hexdigest()[:16],
+                     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- carmel --crp --crp-parallel -M 40 on the tagging "
+                                "cascade x 100  [tools/gibbs_profile.sh]"})
     meta["kernels"] = kernels
     print(json.dumps(meta, indent=1))
 

@@ -18,7 +18,7 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if "mstep_max_final" in r["Kernel_Name"]]
 i0 = idx[-2] + 1 if len(idx) > 1 else 0
 t0=int(rows[i0]["Start_Timestamp"])
-for r in rows[i0:i0+16]:
+for r in rows[i0:i0+28]:
     n=r["Kernel_Name"].replace("carmel_hip::","").replace("void ","")[:60]
     print("%-62s q=%s start %8.1f end %8.1f us" % (n, r.get("Queue_Id","?"), (int(r["Start_Timestamp"])-t0)/1e3, (int(r["End_Timestamp"])-t0)/1e3))
 P
