@@ -693,7 +693,7 @@ bool build_lattices(const HostWfst& w, const HostCorpus& c, const BuildOptions& 
     if (L.cyclic)
       cyc.push_back(p);
     else if (opt.lane_states && window_of(L) && L.edges.size() <= LANE_POS_MAX) {
-      if (!plain_lane && n_windowed < opt.wave_lane_threshold && wave_fits(L, opt.wave_lane_min_width))
+      if (!plain_lane && (n_windowed < opt.wave_lane_threshold || L.edges.size() > opt.wave_lane_arcs) && wave_fits(L, opt.wave_lane_min_width))
         wave.push_back(p);
       else
         lane_win.push_back(p);

@@ -277,6 +277,9 @@ struct BuildOptions {
                                    // (narrower ones stay in bundles: 64 of them side by side feed a wave better)
   double wave_lane_min_width = 16.0;    // ... for lattices a WINDOWED lane would take: this wide, and only when the corpus
   uint64_t wave_lane_threshold = 262144;  // has fewer lane-sized lattices than this (4 waves per SIMD of one-per-lane work)
+  uint32_t wave_lane_arcs = 2048;       // ... or the lattice has more arcs than this, however large the corpus: a lane group's time is
+                                        // its longest lane's stream, and a few groups of 8 000-arc lattices beside thousands of
+                                        // 300-arc ones are a tail of a dozen wavefronts the chip waits for (`mix`, round 6: 5.4 ms)
   bool tile_sweep = true;          // lay a corpus of plain lane lattices out for the one-kernel tile sweep (LatticeSet::tile_sweep)
   bool wave_gather = false;        // one-per-wavefront lattices: forward record y = the WFST arc id, not the arc's backward position
                                    // (the sweep gathers its weights from the table; no weight is laid out in lattice order)

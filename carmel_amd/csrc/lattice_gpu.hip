@@ -439,6 +439,7 @@ struct ClassArgs {
   uint64_t n;
   uint32_t use_window, lane_window, lane_states;
   double wave_min_width;  // (BuildOptions::wave_lane_min_width)
+  uint32_t wave_lane_arcs;  // (BuildOptions::wave_lane_arcs)
 };
 // what a pair is: 0 = plain lane, w = windowed lane with a ring of w rows, 0xff = neither (the host builder's business);
 // counts {plain, windowed, other, windowed AND above lane_states AND wide enough for a wavefront of its own}
@@ -452,7 +453,10 @@ __global__ void classify_kernel(ClassArgs C, uint8_t* win, unsigned long long* o
       if (w) {
         k = (uint8_t)w;
         ++v[1];
-        if (S > C.lane_states && C.L[p] > 1 && (double)E >= C.wave_min_width * (double)(C.L[p] - 1)) ++v[3];
+        if (S > C.lane_states && C.L[p] > 1 && (double)E >= C.wave_min_width * (double)(C.L[p] - 1)) {
+          ++v[3];
+          if (E > C.wave_lane_arcs) ++v[2];  // (wide and long: a wavefront of its own whatever the corpus' size -- the host builder's)
+        }
       } else if (S <= C.lane_states)
         ++v[0];
       else {
@@ -1261,6 +1265,7 @@ int gpu_build_lattices(carmel_hip_trainer* t, const BuildOptions& opt, uint8_t* 
     CA.lane_window = opt.lane_window;
     CA.lane_states = opt.lane_states;
     CA.wave_min_width = opt.wave_lane_min_width;
+    CA.wave_lane_arcs = opt.wave ? opt.wave_lane_arcs : 0xffffffffu;
     HIPCHK(hipMemsetAsync(d_stats.p, 0, 64, s));
     hipLaunchKernelGGL(classify_kernel, dim3(1024), dim3(256), 0, s, CA, pp_win.p, d_stats.p);
     HIPCHK(hipMemcpyAsync(hc, d_stats.p, 32, hipMemcpyDeviceToHost, s));

@@ -267,10 +267,11 @@ def make_config(name, n_pairs=None, rank=0, walk=None):
     """(transducer, corpus) of a named synthetic workload; rank r > 0 draws another shard of the same size (other walks over
     the same transducer), walk = (min_arcs, max_arcs) overrides the walk lengths (experiments)"""
     if name in ("mix", "toymix"):
-        # a corpus of all three lattice classes over one transducer (mixed_wfst): 200 000 pairs, 90 / 9 / 1 % by class
+        # a corpus of all three lattice classes over one transducer (mixed_wfst): 500 000 pairs, 90 / 9 / 1 % by class (5 000 long
+        # lattices, as many as `long` has: fewer leave the chip's SIMDs with a wavefront or two each -- 200 000 pairs: 16.5 % against 18 %)
         regions = MIX_REGIONS if name == "mix" else ((300, 1, 6, 16, (3, 12), 0.7), (90, 3, 4, 4, (3, 12), 0.2), (24, 8, 4, 4, (8, 30), 0.1))
         w, layout = mixed_wfst(regions, seed=9)
-        c, _reg = mixed_walk_corpus(w, layout, n_pairs or (200000 if name == "mix" else 400), seed=9 + 7919 * rank)
+        c, _reg = mixed_walk_corpus(w, layout, n_pairs or (500000 if name == "mix" else 400), seed=9 + 7919 * rank)
         return w, c
     if name in CLUSTERED:
         n_states, deg, members, npairs, seed, lo, hi = CLUSTERED[name]

@@ -32,7 +32,7 @@ def main():
         kernels[k] = {"launches": nf or nw, "fetch_kb_per_launch": f / nf if nf else None,
                       "write_kb_per_launch": w / nw if nw else None}
     meta = {"config": cfg, "unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE, raw, per launch)"}
-    pairs = {"c4": 1000000, "c2": 50000, "c4a": 1000000, "long": 5000, "mix": 200000}.get(cfg)
+    pairs = {"c4": 1000000, "c2": 50000, "c4a": 1000000, "long": 5000, "mix": 500000}.get(cfg)
     sweeps = [v["launches"] for k, v in kernels.items() if "sweep_lane_kernel" in k or "sweep_wave_kernel" in k or "tile_sweep_kernel" in k]
     if pairs and sweeps:  # what bench.py's roofline.traffic needs: E-steps profiled, workload size, the command
         meta.update({"pairs_per_gpu": pairs, "estep_count": max(sweeps),
