@@ -8,7 +8,7 @@
 
 namespace carmel_hip {
 namespace {
-// every key the library reads: what it switches is documented where it is read (grep lib_opt("key")) and in DESIGN.md section 7
+// every key the library reads: what it switches is documented where it is read (grep for lib_opt and the key) and in DESIGN.md section 7
 const char* const kKeys[] = {
     "timing",  // phase times of the lattice build / layout and the samplers on stderr (the front ends' CARMEL_TIMING)
     // E-step layouts and formulations (engine.cpp, lattice_gpu.hip, host_api.cpp)
