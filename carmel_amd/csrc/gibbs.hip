@@ -1539,7 +1539,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
           LA.recB = (const uint4*)g->gl_recB.p;
           LA.arc_id = g->gl_arc.p;
           LA.sw = (double2*)g->gl_sw.p;
-          LA.tot = g->gl_sw.p + 2 * (g->gl_sw.n / 3);
+          LA.wq = g->gl_sw.p + 2 * (g->gl_sw.n / 3);
           LA.samp_old = (const uint4*)g->gl_samp[g->gl_cur].p;
           LA.samp_new = (uint4*)g->gl_samp[g->gl_cur ^ 1].p;
           LA.p_x = g->snap_x.p;

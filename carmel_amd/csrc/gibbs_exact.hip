@@ -267,6 +267,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     for (uint32_t s = lane; s <= B.n_states; s += 64) ooff[s] = A.out_off[B.off_base + s];
     const uint32_t n_levels = B.n_levels & 0x7fffffffu;  // (bit 31: the lattice is a trellis)
     for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
+    // the first arc of every level, two registers a lane (round 6): a level's arc range is a v_readlane away instead of two
+    // dependent LDS reads (level -> its first state -> that state's first arc); lattices of more levels keep the reads
+    const bool lev_regs = n_levels < 128u;
+    uint32_t lev_r[2] = {0u, 0u};
+    if (lev_regs) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) lev_r[j] = (uint32_t)j * 64u + lane <= n_levels ? A.lev_arc[B.level_base + (uint32_t)j * 64u + lane] : B.n_arcs;
+    }
     // the next block's previous sample sets out now
     GxOld On;
     gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
@@ -292,6 +300,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         be[B.fin] = ext ? 1 : 0;
       }
       GX_WAVE_SYNC();
+      if (lev_regs && !ext) {
+        // a level's first 64 arcs (their ends and weights) are requested a level ahead, before this level's terms wait for
+        // their destinations' values: what is left between two syncs is value -> product -> add
+#define GX_LEV(l) ((l) < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lev_r[0], (int)(l)) : (uint32_t)__builtin_amdgcn_readlane((int)lev_r[1], (int)((l) - 64u)))
+        uint32_t a_hi = B.n_arcs;
+        uint32_t pd = 0;
+        double pg = 0.0;
+        if (n_levels) {
+          const uint32_t a0 = GX_LEV(n_levels - 1);
+          if (a0 + lane < a_hi) {
+            pd = ds[a0 + lane];
+            pg = gw[a0 + lane];
+          }
+        }
+        for (uint32_t l = n_levels; l-- > 0;) {
+          const uint32_t a_lo = GX_LEV(l);
+          const uint32_t n_lo = l ? GX_LEV(l - 1) : a_lo;  // the next level's arcs: [n_lo, a_lo)
+          uint32_t nd = 0;
+          double ng = 0.0;
+          if (n_lo + lane < a_lo) {
+            nd = ds[n_lo + lane];
+            ng = gw[n_lo + lane];
+          }
+          if (a_lo != a_hi) {
+            if (a_lo + lane < a_hi) {
+              const double term = pg * bv[pd & 0xffffu];
+              sh[a_lo + lane] = term;
+              if (term != 0.0) gx_lds_add(&bv[pd >> 16], term);
+            }
+            for (uint32_t a = a_lo + 64 + lane; a < a_hi; a += 64) {  // (a level of more than 64 arcs)
+              const uint32_t d = ds[a];
+              const double term = gw[a] * bv[d & 0xffffu];
+              sh[a] = term;
+              if (term != 0.0) gx_lds_add(&bv[d >> 16], term);
+            }
+            GX_WAVE_SYNC();
+          }
+          pd = nd;
+          pg = ng;
+          a_hi = a_lo;
+        }
+#undef GX_LEV
+      } else {
       uint32_t a_hi = ooff[lvl[n_levels]];
       uint32_t s_next = n_levels ? lvl[n_levels - 1] : 0u;
       for (uint32_t l = n_levels; l-- > 0;) {
@@ -332,6 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         }
         a_hi = a_lo;
       }
+      }
       const double root = bv[B.start];
       if (ext || (root >= 1e-250 && root <= 1e250)) break;
       ext = true;  // plain doubles ran out: once more with exponents
@@ -353,22 +405,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         uint32_t pick = a0;
         if (a1 > a0) {
           double choice = gibbs_uniform(A.seed, A.iter, b, A.state_lev[B.off_base + s]) * tot[s];
-          for (uint32_t a = a1; a-- > a0;) {  // list order: newest first
-            choice -= sh[a];
-            pick = a;
-            if (choice < 0) break;
+          bool done = false;
+          for (uint32_t top = a1; top > a0 && !done; top -= min(4u, top - a0)) {  // list order: newest first, four shares a round
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = top >= a0 + 1u + (uint32_t)i ? sh[top - 1u - (uint32_t)i] : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (!done && top >= a0 + 1u + (uint32_t)i) {
+                choice -= v[i];
+                pick = top - 1u - (uint32_t)i;
+                done = choice < 0;
+              }
           }
         }
-        be[s] = (int)pick;
-        emx[s] = a1 > a0 ? (int)(ds[pick] & 0xffffu) : (int)B.fin;
+        // (the chosen arc and its destination in one word: a step of the path below is one LDS read)
+        be[s] = (int)(pick | ((a1 > a0 ? (ds[pick] & 0xffffu) : B.fin) << 16));
       }
       GX_WAVE_SYNC();
       uint32_t s = B.start, n_path = 0;
       while (s != B.fin && n_path < CM) {
-        const uint32_t a = (uint32_t)be[s];
-        if (lane == 0) idn[n_path] = a;  // (the path's arcs; their parameters are gathered below, side by side)
+        const uint32_t wd = (uint32_t)be[s];
+        if (lane == 0) idn[n_path] = wd & 0xffffu;  // (the path's arcs; their parameters are gathered below, side by side)
         ++n_path;
-        s = (uint32_t)emx[s];
+        s = wd >> 16;
       }
       GX_WAVE_SYNC();
       for (uint32_t base = 0; base < n_path; base += 64) {

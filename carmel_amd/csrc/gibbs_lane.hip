@@ -90,12 +90,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
   const uint4* __restrict__ pa = A.recA + g.rec_base + lane;
   const uint4* __restrict__ pb = A.recB + g.rec_base + lane;
   double2* __restrict__ psw = A.sw + g.rec_base + lane;
-  double* __restrict__ ptt = A.tot + g.rec_base + lane;
+  double* __restrict__ pwq = A.wq + g.rec_base + lane;
   const double wt = L.wt;
   double acc = 0.0, mx = 0.0;
   int e_next = 0;
   uint32_t par = 0;   // the window the arcs READ (the next level's); they write the other
-  uint32_t fr_cur = 0;  // the first row of the state being summed
   uint4 ra[GL_R][GL_CH], rb[GL_R][GL_CH];
   double gx0[2][GL_CH], gs0[2][GL_CH], gx1[2][GL_CH], gs1[2][GL_CH], gin[2][GL_CH];
 #define GL_LOAD(c, S)                                                    \
@@ -126,17 +125,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const double x1_ = (c_ & GL_HAS1) ? gx1[T][q] : 1.0, s1_ = ((c_ & GL_HAS1) && !(c_ & GL_FIX1)) ? gs1[T][q] : 1.0; \
     const double a0 = x0_ - (double)(l0 == 0xffffu ? 0u : u0) * wt, d0 = s0_ - (double)(n0 == 0xffffu ? 0u : m0) * wt; \
     const double a1 = x1_ - (double)(l1 == 0xffffu ? 0u : u1) * wt, d1 = s1_ - (double)(n1 == 0xffffu ? 0u : m1) * wt; \
-    const double wgt = (a0 / d0) * (a1 / d1);                                                          \
+    const double wgt = (a0 * a1) / (d0 * d1); /* (one division: ~30 of a row's ~200 instructions) */   \
     const double gw = INIT ? exp(gin[T][q]) : wgt;                                                     \
     const double term = (c_ & GL_VALID) ? gw * ldexp(bnext, -e_next) : 0.0;                            \
     acc += term;                                                                                       \
-    psw[(size_t)((c) * GL_CH + q) * 64] = make_double2(term, wgt);                                     \
+    /* (a state's total rides with its LAST row's share: known there, and written with the row's own coalesced store) */ \
+    psw[(size_t)((c) * GL_CH + q) * 64] = make_double2(term, (c_ & GL_STATE_LAST) ? acc : 0.0);        \
+    pwq[(size_t)((c) * GL_CH + q) * 64] = wgt;                                                         \
     if (c_ & GL_STATE_LAST) {                                                                          \
       win[((size_t)(par ^ 1u) * W + GL_SRC(c_)) * 64 + lane] = acc;                                    \
-      ptt[(size_t)fr_cur * 64] = acc;                                                                  \
       mx = fmax(mx, acc);                                                                              \
       acc = 0.0;                                                                                       \
-      fr_cur = (c) * GL_CH + q + 1;                                                                    \
     }                                                                                                  \
     if (c_ & GL_LEVEL_LAST) {                                                                          \
       int t_;                                                                                          \
@@ -170,52 +169,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef GL_COMPUTE
   unsigned long long t2 = A.phase_clk ? __builtin_readcyclecounter() : 0;
   // ---- the walk (derivations.h:361-374; random.ipp:111-127): a state per level.  One round of loads per step: the state's
-  // total (written by the sweep at its first row) and its first four rows -- shares, weights, records --; further rows only while
-  // some lane's choice is still above zero ----
+  // first four rows -- shares and records -- and its last row, whose entry carries the state's total (four rows or fewer: the
+  // same line again); further rows only while some lane's choice is still above zero.  What the path needs of the chosen arc
+  // beyond its destination -- its weight, its parameters -- is requested when the arc is chosen and written down a step later,
+  // behind the next step's round ----
   const double2* __restrict__ rsw = A.sw + g.rec_base + lane;
-  const double* __restrict__ rtt = A.tot + g.rec_base + lane;
+  const double* __restrict__ rwq = A.wq + g.rec_base + lane;
   uint4* __restrict__ sn = A.samp_new + 2 * (g.samp_base + lane);
   GlProd cheap{1.0, 0};
   uint32_t cur = active ? L.start : 0u, pos = 0;
-  for (uint32_t k = 0; k < g.path; ++k) {
+  bool pend = false;  // the previous step's arc is still to be written down
+  uint32_t prow = 0;
+  double pw = 1.0;
+  uint4 pb4 = make_uint4(0, 0, 0, 0), pa4 = make_uint4(0, 0, 0, 0);
+  for (uint32_t k = 0; k <= g.path; ++k) {
     const bool on = k < path;
     const uint32_t fr = cur >> 8, deg = on ? (cur & 0xffu) : 0u;
     const uint32_t lastr = fr + (deg ? deg - 1u : 0u);
     const double u = gibbs_uniform(A.seed, A.iter, L.block, k);
-    const double tot = rtt[(size_t)fr * 64];
     double2 s4[4];
-    uint4 b4[4], a4[4];
+    uint4 b4[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t r = min(fr + (uint32_t)j, lastr);
       s4[j] = rsw[(size_t)r * 64];
       b4[j] = pb[(size_t)r * 64];
-      a4[j] = pa[(size_t)r * 64];
+    }
+    const double tot = rsw[(size_t)lastr * 64].y;
+    if (pend) {
+      sn[(size_t)(k - 1) * 128] = make_uint4(prow, pb4.y, pb4.z, pos);
+      sn[(size_t)(k - 1) * 128 + 1] = pa4;  // (the chosen arc's parameters and norm groups: what the recount adds up)
+      pos += GL_NPAR(pb4.x);
+      cheap.mul(pw);
     }
     double choice = u * tot;
     bool done = deg == 0;
     uint32_t pick = 0;
-    uint4 pb4 = make_uint4(0, 0, 0, 0), pa4 = make_uint4(0, 0, 0, 0);
-    double pw = 1.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (!done && (uint32_t)j < deg) {
         choice -= s4[j].x;
         pick = (uint32_t)j;
         pb4 = b4[j];
-        pa4 = a4[j];
-        pw = s4[j].y;
         done = choice < 0;
       }
     for (uint32_t c = 4; __any(!done && c < deg); c += 4) {
       double2 sx[4];
-      uint4 bx[4], ax[4];
+      uint4 bx[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t r = min(fr + c + (uint32_t)j, lastr);
         sx[j] = rsw[(size_t)r * 64];
         bx[j] = pb[(size_t)r * 64];
-        ax[j] = pa[(size_t)r * 64];
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -223,18 +228,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
           choice -= sx[j].x;
           pick = c + j;
           pb4 = bx[j];
-          pa4 = ax[j];
-          pw = sx[j].y;
           done = choice < 0;
         }
     }
-    if (on && deg) {
-      sn[(size_t)k * 128] = make_uint4(fr + pick, pb4.y, pb4.z, pos);
-      sn[(size_t)k * 128 + 1] = pa4;  // (the chosen arc's parameters and norm groups: what the recount adds up)
-      pos += GL_NPAR(pb4.x);
-      cheap.mul(pw);
-      cur = pb4.w;
-    }
+    pend = on && deg;
+    prow = fr + pick;
+    pw = rwq[(size_t)prow * 64];
+    pa4 = pa[(size_t)prow * 64];
+    if (pend) cur = pb4.w;
   }
   double cl = cheap.ln();
   for (int o = 32; o > 0; o >>= 1) cl += __shfl_down(cl, o, 64);

@@ -68,8 +68,8 @@ struct GlArgs {
   const uint4* recB;       // {ctrl, local parameter 0 | 1 << 16, local norm group 0 | 1 << 16 (0xffff: nothing to correct), the
                            //  destination's first row << 8 | its out-degree}
   const uint32_t* arc_id;  // the composed arc (read on the sweeps that sample from --init-em weights only)
-  double2* sw;             // scratch per row: {the arc's share of its state's total, its proposal weight}
-  double* tot;             // ... and at a state's first row: the state's total
+  double2* sw;             // scratch per row: {the arc's share of its state's total; at a state's LAST row: that total}
+  double* wq;              // ... and the arc's proposal weight (read for the chosen arcs only)
   const uint4* samp_old;   // the previous sweep's paths: {row, recB.y, recB.z, place of its first parameter in the block's sample}
   uint4* samp_new;
   const double* p_x;       // the snapshot the sweep samples against

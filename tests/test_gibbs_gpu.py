@@ -493,6 +493,50 @@ def test_parallel_sweep_one_block_per_lane_is_the_wavefront_kernels_sweep(oracle
     np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)
 
 
+def random_tagger(seed):
+    """a random tagger in the tutorial's shape (tagging.fsa / tagging.fst): a tag-bigram acceptor whose arcs write the tag, a
+    one-state lexicon tag:word with 1-4 tags a word, sentences of 1-14 words -- trellis lattices of varied width and degree"""
+    rng = np.random.default_rng(9000 + seed)
+    T, V = int(rng.integers(2, 9)), int(rng.integers(3, 25))
+    tags, words = ["T%d" % i for i in range(T)], ["w%d" % i for i in range(V)]
+    fsa = ["F"] + ['(0 (%s *e* "%s" 1))' % (t, t) for t in tags]
+    for t in tags:
+        fsa.append("(%s (F *e* *e* 1))" % t)
+        fsa += ['(%s (%s *e* "%s" 1))' % (t, u, u) for u in tags]
+    fst = ["0"]
+    for w_ in words:
+        for t in rng.choice(T, size=int(rng.integers(1, min(T, 4) + 1)), replace=False):
+            fst.append('(0 (0 "%s" "%s" 1))' % (tags[int(t)], w_))
+    lines = []
+    for _ in range(int(rng.integers(20, 260))):
+        lines += ["", " ".join('"%s"' % words[int(k)] for k in rng.integers(0, V, size=int(rng.integers(1, 15))))]
+    return "\n".join(fsa) + "\n", "\n".join(fst) + "\n", "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_parallel_sweep_lane_layout_on_random_taggers(oracle, hipopt, seed):
+    """the lane sampler against the wavefront kernels (gibbs_lane = 0) on random taggers: levels of one to eight states, states of
+    one to eight arcs (more than the four a walk's first round of loads holds), sentences of one word, partial groups, with and
+    without --include-self, per-pair weights -- the same paths, sweep probabilities and weights"""
+    from carmel_amd.trainer import HipGibbs
+    fsa, fst, data = random_tagger(seed)
+    res = {}
+    kw = dict(include_self=True) if seed % 3 == 2 else {}
+    for which in ("lane", "wave"):
+        hipopt.set("gibbs_lane", None if which == "lane" else "0")
+        oc, ocorp, fb = _setup(oracle, [fsa, fst], data, [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.3, 0.2])
+        gs = HipGibbs(fb, 7, burnin=2, seed=40 + seed, mode=1, **kw)
+        lp = gs.run()
+        res[which] = (np.array(lp), gs.iter_cheap_logprob.copy(), [gs.sample(b) for b in range(gs.n_blocks)], fb.weights().copy())
+        gs.close()
+        fb.close()
+    a, b = res["lane"], res["wave"]
+    assert a[2] == b[2]
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-10)
+    np.testing.assert_allclose(a[1], b[1], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)
+
+
 def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, hipopt):
     """gibbs_exact.hip's single-wavefront kernel (linear domain, static arc records, DPP choice) and gibbs.hip's workgroup
     kernel (log domain; CARMEL_HIP_GIBBS_WORKGROUP=1) are two implementations of the reference's chain: the same samples,

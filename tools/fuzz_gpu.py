@@ -78,6 +78,7 @@ def main():
         ("cli one-tape cascades", lambda d, s: C.test_random_one_tape_cascades(d, s)),
         ("gibbs exact chain", lambda d, s: G.test_gibbs_exact_chain_on_random_cascades(oracle, s)),
         ("gibbs prior inference", lambda d, s: G.test_gibbs_prior_scale_inference_follows_the_oracle(oracle, s)),
+        ("gibbs lane sampler", lambda d, s, mp=None: G.test_parallel_sweep_lane_layout_on_random_taggers(oracle, mp, s)),
         ("estep random shapes", lambda d, s: P.test_estep_random_shapes(oracle, 2 + s % 100000)),
         ("windowed lane groups", lambda d, s, mp=None: P.test_windowed_lane_groups(oracle, mp, s, [8, 16, 32, 64][s % 4])),
         ("compose on the device", lambda d, s: K.test_random_transducers(oracle, d, s, ["32", "2"][s % 2])),
