@@ -803,6 +803,7 @@ int mstep_args(carmel_hip_trainer* t, int use_counts, int save_old, MstepArgs& M
   if (t->max_partial.n != MSTEP_PARTIALS + t->big_groups.n) {
     HIPCHK(t->max_partial.alloc(MSTEP_PARTIALS + t->big_groups.n));
     HIPCHK(hipMemsetAsync(t->max_partial.p, 0, t->max_partial.bytes(), s));  // once: mstep_max_final_kernel clears what it reads
+    t->mstep_stream_work = true;  // (an M-step launched on another stream must wait for this: exchange.cpp, the direct form)
   }
   M.max_partial = t->max_partial.p;
   M.gscale = t->gscale.p;

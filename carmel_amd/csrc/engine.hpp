@@ -186,6 +186,8 @@ struct carmel_hip_trainer {
   uint64_t lattice_epoch = 0;
   bool use_transpose = false;
   bool em_valid = false;  // em_logw holds the plain EM update of the last (over-relaxed) maximize
+  bool mstep_stream_work = false;  // mstep_args left work on the trainer's stream (scratch re-allocated and cleared after a new
+                                   // set_norm / set_prior) that an M-step on another stream has not yet waited for
   DevBuf<uint32_t> lane_bwd;  // destination | flags words only
   DevBuf<uint32_t> lane_fwdx; // source | backward position | flags words only (transposition path)
   DevBuf<uint32_t> lane_pair, lane_nstates;

@@ -2963,6 +2963,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             MA.prob = F->mt_prob.p;
             class_nodes = fold_proposal;
             const uint32_t nwg = (MA.lane_hi - MA.lane_lo + FM_FPW - 1) / FM_FPW;
+            if (iter == 0 && lib_opt("timing"))
+              fprintf(stderr, "timing: forest sweep class %zu: %u wavefronts of %d forests, nodes <= %u, table <= %u words, frontier <= %u: %zu bytes of LDS a wavefront\n",
+                      ci, nwg, (int)FM_FPW, c.m_n, c.m_tab, c.m_front, fm_per * FM_FPW);
             hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, class_stream(F, s, ci), A, MA, F->max_sample);
           } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || force_gcol) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
