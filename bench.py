@@ -527,7 +527,7 @@ def run_amb(args, steps, warmup, local_rank=0, rank=0):
            "kernel_ms": k_ms,
            "roofline": {"bound": "hbm", "kernel": "E-step (weights to lattice order, lane / wave / bundle sweeps, posteriors to counts), HIP "
                         "events on the trainer's stream", "achieved": alg / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg,
+                        "frac": alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("amb", None, 1005 * reps), "algorithmic_bytes_per_launch": alg,
                         "kernel_ms": k_ms}}
     if not args.no_cpu_baseline and rank == 0:
         # the trace of the reference itself: 25.9-26.5 s per iteration on this cascade (commands.trace:5868-5889,

@@ -11,6 +11,7 @@ for c in c4 c4a c2 long mix; do
   bash tools/pmc_traffic.sh $c > /dev/null 2>&1
   cp gpurun_out/pmc_$c/summary.json gpurun_out/pmc_traffic_$c.json
 done
+bash tools/amb_traffic.sh > /dev/null 2>&1
 bash tools/gibbs_profile.sh $TAG > gpurun_out/${TAG}_gibbs_profile.txt 2>&1
 cp gpurun_out/${TAG}_pmc_traffic_crp.json gpurun_out/pmc_traffic_crp.json
 cp gpurun_out/${TAG}_pmc_traffic_c5.json gpurun_out/pmc_traffic_c5.json

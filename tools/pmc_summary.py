@@ -32,12 +32,15 @@ def main():
         kernels[k] = {"launches": nf or nw, "fetch_kb_per_launch": f / nf if nf else None,
                       "write_kb_per_launch": w / nw if nw else None}
     meta = {"config": cfg, "unit": "KB (rocprofv3 FETCH_SIZE / WRITE_SIZE, raw, per launch)"}
-    pairs = {"c4": 1000000, "c2": 50000, "c4a": 1000000, "long": 5000, "mix": 500000}.get(cfg)
+    pairs = {"c4": 1000000, "c2": 50000, "c4a": 1000000, "long": 5000, "mix": 500000, "amb": 402000}.get(cfg)
     sweeps = [v["launches"] for k, v in kernels.items() if "sweep_lane_kernel" in k or "sweep_wave_kernel" in k or "tile_sweep_kernel" in k]
     if pairs and sweeps:  # what bench.py's roofline.traffic needs: E-steps profiled, workload size, the command
         meta.update({"pairs_per_gpu": pairs, "estep_count": max(sweeps),
                      "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 bench.py --config %s "
                                 "--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-exchange-loopback  [tools/pmc_traffic.sh]" % cfg})
+    if cfg == "amb":
+        meta["command"] = ("rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- carmel --train-cascade -HJ -M 5 on the tagging cascade, corpus x 400 "
+                           "[tools/amb_traffic.sh]")
     # which build of the kernels these counters belong to: bench.py reports them only for the same sources
     import hashlib
     import os
