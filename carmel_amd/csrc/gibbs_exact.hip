@@ -204,6 +204,61 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         }
       GX_WAVE_SYNC();
     }
+    // the first arc of every level, two registers a lane (round 6): a level's arc range is a v_readlane away instead of two
+    // dependent LDS reads (level -> its first state -> that state's first arc); lattices of more levels keep the reads
+    const bool lev_regs = (B.n_levels & 0x7fffffffu) < 128u;
+    uint32_t lev_r[2] = {0u, 0u};
+    if (lev_regs) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)  // (past the last level: the entry behind it, the lattice's arc count)
+        lev_r[j] = A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane, B.n_levels & 0x7fffffffu)];
+    }
+    // the chain's usual block (round 6): at most 256 arcs, 320 states, 190 levels -- every record, offset and level entry is
+    // requested at once, then every count: two round trips for the block instead of two per 64 arcs and one per table
+    const bool staged = !PAR && !A.init_logw && B.n_arcs <= 256u && B.n_states < 320u && (B.n_levels & 0x7fffffffu) < 192u;
+    if (staged) {
+      uint4 r4[4];
+      uint2 n4[4];
+      uint32_t oo[5], ll[3];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a = (uint32_t)q * 64u + lane, at = a < B.n_arcs ? a : 0u;
+        r4[q] = rec[at];
+        n4[q] = nrm[at];
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) oo[j] = A.out_off[B.off_base + min((uint32_t)j * 64u + lane, B.n_states)];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) ll[j] = A.level_off[B.level_base + min((uint32_t)j * 64u + lane, B.n_levels & 0x7fffffffu)];
+      double x0[4], s0[4], x1[4], s1[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const bool h0 = r4[q].z != GX_NONE, h1 = r4[q].w != GX_NONE, f0 = n4[q].x == GX_NONE, f1 = n4[q].y == GX_NONE;
+        x0[q] = gx_ld((f0 ? A.p_prior : (const double*)A.p_x) + (h0 ? r4[q].z : 0u));
+        s0[q] = gx_ld(A.normsum + ((h0 && !f0) ? n4[q].x : 0u));
+        x1[q] = gx_ld((f1 ? A.p_prior : (const double*)A.p_x) + (h1 ? r4[q].w : 0u));
+        s1[q] = gx_ld(A.normsum + ((h1 && !f1) ? n4[q].y : 0u));
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+        if ((uint32_t)j * 64u + lane <= B.n_states) ooff[(uint32_t)j * 64u + lane] = oo[j];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if ((uint32_t)j * 64u + lane <= (B.n_levels & 0x7fffffffu)) lvl[(uint32_t)j * 64u + lane] = ll[j];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a = (uint32_t)q * 64u + lane;
+        if (a < B.n_arcs) {
+          const bool h0 = r4[q].z != GX_NONE, h1 = r4[q].w != GX_NONE, f0 = n4[q].x == GX_NONE, f1 = n4[q].y == GX_NONE;
+          const double w = ((h0 ? x0[q] : 1.0) / ((h0 && !f0) ? s0[q] : 1.0)) * ((h1 ? x1[q] : 1.0) / ((h1 && !f1) ? s1[q] : 1.0));
+          pc[a] = w;
+          gw[a] = w;
+          ds[a] = r4[q].x;
+          par0[a] = r4[q].z;
+          par1[a] = r4[q].w;
+        }
+      }
+    } else
     for (uint32_t a0_ = 0; a0_ < B.n_arcs; a0_ += 64) {
       const uint32_t a = a0_ + lane;
       const bool have = a < B.n_arcs;
@@ -264,17 +319,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
       par0[a] = r.z;
       par1[a] = r.w;
     }
-    for (uint32_t s = lane; s <= B.n_states; s += 64) ooff[s] = A.out_off[B.off_base + s];
+    if (!staged)
+      for (uint32_t s = lane; s <= B.n_states; s += 64) ooff[s] = A.out_off[B.off_base + s];
     const uint32_t n_levels = B.n_levels & 0x7fffffffu;  // (bit 31: the lattice is a trellis)
-    for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
-    // the first arc of every level, two registers a lane (round 6): a level's arc range is a v_readlane away instead of two
-    // dependent LDS reads (level -> its first state -> that state's first arc); lattices of more levels keep the reads
-    const bool lev_regs = n_levels < 128u;
-    uint32_t lev_r[2] = {0u, 0u};
-    if (lev_regs) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) lev_r[j] = (uint32_t)j * 64u + lane <= n_levels ? A.lev_arc[B.level_base + (uint32_t)j * 64u + lane] : B.n_arcs;
-    }
+    if (!staged)
+      for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
     // the next block's previous sample sets out now
     GxOld On;
     gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
