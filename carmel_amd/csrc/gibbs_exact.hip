@@ -28,7 +28,8 @@ namespace carmel_hip {
 #define GX_SQ 2  // entries of a block's previous sample per lane that travel in registers
 #define GX_WAVE_SYNC()                                   \
   do {                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0): as the builtin, so that the compiler's own wait counts know of it */ \
+    asm volatile("" ::: "memory");                       \
     __builtin_amdgcn_wave_barrier();                     \
   } while (0)
 
@@ -111,6 +112,38 @@ __device__ __forceinline__ void gx_take_out(const GxArgs& A, const GxBlock& B, u
   }
 }
 
+// what a block's sweep needs that no sweep changes -- arc records, offsets, levels -- for a block of the chain's usual size (at
+// most 256 arcs, 320 states, 192 levels; every index clamped into the block, so the loads are unconditional): the exact chain
+// requests the NEXT block's while this block's sweep runs
+struct GxStatic {
+  uint4 r4[4];
+  uint2 n4[4];
+  uint32_t oo[5], ll[3], sl[5], lev[2], levn[2];  // (levn: the entry after lev's, for the levels' widths)
+};
+__device__ __forceinline__ void gx_request_static(const GxArgs& A, const GxBlock& B, uint32_t lane, GxStatic& S) {
+  const uint4* __restrict__ rec = A.arc_rec + B.out_base;
+  const uint2* __restrict__ nrm = A.arc_nrm + B.out_base;
+  const uint32_t nl = B.n_levels & 0x7fffffffu;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t a = (uint32_t)q * 64u + lane, at = a < B.n_arcs ? a : 0u;
+    S.r4[q] = rec[at];
+    S.n4[q] = nrm[at];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    S.oo[j] = A.out_off[B.off_base + min((uint32_t)j * 64u + lane, B.n_states)];
+    S.sl[j] = A.state_lev[B.off_base + min((uint32_t)j * 64u + lane, B.n_states)];
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) S.ll[j] = A.level_off[B.level_base + min((uint32_t)j * 64u + lane, nl)];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    S.lev[j] = A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane, nl)];
+    S.levn[j] = A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane + 1u, nl)];
+  }
+}
+
 // PAR = false: the reference's chain, one wavefront, blocks in order, live counts.
 // PAR = true:  the stale-count parallel sweep (never the default): every wavefront of the grid takes blocks
 //              blockIdx, blockIdx + gridDim, ... against the counts of the PREVIOUS sweep (A.p_x / A.normsum point at the
@@ -158,6 +191,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
   uint32_t* idn = ids + CM;
   uint32_t* own_k = idn + CM;  // PAR: the block's previous sample as {parameter -> uses} and {norm group -> uses}
   uint32_t* own_c = own_k + 2 * GX_OWN;
+  // (round 6) the arcs' norm groups, the states' levels and the path's norm groups beside its parameters: what the walk and the
+  // count update used to fetch from global memory -- a dependent round trip each -- in the middle of the block
+  uint32_t* nr0 = own_c + 2 * GX_OWN;
+  uint32_t* nr1 = nr0 + CA;
+  uint32_t* slv = nr1 + CA;
+  uint32_t* idm = slv + CS;
   const uint32_t lane = threadIdx.x;
   const uint32_t nb = A.n_blocks;
   GxProd cheap{1.0, 0}, cnum{1.0, 0}, cden{1.0, 0}, after{1.0, 0};
@@ -170,11 +209,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
   GxOld O;
   gx_request_old(A, B, GX_BLOCK_ID(b0), lane, O);
   if (!PAR && !A.want_after) gx_take_out(A, B, lane, O);
+  GxStatic S;
+  if (!PAR) gx_request_static(A, B, lane, S);
+  // the cache model's factors of the last block's sample (what its adds returned): multiplied in a block late, when the wait
+  // for them is the wait the chain's order asks for anyway
+  double pend_c = 1.0, pend_s = 1.0;
   uint32_t n_prev = 0;
   for (uint32_t bi = b0; bi < nb; bi += stride) {
     const uint32_t b = GX_BLOCK_ID(bi);  // the block's number in the corpus: what its uniforms and its sample are keyed by
     unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
-    if (!PAR) gx_order();  // the counts are as the chain has them
+    if (!PAR) {
+      gx_order();  // the counts are as the chain has them
+      cnum.mul(pend_c);
+      cden.mul(pend_s);
+      pend_c = pend_s = 1.0;
+    }
     if (!PAR && A.want_after) {
       // the previous block's sample scored with itself counted (the "overestimate" of gibbs.hpp:866), then this block's
       // previous sample leaves the counts
@@ -208,28 +257,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     // dependent LDS reads (level -> its first state -> that state's first arc); lattices of more levels keep the reads
     const bool lev_regs = (B.n_levels & 0x7fffffffu) < 128u;
     uint32_t lev_r[2] = {0u, 0u};
-    if (lev_regs) {
+    bool lev_wide = false;  // some level has more than 64 arcs
+    if (!PAR) {
+      lev_r[0] = S.lev[0];
+      lev_r[1] = S.lev[1];
+      lev_wide = __builtin_amdgcn_ballot_w64(S.levn[0] - S.lev[0] > 64u || S.levn[1] - S.lev[1] > 64u) != 0;
+    } else if (lev_regs) {
+      bool w = false;
 #pragma unroll
-      for (int j = 0; j < 2; ++j)  // (past the last level: the entry behind it, the lattice's arc count)
-        lev_r[j] = A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane, B.n_levels & 0x7fffffffu)];
+      for (int j = 0; j < 2; ++j) {  // (past the last level: the entry behind it, the lattice's arc count)
+        const uint32_t nl = B.n_levels & 0x7fffffffu;
+        lev_r[j] = A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane, nl)];
+        w |= A.lev_arc[B.level_base + min((uint32_t)j * 64u + lane + 1u, nl)] - lev_r[j] > 64u;
+      }
+      lev_wide = __builtin_amdgcn_ballot_w64(w) != 0;
     }
-    // the chain's usual block (round 6): at most 256 arcs, 320 states, 190 levels -- every record, offset and level entry is
-    // requested at once, then every count: two round trips for the block instead of two per 64 arcs and one per table
+    // the chain's usual block (round 6): at most 256 arcs, 320 states, 190 levels -- its records, offsets and level entries came
+    // with the block before (GxStatic); every count is requested at once: one round trip for the block
     const bool staged = !PAR && !A.init_logw && B.n_arcs <= 256u && B.n_states < 320u && (B.n_levels & 0x7fffffffu) < 192u;
     if (staged) {
-      uint4 r4[4];
-      uint2 n4[4];
-      uint32_t oo[5], ll[3];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t a = (uint32_t)q * 64u + lane, at = a < B.n_arcs ? a : 0u;
-        r4[q] = rec[at];
-        n4[q] = nrm[at];
-      }
-#pragma unroll
-      for (int j = 0; j < 5; ++j) oo[j] = A.out_off[B.off_base + min((uint32_t)j * 64u + lane, B.n_states)];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) ll[j] = A.level_off[B.level_base + min((uint32_t)j * 64u + lane, B.n_levels & 0x7fffffffu)];
+      uint4(&r4)[4] = S.r4;
+      uint2(&n4)[4] = S.n4;
+      uint32_t(&oo)[5] = S.oo, (&ll)[3] = S.ll, (&sl)[5] = S.sl;
       double x0[4], s0[4], x1[4], s1[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -241,7 +290,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
       }
 #pragma unroll
       for (int j = 0; j < 5; ++j)
-        if ((uint32_t)j * 64u + lane <= B.n_states) ooff[(uint32_t)j * 64u + lane] = oo[j];
+        if ((uint32_t)j * 64u + lane <= B.n_states) {
+          ooff[(uint32_t)j * 64u + lane] = oo[j];
+          if ((uint32_t)j * 64u + lane < B.n_states) slv[(uint32_t)j * 64u + lane] = sl[j];
+        }
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if ((uint32_t)j * 64u + lane <= (B.n_levels & 0x7fffffffu)) lvl[(uint32_t)j * 64u + lane] = ll[j];
@@ -256,6 +308,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           ds[a] = r4[q].x;
           par0[a] = r4[q].z;
           par1[a] = r4[q].w;
+          nr0[a] = n4[q].x;
+          nr1[a] = n4[q].y;
         }
       }
     } else
@@ -318,13 +372,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
       ds[a] = r.x;
       par0[a] = r.z;
       par1[a] = r.w;
+      nr0[a] = n.x;
+      nr1[a] = n.y;
     }
-    if (!staged)
+    if (!staged) {
       for (uint32_t s = lane; s <= B.n_states; s += 64) ooff[s] = A.out_off[B.off_base + s];
+      for (uint32_t s = lane; s < B.n_states; s += 64) slv[s] = A.state_lev[B.off_base + s];
+    }
     const uint32_t n_levels = B.n_levels & 0x7fffffffu;  // (bit 31: the lattice is a trellis)
     if (!staged)
       for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
-    // the next block's previous sample sets out now
+    // the next block's records and its previous sample set out now
+    if (!PAR) gx_request_static(A, Bn, lane, S);
     GxOld On;
     gx_request_old(A, Bn, GX_BLOCK_ID(min(bi + stride, nb - 1)), lane, On);
     const GxBlock Bnn = A.blocks[GX_BLOCK_ID(min(bi + 2 * stride, nb - 1))];
@@ -350,46 +409,72 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
       }
       GX_WAVE_SYNC();
       if (lev_regs && !ext) {
-        // a level's first 64 arcs (their ends and weights) are requested a level ahead, before this level's terms wait for
-        // their destinations' values: what is left between two syncs is value -> product -> add
-#define GX_LEV(l) ((l) < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lev_r[0], (int)(l)) : (uint32_t)__builtin_amdgcn_readlane((int)lev_r[1], (int)((l) - 64u)))
+        // a level's first 64 arcs (their ends and weights) are requested a level ahead.  Every read of the loop is unconditional
+        // (indices clamped into the block) and the destinations' values are requested FIRST: the compiler's wait for them is
+        // then a count that leaves the requests behind them in flight (LDS returns in order) -- with the reads under a
+        // condition it waited for everything, three round trips a level.  Between levels nothing waits: a wavefront's LDS
+        // operations execute in the order they were issued, so the next level's reads see this level's adds.
+#define GX_LEV(l) ((uint32_t)__builtin_amdgcn_readlane((int)((l) < 64u ? lev_r[0] : lev_r[1]), (int)((l) & 63u)))
+#define GX_LDS_ORDER()                   \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_wave_barrier();     \
+  } while (0)
+        const uint32_t a_last = B.n_arcs ? B.n_arcs - 1u : 0u;
         uint32_t a_hi = B.n_arcs;
         uint32_t pd = 0;
         double pg = 0.0;
         if (n_levels) {
           const uint32_t a0 = GX_LEV(n_levels - 1);
-          if (a0 + lane < a_hi) {
-            pd = ds[a0 + lane];
-            pg = gw[a0 + lane];
-          }
+          pd = ds[min(a0 + lane, a_last)];
+          pg = gw[min(a0 + lane, a_last)];
         }
-        for (uint32_t l = n_levels; l-- > 0;) {
-          const uint32_t a_lo = GX_LEV(l);
-          const uint32_t n_lo = l ? GX_LEV(l - 1) : a_lo;  // the next level's arcs: [n_lo, a_lo)
-          uint32_t nd = 0;
-          double ng = 0.0;
-          if (n_lo + lane < a_lo) {
-            nd = ds[n_lo + lane];
-            ng = gw[n_lo + lane];
+        if (!lev_wide) {
+          // no branch in the loop: a lane without an arc of the level stores and adds a zero at a slot of its own in bsum
+          // (this pass does not use it; the pass with exponents clears it first)
+          double* const idle = bsum + min(lane, CS - 1u);
+          uint32_t nidx = min(GX_LEV(n_levels >= 2u ? n_levels - 2u : 0u) + lane, a_last);  // where the level after's arcs are
+          GX_WAVE_SYNC();  // (nothing in flight at the loop's head: its waits count what the loop itself issued)
+          for (uint32_t l = n_levels; l-- > 0;) {
+            const double v = bv[pd & 0xffffu];
+            const uint32_t nd = ds[nidx];
+            const double ng = gw[nidx];
+            const uint32_t a_lo = GX_LEV(l);
+            nidx = min(GX_LEV(l >= 2u ? l - 2u : 0u) + lane, a_last);
+            const bool on = a_lo + lane < a_hi;
+            const double term = on ? pg * v : 0.0;
+            *(on ? &sh[a_lo + lane] : idle) = term;
+            gx_lds_add(on ? &bv[pd >> 16] : idle, term);
+            GX_LDS_ORDER();
+            pd = nd;
+            pg = ng;
+            a_hi = a_lo;
           }
-          if (a_lo != a_hi) {
+        } else
+          for (uint32_t l = n_levels; l-- > 0;) {
+            const uint32_t a_lo = GX_LEV(l);
+            const uint32_t n_lo = l ? GX_LEV(l - 1) : a_lo;
+            const double v = bv[pd & 0xffffu];
+            const uint32_t nd = ds[min(n_lo + lane, a_last)];
+            const double ng = gw[min(n_lo + lane, a_last)];
+            const double term = pg * v;
             if (a_lo + lane < a_hi) {
-              const double term = pg * bv[pd & 0xffffu];
               sh[a_lo + lane] = term;
               if (term != 0.0) gx_lds_add(&bv[pd >> 16], term);
             }
             for (uint32_t a = a_lo + 64 + lane; a < a_hi; a += 64) {  // (a level of more than 64 arcs)
               const uint32_t d = ds[a];
-              const double term = gw[a] * bv[d & 0xffffu];
-              sh[a] = term;
-              if (term != 0.0) gx_lds_add(&bv[d >> 16], term);
+              const double t2 = gw[a] * bv[d & 0xffffu];
+              sh[a] = t2;
+              if (t2 != 0.0) gx_lds_add(&bv[d >> 16], t2);
             }
             GX_WAVE_SYNC();
+            pd = nd;
+            pg = ng;
+            a_hi = a_lo;
           }
-          pd = nd;
-          pg = ng;
-          a_hi = a_lo;
-        }
+        GX_WAVE_SYNC();
+#undef GX_LDS_ORDER
 #undef GX_LEV
       } else {
       uint32_t a_hi = ooff[lvl[n_levels]];
@@ -453,7 +538,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         const uint32_t a0 = ooff[s], a1 = ooff[s + 1];
         uint32_t pick = a0;
         if (a1 > a0) {
-          double choice = gibbs_uniform(A.seed, A.iter, b, A.state_lev[B.off_base + s]) * tot[s];
+          double choice = gibbs_uniform(A.seed, A.iter, b, slv[s]) * tot[s];
           bool done = false;
           for (uint32_t top = a1; top > a0 && !done; top -= min(4u, top - a0)) {  // list order: newest first, four shares a round
             double v[4];
@@ -485,13 +570,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         const bool have = t < n_path;
         const uint32_t a = have ? idn[t] : 0u;
         const uint32_t p0 = have ? par0[a] : GX_NONE, p1 = have ? par1[a] : GX_NONE;
+        const uint32_t g0 = nr0[a], g1 = nr1[a];
         if (have) cheap.mul(pc[a]);
         // slots of the parameters in the sample: chain order within an arc, arcs in path order
         const unsigned long long m0 = __ballot(p0 != GX_NONE), m1 = __ballot(p1 != GX_NONE);
         const unsigned long long below = lane ? (~0ull >> (64 - lane)) : 0ull;
         const uint32_t at = n_ids + (uint32_t)__popcll(m0 & below) + (uint32_t)__popcll(m1 & below);
-        if (p0 != GX_NONE && at < CM) ids[at] = p0;
-        if (p1 != GX_NONE && at + (p0 != GX_NONE) < CM) ids[at + (p0 != GX_NONE)] = p1;
+        if (p0 != GX_NONE && at < CM) {
+          ids[at] = p0;
+          idm[at] = g0;
+        }
+        if (p1 != GX_NONE && at + (p0 != GX_NONE) < CM) {
+          ids[at + (p0 != GX_NONE)] = p1;
+          idm[at + (p0 != GX_NONE)] = g1;
+        }
         n_ids += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
       }
       n_ids = min(n_ids, CM);
@@ -505,7 +597,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         double choice = u * tot[s];
         // lane i holds the i-th arc of the state's list (its share and what the walk records of it): the chosen one's are
         // read across lanes, not fetched again
-        uint32_t p0 = GX_NONE, p1 = GX_NONE, to = B.fin;
+        uint32_t p0 = GX_NONE, p1 = GX_NONE, n0 = GX_NONE, n1 = GX_NONE, to = B.fin;
         double pcv = 1.0;
         if (deg <= 16) {
           // the usual case: the shares' running sums by a scan over the first row of lanes (DPP row shifts, no memory);
@@ -514,6 +606,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           const double share = lane < deg ? sh[at] : 0.0;
           const double pcl = pc[at];
           const uint32_t dl = ds[at], q0 = par0[at], q1 = par1[at];
+          const uint32_t h0 = nr0[at], h1 = nr1[at];
           double run = share;
           run += gx_row_shr<0x111>(run);
           run += gx_row_shr<0x112>(run);
@@ -523,6 +616,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           const uint32_t j = passed ? (uint32_t)__builtin_ctzll(passed) : deg - 1;
           p0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)j);
           p1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)j);
+          n0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, (int)j);
+          n1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, (int)j);
           to = (uint32_t)__builtin_amdgcn_readlane((int)dl, (int)j) & 0xffffu;
           pcv = gx_rl(pcl, j);
         } else {
@@ -532,6 +627,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           const double share = mine < deg ? sh[at] : 0.0;
           const double pcl = pc[at];
           const uint32_t dl = ds[at], q0 = par0[at], q1 = par1[at];
+          const uint32_t h0 = nr0[at], h1 = nr1[at];
           const uint32_t cnt = min(64u, deg - base);
           uint32_t j = 0;
           for (; j < cnt; ++j) {
@@ -544,13 +640,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           if (j == cnt) j = cnt - 1;  // (never below zero: the last arc of the list, as the reference's loop leaves it)
           p0 = (uint32_t)__builtin_amdgcn_readlane((int)q0, (int)j);
           p1 = (uint32_t)__builtin_amdgcn_readlane((int)q1, (int)j);
+          n0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, (int)j);
+          n1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, (int)j);
           to = (uint32_t)__builtin_amdgcn_readlane((int)dl, (int)j) & 0xffffu;
           pcv = gx_rl(pcl, j);
         }
         }
         if (lane == 0) {
-          if (p0 != GX_NONE && n_ids < GX_SAMPLE) ids[n_ids] = p0;
-          if (p1 != GX_NONE && n_ids + 1 < GX_SAMPLE) ids[n_ids + 1] = p1;
+          if (p0 != GX_NONE && n_ids < GX_SAMPLE) {
+            ids[n_ids] = p0;
+            idm[n_ids] = n0;
+          }
+          if (p1 != GX_NONE && n_ids + 1 < GX_SAMPLE) {
+            ids[n_ids + 1] = p1;
+            idm[n_ids + 1] = n1;
+          }
         }
         n_ids += p0 == GX_NONE ? 0u : (p1 != GX_NONE ? 2u : 1u);
         if (lane == 0) cheap.mul(pcv);  // (per-lane products: the trellis path multiplies side by side)
@@ -563,7 +667,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     // ---- the new sample into the counts, the next block's previous sample out (gibbs.hpp:851-871, 712-742, 769-792); the
     // parallel sweep only writes its sample down (gibbs.hip recounts) ----
     for (uint32_t k = lane; k < n_ids; k += 64) {
-      const uint32_t p = ids[k], n = A.p_norm[p];
+      const uint32_t p = ids[k], n = idm[k];  // (= p_norm[p]: the arc's record says so)
       idn[k] = n;
       A.sample_ids[B.sample_off + k] = p;
       A.sample_nrm[B.sample_off + k] = n;
@@ -572,9 +676,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         gx_add(A.p_x + p, B.wt);
         gx_add(A.normsum + n, B.wt);
         if (A.p_touch) A.p_touch[p] = A.time;
-        cnum.mul(gx_add(A.ccount + p, 1.0));
-        cden.mul(gx_add(A.csum + n, 1.0));
-      } else
+        const double rc = gx_add(A.ccount + p, 1.0), rs = gx_add(A.csum + n, 1.0);
+        if (n_ids <= 64u) {  // (a lane's factors keep their order: a longer sample's are multiplied in here)
+          pend_c = rc;
+          pend_s = rs;
+        } else {
+          cnum.mul(rc);
+          cden.mul(rs);
+        }
+      } else if (n_ids <= 64u)
+        pend_c = A.p_prior[p];
+      else
         cnum.mul(A.p_prior[p]);
     }
     if (lane == 0) A.sample_len[b] = n_ids;
@@ -604,6 +716,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     return;
   }
   gx_order();
+  cnum.mul(pend_c);
+  cden.mul(pend_s);
   if (A.want_after)
     for (uint32_t k = lane; k < n_prev; k += 64) {
       const uint32_t p = ids[k], n = idn[k];
@@ -1214,7 +1328,7 @@ hipError_t launch_gibbs_recount_tables(const GxBlock* blocks, const uint32_t* le
 
 size_t gibbs_exact_lds_bytes(uint32_t cap_arcs, uint32_t cap_states, uint32_t cap_levels, uint32_t cap_sample) {
   return (size_t)cap_arcs * (3 * 8 + 3 * 4) + (size_t)cap_states * (2 * 8 + 2 * 4) + ((size_t)cap_states + 1 + cap_levels + 1) * 4 +
-         (size_t)cap_sample * 8 + (size_t)4 * GX_OWN * 4;
+         (size_t)cap_sample * 8 + (size_t)4 * GX_OWN * 4 + (size_t)cap_arcs * 8 + (size_t)cap_states * 4 + (size_t)cap_sample * 4;
 }
 hipError_t launch_gibbs_exact_wave(const GxArgs& A, uint32_t n_waves, hipStream_t s) {
   const size_t lds = gibbs_exact_lds_bytes(A.cap_arcs, A.cap_states, A.cap_levels, A.cap_sample);
