@@ -1247,7 +1247,11 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
   GxArgs GX;
   std::memset(&GX, 0, sizeof GX);
   DevBuf<unsigned long long> gx_clk;
+  DevBuf<double> gx_idle;
   if (wave_run || wave_par) {
+    HIPCHK(gx_idle.alloc(128));
+    HIPCHK(hipMemsetAsync(gx_idle.p, 0, 128 * sizeof(double), s));
+    GX.idle = gx_idle.p;
     GX.blocks = g->gx_blocks.p;
     GX.arc_rec = (const uint4*)g->gx_rec.p;
     GX.arc_nrm = (const uint2*)g->gx_nrm.p;
@@ -1701,7 +1705,7 @@ int carmel_hip_gibbs_run_ex(carmel_hip_gibbs* g, double* iter_logprob, double* i
     unsigned long long c[16];
     HIPCHK(hipMemcpy(c, gx_clk.p, sizeof c, hipMemcpyDeviceToHost));
     if (c[4] && c[8])
-      fprintf(stderr, "[carmel_hip] gibbs_reg_wave: arrivals + own tables %.0f, weights %.0f, offsets + uniforms %.0f, requests %.0f | choices %.0f, path %.0f, "
+      fprintf(stderr, "[carmel_hip] gibbs wave kernels, parts: arrivals (+ own tables) %.0f, weights %.0f, offsets + uniforms %.0f, requests %.0f | choices %.0f, path %.0f, "
                       "parameters %.0f (per block, over ALL blocks of the sweep)\n", c[8] / (double)c[4], c[9] / (double)c[4], c[10] / (double)c[4],
               c[11] / (double)c[4], c[12] / (double)c[4], c[13] / (double)c[4], c[14] / (double)c[4]);
     if (c[4])

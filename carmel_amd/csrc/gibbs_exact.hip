@@ -200,7 +200,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
   const uint32_t lane = threadIdx.x;
   const uint32_t nb = A.n_blocks;
   GxProd cheap{1.0, 0}, cnum{1.0, 0}, cden{1.0, 0}, after{1.0, 0};
-  unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, sub[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define GX_STAMP(v) const unsigned long long v = A.phase_clk ? __builtin_readcyclecounter() : 0;
   // PAR: this launch's blocks are A.list[0 .. nb) (a launch per LDS size class); i counts through the list
   const uint32_t b0 = PAR ? blockIdx.x : 0u, stride = PAR ? gridDim.x : 1u;
   if (b0 >= nb) return;
@@ -213,17 +214,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
   if (!PAR) gx_request_static(A, B, lane, S);
   // the cache model's factors of the last block's sample (what its adds returned): multiplied in a block late, when the wait
   // for them is the wait the chain's order asks for anyway
-  double pend_c = 1.0, pend_s = 1.0;
+  double pend_c = 1.0, pend_s = 1.0, pend_p = 1.0;
+  uint32_t pend_kind = 0;  // 1: a counted parameter (pend_c, pend_s), 2: a fixed one (pend_p: its prior)
   uint32_t n_prev = 0;
   for (uint32_t bi = b0; bi < nb; bi += stride) {
     const uint32_t b = GX_BLOCK_ID(bi);  // the block's number in the corpus: what its uniforms and its sample are keyed by
     unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
     if (!PAR) {
       gx_order();  // the counts are as the chain has them
-      cnum.mul(pend_c);
-      cden.mul(pend_s);
-      pend_c = pend_s = 1.0;
+      cnum.mul(pend_kind == 1u ? pend_c : (pend_kind == 2u ? pend_p : 1.0));
+      cden.mul(pend_kind == 1u ? pend_s : 1.0);
+      pend_kind = 0;
     }
+    GX_STAMP(ta_)
     if (!PAR && A.want_after) {
       // the previous block's sample scored with itself counted (the "overestimate" of gibbs.hpp:866), then this block's
       // previous sample leaves the counts
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     const uint32_t n_levels = B.n_levels & 0x7fffffffu;  // (bit 31: the lattice is a trellis)
     if (!staged)
       for (uint32_t l = lane; l <= n_levels; l += 64) lvl[l] = A.level_off[B.level_base + l];
+    GX_STAMP(tb_)
     // the next block's records and its previous sample set out now
     if (!PAR) gx_request_static(A, Bn, lane, S);
     GxOld On;
@@ -557,18 +561,76 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         be[s] = (int)(pick | ((a1 > a0 ? (ds[pick] & 0xffffu) : B.fin) << 16));
       }
       GX_WAVE_SYNC();
+      GX_STAMP(tc_)
       uint32_t s = B.start, n_path = 0;
-      while (s != B.fin && n_path < CM) {
-        const uint32_t wd = (uint32_t)be[s];
-        if (lane == 0) idn[n_path] = wd & 0xffffu;  // (the path's arcs; their parameters are gathered below, side by side)
-        ++n_path;
-        s = wd >> 16;
-      }
+      // a path of at most 64 arcs (one a level) stays in a register, lane t its t-th arc: no store a step, no read back
+      const bool short_path = n_levels <= 64u && n_levels <= CM && B.n_states <= 320u;
+      uint32_t path_r = 0;
+      if (B.n_states <= 320u) {
+        // (round 6) the states' words in registers, lane s % 64 of register s / 64: a step of the path is a v_readlane (the
+        // state is the same in every lane), not the round trip of an LDS read
+        uint32_t wr[5];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) wr[j] = (uint32_t)be[min((uint32_t)j * 64u + lane, max(B.n_states, 1u) - 1u)];
+        GX_WAVE_SYNC();  // (arrived: the loops below wait for nothing -- their stores of the path's arcs are not waited for)
+        if (short_path && B.n_states <= 64u)
+          while (s != B.fin) {  // (a step: v_readlane, a compare and a select, a shift; the goal's word leads to the goal)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], (int)s);
+              path_r = lane == n_path ? wd : path_r;
+              n_path += s != B.fin;
+              s = wd >> 16;
+            }
+          }
+        else if (short_path)
+          while (s != B.fin) {
+            const uint32_t c = s >> 6;
+            uint32_t w = c == 1u ? wr[1] : wr[0];
+            w = c == 2u ? wr[2] : w;
+            w = c == 3u ? wr[3] : w;
+            w = c == 4u ? wr[4] : w;
+            const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(s & 63u));
+            path_r = lane == n_path ? wd : path_r;
+            ++n_path;
+            s = wd >> 16;
+          }
+        else if (B.n_states <= 64u)
+          while (s != B.fin && n_path < CM) {
+            const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)wr[0], (int)s);
+            if (lane == 0) idn[n_path] = wd & 0xffffu;  // (the path's arcs; their parameters are gathered below, side by side)
+            ++n_path;
+            s = wd >> 16;
+          }
+        else
+          while (s != B.fin && n_path < CM) {
+            const uint32_t c = s >> 6;
+            uint32_t w = c == 1u ? wr[1] : wr[0];
+            w = c == 2u ? wr[2] : w;
+            w = c == 3u ? wr[3] : w;
+            w = c == 4u ? wr[4] : w;
+            const uint32_t wd = (uint32_t)__builtin_amdgcn_readlane((int)w, (int)(s & 63u));
+            if (lane == 0) idn[n_path] = wd & 0xffffu;
+            ++n_path;
+            s = wd >> 16;
+          }
+      } else
+        while (s != B.fin && n_path < CM) {
+          const uint32_t wd = (uint32_t)be[s];
+          if (lane == 0) idn[n_path] = wd & 0xffffu;
+          ++n_path;
+          s = wd >> 16;
+        }
       GX_WAVE_SYNC();
+      GX_STAMP(td_)
+      if (A.phase_clk) {
+        sub[4] += tc_ - t2;
+        sub[5] += td_ - tc_;
+      }
       for (uint32_t base = 0; base < n_path; base += 64) {
         const uint32_t t = base + lane;
         const bool have = t < n_path;
-        const uint32_t a = have ? idn[t] : 0u;
+        const uint32_t a = have ? (short_path ? path_r & 0xffffu : idn[t]) : 0u;
         const uint32_t p0 = have ? par0[a] : GX_NONE, p1 = have ? par1[a] : GX_NONE;
         const uint32_t g0 = nr0[a], g1 = nr1[a];
         if (have) cheap.mul(pc[a]);
@@ -587,6 +649,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         n_ids += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
       }
       n_ids = min(n_ids, CM);
+      if (A.phase_clk) sub[6] += __builtin_readcyclecounter() - td_;
     } else {
       uint32_t s = B.start;
       while (s != B.fin) {
@@ -666,6 +729,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     unsigned long long t3 = A.phase_clk ? __builtin_readcyclecounter() : 0;
     // ---- the new sample into the counts, the next block's previous sample out (gibbs.hpp:851-871, 712-742, 769-792); the
     // parallel sweep only writes its sample down (gibbs.hip recounts) ----
+    // (what was requested before the sweep -- the next block's records and previous sample -- has long arrived; saying so here
+    // keeps the compiler from waiting for it below, behind the adds)
+    if (!PAR) __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+    if (!PAR && n_ids <= 64u) {
+      // the usual sample, an entry a lane: the adds whose results the cache model wants are issued by EVERY lane (a lane without
+      // an entry, or with a fixed parameter, adds zero to a slot of A.idle) and nothing here waits for them -- their results
+      // are multiplied in at the top of the next block, behind the wait the chain's order asks for anyway
+      const bool on = lane < n_ids;
+      const uint32_t p = ids[on ? lane : 0u], n = idm[on ? lane : 0u];
+      const bool cnt = on && n != GX_NONE, fix = on && n == GX_NONE;
+      if (on) {
+        idn[lane] = n;
+        A.sample_ids[B.sample_off + lane] = p;
+        A.sample_nrm[B.sample_off + lane] = n;
+      }
+      if (cnt) {
+        gx_add(A.p_x + p, B.wt);
+        gx_add(A.normsum + n, B.wt);
+        if (A.p_touch) A.p_touch[p] = A.time;
+      }
+      pend_c = gx_add(cnt ? A.ccount + p : A.idle + lane, cnt ? 1.0 : 0.0);
+      pend_s = gx_add(cnt ? A.csum + n : A.idle + 64 + lane, cnt ? 1.0 : 0.0);
+      pend_p = A.p_prior[fix ? p : 0u];
+      pend_kind = cnt ? 1u : (fix ? 2u : 0u);
+    } else
     for (uint32_t k = lane; k < n_ids; k += 64) {
       const uint32_t p = ids[k], n = idm[k];  // (= p_norm[p]: the arc's record says so)
       idn[k] = n;
@@ -676,17 +764,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
         gx_add(A.p_x + p, B.wt);
         gx_add(A.normsum + n, B.wt);
         if (A.p_touch) A.p_touch[p] = A.time;
-        const double rc = gx_add(A.ccount + p, 1.0), rs = gx_add(A.csum + n, 1.0);
-        if (n_ids <= 64u) {  // (a lane's factors keep their order: a longer sample's are multiplied in here)
-          pend_c = rc;
-          pend_s = rs;
-        } else {
-          cnum.mul(rc);
-          cden.mul(rs);
-        }
-      } else if (n_ids <= 64u)
-        pend_c = A.p_prior[p];
-      else
+        cnum.mul(gx_add(A.ccount + p, 1.0));
+        cden.mul(gx_add(A.csum + n, 1.0));
+      } else
         cnum.mul(A.p_prior[p]);
     }
     if (lane == 0) A.sample_len[b] = n_ids;
@@ -703,6 +783,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
       clk[2] += t3 - t2;
       clk[3] += t4 - t3;
       clk[4] += 1;
+      sub[0] += ta_ - t0;
+      sub[1] += tb_ - ta_;
+      sub[2] += t1 - tb_;
     }
   }
   if (PAR) {  // the sweep's proposal probability: every wavefront adds its blocks'
@@ -716,8 +799,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     return;
   }
   gx_order();
-  cnum.mul(pend_c);
-  cden.mul(pend_s);
+  cnum.mul(pend_kind == 1u ? pend_c : (pend_kind == 2u ? pend_p : 1.0));
+  cden.mul(pend_kind == 1u ? pend_s : 1.0);
   if (A.want_after)
     for (uint32_t k = lane; k < n_prev; k += 64) {
       const uint32_t p = ids[k], n = idn[k];
@@ -733,8 +816,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
     A.iter_out[0] = cache_ln;
     A.iter_out[1] = cheap_ln;
     A.iter_out[2] = after_ln;
-    if (A.phase_clk)
+    if (A.phase_clk) {
       for (int k = 0; k < 5; ++k) A.phase_clk[k] += clk[k];
+      for (int k = 0; k < 7; ++k) A.phase_clk[8 + k] += sub[k];
+    }
   }
 }
 

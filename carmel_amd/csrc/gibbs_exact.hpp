@@ -44,6 +44,7 @@ struct GxArgs {
   const double* init_logw;    // --init-em / --init-from-p0: per composed arc, what the first sweep samples from (null: the counts)
   double* iter_out;           // {ln cache-model prob, ln proposal prob, ln proposal prob after the add-back}
   unsigned long long* phase_clk;
+  double* idle;               // 128 doubles nobody reads: where the lanes without a sample entry send their (zero) adds
   uint64_t seed;
   uint32_t iter, n_blocks;
   int want_after;

@@ -10,6 +10,6 @@ PY
 export CARMEL_TRAINED_DIR=/tmp CARMEL_TIMING=1 CARMEL_HIP_GIBBS_CLK=1
 for reg in 1 0; do
   echo "== CARMEL_HIP_GIBBS_REG=$reg"
-  CARMEL_HIP_GIBBS_REG=$reg $R/carmel_amd/bin/carmel --crp --crp-parallel -M 40 -R 7 /tmp/crp_corpus $R/tests/golden/tagging.fsa $R/tests/golden/tagging.fst 2>&1 | grep -E "cycles per block|timing: gibbs|gibbs_reg_wave|rror"
-  CARMEL_HIP_GIBBS_REG=$reg $R/carmel_amd/bin/carmel --crp -M 60 -R 7 $R/tests/golden/tagging.data $R/tests/golden/tagging.fsa $R/tests/golden/tagging.fst 2>&1 | grep -E "cycles per block|timing: gibbs|gibbs_reg_wave|rror"
+  CARMEL_HIP_GIBBS_REG=$reg $R/carmel_amd/bin/carmel --crp --crp-parallel -M 40 -R 7 /tmp/crp_corpus $R/tests/golden/tagging.fsa $R/tests/golden/tagging.fst 2>&1 | grep -E "cycles per block|timing: gibbs|gibbs wave kernels|rror"
+  CARMEL_HIP_GIBBS_REG=$reg $R/carmel_amd/bin/carmel --crp -M 60 -R 7 $R/tests/golden/tagging.data $R/tests/golden/tagging.fsa $R/tests/golden/tagging.fst 2>&1 | grep -E "cycles per block|timing: gibbs|gibbs wave kernels|rror"
 done
