@@ -2689,6 +2689,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
   std::memset(&XA, 0, sizeof XA);
   DevBuf<double> x_ccount, x_csum;
   DevBuf<unsigned long long> x_clk;
+  DevBuf<double> x_idle;
   bool exact_dev = o->mode == 0 && F->multi_ok && !guard.changed && (o->high_temp == 0 || o->high_temp == 1) &&
                    (o->low_temp == 0 || o->low_temp == 1) && nf > 0 && !lib_opt("forest_exact_host");
   if (exact_dev) {
@@ -2723,6 +2724,9 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     XA.iter_out = F->iter_out.p;
     XA.seed = o->seed;
     XA.n_forests = (uint32_t)nf;
+    HIPCHK(x_idle.alloc(256));
+    HIPCHK(hipMemsetAsync(x_idle.p, 0, 256 * sizeof(double), s));
+    XA.idle = x_idle.p;
     if (lib_opt("forest_exact_clk")) {
       HIPCHK(x_clk.alloc(8));
       HIPCHK(hipMemsetAsync(x_clk.p, 0, 64, s));

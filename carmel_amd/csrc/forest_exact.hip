@@ -115,8 +115,17 @@ struct FxProd {
 // barrier would also wait for the global loads in flight: the next forest's prefetch.)
 #define FX_WAVE_SYNC()                                   \
   do {                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0), as the builtin: the compiler's own wait counts know of it */ \
+    asm volatile("" ::: "memory");                       \
     __builtin_amdgcn_wave_barrier();                     \
+  } while (0)
+
+// ... and between the passes of the inside sweep not even the wait: a pass's reads are issued behind the pass before's writes
+// and see them (in order); only the compiler has to be kept from reordering
+#define FX_LDS_ORDER()                   \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_wave_barrier();     \
   } while (0)
 
 // What a forest's walk reads, per node slot of a lane: the node's value, the running sums of its children's shares in the
@@ -124,7 +133,7 @@ struct FxProd {
 template <int NS>
 struct FxWalkTab {
   double val[NS], t0[NS], t1[NS], t2[NS];
-  uint32_t kk[NS][FX_KIDS];
+  uint32_t kp[NS];  // the children, a byte each, first lowest (one register: an array indexed by the choice would live in scratch memory)
 };
 
 // ---- inside (forest.hpp:768-816) for a forest of at most NS * 64 nodes, a node per lane slot.  Every node recomputes its
@@ -152,8 +161,8 @@ __device__ __forceinline__ bool fx_inside(const FxStage& S, const double (&p)[FX
 #pragma unroll
     for (int j = 0; j < FX_KIDS; ++j) {
       ka[q][j] = (uint32_t)j < nch ? kid[j] & (FX_NODES - 1) : none;
-      W.kk[q][j] = kid[j];
     }
+    W.kp[q] = (w0 & 0xffu) | (w1 << 8);
     val[q] = is_and[q] ? p[q] : 0.0;  // height 0: an AND leaf is its rule's probability
     ve[q] = 0;
     if (EXT) val[q] = frexp(val[q], &ve[q]);
@@ -163,7 +172,7 @@ __device__ __forceinline__ bool fx_inside(const FxStage& S, const double (&p)[FX
     c0[q] = c1[q] = c2[q] = 0.0;
     tot[q] = val[q];
   }
-  FX_WAVE_SYNC();
+  FX_LDS_ORDER();
   for (uint32_t h = 1; h < H; ++h) {
     const double* rd = vals + ((h - 1) & 1u) * FX_VALS;
     double* wr = vals + (h & 1u) * FX_VALS;
@@ -217,7 +226,7 @@ __device__ __forceinline__ bool fx_inside(const FxStage& S, const double (&p)[FX
       wr[at] = val[q];
       if (EXT) wre[at] = ve[q];
     }
-    FX_WAVE_SYNC();
+    FX_LDS_ORDER();
   }
   const double root = vals[((H - 1) & 1u) * FX_VALS + n - 1];
 #pragma unroll
@@ -271,11 +280,8 @@ __device__ __forceinline__ uint32_t fx_walk(const FxStage& S, const FxWalkTab<NS
       // child j is chosen when u * value has passed the sums of the shares before it
       const double uv = u * FX_SLOT(W.val);
       const bool g1 = !(uv < FX_SLOT(W.t0)), g2 = g1 && !(uv < FX_SLOT(W.t1)), g3 = g2 && !(uv < FX_SLOT(W.t2));
-      uint32_t pk = NS == 1 ? W.kk[0][0] : (q ? W.kk[NS - 1][0] : W.kk[0][0]);
-      pk = g1 ? (NS == 1 ? W.kk[0][1] : (q ? W.kk[NS - 1][1] : W.kk[0][1])) : pk;
-      pk = g2 ? (NS == 1 ? W.kk[0][2] : (q ? W.kk[NS - 1][2] : W.kk[0][2])) : pk;
-      pk = g3 ? (NS == 1 ? W.kk[0][3] : (q ? W.kk[NS - 1][3] : W.kk[0][3])) : pk;
-      node = fx_rl(pk, node);
+      const uint32_t sel = g3 ? 24u : (g2 ? 16u : (g1 ? 8u : 0u));
+      node = fx_rl((FX_SLOT(W.kp) >> sel) & 0xffu, node);
     }
     if (pop) {
       node = (uint32_t)pend_lo & 0xffu;
@@ -296,11 +302,11 @@ __device__ __forceinline__ bool fx_register_path(const FxStage& S, const double 
                                                  const uint32_t iter, const uint32_t n, const uint32_t H, const uint32_t f,
                                                  const uint32_t lane, double* vals, int* vals_e, const uint32_t* lr,
                                                  const uint32_t* ln, const double* lp, uint32_t& ns, uint32_t (&e_r)[FX_NS],
-                                                 uint32_t (&e_n)[FX_NS], double (&e_p)[FX_NS], unsigned long long* t_inside) {
+                                                 uint32_t (&e_n)[FX_NS], double (&e_p)[FX_NS], const bool stamp, unsigned long long& t_inside) {
   FxWalkTab<NS> W;
   bool ok = fx_inside<NS, false>(S, p, n, H, lane, vals, vals_e, W);
   if (!ok) ok = fx_inside<NS, true>(S, p, n, H, lane, vals, vals_e, W);
-  if (t_inside) *t_inside = __builtin_readcyclecounter();
+  if (stamp) t_inside = __builtin_readcyclecounter();
   uint32_t samp[NS];
   ns = ok ? fx_walk<NS>(S, W, U, seed, iter, f, n, samp) : 0u;
 #pragma unroll
@@ -375,16 +381,22 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
       lr[lane + q * 64] = S.rec[q].z;
       ln[lane + q * 64] = S.rec[q].w;
     }
-  double ret_c[FX_NS], ret_s[FX_NS];  // what the previous forest's cache-model atomics returned (consumed a forest later)
+  // what the previous forest's cache-model atomics returned (consumed a forest later); ret_on: the entry is a counted rule's
+  // (else its factor is ret_p: a fixed rule's probability, or 1 where the lane has no entry)
+  double ret_c[FX_NS], ret_s[FX_NS], ret_p[FX_NS];
+  bool ret_on[FX_NS];
 #pragma unroll
-  for (int q = 0; q < FX_NS; ++q) ret_c[q] = ret_s[q] = 1.0;
+  for (int q = 0; q < FX_NS; ++q) {
+    ret_c[q] = ret_s[q] = ret_p[q] = 1.0;
+    ret_on[q] = false;
+  }
   for (uint32_t f = 0; f < nf; ++f) {
     unsigned long long t0 = A.phase_clk ? __builtin_readcyclecounter() : 0;
     fx_order();  // the counts are as the chain has them: the previous forest's sample in, this forest's previous sample out
 #pragma unroll
     for (int q = 0; q < FX_NS; ++q) {
-      cnum.mul(ret_c[q]);
-      cden.mul(ret_s[q]);
+      cnum.mul(ret_on[q] ? ret_c[q] : ret_p[q]);
+      cden.mul(ret_on[q] ? ret_s[q] : 1.0);
     }
     const uint32_t n = d.y & 0xffffu, H = d.y >> 16;
     const uint64_t so = ((uint64_t)(d.w & 0xffffu) << 32) | d.z;
@@ -414,30 +426,35 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
         if (lane + q * 64 < n) lp[lane + q * 64] = p[q];
       if (A.phase_clk) t1 = __builtin_readcyclecounter();
       FX_WAVE_SYNC();
-      unsigned long long* tp = A.phase_clk ? &t2 : nullptr;
+      const bool stamp = A.phase_clk != nullptr;
       if (n <= 64 && !((d.w >> 17) & 1u))
-        fx_register_path<1>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);
+        fx_register_path<1>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, stamp, t2);
       else
-        fx_register_path<FX_NS>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, tp);
+        fx_register_path<FX_NS>(S, p, U, A.seed, A.iter, n, H, f, lane, vals, vals_e, lr, ln, lp, ns, e_r, e_n, e_p, stamp, t2);
       if (A.phase_clk) t3 = __builtin_readcyclecounter();
     }
     if (!slow) {
       // ---- the new sample goes into the counts with the next forest's previous sample coming out; the cache-model counts
       // answer with what they held (gibbs.hpp:866-871, 712-742, 769-792) ----
+      // (the next forest's records and previous sample, requested before the inside pass, have long arrived; saying so keeps
+      // the compiler from waiting for them below, behind the adds.)  The adds whose results the cache model wants are issued by
+      // EVERY lane -- one without a counted entry adds zero to a slot of A.idle -- so that nothing here waits for them.
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
 #pragma unroll
       for (int q = 0; q < FX_NS; ++q) {
-        ret_c[q] = ret_s[q] = 1.0;
-        if (lane + q * 64 < ns) {
+        const bool on = lane + q * 64 < ns, cnt = on && e_n[q] != FX_NONORM;
+        if (on) {
           A.sample_rules[so + lane + q * 64] = e_r[q];
           A.sample_nn[so + lane + q * 64] = e_n[q];
-          if (e_n[q] != FX_NONORM) {
-            fx_add(A.p_x + e_r[q], 1.0);
-            fx_add(A.normsum + e_n[q], 1.0);
-            ret_c[q] = fx_add(A.ccount + e_r[q], 1.0);
-            ret_s[q] = fx_add(A.csum + e_n[q], 1.0);
-          } else
-            ret_c[q] = e_p[q];
         }
+        if (cnt) {
+          fx_add(A.p_x + e_r[q], 1.0);
+          fx_add(A.normsum + e_n[q], 1.0);
+        }
+        ret_c[q] = fx_add(cnt ? A.ccount + e_r[q] : A.idle + q * 128 + lane, cnt ? 1.0 : 0.0);
+        ret_s[q] = fx_add(cnt ? A.csum + e_n[q] : A.idle + q * 128 + 64 + lane, cnt ? 1.0 : 0.0);
+        ret_p[q] = e_p[q];  // (1 where the lane has no entry)
+        ret_on[q] = cnt;
       }
       if (f + 1 < nf) fx_take_out(A, dn, lane, T, T.plen);
 #pragma unroll
@@ -538,7 +555,10 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
       // into the counts: the first FX_NS * 64 entries report their cache-model counts through ret_c / ret_s as the register
       // path's do, the others are waited for at once
 #pragma unroll
-      for (int q = 0; q < FX_NS; ++q) ret_c[q] = ret_s[q] = 1.0;
+      for (int q = 0; q < FX_NS; ++q) {
+        ret_p[q] = 1.0;
+        ret_on[q] = false;
+      }
       for (uint32_t i = lane; i < ns; i += 64) {
         const uint32_t node = snode[i], r = hr[node] & 0x7fffffffu, nn = hn[node];
         const double pr = pp[node];
@@ -558,6 +578,7 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
             if ((i >> 6) == (uint32_t)q) {
               ret_c[q] = rc;
               ret_s[q] = rs;
+              ret_on[q] = true;
             }
         } else {
           cnum.mul(rc);
@@ -595,8 +616,8 @@ __global__ __launch_bounds__(64) void forest_exact_kernel(FExactArgs A) {
   fx_order();
 #pragma unroll
   for (int q = 0; q < FX_NS; ++q) {
-    cnum.mul(ret_c[q]);
-    cden.mul(ret_s[q]);
+    cnum.mul(ret_on[q] ? ret_c[q] : ret_p[q]);
+    cden.mul(ret_on[q] ? ret_s[q] : 1.0);
   }
   double cheap_ln = cheap.ln(), cache_ln = cnum.ln() - cden.ln();
   for (int o = 32; o > 0; o >>= 1) {

@@ -35,6 +35,7 @@ struct FExactArgs {
   double* csum;
   double* iter_out;        // {ln cache-model prob, ln proposal prob} of the sweep
   unsigned long long* phase_clk;  // experiment: summed cycles per phase (null: none)
+  double* idle;                   // 4 * 64 doubles nobody reads: where the lanes without a counted sample entry send their (zero) adds
   uint64_t seed;
   uint32_t iter, n_forests;
   uint32_t max_n, max_tab, max_stack, max_sample;  // LDS path's carve: nodes, table words, stack entries, sample entries
