@@ -1815,6 +1815,8 @@ struct carmel_hip_forests {
   uint64_t node_total = 0, stream_total = 0;
   static const int N_SIDE = 3;  // + the caller's stream (carmel_hip_forests_create: how they come by hardware queues of their own)
   std::vector<int> class_side;  // per launch class: -1 = the caller's stream, k = side[k] (dealt by load, largest class first)
+  std::vector<int> sweep_side;     // ... for the several-lanes sampler's sweep (sweep_stream): dealt by the classes' LONGEST forest
+  std::vector<size_t> sweep_order;  // ... and the order they are launched in (the class of the largest forests first)
   hipStream_t side[N_SIDE] = {};  // launch classes of one sweep run side by side
   hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {};
   bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
@@ -2369,6 +2371,32 @@ static hipStream_t class_stream(carmel_hip_forests* F, hipStream_t s, size_t ci)
   }
   const int k = F->class_side[ci];
   return k < 0 ? s : F->side[k];
+}
+// The several-lanes sampler's sweep: every wavefront of every class is resident at once, so a class takes what its LONGEST
+// forests take (a wavefront's chain of dependent steps grows with the nodes of its forests), not what its records add up to
+// (round 6, tools/c5_timeline.sh: by records the class of the largest forests -- 204 us -- shared a stream with the smallest and
+// started 19 us after the first).  Classes by their largest forest, the largest on the caller's stream (it need not wait for
+// the fork) and launched first; a stream takes a second class only after every stream has one.
+static hipStream_t sweep_stream(carmel_hip_forests* F, hipStream_t s, size_t ci) {
+  const int n = n_side_for(F);
+  if (!n) return s;
+  const int k = F->sweep_side[ci];
+  return k < 0 ? s : F->side[k];
+}
+static void sweep_schedule(carmel_hip_forests* F) {
+  if (F->sweep_order.size() == F->classes.size()) return;
+  const int n = n_side_for(F);
+  F->sweep_order.resize(F->classes.size());
+  for (size_t i = 0; i < F->sweep_order.size(); ++i) F->sweep_order[i] = i;
+  auto cost = [&](size_t i) { return (double)std::max(F->classes[i].m_n, F->classes[i].max_nodes); };
+  std::stable_sort(F->sweep_order.begin(), F->sweep_order.end(), [&](size_t a, size_t b) { return cost(a) > cost(b); });
+  std::vector<double> load((size_t)n + 1, 0.0);
+  F->sweep_side.assign(F->classes.size(), -1);
+  for (size_t i : F->sweep_order) {
+    const size_t k = (size_t)(std::min_element(load.begin(), load.end()) - load.begin());
+    F->sweep_side[i] = (int)k - 1;
+    load[k] += cost(i);
+  }
 }
 static hipError_t join_side(carmel_hip_forests* F, hipStream_t s) {
   hipError_t e = hipSuccess;
@@ -2930,7 +2958,8 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           HIPCHK(hipMemcpyAsync(F->normsum2.p, F->prior_norm.p, ng * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         HIPCHK(fork_side(F, s));
-        for (size_t ci = 0; ci < F->classes.size(); ++ci) {
+        sweep_schedule(F);
+        for (size_t ci : F->sweep_order) {
           const auto& c = F->classes[ci];
           A.first_group = c.first;
           // temperature 1: mantissa / exponent arithmetic (12 bytes per node); annealing: the log domain
@@ -2945,7 +2974,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           auto launch = [&](auto kernel, size_t bytes) {
             if (bytes > 64 * 1024)
               (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-            hipLaunchKernelGGL(kernel, dim3(c.count), dim3(64), bytes, class_stream(F, s, ci), A, F->max_sample, c.max_nodes,
+            hipLaunchKernelGGL(kernel, dim3(c.count), dim3(64), bytes, sweep_stream(F, s, ci), A, F->max_sample, c.max_nodes,
                                stack_lds, kid_rows);
           };
           // several lanes per forest (temperature 1, tables within LDS): forest_sample_multi_kernel
@@ -2970,7 +2999,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             if (iter == 0 && lib_opt("timing"))
               fprintf(stderr, "timing: forest sweep class %zu: %u wavefronts of %d forests, nodes <= %u, table <= %u words, frontier <= %u: %zu bytes of LDS a wavefront\n",
                       ci, nwg, (int)FM_FPW, c.m_n, c.m_tab, c.m_front, fm_per * FM_FPW);
-            hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, class_stream(F, s, ci), A, MA, F->max_sample);
+            hipLaunchKernelGGL(forest_sample_multi_kernel, dim3(nwg), dim3(64), fm_per * FM_FPW, sweep_stream(F, s, ci), A, MA, F->max_sample);
           } else if ((size_t)c.max_nodes * 64 * 8 * 2 > F_LDS_LIMIT || force_gcol) {
             A.gcol = F->gcol.p + F->gcol_off[ci];
             A.gcol_stride = (uint64_t)2 * c.max_nodes * 64;
@@ -2988,8 +3017,10 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
           else
             launch(forest_sample_kernel<false, false, false>, lds);
           if (split_recount)  // this class's new samples into the counts, on its own stream, while the other classes still sample
+            // (all samplers first, the recounts behind them: 335 us against 316 -- the recounts are bound by their atomics, side
+            // by side at the end they take as long as spread out)
             hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), frc_bytes,
-                               class_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
+                               sweep_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
                                F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
                                (c.first + c.count) * 64u, frc_slots0, frc_slots1, class_nodes ? (const uint32_t*)F->mt_hdr.p : nullptr,
                                (const double*)F->mt_prob.p, (const uint4*)F->mt_slots.p);
