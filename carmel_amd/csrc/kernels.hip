@@ -419,11 +419,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void sw
       if (t > NEG_INF) lds_add_f64(&sm[dr], K_EXP(t - mx[dr]));                                               \
     }                                                                                                         \
     __syncthreads();                                                                                          \
+    /* (RING: a level is at most a wavefront wide -- one pass, and written as one: in front of a LOOP without loads the   \
+       compiler waits for every load in flight, the records and weights requested for the levels ahead included) */      \
+    if (RING) {                                                                                               \
+      if (lane < ns) {                                                                                        \
+        const double m = mx[lane], a = sm[lane];                                                              \
+        const double v = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));                            \
+        val[(s0 + lane) & rm] = v;                                                                            \
+        spill[s0 + lane] = v;                                                                                 \
+        mx[lane] = NEG_INF;                                                                                   \
+        sm[lane] = 0.0;                                                                                       \
+      }                                                                                                       \
+    } else                                                                                                    \
     for (uint32_t i = lane; i < ns; i += 64) {                                                                \
       const double m = mx[i], a = sm[i];                                                                      \
       const double v = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));                              \
       val[(s0 + i) & rm] = v;                                                                                 \
-      if (RING) spill[s0 + i] = v;                                                                            \
       mx[i] = NEG_INF;                                                                                        \
       sm[i] = 0.0;                                                                                            \
     }                                                                                                         \
@@ -537,6 +548,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5))) void sw
       if (t > NEG_INF) lds_add_f64(&sm[sr], K_EXP(t - mx[sr]));                                                       \
     }                                                                                                                 \
     __syncthreads();                                                                                                  \
+    if (RING) { /* (one pass; see the forward step) */                                                                \
+      if (lane < ns) {                                                                                                \
+        const double m = mx[lane], a = sm[lane];                                                                      \
+        val[(s0 + lane) & rm] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a));                             \
+        mx[lane] = NEG_INF;                                                                                           \
+        sm[lane] = 0.0;                                                                                               \
+      }                                                                                                               \
+    } else                                                                                                            \
     for (uint32_t i = lane; i < ns; i += 64) {                                                                        \
       const double m = mx[i], a = sm[i];                                                                              \
       val[(s0 + i) & rm] = (m == NEG_INF) ? NEG_INF : (a == 1.0 ? m : m + K_LOG(a)); /* beta[s] (full form: replaces alpha[s]) */ \
