@@ -15,6 +15,7 @@
 // inside[] (and outside[]) live in the lane's own LDS column(s).  Expected counts reuse the two-phase scheme of the
 // lattice path: one posterior per AND node into post[], then count_reduce_kernel with rules in the role of arcs.
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -1115,6 +1116,9 @@ struct FMultiArgs {
   uint32_t max_tab, max_n, max_front;   // LDS per forest: table words, nodes, frontier entries
   int own_proposal;                     // the kernel computes the rules' proposal probabilities itself (forest_proposal_kernel
                                         // folded in: each AND node scans the forest's previous sample for its own uses)
+  uint16_t* node_cnt;                   // own_proposal, non-null: per node (in the order of hdr) how often this sweep's sample
+                                        // records it -- what the counts are gathered from afterwards (forest_rule_gather_kernel);
+                                        // counted in the low half of the node's header word in LDS, which the walk does not use
   double* prob;                         // own_proposal: per node (in the order of hdr, four words a node) its rule's proposal
                                         // probability, and the sample is written as NODE numbers: what the recount needs of a
                                         // sampled rule -- id, class word, norm group, probability -- then lies in the forest's
@@ -1245,6 +1249,7 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
 #define FM_ROW(k, hh, px, pn)                                                                                 \
   {                                                                                                          \
     uint32_t hw = (hh).x;                                                                                     \
+    if (own) hw &= 0x80000000u; /* (the row of the header record: the one-per-lane kernels' business; here: a counter) */ \
     if (hw & 0x80000000u) {                                                                                  \
       double pr = (px);                                                                                       \
       if (own) {                                                                                             \
@@ -1423,7 +1428,10 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
       const uint32_t at = fm_prefix(push, li, tot_push), ar = fm_prefix(rec, li, tot_rec);
       if (have) {
         if (is_and) {
-          if (ns + ar < max_sample) outh[ns + ar] = own ? node : (hd[node] & 0xffffu);
+          if (ns + ar < max_sample) {
+            outh[ns + ar] = own ? node : (hd[node] & 0xffffu);
+            if (own && M.node_cnt) __hip_atomic_fetch_add(&hd[node], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
           for (uint32_t k = 0; k < push; ++k)
             if (nn + at + k < M.max_front) nxt[nn + at + k] = kids[k0 + k];
         } else if (push) {
@@ -1441,6 +1449,10 @@ __global__ __launch_bounds__(64) void forest_sample_multi_kernel(ForestArgs A, F
     nxt = t;
   }
   if (active && li == 0) A.sample_len[forest] = ns < max_sample ? ns : max_sample;
+  if (own && M.node_cnt && active) {  // every node of the forest says how often it was recorded (most: not at all)
+    uint16_t* __restrict__ nc = M.node_cnt + ((((uint64_t)d0.w << 32) | d0.z) >> 2);
+    for (uint32_t k = li; k < n; k += FM_G) nc[k] = (uint16_t)(hd[k] & 0xffffu);
+  }
   if (A.trace) {
     tr3 = __builtin_readcyclecounter();
     uint32_t nmax = n, hmax = H, vmax = visited;
@@ -1575,16 +1587,18 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
   uint32_t* const key1 = cnt0 + n_slots0;
   uint32_t* const cnt1 = key1 + n_slots1;
   __shared__ double cheap_sh[16];
-  for (uint32_t i = threadIdx.x; i < n_slots0; i += 1024) {
+  const bool count_here = !(sweep2 & 2);  // (bit 1: the counts are gathered from the nodes' use counts, forest_rule_gather_kernel)
+  for (uint32_t i = threadIdx.x; i < n_slots0 && count_here; i += 1024) {
     key0[i] = 0xffffffffu;
     cnt0[i] = 0u;
   }
-  for (uint32_t i = threadIdx.x; i < n_slots1; i += 1024) {
+  for (uint32_t i = threadIdx.x; i < n_slots1 && count_here; i += 1024) {
     key1[i] = 0xffffffffu;
     cnt1[i] = 0u;
   }
   __syncthreads();
   auto add = [&](int t, uint32_t id, double* g) {
+    if (!count_here) return;
     uint32_t* const key = t ? key1 : key0;
     uint32_t* const cnt = t ? cnt1 : cnt0;
     const uint32_t slot = (id * 2654435761u >> 9) & ((t ? n_slots1 : n_slots0) - 1);
@@ -1736,9 +1750,9 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     if ((threadIdx.x & 63) == 0) cheap_sh[threadIdx.x >> 6] = cheap;
   }
   __syncthreads();
-  for (uint32_t i = threadIdx.x; i < n_slots0; i += 1024)
+  for (uint32_t i = threadIdx.x; i < n_slots0 && count_here; i += 1024)
     if (cnt0[i]) unsafeAtomicAdd(x + key0[i], (double)cnt0[i]);
-  for (uint32_t i = threadIdx.x; i < n_slots1; i += 1024)
+  for (uint32_t i = threadIdx.x; i < n_slots1 && count_here; i += 1024)
     if (cnt1[i]) unsafeAtomicAdd(normsum + key1[i], (double)cnt1[i]);
   if (sweep2 && threadIdx.x == 0) {
     double t = 0.0;
@@ -1746,18 +1760,82 @@ __global__ __launch_bounds__(1024) void forest_recount_kernel(const uint64_t* sa
     unsafeAtomicAdd(A.iter_out + 1, t);
   }
 }
+// ---- the parallel sweep's counts WITHOUT atomics (round 6).  The recount above ends in one device-scope atomic per distinct
+// rule and norm group of every 256 forests -- ~4 M a sweep on config 5, most of them rules of the Zipf tail that no LDS table
+// folds -- and those atomics, not its reads, are what it takes 85 us for.  But which nodes carry a rule never changes: the
+// sampler leaves per node how often it recorded it (FMultiArgs::node_cnt, two bytes a node, every node written every sweep),
+// and a rule's uses are the sum over ITS nodes (inv_off / inv_node, built with the forests): a gather through a static index,
+// one thread a rule; rules on more than FRG_COLD nodes in pieces of FRG_PIECE, a workgroup each, added with integer atomics
+// (a few hundred a sweep).  The norm groups' sums are sums over their rules' integers; both meet their priors in ONE rounding
+// (prior + uses), whatever the order the samples came in -- the atomics' sums depended on it.
+#define FRG_COLD 8u      // a rule on at most so many nodes: one thread, its loads side by side
+#define FRG_PIECE 512u   // other rules: pieces of so many nodes, a wavefront each (eight loads a lane, side by side)
+__global__ __launch_bounds__(256) void forest_rule_gather_kernel(const uint32_t* __restrict__ inv_off, const uint32_t* __restrict__ inv_node,
+                                                                 const uint16_t* __restrict__ node_cnt, uint32_t* __restrict__ rule_cnt,
+                                                                 uint32_t n_rules, const uint32_t* __restrict__ pieces, uint32_t n_pieces,
+                                                                 uint32_t cold_blocks, uint32_t n_inv) {
+  if (blockIdx.x >= cold_blocks) {  // four pieces a workgroup: {rule, first, end} each
+    const uint32_t pc = (blockIdx.x - cold_blocks) * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (pc >= n_pieces) return;
+    const uint32_t r = pieces[3 * pc], j0 = pieces[3 * pc + 1], j1 = pieces[3 * pc + 2];
+    uint32_t nd[FRG_PIECE / 64], c = 0;
+#pragma unroll
+    for (int q = 0; q < (int)(FRG_PIECE / 64); ++q) nd[q] = j0 + lane + 64u * q < j1 ? inv_node[j0 + lane + 64u * q] : 0xffffffffu;
+#pragma unroll
+    for (int q = 0; q < (int)(FRG_PIECE / 64); ++q)
+      if (nd[q] != 0xffffffffu) c += node_cnt[nd[q]];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if (lane == 0 && c) atomicAdd(rule_cnt + r, c);
+    return;
+  }
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= n_rules) return;
+  const uint32_t j0 = inv_off[r], j1 = inv_off[r + 1];
+  if (j1 - j0 > FRG_COLD) return;  // (its pieces add into rule_cnt[r], zero since the last sweep's apply)
+  if (j1 == j0) return;  // (a rule on no node: its count stays zero)
+  uint32_t nd[FRG_COLD], c = 0;
+#pragma unroll
+  for (int q = 0; q < (int)FRG_COLD; ++q) nd[q] = j0 + (uint32_t)q < j1 ? inv_node[j0 + (uint32_t)q] : 0xffffffffu;
+#pragma unroll
+  for (int q = 0; q < (int)FRG_COLD; ++q)
+    if (nd[q] != 0xffffffffu) c += node_cnt[nd[q]];
+  rule_cnt[r] = c;
+}
+// the norm groups' sums from their rules' use counts (the rules' own new counts: forest_commit_kernel, in rule order).  Eight
+// lanes a group (config 5: eight rules a group on average).
+__global__ __launch_bounds__(256) void forest_group_sum_kernel(const uint64_t* __restrict__ group_off, const uint32_t* __restrict__ group_rule,
+                                                               uint64_t n_groups, const uint32_t* __restrict__ rule_cnt,
+                                                               const double* __restrict__ prior_norm, double* __restrict__ normsum) {
+  const uint64_t g = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const uint32_t li = threadIdx.x & 7u;
+  const bool on = g < n_groups;
+  const uint64_t j0 = on ? group_off[g] : 0, j1 = on ? group_off[g + 1] : 0;
+  uint32_t sum = 0;
+  for (uint64_t j = j0 + li; j < j1; j += 8) sum += rule_cnt[group_rule[j]];
+  sum += __shfl_xor(sum, 1, 8);
+  sum += __shfl_xor(sum, 2, 8);
+  sum += __shfl_xor(sum, 4, 8);
+  if (on && li == 0) normsum[g] = prior_norm[g] + (double)sum;
+}
 // reset_x / reset_norm (may be null): the count buffers of the NEXT sweep start from the priors -- set here, by the thread
 // that has just read the slot, instead of two copies behind the kernel
 __global__ void forest_commit_kernel(double* new_x, double* p_x, double* p_s, double* p_tmax, const uint32_t* p_norm,
                                      double time, uint64_t n, const double* reset_x, double* next_norm,
-                                     const double* reset_norm, uint64_t n_norm) {
+                                     const double* reset_norm, uint64_t n_norm, uint32_t* rule_cnt = nullptr,
+                                     const double* prior = nullptr) {
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_norm && next_norm;
        p += (uint64_t)gridDim.x * blockDim.x)
     next_norm[p] = reset_norm[p];
   for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (uint64_t)gridDim.x * blockDim.x) {
     if (p_norm[p] == F_NONORM) continue;
-    const double nx = new_x[p];
-    if (reset_x) new_x[p] = reset_x[p];
+    double nx;
+    if (rule_cnt) {  // the sweep's use counts, gathered (forest_rule_gather_kernel): the new count in one rounding; cleared for the next sweep
+      nx = prior[p] + (double)rule_cnt[p];
+      rule_cnt[p] = 0u;
+    } else {
+      nx = new_x[p];
+      if (reset_x) new_x[p] = reset_x[p];
+    }
     const double d = nx - p_x[p];
     const double moret = time - p_tmax[p];
     if (moret > 0) {
@@ -1818,7 +1896,7 @@ struct carmel_hip_forests {
   std::vector<int> sweep_side;     // ... for the several-lanes sampler's sweep (sweep_stream): dealt by the classes' LONGEST forest
   std::vector<size_t> sweep_order;  // ... and the order they are launched in (the class of the largest forests first)
   hipStream_t side[N_SIDE] = {};  // launch classes of one sweep run side by side
-  hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {};
+  hipEvent_t ev_fork = nullptr, ev_side[N_SIDE] = {}, ev_samp[N_SIDE] = {};  // (ev_samp: a side stream's samplers are done)
   bool sweep2_ok = false;  // the second formulation of the parallel sweep applies (class ids fit 16 bits)
   // several lanes per forest (forest_sample_multi_kernel): per-forest tables, per lane slot
   bool multi_ok = false;
@@ -1826,6 +1904,9 @@ struct carmel_hip_forests {
   DevBuf<uint32_t> mt_hdr;
   DevBuf<uint32_t> mt_slots;  // FMultiArgs::slots
   DevBuf<double> mt_prob;     // FMultiArgs::prob
+  DevBuf<uint16_t> mt_node_cnt;                         // FMultiArgs::node_cnt
+  DevBuf<uint32_t> inv_off, inv_node, inv_pieces, rule_cnt;  // forest_rule_gather_kernel: rule -> its AND nodes (indices into mt_hdr / 4)
+  uint32_t n_inv_pieces = 0;
   DevBuf<uint32_t> x_desc, x_rec;  // forest_exact_kernel's per-forest descriptors and per-node records (forest_exact.hpp)
   std::vector<FGroup> h_groups;
   struct Cls {
@@ -1885,6 +1966,7 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
     for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
       HIPCHK(hipStreamCreateWithPriority(&F->side[k], hipStreamNonBlocking, prio_hi));
       HIPCHK(hipEventCreateWithFlags(&F->ev_side[k], hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&F->ev_samp[k], hipEventDisableTiming));
     }
   }
   hipStream_t s = F->stream;
@@ -2238,6 +2320,33 @@ int carmel_hip_forests_create(carmel_hip_forests** out, int device, uint64_t n_f
       HIPCHK(F->mt_tab.upload(tab, s));
       HIPCHK(F->mt_hdr.upload(hdrs, s));
       HIPCHK(F->mt_slots.upload(slots, s));
+      if (hdrs.size() / 4 < 0xffffffffull) {  // rule -> the AND nodes that carry it (rules inside a normalisation group: the counted ones)
+        const size_t nn_ = hdrs.size() / 4;
+        std::vector<uint32_t> ioff((size_t)n_rules + 1, 0u);
+        for (size_t q = 0; q < nn_; ++q)
+          if ((hdrs[4 * q] & 0x80000000u) && hdrs[4 * q + 3] != F_NONORM) ioff[(size_t)hdrs[4 * q + 1] + 1]++;
+        for (uint32_t r = 0; r < n_rules; ++r) ioff[r + 1] += ioff[r];
+        std::vector<uint32_t> inode(ioff[n_rules]), fill(ioff.begin(), ioff.end() - 1), pieces;
+        for (size_t q = 0; q < nn_; ++q)
+          if ((hdrs[4 * q] & 0x80000000u) && hdrs[4 * q + 3] != F_NONORM) inode[fill[hdrs[4 * q + 1]]++] = (uint32_t)q;
+        for (uint32_t r = 0; r < n_rules; ++r)
+          if (ioff[r + 1] - ioff[r] > FRG_COLD)
+            for (uint32_t j = ioff[r]; j < ioff[r + 1]; j += FRG_PIECE) {
+              pieces.push_back(r);
+              pieces.push_back(j);
+              pieces.push_back(std::min(ioff[r + 1], j + FRG_PIECE));
+            }
+        F->n_inv_pieces = (uint32_t)(pieces.size() / 3);
+        if (pieces.empty()) pieces.assign(3, 0u);
+        if (inode.empty()) inode.assign(1, 0u);
+        HIPCHK(F->inv_off.upload(ioff, s));
+        HIPCHK(F->inv_node.upload(inode, s));
+        HIPCHK(F->inv_pieces.upload(pieces, s));
+        HIPCHK(F->mt_node_cnt.alloc(nn_ + 8));
+        HIPCHK(hipMemsetAsync(F->mt_node_cnt.p, 0, (nn_ + 8) * sizeof(uint16_t), s));
+        HIPCHK(F->rule_cnt.alloc((size_t)n_rules + 1));
+        HIPCHK(hipMemsetAsync(F->rule_cnt.p, 0, ((size_t)n_rules + 1) * sizeof(uint32_t), s));
+      }
       // the exact chain's records (forest_exact.hip), forest after forest in the order of the chain: per node its children,
       // rule, norm group, height; per forest where they start, how many, how high, where its sample lives, and whether it
       // fits the register path (FX_NODES nodes, FX_KIDS children a node, FX_STACK pending nodes, FX_NODES rules a derivation)
@@ -2329,6 +2438,7 @@ int carmel_hip_forests_destroy(carmel_hip_forests* F) {
     for (int k = 0; k < carmel_hip_forests::N_SIDE; ++k) {
       if (F->side[k]) (void)hipStreamDestroy(F->side[k]);
       if (F->ev_side[k]) (void)hipEventDestroy(F->ev_side[k]);
+      if (F->ev_samp[k]) (void)hipEventDestroy(F->ev_samp[k]);
     }
     if (F->ev_fork) (void)hipEventDestroy(F->ev_fork);
     delete F;
@@ -2920,11 +3030,14 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
     HIPCHK(hipMemsetAsync(iter_all.p, 0, iter_all.bytes(), s));
     iter_host.assign(2 * ((size_t)Ni + 1), 0.0);
   }
+  bool side_pending = false;  // recounts of the parallel sweep still on the side streams (joined before anything reads what they write)
   for (uint32_t iter = 0; iter <= Ni; ++iter) {
     const double time = iter == 0 ? 0.0 : std::max(0.0, (double)iter - (double)burnin);
     A.iter = iter;
     A.power = gibbs_anneal_power(o->high_temp, o->low_temp, Ni, iter);
     double cache_lp = 0.0, cheap_lp = 0.0;
+    std::vector<std::function<void()>> late_recounts;  // (parallel sweep with gathered counts: the recounts, launched behind the commit)
+    bool gathered = false;  // this sweep's counts are in rule_cnt (forest_rule_gather_kernel), not in new_x
     if (o->mode == 1)  // a slot per sweep, read back in batches: the host runs ahead of the device, no round trip per sweep
       A.iter_out = iter_all.p + 2 * (size_t)iter;
     else
@@ -2950,6 +3063,12 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         for (auto& c : F->classes)
           if (fm_bytes(c) * FM_FPW > 64 * 1024) fold_proposal = false;
         if (lib_opt("forest_gcol")) fold_proposal = false;
+        // the counts gathered from the nodes' use counts instead of added up by the recounts' atomics (forest_rule_gather_kernel)
+        // (forest_gather = 1; measured on config 5: 348 us a sweep against 316 -- the gather is 2.5 M scattered two-byte reads, 47 us,
+        // as many requests as the atomics it replaces, and the sweep gains two cross-stream waits; what it buys is counts that
+        // are the same bits run after run)
+        const bool gather_counts = fold_proposal && split_recount && F->inv_off.n && F->mt_node_cnt.n && lib_opt("forest_gather") &&
+                                   atoi(lib_opt("forest_gather")) == 1;
         if (F->n_and && !fold_proposal)
           hipLaunchKernelGGL(forest_proposal_kernel, dim3((unsigned)((F->n_and + 255) / 256)), dim3(256), 0, s, A);
         if (split_recount && iter == 0) {  // the new counts start from the priors; the norm sums go to the other buffer (this
@@ -2994,6 +3113,7 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             MA.own_proposal = fold_proposal ? 1 : 0;
             if (fold_proposal && !F->mt_prob.n) HIPCHK(F->mt_prob.alloc(F->mt_hdr.n / 4 + 8));
             MA.prob = F->mt_prob.p;
+            MA.node_cnt = gather_counts ? F->mt_node_cnt.p : nullptr;
             class_nodes = fold_proposal;
             const uint32_t nwg = (MA.lane_hi - MA.lane_lo + FM_FPW - 1) / FM_FPW;
             if (iter == 0 && lib_opt("timing"))
@@ -3016,16 +3136,43 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
             launch(forest_sample_kernel<false, true, false>, lds);
           else
             launch(forest_sample_kernel<false, false, false>, lds);
-          if (split_recount)  // this class's new samples into the counts, on its own stream, while the other classes still sample
-            // (all samplers first, the recounts behind them: 335 us against 316 -- the recounts are bound by their atomics, side
-            // by side at the end they take as long as spread out)
-            hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(c.count / recount_div, 1u), 2048u)), dim3(1024), frc_bytes,
-                               sweep_stream(F, s, ci), F->sample_off.p, F->sample_len[cur ^ 1].p, F->sample_rules[cur ^ 1].p,
-                               F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, A, 1, F->lane_forest.p, c.first * 64u,
-                               (c.first + c.count) * 64u, frc_slots0, frc_slots1, class_nodes ? (const uint32_t*)F->mt_hdr.p : nullptr,
-                               (const double*)F->mt_prob.p, (const uint4*)F->mt_slots.p);
+          if (split_recount) {
+            // this class's new samples: rule ids, class words, ln proposal probability -- and, unless the counts are gathered, the
+            // counts -- on its own stream, while the other classes still sample.  (With the counts in it, all samplers first and
+            // the recounts behind them was 335 us against 316: bound by their atomics they take as long side by side.)
+            const ForestArgs Ac = A;
+            const int cur_new = cur ^ 1;
+            auto rc = [=]() {
+              const auto& cc = F->classes[ci];
+              hipLaunchKernelGGL(forest_recount_kernel, dim3(std::min<uint32_t>(std::max<uint32_t>(cc.count / recount_div, 1u), 2048u)), dim3(1024), frc_bytes,
+                                 sweep_stream(F, s, ci), F->sample_off.p, F->sample_len[cur_new].p, F->sample_rules[cur_new].p,
+                                 F->p_norm.p, F->new_x.p, F->normsum2.p, (uint32_t)nf, Ac, gather_counts ? 3 : 1, F->lane_forest.p, cc.first * 64u,
+                                 (cc.first + cc.count) * 64u, frc_slots0, frc_slots1, class_nodes ? (const uint32_t*)F->mt_hdr.p : nullptr,
+                                 (const double*)F->mt_prob.p, (const uint4*)F->mt_slots.p);
+            };
+            if (gather_counts)
+              late_recounts.push_back(rc);  // (behind the commit: nothing the next sweep's counts need waits for them)
+            else
+              rc();
+          }
         }
-        HIPCHK(join_side(F, s));
+        if (gather_counts) {
+          // the caller's stream waits for the SAMPLERS of the side streams only, gathers the counts and commits them; the recounts
+          // follow on their streams and run into the next sweep (a class's next sampler is behind its recount on its own stream)
+          for (int k = 0; k < n_side_for(F); ++k) {
+            HIPCHK(hipEventRecord(F->ev_samp[k], F->side[k]));
+            HIPCHK(hipStreamWaitEvent(s, F->ev_samp[k], 0));
+          }
+          const uint32_t cold_blocks = (uint32_t)((nr + 255) / 256);
+          hipLaunchKernelGGL(forest_rule_gather_kernel, dim3(cold_blocks + (F->n_inv_pieces + 3) / 4), dim3(256), 0, s, F->inv_off.p, F->inv_node.p,
+                             (const uint16_t*)F->mt_node_cnt.p, F->rule_cnt.p, (uint32_t)nr, (const uint32_t*)F->inv_pieces.p, F->n_inv_pieces,
+                             cold_blocks, (uint32_t)F->inv_node.n);
+          hipLaunchKernelGGL(forest_group_sum_kernel, dim3((unsigned)((ng * 8 + 255) / 256)), dim3(256), 0, s, F->group_off.p, F->group_rule.p,
+                             (uint64_t)ng, (const uint32_t*)F->rule_cnt.p, (const double*)F->prior_norm.p, F->normsum2.p);
+          side_pending = true;
+          gathered = true;
+        } else
+          HIPCHK(join_side(F, s));
       } else
       for (auto& c : F->classes) {
         A.first_group = c.first;
@@ -3066,10 +3213,16 @@ int carmel_hip_forests_gibbs(carmel_hip_forests* F, const carmel_hip_gibbs_opts*
         const bool reset = split_recount && iter < Ni;
         hipLaunchKernelGGL(forest_commit_kernel, dim3((nr + 255) / 256), dim3(256), 0, s, F->new_x.p, F->p_x.p, F->p_s.p,
                            F->p_tmax.p, F->p_norm.p, time, (uint64_t)nr, reset ? (const double*)F->p_prior.p : nullptr,
-                           reset ? F->normsum2.p : nullptr, (const double*)F->prior_norm.p, (uint64_t)ng);
+                           reset ? F->normsum2.p : nullptr, (const double*)F->prior_norm.p, (uint64_t)ng,
+                           gathered ? F->rule_cnt.p : nullptr, (const double*)F->p_prior.p);
       }
+      for (auto& r : late_recounts) r();
       HIPCHK(hipGetLastError());
       if (iter == Ni || (iter & 63u) == 63u) {  // the sweeps' probabilities, 64 sweeps at a time
+        if (side_pending) {  // (the side streams' recounts add to the sweeps' probabilities)
+          HIPCHK(join_side(F, s));
+          side_pending = false;
+        }
         HIPCHK(hipMemcpyAsync(iter_host.data() + 2 * (size_t)io_done, iter_all.p + 2 * (size_t)io_done,
                               2 * (size_t)(iter + 1 - io_done) * sizeof(double), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));

@@ -19,7 +19,7 @@ const char* const kKeys[] = {
     "dense", "unrolled", "unrolled_ragged",
     // the samplers (gibbs.hip, forest.hip)
     "gibbs_chains", "gibbs_own_cap", "gibbs_workgroup", "gibbs_clk", "gibbs_reg", "gibbs_lane", "forest_sweep", "forest_ldswalk", "forest_multi",
-    "forest_nohash", "forest_trace", "forest_exact_host", "forest_exact_clk", "forest_logdomain", "forest_gcol"};
+    "forest_nohash", "forest_trace", "forest_exact_host", "forest_exact_clk", "forest_logdomain", "forest_gcol", "forest_gather"};
 constexpr int kN = (int)(sizeof kKeys / sizeof kKeys[0]);
 const char* volatile g_val[kN];  // interned strings (a replaced value is not freed: a reader may still hold it)
 std::mutex g_mu;

@@ -440,6 +440,12 @@ def test_several_lanes_per_forest_sampler(oracle, shape):
     # (where the chain settles is checked on the enumerated stationary distribution, tests/test_bench_workloads_gpu.py: after eight
     # sweeps two chains with different draws are still 10 % apart on these corpora)
     assert np.all(np.isfinite(a[0])) and np.all(a[0] < 0)
+    # the counts gathered from the nodes' use counts through the static rule -> nodes index (forest_gather = 1; no atomics, one
+    # rounding a count): the same chain -- samples draw for draw, weights to the last bits
+    g = run({"CARMEL_HIP_FOREST_GATHER": "1"}, final_counts=True)
+    assert g[1] == a[1]
+    np.testing.assert_allclose(g[0], a[0], rtol=1e-12)
+    np.testing.assert_allclose(np.exp(g[2][in_g]), np.exp(a[2][in_g]), rtol=1e-12, atol=1e-300)
 
 
 def test_exact_chain_on_deep_spines_whose_values_underflow_plain_doubles(oracle):
