@@ -437,14 +437,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(PAR ? GX_PAR
           // no branch in the loop: a lane without an arc of the level stores and adds a zero at a slot of its own in bsum
           // (this pass does not use it; the pass with exponents clears it first)
           double* const idle = bsum + min(lane, CS - 1u);
-          uint32_t nidx = min(GX_LEV(n_levels >= 2u ? n_levels - 2u : 0u) + lane, a_last);  // where the level after's arcs are
+          // (a level's first arc: ONE v_readlane a level -- the one two levels ahead; the others are carried)
+          uint32_t lo0 = n_levels ? GX_LEV(n_levels - 1u) : 0u, lo1 = GX_LEV(n_levels >= 2u ? n_levels - 2u : 0u);
+          uint32_t nidx = min(lo1 + lane, a_last);  // where the level after's arcs are
           GX_WAVE_SYNC();  // (nothing in flight at the loop's head: its waits count what the loop itself issued)
           for (uint32_t l = n_levels; l-- > 0;) {
             const double v = bv[pd & 0xffffu];
             const uint32_t nd = ds[nidx];
             const double ng = gw[nidx];
-            const uint32_t a_lo = GX_LEV(l);
-            nidx = min(GX_LEV(l >= 2u ? l - 2u : 0u) + lane, a_last);
+            const uint32_t a_lo = lo0;
+            const uint32_t lo2 = GX_LEV(l >= 2u ? l - 2u : 0u);
+            lo0 = lo1;
+            lo1 = lo2;
+            nidx = min(lo2 + lane, a_last);
             const bool on = a_lo + lane < a_hi;
             const double term = on ? pg * v : 0.0;
             *(on ? &sh[a_lo + lane] : idle) = term;
