@@ -537,6 +537,58 @@ def test_parallel_sweep_lane_layout_on_random_taggers(oracle, hipopt, seed):
     np.testing.assert_allclose(np.exp(a[3]), np.exp(b[3]), rtol=1e-9, atol=1e-15)
 
 
+def wide_long_tagger(seed):
+    """taggers beyond the exact chain's usual block (gibbs_exact_wave_kernel: at most 256 arcs, 320 states, 64 / 128 / 192 levels
+    and 64 arcs a level take the staged, register-resident paths) that still fit the single-wavefront kernel's LDS: narrow words
+    (one or two tags) in sentences of up to 230 words -- more levels than the level offsets' two registers hold, paths longer than a
+    register, more than 320 states -- and wide words (nine to eleven tags) side by side: levels of more than 64 arcs"""
+    rng = np.random.default_rng(7100 + seed)
+    T = int(rng.integers(9, 12))
+    tags = ["T%d" % i for i in range(T)]
+    narrow, wide = ["n%d" % i for i in range(int(rng.integers(3, 9)))], ["W%d" % i for i in range(2)]
+    fsa = ["F"] + ['(0 (%s *e* "%s" 1))' % (t, t) for t in tags]
+    for t in tags:
+        fsa.append("(%s (F *e* *e* 1))" % t)
+        fsa += ['(%s (%s *e* "%s" 1))' % (t, u, u) for u in tags]
+    fst = ["0"]
+    for w_ in narrow:
+        for t in rng.choice(T, size=int(rng.integers(1, 3)), replace=False):
+            fst.append('(0 (0 "%s" "%s" 1))' % (tags[int(t)], w_))
+    for w_ in wide:
+        for t in rng.choice(T, size=int(rng.integers(9, T + 1)), replace=False):
+            fst.append('(0 (0 "%s" "%s" 1))' % (tags[int(t)], w_))
+    lines = []
+    for n in [230, 150, 70, 30] + [int(k) for k in rng.integers(1, 40, size=8)]:
+        ws = [narrow[int(k)] for k in rng.integers(0, len(narrow), size=n)]
+        if n >= 30 or rng.random() < 0.5:  # two wide words side by side
+            at = int(rng.integers(0, n - 1)) if n > 1 else 0
+            ws[at:at + 2] = wide[:len(ws[at:at + 2])]
+        lines += ["", " ".join('"%s"' % w_ for w_ in ws)]
+    return "\n".join(fsa) + "\n", "\n".join(fst) + "\n", "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_exact_chain_on_wide_and_long_taggers(oracle, hipopt, capfd, seed):
+    """the exact chain on lattices beyond the staged block of gibbs_exact_wave_kernel (wide_long_tagger) -- run by THAT kernel, as its
+    cycle counts on stderr say (gibbs_clk) --: the oracle's chain draw for draw, its sweep probabilities and time-averaged weights"""
+    from carmel_amd.trainer import HipGibbs
+    fsa, fst, data = wide_long_tagger(seed)
+    oc, ocorp, fb = _setup(oracle, [fsa, fst], data, [NORM_CONDITIONAL, NORM_CONDITIONAL], [0.3, 0.2])
+    iters, burnin = 5, 1
+    hipopt.set("gibbs_clk", "1")
+    gs = HipGibbs(fb, iters, burnin=burnin, seed=70 + seed, mode=0)
+    got_lp = gs.run()
+    assert "gibbs_exact_wave cycles per block" in capfd.readouterr().err
+    ref = oracle.gibbs_run(oc, ocorp, gs.uniform, normby="CC", priors=[0.3, 0.2], iters=iters, burnin=burnin)
+    assert gs.n_blocks == len(ref["samples"]) and max(len(x) for x in ref["samples"]) > 2 * 192
+    for blk in range(gs.n_blocks):
+        assert gs.sample(blk) == ref["samples"][blk]
+    np.testing.assert_allclose(got_lp, ref["iter_logprob"], rtol=1e-10)
+    np.testing.assert_allclose(np.exp(fb.weights()), np.exp(ref["param_logw"]), rtol=1e-9, atol=1e-15)
+    gs.close()
+    fb.close()
+
+
 def test_gibbs_wavefront_and_workgroup_kernels_are_one_chain(oracle, golden_dir, hipopt):
     """gibbs_exact.hip's single-wavefront kernel (linear domain, static arc records, DPP choice) and gibbs.hip's workgroup
     kernel (log domain; CARMEL_HIP_GIBBS_WORKGROUP=1) are two implementations of the reference's chain: the same samples,
